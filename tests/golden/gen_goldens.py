@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the reference's NumPy code in THIS container.
+
+Runs only where /root/reference exists (the build container). Nothing from the
+reference travels: this script executes the reference functions on inputs and
+stores inputs + outputs (data) as small .npz fixtures under tests/golden/.
+
+`mindspore` is not installed here, and every reference module imports it at top
+level, so a throw-away stub is registered in sys.modules first (attribute access
+only; no arithmetic goes through the stub).  The functions executed are the pure
+NumPy/SciPy ones:
+
+  mindaudio/data/io.py::read                     (io.py:552)
+  mindaudio/data/spectrum.py::stft               (spectrum.py:125-278)
+  mindaudio/data/spectrum.py::frame              (spectrum.py:281-304)
+  mindaudio/data/spectrum.py::amplitude_to_dB    (spectrum.py:25-90)
+  examples/conformer/dataset.py::get_mel_banks / compute_fbank_feats (dataset.py:68-168)
+  mindaudio/utils/common.py::pad_sequence / add_sos_eos  (common.py:10-88)
+  mindaudio/utils/mask.py::make_pad_mask / subsequent_mask (mask.py:19-67)
+
+melspectrogram / features.fbank run inside MindSpore C++ and cannot be executed
+here: no golden vectors exist for them ("parity unpinned").
+
+usage: python tests/golden/gen_goldens.py
+"""
+import importlib.util
+import os
+import shutil
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Anything:
+    """Attribute sink: any attribute / call returns another sink."""
+
+    def __init__(self, name="stub"):
+        self._name = name
+
+    def __getattr__(self, k):
+        if k.startswith("__") and k.endswith("__"):
+            raise AttributeError(k)
+        return _Anything(self._name + "." + k)
+
+    def __call__(self, *a, **k):
+        return _Anything(self._name + "()")
+
+
+class _StubModule(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__") and k.endswith("__"):
+            raise AttributeError(k)
+        return _Anything(self.__name__ + "." + k)
+
+
+def _install_stubs():
+    names = [
+        "mindspore",
+        "mindspore.nn",
+        "mindspore.ops",
+        "mindspore.dataset",
+        "mindspore.dataset.audio",
+        "mindspore.dataset.audio.utils",
+        "mindspore.dataset.engine",
+        "mindspore.common",
+        "mindspore.common.dtype",
+    ]
+    for n in names:
+        m = _StubModule(n)
+        m.__path__ = []
+        sys.modules[n] = m
+    for n in names:
+        if "." in n:
+            parent, child = n.rsplit(".", 1)
+            setattr(sys.modules[parent], child, sys.modules[n])
+    # isinstance(x, ms.Tensor) is evaluated inside spectrum.frame
+    sys.modules["mindspore"].Tensor = type("Tensor", (), {"__init__": lambda self, *a, **k: None})
+
+
+def _load(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    _install_stubs()
+    io = _load("ref_io", "mindaudio/data/io.py")
+    spectrum = _load("ref_spectrum", "mindaudio/data/spectrum.py")
+    # fake `mindaudio` package so examples/conformer/dataset.py imports resolve
+    pkg = types.ModuleType("mindaudio")
+    pkg.__path__ = []
+    sys.modules["mindaudio"] = pkg
+    utils = types.ModuleType("mindaudio.utils")
+    utils.__path__ = []
+    sys.modules["mindaudio.utils"] = utils
+    pkg.utils = utils
+    pkg.read = io.read
+    common = _load("mindaudio.utils.common", "mindaudio/utils/common.py")
+    dist = _load("mindaudio.utils.distributed", "mindaudio/utils/distributed.py")
+    logm = types.ModuleType("mindaudio.utils.log")
+    import logging
+
+    logm.get_logger = lambda *a, **k: logging.getLogger("ref")
+    sys.modules["mindaudio.utils.log"] = logm
+    mask = _load("mindaudio.utils.mask", "mindaudio/utils/mask.py")
+    dataset = _load("ref_conformer_dataset", "examples/conformer/dataset.py")
+    return dict(io=io, spectrum=spectrum, common=common, mask=mask, dataset=dataset, dist=dist)
+
+
+def _cols(n_frames):
+    """Columns (frames) kept from a big STFT: edges + a sparse interior sample."""
+    idx = sorted(set([0, 1, 2, 3, 4, n_frames - 5, n_frames - 4, n_frames - 3, n_frames - 2, n_frames - 1]
+                     + list(range(7, n_frames, 53))))
+    return np.array([i for i in idx if 0 <= i < n_frames], dtype=np.int64)
+
+
+def main():
+    ref = load_reference()
+    sp, io, ds = ref["spectrum"], ref["io"], ref["dataset"]
+
+    wav_src = os.path.join(REF, "tests/samples/ASR/BAC009S0002W0122.wav")
+    wav_dst = os.path.join(HERE, "BAC009S0002W0122.wav")
+    if not os.path.exists(wav_dst):
+        shutil.copyfile(wav_src, wav_dst)  # data file held by the reference's own tests
+    wav, sr = io.read(wav_src)
+    assert sr == 16000 and wav.shape == (95984,) and wav.dtype == np.float64
+
+    out = {}
+    out["wav_sr"] = np.int64(sr)
+    out["wav_len"] = np.int64(wav.shape[0])
+    out["wav_head"] = wav[:64].copy()
+    out["wav_sum"] = np.float64(wav.sum())
+    out["wav_sqsum"] = np.float64((wav**2).sum())
+
+    # ---- stft on the sample wav (cfg 1) -----------------------------------
+    def keep(tag, S):
+        S = np.asarray(S)
+        assert S.dtype == np.complex64
+        c = _cols(S.shape[-1])
+        out[tag + "_shape"] = np.array(S.shape, dtype=np.int64)
+        out[tag + "_cols"] = c
+        out[tag + "_vals"] = np.ascontiguousarray(S[..., c])
+        out[tag + "_abs_sum"] = np.float64(np.abs(S).astype(np.float64).sum())
+        out[tag + "_re_sum"] = np.float64(S.real.astype(np.float64).sum())
+        out[tag + "_im_sum"] = np.float64(S.imag.astype(np.float64).sum())
+        out[tag + "_fortran"] = np.bool_(S.flags["F_CONTIGUOUS"])
+
+    S = sp.stft(wav)
+    assert S.shape == (257, 750)
+    keep("stft_default", S)
+    keep("stft_512_160", sp.stft(wav, n_fft=512, hop_length=160))
+    keep("stft_400_160_reflect", sp.stft(wav, n_fft=400, hop_length=160, pad_mode="reflect"))
+    keep("stft_512_win400_hop160", sp.stft(wav, n_fft=512, win_length=400, hop_length=160))
+    keep("stft_nocenter_512_160", sp.stft(wav, n_fft=512, hop_length=160, center=False))
+    keep("stft_hamming_256", sp.stft(wav, n_fft=256, window="hamming"))
+    keep("stft_1024_256", sp.stft(wav, n_fft=1024, hop_length=256))
+    keep("stft_f32in_512_160", sp.stft(wav.astype(np.float32), n_fft=512, hop_length=160))
+    ri = sp.stft(wav[:4000], n_fft=512, hop_length=160, return_complex=False)
+    out["stft_ri_4000"] = ri.astype(np.float32)
+
+    # ---- seeded synthetic batch (cfg 2 shape, smaller batch) ---------------
+    rng = np.random.RandomState(1234)
+    x = (0.1 * rng.randn(4, 160000)).astype(np.float32)
+    out["synth_seed"] = np.int64(1234)
+    Sb = sp.stft(x, n_fft=512, hop_length=160)
+    assert Sb.shape == (4, 257, 1001)
+    keep("stft_synth4", Sb)
+    # short ragged-ish lengths around the n_fft / hop edges
+    for n in (512, 513, 671, 672, 673, 1000, 1601):
+        xs = (0.1 * np.random.RandomState(n).randn(2, n)).astype(np.float32)
+        out["stft_short_%d" % n] = np.ascontiguousarray(sp.stft(xs, n_fft=512, hop_length=160))
+
+    # ---- frame() ----------------------------------------------------------
+    fr = sp.frame(np.arange(40, dtype=np.float64).reshape(2, 20), frame_length=8, hop_length=3)
+    out["frame_2x20_8_3"] = fr
+
+    # ---- amplitude_to_dB --------------------------------------------------
+    rng = np.random.RandomState(7)
+    a2 = rng.rand(41, 30) ** 6
+    a3 = rng.rand(3, 41, 30) ** 6
+    a3[1] *= 1e-7  # quiet utterance batched with loud ones: batch-global top_db floor
+    a4 = rng.rand(2, 3, 17, 11) ** 8
+    a4[1, 2] *= 1e-9
+    a3[0, 0, 0] = 0.0  # hits amin
+    for tag, a in (("db2", a2), ("db3", a3), ("db4", a4)):
+        out[tag + "_in"] = a
+        out[tag + "_power"] = sp.amplitude_to_dB(a)
+        out[tag + "_mag_ref2_top60"] = sp.amplitude_to_dB(a, stype="magnitude", ref=2.0, top_db=60.0)
+        out[tag + "_notop"] = sp.amplitude_to_dB(a, top_db=None)
+    out["db3_f32_power"] = sp.amplitude_to_dB(a3.astype(np.float32))
+
+    # ---- Kaldi-style fbank of examples/conformer --------------------------
+    banks, centers = ds.get_mel_banks(80, 512, 16000, 20, 8000)
+    assert banks.shape == (80, 257)
+    nz = np.nonzero(banks)
+    out["kaldi_mel_shape"] = np.array(banks.shape, dtype=np.int64)
+    out["kaldi_mel_rows"] = nz[0].astype(np.int32)
+    out["kaldi_mel_cols"] = nz[1].astype(np.int32)
+    out["kaldi_mel_vals"] = banks[nz]
+    out["kaldi_mel_centers"] = centers.reshape(-1)
+    banks23, _ = ds.get_mel_banks(23, 512, 16000, 20, 8000)
+    out["kaldi_mel23_dense"] = banks23
+
+    f = ds.compute_fbank_feats(wav * (1 << 15), 16000, 25, 10, 80)
+    assert f.shape == (598, 80)
+    out["kaldi_wav_shape"] = np.array(f.shape, dtype=np.int64)
+    rows = np.array(sorted(set([0, 1, 2, 595, 596, 597] + list(range(5, 598, 23)))), dtype=np.int64)
+    out["kaldi_wav_rows"] = rows
+    out["kaldi_wav_vals"] = f[rows]
+    out["kaldi_wav_sum"] = np.float64(f.sum())
+    out["kaldi_wav_min"] = np.float64(f.min())
+    out["kaldi_wav_max"] = np.float64(f.max())
+    for i, n in enumerate((16000, 12345, 400, 559, 560)):
+        w = np.round(np.random.RandomState(100 + i).randn(n) * 3000.0)
+        out["kaldi_synth_in_%d" % n] = w
+        out["kaldi_synth_out_%d" % n] = ds.compute_fbank_feats(w, 16000, 25, 10, 80)
+    out["preemph_10"] = ds.preemphasis(np.arange(10, dtype=np.float64) ** 2)
+
+    # ---- collate helpers --------------------------------------------------
+    cm, mk = ref["common"], ref["mask"]
+    seqs = [np.arange(12, dtype=np.float32).reshape(4, 3), np.ones((2, 3), np.float32), 2 * np.ones((3, 3), np.float32)]
+    out["pad_sequence_f32"] = cm.pad_sequence(seqs, batch_first=True, padding_value=0.0, padding_max_len=6, atype=np.float32)
+    ys = [np.array([1, 2, 3, 4, 5], np.int32), np.array([4, 5, 6], np.int32), np.array([7, 8, 9, 10], np.int32)]
+    out["pad_sequence_i32"] = cm.pad_sequence(ys, batch_first=True, padding_value=-1, padding_max_len=7, atype=np.int32)
+    ys_in, ys_out = cm.add_sos_eos(ys, 10, 11)
+    out["add_sos_eos_in"] = np.concatenate(ys_in)
+    out["add_sos_eos_out"] = np.concatenate(ys_out)
+    out["make_pad_mask_5_3_2"] = np.asarray(mk.make_pad_mask([5, 3, 2]))
+    out["make_pad_mask_max8"] = np.asarray(mk.make_pad_mask([5, 3, 2], max_len=8))
+    out["subsequent_mask_5"] = np.asarray(mk.subsequent_mask(5))
+
+    path = os.path.join(HERE, "reference_goldens.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+/*
+ * mindaudio_amd — C-ABI of the MI355X (gfx950) hot path of mindspore-lab/mindaudio.
+ *
+ * mindaudio has no FFI/plugin layer of its own (it is 100 % Python); the
+ * boundary it offers is its Python call signatures.  Each entry point below replaces the
+ * native arithmetic behind one of those signatures and is what a binding in the reference
+ * (ctypes) would call.  Conventions:
+ *
+ *   - plain C, no torch / C++ types; every pointer marked "device" is HBM memory of the
+ *     current HIP device, everything else is a host scalar;
+ *   - no allocation, no synchronisation inside: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream) and the call returns;
+ *   - return value: MA_OK or a negative MA_ERR_* code; the Python mirror maps the codes to
+ *     the exceptions the reference raises (ValueError for n_fft > len, hop < 1, ...).
+ *
+ * All shapes are row-major unless stated.
+ */
+#ifndef MINDAUDIO_AMD_H_
+#define MINDAUDIO_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MA_ABI_VERSION 1
+
+typedef void* ma_stream_t; /* hipStream_t */
+
+enum ma_status {
+  MA_OK = 0,
+  MA_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, unsupported enum */
+  MA_ERR_NFFT_TOO_LARGE = -2, /* n_fft > signal length: spectrum.py:182-187, :243-246 */
+  MA_ERR_HOP = -3,            /* hop < 1: spectrum.py:295-296 */
+  MA_ERR_WINDOW = -4,         /* win_length > n_fft: spectrum.py:331-334 */
+  MA_ERR_UNSUPPORTED = -5,    /* valid request that this build has no kernel for */
+  MA_ERR_LAUNCH = -6,         /* hipLaunch / hipGetLastError failure */
+  MA_ERR_WORKSPACE = -7       /* workspace too small */
+};
+
+/* np.pad modes the reference forwards (stft: pad_mode, spectrum.py:132; Spectrogram:
+ * BorderType, spectrum.py:671). */
+enum ma_pad_mode { MA_PAD_CONSTANT = 0, MA_PAD_REFLECT = 1, MA_PAD_EDGE = 2, MA_PAD_SYMMETRIC = 3 };
+
+/* Output layout of ma_stft_f32. */
+enum ma_stft_layout {
+  MA_STFT_FRAME_MAJOR = 0, /* (batch, n_frames, n_freq) complex64 — for a 1-D wave this is exactly the
+                              Fortran-ordered (n_freq, n_frames) array of spectrum.py:252 */
+  MA_STFT_FREQ_MAJOR = 1   /* (batch, n_freq, n_frames) complex64, C order */
+};
+
+int ma_abi_version(void);
+const char* ma_status_string(int status);
+
+/* 1 + n // hop (center) or 1 + (n - n_fft) // hop — spectrum.py:196,298; <0 on invalid args. */
+int64_t ma_num_frames(int64_t n, int32_t n_fft, int32_t hop, int32_t center);
+
+/*
+ * Triangular mel filterbank in "band" form: filter m covers the contiguous FFT bins
+ * [start[m], start[m] + count[m]) with weights[offset[m] ...].  Built on the host in float64
+ * (HTK bank of MelScale, spectrum.py:686-694; Kaldi bank of dataset.py:68-113) and uploaded once.
+ */
+typedef struct ma_melbank {
+  int32_t n_mels;
+  int32_t n_freqs;          /* n_fft / 2 + 1 */
+  int32_t nnz;              /* total number of weights */
+  int32_t max_count;        /* max over m of count[m] */
+  const int32_t* start;     /* device, [n_mels] */
+  const int32_t* count;     /* device, [n_mels] */
+  const int32_t* offset;    /* device, [n_mels] */
+  const float* weights;     /* device, [nnz] */
+} ma_melbank_t;
+
+/*
+ * spectrum.stft (mindaudio/data/spectrum.py:125-278), batched.
+ *   wav     device (batch, n) float32, row stride `wav_stride` elements
+ *   window  device (n_fft,) float32: scipy get_window(..., fftbins=True) centred-padded to
+ *           n_fft by the host (spectrum.py:173-175)
+ *   out     device complex64 as interleaved float pairs, layout per `layout`
+ * n_frames = ma_num_frames(n, n_fft, hop, center).
+ */
+int ma_stft_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stride,
+                int32_t n_fft, int32_t hop, const float* window,
+                int32_t center, int32_t pad_mode, int32_t layout,
+                float* out, ma_stream_t stream);
+
+/* Bytes of device workspace ma_fbank_db_f32 / ma_fbank_kaldi_f32 need. */
+int64_t ma_fbank_workspace_bytes(int64_t batch, int64_t n_frames);
+
+/*
+ * features.fbank with deltas=False, context=False (mindaudio/data/features.py:196-270):
+ * melspectrogram (spectrum.py:609-698: centred power spectrogram -> mel bank) followed by
+ * amplitude_to_dB (spectrum.py:25-90), fused.
+ *   out[b, m, t] = mult*log10(max(mel, amin)) - db_offset, then, if top_db >= 0,
+ *   max(out, max_over_the_whole_call(out) - top_db)   (batch-global floor, spectrum.py:79-89)
+ *   power: exponent of |X| (1.0 or 2.0);  db_offset = mult*log10(max(amin, |ref|)).
+ *   out     device (batch, n_mels, n_frames) float32
+ *   workspace device, >= ma_fbank_workspace_bytes(batch, n_frames)
+ */
+int ma_fbank_db_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stride,
+                    int32_t n_fft, int32_t hop, const float* window,
+                    int32_t center, int32_t pad_mode, const ma_melbank_t* mel,
+                    float power, float mult, float amin, float db_offset, float top_db,
+                    float* out, void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+
+/* Same front end, no dB: spectrum.melspectrogram (spectrum.py:609-698). out (batch, n_mels, n_frames). */
+int ma_melspectrogram_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stride,
+                          int32_t n_fft, int32_t hop, const float* window,
+                          int32_t center, int32_t pad_mode, const ma_melbank_t* mel, float power,
+                          float* out, ma_stream_t stream);
+
+/*
+ * Kaldi-style log-mel of the Conformer data loader, batched on device
+ * (examples/conformer/dataset.py:117-168 compute_fbank_feats; replaces the Pool(8) of :449,479).
+ *   wav      device (batch, max_n) float32, already scaled by 2^15 (dataset.py:390)
+ *   lengths  device (batch,) int64 valid samples per utterance
+ *   window   device (frame_len,) float32 = hanning(frame_len)^0.85 (dataset.py:126)
+ *   out      device (batch, max_frames, n_mels) float32, rows t >= frames(b) are zero
+ *            (pad_sequence padding value, dataset.py:563-569); max_frames = (max_n - frame_len)/shift + 1
+ * Per utterance: pre-emphasis over the whole signal, framing without centring, window,
+ * subtraction of ONE scalar mean over all windowed frames (dataset.py:165), zero-pad to n_fft,
+ * |rFFT|^2, mel bank, zeros -> eps, natural log.
+ */
+int ma_fbank_kaldi_f32(const float* wav, const int64_t* lengths, int64_t batch, int64_t max_n,
+                       int64_t wav_stride, int32_t frame_len, int32_t frame_shift, int32_t n_fft,
+                       const float* window, const ma_melbank_t* mel, float preemph,
+                       float* out, void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+
+/* Bytes of device workspace ma_amplitude_to_db_f32 needs. */
+int64_t ma_db_workspace_bytes(int64_t groups, int64_t elems_per_group);
+
+/* spectrum.amplitude_to_dB on a device array viewed as (groups, elems_per_group): the top_db floor is
+ * taken per group (spectrum.py:79-89: one group per leading index after the reshape). In place allowed. */
+int ma_amplitude_to_db_f32(const float* in, int64_t groups, int64_t elems_per_group,
+                           float mult, float amin, float db_offset, float top_db,
+                           float* out, void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINDAUDIO_AMD_H_ */

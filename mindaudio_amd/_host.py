@@ -1,0 +1,177 @@
+"""Host-side plumbing shared by the Python mirrors: tensor marshalling, cached device tables
+(windows, mel banks), workspaces.  PyTorch is used for device memory and streams only."""
+import ctypes
+import math
+
+import numpy as np
+from scipy.signal import get_window
+
+from . import _lib
+
+_torch = None
+
+
+def torch():
+    global _torch
+    if _torch is None:
+        import torch as _t
+
+        _torch = _t
+    return _torch
+
+
+def require_gpu():
+    t = torch()
+    if not t.cuda.is_available():
+        raise _lib.MindaudioAmdError("mindaudio_amd needs a HIP device (torch.cuda.is_available() is False); "
+                                     "there is no CPU fallback")
+    return t
+
+
+def current_stream_ptr():
+    return ctypes.c_void_p(torch().cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def to_device_2d(x, dtype=None):
+    """(array-like | tensor) with time on the last axis -> (cuda float32 (B, N) tensor, leading shape, was_numpy)."""
+    t = require_gpu()
+    was_numpy = not isinstance(x, t.Tensor)
+    if was_numpy:
+        arr = np.asarray(x)
+        if arr.dtype not in (np.float32, np.float64, np.int16, np.int32):
+            arr = arr.astype(np.float64)
+        x = t.from_numpy(np.ascontiguousarray(arr))
+    if not x.is_cuda:
+        x = x.cuda()
+    lead = tuple(x.shape[:-1])
+    x = x.reshape(-1, x.shape[-1]).to(t.float32)
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    return x, lead, was_numpy
+
+
+# ---- windows ---------------------------------------------------------------------------------
+def centred_window_f64(window, win_length, n_fft):
+    """scipy get_window(window, win_length, fftbins=True) padded centred to n_fft (spectrum.py:173-175)."""
+    w = get_window(window, win_length, fftbins=True)
+    if win_length > n_fft:
+        raise ValueError("Target size ({:d}) must be at least input size ({:d})".format(n_fft, win_length))
+    left = (n_fft - win_length) // 2
+    return np.pad(w, (left, n_fft - win_length - left))
+
+
+_window_cache = {}
+
+
+def device_window(window, win_length, n_fft, device):
+    key = ("centred", str(window), int(win_length), int(n_fft), str(device))
+    if key not in _window_cache:
+        w = centred_window_f64(window, win_length, n_fft).astype(np.float32)
+        _window_cache[key] = torch().from_numpy(w).to(device)
+    return _window_cache[key]
+
+
+def device_kaldi_window(frame_len, device):
+    key = ("kaldi", int(frame_len), str(device))
+    if key not in _window_cache:
+        w = np.power(np.hanning(frame_len), 0.85).astype(np.float32)  # dataset.py:126
+        _window_cache[key] = torch().from_numpy(w).to(device)
+    return _window_cache[key]
+
+
+# ---- mel banks ------------------------------------------------------------------------------
+def htk_fbanks_f64(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """MelScale(mel_type=HTK, norm=NONE) triangles, (n_freqs, n_mels) float64 (spectrum.py:686-694)."""
+    all_freqs = np.linspace(0.0, float(sample_rate // 2), n_freqs)
+    m_lo = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_hi = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    f_pts = 700.0 * (10.0 ** (np.linspace(m_lo, m_hi, n_mels + 2) / 2595.0) - 1.0)
+    f_diff = np.diff(f_pts)
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up))
+
+
+def kaldi_banks_f64(num_bins, n_fft_padded, sample_freq, low_freq, high_freq):
+    """(num_bins, n_fft_padded//2+1) Kaldi-style triangles in the mel domain (dataset.py:68-113)."""
+    nb = n_fft_padded // 2
+    width = sample_freq / n_fft_padded
+    lo = 1127.0 * math.log(1.0 + low_freq / 700.0)
+    hi = 1127.0 * math.log(1.0 + high_freq / 700.0)
+    delta = (hi - lo) / (num_bins + 1)
+    idx = np.arange(num_bins).reshape(-1, 1)
+    left, centre, right = lo + idx * delta, lo + (idx + 1.0) * delta, lo + (idx + 2.0) * delta
+    mel = (1127.0 * np.log(1.0 + width * np.arange(nb) / 700.0))[None, :]
+    up = (mel - left) / (centre - left)
+    down = (right - mel) / (right - centre)
+    tri = np.where(up > down, down, up)
+    tri = np.where(tri < 0, 0, tri)
+    return np.pad(tri, ((0, 0), (0, 1)), "constant")
+
+
+class DeviceMelBank:
+    """Band form of a (n_mels, n_freqs) filterbank on the device + its ma_melbank struct."""
+
+    def __init__(self, dense_mels_by_freqs, device):
+        t = torch()
+        dense = np.asarray(dense_mels_by_freqs, dtype=np.float64)
+        n_mels, n_freqs = dense.shape
+        start = np.zeros(n_mels, np.int32)
+        count = np.zeros(n_mels, np.int32)
+        offset = np.zeros(n_mels, np.int32)
+        weights = []
+        for m in range(n_mels):
+            nz = np.nonzero(dense[m])[0]
+            offset[m] = len(weights)
+            if nz.size:
+                start[m] = nz[0]
+                count[m] = nz[-1] - nz[0] + 1
+                weights.extend(dense[m, nz[0]:nz[-1] + 1].tolist())
+        if not weights:
+            weights = [0.0]
+        self.n_mels, self.n_freqs = n_mels, n_freqs
+        self.start = t.from_numpy(start).to(device)
+        self.count = t.from_numpy(count).to(device)
+        self.offset = t.from_numpy(offset).to(device)
+        self.weights = t.from_numpy(np.asarray(weights, dtype=np.float32)).to(device)
+        self.struct = _lib.MelBank(n_mels, n_freqs, len(weights), int(count.max()), self.start.data_ptr(),
+                                   self.count.data_ptr(), self.offset.data_ptr(), self.weights.data_ptr())
+
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+
+_mel_cache = {}
+
+
+def device_htk_bank(n_fft, f_min, f_max, n_mels, sample_rate, device):
+    key = ("htk", n_fft, float(f_min), float(f_max), n_mels, sample_rate, str(device))
+    if key not in _mel_cache:
+        fb = htk_fbanks_f64(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
+        _mel_cache[key] = DeviceMelBank(fb.T, device)
+    return _mel_cache[key]
+
+
+def device_kaldi_bank(mel_bin, n_fft, sample_freq, low, high, device):
+    key = ("kaldi", mel_bin, n_fft, float(sample_freq), float(low), float(high), str(device))
+    if key not in _mel_cache:
+        _mel_cache[key] = DeviceMelBank(kaldi_banks_f64(mel_bin, n_fft, sample_freq, low, high), device)
+    return _mel_cache[key]
+
+
+# ---- workspaces ------------------------------------------------------------------------------
+_ws = {}
+
+
+def workspace(nbytes, device):
+    key = str(device)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch().empty(max(int(nbytes), 1 << 16), dtype=torch().uint8, device=device)
+        _ws[key] = buf
+    return buf

@@ -1,0 +1,105 @@
+"""ctypes binding of libmindaudio_amd.so (the C-ABI declared in include/mindaudio_amd.h).
+
+There is NO CPU fallback: if the library is missing, or a call returns an error code, this module
+raises.  The only thing resolved without the library is the symbol table used by the CPU tests.
+"""
+import ctypes
+import os
+
+from . import _build
+
+MA_OK = 0
+MA_ERR_INVALID_ARG = -1
+MA_ERR_NFFT_TOO_LARGE = -2
+MA_ERR_HOP = -3
+MA_ERR_WINDOW = -4
+MA_ERR_UNSUPPORTED = -5
+MA_ERR_LAUNCH = -6
+MA_ERR_WORKSPACE = -7
+
+PAD_MODES = {"constant": 0, "reflect": 1, "edge": 2, "symmetric": 3}
+STFT_FRAME_MAJOR = 0
+STFT_FREQ_MAJOR = 1
+
+c_f32p = ctypes.c_void_p  # device pointers travel as integers
+i64 = ctypes.c_int64
+i32 = ctypes.c_int32
+f32 = ctypes.c_float
+
+
+class MelBank(ctypes.Structure):
+    """struct ma_melbank (include/mindaudio_amd.h)."""
+
+    _fields_ = [
+        ("n_mels", i32),
+        ("n_freqs", i32),
+        ("nnz", i32),
+        ("max_count", i32),
+        ("start", ctypes.c_void_p),
+        ("count", ctypes.c_void_p),
+        ("offset", ctypes.c_void_p),
+        ("weights", ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/mindaudio_amd.h declares
+PROTOTYPES = {
+    "ma_abi_version": (ctypes.c_int, []),
+    "ma_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "ma_num_frames": (i64, [i64, i32, i32, i32]),
+    "ma_stft_f32": (ctypes.c_int, [c_f32p, i64, i64, i64, i32, i32, c_f32p, i32, i32, i32, c_f32p, ctypes.c_void_p]),
+    "ma_fbank_workspace_bytes": (i64, [i64, i64]),
+    "ma_fbank_db_f32": (ctypes.c_int, [c_f32p, i64, i64, i64, i32, i32, c_f32p, i32, i32, ctypes.POINTER(MelBank),
+                                       f32, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64, ctypes.c_void_p]),
+    "ma_melspectrogram_f32": (ctypes.c_int, [c_f32p, i64, i64, i64, i32, i32, c_f32p, i32, i32,
+                                             ctypes.POINTER(MelBank), f32, c_f32p, ctypes.c_void_p]),
+    "ma_fbank_kaldi_f32": (ctypes.c_int, [c_f32p, ctypes.c_void_p, i64, i64, i64, i32, i32, i32, c_f32p,
+                                          ctypes.POINTER(MelBank), f32, c_f32p, ctypes.c_void_p, i64,
+                                          ctypes.c_void_p]),
+    "ma_db_workspace_bytes": (i64, [i64, i64]),
+    "ma_amplitude_to_db_f32": (ctypes.c_int, [c_f32p, i64, i64, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64,
+                                              ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class MindaudioAmdError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load the shared library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MindaudioAmdError(
+            "libmindaudio_amd.so is missing (%s). Build it with `python -m mindaudio_amd._build` "
+            "(or __graft_entry__.build()); there is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ma_abi_version() != 1:
+        raise MindaudioAmdError("ABI version mismatch: library %d, binding 1" % lib.ma_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    """Map a C-ABI status to the exception the reference raises for the same condition."""
+    if status == MA_OK:
+        return
+    msg = load().ma_status_string(int(status)).decode()
+    if status in (MA_ERR_NFFT_TOO_LARGE, MA_ERR_HOP, MA_ERR_WINDOW, MA_ERR_INVALID_ARG):
+        raise ValueError("%s: %s" % (what, msg))  # spectrum.py:182-187, 295-296, 331-334
+    if status == MA_ERR_UNSUPPORTED:
+        raise NotImplementedError("%s: %s" % (what, msg))
+    raise MindaudioAmdError("%s: %s (status %d)" % (what, msg, status))

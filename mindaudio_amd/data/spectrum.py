@@ -1,0 +1,135 @@
+"""Drop-in mirrors of mindaudio.data.spectrum for the functions on the hot path
+(stft, melspectrogram, amplitude_to_dB), executing on MI355X through the C-ABI.
+
+Inputs may be NumPy arrays (the reference's container; results come back as NumPy) or CUDA/HIP
+torch tensors (results stay on the device).  Arithmetic is float32 on the device: the reference's
+stft computes in float64 and rounds to complex64 (spectrum.py:252), so results agree to float32
+round-off of the frame norm, not bit for bit.
+"""
+import numpy as np
+
+from .. import _host, _lib
+
+__all__ = ["stft", "melspectrogram", "amplitude_to_dB"]
+
+
+def _finish(out, lead, was_numpy):
+    out = out.reshape(lead + tuple(out.shape[1:]))
+    return out.cpu().numpy() if was_numpy else out
+
+
+def stft(waveforms, n_fft=512, win_length=None, hop_length=None, window="hann", center=True,
+         pad_mode="constant", return_complex=True):
+    """Short-time Fourier transform — same signature and defaults as spectrum.py:125-134.
+
+    Returns (..., 1 + n_fft/2, 1 + N // hop) complex64 (or a trailing (…, 2) real/imag stack when
+    return_complex is False, spectrum.py:275-278).  For a 1-D wave the memory layout is the
+    reference's Fortran order (spectrum.py:252).
+    """
+    t = _host.require_gpu()
+    lib = _lib.load()
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = win_length // 4
+    x, lead, was_numpy = _host.to_device_2d(waveforms)
+    n = x.shape[-1]
+    win = _host.device_window(window, win_length, n_fft, x.device)  # ValueError if win_length > n_fft
+    if n_fft > n:
+        raise ValueError("n_fft={} is too large for input signal of length={}".format(n_fft, n))
+    if hop_length < 1:
+        raise ValueError("Invalid hop_length: {:d}".format(hop_length))
+    if pad_mode not in _lib.PAD_MODES:
+        raise ValueError("unsupported pad_mode %r" % (pad_mode,))
+    n_frames = lib.ma_num_frames(n, n_fft, hop_length, int(bool(center)))
+    _lib.check(min(n_frames, 0), "stft")
+    n_freq = n_fft // 2 + 1
+    out = t.empty((x.shape[0], n_frames, n_freq, 2), dtype=t.float32, device=x.device)
+    rc = lib.ma_stft_f32(_host.ptr(x), x.shape[0], n, x.stride(0), n_fft, hop_length, _host.ptr(win),
+                         int(bool(center)), _lib.PAD_MODES[pad_mode], _lib.STFT_FRAME_MAJOR, _host.ptr(out),
+                         _host.current_stream_ptr())
+    _lib.check(rc, "stft")
+    spec = t.view_as_complex(out).transpose(1, 2)  # (B, n_freq, n_frames) view of frame-major memory
+    if not return_complex:
+        spec = t.stack((spec.real, spec.imag), -1)
+    return _finish(spec, lead, was_numpy)
+
+
+def _mel_args(n_fft, win_length, hop_length, window, center, pad_mode, n_mels, sample_rate, f_min, f_max, device):
+    win_length = win_length if win_length is not None else n_fft  # spectrum.py:665
+    hop_length = hop_length if hop_length is not None else win_length // 2  # spectrum.py:666
+    f_max = f_max if f_max is not None else sample_rate // 2  # spectrum.py:770 / MelScale default
+    if pad_mode not in _lib.PAD_MODES:
+        raise ValueError("unsupported pad_mode %r" % (pad_mode,))
+    win = _host.device_window(window, win_length, n_fft, device)
+    bank = _host.device_htk_bank(n_fft, float(f_min), float(f_max), int(n_mels), int(sample_rate), device)
+    return win_length, hop_length, win, bank
+
+
+def melspectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0, window="hann", power=2.0,
+                   normalized=False, center=True, pad_mode="reflect", onesided=True, n_mels=128,
+                   sample_rate=16000, f_min=0, f_max=None, norm="none", mel_type="htk"):
+    """Mel-scaled spectrogram — signature of spectrum.py:609-627 (norm/mel_type as strings)."""
+    t = _host.require_gpu()
+    lib = _lib.load()
+    if normalized or not onesided or str(norm).lower() not in ("none", "normtype.none") \
+            or str(mel_type).lower() not in ("htk", "meltype.htk"):
+        raise NotImplementedError("only normalized=False, onesided=True, norm='none', mel_type='htk' are on the "
+                                  "hot path (SURVEY §8 row a3)")
+    x, lead, was_numpy = _host.to_device_2d(waveforms)
+    if pad > 0:
+        x = t.nn.functional.pad(x, (pad, pad))
+    n = x.shape[-1]
+    win_length, hop_length, win, bank = _mel_args(n_fft, win_length, hop_length, window, center, pad_mode, n_mels,
+                                                  sample_rate, f_min, f_max, x.device)
+    n_frames = lib.ma_num_frames(n, n_fft, hop_length, int(bool(center)))
+    _lib.check(min(n_frames, 0), "melspectrogram")
+    out = t.empty((x.shape[0], n_mels, n_frames), dtype=t.float32, device=x.device)
+    rc = lib.ma_melspectrogram_f32(_host.ptr(x), x.shape[0], n, x.stride(0), n_fft, hop_length, _host.ptr(win),
+                                   int(bool(center)), _lib.PAD_MODES[pad_mode], bank.ref(), float(power),
+                                   _host.ptr(out), _host.current_stream_ptr())
+    _lib.check(rc, "melspectrogram")
+    return _finish(out, lead, was_numpy)
+
+
+def amplitude_to_dB(wavform, stype="power", ref=1.0, amin=1e-10, top_db=80.0):
+    """spectrum.py:25-90: 10/20*log10(clip(x, amin)) - mult*log10(max(amin, |ref|)), then the top_db floor
+    relative to the maximum over the last three axes after the reference's reshape — for a (B, F, T) input
+    that is ONE floor for the whole batch (spectrum.py:79-89)."""
+    t = _host.require_gpu()
+    lib = _lib.load()
+    was_numpy = not isinstance(wavform, t.Tensor)
+    if was_numpy:
+        wavform = np.asarray(wavform)
+        is_complex = np.issubdtype(wavform.dtype, np.complexfloating)
+    else:
+        is_complex = wavform.is_complex()
+    if is_complex:  # the reference raises (not warns): spectrum.py:59-64
+        raise UserWarning("amplitude_to_db was called on complex input so phase information will be discarded. "
+                          "To suppress this warning, call amplitude_to_db(np.abs(D)**2) instead.")
+    ref_value = float(ref(wavform)) if callable(ref) else abs(float(ref))
+    mult = 10.0 if stype == "power" else 20.0
+    in_dtype = wavform.dtype
+    x = t.from_numpy(np.ascontiguousarray(wavform)) if was_numpy else wavform
+    shape = tuple(x.shape)
+    x = x.to(device="cuda", dtype=t.float32).contiguous()
+    channels = shape[-3] if len(shape) > 2 else 1
+    elems = channels * shape[-2] * shape[-1]
+    groups = x.numel() // elems
+    out = t.empty_like(x)
+    ws_bytes = lib.ma_db_workspace_bytes(groups, elems)
+    ws = _host.workspace(ws_bytes, x.device)
+    import math
+
+    rc = lib.ma_amplitude_to_db_f32(_host.ptr(x), groups, elems, mult, float(amin),
+                                    mult * math.log10(max(amin, ref_value)),
+                                    -1.0 if top_db is None else float(top_db), _host.ptr(out), _host.ptr(ws),
+                                    ws.numel(), _host.current_stream_ptr())
+    _lib.check(rc, "amplitude_to_dB")
+    if was_numpy:
+        return out.cpu().numpy().astype(in_dtype, copy=False)
+    return out.to(in_dtype)
+
+
+def spectrogram_unsupported(*a, **k):
+    raise NotImplementedError("spectrum.spectrogram is not on the fbank->Conformer path; use melspectrogram/stft")

@@ -60,6 +60,8 @@ int64_t ma_num_frames(int64_t n, int32_t n_fft, int32_t hop, int32_t center);
  * Triangular mel filterbank in "band" form: filter m covers the contiguous FFT bins
  * [start[m], start[m] + count[m]) with weights[offset[m] ...].  Built on the host in float64
  * (HTK bank of MelScale, spectrum.py:686-694; Kaldi bank of dataset.py:68-113) and uploaded once.
+ * Layout contract: offset[m] % 4 == 0 and each filter's weights are followed by zeros up to a multiple
+ * of 4 entries (the kernels read them 16 bytes at a time); nnz counts the padded entries.
  */
 typedef struct ma_melbank {
   int32_t n_mels;

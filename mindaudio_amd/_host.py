@@ -132,8 +132,9 @@ class DeviceMelBank:
                 start[m] = nz[0]
                 count[m] = nz[-1] - nz[0] + 1
                 weights.extend(dense[m, nz[0]:nz[-1] + 1].tolist())
+                weights.extend([0.0] * (-len(weights) % 4))  # header contract: 16-byte groups per filter
         if not weights:
-            weights = [0.0]
+            weights = [0.0] * 4
         self.n_mels, self.n_freqs = n_mels, n_freqs
         self.start = t.from_numpy(start).to(device)
         self.count = t.from_numpy(count).to(device)

@@ -82,6 +82,11 @@ def load():
         raise MindaudioAmdError(
             "libmindaudio_amd.so is missing (%s). Build it with `python -m mindaudio_amd._build` "
             "(or __graft_entry__.build()); there is no CPU fallback." % path)
+    # PyTorch-ROCm bundles its own libamdhip64.so.7.  The process must hold ONE HIP runtime: import torch
+    # first so that our library binds to the runtime that owns torch's context, streams and allocations
+    # (loading ours first pulls /opt/rocm's copy and every launch on a torch stream then fails).
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -25,6 +25,15 @@
 #include "../../include/mindaudio_amd.h"
 #include "fft512.h"
 
+// Launch + error check.  hipGetLastError() is sticky across unrelated runtime calls of the host process
+// (e.g. a benign probe inside the framework that owns the context), so clear it first.
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
 namespace ma {
 
 constexpr int kThreads = 256;
@@ -92,28 +101,36 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
   return r;
 }
 
+#include "fft_tables.inc"
+
 // LDS carve (bytes). All offsets multiples of 16.
-constexpr int kOffTw256 = 0;                                   // 256 v2f
-constexpr int kOffTw512 = kOffTw256 + 256 * 8;                 // 256 v2f
-constexpr int kOffWin = kOffTw512 + 256 * 8;                   // 256 v2f (512 floats)
-constexpr int kOffScratch = kOffWin + 512 * 4;                 // kWaves*4 slots * kSlotStride v2f
-constexpr int kScratchBytes = kWaves * 4 * kSlotStride * 8;    // 34816
-constexpr int kOffP = kOffScratch + kScratchBytes;             // 32*257 floats
-constexpr int kPBytes = ((kTileFrames * kBins * 4 + 15) / 16) * 16;
-constexpr int kOffMel = kOffP + kPBytes;                       // 3*n_mels ints + nnz floats
+//   P tile: 32 rows (frames) x kPStride floats.  Row f first serves as frame f's FFT transpose slot
+//   (kSlotFloats = 272 floats), then receives the 257 powers of the frame; kPStride = 273 is odd, so the
+//   mel phase (lane = frame) reads it conflict-free.
+constexpr int kPStride = 273;
+constexpr int kOffTw256 = 0;                          // 256 v2f
+constexpr int kOffTw512 = kOffTw256 + 256 * 8;        // 256 v2f
+constexpr int kOffWin = kOffTw512 + 256 * 8;          // 512 floats
+constexpr int kOffP = kOffWin + 512 * 4;              // 32 * 273 floats
+constexpr int kPBytes = ((kTileFrames * kPStride * 4 + 15) / 16) * 16;
+constexpr int kOffMel = kOffP + kPBytes;              // 3*n_mels ints (padded to 16 B) + nnz floats
+constexpr int kMaxMels = 128;                         // mel values a thread keeps in registers: 128 / 8
+static_assert(kSlotFloats <= kPStride, "transpose slot must fit in a P row");
+
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32, 1 ulp
 
 template <int MODE>
-__global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p) {
+__global__ __launch_bounds__(kThreads, 3) void feat512_kernel(const FeatParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* tw256 = reinterpret_cast<v2f*>(smem + kOffTw256);
   v2f* tw512 = reinterpret_cast<v2f*>(smem + kOffTw512);
   float* win = reinterpret_cast<float*>(smem + kOffWin);
-  v2f* scratch = reinterpret_cast<v2f*>(smem + kOffScratch);
   float* P = reinterpret_cast<float*>(smem + kOffP);
+  const int mel_ints = ((3 * p.n_mels + 3) / 4) * 4;
   int* mstart = reinterpret_cast<int*>(smem + kOffMel);
   int* mcount = mstart + p.n_mels;
   int* moffset = mcount + p.n_mels;
-  float* mw = reinterpret_cast<float*>(moffset + p.n_mels);
+  float* mw = reinterpret_cast<float*>(mstart + mel_ints);  // 16-byte aligned
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -123,12 +140,8 @@ __global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p
 
   // ---- per-workgroup tables (once; the grid is persistent) -------------------------------
   {
-    const int q = tid >> 4, jj = tid & 15;
-    double s, c;
-    sincospi(-2.0 * (double)(q * jj) / 256.0, &s, &c);
-    tw256[tid] = v2f{(float)c, (float)s};  // W256^(q*jj)
-    sincospi(2.0 * (double)tid / 512.0, &s, &c);
-    tw512[tid] = v2f{(float)c, (float)s};  // (cos, sin)(2 pi k / 512)
+    tw256[tid] = v2f{kTw256[2 * tid], kTw256[2 * tid + 1]};
+    tw512[tid] = v2f{kTw512[2 * tid], kTw512[2 * tid + 1]};
     for (int i = tid; i < 512; i += kThreads) win[i] = (i < p.frame_len) ? p.window[i] : 0.0f;
     if (MODE != kModeStft) {
       for (int i = tid; i < p.n_mels; i += kThreads) {
@@ -140,8 +153,6 @@ __global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p
     }
   }
   __syncthreads();
-
-  v2f* slot = scratch + (wave * 4 + g) * kSlotStride;
 
   for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
     const int64_t b = tile / p.tiles_per_utt;
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p
 #pragma unroll
           for (int m1 = 0; m1 < 16; ++m1) a[m1] = src[16 * m1] * w2[16 * m1];
         } else {
-#pragma unroll
+#pragma unroll 1
           for (int m1 = 0; m1 < 16; ++m1) {
             const int nn = 32 * m1 + 2 * j;
             float x0 = 0.0f, x1 = 0.0f;
@@ -207,12 +218,16 @@ __global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p
               x0 = fetch_padded(xb, s0 + nn, n_valid, p.pad_mode);
               x1 = fetch_padded(xb, s0 + nn + 1, n_valid, p.pad_mode);
             }
-            a[m1] = v2f{x0 * win[nn], x1 * win[nn + 1]};
+            // dynamic index into a[] would spill: select through a static unrolled scan
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (q == m1) a[q] = v2f{x0 * win[nn], x1 * win[nn + 1]};
           }
         }
       }
 
-      const float x256 = rfft512_row(a, j, tw256, tw512, slot);
+      float* __restrict__ prow = P + f * kPStride;
+      const float x256 = rfft512_row(a, j, tw256, tw512, prow);
 
       if (MODE == kModeStft) {
         if (valid) {
@@ -229,7 +244,6 @@ __global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p
           }
         }
       } else {
-        float* __restrict__ prow = P + f * kBins;
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
           const v2f x = a[rev4(k2)];
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p
           prow[j + 16 * k2] = pw;
         }
         if (j == 0) prow[256] = p.power_is_1 ? fabsf(x256) : x256 * x256;
+        if (j >= 1 && j < 4) prow[256 + j] = 0.0f;  // zero tail read by the 4-wide mel loop
       }
     }
 
@@ -249,31 +264,47 @@ __global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p
     const int mg = tid >> 5;  // 0..7
     const int64_t t = t0 + f;
     const bool fvalid = t < frames_b;
-    const float* __restrict__ prow = P + f * kBins;
+    const float* __restrict__ prow = P + f * kPStride;
     float vmax = -INFINITY, vmin = INFINITY;
-    float* stage = reinterpret_cast<float*>(scratch);  // kaldi: [32][n_mels+1] staging (aliases scratch)
-    for (int m = mg; m < p.n_mels; m += 8) {
-      const int k0 = mstart[m], cnt = mcount[m];
-      const float* __restrict__ w = mw + moffset[m];
-      float acc = 0.0f;
-      for (int i = 0; i < cnt; ++i) acc = fmaf(w[i], prow[k0 + i], acc);
-      if (MODE == kModeMel) {
-        float v = acc;
-        if (p.apply_db) v = p.mult * log10f(fmaxf(acc, p.amin)) - p.db_offset;
-        if (fvalid) {
-          p.out[(b * p.n_mels + m) * p.n_frames + t] = v;
-          vmax = fmaxf(vmax, v);
-          vmin = fminf(vmin, v);
+    float vals[kMaxMels / 8];
+    const float kLog2ToDb = p.mult * 0.30102999566398120f;  // mult * log10(2)
+#pragma unroll
+    for (int i8 = 0; i8 < kMaxMels / 8; ++i8) {
+      const int m = mg + 8 * i8;
+      float v = 0.0f;
+      if (m < p.n_mels) {
+        const int k0 = mstart[m], cnt = mcount[m];
+        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(mw + moffset[m]);
+        const float* __restrict__ pk = prow + k0;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int i = 0; i < cnt; i += 4) {  // weights are zero-padded to a multiple of 4 per filter
+          const float4 w = w4[i >> 2];
+          a0 = fmaf(w.x, pk[i], a0);
+          a1 = fmaf(w.y, pk[i + 1], a1);
+          a2 = fmaf(w.z, pk[i + 2], a2);
+          a3 = fmaf(w.w, pk[i + 3], a3);
         }
-      } else {
-        // dataset.py:154-155: zeros -> float64 eps, natural log
-        const float e = (acc == 0.0f) ? 2.220446049250313e-16f : acc;
-        stage[f * (p.n_mels + 1) + m] = logf(e);
+        const float acc = (a0 + a1) + (a2 + a3);
+        if (MODE == kModeMel) {
+          v = acc;
+          if (p.apply_db) v = kLog2ToDb * fast_log2(fmaxf(acc, p.amin)) - p.db_offset;
+          if (fvalid) {
+            p.out[(b * p.n_mels + m) * p.n_frames + t] = v;
+            vmax = fmaxf(vmax, v);
+            vmin = fminf(vmin, v);
+          }
+        } else {
+          // dataset.py:154-155: zeros -> float64 eps, natural log
+          const float e = (acc == 0.0f) ? 2.220446049250313e-16f : acc;
+          v = 0.69314718055994531f * fast_log2(e);
+        }
       }
+      vals[i8] = v;
     }
     if (MODE == kModeMel) {
       if (p.apply_db) {
-        float* red = reinterpret_cast<float*>(scratch);
+        float* red = P;  // P is dead after the barrier inside block_reduce
+        __syncthreads();
         const float bmax = block_reduce(vmax, red, true);
         const float bmin = block_reduce(vmin, red, false);
         if (tid == 0) {
@@ -284,13 +315,22 @@ __global__ __launch_bounds__(kThreads, 2) void feat512_kernel(const FeatParams p
         __syncthreads();
       }
     } else {
+      // stage the (32, n_mels) block in LDS (aliasing the dead P tile) so that the store is one
+      // contiguous 32*n_mels*4-byte run; rows past the utterance end are written as zeros.
       __syncthreads();
-      // coalesced store of the (32, n_mels) block, zero rows past the utterance end
+      float* stage = P;
+      const int sstride = p.n_mels + 1;
+#pragma unroll
+      for (int i8 = 0; i8 < kMaxMels / 8; ++i8) {
+        const int m = mg + 8 * i8;
+        if (m < p.n_mels) stage[f * sstride + m] = vals[i8];
+      }
+      __syncthreads();
       const int64_t rows = (p.n_frames - t0) < kTileFrames ? (p.n_frames - t0) : kTileFrames;
       float* __restrict__ o = p.out + (b * p.n_frames + t0) * p.n_mels;
       for (int idx = tid; idx < rows * p.n_mels; idx += kThreads) {
         const int ff = idx / p.n_mels, mm = idx - ff * p.n_mels;
-        o[idx] = (t0 + ff < frames_b) ? stage[ff * (p.n_mels + 1) + mm] : 0.0f;
+        o[idx] = (t0 + ff < frames_b) ? stage[ff * sstride + mm] : 0.0f;
       }
       __syncthreads();
     }
@@ -399,7 +439,9 @@ static int num_cus() {
   return g_num_cus;
 }
 
-static size_t feat_lds_bytes(int n_mels, int nnz) { return (size_t)kOffMel + 12 * (size_t)n_mels + 4 * (size_t)nnz + 16; }
+static size_t feat_lds_bytes(int n_mels, int nnz) {
+  return (size_t)kOffMel + 4 * (size_t)(((3 * n_mels + 3) / 4) * 4) + 4 * (size_t)nnz + 16;
+}
 
 template <int MODE>
 static int launch_feat(const FeatParams& p, hipStream_t stream) {
@@ -412,18 +454,20 @@ static int launch_feat(const FeatParams& p, hipStream_t stream) {
       return MA_ERR_LAUNCH;
     attr_set = true;
   }
-  const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;
+  int per_cu = (int)((160 * 1024) / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
   int64_t grid = (int64_t)num_cus() * per_cu;
   if (grid > p.num_tiles) grid = p.num_tiles;
   if (grid < 1) return MA_OK;
-  hipLaunchKernelGGL(feat512_kernel<MODE>, dim3((unsigned)grid), dim3(kThreads), lds, stream, p);
-  return hipGetLastError() == hipSuccess ? MA_OK : MA_ERR_LAUNCH;
+  MA_LAUNCH(feat512_kernel<MODE>, dim3((unsigned)grid), dim3(kThreads), lds, stream, p);
+  return MA_OK;
 }
 
 static int check_mel(const ma_melbank_t* mel, int n_fft) {
   if (!mel || !mel->start || !mel->count || !mel->offset || !mel->weights) return MA_ERR_INVALID_ARG;
   if (mel->n_mels < 1 || mel->nnz < 1 || mel->n_freqs != n_fft / 2 + 1) return MA_ERR_INVALID_ARG;
-  if ((int64_t)kTileFrames * (mel->n_mels + 1) * 4 > kScratchBytes) return MA_ERR_UNSUPPORTED;
+  if (mel->n_mels > kMaxMels) return MA_ERR_UNSUPPORTED;
+  if (mel->nnz % 4 != 0) return MA_ERR_INVALID_ARG;  // per-filter zero padding to 4 weights (header contract)
   return MA_OK;
 }
 
@@ -545,9 +589,8 @@ int ma_fbank_db_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stri
   rc = launch_feat<kModeMel>(p, (hipStream_t)stream);
   if (rc != MA_OK) return rc;
   if (top_db >= 0.0f) {
-    hipLaunchKernelGGL(topdb_tiles_kernel, dim3((unsigned)p.num_tiles), dim3(kThreads), 0, (hipStream_t)stream, out,
-                       p.tile_max, p.tile_min, p.num_tiles, p.tiles_per_utt, p.n_frames, p.n_mels, top_db);
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;
+    MA_LAUNCH(topdb_tiles_kernel, dim3((unsigned)p.num_tiles), dim3(kThreads), 0, (hipStream_t)stream, out,
+              p.tile_max, p.tile_min, p.num_tiles, p.tiles_per_utt, p.n_frames, p.n_mels, top_db);
   }
   return MA_OK;
 }
@@ -580,8 +623,7 @@ int ma_fbank_kaldi_f32(const float* wav, const int64_t* lengths, int64_t batch, 
   p.num_tiles = batch * p.tiles_per_utt;
   if (workspace_bytes < ma_fbank_workspace_bytes(batch, p.n_frames)) return MA_ERR_WORKSPACE;
   p.partial = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(kaldi_sum_kernel, dim3((unsigned)p.num_tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
-  if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;
+  MA_LAUNCH(kaldi_sum_kernel, dim3((unsigned)p.num_tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
   return launch_feat<kModeKaldi>(p, (hipStream_t)stream);
 }
 
@@ -602,13 +644,11 @@ int ma_amplitude_to_db_f32(const float* in, int64_t groups, int64_t elems, float
   const int chunks = db_chunks(elems);
   if (!workspace || workspace_bytes < ma_db_workspace_bytes(groups, elems)) return MA_ERR_WORKSPACE;
   float* cmax = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(db_kernel, dim3(chunks, (unsigned)groups), dim3(kThreads), 0, (hipStream_t)stream, in, out,
-                     elems, chunks, mult, amin, db_offset, cmax);
-  if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;
+  MA_LAUNCH(db_kernel, dim3(chunks, (unsigned)groups), dim3(kThreads), 0, (hipStream_t)stream, in, out, elems,
+            chunks, mult, amin, db_offset, cmax);
   if (top_db >= 0.0f) {
-    hipLaunchKernelGGL(db_floor_kernel, dim3(chunks, (unsigned)groups), dim3(kThreads), 0, (hipStream_t)stream, out,
-                       elems, chunks, top_db, cmax);
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;
+    MA_LAUNCH(db_floor_kernel, dim3(chunks, (unsigned)groups), dim3(kThreads), 0, (hipStream_t)stream, out, elems,
+              chunks, top_db, cmax);
   }
   return MA_OK;
 }

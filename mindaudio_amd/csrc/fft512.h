@@ -3,7 +3,8 @@
 // A wave64 holds FOUR frames at once (one per 16-lane DPP row).  Per frame:
 //   z[m] = x[2m] + i x[2m+1]            (256 complex points, 16 per lane, in VGPRs)
 //   pass 1: 16-point FFT in registers over m1 (m = 16 m1 + lane)
-//   twiddle W256^(lane*q), transpose 16x16 through a padded LDS slot (the ONLY exchange)
+//   twiddle W256^(lane*q), transpose 16x16 through a padded LDS slot (the ONLY exchange; re and im
+//   go through the same 1 KiB slot one after the other)
 //   pass 2: 16-point FFT in registers over m2  -> Z[lane + 16 k2]
 //   real split: X[k] = E[k] + W512^k O[k] with the k <-> 256-k partner fetched from lane
 //   (16-lane)%16 by two DPP row ops (row_mirror, row_ror:1) — no LDS, no bpermute.
@@ -61,27 +62,41 @@ __device__ __forceinline__ float row_partner(float v) {
   return __builtin_bit_cast(float, r);
 }
 
-constexpr int kSlotStride = 16 * 17;  // v2f elements per frame slot (row stride 17: conflict-free both ways)
+constexpr int kSlotFloats = 16 * 17;  // floats per frame slot (row stride 17: conflict-free both ways)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // In : a[m1] = windowed z[16*m1 + j] for this lane's frame (j = lane & 15)
 // Out: a[rev4(k2)] = X[j + 16*k2]; returns X[256] (real) valid on lane j == 0.
 //   tw256: LDS table [q*16 + j] = W256^(q*j);  tw512: LDS table [k] = (cos, sin)(2 pi k / 512)
-//   slot : this frame's private LDS transpose area (kSlotStride v2f)
+//   slot : this frame's private LDS transpose area (kSlotFloats floats); the 16x16 complex transpose goes
+//          through it one component at a time (re, then im), so the slot is only 1088 bytes and can alias
+//          the frame's row of the power tile.
 __device__ __forceinline__ float rfft512_row(v2f (&a)[16], int j, const v2f* __restrict__ tw256,
-                                            const v2f* __restrict__ tw512, v2f* __restrict__ slot) {
+                                            const v2f* __restrict__ tw512, float* __restrict__ slot) {
   fft16(a);
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const int q = rev4(p);
-    v2f y = a[p];
-    if (q != 0) y = cmul(y, tw256[q * 16 + j]);
-    slot[q * 17 + j] = y;
+    if (q != 0) a[p] = cmul(a[p], tw256[q * 16 + j]);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int m2 = 0; m2 < 16; ++m2) a[m2] = slot[j * 17 + m2];
+  for (int p = 0; p < 16; ++p) slot[rev4(p) * 17 + j] = a[p].x;
+  wave_lds_sync();
+  float re[16];
+#pragma unroll
+  for (int m2 = 0; m2 < 16; ++m2) re[m2] = slot[j * 17 + m2];
+  wave_lds_sync();
+#pragma unroll
+  for (int p = 0; p < 16; ++p) slot[rev4(p) * 17 + j] = a[p].y;
+  wave_lds_sync();
+#pragma unroll
+  for (int m2 = 0; m2 < 16; ++m2) a[m2] = v2f{re[m2], slot[j * 17 + m2]};
+  wave_lds_sync();
   fft16(a);  // a[rev4(k2)] = Z[j + 16 k2]
 
   const float x256 = a[0].x - a[0].y;  // lane 0: Z[0] -> X[256] = Re - Im

@@ -57,21 +57,29 @@ const char* ma_status_string(int status);
 int64_t ma_num_frames(int64_t n, int32_t n_fft, int32_t hop, int32_t center);
 
 /*
- * Triangular mel filterbank in "band" form: filter m covers the contiguous FFT bins
- * [start[m], start[m] + count[m]) with weights[offset[m] ...].  Built on the host in float64
- * (HTK bank of MelScale, spectrum.py:686-694; Kaldi bank of dataset.py:68-113) and uploaded once.
- * Layout contract: offset[m] % 4 == 0 and each filter's weights are followed by zeros up to a multiple
- * of 4 entries (the kernels read them 16 bytes at a time); nnz counts the padded entries.
+ * Triangular mel filterbank in grouped band form.  Built on the host in float64 (HTK bank of MelScale,
+ * spectrum.py:686-694; Kaldi bank of dataset.py:68-113), rounded to float32 and uploaded once.
+ *
+ * Filters are taken eight at a time: "row" i holds filters 8i .. 8i+7 (g = m % 8 is the lane group that
+ * evaluates filter m).  Every filter of a row is evaluated over the same number steps[i] of 4-bin steps
+ * (the widest filter of the row decides; the others carry zero weights), so the mel loop has wave-uniform
+ * trip counts and reads bins and weights 16 bytes at a time:
+ *
+ *   mel[m = 8i+g] = sum_{s < steps[i]} sum_{c < 4} weights[((row_off[i] + s) * 8 + g) * 4 + c]
+ *                                                 * spectrum[start[8i+g] + 4s + c]
+ *
+ * Contract: start[] % 4 == 0 and start[8i+g] + 4*steps[i] <= 260 (the kernels keep bins 257..259 at
+ * zero); row_off is the exclusive prefix sum of steps; filters >= n_mels in the last row have zero weights.
  */
 typedef struct ma_melbank {
   int32_t n_mels;
   int32_t n_freqs;          /* n_fft / 2 + 1 */
-  int32_t nnz;              /* total number of weights */
-  int32_t max_count;        /* max over m of count[m] */
-  const int32_t* start;     /* device, [n_mels] */
-  const int32_t* count;     /* device, [n_mels] */
-  const int32_t* offset;    /* device, [n_mels] */
-  const float* weights;     /* device, [nnz] */
+  int32_t n_rows;           /* ceil(n_mels / 8) */
+  int32_t total_steps;      /* sum of steps[] */
+  const int32_t* steps;     /* device, [n_rows] */
+  const int32_t* row_off;   /* device, [n_rows] */
+  const int32_t* start;     /* device, [n_rows * 8] */
+  const float* weights;     /* device, [total_steps * 8 * 4] */
 } ma_melbank_t;
 
 /*

@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
                "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

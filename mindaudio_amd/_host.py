@@ -114,34 +114,56 @@ def kaldi_banks_f64(num_bins, n_fft_padded, sample_freq, low_freq, high_freq):
     return np.pad(tri, ((0, 0), (0, 1)), "constant")
 
 
+def group_melbank(dense_mels_by_freqs, row_limit=260):
+    """(n_mels, n_freqs) float64 bank -> grouped band form of include/mindaudio_amd.h (struct ma_melbank):
+    steps[n_rows], row_off[n_rows], start[n_rows*8], weights[total_steps, 8, 4] (float32)."""
+    dense = np.asarray(dense_mels_by_freqs, dtype=np.float64)
+    n_mels, n_freqs = dense.shape
+    n_rows = (n_mels + 7) // 8
+    lo4 = np.zeros(n_rows * 8, np.int64)
+    hi4 = np.zeros(n_rows * 8, np.int64)
+    for m in range(n_mels):
+        nz = np.nonzero(dense[m])[0]
+        if nz.size:
+            lo4[m] = (int(nz[0]) // 4) * 4
+            hi4[m] = -(-(int(nz[-1]) + 1) // 4) * 4
+    steps = np.zeros(n_rows, np.int32)
+    for i in range(n_rows):
+        steps[i] = max(1, int(((hi4[8 * i:8 * i + 8] - lo4[8 * i:8 * i + 8]) // 4).max()))
+    row_off = np.concatenate(([0], np.cumsum(steps)[:-1])).astype(np.int32)
+    total = int(steps.sum())
+    start = np.zeros(n_rows * 8, np.int32)
+    weights = np.zeros((total, 8, 4), np.float64)
+    for i in range(n_rows):
+        span = 4 * int(steps[i])
+        for g in range(8):
+            m = 8 * i + g
+            st = int(min(lo4[m], row_limit - span))  # keep start + span inside the zero-padded row
+            st = max(st - st % 4, 0)
+            start[m] = st
+            if m < n_mels:
+                seg = np.zeros(span)
+                hi = min(st + span, n_freqs)
+                seg[:hi - st] = dense[m, st:hi]
+                assert np.count_nonzero(dense[m]) == np.count_nonzero(seg), "band does not fit its row"
+                weights[row_off[i]:row_off[i] + steps[i], g, :] = seg.reshape(-1, 4)
+    return steps, row_off, start, weights.astype(np.float32)
+
+
 class DeviceMelBank:
-    """Band form of a (n_mels, n_freqs) filterbank on the device + its ma_melbank struct."""
+    """Grouped band form of a (n_mels, n_freqs) filterbank on the device + its ma_melbank struct."""
 
     def __init__(self, dense_mels_by_freqs, device):
         t = torch()
         dense = np.asarray(dense_mels_by_freqs, dtype=np.float64)
-        n_mels, n_freqs = dense.shape
-        start = np.zeros(n_mels, np.int32)
-        count = np.zeros(n_mels, np.int32)
-        offset = np.zeros(n_mels, np.int32)
-        weights = []
-        for m in range(n_mels):
-            nz = np.nonzero(dense[m])[0]
-            offset[m] = len(weights)
-            if nz.size:
-                start[m] = nz[0]
-                count[m] = nz[-1] - nz[0] + 1
-                weights.extend(dense[m, nz[0]:nz[-1] + 1].tolist())
-                weights.extend([0.0] * (-len(weights) % 4))  # header contract: 16-byte groups per filter
-        if not weights:
-            weights = [0.0] * 4
-        self.n_mels, self.n_freqs = n_mels, n_freqs
+        self.n_mels, self.n_freqs = dense.shape
+        steps, row_off, start, weights = group_melbank(dense)
+        self.steps = t.from_numpy(steps).to(device)
+        self.row_off = t.from_numpy(row_off).to(device)
         self.start = t.from_numpy(start).to(device)
-        self.count = t.from_numpy(count).to(device)
-        self.offset = t.from_numpy(offset).to(device)
-        self.weights = t.from_numpy(np.asarray(weights, dtype=np.float32)).to(device)
-        self.struct = _lib.MelBank(n_mels, n_freqs, len(weights), int(count.max()), self.start.data_ptr(),
-                                   self.count.data_ptr(), self.offset.data_ptr(), self.weights.data_ptr())
+        self.weights = t.from_numpy(np.ascontiguousarray(weights)).to(device)
+        self.struct = _lib.MelBank(self.n_mels, self.n_freqs, len(steps), int(steps.sum()), self.steps.data_ptr(),
+                                   self.row_off.data_ptr(), self.start.data_ptr(), self.weights.data_ptr())
 
     def ref(self):
         return ctypes.byref(self.struct)

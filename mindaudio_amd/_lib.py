@@ -33,11 +33,11 @@ class MelBank(ctypes.Structure):
     _fields_ = [
         ("n_mels", i32),
         ("n_freqs", i32),
-        ("nnz", i32),
-        ("max_count", i32),
+        ("n_rows", i32),
+        ("total_steps", i32),
+        ("steps", ctypes.c_void_p),
+        ("row_off", ctypes.c_void_p),
         ("start", ctypes.c_void_p),
-        ("count", ctypes.c_void_p),
-        ("offset", ctypes.c_void_p),
         ("weights", ctypes.c_void_p),
     ]
 
@@ -69,7 +69,8 @@ class MindaudioAmdError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    # MINDAUDIO_AMD_LIB: developer override used by tools/ to load an instrumented build of the same sources
+    return os.environ.get("MINDAUDIO_AMD_LIB") or _build.LIB_PATH
 
 
 def load():

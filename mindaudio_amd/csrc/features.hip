@@ -9,15 +9,17 @@
 //   examples/conformer/dataset.py:117-168 compute_fbank_feats         (NumPy, Pool(8))
 //
 // Work decomposition (fast path, n_fft == 512):
-//   workgroup = 256 threads = 4 waves, persistent over "tiles" of 32 consecutive frames of one
-//   utterance.  Each wave transforms 4 frames at a time (one per 16-lane row, see fft512.h), two
-//   rounds per tile, and drops the 257 powers of every frame into an LDS tile P[32][257].
-//   After one barrier the same 256 threads apply the band mel bank with lane = frame (so every
-//   LDS read is conflict-free and every HBM store is a full 128-byte line per half-wave), take the
-//   log, track the tile min/max, and store.  The batch-global top_db floor is a second, tiny
-//   kernel that only rewrites tiles whose minimum is below (global max - top_db).
-//   HBM traffic: each wave sample is fetched from HBM once (the 3.2x frame overlap is served by
-//   L1/L2), each output element is written once.
+//   Each WAVE is an independent worker, persistent over "units" of 8 consecutive frames of one utterance
+//   (a workgroup is 4 such waves sharing the twiddle/window/mel tables in LDS; there is no workgroup
+//   barrier in the steady state).  Per unit the wave: (1) multiplies the samples it prefetched during the
+//   previous unit by the window, (2) issues the 16-byte loads of its NEXT unit, (3) runs the 8-lane-per-frame
+//   512-point real FFT (fft512.h) and drops the 257 powers of each frame into its private LDS tile
+//   Pw[8][260], (4) applies the band mel bank with lane&7 = frame, lane>>3 = mel group, takes the log and
+//   stores, tracking the unit minimum and the wave maximum.  The batch-global top_db floor is a second, tiny
+//   kernel that only rewrites units whose minimum is below (global max - top_db).
+//   HBM traffic: each wave sample is fetched from HBM once (the 3.2x frame overlap is served by L1/L2); each
+//   output element is written once (the four 32-byte pieces of a 128-byte output line come from the four
+//   waves of neighbouring units and merge in L2).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -34,12 +36,68 @@
     if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
   } while (0)
 
+// Phase timing for tools/ (compiled in only with -DMA_PROFILE; the shipped library has none of it).
+#ifdef MA_PROFILE
+#define MA_PROF_DECL               \
+  unsigned long long prof_t_ = 0;  \
+  int prof_stamp_n_ = 0;           \
+  unsigned long long prof_acc_[6] = {0, 0, 0, 0, 0, 0}
+#define MA_PROF_START()                          \
+  do {                                           \
+    __builtin_amdgcn_sched_barrier(0);           \
+    prof_t_ = __builtin_readcyclecounter();      \
+  } while (0)
+#define MA_PROF(i)                                                \
+  do {                                                            \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    prof_acc_[i] += now_ - prof_t_;                               \
+    prof_t_ = now_;                                               \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  } while (0)
+#define MA_STAMP(i)                                                                          \
+  do {                                                                                       \
+    if (p.prof && blockIdx.x == 0 && threadIdx.x == 0 && prof_stamp_n_ < 40) {               \
+      p.prof[16 + prof_stamp_n_] = ((unsigned long long)(i) << 56) | (wall_clock64() & 0xffffffffffffffull); \
+      ++prof_stamp_n_;                                                                       \
+    }                                                                                        \
+  } while (0)
+#define MA_PROF_FLUSH()                                                      \
+  do {                                                                       \
+    if ((threadIdx.x & 63) == 0 && p.prof)                                   \
+      for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&p.prof[i_], prof_acc_[i_]);  \
+  } while (0)
+#else
+#define MA_PROF_DECL
+#define MA_PROF_START()
+#define MA_PROF(i)
+#define MA_STAMP(i)
+#define MA_PROF_FLUSH()
+#endif
+
+#ifdef MA_PROFILE
+static unsigned long long* g_prof = nullptr;
+static int g_debug = 0;
+extern "C" void ma_debug_set_prof(void* buf) { g_prof = reinterpret_cast<unsigned long long*>(buf); }
+extern "C" void ma_debug_set_flags(int f) { g_debug = f; }
+#define MA_SET_PROF(p) \
+  (p).prof = g_prof;   \
+  (p).debug = g_debug
+#define MA_DBG(bit) (p.debug & (bit))
+#else
+#define MA_SET_PROF(p)
+#define MA_DBG(bit) 0
+#endif
+
 namespace ma {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kTileFrames = 32;
+constexpr int kUnitFrames = 8;    // frames one wave transforms at once (fft512.h)
+constexpr int kSumTileFrames = 32;  // frames per partial sum of the Kaldi mean pre-pass
 constexpr int kBins = 257;
+constexpr int kMaxGrid = 1024;
 
 enum Mode { kModeStft = 0, kModeMel = 1, kModeKaldi = 2 };
 
@@ -48,49 +106,61 @@ struct FeatParams {
   const int64_t* lengths;  // kaldi: valid samples per utterance (device)
   const float* window;     // n_fft (stft/mel) or frame_len (kaldi) floats
   float* out;
-  float* tile_max;  // [num_tiles] (mel with dB)
-  float* tile_min;
-  double* partial;  // kaldi: [num_tiles] windowed sums
-  const int* mel_start;
-  const int* mel_count;
-  const int* mel_offset;
-  const float* mel_w;
+  float* unit_min;  // [num_units] minimum dB of each 8-frame unit (mel with dB)
+  float* wg_max;    // [gridDim.x] maximum dB seen by each workgroup
+  double* partial;  // kaldi: [batch * sum_tiles_per_utt] windowed sums
+  unsigned long long* prof;  // MA_PROFILE builds only: per-phase cycle totals
+  const int* mel_steps;    // [n_rows]
+  const int* mel_row_off;  // [n_rows]
+  const int* mel_start;    // [n_rows * 8]
+  const float* mel_w;      // [total_steps * 8 * 4]
   int64_t n;           // samples per utterance (kaldi: max_n)
   int64_t wav_stride;
   int64_t n_frames;    // frames per utterance (kaldi: max frames)
-  int64_t num_tiles;
-  int32_t tiles_per_utt;
+  int32_t num_units;
+  int32_t units_per_utt;
+  int32_t sum_tiles_per_utt;
   int32_t hop;
   int32_t pad_left;    // n_fft/2 when centred, else 0
   int32_t pad_mode;
   int32_t frame_len;   // kaldi: 400; else 512
   int32_t n_mels;
-  int32_t nnz;
+  int32_t n_rows;
+  int32_t total_steps;
   int32_t apply_db;    // mel: 1 -> dB, 0 -> raw mel energies
   int32_t power_is_1;  // |X| instead of |X|^2
   int32_t layout;      // stft layout
+  int32_t debug;       // MA_PROFILE builds only: ablation bits
   float mult, amin, db_offset;
   float preemph;
 };
 
-// ---- sample fetch with np.pad semantics -------------------------------------------------
-__device__ __forceinline__ float fetch_padded(const float* __restrict__ x, int64_t i, int64_t n, int mode) {
-  if (i >= 0 && i < n) return x[i];
-  if (mode == MA_PAD_CONSTANT) return 0.0f;
-  if (mode == MA_PAD_REFLECT) i = (i < 0) ? -i : 2 * (n - 1) - i;
-  else if (mode == MA_PAD_EDGE) i = (i < 0) ? 0 : n - 1;
-  else i = (i < 0) ? -i - 1 : 2 * n - 1 - i;  // symmetric
-  i = i < 0 ? 0 : (i >= n ? n - 1 : i);
-  return x[i];
+// ---- sample fetch with np.pad semantics, branch-free (every load is issued, none waits on a branch) ----
+// 32-bit indices: signals are < 2^30 samples (checked on the host side of the C-ABI).
+__device__ __forceinline__ float fetch_padded(const float* __restrict__ x, int i, int n, int mode, bool valid) {
+  const bool inside = i >= 0 && i < n;
+  int r;
+  if (mode == MA_PAD_REFLECT) r = (i < 0) ? -i : 2 * (n - 1) - i;
+  else if (mode == MA_PAD_SYMMETRIC) r = (i < 0) ? -i - 1 : 2 * n - 1 - i;
+  else r = i;  // edge: clamped below; constant: value masked below
+  r = inside ? i : r;
+  r = r < 0 ? 0 : (r >= n ? n - 1 : r);
+  const float v = x[r];
+  const bool keep = valid && (inside || mode != MA_PAD_CONSTANT);
+  return keep ? v : 0.0f;
+}
+
+__device__ __forceinline__ float wave_reduce(float v, bool is_max) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off, 64);
+    v = is_max ? fmaxf(v, o) : fminf(v, o);
+  }
+  return v;
 }
 
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
-  // wave reduce via shuffles, then 4 partials through LDS
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    float o = __shfl_xor(v, off, 64);
-    v = is_max ? fmaxf(v, o) : fminf(v, o);
-  }
+  v = wave_reduce(v, is_max);
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) red[wave] = v;
   __syncthreads();
@@ -104,260 +174,377 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 #include "fft_tables.inc"
 
 // LDS carve (bytes). All offsets multiples of 16.
-//   P tile: 32 rows (frames) x kPStride floats.  Row f first serves as frame f's FFT transpose slot
-//   (kSlotFloats = 272 floats), then receives the 257 powers of the frame; kPStride = 273 is odd, so the
-//   mel phase (lane = frame) reads it conflict-free.
-constexpr int kPStride = 273;
-constexpr int kOffTw256 = 0;                          // 256 v2f
-constexpr int kOffTw512 = kOffTw256 + 256 * 8;        // 256 v2f
-constexpr int kOffWin = kOffTw512 + 256 * 8;          // 512 floats
-constexpr int kOffP = kOffWin + 512 * 4;              // 32 * 273 floats
-constexpr int kPBytes = ((kTileFrames * kPStride * 4 + 15) / 16) * 16;
-constexpr int kOffMel = kOffP + kPBytes;              // 3*n_mels ints (padded to 16 B) + nnz floats
-constexpr int kMaxMels = 128;                         // mel values a thread keeps in registers: 128 / 8
-static_assert(kSlotFloats <= kPStride, "transpose slot must fit in a P row");
+//   Each wave owns a power tile Pw: 8 rows (frames) x kPStride floats.  Row f first serves as frame f's FFT
+//   transpose slot (kSlotFloats = 256 floats), then receives the 257 powers of the frame (+3 zeros).
+//   kPStride = 260: a multiple of 4 (16-byte row reads in the mel phase) with kPStride/4 odd (rows land on
+//   different bank quads).
+constexpr int kPStride = 260;
+constexpr int kOffTw256 = 0;                          // 128 float4
+constexpr int kOffTw512 = kOffTw256 + 256 * 8;        // 257 float2 (+pad)
+constexpr int kOffWin = kOffTw512 + 264 * 8;          // 512 floats, pre-scaled by 1/2
+constexpr int kOffP = kOffWin + 512 * 4;              // kWaves * 8 * 260 floats
+constexpr int kPwFloats = kUnitFrames * kPStride;
+constexpr int kPBytes = kWaves * kPwFloats * 4;
+constexpr int kOffMel = kOffP + kPBytes;              // mel tables, then (kaldi) the per-wave output stage
+constexpr int kMaxRows = 16;                          // mel rows (8 filters each): n_mels <= 128
+static_assert(kSlotFloats <= kPStride && kPStride % 4 == 0 && (kPStride / 4) % 2 == 1, "P row layout");
+static_assert(kOffP % 16 == 0 && kOffMel % 16 == 0, "LDS alignment");
 
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32, 1 ulp
 
+// What one wave needs to know about its next 8-frame unit.
+struct Unit {
+  const float* xb;   // utterance base
+  int b;             // utterance
+  int t;             // this lane's frame index (t0 + (lane >> 3))
+  int t0;            // first frame of the unit
+  int frames_b;      // frames of the utterance
+  int n_valid;       // samples of the utterance
+  int s0;            // first sample of this lane's frame
+  bool valid;        // this lane's frame exists
+  bool fast;         // wave-uniform: every live frame can use aligned 16-byte loads
+  bool live;         // wave-uniform: at least one frame exists
+  float half_mean;   // kaldi: 0.5 * scalar mean of the utterance's windowed frames
+};
+
 template <int MODE>
-__global__ __launch_bounds__(kThreads, 3) void feat512_kernel(const FeatParams p) {
+__device__ __forceinline__ Unit decode_unit(const FeatParams& p, int unit, int lane) {
+  Unit u;
+  u.b = unit / p.units_per_utt;
+  u.t0 = (unit - u.b * p.units_per_utt) * kUnitFrames;
+  u.t = u.t0 + (lane >> 3);
+  u.xb = p.wav + (int64_t)u.b * p.wav_stride;
+  u.n_valid = (int)p.n;
+  u.frames_b = (int)p.n_frames;
+  u.half_mean = 0.0f;
+  if (MODE == kModeKaldi) {
+    int64_t nv = p.lengths[u.b];
+    if (nv > p.n) nv = p.n;
+    u.n_valid = (int)nv;
+    int fb = (u.n_valid >= p.frame_len) ? (u.n_valid - p.frame_len) / p.hop + 1 : 0;
+    if (fb > (int)p.n_frames) fb = (int)p.n_frames;
+    u.frames_b = fb;
+    // ONE scalar mean over all windowed frames of the utterance (dataset.py:165): fixed-order sum of the
+    // per-tile partials written by kaldi_sum_kernel (uniform addresses -> scalar loads).
+    double acc = 0.0;
+    const int tiles_b = (fb + kSumTileFrames - 1) / kSumTileFrames;
+    for (int i = 0; i < tiles_b; ++i) acc += p.partial[(int64_t)u.b * p.sum_tiles_per_utt + i];
+    u.half_mean = fb > 0 ? 0.5f * (float)(acc / ((double)fb * (double)p.frame_len)) : 0.0f;
+  }
+  u.valid = u.t < u.frames_b;
+  u.s0 = u.t * p.hop - p.pad_left;
+  const bool aligned16 = (reinterpret_cast<uintptr_t>(u.xb + u.s0) & 15) == 0;
+  bool ok;
+  if (MODE == kModeKaldi) ok = aligned16 && (p.frame_len & 3) == 0;
+  else ok = aligned16 && u.s0 >= 0 && u.s0 + 512 <= u.n_valid;
+  u.fast = __all(ok || !u.valid);
+  u.live = __any(u.valid);
+  return u;
+}
+
+#ifndef MA_LB_WAVES
+#define MA_LB_WAVES 2
+#endif
+template <int MODE, bool MAG>
+__global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const FeatParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  v2f* tw256 = reinterpret_cast<v2f*>(smem + kOffTw256);
-  v2f* tw512 = reinterpret_cast<v2f*>(smem + kOffTw512);
+  float4* tw256 = reinterpret_cast<float4*>(smem + kOffTw256);
+  float2* tw512 = reinterpret_cast<float2*>(smem + kOffTw512);
   float* win = reinterpret_cast<float*>(smem + kOffWin);
-  float* P = reinterpret_cast<float*>(smem + kOffP);
-  const int mel_ints = ((3 * p.n_mels + 3) / 4) * 4;
-  int* mstart = reinterpret_cast<int*>(smem + kOffMel);
-  int* mcount = mstart + p.n_mels;
-  int* moffset = mcount + p.n_mels;
-  float* mw = reinterpret_cast<float*>(mstart + mel_ints);  // 16-byte aligned
+  // mel tables: steps[16] | row_off[16] | start[n_rows*8] | weights[total_steps*8] float4 | kaldi stage
+  int* msteps = reinterpret_cast<int*>(smem + kOffMel);
+  int* mrowoff = msteps + kMaxRows;
+  int* mstart = mrowoff + kMaxRows;
+  float4* mw = reinterpret_cast<float4*>(mstart + kMaxRows * 8);  // 16-byte aligned
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int j = lane & 15;
-  const int g = lane >> 4;
+  float* Pw = reinterpret_cast<float*>(smem + kOffP) + wave * kPwFloats;  // this wave's power tile
 
-  // ---- per-workgroup tables (once; the grid is persistent) -------------------------------
-  {
-    tw256[tid] = v2f{kTw256[2 * tid], kTw256[2 * tid + 1]};
-    tw512[tid] = v2f{kTw512[2 * tid], kTw512[2 * tid + 1]};
-    for (int i = tid; i < 512; i += kThreads) win[i] = (i < p.frame_len) ? p.window[i] : 0.0f;
-    if (MODE != kModeStft) {
-      for (int i = tid; i < p.n_mels; i += kThreads) {
-        mstart[i] = p.mel_start[i];
-        mcount[i] = p.mel_count[i];
-        moffset[i] = p.mel_offset[i];
+  const Rfft512Lane L = rfft512_lane_setup(lane);
+  const int l = L.l;
+  float* __restrict__ prow_fft = Pw + (lane >> 3) * kPStride;  // FFT phase: lane group = frame
+  const int fm = lane & 7;                                      // mel phase: lane & 7 = frame,
+  const int mg = lane >> 3;                                     //            lane >> 3 = mel group
+  const float* __restrict__ prow_mel = Pw + fm * kPStride;
+  const float kLog2ToDb = p.mult * 0.30102999566398120f;        // mult * log10(2)
+  float wmax = -INFINITY;
+
+  const int ustride = gridDim.x * kWaves;
+  int unit = blockIdx.x * kWaves + wave;
+  MA_PROF_DECL;
+  MA_PROF_START();
+  MA_STAMP(1);  // kernel entry
+
+  // Software pipeline: the 16-byte sample loads of unit k+1 are issued before the FFT of unit k.
+  float4 X[16];
+  float xm[16];  // kaldi: the sample before each 4-sample group (pre-emphasis)
+  Unit cur;
+  auto issue = [&](const Unit& u) {
+    if (MODE == kModeKaldi) {
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) {
+        const int nn = 32 * m1 + 4 * l;
+        const bool in = u.valid && nn < p.frame_len;
+        const float* src = u.xb + (in ? u.s0 + nn : 0);
+        X[m1] = *reinterpret_cast<const float4*>(src);
+        xm[m1] = (in && u.s0 + nn > 0) ? src[-1] : 0.0f;
       }
-      for (int i = tid; i < p.nnz; i += kThreads) mw[i] = p.mel_w[i];
+    } else {
+      const float4* __restrict__ src = reinterpret_cast<const float4*>(u.xb + (u.valid ? u.s0 : 0)) + l;
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) X[m1] = src[8 * m1];
+    }
+  };
+  if (unit < p.num_units) {
+    cur = decode_unit<MODE>(p, unit, lane);
+    if (cur.live && cur.fast && !MA_DBG(1)) issue(cur);
+  }
+
+  // ---- per-workgroup tables (once: the grid is persistent); the first sample loads are already in flight
+  {
+    reinterpret_cast<float2*>(tw256)[tid] = make_float2(kTw256[2 * tid], kTw256[2 * tid + 1]);
+    for (int i = tid; i < 257; i += kThreads) tw512[i] = make_float2(kTw512[2 * i], kTw512[2 * i + 1]);
+    for (int i = tid; i < 512; i += kThreads) win[i] = (i < p.frame_len) ? 0.5f * p.window[i] : 0.0f;
+    if (MODE != kModeStft) {
+      if (tid < p.n_rows) {
+        msteps[tid] = p.mel_steps[tid];
+        mrowoff[tid] = p.mel_row_off[tid];
+      }
+      for (int i = tid; i < p.n_rows * 8; i += kThreads) mstart[i] = p.mel_start[i];
+      const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(p.mel_w);
+      for (int i = tid; i < p.total_steps * 8; i += kThreads) mw[i] = wsrc[i];
     }
   }
   __syncthreads();
+  MA_STAMP(2);  // tables ready
 
-  for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
-    const int64_t b = tile / p.tiles_per_utt;
-    const int64_t t0 = (int64_t)(tile % p.tiles_per_utt) * kTileFrames;
-    const float* __restrict__ xb = p.wav + b * p.wav_stride;
-    int64_t n_valid = p.n;        // samples of this utterance
-    int64_t frames_b = p.n_frames;
-    float mean = 0.0f;
-    if (MODE == kModeKaldi) {
-      n_valid = p.lengths[b];
-      if (n_valid > p.n) n_valid = p.n;
-      frames_b = (n_valid >= p.frame_len) ? (n_valid - p.frame_len) / p.hop + 1 : 0;
-      if (frames_b > p.n_frames) frames_b = p.n_frames;
-      // ONE scalar mean over all windowed frames of the utterance (dataset.py:165): fixed-order sum
-      // of the per-tile partials written by kaldi_sum_kernel.
-      double acc = 0.0;
-      const int64_t tiles_b = (frames_b + kTileFrames - 1) / kTileFrames;
-      for (int64_t i = 0; i < tiles_b; ++i) acc += p.partial[b * p.tiles_per_utt + i];
-      mean = frames_b > 0 ? (float)(acc / ((double)frames_b * (double)p.frame_len)) : 0.0f;
-    }
-
-#pragma unroll 1
-    for (int it = 0; it < kTileFrames / (kWaves * 4); ++it) {
-      const int f = it * (kWaves * 4) + wave * 4 + g;  // frame slot in the tile
-      const int64_t t = t0 + f;
-      const bool valid = t < frames_b;
-      // wave-uniform skip when none of the wave's 4 frames exists
-      if (!__any(valid)) continue;
-
-      v2f a[16];
-      const int64_t s0 = t * p.hop - p.pad_left;  // first sample of the frame
-      if (MODE == kModeKaldi) {
+  while (unit < p.num_units) {
+    MA_PROF(0);
+    const int next = unit + ustride;
+    float ar[16], ai[16], br[16], bi[16];
+    if (cur.live) {
+      // ---- consume the prefetched samples: window (pre-scaled by 1/2), pre-emphasis, mean ----------
+      if (MA_DBG(1)) {
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) { ar[m1] = l + m1; ai[m1] = 0.5f * l; br[m1] = m1; bi[m1] = 1.0f; }
+      } else if (cur.fast) {
 #pragma unroll
         for (int m1 = 0; m1 < 16; ++m1) {
-          const int nn = 32 * m1 + 2 * j;  // position inside the frame
-          float y0 = 0.0f, y1 = 0.0f;
-          if (valid && nn < p.frame_len) {
-            const int64_t s = s0 + nn;
-            const float xm = s > 0 ? xb[s - 1] : 0.0f;
-            const float x0 = xb[s];
-            y0 = (s > 0 ? x0 - p.preemph * xm : x0) * win[nn] - mean;
-            if (nn + 1 < p.frame_len) {
-              const float x1 = xb[s + 1];
-              y1 = (x1 - p.preemph * x0) * win[nn + 1] - mean;
-            }
-          }
-          a[m1] = v2f{y0, y1};
-        }
-      } else {
-        const bool interior = valid && s0 >= 0 && s0 + 512 <= n_valid &&
-                              ((reinterpret_cast<uintptr_t>(xb + s0) & 7) == 0);
-        if (interior) {
-          const v2f* __restrict__ src = reinterpret_cast<const v2f*>(xb + s0) + j;
-          const v2f* __restrict__ w2 = reinterpret_cast<const v2f*>(win) + j;
-#pragma unroll
-          for (int m1 = 0; m1 < 16; ++m1) a[m1] = src[16 * m1] * w2[16 * m1];
-        } else {
-#pragma unroll 1
-          for (int m1 = 0; m1 < 16; ++m1) {
-            const int nn = 32 * m1 + 2 * j;
-            float x0 = 0.0f, x1 = 0.0f;
-            if (valid) {
-              x0 = fetch_padded(xb, s0 + nn, n_valid, p.pad_mode);
-              x1 = fetch_padded(xb, s0 + nn + 1, n_valid, p.pad_mode);
-            }
-            // dynamic index into a[] would spill: select through a static unrolled scan
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-              if (q == m1) a[q] = v2f{x0 * win[nn], x1 * win[nn + 1]};
-          }
-        }
-      }
-
-      float* __restrict__ prow = P + f * kPStride;
-      const float x256 = rfft512_row(a, j, tw256, tw512, prow);
-
-      if (MODE == kModeStft) {
-        if (valid) {
-          if (p.layout == MA_STFT_FRAME_MAJOR) {
-            v2f* __restrict__ o = reinterpret_cast<v2f*>(p.out) + (b * p.n_frames + t) * kBins;
-#pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) o[j + 16 * k2] = a[rev4(k2)];
-            if (j == 0) o[256] = v2f{x256, 0.0f};
+          const int nn = 32 * m1 + 4 * l;
+          const float4 w = *reinterpret_cast<const float4*>(win + nn);
+          const float4 x = X[m1];
+          if (MODE == kModeKaldi) {
+            const bool in = cur.valid && nn < p.frame_len;
+            const float y0 = (cur.s0 + nn > 0) ? x.x - p.preemph * xm[m1] : x.x;
+            const float hm = in ? cur.half_mean : 0.0f;
+            const float k = in ? 1.0f : 0.0f;
+            ar[m1] = k * y0 * w.x - hm;
+            ai[m1] = k * (x.y - p.preemph * x.x) * w.y - hm;
+            br[m1] = k * (x.z - p.preemph * x.y) * w.z - hm;
+            bi[m1] = k * (x.w - p.preemph * x.z) * w.w - hm;
           } else {
-            v2f* __restrict__ o = reinterpret_cast<v2f*>(p.out) + b * (int64_t)kBins * p.n_frames + t;
-#pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) o[(int64_t)(j + 16 * k2) * p.n_frames] = a[rev4(k2)];
-            if (j == 0) o[(int64_t)256 * p.n_frames] = v2f{x256, 0.0f};
+            const float k = cur.valid ? 1.0f : 0.0f;
+            ar[m1] = k * x.x * w.x; ai[m1] = k * x.y * w.y; br[m1] = k * x.z * w.z; bi[m1] = k * x.w * w.w;
           }
         }
       } else {
+        // edge / unaligned frames (rare): scalar loads, 16 in flight at a time
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-          const v2f x = a[rev4(k2)];
-          float pw = x.x * x.x + x.y * x.y;
-          if (p.power_is_1) pw = sqrtf(pw);
-          prow[j + 16 * k2] = pw;
+        for (int m1 = 0; m1 < 16; ++m1) {
+          const int nn = 32 * m1 + 4 * l;
+          const float4 w = *reinterpret_cast<const float4*>(win + nn);
+          float v[4];
+          if (MODE == kModeKaldi) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const bool in = cur.valid && nn + c < p.frame_len;
+              const int sidx = in ? cur.s0 + nn + c : 0;
+              const float x0 = cur.xb[sidx];
+              const float xp = cur.xb[sidx > 0 ? sidx - 1 : 0];
+              const float wc = c == 0 ? w.x : (c == 1 ? w.y : (c == 2 ? w.z : w.w));
+              const float y = (sidx > 0 ? x0 - p.preemph * xp : x0) * wc - cur.half_mean;
+              v[c] = in ? y : 0.0f;
+            }
+          } else {
+            v[0] = fetch_padded(cur.xb, cur.s0 + nn, cur.n_valid, p.pad_mode, cur.valid) * w.x;
+            v[1] = fetch_padded(cur.xb, cur.s0 + nn + 1, cur.n_valid, p.pad_mode, cur.valid) * w.y;
+            v[2] = fetch_padded(cur.xb, cur.s0 + nn + 2, cur.n_valid, p.pad_mode, cur.valid) * w.z;
+            v[3] = fetch_padded(cur.xb, cur.s0 + nn + 3, cur.n_valid, p.pad_mode, cur.valid) * w.w;
+          }
+          ar[m1] = v[0]; ai[m1] = v[1]; br[m1] = v[2]; bi[m1] = v[3];
+          if ((m1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        if (j == 0) prow[256] = p.power_is_1 ? fabsf(x256) : x256 * x256;
-        if (j >= 1 && j < 4) prow[256 + j] = 0.0f;  // zero tail read by the 4-wide mel loop
       }
     }
+    MA_PROF(1);
+    MA_STAMP(3);  // samples consumed
 
-    if (MODE == kModeStft) continue;
-    __syncthreads();
+    // ---- prefetch the next unit ------------------------------------------------------------------
+    Unit nxt = cur;
+    if (next < p.num_units) {
+      nxt = decode_unit<MODE>(p, next, lane);
+      if (nxt.live && nxt.fast && !MA_DBG(1)) issue(nxt);
+    }
 
-    // ---- mel phase: lane = frame, mel filter uniform per half-wave ------------------------
-    const int f = tid & 31;
-    const int mg = tid >> 5;  // 0..7
-    const int64_t t = t0 + f;
-    const bool fvalid = t < frames_b;
-    const float* __restrict__ prow = P + f * kPStride;
-    float vmax = -INFINITY, vmin = INFINITY;
-    float vals[kMaxMels / 8];
-    const float kLog2ToDb = p.mult * 0.30102999566398120f;  // mult * log10(2)
+    if (cur.live) {
+      const int t = cur.t;
+      const bool valid = cur.valid;
+      if (MA_DBG(8)) {
+        float sacc = 0.f;
 #pragma unroll
-    for (int i8 = 0; i8 < kMaxMels / 8; ++i8) {
-      const int m = mg + 8 * i8;
-      float v = 0.0f;
-      if (m < p.n_mels) {
-        const int k0 = mstart[m], cnt = mcount[m];
-        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(mw + moffset[m]);
-        const float* __restrict__ pk = prow + k0;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        for (int i = 0; i < cnt; i += 4) {  // weights are zero-padded to a multiple of 4 per filter
-          const float4 w = w4[i >> 2];
-          a0 = fmaf(w.x, pk[i], a0);
-          a1 = fmaf(w.y, pk[i + 1], a1);
-          a2 = fmaf(w.z, pk[i + 2], a2);
-          a3 = fmaf(w.w, pk[i + 3], a3);
+        for (int m1 = 0; m1 < 16; ++m1) sacc += ar[m1] + ai[m1] + br[m1] + bi[m1];
+        prow_fft[l * 32] = sacc;
+      } else if (MODE == kModeStft) {
+        const int64_t stride = (p.layout == MA_STFT_FRAME_MAJOR) ? 1 : p.n_frames;
+        float2* __restrict__ o = reinterpret_cast<float2*>(p.out) +
+                                 ((p.layout == MA_STFT_FRAME_MAJOR)
+                                      ? ((int64_t)cur.b * p.n_frames + t) * kBins
+                                      : (int64_t)cur.b * kBins * p.n_frames + t);
+        rfft512_x8(ar, ai, br, bi, L, tw256, tw512, prow_fft,
+                   [&](int q, float xr, float xi, float yr, float yi) {
+                     if (valid) {
+                       const int ka = (q < 8 ? L.ka_lo : L.ka_hi) + 16 * q;
+                       o[(int64_t)ka * stride] = make_float2(xr, xi);
+                       o[(int64_t)(256 - ka) * stride] = make_float2(yr, yi);
+                     }
+                   },
+                   [&](float xr, float xi) {
+                     if (valid && L.lane0) o[(int64_t)128 * stride] = make_float2(xr, xi);
+                   });
+      } else {
+        float* __restrict__ pa_lo = prow_fft + L.ka_lo;
+        float* __restrict__ pa_hi = prow_fft + L.ka_hi;
+        float* __restrict__ pb_lo = prow_fft + 256 - L.ka_lo;
+        float* __restrict__ pb_hi = prow_fft + 256 - L.ka_hi;
+        rfft512_x8(ar, ai, br, bi, L, tw256, tw512, prow_fft,
+                   [&](int q, float xr, float xi, float yr, float yi) {
+                     float pa = xr * xr + xi * xi;
+                     float pb = yr * yr + yi * yi;
+                     if (MAG) { pa = sqrtf(pa); pb = sqrtf(pb); }
+                     if (q < 8) { pa_lo[16 * q] = pa; pb_lo[-16 * q] = pb; }
+                     else       { pa_hi[16 * q] = pa; pb_hi[-16 * q] = pb; }
+                   },
+                   [&](float xr, float xi) {
+                     if (L.lane0) {
+                       const float pc = xr * xr + xi * xi;
+                       prow_fft[128] = MAG ? sqrtf(pc) : pc;
+                     } else if (l < 4) {
+                       prow_fft[256 + l] = 0.0f;  // zero tail [257..259] read by the 16-byte mel loop
+                     }
+                   });
+      }
+      MA_PROF(2);
+      MA_STAMP(4);  // fft done
+
+      if (MODE != kModeStft) {
+        wave_lds_sync();
+        // ---- mel phase inside the wave: lane & 7 = frame, lane >> 3 = mel group (m = mg + 8 i) -------
+        const int tm = cur.t0 + fm;
+        const bool fvalid = tm < cur.frames_b;
+        float vmin = INFINITY;
+        float* __restrict__ stage = reinterpret_cast<float*>(mw + p.total_steps * 8) + wave * (kUnitFrames * (p.n_mels + 1));
+        float* __restrict__ ocol = p.out + ((int64_t)cur.b * p.n_mels + mg) * p.n_frames + tm;
+        const int64_t ostep = 8 * p.n_frames;
+#pragma unroll 2
+        for (int i = 0; i < p.n_rows; ++i) {
+          // grouped band form (include/mindaudio_amd.h): every filter of row i takes steps[i] 16-byte steps
+          const int n = __builtin_amdgcn_readfirstlane(MA_DBG(2) ? 1 : msteps[i]);
+          const float4* __restrict__ w4 = mw + mrowoff[i] * 8 + mg;
+          const float4* __restrict__ p4 = reinterpret_cast<const float4*>(prow_mel + mstart[i * 8 + mg]);
+          float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll 4
+          for (int st = 0; st < n; ++st) {
+            const float4 w = w4[st * 8];
+            const float4 x = p4[st];
+            a0 = fmaf(w.x, x.x, a0);
+            a1 = fmaf(w.y, x.y, a1);
+            a2 = fmaf(w.z, x.z, a2);
+            a3 = fmaf(w.w, x.w, a3);
+          }
+          const float acc = (a0 + a1) + (a2 + a3);
+          const int m = mg + 8 * i;
+          if (MODE == kModeMel) {
+            float v = acc;
+            if (p.apply_db) v = kLog2ToDb * fast_log2(fmaxf(acc, p.amin)) - p.db_offset;
+            if (fvalid && m < p.n_mels && !(MA_DBG(4) && v != 12345.0f)) {
+              ocol[i * ostep] = v;
+              wmax = fmaxf(wmax, v);
+              vmin = fminf(vmin, v);
+            }
+          } else {
+            // dataset.py:154-155: zeros -> float64 eps, natural log
+            const float e = (acc == 0.0f) ? 2.220446049250313e-16f : acc;
+            if (m < p.n_mels) stage[fm * (p.n_mels + 1) + m] = 0.69314718055994531f * fast_log2(e);
+          }
         }
-        const float acc = (a0 + a1) + (a2 + a3);
+        MA_PROF(4);
         if (MODE == kModeMel) {
-          v = acc;
-          if (p.apply_db) v = kLog2ToDb * fast_log2(fmaxf(acc, p.amin)) - p.db_offset;
-          if (fvalid) {
-            p.out[(b * p.n_mels + m) * p.n_frames + t] = v;
-            vmax = fmaxf(vmax, v);
-            vmin = fminf(vmin, v);
+          if (p.apply_db) {
+            vmin = wave_reduce(vmin, false);
+            if (lane == 0) p.unit_min[unit] = vmin;
           }
+          wave_lds_sync();  // Pw is rewritten by the next unit's transpose
         } else {
-          // dataset.py:154-155: zeros -> float64 eps, natural log
-          const float e = (acc == 0.0f) ? 2.220446049250313e-16f : acc;
-          v = 0.69314718055994531f * fast_log2(e);
+          // the (8, n_mels) block was staged in LDS so that the store is one contiguous 8*n_mels*4-byte
+          // run; rows past the utterance end are written as zeros.
+          wave_lds_sync();
+          const int sstride = p.n_mels + 1;
+          const int rows = ((int)p.n_frames - cur.t0) < kUnitFrames ? ((int)p.n_frames - cur.t0) : kUnitFrames;
+          float* __restrict__ o = p.out + ((int64_t)cur.b * p.n_frames + cur.t0) * p.n_mels;
+          for (int idx = lane; idx < rows * p.n_mels; idx += 64) {
+            const int ff = idx / p.n_mels, mm = idx - ff * p.n_mels;
+            o[idx] = (cur.t0 + ff < cur.frames_b) ? stage[ff * sstride + mm] : 0.0f;
+          }
+          wave_lds_sync();
         }
+        MA_PROF(5);
+        MA_STAMP(5);  // mel done
       }
-      vals[i8] = v;
+    } else if (MODE == kModeKaldi) {
+      // unit entirely past the utterance end: zero rows (pad_sequence padding, dataset.py:563-569)
+      const int rows = ((int)p.n_frames - cur.t0) < kUnitFrames ? ((int)p.n_frames - cur.t0) : kUnitFrames;
+      float* __restrict__ o = p.out + ((int64_t)cur.b * p.n_frames + cur.t0) * p.n_mels;
+      for (int idx = lane; idx < rows * p.n_mels; idx += 64) o[idx] = 0.0f;
+    } else if (MODE == kModeMel && p.apply_db) {
+      if (lane == 0) p.unit_min[unit] = INFINITY;
     }
-    if (MODE == kModeMel) {
-      if (p.apply_db) {
-        float* red = P;  // P is dead after the barrier inside block_reduce
-        __syncthreads();
-        const float bmax = block_reduce(vmax, red, true);
-        const float bmin = block_reduce(vmin, red, false);
-        if (tid == 0) {
-          p.tile_max[tile] = bmax;
-          p.tile_min[tile] = bmin;
-        }
-      } else {
-        __syncthreads();
-      }
-    } else {
-      // stage the (32, n_mels) block in LDS (aliasing the dead P tile) so that the store is one
-      // contiguous 32*n_mels*4-byte run; rows past the utterance end are written as zeros.
-      __syncthreads();
-      float* stage = P;
-      const int sstride = p.n_mels + 1;
-#pragma unroll
-      for (int i8 = 0; i8 < kMaxMels / 8; ++i8) {
-        const int m = mg + 8 * i8;
-        if (m < p.n_mels) stage[f * sstride + m] = vals[i8];
-      }
-      __syncthreads();
-      const int64_t rows = (p.n_frames - t0) < kTileFrames ? (p.n_frames - t0) : kTileFrames;
-      float* __restrict__ o = p.out + (b * p.n_frames + t0) * p.n_mels;
-      for (int idx = tid; idx < rows * p.n_mels; idx += kThreads) {
-        const int ff = idx / p.n_mels, mm = idx - ff * p.n_mels;
-        o[idx] = (t0 + ff < frames_b) ? stage[ff * sstride + mm] : 0.0f;
-      }
-      __syncthreads();
-    }
+    unit = next;
+    cur = nxt;
   }
+
+  if (MODE == kModeMel && p.apply_db) {
+    float* red = reinterpret_cast<float*>(smem + kOffTw256);  // tables are dead now
+    __syncthreads();
+    const float bmax = block_reduce(wmax, red, true);
+    if (tid == 0) p.wg_max[blockIdx.x] = bmax;
+  }
+  MA_STAMP(6);  // end
+  MA_PROF_FLUSH();
 }
 
 // ---- batch-global top_db floor (spectrum.py:79-89) ---------------------------------------
-// One workgroup per tile of the fbank kernel.  Every workgroup reduces the per-tile maxima
-// (num_tiles floats, L2-resident) to the global maximum, and only tiles whose minimum is below
-// the floor rewrite their 32 x n_mels block.
-__global__ __launch_bounds__(kThreads) void topdb_tiles_kernel(float* out, const float* tile_max,
-                                                               const float* tile_min, int64_t num_tiles,
-                                                               int tiles_per_utt, int64_t n_frames, int n_mels,
+// One wave per 8-frame unit of the fbank kernel.  Every workgroup reduces the per-workgroup maxima
+// (<= 1024 floats, L2-resident) to the global maximum; only units whose minimum is below the floor are
+// rewritten.
+__global__ __launch_bounds__(kThreads) void topdb_units_kernel(float* out, const float* wg_max, int n_wg,
+                                                               const float* unit_min, int num_units,
+                                                               int units_per_utt, int64_t n_frames, int n_mels,
                                                                float top_db) {
   __shared__ float red[kWaves];
   float m = -INFINITY;
-  for (int64_t i = threadIdx.x; i < num_tiles; i += kThreads) m = fmaxf(m, tile_max[i]);
-  const float gmax = block_reduce(m, red, true);
-  const float floor_db = gmax - top_db;
-  const int64_t tile = blockIdx.x;
-  if (tile_min[tile] >= floor_db) return;
-  const int64_t b = tile / tiles_per_utt;
-  const int64_t t0 = (tile % tiles_per_utt) * kTileFrames;
-  const int f = threadIdx.x & 31;
-  if (t0 + f >= n_frames) return;
-  for (int mm = threadIdx.x >> 5; mm < n_mels; mm += 8) {
-    float* q = out + (b * n_mels + mm) * n_frames + t0 + f;
+  for (int i = threadIdx.x; i < n_wg; i += kThreads) m = fmaxf(m, wg_max[i]);
+  const float floor_db = block_reduce(m, red, true) - top_db;
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (unit >= num_units) return;
+  if (unit_min[unit] >= floor_db) return;
+  const int b = unit / units_per_utt;
+  const int t = (unit - b * units_per_utt) * kUnitFrames + (lane & 7);
+  if (t >= n_frames) return;
+  for (int mm = lane >> 3; mm < n_mels; mm += 8) {
+    float* q = out + ((int64_t)b * n_mels + mm) * n_frames + t;
     *q = fmaxf(*q, floor_db);
   }
 }
@@ -366,15 +553,15 @@ __global__ __launch_bounds__(kThreads) void topdb_tiles_kernel(float* out, const
 __global__ __launch_bounds__(kThreads) void kaldi_sum_kernel(const FeatParams p) {
   __shared__ double red[kWaves];
   const int64_t tile = blockIdx.x;
-  const int64_t b = tile / p.tiles_per_utt;
-  const int64_t t0 = (tile % p.tiles_per_utt) * kTileFrames;
+  const int64_t b = tile / p.sum_tiles_per_utt;
+  const int64_t t0 = (tile % p.sum_tiles_per_utt) * kSumTileFrames;
   const float* __restrict__ xb = p.wav + b * p.wav_stride;
   int64_t n_valid = p.lengths[b];
   if (n_valid > p.n) n_valid = p.n;
   int64_t frames_b = (n_valid >= p.frame_len) ? (n_valid - p.frame_len) / p.hop + 1 : 0;
   if (frames_b > p.n_frames) frames_b = p.n_frames;
   double acc = 0.0;
-  const int total = kTileFrames * p.frame_len;
+  const int total = kSumTileFrames * p.frame_len;
   for (int idx = threadIdx.x; idx < total; idx += kThreads) {
     const int f = idx / p.frame_len, nn = idx - f * p.frame_len;
     const int64_t t = t0 + f;
@@ -439,35 +626,55 @@ static int num_cus() {
   return g_num_cus;
 }
 
-static size_t feat_lds_bytes(int n_mels, int nnz) {
-  return (size_t)kOffMel + 4 * (size_t)(((3 * n_mels + 3) / 4) * 4) + 4 * (size_t)nnz + 16;
+static size_t feat_lds_bytes(int mode, int n_mels, int n_rows, int total_steps) {
+  size_t b = (size_t)kOffMel;
+  if (mode == kModeStft) return b;
+  b += 4 * (size_t)(2 * kMaxRows + 8 * kMaxRows) + 16 * 8 * (size_t)total_steps;
+  if (mode == kModeKaldi) b += 4 * (size_t)kWaves * kUnitFrames * (n_mels + 1);
+  return (b + 15) & ~(size_t)15;
 }
 
-template <int MODE>
-static int launch_feat(const FeatParams& p, hipStream_t stream) {
-  const size_t lds = feat_lds_bytes(MODE == kModeStft ? 0 : p.n_mels, MODE == kModeStft ? 0 : p.nnz);
+template <int MODE, bool MAG>
+static int launch_feat_impl(const FeatParams& p_in, hipStream_t stream, int* grid_out) {
+  FeatParams p = p_in;
+  MA_SET_PROF(p);
+  const size_t lds = feat_lds_bytes(MODE, p.n_mels, p.n_rows, p.total_steps);
   if (lds > 160 * 1024) return MA_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&feat512_kernel<MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+  // The grid is persistent (unit = wave id + k * waves in the grid), so it must equal what the device really
+  // keeps resident: ask the runtime once per (kernel, LDS size) instead of assuming.
+  static size_t cached_lds = 0;
+  static int cached_per_cu = 0;
+  if (cached_lds != lds) {
+    const void* fn = reinterpret_cast<const void*>(&feat512_kernel<MODE, MAG>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return MA_ERR_LAUNCH;
-    attr_set = true;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kThreads, lds) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    cached_per_cu = per_cu > 4 ? 4 : per_cu;
+    cached_lds = lds;
   }
-  int per_cu = (int)((160 * 1024) / lds);
-  per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
-  int64_t grid = (int64_t)num_cus() * per_cu;
-  if (grid > p.num_tiles) grid = p.num_tiles;
+  int64_t grid = (int64_t)num_cus() * cached_per_cu;
+  if (grid > kMaxGrid) grid = kMaxGrid;
+  const int64_t need = (p.num_units + kWaves - 1) / kWaves;
+  if (grid > need) grid = need;
   if (grid < 1) return MA_OK;
-  MA_LAUNCH(feat512_kernel<MODE>, dim3((unsigned)grid), dim3(kThreads), lds, stream, p);
+  if (grid_out) *grid_out = (int)grid;
+  MA_LAUNCH((feat512_kernel<MODE, MAG>), dim3((unsigned)grid), dim3(kThreads), lds, stream, p);
   return MA_OK;
 }
 
+template <int MODE>
+static int launch_feat(const FeatParams& p, hipStream_t stream, int* grid_out = nullptr) {
+  if (MODE == kModeMel && p.power_is_1) return launch_feat_impl<MODE, true>(p, stream, grid_out);
+  return launch_feat_impl<MODE, false>(p, stream, grid_out);
+}
+
 static int check_mel(const ma_melbank_t* mel, int n_fft) {
-  if (!mel || !mel->start || !mel->count || !mel->offset || !mel->weights) return MA_ERR_INVALID_ARG;
-  if (mel->n_mels < 1 || mel->nnz < 1 || mel->n_freqs != n_fft / 2 + 1) return MA_ERR_INVALID_ARG;
-  if (mel->n_mels > kMaxMels) return MA_ERR_UNSUPPORTED;
-  if (mel->nnz % 4 != 0) return MA_ERR_INVALID_ARG;  // per-filter zero padding to 4 weights (header contract)
+  if (!mel || !mel->steps || !mel->row_off || !mel->start || !mel->weights) return MA_ERR_INVALID_ARG;
+  if (mel->n_mels < 1 || mel->total_steps < 1 || mel->n_freqs != n_fft / 2 + 1) return MA_ERR_INVALID_ARG;
+  if (mel->n_rows != (mel->n_mels + 7) / 8) return MA_ERR_INVALID_ARG;
+  if (mel->n_rows > kMaxRows) return MA_ERR_UNSUPPORTED;
   return MA_OK;
 }
 
@@ -500,15 +707,22 @@ int64_t ma_num_frames(int64_t n, int32_t n_fft, int32_t hop, int32_t center) {
   return center ? 1 + n / hop : 1 + (n - n_fft) / hop;
 }
 
+// workspace layout: [partial sums: batch*sum_tiles doubles][unit_min: num_units floats][wg_max: kMaxGrid floats]
+static int64_t ws_partial_bytes(int64_t batch, int64_t n_frames) {
+  return batch * ((n_frames + kSumTileFrames - 1) / kSumTileFrames) * 8;
+}
+static int64_t ws_units(int64_t batch, int64_t n_frames) {
+  return batch * ((n_frames + kUnitFrames - 1) / kUnitFrames);
+}
+
 int64_t ma_fbank_workspace_bytes(int64_t batch, int64_t n_frames) {
   if (batch < 1 || n_frames < 1) return MA_ERR_INVALID_ARG;
-  const int64_t tiles = batch * ((n_frames + kTileFrames - 1) / kTileFrames);
-  return tiles * 16 + 256;
+  return ws_partial_bytes(batch, n_frames) + ws_units(batch, n_frames) * 4 + kMaxGrid * 4 + 256;
 }
 
 static int fill_common(FeatParams& p, const float* wav, int64_t batch, int64_t n, int64_t wav_stride, int32_t n_fft,
                        int32_t hop, const float* window, int32_t center, int32_t pad_mode) {
-  if (!wav || !window || batch < 1 || n < 1 || wav_stride < n) return MA_ERR_INVALID_ARG;
+  if (!wav || !window || batch < 1 || n < 1 || wav_stride < n || n > (int64_t)0x3fffffff) return MA_ERR_INVALID_ARG;
   if (hop < 1) return MA_ERR_HOP;
   if (n_fft > n) return MA_ERR_NFFT_TOO_LARGE;
   if (pad_mode < MA_PAD_CONSTANT || pad_mode > MA_PAD_SYMMETRIC) return MA_ERR_INVALID_ARG;
@@ -523,8 +737,9 @@ static int fill_common(FeatParams& p, const float* wav, int64_t batch, int64_t n
   p.pad_mode = pad_mode;
   p.frame_len = n_fft;
   p.n_frames = center ? 1 + n / hop : 1 + (n - n_fft) / hop;
-  p.tiles_per_utt = (int32_t)((p.n_frames + kTileFrames - 1) / kTileFrames);
-  p.num_tiles = batch * p.tiles_per_utt;
+  p.units_per_utt = (int32_t)((p.n_frames + kUnitFrames - 1) / kUnitFrames);
+  if (batch * (int64_t)p.units_per_utt > (int64_t)0x7fffffff) return MA_ERR_INVALID_ARG;
+  p.num_units = (int32_t)(batch * p.units_per_utt);
   return MA_OK;
 }
 
@@ -544,12 +759,13 @@ static int mel_front(FeatParams& p, const ma_melbank_t* mel, float power) {
   int rc = check_mel(mel, 512);
   if (rc != MA_OK) return rc;
   if (power != 1.0f && power != 2.0f) return MA_ERR_UNSUPPORTED;
+  p.mel_steps = mel->steps;
+  p.mel_row_off = mel->row_off;
   p.mel_start = mel->start;
-  p.mel_count = mel->count;
-  p.mel_offset = mel->offset;
   p.mel_w = mel->weights;
   p.n_mels = mel->n_mels;
-  p.nnz = mel->nnz;
+  p.n_rows = mel->n_rows;
+  p.total_steps = mel->total_steps;
   p.power_is_1 = power == 1.0f;
   return MA_OK;
 }
@@ -584,13 +800,15 @@ int ma_fbank_db_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stri
   p.mult = mult;
   p.amin = amin;
   p.db_offset = db_offset;
-  p.tile_max = reinterpret_cast<float*>(workspace);
-  p.tile_min = p.tile_max + p.num_tiles;
-  rc = launch_feat<kModeMel>(p, (hipStream_t)stream);
+  p.unit_min = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_partial_bytes(batch, p.n_frames));
+  p.wg_max = p.unit_min + p.num_units;
+  int grid = 0;
+  rc = launch_feat<kModeMel>(p, (hipStream_t)stream, &grid);
   if (rc != MA_OK) return rc;
-  if (top_db >= 0.0f) {
-    MA_LAUNCH(topdb_tiles_kernel, dim3((unsigned)p.num_tiles), dim3(kThreads), 0, (hipStream_t)stream, out,
-              p.tile_max, p.tile_min, p.num_tiles, p.tiles_per_utt, p.n_frames, p.n_mels, top_db);
+  if (top_db >= 0.0f && grid > 0) {
+    MA_LAUNCH(topdb_units_kernel, dim3((unsigned)((p.num_units + kWaves - 1) / kWaves)), dim3(kThreads), 0,
+              (hipStream_t)stream, out, p.wg_max, grid, p.unit_min, p.num_units, p.units_per_utt, p.n_frames,
+              p.n_mels, top_db);
   }
   return MA_OK;
 }
@@ -599,7 +817,8 @@ int ma_fbank_kaldi_f32(const float* wav, const int64_t* lengths, int64_t batch, 
                        int32_t frame_len, int32_t frame_shift, int32_t n_fft, const float* window,
                        const ma_melbank_t* mel, float preemph, float* out, void* workspace,
                        int64_t workspace_bytes, ma_stream_t stream) {
-  if (!wav || !lengths || !window || !out || !workspace || batch < 1 || max_n < 1 || wav_stride < max_n)
+  if (!wav || !lengths || !window || !out || !workspace || batch < 1 || max_n < 1 || wav_stride < max_n ||
+      max_n > (int64_t)0x3fffffff)
     return MA_ERR_INVALID_ARG;
   if (frame_shift < 1) return MA_ERR_HOP;
   if (frame_len < 2 || frame_len > n_fft) return MA_ERR_WINDOW;
@@ -619,11 +838,14 @@ int ma_fbank_kaldi_f32(const float* wav, const int64_t* lengths, int64_t batch, 
   p.frame_len = frame_len;
   p.preemph = preemph;
   p.n_frames = (max_n - frame_len) / frame_shift + 1;
-  p.tiles_per_utt = (int32_t)((p.n_frames + kTileFrames - 1) / kTileFrames);
-  p.num_tiles = batch * p.tiles_per_utt;
+  p.units_per_utt = (int32_t)((p.n_frames + kUnitFrames - 1) / kUnitFrames);
+  p.sum_tiles_per_utt = (int32_t)((p.n_frames + kSumTileFrames - 1) / kSumTileFrames);
+  if (batch * (int64_t)p.units_per_utt > (int64_t)0x7fffffff) return MA_ERR_INVALID_ARG;
+  p.num_units = (int32_t)(batch * p.units_per_utt);
   if (workspace_bytes < ma_fbank_workspace_bytes(batch, p.n_frames)) return MA_ERR_WORKSPACE;
   p.partial = reinterpret_cast<double*>(workspace);
-  MA_LAUNCH(kaldi_sum_kernel, dim3((unsigned)p.num_tiles), dim3(kThreads), 0, (hipStream_t)stream, p);
+  MA_LAUNCH(kaldi_sum_kernel, dim3((unsigned)(batch * p.sum_tiles_per_utt)), dim3(kThreads), 0,
+            (hipStream_t)stream, p);
   return launch_feat<kModeKaldi>(p, (hipStream_t)stream);
 }
 

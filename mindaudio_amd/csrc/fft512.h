@@ -1,68 +1,68 @@
-// 512-point real FFT on one 16-lane row of a wavefront (gfx950, wave64).
+// 512-point real FFT on 8 lanes of a wavefront (gfx950, wave64): a wave transforms EIGHT frames at once.
 //
-// A wave64 holds FOUR frames at once (one per 16-lane DPP row).  Per frame:
-//   z[m] = x[2m] + i x[2m+1]            (256 complex points, 16 per lane, in VGPRs)
-//   pass 1: 16-point FFT in registers over m1 (m = 16 m1 + lane)
-//   twiddle W256^(lane*q), transpose 16x16 through a padded LDS slot (the ONLY exchange; re and im
-//   go through the same 1 KiB slot one after the other)
-//   pass 2: 16-point FFT in registers over m2  -> Z[lane + 16 k2]
-//   real split: X[k] = E[k] + W512^k O[k] with the k <-> 256-k partner fetched from lane
-//   (16-lane)%16 by two DPP row ops (row_mirror, row_ror:1) — no LDS, no bpermute.
-// Result: lane j holds X[j + 16 k2], k2 = 0..15 (register slot rev4(k2)); lane 0 also X[256].
+// Per frame (lane l = 0..7 of its 8-lane group), with z[m] = x[2m] + i x[2m+1], m = 16 m1 + m2:
+//   pass 1  lane l owns the two columns m2 = 2l, 2l+1 (one 16-byte load per m1 brings both): two 16-point
+//           FFTs over m1 in registers, then the twiddle W256^(q m2).
+//   swap    the 16x16 complex matrix goes through a 256-float LDS slot, one component at a time (re, im);
+//           8-byte writes, 16-byte reads, XOR-swizzled chunks.  This is the ONLY cross-lane exchange.
+//   pass 2  lane l owns the column PAIR (k1, 16-k1) (lane 0: columns 8 and 0): two 16-point FFTs over m2.
+//           Z[k] and Z[256-k] now sit in the SAME lane, so the real-FFT split
+//               A = Z[k] + conj(Z[256-k]),  B = Z[k] - conj(Z[256-k]),  T = i W512^k B,
+//               X[k] = A - T,   X[256-k] = conj(A + T)
+//           needs no lane traffic and each twiddle serves two outputs.  (The window is pre-scaled by 1/2 by
+//           the caller, which makes these exactly X, not 2X.)
+//   Lane 0's columns pair with themselves (0: r <-> 16-r, 8: r <-> 15-r); 32 selects put its operands in
+//   the generic slots, and X[128] is a one-liner.
+// All arithmetic is planar scalar f32 (packed f32 ops buy no throughput on gfx950 and cost register moves).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace ma {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ v2f cmul(v2f a, v2f w) {
-  return v2f{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
-}
-__device__ __forceinline__ v2f mul_mi(v2f a) { return v2f{a.y, -a.x}; }  // * (-i)
-__device__ __forceinline__ v2f mul_pi(v2f a) { return v2f{-a.y, a.x}; }  // * (+i)
-
 // base-4 digit reversal of a 4-bit index: where X[k] lives after fft16
 __host__ __device__ constexpr int rev4(int p) { return ((p >> 2) & 3) | ((p & 3) << 2); }
 
-__device__ __forceinline__ void radix4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
-  v2f s0 = a0 + a2, s1 = a0 - a2, s2 = a1 + a3, s3 = a1 - a3;
-  a0 = s0 + s2;
-  a2 = s0 - s2;
-  a1 = s1 + mul_mi(s3);
-  a3 = s1 + mul_pi(s3);
+__device__ __forceinline__ void radix4(float& r0, float& i0, float& r1, float& i1, float& r2, float& i2,
+                                       float& r3, float& i3) {
+  const float s0r = r0 + r2, s0i = i0 + i2, s1r = r0 - r2, s1i = i0 - i2;
+  const float s2r = r1 + r3, s2i = i1 + i3, s3r = r1 - r3, s3i = i1 - i3;
+  r0 = s0r + s2r; i0 = s0i + s2i;
+  r2 = s0r - s2r; i2 = s0i - s2i;
+  r1 = s1r + s3i; i1 = s1i - s3r;  // s1 - i s3
+  r3 = s1r - s3i; i3 = s1i + s3r;  // s1 + i s3
 }
 
-// forward 16-point DFT, input natural order, output X[k] at a[rev4(k)]
-__device__ __forceinline__ void fft16(v2f (&a)[16]) {
+__device__ __forceinline__ void cmul_inplace(float& r, float& i, float wr, float wi) {
+  const float nr = r * wr - i * wi;
+  i = r * wi + i * wr;
+  r = nr;
+}
+
+// forward 16-point DFT, input natural order, output X[k] at index rev4(k)
+__device__ __forceinline__ void fft16(float (&r)[16], float (&i)[16]) {
   constexpr float C1 = 0.92387953251128674f;  // cos(pi/8)
   constexpr float S1 = 0.38268343236508977f;  // sin(pi/8)
   constexpr float H = 0.70710678118654752f;
 #pragma unroll
-  for (int n2 = 0; n2 < 4; ++n2) radix4(a[n2], a[4 + n2], a[8 + n2], a[12 + n2]);
-  // a[4*k1 + n2] *= W16^(n2*k1)
-  a[5] = cmul(a[5], v2f{C1, -S1});
-  a[6] = v2f{(a[6].x + a[6].y) * H, (a[6].y - a[6].x) * H};
-  a[7] = cmul(a[7], v2f{S1, -C1});
-  a[9] = v2f{(a[9].x + a[9].y) * H, (a[9].y - a[9].x) * H};
-  a[10] = mul_mi(a[10]);
-  a[11] = v2f{(a[11].y - a[11].x) * H, -(a[11].x + a[11].y) * H};
-  a[13] = cmul(a[13], v2f{S1, -C1});
-  a[14] = v2f{(a[14].y - a[14].x) * H, -(a[14].x + a[14].y) * H};
-  a[15] = cmul(a[15], v2f{-C1, S1});
+  for (int n2 = 0; n2 < 4; ++n2)
+    radix4(r[n2], i[n2], r[4 + n2], i[4 + n2], r[8 + n2], i[8 + n2], r[12 + n2], i[12 + n2]);
+  // element [4*k1 + n2] *= W16^(n2*k1)
+  cmul_inplace(r[5], i[5], C1, -S1);
+  { const float a = r[6], b = i[6]; r[6] = (a + b) * H; i[6] = (b - a) * H; }
+  cmul_inplace(r[7], i[7], S1, -C1);
+  { const float a = r[9], b = i[9]; r[9] = (a + b) * H; i[9] = (b - a) * H; }
+  { const float a = r[10]; r[10] = i[10]; i[10] = -a; }
+  { const float a = r[11], b = i[11]; r[11] = (b - a) * H; i[11] = -(a + b) * H; }
+  cmul_inplace(r[13], i[13], S1, -C1);
+  { const float a = r[14], b = i[14]; r[14] = (b - a) * H; i[14] = -(a + b) * H; }
+  cmul_inplace(r[15], i[15], -C1, S1);
 #pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) radix4(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+  for (int k1 = 0; k1 < 4; ++k1)
+    radix4(r[4 * k1], i[4 * k1], r[4 * k1 + 1], i[4 * k1 + 1], r[4 * k1 + 2], i[4 * k1 + 2], r[4 * k1 + 3],
+           i[4 * k1 + 3]);
 }
 
-// value of `v` held by lane (16 - j) % 16 of the same 16-lane row
-__device__ __forceinline__ float row_partner(float v) {
-  int x = __builtin_bit_cast(int, v);
-  int m = __builtin_amdgcn_update_dpp(0, x, 0x140 /*row_mirror*/, 0xf, 0xf, false);  // m[j] = v[15-j]
-  int r = __builtin_amdgcn_update_dpp(0, m, 0x121 /*row_ror:1*/, 0xf, 0xf, false);   // r[j] = m[(j-1)&15]
-  return __builtin_bit_cast(float, r);
-}
-
-constexpr int kSlotFloats = 16 * 17;  // floats per frame slot (row stride 17: conflict-free both ways)
+constexpr int kSlotFloats = 256;  // one component of the 16x16 matrix
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -70,52 +70,136 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// In : a[m1] = windowed z[16*m1 + j] for this lane's frame (j = lane & 15)
-// Out: a[rev4(k2)] = X[j + 16*k2]; returns X[256] (real) valid on lane j == 0.
-//   tw256: LDS table [q*16 + j] = W256^(q*j);  tw512: LDS table [k] = (cos, sin)(2 pi k / 512)
-//   slot : this frame's private LDS transpose area (kSlotFloats floats); the 16x16 complex transpose goes
-//          through it one component at a time (re, then im), so the slot is only 1088 bytes and can alias
-//          the frame's row of the power tile.
-__device__ __forceinline__ float rfft512_row(v2f (&a)[16], int j, const v2f* __restrict__ tw256,
-                                            const v2f* __restrict__ tw512, float* __restrict__ slot) {
-  fft16(a);
+// Per-lane constants of the 8-lane layout (kernel-invariant; l = lane & 7).
+struct Rfft512Lane {
+  int l;        // lane within the frame group
+  int wr_off[4];  // pass-1 write offset (floats) inside the slot for rows with (q >> 2) == c
+  int rd_a[4];  // pass-2 read offsets (floats) of column A chunks 0..3
+  int rd_b[4];  // ... column B
+  int ka_lo;    // kA of slot p (p < 8)  = ka_lo + 16 p
+  int ka_hi;    // kA of slot p (p >= 8) = ka_hi + 16 p
+  bool lane0;
+};
+
+__device__ __forceinline__ Rfft512Lane rfft512_lane_setup(int lane) {
+  Rfft512Lane s;
+  const int l = lane & 7;
+  s.l = l;
+  s.lane0 = (l == 0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) s.wr_off[c] = ((((2 * l) >> 2) ^ c) << 2) + ((2 * l) & 3);
+  const int k1a = s.lane0 ? 8 : l;         // column A
+  const int k1b = s.lane0 ? 0 : 16 - l;    // column B
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    s.rd_a[c] = k1a * 16 + ((c ^ (k1a >> 2)) << 2);
+    s.rd_b[c] = k1b * 16 + ((c ^ (k1b >> 2)) << 2);
+  }
+  s.ka_lo = s.lane0 ? 8 : l;    // generic: l + 16p ; lane 0, p < 8: 8 + 16p
+  s.ka_hi = s.lane0 ? 16 : l;   // lane 0, p >= 8: 16 (p + 1)
+  return s;
+}
+
+// One output pair of the real-FFT split.  u = Z[kA], v = Z[256 - kA], (c, s) = (cos, sin)(2 pi kA / 512).
+// Returns X[kA] in (xr, xi) and X[256 - kA] in (yr, yi).
+__device__ __forceinline__ void rsplit_pair(float ur, float ui, float vr, float vi, float c, float s, float& xr,
+                                            float& xi, float& yr, float& yi) {
+  const float ar = ur + vr, ai = ui - vi;  // A = u + conj(v)
+  const float br = ur - vr, bi = ui + vi;  // B = u - conj(v)
+  const float tr = s * br - c * bi;        // T = i W B,  W = c - i s
+  const float ti = c * br + s * bi;
+  xr = ar - tr; xi = ai - ti;
+  yr = ar + tr; yi = -(ai + ti);
+}
+
+// 512-point real FFT of 8 frames per wave.
+//   In : (ar, ai)[m1] = windowed (x[32 m1 + 4l], x[32 m1 + 4l + 1]) * 1/2   (column m2 = 2l)
+//        (br, bi)[m1] = windowed (x[32 m1 + 4l + 2], x[32 m1 + 4l + 3]) * 1/2 (column m2 = 2l + 1)
+//   Out: for slot p = 0..15 (compile-time constant): emit(p, xr, xi, yr, yi) with (xr, xi) = X[kA(p)],
+//        (yr, yi) = X[256 - kA(p)], kA(p) = (p < 8 ? ka_lo : ka_hi) + 16 p; emit128(re, im) = X[128],
+//        meaningful on lane 0 only.  Emitting inside the loop keeps the live register set at the 64 data
+//        registers instead of 128.
+//   tw256: LDS float4 table [q*8 + l] = (W256^(q*2l), W256^(q*(2l+1))) as (re, im, re, im)
+//   tw512: LDS float2 table [k] = (cos, sin)(2 pi k / 512), k = 0..256
+//   slot : this frame's 256-float LDS area (16-byte aligned)
+template <class Emit, class Emit128>
+__device__ __forceinline__ void rfft512_x8(float (&ar)[16], float (&ai)[16], float (&br)[16], float (&bi)[16],
+                                           const Rfft512Lane& s, const float4* __restrict__ tw256,
+                                           const float2* __restrict__ tw512, float* __restrict__ slot,
+                                           Emit&& emit, Emit128&& emit128) {
+  // sched_barrier(0) at the phase seams: without them hipcc hoists the LDS table reads of the later phases
+  // (3 x 60 registers) above the first FFT and the kernel drops from 3 to 2 waves per SIMD.
+  __builtin_amdgcn_sched_barrier(0);
+  fft16(ar, ai);
+  fft16(br, bi);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const int q = rev4(p);
-    if (q != 0) a[p] = cmul(a[p], tw256[q * 16 + j]);
+    if (q != 0) {
+      const float4 w = tw256[q * 8 + s.l];
+      cmul_inplace(ar[p], ai[p], w.x, w.y);
+      cmul_inplace(br[p], bi[p], w.z, w.w);
+    }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 16x16 transpose through LDS, real parts then imaginary parts -----------------------
 #pragma unroll
-  for (int p = 0; p < 16; ++p) slot[rev4(p) * 17 + j] = a[p].x;
+  for (int p = 0; p < 16; ++p) {
+    const int q = rev4(p);
+    *reinterpret_cast<float2*>(slot + q * 16 + s.wr_off[q >> 2]) = make_float2(ar[p], br[p]);
+  }
   wave_lds_sync();
-  float re[16];
+  float4 ca[4], cb[4];
 #pragma unroll
-  for (int m2 = 0; m2 < 16; ++m2) re[m2] = slot[j * 17 + m2];
+  for (int c = 0; c < 4; ++c) {
+    ca[c] = *reinterpret_cast<const float4*>(slot + s.rd_a[c]);
+    cb[c] = *reinterpret_cast<const float4*>(slot + s.rd_b[c]);
+  }
   wave_lds_sync();
 #pragma unroll
-  for (int p = 0; p < 16; ++p) slot[rev4(p) * 17 + j] = a[p].y;
+  for (int p = 0; p < 16; ++p) {
+    const int q = rev4(p);
+    *reinterpret_cast<float2*>(slot + q * 16 + s.wr_off[q >> 2]) = make_float2(ai[p], bi[p]);
+  }
   wave_lds_sync();
 #pragma unroll
-  for (int m2 = 0; m2 < 16; ++m2) a[m2] = v2f{re[m2], slot[j * 17 + m2]};
+  for (int c = 0; c < 4; ++c) {
+    const float4 ia = *reinterpret_cast<const float4*>(slot + s.rd_a[c]);
+    const float4 ib = *reinterpret_cast<const float4*>(slot + s.rd_b[c]);
+    ar[4 * c] = ca[c].x; ar[4 * c + 1] = ca[c].y; ar[4 * c + 2] = ca[c].z; ar[4 * c + 3] = ca[c].w;
+    br[4 * c] = cb[c].x; br[4 * c + 1] = cb[c].y; br[4 * c + 2] = cb[c].z; br[4 * c + 3] = cb[c].w;
+    ai[4 * c] = ia.x; ai[4 * c + 1] = ia.y; ai[4 * c + 2] = ia.z; ai[4 * c + 3] = ia.w;
+    bi[4 * c] = ib.x; bi[4 * c + 1] = ib.y; bi[4 * c + 2] = ib.z; bi[4 * c + 3] = ib.w;
+  }
   wave_lds_sync();
-  fft16(a);  // a[rev4(k2)] = Z[j + 16 k2]
+  __builtin_amdgcn_sched_barrier(0);
+  fft16(ar, ai);  // (ar, ai)[rev4(r)] = Z[k1a + 16 r]
+  fft16(br, bi);  // (br, bi)[rev4(r)] = Z[k1b + 16 r]
+  __builtin_amdgcn_sched_barrier(0);
 
-  const float x256 = a[0].x - a[0].y;  // lane 0: Z[0] -> X[256] = Re - Im
-  v2f x[16];
+  // ---- real-FFT split, 16 pair slots ---------------------------------------------------------
+  // generic lane: slot p pairs a[p] with b[15-p].  lane 0 (a = column 8, b = column 0):
+  //   p < 8 : a[p] with a[15-p]   (column 8 pairs with itself, r <-> 15 - r)
+  //   p >= 8: b[p+1 mod 16] with b[15-p]   (column 0, r <-> 16 - r; p = 15 is the k = 0 / 256 self pair)
 #pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) {
-    const v2f z = a[rev4(k2)];
-    const v2f src = a[rev4(15 - k2)];
-    v2f zp = v2f{row_partner(src.x), row_partner(src.y)};  // Z[256-k] for j != 0
-    const v2f own = a[rev4((16 - k2) & 15)];                // Z[256-k] for j == 0
-    zp = (j == 0) ? own : zp;
-    const v2f e = v2f{0.5f * (z.x + zp.x), 0.5f * (z.y - zp.y)};
-    const v2f o = v2f{0.5f * (z.y + zp.y), -0.5f * (z.x - zp.x)};
-    const v2f w = tw512[j + 16 * k2];  // (c, s); W512^k = c - i s
-    x[k2] = v2f{e.x + (w.x * o.x + w.y * o.y), e.y + (w.x * o.y - w.y * o.x)};
+  for (int p = 0; p < 16; ++p) {
+    float ur = ar[rev4(p)], ui = ai[rev4(p)];
+    float vr = br[rev4(15 - p)], vi = bi[rev4(15 - p)];
+    if (p < 8) {
+      vr = s.lane0 ? ar[rev4(15 - p)] : vr;
+      vi = s.lane0 ? ai[rev4(15 - p)] : vi;
+    } else {
+      ur = s.lane0 ? br[rev4((p + 1) & 15)] : ur;
+      ui = s.lane0 ? bi[rev4((p + 1) & 15)] : ui;
+    }
+    const float2 w = tw512[(p < 8 ? s.ka_lo : s.ka_hi) + 16 * p];
+    float xr, xi, yr, yi;
+    rsplit_pair(ur, ui, vr, vi, w.x, w.y, xr, xi, yr, yi);
+    emit(p, xr, xi, yr, yi);
   }
-#pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) a[rev4(k2)] = x[k2];
-  return x256;
+  // X[128] = conj(Z[128]) * 2 (window pre-scaled by 1/2): lane 0, column 0 (= b), r = 8
+  emit128(2.0f * br[rev4(8)], -2.0f * bi[rev4(8)]);
 }
 
 }  // namespace ma

@@ -146,6 +146,69 @@ int ma_amplitude_to_db_f32(const float* in, int64_t groups, int64_t elems_per_gr
                            float mult, float amin, float db_offset, float top_db,
                            float* out, void* workspace, int64_t workspace_bytes, ma_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Conformer encoder building blocks (mindaudio/models/conformer.py, mindaudio/models/layers/...).
+ * Activations that feed a matmul are bf16 (stored as uint16 bit patterns), the residual stream and all
+ * reductions are float32; every matmul accumulates in float32 on the MFMA units.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* What happens to acc = A . W^T before it is stored:
+ *   v = act(acc + bias[n]) * alpha * row_scale[m] (+ residual[m, n])
+ * act: 0 none, 1 swish x*sigmoid(x) (layers/swish.py:14-16), 2 relu.  NULL pointers switch a term off. */
+typedef struct ma_gemm_epilogue {
+  const float* bias;       /* device [N] */
+  const float* residual;   /* device (M, N) float32, row stride ldr */
+  const float* row_scale;  /* device [M]: the mask_pad multiply of layers/convolution.py:97-98,126-127 */
+  int64_t ldr;
+  float alpha;             /* e.g. ff_scale 0.5 (models/conformer.py:69) or sqrt(d_model) (embedding.py:84) */
+  int32_t act;
+  int32_t out_bf16;        /* 1: out is bf16, 0: float32 */
+} ma_gemm_epilogue_t;
+
+/* Dense / k=1 Conv1d (layers/dense.py:51-58, layers/conv1d.py): out (M, N) = epilogue(A (M, K) . W (N, K)^T).
+ * A, W device bf16 with K contiguous (W is the (out, in) weight as stored by the reference), K % 64 == 0,
+ * lda/ldw multiples of 8, 16-byte aligned bases. */
+int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* out, int64_t ldo,
+                 int64_t M, int64_t N, int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream);
+
+/* 3x3, stride 2, valid Conv2d (layers/subsampling.py:43) as an implicit GEMM.
+ *   act device bf16 NHWC (batch, H, Wd, C), C % 64 == 0;  W device bf16 (Cout, 3, 3, C) i.e. k = (kh, kw, c);
+ *   out (batch, Ho, Wo, Cout), Ho = (H-3)/2+1, Wo = (Wd-3)/2+1, dtype per epilogue. */
+int ma_conv2d_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* W,
+                              int64_t Cout, void* out, const ma_gemm_epilogue_t* epi, ma_stream_t stream);
+
+/* LayerNorm of layers/layernorm.py:53-60: (x - mean) / sqrt(biased_var + eps) * gamma + beta, one row per
+ * wave; optional row_scale[m] multiply (the `x * mask` in front of pointwise_conv1, convolution.py:97-98).
+ * x (rows, cols) float32; out bf16 or float32; cols in {256, 512, 768, 1024}. */
+int ma_layernorm_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma,
+                     const float* beta, float eps, const float* row_scale, void* out, int64_t ldo,
+                     int32_t out_bf16, ma_stream_t stream);
+
+/* GlobalCMVN (layers/cmvn.py:33-35; mean/istd may be NULL) + Conv2d(1 -> C, 3x3, stride 2, valid) + ReLU
+ * (layers/subsampling.py:41-42).  x (batch, T, idim) float32; w (C, 3, 3), bias (C) float32;
+ * out NHWC bf16 (batch, (T-3)/2+1, (idim-3)/2+1, C). */
+int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t idim, const float* cmvn_mean,
+                            const float* cmvn_istd, const float* w, const float* bias, int32_t C, void* out,
+                            ma_stream_t stream);
+
+/* RelPositionMultiHeadedAttention core (layers/attention.py:214-235 + 100-113), one fused kernel:
+ *   score = ((q + u) k^T + (q + v) p^T) / sqrt(d_k) + (mask == 0) * -10000 ; softmax ; . v     (no rel-shift)
+ *   qkv  device bf16 (batch*T, >= 768): columns [0,256) q, [256,512) k, [512,768) v, head h at h*64
+ *   pos  device bf16 (T, 256): linear_pos(pos_emb), shared by the batch (attention.py:210-211,230)
+ *   bias_u / bias_v float32 (heads, 64); mask float32 (batch, T) or NULL; ctx bf16 (batch*T, 256). */
+int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos,
+                             const float* bias_u, const float* bias_v, const float* mask, int64_t batch,
+                             int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
+                             ma_stream_t stream);
+
+/* Middle of ConvolutionModule (layers/convolution.py:100-121): GLU(dim=channels) -> depthwise Conv1d(k, same
+ * zero padding per utterance) -> BatchNorm1d in affine form -> Swish.
+ *   y (batch*T, 2C) bf16 = pointwise_conv1 output; dw (C, k) float32; out (batch*T, C) bf16
+ *   bn_scale = gamma / sqrt(var + eps), bn_shift = beta + (dw_bias - mean) * bn_scale  (host-folded). */
+int ma_convmodule_mid_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw,
+                           int32_t kernel_size, const float* bn_scale, const float* bn_shift, void* out,
+                           int64_t ldo, ma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

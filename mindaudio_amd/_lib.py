@@ -42,6 +42,22 @@ class MelBank(ctypes.Structure):
     ]
 
 
+class GemmEpilogue(ctypes.Structure):
+    """struct ma_gemm_epilogue (include/mindaudio_amd.h)."""
+
+    _fields_ = [
+        ("bias", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p),
+        ("row_scale", ctypes.c_void_p),
+        ("ldr", i64),
+        ("alpha", f32),
+        ("act", i32),
+        ("out_bf16", i32),
+    ]
+
+
+ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
+
 # name -> (restype, argtypes); must list every symbol include/mindaudio_amd.h declares
 PROTOTYPES = {
     "ma_abi_version": (ctypes.c_int, []),
@@ -56,6 +72,21 @@ PROTOTYPES = {
     "ma_fbank_kaldi_f32": (ctypes.c_int, [c_f32p, ctypes.c_void_p, i64, i64, i64, i32, i32, i32, c_f32p,
                                           ctypes.POINTER(MelBank), f32, c_f32p, ctypes.c_void_p, i64,
                                           ctypes.c_void_p]),
+    "ma_gemm_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p, i64, i64, i64, i64,
+                                    ctypes.POINTER(GemmEpilogue), ctypes.c_void_p]),
+    "ma_conv2d_3x3s2_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i64, ctypes.c_void_p, i64,
+                                                 ctypes.c_void_p, ctypes.POINTER(GemmEpilogue), ctypes.c_void_p]),
+    "ma_layernorm_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_void_p, f32,
+                                        ctypes.c_void_p, ctypes.c_void_p, i64, i32, ctypes.c_void_p]),
+    "ma_subsample_conv1_nhwc": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p, i32, ctypes.c_void_p,
+                                               ctypes.c_void_p]),
+    "ma_relpos_attention_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_void_p, i64, i64, i32, i32,
+                                                ctypes.c_void_p, i64, ctypes.c_void_p]),
+    "ma_convmodule_mid_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i32, ctypes.c_void_p, i32,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64,
+                                              ctypes.c_void_p]),
     "ma_db_workspace_bytes": (i64, [i64, i64]),
     "ma_amplitude_to_db_f32": (ctypes.c_int, [c_f32p, i64, i64, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),

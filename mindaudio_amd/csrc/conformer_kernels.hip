@@ -1,0 +1,407 @@
+// Non-GEMM kernels of the Conformer encoder forward for gfx950:
+//   ma_layernorm_f32            layers/layernorm.py:53-60 (biased variance, eps inside sqrt) [+ mask_pad multiply]
+//   ma_subsample_conv1_nhwc     layers/cmvn.py:33-35 fused into Conv2d(1->C, 3x3, s2)+ReLU of layers/subsampling.py:41-42
+//   ma_relpos_attention_bf16    layers/attention.py:182-237 + :100-115 (no rel-shift, additive -10000 mask)
+//   ma_convmodule_mid_bf16      layers/convolution.py:100-121: GLU -> depthwise k-tap conv -> BatchNorm (affine form)
+//                               -> Swish, between the two pointwise convolutions (which run on ma_gemm_bf16)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ uint16_t to_bf16(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float from_bf16(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- LayerNorm: one wave per row, D = 4 * 64 * VEC floats held in registers ---------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ row_scale, void* out,
+                                                        int64_t ldo, int out_bf16) {
+  constexpr int D = 256 * VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float4 v[VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float var = wave_sum(q) * (1.0f / D);
+  const float inv = 1.0f / sqrtf(var + eps);
+  const float rs = row_scale ? row_scale[row] : 1.0f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = (v[i].x * inv * g.x + b.x) * rs;
+    o.y = (v[i].y * inv * g.y + b.y) * rs;
+    o.z = (v[i].z * inv * g.z + b.z) * rs;
+    o.w = (v[i].w * inv * g.w + b.w) * rs;
+    if (out_bf16) {
+      uint2 pk;
+      pk.x = (uint32_t)to_bf16(o.x) | ((uint32_t)to_bf16(o.y) << 16);
+      pk.y = (uint32_t)to_bf16(o.z) | ((uint32_t)to_bf16(o.w) << 16);
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + row * ldo + c) = pk;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row * ldo + c) = o;
+    }
+  }
+}
+
+// ---- CMVN + Conv2d(1 -> C, 3x3, stride 2, valid) + ReLU, output NHWC bf16 -----------------------------------
+// One workgroup per (b, output time t): 256 threads = channels (C == 256) or C/… loop; the 3 x idim input rows are
+// normalised into LDS once, each thread keeps its 9 weights in registers and walks the F1 output columns.
+__global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __restrict__ x, int64_t T, int idim,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ istd,
+                                                              const float* __restrict__ w,  // (C, 3, 3)
+                                                              const float* __restrict__ bias, int C, int T1, int F1,
+                                                              uint16_t* __restrict__ out) {
+  extern __shared__ float rows[];  // 3 * idim
+  const int64_t bt = blockIdx.x;
+  const int64_t b = bt / T1;
+  const int t1 = (int)(bt - b * T1);
+  for (int i = threadIdx.x; i < 3 * idim; i += blockDim.x) {
+    const int kh = i / idim, f = i - kh * idim;
+    float v = x[(b * T + 2 * t1 + kh) * idim + f];
+    if (mean) v = (v - mean[f]) * istd[f];
+    rows[i] = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    const float bc = bias[c];
+    uint16_t* o = out + (bt * F1) * C + c;
+    for (int f1 = 0; f1 < F1; ++f1) {
+      float acc = bc;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], rows[kh * idim + 2 * f1 + kw], acc);
+      o[(int64_t)f1 * C] = to_bf16(fmaxf(acc, 0.0f));
+    }
+  }
+}
+
+// ---- relative-position attention (no shift) ------------------------------------------------------------------
+//   score[i, j] = ((q_i + u) . k_j + (q_i + v) . p_j) / sqrt(dk) + (mask[b, j] == 0 ? -10000 : 0)
+//   ctx_i = softmax_j(score[i, :]) . V            (dk == 64; the two dot products run as ONE K = 128 contraction
+//   of [q+u | q+v] with [k_j | p_j])
+// Workgroup = (batch b, head h, 64 query rows): 4 waves x 16 rows.  Keys are visited in tiles of 64 with an
+// online softmax; K' = [k | p] tile and V^T tile live in LDS, probabilities go C-layout -> A-layout through a
+// per-wave 2 KiB LDS patch.
+constexpr int kAttQ = 64, kAttK = 64, kDk = 64;
+constexpr int kKpStride = 128 + 8;   // bf16 elements per K' row (padded: 272 B -> conflict-free b128 reads)
+constexpr int kVtStride = 64 + 8;    // bf16 elements per V^T row
+constexpr int kPStride2 = 64 + 8;    // bf16 elements per probability row
+
+__global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+                                                               const uint16_t* __restrict__ pos, int64_t ld_pos,
+                                                               const float* __restrict__ bias_u,
+                                                               const float* __restrict__ bias_v,
+                                                               const float* __restrict__ mask, int T, int H,
+                                                               float scale, uint16_t* __restrict__ ctx,
+                                                               int64_t ld_ctx) {
+  __shared__ __attribute__((aligned(16))) uint16_t Kp[kAttK * kKpStride];
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[kDk * kVtStride];
+  __shared__ __attribute__((aligned(16))) uint16_t Pw[4][16 * kPStride2];
+  __shared__ float maskadd[kAttK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int64_t row0 = (int64_t)b * T;
+  const int q_base = qt * kAttQ + wave * 16;
+
+  // ---- Q' fragments: A operand, lane holds row (lane & 15), k = kstep*32 + (lane >> 4)*8 .. +7 ----------------
+  bf16x8 qf[4];
+  {
+    int qi = q_base + (lane & 15);
+    if (qi >= T) qi = T - 1;
+    const uint16_t* qrow = qkv + (row0 + qi) * ld_qkv + h * kDk;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int d0 = (ks & 1) * 32 + (lane >> 4) * 8;  // ks 0,1 -> q + u ; ks 2,3 -> q + v
+      const float* bias = (ks < 2 ? bias_u : bias_v) + h * kDk + d0;
+      const uint4 raw = *reinterpret_cast<const uint4*>(qrow + d0);
+      const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = from_bf16((uint16_t)(wds[e] & 0xffff)) + bias[2 * e];
+        const float hi = from_bf16((uint16_t)(wds[e] >> 16)) + bias[2 * e + 1];
+        o[e] = (uint32_t)to_bf16(lo) | ((uint32_t)to_bf16(hi) << 16);
+      }
+      uint4 pk = make_uint4(o[0], o[1], o[2], o[3]);
+      qf[ks] = __builtin_bit_cast(bf16x8, pk);
+    }
+  }
+
+  f32x4 oacc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrow[4], lrow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
+
+  const int n_kt = (T + kAttK - 1) / kAttK;
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int k0 = kt * kAttK;
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K' = [k | p] (64 x 128) and V^T (64 d x 64 keys) ------------------------------------------------
+    for (int c = tid; c < kAttK * 16; c += 256) {  // 16 chunks of 8 bf16 per key row
+      const int key = c >> 4, ch = c & 15;
+      int kj = k0 + key;
+      const bool ok = kj < T;
+      if (!ok) kj = T - 1;
+      uint4 val;
+      if (ch < 8) val = *reinterpret_cast<const uint4*>(qkv + (row0 + kj) * ld_qkv + 256 + h * kDk + ch * 8);
+      else val = *reinterpret_cast<const uint4*>(pos + (int64_t)kj * ld_pos + h * kDk + (ch - 8) * 8);
+      *reinterpret_cast<uint4*>(&Kp[key * kKpStride + ch * 8]) = val;
+    }
+    for (int c = tid; c < kAttK * 8; c += 256) {  // V: 8 chunks per key row, transposed into Vt[d][key]
+      const int key = c >> 3, ch = c & 7;
+      int kj = k0 + key;
+      const bool ok = kj < T;
+      if (!ok) kj = T - 1;
+      const uint4 val = *reinterpret_cast<const uint4*>(qkv + (row0 + kj) * ld_qkv + 512 + h * kDk + ch * 8);
+      const uint32_t wds[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Vt[(ch * 8 + 2 * e) * kVtStride + key] = ok ? (uint16_t)(wds[e] & 0xffff) : (uint16_t)0;
+        Vt[(ch * 8 + 2 * e + 1) * kVtStride + key] = ok ? (uint16_t)(wds[e] >> 16) : (uint16_t)0;
+      }
+    }
+    if (tid < kAttK) {
+      const int kj = k0 + tid;
+      // keys past T do not exist (-inf); padded keys inside T get the reference's additive -10000
+      maskadd[tid] = kj >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + kj] == 0.0f) ? -10000.0f : 0.0f);
+    }
+    __syncthreads();
+
+    // ---- S = Q' . K'^T : 4 key tiles x 4 k-steps -----------------------------------------------------------------
+    f32x4 s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kp[(c * 16 + (lane & 15)) * kKpStride + ks * 32 + (lane >> 4) * 8]);
+        s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[c], 0, 0, 0);
+      }
+    }
+    // lane holds rows (lane >> 4) * 4 + r, keys c * 16 + (lane & 15)
+    float tmax[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tmax[r] = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float ma_ = maskadd[c * 16 + (lane & 15)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[c][r] = s[c][r] * scale + ma_;
+        tmax[r] = fmaxf(tmax[r], s[c][r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) tmax[r] = fmaxf(tmax[r], __shfl_xor(tmax[r], off, 64));
+    }
+    float alpha[4], psum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mnew = fmaxf(mrow[r], tmax[r]);
+      alpha[r] = (mrow[r] == -INFINITY) ? 0.0f : __expf(mrow[r] - mnew);
+      mrow[r] = mnew;
+      psum[r] = 0.f;
+    }
+    uint16_t* pw = Pw[wave];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = (mrow[r] == -INFINITY) ? 0.0f : __expf(s[c][r] - mrow[r]);
+        psum[r] += e;
+        pw[((lane >> 4) * 4 + r) * kPStride2 + c * 16 + (lane & 15)] = to_bf16(e);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) psum[r] += __shfl_xor(psum[r], off, 64);
+      lrow[r] = lrow[r] * alpha[r] + psum[r];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[c][r] *= alpha[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- O += P . V : A = P (row = lane & 15, keys), B = V^T rows (d = lane & 15, keys) -----------------------
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pw[(lane & 15) * kPStride2 + ks * 32 + (lane >> 4) * 8]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(c * 16 + (lane & 15)) * kVtStride + ks * 32 + (lane >> 4) * 8]);
+        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, oacc[c], 0, 0, 0);
+      }
+    }
+  }
+  // ---- ctx = O / l ------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = q_base + (lane >> 4) * 4 + r;
+    if (qi >= T) continue;
+    const float inv = 1.0f / lrow[r];
+    uint16_t* o = ctx + (row0 + qi) * ld_ctx + h * kDk + (lane & 15);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c * 16] = to_bf16(oacc[c][r] * inv);
+  }
+}
+
+// ---- conv module middle: GLU -> depthwise conv (KS taps, zero padded per utterance) -> affine (BN) -> Swish ----
+// y: (B*T, 2C) bf16 = pointwise_conv1 output (value | gate); out (B*T, C) bf16.
+//   z[t, c] = sum_k dw[c, k] * glu[t + k - KS/2, c];  out = swish(z * bn_scale[c] + bn_shift[c])
+// (conv bias and BatchNorm statistics are folded into bn_scale / bn_shift by the host.)
+constexpr int kCmTile = 32;
+__global__ __launch_bounds__(256) void convmodule_mid_kernel(const uint16_t* __restrict__ y, int64_t ldy, int T, int C,
+                                                             const float* __restrict__ dw, int KS,
+                                                             const float* __restrict__ bn_scale,
+                                                             const float* __restrict__ bn_shift,
+                                                             uint16_t* __restrict__ out, int64_t ldo) {
+  extern __shared__ float glu[];  // (kCmTile + KS - 1) x 256 channels of this block, then KS x 256 weights
+  const int b = blockIdx.z, cb = blockIdx.y * 256, t0 = blockIdx.x * kCmTile;
+  const int c = cb + threadIdx.x;
+  const int half = KS / 2, span = kCmTile + KS - 1;
+  const int64_t row0 = (int64_t)b * T;
+  if (c < C) {
+    for (int i = 0; i < span; ++i) {
+      const int t = t0 + i - half;
+      float g = 0.0f;
+      if (t >= 0 && t < T) {
+        const float a = from_bf16(y[(row0 + t) * ldy + c]);
+        const float gate = from_bf16(y[(row0 + t) * ldy + C + c]);
+        g = a / (1.0f + __expf(-gate));  // layers/glu.py:24-28
+      }
+      glu[i * 256 + threadIdx.x] = g;
+    }
+  }
+  float* wl = glu + span * 256;
+  if (c < C)
+    for (int k = 0; k < KS; ++k) wl[k * 256 + threadIdx.x] = dw[c * KS + k];
+  __syncthreads();
+  if (c >= C) return;
+  const float sc = bn_scale[c], sh = bn_shift[c];
+  for (int i = 0; i < kCmTile; ++i) {
+    const int t = t0 + i;
+    if (t >= T) break;
+    float acc = 0.f;
+    for (int k = 0; k < KS; ++k) acc = fmaf(wl[k * 256 + threadIdx.x], glu[(i + k) * 256 + threadIdx.x], acc);
+    const float z = acc * sc + sh;
+    out[(row0 + t) * ldo + c] = to_bf16(z / (1.0f + __expf(-z)));
+  }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int ma_layernorm_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma, const float* beta,
+                     float eps, const float* row_scale, void* out, int64_t ldo, int32_t out_bf16,
+                     ma_stream_t stream) {
+  if (!x || !gamma || !beta || !out || rows < 1 || cols < 1 || ldx < cols || ldo < cols) return MA_ERR_INVALID_ARG;
+  if ((ldx & 3) || (ldo & 3)) return MA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (cols) {
+    case 256: MA_LAUNCH(layernorm_kernel<1>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
+    case 512: MA_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
+    case 768: MA_LAUNCH(layernorm_kernel<3>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
+    case 1024: MA_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
+    default: return MA_ERR_UNSUPPORTED;
+  }
+  return MA_OK;
+}
+
+int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t idim, const float* cmvn_mean,
+                            const float* cmvn_istd, const float* w, const float* bias, int32_t C, void* out,
+                            ma_stream_t stream) {
+  if (!x || !w || !bias || !out || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
+  if ((cmvn_mean == nullptr) != (cmvn_istd == nullptr)) return MA_ERR_INVALID_ARG;
+  const int T1 = (int)((T - 3) / 2 + 1), F1 = (idim - 3) / 2 + 1;
+  MA_LAUNCH(subsample_conv1_kernel, dim3((unsigned)(batch * T1)), dim3(256), 3 * idim * sizeof(float),
+            (hipStream_t)stream, x, T, idim, cmvn_mean, cmvn_istd, w, bias, C, T1, F1,
+            reinterpret_cast<uint16_t*>(out));
+  return MA_OK;
+}
+
+int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                             const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads,
+                             int32_t d_k, void* ctx, int64_t ld_ctx, ma_stream_t stream) {
+  if (!qkv || !pos || !bias_u || !bias_v || !ctx || batch < 1 || T < 1 || heads < 1) return MA_ERR_INVALID_ARG;
+  if (d_k != kDk || heads * d_k != 256) return MA_ERR_UNSUPPORTED;  // q | k | v blocks are 256 wide
+  if ((ld_qkv & 7) || (ld_pos & 7) || batch > 65535) return MA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((T + kAttQ - 1) / kAttQ), (unsigned)heads, (unsigned)batch);
+  MA_LAUNCH(relpos_attention_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+            reinterpret_cast<const uint16_t*>(qkv), ld_qkv, reinterpret_cast<const uint16_t*>(pos), ld_pos, bias_u,
+            bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx);
+  return MA_OK;
+}
+
+int ma_convmodule_mid_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw,
+                           int32_t kernel_size, const float* bn_scale, const float* bn_shift, void* out, int64_t ldo,
+                           ma_stream_t stream) {
+  if (!y || !dw || !bn_scale || !bn_shift || !out || batch < 1 || T < 1 || C < 1) return MA_ERR_INVALID_ARG;
+  if (kernel_size < 1 || kernel_size > 31 || (kernel_size & 1) == 0 || batch > 65535) return MA_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)(kCmTile + 2 * kernel_size - 1) * 256 * sizeof(float);
+  const dim3 grid((unsigned)((T + kCmTile - 1) / kCmTile), (unsigned)((C + 255) / 256), (unsigned)batch);
+  MA_LAUNCH(convmodule_mid_kernel, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(y),
+            ldy, (int)T, (int)C, dw, (int)kernel_size, bn_scale, bn_shift, reinterpret_cast<uint16_t*>(out), ldo);
+  return MA_OK;
+}
+
+}  // extern "C"

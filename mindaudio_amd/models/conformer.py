@@ -1,0 +1,234 @@
+"""ConformerEncoder on MI355X — mirror of mindaudio.models.conformer.ConformerEncoder
+(mindaudio/models/conformer.py:261-379 over BaseEncoder :164-258), forward pass in hand-written HIP kernels.
+
+The module keeps float32 master parameters under the same structure as the reference cells (PyTorch layers are
+used as parameter containers only — their forward() is never called); `forward` runs bf16 MFMA GEMMs with fused
+epilogues, a fused rel-pos attention kernel, a fused GLU/depthwise/BatchNorm/Swish kernel and LayerNorm kernels
+through the C-ABI (include/mindaudio_amd.h).  The residual stream, LayerNorm statistics and softmax are float32.
+
+Round-1 scope: inference forward (eval mode: dropout off, BatchNorm running statistics) — the path the
+`utterances/s fbanks+Conformer fwd` metric measures.  Training-mode forward/backward is the next row.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+
+
+def _sinusoid_table(max_len, d_model):
+    """layers/embedding.py:36-44."""
+    pe = np.zeros((max_len, d_model))
+    position = np.expand_dims(np.arange(0, max_len, dtype=np.float32), 1)
+    div_term = np.exp(np.arange(0, d_model, 2, dtype=np.float32) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = np.sin(position * div_term)
+    pe[:, 1::2] = np.cos(position * div_term)
+    return torch.from_numpy(pe.astype(np.float32))
+
+
+class _LN(nn.Module):
+    def __init__(self, size):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(size))
+        self.beta = nn.Parameter(torch.zeros(size))
+
+
+class _FFN(nn.Module):
+    def __init__(self, d, hidden):
+        super().__init__()
+        self.w_1 = nn.Linear(d, hidden)
+        self.w_2 = nn.Linear(hidden, d)
+
+
+class _Attn(nn.Module):
+    def __init__(self, heads, d):
+        super().__init__()
+        self.linear_q = nn.Linear(d, d)
+        self.linear_k = nn.Linear(d, d)
+        self.linear_v = nn.Linear(d, d)
+        self.linear_out = nn.Linear(d, d)
+        self.linear_pos = nn.Linear(d, d, bias=False)
+        self.pos_bias_u = nn.Parameter(torch.empty(heads, d // heads))
+        self.pos_bias_v = nn.Parameter(torch.empty(heads, d // heads))
+        nn.init.xavier_uniform_(self.pos_bias_u)  # layers/attention.py:173-178
+        nn.init.xavier_uniform_(self.pos_bias_v)
+
+
+class _ConvModule(nn.Module):
+    def __init__(self, d, kernel):
+        super().__init__()
+        self.pointwise_conv1 = nn.Conv1d(d, 2 * d, 1)
+        self.depthwise_conv = nn.Conv1d(d, d, kernel, padding=(kernel - 1) // 2, groups=d)
+        self.norm = nn.BatchNorm1d(d, eps=1e-5, momentum=0.1)
+        self.pointwise_conv2 = nn.Conv1d(d, d, 1)
+
+
+class _Layer(nn.Module):
+    def __init__(self, d, heads, hidden, kernel):
+        super().__init__()
+        self.self_attn = _Attn(heads, d)
+        self.feed_forward = _FFN(d, hidden)
+        self.feed_forward_macaron = _FFN(d, hidden)
+        self.conv_module = _ConvModule(d, kernel)
+        self.norm_ff = _LN(d)
+        self.norm_mha = _LN(d)
+        self.norm_ff_macaron = _LN(d)
+        self.norm_conv = _LN(d)
+        self.norm_final = _LN(d)
+
+
+class _Embed(nn.Module):
+    def __init__(self, idim, odim):
+        super().__init__()
+        self.conv1 = nn.Conv2d(1, odim, 3, 2)
+        self.conv2 = nn.Conv2d(odim, odim, 3, 2)
+        self.out = nn.Linear(odim * (((idim - 1) // 2 - 1) // 2), odim)
+
+
+class ConformerEncoder(nn.Module):
+    """Same constructor arguments as the reference (models/conformer.py:293-313).  `global_cmvn` is a
+    (mean, istd) pair of arrays (layers/cmvn.py); `compute_type` is accepted for signature parity — matmul
+    inputs are bf16, accumulation float32."""
+
+    def __init__(self, input_size, output_size=256, attention_heads=4, linear_units=2048, num_blocks=6,
+                 dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.0, input_layer="conv2d",
+                 pos_enc_layer_type="rel_pos", normalize_before=True, feature_norm=True, concat_after=False,
+                 activation_type="relu", cnn_module_kernel=15, cnn_module_norm="batch_norm", global_cmvn=None,
+                 compute_type=None, max_len=5000):
+        super().__init__()
+        if input_layer != "conv2d" or pos_enc_layer_type != "rel_pos" or not normalize_before or concat_after \
+                or cnn_module_norm != "batch_norm":
+            raise NotImplementedError("only the shipped conformer.yaml configuration is on the hot path: conv2d "
+                                      "input, rel_pos, pre-norm, no concat, batch_norm conv module")
+        if output_size != 256 or output_size // attention_heads != 64:
+            raise NotImplementedError("kernels are built for d_model 256 with 64-wide heads (Conformer-small)")
+        self.d, self.heads, self.idim = output_size, attention_heads, input_size
+        self.kernel = cnn_module_kernel
+        self.embed = _Embed(input_size, output_size)
+        self.encoders = nn.ModuleList([_Layer(output_size, attention_heads, linear_units, cnn_module_kernel)
+                                       for _ in range(num_blocks)])
+        self.after_norm = _LN(output_size)
+        self.register_buffer("pe", _sinusoid_table(max_len, output_size), persistent=False)
+        if global_cmvn is not None:
+            mean, istd = global_cmvn
+            self.register_buffer("cmvn_mean", torch.as_tensor(np.asarray(mean), dtype=torch.float32))
+            self.register_buffer("cmvn_istd", torch.as_tensor(np.asarray(istd), dtype=torch.float32))
+        else:
+            self.cmvn_mean = self.cmvn_istd = None
+        self._prepared = None
+        self._pos_cache = {}
+
+    def output_size(self):
+        return self.d
+
+    # ---- weight preparation: bf16 copies in the layouts the kernels read ------------------------------------
+    @torch.no_grad()
+    def prepare(self):
+        """(Re)build the bf16 / folded tensors from the float32 masters. Call after loading or updating weights."""
+        bf = torch.bfloat16
+        e = self.embed
+        c = self.d
+        f2 = e.out.in_features // c
+        prep = {
+            "conv1_w": e.conv1.weight.detach().reshape(c, 9).contiguous().float(),
+            "conv1_b": e.conv1.bias.detach().float().contiguous(),
+            # (Cout, Cin, 3, 3) -> (Cout, kh, kw, Cin): k = (kh, kw, c) of the implicit GEMM
+            "conv2_w": e.conv2.weight.detach().permute(0, 2, 3, 1).contiguous().to(bf),
+            "conv2_b": e.conv2.bias.detach().float().contiguous(),
+            # reference flattens (c, f) (subsampling.py:76); our activation is (f, c): permute the columns once
+            "out_w": e.out.weight.detach().view(c, c, f2).permute(0, 2, 1).reshape(c, f2 * c).contiguous().to(bf),
+            "out_b": e.out.bias.detach().float().contiguous(),
+            "pos_w": torch.cat([l.self_attn.linear_pos.weight.detach() for l in self.encoders], 0).contiguous().to(bf),
+            "layers": [],
+        }
+        for l in self.encoders:
+            a, cm = l.self_attn, l.conv_module
+            bn = cm.norm
+            scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias.detach() + (cm.depthwise_conv.bias.detach() - bn.running_mean) * scale
+            prep["layers"].append({
+                "ffm_w1": l.feed_forward_macaron.w_1.weight.detach().to(bf).contiguous(),
+                "ffm_b1": l.feed_forward_macaron.w_1.bias.detach().float().contiguous(),
+                "ffm_w2": l.feed_forward_macaron.w_2.weight.detach().to(bf).contiguous(),
+                "ffm_b2": l.feed_forward_macaron.w_2.bias.detach().float().contiguous(),
+                "ff_w1": l.feed_forward.w_1.weight.detach().to(bf).contiguous(),
+                "ff_b1": l.feed_forward.w_1.bias.detach().float().contiguous(),
+                "ff_w2": l.feed_forward.w_2.weight.detach().to(bf).contiguous(),
+                "ff_b2": l.feed_forward.w_2.bias.detach().float().contiguous(),
+                "qkv_w": torch.cat([a.linear_q.weight, a.linear_k.weight, a.linear_v.weight], 0).detach().to(bf).contiguous(),
+                "qkv_b": torch.cat([a.linear_q.bias, a.linear_k.bias, a.linear_v.bias], 0).detach().float().contiguous(),
+                "o_w": a.linear_out.weight.detach().to(bf).contiguous(),
+                "o_b": a.linear_out.bias.detach().float().contiguous(),
+                "u": a.pos_bias_u.detach().float().contiguous(),
+                "v": a.pos_bias_v.detach().float().contiguous(),
+                "pw1_w": cm.pointwise_conv1.weight.detach().squeeze(-1).to(bf).contiguous(),
+                "pw1_b": cm.pointwise_conv1.bias.detach().float().contiguous(),
+                "dw_w": cm.depthwise_conv.weight.detach().squeeze(1).float().contiguous(),
+                "bn_scale": scale.float().contiguous(),
+                "bn_shift": shift.float().contiguous(),
+                "pw2_w": cm.pointwise_conv2.weight.detach().squeeze(-1).to(bf).contiguous(),
+                "pw2_b": cm.pointwise_conv2.bias.detach().float().contiguous(),
+            })
+        self._prepared = prep
+        self._pos_cache = {}
+        return self
+
+    def _pos_projection(self, t2):
+        """linear_pos(pos_emb) of every layer in one GEMM, cached per length: (t2, num_blocks * 256) bf16.
+        pos_emb = rows 0..t2-1 of the absolute table (embedding.py:86-88); no dropout in eval."""
+        if t2 not in self._pos_cache:
+            pe = self.pe[:t2].to(torch.bfloat16).contiguous()
+            self._pos_cache[t2] = ops.gemm(pe, self._prepared["pos_w"])
+        return self._pos_cache[t2]
+
+    @torch.no_grad()
+    def forward(self, xs, masks, xs_chunk_masks=None):
+        """xs (B, T, idim) float32 on the HIP device; masks (B, 1, T') — the subsampled pad mask the collate
+        function builds (dataset.py:620-632). Returns (xs (B, T', 256) float32, masks) like BaseEncoder.construct
+        (models/conformer.py:229-258)."""
+        if self.training:
+            raise NotImplementedError("training-mode forward (dropout, BatchNorm batch statistics, backward) is the "
+                                      "next row; call .eval()")
+        if self._prepared is None:
+            self.prepare()
+        P = self._prepared
+        f32 = torch.float32
+        b, t, idim = xs.shape
+        xs = xs.to(f32).contiguous()
+        act1 = ops.subsample_conv1(xs, P["conv1_w"], P["conv1_b"], self.cmvn_mean, self.cmvn_istd)
+        act2 = ops.conv2d_3x3s2_nhwc(act1, P["conv2_w"], P["conv2_b"], relu=True)
+        _, t2, f2, c = act2.shape
+        m = b * t2
+        if masks.shape[-1] != t2:
+            raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(masks.shape)))
+        mask2d = masks.reshape(b, t2).to(f32).contiguous()
+        mask_rows = mask2d.reshape(m)
+        att_mask = mask2d if xs_chunk_masks is None else xs_chunk_masks.reshape(b, t2).to(f32).contiguous()
+        # Dense(4864 -> 256) then x * sqrt(d) (subsampling.py:76, embedding.py:84)
+        x = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(self.d), out_dtype=f32)
+        pos_all = self._pos_projection(t2)
+        for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
+            # x = x + 0.5 * FFN_macaron(LN(x))                                   models/conformer.py:109-112
+            a = ops.layernorm(x, l.norm_ff_macaron.gamma, l.norm_ff_macaron.beta)
+            h = ops.gemm(a, W["ffm_w1"], bias=W["ffm_b1"], act=_lib.ACT_SWISH)
+            ops.gemm(h, W["ffm_w2"], bias=W["ffm_b2"], residual=x, alpha=0.5, out_dtype=f32, out=x)
+            # x = x + MHA(LN(x))                                                   :117-135
+            a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta)
+            qkv = ops.gemm(a, W["qkv_w"], bias=W["qkv_b"])
+            ctx = ops.relpos_attention(qkv, pos_all[:, li * 256:(li + 1) * 256], W["u"], W["v"], att_mask, b, t2,
+                                       self.heads, 64)
+            ops.gemm(ctx, W["o_w"], bias=W["o_b"], residual=x, out_dtype=f32, out=x)
+            # x = x + ConvModule(LN(x), mask_pad)                                  :139-143, convolution.py:83-129
+            a = ops.layernorm(x, l.norm_conv.gamma, l.norm_conv.beta, row_scale=mask_rows)
+            y = ops.gemm(a, W["pw1_w"], bias=W["pw1_b"])
+            z = ops.convmodule_mid(y, W["dw_w"], W["bn_scale"], W["bn_shift"], b, t2)
+            ops.gemm(z, W["pw2_w"], bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
+            # x = x + 0.5 * FFN(LN(x)) ; x = LN_final(x)                           :147-156
+            a = ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta)
+            h = ops.gemm(a, W["ff_w1"], bias=W["ff_b1"], act=_lib.ACT_SWISH)
+            ops.gemm(h, W["ff_w2"], bias=W["ff_b2"], residual=x, alpha=0.5, out_dtype=f32, out=x)
+            x = ops.layernorm(x, l.norm_final.gamma, l.norm_final.beta, out_dtype=f32)
+        x = ops.layernorm(x, self.after_norm.gamma, self.after_norm.beta, out_dtype=f32)
+        return x.view(b, t2, self.d), masks

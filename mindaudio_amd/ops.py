@@ -1,0 +1,117 @@
+"""Thin Python wrappers over the Conformer C-ABI entry points (include/mindaudio_amd.h).
+Tensors are torch HIP tensors used as device buffers; all arithmetic happens in the HIP kernels."""
+import ctypes
+
+from . import _host, _lib
+
+
+def _epilogue(bias=None, residual=None, row_scale=None, alpha=1.0, act=_lib.ACT_NONE, out_bf16=True):
+    e = _lib.GemmEpilogue()
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.residual = residual.data_ptr() if residual is not None else None
+    e.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    e.ldr = residual.stride(0) if residual is not None else 0
+    e.alpha = float(alpha)
+    e.act = int(act)
+    e.out_bf16 = 1 if out_bf16 else 0
+    return e
+
+
+def gemm(a, w, bias=None, residual=None, row_scale=None, alpha=1.0, act=_lib.ACT_NONE, out_dtype=None, out=None):
+    """out (M, N) = act(a (M, K) @ w (N, K)^T + bias) * alpha * row_scale[:, None] (+ residual).
+    a, w: bf16 device tensors (K contiguous); bias/row_scale/residual float32."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and w.dtype == t.bfloat16 and a.dim() == 2 and w.dim() == 2
+    assert a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    m, k = a.shape
+    n = w.shape[0]
+    out_dtype = out_dtype or t.bfloat16
+    if out is None:
+        out = t.empty((m, n), dtype=out_dtype, device=a.device)
+    assert out.dtype == out_dtype and out.stride(1) == 1 and tuple(out.shape) == (m, n)
+    for x in (bias, residual, row_scale):
+        assert x is None or x.dtype == t.float32
+    e = _epilogue(bias, residual, row_scale, alpha, act, out_dtype == t.bfloat16)
+    rc = lib.ma_gemm_bf16(_host.ptr(a), a.stride(0), _host.ptr(w), w.stride(0), _host.ptr(out), out.stride(0), m, n, k,
+                          ctypes.byref(e), _host.current_stream_ptr())
+    _lib.check(rc, "gemm_bf16")
+    return out
+
+
+def conv2d_3x3s2_nhwc(act, w, bias=None, relu=True, out_dtype=None):
+    """act (B, H, W, C) bf16 NHWC, w (Cout, 3, 3, C) bf16 -> (B, Ho, Wo, Cout)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert act.dtype == t.bfloat16 and w.dtype == t.bfloat16 and act.is_contiguous() and w.is_contiguous()
+    b, h, wd, c = act.shape
+    cout = w.shape[0]
+    ho, wo = (h - 3) // 2 + 1, (wd - 3) // 2 + 1
+    out_dtype = out_dtype or t.bfloat16
+    out = t.empty((b, ho, wo, cout), dtype=out_dtype, device=act.device)
+    e = _epilogue(bias, None, None, 1.0, _lib.ACT_RELU if relu else _lib.ACT_NONE, out_dtype == t.bfloat16)
+    rc = lib.ma_conv2d_3x3s2_nhwc_bf16(_host.ptr(act), b, h, wd, c, _host.ptr(w), cout, _host.ptr(out),
+                                       ctypes.byref(e), _host.current_stream_ptr())
+    _lib.check(rc, "conv2d_3x3s2_nhwc_bf16")
+    return out
+
+
+def _opt(x):
+    return _host.ptr(x) if x is not None else None
+
+
+def layernorm(x, gamma, beta, eps=1e-5, row_scale=None, out_dtype=None, out=None):
+    """x (rows, D) float32 -> LayerNorm(x) [* row_scale[:, None]] as bf16 (default) or float32."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert x.dtype == t.float32 and x.dim() == 2 and x.stride(1) == 1
+    out_dtype = out_dtype or t.bfloat16
+    if out is None:
+        out = t.empty(x.shape, dtype=out_dtype, device=x.device)
+    rc = lib.ma_layernorm_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(gamma), _host.ptr(beta),
+                              float(eps), _opt(row_scale), _host.ptr(out), out.stride(0),
+                              1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    _lib.check(rc, "layernorm")
+    return out
+
+
+def subsample_conv1(x, w, bias, cmvn_mean=None, cmvn_istd=None):
+    """x (B, T, idim) float32; w (C, 3, 3), bias (C) float32 -> NHWC bf16 (B, T1, F1, C) after CMVN, conv, ReLU."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert x.dtype == t.float32 and x.is_contiguous() and w.is_contiguous()
+    b, tt, idim = x.shape
+    c = w.shape[0]
+    out = t.empty((b, (tt - 3) // 2 + 1, (idim - 3) // 2 + 1, c), dtype=t.bfloat16, device=x.device)
+    rc = lib.ma_subsample_conv1_nhwc(_host.ptr(x), b, tt, idim, _opt(cmvn_mean), _opt(cmvn_istd), _host.ptr(w),
+                                     _host.ptr(bias), c, _host.ptr(out), _host.current_stream_ptr())
+    _lib.check(rc, "subsample_conv1")
+    return out
+
+
+def relpos_attention(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64, out=None):
+    """qkv (B*T, 768) bf16; pos (T, 256) bf16; bias_u/v (heads, d_k) f32; mask (B, T) f32 or None -> ctx (B*T, 256)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert qkv.dtype == t.bfloat16 and pos.dtype == t.bfloat16 and qkv.stride(1) == 1 and pos.stride(1) == 1
+    if out is None:
+        out = t.empty((batch * T, heads * d_k), dtype=t.bfloat16, device=qkv.device)
+    rc = lib.ma_relpos_attention_bf16(_host.ptr(qkv), qkv.stride(0), _host.ptr(pos), pos.stride(0), _host.ptr(bias_u),
+                                      _host.ptr(bias_v), _opt(mask), batch, T, heads, d_k, _host.ptr(out),
+                                      out.stride(0), _host.current_stream_ptr())
+    _lib.check(rc, "relpos_attention")
+    return out
+
+
+def convmodule_mid(y, dw, bn_scale, bn_shift, batch, T, out=None):
+    """y (B*T, 2C) bf16 -> swish(bn(depthwise(glu(y)))) as bf16 (B*T, C)."""
+    t = _host.torch()
+    lib = _lib.load()
+    c, ks = dw.shape
+    assert y.dtype == t.bfloat16 and y.shape[1] == 2 * c and y.stride(1) == 1
+    if out is None:
+        out = t.empty((batch * T, c), dtype=t.bfloat16, device=y.device)
+    rc = lib.ma_convmodule_mid_bf16(_host.ptr(y), y.stride(0), batch, T, c, _host.ptr(dw), ks, _host.ptr(bn_scale),
+                                    _host.ptr(bn_shift), _host.ptr(out), out.stride(0), _host.current_stream_ptr())
+    _lib.check(rc, "convmodule_mid")
+    return out

@@ -1,0 +1,177 @@
+"""GPU parity of the Conformer building-block kernels against plain PyTorch float32/float64 references of the
+same op computed on the SAME bf16-rounded inputs (so the only differences are accumulation order and the
+final rounding): float32 outputs within 2e-5 of the output scale, bf16 outputs within one bf16 ulp (2^-8)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def t():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _rand(t, *shape, seed=0, scale=1.0):
+    g = t.Generator(device="cpu").manual_seed(seed)
+    return (t.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (250, 256, 256), (7968, 2048, 256), (1000, 256, 2048),
+                                   (333, 4233, 256), (513, 768, 256), (64, 256, 4864)])
+def test_gemm_plain_and_transpose_detecting(t, m, n, k):
+    from mindaudio_amd import ops
+
+    a = _rand(t, m, k, seed=1).bfloat16().cuda()
+    w = _rand(t, n, k, seed=2, scale=1.0 / math.sqrt(k)).bfloat16().cuda()
+    bias = _rand(t, n, seed=3).cuda()
+    ref = a.double() @ w.double().T + bias.double()
+    out32 = ops.gemm(a, w, bias=bias, out_dtype=t.float32)
+    scale = float(ref.abs().max())
+    assert float((out32.double() - ref).abs().max()) <= 2e-5 * scale
+    out16 = ops.gemm(a, w, bias=bias)
+    assert out16.dtype == t.bfloat16
+    assert float((out16.double() - ref).abs().max()) <= 2 ** -8 * scale * 1.01
+
+
+def test_gemm_epilogues(t):
+    from mindaudio_amd import _lib, ops
+
+    m, n, k = 777, 512, 256
+    a = _rand(t, m, k, seed=4).bfloat16().cuda()
+    w = _rand(t, n, k, seed=5, scale=0.06).bfloat16().cuda()
+    bias = _rand(t, n, seed=6).cuda()
+    res = _rand(t, m, n, seed=7).cuda()
+    rs = (t.rand(m, generator=t.Generator().manual_seed(8)) > 0.3).float().cuda()
+    z = a.double() @ w.double().T + bias.double()
+    # swish -> bf16 (FFN w_1), relu, residual + 0.5 * (...) in f32 (FFN w_2), row mask (conv module)
+    got = ops.gemm(a, w, bias=bias, act=_lib.ACT_SWISH).double()
+    want = z * t.sigmoid(z)
+    assert float((got - want).abs().max()) <= 2 ** -8 * float(want.abs().max()) * 1.01
+    got = ops.gemm(a, w, bias=bias, act=_lib.ACT_RELU, out_dtype=t.float32).double()
+    assert float((got - z.clamp(min=0)).abs().max()) <= 2e-5 * float(z.abs().max())
+    got = ops.gemm(a, w, bias=bias, residual=res, alpha=0.5, out_dtype=t.float32).double()
+    want = res.double() + 0.5 * z
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    got = ops.gemm(a, w, bias=bias, residual=res, row_scale=rs, out_dtype=t.float32).double()
+    want = res.double() + z * rs.double()[:, None]
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # strided A (a column slice of a wider buffer) and in-place residual update
+    wide = _rand(t, m, 3 * k, seed=9).bfloat16().cuda()
+    got = ops.gemm(wide[:, k:2 * k], w, out_dtype=t.float32).double()
+    want = wide[:, k:2 * k].double() @ w.double().T
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    x = res.clone()
+    ops.gemm(a, w, bias=bias, residual=x, alpha=0.5, out_dtype=t.float32, out=x)
+    assert float((x.double() - (res.double() + 0.5 * z)).abs().max()) <= 2e-5 * float(z.abs().max())
+
+
+def test_gemm_rejects_bad_shapes(t):
+    from mindaudio_amd import ops
+
+    a = t.zeros(16, 100, dtype=t.bfloat16, device="cuda")
+    w = t.zeros(16, 100, dtype=t.bfloat16, device="cuda")
+    with pytest.raises(NotImplementedError):
+        ops.gemm(a, w)  # K % 64 != 0
+
+
+@pytest.mark.parametrize("b,h,wd,c,cout", [(2, 21, 9, 64, 128), (3, 99, 39, 256, 256)])
+def test_conv2d_3x3s2_implicit_gemm(t, b, h, wd, c, cout):
+    from mindaudio_amd import ops
+
+    x = _rand(t, b, c, h, wd, seed=11).bfloat16()
+    w = _rand(t, cout, c, 3, 3, seed=12, scale=1.0 / math.sqrt(9 * c)).bfloat16()
+    bias = _rand(t, cout, seed=13)
+    ref = t.nn.functional.relu(t.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride=2))
+    got = ops.conv2d_3x3s2_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(),
+                                bias=bias.cuda(), relu=True, out_dtype=t.float32)
+    got = got.permute(0, 3, 1, 2).double().cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_layernorm(t):
+    from mindaudio_amd import ops
+
+    x = (_rand(t, 1001, 256, seed=20) * 3 + 0.7).cuda()
+    g = _rand(t, 256, seed=21).cuda()
+    bta = _rand(t, 256, seed=22).cuda()
+    rs = (t.rand(1001, generator=t.Generator().manual_seed(23)) > 0.2).float().cuda()
+    xd = x.double()
+    mean = xd.mean(-1, keepdim=True)
+    var = ((xd - mean) ** 2).mean(-1, keepdim=True)
+    ref = (xd - mean) / t.sqrt(var + 1e-5) * g.double() + bta.double()
+    got = ops.layernorm(x, g, bta, out_dtype=t.float32).double()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    got = ops.layernorm(x, g, bta, row_scale=rs).double()
+    ref2 = ref * rs.double()[:, None]
+    assert float((got - ref2).abs().max()) <= 2 ** -8 * float(ref2.abs().max()) * 1.01
+
+
+def test_subsample_conv1(t):
+    from mindaudio_amd import ops
+
+    x = _rand(t, 3, 103, 80, seed=30)
+    w = _rand(t, 256, 1, 3, 3, seed=31, scale=0.3)
+    bias = _rand(t, 256, seed=32, scale=0.1)
+    mean = _rand(t, 80, seed=33)
+    istd = t.rand(80, generator=t.Generator().manual_seed(34)) + 0.5
+    ref = t.nn.functional.relu(t.nn.functional.conv2d(((x - mean) * istd).double().unsqueeze(1), w.double(), bias.double(), stride=2))
+    got = ops.subsample_conv1(x.cuda(), w.reshape(256, 9).contiguous().cuda(), bias.cuda(), mean.cuda(), istd.cuda())
+    got = got.permute(0, 3, 1, 2).double().cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) * 1.01
+
+
+@pytest.mark.parametrize("b,tt", [(2, 64), (3, 249), (1, 301)])
+def test_relpos_attention(t, b, tt):
+    from mindaudio_amd import ops
+
+    h, dk = 4, 64
+    qkv = _rand(t, b * tt, 768, seed=40).bfloat16()
+    pos = _rand(t, tt, 256, seed=41).bfloat16()
+    u = _rand(t, h, dk, seed=42, scale=0.2)
+    v = _rand(t, h, dk, seed=43, scale=0.2)
+    lens = [tt, max(1, tt - 37), max(1, tt // 2)][:b]
+    mask = t.zeros(b, tt)
+    for i, n in enumerate(lens):
+        mask[i, :n] = 1.0
+    q = qkv[:, :256].double().view(b, tt, h, dk)
+    k = qkv[:, 256:512].double().view(b, tt, h, dk).transpose(1, 2)
+    vv = qkv[:, 512:].double().view(b, tt, h, dk).transpose(1, 2)
+    p = pos.double().view(1, tt, h, dk).transpose(1, 2)
+    # the kernel rounds (q + u), (q + v) to bf16 before the MFMA: mirror that rounding in the reference
+    qu = (q.float() + u).bfloat16().double().transpose(1, 2)
+    qv = (q.float() + v).bfloat16().double().transpose(1, 2)
+    scores = (qu @ k.transpose(-1, -2) + qv @ p.transpose(-1, -2)) / 8.0
+    scores = scores + (mask[:, None, None, :] == 0).double() * (-10000.0)
+    ref = (t.softmax(scores, -1) @ vv).transpose(1, 2).reshape(b * tt, 256)
+    got = ops.relpos_attention(qkv.cuda(), pos.cuda(), u.cuda(), v.cuda(), mask.cuda(), b, tt).double().cpu()
+    # probabilities are rounded to bf16 before P.V: ~2^-8 relative on sums of <= 1-weighted values
+    assert float((got - ref).abs().max()) <= 1.5e-2 * float(ref.abs().max())
+    assert float((got - ref).abs().mean()) <= 2e-3 * float(ref.abs().max())
+    got_nomask = ops.relpos_attention(qkv.cuda(), pos.cuda(), u.cuda(), v.cuda(), None, b, tt).double().cpu()
+    ref_nomask = (t.softmax((qu @ k.transpose(-1, -2) + qv @ p.transpose(-1, -2)) / 8.0, -1) @ vv).transpose(1, 2).reshape(b * tt, 256)
+    assert float((got_nomask - ref_nomask).abs().max()) <= 1.5e-2 * float(ref_nomask.abs().max())
+
+
+def test_convmodule_mid(t):
+    from mindaudio_amd import ops
+
+    b, tt, c, ks = 3, 77, 256, 15
+    y = _rand(t, b * tt, 2 * c, seed=50).bfloat16()
+    dw = _rand(t, c, ks, seed=51, scale=0.3)
+    sc = t.rand(c, generator=t.Generator().manual_seed(52)) + 0.5
+    sh = _rand(t, c, seed=53, scale=0.2)
+    yd = y.double().view(b, tt, 2 * c)
+    glu = (yd[..., :c] * t.sigmoid(yd[..., c:])).transpose(1, 2)
+    z = t.nn.functional.conv1d(glu, dw.double().unsqueeze(1), padding=ks // 2, groups=c).transpose(1, 2)
+    z = z * sc.double() + sh.double()
+    ref = (z * t.sigmoid(z)).reshape(b * tt, c)
+    got = ops.convmodule_mid(y.cuda(), dw.cuda(), sc.cuda(), sh.cuda(), b, tt).double().cpu()
+    assert float((got - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) * 1.01 + 1e-4

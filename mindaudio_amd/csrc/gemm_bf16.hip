@@ -6,15 +6,15 @@
 // Conv1d's of layers/convolution.py:38-76; the IM2COL instantiation is the 3x3 stride-2 Conv2d of
 // layers/subsampling.py:43 as an implicit GEMM over an NHWC bf16 activation.
 //
-// Tile: 128 x 128 x 64, 256 threads = 4 waves in 2 x 2, each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles
-// (64 accumulator VGPRs).  LDS holds two stages of A and B (2 x 2 x 16 KiB = 64 KiB -> 2 workgroups/CU):
-// rows are 128 bytes, 16-byte chunks XOR-swizzled by (row & 7) so that the ds_read_b128 fragment loads of
-// 16 different rows do not pile onto one bank quad.  Global loads of K-tile t+1 are issued into registers
-// before the MFMAs of tile t and written to the other LDS stage after them.  The MFMA is issued as
+// Tile 128x128x64 or 64x128x64 (picked so that every CU gets work), 4 waves in 2 x 2, MFMA 16x16x32 bf16.
+// Operands stream HBM/L2 -> LDS with global_load_lds_dwordx4 into a 3-stage ring, two K-tiles ahead of the
+// MFMAs (counted vmcnt + raw s_barrier, no VGPR staging); LDS rows are 128 bytes with 16-byte chunks
+// XOR-swizzled by (row & 7) so the ds_read_b128 fragment loads spread over the banks.  The MFMA is issued as
 // mfma(W_frag, A_frag): D[n][m], so a lane ends up holding 4 CONSECUTIVE columns of one output row and the
-// epilogue stores 8-byte (bf16) / 16-byte (f32) vectors.
+// epilogue loads/stores 8-byte (bf16) / 16-byte (f32) vectors.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mindaudio_amd.h"
 
@@ -30,9 +30,12 @@ namespace ma {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int kGemmThreads = 256;
-constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB per stage
+constexpr int kStages = 3;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gl_void_t;
 
 struct GemmParams {
   const uint16_t* A;
@@ -49,21 +52,30 @@ struct GemmParams {
   int32_t H, Wd, C, Ho, Wo;
 };
 
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-  return (uint16_t)(u >> 16);
+// two f32 -> packed bf16x2, round to nearest even (v_cvt_pk_bf16_f32, gfx950)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == 1) return v / (1.0f + __expf(-v));  // swish: x * sigmoid(x)  (layers/swish.py:14-16)
+  // swish: x * sigmoid(x) (layers/swish.py:14-16) = x / (1 + 2^(-x log2 e))
+  if (act == 1) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
   if (act == 2) return fmaxf(v, 0.0f);
   return v;
 }
 
-template <bool IM2COL>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const GemmParams p) {
+// Tile BM x BN x 64, 256 threads = 4 waves in 2 x 2, each wave (BM/2) x (BN/2) = FM x FN MFMA 16x16x32 tiles.
+// LDS: a ring of kStages stages, each the A tile (BM rows) followed by the W tile (BN rows), rows of 128 bytes
+// whose 16-byte chunks are XOR-swizzled by (row & 7).  Tiles are filled by global_load_lds_dwordx4 (one
+// instruction = 8 rows = 1 KiB, no VGPR staging; the swizzle is applied to the per-lane SOURCE address), two
+// tiles ahead of the MFMAs: per K-step one counted s_waitcnt vmcnt + one raw s_barrier.
+template <int BM, int BN, bool IM2COL>
+__global__ __launch_bounds__(kGemmThreads, (BM + BN) > 192 ? 1 : 2) void gemm_bf16_kernel(const GemmParams p) {
+  constexpr int FM = BM / 32, FN = BN / 32;          // fragments per wave
+  constexpr int GA = BM / 32, GW = BN / 32;          // global_load_lds instructions per wave per tile
+  constexpr int kStageBytes = (BM + BN) * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const GemmPa
   const int wm = wave >> 1, wn = wave & 1;
 
   // XCD-aware tile order: consecutive blockIdx go to different XCDs; give each XCD a contiguous run of
-  // tiles so that the W panel (shared by the tiles of one N column) stays in that XCD's L2.
+  // tiles so that the A panel shared by the tiles of one row block stays in that XCD's L2.
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int ntiles = tiles_m * tiles_n;
@@ -83,151 +95,155 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const GemmPa
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- global -> LDS staging assignment: 4 A chunks + 4 W chunks of 16 bytes per thread ----------------
-  int a_row[4], a_kc[4];
-  int64_t a_base[4], w_base[4];
+  // ---- per-lane source addresses of the direct-to-LDS loads ---------------------------------------------------
+  // instruction g of the wave covers rows 8*(wave + 4g) .. +7; lane -> row r = lane >> 3, LDS chunk slot lane & 7,
+  // which must hold logical chunk (slot ^ r)
+  const int lr = lane >> 3;
+  const int kc_src = (lane & 7) ^ lr;
+  const uint16_t* a_src[GA];
+  const uint16_t* w_src[GW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + kGemmThreads * i;
-    a_row[i] = c >> 3;
-    a_kc[i] = c & 7;
-    int m = m0 + a_row[i];
+  for (int g = 0; g < GA; ++g) {
+    int m = m0 + 8 * (wave + 4 * g) + lr;
     if (m >= p.M) m = p.M - 1;  // clamp: rows past M are computed and never stored
+    int64_t base;
     if (IM2COL) {
       const int wo = m % p.Wo;
       const int t = m / p.Wo;
       const int ho = t % p.Ho;
       const int b = t / p.Ho;
-      a_base[i] = (((int64_t)b * p.H + 2 * ho) * p.Wd + 2 * wo) * p.C;
+      base = (((int64_t)b * p.H + 2 * ho) * p.Wd + 2 * wo) * p.C;
     } else {
-      a_base[i] = (int64_t)m * p.lda;
+      base = (int64_t)m * p.lda;
     }
-    int n = n0 + a_row[i];
-    if (n >= p.N) n = p.N - 1;
-    w_base[i] = (int64_t)n * p.ldw;
+    a_src[g] = p.A + base + kc_src * 8;
   }
-  auto lds_off = [](int row, int kc) { return row * (BK * 2) + ((kc ^ (row & 7)) << 4); };
-
-  // K-tile offsets: plain GEMM k0; im2col (kh, kw) shift + channel offset (BK divides C: one (kh, kw) per tile)
+#pragma unroll
+  for (int g = 0; g < GW; ++g) {
+    int n = n0 + 8 * (wave + 4 * g) + lr;
+    if (n >= p.N) n = p.N - 1;
+    w_src[g] = p.W + (int64_t)n * p.ldw + kc_src * 8;
+  }
   auto a_koff = [&](int kt) -> int64_t {
     const int k0 = kt * BK;
     if (!IM2COL) return k0;
-    const int khw = k0 / p.C;
+    const int khw = k0 / p.C;  // BK divides C: one (kh, kw) per K-tile
     const int kh = khw / 3, kw = khw - 3 * kh;
     return ((int64_t)kh * p.Wd + kw) * p.C + (k0 - khw * p.C);
   };
-  const uint16_t* __restrict__ gA = p.A;
-  const uint16_t* __restrict__ gW = p.W;
-#define MA_LOAD_TILE(kt)                                                                         \
-  {                                                                                              \
-    const int64_t ko_ = a_koff(kt);                                                              \
-    const int k0_ = (kt)*BK;                                                                     \
-    ra0 = *reinterpret_cast<const uint4*>(gA + a_base[0] + ko_ + a_kc[0] * 8);                   \
-    ra1 = *reinterpret_cast<const uint4*>(gA + a_base[1] + ko_ + a_kc[1] * 8);                   \
-    ra2 = *reinterpret_cast<const uint4*>(gA + a_base[2] + ko_ + a_kc[2] * 8);                   \
-    ra3 = *reinterpret_cast<const uint4*>(gA + a_base[3] + ko_ + a_kc[3] * 8);                   \
-    rw0 = *reinterpret_cast<const uint4*>(gW + w_base[0] + k0_ + a_kc[0] * 8);                   \
-    rw1 = *reinterpret_cast<const uint4*>(gW + w_base[1] + k0_ + a_kc[1] * 8);                   \
-    rw2 = *reinterpret_cast<const uint4*>(gW + w_base[2] + k0_ + a_kc[2] * 8);                   \
-    rw3 = *reinterpret_cast<const uint4*>(gW + w_base[3] + k0_ + a_kc[3] * 8);                   \
-  }
-#define MA_STORE_TILE(stage)                                                                     \
-  {                                                                                              \
-    char* sa_ = smem + (stage)*kStageBytes;                                                      \
-    char* sw_ = sa_ + BM * BK * 2;                                                               \
-    *reinterpret_cast<uint4*>(sa_ + soff[0]) = ra0;                                              \
-    *reinterpret_cast<uint4*>(sa_ + soff[1]) = ra1;                                              \
-    *reinterpret_cast<uint4*>(sa_ + soff[2]) = ra2;                                              \
-    *reinterpret_cast<uint4*>(sa_ + soff[3]) = ra3;                                              \
-    *reinterpret_cast<uint4*>(sw_ + soff[0]) = rw0;                                              \
-    *reinterpret_cast<uint4*>(sw_ + soff[1]) = rw1;                                              \
-    *reinterpret_cast<uint4*>(sw_ + soff[2]) = rw2;                                              \
-    *reinterpret_cast<uint4*>(sw_ + soff[3]) = rw3;                                              \
-  }
-  int soff[4];
+  auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
+    char* st = smem + stage * kStageBytes;
+    const int64_t ka = a_koff(kt);
+    const int64_t kw = (int64_t)kt * BK;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) soff[i] = lds_off(a_row[i], a_kc[i]);
-  uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    for (int g = 0; g < GA; ++g)
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(a_src[g] + ka), (lds_void_t*)(st + (wave + 4 * g) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int g = 0; g < GW; ++g)
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(w_src[g] + kw),
+                                       (lds_void_t*)(st + BM * 128 + (wave + 4 * g) * 1024), 16, 0, 0);
+  };
 
-  f32x4 acc[4][4];
+  f32x4 acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto lds_off = [](int row, int kc) { return row * (BK * 2) + ((kc ^ (row & 7)) << 4); };
+  const int frow = lane & 15, fk = lane >> 4;
+  int foff_a[FM], foff_w[FN];  // fragment byte offsets for kk = 0; kk = 1 flips chunk bit 2 (XOR 64 bytes)
+#pragma unroll
+  for (int i = 0; i < FM; ++i) foff_a[i] = lds_off(wm * (BM / 2) + i * 16 + frow, fk);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) foff_w[j] = BM * 128 + lds_off(wn * (BN / 2) + j * 16 + frow, fk);
 
   const int nk = p.K / BK;
-  MA_LOAD_TILE(0);
-  MA_STORE_TILE(0);
-  __syncthreads();
-
-  const int frow = lane & 15, fk = lane >> 4;
-  int foff_a[4], foff_w[4];  // fragment byte offsets for kk = 0; kk = 1 flips chunk bit 2 (XOR 64 bytes)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    foff_a[i] = lds_off(wm * 64 + i * 16 + frow, fk);
-    foff_w[i] = BM * BK * 2 + lds_off(wn * 64 + i * 16 + frow, fk);
-  }
-  auto compute = [&](int stage) __attribute__((always_inline)) {
-    const char* st = smem + stage * kStageBytes;
+  issue_tile(0, 0);
+  if (nk > 1) issue_tile(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most one younger tile of this wave is still in flight
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's part of tile kt is in LDS; everyone is done reading tile kt-1
+    if (kt + 2 < nk) issue_tile(kt + 2, (kt + 2) % kStages);
+    const char* st = smem + (kt % kStages) * kStageBytes;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], wf[4];
+      bf16x8 af[FM], wf[FN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(st + (foff_a[i] ^ (kk << 6)));
-        wf[i] = *reinterpret_cast<const bf16x8*>(st + (foff_w[i] ^ (kk << 6)));
-      }
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (foff_a[i] ^ (kk << 6)));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(st + (foff_w[j] ^ (kk << 6)));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
-  };
-  for (int kt = 0; kt + 1 < nk; ++kt) {
-    const int stage = kt & 1;
-    MA_LOAD_TILE(kt + 1);
-    compute(stage);
-    MA_STORE_TILE(stage ^ 1);
-    __syncthreads();
   }
-  compute((nk - 1) & 1);
-#undef MA_LOAD_TILE
-#undef MA_STORE_TILE
 
   // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] ------------------
   const int em = lane & 15, en = (lane >> 4) * 4;
+  // bf16 tiles that lie fully inside the matrix go through LDS so that HBM sees whole 256-byte rows
+  const bool staged = p.out_bf16 && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 7) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+  if (staged) __builtin_amdgcn_s_barrier();  // all waves are done reading the last K-tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + em;
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 16 + em;
     if (m >= p.M) continue;
-    const float rs = p.row_scale ? p.row_scale[m] : 1.0f;
+    const float rs = (p.row_scale ? p.row_scale[m] : 1.0f) * p.alpha;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + en;
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + en;
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const bool full = n + 3 < p.N;
+      const bool full = (n + 3 < p.N);
+      if (full) {
+        if (p.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (full || n + r < p.N) {
-          float x = v[r] + (p.bias ? p.bias[n + r] : 0.0f);
-          x = apply_act(x, p.act) * p.alpha * rs;
-          if (p.residual) x += p.residual[(int64_t)m * p.ldr + n + r];
-          v[r] = x;
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act) * rs;
+        if (p.residual) {
+          const float* rp = p.residual + (int64_t)m * p.ldr + n;
+          if ((p.ldr & 3) == 0) {
+            const float4 rv = *reinterpret_cast<const float4*>(rp);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rp[r];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            float x = v[r] + (p.bias ? p.bias[n + r] : 0.0f);
+            x = apply_act(x, p.act) * rs;
+            if (p.residual) x += p.residual[(int64_t)m * p.ldr + n + r];
+            v[r] = x;
+          }
         }
       }
       if (p.out_bf16) {
-        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
-        if (full && ((p.ldo & 3) == 0)) {
-          uint2 pk;
-          pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-          pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-          *reinterpret_cast<uint2*>(o) = pk;
+        const uint32_t lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+        if (staged) {
+          // C tile -> LDS (row-major bf16, BN*2-byte rows), whole rows leave below as 16-byte vectors
+          const int lr_ = wm * (BM / 2) + i * 16 + em, lc_ = wn * (BN / 2) + j * 16 + en;
+          *reinterpret_cast<uint2*>(smem + lr_ * (BN * 2 + 16) + lc_ * 2) = make_uint2(lo, hi);
         } else {
+          uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
+          if (full && ((p.ldo & 3) == 0)) {
+            *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
+          } else {
+            const uint16_t h[4] = {(uint16_t)(lo & 0xffff), (uint16_t)(lo >> 16), (uint16_t)(hi & 0xffff), (uint16_t)(hi >> 16)};
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) o[r] = f32_to_bf16(v[r]);
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) o[r] = h[r];
+          }
         }
       } else {
         float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
@@ -241,20 +257,54 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_bf16_kernel(const GemmPa
       }
     }
   }
+  if (staged) {
+    __syncthreads();
+    constexpr int kRowBytes = BN * 2, kChunks = kRowBytes / 16;
+    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m0 * p.ldo + n0;
+    for (int c = tid; c < BM * kChunks; c += kGemmThreads) {
+      const int r = c / kChunks, cc = c - r * kChunks;
+      *reinterpret_cast<uint4*>(o + (int64_t)r * p.ldo + cc * 8) =
+          *reinterpret_cast<const uint4*>(smem + r * (kRowBytes + 16) + cc * 16);
+    }
+  }
 }
 
-template <bool IM2COL>
-static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+static int g_gemm_cus = 0;
+static int gemm_num_cus() {
+  if (g_gemm_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_gemm_cus = prop.multiProcessorCount;
+    if (g_gemm_cus <= 0) g_gemm_cus = 256;
+  }
+  return g_gemm_cus;
+}
+
+template <int BM, int BN, bool IM2COL>
+static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
+  constexpr int lds = kStages * (BM + BN) * BK * 2;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<IM2COL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, IM2COL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MA_ERR_LAUNCH;
     attr = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  MA_LAUNCH(gemm_bf16_kernel<IM2COL>, dim3(tiles), dim3(kGemmThreads), 2 * kStageBytes, stream, p);
+  MA_LAUNCH((gemm_bf16_kernel<BM, BN, IM2COL>), dim3(tiles), dim3(kGemmThreads), lds, stream, p);
   return MA_OK;
+}
+
+template <bool IM2COL>
+static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+  // 128 x 128 tiles unless they would leave most CUs without a workgroup (N = 256 .. 768 at M ~ 8k)
+  const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  static const char* force = getenv("MA_GEMM_TILE");  // developer override: "128" / "64"
+  if (force && force[0] == '1') return launch_gemm_tile<128, 128, IM2COL>(p, stream);
+  if (force && force[0] == '6') return launch_gemm_tile<64, 128, IM2COL>(p, stream);
+  if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, IM2COL>(p, stream);
+  return launch_gemm_tile<64, 128, IM2COL>(p, stream);
 }
 
 static int fill_epilogue(GemmParams& p, const ma_gemm_epilogue_t* e) {
@@ -282,6 +332,7 @@ int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* o
                  int64_t N, int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream) {
   if (!A || !W || !out || M < 1 || N < 1 || K < 1 || M > 0x7fffffff || N > 0x7fffffff) return MA_ERR_INVALID_ARG;
   if (K % BK != 0 || lda < K || ldw < K || ldo < N || (lda & 7) || (ldw & 7)) return MA_ERR_UNSUPPORTED;
+  if (epi && epi->bias && (reinterpret_cast<uintptr_t>(epi->bias) & 15)) return MA_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return MA_ERR_INVALID_ARG;
   GemmParams p = GemmParams{};
   p.A = reinterpret_cast<const uint16_t*>(A);

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Small fixed workloads for rocprofv3 passes: `fbank` (cfg-2 fbank kernel), `gemm` (FFN w_1 shape), `step` (bench step)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import mindaudio_amd as ma
+from mindaudio_amd import _host, _lib, ops
+from mindaudio_amd.models import ConformerEncoder
+what = sys.argv[1] if len(sys.argv) > 1 else "step"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+B, N = 64, 160000
+x = torch.from_numpy((0.1 * np.random.RandomState(1234).randn(B, N)).astype(np.float32)).cuda()
+if what == "fbank":
+    for _ in range(n): ma.fbank(x, n_mels=80, n_fft=512, hop_length=160)
+elif what == "gemm":
+    m, nn, k = B * 249, 2048, 256
+    a = torch.randn(m, k, device="cuda").bfloat16(); w = (torch.randn(nn, k, device="cuda") / 16).bfloat16(); bias = torch.randn(nn, device="cuda")
+    out = torch.empty(m, nn, dtype=torch.bfloat16, device="cuda")
+    for _ in range(n): ops.gemm(a, w, bias=bias, act=_lib.ACT_SWISH, out=out)
+else:
+    torch.manual_seed(777)
+    enc = ConformerEncoder(80, 256, 4, 2048, 12).eval().cuda().prepare()
+    masks = torch.ones(B, 1, 249, device="cuda")
+    for _ in range(n):
+        feats = ma.fbank(x, n_mels=80, n_fft=512, hop_length=160)
+        enc(feats.transpose(1, 2)[:, :1000].contiguous(), masks)
+torch.cuda.synchronize()

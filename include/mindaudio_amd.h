@@ -171,6 +171,15 @@ typedef struct ma_gemm_epilogue {
 int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* out, int64_t ldo,
                  int64_t M, int64_t N, int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream);
 
+/* PositionwiseFeedForward + residual in ONE kernel (layers/positionwise_feed_forward.py:33-46 with Swish,
+ * models/conformer.py:109-112 / 147-151):   x[m, :] += alpha * (swish(a[m, :] . W1^T + b1) . W2^T + b2)
+ *   a (M, d_model) bf16 = LayerNorm(x); W1 (hidden, d_model), W2 (d_model, hidden) bf16 as stored by the
+ *   reference Dense cells; b1 (hidden), b2 (d_model) float32; x (M, d_model) float32 updated in place.
+ * The (M, hidden) activation never reaches HBM.  d_model == 256, hidden % 256 == 0 (<= 4096), 16-byte aligned pointers. */
+int ma_ffn_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2,
+                float* x, int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha,
+                ma_stream_t stream);
+
 /* 3x3, stride 2, valid Conv2d (layers/subsampling.py:43) as an implicit GEMM.
  *   act device bf16 NHWC (batch, H, Wd, C), C % 64 == 0;  W device bf16 (Cout, 3, 3, C) i.e. k = (kh, kw, c);
  *   out (batch, Ho, Wo, Cout), Ho = (H-3)/2+1, Wo = (Wd-3)/2+1, dtype per epilogue. */
@@ -183,6 +192,13 @@ int ma_conv2d_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t
 int ma_layernorm_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma,
                      const float* beta, float eps, const float* row_scale, void* out, int64_t ldo,
                      int32_t out_bf16, ma_stream_t stream);
+
+/* Two chained LayerNorms in one pass over 256-wide rows: out1 = LN(x; gamma1, beta1) float32 (may alias x),
+ * out2 = LN(out1; gamma2, beta2) bf16 or float32 — norm_final of one block followed by norm_ff_macaron of the
+ * next, or by after_norm (models/conformer.py:155-156, 109-110, 253-254). */
+int ma_layernorm2_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma1,
+                      const float* beta1, const float* gamma2, const float* beta2, float eps, float* out1,
+                      int64_t ldo1, void* out2, int64_t ldo2, int32_t out2_bf16, ma_stream_t stream);
 
 /* GlobalCMVN (layers/cmvn.py:33-35; mean/istd may be NULL) + Conv2d(1 -> C, 3x3, stride 2, valid) + ReLU
  * (layers/subsampling.py:41-42).  x (batch, T, idim) float32; w (C, 3, 3), bias (C) float32;

@@ -74,10 +74,15 @@ PROTOTYPES = {
                                           ctypes.c_void_p]),
     "ma_gemm_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p, i64, i64, i64, i64,
                                     ctypes.POINTER(GemmEpilogue), ctypes.c_void_p]),
+    "ma_ffn_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, i64, i64, i32, i32, f32, ctypes.c_void_p]),
     "ma_conv2d_3x3s2_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i64, ctypes.c_void_p, i64,
                                                  ctypes.c_void_p, ctypes.POINTER(GemmEpilogue), ctypes.c_void_p]),
     "ma_layernorm_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_void_p, f32,
                                         ctypes.c_void_p, ctypes.c_void_p, i64, i32, ctypes.c_void_p]),
+    "ma_layernorm2_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, f32, ctypes.c_void_p, i64, ctypes.c_void_p,
+                                         i64, i32, ctypes.c_void_p]),
     "ma_subsample_conv1_nhwc": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p, i32, ctypes.c_void_p,
                                                ctypes.c_void_p]),

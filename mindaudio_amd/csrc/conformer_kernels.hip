@@ -86,6 +86,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// ---- two chained LayerNorms in one pass: y1 = LN1(x) (f32, may overwrite x), y2 = LN2(y1) (bf16 or f32) -------
+// (norm_final of block l followed by norm_ff_macaron of block l+1, or by after_norm: models/conformer.py:155-156,
+//  :109-110, :253-254)
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
+                                                         const float* __restrict__ g1, const float* __restrict__ b1,
+                                                         const float* __restrict__ g2, const float* __restrict__ b2,
+                                                         float eps, float* __restrict__ out1, int64_t ldo1, void* out2,
+                                                         int64_t ldo2, int out2_bf16) {
+  constexpr int D = 256;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c = lane * 4;
+  float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+  float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / D);
+  v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+  float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / D);
+  float inv = 1.0f / sqrtf(var + eps);
+  float4 g = *reinterpret_cast<const float4*>(g1 + c), b = *reinterpret_cast<const float4*>(b1 + c);
+  v.x = v.x * inv * g.x + b.x; v.y = v.y * inv * g.y + b.y; v.z = v.z * inv * g.z + b.z; v.w = v.w * inv * g.w + b.w;
+  *reinterpret_cast<float4*>(out1 + row * ldo1 + c) = v;
+  mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / D);
+  v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+  var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / D);
+  inv = 1.0f / sqrtf(var + eps);
+  g = *reinterpret_cast<const float4*>(g2 + c);
+  b = *reinterpret_cast<const float4*>(b2 + c);
+  v.x = v.x * inv * g.x + b.x; v.y = v.y * inv * g.y + b.y; v.z = v.z * inv * g.z + b.z; v.w = v.w * inv * g.w + b.w;
+  if (out2_bf16) {
+    uint2 pk;
+    pk.x = (uint32_t)to_bf16(v.x) | ((uint32_t)to_bf16(v.y) << 16);
+    pk.y = (uint32_t)to_bf16(v.z) | ((uint32_t)to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out2) + row * ldo2 + c) = pk;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out2) + row * ldo2 + c) = v;
+  }
+}
+
 // ---- CMVN + Conv2d(1 -> C, 3x3, stride 2, valid) + ReLU, output NHWC bf16 -----------------------------------
 // One workgroup per (b, output time t): 256 threads = channels (C == 256) or C/… loop; the 3 x idim input rows are
 // normalised into LDS once, each thread keeps its 9 weights in registers and walks the F1 output columns.
@@ -306,41 +344,76 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
 //   z[t, c] = sum_k dw[c, k] * glu[t + k - KS/2, c];  out = swish(z * bn_scale[c] + bn_shift[c])
 // (conv bias and BatchNorm statistics are folded into bn_scale / bn_shift by the host.)
 constexpr int kCmTile = 32;
+// Thread (cg = tid & 31, rg = tid >> 5) owns channels 8cg..8cg+7: 16-byte bf16 loads/stores, 16-byte LDS rows.
+// LDS: glu[(kCmTile + KS - 1)][C=256] f32, then the KS x 256 weights.  C must be 256 per block column.
 __global__ __launch_bounds__(256) void convmodule_mid_kernel(const uint16_t* __restrict__ y, int64_t ldy, int T, int C,
                                                              const float* __restrict__ dw, int KS,
                                                              const float* __restrict__ bn_scale,
                                                              const float* __restrict__ bn_shift,
                                                              uint16_t* __restrict__ out, int64_t ldo) {
-  extern __shared__ float glu[];  // (kCmTile + KS - 1) x 256 channels of this block, then KS x 256 weights
+  extern __shared__ __attribute__((aligned(16))) float glu[];
   const int b = blockIdx.z, cb = blockIdx.y * 256, t0 = blockIdx.x * kCmTile;
-  const int c = cb + threadIdx.x;
+  const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c0 = cb + cg * 8;
   const int half = KS / 2, span = kCmTile + KS - 1;
   const int64_t row0 = (int64_t)b * T;
-  if (c < C) {
-    for (int i = 0; i < span; ++i) {
+  float* wl = glu + span * 256;
+  for (int i = threadIdx.x; i < KS * 256; i += 256) {  // wl[k][c]
+    const int k = i >> 8, c = i & 255;
+    wl[i] = (cb + c < C) ? dw[(cb + c) * KS + k] : 0.0f;
+  }
+  if (c0 < C) {
+    for (int i = rg; i < span; i += 8) {
       const int t = t0 + i - half;
-      float g = 0.0f;
+      float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (t >= 0 && t < T) {
-        const float a = from_bf16(y[(row0 + t) * ldy + c]);
-        const float gate = from_bf16(y[(row0 + t) * ldy + C + c]);
-        g = a / (1.0f + __expf(-gate));  // layers/glu.py:24-28
+        const uint4 av = *reinterpret_cast<const uint4*>(y + (row0 + t) * ldy + c0);
+        const uint4 gv = *reinterpret_cast<const uint4*>(y + (row0 + t) * ldy + C + c0);
+        const uint32_t aw[4] = {av.x, av.y, av.z, av.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = from_bf16((uint16_t)(aw[e] & 0xffff)), a1 = from_bf16((uint16_t)(aw[e] >> 16));
+          const float g0 = from_bf16((uint16_t)(gw[e] & 0xffff)), g1 = from_bf16((uint16_t)(gw[e] >> 16));
+          // layers/glu.py:24-28: out * sigmoid(gate)
+          g[2 * e] = a0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g0));
+          g[2 * e + 1] = a1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g1));
+        }
       }
-      glu[i * 256 + threadIdx.x] = g;
+      float4* dst = reinterpret_cast<float4*>(glu + i * 256 + cg * 8);
+      dst[0] = make_float4(g[0], g[1], g[2], g[3]);
+      dst[1] = make_float4(g[4], g[5], g[6], g[7]);
     }
   }
-  float* wl = glu + span * 256;
-  if (c < C)
-    for (int k = 0; k < KS; ++k) wl[k * 256 + threadIdx.x] = dw[c * KS + k];
   __syncthreads();
-  if (c >= C) return;
-  const float sc = bn_scale[c], sh = bn_shift[c];
-  for (int i = 0; i < kCmTile; ++i) {
+  if (c0 >= C) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = bn_scale[c0 + e]; sh[e] = bn_shift[c0 + e]; }
+#pragma unroll
+  for (int rr = 0; rr < kCmTile / 8; ++rr) {
+    const int i = rg + 8 * rr;
     const int t = t0 + i;
     if (t >= T) break;
-    float acc = 0.f;
-    for (int k = 0; k < KS; ++k) acc = fmaf(wl[k * 256 + threadIdx.x], glu[(i + k) * 256 + threadIdx.x], acc);
-    const float z = acc * sc + sh;
-    out[(row0 + t) * ldo + c] = to_bf16(z / (1.0f + __expf(-z)));
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < KS; ++k) {
+      const float4* gp = reinterpret_cast<const float4*>(glu + (i + k) * 256 + cg * 8);
+      const float4* wp = reinterpret_cast<const float4*>(wl + k * 256 + cg * 8);
+      const float4 g0 = gp[0], g1 = gp[1], w0 = wp[0], w1 = wp[1];
+      acc[0] = fmaf(w0.x, g0.x, acc[0]); acc[1] = fmaf(w0.y, g0.y, acc[1]);
+      acc[2] = fmaf(w0.z, g0.z, acc[2]); acc[3] = fmaf(w0.w, g0.w, acc[3]);
+      acc[4] = fmaf(w1.x, g1.x, acc[4]); acc[5] = fmaf(w1.y, g1.y, acc[5]);
+      acc[6] = fmaf(w1.z, g1.z, acc[6]); acc[7] = fmaf(w1.w, g1.w, acc[7]);
+    }
+    uint32_t pk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float z0 = acc[2 * e] * sc[2 * e] + sh[2 * e];
+      float z1 = acc[2 * e + 1] * sc[2 * e + 1] + sh[2 * e + 1];
+      z0 = z0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z0));
+      z1 = z1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z1));
+      pk[e] = (uint32_t)to_bf16(z0) | ((uint32_t)to_bf16(z1) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + (row0 + t) * ldo + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
 }
 
@@ -364,6 +437,16 @@ int ma_layernorm_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, co
     case 1024: MA_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
     default: return MA_ERR_UNSUPPORTED;
   }
+  return MA_OK;
+}
+
+int ma_layernorm2_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma1, const float* beta1,
+                      const float* gamma2, const float* beta2, float eps, float* out1, int64_t ldo1, void* out2,
+                      int64_t ldo2, int32_t out2_bf16, ma_stream_t stream) {
+  if (!x || !gamma1 || !beta1 || !gamma2 || !beta2 || !out1 || !out2 || rows < 1) return MA_ERR_INVALID_ARG;
+  if (cols != 256 || (ldx & 3) || (ldo1 & 3) || (ldo2 & 3)) return MA_ERR_UNSUPPORTED;
+  MA_LAUNCH(layernorm2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
+            gamma1, beta1, gamma2, beta2, eps, out1, ldo1, out2, ldo2, out2_bf16);
   return MA_OK;
 }
 
@@ -397,6 +480,7 @@ int ma_convmodule_mid_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T,
                            ma_stream_t stream) {
   if (!y || !dw || !bn_scale || !bn_shift || !out || batch < 1 || T < 1 || C < 1) return MA_ERR_INVALID_ARG;
   if (kernel_size < 1 || kernel_size > 31 || (kernel_size & 1) == 0 || batch > 65535) return MA_ERR_UNSUPPORTED;
+  if ((C & 7) || (ldy & 7) || (ldo & 7)) return MA_ERR_UNSUPPORTED;  // 16-byte channel groups
   const size_t lds = (size_t)(kCmTile + 2 * kernel_size - 1) * 256 * sizeof(float);
   const dim3 grid((unsigned)((T + kCmTile - 1) / kCmTile), (unsigned)((C + 255) / 256), (unsigned)batch);
   MA_LAUNCH(convmodule_mid_kernel, grid, dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(y),

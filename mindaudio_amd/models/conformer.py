@@ -183,6 +183,15 @@ class ConformerEncoder(nn.Module):
             self._pos_cache[t2] = ops.gemm(pe, self._prepared["pos_w"])
         return self._pos_cache[t2]
 
+    @staticmethod
+    def _ffn(a, W, key, x, fused):
+        """x += 0.5 * FFN(a) (positionwise_feed_forward.py:33-46 + models/conformer.py:109-112 / 147-151)."""
+        if fused:
+            ops.ffn(a, W[key + "_w1"], W[key + "_b1"], W[key + "_w2"], W[key + "_b2"], x, alpha=0.5)
+        else:
+            h = ops.gemm(a, W[key + "_w1"], bias=W[key + "_b1"], act=_lib.ACT_SWISH)
+            ops.gemm(h, W[key + "_w2"], bias=W[key + "_b2"], residual=x, alpha=0.5, out_dtype=torch.float32, out=x)
+
     @torch.no_grad()
     def forward(self, xs, masks, xs_chunk_masks=None):
         """xs (B, T, idim) float32 on the HIP device; masks (B, 1, T') — the subsampled pad mask the collate
@@ -209,11 +218,14 @@ class ConformerEncoder(nn.Module):
         # Dense(4864 -> 256) then x * sqrt(d) (subsampling.py:76, embedding.py:84)
         x = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(self.d), out_dtype=f32)
         pos_all = self._pos_projection(t2)
+        n_layers = len(self.encoders)
+        # the fused FFN kernel works on 64-row blocks, one workgroup per CU: it wins once those fill the chip
+        fused_ffn = m >= 64 * 200
+        a = ops.layernorm(x, self.encoders[0].norm_ff_macaron.gamma, self.encoders[0].norm_ff_macaron.beta)
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
-            # x = x + 0.5 * FFN_macaron(LN(x))                                   models/conformer.py:109-112
-            a = ops.layernorm(x, l.norm_ff_macaron.gamma, l.norm_ff_macaron.beta)
-            h = ops.gemm(a, W["ffm_w1"], bias=W["ffm_b1"], act=_lib.ACT_SWISH)
-            ops.gemm(h, W["ffm_w2"], bias=W["ffm_b2"], residual=x, alpha=0.5, out_dtype=f32, out=x)
+            # x = x + 0.5 * FFN_macaron(LN(x))   (a = LN(x) comes from the previous block's fused LN pair)
+            #                                                                      models/conformer.py:109-112
+            self._ffn(a, W, "ffm", x, fused_ffn)
             # x = x + MHA(LN(x))                                                   :117-135
             a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta)
             qkv = ops.gemm(a, W["qkv_w"], bias=W["qkv_b"])
@@ -227,8 +239,12 @@ class ConformerEncoder(nn.Module):
             ops.gemm(z, W["pw2_w"], bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
             # x = x + 0.5 * FFN(LN(x)) ; x = LN_final(x)                           :147-156
             a = ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta)
-            h = ops.gemm(a, W["ff_w1"], bias=W["ff_b1"], act=_lib.ACT_SWISH)
-            ops.gemm(h, W["ff_w2"], bias=W["ff_b2"], residual=x, alpha=0.5, out_dtype=f32, out=x)
-            x = ops.layernorm(x, l.norm_final.gamma, l.norm_final.beta, out_dtype=f32)
-        x = ops.layernorm(x, self.after_norm.gamma, self.after_norm.beta, out_dtype=f32)
+            self._ffn(a, W, "ff", x, fused_ffn)
+            # x = LN_final(x), fused with the LayerNorm that consumes it next
+            if li + 1 < n_layers:
+                nxt = self.encoders[li + 1].norm_ff_macaron
+                a = ops.layernorm2(x, l.norm_final.gamma, l.norm_final.beta, nxt.gamma, nxt.beta)
+            else:
+                x = ops.layernorm2(x, l.norm_final.gamma, l.norm_final.beta, self.after_norm.gamma,
+                                   self.after_norm.beta, out2_dtype=f32)
         return x.view(b, t2, self.d), masks

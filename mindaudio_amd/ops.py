@@ -39,6 +39,21 @@ def gemm(a, w, bias=None, residual=None, row_scale=None, alpha=1.0, act=_lib.ACT
     return out
 
 
+def ffn(a, w1, b1, w2, b2, x, alpha=0.5):
+    """In place x += alpha * (swish(a @ w1^T + b1) @ w2^T + b2); a (M, 256) bf16, x (M, 256) float32."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and w1.dtype == t.bfloat16 and w2.dtype == t.bfloat16 and x.dtype == t.float32
+    assert a.stride(1) == 1 and x.stride(1) == 1 and w1.is_contiguous() and w2.is_contiguous()
+    m, d = a.shape
+    hidden = w1.shape[0]
+    assert tuple(w1.shape) == (hidden, d) and tuple(w2.shape) == (d, hidden) and tuple(x.shape) == (m, d)
+    rc = lib.ma_ffn_bf16(_host.ptr(a), a.stride(0), _host.ptr(w1), _host.ptr(b1), _host.ptr(w2), _host.ptr(b2),
+                         _host.ptr(x), x.stride(0), m, d, hidden, float(alpha), _host.current_stream_ptr())
+    _lib.check(rc, "ffn_bf16")
+    return x
+
+
 def conv2d_3x3s2_nhwc(act, w, bias=None, relu=True, out_dtype=None):
     """act (B, H, W, C) bf16 NHWC, w (Cout, 3, 3, C) bf16 -> (B, Ho, Wo, Cout)."""
     t = _host.torch()
@@ -73,6 +88,20 @@ def layernorm(x, gamma, beta, eps=1e-5, row_scale=None, out_dtype=None, out=None
                               1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
     _lib.check(rc, "layernorm")
     return out
+
+
+def layernorm2(x, g1, b1, g2, b2, eps=1e-5, out2_dtype=None):
+    """In place x <- LN(x; g1, b1) (float32) and returns LN(x_new; g2, b2) as bf16 (default) or float32."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert x.dtype == t.float32 and x.dim() == 2 and x.stride(1) == 1
+    out2_dtype = out2_dtype or t.bfloat16
+    out2 = t.empty(x.shape, dtype=out2_dtype, device=x.device)
+    rc = lib.ma_layernorm2_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(g1), _host.ptr(b1),
+                               _host.ptr(g2), _host.ptr(b2), float(eps), _host.ptr(x), x.stride(0), _host.ptr(out2),
+                               out2.stride(0), 1 if out2_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    _lib.check(rc, "layernorm2")
+    return out2
 
 
 def subsample_conv1(x, w, bias, cmvn_mean=None, cmvn_istd=None):

@@ -175,3 +175,25 @@ def test_convmodule_mid(t):
     ref = (z * t.sigmoid(z)).reshape(b * tt, c)
     got = ops.convmodule_mid(y.cuda(), dw.cuda(), sc.cuda(), sh.cuda(), b, tt).double().cpu()
     assert float((got - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) * 1.01 + 1e-4
+
+
+@pytest.mark.parametrize("m,hidden", [(64, 256), (250, 2048), (7968, 2048), (1000, 512)])
+def test_ffn_fused(t, m, hidden):
+    from mindaudio_amd import ops
+
+    d = 256
+    a = _rand(t, m, d, seed=60).bfloat16()
+    w1 = _rand(t, hidden, d, seed=61, scale=1.0 / 16).bfloat16()
+    b1 = _rand(t, hidden, seed=62, scale=0.3)
+    w2 = _rand(t, d, hidden, seed=63, scale=1.0 / math.sqrt(hidden)).bfloat16()
+    b2 = _rand(t, d, seed=64, scale=0.3)
+    x = _rand(t, m, d, seed=65)
+    z = a.double() @ w1.double().T + b1.double()
+    h = (z * t.sigmoid(z)).bfloat16().double()  # the kernel rounds the hidden activation to bf16 (as the 2-GEMM form does)
+    ref = x.double() + 0.5 * (h @ w2.double().T + b2.double())
+    xg = x.clone().cuda()
+    ops.ffn(a.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), xg, alpha=0.5)
+    err = float((xg.double().cpu() - ref).abs().max())
+    # bf16 rounding of h can flip by one ulp where the device's fast sigmoid differs in the last bit:
+    # error budget = a few bf16 ulps of |h| spread over `hidden` terms
+    assert err <= 3e-3 * float(ref.abs().max()), err

@@ -225,6 +225,20 @@ int ma_convmodule_mid_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T,
                            int32_t kernel_size, const float* bn_scale, const float* bn_shift, void* out,
                            int64_t ldo, ma_stream_t stream);
 
+/* CTC branch, forward value (mindaudio/loss/ctc_loss.py:53-64): float32 log_softmax over V + CTCLossV2(blank,
+ * reduction none, zero_infinity) + sum over the batch / batch.
+ *   logits (batch*T, V) float32 row stride ld (= ctc_lo output, ma_gemm_bf16 with float32 out);
+ *   ys (batch, Lmax) int32 padded labels; hlens / ylens (batch) int32 input / target lengths;
+ *   per_utt_loss (batch) float32 out; lse_workspace (batch*T) float32; loss_out (1) float32.
+ * Targets up to 127 labels (2*Lmax + 1 <= 256). */
+int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
+                    int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
+                    int32_t zero_infinity, float* per_utt_loss, float* lse_workspace, float* loss_out,
+                    ma_stream_t stream);
+
+/* float32 -> bf16 (round to nearest even), n % 4 == 0: the `cast` in front of a matmul operand. */
+int ma_cast_f32_bf16(const float* x, void* y, int64_t n, ma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

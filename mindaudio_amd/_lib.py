@@ -92,6 +92,10 @@ PROTOTYPES = {
     "ma_convmodule_mid_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i32, ctypes.c_void_p, i32,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),
+    "ma_ctc_loss_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i32, ctypes.c_void_p, i32, ctypes.c_void_p,
+                                       ctypes.c_void_p, i32, i32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p]),
+    "ma_cast_f32_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p]),
     "ma_db_workspace_bytes": (i64, [i64, i64]),
     "ma_amplitude_to_db_f32": (ctypes.c_int, [c_f32p, i64, i64, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),

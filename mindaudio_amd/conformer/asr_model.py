@@ -1,0 +1,94 @@
+"""Mirror of examples/conformer/asr_model.py for the CTC configuration (ctc_weight = 1.0, decoder None:
+asr_model.py:327-328) — forward / evaluation loss on MI355X.
+
+ASRModel.forward takes the 11 columns of the reference batch in the reference order (train.py:38-50) and returns
+(loss, acc_att) like ASRModelWithAcc.construct (asr_model.py:75-153).  The attention-decoder branch
+(ctc_weight != 1.0) is a later row."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..models.conformer import ConformerEncoder
+
+
+class CTC(nn.Module):
+    """mindaudio/loss/ctc_loss.py:10-64: Dense(eprojs -> odim), float32 log_softmax, CTCLossV2(blank 0,
+    zero_infinity), sum / batch."""
+
+    def __init__(self, odim, encoder_output_size, dropout_rate=0.0, compute_type=None):
+        super().__init__()
+        self.ctc_lo = nn.Linear(encoder_output_size, odim)
+        self._w = None
+
+    @torch.no_grad()
+    def prepare(self):
+        self._w = (self.ctc_lo.weight.detach().to(torch.bfloat16).contiguous(),
+                   self.ctc_lo.bias.detach().float().contiguous())
+        return self
+
+    @torch.no_grad()
+    def logits(self, hs_pad):
+        if self._w is None:
+            self.prepare()
+        b, t, d = hs_pad.shape
+        a = ops.cast_bf16(hs_pad.reshape(b * t, d).contiguous())
+        return ops.gemm(a, self._w[0], bias=self._w[1], out_dtype=torch.float32)
+
+    @torch.no_grad()
+    def forward(self, hs_pad, hlens, ys_pad, ys_lengths):
+        b, t, _ = hs_pad.shape
+        loss, _ = ops.ctc_loss(self.logits(hs_pad), b, t, ys_pad, hlens, ys_lengths, blank=0, zero_infinity=True)
+        return loss
+
+
+class ASRModel(nn.Module):
+    """Encoder + CTC loss (asr_model.py:16-153 with ctc_weight == 1.0)."""
+
+    def __init__(self, vocab_size, encoder, ctc, ctc_weight=1.0):
+        super().__init__()
+        if ctc_weight != 1.0:
+            raise NotImplementedError("attention-decoder branch (ctc_weight != 1.0) is not on the built path yet")
+        self.vocab_size, self.encoder, self.ctc, self.ctc_weight = vocab_size, encoder, ctc, ctc_weight
+
+    @torch.no_grad()
+    def forward(self, xs_pad, ys_pad, ys_in_pad=None, ys_out_pad=None, r_ys_in_pad=None, r_ys_out_pad=None,
+                xs_masks=None, ys_sub_masks=None, ys_masks=None, ys_lengths=None, xs_chunk_masks=None):
+        encoder_out, encoder_mask = self.encoder(xs_pad, xs_masks, xs_chunk_masks)
+        # asr_model.py:109-114: lengths = mask.squeeze().sum(1) as int32
+        encoder_out_lens = encoder_mask.to(torch.float32).reshape(encoder_mask.shape[0], -1).sum(1).to(torch.int32)
+        loss_ctc = self.ctc(encoder_out, encoder_out_lens, ys_pad, ys_lengths)
+        return loss_ctc, None
+
+
+def create_asr_model(input_dim, vocab_size, encoder_conf=None, global_cmvn=None, ctc_weight=1.0):
+    """creadte_asr_model (asr_model.py:301-352) for the CTC-only configuration."""
+    encoder = ConformerEncoder(input_dim, global_cmvn=global_cmvn, **(encoder_conf or {}))
+    ctc = CTC(vocab_size, encoder.output_size())
+    return ASRModel(vocab_size, encoder, ctc, ctc_weight)
+
+
+class ASREvalNet(nn.Module):
+    """create_asr_eval_net (asr_model.py:355-371): all-reduce (SUM) of the loss over the data-parallel ranks, divided
+    by device_num.  One process per GPU; the collective is torch.distributed's (backend "nccl" = RCCL over xGMI on the
+    GPU box, "gloo" in the CPU tests)."""
+
+    def __init__(self, network, device_num):
+        super().__init__()
+        self.network, self.device_num = network, device_num
+
+    @torch.no_grad()
+    def forward(self, *inputs, **kwargs):
+        out = self.network(*inputs, **kwargs)
+        loss = out[0] if isinstance(out, tuple) else out
+        loss = loss.clone().reshape(1)
+        if self.device_num > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+        return loss[0] / self.device_num
+
+
+def shard_batch(columns, rank, group_size):
+    """Every rank builds the same global batch and keeps the strided slice batch[rank::group_size]
+    (examples/conformer/dataset.py:552-553)."""
+    return [c[rank::group_size] for c in columns]

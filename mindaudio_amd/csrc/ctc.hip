@@ -1,0 +1,181 @@
+// CTC branch of the ASR model, forward (loss value) — mindaudio/loss/ctc_loss.py:53-64:
+//   ys_hat = Dense(256 -> V) [ma_gemm_bf16] -> float32 log_softmax over V -> CTCLossV2(blank = 0, reduction none,
+//   zero_infinity) -> sum over the batch / B.
+// The (T, B, V) log-prob tensor is never materialised: ctc_lse_kernel reduces each logits row to its log-sum-exp,
+// ctc_alpha_kernel runs the alpha recursion of one utterance per wave (extended label states on lanes, neighbours
+// fetched with wave shuffles), reading only logit[t, blank] and logit[t, label_s].
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_add(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float log_add(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + log1pf(expf(fminf(a, b) - m));
+}
+
+// one wave per row: lse[row] = log(sum_v exp(logits[row, v]))
+__global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ logits, int64_t ld, int64_t rows, int V,
+                                                      float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = logits + row * ld;
+  float m = -INFINITY;
+  for (int v = lane; v < V; v += 64) m = fmaxf(m, p[v]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int v = lane; v < V; v += 64) s += expf(p[v] - m);
+  s = wave_add(s);
+  if (lane == 0) lse[row] = m + logf(s);
+}
+
+// one wave per utterance; extended label sequence l' (blank, y1, blank, y2, ..., blank), state s on lane s % 64,
+// up to kMaxChunks * 64 states (targets up to 127 labels).
+constexpr int kMaxChunks = 4;
+__global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__ logits, int64_t ld, int T,
+                                                       const float* __restrict__ lse, const int32_t* __restrict__ ys,
+                                                       int Lmax, const int32_t* __restrict__ hlens,
+                                                       const int32_t* __restrict__ ylens, int blank,
+                                                       float* __restrict__ loss) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int tlen = hlens[b];
+  if (tlen > T) tlen = T;
+  const int U = ylens[b];
+  const int S = 2 * U + 1;
+  const int nch = (S + 63) / 64;
+  int lab[kMaxChunks];
+  bool skip[kMaxChunks];  // transition from s-2 allowed
+  float alpha[kMaxChunks];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int s = c * 64 + lane;
+    int l = blank;
+    bool sk = false;
+    if (s < S && (s & 1)) {
+      l = ys[(int64_t)b * Lmax + (s >> 1)];
+      sk = (s >= 3) && (ys[(int64_t)b * Lmax + (s >> 1) - 1] != l);
+    }
+    lab[c] = l;
+    skip[c] = sk;
+    alpha[c] = -INFINITY;
+  }
+  if (tlen < 1 || U < 0 || nch > kMaxChunks) {
+    if (lane == 0) loss[b] = (tlen < 1 && U == 0) ? 0.0f : INFINITY;
+    return;
+  }
+  const float* row0 = logits + (int64_t)b * T * ld;
+  // t = 0: alpha(0) = logp(blank), alpha(1) = logp(y1)
+  {
+    const float z = lse[(int64_t)b * T];
+    if (lane == 0) alpha[0] = row0[blank] - z;
+    if (lane == 1 && S > 1) alpha[0] = row0[lab[0]] - z;
+  }
+  for (int t = 1; t < tlen; ++t) {
+    const float* row = row0 + (int64_t)t * ld;
+    const float z = lse[(int64_t)b * T + t];
+    float carry1 = -INFINITY, carry2 = -INFINITY;  // alpha(s-1), alpha(s-2) coming from the previous chunk
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+      if (c >= nch) break;
+      const float a0 = alpha[c];
+      float a1 = __shfl_up(a0, 1, 64);
+      float a2 = __shfl_up(a0, 2, 64);
+      const float last1 = __shfl(a0, 63, 64), last2 = __shfl(a0, 62, 64);
+      if (lane == 0) { a1 = carry1; a2 = carry2; }
+      if (lane == 1) a2 = carry1;
+      carry1 = last1;
+      carry2 = last2;
+      float v = log_add(a0, a1);
+      if (skip[c]) v = log_add(v, a2);
+      const int s = c * 64 + lane;
+      alpha[c] = (s < S) ? v + (row[lab[c]] - z) : -INFINITY;
+    }
+  }
+  // -log( alpha_T(S-1) + alpha_T(S-2) )
+  float fin = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int s = c * 64 + lane;
+    if (s == S - 1 || (s == S - 2 && S > 1)) fin = log_add(fin, alpha[c]);
+  }
+  float m = wave_max(fin);
+  float sum = wave_add(fin == -INFINITY ? 0.0f : expf(fin - m));
+  if (lane == 0) loss[b] = (m == -INFINITY) ? INFINITY : -(m + logf(sum));
+}
+
+__global__ void ctc_reduce_kernel(const float* __restrict__ loss, int B, int zero_infinity, float* __restrict__ out) {
+  // fixed-order sum over the batch (deterministic), zero_infinity as CTCLossV2, then / B (ctc_loss.py:61-62)
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float v = loss[b];
+      if (zero_infinity && isinf(v)) v = 0.0f;
+      s += v;
+    }
+    out[0] = s / (float)B;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    uint32_t lo, hi;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v.x), "v"(v.y));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v.z), "v"(v.w));
+    reinterpret_cast<uint2*>(y)[i] = make_uint2(lo, hi);
+  }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
+                    int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank, int32_t zero_infinity,
+                    float* per_utt_loss, float* lse_workspace, float* loss_out, ma_stream_t stream) {
+  if (!logits || !ys || !hlens || !ylens || !per_utt_loss || !lse_workspace || !loss_out) return MA_ERR_INVALID_ARG;
+  if (batch < 1 || T < 1 || V < 1 || ld < V || Lmax < 1 || blank < 0 || blank >= V) return MA_ERR_INVALID_ARG;
+  if (2 * Lmax + 1 > kMaxChunks * 64) return MA_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t rows = batch * T;
+  MA_LAUNCH(ctc_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, ld, rows, (int)V, lse_workspace);
+  MA_LAUNCH(ctc_alpha_kernel, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
+            hlens, ylens, (int)blank, per_utt_loss);
+  MA_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, per_utt_loss, (int)batch, (int)zero_infinity, loss_out);
+  return MA_OK;
+}
+
+int ma_cast_f32_bf16(const float* x, void* y, int64_t n, ma_stream_t stream) {
+  if (!x || !y || n < 1 || (n & 3)) return MA_ERR_INVALID_ARG;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  MA_LAUNCH(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+            reinterpret_cast<uint16_t*>(y), n / 4);
+  return MA_OK;
+}
+
+}  // extern "C"

@@ -144,3 +144,32 @@ def convmodule_mid(y, dw, bn_scale, bn_shift, batch, T, out=None):
                                     _host.ptr(bn_shift), _host.ptr(out), out.stride(0), _host.current_stream_ptr())
     _lib.check(rc, "convmodule_mid")
     return out
+
+
+def cast_bf16(x):
+    """float32 device tensor -> bf16 copy (round to nearest even)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert x.dtype == t.float32 and x.is_contiguous() and x.numel() % 4 == 0
+    y = t.empty(x.shape, dtype=t.bfloat16, device=x.device)
+    _lib.check(lib.ma_cast_f32_bf16(_host.ptr(x), _host.ptr(y), x.numel(), _host.current_stream_ptr()), "cast_bf16")
+    return y
+
+
+def ctc_loss(logits, batch, T, ys_pad, hlens, ys_lens, blank=0, zero_infinity=True):
+    """logits (B*T, V) float32; ys_pad (B, Lmax) int32; hlens, ys_lens (B,) int32.
+    Returns (loss scalar tensor = sum(per-utterance CTC) / B, per-utterance losses)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert logits.dtype == t.float32 and logits.stride(1) == 1 and logits.shape[0] == batch * T
+    ys_pad = ys_pad.to(t.int32).contiguous()
+    hlens = hlens.to(t.int32).contiguous()
+    ys_lens = ys_lens.to(t.int32).contiguous()
+    per = t.empty(batch, dtype=t.float32, device=logits.device)
+    lse = t.empty(batch * T, dtype=t.float32, device=logits.device)
+    out = t.empty(1, dtype=t.float32, device=logits.device)
+    rc = lib.ma_ctc_loss_f32(_host.ptr(logits), logits.stride(0), batch, T, logits.shape[1], _host.ptr(ys_pad),
+                             ys_pad.shape[1], _host.ptr(hlens), _host.ptr(ys_lens), blank, 1 if zero_infinity else 0,
+                             _host.ptr(per), _host.ptr(lse), _host.ptr(out), _host.current_stream_ptr())
+    _lib.check(rc, "ctc_loss")
+    return out[0], per

@@ -85,3 +85,66 @@ def test_encoder_full_config_shapes_and_determinism():
     assert float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) <= 2e-2
     with pytest.raises(NotImplementedError):
         dut.train()(xs.cuda(), sub.cuda())
+
+
+def test_ctc_loss_matches_oracle():
+    import torch
+
+    from mindaudio_amd import ops
+    from oracle import conformer_oracle as C
+
+    torch.manual_seed(11)
+    b, t, v, lmax = 5, 61, 501, 12
+    logits = torch.randn(b * t, v) * 2.0
+    ys_lens = torch.tensor([12, 7, 1, 3, 9], dtype=torch.int32)
+    hlens = torch.tensor([61, 40, 61, 5, 8], dtype=torch.int32)  # the last one is infeasible (8 frames, 9 labels)
+    ys = torch.full((b, lmax), -1, dtype=torch.int32)
+    for i, n in enumerate(ys_lens.tolist()):
+        ys[i, :n] = torch.randint(1, v, (n,), dtype=torch.int32)
+    ys[1, 2] = ys[1, 1]  # repeated label: no skip transition
+    lp = torch.log_softmax(logits.double().view(b, t, v), -1).transpose(0, 1)
+    per_ref = torch.nn.functional.ctc_loss(lp, ys.long().clamp(min=0), hlens.long(), ys_lens.long(), blank=0,
+                                           reduction="none", zero_infinity=False)
+    loss, per = ops.ctc_loss(logits.cuda(), b, t, ys.cuda(), hlens.cuda(), ys_lens.cuda())
+    per = per.cpu().double()
+    assert torch.isinf(per_ref[4]) and torch.isinf(per[4])
+    assert float((per[:4] - per_ref[:4]).abs().max()) <= 1e-4 * float(per_ref[:4].abs().max())
+    want = float(per_ref[:4].sum() / b)  # zero_infinity, sum / B (ctc_loss.py:32, 61-62)
+    assert abs(float(loss) - want) <= 1e-4 * abs(want)
+
+
+def test_asr_model_ctc_eval_loss_matches_oracle():
+    import torch
+
+    from mindaudio_amd.conformer.asr_model import ASREvalNet, create_asr_model
+    from oracle import conformer_oracle as C
+
+    torch.manual_seed(21)
+    vocab, blocks, b, tlen = 300, 2, 3, 163
+    ref_enc = C.ConformerEncoder(80, 256, 4, 2048, blocks).eval()
+    ref_ctc = C.CTC(vocab, 256).eval()
+    model = create_asr_model(80, vocab, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks)).eval()
+    model.encoder.load_state_dict(ref_enc.state_dict(), strict=False)
+    model.ctc.load_state_dict(ref_ctc.state_dict())
+    model = model.cuda()
+    model.encoder.prepare()
+    model.ctc.prepare()
+    xs = torch.randn(b, tlen, 80)
+    lens = [tlen, tlen - 30, tlen - 61]
+    mask = torch.zeros(b, 1, tlen)
+    for i, n in enumerate(lens):
+        mask[i, 0, :n] = 1
+    sub = C.subsample_mask(mask)
+    ys_lens = torch.tensor([9, 6, 4], dtype=torch.int32)
+    ys = torch.full((b, 9), -1, dtype=torch.int32)
+    for i, n in enumerate(ys_lens.tolist()):
+        ys[i, :n] = torch.randint(1, vocab, (n,), dtype=torch.int32)
+    with torch.no_grad():
+        enc, m2 = ref_enc(xs, sub)
+        hl = m2.squeeze(1).sum(1).to(torch.int32)
+        want = float(ref_ctc(enc, hl.long(), ys.long().clamp(min=0), ys_lens.long()))
+    loss, acc = model(xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), sub.cuda())
+    assert acc is None
+    assert abs(float(loss) - want) <= 2e-2 * abs(want), (float(loss), want)  # bf16 matmuls vs float32 oracle
+    assert abs(float(ASREvalNet(model, 1)(xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None,
+                                          ys_lens.cuda(), sub.cuda())) - float(loss)) == 0.0

@@ -134,15 +134,17 @@ def main():
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / reps * 1e-3  # seconds per launch
 
-    # ---- roofline of the dominant kernel: gemm_bf16_kernel (MFMA bound) on its heaviest launch shape, the FFN
-    #      w_1 matmul + Swish (M = 64*249, N = 2048, K = 256; 24 launches per forward) ------------------------
-    m, n, k = BATCH * t2, 2048, 256
-    a = torch.randn(m, k, device=dev).bfloat16()
-    w = (torch.randn(n, k, device=dev) / 16).bfloat16()
-    bias = torch.randn(n, device=dev)
-    hbuf = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
-    gemm_s = event_time(lambda: ops.gemm(a, w, bias=bias, act=_lib.ACT_SWISH, out=hbuf), max(args.steps, 50))
-    gemm_tf = 2.0 * m * n * k / gemm_s / 1e12
+    # ---- roofline of the dominant kernel: ffn_fused_kernel (MFMA bound; 24 launches per forward, ~1/3 of the
+    #      step).  Algorithmic FLOPs per launch = 2 * M * (256*2048 + 2048*256) with M = 64*249 rows. -----------
+    m, hid = BATCH * t2, 2048
+    a = torch.randn(m, 256, device=dev).bfloat16()
+    w1 = (torch.randn(hid, 256, device=dev) / 16).bfloat16()
+    w2 = (torch.randn(256, hid, device=dev) / 45).bfloat16()
+    b1, b2 = torch.randn(hid, device=dev), torch.randn(256, device=dev)
+    xres = torch.randn(m, 256, device=dev)
+    gemm_s = event_time(lambda: ops.ffn(a, w1, b1, w2, b2, xres, alpha=0.5), max(args.steps, 50))
+    ffn_flops = 2.0 * m * 256 * hid * 2
+    gemm_tf = ffn_flops / gemm_s / 1e12
 
     # ---- roofline of the fbank kernel (HBM bound): algorithmic bytes = waves in + features out ------------
     n_frames = 1 + SAMPLES // HOP
@@ -184,10 +186,10 @@ def main():
                        "global_batch": BATCH * world, "frames": FRAMES,
                        "sharding": "independent utterance shards per rank, no collective",
                        "encoder_tflops": round(world * BATCH * args.steps * flops_utt / dt / 1e12, 1)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<64,128> (FFN w_1 + Swish, M=%d N=%d K=%d)" % (m, n, k),
+            "roofline": {"bound": "mfma", "kernel": "ffn_fused_kernel (w_1 -> Swish -> w_2 + residual, M=%d d=256 hidden=%d)" % (m, hid),
                          "achieved": round(gemm_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
-                         "algorithmic_flops_per_launch": 2 * m * n * k, "kernel_ms": round(gemm_s * 1e3, 5)},
+                         "algorithmic_flops_per_launch": int(ffn_flops), "kernel_ms": round(gemm_s * 1e3, 5)},
             "roofline_fbank": {"bound": "hbm", "kernel": "feat512_kernel<mel>", "achieved": round(fb_gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fb_gbs / HBM_PEAK_GBS, 4),
                                "traffic": None, "algorithmic_bytes_per_launch": fb_bytes,

@@ -10,9 +10,9 @@
 //     O (64 x 256) += h (64 x 128) . W2[:, chunk]^T   (accumulators stay in registers across all chunks)
 // which removes the 2 x M x 2048 x 2 bytes of HBM traffic of the two-GEMM form and its two extra launches.
 //
-// 256 threads = 4 waves in 2 (rows) x 2 (cols).  LDS: a tile 32 KiB (resident) + h tile 16 KiB + a 3-slot ring of
+// 512 threads = 8 waves in 2 (rows) x 4 (cols), two per SIMD.  LDS: a tile 32 KiB (resident) + h tile 16 KiB + a 3-slot ring of
 // 32 KiB weight slabs streamed with global_load_lds_dwordx4 two slabs ahead of the MFMAs (W1: 128 hidden rows x 128 k,
-// W2: 256 output rows x 64 k; every slab feeds 32 MFMA 16x16x32 per wave).  All tiles use 128-byte rows with the
+// W2: 256 output rows x 64 k; every slab feeds 16 MFMA 16x16x32 per wave).  All tiles use 128-byte rows with the
 // 16-byte chunks XOR-swizzled by (row & 7), the swizzle applied on the source side of the LDS-DMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -63,10 +63,13 @@ __device__ __forceinline__ float ffn_swish(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 
-__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
+// 512 threads = 8 waves in 2 (rows) x 4 (cols): two waves per SIMD, so one wave's LDS/VALU phases hide under the
+// other's MFMAs.  Per wave: S sub-tile 32 x 32 (2 x 2 fragments), O sub-tile 32 x 64 (2 x 4 fragments).
+constexpr int kFfnThreads = 512, kFfnWaves = 8;
+__global__ __launch_bounds__(kFfnThreads, 2) void ffn_fused_kernel(const FfnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;
   const int m0 = blockIdx.x * kFfnBM;
   const int lr = lane >> 3;                 // row inside an 8-row LDS-DMA group
   const int kc_src = (lane & 7) ^ lr;       // logical 16-byte chunk this lane must fetch (source-side swizzle)
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
 
   // ---- a tile: 32 (K-slab, row-group) pieces of 1 KiB, 8 per wave --------------------------------------------
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    const int piece = wave * 8 + g;          // 0..31
+  for (int g = 0; g < 4; ++g) {
+    const int piece = wave * 4 + g;          // 0..31
     const int ks = piece >> 3, rg = piece & 7;
     int m = m0 + rg * 8 + lr;
     if (m >= p.M) m = p.M - 1;
@@ -94,23 +97,23 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     const int ty = s & 3;
     if (ty < 2) {
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int piece = wave * 8 + g;      // (ks2, rg): 2 x 16
+      for (int g = 0; g < 4; ++g) {
+        const int piece = wave * 4 + g;      // (ks2, rg): 2 x 16
         const int ks2 = piece >> 4, rg = piece & 15;
         const uint16_t* src = p.w1 + (int64_t)(c * kFfnHC + rg * 8 + lr) * kFfnD + ty * 128 + ks2 * 64 + kc_src * 8;
         __builtin_amdgcn_global_load_lds((gl_void_t*)src, (lds_void_t*)(slot + ks2 * 16384 + rg * 1024), 16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int rg = wave * 8 + g;         // 32 row groups of 8 output rows
+      for (int g = 0; g < 4; ++g) {
+        const int rg = wave * 4 + g;         // 32 row groups of 8 output rows
         const uint16_t* src = p.w2 + (int64_t)(rg * 8 + lr) * p.H + c * kFfnHC + (ty - 2) * 64 + kc_src * 8;
         __builtin_amdgcn_global_load_lds((gl_void_t*)src, (lds_void_t*)(slot + rg * 1024), 16, 0, 0);
       }
     }
   };
   // b1 -> LDS (lane-linear copy, 1 KiB per instruction), ahead of the slabs in the same in-order queue
-  for (int piece = wave; piece * 256 < p.H; piece += 4) {
+  for (int piece = wave; piece * 256 < p.H; piece += kFfnWaves) {
     const int idx = piece * 256 + lane * 4;
     const float* src = p.b1 + (idx < p.H ? idx : 0);
     __builtin_amdgcn_global_load_lds((gl_void_t*)src, (lds_void_t*)(smem + kOffB1 + piece * 1024), 16, 0, 0);
@@ -121,68 +124,78 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
   auto lds_off = [](int row, int kc) { return row * 128 + ((kc ^ (row & 7)) << 4); };
   const int frow = lane & 15, fk = lane >> 4;
   int off_rows[2];   // a / h fragment rows of this wave (row tiles i = 0, 1), chunk fk
-  int off_w1[4];     // W1 fragment rows (hidden units wn*64 + j*16 + frow)
-  int off_w2[8];     // W2 fragment rows (output features wn*128 + j*16 + frow)
+  int off_w1[2];     // W1 fragment rows (hidden units wn*32 + j*16 + frow)
+  int off_w2[4];     // W2 fragment rows (output features wn*64 + j*16 + frow)
 #pragma unroll
   for (int i = 0; i < 2; ++i) off_rows[i] = lds_off(wm * 32 + i * 16 + frow, fk);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) off_w1[j] = lds_off(wn * 64 + j * 16 + frow, fk);
+  for (int j = 0; j < 2; ++j) off_w1[j] = lds_off(wn * 32 + j * 16 + frow, fk);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) off_w2[j] = lds_off(wn * 128 + j * 16 + frow, fk);
+  for (int j = 0; j < 4; ++j) off_w2[j] = lds_off(wn * 64 + j * 16 + frow, fk);
 
-  f32x4 sacc[2][4], oacc[2][8];
+  f32x4 sacc[2][2], oacc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // One hidden chunk = 4 slab steps written out straight-line (W1 k-half 0, W1 k-half 1 + swish, W2 k-half 0,
   // W2 k-half 1).  A single loop over steps with `if (type)` in the body makes hipcc shuttle all 96 accumulator
   // registers through v_accvgpr moves every step (measured: 430 VALU instructions per 32 MFMAs).
   auto step_begin = [&](int s) __attribute__((always_inline)) {
-    // slab s (and, at s = 0, the a tile / b1 copy) has landed once at most the 8 loads of slab s+1 are outstanding
-    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    // slab s (and, at s = 0, the a tile / b1 copy) has landed once at most the 4 loads of slab s+1 are outstanding
+    if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (s + 2 < nsteps) issue_slab(s + 2);
   };
+  // Fragment loads of k-step kk+1 are issued before the MFMAs of k-step kk (one wave per SIMD: nobody else hides the
+  // ~130-cycle LDS latency).
   auto w1_half = [&](int s, int ty) __attribute__((always_inline)) {
     const char* slot = smem + kOffRing + (s % 3) * kSlab;
     // S += a[:, ty*128 .. +128) . W1c[:, same k]^T : 4 k-steps of 32
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 af[2][2], wf[2][2];
+    auto load = [&](int kk, int buf) __attribute__((always_inline)) {
       const char* abase = smem + kOffA + (ty * 2 + (kk >> 1)) * 8192;
       const char* wbase = slot + (kk >> 1) * 16384;
       const int kx = (kk & 1) << 6;  // chunk + 4  <=>  byte offset ^ 64
-      bf16x8 af[2], wf[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(abase + (off_rows[i] ^ kx));
+      for (int i = 0; i < 2; ++i) af[buf][i] = *reinterpret_cast<const bf16x8*>(abase + (off_rows[i] ^ kx));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wbase + (off_w1[j] ^ kx));
+      for (int j = 0; j < 2; ++j) wf[buf][j] = *reinterpret_cast<const bf16x8*>(wbase + (off_w1[j] ^ kx));
+    };
+    load(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk + 1 < 4) load(kk + 1, (kk + 1) & 1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], sacc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
+          sacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][j], af[kk & 1][i], sacc[i][j], 0, 0, 0);
     }
   };
   auto w2_half = [&](int s, int hf) __attribute__((always_inline)) {
     const char* slot = smem + kOffRing + (s % 3) * kSlab;
     // O += h[:, K-slab hf] . W2c[:, same k]^T : 2 k-steps of 32
     const char* hbase = smem + kOffH + hf * 8192;
+    bf16x8 hf2[2][2], wf[2][4];
+    auto load = [&](int kk, int buf) __attribute__((always_inline)) {
+      const int kx = kk << 6;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) hf2[buf][i] = *reinterpret_cast<const bf16x8*>(hbase + (off_rows[i] ^ kx));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[buf][j] = *reinterpret_cast<const bf16x8*>(slot + (off_w2[j] ^ kx));
+    };
+    load(0, 0);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const int kx = kk << 6;
-      bf16x8 hf2[2], wf[8];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) hf2[i] = *reinterpret_cast<const bf16x8*>(hbase + (off_rows[i] ^ kx));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(slot + (off_w2[j] ^ kx));
+      if (kk + 1 < 2) load(kk + 1, (kk + 1) & 1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], hf2[i], oacc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+          oacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][j], hf2[kk & 1][i], oacc[i][j], 0, 0, 0);
     }
   };
 
@@ -193,23 +206,23 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j) sacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     step_begin(s0);
     w1_half(s0, 0);
     step_begin(s0 + 1);
     w1_half(s0 + 1, 1);
     {
-      // h = swish(S + b1) -> bf16 -> h tile (K-slab wn: hidden units wn*64 .. +64 of the chunk)
-      // lane holds S[row = wm*32 + i*16 + (lane & 15)][hidden = wn*64 + j*16 + (lane >> 4)*4 + r]
-      char* hbase = smem + kOffH + wn * 8192;
+      // h = swish(S + b1) -> bf16 -> h tile (K-slab wn >> 1: hidden units 64*(wn >> 1) .. +64 of the chunk)
+      // lane holds S[row = wm*32 + i*16 + (lane & 15)][hidden = wn*32 + j*16 + (lane >> 4)*4 + r]
+      char* hbase = smem + kOffH + (wn >> 1) * 8192;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kq = j * 16 + (lane >> 4) * 4;  // k inside the K-slab
+      for (int j = 0; j < 2; ++j) {
+        const int kq = (wn & 1) * 32 + j * 16 + (lane >> 4) * 4;  // k inside the K-slab
         // inline asm LDS accesses: a compiler-visible LDS read/write that may alias the LDS-DMA destinations gets an
         // s_waitcnt vmcnt(0) in front of it, which drains the slab ring once per chunk
         f32x4 bv;
         {
-          const uint32_t baddr = (uint32_t)(uintptr_t)(lds_void_t*)(smem + kOffB1 + (c * kFfnHC + wn * 64 + kq) * 4);
+          const uint32_t baddr = (uint32_t)(uintptr_t)(lds_void_t*)(smem + kOffB1 + (c * kFfnHC + (wn >> 1) * 64 + kq) * 4);
           asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bv) : "v"(baddr) : "memory");
         }
 #pragma unroll
@@ -230,14 +243,14 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     w2_half(s0 + 3, 1);
   }
 
-  // ---- x += alpha * (O + b2): lane holds O[row = .. + (lane & 15)][n = wn*128 + j*16 + (lane >> 4)*4 + 0..3] ---
+  // ---- x += alpha * (O + b2): lane holds O[row = .. + (lane & 15)][n = wn*64 + j*16 + (lane >> 4)*4 + 0..3] ---
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 32 + i * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int n = wn * 128 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < 4; ++j) {
+      const int n = wn * 64 + j * 16 + (lane >> 4) * 4;
       const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
       float4* xp = reinterpret_cast<float4*>(p.x + (int64_t)m * p.ldx + n);
       float4 xv = *xp;
@@ -283,6 +296,6 @@ extern "C" int ma_ffn_bf16(const void* a, int64_t lda, const void* w1, const flo
   p.M = (int32_t)M;
   p.H = hidden;
   p.alpha = alpha;
-  MA_LAUNCH(ffn_fused_kernel, dim3((unsigned)((M + kFfnBM - 1) / kFfnBM)), dim3(256), kFfnLds, (hipStream_t)stream, p);
+  MA_LAUNCH(ffn_fused_kernel, dim3((unsigned)((M + kFfnBM - 1) / kFfnBM)), dim3(kFfnThreads), kFfnLds, (hipStream_t)stream, p);
   return MA_OK;
 }

@@ -219,8 +219,9 @@ class ConformerEncoder(nn.Module):
         x = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(self.d), out_dtype=f32)
         pos_all = self._pos_projection(t2)
         n_layers = len(self.encoders)
-        # the fused FFN kernel works on 64-row blocks, one workgroup per CU: it wins once those fill the chip
-        fused_ffn = m >= 64 * 200
+        # the fused FFN kernel works on 64-row blocks, one workgroup per CU: it wins (measured at M = 7968 and
+        # 15936) once there are enough blocks to cover a good part of the chip
+        fused_ffn = m >= 64 * 64
         a = ops.layernorm(x, self.encoders[0].norm_ff_macaron.gamma, self.encoders[0].norm_ff_macaron.beta)
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
             # x = x + 0.5 * FFN_macaron(LN(x))   (a = LN(x) comes from the previous block's fused LN pair)

@@ -32,7 +32,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int BK = 64;
 constexpr int kGemmThreads = 256;
-constexpr int kStages = 3;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gl_void_t;
@@ -71,8 +70,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // whose 16-byte chunks are XOR-swizzled by (row & 7).  Tiles are filled by global_load_lds_dwordx4 (one
 // instruction = 8 rows = 1 KiB, no VGPR staging; the swizzle is applied to the per-lane SOURCE address), two
 // tiles ahead of the MFMAs: per K-step one counted s_waitcnt vmcnt + one raw s_barrier.
-template <int BM, int BN, bool IM2COL>
-__global__ __launch_bounds__(kGemmThreads, (BM + BN) > 192 ? 1 : 2) void gemm_bf16_kernel(const GemmParams p) {
+template <int BM, int BN, int NST, bool IM2COL>
+__global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024) ? 1 : ((NST * (BM + BN) * BK * 2 > 53 * 1024) ? 2 : 3)) void gemm_bf16_kernel(
+    const GemmParams p) {
+  constexpr int kStages = NST;
   constexpr int FM = BM / 32, FN = BN / 32;          // fragments per wave
   constexpr int GA = BM / 32, GW = BN / 32;          // global_load_lds instructions per wave per tile
   constexpr int kStageBytes = (BM + BN) * BK * 2;
@@ -160,13 +161,13 @@ __global__ __launch_bounds__(kGemmThreads, (BM + BN) > 192 ? 1 : 2) void gemm_bf
 
   const int nk = p.K / BK;
   issue_tile(0, 0);
-  if (nk > 1) issue_tile(1, 1);
+  if (kStages > 2 && nk > 1) issue_tile(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most one younger tile of this wave is still in flight
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GW) : "memory");
+    // tile kt has landed once at most (kStages - 2) younger tiles of this wave are still in flight
+    if (kStages > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's part of tile kt is in LDS; everyone is done reading tile kt-1
-    if (kt + 2 < nk) issue_tile(kt + 2, (kt + 2) % kStages);
+    if (kt + kStages - 1 < nk) issue_tile(kt + kStages - 1, (kt + kStages - 1) % kStages);
     const char* st = smem + (kt % kStages) * kStageBytes;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -281,18 +282,18 @@ static int gemm_num_cus() {
   return g_gemm_cus;
 }
 
-template <int BM, int BN, bool IM2COL>
+template <int BM, int BN, int NST, bool IM2COL>
 static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
-  constexpr int lds = kStages * (BM + BN) * BK * 2;
+  constexpr int lds = NST * (BM + BN) * BK * 2;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, IM2COL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, NST, IM2COL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MA_ERR_LAUNCH;
     attr = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  MA_LAUNCH((gemm_bf16_kernel<BM, BN, IM2COL>), dim3(tiles), dim3(kGemmThreads), lds, stream, p);
+  MA_LAUNCH((gemm_bf16_kernel<BM, BN, NST, IM2COL>), dim3(tiles), dim3(kGemmThreads), lds, stream, p);
   return MA_OK;
 }
 
@@ -300,11 +301,17 @@ template <bool IM2COL>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   // 128 x 128 tiles unless they would leave most CUs without a workgroup (N = 256 .. 768 at M ~ 8k)
   const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  static const char* force = getenv("MA_GEMM_TILE");  // developer override: "128" / "64"
-  if (force && force[0] == '1') return launch_gemm_tile<128, 128, IM2COL>(p, stream);
-  if (force && force[0] == '6') return launch_gemm_tile<64, 128, IM2COL>(p, stream);
-  if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, IM2COL>(p, stream);
-  return launch_gemm_tile<64, 128, IM2COL>(p, stream);
+  static const char* force = getenv("MA_GEMM_TILE");  // developer override: "1" 128x128x3, "2" 128x128x2, "6" 64x128x3
+  if (force && force[0] == '1') return launch_gemm_tile<128, 128, 3, IM2COL>(p, stream);
+  if (force && force[0] == '2') return launch_gemm_tile<128, 128, 2, IM2COL>(p, stream);
+  if (force && force[0] == '6') return launch_gemm_tile<64, 128, 3, IM2COL>(p, stream);
+  if (force && force[0] == '7') return launch_gemm_tile<64, 128, 2, IM2COL>(p, stream);
+  // measured on MI355X (tools/gemm_bench.py): 2 workgroups/CU beat a deeper ring for the 128x128 tile; the
+  // 64x128 tile prefers 3 workgroups/CU (2 stages) when there are enough tiles to fill them, else the 3-stage ring
+  if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, 2, IM2COL>(p, stream);
+  const int64_t small = (int64_t)((p.M + 63) / 64) * ((p.N + 127) / 128);
+  if (small >= (int64_t)(2.4 * gemm_num_cus())) return launch_gemm_tile<64, 128, 2, IM2COL>(p, stream);
+  return launch_gemm_tile<64, 128, 3, IM2COL>(p, stream);
 }
 
 static int fill_epilogue(GemmParams& p, const ma_gemm_epilogue_t* e) {

@@ -86,9 +86,10 @@ PROTOTYPES = {
     "ma_subsample_conv1_nhwc": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p, i32, ctypes.c_void_p,
                                                ctypes.c_void_p]),
+    "ma_relpos_attention_workspace_bytes": (i64, [i64, i64, i32, i32]),
     "ma_relpos_attention_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p,
                                                 ctypes.c_void_p, ctypes.c_void_p, i64, i64, i32, i32,
-                                                ctypes.c_void_p, i64, ctypes.c_void_p]),
+                                                ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p]),
     "ma_convmodule_mid_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i32, ctypes.c_void_p, i32,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),

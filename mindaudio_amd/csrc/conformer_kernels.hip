@@ -165,16 +165,25 @@ __global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __res
 //   score[i, j] = ((q_i + u) . k_j + (q_i + v) . p_j) / sqrt(dk) + (mask[b, j] == 0 ? -10000 : 0)
 //   ctx_i = softmax_j(score[i, :]) . V            (dk == 64; the two dot products run as ONE K = 128 contraction
 //   of [q+u | q+v] with [k_j | p_j])
-// Workgroup = (batch b, head h, 64 query rows): 4 waves x 16 rows.  Keys are visited in tiles of 64 with an
-// online softmax; K' = [k | p] tile and V^T tile live in LDS, probabilities go C-layout -> A-layout through a
-// per-wave 2 KiB LDS patch.
+// Workgroup = (batch b, head h, 64 query rows): 4 waves x 16 rows; keys in tiles of 64 with an online softmax.
+// Everything is computed TRANSPOSED so that no probability ever goes through LDS:
+//   S^T = K' . Q'^T  : mfma(A = K' rows (keys), B = Q' rows)      -> lane holds query q = lane & 15 and, per 16-key
+//                                                                    tile, the 4 keys (lane >> 4) * 4 + r
+//   O^T += V^T . P^T : mfma(A = V^T rows (d), B = P^T)            -> the lane's own 8 probabilities of two adjacent
+//                                                                    key tiles ARE its B fragment if the k-slot
+//                                                                    (lane >> 4) * 8 + j of the MFMA is mapped to
+//                                                                    key (j >> 2) * 16 + (lane >> 4) * 4 + (j & 3);
+//                                                                    V^T is read with the same mapping (two 8-byte
+//                                                                    LDS reads per fragment).
+// Row max / sum: 16 values in the lane + two shuffles (xor 16, 32).  Output row q = lane & 15 again, 4 consecutive d
+// per accumulator -> 8-byte bf16 stores.  V^T comes from ma_transpose_v (vt: (B, H, 64, Tp), Tp % 64 == 0, zero padded).
 constexpr int kAttQ = 64, kAttK = 64, kDk = 64;
-constexpr int kKpStride = 128 + 8;   // bf16 elements per K' row (padded: 272 B -> conflict-free b128 reads)
-constexpr int kVtStride = 64 + 8;    // bf16 elements per V^T row
-constexpr int kPStride2 = 64 + 8;    // bf16 elements per probability row
+constexpr int kKpStride = 128 + 8;   // bf16 elements per K' row (272 B: conflict-free 16-byte fragment reads)
+constexpr int kVtStride = 64 + 4;    // bf16 elements per V^T row (136 B: 8-byte aligned rows)
 
 __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                                const uint16_t* __restrict__ pos, int64_t ld_pos,
+                                                               const uint16_t* __restrict__ vt, int Tp,
                                                                const float* __restrict__ bias_u,
                                                                const float* __restrict__ bias_v,
                                                                const float* __restrict__ mask, int T, int H,
@@ -182,23 +191,24 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
                                                                int64_t ld_ctx) {
   __shared__ __attribute__((aligned(16))) uint16_t Kp[kAttK * kKpStride];
   __shared__ __attribute__((aligned(16))) uint16_t Vt[kDk * kVtStride];
-  __shared__ __attribute__((aligned(16))) uint16_t Pw[4][16 * kPStride2];
   __shared__ float maskadd[kAttK];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int64_t row0 = (int64_t)b * T;
   const int q_base = qt * kAttQ + wave * 16;
+  const int lq = lane & 15, lg = lane >> 4;
+  const uint16_t* vt_bh = vt + ((int64_t)b * H + h) * kDk * Tp;
 
-  // ---- Q' fragments: A operand, lane holds row (lane & 15), k = kstep*32 + (lane >> 4)*8 .. +7 ----------------
+  // ---- Q' fragments (B operand): lane holds query row lq, k = kstep*32 + lg*8 .. +7 of [q+u | q+v] -------------
   bf16x8 qf[4];
   {
-    int qi = q_base + (lane & 15);
+    int qi = q_base + lq;
     if (qi >= T) qi = T - 1;
     const uint16_t* qrow = qkv + (row0 + qi) * ld_qkv + h * kDk;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int d0 = (ks & 1) * 32 + (lane >> 4) * 8;  // ks 0,1 -> q + u ; ks 2,3 -> q + v
+      const int d0 = (ks & 1) * 32 + lg * 8;  // ks 0,1 -> q + u ; ks 2,3 -> q + v
       const float* bias = (ks < 2 ? bias_u : bias_v) + h * kDk + d0;
       const uint4 raw = *reinterpret_cast<const uint4*>(qrow + d0);
       const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -209,45 +219,54 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
         const float hi = from_bf16((uint16_t)(wds[e] >> 16)) + bias[2 * e + 1];
         o[e] = (uint32_t)to_bf16(lo) | ((uint32_t)to_bf16(hi) << 16);
       }
-      uint4 pk = make_uint4(o[0], o[1], o[2], o[3]);
+      const uint4 pk = make_uint4(o[0], o[1], o[2], o[3]);
       qf[ks] = __builtin_bit_cast(bf16x8, pk);
     }
   }
 
-  f32x4 oacc[4];
+  f32x4 oacc[4];  // O^T: rows d = dt*16 + lg*4 + r, column q = lq
 #pragma unroll
   for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrow[4], lrow[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { mrow[r] = -INFINITY; lrow[r] = 0.f; }
+  float mrow = -INFINITY, lrow = 0.f;  // running max / sum of query row lq (replicated over the 4 lane groups)
 
+  // Staging assignment (fixed per thread): 4 x 16-byte pieces of K' = [k | p] and 2 of V^T per 64-key tile.  The
+  // global loads of tile kt+1 are issued right after tile kt is published and stay in flight during its MFMAs.
   const int n_kt = (T + kAttK - 1) / kAttK;
+  // (named registers + a macro: arrays captured by a lambda end up in scratch memory)
+  uint4 rk0, rk1, rk2, rk3, rv0, rv1;
+  const int sk_key = tid >> 4, sk_ch = tid & 15;   // K' piece i: key sk_key + 16 i, 16-byte chunk sk_ch
+  const int sv_d = tid >> 3, sv_ch = tid & 7;      // V^T piece i: d sv_d + 32 i, chunk sv_ch
+  const uint16_t* ksrc_base = (sk_ch < 8) ? qkv + row0 * ld_qkv + 256 + h * kDk + sk_ch * 8
+                                          : pos + h * kDk + (sk_ch - 8) * 8;
+  const int64_t ksrc_ld = (sk_ch < 8) ? ld_qkv : ld_pos;
+#define MA_ATT_KLOAD(dst, i, k0_)                                                     \
+  {                                                                                   \
+    int kj_ = (k0_) + sk_key + 16 * (i);                                              \
+    if (kj_ >= T) kj_ = T - 1;                                                        \
+    dst = *reinterpret_cast<const uint4*>(ksrc_base + (int64_t)kj_ * ksrc_ld);        \
+  }
+#define MA_ATT_FETCH(kt_)                                                             \
+  {                                                                                   \
+    const int k0f_ = (kt_)*kAttK;                                                     \
+    MA_ATT_KLOAD(rk0, 0, k0f_) MA_ATT_KLOAD(rk1, 1, k0f_) MA_ATT_KLOAD(rk2, 2, k0f_) MA_ATT_KLOAD(rk3, 3, k0f_) \
+    rv0 = *reinterpret_cast<const uint4*>(vt_bh + (int64_t)sv_d * Tp + k0f_ + sv_ch * 8);         \
+    rv1 = *reinterpret_cast<const uint4*>(vt_bh + (int64_t)(sv_d + 32) * Tp + k0f_ + sv_ch * 8);  \
+  }
+  MA_ATT_FETCH(0)
   for (int kt = 0; kt < n_kt; ++kt) {
     const int k0 = kt * kAttK;
     __syncthreads();  // previous tile fully consumed
-    // ---- stage K' = [k | p] (64 x 128) and V^T (64 d x 64 keys) ------------------------------------------------
-    for (int c = tid; c < kAttK * 16; c += 256) {  // 16 chunks of 8 bf16 per key row
-      const int key = c >> 4, ch = c & 15;
-      int kj = k0 + key;
-      const bool ok = kj < T;
-      if (!ok) kj = T - 1;
-      uint4 val;
-      if (ch < 8) val = *reinterpret_cast<const uint4*>(qkv + (row0 + kj) * ld_qkv + 256 + h * kDk + ch * 8);
-      else val = *reinterpret_cast<const uint4*>(pos + (int64_t)kj * ld_pos + h * kDk + (ch - 8) * 8);
-      *reinterpret_cast<uint4*>(&Kp[key * kKpStride + ch * 8]) = val;
-    }
-    for (int c = tid; c < kAttK * 8; c += 256) {  // V: 8 chunks per key row, transposed into Vt[d][key]
-      const int key = c >> 3, ch = c & 7;
-      int kj = k0 + key;
-      const bool ok = kj < T;
-      if (!ok) kj = T - 1;
-      const uint4 val = *reinterpret_cast<const uint4*>(qkv + (row0 + kj) * ld_qkv + 512 + h * kDk + ch * 8);
-      const uint32_t wds[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Vt[(ch * 8 + 2 * e) * kVtStride + key] = ok ? (uint16_t)(wds[e] & 0xffff) : (uint16_t)0;
-        Vt[(ch * 8 + 2 * e + 1) * kVtStride + key] = ok ? (uint16_t)(wds[e] >> 16) : (uint16_t)0;
-      }
+    *reinterpret_cast<uint4*>(&Kp[(sk_key)*kKpStride + sk_ch * 8]) = rk0;
+    *reinterpret_cast<uint4*>(&Kp[(sk_key + 16) * kKpStride + sk_ch * 8]) = rk1;
+    *reinterpret_cast<uint4*>(&Kp[(sk_key + 32) * kKpStride + sk_ch * 8]) = rk2;
+    *reinterpret_cast<uint4*>(&Kp[(sk_key + 48) * kKpStride + sk_ch * 8]) = rk3;
+    {
+      uint2* d0 = reinterpret_cast<uint2*>(&Vt[sv_d * kVtStride + sv_ch * 8]);
+      d0[0] = make_uint2(rv0.x, rv0.y);
+      d0[1] = make_uint2(rv0.z, rv0.w);
+      uint2* d1 = reinterpret_cast<uint2*>(&Vt[(sv_d + 32) * kVtStride + sv_ch * 8]);
+      d1[0] = make_uint2(rv1.x, rv1.y);
+      d1[1] = make_uint2(rv1.z, rv1.w);
     }
     if (tid < kAttK) {
       const int kj = k0 + tid;
@@ -255,87 +274,103 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
       maskadd[tid] = kj >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + kj] == 0.0f) ? -10000.0f : 0.0f);
     }
     __syncthreads();
+    if (kt + 1 < n_kt) MA_ATT_FETCH(kt + 1)
 
-    // ---- S = Q' . K'^T : 4 key tiles x 4 k-steps -----------------------------------------------------------------
+    // ---- S^T = K' . Q'^T : 4 key tiles x 4 k-steps; lane: query lq, keys c*16 + lg*4 + r ------------------------
     f32x4 s[4];
+    float tmax = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kp[(c * 16 + (lane & 15)) * kKpStride + ks * 32 + (lane >> 4) * 8]);
-        s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[c], 0, 0, 0);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kp[(c * 16 + lq) * kKpStride + ks * 32 + lg * 8]);
+        s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[c], 0, 0, 0);
       }
+      const float4 ma_ = *reinterpret_cast<const float4*>(&maskadd[c * 16 + lg * 4]);
+      s[c][0] = s[c][0] * scale + ma_.x;
+      s[c][1] = s[c][1] * scale + ma_.y;
+      s[c][2] = s[c][2] * scale + ma_.z;
+      s[c][3] = s[c][3] * scale + ma_.w;
+      tmax = fmaxf(fmaxf(tmax, fmaxf(s[c][0], s[c][1])), fmaxf(s[c][2], s[c][3]));
     }
-    // lane holds rows (lane >> 4) * 4 + r, keys c * 16 + (lane & 15)
-    float tmax[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tmax[r] = -INFINITY;
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(mrow, tmax);  // finite: key 0 of the first tile always exists
+    const float alpha = (mrow == -INFINITY) ? 0.0f : __expf(mrow - mnew);
+    mrow = mnew;
+    float psum = 0.f;
+    uint32_t pb[4][2];  // bf16 pairs: tile c, keys lg*4 + {0,1}, {2,3}
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float ma_ = maskadd[c * 16 + (lane & 15)];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[c][r] = s[c][r] * scale + ma_;
-        tmax[r] = fmaxf(tmax[r], s[c][r]);
-      }
+      const float e0 = __expf(s[c][0] - mnew), e1 = __expf(s[c][1] - mnew);
+      const float e2 = __expf(s[c][2] - mnew), e3 = __expf(s[c][3] - mnew);
+      psum += (e0 + e1) + (e2 + e3);
+      pb[c][0] = (uint32_t)to_bf16(e0) | ((uint32_t)to_bf16(e1) << 16);
+      pb[c][1] = (uint32_t)to_bf16(e2) | ((uint32_t)to_bf16(e3) << 16);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) tmax[r] = fmaxf(tmax[r], __shfl_xor(tmax[r], off, 64));
-    }
-    float alpha[4], psum[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float mnew = fmaxf(mrow[r], tmax[r]);
-      alpha[r] = (mrow[r] == -INFINITY) ? 0.0f : __expf(mrow[r] - mnew);
-      mrow[r] = mnew;
-      psum[r] = 0.f;
-    }
-    uint16_t* pw = Pw[wave];
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    lrow = lrow * alpha + psum;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = (mrow[r] == -INFINITY) ? 0.0f : __expf(s[c][r] - mrow[r]);
-        psum[r] += e;
-        pw[((lane >> 4) * 4 + r) * kPStride2 + c * 16 + (lane & 15)] = to_bf16(e);
-      }
+      oacc[c][0] *= alpha; oacc[c][1] *= alpha; oacc[c][2] *= alpha; oacc[c][3] *= alpha;
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) psum[r] += __shfl_xor(psum[r], off, 64);
-      lrow[r] = lrow[r] * alpha[r] + psum[r];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[c][r] *= alpha[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- O += P . V : A = P (row = lane & 15, keys), B = V^T rows (d = lane & 15, keys) -----------------------
+    // ---- O^T += V^T . P^T : k-step ks covers key tiles 2ks, 2ks+1 with slot (lg*8 + j) <-> key (j>>2)*16 + lg*4 + (j&3)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&pw[(lane & 15) * kPStride2 + ks * 32 + (lane >> 4) * 8]);
+      const uint4 ppk = make_uint4(pb[2 * ks][0], pb[2 * ks][1], pb[2 * ks + 1][0], pb[2 * ks + 1][1]);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, ppk);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(c * 16 + (lane & 15)) * kVtStride + ks * 32 + (lane >> 4) * 8]);
-        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, oacc[c], 0, 0, 0);
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint16_t* vrow = &Vt[(dt * 16 + lq) * kVtStride + ks * 32 + lg * 4];
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);        // keys (2ks)*16 + lg*4 .. +3
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 16);   // keys (2ks+1)*16 + lg*4 .. +3
+        const uint4 vpk = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vpk), pf, oacc[dt], 0, 0, 0);
       }
     }
   }
-  // ---- ctx = O / l ------------------------------------------------------------------------------------------------
+  // ---- ctx[q, h*64 + d] = O^T[d, q] / l ---------------------------------------------------------------------------
+  const int qi = q_base + lq;
+  if (qi < T) {
+    const float inv = 1.0f / lrow;
+    uint16_t* o = ctx + (row0 + qi) * ld_ctx + h * kDk + lg * 4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qi = q_base + (lane >> 4) * 4 + r;
-    if (qi >= T) continue;
-    const float inv = 1.0f / lrow[r];
-    uint16_t* o = ctx + (row0 + qi) * ld_ctx + h * kDk + (lane & 15);
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 pk;
+      pk.x = (uint32_t)to_bf16(oacc[dt][0] * inv) | ((uint32_t)to_bf16(oacc[dt][1] * inv) << 16);
+      pk.y = (uint32_t)to_bf16(oacc[dt][2] * inv) | ((uint32_t)to_bf16(oacc[dt][3] * inv) << 16);
+      *reinterpret_cast<uint2*>(o + dt * 16) = pk;
+    }
+  }
+}
+
+#undef MA_ATT_FETCH
+#undef MA_ATT_KLOAD
+
+// V (B*T, H*64) slice of the qkv buffer -> V^T (B, H, 64, Tp) bf16, zero padded to Tp (multiple of 64) keys.
+__global__ __launch_bounds__(256) void transpose_v_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv, int T, int H,
+                                                          int Tp, uint16_t* __restrict__ vt) {
+  __shared__ uint16_t tile[64][64 + 2];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  for (int c = threadIdx.x; c < 64 * 8; c += 256) {  // 64 keys x 8 chunks of 8 d
+    const int key = c >> 3, ch = c & 7;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (t0 + key < T) val = *reinterpret_cast<const uint4*>(qkv + ((int64_t)b * T + t0 + key) * ld_qkv + 512 + h * 64 + ch * 8);
+    const uint32_t w[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c * 16] = to_bf16(oacc[c][r] * inv);
+    for (int e = 0; e < 4; ++e) {
+      tile[key][ch * 8 + 2 * e] = (uint16_t)(w[e] & 0xffff);
+      tile[key][ch * 8 + 2 * e + 1] = (uint16_t)(w[e] >> 16);
+    }
+  }
+  __syncthreads();
+  uint16_t* o = vt + ((int64_t)b * H + h) * 64 * Tp + t0;
+  for (int c = threadIdx.x; c < 64 * 32; c += 256) {  // 64 d x 32 key pairs
+    const int d = c >> 5, kp = c & 31;
+    const uint32_t v = (uint32_t)tile[2 * kp][d] | ((uint32_t)tile[2 * kp + 1][d] << 16);
+    *reinterpret_cast<uint32_t*>(o + (int64_t)d * Tp + 2 * kp) = v;
   }
 }
 
@@ -464,15 +499,28 @@ int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t id
 
 int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
                              const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads,
-                             int32_t d_k, void* ctx, int64_t ld_ctx, ma_stream_t stream) {
-  if (!qkv || !pos || !bias_u || !bias_v || !ctx || batch < 1 || T < 1 || heads < 1) return MA_ERR_INVALID_ARG;
+                             int32_t d_k, void* ctx, int64_t ld_ctx, void* vt_workspace, int64_t vt_bytes,
+                             ma_stream_t stream) {
+  if (!qkv || !pos || !bias_u || !bias_v || !ctx || !vt_workspace || batch < 1 || T < 1 || heads < 1)
+    return MA_ERR_INVALID_ARG;
   if (d_k != kDk || heads * d_k != 256) return MA_ERR_UNSUPPORTED;  // q | k | v blocks are 256 wide
-  if ((ld_qkv & 7) || (ld_pos & 7) || batch > 65535) return MA_ERR_UNSUPPORTED;
+  if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 3) || batch > 65535) return MA_ERR_UNSUPPORTED;
+  const int Tp = (int)((T + 63) / 64 * 64);
+  if (vt_bytes < ma_relpos_attention_workspace_bytes(batch, T, heads, d_k)) return MA_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  MA_LAUNCH(transpose_v_kernel, dim3((unsigned)(Tp / 64), (unsigned)heads, (unsigned)batch), dim3(256), 0, s,
+            reinterpret_cast<const uint16_t*>(qkv), ld_qkv, (int)T, (int)heads, Tp,
+            reinterpret_cast<uint16_t*>(vt_workspace));
   const dim3 grid((unsigned)((T + kAttQ - 1) / kAttQ), (unsigned)heads, (unsigned)batch);
-  MA_LAUNCH(relpos_attention_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-            reinterpret_cast<const uint16_t*>(qkv), ld_qkv, reinterpret_cast<const uint16_t*>(pos), ld_pos, bias_u,
+  MA_LAUNCH(relpos_attention_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
+            reinterpret_cast<const uint16_t*>(pos), ld_pos, reinterpret_cast<const uint16_t*>(vt_workspace), Tp, bias_u,
             bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx);
   return MA_OK;
+}
+
+int64_t ma_relpos_attention_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k) {
+  if (batch < 1 || T < 1 || heads < 1 || d_k < 1) return MA_ERR_INVALID_ARG;
+  return batch * heads * d_k * ((T + 63) / 64 * 64) * 2;
 }
 
 int ma_convmodule_mid_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw,

@@ -125,9 +125,11 @@ def relpos_attention(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64, 
     assert qkv.dtype == t.bfloat16 and pos.dtype == t.bfloat16 and qkv.stride(1) == 1 and pos.stride(1) == 1
     if out is None:
         out = t.empty((batch * T, heads * d_k), dtype=t.bfloat16, device=qkv.device)
+    ws_bytes = lib.ma_relpos_attention_workspace_bytes(batch, T, heads, d_k)
+    ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
     rc = lib.ma_relpos_attention_bf16(_host.ptr(qkv), qkv.stride(0), _host.ptr(pos), pos.stride(0), _host.ptr(bias_u),
                                       _host.ptr(bias_v), _opt(mask), batch, T, heads, d_k, _host.ptr(out),
-                                      out.stride(0), _host.current_stream_ptr())
+                                      out.stride(0), _host.ptr(ws), ws_bytes, _host.current_stream_ptr())
     _lib.check(rc, "relpos_attention")
     return out
 

@@ -68,8 +68,9 @@ int64_t ma_num_frames(int64_t n, int32_t n_fft, int32_t hop, int32_t center);
  *   mel[m = 8i+g] = sum_{s < steps[i]} sum_{c < 4} weights[((row_off[i] + s) * 8 + g) * 4 + c]
  *                                                 * spectrum[start[8i+g] + 4s + c]
  *
- * Contract: start[] % 4 == 0 and start[8i+g] + 4*steps[i] <= 260 (the kernels keep bins 257..259 at
- * zero); row_off is the exclusive prefix sum of steps; filters >= n_mels in the last row have zero weights.
+ * Contract: start[] % 4 == 0 and start[8i+g] + 4*steps[i] <= ma_mel_row_stride(n_fft) (260 for n_fft = 512; the
+ * kernels keep the bins from n_freqs up to that stride at zero); row_off is the exclusive prefix sum of steps;
+ * filters >= n_mels in the last row have zero weights.
  */
 typedef struct ma_melbank {
   int32_t n_mels;
@@ -81,6 +82,11 @@ typedef struct ma_melbank {
   const int32_t* start;     /* device, [n_rows * 8] */
   const float* weights;     /* device, [total_steps * 8 * 4] */
 } ma_melbank_t;
+
+/* Row length (floats) of the kernels' spectrum tile for this n_fft: the `row_limit` of the grouped bank above.
+ * n_fft = 512 is the FFT fast path; any other even n_fft in [4, 1024] (the reference's default n_fft = 400,
+ * features.py:201, spectrum.py:611) runs the exact-f32 MFMA DFT path.  <0 when unsupported. */
+int32_t ma_mel_row_stride(int32_t n_fft);
 
 /*
  * spectrum.stft (mindaudio/data/spectrum.py:125-278), batched.

@@ -157,7 +157,11 @@ class DeviceMelBank:
         t = torch()
         dense = np.asarray(dense_mels_by_freqs, dtype=np.float64)
         self.n_mels, self.n_freqs = dense.shape
-        steps, row_off, start, weights = group_melbank(dense)
+        n_fft = 2 * (self.n_freqs - 1)
+        row_limit = int(_lib.load().ma_mel_row_stride(n_fft))
+        if row_limit < 0:
+            _lib.check(row_limit, "mel bank for n_fft=%d" % n_fft)
+        steps, row_off, start, weights = group_melbank(dense, row_limit)
         self.steps = t.from_numpy(steps).to(device)
         self.row_off = t.from_numpy(row_off).to(device)
         self.start = t.from_numpy(start).to(device)

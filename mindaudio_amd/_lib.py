@@ -63,6 +63,7 @@ PROTOTYPES = {
     "ma_abi_version": (ctypes.c_int, []),
     "ma_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "ma_num_frames": (i64, [i64, i32, i32, i32]),
+    "ma_mel_row_stride": (i32, [i32]),
     "ma_stft_f32": (ctypes.c_int, [c_f32p, i64, i64, i64, i32, i32, c_f32p, i32, i32, i32, c_f32p, ctypes.c_void_p]),
     "ma_fbank_workspace_bytes": (i64, [i64, i64]),
     "ma_fbank_db_f32": (ctypes.c_int, [c_f32p, i64, i64, i64, i32, i32, c_f32p, i32, i32, ctypes.POINTER(MelBank),

@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "../../include/mindaudio_amd.h"
+#include "features_common.h"
 #include "fft512.h"
 
 // Launch + error check.  hipGetLastError() is sticky across unrelated runtime calls of the host process
@@ -91,64 +92,6 @@ extern "C" void ma_debug_set_flags(int f) { g_debug = f; }
 #endif
 
 namespace ma {
-
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
-constexpr int kUnitFrames = 8;    // frames one wave transforms at once (fft512.h)
-constexpr int kSumTileFrames = 32;  // frames per partial sum of the Kaldi mean pre-pass
-constexpr int kBins = 257;
-constexpr int kMaxGrid = 1024;
-
-enum Mode { kModeStft = 0, kModeMel = 1, kModeKaldi = 2 };
-
-struct FeatParams {
-  const float* wav;
-  const int64_t* lengths;  // kaldi: valid samples per utterance (device)
-  const float* window;     // n_fft (stft/mel) or frame_len (kaldi) floats
-  float* out;
-  float* unit_min;  // [num_units] minimum dB of each 8-frame unit (mel with dB)
-  float* wg_max;    // [gridDim.x] maximum dB seen by each workgroup
-  double* partial;  // kaldi: [batch * sum_tiles_per_utt] windowed sums
-  unsigned long long* prof;  // MA_PROFILE builds only: per-phase cycle totals
-  const int* mel_steps;    // [n_rows]
-  const int* mel_row_off;  // [n_rows]
-  const int* mel_start;    // [n_rows * 8]
-  const float* mel_w;      // [total_steps * 8 * 4]
-  int64_t n;           // samples per utterance (kaldi: max_n)
-  int64_t wav_stride;
-  int64_t n_frames;    // frames per utterance (kaldi: max frames)
-  int32_t num_units;
-  int32_t units_per_utt;
-  int32_t sum_tiles_per_utt;
-  int32_t hop;
-  int32_t pad_left;    // n_fft/2 when centred, else 0
-  int32_t pad_mode;
-  int32_t frame_len;   // kaldi: 400; else 512
-  int32_t n_mels;
-  int32_t n_rows;
-  int32_t total_steps;
-  int32_t apply_db;    // mel: 1 -> dB, 0 -> raw mel energies
-  int32_t power_is_1;  // |X| instead of |X|^2
-  int32_t layout;      // stft layout
-  int32_t debug;       // MA_PROFILE builds only: ablation bits
-  float mult, amin, db_offset;
-  float preemph;
-};
-
-// ---- sample fetch with np.pad semantics, branch-free (every load is issued, none waits on a branch) ----
-// 32-bit indices: signals are < 2^30 samples (checked on the host side of the C-ABI).
-__device__ __forceinline__ float fetch_padded(const float* __restrict__ x, int i, int n, int mode, bool valid) {
-  const bool inside = i >= 0 && i < n;
-  int r;
-  if (mode == MA_PAD_REFLECT) r = (i < 0) ? -i : 2 * (n - 1) - i;
-  else if (mode == MA_PAD_SYMMETRIC) r = (i < 0) ? -i - 1 : 2 * n - 1 - i;
-  else r = i;  // edge: clamped below; constant: value masked below
-  r = inside ? i : r;
-  r = r < 0 ? 0 : (r >= n ? n - 1 : r);
-  const float v = x[r];
-  const bool keep = valid && (inside || mode != MA_PAD_CONSTANT);
-  return keep ? v : 0.0f;
-}
 
 __device__ __forceinline__ float wave_reduce(float v, bool is_max) {
 #pragma unroll
@@ -726,7 +669,7 @@ static int fill_common(FeatParams& p, const float* wav, int64_t batch, int64_t n
   if (hop < 1) return MA_ERR_HOP;
   if (n_fft > n) return MA_ERR_NFFT_TOO_LARGE;
   if (pad_mode < MA_PAD_CONSTANT || pad_mode > MA_PAD_SYMMETRIC) return MA_ERR_INVALID_ARG;
-  if (n_fft != 512) return MA_ERR_UNSUPPORTED;
+  if (n_fft != 512 && (n_fft < 4 || (n_fft & 1) || n_fft > 1024)) return MA_ERR_UNSUPPORTED;
   p = FeatParams{};
   p.wav = wav;
   p.window = window;
@@ -752,11 +695,12 @@ int ma_stft_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stride, 
   if (!out || (layout != MA_STFT_FRAME_MAJOR && layout != MA_STFT_FREQ_MAJOR)) return MA_ERR_INVALID_ARG;
   p.out = out;
   p.layout = layout;
+  if (n_fft != 512) return launch_feat_generic(p, kModeStft, n_fft, (hipStream_t)stream, nullptr);
   return launch_feat<kModeStft>(p, (hipStream_t)stream);
 }
 
-static int mel_front(FeatParams& p, const ma_melbank_t* mel, float power) {
-  int rc = check_mel(mel, 512);
+static int mel_front(FeatParams& p, const ma_melbank_t* mel, float power, int n_fft = 512) {
+  int rc = check_mel(mel, n_fft);
   if (rc != MA_OK) return rc;
   if (power != 1.0f && power != 2.0f) return MA_ERR_UNSUPPORTED;
   p.mel_steps = mel->steps;
@@ -777,10 +721,11 @@ int ma_melspectrogram_f32(const float* wav, int64_t batch, int64_t n, int64_t wa
   int rc = fill_common(p, wav, batch, n, wav_stride, n_fft, hop, window, center, pad_mode);
   if (rc != MA_OK) return rc;
   if (!out) return MA_ERR_INVALID_ARG;
-  rc = mel_front(p, mel, power);
+  rc = mel_front(p, mel, power, n_fft);
   if (rc != MA_OK) return rc;
   p.out = out;
   p.apply_db = 0;
+  if (n_fft != 512) return launch_feat_generic(p, kModeMel, n_fft, (hipStream_t)stream, nullptr);
   return launch_feat<kModeMel>(p, (hipStream_t)stream);
 }
 
@@ -792,7 +737,7 @@ int ma_fbank_db_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stri
   int rc = fill_common(p, wav, batch, n, wav_stride, n_fft, hop, window, center, pad_mode);
   if (rc != MA_OK) return rc;
   if (!out || !workspace || !(amin > 0.0f)) return MA_ERR_INVALID_ARG;
-  rc = mel_front(p, mel, power);
+  rc = mel_front(p, mel, power, n_fft);
   if (rc != MA_OK) return rc;
   if (workspace_bytes < ma_fbank_workspace_bytes(batch, p.n_frames)) return MA_ERR_WORKSPACE;
   p.out = out;
@@ -803,7 +748,8 @@ int ma_fbank_db_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stri
   p.unit_min = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_partial_bytes(batch, p.n_frames));
   p.wg_max = p.unit_min + p.num_units;
   int grid = 0;
-  rc = launch_feat<kModeMel>(p, (hipStream_t)stream, &grid);
+  rc = n_fft != 512 ? launch_feat_generic(p, kModeMel, n_fft, (hipStream_t)stream, &grid)
+                    : launch_feat<kModeMel>(p, (hipStream_t)stream, &grid);
   if (rc != MA_OK) return rc;
   if (top_db >= 0.0f && grid > 0) {
     MA_LAUNCH(topdb_units_kernel, dim3((unsigned)((p.num_units + kWaves - 1) / kWaves)), dim3(kThreads), 0,

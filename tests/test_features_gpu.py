@@ -39,6 +39,10 @@ STFT_CASES = {
     "stft_512_160": dict(n_fft=512, hop_length=160),
     "stft_512_win400_hop160": dict(n_fft=512, win_length=400, hop_length=160),
     "stft_nocenter_512_160": dict(n_fft=512, hop_length=160, center=False),
+    # n_fft != 512: exact-f32 MFMA DFT path (features_generic.hip)
+    "stft_400_160_reflect": dict(n_fft=400, hop_length=160, pad_mode="reflect"),
+    "stft_hamming_256": dict(n_fft=256, window="hamming"),
+    "stft_1024_256": dict(n_fft=1024, hop_length=256),
 }
 
 
@@ -197,6 +201,34 @@ def test_fbank_device_tensor_and_unsupported(ma):
         ma.fbank(x, n_fft=512, deltas=True)
     with pytest.raises(ValueError):
         ma.fbank(x[:, :300], n_fft=512)
+
+
+# ---- generic n_fft (reference defaults: fbank n_fft=400, features.py:201) ------------------------------
+@pytest.mark.parametrize("n_fft,hop,kw", [(400, 160, dict()), (400, None, dict(center=False)), (256, 100, dict(window="hamming")),
+                                           (1024, 256, dict(pad_mode="edge")), (62, 16, dict()), (130, 33, dict(win_length=100))])
+def test_stft_generic_nfft_vs_oracle(ma, n_fft, hop, kw):
+    x = _speechlike(n_fft, 3, 9001)
+    got = ma.stft(x, n_fft=n_fft, hop_length=hop, **kw)
+    want = O.stft_vec(x, n_fft=n_fft, hop_length=hop, **kw)
+    assert got.shape == want.shape
+    assert _frame_rel_err(got, want) <= TOL_STFT
+
+
+def test_fbank_reference_defaults_nfft400(ma, sample_wav):
+    # features.fbank docstring example (features.py:247-251): inputs (10, 16000) -> (10, 40, 81) at defaults
+    x = _speechlike(3, 10, 16000)
+    got = ma.fbank(x)
+    assert got.shape == (10, 40, 81)
+    _check_db(got, O.fbank(x), O.melspectrogram(x, n_fft=400, n_mels=40))
+    # ECAPA call site shape (examples/ECAPA-TDNN/speaker_verification_cosine.py:53): n_mels=80 at the default n_fft
+    got = ma.fbank(sample_wav, n_mels=80)
+    want = O.fbank(sample_wav, n_mels=80)
+    assert got.shape == want.shape == (80, 1 + len(sample_wav) // 200)
+    _check_db(got, want, O.melspectrogram(sample_wav, n_fft=400, n_mels=80))
+    for kw in (dict(n_fft=400, hop_length=160, n_mels=80), dict(n_fft=1024, hop_length=256, n_mels=128),
+               dict(n_fft=256, n_mels=23, power=1.0)):
+        m = ma.melspectrogram(sample_wav, **kw)
+        assert _frame_rel_err(m, O.melspectrogram(sample_wav, **kw)) <= TOL_MEL
 
 
 # ---- amplitude_to_dB vs reference goldens ---------------------------------------------------

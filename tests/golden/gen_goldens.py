@@ -239,6 +239,110 @@ def main():
     path = os.path.join(HERE, "reference_goldens.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+    collate_goldens(ref)
+
+
+def _write_wav(path, pcm16):
+    import wave
+
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm16.astype("<i2").tobytes())
+
+
+def collate_goldens(ref):
+    """Row a7: BucketASRDataset (dataset.py:290-381), DistributedSampler (distributed.py:4-29) and
+    CollateFunc.__call__ (dataset.py:536-656) of the reference, run on small synthetic wav files written to a
+    temporary directory.  `np.bool` (removed in NumPy 1.24; the reference pins numpy<2) is aliased for the run."""
+    import random
+    import tempfile
+
+    if not hasattr(np, "bool"):
+        np.bool = bool  # mask.py:190,233 use the removed alias
+    ds, dist = ref["dataset"], ref["dist"]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="ma_collate_")
+    rng = np.random.RandomState(4242)
+    chars = list("abcdefghij")
+    with open(os.path.join(tmp, "dict.txt"), "w") as f:
+        f.write("<blank> 0\n<unk> 1\n")
+        for i, c in enumerate(chars):
+            f.write("%s %d\n" % (c, i + 2))
+    n_utt = 23
+    lens = rng.randint(4000, 30000, n_utt)
+    lens[3] = lens[7]  # equal durations: exercises the sort ties
+    rows = [["id", "duration", "wav", "transcript"]]
+    pcm_all, trans = [], []
+    for i in range(n_utt):
+        pcm = np.round(rng.randn(lens[i]) * 2500.0).clip(-32768, 32767).astype(np.int16)
+        path = os.path.join(tmp, "utt%02d.wav" % i)
+        _write_wav(path, pcm)
+        ntok = int(rng.randint(1, 9))
+        tr = "".join(rng.choice(chars + ["z"], ntok))  # 'z' is out of vocabulary -> id 1
+        rows.append([str(i), "%.4f" % (lens[i] / 16000.0), path, tr])
+        pcm_all.append(pcm)
+        trans.append(tr)
+    import csv
+
+    data_file = os.path.join(tmp, "train.csv")
+    with open(data_file, "w", newline="") as f:
+        csv.writer(f).writerows(rows)
+    out["utt_lens"] = lens.astype(np.int64)
+    out["utt_pcm"] = np.concatenate(pcm_all)
+    out["utt_transcripts"] = np.array(trans)
+    out["dict_chars"] = np.array(chars)
+
+    kw = dict(max_length=180, min_length=30, token_max_length=7, token_min_length=1, frame_bucket_limit="60,120,200",
+              batch_bucket_limit="20,15,10", batch_factor=0.2)
+    for gs in (1, 2):
+        dset = ds.BucketASRDataset(data_file, os.path.join(tmp, "dict.txt"), frame_factor=100, group_size=gs, **kw)
+        out["bucket_g%d_nbatches" % gs] = np.int64(len(dset))
+        flat, sizes, limits = [], [], []
+        for b in range(len(dset)):
+            data, sos, eos, max_src, max_tgt = dset[b]
+            sizes.append(len(data))
+            limits.append(max_src)
+            flat += [int(d[0][3:5]) for d in data]  # uttid "uttNN.wav"
+        out["bucket_g%d_sizes" % gs] = np.array(sizes, np.int64)
+        out["bucket_g%d_limits" % gs] = np.array(limits, np.int64)
+        out["bucket_g%d_utts" % gs] = np.array(flat, np.int64)
+        out["bucket_g%d_sos_eos_tgt" % gs] = np.array([sos, eos, max_tgt], np.int64)
+        out["bucket_g%d_labels0" % gs] = np.array([d[2] for d in dset[0][0]])
+
+    for tag, (rank, gs, group) in {"r0g1": (0, 1, False), "r1g3": (1, 3, True)}.items():
+        smp = dist.DistributedSampler(list(range(17)), rank, gs, shuffle=True, group=group)
+        out["sampler_%s_epoch1" % tag] = np.array(list(iter(smp)), np.int64)
+        out["sampler_%s_epoch2" % tag] = np.array(list(iter(smp)), np.int64)
+    smp = dist.DistributedSampler(list(range(7)), 1, 2, shuffle=False, group=True)
+    out["sampler_noshuffle"] = np.array(list(iter(smp)), np.int64)
+
+    names = ["xs_pad", "ys_pad", "ys_in_pad", "ys_out_pad", "r_ys_in_pad", "r_ys_out_pad", "xs_masks", "ys_sub_masks",
+             "ys_masks", "ys_lengths", "xs_chunk_masks"]
+    dset = ds.BucketASRDataset(data_file, os.path.join(tmp, "dict.txt"), frame_factor=100, group_size=2, **kw)
+    fe = {"mel_bins": 80, "frame_length": 25, "frame_shift": 10}
+    cases = {
+        "plain_r0g1": dict(rank=0, group_size=1),
+        "plain_r1g2": dict(rank=1, group_size=2),
+        "specaug_r0g2": dict(rank=0, group_size=2, use_spec_aug=True,
+                             spec_aug_conf={"num_t_mask": 2, "num_f_mask": 2, "max_t": 50, "max_f": 10}),
+        "static_chunk_r0g1": dict(rank=0, group_size=1, static_chunk_size=4, num_decoding_left_chunks=1),
+    }
+    for tag, conf in cases.items():
+        cf = ds.CollateFunc(feature_extraction_conf=fe, **conf)
+        for bi in (0, len(dset) - 1):
+            data, sos, eos, max_src, max_tgt = dset[bi]
+            random.seed(99 + bi)
+            res = cf(data, sos, eos, max_src, max_tgt)
+            for nme, arr in zip(names, res):
+                out["collate_%s_b%d_%s" % (tag, bi, nme)] = np.asarray(arr)
+        cf.pool.close()
+        cf.pool.join()
+    path = os.path.join(HERE, "collate_goldens.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+    shutil.rmtree(tmp)
 
 
 if __name__ == "__main__":

@@ -247,6 +247,40 @@ int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, i
 /* float32 -> bf16 (round to nearest even), n % 4 == 0: the `cast` in front of a matmul operand. */
 int ma_cast_f32_bf16(const float* x, void* y, int64_t n, ma_stream_t stream);
 
+/* ---- batch assembly of the training loop (examples/conformer/dataset.py:536-656) -------------------------- */
+
+/* len(range(max_src_len)[:-2:2][:-2:2]): width of xs_masks after the two stride-2 slicings (dataset.py:625). */
+int32_t ma_subsampled_mask_len(int32_t max_src_len);
+
+/*
+ * Label and mask columns of CollateFunc.__call__ (dataset.py:570-642) for utterances already sorted by the host
+ * (np.argsort(lengths)[::-1], dataset.py:484) — one launch, bit-exact:
+ *   tokens   device int32, all label ids of the batch back to back; tok_off (batch+1) int32 offsets
+ *   xs_lengths (batch) int32 feature frames per utterance
+ *   ys_pad (batch, L) pad -1; ys_in_pad / r_ys_in_pad (batch, L+1) pad eos; ys_out_pad / r_ys_out_pad (batch, L+1)
+ *   pad -1 (pad_sequence truncates over-long sequences, common.py:44); L = max_tgt_len
+ *   xs_masks (batch, 1, T2) float32, T2 = ma_subsampled_mask_len(max_src_len); ys_masks (batch, 1, L+1),
+ *   ys_sub_masks (batch, L+1, L+1) float32; ys_lengths (batch) int32
+ *   xs_chunk_masks bool bytes: (batch, 1, T2) when chunk_size == 0 (add_optional_chunk_mask's pass-through,
+ *   mask.py:270), else (batch, T2, T2) = masks & subsequent_chunk_mask(T2, chunk_size, num_left_chunks)
+ *   (mask.py:154-199, 252-268; num_left_chunks < 0: all left chunks).
+ */
+int ma_collate_asr_i32(const int32_t* tokens, const int32_t* tok_off, const int32_t* xs_lengths, int32_t batch,
+                       int32_t sos, int32_t eos, int32_t max_tgt_len, int32_t max_src_len, int32_t chunk_size,
+                       int32_t num_left_chunks, int32_t* ys_pad, int32_t* ys_in_pad, int32_t* ys_out_pad,
+                       int32_t* r_ys_in_pad, int32_t* r_ys_out_pad, float* xs_masks, float* ys_sub_masks,
+                       float* ys_masks, int32_t* ys_lengths, uint8_t* xs_chunk_masks, ma_stream_t stream);
+
+/*
+ * CollateFunc.spec_aug (dataset.py:493-534) on the padded batch xs (batch, max_frames, n_freq) float32, in place.
+ * The host draws the intervals with the reference's `random` call order; t_intervals (batch, n_t, 2) /
+ * f_intervals (batch, n_f, 2) int32 hold [start, end) per mask, an empty interval for a mask the 20 % coin skipped.
+ * Frequency masks cover the utterance's xs_lengths[b] valid frames.
+ */
+int ma_spec_aug_f32(float* xs, int64_t batch, int64_t max_frames, int32_t n_freq, const int32_t* xs_lengths,
+                    const int32_t* t_intervals, int32_t n_t, const int32_t* f_intervals, int32_t n_f,
+                    ma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,10 @@ PROTOTYPES = {
                                        ctypes.c_void_p, i32, i32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),
     "ma_cast_f32_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p]),
+    "ma_subsampled_mask_len": (i32, [i32]),
+    "ma_collate_asr_i32": (ctypes.c_int, [ctypes.c_void_p] * 3 + [i32] * 7 + [ctypes.c_void_p] * 11),
+    "ma_spec_aug_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p, i32,
+                                       ctypes.c_void_p, i32, ctypes.c_void_p]),
     "ma_db_workspace_bytes": (i64, [i64, i64]),
     "ma_amplitude_to_db_f32": (ctypes.c_int, [c_f32p, i64, i64, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),

@@ -39,3 +39,246 @@ def compute_fbank_feats(wav, sample_rate, frame_len, frame_shift, mel_bin):
     out, frames = compute_fbank_feats_batch(wav[None, :], [wav.shape[0]], sample_rate, frame_len, frame_shift,
                                             mel_bin)
     return out[0, :int(frames[0])].cpu().numpy().astype(np.float64)
+
+
+# ---- batch assembly (dataset.py:170-726): host bookkeeping + device collate --------------------------------
+import csv  # noqa: E402
+import math  # noqa: E402
+import random  # noqa: E402
+
+from ..data import io as _io  # noqa: E402
+from ..utils.distributed import DistributedSampler  # noqa: E402
+
+IGNORE_ID = -1  # mindaudio/utils/common.py:7
+
+COLUMNS = ("xs_pad", "ys_pad", "ys_in_pad", "ys_out_pad", "r_ys_in_pad", "r_ys_out_pad", "xs_masks", "ys_sub_masks",
+           "ys_masks", "ys_lengths", "xs_chunk_masks")  # return order of CollateFunc.__call__ (dataset.py:644-656)
+
+
+def load_samples(data_file, dict_file, frame_factor=100):
+    """Index file -> [(uttid, wav_path, duration_in_frames, "id id ... ", output_dim)] (dataset.py:178-209).
+    csv columns: _, seconds, wav path, transcript; characters outside the dictionary map to id 1."""
+    with open(dict_file, "r") as fh:
+        vocab = [ln.split()[0] for ln in fh]
+    first_pos = {}
+    for i, sym in enumerate(vocab):
+        first_pos.setdefault(sym, i)
+    out_dim = len(vocab) + 1
+    samples = []
+    with open(data_file, "r") as fh:
+        rows = csv.reader(fh)
+        next(rows, None)  # header line
+        for row in rows:
+            ids = "".join("{} ".format(first_pos.get(ch, 1)) for ch in row[3].replace(" ", ""))
+            samples.append((row[2].split("/")[-1], row[2], int(float(row[1]) * frame_factor), ids, out_dim))
+    return samples
+
+
+class BucketASRDataset:
+    """Length-bucketed batches of (uttid, wav_path, label ids) — constructor and item layout of dataset.py:290-381
+    (`data_file`/`dict_file` may be replaced by a pre-parsed `samples=` list)."""
+
+    def __init__(self, data_file=None, dict_file=None, max_length=10240, min_length=0, token_max_length=200,
+                 token_min_length=1, frame_bucket_limit="200,300", batch_bucket_limit="220,200", batch_factor=0.2,
+                 frame_factor=100, group_size=1, samples=None):
+        self.group_size = group_size
+        self.frame_bucket_limit = [int(v) for v in frame_bucket_limit.split(",")]
+        self.batch_bucket_limit = [int(int(v) * batch_factor * group_size) for v in batch_bucket_limit.split(",")]
+        if len(self.frame_bucket_limit) != len(self.batch_bucket_limit):
+            raise AssertionError("frame_bucket_limit and batch_bucket_limit differ in length")
+        if samples is None:
+            samples = load_samples(data_file, dict_file, frame_factor)
+        self.data = sorted(samples, key=lambda s: s[2])  # stable, by duration (dataset.py:270)
+        self.token_max_length = token_max_length
+        self.output_dim = self.data[-1][4] if self.data else 0
+        open_buckets = [[] for _ in self.frame_bucket_limit]
+        self.batches = []
+        kept = 0
+        for uttid, path, frames, ids, _ in self.data:
+            n_tok = len(ids.split())
+            if not (min_length <= frames <= max_length and token_min_length <= n_tok <= token_max_length):
+                continue
+            kept += 1
+            b = self._bucket(frames)
+            open_buckets[b].append((uttid, path, ids))
+            if len(open_buckets[b]) >= self.batch_bucket_limit[b]:
+                self.batches.append((open_buckets[b], self.frame_bucket_limit[b]))
+                open_buckets[b] = []
+        for b, rest in enumerate(open_buckets):  # leftovers are repeated to a full batch (dataset.py:360-368)
+            if rest:
+                want = self.batch_bucket_limit[b]
+                self.batches.append(((rest * math.ceil(want / len(rest)))[:want], self.frame_bucket_limit[b]))
+        self.num_kept, self.num_dropped = kept, len(self.data) - kept
+        self.sos = self.eos = self.output_dim - 1
+
+    def _bucket(self, frames):
+        for i, limit in enumerate(self.frame_bucket_limit):
+            if frames <= limit:
+                return i
+        raise KeyError(frames)  # longer than the last bucket: the reference's dict lookup fails the same way
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __getitem__(self, index):
+        data, max_src_len = self.batches[index]
+        return data, self.sos, self.eos, max_src_len, self.token_max_length
+
+
+class CollateFunc:
+    """CollateFunc of dataset.py:409-656 with the feature extraction, padding, SpecAugment masking and every
+    label/mask column computed on the device.  `__call__` returns the reference's 11 columns (COLUMNS) as device
+    tensors: float32 / int32 as in the reference, xs_chunk_masks as torch.bool.
+
+    Host-side work that stays: reading the wav files, the length sort (NumPy's argsort, so ties fall as in the
+    reference) and the `random` / `np.random` draws of SpecAugment and dynamic chunks, issued in the reference's call
+    order so that a seeded run selects the same masks."""
+
+    def __init__(self, rank, group_size, feature_extraction_conf=None, feature_dither=0.0, use_speed_perturb=False,
+                 use_spec_aug=False, spec_aug_conf=None, use_dynamic_chunk=False, use_dynamic_left_chunk=False,
+                 decoding_chunk_size=0, static_chunk_size=0, num_decoding_left_chunks=-1, reader=_io.read):
+        self.rank, self.group_size = rank, group_size
+        self.feature_extraction_conf = feature_extraction_conf
+        self.feature_dither = feature_dither
+        self.use_speed_perturb = use_speed_perturb
+        self.use_spec_aug, self.spec_aug_conf = use_spec_aug, spec_aug_conf
+        self.use_dynamic_chunk, self.use_dynamic_left_chunk = use_dynamic_chunk, use_dynamic_left_chunk
+        self.decoding_chunk_size, self.static_chunk_size = decoding_chunk_size, static_chunk_size
+        self.num_decoding_left_chunks = num_decoding_left_chunks
+        self.reader = reader
+
+    # -- host draws ------------------------------------------------------------------------------
+    def _spec_aug_intervals(self, frames_sorted, n_freq):
+        conf = self.spec_aug_conf
+        n_t, n_f = int(conf.get("num_t_mask", 0)), int(conf.get("num_f_mask", 0))
+        max_t, max_f = conf.get("max_t", 0), conf.get("max_f", 0)
+        t_iv = np.zeros((len(frames_sorted), max(n_t, 1), 2), np.int32)
+        f_iv = np.zeros((len(frames_sorted), max(n_f, 1), 2), np.int32)
+        for b, frames in enumerate(frames_sorted):  # same draw order as dataset.py:516-533
+            for k in range(n_t):
+                start = random.randint(0, frames - 1)
+                end = min(frames, start + random.randint(1, max_t))
+                if random.randint(1, 100) > 20:
+                    t_iv[b, k] = (start, end)
+            for k in range(n_f):
+                start = random.randint(0, n_freq - 1)
+                end = min(n_freq, start + random.randint(1, max_f))
+                if random.randint(1, 100) > 20:
+                    f_iv[b, k] = (start, end)
+        return t_iv, n_t, f_iv, n_f
+
+    def _chunk_draw(self, max_len):
+        """(chunk_size, num_left_chunks) of add_optional_chunk_mask (mask.py:232-268); chunk_size 0 = no chunk mask."""
+        if self.use_dynamic_chunk:
+            if self.decoding_chunk_size < 0:
+                return max_len, -1
+            if self.decoding_chunk_size > 0:
+                return self.decoding_chunk_size, self.num_decoding_left_chunks
+            chunk = np.random.randint(1, max_len, (1,)).tolist()[0]
+            left = -1
+            if chunk > max_len // 2:
+                chunk = max_len
+            else:
+                chunk = chunk % 25 + 1
+                if self.use_dynamic_left_chunk:
+                    left = np.random.randint(0, (max_len - 1) // chunk, (1,)).tolist()[0]
+            return chunk, left
+        if self.static_chunk_size > 0:
+            return self.static_chunk_size, self.num_decoding_left_chunks
+        return 0, -1
+
+    # -- the collate call --------------------------------------------------------------------------
+    def __call__(self, batch, sos=0, eos=0, max_src_len=2000, max_tgt_len=30):
+        if self.feature_dither != 0.0:
+            raise NotImplementedError  # as the reference (dataset.py:559-560)
+        if self.use_speed_perturb:
+            raise NotImplementedError("speed perturbation (scipy resample) is a next row (SURVEY §8f-2)")
+        t = _host.require_gpu()
+        lib = _lib.load()
+        conf = self.feature_extraction_conf
+        mel_bin, frame_len, frame_shift = int(conf["mel_bins"]), int(conf["frame_length"]), int(conf["frame_shift"])
+        mine = batch[self.rank::self.group_size]
+        waves = []
+        for utt in mine:
+            wav, rate = self.reader(utt[1])
+            if rate != 16000:
+                raise ValueError("the loader expects 16 kHz audio (dataset.py:390-396)")
+            waves.append(wav)
+        flen, fshift = 16000 * frame_len // 1000, 16000 * frame_shift // 1000
+        frames = [int(math.floor((w.shape[0] - flen) / fshift) + 1) for w in waves]
+        order = np.argsort(frames)[::-1]  # dataset.py:484
+        frames_sorted = [frames[i] for i in order]
+        labels = [np.fromiter(map(int, mine[i][2].split()), dtype=np.int32) for i in order]
+        n_b = len(order)
+        # padded wave matrix: long enough for max_src_len frames so that the kernel's output *is* xs_pad
+        max_n = max(max(w.shape[0] for w in waves), (max_src_len - 1) * fshift + flen)
+        host = np.zeros((n_b, (max_n + 3) // 4 * 4), np.float32)
+        for row, i in enumerate(order):
+            host[row, :waves[i].shape[0]] = waves[i] * 32768.0  # waveform * (1 << 15), dataset.py:390 (exact in f32)
+        lengths = np.array([waves[i].shape[0] for i in order], np.int64)
+        dev = t.device("cuda", t.cuda.current_device())
+        xs_all, _ = compute_fbank_feats_batch(t.from_numpy(host).to(dev)[:, :max_n], lengths, 16000, frame_len,
+                                              frame_shift, mel_bin)
+        xs_pad = xs_all if xs_all.shape[1] == max_src_len else xs_all[:, :max_src_len].contiguous()
+        stream = _host.current_stream_ptr()
+        xs_len_dev = t.tensor(frames_sorted, dtype=t.int32, device=dev)
+        if self.use_spec_aug:
+            t_iv, n_t, f_iv, n_f = self._spec_aug_intervals(frames_sorted, mel_bin)
+            t_dev, f_dev = t.from_numpy(t_iv).to(dev), t.from_numpy(f_iv).to(dev)
+            _lib.check(lib.ma_spec_aug_f32(_host.ptr(xs_pad), n_b, max_src_len, mel_bin, _host.ptr(xs_len_dev),
+                                           _host.ptr(t_dev), n_t, _host.ptr(f_dev), n_f, stream), "spec_aug")
+        tok_off = np.zeros(n_b + 1, np.int32)
+        tok_off[1:] = np.cumsum([len(y) for y in labels])
+        tokens = np.concatenate(labels) if tok_off[-1] else np.zeros(1, np.int32)
+        tok_dev, off_dev = t.from_numpy(tokens).to(dev), t.from_numpy(tok_off).to(dev)
+        t2 = lib.ma_subsampled_mask_len(max_src_len)
+        chunk, left = self._chunk_draw((max_src_len - 3) // 4)
+        l1 = max_tgt_len + 1
+        i32 = dict(dtype=t.int32, device=dev)
+        f32 = dict(dtype=t.float32, device=dev)
+        ys_pad, ys_lengths = t.empty((n_b, max_tgt_len), **i32), t.empty((n_b,), **i32)
+        ys_in, ys_out, r_in, r_out = (t.empty((n_b, l1), **i32) for _ in range(4))
+        xs_masks, ys_masks, ys_sub = t.empty((n_b, 1, t2), **f32), t.empty((n_b, 1, l1), **f32), t.empty((n_b, l1, l1), **f32)
+        chunk_masks = t.empty((n_b, t2 if chunk else 1, t2), dtype=t.bool, device=dev)
+        rc = lib.ma_collate_asr_i32(_host.ptr(tok_dev), _host.ptr(off_dev), _host.ptr(xs_len_dev), n_b, int(sos),
+                                    int(eos), max_tgt_len, max_src_len, chunk, left, _host.ptr(ys_pad),
+                                    _host.ptr(ys_in), _host.ptr(ys_out), _host.ptr(r_in), _host.ptr(r_out),
+                                    _host.ptr(xs_masks), _host.ptr(ys_sub), _host.ptr(ys_masks),
+                                    _host.ptr(ys_lengths), _host.ptr(chunk_masks), stream)
+        _lib.check(rc, "collate")
+        return xs_pad, ys_pad, ys_in, ys_out, r_in, r_out, xs_masks, ys_sub, ys_masks, ys_lengths, chunk_masks
+
+
+class _BatchIterable:
+    """What the reference builds with GeneratorDataset + map + project (dataset.py:697-743): one collated batch per
+    sampler index, re-iterable per epoch."""
+
+    def __init__(self, dataset, sampler, collate):
+        self.dataset, self.sampler, self.collate = dataset, sampler, collate
+
+    def __len__(self):
+        return len(self.sampler)
+
+    def get_dataset_size(self):
+        return len(self)
+
+    def __iter__(self):
+        for idx in self.sampler:
+            yield self.collate(*self.dataset[int(idx)])
+
+    create_tuple_iterator = __iter__
+
+
+def create_dataset(data_file, dict_file, collate_conf, dataset_conf, rank=0, group_size=1, number_workers=8):
+    """(output_dim, iterable of collated batches) — dataset.py:659-743.  Every rank walks the same shuffled batch
+    order (sampler group=False, dataset.py:693) and keeps batch[rank::group_size] inside the collate."""
+    collate = CollateFunc(rank=rank, group_size=group_size, **collate_conf)
+    dataset = BucketASRDataset(data_file, dict_file, max_length=dataset_conf["max_length"],
+                               min_length=dataset_conf["min_length"],
+                               token_max_length=dataset_conf["token_max_length"],
+                               token_min_length=dataset_conf["token_min_length"],
+                               frame_bucket_limit=dataset_conf["frame_bucket_limit"],
+                               batch_bucket_limit=dataset_conf["batch_bucket_limit"],
+                               batch_factor=dataset_conf["batch_factor"], frame_factor=100, group_size=group_size)
+    sampler = DistributedSampler(dataset, rank, group_size, shuffle=True, group=False)
+    return dataset.output_dim, _BatchIterable(dataset, sampler, collate)

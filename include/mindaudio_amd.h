@@ -281,6 +281,80 @@ int ma_spec_aug_f32(float* xs, int64_t batch, int64_t max_frames, int32_t n_freq
                     const int32_t* t_intervals, int32_t n_t, const int32_t* f_intervals, int32_t n_f,
                     ma_stream_t stream);
 
+/* ---- training step (mindaudio/utils/train_one_step.py:13-48 around examples/conformer/asr_model.py) -------------
+ * Memory-bound backward pieces and the optimizer; the matmuls of the backward pass reuse ma_gemm_bf16
+ * (dX = dY . W on a transposed weight copy) and ma_gemm_bf16_splitk_f32 (dW = dY^T . X on transposed activations). */
+
+/* out (M, N) float32 += alpha * A (M, K) . W (N, K)^T, contraction split across workgroups with float32 atomics
+ * (weight gradients: small outputs, K = batch*time).  The caller zeroes `out`.  K % 64 == 0. */
+int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t ldw, float* out, int64_t ldo,
+                            int64_t M, int64_t N, int64_t K, float alpha, ma_stream_t stream);
+
+/* out[c][r] = in[r][c] (bf16); columns r in [rows, ld_out) of `out` are not written (keep them zero to use the
+ * result as a K-padded GEMM operand).  colsum (cols) float32, optional: += column sums of `in` (bias gradients). */
+int ma_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols, void* out, int64_t ld_out,
+                      float* colsum, ma_stream_t stream);
+
+/* Backward of ma_layernorm_f32 (layers/layernorm.py:53-60): g (+)= dL/dx, dgamma/dbeta (D) float32 += (atomics).
+ * dy bf16 or float32; row_scale as in the forward; D == 256. */
+int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
+                         const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
+                         int32_t accumulate, float* dgamma, float* dbeta, ma_stream_t stream);
+
+/* h = dropout(swish(u)) between w_1 and w_2 (positionwise_feed_forward.py:33-46), bf16, n elements; the keep mask is a
+ * pure function of (seed, salt, element index) and is regenerated by the backward: du = dh * keep/(1-p) * swish'(u). */
+int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
+int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, float p, uint32_t seed, uint32_t salt,
+                            ma_stream_t stream);
+
+/* x (rows, cols) float32 += alpha * dropout(y) (models/conformer.py:109-151 branch joins); y bf16 or float32.
+ * Backward: dy (bf16) = alpha * keep/(1-p) * g * row_scale[r]. */
+int ma_dropout_add_f32(float* x, int64_t ldx, const void* y, int64_t ldy, int32_t y_bf16, int64_t rows, int64_t cols,
+                       float alpha, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
+int ma_dropout_bwd_bf16(const float* g, int64_t ldg, void* dy, int64_t ldy, int64_t rows, int64_t cols, float alpha,
+                        const float* row_scale, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
+
+/* Convolution module in training mode (layers/convolution.py:83-129), between the two pointwise GEMMs:
+ *   ma_convmid_fwd_train   z (B*T, C) float32 = depthwise_k(glu(y)) + bias, y (B*T, 2C) bf16; sums (2C) float32 +=
+ *                          per-channel sum z, sum z^2 (caller zeroes)
+ *   ma_bn_finalize_f32     stats = (mean[C], rstd[C]) of the B*T rows (biased variance); running statistics updated
+ *                          with momentum and the unbiased variance (nn.BatchNorm1d)
+ *   ma_bn_swish_fwd_bf16   out = swish(gamma * (z - mean) * rstd + beta) bf16
+ *   ma_bn_swish_bwd_f32    dz (float32) from dout (bf16): Swish', then the BatchNorm backward; dsum (2C) float32 +=
+ *                          (dbeta, dgamma) (caller zeroes)
+ *   ma_convmid_bwd_bf16    dy (B*T, 2C) bf16 from dz: depthwise-conv backward + GLU backward; d_dw_w (C, k), d_dw_b (C)
+ *                          float32 += (atomics) */
+int ma_convmid_fwd_train(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
+                         int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream);
+int ma_bn_finalize_f32(const float* sums, int32_t C, int64_t count, float eps, float momentum, float* running_mean,
+                       float* running_var, float* stats, ma_stream_t stream);
+int ma_bn_swish_fwd_bf16(const float* z, const float* stats, const float* gamma, const float* beta, void* out,
+                         int64_t rows, int32_t C, ma_stream_t stream);
+int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
+                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream);
+int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
+                        const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
+                        ma_stream_t stream);
+
+/* Conv2dSubsampling4 backward (layers/subsampling.py:21-78): ReLU mask in place; transposed im2col matrix
+ * (9C, ld_out >= B*Ho*Wo) of an NHWC bf16 activation (weight gradient of conv2 as a split-K GEMM); col2im + ReLU mask
+ * (input gradient of conv2 from dcol (B*Ho*Wo, 9C) bf16); conv1 weight/bias gradient (C, 9) / (C) float32 +=. */
+int ma_relu_bwd_bf16(void* dy, const void* y, int64_t n, ma_stream_t stream);
+int ma_im2col_t_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, void* out,
+                                int64_t ld_out, ma_stream_t stream);
+int ma_col2im_3x3s2_relu_bf16(const void* dcol, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
+                              void* dact, ma_stream_t stream);
+int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, int64_t T, int32_t idim,
+                              const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
+                              ma_stream_t stream);
+
+/* TrainOneStepWithLossScaleCell pieces (train_one_step.py:37-47): *flag |= 1 if any gradient is inf/nan; Adam
+ * (MindSpore nn.Adam: p -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t) from the host) on
+ * grad * inv_scale, skipped on the device when *overflow != 0. */
+int ma_grad_overflow_f32(const float* g, int64_t n, int32_t* flag, ma_stream_t stream);
+int ma_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                float eps, float inv_scale, const int32_t* overflow, ma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

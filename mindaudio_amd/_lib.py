@@ -25,6 +25,8 @@ c_f32p = ctypes.c_void_p  # device pointers travel as integers
 i64 = ctypes.c_int64
 i32 = ctypes.c_int32
 f32 = ctypes.c_float
+u32 = ctypes.c_uint32
+vp = ctypes.c_void_p
 
 
 class MelBank(ctypes.Structure):
@@ -102,6 +104,24 @@ PROTOTYPES = {
     "ma_collate_asr_i32": (ctypes.c_int, [ctypes.c_void_p] * 3 + [i32] * 7 + [ctypes.c_void_p] * 11),
     "ma_spec_aug_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p, i32,
                                        ctypes.c_void_p, i32, ctypes.c_void_p]),
+    "ma_gemm_bf16_splitk_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp]),
+    "ma_transpose_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
+    "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp]),
+    "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, f32, u32, u32, vp]),
+    "ma_act_dropout_bwd_bf16": (ctypes.c_int, [vp, vp, vp, i64, f32, u32, u32, vp]),
+    "ma_dropout_add_f32": (ctypes.c_int, [vp, i64, vp, i64, i32, i64, i64, f32, f32, u32, u32, vp]),
+    "ma_dropout_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, f32, vp, f32, u32, u32, vp]),
+    "ma_convmid_fwd_train": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, vp, vp]),
+    "ma_bn_finalize_f32": (ctypes.c_int, [vp, i32, i64, f32, f32, vp, vp, vp, vp]),
+    "ma_bn_swish_fwd_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, i32, vp]),
+    "ma_bn_swish_bwd_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "ma_convmid_bwd_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp]),
+    "ma_relu_bwd_bf16": (ctypes.c_int, [vp, vp, i64, vp]),
+    "ma_im2col_t_3x3s2_nhwc_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, i64, vp]),
+    "ma_col2im_3x3s2_relu_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
+    "ma_subsample_conv1_dw_f32": (ctypes.c_int, [vp, vp, i64, i64, i32, vp, vp, i32, vp, vp, vp]),
+    "ma_grad_overflow_f32": (ctypes.c_int, [vp, i64, vp, vp]),
+    "ma_adam_f32": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
     "ma_db_workspace_bytes": (i64, [i64, i64]),
     "ma_amplitude_to_db_f32": (ctypes.c_int, [c_f32p, i64, i64, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),

@@ -49,6 +49,9 @@ struct GemmParams {
   float alpha;
   // im2col (3x3, stride 2, valid) over an NHWC activation (B, H, Wd, C): row m = (b, ho, wo), k = (kh, kw, c)
   int32_t H, Wd, C, Ho, Wo;
+  // split-K (weight gradients: small outputs, long contraction): blockIdx.y owns K-tiles [y * kt_split, ...) and
+  // atomically adds its partial product into the float32 output (kt_split == 0: the whole K range, plain stores)
+  int32_t kt_split;
 };
 
 // two f32 -> packed bf16x2, round to nearest even (v_cvt_pk_bf16_f32, gfx950)
@@ -159,15 +162,19 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
 #pragma unroll
   for (int j = 0; j < FN; ++j) foff_w[j] = BM * 128 + lds_off(wn * (BN / 2) + j * 16 + frow, fk);
 
-  const int nk = p.K / BK;
-  issue_tile(0, 0);
-  if (kStages > 2 && nk > 1) issue_tile(1, 1);
+  int kt_lo = 0, nk = p.K / BK;
+  if (p.kt_split > 0) {
+    kt_lo = blockIdx.y * p.kt_split;
+    nk = min(nk - kt_lo, p.kt_split);
+  }
+  issue_tile(kt_lo, 0);
+  if (kStages > 2 && nk > 1) issue_tile(kt_lo + 1, 1);
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most (kStages - 2) younger tiles of this wave are still in flight
     if (kStages > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's part of tile kt is in LDS; everyone is done reading tile kt-1
-    if (kt + kStages - 1 < nk) issue_tile(kt + kStages - 1, (kt + kStages - 1) % kStages);
+    if (kt + kStages - 1 < nk) issue_tile(kt_lo + kt + kStages - 1, (kt + kStages - 1) % kStages);
     const char* st = smem + (kt % kStages) * kStageBytes;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -186,6 +193,22 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
 
   // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] ------------------
   const int em = lane & 15, en = (lane >> 4) * 4;
+  if (p.kt_split > 0) {  // split-K partial: out (float32) += alpha * acc
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm * (BM / 2) + i * 16 + em;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + en;
+        float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) atomicAdd(o + r, acc[i][j][r] * p.alpha);
+      }
+    }
+    return;
+  }
   // bf16 tiles that lie fully inside the matrix go through LDS so that HBM sees whole 256-byte rows
   const bool staged = p.out_bf16 && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 7) == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
@@ -293,7 +316,8 @@ static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
     attr = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  MA_LAUNCH((gemm_bf16_kernel<BM, BN, NST, IM2COL>), dim3(tiles), dim3(kGemmThreads), lds, stream, p);
+  const int splits = p.kt_split > 0 ? (p.K / BK + p.kt_split - 1) / p.kt_split : 1;
+  MA_LAUNCH((gemm_bf16_kernel<BM, BN, NST, IM2COL>), dim3(tiles, splits), dim3(kGemmThreads), lds, stream, p);
   return MA_OK;
 }
 
@@ -354,6 +378,32 @@ int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* o
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
   return launch_gemm<false>(p, (hipStream_t)stream);
+}
+
+int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t ldw, float* out, int64_t ldo,
+                            int64_t M, int64_t N, int64_t K, float alpha, ma_stream_t stream) {
+  if (!A || !W || !out || M < 1 || N < 1 || K < 1 || M > 0x7fffffff || N > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (K % BK != 0 || lda < K || ldw < K || ldo < N || (lda & 7) || (ldw & 7)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return MA_ERR_INVALID_ARG;
+  GemmParams p = GemmParams{};
+  p.A = reinterpret_cast<const uint16_t*>(A);
+  p.W = reinterpret_cast<const uint16_t*>(W);
+  p.out = out;
+  p.lda = lda;
+  p.ldw = ldw;
+  p.ldo = ldo;
+  p.M = (int32_t)M;
+  p.N = (int32_t)N;
+  p.K = (int32_t)K;
+  p.alpha = alpha;
+  // enough splits to put ~3 workgroups on every CU, at least 4 K-tiles (256 contraction elements) each
+  const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
+  const int64_t nk = K / BK;
+  int64_t splits = (3 * gemm_num_cus() + tiles - 1) / tiles;
+  if (splits > nk / 4) splits = nk / 4;
+  if (splits < 1) splits = 1;
+  p.kt_split = (int32_t)((nk + splits - 1) / splits);
+  return launch_gemm_tile<64, 128, 3, false>(p, (hipStream_t)stream);
 }
 
 int ma_conv2d_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* W,

@@ -1,0 +1,670 @@
+// Training-step kernels of the Conformer path: the memory-bound pieces of the backward pass and the
+// optimizer.  Matmuls go through gemm_bf16.hip (dX = dY . W as the NT kernel on a transposed weight copy, dW = dY^T . X
+// as the split-K NT kernel on transposed activations produced by transpose_bf16_kernel here).
+//
+//   transpose_bf16_kernel      (rows, cols) bf16 -> (cols, rows) bf16, optional float32 column sums (bias gradients)
+//   layernorm_bwd_kernel       layers/layernorm.py:53-60 backward, accumulates into the residual-stream gradient
+//   act_dropout fwd/bwd        Swish (layers/swish.py:14-16) + inverted dropout between w_1 and w_2
+//   dropout_add / dropout_bwd  x += alpha * dropout(y) of the four branch joins (models/conformer.py:109-151)
+//   convmid_* / bn_*           GLU -> depthwise conv -> BatchNorm (batch statistics over B*T rows) -> Swish
+//                              (layers/convolution.py:83-129) forward in training mode and backward
+//   relu_bwd, im2col_t, col2im, conv1_dw   Conv2dSubsampling4 backward (layers/subsampling.py:21-78)
+//   adam / overflow / cast     nn.Adam update with the loss-scale overflow skip (utils/train_one_step.py:13-48)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                             // round to nearest even
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// Counter-based dropout: the keep decision of element `idx` of dropout site `salt` at step seed `seed` is a pure
+// function, so the backward pass regenerates the mask instead of storing it.
+__device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t salt, uint64_t idx, uint32_t thresh) {
+  uint32_t x = (uint32_t)idx ^ (seed * 0x9E3779B9u) ^ (salt * 0x85EBCA6Bu) ^ ((uint32_t)(idx >> 32) * 0xC2B2AE35u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  x += salt; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+  return x >= thresh;
+}
+struct Drop {
+  uint32_t seed, salt, thresh;  // thresh = p * 2^32; 0 = no dropout
+  float inv_keep;               // 1 / (1 - p)
+};
+
+// ---- transpose (+ column sums) --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, int64_t ld_in, int rows,
+                                                             int cols, uint16_t* __restrict__ out, int64_t ld_out,
+                                                             float* colsum) {
+  __shared__ uint16_t tile[64][66];
+  __shared__ float csum[4][64];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  float s = 0.0f;
+  for (int r = ty; r < 64; r += 4) {
+    const int rr = r0 + r, cc = c0 + tx;
+    uint16_t v = 0;
+    if (rr < rows && cc < cols) v = in[(int64_t)rr * ld_in + cc];
+    tile[r][tx] = v;
+    s += bf2f(v);
+  }
+  if (colsum) csum[ty][tx] = s;
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int cc = c0 + c, rr = r0 + tx;
+    if (cc < cols && rr < rows) out[(int64_t)cc * ld_out + rr] = tile[tx][c];
+  }
+  if (colsum && ty == 0 && c0 + tx < cols) atomicAdd(colsum + c0 + tx, (csum[0][tx] + csum[1][tx]) + (csum[2][tx] + csum[3][tx]));
+}
+
+// ---- LayerNorm backward -----------------------------------------------------------------------------------------
+// y = ((x - mu) * rstd * gamma + beta) * row_scale.  One wave per row (D = 256: 4 columns per lane), persistent over
+// rows; per-workgroup partial dgamma / dbeta leave through float32 atomics.
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
+                                                            const float* __restrict__ gamma, float eps,
+                                                            const float* __restrict__ row_scale, const void* dy_,
+                                                            int64_t ldy, float* g, int64_t ldg, int accumulate,
+                                                            float* dgamma, float* dbeta) {
+  __shared__ float red[2][4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + lane * 4);
+    float dv[4];
+    if (DY_BF16) {
+      const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(dy_) + row * ldy + lane * 4);
+      dv[0] = __uint_as_float(raw.x << 16); dv[1] = __uint_as_float(raw.x & 0xffff0000u);
+      dv[2] = __uint_as_float(raw.y << 16); dv[3] = __uint_as_float(raw.y & 0xffff0000u);
+    } else {
+      const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + row * ldy + lane * 4);
+      dv[0] = t.x; dv[1] = t.y; dv[2] = t.z; dv[3] = t.w;
+    }
+    const float rs = row_scale ? row_scale[row] : 1.0f;
+    float s = (xv.x + xv.y) + (xv.z + xv.w);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mu = s * (1.0f / 256.0f);
+    const float d0 = xv.x - mu, d1 = xv.y - mu, d2 = xv.z - mu, d3 = xv.w - mu;
+    float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + eps);
+    const float xh[4] = {d0 * rstd, d1 * rstd, d2 * rstd, d3 * rstd};
+    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+    float a = 0.0f, b = 0.0f, w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dyi = dv[i] * rs;
+      dg[i] += dyi * xh[i];
+      db[i] += dyi;
+      w[i] = dyi * gmv[i];
+      a += w[i];
+      b += w[i] * xh[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      b += __shfl_xor(b, off, 64);
+    }
+    a *= (1.0f / 256.0f);
+    b *= (1.0f / 256.0f);
+    float* gp = g + row * ldg + lane * 4;
+    float4 o = accumulate ? *reinterpret_cast<const float4*>(gp) : make_float4(0, 0, 0, 0);
+    o.x += rstd * (w[0] - a - xh[0] * b);
+    o.y += rstd * (w[1] - a - xh[1] * b);
+    o.z += rstd * (w[2] - a - xh[2] * b);
+    o.w += rstd * (w[3] - a - xh[3] * b);
+    *reinterpret_cast<float4*>(gp) = o;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    red[0][wave][lane * 4 + i] = dg[i];
+    red[1][wave][lane * 4 + i] = db[i];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+  atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+}
+
+// ---- Swish + dropout between w_1 and w_2 -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_dropout_fwd_kernel(const uint16_t* __restrict__ u, uint16_t* __restrict__ h,
+                                                              int64_t n, Drop d) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = bf2f(u[i]);
+    float r = v * sigmoidf_(v);
+    if (d.thresh) r = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? r * d.inv_keep : 0.0f;
+    h[i] = f2bf(r);
+  }
+}
+// du = dh * keep / (1 - p) * swish'(u),  swish'(u) = s + u s (1 - s)
+__global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ dh,
+                                                              uint16_t* __restrict__ du, int64_t n, Drop d) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = bf2f(u[i]);
+    const float s = sigmoidf_(v);
+    float gr = bf2f(dh[i]) * (s + v * s * (1.0f - s));
+    if (d.thresh) gr = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? gr * d.inv_keep : 0.0f;
+    du[i] = f2bf(gr);
+  }
+}
+
+// x[r][c] += alpha * dropout(y[r][c]); y bf16 or f32 with row stride ldy; element index = r * cols + c
+template <bool Y_BF16>
+__global__ __launch_bounds__(256) void dropout_add_kernel(float* __restrict__ x, int64_t ldx, const void* y_, int64_t ldy,
+                                                          int64_t rows, int cols, float alpha, Drop d) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    float v = Y_BF16 ? bf2f(reinterpret_cast<const uint16_t*>(y_)[r * ldy + c]) : reinterpret_cast<const float*>(y_)[r * ldy + c];
+    if (d.thresh) v = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? v * d.inv_keep : 0.0f;
+    x[r * ldx + c] += alpha * v;
+  }
+}
+// dy = alpha * keep / (1 - p) * g * row_scale  (bf16 operand of the branch's last GEMM backward)
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ g, int64_t ldg, uint16_t* __restrict__ dy,
+                                                          int64_t ldy, int64_t rows, int cols, float alpha,
+                                                          const float* __restrict__ row_scale, Drop d) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    float v = g[r * ldg + c] * alpha;
+    if (row_scale) v *= row_scale[r];
+    if (d.thresh) v = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? v * d.inv_keep : 0.0f;
+    dy[r * ldy + c] = f2bf(v);
+  }
+}
+
+// ---- convolution module, training mode --------------------------------------------------------------------------
+// z[b,t,c] = bias[c] + sum_j w[c][j] * glu(y)[b, t + j - pad, c] (zero outside [0, T)), float32; per-channel sums of z
+// and z^2 for the batch statistics.  Thread = (row, 4 channels).
+__global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const uint16_t* __restrict__ y, int64_t ldy, int T, int C,
+                                                                int ks, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ z,
+                                                                int64_t rows, float* sums) {
+  extern __shared__ float lsum[];  // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) lsum[i] = 0.0f;
+  __syncthreads();
+  const int cg = C / 4, pad = (ks - 1) / 2;
+  const int64_t total = rows * cg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cg;
+    const int c = (int)(i - row * cg) * 4;
+    const int t = (int)(row % T);
+    float acc[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
+    for (int j = 0; j < ks; ++j) {
+      const int tt = t + j - pad;
+      if (tt < 0 || tt >= T) continue;
+      const uint16_t* yp = y + (row + j - pad) * ldy + c;
+      const uint2 a = *reinterpret_cast<const uint2*>(yp);
+      const uint2 gt = *reinterpret_cast<const uint2*>(yp + C);
+      const float av[4] = {__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+      const float gv[4] = {__uint_as_float(gt.x << 16), __uint_as_float(gt.x & 0xffff0000u), __uint_as_float(gt.y << 16), __uint_as_float(gt.y & 0xffff0000u)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[(c + q) * ks + j], av[q] * sigmoidf_(gv[q]), acc[q]);
+    }
+    *reinterpret_cast<float4*>(z + row * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(&lsum[c + q], acc[q]);
+      atomicAdd(&lsum[C + c + q], acc[q] * acc[q]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(sums + i, lsum[i]);
+}
+
+// stats[c] = mean, stats[C + c] = rstd (biased variance, nn.BatchNorm1d training mode); running statistics updated
+// with the unbiased variance: running = (1 - momentum) * running + momentum * batch.
+__global__ void bn_finalize_kernel(const float* sums, int C, float count, float eps, float momentum, float* run_mean,
+                                   float* run_var, float* stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = sums[c] / count;
+  float var = sums[C + c] / count - mean * mean;
+  var = var < 0.0f ? 0.0f : var;
+  stats[c] = mean;
+  stats[C + c] = 1.0f / sqrtf(var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * (count / fmaxf(count - 1.0f, 1.0f));
+  }
+}
+
+// out = swish(gamma * (z - mean) * rstd + beta) as bf16
+__global__ __launch_bounds__(256) void bn_swish_fwd_kernel(const float* __restrict__ z, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           uint16_t* __restrict__ out, int64_t rows, int C) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float nv = gamma[c] * (z[i] - stats[c]) * stats[C + c] + beta[c];
+    out[i] = f2bf(nv * sigmoidf_(nv));
+  }
+}
+
+// dn = dout * swish'(n) (float32, stored) and the BatchNorm reductions dsum[c] = sum dn, dsum[C + c] = sum dn * zhat
+__global__ __launch_bounds__(256) void bn_swish_bwd1_kernel(const uint16_t* __restrict__ dout, const float* __restrict__ z,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ dn,
+                                                            int64_t rows, int C, float* dsum) {
+  extern __shared__ float lsum[];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) lsum[i] = 0.0f;
+  __syncthreads();
+  // thread owns channel c = tid % C... keep a fixed channel per thread so the sums stay in registers
+  const int c = threadIdx.x % C;
+  const int rpb = 256 / C > 0 ? 256 / C : 1;  // rows per pass of this block (C = 256 -> 1)
+  const int rsub = threadIdx.x / C;
+  float s0 = 0.0f, s1 = 0.0f;
+  for (int64_t row = (int64_t)blockIdx.x * rpb + rsub; row < rows; row += (int64_t)gridDim.x * rpb) {
+    if (rsub >= rpb) break;
+    const int64_t i = row * C + c;
+    const float zh = (z[i] - stats[c]) * stats[C + c];
+    const float nv = gamma[c] * zh + beta[c];
+    const float s = sigmoidf_(nv);
+    const float d = bf2f(dout[i]) * (s + nv * s * (1.0f - s));
+    dn[i] = d;
+    s0 += d;
+    s1 += d * zh;
+  }
+  atomicAdd(&lsum[c], s0);
+  atomicAdd(&lsum[C + c], s1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dsum + i, lsum[i]);
+}
+
+// dz = gamma * rstd * (dn - dsum0 / N - zhat * dsum1 / N), in place over dn
+__global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ dn, const float* __restrict__ z,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ dsum, int64_t rows, int C, float inv_count) {
+  const int64_t n = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float zh = (z[i] - stats[c]) * stats[C + c];
+    dn[i] = gamma[c] * stats[C + c] * (dn[i] - dsum[c] * inv_count - zh * dsum[C + c] * inv_count);
+  }
+}
+
+// Depthwise-conv + GLU backward.  ds[t] = sum_j w[c][j] dz[t - (j - pad)]; dy = (ds * sig(g), ds * a * sig(g)(1 - sig(g)));
+// dw[c][j] += sum_t dz[t] * s[t + j - pad], db[c] += sum_t dz[t].  One thread = one (b, c) x time strip.
+template <int KS>
+__global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ y,
+                                                          int64_t ldy, int B, int T, int C,
+                                                          const float* __restrict__ w, uint16_t* __restrict__ dy,
+                                                          int64_t lddy, float* dw, float* db, int strip) {
+  // grid: (ceil(T / strip), B, C / 256); thread = channel
+  const int c = blockIdx.z * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * strip, t1 = min(T, t0 + strip);
+  constexpr int ks = KS, pad = (KS - 1) / 2;
+  float wr[KS], dwr[KS];
+#pragma unroll
+  for (int j = 0; j < ks; ++j) { wr[j] = w[c * ks + j]; dwr[j] = 0.0f; }
+  float dbr = 0.0f;
+  const int64_t base = (int64_t)b * T;
+  for (int t = t0; t < t1; ++t) {
+    const float dzt = dz[(base + t) * C + c];
+    dbr += dzt;
+    float ds = 0.0f;
+#pragma unroll
+    for (int j = 0; j < ks; ++j) {
+      const int tz = t - (j - pad);  // z[tz] used s[t] with tap j
+      if (tz >= 0 && tz < T) ds = fmaf(wr[j], dz[(base + tz) * C + c], ds);
+      const int tsrc = t + j - pad;  // z[t] used s[tsrc] with tap j
+      if (tsrc >= 0 && tsrc < T) {
+        const uint16_t* yp = y + (base + tsrc) * ldy + c;
+        dwr[j] = fmaf(dzt, bf2f(yp[0]) * sigmoidf_(bf2f(yp[C])), dwr[j]);
+      }
+    }
+    const uint16_t* yp = y + (base + t) * ldy + c;
+    const float a = bf2f(yp[0]), sg = sigmoidf_(bf2f(yp[C]));
+    dy[(base + t) * lddy + c] = f2bf(ds * sg);
+    dy[(base + t) * lddy + C + c] = f2bf(ds * a * sg * (1.0f - sg));
+  }
+#pragma unroll
+  for (int j = 0; j < ks; ++j) atomicAdd(dw + c * ks + j, dwr[j]);
+  atomicAdd(db + c, dbr);
+}
+
+// ---- subsampling backward ---------------------------------------------------------------------------------------
+// dy *= (y > 0), bf16 in place
+__global__ __launch_bounds__(256) void relu_bwd_kernel(uint16_t* __restrict__ dy, const uint16_t* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (!(bf2f(y[i]) > 0.0f)) dy[i] = 0;
+}
+
+// colT[(kh, kw, c)][m] = act[b, 2 ho + kh, 2 wo + kw, c], m = (b, ho, wo): the transposed im2col matrix of the 3x3
+// stride-2 valid convolution over NHWC bf16, written with m contiguous (row stride ld_out).
+__global__ __launch_bounds__(256) void im2col_t_kernel(const uint16_t* __restrict__ act, int H, int Wd, int C, int Ho, int Wo,
+                                                       int64_t M, uint16_t* __restrict__ out, int64_t ld_out) {
+  __shared__ uint16_t tile[64][66];
+  const int khw = blockIdx.z, kh = khw / 3, kw = khw - 3 * kh;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t m = m0 + r;
+    uint16_t v = 0;
+    if (m < M && c0 + tx < C) {
+      const int wo = (int)(m % Wo);
+      const int64_t t = m / Wo;
+      const int ho = (int)(t % Ho);
+      const int64_t b = t / Ho;
+      v = act[((b * H + 2 * ho + kh) * Wd + 2 * wo + kw) * C + c0 + tx];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int64_t m = m0 + tx;
+    if (c0 + c < C && m < M) out[((int64_t)khw * C + c0 + c) * ld_out + m] = tile[tx][c];
+  }
+}
+
+// dact[b, h, w, c] = relu'(act) * sum over the (<= 4) windows (ho, kh), (wo, kw) containing (h, w) of
+// dcol[(b, ho, wo)][(kh, kw, c)]
+__global__ __launch_bounds__(256) void col2im_relu_kernel(const uint16_t* __restrict__ dcol, const uint16_t* __restrict__ act,
+                                                          int B, int H, int Wd, int C, int Ho, int Wo,
+                                                          uint16_t* __restrict__ dact) {
+  const int64_t n = (int64_t)B * H * Wd * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int w = (int)(t % Wd);
+    t /= Wd;
+    const int h = (int)(t % H);
+    const int64_t b = t / H;
+    float acc = 0.0f;
+    if (bf2f(act[i]) > 0.0f) {
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h - kh;
+        if (hh < 0 || (hh & 1) || hh / 2 >= Ho) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ww = w - kw;
+          if (ww < 0 || (ww & 1) || ww / 2 >= Wo) continue;
+          const int64_t m = (b * Ho + hh / 2) * Wo + ww / 2;
+          acc += bf2f(dcol[m * (9 * C) + (kh * 3 + kw) * C + c]);
+        }
+      }
+    }
+    dact[i] = f2bf(acc);
+  }
+}
+
+// conv1 (1 -> C channels, 3x3 stride 2) weight gradient: dw[c][kh*3+kw] = sum_{b,h1,w1} dact[b,h1,w1,c] * xin[b, 2 h1 + kh, 2 w1 + kw],
+// db[c] = sum dact; xin = (x - mean) * istd when CMVN is on.  Block = 256 channels x a strip of output positions.
+__global__ __launch_bounds__(256) void conv1_dw_kernel(const uint16_t* __restrict__ dact, const float* __restrict__ x, int B,
+                                                       int T, int idim, int H1, int W1, int C,
+                                                       const float* __restrict__ cm_mean, const float* __restrict__ cm_istd,
+                                                       float* dw, float* db, int strip) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int64_t npos = (int64_t)B * H1 * W1;
+  const int64_t p0 = (int64_t)blockIdx.x * strip, p1 = min(npos, p0 + (int64_t)strip);
+  float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, accb = 0.0f;
+  for (int64_t pidx = p0; pidx < p1; ++pidx) {
+    const int w1 = (int)(pidx % W1);
+    const int64_t t = pidx / W1;
+    const int h1 = (int)(t % H1);
+    const int64_t b = t / H1;
+    const float d = c < C ? bf2f(dact[pidx * C + c]) : 0.0f;
+    accb += d;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int f = 2 * w1 + kw;
+        float xv = x[(b * T + 2 * h1 + kh) * idim + f];
+        if (cm_mean) xv = (xv - cm_mean[f]) * cm_istd[f];
+        acc[kh * 3 + kw] = fmaf(d, xv, acc[kh * 3 + kw]);
+      }
+  }
+  if (c < C) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) atomicAdd(dw + c * 9 + k, acc[k]);
+    atomicAdd(db + c, accb);
+  }
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void overflow_kernel(const float* __restrict__ g, int64_t n, int32_t* flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t u = __float_as_uint(g[i]);
+    bad |= (u & 0x7f800000u) == 0x7f800000u;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// nn.Adam (MindSpore): m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr_t * m / (sqrt(v) + eps),
+// lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) folded by the host into `lr_t`.  g is divided by `inv_scale`-1 first (loss
+// scale and world size); the whole update is skipped when *overflow != 0 (train_one_step.py:40-47).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps,
+                                                   float inv_scale, const int32_t* overflow) {
+  if (overflow && *overflow) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * inv_scale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+static int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  return g < 1 ? 1 : (int)g;
+}
+
+static Drop make_drop(float p, uint32_t seed, uint32_t salt) {
+  Drop d;
+  d.seed = seed;
+  d.salt = salt;
+  if (!(p > 0.0f)) {
+    d.thresh = 0;
+    d.inv_keep = 1.0f;
+  } else {
+    double th = (double)p * 4294967296.0;
+    d.thresh = th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th;
+    d.inv_keep = 1.0f / (1.0f - p);
+  }
+  return d;
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int ma_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols, void* out, int64_t ld_out,
+                      float* colsum, ma_stream_t stream) {
+  if (!in || !out || rows < 1 || cols < 1 || ld_in < cols || ld_out < rows || rows > 0x7fffffff || cols > 0x7fffffff)
+    return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(transpose_bf16_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64)), dim3(256), 0,
+            (hipStream_t)stream, (const uint16_t*)in, ld_in, (int)rows, (int)cols, (uint16_t*)out, ld_out, colsum);
+  return MA_OK;
+}
+
+int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
+                         const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
+                         int32_t accumulate, float* dgamma, float* dbeta, ma_stream_t stream) {
+  if (!x || !gamma || !dy || !g || !dgamma || !dbeta || rows < 1) return MA_ERR_INVALID_ARG;
+  if (D != 256 || (ldx & 3) || (ldy & 3) || (ldg & 3)) return MA_ERR_UNSUPPORTED;
+  const int grid = grid_for(rows, 4, 1024);
+  if (dy_bf16)
+    MA_LAUNCH(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
+              row_scale, dy, ldy, g, ldg, accumulate, dgamma, dbeta);
+  else
+    MA_LAUNCH(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
+              row_scale, dy, ldy, g, ldg, accumulate, dgamma, dbeta);
+  return MA_OK;
+}
+
+int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
+  if (!u || !h || n < 1 || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(act_dropout_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u,
+            (uint16_t*)h, n, make_drop(p, seed, salt));
+  return MA_OK;
+}
+
+int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, float p, uint32_t seed, uint32_t salt,
+                            ma_stream_t stream) {
+  if (!u || !dh || !du || n < 1 || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(act_dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u,
+            (const uint16_t*)dh, (uint16_t*)du, n, make_drop(p, seed, salt));
+  return MA_OK;
+}
+
+int ma_dropout_add_f32(float* x, int64_t ldx, const void* y, int64_t ldy, int32_t y_bf16, int64_t rows, int64_t cols,
+                       float alpha, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
+  if (!x || !y || rows < 1 || cols < 1 || ldx < cols || ldy < cols || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+  const Drop d = make_drop(p, seed, salt);
+  if (y_bf16)
+    MA_LAUNCH(dropout_add_kernel<true>, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+              rows, (int)cols, alpha, d);
+  else
+    MA_LAUNCH(dropout_add_kernel<false>, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+              rows, (int)cols, alpha, d);
+  return MA_OK;
+}
+
+int ma_dropout_bwd_bf16(const float* g, int64_t ldg, void* dy, int64_t ldy, int64_t rows, int64_t cols, float alpha,
+                        const float* row_scale, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
+  if (!g || !dy || rows < 1 || cols < 1 || ldg < cols || ldy < cols || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(dropout_bwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, g, ldg, (uint16_t*)dy,
+            ldy, rows, (int)cols, alpha, row_scale, make_drop(p, seed, salt));
+  return MA_OK;
+}
+
+int ma_convmid_fwd_train(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
+                         int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
+  if (!y || !dw_w || !dw_b || !z || !sums || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
+  if (C < 4 || (C & 3) || ks < 1 || ks > 31 || !(ks & 1) || (ldy & 3) || C > 1024) return MA_ERR_UNSUPPORTED;
+  const int64_t rows = batch * T;
+  MA_LAUNCH(convmid_fwd_train_kernel, dim3(grid_for(rows * (C / 4), 256, 2048)), dim3(256), 2 * C * sizeof(float),
+            (hipStream_t)stream, (const uint16_t*)y, ldy, (int)T, C, ks, dw_w, dw_b, z, rows, sums);
+  return MA_OK;
+}
+
+int ma_bn_finalize_f32(const float* sums, int32_t C, int64_t count, float eps, float momentum, float* running_mean,
+                       float* running_var, float* stats, ma_stream_t stream) {
+  if (!sums || !stats || C < 1 || count < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, (float)count, eps,
+            momentum, running_mean, running_var, stats);
+  return MA_OK;
+}
+
+int ma_bn_swish_fwd_bf16(const float* z, const float* stats, const float* gamma, const float* beta, void* out,
+                         int64_t rows, int32_t C, ma_stream_t stream) {
+  if (!z || !stats || !gamma || !beta || !out || rows < 1 || C < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(bn_swish_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, z, stats, gamma, beta,
+            (uint16_t*)out, rows, C);
+  return MA_OK;
+}
+
+int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
+                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream) {
+  if (!dout || !z || !stats || !gamma || !beta || !dz || !dsum || rows < 1) return MA_ERR_INVALID_ARG;
+  if (C < 1 || C > 256 || 256 % C) return MA_ERR_UNSUPPORTED;
+  const int rpb = 256 / C;
+  MA_LAUNCH(bn_swish_bwd1_kernel, dim3(grid_for(rows, rpb, 1024)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+            (const uint16_t*)dout, z, stats, gamma, beta, dz, rows, C, dsum);
+  MA_LAUNCH(bn_bwd2_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dz, z, stats, gamma, dsum, rows,
+            C, 1.0f / (float)rows);
+  return MA_OK;
+}
+
+int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
+                        const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
+                        ma_stream_t stream) {
+  if (!dz || !y || !dw_w || !dy || !d_dw_w || !d_dw_b || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
+  if (C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
+  const int strip = 32;
+  const dim3 grid((unsigned)((T + strip - 1) / strip), (unsigned)batch, (unsigned)(C / 256));
+#define MA_CMB(KS_)                                                                                                  \
+  MA_LAUNCH(convmid_bwd_kernel<KS_>, grid, dim3(256), 0, (hipStream_t)stream, dz, (const uint16_t*)y, ldy, (int)batch, \
+            (int)T, C, dw_w, (uint16_t*)dy, lddy, d_dw_w, d_dw_b, strip)
+  if (ks == 3) MA_CMB(3);
+  else if (ks == 7) MA_CMB(7);
+  else if (ks == 15) MA_CMB(15);
+  else MA_CMB(31);
+#undef MA_CMB
+  return MA_OK;
+}
+
+int ma_relu_bwd_bf16(void* dy, const void* y, int64_t n, ma_stream_t stream) {
+  if (!dy || !y || n < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dy, (const uint16_t*)y, n);
+  return MA_OK;
+}
+
+int ma_im2col_t_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, void* out,
+                                int64_t ld_out, ma_stream_t stream) {
+  if (!act || !out || batch < 1 || H < 3 || Wd < 3 || C < 1) return MA_ERR_INVALID_ARG;
+  const int Ho = (int)((H - 3) / 2 + 1), Wo = (int)((Wd - 3) / 2 + 1);
+  const int64_t M = batch * Ho * Wo;
+  if (ld_out < M) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(im2col_t_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((C + 63) / 64), 9), dim3(256), 0,
+            (hipStream_t)stream, (const uint16_t*)act, (int)H, (int)Wd, (int)C, Ho, Wo, M, (uint16_t*)out, ld_out);
+  return MA_OK;
+}
+
+int ma_col2im_3x3s2_relu_bf16(const void* dcol, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
+                              void* dact, ma_stream_t stream) {
+  if (!dcol || !act || !dact || batch < 1 || H < 3 || Wd < 3 || C < 1) return MA_ERR_INVALID_ARG;
+  const int Ho = (int)((H - 3) / 2 + 1), Wo = (int)((Wd - 3) / 2 + 1);
+  MA_LAUNCH(col2im_relu_kernel, dim3(grid_for(batch * H * Wd * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+            (const uint16_t*)dcol, (const uint16_t*)act, (int)batch, (int)H, (int)Wd, (int)C, Ho, Wo, (uint16_t*)dact);
+  return MA_OK;
+}
+
+int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, int64_t T, int32_t idim,
+                              const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
+                              ma_stream_t stream) {
+  if (!dact || !x || !dw || !db || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
+  const int H1 = (int)((T - 3) / 2 + 1), W1 = (idim - 3) / 2 + 1;
+  const int64_t npos = batch * H1 * W1;
+  const int strip = 256;
+  MA_LAUNCH(conv1_dw_kernel, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,
+            (hipStream_t)stream, (const uint16_t*)dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, dw,
+            db, strip);
+  return MA_OK;
+}
+
+int ma_grad_overflow_f32(const float* g, int64_t n, int32_t* flag, ma_stream_t stream) {
+  if (!g || !flag || n < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(overflow_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, g, n, flag);
+  return MA_OK;
+}
+
+int ma_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                float eps, float inv_scale, const int32_t* overflow, ma_stream_t stream) {
+  if (!param || !grad || !m || !v || n < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t,
+            beta1, beta2, eps, inv_scale, overflow);
+  return MA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+"""Python wrappers over the training C-ABI entry points (include/mindaudio_amd.h, "training step" section).
+Tensors are torch HIP tensors used as device buffers; all arithmetic happens in the HIP kernels."""
+from .. import _host, _lib
+
+
+def _t():
+    return _host.torch()
+
+
+def _s():
+    return _host.current_stream_ptr()
+
+
+def _p(x):
+    return _host.ptr(x) if x is not None else None
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def transpose(x, out=None, colsum=None):
+    """x (rows, cols) bf16 -> (cols, pad64(rows)) bf16 with zero padding (a K-padded GEMM operand)."""
+    t = _t()
+    rows, cols = x.shape
+    if out is None:
+        out = t.zeros((cols, pad64(rows)), dtype=t.bfloat16, device=x.device)
+    _lib.check(_lib.load().ma_transpose_bf16(_p(x), x.stride(0), rows, cols, _p(out), out.stride(0), _p(colsum), _s()),
+               "transpose")
+    return out
+
+
+def gemm_splitk(a, w, out, alpha=1.0):
+    """out (M, N) f32 += alpha * a (M, K) @ w (N, K)^T."""
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and tuple(out.shape) == (m, n) and out.dtype == _t().float32
+    _lib.check(_lib.load().ma_gemm_bf16_splitk_f32(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), m, n,
+                                                   k, float(alpha), _s()), "gemm_splitk")
+    return out
+
+
+def layernorm_bwd(x, gamma, dy, g, dgamma, dbeta, row_scale=None, accumulate=True, eps=1e-5):
+    t = _t()
+    _lib.check(_lib.load().ma_layernorm_bwd_f32(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(gamma), float(eps),
+                                                _p(row_scale), _p(dy), dy.stride(0), 1 if dy.dtype == t.bfloat16 else 0,
+                                                _p(g), g.stride(0), 1 if accumulate else 0, _p(dgamma), _p(dbeta), _s()),
+               "layernorm_bwd")
+    return g
+
+
+def act_dropout_fwd(u, p, seed, salt):
+    h = _t().empty_like(u)
+    _lib.check(_lib.load().ma_act_dropout_fwd_bf16(_p(u), _p(h), u.numel(), float(p), seed, salt, _s()), "act_dropout")
+    return h
+
+
+def act_dropout_bwd(u, dh, p, seed, salt, out=None):
+    du = out if out is not None else _t().empty_like(u)
+    _lib.check(_lib.load().ma_act_dropout_bwd_bf16(_p(u), _p(dh), _p(du), u.numel(), float(p), seed, salt, _s()),
+               "act_dropout_bwd")
+    return du
+
+
+def dropout_add(x, y, alpha, p, seed, salt):
+    t = _t()
+    _lib.check(_lib.load().ma_dropout_add_f32(_p(x), x.stride(0), _p(y), y.stride(0), 1 if y.dtype == t.bfloat16 else 0,
+                                              x.shape[0], x.shape[1], float(alpha), float(p), seed, salt, _s()),
+               "dropout_add")
+    return x
+
+
+def dropout_bwd(g, alpha, p, seed, salt, row_scale=None):
+    t = _t()
+    dy = t.empty(g.shape, dtype=t.bfloat16, device=g.device)
+    _lib.check(_lib.load().ma_dropout_bwd_bf16(_p(g), g.stride(0), _p(dy), dy.stride(0), g.shape[0], g.shape[1],
+                                               float(alpha), _p(row_scale), float(p), seed, salt, _s()), "dropout_bwd")
+    return dy
+
+
+def convmid_fwd_train(y, batch, T, dw_w, dw_b, gamma, beta, run_mean, run_var, eps=1e-5, momentum=0.1):
+    """y (B*T, 2C) bf16 -> (out bf16 (B*T, C), z f32, stats f32 (2C)); updates the running statistics in place."""
+    t = _t()
+    lib = _lib.load()
+    c, ks = dw_w.shape
+    rows = batch * T
+    z = t.empty((rows, c), dtype=t.float32, device=y.device)
+    sums = t.zeros(2 * c, dtype=t.float32, device=y.device)
+    stats = t.empty(2 * c, dtype=t.float32, device=y.device)
+    out = t.empty((rows, c), dtype=t.bfloat16, device=y.device)
+    _lib.check(lib.ma_convmid_fwd_train(_p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dw_b), _p(z), _p(sums), _s()),
+               "convmid_fwd_train")
+    _lib.check(lib.ma_bn_finalize_f32(_p(sums), c, rows, float(eps), float(momentum), _p(run_mean), _p(run_var),
+                                      _p(stats), _s()), "bn_finalize")
+    _lib.check(lib.ma_bn_swish_fwd_bf16(_p(z), _p(stats), _p(gamma), _p(beta), _p(out), rows, c, _s()), "bn_swish_fwd")
+    return out, z, stats
+
+
+def convmid_bwd(dout, y, z, stats, batch, T, dw_w, gamma, beta, d_dw_w, d_dw_b, d_gamma, d_beta):
+    """dout (B*T, C) bf16 -> dy (B*T, 2C) bf16; parameter gradients accumulate into the given float32 buffers."""
+    t = _t()
+    lib = _lib.load()
+    c, ks = dw_w.shape
+    rows = batch * T
+    dz = t.empty((rows, c), dtype=t.float32, device=y.device)
+    dsum = t.zeros(2 * c, dtype=t.float32, device=y.device)
+    _lib.check(lib.ma_bn_swish_bwd_f32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _s()),
+               "bn_swish_bwd")
+    d_beta += dsum[:c]
+    d_gamma += dsum[c:]
+    dy = t.empty((rows, 2 * c), dtype=t.bfloat16, device=y.device)
+    _lib.check(lib.ma_convmid_bwd_bf16(_p(dz), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dy), dy.stride(0),
+                                       _p(d_dw_w), _p(d_dw_b), _s()), "convmid_bwd")
+    return dy
+
+
+def relu_bwd(dy, y):
+    _lib.check(_lib.load().ma_relu_bwd_bf16(_p(dy), _p(y), dy.numel(), _s()), "relu_bwd")
+    return dy
+
+
+def im2col_t(act):
+    """act (B, H, W, C) bf16 NHWC -> (9C, pad64(B*Ho*Wo)) bf16."""
+    t = _t()
+    b, h, w, c = act.shape
+    m = b * ((h - 3) // 2 + 1) * ((w - 3) // 2 + 1)
+    out = t.zeros((9 * c, pad64(m)), dtype=t.bfloat16, device=act.device)
+    _lib.check(_lib.load().ma_im2col_t_3x3s2_nhwc_bf16(_p(act), b, h, w, c, _p(out), out.stride(0), _s()), "im2col_t")
+    return out
+
+
+def col2im_relu(dcol, act):
+    dact = _t().empty_like(act)
+    b, h, w, c = act.shape
+    _lib.check(_lib.load().ma_col2im_3x3s2_relu_bf16(_p(dcol), _p(act), b, h, w, c, _p(dact), _s()), "col2im")
+    return dact
+
+
+def conv1_dw(dact, x, cmvn_mean, cmvn_istd, dw, db):
+    b, tt, idim = x.shape
+    _lib.check(_lib.load().ma_subsample_conv1_dw_f32(_p(dact), _p(x), b, tt, idim, _p(cmvn_mean), _p(cmvn_istd),
+                                                     dact.shape[-1], _p(dw), _p(db), _s()), "conv1_dw")
+
+
+def grad_overflow(g, flag):
+    _lib.check(_lib.load().ma_grad_overflow_f32(_p(g), g.numel(), _p(flag), _s()), "grad_overflow")
+
+
+def adam(param, grad, m, v, lr_t, beta1, beta2, eps, inv_scale, overflow=None):
+    _lib.check(_lib.load().ma_adam_f32(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr_t), float(beta1),
+                                       float(beta2), float(eps), float(inv_scale), _p(overflow), _s()), "adam")

@@ -1,0 +1,209 @@
+"""GPU parity of the training-step kernels (mindaudio_amd/csrc/train_kernels.hip) against float32 PyTorch-CPU
+restatements of the same formulas (autograd of the oracle's layer definitions)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available()
+    from mindaudio_amd.train import kernels
+
+    return kernels
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel(got, want):
+    return float((got.float().cpu() - want).norm() / (want.norm() + 1e-30))
+
+
+def test_transpose_and_colsum(K):
+    g = torch.Generator().manual_seed(0)
+    for rows, cols in ((130, 72), (64, 64), (1000, 4233), (7, 256)):
+        x = bf(torch.randn(rows, cols, generator=g))
+        cs = torch.zeros(cols, device="cuda")
+        out = K.transpose(x.cuda(), colsum=cs)
+        assert out.shape == (cols, K.pad64(rows))
+        assert torch.equal(out[:, :rows].cpu(), x.t())
+        assert float(out[:, rows:].abs().sum()) == 0.0
+        assert rel(cs, x.float().sum(0)) < 1e-5
+
+
+def test_gemm_splitk(K):
+    g = torch.Generator().manual_seed(1)
+    for m, n, k in ((256, 256, 10240), (2048, 256, 4096), (100, 300, 640), (256, 2304, 64 * 300)):
+        a, w = bf(torch.randn(m, k, generator=g)), bf(torch.randn(n, k, generator=g))
+        out = torch.zeros(m, n, device="cuda")
+        K.gemm_splitk(a.cuda(), w.cuda(), out, alpha=0.5)
+        want = 0.5 * (a.float() @ w.float().t())
+        assert rel(out, want) < 2e-5
+
+
+def test_layernorm_bwd(K):
+    from mindaudio_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    rows = 1001
+    x = (torch.randn(rows, 256, generator=g) * 2 + 0.3).requires_grad_()
+    gamma = (1 + 0.1 * torch.randn(256, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(256, generator=g)).requires_grad_()
+    rs = (torch.rand(rows, generator=g) > 0.2).float()
+    dy = torch.randn(rows, 256, generator=g)
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    y = ((x - mu) / torch.sqrt(var + 1e-5) * gamma + beta) * rs[:, None]
+    y.backward(dy)
+    for dy_dev in (dy.cuda(), bf(dy).cuda()):
+        g0 = torch.randn(rows, 256, generator=g)
+        gbuf = g0.clone().cuda()
+        dg, db = torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")
+        K.layernorm_bwd(x.detach().cuda(), gamma.detach().cuda(), dy_dev, gbuf, dg, db, row_scale=rs.cuda())
+        tol = 1e-5 if dy_dev.dtype == torch.float32 else 4e-3
+        assert rel(gbuf, g0 + x.grad) < tol
+        assert rel(dg, gamma.grad) < tol and rel(db, beta.grad) < tol
+    # in place (dy is g itself, no accumulation)
+    gbuf = dy.clone().cuda()
+    K.layernorm_bwd(x.detach().cuda(), gamma.detach().cuda(), gbuf, gbuf, torch.zeros(256, device="cuda"),
+                    torch.zeros(256, device="cuda"), row_scale=rs.cuda(), accumulate=False)
+    assert rel(gbuf, x.grad) < 1e-5
+
+
+def test_act_dropout_and_dropout_add(K):
+    g = torch.Generator().manual_seed(3)
+    u = bf(torch.randn(300, 2048, generator=g) * 2)
+    for p in (0.0, 0.1):
+        h = K.act_dropout_fwd(u.cuda(), p, 77, 5).float().cpu()
+        sw = u.float() * torch.sigmoid(u.float())
+        keep = (h != 0) | (sw.abs() < 1e-30)
+        if p == 0.0:
+            assert rel(h, bf(sw).float()) < 1e-6
+        else:
+            frac = 1.0 - keep.float().mean().item()
+            assert abs(frac - p) < 0.01
+            assert rel(h[keep], bf(sw / (1 - p)).float()[keep]) < 4e-3
+        dh = bf(torch.randn(300, 2048, generator=g))
+        du = K.act_dropout_bwd(u.cuda(), dh.cuda(), p, 77, 5).float().cpu()
+        s = torch.sigmoid(u.float())
+        want = dh.float() * (s + u.float() * s * (1 - s)) * keep.float() / (1 - p)
+        assert rel(du, want) < 4e-3
+        # same (seed, salt) -> same mask; a different salt decorrelates
+        h2 = K.act_dropout_fwd(u.cuda(), p, 77, 6).float().cpu()
+        if p > 0:
+            assert ((h2 != 0) != (h != 0)).float().mean() > 0.1
+    x = torch.randn(257, 256, generator=g)
+    y = torch.randn(257, 256, generator=g)
+    for yy in (y, bf(y)):
+        xd = x.clone().cuda()
+        K.dropout_add(xd, yy.cuda(), 0.5, 0.1, 9, 3)
+        delta = (xd.cpu() - x) / 0.5
+        keep = delta != 0
+        assert abs(1 - keep.float().mean().item() - 0.1) < 0.02
+        assert rel(delta[keep], (yy.float() / 0.9)[keep]) < 1e-5
+        gg = torch.randn(257, 256, generator=g)
+        rs = (torch.rand(257, generator=g) > 0.3).float()
+        dy = K.dropout_bwd(gg.cuda(), 0.5, 0.1, 9, 3, row_scale=rs.cuda()).float().cpu()
+        assert rel(dy, bf(0.5 * gg * keep.float() / 0.9 * rs[:, None]).float()) < 1e-6
+
+
+def test_convmid_train_fwd_bwd(K):
+    g = torch.Generator().manual_seed(4)
+    b, t, c, ks = 3, 37, 256, 15
+    y = bf(torch.randn(b * t, 2 * c, generator=g))
+    dw_w = (0.3 * torch.randn(c, ks, generator=g)).requires_grad_()
+    dw_b = (0.1 * torch.randn(c, generator=g)).requires_grad_()
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(c, generator=g)).requires_grad_()
+    yf = y.float().requires_grad_()
+    a, gate = yf[:, :c], yf[:, c:]
+    s = (a * torch.sigmoid(gate)).view(b, t, c).transpose(1, 2)
+    z = F.conv1d(s, dw_w[:, None, :], dw_b, padding=ks // 2, groups=c).transpose(1, 2).reshape(b * t, c)
+    bn = torch.nn.BatchNorm1d(c, eps=1e-5, momentum=0.1)
+    bn.weight.data, bn.bias.data = gamma.detach().clone(), beta.detach().clone()
+    bn.train()
+    n = bn(z)
+    out = n * torch.sigmoid(n)
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    o_d, z_d, st = K.convmid_fwd_train(y.cuda(), b, t, dw_w.detach().cuda(), dw_b.detach().cuda(), gamma.detach().cuda(),
+                                       beta.detach().cuda(), rm, rv)
+    assert rel(z_d, z.detach()) < 1e-5
+    assert rel(o_d, out.detach()) < 4e-3
+    assert rel(rm, bn.running_mean) < 1e-4 and rel(rv, bn.running_var) < 1e-4
+    dout = bf(torch.randn(b * t, c, generator=g))
+    out.backward(dout.float())
+    dws, dbs = torch.zeros(c, ks, device="cuda"), torch.zeros(c, device="cuda")
+    dgs, dbe = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    dy = K.convmid_bwd(dout.cuda(), y.cuda(), z_d, st, b, t, dw_w.detach().cuda(), gamma.detach().cuda(),
+                       beta.detach().cuda(), dws, dbs, dgs, dbe)
+    assert rel(dy, yf.grad) < 5e-3
+    assert rel(dws, dw_w.grad) < 1e-3
+    # the depthwise bias feeds a BatchNorm: its gradient is identically zero (both sides hold rounding noise)
+    assert float(dbs.abs().max()) < 1e-3 and float(dw_b.grad.abs().max()) < 1e-3
+    assert rel(dgs, bn.weight.grad) < 1e-3 and rel(dbe, bn.bias.grad) < 1e-3
+
+
+def test_subsampling_backward_pieces(K):
+    g = torch.Generator().manual_seed(5)
+    b, h, w, c = 2, 21, 19, 64
+    act = bf(torch.randn(b, h, w, c, generator=g))
+    ho, wo = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    m = b * ho * wo
+    colt = K.im2col_t(act.cuda())
+    cols = F.unfold(act.float().permute(0, 3, 1, 2), 3, stride=2)  # (B, C*9, L) with (c, kh, kw) ordering
+    cols = cols.view(b, c, 9, ho * wo).permute(2, 1, 0, 3).reshape(9 * c, m)  # -> (khw, c) x (b, ho, wo)
+    assert torch.equal(colt[:, :m].cpu().float(), cols)
+    dcol = bf(torch.randn(m, 9 * c, generator=g))
+    dact = K.col2im_relu(dcol.cuda(), act.cuda()).float().cpu()
+    dc = dcol.float().view(b, ho * wo, 9, c).permute(0, 3, 2, 1).reshape(b, c * 9, ho * wo)
+    want = F.fold(dc, (h, w), 3, stride=2).permute(0, 2, 3, 1) * (act.float() > 0)
+    assert rel(dact, bf(want).float()) < 3e-3
+    dy = bf(torch.randn(1000, generator=g)).cuda()
+    yv = bf(torch.randn(1000, generator=g))
+    assert torch.equal(K.relu_bwd(dy.clone(), yv.cuda()).cpu(), dy.cpu() * (yv.float() > 0).to(torch.bfloat16))
+    # conv1 weight gradient
+    bb, tt, idim, cc = 2, 31, 80, 256
+    x = torch.randn(bb, tt, idim, generator=g)
+    mean, istd = torch.randn(idim, generator=g), 0.5 + torch.rand(idim, generator=g)
+    h1, w1 = (tt - 3) // 2 + 1, (idim - 3) // 2 + 1
+    dact1 = bf(torch.randn(bb, h1, w1, cc, generator=g))
+    wgt = torch.zeros(cc, 1, 3, 3, requires_grad=True)
+    bias = torch.zeros(cc, requires_grad=True)
+    o = F.conv2d(((x - mean) * istd)[:, None], wgt, bias, stride=2)
+    o.backward(dact1.float().permute(0, 3, 1, 2))
+    dw, db = torch.zeros(cc, 9, device="cuda"), torch.zeros(cc, device="cuda")
+    K.conv1_dw(dact1.cuda(), x.cuda(), mean.cuda(), istd.cuda(), dw, db)
+    assert rel(dw, wgt.grad.view(cc, 9)) < 1e-4 and rel(db, bias.grad) < 1e-4
+
+
+def test_adam_and_overflow(K):
+    g = torch.Generator().manual_seed(6)
+    n = 100003
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1024
+    p, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    K.grad_overflow(gr.cuda(), flag)
+    assert int(flag) == 0
+    pm, mm, vm = p0.clone(), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        K.adam(p, gr.cuda(), m, v, lr_t, 0.9, 0.999, 1e-8, 1.0 / 1024, flag)
+        gi = gr / 1024
+        mm = 0.9 * mm + 0.1 * gi
+        vm = 0.999 * vm + 0.001 * gi * gi
+        pm = pm - lr_t * mm / (vm.sqrt() + 1e-8)
+    assert rel(p, pm) < 1e-6
+    bad = gr.clone()
+    bad[777] = float("inf")
+    K.grad_overflow(bad.cuda(), flag)
+    assert int(flag) == 1
+    before = p.clone()
+    K.adam(p, gr.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1.0, flag)
+    assert torch.equal(p, before)  # update skipped on overflow

@@ -348,6 +348,21 @@ int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, i
                               const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
                               ma_stream_t stream);
 
+/* Rel-pos attention for training: the forward of ma_relpos_attention_bf16 that also writes lse (batch, heads, T)
+ * float32 = log-sum-exp of the scaled, masked scores of every query row, and the backward pass
+ * (layers/attention.py:182-237): from dctx (batch*T, 256) bf16 to dqkv (batch*T, 768) bf16 (dq | dk | dv),
+ * dpos (T, 256) float32 += (summed over the batch), dbias_u / dbias_v (heads, 64) float32 += (caller zeroes the three). */
+int ma_relpos_attention_train_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos,
+                                   const float* bias_u, const float* bias_v, const float* mask, int64_t batch,
+                                   int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
+                                   void* vt_workspace, int64_t vt_bytes, float* lse, ma_stream_t stream);
+int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k);
+int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                                 const float* bias_v, const float* mask, const void* ctx, int64_t ld_ctx,
+                                 const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
+                                 int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, float* dbias_u,
+                                 float* dbias_v, void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+
 /* TrainOneStepWithLossScaleCell pieces (train_one_step.py:37-47): *flag |= 1 if any gradient is inf/nan; Adam
  * (MindSpore nn.Adam: p -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t) from the host) on
  * grad * inv_scale, skipped on the device when *overflow != 0. */

@@ -120,6 +120,11 @@ PROTOTYPES = {
     "ma_im2col_t_3x3s2_nhwc_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, i64, vp]),
     "ma_col2im_3x3s2_relu_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
     "ma_subsample_conv1_dw_f32": (ctypes.c_int, [vp, vp, i64, i64, i32, vp, vp, i32, vp, vp, vp]),
+    "ma_relpos_attention_train_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, vp, i64, vp, i64,
+                                                      vp, vp]),
+    "ma_relpos_attention_bwd_workspace_bytes": (i64, [i64, i64, i32, i32]),
+    "ma_relpos_attention_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32,
+                                                    i32, vp, i64, vp, vp, vp, vp, i64, vp]),
     "ma_grad_overflow_f32": (ctypes.c_int, [vp, i64, vp, vp]),
     "ma_adam_f32": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
     "ma_db_workspace_bytes": (i64, [i64, i64]),

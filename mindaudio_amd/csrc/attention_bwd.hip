@@ -1,0 +1,364 @@
+// Backward of the relative-position attention (layers/attention.py:182-237, no rel-shift, additive -10000 mask) for
+// gfx950.  Forward (conformer_kernels.hip): S = scale * Q'.K'^T + maskadd, Q' = [q+u | q+v], K' = [k | p] (one K = 128
+// contraction), P = softmax(S), O = P.V, and lse = logsumexp(S) per row is kept.
+//
+//   D_i   = sum_d dO[i,d] O[i,d]                      dP = dO.V^T          dS = P * (dP - D)   (w.r.t. the scaled S)
+//   dV    = P^T.dO      dK' = scale * dS^T.Q'          dQ' = scale * dS.K'
+//   dq = dQ'[:, :64] + dQ'[:, 64:],  du = sum_i dQ'[:, :64],  dv = sum_i dQ'[:, 64:],  dk = dK'[:, :64],
+//   dp = sum_b dK'[:, 64:]
+//
+// Three kernels:
+//   attn_bwd_prep_kernel   per (b, h, 64 rows): Q', K' row-major and transposed, dO^T (bf16 workspace), D (float32)
+//   attn_bwd_kernel<true>  keys fixed   (workgroup = 64 keys, wave = 16 keys), queries streamed: dK', dV
+//   attn_bwd_kernel<false> queries fixed (workgroup = 64 queries),             keys streamed:    dQ'
+// Both recompute the 64 x 64 score tile with the streamed side as the MFMA row operand, so the lane holds, for its
+// fixed item n = lane & 15, the 4 streamed rows (lane >> 4) * 4 + r of every 16-row tile: exactly the B-operand layout
+// of the next MFMA whose contraction runs over the streamed side (k-slot (lane>>4)*8 + e <-> row (e>>2)*16 + (lane>>4)*4
+// + (e&3) of a 32-row step; the transposed A operands are read from LDS with the same mapping).  No probability or
+// score gradient goes through LDS or HBM.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ uint16_t ab_to_bf16(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float ab_from_bf16(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ __forceinline__ uint32_t ab_pack(float lo, float hi) {
+  return (uint32_t)ab_to_bf16(lo) | ((uint32_t)ab_to_bf16(hi) << 16);
+}
+
+// workspace layout per (b, h), bf16 elements: Q'[Tp][128] | K'[Tp][128] | Q'^T[128][Tp] | K'^T[128][Tp] | dO^T[64][Tp];
+// then, after all (b, h): D float32 [B*H][Tp]
+struct AttnWs {
+  uint16_t* base;
+  float* D;
+  int Tp;
+  __host__ __device__ int64_t per_bh() const { return (int64_t)Tp * (128 * 4 + 64); }
+  __device__ uint16_t* q(int64_t bh) const { return base + bh * per_bh(); }
+  __device__ uint16_t* k(int64_t bh) const { return q(bh) + (int64_t)Tp * 128; }
+  __device__ uint16_t* qt(int64_t bh) const { return q(bh) + (int64_t)Tp * 256; }
+  __device__ uint16_t* kt(int64_t bh) const { return q(bh) + (int64_t)Tp * 384; }
+  __device__ uint16_t* dot(int64_t bh) const { return q(bh) + (int64_t)Tp * 512; }
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+                                                            const uint16_t* __restrict__ pos, int64_t ld_pos,
+                                                            const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+                                                            const uint16_t* __restrict__ ctx, int64_t ld_ctx,
+                                                            const uint16_t* __restrict__ dctx, int64_t ld_dctx, int T, int H,
+                                                            AttnWs ws) {
+  __shared__ uint16_t tq[64][128 + 2], tk[64][128 + 2], td[64][64 + 2];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * H + h, row0 = (int64_t)b * T;
+  const int Tp = ws.Tp;
+  // rows: thread (r = tid >> 2, part = tid & 3) handles 16 of the 64 head columns
+  const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const int t = t0 + r;
+  float dsum = 0.0f;
+  for (int c = part * 16; c < part * 16 + 16; ++c) {
+    float qv = 0.f, kv = 0.f, pv = 0.f, dov = 0.f, ov = 0.f;
+    if (t < T) {
+      const uint16_t* row = qkv + (row0 + t) * ld_qkv + h * 64 + c;
+      qv = ab_from_bf16(row[0]);
+      kv = ab_from_bf16(row[256]);
+      pv = ab_from_bf16(pos[(int64_t)t * ld_pos + h * 64 + c]);
+      dov = ab_from_bf16(dctx[(row0 + t) * ld_dctx + h * 64 + c]);
+      ov = ab_from_bf16(ctx[(row0 + t) * ld_ctx + h * 64 + c]);
+    }
+    const bool in = t < T;
+    tq[r][c] = in ? ab_to_bf16(qv + bias_u[h * 64 + c]) : 0;
+    tq[r][64 + c] = in ? ab_to_bf16(qv + bias_v[h * 64 + c]) : 0;
+    tk[r][c] = in ? ab_to_bf16(kv) : 0;
+    tk[r][64 + c] = in ? ab_to_bf16(pv) : 0;
+    td[r][c] = in ? ab_to_bf16(dov) : 0;
+    dsum += dov * ov;
+  }
+  dsum += __shfl_xor(dsum, 1, 64);
+  dsum += __shfl_xor(dsum, 2, 64);
+  if (part == 0) ws.D[bh * Tp + t] = dsum;
+  __syncthreads();
+  uint16_t* q = ws.q(bh);
+  uint16_t* k = ws.k(bh);
+  for (int i = threadIdx.x; i < 64 * 128; i += 256) {
+    const int rr = i >> 7, cc = i & 127;
+    q[(int64_t)(t0 + rr) * 128 + cc] = tq[rr][cc];
+    k[(int64_t)(t0 + rr) * 128 + cc] = tk[rr][cc];
+  }
+  uint16_t* qt = ws.qt(bh);
+  uint16_t* kt = ws.kt(bh);
+  for (int i = threadIdx.x; i < 128 * 64; i += 256) {
+    const int cc = i >> 6, rr = i & 63;
+    qt[(int64_t)cc * Tp + t0 + rr] = tq[rr][cc];
+    kt[(int64_t)cc * Tp + t0 + rr] = tk[rr][cc];
+  }
+  uint16_t* dot = ws.dot(bh);
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int cc = i >> 6, rr = i & 63;
+    dot[(int64_t)cc * Tp + t0 + rr] = td[rr][cc];
+  }
+}
+
+constexpr int kXs = 128 + 8;  // bf16 row stride of the row-major X' tile (272 B)
+constexpr int kYs = 64 + 8;   // row-major Y tile (144 B)
+constexpr int kTs = 64 + 4;   // transposed tiles: 64 streamed items per row (136 B, 8-byte aligned)
+
+// KEYS_FIXED = true : fixed = keys (K', V), streamed = queries (Q', dO, Q'^T, dO^T, lse, D): outputs dK', dV
+// KEYS_FIXED = false: fixed = queries (Q', dO, lse, D), streamed = keys (K', V, K'^T, maskadd): output dQ'
+template <bool KEYS_FIXED>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+                                                       const uint16_t* __restrict__ dctx, int64_t ld_dctx,
+                                                       const float* __restrict__ mask, const float* __restrict__ lse,
+                                                       AttnWs ws, int T, int H, float scale,
+                                                       uint16_t* __restrict__ dqkv, int64_t ld_dqkv, float* dpos,
+                                                       float* du, float* dv) {
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[64 * kXs];       // streamed X' rows
+  __shared__ __attribute__((aligned(16))) uint16_t Ys[64 * kYs];       // streamed Y rows (dO or V)
+  __shared__ __attribute__((aligned(16))) uint16_t Xt[128 * kTs];      // streamed X'^T
+  __shared__ __attribute__((aligned(16))) uint16_t Yt[64 * kTs];       // streamed dO^T (KEYS_FIXED only)
+  __shared__ __attribute__((aligned(16))) float srow[2][64];           // streamed per-row scalars: lse & D, or maskadd
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int fb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * H + h, row0 = (int64_t)b * T;
+  const int Tp = ws.Tp;
+  const int fidx = fb * 64 + wave * 16 + lq;  // this lane's fixed item (key or query)
+  const int fcl = fidx < T ? fidx : T - 1;
+
+  // ---- fixed-side B fragments: X'[fidx] (4 k-steps over 128) and Y[fidx] (2 k-steps over 64) -------------------
+  bf16x8 xf[4], yf[2];
+  {
+    const uint16_t* xr = (KEYS_FIXED ? ws.k(bh) : ws.q(bh)) + (int64_t)fcl * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 32 + lg * 8);
+    const uint16_t* yr = KEYS_FIXED ? qkv + (row0 + fcl) * ld_qkv + 512 + h * 64 : dctx + (row0 + fcl) * ld_dctx + h * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) yf[ks] = *reinterpret_cast<const bf16x8*>(yr + ks * 32 + lg * 8);
+  }
+  float f_mask = 0.0f, f_lse = 0.0f, f_D = 0.0f;
+  if (KEYS_FIXED) {
+    f_mask = fidx >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + fidx] == 0.0f) ? -10000.0f : 0.0f);
+  } else {
+    f_lse = fidx < T ? lse[bh * T + fidx] : INFINITY;
+    f_D = fidx < T ? ws.D[bh * Tp + fidx] : 0.0f;
+  }
+
+  f32x4 acc_x[8];  // (dK' or dQ')^T: rows c = ct*16 + lg*4 + r, column = fixed item lq
+  f32x4 acc_y[4];  // dV^T (KEYS_FIXED)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc_x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc_y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint16_t* sx = KEYS_FIXED ? ws.q(bh) : ws.k(bh);
+  const uint16_t* sxt = KEYS_FIXED ? ws.qt(bh) : ws.kt(bh);
+  const uint16_t* syt = ws.dot(bh);
+  const int n_st = Tp / 64;
+  for (int st = 0; st < n_st; ++st) {
+    const int s0 = st * 64;
+    __syncthreads();
+    // ---- stage the streamed tile -------------------------------------------------------------------------------
+    for (int c = tid; c < 64 * 16; c += 256) {  // X' rows: 64 x 16 chunks of 8
+      const int r = c >> 4, ch = c & 15;
+      *reinterpret_cast<uint4*>(&Xs[r * kXs + ch * 8]) = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0 + r) * 128 + ch * 8);
+    }
+    for (int c = tid; c < 64 * 8; c += 256) {   // Y rows: dO (queries) or V (keys), zero past T
+      const int r = c >> 3, ch = c & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (s0 + r < T)
+        v = KEYS_FIXED ? *reinterpret_cast<const uint4*>(dctx + (row0 + s0 + r) * ld_dctx + h * 64 + ch * 8)
+                       : *reinterpret_cast<const uint4*>(qkv + (row0 + s0 + r) * ld_qkv + 512 + h * 64 + ch * 8);
+      *reinterpret_cast<uint4*>(&Ys[r * kYs + ch * 8]) = v;
+    }
+    for (int c = tid; c < 128 * 8; c += 256) {  // X'^T rows: 128 x 8 chunks of 8 streamed items
+      const int r = c >> 3, ch = c & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(sxt + (int64_t)r * Tp + s0 + ch * 8);
+      uint2* d = reinterpret_cast<uint2*>(&Xt[r * kTs + ch * 8]);
+      d[0] = make_uint2(v.x, v.y);
+      d[1] = make_uint2(v.z, v.w);
+    }
+    if (KEYS_FIXED) {
+      for (int c = tid; c < 64 * 8; c += 256) {
+        const int r = c >> 3, ch = c & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(syt + (int64_t)r * Tp + s0 + ch * 8);
+        uint2* d = reinterpret_cast<uint2*>(&Yt[r * kTs + ch * 8]);
+        d[0] = make_uint2(v.x, v.y);
+        d[1] = make_uint2(v.z, v.w);
+      }
+    }
+    if (tid < 64) {
+      const int si = s0 + tid;
+      if (KEYS_FIXED) {
+        srow[0][tid] = si < T ? lse[bh * T + si] : INFINITY;  // exp(. - inf) = 0: streamed queries past T vanish
+        srow[1][tid] = si < T ? ws.D[bh * Tp + si] : 0.0f;
+      } else {
+        srow[0][tid] = si >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + si] == 0.0f) ? -10000.0f : 0.0f);
+      }
+    }
+    __syncthreads();
+
+    // ---- score tile and dP tile: rows = streamed (4 tiles of 16), column = fixed item lq --------------------------
+    uint32_t pb[4][2], db[4][2];  // bf16 pairs of P and scale * dS for rows lg*4 + {0,1}, {2,3} of tile mt
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Xs[(mt * 16 + lq) * kXs + ks * 32 + lg * 8]);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[ks], s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ys[(mt * 16 + lq) * kYs + ks * 32 + lg * 8]);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, yf[ks], dp, 0, 0, 0);
+      }
+      float p[4], g[4];
+      const float4 r0 = *reinterpret_cast<const float4*>(&srow[0][mt * 16 + lg * 4]);
+      const float r0v[4] = {r0.x, r0.y, r0.z, r0.w};
+      float r1v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (KEYS_FIXED) {
+        const float4 r1 = *reinterpret_cast<const float4*>(&srow[1][mt * 16 + lg * 4]);
+        r1v[0] = r1.x; r1v[1] = r1.y; r1v[2] = r1.z; r1v[3] = r1.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // KEYS_FIXED: row = query (lse, D from srow), column = key (mask per lane); else row = key (mask from srow)
+        const float e = KEYS_FIXED ? s[r] * scale + f_mask - r0v[r] : s[r] * scale + r0v[r] - f_lse;
+        p[r] = __expf(e);
+        g[r] = p[r] * (dp[r] - (KEYS_FIXED ? r1v[r] : f_D)) * scale;
+      }
+      pb[mt][0] = ab_pack(p[0], p[1]);
+      pb[mt][1] = ab_pack(p[2], p[3]);
+      db[mt][0] = ab_pack(g[0], g[1]);
+      db[mt][1] = ab_pack(g[2], g[3]);
+    }
+    // ---- contractions over the streamed side ----------------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 gpk = make_uint4(db[2 * ks][0], db[2 * ks][1], db[2 * ks + 1][0], db[2 * ks + 1][1]);
+      const bf16x8 gf = __builtin_bit_cast(bf16x8, gpk);
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const uint16_t* xr = &Xt[(ct * 16 + lq) * kTs + ks * 32 + lg * 4];
+        const uint2 v0 = *reinterpret_cast<const uint2*>(xr);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(xr + 16);
+        const uint4 apk = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        acc_x[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, apk), gf, acc_x[ct], 0, 0, 0);
+      }
+      if (KEYS_FIXED) {
+        const uint4 ppk = make_uint4(pb[2 * ks][0], pb[2 * ks][1], pb[2 * ks + 1][0], pb[2 * ks + 1][1]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, ppk);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const uint16_t* yr = &Yt[(dt * 16 + lq) * kTs + ks * 32 + lg * 4];
+          const uint2 v0 = *reinterpret_cast<const uint2*>(yr);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(yr + 16);
+          const uint4 apk = make_uint4(v0.x, v0.y, v1.x, v1.y);
+          acc_y[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, apk), pf, acc_y[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- outputs: lane holds rows c = ct*16 + lg*4 + r of the transposed result for its fixed item -----------------
+  if (KEYS_FIXED) {
+    if (fidx < T) {
+      uint16_t* orow = dqkv + (row0 + fidx) * ld_dqkv + h * 64 + lg * 4;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)  // dk
+        *reinterpret_cast<uint2*>(orow + 256 + ct * 16) =
+            make_uint2(ab_pack(acc_x[ct][0], acc_x[ct][1]), ab_pack(acc_x[ct][2], acc_x[ct][3]));
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)  // dv
+        *reinterpret_cast<uint2*>(orow + 512 + dt * 16) =
+            make_uint2(ab_pack(acc_y[dt][0], acc_y[dt][1]), ab_pack(acc_y[dt][2], acc_y[dt][3]));
+      float* prow = dpos + (int64_t)fidx * 256 + h * 64 + lg * 4;  // dp: summed over the batch
+#pragma unroll
+      for (int ct = 4; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(prow + (ct - 4) * 16 + r, acc_x[ct][r]);
+    }
+  } else {
+    const bool live = fidx < T;
+    if (live) {
+      uint16_t* orow = dqkv + (row0 + fidx) * ld_dqkv + h * 64 + lg * 4;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)  // dq = dQ'[:, c] + dQ'[:, 64 + c]
+        *reinterpret_cast<uint2*>(orow + ct * 16) =
+            make_uint2(ab_pack(acc_x[ct][0] + acc_x[ct + 4][0], acc_x[ct][1] + acc_x[ct + 4][1]),
+                       ab_pack(acc_x[ct][2] + acc_x[ct + 4][2], acc_x[ct][3] + acc_x[ct + 4][3]));
+    }
+    // du / dv: sum over the queries of this wave (16 lanes lq), then one atomic per (c) from lane lq == 0
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = live ? acc_x[ct][r] : 0.0f;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if (lq == 0) atomicAdd((ct < 4 ? du : dv) + h * 64 + (ct & 3) * 16 + lg * 4 + r, v);
+      }
+  }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k) {
+  if (batch < 1 || T < 1 || heads < 1 || d_k != 64) return MA_ERR_INVALID_ARG;
+  const int64_t Tp = (T + 63) / 64 * 64;
+  return batch * heads * Tp * (128 * 4 + 64) * 2 + batch * heads * Tp * 4 + 256;
+}
+
+int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                                 const float* bias_v, const float* mask, const void* ctx, int64_t ld_ctx,
+                                 const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
+                                 int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, float* dbias_u,
+                                 float* dbias_v, void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  if (!qkv || !pos || !bias_u || !bias_v || !ctx || !dctx || !lse || !dqkv || !dpos || !dbias_u || !dbias_v || !workspace ||
+      batch < 1 || T < 1)
+    return MA_ERR_INVALID_ARG;
+  if (d_k != 64 || heads * d_k != 256 || batch > 65535) return MA_ERR_UNSUPPORTED;
+  if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 7) || (ld_dctx & 7) || (ld_dqkv & 3)) return MA_ERR_UNSUPPORTED;
+  if (workspace_bytes < ma_relpos_attention_bwd_workspace_bytes(batch, T, heads, d_k)) return MA_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return MA_ERR_INVALID_ARG;
+  AttnWs ws;
+  ws.Tp = (int)((T + 63) / 64 * 64);
+  ws.base = reinterpret_cast<uint16_t*>(workspace);
+  ws.D = reinterpret_cast<float*>(ws.base + batch * heads * ws.per_bh());
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)(ws.Tp / 64), (unsigned)heads, (unsigned)batch);
+  const float scale = 1.0f / sqrtf((float)d_k);
+  MA_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
+            bias_u, bias_v, (const uint16_t*)ctx, ld_ctx, (const uint16_t*)dctx, ld_dctx, (int)T, (int)heads, ws);
+  MA_LAUNCH(attn_bwd_kernel<true>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
+            mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, dbias_u, dbias_v);
+  MA_LAUNCH(attn_bwd_kernel<false>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
+            mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, dbias_u, dbias_v);
+  return MA_OK;
+}
+
+}  // extern "C"

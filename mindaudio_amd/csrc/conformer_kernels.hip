@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
                                                                const float* __restrict__ bias_v,
                                                                const float* __restrict__ mask, int T, int H,
                                                                float scale, uint16_t* __restrict__ ctx,
-                                                               int64_t ld_ctx) {
+                                                               int64_t ld_ctx, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) uint16_t Kp[kAttK * kKpStride];
   __shared__ __attribute__((aligned(16))) uint16_t Vt[kDk * kVtStride];
   __shared__ float maskadd[kAttK];
@@ -333,6 +333,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
   }
   // ---- ctx[q, h*64 + d] = O^T[d, q] / l ---------------------------------------------------------------------------
   const int qi = q_base + lq;
+  // log-sum-exp of the scaled, masked scores of row qi: what the backward pass needs to rebuild the probabilities
+  if (lse && qi < T && lg == 0) lse[((int64_t)b * H + h) * T + qi] = mrow + __logf(lrow);
   if (qi < T) {
     const float inv = 1.0f / lrow;
     uint16_t* o = ctx + (row0 + qi) * ld_ctx + h * kDk + lg * 4;
@@ -497,10 +499,10 @@ int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t id
   return MA_OK;
 }
 
-int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
-                             const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads,
-                             int32_t d_k, void* ctx, int64_t ld_ctx, void* vt_workspace, int64_t vt_bytes,
-                             ma_stream_t stream) {
+static int relpos_attention_fwd(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                                const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads,
+                                int32_t d_k, void* ctx, int64_t ld_ctx, void* vt_workspace, int64_t vt_bytes,
+                                float* lse, ma_stream_t stream) {
   if (!qkv || !pos || !bias_u || !bias_v || !ctx || !vt_workspace || batch < 1 || T < 1 || heads < 1)
     return MA_ERR_INVALID_ARG;
   if (d_k != kDk || heads * d_k != 256) return MA_ERR_UNSUPPORTED;  // q | k | v blocks are 256 wide
@@ -514,8 +516,25 @@ int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, i
   const dim3 grid((unsigned)((T + kAttQ - 1) / kAttQ), (unsigned)heads, (unsigned)batch);
   MA_LAUNCH(relpos_attention_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
             reinterpret_cast<const uint16_t*>(pos), ld_pos, reinterpret_cast<const uint16_t*>(vt_workspace), Tp, bias_u,
-            bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx);
+            bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx, lse);
   return MA_OK;
+}
+
+int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                             const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads,
+                             int32_t d_k, void* ctx, int64_t ld_ctx, void* vt_workspace, int64_t vt_bytes,
+                             ma_stream_t stream) {
+  return relpos_attention_fwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, batch, T, heads, d_k, ctx, ld_ctx,
+                              vt_workspace, vt_bytes, nullptr, stream);
+}
+
+int ma_relpos_attention_train_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos,
+                                   const float* bias_u, const float* bias_v, const float* mask, int64_t batch,
+                                   int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
+                                   void* vt_workspace, int64_t vt_bytes, float* lse, ma_stream_t stream) {
+  if (!lse) return MA_ERR_INVALID_ARG;
+  return relpos_attention_fwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, batch, T, heads, d_k, ctx, ld_ctx,
+                              vt_workspace, vt_bytes, lse, stream);
 }
 
 int64_t ma_relpos_attention_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k) {

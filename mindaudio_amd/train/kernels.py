@@ -149,3 +149,31 @@ def grad_overflow(g, flag):
 def adam(param, grad, m, v, lr_t, beta1, beta2, eps, inv_scale, overflow=None):
     _lib.check(_lib.load().ma_adam_f32(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr_t), float(beta1),
                                        float(beta2), float(eps), float(inv_scale), _p(overflow), _s()), "adam")
+
+
+def attention_fwd(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64):
+    """Training forward: (ctx (B*T, 256) bf16, lse (B, H, T) f32)."""
+    t = _t()
+    lib = _lib.load()
+    ctx = t.empty((batch * T, heads * d_k), dtype=t.bfloat16, device=qkv.device)
+    lse = t.empty((batch, heads, T), dtype=t.float32, device=qkv.device)
+    ws_bytes = lib.ma_relpos_attention_workspace_bytes(batch, T, heads, d_k)
+    ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
+    _lib.check(lib.ma_relpos_attention_train_bf16(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v),
+                                                  _p(mask), batch, T, heads, d_k, _p(ctx), ctx.stride(0), _p(ws),
+                                                  ws_bytes, _p(lse), _s()), "attention_fwd")
+    return ctx, lse
+
+
+def attention_bwd(qkv, pos, bias_u, bias_v, mask, ctx, dctx, lse, batch, T, dpos, dbias_u, dbias_v, heads=4, d_k=64):
+    """-> dqkv (B*T, 768) bf16; dpos (T, 256), dbias_u/v (H, 64) float32 accumulate."""
+    t = _t()
+    lib = _lib.load()
+    dqkv = t.empty((batch * T, 3 * heads * d_k), dtype=t.bfloat16, device=qkv.device)
+    ws_bytes = lib.ma_relpos_attention_bwd_workspace_bytes(batch, T, heads, d_k)
+    ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
+    _lib.check(lib.ma_relpos_attention_bwd_bf16(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v),
+                                                _p(mask), _p(ctx), ctx.stride(0), _p(dctx), dctx.stride(0), _p(lse),
+                                                batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos), _p(dbias_u),
+                                                _p(dbias_v), _p(ws), ws_bytes, _s()), "attention_bwd")
+    return dqkv

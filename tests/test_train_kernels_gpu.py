@@ -207,3 +207,41 @@ def test_adam_and_overflow(K):
     before = p.clone()
     K.adam(p, gr.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1.0, flag)
     assert torch.equal(p, before)  # update skipped on overflow
+
+
+@pytest.mark.parametrize("b,t", [(2, 100), (3, 255), (1, 64), (2, 37)])
+def test_attention_backward(K, b, t):
+    g = torch.Generator().manual_seed(7 + t)
+    h, dk = 4, 64
+    qkv = bf(torch.randn(b * t, 768, generator=g) * 0.8)
+    pos = bf(torch.randn(t, 256, generator=g) * 0.8)
+    u = (0.3 * torch.randn(h, dk, generator=g)).requires_grad_()
+    v = (0.3 * torch.randn(h, dk, generator=g)).requires_grad_()
+    lens = torch.randint(t // 2, t + 1, (b,), generator=g)
+    lens[0] = t
+    mask = (torch.arange(t)[None, :] < lens[:, None]).float()
+    qf = qkv.float().requires_grad_()
+    pf = pos.float().requires_grad_()
+    q = qf[:, :256].view(b, t, h, dk)
+    k = qf[:, 256:512].view(b, t, h, dk).transpose(1, 2)
+    vv = qf[:, 512:].view(b, t, h, dk).transpose(1, 2)
+    p = pf.view(1, t, h, dk).transpose(1, 2)
+    qu = bf((q + u).detach()).float() + ((q + u) - (q + u).detach())  # the kernels round q + bias to bf16 (straight-through)
+    qv = bf((q + v).detach()).float() + ((q + v) - (q + v).detach())
+    scores = (qu.transpose(1, 2) @ k.transpose(-1, -2) + qv.transpose(1, 2) @ p.transpose(-1, -2)) / math.sqrt(dk)
+    scores = scores + (mask[:, None, None, :] == 0).float() * -10000.0
+    attn = torch.softmax(scores, -1)
+    ctx_ref = (attn @ vv).transpose(1, 2).reshape(b * t, 256)
+    dctx = bf(torch.randn(b * t, 256, generator=g))
+    ctx_ref.backward(dctx.float())
+    ctx, lse = K.attention_fwd(qkv.cuda(), pos.cuda(), u.detach().cuda(), v.detach().cuda(), mask.cuda(), b, t)
+    assert rel(ctx, ctx_ref.detach()) < 1e-2
+    assert rel(lse, torch.logsumexp(scores.detach(), -1)) < 1e-3
+    dpos = torch.zeros(t, 256, device="cuda")
+    du, dv = torch.zeros(h, dk, device="cuda"), torch.zeros(h, dk, device="cuda")
+    dqkv = K.attention_bwd(qkv.cuda(), pos.cuda(), u.detach().cuda(), v.detach().cuda(), mask.cuda(), ctx, dctx.cuda(),
+                           lse, b, t, dpos, du, dv)
+    for name, lo in (("dq", 0), ("dk", 256), ("dv", 512)):
+        assert rel(dqkv[:, lo:lo + 256], qf.grad[:, lo:lo + 256]) < 2e-2, name
+    assert rel(dpos, pf.grad) < 2e-2
+    assert rel(du, u.grad) < 2e-2 and rel(dv, v.grad) < 2e-2

@@ -244,6 +244,17 @@ int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, i
                     int32_t zero_infinity, float* per_utt_loss, float* lse_workspace, float* loss_out,
                     ma_stream_t stream);
 
+/* Loss value AND gradient of the CTC branch: as ma_ctc_loss_f32, plus dlogits (batch*T, ld_out) bf16 =
+ * grad_scale * d(sum of per-utterance CTC) / d logits (softmax - state occupancies; zero for frames past hlens and
+ * for utterances whose loss is infinite — zero_infinity must be on).  Columns [V, ld_out) are zero-filled so the buffer
+ * can be a K-padded GEMM operand.  workspace >= ma_ctc_grad_workspace_bytes (the alpha/occupancy lattice). */
+int64_t ma_ctc_grad_workspace_bytes(int64_t batch, int64_t T, int32_t Lmax);
+int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
+                         int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
+                         int32_t zero_infinity, float grad_scale, float* per_utt_loss, float* lse_workspace,
+                         float* loss_out, void* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
+                         ma_stream_t stream);
+
 /* float32 -> bf16 (round to nearest even), n % 4 == 0: the `cast` in front of a matmul operand. */
 int ma_cast_f32_bf16(const float* x, void* y, int64_t n, ma_stream_t stream);
 

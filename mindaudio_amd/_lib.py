@@ -99,6 +99,9 @@ PROTOTYPES = {
     "ma_ctc_loss_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i32, ctypes.c_void_p, i32, ctypes.c_void_p,
                                        ctypes.c_void_p, i32, i32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),
+    "ma_ctc_grad_workspace_bytes": (i64, [i64, i64, i32]),
+    "ma_ctc_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, i32, i32, f32, vp, vp, vp, vp, i64,
+                                            vp, i64, vp]),
     "ma_cast_f32_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p]),
     "ma_subsampled_mask_len": (i32, [i32]),
     "ma_collate_asr_i32": (ctypes.c_int, [ctypes.c_void_p] * 3 + [i32] * 7 + [ctypes.c_void_p] * 11),

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
                                                        const float* __restrict__ lse, const int32_t* __restrict__ ys,
                                                        int Lmax, const int32_t* __restrict__ hlens,
                                                        const int32_t* __restrict__ ylens, int blank,
-                                                       float* __restrict__ loss) {
+                                                       float* __restrict__ loss, float* __restrict__ alpha_out,
+                                                       int Smax) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int tlen = hlens[b];
   if (tlen > T) tlen = T;
@@ -91,6 +92,11 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
     const float z = lse[(int64_t)b * T];
     if (lane == 0) alpha[0] = row0[blank] - z;
     if (lane == 1 && S > 1) alpha[0] = row0[lab[0]] - z;
+    if (alpha_out) {
+#pragma unroll
+      for (int c = 0; c < kMaxChunks; ++c)
+        if (c * 64 + lane < S) alpha_out[((int64_t)b * T) * Smax + c * 64 + lane] = alpha[c];
+    }
   }
   for (int t = 1; t < tlen; ++t) {
     const float* row = row0 + (int64_t)t * ld;
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
       if (skip[c]) v = log_add(v, a2);
       const int s = c * 64 + lane;
       alpha[c] = (s < S) ? v + (row[lab[c]] - z) : -INFINITY;
+      if (alpha_out && s < S) alpha_out[((int64_t)b * T + t) * Smax + s] = alpha[c];
     }
   }
   // -log( alpha_T(S-1) + alpha_T(S-2) )
@@ -123,6 +130,115 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
   float m = wave_max(fin);
   float sum = wave_add(fin == -INFINITY ? 0.0f : expf(fin - m));
   if (lane == 0) loss[b] = (m == -INFINITY) ? INFINITY : -(m + logf(sum));
+}
+
+// Backward, step 1: beta recursion of one utterance per wave (mirror image of ctc_alpha_kernel), turning the stored
+// alpha_t(s) in place into the state occupancy w_t(s) = alpha_t(s) beta_t(s) / (y_t(l'_s) P(l|x)).
+__global__ __launch_bounds__(64) void ctc_beta_kernel(const float* __restrict__ logits, int64_t ld, int T,
+                                                      const float* __restrict__ lse, const int32_t* __restrict__ ys,
+                                                      int Lmax, const int32_t* __restrict__ hlens,
+                                                      const int32_t* __restrict__ ylens, int blank,
+                                                      const float* __restrict__ loss, float* __restrict__ ab, int Smax) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int tlen = hlens[b];
+  if (tlen > T) tlen = T;
+  const int U = ylens[b];
+  const int S = 2 * U + 1;
+  const int nch = (S + 63) / 64;
+  const float nll = loss[b];
+  if (tlen < 1 || U < 0 || nch > kMaxChunks || isinf(nll)) return;  // no gradient (zero_infinity / degenerate)
+  int lab[kMaxChunks];
+  bool skip[kMaxChunks];  // transition s -> s+2 allowed
+  float beta[kMaxChunks];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int s = c * 64 + lane;
+    int l = blank;
+    bool sk = false;
+    if (s < S && (s & 1)) {
+      l = ys[(int64_t)b * Lmax + (s >> 1)];
+      sk = (s + 2 < S) && (ys[(int64_t)b * Lmax + (s >> 1) + 1] != l);
+    }
+    lab[c] = l;
+    skip[c] = sk;
+    beta[c] = -INFINITY;
+  }
+  const float* row0 = logits + (int64_t)b * T * ld;
+  for (int t = tlen - 1; t >= 0; --t) {
+    const float* row = row0 + (int64_t)t * ld;
+    const float z = lse[(int64_t)b * T + t];
+    float carry1 = -INFINITY, carry2 = -INFINITY;  // beta_{t+1}(s+1), (s+2) coming from the next chunk
+    float nb[kMaxChunks];
+#pragma unroll
+    for (int c = kMaxChunks - 1; c >= 0; --c) {
+      nb[c] = -INFINITY;
+      if (c >= nch) continue;
+      const int s = c * 64 + lane;
+      const float lp = row[lab[c]] - z;
+      float v;
+      if (t == tlen - 1) {
+        v = (s == S - 1 || (s == S - 2 && S > 1)) ? 0.0f : -INFINITY;
+      } else {
+        const float b0 = beta[c];
+        float b1 = __shfl_down(b0, 1, 64);
+        float b2 = __shfl_down(b0, 2, 64);
+        const float first1 = __shfl(b0, 0, 64), first2 = __shfl(b0, 1, 64);
+        if (lane == 63) { b1 = carry1; b2 = carry2; }
+        if (lane == 62) b2 = carry1;
+        carry1 = first1;
+        carry2 = first2;
+        v = log_add(b0, b1);
+        if (skip[c]) v = log_add(v, b2);
+      }
+      nb[c] = (s < S) ? v + lp : -INFINITY;
+      if (s < S) {
+        float* cell = ab + ((int64_t)b * T + t) * Smax + s;
+        const float e = *cell + nb[c] - lp + nll;  // log of alpha beta / (y P)
+        *cell = e > -80.0f ? expf(e) : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) beta[c] = nb[c];
+  }
+}
+
+// Backward, step 2: one workgroup per (b, t) row: dlogits[v] = scale * (softmax[v] - sum_{s: l'_s = v} w_t(s)) as bf16;
+// rows past the utterance's length, and utterances with an infinite loss (zero_infinity), get zeros.  Columns
+// [V, ld_out) are zeroed (GEMM K padding).
+__global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restrict__ logits, int64_t ld, int T, int V,
+                                                          const float* __restrict__ lse, const int32_t* __restrict__ ys,
+                                                          int Lmax, const int32_t* __restrict__ hlens,
+                                                          const int32_t* __restrict__ ylens, int blank,
+                                                          const float* __restrict__ loss, const float* __restrict__ ab,
+                                                          int Smax, float scale, uint16_t* __restrict__ out,
+                                                          int64_t ld_out) {
+  extern __shared__ float occ[];
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+  uint16_t* o = out + row * ld_out;
+  int tlen = hlens[b];
+  if (tlen > T) tlen = T;
+  const int U = ylens[b], S = 2 * U + 1;
+  if (t >= tlen || isinf(loss[b]) || S > Smax) {
+    for (int v = threadIdx.x; v < ld_out; v += 256) o[v] = 0;
+    return;
+  }
+  for (int v = threadIdx.x; v < V; v += 256) occ[v] = 0.0f;
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const int l = (s & 1) ? ys[(int64_t)b * Lmax + (s >> 1)] : blank;
+    atomicAdd(&occ[l], ab[row * Smax + s]);
+  }
+  __syncthreads();
+  const float* p = logits + row * ld;
+  const float z = lse[row];
+  for (int v = threadIdx.x; v < ld_out; v += 256) {
+    float gval = 0.0f;
+    if (v < V) gval = scale * (expf(p[v] - z) - occ[v]);
+    uint32_t u = __float_as_uint(gval);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    o[v] = (uint16_t)(u >> 16);
+  }
 }
 
 __global__ void ctc_reduce_kernel(const float* __restrict__ loss, int B, int zero_infinity, float* __restrict__ out) {
@@ -164,8 +280,39 @@ int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, i
   const int64_t rows = batch * T;
   MA_LAUNCH(ctc_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, ld, rows, (int)V, lse_workspace);
   MA_LAUNCH(ctc_alpha_kernel, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
-            hlens, ylens, (int)blank, per_utt_loss);
+            hlens, ylens, (int)blank, per_utt_loss, (float*)nullptr, 0);
   MA_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, per_utt_loss, (int)batch, (int)zero_infinity, loss_out);
+  return MA_OK;
+}
+
+int64_t ma_ctc_grad_workspace_bytes(int64_t batch, int64_t T, int32_t Lmax) {
+  if (batch < 1 || T < 1 || Lmax < 1) return MA_ERR_INVALID_ARG;
+  return batch * T * (2 * (int64_t)Lmax + 1) * 4;
+}
+
+int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
+                         int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
+                         int32_t zero_infinity, float grad_scale, float* per_utt_loss, float* lse_workspace,
+                         float* loss_out, void* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
+                         ma_stream_t stream) {
+  if (!logits || !ys || !hlens || !ylens || !per_utt_loss || !lse_workspace || !loss_out || !dlogits || !workspace)
+    return MA_ERR_INVALID_ARG;
+  if (batch < 1 || T < 1 || V < 1 || ld < V || ld_out < V || Lmax < 1 || blank < 0 || blank >= V) return MA_ERR_INVALID_ARG;
+  if (2 * Lmax + 1 > kMaxChunks * 64 || !zero_infinity || (int64_t)V * 4 > 60 * 1024) return MA_ERR_UNSUPPORTED;
+  if (workspace_bytes < ma_ctc_grad_workspace_bytes(batch, T, Lmax)) return MA_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t rows = batch * T;
+  const int Smax = 2 * Lmax + 1;
+  float* ab = reinterpret_cast<float*>(workspace);
+  MA_LAUNCH(ctc_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, ld, rows, (int)V, lse_workspace);
+  MA_LAUNCH(ctc_alpha_kernel, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
+            hlens, ylens, (int)blank, per_utt_loss, ab, Smax);
+  MA_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, per_utt_loss, (int)batch, 1, loss_out);
+  MA_LAUNCH(ctc_beta_kernel, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
+            hlens, ylens, (int)blank, per_utt_loss, ab, Smax);
+  MA_LAUNCH(ctc_dlogits_kernel, dim3((unsigned)rows), dim3(256), (size_t)V * 4, s, logits, ld, (int)T, (int)V,
+            lse_workspace, ys, (int)Lmax, hlens, ylens, (int)blank, per_utt_loss, ab, Smax, grad_scale,
+            reinterpret_cast<uint16_t*>(dlogits), ld_out);
   return MA_OK;
 }
 

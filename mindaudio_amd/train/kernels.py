@@ -177,3 +177,23 @@ def attention_bwd(qkv, pos, bias_u, bias_v, mask, ctx, dctx, lse, batch, T, dpos
                                                 batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos), _p(dbias_u),
                                                 _p(dbias_v), _p(ws), ws_bytes, _s()), "attention_bwd")
     return dqkv
+
+
+def ctc_loss_grad(logits, V, batch, T, ys_pad, hlens, ys_lens, grad_scale, blank=0):
+    """logits (B*T, ld>=V) float32 -> (loss scalar tensor, per-utterance nll, dlogits (B*T, ld) bf16 scaled by grad_scale)."""
+    t = _t()
+    lib = _lib.load()
+    dev = logits.device
+    ys_pad = ys_pad.to(t.int32).contiguous()
+    hlens = hlens.to(t.int32).contiguous()
+    ys_lens = ys_lens.to(t.int32).contiguous()
+    per = t.empty(batch, dtype=t.float32, device=dev)
+    lse = t.empty(batch * T, dtype=t.float32, device=dev)
+    out = t.empty(1, dtype=t.float32, device=dev)
+    dlog = t.empty((batch * T, logits.stride(0)), dtype=t.bfloat16, device=dev)
+    ws_bytes = lib.ma_ctc_grad_workspace_bytes(batch, T, ys_pad.shape[1])
+    ws = t.empty(ws_bytes, dtype=t.uint8, device=dev)
+    _lib.check(lib.ma_ctc_loss_grad_f32(_p(logits), logits.stride(0), batch, T, V, _p(ys_pad), ys_pad.shape[1],
+                                        _p(hlens), _p(ys_lens), blank, 1, float(grad_scale), _p(per), _p(lse), _p(out),
+                                        _p(dlog), dlog.stride(0), _p(ws), ws_bytes, _s()), "ctc_loss_grad")
+    return out[0], per, dlog

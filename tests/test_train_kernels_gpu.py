@@ -245,3 +245,29 @@ def test_attention_backward(K, b, t):
         assert rel(dqkv[:, lo:lo + 256], qf.grad[:, lo:lo + 256]) < 2e-2, name
     assert rel(dpos, pf.grad) < 2e-2
     assert rel(du, u.grad) < 2e-2 and rel(dv, v.grad) < 2e-2
+
+
+def test_ctc_loss_grad(K):
+    g = torch.Generator().manual_seed(11)
+    b, t, v, lmax = 5, 61, 203, 12
+    vp = (v + 63) // 64 * 64
+    logits = torch.zeros(b * t, vp)
+    logits[:, :v] = torch.randn(b * t, v, generator=g) * 2
+    hlens = torch.tensor([61, 50, 33, 61, 4])
+    ylens = torch.tensor([12, 7, 1, 0, 9])  # the last one is infeasible (9 labels in 4 frames): zero_infinity
+    ys = torch.randint(1, v, (b, lmax), generator=g)
+    ys[1, 3] = ys[1, 2]  # a repeated label
+    lg = logits[:, :v].clone().view(b, t, v).requires_grad_()
+    lp = torch.log_softmax(lg, -1).transpose(0, 1)
+    per_ref = F.ctc_loss(lp, ys, hlens, ylens, blank=0, reduction="none", zero_infinity=True)
+    (per_ref.sum() * 3.0).backward()
+    loss, per, dlog = K.ctc_loss_grad(logits.cuda(), v, b, t, ys.cuda(), hlens.cuda(), ylens.cuda(), 3.0)
+    want_per = per_ref.detach().clone()
+    got_per = per.cpu()
+    assert torch.isinf(got_per[4]) and want_per[4] == 0
+    assert rel(got_per[:4], want_per[:4]) < 1e-5
+    assert abs(float(loss) - float(want_per.sum()) / b) < 1e-4 * abs(float(want_per.sum()) / b)
+    got = dlog.float().cpu().view(b, t, vp)
+    assert float(got[..., v:].abs().max()) == 0.0
+    assert rel(got[..., :v], lg.grad) < 5e-3
+    assert float(got[4].abs().max()) == 0.0 and float(got[1, 50:].abs().max()) == 0.0

@@ -318,10 +318,10 @@ int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, float p, uint32_t
 int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, float p, uint32_t seed, uint32_t salt,
                             ma_stream_t stream);
 
-/* x (rows, cols) float32 += alpha * dropout(y) (models/conformer.py:109-151 branch joins); y bf16 or float32.
- * Backward: dy (bf16) = alpha * keep/(1-p) * g * row_scale[r]. */
-int ma_dropout_add_f32(float* x, int64_t ldx, const void* y, int64_t ldy, int32_t y_bf16, int64_t rows, int64_t cols,
-                       float alpha, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
+/* x (rows, cols) float32 = xin + alpha * dropout(y) (models/conformer.py:109-151 branch joins; xin may be x); y bf16 or
+ * float32.  Backward: dy (bf16) = alpha * keep/(1-p) * g * row_scale[r]. */
+int ma_dropout_add_f32(float* x, int64_t ldx, const float* xin, int64_t ldxin, const void* y, int64_t ldy, int32_t y_bf16,
+                       int64_t rows, int64_t cols, float alpha, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
 int ma_dropout_bwd_bf16(const float* g, int64_t ldg, void* dy, int64_t ldy, int64_t rows, int64_t cols, float alpha,
                         const float* row_scale, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
 
@@ -362,7 +362,8 @@ int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, i
 /* Rel-pos attention for training: the forward of ma_relpos_attention_bf16 that also writes lse (batch, heads, T)
  * float32 = log-sum-exp of the scaled, masked scores of every query row, and the backward pass
  * (layers/attention.py:182-237): from dctx (batch*T, 256) bf16 to dqkv (batch*T, 768) bf16 (dq | dk | dv),
- * dpos (T, 256) float32 += (summed over the batch), dbias_u / dbias_v (heads, 64) float32 += (caller zeroes the three). */
+ * dpos (T, 256) float32 with row stride ld_dpos += (summed over the batch), dbias_u / dbias_v (heads, 64) float32 +=
+ * (caller zeroes the three). */
 int ma_relpos_attention_train_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos,
                                    const float* bias_u, const float* bias_v, const float* mask, int64_t batch,
                                    int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
@@ -371,8 +372,9 @@ int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_
 int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
                                  const float* bias_v, const float* mask, const void* ctx, int64_t ld_ctx,
                                  const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
-                                 int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, float* dbias_u,
-                                 float* dbias_v, void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+                                 int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
+                                 float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
+                                 ma_stream_t stream);
 
 /* TrainOneStepWithLossScaleCell pieces (train_one_step.py:37-47): *flag |= 1 if any gradient is inf/nan; Adam
  * (MindSpore nn.Adam: p -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t) from the host) on

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restric
                                                        const float* __restrict__ mask, const float* __restrict__ lse,
                                                        AttnWs ws, int T, int H, float scale,
                                                        uint16_t* __restrict__ dqkv, int64_t ld_dqkv, float* dpos,
-                                                       float* du, float* dv) {
+                                                       int64_t ld_dpos, float* du, float* dv) {
   __shared__ __attribute__((aligned(16))) uint16_t Xs[64 * kXs];       // streamed X' rows
   __shared__ __attribute__((aligned(16))) uint16_t Ys[64 * kYs];       // streamed Y rows (dO or V)
   __shared__ __attribute__((aligned(16))) uint16_t Xt[128 * kTs];      // streamed X'^T
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restric
       for (int dt = 0; dt < 4; ++dt)  // dv
         *reinterpret_cast<uint2*>(orow + 512 + dt * 16) =
             make_uint2(ab_pack(acc_y[dt][0], acc_y[dt][1]), ab_pack(acc_y[dt][2], acc_y[dt][3]));
-      float* prow = dpos + (int64_t)fidx * 256 + h * 64 + lg * 4;  // dp: summed over the batch
+      float* prow = dpos + (int64_t)fidx * ld_dpos + h * 64 + lg * 4;  // dp: summed over the batch
 #pragma unroll
       for (int ct = 4; ct < 8; ++ct)
 #pragma unroll
@@ -336,13 +336,14 @@ int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_
 int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
                                  const float* bias_v, const float* mask, const void* ctx, int64_t ld_ctx,
                                  const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
-                                 int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, float* dbias_u,
-                                 float* dbias_v, void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+                                 int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
+                                 float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
+                                 ma_stream_t stream) {
   if (!qkv || !pos || !bias_u || !bias_v || !ctx || !dctx || !lse || !dqkv || !dpos || !dbias_u || !dbias_v || !workspace ||
       batch < 1 || T < 1)
     return MA_ERR_INVALID_ARG;
   if (d_k != 64 || heads * d_k != 256 || batch > 65535) return MA_ERR_UNSUPPORTED;
-  if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 7) || (ld_dctx & 7) || (ld_dqkv & 3)) return MA_ERR_UNSUPPORTED;
+  if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 7) || (ld_dctx & 7) || (ld_dqkv & 3) || ld_dpos < 256) return MA_ERR_UNSUPPORTED;
   if (workspace_bytes < ma_relpos_attention_bwd_workspace_bytes(batch, T, heads, d_k)) return MA_ERR_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(workspace) & 15) return MA_ERR_INVALID_ARG;
   AttnWs ws;
@@ -355,9 +356,9 @@ int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* po
   MA_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
             bias_u, bias_v, (const uint16_t*)ctx, ld_ctx, (const uint16_t*)dctx, ld_dctx, (int)T, (int)heads, ws);
   MA_LAUNCH(attn_bwd_kernel<true>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
-            mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, dbias_u, dbias_v);
+            mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   MA_LAUNCH(attn_bwd_kernel<false>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
-            mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, dbias_u, dbias_v);
+            mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   return MA_OK;
 }
 

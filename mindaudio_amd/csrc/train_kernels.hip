@@ -168,15 +168,16 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const uint16_t* __
 
 // x[r][c] += alpha * dropout(y[r][c]); y bf16 or f32 with row stride ldy; element index = r * cols + c
 template <bool Y_BF16>
-__global__ __launch_bounds__(256) void dropout_add_kernel(float* __restrict__ x, int64_t ldx, const void* y_, int64_t ldy,
-                                                          int64_t rows, int cols, float alpha, Drop d) {
+__global__ __launch_bounds__(256) void dropout_add_kernel(float* x, int64_t ldx, const float* xin, int64_t ldxin,
+                                                          const void* y_, int64_t ldy, int64_t rows, int cols, float alpha,
+                                                          Drop d) {
   const int64_t n = rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / cols;
     const int c = (int)(i - r * cols);
     float v = Y_BF16 ? bf2f(reinterpret_cast<const uint16_t*>(y_)[r * ldy + c]) : reinterpret_cast<const float*>(y_)[r * ldy + c];
     if (d.thresh) v = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? v * d.inv_keep : 0.0f;
-    x[r * ldx + c] += alpha * v;
+    x[r * ldx + c] = xin[r * ldxin + c] + alpha * v;
   }
 }
 // dy = alpha * keep / (1 - p) * g * row_scale  (bf16 operand of the branch's last GEMM backward)
@@ -537,16 +538,17 @@ int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, 
   return MA_OK;
 }
 
-int ma_dropout_add_f32(float* x, int64_t ldx, const void* y, int64_t ldy, int32_t y_bf16, int64_t rows, int64_t cols,
-                       float alpha, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
-  if (!x || !y || rows < 1 || cols < 1 || ldx < cols || ldy < cols || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+int ma_dropout_add_f32(float* x, int64_t ldx, const float* xin, int64_t ldxin, const void* y, int64_t ldy, int32_t y_bf16,
+                       int64_t rows, int64_t cols, float alpha, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
+  if (!x || !xin || !y || rows < 1 || cols < 1 || ldx < cols || ldxin < cols || ldy < cols || p < 0.0f || p >= 1.0f)
+    return MA_ERR_INVALID_ARG;
   const Drop d = make_drop(p, seed, salt);
   if (y_bf16)
-    MA_LAUNCH(dropout_add_kernel<true>, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
-              rows, (int)cols, alpha, d);
+    MA_LAUNCH(dropout_add_kernel<true>, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, xin, ldxin,
+              y, ldy, rows, (int)cols, alpha, d);
   else
-    MA_LAUNCH(dropout_add_kernel<false>, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
-              rows, (int)cols, alpha, d);
+    MA_LAUNCH(dropout_add_kernel<false>, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, x, ldx, xin, ldxin,
+              y, ldy, rows, (int)cols, alpha, d);
   return MA_OK;
 }
 

@@ -1,0 +1,450 @@
+"""Training step of the Conformer CTC model on MI355X — what `TrainOneStepWithLossScaleCell(ASRModelWithAcc, Adam,
+DynamicLossScaleUpdateCell)` does in the reference (mindaudio/utils/train_one_step.py:13-48,
+examples/conformer/train.py:104-141, examples/conformer/asr_model.py:75-153), with a hand-written backward pass.
+
+* All parameters live in ONE flat float32 buffer (masters), with a bf16 mirror at the same offsets (refreshed by one
+  cast kernel per step) and bf16 transposed copies of the matmul weights (the dX GEMMs read those).  Gradients, Adam
+  moments: flat buffers of the same layout -> one overflow check, one Adam launch, bucketed all-reduce on slices.
+* Forward keeps what the backward needs on an explicit tape (no autograd graph); dropout masks are regenerated from
+  (seed, site, index).  Matmuls are bf16 MFMA with float32 accumulation; residual stream, LayerNorm/BatchNorm
+  statistics, softmax, CTC lattice, gradients of parameters and the optimizer are float32.
+* Data parallel: one process per GPU; each rank runs the same step on its shard and the flat gradient is all-reduced
+  (SUM, then 1/world inside the Adam scale) in per-layer buckets launched as soon as a layer's backward is done
+  (torch.distributed: "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests of the bucketing logic).
+"""
+import math
+
+import torch
+
+from .. import _lib, ops
+from . import kernels as K
+
+_PAD = 64  # every entry of the flat buffers starts on a 64-element boundary (16-byte aligned in bf16 and f32)
+
+
+class FlatParams:
+    """Name -> (offset, shape) views into flat float32 / bf16 buffers."""
+
+    def __init__(self, entries, device):
+        self.index = {}
+        off = 0
+        for name, shape in entries:
+            n = 1
+            for s in shape:
+                n *= s
+            self.index[name] = (off, tuple(shape), n)
+            off += (n + _PAD - 1) // _PAD * _PAD
+        self.size = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
+        self.bf16 = torch.zeros(off, dtype=torch.bfloat16, device=device)
+
+    def _view(self, buf, name):
+        off, shape, n = self.index[name]
+        return buf[off:off + n].view(shape)
+
+    def p(self, name):
+        return self._view(self.master, name)
+
+    def g(self, name):
+        return self._view(self.grad, name)
+
+    def w(self, name):
+        return self._view(self.bf16, name)
+
+    def span(self, names):
+        lo = min(self.index[n][0] for n in names)
+        hi = max(self.index[n][0] + (self.index[n][2] + _PAD - 1) // _PAD * _PAD for n in names)
+        return lo, hi
+
+
+def asr_warmup_lr(step, base_lr=1e-3, warmup_steps=25000, start_steps=0):
+    """ASRWarmupLR (mindaudio/scheduler/scheduler_factory.py:14-52): 0 at step 0, peak base_lr at warmup_steps."""
+    s = float(step + start_steps)
+    if s <= 0.0:
+        return 0.0
+    return base_lr * warmup_steps ** 0.5 * min(s ** -0.5, s * warmup_steps ** -1.5)
+
+
+class DynamicLossScale:
+    """DynamicLossScaleUpdateCell(loss_scale_value, scale_factor, scale_window) (train.py:126-129): halve (min 1) on
+    overflow, double after `scale_window` consecutive clean steps."""
+
+    def __init__(self, init=1024.0, factor=2.0, window=1000):
+        self.scale, self.factor, self.window, self.good = float(init), float(factor), int(window), 0
+
+    def update(self, overflow):
+        if overflow:
+            self.scale = max(self.scale / self.factor, 1.0)
+            self.good = 0
+        else:
+            self.good += 1
+            if self.good >= self.window:
+                self.scale *= self.factor
+                self.good = 0
+
+
+_LAYER_W = (("ffm_w1", "feed_forward_macaron.w_1"), ("ffm_w2", "feed_forward_macaron.w_2"),
+            ("o_w", "self_attn.linear_out"), ("ff_w1", "feed_forward.w_1"), ("ff_w2", "feed_forward.w_2"))
+_LAYER_LN = ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final")
+
+
+class ConformerCTCTrainStep:
+    """step(batch columns) -> (loss, overflow, loss_scale, lr): one optimizer step of the CTC-only ASR model.
+
+    `model` is a mindaudio_amd.conformer.asr_model.ASRModel; its nn.Parameters provide the initial values (reference
+    init, train.py:56 seeds) and receive the trained values back through `sync_to_module()`."""
+
+    def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
+                 beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
+                 process_group=None, world_size=1, bn_momentum=0.1):
+        enc = model.encoder
+        self.model, self.enc = model, enc
+        self.dev = next(model.parameters()).device
+        self.L = len(enc.encoders)
+        self.d, self.heads = enc.d, enc.heads
+        self.V = model.ctc.ctc_lo.out_features
+        self.Vp = K.pad64(self.V)
+        self.hidden = enc.encoders[0].feed_forward.w_1.out_features
+        self.ks = enc.kernel
+        self.f2 = enc.embed.out.in_features // self.d
+        self.p_drop, self.p_pos = float(dropout_rate), float(positional_dropout_rate)
+        self.base_lr, self.warmup = base_lr, warmup_steps
+        self.b1, self.b2, self.eps = beta1, beta2, eps
+        self.scaler = DynamicLossScale(loss_scale, scale_factor, scale_window)
+        self.seed, self.global_step = int(seed), 0
+        self.pg, self.world = process_group, int(world_size)
+        self.bn_momentum = bn_momentum
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._pending = []
+        self._build_flat()
+        self.refresh_weights()
+
+    # ---- flat parameter layout ------------------------------------------------------------------------------------
+    def _build_flat(self):
+        d, hid, L, ks = self.d, self.hidden, self.L, self.ks
+        ent = [("conv1_w", (d, 9)), ("conv1_b", (d,)), ("conv2_w", (d, 9 * d)), ("conv2_b", (d,)),
+               ("out_w", (d, self.f2 * d)), ("out_b", (d,)), ("pos_w", (L * d, d))]
+        for i in range(L):
+            pre = "l%d." % i
+            ent += [(pre + "ffm_w1", (hid, d)), (pre + "ffm_b1", (hid,)), (pre + "ffm_w2", (d, hid)), (pre + "ffm_b2", (d,)),
+                    (pre + "qkv_w", (3 * d, d)), (pre + "qkv_b", (3 * d,)), (pre + "o_w", (d, d)), (pre + "o_b", (d,)),
+                    (pre + "u", (self.heads, d // self.heads)), (pre + "v", (self.heads, d // self.heads)),
+                    (pre + "pw1_w", (2 * d, d)), (pre + "pw1_b", (2 * d,)), (pre + "dw_w", (d, ks)), (pre + "dw_b", (d,)),
+                    (pre + "bn_g", (d,)), (pre + "bn_b", (d,)), (pre + "pw2_w", (d, d)), (pre + "pw2_b", (d,)),
+                    (pre + "ff_w1", (hid, d)), (pre + "ff_b1", (hid,)), (pre + "ff_w2", (d, hid)), (pre + "ff_b2", (d,))]
+            for ln in _LAYER_LN:
+                ent += [(pre + ln + ".g", (d,)), (pre + ln + ".b", (d,))]
+        ent += [("after_norm.g", (d,)), ("after_norm.b", (d,)), ("ctc_w", (self.V, d)), ("ctc_b", (self.Vp,))]
+        self.fp = FlatParams(ent, self.dev)
+        self._copy_params(to_flat=True)
+        # BatchNorm running statistics (buffers, not optimised)
+        self.bn_mean = [l.conv_module.norm.running_mean.detach().clone().float() for l in self.enc.encoders]
+        self.bn_var = [l.conv_module.norm.running_var.detach().clone().float() for l in self.enc.encoders]
+        self.layer_names = [[n for n in self.fp.index if n.startswith("l%d." % i)] for i in range(L)]
+        self.embed_names = ["conv1_w", "conv1_b", "conv2_w", "conv2_b", "out_w", "out_b"]
+
+    @torch.no_grad()
+    def _copy_params(self, to_flat, grads_out=None):
+        """to_flat: module parameters -> flat masters.  Otherwise flat -> module (masters into .data, or, when
+        `grads_out` is a dict, the flat gradients into grads_out[parameter name] in the module's layouts)."""
+        fp, e, d = self.fp, self.enc.embed, self.d
+        buf = fp.grad if grads_out is not None else fp.master
+        pname = {id(p): n for n, p in self.model.named_parameters()}
+
+        class _Flat:  # fp.p(...) of the selected buffer
+            @staticmethod
+            def p(name):
+                return fp._view(buf, name)
+
+        def put(param, value):
+            if grads_out is not None:
+                grads_out[pname[id(param)]] = value.reshape(param.shape).clone()
+            else:
+                param.data.copy_(value.reshape(param.shape))
+
+        def mv(name, param, fwd=None, bwd=None):
+            if to_flat:
+                src = param.detach().float()
+                fp.p(name).copy_((fwd(src) if fwd else src).reshape(fp.p(name).shape))
+            else:
+                src = _Flat.p(name)
+                put(param, bwd(src) if bwd else src)
+
+        mv("conv1_w", e.conv1.weight)
+        mv("conv1_b", e.conv1.bias)
+        # (Cout, Cin, 3, 3) <-> (Cout, kh, kw, Cin): k = (kh, kw, c) of the implicit GEMM
+        mv("conv2_w", e.conv2.weight, lambda w: w.permute(0, 2, 3, 1), lambda w: w.view(d, 3, 3, d).permute(0, 3, 1, 2))
+        mv("conv2_b", e.conv2.bias)
+        # reference flattens (c, f) (subsampling.py:76); the NHWC activation is (f, c)
+        mv("out_w", e.out.weight, lambda w: w.view(d, d, self.f2).permute(0, 2, 1),
+           lambda w: w.view(d, self.f2, d).permute(0, 2, 1))
+        mv("out_b", e.out.bias)
+        for i, l in enumerate(self.enc.encoders):
+            pre = "l%d." % i
+            a, cm = l.self_attn, l.conv_module
+            if to_flat:
+                fp.p("pos_w")[i * d:(i + 1) * d].copy_(a.linear_pos.weight.detach().float())
+            else:
+                put(a.linear_pos.weight, _Flat.p("pos_w")[i * d:(i + 1) * d])
+            for short, path in _LAYER_W:
+                mod = l
+                for part in path.split("."):
+                    mod = getattr(mod, part)
+                mv(pre + short, mod.weight)
+                mv(pre + short.replace("_w", "_b"), mod.bias)
+            for j, lin in enumerate((a.linear_q, a.linear_k, a.linear_v)):
+                if to_flat:
+                    fp.p(pre + "qkv_w")[j * d:(j + 1) * d].copy_(lin.weight.detach().float())
+                    fp.p(pre + "qkv_b")[j * d:(j + 1) * d].copy_(lin.bias.detach().float())
+                else:
+                    put(lin.weight, _Flat.p(pre + "qkv_w")[j * d:(j + 1) * d])
+                    put(lin.bias, _Flat.p(pre + "qkv_b")[j * d:(j + 1) * d])
+            mv(pre + "u", a.pos_bias_u)
+            mv(pre + "v", a.pos_bias_v)
+            mv(pre + "pw1_w", cm.pointwise_conv1.weight)
+            mv(pre + "pw1_b", cm.pointwise_conv1.bias)
+            mv(pre + "dw_w", cm.depthwise_conv.weight)
+            mv(pre + "dw_b", cm.depthwise_conv.bias)
+            mv(pre + "bn_g", cm.norm.weight)
+            mv(pre + "bn_b", cm.norm.bias)
+            mv(pre + "pw2_w", cm.pointwise_conv2.weight)
+            mv(pre + "pw2_b", cm.pointwise_conv2.bias)
+            for ln in _LAYER_LN:
+                mv(pre + ln + ".g", getattr(l, ln).gamma)
+                mv(pre + ln + ".b", getattr(l, ln).beta)
+        mv("after_norm.g", self.enc.after_norm.gamma)
+        mv("after_norm.b", self.enc.after_norm.beta)
+        mv("ctc_w", self.model.ctc.ctc_lo.weight)
+        if to_flat:
+            fp.p("ctc_b")[:self.V].copy_(self.model.ctc.ctc_lo.bias.detach().float())
+        else:
+            put(self.model.ctc.ctc_lo.bias, _Flat.p("ctc_b")[:self.V])
+
+    def gradients(self):
+        """{parameter name: gradient} of the last forward_backward, in the module's (reference) layouts."""
+        out = {}
+        self._copy_params(to_flat=False, grads_out=out)
+        return out
+
+    def sync_to_module(self):
+        """Write the trained masters (and BatchNorm running statistics) back into the nn.Module parameters."""
+        self._copy_params(to_flat=False)
+        for l, m, v in zip(self.enc.encoders, self.bn_mean, self.bn_var):
+            l.conv_module.norm.running_mean.copy_(m)
+            l.conv_module.norm.running_var.copy_(v)
+        self.enc._prepared = None
+        self.model.ctc._w = None
+
+    @torch.no_grad()
+    def refresh_weights(self):
+        """bf16 mirror of the masters (one cast launch) + transposed bf16 copies of the matmul weights."""
+        fp = self.fp
+        _lib.check(_lib.load().ma_cast_f32_bf16(fp.master.data_ptr(), fp.bf16.data_ptr(), fp.size,
+                                                torch.cuda.current_stream().cuda_stream), "cast")
+        if not hasattr(self, "wt"):
+            self.wt = {}
+        names = ["conv2_w", "out_w", "ctc_w"]
+        for i in range(self.L):
+            names += ["l%d.%s" % (i, s) for s in ("ffm_w1", "ffm_w2", "qkv_w", "o_w", "pw1_w", "pw2_w", "ff_w1", "ff_w2")]
+        for n in names:
+            self.wt[n] = K.transpose(fp.w(n), out=self.wt.get(n))
+
+    # ---- helpers ---------------------------------------------------------------------------------------------------
+    def _salt(self, layer, site):
+        return (layer + 1) * 16 + site
+
+    def _dW(self, dy, x, wname, bname):
+        """grad[wname] (N, K) += dy^T x ; grad[bname] += column sums of dy.  dy (M, N), x (M, K) bf16."""
+        fp = self.fp
+        dyt = K.transpose(dy, colsum=fp.g(bname) if bname else None)
+        xt = K.transpose(x)
+        K.gemm_splitk(dyt, xt, fp.g(wname))
+
+    # ---- forward + backward ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_backward(self, xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks=None, grad_scale=1.0):
+        """Runs the training-mode forward and the backward pass; flat gradients hold grad_scale * dLoss/dparam.
+        Returns the (unscaled) loss tensor."""
+        fp, d, L = self.fp, self.d, self.L
+        f32, bf = torch.float32, torch.bfloat16
+        seed = (self.seed + self.global_step) & 0x7fffffff
+        pd, pp = self.p_drop, self.p_pos
+        b, t, idim = xs_pad.shape
+        xs = xs_pad.to(f32).contiguous()
+        enc = self.enc
+        fp.grad.zero_()
+
+        # ================= forward =================
+        act1 = ops.subsample_conv1(xs, fp.p("conv1_w"), fp.p("conv1_b"), enc.cmvn_mean, enc.cmvn_istd)
+        act2 = ops.conv2d_3x3s2_nhwc(act1, fp.w("conv2_w").view(d, 3, 3, d), fp.p("conv2_b"), relu=True)
+        _, t2, f2, c = act2.shape
+        m = b * t2
+        if xs_masks.shape[-1] != t2:
+            raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(xs_masks.shape)))
+        mask2d = xs_masks.reshape(b, t2).to(f32).contiguous()
+        mask_rows = mask2d.reshape(m)
+        if xs_chunk_masks is not None and xs_chunk_masks.numel() != b * t2:
+            raise NotImplementedError("(B, T', T') chunk masks are not on the built training path")
+        att_mask = mask2d if xs_chunk_masks is None else xs_chunk_masks.reshape(b, t2).to(f32).contiguous()
+        hlens = mask2d.sum(1).to(torch.int32)
+        a2 = act2.view(m, f2 * c)
+        e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)
+        x = K.dropout_add(torch.zeros_like(e), e, 1.0, pp, seed, self._salt(-1, 0)) if pp > 0 else e
+        pe = enc.pe[:t2].to(f32).contiguous()
+        if pp > 0:
+            pe = K.dropout_add(torch.zeros_like(pe), pe, 1.0, pp, seed, self._salt(-1, 1))
+        pe_bf = ops.cast_bf16(pe)
+        pos_all = ops.gemm(pe_bf, fp.w("pos_w"))  # (t2, L*256) bf16
+        tape = []
+        for li in range(L):
+            pre = "l%d." % li
+            W, P = (lambda n, pre=pre: fp.w(pre + n)), (lambda n, pre=pre: fp.p(pre + n))
+            T = {}
+            # -- macaron FFN: x = x + 0.5 * drop(W2 drop(swish(W1 LN(x))))           models/conformer.py:109-112
+            T["ffm"] = self._ffn_fwd(x, "ffm", "norm_ff_macaron", W, P, seed, li, 0)
+            x = T["ffm"]["x_out"]
+            # -- MHSA                                                                :117-135
+            a = ops.layernorm(x, P("norm_mha.g"), P("norm_mha.b"))
+            qkv = ops.gemm(a, W("qkv_w"), bias=P("qkv_b"))
+            pos_l = pos_all[:, li * d:(li + 1) * d]
+            ctx, lse = K.attention_fwd(qkv, pos_l, P("u"), P("v"), att_mask, b, t2, self.heads, d // self.heads)
+            o = ops.gemm(ctx, W("o_w"), bias=P("o_b"))
+            x_new = K.dropout_add(x, o, 1.0, pd, seed, self._salt(li, 2))
+            T["mha"] = dict(x_in=x, a=a, qkv=qkv, ctx=ctx, lse=lse)
+            x = x_new
+            # -- convolution module                                                  :139-143, convolution.py:83-129
+            a = ops.layernorm(x, P("norm_conv.g"), P("norm_conv.b"), row_scale=mask_rows)
+            y = ops.gemm(a, W("pw1_w"), bias=P("pw1_b"))
+            wv, z, stats = K.convmid_fwd_train(y, b, t2, P("dw_w"), P("dw_b"), P("bn_g"), P("bn_b"), self.bn_mean[li],
+                                               self.bn_var[li], momentum=self.bn_momentum)
+            o = ops.gemm(wv, W("pw2_w"), bias=P("pw2_b"), row_scale=mask_rows)
+            x_new = K.dropout_add(x, o, 1.0, pd, seed, self._salt(li, 3))
+            T["conv"] = dict(x_in=x, a=a, y=y, w=wv, z=z, stats=stats)
+            x = x_new
+            # -- FFN                                                                 :147-151
+            T["ff"] = self._ffn_fwd(x, "ff", "norm_ff", W, P, seed, li, 6)
+            x = T["ff"]["x_out"]
+            # -- final LayerNorm of the block                                        :153-156
+            T["final_in"] = x
+            x = ops.layernorm(x, P("norm_final.g"), P("norm_final.b"), out_dtype=f32)
+            tape.append(T)
+        enc_bf = ops.layernorm(x, fp.p("after_norm.g"), fp.p("after_norm.b"))
+        logits = torch.empty((m, self.Vp), dtype=f32, device=self.dev)
+        ops.gemm(enc_bf, fp.w("ctc_w"), bias=fp.p("ctc_b"), out_dtype=f32, out=logits[:, :self.V])
+        loss, per_utt, dlog = K.ctc_loss_grad(logits, self.V, b, t2, ys_pad, hlens, ys_lengths, grad_scale / b)
+        self.last_encoder_out = None
+
+        # ================= backward =================
+        # CTC head: logits = enc_bf W^T + b
+        dlt = K.transpose(dlog, colsum=fp.g("ctc_b"))           # (Vp, Mp)
+        K.gemm_splitk(dlt[:self.V], K.transpose(enc_bf), fp.g("ctc_w"))
+        d_enc = ops.gemm(dlog, self.wt["ctc_w"])                # (m, 256) bf16
+        g = torch.empty((m, d), dtype=f32, device=self.dev)
+        K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
+        dpos_all = torch.zeros((t2, L * d), dtype=f32, device=self.dev)
+        for li in reversed(range(L)):
+            pre = "l%d." % li
+            W, P, G = (lambda n, pre=pre: fp.w(pre + n)), (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n))
+            WT = lambda n, pre=pre: self.wt[pre + n]  # noqa: E731
+            T = tape[li]
+            K.layernorm_bwd(T["final_in"], P("norm_final.g"), g, g, G("norm_final.g"), G("norm_final.b"), accumulate=False)
+            self._ffn_bwd(g, T["ff"], "ff", "norm_ff", pre, seed, li, 6)
+            # conv module
+            C = T["conv"]
+            do = K.dropout_bwd(g, 1.0, pd, seed, self._salt(li, 3), row_scale=mask_rows)
+            self._dW(do, C["w"], pre + "pw2_w", pre + "pw2_b")
+            dwv = ops.gemm(do, WT("pw2_w"))
+            dy = K.convmid_bwd(dwv, C["y"], C["z"], C["stats"], b, t2, P("dw_w"), P("bn_g"), P("bn_b"), G("dw_w"),
+                               G("dw_b"), G("bn_g"), G("bn_b"))
+            self._dW(dy, C["a"], pre + "pw1_w", pre + "pw1_b")
+            da = ops.gemm(dy, WT("pw1_w"))
+            K.layernorm_bwd(C["x_in"], P("norm_conv.g"), da, g, G("norm_conv.g"), G("norm_conv.b"), row_scale=mask_rows)
+            # MHSA
+            A = T["mha"]
+            do = K.dropout_bwd(g, 1.0, pd, seed, self._salt(li, 2))
+            self._dW(do, A["ctx"], pre + "o_w", pre + "o_b")
+            dctx = ops.gemm(do, WT("o_w"))
+            dqkv = K.attention_bwd(A["qkv"], pos_all[:, li * d:(li + 1) * d], P("u"), P("v"), att_mask, A["ctx"], dctx,
+                                   A["lse"], b, t2, dpos_all[:, li * d:(li + 1) * d], G("u"), G("v"), self.heads,
+                                   d // self.heads)
+            self._dW(dqkv, A["a"], pre + "qkv_w", pre + "qkv_b")
+            da = ops.gemm(dqkv, WT("qkv_w"))
+            K.layernorm_bwd(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"))
+            self._ffn_bwd(g, T["ffm"], "ffm", "norm_ff_macaron", pre, seed, li, 0)
+            self._layer_done(li)
+        # positional projection of every layer: dW_pos (L*256, 256) = dpos_all^T pe
+        self._dW(ops.cast_bf16(dpos_all), pe_bf, "pos_w", None)
+        # embedding: x = dropout(sqrt(d) * (a2 W_out^T + b))
+        de = K.dropout_bwd(g, math.sqrt(d), pp, seed, self._salt(-1, 0))
+        self._dW(de, a2, "out_w", "out_b")
+        dact2 = ops.gemm(de, self.wt["out_w"])                  # (m, f2*c) bf16
+        K.relu_bwd(dact2, a2)
+        dy2 = dact2.view(m * f2, c)
+        dy2t = K.transpose(dy2, colsum=fp.g("conv2_b"))
+        K.gemm_splitk(dy2t, K.im2col_t(act1), fp.g("conv2_w"))
+        dcol = ops.gemm(dy2, self.wt["conv2_w"])                # (B*T2*F2, 9c) bf16
+        dact1 = K.col2im_relu(dcol, act1)
+        K.conv1_dw(dact1, xs, enc.cmvn_mean, enc.cmvn_istd, fp.g("conv1_w"), fp.g("conv1_b"))
+        self._embed_done()
+        return loss
+
+    def _ffn_fwd(self, x, key, ln, W, P, seed, li, s0):
+        a = ops.layernorm(x, P(ln + ".g"), P(ln + ".b"))
+        u = ops.gemm(a, W(key + "_w1"), bias=P(key + "_b1"))
+        h = K.act_dropout_fwd(u, self.p_drop, seed, self._salt(li, s0))
+        y = ops.gemm(h, W(key + "_w2"), bias=P(key + "_b2"))
+        x_out = K.dropout_add(x, y, 0.5, self.p_drop, seed, self._salt(li, s0 + 1))
+        return dict(x_in=x, a=a, u=u, h=h, x_out=x_out)
+
+    def _ffn_bwd(self, g, T, key, ln, pre, seed, li, s0):
+        fp = self.fp
+        dy = K.dropout_bwd(g, 0.5, self.p_drop, seed, self._salt(li, s0 + 1))
+        self._dW(dy, T["h"], pre + key + "_w2", pre + key + "_b2")
+        dh = ops.gemm(dy, self.wt[pre + key + "_w2"])
+        du = K.act_dropout_bwd(T["u"], dh, self.p_drop, seed, self._salt(li, s0), out=dh)
+        self._dW(du, T["a"], pre + key + "_w1", pre + key + "_b1")
+        da = ops.gemm(du, self.wt[pre + key + "_w1"])
+        K.layernorm_bwd(T["x_in"], fp.p(pre + ln + ".g"), da, g, fp.g(pre + ln + ".g"), fp.g(pre + ln + ".b"))
+
+    # ---- data-parallel gradient reduction ----------------------------------------------------------------------------
+    def _all_reduce(self, lo, hi):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            self._pending.append(dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _layer_done(self, li):
+        """Backward of block li is complete: its slice of the flat gradient can go on the wire while earlier blocks
+        are still being differentiated."""
+        self._all_reduce(*self.fp.span(self.layer_names[li]))
+
+    def _embed_done(self):
+        self._all_reduce(*self.fp.span(["after_norm.g", "ctc_b"]))
+        self._all_reduce(*self.fp.span(self.embed_names + ["pos_w"]))
+
+    # ---- one optimizer step ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, xs_pad, ys_pad, ys_in_pad=None, ys_out_pad=None, r_ys_in_pad=None, r_ys_out_pad=None,
+             xs_masks=None, ys_sub_masks=None, ys_masks=None, ys_lengths=None, xs_chunk_masks=None):
+        """Same 11 inputs as ASRModelWithAcc.construct (train.py:38-50).  Returns (loss, overflow, scaling_sens, lr) —
+        the fields TrainOneStepWithLossScaleCell.construct returns (train_one_step.py:48) minus the duplicate."""
+        scale = self.scaler.scale
+        self._pending = []
+        self.flag.zero_()
+        loss = self.forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale=scale)
+        for work in self._pending:
+            work.wait()
+        K.grad_overflow(self.fp.grad, self.flag)
+        lr = asr_warmup_lr(self.global_step, self.base_lr, self.warmup)
+        tstep = self.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - self.b2 ** tstep) / (1.0 - self.b1 ** tstep)
+        K.adam(self.fp.master, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, lr_t, self.b1, self.b2, self.eps,
+               1.0 / (scale * self.world), self.flag)
+        self.refresh_weights()
+        overflow = bool(int(self.flag.item()))  # the reference also hands `cond` back to the host every step
+        self.scaler.update(overflow)
+        self.global_step += 1
+        return loss, overflow, scale, lr

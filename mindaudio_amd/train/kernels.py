@@ -62,12 +62,15 @@ def act_dropout_bwd(u, dh, p, seed, salt, out=None):
     return du
 
 
-def dropout_add(x, y, alpha, p, seed, salt):
+def dropout_add(x, y, alpha, p, seed, salt, out=None):
+    """out (default: a new tensor) = x + alpha * dropout(y); pass out=x for the in-place form."""
     t = _t()
-    _lib.check(_lib.load().ma_dropout_add_f32(_p(x), x.stride(0), _p(y), y.stride(0), 1 if y.dtype == t.bfloat16 else 0,
-                                              x.shape[0], x.shape[1], float(alpha), float(p), seed, salt, _s()),
-               "dropout_add")
-    return x
+    if out is None:
+        out = t.empty_like(x)
+    _lib.check(_lib.load().ma_dropout_add_f32(_p(out), out.stride(0), _p(x), x.stride(0), _p(y), y.stride(0),
+                                              1 if y.dtype == t.bfloat16 else 0, x.shape[0], x.shape[1], float(alpha),
+                                              float(p), seed, salt, _s()), "dropout_add")
+    return out
 
 
 def dropout_bwd(g, alpha, p, seed, salt, row_scale=None):
@@ -174,7 +177,7 @@ def attention_bwd(qkv, pos, bias_u, bias_v, mask, ctx, dctx, lse, batch, T, dpos
     ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
     _lib.check(lib.ma_relpos_attention_bwd_bf16(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v),
                                                 _p(mask), _p(ctx), ctx.stride(0), _p(dctx), dctx.stride(0), _p(lse),
-                                                batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos), _p(dbias_u),
+                                                batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos), dpos.stride(0), _p(dbias_u),
                                                 _p(dbias_v), _p(ws), ws_bytes, _s()), "attention_bwd")
     return dqkv
 

@@ -1,0 +1,152 @@
+"""GPU parity of the hand-written training step (mindaudio_amd.train.engine) against PyTorch-CPU autograd of the
+oracle model (oracle/conformer_oracle.py, float32): loss, every parameter gradient, the Adam update with the
+reference's loss-scale semantics, and BatchNorm running statistics.  The device multiplies in bf16 (float32
+accumulation), the oracle in float32: gradients are compared per tensor by relative RMS error."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(vocab=97, blocks=2, seed=5, cmvn=True):
+    from mindaudio_amd.conformer.asr_model import create_asr_model
+    from oracle import conformer_oracle as C
+
+    torch.manual_seed(seed)
+    mean = istd = None
+    kw = {}
+    if cmvn:
+        mean, istd = torch.randn(80) * 0.5, torch.rand(80) + 0.5
+        kw = dict(cmvn_mean=mean, cmvn_istd=istd)
+    ref_enc = C.ConformerEncoder(80, 256, 4, 2048, blocks, dropout_rate=0.0, positional_dropout_rate=0.0, **kw)
+    ref_ctc = C.CTC(vocab, 256)
+    with torch.no_grad():
+        for m in ref_enc.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.8, 1.2)
+                m.bias.normal_(0, 0.1)
+            if isinstance(m, C.LayerNorm):
+                m.gamma.uniform_(0.8, 1.2)
+                m.beta.normal_(0, 0.1)
+    model = create_asr_model(80, vocab, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks),
+                             global_cmvn=(mean, istd) if cmvn else None)
+    missing, unexpected = model.encoder.load_state_dict(ref_enc.state_dict(), strict=False)
+    assert not [k for k in missing if "cmvn" not in k] and not unexpected
+    model.ctc.load_state_dict(ref_ctc.state_dict())
+    return ref_enc.train(), ref_ctc.train(), model.cuda()
+
+
+def batch(b=3, tlen=131, vocab=97, seed=9):
+    from oracle import conformer_oracle as C
+
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.randn(b, tlen, 80, generator=g)
+    lens = [tlen, tlen - 30, tlen - 61][:b]
+    mask = torch.zeros(b, 1, tlen)
+    for i, n in enumerate(lens):
+        mask[i, 0, :n] = 1
+        xs[i, n:] = 0
+    sub = C.subsample_mask(mask)
+    ys_lens = torch.tensor([9, 6, 4][:b], dtype=torch.int32)
+    ys = torch.full((b, 9), -1, dtype=torch.int32)
+    for i, n in enumerate(ys_lens.tolist()):
+        ys[i, :n] = torch.randint(1, vocab, (n,), generator=g, dtype=torch.int32)
+    return xs, ys, sub, ys_lens
+
+
+def oracle_loss(ref_enc, ref_ctc, xs, ys, sub, ys_lens):
+    out, m = ref_enc(xs, sub)
+    hlens = m.reshape(m.shape[0], -1).sum(1).to(torch.int32)
+    return ref_ctc(out, hlens, ys.clamp(min=0).long(), ys_lens.long())
+
+
+def rel_rms(got, want):
+    return float((got.float().cpu() - want).norm() / (want.norm() + 1e-12))
+
+
+def test_forward_backward_matches_oracle_autograd():
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    ref_enc, ref_ctc, model = build()
+    xs, ys, sub, ys_lens = batch()
+    loss_ref = oracle_loss(ref_enc, ref_ctc, xs, ys, sub, ys_lens)
+    loss_ref.backward()
+    eng = ConformerCTCTrainStep(model, dropout_rate=0.0, positional_dropout_rate=0.0)
+    loss = eng.forward_backward(xs.cuda(), ys.cuda(), sub.cuda(), ys_lens.cuda(), grad_scale=1.0)
+    assert abs(float(loss) - float(loss_ref.detach())) <= 2e-2 * abs(float(loss_ref.detach()))
+    grads = eng.gradients()
+    want = {"encoder." + n: p.grad for n, p in ref_enc.named_parameters()}
+    want.update({"ctc." + n: p.grad for n, p in ref_ctc.named_parameters()})
+    assert set(grads) == set(want)
+    worst = {}
+    for name, gw in want.items():
+        # identically-zero gradients (rounding noise on both sides): the depthwise bias feeds a BatchNorm; a key
+        # bias shifts every score of a row by the same amount, which softmax ignores
+        if "depthwise_conv.bias" in name or "linear_k.bias" in name:
+            assert float(grads[name].abs().max()) < 1e-3 * float(max(p.abs().max() for p in want.values()))
+            continue
+        worst[name] = rel_rms(grads[name], gw)
+    bad = {k: round(v, 4) for k, v in worst.items() if v > 6e-2}
+    assert not bad, bad
+    assert sum(worst.values()) / len(worst) < 2.5e-2
+    # BatchNorm running statistics moved as nn.BatchNorm1d's do
+    for l_ref, m_, v_ in zip(ref_enc.encoders, eng.bn_mean, eng.bn_var):
+        assert rel_rms(m_, l_ref.conv_module.norm.running_mean) < 2e-2
+        assert rel_rms(v_, l_ref.conv_module.norm.running_var) < 2e-2
+
+
+def test_train_steps_follow_the_oracle_loss_curve():
+    """A few optimizer steps on one batch: Adam + ASRWarmupLR + dynamic loss scale vs the same recipe in PyTorch."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep, asr_warmup_lr
+
+    ref_enc, ref_ctc, model = build(seed=6, cmvn=False)
+    xs, ys, sub, ys_lens = batch(seed=10)
+    params = list(ref_enc.parameters()) + list(ref_ctc.parameters())
+    opt = torch.optim.Adam(params, lr=1.0, betas=(0.9, 0.999), eps=1e-8)
+    warm = 8
+    eng = ConformerCTCTrainStep(model, base_lr=2e-3, warmup_steps=warm, dropout_rate=0.0, positional_dropout_rate=0.0)
+    cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
+    got, want = [], []
+    for step in range(6):
+        lr = asr_warmup_lr(step, 2e-3, warm)
+        for gq in opt.param_groups:
+            gq["lr"] = lr
+        opt.zero_grad()
+        l_ref = oracle_loss(ref_enc, ref_ctc, xs, ys, sub, ys_lens)
+        l_ref.backward()
+        opt.step()
+        want.append(float(l_ref))
+        loss, overflow, scale, lr_dev = eng.step(*cols)
+        assert not overflow and scale == 1024.0 and abs(lr_dev - lr) < 1e-12
+        got.append(float(loss))
+    assert want[-1] < want[0]  # the recipe learns on this batch
+    for a, b_ in zip(got, want):
+        assert abs(a - b_) <= 3e-2 * abs(b_), (got, want)
+    # lr is 0 at step 0 (scheduler_factory.py:44-50): the first step must not move the weights
+    assert abs(got[0] - got[1]) <= 2e-2 * abs(got[0]) or got[1] < got[0]
+
+
+def test_overflow_skips_update_and_halves_scale():
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    _, _, model = build(blocks=1, seed=7, cmvn=False)
+    xs, ys, sub, ys_lens = batch(b=2, seed=11)
+    eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1,
+                                scale_window=2)
+    cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
+    eng.step(*cols)
+    before = eng.fp.master.clone()
+    xs_bad = xs.clone()
+    xs_bad[0, 3, 5] = float("inf")
+    loss, overflow, scale, _ = eng.step(xs_bad.cuda(), *cols[1:])
+    assert overflow and scale == 1024.0 and eng.scaler.scale == 512.0
+    assert torch.equal(eng.fp.master, before)
+    _, overflow, scale, _ = eng.step(*cols)
+    assert not overflow and scale == 512.0
+    eng.step(*cols)
+    assert eng.scaler.scale == 1024.0  # two clean steps (scale_window=2) double it again
+    assert not torch.equal(eng.fp.master, before)
+    eng.sync_to_module()
+    assert torch.equal(model.encoder.after_norm.gamma.detach(), eng.fp.p("after_norm.g"))

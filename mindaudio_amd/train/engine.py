@@ -86,9 +86,65 @@ class DynamicLossScale:
                 self.good = 0
 
 
+class BucketedAllReduce:
+    """Gradient all-reduce of the data-parallel step (the reference's grad_reducer, train_one_step.py:36): slices of the
+    flat gradient buffer are summed across ranks as soon as the backward pass has finished them (asynchronous
+    collectives on the backend's own stream), and `wait()` joins them before the optimizer.  With world == 1 it is a
+    no-op.  Division by the world size happens inside the Adam kernel's scale."""
+
+    def __init__(self, flat_grad, world_size=1, process_group=None):
+        self.grad, self.world, self.pg = flat_grad, int(world_size), process_group
+        self.pending, self.launched = [], []
+
+    def launch(self, lo, hi):
+        self.launched.append((lo, hi))
+        if self.world > 1:
+            import torch.distributed as dist
+
+            self.pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def wait(self):
+        for work in self.pending:
+            work.wait()
+        covered = sorted(self.launched)
+        self.pending, self.launched = [], []
+        return covered
+
+
 _LAYER_W = (("ffm_w1", "feed_forward_macaron.w_1"), ("ffm_w2", "feed_forward_macaron.w_2"),
             ("o_w", "self_attn.linear_out"), ("ff_w1", "feed_forward.w_1"), ("ff_w2", "feed_forward.w_2"))
 _LAYER_LN = ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final")
+
+
+def conformer_ctc_entries(d, hid, L, ks, heads, f2, V):
+    """(name, shape) of every trainable tensor in flat order: front (subsampling + positional projections), blocks
+    0..L-1, head (after_norm + CTC).  Matmul weights are stored in the layouts the kernels read (see _copy_params)."""
+    ent = [("conv1_w", (d, 9)), ("conv1_b", (d,)), ("conv2_w", (d, 9 * d)), ("conv2_b", (d,)),
+           ("out_w", (d, f2 * d)), ("out_b", (d,)), ("pos_w", (L * d, d))]
+    for i in range(L):
+        pre = "l%d." % i
+        ent += [(pre + "ffm_w1", (hid, d)), (pre + "ffm_b1", (hid,)), (pre + "ffm_w2", (d, hid)), (pre + "ffm_b2", (d,)),
+                (pre + "qkv_w", (3 * d, d)), (pre + "qkv_b", (3 * d,)), (pre + "o_w", (d, d)), (pre + "o_b", (d,)),
+                (pre + "u", (heads, d // heads)), (pre + "v", (heads, d // heads)),
+                (pre + "pw1_w", (2 * d, d)), (pre + "pw1_b", (2 * d,)), (pre + "dw_w", (d, ks)), (pre + "dw_b", (d,)),
+                (pre + "bn_g", (d,)), (pre + "bn_b", (d,)), (pre + "pw2_w", (d, d)), (pre + "pw2_b", (d,)),
+                (pre + "ff_w1", (hid, d)), (pre + "ff_b1", (hid,)), (pre + "ff_w2", (d, hid)), (pre + "ff_b2", (d,))]
+        for ln in _LAYER_LN:
+            ent += [(pre + ln + ".g", (d,)), (pre + ln + ".b", (d,))]
+    ent += [("after_norm.g", (d,)), ("after_norm.b", (d,)), ("ctc_w", (V, d)), ("ctc_b", ((V + 63) // 64 * 64,))]
+    return ent
+
+
+def bucket_names(fp, L):
+    layer_names = [[n for n in fp.index if n.startswith("l%d." % i)] for i in range(L)]
+    return layer_names, ["conv1_w", "conv1_b", "conv2_w", "conv2_b", "out_w", "out_b"]
+
+
+def bucket_spans(fp, L):
+    """[(lo, hi)] of the gradient buckets in launch order: blocks L-1 .. 0, then the head and the front."""
+    layer_names, embed_names = bucket_names(fp, L)
+    spans = [fp.span(layer_names[li]) for li in reversed(range(L))]
+    return spans + [fp.span(["after_norm.g", "ctc_b"]), fp.span(embed_names + ["pos_w"])]
 
 
 class ConformerCTCTrainStep:
@@ -118,33 +174,19 @@ class ConformerCTCTrainStep:
         self.pg, self.world = process_group, int(world_size)
         self.bn_momentum = bn_momentum
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self._pending = []
         self._build_flat()
+        self.reducer = BucketedAllReduce(self.fp.grad, self.world, self.pg)
         self.refresh_weights()
 
     # ---- flat parameter layout ------------------------------------------------------------------------------------
     def _build_flat(self):
-        d, hid, L, ks = self.d, self.hidden, self.L, self.ks
-        ent = [("conv1_w", (d, 9)), ("conv1_b", (d,)), ("conv2_w", (d, 9 * d)), ("conv2_b", (d,)),
-               ("out_w", (d, self.f2 * d)), ("out_b", (d,)), ("pos_w", (L * d, d))]
-        for i in range(L):
-            pre = "l%d." % i
-            ent += [(pre + "ffm_w1", (hid, d)), (pre + "ffm_b1", (hid,)), (pre + "ffm_w2", (d, hid)), (pre + "ffm_b2", (d,)),
-                    (pre + "qkv_w", (3 * d, d)), (pre + "qkv_b", (3 * d,)), (pre + "o_w", (d, d)), (pre + "o_b", (d,)),
-                    (pre + "u", (self.heads, d // self.heads)), (pre + "v", (self.heads, d // self.heads)),
-                    (pre + "pw1_w", (2 * d, d)), (pre + "pw1_b", (2 * d,)), (pre + "dw_w", (d, ks)), (pre + "dw_b", (d,)),
-                    (pre + "bn_g", (d,)), (pre + "bn_b", (d,)), (pre + "pw2_w", (d, d)), (pre + "pw2_b", (d,)),
-                    (pre + "ff_w1", (hid, d)), (pre + "ff_b1", (hid,)), (pre + "ff_w2", (d, hid)), (pre + "ff_b2", (d,))]
-            for ln in _LAYER_LN:
-                ent += [(pre + ln + ".g", (d,)), (pre + ln + ".b", (d,))]
-        ent += [("after_norm.g", (d,)), ("after_norm.b", (d,)), ("ctc_w", (self.V, d)), ("ctc_b", (self.Vp,))]
+        ent = conformer_ctc_entries(self.d, self.hidden, self.L, self.ks, self.heads, self.f2, self.V)
         self.fp = FlatParams(ent, self.dev)
         self._copy_params(to_flat=True)
         # BatchNorm running statistics (buffers, not optimised)
         self.bn_mean = [l.conv_module.norm.running_mean.detach().clone().float() for l in self.enc.encoders]
         self.bn_var = [l.conv_module.norm.running_var.detach().clone().float() for l in self.enc.encoders]
-        self.layer_names = [[n for n in self.fp.index if n.startswith("l%d." % i)] for i in range(L)]
-        self.embed_names = ["conv1_w", "conv1_b", "conv2_w", "conv2_b", "out_w", "out_b"]
+        self.layer_names, self.embed_names = bucket_names(self.fp, self.L)
 
     @torch.no_grad()
     def _copy_params(self, to_flat, grads_out=None):
@@ -410,20 +452,14 @@ class ConformerCTCTrainStep:
         K.layernorm_bwd(T["x_in"], fp.p(pre + ln + ".g"), da, g, fp.g(pre + ln + ".g"), fp.g(pre + ln + ".b"))
 
     # ---- data-parallel gradient reduction ----------------------------------------------------------------------------
-    def _all_reduce(self, lo, hi):
-        if self.world > 1:
-            import torch.distributed as dist
-
-            self._pending.append(dist.all_reduce(self.fp.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-
     def _layer_done(self, li):
         """Backward of block li is complete: its slice of the flat gradient can go on the wire while earlier blocks
         are still being differentiated."""
-        self._all_reduce(*self.fp.span(self.layer_names[li]))
+        self.reducer.launch(*self.fp.span(self.layer_names[li]))
 
     def _embed_done(self):
-        self._all_reduce(*self.fp.span(["after_norm.g", "ctc_b"]))
-        self._all_reduce(*self.fp.span(self.embed_names + ["pos_w"]))
+        self.reducer.launch(*self.fp.span(["after_norm.g", "ctc_b"]))
+        self.reducer.launch(*self.fp.span(self.embed_names + ["pos_w"]))
 
     # ---- one optimizer step ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -432,11 +468,9 @@ class ConformerCTCTrainStep:
         """Same 11 inputs as ASRModelWithAcc.construct (train.py:38-50).  Returns (loss, overflow, scaling_sens, lr) —
         the fields TrainOneStepWithLossScaleCell.construct returns (train_one_step.py:48) minus the duplicate."""
         scale = self.scaler.scale
-        self._pending = []
         self.flag.zero_()
         loss = self.forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale=scale)
-        for work in self._pending:
-            work.wait()
+        self.reducer.wait()
         K.grad_overflow(self.fp.grad, self.flag)
         lr = asr_warmup_lr(self.global_step, self.base_lr, self.warmup)
         tstep = self.global_step + 1

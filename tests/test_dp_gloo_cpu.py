@@ -61,3 +61,64 @@ def test_eval_net_single_rank_is_identity():
             return x.sum()
 
     assert float(ASREvalNet(Net(), 1)(torch.ones(3))) == 3.0
+
+
+# ---- gradient buckets of the training step (mindaudio_amd/train/engine.py) on gloo, world_size 2 ---------------------
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mindaudio_amd.train.engine import BucketedAllReduce, FlatParams, bucket_spans, conformer_ctc_entries
+
+    L = 3
+    fp = FlatParams(conformer_ctc_entries(256, 512, L, 15, 4, 19, 101), "cpu")
+    g = torch.Generator().manual_seed(100 + rank)
+    fp.grad.copy_(torch.randn(fp.size, generator=g))
+    mine = fp.grad.clone()
+    red = BucketedAllReduce(fp.grad, world)
+    for lo, hi in bucket_spans(fp, L):  # the order the backward pass launches them
+        red.launch(lo, hi)
+    covered = red.wait()
+    q.put((rank, mine.numpy(), fp.grad.numpy().copy(), covered, fp.size))  # by value: the child exits right after
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_cover_everything_and_sum_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = torch.from_numpy(res[0][1]) + torch.from_numpy(res[1][1])
+    for rank, _, reduced, covered, size in res:
+        assert torch.allclose(torch.from_numpy(reduced), total)  # every element was reduced exactly once
+        pos = 0
+        for lo, hi in covered:  # the buckets tile the flat buffer: no gap, no overlap
+            assert lo == pos
+            pos = hi
+        assert pos == size
+
+
+def test_lr_schedule_and_loss_scale_rules():
+    from mindaudio_amd.train.engine import DynamicLossScale, asr_warmup_lr
+
+    assert asr_warmup_lr(0) == 0.0  # scheduler_factory.py:44-50 at global_step 0
+    assert asr_warmup_lr(25000) == pytest.approx(1e-3)
+    assert asr_warmup_lr(100) == pytest.approx(1e-3 * 25000 ** 0.5 * 100 * 25000 ** -1.5)
+    assert asr_warmup_lr(100000) == pytest.approx(1e-3 * 25000 ** 0.5 * 100000 ** -0.5)
+    s = DynamicLossScale(1024, 2, 3)
+    s.update(True)
+    assert s.scale == 512
+    for _ in range(3):
+        s.update(False)
+    assert s.scale == 1024
+    for _ in range(12):
+        s.update(True)
+    assert s.scale == 1.0  # floor (DynamicLossScaleUpdateCell: max(scale / factor, 1))

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""cfg 4 of SURVEY §8(d): data-parallel CTC training step of Conformer-small on synthetic AISHELL-shaped batches.
+
+  python tools/train_bench.py [--steps K --warmup W --batch 40 --frames 1024 --vocab 4233 --blocks 12]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py ...
+
+One rank per GPU; every rank steps on its own (batch, frames, 80) shard (bucket 1024 of conformer.yaml), gradients are
+all-reduced over RCCL in per-block buckets overlapped with the backward pass.  Prints one JSON line on rank 0."""
+import argparse, json, os, sys, time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=40)
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--vocab", type=int, default=4233)
+    ap.add_argument("--blocks", type=int, default=12)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    args = ap.parse_args()
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from mindaudio_amd.conformer.asr_model import create_asr_model
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    torch.manual_seed(777)  # same initial weights on every rank (train.py:56)
+    model = create_asr_model(80, args.vocab, dict(output_size=256, attention_heads=4, linear_units=2048,
+                                                  num_blocks=args.blocks)).to(dev)
+    eng = ConformerCTCTrainStep(model, dropout_rate=args.dropout, positional_dropout_rate=args.dropout,
+                                world_size=world)
+    rng = np.random.RandomState(1234 + rank)
+    b, t = args.batch, args.frames
+    xs = torch.from_numpy(rng.randn(b, t, 80).astype(np.float32)).to(dev)
+    lens = rng.randint(int(0.7 * t), t + 1, b)
+    lens[0] = t
+    t2 = ((t - 3) // 2 + 1 - 3) // 2 + 1
+    masks = torch.zeros(b, 1, t2)
+    for i, n in enumerate(lens):
+        masks[i, 0, :(n - 1) // 4] = 1  # frames 4j < n (dataset.py:625)
+        xs[i, n:] = 0
+    masks = masks.to(dev)
+    ylens = rng.randint(5, 31, b).astype(np.int32)
+    ys = np.full((b, 30), -1, np.int32)
+    for i, n in enumerate(ylens):
+        ys[i, :n] = rng.randint(1, args.vocab - 1, n)
+    cols = (xs, torch.from_numpy(ys).to(dev), None, None, None, None, masks, None, None,
+            torch.from_numpy(ylens).to(dev), None)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(float(eng.step(*cols)[0]))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.step(*cols)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        nparam = eng.fp.size
+        print(json.dumps({
+            "metric": "utterances/s, Conformer-small CTC training step (fwd + bwd + all-reduce + Adam)",
+            "value": round(world * b * args.steps / dt, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "dtype": "bf16 matmuls, f32 master/grads/optimizer", "data": "synthetic",
+            "config": {"workload": "bucket-1024 batch (%d, %d, 80) per rank, V=%d, %d blocks, dropout %.2f, pure CTC, "
+                                   "Adam + ASRWarmupLR + dynamic loss scale" % (b, t, args.vocab, args.blocks, args.dropout),
+                       "global_batch": b * world, "flat_params": nparam,
+                       "grad_bytes_allreduced_per_step": nparam * 4 if world > 1 else 0},
+            "first_losses": [round(v, 3) for v in losses[:3]], "last_loss": round(float(out[0]), 3),
+            "loss_scale": out[2], "overflow": out[1]}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,28 +48,63 @@ struct Drop {
 };
 
 // ---- transpose (+ column sums) --------------------------------------------------------------------------------
+// 64 x 64 tile through LDS.  VEC: 16-byte global loads and stores (ld_in, ld_out, cols multiples of 8, 16-byte aligned
+// bases); otherwise element-wise with bounds checks.
+template <bool VEC>
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, int64_t ld_in, int rows,
                                                              int cols, uint16_t* __restrict__ out, int64_t ld_out,
                                                              float* colsum) {
-  __shared__ uint16_t tile[64][66];
-  __shared__ float csum[4][64];
+  __shared__ uint16_t tile[64][64 + 2];
+  __shared__ float csum[64];
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  float s = 0.0f;
-  for (int r = ty; r < 64; r += 4) {
-    const int rr = r0 + r, cc = c0 + tx;
-    uint16_t v = 0;
-    if (rr < rows && cc < cols) v = in[(int64_t)rr * ld_in + cc];
-    tile[r][tx] = v;
-    s += bf2f(v);
+  const int tid = threadIdx.x;
+  if (colsum && tid < 64) csum[tid] = 0.0f;
+  if (VEC) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256, r = idx >> 3, ch = idx & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const uint4*>(in + (int64_t)(r0 + r) * ld_in + c0 + ch * 8);
+      uint32_t* d = reinterpret_cast<uint32_t*>(&tile[r][ch * 8]);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int r = ty; r < 64; r += 4) {
+      uint16_t v = 0;
+      if (r0 + r < rows && c0 + tx < cols) v = in[(int64_t)(r0 + r) * ld_in + c0 + tx];
+      tile[r][tx] = v;
+    }
   }
-  if (colsum) csum[ty][tx] = s;
   __syncthreads();
-  for (int c = ty; c < 64; c += 4) {
-    const int cc = c0 + c, rr = r0 + tx;
-    if (cc < cols && rr < rows) out[(int64_t)cc * ld_out + rr] = tile[tx][c];
+  // thread -> output row c (input column), 8 consecutive input rows rc*8 .. +7
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + it * 256, c = idx & 63, rc = idx >> 6;
+    uint16_t e[8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      e[i] = tile[rc * 8 + i][c];
+      s += bf2f(e[i]);
+    }
+    if (colsum) atomicAdd(&csum[c], s);
+    if (c0 + c < cols) {
+      uint16_t* o = out + (int64_t)(c0 + c) * ld_out + r0 + rc * 8;
+      if (VEC && r0 + rc * 8 + 8 <= rows) {
+        *reinterpret_cast<uint4*>(o) = make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                                                  (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (r0 + rc * 8 + i < rows) o[i] = e[i];
+      }
+    }
   }
-  if (colsum && ty == 0 && c0 + tx < cols) atomicAdd(colsum + c0 + tx, (csum[0][tx] + csum[1][tx]) + (csum[2][tx] + csum[3][tx]));
+  if (colsum) {
+    __syncthreads();
+    if (tid < 64 && c0 + tid < cols) atomicAdd(colsum + c0 + tid, csum[tid]);
+  }
 }
 
 // ---- LayerNorm backward -----------------------------------------------------------------------------------------
@@ -306,43 +341,63 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ dn, co
 }
 
 // Depthwise-conv + GLU backward.  ds[t] = sum_j w[c][j] dz[t - (j - pad)]; dy = (ds * sig(g), ds * a * sig(g)(1 - sig(g)));
-// dw[c][j] += sum_t dz[t] * s[t + j - pad], db[c] += sum_t dz[t].  One thread = one (b, c) x time strip.
+// dw[c][j] += sum_t dz[t] * s[t + j - pad], db[c] += sum_t dz[t], s = glu(y).
+// Workgroup = (utterance b, strip of kCbStrip frames) x 256 channels (thread = channel): the strip plus its halo of
+// s and dz go through LDS once, so every tap is an LDS read with unit channel stride.
+constexpr int kCbStrip = 16, kCbPerBlock = 4;
 template <int KS>
 __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ y,
                                                           int64_t ldy, int B, int T, int C,
                                                           const float* __restrict__ w, uint16_t* __restrict__ dy,
-                                                          int64_t lddy, float* dw, float* db, int strip) {
-  // grid: (ceil(T / strip), B, C / 256); thread = channel
-  const int c = blockIdx.z * 256 + threadIdx.x;
+                                                          int64_t lddy, float* dw, float* db) {
+  constexpr int pad = (KS - 1) / 2, kRows = kCbStrip + KS - 1;
+  extern __shared__ float cb_lds[];
+  float* s_t = cb_lds;                // [kRows][256] glu(y)
+  float* z_t = cb_lds + kRows * 256;  // [kRows][256] dz
+  const int tid = threadIdx.x;
+  const int c = blockIdx.z * 256 + tid;
   const int b = blockIdx.y;
-  const int t0 = blockIdx.x * strip, t1 = min(T, t0 + strip);
-  constexpr int ks = KS, pad = (KS - 1) / 2;
+  const int64_t base = (int64_t)b * T;
   float wr[KS], dwr[KS];
 #pragma unroll
-  for (int j = 0; j < ks; ++j) { wr[j] = w[c * ks + j]; dwr[j] = 0.0f; }
+  for (int j = 0; j < KS; ++j) { wr[j] = w[c * KS + j]; dwr[j] = 0.0f; }
   float dbr = 0.0f;
-  const int64_t base = (int64_t)b * T;
+  // a workgroup walks kCbPerBlock consecutive strips so that the parameter-gradient atomics (one per channel and tap
+  // per workgroup) stay a small fraction of the work
+  for (int sidx = 0; sidx < kCbPerBlock; ++sidx) {
+  const int t0 = (blockIdx.x * kCbPerBlock + sidx) * kCbStrip;
+  if (t0 >= T) break;
+  for (int r = 0; r < kRows; ++r) {
+    const int t = t0 - pad + r;
+    float sv = 0.0f, zv = 0.0f;
+    if (t >= 0 && t < T) {
+      const uint16_t* yp = y + (base + t) * ldy + c;
+      sv = bf2f(yp[0]) * sigmoidf_(bf2f(yp[C]));
+      zv = dz[(base + t) * C + c];
+    }
+    s_t[r * 256 + tid] = sv;
+    z_t[r * 256 + tid] = zv;
+  }
+  // (each thread only reads its own column: no barrier needed)
+  const int t1 = min(T, t0 + kCbStrip);
   for (int t = t0; t < t1; ++t) {
-    const float dzt = dz[(base + t) * C + c];
+    const int r = t - t0 + pad;  // row of frame t in the tiles
+    const float dzt = z_t[r * 256 + tid];
     dbr += dzt;
     float ds = 0.0f;
 #pragma unroll
-    for (int j = 0; j < ks; ++j) {
-      const int tz = t - (j - pad);  // z[tz] used s[t] with tap j
-      if (tz >= 0 && tz < T) ds = fmaf(wr[j], dz[(base + tz) * C + c], ds);
-      const int tsrc = t + j - pad;  // z[t] used s[tsrc] with tap j
-      if (tsrc >= 0 && tsrc < T) {
-        const uint16_t* yp = y + (base + tsrc) * ldy + c;
-        dwr[j] = fmaf(dzt, bf2f(yp[0]) * sigmoidf_(bf2f(yp[C])), dwr[j]);
-      }
+    for (int j = 0; j < KS; ++j) {
+      ds = fmaf(wr[j], z_t[(r - (j - pad)) * 256 + tid], ds);      // z[t - (j - pad)] used s[t] with tap j
+      dwr[j] = fmaf(dzt, s_t[(r + j - pad) * 256 + tid], dwr[j]);  // z[t] used s[t + j - pad] with tap j
     }
     const uint16_t* yp = y + (base + t) * ldy + c;
     const float a = bf2f(yp[0]), sg = sigmoidf_(bf2f(yp[C]));
     dy[(base + t) * lddy + c] = f2bf(ds * sg);
     dy[(base + t) * lddy + C + c] = f2bf(ds * a * sg * (1.0f - sg));
   }
+  }
 #pragma unroll
-  for (int j = 0; j < ks; ++j) atomicAdd(dw + c * ks + j, dwr[j]);
+  for (int j = 0; j < KS; ++j) atomicAdd(dw + c * KS + j, dwr[j]);
   atomicAdd(db + c, dbr);
 }
 
@@ -503,8 +558,15 @@ int ma_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols,
                       float* colsum, ma_stream_t stream) {
   if (!in || !out || rows < 1 || cols < 1 || ld_in < cols || ld_out < rows || rows > 0x7fffffff || cols > 0x7fffffff)
     return MA_ERR_INVALID_ARG;
-  MA_LAUNCH(transpose_bf16_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64)), dim3(256), 0,
-            (hipStream_t)stream, (const uint16_t*)in, ld_in, (int)rows, (int)cols, (uint16_t*)out, ld_out, colsum);
+  const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64));
+  const bool vec = !(ld_in & 7) && !(ld_out & 7) && !(cols & 7) && !(reinterpret_cast<uintptr_t>(in) & 15) &&
+                   !(reinterpret_cast<uintptr_t>(out) & 15);
+  if (vec)
+    MA_LAUNCH(transpose_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, ld_in, (int)rows,
+              (int)cols, (uint16_t*)out, ld_out, colsum);
+  else
+    MA_LAUNCH(transpose_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, ld_in, (int)rows,
+              (int)cols, (uint16_t*)out, ld_out, colsum);
   return MA_OK;
 }
 
@@ -513,7 +575,7 @@ int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, c
                          int32_t accumulate, float* dgamma, float* dbeta, ma_stream_t stream) {
   if (!x || !gamma || !dy || !g || !dgamma || !dbeta || rows < 1) return MA_ERR_INVALID_ARG;
   if (D != 256 || (ldx & 3) || (ldy & 3) || (ldg & 3)) return MA_ERR_UNSUPPORTED;
-  const int grid = grid_for(rows, 4, 1024);
+  const int grid = grid_for(rows, 4, 512);
   if (dy_bf16)
     MA_LAUNCH(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
               row_scale, dy, ldy, g, ldg, accumulate, dgamma, dbeta);
@@ -603,15 +665,18 @@ int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t bat
                         ma_stream_t stream) {
   if (!dz || !y || !dw_w || !dy || !d_dw_w || !d_dw_b || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
   if (C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
-  const int strip = 32;
-  const dim3 grid((unsigned)((T + strip - 1) / strip), (unsigned)batch, (unsigned)(C / 256));
-#define MA_CMB(KS_)                                                                                                  \
-  MA_LAUNCH(convmid_bwd_kernel<KS_>, grid, dim3(256), 0, (hipStream_t)stream, dz, (const uint16_t*)y, ldy, (int)batch, \
-            (int)T, C, dw_w, (uint16_t*)dy, lddy, d_dw_w, d_dw_b, strip)
-  if (ks == 3) MA_CMB(3);
-  else if (ks == 7) MA_CMB(7);
-  else if (ks == 15) MA_CMB(15);
-  else MA_CMB(31);
+  const dim3 grid((unsigned)((T + kCbStrip * kCbPerBlock - 1) / (kCbStrip * kCbPerBlock)), (unsigned)batch, (unsigned)(C / 256));
+#define MA_CMB(KS_)                                                                                                    \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_bwd_kernel<KS_>),                                     \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kCbStrip + KS_ - 1) * 256 * 4) != hipSuccess) \
+    return MA_ERR_LAUNCH;                                                                                              \
+  MA_LAUNCH(convmid_bwd_kernel<KS_>, grid, dim3(256), (size_t)2 * (kCbStrip + KS_ - 1) * 256 * sizeof(float),          \
+            (hipStream_t)stream, dz, (const uint16_t*)y, ldy, (int)batch, (int)T, C, dw_w, (uint16_t*)dy, lddy, d_dw_w,  \
+            d_dw_b)
+  if (ks == 3) { MA_CMB(3); }
+  else if (ks == 7) { MA_CMB(7); }
+  else if (ks == 15) { MA_CMB(15); }
+  else { MA_CMB(31); }
 #undef MA_CMB
   return MA_OK;
 }

@@ -292,7 +292,10 @@ class ConformerCTCTrainStep:
         for i in range(self.L):
             names += ["l%d.%s" % (i, s) for s in ("ffm_w1", "ffm_w2", "qkv_w", "o_w", "pw1_w", "pw2_w", "ff_w1", "ff_w2")]
         for n in names:
-            self.wt[n] = K.transpose(fp.w(n), out=self.wt.get(n))
+            if n not in self.wt:
+                rows, cols = fp.w(n).shape
+                self.wt[n] = torch.zeros((cols, K.pad64(rows)), dtype=torch.bfloat16, device=self.dev)
+            K.transpose(fp.w(n), out=self.wt[n])
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _salt(self, layer, site):
@@ -301,8 +304,8 @@ class ConformerCTCTrainStep:
     def _dW(self, dy, x, wname, bname):
         """grad[wname] (N, K) += dy^T x ; grad[bname] += column sums of dy.  dy (M, N), x (M, K) bf16."""
         fp = self.fp
-        dyt = K.transpose(dy, colsum=fp.g(bname) if bname else None)
-        xt = K.transpose(x)
+        dyt = K.transpose(dy, colsum=fp.g(bname) if bname else None, slot=0)
+        xt = K.transpose(x, slot=1)
         K.gemm_splitk(dyt, xt, fp.g(wname))
 
     # ---- forward + backward ------------------------------------------------------------------------------------------
@@ -381,8 +384,8 @@ class ConformerCTCTrainStep:
 
         # ================= backward =================
         # CTC head: logits = enc_bf W^T + b
-        dlt = K.transpose(dlog, colsum=fp.g("ctc_b"))           # (Vp, Mp)
-        K.gemm_splitk(dlt[:self.V], K.transpose(enc_bf), fp.g("ctc_w"))
+        dlt = K.transpose(dlog, colsum=fp.g("ctc_b"), slot=0)   # (Vp, Mp)
+        K.gemm_splitk(dlt[:self.V], K.transpose(enc_bf, slot=1), fp.g("ctc_w"))
         d_enc = ops.gemm(dlog, self.wt["ctc_w"])                # (m, 256) bf16
         g = torch.empty((m, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
@@ -425,7 +428,7 @@ class ConformerCTCTrainStep:
         dact2 = ops.gemm(de, self.wt["out_w"])                  # (m, f2*c) bf16
         K.relu_bwd(dact2, a2)
         dy2 = dact2.view(m * f2, c)
-        dy2t = K.transpose(dy2, colsum=fp.g("conv2_b"))
+        dy2t = K.transpose(dy2, colsum=fp.g("conv2_b"), slot=0)
         K.gemm_splitk(dy2t, K.im2col_t(act1), fp.g("conv2_w"))
         dcol = ops.gemm(dy2, self.wt["conv2_w"])                # (B*T2*F2, 9c) bf16
         dact1 = K.col2im_relu(dcol, act1)

@@ -19,12 +19,20 @@ def pad64(n):
     return (n + 63) // 64 * 64
 
 
-def transpose(x, out=None, colsum=None):
-    """x (rows, cols) bf16 -> (cols, pad64(rows)) bf16 with zero padding (a K-padded GEMM operand)."""
+_tr_pool = {}
+
+
+def transpose(x, out=None, colsum=None, slot=0):
+    """x (rows, cols) bf16 -> (cols, pad64(rows)) bf16 with zero padding (a K-padded GEMM operand).
+    Without `out` the result lives in a pooled scratch buffer keyed by (shape, slot): it is valid until the next
+    transpose of the same shape and slot (the pad columns are zeroed once, when the buffer is created)."""
     t = _t()
     rows, cols = x.shape
     if out is None:
-        out = t.zeros((cols, pad64(rows)), dtype=t.bfloat16, device=x.device)
+        key = (rows, cols, slot, str(x.device))
+        out = _tr_pool.get(key)
+        if out is None:
+            out = _tr_pool[key] = t.zeros((cols, pad64(rows)), dtype=t.bfloat16, device=x.device)
     _lib.check(_lib.load().ma_transpose_bf16(_p(x), x.stride(0), rows, cols, _p(out), out.stride(0), _p(colsum), _s()),
                "transpose")
     return out
@@ -127,7 +135,10 @@ def im2col_t(act):
     t = _t()
     b, h, w, c = act.shape
     m = b * ((h - 3) // 2 + 1) * ((w - 3) // 2 + 1)
-    out = t.zeros((9 * c, pad64(m)), dtype=t.bfloat16, device=act.device)
+    key = ("im2col", 9 * c, m, str(act.device))
+    out = _tr_pool.get(key)
+    if out is None:  # pooled like transpose(): the pad columns are zeroed once
+        out = _tr_pool[key] = t.zeros((9 * c, pad64(m)), dtype=t.bfloat16, device=act.device)
     _lib.check(_lib.load().ma_im2col_t_3x3s2_nhwc_bf16(_p(act), b, h, w, c, _p(out), out.stride(0), _s()), "im2col_t")
     return out
 

@@ -159,8 +159,10 @@ int ma_amplitude_to_db_f32(const float* in, int64_t groups, int64_t elems_per_gr
  * ---------------------------------------------------------------------------------------------- */
 
 /* What happens to acc = A . W^T before it is stored:
- *   v = act(acc + bias[n]) * alpha * row_scale[m] (+ residual[m, n])
- * act: 0 none, 1 swish x*sigmoid(x) (layers/swish.py:14-16), 2 relu.  NULL pointers switch a term off. */
+ *   v = act2(act(acc + bias[n]) * col_scale[n] + col_shift[n]) * alpha * row_scale[m] (+ residual[m, n])
+ * act / act2: 0 none, 1 swish x*sigmoid(x) (layers/swish.py:14-16), 2 relu, 3 sigmoid, 4 tanh.  NULL pointers switch a
+ * term off.  col_scale/col_shift: a BatchNorm in affine form behind the activation (ecapatdnn.py:60-64: conv -> ReLU ->
+ * BatchNorm). */
 typedef struct ma_gemm_epilogue {
   const float* bias;       /* device [N] */
   const float* residual;   /* device (M, N) float32, row stride ldr */
@@ -169,6 +171,10 @@ typedef struct ma_gemm_epilogue {
   float alpha;             /* e.g. ff_scale 0.5 (models/conformer.py:69) or sqrt(d_model) (embedding.py:84) */
   int32_t act;
   int32_t out_bf16;        /* 1: out is bf16, 0: float32 */
+  const float* col_scale;  /* device [N], 16-byte aligned; NULL: no affine */
+  const float* col_shift;  /* device [N] */
+  int32_t act2;
+  int32_t reserved;
 } ma_gemm_epilogue_t;
 
 /* Dense / k=1 Conv1d (layers/dense.py:51-58, layers/conv1d.py): out (M, N) = epilogue(A (M, K) . W (N, K)^T).
@@ -257,6 +263,38 @@ int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t
 
 /* float32 -> bf16 (round to nearest even), n % 4 == 0: the `cast` in front of a matmul operand. */
 int ma_cast_f32_bf16(const float* x, void* y, int64_t n, ma_stream_t stream);
+
+/* nn.Conv1d(C -> N, kernel `taps`, dilation, pad_mode "same") of mindaudio/models/ecapatdnn.py:47-56 as an implicit
+ * GEMM over a (rows, C) bf16 activation with row stride lda:
+ *   out[m, n] = epilogue( sum_{j < taps} sum_{c < C} act[m + (j - taps/2) * dilation, c] * W[n, j, c] )
+ * W (N, taps, C) bf16.  "Same" zero padding comes from the layout: every utterance is stored with >= (taps/2)*dilation
+ * zero halo rows before and after it (and the buffer with that many margin rows at both ends), and the epilogue's
+ * row_scale zeroes the halo rows of the output so that it can feed the next convolution.  C % 64 == 0. */
+int ma_conv1d_taps_bf16(const void* act, int64_t lda, int64_t rows, int64_t C, int32_t taps, int32_t dilation,
+                        const void* W, void* out, int64_t ldo, int64_t N, const ma_gemm_epilogue_t* epi,
+                        ma_stream_t stream);
+
+/* ---- ECAPA-TDNN forward (mindaudio/models/ecapatdnn.py:7-433): the pieces between its convolutions ------------
+ * Activations: (batch, T + 2*halo, C) bf16, zero halo frames around every utterance (see ma_conv1d_taps_bf16). */
+
+/* (batch, T, F) float32 features -> (batch, T + 2*halo, Cpad) bf16, zero halo frames and zero channels F..Cpad-1. */
+int ma_ecapa_pack_input_bf16(const float* x, int64_t batch, int64_t T, int32_t F, int32_t halo, int32_t Cpad, void* out,
+                             ma_stream_t stream);
+/* out = a + b on (rows, cols) bf16 slices with their own row strides (Res2Net's x_i + y_{i-1}, ecapatdnn.py:108-111);
+ * b == NULL: strided copy.  cols and strides multiples of 8. */
+int ma_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols,
+                ma_stream_t stream);
+/* SE squeeze (ecapatdnn.py:152-153): out (batch, C) bf16 = mean over the T frames of every utterance. */
+int ma_time_mean_bf16(const void* x, int64_t ldx, int64_t batch, int64_t T, int32_t halo, int32_t C, void* out,
+                      ma_stream_t stream);
+/* SE excite + block residual (ecapatdnn.py:156, 246): out = gate[b, c] * x + residual on the T frames, 0 on halo frames. */
+int ma_se_apply_bf16(const void* x, int64_t ldx, const void* gate, const void* residual, int64_t ldr, void* out,
+                     int64_t ldo, int64_t batch, int64_t T, int32_t halo, int32_t C, ma_stream_t stream);
+/* Attentive statistics pooling (ecapatdnn.py:284-308) + the BatchNorm behind it in affine form (ecapatdnn.py:427):
+ * w = softmax over T of logits[:, c]; mean = sum w x; std = sqrt(clip(sum w (x - mean)^2, eps));
+ * out (batch, 2C) bf16 = (mean | std) * bn_scale + bn_shift (bn_* have 2C entries). */
+int ma_asp_pool_bf16(const void* logits, int64_t ldl, const void* x, int64_t ldx, int64_t batch, int64_t T, int32_t halo,
+                     int32_t C, float eps, const float* bn_scale, const float* bn_shift, void* out, ma_stream_t stream);
 
 /* ---- batch assembly of the training loop (examples/conformer/dataset.py:536-656) -------------------------- */
 

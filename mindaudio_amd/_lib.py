@@ -55,10 +55,14 @@ class GemmEpilogue(ctypes.Structure):
         ("alpha", f32),
         ("act", i32),
         ("out_bf16", i32),
+        ("col_scale", ctypes.c_void_p),
+        ("col_shift", ctypes.c_void_p),
+        ("act2", i32),
+        ("reserved", i32),
     ]
 
 
-ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); must list every symbol include/mindaudio_amd.h declares
 PROTOTYPES = {
@@ -103,10 +107,17 @@ PROTOTYPES = {
     "ma_ctc_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, i32, i32, f32, vp, vp, vp, vp, i64,
                                             vp, i64, vp]),
     "ma_cast_f32_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p]),
+    "ma_ecapa_pack_input_bf16": (ctypes.c_int, [vp, i64, i64, i32, i32, i32, vp, vp]),
+    "ma_add_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
+    "ma_time_mean_bf16": (ctypes.c_int, [vp, i64, i64, i64, i32, i32, vp, vp]),
+    "ma_se_apply_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]),
+    "ma_asp_pool_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i32, i32, f32, vp, vp, vp, vp]),
     "ma_subsampled_mask_len": (i32, [i32]),
     "ma_collate_asr_i32": (ctypes.c_int, [ctypes.c_void_p] * 3 + [i32] * 7 + [ctypes.c_void_p] * 11),
     "ma_spec_aug_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p, i32,
                                        ctypes.c_void_p, i32, ctypes.c_void_p]),
+    "ma_conv1d_taps_bf16": (ctypes.c_int, [vp, i64, i64, i64, i32, i32, vp, vp, i64, i64, ctypes.POINTER(GemmEpilogue),
+                                           vp]),
     "ma_gemm_bf16_splitk_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp]),
     "ma_transpose_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
     "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp]),

@@ -49,6 +49,13 @@ struct GemmParams {
   float alpha;
   // im2col (3x3, stride 2, valid) over an NHWC activation (B, H, Wd, C): row m = (b, ho, wo), k = (kh, kw, c)
   int32_t H, Wd, C, Ho, Wo;
+  // mode 2 (Conv1d taps over a (rows, C) bf16 activation with zero halo rows): K index = tap * C + c reads row
+  // m + (tap - taps/2) * dil; `C` above is the channel count
+  int32_t dil, taps;
+  // after the activation: v = v * col_scale[n] + col_shift[n] (BatchNorm in affine form), then act2 (0 none, 4 tanh)
+  const float* col_scale;
+  const float* col_shift;
+  int32_t act2;
   // split-K (weight gradients: small outputs, long contraction): blockIdx.y owns K-tiles [y * kt_split, ...) and
   // atomically adds its partial product into the float32 output (kt_split == 0: the whole K range, plain stores)
   int32_t kt_split;
@@ -65,6 +72,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   // swish: x * sigmoid(x) (layers/swish.py:14-16) = x / (1 + 2^(-x log2 e))
   if (act == 1) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
   if (act == 2) return fmaxf(v, 0.0f);
+  if (act == 3) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));  // sigmoid
+  if (act == 4) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * v)) - 1.0f;  // tanh
   return v;
 }
 
@@ -73,7 +82,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // whose 16-byte chunks are XOR-swizzled by (row & 7).  Tiles are filled by global_load_lds_dwordx4 (one
 // instruction = 8 rows = 1 KiB, no VGPR staging; the swizzle is applied to the per-lane SOURCE address), two
 // tiles ahead of the MFMAs: per K-step one counted s_waitcnt vmcnt + one raw s_barrier.
-template <int BM, int BN, int NST, bool IM2COL>
+template <int BM, int BN, int NST, int IM2COL>
 __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024) ? 1 : ((NST * (BM + BN) * BK * 2 > 53 * 1024) ? 2 : 3)) void gemm_bf16_kernel(
     const GemmParams p) {
   constexpr int kStages = NST;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
     int m = m0 + 8 * (wave + 4 * g) + lr;
     if (m >= p.M) m = p.M - 1;  // clamp: rows past M are computed and never stored
     int64_t base;
-    if (IM2COL) {
+    if (IM2COL == 1) {
       const int wo = m % p.Wo;
       const int t = m / p.Wo;
       const int ho = t % p.Ho;
@@ -130,7 +139,11 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
   }
   auto a_koff = [&](int kt) -> int64_t {
     const int k0 = kt * BK;
-    if (!IM2COL) return k0;
+    if (IM2COL == 0) return k0;
+    if (IM2COL == 2) {
+      const int tap = k0 / p.C;  // BK divides C: one tap per K-tile
+      return (int64_t)(tap - p.taps / 2) * p.dil * p.lda + (k0 - tap * p.C);
+    }
     const int khw = k0 / p.C;  // BK divides C: one (kh, kw) per K-tile
     const int kh = khw / 3, kw = khw - 3 * kh;
     return ((int64_t)kh * p.Wd + kw) * p.C + (k0 - khw * p.C);
@@ -230,7 +243,14 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
           v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act) * rs;
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+        if (p.col_scale) {
+          const float4 cs = *reinterpret_cast<const float4*>(p.col_scale + n);
+          const float4 ct = *reinterpret_cast<const float4*>(p.col_shift + n);
+          v[0] = v[0] * cs.x + ct.x; v[1] = v[1] * cs.y + ct.y; v[2] = v[2] * cs.z + ct.z; v[3] = v[3] * cs.w + ct.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2) * rs;
         if (p.residual) {
           const float* rp = p.residual + (int64_t)m * p.ldr + n;
           if ((p.ldr & 3) == 0) {
@@ -246,7 +266,9 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
         for (int r = 0; r < 4; ++r) {
           if (n + r < p.N) {
             float x = v[r] + (p.bias ? p.bias[n + r] : 0.0f);
-            x = apply_act(x, p.act) * rs;
+            x = apply_act(x, p.act);
+            if (p.col_scale) x = x * p.col_scale[n + r] + p.col_shift[n + r];
+            x = apply_act(x, p.act2) * rs;
             if (p.residual) x += p.residual[(int64_t)m * p.ldr + n + r];
             v[r] = x;
           }
@@ -305,7 +327,7 @@ static int gemm_num_cus() {
   return g_gemm_cus;
 }
 
-template <int BM, int BN, int NST, bool IM2COL>
+template <int BM, int BN, int NST, int IM2COL>
 static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
   constexpr int lds = NST * (BM + BN) * BK * 2;
   static bool attr = false;
@@ -321,7 +343,7 @@ static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
   return MA_OK;
 }
 
-template <bool IM2COL>
+template <int IM2COL>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   // 128 x 128 tiles unless they would leave most CUs without a workgroup (N = 256 .. 768 at M ~ 8k)
   const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -341,7 +363,13 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
 static int fill_epilogue(GemmParams& p, const ma_gemm_epilogue_t* e) {
   p.alpha = 1.0f;
   if (!e) return MA_OK;
-  if (e->act < 0 || e->act > 2) return MA_ERR_INVALID_ARG;
+  if (e->act < 0 || e->act > 4 || e->act2 < 0 || e->act2 > 4) return MA_ERR_INVALID_ARG;
+  if ((e->col_scale == nullptr) != (e->col_shift == nullptr)) return MA_ERR_INVALID_ARG;
+  if (e->col_scale && ((reinterpret_cast<uintptr_t>(e->col_scale) | reinterpret_cast<uintptr_t>(e->col_shift)) & 15))
+    return MA_ERR_INVALID_ARG;
+  p.col_scale = e->col_scale;
+  p.col_shift = e->col_shift;
+  p.act2 = e->act2;
   p.bias = e->bias;
   p.residual = e->residual;
   p.row_scale = e->row_scale;
@@ -377,7 +405,31 @@ int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* o
   p.K = (int32_t)K;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
-  return launch_gemm<false>(p, (hipStream_t)stream);
+  return launch_gemm<0>(p, (hipStream_t)stream);
+}
+
+int ma_conv1d_taps_bf16(const void* act, int64_t lda, int64_t rows, int64_t C, int32_t taps, int32_t dilation,
+                        const void* W, void* out, int64_t ldo, int64_t N, const ma_gemm_epilogue_t* epi,
+                        ma_stream_t stream) {
+  if (!act || !W || !out || rows < 1 || C < 1 || N < 1 || taps < 1 || !(taps & 1) || dilation < 1) return MA_ERR_INVALID_ARG;
+  if (C % BK != 0 || lda < C || (lda & 7) || ldo < N || rows > 0x7fffffff) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(act) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return MA_ERR_INVALID_ARG;
+  GemmParams p = GemmParams{};
+  p.A = reinterpret_cast<const uint16_t*>(act);
+  p.W = reinterpret_cast<const uint16_t*>(W);
+  p.out = out;
+  p.lda = lda;
+  p.ldw = (int64_t)taps * C;
+  p.ldo = ldo;
+  p.M = (int32_t)rows;
+  p.N = (int32_t)N;
+  p.K = (int32_t)(taps * C);
+  p.C = (int32_t)C;
+  p.taps = taps;
+  p.dil = dilation;
+  const int rc = fill_epilogue(p, epi);
+  if (rc != MA_OK) return rc;
+  return launch_gemm<2>(p, (hipStream_t)stream);
 }
 
 int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t ldw, float* out, int64_t ldo,
@@ -403,7 +455,7 @@ int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t l
   if (splits > nk / 4) splits = nk / 4;
   if (splits < 1) splits = 1;
   p.kt_split = (int32_t)((nk + splits - 1) / splits);
-  return launch_gemm_tile<64, 128, 3, false>(p, (hipStream_t)stream);
+  return launch_gemm_tile<64, 128, 3, 0>(p, (hipStream_t)stream);
 }
 
 int ma_conv2d_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* W,
@@ -428,7 +480,7 @@ int ma_conv2d_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t
   p.ldo = Cout;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
-  return launch_gemm<true>(p, (hipStream_t)stream);
+  return launch_gemm<1>(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

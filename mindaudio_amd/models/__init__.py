@@ -1,1 +1,2 @@
 from .conformer import ConformerEncoder  # noqa: F401
+from .ecapatdnn import EcapaTDNN  # noqa: F401

@@ -1,0 +1,73 @@
+"""GPU parity: EcapaTDNN forward (mindaudio_amd.models.EcapaTDNN, HIP kernels) vs the PyTorch-CPU float32 oracle
+(oracle/ecapa_oracle.py, parity unpinned).  The device multiplies in bf16 with float32 accumulation: the embedding is
+compared by relative RMS error and cosine similarity."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(c=512, seed=3):
+    from mindaudio_amd.models import EcapaTDNN
+    from oracle import ecapa_oracle as E
+
+    torch.manual_seed(seed)
+    ref = E.EcapaTDNN(80, channels=(c, c, c, c, 3 * c)).eval()
+    with torch.no_grad():
+        for m in ref.modules():  # non-trivial BatchNorm statistics
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.8, 1.2)
+                m.bias.normal_(0, 0.1)
+    dut = EcapaTDNN(80, channels=(c, c, c, c, 3 * c)).eval()
+    missing, unexpected = dut.load_state_dict(ref.state_dict(), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return ref, dut.cuda().prepare()
+
+
+@pytest.mark.parametrize("b,t", [(3, 57), (2, 300)])
+def test_ecapa_forward_matches_oracle(b, t):
+    ref, dut = build()
+    x = torch.randn(b, t, 80)
+    with torch.no_grad():
+        want = ref(x)
+    got = dut(x.cuda()).cpu()
+    assert got.shape == want.shape == (b, 192)
+    rel = float((got - want).norm() / want.norm())
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=1)
+    assert rel < 3e-2, rel
+    assert float(cos.min()) > 0.999
+
+
+def test_ecapa_conv_taps_and_epilogue_against_torch():
+    """The tap-convolution GEMM mode and the ReLU -> BatchNorm -> tanh epilogue on their own, float32 reference."""
+    import ctypes
+
+    from mindaudio_amd import _host, _lib
+    from mindaudio_amd.models.ecapatdnn import HALO, _conv
+
+    torch.manual_seed(0)
+    b, t, cin, cout, k, d = 2, 41, 64, 128, 3, 3
+    x = torch.randn(b, cin, t)
+    conv = torch.nn.Conv1d(cin, cout, k, dilation=d, padding=d)
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    want = torch.tanh(torch.relu(conv(x.bfloat16().float())) * scale[None, :, None] + shift[None, :, None])
+    tp = t + 2 * HALO
+    full = torch.zeros(b * tp + 2 * HALO, cin, dtype=torch.bfloat16)
+    view = full[HALO:HALO + b * tp].view(b, tp, cin)
+    view[:, HALO:HALO + t] = x.transpose(1, 2).bfloat16()
+    full = full.cuda()
+    w = conv.weight.detach().permute(0, 2, 1).contiguous().bfloat16().view(cout, -1).cuda()
+    out = torch.empty(b * tp, cout, dtype=torch.bfloat16, device="cuda")
+    rs = torch.zeros(b, tp)
+    rs[:, HALO:HALO + t] = 1
+    _conv(full[HALO:].data_ptr(), cin, b * tp, cin, w, k, d, out.data_ptr(), cout, cout, conv.bias.detach().cuda(),
+          _lib.ACT_RELU, (scale.cuda(), shift.cuda()), act2=_lib.ACT_TANH, row_scale=rs.view(-1).cuda())
+    got = out.float().cpu().view(b, tp, cout)
+    assert float(got[:, :HALO].abs().max()) == 0.0 and float(got[:, HALO + t:].abs().max()) == 0.0
+    got = got[:, HALO:HALO + t].transpose(1, 2)
+    wq = conv.weight.detach().bfloat16().float()
+    want = torch.tanh(torch.relu(torch.nn.functional.conv1d(x.bfloat16().float(), wq, conv.bias, dilation=d, padding=d))
+                      * scale[None, :, None] + shift[None, :, None])
+    assert float((got - want).abs().max()) < 1.5e-2

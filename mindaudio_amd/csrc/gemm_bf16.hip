@@ -68,12 +68,13 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return r;
 }
 
+template <bool EXT = true>
 __device__ __forceinline__ float apply_act(float v, int act) {
   // swish: x * sigmoid(x) (layers/swish.py:14-16) = x / (1 + 2^(-x log2 e))
   if (act == 1) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
   if (act == 2) return fmaxf(v, 0.0f);
-  if (act == 3) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));  // sigmoid
-  if (act == 4) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * v)) - 1.0f;  // tanh
+  if (EXT && act == 3) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));  // sigmoid
+  if (EXT && act == 4) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * v)) - 1.0f;  // tanh
   return v;
 }
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // whose 16-byte chunks are XOR-swizzled by (row & 7).  Tiles are filled by global_load_lds_dwordx4 (one
 // instruction = 8 rows = 1 KiB, no VGPR staging; the swizzle is applied to the per-lane SOURCE address), two
 // tiles ahead of the MFMAs: per K-step one counted s_waitcnt vmcnt + one raw s_barrier.
-template <int BM, int BN, int NST, int IM2COL>
+template <int BM, int BN, int NST, int IM2COL, int EPI>
 __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024) ? 1 : ((NST * (BM + BN) * BK * 2 > 53 * 1024) ? 2 : 3)) void gemm_bf16_kernel(
     const GemmParams p) {
   constexpr int kStages = NST;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
   for (int j = 0; j < FN; ++j) foff_w[j] = BM * 128 + lds_off(wn * (BN / 2) + j * 16 + frow, fk);
 
   int kt_lo = 0, nk = p.K / BK;
-  if (p.kt_split > 0) {
+  if (EPI == 2) {
     kt_lo = blockIdx.y * p.kt_split;
     nk = min(nk - kt_lo, p.kt_split);
   }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
 
   // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] ------------------
   const int em = lane & 15, en = (lane >> 4) * 4;
-  if (p.kt_split > 0) {  // split-K partial: out (float32) += alpha * acc
+  if (EPI == 2) {  // split-K partial: out (float32) += alpha * acc
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m = m0 + wm * (BM / 2) + i * 16 + em;
@@ -243,14 +244,14 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
           v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-        if (p.col_scale) {
+        for (int r = 0; r < 4; ++r) v[r] = apply_act<EPI == 1>(v[r], p.act);
+        if (EPI == 1 && p.col_scale) {
           const float4 cs = *reinterpret_cast<const float4*>(p.col_scale + n);
           const float4 ct = *reinterpret_cast<const float4*>(p.col_shift + n);
           v[0] = v[0] * cs.x + ct.x; v[1] = v[1] * cs.y + ct.y; v[2] = v[2] * cs.z + ct.z; v[3] = v[3] * cs.w + ct.w;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2) * rs;
+        for (int r = 0; r < 4; ++r) v[r] = (EPI == 1 ? apply_act(v[r], p.act2) : v[r]) * rs;
         if (p.residual) {
           const float* rp = p.residual + (int64_t)m * p.ldr + n;
           if ((p.ldr & 3) == 0) {
@@ -266,9 +267,9 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
         for (int r = 0; r < 4; ++r) {
           if (n + r < p.N) {
             float x = v[r] + (p.bias ? p.bias[n + r] : 0.0f);
-            x = apply_act(x, p.act);
-            if (p.col_scale) x = x * p.col_scale[n + r] + p.col_shift[n + r];
-            x = apply_act(x, p.act2) * rs;
+            x = apply_act<EPI == 1>(x, p.act);
+            if (EPI == 1 && p.col_scale) x = x * p.col_scale[n + r] + p.col_shift[n + r];
+            x = (EPI == 1 ? apply_act(x, p.act2) : x) * rs;
             if (p.residual) x += p.residual[(int64_t)m * p.ldr + n + r];
             v[r] = x;
           }
@@ -327,37 +328,37 @@ static int gemm_num_cus() {
   return g_gemm_cus;
 }
 
-template <int BM, int BN, int NST, int IM2COL>
+template <int BM, int BN, int NST, int IM2COL, int EPI>
 static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
   constexpr int lds = NST * (BM + BN) * BK * 2;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, NST, IM2COL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, NST, IM2COL, EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MA_ERR_LAUNCH;
     attr = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int splits = p.kt_split > 0 ? (p.K / BK + p.kt_split - 1) / p.kt_split : 1;
-  MA_LAUNCH((gemm_bf16_kernel<BM, BN, NST, IM2COL>), dim3(tiles, splits), dim3(kGemmThreads), lds, stream, p);
+  MA_LAUNCH((gemm_bf16_kernel<BM, BN, NST, IM2COL, EPI>), dim3(tiles, splits), dim3(kGemmThreads), lds, stream, p);
   return MA_OK;
 }
 
-template <int IM2COL>
+template <int IM2COL, int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   // 128 x 128 tiles unless they would leave most CUs without a workgroup (N = 256 .. 768 at M ~ 8k)
   const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
   static const char* force = getenv("MA_GEMM_TILE");  // developer override: "1" 128x128x3, "2" 128x128x2, "6" 64x128x3
-  if (force && force[0] == '1') return launch_gemm_tile<128, 128, 3, IM2COL>(p, stream);
-  if (force && force[0] == '2') return launch_gemm_tile<128, 128, 2, IM2COL>(p, stream);
-  if (force && force[0] == '6') return launch_gemm_tile<64, 128, 3, IM2COL>(p, stream);
-  if (force && force[0] == '7') return launch_gemm_tile<64, 128, 2, IM2COL>(p, stream);
+  if (force && force[0] == '1') return launch_gemm_tile<128, 128, 3, IM2COL, EPI>(p, stream);
+  if (force && force[0] == '2') return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
+  if (force && force[0] == '6') return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
+  if (force && force[0] == '7') return launch_gemm_tile<64, 128, 2, IM2COL, EPI>(p, stream);
   // measured on MI355X (tools/gemm_bench.py): 2 workgroups/CU beat a deeper ring for the 128x128 tile; the
   // 64x128 tile prefers 3 workgroups/CU (2 stages) when there are enough tiles to fill them, else the 3-stage ring
-  if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, 2, IM2COL>(p, stream);
+  if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
   const int64_t small = (int64_t)((p.M + 63) / 64) * ((p.N + 127) / 128);
-  if (small >= (int64_t)(2.4 * gemm_num_cus())) return launch_gemm_tile<64, 128, 2, IM2COL>(p, stream);
-  return launch_gemm_tile<64, 128, 3, IM2COL>(p, stream);
+  if (small >= (int64_t)(2.4 * gemm_num_cus())) return launch_gemm_tile<64, 128, 2, IM2COL, EPI>(p, stream);
+  return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
 }
 
 static int fill_epilogue(GemmParams& p, const ma_gemm_epilogue_t* e) {
@@ -405,7 +406,8 @@ int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* o
   p.K = (int32_t)K;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
-  return launch_gemm<0>(p, (hipStream_t)stream);
+  if (p.col_scale || p.act2 || p.act > 2) return launch_gemm<0, 1>(p, (hipStream_t)stream);
+  return launch_gemm<0, 0>(p, (hipStream_t)stream);
 }
 
 int ma_conv1d_taps_bf16(const void* act, int64_t lda, int64_t rows, int64_t C, int32_t taps, int32_t dilation,
@@ -429,7 +431,7 @@ int ma_conv1d_taps_bf16(const void* act, int64_t lda, int64_t rows, int64_t C, i
   p.dil = dilation;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
-  return launch_gemm<2>(p, (hipStream_t)stream);
+  return launch_gemm<2, 1>(p, (hipStream_t)stream);
 }
 
 int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t ldw, float* out, int64_t ldo,
@@ -455,7 +457,7 @@ int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t l
   if (splits > nk / 4) splits = nk / 4;
   if (splits < 1) splits = 1;
   p.kt_split = (int32_t)((nk + splits - 1) / splits);
-  return launch_gemm_tile<64, 128, 3, 0>(p, (hipStream_t)stream);
+  return launch_gemm_tile<64, 128, 3, 0, 2>(p, (hipStream_t)stream);
 }
 
 int ma_conv2d_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* W,
@@ -480,7 +482,8 @@ int ma_conv2d_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t
   p.ldo = Cout;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
-  return launch_gemm<1>(p, (hipStream_t)stream);
+  if (p.col_scale || p.act2 || p.act > 2) return MA_ERR_UNSUPPORTED;
+  return launch_gemm<1, 0>(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -334,10 +334,22 @@ int ma_spec_aug_f32(float* xs, int64_t batch, int64_t max_frames, int32_t n_freq
  * Memory-bound backward pieces and the optimizer; the matmuls of the backward pass reuse ma_gemm_bf16
  * (dX = dY . W on a transposed weight copy) and ma_gemm_bf16_splitk_f32 (dW = dY^T . X on transposed activations). */
 
-/* out (M, N) float32 += alpha * A (M, K) . W (N, K)^T, contraction split across workgroups with float32 atomics
- * (weight gradients: small outputs, K = batch*time).  The caller zeroes `out`.  K % 64 == 0. */
+/* out (M, N) float32 (+)= alpha * A (M, K) . W (N, K)^T with the contraction split across workgroups (weight
+ * gradients: small outputs, K = batch*time): every split writes its partial product to `workspace`
+ * (>= ma_gemm_splitk_workspace_bytes), a second kernel sums the splits in a fixed order (deterministic).  K % 64 == 0. */
+int64_t ma_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t ldw, float* out, int64_t ldo,
-                            int64_t M, int64_t N, int64_t K, float alpha, ma_stream_t stream);
+                            int64_t M, int64_t N, int64_t K, float alpha, int32_t accumulate, void* workspace,
+                            int64_t workspace_bytes, ma_stream_t stream);
+
+/* out (Mo_store, No) float32 (+)= alpha * A^T . B for ROW-major A (Kc, Mo), B (Kc, No) bf16: dW = dY^T . X straight from
+ * the activations (no transposed copies; LDS transpose-reads feed the MFMAs).  Rows i >= Mo_store of the product are
+ * not stored (zero-padded vocabulary columns).  colsum (Mo_store) float32, optional: += column sums of A (bias
+ * gradient).  Mo, No, lda, ldb multiples of 8; workspace >= ma_gemm_tn_workspace_bytes(Mo, No, Kc). */
+int64_t ma_gemm_tn_workspace_bytes(int64_t Mo, int64_t No, int64_t Kc);
+int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, float* out, int64_t ldo, int64_t Mo,
+                        int64_t No, int64_t Kc, int64_t Mo_store, float alpha, int32_t accumulate, float* colsum,
+                        void* workspace, int64_t workspace_bytes, ma_stream_t stream);
 
 /* out[c][r] = in[r][c] (bf16); columns r in [rows, ld_out) of `out` are not written (keep them zero to use the
  * result as a K-padded GEMM operand).  colsum (cols) float32, optional: += column sums of `in` (bias gradients). */

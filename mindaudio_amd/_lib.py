@@ -118,7 +118,10 @@ PROTOTYPES = {
                                        ctypes.c_void_p, i32, ctypes.c_void_p]),
     "ma_conv1d_taps_bf16": (ctypes.c_int, [vp, i64, i64, i64, i32, i32, vp, vp, i64, i64, ctypes.POINTER(GemmEpilogue),
                                            vp]),
-    "ma_gemm_bf16_splitk_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp]),
+    "ma_gemm_splitk_workspace_bytes": (i64, [i64, i64, i64]),
+    "ma_gemm_bf16_splitk_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, i32, vp, i64, vp]),
+    "ma_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
+    "ma_gemm_tn_bf16_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, f32, i32, vp, vp, i64, vp]),
     "ma_transpose_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
     "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp]),
     "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, f32, u32, u32, vp]),

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
 
   // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] ------------------
   const int em = lane & 15, en = (lane >> 4) * 4;
-  if (EPI == 2) {  // split-K partial: out (float32) += alpha * acc
+  if (EPI == 2) {  // split-K partial product of K-range blockIdx.y: plain stores into workspace[split][M][N]
+    float* part = reinterpret_cast<float*>(p.out) + (int64_t)blockIdx.y * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m = m0 + wm * (BM / 2) + i * 16 + em;
@@ -215,10 +216,14 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 16 + en;
-        float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
+        float* o = part + (int64_t)m * p.N + n;
+        if (n + 3 < p.N && (p.N & 3) == 0) {
+          *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) atomicAdd(o + r, acc[i][j][r] * p.alpha);
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) o[r] = acc[i][j][r];
+        }
       }
     }
     return;
@@ -313,6 +318,19 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
       *reinterpret_cast<uint4*>(o + (int64_t)r * p.ldo + cc * 8) =
           *reinterpret_cast<const uint4*>(smem + r * (kRowBytes + 16) + cc * 16);
     }
+  }
+}
+
+// out[m][n] (+)= alpha * sum_s part[s][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn,
+                                                            float* __restrict__ out, int64_t ldo, int N, float alpha,
+                                                            int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) {
+    float s = 0.0f;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * mn + i];
+    const int64_t m = i / N;
+    float* o = out + m * ldo + (i - m * N);
+    *o = accumulate ? *o + alpha * s : alpha * s;
   }
 }
 
@@ -434,30 +452,54 @@ int ma_conv1d_taps_bf16(const void* act, int64_t lda, int64_t rows, int64_t C, i
   return launch_gemm<2, 1>(p, (hipStream_t)stream);
 }
 
+static int splitk_plan(int64_t M, int64_t N, int64_t K, int* kt_split) {
+  // about two workgroups per CU, at least 8 K-tiles (512 contraction elements) per split
+  const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
+  const int64_t nk = K / BK;
+  int64_t splits = (2 * gemm_num_cus() + tiles - 1) / tiles;
+  if (splits > nk / 8) splits = nk / 8;
+  if (splits < 1) splits = 1;
+  *kt_split = (int)((nk + splits - 1) / splits);
+  return (int)((nk + *kt_split - 1) / *kt_split);
+}
+
+int64_t ma_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || N < 1 || K < BK) return MA_ERR_INVALID_ARG;
+  int kt = 0;
+  return (int64_t)splitk_plan(M, N, K, &kt) * M * N * 4;
+}
+
 int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t ldw, float* out, int64_t ldo,
-                            int64_t M, int64_t N, int64_t K, float alpha, ma_stream_t stream) {
-  if (!A || !W || !out || M < 1 || N < 1 || K < 1 || M > 0x7fffffff || N > 0x7fffffff) return MA_ERR_INVALID_ARG;
+                            int64_t M, int64_t N, int64_t K, float alpha, int32_t accumulate, void* workspace,
+                            int64_t workspace_bytes, ma_stream_t stream) {
+  if (!A || !W || !out || !workspace || M < 1 || N < 1 || K < 1 || M > 0x7fffffff || N > 0x7fffffff) return MA_ERR_INVALID_ARG;
   if (K % BK != 0 || lda < K || ldw < K || ldo < N || (lda & 7) || (ldw & 7)) return MA_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return MA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return MA_ERR_INVALID_ARG;
   GemmParams p = GemmParams{};
   p.A = reinterpret_cast<const uint16_t*>(A);
   p.W = reinterpret_cast<const uint16_t*>(W);
-  p.out = out;
+  p.out = workspace;
   p.lda = lda;
   p.ldw = ldw;
-  p.ldo = ldo;
+  p.ldo = N;
   p.M = (int32_t)M;
   p.N = (int32_t)N;
   p.K = (int32_t)K;
-  p.alpha = alpha;
-  // enough splits to put ~3 workgroups on every CU, at least 4 K-tiles (256 contraction elements) each
-  const int64_t tiles = ((M + 63) / 64) * ((N + 127) / 128);
-  const int64_t nk = K / BK;
-  int64_t splits = (3 * gemm_num_cus() + tiles - 1) / tiles;
-  if (splits > nk / 4) splits = nk / 4;
-  if (splits < 1) splits = 1;
-  p.kt_split = (int32_t)((nk + splits - 1) / splits);
-  return launch_gemm_tile<64, 128, 3, 0, 2>(p, (hipStream_t)stream);
+  p.alpha = 1.0f;
+  int kt = 0;
+  const int splits = splitk_plan(M, N, K, &kt);
+  p.kt_split = kt;
+  if (workspace_bytes < (int64_t)splits * M * N * 4) return MA_ERR_WORKSPACE;
+  const int rc = launch_gemm_tile<64, 128, 3, 0, 2>(p, (hipStream_t)stream);
+  if (rc != MA_OK) return rc;
+  const int64_t mn = M * N;
+  int64_t blocks = (mn + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  MA_LAUNCH(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+            reinterpret_cast<const float*>(workspace), splits, mn, out, ldo, (int)N, alpha, (int)accumulate);
+  return MA_OK;
 }
 
 int ma_conv2d_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* W,

@@ -1,0 +1,333 @@
+// Weight-gradient GEMM of the training step without transposed operand copies (gfx950):
+//   out[i][j] (+)= alpha * sum_m A[m][i] * B[m][j]        A (Kc, Mo), B (Kc, No) bf16 ROW-major, contraction over rows
+// i.e. dW = dY^T . X straight from the row-major activations the forward / backward kernels wrote.
+//
+// Both operands stream HBM/L2 -> LDS with global_load_lds_dwordx4 as [64 contraction rows][tile columns] row-major
+// tiles (3-stage ring, counted vmcnt, one barrier per K-step, as gemm_bf16.hip).  The MFMA wants, per lane, 8
+// consecutive contraction elements of one output row/column, which in this layout is a COLUMN walk: the fragments are
+// read with ds_read_b64_tr_b16 (16 lanes address a [4 rows][16 cols] block, 8 bytes each; lane i receives column i,
+// rows 0..3 — measured with tools/ubench/tr_read.hip), two reads per 8-element fragment.  The 16 rows touched by one
+// read share a column offset, so 32-byte granules of every LDS row are XOR-swizzled by row bits (applied to the
+// per-lane SOURCE address of the LDS-DMA, whose destinations are lane-linear).
+// The contraction is split over blockIdx.y; partial products go to a workspace and are summed by splitk_reduce_kernel
+// (deterministic).  Optional column sums of A (bias gradients) ride on one extra MFMA per fragment with an all-ones
+// operand in the workgroups of the first column tile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void tn_lds_t;
+typedef __attribute__((address_space(1))) const void tn_gl_t;
+
+struct TnParams {
+  const uint16_t* A;  // (Kc, >= Mo) row stride lda
+  const uint16_t* B;  // (Kc, >= No) row stride ldb
+  float* part;        // workspace [splits][Mo_store][No]
+  float* colsum;      // optional [Mo]: += column sums of A (atomics across splits)
+  int64_t lda, ldb;
+  int32_t Mo, No, Kc, Mo_store, kt_split;
+};
+
+constexpr int kTnBK = 64, kTnStages = 3, kTnThreads = 256;
+
+// swizzle of the 32-byte granules of LDS row r: rows r = a + 4h + 8g (a < 4) of one tr-read must hit different banks
+template <int ROWB>
+__device__ __forceinline__ int tn_f(int r) {
+  if (ROWB == 256) return (r & 3) | (((r >> 3) & 1) << 2);  // 8 granules per row
+  return ((r >> 1) & 1) | (((r >> 3) & 1) << 1);            // 128-byte rows: 4 granules, two rows per bank sweep
+}
+
+template <int BM>  // output rows per workgroup (columns of A): 64 or 128; output columns per workgroup: 128
+__global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnParams p) {
+  constexpr int BN = 128;
+  constexpr int RA = BM * 2, RB = BN * 2;                    // row bytes of the A / B tiles
+  constexpr int kABytes = kTnBK * RA, kStage = kABytes + kTnBK * RB;
+  constexpr int FM = BM / 32, FN = BN / 32;                  // 16-wide fragments per wave (2 x 2 waves)
+  constexpr int GA = (kTnBK * RA / 1024) / 4, GB = (kTnBK * RB / 1024) / 4;  // LDS-DMA instructions per wave and tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.No + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int i0 = tile_m * BM, j0 = tile_n * BN;
+
+  // ---- LDS-DMA source addresses ---------------------------------------------------------------------------------
+  // A tile rows are RA bytes: one instruction covers 1024 / RA rows; lane -> (row in instruction, 16-byte chunk)
+  constexpr int kRowsA = 1024 / RA, kChA = RA / 16, kRowsB = 1024 / RB, kChB = RB / 16;
+  const uint16_t* a_src[GA];
+  const uint16_t* b_src[GB];
+  int a_row[GA], b_row[GB];
+#pragma unroll
+  for (int g = 0; g < GA; ++g) {
+    const int r = (wave + 4 * g) * kRowsA + lane / kChA, pch = lane % kChA;
+    const int sch = (((pch >> 1) ^ tn_f<RA>(r)) << 1) | (pch & 1);  // logical chunk stored at position pch of row r
+    int col = i0 + sch * 8;
+    if (col + 8 > p.Mo) col = p.Mo - 8;  // clamp: columns past Mo are computed and never stored
+    a_row[g] = r;
+    a_src[g] = p.A + col;
+  }
+#pragma unroll
+  for (int g = 0; g < GB; ++g) {
+    const int r = (wave + 4 * g) * kRowsB + lane / kChB, pch = lane % kChB;
+    const int sch = (((pch >> 1) ^ tn_f<RB>(r)) << 1) | (pch & 1);
+    int col = j0 + sch * 8;
+    if (col + 8 > p.No) col = p.No - 8;
+    b_row[g] = r;
+    b_src[g] = p.B + col;
+  }
+  const int nk_all = (p.Kc + kTnBK - 1) / kTnBK;
+  const int kt_lo = blockIdx.y * p.kt_split;
+  const int nk = min(nk_all - kt_lo, p.kt_split);
+  auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
+    char* st = smem + stage * kStage;
+    const int m0 = kt * kTnBK;
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+      int m = m0 + a_row[g];
+      if (m >= p.Kc) m = p.Kc - 1;  // rows past Kc: finite duplicates, masked out of the A fragments below
+      __builtin_amdgcn_global_load_lds((tn_gl_t*)(a_src[g] + (int64_t)m * p.lda), (tn_lds_t*)(st + (wave + 4 * g) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      int m = m0 + b_row[g];
+      if (m >= p.Kc) m = p.Kc - 1;
+      __builtin_amdgcn_global_load_lds((tn_gl_t*)(b_src[g] + (int64_t)m * p.ldb),
+                                       (tn_lds_t*)(st + kABytes + (wave + 4 * g) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[FM][FN], cs[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // ---- fragment byte offsets inside a stage (kk = 0, first of the two reads; second read = + 4 rows) ---------------
+  // lane (g = lane >> 4, a = (lane & 15) >> 2, b = lane & 3) addresses row g * 8 + a, bytes b * 8 of the fragment's
+  // 32-byte granule; it receives rows g*8 .. g*8+3 (+4 .. +7) of column (lane & 15)
+  const int lg = lane >> 4, la = (lane & 15) >> 2, lb = lane & 3;
+  const int r_frag = lg * 8 + la;
+  uint32_t off_a[FM], off_b[FN];
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(tn_lds_t*)smem;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int gran = (wm * (BM / 2) + i * 16) / 16;
+    off_a[i] = r_frag * RA + ((gran ^ tn_f<RA>(r_frag)) << 5) + lb * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int gran = (wn * (BN / 2) + j * 16) / 16;
+    off_b[j] = kABytes + r_frag * RB + ((gran ^ tn_f<RB>(r_frag)) << 5) + lb * 8;
+  }
+  const bool want_cs = p.colsum != nullptr && tile_n == 0;
+  const uint4 ones_pk = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);  // bf16 1.0 x 8
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_pk);
+
+  issue_tile(kt_lo, 0);
+  if (nk > 1) issue_tile(kt_lo + 1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue_tile(kt_lo + kt + 2, (kt + 2) % kTnStages);
+    const uint32_t st = lds_base + (kt % kTnStages) * kStage;
+    const int mrow0 = (kt_lo + kt) * kTnBK;
+    const bool tail = mrow0 + kTnBK > p.Kc;  // wave-uniform: only the last K-tile of the whole contraction
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      unsigned long long alo_[FM], ahi_[FM], blo_[FN], bhi_[FN];
+      // rows of this half: kk * 32 + r_frag (+4); the swizzle function is unchanged by the kk * 32 and +4 offsets
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const uint32_t ad = st + off_a[i] + kk * 32 * RA;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(alo_[i]) : "v"(ad) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi_[i]) : "v"(ad), "n"(4 * RA) : "memory");
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const uint32_t ad = st + off_b[j] + kk * 32 * RB;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo_[j]) : "v"(ad) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi_[j]) : "v"(ad), "n"(4 * RB) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      uint2 alo[FM], ahi[FM], blo[FN], bhi[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        alo[i] = make_uint2((uint32_t)alo_[i], (uint32_t)(alo_[i] >> 32));
+        ahi[i] = make_uint2((uint32_t)ahi_[i], (uint32_t)(ahi_[i] >> 32));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        blo[j] = make_uint2((uint32_t)blo_[j], (uint32_t)(blo_[j] >> 32));
+        bhi[j] = make_uint2((uint32_t)bhi_[j], (uint32_t)(bhi_[j] >> 32));
+      }
+      if (tail) {  // zero the contraction rows past Kc in the A fragments: element e of the lane is row base + e
+        const int base = mrow0 + kk * 32 + lg * 8;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          if (base + 0 >= p.Kc) alo[i].x &= 0xffff0000u;
+          if (base + 1 >= p.Kc) alo[i].x &= 0x0000ffffu;
+          if (base + 2 >= p.Kc) alo[i].y &= 0xffff0000u;
+          if (base + 3 >= p.Kc) alo[i].y &= 0x0000ffffu;
+          if (base + 4 >= p.Kc) ahi[i].x &= 0xffff0000u;
+          if (base + 5 >= p.Kc) ahi[i].x &= 0x0000ffffu;
+          if (base + 6 >= p.Kc) ahi[i].y &= 0xffff0000u;
+          if (base + 7 >= p.Kc) ahi[i].y &= 0x0000ffffu;
+        }
+      }
+      bf16x8 af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = __builtin_bit_cast(bf16x8, make_uint4(alo[i].x, alo[i].y, ahi[i].x, ahi[i].y));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[j] = __builtin_bit_cast(bf16x8, make_uint4(blo[j].x, blo[j].y, bhi[j].x, bhi[j].y));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      if (want_cs) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], cs[i], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds out[i = .. + (lane & 15)][j = .. + (lane >> 4) * 4 + 0..3] -----------------------------
+  const int ei = lane & 15, ej = (lane >> 4) * 4;
+  float* part = p.part + (int64_t)blockIdx.y * p.Mo_store * p.No;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int oi = i0 + wm * (BM / 2) + i * 16 + ei;
+    if (want_cs && wn == 0 && lg == 0 && oi < p.Mo_store) atomicAdd(p.colsum + oi, cs[i][0]);
+    if (oi >= p.Mo_store) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int oj = j0 + wn * (BN / 2) + j * 16 + ej;
+      float* o = part + (int64_t)oi * p.No + oj;
+      if (oj + 3 < p.No && (p.No & 3) == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (oj + r < p.No) o[r] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn,
+                                                        float* __restrict__ out, int64_t ldo, int N, float alpha,
+                                                        int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) {
+    float s = 0.0f;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * mn + i];
+    const int64_t m = i / N;
+    float* o = out + m * ldo + (i - m * N);
+    *o = accumulate ? *o + alpha * s : alpha * s;
+  }
+}
+
+static int tn_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+static int tn_plan(int64_t Mo, int64_t No, int64_t Kc, int* bm, int* kt_split) {
+  // 128-row tiles when there are enough of them; about two workgroups per CU; >= 8 K-tiles per split
+  const int64_t big = ((Mo + 127) / 128) * ((No + 127) / 128);
+  *bm = big >= 64 ? 128 : 64;
+  const int64_t tiles = ((Mo + *bm - 1) / *bm) * ((No + 127) / 128);
+  const int64_t nk = (Kc + kTnBK - 1) / kTnBK;
+  int64_t splits = (2 * tn_cus() + tiles - 1) / tiles;
+  if (splits > nk / 8) splits = nk / 8;
+  if (splits < 1) splits = 1;
+  *kt_split = (int)((nk + splits - 1) / splits);
+  return (int)((nk + *kt_split - 1) / *kt_split);
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int64_t ma_gemm_tn_workspace_bytes(int64_t Mo, int64_t No, int64_t Kc) {
+  if (Mo < 1 || No < 1 || Kc < 1) return MA_ERR_INVALID_ARG;
+  int bm = 0, kt = 0;
+  return (int64_t)tn_plan(Mo, No, Kc, &bm, &kt) * Mo * No * 4;
+}
+
+int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, float* out, int64_t ldo, int64_t Mo,
+                        int64_t No, int64_t Kc, int64_t Mo_store, float alpha, int32_t accumulate, float* colsum,
+                        void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  if (!A || !B || !out || !workspace || Mo < 8 || No < 8 || Kc < 1 || Mo_store < 1 || Mo_store > Mo) return MA_ERR_INVALID_ARG;
+  if ((Mo & 7) || (No & 7) || (lda & 7) || (ldb & 7) || lda < Mo || ldb < No || ldo < No || Mo > 0x7fffffff ||
+      No > 0x7fffffff || Kc > 0x7fffffff)
+    return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return MA_ERR_INVALID_ARG;
+  TnParams p;
+  p.A = reinterpret_cast<const uint16_t*>(A);
+  p.B = reinterpret_cast<const uint16_t*>(B);
+  p.part = reinterpret_cast<float*>(workspace);
+  p.colsum = colsum;
+  p.lda = lda;
+  p.ldb = ldb;
+  p.Mo = (int32_t)Mo;
+  p.No = (int32_t)No;
+  p.Kc = (int32_t)Kc;
+  p.Mo_store = (int32_t)Mo_store;
+  int bm = 64, kt = 0;
+  const int splits = tn_plan(Mo, No, Kc, &bm, &kt);
+  p.kt_split = kt;
+  if (workspace_bytes < (int64_t)splits * Mo_store * No * 4) return MA_ERR_WORKSPACE;
+  const int tiles = (int)(((Mo + bm - 1) / bm) * ((No + 127) / 128));
+  hipStream_t s = (hipStream_t)stream;
+  if (bm == 128) {
+    constexpr int lds = kTnStages * (kTnBK * 256 + kTnBK * 256);
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel<128>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MA_ERR_LAUNCH;
+      attr = true;
+    }
+    MA_LAUNCH(gemm_tn_bf16_kernel<128>, dim3(tiles, splits), dim3(kTnThreads), lds, s, p);
+  } else {
+    constexpr int lds = kTnStages * (kTnBK * 128 + kTnBK * 256);
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel<64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MA_ERR_LAUNCH;
+      attr = true;
+    }
+    MA_LAUNCH(gemm_tn_bf16_kernel<64>, dim3(tiles, splits), dim3(kTnThreads), lds, s, p);
+  }
+  const int64_t mn = Mo_store * No;
+  int64_t blocks = (mn + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  MA_LAUNCH(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), splits, mn,
+            out, ldo, (int)No, alpha, (int)accumulate);
+  return MA_OK;
+}
+
+}  // extern "C"

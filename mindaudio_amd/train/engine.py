@@ -304,9 +304,7 @@ class ConformerCTCTrainStep:
     def _dW(self, dy, x, wname, bname):
         """grad[wname] (N, K) += dy^T x ; grad[bname] += column sums of dy.  dy (M, N), x (M, K) bf16."""
         fp = self.fp
-        dyt = K.transpose(dy, colsum=fp.g(bname) if bname else None, slot=0)
-        xt = K.transpose(x, slot=1)
-        K.gemm_splitk(dyt, xt, fp.g(wname))
+        K.gemm_tn(dy, x, fp.g(wname), colsum=fp.g(bname) if bname else None)
 
     # ---- forward + backward ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -384,8 +382,7 @@ class ConformerCTCTrainStep:
 
         # ================= backward =================
         # CTC head: logits = enc_bf W^T + b
-        dlt = K.transpose(dlog, colsum=fp.g("ctc_b"), slot=0)   # (Vp, Mp)
-        K.gemm_splitk(dlt[:self.V], K.transpose(enc_bf, slot=1), fp.g("ctc_w"))
+        K.gemm_tn(dlog, enc_bf, fp.g("ctc_w"), colsum=fp.g("ctc_b"), rows_store=self.V)
         d_enc = ops.gemm(dlog, self.wt["ctc_w"])                # (m, 256) bf16
         g = torch.empty((m, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)

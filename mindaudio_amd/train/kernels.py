@@ -38,13 +38,32 @@ def transpose(x, out=None, colsum=None, slot=0):
     return out
 
 
-def gemm_splitk(a, w, out, alpha=1.0):
-    """out (M, N) f32 += alpha * a (M, K) @ w (N, K)^T."""
+def gemm_splitk(a, w, out, alpha=1.0, accumulate=True):
+    """out (M, N) f32 (+)= alpha * a (M, K) @ w (N, K)^T."""
+    t = _t()
+    lib = _lib.load()
     m, k = a.shape
     n = w.shape[0]
-    assert w.shape[1] == k and tuple(out.shape) == (m, n) and out.dtype == _t().float32
-    _lib.check(_lib.load().ma_gemm_bf16_splitk_f32(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), m, n,
-                                                   k, float(alpha), _s()), "gemm_splitk")
+    assert w.shape[1] == k and tuple(out.shape) == (m, n) and out.dtype == t.float32
+    ws = _host.workspace(lib.ma_gemm_splitk_workspace_bytes(m, n, k), a.device)
+    _lib.check(lib.ma_gemm_bf16_splitk_f32(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), m, n, k,
+                                           float(alpha), 1 if accumulate else 0, _p(ws), ws.numel(), _s()), "gemm_splitk")
+    return out
+
+
+def gemm_tn(a, b, out, colsum=None, rows_store=None, alpha=1.0, accumulate=True):
+    """out (Mo_store, No) f32 (+)= alpha * a^T @ b for row-major a (Kc, Mo), b (Kc, No) bf16; colsum (+)= column sums
+    of a."""
+    t = _t()
+    lib = _lib.load()
+    kc, mo = a.shape
+    no = b.shape[1]
+    rows_store = mo if rows_store is None else rows_store
+    assert b.shape[0] == kc and tuple(out.shape) == (rows_store, no) and out.dtype == t.float32
+    ws = _host.workspace(lib.ma_gemm_tn_workspace_bytes(mo, no, kc), a.device)
+    _lib.check(lib.ma_gemm_tn_bf16_f32(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), mo, no, kc,
+                                       rows_store, float(alpha), 1 if accumulate else 0, _p(colsum), _p(ws), ws.numel(),
+                                       _s()), "gemm_tn")
     return out
 
 

@@ -270,3 +270,24 @@ def test_ctc_loss_grad(K):
     assert float(got[..., v:].abs().max()) == 0.0
     assert rel(got[..., :v], lg.grad) < 5e-3
     assert float(got[4].abs().max()) == 0.0 and float(got[1, 50:].abs().max()) == 0.0
+
+
+def test_gemm_tn(K):
+    g = torch.Generator().manual_seed(21)
+    # (Kc, Mo, No, rows_store): tails in every dimension, small and large contractions
+    for kc, mo, no, rs in ((10200, 256, 2048, None), (10200, 2048, 256, None), (255, 3072, 256, None), (1000, 768, 256, None),
+                           (777, 4288, 256, 4233), (130, 64, 72, None), (64 * 9 + 1, 512, 256, None)):
+        a, b = bf(torch.randn(kc, mo, generator=g)), bf(torch.randn(kc, no, generator=g))
+        rs_ = mo if rs is None else rs
+        out = torch.full((rs_, no), 0.5, device="cuda")
+        cs = torch.zeros(mo, device="cuda")
+        K.gemm_tn(a.cuda(), b.cuda(), out, colsum=cs, rows_store=rs, alpha=0.25)
+        want = 0.5 + 0.25 * (a.float().t() @ b.float())[:rs_]
+        assert rel(out, want) < 2e-5, (kc, mo, no)
+        assert rel(cs[:rs_], a.float().sum(0)[:rs_]) < 2e-5, (kc, mo, no)
+    # strided views (column slices of wider buffers)
+    wide = bf(torch.randn(500, 1024, generator=g)).cuda()
+    a, b = wide[:, 256:512], wide[:, 512:]
+    out = torch.zeros(256, 512, device="cuda")
+    K.gemm_tn(a, b, out, accumulate=False)
+    assert rel(out, a.float().cpu().t() @ b.float().cpu()) < 2e-5

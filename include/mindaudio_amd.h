@@ -351,6 +351,14 @@ int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, 
                         int64_t No, int64_t Kc, int64_t Mo_store, float alpha, int32_t accumulate, float* colsum,
                         void* workspace, int64_t workspace_bytes, ma_stream_t stream);
 
+/* Weight gradient of the 3x3 stride-2 valid Conv2d of the subsampling layer (layers/subsampling.py:42) as the same TN
+ * GEMM with an implicit im2col B operand: dw (Cout, 9C) float32 += dy^T . im2col(act), dbias (Cout) += column sums of dy.
+ * dy (batch*Ho*Wo, Cout) bf16 row stride ld_dy; act (batch, H, Wd, C) NHWC bf16; C % 128 == 0.
+ * workspace >= ma_gemm_tn_workspace_bytes(Cout, 9C, batch*Ho*Wo). */
+int ma_conv2d_3x3s2_dw_bf16(const void* dy, int64_t ld_dy, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
+                            int64_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+                            ma_stream_t stream);
+
 /* out[c][r] = in[r][c] (bf16); columns r in [rows, ld_out) of `out` are not written (keep them zero to use the
  * result as a K-padded GEMM operand).  colsum (cols) float32, optional: += column sums of `in` (bias gradients). */
 int ma_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols, void* out, int64_t ld_out,
@@ -360,7 +368,11 @@ int ma_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols,
  * dy bf16 or float32; row_scale as in the forward; D == 256. */
 int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
                          const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
-                         int32_t accumulate, float* dgamma, float* dbeta, ma_stream_t stream);
+                         int32_t accumulate, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                         ma_stream_t stream);
+/* Scratch for the two-stage parameter-gradient reductions of ma_layernorm_bwd_f32, ma_convmid_bwd_bf16 and
+ * ma_subsample_conv1_dw_f32 (per-workgroup partial sums, then a fixed-order sum: no contended atomics). */
+int64_t ma_train_reduce_workspace_bytes(void);
 
 /* h = dropout(swish(u)) between w_1 and w_2 (positionwise_feed_forward.py:33-46), bf16, n elements; the keep mask is a
  * pure function of (seed, salt, element index) and is regenerated by the backward: du = dh * keep/(1-p) * swish'(u). */
@@ -395,7 +407,7 @@ int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, co
                         float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream);
 int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                         const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
-                        ma_stream_t stream);
+                        void* workspace, int64_t workspace_bytes, ma_stream_t stream);
 
 /* Conv2dSubsampling4 backward (layers/subsampling.py:21-78): ReLU mask in place; transposed im2col matrix
  * (9C, ld_out >= B*Ho*Wo) of an NHWC bf16 activation (weight gradient of conv2 as a split-K GEMM); col2im + ReLU mask
@@ -407,7 +419,7 @@ int ma_col2im_3x3s2_relu_bf16(const void* dcol, const void* act, int64_t batch, 
                               void* dact, ma_stream_t stream);
 int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, int64_t T, int32_t idim,
                               const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
-                              ma_stream_t stream);
+                              void* workspace, int64_t workspace_bytes, ma_stream_t stream);
 
 /* Rel-pos attention for training: the forward of ma_relpos_attention_bf16 that also writes lse (batch, heads, T)
  * float32 = log-sum-exp of the scaled, masked scores of every query row, and the backward pass

@@ -122,8 +122,10 @@ PROTOTYPES = {
     "ma_gemm_bf16_splitk_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, i32, vp, i64, vp]),
     "ma_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
     "ma_gemm_tn_bf16_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, f32, i32, vp, vp, i64, vp]),
+    "ma_conv2d_3x3s2_dw_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp, i64, vp]),
     "ma_transpose_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
-    "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp]),
+    "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp]),
+    "ma_train_reduce_workspace_bytes": (i64, []),
     "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, f32, u32, u32, vp]),
     "ma_act_dropout_bwd_bf16": (ctypes.c_int, [vp, vp, vp, i64, f32, u32, u32, vp]),
     "ma_dropout_add_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i32, i64, i64, f32, f32, u32, u32, vp]),
@@ -132,11 +134,11 @@ PROTOTYPES = {
     "ma_bn_finalize_f32": (ctypes.c_int, [vp, i32, i64, f32, f32, vp, vp, vp, vp]),
     "ma_bn_swish_fwd_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, i32, vp]),
     "ma_bn_swish_bwd_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
-    "ma_convmid_bwd_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp]),
+    "ma_convmid_bwd_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp, i64, vp]),
     "ma_relu_bwd_bf16": (ctypes.c_int, [vp, vp, i64, vp]),
     "ma_im2col_t_3x3s2_nhwc_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, i64, vp]),
     "ma_col2im_3x3s2_relu_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
-    "ma_subsample_conv1_dw_f32": (ctypes.c_int, [vp, vp, i64, i64, i32, vp, vp, i32, vp, vp, vp]),
+    "ma_subsample_conv1_dw_f32": (ctypes.c_int, [vp, vp, i64, i64, i32, vp, vp, i32, vp, vp, vp, i64, vp]),
     "ma_relpos_attention_train_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, vp, i64, vp, i64,
                                                       vp, vp]),
     "ma_relpos_attention_bwd_workspace_bytes": (i64, [i64, i64, i32, i32]),

@@ -38,6 +38,10 @@ struct TnParams {
   float* colsum;      // optional [Mo]: += column sums of A (atomics across splits)
   int64_t lda, ldb;
   int32_t Mo, No, Kc, Mo_store, kt_split;
+  // IM2COL: B is the im2col matrix of a 3x3 stride-2 valid convolution over an NHWC activation (batch, H, Wd, C):
+  // row m = (b, ho, wo), column (kh, kw, c); B points at the activation
+  int32_t H, Wd, C, Ho, Wo;
+  float inv_wo, inv_ho;
 };
 
 constexpr int kTnBK = 64, kTnStages = 3, kTnThreads = 256;
@@ -49,7 +53,14 @@ __device__ __forceinline__ int tn_f(int r) {
   return ((r >> 1) & 1) | (((r >> 3) & 1) << 1);            // 128-byte rows: 4 granules, two rows per bank sweep
 }
 
-template <int BM>  // output rows per workgroup (columns of A): 64 or 128; output columns per workgroup: 128
+__device__ __forceinline__ int tn_div(int m, int d, float inv) {  // floor(m / d) for 0 <= m < 2^24
+  int q = (int)((float)m * inv);
+  if (q * d > m) --q;
+  if ((q + 1) * d <= m) ++q;
+  return q;
+}
+
+template <int BM, bool IM2COL>  // output rows per workgroup (columns of A): 64 or 128; output columns per workgroup: 128
 __global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnParams p) {
   constexpr int BN = 128;
   constexpr int RA = BM * 2, RB = BN * 2;                    // row bytes of the A / B tiles
@@ -85,7 +96,12 @@ __global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnPar
     int col = j0 + sch * 8;
     if (col + 8 > p.No) col = p.No - 8;
     b_row[g] = r;
-    b_src[g] = p.B + col;
+    if (IM2COL) {  // C % 128 == 0: the 128 columns of this tile share one (kh, kw)
+      const int khw = col / p.C, kh = khw / 3, kw = khw - 3 * kh;
+      b_src[g] = p.B + ((int64_t)kh * p.Wd + kw) * p.C + (col - khw * p.C);
+    } else {
+      b_src[g] = p.B + col;
+    }
   }
   const int nk_all = (p.Kc + kTnBK - 1) / kTnBK;
   const int kt_lo = blockIdx.y * p.kt_split;
@@ -103,7 +119,15 @@ __global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnPar
     for (int g = 0; g < GB; ++g) {
       int m = m0 + b_row[g];
       if (m >= p.Kc) m = p.Kc - 1;
-      __builtin_amdgcn_global_load_lds((tn_gl_t*)(b_src[g] + (int64_t)m * p.ldb),
+      int64_t roff;
+      if (IM2COL) {
+        const int t = tn_div(m, p.Wo, p.inv_wo), wo = m - t * p.Wo;
+        const int b = tn_div(t, p.Ho, p.inv_ho), ho = t - b * p.Ho;
+        roff = (((int64_t)b * p.H + 2 * ho) * p.Wd + 2 * wo) * p.C;
+      } else {
+        roff = (int64_t)m * p.ldb;
+      }
+      __builtin_amdgcn_global_load_lds((tn_gl_t*)(b_src[g] + roff),
                                        (tn_lds_t*)(st + kABytes + (wave + 4 * g) * 1024), 16, 0, 0);
     }
   };
@@ -269,6 +293,38 @@ using namespace ma;
 
 extern "C" {
 
+static int tn_launch(TnParams& p, bool im2col, float* out, int64_t ldo, float alpha, int accumulate, void* workspace,
+                     int64_t workspace_bytes, hipStream_t s) {
+  int bm = 64, kt = 0;
+  const int splits = tn_plan(p.Mo, p.No, p.Kc, &bm, &kt);
+  p.kt_split = kt;
+  if (workspace_bytes < (int64_t)splits * p.Mo_store * p.No * 4) return MA_ERR_WORKSPACE;
+  const int tiles = (int)(((p.Mo + bm - 1) / bm) * ((p.No + 127) / 128));
+  const int lds = kTnStages * (kTnBK * bm * 2 + kTnBK * 256);
+#define MA_TN_GO(BM_, IM_)                                                                                            \
+  {                                                                                                                   \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel<BM_, IM_>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                         \
+        return MA_ERR_LAUNCH;                                                                                         \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    MA_LAUNCH((gemm_tn_bf16_kernel<BM_, IM_>), dim3(tiles, splits), dim3(kTnThreads), lds, s, p);                     \
+  }
+  if (bm == 128 && im2col) MA_TN_GO(128, true)
+  else if (bm == 128) MA_TN_GO(128, false)
+  else if (im2col) MA_TN_GO(64, true)
+  else MA_TN_GO(64, false)
+#undef MA_TN_GO
+  const int64_t mn = (int64_t)p.Mo_store * p.No;
+  int64_t blocks = (mn + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  MA_LAUNCH(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), splits, mn,
+            out, ldo, p.No, alpha, accumulate);
+  return MA_OK;
+}
+
 int64_t ma_gemm_tn_workspace_bytes(int64_t Mo, int64_t No, int64_t Kc) {
   if (Mo < 1 || No < 1 || Kc < 1) return MA_ERR_INVALID_ARG;
   int bm = 0, kt = 0;
@@ -284,7 +340,7 @@ int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, 
     return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return MA_ERR_INVALID_ARG;
-  TnParams p;
+  TnParams p = TnParams{};
   p.A = reinterpret_cast<const uint16_t*>(A);
   p.B = reinterpret_cast<const uint16_t*>(B);
   p.part = reinterpret_cast<float*>(workspace);
@@ -295,39 +351,30 @@ int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, 
   p.No = (int32_t)No;
   p.Kc = (int32_t)Kc;
   p.Mo_store = (int32_t)Mo_store;
-  int bm = 64, kt = 0;
-  const int splits = tn_plan(Mo, No, Kc, &bm, &kt);
-  p.kt_split = kt;
-  if (workspace_bytes < (int64_t)splits * Mo_store * No * 4) return MA_ERR_WORKSPACE;
-  const int tiles = (int)(((Mo + bm - 1) / bm) * ((No + 127) / 128));
-  hipStream_t s = (hipStream_t)stream;
-  if (bm == 128) {
-    constexpr int lds = kTnStages * (kTnBK * 256 + kTnBK * 256);
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel<128>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return MA_ERR_LAUNCH;
-      attr = true;
-    }
-    MA_LAUNCH(gemm_tn_bf16_kernel<128>, dim3(tiles, splits), dim3(kTnThreads), lds, s, p);
-  } else {
-    constexpr int lds = kTnStages * (kTnBK * 128 + kTnBK * 256);
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel<64>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return MA_ERR_LAUNCH;
-      attr = true;
-    }
-    MA_LAUNCH(gemm_tn_bf16_kernel<64>, dim3(tiles, splits), dim3(kTnThreads), lds, s, p);
-  }
-  const int64_t mn = Mo_store * No;
-  int64_t blocks = (mn + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  MA_LAUNCH(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), splits, mn,
-            out, ldo, (int)No, alpha, (int)accumulate);
-  return MA_OK;
+  return tn_launch(p, false, out, ldo, alpha, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ma_conv2d_3x3s2_dw_bf16(const void* dy, int64_t ld_dy, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
+                            int64_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+                            ma_stream_t stream) {
+  if (!dy || !act || !dw || !workspace || batch < 1 || H < 3 || Wd < 3 || C < 1 || Cout < 8) return MA_ERR_INVALID_ARG;
+  if ((C % 128) || (Cout & 7) || (ld_dy & 7) || ld_dy < Cout) return MA_ERR_UNSUPPORTED;
+  const int64_t Ho = (H - 3) / 2 + 1, Wo = (Wd - 3) / 2 + 1, M = batch * Ho * Wo;
+  if (M >= (1 << 24)) return MA_ERR_UNSUPPORTED;
+  TnParams p = TnParams{};
+  p.A = reinterpret_cast<const uint16_t*>(dy);
+  p.B = reinterpret_cast<const uint16_t*>(act);
+  p.part = reinterpret_cast<float*>(workspace);
+  p.colsum = dbias;
+  p.lda = ld_dy;
+  p.Mo = (int32_t)Cout;
+  p.No = (int32_t)(9 * C);
+  p.Kc = (int32_t)M;
+  p.Mo_store = (int32_t)Cout;
+  p.H = (int32_t)H; p.Wd = (int32_t)Wd; p.C = (int32_t)C; p.Ho = (int32_t)Ho; p.Wo = (int32_t)Wo;
+  p.inv_wo = 1.0f / (float)Wo;
+  p.inv_ho = 1.0f / (float)Ho;
+  return tn_launch(p, true, dw, 9 * C, 1.0f, 1, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -107,6 +107,28 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+// out_a[j] += sum_b part[b][j] (j < na), out_b[j - na] += sum_b part[b][j] (na <= j < n): second stage of the
+// parameter-gradient reductions (fixed summation order; no contended atomics)
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* out_a,
+                                                             int na, float* out_b) {
+  // grid (ceil(n / 64), kRedSlices): 64 columns x 4 row groups per workgroup, blockIdx.y owns a slice of the partial
+  // rows; the kRedSlices slice sums meet in one float32 atomic per output element
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float s = 0.0f;
+  if (j < n)
+    for (int b = b0 + ty; b < b1; b += 4) s += part[(int64_t)b * n + j];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < n) {
+    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    atomicAdd(j < na ? out_a + j : out_b + (j - na), s);
+  }
+}
+
 // ---- LayerNorm backward -----------------------------------------------------------------------------------------
 // y = ((x - mu) * rstd * gamma + beta) * row_scale.  One wave per row (D = 256: 4 columns per lane), persistent over
 // rows; per-workgroup partial dgamma / dbeta leave through float32 atomics.
@@ -115,7 +137,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, float eps,
                                                             const float* __restrict__ row_scale, const void* dy_,
                                                             int64_t ldy, float* g, int64_t ldg, int accumulate,
-                                                            float* dgamma, float* dbeta) {
+                                                            float* __restrict__ part) {
   __shared__ float red[2][4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4);
@@ -175,8 +197,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
   __syncthreads();
   const int c = threadIdx.x;
-  atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-  atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+  // per-workgroup partial (dgamma | dbeta); summed over workgroups by partial_reduce_kernel
+  part[(int64_t)blockIdx.x * 512 + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+  part[(int64_t)blockIdx.x * 512 + 256 + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
 }
 
 // ---- Swish + dropout between w_1 and w_2 -----------------------------------------------------------------------
@@ -344,18 +367,18 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ dn, co
 // dw[c][j] += sum_t dz[t] * s[t + j - pad], db[c] += sum_t dz[t], s = glu(y).
 // Workgroup = (utterance b, strip of kCbStrip frames) x 256 channels (thread = channel): the strip plus its halo of
 // s and dz go through LDS once, so every tap is an LDS read with unit channel stride.
-constexpr int kCbStrip = 16, kCbPerBlock = 4;
+constexpr int kCbStrip = 16, kCbPerBlock = 1;
 template <int KS>
 __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ y,
                                                           int64_t ldy, int B, int T, int C,
                                                           const float* __restrict__ w, uint16_t* __restrict__ dy,
-                                                          int64_t lddy, float* dw, float* db) {
+                                                          int64_t lddy, float* __restrict__ part, int per_block) {
   constexpr int pad = (KS - 1) / 2, kRows = kCbStrip + KS - 1;
   extern __shared__ float cb_lds[];
   float* s_t = cb_lds;                // [kRows][256] glu(y)
   float* z_t = cb_lds + kRows * 256;  // [kRows][256] dz
   const int tid = threadIdx.x;
-  const int c = blockIdx.z * 256 + tid;
+  const int c = tid;
   const int b = blockIdx.y;
   const int64_t base = (int64_t)b * T;
   float wr[KS], dwr[KS];
@@ -364,8 +387,8 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
   float dbr = 0.0f;
   // a workgroup walks kCbPerBlock consecutive strips so that the parameter-gradient atomics (one per channel and tap
   // per workgroup) stay a small fraction of the work
-  for (int sidx = 0; sidx < kCbPerBlock; ++sidx) {
-  const int t0 = (blockIdx.x * kCbPerBlock + sidx) * kCbStrip;
+  for (int sidx = 0; sidx < per_block; ++sidx) {
+  const int t0 = (blockIdx.x * per_block + sidx) * kCbStrip;
   if (t0 >= T) break;
   for (int r = 0; r < kRows; ++r) {
     const int t = t0 - pad + r;
@@ -396,9 +419,11 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
     dy[(base + t) * lddy + C + c] = f2bf(ds * a * sg * (1.0f - sg));
   }
   }
+  // per-workgroup partial (dw (C, KS) | db (C)); summed by partial_reduce_kernel
+  float* pp = part + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * ((int64_t)C * (KS + 1));
 #pragma unroll
-  for (int j = 0; j < KS; ++j) atomicAdd(dw + c * KS + j, dwr[j]);
-  atomicAdd(db + c, dbr);
+  for (int j = 0; j < KS; ++j) pp[c * KS + j] = dwr[j];
+  pp[C * KS + c] = dbr;
 }
 
 // ---- subsampling backward ---------------------------------------------------------------------------------------
@@ -437,32 +462,46 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const uint16_t* __restric
 }
 
 // dact[b, h, w, c] = relu'(act) * sum over the (<= 4) windows (ho, kh), (wo, kw) containing (h, w) of
-// dcol[(b, ho, wo)][(kh, kw, c)]
+// dcol[(b, ho, wo)][(kh, kw, c)]; 8 channels (16 bytes) per thread
 __global__ __launch_bounds__(256) void col2im_relu_kernel(const uint16_t* __restrict__ dcol, const uint16_t* __restrict__ act,
                                                           int B, int H, int Wd, int C, int Ho, int Wo,
                                                           uint16_t* __restrict__ dact) {
-  const int64_t n = (int64_t)B * H * Wd * C;
+  const int c8 = C / 8;
+  const int64_t n = (int64_t)B * H * Wd * c8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    int64_t t = i / C;
+    const int c = (int)(i % c8) * 8;
+    int64_t t = i / c8;
     const int w = (int)(t % Wd);
     t /= Wd;
     const int h = (int)(t % H);
     const int64_t b = t / H;
-    float acc = 0.0f;
-    if (bf2f(act[i]) > 0.0f) {
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hh = h - kh;
-        if (hh < 0 || (hh & 1) || hh / 2 >= Ho) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-          const int ww = w - kw;
-          if (ww < 0 || (ww & 1) || ww / 2 >= Wo) continue;
-          const int64_t m = (b * Ho + hh / 2) * Wo + ww / 2;
-          acc += bf2f(dcol[m * (9 * C) + (kh * 3 + kw) * C + c]);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h - kh;
+      if (hh < 0 || (hh & 1) || hh / 2 >= Ho) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w - kw;
+        if (ww < 0 || (ww & 1) || ww / 2 >= Wo) continue;
+        const int64_t m = (b * Ho + hh / 2) * Wo + ww / 2;
+        const uint4 v = *reinterpret_cast<const uint4*>(dcol + m * (9 * C) + (kh * 3 + kw) * C + c);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] += __uint_as_float(wds[e] << 16);
+          acc[2 * e + 1] += __uint_as_float(wds[e] & 0xffff0000u);
         }
       }
     }
-    dact[i] = f2bf(acc);
+    const uint4 av = *reinterpret_cast<const uint4*>(act + ((b * H + h) * Wd + w) * (int64_t)C + c);
+    const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = __uint_as_float(aw[e] << 16) > 0.0f ? acc[2 * e] : 0.0f;
+      const float hi = __uint_as_float(aw[e] & 0xffff0000u) > 0.0f ? acc[2 * e + 1] : 0.0f;
+      o[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+    *reinterpret_cast<uint4*>(dact + ((b * H + h) * Wd + w) * (int64_t)C + c) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -471,32 +510,37 @@ __global__ __launch_bounds__(256) void col2im_relu_kernel(const uint16_t* __rest
 __global__ __launch_bounds__(256) void conv1_dw_kernel(const uint16_t* __restrict__ dact, const float* __restrict__ x, int B,
                                                        int T, int idim, int H1, int W1, int C,
                                                        const float* __restrict__ cm_mean, const float* __restrict__ cm_istd,
-                                                       float* dw, float* db, int strip) {
+                                                       float* __restrict__ part, int strip) {
   const int c = blockIdx.y * 256 + threadIdx.x;
-  const int64_t npos = (int64_t)B * H1 * W1;
-  const int64_t p0 = (int64_t)blockIdx.x * strip, p1 = min(npos, p0 + (int64_t)strip);
+  const int npos = B * H1 * W1;
+  const int p0 = blockIdx.x * strip, p1 = min(npos, p0 + strip);
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, accb = 0.0f;
-  for (int64_t pidx = p0; pidx < p1; ++pidx) {
-    const int w1 = (int)(pidx % W1);
-    const int64_t t = pidx / W1;
-    const int h1 = (int)(t % H1);
-    const int64_t b = t / H1;
-    const float d = c < C ? bf2f(dact[pidx * C + c]) : 0.0f;
+  // (b, h1, w1) of the first position, then advanced incrementally
+  int w1 = p0 % W1, tq = p0 / W1;
+  int h1 = tq % H1, b = tq / H1;
+#pragma unroll 2
+  for (int pidx = p0; pidx < p1; ++pidx) {
+    const float d = c < C ? bf2f(dact[(int64_t)pidx * C + c]) : 0.0f;
     accb += d;
+    const float* xr = x + ((int64_t)b * T + 2 * h1) * idim + 2 * w1;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const int f = 2 * w1 + kw;
-        float xv = x[(b * T + 2 * h1 + kh) * idim + f];
-        if (cm_mean) xv = (xv - cm_mean[f]) * cm_istd[f];
+        float xv = xr[kh * idim + kw];
+        if (cm_mean) xv = (xv - cm_mean[2 * w1 + kw]) * cm_istd[2 * w1 + kw];
         acc[kh * 3 + kw] = fmaf(d, xv, acc[kh * 3 + kw]);
       }
+    if (++w1 == W1) {
+      w1 = 0;
+      if (++h1 == H1) { h1 = 0; ++b; }
+    }
   }
-  if (c < C) {
+  if (c < C) {  // per-workgroup partial (dw (C, 9) | db (C))
+    float* pp = part + (int64_t)blockIdx.x * ((int64_t)C * 10);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) atomicAdd(dw + c * 9 + k, acc[k]);
-    atomicAdd(db + c, accb);
+    for (int k = 0; k < 9; ++k) pp[c * 9 + k] = acc[k];
+    pp[C * 9 + c] = accb;
   }
 }
 
@@ -526,6 +570,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] -= lr_t * mi / (sqrtf(vi) + eps);
   }
 }
+
+constexpr int kRedSlices = 16;
+constexpr int kMaxPartBlocks = 2048, kMaxPartWidth = 8448;  // partial-sum workspace of the two-stage reductions
 
 static int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
   int64_t g = (n + per_block - 1) / per_block;
@@ -570,18 +617,24 @@ int ma_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols,
   return MA_OK;
 }
 
+int64_t ma_train_reduce_workspace_bytes(void) { return (int64_t)kMaxPartBlocks * kMaxPartWidth * 4; }
+
 int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
                          const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
-                         int32_t accumulate, float* dgamma, float* dbeta, ma_stream_t stream) {
-  if (!x || !gamma || !dy || !g || !dgamma || !dbeta || rows < 1) return MA_ERR_INVALID_ARG;
+                         int32_t accumulate, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                         ma_stream_t stream) {
+  if (!x || !gamma || !dy || !g || !dgamma || !dbeta || !workspace || rows < 1) return MA_ERR_INVALID_ARG;
   if (D != 256 || (ldx & 3) || (ldy & 3) || (ldg & 3)) return MA_ERR_UNSUPPORTED;
-  const int grid = grid_for(rows, 4, 512);
+  if (workspace_bytes < ma_train_reduce_workspace_bytes()) return MA_ERR_WORKSPACE;
+  const int grid = grid_for(rows, 4, 1024);
+  float* part = reinterpret_cast<float*>(workspace);
   if (dy_bf16)
     MA_LAUNCH(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
-              row_scale, dy, ldy, g, ldg, accumulate, dgamma, dbeta);
+              row_scale, dy, ldy, g, ldg, accumulate, part);
   else
     MA_LAUNCH(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
-              row_scale, dy, ldy, g, ldg, accumulate, dgamma, dbeta);
+              row_scale, dy, ldy, g, ldg, accumulate, part);
+  MA_LAUNCH(partial_reduce_kernel, dim3(8, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, grid, 512, dgamma, 256, dbeta);
   return MA_OK;
 }
 
@@ -662,22 +715,31 @@ int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, co
 
 int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                         const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
-                        ma_stream_t stream) {
-  if (!dz || !y || !dw_w || !dy || !d_dw_w || !d_dw_b || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
-  if (C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)((T + kCbStrip * kCbPerBlock - 1) / (kCbStrip * kCbPerBlock)), (unsigned)batch, (unsigned)(C / 256));
+                        void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  if (!dz || !y || !dw_w || !dy || !d_dw_w || !d_dw_b || !workspace || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
+  if (C != 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
+  if (workspace_bytes < ma_train_reduce_workspace_bytes()) return MA_ERR_WORKSPACE;
+  float* part = reinterpret_cast<float*>(workspace);
+  // strips per workgroup: as few as keep the number of partial vectors inside the workspace
+  int64_t strips = (T + kCbStrip - 1) / kCbStrip;
+  int per_block = 1;
+  while (((strips + per_block - 1) / per_block) * batch > kMaxPartBlocks) ++per_block;
+  const dim3 grid((unsigned)((strips + per_block - 1) / per_block), (unsigned)batch, 1);
+  const int nblk = (int)(grid.x * grid.y), width = C * (ks + 1);
 #define MA_CMB(KS_)                                                                                                    \
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_bwd_kernel<KS_>),                                     \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kCbStrip + KS_ - 1) * 256 * 4) != hipSuccess) \
     return MA_ERR_LAUNCH;                                                                                              \
   MA_LAUNCH(convmid_bwd_kernel<KS_>, grid, dim3(256), (size_t)2 * (kCbStrip + KS_ - 1) * 256 * sizeof(float),          \
-            (hipStream_t)stream, dz, (const uint16_t*)y, ldy, (int)batch, (int)T, C, dw_w, (uint16_t*)dy, lddy, d_dw_w,  \
-            d_dw_b)
+            (hipStream_t)stream, dz, (const uint16_t*)y, ldy, (int)batch, (int)T, C, dw_w, (uint16_t*)dy, lddy, part,    \
+            per_block)
   if (ks == 3) { MA_CMB(3); }
   else if (ks == 7) { MA_CMB(7); }
   else if (ks == 15) { MA_CMB(15); }
   else { MA_CMB(31); }
 #undef MA_CMB
+  MA_LAUNCH(partial_reduce_kernel, dim3((width + 63) / 64, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, nblk, width, d_dw_w,
+            C * ks, d_dw_b);
   return MA_OK;
 }
 
@@ -700,23 +762,31 @@ int ma_im2col_t_3x3s2_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64
 
 int ma_col2im_3x3s2_relu_bf16(const void* dcol, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
                               void* dact, ma_stream_t stream) {
-  if (!dcol || !act || !dact || batch < 1 || H < 3 || Wd < 3 || C < 1) return MA_ERR_INVALID_ARG;
+  if (!dcol || !act || !dact || batch < 1 || H < 3 || Wd < 3 || C < 8) return MA_ERR_INVALID_ARG;
+  if (C & 7) return MA_ERR_UNSUPPORTED;
   const int Ho = (int)((H - 3) / 2 + 1), Wo = (int)((Wd - 3) / 2 + 1);
-  MA_LAUNCH(col2im_relu_kernel, dim3(grid_for(batch * H * Wd * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+  MA_LAUNCH(col2im_relu_kernel, dim3(grid_for(batch * H * Wd * (C / 8), 256, 16384)), dim3(256), 0, (hipStream_t)stream,
             (const uint16_t*)dcol, (const uint16_t*)act, (int)batch, (int)H, (int)Wd, (int)C, Ho, Wo, (uint16_t*)dact);
   return MA_OK;
 }
 
 int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, int64_t T, int32_t idim,
                               const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
-                              ma_stream_t stream) {
-  if (!dact || !x || !dw || !db || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
+                              void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  if (!dact || !x || !dw || !db || !workspace || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
+  if (C > 256) return MA_ERR_UNSUPPORTED;
+  if (workspace_bytes < ma_train_reduce_workspace_bytes()) return MA_ERR_WORKSPACE;
+  float* part = reinterpret_cast<float*>(workspace);
   const int H1 = (int)((T - 3) / 2 + 1), W1 = (idim - 3) / 2 + 1;
   const int64_t npos = batch * H1 * W1;
-  const int strip = 256;
+  int64_t strip64 = (npos + kMaxPartBlocks - 1) / kMaxPartBlocks;  // as many workgroups as the partial workspace holds
+  const int strip = (int)(strip64 < 64 ? 64 : strip64);
+  const int nblk = (int)((npos + strip - 1) / strip);
   MA_LAUNCH(conv1_dw_kernel, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,
-            (hipStream_t)stream, (const uint16_t*)dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, dw,
-            db, strip);
+            (hipStream_t)stream, (const uint16_t*)dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, part,
+            strip);
+  MA_LAUNCH(partial_reduce_kernel, dim3((C * 10 + 63) / 64, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, nblk, C * 10, dw,
+            C * 9, db);
   return MA_OK;
 }
 

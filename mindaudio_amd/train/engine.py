@@ -425,8 +425,7 @@ class ConformerCTCTrainStep:
         dact2 = ops.gemm(de, self.wt["out_w"])                  # (m, f2*c) bf16
         K.relu_bwd(dact2, a2)
         dy2 = dact2.view(m * f2, c)
-        dy2t = K.transpose(dy2, colsum=fp.g("conv2_b"), slot=0)
-        K.gemm_splitk(dy2t, K.im2col_t(act1), fp.g("conv2_w"))
+        K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"))
         dcol = ops.gemm(dy2, self.wt["conv2_w"])                # (B*T2*F2, 9c) bf16
         dact1 = K.col2im_relu(dcol, act1)
         K.conv1_dw(dact1, xs, enc.cmvn_mean, enc.cmvn_istd, fp.g("conv1_w"), fp.g("conv1_b"))

@@ -15,6 +15,17 @@ def _p(x):
     return _host.ptr(x) if x is not None else None
 
 
+_red_ws = {}
+
+
+def _reduce_ws(device):
+    """Scratch of the two-stage parameter-gradient reductions (own buffer: it must not alias the GEMM workspace)."""
+    key = str(device)
+    if key not in _red_ws:
+        _red_ws[key] = _t().empty(_lib.load().ma_train_reduce_workspace_bytes(), dtype=_t().uint8, device=device)
+    return _red_ws[key]
+
+
 def pad64(n):
     return (n + 63) // 64 * 64
 
@@ -67,11 +78,22 @@ def gemm_tn(a, b, out, colsum=None, rows_store=None, alpha=1.0, accumulate=True)
     return out
 
 
+def conv2d_dw(dy, act, dw, dbias):
+    """dw (Cout, 9C) f32 += dy^T @ im2col(act); dbias (Cout) += column sums.  dy (B*Ho*Wo, Cout) bf16, act NHWC bf16."""
+    lib = _lib.load()
+    b, h, w, c = act.shape
+    cout = dy.shape[1]
+    ws = _host.workspace(lib.ma_gemm_tn_workspace_bytes(cout, 9 * c, dy.shape[0]), dy.device)
+    _lib.check(lib.ma_conv2d_3x3s2_dw_bf16(_p(dy), dy.stride(0), _p(act), b, h, w, c, cout, _p(dw), _p(dbias), _p(ws),
+                                           ws.numel(), _s()), "conv2d_dw")
+
+
 def layernorm_bwd(x, gamma, dy, g, dgamma, dbeta, row_scale=None, accumulate=True, eps=1e-5):
     t = _t()
     _lib.check(_lib.load().ma_layernorm_bwd_f32(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(gamma), float(eps),
                                                 _p(row_scale), _p(dy), dy.stride(0), 1 if dy.dtype == t.bfloat16 else 0,
-                                                _p(g), g.stride(0), 1 if accumulate else 0, _p(dgamma), _p(dbeta), _s()),
+                                                _p(g), g.stride(0), 1 if accumulate else 0, _p(dgamma), _p(dbeta),
+                                                _p(_reduce_ws(x.device)), _reduce_ws(x.device).numel(), _s()),
                "layernorm_bwd")
     return g
 
@@ -139,8 +161,9 @@ def convmid_bwd(dout, y, z, stats, batch, T, dw_w, gamma, beta, d_dw_w, d_dw_b, 
     d_beta += dsum[:c]
     d_gamma += dsum[c:]
     dy = t.empty((rows, 2 * c), dtype=t.bfloat16, device=y.device)
+    rw = _reduce_ws(y.device)
     _lib.check(lib.ma_convmid_bwd_bf16(_p(dz), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dy), dy.stride(0),
-                                       _p(d_dw_w), _p(d_dw_b), _s()), "convmid_bwd")
+                                       _p(d_dw_w), _p(d_dw_b), _p(rw), rw.numel(), _s()), "convmid_bwd")
     return dy
 
 
@@ -171,8 +194,9 @@ def col2im_relu(dcol, act):
 
 def conv1_dw(dact, x, cmvn_mean, cmvn_istd, dw, db):
     b, tt, idim = x.shape
+    rw = _reduce_ws(x.device)
     _lib.check(_lib.load().ma_subsample_conv1_dw_f32(_p(dact), _p(x), b, tt, idim, _p(cmvn_mean), _p(cmvn_istd),
-                                                     dact.shape[-1], _p(dw), _p(db), _s()), "conv1_dw")
+                                                     dact.shape[-1], _p(dw), _p(db), _p(rw), rw.numel(), _s()), "conv1_dw")
 
 
 def grad_overflow(g, flag):

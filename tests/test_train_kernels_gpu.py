@@ -164,6 +164,18 @@ def test_subsampling_backward_pieces(K):
     dc = dcol.float().view(b, ho * wo, 9, c).permute(0, 3, 2, 1).reshape(b, c * 9, ho * wo)
     want = F.fold(dc, (h, w), 3, stride=2).permute(0, 2, 3, 1) * (act.float() > 0)
     assert rel(dact, bf(want).float()) < 3e-3
+    # conv2 weight gradient as a TN GEMM with the implicit im2col operand
+    b2, h2, w2, c2, co2 = 2, 23, 19, 128, 64
+    act_b = bf(torch.randn(b2, h2, w2, c2, generator=g))
+    ho2, wo2 = (h2 - 3) // 2 + 1, (w2 - 3) // 2 + 1
+    dy_b = bf(torch.randn(b2 * ho2 * wo2, co2, generator=g))
+    wgt2 = torch.zeros(co2, c2, 3, 3, requires_grad=True)
+    bias2 = torch.zeros(co2, requires_grad=True)
+    o2 = F.conv2d(act_b.float().permute(0, 3, 1, 2), wgt2, bias2, stride=2)
+    o2.backward(dy_b.float().view(b2, ho2, wo2, co2).permute(0, 3, 1, 2))
+    dw2, db2 = torch.zeros(co2, 9 * c2, device="cuda"), torch.zeros(co2, device="cuda")
+    K.conv2d_dw(dy_b.cuda(), act_b.cuda(), dw2, db2)
+    assert rel(dw2.view(co2, 3, 3, c2), wgt2.grad.permute(0, 2, 3, 1)) < 2e-5 and rel(db2, bias2.grad) < 2e-5
     dy = bf(torch.randn(1000, generator=g)).cuda()
     yv = bf(torch.randn(1000, generator=g))
     assert torch.equal(K.relu_bwd(dy.clone(), yv.cuda()).cpu(), dy.cpu() * (yv.float() > 0).to(torch.bfloat16))

@@ -374,11 +374,13 @@ int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, c
  * ma_subsample_conv1_dw_f32 (per-workgroup partial sums, then a fixed-order sum: no contended atomics). */
 int64_t ma_train_reduce_workspace_bytes(void);
 
-/* h = dropout(swish(u)) between w_1 and w_2 (positionwise_feed_forward.py:33-46), bf16, n elements; the keep mask is a
- * pure function of (seed, salt, element index) and is regenerated by the backward: du = dh * keep/(1-p) * swish'(u). */
-int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
-int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, float p, uint32_t seed, uint32_t salt,
+/* h = dropout(act(u)) between w_1 and w_2 (positionwise_feed_forward.py:33-46), bf16, n elements; act: 1 swish
+ * (encoder), 2 relu (decoder, conformer.py:521).  The keep mask is a pure function of (seed, salt, element index) and is
+ * regenerated by the backward: du = dh * keep/(1-p) * act'(u). */
+int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, int32_t act, float p, uint32_t seed, uint32_t salt,
                             ma_stream_t stream);
+int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, int32_t act, float p, uint32_t seed,
+                            uint32_t salt, ma_stream_t stream);
 
 /* x (rows, cols) float32 = xin + alpha * dropout(y) (models/conformer.py:109-151 branch joins; xin may be x); y bf16 or
  * float32.  Backward: dy (bf16) = alpha * keep/(1-p) * g * row_scale[r]. */
@@ -437,6 +439,36 @@ int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* po
                                  int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
                                  float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
                                  ma_stream_t stream);
+
+/* ---- attention-decoder branch of the hybrid loss (models/conformer.py:382-639, asr_model.py:154-186) -----------
+ * Token-sized pieces; the decoder's matmuls, LayerNorms (eps 1e-12) and dropouts reuse the entry points above. */
+
+/* nn.Embedding -> x * xscale + pe[l] -> dropout (layers/embedding.py:16-62): out (rows, D) float32, rows = batch * L,
+ * token ids clamped into [0, V).  Backward: dtable (V, D) float32 += scatter of xscale * keep/(1-p) * g. */
+int ma_embed_posenc_f32(const int32_t* tokens, const float* table, const float* pe, int64_t rows, int32_t L, int32_t D,
+                        int32_t V, float xscale, float p, uint32_t seed, uint32_t salt, float* out, ma_stream_t stream);
+int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_t D, int32_t V, float xscale, float p,
+                     uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream);
+
+/* MultiHeadedAttention core (layers/attention.py:86-157) for Lq <= 32 queries and Lk <= 256 keys per (batch, head),
+ * d_k = 64: ctx = softmax(scale * q k^T + (mask == 0 ? -10000 : 0)) v.  q (batch*Lq, H*64) / k, v (batch*Lk, H*64) bf16
+ * with row strides; mask_mode 0 none, 1 (batch, 1, Lk), 2 (batch, Lq, Lk) float32; probs (batch, H, Lq, Lk) float32 is
+ * written by the forward and read by the backward (dq, dk, dv bf16 with their own row strides). */
+int ma_mha_small_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads,
+                          int32_t d_k, float scale, void* ctx, int64_t ldc, float* probs, ma_stream_t stream);
+int ma_mha_small_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          const float* probs, const void* ctx, int64_t ldc, const void* dctx, int64_t lddc, int64_t batch,
+                          int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k, float scale, void* dq, int64_t lddq, void* dk,
+                          int64_t lddk, void* dv, int64_t lddv, ma_stream_t stream);
+
+/* LabelSmoothingLoss (loss/label_smoothing_loss.py:24-117) on logits (rows, ld >= V) float32: stats[0] += sum over
+ * unmasked rows of KL(true_dist || softmax), stats[1] += correct argmax count, stats[2] += unmasked rows (caller zeroes;
+ * the loss is stats[0] / batch, the accuracy stats[1] / stats[2], asr_model.py:188-209);
+ * dlogits (rows, ld_out) bf16 = grad_scale * mask * (softmax - true_dist), zero in columns >= V. */
+int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
+                                     const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
+                                     float* stats, ma_stream_t stream);
 
 /* TrainOneStepWithLossScaleCell pieces (train_one_step.py:37-47): *flag |= 1 if any gradient is inf/nan; Adam
  * (MindSpore nn.Adam: p -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t) from the host) on

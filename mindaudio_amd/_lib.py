@@ -126,8 +126,8 @@ PROTOTYPES = {
     "ma_transpose_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
     "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp]),
     "ma_train_reduce_workspace_bytes": (i64, []),
-    "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, f32, u32, u32, vp]),
-    "ma_act_dropout_bwd_bf16": (ctypes.c_int, [vp, vp, vp, i64, f32, u32, u32, vp]),
+    "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, i32, f32, u32, u32, vp]),
+    "ma_act_dropout_bwd_bf16": (ctypes.c_int, [vp, vp, vp, i64, i32, f32, u32, u32, vp]),
     "ma_dropout_add_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i32, i64, i64, f32, f32, u32, u32, vp]),
     "ma_dropout_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, f32, vp, f32, u32, u32, vp]),
     "ma_convmid_fwd_train": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, vp, vp]),
@@ -144,6 +144,13 @@ PROTOTYPES = {
     "ma_relpos_attention_bwd_workspace_bytes": (i64, [i64, i64, i32, i32]),
     "ma_relpos_attention_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32,
                                                     i32, vp, i64, vp, i64, vp, vp, vp, i64, vp]),
+    "ma_embed_posenc_f32": (ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, f32, f32, u32, u32, vp, vp]),
+    "ma_embed_bwd_f32": (ctypes.c_int, [vp, vp, i64, i32, i32, f32, f32, u32, u32, vp, vp]),
+    "ma_mha_small_fwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i64, i32, i32, i32, i32, f32, vp, i64, vp,
+                                             vp]),
+    "ma_mha_small_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32,
+                                             vp, i64, vp, i64, vp, i64, vp]),
+    "ma_label_smoothing_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, i64, vp, vp]),
     "ma_grad_overflow_f32": (ctypes.c_int, [vp, i64, vp, vp]),
     "ma_adam_f32": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
     "ma_db_workspace_bytes": (i64, [i64, i64]),

@@ -42,17 +42,25 @@ class CTC(nn.Module):
 
 
 class ASRModel(nn.Module):
-    """Encoder + CTC loss (asr_model.py:16-153 with ctc_weight == 1.0)."""
+    """Encoder + CTC [+ attention decoder] (asr_model.py:16-153).  The evaluation forward below covers the CTC branch
+    (ctc_weight == 1.0); the hybrid loss (decoder + label smoothing) runs in mindaudio_amd.train.engine, which is where
+    the reference uses it (training)."""
 
-    def __init__(self, vocab_size, encoder, ctc, ctc_weight=1.0):
+    def __init__(self, vocab_size, encoder, ctc, ctc_weight=1.0, decoder=None, lsm_weight=0.0, reverse_weight=0.0,
+                 length_normalized_loss=False):
         super().__init__()
-        if ctc_weight != 1.0:
-            raise NotImplementedError("attention-decoder branch (ctc_weight != 1.0) is not on the built path yet")
+        if ctc_weight != 1.0 and decoder is None:
+            raise ValueError("ctc_weight != 1.0 needs a decoder (asr_model.py:327-337)")
+        if reverse_weight != 0.0 or length_normalized_loss:
+            raise NotImplementedError("reverse decoder / length-normalised loss are off in the shipped configuration")
         self.vocab_size, self.encoder, self.ctc, self.ctc_weight = vocab_size, encoder, ctc, ctc_weight
+        self.decoder, self.lsm_weight = decoder, lsm_weight
 
     @torch.no_grad()
     def forward(self, xs_pad, ys_pad, ys_in_pad=None, ys_out_pad=None, r_ys_in_pad=None, r_ys_out_pad=None,
                 xs_masks=None, ys_sub_masks=None, ys_masks=None, ys_lengths=None, xs_chunk_masks=None):
+        if self.ctc_weight != 1.0:
+            raise NotImplementedError("evaluation forward of the hybrid loss: use mindaudio_amd.train.engine")
         encoder_out, encoder_mask = self.encoder(xs_pad, xs_masks, xs_chunk_masks)
         # asr_model.py:109-114: lengths = mask.squeeze().sum(1) as int32
         encoder_out_lens = encoder_mask.to(torch.float32).reshape(encoder_mask.shape[0], -1).sum(1).to(torch.int32)
@@ -60,11 +68,17 @@ class ASRModel(nn.Module):
         return loss_ctc, None
 
 
-def create_asr_model(input_dim, vocab_size, encoder_conf=None, global_cmvn=None, ctc_weight=1.0):
-    """creadte_asr_model (asr_model.py:301-352) for the CTC-only configuration."""
+def create_asr_model(input_dim, vocab_size, encoder_conf=None, global_cmvn=None, ctc_weight=1.0, decoder_conf=None,
+                     lsm_weight=0.0):
+    """creadte_asr_model (asr_model.py:301-352): decoder None when ctc_weight == 1.0, else a TransformerDecoder."""
+    from ..models.decoder import TransformerDecoder
+
     encoder = ConformerEncoder(input_dim, global_cmvn=global_cmvn, **(encoder_conf or {}))
     ctc = CTC(vocab_size, encoder.output_size())
-    return ASRModel(vocab_size, encoder, ctc, ctc_weight)
+    decoder = None
+    if ctc_weight != 1.0:
+        decoder = TransformerDecoder(vocab_size, encoder.output_size(), **(decoder_conf or {}))
+    return ASRModel(vocab_size, encoder, ctc, ctc_weight, decoder=decoder, lsm_weight=lsm_weight)
 
 
 class ASREvalNet(nn.Module):

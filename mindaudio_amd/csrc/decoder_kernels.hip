@@ -1,0 +1,422 @@
+// Attention-decoder branch of the hybrid CTC/attention loss for gfx950:
+//   TransformerDecoder / DecoderLayer (mindaudio/models/conformer.py:382-639), MultiHeadedAttention
+//   (mindaudio/models/layers/attention.py:17-157), LabelSmoothingLoss (mindaudio/loss/label_smoothing_loss.py:24-117).
+// The decoder works on B x (max_tgt_len + 1) <= B x 32 tokens: its matmuls reuse gemm_bf16 / gemm_tn_bf16, LayerNorm
+// and dropout reuse the encoder kernels; this file adds the token-sized pieces:
+//   embed_posenc fwd/bwd      nn.Embedding -> x * sqrt(d) + pe -> dropout (embedding.py:16-62)
+//   mha_small fwd/bwd         softmax(q k^T / d_k + mask) v for <= 32 queries x <= 256 keys per (batch, head); scores are
+//                             q*s . k*s with s = 1/sqrt(d_k), i.e. divided by d_k (attention.py:150-152); additive -10000
+//                             mask of shape (B, 1, Lk) or (B, Lq, Lk); probabilities are kept for the backward pass
+//   label_smoothing           KL(true_dist || softmax) summed over unmasked tokens / batch + its gradient + accuracy
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+__device__ __forceinline__ float d_bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t d_f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ bool d_keep(uint32_t seed, uint32_t salt, uint64_t idx, uint32_t thresh) {  // = train_kernels.hip
+  uint32_t x = (uint32_t)idx ^ (seed * 0x9E3779B9u) ^ (salt * 0x85EBCA6Bu) ^ ((uint32_t)(idx >> 32) * 0xC2B2AE35u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  x += salt; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+  return x >= thresh;
+}
+static uint32_t d_thresh(float p) {
+  if (!(p > 0.0f)) return 0;
+  const double th = (double)p * 4294967296.0;
+  return th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th;
+}
+
+// ---- embedding + positional encoding ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ table,
+                                                        const float* __restrict__ pe, int L, int D, int V, float xscale,
+                                                        uint32_t seed, uint32_t salt, uint32_t thresh, float inv_keep,
+                                                        float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D);
+    const int64_t r = i / D;
+    const int l = (int)(r % L);
+    int t = tok[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    float v = table[(int64_t)t * D + d] * xscale + pe[(int64_t)l * D + d];
+    if (thresh) v = d_keep(seed, salt, (uint64_t)i, thresh) ? v * inv_keep : 0.0f;
+    out[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ g, int D, int V,
+                                                        float xscale, uint32_t seed, uint32_t salt, uint32_t thresh,
+                                                        float inv_keep, float* dtable, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D);
+    const int64_t r = i / D;
+    int t = tok[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    float v = g[i] * xscale;
+    if (thresh) v = d_keep(seed, salt, (uint64_t)i, thresh) ? v * inv_keep : 0.0f;
+    atomicAdd(dtable + (int64_t)t * D + d, v);
+  }
+}
+
+// ---- small multi-head attention ----------------------------------------------------------------------------------
+constexpr int kSmQ = 32, kSmK = 320, kSmD = 64;
+struct SmallAttn {
+  const uint16_t *q, *k, *v;
+  int64_t ldq, ldk, ldv;
+  const float* mask;
+  int mask_mode;  // 0 none, 1 (B, 1, Lk), 2 (B, Lq, Lk)
+  int Lq, Lk, H;
+  float scale;
+};
+
+// workgroup = (head, batch): thread j owns key j for the scores, (query, 8 d's) for the context
+__global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, uint16_t* __restrict__ ctx, int64_t ldc,
+                                                            float* __restrict__ probs) {
+  extern __shared__ __attribute__((aligned(16))) char sm_lds[];
+  uint16_t (*Vs)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);                                  // 32 KiB
+  float (*S)[kSmK + 1] = reinterpret_cast<float (*)[kSmK + 1]>(sm_lds + kSmK * kSmD * 2);               // 32.1 KiB
+  float (*Qs)[kSmD + 1] = reinterpret_cast<float (*)[kSmD + 1]>(sm_lds + kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4);
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int Lq = p.Lq, Lk = p.Lk;
+  for (int i = tid; i < kSmQ * kSmD; i += 256) {
+    const int qi = i / kSmD, d = i % kSmD;
+    Qs[qi][d] = qi < Lq ? d_bf2f(p.q[((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d]) : 0.0f;
+  }
+  for (int i = tid; i < kSmK * (kSmD / 8); i += 256) {
+    const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (kj < Lk) val = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + ch * 8);
+    *reinterpret_cast<uint4*>(&Vs[kj][ch * 8]) = val;
+  }
+  __syncthreads();
+  for (int j = tid; j < Lk; j += 256) {
+    float kr[kSmD];
+    const uint16_t* kp = p.k + ((int64_t)b * Lk + j) * p.ldk + h * kSmD;
+#pragma unroll
+    for (int d = 0; d < kSmD; ++d) kr[d] = d_bf2f(kp[d]);
+    for (int i = 0; i < Lq; ++i) {
+      float s = 0.0f;
+#pragma unroll
+      for (int d = 0; d < kSmD; ++d) s = fmaf(Qs[i][d], kr[d], s);
+      s *= p.scale;
+      if (p.mask_mode == 1 && p.mask[(int64_t)b * Lk + j] == 0.0f) s += -10000.0f;
+      if (p.mask_mode == 2 && p.mask[((int64_t)b * Lq + i) * Lk + j] == 0.0f) s += -10000.0f;
+      S[i][j] = s;
+    }
+  }
+  __syncthreads();
+  // softmax of row i by wave (i % 4)
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int i = wave; i < Lq; i += 4) {
+    float m = -INFINITY;
+    for (int jj = lane; jj < Lk; jj += 64) m = fmaxf(m, S[i][jj]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float sum = 0.0f;
+    for (int jj = lane; jj < Lk; jj += 64) {
+      const float e = __expf(S[i][jj] - m);
+      S[i][jj] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float inv = 1.0f / sum;
+    float* pr = probs + (((int64_t)b * p.H + h) * Lq + i) * Lk;
+    for (int jj = lane; jj < Lk; jj += 64) {
+      const float pv = S[i][jj] * inv;
+      S[i][jj] = pv;
+      pr[jj] = pv;
+    }
+  }
+  __syncthreads();
+  const int qi = tid >> 3, dg = (tid & 7) * 8;
+  if (qi < Lq) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int jj = 0; jj < Lk; ++jj) {
+      const float pv = S[qi][jj];
+      const uint4 vv = *reinterpret_cast<const uint4*>(&Vs[jj][dg]);
+      const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] = fmaf(pv, __uint_as_float(w[e] << 16), acc[2 * e]);
+        acc[2 * e + 1] = fmaf(pv, __uint_as_float(w[e] & 0xffff0000u), acc[2 * e + 1]);
+      }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)d_f2bf(acc[2 * e]) | ((uint32_t)d_f2bf(acc[2 * e + 1]) << 16);
+    *reinterpret_cast<uint4*>(ctx + ((int64_t)b * Lq + qi) * ldc + h * kSmD + dg) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// Backward: D_i = dO_i . O_i; thread j: dP_ij = dO_i . v_j, dS_ij = P_ij (dP_ij - D_i), dv_j = sum_i P_ij dO_i,
+// dk_j = scale sum_i dS_ij q_i; then thread (i, 8 d's): dq_i = scale sum_j dS_ij k_j.
+__global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, const float* __restrict__ probs,
+                                                            const uint16_t* __restrict__ ctx, int64_t ldc,
+                                                            const uint16_t* __restrict__ dctx, int64_t lddc,
+                                                            uint16_t* __restrict__ dq, int64_t lddq, uint16_t* __restrict__ dk,
+                                                            int64_t lddk, uint16_t* __restrict__ dv, int64_t lddv) {
+  extern __shared__ __attribute__((aligned(16))) char sm_lds[];
+  uint16_t (*Ks)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);
+  float (*S)[kSmK + 1] = reinterpret_cast<float (*)[kSmK + 1]>(sm_lds + kSmK * kSmD * 2);
+  float (*Qs)[kSmD + 1] = reinterpret_cast<float (*)[kSmD + 1]>(sm_lds + kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4);
+  float (*dOs)[kSmD + 1] = Qs + kSmQ;
+  float* Dq = reinterpret_cast<float*>(dOs + kSmQ);
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int Lq = p.Lq, Lk = p.Lk;
+  for (int i = tid; i < kSmQ * kSmD; i += 256) {
+    const int qi = i / kSmD, d = i % kSmD;
+    const bool in = qi < Lq;
+    Qs[qi][d] = in ? d_bf2f(p.q[((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d]) : 0.0f;
+    dOs[qi][d] = in ? d_bf2f(dctx[((int64_t)b * Lq + qi) * lddc + h * kSmD + d]) : 0.0f;
+  }
+  for (int i = tid; i < kSmK * (kSmD / 8); i += 256) {
+    const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (kj < Lk) val = *reinterpret_cast<const uint4*>(p.k + ((int64_t)b * Lk + kj) * p.ldk + h * kSmD + ch * 8);
+    *reinterpret_cast<uint4*>(&Ks[kj][ch * 8]) = val;
+  }
+  for (int i = tid; i < Lq * Lk; i += 256) {
+    const int qi = i / Lk, jj = i - qi * Lk;
+    S[qi][jj] = probs[(((int64_t)b * p.H + h) * Lq + qi) * Lk + jj];
+  }
+  __syncthreads();
+  if (tid < Lq) {
+    float s = 0.0f;
+    const uint16_t* op = ctx + ((int64_t)b * Lq + tid) * ldc + h * kSmD;
+    for (int d = 0; d < kSmD; ++d) s = fmaf(dOs[tid][d], d_bf2f(op[d]), s);
+    Dq[tid] = s;
+  }
+  __syncthreads();
+  for (int j = tid; j < Lk; j += 256) {
+    float vr[kSmD], dvr[kSmD], dkr[kSmD];
+    const uint16_t* vp = p.v + ((int64_t)b * Lk + j) * p.ldv + h * kSmD;
+#pragma unroll
+    for (int d = 0; d < kSmD; ++d) {
+      vr[d] = d_bf2f(vp[d]);
+      dvr[d] = 0.0f;
+      dkr[d] = 0.0f;
+    }
+    for (int i = 0; i < Lq; ++i) {
+      float dp = 0.0f;
+#pragma unroll
+      for (int d = 0; d < kSmD; ++d) dp = fmaf(dOs[i][d], vr[d], dp);
+      const float pij = S[i][j];
+      const float ds = pij * (dp - Dq[i]) * p.scale;
+      S[i][j] = ds;
+#pragma unroll
+      for (int d = 0; d < kSmD; ++d) {
+        dvr[d] = fmaf(pij, dOs[i][d], dvr[d]);
+        dkr[d] = fmaf(ds, Qs[i][d], dkr[d]);
+      }
+    }
+    uint16_t* dvp = dv + ((int64_t)b * Lk + j) * lddv + h * kSmD;
+    uint16_t* dkp = dk + ((int64_t)b * Lk + j) * lddk + h * kSmD;
+#pragma unroll
+    for (int d = 0; d < kSmD; d += 2) {
+      *reinterpret_cast<uint32_t*>(dvp + d) = (uint32_t)d_f2bf(dvr[d]) | ((uint32_t)d_f2bf(dvr[d + 1]) << 16);
+      *reinterpret_cast<uint32_t*>(dkp + d) = (uint32_t)d_f2bf(dkr[d]) | ((uint32_t)d_f2bf(dkr[d + 1]) << 16);
+    }
+  }
+  __syncthreads();
+  const int qi = tid >> 3, dg = (tid & 7) * 8;
+  if (qi < Lq) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int jj = 0; jj < Lk; ++jj) {
+      const float ds = S[qi][jj];
+      const uint4 kv = *reinterpret_cast<const uint4*>(&Ks[jj][dg]);
+      const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] = fmaf(ds, __uint_as_float(w[e] << 16), acc[2 * e]);
+        acc[2 * e + 1] = fmaf(ds, __uint_as_float(w[e] & 0xffff0000u), acc[2 * e + 1]);
+      }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)d_f2bf(acc[2 * e]) | ((uint32_t)d_f2bf(acc[2 * e + 1]) << 16);
+    *reinterpret_cast<uint4*>(dq + ((int64_t)b * Lq + qi) * lddq + h * kSmD + dg) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---- label smoothing loss --------------------------------------------------------------------------------------
+// one workgroup per token row: kl = sum_v q_v (log q_v - logp_v), q = on at the target, off elsewhere; masked rows
+// contribute nothing.  stats[0] += kl, stats[1] += (argmax == target) * mask, stats[2] += mask.
+__global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __restrict__ logits, int64_t ld, int V,
+                                                              const int32_t* __restrict__ target, const float* __restrict__ mask,
+                                                              float on, float off, float ent, float scale,
+                                                              uint16_t* __restrict__ dlogits, int64_t ldo, float* stats) {
+  __shared__ float red[4];
+  __shared__ int redi[4];
+  const int64_t row = blockIdx.x;
+  const float* p = logits + row * ld;
+  uint16_t* o = dlogits + row * ldo;
+  const float mk = mask[row];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (mk == 0.0f) {
+    for (int v = threadIdx.x; v < ldo; v += 256) o[v] = 0;
+    return;
+  }
+  int tg = target[row];
+  tg = tg < 0 ? 0 : tg;  // target * mask: "avoid -1 index" (label_smoothing_loss.py:100-102)
+  float m = -INFINITY;
+  int am = 0;
+  for (int v = threadIdx.x; v < V; v += 256)
+    if (p[v] > m) { m = p[v]; am = v; }
+#pragma unroll
+  for (int off2 = 32; off2 > 0; off2 >>= 1) {
+    const float om = __shfl_xor(m, off2, 64);
+    const int oa = __shfl_xor(am, off2, 64);
+    if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+  }
+  if (lane == 0) { red[wave] = m; redi[wave] = am; }
+  __syncthreads();
+  m = red[0]; am = redi[0];
+  for (int w = 1; w < 4; ++w)
+    if (red[w] > m || (red[w] == m && redi[w] < am)) { m = red[w]; am = redi[w]; }
+  __syncthreads();
+  float s = 0.0f, sl = 0.0f;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    s += __expf(p[v] - m);
+    sl += p[v];
+  }
+#pragma unroll
+  for (int off2 = 32; off2 > 0; off2 >>= 1) {
+    s += __shfl_xor(s, off2, 64);
+    sl += __shfl_xor(sl, off2, 64);
+  }
+  __shared__ float red2[4];
+  if (lane == 0) { red[wave] = s; red2[wave] = sl; }
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  sl = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+  const float lse = m + __logf(s);
+  if (threadIdx.x == 0) {
+    const float logp_t = p[tg] - lse;
+    const float sum_logp = sl - (float)V * lse;
+    // sum_v q_v log q_v = ent (host); - sum_v q_v logp_v
+    const float kl = ent - (on * logp_t + off * (sum_logp - logp_t));
+    atomicAdd(stats, kl);
+    atomicAdd(stats + 1, am == tg ? 1.0f : 0.0f);
+    atomicAdd(stats + 2, 1.0f);
+  }
+  for (int v = threadIdx.x; v < ldo; v += 256) {
+    float gval = 0.0f;
+    if (v < V) gval = scale * (__expf(p[v] - lse) - (v == tg ? on : off));
+    o[v] = d_f2bf(gval);
+  }
+}
+
+static int d_grid(int64_t n, int cap = 4096) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int ma_embed_posenc_f32(const int32_t* tokens, const float* table, const float* pe, int64_t rows, int32_t L, int32_t D,
+                        int32_t V, float xscale, float p, uint32_t seed, uint32_t salt, float* out, ma_stream_t stream) {
+  if (!tokens || !table || !pe || !out || rows < 1 || L < 1 || D < 1 || V < 1 || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+  const int64_t n = rows * D;
+  MA_LAUNCH(embed_fwd_kernel, dim3(d_grid(n)), dim3(256), 0, (hipStream_t)stream, tokens, table, pe, L, D, V, xscale, seed,
+            salt, d_thresh(p), 1.0f / (1.0f - p), out, n);
+  return MA_OK;
+}
+
+int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_t D, int32_t V, float xscale, float p,
+                     uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream) {
+  if (!tokens || !g || !dtable || rows < 1 || D < 1 || V < 1 || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+  const int64_t n = rows * D;
+  MA_LAUNCH(embed_bwd_kernel, dim3(d_grid(n)), dim3(256), 0, (hipStream_t)stream, tokens, g, D, V, xscale, seed, salt,
+            d_thresh(p), 1.0f / (1.0f - p), dtable, n);
+  return MA_OK;
+}
+
+static int fill_small(SmallAttn& a, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                      const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k,
+                      float scale) {
+  if (!q || !k || !v || batch < 1 || Lq < 1 || Lk < 1 || heads < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
+  if (d_k != kSmD || Lq > kSmQ || Lk > kSmK || (ldk & 7) || (ldv & 7)) return MA_ERR_UNSUPPORTED;
+  if (mask_mode < 0 || mask_mode > 2 || (mask_mode && !mask)) return MA_ERR_INVALID_ARG;
+  a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.mask = mask; a.mask_mode = mask_mode;
+  a.Lq = Lq; a.Lk = Lk; a.H = heads; a.scale = scale;
+  return MA_OK;
+}
+
+int ma_mha_small_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads,
+                          int32_t d_k, float scale, void* ctx, int64_t ldc, float* probs, ma_stream_t stream) {
+  SmallAttn a;
+  const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, mask, mask_mode, batch, Lq, Lk, heads, d_k, scale);
+  if (rc != MA_OK) return rc;
+  if (!ctx || !probs || (ldc & 7)) return MA_ERR_INVALID_ARG;
+  constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * (kSmD + 1) * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds) != hipSuccess)
+      return MA_ERR_LAUNCH;
+    attr = true;
+  }
+  MA_LAUNCH(mha_small_fwd_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
+            (uint16_t*)ctx, ldc, probs);
+  return MA_OK;
+}
+
+int ma_mha_small_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          const float* probs, const void* ctx, int64_t ldc, const void* dctx, int64_t lddc, int64_t batch,
+                          int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k, float scale, void* dq, int64_t lddq, void* dk,
+                          int64_t lddk, void* dv, int64_t lddv, ma_stream_t stream) {
+  SmallAttn a;
+  const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, nullptr, 0, batch, Lq, Lk, heads, d_k, scale);
+  if (rc != MA_OK) return rc;
+  if (!probs || !ctx || !dctx || !dq || !dk || !dv || (lddq & 7) || (lddk & 1) || (lddv & 1)) return MA_ERR_INVALID_ARG;
+  constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 1) * 4 + kSmQ * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds) != hipSuccess)
+      return MA_ERR_LAUNCH;
+    attr = true;
+  }
+  MA_LAUNCH(mha_small_bwd_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
+            (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv,
+            lddv);
+  return MA_OK;
+}
+
+int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
+                                     const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
+                                     float* stats, ma_stream_t stream) {
+  if (!logits || !target || !mask || !dlogits || !stats || rows < 1 || V < 2 || ld < V || ld_out < V) return MA_ERR_INVALID_ARG;
+  if (smoothing < 0.0f || smoothing >= 1.0f) return MA_ERR_INVALID_ARG;
+  const float on = 1.0f - smoothing, off = smoothing / (float)(V - 1);
+  // sum_v q_v log q_v (0 log 0 = 0)
+  float ent = on * logf(on);
+  if (off > 0.0f) ent += (float)(V - 1) * off * logf(off);
+  MA_LAUNCH(label_smoothing_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, target, mask, on,
+            off, ent, grad_scale, (uint16_t*)dlogits, ld_out, stats);
+  return MA_OK;
+}
+
+}  // extern "C"

@@ -204,21 +204,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // ---- Swish + dropout between w_1 and w_2 -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_dropout_fwd_kernel(const uint16_t* __restrict__ u, uint16_t* __restrict__ h,
-                                                              int64_t n, Drop d) {
+                                                              int64_t n, Drop d, int relu) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float v = bf2f(u[i]);
-    float r = v * sigmoidf_(v);
+    float r = relu ? fmaxf(v, 0.0f) : v * sigmoidf_(v);
     if (d.thresh) r = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? r * d.inv_keep : 0.0f;
     h[i] = f2bf(r);
   }
 }
 // du = dh * keep / (1 - p) * swish'(u),  swish'(u) = s + u s (1 - s)
 __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ dh,
-                                                              uint16_t* __restrict__ du, int64_t n, Drop d) {
+                                                              uint16_t* __restrict__ du, int64_t n, Drop d, int relu) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float v = bf2f(u[i]);
     const float s = sigmoidf_(v);
-    float gr = bf2f(dh[i]) * (s + v * s * (1.0f - s));
+    float gr = bf2f(dh[i]) * (relu ? (v > 0.0f ? 1.0f : 0.0f) : (s + v * s * (1.0f - s)));
     if (d.thresh) gr = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? gr * d.inv_keep : 0.0f;
     du[i] = f2bf(gr);
   }
@@ -638,18 +638,19 @@ int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, c
   return MA_OK;
 }
 
-int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
-  if (!u || !h || n < 1 || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, int32_t act, float p, uint32_t seed, uint32_t salt,
+                            ma_stream_t stream) {
+  if (!u || !h || n < 1 || p < 0.0f || p >= 1.0f || (act != 1 && act != 2)) return MA_ERR_INVALID_ARG;
   MA_LAUNCH(act_dropout_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u,
-            (uint16_t*)h, n, make_drop(p, seed, salt));
+            (uint16_t*)h, n, make_drop(p, seed, salt), act == 2 ? 1 : 0);
   return MA_OK;
 }
 
-int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, float p, uint32_t seed, uint32_t salt,
-                            ma_stream_t stream) {
-  if (!u || !dh || !du || n < 1 || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, int32_t act, float p, uint32_t seed,
+                            uint32_t salt, ma_stream_t stream) {
+  if (!u || !dh || !du || n < 1 || p < 0.0f || p >= 1.0f || (act != 1 && act != 2)) return MA_ERR_INVALID_ARG;
   MA_LAUNCH(act_dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u,
-            (const uint16_t*)dh, (uint16_t*)du, n, make_drop(p, seed, salt));
+            (const uint16_t*)dh, (uint16_t*)du, n, make_drop(p, seed, salt), act == 2 ? 1 : 0);
   return MA_OK;
 }
 

@@ -135,6 +135,24 @@ def conformer_ctc_entries(d, hid, L, ks, heads, f2, V):
     return ent
 
 
+_DEC_W = ("sa_qkv_w", "sa_o_w", "ca_q_w", "ca_kv_w", "ca_o_w", "ff_w1", "ff_w2")
+
+
+def decoder_entries(d, hid, Ld, V):
+    """Trainable tensors of the TransformerDecoder, appended after the encoder/CTC entries."""
+    ent = [("dec.embed", (V, d))]
+    for i in range(Ld):
+        pre = "d%d." % i
+        ent += [(pre + "sa_qkv_w", (3 * d, d)), (pre + "sa_qkv_b", (3 * d,)), (pre + "sa_o_w", (d, d)), (pre + "sa_o_b", (d,)),
+                (pre + "ca_q_w", (d, d)), (pre + "ca_q_b", (d,)), (pre + "ca_kv_w", (2 * d, d)), (pre + "ca_kv_b", (2 * d,)),
+                (pre + "ca_o_w", (d, d)), (pre + "ca_o_b", (d,)), (pre + "ff_w1", (hid, d)), (pre + "ff_b1", (hid,)),
+                (pre + "ff_w2", (d, hid)), (pre + "ff_b2", (d,))]
+        for ln in ("norm1", "norm2", "norm3"):
+            ent += [(pre + ln + ".g", (d,)), (pre + ln + ".b", (d,))]
+    ent += [("dec.after_norm.g", (d,)), ("dec.after_norm.b", (d,)), ("dec.out_w", (V, d)), ("dec.out_b", ((V + 63) // 64 * 64,))]
+    return ent
+
+
 def bucket_names(fp, L):
     layer_names = [[n for n in fp.index if n.startswith("l%d." % i)] for i in range(L)]
     return layer_names, ["conv1_w", "conv1_b", "conv2_w", "conv2_b", "out_w", "out_b"]
@@ -173,6 +191,14 @@ class ConformerCTCTrainStep:
         self.seed, self.global_step = int(seed), 0
         self.pg, self.world = process_group, int(world_size)
         self.bn_momentum = bn_momentum
+        self.dec = getattr(model, "decoder", None)
+        self.ctc_weight = float(model.ctc_weight)
+        self.lsm = float(getattr(model, "lsm_weight", 0.0))
+        if self.ctc_weight != 1.0 and self.dec is None:
+            raise ValueError("ctc_weight != 1.0 needs model.decoder")
+        self.Ld = len(self.dec.decoders) if self.dec is not None else 0
+        self.dec_hidden = self.dec.decoders[0].feed_forward.w_1.out_features if self.dec is not None else 0
+        self.last_acc = None
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._build_flat()
         self.reducer = BucketedAllReduce(self.fp.grad, self.world, self.pg)
@@ -181,12 +207,15 @@ class ConformerCTCTrainStep:
     # ---- flat parameter layout ------------------------------------------------------------------------------------
     def _build_flat(self):
         ent = conformer_ctc_entries(self.d, self.hidden, self.L, self.ks, self.heads, self.f2, self.V)
+        if self.dec is not None:
+            ent += decoder_entries(self.d, self.dec_hidden, self.Ld, self.V)
         self.fp = FlatParams(ent, self.dev)
         self._copy_params(to_flat=True)
         # BatchNorm running statistics (buffers, not optimised)
         self.bn_mean = [l.conv_module.norm.running_mean.detach().clone().float() for l in self.enc.encoders]
         self.bn_var = [l.conv_module.norm.running_var.detach().clone().float() for l in self.enc.encoders]
         self.layer_names, self.embed_names = bucket_names(self.fp, self.L)
+        self.dec_names = [n for n in self.fp.index if n.startswith("dec.") or (n[0] == "d" and n[1].isdigit())]
 
     @torch.no_grad()
     def _copy_params(self, to_flat, grads_out=None):
@@ -259,6 +288,46 @@ class ConformerCTCTrainStep:
                 mv(pre + ln + ".b", getattr(l, ln).beta)
         mv("after_norm.g", self.enc.after_norm.gamma)
         mv("after_norm.b", self.enc.after_norm.beta)
+        if self.dec is not None:
+            dec = self.dec
+            mv("dec.embed", dec.embed.weight)
+            for i, l in enumerate(dec.decoders):
+                pre = "d%d." % i
+                sa, ca, ff = l.self_attn, l.src_attn, l.feed_forward
+                for j, lin in enumerate((sa.linear_q, sa.linear_k, sa.linear_v)):
+                    if to_flat:
+                        fp.p(pre + "sa_qkv_w")[j * d:(j + 1) * d].copy_(lin.weight.detach().float())
+                        fp.p(pre + "sa_qkv_b")[j * d:(j + 1) * d].copy_(lin.bias.detach().float())
+                    else:
+                        put(lin.weight, _Flat.p(pre + "sa_qkv_w")[j * d:(j + 1) * d])
+                        put(lin.bias, _Flat.p(pre + "sa_qkv_b")[j * d:(j + 1) * d])
+                for j, lin in enumerate((ca.linear_k, ca.linear_v)):
+                    if to_flat:
+                        fp.p(pre + "ca_kv_w")[j * d:(j + 1) * d].copy_(lin.weight.detach().float())
+                        fp.p(pre + "ca_kv_b")[j * d:(j + 1) * d].copy_(lin.bias.detach().float())
+                    else:
+                        put(lin.weight, _Flat.p(pre + "ca_kv_w")[j * d:(j + 1) * d])
+                        put(lin.bias, _Flat.p(pre + "ca_kv_b")[j * d:(j + 1) * d])
+                mv(pre + "sa_o_w", sa.linear_out.weight)
+                mv(pre + "sa_o_b", sa.linear_out.bias)
+                mv(pre + "ca_q_w", ca.linear_q.weight)
+                mv(pre + "ca_q_b", ca.linear_q.bias)
+                mv(pre + "ca_o_w", ca.linear_out.weight)
+                mv(pre + "ca_o_b", ca.linear_out.bias)
+                mv(pre + "ff_w1", ff.w_1.weight)
+                mv(pre + "ff_b1", ff.w_1.bias)
+                mv(pre + "ff_w2", ff.w_2.weight)
+                mv(pre + "ff_b2", ff.w_2.bias)
+                for ln in ("norm1", "norm2", "norm3"):
+                    mv(pre + ln + ".g", getattr(l, ln).gamma)
+                    mv(pre + ln + ".b", getattr(l, ln).beta)
+            mv("dec.after_norm.g", dec.after_norm.gamma)
+            mv("dec.after_norm.b", dec.after_norm.beta)
+            mv("dec.out_w", dec.output_layer.weight)
+            if to_flat:
+                fp.p("dec.out_b")[:self.V].copy_(dec.output_layer.bias.detach().float())
+            else:
+                put(dec.output_layer.bias, _Flat.p("dec.out_b")[:self.V])
         mv("ctc_w", self.model.ctc.ctc_lo.weight)
         if to_flat:
             fp.p("ctc_b")[:self.V].copy_(self.model.ctc.ctc_lo.bias.detach().float())
@@ -291,6 +360,10 @@ class ConformerCTCTrainStep:
         names = ["conv2_w", "out_w", "ctc_w"]
         for i in range(self.L):
             names += ["l%d.%s" % (i, s) for s in ("ffm_w1", "ffm_w2", "qkv_w", "o_w", "pw1_w", "pw2_w", "ff_w1", "ff_w2")]
+        if self.dec is not None:
+            names.append("dec.out_w")
+            for i in range(self.Ld):
+                names += ["d%d.%s" % (i, w) for w in _DEC_W]
         for n in names:
             if n not in self.wt:
                 rows, cols = fp.w(n).shape
@@ -308,7 +381,8 @@ class ConformerCTCTrainStep:
 
     # ---- forward + backward ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward_backward(self, xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks=None, grad_scale=1.0):
+    def forward_backward(self, xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks=None, grad_scale=1.0, ys_in_pad=None,
+                         ys_out_pad=None, ys_sub_masks=None, ys_masks=None):
         """Runs the training-mode forward and the backward pass; flat gradients hold grad_scale * dLoss/dparam.
         Returns the (unscaled) loss tensor."""
         fp, d, L = self.fp, self.d, self.L
@@ -377,13 +451,24 @@ class ConformerCTCTrainStep:
         enc_bf = ops.layernorm(x, fp.p("after_norm.g"), fp.p("after_norm.b"))
         logits = torch.empty((m, self.Vp), dtype=f32, device=self.dev)
         ops.gemm(enc_bf, fp.w("ctc_w"), bias=fp.p("ctc_b"), out_dtype=f32, out=logits[:, :self.V])
-        loss, per_utt, dlog = K.ctc_loss_grad(logits, self.V, b, t2, ys_pad, hlens, ys_lengths, grad_scale / b)
-        self.last_encoder_out = None
+        wc = self.ctc_weight
+        loss, per_utt, dlog = K.ctc_loss_grad(logits, self.V, b, t2, ys_pad, hlens, ys_lengths, grad_scale * wc / b)
+        d_mem = None
+        if self.dec is not None:  # attention branch: loss = w * ctc + (1 - w) * att (asr_model.py:138-139)
+            if ys_in_pad is None or ys_out_pad is None or ys_sub_masks is None or ys_masks is None:
+                raise ValueError("the hybrid loss needs ys_in_pad, ys_out_pad, ys_sub_masks and ys_masks")
+            loss_att, d_mem = self._decoder_forward_backward(enc_bf, mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks,
+                                                             ys_masks, grad_scale * (1.0 - wc) / b, seed)
+            self.last_loss_ctc, self.last_loss_att = loss, loss_att
+            loss = wc * loss + (1.0 - wc) * loss_att
 
         # ================= backward =================
         # CTC head: logits = enc_bf W^T + b
         K.gemm_tn(dlog, enc_bf, fp.g("ctc_w"), colsum=fp.g("ctc_b"), rows_store=self.V)
-        d_enc = ops.gemm(dlog, self.wt["ctc_w"])                # (m, 256) bf16
+        if d_mem is None:
+            d_enc = ops.gemm(dlog, self.wt["ctc_w"])            # (m, 256) bf16
+        else:                                                   # + the decoder's gradient w.r.t. the encoder output
+            d_enc = ops.gemm(dlog, self.wt["ctc_w"], residual=d_mem, out_dtype=f32, out=d_mem)
         g = torch.empty((m, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
         dpos_all = torch.zeros((t2, L * d), dtype=f32, device=self.dev)
@@ -432,6 +517,105 @@ class ConformerCTCTrainStep:
         self._embed_done()
         return loss
 
+    def _decoder_forward_backward(self, mem_bf, enc_mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks, ys_masks, gscale,
+                                  seed):
+        """TransformerDecoder forward + label-smoothing loss + backward (models/conformer.py:594-639,
+        asr_model.py:154-186).  Fills the decoder gradients; returns (loss_att tensor, d_memory (B*T', 256) float32)."""
+        fp, d, dec = self.fp, self.d, self.dec
+        f32 = torch.float32
+        pd, pp = float(dec.dropout_rate), float(dec.positional_dropout_rate)
+        eps = 1e-12  # models/conformer.py:417-419, 548
+        dk = d // self.heads
+        scale = 1.0 / dk  # q / sqrt(dk) . k / sqrt(dk) (attention.py:150-152)
+        L1 = ys_in_pad.shape[1]
+        md, m = b * L1, b * t2
+        toks = ys_in_pad.to(torch.int32).contiguous().reshape(-1)
+        sub = ys_sub_masks.to(f32).contiguous()
+        emask = enc_mask2d
+        RELU = _lib.ACT_RELU
+        salt = lambda li, site: self._salt(100 + li, site)  # noqa: E731
+        xscale = math.sqrt(d)
+        pe = dec.pe[:L1].to(f32).contiguous()
+        x = K.embed_posenc(toks, fp.p("dec.embed"), pe, L1, xscale, pp, seed, salt(-1, 0))
+        tape = []
+        for li in range(self.Ld):
+            pre = "d%d." % li
+            W, P = (lambda n, pre=pre: fp.w(pre + n)), (lambda n, pre=pre: fp.p(pre + n))
+            T = {"x0": x}
+            a = ops.layernorm(x, P("norm1.g"), P("norm1.b"), eps=eps)
+            qkv = ops.gemm(a, W("sa_qkv_w"), bias=P("sa_qkv_b"))
+            ctx, probs = K.mha_small_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], sub, 2, b, L1, L1, scale, self.heads, dk)
+            o = ops.gemm(ctx, W("sa_o_w"), bias=P("sa_o_b"))
+            x1 = K.dropout_add(x, o, 1.0, pd, seed, salt(li, 0))
+            T.update(a=a, qkv=qkv, ctx=ctx, probs=probs, x1=x1)
+            a2 = ops.layernorm(x1, P("norm2.g"), P("norm2.b"), eps=eps)
+            q = ops.gemm(a2, W("ca_q_w"), bias=P("ca_q_b"))
+            kv = ops.gemm(mem_bf, W("ca_kv_w"), bias=P("ca_kv_b"))
+            ctx2, probs2 = K.mha_small_fwd(q, kv[:, :d], kv[:, d:], emask, 1, b, L1, t2, scale, self.heads, dk)
+            o2 = ops.gemm(ctx2, W("ca_o_w"), bias=P("ca_o_b"))
+            x2 = K.dropout_add(x1, o2, 1.0, pd, seed, salt(li, 1))
+            T.update(a2=a2, q=q, kv=kv, ctx2=ctx2, probs2=probs2, x2=x2)
+            a3 = ops.layernorm(x2, P("norm3.g"), P("norm3.b"), eps=eps)
+            u = ops.gemm(a3, W("ff_w1"), bias=P("ff_b1"))
+            h = K.act_dropout_fwd(u, pd, seed, salt(li, 2), act=RELU)
+            y = ops.gemm(h, W("ff_w2"), bias=P("ff_b2"))
+            x = K.dropout_add(x2, y, 1.0, pd, seed, salt(li, 3))
+            T.update(a3=a3, u=u, h=h)
+            tape.append(T)
+        yb = ops.layernorm(x, fp.p("dec.after_norm.g"), fp.p("dec.after_norm.b"), eps=eps)
+        logits = torch.empty((md, self.Vp), dtype=f32, device=self.dev)
+        ops.gemm(yb, fp.w("dec.out_w"), bias=fp.p("dec.out_b"), out_dtype=f32, out=logits[:, :self.V])
+        tgt = ys_out_pad.to(torch.int32).contiguous().reshape(-1)
+        tmask = ys_masks.to(f32).contiguous().reshape(-1)
+        stats, dlog = K.label_smoothing_loss_grad(logits, self.V, tgt, tmask, self.lsm, gscale)
+        loss_att = stats[0] / b
+        self.last_acc = stats[1] / stats[2]
+        # ---- backward ----
+        K.gemm_tn(dlog, yb, fp.g("dec.out_w"), colsum=fp.g("dec.out_b"), rows_store=self.V)
+        dy = ops.gemm(dlog, self.wt["dec.out_w"])
+        g = torch.empty((md, d), dtype=f32, device=self.dev)
+        K.layernorm_bwd(x, fp.p("dec.after_norm.g"), dy, g, fp.g("dec.after_norm.g"), fp.g("dec.after_norm.b"),
+                        accumulate=False, eps=eps)
+        d_mem = torch.zeros((m, d), dtype=f32, device=self.dev)
+        for li in reversed(range(self.Ld)):
+            pre = "d%d." % li
+            P, G = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n))
+            WT = lambda n, pre=pre: self.wt[pre + n]  # noqa: E731
+            T = tape[li]
+            # feed-forward
+            dyf = K.dropout_bwd(g, 1.0, pd, seed, salt(li, 3))
+            self._dW(dyf, T["h"], pre + "ff_w2", pre + "ff_b2")
+            dh = ops.gemm(dyf, WT("ff_w2"))
+            du = K.act_dropout_bwd(T["u"], dh, pd, seed, salt(li, 2), out=dh, act=RELU)
+            self._dW(du, T["a3"], pre + "ff_w1", pre + "ff_b1")
+            K.layernorm_bwd(T["x2"], P("norm3.g"), ops.gemm(du, WT("ff_w1")), g, G("norm3.g"), G("norm3.b"), eps=eps)
+            # source attention
+            do = K.dropout_bwd(g, 1.0, pd, seed, salt(li, 1))
+            self._dW(do, T["ctx2"], pre + "ca_o_w", pre + "ca_o_b")
+            dctx = ops.gemm(do, WT("ca_o_w"))
+            dq = torch.empty_like(T["q"])
+            dkv = torch.empty_like(T["kv"])
+            K.mha_small_bwd(T["q"], T["kv"][:, :d], T["kv"][:, d:], T["probs2"], T["ctx2"], dctx, b, L1, t2, scale, dq,
+                            dkv[:, :d], dkv[:, d:], self.heads, dk)
+            self._dW(dq, T["a2"], pre + "ca_q_w", pre + "ca_q_b")
+            K.layernorm_bwd(T["x1"], P("norm2.g"), ops.gemm(dq, WT("ca_q_w")), g, G("norm2.g"), G("norm2.b"), eps=eps)
+            self._dW(dkv, mem_bf, pre + "ca_kv_w", pre + "ca_kv_b")
+            ops.gemm(dkv, WT("ca_kv_w"), residual=d_mem, out_dtype=f32, out=d_mem)
+            # self attention
+            do = K.dropout_bwd(g, 1.0, pd, seed, salt(li, 0))
+            self._dW(do, T["ctx"], pre + "sa_o_w", pre + "sa_o_b")
+            dctx = ops.gemm(do, WT("sa_o_w"))
+            dqkv = torch.empty_like(T["qkv"])
+            qkv = T["qkv"]
+            K.mha_small_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], T["probs"], T["ctx"], dctx, b, L1, L1, scale,
+                            dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], self.heads, dk)
+            self._dW(dqkv, T["a"], pre + "sa_qkv_w", pre + "sa_qkv_b")
+            K.layernorm_bwd(T["x0"], P("norm1.g"), ops.gemm(dqkv, WT("sa_qkv_w")), g, G("norm1.g"), G("norm1.b"), eps=eps)
+        K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0))
+        if self.dec_names:
+            self.reducer.launch(*fp.span(self.dec_names))
+        return loss_att, d_mem
+
     def _ffn_fwd(self, x, key, ln, W, P, seed, li, s0):
         a = ops.layernorm(x, P(ln + ".g"), P(ln + ".b"))
         u = ops.gemm(a, W(key + "_w1"), bias=P(key + "_b1"))
@@ -468,7 +652,9 @@ class ConformerCTCTrainStep:
         the fields TrainOneStepWithLossScaleCell.construct returns (train_one_step.py:48) minus the duplicate."""
         scale = self.scaler.scale
         self.flag.zero_()
-        loss = self.forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale=scale)
+        loss = self.forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale=scale,
+                                     ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_sub_masks=ys_sub_masks,
+                                     ys_masks=ys_masks)
         self.reducer.wait()
         K.grad_overflow(self.fp.grad, self.flag)
         lr = asr_warmup_lr(self.global_step, self.base_lr, self.warmup)

@@ -98,17 +98,63 @@ def layernorm_bwd(x, gamma, dy, g, dgamma, dbeta, row_scale=None, accumulate=Tru
     return g
 
 
-def act_dropout_fwd(u, p, seed, salt):
+def act_dropout_fwd(u, p, seed, salt, act=_lib.ACT_SWISH):
     h = _t().empty_like(u)
-    _lib.check(_lib.load().ma_act_dropout_fwd_bf16(_p(u), _p(h), u.numel(), float(p), seed, salt, _s()), "act_dropout")
+    _lib.check(_lib.load().ma_act_dropout_fwd_bf16(_p(u), _p(h), u.numel(), act, float(p), seed, salt, _s()),
+               "act_dropout")
     return h
 
 
-def act_dropout_bwd(u, dh, p, seed, salt, out=None):
+def act_dropout_bwd(u, dh, p, seed, salt, out=None, act=_lib.ACT_SWISH):
     du = out if out is not None else _t().empty_like(u)
-    _lib.check(_lib.load().ma_act_dropout_bwd_bf16(_p(u), _p(dh), _p(du), u.numel(), float(p), seed, salt, _s()),
+    _lib.check(_lib.load().ma_act_dropout_bwd_bf16(_p(u), _p(dh), _p(du), u.numel(), act, float(p), seed, salt, _s()),
                "act_dropout_bwd")
     return du
+
+
+def embed_posenc(tokens, table, pe, L, xscale, p, seed, salt):
+    t = _t()
+    rows, (v, d) = tokens.numel(), table.shape
+    out = t.empty((rows, d), dtype=t.float32, device=table.device)
+    _lib.check(_lib.load().ma_embed_posenc_f32(_p(tokens), _p(table), _p(pe), rows, L, d, v, float(xscale), float(p), seed,
+                                               salt, _p(out), _s()), "embed_posenc")
+    return out
+
+
+def embed_bwd(tokens, g, dtable, xscale, p, seed, salt):
+    v, d = dtable.shape
+    _lib.check(_lib.load().ma_embed_bwd_f32(_p(tokens), _p(g), tokens.numel(), d, v, float(xscale), float(p), seed, salt,
+                                            _p(dtable), _s()), "embed_bwd")
+
+
+def mha_small_fwd(q, k, v, mask, mask_mode, batch, lq, lk, scale, heads=4, d_k=64):
+    """q (B*Lq, >=H*64) / k, v (B*Lk, ...) bf16 views -> (ctx (B*Lq, H*64) bf16, probs (B, H, Lq, Lk) f32)."""
+    t = _t()
+    ctx = t.empty((batch * lq, heads * d_k), dtype=t.bfloat16, device=q.device)
+    probs = t.empty((batch, heads, lq, lk), dtype=t.float32, device=q.device)
+    _lib.check(_lib.load().ma_mha_small_fwd_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(mask),
+                                                 mask_mode, batch, lq, lk, heads, d_k, float(scale), _p(ctx),
+                                                 ctx.stride(0), _p(probs), _s()), "mha_small_fwd")
+    return ctx, probs
+
+
+def mha_small_bwd(q, k, v, probs, ctx, dctx, batch, lq, lk, scale, dq, dk, dv, heads=4, d_k=64):
+    _lib.check(_lib.load().ma_mha_small_bwd_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(probs),
+                                                 _p(ctx), ctx.stride(0), _p(dctx), dctx.stride(0), batch, lq, lk, heads,
+                                                 d_k, float(scale), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv),
+                                                 dv.stride(0), _s()), "mha_small_bwd")
+
+
+def label_smoothing_loss_grad(logits, V, target, mask, smoothing, grad_scale):
+    """-> (stats (3,) f32 = [sum kl, correct, tokens], dlogits (rows, ld) bf16)."""
+    t = _t()
+    rows = logits.shape[0]
+    stats = t.zeros(3, dtype=t.float32, device=logits.device)
+    dlog = t.empty((rows, logits.stride(0)), dtype=t.bfloat16, device=logits.device)
+    _lib.check(_lib.load().ma_label_smoothing_loss_grad_f32(_p(logits), logits.stride(0), rows, V, _p(target), _p(mask),
+                                                            float(smoothing), float(grad_scale), _p(dlog), dlog.stride(0),
+                                                            _p(stats), _s()), "label_smoothing")
+    return stats, dlog
 
 
 def dropout_add(x, y, alpha, p, seed, salt, out=None):

@@ -243,3 +243,116 @@ def forward_flops_per_utt(t_in=1000, idim=80, d=256, heads=4, ff=2048, layers=12
     per_layer += 2 * 3 * heads * t2 * t2 * (d // heads)  # ac, bd, attn @ v
     per_layer += 2 * t2 * (d * 2 * d + d * kernel + d * d)  # conv module
     return sub + layers * per_layer
+
+
+# ---- attention decoder + label smoothing: the hybrid loss of examples/conformer/asr_model.py:75-209 -----------------
+class MultiHeadedAttention(nn.Module):
+    """layers/attention.py:17-157.  Quirk: q and k are BOTH multiplied by 1/sqrt(d_k) before the product, i.e. the
+    scores are divided by d_k (attention.py:150-152); additive -10000 mask of shape (B, 1, T2) or (B, T1, T2)."""
+
+    def __init__(self, n_head, n_feat):
+        super().__init__()
+        self.h, self.d_k = n_head, n_feat // n_head
+        self.linear_q = nn.Linear(n_feat, n_feat)
+        self.linear_k = nn.Linear(n_feat, n_feat)
+        self.linear_v = nn.Linear(n_feat, n_feat)
+        self.linear_out = nn.Linear(n_feat, n_feat)
+
+    def forward(self, query, key, value, mask):
+        b = query.shape[0]
+        q = self.linear_q(query).view(b, -1, self.h, self.d_k).transpose(1, 2)
+        k = self.linear_k(key).view(b, -1, self.h, self.d_k).transpose(1, 2)
+        v = self.linear_v(value).view(b, -1, self.h, self.d_k).transpose(1, 2)
+        s = 1.0 / math.sqrt(self.d_k)
+        scores = (q * s) @ (k * s).transpose(-1, -2)
+        if mask is not None:
+            scores = scores + (mask.unsqueeze(1) == 0).to(scores.dtype) * (-10000.0)
+        ctx = (torch.softmax(scores, dim=-1) @ v).transpose(1, 2).reshape(b, -1, self.h * self.d_k)
+        return self.linear_out(ctx)
+
+
+class DecoderFeedForward(nn.Module):
+    """PositionwiseFeedForward with the decoder's ReLU (models/conformer.py:521)."""
+
+    def __init__(self, idim, hidden, dropout):
+        super().__init__()
+        self.w_1 = nn.Linear(idim, hidden)
+        self.w_2 = nn.Linear(hidden, idim)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.w_2(self.dropout(torch.relu(self.w_1(x))))
+
+
+class DecoderLayer(nn.Module):
+    """models/conformer.py:382-497 (normalize_before=True, concat_after=False); LayerNorm eps 1e-12 (:417-419)."""
+
+    def __init__(self, size, heads, linear_units, dropout):
+        super().__init__()
+        self.self_attn = MultiHeadedAttention(heads, size)
+        self.src_attn = MultiHeadedAttention(heads, size)
+        self.feed_forward = DecoderFeedForward(size, linear_units, dropout)
+        self.norm1, self.norm2, self.norm3 = LayerNorm(size, 1e-12), LayerNorm(size, 1e-12), LayerNorm(size, 1e-12)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, tgt, tgt_mask, memory, memory_mask):
+        t = self.norm1(tgt)
+        x = tgt + self.dropout(self.self_attn(t, t, t, tgt_mask))
+        x = x + self.dropout(self.src_attn(self.norm2(x), memory, memory, memory_mask))
+        return x + self.dropout(self.feed_forward(self.norm3(x)))
+
+
+class TransformerDecoder(nn.Module):
+    """models/conformer.py:500-639: Embedding -> x*sqrt(d) + pe -> dropout, N DecoderLayers, after_norm, output layer."""
+
+    def __init__(self, vocab_size, encoder_output_size, attention_heads=4, linear_units=2048, num_blocks=6,
+                 dropout_rate=0.1, positional_dropout_rate=0.1, max_len=5000):
+        super().__init__()
+        d = encoder_output_size
+        self.embed = nn.Embedding(vocab_size, d)
+        self.xscale = math.sqrt(d)
+        self.register_buffer("pe", sinusoid_table(max_len, d), persistent=False)
+        self.pos_dropout = nn.Dropout(positional_dropout_rate)
+        self.decoders = nn.ModuleList([DecoderLayer(d, attention_heads, linear_units, dropout_rate)
+                                       for _ in range(num_blocks)])
+        self.after_norm = LayerNorm(d, 1e-12)
+        self.output_layer = nn.Linear(d, vocab_size)
+
+    def forward(self, memory, memory_mask, ys_in_pad, ys_masks):
+        x = self.pos_dropout(self.embed(ys_in_pad) * self.xscale + self.pe[:ys_in_pad.shape[1]].unsqueeze(0))
+        for layer in self.decoders:
+            x = layer(x, ys_masks, memory, memory_mask)
+        return self.output_layer(self.after_norm(x))
+
+
+def label_smoothing_loss(x, target, target_masks, smoothing, normalize_length=False):
+    """loss/label_smoothing_loss.py:84-117: x (B, L, V) logits, target (B, L) with -1 padding, target_masks (B, 1, L)."""
+    b, _, v = x.shape
+    x = x.reshape(-1, v)
+    tm = target_masks.reshape(-1).to(x.dtype)
+    tgt = (target.reshape(-1).to(x.dtype) * tm).long()
+    true = torch.full_like(x, smoothing / (v - 1))
+    true.scatter_(1, tgt.unsqueeze(1), 1.0 - smoothing)
+    kl = true * (torch.log(true) - torch.log_softmax(x, dim=1))
+    kl = kl * tm.unsqueeze(1)
+    return kl.sum() / (tm.sum() if normalize_length else b)
+
+
+def th_accuracy(pad_outputs, pad_targets, ys_masks):
+    """asr_model.py:188-209."""
+    pred = pad_outputs.argmax(2)
+    m = ys_masks.squeeze(1).to(torch.float32)
+    return ((pred == pad_targets).to(torch.float32) * m).sum() / m.sum()
+
+
+def hybrid_loss(encoder, ctc, decoder, batch, ctc_weight=0.3, lsm_weight=0.1):
+    """ASRModelWithAcc.construct (asr_model.py:75-153) with reverse_weight 0: returns (loss, acc_att, loss_ctc, loss_att).
+    `batch` = the 11 collate columns."""
+    xs_pad, ys_pad, ys_in_pad, ys_out_pad, _, _, xs_masks, ys_sub_masks, ys_masks, ys_lengths, xs_chunk_masks = batch
+    enc, enc_mask = encoder(xs_pad, xs_masks, xs_chunk_masks)
+    hlens = enc_mask.reshape(enc_mask.shape[0], -1).sum(1).to(torch.int32)
+    loss_ctc = ctc(enc, hlens, ys_pad.clamp(min=0).long(), ys_lengths.long())
+    dec_out = decoder(enc, enc_mask, ys_in_pad.long(), ys_sub_masks)
+    loss_att = label_smoothing_loss(dec_out, ys_out_pad, ys_masks, lsm_weight)
+    acc = th_accuracy(dec_out, ys_out_pad, ys_masks)
+    return ctc_weight * loss_ctc + (1 - ctc_weight) * loss_att, acc, loss_ctc, loss_att

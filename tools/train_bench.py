@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=4233)
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--ctc-weight", type=float, default=1.0, help="< 1: hybrid loss with a 6-block TransformerDecoder")
     args = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local)
@@ -36,8 +37,12 @@ def main():
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
     torch.manual_seed(777)  # same initial weights on every rank (train.py:56)
+    hybrid = args.ctc_weight != 1.0
     model = create_asr_model(80, args.vocab, dict(output_size=256, attention_heads=4, linear_units=2048,
-                                                  num_blocks=args.blocks)).to(dev)
+                                                  num_blocks=args.blocks), ctc_weight=args.ctc_weight,
+                             decoder_conf=dict(attention_heads=4, linear_units=2048, num_blocks=6,
+                                               dropout_rate=args.dropout, positional_dropout_rate=args.dropout)
+                             if hybrid else None, lsm_weight=0.1 if hybrid else 0.0).to(dev)
     eng = ConformerCTCTrainStep(model, dropout_rate=args.dropout, positional_dropout_rate=args.dropout,
                                 world_size=world)
     rng = np.random.RandomState(1234 + rank)
@@ -55,8 +60,19 @@ def main():
     ys = np.full((b, 30), -1, np.int32)
     for i, n in enumerate(ylens):
         ys[i, :n] = rng.randint(1, args.vocab - 1, n)
-    cols = (xs, torch.from_numpy(ys).to(dev), None, None, None, None, masks, None, None,
-            torch.from_numpy(ylens).to(dev), None)
+    sos = eos = args.vocab - 1
+    ys_in = np.full((b, 31), eos, np.int32)
+    ys_out = np.full((b, 31), -1, np.int32)
+    ys_m = np.zeros((b, 1, 31), np.float32)
+    for i, n in enumerate(ylens):
+        ys_in[i, 0] = sos
+        ys_in[i, 1:n + 1] = ys[i, :n]
+        ys_out[i, :n] = ys[i, :n]
+        ys_out[i, n] = eos
+        ys_m[i, 0, :n + 1] = 1
+    ys_sub = (ys_m.astype(bool) & np.tril(np.ones((31, 31), bool))[None]).astype(np.float32)
+    cols = (xs, torch.from_numpy(ys).to(dev), torch.from_numpy(ys_in).to(dev), torch.from_numpy(ys_out).to(dev), None, None,
+            masks, torch.from_numpy(ys_sub).to(dev), torch.from_numpy(ys_m).to(dev), torch.from_numpy(ylens).to(dev), None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -84,8 +100,8 @@ def main():
             "value": round(world * b * args.steps / dt, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "dtype": "bf16 matmuls, f32 master/grads/optimizer", "data": "synthetic",
-            "config": {"workload": "bucket-1024 batch (%d, %d, 80) per rank, V=%d, %d blocks, dropout %.2f, pure CTC, "
-                                   "Adam + ASRWarmupLR + dynamic loss scale" % (b, t, args.vocab, args.blocks, args.dropout),
+            "config": {"workload": "bucket-1024 batch (%d, %d, 80) per rank, V=%d, %d blocks, dropout %.2f, %s, "
+                                   "Adam + ASRWarmupLR + dynamic loss scale" % (b, t, args.vocab, args.blocks, args.dropout, "hybrid CTC %.1f / attention (6-block decoder, label smoothing 0.1)" % args.ctc_weight if hybrid else "pure CTC"),
                        "global_batch": b * world, "flat_params": nparam,
                        "grad_bytes_allreduced_per_step": nparam * 4 if world > 1 else 0},
             "first_losses": [round(v, 3) for v in losses[:3]], "last_loss": round(float(out[0]), 3),

@@ -41,8 +41,10 @@ __device__ __forceinline__ uint16_t ab_to_bf16(float f) {
   return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float ab_from_bf16(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
-__device__ __forceinline__ uint32_t ab_pack(float lo, float hi) {
-  return (uint32_t)ab_to_bf16(lo) | ((uint32_t)ab_to_bf16(hi) << 16);
+__device__ __forceinline__ uint32_t ab_pack(float lo, float hi) {  // v_cvt_pk_bf16_f32: RNE, one instruction
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
 
 // workspace layout per (b, h), bf16 elements: Q'[Tp][128] | K'[Tp][128] | Q'^T[128][Tp] | K'^T[128][Tp] | dO^T[64][Tp];

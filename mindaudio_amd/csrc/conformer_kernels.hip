@@ -29,6 +29,12 @@ __device__ __forceinline__ uint16_t to_bf16(float f) {
   return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float from_bf16(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+// two f32 -> packed bf16x2, round to nearest even, one instruction (v_cvt_pk_bf16_f32, gfx950)
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
   const int q_base = qt * kAttQ + wave * 16;
   const int lq = lane & 15, lg = lane >> 4;
   const uint16_t* vt_bh = vt + ((int64_t)b * H + h) * kDk * Tp;
+  const float scale2 = scale * 1.4426950408889634f;
 
   // ---- Q' fragments (B operand): lane holds query row lq, k = kstep*32 + lg*8 .. +7 of [q+u | q+v] -------------
   bf16x8 qf[4];
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
       for (int e = 0; e < 4; ++e) {
         const float lo = from_bf16((uint16_t)(wds[e] & 0xffff)) + bias[2 * e];
         const float hi = from_bf16((uint16_t)(wds[e] >> 16)) + bias[2 * e + 1];
-        o[e] = (uint32_t)to_bf16(lo) | ((uint32_t)to_bf16(hi) << 16);
+        o[e] = pack2_bf16(lo, hi);
       }
       const uint4 pk = make_uint4(o[0], o[1], o[2], o[3]);
       qf[ks] = __builtin_bit_cast(bf16x8, pk);
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
     if (tid < kAttK) {
       const int kj = k0 + tid;
       // keys past T do not exist (-inf); padded keys inside T get the reference's additive -10000
-      maskadd[tid] = kj >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + kj] == 0.0f) ? -10000.0f : 0.0f);
+      maskadd[tid] = kj >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + kj] == 0.0f) ? -10000.0f * 1.4426950408889634f : 0.0f);
     }
     __syncthreads();
     if (kt + 1 < n_kt) MA_ATT_FETCH(kt + 1)
@@ -288,26 +295,27 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
         s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[c], 0, 0, 0);
       }
       const float4 ma_ = *reinterpret_cast<const float4*>(&maskadd[c * 16 + lg * 4]);
-      s[c][0] = s[c][0] * scale + ma_.x;
-      s[c][1] = s[c][1] * scale + ma_.y;
-      s[c][2] = s[c][2] * scale + ma_.z;
-      s[c][3] = s[c][3] * scale + ma_.w;
+      // scores in log2 units: scale2 = scale * log2(e), maskadd pre-multiplied by log2(e) -> exp2 below
+      s[c][0] = s[c][0] * scale2 + ma_.x;
+      s[c][1] = s[c][1] * scale2 + ma_.y;
+      s[c][2] = s[c][2] * scale2 + ma_.z;
+      s[c][3] = s[c][3] * scale2 + ma_.w;
       tmax = fmaxf(fmaxf(tmax, fmaxf(s[c][0], s[c][1])), fmaxf(s[c][2], s[c][3]));
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float mnew = fmaxf(mrow, tmax);  // finite: key 0 of the first tile always exists
-    const float alpha = (mrow == -INFINITY) ? 0.0f : __expf(mrow - mnew);
+    const float alpha = (mrow == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mrow - mnew);
     mrow = mnew;
     float psum = 0.f;
     uint32_t pb[4][2];  // bf16 pairs: tile c, keys lg*4 + {0,1}, {2,3}
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float e0 = __expf(s[c][0] - mnew), e1 = __expf(s[c][1] - mnew);
-      const float e2 = __expf(s[c][2] - mnew), e3 = __expf(s[c][3] - mnew);
+      const float e0 = __builtin_amdgcn_exp2f(s[c][0] - mnew), e1 = __builtin_amdgcn_exp2f(s[c][1] - mnew);
+      const float e2 = __builtin_amdgcn_exp2f(s[c][2] - mnew), e3 = __builtin_amdgcn_exp2f(s[c][3] - mnew);
       psum += (e0 + e1) + (e2 + e3);
-      pb[c][0] = (uint32_t)to_bf16(e0) | ((uint32_t)to_bf16(e1) << 16);
-      pb[c][1] = (uint32_t)to_bf16(e2) | ((uint32_t)to_bf16(e3) << 16);
+      pb[c][0] = pack2_bf16(e0, e1);
+      pb[c][1] = pack2_bf16(e2, e3);
     }
     psum += __shfl_xor(psum, 16, 64);
     psum += __shfl_xor(psum, 32, 64);
@@ -334,15 +342,15 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
   // ---- ctx[q, h*64 + d] = O^T[d, q] / l ---------------------------------------------------------------------------
   const int qi = q_base + lq;
   // log-sum-exp of the scaled, masked scores of row qi: what the backward pass needs to rebuild the probabilities
-  if (lse && qi < T && lg == 0) lse[((int64_t)b * H + h) * T + qi] = mrow + __logf(lrow);
+  if (lse && qi < T && lg == 0) lse[((int64_t)b * H + h) * T + qi] = (mrow + __log2f(lrow)) * 0.6931471805599453f;
   if (qi < T) {
     const float inv = 1.0f / lrow;
     uint16_t* o = ctx + (row0 + qi) * ld_ctx + h * kDk + lg * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       uint2 pk;
-      pk.x = (uint32_t)to_bf16(oacc[dt][0] * inv) | ((uint32_t)to_bf16(oacc[dt][1] * inv) << 16);
-      pk.y = (uint32_t)to_bf16(oacc[dt][2] * inv) | ((uint32_t)to_bf16(oacc[dt][3] * inv) << 16);
+      pk.x = pack2_bf16(oacc[dt][0] * inv, oacc[dt][1] * inv);
+      pk.y = pack2_bf16(oacc[dt][2] * inv, oacc[dt][3] * inv);
       *reinterpret_cast<uint2*>(o + dt * 16) = pk;
     }
   }

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     o.w = (v[i].w * inv * g.w + b.w) * rs;
     if (out_bf16) {
       uint2 pk;
-      pk.x = (uint32_t)to_bf16(o.x) | ((uint32_t)to_bf16(o.y) << 16);
-      pk.y = (uint32_t)to_bf16(o.z) | ((uint32_t)to_bf16(o.w) << 16);
+      pk.x = pack2_bf16(o.x, o.y);
+      pk.y = pack2_bf16(o.z, o.w);
       *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + row * ldo + c) = pk;
     } else {
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row * ldo + c) = o;
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
   v.x = v.x * inv * g.x + b.x; v.y = v.y * inv * g.y + b.y; v.z = v.z * inv * g.z + b.z; v.w = v.w * inv * g.w + b.w;
   if (out2_bf16) {
     uint2 pk;
-    pk.x = (uint32_t)to_bf16(v.x) | ((uint32_t)to_bf16(v.y) << 16);
-    pk.y = (uint32_t)to_bf16(v.z) | ((uint32_t)to_bf16(v.w) << 16);
+    pk.x = pack2_bf16(v.x, v.y);
+    pk.y = pack2_bf16(v.z, v.w);
     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out2) + row * ldo2 + c) = pk;
   } else {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out2) + row * ldo2 + c) = v;
@@ -150,19 +150,30 @@ __global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __res
     rows[i] = v;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float wk[9];
+  // thread = (channel pair, f1 parity): 4-byte stores, a wave writes 256 contiguous bytes of one (t1, f1) cell
+  const int npairs = C / 2;
+  for (int item = threadIdx.x; item < 2 * npairs; item += blockDim.x) {
+    const int cp = item % npairs, par = item / npairs;
+    const int c = 2 * cp;
+    float wa[9], wb[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
-    const float bc = bias[c];
+    for (int i = 0; i < 9; ++i) {
+      wa[i] = w[c * 9 + i];
+      wb[i] = w[(c + 1) * 9 + i];
+    }
+    const float ba = bias[c], bb = bias[c + 1];
     uint16_t* o = out + (bt * F1) * C + c;
-    for (int f1 = 0; f1 < F1; ++f1) {
-      float acc = bc;
+    for (int f1 = par; f1 < F1; f1 += 2) {
+      float a0 = ba, a1 = bb;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kh * 3 + kw], rows[kh * idim + 2 * f1 + kw], acc);
-      o[(int64_t)f1 * C] = to_bf16(fmaxf(acc, 0.0f));
+        for (int kw = 0; kw < 3; ++kw) {
+          const float xv = rows[kh * idim + 2 * f1 + kw];
+          a0 = fmaf(wa[kh * 3 + kw], xv, a0);
+          a1 = fmaf(wb[kh * 3 + kw], xv, a1);
+        }
+      *reinterpret_cast<uint32_t*>(o + (int64_t)f1 * C) = pack2_bf16(fmaxf(a0, 0.0f), fmaxf(a1, 0.0f));
     }
   }
 }
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(256) void convmodule_mid_kernel(const uint16_t* __r
       float z1 = acc[2 * e + 1] * sc[2 * e + 1] + sh[2 * e + 1];
       z0 = z0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z0));
       z1 = z1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z1));
-      pk[e] = (uint32_t)to_bf16(z0) | ((uint32_t)to_bf16(z1) << 16);
+      pk[e] = pack2_bf16(z0, z1);
     }
     *reinterpret_cast<uint4*>(out + (row0 + t) * ldo + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
@@ -500,6 +511,7 @@ int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t id
                             ma_stream_t stream) {
   if (!x || !w || !bias || !out || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
   if ((cmvn_mean == nullptr) != (cmvn_istd == nullptr)) return MA_ERR_INVALID_ARG;
+  if (C & 1) return MA_ERR_UNSUPPORTED;  // channel pairs per thread
   const int T1 = (int)((T - 3) / 2 + 1), F1 = (idim - 3) / 2 + 1;
   MA_LAUNCH(subsample_conv1_kernel, dim3((unsigned)(batch * T1)), dim3(256), 3 * idim * sizeof(float),
             (hipStream_t)stream, x, T, idim, cmvn_mean, cmvn_istd, w, bias, C, T1, F1,

@@ -470,6 +470,22 @@ int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t ro
                                      const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
                                      float* stats, ma_stream_t stream);
 
+/* Fused feed-forward, 128-row formulation: grid (ceil(M/128), 2) — the workgroup of hidden half 0 updates x in place
+ * (x += alpha * (O_0 + b2)), half 1 writes partial (M, 256) float32 = alpha * O_1; the LayerNorm that follows the module
+ * adds it back:
+ *   ma_layernorm_add_f32   x <- x + addend (written back: the new residual stream), out = LayerNorm(x)
+ *   ma_layernorm2_add_f32  out1 = LN1(x + addend) (float32, may overwrite x), out2 = LN2(out1)
+ * hidden % 128 == 0.  Other arguments as ma_ffn_bf16 / ma_layernorm_f32 / ma_layernorm2_f32. */
+int ma_ffn128_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
+                   int64_t ldx, float* partial, int64_t ldp, int64_t M, int32_t d_model, int32_t hidden, float alpha,
+                   ma_stream_t stream);
+int ma_layernorm_add_f32(float* x, int64_t ldx, const float* addend, int64_t ld_add, int64_t rows, int64_t cols,
+                         const float* gamma, const float* beta, float eps, const float* row_scale, void* out, int64_t ldo,
+                         int32_t out_bf16, ma_stream_t stream);
+int ma_layernorm2_add_f32(const float* x, int64_t ldx, const float* addend, int64_t ld_add, int64_t rows, int64_t cols,
+                          const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
+                          float* out1, int64_t ldo1, void* out2, int64_t ldo2, int32_t out2_bf16, ma_stream_t stream);
+
 /* TrainOneStepWithLossScaleCell pieces (train_one_step.py:37-47): *flag |= 1 if any gradient is inf/nan; Adam
  * (MindSpore nn.Adam: p -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t) from the host) on
  * grad * inv_scale, skipped on the device when *overflow != 0. */

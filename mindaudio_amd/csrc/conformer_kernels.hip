@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         const float* __restrict__ row_scale, void* out,
-                                                        int64_t ldo, int out_bf16) {
+                                                        int64_t ldo, int out_bf16, const float* __restrict__ addend,
+                                                        int64_t ld_add, float* sum_out, int64_t ld_sum) {
   constexpr int D = 256 * VEC;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -59,6 +60,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+    if (addend) {  // x + partial product of the split feed-forward kernel; the sum is the new residual stream
+      const float4 a = *reinterpret_cast<const float4*>(addend + row * ld_add + (i * 64 + lane) * 4);
+      v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+      if (sum_out) *reinterpret_cast<float4*>(sum_out + row * ld_sum + (i * 64 + lane) * 4) = v[i];
+    }
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mean = wave_sum(s) * (1.0f / D);
@@ -99,13 +105,18 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
                                                          const float* __restrict__ g1, const float* __restrict__ b1,
                                                          const float* __restrict__ g2, const float* __restrict__ b2,
                                                          float eps, float* __restrict__ out1, int64_t ldo1, void* out2,
-                                                         int64_t ldo2, int out2_bf16) {
+                                                         int64_t ldo2, int out2_bf16, const float* __restrict__ addend,
+                                                         int64_t ld_add) {
   constexpr int D = 256;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int c = lane * 4;
   float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c);
+  if (addend) {
+    const float4 a = *reinterpret_cast<const float4*>(addend + row * ld_add + c);
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+  }
   float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / D);
   v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
   float var = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / D);
@@ -479,31 +490,65 @@ using namespace ma;
 
 extern "C" {
 
+static int layernorm_launch(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma, const float* beta,
+                            float eps, const float* row_scale, void* out, int64_t ldo, int32_t out_bf16,
+                            const float* addend, int64_t ld_add, float* sum_out, int64_t ld_sum, ma_stream_t stream) {
+  if (!x || !gamma || !beta || !out || rows < 1 || cols < 1 || ldx < cols || ldo < cols) return MA_ERR_INVALID_ARG;
+  if ((ldx & 3) || (ldo & 3) || (addend && ((ld_add & 3) || ld_add < cols)) || (sum_out && ((ld_sum & 3) || ld_sum < cols)))
+    return MA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define MA_LN(V_) MA_LAUNCH(layernorm_kernel<V_>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, \
+                            out_bf16, addend, ld_add, sum_out, ld_sum)
+  switch (cols) {
+    case 256: MA_LN(1); break;
+    case 512: MA_LN(2); break;
+    case 768: MA_LN(3); break;
+    case 1024: MA_LN(4); break;
+    default: return MA_ERR_UNSUPPORTED;
+  }
+#undef MA_LN
+  return MA_OK;
+}
+
 int ma_layernorm_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma, const float* beta,
                      float eps, const float* row_scale, void* out, int64_t ldo, int32_t out_bf16,
                      ma_stream_t stream) {
-  if (!x || !gamma || !beta || !out || rows < 1 || cols < 1 || ldx < cols || ldo < cols) return MA_ERR_INVALID_ARG;
-  if ((ldx & 3) || (ldo & 3)) return MA_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  switch (cols) {
-    case 256: MA_LAUNCH(layernorm_kernel<1>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
-    case 512: MA_LAUNCH(layernorm_kernel<2>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
-    case 768: MA_LAUNCH(layernorm_kernel<3>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
-    case 1024: MA_LAUNCH(layernorm_kernel<4>, grid, block, 0, s, x, ldx, rows, gamma, beta, eps, row_scale, out, ldo, out_bf16); break;
-    default: return MA_ERR_UNSUPPORTED;
-  }
+  return layernorm_launch(x, ldx, rows, cols, gamma, beta, eps, row_scale, out, ldo, out_bf16, nullptr, 0, nullptr, 0, stream);
+}
+
+int ma_layernorm_add_f32(float* x, int64_t ldx, const float* addend, int64_t ld_add, int64_t rows, int64_t cols,
+                         const float* gamma, const float* beta, float eps, const float* row_scale, void* out, int64_t ldo,
+                         int32_t out_bf16, ma_stream_t stream) {
+  if (!addend) return MA_ERR_INVALID_ARG;
+  return layernorm_launch(x, ldx, rows, cols, gamma, beta, eps, row_scale, out, ldo, out_bf16, addend, ld_add, x, ldx, stream);
+}
+
+static int layernorm2_launch(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma1, const float* beta1,
+                             const float* gamma2, const float* beta2, float eps, float* out1, int64_t ldo1, void* out2,
+                             int64_t ldo2, int32_t out2_bf16, const float* addend, int64_t ld_add, ma_stream_t stream) {
+  if (!x || !gamma1 || !beta1 || !gamma2 || !beta2 || !out1 || !out2 || rows < 1) return MA_ERR_INVALID_ARG;
+  if (cols != 256 || (ldx & 3) || (ldo1 & 3) || (ldo2 & 3) || ldx < cols || ldo1 < cols || ldo2 < cols ||
+      (addend && ((ld_add & 3) || ld_add < cols)))
+    return MA_ERR_UNSUPPORTED;
+  MA_LAUNCH(layernorm2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma1,
+            beta1, gamma2, beta2, eps, out1, ldo1, out2, ldo2, out2_bf16, addend, ld_add);
   return MA_OK;
 }
 
 int ma_layernorm2_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma1, const float* beta1,
                       const float* gamma2, const float* beta2, float eps, float* out1, int64_t ldo1, void* out2,
                       int64_t ldo2, int32_t out2_bf16, ma_stream_t stream) {
-  if (!x || !gamma1 || !beta1 || !gamma2 || !beta2 || !out1 || !out2 || rows < 1) return MA_ERR_INVALID_ARG;
-  if (cols != 256 || (ldx & 3) || (ldo1 & 3) || (ldo2 & 3)) return MA_ERR_UNSUPPORTED;
-  MA_LAUNCH(layernorm2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
-            gamma1, beta1, gamma2, beta2, eps, out1, ldo1, out2, ldo2, out2_bf16);
-  return MA_OK;
+  return layernorm2_launch(x, ldx, rows, cols, gamma1, beta1, gamma2, beta2, eps, out1, ldo1, out2, ldo2, out2_bf16, nullptr,
+                           0, stream);
+}
+
+int ma_layernorm2_add_f32(const float* x, int64_t ldx, const float* addend, int64_t ld_add, int64_t rows, int64_t cols,
+                          const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
+                          float* out1, int64_t ldo1, void* out2, int64_t ldo2, int32_t out2_bf16, ma_stream_t stream) {
+  if (!addend) return MA_ERR_INVALID_ARG;
+  return layernorm2_launch(x, ldx, rows, cols, gamma1, beta1, gamma2, beta2, eps, out1, ldo1, out2, ldo2, out2_bf16, addend,
+                           ld_add, stream);
 }
 
 int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t idim, const float* cmvn_mean,

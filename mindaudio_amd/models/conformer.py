@@ -10,6 +10,7 @@ Round-1 scope: inference forward (eval mode: dropout off, BatchNorm running stat
 `utterances/s fbanks+Conformer fwd` metric measures.  Training-mode forward/backward is the next row.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -184,13 +185,18 @@ class ConformerEncoder(nn.Module):
         return self._pos_cache[t2]
 
     @staticmethod
-    def _ffn(a, W, key, x, fused):
-        """x += 0.5 * FFN(a) (positionwise_feed_forward.py:33-46 + models/conformer.py:109-112 / 147-151)."""
+    def _ffn(a, W, key, x, fused, partial=None):
+        """x += 0.5 * FFN(a) (positionwise_feed_forward.py:33-46 + models/conformer.py:109-112 / 147-151).
+        Returns the partial product the NEXT LayerNorm must add (128-row fused kernel) or None."""
+        if fused and partial is not None:
+            ops.ffn128(a, W[key + "_w1"], W[key + "_b1"], W[key + "_w2"], W[key + "_b2"], x, partial, alpha=0.5)
+            return partial
         if fused:
             ops.ffn(a, W[key + "_w1"], W[key + "_b1"], W[key + "_w2"], W[key + "_b2"], x, alpha=0.5)
         else:
             h = ops.gemm(a, W[key + "_w1"], bias=W[key + "_b1"], act=_lib.ACT_SWISH)
             ops.gemm(h, W[key + "_w2"], bias=W[key + "_b2"], residual=x, alpha=0.5, out_dtype=torch.float32, out=x)
+        return None
 
     @torch.no_grad()
     def forward(self, xs, masks, xs_chunk_masks=None):
@@ -222,13 +228,18 @@ class ConformerEncoder(nn.Module):
         # the fused FFN kernel works on 64-row blocks, one workgroup per CU: it wins (measured at M = 7968 and
         # 15936) once there are enough blocks to cover a good part of the chip
         fused_ffn = m >= 64 * 64
+        # 128-row formulation of the fused kernel (hidden units split over two workgroups; the following LayerNorm adds
+        # the second half's partial product back).  Measured at B = 64: the kernel itself is ~7 % faster, but the extra
+        # partial-product traffic makes the step 1.5 % slower, so it is off unless MA_FFN128=1 (developer A/B switch).
+        use128 = m >= 128 * 100 and os.environ.get("MA_FFN128", "0") == "1"
+        part = torch.empty((m, self.d), dtype=f32, device=x.device) if use128 else None
         a = ops.layernorm(x, self.encoders[0].norm_ff_macaron.gamma, self.encoders[0].norm_ff_macaron.beta)
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
             # x = x + 0.5 * FFN_macaron(LN(x))   (a = LN(x) comes from the previous block's fused LN pair)
             #                                                                      models/conformer.py:109-112
-            self._ffn(a, W, "ffm", x, fused_ffn)
+            add = self._ffn(a, W, "ffm", x, fused_ffn, part)
             # x = x + MHA(LN(x))                                                   :117-135
-            a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta)
+            a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta, addend=add)
             qkv = ops.gemm(a, W["qkv_w"], bias=W["qkv_b"])
             ctx = ops.relpos_attention(qkv, pos_all[:, li * 256:(li + 1) * 256], W["u"], W["v"], att_mask, b, t2,
                                        self.heads, 64)
@@ -240,12 +251,12 @@ class ConformerEncoder(nn.Module):
             ops.gemm(z, W["pw2_w"], bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
             # x = x + 0.5 * FFN(LN(x)) ; x = LN_final(x)                           :147-156
             a = ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta)
-            self._ffn(a, W, "ff", x, fused_ffn)
+            add = self._ffn(a, W, "ff", x, fused_ffn, part)
             # x = LN_final(x), fused with the LayerNorm that consumes it next
             if li + 1 < n_layers:
                 nxt = self.encoders[li + 1].norm_ff_macaron
-                a = ops.layernorm2(x, l.norm_final.gamma, l.norm_final.beta, nxt.gamma, nxt.beta)
+                a = ops.layernorm2(x, l.norm_final.gamma, l.norm_final.beta, nxt.gamma, nxt.beta, addend=add)
             else:
                 x = ops.layernorm2(x, l.norm_final.gamma, l.norm_final.beta, self.after_norm.gamma,
-                                   self.after_norm.beta, out2_dtype=f32)
+                                   self.after_norm.beta, out2_dtype=f32, addend=add)
         return x.view(b, t2, self.d), masks

@@ -54,6 +54,20 @@ def ffn(a, w1, b1, w2, b2, x, alpha=0.5):
     return x
 
 
+def ffn128(a, w1, b1, w2, b2, x, partial, alpha=0.5):
+    """128-row formulation: x += alpha * (half-0 product + b2) in place, partial (M, 256) f32 = alpha * half-1 product;
+    the caller's next LayerNorm adds `partial` back (layernorm(..., addend=partial) / layernorm2(..., addend=partial))."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and x.dtype == t.float32 and partial.dtype == t.float32
+    m, d = a.shape
+    rc = lib.ma_ffn128_bf16(_host.ptr(a), a.stride(0), _host.ptr(w1), _host.ptr(b1), _host.ptr(w2), _host.ptr(b2),
+                            _host.ptr(x), x.stride(0), _host.ptr(partial), partial.stride(0), m, d, w1.shape[0],
+                            float(alpha), _host.current_stream_ptr())
+    _lib.check(rc, "ffn128_bf16")
+    return x
+
+
 def conv2d_3x3s2_nhwc(act, w, bias=None, relu=True, out_dtype=None):
     """act (B, H, W, C) bf16 NHWC, w (Cout, 3, 3, C) bf16 -> (B, Ho, Wo, Cout)."""
     t = _host.torch()
@@ -75,31 +89,44 @@ def _opt(x):
     return _host.ptr(x) if x is not None else None
 
 
-def layernorm(x, gamma, beta, eps=1e-5, row_scale=None, out_dtype=None, out=None):
-    """x (rows, D) float32 -> LayerNorm(x) [* row_scale[:, None]] as bf16 (default) or float32."""
+def layernorm(x, gamma, beta, eps=1e-5, row_scale=None, out_dtype=None, out=None, addend=None):
+    """x (rows, D) float32 -> LayerNorm(x) [* row_scale[:, None]] as bf16 (default) or float32.
+    With `addend` (rows, D) float32: x <- x + addend in place first (the split feed-forward kernel's partial product)."""
     t = _host.torch()
     lib = _lib.load()
     assert x.dtype == t.float32 and x.dim() == 2 and x.stride(1) == 1
     out_dtype = out_dtype or t.bfloat16
     if out is None:
         out = t.empty(x.shape, dtype=out_dtype, device=x.device)
-    rc = lib.ma_layernorm_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(gamma), _host.ptr(beta),
-                              float(eps), _opt(row_scale), _host.ptr(out), out.stride(0),
-                              1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    if addend is None:
+        rc = lib.ma_layernorm_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(gamma), _host.ptr(beta),
+                                  float(eps), _opt(row_scale), _host.ptr(out), out.stride(0),
+                                  1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    else:
+        rc = lib.ma_layernorm_add_f32(_host.ptr(x), x.stride(0), _host.ptr(addend), addend.stride(0), x.shape[0],
+                                      x.shape[1], _host.ptr(gamma), _host.ptr(beta), float(eps), _opt(row_scale),
+                                      _host.ptr(out), out.stride(0), 1 if out_dtype == t.bfloat16 else 0,
+                                      _host.current_stream_ptr())
     _lib.check(rc, "layernorm")
     return out
 
 
-def layernorm2(x, g1, b1, g2, b2, eps=1e-5, out2_dtype=None):
-    """In place x <- LN(x; g1, b1) (float32) and returns LN(x_new; g2, b2) as bf16 (default) or float32."""
+def layernorm2(x, g1, b1, g2, b2, eps=1e-5, out2_dtype=None, addend=None):
+    """In place x <- LN(x [+ addend]; g1, b1) (float32) and returns LN(x_new; g2, b2) as bf16 (default) or float32."""
     t = _host.torch()
     lib = _lib.load()
     assert x.dtype == t.float32 and x.dim() == 2 and x.stride(1) == 1
     out2_dtype = out2_dtype or t.bfloat16
     out2 = t.empty(x.shape, dtype=out2_dtype, device=x.device)
-    rc = lib.ma_layernorm2_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(g1), _host.ptr(b1),
-                               _host.ptr(g2), _host.ptr(b2), float(eps), _host.ptr(x), x.stride(0), _host.ptr(out2),
-                               out2.stride(0), 1 if out2_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    if addend is None:
+        rc = lib.ma_layernorm2_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(g1), _host.ptr(b1),
+                                   _host.ptr(g2), _host.ptr(b2), float(eps), _host.ptr(x), x.stride(0), _host.ptr(out2),
+                                   out2.stride(0), 1 if out2_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    else:
+        rc = lib.ma_layernorm2_add_f32(_host.ptr(x), x.stride(0), _host.ptr(addend), addend.stride(0), x.shape[0],
+                                       x.shape[1], _host.ptr(g1), _host.ptr(b1), _host.ptr(g2), _host.ptr(b2), float(eps),
+                                       _host.ptr(x), x.stride(0), _host.ptr(out2), out2.stride(0),
+                                       1 if out2_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
     _lib.check(rc, "layernorm2")
     return out2
 

@@ -197,3 +197,41 @@ def test_ffn_fused(t, m, hidden):
     # bf16 rounding of h can flip by one ulp where the device's fast sigmoid differs in the last bit:
     # error budget = a few bf16 ulps of |h| spread over `hidden` terms
     assert err <= 3e-3 * float(ref.abs().max()), err
+
+
+@pytest.mark.parametrize("m,hidden", [(64 * 7 + 5, 2048), (128, 256), (300, 1024)])
+def test_ffn_fused128_and_layernorm_add(t, m, hidden):
+    """128-row formulation: half 0 updates x, half 1 leaves a partial product that the next LayerNorm adds back."""
+    from mindaudio_amd import ops
+
+    d = 256
+    a = _rand(t, m, d, seed=70).bfloat16()
+    w1 = _rand(t, hidden, d, seed=71, scale=1.0 / 16).bfloat16()
+    b1 = _rand(t, hidden, seed=72, scale=0.3)
+    w2 = _rand(t, d, hidden, seed=73, scale=1.0 / math.sqrt(hidden)).bfloat16()
+    b2 = _rand(t, d, seed=74, scale=0.3)
+    x = _rand(t, m, d, seed=75)
+    g1, be1 = 1 + 0.1 * _rand(t, d, seed=76), 0.1 * _rand(t, d, seed=77)
+    g2, be2 = 1 + 0.1 * _rand(t, d, seed=78), 0.1 * _rand(t, d, seed=79)
+    z = a.double() @ w1.double().T + b1.double()
+    h = (z * t.sigmoid(z)).bfloat16().double()
+    ref = x.double() + 0.5 * (h @ w2.double().T + b2.double())
+
+    def ln(v, g, b):
+        mu = v.mean(-1, keepdim=True)
+        return (v - mu) / t.sqrt(((v - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * g.double() + b.double()
+
+    tol = 3e-3 * float(ref.abs().max())
+    # layernorm(addend=partial): x becomes the full sum, the output its LayerNorm
+    xg, part = x.clone().cuda(), t.empty(m, d, device="cuda")
+    ops.ffn128(a.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), xg, part, alpha=0.5)
+    out = ops.layernorm(xg, g1.cuda(), be1.cuda(), addend=part, out_dtype=t.float32)
+    assert float((xg.double().cpu() - ref).abs().max()) <= tol
+    assert float((out.double().cpu() - ln(ref, g1, be1)).abs().max()) <= 2e-2
+    # layernorm2(addend=partial): x <- LN1(sum), returns LN2(LN1(sum))
+    xg = x.clone().cuda()
+    ops.ffn128(a.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), xg, part, alpha=0.5)
+    out2 = ops.layernorm2(xg, g1.cuda(), be1.cuda(), g2.cuda(), be2.cuda(), addend=part, out2_dtype=t.float32)
+    y1 = ln(ref, g1, be1)
+    assert float((xg.double().cpu() - y1).abs().max()) <= 2e-2
+    assert float((out2.double().cpu() - ln(y1, g2, be2)).abs().max()) <= 3e-2

@@ -16,3 +16,5 @@ us = t(lambda: ops.ffn(a, w1, b1, w2, b2, x)); print("fused ffn  M=%d: %.1f us  
 def unf():
     h = ops.gemm(a, w1, bias=b1, act=_lib.ACT_SWISH); ops.gemm(h, w2, bias=b2, residual=x, alpha=0.5, out_dtype=torch.float32, out=x)
 us = t(unf); print("2-gemm ffn M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
+part = torch.empty(m, 256, device="cuda")
+us = t(lambda: ops.ffn128(a, w1, b1, w2, b2, x, part)); print("fused128   M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))

@@ -470,6 +470,16 @@ int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t ro
                                      const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
                                      float* stats, ma_stream_t stream);
 
+/* ma_ffn_bf16 with the LayerNorm(s) that follow the module fused into its epilogue (the workgroup owns whole rows):
+ *   ln_mode 1: x += alpha * FFN(a);  ln_out = LN(x; gamma1, beta1)                       (macaron FFN -> norm_mha)
+ *   ln_mode 2: x <- LN(x + alpha * FFN(a); gamma1, beta1);  ln_out = LN(x; gamma2, beta2)
+ *              (FFN -> norm_final -> the next block's norm_ff_macaron / after_norm, models/conformer.py:147-156, 253)
+ * ln_out (M, 256) bf16 or float32 with row stride ld_ln. */
+int ma_ffn_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
+                   int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, int32_t ln_mode,
+                   const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
+                   void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, ma_stream_t stream);
+
 /* Fused feed-forward, 128-row formulation: grid (ceil(M/128), 2) — the workgroup of hidden half 0 updates x in place
  * (x += alpha * (O_0 + b2)), half 1 writes partial (M, 256) float32 = alpha * O_1; the LayerNorm that follows the module
  * adds it back:

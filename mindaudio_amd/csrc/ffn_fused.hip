@@ -52,6 +52,14 @@ struct FfnParams {
   int64_t lda, ldx;
   int32_t M, H;
   float alpha;
+  // optional LayerNorm(s) of the updated rows, fused into the epilogue (the workgroup owns whole 256-wide rows):
+  //   ln_mode 0: none; 1: y = LN(x_new; g1, be1) -> ln_out;  2: x_new <- LN(x_new; g1, be1) (the block's norm_final,
+  //   models/conformer.py:155-156), y = LN(x_new; g2, be2) -> ln_out.  ln_out bf16 or float32 (ln_out_bf16).
+  int32_t ln_mode, ln_out_bf16;
+  const float *g1, *be1, *g2, *be2;
+  void* ln_out;
+  int64_t ld_ln;
+  float eps;
 };
 
 __device__ __forceinline__ uint32_t ffn_pack_bf16(float lo, float hi) {
@@ -244,6 +252,115 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_fused_kernel(const FfnPara
   }
 
   // ---- x += alpha * (O + b2): lane holds O[row = .. + (lane & 15)][n = wn*64 + j*16 + (lane >> 4)*4 + 0..3] ---
+  if (p.ln_mode == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = wn * 64 + j * 16 + (lane >> 4) * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
+        float4* xp = reinterpret_cast<float4*>(p.x + (int64_t)m * p.ldx + n);
+        float4 xv = *xp;
+        xv.x += p.alpha * (oacc[i][j][0] + bv.x);
+        xv.y += p.alpha * (oacc[i][j][1] + bv.y);
+        xv.z += p.alpha * (oacc[i][j][2] + bv.z);
+        xv.w += p.alpha * (oacc[i][j][3] + bv.w);
+        *xp = xv;
+      }
+    }
+    return;
+  }
+  // ---- fused LayerNorm epilogue ----------------------------------------------------------------------------------
+  // A row's 256 values live in 4 lane groups (lane >> 4) x 4 waves (wn): sums go through two shuffles and a small LDS
+  // exchange (the b1 copy is dead by now: every wave has passed the last step's barrier).
+  float* red = reinterpret_cast<float*>(smem + kOffB1);  // [2 stats][4 wn][64 rows]
+  float v[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + wm * 32 + i * 16 + (lane & 15);
+    if (m >= p.M) m = p.M - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = wn * 64 + j * 16 + (lane >> 4) * 4;
+      const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
+      const float4 xv = *reinterpret_cast<const float4*>(p.x + (int64_t)m * p.ldx + n);
+      v[i][j * 4 + 0] = xv.x + p.alpha * (oacc[i][j][0] + bv.x);
+      v[i][j * 4 + 1] = xv.y + p.alpha * (oacc[i][j][1] + bv.y);
+      v[i][j * 4 + 2] = xv.z + p.alpha * (oacc[i][j][2] + bv.z);
+      v[i][j * 4 + 3] = xv.w + p.alpha * (oacc[i][j][3] + bv.w);
+    }
+  }
+  auto row_stats = [&](float (&mean)[2], float (&rstd)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s += v[i][e];
+        q += v[i][e] * v[i][e];
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const int row = wm * 32 + i * 16 + (lane & 15);
+      if ((lane >> 4) == 0) {
+        red[wn * 64 + row] = s;
+        red[256 + wn * 64 + row] = q;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wm * 32 + i * 16 + (lane & 15);
+      const float s = (red[row] + red[64 + row]) + (red[128 + row] + red[192 + row]);
+      const float q = (red[256 + row] + red[320 + row]) + (red[384 + row] + red[448 + row]);
+      mean[i] = s * (1.0f / 256.0f);
+      const float var = fmaxf(q * (1.0f / 256.0f) - mean[i] * mean[i], 0.0f);
+      rstd[i] = 1.0f / sqrtf(var + p.eps);
+    }
+    __syncthreads();  // red may be rewritten by the second LayerNorm
+  };
+  auto normalise = [&](const float* g, const float* be, const float (&mean)[2], const float (&rstd)[2])
+                       __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = wn * 64 + j * 16 + (lane >> 4) * 4;
+      const float4 gv = *reinterpret_cast<const float4*>(g + n);
+      const float4 bv = *reinterpret_cast<const float4*>(be + n);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        v[i][j * 4 + 0] = (v[i][j * 4 + 0] - mean[i]) * rstd[i] * gv.x + bv.x;
+        v[i][j * 4 + 1] = (v[i][j * 4 + 1] - mean[i]) * rstd[i] * gv.y + bv.y;
+        v[i][j * 4 + 2] = (v[i][j * 4 + 2] - mean[i]) * rstd[i] * gv.z + bv.z;
+        v[i][j * 4 + 3] = (v[i][j * 4 + 3] - mean[i]) * rstd[i] * gv.w + bv.w;
+      }
+    }
+  };
+  auto store_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = wn * 64 + j * 16 + (lane >> 4) * 4;
+        *reinterpret_cast<float4*>(p.x + (int64_t)m * p.ldx + n) =
+            make_float4(v[i][j * 4], v[i][j * 4 + 1], v[i][j * 4 + 2], v[i][j * 4 + 3]);
+      }
+    }
+  };
+  float mean[2], rstd[2];
+  if (p.ln_mode == 1) store_x();  // the un-normalised sum is the new residual stream
+  row_stats(mean, rstd);
+  normalise(p.g1, p.be1, mean, rstd);
+  if (p.ln_mode == 2) {
+    store_x();  // x <- norm_final(x)
+    row_stats(mean, rstd);
+    normalise(p.g2, p.be2, mean, rstd);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 32 + i * 16 + (lane & 15);
@@ -251,14 +368,13 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_fused_kernel(const FfnPara
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = wn * 64 + j * 16 + (lane >> 4) * 4;
-      const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
-      float4* xp = reinterpret_cast<float4*>(p.x + (int64_t)m * p.ldx + n);
-      float4 xv = *xp;
-      xv.x += p.alpha * (oacc[i][j][0] + bv.x);
-      xv.y += p.alpha * (oacc[i][j][1] + bv.y);
-      xv.z += p.alpha * (oacc[i][j][2] + bv.z);
-      xv.w += p.alpha * (oacc[i][j][3] + bv.w);
-      *xp = xv;
+      if (p.ln_out_bf16) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.ln_out) + (int64_t)m * p.ld_ln + n) =
+            make_uint2(ffn_pack_bf16(v[i][j * 4], v[i][j * 4 + 1]), ffn_pack_bf16(v[i][j * 4 + 2], v[i][j * 4 + 3]));
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.ln_out) + (int64_t)m * p.ld_ln + n) =
+            make_float4(v[i][j * 4], v[i][j * 4 + 1], v[i][j * 4 + 2], v[i][j * 4 + 3]);
+      }
     }
   }
 }
@@ -267,20 +383,27 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_fused_kernel(const FfnPara
 
 using namespace ma;
 
-extern "C" int ma_ffn_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2,
-                           const float* b2, float* x, int64_t ldx, int64_t M, int32_t d_model, int32_t hidden,
-                           float alpha, ma_stream_t stream) {
+static int ffn_launch(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
+                      int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, int32_t ln_mode,
+                      const float* g1, const float* be1, const float* g2, const float* be2, float eps, void* ln_out,
+                      int64_t ld_ln, int32_t ln_out_bf16, ma_stream_t stream) {
   if (!a || !w1 || !b1 || !w2 || !b2 || !x || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
   if (d_model != kFfnD || hidden < kFfnHC || hidden % 256 != 0 || hidden > kFfnMaxHidden) return MA_ERR_UNSUPPORTED;
-  const int kFfnLds = kOffB1 + hidden * 4;
+  const int kFfnLds = kOffB1 + (hidden * 4 > 2048 ? hidden * 4 : 2048);  // b1 copy; reused by the LayerNorm epilogue
   if ((lda & 7) || (ldx & 3) || lda < kFfnD || ldx < kFfnD) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) |
        reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(x)) & 15)
     return MA_ERR_INVALID_ARG;
+  if (ln_mode < 0 || ln_mode > 2) return MA_ERR_INVALID_ARG;
+  if (ln_mode >= 1 && (!g1 || !be1 || !ln_out || ld_ln < kFfnD || (ld_ln & 3) ||
+                       ((reinterpret_cast<uintptr_t>(g1) | reinterpret_cast<uintptr_t>(be1) | reinterpret_cast<uintptr_t>(ln_out)) & 15)))
+    return MA_ERR_INVALID_ARG;
+  if (ln_mode == 2 && (!g2 || !be2 || ((reinterpret_cast<uintptr_t>(g2) | reinterpret_cast<uintptr_t>(be2)) & 15)))
+    return MA_ERR_INVALID_ARG;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kOffB1 + kFfnMaxHidden * 4) != hipSuccess)
       return MA_ERR_LAUNCH;
     attr = true;
   }
@@ -296,6 +419,29 @@ extern "C" int ma_ffn_bf16(const void* a, int64_t lda, const void* w1, const flo
   p.M = (int32_t)M;
   p.H = hidden;
   p.alpha = alpha;
+  p.ln_mode = ln_mode;
+  p.ln_out_bf16 = ln_out_bf16;
+  p.g1 = g1; p.be1 = be1; p.g2 = g2; p.be2 = be2;
+  p.ln_out = ln_out;
+  p.ld_ln = ld_ln;
+  p.eps = eps;
   MA_LAUNCH(ffn_fused_kernel, dim3((unsigned)((M + kFfnBM - 1) / kFfnBM)), dim3(kFfnThreads), kFfnLds, (hipStream_t)stream, p);
   return MA_OK;
+}
+
+extern "C" int ma_ffn_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2,
+                           const float* b2, float* x, int64_t ldx, int64_t M, int32_t d_model, int32_t hidden,
+                           float alpha, ma_stream_t stream) {
+  return ffn_launch(a, lda, w1, b1, w2, b2, x, ldx, M, d_model, hidden, alpha, 0, nullptr, nullptr, nullptr, nullptr, 0.f,
+                    nullptr, 0, 0, stream);
+}
+
+extern "C" int ma_ffn_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2,
+                              float* x, int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha,
+                              int32_t ln_mode, const float* gamma1, const float* beta1, const float* gamma2,
+                              const float* beta2, float eps, void* ln_out, int64_t ld_ln, int32_t ln_out_bf16,
+                              ma_stream_t stream) {
+  if (ln_mode < 1) return MA_ERR_INVALID_ARG;
+  return ffn_launch(a, lda, w1, b1, w2, b2, x, ldx, M, d_model, hidden, alpha, ln_mode, gamma1, beta1, gamma2, beta2, eps,
+                    ln_out, ld_ln, ln_out_bf16, stream);
 }

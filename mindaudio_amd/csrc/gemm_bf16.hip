@@ -348,7 +348,8 @@ static int gemm_num_cus() {
 
 template <int BM, int BN, int NST, int IM2COL, int EPI>
 static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
-  constexpr int lds = NST * (BM + BN) * BK * 2;
+  constexpr int ring = NST * (BM + BN) * BK * 2, stage_c = BM * (BN * 2 + 16);  // K-tile ring / staged bf16 C tile
+  constexpr int lds = ring > stage_c ? ring : stage_c;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, NST, IM2COL, EPI>),
@@ -371,6 +372,8 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   if (force && force[0] == '2') return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
   if (force && force[0] == '6') return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
   if (force && force[0] == '7') return launch_gemm_tile<64, 128, 2, IM2COL, EPI>(p, stream);
+  if (force && force[0] == '8') return launch_gemm_tile<128, 256, 2, IM2COL, EPI>(p, stream);
+  if (force && force[0] == '9') return launch_gemm_tile<256, 256, 2, IM2COL, EPI>(p, stream);
   // measured on MI355X (tools/gemm_bench.py): 2 workgroups/CU beat a deeper ring for the 128x128 tile; the
   // 64x128 tile prefers 3 workgroups/CU (2 stages) when there are enough tiles to fill them, else the 3-stage ring
   if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);

@@ -237,9 +237,12 @@ class ConformerEncoder(nn.Module):
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
             # x = x + 0.5 * FFN_macaron(LN(x))   (a = LN(x) comes from the previous block's fused LN pair)
             #                                                                      models/conformer.py:109-112
-            add = self._ffn(a, W, "ffm", x, fused_ffn, part)
-            # x = x + MHA(LN(x))                                                   :117-135
-            a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta, addend=add)
+            if fused_ffn and part is None:  # FFN + the LayerNorm in front of the attention in one kernel
+                a = ops.ffn_ln(a, W["ffm_w1"], W["ffm_b1"], W["ffm_w2"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
+            else:
+                add = self._ffn(a, W, "ffm", x, fused_ffn, part)
+                # x = x + MHA(LN(x))                                               :117-135
+                a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta, addend=add)
             qkv = ops.gemm(a, W["qkv_w"], bias=W["qkv_b"])
             ctx = ops.relpos_attention(qkv, pos_all[:, li * 256:(li + 1) * 256], W["u"], W["v"], att_mask, b, t2,
                                        self.heads, 64)
@@ -251,6 +254,16 @@ class ConformerEncoder(nn.Module):
             ops.gemm(z, W["pw2_w"], bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
             # x = x + 0.5 * FFN(LN(x)) ; x = LN_final(x)                           :147-156
             a = ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta)
+            last = li + 1 == n_layers
+            if fused_ffn and part is None:  # FFN + norm_final + the next consumer's LayerNorm in one kernel
+                nxt = self.after_norm if last else self.encoders[li + 1].norm_ff_macaron
+                y = ops.ffn_ln(a, W["ff_w1"], W["ff_b1"], W["ff_w2"], W["ff_b2"], x, l.norm_final.gamma, l.norm_final.beta,
+                               nxt.gamma, nxt.beta, out_dtype=f32 if last else None)
+                if last:
+                    x = y
+                else:
+                    a = y
+                continue
             add = self._ffn(a, W, "ff", x, fused_ffn, part)
             # x = LN_final(x), fused with the LayerNorm that consumes it next
             if li + 1 < n_layers:

@@ -54,6 +54,23 @@ def ffn(a, w1, b1, w2, b2, x, alpha=0.5):
     return x
 
 
+def ffn_ln(a, w1, b1, w2, b2, x, g1, be1, g2=None, be2=None, alpha=0.5, eps=1e-5, out_dtype=None):
+    """Fused FFN + the LayerNorm(s) behind it.  g2 None: x += alpha*FFN(a) in place, returns LN(x; g1, be1).
+    With g2: x <- LN(x + alpha*FFN(a); g1, be1) in place, returns LN(x; g2, be2).  Output bf16 (default) or float32."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and x.dtype == t.float32 and a.stride(1) == 1 and x.stride(1) == 1
+    m, d = a.shape
+    out_dtype = out_dtype or t.bfloat16
+    out = t.empty((m, d), dtype=out_dtype, device=a.device)
+    rc = lib.ma_ffn_ln_bf16(_host.ptr(a), a.stride(0), _host.ptr(w1), _host.ptr(b1), _host.ptr(w2), _host.ptr(b2),
+                            _host.ptr(x), x.stride(0), m, d, w1.shape[0], float(alpha), 2 if g2 is not None else 1,
+                            _host.ptr(g1), _host.ptr(be1), _opt(g2), _opt(be2), float(eps), _host.ptr(out), out.stride(0),
+                            1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    _lib.check(rc, "ffn_ln_bf16")
+    return out
+
+
 def ffn128(a, w1, b1, w2, b2, x, partial, alpha=0.5):
     """128-row formulation: x += alpha * (half-0 product + b2) in place, partial (M, 256) f32 = alpha * half-1 product;
     the caller's next LayerNorm adds `partial` back (layernorm(..., addend=partial) / layernorm2(..., addend=partial))."""

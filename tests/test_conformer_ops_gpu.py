@@ -235,3 +235,40 @@ def test_ffn_fused128_and_layernorm_add(t, m, hidden):
     y1 = ln(ref, g1, be1)
     assert float((xg.double().cpu() - y1).abs().max()) <= 2e-2
     assert float((out2.double().cpu() - ln(y1, g2, be2)).abs().max()) <= 3e-2
+
+
+@pytest.mark.parametrize("m,hidden,mode", [(250, 2048, 1), (7968, 2048, 2), (64 * 3 + 1, 256, 2), (100, 512, 1)])
+def test_ffn_fused_layernorm_epilogue(t, m, hidden, mode):
+    from mindaudio_amd import ops
+
+    d = 256
+    a = _rand(t, m, d, seed=80).bfloat16()
+    w1 = _rand(t, hidden, d, seed=81, scale=1.0 / 16).bfloat16()
+    b1 = _rand(t, hidden, seed=82, scale=0.3)
+    w2 = _rand(t, d, hidden, seed=83, scale=1.0 / math.sqrt(hidden)).bfloat16()
+    b2 = _rand(t, d, seed=84, scale=0.3)
+    x = _rand(t, m, d, seed=85) * 3 + 0.5
+    g1, be1 = 1 + 0.1 * _rand(t, d, seed=86), 0.1 * _rand(t, d, seed=87)
+    g2, be2 = 1 + 0.1 * _rand(t, d, seed=88), 0.1 * _rand(t, d, seed=89)
+    z = a.double() @ w1.double().T + b1.double()
+    h = (z * t.sigmoid(z)).bfloat16().double()
+    xs = x.double() + 0.5 * (h @ w2.double().T + b2.double())
+
+    def ln(v, g, b):
+        mu = v.mean(-1, keepdim=True)
+        return (v - mu) / t.sqrt(((v - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * g.double() + b.double()
+
+    xg = x.clone().cuda()
+    if mode == 1:
+        out = ops.ffn_ln(a.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), xg, g1.cuda(), be1.cuda(), out_dtype=t.float32)
+        assert float((xg.double().cpu() - xs).abs().max()) <= 3e-3 * float(xs.abs().max())
+        assert float((out.double().cpu() - ln(xs, g1, be1)).abs().max()) <= 2e-2
+    else:
+        out = ops.ffn_ln(a.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), xg, g1.cuda(), be1.cuda(), g2.cuda(),
+                         be2.cuda(), out_dtype=t.float32)
+        y1 = ln(xs, g1, be1)
+        assert float((xg.double().cpu() - y1).abs().max()) <= 2e-2
+        assert float((out.double().cpu() - ln(y1, g2, be2)).abs().max()) <= 3e-2
+    outb = ops.ffn_ln(a.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), x.clone().cuda(), g1.cuda(), be1.cuda(),
+                      *((g2.cuda(), be2.cuda()) if mode == 2 else ()))
+    assert outb.dtype == t.bfloat16 and float((outb.float().cpu().double() - out.double().cpu()).abs().max()) <= 3e-2

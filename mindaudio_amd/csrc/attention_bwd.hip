@@ -52,6 +52,8 @@ __device__ __forceinline__ uint32_t ab_pack(float lo, float hi) {  // v_cvt_pk_b
 struct AttnWs {
   uint16_t* base;
   float* D;
+  float* bias_part;  // [B*H*(Tp/64)][128] per-workgroup partial sums of (du | dv)
+  float* dp_part;    // [B][Tp][256] per-batch gradient of the positional projection
   int Tp;
   __host__ __device__ int64_t per_bh() const { return (int64_t)Tp * (128 * 4 + 64); }
   __device__ uint16_t* q(int64_t bh) const { return base + bh * per_bh(); }
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restric
   __shared__ __attribute__((aligned(16))) uint16_t Xt[128 * kTs];      // streamed X'^T
   __shared__ __attribute__((aligned(16))) uint16_t Yt[64 * kTs];       // streamed dO^T (KEYS_FIXED only)
   __shared__ __attribute__((aligned(16))) float srow[2][64];           // streamed per-row scalars: lse & D, or maskadd
+  __shared__ float wg_part[4][128];                                     // queries-fixed epilogue: (du | dv) per wave
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
@@ -174,48 +177,78 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restric
   const uint16_t* sxt = KEYS_FIXED ? ws.qt(bh) : ws.kt(bh);
   const uint16_t* syt = ws.dot(bh);
   const int n_st = Tp / 64;
+  // Staging registers (named, filled by macros: arrays captured by lambdas end up in scratch).  The global loads of
+  // streamed tile st+1 are issued right after tile st is published to LDS and stay in flight during its MFMAs.
+  //   X' rows : 64 x 16 chunks -> thread (r = tid >> 4 (+16 i), ch = tid & 15), i < 4
+  //   Y rows  : 64 x 8 chunks  -> thread (r = tid >> 3 (+32 i), ch = tid & 7),  i < 2
+  //   X'^T    : 128 x 8 chunks -> thread (r = tid >> 3 (+32 i), ch = tid & 7),  i < 4
+  //   dO^T    : 64 x 8 chunks  -> as Y rows (KEYS_FIXED only)
+  uint4 rx0, rx1, rx2, rx3, ry0, ry1, rt0, rt1, rt2, rt3, rd0 = make_uint4(0, 0, 0, 0), rd1 = make_uint4(0, 0, 0, 0);
+  float rs0 = 0.0f, rs1 = 0.0f;
+  const int xr_ = tid >> 4, xc_ = tid & 15, yr_ = tid >> 3, yc_ = tid & 7;
+#define MA_AB_YLOAD(dst, i, s0_)                                                                                       \
+  {                                                                                                                    \
+    const int r_ = yr_ + 32 * (i);                                                                                     \
+    dst = make_uint4(0, 0, 0, 0);                                                                                      \
+    if ((s0_) + r_ < T)                                                                                                \
+      dst = KEYS_FIXED ? *reinterpret_cast<const uint4*>(dctx + (row0 + (s0_) + r_) * ld_dctx + h * 64 + yc_ * 8)      \
+                       : *reinterpret_cast<const uint4*>(qkv + (row0 + (s0_) + r_) * ld_qkv + 512 + h * 64 + yc_ * 8); \
+  }
+#define MA_AB_FETCH(st_)                                                                                               \
+  {                                                                                                                    \
+    const int s0f_ = (st_)*64;                                                                                         \
+    rx0 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_) * 128 + xc_ * 8);                                 \
+    rx1 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 16) * 128 + xc_ * 8);                            \
+    rx2 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 32) * 128 + xc_ * 8);                            \
+    rx3 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 48) * 128 + xc_ * 8);                            \
+    MA_AB_YLOAD(ry0, 0, s0f_) MA_AB_YLOAD(ry1, 1, s0f_)                                                                \
+    rt0 = *reinterpret_cast<const uint4*>(sxt + (int64_t)(yr_)*Tp + s0f_ + yc_ * 8);                                   \
+    rt1 = *reinterpret_cast<const uint4*>(sxt + (int64_t)(yr_ + 32) * Tp + s0f_ + yc_ * 8);                            \
+    rt2 = *reinterpret_cast<const uint4*>(sxt + (int64_t)(yr_ + 64) * Tp + s0f_ + yc_ * 8);                            \
+    rt3 = *reinterpret_cast<const uint4*>(sxt + (int64_t)(yr_ + 96) * Tp + s0f_ + yc_ * 8);                            \
+    if (KEYS_FIXED) {                                                                                                  \
+      rd0 = *reinterpret_cast<const uint4*>(syt + (int64_t)(yr_)*Tp + s0f_ + yc_ * 8);                                 \
+      rd1 = *reinterpret_cast<const uint4*>(syt + (int64_t)(yr_ + 32) * Tp + s0f_ + yc_ * 8);                          \
+    }                                                                                                                  \
+    if (tid < 64) {                                                                                                    \
+      const int si_ = s0f_ + tid;                                                                                      \
+      if (KEYS_FIXED) {                                                                                                \
+        rs0 = si_ < T ? lse[bh * T + si_] : INFINITY; /* exp(. - inf) = 0: streamed queries past T vanish */           \
+        rs1 = si_ < T ? ws.D[bh * Tp + si_] : 0.0f;                                                                    \
+      } else {                                                                                                         \
+        rs0 = si_ >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + si_] == 0.0f) ? -10000.0f : 0.0f);                \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+#define MA_AB_ST8(arr, r, ch, v)                                                   \
+  {                                                                                \
+    uint2* d_ = reinterpret_cast<uint2*>(&arr[(r)*kTs + (ch)*8]);                   \
+    d_[0] = make_uint2((v).x, (v).y);                                              \
+    d_[1] = make_uint2((v).z, (v).w);                                              \
+  }
+  MA_AB_FETCH(0)
   for (int st = 0; st < n_st; ++st) {
-    const int s0 = st * 64;
-    __syncthreads();
-    // ---- stage the streamed tile -------------------------------------------------------------------------------
-    for (int c = tid; c < 64 * 16; c += 256) {  // X' rows: 64 x 16 chunks of 8
-      const int r = c >> 4, ch = c & 15;
-      *reinterpret_cast<uint4*>(&Xs[r * kXs + ch * 8]) = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0 + r) * 128 + ch * 8);
-    }
-    for (int c = tid; c < 64 * 8; c += 256) {   // Y rows: dO (queries) or V (keys), zero past T
-      const int r = c >> 3, ch = c & 7;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (s0 + r < T)
-        v = KEYS_FIXED ? *reinterpret_cast<const uint4*>(dctx + (row0 + s0 + r) * ld_dctx + h * 64 + ch * 8)
-                       : *reinterpret_cast<const uint4*>(qkv + (row0 + s0 + r) * ld_qkv + 512 + h * 64 + ch * 8);
-      *reinterpret_cast<uint4*>(&Ys[r * kYs + ch * 8]) = v;
-    }
-    for (int c = tid; c < 128 * 8; c += 256) {  // X'^T rows: 128 x 8 chunks of 8 streamed items
-      const int r = c >> 3, ch = c & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(sxt + (int64_t)r * Tp + s0 + ch * 8);
-      uint2* d = reinterpret_cast<uint2*>(&Xt[r * kTs + ch * 8]);
-      d[0] = make_uint2(v.x, v.y);
-      d[1] = make_uint2(v.z, v.w);
-    }
+    __syncthreads();  // previous tile fully consumed
+    *reinterpret_cast<uint4*>(&Xs[(xr_)*kXs + xc_ * 8]) = rx0;
+    *reinterpret_cast<uint4*>(&Xs[(xr_ + 16) * kXs + xc_ * 8]) = rx1;
+    *reinterpret_cast<uint4*>(&Xs[(xr_ + 32) * kXs + xc_ * 8]) = rx2;
+    *reinterpret_cast<uint4*>(&Xs[(xr_ + 48) * kXs + xc_ * 8]) = rx3;
+    *reinterpret_cast<uint4*>(&Ys[(yr_)*kYs + yc_ * 8]) = ry0;
+    *reinterpret_cast<uint4*>(&Ys[(yr_ + 32) * kYs + yc_ * 8]) = ry1;
+    MA_AB_ST8(Xt, yr_, yc_, rt0)
+    MA_AB_ST8(Xt, yr_ + 32, yc_, rt1)
+    MA_AB_ST8(Xt, yr_ + 64, yc_, rt2)
+    MA_AB_ST8(Xt, yr_ + 96, yc_, rt3)
     if (KEYS_FIXED) {
-      for (int c = tid; c < 64 * 8; c += 256) {
-        const int r = c >> 3, ch = c & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(syt + (int64_t)r * Tp + s0 + ch * 8);
-        uint2* d = reinterpret_cast<uint2*>(&Yt[r * kTs + ch * 8]);
-        d[0] = make_uint2(v.x, v.y);
-        d[1] = make_uint2(v.z, v.w);
-      }
+      MA_AB_ST8(Yt, yr_, yc_, rd0)
+      MA_AB_ST8(Yt, yr_ + 32, yc_, rd1)
     }
     if (tid < 64) {
-      const int si = s0 + tid;
-      if (KEYS_FIXED) {
-        srow[0][tid] = si < T ? lse[bh * T + si] : INFINITY;  // exp(. - inf) = 0: streamed queries past T vanish
-        srow[1][tid] = si < T ? ws.D[bh * Tp + si] : 0.0f;
-      } else {
-        srow[0][tid] = si >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + si] == 0.0f) ? -10000.0f : 0.0f);
-      }
+      srow[0][tid] = rs0;
+      if (KEYS_FIXED) srow[1][tid] = rs1;
     }
     __syncthreads();
+    if (st + 1 < n_st) MA_AB_FETCH(st + 1)
 
     // ---- score tile and dP tile: rows = streamed (4 tiles of 16), column = fixed item lq --------------------------
     uint32_t pb[4][2], db[4][2];  // bf16 pairs of P and scale * dS for rows lg*4 + {0,1}, {2,3} of tile mt
@@ -280,6 +313,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restric
     }
   }
 
+#undef MA_AB_FETCH
+#undef MA_AB_YLOAD
+#undef MA_AB_ST8
   // ---- outputs: lane holds rows c = ct*16 + lg*4 + r of the transposed result for its fixed item -----------------
   if (KEYS_FIXED) {
     if (fidx < T) {
@@ -292,11 +328,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restric
       for (int dt = 0; dt < 4; ++dt)  // dv
         *reinterpret_cast<uint2*>(orow + 512 + dt * 16) =
             make_uint2(ab_pack(acc_y[dt][0], acc_y[dt][1]), ab_pack(acc_y[dt][2], acc_y[dt][3]));
-      float* prow = dpos + (int64_t)fidx * ld_dpos + h * 64 + lg * 4;  // dp: summed over the batch
+      // dp: per-batch partial (B, Tp, 256) float32; attn_dpos_reduce_kernel sums over the batch (2.6 M contended atomics
+      // on (T, 256) cost more than the kernel's MFMAs)
+      float* prow = ws.dp_part + ((int64_t)b * Tp + fidx) * 256 + h * 64 + lg * 4;
 #pragma unroll
       for (int ct = 4; ct < 8; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(prow + (ct - 4) * 16 + r, acc_x[ct][r]);
+        *reinterpret_cast<float4*>(prow + (ct - 4) * 16) = make_float4(acc_x[ct][0], acc_x[ct][1], acc_x[ct][2], acc_x[ct][3]);
     }
   } else {
     const bool live = fidx < T;
@@ -318,9 +355,45 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restric
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 4, 64);
         v += __shfl_xor(v, 8, 64);
-        if (lq == 0) atomicAdd((ct < 4 ? du : dv) + h * 64 + (ct & 3) * 16 + lg * 4 + r, v);
+        // workgroup partial in LDS (Xs is dead: every wave is past the last tile's MFMAs only after the barrier below)
+        if (lq == 0) wg_part[wave][(ct >> 2) * 64 + (ct & 3) * 16 + lg * 4 + r] = v;
       }
+    __syncthreads();
+    if (tid < 128) {
+      // per-workgroup partial of (du | dv) for head h; attn_bias_reduce_kernel sums them (no contended atomics)
+      const float t4 = (wg_part[0][tid] + wg_part[1][tid]) + (wg_part[2][tid] + wg_part[3][tid]);
+      ws.bias_part[(((int64_t)b * H + h) * gridDim.x + fb) * 128 + tid] = t4;
+    }
   }
+}
+
+// du[h][c] += sum over (b, query block) of the workgroup partials; grid = H, block = 1024 = 8 slices x 128 (du | dv)
+__global__ __launch_bounds__(1024) void attn_bias_reduce_kernel(const float* __restrict__ part, int B, int H, int nfb,
+                                                                float* du, float* dv) {
+  __shared__ float red[8][128];
+  const int h = blockIdx.x, c = threadIdx.x & 127, sl = threadIdx.x >> 7;
+  const int n = B * nfb;
+  float s = 0.0f;
+  for (int i = sl; i < n; i += 8) {
+    const int b = i / nfb, f = i - b * nfb;
+    s += part[(((int64_t)b * H + h) * nfb + f) * 128 + c];
+  }
+  red[sl][c] = s;
+  __syncthreads();
+  if (sl == 0) {
+    s = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+    if (c < 64) du[h * 64 + c] += s;
+    else dv[h * 64 + (c - 64)] += s;
+  }
+}
+
+// dpos[t][c] += sum_b part[b][t][c]
+__global__ __launch_bounds__(256) void attn_dpos_reduce_kernel(const float* __restrict__ part, int B, int T, int Tp,
+                                                               float* dpos, int64_t ld_dpos) {
+  const int t = blockIdx.x, c = threadIdx.x;
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b) s += part[((int64_t)b * Tp + t) * 256 + c];
+  dpos[(int64_t)t * ld_dpos + c] += s;
 }
 
 }  // namespace ma
@@ -332,7 +405,7 @@ extern "C" {
 int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k) {
   if (batch < 1 || T < 1 || heads < 1 || d_k != 64) return MA_ERR_INVALID_ARG;
   const int64_t Tp = (T + 63) / 64 * 64;
-  return batch * heads * Tp * (128 * 4 + 64) * 2 + batch * heads * Tp * 4 + 256;
+  return batch * heads * Tp * (128 * 4 + 64) * 2 + batch * heads * Tp * 4 + batch * heads * (Tp / 64) * 128 * 4 + batch * Tp * 256 * 4 + 256;
 }
 
 int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
@@ -352,6 +425,8 @@ int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* po
   ws.Tp = (int)((T + 63) / 64 * 64);
   ws.base = reinterpret_cast<uint16_t*>(workspace);
   ws.D = reinterpret_cast<float*>(ws.base + batch * heads * ws.per_bh());
+  ws.bias_part = ws.D + batch * heads * ws.Tp;
+  ws.dp_part = ws.bias_part + batch * heads * (ws.Tp / 64) * 128;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)(ws.Tp / 64), (unsigned)heads, (unsigned)batch);
   const float scale = 1.0f / sqrtf((float)d_k);
@@ -361,6 +436,10 @@ int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* po
             mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   MA_LAUNCH(attn_bwd_kernel<false>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
             mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+  MA_LAUNCH(attn_dpos_reduce_kernel, dim3((unsigned)T), dim3(256), 0, s, ws.dp_part, (int)batch, (int)T, ws.Tp, dpos,
+            ld_dpos);
+  MA_LAUNCH(attn_bias_reduce_kernel, dim3((unsigned)heads), dim3(1024), 0, s, ws.bias_part, (int)batch, (int)heads,
+            ws.Tp / 64, dbias_u, dbias_v);
   return MA_OK;
 }
 

@@ -203,24 +203,53 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // ---- Swish + dropout between w_1 and w_2 -----------------------------------------------------------------------
+// 8 elements (16 bytes) per thread; n % 8 == 0
 __global__ __launch_bounds__(256) void act_dropout_fwd_kernel(const uint16_t* __restrict__ u, uint16_t* __restrict__ h,
                                                               int64_t n, Drop d, int relu) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float v = bf2f(u[i]);
-    float r = relu ? fmaxf(v, 0.0f) : v * sigmoidf_(v);
-    if (d.thresh) r = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? r * d.inv_keep : 0.0f;
-    h[i] = f2bf(r);
+  const int64_t n8 = n >> 3;
+  for (int64_t i8 = (int64_t)blockIdx.x * 256 + threadIdx.x; i8 < n8; i8 += (int64_t)gridDim.x * 256) {
+    const uint4 raw = reinterpret_cast<const uint4*>(u)[i8];
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v0 = __uint_as_float(w[e] << 16), v1 = __uint_as_float(w[e] & 0xffff0000u);
+      float r0 = relu ? fmaxf(v0, 0.0f) : v0 * sigmoidf_(v0);
+      float r1 = relu ? fmaxf(v1, 0.0f) : v1 * sigmoidf_(v1);
+      if (d.thresh) {
+        const uint64_t i = (uint64_t)i8 * 8 + 2 * e;
+        r0 = keep_elem(d.seed, d.salt, i, d.thresh) ? r0 * d.inv_keep : 0.0f;
+        r1 = keep_elem(d.seed, d.salt, i + 1, d.thresh) ? r1 * d.inv_keep : 0.0f;
+      }
+      o[e] = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
+    }
+    reinterpret_cast<uint4*>(h)[i8] = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
-// du = dh * keep / (1 - p) * swish'(u),  swish'(u) = s + u s (1 - s)
+// du = dh * keep / (1 - p) * act'(u),  swish'(u) = s + u s (1 - s)
 __global__ __launch_bounds__(256) void act_dropout_bwd_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ dh,
                                                               uint16_t* __restrict__ du, int64_t n, Drop d, int relu) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float v = bf2f(u[i]);
-    const float s = sigmoidf_(v);
-    float gr = bf2f(dh[i]) * (relu ? (v > 0.0f ? 1.0f : 0.0f) : (s + v * s * (1.0f - s)));
-    if (d.thresh) gr = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? gr * d.inv_keep : 0.0f;
-    du[i] = f2bf(gr);
+  const int64_t n8 = n >> 3;
+  for (int64_t i8 = (int64_t)blockIdx.x * 256 + threadIdx.x; i8 < n8; i8 += (int64_t)gridDim.x * 256) {
+    const uint4 ru = reinterpret_cast<const uint4*>(u)[i8];
+    const uint4 rd = reinterpret_cast<const uint4*>(dh)[i8];
+    const uint32_t wu[4] = {ru.x, ru.y, ru.z, ru.w}, wd[4] = {rd.x, rd.y, rd.z, rd.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float v = q ? __uint_as_float(wu[e] & 0xffff0000u) : __uint_as_float(wu[e] << 16);
+        const float dv = q ? __uint_as_float(wd[e] & 0xffff0000u) : __uint_as_float(wd[e] << 16);
+        const float sg = sigmoidf_(v);
+        float gr = dv * (relu ? (v > 0.0f ? 1.0f : 0.0f) : (sg + v * sg * (1.0f - sg)));
+        if (d.thresh) gr = keep_elem(d.seed, d.salt, (uint64_t)i8 * 8 + 2 * e + q, d.thresh) ? gr * d.inv_keep : 0.0f;
+        g[q] = gr;
+      }
+      o[e] = (uint32_t)f2bf(g[0]) | ((uint32_t)f2bf(g[1]) << 16);
+    }
+    reinterpret_cast<uint4*>(du)[i8] = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -255,41 +284,50 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
 
 // ---- convolution module, training mode --------------------------------------------------------------------------
 // z[b,t,c] = bias[c] + sum_j w[c][j] * glu(y)[b, t + j - pad, c] (zero outside [0, T)), float32; per-channel sums of z
-// and z^2 for the batch statistics.  Thread = (row, 4 channels).
+// and z^2 for the batch statistics.  Workgroup = (utterance, kCfPerBlock strips of 16 frames) x 256 channels (thread =
+// channel): glu of the strip + halo goes through LDS once (the sigmoid is evaluated once per element, not once per tap).
+constexpr int kCfStrip = 16, kCfPerBlock = 4;
+template <int KS>
 __global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const uint16_t* __restrict__ y, int64_t ldy, int T, int C,
-                                                                int ks, const float* __restrict__ w,
+                                                                const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ z,
-                                                                int64_t rows, float* sums) {
-  extern __shared__ float lsum[];  // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) lsum[i] = 0.0f;
-  __syncthreads();
-  const int cg = C / 4, pad = (ks - 1) / 2;
-  const int64_t total = rows * cg;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / cg;
-    const int c = (int)(i - row * cg) * 4;
-    const int t = (int)(row % T);
-    float acc[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
-    for (int j = 0; j < ks; ++j) {
-      const int tt = t + j - pad;
-      if (tt < 0 || tt >= T) continue;
-      const uint16_t* yp = y + (row + j - pad) * ldy + c;
-      const uint2 a = *reinterpret_cast<const uint2*>(yp);
-      const uint2 gt = *reinterpret_cast<const uint2*>(yp + C);
-      const float av[4] = {__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
-      const float gv[4] = {__uint_as_float(gt.x << 16), __uint_as_float(gt.x & 0xffff0000u), __uint_as_float(gt.y << 16), __uint_as_float(gt.y & 0xffff0000u)};
+                                                                float* sums) {
+  constexpr int pad = (KS - 1) / 2, kRows = kCfStrip + KS - 1;
+  __shared__ float s_t[kRows * 256];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.z * 256 + tid;
+  const int b = blockIdx.y;
+  const int64_t base = (int64_t)b * T;
+  float wr[KS];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[(c + q) * ks + j], av[q] * sigmoidf_(gv[q]), acc[q]);
+  for (int j = 0; j < KS; ++j) wr[j] = w[c * KS + j];
+  const float bc = bias[c];
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int sidx = 0; sidx < kCfPerBlock; ++sidx) {
+    const int t0 = (blockIdx.x * kCfPerBlock + sidx) * kCfStrip;
+    if (t0 >= T) break;
+    for (int r = 0; r < kRows; ++r) {
+      const int t = t0 - pad + r;
+      float sv = 0.0f;
+      if (t >= 0 && t < T) {
+        const uint16_t* yp = y + (base + t) * ldy + c;
+        sv = bf2f(yp[0]) * sigmoidf_(bf2f(yp[C]));
+      }
+      s_t[r * 256 + tid] = sv;  // a thread only reads its own column: no barrier needed
     }
-    *reinterpret_cast<float4*>(z + row * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    const int t1 = min(T, t0 + kCfStrip);
+    for (int t = t0; t < t1; ++t) {
+      const int r = t - t0;
+      float acc = bc;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      atomicAdd(&lsum[c + q], acc[q]);
-      atomicAdd(&lsum[C + c + q], acc[q] * acc[q]);
+      for (int j = 0; j < KS; ++j) acc = fmaf(wr[j], s_t[(r + j) * 256 + tid], acc);
+      z[(base + t) * C + c] = acc;
+      s1 += acc;
+      s2 += acc * acc;
     }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(sums + i, lsum[i]);
+  atomicAdd(sums + c, s1);
+  atomicAdd(sums + C + c, s2);
 }
 
 // stats[c] = mean, stats[C + c] = rstd (biased variance, nn.BatchNorm1d training mode); running statistics updated
@@ -641,7 +679,8 @@ int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, c
 int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, int32_t act, float p, uint32_t seed, uint32_t salt,
                             ma_stream_t stream) {
   if (!u || !h || n < 1 || p < 0.0f || p >= 1.0f || (act != 1 && act != 2)) return MA_ERR_INVALID_ARG;
-  MA_LAUNCH(act_dropout_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u,
+  if ((n & 7) || ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(h)) & 15)) return MA_ERR_UNSUPPORTED;
+  MA_LAUNCH(act_dropout_fwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u,
             (uint16_t*)h, n, make_drop(p, seed, salt), act == 2 ? 1 : 0);
   return MA_OK;
 }
@@ -649,7 +688,9 @@ int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, int32_t act, floa
 int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, int32_t act, float p, uint32_t seed,
                             uint32_t salt, ma_stream_t stream) {
   if (!u || !dh || !du || n < 1 || p < 0.0f || p >= 1.0f || (act != 1 && act != 2)) return MA_ERR_INVALID_ARG;
-  MA_LAUNCH(act_dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u,
+  if ((n & 7) || ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(du)) & 15))
+    return MA_ERR_UNSUPPORTED;
+  MA_LAUNCH(act_dropout_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u,
             (const uint16_t*)dh, (uint16_t*)du, n, make_drop(p, seed, salt), act == 2 ? 1 : 0);
   return MA_OK;
 }
@@ -678,11 +719,17 @@ int ma_dropout_bwd_bf16(const float* g, int64_t ldg, void* dy, int64_t ldy, int6
 
 int ma_convmid_fwd_train(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
                          int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
-  if (!y || !dw_w || !dw_b || !z || !sums || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
-  if (C < 4 || (C & 3) || ks < 1 || ks > 31 || !(ks & 1) || (ldy & 3) || C > 1024) return MA_ERR_UNSUPPORTED;
-  const int64_t rows = batch * T;
-  MA_LAUNCH(convmid_fwd_train_kernel, dim3(grid_for(rows * (C / 4), 256, 2048)), dim3(256), 2 * C * sizeof(float),
-            (hipStream_t)stream, (const uint16_t*)y, ldy, (int)T, C, ks, dw_w, dw_b, z, rows, sums);
+  if (!y || !dw_w || !dw_b || !z || !sums || batch < 1 || T < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
+  if (C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31) || (ldy & 1)) return MA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((T + kCfStrip * kCfPerBlock - 1) / (kCfStrip * kCfPerBlock)), (unsigned)batch, (unsigned)(C / 256));
+#define MA_CF(KS_)                                                                                                  \
+  MA_LAUNCH(convmid_fwd_train_kernel<KS_>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y, ldy, (int)T, C, \
+            dw_w, dw_b, z, sums)
+  if (ks == 3) { MA_CF(3); }
+  else if (ks == 7) { MA_CF(7); }
+  else if (ks == 15) { MA_CF(15); }
+  else { MA_CF(31); }
+#undef MA_CF
   return MA_OK;
 }
 
@@ -707,7 +754,7 @@ int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, co
   if (!dout || !z || !stats || !gamma || !beta || !dz || !dsum || rows < 1) return MA_ERR_INVALID_ARG;
   if (C < 1 || C > 256 || 256 % C) return MA_ERR_UNSUPPORTED;
   const int rpb = 256 / C;
-  MA_LAUNCH(bn_swish_bwd1_kernel, dim3(grid_for(rows, rpb, 1024)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+  MA_LAUNCH(bn_swish_bwd1_kernel, dim3(grid_for(rows, rpb, 256)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
             (const uint16_t*)dout, z, stats, gamma, beta, dz, rows, C, dsum);
   MA_LAUNCH(bn_bwd2_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dz, z, stats, gamma, dsum, rows,
             C, 1.0f / (float)rows);

@@ -261,6 +261,14 @@ int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t
                          float* loss_out, void* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
                          ma_stream_t stream);
 
+/* CTC greedy search (models/decoders/decoder_factory.py:9-56 + utils/recognize.py:254-270): per frame the arg-max class
+ * of log_softmax(logits) (first index on ties) and its log-probability; frames with mask == 0 (mask (batch*T) float32,
+ * optional) become 0 = blank as in `topk_index * encoder_mask`; then remove_duplicates_and_blank
+ * (utils/common.py:116-125) per utterance: hyp (batch, T) int32 zero padded, hyp_len (batch). */
+int ma_ctc_greedy_search_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const float* mask,
+                             int32_t blank, int32_t* best, float* best_logp, int32_t* hyp, int32_t* hyp_len,
+                             ma_stream_t stream);
+
 /* float32 -> bf16 (round to nearest even), n % 4 == 0: the `cast` in front of a matmul operand. */
 int ma_cast_f32_bf16(const float* x, void* y, int64_t n, ma_stream_t stream);
 

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "ma_ctc_grad_workspace_bytes": (i64, [i64, i64, i32]),
     "ma_ctc_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, i32, i32, f32, vp, vp, vp, vp, i64,
                                             vp, i64, vp]),
+    "ma_ctc_greedy_search_f32": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, vp, vp, vp]),
     "ma_cast_f32_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p]),
     "ma_ecapa_pack_input_bf16": (ctypes.c_int, [vp, i64, i64, i32, i32, i32, vp, vp]),
     "ma_add_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),

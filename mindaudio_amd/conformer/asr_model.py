@@ -106,3 +106,47 @@ def shard_batch(columns, rank, group_size):
     """Every rank builds the same global batch and keeps the strided slice batch[rank::group_size]
     (examples/conformer/dataset.py:552-553)."""
     return [c[rank::group_size] for c in columns]
+
+
+def remove_duplicates_and_blank(hyp):
+    """mindaudio/utils/common.py:116-125 on a host list (the device version lives in ma_ctc_greedy_search_f32)."""
+    out, prev = [], None
+    for tok in hyp:
+        if tok != prev and tok != 0:
+            out.append(tok)
+        prev = tok
+    return out
+
+
+class CTCGreedySearch(nn.Module):
+    """CTC greedy search net (models/decoders/decoder_factory.py:9-56): forward(xs_pad, xs_masks, xs_lengths) ->
+    (topk_index (B, T') int32 with padded frames zeroed, topk_prob (B, T') float32 log-probabilities).
+    `xs_masks` is the un-subsampled (B, 1, T) pad mask, sliced [:, :, :-2:2][:, :, :-2:2] here as in the reference."""
+
+    def __init__(self, backbone, pretrained_model=False):
+        super().__init__()
+        if pretrained_model:
+            raise NotImplementedError("wav2vec front ends are outside the built path")
+        self.backbone = backbone
+
+    @torch.no_grad()
+    def forward(self, xs_pad, xs_masks, xs_lengths=None):
+        best, logp, _, _ = self._search(xs_pad, xs_masks)
+        return best, logp
+
+    @torch.no_grad()
+    def _search(self, xs_pad, xs_masks):
+        sub = xs_masks[:, :, :-2:2][:, :, :-2:2].contiguous()
+        enc, enc_mask = self.backbone.encoder(xs_pad, sub, sub)
+        b, t2, _ = enc.shape
+        logits = self.backbone.ctc.logits(enc)
+        return ops.ctc_greedy_search(logits, b, t2, logits.shape[1], enc_mask.reshape(-1).to(torch.float32).contiguous())
+
+
+def ctc_greedy_search(model, xs_pad, xs_masks, xs_lengths=None):
+    """utils/recognize.py:254-270: (hyps: list of token lists with repeats and blanks removed, scores: per-utterance
+    maximum frame log-probability).  `model` is a CTCGreedySearch."""
+    best, logp, hyp, hyp_len = model._search(xs_pad, xs_masks)
+    lens = hyp_len.cpu().tolist()
+    rows = hyp.cpu().tolist()
+    return [r[:n] for r, n in zip(rows, lens)], logp.max(1).values

@@ -241,6 +241,54 @@ __global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restric
   }
 }
 
+// CTC greedy search (mindaudio/models/decoders/decoder_factory.py:9-56): one wave per frame row: argmax over the
+// vocabulary (first index on ties, like TopK) of the logits = argmax of the log-softmax, its log-probability, and the
+// frame index masked by the encoder mask (padded frames -> 0 = blank).
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logits, int64_t ld, int64_t rows, int V,
+                                                         const float* __restrict__ mask, int32_t* __restrict__ best,
+                                                         float* __restrict__ best_logp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = logits + row * ld;
+  float m = -INFINITY;
+  int am = 0;
+  for (int v = lane; v < V; v += 64)
+    if (p[v] > m) { m = p[v]; am = v; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float om = __shfl_xor(m, off, 64);
+    const int oa = __shfl_xor(am, off, 64);
+    if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+  }
+  float s = 0.f;
+  for (int v = lane; v < V; v += 64) s += expf(p[v] - m);
+  s = wave_add(s);
+  if (lane == 0) {
+    const bool keep = !mask || mask[row] != 0.0f;
+    best[row] = keep ? am : 0;
+    best_logp[row] = -logf(s);  // logp(argmax) = max - (max + log sum exp(p - max))
+  }
+}
+
+// remove_duplicates_and_blank (mindaudio/utils/common.py:116-125): collapse repeats, drop blanks; one thread per
+// utterance (T is a few hundred frames).  hyp (batch, T) int32 zero-padded, hyp_len (batch).
+__global__ void ctc_collapse_kernel(const int32_t* __restrict__ best, int B, int T, int blank, int32_t* __restrict__ hyp,
+                                    int32_t* __restrict__ hyp_len) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int32_t* src = best + (int64_t)b * T;
+  int32_t* dst = hyp + (int64_t)b * T;
+  int n = 0, prev = -1;
+  for (int t = 0; t < T; ++t) {
+    const int v = src[t];
+    if (v != prev && v != blank) dst[n++] = v;
+    prev = v;
+  }
+  hyp_len[b] = n;
+  for (int t = n; t < T; ++t) dst[t] = 0;
+}
+
 __global__ void ctc_reduce_kernel(const float* __restrict__ loss, int B, int zero_infinity, float* __restrict__ out) {
   // fixed-order sum over the batch (deterministic), zero_infinity as CTCLossV2, then / B (ctc_loss.py:61-62)
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -313,6 +361,19 @@ int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t
   MA_LAUNCH(ctc_dlogits_kernel, dim3((unsigned)rows), dim3(256), (size_t)V * 4, s, logits, ld, (int)T, (int)V,
             lse_workspace, ys, (int)Lmax, hlens, ylens, (int)blank, per_utt_loss, ab, Smax, grad_scale,
             reinterpret_cast<uint16_t*>(dlogits), ld_out);
+  return MA_OK;
+}
+
+int ma_ctc_greedy_search_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const float* mask,
+                             int32_t blank, int32_t* best, float* best_logp, int32_t* hyp, int32_t* hyp_len,
+                             ma_stream_t stream) {
+  if (!logits || !best || !best_logp || !hyp || !hyp_len || batch < 1 || T < 1 || V < 1 || ld < V || blank < 0 || blank >= V)
+    return MA_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t rows = batch * T;
+  MA_LAUNCH(ctc_greedy_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, ld, rows, (int)V, mask, best, best_logp);
+  MA_LAUNCH(ctc_collapse_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, best, (int)batch, (int)T, (int)blank, hyp,
+            hyp_len);
   return MA_OK;
 }
 

@@ -219,3 +219,18 @@ def ctc_loss(logits, batch, T, ys_pad, hlens, ys_lens, blank=0, zero_infinity=Tr
                              _host.ptr(per), _host.ptr(lse), _host.ptr(out), _host.current_stream_ptr())
     _lib.check(rc, "ctc_loss")
     return out[0], per
+
+
+def ctc_greedy_search(logits, batch, T, V, mask=None, blank=0):
+    """logits (B*T, ld >= V) float32 -> (best (B, T) int32 masked, best_logp (B, T) f32, hyp (B, T) int32, hyp_len (B,))."""
+    t = _host.torch()
+    lib = _lib.load()
+    dev = logits.device
+    best = t.empty((batch, T), dtype=t.int32, device=dev)
+    logp = t.empty((batch, T), dtype=t.float32, device=dev)
+    hyp = t.empty((batch, T), dtype=t.int32, device=dev)
+    hyp_len = t.empty((batch,), dtype=t.int32, device=dev)
+    rc = lib.ma_ctc_greedy_search_f32(_host.ptr(logits), logits.stride(0), batch, T, V, _opt(mask), blank, _host.ptr(best),
+                                      _host.ptr(logp), _host.ptr(hyp), _host.ptr(hyp_len), _host.current_stream_ptr())
+    _lib.check(rc, "ctc_greedy_search")
+    return best, logp, hyp, hyp_len

@@ -240,6 +240,38 @@ def main():
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
     collate_goldens(ref)
+    decode_goldens(ref)
+
+
+def decode_goldens(ref):
+    """remove_duplicates_and_blank (mindaudio/utils/common.py:116-125) and wer (mindaudio/metric/wer.py:4-57),
+    both pure Python in the reference."""
+    cm = ref["common"]
+    wer_mod = _load("ref_wer", "mindaudio/metric/wer.py")
+    rng = np.random.RandomState(77)
+    out = {}
+    frames = rng.randint(0, 6, (12, 40)).astype(np.int32)  # small alphabet: many repeats and blanks (0)
+    frames[3] = 0
+    frames[4] = 2
+    out["greedy_frames"] = frames
+    hyps = [cm.remove_duplicates_and_blank(row.tolist()) for row in frames]
+    out["greedy_hyp_len"] = np.array([len(h) for h in hyps], np.int32)
+    out["greedy_hyp_flat"] = np.array([t for h in hyps for t in h], np.int32)
+    refs, hys, vals = [], [], []
+    for _ in range(40):
+        r = rng.randint(1, 8, rng.randint(1, 12)).tolist()
+        h = rng.randint(1, 8, rng.randint(0, 12)).tolist()
+        refs.append(r)
+        hys.append(h)
+        vals.append(wer_mod.wer(r, h))
+    out["wer_ref_len"] = np.array([len(r) for r in refs], np.int32)
+    out["wer_ref_flat"] = np.array([t for r in refs for t in r], np.int32)
+    out["wer_hyp_len"] = np.array([len(h) for h in hys], np.int32)
+    out["wer_hyp_flat"] = np.array([t for h in hys for t in h], np.int32)
+    out["wer_values"] = np.array(vals, np.float64)
+    path = os.path.join(HERE, "decode_goldens.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
 
 
 def _write_wav(path, pcm16):

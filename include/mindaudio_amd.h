@@ -304,6 +304,27 @@ int ma_se_apply_bf16(const void* x, int64_t ldx, const void* gate, const void* r
 int ma_asp_pool_bf16(const void* logits, int64_t ldl, const void* x, int64_t ldx, int64_t batch, int64_t T, int32_t halo,
                      int32_t C, float eps, const float* bn_scale, const float* bn_shift, void* out, ma_stream_t stream);
 
+/* ---- post-processing around the feature kernels (mindaudio/data/features.py, spectrum.py, compute_cmvn_stats.py) --- */
+
+/* features.compute_deltas (features.py:158-193): x (rows, T) float32, n = (win_length - 1) / 2,
+ * out[t] = sum_{j=1..n} j (x[t+j] - x[t-j]) / (n (n+1) (2n+1) / 3) with the time axis padded by `pad_mode`. */
+int ma_compute_deltas_f32(const float* x, int64_t rows, int64_t T, int32_t win_length, int32_t pad_mode, float* out,
+                          ma_stream_t stream);
+/* features.context_window (features.py:64-155): x (batch, F, T) -> out (batch, F*(left+right+1), T),
+ * out[b, f*cs + k, t] = x[b, f, t + k + max(right-left, 0) - max(left, right)], zero outside [0, T). */
+int ma_context_window_f32(const float* x, int64_t batch, int32_t F, int64_t T, int32_t left, int32_t right, float* out,
+                          ma_stream_t stream);
+/* DCT step of features.mfcc (features.py:339-356): out (batch, n_mfcc, T) = dct^T (n_mfcc, n_mels) . x (batch, n_mels, T). */
+int ma_dct_f32(const float* x, int64_t batch, int32_t n_mels, int64_t T, const float* dct, int32_t n_mfcc, float* out,
+               ma_stream_t stream);
+/* spectrum.magphase (spectrum.py:701-735) on n complex64 values: mag = |z|^power, phase = z / |z| (1+0i at zero; phase
+ * may be NULL: complex_norm). */
+int ma_magphase_f32(const float* z, int64_t n, float power, float* mag, float* phase, ma_stream_t stream);
+/* compute_cmvn_stats.py:45-60 on a padded feature batch x (batch, T, F) float32 with frames[b] valid rows:
+ * stats (2, F) float64 += per-feature sum and sum of squares (F <= 256; the frame count is the host's sum(frames)). */
+int ma_cmvn_stats_f64(const float* x, const int32_t* frames, int64_t batch, int64_t T, int32_t F, double* stats,
+                      ma_stream_t stream);
+
 /* ---- batch assembly of the training loop (examples/conformer/dataset.py:536-656) -------------------------- */
 
 /* len(range(max_src_len)[:-2:2][:-2:2]): width of xs_masks after the two stride-2 slicings (dataset.py:625). */

@@ -113,6 +113,11 @@ PROTOTYPES = {
     "ma_time_mean_bf16": (ctypes.c_int, [vp, i64, i64, i64, i32, i32, vp, vp]),
     "ma_se_apply_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]),
     "ma_asp_pool_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i32, i32, f32, vp, vp, vp, vp]),
+    "ma_compute_deltas_f32": (ctypes.c_int, [vp, i64, i64, i32, i32, vp, vp]),
+    "ma_context_window_f32": (ctypes.c_int, [vp, i64, i32, i64, i32, i32, vp, vp]),
+    "ma_dct_f32": (ctypes.c_int, [vp, i64, i32, i64, vp, i32, vp, vp]),
+    "ma_magphase_f32": (ctypes.c_int, [vp, i64, f32, vp, vp, vp]),
+    "ma_cmvn_stats_f64": (ctypes.c_int, [vp, vp, i64, i64, i32, vp, vp]),
     "ma_subsampled_mask_len": (i32, [i32]),
     "ma_collate_asr_i32": (ctypes.c_int, [ctypes.c_void_p] * 3 + [i32] * 7 + [ctypes.c_void_p] * 11),
     "ma_spec_aug_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p, i32,

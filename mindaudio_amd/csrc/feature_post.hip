@@ -1,0 +1,169 @@
+// Small post-processing kernels around the feature path: the pieces of mindaudio.data.features /
+// spectrum / examples/conformer/compute_cmvn_stats.py that follow the STFT / mel kernels.
+//   compute_deltas_kernel   features.compute_deltas (features.py:158-193 -> MindSpore ComputeDeltas = torchaudio
+//                           functional.compute_deltas): out[t] = sum_{j=-n..n} j x[t+j] / (n (n+1) (2n+1) / 3), padded
+//   context_window_kernel   features.context_window (features.py:64-155): L past + R future frames stacked per channel
+//   dct_kernel              the DCT matmul of features.mfcc (features.py:339-356)
+//   complex_norm / magphase spectrum.magphase (spectrum.py:701-735), |z|^power
+//   cmvn_stats_kernel       compute_cmvn_stats.py:45-60: per-feature sum / sum of squares over the valid frames (float64)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+__device__ __forceinline__ int fp_pad_index(int t, int T, int mode) {  // index into [0, T) of padded position t, -1 = zero
+  if (t >= 0 && t < T) return t;
+  if (mode == MA_PAD_CONSTANT) return -1;
+  if (mode == MA_PAD_EDGE) return t < 0 ? 0 : T - 1;
+  if (T == 1) return 0;
+  const int period = mode == MA_PAD_REFLECT ? 2 * (T - 1) : 2 * T;
+  int m = t % period;
+  if (m < 0) m += period;
+  if (mode == MA_PAD_REFLECT) return m < T ? m : period - m;
+  return m < T ? m : period - 1 - m;  // symmetric
+}
+
+__global__ __launch_bounds__(256) void compute_deltas_kernel(const float* __restrict__ x, int64_t rows, int T, int n, int mode,
+                                                             float inv_denom, float* __restrict__ out) {
+  const int64_t total = rows * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / T;
+    const int t = (int)(i - r * T);
+    const float* xr = x + r * T;
+    float acc = 0.0f;
+    for (int j = 1; j <= n; ++j) {
+      const int ip = fp_pad_index(t + j, T, mode), im = fp_pad_index(t - j, T, mode);
+      acc += (float)j * ((ip >= 0 ? xr[ip] : 0.0f) - (im >= 0 ? xr[im] : 0.0f));
+    }
+    out[i] = acc * inv_denom;
+  }
+}
+
+// x (B, F, T) -> out (B, F * cs, T): out[b, f * cs + k, t] = x[b, f, t + k + off] (0 outside), off = max(R - L, 0) - max(L, R)
+__global__ __launch_bounds__(256) void context_window_kernel(const float* __restrict__ x, int64_t B, int F, int T, int cs, int off,
+                                                             float* __restrict__ out) {
+  const int64_t total = B * F * cs * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % T);
+    int64_t q = i / T;
+    const int k = (int)(q % cs);
+    q /= cs;  // = b * F + f
+    const int ts = t + k + off;
+    out[i] = (ts >= 0 && ts < T) ? x[q * T + ts] : 0.0f;
+  }
+}
+
+// out[b, k, t] = sum_m x[b, m, t] * dct[m, k]
+__global__ __launch_bounds__(256) void dct_kernel(const float* __restrict__ x, int64_t B, int M, int T, const float* __restrict__ dct,
+                                                  int K, float* __restrict__ out) {
+  const int64_t total = B * K * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % T);
+    const int64_t q = i / T;
+    const int k = (int)(q % K);
+    const int64_t b = q / K;
+    const float* xb = x + b * M * T + t;
+    float acc = 0.0f;
+    for (int m = 0; m < M; ++m) acc = fmaf(xb[(int64_t)m * T], dct[m * K + k], acc);
+    out[i] = acc;
+  }
+}
+
+// mag = |z|^power; phase = z / |z| (1 + 0i where |z| == 0), spectrum.py:722-732
+__global__ __launch_bounds__(256) void magphase_kernel(const float2* __restrict__ z, int64_t n, float power, float* __restrict__ mag,
+                                                       float2* __restrict__ phase) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float2 v = z[i];
+    const float m = hypotf(v.x, v.y);
+    if (phase) {
+      const float d = m == 0.0f ? 1.0f : m;
+      phase[i] = make_float2(v.x / d + (m == 0.0f ? 1.0f : 0.0f), v.y / d);
+    }
+    mag[i] = power == 1.0f ? m : (power == 2.0f ? m * m : powf(m, power));
+  }
+}
+
+// x (B, T, F) float32 with frames[b] valid rows -> stats (2, F) float64: sum, sum of squares; count handled by the host
+__global__ __launch_bounds__(256) void cmvn_stats_kernel(const float* __restrict__ x, const int32_t* __restrict__ frames, int T, int F,
+                                                         double* stats) {
+  const int b = blockIdx.y;
+  const int nf = min(frames[b], T);
+  const int f = threadIdx.x % F, sub = threadIdx.x / F, nsub = 256 / F;
+  if (sub >= nsub) return;
+  double s = 0.0, q = 0.0;
+  for (int t = blockIdx.x * nsub + sub; t < nf; t += gridDim.x * nsub) {
+    const double v = (double)x[((int64_t)b * T + t) * F + f];
+    s += v;
+    q += v * v;
+  }
+  atomicAdd(stats + f, s);
+  atomicAdd(stats + F + f, q);
+}
+
+static int fp_grid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int ma_compute_deltas_f32(const float* x, int64_t rows, int64_t T, int32_t win_length, int32_t pad_mode, float* out,
+                          ma_stream_t stream) {
+  if (!x || !out || rows < 1 || T < 1 || win_length < 3 || pad_mode < MA_PAD_CONSTANT || pad_mode > MA_PAD_SYMMETRIC)
+    return MA_ERR_INVALID_ARG;
+  const int n = (win_length - 1) / 2;
+  const float denom = (float)n * (n + 1) * (2 * n + 1) / 3.0f;
+  MA_LAUNCH(compute_deltas_kernel, dim3(fp_grid(rows * T)), dim3(256), 0, (hipStream_t)stream, x, rows, (int)T, n, pad_mode,
+            1.0f / denom, out);
+  return MA_OK;
+}
+
+int ma_context_window_f32(const float* x, int64_t batch, int32_t F, int64_t T, int32_t left, int32_t right, float* out,
+                          ma_stream_t stream) {
+  if (!x || !out || batch < 1 || F < 1 || T < 1 || left < 0 || right < 0) return MA_ERR_INVALID_ARG;
+  const int cs = left + right + 1, mx = left > right ? left : right, shift = right - left;
+  MA_LAUNCH(context_window_kernel, dim3(fp_grid(batch * F * cs * T)), dim3(256), 0, (hipStream_t)stream, x, batch, F, (int)T, cs,
+            (shift > 0 ? shift : 0) - mx, out);
+  return MA_OK;
+}
+
+int ma_dct_f32(const float* x, int64_t batch, int32_t n_mels, int64_t T, const float* dct, int32_t n_mfcc, float* out,
+               ma_stream_t stream) {
+  if (!x || !dct || !out || batch < 1 || n_mels < 1 || T < 1 || n_mfcc < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(dct_kernel, dim3(fp_grid(batch * n_mfcc * T)), dim3(256), 0, (hipStream_t)stream, x, batch, n_mels, (int)T, dct,
+            n_mfcc, out);
+  return MA_OK;
+}
+
+int ma_magphase_f32(const float* z, int64_t n, float power, float* mag, float* phase, ma_stream_t stream) {
+  if (!z || !mag || n < 1 || power < 0.0f) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(magphase_kernel, dim3(fp_grid(n)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2*>(z), n, power,
+            mag, reinterpret_cast<float2*>(phase));
+  return MA_OK;
+}
+
+int ma_cmvn_stats_f64(const float* x, const int32_t* frames, int64_t batch, int64_t T, int32_t F, double* stats,
+                      ma_stream_t stream) {
+  if (!x || !frames || !stats || batch < 1 || T < 1 || F < 1 || F > 256 || batch > 65535) return MA_ERR_INVALID_ARG;
+  const int nsub = 256 / F;
+  int gx = (int)((T + nsub - 1) / nsub);
+  if (gx > 64) gx = 64;
+  MA_LAUNCH(cmvn_stats_kernel, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, x, frames, (int)T, F, stats);
+  return MA_OK;
+}
+
+}  // extern "C"

@@ -10,7 +10,7 @@ import numpy as np
 
 from .. import _host, _lib
 
-__all__ = ["stft", "melspectrogram", "amplitude_to_dB"]
+__all__ = ["stft", "melspectrogram", "amplitude_to_dB", "spectrogram", "magphase"]
 
 
 def _finish(out, lead, was_numpy):
@@ -131,5 +131,44 @@ def amplitude_to_dB(wavform, stype="power", ref=1.0, amin=1e-10, top_db=80.0):
     return out.to(in_dtype)
 
 
-def spectrogram_unsupported(*a, **k):
-    raise NotImplementedError("spectrum.spectrogram is not on the fbank->Conformer path; use melspectrogram/stft")
+def spectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0, window="hann", power=2.0,
+                normalized=False, center=True, pad_mode="reflect", onesided=True):
+    """spectrum.spectrogram (spectrum.py:560-606 -> MindSpore Spectrogram): |STFT| ** power with reflect padding by
+    default, hop = win_length // 2; (..., n_fft // 2 + 1, frames) float32.  `normalized` / two-sided output are not built."""
+    if normalized or not onesided:
+        raise NotImplementedError("normalized / two-sided spectrograms are not built")
+    t = _host.require_gpu()
+    was_numpy = not isinstance(waveforms, t.Tensor)
+    x = t.as_tensor(np.asarray(waveforms)).cuda() if was_numpy else waveforms
+    if pad > 0:
+        x = t.nn.functional.pad(x, (pad, pad))
+    win_length = win_length or n_fft
+    hop_length = hop_length or win_length // 2
+    S = stft(x, n_fft=n_fft, win_length=win_length, hop_length=hop_length, window=window, center=center, pad_mode=pad_mode)
+    mag = t.empty(S.shape, dtype=t.float32, device=S.device)
+    Sc = S.contiguous()
+    _lib.check(_lib.load().ma_magphase_f32(_host.ptr(t.view_as_real(Sc)), Sc.numel(), float(power), _host.ptr(mag), None,
+                                           _host.current_stream_ptr()), "spectrogram")
+    return mag.cpu().numpy() if was_numpy else mag
+
+
+def spectrogram_unsupported(*a, **k):  # kept for callers of the round-1 name
+    return spectrogram(*a, **k)
+
+
+def magphase(waveform, power, iscomplex=True):
+    """spectrum.magphase (spectrum.py:701-735) for complex input: (|D| ** power, D / |D|), phase 1+0j where D == 0."""
+    if not iscomplex:
+        raise NotImplementedError("real (..., 2) input goes through MindSpore's Magphase in the reference")
+    t = _host.require_gpu()
+    lib = _lib.load()
+    was_numpy = not isinstance(waveform, t.Tensor)
+    z = t.as_tensor(np.ascontiguousarray(waveform) if was_numpy else waveform).to(device="cuda", dtype=t.complex64).contiguous()
+    mag = t.empty(z.shape, dtype=t.float32, device=z.device)
+    phase = t.empty_like(z)
+    zr, pr = t.view_as_real(z), t.view_as_real(phase)
+    _lib.check(lib.ma_magphase_f32(_host.ptr(zr), z.numel(), float(power), _host.ptr(mag), _host.ptr(pr),
+                                   _host.current_stream_ptr()), "magphase")
+    if was_numpy:
+        return mag.cpu().numpy(), phase.cpu().numpy()
+    return mag, phase

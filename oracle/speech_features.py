@@ -376,3 +376,82 @@ def make_pad_mask(lengths, max_len=0):
 def subsequent_mask(size):
     r = np.arange(size)
     return r[None, :] <= r[:, None]
+
+
+# --------------------------------------------------------------------------
+# post-processing of features.py / spectrum.py.  magphase and load_cmvn are pinned by
+# tests/golden/post_goldens.npz (reference NumPy code); compute_deltas / context_window / mfcc go through MindSpore
+# operators in the reference and are restated from their documented torchaudio-equivalent semantics: parity unpinned.
+# --------------------------------------------------------------------------
+def magphase(D, power):
+    """spectrum.py:722-732 (iscomplex=True)."""
+    mag = np.abs(D)
+    zero = mag == 0
+    nz = mag + zero
+    phase = np.empty(D.shape, dtype=np.complex64)
+    phase.real = D.real / nz + zero
+    phase.imag = D.imag / nz
+    return mag ** power, phase
+
+
+def compute_deltas(x, win_length=5, pad_mode="edge"):
+    """features.py:158-193 -> ComputeDeltas: sum_j j x[t + j] / (n (n + 1) (2n + 1) / 3) over the padded time axis."""
+    n = (win_length - 1) // 2
+    denom = n * (n + 1) * (2 * n + 1) / 3.0
+    xp = np.pad(np.asarray(x, np.float64), [(0, 0)] * (x.ndim - 1) + [(n, n)], mode=pad_mode)
+    t = x.shape[-1]
+    out = np.zeros(x.shape, np.float64)
+    for j in range(-n, n + 1):
+        out += j * xp[..., n + j:n + j + t]
+    return out / denom
+
+
+def context_window(x, left_frames=0, right_frames=0):
+    """features.py:64-155: grouped Conv1d with an identity kernel — channel f*cs + k of the output is channel f of the
+    input shifted by k + max(R - L, 0) - max(L, R) frames, zero padded."""
+    x = np.asarray(x)
+    cs = left_frames + right_frames + 1
+    off = max(right_frames - left_frames, 0) - max(left_frames, right_frames)
+    f, t = x.shape[-2], x.shape[-1]
+    out = np.zeros(x.shape[:-2] + (f * cs, t), x.dtype)
+    for k in range(cs):
+        sh = k + off
+        lo, hi = max(0, -sh), min(t, t - sh)
+        if hi > lo:
+            out[..., k::cs, lo:hi] = x[..., :, lo + sh:hi + sh]
+    return out
+
+
+def create_dct(n_mfcc, n_mels, norm="ortho"):
+    n = np.arange(n_mels, dtype=np.float64)
+    k = np.arange(n_mfcc, dtype=np.float64)[:, None]
+    dct = np.cos(np.pi / n_mels * (n + 0.5) * k)
+    if norm in (None, "none"):
+        dct *= 2.0
+    else:
+        dct[0] *= 1.0 / np.sqrt(2.0)
+        dct *= np.sqrt(2.0 / n_mels)
+    return dct.T
+
+
+def mfcc(waveforms, deltas=True, context=True, n_mels=23, n_mfcc=20, n_fft=400, sample_rate=16000, f_min=0.0, f_max=None,
+         left_frames=5, right_frames=5, win_length=None, hop_length=None, norm="ortho"):
+    """features.py:273-373 (log_mels=False)."""
+    mel = melspectrogram(waveforms, n_fft=n_fft, win_length=win_length, hop_length=hop_length, n_mels=n_mels,
+                         sample_rate=sample_rate, f_min=f_min, f_max=f_max)
+    db = amplitude_to_dB(mel, stype="power", ref=1.0, top_db=80.0)
+    out = np.swapaxes(np.matmul(np.swapaxes(db, -1, -2), create_dct(n_mfcc, n_mels, norm)), -1, -2)
+    if deltas:
+        d1 = compute_deltas(out)
+        d2 = compute_deltas(d1)
+        out = np.concatenate((out, d1, d2), axis=-2)
+    if context:
+        out = context_window(out, left_frames, right_frames)
+    return out
+
+
+def load_cmvn_stats(mean_stat, var_stat, frame_num):
+    """mindaudio/utils/load_files.py:9-36 on the three json fields."""
+    mean = np.asarray(mean_stat, np.float64) / frame_num
+    var = np.maximum(np.asarray(var_stat, np.float64) / frame_num - mean * mean, 1.0e-20)
+    return mean, 1.0 / np.sqrt(var)

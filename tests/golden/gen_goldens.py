@@ -241,6 +241,7 @@ def main():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
     collate_goldens(ref)
     decode_goldens(ref)
+    post_goldens(ref)
 
 
 def decode_goldens(ref):
@@ -270,6 +271,40 @@ def decode_goldens(ref):
     out["wer_hyp_flat"] = np.array([t for h in hys for t in h], np.int32)
     out["wer_values"] = np.array(vals, np.float64)
     path = os.path.join(HERE, "decode_goldens.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+
+
+def post_goldens(ref):
+    """SURVEY 8f-4, the pieces that are pure NumPy / Python in the reference: spectrum.magphase (spectrum.py:701-735),
+    load_cmvn (mindaudio/utils/load_files.py:9-36) and the per-utterance CMVN sums of compute_cmvn_stats.py:45-60."""
+    import json
+    import tempfile
+
+    sp, io, ds = ref["spectrum"], ref["io"], ref["dataset"]
+    out = {}
+    wav, _ = io.read(os.path.join(REF, "tests/samples/ASR/BAC009S0002W0122.wav"))
+    D = sp.stft(wav[:8000], n_fft=512, hop_length=160)
+    D[3, 5] = 0  # exercises the zero-magnitude branch
+    out["magphase_in"] = D
+    for pw in (1.0, 2.0, 0.5):
+        mag, ph = sp.magphase(D.copy(), power=pw, iscomplex=True)
+        out["magphase_mag_%g" % pw] = mag
+        out["magphase_phase_%g" % pw] = ph
+    feats = ds.compute_fbank_feats(wav * (1 << 15), 16000, mel_bin=80, frame_len=25, frame_shift=10)
+    out["cmvn_mean_stat"] = np.sum(feats, axis=0)
+    out["cmvn_var_stat"] = np.sum(np.square(feats), axis=0)
+    out["cmvn_frames"] = np.int64(feats.shape[0])
+    lf = _load("ref_load_files", "mindaudio/utils/load_files.py")
+    tmp = tempfile.mkdtemp(prefix="ma_cmvn_")
+    path = os.path.join(tmp, "global_cmvn")
+    with open(path, "w") as f:
+        f.write(json.dumps({"mean_stat": out["cmvn_mean_stat"].tolist(), "var_stat": out["cmvn_var_stat"].tolist(),
+                            "frame_num": int(out["cmvn_frames"])}))
+    mean, istd = lf.load_cmvn(path, True)
+    out["cmvn_mean"], out["cmvn_istd"] = np.asarray(mean), np.asarray(istd)
+    shutil.rmtree(tmp)
+    path = os.path.join(HERE, "post_goldens.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
 

@@ -197,8 +197,8 @@ def test_fbank_device_tensor_and_unsupported(ma):
     x = torch.from_numpy(_speechlike(2, 2, 16000)).cuda()
     out = ma.fbank(x, n_fft=512, n_mels=40)
     assert out.is_cuda and tuple(out.shape) == (2, 40, 63)  # default hop = n_fft // 2 (spectrum.py:666)
-    with pytest.raises(NotImplementedError):
-        ma.fbank(x, n_fft=512, deltas=True)
+    d = ma.fbank(x, n_fft=512, n_mels=40, deltas=True)  # features.py:264-267: static + delta + delta-delta
+    assert d.is_cuda and tuple(d.shape) == (2, 120, 63) and torch.equal(d[:, :40], out)
     with pytest.raises(ValueError):
         ma.fbank(x[:, :300], n_fft=512)
 

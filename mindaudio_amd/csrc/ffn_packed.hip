@@ -1,0 +1,433 @@
+// Fused position-wise feed-forward for gfx950, "hidden-slice owner" form (d_model = 256):
+//
+//     x[m, :] += alpha * ( swish(a[m, :] . W1^T + b1) . W2^T + b2 )        [+ the LayerNorm(s) that follow]
+//
+// Same contract as ffn_fused.hip (PositionwiseFeedForward, mindaudio/models/layers/positionwise_feed_forward.py:33-46,
+// with the residual of models/conformer.py:109-112,147-151), different decomposition.  ffn_fused.hip splits the 64 x 128
+// S tile and the 64 x 256 O tile over 8 waves, so every k-step of every wave re-reads activation AND weight fragments from
+// LDS and the hidden tile takes a write + barrier + read round trip: that kernel is LDS-bound.  Here
+//   * a workgroup is 4 waves (one per SIMD, up to 512 registers each) and owns 64 rows;
+//   * a WAVE owns a slice of the hidden units: per block of 32 hidden units it computes S^T (32 x 64 rows, K = 256), applies
+//     bias + Swish in registers, and feeds the result straight back as the B operand of O^T (256 x 64) += W2[:, block] . h^T.
+//     The hidden activation never leaves the registers: a 16x16 accumulator tile holds rows 4g..4g+3 for lane group g, an MFMA
+//     B operand wants k = 8g..8g+7, so the two S tiles of a block are given the hidden units {8g + r} and {8g + 4 + r}
+//     (a row permutation of W1 that is free: it is folded into the weight packing);
+//   * every weight fragment is used by exactly one wave (against its 4 row tiles), so weights bypass the LDS: they are
+//     pre-packed in fragment order (ma_ffn_pack_weights_bf16, once per weight update) and stream L2 -> registers with
+//     perfectly coalesced 1 KiB loads, 16 fragments (one GEMM phase) ahead of their use;
+//   * the LDS only holds the 64 x 256 activation tile (read-only in the main loop: no barriers) and, at the end, the exchange
+//     buffers of the cross-wave reduction of the four partial O tiles.
+// LDS traffic per MFMA drops 4x and the main loop has no workgroup synchronisation at all.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kPkRows = 64, kPkD = 256, kPkThreads = 256;
+constexpr int kPkBlock = 32;                  // hidden units per (wave, step)
+constexpr int kPkItems = 32;                  // 1 KiB fragments per block: 16 of W1 (k-step, tile), 16 of W2 (output tile)
+constexpr int kPkLds = 128 * 1024;            // a tile (32 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
+constexpr int kPkMaxHidden = 8192;
+
+struct FfnPackedParams {
+  const uint16_t* a;   // (M, 256) bf16
+  const uint4* wp;     // packed weights: [hidden / 32][32 items][64 lanes] x 16 B
+  const float* b1;     // (H)
+  const float* b2;     // (256)
+  float* x;            // (M, 256) f32, updated in place
+  int64_t lda, ldx;
+  int32_t M, H;
+  float alpha;
+  int32_t ln_mode, ln_out_bf16;  // as FfnParams (ffn_fused.hip)
+  const float *g1, *be1, *g2, *be2;
+  void* ln_out;
+  int64_t ld_ln;
+  float eps;
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pk_pack_bf16(float lo, float hi) {
+  const bf16x2 r = __builtin_convertvector((f32x2){lo, hi}, bf16x2);  // v_cvt_pk_bf16_f32 (round to nearest even)
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+template <int ABL>
+__device__ __forceinline__ float pk_swish(float v) {
+  if constexpr (ABL & 1) return v;
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+
+// ---- weight packing ----------------------------------------------------------------------------------------------------
+// item q < 16 of block hb (k-step ks = q >> 1, tile t = q & 1): lane (i = lane & 15, g = lane >> 4) holds
+//     W1[32 hb + 8 (i >> 2) + 4 t + (i & 3)][32 ks + 8 g .. + 8]
+// item 16 + j: lane (i, g) holds W2[16 j + i][32 hb + 8 g .. + 8].
+__global__ void ffn_pack_kernel(const uint16_t* __restrict__ w1, const uint16_t* __restrict__ w2, int hidden,
+                                uint4* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte piece per thread
+  const int64_t total = (int64_t)(hidden / kPkBlock) * kPkItems * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63), q = (int)((idx >> 6) & 31);
+  const int64_t hb = idx >> 11;
+  const int i = lane & 15, g = lane >> 4;
+  const uint16_t* src;
+  if (q < 16) {
+    const int ks = q >> 1, t = q & 1;
+    src = w1 + (hb * kPkBlock + 8 * (i >> 2) + 4 * t + (i & 3)) * kPkD + 32 * ks + 8 * g;
+  } else {
+    const int j = q - 16;
+    src = w2 + (int64_t)(16 * j + i) * hidden + hb * kPkBlock + 8 * g;
+  }
+  out[idx] = *reinterpret_cast<const uint4*>(src);
+}
+
+// ABL (development ablations, tools/ffn_bench.py): 1 = no Swish, 2 = no weight loads in the loop, 4 = no MFMAs; 0 = product.
+template <int ABL>
+__global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPackedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: block bases live in SGPRs
+  const int c = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * kPkRows;
+
+  // ---- activation tile -> LDS: [64 rows][512 B], 16-byte chunk index XORed with (row & 15) --------------------------------
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = it * kPkThreads + tid;
+    const int row = idx >> 5, ch = idx & 31;
+    int m = m0 + row;
+    if (m >= p.M) m = p.M - 1;
+    const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
+    *reinterpret_cast<uint4*>(smem + row * 512 + ((ch ^ (row & 15)) << 4)) = v;
+  }
+  __syncthreads();
+
+  // Row-tile slot s of wave w is row tile (s + w) & 3: slot 0 is the tile the wave owns after the final reduction, and all
+  // accumulator indices stay compile-time constants.
+  int a_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a_off[s] = (16 * ((s + wave) & 3) + c) * 512 + ((g ^ c) << 4);
+
+  const int nsb_all = p.H >> 7;
+  const int nsb = ABL == 7 && p.alpha == 0.25f ? 0 : nsb_all;  // (ablation 7 with alpha 0.25: no main loop at all)
+  //                                         super-blocks of 4 x 32 hidden units, one block per wave
+  const int rot = blockIdx.x % nsb_all;      // workgroups start at different super-blocks: spreads the L2 channel load
+  auto block_of = [&](int ci) {
+    int sb = ci + rot;
+    if (sb >= nsb_all) sb -= nsb_all;
+    return sb * 4 + wave;
+  };
+  // Weight fragments: wave-uniform block base in SGPRs + a per-lane byte offset; the immediate field covers +-4 KiB, so four
+  // lane offsets (lane * 16 + 4096 + 8192 k) reach the 32 items of a block.  The loads are inline asm so that their ORDER is
+  // ours: hipcc otherwise sinks each load to a few MFMAs before its use and the L2 latency lands on the MFMA pipe
+  // (one wave per SIMD: nobody else to hide it).  Every use goes through pk_wait, which ties the counted s_waitcnt to the
+  // register it protects.
+  const uint32_t voff0 = lane * 16 + 4096, voff1 = voff0 + 8192, voff2 = voff0 + 16384, voff3 = voff0 + 24576;
+  const uint32_t boff = g * 32;
+#define PK_VOFF(q) ((q) < 8 ? voff0 : (q) < 16 ? voff1 : (q) < 24 ? voff2 : voff3)
+#define PK_LOAD(dst, base, q)                                                                                    \
+  if constexpr (!(ABL & 2)) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(PK_VOFF(q)), "s"(base), "n"((((q) & 7) - 4) * 1024) \
+               : "memory")
+#define PK_LOAD0(dst, base, q)                                                                                   \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(PK_VOFF(q)), "s"(base), "n"((((q) & 7) - 4) * 1024) \
+               : "memory")
+#define PK_WAIT(reg, n) if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n) : "memory")
+  // The 256 O accumulators fill the AGPR half of the register file; hipcc gives every MFMA builtin of a kernel the AGPR form,
+  // so S tiles written with the builtin are shuttled through v_accvgpr moves around every block (measured: 240 moves per 128
+  // MFMAs).  The S products are therefore inline asm in VGPR form.  Their hazards are ours: dependent MFMAs on one S tile are
+  // 8 MFMAs apart (no wait states needed); the VALU read after the last one is covered by the s_nop in PK_S_DONE.
+#define PK_MFMA_S0(acc, wf, af) \
+  do { if constexpr (ABL & 4) { acc = f32x4{0.f, 0.f, 0.f, 0.f}; asm("" : "+v"(acc) : "v"(wf), "v"(af)); } else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(wf), "v"(af)); } while (0)
+#define PK_MFMA_S(acc, wf, af) \
+  do { if constexpr (ABL & 4) asm("" : "+v"(acc) : "v"(wf), "v"(af)); else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af)); } while (0)
+  // The O products are asm as well, with the accumulator TIED ("+a"): with all 256 AGPRs live the register allocator otherwise
+  // gives vdst and srcC of the builtin different registers and permutes the accumulators with copies on every iteration.
+#define PK_MFMA_O(acc, wf, hf) \
+  do { if constexpr (ABL & 4) asm("" : "+a"(acc) : "v"(wf), "v"(hf)); else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wf), "v"(hf)); } while (0)
+
+  f32x4 O[16][4];
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) O[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 ring[16];
+  f32x4 b1lo, b1hi;
+  int hb = block_of(0);
+  const char* cur = reinterpret_cast<const char*>(p.wp) + (int64_t)hb * (kPkItems * 1024);
+  {
+    const float* bsrc = p.b1 + hb * kPkBlock;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b1lo) : "v"(boff), "s"(bsrc) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b1hi) : "v"(boff), "s"(bsrc) : "memory");
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) PK_LOAD0(ring[q], cur, q);
+  if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // Outstanding loads, oldest first, when item i of a phase is consumed:
+  //   product 1: W1[i..15] of this block, then W2[0..i-1] issued so far                      -> vmcnt(15)
+  //   Swish    : b1 was issued before W1 of this block; W2[0..15] are younger                -> vmcnt(16)
+  //   product 2: W2[i..15], the two b1 loads of the next block, W1'[0..i-1] of the next one  -> vmcnt(17)
+  for (int ci = 0; ci < nsb; ++ci) {
+    const int hb_next = block_of(ci + 1 < nsb ? ci + 1 : 0);  // the last step re-fetches a valid block (never used)
+    const char* nxt = reinterpret_cast<const char*>(p.wp) + (int64_t)hb_next * (kPkItems * 1024);
+
+    // ---- S^T (2 tiles x 4 row tiles) = W1[block] . a^T over K = 256 -----------------------------------------------------
+    f32x4 S[2][4];
+    bf16x8 af[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) af[0][s] = *reinterpret_cast<const bf16x8*>(smem + a_off[s]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          af[(ks + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(smem + (a_off[s] ^ ((ks + 1) << 6)));
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        PK_WAIT(ring[2 * ks + t], 15);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (ks == 0) PK_MFMA_S0(S[t][s], ring[2 * ks + t], af[ks & 1][s]);
+          else PK_MFMA_S(S[t][s], ring[2 * ks + t], af[ks & 1][s]);
+        }
+        PK_LOAD(ring[2 * ks + t], cur, 16 + 2 * ks + t);  // W2 fragment (output tile 2 ks + t) of this block
+      }
+    }
+    // ---- h = swish(S + b1) as the B operand of the second product: lane (c, g) holds k = 8 g + {0..3 (tile 0), 4..7 (tile 1)}
+    PK_WAIT(b1lo, 16);
+    PK_WAIT(b1hi, 16);
+    // MFMA (8 passes) result -> VALU read needs 11+ wait states; the asm MFMAs are invisible to the hazard recogniser
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]),
+                 "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]));
+    bf16x8 hf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 hv = make_uint4(
+          pk_pack_bf16(pk_swish<ABL>(S[0][s][0] + b1lo[0]), pk_swish<ABL>(S[0][s][1] + b1lo[1])),
+          pk_pack_bf16(pk_swish<ABL>(S[0][s][2] + b1lo[2]), pk_swish<ABL>(S[0][s][3] + b1lo[3])),
+          pk_pack_bf16(pk_swish<ABL>(S[1][s][0] + b1hi[0]), pk_swish<ABL>(S[1][s][1] + b1hi[1])),
+          pk_pack_bf16(pk_swish<ABL>(S[1][s][2] + b1hi[2]), pk_swish<ABL>(S[1][s][3] + b1hi[3])));
+      hf[s] = *reinterpret_cast<const bf16x8*>(&hv);
+    }
+    asm volatile("s_nop 3" : "+v"(hf[0]), "+v"(hf[1]), "+v"(hf[2]), "+v"(hf[3]));  // VALU write -> MFMA operand read
+    if constexpr (!(ABL & 2)) {
+      const float* bsrc = p.b1 + hb_next * kPkBlock;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b1lo) : "v"(boff), "s"(bsrc) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b1hi) : "v"(boff), "s"(bsrc) : "memory");
+    }
+    // ---- O^T (16 tiles x 4 row tiles) += W2[:, block] . h^T ---------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      PK_WAIT(ring[j], 17);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) PK_MFMA_O(O[j][s], ring[j], hf[s]);
+      PK_LOAD(ring[j], nxt, j);  // W1 fragment of the next block
+    }
+    cur = nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // drain the ring; last MFMA -> accumulator reads
+#undef PK_MFMA_O
+#undef PK_LOAD
+#undef PK_LOAD0
+#undef PK_MFMA_S0
+#undef PK_MFMA_S
+#undef PK_WAIT
+#undef PK_VOFF
+
+  // ---- cross-wave reduction: wave w ends up with row tile w (its slot 0) ---------------------------------------------------
+  // Exchange slot (owner, k): 16 KiB = [16 j][64 lanes] x float4, written and read with the same lane -> conflict-free.
+  __syncthreads();  // every wave is done reading the activation tile
+  auto xslot = [&](int owner, int k) { return reinterpret_cast<f32x4*>(smem + (owner * 2 + k) * 16384) + lane; };
+  {
+    f32x4* d1 = xslot((wave + 1) & 3, 0);
+    f32x4* d2 = xslot((wave + 2) & 3, 1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      d1[j * 64] = O[j][1];
+      d2[j * 64] = O[j][2];
+    }
+  }
+  __syncthreads();
+  {
+    const f32x4* s1 = xslot(wave, 0);
+    const f32x4* s2 = xslot(wave, 1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) O[j][0] = (O[j][0] + s1[j * 64]) + s2[j * 64];
+  }
+  __syncthreads();
+  {
+    f32x4* d3 = xslot((wave + 3) & 3, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d3[j * 64] = O[j][3];
+  }
+  __syncthreads();
+  {
+    const f32x4* s3 = xslot(wave, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) O[j][0] += s3[j * 64];
+  }
+
+  // ---- epilogue: lane (c, g) holds row m0 + 16 wave + c, features n = 16 j + 4 g + r -------------------------------------
+  const int m = m0 + 16 * wave + c;
+  const bool live = m < p.M;
+  const int mc = live ? m : p.M - 1;
+  float* xrow = p.x + (int64_t)mc * p.ldx + 4 * g;
+  float v[64];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + 16 * j + 4 * g);
+    const float4 xv = *reinterpret_cast<const float4*>(xrow + 16 * j);
+    v[4 * j + 0] = xv.x + p.alpha * (O[j][0][0] + bv.x);
+    v[4 * j + 1] = xv.y + p.alpha * (O[j][0][1] + bv.y);
+    v[4 * j + 2] = xv.z + p.alpha * (O[j][0][2] + bv.z);
+    v[4 * j + 3] = xv.w + p.alpha * (O[j][0][3] + bv.w);
+  }
+  auto store_x = [&]() __attribute__((always_inline)) {
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<float4*>(xrow + 16 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+  };
+  if (p.ln_mode == 0) {
+    store_x();
+    return;
+  }
+  // A row lives in the 4 lanes {c, c + 16, c + 32, c + 48} of one wave: two shuffles, no LDS.
+  auto layer_norm = [&](const float* gam, const float* bet) __attribute__((always_inline)) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) {
+      s += v[e];
+      q += v[e] * v[e];
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float mean = s * (1.0f / 256.0f);
+    const float var = fmaxf(q * (1.0f / 256.0f) - mean * mean, 0.0f);
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float4 gv = *reinterpret_cast<const float4*>(gam + 16 * j + 4 * g);
+      const float4 bv = *reinterpret_cast<const float4*>(bet + 16 * j + 4 * g);
+      v[4 * j + 0] = (v[4 * j + 0] - mean) * rstd * gv.x + bv.x;
+      v[4 * j + 1] = (v[4 * j + 1] - mean) * rstd * gv.y + bv.y;
+      v[4 * j + 2] = (v[4 * j + 2] - mean) * rstd * gv.z + bv.z;
+      v[4 * j + 3] = (v[4 * j + 3] - mean) * rstd * gv.w + bv.w;
+    }
+  };
+  if (p.ln_mode == 1) store_x();  // the un-normalised sum is the new residual stream
+  layer_norm(p.g1, p.be1);
+  if (p.ln_mode == 2) {
+    store_x();  // x <- norm_final(x)  (models/conformer.py:155-156)
+    layer_norm(p.g2, p.be2);
+  }
+  if (!live) return;
+  if (p.ln_out_bf16) {
+    uint16_t* orow = reinterpret_cast<uint16_t*>(p.ln_out) + (int64_t)m * p.ld_ln + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<uint2*>(orow + 16 * j) =
+          make_uint2(pk_pack_bf16(v[4 * j], v[4 * j + 1]), pk_pack_bf16(v[4 * j + 2], v[4 * j + 3]));
+  } else {
+    float* orow = reinterpret_cast<float*>(p.ln_out) + (int64_t)m * p.ld_ln + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<float4*>(orow + 16 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+  }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" int64_t ma_ffn_packed_bytes(int32_t d_model, int32_t hidden) {
+  if (d_model != kPkD || hidden < 128 || hidden % 128 != 0 || hidden > kPkMaxHidden) return MA_ERR_UNSUPPORTED;
+  return (int64_t)2 * d_model * hidden * 2;
+}
+
+extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t d_model, int32_t hidden, void* packed,
+                                        ma_stream_t stream) {
+  if (!w1 || !w2 || !packed) return MA_ERR_INVALID_ARG;
+  if (ma_ffn_packed_bytes(d_model, hidden) < 0) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) | reinterpret_cast<uintptr_t>(packed)) & 15)
+    return MA_ERR_INVALID_ARG;
+  const int64_t total = (int64_t)(hidden / kPkBlock) * kPkItems * 64;
+  MA_LAUNCH(ffn_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+            reinterpret_cast<const uint16_t*>(w1), reinterpret_cast<const uint16_t*>(w2), hidden,
+            reinterpret_cast<uint4*>(packed));
+  return MA_OK;
+}
+
+extern "C" int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed, const float* b1, const float* b2, float* x,
+                                  int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, int32_t ln_mode,
+                                  const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
+                                  void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, ma_stream_t stream) {
+  if (!a || !packed || !b1 || !b2 || !x || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (ma_ffn_packed_bytes(d_model, hidden) < 0) return MA_ERR_UNSUPPORTED;
+  if ((lda & 7) || (ldx & 3) || lda < kPkD || ldx < kPkD) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(b1) |
+       reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(x)) & 15)
+    return MA_ERR_INVALID_ARG;
+  if (ln_mode < 0 || ln_mode > 2) return MA_ERR_INVALID_ARG;
+  if (ln_mode >= 1 && (!gamma1 || !beta1 || !ln_out || ld_ln < kPkD || (ld_ln & 3) ||
+                       ((reinterpret_cast<uintptr_t>(gamma1) | reinterpret_cast<uintptr_t>(beta1) |
+                         reinterpret_cast<uintptr_t>(ln_out)) & 15)))
+    return MA_ERR_INVALID_ARG;
+  if (ln_mode == 2 && (!gamma2 || !beta2 || ((reinterpret_cast<uintptr_t>(gamma2) | reinterpret_cast<uintptr_t>(beta2)) & 15)))
+    return MA_ERR_INVALID_ARG;
+  static int abl = -1;
+  if (abl < 0) {
+    const char* e = getenv("MA_FFNPK_ABLATE");
+    abl = e ? atoi(e) & 7 : 0;
+    const void* fns[8] = {(const void*)&ffn_packed_kernel<0>, (const void*)&ffn_packed_kernel<1>, (const void*)&ffn_packed_kernel<2>,
+                          (const void*)&ffn_packed_kernel<3>, (const void*)&ffn_packed_kernel<4>, (const void*)&ffn_packed_kernel<5>,
+                          (const void*)&ffn_packed_kernel<6>, (const void*)&ffn_packed_kernel<7>};
+    for (int i = 0; i < 8; ++i)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kPkLds) != hipSuccess) return MA_ERR_LAUNCH;
+  }
+  FfnPackedParams p;
+  p.a = reinterpret_cast<const uint16_t*>(a);
+  p.wp = reinterpret_cast<const uint4*>(packed);
+  p.b1 = b1;
+  p.b2 = b2;
+  p.x = x;
+  p.lda = lda;
+  p.ldx = ldx;
+  p.M = (int32_t)M;
+  p.H = hidden;
+  p.alpha = alpha;
+  p.ln_mode = ln_mode;
+  p.ln_out_bf16 = ln_out_bf16;
+  p.g1 = gamma1; p.be1 = beta1; p.g2 = gamma2; p.be2 = beta2;
+  p.ln_out = ln_out;
+  p.ld_ln = ld_ln;
+  p.eps = eps;
+  const dim3 grid((unsigned)((M + kPkRows - 1) / kPkRows));
+  switch (abl) {
+    case 0: MA_LAUNCH(ffn_packed_kernel<0>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 1: MA_LAUNCH(ffn_packed_kernel<1>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 2: MA_LAUNCH(ffn_packed_kernel<2>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 3: MA_LAUNCH(ffn_packed_kernel<3>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 4: MA_LAUNCH(ffn_packed_kernel<4>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 5: MA_LAUNCH(ffn_packed_kernel<5>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 6: MA_LAUNCH(ffn_packed_kernel<6>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    default: MA_LAUNCH(ffn_packed_kernel<7>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+  }
+  return MA_OK;
+}

@@ -71,6 +71,40 @@ def ffn_ln(a, w1, b1, w2, b2, x, g1, be1, g2=None, be2=None, alpha=0.5, eps=1e-5
     return out
 
 
+def ffn_pack_weights(w1, w2):
+    """Fragment-ordered packed copy of (w1 (hidden, 256), w2 (256, hidden)) bf16 for ffn_packed; redo after a weight update."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert w1.dtype == t.bfloat16 and w2.dtype == t.bfloat16 and w1.is_contiguous() and w2.is_contiguous()
+    hidden, d = w1.shape
+    assert tuple(w2.shape) == (d, hidden)
+    nbytes = lib.ma_ffn_packed_bytes(d, hidden)
+    _lib.check(min(nbytes, 0), "ffn_packed_bytes")
+    packed = t.empty((nbytes // 2,), dtype=t.bfloat16, device=w1.device)
+    _lib.check(lib.ma_ffn_pack_weights_bf16(_host.ptr(w1), _host.ptr(w2), d, hidden, _host.ptr(packed),
+                                            _host.current_stream_ptr()), "ffn_pack_weights_bf16")
+    return packed
+
+
+def ffn_packed(a, packed, b1, b2, x, g1=None, be1=None, g2=None, be2=None, alpha=0.5, eps=1e-5, out_dtype=None):
+    """ffn / ffn_ln on packed weights (ffn_pack_weights).  g1 None: x += alpha * FFN(a) in place, returns x.
+    Otherwise as ffn_ln: returns the LayerNorm output (bf16 default)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and x.dtype == t.float32 and a.stride(1) == 1 and x.stride(1) == 1
+    m, d = a.shape
+    hidden = b1.numel()
+    mode = 0 if g1 is None else (2 if g2 is not None else 1)
+    out_dtype = out_dtype or t.bfloat16
+    out = t.empty((m, d), dtype=out_dtype, device=a.device) if mode else None
+    rc = lib.ma_ffn_packed_bf16(_host.ptr(a), a.stride(0), _host.ptr(packed), _host.ptr(b1), _host.ptr(b2), _host.ptr(x),
+                                x.stride(0), m, d, hidden, float(alpha), mode, _opt(g1), _opt(be1), _opt(g2), _opt(be2),
+                                float(eps), _opt(out), out.stride(0) if mode else 0,
+                                1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    _lib.check(rc, "ffn_packed_bf16")
+    return out if mode else x
+
+
 def ffn128(a, w1, b1, w2, b2, x, partial, alpha=0.5):
     """128-row formulation: x += alpha * (half-0 product + b2) in place, partial (M, 256) f32 = alpha * half-1 product;
     the caller's next LayerNorm adds `partial` back (layernorm(..., addend=partial) / layernorm2(..., addend=partial))."""

@@ -237,6 +237,59 @@ def test_ffn_fused128_and_layernorm_add(t, m, hidden):
     assert float((out2.double().cpu() - ln(y1, g2, be2)).abs().max()) <= 3e-2
 
 
+@pytest.mark.parametrize("m,hidden,mode", [(64, 128, 0), (250, 2048, 0), (15936, 2048, 1), (7968, 2048, 2), (64 * 3 + 1, 256, 2),
+                                           (100, 512, 1), (1, 2048, 0)])
+def test_ffn_packed(t, m, hidden, mode):
+    """Hidden-slice-owner FFN on fragment-packed weights: same contract as ffn / ffn_ln."""
+    from mindaudio_amd import ops
+
+    d = 256
+    a = _rand(t, m, d, seed=90).bfloat16()
+    w1 = _rand(t, hidden, d, seed=91, scale=1.0 / 16).bfloat16()
+    b1 = _rand(t, hidden, seed=92, scale=0.3)
+    w2 = _rand(t, d, hidden, seed=93, scale=1.0 / math.sqrt(hidden)).bfloat16()
+    b2 = _rand(t, d, seed=94, scale=0.3)
+    x = _rand(t, m, d, seed=95) * 3 + 0.5
+    g1, be1 = 1 + 0.1 * _rand(t, d, seed=96), 0.1 * _rand(t, d, seed=97)
+    g2, be2 = 1 + 0.1 * _rand(t, d, seed=98), 0.1 * _rand(t, d, seed=99)
+    z = a.double() @ w1.double().T + b1.double()
+    h = (z * t.sigmoid(z)).bfloat16().double()
+    xs = x.double() + 0.5 * (h @ w2.double().T + b2.double())
+
+    def ln(v, g, b):
+        mu = v.mean(-1, keepdim=True)
+        return (v - mu) / t.sqrt(((v - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * g.double() + b.double()
+
+    packed = ops.ffn_pack_weights(w1.cuda(), w2.cuda())
+    assert packed.numel() == 2 * d * hidden
+    # the packing is a permutation of the weights
+    assert t.equal(packed.view(t.int16).sort().values.cpu(), t.cat((w1.flatten(), w2.flatten())).view(t.int16).sort().values)
+    xg = x.clone().cuda()
+    tol = 3e-3 * float(xs.abs().max())
+    if mode == 0:
+        r = ops.ffn_packed(a.cuda(), packed, b1.cuda(), b2.cuda(), xg, alpha=0.5)
+        assert r is xg and float((xg.double().cpu() - xs).abs().max()) <= tol
+        return
+    if mode == 1:
+        out = ops.ffn_packed(a.cuda(), packed, b1.cuda(), b2.cuda(), xg, g1.cuda(), be1.cuda(), out_dtype=t.float32)
+        assert float((xg.double().cpu() - xs).abs().max()) <= tol
+        assert float((out.double().cpu() - ln(xs, g1, be1)).abs().max()) <= 2e-2
+    else:
+        out = ops.ffn_packed(a.cuda(), packed, b1.cuda(), b2.cuda(), xg, g1.cuda(), be1.cuda(), g2.cuda(), be2.cuda(),
+                             out_dtype=t.float32)
+        y1 = ln(xs, g1, be1)
+        assert float((xg.double().cpu() - y1).abs().max()) <= 2e-2
+        assert float((out.double().cpu() - ln(y1, g2, be2)).abs().max()) <= 3e-2
+    outb = ops.ffn_packed(a.cuda(), packed, b1.cuda(), b2.cuda(), x.clone().cuda(), g1.cuda(), be1.cuda(),
+                          *((g2.cuda(), be2.cuda()) if mode == 2 else ()))
+    assert outb.dtype == t.bfloat16 and float((outb.float().cpu().double() - out.double().cpu()).abs().max()) <= 3e-2
+    # run-to-run determinism (fixed reduction order across the four waves)
+    xg2 = x.clone().cuda()
+    ops.ffn_packed(a.cuda(), packed, b1.cuda(), b2.cuda(), xg2, g1.cuda(), be1.cuda(), *((g2.cuda(), be2.cuda()) if mode == 2 else ()),
+                   out_dtype=t.float32)
+    assert t.equal(xg2, xg)
+
+
 @pytest.mark.parametrize("m,hidden,mode", [(250, 2048, 1), (7968, 2048, 2), (64 * 3 + 1, 256, 2), (100, 512, 1)])
 def test_ffn_fused_layernorm_epilogue(t, m, hidden, mode):
     from mindaudio_amd import ops

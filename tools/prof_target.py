@@ -28,6 +28,12 @@ elif what == "ffn128":
     w2 = (torch.randn(256, 2048, device="cuda") / 45).bfloat16(); b2 = torch.randn(256, device="cuda"); xx = torch.randn(m, 256, device="cuda")
     part = torch.empty(m, 256, device="cuda")
     for _ in range(n): ops.ffn128(a, w1, b1, w2, b2, xx, part)
+elif what == "ffnpk":
+    m = B * 249
+    a = torch.randn(m, 256, device="cuda").bfloat16(); w1 = (torch.randn(2048, 256, device="cuda") / 16).bfloat16(); b1 = torch.randn(2048, device="cuda")
+    w2 = (torch.randn(256, 2048, device="cuda") / 45).bfloat16(); b2 = torch.randn(256, device="cuda"); xx = torch.randn(m, 256, device="cuda")
+    pk = ops.ffn_pack_weights(w1, w2)
+    for _ in range(n): ops.ffn_packed(a, pk, b1, b2, xx)
 elif what == "attn":
     T = 249
     qkv = (torch.randn(B * T, 768, device="cuda") * 0.5).bfloat16(); pos = (torch.randn(T, 256, device="cuda") * 0.5).bfloat16()

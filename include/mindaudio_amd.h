@@ -514,7 +514,7 @@ int ma_ffn_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, 
  * 147-156), but W1 / W2 are taken in the fragment-ordered packed form that lets them stream L2 -> registers without an LDS
  * stage.  Pack once per weight update:
  *   ma_ffn_packed_bytes(d_model, hidden) -> bytes of the packed buffer (negative: unsupported shape; d_model = 256,
- *                                           hidden % 128 == 0);
+ *                                           hidden % 256 == 0);
  *   ma_ffn_pack_weights_bf16(w1 (hidden, d_model) bf16, w2 (d_model, hidden) bf16, ..., packed).
  * ma_ffn_packed_bf16: ln_mode 0 = no LayerNorm (gamma/beta/ln_out ignored), 1 / 2 as ma_ffn_ln_bf16. */
 int64_t ma_ffn_packed_bytes(int32_t d_model, int32_t hidden);

@@ -22,6 +22,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/mindaudio_amd.h"
 
 #define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
@@ -36,7 +39,18 @@ namespace ma {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+template <int... Is, class F>
+__device__ __forceinline__ void pk_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// compile-time loop: every index inside f is a constant expression, so register arrays never need dynamic indexing
+template <int N, class F>
+__device__ __forceinline__ void pk_static_for(F&& f) {
+  pk_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
 constexpr int kPkRows = 64, kPkD = 256, kPkThreads = 256;
+constexpr int kPkPitch = 544;                // LDS row pitch of the activation tile (bytes)
 constexpr int kPkBlock = 32;                  // hidden units per (wave, step)
 constexpr int kPkItems = 32;                  // 1 KiB fragments per block: 16 of W1 (k-step, tile), 16 of W2 (output tile)
 constexpr int kPkLds = 128 * 1024;            // a tile (32 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
@@ -102,7 +116,9 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   const int c = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * kPkRows;
 
-  // ---- activation tile -> LDS: [64 rows][512 B], 16-byte chunk index XORed with (row & 15) --------------------------------
+  // ---- activation tile -> LDS: [64 rows][544 B] (512 + 32 of padding).  A ds_read_b128 serves lanes in groups of 16
+  // ({0-3,12-15,20-27}, ...); with this pitch the 16-byte slot of lane (c, g) is (2 c + g + 4 ks) mod 16, distinct inside every
+  // group, and the k-step is a plain +64 B immediate offset (an XOR swizzle costs an address register per k-step) -------------
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int idx = it * kPkThreads + tid;
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     int m = m0 + row;
     if (m >= p.M) m = p.M - 1;
     const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
-    *reinterpret_cast<uint4*>(smem + row * 512 + ((ch ^ (row & 15)) << 4)) = v;
+    *reinterpret_cast<uint4*>(smem + row * kPkPitch + ch * 16) = v;
   }
   __syncthreads();
 
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // accumulator indices stay compile-time constants.
   int a_off[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) a_off[s] = (16 * ((s + wave) & 3) + c) * 512 + ((g ^ c) << 4);
+  for (int s = 0; s < 4; ++s) a_off[s] = (16 * ((s + wave) & 3) + c) * kPkPitch + g * 16;
 
   const int nsb_all = p.H >> 7;
   const int nsb = ABL == 7 && p.alpha == 0.25f ? 0 : nsb_all;  // (ablation 7 with alpha 0.25: no main loop at all)
@@ -130,32 +146,49 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     return sb * 4 + wave;
   };
   // Weight fragments: wave-uniform block base in SGPRs + a per-lane byte offset; the immediate field covers +-4 KiB, so four
-  // lane offsets (lane * 16 + 4096 + 8192 k) reach the 32 items of a block.  The loads are inline asm so that their ORDER is
-  // ours: hipcc otherwise sinks each load to a few MFMAs before its use and the L2 latency lands on the MFMA pipe
-  // (one wave per SIMD: nobody else to hide it).  Every use goes through pk_wait, which ties the counted s_waitcnt to the
-  // register it protects.
+  // lane offsets (lane * 16 + 4096 + 8192 k) reach the 32 items of a block.  Loads, waits and MFMAs are inline asm and every
+  // MFMA slot ends in a sched_barrier, so the instruction ORDER is the source order: hipcc otherwise sinks each load to a few
+  // MFMAs before its use, and it cannot interleave VALU work with MFMAs it does not see.  PK_WAIT ties the counted s_waitcnt
+  // to the register it protects.
   const uint32_t voff0 = lane * 16 + 4096, voff1 = voff0 + 8192, voff2 = voff0 + 16384, voff3 = voff0 + 24576;
   const uint32_t boff = g * 32;
 #define PK_VOFF(q) ((q) < 8 ? voff0 : (q) < 16 ? voff1 : (q) < 24 ? voff2 : voff3)
 #define PK_LOAD(dst, base, q)                                                                                    \
-  if constexpr (!(ABL & 2)) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(PK_VOFF(q)), "s"(base), "n"((((q) & 7) - 4) * 1024) \
-               : "memory")
-#define PK_LOAD0(dst, base, q)                                                                                   \
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(PK_VOFF(q)), "s"(base), "n"((((q) & 7) - 4) * 1024) \
-               : "memory")
-#define PK_WAIT(reg, n) if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n) : "memory")
-  // The 256 O accumulators fill the AGPR half of the register file; hipcc gives every MFMA builtin of a kernel the AGPR form,
-  // so S tiles written with the builtin are shuttled through v_accvgpr moves around every block (measured: 240 moves per 128
-  // MFMAs).  The S products are therefore inline asm in VGPR form.  Their hazards are ours: dependent MFMAs on one S tile are
-  // 8 MFMAs apart (no wait states needed); the VALU read after the last one is covered by the s_nop in PK_S_DONE.
-#define PK_MFMA_S0(acc, wf, af) \
-  do { if constexpr (ABL & 4) { acc = f32x4{0.f, 0.f, 0.f, 0.f}; asm("" : "+v"(acc) : "v"(wf), "v"(af)); } else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(wf), "v"(af)); } while (0)
-#define PK_MFMA_S(acc, wf, af) \
-  do { if constexpr (ABL & 4) asm("" : "+v"(acc) : "v"(wf), "v"(af)); else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af)); } while (0)
-  // The O products are asm as well, with the accumulator TIED ("+a"): with all 256 AGPRs live the register allocator otherwise
-  // gives vdst and srcC of the builtin different registers and permutes the accumulators with copies on every iteration.
-#define PK_MFMA_O(acc, wf, hf) \
-  do { if constexpr (ABL & 4) asm("" : "+a"(acc) : "v"(wf), "v"(hf)); else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wf), "v"(hf)); } while (0)
+  do {                                                                                                           \
+    if constexpr (!(ABL & 2))                                                                                    \
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                                    \
+                   : "=v"(dst) : "v"(PK_VOFF(q)), "s"(base), "n"((((q) & 7) - 4) * 1024) : "memory");              \
+  } while (0)
+#define PK_LOAD_B1(blk)                                                                                          \
+  do {                                                                                                           \
+    const float* bsrc = p.b1 + (blk) * kPkBlock;                                                                 \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b1lo) : "v"(boff), "s"(bsrc) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b1hi) : "v"(boff), "s"(bsrc) : "memory");     \
+  } while (0)
+#define PK_WAIT(reg, n)                                                                          \
+  do {                                                                                           \
+    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n) : "memory"); \
+  } while (0)
+  // The 256 O accumulators fill the AGPR half of the register file.  hipcc gives every MFMA builtin of a kernel the AGPR form
+  // and, with no AGPR to spare, permutes accumulators with copies on every iteration (measured: 240 v_accvgpr moves per 128
+  // MFMAs).  So: S products in VGPR form, O products with the accumulator tied ("+a").  Hazards that the compiler would have
+  // handled are ours: dependent MFMAs on one tile are >= 8 MFMAs apart; S tiles are read by the VALU a whole phase after their
+  // last MFMA; the VALU-written h fragments get an s_nop before the first O product; the accumulator reads after the loop too.
+#define PK_MFMA_S0(acc, wf, af, bias)                                                                                  \
+  do {                                                                                                                 \
+    if constexpr (ABL & 4) { acc = bias; asm volatile("" : "+v"(acc) : "v"(wf), "v"(af)); }                            \
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(wf), "v"(af), "v"(bias));           \
+  } while (0)
+#define PK_MFMA_S(acc, wf, af)                                                                                         \
+  do {                                                                                                                 \
+    if constexpr (ABL & 4) asm volatile("" : "+v"(acc) : "v"(wf), "v"(af));                                            \
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af));                       \
+  } while (0)
+#define PK_MFMA_O(acc, wf, hf)                                                                                         \
+  do {                                                                                                                 \
+    if constexpr (ABL & 4) asm volatile("" : "+a"(acc) : "v"(wf), "v"(hf));                                            \
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wf), "v"(hf));                       \
+  } while (0)
 
   f32x4 O[16][4];
 #pragma unroll
@@ -163,86 +196,165 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 #pragma unroll
     for (int s = 0; s < 4; ++s) O[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  bf16x8 ring[16];
-  f32x4 b1lo, b1hi;
-  int hb = block_of(0);
-  const char* cur = reinterpret_cast<const char*>(p.wp) + (int64_t)hb * (kPkItems * 1024);
-  {
-    const float* bsrc = p.b1 + hb * kPkBlock;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b1lo) : "v"(boff), "s"(bsrc) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b1hi) : "v"(boff), "s"(bsrc) : "memory");
-  }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) PK_LOAD0(ring[q], cur, q);
-  if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bf16x8 ring[16];   // weight fragments: W1 of block b+1 / W2 of block b / W1 of block b+2 ... rotate through the same 16 slots
+  bf16x8 af[3][4];   // activation fragments of k-step ks live in af[ks % 3]; fetched two k-steps ahead (LDS latency ~200 cycles)
+  f32x4 b1lo, b1hi;  // bias of the block whose first product comes next: b1[8 g + 0..3], b1[8 g + 4..7]
+  f32x4 SA[2][4], SB[2][4];
+  uint32_t hfw[4][4];
+  auto wbase = [&](int ci) { return reinterpret_cast<const char*>(p.wp) + (int64_t)block_of(ci) * (kPkItems * 1024); };
+  auto blk_wrap = [&](int ci) { return ci < nsb_all ? ci : ci - nsb_all; };
 
-  // Outstanding loads, oldest first, when item i of a phase is consumed:
-  //   product 1: W1[i..15] of this block, then W2[0..i-1] issued so far                      -> vmcnt(15)
-  //   Swish    : b1 was issued before W1 of this block; W2[0..15] are younger                -> vmcnt(16)
-  //   product 2: W2[i..15], the two b1 loads of the next block, W1'[0..i-1] of the next one  -> vmcnt(17)
-  for (int ci = 0; ci < nsb; ++ci) {
-    const int hb_next = block_of(ci + 1 < nsb ? ci + 1 : 0);  // the last step re-fetches a valid block (never used)
-    const char* nxt = reinterpret_cast<const char*>(p.wp) + (int64_t)hb_next * (kPkItems * 1024);
-
-    // ---- S^T (2 tiles x 4 row tiles) = W1[block] . a^T over K = 256 -----------------------------------------------------
-    f32x4 S[2][4];
-    bf16x8 af[2][4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) af[0][s] = *reinterpret_cast<const bf16x8*>(smem + a_off[s]);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      if (ks + 1 < 8) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          af[(ks + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(smem + (a_off[s] ^ ((ks + 1) << 6)));
+  // ---- Swish pipeline -------------------------------------------------------------------------------------------------------
+  // h = swish(S) for the 32 values per lane of one block, cut into 68 micro-slots of at most three independent VALU operations:
+  //     element k (= 8 s + 4 t + r of the S tiles):  micro-slot 2k: m = -log2(e) v    2k+1: x = exp2(m)    2k+2: d = 1 + x
+  //                                                  2k+3: r = 1/d                    2k+4: h = v r        2k+5: pack (odd k)
+  // No micro-operation depends on a result younger than one micro-slot.  With one wave per SIMD nothing else hides VALU work, so
+  // the micro-slots ride in the shadow of MFMAs: an MFMA leaves room for about two other instructions, the block has 128 MFMAs,
+  // and the Swish of block b is spread over BOTH products that lie between S(b) and its use: micro-slots 0..31 inside the second
+  // product of block b-1, micro-slots 32..67 inside the first product of block b+1.
+  float tm[32], hh[32];
+  auto micro = [&](auto ic, f32x4 (&So)[2][4]) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (ABL & 1) {
+      if constexpr ((i & 1) && ((i - 1) >> 1) - 2 >= 1 && (((i - 1) >> 1) - 2) % 2 == 1 && ((i - 1) >> 1) - 2 < 32) {
+        constexpr int kp = ((i - 1) >> 1) - 2;
+        hfw[kp >> 3][(kp & 7) >> 1] = pk_pack_bf16(So[((kp - 1) >> 2) & 1][(kp - 1) >> 3][(kp - 1) & 3], So[(kp >> 2) & 1][kp >> 3][kp & 3]);
       }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        PK_WAIT(ring[2 * ks + t], 15);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (ks == 0) PK_MFMA_S0(S[t][s], ring[2 * ks + t], af[ks & 1][s]);
-          else PK_MFMA_S(S[t][s], ring[2 * ks + t], af[ks & 1][s]);
+    } else if constexpr ((i & 1) == 0) {
+      constexpr int k = i >> 1;
+      if constexpr (k < 32) tm[k] = So[(k >> 2) & 1][k >> 3][k & 3] * -1.4426950408889634f;
+      if constexpr (k - 1 >= 0 && k - 1 < 32) tm[k - 1] = 1.0f + tm[k - 1];
+      if constexpr (k - 2 >= 0 && k - 2 < 32) hh[k - 2] = So[((k - 2) >> 2) & 1][(k - 2) >> 3][(k - 2) & 3] * tm[k - 2];
+    } else {
+      constexpr int k = (i - 1) >> 1;
+      if constexpr (k < 32) tm[k] = __builtin_amdgcn_exp2f(tm[k]);
+      if constexpr (k - 1 >= 0 && k - 1 < 32) tm[k - 1] = __builtin_amdgcn_rcpf(tm[k - 1]);
+      constexpr int kp = k - 2;  // pack once both halves of a pair exist: h[kp] was made in micro-slot 2 kp + 4 = i - 1
+      if constexpr (kp >= 1 && kp < 32 && (kp & 1)) hfw[kp >> 3][(kp & 7) >> 1] = pk_pack_bf16(hh[kp - 1], hh[kp]);
+    }
+  };
+
+  // ---- first product of one block (64 MFMAs): S' = b1 + W1[blk] . a^T; slot i = (ks, t, s) -----------------------------------
+  // `refill` = where ring slot i is re-loaded from once consumed.  With sw_tag: micro-slots 32..67 of the Swish of So.
+  auto product1 = [&](auto sw_tag, auto wait_tag, f32x4 (&Sn)[2][4], f32x4 (&So)[2][4], const char* refill, auto item0_tag,
+                      f32x4& blo, f32x4& bhi)
+                      __attribute__((always_inline)) {
+    constexpr bool kSw = decltype(sw_tag)::value;
+    constexpr int kWait = decltype(wait_tag)::value;
+    constexpr int kItem0 = decltype(item0_tag)::value;
+    PK_WAIT(blo, kWait + 1);
+    PK_WAIT(bhi, kWait + 1);
+    pk_static_for<64>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int ks = i >> 3, t = (i >> 2) & 1, s = i & 3;
+      if constexpr ((i & 7) == 0) {
+        if constexpr (ks <= 5) {
+          pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s2 = decltype(sc)::value;
+            af[(ks + 2) % 3][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2] + ((ks + 2) << 6));
+          });
+        } else if constexpr (ks == 7) {  // k-step 0 of the next block (k-step 1 is fetched in product2)
+          pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s2 = decltype(sc)::value;
+            af[0][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2]);
+          });
         }
-        PK_LOAD(ring[2 * ks + t], cur, 16 + 2 * ks + t);  // W2 fragment (output tile 2 ks + t) of this block
       }
-    }
-    // ---- h = swish(S + b1) as the B operand of the second product: lane (c, g) holds k = 8 g + {0..3 (tile 0), 4..7 (tile 1)}
-    PK_WAIT(b1lo, 16);
-    PK_WAIT(b1hi, 16);
-    // MFMA (8 passes) result -> VALU read needs 11+ wait states; the asm MFMAs are invisible to the hazard recogniser
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]),
-                 "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]));
+      if constexpr (s == 0) PK_WAIT(ring[2 * ks + t], kWait);
+      if constexpr (ks == 0) {
+        if constexpr (t == 0) PK_MFMA_S0(Sn[t][s], ring[2 * ks + t], af[ks % 3][s], blo);
+        else PK_MFMA_S0(Sn[t][s], ring[2 * ks + t], af[ks % 3][s], bhi);
+      } else {
+        PK_MFMA_S(Sn[t][s], ring[2 * ks + t], af[ks % 3][s]);
+      }
+      if constexpr (s == 3) PK_LOAD(ring[2 * ks + t], refill, kItem0 + 2 * ks + t);
+      // 36 micro-slots over 64 MFMAs: slot i carries micro-slot 32 + 9 i / 16 when (9 i) mod 16 < 9
+      if constexpr (kSw && (i * 9) % 16 < 9) micro(std::integral_constant<int, 32 + (i * 9) / 16>{}, So);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // ---- second product of one block (64 MFMAs): O^T (16 tiles x 4 row tiles) += W2[:, blk] . h^T, h from hfw; carries
+  // micro-slots 0..31 of the Swish of Snext (the S tiles the first product has just finished) ------------------------------------
+  auto product2 = [&](const char* refill, int b1_blk, f32x4 (&Snext)[2][4]) __attribute__((always_inline)) {
     bf16x8 hf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const uint4 hv = make_uint4(
-          pk_pack_bf16(pk_swish<ABL>(S[0][s][0] + b1lo[0]), pk_swish<ABL>(S[0][s][1] + b1lo[1])),
-          pk_pack_bf16(pk_swish<ABL>(S[0][s][2] + b1lo[2]), pk_swish<ABL>(S[0][s][3] + b1lo[3])),
-          pk_pack_bf16(pk_swish<ABL>(S[1][s][0] + b1hi[0]), pk_swish<ABL>(S[1][s][1] + b1hi[1])),
-          pk_pack_bf16(pk_swish<ABL>(S[1][s][2] + b1hi[2]), pk_swish<ABL>(S[1][s][3] + b1hi[3])));
+    pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      const uint4 hv = make_uint4(hfw[s][0], hfw[s][1], hfw[s][2], hfw[s][3]);
       hf[s] = *reinterpret_cast<const bf16x8*>(&hv);
-    }
+    });
     asm volatile("s_nop 3" : "+v"(hf[0]), "+v"(hf[1]), "+v"(hf[2]), "+v"(hf[3]));  // VALU write -> MFMA operand read
-    if constexpr (!(ABL & 2)) {
-      const float* bsrc = p.b1 + hb_next * kPkBlock;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b1lo) : "v"(boff), "s"(bsrc) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b1hi) : "v"(boff), "s"(bsrc) : "memory");
-    }
-    // ---- O^T (16 tiles x 4 row tiles) += W2[:, block] . h^T ---------------------------------------------------------------
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    if constexpr (!(ABL & 2)) PK_LOAD_B1(b1_blk);
+    pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s2 = decltype(sc)::value;
+      af[1][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2] + (1 << 6));
+    });
+    pk_static_for<16>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
       PK_WAIT(ring[j], 17);
+      PK_MFMA_O(O[j][0], ring[j], hf[0]);
+      PK_MFMA_O(O[j][1], ring[j], hf[1]);
+      micro(std::integral_constant<int, 2 * j>{}, Snext);
+      __builtin_amdgcn_sched_barrier(0);
+      PK_MFMA_O(O[j][2], ring[j], hf[2]);
+      PK_MFMA_O(O[j][3], ring[j], hf[3]);
+      PK_LOAD(ring[j], refill, j);  // W1 fragment of the block after next
+      micro(std::integral_constant<int, 2 * j + 1>{}, Snext);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // Outstanding loads, oldest first, when a fragment is consumed (steady state):
+  //   product1 of block b+1, item i : W1'[i..15], then W2(b)[0..i-1] issued so far                      -> vmcnt(15)
+  //   its bias (issued before W1') : W1'[0..15] are younger                                             -> vmcnt(16)
+  //   product2 of block b, item j  : W2[j..15], the 2 bias loads of block b+2, W1''[0..j-1]             -> vmcnt(17)
+  //   prologue (product1 of block 0, refilled with W1 of block 1): everything but block 1's bias has landed (counts 17 / 18 hold trivially)
+  if (nsb > 0) {
+    {
+      const char* w0 = wbase(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) PK_MFMA_O(O[j][s], ring[j], hf[s]);
-      PK_LOAD(ring[j], nxt, j);  // W1 fragment of the next block
+      for (int q = 0; q < 16; ++q)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                     : "=v"(ring[q]) : "v"(PK_VOFF(q)), "s"(w0), "n"((((q) & 7) - 4) * 1024) : "memory");
+      if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    cur = nxt;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      af[0][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2]);
+      af[1][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2] + (1 << 6));
+    }
+    // block 0's bias has registers of its own: b1lo / b1hi are already being re-loaded (block 1) while the prologue runs, and an
+    // in-flight register must never be copied
+    f32x4 b0lo, b0hi;
+    {
+      const float* bsrc = p.b1 + block_of(0) * kPkBlock;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b0lo) : "v"(boff), "s"(bsrc) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b0hi) : "v"(boff), "s"(bsrc) : "memory");
+    }
+    if constexpr (!(ABL & 2)) PK_LOAD_B1(block_of(blk_wrap(1)));
+    if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // only block 1's bias pair may stay in flight: the prologue starts with the ring and block 0's bias landed
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(b0lo), "+v"(b0hi)::"memory");
+    product1(std::false_type{}, std::integral_constant<int, 17>{}, SA, SB, wbase(blk_wrap(1)), std::integral_constant<int, 0>{},
+             b0lo, b0hi);
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(SA[0][0]), "+v"(SA[0][1]), "+v"(SA[0][2]), "+v"(SA[0][3]), "+v"(SA[1][0]),
+                 "+v"(SA[1][1]), "+v"(SA[1][2]), "+v"(SA[1][3]));  // MFMA result -> VALU read
+    pk_static_for<32>([&](auto ic) __attribute__((always_inline)) { micro(ic, SA); });  // first half of block 0's Swish, exposed
+    pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {  // (no second product ran to fetch k-step 1)
+      constexpr int s2 = decltype(sc)::value;
+      af[1][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2] + (1 << 6));
+    });
+  }
+  for (int ci = 0; ci < nsb; ci += 2) {
+    // even block ci: its S tiles are in SA; product1 of block ci + 1 fills SB
+    product1(std::true_type{}, std::integral_constant<int, 15>{}, SB, SA, wbase(ci), std::integral_constant<int, 16>{}, b1lo, b1hi);
+    product2(wbase(blk_wrap(ci + 2)), block_of(blk_wrap(ci + 2)), SB);
+    product1(std::true_type{}, std::integral_constant<int, 15>{}, SA, SB, wbase(ci + 1), std::integral_constant<int, 16>{}, b1lo, b1hi);
+    product2(wbase(blk_wrap(ci + 3)), block_of(blk_wrap(ci + 3)), SA);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // drain the ring; last MFMA -> accumulator reads
 #undef PK_MFMA_O
 #undef PK_LOAD
-#undef PK_LOAD0
+#undef PK_LOAD_B1
 #undef PK_MFMA_S0
 #undef PK_MFMA_S
 #undef PK_WAIT
@@ -357,7 +469,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 using namespace ma;
 
 extern "C" int64_t ma_ffn_packed_bytes(int32_t d_model, int32_t hidden) {
-  if (d_model != kPkD || hidden < 128 || hidden % 128 != 0 || hidden > kPkMaxHidden) return MA_ERR_UNSUPPORTED;
+  if (d_model != kPkD || hidden < 256 || hidden % 256 != 0 || hidden > kPkMaxHidden) return MA_ERR_UNSUPPORTED;
   return (int64_t)2 * d_model * hidden * 2;
 }
 

@@ -237,7 +237,7 @@ def test_ffn_fused128_and_layernorm_add(t, m, hidden):
     assert float((out2.double().cpu() - ln(y1, g2, be2)).abs().max()) <= 3e-2
 
 
-@pytest.mark.parametrize("m,hidden,mode", [(64, 128, 0), (250, 2048, 0), (15936, 2048, 1), (7968, 2048, 2), (64 * 3 + 1, 256, 2),
+@pytest.mark.parametrize("m,hidden,mode", [(64, 256, 0), (250, 2048, 0), (15936, 2048, 1), (7968, 2048, 2), (64 * 3 + 1, 256, 2),
                                            (100, 512, 1), (1, 2048, 0)])
 def test_ffn_packed(t, m, hidden, mode):
     """Hidden-slice-owner FFN on fragment-packed weights: same contract as ffn / ffn_ln."""

@@ -172,6 +172,11 @@ class ConformerEncoder(nn.Module):
                 "pw2_w": cm.pointwise_conv2.weight.detach().squeeze(-1).to(bf).contiguous(),
                 "pw2_b": cm.pointwise_conv2.bias.detach().float().contiguous(),
             })
+        # fragment-ordered packed copies of the FFN weights for the hidden-slice-owner kernel (ops.ffn_packed)
+        for W in prep["layers"]:
+            for key in ("ffm", "ff"):
+                w1 = W[key + "_w1"]
+                W[key + "_pk"] = ops.ffn_pack_weights(w1, W[key + "_w2"]) if w1.shape[0] % 256 == 0 and w1.shape[1] == 256 else None
         self._prepared = prep
         self._pos_cache = {}
         return self
@@ -232,12 +237,16 @@ class ConformerEncoder(nn.Module):
         # the second half's partial product back).  Measured at B = 64: the kernel itself is ~7 % faster, but the extra
         # partial-product traffic makes the step 1.5 % slower, so it is off unless MA_FFN128=1 (developer A/B switch).
         use128 = m >= 128 * 100 and os.environ.get("MA_FFN128", "0") == "1"
+        # hidden-slice-owner kernel on packed weights (ffn_packed.hip): 43 us vs 60 us at M = 15936 (MA_FFN_PACKED=0: A/B switch)
+        packed_ffn = os.environ.get("MA_FFN_PACKED", "1") != "0"
         part = torch.empty((m, self.d), dtype=f32, device=x.device) if use128 else None
         a = ops.layernorm(x, self.encoders[0].norm_ff_macaron.gamma, self.encoders[0].norm_ff_macaron.beta)
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
             # x = x + 0.5 * FFN_macaron(LN(x))   (a = LN(x) comes from the previous block's fused LN pair)
             #                                                                      models/conformer.py:109-112
-            if fused_ffn and part is None:  # FFN + the LayerNorm in front of the attention in one kernel
+            if fused_ffn and part is None and packed_ffn and W["ffm_pk"] is not None:
+                a = ops.ffn_packed(a, W["ffm_pk"], W["ffm_b1"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
+            elif fused_ffn and part is None:  # FFN + the LayerNorm in front of the attention in one kernel
                 a = ops.ffn_ln(a, W["ffm_w1"], W["ffm_b1"], W["ffm_w2"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
             else:
                 add = self._ffn(a, W, "ffm", x, fused_ffn, part)
@@ -257,8 +266,12 @@ class ConformerEncoder(nn.Module):
             last = li + 1 == n_layers
             if fused_ffn and part is None:  # FFN + norm_final + the next consumer's LayerNorm in one kernel
                 nxt = self.after_norm if last else self.encoders[li + 1].norm_ff_macaron
-                y = ops.ffn_ln(a, W["ff_w1"], W["ff_b1"], W["ff_w2"], W["ff_b2"], x, l.norm_final.gamma, l.norm_final.beta,
-                               nxt.gamma, nxt.beta, out_dtype=f32 if last else None)
+                if packed_ffn and W["ff_pk"] is not None:
+                    y = ops.ffn_packed(a, W["ff_pk"], W["ff_b1"], W["ff_b2"], x, l.norm_final.gamma, l.norm_final.beta,
+                                       nxt.gamma, nxt.beta, out_dtype=f32 if last else None)
+                else:
+                    y = ops.ffn_ln(a, W["ff_w1"], W["ff_b1"], W["ff_w2"], W["ff_b2"], x, l.norm_final.gamma,
+                                   l.norm_final.beta, nxt.gamma, nxt.beta, out_dtype=f32 if last else None)
                 if last:
                     x = y
                 else:

@@ -34,6 +34,12 @@ elif what == "ffnpk":
     w2 = (torch.randn(256, 2048, device="cuda") / 45).bfloat16(); b2 = torch.randn(256, device="cuda"); xx = torch.randn(m, 256, device="cuda")
     pk = ops.ffn_pack_weights(w1, w2)
     for _ in range(n): ops.ffn_packed(a, pk, b1, b2, xx)
+elif what == "ffnpkln":  # the form the encoder launches: FFN + residual + LayerNorm (bf16 out)
+    m = B * 249
+    a = torch.randn(m, 256, device="cuda").bfloat16(); w1 = (torch.randn(2048, 256, device="cuda") / 16).bfloat16(); b1 = torch.randn(2048, device="cuda")
+    w2 = (torch.randn(256, 2048, device="cuda") / 45).bfloat16(); b2 = torch.randn(256, device="cuda"); xx = torch.randn(m, 256, device="cuda")
+    pk = ops.ffn_pack_weights(w1, w2); g = torch.ones(256, device="cuda"); be = torch.zeros(256, device="cuda")
+    for _ in range(n): ops.ffn_packed(a, pk, b1, b2, xx, g, be)
 elif what == "attn":
     T = 249
     qkv = (torch.randn(B * T, 768, device="cuda") * 0.5).bfloat16(); pos = (torch.randn(T, 256, device="cuda") * 0.5).bfloat16()

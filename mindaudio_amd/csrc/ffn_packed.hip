@@ -53,7 +53,8 @@ constexpr int kPkRows = 64, kPkD = 256, kPkThreads = 256;
 constexpr int kPkPitch = 544;                // LDS row pitch of the activation tile (bytes)
 constexpr int kPkBlock = 32;                  // hidden units per (wave, step)
 constexpr int kPkItems = 32;                  // 1 KiB fragments per block: 16 of W1 (k-step, tile), 16 of W2 (output tile)
-constexpr int kPkLds = 128 * 1024;            // a tile (32 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
+constexpr int kPkOffPar = 128 * 1024;         // b2, gamma1, beta1, gamma2, beta2 (5 x 1 KiB), staged once at kernel start
+constexpr int kPkLds = kPkOffPar + 5 * 1024;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
 constexpr int kPkMaxHidden = 8192;
 
 struct FfnPackedParams {
@@ -127,6 +128,18 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     if (m >= p.M) m = p.M - 1;
     const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
     *reinterpret_cast<uint4*>(smem + row * kPkPitch + ch * 16) = v;
+  }
+  {  // epilogue parameters -> LDS (5 x 256 floats; thread t copies element t of each): no global latency at the tail
+    float* par = reinterpret_cast<float*>(smem + kPkOffPar);
+    par[tid] = p.b2[tid];
+    if (p.ln_mode >= 1) {
+      par[256 + tid] = p.g1[tid];
+      par[512 + tid] = p.be1[tid];
+    }
+    if (p.ln_mode == 2) {
+      par[768 + tid] = p.g2[tid];
+      par[1024 + tid] = p.be2[tid];
+    }
   }
   __syncthreads();
 
@@ -362,6 +375,14 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 
   // ---- cross-wave reduction: wave w ends up with row tile w (its slot 0) ---------------------------------------------------
   // Exchange slot (owner, k): 16 KiB = [16 j][64 lanes] x float4, written and read with the same lane -> conflict-free.
+  // The residual rows this wave will update are fetched first, so that their HBM latency hides under the exchange.
+  const int m = m0 + 16 * wave + c;
+  const bool live = m < p.M;
+  const int mc = live ? m : p.M - 1;
+  float* xrow = p.x + (int64_t)mc * p.ldx + 4 * g;
+  float4 xres[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xres[j] = *reinterpret_cast<const float4*>(xrow + 16 * j);
   __syncthreads();  // every wave is done reading the activation tile
   auto xslot = [&](int owner, int k) { return reinterpret_cast<f32x4*>(smem + (owner * 2 + k) * 16384) + lane; };
   {
@@ -394,15 +415,12 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   }
 
   // ---- epilogue: lane (c, g) holds row m0 + 16 wave + c, features n = 16 j + 4 g + r -------------------------------------
-  const int m = m0 + 16 * wave + c;
-  const bool live = m < p.M;
-  const int mc = live ? m : p.M - 1;
-  float* xrow = p.x + (int64_t)mc * p.ldx + 4 * g;
+  const float* par = reinterpret_cast<const float*>(smem + kPkOffPar) + 4 * g;
   float v[64];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const float4 bv = *reinterpret_cast<const float4*>(p.b2 + 16 * j + 4 * g);
-    const float4 xv = *reinterpret_cast<const float4*>(xrow + 16 * j);
+    const float4 bv = *reinterpret_cast<const float4*>(par + 16 * j);
+    const float4 xv = xres[j];
     v[4 * j + 0] = xv.x + p.alpha * (O[j][0][0] + bv.x);
     v[4 * j + 1] = xv.y + p.alpha * (O[j][0][1] + bv.y);
     v[4 * j + 2] = xv.z + p.alpha * (O[j][0][2] + bv.z);
@@ -435,8 +453,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     const float rstd = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float4 gv = *reinterpret_cast<const float4*>(gam + 16 * j + 4 * g);
-      const float4 bv = *reinterpret_cast<const float4*>(bet + 16 * j + 4 * g);
+      const float4 gv = *reinterpret_cast<const float4*>(gam + 16 * j);  // LDS copies, already offset by 4 g
+      const float4 bv = *reinterpret_cast<const float4*>(bet + 16 * j);
       v[4 * j + 0] = (v[4 * j + 0] - mean) * rstd * gv.x + bv.x;
       v[4 * j + 1] = (v[4 * j + 1] - mean) * rstd * gv.y + bv.y;
       v[4 * j + 2] = (v[4 * j + 2] - mean) * rstd * gv.z + bv.z;
@@ -444,19 +462,29 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     }
   };
   if (p.ln_mode == 1) store_x();  // the un-normalised sum is the new residual stream
-  layer_norm(p.g1, p.be1);
+  layer_norm(par + 256, par + 512);
   if (p.ln_mode == 2) {
     store_x();  // x <- norm_final(x)  (models/conformer.py:155-156)
-    layer_norm(p.g2, p.be2);
+    layer_norm(par + 768, par + 1024);
   }
-  if (!live) return;
   if (p.ln_out_bf16) {
-    uint16_t* orow = reinterpret_cast<uint16_t*>(p.ln_out) + (int64_t)m * p.ld_ln + 4 * g;
+    // A 16-feature tile is 32 B of bf16: storing from the accumulator layout writes 32-byte fragments (measured: +5 us per
+    // launch).  Stage the wave's 16 x 256 tile in its private exchange slot (owner = wave, k = 1: nobody else touches it after
+    // the first exchange round) and write whole 512-byte rows, 16 B per lane.
+    constexpr int kPitch = 528;  // 512 + 16: 16-byte aligned rows, 2-way conflicts at most on the 8-byte writes
+    char* stage = smem + (wave * 2 + 1) * 16384;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      *reinterpret_cast<uint2*>(orow + 16 * j) =
+      *reinterpret_cast<uint2*>(stage + c * kPitch + 32 * j + 8 * g) =
           make_uint2(pk_pack_bf16(v[4 * j], v[4 * j + 1]), pk_pack_bf16(v[4 * j + 2], v[4 * j + 3]));
-  } else {
+    uint16_t* obase = reinterpret_cast<uint16_t*>(p.ln_out) + (int64_t)(m0 + 16 * wave) * p.ld_ln + (lane & 31) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 2 * i + (lane >> 5);
+      const uint4 q = *reinterpret_cast<const uint4*>(stage + r * kPitch + (lane & 31) * 16);
+      if (m0 + 16 * wave + r < p.M) *reinterpret_cast<uint4*>(obase + (int64_t)r * p.ld_ln) = q;
+    }
+  } else if (live) {
     float* orow = reinterpret_cast<float*>(p.ln_out) + (int64_t)m * p.ld_ln + 4 * g;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -501,6 +529,7 @@ extern "C" int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed
                        ((reinterpret_cast<uintptr_t>(gamma1) | reinterpret_cast<uintptr_t>(beta1) |
                          reinterpret_cast<uintptr_t>(ln_out)) & 15)))
     return MA_ERR_INVALID_ARG;
+  if (ln_mode >= 1 && ln_out_bf16 && (ld_ln & 7)) return MA_ERR_UNSUPPORTED;  // 16-byte row stores
   if (ln_mode == 2 && (!gamma2 || !beta2 || ((reinterpret_cast<uintptr_t>(gamma2) | reinterpret_cast<uintptr_t>(beta2)) & 15)))
     return MA_ERR_INVALID_ARG;
   static int abl = -1;

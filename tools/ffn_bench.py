@@ -26,3 +26,5 @@ us = t(lambda: ops.ffn_ln(a, w1, b1, w2, b2, x, g, be)); print("fused+LN   M=%d:
 if os.environ.get("MA_FFNPK_ABLATE") == "7":
     us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, alpha=0.25)); print("packed, no main loop: %.1f us" % us)
 us = t(lambda: ops.ffn_packed(a[:64], pk, b1, b2, x[:64])); print("packed M=64 (launch floor + one workgroup): %.1f us" % us)
+us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, g, be, out_dtype=torch.float32)); print("packed+LN f32 out: %.1f us" % us)
+us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, g, be, g, be)); print("packed+LN2 bf16 out: %.1f us" % us)

@@ -218,37 +218,57 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   auto blk_wrap = [&](int ci) { return ci < nsb_all ? ci : ci - nsb_all; };
 
   // ---- Swish pipeline -------------------------------------------------------------------------------------------------------
-  // h = swish(S) for the 32 values per lane of one block, cut into 68 micro-slots of at most three independent VALU operations:
-  //     element k (= 8 s + 4 t + r of the S tiles):  micro-slot 2k: m = -log2(e) v    2k+1: x = exp2(m)    2k+2: d = 1 + x
-  //                                                  2k+3: r = 1/d                    2k+4: h = v r        2k+5: pack (odd k)
-  // No micro-operation depends on a result younger than one micro-slot.  With one wave per SIMD nothing else hides VALU work, so
-  // the micro-slots ride in the shadow of MFMAs: an MFMA leaves room for about two other instructions, the block has 128 MFMAs,
-  // and the Swish of block b is spread over BOTH products that lie between S(b) and its use: micro-slots 0..31 inside the second
-  // product of block b-1, micro-slots 32..67 inside the first product of block b+1.
+  // h = swish(S) for the 32 values per lane of one block, cut into "nano-slots" that ride one per MFMA:
+  //     element k (= 8 s + 4 t + r of the S tiles):   nano 4k: A  m = -log2(e) v  (+ E of element k-1: h = v r)
+  //                                                   4k+1:    B  x = exp2(m)                      [transcendental]
+  //                                                   4k+2:    C  d = 1 + x       (+ pack of the pair (k-2, k-1) for odd k-1)
+  //                                                   4k+3:    D  r = 1/d                          [transcendental]
+  // An MFMA 16x16x32 occupies the matrix pipe for 16 cycles and takes 4 to issue, so a slot has room for ~12 cycles of other
+  // instructions from this wave (one wave per SIMD: nobody else fills it): a transcendental costs 16, a plain VALU operation 4.
+  // Hence at most ONE transcendental per slot, alternating with the plain slots that also carry the loads / LDS reads / waits.
+  // The Swish of block b runs between S(b) and its use: nano 1..64 in the second product of block b-1, nano 65..128 in the first
+  // product of block b+1 (MFMA slot i of a product carries nano i + 1, which puts the transcendentals on the even slots and
+  // leaves the odd ones for the memory instructions); nano 0 and 129..130 run exposed (three instructions).
   float tm[32], hh[32];
-  auto micro = [&](auto ic, f32x4 (&So)[2][4]) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;
+  auto nano = [&](auto nc, f32x4 (&So)[2][4]) __attribute__((always_inline)) {
+    constexpr int n = decltype(nc)::value;
+    constexpr int k = n >> 2, q = n & 3;
+    auto val = [&](auto kc) __attribute__((always_inline)) -> float {
+      constexpr int kk = decltype(kc)::value;
+      return So[(kk >> 2) & 1][kk >> 3][kk & 3];
+    };
+    // inline asm (volatile): the micro-operations must stay in THEIR slot; hipcc moves plain C++ arithmetic across the
+    // sched_barriers at instruction selection and pairs dependent operations back to back
     if constexpr (ABL & 1) {
-      if constexpr ((i & 1) && ((i - 1) >> 1) - 2 >= 1 && (((i - 1) >> 1) - 2) % 2 == 1 && ((i - 1) >> 1) - 2 < 32) {
-        constexpr int kp = ((i - 1) >> 1) - 2;
-        hfw[kp >> 3][(kp & 7) >> 1] = pk_pack_bf16(So[((kp - 1) >> 2) & 1][(kp - 1) >> 3][(kp - 1) & 3], So[(kp >> 2) & 1][kp >> 3][kp & 3]);
-      }
-    } else if constexpr ((i & 1) == 0) {
-      constexpr int k = i >> 1;
-      if constexpr (k < 32) tm[k] = So[(k >> 2) & 1][k >> 3][k & 3] * -1.4426950408889634f;
-      if constexpr (k - 1 >= 0 && k - 1 < 32) tm[k - 1] = 1.0f + tm[k - 1];
-      if constexpr (k - 2 >= 0 && k - 2 < 32) hh[k - 2] = So[((k - 2) >> 2) & 1][(k - 2) >> 3][(k - 2) & 3] * tm[k - 2];
+      if constexpr (q == 2 && k - 1 >= 1 && k - 1 < 32 && ((k - 1) & 1))
+        hfw[(k - 1) >> 3][((k - 1) & 7) >> 1] = pk_pack_bf16(val(std::integral_constant<int, k - 2>{}), val(std::integral_constant<int, k - 1>{}));
+    } else if constexpr (q == 0) {
+      if constexpr (k < 32)
+        asm volatile("v_mul_f32 %0, 0xbfb8aa3b, %1" : "=v"(tm[k < 32 ? k : 0]) : "v"(val(std::integral_constant<int, k < 32 ? k : 0>{})));
+      if constexpr (k >= 1 && k - 1 < 32)
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(hh[k >= 1 ? k - 1 : 0]) : "v"(val(std::integral_constant<int, k >= 1 ? k - 1 : 0>{})), "v"(tm[k >= 1 ? k - 1 : 0]));
+    } else if constexpr (q == 1) {
+      if constexpr (k < 32) asm volatile("v_exp_f32 %0, %0" : "+v"(tm[k < 32 ? k : 0]));
+    } else if constexpr (q == 2) {
+      if constexpr (k < 32) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(tm[k < 32 ? k : 0]));
+      if constexpr (k - 1 >= 1 && k - 1 < 32 && ((k - 1) & 1))
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hfw[(k - 1) >> 3][((k - 1) & 7) >> 1]) : "v"(hh[k >= 2 ? k - 2 : 0]), "v"(hh[k >= 1 ? k - 1 : 0]));
     } else {
-      constexpr int k = (i - 1) >> 1;
-      if constexpr (k < 32) tm[k] = __builtin_amdgcn_exp2f(tm[k]);
-      if constexpr (k - 1 >= 0 && k - 1 < 32) tm[k - 1] = __builtin_amdgcn_rcpf(tm[k - 1]);
-      constexpr int kp = k - 2;  // pack once both halves of a pair exist: h[kp] was made in micro-slot 2 kp + 4 = i - 1
-      if constexpr (kp >= 1 && kp < 32 && (kp & 1)) hfw[kp >> 3][(kp & 7) >> 1] = pk_pack_bf16(hh[kp - 1], hh[kp]);
+      if constexpr (k < 32) asm volatile("v_rcp_f32 %0, %0" : "+v"(tm[k < 32 ? k : 0]));
     }
   };
+  // activation fragments: asm LDS reads with counted waits of our own (one per k-step instead of hipcc's one per MFMA)
+#define PK_LDS(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define PK_LWAIT(buf, n) \
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(af[buf][0]), "+v"(af[buf][1]), "+v"(af[buf][2]), "+v"(af[buf][3]) : "n"(n) : "memory")
+  uint32_t a_addr[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a_addr[s] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + a_off[s]);
 
   // ---- first product of one block (64 MFMAs): S' = b1 + W1[blk] . a^T; slot i = (ks, t, s) -----------------------------------
-  // `refill` = where ring slot i is re-loaded from once consumed.  With sw_tag: micro-slots 32..67 of the Swish of So.
+  // `refill` = where ring slot i is re-loaded from once consumed.  With sw_tag: nano-slots 65..128 of the Swish of So.
+  // LDS reads of k-step ks + 2 are issued during k-step ks (slots 1 and 5); outstanding at the start of k-step ks: the 4 reads of
+  // k-step ks + 1 (none before k-step 7, whose successor is fetched later) -> lgkmcnt(4), lgkmcnt(0) for k-step 7.
   auto product1 = [&](auto sw_tag, auto wait_tag, f32x4 (&Sn)[2][4], f32x4 (&So)[2][4], const char* refill, auto item0_tag,
                       f32x4& blo, f32x4& bhi)
                       __attribute__((always_inline)) {
@@ -261,17 +281,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       constexpr int i = decltype(ic)::value;
       constexpr int ks = i >> 3, t = (i >> 2) & 1, s = i & 3;
       if constexpr ((i & 7) == 0) {
-        if constexpr (ks <= 5) {
-          pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
-            constexpr int s2 = decltype(sc)::value;
-            af[(ks + 2) % 3][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2] + ((ks + 2) << 6));
-          });
-        } else if constexpr (ks == 7) {  // k-step 0 of the next block (k-step 1 is fetched in product2)
-          pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
-            constexpr int s2 = decltype(sc)::value;
-            af[0][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2]);
-          });
-        }
+        if constexpr (ks == 7) PK_LWAIT(ks % 3, 0);
+        else PK_LWAIT(ks % 3, 4);
       }
       if constexpr (s == 0) PK_WAIT(ring[2 * ks + t], kWait);
       if constexpr (ks == 0) {
@@ -281,13 +292,22 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
         PK_MFMA_S(Sn[t][s], ring[2 * ks + t], af[ks % 3][s]);
       }
       if constexpr (s == 3) PK_LOAD(ring[2 * ks + t], refill, kItem0 + 2 * ks + t);
-      // 36 micro-slots over 64 MFMAs: slot i carries micro-slot 32 + 9 i / 16 when (9 i) mod 16 < 9
-      if constexpr (kSw && (i * 9) % 16 < 9) micro(std::integral_constant<int, 32 + (i * 9) / 16>{}, So);
+      if constexpr ((i & 3) == 1) {  // two LDS reads on each of the k-step's two plain odd slots
+        constexpr int h2 = (i >> 2) & 1;  // first / second pair of row tiles
+        if constexpr (ks <= 5) {
+          PK_LDS(af[(ks + 2) % 3][2 * h2], a_addr[2 * h2], (ks + 2) << 6);
+          PK_LDS(af[(ks + 2) % 3][2 * h2 + 1], a_addr[2 * h2 + 1], (ks + 2) << 6);
+        } else if constexpr (ks == 7) {  // k-step 0 of the next block (k-step 1 is fetched in product2)
+          PK_LDS(af[0][2 * h2], a_addr[2 * h2], 0);
+          PK_LDS(af[0][2 * h2 + 1], a_addr[2 * h2 + 1], 0);
+        }
+      }
+      if constexpr (kSw) nano(std::integral_constant<int, 65 + i>{}, So);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
   // ---- second product of one block (64 MFMAs): O^T (16 tiles x 4 row tiles) += W2[:, blk] . h^T, h from hfw; carries
-  // micro-slots 0..31 of the Swish of Snext (the S tiles the first product has just finished) ------------------------------------
+  // nano-slots 1..64 of the Swish of Snext (the S tiles the first product has just finished) -------------------------------------
   auto product2 = [&](const char* refill, int b1_blk, f32x4 (&Snext)[2][4]) __attribute__((always_inline)) {
     bf16x8 hf[4];
     pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
@@ -295,25 +315,31 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       const uint4 hv = make_uint4(hfw[s][0], hfw[s][1], hfw[s][2], hfw[s][3]);
       hf[s] = *reinterpret_cast<const bf16x8*>(&hv);
     });
+    nano(std::integral_constant<int, 0>{}, Snext);
     asm volatile("s_nop 3" : "+v"(hf[0]), "+v"(hf[1]), "+v"(hf[2]), "+v"(hf[3]));  // VALU write -> MFMA operand read
     if constexpr (!(ABL & 2)) PK_LOAD_B1(b1_blk);
-    pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
-      constexpr int s2 = decltype(sc)::value;
-      af[1][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2] + (1 << 6));
-    });
     pk_static_for<16>([&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
       PK_WAIT(ring[j], 17);
       PK_MFMA_O(O[j][0], ring[j], hf[0]);
+      nano(std::integral_constant<int, 4 * j + 1>{}, Snext);
+      __builtin_amdgcn_sched_barrier(0);
       PK_MFMA_O(O[j][1], ring[j], hf[1]);
-      micro(std::integral_constant<int, 2 * j>{}, Snext);
+      if constexpr (j < 4) PK_LDS(af[1][j], a_addr[j], 1 << 6);  // k-step 1 of the next first product
+      nano(std::integral_constant<int, 4 * j + 2>{}, Snext);
       __builtin_amdgcn_sched_barrier(0);
       PK_MFMA_O(O[j][2], ring[j], hf[2]);
+      nano(std::integral_constant<int, 4 * j + 3>{}, Snext);
+      __builtin_amdgcn_sched_barrier(0);
       PK_MFMA_O(O[j][3], ring[j], hf[3]);
       PK_LOAD(ring[j], refill, j);  // W1 fragment of the block after next
-      micro(std::integral_constant<int, 2 * j + 1>{}, Snext);
+      nano(std::integral_constant<int, 4 * j + 4>{}, Snext);
       __builtin_amdgcn_sched_barrier(0);
     });
+  };
+  auto swish_drain = [&](f32x4 (&So)[2][4]) __attribute__((always_inline)) {
+    nano(std::integral_constant<int, 129>{}, So);
+    nano(std::integral_constant<int, 130>{}, So);
   };
 
   // Outstanding loads, oldest first, when a fragment is consumed (steady state):
@@ -330,11 +356,14 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
                      : "=v"(ring[q]) : "v"(PK_VOFF(q)), "s"(w0), "n"((((q) & 7) - 4) * 1024) : "memory");
       if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      af[0][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2]);
-      af[1][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2] + (1 << 6));
-    }
+    PK_LDS(af[0][0], a_addr[0], 0);
+    PK_LDS(af[0][1], a_addr[1], 0);
+    PK_LDS(af[0][2], a_addr[2], 0);
+    PK_LDS(af[0][3], a_addr[3], 0);
+    PK_LDS(af[1][0], a_addr[0], 1 << 6);
+    PK_LDS(af[1][1], a_addr[1], 1 << 6);
+    PK_LDS(af[1][2], a_addr[2], 1 << 6);
+    PK_LDS(af[1][3], a_addr[3], 1 << 6);
     // block 0's bias has registers of its own: b1lo / b1hi are already being re-loaded (block 1) while the prologue runs, and an
     // in-flight register must never be copied
     f32x4 b0lo, b0hi;
@@ -351,21 +380,26 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
              b0lo, b0hi);
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(SA[0][0]), "+v"(SA[0][1]), "+v"(SA[0][2]), "+v"(SA[0][3]), "+v"(SA[1][0]),
                  "+v"(SA[1][1]), "+v"(SA[1][2]), "+v"(SA[1][3]));  // MFMA result -> VALU read
-    pk_static_for<32>([&](auto ic) __attribute__((always_inline)) { micro(ic, SA); });  // first half of block 0's Swish, exposed
-    pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {  // (no second product ran to fetch k-step 1)
-      constexpr int s2 = decltype(sc)::value;
-      af[1][s2] = *reinterpret_cast<const bf16x8*>(smem + a_off[s2] + (1 << 6));
-    });
+    pk_static_for<65>([&](auto nc) __attribute__((always_inline)) { nano(nc, SA); });  // first half of block 0's Swish, exposed
+    // (no second product ran to fetch k-step 1)
+    PK_LDS(af[1][0], a_addr[0], 1 << 6);
+    PK_LDS(af[1][1], a_addr[1], 1 << 6);
+    PK_LDS(af[1][2], a_addr[2], 1 << 6);
+    PK_LDS(af[1][3], a_addr[3], 1 << 6);
   }
   for (int ci = 0; ci < nsb; ci += 2) {
     // even block ci: its S tiles are in SA; product1 of block ci + 1 fills SB
     product1(std::true_type{}, std::integral_constant<int, 15>{}, SB, SA, wbase(ci), std::integral_constant<int, 16>{}, b1lo, b1hi);
+    swish_drain(SA);
     product2(wbase(blk_wrap(ci + 2)), block_of(blk_wrap(ci + 2)), SB);
     product1(std::true_type{}, std::integral_constant<int, 15>{}, SA, SB, wbase(ci + 1), std::integral_constant<int, 16>{}, b1lo, b1hi);
+    swish_drain(SB);
     product2(wbase(blk_wrap(ci + 3)), block_of(blk_wrap(ci + 3)), SA);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // drain the ring; last MFMA -> accumulator reads
 #undef PK_MFMA_O
+#undef PK_LDS
+#undef PK_LWAIT
 #undef PK_LOAD
 #undef PK_LOAD_B1
 #undef PK_MFMA_S0

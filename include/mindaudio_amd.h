@@ -509,6 +509,16 @@ int ma_ffn_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, 
                    const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
                    void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, ma_stream_t stream);
 
+/* Dense / k=1 Conv1d with K = 256 inputs (linear_q/k/v/out: layers/attention.py:51-56; pointwise_conv1/2:
+ * layers/convolution.py:52-78) on a fragment-ordered packed copy of W (gemm_k256.hip): same result as ma_gemm_bf16.
+ *   ma_gemm_k256_packed_bytes(N, K) -> bytes of the packed buffer (negative: unsupported; K = 256, N % 256 == 0);
+ *   ma_gemm_k256_pack_bf16(W (N, K) bf16 row stride ldw, ..., packed): once per weight update;
+ *   ma_gemm_k256_packed_bf16: epilogue as ma_gemm_bf16 without col_scale / col_shift / act2, act in {0, 1 swish, 2 relu}. */
+int64_t ma_gemm_k256_packed_bytes(int64_t N, int64_t K);
+int ma_gemm_k256_pack_bf16(const void* W, int64_t ldw, int64_t N, int64_t K, void* packed, ma_stream_t stream);
+int ma_gemm_k256_packed_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N,
+                             int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream);
+
 /* Fused feed-forward, "hidden-slice owner" form (ffn_packed.hip): same contract as ma_ffn_bf16 / ma_ffn_ln_bf16
  * (mindaudio/models/layers/positionwise_feed_forward.py:33-46 + the residual and LayerNorms of models/conformer.py:109-112,
  * 147-156), but W1 / W2 are taken in the fragment-ordered packed form that lets them stream L2 -> registers without an LDS

@@ -1,0 +1,207 @@
+// Dense / pointwise-Conv1d layers with K = 256 input features (the Conformer's d_model): linear_q/k/v, linear_out
+// (mindaudio/models/layers/attention.py:51-56), pointwise_conv1/2 (layers/convolution.py:52-78):
+//
+//     out[m, n] = epilogue( sum_k a[m, k] W[n, k] )                 a (M, 256) bf16, W (N, 256) bf16, N % 256 == 0
+//
+// The general kernel (gemm_bf16.hip) tiles K and streams both operands through an LDS ring; with only 4 k-tiles its time is
+// all prologue/epilogue latency (16-19 us for 2 GFLOP at M = 15936).  Here, as in ffn_packed.hip:
+//   * a workgroup (4 waves) owns 64 rows x 256 output columns; the 64 x 256 activation tile is staged in LDS once (the only
+//     barrier); a wave owns 64 of the columns against all 64 rows, so every weight fragment is used by exactly one wave and
+//     goes L2 -> registers directly, from a fragment-ordered packed copy of W (ma_gemm_k256_pack_bf16; one 1 KiB coalesced
+//     load per fragment, all 32 of a wave in flight at once while the activation tile lands);
+//   * 128 MFMA 16x16x32 per wave, 16 accumulator tiles (64 registers), two workgroups per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int kG2K = 256, kG2Cols = 256, kG2Threads = 256;
+constexpr int kG2Pitch = 544;  // LDS row pitch of the activation tile: conflict-free ds_read_b128 (see ffn_packed.hip)
+
+struct GemmK256Params {
+  const uint16_t* a;   // (M, 256) bf16
+  const uint4* wp;     // packed W: [N / 16 tiles][8 k-steps][64 lanes] x 16 B
+  void* out;           // (M, N) float32 or bf16
+  const float* bias;
+  const float* residual;
+  const float* row_scale;
+  int64_t lda, ldo, ldr;
+  int32_t M, N;
+  float alpha;
+  int32_t act, out_bf16;
+};
+
+__device__ __forceinline__ uint32_t g2_pack_bf16(float lo, float hi) {
+  const bf16x2 r = __builtin_convertvector((f32x2){lo, hi}, bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+
+// fragment (tile nt, k-step ks): lane (i = lane & 15, g = lane >> 4) holds W[16 nt + i][32 ks + 8 g .. + 8]
+__global__ void gemm_k256_pack_kernel(const uint16_t* __restrict__ w, int64_t ldw, int64_t total, uint4* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63), ks = (int)((idx >> 6) & 7);
+  const int64_t nt = idx >> 9;
+  out[idx] = *reinterpret_cast<const uint4*>(w + (nt * 16 + (lane & 15)) * ldw + 32 * ks + 8 * (lane >> 4));
+}
+
+// ROWS = 64 or 32 rows per workgroup; grid = (M / ROWS, N / 256).  32 rows when the grid would otherwise not give every CU its two
+// workgroups (N = 256 at M = 15936: 249 -> 498 workgroups).
+template <int ROWS>
+__global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_kernel(const GemmK256Params p) {
+  constexpr int MT = ROWS / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * ROWS;
+  const int n0 = blockIdx.y * kG2Cols + wave * 64;  // first of this wave's 64 output columns
+
+  // ---- this wave's 32 weight fragments: all in flight before anything else ---------------------------------------------------
+  bf16x8 wf[4][8];
+  {
+    const uint4* base = p.wp + ((int64_t)(n0 >> 4) * 8) * 64 + lane;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
+  }
+  // ---- activation tile -> LDS ---------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int it = 0; it < ROWS / 8; ++it) {
+    const int idx = it * kG2Threads + tid;
+    const int row = idx >> 5, ch = idx & 31;
+    int m = m0 + row;
+    if (m >= p.M) m = p.M - 1;
+    const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
+    *reinterpret_cast<uint4*>(smem + row * kG2Pitch + ch * 16) = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[4][MT];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int s = 0; s < MT; ++s) acc[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* abase = smem + c * kG2Pitch + g * 16;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    bf16x8 af[MT];
+#pragma unroll
+    for (int s = 0; s < MT; ++s) af[s] = *reinterpret_cast<const bf16x8*>(abase + s * 16 * kG2Pitch + ks * 64);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int s = 0; s < MT; ++s) acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], af[s], acc[jt][s], 0, 0, 0);
+  }
+
+  // ---- epilogue: lane (c, g) holds rows m0 + 16 s + c, columns n0 + 16 jt + 4 g + r ------------------------------------------------
+  float4 bv[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+    bv[jt] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int m = m0 + 16 * s + c;
+    if (m >= p.M) continue;
+    const float rs = p.alpha * (p.row_scale ? p.row_scale[m] : 1.0f);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = n0 + 16 * jt + 4 * g;
+      float v0 = acc[jt][s][0] + bv[jt].x, v1 = acc[jt][s][1] + bv[jt].y;
+      float v2 = acc[jt][s][2] + bv[jt].z, v3 = acc[jt][s][3] + bv[jt].w;
+      if (p.act == 1) {
+        v0 *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v0));
+        v1 *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v1));
+        v2 *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v2));
+        v3 *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v3));
+      } else if (p.act == 2) {
+        v0 = fmaxf(v0, 0.f);
+        v1 = fmaxf(v1, 0.f);
+        v2 = fmaxf(v2, 0.f);
+        v3 = fmaxf(v3, 0.f);
+      }
+      v0 *= rs;
+      v1 *= rs;
+      v2 *= rs;
+      v3 *= rs;
+      if (p.residual) {
+        const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldr + n);
+        v0 += r.x;
+        v1 += r.y;
+        v2 += r.z;
+        v3 += r.w;
+      }
+      if (p.out_bf16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) =
+            make_uint2(g2_pack_bf16(v0, v1), g2_pack_bf16(v2, v3));
+      else
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = make_float4(v0, v1, v2, v3);
+    }
+  }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" int64_t ma_gemm_k256_packed_bytes(int64_t N, int64_t K) {
+  if (K != kG2K || N < kG2Cols || N % kG2Cols != 0) return MA_ERR_UNSUPPORTED;
+  return N * K * 2;
+}
+
+extern "C" int ma_gemm_k256_pack_bf16(const void* W, int64_t ldw, int64_t N, int64_t K, void* packed, ma_stream_t stream) {
+  if (!W || !packed) return MA_ERR_INVALID_ARG;
+  if (ma_gemm_k256_packed_bytes(N, K) < 0 || ldw < K || (ldw & 7)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(packed)) & 15) return MA_ERR_INVALID_ARG;
+  const int64_t total = (N / 16) * 8 * 64;
+  MA_LAUNCH(gemm_k256_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+            reinterpret_cast<const uint16_t*>(W), ldw, total, reinterpret_cast<uint4*>(packed));
+  return MA_OK;
+}
+
+extern "C" int ma_gemm_k256_packed_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M,
+                                        int64_t N, int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream) {
+  if (!A || !packed || !out || !epi || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (ma_gemm_k256_packed_bytes(N, K) < 0 || N > 0x7fffff00) return MA_ERR_UNSUPPORTED;
+  if (epi->col_scale || epi->col_shift || epi->act2 || epi->act < 0 || epi->act > 2) return MA_ERR_UNSUPPORTED;
+  if ((lda & 7) || lda < K || ldo < N || (ldo & 3) || (epi->residual && (epi->ldr < N || (epi->ldr & 3)))) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |
+       reinterpret_cast<uintptr_t>(epi->bias) | reinterpret_cast<uintptr_t>(epi->residual)) & 15)
+    return MA_ERR_INVALID_ARG;
+  GemmK256Params p;
+  p.a = reinterpret_cast<const uint16_t*>(A);
+  p.wp = reinterpret_cast<const uint4*>(packed);
+  p.out = out;
+  p.bias = epi->bias;
+  p.residual = epi->residual;
+  p.row_scale = epi->row_scale;
+  p.lda = lda;
+  p.ldo = ldo;
+  p.ldr = epi->ldr;
+  p.M = (int32_t)M;
+  p.N = (int32_t)N;
+  p.alpha = epi->alpha;
+  p.act = epi->act;
+  p.out_bf16 = epi->out_bf16;
+  const unsigned nby = (unsigned)(N / kG2Cols);
+  if ((M + 63) / 64 * nby < 384) {  // well under two 64-row workgroups per CU: halve the rows
+    MA_LAUNCH(gemm_k256_kernel<32>, dim3((unsigned)((M + 31) / 32), nby), dim3(kG2Threads), 32 * kG2Pitch, (hipStream_t)stream, p);
+  } else {
+    MA_LAUNCH(gemm_k256_kernel<64>, dim3((unsigned)((M + 63) / 64), nby), dim3(kG2Threads), 64 * kG2Pitch, (hipStream_t)stream, p);
+  }
+  return MA_OK;
+}

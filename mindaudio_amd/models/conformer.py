@@ -172,8 +172,11 @@ class ConformerEncoder(nn.Module):
                 "pw2_w": cm.pointwise_conv2.weight.detach().squeeze(-1).to(bf).contiguous(),
                 "pw2_b": cm.pointwise_conv2.bias.detach().float().contiguous(),
             })
-        # fragment-ordered packed copies of the FFN weights for the hidden-slice-owner kernel (ops.ffn_packed)
+        # fragment-ordered packed copies: FFN weights for the hidden-slice-owner kernel (ops.ffn_packed), the K = 256 dense
+        # layers for ops.gemm_packed
         for W in prep["layers"]:
+            for key in ("qkv", "o", "pw1", "pw2"):
+                W[key + "_pk"] = ops.gemm_k256_pack(W[key + "_w"]) if W[key + "_w"].shape[1] == 256 else None
             for key in ("ffm", "ff"):
                 w1 = W[key + "_w1"]
                 W[key + "_pk"] = ops.ffn_pack_weights(w1, W[key + "_w2"]) if w1.shape[0] % 256 == 0 and w1.shape[1] == 256 else None
@@ -239,6 +242,14 @@ class ConformerEncoder(nn.Module):
         use128 = m >= 128 * 100 and os.environ.get("MA_FFN128", "0") == "1"
         # hidden-slice-owner kernel on packed weights (ffn_packed.hip): 43 us vs 60 us at M = 15936 (MA_FFN_PACKED=0: A/B switch)
         packed_ffn = os.environ.get("MA_FFN_PACKED", "1") != "0"
+        # K = 256 dense layers: packed-weight kernel (gemm_k256.hip) once the rows cover the chip (MA_GEMM_PACKED=0: A/B switch)
+        packed_gemm = m >= 64 * 64 and os.environ.get("MA_GEMM_PACKED", "1") != "0"
+
+        def dense(inp, W, key, **kw):
+            if packed_gemm and W[key + "_pk"] is not None:
+                return ops.gemm_packed(inp, W[key + "_pk"], **kw)
+            return ops.gemm(inp, W[key + "_w"], **kw)
+
         part = torch.empty((m, self.d), dtype=f32, device=x.device) if use128 else None
         a = ops.layernorm(x, self.encoders[0].norm_ff_macaron.gamma, self.encoders[0].norm_ff_macaron.beta)
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
@@ -252,15 +263,15 @@ class ConformerEncoder(nn.Module):
                 add = self._ffn(a, W, "ffm", x, fused_ffn, part)
                 # x = x + MHA(LN(x))                                               :117-135
                 a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta, addend=add)
-            qkv = ops.gemm(a, W["qkv_w"], bias=W["qkv_b"])
+            qkv = dense(a, W, "qkv", bias=W["qkv_b"])
             ctx = ops.relpos_attention(qkv, pos_all[:, li * 256:(li + 1) * 256], W["u"], W["v"], att_mask, b, t2,
                                        self.heads, 64)
-            ops.gemm(ctx, W["o_w"], bias=W["o_b"], residual=x, out_dtype=f32, out=x)
+            dense(ctx, W, "o", bias=W["o_b"], residual=x, out_dtype=f32, out=x)
             # x = x + ConvModule(LN(x), mask_pad)                                  :139-143, convolution.py:83-129
             a = ops.layernorm(x, l.norm_conv.gamma, l.norm_conv.beta, row_scale=mask_rows)
-            y = ops.gemm(a, W["pw1_w"], bias=W["pw1_b"])
+            y = dense(a, W, "pw1", bias=W["pw1_b"])
             z = ops.convmodule_mid(y, W["dw_w"], W["bn_scale"], W["bn_shift"], b, t2)
-            ops.gemm(z, W["pw2_w"], bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
+            dense(z, W, "pw2", bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
             # x = x + 0.5 * FFN(LN(x)) ; x = LN_final(x)                           :147-156
             a = ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta)
             last = li + 1 == n_layers

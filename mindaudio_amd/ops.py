@@ -39,6 +39,39 @@ def gemm(a, w, bias=None, residual=None, row_scale=None, alpha=1.0, act=_lib.ACT
     return out
 
 
+def gemm_k256_pack(w):
+    """Fragment-ordered packed copy of w (N, 256) bf16 for gemm_packed; None if the shape is not covered (N % 256, K != 256)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert w.dtype == t.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    n, k = w.shape
+    nbytes = lib.ma_gemm_k256_packed_bytes(n, k)
+    if nbytes < 0:
+        return None
+    packed = t.empty((n, k), dtype=t.bfloat16, device=w.device)
+    _lib.check(lib.ma_gemm_k256_pack_bf16(_host.ptr(w), w.stride(0), n, k, _host.ptr(packed), _host.current_stream_ptr()),
+               "gemm_k256_pack_bf16")
+    return packed
+
+
+def gemm_packed(a, packed, bias=None, residual=None, row_scale=None, alpha=1.0, act=_lib.ACT_NONE, out_dtype=None, out=None):
+    """ops.gemm on a packed weight (gemm_k256_pack): a (M, 256) bf16, packed (N, 256)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and a.shape[1] == packed.shape[1]
+    m, k = a.shape
+    n = packed.shape[0]
+    out_dtype = out_dtype or t.bfloat16
+    if out is None:
+        out = t.empty((m, n), dtype=out_dtype, device=a.device)
+    assert out.dtype == out_dtype and out.stride(1) == 1 and tuple(out.shape) == (m, n)
+    e = _epilogue(bias, residual, row_scale, alpha, act, out_dtype == t.bfloat16)
+    rc = lib.ma_gemm_k256_packed_bf16(_host.ptr(a), a.stride(0), _host.ptr(packed), _host.ptr(out), out.stride(0), m, n, k,
+                                      ctypes.byref(e), _host.current_stream_ptr())
+    _lib.check(rc, "gemm_k256_packed_bf16")
+    return out
+
+
 def ffn(a, w1, b1, w2, b2, x, alpha=0.5):
     """In place x += alpha * (swish(a @ w1^T + b1) @ w2^T + b2); a (M, 256) bf16, x (M, 256) float32."""
     t = _host.torch()

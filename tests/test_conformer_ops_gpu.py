@@ -71,6 +71,40 @@ def test_gemm_epilogues(t):
     assert float((x.double() - (res.double() + 0.5 * z)).abs().max()) <= 2e-5 * float(z.abs().max())
 
 
+@pytest.mark.parametrize("m,n", [(64, 256), (777, 512), (15936, 768), (1, 256), (130, 1024)])
+def test_gemm_k256_packed(t, m, n):
+    """K = 256 dense layers on fragment-packed weights: same contract (and epilogues) as ops.gemm."""
+    from mindaudio_amd import _lib, ops
+
+    k = 256
+    a = _rand(t, m, k, seed=14).bfloat16().cuda()
+    w = _rand(t, n, k, seed=15, scale=0.06).bfloat16().cuda()
+    bias = _rand(t, n, seed=16).cuda()
+    res = _rand(t, m, n, seed=17).cuda()
+    rs = (t.rand(m, generator=t.Generator().manual_seed(18)) > 0.3).float().cuda()
+    pk = ops.gemm_k256_pack(w)
+    assert pk is not None and t.equal(pk.view(t.int16).flatten().sort().values, w.view(t.int16).flatten().sort().values)
+    assert ops.gemm_k256_pack(w[:, :128].contiguous()) is None and ops.gemm_k256_pack(w[:100]) is None
+    z = a.double() @ w.double().T + bias.double()
+    got = ops.gemm_packed(a, pk, bias=bias, out_dtype=t.float32).double()
+    assert float((got - z).abs().max()) <= 2e-5 * float(z.abs().max())
+    # bit-identical to the general kernel?  both accumulate k in the same order inside one MFMA chain per output
+    assert t.equal(ops.gemm_packed(a, pk, bias=bias), ops.gemm(a, w, bias=bias))
+    got = ops.gemm_packed(a, pk, bias=bias, act=_lib.ACT_SWISH).double()
+    want = z * t.sigmoid(z)
+    assert float((got - want).abs().max()) <= 2 ** -8 * float(want.abs().max()) * 1.01
+    got = ops.gemm_packed(a, pk, bias=bias, act=_lib.ACT_RELU, out_dtype=t.float32).double()
+    assert float((got - z.clamp(min=0)).abs().max()) <= 2e-5 * float(z.abs().max())
+    got = ops.gemm_packed(a, pk, bias=bias, residual=res, row_scale=rs, alpha=0.5, out_dtype=t.float32).double()
+    want = res.double() + 0.5 * z * rs.double()[:, None]
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    wide = _rand(t, m, 3 * k, seed=19).bfloat16().cuda()  # strided A, in-place residual
+    x = res.clone()
+    ops.gemm_packed(wide[:, k:2 * k], pk, residual=x, out_dtype=t.float32, out=x)
+    want = res.double() + wide[:, k:2 * k].double() @ w.double().T
+    assert float((x.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
 def test_gemm_rejects_bad_shapes(t):
     from mindaudio_amd import ops
 

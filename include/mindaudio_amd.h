@@ -325,6 +325,17 @@ int ma_magphase_f32(const float* z, int64_t n, float power, float* mag, float* p
 int ma_cmvn_stats_f64(const float* x, const int32_t* frames, int64_t batch, int64_t T, int32_t F, double* stats,
                       ma_stream_t stream);
 
+/* spectrum.istft (spectrum.py:346-474): spec (batch, 1 + n_fft/2, frames_total) complex64 as ma_stft_f32 writes it (frame index
+ * contiguous); the first n_frames frames are inverted (the reference trims them when `length` is given, :418-423), multiplied by
+ * `window` (n_fft floats: get_window(fftbins=True) centred in n_fft, :411-415), overlap-added every `hop` samples and divided
+ * by the window sum-square where that exceeds 1e-9 (:448-459).  out[b, i] = sample i + start of the overlap-added signal
+ * (start = n_fft/2 when center, :461-472), zeros past its end.  Even n_fft <= 4096.
+ * workspace >= ma_istft_workspace_bytes (the time-domain frames). */
+int64_t ma_istft_workspace_bytes(int64_t batch, int64_t n_frames, int32_t n_fft);
+int ma_istft_f32(const float* spec, int64_t batch, int32_t n_fft, int64_t frames_total, int64_t n_frames, int32_t hop,
+                 const float* window, int32_t start, float* out, int64_t out_len, void* workspace, int64_t workspace_bytes,
+                 ma_stream_t stream);
+
 /* ---- batch assembly of the training loop (examples/conformer/dataset.py:536-656) -------------------------- */
 
 /* len(range(max_src_len)[:-2:2][:-2:2]): width of xs_masks after the two stride-2 slicings (dataset.py:625). */

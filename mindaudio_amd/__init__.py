@@ -6,7 +6,7 @@ amplitude_to_dB, melspectrogram, and the Conformer loader's Kaldi-style fbank.
 Every function runs hand-written HIP kernels through the C-ABI in include/mindaudio_amd.h;
 nothing here falls back to NumPy/PyTorch arithmetic.
 """
-from .data.spectrum import amplitude_to_dB, magphase, melspectrogram, spectrogram, stft  # noqa: F401
+from .data.spectrum import amplitude_to_dB, istft, magphase, melspectrogram, spectrogram, stft  # noqa: F401
 from .data.features import compute_deltas, context_window, fbank, fbanks, mfcc  # noqa: F401
 
 __version__ = "0.1.0"

@@ -159,6 +159,8 @@ PROTOTYPES = {
     "ma_label_smoothing_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, i64, vp, vp]),
     "ma_ffn_ln_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, f32, vp, i64,
                                       i32, vp]),
+    "ma_istft_workspace_bytes": (i64, [i64, i64, i32]),
+    "ma_istft_f32": (ctypes.c_int, [vp, i64, i32, i64, i64, i32, vp, i32, vp, i64, vp, i64, vp]),
     "ma_gemm_k256_packed_bytes": (i64, [i64, i64]),
     "ma_gemm_k256_pack_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp]),
     "ma_gemm_k256_packed_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp]),

@@ -115,6 +115,77 @@ static int fp_grid(int64_t n) {
   return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
+
+// ---- spectrum.istft (spectrum.py:346-474) ------------------------------------------------------------------------------------
+// (1) istft_frames_kernel: the real inverse DFT of 16 frames per workgroup,
+//       f[t][j] = (1/N) (Re S_0 + (-1)^j Re S_{N/2} + 2 sum_{k=1}^{N/2-1} (Re S_k cos(2 pi k j / N) - Im S_k sin(2 pi k j / N)))
+//     (imaginary parts of the DC and Nyquist bins ignored, as the C2R transform behind numpy.fft.irfft does).  The spectrum tile
+//     and one period of the cos / sin table sit in LDS; the angle index k j mod N is advanced by addition, so any even N works.
+// (2) istft_ola_kernel: synthesis window, overlap-add and the division by the window sum-square (> 1e-9), evaluated per OUTPUT
+//     sample (at most ceil(N / hop) frames touch a sample), with the centre trimming / `length` handling folded into the index.
+constexpr int kIstftFrames = 16;
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float2* __restrict__ spec, int64_t spec_bstride, int n_freq,
+                                                           int64_t frames_total, int n_frames, int N, float* __restrict__ fr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float2* S = reinterpret_cast<float2*>(smem);                      // [n_freq][16]
+  float2* tab = S + (size_t)n_freq * kIstftFrames;                  // [N] (cos, sin)(2 pi m / N)
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * kIstftFrames;
+  const float2* sb = spec + (int64_t)blockIdx.y * spec_bstride;
+  for (int i = tid; i < n_freq * kIstftFrames; i += 256) {
+    const int k = i / kIstftFrames, f = i % kIstftFrames;
+    S[i] = (t0 + f < n_frames) ? sb[(int64_t)k * frames_total + t0 + f] : make_float2(0.f, 0.f);
+  }
+  for (int m = tid; m < N; m += 256) {
+    float sn, cs;
+    sincospif(2.0f * (float)m / (float)N, &sn, &cs);
+    tab[m] = make_float2(cs, sn);
+  }
+  __syncthreads();
+  const int f = tid & 15;
+  if (t0 + f >= n_frames) return;
+  const float inv = 1.0f / (float)N;
+  float* o = fr + ((int64_t)blockIdx.y * n_frames + t0 + f) * N;
+  const int half = N >> 1;
+  for (int j = tid >> 4; j < N; j += 16) {
+    float acc = 0.0f;
+    int idx = 0;
+    for (int k = 1; k < half; ++k) {
+      idx += j;
+      if (idx >= N) idx -= N;
+      const float2 s = S[k * kIstftFrames + f];
+      const float2 cs = tab[idx];
+      acc = fmaf(s.x, cs.x, acc);
+      acc = fmaf(-s.y, cs.y, acc);
+    }
+    const float dc = S[f].x, ny = S[half * kIstftFrames + f].x;
+    o[j] = inv * (dc + ((j & 1) ? -ny : ny) + 2.0f * acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ fr, const float* __restrict__ win, int n_frames,
+                                                        int N, int hop, int start, int64_t out_len, float* __restrict__ out) {
+  const int64_t exp_len = (int64_t)N + (int64_t)hop * (n_frames - 1);
+  const float* fb = fr + (int64_t)blockIdx.y * n_frames * N;
+  float* ob = out + (int64_t)blockIdx.y * out_len;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < out_len; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i + start;
+    float y = 0.0f, wss = 0.0f;
+    if (n < exp_len) {
+      int64_t t_hi = n / hop;
+      if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+      for (int64_t t = t_hi; t >= 0; --t) {
+        const int64_t j = n - t * hop;
+        if (j >= N) break;
+        const float w = win[j];
+        y = fmaf(w, fb[t * N + j], y);
+        wss = fmaf(w, w, wss);
+      }
+    }
+    ob[i] = wss > 1e-9f ? y / wss : y;
+  }
+}
+
 }  // namespace ma
 
 using namespace ma;
@@ -163,6 +234,40 @@ int ma_cmvn_stats_f64(const float* x, const int32_t* frames, int64_t batch, int6
   int gx = (int)((T + nsub - 1) / nsub);
   if (gx > 64) gx = 64;
   MA_LAUNCH(cmvn_stats_kernel, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, x, frames, (int)T, F, stats);
+  return MA_OK;
+}
+
+
+int64_t ma_istft_workspace_bytes(int64_t batch, int64_t n_frames, int32_t n_fft) {
+  if (batch < 1 || n_frames < 1 || n_fft < 2) return MA_ERR_INVALID_ARG;
+  return batch * n_frames * (int64_t)n_fft * 4;
+}
+
+int ma_istft_f32(const float* spec, int64_t batch, int32_t n_fft, int64_t frames_total, int64_t n_frames, int32_t hop,
+                 const float* window, int32_t start, float* out, int64_t out_len, void* workspace, int64_t workspace_bytes,
+                 ma_stream_t stream) {
+  if (!spec || !window || !out || !workspace || batch < 1 || n_frames < 1 || frames_total < n_frames || out_len < 1 || start < 0)
+    return MA_ERR_INVALID_ARG;
+  if (hop < 1) return MA_ERR_HOP;
+  if (n_fft < 2 || (n_fft & 1) || n_fft > 4096 || n_frames > 0x7fffffff || batch > 65535) return MA_ERR_UNSUPPORTED;
+  if (workspace_bytes < ma_istft_workspace_bytes(batch, n_frames, n_fft)) return MA_ERR_WORKSPACE;
+  const int n_freq = n_fft / 2 + 1;
+  const size_t lds = ((size_t)n_freq * ma::kIstftFrames + n_fft) * sizeof(float2);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ma::istft_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 1024) != hipSuccess)
+      return MA_ERR_LAUNCH;
+    attr = true;
+  }
+  float* fr = reinterpret_cast<float*>(workspace);
+  MA_LAUNCH(ma::istft_frames_kernel, dim3((unsigned)((n_frames + ma::kIstftFrames - 1) / ma::kIstftFrames), (unsigned)batch),
+            dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const float2*>(spec), (int64_t)n_freq * frames_total, n_freq,
+            frames_total, (int)n_frames, (int)n_fft, fr);
+  int64_t blocks = (out_len + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  MA_LAUNCH(ma::istft_ola_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, fr, window,
+            (int)n_frames, (int)n_fft, (int)hop, (int)start, out_len, out);
   return MA_OK;
 }
 

@@ -10,7 +10,7 @@ import numpy as np
 
 from .. import _host, _lib
 
-__all__ = ["stft", "melspectrogram", "amplitude_to_dB", "spectrogram", "magphase"]
+__all__ = ["stft", "istft", "melspectrogram", "amplitude_to_dB", "spectrogram", "magphase"]
 
 
 def _finish(out, lead, was_numpy):
@@ -53,6 +53,54 @@ def stft(waveforms, n_fft=512, win_length=None, hop_length=None, window="hann", 
     if not return_complex:
         spec = t.stack((spec.real, spec.imag), -1)
     return _finish(spec, lead, was_numpy)
+
+
+def istft(stft_matrix, n_fft=None, win_length=None, hop_length=None, window="hann", center=True, length=None):
+    """Inverse STFT — same signature and defaults as spectrum.py:346-354: irfft of every frame, synthesis window, overlap-add,
+    division by the window sum-square, centre trimming or `length`.  stft_matrix (..., 1 + n_fft/2, frames) complex64, NumPy
+    (returns float64 like the reference's np.float_ buffer, :429) or a device tensor (returns float32).  Arithmetic is float32."""
+    import math
+
+    t = _host.require_gpu()
+    lib = _lib.load()
+    was_numpy = not isinstance(stft_matrix, t.Tensor)
+    D = t.as_tensor(np.ascontiguousarray(stft_matrix) if was_numpy else stft_matrix).to(device="cuda", dtype=t.complex64)
+    if D.dim() < 2:
+        raise ValueError("stft_matrix must be (..., 1 + n_fft/2, frames)")
+    lead = tuple(D.shape[:-2])
+    n_freq, frames_total = D.shape[-2], D.shape[-1]
+    D = D.reshape((-1, n_freq, frames_total)).contiguous()
+    if n_fft is None:
+        n_fft = 2 * (n_freq - 1)  # :400-401
+    if n_freq != n_fft // 2 + 1:
+        raise ValueError("stft_matrix has %d rows, n_fft=%d needs %d" % (n_freq, n_fft, n_fft // 2 + 1))
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length // 4)  # :408-409
+    if hop_length < 1:
+        raise ValueError("Invalid hop_length: {:d}".format(hop_length))
+    win = _host.device_window(window, win_length, n_fft, D.device)  # get_window(fftbins=True) + _pad_center (:411-415)
+    if length:
+        padded = length + int(n_fft) if center else length
+        n_frames = min(frames_total, int(math.ceil(padded / hop_length)))  # :418-423
+    else:
+        n_frames = frames_total
+    exp_len = n_fft + hop_length * (n_frames - 1)
+    start = n_fft // 2 if center else 0
+    out_len = int(length) if length else (exp_len - 2 * (n_fft // 2) if center else exp_len)
+    if out_len < 1:
+        raise ValueError("istft output would be empty")
+    b = D.shape[0]
+    out = t.empty((b, out_len), dtype=t.float32, device=D.device)
+    ws_bytes = lib.ma_istft_workspace_bytes(b, n_frames, n_fft)
+    _lib.check(min(ws_bytes, 0), "istft")
+    ws = _host.workspace(ws_bytes, D.device)
+    rc = lib.ma_istft_f32(_host.ptr(t.view_as_real(D)), b, n_fft, frames_total, n_frames, hop_length, _host.ptr(win), start,
+                          _host.ptr(out), out_len, _host.ptr(ws), ws.numel() * ws.element_size(), _host.current_stream_ptr())
+    _lib.check(rc, "istft")
+    out = out.reshape(lead + (out_len,))
+    return out.cpu().numpy().astype(np.float64) if was_numpy else out
 
 
 def _mel_args(n_fft, win_length, hop_length, window, center, pad_mode, n_mels, sample_rate, f_min, f_max, device):

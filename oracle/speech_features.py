@@ -455,3 +455,43 @@ def load_cmvn_stats(mean_stat, var_stat, frame_num):
     mean = np.asarray(mean_stat, np.float64) / frame_num
     var = np.maximum(np.asarray(var_stat, np.float64) / frame_num - mean * mean, 1.0e-20)
     return mean, 1.0 / np.sqrt(var)
+
+
+def istft(stft_matrix, n_fft=None, win_length=None, hop_length=None, window="hann", center=True, length=None,
+          return_wss=False):
+    """spectrum.py:346-474 (pinned by tests/golden/istft_goldens.npz): irfft of every frame, synthesis window, overlap-add,
+    division by the window sum-square where it exceeds 1e-9, centre trimming / `length` handling."""
+    D = np.asarray(stft_matrix)
+    if n_fft is None:
+        n_fft = 2 * (D.shape[-2] - 1)  # :400-401
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length // 4)  # :408-409
+    w = _centered_window(window, win_length, n_fft)  # get_window(fftbins=True) + _pad_center (:411-415)
+    if length:
+        padded = length + int(n_fft) if center else length
+        n_frames = min(D.shape[-1], int(np.ceil(padded / hop_length)))  # :418-423
+    else:
+        n_frames = D.shape[-1]
+    exp_len = n_fft + hop_length * (n_frames - 1)
+    y = np.zeros(D.shape[:-2] + (exp_len,), np.float64)
+    fr = np.fft.irfft(D[..., :n_frames], n=n_fft, axis=-2) * w[:, None]
+    wss = np.zeros(exp_len, np.float64)
+    for t in range(n_frames):
+        y[..., t * hop_length:t * hop_length + n_fft] += fr[..., t]
+        wss[t * hop_length:t * hop_length + n_fft] += w * w  # _window_sumsquare (:476-493)
+    nz = wss > 1e-9
+    y[..., nz] /= wss[nz]
+
+    def crop(v):
+        if length is None:
+            return v[..., n_fft // 2:-(n_fft // 2)] if center else v
+        v = v[..., (n_fft // 2 if center else 0):]
+        if v.shape[-1] > length:
+            return v[..., :length]
+        return np.pad(v, [(0, 0)] * (v.ndim - 1) + [(0, length - v.shape[-1])])
+
+    if return_wss:  # the divisor of every output sample: tells a test where float32 round-off is amplified
+        return crop(y), crop(wss)
+    return crop(y)

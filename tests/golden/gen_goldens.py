@@ -242,6 +242,7 @@ def main():
     collate_goldens(ref)
     decode_goldens(ref)
     post_goldens(ref)
+    istft_goldens(ref)
 
 
 def decode_goldens(ref):
@@ -307,6 +308,44 @@ def post_goldens(ref):
     path = os.path.join(HERE, "post_goldens.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+
+
+def istft_goldens(ref):
+    """spectrum.istft (spectrum.py:346-474).  The reference uses np.float_ (removed in NumPy 2; its
+    requirements.txt pins numpy<2), so the alias is restored for the duration of the call — the arithmetic is untouched."""
+    sp, io = ref["spectrum"], ref["io"]
+    had = hasattr(np, "float_")
+    if not had:
+        np.float_ = np.float64
+    try:
+        wav, _ = io.read(os.path.join(REF, "tests/samples/ASR/BAC009S0002W0122.wav"))
+        x = wav[2000:8000]
+        out = {"wave": x}
+        cases = {
+            "default": (dict(), dict()),                                        # n_fft 512, hop 128 both ways
+            "h160": (dict(n_fft=512, hop_length=160), dict(hop_length=160)),
+            "nocenter": (dict(n_fft=256, hop_length=64, center=False), dict(hop_length=64, center=False)),
+            "len5000": (dict(n_fft=512, hop_length=160), dict(hop_length=160, length=5000)),
+            "len7000": (dict(n_fft=512, hop_length=160), dict(hop_length=160, length=7000)),
+            "win400": (dict(n_fft=512, win_length=400, hop_length=100, window="hamming"),
+                       dict(win_length=400, hop_length=100, window="hamming")),
+            "n400": (dict(n_fft=400, hop_length=100), dict(hop_length=100)),
+        }
+        for tag, (kw_f, kw_i) in cases.items():
+            D = sp.stft(x, **kw_f)
+            out["spec_" + tag] = np.ascontiguousarray(D)
+            out["y_" + tag] = sp.istft(D, **kw_i)
+        rng = np.random.RandomState(7)
+        xb = (0.1 * rng.randn(3, 3000)).astype(np.float32)
+        D = sp.stft(xb, n_fft=512, hop_length=160)
+        out["spec_batch"] = np.ascontiguousarray(D)
+        out["y_batch"] = sp.istft(D, hop_length=160)
+    finally:
+        if not had:
+            del np.float_
+    path = os.path.join(HERE, "istft_goldens.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.0f KiB" % (os.path.getsize(path) / 1024), len(out), "arrays")
 
 
 def _write_wav(path, pcm16):

@@ -102,3 +102,50 @@ def test_device_cmvn_stats_vs_reference(pg):
     assert info["frame_num"] == 3 * int(pg["cmvn_frames"])
     assert np.allclose(np.array(info["mean_stat"]), 3 * pg["cmvn_mean_stat"], rtol=2e-5)
     assert np.allclose(np.array(info["var_stat"]), 3 * pg["cmvn_var_stat"], rtol=2e-5)
+
+
+# ---- spectrum.istft (spectrum.py:346-474), pinned by the reference run here (tests/golden/istft_goldens.npz) -----------------
+ISTFT_CASES = {"default": dict(), "h160": dict(hop_length=160), "nocenter": dict(hop_length=64, center=False),
+               "len5000": dict(hop_length=160, length=5000), "len7000": dict(hop_length=160, length=7000),
+               "win400": dict(win_length=400, hop_length=100, window="hamming"), "n400": dict(hop_length=100),
+               "batch": dict(hop_length=160)}
+
+
+@pytest.fixture(scope="module")
+def ig():
+    return np.load(os.path.join(HERE, "golden", "istft_goldens.npz"))
+
+
+def test_oracle_istft_vs_reference(ig):
+    for tag, kw in ISTFT_CASES.items():
+        y = O.istft(ig["spec_" + tag], **kw)
+        assert y.shape == ig["y_" + tag].shape and y.dtype == np.float64
+        assert np.abs(y - ig["y_" + tag]).max() <= 1e-12
+    # the reference's round trip (tests/test_spectrum.py:38-41): istft(stft(x)) == x away from the edges
+    assert np.abs(ig["y_h160"][256:-256] - ig["wave"][256:256 + ig["y_h160"].size - 512]).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_device_istft_vs_reference(ig):
+    import torch
+
+    import mindaudio_amd as ma
+
+    for tag, kw in ISTFT_CASES.items():
+        want = ig["y_" + tag]
+        got = ma.istft(ig["spec_" + tag], **kw)
+        assert got.shape == want.shape and got.dtype == np.float64
+        scale = max(np.abs(want).max(), 1e-3)
+        # float32 arithmetic (the reference accumulates in float64): 2e-6 of the signal scale where the window sum-square the
+        # sample is divided by is O(1); where it is tiny (first / last samples without centring, the un-trimmed tail when
+        # `length` exceeds the signal) the quotient y / wss ~ (w f) / w^2 amplifies the round-off of f by 1 / w = wss^-1/2
+        _, wss = O.istft(ig["spec_" + tag], return_wss=True, **kw)
+        tol = 4e-6 * scale / np.sqrt(np.clip(wss, 1e-9, 1.0))
+        assert (np.abs(got - want) <= tol).all(), tag
+    # device tensors stay on the device; stft -> istft round trip through our own kernels
+    x = torch.from_numpy(ig["wave"].astype(np.float32)).cuda()
+    y = ma.istft(ma.stft(x, n_fft=512, hop_length=160), hop_length=160)
+    assert y.is_cuda and y.dtype == torch.float32 and y.shape[-1] == 5920
+    assert float((y[256:-256] - x[256:5920 - 256]).abs().max()) <= 2e-6
+    with pytest.raises(ValueError):
+        ma.istft(ig["spec_h160"], n_fft=400)

@@ -336,6 +336,20 @@ int ma_istft_f32(const float* spec, int64_t batch, int32_t n_fft, int64_t frames
                  const float* window, int32_t start, float* out, int64_t out_len, void* workspace, int64_t workspace_bytes,
                  ma_stream_t stream);
 
+/* ---- on-device speed perturbation (examples/conformer/dataset.py:398-406 -> mindaudio/data/processing.py:132-176) ----------
+ * resample(res_type="fft") = scipy.signal.resample over the whole utterance: out[b, :n_out[b]] = irfft(Y, n_out[b]) * n_out / n_in
+ * with Y the rfft of x[b, :n_in[b]] truncated / zero-padded (Nyquist bin doubled or halved when min(n_in, n_out) is even);
+ * out[b, n_out[b]:max_out] = 0.  Any lengths (Bluestein on a power-of-two length ma_resample_fft_length(max_in, max_out)
+ * <= 2^23); n_in / n_out are device int32 arrays; workspace >= ma_resample_fft_workspace_bytes. */
+int64_t ma_resample_fft_length(int64_t max_in, int64_t max_out);
+int64_t ma_resample_fft_workspace_bytes(int64_t batch, int64_t max_in, int64_t max_out);
+int ma_resample_fft_f32(const float* x, int64_t ldx, const int32_t* n_in, const int32_t* n_out, int64_t batch, int64_t max_in,
+                        int64_t max_out, float* out, int64_t ldo, void* workspace, int64_t workspace_bytes,
+                        ma_stream_t stream);
+/* The power-of-two complex64 FFT underneath (Stockham autosort, LDS super-passes): `batch` signals of length L = 2^11 .. 2^26 in
+ * `data`, scratch `tmp` of the same size; *result = whichever of the two holds the (unnormalised) transform. */
+int ma_fft_pow2_c32(void* data, void* tmp, int64_t batch, int64_t L, int32_t inverse, void** result, ma_stream_t stream);
+
 /* ---- batch assembly of the training loop (examples/conformer/dataset.py:536-656) -------------------------- */
 
 /* len(range(max_src_len)[:-2:2][:-2:2]): width of xs_masks after the two stride-2 slicings (dataset.py:625). */

@@ -159,6 +159,10 @@ PROTOTYPES = {
     "ma_label_smoothing_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, i64, vp, vp]),
     "ma_ffn_ln_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, f32, vp, i64,
                                       i32, vp]),
+    "ma_resample_fft_length": (i64, [i64, i64]),
+    "ma_resample_fft_workspace_bytes": (i64, [i64, i64, i64]),
+    "ma_resample_fft_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, i64, vp, i64, vp]),
+    "ma_fft_pow2_c32": (ctypes.c_int, [vp, vp, i64, i64, i32, ctypes.POINTER(ctypes.c_void_p), vp]),
     "ma_istft_workspace_bytes": (i64, [i64, i64, i32]),
     "ma_istft_f32": (ctypes.c_int, [vp, i64, i32, i64, i64, i32, vp, i32, vp, i64, vp, i64, vp]),
     "ma_gemm_k256_packed_bytes": (i64, [i64, i64]),

@@ -125,6 +125,39 @@ class BucketASRDataset:
         return data, self.sos, self.eos, max_src_len, self.token_max_length
 
 
+SPEEDS = (0.9, 1.0, 1.1)  # dataset.py:400
+
+
+def speed_perturb_batch(waves, sample_rate, device, speeds=None):
+    """speed_perturb (dataset.py:398-406) over a list of host waves: draws random.choice(SPEEDS) per utterance (or takes
+    `speeds`), resamples the perturbed ones in ONE batched device call and returns the list of host float64 waves."""
+    from ..data import processing
+
+    t = _host.require_gpu()
+    if speeds is None:
+        speeds = [random.choice(SPEEDS) for _ in waves]
+    todo = [i for i, s in enumerate(speeds) if s != 1.0]
+    if not todo:
+        return list(waves)
+    n_in = [waves[i].shape[0] for i in todo]
+    n_out = [processing.resampled_length(waves[i].shape[0], sample_rate * speeds[i], sample_rate) for i in todo]
+    host = np.zeros((len(todo), max(n_in)), np.float32)
+    for row, i in enumerate(todo):
+        host[row, :n_in[row]] = waves[i]
+    y = processing.resample_batch(t.from_numpy(host).to(device), n_in, n_out).cpu().numpy()
+    out = list(waves)
+    for row, i in enumerate(todo):
+        out[i] = y[row, :n_out[row]].astype(np.float64)
+    return out
+
+
+def speed_perturb(waveform, sample_rate, speed=None):
+    """speed_perturb of dataset.py:398-406 for one utterance."""
+    t = _host.require_gpu()
+    return speed_perturb_batch([np.asarray(waveform)], sample_rate, t.device("cuda", t.cuda.current_device()),
+                               None if speed is None else [speed])[0]
+
+
 class CollateFunc:
     """CollateFunc of dataset.py:409-656 with the feature extraction, padding, SpecAugment masking and every
     label/mask column computed on the device.  `__call__` returns the reference's 11 columns (COLUMNS) as device
@@ -191,8 +224,6 @@ class CollateFunc:
     def __call__(self, batch, sos=0, eos=0, max_src_len=2000, max_tgt_len=30):
         if self.feature_dither != 0.0:
             raise NotImplementedError  # as the reference (dataset.py:559-560)
-        if self.use_speed_perturb:
-            raise NotImplementedError("speed perturbation (scipy resample) is a next row (SURVEY §8f-2)")
         t = _host.require_gpu()
         lib = _lib.load()
         conf = self.feature_extraction_conf
@@ -205,6 +236,12 @@ class CollateFunc:
                 raise ValueError("the loader expects 16 kHz audio (dataset.py:390-396)")
             waves.append(wav)
         flen, fshift = 16000 * frame_len // 1000, 16000 * frame_shift // 1000
+        dev = t.device("cuda", t.cuda.current_device())
+        if self.use_speed_perturb:
+            # speed_perturb (dataset.py:398-406): one random.choice per utterance (the reference draws inside its worker
+            # processes, so no cross-process draw order exists to reproduce), then resample(wave, 16000 * speed, 16000) =
+            # scipy.signal.resample, here batched on the device
+            waves = speed_perturb_batch(waves, 16000, dev)
         frames = [int(math.floor((w.shape[0] - flen) / fshift) + 1) for w in waves]
         order = np.argsort(frames)[::-1]  # dataset.py:484
         frames_sorted = [frames[i] for i in order]
@@ -216,7 +253,6 @@ class CollateFunc:
         for row, i in enumerate(order):
             host[row, :waves[i].shape[0]] = waves[i] * 32768.0  # waveform * (1 << 15), dataset.py:390 (exact in f32)
         lengths = np.array([waves[i].shape[0] for i in order], np.int64)
-        dev = t.device("cuda", t.cuda.current_device())
         xs_all, _ = compute_fbank_feats_batch(t.from_numpy(host).to(dev)[:, :max_n], lengths, 16000, frame_len,
                                               frame_shift, mel_bin)
         xs_pad = xs_all if xs_all.shape[1] == max_src_len else xs_all[:, :max_src_len].contiguous()

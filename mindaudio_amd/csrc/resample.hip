@@ -1,0 +1,276 @@
+// On-device speed perturbation: mindaudio.data.processing.resample(res_type="fft")
+// (mindaudio/data/processing.py:132-176) = scipy.signal.resample on the whole utterance, as called by speed_perturb in
+// examples/conformer/dataset.py:398-406:
+//     X = rfft(x)  (length N, any N);  Y[:nyq] = X[:nyq], nyq = min(N, M)//2 + 1, Nyquist bin doubled (M < N) or halved (N < M)
+//     when min(N, M) is even;  y = irfft(Y, M) * M / N.
+// N and M are arbitrary (utterance lengths), so both transforms are evaluated with Bluestein's chirp-z identity on a common
+// power-of-two length L >= 2 max(N, M):
+//     DFT_N(x)[k] = c_N[k] * sum_n (x[n] c_N[n]) conj(c_N)[k - n],          c_N[n] = exp(-i pi n^2 / N)
+// i.e. three length-L FFTs per transform (signal, chirp filter, inverse of the product).  Chirp phases are reduced exactly in
+// integers (n^2 mod 2N) before the sine/cosine, so float32 is enough.
+// The length-L FFT is a Stockham autosort radix-2 transform done in "super-passes": a workgroup takes 64 interleaved groups of
+// R = 2^t (t <= 5) elements that stay closed under t consecutive stages, runs those stages in LDS and writes the group back
+// in autosort order; 4 passes over HBM for L = 2^19.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+__device__ __forceinline__ float2 rs_cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// exp(sign * i * pi * n^2 / N), phase reduced exactly: n^2 mod 2N < 2N <= 2^24 is exact in float32
+__device__ __forceinline__ float2 rs_chirp(int64_t n, int64_t N, float sign) {
+  const int64_t r = (n * n) % (2 * N);
+  float sn, cs;
+  sincospif((float)r / (float)N, &sn, &cs);
+  return make_float2(cs, sign * sn);
+}
+
+// ---- one Stockham super-pass: T radix-2 stages on groups {u + j L/R : j < R}, u in [0, L/R) --------------------------------------
+// State before the pass: sub-transform size n, stride s (n s = L).  Group u = q + s p0 holds x[q + s (p0 + j n/R)]; stage i pairs
+// local (p, p + n_loc/2) with twiddle exp(-+ 2 pi i (p n/R + p0) / (n / 2^(i-1))); after T stages local index ql is global
+// q + s ql + R s p0.
+constexpr int kFftGroups = 64;
+template <int T>
+__global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int64_t L,
+                                                          int64_t n, int64_t s, float sign) {
+  constexpr int R = 1 << T;
+  constexpr int P = R + 1;  // LDS pitch (float2) of one group: odd -> the 64 groups spread over the banks
+  __shared__ float2 buf[2][kFftGroups * P];
+  const int tid = threadIdx.x;
+  const int64_t u0 = (int64_t)blockIdx.x * kFftGroups;
+  const float2* sb = src + (int64_t)blockIdx.y * L;
+  float2* db = dst + (int64_t)blockIdx.y * L;
+  const int64_t gstride = L / R;
+  for (int idx = tid; idx < kFftGroups * R; idx += 256) {
+    const int ul = idx % kFftGroups, j = idx / kFftGroups;
+    buf[0][ul * P + j] = sb[u0 + ul + j * gstride];
+  }
+  __syncthreads();
+  const int64_t nR = n / R;
+  int cur = 0;
+#pragma unroll
+  for (int i = 1; i <= T; ++i) {
+    const int n_loc = R >> (i - 1), s_loc = 1 << (i - 1);
+    const int64_t n_i = n >> (i - 1);
+    const float2* X = buf[cur];
+    float2* Y = buf[cur ^ 1];
+    for (int bf = tid; bf < kFftGroups * (R / 2); bf += 256) {
+      const int ul = bf / (R / 2), r = bf % (R / 2);
+      const int p_loc = r / s_loc, q_loc = r % s_loc;
+      const float2 a = X[ul * P + q_loc + s_loc * p_loc];
+      const float2 b = X[ul * P + q_loc + s_loc * (p_loc + n_loc / 2)];
+      const int64_t u = u0 + ul;
+      const int64_t p0 = u / s;
+      const int64_t num = (int64_t)p_loc * nR + p0;  // < n_i
+      float sn, cs;
+      sincospif(2.0f * (float)num / (float)n_i, &sn, &cs);  // n_i is a power of two: the quotient is exact
+      const float2 w = make_float2(cs, sign * sn);
+      Y[ul * P + q_loc + s_loc * (2 * p_loc)] = make_float2(a.x + b.x, a.y + b.y);
+      Y[ul * P + q_loc + s_loc * (2 * p_loc + 1)] = rs_cmul(make_float2(a.x - b.x, a.y - b.y), w);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const float2* X = buf[cur];
+  for (int idx = tid; idx < kFftGroups * R; idx += 256) {
+    int ul, ql;
+    if (s >= kFftGroups) {  // consecutive groups are consecutive q: contiguous for a fixed local index
+      ul = idx % kFftGroups;
+      ql = idx / kFftGroups;
+    } else {                // small stride: the R outputs of a group are (nearly) contiguous
+      ql = idx % R;
+      ul = idx / R;
+    }
+    const int64_t u = u0 + ul;
+    const int64_t q = u % s, p0 = u / s;
+    db[q + s * ql + (int64_t)R * s * p0] = X[ul * P + ql];
+  }
+}
+
+// a[i] = x[i] c_N[i] (i < N), b = conj(c_N) wrapped to length L
+__global__ __launch_bounds__(256) void rs_chirp_in_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ n_in,
+                                                          int64_t L, float2* __restrict__ A, float2* __restrict__ B) {
+  const int b = blockIdx.y;
+  const int64_t N = n_in[b];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= L) return;
+  float2 av = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
+  if (i < N) {
+    const float2 c = rs_chirp(i, N, -1.0f);
+    const float xv = x[(int64_t)b * ldx + i];
+    av = make_float2(xv * c.x, xv * c.y);
+    bv = make_float2(c.x, -c.y);
+  } else if (L - i < N) {
+    const float2 c = rs_chirp(L - i, N, -1.0f);
+    bv = make_float2(c.x, -c.y);
+  }
+  A[(int64_t)b * L + i] = av;
+  B[(int64_t)b * L + i] = bv;
+}
+
+__global__ __launch_bounds__(256) void rs_mul_kernel(float2* __restrict__ A, const float2* __restrict__ B, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) A[i] = rs_cmul(A[i], B[i]);
+}
+
+// C = unscaled inverse FFT of FFT(a) FFT(b): X[k] = c_N[k] C[k] / L.  Builds the inverse transform's Bluestein input
+// A2[k] = Z[k] exp(+i pi k^2 / M) from the Hermitian spectrum Z of scipy's Y, and its chirp filter B2.
+__global__ __launch_bounds__(256) void rs_spectrum_kernel(const float2* __restrict__ C, const int32_t* __restrict__ n_in,
+                                                          const int32_t* __restrict__ n_out, int64_t L, float2* __restrict__ A2,
+                                                          float2* __restrict__ B2) {
+  const int b = blockIdx.y;
+  const int64_t N = n_in[b], M = n_out[b];
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= L) return;
+  float2 av = make_float2(0.f, 0.f), bv = make_float2(0.f, 0.f);
+  if (k < M) {
+    const int64_t nmin = N < M ? N : M;
+    const int64_t nyq = nmin / 2 + 1;
+    const bool upper = 2 * k > M;
+    const int64_t kk = upper ? M - k : k;
+    if (kk < nyq) {
+      const float2 c = rs_chirp(kk, N, -1.0f);
+      float2 X = rs_cmul(c, C[(int64_t)b * L + kk]);
+      float f = 1.0f / (float)L;
+      if ((nmin & 1) == 0 && kk == nmin / 2) f *= (M < N) ? 2.0f : (N < M ? 0.5f : 1.0f);
+      X.x *= f;
+      X.y *= f;
+      if (upper) X.y = -X.y;
+      if (k == 0 || 2 * k == M) X.y = 0.0f;  // irfft ignores the imaginary part of the DC and Nyquist bins
+      av = rs_cmul(X, rs_chirp(k, M, 1.0f));
+    }
+    const float2 c = rs_chirp(k, M, 1.0f);
+    bv = make_float2(c.x, -c.y);
+  } else if (L - k < M) {
+    const float2 c = rs_chirp(L - k, M, 1.0f);
+    bv = make_float2(c.x, -c.y);
+  }
+  A2[(int64_t)b * L + k] = av;
+  B2[(int64_t)b * L + k] = bv;
+}
+
+// y[m] = Re(exp(+i pi m^2 / M) C2[m]) / (L N)        (1/M of the inverse DFT times scipy's M / N)
+__global__ __launch_bounds__(256) void rs_out_kernel(const float2* __restrict__ C2, const int32_t* __restrict__ n_in,
+                                                     const int32_t* __restrict__ n_out, int64_t L, float* __restrict__ out,
+                                                     int64_t ldo, int64_t max_out) {
+  const int b = blockIdx.y;
+  const int64_t N = n_in[b], M = n_out[b];
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= max_out) return;
+  float v = 0.0f;
+  if (m < M) {
+    const float2 c = rs_chirp(m, M, 1.0f);
+    const float2 z = C2[(int64_t)b * L + m];
+    v = (c.x * z.x - c.y * z.y) / ((float)L * (float)N);
+  }
+  out[(int64_t)b * ldo + m] = v;
+}
+
+// length-L FFT of `batch` signals: ping-pong between data and tmp; returns the buffer that holds the result
+static int rs_fft(float2*& data, float2*& tmp, int64_t batch, int64_t L, int log2L, float sign, hipStream_t stream) {
+  int64_t n = L, s = 1;
+  int rem = log2L;
+  while (rem > 0) {
+    const int t = rem >= 5 ? 5 : rem;
+    const dim3 grid((unsigned)((L >> t) / kFftGroups), (unsigned)batch);
+    switch (t) {
+      case 5: MA_LAUNCH(rs_fft_pass_kernel<5>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
+      case 4: MA_LAUNCH(rs_fft_pass_kernel<4>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
+      case 3: MA_LAUNCH(rs_fft_pass_kernel<3>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
+      case 2: MA_LAUNCH(rs_fft_pass_kernel<2>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
+      default: MA_LAUNCH(rs_fft_pass_kernel<1>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
+    }
+    n >>= t;
+    s <<= t;
+    rem -= t;
+    float2* sw = data;
+    data = tmp;
+    tmp = sw;
+  }
+  return MA_OK;
+}
+
+static int rs_log2(int64_t L) {
+  int k = 0;
+  while (((int64_t)1 << k) < L) ++k;
+  return ((int64_t)1 << k) == L ? k : -1;
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" int ma_fft_pow2_c32(void* data, void* tmp, int64_t batch, int64_t L, int32_t inverse, void** result,
+                               ma_stream_t stream) {
+  if (!data || !tmp || !result || batch < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
+  const int k = rs_log2(L);
+  if (k < 11 || k > 26) return MA_ERR_UNSUPPORTED;  // a pass needs 64 groups of up to 32 elements
+  float2* d = reinterpret_cast<float2*>(data);
+  float2* t = reinterpret_cast<float2*>(tmp);
+  const int rc = rs_fft(d, t, batch, L, k, inverse ? 1.0f : -1.0f, (hipStream_t)stream);
+  *result = d;
+  return rc;
+}
+
+extern "C" int64_t ma_resample_fft_length(int64_t max_in, int64_t max_out) {
+  if (max_in < 1 || max_out < 1) return MA_ERR_INVALID_ARG;
+  const int64_t need = 2 * (max_in > max_out ? max_in : max_out);
+  int64_t L = 2048;
+  while (L < need) L <<= 1;
+  return L > ((int64_t)1 << 23) ? MA_ERR_UNSUPPORTED : L;  // chirp phases are exact in float32 up to 2 N <= 2^24
+}
+
+extern "C" int64_t ma_resample_fft_workspace_bytes(int64_t batch, int64_t max_in, int64_t max_out) {
+  const int64_t L = ma_resample_fft_length(max_in, max_out);
+  if (L < 0 || batch < 1) return L < 0 ? L : MA_ERR_INVALID_ARG;
+  return 3 * batch * L * 8;
+}
+
+extern "C" int ma_resample_fft_f32(const float* x, int64_t ldx, const int32_t* n_in, const int32_t* n_out, int64_t batch,
+                                   int64_t max_in, int64_t max_out, float* out, int64_t ldo, void* workspace,
+                                   int64_t workspace_bytes, ma_stream_t stream) {
+  if (!x || !n_in || !n_out || !out || !workspace || batch < 1 || batch > 65535 || ldx < max_in || ldo < max_out)
+    return MA_ERR_INVALID_ARG;
+  const int64_t L = ma_resample_fft_length(max_in, max_out);
+  if (L < 0) return (int)L;
+  if (workspace_bytes < 3 * batch * L * 8) return MA_ERR_WORKSPACE;
+  const int k = rs_log2(L);
+  hipStream_t st = (hipStream_t)stream;
+  float2* A = reinterpret_cast<float2*>(workspace);
+  float2* B = A + batch * L;
+  float2* T = B + batch * L;
+  const dim3 gl((unsigned)((L + 255) / 256), (unsigned)batch);
+  const int64_t total = batch * L;
+  const dim3 gt((unsigned)((total + 255) / 256));
+  int rc;
+  // forward transform of length n_in
+  MA_LAUNCH(rs_chirp_in_kernel, gl, dim3(256), 0, st, x, ldx, n_in, L, A, B);
+  if ((rc = rs_fft(A, T, batch, L, k, -1.0f, st)) != MA_OK) return rc;
+  if ((rc = rs_fft(B, T, batch, L, k, -1.0f, st)) != MA_OK) return rc;
+  MA_LAUNCH(rs_mul_kernel, gt, dim3(256), 0, st, A, B, total);
+  if ((rc = rs_fft(A, T, batch, L, k, 1.0f, st)) != MA_OK) return rc;  // A = C (unscaled)
+  // spectrum mapping + the inverse transform of length n_out (B and T are free)
+  MA_LAUNCH(rs_spectrum_kernel, gl, dim3(256), 0, st, A, n_in, n_out, L, B, T);
+  {
+    float2 *a2 = B, *b2 = T, *t2 = A;
+    if ((rc = rs_fft(a2, t2, batch, L, k, -1.0f, st)) != MA_OK) return rc;   // result in a2, scratch t2
+    if ((rc = rs_fft(b2, t2, batch, L, k, -1.0f, st)) != MA_OK) return rc;
+    MA_LAUNCH(rs_mul_kernel, gt, dim3(256), 0, st, a2, b2, total);
+    if ((rc = rs_fft(a2, t2, batch, L, k, 1.0f, st)) != MA_OK) return rc;
+    MA_LAUNCH(rs_out_kernel, dim3((unsigned)((max_out + 255) / 256), (unsigned)batch), dim3(256), 0, st, a2, n_in, n_out, L, out,
+              ldo, max_out);
+  }
+  return MA_OK;
+}

@@ -495,3 +495,21 @@ def istft(stft_matrix, n_fft=None, win_length=None, hop_length=None, window="han
     if return_wss:  # the divisor of every output sample: tells a test where float32 round-off is amplified
         return crop(y), crop(wss)
     return crop(y)
+
+
+def resample_fft(x, num):
+    """scipy.signal.resample for real input (the call behind mindaudio.data.processing.resample, processing.py:168-170),
+    restated with numpy FFTs; pinned against scipy itself in tests/test_resample.py."""
+    x = np.asarray(x, np.float64)
+    n = x.shape[-1]
+    X = np.fft.rfft(x, axis=-1)
+    Y = np.zeros(x.shape[:-1] + (num // 2 + 1,), np.complex128)
+    nmin = min(n, num)
+    nyq = nmin // 2 + 1
+    Y[..., :nyq] = X[..., :nyq]
+    if nmin % 2 == 0:
+        if num < n:
+            Y[..., nmin // 2] *= 2.0
+        elif n < num:
+            Y[..., nmin // 2] *= 0.5
+    return np.fft.irfft(Y, num, axis=-1) * (float(num) / float(n))

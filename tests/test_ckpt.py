@@ -1,0 +1,98 @@
+"""MindSpore .ckpt importer (mindaudio_amd/utils/ckpt.py).  Parity unpinned: MindSpore is not installed and no
+reference checkpoint exists in the container, so the wire format is exercised through the package's own writer and the name
+mapping against names derived from the reference's cell attributes."""
+import numpy as np
+import pytest
+
+from mindaudio_amd.utils import ckpt as K
+
+
+def _to_reference_names(state):
+    """Inverse of convert_names for the modules of this package (what MindSpore would call each parameter)."""
+    out = {}
+    for k, v in state.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        a = v.detach().cpu().numpy()
+        n = k
+        if ".embed.conv1." in n or ".embed.conv2." in n:
+            n = n.replace(".embed.conv1.", ".embed.conv.0.conv2d.").replace(".embed.conv2.", ".embed.conv.2.conv2d.")
+        elif ".conv_module." in n and ("pointwise_conv" in n or "depthwise_conv" in n):
+            n = n.replace(".weight", ".conv1d.weight").replace(".bias", ".conv1d.bias")
+            if a.ndim == 3:
+                a = a[:, :, None, :]
+        elif ".conv_module.norm." in n:
+            n = (n.replace(".norm.weight", ".norm.gamma").replace(".norm.bias", ".norm.beta")
+                 .replace("running_mean", "moving_mean").replace("running_var", "moving_variance"))
+        elif n == "decoder.embed.weight":
+            n = "decoder.embed.0.embedding_table"
+        elif n.startswith("ctc.ctc_lo.") or n.endswith((".gamma", ".beta", "pos_bias_u", "pos_bias_v")):
+            pass
+        else:  # Dense wrapper
+            n = n.replace(".weight", ".dense.weight").replace(".bias", ".dense.bias")
+        out["network." + n] = a
+    out["global_step"] = np.array([123], np.int32)
+    out["moments.network.encoder.after_norm.gamma"] = np.zeros(256, np.float32)
+    out["scale_sense"] = np.array(1024.0, np.float32)
+    return out
+
+
+def test_wire_format_round_trip(tmp_path):
+    rng = np.random.RandomState(0)
+    params = {"a.weight": rng.randn(7, 5).astype(np.float32), "b": rng.randn(3).astype(np.float16),
+              "step": np.array([5], np.int32), "scalar": np.array(2.5, np.float32),
+              "big": rng.randn(1000, 16).astype(np.float32), "idx": np.arange(10, dtype=np.int64) - 5}
+    path = str(tmp_path / "x.ckpt")
+    K.write_mindspore_ckpt(path, params, slice_bytes=20000)  # "big" is written as 4 slices with the same tag
+    got = K.read_mindspore_ckpt(path)
+    assert set(got) == set(params)
+    for k, v in params.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    raw = open(path, "rb").read()
+    assert raw.count(b"big") == 4 and raw[0] == 0x0A  # field 1, length-delimited
+    open(path, "wb").write(raw[:-7])
+    with pytest.raises(ValueError):
+        K.read_mindspore_ckpt(path)
+
+
+def test_import_into_asr_model(tmp_path):
+    import torch
+
+    from mindaudio_amd.conformer.asr_model import create_asr_model
+
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=2)
+    dec = dict(attention_heads=4, linear_units=2048, num_blocks=1)
+    torch.manual_seed(1)
+    src = create_asr_model(80, 100, conf, None, ctc_weight=0.3, decoder_conf=dec)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+        bn = src.encoder.encoders[0].conv_module.norm
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    ref_named = _to_reference_names(src.state_dict())
+    assert "network.encoder.embed.conv.2.conv2d.weight" in ref_named
+    assert ref_named["network.encoder.encoders.0.conv_module.depthwise_conv.conv1d.weight"].shape == (256, 1, 1, 15)
+    assert "network.encoder.encoders.1.self_attn.linear_pos.dense.weight" in ref_named
+    path = str(tmp_path / "avg_30.ckpt")
+    K.write_mindspore_ckpt(path, ref_named)
+    torch.manual_seed(2)
+    dst = create_asr_model(80, 100, conf, None, ctc_weight=0.3, decoder_conf=dec)
+    missing, unexpected = K.load_mindspore_checkpoint(dst, path)
+    assert not missing and not unexpected
+    a, b = src.state_dict(), dst.state_dict()
+    for k in a:
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(a[k], b[k]), k
+    # strictness: a parameter the module does not have / a missing one / a wrong shape
+    bad = dict(ref_named)
+    bad["network.encoder.extra.weight"] = np.zeros(3, np.float32)
+    K.write_mindspore_ckpt(path, bad)
+    with pytest.raises(KeyError):
+        K.load_mindspore_checkpoint(dst, path)
+    assert K.load_mindspore_checkpoint(dst, path, strict=False)[1] == ["encoder.extra.weight"]
+    bad = dict(ref_named)
+    bad["network.ctc.ctc_lo.weight"] = np.zeros((99, 256), np.float32)
+    K.write_mindspore_ckpt(path, bad)
+    with pytest.raises(ValueError):
+        K.load_mindspore_checkpoint(dst, path)

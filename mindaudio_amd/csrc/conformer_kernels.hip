@@ -456,6 +456,63 @@ __global__ __launch_bounds__(256) void convmodule_mid_kernel(const uint16_t* __r
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = bn_scale[c0 + e]; sh[e] = bn_shift[c0 + e]; }
+  // Thread (cg, rg) produces the 4 CONSECUTIVE time steps 4 rg .. 4 rg + 3 of its 8 channels: every GLU row it needs is read from
+  // LDS once (KS + 3 rows for 4 outputs instead of 4 KS) and the KS x 8 taps stay in registers (KS <= 15; larger kernels take the
+  // per-tap path below).
+  constexpr int kOut = kCmTile / 8;  // 4
+  if (KS <= 15) {
+    float w[15][8];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+      if (k < KS) {
+        const float4* wp = reinterpret_cast<const float4*>(wl + k * 256 + cg * 8);
+        const float4 w0 = wp[0], w1 = wp[1];
+        w[k][0] = w0.x; w[k][1] = w0.y; w[k][2] = w0.z; w[k][3] = w0.w;
+        w[k][4] = w1.x; w[k][5] = w1.y; w[k][6] = w1.z; w[k][7] = w1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[k][e] = 0.0f;
+      }
+    }
+    float acc[kOut][8];
+#pragma unroll
+    for (int o = 0; o < kOut; ++o)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[o][e] = 0.0f;
+    const int i0 = rg * kOut;
+#pragma unroll
+    for (int r = 0; r < 15 + kOut - 1; ++r) {  // GLU row i0 + r feeds output o with tap k = r - o
+      if (r < KS + kOut - 1) {
+        const float4* gp = reinterpret_cast<const float4*>(glu + (i0 + r) * 256 + cg * 8);
+        const float4 g0 = gp[0], g1 = gp[1];
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int o = 0; o < kOut; ++o) {
+          const int k = r - o;
+          if (k >= 0 && k < 15) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(w[k][e], gv[e], acc[o][e]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < kOut; ++o) {
+      const int t = t0 + i0 + o;
+      if (t >= T) break;
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float z0 = acc[o][2 * e] * sc[2 * e] + sh[2 * e];
+        float z1 = acc[o][2 * e + 1] * sc[2 * e + 1] + sh[2 * e + 1];
+        z0 = z0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z0));
+        z1 = z1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z1));
+        pk[e] = pack2_bf16(z0, z1);
+      }
+      *reinterpret_cast<uint4*>(out + (row0 + t) * ldo + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+    return;
+  }
 #pragma unroll
   for (int rr = 0; rr < kCmTile / 8; ++rr) {
     const int i = rg + 8 * rr;

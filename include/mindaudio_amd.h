@@ -534,6 +534,15 @@ int ma_ffn_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, 
                    const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
                    void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, ma_stream_t stream);
 
+/* ma_conv2d_3x3s2_nhwc_bf16 for the subsampling layer's second convolution (C = Cout = 256; layers/subsampling.py:40-45) on a
+ * fragment-ordered packed copy of W (conv2_packed.hip): out (batch, Ho, Wo, 256) bf16 = [relu](bias + conv).
+ *   ma_conv2d_3x3s2_packed_bytes(C, Cout) -> bytes of the packed buffer (negative: unsupported shape);
+ *   ma_conv2d_3x3s2_pack_bf16(W (Cout, 3, 3, C) bf16, ..., packed): once per weight update. */
+int64_t ma_conv2d_3x3s2_packed_bytes(int64_t C, int64_t Cout);
+int ma_conv2d_3x3s2_pack_bf16(const void* W, int64_t C, int64_t Cout, void* packed, ma_stream_t stream);
+int ma_conv2d_3x3s2_packed_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* packed,
+                                     int64_t Cout, const float* bias, int32_t relu, void* out, ma_stream_t stream);
+
 /* Dense / k=1 Conv1d with K = 256 inputs (linear_q/k/v/out: layers/attention.py:51-56; pointwise_conv1/2:
  * layers/convolution.py:52-78) on a fragment-ordered packed copy of W (gemm_k256.hip): same result as ma_gemm_bf16.
  *   ma_gemm_k256_packed_bytes(N, K) -> bytes of the packed buffer (negative: unsupported; K = 256, N % 256 == 0);

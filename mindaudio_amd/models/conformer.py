@@ -172,6 +172,7 @@ class ConformerEncoder(nn.Module):
                 "pw2_w": cm.pointwise_conv2.weight.detach().squeeze(-1).to(bf).contiguous(),
                 "pw2_b": cm.pointwise_conv2.bias.detach().float().contiguous(),
             })
+        prep["conv2_pk"] = ops.conv2d_3x3s2_pack(prep["conv2_w"])
         # fragment-ordered packed copies: FFN weights for the hidden-slice-owner kernel (ops.ffn_packed), the K = 256 dense
         # layers for ops.gemm_packed
         for W in prep["layers"]:
@@ -221,7 +222,10 @@ class ConformerEncoder(nn.Module):
         b, t, idim = xs.shape
         xs = xs.to(f32).contiguous()
         act1 = ops.subsample_conv1(xs, P["conv1_w"], P["conv1_b"], self.cmvn_mean, self.cmvn_istd)
-        act2 = ops.conv2d_3x3s2_nhwc(act1, P["conv2_w"], P["conv2_b"], relu=True)
+        if P.get("conv2_pk") is not None and os.environ.get("MA_CONV2_PACKED", "1") != "0":
+            act2 = ops.conv2d_3x3s2_packed(act1, P["conv2_pk"], P["conv2_b"], relu=True)
+        else:
+            act2 = ops.conv2d_3x3s2_nhwc(act1, P["conv2_w"], P["conv2_b"], relu=True)
         _, t2, f2, c = act2.shape
         m = b * t2
         if masks.shape[-1] != t2:

@@ -39,6 +39,36 @@ def gemm(a, w, bias=None, residual=None, row_scale=None, alpha=1.0, act=_lib.ACT
     return out
 
 
+def conv2d_3x3s2_pack(w):
+    """Fragment-ordered packed copy of w (Cout, 3, 3, C) bf16 for conv2d_3x3s2_packed; None if the shape is not covered."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert w.dtype == t.bfloat16 and w.dim() == 4 and w.is_contiguous() and w.shape[1] == 3 and w.shape[2] == 3
+    cout, c = w.shape[0], w.shape[3]
+    nbytes = lib.ma_conv2d_3x3s2_packed_bytes(c, cout)
+    if nbytes < 0:
+        return None
+    packed = t.empty((nbytes // 2,), dtype=t.bfloat16, device=w.device)
+    _lib.check(lib.ma_conv2d_3x3s2_pack_bf16(_host.ptr(w), c, cout, _host.ptr(packed), _host.current_stream_ptr()),
+               "conv2d_3x3s2_pack_bf16")
+    return packed
+
+
+def conv2d_3x3s2_packed(act, packed, bias, relu=True):
+    """conv2d_3x3s2_nhwc on a packed weight: act (B, H, W, 256) bf16 NHWC -> (B, Ho, Wo, 256) bf16."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert act.dtype == t.bfloat16 and act.is_contiguous() and bias.dtype == t.float32
+    b, h, wd, c = act.shape
+    cout = bias.numel()
+    ho, wo = (h - 3) // 2 + 1, (wd - 3) // 2 + 1
+    out = t.empty((b, ho, wo, cout), dtype=t.bfloat16, device=act.device)
+    rc = lib.ma_conv2d_3x3s2_packed_nhwc_bf16(_host.ptr(act), b, h, wd, c, _host.ptr(packed), cout, _host.ptr(bias),
+                                              1 if relu else 0, _host.ptr(out), _host.current_stream_ptr())
+    _lib.check(rc, "conv2d_3x3s2_packed")
+    return out
+
+
 def gemm_k256_pack(w):
     """Fragment-ordered packed copy of w (N, 256) bf16 for gemm_packed; None if the shape is not covered (N % 256, K != 256)."""
     t = _host.torch()

@@ -71,6 +71,32 @@ def test_gemm_epilogues(t):
     assert float((x.double() - (res.double() + 0.5 * z)).abs().max()) <= 2e-5 * float(z.abs().max())
 
 
+@pytest.mark.parametrize("b,h,wd", [(2, 21, 9), (3, 99, 39), (1, 7, 5), (5, 131, 39)])
+def test_conv2d_3x3s2_packed(t, b, h, wd):
+    """Subsampling conv 2 on fragment-packed weights: same result as the general implicit-GEMM kernel."""
+    from mindaudio_amd import ops
+
+    c = cout = 256
+    x = _rand(t, b, c, h, wd, seed=21).bfloat16()
+    w = _rand(t, cout, c, 3, 3, seed=22, scale=1.0 / math.sqrt(9 * c)).bfloat16()
+    bias = _rand(t, cout, seed=23)
+    act = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wk = w.permute(0, 2, 3, 1).contiguous().cuda()
+    pk = ops.conv2d_3x3s2_pack(wk)
+    assert pk is not None and t.equal(pk.view(t.int16).sort().values, wk.view(t.int16).flatten().sort().values)
+    for relu in (True, False):
+        got = ops.conv2d_3x3s2_packed(act, pk, bias.cuda(), relu=relu)
+        ref = t.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride=2)
+        if relu:
+            ref = t.nn.functional.relu(ref)
+        gd = got.permute(0, 3, 1, 2).double().cpu()
+        assert gd.shape == ref.shape
+        assert float((gd - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) * 1.01
+        # and bit-identical to the general kernel (same k order inside every accumulation chain)
+        assert t.equal(got, ops.conv2d_3x3s2_nhwc(act, wk, bias=bias.cuda(), relu=relu))
+    assert ops.conv2d_3x3s2_pack(wk[:, :, :, :128].contiguous()) is None
+
+
 @pytest.mark.parametrize("m,n", [(64, 256), (777, 512), (15936, 768), (1, 256), (130, 1024)])
 def test_gemm_k256_packed(t, m, n):
     """K = 256 dense layers on fragment-packed weights: same contract (and epilogues) as ops.gemm."""

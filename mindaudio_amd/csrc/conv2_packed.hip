@@ -141,25 +141,31 @@ __global__ __launch_bounds__(kC2Threads, 2) void conv2_packed_kernel(const Conv2
     else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue_a(chunk + 2, (ST + 2) % 3);  // the stage chunk - 1 used: every wave is past its reads (barrier above)
-    // (accumulators 128 + ring 32 registers leave room for ONE k-step's activation fragments; the LDS latency of a k-step is
-    // covered by the other workgroup's wave on this SIMD)
+    // both k-steps' activation fragments are requested up front: the second set lands under the first 32 MFMAs
+    bf16x8 af[2][8];
+#define C2_LDS(kk_, s_)                                                                                        \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kk_][s_]) : "v"(kk_ ? a_addr1 : a_addr0), "n"(ST * kC2Stage + (s_) * 2048) \
+               : "memory")
+    C2_LDS(0, 0); C2_LDS(0, 1); C2_LDS(0, 2); C2_LDS(0, 3); C2_LDS(0, 4); C2_LDS(0, 5); C2_LDS(0, 6); C2_LDS(0, 7);
+    C2_LDS(1, 0); C2_LDS(1, 1); C2_LDS(1, 2); C2_LDS(1, 3); C2_LDS(1, 4); C2_LDS(1, 5); C2_LDS(1, 6); C2_LDS(1, 7);
+#undef C2_LDS
     c2_static_for<2>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kk = decltype(kc)::value;
-      bf16x8 af[8];
-#define C2_LDS(s_)                                                                                         \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[s_]) : "v"(kk ? a_addr1 : a_addr0), "n"(ST * kC2Stage + (s_) * 2048) \
-               : "memory")
-      C2_LDS(0); C2_LDS(1); C2_LDS(2); C2_LDS(3); C2_LDS(4); C2_LDS(5); C2_LDS(6); C2_LDS(7);
-#undef C2_LDS
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7])::"memory");
+      if constexpr (kk == 0)
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[0][4]), "+v"(af[0][5]),
+                       "+v"(af[0][6]), "+v"(af[0][7])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]), "+v"(af[1][4]), "+v"(af[1][5]),
+                       "+v"(af[1][6]), "+v"(af[1][7])::"memory");
       c2_static_for<4>([&](auto tc) __attribute__((always_inline)) {
         constexpr int jt = decltype(tc)::value;
         constexpr int q = kk * 4 + jt;
         asm volatile("s_waitcnt vmcnt(11)" : "+v"(ring[q])::"memory");
         c2_static_for<8>([&](auto sc) __attribute__((always_inline)) {
           constexpr int s = decltype(sc)::value;
-          acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[q], af[s], acc[jt][s], 0, 0, 0);
+          acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[q], af[kk][s], acc[jt][s], 0, 0, 0);
         });
         __builtin_amdgcn_sched_barrier(0);
         C2_LOAD(ring[q], chunk + 1, q);

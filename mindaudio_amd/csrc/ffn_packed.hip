@@ -117,32 +117,6 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   const int c = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * kPkRows;
 
-  // ---- activation tile -> LDS: [64 rows][544 B] (512 + 32 of padding).  A ds_read_b128 serves lanes in groups of 16
-  // ({0-3,12-15,20-27}, ...); with this pitch the 16-byte slot of lane (c, g) is (2 c + g + 4 ks) mod 16, distinct inside every
-  // group, and the k-step is a plain +64 B immediate offset (an XOR swizzle costs an address register per k-step) -------------
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int idx = it * kPkThreads + tid;
-    const int row = idx >> 5, ch = idx & 31;
-    int m = m0 + row;
-    if (m >= p.M) m = p.M - 1;
-    const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
-    *reinterpret_cast<uint4*>(smem + row * kPkPitch + ch * 16) = v;
-  }
-  {  // epilogue parameters -> LDS (5 x 256 floats; thread t copies element t of each): no global latency at the tail
-    float* par = reinterpret_cast<float*>(smem + kPkOffPar);
-    par[tid] = p.b2[tid];
-    if (p.ln_mode >= 1) {
-      par[256 + tid] = p.g1[tid];
-      par[512 + tid] = p.be1[tid];
-    }
-    if (p.ln_mode == 2) {
-      par[768 + tid] = p.g2[tid];
-      par[1024 + tid] = p.be2[tid];
-    }
-  }
-  __syncthreads();
-
   // Row-tile slot s of wave w is row tile (s + w) & 3: slot 0 is the tile the wave owns after the final reduction, and all
   // accumulator indices stay compile-time constants.
   int a_off[4];
@@ -347,15 +321,41 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   //   its bias (issued before W1') : W1'[0..15] are younger                                             -> vmcnt(16)
   //   product2 of block b, item j  : W2[j..15], the 2 bias loads of block b+2, W1''[0..j-1]             -> vmcnt(17)
   //   prologue (product1 of block 0, refilled with W1 of block 1): everything but block 1's bias has landed (counts 17 / 18 hold trivially)
-  if (nsb > 0) {
-    {
-      const char* w0 = wbase(0);
+  if (nsb > 0) {  // the first block's weight fragments are requested before the activation tile: their L2 latency hides under it
+    const char* w0 = wbase(0);
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-                     : "=v"(ring[q]) : "v"(PK_VOFF(q)), "s"(w0), "n"((((q) & 7) - 4) * 1024) : "memory");
-      if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int q = 0; q < 16; ++q)
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                   : "=v"(ring[q]) : "v"(PK_VOFF(q)), "s"(w0), "n"((((q) & 7) - 4) * 1024) : "memory");
+    if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // ---- activation tile -> LDS: [64 rows][544 B] (512 + 32 of padding).  A ds_read_b128 serves lanes in groups of 16
+  // ({0-3,12-15,20-27}, ...); with this pitch the 16-byte slot of lane (c, g) is (2 c + g + 4 ks) mod 16, distinct inside every
+  // group, and the k-step is a plain +64 B immediate offset (an XOR swizzle costs an address register per k-step) -------------
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = it * kPkThreads + tid;
+    const int row = idx >> 5, ch = idx & 31;
+    int m = m0 + row;
+    if (m >= p.M) m = p.M - 1;
+    const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
+    *reinterpret_cast<uint4*>(smem + row * kPkPitch + ch * 16) = v;
+  }
+  {  // epilogue parameters -> LDS (5 x 256 floats; thread t copies element t of each): no global latency at the tail
+    float* par = reinterpret_cast<float*>(smem + kPkOffPar);
+    par[tid] = p.b2[tid];
+    if (p.ln_mode >= 1) {
+      par[256 + tid] = p.g1[tid];
+      par[512 + tid] = p.be1[tid];
     }
+    if (p.ln_mode == 2) {
+      par[768 + tid] = p.g2[tid];
+      par[1024 + tid] = p.be2[tid];
+    }
+  }
+  __syncthreads();
+
+  if (nsb > 0) {
     PK_LDS(af[0][0], a_addr[0], 0);
     PK_LDS(af[0][1], a_addr[1], 0);
     PK_LDS(af[0][2], a_addr[2], 0);

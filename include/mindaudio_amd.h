@@ -560,14 +560,17 @@ int ma_gemm_k256_packed_bf16(const void* A, int64_t lda, const void* packed, voi
  *   ma_ffn_packed_bytes(d_model, hidden) -> bytes of the packed buffer (negative: unsupported shape; d_model = 256,
  *                                           hidden % 256 == 0);
  *   ma_ffn_pack_weights_bf16(w1 (hidden, d_model) bf16, w2 (d_model, hidden) bf16, ..., packed).
- * ma_ffn_packed_bf16: ln_mode 0 = no LayerNorm (gamma/beta/ln_out ignored), 1 / 2 as ma_ffn_ln_bf16. */
+ * ma_ffn_packed_bf16: ln_mode 0 = no LayerNorm (gamma/beta/ln_out ignored), 1 / 2 as ma_ffn_ln_bf16.  gamma0 / beta0 non-NULL:
+ * the input is a = LayerNorm(x; gamma0, beta0, eps) computed while the tile is staged (models/conformer.py:147-148) and the `a`
+ * operand is ignored (may be NULL). */
 int64_t ma_ffn_packed_bytes(int32_t d_model, int32_t hidden);
 int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t d_model, int32_t hidden, void* packed,
                              ma_stream_t stream);
 int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed, const float* b1, const float* b2, float* x,
                        int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, int32_t ln_mode,
                        const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
-                       void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, ma_stream_t stream);
+                       void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, const float* gamma0, const float* beta0,
+                       ma_stream_t stream);
 
 /* Fused feed-forward, 128-row formulation: grid (ceil(M/128), 2) — the workgroup of hidden half 0 updates x in place
  * (x += alpha * (O_0 + b2)), half 1 writes partial (M, 256) float32 = alpha * O_1; the LayerNorm that follows the module

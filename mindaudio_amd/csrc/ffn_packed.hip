@@ -68,6 +68,7 @@ struct FfnPackedParams {
   float alpha;
   int32_t ln_mode, ln_out_bf16;  // as FfnParams (ffn_fused.hip)
   const float *g1, *be1, *g2, *be2;
+  const float *g0, *be0;  // optional LayerNorm of the INPUT: a = LN(x; g0, be0) computed while staging (models/conformer.py:147-148)
   void* ln_out;
   int64_t ld_ln;
   float eps;
@@ -332,14 +333,55 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // ---- activation tile -> LDS: [64 rows][544 B] (512 + 32 of padding).  A ds_read_b128 serves lanes in groups of 16
   // ({0-3,12-15,20-27}, ...); with this pitch the 16-byte slot of lane (c, g) is (2 c + g + 4 ks) mod 16, distinct inside every
   // group, and the k-step is a plain +64 B immediate offset (an XOR swizzle costs an address register per k-step) -------------
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int idx = it * kPkThreads + tid;
-    const int row = idx >> 5, ch = idx & 31;
+  if (p.g0) {
+    // a = LayerNorm(x) on the fly (two-pass, as layernorm_kernel): 4 threads per row, 64 features each
+    const int row = tid >> 2, part = tid & 3;
     int m = m0 + row;
     if (m >= p.M) m = p.M - 1;
-    const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
-    *reinterpret_cast<uint4*>(smem + row * kPkPitch + ch * 16) = v;
+    const float* xr = p.x + (int64_t)m * p.ldx + part * 64;
+    float4 v[16];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i] = *reinterpret_cast<const float4*>(xr + 4 * i);
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float mean = sum * (1.0f / 256.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    const float inv = 1.0f / sqrtf(q * (1.0f / 256.0f) + p.eps);
+    char* dst = smem + row * kPkPitch + part * 128;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 ga = *reinterpret_cast<const float4*>(p.g0 + part * 64 + 8 * j);
+      const float4 gb = *reinterpret_cast<const float4*>(p.g0 + part * 64 + 8 * j + 4);
+      const float4 ba = *reinterpret_cast<const float4*>(p.be0 + part * 64 + 8 * j);
+      const float4 bb = *reinterpret_cast<const float4*>(p.be0 + part * 64 + 8 * j + 4);
+      const float4 a0 = v[2 * j], a1 = v[2 * j + 1];
+      *reinterpret_cast<uint4*>(dst + 16 * j) =
+          make_uint4(pk_pack_bf16(a0.x * inv * ga.x + ba.x, a0.y * inv * ga.y + ba.y),
+                     pk_pack_bf16(a0.z * inv * ga.z + ba.z, a0.w * inv * ga.w + ba.w),
+                     pk_pack_bf16(a1.x * inv * gb.x + bb.x, a1.y * inv * gb.y + bb.y),
+                     pk_pack_bf16(a1.z * inv * gb.z + bb.z, a1.w * inv * gb.w + bb.w));
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * kPkThreads + tid;
+      const int row = idx >> 5, ch = idx & 31;
+      int m = m0 + row;
+      if (m >= p.M) m = p.M - 1;
+      const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
+      *reinterpret_cast<uint4*>(smem + row * kPkPitch + ch * 16) = v;
+    }
   }
   {  // epilogue parameters -> LDS (5 x 256 floats; thread t copies element t of each): no global latency at the tail
     float* par = reinterpret_cast<float*>(smem + kPkOffPar);
@@ -551,8 +593,14 @@ extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t 
 extern "C" int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed, const float* b1, const float* b2, float* x,
                                   int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, int32_t ln_mode,
                                   const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
-                                  void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, ma_stream_t stream) {
-  if (!a || !packed || !b1 || !b2 || !x || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+                                  void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, const float* gamma0, const float* beta0,
+                                  ma_stream_t stream) {
+  if ((!a && !gamma0) || !packed || !b1 || !b2 || !x || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (gamma0 && (!beta0 || ((reinterpret_cast<uintptr_t>(gamma0) | reinterpret_cast<uintptr_t>(beta0)) & 15))) return MA_ERR_INVALID_ARG;
+  if (gamma0) {  // the activation operand is not read
+    a = x;
+    lda = kPkD;
+  }
   if (ma_ffn_packed_bytes(d_model, hidden) < 0) return MA_ERR_UNSUPPORTED;
   if ((lda & 7) || (ldx & 3) || lda < kPkD || ldx < kPkD) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(b1) |
@@ -590,6 +638,7 @@ extern "C" int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed
   p.ln_mode = ln_mode;
   p.ln_out_bf16 = ln_out_bf16;
   p.g1 = gamma1; p.be1 = beta1; p.g2 = gamma2; p.be2 = beta2;
+  p.g0 = gamma0; p.be0 = beta0;
   p.ln_out = ln_out;
   p.ld_ln = ld_ln;
   p.eps = eps;

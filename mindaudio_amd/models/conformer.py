@@ -277,13 +277,16 @@ class ConformerEncoder(nn.Module):
             z = ops.convmodule_mid(y, W["dw_w"], W["bn_scale"], W["bn_shift"], b, t2)
             dense(z, W, "pw2", bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
             # x = x + 0.5 * FFN(LN(x)) ; x = LN_final(x)                           :147-156
-            a = ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta)
             last = li + 1 == n_layers
+            use_pk = fused_ffn and part is None and packed_ffn and W["ff_pk"] is not None
+            # (the packed kernel computes LN_ff(x) itself while it stages the rows)
+            a = None if use_pk else ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta)
             if fused_ffn and part is None:  # FFN + norm_final + the next consumer's LayerNorm in one kernel
                 nxt = self.after_norm if last else self.encoders[li + 1].norm_ff_macaron
-                if packed_ffn and W["ff_pk"] is not None:
-                    y = ops.ffn_packed(a, W["ff_pk"], W["ff_b1"], W["ff_b2"], x, l.norm_final.gamma, l.norm_final.beta,
-                                       nxt.gamma, nxt.beta, out_dtype=f32 if last else None)
+                if use_pk:
+                    y = ops.ffn_packed(None, W["ff_pk"], W["ff_b1"], W["ff_b2"], x, l.norm_final.gamma, l.norm_final.beta,
+                                       nxt.gamma, nxt.beta, out_dtype=f32 if last else None,
+                                       ln_in=(l.norm_ff.gamma, l.norm_ff.beta))
                 else:
                     y = ops.ffn_ln(a, W["ff_w1"], W["ff_b1"], W["ff_w2"], W["ff_b2"], x, l.norm_final.gamma,
                                    l.norm_final.beta, nxt.gamma, nxt.beta, out_dtype=f32 if last else None)

@@ -149,21 +149,25 @@ def ffn_pack_weights(w1, w2):
     return packed
 
 
-def ffn_packed(a, packed, b1, b2, x, g1=None, be1=None, g2=None, be2=None, alpha=0.5, eps=1e-5, out_dtype=None):
+def ffn_packed(a, packed, b1, b2, x, g1=None, be1=None, g2=None, be2=None, alpha=0.5, eps=1e-5, out_dtype=None, ln_in=None):
     """ffn / ffn_ln on packed weights (ffn_pack_weights).  g1 None: x += alpha * FFN(a) in place, returns x.
-    Otherwise as ffn_ln: returns the LayerNorm output (bf16 default)."""
+    Otherwise as ffn_ln: returns the LayerNorm output (bf16 default).  ln_in = (gamma0, beta0): a is LayerNorm(x) computed
+    inside the kernel (pass a=None)."""
     t = _host.torch()
     lib = _lib.load()
-    assert a.dtype == t.bfloat16 and x.dtype == t.float32 and a.stride(1) == 1 and x.stride(1) == 1
-    m, d = a.shape
+    assert x.dtype == t.float32 and x.stride(1) == 1
+    if ln_in is None:
+        assert a.dtype == t.bfloat16 and a.stride(1) == 1 and tuple(a.shape) == tuple(x.shape)
+    m, d = x.shape
     hidden = b1.numel()
     mode = 0 if g1 is None else (2 if g2 is not None else 1)
     out_dtype = out_dtype or t.bfloat16
-    out = t.empty((m, d), dtype=out_dtype, device=a.device) if mode else None
-    rc = lib.ma_ffn_packed_bf16(_host.ptr(a), a.stride(0), _host.ptr(packed), _host.ptr(b1), _host.ptr(b2), _host.ptr(x),
-                                x.stride(0), m, d, hidden, float(alpha), mode, _opt(g1), _opt(be1), _opt(g2), _opt(be2),
-                                float(eps), _opt(out), out.stride(0) if mode else 0,
-                                1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    out = t.empty((m, d), dtype=out_dtype, device=x.device) if mode else None
+    rc = lib.ma_ffn_packed_bf16(_opt(a) if ln_in is None else None, a.stride(0) if ln_in is None else 0, _host.ptr(packed),
+                                _host.ptr(b1), _host.ptr(b2), _host.ptr(x), x.stride(0), m, d, hidden, float(alpha), mode,
+                                _opt(g1), _opt(be1), _opt(g2), _opt(be2), float(eps), _opt(out), out.stride(0) if mode else 0,
+                                1 if out_dtype == t.bfloat16 else 0, _opt(ln_in[0]) if ln_in else None,
+                                _opt(ln_in[1]) if ln_in else None, _host.current_stream_ptr())
     _lib.check(rc, "ffn_packed_bf16")
     return out if mode else x
 

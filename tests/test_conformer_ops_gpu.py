@@ -343,6 +343,16 @@ def test_ffn_packed(t, m, hidden, mode):
     outb = ops.ffn_packed(a.cuda(), packed, b1.cuda(), b2.cuda(), x.clone().cuda(), g1.cuda(), be1.cuda(),
                           *((g2.cuda(), be2.cuda()) if mode == 2 else ()))
     assert outb.dtype == t.bfloat16 and float((outb.float().cpu().double() - out.double().cpu()).abs().max()) <= 3e-2
+    # LayerNorm of the INPUT folded into the tile staging: a = LN(x; g0, b0)
+    g0, b0 = 1 + 0.1 * _rand(t, d, seed=101), 0.1 * _rand(t, d, seed=102)
+    a_ln = ln(x.double(), g0, b0).bfloat16()
+    x1, x2 = x.clone().cuda(), x.clone().cuda()
+    args = (g1.cuda(), be1.cuda()) + ((g2.cuda(), be2.cuda()) if mode == 2 else ())
+    o1 = ops.ffn_packed(a_ln.cuda(), packed, b1.cuda(), b2.cuda(), x1, *args, out_dtype=t.float32)
+    o2 = ops.ffn_packed(None, packed, b1.cuda(), b2.cuda(), x2, *args, out_dtype=t.float32, ln_in=(g0.cuda(), b0.cuda()))
+    # identical up to bf16 roundings of a that flip on float32-vs-float64 LayerNorm arithmetic
+    assert float((x1 - x2).abs().max()) <= 2e-2 * float(x1.abs().max()) and float((o1 - o2).abs().max()) <= 5e-2
+    assert float((x1 - x2).abs().mean()) <= 2e-4 * float(x1.abs().max())
     # run-to-run determinism (fixed reduction order across the four waves)
     xg2 = x.clone().cuda()
     ops.ffn_packed(a.cuda(), packed, b1.cuda(), b2.cuda(), xg2, g1.cuda(), be1.cuda(), *((g2.cuda(), be2.cuda()) if mode == 2 else ()),

@@ -552,6 +552,13 @@ int64_t ma_gemm_k256_packed_bytes(int64_t N, int64_t K);
 int ma_gemm_k256_pack_bf16(const void* W, int64_t ldw, int64_t N, int64_t K, void* packed, ma_stream_t stream);
 int ma_gemm_k256_packed_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N,
                              int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream);
+/* The same for N = 256 with the LayerNorm that follows fused behind the epilogue (a workgroup owns whole rows):
+ * ln_out (M, 256) bf16 = LayerNorm(out[m, :]; ln_gamma, ln_beta, ln_eps) * ln_row_scale[m] (ln_row_scale may be NULL) — the
+ * attention output projection + residual, then `norm_conv` and the mask_pad multiply (models/conformer.py:133-141,
+ * layers/convolution.py:97-98), in one launch. */
+int ma_gemm_k256_packed_ln_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N,
+                                int64_t K, const ma_gemm_epilogue_t* epi, const float* ln_gamma, const float* ln_beta,
+                                float ln_eps, const float* ln_row_scale, void* ln_out, int64_t ld_ln, ma_stream_t stream);
 
 /* Fused feed-forward, "hidden-slice owner" form (ffn_packed.hip): same contract as ma_ffn_bf16 / ma_ffn_ln_bf16
  * (mindaudio/models/layers/positionwise_feed_forward.py:33-46 + the residual and LayerNorms of models/conformer.py:109-112,

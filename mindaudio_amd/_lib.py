@@ -171,6 +171,7 @@ PROTOTYPES = {
     "ma_gemm_k256_packed_bytes": (i64, [i64, i64]),
     "ma_gemm_k256_pack_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp]),
     "ma_gemm_k256_packed_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp]),
+    "ma_gemm_k256_packed_ln_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp, vp, f32, vp, vp, i64, vp]),
     "ma_ffn_packed_bytes": (i64, [i32, i32]),
     "ma_ffn_pack_weights_bf16": (ctypes.c_int, [vp, vp, i32, i32, vp, vp]),
     "ma_ffn_packed_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, f32, vp, i64,

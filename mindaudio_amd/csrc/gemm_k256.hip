@@ -43,6 +43,15 @@ struct GemmK256Params {
   int32_t M, N;
   float alpha;
   int32_t act, out_bf16;
+  // optional LayerNorm of the OUTPUT rows (N = 256 only: a workgroup owns whole rows): ln_out[m, :] = bf16(LayerNorm(out[m, :];
+  // ln_gamma, ln_beta, ln_eps) * ln_row_scale[m]) — the `x = norm_conv(x)` + mask_pad multiply that follows the attention output
+  // projection (models/conformer.py:139-141, layers/convolution.py:97-98) without a LayerNorm launch
+  const float* ln_gamma;
+  const float* ln_beta;
+  const float* ln_row_scale;
+  uint16_t* ln_out;
+  int64_t ld_ln;
+  float ln_eps;
 };
 
 __device__ __forceinline__ uint32_t g2_pack_bf16(float lo, float hi) {
@@ -113,11 +122,15 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_kernel(const GemmK256
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
     bv[jt] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float rsum[MT], rsq[MT];
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
+    rsum[s] = 0.f;
+    rsq[s] = 0.f;
     const int m = m0 + 16 * s + c;
-    if (m >= p.M) continue;
-    const float rs = p.alpha * (p.row_scale ? p.row_scale[m] : 1.0f);
+    const bool live = m < p.M;
+    const int mc = live ? m : p.M - 1;
+    const float rs = p.alpha * (p.row_scale ? p.row_scale[mc] : 1.0f);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       const int n = n0 + 16 * jt + 4 * g;
@@ -139,17 +152,63 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_kernel(const GemmK256
       v2 *= rs;
       v3 *= rs;
       if (p.residual) {
-        const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldr + n);
+        const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)mc * p.ldr + n);
         v0 += r.x;
         v1 += r.y;
         v2 += r.z;
         v3 += r.w;
       }
-      if (p.out_bf16)
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) =
-            make_uint2(g2_pack_bf16(v0, v1), g2_pack_bf16(v2, v3));
-      else
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = make_float4(v0, v1, v2, v3);
+      if (live) {
+        if (p.out_bf16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) =
+              make_uint2(g2_pack_bf16(v0, v1), g2_pack_bf16(v2, v3));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = make_float4(v0, v1, v2, v3);
+      }
+      if (p.ln_out) {  // keep the row for the LayerNorm below
+        acc[jt][s] = f32x4{v0, v1, v2, v3};
+        rsum[s] += (v0 + v1) + (v2 + v3);
+        rsq[s] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      }
+    }
+  }
+  if (!p.ln_out) return;
+  // ---- LayerNorm of the finished rows: a row's 256 values live in 4 lane groups (g) x 4 waves -------------------------------------
+  __syncthreads();  // the activation tile is dead: its LDS becomes the exchange buffer [2][4 waves][ROWS]
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    float a = rsum[s], b = rsq[s];
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 16, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (g == 0) {
+      red[wave * ROWS + 16 * s + c] = a;
+      red[4 * ROWS + wave * ROWS + 16 * s + c] = b;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int r = 16 * s + c;
+    const int m = m0 + r;
+    if (m >= p.M) continue;
+    const float sum = (red[r] + red[ROWS + r]) + (red[2 * ROWS + r] + red[3 * ROWS + r]);
+    const float sq = (red[4 * ROWS + r] + red[5 * ROWS + r]) + (red[6 * ROWS + r] + red[7 * ROWS + r]);
+    const float mean = sum * (1.0f / 256.0f);
+    const float var = fmaxf(sq * (1.0f / 256.0f) - mean * mean, 0.0f);
+    const float inv = 1.0f / sqrtf(var + p.ln_eps);
+    const float lrs = p.ln_row_scale ? p.ln_row_scale[m] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = n0 + 16 * jt + 4 * g;
+      const float4 ga = *reinterpret_cast<const float4*>(p.ln_gamma + n);
+      const float4 be = *reinterpret_cast<const float4*>(p.ln_beta + n);
+      const f32x4 v = acc[jt][s];
+      *reinterpret_cast<uint2*>(p.ln_out + (int64_t)m * p.ld_ln + n) =
+          make_uint2(g2_pack_bf16(((v[0] - mean) * inv * ga.x + be.x) * lrs, ((v[1] - mean) * inv * ga.y + be.y) * lrs),
+                     g2_pack_bf16(((v[2] - mean) * inv * ga.z + be.z) * lrs, ((v[3] - mean) * inv * ga.w + be.w) * lrs));
     }
   }
 }
@@ -173,8 +232,14 @@ extern "C" int ma_gemm_k256_pack_bf16(const void* W, int64_t ldw, int64_t N, int
   return MA_OK;
 }
 
-extern "C" int ma_gemm_k256_packed_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M,
-                                        int64_t N, int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream) {
+static int g2_launch(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
+                     const ma_gemm_epilogue_t* epi, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                     const float* ln_row_scale, void* ln_out, int64_t ld_ln, ma_stream_t stream) {
+  if (ln_out) {
+    if (!ln_gamma || !ln_beta || N != kG2Cols || ld_ln < N || (ld_ln & 3)) return MA_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(ln_gamma) | reinterpret_cast<uintptr_t>(ln_beta) | reinterpret_cast<uintptr_t>(ln_out)) & 15)
+      return MA_ERR_INVALID_ARG;
+  }
   if (!A || !packed || !out || !epi || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
   if (ma_gemm_k256_packed_bytes(N, K) < 0 || N > 0x7fffff00) return MA_ERR_UNSUPPORTED;
   if (epi->col_scale || epi->col_shift || epi->act2 || epi->act < 0 || epi->act > 2) return MA_ERR_UNSUPPORTED;
@@ -197,6 +262,12 @@ extern "C" int ma_gemm_k256_packed_bf16(const void* A, int64_t lda, const void* 
   p.alpha = epi->alpha;
   p.act = epi->act;
   p.out_bf16 = epi->out_bf16;
+  p.ln_gamma = ln_gamma;
+  p.ln_beta = ln_beta;
+  p.ln_row_scale = ln_row_scale;
+  p.ln_out = reinterpret_cast<uint16_t*>(ln_out);
+  p.ld_ln = ld_ln;
+  p.ln_eps = ln_eps;
   const unsigned nby = (unsigned)(N / kG2Cols);
   if ((M + 63) / 64 * nby < 384) {  // well under two 64-row workgroups per CU: halve the rows
     MA_LAUNCH(gemm_k256_kernel<32>, dim3((unsigned)((M + 31) / 32), nby), dim3(kG2Threads), 32 * kG2Pitch, (hipStream_t)stream, p);
@@ -204,4 +275,17 @@ extern "C" int ma_gemm_k256_packed_bf16(const void* A, int64_t lda, const void* 
     MA_LAUNCH(gemm_k256_kernel<64>, dim3((unsigned)((M + 63) / 64), nby), dim3(kG2Threads), 64 * kG2Pitch, (hipStream_t)stream, p);
   }
   return MA_OK;
+}
+
+extern "C" int ma_gemm_k256_packed_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M,
+                                        int64_t N, int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream) {
+  return g2_launch(A, lda, packed, out, ldo, M, N, K, epi, nullptr, nullptr, 0.f, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int ma_gemm_k256_packed_ln_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M,
+                                           int64_t N, int64_t K, const ma_gemm_epilogue_t* epi, const float* ln_gamma,
+                                           const float* ln_beta, float ln_eps, const float* ln_row_scale, void* ln_out,
+                                           int64_t ld_ln, ma_stream_t stream) {
+  if (!ln_out) return MA_ERR_INVALID_ARG;
+  return g2_launch(A, lda, packed, out, ldo, M, N, K, epi, ln_gamma, ln_beta, ln_eps, ln_row_scale, ln_out, ld_ln, stream);
 }

@@ -270,9 +270,14 @@ class ConformerEncoder(nn.Module):
             qkv = dense(a, W, "qkv", bias=W["qkv_b"])
             ctx = ops.relpos_attention(qkv, pos_all[:, li * 256:(li + 1) * 256], W["u"], W["v"], att_mask, b, t2,
                                        self.heads, 64)
-            dense(ctx, W, "o", bias=W["o_b"], residual=x, out_dtype=f32, out=x)
             # x = x + ConvModule(LN(x), mask_pad)                                  :139-143, convolution.py:83-129
-            a = ops.layernorm(x, l.norm_conv.gamma, l.norm_conv.beta, row_scale=mask_rows)
+            if packed_gemm and W["o_pk"] is not None and os.environ.get("MA_GEMM_LN", "1") != "0":
+                # output projection + residual + norm_conv (+ mask) in one launch
+                _, a = ops.gemm_packed_ln(ctx, W["o_pk"], l.norm_conv.gamma, l.norm_conv.beta, ln_row_scale=mask_rows,
+                                          bias=W["o_b"], residual=x, out=x)
+            else:
+                dense(ctx, W, "o", bias=W["o_b"], residual=x, out_dtype=f32, out=x)
+                a = ops.layernorm(x, l.norm_conv.gamma, l.norm_conv.beta, row_scale=mask_rows)
             y = dense(a, W, "pw1", bias=W["pw1_b"])
             z = ops.convmodule_mid(y, W["dw_w"], W["bn_scale"], W["bn_shift"], b, t2)
             dense(z, W, "pw2", bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)

@@ -102,6 +102,26 @@ def gemm_packed(a, packed, bias=None, residual=None, row_scale=None, alpha=1.0, 
     return out
 
 
+def gemm_packed_ln(a, packed, ln_gamma, ln_beta, ln_row_scale=None, eps=1e-5, bias=None, residual=None, row_scale=None,
+                   alpha=1.0, act=_lib.ACT_NONE, out=None):
+    """gemm_packed (N = 256, float32 out) + the LayerNorm behind it in one launch: returns (out, bf16 LayerNorm(out) * ln_row_scale)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and a.shape[1] == packed.shape[1]
+    m, k = a.shape
+    n = packed.shape[0]
+    if out is None:
+        out = t.empty((m, n), dtype=t.float32, device=a.device)
+    assert out.dtype == t.float32 and out.stride(1) == 1 and tuple(out.shape) == (m, n)
+    ln_out = t.empty((m, n), dtype=t.bfloat16, device=a.device)
+    e = _epilogue(bias, residual, row_scale, alpha, act, False)
+    rc = lib.ma_gemm_k256_packed_ln_bf16(_host.ptr(a), a.stride(0), _host.ptr(packed), _host.ptr(out), out.stride(0), m, n, k,
+                                         ctypes.byref(e), _host.ptr(ln_gamma), _host.ptr(ln_beta), float(eps),
+                                         _opt(ln_row_scale), _host.ptr(ln_out), ln_out.stride(0), _host.current_stream_ptr())
+    _lib.check(rc, "gemm_k256_packed_ln_bf16")
+    return out, ln_out
+
+
 def ffn(a, w1, b1, w2, b2, x, alpha=0.5):
     """In place x += alpha * (swish(a @ w1^T + b1) @ w2^T + b2); a (M, 256) bf16, x (M, 256) float32."""
     t = _host.torch()

@@ -124,6 +124,14 @@ def test_gemm_k256_packed(t, m, n):
     got = ops.gemm_packed(a, pk, bias=bias, residual=res, row_scale=rs, alpha=0.5, out_dtype=t.float32).double()
     want = res.double() + 0.5 * z * rs.double()[:, None]
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    if n == 256:  # LayerNorm of the output rows fused behind the epilogue
+        gam, bet = (1 + 0.1 * _rand(t, n, seed=24)).cuda(), (0.1 * _rand(t, n, seed=25)).cuda()
+        x2 = res.clone()
+        o, a_ln = ops.gemm_packed_ln(a, pk, gam, bet, ln_row_scale=rs, bias=bias, residual=x2, out=x2)
+        want_o = ops.gemm_packed(a, pk, bias=bias, residual=res, out_dtype=t.float32)
+        assert o is x2 and t.equal(o, want_o)
+        want_ln = ops.layernorm(want_o, gam, bet, row_scale=rs).float()
+        assert a_ln.dtype == t.bfloat16 and float((a_ln.float() - want_ln).abs().max()) <= 2 ** -7 * float(want_ln.abs().max())
     wide = _rand(t, m, 3 * k, seed=19).bfloat16().cuda()  # strided A, in-place residual
     x = res.clone()
     ops.gemm_packed(wide[:, k:2 * k], pk, residual=x, out_dtype=t.float32, out=x)

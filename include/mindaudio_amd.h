@@ -224,7 +224,8 @@ int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t id
  *   qkv  device bf16 (batch*T, >= 768): columns [0,256) q, [256,512) k, [512,768) v, head h at h*64
  *   pos  device bf16 (T, 256): linear_pos(pos_emb), shared by the batch (attention.py:210-211,230)
  *   bias_u / bias_v float32 (heads, 64); mask float32 (batch, T) or NULL; ctx bf16 (batch*T, 256);
- *   vt_workspace: device scratch of ma_relpos_attention_workspace_bytes() for the per-head transposed V. */
+ *   vt_workspace: device scratch of ma_relpos_attention_workspace_bytes() (reserved: V is now read from qkv as stored, with
+ *   transposing LDS reads; the buffer is not written). */
 int64_t ma_relpos_attention_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k);
 int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos,
                              const float* bias_u, const float* bias_v, const float* mask, int64_t batch,

@@ -202,12 +202,13 @@ __global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __res
 //                                                                    (lane >> 4) * 8 + j of the MFMA is mapped to
 //                                                                    key (j >> 2) * 16 + (lane >> 4) * 4 + (j & 3);
 //                                                                    V^T is read with the same mapping (two 8-byte
-//                                                                    LDS reads per fragment).
+//                                                                    transposing LDS reads per fragment).
 // Row max / sum: 16 values in the lane + two shuffles (xor 16, 32).  Output row q = lane & 15 again, 4 consecutive d
-// per accumulator -> 8-byte bf16 stores.  V^T comes from ma_transpose_v (vt: (B, H, 64, Tp), Tp % 64 == 0, zero padded).
+// per accumulator -> 8-byte bf16 stores.  V is staged as stored ([key][d]) and read with ds_read_b64_tr_b16; the `vt` / `Tp` arguments are unused (kept for the ABI).
 constexpr int kAttQ = 64, kAttK = 64, kDk = 64;
 constexpr int kKpStride = 128 + 8;   // bf16 elements per K' row (272 B: conflict-free 16-byte fragment reads)
-constexpr int kVtStride = 64 + 4;    // bf16 elements per V^T row (136 B: 8-byte aligned rows)
+constexpr int kVsStride = 80;        // bf16 elements per V row (160 B = 40 dwords: the 8 rows x 32 B that one half-wave of a
+                                     // transposing read touches fall on 64 distinct banks)
 
 __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                                const uint16_t* __restrict__ pos, int64_t ld_pos,
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
                                                                float scale, uint16_t* __restrict__ ctx,
                                                                int64_t ld_ctx, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) uint16_t Kp[kAttK * kKpStride];
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[kDk * kVtStride];
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[kAttK * kVsStride];  // V tile as stored: [key][d]
   __shared__ float maskadd[kAttK];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
   const int64_t row0 = (int64_t)b * T;
   const int q_base = qt * kAttQ + wave * 16;
   const int lq = lane & 15, lg = lane >> 4;
-  const uint16_t* vt_bh = vt + ((int64_t)b * H + h) * kDk * Tp;
+  (void)vt;
+  (void)Tp;
   const float scale2 = scale * 1.4426950408889634f;
 
   // ---- Q' fragments (B operand): lane holds query row lq, k = kstep*32 + lg*8 .. +7 of [q+u | q+v] -------------
@@ -253,6 +255,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
     }
   }
 
+  const uint32_t vs_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Vs +
+                           ((lg * 4 + (lq >> 2)) * kVsStride + (lq & 3) * 4) * 2;
   f32x4 oacc[4];  // O^T: rows d = dt*16 + lg*4 + r, column q = lq
 #pragma unroll
   for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
   // (named registers + a macro: arrays captured by a lambda end up in scratch memory)
   uint4 rk0, rk1, rk2, rk3, rv0, rv1;
   const int sk_key = tid >> 4, sk_ch = tid & 15;   // K' piece i: key sk_key + 16 i, 16-byte chunk sk_ch
-  const int sv_d = tid >> 3, sv_ch = tid & 7;      // V^T piece i: d sv_d + 32 i, chunk sv_ch
+  const int sv_key = tid >> 3, sv_ch = tid & 7;    // V piece i: key sv_key + 32 i, 16-byte chunk sv_ch of its 64 d
   const uint16_t* ksrc_base = (sk_ch < 8) ? qkv + row0 * ld_qkv + 256 + h * kDk + sk_ch * 8
                                           : pos + h * kDk + (sk_ch - 8) * 8;
   const int64_t ksrc_ld = (sk_ch < 8) ? ld_qkv : ld_pos;
@@ -278,8 +282,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
   {                                                                                   \
     const int k0f_ = (kt_)*kAttK;                                                     \
     MA_ATT_KLOAD(rk0, 0, k0f_) MA_ATT_KLOAD(rk1, 1, k0f_) MA_ATT_KLOAD(rk2, 2, k0f_) MA_ATT_KLOAD(rk3, 3, k0f_) \
-    rv0 = *reinterpret_cast<const uint4*>(vt_bh + (int64_t)sv_d * Tp + k0f_ + sv_ch * 8);         \
-    rv1 = *reinterpret_cast<const uint4*>(vt_bh + (int64_t)(sv_d + 32) * Tp + k0f_ + sv_ch * 8);  \
+    {                                                                                 \
+      const int v0_ = k0f_ + sv_key, v1_ = k0f_ + sv_key + 32;                        \
+      const uint16_t* vb_ = qkv + row0 * ld_qkv + 512 + h * kDk + sv_ch * 8;          \
+      rv0 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)(v0_ < T ? v0_ : T - 1) * ld_qkv);     \
+      rv1 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)(v1_ < T ? v1_ : T - 1) * ld_qkv);     \
+      if (v0_ >= T) rv0 = make_uint4(0, 0, 0, 0); /* keys past T: probability 0 x a FINITE value */ \
+      if (v1_ >= T) rv1 = make_uint4(0, 0, 0, 0);                                     \
+    }                                                                                 \
   }
   MA_ATT_FETCH(0)
   for (int kt = 0; kt < n_kt; ++kt) {
@@ -289,14 +299,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
     *reinterpret_cast<uint4*>(&Kp[(sk_key + 16) * kKpStride + sk_ch * 8]) = rk1;
     *reinterpret_cast<uint4*>(&Kp[(sk_key + 32) * kKpStride + sk_ch * 8]) = rk2;
     *reinterpret_cast<uint4*>(&Kp[(sk_key + 48) * kKpStride + sk_ch * 8]) = rk3;
-    {
-      uint2* d0 = reinterpret_cast<uint2*>(&Vt[sv_d * kVtStride + sv_ch * 8]);
-      d0[0] = make_uint2(rv0.x, rv0.y);
-      d0[1] = make_uint2(rv0.z, rv0.w);
-      uint2* d1 = reinterpret_cast<uint2*>(&Vt[(sv_d + 32) * kVtStride + sv_ch * 8]);
-      d1[0] = make_uint2(rv1.x, rv1.y);
-      d1[1] = make_uint2(rv1.z, rv1.w);
-    }
+    *reinterpret_cast<uint4*>(&Vs[sv_key * kVsStride + sv_ch * 8]) = rv0;
+    *reinterpret_cast<uint4*>(&Vs[(sv_key + 32) * kVsStride + sv_ch * 8]) = rv1;
     if (tid < kAttK) {
       const int kj = k0 + tid;
       // keys past T do not exist (-inf); padded keys inside T get the reference's additive -10000
@@ -351,12 +355,22 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
     for (int ks = 0; ks < 2; ++ks) {
       const uint4 ppk = make_uint4(pb[2 * ks][0], pb[2 * ks][1], pb[2 * ks + 1][0], pb[2 * ks + 1][1]);
       const bf16x8 pf = __builtin_bit_cast(bf16x8, ppk);
+      // V^T fragments straight from the [key][d] tile with transposing reads: in a 16-lane group, lane 4a + b addresses
+      // (key k0 + a, d n0 + 4b .. +3) and receives keys k0 .. k0+3 of d = n0 + (lane & 15)   [tools/ubench/tr_read.hip]
+      unsigned long long vlo[4], vhi[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const uint16_t* vrow = &Vt[(dt * 16 + lq) * kVtStride + ks * 32 + lg * 4];
-        const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);        // keys (2ks)*16 + lg*4 .. +3
-        const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 16);   // keys (2ks+1)*16 + lg*4 .. +3
-        const uint4 vpk = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        const uint32_t ad = vs_addr + (ks * 32 * kVsStride + dt * 16) * 2;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[dt]) : "v"(ad) : "memory");                             // keys (2ks)*16 + lg*4 ..
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[dt]) : "v"(ad), "n"(16 * kVsStride * 2) : "memory");  // (2ks+1)*16 + ..
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vlo[0]), "+v"(vlo[1]), "+v"(vlo[2]), "+v"(vlo[3]), "+v"(vhi[0]), "+v"(vhi[1]), "+v"(vhi[2]), "+v"(vhi[3])
+                   :
+                   : "memory");
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint4 vpk = make_uint4((uint32_t)vlo[dt], (uint32_t)(vlo[dt] >> 32), (uint32_t)vhi[dt], (uint32_t)(vhi[dt] >> 32));
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vpk), pf, oacc[dt], 0, 0, 0);
       }
     }
@@ -380,31 +394,6 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* _
 
 #undef MA_ATT_FETCH
 #undef MA_ATT_KLOAD
-
-// V (B*T, H*64) slice of the qkv buffer -> V^T (B, H, 64, Tp) bf16, zero padded to Tp (multiple of 64) keys.
-__global__ __launch_bounds__(256) void transpose_v_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv, int T, int H,
-                                                          int Tp, uint16_t* __restrict__ vt) {
-  __shared__ uint16_t tile[64][64 + 2];
-  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  for (int c = threadIdx.x; c < 64 * 8; c += 256) {  // 64 keys x 8 chunks of 8 d
-    const int key = c >> 3, ch = c & 7;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (t0 + key < T) val = *reinterpret_cast<const uint4*>(qkv + ((int64_t)b * T + t0 + key) * ld_qkv + 512 + h * 64 + ch * 8);
-    const uint32_t w[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      tile[key][ch * 8 + 2 * e] = (uint16_t)(w[e] & 0xffff);
-      tile[key][ch * 8 + 2 * e + 1] = (uint16_t)(w[e] >> 16);
-    }
-  }
-  __syncthreads();
-  uint16_t* o = vt + ((int64_t)b * H + h) * 64 * Tp + t0;
-  for (int c = threadIdx.x; c < 64 * 32; c += 256) {  // 64 d x 32 key pairs
-    const int d = c >> 5, kp = c & 31;
-    const uint32_t v = (uint32_t)tile[2 * kp][d] | ((uint32_t)tile[2 * kp + 1][d] << 16);
-    *reinterpret_cast<uint32_t*>(o + (int64_t)d * Tp + 2 * kp) = v;
-  }
-}
 
 // ---- conv module middle: GLU -> depthwise conv (KS taps, zero padded per utterance) -> affine (BN) -> Swish ----
 // y: (B*T, 2C) bf16 = pointwise_conv1 output (value | gate); out (B*T, C) bf16.
@@ -632,9 +621,7 @@ static int relpos_attention_fwd(const void* qkv, int64_t ld_qkv, const void* pos
   const int Tp = (int)((T + 63) / 64 * 64);
   if (vt_bytes < ma_relpos_attention_workspace_bytes(batch, T, heads, d_k)) return MA_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  MA_LAUNCH(transpose_v_kernel, dim3((unsigned)(Tp / 64), (unsigned)heads, (unsigned)batch), dim3(256), 0, s,
-            reinterpret_cast<const uint16_t*>(qkv), ld_qkv, (int)T, (int)heads, Tp,
-            reinterpret_cast<uint16_t*>(vt_workspace));
+  // (V is read from the qkv buffer as stored; the V^T workspace of earlier revisions is no longer written)
   const dim3 grid((unsigned)((T + kAttQ - 1) / kAttQ), (unsigned)heads, (unsigned)batch);
   MA_LAUNCH(relpos_attention_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
             reinterpret_cast<const uint16_t*>(pos), ld_pos, reinterpret_cast<const uint16_t*>(vt_workspace), Tp, bias_u,

@@ -544,6 +544,15 @@ int ma_conv2d_3x3s2_pack_bf16(const void* W, int64_t C, int64_t Cout, void* pack
 int ma_conv2d_3x3s2_packed_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* packed,
                                      int64_t Cout, const float* bias, int32_t relu, void* out, ma_stream_t stream);
 
+/* ma_convmodule_mid_bf16 + pointwise_conv2 + mask_pad + the block's residual in one launch (layers/convolution.py:100-127,
+ * models/conformer.py:143; C = 256, odd kernel_size <= 15):
+ *   x[m, :] += mask[m] * (swish(bn(depthwise(glu(y))))[m, :] . Wp2^T + pw2_bias)
+ * y (batch*T, 512) bf16; pw2_packed = ma_gemm_k256_pack_bf16 of the (256, 256) pointwise_conv2 weight; mask (batch*T) or NULL;
+ * x (batch*T, 256) float32 updated in place. */
+int ma_convmid_pw2_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw, int32_t kernel_size,
+                        const float* bn_scale, const float* bn_shift, const void* pw2_packed, const float* pw2_bias,
+                        const float* mask, float* x, int64_t ldx, ma_stream_t stream);
+
 /* Dense / k=1 Conv1d with K = 256 inputs (linear_q/k/v/out: layers/attention.py:51-56; pointwise_conv1/2:
  * layers/convolution.py:52-78) on a fragment-ordered packed copy of W (gemm_k256.hip): same result as ma_gemm_bf16.
  *   ma_gemm_k256_packed_bytes(N, K) -> bytes of the packed buffer (negative: unsupported; K = 256, N % 256 == 0);

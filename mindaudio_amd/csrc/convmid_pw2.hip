@@ -1,0 +1,230 @@
+// Second half of ConvolutionModule in one launch (mindaudio/models/layers/convolution.py:100-127, C = 256, odd k <= 15):
+//
+//     z = swish(bn(depthwise_k(glu(y))))                 (convmodule_mid_kernel, conformer_kernels.hip)
+//     x[m, :] += mask[m] * (z[m, :] . Wp2^T + bp2)       (pointwise_conv2 + mask_pad + the block's residual, models/conformer.py:143)
+//
+// The conv-middle kernel writes z (M x 256 bf16) and the pointwise GEMM reads it back; here a workgroup produces a 32-frame tile
+// of z for one utterance in registers, drops it as bf16 into the LDS tile the K = 256 GEMM of gemm_k256.hip wants, and multiplies
+// it by the fragment-packed Wp2 (each wave owns 64 output columns, weights L2 -> registers).  One launch and 16 MB of HBM round
+// trip fewer per block.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int kCpTile = 32, kCpC = 256, kCpMaxK = 15, kCpPitch = 544;
+
+__device__ __forceinline__ float cp_from_bf16(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+__device__ __forceinline__ uint32_t cp_pack_bf16(float lo, float hi) {
+  const bf16x2 r = __builtin_convertvector((f32x2){lo, hi}, bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+__device__ __forceinline__ float cp_sigmoid_mul(float v, float gate) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gate));
+}
+
+struct ConvPw2Params {
+  const uint16_t* y;   // (B*T, 512) bf16: pointwise_conv1 output (value | gate)
+  int64_t ldy;
+  const float* dw;     // (256, KS)
+  const float* bn_scale;
+  const float* bn_shift;
+  const uint4* wp;     // pointwise_conv2 weight, packed as gemm_k256.hip: [16 tiles][8 k-steps][64 lanes] x 16 B
+  const float* bias;   // (256)
+  const float* mask;   // (B*T) or NULL
+  float* x;            // (B*T, 256) f32 residual stream, updated in place
+  int64_t ldx;
+  int32_t T, KS;
+};
+
+__global__ __launch_bounds__(256, 2) void convmid_pw2_kernel(const ConvPw2Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* glu = reinterpret_cast<float*>(smem);  // [(32 + KS - 1)][256] f32, then the KS x 256 taps; later the bf16 z tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * kCpTile;
+  const int cg = tid & 31, rg = tid >> 5;  // conv phase: channels 8 cg .. + 7, frames 4 rg .. + 3 of the tile
+  const int c0 = cg * 8;
+  const int KS = p.KS, half = KS / 2, span = kCpTile + KS - 1;
+  const int64_t row0 = (int64_t)b * p.T;
+  float* wl = glu + span * 256;
+  for (int i = tid; i < KS * 256; i += 256) wl[i] = p.dw[(i & 255) * KS + (i >> 8)];  // wl[k][c]
+  for (int i = rg; i < span; i += 8) {
+    const int t = t0 + i - half;
+    float gl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t >= 0 && t < p.T) {
+      const uint4 av = *reinterpret_cast<const uint4*>(p.y + (row0 + t) * p.ldy + c0);
+      const uint4 gv = *reinterpret_cast<const uint4*>(p.y + (row0 + t) * p.ldy + kCpC + c0);
+      const uint32_t aw[4] = {av.x, av.y, av.z, av.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // layers/glu.py:24-28: out * sigmoid(gate)
+        gl[2 * e] = cp_sigmoid_mul(cp_from_bf16(aw[e] & 0xffff), cp_from_bf16(gw[e] & 0xffff));
+        gl[2 * e + 1] = cp_sigmoid_mul(cp_from_bf16(aw[e] >> 16), cp_from_bf16(gw[e] >> 16));
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(glu + i * 256 + c0);
+    dst[0] = make_float4(gl[0], gl[1], gl[2], gl[3]);
+    dst[1] = make_float4(gl[4], gl[5], gl[6], gl[7]);
+  }
+  __syncthreads();
+  // ---- depthwise conv + BatchNorm (affine) + Swish: 4 consecutive frames x 8 channels per thread, taps in registers ----------
+  uint4 zrow[4];
+  {
+    float w[kCpMaxK][8];
+#pragma unroll
+    for (int k = 0; k < kCpMaxK; ++k) {
+      if (k < KS) {
+        const float4* wp4 = reinterpret_cast<const float4*>(wl + k * 256 + c0);
+        const float4 w0 = wp4[0], w1 = wp4[1];
+        w[k][0] = w0.x; w[k][1] = w0.y; w[k][2] = w0.z; w[k][3] = w0.w;
+        w[k][4] = w1.x; w[k][5] = w1.y; w[k][6] = w1.z; w[k][7] = w1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[k][e] = 0.0f;
+      }
+    }
+    float acc[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[o][e] = 0.0f;
+    const int i0 = rg * 4;
+#pragma unroll
+    for (int r = 0; r < kCpMaxK + 3; ++r) {  // GLU row i0 + r feeds output o with tap k = r - o
+      if (r < KS + 3) {
+        const float4* gp = reinterpret_cast<const float4*>(glu + (i0 + r) * 256 + c0);
+        const float4 g0 = gp[0], g1 = gp[1];
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int k = r - o;
+          if (k >= 0 && k < kCpMaxK) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(w[k][e], gv[e], acc[o][e]);
+          }
+        }
+      }
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = p.bn_scale[c0 + e];
+      sh[e] = p.bn_shift[c0 + e];
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z0 = acc[o][2 * e] * sc[2 * e] + sh[2 * e];
+        const float z1 = acc[o][2 * e + 1] * sc[2 * e + 1] + sh[2 * e + 1];
+        pk[e] = cp_pack_bf16(cp_sigmoid_mul(z0, z0), cp_sigmoid_mul(z1, z1));
+      }
+      zrow[o] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+  }
+  // ---- pointwise_conv2 weights of this wave (64 output columns): L2 -> registers, in flight across the barrier ----------------
+  bf16x8 wf[4][8];
+  {
+    const uint4* base = p.wp + ((int64_t)(wave * 4) * 8) * 64 + lane;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
+  }
+  __syncthreads();  // every thread is done with the GLU rows: their LDS becomes the z tile [32][544 B]
+#pragma unroll
+  for (int o = 0; o < 4; ++o) *reinterpret_cast<uint4*>(smem + (rg * 4 + o) * kCpPitch + cg * 16) = zrow[o];
+  __syncthreads();
+  // ---- z . Wp2^T : as gemm_k256_kernel<32> ------------------------------------------------------------------------------------
+  const int c = lane & 15, g = lane >> 4;
+  f32x4 acc2[4][2];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc2[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* abase = smem + c * kCpPitch + g * 16;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    bf16x8 af[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) af[s] = *reinterpret_cast<const bf16x8*>(abase + s * 16 * kCpPitch + ks * 64);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc2[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], af[s], acc2[jt][s], 0, 0, 0);
+  }
+  // ---- x += mask * (acc + bias): lane (c, g) holds frames t0 + 16 s + c, columns 64 wave + 16 jt + 4 g + r -----------------------
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = t0 + 16 * s + c;
+    if (t >= p.T) continue;
+    const int64_t m = row0 + t;
+    const float rs = p.mask ? p.mask[m] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = 64 * wave + 16 * jt + 4 * g;
+      const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+      float4* xp = reinterpret_cast<float4*>(p.x + m * p.ldx + n);
+      float4 xv = *xp;
+      xv.x += (acc2[jt][s][0] + bv.x) * rs;
+      xv.y += (acc2[jt][s][1] + bv.y) * rs;
+      xv.z += (acc2[jt][s][2] + bv.z) * rs;
+      xv.w += (acc2[jt][s][3] + bv.w) * rs;
+      *xp = xv;
+    }
+  }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" int ma_convmid_pw2_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw,
+                                   int32_t kernel_size, const float* bn_scale, const float* bn_shift, const void* pw2_packed,
+                                   const float* pw2_bias, const float* mask, float* x, int64_t ldx, ma_stream_t stream) {
+  if (!y || !dw || !bn_scale || !bn_shift || !pw2_packed || !pw2_bias || !x || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
+  if (C != kCpC || kernel_size < 1 || kernel_size > kCpMaxK || (kernel_size & 1) == 0 || batch > 65535) return MA_ERR_UNSUPPORTED;
+  if ((ldy & 7) || ldy < 2 * kCpC || (ldx & 3) || ldx < kCpC) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(pw2_packed) | reinterpret_cast<uintptr_t>(x) |
+       reinterpret_cast<uintptr_t>(pw2_bias) | reinterpret_cast<uintptr_t>(bn_scale) | reinterpret_cast<uintptr_t>(bn_shift)) & 15)
+    return MA_ERR_INVALID_ARG;
+  ConvPw2Params p;
+  p.y = reinterpret_cast<const uint16_t*>(y);
+  p.ldy = ldy;
+  p.dw = dw;
+  p.bn_scale = bn_scale;
+  p.bn_shift = bn_shift;
+  p.wp = reinterpret_cast<const uint4*>(pw2_packed);
+  p.bias = pw2_bias;
+  p.mask = mask;
+  p.x = x;
+  p.ldx = ldx;
+  p.T = (int32_t)T;
+  p.KS = kernel_size;
+  size_t lds = (size_t)(kCpTile + 2 * kernel_size - 1) * 256 * sizeof(float);
+  if (lds < (size_t)kCpTile * kCpPitch) lds = (size_t)kCpTile * kCpPitch;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_pw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (kCpTile + 2 * kCpMaxK - 1) * 256 * 4) != hipSuccess)
+      return MA_ERR_LAUNCH;
+    attr = true;
+  }
+  MA_LAUNCH(convmid_pw2_kernel, dim3((unsigned)((T + kCpTile - 1) / kCpTile), (unsigned)batch), dim3(256), lds, (hipStream_t)stream,
+            p);
+  return MA_OK;
+}

@@ -313,6 +313,19 @@ def convmodule_mid(y, dw, bn_scale, bn_shift, batch, T, out=None):
     return out
 
 
+def convmid_pw2(y, dw, bn_scale, bn_shift, pw2_packed, pw2_bias, mask_rows, x, batch, T):
+    """In place x += mask * (convmodule_mid(y) @ Wp2^T + bias): conv-module middle + pointwise_conv2 + residual in one launch."""
+    t = _host.torch()
+    lib = _lib.load()
+    c, ks = dw.shape
+    assert y.dtype == t.bfloat16 and y.shape[1] == 2 * c and y.stride(1) == 1 and x.dtype == t.float32 and x.stride(1) == 1
+    rc = lib.ma_convmid_pw2_bf16(_host.ptr(y), y.stride(0), batch, T, c, _host.ptr(dw), ks, _host.ptr(bn_scale),
+                                 _host.ptr(bn_shift), _host.ptr(pw2_packed), _host.ptr(pw2_bias), _opt(mask_rows), _host.ptr(x),
+                                 x.stride(0), _host.current_stream_ptr())
+    _lib.check(rc, "convmid_pw2")
+    return x
+
+
 def cast_bf16(x):
     """float32 device tensor -> bf16 copy (round to nearest even)."""
     t = _host.torch()

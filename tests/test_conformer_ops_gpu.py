@@ -97,6 +97,33 @@ def test_conv2d_3x3s2_packed(t, b, h, wd):
     assert ops.conv2d_3x3s2_pack(wk[:, :, :, :128].contiguous()) is None
 
 
+@pytest.mark.parametrize("b,tt,ks", [(3, 249, 15), (2, 33, 7), (5, 64, 15), (1, 5, 3)])
+def test_convmid_pw2_fused(t, b, tt, ks):
+    """conv-module middle + pointwise_conv2 + mask + residual in one launch == the two-kernel path."""
+    from mindaudio_amd import ops
+
+    c = 256
+    y = _rand(t, b * tt, 2 * c, seed=31).bfloat16().cuda()
+    dw = _rand(t, c, ks, seed=32, scale=0.3).cuda()
+    sc, sh = (1 + 0.1 * _rand(t, c, seed=33)).cuda(), (0.1 * _rand(t, c, seed=34)).cuda()
+    w2 = _rand(t, c, c, seed=35, scale=1.0 / 16).bfloat16().cuda()
+    b2 = _rand(t, c, seed=36).cuda()
+    mask = (t.rand(b * tt, generator=t.Generator().manual_seed(37)) > 0.2).float().cuda()
+    x0 = _rand(t, b * tt, c, seed=38).cuda()
+    pk = ops.gemm_k256_pack(w2)
+    z = ops.convmodule_mid(y, dw, sc, sh, b, tt)
+    want = x0.clone()
+    ops.gemm(z, w2, bias=b2, row_scale=mask, residual=want, out_dtype=t.float32, out=want)
+    got = x0.clone()
+    assert ops.convmid_pw2(y, dw, sc, sh, pk, b2, mask, got, b, tt) is got
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    got2 = x0.clone()
+    ops.convmid_pw2(y, dw, sc, sh, pk, b2, None, got2, b, tt)
+    want2 = x0.clone()
+    ops.gemm(z, w2, bias=b2, residual=want2, out_dtype=t.float32, out=want2)
+    assert float((got2 - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
+
+
 @pytest.mark.parametrize("m,n", [(64, 256), (777, 512), (15936, 768), (1, 256), (130, 1024)])
 def test_gemm_k256_packed(t, m, n):
     """K = 256 dense layers on fragment-packed weights: same contract (and epilogues) as ops.gemm."""

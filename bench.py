@@ -99,7 +99,7 @@ def main():
 
     def step():
         feats = ma.fbank(x, **kw)                                   # (64, 80, 1001) dB
-        xs = feats.transpose(1, 2)[:, :FRAMES].contiguous()         # (64, 1000, 80): layout glue only
+        xs = feats.transpose(1, 2)[:, :FRAMES]                      # (64, 1000, 80) VIEW of the (64, 80, 1001) fbank output
         return enc(xs, masks)[0]
 
     def barrier():

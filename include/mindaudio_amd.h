@@ -218,6 +218,11 @@ int ma_layernorm2_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, c
 int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t idim, const float* cmvn_mean,
                             const float* cmvn_istd, const float* w, const float* bias, int32_t C, void* out,
                             ma_stream_t stream);
+/* The same on a strided view x[b * stride_b + t * stride_t + f * stride_f] (element strides): lets the encoder take
+ * features.fbank's (batch, n_mels, frames) output as (batch, frames, n_mels) without a transposing copy. */
+int ma_subsample_conv1_strided_nhwc(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_f, int64_t batch, int64_t T,
+                                    int32_t idim, const float* cmvn_mean, const float* cmvn_istd, const float* w,
+                                    const float* bias, int32_t C, void* out, ma_stream_t stream);
 
 /* RelPositionMultiHeadedAttention core (layers/attention.py:214-235 + 100-113), one fused kernel:
  *   score = ((q + u) k^T + (q + v) p^T) / sqrt(d_k) + (mask == 0) * -10000 ; softmax ; . v     (no rel-shift)

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "ma_layernorm2_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, f32, ctypes.c_void_p, i64, ctypes.c_void_p,
                                          i64, i32, ctypes.c_void_p]),
+    "ma_subsample_conv1_strided_nhwc": (ctypes.c_int, [vp, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp]),
     "ma_subsample_conv1_nhwc": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p, i32, ctypes.c_void_p,
                                                ctypes.c_void_p]),

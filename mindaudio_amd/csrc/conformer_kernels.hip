@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
 // ---- CMVN + Conv2d(1 -> C, 3x3, stride 2, valid) + ReLU, output NHWC bf16 -----------------------------------
 // One workgroup per (b, output time t): 256 threads = channels (C == 256) or C/… loop; the 3 x idim input rows are
 // normalised into LDS once, each thread keeps its 9 weights in registers and walks the F1 output columns.
-__global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __restrict__ x, int64_t T, int idim,
+__global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __restrict__ x, int64_t sb, int64_t st, int64_t sf,
+                                                              int64_t T, int idim,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ istd,
                                                               const float* __restrict__ w,  // (C, 3, 3)
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __res
   const int t1 = (int)(bt - b * T1);
   for (int i = threadIdx.x; i < 3 * idim; i += blockDim.x) {
     const int kh = i / idim, f = i - kh * idim;
-    float v = x[(b * T + 2 * t1 + kh) * idim + f];
+    float v = x[b * sb + (2 * t1 + kh) * st + f * sf];  // any (batch, time, feature) strides: e.g. fbank's (B, n_mels, T)
     if (mean) v = (v - mean[f]) * istd[f];
     rows[i] = v;
   }
@@ -597,17 +598,30 @@ int ma_layernorm2_add_f32(const float* x, int64_t ldx, const float* addend, int6
                            ld_add, stream);
 }
 
-int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t idim, const float* cmvn_mean,
-                            const float* cmvn_istd, const float* w, const float* bias, int32_t C, void* out,
-                            ma_stream_t stream) {
+static int subsample_conv1_launch(const float* x, int64_t sb, int64_t st, int64_t sf, int64_t batch, int64_t T, int32_t idim,
+                                  const float* cmvn_mean, const float* cmvn_istd, const float* w, const float* bias, int32_t C,
+                                  void* out, ma_stream_t stream) {
   if (!x || !w || !bias || !out || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
   if ((cmvn_mean == nullptr) != (cmvn_istd == nullptr)) return MA_ERR_INVALID_ARG;
   if (C & 1) return MA_ERR_UNSUPPORTED;  // channel pairs per thread
   const int T1 = (int)((T - 3) / 2 + 1), F1 = (idim - 3) / 2 + 1;
   MA_LAUNCH(subsample_conv1_kernel, dim3((unsigned)(batch * T1)), dim3(256), 3 * idim * sizeof(float),
-            (hipStream_t)stream, x, T, idim, cmvn_mean, cmvn_istd, w, bias, C, T1, F1,
+            (hipStream_t)stream, x, sb, st, sf, T, idim, cmvn_mean, cmvn_istd, w, bias, C, T1, F1,
             reinterpret_cast<uint16_t*>(out));
   return MA_OK;
+}
+
+int ma_subsample_conv1_nhwc(const float* x, int64_t batch, int64_t T, int32_t idim, const float* cmvn_mean,
+                            const float* cmvn_istd, const float* w, const float* bias, int32_t C, void* out,
+                            ma_stream_t stream) {
+  return subsample_conv1_launch(x, T * idim, idim, 1, batch, T, idim, cmvn_mean, cmvn_istd, w, bias, C, out, stream);
+}
+
+int ma_subsample_conv1_strided_nhwc(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_f, int64_t batch, int64_t T,
+                                    int32_t idim, const float* cmvn_mean, const float* cmvn_istd, const float* w,
+                                    const float* bias, int32_t C, void* out, ma_stream_t stream) {
+  if (stride_b < 0 || stride_t < 0 || stride_f < 0) return MA_ERR_INVALID_ARG;
+  return subsample_conv1_launch(x, stride_b, stride_t, stride_f, batch, T, idim, cmvn_mean, cmvn_istd, w, bias, C, out, stream);
 }
 
 static int relpos_attention_fwd(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,

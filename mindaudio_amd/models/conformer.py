@@ -220,7 +220,7 @@ class ConformerEncoder(nn.Module):
         P = self._prepared
         f32 = torch.float32
         b, t, idim = xs.shape
-        xs = xs.to(f32).contiguous()
+        xs = xs.to(f32)  # (any strides: conv1 reads the view as it is)
         act1 = ops.subsample_conv1(xs, P["conv1_w"], P["conv1_b"], self.cmvn_mean, self.cmvn_istd)
         if P.get("conv2_pk") is not None and os.environ.get("MA_CONV2_PACKED", "1") != "0":
             act2 = ops.conv2d_3x3s2_packed(act1, P["conv2_pk"], P["conv2_b"], relu=True)

@@ -273,12 +273,13 @@ def subsample_conv1(x, w, bias, cmvn_mean=None, cmvn_istd=None):
     """x (B, T, idim) float32; w (C, 3, 3), bias (C) float32 -> NHWC bf16 (B, T1, F1, C) after CMVN, conv, ReLU."""
     t = _host.torch()
     lib = _lib.load()
-    assert x.dtype == t.float32 and x.is_contiguous() and w.is_contiguous()
+    assert x.dtype == t.float32 and x.dim() == 3 and w.is_contiguous()  # x: any strides (e.g. a transposed fbank output)
     b, tt, idim = x.shape
     c = w.shape[0]
     out = t.empty((b, (tt - 3) // 2 + 1, (idim - 3) // 2 + 1, c), dtype=t.bfloat16, device=x.device)
-    rc = lib.ma_subsample_conv1_nhwc(_host.ptr(x), b, tt, idim, _opt(cmvn_mean), _opt(cmvn_istd), _host.ptr(w),
-                                     _host.ptr(bias), c, _host.ptr(out), _host.current_stream_ptr())
+    rc = lib.ma_subsample_conv1_strided_nhwc(_host.ptr(x), x.stride(0), x.stride(1), x.stride(2), b, tt, idim, _opt(cmvn_mean),
+                                             _opt(cmvn_istd), _host.ptr(w), _host.ptr(bias), c, _host.ptr(out),
+                                             _host.current_stream_ptr())
     _lib.check(rc, "subsample_conv1")
     return out
 

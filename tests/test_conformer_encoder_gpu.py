@@ -148,3 +148,21 @@ def test_asr_model_ctc_eval_loss_matches_oracle():
     assert abs(float(loss) - want) <= 2e-2 * abs(want), (float(loss), want)  # bf16 matmuls vs float32 oracle
     assert abs(float(ASREvalNet(model, 1)(xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None,
                                           ys_lens.cuda(), sub.cuda())) - float(loss)) == 0.0
+
+
+def test_encoder_accepts_strided_features():
+    """The encoder takes features.fbank's (B, n_mels, T) output as a transposed VIEW: same result as on the contiguous copy."""
+    import torch
+
+    from mindaudio_amd.models import ConformerEncoder
+
+    torch.manual_seed(3)
+    enc = ConformerEncoder(80, 256, 4, 2048, 2).eval().cuda().prepare()
+    feats = torch.randn(3, 80, 131, device="cuda")            # fbank layout
+    view = feats.transpose(1, 2)[:, :128]                       # (3, 128, 80), strides (80*131, 1, 131)
+    masks = torch.ones(3, 1, (128 - 3) // 2 // 2, device="cuda")[:, :, :31]
+    t2 = ((128 - 3) // 2 + 1 - 3) // 2 + 1
+    masks = torch.ones(3, 1, t2, device="cuda")
+    a, _ = enc(view, masks)
+    b, _ = enc(view.contiguous(), masks)
+    assert not view.is_contiguous() and torch.equal(a, b)

@@ -97,20 +97,25 @@ def test_forward_backward_matches_oracle_autograd():
         assert rel_rms(v_, l_ref.conv_module.norm.running_var) < 2e-2
 
 
-def test_train_steps_follow_the_oracle_loss_curve():
-    """A few optimizer steps on one batch: Adam + ASRWarmupLR + dynamic loss scale vs the same recipe in PyTorch."""
+@pytest.mark.parametrize("n_steps", [6, 50])
+def test_train_steps_follow_the_oracle_loss_curve(n_steps):
+    """Optimizer steps on one batch: Adam + ASRWarmupLR + dynamic loss scale vs the same recipe in PyTorch (float32 oracle).
+    SURVEY 8d asks for >= 50 steps; the device path multiplies in bf16 (the reference's own compute_type is float16), so the
+    curves agree to bf16 round-off, not to 1e-4: the measured deviation is asserted and reported."""
     from mindaudio_amd.train.engine import ConformerCTCTrainStep, asr_warmup_lr
 
     ref_enc, ref_ctc, model = build(seed=6, cmvn=False)
     xs, ys, sub, ys_lens = batch(seed=10)
     params = list(ref_enc.parameters()) + list(ref_ctc.parameters())
     opt = torch.optim.Adam(params, lr=1.0, betas=(0.9, 0.999), eps=1e-8)
-    warm = 8
-    eng = ConformerCTCTrainStep(model, base_lr=2e-3, warmup_steps=warm, dropout_rate=0.0, positional_dropout_rate=0.0)
+    # 6 steps at an aggressive rate (the loss falls 4x: every part of the update rule matters); 50 steps at a gentle one, where
+    # two trajectories that differ by bf16 round-off stay comparable instead of diverging chaotically
+    warm, base = (8, 2e-3) if n_steps == 6 else (25, 2e-4)
+    eng = ConformerCTCTrainStep(model, base_lr=base, warmup_steps=warm, dropout_rate=0.0, positional_dropout_rate=0.0)
     cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
     got, want = [], []
-    for step in range(6):
-        lr = asr_warmup_lr(step, 2e-3, warm)
+    for step in range(n_steps):
+        lr = asr_warmup_lr(step, base, warm)
         for gq in opt.param_groups:
             gq["lr"] = lr
         opt.zero_grad()
@@ -122,8 +127,11 @@ def test_train_steps_follow_the_oracle_loss_curve():
         assert not overflow and scale == 1024.0 and abs(lr_dev - lr) < 1e-12
         got.append(float(loss))
     assert want[-1] < want[0]  # the recipe learns on this batch
+    dev = max(abs(a - b_) / abs(b_) for a, b_ in zip(got, want))
+    print("loss curve over %d steps: %.3f -> %.3f, max relative deviation from the float32 oracle %.2e" % (n_steps, want[0], want[-1], dev))
+    tol = 3e-2 if n_steps == 6 else 5e-3  # measured: 8e-3 / 1.3e-3
     for a, b_ in zip(got, want):
-        assert abs(a - b_) <= 3e-2 * abs(b_), (got, want)
+        assert abs(a - b_) <= tol * abs(b_), (got, want)
     # lr is 0 at step 0 (scheduler_factory.py:44-50): the first step must not move the weights
     assert abs(got[0] - got[1]) <= 2e-2 * abs(got[0]) or got[1] < got[0]
 

@@ -190,6 +190,87 @@ __global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __res
   }
 }
 
+// C == 256 form of the kernel above, shaped for the 2.9 GFMA / 637 MB of the north-star batch: a workgroup owns 8
+// consecutive output times of one utterance (17 input rows normalised into LDS once), a thread owns 8 channels (its
+// 72 weights stay in registers for all 8 rows) and every 8th output column; per output cell that is 9 broadcast LDS
+// reads for 72 FMAs (issued as v_pk_fma_f32 on channel pairs) and one 16-byte store - 32 lanes write the cell's 512
+// contiguous bytes.  Same FMA order per channel as the kernel above (bias, then taps kh-major): bit-identical output.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int kC1Rows = 8;
+
+__global__ __launch_bounds__(256) void subsample_conv1_c256_kernel(const float* __restrict__ x, int64_t sb, int64_t st, int64_t sf,
+                                                                   int64_t T, int idim, const float* __restrict__ mean,
+                                                                   const float* __restrict__ istd,
+                                                                   const float* __restrict__ w,  // (256, 3, 3)
+                                                                   const float* __restrict__ bias, int T1, int F1,
+                                                                   uint16_t* __restrict__ out) {
+  extern __shared__ float rows[];  // (2 * kC1Rows + 1) * idim
+  const int64_t b = blockIdx.y;
+  const int t1_0 = blockIdx.x * kC1Rows;
+  const int nrow = min(kC1Rows, T1 - t1_0);
+  const int nin = 2 * nrow + 1;
+  const int tid = threadIdx.x;
+  const float* xb = x + b * sb + (int64_t)(2 * t1_0) * st;
+  if (st <= sf) {  // time is the fast axis of the input view (fbank's (B, n_mels, T) layout): walk it first
+    for (int i = tid; i < nin * idim; i += 256) {
+      const int f = i / nin, r = i - f * nin;
+      float v = xb[r * st + f * sf];
+      if (mean) v = (v - mean[f]) * istd[f];
+      rows[r * idim + f] = v;
+    }
+  } else {
+    for (int i = tid; i < nin * idim; i += 256) {
+      const int r = i / idim, f = i - r * idim;
+      float v = xb[r * st + f * sf];
+      if (mean) v = (v - mean[f]) * istd[f];
+      rows[i] = v;
+    }
+  }
+  const int c0 = 8 * (tid & 31), fg = tid >> 5;
+  f32x2_t wv[4][9];
+  {
+    float wf[72];
+    const float4* wp = reinterpret_cast<const float4*>(w + c0 * 9);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const float4 q = wp[i];
+      wf[4 * i] = q.x, wf[4 * i + 1] = q.y, wf[4 * i + 2] = q.z, wf[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wv[j][k] = f32x2_t{wf[(2 * j) * 9 + k], wf[(2 * j + 1) * 9 + k]};
+  }
+  f32x2_t bv[4];
+  {
+    const float4 q0 = *reinterpret_cast<const float4*>(bias + c0), q1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+    bv[0] = f32x2_t{q0.x, q0.y}, bv[1] = f32x2_t{q0.z, q0.w}, bv[2] = f32x2_t{q1.x, q1.y}, bv[3] = f32x2_t{q1.z, q1.w};
+  }
+  __syncthreads();
+  for (int r = 0; r < nrow; ++r) {
+    uint16_t* o = out + ((b * T1 + t1_0 + r) * F1) * 256 + c0;
+    const float* in = rows + 2 * r * idim;
+    for (int f1 = fg; f1 < F1; f1 += 8) {
+      f32x2_t acc[4] = {bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float xv = in[kh * idim + 2 * f1 + kw];
+          const f32x2_t xx{xv, xv};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_elementwise_fma(wv[j][kh * 3 + kw], xx, acc[j]);
+        }
+      uint4 pk;
+      pk.x = pack2_bf16(fmaxf(acc[0].x, 0.0f), fmaxf(acc[0].y, 0.0f));
+      pk.y = pack2_bf16(fmaxf(acc[1].x, 0.0f), fmaxf(acc[1].y, 0.0f));
+      pk.z = pack2_bf16(fmaxf(acc[2].x, 0.0f), fmaxf(acc[2].y, 0.0f));
+      pk.w = pack2_bf16(fmaxf(acc[3].x, 0.0f), fmaxf(acc[3].y, 0.0f));
+      *reinterpret_cast<uint4*>(o + (int64_t)f1 * 256) = pk;
+    }
+  }
+}
+
 // ---- relative-position attention (no shift) ------------------------------------------------------------------
 //   score[i, j] = ((q_i + u) . k_j + (q_i + v) . p_j) / sqrt(dk) + (mask[b, j] == 0 ? -10000 : 0)
 //   ctx_i = softmax_j(score[i, :]) . V            (dk == 64; the two dot products run as ONE K = 128 contraction
@@ -605,6 +686,13 @@ static int subsample_conv1_launch(const float* x, int64_t sb, int64_t st, int64_
   if ((cmvn_mean == nullptr) != (cmvn_istd == nullptr)) return MA_ERR_INVALID_ARG;
   if (C & 1) return MA_ERR_UNSUPPORTED;  // channel pairs per thread
   const int T1 = (int)((T - 3) / 2 + 1), F1 = (idim - 3) / 2 + 1;
+  if (C == 256 && batch <= 65535 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0 && idim <= 512) {
+    MA_LAUNCH(subsample_conv1_c256_kernel, dim3((unsigned)((T1 + kC1Rows - 1) / kC1Rows), (unsigned)batch), dim3(256),
+              (2 * kC1Rows + 1) * idim * sizeof(float), (hipStream_t)stream, x, sb, st, sf, T, idim, cmvn_mean, cmvn_istd, w,
+              bias, T1, F1, reinterpret_cast<uint16_t*>(out));
+    return MA_OK;
+  }
   MA_LAUNCH(subsample_conv1_kernel, dim3((unsigned)(batch * T1)), dim3(256), 3 * idim * sizeof(float),
             (hipStream_t)stream, x, sb, st, sf, T, idim, cmvn_mean, cmvn_istd, w, bias, C, T1, F1,
             reinterpret_cast<uint16_t*>(out));

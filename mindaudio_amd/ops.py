@@ -54,15 +54,17 @@ def conv2d_3x3s2_pack(w):
     return packed
 
 
-def conv2d_3x3s2_packed(act, packed, bias, relu=True):
-    """conv2d_3x3s2_nhwc on a packed weight: act (B, H, W, 256) bf16 NHWC -> (B, Ho, Wo, 256) bf16."""
+def conv2d_3x3s2_packed(act, packed, bias, relu=True, out=None):
+    """conv2d_3x3s2_nhwc on a packed weight: act (B, H, W, 256) bf16 NHWC -> (B, Ho, Wo, 256) bf16 (into `out` if given)."""
     t = _host.torch()
     lib = _lib.load()
     assert act.dtype == t.bfloat16 and act.is_contiguous() and bias.dtype == t.float32
     b, h, wd, c = act.shape
     cout = bias.numel()
     ho, wo = (h - 3) // 2 + 1, (wd - 3) // 2 + 1
-    out = t.empty((b, ho, wo, cout), dtype=t.bfloat16, device=act.device)
+    if out is None:
+        out = t.empty((b, ho, wo, cout), dtype=t.bfloat16, device=act.device)
+    assert out.shape == (b, ho, wo, cout) and out.dtype == t.bfloat16 and out.is_contiguous()
     rc = lib.ma_conv2d_3x3s2_packed_nhwc_bf16(_host.ptr(act), b, h, wd, c, _host.ptr(packed), cout, _host.ptr(bias),
                                               1 if relu else 0, _host.ptr(out), _host.current_stream_ptr())
     _lib.check(rc, "conv2d_3x3s2_packed")
@@ -269,14 +271,17 @@ def layernorm2(x, g1, b1, g2, b2, eps=1e-5, out2_dtype=None, addend=None):
     return out2
 
 
-def subsample_conv1(x, w, bias, cmvn_mean=None, cmvn_istd=None):
+def subsample_conv1(x, w, bias, cmvn_mean=None, cmvn_istd=None, out=None):
     """x (B, T, idim) float32; w (C, 3, 3), bias (C) float32 -> NHWC bf16 (B, T1, F1, C) after CMVN, conv, ReLU."""
     t = _host.torch()
     lib = _lib.load()
     assert x.dtype == t.float32 and x.dim() == 3 and w.is_contiguous()  # x: any strides (e.g. a transposed fbank output)
     b, tt, idim = x.shape
     c = w.shape[0]
-    out = t.empty((b, (tt - 3) // 2 + 1, (idim - 3) // 2 + 1, c), dtype=t.bfloat16, device=x.device)
+    shape = (b, (tt - 3) // 2 + 1, (idim - 3) // 2 + 1, c)
+    if out is None:
+        out = t.empty(shape, dtype=t.bfloat16, device=x.device)
+    assert out.shape == shape and out.dtype == t.bfloat16 and out.is_contiguous()
     rc = lib.ma_subsample_conv1_strided_nhwc(_host.ptr(x), x.stride(0), x.stride(1), x.stride(2), b, tt, idim, _opt(cmvn_mean),
                                              _opt(cmvn_istd), _host.ptr(w), _host.ptr(bias), c, _host.ptr(out),
                                              _host.current_stream_ptr())

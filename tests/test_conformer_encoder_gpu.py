@@ -42,7 +42,9 @@ def _pair(num_blocks, seed=0, cmvn=False):
     return ref, dut.cuda().prepare()
 
 
-@pytest.mark.parametrize("blocks,b,tlen,cmvn", [(1, 2, 131, False), (2, 3, 203, True)])
+# the last case has 18 x 249 = 4482 subsampled rows: above the 4096-row switch, so the packed-weight kernels
+# (gemm_k256, convmid_pw2, gemm+LayerNorm epilogue, conv2_packed) are the ones compared with the oracle
+@pytest.mark.parametrize("blocks,b,tlen,cmvn", [(1, 2, 131, False), (2, 3, 203, True), (2, 18, 1000, True)])
 def test_encoder_matches_oracle(blocks, b, tlen, cmvn):
     import torch
 
@@ -51,7 +53,7 @@ def test_encoder_matches_oracle(blocks, b, tlen, cmvn):
     ref, dut = _pair(blocks, seed=blocks, cmvn=cmvn)
     g = torch.Generator().manual_seed(5)
     xs = torch.randn(b, tlen, 80, generator=g)
-    lens = [tlen, tlen - 40, tlen // 2][:b]
+    lens = ([tlen, tlen - 40, tlen // 2] + [tlen - 7 * i for i in range(3, b)])[:b]
     mask = torch.zeros(b, 1, tlen)
     for i, n in enumerate(lens):
         mask[i, 0, :n] = 1

@@ -208,16 +208,26 @@ def test_layernorm(t):
     assert float((got - ref2).abs().max()) <= 2 ** -8 * float(ref2.abs().max()) * 1.01
 
 
-def test_subsample_conv1(t):
+# C = 256 runs the 8-rows-per-workgroup kernel (ragged last group, odd idim, both input layouts); C = 64 the general one
+@pytest.mark.parametrize("tt,idim,c,cmvn,transposed", [(103, 80, 256, True, False), (103, 80, 256, False, True),
+                                                        (20, 23, 256, True, True), (3, 3, 256, False, False),
+                                                        (35, 80, 64, True, False)])
+def test_subsample_conv1(t, tt, idim, c, cmvn, transposed):
     from mindaudio_amd import ops
 
-    x = _rand(t, 3, 103, 80, seed=30)
-    w = _rand(t, 256, 1, 3, 3, seed=31, scale=0.3)
-    bias = _rand(t, 256, seed=32, scale=0.1)
-    mean = _rand(t, 80, seed=33)
-    istd = t.rand(80, generator=t.Generator().manual_seed(34)) + 0.5
-    ref = t.nn.functional.relu(t.nn.functional.conv2d(((x - mean) * istd).double().unsqueeze(1), w.double(), bias.double(), stride=2))
-    got = ops.subsample_conv1(x.cuda(), w.reshape(256, 9).contiguous().cuda(), bias.cuda(), mean.cuda(), istd.cuda())
+    x = _rand(t, 3, tt, idim, seed=30)
+    w = _rand(t, c, 1, 3, 3, seed=31, scale=0.3)
+    bias = _rand(t, c, seed=32, scale=0.1)
+    mean = _rand(t, idim, seed=33)
+    istd = t.rand(idim, generator=t.Generator().manual_seed(34)) + 0.5
+    xin = (x - mean) * istd if cmvn else x
+    ref = t.nn.functional.relu(t.nn.functional.conv2d(xin.double().unsqueeze(1), w.double(), bias.double(), stride=2))
+    xd = x.cuda()
+    if transposed:  # the (B, n_mels, T) fbank output viewed as (B, T, n_mels)
+        xd = xd.transpose(1, 2).contiguous().transpose(1, 2)
+        assert xd.stride(1) == 1
+    got = ops.subsample_conv1(xd, w.reshape(c, 9).contiguous().cuda(), bias.cuda(), mean.cuda() if cmvn else None,
+                              istd.cuda() if cmvn else None)
     got = got.permute(0, 3, 1, 2).double().cpu()
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) * 1.01

@@ -558,6 +558,17 @@ int ma_convmid_pw2_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T, in
                         const float* bn_scale, const float* bn_shift, const void* pw2_packed, const float* pw2_bias,
                         const float* mask, float* x, int64_t ldx, ma_stream_t stream);
 
+/* The whole ConvolutionModule behind its LayerNorm in one launch (layers/convolution.py:96-127 + models/conformer.py:143;
+ * C = 256, odd kernel_size <= 15): pointwise_conv1 + GLU + depthwise + BatchNorm(affine) + Swish + pointwise_conv2 + mask_pad +
+ * the block's residual:
+ *   x[m, :] += mask[m] * (swish(bn(depthwise(glu(a . Wp1^T + pw1_bias))))[m, :] . Wp2^T + pw2_bias)
+ * a (batch*T, 256) bf16 = norm_conv(x) * mask_pad; pw1_packed / pw2_packed = ma_gemm_k256_pack_bf16 of the (512, 256) /
+ * (256, 256) pointwise weights; mask (batch*T) or NULL; x (batch*T, 256) float32 updated in place. */
+int ma_convmodule_bf16(const void* a, int64_t lda, int64_t batch, int64_t T, int32_t C, const void* pw1_packed,
+                       const float* pw1_bias, const float* dw, int32_t kernel_size, const float* bn_scale, const float* bn_shift,
+                       const void* pw2_packed, const float* pw2_bias, const float* mask, float* x, int64_t ldx,
+                       ma_stream_t stream);
+
 /* Dense / k=1 Conv1d with K = 256 inputs (linear_q/k/v/out: layers/attention.py:51-56; pointwise_conv1/2:
  * layers/convolution.py:52-78) on a fragment-ordered packed copy of W (gemm_k256.hip): same result as ma_gemm_bf16.
  *   ma_gemm_k256_packed_bytes(N, K) -> bytes of the packed buffer (negative: unsupported; K = 256, N % 256 == 0);

@@ -189,6 +189,216 @@ __global__ __launch_bounds__(256, 2) void convmid_pw2_kernel(const ConvPw2Params
   }
 }
 
+
+// ---- the whole ConvolutionModule after its LayerNorm in one launch (convolution.py:96-127 + the block's residual) --------------
+//     y = glu(a . Wp1^T + bp1);  z = swish(bn(depthwise_k(y)));  x[m, :] += mask[m] * (z[m, :] . Wp2^T + bp2)
+// pointwise_conv1 is run by the workgroup itself on the 32 + k - 1 <= 46 (padded to 48) frames its 32-frame tile needs: the
+// (B*T, 512) intermediate (16 MB written + 24 MB read with halos at the north-star shape) and one launch per block disappear for
+// 1.5x the pointwise_conv1 MFMA work.  Phases:
+//   1. a-tile (48 frames x 256, bf16, pitch 544) -> LDS; a wave owns value columns 64w..64w+63 and their gate columns 256+64w..,
+//      in two passes of 32 columns (4 weight tiles x 8 k-steps = 32 fragments in registers, 12 accumulator tiles); GLU on the
+//      accumulators (out-of-utterance frames -> 0, the conv's zero padding), bf16 into the y tile [48][528 B];
+//   2. depthwise conv + BN + Swish as convmid_pw2_kernel (4 frames x 8 channels per thread), z tile over the dead a-tile;
+//   3. z . Wp2^T + epilogue as convmid_pw2_kernel.
+constexpr int kCmRows = 48, kCmYPitch = 528;
+constexpr int kCmOffY = kCmRows * kCpPitch;                 // 26112
+constexpr int kCmOffW = kCmOffY + kCmRows * kCmYPitch;      // 51456
+constexpr int kCmLds = kCmOffW + kCpMaxK * 256 * 4;         // 66816
+
+struct ConvModParams {
+  const uint16_t* a;   // (B*T, 256) bf16: norm_conv(x) * mask
+  int64_t lda;
+  const uint4* w1p;    // pointwise_conv1 weight (512 x 256), packed as gemm_k256.hip (32 tiles)
+  const float* b1;     // (512)
+  const float* dw;
+  const float* bn_scale;
+  const float* bn_shift;
+  const uint4* wp;
+  const float* bias;
+  const float* mask;
+  float* x;
+  int64_t ldx;
+  int32_t T, KS;
+};
+
+__global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * kCpTile;
+  const int KS = p.KS, half = KS / 2;
+  const int64_t row0 = (int64_t)b * p.T;
+  float* wl = reinterpret_cast<float*>(smem + kCmOffW);
+  char* ytile = smem + kCmOffY;
+
+  // ---- pass A weight fragments: tiles (value 4w, 4w+1 | gate 16+4w, 16+4w+1) ------------------------------------------------------
+  bf16x8 wf[4][8];
+#define CM_LOAD_W1(pass)                                                                                        \
+  {                                                                                                             \
+    _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) {                                                          \
+      const int tile = (jt >> 1) * 16 + wave * 4 + (pass) * 2 + (jt & 1);                                       \
+      const uint4* base = p.w1p + ((int64_t)tile * 8) * 64 + lane;                                              \
+      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + ks * 64); \
+    }                                                                                                           \
+  }
+  CM_LOAD_W1(0)
+  // ---- a-tile: frames t0 - half .. t0 - half + 47 (clamped into the utterance; clamped rows are zeroed after the GLU) -----------
+#pragma unroll
+  for (int it = 0; it < kCmRows / 8; ++it) {
+    const int idx = it * 256 + tid;
+    const int row = idx >> 5, ch = idx & 31;
+    int t = t0 + row - half;
+    t = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);
+    *reinterpret_cast<uint4*>(smem + row * kCpPitch + ch * 16) = *reinterpret_cast<const uint4*>(p.a + (row0 + t) * p.lda + ch * 8);
+  }
+  for (int i = tid; i < KS * 256; i += 256) wl[i] = p.dw[(i & 255) * KS + (i >> 8)];  // wl[k][c]
+  __syncthreads();
+
+  const char* abase = smem + c * kCpPitch + g * 16;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) acc[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bf16x8 af[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) af[s] = *reinterpret_cast<const bf16x8*>(abase + s * 16 * kCpPitch + ks * 64);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], af[s], acc[jt][s], 0, 0, 0);
+    }
+    if (pass == 0) CM_LOAD_W1(1)  // the registers are free: pass B's fragments fly under pass A's GLU
+    // GLU: lane (c, g) holds frames 16 s + c, value columns 64 w + 32 pass + 16 jt + 4 g + r (jt = 0, 1) and their gates (jt + 2)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const int n = 64 * wave + 32 * pass + 16 * jt + 4 * g;
+      const float4 bv = *reinterpret_cast<const float4*>(p.b1 + n);
+      const float4 bg = *reinterpret_cast<const float4*>(p.b1 + kCpC + n);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int t = t0 + 16 * s + c - half;
+        const bool live = t >= 0 && t < p.T;
+        const float y0 = live ? cp_sigmoid_mul(acc[jt][s][0] + bv.x, acc[jt + 2][s][0] + bg.x) : 0.f;
+        const float y1 = live ? cp_sigmoid_mul(acc[jt][s][1] + bv.y, acc[jt + 2][s][1] + bg.y) : 0.f;
+        const float y2 = live ? cp_sigmoid_mul(acc[jt][s][2] + bv.z, acc[jt + 2][s][2] + bg.z) : 0.f;
+        const float y3 = live ? cp_sigmoid_mul(acc[jt][s][3] + bv.w, acc[jt + 2][s][3] + bg.w) : 0.f;
+        *reinterpret_cast<uint2*>(ytile + (16 * s + c) * kCmYPitch + n * 2) = make_uint2(cp_pack_bf16(y0, y1), cp_pack_bf16(y2, y3));
+      }
+    }
+  }
+#undef CM_LOAD_W1
+  __syncthreads();  // y tile complete; the a-tile is dead
+
+  // ---- depthwise conv + BatchNorm (affine) + Swish: 4 consecutive frames x 8 channels per thread -------------------------------------
+  const int cg = tid & 31, rg = tid >> 5;
+  const int c0 = cg * 8;
+  uint4 zrow[4];
+  {
+    float w[kCpMaxK][8];
+#pragma unroll
+    for (int k = 0; k < kCpMaxK; ++k) {
+      if (k < KS) {
+        const float4* wp4 = reinterpret_cast<const float4*>(wl + k * 256 + c0);
+        const float4 w0 = wp4[0], w1 = wp4[1];
+        w[k][0] = w0.x; w[k][1] = w0.y; w[k][2] = w0.z; w[k][3] = w0.w;
+        w[k][4] = w1.x; w[k][5] = w1.y; w[k][6] = w1.z; w[k][7] = w1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[k][e] = 0.0f;
+      }
+    }
+    float acc[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[o][e] = 0.0f;
+    const int i0 = rg * 4;
+#pragma unroll
+    for (int r = 0; r < kCpMaxK + 3; ++r) {  // y row i0 + r feeds output o with tap k = r - o
+      if (r < KS + 3) {
+        const uint4 q = *reinterpret_cast<const uint4*>(ytile + (i0 + r) * kCmYPitch + c0 * 2);
+        const float gv[8] = {cp_from_bf16(q.x & 0xffff), cp_from_bf16(q.x >> 16), cp_from_bf16(q.y & 0xffff), cp_from_bf16(q.y >> 16),
+                             cp_from_bf16(q.z & 0xffff), cp_from_bf16(q.z >> 16), cp_from_bf16(q.w & 0xffff), cp_from_bf16(q.w >> 16)};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int k = r - o;
+          if (k >= 0 && k < kCpMaxK) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(w[k][e], gv[e], acc[o][e]);
+          }
+        }
+      }
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = p.bn_scale[c0 + e];
+      sh[e] = p.bn_shift[c0 + e];
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z0 = acc[o][2 * e] * sc[2 * e] + sh[2 * e];
+        const float z1 = acc[o][2 * e + 1] * sc[2 * e + 1] + sh[2 * e + 1];
+        pk[e] = cp_pack_bf16(cp_sigmoid_mul(z0, z0), cp_sigmoid_mul(z1, z1));
+      }
+      zrow[o] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+  }
+  // ---- pointwise_conv2 weights of this wave (64 output columns) --------------------------------------------------------------------
+  {
+    const uint4* base = p.wp + ((int64_t)(wave * 4) * 8) * 64 + lane;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) *reinterpret_cast<uint4*>(smem + (rg * 4 + o) * kCpPitch + cg * 16) = zrow[o];  // z tile over the a-tile
+  __syncthreads();
+  f32x4 acc2[4][2];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc2[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    bf16x8 af[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) af[s] = *reinterpret_cast<const bf16x8*>(abase + s * 16 * kCpPitch + ks * 64);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc2[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], af[s], acc2[jt][s], 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = t0 + 16 * s + c;
+    if (t >= p.T) continue;
+    const int64_t m = row0 + t;
+    const float rs = p.mask ? p.mask[m] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = 64 * wave + 16 * jt + 4 * g;
+      const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+      float4* xp = reinterpret_cast<float4*>(p.x + m * p.ldx + n);
+      float4 xv = *xp;
+      xv.x += (acc2[jt][s][0] + bv.x) * rs;
+      xv.y += (acc2[jt][s][1] + bv.y) * rs;
+      xv.z += (acc2[jt][s][2] + bv.z) * rs;
+      xv.w += (acc2[jt][s][3] + bv.w) * rs;
+      *xp = xv;
+    }
+  }
+}
+
 }  // namespace ma
 
 using namespace ma;
@@ -225,6 +435,45 @@ extern "C" int ma_convmid_pw2_bf16(const void* y, int64_t ldy, int64_t batch, in
     attr = true;
   }
   MA_LAUNCH(convmid_pw2_kernel, dim3((unsigned)((T + kCpTile - 1) / kCpTile), (unsigned)batch), dim3(256), lds, (hipStream_t)stream,
+            p);
+  return MA_OK;
+}
+
+extern "C" int ma_convmodule_bf16(const void* a, int64_t lda, int64_t batch, int64_t T, int32_t C, const void* pw1_packed,
+                                  const float* pw1_bias, const float* dw, int32_t kernel_size, const float* bn_scale,
+                                  const float* bn_shift, const void* pw2_packed, const float* pw2_bias, const float* mask, float* x,
+                                  int64_t ldx, ma_stream_t stream) {
+  if (!a || !pw1_packed || !pw1_bias || !dw || !bn_scale || !bn_shift || !pw2_packed || !pw2_bias || !x || batch < 1 || T < 1)
+    return MA_ERR_INVALID_ARG;
+  if (C != kCpC || kernel_size < 1 || kernel_size > kCpMaxK || (kernel_size & 1) == 0 || batch > 65535) return MA_ERR_UNSUPPORTED;
+  if ((lda & 7) || lda < kCpC || (ldx & 3) || ldx < kCpC) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(pw1_packed) | reinterpret_cast<uintptr_t>(pw1_bias) |
+       reinterpret_cast<uintptr_t>(pw2_packed) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(pw2_bias) |
+       reinterpret_cast<uintptr_t>(bn_scale) | reinterpret_cast<uintptr_t>(bn_shift)) & 15)
+    return MA_ERR_INVALID_ARG;
+  ConvModParams p;
+  p.a = reinterpret_cast<const uint16_t*>(a);
+  p.lda = lda;
+  p.w1p = reinterpret_cast<const uint4*>(pw1_packed);
+  p.b1 = pw1_bias;
+  p.dw = dw;
+  p.bn_scale = bn_scale;
+  p.bn_shift = bn_shift;
+  p.wp = reinterpret_cast<const uint4*>(pw2_packed);
+  p.bias = pw2_bias;
+  p.mask = mask;
+  p.x = x;
+  p.ldx = ldx;
+  p.T = (int32_t)T;
+  p.KS = kernel_size;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmodule_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kCmLds) !=
+        hipSuccess)
+      return MA_ERR_LAUNCH;
+    attr = true;
+  }
+  MA_LAUNCH(convmodule_kernel, dim3((unsigned)((T + kCpTile - 1) / kCpTile), (unsigned)batch), dim3(256), kCmLds, (hipStream_t)stream,
             p);
   return MA_OK;
 }

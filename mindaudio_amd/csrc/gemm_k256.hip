@@ -12,6 +12,7 @@
 //   * 128 MFMA 16x16x32 per wave, 16 accumulator tiles (64 registers), two workgroups per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mindaudio_amd.h"
 
@@ -30,6 +31,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int kG2K = 256, kG2Cols = 256, kG2Threads = 256;
+constexpr int kG2StagePitch = 144;  // bf16 output staging: 128 B of a wave's 64 columns + 16 B pad
 constexpr int kG2Pitch = 544;  // LDS row pitch of the activation tile: conflict-free ds_read_b128 (see ffn_packed.hip)
 
 struct GemmK256Params {
@@ -52,6 +54,7 @@ struct GemmK256Params {
   uint16_t* ln_out;
   int64_t ld_ln;
   float ln_eps;
+  int32_t ablate;
 };
 
 __device__ __forceinline__ uint32_t g2_pack_bf16(float lo, float hi) {
@@ -68,25 +71,27 @@ __global__ void gemm_k256_pack_kernel(const uint16_t* __restrict__ w, int64_t ld
   out[idx] = *reinterpret_cast<const uint4*>(w + (nt * 16 + (lane & 15)) * ldw + 32 * ks + 8 * (lane >> 4));
 }
 
+// NBL = column blocks walked by one workgroup (weights double-buffered in registers, one workgroup per CU).  Only NBL = 1 is
+// launched: the row-owner forms (NBL = 2, 3: activation tile staged once for all of N = 512 / 768) measured 3.4 % slower end to end.
 // ROWS = 64 or 32 rows per workgroup; grid = (M / ROWS, N / 256).  32 rows when the grid would otherwise not give every CU its two
 // workgroups (N = 256 at M = 15936: 249 -> 498 workgroups).
-template <int ROWS>
-__global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_kernel(const GemmK256Params p) {
+template <int ROWS, int NBL>
+__global__ __launch_bounds__(kG2Threads, NBL > 1 ? 1 : 2) void gemm_k256_kernel(const GemmK256Params p) {
   constexpr int MT = ROWS / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * ROWS;
-  const int n0 = blockIdx.y * kG2Cols + wave * 64;  // first of this wave's 64 output columns
+  int n0 = blockIdx.y * NBL * kG2Cols + wave * 64;  // first of this wave's 64 output columns (of the first of its nbl column blocks)
 
   // ---- this wave's 32 weight fragments: all in flight before anything else ---------------------------------------------------
-  bf16x8 wf[4][8];
+  bf16x8 wfb[NBL > 1 ? 2 : 1][4][8];
   {
     const uint4* base = p.wp + ((int64_t)(n0 >> 4) * 8) * 64 + lane;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
+      for (int ks = 0; ks < 8; ++ks) wfb[0][jt][ks] = (p.ablate & 4) ? bf16x8{} : *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
   }
   // ---- activation tile -> LDS ---------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -95,17 +100,29 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_kernel(const GemmK256
     const int row = idx >> 5, ch = idx & 31;
     int m = m0 + row;
     if (m >= p.M) m = p.M - 1;
+    if (p.ablate & 2) continue;
     const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
     *reinterpret_cast<uint4*>(smem + row * kG2Pitch + ch * 16) = v;
   }
   __syncthreads();
 
+  const char* abase = smem + c * kG2Pitch + g * 16;
   f32x4 acc[4][MT];
+  float rsum[MT], rsq[MT];
+#pragma unroll
+  for (int nb = 0; nb < NBL; ++nb, n0 += kG2Cols) {
+  auto& wf = wfb[nb & (NBL > 1 ? 1 : 0)];
+  if (nb + 1 < NBL) {  // the next column block's fragments (one workgroup per CU in this form: 512 registers to spend)
+    const uint4* base = p.wp + ((int64_t)((n0 + kG2Cols) >> 4) * 8) * 64 + lane;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) wfb[(nb + 1) & 1][jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
+  }
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
     for (int s = 0; s < MT; ++s) acc[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const char* abase = smem + c * kG2Pitch + g * 16;
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
     bf16x8 af[MT];
@@ -118,11 +135,11 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_kernel(const GemmK256
   }
 
   // ---- epilogue: lane (c, g) holds rows m0 + 16 s + c, columns n0 + 16 jt + 4 g + r ------------------------------------------------
+  char* stage = smem + ROWS * kG2Pitch + wave * (ROWS * kG2StagePitch);
   float4 bv[4];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
     bv[jt] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-  float rsum[MT], rsq[MT];
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
     rsum[s] = 0.f;
@@ -158,7 +175,10 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_kernel(const GemmK256
         v2 += r.z;
         v3 += r.w;
       }
-      if (live) {
+      if (p.out_bf16 && !(p.ablate & 8)) {  // staged in this wave's own LDS strip, written below as whole 128-byte row segments
+        *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
+            make_uint2(g2_pack_bf16(v0, v1), g2_pack_bf16(v2, v3));
+      } else if (live && !((p.ablate & 1) && v0 != 12345.678f)) {
         if (p.out_bf16)
           *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) =
               make_uint2(g2_pack_bf16(v0, v1), g2_pack_bf16(v2, v3));
@@ -172,6 +192,21 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_kernel(const GemmK256
       }
     }
   }
+  if (p.out_bf16 && !(p.ablate & 8)) {
+    // the wave's ROWS x 64 bf16 block: 8 lanes x 16 B cover a row's 128 bytes, 8 rows per store instruction
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int rr = lane >> 3, cc = lane & 7;
+    uint16_t* ob = reinterpret_cast<uint16_t*>(p.out) + n0 + cc * 8;
+#pragma unroll
+    for (int it = 0; it < ROWS / 8; ++it) {
+      const int row = it * 8 + rr;
+      const uint4 v = *reinterpret_cast<const uint4*>(stage + row * kG2StagePitch + cc * 16);
+      if (m0 + row < p.M && !((p.ablate & 1) && v.x != 12345u)) *reinterpret_cast<uint4*>(ob + (int64_t)(m0 + row) * p.ldo) = v;
+    }
+  }
+  }  // column blocks
+  n0 -= kG2Cols;
   if (!p.ln_out) return;
   // ---- LayerNorm of the finished rows: a row's 256 values live in 4 lane groups (g) x 4 waves -------------------------------------
   __syncthreads();  // the activation tile is dead: its LDS becomes the exchange buffer [2][4 waves][ROWS]
@@ -243,6 +278,7 @@ static int g2_launch(const void* A, int64_t lda, const void* packed, void* out, 
   if (!A || !packed || !out || !epi || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
   if (ma_gemm_k256_packed_bytes(N, K) < 0 || N > 0x7fffff00) return MA_ERR_UNSUPPORTED;
   if (epi->col_scale || epi->col_shift || epi->act2 || epi->act < 0 || epi->act > 2) return MA_ERR_UNSUPPORTED;
+  if (epi->out_bf16 && (ldo & 7)) return MA_ERR_UNSUPPORTED;  // 16-byte row stores
   if ((lda & 7) || lda < K || ldo < N || (ldo & 3) || (epi->residual && (epi->ldr < N || (epi->ldr & 3)))) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |
        reinterpret_cast<uintptr_t>(epi->bias) | reinterpret_cast<uintptr_t>(epi->residual)) & 15)
@@ -268,11 +304,21 @@ static int g2_launch(const void* A, int64_t lda, const void* packed, void* out, 
   p.ln_out = reinterpret_cast<uint16_t*>(ln_out);
   p.ld_ln = ld_ln;
   p.ln_eps = ln_eps;
+  static bool lds_set = false;
+  if (!lds_set) {  // 64 rows: 70 KiB of dynamic LDS (tile + the four staging strips)
+    if (hipFuncSetAttribute((const void*)&gemm_k256_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            64 * (kG2Pitch + 4 * kG2StagePitch)) != hipSuccess)
+      return MA_ERR_LAUNCH;
+    lds_set = true;
+  }
+  static const int ablate = getenv("MA_G2_ABLATE") ? atoi(getenv("MA_G2_ABLATE")) : 0;
+  p.ablate = ablate;
   const unsigned nby = (unsigned)(N / kG2Cols);
+  const size_t lds64 = 64 * (kG2Pitch + 4 * kG2StagePitch);
   if ((M + 63) / 64 * nby < 384) {  // well under two 64-row workgroups per CU: halve the rows
-    MA_LAUNCH(gemm_k256_kernel<32>, dim3((unsigned)((M + 31) / 32), nby), dim3(kG2Threads), 32 * kG2Pitch, (hipStream_t)stream, p);
+    MA_LAUNCH((gemm_k256_kernel<32, 1>), dim3((unsigned)((M + 31) / 32), nby), dim3(kG2Threads), 32 * (kG2Pitch + 4 * kG2StagePitch), (hipStream_t)stream, p);
   } else {
-    MA_LAUNCH(gemm_k256_kernel<64>, dim3((unsigned)((M + 63) / 64), nby), dim3(kG2Threads), 64 * kG2Pitch, (hipStream_t)stream, p);
+    MA_LAUNCH((gemm_k256_kernel<64, 1>), dim3((unsigned)((M + 63) / 64), nby), dim3(kG2Threads), lds64, (hipStream_t)stream, p);
   }
   return MA_OK;
 }

@@ -295,12 +295,18 @@ class ConformerEncoder(nn.Module):
             else:
                 dense(ctx, W, "o", bias=W["o_b"], residual=x, out_dtype=f32, out=x)
                 a = ops.layernorm(x, l.norm_conv.gamma, l.norm_conv.beta, row_scale=mask_rows)
-            y = dense(a, W, "pw1", bias=W["pw1_b"])
-            if packed_gemm and W["pw2_pk"] is not None and W["dw_w"].shape[1] <= 15 and os.environ.get("MA_CONV_PW2", "1") != "0":
-                ops.convmid_pw2(y, W["dw_w"], W["bn_scale"], W["bn_shift"], W["pw2_pk"], W["pw2_b"], mask_rows, x, b, t2)
+            conv_pk = packed_gemm and W["pw2_pk"] is not None and W["dw_w"].shape[1] <= 15 and os.environ.get("MA_CONV_PW2", "1") != "0"
+            if conv_pk and W["pw1_pk"] is not None and os.environ.get("MA_CONVMODULE", "1") != "0":
+                # pointwise_conv1 .. pointwise_conv2 + residual in one launch (convmid_pw2.hip: convmodule_kernel)
+                ops.convmodule(a, W["pw1_pk"], W["pw1_b"], W["dw_w"], W["bn_scale"], W["bn_shift"], W["pw2_pk"], W["pw2_b"],
+                               mask_rows, x, b, t2)
             else:
-                z = ops.convmodule_mid(y, W["dw_w"], W["bn_scale"], W["bn_shift"], b, t2)
-                dense(z, W, "pw2", bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
+                y = dense(a, W, "pw1", bias=W["pw1_b"])
+                if conv_pk:
+                    ops.convmid_pw2(y, W["dw_w"], W["bn_scale"], W["bn_shift"], W["pw2_pk"], W["pw2_b"], mask_rows, x, b, t2)
+                else:
+                    z = ops.convmodule_mid(y, W["dw_w"], W["bn_scale"], W["bn_shift"], b, t2)
+                    dense(z, W, "pw2", bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
             # x = x + 0.5 * FFN(LN(x)) ; x = LN_final(x)                           :147-156
             last = li + 1 == n_layers
             use_pk = fused_ffn and part is None and packed_ffn and W["ff_pk"] is not None

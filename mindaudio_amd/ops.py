@@ -332,6 +332,20 @@ def convmid_pw2(y, dw, bn_scale, bn_shift, pw2_packed, pw2_bias, mask_rows, x, b
     return x
 
 
+def convmodule(a, pw1_packed, pw1_bias, dw, bn_scale, bn_shift, pw2_packed, pw2_bias, mask_rows, x, batch, T):
+    """In place x += mask * ConvolutionModule_after_LayerNorm(a): pointwise_conv1 + GLU + depthwise + BN + Swish + pointwise_conv2
+    + residual in one launch.  a (B*T, 256) bf16 = norm_conv(x) * mask; packed weights from gemm_k256_pack."""
+    t = _host.torch()
+    lib = _lib.load()
+    c, ks = dw.shape
+    assert a.dtype == t.bfloat16 and a.shape[1] == c and a.stride(1) == 1 and x.dtype == t.float32 and x.stride(1) == 1
+    rc = lib.ma_convmodule_bf16(_host.ptr(a), a.stride(0), batch, T, c, _host.ptr(pw1_packed), _host.ptr(pw1_bias), _host.ptr(dw),
+                                ks, _host.ptr(bn_scale), _host.ptr(bn_shift), _host.ptr(pw2_packed), _host.ptr(pw2_bias),
+                                _opt(mask_rows), _host.ptr(x), x.stride(0), _host.current_stream_ptr())
+    _lib.check(rc, "convmodule")
+    return x
+
+
 def cast_bf16(x):
     """float32 device tensor -> bf16 copy (round to nearest even)."""
     t = _host.torch()

@@ -124,6 +124,40 @@ def test_convmid_pw2_fused(t, b, tt, ks):
     assert float((got2 - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("b,tt,ks", [(3, 249, 15), (2, 33, 7), (5, 64, 15), (1, 5, 3), (2, 32, 15)])
+def test_convmodule_one_launch(t, b, tt, ks):
+    """pointwise_conv1 + GLU + depthwise + BN + Swish + pointwise_conv2 + mask + residual in one launch, against a float64
+    evaluation of layers/convolution.py:96-127 on the same bf16 inputs/weights (the GLU here works on the float32 accumulators
+    and is rounded to bf16 once; the z tile is bf16 as in the two-kernel path: tolerance = a few bf16 ulps of the branch)."""
+    from mindaudio_amd import ops
+
+    c = 256
+    a = _rand(t, b * tt, c, seed=41).bfloat16()
+    w1 = _rand(t, 2 * c, c, seed=42, scale=1.0 / 16).bfloat16()
+    b1 = _rand(t, 2 * c, seed=43, scale=0.2)
+    dw = _rand(t, c, ks, seed=32, scale=0.3)
+    sc, sh = 1 + 0.1 * _rand(t, c, seed=33), 0.1 * _rand(t, c, seed=34)
+    w2 = _rand(t, c, c, seed=35, scale=1.0 / 16).bfloat16()
+    b2 = _rand(t, c, seed=36)
+    mask = (t.rand(b * tt, generator=t.Generator().manual_seed(37)) > 0.2).float()
+    x0 = _rand(t, b * tt, c, seed=38)
+    # float64 reference
+    y = a.double() @ w1.double().T + b1.double()
+    y = (y[:, :c] * t.sigmoid(y[:, c:])).view(b, tt, c).transpose(1, 2)                       # (B, C, T)
+    z = t.nn.functional.conv1d(y, dw.double().unsqueeze(1), padding=ks // 2, groups=c)
+    z = z * sc.double()[None, :, None] + sh.double()[None, :, None]
+    z = (z * t.sigmoid(z)).transpose(1, 2).reshape(b * tt, c)
+    branch = z @ w2.double().T + b2.double()
+    for m_ in (mask, None):
+        want = x0.double() + (branch * m_.double()[:, None] if m_ is not None else branch)
+        got = x0.clone().cuda()
+        out = ops.convmodule(a.cuda(), ops.gemm_k256_pack(w1.cuda()), b1.cuda(), dw.cuda(), sc.cuda(), sh.cuda(),
+                             ops.gemm_k256_pack(w2.cuda()), b2.cuda(), m_.cuda() if m_ is not None else None, got, b, tt)
+        assert out is got
+        err = (got.double().cpu() - want).abs().max()
+        assert float(err) <= 2 ** -7 * float(branch.abs().max()), float(err)
+
+
 @pytest.mark.parametrize("m,n", [(64, 256), (777, 512), (15936, 768), (1, 256), (130, 1024)])
 def test_gemm_k256_packed(t, m, n):
     """K = 256 dense layers on fragment-packed weights: same contract (and epilogues) as ops.gemm."""

@@ -605,6 +605,18 @@ int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed, const flo
                        void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, const float* gamma0, const float* beta0,
                        ma_stream_t stream);
 
+/* Two FFNs on the same 64-row tiles in one launch: the last FFN of Conformer block i and the macaron FFN of block i + 1
+ * (models/conformer.py:147-156 of block i, :109-112 of block i + 1), with the three LayerNorms between and after them:
+ *   x1 = x + alpha FFN_A(LN(x; gamma0, beta0));  x2 = LN(x1; gamma1, beta1);  x <- x2 + alpha FFN_B(LN(x2; gamma2, beta2));
+ *   ln_out = bf16 LN(x; gamma3, beta3)
+ * x2 and the second FFN's input stay in LDS: one read and one write of the residual stream instead of two each.
+ * packed_a / packed_b from ma_ffn_pack_weights_bf16 (same d_model = 256 and hidden). */
+int ma_ffn_packed_pair_bf16(const void* packed_a, const float* b1_a, const float* b2_a, const void* packed_b, const float* b1_b,
+                            const float* b2_b, float* x, int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha,
+                            const float* gamma0, const float* beta0, const float* gamma1, const float* beta1,
+                            const float* gamma2, const float* beta2, const float* gamma3, const float* beta3, float eps,
+                            void* ln_out, int64_t ld_ln, ma_stream_t stream);
+
 /* Fused feed-forward, 128-row formulation: grid (ceil(M/128), 2) — the workgroup of hidden half 0 updates x in place
  * (x += alpha * (O_0 + b2)), half 1 writes partial (M, 256) float32 = alpha * O_1; the LayerNorm that follows the module
  * adds it back:

@@ -179,6 +179,8 @@ PROTOTYPES = {
     "ma_ffn_pack_weights_bf16": (ctypes.c_int, [vp, vp, i32, i32, vp, vp]),
     "ma_ffn_packed_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, f32, vp, i64,
                                           i32, vp, vp, vp]),
+    "ma_ffn_packed_pair_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp,
+                                               f32, vp, i64, vp]),
     "ma_ffn128_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i64, i32, i32, f32, vp]),
     "ma_layernorm_add_f32": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, f32, vp, vp, i64, i32, vp]),
     "ma_layernorm2_add_f32": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, f32, vp, i64, vp, i64, i32, vp]),

@@ -51,10 +51,13 @@ __device__ __forceinline__ void pk_static_for(F&& f) {
 
 constexpr int kPkRows = 64, kPkD = 256, kPkThreads = 256;
 constexpr int kPkPitch = 544;                // LDS row pitch of the activation tile (bytes)
+constexpr int kPkTileStride = 32768;         // the 16-row tiles of the activation tile sit 32 KiB apart: tile w lies inside the two
+                                             // exchange slots wave w owns, so in pair mode a wave can write its rows of the next stage's tile
 constexpr int kPkBlock = 32;                  // hidden units per (wave, step)
 constexpr int kPkItems = 32;                  // 1 KiB fragments per block: 16 of W1 (k-step, tile), 16 of W2 (output tile)
 constexpr int kPkOffPar = 128 * 1024;         // b2, gamma1, beta1, gamma2, beta2 (5 x 1 KiB), staged once at kernel start
-constexpr int kPkLds = kPkOffPar + 5 * 1024;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
+constexpr int kPkOffPar2 = kPkOffPar + 5 * 1024;  // pair mode, second stage: b2', gamma3, beta3
+constexpr int kPkLds = kPkOffPar2 + 3 * 1024;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
 constexpr int kPkMaxHidden = 8192;
 
 struct FfnPackedParams {
@@ -72,6 +75,13 @@ struct FfnPackedParams {
   void* ln_out;
   int64_t ld_ln;
   float eps;
+  // pair mode (ma_ffn_packed_pair_bf16): a second FFN on the rows this workgroup has just produced, without leaving the CU:
+  //   stage 0: x1 = x + alpha FFN_A(a);  x2 = LN(x1; g1, be1)  [norm_final];  a' = LN(x2; g2, be2)  [the next block's norm_ff_macaron]
+  //   stage 1: x  = x2 + alpha FFN_B(a'); ln_out = LN(x; g3, be3)  [the next block's norm_mha]
+  // x2 (float32) and a' (bf16) never leave LDS.
+  int32_t pair;
+  const uint4* wp_b;
+  const float *b1_b, *b2_b, *g3, *be3;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // accumulator indices stay compile-time constants.
   int a_off[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) a_off[s] = (16 * ((s + wave) & 3) + c) * kPkPitch + g * 16;
+  for (int s = 0; s < 4; ++s) a_off[s] = ((s + wave) & 3) * kPkTileStride + c * kPkPitch + g * 16;
 
   const int nsb_all = p.H >> 7;
   const int nsb = ABL == 7 && p.alpha == 0.25f ? 0 : nsb_all;  // (ablation 7 with alpha 0.25: no main loop at all)
@@ -138,6 +148,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // MFMA slot ends in a sched_barrier, so the instruction ORDER is the source order: hipcc otherwise sinks each load to a few
   // MFMAs before its use, and it cannot interleave VALU work with MFMAs it does not see.  PK_WAIT ties the counted s_waitcnt
   // to the register it protects.
+  const char* wp_cur = reinterpret_cast<const char*>(p.wp);
+  const float* b1_cur = p.b1;
   const uint32_t voff0 = lane * 16 + 4096, voff1 = voff0 + 8192, voff2 = voff0 + 16384, voff3 = voff0 + 24576;
   const uint32_t boff = g * 32;
 #define PK_VOFF(q) ((q) < 8 ? voff0 : (q) < 16 ? voff1 : (q) < 24 ? voff2 : voff3)
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   } while (0)
 #define PK_LOAD_B1(blk)                                                                                          \
   do {                                                                                                           \
-    const float* bsrc = p.b1 + (blk) * kPkBlock;                                                                 \
+    const float* bsrc = b1_cur + (blk) * kPkBlock;                                                               \
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b1lo) : "v"(boff), "s"(bsrc) : "memory");               \
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b1hi) : "v"(boff), "s"(bsrc) : "memory");     \
   } while (0)
@@ -179,17 +191,13 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   } while (0)
 
   f32x4 O[16][4];
-#pragma unroll
-  for (int j = 0; j < 16; ++j)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) O[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   bf16x8 ring[16];   // weight fragments: W1 of block b+1 / W2 of block b / W1 of block b+2 ... rotate through the same 16 slots
   bf16x8 af[3][4];   // activation fragments of k-step ks live in af[ks % 3]; fetched two k-steps ahead (LDS latency ~200 cycles)
   f32x4 b1lo, b1hi;  // bias of the block whose first product comes next: b1[8 g + 0..3], b1[8 g + 4..7]
   f32x4 SA[2][4], SB[2][4];
   uint32_t hfw[4][4];
-  auto wbase = [&](int ci) { return reinterpret_cast<const char*>(p.wp) + (int64_t)block_of(ci) * (kPkItems * 1024); };
+  auto wbase = [&](int ci) { return wp_cur + (int64_t)block_of(ci) * (kPkItems * 1024); };
   auto blk_wrap = [&](int ci) { return ci < nsb_all ? ci : ci - nsb_all; };
 
   // ---- Swish pipeline -------------------------------------------------------------------------------------------------------
@@ -322,6 +330,22 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   //   its bias (issued before W1') : W1'[0..15] are younger                                             -> vmcnt(16)
   //   product2 of block b, item j  : W2[j..15], the 2 bias loads of block b+2, W1''[0..j-1]             -> vmcnt(17)
   //   prologue (product1 of block 0, refilled with W1 of block 1): everything but block 1's bias has landed (counts 17 / 18 hold trivially)
+  const int nstage = p.pair ? 2 : 1;
+  for (int stg = 0; stg < nstage; ++stg) {
+  // The staging and epilogue addresses below are loop-invariant, and hipcc would hoist all of them out of this loop and SPILL them
+  // around the main loop (measured: +4 us on one workgroup's critical path, every scratch reload drains the loads in flight).
+  // They are cheap to recompute: derive them from per-iteration opaque copies of the block / thread index instead.
+  int m0v = m0, tidv = tid;
+  asm volatile("" : "+s"(m0v));
+  asm volatile("" : "+v"(tidv));
+  if (stg == 1) {
+    wp_cur = reinterpret_cast<const char*>(p.wp_b);
+    b1_cur = p.b1_b;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) O[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (nsb > 0) {  // the first block's weight fragments are requested before the activation tile: their L2 latency hides under it
     const char* w0 = wbase(0);
 #pragma unroll
@@ -333,6 +357,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // ---- activation tile -> LDS: [64 rows][544 B] (512 + 32 of padding).  A ds_read_b128 serves lanes in groups of 16
   // ({0-3,12-15,20-27}, ...); with this pitch the 16-byte slot of lane (c, g) is (2 c + g + 4 ks) mod 16, distinct inside every
   // group, and the k-step is a plain +64 B immediate offset (an XOR swizzle costs an address register per k-step) -------------
+  if (stg == 0) {
+  const int tid = tidv, m0 = m0v;
   if (p.g0) {
     // a = LayerNorm(x) on the fly (two-pass, as layernorm_kernel): 4 threads per row, 64 features each
     const int row = tid >> 2, part = tid & 3;
@@ -358,7 +384,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     q += __shfl_xor(q, 1, 64);
     q += __shfl_xor(q, 2, 64);
     const float inv = 1.0f / sqrtf(q * (1.0f / 256.0f) + p.eps);
-    char* dst = smem + row * kPkPitch + part * 128;
+    char* dst = smem + (row >> 4) * kPkTileStride + (row & 15) * kPkPitch + part * 128;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float4 ga = *reinterpret_cast<const float4*>(p.g0 + part * 64 + 8 * j);
@@ -380,7 +406,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       int m = m0 + row;
       if (m >= p.M) m = p.M - 1;
       const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
-      *reinterpret_cast<uint4*>(smem + row * kPkPitch + ch * 16) = v;
+      *reinterpret_cast<uint4*>(smem + (row >> 4) * kPkTileStride + (row & 15) * kPkPitch + ch * 16) = v;
     }
   }
   {  // epilogue parameters -> LDS (5 x 256 floats; thread t copies element t of each): no global latency at the tail
@@ -394,8 +420,15 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       par[768 + tid] = p.g2[tid];
       par[1024 + tid] = p.be2[tid];
     }
+    if (p.pair) {
+      float* par2 = reinterpret_cast<float*>(smem + kPkOffPar2);
+      par2[tid] = p.b2_b[tid];
+      par2[256 + tid] = p.g3[tid];
+      par2[512 + tid] = p.be3[tid];
+    }
   }
-  __syncthreads();
+  }  // stage 0
+  __syncthreads();  // (stage 1: the rows every wave wrote into the next activation tile are visible)
 
   if (nsb > 0) {
     PK_LDS(af[0][0], a_addr[0], 0);
@@ -410,7 +443,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     // in-flight register must never be copied
     f32x4 b0lo, b0hi;
     {
-      const float* bsrc = p.b1 + block_of(0) * kPkBlock;
+      const float* bsrc = b1_cur + block_of(0) * kPkBlock;
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b0lo) : "v"(boff), "s"(bsrc) : "memory");
       asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b0hi) : "v"(boff), "s"(bsrc) : "memory");
     }
@@ -448,6 +481,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 #undef PK_MFMA_S
 #undef PK_WAIT
 #undef PK_VOFF
+  const int tid = tidv, lane = tidv & 63, c = lane & 15, g = lane >> 4, m0 = m0v;  // (see the top of the stage loop)
 
   // ---- cross-wave reduction: wave w ends up with row tile w (its slot 0) ---------------------------------------------------
   // Exchange slot (owner, k): 16 KiB = [16 j][64 lanes] x float4, written and read with the same lane -> conflict-free.
@@ -457,8 +491,14 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   const int mc = live ? m : p.M - 1;
   float* xrow = p.x + (int64_t)mc * p.ldx + 4 * g;
   float4 xres[16];
+  float4* park = reinterpret_cast<float4*>(smem + (wave * 2 + 1) * 16384) + lane;  // pair mode: x2 of this wave's rows, [16 j][64 lanes]
+  if (stg == 0) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) xres[j] = *reinterpret_cast<const float4*>(xrow + 16 * j);
+    for (int j = 0; j < 16; ++j) xres[j] = *reinterpret_cast<const float4*>(xrow + 16 * j);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xres[j] = park[j * 64];
+  }
   __syncthreads();  // every wave is done reading the activation tile
   auto xslot = [&](int owner, int k) { return reinterpret_cast<f32x4*>(smem + (owner * 2 + k) * 16384) + lane; };
   {
@@ -491,7 +531,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   }
 
   // ---- epilogue: lane (c, g) holds row m0 + 16 wave + c, features n = 16 j + 4 g + r -------------------------------------
-  const float* par = reinterpret_cast<const float*>(smem + kPkOffPar) + 4 * g;
+  const float* par = reinterpret_cast<const float*>(smem + (stg == 0 ? kPkOffPar : kPkOffPar2)) + 4 * g;
   float v[64];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -508,7 +548,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     for (int j = 0; j < 16; ++j)
       *reinterpret_cast<float4*>(xrow + 16 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
   };
-  if (p.ln_mode == 0) {
+  if (!p.pair && p.ln_mode == 0) {
     store_x();
     return;
   }
@@ -537,9 +577,21 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       v[4 * j + 3] = (v[4 * j + 3] - mean) * rstd * gv.w + bv.w;
     }
   };
-  if (p.ln_mode == 1) store_x();  // the un-normalised sum is the new residual stream
+  if (p.pair && stg == 0) {
+    layer_norm(par + 256, par + 512);  // x2 = norm_final(x1): the second stage's residual, parked in this wave's own slot
+#pragma unroll
+    for (int j = 0; j < 16; ++j) park[j * 64] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    layer_norm(par + 768, par + 1024);  // a' = norm_ff_macaron'(x2): this wave's 16 rows of the next activation tile
+    char* arow = smem + wave * kPkTileStride + c * kPkPitch + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<uint2*>(arow + 32 * j) = make_uint2(pk_pack_bf16(v[4 * j], v[4 * j + 1]), pk_pack_bf16(v[4 * j + 2], v[4 * j + 3]));
+    continue;
+  }
+  const int mode = p.pair ? 1 : p.ln_mode;
+  if (mode == 1) store_x();  // the un-normalised sum is the new residual stream
   layer_norm(par + 256, par + 512);
-  if (p.ln_mode == 2) {
+  if (mode == 2) {
     store_x();  // x <- norm_final(x)  (models/conformer.py:155-156)
     layer_norm(par + 768, par + 1024);
   }
@@ -566,6 +618,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     for (int j = 0; j < 16; ++j)
       *reinterpret_cast<float4*>(orow + 16 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
   }
+  }  // stages
 }
 
 }  // namespace ma
@@ -587,6 +640,32 @@ extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t 
   MA_LAUNCH(ffn_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
             reinterpret_cast<const uint16_t*>(w1), reinterpret_cast<const uint16_t*>(w2), hidden,
             reinterpret_cast<uint4*>(packed));
+  return MA_OK;
+}
+
+static int ffn_packed_launch(const FfnPackedParams& p, ma_stream_t stream) {
+  const int64_t M = p.M;
+  static int abl = -1;
+  if (abl < 0) {
+    const char* e = getenv("MA_FFNPK_ABLATE");
+    abl = e ? atoi(e) & 7 : 0;
+    const void* fns[8] = {(const void*)&ffn_packed_kernel<0>, (const void*)&ffn_packed_kernel<1>, (const void*)&ffn_packed_kernel<2>,
+                          (const void*)&ffn_packed_kernel<3>, (const void*)&ffn_packed_kernel<4>, (const void*)&ffn_packed_kernel<5>,
+                          (const void*)&ffn_packed_kernel<6>, (const void*)&ffn_packed_kernel<7>};
+    for (int i = 0; i < 8; ++i)
+      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kPkLds) != hipSuccess) return MA_ERR_LAUNCH;
+  }
+  const dim3 grid((unsigned)((M + kPkRows - 1) / kPkRows));
+  switch (abl) {
+    case 0: MA_LAUNCH(ffn_packed_kernel<0>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 1: MA_LAUNCH(ffn_packed_kernel<1>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 2: MA_LAUNCH(ffn_packed_kernel<2>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 3: MA_LAUNCH(ffn_packed_kernel<3>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 4: MA_LAUNCH(ffn_packed_kernel<4>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 5: MA_LAUNCH(ffn_packed_kernel<5>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    case 6: MA_LAUNCH(ffn_packed_kernel<6>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+    default: MA_LAUNCH(ffn_packed_kernel<7>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
+  }
   return MA_OK;
 }
 
@@ -614,16 +693,6 @@ extern "C" int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed
   if (ln_mode >= 1 && ln_out_bf16 && (ld_ln & 7)) return MA_ERR_UNSUPPORTED;  // 16-byte row stores
   if (ln_mode == 2 && (!gamma2 || !beta2 || ((reinterpret_cast<uintptr_t>(gamma2) | reinterpret_cast<uintptr_t>(beta2)) & 15)))
     return MA_ERR_INVALID_ARG;
-  static int abl = -1;
-  if (abl < 0) {
-    const char* e = getenv("MA_FFNPK_ABLATE");
-    abl = e ? atoi(e) & 7 : 0;
-    const void* fns[8] = {(const void*)&ffn_packed_kernel<0>, (const void*)&ffn_packed_kernel<1>, (const void*)&ffn_packed_kernel<2>,
-                          (const void*)&ffn_packed_kernel<3>, (const void*)&ffn_packed_kernel<4>, (const void*)&ffn_packed_kernel<5>,
-                          (const void*)&ffn_packed_kernel<6>, (const void*)&ffn_packed_kernel<7>};
-    for (int i = 0; i < 8; ++i)
-      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kPkLds) != hipSuccess) return MA_ERR_LAUNCH;
-  }
   FfnPackedParams p;
   p.a = reinterpret_cast<const uint16_t*>(a);
   p.wp = reinterpret_cast<const uint4*>(packed);
@@ -642,16 +711,51 @@ extern "C" int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed
   p.ln_out = ln_out;
   p.ld_ln = ld_ln;
   p.eps = eps;
-  const dim3 grid((unsigned)((M + kPkRows - 1) / kPkRows));
-  switch (abl) {
-    case 0: MA_LAUNCH(ffn_packed_kernel<0>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 1: MA_LAUNCH(ffn_packed_kernel<1>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 2: MA_LAUNCH(ffn_packed_kernel<2>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 3: MA_LAUNCH(ffn_packed_kernel<3>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 4: MA_LAUNCH(ffn_packed_kernel<4>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 5: MA_LAUNCH(ffn_packed_kernel<5>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 6: MA_LAUNCH(ffn_packed_kernel<6>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    default: MA_LAUNCH(ffn_packed_kernel<7>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-  }
-  return MA_OK;
+  p.pair = 0;
+  p.wp_b = nullptr;
+  p.b1_b = p.b2_b = p.g3 = p.be3 = nullptr;
+  return ffn_packed_launch(p, stream);
+}
+
+extern "C" int ma_ffn_packed_pair_bf16(const void* packed_a, const float* b1_a, const float* b2_a, const void* packed_b,
+                                       const float* b1_b, const float* b2_b, float* x, int64_t ldx, int64_t M, int32_t d_model,
+                                       int32_t hidden, float alpha, const float* gamma0, const float* beta0, const float* gamma1,
+                                       const float* beta1, const float* gamma2, const float* beta2, const float* gamma3,
+                                       const float* beta3, float eps, void* ln_out, int64_t ld_ln, ma_stream_t stream) {
+  if (!packed_a || !b1_a || !b2_a || !packed_b || !b1_b || !b2_b || !x || !ln_out || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (!gamma0 || !beta0 || !gamma1 || !beta1 || !gamma2 || !beta2 || !gamma3 || !beta3) return MA_ERR_INVALID_ARG;
+  if (ma_ffn_packed_bytes(d_model, hidden) < 0) return MA_ERR_UNSUPPORTED;
+  if ((ldx & 3) || ldx < kPkD || ld_ln < kPkD || (ld_ln & 7)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(packed_a) | reinterpret_cast<uintptr_t>(packed_b) | reinterpret_cast<uintptr_t>(b1_a) |
+       reinterpret_cast<uintptr_t>(b1_b) | reinterpret_cast<uintptr_t>(b2_a) | reinterpret_cast<uintptr_t>(b2_b) |
+       reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ln_out) | reinterpret_cast<uintptr_t>(gamma0) |
+       reinterpret_cast<uintptr_t>(beta0) | reinterpret_cast<uintptr_t>(gamma1) | reinterpret_cast<uintptr_t>(beta1) |
+       reinterpret_cast<uintptr_t>(gamma2) | reinterpret_cast<uintptr_t>(beta2) | reinterpret_cast<uintptr_t>(gamma3) |
+       reinterpret_cast<uintptr_t>(beta3)) & 15)
+    return MA_ERR_INVALID_ARG;
+  FfnPackedParams p;
+  p.a = reinterpret_cast<const uint16_t*>(x);  // not read: the input is LayerNorm(x; gamma0, beta0)
+  p.lda = kPkD;
+  p.wp = reinterpret_cast<const uint4*>(packed_a);
+  p.b1 = b1_a;
+  p.b2 = b2_a;
+  p.x = x;
+  p.ldx = ldx;
+  p.M = (int32_t)M;
+  p.H = hidden;
+  p.alpha = alpha;
+  p.ln_mode = 2;
+  p.ln_out_bf16 = 1;
+  p.g1 = gamma1; p.be1 = beta1; p.g2 = gamma2; p.be2 = beta2;
+  p.g0 = gamma0; p.be0 = beta0;
+  p.ln_out = ln_out;
+  p.ld_ln = ld_ln;
+  p.eps = eps;
+  p.pair = 1;
+  p.wp_b = reinterpret_cast<const uint4*>(packed_b);
+  p.b1_b = b1_b;
+  p.b2_b = b2_b;
+  p.g3 = gamma3;
+  p.be3 = beta3;
+  return ffn_packed_launch(p, stream);
 }

@@ -273,10 +273,15 @@ class ConformerEncoder(nn.Module):
 
         part = torch.empty((m, self.d), dtype=f32, device=x.device) if use128 else None
         a = ops.layernorm(x, self.encoders[0].norm_ff_macaron.gamma, self.encoders[0].norm_ff_macaron.beta)
+        # the last FFN of block i and the macaron FFN of block i + 1 act on the same rows: one launch (ffn_packed pair mode)
+        pair_ffn = fused_ffn and part is None and packed_ffn and os.environ.get("MA_FFN_PAIR", "1") != "0"
+        paired = False  # this block's macaron FFN already ran inside the previous block's last launch
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
             # x = x + 0.5 * FFN_macaron(LN(x))   (a = LN(x) comes from the previous block's fused LN pair)
             #                                                                      models/conformer.py:109-112
-            if fused_ffn and part is None and packed_ffn and W["ffm_pk"] is not None:
+            if paired:
+                pass  # a = norm_mha(x) came out of the pair launch
+            elif fused_ffn and part is None and packed_ffn and W["ffm_pk"] is not None:
                 a = ops.ffn_packed(a, W["ffm_pk"], W["ffm_b1"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
             elif fused_ffn and part is None:  # FFN + the LayerNorm in front of the attention in one kernel
                 a = ops.ffn_ln(a, W["ffm_w1"], W["ffm_b1"], W["ffm_w2"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
@@ -314,6 +319,14 @@ class ConformerEncoder(nn.Module):
             a = None if use_pk else ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta)
             if fused_ffn and part is None:  # FFN + norm_final + the next consumer's LayerNorm in one kernel
                 nxt = self.after_norm if last else self.encoders[li + 1].norm_ff_macaron
+                paired = False
+                if use_pk and pair_ffn and not last and P["layers"][li + 1]["ffm_pk"] is not None:
+                    ln, Wn = self.encoders[li + 1], P["layers"][li + 1]
+                    a = ops.ffn_packed_pair(W["ff_pk"], W["ff_b1"], W["ff_b2"], Wn["ffm_pk"], Wn["ffm_b1"], Wn["ffm_b2"], x,
+                                            (l.norm_ff.gamma, l.norm_ff.beta), (l.norm_final.gamma, l.norm_final.beta),
+                                            (nxt.gamma, nxt.beta), (ln.norm_mha.gamma, ln.norm_mha.beta))
+                    paired = True
+                    continue
                 if use_pk:
                     y = ops.ffn_packed(None, W["ff_pk"], W["ff_b1"], W["ff_b2"], x, l.norm_final.gamma, l.norm_final.beta,
                                        nxt.gamma, nxt.beta, out_dtype=f32 if last else None,

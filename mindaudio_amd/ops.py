@@ -194,6 +194,24 @@ def ffn_packed(a, packed, b1, b2, x, g1=None, be1=None, g2=None, be2=None, alpha
     return out if mode else x
 
 
+def ffn_packed_pair(packed_a, b1_a, b2_a, packed_b, b1_b, b2_b, x, ln_in, ln_mid, ln_next, ln_out, alpha=0.5, eps=1e-5):
+    """Two position-wise FFNs on the same rows in one launch (the last FFN of a Conformer block and the macaron FFN of the next):
+        x1 = x + alpha FFN_A(LN(x; ln_in));   x2 = LN(x1; ln_mid);   x <- x2 + alpha FFN_B(LN(x2; ln_next))   (in place)
+    returns bf16 LN(x; ln_out).  Each ln_* is a (gamma, beta) pair; packed_* from ffn_pack_weights."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert x.dtype == t.float32 and x.stride(1) == 1
+    m, d = x.shape
+    out = t.empty((m, d), dtype=t.bfloat16, device=x.device)
+    rc = lib.ma_ffn_packed_pair_bf16(_host.ptr(packed_a), _host.ptr(b1_a), _host.ptr(b2_a), _host.ptr(packed_b), _host.ptr(b1_b),
+                                     _host.ptr(b2_b), _host.ptr(x), x.stride(0), m, d, b1_a.numel(), float(alpha),
+                                     _host.ptr(ln_in[0]), _host.ptr(ln_in[1]), _host.ptr(ln_mid[0]), _host.ptr(ln_mid[1]),
+                                     _host.ptr(ln_next[0]), _host.ptr(ln_next[1]), _host.ptr(ln_out[0]), _host.ptr(ln_out[1]),
+                                     float(eps), _host.ptr(out), out.stride(0), _host.current_stream_ptr())
+    _lib.check(rc, "ffn_packed_pair_bf16")
+    return out
+
+
 def ffn128(a, w1, b1, w2, b2, x, partial, alpha=0.5):
     """128-row formulation: x += alpha * (half-0 product + b2) in place, partial (M, 256) f32 = alpha * half-1 product;
     the caller's next LayerNorm adds `partial` back (layernorm(..., addend=partial) / layernorm2(..., addend=partial))."""

@@ -376,6 +376,46 @@ def test_ffn_fused128_and_layernorm_add(t, m, hidden):
     assert float((out2.double().cpu() - ln(y1, g2, be2)).abs().max()) <= 3e-2
 
 
+@pytest.mark.parametrize("m,hidden", [(64, 256), (200, 2048), (15936, 2048), (1, 512)])
+def test_ffn_packed_pair(t, m, hidden):
+    """Last FFN of a block + macaron FFN of the next in one launch == the two single launches (same arithmetic on the same rows:
+    the only difference is that x2 / a' stay on chip), and both follow the float64 chain."""
+    from mindaudio_amd import ops
+
+    d = 256
+    wa1, wb1 = (_rand(t, hidden, d, seed=s_, scale=1.0 / 16).bfloat16().cuda() for s_ in (111, 112))
+    wa2, wb2 = (_rand(t, d, hidden, seed=s_, scale=1.0 / math.sqrt(hidden)).bfloat16().cuda() for s_ in (113, 114))
+    ba1, bb1 = (_rand(t, hidden, seed=s_, scale=0.3).cuda() for s_ in (115, 116))
+    ba2, bb2 = (_rand(t, d, seed=s_, scale=0.3).cuda() for s_ in (117, 118))
+    lns = [((1 + 0.1 * _rand(t, d, seed=120 + 2 * i)).cuda(), (0.1 * _rand(t, d, seed=121 + 2 * i)).cuda()) for i in range(4)]
+    x = (_rand(t, m, d, seed=119) * 3 + 0.5).cuda()
+    pa, pb = ops.ffn_pack_weights(wa1, wa2), ops.ffn_pack_weights(wb1, wb2)
+    # two launches: FFN_A (+ norm_final + next norm_ff_macaron), then FFN_B (+ norm_mha)
+    x_two = x.clone()
+    a2 = ops.ffn_packed(None, pa, ba1, ba2, x_two, lns[1][0], lns[1][1], lns[2][0], lns[2][1], ln_in=lns[0])
+    out_two = ops.ffn_packed(a2, pb, bb1, bb2, x_two, lns[3][0], lns[3][1])
+    x_one = x.clone()
+    out_one = ops.ffn_packed_pair(pa, ba1, ba2, pb, bb1, bb2, x_one, lns[0], lns[1], lns[2], lns[3])
+    assert out_one.dtype == t.bfloat16 and out_one.shape == (m, d)
+    assert t.equal(x_one, x_two) and t.equal(out_one, out_two)
+
+    def ln(v, gb):
+        mu = v.mean(-1, keepdim=True)
+        return (v - mu) / t.sqrt(((v - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * gb[0].double().cpu() + gb[1].double().cpu()
+
+    def ffn(a, w1, b1, w2, b2):
+        z = a.bfloat16().double() @ w1.double().cpu().T + b1.double().cpu()
+        return (z * t.sigmoid(z)).bfloat16().double() @ w2.double().cpu().T + b2.double().cpu()
+
+    if m <= 200:
+        xd = x.double().cpu()
+        x1 = xd + 0.5 * ffn(ln(xd, lns[0]), wa1, ba1, wa2, ba2)
+        x2 = ln(x1, lns[1])
+        x3 = x2 + 0.5 * ffn(ln(x2, lns[2]), wb1, bb1, wb2, bb2)
+        assert float((x_one.double().cpu() - x3).abs().max()) <= 3e-2
+        assert float((out_one.double().cpu() - ln(x3, lns[3])).abs().max()) <= 4e-2
+
+
 @pytest.mark.parametrize("m,hidden,mode", [(64, 256, 0), (250, 2048, 0), (15936, 2048, 1), (7968, 2048, 2), (64 * 3 + 1, 256, 2),
                                            (100, 512, 1), (1, 2048, 0)])
 def test_ffn_packed(t, m, hidden, mode):

@@ -181,6 +181,12 @@ PROTOTYPES = {
                                           i32, vp, vp, vp]),
     "ma_ffn_packed_pair_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp,
                                                f32, vp, i64, vp]),
+    "ma_ffn_qkv_packed_bytes": (i64, [i64]),
+    "ma_ffn_qkv_pack_bf16": (ctypes.c_int, [vp, i64, i64, vp, vp]),
+    "ma_ffn_packed_qkv_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, f32, vp, vp, i64, vp, i64,
+                                              vp]),
+    "ma_ffn_packed_pair_qkv_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp,
+                                                   vp, f32, vp, vp, i64, vp, i64, vp]),
     "ma_ffn128_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i64, i32, i32, f32, vp]),
     "ma_layernorm_add_f32": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, f32, vp, vp, i64, i32, vp]),
     "ma_layernorm2_add_f32": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, f32, vp, i64, vp, i64, i32, vp]),

@@ -82,6 +82,14 @@ struct FfnPackedParams {
   int32_t pair;
   const uint4* wp_b;
   const float *b1_b, *b2_b, *g3, *be3;
+  // optional tail: the K = 256 dense layer that consumes the final LayerNorm (linear_q/k/v, layers/attention.py:51-53) runs on the
+  // tile while it is still in LDS: qkv_out[m, :] = bf16(LN_out[m, :] . Wq^T + qkv_b); Wq packed by ma_ffn_qkv_pack_bf16
+  // ([N / 32 blocks][16 items][64 lanes] x 16 B, the W1 half of the FFN block format).  ln_out is then not written.
+  const uint4* qkv_wp;
+  const float* qkv_b;
+  uint16_t* qkv_out;
+  int64_t ld_qkv;
+  int32_t qkv_n;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -117,6 +125,16 @@ __global__ void ffn_pack_kernel(const uint16_t* __restrict__ w1, const uint16_t*
     src = w2 + (int64_t)(16 * j + i) * hidden + hb * kPkBlock + 8 * g;
   }
   out[idx] = *reinterpret_cast<const uint4*>(src);
+}
+
+// W (N, 256) of a dense layer in the W1 half of the block format: [N / 32 blocks][16 items][64 lanes] x 16 B
+__global__ void ffn_qkv_pack_kernel(const uint16_t* __restrict__ w, int64_t ldw, int64_t total, uint4* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63), q = (int)((idx >> 6) & 15);
+  const int64_t hb = idx >> 10;
+  const int i = lane & 15, g = lane >> 4, ks = q >> 1, t = q & 1;
+  out[idx] = *reinterpret_cast<const uint4*>(w + (hb * kPkBlock + 8 * (i >> 2) + 4 * t + (i & 3)) * ldw + 32 * ks + 8 * g);
 }
 
 // ABL (development ablations, tools/ffn_bench.py): 1 = no Swish, 2 = no weight loads in the loop, 4 = no MFMAs; 0 = product.
@@ -472,15 +490,6 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     product2(wbase(blk_wrap(ci + 3)), block_of(blk_wrap(ci + 3)), SA);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // drain the ring; last MFMA -> accumulator reads
-#undef PK_MFMA_O
-#undef PK_LDS
-#undef PK_LWAIT
-#undef PK_LOAD
-#undef PK_LOAD_B1
-#undef PK_MFMA_S0
-#undef PK_MFMA_S
-#undef PK_WAIT
-#undef PK_VOFF
   const int tid = tidv, lane = tidv & 63, c = lane & 15, g = lane >> 4, m0 = m0v;  // (see the top of the stage loop)
 
   // ---- cross-wave reduction: wave w ends up with row tile w (its slot 0) ---------------------------------------------------
@@ -595,7 +604,12 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     store_x();  // x <- norm_final(x)  (models/conformer.py:155-156)
     layer_norm(par + 768, par + 1024);
   }
-  if (p.ln_out_bf16) {
+  if (p.qkv_wp) {  // the rows go to the LDS tile of the dense layer below instead of HBM
+    char* arow = smem + wave * kPkTileStride + c * kPkPitch + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<uint2*>(arow + 32 * j) = make_uint2(pk_pack_bf16(v[4 * j], v[4 * j + 1]), pk_pack_bf16(v[4 * j + 2], v[4 * j + 3]));
+  } else if (p.ln_out_bf16) {
     // A 16-feature tile is 32 B of bf16: storing from the accumulator layout writes 32-byte fragments (measured: +5 us per
     // launch).  Stage the wave's 16 x 256 tile in its private exchange slot (owner = wave, k = 1: nobody else touches it after
     // the first exchange round) and write whole 512-byte rows, 16 B per lane.
@@ -619,6 +633,90 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       *reinterpret_cast<float4*>(orow + 16 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
   }
   }  // stages
+
+  // ---- tail: out = LN_out . Wq^T + b on the tile (N = 128 nq columns; block hb = 32 columns, one per wave and step) -------------
+  // A block is the first product of the FFN loop with nothing behind it: S' = b + Wq[blk] . a^T through the same 16-slot ring
+  // (refilled with the next block's fragments), then the 32 x 64 result goes out as bf16 (lane (c, g): row 16 tile + c, columns
+  // 32 blk + 8 g .. + 7 = 16 bytes).  Wait counts: a slot's load is followed by <= 15 - i fragment loads of its block, the next
+  // block's 2 bias loads, this block's stores (0..4, skipped on dead rows) and i refills -> vmcnt(17) is safe with or without the stores.
+  if (p.qkv_wp) {
+    __syncthreads();
+    const int nq = p.qkv_n >> 7;
+    const int rotq = blockIdx.x % nq;
+    auto qblk = [&](int ci) {
+      int sb = ci + rotq;
+      while (sb >= nq) sb -= nq;
+      return sb * 4 + wave;
+    };
+    auto qbase = [&](int ci) { return reinterpret_cast<const char*>(p.qkv_wp) + (int64_t)qblk(ci) * (16 * 1024); };
+    {
+      const char* w0 = qbase(0);
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                     : "=v"(ring[q]) : "v"(PK_VOFF(q)), "s"(w0), "n"((((q) & 7) - 4) * 1024) : "memory");
+    }
+    f32x4 qalo, qahi, qblo, qbhi;
+#define PK_LOAD_QB(lo, hi, blk)                                                                                  \
+  do {                                                                                                           \
+    const float* bsrc = p.qkv_b + (blk) * kPkBlock;                                                              \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(lo) : "v"(boff), "s"(bsrc) : "memory");                 \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(hi) : "v"(boff), "s"(bsrc) : "memory");       \
+  } while (0)
+    PK_LOAD_QB(qalo, qahi, qblk(0));
+    PK_LDS(af[0][0], a_addr[0], 0);
+    PK_LDS(af[0][1], a_addr[1], 0);
+    PK_LDS(af[0][2], a_addr[2], 0);
+    PK_LDS(af[0][3], a_addr[3], 0);
+    PK_LDS(af[1][0], a_addr[0], 1 << 6);
+    PK_LDS(af[1][1], a_addr[1], 1 << 6);
+    PK_LDS(af[1][2], a_addr[2], 1 << 6);
+    PK_LDS(af[1][3], a_addr[3], 1 << 6);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qalo), "+v"(qahi)::"memory");
+    const int lane_q = tid & 63, cq = lane_q & 15, gq = lane_q >> 4;
+    auto store_s = [&](f32x4 (&S)[2][4], int blk) __attribute__((always_inline)) {
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]),
+                   "+v"(S[1][2]), "+v"(S[1][3]));  // MFMA result -> VALU read
+      pk_static_for<4>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int sI = decltype(sc)::value;
+        const int row = m0 + 16 * ((sI + wave) & 3) + cq;
+        const uint4 pk = make_uint4(pk_pack_bf16(S[0][sI][0], S[0][sI][1]), pk_pack_bf16(S[0][sI][2], S[0][sI][3]),
+                                    pk_pack_bf16(S[1][sI][0], S[1][sI][1]), pk_pack_bf16(S[1][sI][2], S[1][sI][3]));
+        if (row < p.M) *reinterpret_cast<uint4*>(p.qkv_out + (int64_t)row * p.ld_qkv + blk * kPkBlock + 8 * gq) = pk;
+      });
+    };
+    auto refetch_k1 = [&]() __attribute__((always_inline)) {
+      PK_LDS(af[1][0], a_addr[0], 1 << 6);
+      PK_LDS(af[1][1], a_addr[1], 1 << 6);
+      PK_LDS(af[1][2], a_addr[2], 1 << 6);
+      PK_LDS(af[1][3], a_addr[3], 1 << 6);
+    };
+    for (int ci = 0; ci < nq; ci += 2) {
+      PK_LOAD_QB(qblo, qbhi, qblk(ci + 1 < nq ? ci + 1 : ci));
+      product1(std::false_type{}, std::integral_constant<int, 17>{}, SA, SB, qbase(ci + 1 < nq ? ci + 1 : ci),
+               std::integral_constant<int, 0>{}, qalo, qahi);
+      refetch_k1();
+      store_s(SA, qblk(ci));
+      if (ci + 1 < nq) {
+        PK_LOAD_QB(qalo, qahi, qblk(ci + 2 < nq ? ci + 2 : ci + 1));
+        product1(std::false_type{}, std::integral_constant<int, 17>{}, SB, SA, qbase(ci + 2 < nq ? ci + 2 : ci + 1),
+                 std::integral_constant<int, 0>{}, qblo, qbhi);
+        refetch_k1();
+        store_s(SB, qblk(ci + 1));
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the ring's and the tile's last (unused) prefetches
+#undef PK_LOAD_QB
+  }
+#undef PK_MFMA_O
+#undef PK_LDS
+#undef PK_LWAIT
+#undef PK_LOAD
+#undef PK_LOAD_B1
+#undef PK_MFMA_S0
+#undef PK_MFMA_S
+#undef PK_WAIT
+#undef PK_VOFF
 }
 
 }  // namespace ma
@@ -628,6 +726,21 @@ using namespace ma;
 extern "C" int64_t ma_ffn_packed_bytes(int32_t d_model, int32_t hidden) {
   if (d_model != kPkD || hidden < 256 || hidden % 256 != 0 || hidden > kPkMaxHidden) return MA_ERR_UNSUPPORTED;
   return (int64_t)2 * d_model * hidden * 2;
+}
+
+extern "C" int64_t ma_ffn_qkv_packed_bytes(int64_t N) {
+  if (N < 128 || N % 128 != 0 || N > 8192) return MA_ERR_UNSUPPORTED;
+  return N * kPkD * 2;
+}
+
+extern "C" int ma_ffn_qkv_pack_bf16(const void* W, int64_t ldw, int64_t N, void* packed, ma_stream_t stream) {
+  if (!W || !packed) return MA_ERR_INVALID_ARG;
+  if (ma_ffn_qkv_packed_bytes(N) < 0 || ldw < kPkD || (ldw & 7)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(packed)) & 15) return MA_ERR_INVALID_ARG;
+  const int64_t total = (N / kPkBlock) * 16 * 64;
+  MA_LAUNCH(ffn_qkv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+            reinterpret_cast<const uint16_t*>(W), ldw, total, reinterpret_cast<uint4*>(packed));
+  return MA_OK;
 }
 
 extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t d_model, int32_t hidden, void* packed,
@@ -714,14 +827,34 @@ extern "C" int ma_ffn_packed_bf16(const void* a, int64_t lda, const void* packed
   p.pair = 0;
   p.wp_b = nullptr;
   p.b1_b = p.b2_b = p.g3 = p.be3 = nullptr;
+  p.qkv_wp = nullptr;
+  p.qkv_b = nullptr;
+  p.qkv_out = nullptr;
+  p.ld_qkv = 0;
+  p.qkv_n = 0;
   return ffn_packed_launch(p, stream);
 }
 
-extern "C" int ma_ffn_packed_pair_bf16(const void* packed_a, const float* b1_a, const float* b2_a, const void* packed_b,
+static int qkv_tail_check(const void* qkv_packed, const float* qkv_bias, int64_t qkv_n, void* qkv_out, int64_t ld_qkv) {
+  if (!qkv_packed || !qkv_bias || !qkv_out) return MA_ERR_INVALID_ARG;
+  if (ma_ffn_qkv_packed_bytes(qkv_n) < 0 || ld_qkv < qkv_n || (ld_qkv & 7)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(qkv_packed) | reinterpret_cast<uintptr_t>(qkv_bias) | reinterpret_cast<uintptr_t>(qkv_out)) & 15)
+    return MA_ERR_INVALID_ARG;
+  return MA_OK;
+}
+
+static int ffn_pair_launch(const void* packed_a, const float* b1_a, const float* b2_a, const void* packed_b,
                                        const float* b1_b, const float* b2_b, float* x, int64_t ldx, int64_t M, int32_t d_model,
                                        int32_t hidden, float alpha, const float* gamma0, const float* beta0, const float* gamma1,
                                        const float* beta1, const float* gamma2, const float* beta2, const float* gamma3,
-                                       const float* beta3, float eps, void* ln_out, int64_t ld_ln, ma_stream_t stream) {
+                                       const float* beta3, float eps, void* ln_out, int64_t ld_ln, const void* qkv_packed,
+                                       const float* qkv_bias, int64_t qkv_n, void* qkv_out, int64_t ld_qkv, ma_stream_t stream) {
+  if (qkv_packed) {
+    const int rc = qkv_tail_check(qkv_packed, qkv_bias, qkv_n, qkv_out, ld_qkv);
+    if (rc != MA_OK) return rc;
+    ln_out = qkv_out;  // (not written: only the pointer checks below see it)
+    ld_ln = kPkD;
+  }
   if (!packed_a || !b1_a || !b2_a || !packed_b || !b1_b || !b2_b || !x || !ln_out || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
   if (!gamma0 || !beta0 || !gamma1 || !beta1 || !gamma2 || !beta2 || !gamma3 || !beta3) return MA_ERR_INVALID_ARG;
   if (ma_ffn_packed_bytes(d_model, hidden) < 0) return MA_ERR_UNSUPPORTED;
@@ -757,5 +890,72 @@ extern "C" int ma_ffn_packed_pair_bf16(const void* packed_a, const float* b1_a, 
   p.b2_b = b2_b;
   p.g3 = gamma3;
   p.be3 = beta3;
+  p.qkv_wp = reinterpret_cast<const uint4*>(qkv_packed);
+  p.qkv_b = qkv_bias;
+  p.qkv_out = reinterpret_cast<uint16_t*>(qkv_out);
+  p.ld_qkv = ld_qkv;
+  p.qkv_n = (int32_t)qkv_n;
+  return ffn_packed_launch(p, stream);
+}
+
+extern "C" int ma_ffn_packed_pair_bf16(const void* packed_a, const float* b1_a, const float* b2_a, const void* packed_b,
+                                       const float* b1_b, const float* b2_b, float* x, int64_t ldx, int64_t M, int32_t d_model,
+                                       int32_t hidden, float alpha, const float* gamma0, const float* beta0, const float* gamma1,
+                                       const float* beta1, const float* gamma2, const float* beta2, const float* gamma3,
+                                       const float* beta3, float eps, void* ln_out, int64_t ld_ln, ma_stream_t stream) {
+  return ffn_pair_launch(packed_a, b1_a, b2_a, packed_b, b1_b, b2_b, x, ldx, M, d_model, hidden, alpha, gamma0, beta0, gamma1, beta1,
+                         gamma2, beta2, gamma3, beta3, eps, ln_out, ld_ln, nullptr, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int ma_ffn_packed_pair_qkv_bf16(const void* packed_a, const float* b1_a, const float* b2_a, const void* packed_b,
+                                           const float* b1_b, const float* b2_b, float* x, int64_t ldx, int64_t M, int32_t d_model,
+                                           int32_t hidden, float alpha, const float* gamma0, const float* beta0, const float* gamma1,
+                                           const float* beta1, const float* gamma2, const float* beta2, const float* gamma3,
+                                           const float* beta3, float eps, const void* qkv_packed, const float* qkv_bias,
+                                           int64_t qkv_n, void* qkv_out, int64_t ld_qkv, ma_stream_t stream) {
+  if (!qkv_packed) return MA_ERR_INVALID_ARG;
+  return ffn_pair_launch(packed_a, b1_a, b2_a, packed_b, b1_b, b2_b, x, ldx, M, d_model, hidden, alpha, gamma0, beta0, gamma1, beta1,
+                         gamma2, beta2, gamma3, beta3, eps, nullptr, 0, qkv_packed, qkv_bias, qkv_n, qkv_out, ld_qkv, stream);
+}
+
+extern "C" int ma_ffn_packed_qkv_bf16(const void* a, int64_t lda, const void* packed, const float* b1, const float* b2, float* x,
+                                      int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, const float* gamma1,
+                                      const float* beta1, float eps, const void* qkv_packed, const float* qkv_bias, int64_t qkv_n,
+                                      void* qkv_out, int64_t ld_qkv, ma_stream_t stream) {
+  const int rc = qkv_tail_check(qkv_packed, qkv_bias, qkv_n, qkv_out, ld_qkv);
+  if (rc != MA_OK) return rc;
+  if (!a || !packed || !b1 || !b2 || !x || !gamma1 || !beta1 || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (ma_ffn_packed_bytes(d_model, hidden) < 0) return MA_ERR_UNSUPPORTED;
+  if ((lda & 7) || (ldx & 3) || lda < kPkD || ldx < kPkD) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(b1) |
+       reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma1) |
+       reinterpret_cast<uintptr_t>(beta1)) & 15)
+    return MA_ERR_INVALID_ARG;
+  FfnPackedParams p;
+  p.a = reinterpret_cast<const uint16_t*>(a);
+  p.wp = reinterpret_cast<const uint4*>(packed);
+  p.b1 = b1;
+  p.b2 = b2;
+  p.x = x;
+  p.lda = lda;
+  p.ldx = ldx;
+  p.M = (int32_t)M;
+  p.H = hidden;
+  p.alpha = alpha;
+  p.ln_mode = 1;
+  p.ln_out_bf16 = 1;
+  p.g1 = gamma1; p.be1 = beta1; p.g2 = nullptr; p.be2 = nullptr;
+  p.g0 = nullptr; p.be0 = nullptr;
+  p.ln_out = nullptr;
+  p.ld_ln = 0;
+  p.eps = eps;
+  p.pair = 0;
+  p.wp_b = nullptr;
+  p.b1_b = p.b2_b = p.g3 = p.be3 = nullptr;
+  p.qkv_wp = reinterpret_cast<const uint4*>(qkv_packed);
+  p.qkv_b = qkv_bias;
+  p.qkv_out = reinterpret_cast<uint16_t*>(qkv_out);
+  p.ld_qkv = ld_qkv;
+  p.qkv_n = (int32_t)qkv_n;
   return ffn_packed_launch(p, stream);
 }

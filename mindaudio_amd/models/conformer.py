@@ -178,6 +178,7 @@ class ConformerEncoder(nn.Module):
         for W in prep["layers"]:
             for key in ("qkv", "o", "pw1", "pw2"):
                 W[key + "_pk"] = ops.gemm_k256_pack(W[key + "_w"]) if W[key + "_w"].shape[1] == 256 else None
+            W["qkv_fpk"] = ops.ffn_qkv_pack(W["qkv_w"])  # for the linear_q/k/v tail of the FFN launch in front of the attention
             for key in ("ffm", "ff"):
                 w1 = W[key + "_w1"]
                 W[key + "_pk"] = ops.ffn_pack_weights(w1, W[key + "_w2"]) if w1.shape[0] % 256 == 0 and w1.shape[1] == 256 else None
@@ -276,20 +277,28 @@ class ConformerEncoder(nn.Module):
         # the last FFN of block i and the macaron FFN of block i + 1 act on the same rows: one launch (ffn_packed pair mode)
         pair_ffn = fused_ffn and part is None and packed_ffn and os.environ.get("MA_FFN_PAIR", "1") != "0"
         paired = False  # this block's macaron FFN already ran inside the previous block's last launch
+        # linear_q/k/v computed by the FFN launch in front of it, on the tile in LDS (MA_FFN_QKV=0: A/B switch)
+        qkv_tail = pair_ffn and all(W["qkv_fpk"] is not None for W in P["layers"]) and os.environ.get("MA_FFN_QKV", "1") != "0"
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
             # x = x + 0.5 * FFN_macaron(LN(x))   (a = LN(x) comes from the previous block's fused LN pair)
             #                                                                      models/conformer.py:109-112
+            qkv = None
             if paired:
-                pass  # a = norm_mha(x) came out of the pair launch
+                qkv = a if qkv_tail else None  # norm_mha(x) — or already linear_q/k/v of it — came out of the pair launch
             elif fused_ffn and part is None and packed_ffn and W["ffm_pk"] is not None:
-                a = ops.ffn_packed(a, W["ffm_pk"], W["ffm_b1"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
+                if qkv_tail and W["qkv_fpk"] is not None:
+                    qkv = ops.ffn_packed_qkv(a, W["ffm_pk"], W["ffm_b1"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta,
+                                             W["qkv_fpk"], W["qkv_b"])
+                else:
+                    a = ops.ffn_packed(a, W["ffm_pk"], W["ffm_b1"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
             elif fused_ffn and part is None:  # FFN + the LayerNorm in front of the attention in one kernel
                 a = ops.ffn_ln(a, W["ffm_w1"], W["ffm_b1"], W["ffm_w2"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
             else:
                 add = self._ffn(a, W, "ffm", x, fused_ffn, part)
                 # x = x + MHA(LN(x))                                               :117-135
                 a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta, addend=add)
-            qkv = dense(a, W, "qkv", bias=W["qkv_b"])
+            if qkv is None:
+                qkv = dense(a, W, "qkv", bias=W["qkv_b"])
             ctx = ops.relpos_attention(qkv, pos_all[:, li * 256:(li + 1) * 256], W["u"], W["v"], att_mask, b, t2,
                                        self.heads, 64)
             # x = x + ConvModule(LN(x), mask_pad)                                  :139-143, convolution.py:83-129
@@ -324,7 +333,8 @@ class ConformerEncoder(nn.Module):
                     ln, Wn = self.encoders[li + 1], P["layers"][li + 1]
                     a = ops.ffn_packed_pair(W["ff_pk"], W["ff_b1"], W["ff_b2"], Wn["ffm_pk"], Wn["ffm_b1"], Wn["ffm_b2"], x,
                                             (l.norm_ff.gamma, l.norm_ff.beta), (l.norm_final.gamma, l.norm_final.beta),
-                                            (nxt.gamma, nxt.beta), (ln.norm_mha.gamma, ln.norm_mha.beta))
+                                            (nxt.gamma, nxt.beta), (ln.norm_mha.gamma, ln.norm_mha.beta),
+                                            qkv=(Wn["qkv_fpk"], Wn["qkv_b"]) if qkv_tail else None)
                     paired = True
                     continue
                 if use_pk:

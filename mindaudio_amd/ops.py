@@ -194,14 +194,56 @@ def ffn_packed(a, packed, b1, b2, x, g1=None, be1=None, g2=None, be2=None, alpha
     return out if mode else x
 
 
-def ffn_packed_pair(packed_a, b1_a, b2_a, packed_b, b1_b, b2_b, x, ln_in, ln_mid, ln_next, ln_out, alpha=0.5, eps=1e-5):
+def ffn_qkv_pack(w):
+    """Packed copy of a dense weight w (N, 256) bf16 for the `qkv=` tail of ffn_packed / ffn_packed_pair; None if not covered."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert w.dtype == t.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    n, k = w.shape
+    if k != 256 or lib.ma_ffn_qkv_packed_bytes(n) < 0:
+        return None
+    packed = t.empty((n * k,), dtype=t.bfloat16, device=w.device)
+    _lib.check(lib.ma_ffn_qkv_pack_bf16(_host.ptr(w), w.stride(0), n, _host.ptr(packed), _host.current_stream_ptr()),
+               "ffn_qkv_pack_bf16")
+    return packed
+
+
+def ffn_packed_qkv(a, packed, b1, b2, x, g1, be1, qkv_packed, qkv_bias, alpha=0.5, eps=1e-5):
+    """x += alpha FFN(a) in place, then qkv = bf16(LN(x; g1, be1) @ Wq^T + qkv_bias) on the same tile; returns qkv (M, N)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and a.stride(1) == 1 and x.dtype == t.float32 and x.stride(1) == 1
+    m, d = x.shape
+    n = qkv_bias.numel()
+    out = t.empty((m, n), dtype=t.bfloat16, device=x.device)
+    rc = lib.ma_ffn_packed_qkv_bf16(_host.ptr(a), a.stride(0), _host.ptr(packed), _host.ptr(b1), _host.ptr(b2), _host.ptr(x),
+                                    x.stride(0), m, d, b1.numel(), float(alpha), _host.ptr(g1), _host.ptr(be1), float(eps),
+                                    _host.ptr(qkv_packed), _host.ptr(qkv_bias), n, _host.ptr(out), out.stride(0),
+                                    _host.current_stream_ptr())
+    _lib.check(rc, "ffn_packed_qkv_bf16")
+    return out
+
+
+def ffn_packed_pair(packed_a, b1_a, b2_a, packed_b, b1_b, b2_b, x, ln_in, ln_mid, ln_next, ln_out, alpha=0.5, eps=1e-5, qkv=None):
     """Two position-wise FFNs on the same rows in one launch (the last FFN of a Conformer block and the macaron FFN of the next):
         x1 = x + alpha FFN_A(LN(x; ln_in));   x2 = LN(x1; ln_mid);   x <- x2 + alpha FFN_B(LN(x2; ln_next))   (in place)
-    returns bf16 LN(x; ln_out).  Each ln_* is a (gamma, beta) pair; packed_* from ffn_pack_weights."""
+    returns bf16 LN(x; ln_out) — or, with qkv = (packed weight from ffn_qkv_pack, bias), bf16(LN(x; ln_out) @ Wq^T + bias).
+    Each ln_* is a (gamma, beta) pair; packed_* from ffn_pack_weights."""
     t = _host.torch()
     lib = _lib.load()
     assert x.dtype == t.float32 and x.stride(1) == 1
     m, d = x.shape
+    if qkv is not None:
+        n = qkv[1].numel()
+        out = t.empty((m, n), dtype=t.bfloat16, device=x.device)
+        rc = lib.ma_ffn_packed_pair_qkv_bf16(_host.ptr(packed_a), _host.ptr(b1_a), _host.ptr(b2_a), _host.ptr(packed_b),
+                                             _host.ptr(b1_b), _host.ptr(b2_b), _host.ptr(x), x.stride(0), m, d, b1_a.numel(),
+                                             float(alpha), _host.ptr(ln_in[0]), _host.ptr(ln_in[1]), _host.ptr(ln_mid[0]),
+                                             _host.ptr(ln_mid[1]), _host.ptr(ln_next[0]), _host.ptr(ln_next[1]),
+                                             _host.ptr(ln_out[0]), _host.ptr(ln_out[1]), float(eps), _host.ptr(qkv[0]),
+                                             _host.ptr(qkv[1]), n, _host.ptr(out), out.stride(0), _host.current_stream_ptr())
+        _lib.check(rc, "ffn_packed_pair_qkv_bf16")
+        return out
     out = t.empty((m, d), dtype=t.bfloat16, device=x.device)
     rc = lib.ma_ffn_packed_pair_bf16(_host.ptr(packed_a), _host.ptr(b1_a), _host.ptr(b2_a), _host.ptr(packed_b), _host.ptr(b1_b),
                                      _host.ptr(b2_b), _host.ptr(x), x.stride(0), m, d, b1_a.numel(), float(alpha),

@@ -407,6 +407,28 @@ def test_ffn_packed_pair(t, m, hidden):
         z = a.bfloat16().double() @ w1.double().cpu().T + b1.double().cpu()
         return (z * t.sigmoid(z)).bfloat16().double() @ w2.double().cpu().T + b2.double().cpu()
 
+    # ... and with linear_q/k/v of the attention behind it as the launch's tail: same x, qkv == the K = 256 dense layer on out_one
+    wq = _rand(t, 768, d, seed=131, scale=1.0 / 16).bfloat16().cuda()
+    bq = _rand(t, 768, seed=132, scale=0.3).cuda()
+    pq = ops.ffn_qkv_pack(wq)
+    assert pq is not None and t.equal(pq.view(t.int16).sort().values, wq.flatten().view(t.int16).sort().values)
+    assert ops.ffn_qkv_pack(wq[:100]) is None
+    want_qkv = ops.gemm(out_one, wq, bias=bq)
+    x_q = x.clone()
+    qkv = ops.ffn_packed_pair(pa, ba1, ba2, pb, bb1, bb2, x_q, lns[0], lns[1], lns[2], lns[3], qkv=(pq, bq))
+    assert qkv.shape == (m, 768) and t.equal(x_q, x_one)
+
+    def close(got, want):  # the bias is the accumulator's initial value here, an epilogue add in ops.gemm: last-bit differences
+        d_ = (got.float() - want.float()).abs()
+        return float(d_.max()) <= 2 ** -7 * float(want.float().abs().max()) and float((d_ > 0).float().mean()) < 0.1
+
+    assert close(qkv, want_qkv)
+    # single FFN + LayerNorm + linear_q/k/v
+    a_in = _rand(t, m, d, seed=133).bfloat16().cuda()
+    x_s1, x_s2 = x.clone(), x.clone()
+    ln_s = ops.ffn_packed(a_in, pa, ba1, ba2, x_s1, lns[3][0], lns[3][1])
+    qkv_s = ops.ffn_packed_qkv(a_in, pa, ba1, ba2, x_s2, lns[3][0], lns[3][1], pq, bq)
+    assert t.equal(x_s1, x_s2) and close(qkv_s, ops.gemm(ln_s, wq, bias=bq))
     if m <= 200:
         xd = x.double().cpu()
         x1 = xd + 0.5 * ffn(ln(xd, lns[0]), wa1, ba1, wa2, ba2)

@@ -134,19 +134,23 @@ def main():
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / reps * 1e-3  # seconds per launch
 
-    # ---- roofline of the dominant kernel: ffn_packed_kernel (MFMA bound; 24 launches per forward, ~1/3 of the
-    #      step), timed in the form the encoder launches it (FFN + residual + the LayerNorm that follows).
-    #      Algorithmic FLOPs per launch = 2 * M * (256*2048 + 2048*256) with M = 64*249 rows. -----------------
-    m, hid = BATCH * t2, 2048
-    a = torch.randn(m, 256, device=dev).bfloat16()
-    w1 = (torch.randn(hid, 256, device=dev) / 16).bfloat16()
-    w2 = (torch.randn(256, hid, device=dev) / 45).bfloat16()
-    b1, b2 = torch.randn(hid, device=dev), torch.randn(256, device=dev)
-    xres = torch.randn(m, 256, device=dev)
-    w_packed = ops.ffn_pack_weights(w1, w2)
-    ln_g, ln_b = torch.ones(256, device=dev), torch.zeros(256, device=dev)
-    gemm_s = event_time(lambda: ops.ffn_packed(a, w_packed, b1, b2, xres, ln_g, ln_b, alpha=0.5), max(args.steps, 50))
-    ffn_flops = 2.0 * m * 256 * hid * 2
+    # ---- roofline of the dominant kernel: ffn_packed_kernel (MFMA bound; ~45 % of the step), timed in the form the encoder
+    #      launches it 11 times per forward: the last FFN of a block + the macaron FFN of the next + the three LayerNorms
+    #      around them + linear_q/k/v of the next attention, one launch (the other 2 launches per forward are single FFNs).
+    #      Algorithmic FLOPs per launch = 2 FFNs x 2 M (256*2048 + 2048*256) + 2 M 256*768, M = 64*249 rows. ---------------
+    m, hid, nqkv = BATCH * t2, 2048, 768
+    gen = torch.Generator(device=dev).manual_seed(99)
+    rnd = lambda *shape: torch.randn(*shape, device=dev, generator=gen)
+    wa1, wb1 = (rnd(hid, 256) / 16).bfloat16(), (rnd(hid, 256) / 16).bfloat16()
+    wa2, wb2 = (rnd(256, hid) / 45).bfloat16(), (rnd(256, hid) / 45).bfloat16()
+    wq, bq = (rnd(nqkv, 256) / 16).bfloat16(), rnd(nqkv)
+    b1, b2 = rnd(hid), rnd(256)
+    xres = rnd(m, 256)
+    pa, pb, pq = ops.ffn_pack_weights(wa1, wa2), ops.ffn_pack_weights(wb1, wb2), ops.ffn_qkv_pack(wq)
+    ln = (torch.ones(256, device=dev), torch.zeros(256, device=dev))
+    gemm_s = event_time(lambda: ops.ffn_packed_pair(pa, b1, b2, pb, b1, b2, xres, ln, ln, ln, ln, alpha=0.5, qkv=(pq, bq)),
+                        max(args.steps, 50))
+    ffn_flops = 2 * (2.0 * m * 256 * hid * 2) + 2.0 * m * 256 * nqkv
     gemm_tf = ffn_flops / gemm_s / 1e12
 
     # ---- roofline of the fbank kernel (HBM bound): algorithmic bytes = waves in + features out ------------
@@ -197,7 +201,8 @@ def main():
                        "global_batch": BATCH * world, "frames": FRAMES,
                        "sharding": "independent utterance shards per rank, no collective",
                        "encoder_tflops": round(world * BATCH * args.steps * flops_utt / dt / 1e12, 1)},
-            "roofline": {"bound": "mfma", "kernel": "ffn_packed_kernel (w_1 -> Swish -> w_2 + residual + LayerNorm, M=%d d=256 hidden=%d)" % (m, hid),
+            "roofline": {"bound": "mfma", "kernel": "ffn_packed_kernel, pair + qkv form (2 x [w_1 -> Swish -> w_2 + residual] + 4 LayerNorms + linear_q/k/v, "
+                                                    "M=%d d=256 hidden=%d)" % (m, hid),
                          "achieved": round(gemm_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / MFMA_BF16_PEAK_TF, 4), "traffic": pmc_traffic("ffn_packed_kernel"),
                          "algorithmic_flops_per_launch": int(ffn_flops), "kernel_ms": round(gemm_s * 1e3, 5)},

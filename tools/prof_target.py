@@ -40,6 +40,14 @@ elif what == "ffnpkln":  # the form the encoder launches: FFN + residual + Layer
     w2 = (torch.randn(256, 2048, device="cuda") / 45).bfloat16(); b2 = torch.randn(256, device="cuda"); xx = torch.randn(m, 256, device="cuda")
     pk = ops.ffn_pack_weights(w1, w2); g = torch.ones(256, device="cuda"); be = torch.zeros(256, device="cuda")
     for _ in range(n): ops.ffn_packed(a, pk, b1, b2, xx, g, be)
+elif what == "ffnpair":  # the form the encoder launches 11 x per forward: FFN + FFN' + LayerNorms + linear_q/k/v
+    m = B * 249
+    r = lambda *sh: torch.randn(*sh, device="cuda")
+    pa = ops.ffn_pack_weights((r(2048, 256) / 16).bfloat16(), (r(256, 2048) / 45).bfloat16())
+    pb = ops.ffn_pack_weights((r(2048, 256) / 16).bfloat16(), (r(256, 2048) / 45).bfloat16())
+    pq = ops.ffn_qkv_pack((r(768, 256) / 16).bfloat16()); bq = r(768); b1 = r(2048); b2 = r(256); xx = r(m, 256)
+    ln = (torch.ones(256, device="cuda"), torch.zeros(256, device="cuda"))
+    for _ in range(n): ops.ffn_packed_pair(pa, b1, b2, pb, b1, b2, xx, ln, ln, ln, ln, qkv=(pq, bq))
 elif what == "attn":
     T = 249
     qkv = (torch.randn(B * T, 768, device="cuda") * 0.5).bfloat16(); pos = (torch.randn(T, 256, device="cuda") * 0.5).bfloat16()

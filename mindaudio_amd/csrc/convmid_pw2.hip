@@ -360,6 +360,19 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
   }
+  // the residual rows, mask and bias of the final epilogue: requested here so that their latency hides under the barrier and the MFMAs
+  float4 xres[2][4], bv2[4];
+  float rs2[2];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) bv2[jt] = *reinterpret_cast<const float4*>(p.bias + 64 * wave + 16 * jt + 4 * g);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = min(t0 + 16 * s + c, p.T - 1);
+    const int64_t m = row0 + t;
+    rs2[s] = p.mask ? p.mask[m] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) xres[s][jt] = *reinterpret_cast<const float4*>(p.x + m * p.ldx + 64 * wave + 16 * jt + 4 * g);
+  }
 #pragma unroll
   for (int o = 0; o < 4; ++o) *reinterpret_cast<uint4*>(smem + (rg * 4 + o) * kCpPitch + cg * 16) = zrow[o];  // z tile over the a-tile
   __syncthreads();
@@ -383,13 +396,13 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
     const int t = t0 + 16 * s + c;
     if (t >= p.T) continue;
     const int64_t m = row0 + t;
-    const float rs = p.mask ? p.mask[m] : 1.0f;
+    const float rs = rs2[s];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       const int n = 64 * wave + 16 * jt + 4 * g;
-      const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+      const float4 bv = bv2[jt];
       float4* xp = reinterpret_cast<float4*>(p.x + m * p.ldx + n);
-      float4 xv = *xp;
+      float4 xv = xres[s][jt];
       xv.x += (acc2[jt][s][0] + bv.x) * rs;
       xv.y += (acc2[jt][s][1] + bv.y) * rs;
       xv.z += (acc2[jt][s][2] + bv.z) * rs;

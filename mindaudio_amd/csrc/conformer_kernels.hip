@@ -292,7 +292,7 @@ constexpr int kKpStride = 128 + 8;   // bf16 elements per K' row (272 B: conflic
 constexpr int kVsStride = 80;        // bf16 elements per V row (160 B = 40 dwords: the 8 rows x 32 B that one half-wave of a
                                      // transposing read touches fall on 64 distinct banks)
 
-__global__ __launch_bounds__(256) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+__global__ __launch_bounds__(256, 4) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                                const uint16_t* __restrict__ pos, int64_t ld_pos,
                                                                const uint16_t* __restrict__ vt, int Tp,
                                                                const float* __restrict__ bias_u,

@@ -127,7 +127,7 @@ constexpr int kTs = 64 + 4;   // transposed tiles: 64 streamed items per row (13
 // KEYS_FIXED = true : fixed = keys (K', V), streamed = queries (Q', dO, Q'^T, dO^T, lse, D): outputs dK', dV
 // KEYS_FIXED = false: fixed = queries (Q', dO, lse, D), streamed = keys (K', V, K'^T, maskadd): output dQ'
 template <bool KEYS_FIXED>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+__global__ __launch_bounds__(256, KEYS_FIXED ? 2 : 3) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                        const uint16_t* __restrict__ dctx, int64_t ld_dctx,
                                                        const float* __restrict__ mask, const float* __restrict__ lse,
                                                        AttnWs ws, int T, int H, float scale,

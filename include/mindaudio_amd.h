@@ -620,14 +620,16 @@ int ma_ffn_packed_pair_bf16(const void* packed_a, const float* b1_a, const float
 /* The dense layer that consumes the final LayerNorm of ma_ffn_packed_bf16 (ln_mode 1) / ma_ffn_packed_pair_bf16 — linear_q/k/v of
  * the attention that follows (layers/attention.py:51-53, models/conformer.py:117-119) — run by the same launch on the tile while
  * it is in LDS:  qkv_out[m, :] = bf16(LN_out[m, :] . Wq^T + qkv_bias)   (qkv_out (M, qkv_n) bf16; LN_out itself is not written).
+ * gamma0 / beta0 of ma_ffn_packed_qkv_bf16 (optional, then a may be NULL): the FFN input is LayerNorm(x; gamma0, beta0), as in
+ * ma_ffn_packed_bf16.
  *   ma_ffn_qkv_packed_bytes(N) -> bytes of the packed weight (negative: unsupported; K = 256, N % 128 == 0);
  *   ma_ffn_qkv_pack_bf16(W (N, 256) bf16, ldw, N, packed): once per weight update. */
 int64_t ma_ffn_qkv_packed_bytes(int64_t N);
 int ma_ffn_qkv_pack_bf16(const void* W, int64_t ldw, int64_t N, void* packed, ma_stream_t stream);
 int ma_ffn_packed_qkv_bf16(const void* a, int64_t lda, const void* packed, const float* b1, const float* b2, float* x, int64_t ldx,
-                           int64_t M, int32_t d_model, int32_t hidden, float alpha, const float* gamma1, const float* beta1,
-                           float eps, const void* qkv_packed, const float* qkv_bias, int64_t qkv_n, void* qkv_out, int64_t ld_qkv,
-                           ma_stream_t stream);
+                           int64_t M, int32_t d_model, int32_t hidden, float alpha, const float* gamma0, const float* beta0,
+                           const float* gamma1, const float* beta1, float eps, const void* qkv_packed, const float* qkv_bias,
+                           int64_t qkv_n, void* qkv_out, int64_t ld_qkv, ma_stream_t stream);
 int ma_ffn_packed_pair_qkv_bf16(const void* packed_a, const float* b1_a, const float* b2_a, const void* packed_b,
                                 const float* b1_b, const float* b2_b, float* x, int64_t ldx, int64_t M, int32_t d_model,
                                 int32_t hidden, float alpha, const float* gamma0, const float* beta0, const float* gamma1,

@@ -183,8 +183,8 @@ PROTOTYPES = {
                                                f32, vp, i64, vp]),
     "ma_ffn_qkv_packed_bytes": (i64, [i64]),
     "ma_ffn_qkv_pack_bf16": (ctypes.c_int, [vp, i64, i64, vp, vp]),
-    "ma_ffn_packed_qkv_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, f32, vp, vp, i64, vp, i64,
-                                              vp]),
+    "ma_ffn_packed_qkv_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, vp, vp, f32, vp, vp, i64, vp,
+                                              i64, vp]),
     "ma_ffn_packed_pair_qkv_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp,
                                                    vp, f32, vp, vp, i64, vp, i64, vp]),
     "ma_ffn128_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i64, i32, i32, f32, vp]),

@@ -919,12 +919,17 @@ extern "C" int ma_ffn_packed_pair_qkv_bf16(const void* packed_a, const float* b1
 }
 
 extern "C" int ma_ffn_packed_qkv_bf16(const void* a, int64_t lda, const void* packed, const float* b1, const float* b2, float* x,
-                                      int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, const float* gamma1,
-                                      const float* beta1, float eps, const void* qkv_packed, const float* qkv_bias, int64_t qkv_n,
-                                      void* qkv_out, int64_t ld_qkv, ma_stream_t stream) {
+                                      int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, const float* gamma0,
+                                      const float* beta0, const float* gamma1, const float* beta1, float eps, const void* qkv_packed,
+                                      const float* qkv_bias, int64_t qkv_n, void* qkv_out, int64_t ld_qkv, ma_stream_t stream) {
   const int rc = qkv_tail_check(qkv_packed, qkv_bias, qkv_n, qkv_out, ld_qkv);
   if (rc != MA_OK) return rc;
-  if (!a || !packed || !b1 || !b2 || !x || !gamma1 || !beta1 || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if ((!a && !gamma0) || !packed || !b1 || !b2 || !x || !gamma1 || !beta1 || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (gamma0 && (!beta0 || ((reinterpret_cast<uintptr_t>(gamma0) | reinterpret_cast<uintptr_t>(beta0)) & 15))) return MA_ERR_INVALID_ARG;
+  if (gamma0) {  // the activation operand is not read: a = LayerNorm(x; gamma0, beta0) while staging
+    a = x;
+    lda = kPkD;
+  }
   if (ma_ffn_packed_bytes(d_model, hidden) < 0) return MA_ERR_UNSUPPORTED;
   if ((lda & 7) || (ldx & 3) || lda < kPkD || ldx < kPkD) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(b1) |
@@ -945,7 +950,7 @@ extern "C" int ma_ffn_packed_qkv_bf16(const void* a, int64_t lda, const void* pa
   p.ln_mode = 1;
   p.ln_out_bf16 = 1;
   p.g1 = gamma1; p.be1 = beta1; p.g2 = nullptr; p.be2 = nullptr;
-  p.g0 = nullptr; p.be0 = nullptr;
+  p.g0 = gamma0; p.be0 = beta0;
   p.ln_out = nullptr;
   p.ld_ln = 0;
   p.eps = eps;

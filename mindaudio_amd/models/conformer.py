@@ -273,12 +273,15 @@ class ConformerEncoder(nn.Module):
             return ops.gemm(inp, W[key + "_w"], **kw)
 
         part = torch.empty((m, self.d), dtype=f32, device=x.device) if use128 else None
-        a = ops.layernorm(x, self.encoders[0].norm_ff_macaron.gamma, self.encoders[0].norm_ff_macaron.beta)
+        a = None  # (computed below unless the first FFN launch normalises its input itself)
         # the last FFN of block i and the macaron FFN of block i + 1 act on the same rows: one launch (ffn_packed pair mode)
         pair_ffn = fused_ffn and part is None and packed_ffn and os.environ.get("MA_FFN_PAIR", "1") != "0"
         paired = False  # this block's macaron FFN already ran inside the previous block's last launch
         # linear_q/k/v computed by the FFN launch in front of it, on the tile in LDS (MA_FFN_QKV=0: A/B switch)
         qkv_tail = pair_ffn and all(W["qkv_fpk"] is not None for W in P["layers"]) and os.environ.get("MA_FFN_QKV", "1") != "0"
+        first_ln_in = qkv_tail and fused_ffn and part is None and packed_ffn and P["layers"][0]["ffm_pk"] is not None
+        if not first_ln_in:
+            a = ops.layernorm(x, self.encoders[0].norm_ff_macaron.gamma, self.encoders[0].norm_ff_macaron.beta)
         for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
             # x = x + 0.5 * FFN_macaron(LN(x))   (a = LN(x) comes from the previous block's fused LN pair)
             #                                                                      models/conformer.py:109-112
@@ -288,7 +291,8 @@ class ConformerEncoder(nn.Module):
             elif fused_ffn and part is None and packed_ffn and W["ffm_pk"] is not None:
                 if qkv_tail and W["qkv_fpk"] is not None:
                     qkv = ops.ffn_packed_qkv(a, W["ffm_pk"], W["ffm_b1"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta,
-                                             W["qkv_fpk"], W["qkv_b"])
+                                             W["qkv_fpk"], W["qkv_b"],
+                                             ln_in=(l.norm_ff_macaron.gamma, l.norm_ff_macaron.beta) if a is None else None)
                 else:
                     a = ops.ffn_packed(a, W["ffm_pk"], W["ffm_b1"], W["ffm_b2"], x, l.norm_mha.gamma, l.norm_mha.beta)
             elif fused_ffn and part is None:  # FFN + the LayerNorm in front of the attention in one kernel

@@ -208,16 +208,21 @@ def ffn_qkv_pack(w):
     return packed
 
 
-def ffn_packed_qkv(a, packed, b1, b2, x, g1, be1, qkv_packed, qkv_bias, alpha=0.5, eps=1e-5):
-    """x += alpha FFN(a) in place, then qkv = bf16(LN(x; g1, be1) @ Wq^T + qkv_bias) on the same tile; returns qkv (M, N)."""
+def ffn_packed_qkv(a, packed, b1, b2, x, g1, be1, qkv_packed, qkv_bias, alpha=0.5, eps=1e-5, ln_in=None):
+    """x += alpha FFN(a) in place, then qkv = bf16(LN(x; g1, be1) @ Wq^T + qkv_bias) on the same tile; returns qkv (M, N).
+    ln_in = (gamma0, beta0): a = LayerNorm(x; gamma0, beta0) computed inside the kernel (pass a=None)."""
     t = _host.torch()
     lib = _lib.load()
-    assert a.dtype == t.bfloat16 and a.stride(1) == 1 and x.dtype == t.float32 and x.stride(1) == 1
+    assert x.dtype == t.float32 and x.stride(1) == 1
+    if ln_in is None:
+        assert a.dtype == t.bfloat16 and a.stride(1) == 1
     m, d = x.shape
     n = qkv_bias.numel()
     out = t.empty((m, n), dtype=t.bfloat16, device=x.device)
-    rc = lib.ma_ffn_packed_qkv_bf16(_host.ptr(a), a.stride(0), _host.ptr(packed), _host.ptr(b1), _host.ptr(b2), _host.ptr(x),
-                                    x.stride(0), m, d, b1.numel(), float(alpha), _host.ptr(g1), _host.ptr(be1), float(eps),
+    rc = lib.ma_ffn_packed_qkv_bf16(_host.ptr(a) if ln_in is None else None, a.stride(0) if ln_in is None else 0,
+                                    _host.ptr(packed), _host.ptr(b1), _host.ptr(b2), _host.ptr(x),
+                                    x.stride(0), m, d, b1.numel(), float(alpha), _opt(ln_in[0]) if ln_in else None,
+                                    _opt(ln_in[1]) if ln_in else None, _host.ptr(g1), _host.ptr(be1), float(eps),
                                     _host.ptr(qkv_packed), _host.ptr(qkv_bias), n, _host.ptr(out), out.stride(0),
                                     _host.current_stream_ptr())
     _lib.check(rc, "ffn_packed_qkv_bf16")

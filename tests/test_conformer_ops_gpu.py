@@ -429,6 +429,11 @@ def test_ffn_packed_pair(t, m, hidden):
     ln_s = ops.ffn_packed(a_in, pa, ba1, ba2, x_s1, lns[3][0], lns[3][1])
     qkv_s = ops.ffn_packed_qkv(a_in, pa, ba1, ba2, x_s2, lns[3][0], lns[3][1], pq, bq)
     assert t.equal(x_s1, x_s2) and close(qkv_s, ops.gemm(ln_s, wq, bias=bq))
+    # ... with the LayerNorm of the FFN input folded in as well
+    x_s3, x_s4 = x.clone(), x.clone()
+    ln_s3 = ops.ffn_packed(None, pa, ba1, ba2, x_s3, lns[3][0], lns[3][1], ln_in=lns[0])
+    qkv_s4 = ops.ffn_packed_qkv(None, pa, ba1, ba2, x_s4, lns[3][0], lns[3][1], pq, bq, ln_in=lns[0])
+    assert t.equal(x_s3, x_s4) and close(qkv_s4, ops.gemm(ln_s3, wq, bias=bq))
     if m <= 200:
         xd = x.double().cpu()
         x1 = xd + 0.5 * ffn(ln(xd, lns[0]), wa1, ba1, wa2, ba2)

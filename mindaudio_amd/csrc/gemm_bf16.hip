@@ -378,7 +378,7 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   // 64x128 tile prefers 3 workgroups/CU (2 stages) when there are enough tiles to fill them, else the 3-stage ring
   if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
   // long K with about one 128 x 128 tile per CU (the 4864 -> 256 embed layer at M = 15936: 250 tiles): half the L2 -> LDS traffic
-  // of the 64-row tile, and the deep ring has 76 k-steps to pay for itself (measured 77 -> 68 us)
+  // of the 64-row tile, and the deep ring has 76 k-steps to pay for itself (measured 77 -> 72 us)
   if (p.K >= 2048 && big <= gemm_num_cus() && big >= (int64_t)(0.9 * gemm_num_cus()))
     return launch_gemm_tile<128, 128, 3, IM2COL, EPI>(p, stream);
   const int64_t small = (int64_t)((p.M + 63) / 64) * ((p.N + 127) / 128);

@@ -255,9 +255,11 @@ class ConformerEncoder(nn.Module):
         x = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(self.d), out_dtype=f32)
         pos_all = self._pos_projection(t2)
         n_layers = len(self.encoders)
-        # the fused FFN kernel works on 64-row blocks, one workgroup per CU: it wins (measured at M = 7968 and
-        # 15936) once there are enough blocks to cover a good part of the chip
-        fused_ffn = m >= 64 * 64
+        # The packed-weight / fused launches (4 per block) win at every batch size measured (B = 1 .. 64 at T = 1000: 1.44 vs 2.25 ms
+        # at B = 1, 1.61 vs 2.24 ms at B = 16, where both are bound by the launch rate); MA_FUSE_MIN_ROWS raises the row count
+        # below which the general kernels are used instead (tests run both).
+        min_rows = int(os.environ.get("MA_FUSE_MIN_ROWS", 1))
+        fused_ffn = m >= min_rows
         # 128-row formulation of the fused kernel (hidden units split over two workgroups; the following LayerNorm adds
         # the second half's partial product back).  Measured at B = 64: the kernel itself is ~7 % faster, but the extra
         # partial-product traffic makes the step 1.5 % slower, so it is off unless MA_FFN128=1 (developer A/B switch).
@@ -265,7 +267,7 @@ class ConformerEncoder(nn.Module):
         # hidden-slice-owner kernel on packed weights (ffn_packed.hip): 43 us vs 60 us at M = 15936 (MA_FFN_PACKED=0: A/B switch)
         packed_ffn = os.environ.get("MA_FFN_PACKED", "1") != "0"
         # K = 256 dense layers: packed-weight kernel (gemm_k256.hip) once the rows cover the chip (MA_GEMM_PACKED=0: A/B switch)
-        packed_gemm = m >= 64 * 64 and os.environ.get("MA_GEMM_PACKED", "1") != "0"
+        packed_gemm = m >= min_rows and os.environ.get("MA_GEMM_PACKED", "1") != "0"
 
         def dense(inp, W, key, **kw):
             if packed_gemm and W[key + "_pk"] is not None:

@@ -42,10 +42,16 @@ def _pair(num_blocks, seed=0, cmvn=False):
     return ref, dut.cuda().prepare()
 
 
-# the last case has 18 x 249 = 4482 subsampled rows: above the 4096-row switch, so the packed-weight kernels
-# (gemm_k256, convmid_pw2, gemm+LayerNorm epilogue, conv2_packed) are the ones compared with the oracle
+# default: the fused / packed-weight launches (ffn_packed pair + qkv, convmodule, gemm + LayerNorm epilogue, conv2_packed); the last
+# case has 4482 rows (70 row tiles, ragged lengths)
+@pytest.mark.parametrize("general", [False, True])
 @pytest.mark.parametrize("blocks,b,tlen,cmvn", [(1, 2, 131, False), (2, 3, 203, True), (2, 18, 1000, True)])
-def test_encoder_matches_oracle(blocks, b, tlen, cmvn):
+def test_encoder_matches_oracle(blocks, b, tlen, cmvn, general, monkeypatch):
+    # general = True: the un-fused launches on the general kernels (what MA_FUSE_MIN_ROWS selects below a row count)
+    if general:
+        if b > 3:
+            pytest.skip("one size is enough for the general path")
+        monkeypatch.setenv("MA_FUSE_MIN_ROWS", "1000000")
     import torch
 
     from oracle import conformer_oracle as C

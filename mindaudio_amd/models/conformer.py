@@ -225,14 +225,15 @@ class ConformerEncoder(nn.Module):
         if P.get("conv2_pk") is not None and os.environ.get("MA_CONV2_PACKED", "1") != "0":
             # conv1's output (B x 10 MB at T = 1000) is written once and read once: run conv1 -> conv2 over groups of
             # utterances through ONE reused buffer so the intermediate lives in the 256 MB Infinity Cache instead of HBM.
-            # Group = what one resident round of conv2_packed covers (512 workgroups of 128 output cells): 13 utterances
-            # at the north-star shape, 453 us vs 518 us for the two full-batch launches (MA_SUB_CHUNK=0: A/B switch).
+            # Group = what fits ~220 MB (22 utterances at the north-star shape, 3 groups).  Measured inside the bench step:
+            # 2.465 ms with groups of 20-22, 2.496 ms ungrouped, 2.51 ms with groups of 13 (= one resident round of
+            # conv2_packed, the best size when the two kernels are timed alone); MA_SUB_CHUNK=<n> / 0: A/B switch.
             t1, f1 = (t - 3) // 2 + 1, (idim - 3) // 2 + 1
             t2, f2 = (t1 - 3) // 2 + 1, (f1 - 3) // 2 + 1
             c = P["conv2_b"].numel()
             group = b
             if b * t1 * f1 * c * 2 > 240e6:
-                group = max(1, min(b, (512 * 128) // max(1, t2 * f2)))
+                group = max(1, min(b, int(220e6 // (t1 * f1 * c * 2))))
                 group = -(-b // -(-b // group))
             group = int(os.environ.get("MA_SUB_CHUNK", group)) or b
             act2 = torch.empty((b, t2, f2, c), dtype=torch.bfloat16, device=xs.device)

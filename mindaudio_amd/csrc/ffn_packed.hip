@@ -390,6 +390,14 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       v[i] = *reinterpret_cast<const float4*>(xr + 4 * i);
       sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
+    {
+      // the same rows are this stage's residual: parked now in the (odd) exchange slot of the wave that will own them, in the
+      // epilogue's layout [16 j][64 lanes] (lane = 16 g + c holds features 16 j + 4 g .. + 3 of row 16 w + c) - the epilogue
+      // then has no global fetch on its critical path
+      float4* pk = reinterpret_cast<float4*>(smem + ((row >> 4) * 2 + 1) * 16384) + (row & 15);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pk[((part * 4 + (i >> 2)) * 64) + (i & 3) * 16] = v[i];
+    }
     sum += __shfl_xor(sum, 1, 64);
     sum += __shfl_xor(sum, 2, 64);
     const float mean = sum * (1.0f / 256.0f);
@@ -501,10 +509,10 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   float* xrow = p.x + (int64_t)mc * p.ldx + 4 * g;
   float4 xres[16];
   float4* park = reinterpret_cast<float4*>(smem + (wave * 2 + 1) * 16384) + lane;  // pair mode: x2 of this wave's rows, [16 j][64 lanes]
-  if (stg == 0) {
+  if (stg == 0 && !p.g0) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) xres[j] = *reinterpret_cast<const float4*>(xrow + 16 * j);
-  } else {
+  } else {  // parked by the tile staging (stage 0 with the input LayerNorm) or by the previous stage's epilogue
 #pragma unroll
     for (int j = 0; j < 16; ++j) xres[j] = park[j * 64];
   }

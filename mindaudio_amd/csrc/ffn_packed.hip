@@ -497,7 +497,9 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     swish_drain(SB);
     product2(wbase(blk_wrap(ci + 3)), block_of(blk_wrap(ci + 3)), SA);
   }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // drain the ring; last MFMA -> accumulator reads
+  // last MFMA -> accumulator reads.  The ring's last (wrapped, unused) prefetches are NOT waited for here: their registers stay
+  // reserved until the drain below, one exchange round later, by which time they have long landed (~1 us of L2 latency per stage)
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
   const int tid = tidv, lane = tidv & 63, c = lane & 15, g = lane >> 4, m0 = m0v;  // (see the top of the stage loop)
 
   // ---- cross-wave reduction: wave w ends up with row tile w (its slot 0) ---------------------------------------------------
@@ -528,6 +530,12 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     }
   }
   __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(ring[0]), "+v"(ring[1]), "+v"(ring[2]), "+v"(ring[3]), "+v"(ring[4]), "+v"(ring[5]), "+v"(ring[6]), "+v"(ring[7]),
+                 "+v"(ring[8]), "+v"(ring[9]), "+v"(ring[10]), "+v"(ring[11]), "+v"(ring[12]), "+v"(ring[13]), "+v"(ring[14]),
+                 "+v"(ring[15]), "+v"(b1lo), "+v"(b1hi)
+               :
+               : "memory");  // drain of the main loop's last prefetches (see above)
   {
     const f32x4* s1 = xslot(wave, 0);
     const f32x4* s2 = xslot(wave, 1);

@@ -95,6 +95,49 @@ def test_encoder_full_config_shapes_and_determinism():
         dut.train()(xs.cuda(), sub.cuda())
 
 
+def test_encoder_north_star_size_properties():
+    """BASELINE size (64 x 1000 x 80, 12 blocks): properties that need no oracle run at that size - run-to-run determinism,
+    utterances are independent (a permuted batch gives the permuted output; utterances taken out of the batch give the same rows),
+    and frames behind an utterance's length do not influence the frames in front of it."""
+    import torch
+
+    from oracle import conformer_oracle as C
+
+    _, dut = _pair(12, seed=11)
+    g = torch.Generator().manual_seed(21)
+    xs = torch.randn(64, 1000, 80, generator=g).cuda()
+    lens = torch.randint(400, 1001, (64,), generator=g)
+    lens[0] = 1000
+    mask = (torch.arange(1000)[None, :] < lens[:, None]).float().unsqueeze(1)
+    sub = C.subsample_mask(mask).cuda()
+    out, _ = dut(xs, sub)
+    out2, _ = dut(xs, sub)
+    assert torch.equal(out, out2)
+    assert bool(torch.isfinite(out).all())
+
+    def close(a, b):  # a row's float32 sums are accumulated in an order that depends on the 64-row tile it falls in (the FFN
+        # workgroups start at different hidden blocks), so a moved utterance differs by float32 round-off, amplified to a few
+        # bf16 ulps of the activations over 12 blocks; measured 2e-3
+        rel = float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+        return rel <= 6e-3
+
+    perm = torch.randperm(64, generator=g).cuda()
+    outp, _ = dut(xs[perm].contiguous(), sub[perm].contiguous())
+    assert close(outp, out[perm])
+    outs, _ = dut(xs[8:24].contiguous(), sub[8:24].contiguous())
+    assert close(outs, out[8:24])
+    # garbage behind the receptive field of an utterance's last valid (subsampled) frame leaves its valid frames untouched: masked
+    # keys get probability exactly 0, the conv module zeroes masked frames, everything else is row-local.  (Frames between the
+    # length and that point are seen by the last valid frames through the two stride-2 convolutions - in the reference as well.)
+    valid = sub[:, 0, :].bool()  # (64, 249)
+    n_valid = valid.sum(1)
+    xg = xs.clone()
+    for i in range(64):
+        xg[i, 4 * (int(n_valid[i]) - 1) + 7:] = 37.0
+    outg, _ = dut(xg, sub)
+    assert float((outg - out).abs()[valid].max()) == 0.0
+
+
 def test_ctc_loss_matches_oracle():
     import torch
 

@@ -32,15 +32,21 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);                                             // round to nearest even
   return (uint16_t)(u >> 16);
 }
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// (v_rcp_f32 instead of an IEEE division: these element-wise kernels are VALU-bound - exp, the reciprocal and the integer
+// multiplies of the dropout hash - not bandwidth-bound; 1 ulp, invisible after the bf16 rounding of every consumer)
+__device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // Counter-based dropout: the keep decision of element `idx` of dropout site `salt` at step seed `seed` is a pure
 // function, so the backward pass regenerates the mask instead of storing it.
+// One 32-bit hash serves the element pair (idx & ~1, idx | 1), 16 bits each (p is resolved to 2^-16): the three integer multiplies
+// of the mixer are quarter-rate instructions and made these element-wise kernels VALU-bound; kernels that walk consecutive
+// elements get the pair's hash once (common subexpression after inlining).
 __device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t salt, uint64_t idx, uint32_t thresh) {
-  uint32_t x = (uint32_t)idx ^ (seed * 0x9E3779B9u) ^ (salt * 0x85EBCA6Bu) ^ ((uint32_t)(idx >> 32) * 0xC2B2AE35u);
+  const uint64_t pair = idx >> 1;
+  uint32_t x = (uint32_t)pair ^ (seed * 0x9E3779B9u) ^ (salt * 0x85EBCA6Bu) ^ ((uint32_t)(pair >> 32) * 0xC2B2AE35u);
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   x += salt; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
-  return x >= thresh;
+  return ((idx & 1) ? (x >> 16) : (x & 0xffffu)) >= (thresh >> 16);
 }
 struct Drop {
   uint32_t seed, salt, thresh;  // thresh = p * 2^32; 0 = no dropout

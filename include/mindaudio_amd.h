@@ -569,6 +569,17 @@ int ma_convmodule_bf16(const void* a, int64_t lda, int64_t batch, int64_t T, int
                        const void* pw2_packed, const float* pw2_bias, const float* mask, float* x, int64_t ldx,
                        ma_stream_t stream);
 
+/* ma_convmodule_bf16 with the attention output projection, its residual and norm_conv in front (layers/attention.py:56 linear_out,
+ * models/conformer.py:135-141): per 32-frame tile
+ *   x' = x + ctx . Wo^T + wo_bias;   a = LN(x'; ln_gamma, ln_beta) * mask;   x <- x' + mask * ConvModule(a)
+ * ctx (batch*T, 256) bf16 attention context; wo_packed = ma_gemm_k256_pack_bf16 of the (256, 256) linear_out weight.  x is read
+ * and written once; x' and a never leave the CU (the halo frames of a tile recompute the projection). */
+int ma_attn_out_convmodule_bf16(const void* ctx, int64_t ldc, const void* wo_packed, const float* wo_bias, const float* ln_gamma,
+                                const float* ln_beta, float ln_eps, int64_t batch, int64_t T, int32_t C, const void* pw1_packed,
+                                const float* pw1_bias, const float* dw, int32_t kernel_size, const float* bn_scale,
+                                const float* bn_shift, const void* pw2_packed, const float* pw2_bias, const float* mask, float* x,
+                                int64_t ldx, ma_stream_t stream);
+
 /* Dense / k=1 Conv1d with K = 256 inputs (linear_q/k/v/out: layers/attention.py:51-56; pointwise_conv1/2:
  * layers/convolution.py:52-78) on a fragment-ordered packed copy of W (gemm_k256.hip): same result as ma_gemm_bf16.
  *   ma_gemm_k256_packed_bytes(N, K) -> bytes of the packed buffer (negative: unsupported; K = 256, N % 256 == 0);

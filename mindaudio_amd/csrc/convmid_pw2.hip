@@ -200,10 +200,19 @@ __global__ __launch_bounds__(256, 2) void convmid_pw2_kernel(const ConvPw2Params
 //      accumulators (out-of-utterance frames -> 0, the conv's zero padding), bf16 into the y tile [48][528 B];
 //   2. depthwise conv + BN + Swish as convmid_pw2_kernel (4 frames x 8 channels per thread), z tile over the dead a-tile;
 //   3. z . Wp2^T + epilogue as convmid_pw2_kernel.
-constexpr int kCmRows = 48, kCmYPitch = 528;
-constexpr int kCmOffY = kCmRows * kCpPitch;                 // 26112
-constexpr int kCmOffW = kCmOffY + kCmRows * kCmYPitch;      // 51456
-constexpr int kCmLds = kCmOffW + kCpMaxK * 256 * 4;         // 66816
+// OPROJ form (ma_attn_out_convmodule_bf16): the attention output projection + residual + norm_conv run in front, as phase 0, on the
+// 64 frames t0 - 16 .. t0 + 47 (4 MFMA row tiles; only the frames t0 - half .. t0 + 31 + half are loaded and used):
+// x' = x + ctx . Wo^T + bo and a = LN(x'; gamma, beta) * mask never leave the CU - the tile's own 32 frames are row tiles 1 and 2,
+// so their x' values stay in 32 accumulator registers in exactly the layout of the final epilogue, which adds the conv branch and
+// stores x once.  To make room for them, phase 1 of this form runs in four sub-passes of one value + one gate column tile
+// (16 weight fragments each, double-buffered) instead of two passes of 32 fragments.
+constexpr int kCmRows = 48, kCmRowsO = 64, kCmYPitch = 528;
+template <bool OPROJ> struct CmLayout {
+  static constexpr int kRows = OPROJ ? kCmRowsO : kCmRows;
+  static constexpr int kOffY = kRows * kCpPitch;
+  static constexpr int kOffW = kOffY + kCmRows * kCmYPitch;
+  static constexpr int kLds = kOffW + kCpMaxK * 256 * 4;  // 66816 / 75520 bytes: two workgroups per CU either way
+};
 
 struct ConvModParams {
   const uint16_t* a;   // (B*T, 256) bf16: norm_conv(x) * mask
@@ -219,20 +228,179 @@ struct ConvModParams {
   float* x;
   int64_t ldx;
   int32_t T, KS;
+  // OPROJ
+  const uint16_t* ctx;  // (B*T, 256) bf16 attention context
+  int64_t ldc;
+  const uint4* wop;     // linear_out weight (256 x 256), packed as gemm_k256.hip
+  const float* bo;
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
 };
 
+template <bool OPROJ>
 __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams p) {
+  typedef CmLayout<OPROJ> L;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int b = blockIdx.y, t0 = blockIdx.x * kCpTile;
   const int KS = p.KS, half = KS / 2;
   const int64_t row0 = (int64_t)b * p.T;
-  float* wl = reinterpret_cast<float*>(smem + kCmOffW);
-  char* ytile = smem + kCmOffY;
+  float* wl = reinterpret_cast<float*>(smem + L::kOffW);
+  char* ytile = smem + L::kOffY;
 
-  // ---- pass A weight fragments: tiles (value 4w, 4w+1 | gate 16+4w, 16+4w+1) ------------------------------------------------------
+  f32x4 xo[OPROJ ? 4 : 1][2];  // OPROJ: x' of the tile's own 32 frames, in the final epilogue's layout
+  const char* abase = smem + c * kCpPitch + g * 16;
+  if constexpr (OPROJ) {
+    // ---- phase 0: x' = x + ctx . Wo^T + bo; a = LN(x') * mask on frames t0 - 16 + r, r = 16 - half .. 47 + half ---------------------
+    const int r_lo = 16 - half, r_hi = 48 + half;
+    f32x4 acc[4][4];
+    {
+      bf16x8 wo[4][8];
+      const uint4* base = p.wop + ((int64_t)(wave * 4) * 8) * 64 + lane;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wo[jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
+#pragma unroll
+      for (int it = 0; it < kCmRowsO / 8; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx >> 5, ch = idx & 31;
+        if (row < r_lo || row >= r_hi) continue;  // not needed: their (garbage) results are never read
+        int t = t0 - 16 + row;
+        t = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);
+        *reinterpret_cast<uint4*>(smem + row * kCpPitch + ch * 16) = *reinterpret_cast<const uint4*>(p.ctx + (row0 + t) * p.ldc + ch * 8);
+      }
+      for (int i = tid; i < KS * 256; i += 256) wl[i] = p.dw[(i & 255) * KS + (i >> 8)];  // wl[k][c]
+      __syncthreads();
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) af[s] = *reinterpret_cast<const bf16x8*>(abase + s * 16 * kCpPitch + ks * 64);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[jt][ks], af[s], acc[jt][s], 0, 0, 0);
+      }
+    }
+    float rsum[4], rsq[4], msk[4];
+    float4 bv[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) bv[jt] = *reinterpret_cast<const float4*>(p.bo + 64 * wave + 16 * jt + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r = 16 * s + c, t = t0 - 16 + r;
+      const bool live = r >= r_lo && r < r_hi && t >= 0 && t < p.T;
+      const int64_t m = row0 + (live ? t : 0);
+      msk[s] = live ? (p.mask ? p.mask[m] : 1.0f) : 0.0f;
+      rsum[s] = 0.f;
+      rsq[s] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) xv = *reinterpret_cast<const float4*>(p.x + m * p.ldx + 64 * wave + 16 * jt + 4 * g);
+        const float v0 = (acc[jt][s][0] + bv[jt].x) + xv.x, v1 = (acc[jt][s][1] + bv[jt].y) + xv.y;
+        const float v2 = (acc[jt][s][2] + bv[jt].z) + xv.z, v3 = (acc[jt][s][3] + bv[jt].w) + xv.w;
+        acc[jt][s] = f32x4{v0, v1, v2, v3};
+        rsum[s] += (v0 + v1) + (v2 + v3);
+        rsq[s] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      }
+    }
+    // a row's 256 values live in 4 lane groups (g) x 4 waves: two shuffles + an LDS exchange (in the still unused y tile)
+    float* red = reinterpret_cast<float*>(ytile);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float a = rsum[s], b = rsq[s];
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 16, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (g == 0) {
+        red[wave * 64 + 16 * s + c] = a;
+        red[256 + wave * 64 + 16 * s + c] = b;
+      }
+    }
+    __syncthreads();  // (also: every wave is done reading the ctx tile)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r = 16 * s + c;
+      const float sum = (red[r] + red[64 + r]) + (red[128 + r] + red[192 + r]);
+      const float sq = (red[256 + r] + red[320 + r]) + (red[384 + r] + red[448 + r]);
+      const float mean = sum * (1.0f / 256.0f);
+      const float var = fmaxf(sq * (1.0f / 256.0f) - mean * mean, 0.0f);
+      const float inv = 1.0f / sqrtf(var + p.ln_eps);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int n = 64 * wave + 16 * jt + 4 * g;
+        const float4 ga = *reinterpret_cast<const float4*>(p.ln_g + n);
+        const float4 be = *reinterpret_cast<const float4*>(p.ln_b + n);
+        const f32x4 v = acc[jt][s];
+        *reinterpret_cast<uint2*>(smem + r * kCpPitch + n * 2) =
+            make_uint2(cp_pack_bf16(((v[0] - mean) * inv * ga.x + be.x) * msk[s], ((v[1] - mean) * inv * ga.y + be.y) * msk[s]),
+                       cp_pack_bf16(((v[2] - mean) * inv * ga.z + be.z) * msk[s], ((v[3] - mean) * inv * ga.w + be.w) * msk[s]));
+      }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      xo[jt][0] = acc[jt][1];
+      xo[jt][1] = acc[jt][2];
+    }
+    __syncthreads();  // the a-tile (rows 16 - half .. 47 + half of the 64) is complete; the exchange buffer is free again
+
+    // ---- phase 1 in four sub-passes: value tile 4 w + sp and its gate tile, 16 fragments, double-buffered ------------------------------
+    const char* abase1 = abase + (16 - half) * kCpPitch;  // a-tile row of frame t0 - half
+    bf16x8 wq[2][2][8];
+#define CM_LOAD_SP(buf, sp)                                                                                       \
+  {                                                                                                             \
+    _Pragma("unroll") for (int vg = 0; vg < 2; ++vg) {                                                          \
+      const uint4* base = p.w1p + ((int64_t)(vg * 16 + wave * 4 + (sp)) * 8) * 64 + lane;                       \
+      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) wq[buf][vg][ks] = *reinterpret_cast<const bf16x8*>(base + ks * 64); \
+    }                                                                                                           \
+  }
+    CM_LOAD_SP(0, 0)
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      if (sp + 1 < 4) CM_LOAD_SP((sp + 1) & 1, sp + 1)
+      f32x4 a2[2][3];
+#pragma unroll
+      for (int vg = 0; vg < 2; ++vg)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a2[vg][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8 af[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) af[s] = *reinterpret_cast<const bf16x8*>(abase1 + s * 16 * kCpPitch + ks * 64);
+#pragma unroll
+        for (int vg = 0; vg < 2; ++vg)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) a2[vg][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sp & 1][vg][ks], af[s], a2[vg][s], 0, 0, 0);
+      }
+      const int n = 64 * wave + 16 * sp + 4 * g;
+      const float4 bvv = *reinterpret_cast<const float4*>(p.b1 + n);
+      const float4 bg = *reinterpret_cast<const float4*>(p.b1 + kCpC + n);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int t = t0 + 16 * s + c - half;
+        const bool live = t >= 0 && t < p.T;
+        const float y0 = live ? cp_sigmoid_mul(a2[0][s][0] + bvv.x, a2[1][s][0] + bg.x) : 0.f;
+        const float y1 = live ? cp_sigmoid_mul(a2[0][s][1] + bvv.y, a2[1][s][1] + bg.y) : 0.f;
+        const float y2 = live ? cp_sigmoid_mul(a2[0][s][2] + bvv.z, a2[1][s][2] + bg.z) : 0.f;
+        const float y3 = live ? cp_sigmoid_mul(a2[0][s][3] + bvv.w, a2[1][s][3] + bg.w) : 0.f;
+        *reinterpret_cast<uint2*>(ytile + (16 * s + c) * kCmYPitch + n * 2) = make_uint2(cp_pack_bf16(y0, y1), cp_pack_bf16(y2, y3));
+      }
+    }
+#undef CM_LOAD_SP
+  }
   bf16x8 wf[4][8];
+  if constexpr (!OPROJ) {
+  // ---- pass A weight fragments: tiles (value 4w, 4w+1 | gate 16+4w, 16+4w+1) ------------------------------------------------------
 #define CM_LOAD_W1(pass)                                                                                        \
   {                                                                                                             \
     _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) {                                                          \
@@ -254,7 +422,6 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
   for (int i = tid; i < KS * 256; i += 256) wl[i] = p.dw[(i & 255) * KS + (i >> 8)];  // wl[k][c]
   __syncthreads();
 
-  const char* abase = smem + c * kCpPitch + g * 16;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     f32x4 acc[4][3];
@@ -292,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
     }
   }
 #undef CM_LOAD_W1
+  }
   __syncthreads();  // y tile complete; the a-tile is dead
 
   // ---- depthwise conv + BatchNorm (affine) + Swish: 4 consecutive frames x 8 channels per thread -------------------------------------
@@ -371,7 +539,10 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
     const int64_t m = row0 + t;
     rs2[s] = p.mask ? p.mask[m] : 1.0f;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) xres[s][jt] = *reinterpret_cast<const float4*>(p.x + m * p.ldx + 64 * wave + 16 * jt + 4 * g);
+    for (int jt = 0; jt < 4; ++jt) {
+      if constexpr (OPROJ) xres[s][jt] = make_float4(xo[jt][s][0], xo[jt][s][1], xo[jt][s][2], xo[jt][s][3]);
+      else xres[s][jt] = *reinterpret_cast<const float4*>(p.x + m * p.ldx + 64 * wave + 16 * jt + 4 * g);
+    }
   }
 #pragma unroll
   for (int o = 0; o < 4; ++o) *reinterpret_cast<uint4*>(smem + (rg * 4 + o) * kCpPitch + cg * 16) = zrow[o];  // z tile over the a-tile
@@ -452,21 +623,35 @@ extern "C" int ma_convmid_pw2_bf16(const void* y, int64_t ldy, int64_t batch, in
   return MA_OK;
 }
 
-extern "C" int ma_convmodule_bf16(const void* a, int64_t lda, int64_t batch, int64_t T, int32_t C, const void* pw1_packed,
-                                  const float* pw1_bias, const float* dw, int32_t kernel_size, const float* bn_scale,
-                                  const float* bn_shift, const void* pw2_packed, const float* pw2_bias, const float* mask, float* x,
-                                  int64_t ldx, ma_stream_t stream) {
-  if (!a || !pw1_packed || !pw1_bias || !dw || !bn_scale || !bn_shift || !pw2_packed || !pw2_bias || !x || batch < 1 || T < 1)
+static int convmodule_launch(ConvModParams& p, int64_t batch, int64_t T, ma_stream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmodule_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CmLayout<false>::kLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&convmodule_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CmLayout<true>::kLds) != hipSuccess)
+      return MA_ERR_LAUNCH;
+    attr = true;
+  }
+  const dim3 grid((unsigned)((T + kCpTile - 1) / kCpTile), (unsigned)batch);
+  if (p.ctx)
+    MA_LAUNCH(convmodule_kernel<true>, grid, dim3(256), CmLayout<true>::kLds, (hipStream_t)stream, p);
+  else
+    MA_LAUNCH(convmodule_kernel<false>, grid, dim3(256), CmLayout<false>::kLds, (hipStream_t)stream, p);
+  return MA_OK;
+}
+
+static int convmodule_args(ConvModParams& p, int64_t batch, int64_t T, int32_t C, const void* pw1_packed, const float* pw1_bias,
+                           const float* dw, int32_t kernel_size, const float* bn_scale, const float* bn_shift, const void* pw2_packed,
+                           const float* pw2_bias, const float* mask, float* x, int64_t ldx) {
+  if (!pw1_packed || !pw1_bias || !dw || !bn_scale || !bn_shift || !pw2_packed || !pw2_bias || !x || batch < 1 || T < 1)
     return MA_ERR_INVALID_ARG;
   if (C != kCpC || kernel_size < 1 || kernel_size > kCpMaxK || (kernel_size & 1) == 0 || batch > 65535) return MA_ERR_UNSUPPORTED;
-  if ((lda & 7) || lda < kCpC || (ldx & 3) || ldx < kCpC) return MA_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(pw1_packed) | reinterpret_cast<uintptr_t>(pw1_bias) |
-       reinterpret_cast<uintptr_t>(pw2_packed) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(pw2_bias) |
-       reinterpret_cast<uintptr_t>(bn_scale) | reinterpret_cast<uintptr_t>(bn_shift)) & 15)
+  if ((ldx & 3) || ldx < kCpC) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(pw1_packed) | reinterpret_cast<uintptr_t>(pw1_bias) | reinterpret_cast<uintptr_t>(pw2_packed) |
+       reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(pw2_bias) | reinterpret_cast<uintptr_t>(bn_scale) |
+       reinterpret_cast<uintptr_t>(bn_shift)) & 15)
     return MA_ERR_INVALID_ARG;
-  ConvModParams p;
-  p.a = reinterpret_cast<const uint16_t*>(a);
-  p.lda = lda;
   p.w1p = reinterpret_cast<const uint4*>(pw1_packed);
   p.b1 = pw1_bias;
   p.dw = dw;
@@ -479,14 +664,50 @@ extern "C" int ma_convmodule_bf16(const void* a, int64_t lda, int64_t batch, int
   p.ldx = ldx;
   p.T = (int32_t)T;
   p.KS = kernel_size;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmodule_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kCmLds) !=
-        hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
-  }
-  MA_LAUNCH(convmodule_kernel, dim3((unsigned)((T + kCpTile - 1) / kCpTile), (unsigned)batch), dim3(256), kCmLds, (hipStream_t)stream,
-            p);
   return MA_OK;
+}
+
+extern "C" int ma_convmodule_bf16(const void* a, int64_t lda, int64_t batch, int64_t T, int32_t C, const void* pw1_packed,
+                                  const float* pw1_bias, const float* dw, int32_t kernel_size, const float* bn_scale,
+                                  const float* bn_shift, const void* pw2_packed, const float* pw2_bias, const float* mask, float* x,
+                                  int64_t ldx, ma_stream_t stream) {
+  ConvModParams p;
+  const int rc = convmodule_args(p, batch, T, C, pw1_packed, pw1_bias, dw, kernel_size, bn_scale, bn_shift, pw2_packed, pw2_bias,
+                                 mask, x, ldx);
+  if (rc != MA_OK) return rc;
+  if (!a || (lda & 7) || lda < kCpC || (reinterpret_cast<uintptr_t>(a) & 15)) return MA_ERR_INVALID_ARG;
+  p.a = reinterpret_cast<const uint16_t*>(a);
+  p.lda = lda;
+  p.ctx = nullptr;
+  p.ldc = 0;
+  p.wop = nullptr;
+  p.bo = p.ln_g = p.ln_b = nullptr;
+  p.ln_eps = 0.f;
+  return convmodule_launch(p, batch, T, stream);
+}
+
+extern "C" int ma_attn_out_convmodule_bf16(const void* ctx, int64_t ldc, const void* wo_packed, const float* wo_bias,
+                                           const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t batch, int64_t T,
+                                           int32_t C, const void* pw1_packed, const float* pw1_bias, const float* dw,
+                                           int32_t kernel_size, const float* bn_scale, const float* bn_shift,
+                                           const void* pw2_packed, const float* pw2_bias, const float* mask, float* x, int64_t ldx,
+                                           ma_stream_t stream) {
+  ConvModParams p;
+  const int rc = convmodule_args(p, batch, T, C, pw1_packed, pw1_bias, dw, kernel_size, bn_scale, bn_shift, pw2_packed, pw2_bias,
+                                 mask, x, ldx);
+  if (rc != MA_OK) return rc;
+  if (!ctx || !wo_packed || !wo_bias || !ln_gamma || !ln_beta || (ldc & 7) || ldc < kCpC) return MA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(wo_packed) | reinterpret_cast<uintptr_t>(wo_bias) |
+       reinterpret_cast<uintptr_t>(ln_gamma) | reinterpret_cast<uintptr_t>(ln_beta)) & 15)
+    return MA_ERR_INVALID_ARG;
+  p.a = nullptr;
+  p.lda = 0;
+  p.ctx = reinterpret_cast<const uint16_t*>(ctx);
+  p.ldc = ldc;
+  p.wop = reinterpret_cast<const uint4*>(wo_packed);
+  p.bo = wo_bias;
+  p.ln_g = ln_gamma;
+  p.ln_b = ln_beta;
+  p.ln_eps = ln_eps;
+  return convmodule_launch(p, batch, T, stream);
 }

@@ -306,18 +306,27 @@ class ConformerEncoder(nn.Module):
                 a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta, addend=add)
             if qkv is None:
                 qkv = dense(a, W, "qkv", bias=W["qkv_b"])
+            conv_done = False
             ctx = ops.relpos_attention(qkv, pos_all[:, li * 256:(li + 1) * 256], W["u"], W["v"], att_mask, b, t2,
                                        self.heads, 64)
             # x = x + ConvModule(LN(x), mask_pad)                                  :139-143, convolution.py:83-129
-            if packed_gemm and W["o_pk"] is not None and os.environ.get("MA_GEMM_LN", "1") != "0":
+            conv_pk = packed_gemm and W["pw2_pk"] is not None and W["dw_w"].shape[1] <= 15 and os.environ.get("MA_CONV_PW2", "1") != "0"
+            conv_one = conv_pk and W["pw1_pk"] is not None and os.environ.get("MA_CONVMODULE", "1") != "0"
+            if conv_one and W["o_pk"] is not None and os.environ.get("MA_ATTN_CONV", "1") != "0":
+                # output projection + residual + norm_conv + the whole ConvolutionModule in one launch (x read and written once)
+                ops.attn_out_convmodule(ctx, W["o_pk"], W["o_b"], l.norm_conv.gamma, l.norm_conv.beta, W["pw1_pk"], W["pw1_b"],
+                                        W["dw_w"], W["bn_scale"], W["bn_shift"], W["pw2_pk"], W["pw2_b"], mask_rows, x, b, t2)
+                conv_done = True
+            elif packed_gemm and W["o_pk"] is not None and os.environ.get("MA_GEMM_LN", "1") != "0":
                 # output projection + residual + norm_conv (+ mask) in one launch
                 _, a = ops.gemm_packed_ln(ctx, W["o_pk"], l.norm_conv.gamma, l.norm_conv.beta, ln_row_scale=mask_rows,
                                           bias=W["o_b"], residual=x, out=x)
             else:
                 dense(ctx, W, "o", bias=W["o_b"], residual=x, out_dtype=f32, out=x)
                 a = ops.layernorm(x, l.norm_conv.gamma, l.norm_conv.beta, row_scale=mask_rows)
-            conv_pk = packed_gemm and W["pw2_pk"] is not None and W["dw_w"].shape[1] <= 15 and os.environ.get("MA_CONV_PW2", "1") != "0"
-            if conv_pk and W["pw1_pk"] is not None and os.environ.get("MA_CONVMODULE", "1") != "0":
+            if conv_done:
+                pass
+            elif conv_one:
                 # pointwise_conv1 .. pointwise_conv2 + residual in one launch (convmid_pw2.hip: convmodule_kernel)
                 ops.convmodule(a, W["pw1_pk"], W["pw1_b"], W["dw_w"], W["bn_scale"], W["bn_shift"], W["pw2_pk"], W["pw2_b"],
                                mask_rows, x, b, t2)

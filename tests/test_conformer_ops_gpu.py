@@ -158,6 +158,36 @@ def test_convmodule_one_launch(t, b, tt, ks):
         assert float(err) <= 2 ** -7 * float(branch.abs().max()), float(err)
 
 
+@pytest.mark.parametrize("b,tt,ks", [(3, 249, 15), (2, 33, 7), (5, 64, 15), (1, 5, 3), (2, 32, 15)])
+def test_attn_out_convmodule_one_launch(t, b, tt, ks):
+    """linear_out + residual + norm_conv + ConvolutionModule in one launch == output projection with the LayerNorm epilogue
+    (ops.gemm_packed_ln) followed by ops.convmodule (same arithmetic per row; halo frames recomputed)."""
+    from mindaudio_amd import ops
+
+    c = 256
+    ctx = _rand(t, b * tt, c, seed=51).bfloat16().cuda()
+    wo = _rand(t, c, c, seed=52, scale=1.0 / 16).bfloat16().cuda()
+    bo = _rand(t, c, seed=53, scale=0.2).cuda()
+    lg, lb = (1 + 0.1 * _rand(t, c, seed=54)).cuda(), (0.1 * _rand(t, c, seed=55)).cuda()
+    w1 = _rand(t, 2 * c, c, seed=42, scale=1.0 / 16).bfloat16().cuda()
+    b1 = _rand(t, 2 * c, seed=43, scale=0.2).cuda()
+    dw = _rand(t, c, ks, seed=32, scale=0.3).cuda()
+    sc, sh = (1 + 0.1 * _rand(t, c, seed=33)).cuda(), (0.1 * _rand(t, c, seed=34)).cuda()
+    w2 = _rand(t, c, c, seed=35, scale=1.0 / 16).bfloat16().cuda()
+    b2 = _rand(t, c, seed=36).cuda()
+    mask = (t.rand(b * tt, generator=t.Generator().manual_seed(37)) > 0.2).float().cuda()
+    x0 = _rand(t, b * tt, c, seed=38).cuda()
+    po, p1, p2 = ops.gemm_k256_pack(wo), ops.gemm_k256_pack(w1), ops.gemm_k256_pack(w2)
+    for m_ in (mask, None):
+        want = x0.clone()
+        _, a = ops.gemm_packed_ln(ctx, po, lg, lb, ln_row_scale=m_, bias=bo, residual=want, out=want)
+        ops.convmodule(a, p1, b1, dw, sc, sh, p2, b2, m_, want, b, tt)
+        got = x0.clone()
+        assert ops.attn_out_convmodule(ctx, po, bo, lg, lb, p1, b1, dw, sc, sh, p2, b2, m_, got, b, tt) is got
+        err = float((got - want).abs().max())
+        assert err <= 1e-5 * float(want.abs().max()), err
+
+
 @pytest.mark.parametrize("m,n", [(64, 256), (777, 512), (15936, 768), (1, 256), (130, 1024)])
 def test_gemm_k256_packed(t, m, n):
     """K = 256 dense layers on fragment-packed weights: same contract (and epilogues) as ops.gemm."""

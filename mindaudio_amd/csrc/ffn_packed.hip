@@ -558,6 +558,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // ---- epilogue: lane (c, g) holds row m0 + 16 wave + c, features n = 16 j + 4 g + r -------------------------------------
   const float* par = reinterpret_cast<const float*>(smem + (stg == 0 ? kPkOffPar : kPkOffPar2)) + 4 * g;
   float v[64];
+  float vs = 0.f, vq = 0.f;  // sum / sum of squares of the row slice, accumulated while it is produced (first LayerNorm's statistics)
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const float4 bv = *reinterpret_cast<const float4*>(par + 16 * j);
@@ -566,6 +567,11 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     v[4 * j + 1] = xv.y + p.alpha * (O[j][0][1] + bv.y);
     v[4 * j + 2] = xv.z + p.alpha * (O[j][0][2] + bv.z);
     v[4 * j + 3] = xv.w + p.alpha * (O[j][0][3] + bv.w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vs += v[4 * j + r];
+      vq += v[4 * j + r] * v[4 * j + r];
+    }
   }
   auto store_x = [&]() __attribute__((always_inline)) {
     if (!live) return;
@@ -578,13 +584,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     return;
   }
   // A row lives in the 4 lanes {c, c + 16, c + 32, c + 48} of one wave: two shuffles, no LDS.
-  auto layer_norm = [&](const float* gam, const float* bet) __attribute__((always_inline)) {
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int e = 0; e < 64; ++e) {
-      s += v[e];
-      q += v[e] * v[e];
-    }
+  // (the statistics come in as s, q; the normalised values' own statistics go out the same way, for a LayerNorm chained behind)
+  auto layer_norm = [&](const float* gam, const float* bet, float& s, float& q) __attribute__((always_inline)) {
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     q += __shfl_xor(q, 16, 64);
@@ -601,12 +602,19 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       v[4 * j + 2] = (v[4 * j + 2] - mean) * rstd * gv.z + bv.z;
       v[4 * j + 3] = (v[4 * j + 3] - mean) * rstd * gv.w + bv.w;
     }
+    s = 0.f;
+    q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) {
+      s += v[e];
+      q += v[e] * v[e];
+    }
   };
   if (p.pair && stg == 0) {
-    layer_norm(par + 256, par + 512);  // x2 = norm_final(x1): the second stage's residual, parked in this wave's own slot
+    layer_norm(par + 256, par + 512, vs, vq);  // x2 = norm_final(x1): the second stage's residual, parked in this wave's own slot
 #pragma unroll
     for (int j = 0; j < 16; ++j) park[j * 64] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-    layer_norm(par + 768, par + 1024);  // a' = norm_ff_macaron'(x2): this wave's 16 rows of the next activation tile
+    layer_norm(par + 768, par + 1024, vs, vq);  // a' = norm_ff_macaron'(x2): this wave's 16 rows of the next activation tile
     char* arow = smem + wave * kPkTileStride + c * kPkPitch + 8 * g;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -615,10 +623,10 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   }
   const int mode = p.pair ? 1 : p.ln_mode;
   if (mode == 1) store_x();  // the un-normalised sum is the new residual stream
-  layer_norm(par + 256, par + 512);
+  layer_norm(par + 256, par + 512, vs, vq);
   if (mode == 2) {
     store_x();  // x <- norm_final(x)  (models/conformer.py:155-156)
-    layer_norm(par + 768, par + 1024);
+    layer_norm(par + 768, par + 1024, vs, vq);
   }
   if (p.qkv_wp) {  // the rows go to the LDS tile of the dense layer below instead of HBM
     char* arow = smem + wave * kPkTileStride + c * kPkPitch + 8 * g;

@@ -98,6 +98,11 @@ __device__ __forceinline__ uint32_t pk_pack_bf16(float lo, float hi) {
   const bf16x2 r = __builtin_convertvector((f32x2){lo, hi}, bf16x2);  // v_cvt_pk_bf16_f32 (round to nearest even)
   return *reinterpret_cast<const uint32_t*>(&r);
 }
+// __shfl_xor with the caller's own lane index: the library form derives the lane from v_mbcnt once per kernel, a value that then
+// lives across the whole stage loop and was spilled (its scratch reload sat behind the residual stores: +1 us per stage)
+__device__ __forceinline__ float pk_shfl_xor(float x, int mask, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, __builtin_bit_cast(int, x)));
+}
 template <int ABL>
 __device__ __forceinline__ float pk_swish(float v) {
   if constexpr (ABL & 1) return v;
@@ -398,8 +403,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 #pragma unroll
       for (int i = 0; i < 16; ++i) pk[((part * 4 + (i >> 2)) * 64) + (i & 3) * 16] = v[i];
     }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
+    sum += pk_shfl_xor(sum, 1, tid & 63);
+    sum += pk_shfl_xor(sum, 2, tid & 63);
     const float mean = sum * (1.0f / 256.0f);
     float q = 0.f;
 #pragma unroll
@@ -407,8 +412,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
       q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-    q += __shfl_xor(q, 1, 64);
-    q += __shfl_xor(q, 2, 64);
+    q += pk_shfl_xor(q, 1, tid & 63);
+    q += pk_shfl_xor(q, 2, tid & 63);
     const float inv = 1.0f / sqrtf(q * (1.0f / 256.0f) + p.eps);
     char* dst = smem + (row >> 4) * kPkTileStride + (row & 15) * kPkPitch + part * 128;
 #pragma unroll
@@ -586,10 +591,10 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // A row lives in the 4 lanes {c, c + 16, c + 32, c + 48} of one wave: two shuffles, no LDS.
   // (the statistics come in as s, q; the normalised values' own statistics go out the same way, for a LayerNorm chained behind)
   auto layer_norm = [&](const float* gam, const float* bet, float& s, float& q) __attribute__((always_inline)) {
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
+    s += pk_shfl_xor(s, 16, lane);
+    s += pk_shfl_xor(s, 32, lane);
+    q += pk_shfl_xor(q, 16, lane);
+    q += pk_shfl_xor(q, 32, lane);
     const float mean = s * (1.0f / 256.0f);
     const float var = fmaxf(q * (1.0f / 256.0f) - mean * mean, 0.0f);
     const float rstd = 1.0f / sqrtf(var + p.eps);
@@ -697,7 +702,9 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     PK_LDS(af[1][2], a_addr[2], 1 << 6);
     PK_LDS(af[1][3], a_addr[3], 1 << 6);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qalo), "+v"(qahi)::"memory");
-    const int lane_q = tid & 63, cq = lane_q & 15, gq = lane_q >> 4;
+    int lane_q;  // re-derived here (two instructions): threadIdx.x kept alive across the stage loop would be spilled and reloaded
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_q));
+    const int cq = lane_q & 15, gq = lane_q >> 4;
     auto store_s = [&](f32x4 (&S)[2][4], int blk) __attribute__((always_inline)) {
       asm volatile("s_nop 15\n\ts_nop 3" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]),
                    "+v"(S[1][2]), "+v"(S[1][3]));  // MFMA result -> VALU read

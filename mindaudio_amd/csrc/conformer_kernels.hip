@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/mindaudio_amd.h"
 
@@ -292,7 +293,10 @@ constexpr int kKpStride = 128 + 8;   // bf16 elements per K' row (272 B: conflic
 constexpr int kVsStride = 80;        // bf16 elements per V row (160 B = 40 dwords: the 8 rows x 32 B that one half-wave of a
                                      // transposing read touches fall on 64 distinct banks)
 
-__global__ __launch_bounds__(256, 4) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+// NW = waves per workgroup: 4 (64 query rows, four workgroups per CU) or 8 (128 query rows, two per CU: the K' / V tiles are staged
+// once for twice as many queries; used when the second half of the 128 rows is populated).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                                const uint16_t* __restrict__ pos, int64_t ld_pos,
                                                                const uint16_t* __restrict__ vt, int Tp,
                                                                const float* __restrict__ bias_u,
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256, 4) void relpos_attention_kernel(const uint16_t
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int64_t row0 = (int64_t)b * T;
-  const int q_base = qt * kAttQ + wave * 16;
+  const int q_base = qt * (NW * 16) + wave * 16;
   const int lq = lane & 15, lg = lane >> 4;
   (void)vt;
   (void)Tp;
@@ -349,28 +353,32 @@ __global__ __launch_bounds__(256, 4) void relpos_attention_kernel(const uint16_t
   const int n_kt = (T + kAttK - 1) / kAttK;
   // (named registers + a macro: arrays captured by a lambda end up in scratch memory)
   uint4 rk0, rk1, rk2, rk3, rv0, rv1;
-  const int sk_key = tid >> 4, sk_ch = tid & 15;   // K' piece i: key sk_key + 16 i, 16-byte chunk sk_ch
-  const int sv_key = tid >> 3, sv_ch = tid & 7;    // V piece i: key sv_key + 32 i, 16-byte chunk sv_ch of its 64 d
+  constexpr int kKeyStep = NW * 4;                 // keys covered by one piece index: 16 (4 waves) / 32 (8 waves)
+  const int sk_key = tid >> 4, sk_ch = tid & 15;   // K' piece i: key sk_key + kKeyStep i, 16-byte chunk sk_ch
+  const int sv_key = tid >> 3, sv_ch = tid & 7;    // V piece i: key sv_key + 2 kKeyStep i, 16-byte chunk sv_ch of its 64 d
   const uint16_t* ksrc_base = (sk_ch < 8) ? qkv + row0 * ld_qkv + 256 + h * kDk + sk_ch * 8
                                           : pos + h * kDk + (sk_ch - 8) * 8;
   const int64_t ksrc_ld = (sk_ch < 8) ? ld_qkv : ld_pos;
 #define MA_ATT_KLOAD(dst, i, k0_)                                                     \
   {                                                                                   \
-    int kj_ = (k0_) + sk_key + 16 * (i);                                              \
+    int kj_ = (k0_) + sk_key + kKeyStep * (i);                                        \
     if (kj_ >= T) kj_ = T - 1;                                                        \
     dst = *reinterpret_cast<const uint4*>(ksrc_base + (int64_t)kj_ * ksrc_ld);        \
   }
 #define MA_ATT_FETCH(kt_)                                                             \
   {                                                                                   \
     const int k0f_ = (kt_)*kAttK;                                                     \
-    MA_ATT_KLOAD(rk0, 0, k0f_) MA_ATT_KLOAD(rk1, 1, k0f_) MA_ATT_KLOAD(rk2, 2, k0f_) MA_ATT_KLOAD(rk3, 3, k0f_) \
+    MA_ATT_KLOAD(rk0, 0, k0f_) MA_ATT_KLOAD(rk1, 1, k0f_)                             \
+    if constexpr (NW == 4) { MA_ATT_KLOAD(rk2, 2, k0f_) MA_ATT_KLOAD(rk3, 3, k0f_) }   \
     {                                                                                 \
       const int v0_ = k0f_ + sv_key, v1_ = k0f_ + sv_key + 32;                        \
       const uint16_t* vb_ = qkv + row0 * ld_qkv + 512 + h * kDk + sv_ch * 8;          \
       rv0 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)(v0_ < T ? v0_ : T - 1) * ld_qkv);     \
-      rv1 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)(v1_ < T ? v1_ : T - 1) * ld_qkv);     \
       if (v0_ >= T) rv0 = make_uint4(0, 0, 0, 0); /* keys past T: probability 0 x a FINITE value */ \
-      if (v1_ >= T) rv1 = make_uint4(0, 0, 0, 0);                                     \
+      if constexpr (NW == 4) {                                                        \
+        rv1 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)(v1_ < T ? v1_ : T - 1) * ld_qkv);   \
+        if (v1_ >= T) rv1 = make_uint4(0, 0, 0, 0);                                   \
+      }                                                                               \
     }                                                                                 \
   }
   MA_ATT_FETCH(0)
@@ -378,11 +386,13 @@ __global__ __launch_bounds__(256, 4) void relpos_attention_kernel(const uint16_t
     const int k0 = kt * kAttK;
     __syncthreads();  // previous tile fully consumed
     *reinterpret_cast<uint4*>(&Kp[(sk_key)*kKpStride + sk_ch * 8]) = rk0;
-    *reinterpret_cast<uint4*>(&Kp[(sk_key + 16) * kKpStride + sk_ch * 8]) = rk1;
-    *reinterpret_cast<uint4*>(&Kp[(sk_key + 32) * kKpStride + sk_ch * 8]) = rk2;
-    *reinterpret_cast<uint4*>(&Kp[(sk_key + 48) * kKpStride + sk_ch * 8]) = rk3;
+    *reinterpret_cast<uint4*>(&Kp[(sk_key + kKeyStep) * kKpStride + sk_ch * 8]) = rk1;
     *reinterpret_cast<uint4*>(&Vs[sv_key * kVsStride + sv_ch * 8]) = rv0;
-    *reinterpret_cast<uint4*>(&Vs[(sv_key + 32) * kVsStride + sv_ch * 8]) = rv1;
+    if constexpr (NW == 4) {
+      *reinterpret_cast<uint4*>(&Kp[(sk_key + 32) * kKpStride + sk_ch * 8]) = rk2;
+      *reinterpret_cast<uint4*>(&Kp[(sk_key + 48) * kKpStride + sk_ch * 8]) = rk3;
+      *reinterpret_cast<uint4*>(&Vs[(sv_key + 32) * kVsStride + sv_ch * 8]) = rv1;
+    }
     if (tid < kAttK) {
       const int kj = k0 + tid;
       // keys past T do not exist (-inf); padded keys inside T get the reference's additive -10000
@@ -724,8 +734,17 @@ static int relpos_attention_fwd(const void* qkv, int64_t ld_qkv, const void* pos
   if (vt_bytes < ma_relpos_attention_workspace_bytes(batch, T, heads, d_k)) return MA_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   // (V is read from the qkv buffer as stored; the V^T workspace of earlier revisions is no longer written)
+  // 128-row query tiles when their second half is populated (T = 249: 128 + 121 rows); MA_ATT_Q128=0: developer A/B switch
+  static const int q128 = getenv("MA_ATT_Q128") ? atoi(getenv("MA_ATT_Q128")) : 1;
+  if (q128 && ((T - 1) % 128) >= 96) {
+    const dim3 grid8((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batch);
+    MA_LAUNCH(relpos_attention_kernel<8>, grid8, dim3(512), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
+              reinterpret_cast<const uint16_t*>(pos), ld_pos, reinterpret_cast<const uint16_t*>(vt_workspace), Tp, bias_u,
+              bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx, lse);
+    return MA_OK;
+  }
   const dim3 grid((unsigned)((T + kAttQ - 1) / kAttQ), (unsigned)heads, (unsigned)batch);
-  MA_LAUNCH(relpos_attention_kernel, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
+  MA_LAUNCH(relpos_attention_kernel<4>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
             reinterpret_cast<const uint16_t*>(pos), ld_pos, reinterpret_cast<const uint16_t*>(vt_workspace), Tp, bias_u,
             bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx, lse);
   return MA_OK;

@@ -6,7 +6,10 @@ sys.path.insert(0, ROOT)
 prof_lib = os.path.join(ROOT, "mindaudio_amd", "lib", "libmindaudio_amd_prof.so")
 src = os.path.join(ROOT, "mindaudio_amd", "csrc", "features.hip")
 if not os.path.exists(prof_lib) or os.path.getmtime(prof_lib) < os.path.getmtime(src) or "--rebuild" in sys.argv:
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-DMA_PROFILE", "-shared", src, "-o", prof_lib])
+    # every source goes in (the binding resolves all symbols of the header); only features.hip looks at MA_PROFILE
+    import glob
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-DMA_PROFILE", "-shared"]
+                          + sorted(glob.glob(os.path.join(os.path.dirname(src), "*.hip"))) + ["-o", prof_lib])
 os.environ["MINDAUDIO_AMD_LIB"] = prof_lib
 import numpy as np, torch
 from mindaudio_amd import _host, _lib

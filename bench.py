@@ -9,11 +9,22 @@ One "step" = one pass of the hot path over one synthetic batch resident in HBM:
   bf16 MFMA matmuls with float32 accumulation) --> (64, 249, 256).
 N GPUs = N independent shards of 64 utterances (weak scaling; inference forward has no data-path collective and
 the reference's batch-global top_db floor is per call, i.e. per rank — SURVEY §8e).
-Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N --steps K --warmup W]      N > 1 without WORLD_SIZE in the environment: this process starts
+                                                        `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+                                                        as a child BEFORE anything touches the GPU and relays its output
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (how the driver launches N > 1)
+
+Besides the headline the line carries: `sustained` (the same step timed over >= 2 s, after the burst figure), the two
+rooflines, `train_dp` (cfg 4: data-parallel CTC training steps of Conformer-small with the bucketed RCCL gradient
+all-reduce, its bus bandwidth and the exposed communication time; `--train` makes that leg the headline instead), and at
+N = 1 the CPU baselines.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,39 +37,196 @@ BATCH, SAMPLES, N_FFT, HOP, N_MELS, SR = 64, 160000, 512, 160, 80, 16000
 FRAMES = 1000
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+XGMI_LINK_GBS = 153.0       # per xGMI link, 7 links per GPU
+FBANK_KW = dict(n_mels=N_MELS, n_fft=N_FFT, hop_length=HOP)
+TRAIN_BATCH, TRAIN_FRAMES, TRAIN_VOCAB = 40, 1024, 4233  # conformer.yaml bucket 1024 -> 40 utterances per rank, AISHELL vocabulary
 
 
-def synth_batch(seed):
-    return (0.1 * np.random.RandomState(seed).randn(BATCH, SAMPLES)).astype(np.float32)
+def synth_batch(seed, n=BATCH):
+    return (0.1 * np.random.RandomState(seed).randn(n, SAMPLES)).astype(np.float32)
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle (CPU restatement of the reference algorithms) on a bounded sample of the same workload:
-    fbank in the reference's own cost structure (float64 framing loop + per-column rFFT, 1 process) followed by
-    the PyTorch-CPU float32 eager Conformer forward on all host threads."""
+# ======================================================================================================================
+# CPU baselines (oracle = CPU restatement of the reference; baseline only, never the product path)
+# ======================================================================================================================
+def _cpu_fbank_r(x):
+    from oracle import speech_features as O
+
+    return O.fbank_ref_cost(x[None], n_mels=N_MELS, n_fft=N_FFT, sample_rate=SR, hop_length=HOP).shape
+
+
+def _cpu_fbank_v(x):
+    from oracle import speech_features as O
+
+    return O.fbank(x[None], **FBANK_KW).shape
+
+
+def cpu_baseline():
+    """fbank in two flavours — (R) the reference's own cost structure (float64 framing loop + per-column
+    rFFT + mel matmul + amplitude_to_dB) and (V) vectorised NumPy — each as one process and as Pool(min(8, nproc)) over
+    utterances (the reference's own parallelism, examples/conformer/dataset.py:449,479); Conformer-small forward =
+    PyTorch-CPU float32 eager oracle at batch 64 on all host threads.  `value` = fastest (R) fbank followed by that
+    encoder, end to end."""
+    import multiprocessing as mp
+
     import torch
 
     from oracle import conformer_oracle as C
-    from oracle import speech_features as O
 
-    n_utt = 4
-    x = synth_batch(1234)[:n_utt]
+    nproc = os.cpu_count() or 1
+    n_fb = 16
+    rows = list(synth_batch(1234, n_fb))
+    fb = {}
+    pool_n = min(8, nproc)
+    ctx = mp.get_context("spawn")  # never fork a process that holds a HIP context
+    with ctx.Pool(pool_n) as pool:
+        for name, fn in (("R", _cpu_fbank_r), ("V", _cpu_fbank_v)):
+            fn(rows[0])
+            t0 = time.perf_counter()
+            for r in rows:
+                fn(r)
+            fb[name + "_1proc"] = n_fb / (time.perf_counter() - t0)
+            pool.map(fn, rows[:pool_n])
+            t0 = time.perf_counter()
+            pool.map(fn, rows)
+            fb[name + "_pool%d" % pool_n] = n_fb / (time.perf_counter() - t0)
     torch.manual_seed(0)
     enc = C.ConformerEncoder(80, 256, 4, 2048, 12).eval()
-    mask = C.subsample_mask(torch.ones(n_utt, 1, FRAMES))
-    done, total = 0, 0.0
-    while total < budget_s and done < 4 * n_utt:
+    xs = torch.randn(BATCH, FRAMES, 80)
+    mask = C.subsample_mask(torch.ones(BATCH, 1, FRAMES))
+    with torch.no_grad():
+        enc(xs[:4], mask[:4])
         t0 = time.perf_counter()
-        feats = O.fbank_ref_cost(x, n_mels=N_MELS, n_fft=N_FFT, sample_rate=SR, hop_length=HOP)
-        xs = torch.from_numpy(np.ascontiguousarray(feats.transpose(0, 2, 1)[:, :FRAMES]).astype(np.float32))
-        with torch.no_grad():
-            enc(xs, mask)
-        total += time.perf_counter() - t0
-        done += n_utt
-    return {"value": round(done / total, 3), "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d utterances (10 s @16 kHz): oracle fbank_ref_cost (NumPy float64, 1 process) + oracle "
-                      "Conformer-small forward (PyTorch-CPU float32 eager, %d threads), batches of %d"
-                      % (done, torch.get_num_threads(), n_utt)}
+        enc(xs, mask)
+        enc_rate = BATCH / (time.perf_counter() - t0)
+    best_r = max(v for k, v in fb.items() if k.startswith("R"))
+    e2e = 1.0 / (1.0 / best_r + 1.0 / enc_rate)
+    return {"value": round(e2e, 3), "unit": "utterances/s", "cores": nproc, "kind": "port",
+            "fbank_utt_per_s": {k: round(v, 2) for k, v in fb.items()},
+            "encoder_utt_per_s": round(enc_rate, 3), "encoder_threads": torch.get_num_threads(),
+            "sample": "fbank: %d utterances (10 s @16 kHz) per flavour — R = oracle.fbank_ref_cost (reference cost structure, "
+                      "NumPy float64), V = oracle.fbank (vectorised NumPy); 1 process and Pool(%d) each.  Encoder: one batch "
+                      "of %d x %d x 80 through the oracle Conformer-small (PyTorch-CPU float32 eager, %d threads).  value = "
+                      "fastest R fbank + encoder, end to end" % (n_fb, pool_n, BATCH, FRAMES, torch.get_num_threads())}
+
+
+# ======================================================================================================================
+# launcher: N > 1 ranks as fresh children (decided before any HIP call in this process)
+# ======================================================================================================================
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """Start `torch.distributed.run` with n ranks of this script as a CHILD process (this process has not initialised
+    the GPU and never does), pass its output through and return its exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ======================================================================================================================
+# cfg 4: data-parallel CTC training step
+# ======================================================================================================================
+def synth_train_batch(rank, dev, b=TRAIN_BATCH, t=TRAIN_FRAMES, vocab=TRAIN_VOCAB):
+    """AISHELL-shaped synthetic bucket-1024 batch for one rank: the 11 columns of examples/conformer/train.py:38-50."""
+    import torch
+
+    rng = np.random.RandomState(1234 + rank)
+    xs = torch.from_numpy(rng.randn(b, t, 80).astype(np.float32)).to(dev)
+    lens = rng.randint(int(0.7 * t), t + 1, b)
+    lens[0] = t
+    t2 = ((t - 3) // 2 + 1 - 3) // 2 + 1
+    masks = torch.zeros(b, 1, t2)
+    for i, n in enumerate(lens):
+        masks[i, 0, :(n - 1) // 4] = 1  # frames 4j < n (dataset.py:625)
+        xs[i, n:] = 0
+    ylens = rng.randint(5, 31, b).astype(np.int32)
+    ys = np.full((b, 30), -1, np.int32)
+    for i, n in enumerate(ylens):
+        ys[i, :n] = rng.randint(1, vocab - 1, n)
+    sos = eos = vocab - 1
+    ys_in = np.full((b, 31), eos, np.int32)
+    ys_out = np.full((b, 31), -1, np.int32)
+    ys_m = np.zeros((b, 1, 31), np.float32)
+    for i, n in enumerate(ylens):
+        ys_in[i, 0] = sos
+        ys_in[i, 1:n + 1] = ys[i, :n]
+        ys_out[i, :n] = ys[i, :n]
+        ys_out[i, n] = eos
+        ys_m[i, 0, :n + 1] = 1
+    ys_sub = (ys_m.astype(bool) & np.tril(np.ones((31, 31), bool))[None]).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    return (xs, d(ys), d(ys_in), d(ys_out), None, None, masks.to(dev), d(ys_sub), d(ys_m), d(ylens), None)
+
+
+def train_leg(rank, world, dev, dist, steps, warmup, barrier):
+    """cfg 4: `steps` optimizer steps of ConformerCTCTrainStep on a (40, 1024, 80) batch per rank, gradients
+    all-reduced over RCCL in per-block buckets overlapped with the backward pass.  Also times the same all-reduce alone
+    (bus bandwidth) and the step with communication disabled (exposed communication)."""
+    import torch
+
+    from mindaudio_amd.conformer.asr_model import create_asr_model
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    torch.manual_seed(777)  # same initial weights on every rank (examples/conformer/train.py:56)
+    model = create_asr_model(80, TRAIN_VOCAB, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12),
+                             ctc_weight=1.0).to(dev)
+    eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, world_size=world, rank=rank)
+    cols = synth_train_batch(rank, dev)
+
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = eng.step(*cols)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, out
+
+    first = [float(eng.step(*cols)[0]) for _ in range(max(warmup, 1))]
+    dt, out = timed(steps)
+    res = {"utterances_per_s": round(world * TRAIN_BATCH * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "global_batch": TRAIN_BATCH * world, "frames": TRAIN_FRAMES, "vocab": TRAIN_VOCAB,
+           "workload": "Conformer-small (12 blocks) pure-CTC training step: forward + backward + bucketed gradient "
+                       "all-reduce + Adam/ASRWarmupLR/dynamic loss scale, dropout 0.1, bf16 matmuls, float32 masters",
+           "first_loss": round(first[0], 3), "last_loss": round(float(out[0]), 3), "loss_scale": out[2],
+           "overflow_last_step": bool(out[3]), "grad_bytes": eng.fp.size * 4}
+    if world > 1:
+        # (i) the step without its collective: exposed communication = ms_per_step - ms_per_step_no_comm
+        eng.reducer.world = 1
+        dt0, _ = timed(max(3, steps // 2))
+        eng.reducer.world = world
+        res["ms_per_step_no_allreduce"] = round(dt0 / max(3, steps // 2) * 1e3, 3)
+        res["exposed_comm_ms"] = round(res["ms_per_step"] - res["ms_per_step_no_allreduce"], 3)
+        # (ii) the all-reduce alone, same buckets: bus bandwidth = 2 (N-1)/N x bytes / t  (ring-equivalent)
+        from mindaudio_amd.train.engine import bucket_spans
+
+        spans = bucket_spans(eng.fp, eng.L)
+        reps = 5
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            works = [dist.all_reduce(eng.fp.grad[lo:hi], async_op=True) for lo, hi in spans]
+            for w in works:
+                w.wait()
+        barrier()
+        ar = (time.perf_counter() - t0) / reps
+        nbytes = sum(hi - lo for lo, hi in spans) * 4
+        bus = 2.0 * (world - 1) / world * nbytes / ar / 1e9
+        res["allreduce"] = {"ms": round(ar * 1e3, 3), "bytes": nbytes, "buckets": len(spans),
+                            "bus_GBps": round(bus, 1), "xgmi_link_GBps": XGMI_LINK_GBS,
+                            "frac_of_one_link": round(bus / XGMI_LINK_GBS, 3)}
+    return res
 
 
 def main():
@@ -67,20 +235,50 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train", action="store_true", help="headline = the cfg-4 data-parallel training step")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the train_dp object")
+    ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=10)
     args = ap.parse_args()
+
+    # ---- N > 1: one process per GPU.  Either we already are a rank (WORLD_SIZE set by torch.distributed.run) or this
+    #      process becomes the launcher — decided here, before torch.cuda / any HIP call. ------------------------------
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node %d (or drop WORLD_SIZE and let "
+                     "bench.py start the ranks itself)" % (args.gpus, world, args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = os.environ.get("MA_BENCH_DRY") == "1"  # launcher check on a box without GPUs: gloo ranks, no kernels
+
+    # the CPU baselines use a process pool: run them before this process holds a HIP context
+    cpu = cpu_baseline() if world == 1 and not args.no_cpu_baseline and not dry else None
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.tensor([float(rank + 1)])
+            dist.all_reduce(t)
+            if rank == 0:
+                print(json.dumps({"dry": True, "n_gpus": world, "ranks_sum": float(t.item())}))
+            dist.destroy_process_group()
+            return
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif dry:
+        print(json.dumps({"dry": True, "n_gpus": 1}))
+        return
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -90,17 +288,6 @@ def main():
     from mindaudio_amd.models import ConformerEncoder
 
     lib = _lib.load()
-    torch.manual_seed(777)  # examples/conformer/train.py:56
-    enc = ConformerEncoder(80, 256, 4, 2048, 12).eval().to(dev).prepare()
-    x = torch.from_numpy(synth_batch(1234 + rank)).to(dev)
-    t2 = ((FRAMES - 3) // 2 + 1 - 3) // 2 + 1
-    masks = torch.ones(BATCH, 1, t2, device=dev)
-    kw = dict(n_mels=N_MELS, n_fft=N_FFT, hop_length=HOP)
-
-    def step():
-        feats = ma.fbank(x, **kw)                                   # (64, 80, 1001) dB
-        xs = feats.transpose(1, 2)[:, :FRAMES]                      # (64, 1000, 80) VIEW of the (64, 80, 1001) fbank output
-        return enc(xs, masks)[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -108,19 +295,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert tuple(out.shape) == (BATCH, t2, 256)
+    def max_over_ranks(dt):
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    t2 = ((FRAMES - 3) // 2 + 1 - 3) // 2 + 1
+    res = {}
+    if not args.train:
+        torch.manual_seed(777)  # examples/conformer/train.py:56
+        enc = ConformerEncoder(80, 256, 4, 2048, 12).eval().to(dev).prepare()
+        x = torch.from_numpy(synth_batch(1234 + rank)).to(dev)
+        masks = torch.ones(BATCH, 1, t2, device=dev)
+
+        def step():
+            feats = ma.fbank(x, **FBANK_KW)                             # (64, 80, 1001) dB
+            xs = feats.transpose(1, 2)[:, :FRAMES]                      # (64, 1000, 80) VIEW of the (64, 80, 1001) fbank output
+            return enc(xs, masks)[0]
+
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert tuple(out.shape) == (BATCH, t2, 256)
+
+        sustained = None
+        if not args.no_sustained:
+            # the same step over >= 2 s: the chip reaches its power limit within ~1 s (DVFS), the K-step figure above is a burst
+            n_sus = max(args.steps, int(2.2 / (dt / args.steps)) + 1)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n_sus):
+                out = step()
+            barrier()
+            ds = max_over_ranks(time.perf_counter() - t0)
+            sustained = {"value": round(world * BATCH * n_sus / ds, 1), "unit": "utterances/s", "steps": n_sus,
+                         "seconds": round(ds, 3), "ms_per_step": round(ds / n_sus * 1e3, 4)}
 
     def event_time(fn, reps):
         for _ in range(5):
@@ -140,7 +356,7 @@ def main():
     #      Algorithmic FLOPs per launch = 2 FFNs x 2 M (256*2048 + 2048*256) + 2 M 256*768, M = 64*249 rows. ---------------
     m, hid, nqkv = BATCH * t2, 2048, 768
     gen = torch.Generator(device=dev).manual_seed(99)
-    rnd = lambda *shape: torch.randn(*shape, device=dev, generator=gen)
+    rnd = lambda *shape: torch.randn(*shape, device=dev, generator=gen)  # noqa: E731
     wa1, wb1 = (rnd(hid, 256) / 16).bfloat16(), (rnd(hid, 256) / 16).bfloat16()
     wa2, wb2 = (rnd(256, hid) / 45).bfloat16(), (rnd(256, hid) / 45).bfloat16()
     wq, bq = (rnd(nqkv, 256) / 16).bfloat16(), rnd(nqkv)
@@ -153,23 +369,33 @@ def main():
     ffn_flops = 2 * (2.0 * m * 256 * hid * 2) + 2.0 * m * 256 * nqkv
     gemm_tf = ffn_flops / gemm_s / 1e12
 
-    # ---- roofline of the fbank kernel (HBM bound): algorithmic bytes = waves in + features out ------------
+    # ---- roofline of the fbank kernel (HBM bound): algorithmic bytes = waves in + features out, at the headline batch (64)
+    #      and at 512 utterances (where the launch's fixed cost is amortised) ----------------------------------------------
     n_frames = 1 + SAMPLES // HOP
     win = _host.device_window("hann", N_FFT, N_FFT, dev)
     bank = _host.device_htk_bank(N_FFT, 0.0, float(SR // 2), N_MELS, SR, dev)
-    ws = _host.workspace(lib.ma_fbank_workspace_bytes(BATCH, n_frames), dev)
-    fo = torch.empty((BATCH, N_MELS, n_frames), device=dev)
     stream = _host.current_stream_ptr()
 
-    def fbank_main_kernel():
-        rc = lib.ma_fbank_db_f32(_host.ptr(x), BATCH, SAMPLES, x.stride(0), N_FFT, HOP, _host.ptr(win), 1, 1,
-                                 bank.ref(), 2.0, 10.0, 1e-10, 0.0, -1.0, _host.ptr(fo), _host.ptr(ws), ws.numel(),
-                                 stream)
-        assert rc == 0
+    def fbank_roofline(nb):
+        xb = torch.from_numpy(synth_batch(4321 + rank)).to(dev).repeat(nb // BATCH, 1) if nb != BATCH else \
+            torch.from_numpy(synth_batch(1234 + rank)).to(dev)
+        ws = torch.empty(lib.ma_fbank_workspace_bytes(nb, n_frames), dtype=torch.uint8, device=dev)
+        fo = torch.empty((nb, N_MELS, n_frames), device=dev)
 
-    fb_s = event_time(fbank_main_kernel, max(args.steps, 50))
-    fb_bytes = BATCH * SAMPLES * 4 + BATCH * N_MELS * n_frames * 4  # 61 460 480 B
+        def launch():
+            rc = lib.ma_fbank_db_f32(_host.ptr(xb), nb, SAMPLES, xb.stride(0), N_FFT, HOP, _host.ptr(win), 1, 1,
+                                     bank.ref(), 2.0, 10.0, 1e-10, 0.0, -1.0, _host.ptr(fo), _host.ptr(ws), ws.numel(),
+                                     stream)
+            assert rc == 0
+
+        s = event_time(launch, max(args.steps, 50) if nb == BATCH else 20)
+        nbytes = nb * SAMPLES * 4 + nb * N_MELS * n_frames * 4  # 61 460 480 B at 64 utterances
+        return s, nbytes
+
+    fb_s, fb_bytes = fbank_roofline(BATCH)
     fb_gbs = fb_bytes / fb_s / 1e9
+    fb512_s, fb512_bytes = fbank_roofline(512)
+    fb512_gbs = fb512_bytes / fb512_s / 1e9
 
     def pmc_traffic(kernel):
         """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 cannot run inside the bench)."""
@@ -179,40 +405,64 @@ def main():
         except (OSError, KeyError, ValueError):
             return None
 
+    train = None
+    if args.train or not args.no_train_leg:
+        train = train_leg(rank, world, dev, dist, args.steps if args.train else args.train_steps,
+                          args.warmup if args.train else 2, barrier)
+
     if rank == 0:
         flops_utt = 23.12e9
-        res = {
-            "metric": "utterances/s (16 kHz×10 s) fbanks+Conformer fwd, 1/2/4/8 MI355X",
-            "value": round(world * BATCH * args.steps / dt, 1),
-            "unit": "utterances/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic",
-            "config": {"workload": "features.fbank (n_fft=512 hop=160 n_mels=80, batch-global top_db) on 64 x (10 s "
-                                   "@16 kHz) synthetic waves per GPU -> Conformer-small encoder forward (12 blocks, "
-                                   "d=256, 4 heads, ff=2048, conv k=15, eval mode) on the (64, 1000, 80) features; "
-                                   "random-init weights",
-                       "global_batch": BATCH * world, "frames": FRAMES,
-                       "sharding": "independent utterance shards per rank, no collective",
-                       "encoder_tflops": round(world * BATCH * args.steps * flops_utt / dt / 1e12, 1)},
-            "roofline": {"bound": "mfma", "kernel": "ffn_packed_kernel, pair + qkv form (2 x [w_1 -> Swish -> w_2 + residual] + 4 LayerNorms + linear_q/k/v, "
-                                                    "M=%d d=256 hidden=%d)" % (m, hid),
-                         "achieved": round(gemm_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(gemm_tf / MFMA_BF16_PEAK_TF, 4), "traffic": pmc_traffic("ffn_packed_kernel"),
-                         "algorithmic_flops_per_launch": int(ffn_flops), "kernel_ms": round(gemm_s * 1e3, 5)},
-            "roofline_fbank": {"bound": "hbm", "kernel": "feat512_kernel<mel>", "achieved": round(fb_gbs, 1),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fb_gbs / HBM_PEAK_GBS, 4),
-                               "traffic": pmc_traffic("feat512_kernel"), "algorithmic_bytes_per_launch": fb_bytes,
-                               "kernel_ms": round(fb_s * 1e3, 5)},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline()
+        if args.train:
+            res = {
+                "metric": "utterances/s, Conformer-small CTC training step (fwd + bwd + RCCL all-reduce + Adam), 1/2/4/8 MI355X",
+                "value": train["utterances_per_s"], "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": train["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": train["workload"], "global_batch": TRAIN_BATCH * world, "frames": TRAIN_FRAMES,
+                           "sharding": "data parallel by utterance, bucketed all-reduce (SUM) of the flat float32 gradient"},
+            }
+        else:
+            res = {
+                "metric": "utterances/s (16 kHz×10 s) fbanks+Conformer fwd, 1/2/4/8 MI355X",
+                "value": round(world * BATCH * args.steps / dt, 1),
+                "unit": "utterances/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "bf16",
+                "data": "synthetic",
+                "config": {"workload": "features.fbank (n_fft=512 hop=160 n_mels=80, batch-global top_db) on 64 x (10 s "
+                                       "@16 kHz) synthetic waves per GPU -> Conformer-small encoder forward (12 blocks, "
+                                       "d=256, 4 heads, ff=2048, conv k=15, eval mode) on the (64, 1000, 80) features; "
+                                       "random-init weights",
+                           "global_batch": BATCH * world, "frames": FRAMES,
+                           "sharding": "independent utterance shards per rank, no collective",
+                           "encoder_tflops": round(world * BATCH * args.steps * flops_utt / dt / 1e12, 1)},
+            }
+            if sustained is not None:
+                res["sustained"] = sustained
+        res["roofline"] = {"bound": "mfma", "kernel": "ffn_packed_kernel, pair + qkv form (2 x [w_1 -> Swish -> w_2 + residual] + 4 LayerNorms + linear_q/k/v, "
+                                                      "M=%d d=256 hidden=%d)" % (m, hid),
+                           "achieved": round(gemm_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": round(gemm_tf / MFMA_BF16_PEAK_TF, 4), "traffic": pmc_traffic("ffn_packed_kernel"),
+                           "algorithmic_flops_per_launch": int(ffn_flops), "kernel_ms": round(gemm_s * 1e3, 5)}
+        res["roofline_fbank"] = {"bound": "hbm", "kernel": "feat512_kernel<mel>", "achieved": round(fb_gbs, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fb_gbs / HBM_PEAK_GBS, 4),
+                                 "traffic": pmc_traffic("feat512_kernel"), "algorithmic_bytes_per_launch": fb_bytes,
+                                 "kernel_ms": round(fb_s * 1e3, 5),
+                                 "batch512": {"achieved": round(fb512_gbs, 1), "frac": round(fb512_gbs / HBM_PEAK_GBS, 4),
+                                              "algorithmic_bytes_per_launch": fb512_bytes,
+                                              "kernel_ms": round(fb512_s * 1e3, 5)}}
+        if train is not None and not args.train:
+            res["train_dp"] = train
+        elif train is not None:
+            res["train_dp"] = {k: v for k, v in train.items() if k not in ("utterances_per_s", "ms_per_step", "workload")}
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

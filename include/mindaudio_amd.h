@@ -183,15 +183,6 @@ typedef struct ma_gemm_epilogue {
 int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* out, int64_t ldo,
                  int64_t M, int64_t N, int64_t K, const ma_gemm_epilogue_t* epi, ma_stream_t stream);
 
-/* PositionwiseFeedForward + residual in ONE kernel (layers/positionwise_feed_forward.py:33-46 with Swish,
- * models/conformer.py:109-112 / 147-151):   x[m, :] += alpha * (swish(a[m, :] . W1^T + b1) . W2^T + b2)
- *   a (M, d_model) bf16 = LayerNorm(x); W1 (hidden, d_model), W2 (d_model, hidden) bf16 as stored by the
- *   reference Dense cells; b1 (hidden), b2 (d_model) float32; x (M, d_model) float32 updated in place.
- * The (M, hidden) activation never reaches HBM.  d_model == 256, hidden % 256 == 0 (<= 4096), 16-byte aligned pointers. */
-int ma_ffn_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2,
-                float* x, int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha,
-                ma_stream_t stream);
-
 /* 3x3, stride 2, valid Conv2d (layers/subsampling.py:43) as an implicit GEMM.
  *   act device bf16 NHWC (batch, H, Wd, C), C % 64 == 0;  W device bf16 (Cout, 3, 3, C) i.e. k = (kh, kw, c);
  *   out (batch, Ho, Wo, Cout), Ho = (H-3)/2+1, Wo = (Wd-3)/2+1, dtype per epilogue. */
@@ -530,16 +521,6 @@ int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t ro
                                      const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
                                      float* stats, ma_stream_t stream);
 
-/* ma_ffn_bf16 with the LayerNorm(s) that follow the module fused into its epilogue (the workgroup owns whole rows):
- *   ln_mode 1: x += alpha * FFN(a);  ln_out = LN(x; gamma1, beta1)                       (macaron FFN -> norm_mha)
- *   ln_mode 2: x <- LN(x + alpha * FFN(a); gamma1, beta1);  ln_out = LN(x; gamma2, beta2)
- *              (FFN -> norm_final -> the next block's norm_ff_macaron / after_norm, models/conformer.py:147-156, 253)
- * ln_out (M, 256) bf16 or float32 with row stride ld_ln. */
-int ma_ffn_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
-                   int64_t ldx, int64_t M, int32_t d_model, int32_t hidden, float alpha, int32_t ln_mode,
-                   const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
-                   void* ln_out, int64_t ld_ln, int32_t ln_out_bf16, ma_stream_t stream);
-
 /* ma_conv2d_3x3s2_nhwc_bf16 for the subsampling layer's second convolution (C = Cout = 256; layers/subsampling.py:40-45) on a
  * fragment-ordered packed copy of W (conv2_packed.hip): out (batch, Ho, Wo, 256) bf16 = [relu](bias + conv).
  *   ma_conv2d_3x3s2_packed_bytes(C, Cout) -> bytes of the packed buffer (negative: unsupported shape);
@@ -597,14 +578,20 @@ int ma_gemm_k256_packed_ln_bf16(const void* A, int64_t lda, const void* packed, 
                                 int64_t K, const ma_gemm_epilogue_t* epi, const float* ln_gamma, const float* ln_beta,
                                 float ln_eps, const float* ln_row_scale, void* ln_out, int64_t ld_ln, ma_stream_t stream);
 
-/* Fused feed-forward, "hidden-slice owner" form (ffn_packed.hip): same contract as ma_ffn_bf16 / ma_ffn_ln_bf16
- * (mindaudio/models/layers/positionwise_feed_forward.py:33-46 + the residual and LayerNorms of models/conformer.py:109-112,
- * 147-156), but W1 / W2 are taken in the fragment-ordered packed form that lets them stream L2 -> registers without an LDS
- * stage.  Pack once per weight update:
+/* PositionwiseFeedForward + residual (+ the LayerNorms around it) in ONE kernel, "hidden-slice owner" form (ffn_packed.hip;
+ * layers/positionwise_feed_forward.py:33-46 with Swish, models/conformer.py:109-112 / 147-156):
+ *     x[m, :] += alpha * (swish(a[m, :] . W1^T + b1) . W2^T + b2)
+ *   a (M, 256) bf16 = LayerNorm(x) (or computed by the kernel, see gamma0); b1 (hidden), b2 (256) float32; x (M, 256) float32
+ *   updated in place; the (M, hidden) activation never reaches HBM.  W1 / W2 are taken in a fragment-ordered packed form that
+ *   lets them stream L2 -> registers without an LDS stage.  Pack once per weight update:
  *   ma_ffn_packed_bytes(d_model, hidden) -> bytes of the packed buffer (negative: unsupported shape; d_model = 256,
  *                                           hidden % 256 == 0);
  *   ma_ffn_pack_weights_bf16(w1 (hidden, d_model) bf16, w2 (d_model, hidden) bf16, ..., packed).
- * ma_ffn_packed_bf16: ln_mode 0 = no LayerNorm (gamma/beta/ln_out ignored), 1 / 2 as ma_ffn_ln_bf16.  gamma0 / beta0 non-NULL:
+ * ma_ffn_packed_bf16: ln_mode 0 = no LayerNorm (gamma/beta/ln_out ignored);
+ *   ln_mode 1: x += alpha * FFN(a);  ln_out = LN(x; gamma1, beta1)                       (macaron FFN -> norm_mha)
+ *   ln_mode 2: x <- LN(x + alpha * FFN(a); gamma1, beta1);  ln_out = LN(x; gamma2, beta2)
+ *              (FFN -> norm_final -> the next block's norm_ff_macaron / after_norm, models/conformer.py:147-156, 253)
+ *   ln_out (M, 256) bf16 or float32 with row stride ld_ln.  gamma0 / beta0 non-NULL:
  * the input is a = LayerNorm(x; gamma0, beta0, eps) computed while the tile is staged (models/conformer.py:147-148) and the `a`
  * operand is ignored (may be NULL). */
 int64_t ma_ffn_packed_bytes(int32_t d_model, int32_t hidden);
@@ -647,22 +634,6 @@ int ma_ffn_packed_pair_qkv_bf16(const void* packed_a, const float* b1_a, const f
                                 const float* beta1, const float* gamma2, const float* beta2, const float* gamma3,
                                 const float* beta3, float eps, const void* qkv_packed, const float* qkv_bias, int64_t qkv_n,
                                 void* qkv_out, int64_t ld_qkv, ma_stream_t stream);
-
-/* Fused feed-forward, 128-row formulation: grid (ceil(M/128), 2) — the workgroup of hidden half 0 updates x in place
- * (x += alpha * (O_0 + b2)), half 1 writes partial (M, 256) float32 = alpha * O_1; the LayerNorm that follows the module
- * adds it back:
- *   ma_layernorm_add_f32   x <- x + addend (written back: the new residual stream), out = LayerNorm(x)
- *   ma_layernorm2_add_f32  out1 = LN1(x + addend) (float32, may overwrite x), out2 = LN2(out1)
- * hidden % 128 == 0.  Other arguments as ma_ffn_bf16 / ma_layernorm_f32 / ma_layernorm2_f32. */
-int ma_ffn128_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
-                   int64_t ldx, float* partial, int64_t ldp, int64_t M, int32_t d_model, int32_t hidden, float alpha,
-                   ma_stream_t stream);
-int ma_layernorm_add_f32(float* x, int64_t ldx, const float* addend, int64_t ld_add, int64_t rows, int64_t cols,
-                         const float* gamma, const float* beta, float eps, const float* row_scale, void* out, int64_t ldo,
-                         int32_t out_bf16, ma_stream_t stream);
-int ma_layernorm2_add_f32(const float* x, int64_t ldx, const float* addend, int64_t ld_add, int64_t rows, int64_t cols,
-                          const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
-                          float* out1, int64_t ldo1, void* out2, int64_t ldo2, int32_t out2_bf16, ma_stream_t stream);
 
 /* TrainOneStepWithLossScaleCell pieces (train_one_step.py:37-47): *flag |= 1 if any gradient is inf/nan; Adam
  * (MindSpore nn.Adam: p -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t) from the host) on

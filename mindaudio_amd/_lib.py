@@ -81,8 +81,6 @@ PROTOTYPES = {
                                           ctypes.c_void_p]),
     "ma_gemm_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p, i64, i64, i64, i64,
                                     ctypes.POINTER(GemmEpilogue), ctypes.c_void_p]),
-    "ma_ffn_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                   ctypes.c_void_p, ctypes.c_void_p, i64, i64, i32, i32, f32, ctypes.c_void_p]),
     "ma_conv2d_3x3s2_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i64, ctypes.c_void_p, i64,
                                                  ctypes.c_void_p, ctypes.POINTER(GemmEpilogue), ctypes.c_void_p]),
     "ma_layernorm_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, ctypes.c_void_p, ctypes.c_void_p, f32,
@@ -158,8 +156,6 @@ PROTOTYPES = {
     "ma_mha_small_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32,
                                              vp, i64, vp, i64, vp, i64, vp]),
     "ma_label_smoothing_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, i64, vp, vp]),
-    "ma_ffn_ln_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, i32, vp, vp, vp, vp, f32, vp, i64,
-                                      i32, vp]),
     "ma_resample_fft_length": (i64, [i64, i64]),
     "ma_resample_fft_workspace_bytes": (i64, [i64, i64, i64]),
     "ma_resample_fft_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, i64, vp, i64, vp]),
@@ -189,9 +185,6 @@ PROTOTYPES = {
                                               i64, vp]),
     "ma_ffn_packed_pair_qkv_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp,
                                                    vp, f32, vp, vp, i64, vp, i64, vp]),
-    "ma_ffn128_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i64, i32, i32, f32, vp]),
-    "ma_layernorm_add_f32": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, f32, vp, vp, i64, i32, vp]),
-    "ma_layernorm2_add_f32": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, f32, vp, i64, vp, i64, i32, vp]),
     "ma_grad_overflow_f32": (ctypes.c_int, [vp, i64, vp, vp]),
     "ma_adam_f32": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
     "ma_db_workspace_bytes": (i64, [i64, i64]),

@@ -19,6 +19,7 @@ class CTC(nn.Module):
         super().__init__()
         self.ctc_lo = nn.Linear(encoder_output_size, odim)
         self._w = None
+        self.register_load_state_dict_post_hook(lambda module, _keys: setattr(module, "_w", None))  # stale bf16 copy
 
     @torch.no_grad()
     def prepare(self):

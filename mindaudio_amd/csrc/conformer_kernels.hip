@@ -655,13 +655,6 @@ int ma_layernorm_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, co
   return layernorm_launch(x, ldx, rows, cols, gamma, beta, eps, row_scale, out, ldo, out_bf16, nullptr, 0, nullptr, 0, stream);
 }
 
-int ma_layernorm_add_f32(float* x, int64_t ldx, const float* addend, int64_t ld_add, int64_t rows, int64_t cols,
-                         const float* gamma, const float* beta, float eps, const float* row_scale, void* out, int64_t ldo,
-                         int32_t out_bf16, ma_stream_t stream) {
-  if (!addend) return MA_ERR_INVALID_ARG;
-  return layernorm_launch(x, ldx, rows, cols, gamma, beta, eps, row_scale, out, ldo, out_bf16, addend, ld_add, x, ldx, stream);
-}
-
 static int layernorm2_launch(const float* x, int64_t ldx, int64_t rows, int64_t cols, const float* gamma1, const float* beta1,
                              const float* gamma2, const float* beta2, float eps, float* out1, int64_t ldo1, void* out2,
                              int64_t ldo2, int32_t out2_bf16, const float* addend, int64_t ld_add, ma_stream_t stream) {
@@ -679,14 +672,6 @@ int ma_layernorm2_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, c
                       int64_t ldo2, int32_t out2_bf16, ma_stream_t stream) {
   return layernorm2_launch(x, ldx, rows, cols, gamma1, beta1, gamma2, beta2, eps, out1, ldo1, out2, ldo2, out2_bf16, nullptr,
                            0, stream);
-}
-
-int ma_layernorm2_add_f32(const float* x, int64_t ldx, const float* addend, int64_t ld_add, int64_t rows, int64_t cols,
-                          const float* gamma1, const float* beta1, const float* gamma2, const float* beta2, float eps,
-                          float* out1, int64_t ldo1, void* out2, int64_t ldo2, int32_t out2_bf16, ma_stream_t stream) {
-  if (!addend) return MA_ERR_INVALID_ARG;
-  return layernorm2_launch(x, ldx, rows, cols, gamma1, beta1, gamma2, beta2, eps, out1, ldo1, out2, ldo2, out2_bf16, addend,
-                           ld_add, stream);
 }
 
 static int subsample_conv1_launch(const float* x, int64_t sb, int64_t st, int64_t sf, int64_t batch, int64_t T, int32_t idim,

@@ -200,10 +200,6 @@ def spectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0, w
     return mag.cpu().numpy() if was_numpy else mag
 
 
-def spectrogram_unsupported(*a, **k):  # kept for callers of the round-1 name
-    return spectrogram(*a, **k)
-
-
 def magphase(waveform, power, iscomplex=True):
     """spectrum.magphase (spectrum.py:701-735) for complex input: (|D| ** power, D / |D|), phase 1+0j where D == 0."""
     if not iscomplex:

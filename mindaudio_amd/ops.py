@@ -124,38 +124,6 @@ def gemm_packed_ln(a, packed, ln_gamma, ln_beta, ln_row_scale=None, eps=1e-5, bi
     return out, ln_out
 
 
-def ffn(a, w1, b1, w2, b2, x, alpha=0.5):
-    """In place x += alpha * (swish(a @ w1^T + b1) @ w2^T + b2); a (M, 256) bf16, x (M, 256) float32."""
-    t = _host.torch()
-    lib = _lib.load()
-    assert a.dtype == t.bfloat16 and w1.dtype == t.bfloat16 and w2.dtype == t.bfloat16 and x.dtype == t.float32
-    assert a.stride(1) == 1 and x.stride(1) == 1 and w1.is_contiguous() and w2.is_contiguous()
-    m, d = a.shape
-    hidden = w1.shape[0]
-    assert tuple(w1.shape) == (hidden, d) and tuple(w2.shape) == (d, hidden) and tuple(x.shape) == (m, d)
-    rc = lib.ma_ffn_bf16(_host.ptr(a), a.stride(0), _host.ptr(w1), _host.ptr(b1), _host.ptr(w2), _host.ptr(b2),
-                         _host.ptr(x), x.stride(0), m, d, hidden, float(alpha), _host.current_stream_ptr())
-    _lib.check(rc, "ffn_bf16")
-    return x
-
-
-def ffn_ln(a, w1, b1, w2, b2, x, g1, be1, g2=None, be2=None, alpha=0.5, eps=1e-5, out_dtype=None):
-    """Fused FFN + the LayerNorm(s) behind it.  g2 None: x += alpha*FFN(a) in place, returns LN(x; g1, be1).
-    With g2: x <- LN(x + alpha*FFN(a); g1, be1) in place, returns LN(x; g2, be2).  Output bf16 (default) or float32."""
-    t = _host.torch()
-    lib = _lib.load()
-    assert a.dtype == t.bfloat16 and x.dtype == t.float32 and a.stride(1) == 1 and x.stride(1) == 1
-    m, d = a.shape
-    out_dtype = out_dtype or t.bfloat16
-    out = t.empty((m, d), dtype=out_dtype, device=a.device)
-    rc = lib.ma_ffn_ln_bf16(_host.ptr(a), a.stride(0), _host.ptr(w1), _host.ptr(b1), _host.ptr(w2), _host.ptr(b2),
-                            _host.ptr(x), x.stride(0), m, d, w1.shape[0], float(alpha), 2 if g2 is not None else 1,
-                            _host.ptr(g1), _host.ptr(be1), _opt(g2), _opt(be2), float(eps), _host.ptr(out), out.stride(0),
-                            1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
-    _lib.check(rc, "ffn_ln_bf16")
-    return out
-
-
 def ffn_pack_weights(w1, w2):
     """Fragment-ordered packed copy of (w1 (hidden, 256), w2 (256, hidden)) bf16 for ffn_packed; redo after a weight update."""
     t = _host.torch()
@@ -259,20 +227,6 @@ def ffn_packed_pair(packed_a, b1_a, b2_a, packed_b, b1_b, b2_b, x, ln_in, ln_mid
     return out
 
 
-def ffn128(a, w1, b1, w2, b2, x, partial, alpha=0.5):
-    """128-row formulation: x += alpha * (half-0 product + b2) in place, partial (M, 256) f32 = alpha * half-1 product;
-    the caller's next LayerNorm adds `partial` back (layernorm(..., addend=partial) / layernorm2(..., addend=partial))."""
-    t = _host.torch()
-    lib = _lib.load()
-    assert a.dtype == t.bfloat16 and x.dtype == t.float32 and partial.dtype == t.float32
-    m, d = a.shape
-    rc = lib.ma_ffn128_bf16(_host.ptr(a), a.stride(0), _host.ptr(w1), _host.ptr(b1), _host.ptr(w2), _host.ptr(b2),
-                            _host.ptr(x), x.stride(0), _host.ptr(partial), partial.stride(0), m, d, w1.shape[0],
-                            float(alpha), _host.current_stream_ptr())
-    _lib.check(rc, "ffn128_bf16")
-    return x
-
-
 def conv2d_3x3s2_nhwc(act, w, bias=None, relu=True, out_dtype=None):
     """act (B, H, W, C) bf16 NHWC, w (Cout, 3, 3, C) bf16 -> (B, Ho, Wo, Cout)."""
     t = _host.torch()
@@ -294,44 +248,31 @@ def _opt(x):
     return _host.ptr(x) if x is not None else None
 
 
-def layernorm(x, gamma, beta, eps=1e-5, row_scale=None, out_dtype=None, out=None, addend=None):
-    """x (rows, D) float32 -> LayerNorm(x) [* row_scale[:, None]] as bf16 (default) or float32.
-    With `addend` (rows, D) float32: x <- x + addend in place first (the split feed-forward kernel's partial product)."""
+def layernorm(x, gamma, beta, eps=1e-5, row_scale=None, out_dtype=None, out=None):
+    """x (rows, D) float32 -> LayerNorm(x) [* row_scale[:, None]] as bf16 (default) or float32."""
     t = _host.torch()
     lib = _lib.load()
     assert x.dtype == t.float32 and x.dim() == 2 and x.stride(1) == 1
     out_dtype = out_dtype or t.bfloat16
     if out is None:
         out = t.empty(x.shape, dtype=out_dtype, device=x.device)
-    if addend is None:
-        rc = lib.ma_layernorm_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(gamma), _host.ptr(beta),
-                                  float(eps), _opt(row_scale), _host.ptr(out), out.stride(0),
-                                  1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
-    else:
-        rc = lib.ma_layernorm_add_f32(_host.ptr(x), x.stride(0), _host.ptr(addend), addend.stride(0), x.shape[0],
-                                      x.shape[1], _host.ptr(gamma), _host.ptr(beta), float(eps), _opt(row_scale),
-                                      _host.ptr(out), out.stride(0), 1 if out_dtype == t.bfloat16 else 0,
-                                      _host.current_stream_ptr())
+    rc = lib.ma_layernorm_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(gamma), _host.ptr(beta),
+                              float(eps), _opt(row_scale), _host.ptr(out), out.stride(0),
+                              1 if out_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
     _lib.check(rc, "layernorm")
     return out
 
 
-def layernorm2(x, g1, b1, g2, b2, eps=1e-5, out2_dtype=None, addend=None):
-    """In place x <- LN(x [+ addend]; g1, b1) (float32) and returns LN(x_new; g2, b2) as bf16 (default) or float32."""
+def layernorm2(x, g1, b1, g2, b2, eps=1e-5, out2_dtype=None):
+    """In place x <- LN(x; g1, b1) (float32) and returns LN(x_new; g2, b2) as bf16 (default) or float32."""
     t = _host.torch()
     lib = _lib.load()
     assert x.dtype == t.float32 and x.dim() == 2 and x.stride(1) == 1
     out2_dtype = out2_dtype or t.bfloat16
     out2 = t.empty(x.shape, dtype=out2_dtype, device=x.device)
-    if addend is None:
-        rc = lib.ma_layernorm2_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(g1), _host.ptr(b1),
-                                   _host.ptr(g2), _host.ptr(b2), float(eps), _host.ptr(x), x.stride(0), _host.ptr(out2),
-                                   out2.stride(0), 1 if out2_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
-    else:
-        rc = lib.ma_layernorm2_add_f32(_host.ptr(x), x.stride(0), _host.ptr(addend), addend.stride(0), x.shape[0],
-                                       x.shape[1], _host.ptr(g1), _host.ptr(b1), _host.ptr(g2), _host.ptr(b2), float(eps),
-                                       _host.ptr(x), x.stride(0), _host.ptr(out2), out2.stride(0),
-                                       1 if out2_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
+    rc = lib.ma_layernorm2_f32(_host.ptr(x), x.stride(0), x.shape[0], x.shape[1], _host.ptr(g1), _host.ptr(b1),
+                               _host.ptr(g2), _host.ptr(b2), float(eps), _host.ptr(x), x.stride(0), _host.ptr(out2),
+                               out2.stride(0), 1 if out2_dtype == t.bfloat16 else 0, _host.current_stream_ptr())
     _lib.check(rc, "layernorm2")
     return out2
 

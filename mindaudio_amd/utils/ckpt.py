@@ -187,7 +187,6 @@ def load_mindspore_checkpoint(module, path, strict=True):
     missing = [k for k in own if k not in state and not k.endswith("num_batches_tracked")]
     if strict and (missing or unexpected):
         raise KeyError("checkpoint does not match the module: missing %s, unexpected %s" % (missing[:8], unexpected[:8]))
+    # (ConformerEncoder / CTC drop their bf16 / packed weight copies in load_state_dict post-hooks)
     module.load_state_dict(state, strict=False)
-    if hasattr(module, "encoder") and hasattr(module.encoder, "_prepared"):
-        module.encoder._prepared = None  # bf16 / packed copies are rebuilt on the next forward
     return missing, unexpected

@@ -96,3 +96,35 @@ def test_import_into_asr_model(tmp_path):
     K.write_mindspore_ckpt(path, bad)
     with pytest.raises(ValueError):
         K.load_mindspore_checkpoint(dst, path)
+
+
+def test_strict_import_with_global_cmvn_and_stale_caches(tmp_path):
+    """The shipped conformer.yaml sets cmvn_file: GlobalCMVN's mean/istd are constructor data in the reference (layers/cmvn.py),
+    never in a .ckpt, so a strict load must not ask for them; and a load drops every bf16 / packed weight copy made earlier."""
+    import torch
+
+    from mindaudio_amd.conformer.asr_model import create_asr_model
+
+    conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=1)
+    cmvn = (np.linspace(-1, 1, 80), np.linspace(0.5, 2, 80))
+    torch.manual_seed(3)
+    src = create_asr_model(80, 50, conf, cmvn)
+    assert not [k for k in src.state_dict() if "cmvn" in k]
+    path = str(tmp_path / "cmvn.ckpt")
+    K.write_mindspore_ckpt(path, _to_reference_names(src.state_dict()))
+    torch.manual_seed(4)
+    dst = create_asr_model(80, 50, conf, cmvn)
+    dst.encoder._prepared = {"stale": True}
+    dst.ctc._w = ("stale",)
+    missing, unexpected = K.load_mindspore_checkpoint(dst, path)  # strict
+    assert not missing and not unexpected
+    assert dst.encoder._prepared is None and dst.ctc._w is None
+    assert torch.equal(dst.encoder.cmvn_istd, torch.as_tensor(cmvn[1], dtype=torch.float32))
+    for k, v in src.state_dict().items():
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(v, dst.state_dict()[k]), k
+    # torch's own load_state_dict drops them too
+    dst.encoder._prepared = {"stale": True}
+    dst.ctc._w = ("stale",)
+    dst.load_state_dict(src.state_dict())
+    assert dst.encoder._prepared is None and dst.ctc._w is None

@@ -46,17 +46,18 @@ def _pair(num_blocks, seed=0, cmvn=False):
 # case has 4482 rows (70 row tiles, ragged lengths)
 @pytest.mark.parametrize("general", [False, True])
 @pytest.mark.parametrize("blocks,b,tlen,cmvn", [(1, 2, 131, False), (2, 3, 203, True), (2, 18, 1000, True)])
-def test_encoder_matches_oracle(blocks, b, tlen, cmvn, general, monkeypatch):
-    # general = True: the un-fused launches on the general kernels (what MA_FUSE_MIN_ROWS selects below a row count)
-    if general:
-        if b > 3:
-            pytest.skip("one size is enough for the general path")
-        monkeypatch.setenv("MA_FUSE_MIN_ROWS", "1000000")
+def test_encoder_matches_oracle(blocks, b, tlen, cmvn, general):
+    # general = True: the un-fused launches on the general kernels (what `fuse_min_rows` selects below a row count)
+    if general and b > 3:
+        pytest.skip("one size is enough for the general path")
     import torch
 
     from oracle import conformer_oracle as C
 
     ref, dut = _pair(blocks, seed=blocks, cmvn=cmvn)
+    assert dut._prepared["fused"]
+    if general:
+        dut.fuse_min_rows = 1000000
     g = torch.Generator().manual_seed(5)
     xs = torch.randn(b, tlen, 80, generator=g)
     lens = ([tlen, tlen - 40, tlen // 2] + [tlen - 7 * i for i in range(3, b)])[:b]

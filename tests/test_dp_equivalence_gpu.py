@@ -1,0 +1,63 @@
+"""Data-parallel equivalence of the HIP training step on the one GPU of the box: two FRESH child processes share GPU 0 and
+all-reduce their flat gradients over gloo on device tensors; after one step they must hold what a single process holds after the
+same step on the whole batch (examples/conformer/dataset.py:552-553 shards batch[rank::world]; train_one_step.py:38 reduces the
+gradients; BatchNorm statistics stay per rank).  The 8-GPU RCCL run of the driver goes through the same BucketedAllReduce."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_world(world, tmp_path):
+    port = _free_port()
+    outs = [str(tmp_path / ("w%d_r%d.pt" % (world, r))) for r in range(world)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), str(port), outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    for p in procs:
+        log, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, log[-3000:]
+    import torch
+
+    return [torch.load(o) for o in outs]
+
+
+def test_two_ranks_equal_one_rank_on_the_whole_batch(tmp_path):
+    (one,) = _run_world(1, tmp_path)
+    r0, r1 = _run_world(2, tmp_path)
+    # the reduced gradient is the same tensor on both ranks, and the two ranks saw different losses (different labels)
+    assert (r0["grad"] == r1["grad"]).all() and r0["loss"] != r1["loss"]
+    assert not one["overflow"] and not r0["overflow"] and not r1["overflow"]
+    # loss: mean over the whole batch = mean of the ranks' means (equal shard sizes)
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - one["loss"]) <= 1e-4 * abs(one["loss"])
+    # all-reduce(SUM) of per-rank means = world x the whole-batch mean gradient (same loss scale); 1/world is folded into Adam
+    g2, g1 = r0["grad"].double(), one["grad"].double() * 2.0
+    assert float((g2 - g1).norm() / g1.norm()) <= 2e-3
+    # ... so the applied update is the single-process update (bf16 round-off flips the sign of a few near-zero Adam ratios)
+    d2, d1 = r0["delta"].double(), one["delta"].double()
+    assert float(d1.abs().max()) > 0 and float((d2 - d1).norm() / d1.norm()) <= 5e-2
+    assert (r0["delta"] == r1["delta"]).all()  # replicas stay in lock-step
+    # BatchNorm running statistics are per rank (no SyncBN in the reference): equal here because the shards' inputs are equal
+    for a, b, c in zip(r0["bn_mean"], r1["bn_mean"], one["bn_mean"]):
+        assert (a == b).all() and float((a - c).abs().max()) <= 1e-3 * float(c.abs().max() + 1e-6)
+    # buckets: every element exactly once, launched in backward order (last block first, then head, then front end)
+    order = r0["order"]
+    pos = 0
+    for lo, hi in sorted(order):
+        assert lo == pos
+        pos = hi
+    assert pos == r0["size"]
+    block_los = [lo for lo, _ in order[:2]]
+    assert block_los == sorted(block_los, reverse=True) and order[-1][0] == 0

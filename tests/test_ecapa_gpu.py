@@ -71,3 +71,26 @@ def test_ecapa_conv_taps_and_epilogue_against_torch():
     want = torch.tanh(torch.relu(torch.nn.functional.conv1d(x.bfloat16().float(), wq, conv.bias, dilation=d, padding=d))
                       * scale[None, :, None] + shift[None, :, None])
     assert float((got - want).abs().max()) < 1.5e-2
+
+
+@pytest.mark.parametrize("c", [512, 1024])
+def test_ecapa_cfg5_full_shape(c):
+    """BASELINE cfg 5 at its stated shape — (256, 300, 80) — for the class default C = 512 (ecapatdnn.py:333) and the
+    example's C = 1024 (examples/ECAPA-TDNN/train_speaker_embeddings.py:468-472): the oracle on a sub-batch (eval-mode
+    BatchNorm: every utterance is independent of its batch), and batch-size independence / finiteness on the full batch."""
+    ref, dut = build(c=c, seed=4)
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(256, 300, 80, generator=g)
+    got = dut(x.cuda()).cpu()
+    assert got.shape == (256, 192) and bool(torch.isfinite(got).all())
+    idx = [0, 1, 127, 255]
+    with torch.no_grad():
+        want = ref(x[idx])
+    rel = float((got[idx] - want).norm() / want.norm())
+    cos = torch.nn.functional.cosine_similarity(got[idx], want, dim=1)
+    assert rel < 3e-2 and float(cos.min()) > 0.999, (rel, float(cos.min()))
+    # an utterance's embedding does not depend on what else is in the batch (same kernels, different tiling of rows)
+    alone = dut(x[idx].cuda()).cpu()
+    assert float((alone - got[idx]).abs().max()) <= 2e-2 * float(got[idx].abs().max())
+    # and the launch is deterministic
+    assert torch.equal(dut(x.cuda()).cpu(), got)

@@ -123,8 +123,8 @@ def test_train_steps_follow_the_oracle_loss_curve(n_steps):
         l_ref.backward()
         opt.step()
         want.append(float(l_ref))
-        loss, overflow, scale, lr_dev = eng.step(*cols)
-        assert not overflow and scale == 1024.0 and abs(lr_dev - lr) < 1e-12
+        loss, cond, scale, overflow, lr_dev = eng.step(*cols)
+        assert not overflow and not cond and scale == 1024.0 and abs(lr_dev - lr) < 1e-12
         got.append(float(loss))
     assert want[-1] < want[0]  # the recipe learns on this batch
     dev = max(abs(a - b_) / abs(b_) for a, b_ in zip(got, want))
@@ -137,7 +137,7 @@ def test_train_steps_follow_the_oracle_loss_curve(n_steps):
 
 
 def test_overflow_skips_update_and_halves_scale():
-    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep, asr_warmup_lr
 
     _, _, model = build(blocks=1, seed=7, cmvn=False)
     xs, ys, sub, ys_lens = batch(b=2, seed=11)
@@ -148,11 +148,15 @@ def test_overflow_skips_update_and_halves_scale():
     before = eng.fp.master.clone()
     xs_bad = xs.clone()
     xs_bad[0, 3, 5] = float("inf")
-    loss, overflow, scale, _ = eng.step(xs_bad.cuda(), *cols[1:])
-    assert overflow and scale == 1024.0 and eng.scaler.scale == 512.0
+    loss, cond, scale, overflow, lr_bad = eng.step(xs_bad.cuda(), *cols[1:])
+    assert overflow and cond and scale == 1024.0 and eng.scaler.scale == 512.0
     assert torch.equal(eng.fp.master, before)
-    _, overflow, scale, _ = eng.step(*cols)
-    assert not overflow and scale == 512.0
+    # counters (train_one_step.py:44-46): get_lr() ran on the skipped step too -> the LR index moved on; the optimizer did
+    # not run -> Adam's bias-correction count did not
+    assert (eng.global_step, eng.applied_steps) == (2, 1) and lr_bad == asr_warmup_lr(1, 1e-3, 2)
+    _, _, scale, overflow, lr3 = eng.step(*cols)
+    assert not overflow and scale == 512.0 and lr3 == asr_warmup_lr(2, 1e-3, 2)
+    assert (eng.global_step, eng.applied_steps) == (3, 2)
     eng.step(*cols)
     assert eng.scaler.scale == 1024.0  # two clean steps (scale_window=2) double it again
     assert not torch.equal(eng.fp.master, before)
@@ -228,4 +232,49 @@ def test_hybrid_ctc_attention_loss_and_gradients_match_oracle():
     assert sum(worst.values()) / len(worst) < 2.5e-2
     # one optimizer step runs end to end with the 11 collate columns
     out = eng.step(*dev)
-    assert not out[1] and float(out[0]) > 0
+    assert len(out) == 5 and not out[1] and not out[3] and float(out[0]) > 0
+
+
+def test_adam_bias_correction_counts_applied_updates_only():
+    """After a skipped (overflow) step the next applied update must equal what Adam does at its own step count: the engine with
+    an overflow step in the middle ends on the same masters as one that never saw the bad batch, when the LR is constant across
+    steps (warm-up long past: base_lr * sqrt(w) * s^-0.5 is replaced here by a flat schedule through warmup_steps=1, lr ~ s^-0.5
+    differs per step, so compare against an explicit float64 Adam on the recorded gradients instead)."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep, asr_warmup_lr
+
+    _, _, model = build(blocks=1, seed=8, cmvn=False)
+    xs, ys, sub, ys_lens = batch(b=2, seed=13)
+    eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.0, positional_dropout_rate=0.0)
+    cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
+    xs_bad = xs.clone()
+    xs_bad[0, 3, 5] = float("inf")
+    name = "after_norm.g"
+    p = eng.fp.p(name).double().cpu().clone()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    applied = 0
+    for call, bad in enumerate([False, True, False, False]):
+        out = eng.step(xs_bad.cuda() if bad else cols[0], *cols[1:])
+        assert bool(out[3]) == bad
+        if bad:
+            continue
+        g = eng.fp.g(name).double().cpu() / out[2]       # unscaled gradient of this step
+        applied += 1
+        lr = asr_warmup_lr(call, 1e-3, 2)                # LR index = number of get_lr() calls so far = step() calls
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        lr_t = lr * math.sqrt(1 - 0.999 ** applied) / (1 - 0.9 ** applied)
+        p = p - lr_t * m / (v.sqrt() + 1e-8)
+    assert torch.allclose(eng.fp.p(name).double().cpu(), p, rtol=0, atol=2e-6)
+
+
+def test_lr_step_rule_mindspore23_advances_twice_per_applied_step():
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep, asr_warmup_lr
+
+    _, _, model = build(blocks=1, seed=8, cmvn=False)
+    xs, ys, sub, ys_lens = batch(b=2, seed=13)
+    eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=50, dropout_rate=0.0, positional_dropout_rate=0.0,
+                                lr_step_rule="mindspore23")
+    cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
+    lrs = [eng.step(*cols)[4] for _ in range(3)]
+    assert lrs == [asr_warmup_lr(s, 1e-3, 50) for s in (0, 2, 4)] and eng.global_step == 6 and eng.applied_steps == 3

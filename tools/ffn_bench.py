@@ -12,17 +12,13 @@ def t(fn, reps=50):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / reps * 1e3
 fl = 2.0 * m * 2048 * 256 * 2
-us = t(lambda: ops.ffn(a, w1, b1, w2, b2, x)); print("fused ffn  M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
 def unf():
     h = ops.gemm(a, w1, bias=b1, act=_lib.ACT_SWISH); ops.gemm(h, w2, bias=b2, residual=x, alpha=0.5, out_dtype=torch.float32, out=x)
 us = t(unf); print("2-gemm ffn M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
-part = torch.empty(m, 256, device="cuda")
-us = t(lambda: ops.ffn128(a, w1, b1, w2, b2, x, part)); print("fused128   M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
 pk = ops.ffn_pack_weights(w1, w2)
 g = torch.ones(256, device="cuda"); be = torch.zeros(256, device="cuda")
 us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x)); print("packed ffn M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
 us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, g, be)); print("packed+LN  M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
-us = t(lambda: ops.ffn_ln(a, w1, b1, w2, b2, x, g, be)); print("fused+LN   M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
 if os.environ.get("MA_FFNPK_ABLATE") == "7":
     us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, alpha=0.25)); print("packed, no main loop: %.1f us" % us)
 us = t(lambda: ops.ffn_packed(a[:64], pk, b1, b2, x[:64])); print("packed M=64 (launch floor + one workgroup): %.1f us" % us)

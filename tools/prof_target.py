@@ -17,17 +17,6 @@ elif what == "gemm":
     a = torch.randn(m, k, device="cuda").bfloat16(); w = (torch.randn(nn, k, device="cuda") / 16).bfloat16(); bias = torch.randn(nn, device="cuda")
     out = torch.empty(m, nn, dtype=torch.bfloat16, device="cuda")
     for _ in range(n): ops.gemm(a, w, bias=bias, act=_lib.ACT_SWISH, out=out)
-elif what == "ffn":
-    m = B * 249
-    a = torch.randn(m, 256, device="cuda").bfloat16(); w1 = (torch.randn(2048, 256, device="cuda") / 16).bfloat16(); b1 = torch.randn(2048, device="cuda")
-    w2 = (torch.randn(256, 2048, device="cuda") / 45).bfloat16(); b2 = torch.randn(256, device="cuda"); xx = torch.randn(m, 256, device="cuda")
-    for _ in range(n): ops.ffn(a, w1, b1, w2, b2, xx)
-elif what == "ffn128":
-    m = B * 249
-    a = torch.randn(m, 256, device="cuda").bfloat16(); w1 = (torch.randn(2048, 256, device="cuda") / 16).bfloat16(); b1 = torch.randn(2048, device="cuda")
-    w2 = (torch.randn(256, 2048, device="cuda") / 45).bfloat16(); b2 = torch.randn(256, device="cuda"); xx = torch.randn(m, 256, device="cuda")
-    part = torch.empty(m, 256, device="cuda")
-    for _ in range(n): ops.ffn128(a, w1, b1, w2, b2, xx, part)
 elif what == "ffnpk":
     m = B * 249
     a = torch.randn(m, 256, device="cuda").bfloat16(); w1 = (torch.randn(2048, 256, device="cuda") / 16).bfloat16(); b1 = torch.randn(2048, device="cuda")

@@ -44,7 +44,7 @@ def main():
                                                dropout_rate=args.dropout, positional_dropout_rate=args.dropout)
                              if hybrid else None, lsm_weight=0.1 if hybrid else 0.0).to(dev)
     eng = ConformerCTCTrainStep(model, dropout_rate=args.dropout, positional_dropout_rate=args.dropout,
-                                world_size=world)
+                                world_size=world, rank=rank)
     rng = np.random.RandomState(1234 + rank)
     b, t = args.batch, args.frames
     xs = torch.from_numpy(rng.randn(b, t, 80).astype(np.float32)).to(dev)
@@ -105,7 +105,7 @@ def main():
                        "global_batch": b * world, "flat_params": nparam,
                        "grad_bytes_allreduced_per_step": nparam * 4 if world > 1 else 0},
             "first_losses": [round(v, 3) for v in losses[:3]], "last_loss": round(float(out[0]), 3),
-            "loss_scale": out[2], "overflow": out[1]}))
+            "loss_scale": out[2], "overflow": out[3]}))
     if dist is not None:
         dist.destroy_process_group()
 

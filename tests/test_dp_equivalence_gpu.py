@@ -45,9 +45,14 @@ def test_two_ranks_equal_one_rank_on_the_whole_batch(tmp_path):
     # all-reduce(SUM) of per-rank means = world x the whole-batch mean gradient (same loss scale); 1/world is folded into Adam
     g2, g1 = r0["grad"].double(), one["grad"].double() * 2.0
     assert float((g2 - g1).norm() / g1.norm()) <= 2e-3
-    # ... so the applied update is the single-process update (bf16 round-off flips the sign of a few near-zero Adam ratios)
+    # ... so the applied update is the single-process update.  This is Adam's first applied step, |update| = lr for every element
+    # with a non-zero gradient: round-off can only flip the sign of elements whose gradient is noise (key / depthwise biases,
+    # whose true gradient is zero) - measured 0.1 % of the elements
     d2, d1 = r0["delta"].double(), one["delta"].double()
-    assert float(d1.abs().max()) > 0 and float((d2 - d1).norm() / d1.norm()) <= 5e-2
+    moved = d1.abs() > 0
+    flipped = ((d2 - d1).abs() > 0.5 * r0["lr"]) & moved
+    assert float(d1.abs().max()) > 0.9 * r0["lr"] and int(flipped.sum()) <= 5e-3 * int(moved.sum())
+    assert float((d2 - d1)[~flipped].norm() / d1.norm()) <= 1e-2
     assert (r0["delta"] == r1["delta"]).all()  # replicas stay in lock-step
     # BatchNorm running statistics are per rank (no SyncBN in the reference): equal here because the shards' inputs are equal
     for a, b, c in zip(r0["bn_mean"], r1["bn_mean"], one["bn_mean"]):

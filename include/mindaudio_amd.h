@@ -642,6 +642,70 @@ int ma_grad_overflow_f32(const float* g, int64_t n, int32_t* flag, ma_stream_t s
 int ma_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                 float eps, float inv_scale, const int32_t* overflow, ma_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * float32 validation mode of the training step ("x32"): compute_type = float32 is the reference's default
+ * (mindaudio/models/conformer.py:61, examples/conformer/asr_model.py:307-310).  Every activation and every product stays
+ * float32, so the forward / backward / optimizer chain can be held to the north-star tolerance (loss curve within 1e-4 of a
+ * float32 restatement of the reference); plain FMA kernels sized for validation shapes.  Semantics and argument meaning of
+ * each entry = its bf16 form above with `float*` activations.
+ * ---------------------------------------------------------------------------------------------- */
+/* out (M, N) = epilogue(A . B):  A[m][k] = A[m * a_row_stride + k * a_col_stride],  B[k][n] = B[n * b_n_stride + k * b_k_stride].
+ * NT (Dense forward, W stored (N, K)): b_n_stride = ldw, b_k_stride = 1.   NN (dX = dY . W, W (K, N) row-major): b_n_stride = 1,
+ * b_k_stride = ldw.   TN (dW = dY^T . X): a_row_stride = 1, a_col_stride = ld(dY), b_n_stride = 1, b_k_stride = ld(X).
+ * Epilogue as ma_gemm_bf16 with act in {0 none, 1 swish, 2 relu}, no column affine, float32 output (accumulate into `out` by
+ * passing it as the residual). */
+int ma_gemm_x32(const float* A, int64_t a_row_stride, int64_t a_col_stride, const float* B, int64_t b_n_stride,
+                int64_t b_k_stride, float* out, int64_t ldo, int64_t M, int64_t N, int64_t K, const ma_gemm_epilogue_t* epi,
+                ma_stream_t stream);
+/* out[c] (+)= sum over rows of A[r][c]  (bias gradients) */
+int ma_colsum_x32(const float* A, int64_t lda, int64_t rows, int64_t cols, float* out, int32_t accumulate, ma_stream_t stream);
+/* RelPositionMultiHeadedAttention (layers/attention.py:214-235), d_k = 64: qkv (B*T, >= 3*H*64) = [q | k | v] rows, pos (T, H*64),
+ * mask (B, T) (0 = padded key: additive -10000) -> ctx (B*T, H*64), lse (B, H, T).  Backward: dqkv as qkv, dpos / dbias_u /
+ * dbias_v accumulate; workspace from ma_relpos_attention_bwd_x32_workspace_bytes. */
+int ma_relpos_attention_fwd_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads, int32_t d_k,
+                                float* ctx, int64_t ld_ctx, float* lse, ma_stream_t stream);
+int64_t ma_relpos_attention_bwd_x32_workspace_bytes(int64_t batch, int64_t T, int32_t heads);
+int ma_relpos_attention_bwd_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                const float* bias_v, const float* mask, const float* ctx, int64_t ld_ctx, const float* dctx,
+                                int64_t ld_dctx, const float* lse, int64_t batch, int64_t T, int32_t heads, int32_t d_k,
+                                float* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos, float* dbias_u, float* dbias_v,
+                                void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+/* Conv2dSubsampling4 (layers/subsampling.py:21-78): conv1 with any input strides -> NHWC float32; explicit im2col of the 3x3
+ * stride-2 valid window, col (B*Ho*Wo, 9*C) with k = (kh, kw, c) (conv2 = ma_gemm_x32 on it); backward pieces. */
+int ma_subsample_conv1_nhwc_x32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_f, int64_t batch, int64_t T,
+                                int32_t idim, const float* cmvn_mean, const float* cmvn_istd, const float* w, const float* bias,
+                                int32_t C, float* out, ma_stream_t stream);
+int ma_im2col_3x3s2_nhwc_x32(const float* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, float* col, ma_stream_t stream);
+int ma_col2im_3x3s2_relu_x32(const float* dcol, const float* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
+                             float* dact, ma_stream_t stream);
+int ma_relu_bwd_x32(float* dy, const float* y, int64_t n, ma_stream_t stream);
+int ma_subsample_conv1_dw_x32(const float* dact, const float* x, int64_t batch, int64_t T, int32_t idim,
+                              const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
+                              void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+/* element-wise pieces of the block (layers/swish.py, the dropouts of models/conformer.py:109-151, layers/convolution.py:83-129) */
+int ma_act_dropout_fwd_x32(const float* u, float* h, int64_t n, int32_t act, float p, uint32_t seed, uint32_t salt,
+                           ma_stream_t stream);
+int ma_act_dropout_bwd_x32(const float* u, const float* dh, float* du, int64_t n, int32_t act, float p, uint32_t seed,
+                           uint32_t salt, ma_stream_t stream);
+int ma_dropout_bwd_x32(const float* g, int64_t ldg, float* dy, int64_t ldy, int64_t rows, int64_t cols, float alpha,
+                       const float* row_scale, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
+int ma_convmid_fwd_train_x32(const float* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
+                             int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream);
+int ma_bn_swish_fwd_x32(const float* z, const float* stats, const float* gamma, const float* beta, float* out,
+                        int64_t rows, int32_t C, ma_stream_t stream);
+int ma_bn_swish_bwd_x32(const float* dout, const float* z, const float* stats, const float* gamma, const float* beta,
+                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream);
+int ma_convmid_bwd_x32(const float* dz, const float* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
+                       const float* dw_w, int32_t ks, float* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
+                       void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+/* ma_ctc_loss_grad_f32 with float32 dlogits */
+int ma_ctc_loss_grad_x32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
+                         int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
+                         int32_t zero_infinity, float grad_scale, float* per_utt_loss, float* lse_workspace,
+                         float* loss_out, float* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
+                         ma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,6 +190,27 @@ PROTOTYPES = {
     "ma_db_workspace_bytes": (i64, [i64, i64]),
     "ma_amplitude_to_db_f32": (ctypes.c_int, [c_f32p, i64, i64, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),
+    # ---- float32 validation mode (x32) ----
+    "ma_gemm_x32": (ctypes.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, ctypes.POINTER(GemmEpilogue), vp]),
+    "ma_colsum_x32": (ctypes.c_int, [vp, i64, i64, i64, vp, i32, vp]),
+    "ma_relpos_attention_fwd_x32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, vp, i64, vp, vp]),
+    "ma_relpos_attention_bwd_x32_workspace_bytes": (i64, [i64, i64, i32]),
+    "ma_relpos_attention_bwd_x32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32, i32,
+                                                   vp, i64, vp, i64, vp, vp, vp, i64, vp]),
+    "ma_subsample_conv1_nhwc_x32": (ctypes.c_int, [vp, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "ma_im2col_3x3s2_nhwc_x32": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, vp]),
+    "ma_col2im_3x3s2_relu_x32": (ctypes.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
+    "ma_relu_bwd_x32": (ctypes.c_int, [vp, vp, i64, vp]),
+    "ma_subsample_conv1_dw_x32": (ctypes.c_int, [vp, vp, i64, i64, i32, vp, vp, i32, vp, vp, vp, i64, vp]),
+    "ma_act_dropout_fwd_x32": (ctypes.c_int, [vp, vp, i64, i32, f32, u32, u32, vp]),
+    "ma_act_dropout_bwd_x32": (ctypes.c_int, [vp, vp, vp, i64, i32, f32, u32, u32, vp]),
+    "ma_dropout_bwd_x32": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, f32, vp, f32, u32, u32, vp]),
+    "ma_convmid_fwd_train_x32": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, vp, vp]),
+    "ma_bn_swish_fwd_x32": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, i32, vp]),
+    "ma_bn_swish_bwd_x32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "ma_convmid_bwd_x32": (ctypes.c_int, [vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp, i64, vp]),
+    "ma_ctc_loss_grad_x32": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, i32, i32, f32, vp, vp, vp, vp, i64, vp,
+                                            i64, vp]),
 }
 
 _lib = None

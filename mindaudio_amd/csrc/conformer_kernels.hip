@@ -145,13 +145,16 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
 // ---- CMVN + Conv2d(1 -> C, 3x3, stride 2, valid) + ReLU, output NHWC bf16 -----------------------------------
 // One workgroup per (b, output time t): 256 threads = channels (C == 256) or C/… loop; the 3 x idim input rows are
 // normalised into LDS once, each thread keeps its 9 weights in registers and walks the F1 output columns.
+__device__ __forceinline__ void st_pair(uint16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack2_bf16(a, b); }
+__device__ __forceinline__ void st_pair(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+template <typename OT>  // uint16_t: bf16 NHWC (throughput path); float: the float32 validation mode (ma_subsample_conv1_nhwc_x32)
 __global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __restrict__ x, int64_t sb, int64_t st, int64_t sf,
                                                               int64_t T, int idim,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ istd,
                                                               const float* __restrict__ w,  // (C, 3, 3)
                                                               const float* __restrict__ bias, int C, int T1, int F1,
-                                                              uint16_t* __restrict__ out) {
+                                                              OT* __restrict__ out) {
   extern __shared__ float rows[];  // 3 * idim
   const int64_t bt = blockIdx.x;
   const int64_t b = bt / T1;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __res
       wb[i] = w[(c + 1) * 9 + i];
     }
     const float ba = bias[c], bb = bias[c + 1];
-    uint16_t* o = out + (bt * F1) * C + c;
+    OT* o = out + (bt * F1) * C + c;
     for (int f1 = par; f1 < F1; f1 += 2) {
       float a0 = ba, a1 = bb;
 #pragma unroll
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void subsample_conv1_kernel(const float* __res
           a0 = fmaf(wa[kh * 3 + kw], xv, a0);
           a1 = fmaf(wb[kh * 3 + kw], xv, a1);
         }
-      *reinterpret_cast<uint32_t*>(o + (int64_t)f1 * C) = pack2_bf16(fmaxf(a0, 0.0f), fmaxf(a1, 0.0f));
+      st_pair(o + (int64_t)f1 * C, fmaxf(a0, 0.0f), fmaxf(a1, 0.0f));
     }
   }
 }
@@ -688,9 +691,21 @@ static int subsample_conv1_launch(const float* x, int64_t sb, int64_t st, int64_
               bias, T1, F1, reinterpret_cast<uint16_t*>(out));
     return MA_OK;
   }
-  MA_LAUNCH(subsample_conv1_kernel, dim3((unsigned)(batch * T1)), dim3(256), 3 * idim * sizeof(float),
+  MA_LAUNCH(subsample_conv1_kernel<uint16_t>, dim3((unsigned)(batch * T1)), dim3(256), 3 * idim * sizeof(float),
             (hipStream_t)stream, x, sb, st, sf, T, idim, cmvn_mean, cmvn_istd, w, bias, C, T1, F1,
             reinterpret_cast<uint16_t*>(out));
+  return MA_OK;
+}
+
+int ma_subsample_conv1_nhwc_x32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_f, int64_t batch, int64_t T,
+                                int32_t idim, const float* cmvn_mean, const float* cmvn_istd, const float* w, const float* bias,
+                                int32_t C, float* out, ma_stream_t stream) {
+  if (!x || !w || !bias || !out || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
+  if ((cmvn_mean == nullptr) != (cmvn_istd == nullptr) || stride_b < 0 || stride_t < 0 || stride_f < 0) return MA_ERR_INVALID_ARG;
+  if (C & 1) return MA_ERR_UNSUPPORTED;
+  const int T1 = (int)((T - 3) / 2 + 1), F1 = (idim - 3) / 2 + 1;
+  MA_LAUNCH(subsample_conv1_kernel<float>, dim3((unsigned)(batch * T1)), dim3(256), 3 * idim * sizeof(float),
+            (hipStream_t)stream, x, stride_b, stride_t, stride_f, T, idim, cmvn_mean, cmvn_istd, w, bias, C, T1, F1, out);
   return MA_OK;
 }
 

@@ -205,17 +205,24 @@ __global__ __launch_bounds__(64) void ctc_beta_kernel(const float* __restrict__ 
 // Backward, step 2: one workgroup per (b, t) row: dlogits[v] = scale * (softmax[v] - sum_{s: l'_s = v} w_t(s)) as bf16;
 // rows past the utterance's length, and utterances with an infinite loss (zero_infinity), get zeros.  Columns
 // [V, ld_out) are zeroed (GEMM K padding).
+__device__ __forceinline__ void st_dlogit(uint16_t* p, float g) {
+  uint32_t u = __float_as_uint(g);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  *p = (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ void st_dlogit(float* p, float g) { *p = g; }  // float32 validation mode (ma_ctc_loss_grad_x32)
+template <typename OT>
 __global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restrict__ logits, int64_t ld, int T, int V,
                                                           const float* __restrict__ lse, const int32_t* __restrict__ ys,
                                                           int Lmax, const int32_t* __restrict__ hlens,
                                                           const int32_t* __restrict__ ylens, int blank,
                                                           const float* __restrict__ loss, const float* __restrict__ ab,
-                                                          int Smax, float scale, uint16_t* __restrict__ out,
+                                                          int Smax, float scale, OT* __restrict__ out,
                                                           int64_t ld_out) {
   extern __shared__ float occ[];
   const int64_t row = blockIdx.x;
   const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
-  uint16_t* o = out + row * ld_out;
+  OT* o = out + row * ld_out;
   int tlen = hlens[b];
   if (tlen > T) tlen = T;
   const int U = ylens[b], S = 2 * U + 1;
@@ -235,9 +242,7 @@ __global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restric
   for (int v = threadIdx.x; v < ld_out; v += 256) {
     float gval = 0.0f;
     if (v < V) gval = scale * (expf(p[v] - z) - occ[v]);
-    uint32_t u = __float_as_uint(gval);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    o[v] = (uint16_t)(u >> 16);
+    st_dlogit(o + v, gval);
   }
 }
 
@@ -338,11 +343,13 @@ int64_t ma_ctc_grad_workspace_bytes(int64_t batch, int64_t T, int32_t Lmax) {
   return batch * T * (2 * (int64_t)Lmax + 1) * 4;
 }
 
-int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
-                         int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
-                         int32_t zero_infinity, float grad_scale, float* per_utt_loss, float* lse_workspace,
-                         float* loss_out, void* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
-                         ma_stream_t stream) {
+extern "C++" {
+template <typename OT>
+static int ctc_loss_grad_launch(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
+                                int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
+                                int32_t zero_infinity, float grad_scale, float* per_utt_loss, float* lse_workspace,
+                                float* loss_out, OT* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
+                                ma_stream_t stream) {
   if (!logits || !ys || !hlens || !ylens || !per_utt_loss || !lse_workspace || !loss_out || !dlogits || !workspace)
     return MA_ERR_INVALID_ARG;
   if (batch < 1 || T < 1 || V < 1 || ld < V || ld_out < V || Lmax < 1 || blank < 0 || blank >= V) return MA_ERR_INVALID_ARG;
@@ -358,10 +365,27 @@ int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t
   MA_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, per_utt_loss, (int)batch, 1, loss_out);
   MA_LAUNCH(ctc_beta_kernel, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
             hlens, ylens, (int)blank, per_utt_loss, ab, Smax);
-  MA_LAUNCH(ctc_dlogits_kernel, dim3((unsigned)rows), dim3(256), (size_t)V * 4, s, logits, ld, (int)T, (int)V,
-            lse_workspace, ys, (int)Lmax, hlens, ylens, (int)blank, per_utt_loss, ab, Smax, grad_scale,
-            reinterpret_cast<uint16_t*>(dlogits), ld_out);
+  MA_LAUNCH(ctc_dlogits_kernel<OT>, dim3((unsigned)rows), dim3(256), (size_t)V * 4, s, logits, ld, (int)T, (int)V,
+            lse_workspace, ys, (int)Lmax, hlens, ylens, (int)blank, per_utt_loss, ab, Smax, grad_scale, dlogits, ld_out);
   return MA_OK;
+}
+}  // extern "C++"
+int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
+                         int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
+                         int32_t zero_infinity, float grad_scale, float* per_utt_loss, float* lse_workspace,
+                         float* loss_out, void* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
+                         ma_stream_t stream) {
+  return ctc_loss_grad_launch(logits, ld, batch, T, V, ys, Lmax, hlens, ylens, blank, zero_infinity, grad_scale, per_utt_loss,
+                              lse_workspace, loss_out, reinterpret_cast<uint16_t*>(dlogits), ld_out, workspace, workspace_bytes,
+                              stream);
+}
+int ma_ctc_loss_grad_x32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
+                         int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
+                         int32_t zero_infinity, float grad_scale, float* per_utt_loss, float* lse_workspace,
+                         float* loss_out, float* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
+                         ma_stream_t stream) {
+  return ctc_loss_grad_launch(logits, ld, batch, T, V, ys, Lmax, hlens, ylens, blank, zero_infinity, grad_scale, per_utt_loss,
+                              lse_workspace, loss_out, dlogits, ld_out, workspace, workspace_bytes, stream);
 }
 
 int ma_ctc_greedy_search_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const float* mask,

@@ -48,6 +48,16 @@ __device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t salt, uint64_t
   x += salt; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
   return ((idx & 1) ? (x >> 16) : (x & 0xffffu)) >= (thresh >> 16);
 }
+// activation storage type of the element-wise training kernels: uint16_t = bf16 bit patterns (throughput mode) or float
+// (the float32 validation mode, entry points with the _x32 suffix)
+__device__ __forceinline__ float ldact(const uint16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ float ldact(const float* p) { return *p; }
+__device__ __forceinline__ void stact(uint16_t* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ void stact(float* p, float v) { *p = v; }
+// precise sigmoid for the float32 mode; the bf16 mode keeps the 1-ulp v_rcp / v_exp form (invisible after bf16 rounding)
+template <typename AT> __device__ __forceinline__ float sigm(float v) { return sigmoidf_(v); }
+template <> __device__ __forceinline__ float sigm<float>(float v) { return 1.0f / (1.0f + expf(-v)); }
+
 struct Drop {
   uint32_t seed, salt, thresh;  // thresh = p * 2^32; 0 = no dropout
   float inv_keep;               // 1 / (1 - p)
@@ -274,7 +284,8 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(float* x, int64_t ldx,
   }
 }
 // dy = alpha * keep / (1 - p) * g * row_scale  (bf16 operand of the branch's last GEMM backward)
-__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ g, int64_t ldg, uint16_t* __restrict__ dy,
+template <typename AT>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ g, int64_t ldg, AT* __restrict__ dy,
                                                           int64_t ldy, int64_t rows, int cols, float alpha,
                                                           const float* __restrict__ row_scale, Drop d) {
   const int64_t n = rows * cols;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
     float v = g[r * ldg + c] * alpha;
     if (row_scale) v *= row_scale[r];
     if (d.thresh) v = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? v * d.inv_keep : 0.0f;
-    dy[r * ldy + c] = f2bf(v);
+    stact(dy + r * ldy + c, v);
   }
 }
 
@@ -293,8 +304,8 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
 // and z^2 for the batch statistics.  Workgroup = (utterance, kCfPerBlock strips of 16 frames) x 256 channels (thread =
 // channel): glu of the strip + halo goes through LDS once (the sigmoid is evaluated once per element, not once per tap).
 constexpr int kCfStrip = 16, kCfPerBlock = 4;
-template <int KS>
-__global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const uint16_t* __restrict__ y, int64_t ldy, int T, int C,
+template <int KS, typename AT>
+__global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const AT* __restrict__ y, int64_t ldy, int T, int C,
                                                                 const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ z,
                                                                 float* sums) {
@@ -316,8 +327,8 @@ __global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const uint16_t* 
       const int t = t0 - pad + r;
       float sv = 0.0f;
       if (t >= 0 && t < T) {
-        const uint16_t* yp = y + (base + t) * ldy + c;
-        sv = bf2f(yp[0]) * sigmoidf_(bf2f(yp[C]));
+        const AT* yp = y + (base + t) * ldy + c;
+        sv = ldact(yp) * sigm<AT>(ldact(yp + C));
       }
       s_t[r * 256 + tid] = sv;  // a thread only reads its own column: no barrier needed
     }
@@ -354,19 +365,21 @@ __global__ void bn_finalize_kernel(const float* sums, int C, float count, float 
 }
 
 // out = swish(gamma * (z - mean) * rstd + beta) as bf16
+template <typename AT>
 __global__ __launch_bounds__(256) void bn_swish_fwd_kernel(const float* __restrict__ z, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           uint16_t* __restrict__ out, int64_t rows, int C) {
+                                                           AT* __restrict__ out, int64_t rows, int C) {
   const int64_t n = rows * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % C);
     const float nv = gamma[c] * (z[i] - stats[c]) * stats[C + c] + beta[c];
-    out[i] = f2bf(nv * sigmoidf_(nv));
+    stact(out + i, nv * sigm<AT>(nv));
   }
 }
 
 // dn = dout * swish'(n) (float32, stored) and the BatchNorm reductions dsum[c] = sum dn, dsum[C + c] = sum dn * zhat
-__global__ __launch_bounds__(256) void bn_swish_bwd1_kernel(const uint16_t* __restrict__ dout, const float* __restrict__ z,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_swish_bwd1_kernel(const AT* __restrict__ dout, const float* __restrict__ z,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ dn,
                                                             int64_t rows, int C, float* dsum) {
@@ -383,8 +396,8 @@ __global__ __launch_bounds__(256) void bn_swish_bwd1_kernel(const uint16_t* __re
     const int64_t i = row * C + c;
     const float zh = (z[i] - stats[c]) * stats[C + c];
     const float nv = gamma[c] * zh + beta[c];
-    const float s = sigmoidf_(nv);
-    const float d = bf2f(dout[i]) * (s + nv * s * (1.0f - s));
+    const float s = sigm<AT>(nv);
+    const float d = ldact(dout + i) * (s + nv * s * (1.0f - s));
     dn[i] = d;
     s0 += d;
     s1 += d * zh;
@@ -412,10 +425,10 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ dn, co
 // Workgroup = (utterance b, strip of kCbStrip frames) x 256 channels (thread = channel): the strip plus its halo of
 // s and dz go through LDS once, so every tap is an LDS read with unit channel stride.
 constexpr int kCbStrip = 16, kCbPerBlock = 1;
-template <int KS>
-__global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restrict__ dz, const uint16_t* __restrict__ y,
+template <int KS, typename AT>
+__global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restrict__ dz, const AT* __restrict__ y,
                                                           int64_t ldy, int B, int T, int C,
-                                                          const float* __restrict__ w, uint16_t* __restrict__ dy,
+                                                          const float* __restrict__ w, AT* __restrict__ dy,
                                                           int64_t lddy, float* __restrict__ part, int per_block) {
   constexpr int pad = (KS - 1) / 2, kRows = kCbStrip + KS - 1;
   extern __shared__ float cb_lds[];
@@ -438,8 +451,8 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
     const int t = t0 - pad + r;
     float sv = 0.0f, zv = 0.0f;
     if (t >= 0 && t < T) {
-      const uint16_t* yp = y + (base + t) * ldy + c;
-      sv = bf2f(yp[0]) * sigmoidf_(bf2f(yp[C]));
+      const AT* yp = y + (base + t) * ldy + c;
+      sv = ldact(yp) * sigm<AT>(ldact(yp + C));
       zv = dz[(base + t) * C + c];
     }
     s_t[r * 256 + tid] = sv;
@@ -457,10 +470,10 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
       ds = fmaf(wr[j], z_t[(r - (j - pad)) * 256 + tid], ds);      // z[t - (j - pad)] used s[t] with tap j
       dwr[j] = fmaf(dzt, s_t[(r + j - pad) * 256 + tid], dwr[j]);  // z[t] used s[t + j - pad] with tap j
     }
-    const uint16_t* yp = y + (base + t) * ldy + c;
-    const float a = bf2f(yp[0]), sg = sigmoidf_(bf2f(yp[C]));
-    dy[(base + t) * lddy + c] = f2bf(ds * sg);
-    dy[(base + t) * lddy + C + c] = f2bf(ds * a * sg * (1.0f - sg));
+    const AT* yp = y + (base + t) * ldy + c;
+    const float a = ldact(yp), sg = sigm<AT>(ldact(yp + C));
+    stact(dy + (base + t) * lddy + c, ds * sg);
+    stact(dy + (base + t) * lddy + C + c, ds * a * sg * (1.0f - sg));
   }
   }
   // per-workgroup partial (dw (C, KS) | db (C)); summed by partial_reduce_kernel
@@ -551,7 +564,8 @@ __global__ __launch_bounds__(256) void col2im_relu_kernel(const uint16_t* __rest
 
 // conv1 (1 -> C channels, 3x3 stride 2) weight gradient: dw[c][kh*3+kw] = sum_{b,h1,w1} dact[b,h1,w1,c] * xin[b, 2 h1 + kh, 2 w1 + kw],
 // db[c] = sum dact; xin = (x - mean) * istd when CMVN is on.  Block = 256 channels x a strip of output positions.
-__global__ __launch_bounds__(256) void conv1_dw_kernel(const uint16_t* __restrict__ dact, const float* __restrict__ x, int B,
+template <typename AT>
+__global__ __launch_bounds__(256) void conv1_dw_kernel(const AT* __restrict__ dact, const float* __restrict__ x, int B,
                                                        int T, int idim, int H1, int W1, int C,
                                                        const float* __restrict__ cm_mean, const float* __restrict__ cm_istd,
                                                        float* __restrict__ part, int strip) {
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const uint16_t* __restric
   int h1 = tq % H1, b = tq / H1;
 #pragma unroll 2
   for (int pidx = p0; pidx < p1; ++pidx) {
-    const float d = c < C ? bf2f(dact[(int64_t)pidx * C + c]) : 0.0f;
+    const float d = c < C ? ldact(dact + (int64_t)pidx * C + c) : 0.0f;
     accb += d;
     const float* xr = x + ((int64_t)b * T + 2 * h1) * idim + 2 * w1;
 #pragma unroll
@@ -585,6 +599,55 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const uint16_t* __restric
 #pragma unroll
     for (int k = 0; k < 9; ++k) pp[c * 9 + k] = acc[k];
     pp[C * 9 + c] = accb;
+  }
+}
+
+// ---- float32 validation mode: the kernels above that move 16-byte bf16 vectors, restated element-wise on float ----------
+__global__ __launch_bounds__(256) void act_dropout_fwd_x32_kernel(const float* __restrict__ u, float* __restrict__ h, int64_t n,
+                                                                  Drop d, int relu) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = u[i];
+    float r = relu ? fmaxf(v, 0.0f) : v * sigm<float>(v);
+    if (d.thresh) r = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? r * d.inv_keep : 0.0f;
+    h[i] = r;
+  }
+}
+__global__ __launch_bounds__(256) void act_dropout_bwd_x32_kernel(const float* __restrict__ u, const float* __restrict__ dh,
+                                                                  float* __restrict__ du, int64_t n, Drop d, int relu) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = u[i], sg = sigm<float>(v);
+    float gr = dh[i] * (relu ? (v > 0.0f ? 1.0f : 0.0f) : (sg + v * sg * (1.0f - sg)));
+    if (d.thresh) gr = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? gr * d.inv_keep : 0.0f;
+    du[i] = gr;
+  }
+}
+__global__ __launch_bounds__(256) void relu_bwd_x32_kernel(float* __restrict__ dy, const float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (!(y[i] > 0.0f)) dy[i] = 0.0f;
+}
+// col2im_relu_kernel on float: one element per thread
+__global__ __launch_bounds__(256) void col2im_relu_x32_kernel(const float* __restrict__ dcol, const float* __restrict__ act, int B,
+                                                              int H, int Wd, int C, int Ho, int Wo, float* __restrict__ dact) {
+  const int64_t n = (int64_t)B * H * Wd * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int w = (int)(t % Wd);
+    t /= Wd;
+    const int h = (int)(t % H);
+    const int64_t b = t / H;
+    float acc = 0.0f;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h - kh;
+      if (hh < 0 || (hh & 1) || hh / 2 >= Ho) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w - kw;
+        if (ww < 0 || (ww & 1) || ww / 2 >= Wo) continue;
+        const int64_t m = (b * Ho + hh / 2) * Wo + ww / 2;
+        acc += dcol[m * (9 * C) + (kh * 3 + kw) * C + c];
+      }
+    }
+    dact[i] = act[i] > 0.0f ? acc : 0.0f;
   }
 }
 
@@ -715,28 +778,64 @@ int ma_dropout_add_f32(float* x, int64_t ldx, const float* xin, int64_t ldxin, c
   return MA_OK;
 }
 
+extern "C++" {
+template <typename AT>
+static int dropout_bwd_launch(const float* g, int64_t ldg, AT* dy, int64_t ldy, int64_t rows, int64_t cols, float alpha,
+                              const float* row_scale, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
+  if (!g || !dy || rows < 1 || cols < 1 || ldg < cols || ldy < cols || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(dropout_bwd_kernel<AT>, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, g, ldg, dy, ldy, rows,
+            (int)cols, alpha, row_scale, make_drop(p, seed, salt));
+  return MA_OK;
+}
+}  // extern "C++"
 int ma_dropout_bwd_bf16(const float* g, int64_t ldg, void* dy, int64_t ldy, int64_t rows, int64_t cols, float alpha,
                         const float* row_scale, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
-  if (!g || !dy || rows < 1 || cols < 1 || ldg < cols || ldy < cols || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
-  MA_LAUNCH(dropout_bwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, g, ldg, (uint16_t*)dy,
-            ldy, rows, (int)cols, alpha, row_scale, make_drop(p, seed, salt));
+  return dropout_bwd_launch(g, ldg, (uint16_t*)dy, ldy, rows, cols, alpha, row_scale, p, seed, salt, stream);
+}
+int ma_dropout_bwd_x32(const float* g, int64_t ldg, float* dy, int64_t ldy, int64_t rows, int64_t cols, float alpha,
+                       const float* row_scale, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
+  return dropout_bwd_launch(g, ldg, dy, ldy, rows, cols, alpha, row_scale, p, seed, salt, stream);
+}
+
+int ma_act_dropout_fwd_x32(const float* u, float* h, int64_t n, int32_t act, float p, uint32_t seed, uint32_t salt,
+                           ma_stream_t stream) {
+  if (!u || !h || n < 1 || p < 0.0f || p >= 1.0f || (act != 1 && act != 2)) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(act_dropout_fwd_x32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, h, n, make_drop(p, seed, salt),
+            act == 2 ? 1 : 0);
+  return MA_OK;
+}
+int ma_act_dropout_bwd_x32(const float* u, const float* dh, float* du, int64_t n, int32_t act, float p, uint32_t seed,
+                           uint32_t salt, ma_stream_t stream) {
+  if (!u || !dh || !du || n < 1 || p < 0.0f || p >= 1.0f || (act != 1 && act != 2)) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(act_dropout_bwd_x32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, dh, du, n,
+            make_drop(p, seed, salt), act == 2 ? 1 : 0);
   return MA_OK;
 }
 
-int ma_convmid_fwd_train(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
-                         int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
+extern "C++" {
+template <typename AT>
+static int convmid_fwd_train_launch(const AT* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
+                                    int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
   if (!y || !dw_w || !dw_b || !z || !sums || batch < 1 || T < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
-  if (C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31) || (ldy & 1)) return MA_ERR_UNSUPPORTED;
+  if (C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31) || (sizeof(AT) == 2 && (ldy & 1))) return MA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)((T + kCfStrip * kCfPerBlock - 1) / (kCfStrip * kCfPerBlock)), (unsigned)batch, (unsigned)(C / 256));
 #define MA_CF(KS_)                                                                                                  \
-  MA_LAUNCH(convmid_fwd_train_kernel<KS_>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y, ldy, (int)T, C, \
-            dw_w, dw_b, z, sums)
+  MA_LAUNCH((convmid_fwd_train_kernel<KS_, AT>), grid, dim3(256), 0, (hipStream_t)stream, y, ldy, (int)T, C, dw_w, dw_b, z, sums)
   if (ks == 3) { MA_CF(3); }
   else if (ks == 7) { MA_CF(7); }
   else if (ks == 15) { MA_CF(15); }
   else { MA_CF(31); }
 #undef MA_CF
   return MA_OK;
+}
+}  // extern "C++"
+int ma_convmid_fwd_train(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
+                         int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
+  return convmid_fwd_train_launch((const uint16_t*)y, ldy, batch, T, C, dw_w, ks, dw_b, z, sums, stream);
+}
+int ma_convmid_fwd_train_x32(const float* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
+                             int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
+  return convmid_fwd_train_launch(y, ldy, batch, T, C, dw_w, ks, dw_b, z, sums, stream);
 }
 
 int ma_bn_finalize_f32(const float* sums, int32_t C, int64_t count, float eps, float momentum, float* running_mean,
@@ -747,29 +846,53 @@ int ma_bn_finalize_f32(const float* sums, int32_t C, int64_t count, float eps, f
   return MA_OK;
 }
 
-int ma_bn_swish_fwd_bf16(const float* z, const float* stats, const float* gamma, const float* beta, void* out,
-                         int64_t rows, int32_t C, ma_stream_t stream) {
+extern "C++" {
+template <typename AT>
+static int bn_swish_fwd_launch(const float* z, const float* stats, const float* gamma, const float* beta, AT* out,
+                               int64_t rows, int32_t C, ma_stream_t stream) {
   if (!z || !stats || !gamma || !beta || !out || rows < 1 || C < 1) return MA_ERR_INVALID_ARG;
-  MA_LAUNCH(bn_swish_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, z, stats, gamma, beta,
-            (uint16_t*)out, rows, C);
+  MA_LAUNCH(bn_swish_fwd_kernel<AT>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, z, stats, gamma, beta, out,
+            rows, C);
   return MA_OK;
 }
+}  // extern "C++"
+int ma_bn_swish_fwd_bf16(const float* z, const float* stats, const float* gamma, const float* beta, void* out,
+                         int64_t rows, int32_t C, ma_stream_t stream) {
+  return bn_swish_fwd_launch(z, stats, gamma, beta, (uint16_t*)out, rows, C, stream);
+}
+int ma_bn_swish_fwd_x32(const float* z, const float* stats, const float* gamma, const float* beta, float* out,
+                        int64_t rows, int32_t C, ma_stream_t stream) {
+  return bn_swish_fwd_launch(z, stats, gamma, beta, out, rows, C, stream);
+}
 
-int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
-                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream) {
+extern "C++" {
+template <typename AT>
+static int bn_swish_bwd_launch(const AT* dout, const float* z, const float* stats, const float* gamma, const float* beta,
+                               float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream) {
   if (!dout || !z || !stats || !gamma || !beta || !dz || !dsum || rows < 1) return MA_ERR_INVALID_ARG;
   if (C < 1 || C > 256 || 256 % C) return MA_ERR_UNSUPPORTED;
   const int rpb = 256 / C;
-  MA_LAUNCH(bn_swish_bwd1_kernel, dim3(grid_for(rows, rpb, 256)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
-            (const uint16_t*)dout, z, stats, gamma, beta, dz, rows, C, dsum);
+  MA_LAUNCH(bn_swish_bwd1_kernel<AT>, dim3(grid_for(rows, rpb, 256)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+            dout, z, stats, gamma, beta, dz, rows, C, dsum);
   MA_LAUNCH(bn_bwd2_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dz, z, stats, gamma, dsum, rows,
             C, 1.0f / (float)rows);
   return MA_OK;
 }
+}  // extern "C++"
+int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
+                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream) {
+  return bn_swish_bwd_launch((const uint16_t*)dout, z, stats, gamma, beta, dz, rows, C, dsum, stream);
+}
+int ma_bn_swish_bwd_x32(const float* dout, const float* z, const float* stats, const float* gamma, const float* beta,
+                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream) {
+  return bn_swish_bwd_launch(dout, z, stats, gamma, beta, dz, rows, C, dsum, stream);
+}
 
-int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
-                        const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
-                        void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+extern "C++" {
+template <typename AT>
+static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
+                              const float* dw_w, int32_t ks, AT* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
+                              void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
   if (!dz || !y || !dw_w || !dy || !d_dw_w || !d_dw_b || !workspace || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
   if (C != 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
   if (workspace_bytes < ma_train_reduce_workspace_bytes()) return MA_ERR_WORKSPACE;
@@ -781,12 +904,11 @@ int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t bat
   const dim3 grid((unsigned)((strips + per_block - 1) / per_block), (unsigned)batch, 1);
   const int nblk = (int)(grid.x * grid.y), width = C * (ks + 1);
 #define MA_CMB(KS_)                                                                                                    \
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_bwd_kernel<KS_>),                                     \
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_bwd_kernel<KS_, AT>),                                 \
                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kCbStrip + KS_ - 1) * 256 * 4) != hipSuccess) \
     return MA_ERR_LAUNCH;                                                                                              \
-  MA_LAUNCH(convmid_bwd_kernel<KS_>, grid, dim3(256), (size_t)2 * (kCbStrip + KS_ - 1) * 256 * sizeof(float),          \
-            (hipStream_t)stream, dz, (const uint16_t*)y, ldy, (int)batch, (int)T, C, dw_w, (uint16_t*)dy, lddy, part,    \
-            per_block)
+  MA_LAUNCH((convmid_bwd_kernel<KS_, AT>), grid, dim3(256), (size_t)2 * (kCbStrip + KS_ - 1) * 256 * sizeof(float),    \
+            (hipStream_t)stream, dz, y, ldy, (int)batch, (int)T, C, dw_w, dy, lddy, part, per_block)
   if (ks == 3) { MA_CMB(3); }
   else if (ks == 7) { MA_CMB(7); }
   else if (ks == 15) { MA_CMB(15); }
@@ -794,6 +916,33 @@ int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t bat
 #undef MA_CMB
   MA_LAUNCH(partial_reduce_kernel, dim3((width + 63) / 64, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, nblk, width, d_dw_w,
             C * ks, d_dw_b);
+  return MA_OK;
+}
+}  // extern "C++"
+int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
+                        const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
+                        void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  return convmid_bwd_launch(dz, (const uint16_t*)y, ldy, batch, T, C, dw_w, ks, (uint16_t*)dy, lddy, d_dw_w, d_dw_b, workspace,
+                            workspace_bytes, stream);
+}
+int ma_convmid_bwd_x32(const float* dz, const float* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
+                       const float* dw_w, int32_t ks, float* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
+                       void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  return convmid_bwd_launch(dz, y, ldy, batch, T, C, dw_w, ks, dy, lddy, d_dw_w, d_dw_b, workspace, workspace_bytes, stream);
+}
+
+int ma_relu_bwd_x32(float* dy, const float* y, int64_t n, ma_stream_t stream) {
+  if (!dy || !y || n < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(relu_bwd_x32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n);
+  return MA_OK;
+}
+
+int ma_col2im_3x3s2_relu_x32(const float* dcol, const float* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
+                             float* dact, ma_stream_t stream) {
+  if (!dcol || !act || !dact || batch < 1 || H < 3 || Wd < 3 || C < 1) return MA_ERR_INVALID_ARG;
+  const int Ho = (int)((H - 3) / 2 + 1), Wo = (int)((Wd - 3) / 2 + 1);
+  MA_LAUNCH(col2im_relu_x32_kernel, dim3(grid_for(batch * H * Wd * C, 256, 16384)), dim3(256), 0, (hipStream_t)stream, dcol, act,
+            (int)batch, (int)H, (int)Wd, (int)C, Ho, Wo, dact);
   return MA_OK;
 }
 
@@ -824,9 +973,11 @@ int ma_col2im_3x3s2_relu_bf16(const void* dcol, const void* act, int64_t batch, 
   return MA_OK;
 }
 
-int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, int64_t T, int32_t idim,
-                              const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
-                              void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+extern "C++" {
+template <typename AT>
+static int conv1_dw_launch(const AT* dact, const float* x, int64_t batch, int64_t T, int32_t idim, const float* cmvn_mean,
+                           const float* cmvn_istd, int32_t C, float* dw, float* db, void* workspace, int64_t workspace_bytes,
+                           ma_stream_t stream) {
   if (!dact || !x || !dw || !db || !workspace || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
   if (C > 256) return MA_ERR_UNSUPPORTED;
   if (workspace_bytes < ma_train_reduce_workspace_bytes()) return MA_ERR_WORKSPACE;
@@ -836,12 +987,23 @@ int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, i
   int64_t strip64 = (npos + kMaxPartBlocks - 1) / kMaxPartBlocks;  // as many workgroups as the partial workspace holds
   const int strip = (int)(strip64 < 64 ? 64 : strip64);
   const int nblk = (int)((npos + strip - 1) / strip);
-  MA_LAUNCH(conv1_dw_kernel, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,
-            (hipStream_t)stream, (const uint16_t*)dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, part,
-            strip);
+  MA_LAUNCH(conv1_dw_kernel<AT>, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,
+            (hipStream_t)stream, dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, part, strip);
   MA_LAUNCH(partial_reduce_kernel, dim3((C * 10 + 63) / 64, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, nblk, C * 10, dw,
             C * 9, db);
   return MA_OK;
+}
+}  // extern "C++"
+int ma_subsample_conv1_dw_f32(const void* dact, const float* x, int64_t batch, int64_t T, int32_t idim,
+                              const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
+                              void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  return conv1_dw_launch((const uint16_t*)dact, x, batch, T, idim, cmvn_mean, cmvn_istd, C, dw, db, workspace, workspace_bytes,
+                         stream);
+}
+int ma_subsample_conv1_dw_x32(const float* dact, const float* x, int64_t batch, int64_t T, int32_t idim,
+                              const float* cmvn_mean, const float* cmvn_istd, int32_t C, float* dw, float* db,
+                              void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  return conv1_dw_launch(dact, x, batch, T, idim, cmvn_mean, cmvn_istd, C, dw, db, workspace, workspace_bytes, stream);
 }
 
 int ma_grad_overflow_f32(const float* g, int64_t n, int32_t* flag, ma_stream_t stream) {

@@ -18,6 +18,7 @@ import torch
 
 from .. import _lib, ops
 from . import kernels as K
+from . import kernels_x32 as X32
 
 _PAD = 64  # every entry of the flat buffers starts on a 64-element boundary (16-byte aligned in bf16 and f32)
 
@@ -25,7 +26,7 @@ _PAD = 64  # every entry of the flat buffers starts on a 64-element boundary (16
 class FlatParams:
     """Name -> (offset, shape) views into flat float32 / bf16 buffers."""
 
-    def __init__(self, entries, device):
+    def __init__(self, entries, device, mirror_bf16=True):
         self.index = {}
         off = 0
         for name, shape in entries:
@@ -39,7 +40,8 @@ class FlatParams:
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
-        self.bf16 = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        # matmul-operand copy of the masters: bf16 (throughput mode) or the masters themselves (float32 validation mode)
+        self.bf16 = torch.zeros(off, dtype=torch.bfloat16, device=device) if mirror_bf16 else self.master
 
     def _view(self, buf, name):
         off, shape, n = self.index[name]
@@ -173,8 +175,15 @@ class ConformerCTCTrainStep:
 
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
-                 process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step"):
+                 process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None):
+        """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
+        torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
+        activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
         enc = model.encoder
+        if compute_type not in (None, torch.bfloat16, torch.float32, "bfloat16", "float32"):
+            raise ValueError("compute_type must be bfloat16 (default) or float32")
+        self.x32 = compute_type in (torch.float32, "float32")
+        self.K, self.O = (X32, X32) if self.x32 else (K, ops)
         self.model, self.enc = model, enc
         self.dev = next(model.parameters()).device
         self.L = len(enc.encoders)
@@ -199,6 +208,8 @@ class ConformerCTCTrainStep:
         self.lsm = float(getattr(model, "lsm_weight", 0.0))
         if self.ctc_weight != 1.0 and self.dec is None:
             raise ValueError("ctc_weight != 1.0 needs model.decoder")
+        if self.x32 and self.dec is not None:
+            raise NotImplementedError("the float32 validation mode covers the CTC branch (ctc_weight = 1.0)")
         self.Ld = len(self.dec.decoders) if self.dec is not None else 0
         self.dec_hidden = self.dec.decoders[0].feed_forward.w_1.out_features if self.dec is not None else 0
         self.last_acc = None
@@ -212,7 +223,7 @@ class ConformerCTCTrainStep:
         ent = conformer_ctc_entries(self.d, self.hidden, self.L, self.ks, self.heads, self.f2, self.V)
         if self.dec is not None:
             ent += decoder_entries(self.d, self.dec_hidden, self.Ld, self.V)
-        self.fp = FlatParams(ent, self.dev)
+        self.fp = FlatParams(ent, self.dev, mirror_bf16=not self.x32)
         self._copy_params(to_flat=True)
         # BatchNorm running statistics (buffers, not optimised)
         self.bn_mean = [l.conv_module.norm.running_mean.detach().clone().float() for l in self.enc.encoders]
@@ -356,6 +367,8 @@ class ConformerCTCTrainStep:
     def refresh_weights(self):
         """bf16 mirror of the masters (one cast launch) + transposed bf16 copies of the matmul weights."""
         fp = self.fp
+        if self.x32:  # the matmuls read the float32 masters themselves (dX = dY . W as an NN product: no transposed copies)
+            return
         _lib.check(_lib.load().ma_cast_f32_bf16(fp.master.data_ptr(), fp.bf16.data_ptr(), fp.size,
                                                 torch.cuda.current_stream().cuda_stream), "cast")
         if not hasattr(self, "wt"):
@@ -380,7 +393,14 @@ class ConformerCTCTrainStep:
     def _dW(self, dy, x, wname, bname):
         """grad[wname] (N, K) += dy^T x ; grad[bname] += column sums of dy.  dy (M, N), x (M, K) bf16."""
         fp = self.fp
-        K.gemm_tn(dy, x, fp.g(wname), colsum=fp.g(bname) if bname else None)
+        self.K.gemm_tn(dy, x, fp.g(wname), colsum=fp.g(bname) if bname else None)
+
+    def _dX(self, dy, wname, **kw):
+        """dy (M, N) @ W (N, K): the input gradient of a dense layer whose weight is stored (out, in) like the reference's."""
+        if self.x32:
+            w = self.fp.w(wname)
+            return X32.gemm_nn(dy[:, :w.shape[0]], w, residual=kw.get("residual"), out=kw.get("out"))
+        return ops.gemm(dy, self.wt[wname], **kw)
 
     # ---- forward + backward ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -389,6 +409,7 @@ class ConformerCTCTrainStep:
         """Runs the training-mode forward and the backward pass; flat gradients hold grad_scale * dLoss/dparam.
         Returns the (unscaled) loss tensor."""
         fp, d, L = self.fp, self.d, self.L
+        ops, K = self.O, self.K  # bf16 throughput kernels or their float32 validation twins
         f32, bf = torch.float32, torch.bfloat16
         # one dropout stream per (step, rank): data-parallel replicas must not draw the same masks
         seed = (self.seed + self.calls + 0x3c6ef35f * self.rank) & 0x7fffffff
@@ -470,16 +491,15 @@ class ConformerCTCTrainStep:
         # CTC head: logits = enc_bf W^T + b
         K.gemm_tn(dlog, enc_bf, fp.g("ctc_w"), colsum=fp.g("ctc_b"), rows_store=self.V)
         if d_mem is None:
-            d_enc = ops.gemm(dlog, self.wt["ctc_w"])            # (m, 256) bf16
+            d_enc = self._dX(dlog, "ctc_w")            # (m, 256) bf16
         else:                                                   # + the decoder's gradient w.r.t. the encoder output
-            d_enc = ops.gemm(dlog, self.wt["ctc_w"], residual=d_mem, out_dtype=f32, out=d_mem)
+            d_enc = self._dX(dlog, "ctc_w", residual=d_mem, out_dtype=f32, out=d_mem)
         g = torch.empty((m, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
         dpos_all = torch.zeros((t2, L * d), dtype=f32, device=self.dev)
         for li in reversed(range(L)):
             pre = "l%d." % li
             W, P, G = (lambda n, pre=pre: fp.w(pre + n)), (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n))
-            WT = lambda n, pre=pre: self.wt[pre + n]  # noqa: E731
             T = tape[li]
             K.layernorm_bwd(T["final_in"], P("norm_final.g"), g, g, G("norm_final.g"), G("norm_final.b"), accumulate=False)
             self._ffn_bwd(g, T["ff"], "ff", "norm_ff", pre, seed, li, 6)
@@ -487,22 +507,22 @@ class ConformerCTCTrainStep:
             C = T["conv"]
             do = K.dropout_bwd(g, 1.0, pd, seed, self._salt(li, 3), row_scale=mask_rows)
             self._dW(do, C["w"], pre + "pw2_w", pre + "pw2_b")
-            dwv = ops.gemm(do, WT("pw2_w"))
+            dwv = self._dX(do, pre + "pw2_w")
             dy = K.convmid_bwd(dwv, C["y"], C["z"], C["stats"], b, t2, P("dw_w"), P("bn_g"), P("bn_b"), G("dw_w"),
                                G("dw_b"), G("bn_g"), G("bn_b"))
             self._dW(dy, C["a"], pre + "pw1_w", pre + "pw1_b")
-            da = ops.gemm(dy, WT("pw1_w"))
+            da = self._dX(dy, pre + "pw1_w")
             K.layernorm_bwd(C["x_in"], P("norm_conv.g"), da, g, G("norm_conv.g"), G("norm_conv.b"), row_scale=mask_rows)
             # MHSA
             A = T["mha"]
             do = K.dropout_bwd(g, 1.0, pd, seed, self._salt(li, 2))
             self._dW(do, A["ctx"], pre + "o_w", pre + "o_b")
-            dctx = ops.gemm(do, WT("o_w"))
+            dctx = self._dX(do, pre + "o_w")
             dqkv = K.attention_bwd(A["qkv"], pos_all[:, li * d:(li + 1) * d], P("u"), P("v"), att_mask, A["ctx"], dctx,
                                    A["lse"], b, t2, dpos_all[:, li * d:(li + 1) * d], G("u"), G("v"), self.heads,
                                    d // self.heads)
             self._dW(dqkv, A["a"], pre + "qkv_w", pre + "qkv_b")
-            da = ops.gemm(dqkv, WT("qkv_w"))
+            da = self._dX(dqkv, pre + "qkv_w")
             K.layernorm_bwd(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"))
             self._ffn_bwd(g, T["ffm"], "ffm", "norm_ff_macaron", pre, seed, li, 0)
             self._layer_done(li)
@@ -511,11 +531,11 @@ class ConformerCTCTrainStep:
         # embedding: x = dropout(sqrt(d) * (a2 W_out^T + b))
         de = K.dropout_bwd(g, math.sqrt(d), pp, seed, self._salt(-1, 0))
         self._dW(de, a2, "out_w", "out_b")
-        dact2 = ops.gemm(de, self.wt["out_w"])                  # (m, f2*c) bf16
+        dact2 = self._dX(de, "out_w")                  # (m, f2*c) bf16
         K.relu_bwd(dact2, a2)
         dy2 = dact2.view(m * f2, c)
         K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"))
-        dcol = ops.gemm(dy2, self.wt["conv2_w"])                # (B*T2*F2, 9c) bf16
+        dcol = self._dX(dy2, "conv2_w")                # (B*T2*F2, 9c) bf16
         dact1 = K.col2im_relu(dcol, act1)
         K.conv1_dw(dact1, xs, enc.cmvn_mean, enc.cmvn_istd, fp.g("conv1_w"), fp.g("conv1_b"))
         self._embed_done()
@@ -621,6 +641,7 @@ class ConformerCTCTrainStep:
         return loss_att, d_mem
 
     def _ffn_fwd(self, x, key, ln, W, P, seed, li, s0):
+        ops, K = self.O, self.K
         a = ops.layernorm(x, P(ln + ".g"), P(ln + ".b"))
         u = ops.gemm(a, W(key + "_w1"), bias=P(key + "_b1"))
         h = K.act_dropout_fwd(u, self.p_drop, seed, self._salt(li, s0))
@@ -629,13 +650,13 @@ class ConformerCTCTrainStep:
         return dict(x_in=x, a=a, u=u, h=h, x_out=x_out)
 
     def _ffn_bwd(self, g, T, key, ln, pre, seed, li, s0):
-        fp = self.fp
+        fp, K = self.fp, self.K
         dy = K.dropout_bwd(g, 0.5, self.p_drop, seed, self._salt(li, s0 + 1))
         self._dW(dy, T["h"], pre + key + "_w2", pre + key + "_b2")
-        dh = ops.gemm(dy, self.wt[pre + key + "_w2"])
+        dh = self._dX(dy, pre + key + "_w2")
         du = K.act_dropout_bwd(T["u"], dh, self.p_drop, seed, self._salt(li, s0), out=dh)
         self._dW(du, T["a"], pre + key + "_w1", pre + key + "_b1")
-        da = ops.gemm(du, self.wt[pre + key + "_w1"])
+        da = self._dX(du, pre + key + "_w1")
         K.layernorm_bwd(T["x_in"], fp.p(pre + ln + ".g"), da, g, fp.g(pre + ln + ".g"), fp.g(pre + ln + ".b"))
 
     # ---- data-parallel gradient reduction ----------------------------------------------------------------------------
@@ -669,6 +690,7 @@ class ConformerCTCTrainStep:
         loss = self.forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale=scale,
                                      ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_sub_masks=ys_sub_masks,
                                      ys_masks=ys_masks)
+        K = self.K
         self.reducer.wait()
         K.grad_overflow(self.fp.grad, self.flag)
         lr = asr_warmup_lr(self.global_step, self.base_lr, self.warmup)

@@ -97,11 +97,45 @@ def test_forward_backward_matches_oracle_autograd():
         assert rel_rms(v_, l_ref.conv_module.norm.running_var) < 2e-2
 
 
+def test_float32_mode_gradients_match_oracle_autograd_tightly():
+    """compute_type=float32 (the reference's default, models/conformer.py:61): same tape and backward as the bf16 mode, float32
+    activations and products -> every parameter gradient within 2e-4 of PyTorch-CPU float32 autograd of the oracle (the bf16
+    mode's bound above is 6e-2)."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    ref_enc, ref_ctc, model = build()
+    xs, ys, sub, ys_lens = batch()
+    loss_ref = oracle_loss(ref_enc, ref_ctc, xs, ys, sub, ys_lens)
+    loss_ref.backward()
+    eng = ConformerCTCTrainStep(model, dropout_rate=0.0, positional_dropout_rate=0.0, compute_type=torch.float32)
+    loss = eng.forward_backward(xs.cuda(), ys.cuda(), sub.cuda(), ys_lens.cuda(), grad_scale=1.0)
+    assert abs(float(loss) - float(loss_ref.detach())) <= 2e-6 * abs(float(loss_ref.detach()))
+    grads = eng.gradients()
+    want = {"encoder." + n: p.grad for n, p in ref_enc.named_parameters()}
+    want.update({"ctc." + n: p.grad for n, p in ref_ctc.named_parameters()})
+    assert set(grads) == set(want)
+    gmax = float(max(p.abs().max() for p in want.values()))
+    worst = {}
+    for name, gw in want.items():
+        if "depthwise_conv.bias" in name or "linear_k.bias" in name:  # identically zero: float32 noise on both sides
+            assert float(grads[name].abs().max()) < 1e-5 * gmax
+            continue
+        worst[name] = rel_rms(grads[name], gw)
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    print("float32 mode: worst per-tensor relative gradient error %.2e" % max(worst.values()))
+    assert not bad, bad
+    for l_ref, m_, v_ in zip(ref_enc.encoders, eng.bn_mean, eng.bn_var):
+        assert rel_rms(m_, l_ref.conv_module.norm.running_mean) < 1e-5
+        assert rel_rms(v_, l_ref.conv_module.norm.running_var) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["bf16", "float32"])
 @pytest.mark.parametrize("n_steps", [6, 50])
-def test_train_steps_follow_the_oracle_loss_curve(n_steps):
+def test_train_steps_follow_the_oracle_loss_curve(n_steps, mode):
     """Optimizer steps on one batch: Adam + ASRWarmupLR + dynamic loss scale vs the same recipe in PyTorch (float32 oracle).
-    SURVEY 8d asks for >= 50 steps; the device path multiplies in bf16 (the reference's own compute_type is float16), so the
-    curves agree to bf16 round-off, not to 1e-4: the measured deviation is asserted and reported."""
+    SURVEY 8d / north_star: >= 50 steps within 1e-4.  compute_type=float32 (the reference's default) meets it; the bf16
+    throughput mode (the reference's own mixed-precision compute_type is float16) follows the curve to bf16 round-off, and its
+    measured deviation is asserted and reported."""
     from mindaudio_amd.train.engine import ConformerCTCTrainStep, asr_warmup_lr
 
     ref_enc, ref_ctc, model = build(seed=6, cmvn=False)
@@ -111,7 +145,8 @@ def test_train_steps_follow_the_oracle_loss_curve(n_steps):
     # 6 steps at an aggressive rate (the loss falls 4x: every part of the update rule matters); 50 steps at a gentle one, where
     # two trajectories that differ by bf16 round-off stay comparable instead of diverging chaotically
     warm, base = (8, 2e-3) if n_steps == 6 else (25, 2e-4)
-    eng = ConformerCTCTrainStep(model, base_lr=base, warmup_steps=warm, dropout_rate=0.0, positional_dropout_rate=0.0)
+    eng = ConformerCTCTrainStep(model, base_lr=base, warmup_steps=warm, dropout_rate=0.0, positional_dropout_rate=0.0,
+                                compute_type=torch.float32 if mode == "float32" else None)
     cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
     got, want = [], []
     for step in range(n_steps):
@@ -128,8 +163,12 @@ def test_train_steps_follow_the_oracle_loss_curve(n_steps):
         got.append(float(loss))
     assert want[-1] < want[0]  # the recipe learns on this batch
     dev = max(abs(a - b_) / abs(b_) for a, b_ in zip(got, want))
-    print("loss curve over %d steps: %.3f -> %.3f, max relative deviation from the float32 oracle %.2e" % (n_steps, want[0], want[-1], dev))
-    tol = 3e-2 if n_steps == 6 else 5e-3  # measured: 8e-3 / 1.3e-3
+    print("%s loss curve over %d steps: %.3f -> %.3f, max relative deviation from the float32 oracle %.2e"
+          % (mode, n_steps, want[0], want[-1], dev))
+    if mode == "float32":
+        tol = 1e-4                           # the north-star tolerance
+    else:
+        tol = 3e-2 if n_steps == 6 else 5e-3  # bf16 matmuls, measured: 8e-3 / 1.3e-3
     for a, b_ in zip(got, want):
         assert abs(a - b_) <= tol * abs(b_), (got, want)
     # lr is 0 at step 0 (scheduler_factory.py:44-50): the first step must not move the weights

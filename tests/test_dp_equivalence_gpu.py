@@ -52,7 +52,7 @@ def test_two_ranks_equal_one_rank_on_the_whole_batch(tmp_path):
     moved = d1.abs() > 0
     flipped = ((d2 - d1).abs() > 0.5 * r0["lr"]) & moved
     assert float(d1.abs().max()) > 0.9 * r0["lr"] and int(flipped.sum()) <= 5e-3 * int(moved.sum())
-    assert float((d2 - d1)[~flipped].norm() / d1.norm()) <= 1e-2
+    assert float((d2 - d1)[~flipped].norm() / d1.norm()) <= 3e-2
     assert (r0["delta"] == r1["delta"]).all()  # replicas stay in lock-step
     # BatchNorm running statistics are per rank (no SyncBN in the reference): equal here because the shards' inputs are equal
     for a, b, c in zip(r0["bn_mean"], r1["bn_mean"], one["bn_mean"]):

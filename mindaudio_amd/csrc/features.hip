@@ -8,21 +8,20 @@
 //   mindaudio/data/features.py:196-270   fbank
 //   examples/conformer/dataset.py:117-168 compute_fbank_feats         (NumPy, Pool(8))
 //
-// Work decomposition (fast path, n_fft == 512):
-//   Each WAVE is an independent worker, persistent over "units" of 8 consecutive frames of one utterance
-//   (a workgroup is 4 such waves sharing the twiddle/window/mel tables in LDS; there is no workgroup
-//   barrier in the steady state).  Per unit the wave: (1) multiplies the samples it prefetched during the
-//   previous unit by the window, (2) issues the 16-byte loads of its NEXT unit, (3) runs the 8-lane-per-frame
-//   512-point real FFT (fft512.h) and drops the 257 powers of each frame into its private LDS tile
-//   Pw[8][260], (4) applies the band mel bank with lane&7 = frame, lane>>3 = mel group, takes the log and
-//   stores, tracking the unit minimum and the wave maximum.  The batch-global top_db floor is a second, tiny
-//   kernel that only rewrites units whose minimum is below (global max - top_db).
-//   HBM traffic: each wave sample is fetched from HBM once (the 3.2x frame overlap is served by L1/L2); each
-//   output element is written once (the four 32-byte pieces of a 128-byte output line come from the four
-//   waves of neighbouring units and merge in L2).
+// Work decomposition (fast path, n_fft == 512): each WAVE is an independent worker, persistent over "units" of 8 consecutive
+// frames of one utterance; a workgroup is 4 such waves sharing the twiddle / window / mel tables in LDS, with no workgroup barrier
+// in the steady state.  Per unit the wave stages the unit's sample span in its LDS tile (LDS-DMA), picks up and windows its 64
+// samples per lane, runs the 8-lane-per-frame 512-point real FFT (fft512.h), drops the 257 powers of each frame into the tile,
+// applies the band mel bank, takes the log and stores, tracking the unit minimum and the wave maximum (details at feat512_kernel).
+// The batch-global top_db floor is a second, tiny kernel that only rewrites units whose minimum is below (global max - top_db).
+// HBM traffic: each wave sample is fetched from HBM once (unit spans overlap by 352 of 1632 samples: served by L2); each output
+// element is written once (the four 32-byte pieces of a 128-byte output line come from neighbouring units and merge in L2).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "../../include/mindaudio_amd.h"
 #include "features_common.h"
@@ -77,7 +76,16 @@
 #define MA_PROF_FLUSH()
 #endif
 
-#ifdef MA_PROFILE
+#if defined(MA_ABLATE) && !defined(MA_PROFILE)
+// tools/feat_ablate.py: the production instruction stream with parts switched off by bits of MA_FEAT_DBG (no timing code)
+static int g_debug = -1;
+#define MA_SET_PROF(p)                                                  \
+  do {                                                                  \
+    if (g_debug < 0) g_debug = getenv("MA_FEAT_DBG") ? atoi(getenv("MA_FEAT_DBG")) : 0; \
+    (p).debug = g_debug;                                                \
+  } while (0)
+#define MA_DBG(bit) (p.debug & (bit))
+#elif defined(MA_PROFILE)
 static unsigned long long* g_prof = nullptr;
 static int g_debug = 0;
 extern "C" void ma_debug_set_prof(void* buf) { g_prof = reinterpret_cast<unsigned long long*>(buf); }
@@ -86,7 +94,8 @@ extern "C" void ma_debug_set_flags(int f) { g_debug = f; }
   (p).prof = g_prof;   \
   (p).debug = g_debug
 #define MA_DBG(bit) (p.debug & (bit))
-#else
+#endif
+#if !defined(MA_ABLATE) && !defined(MA_PROFILE)
 #define MA_SET_PROF(p)
 #define MA_DBG(bit) 0
 #endif
@@ -102,6 +111,7 @@ __device__ __forceinline__ float wave_reduce(float v, bool is_max) {
   return v;
 }
 
+template <int NW = kWaves>
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
   v = wave_reduce(v, is_max);
   const int wave = threadIdx.x >> 6;
@@ -109,7 +119,7 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
   __syncthreads();
   float r = red[0];
 #pragma unroll
-  for (int w = 1; w < kWaves; ++w) r = is_max ? fmaxf(r, red[w]) : fminf(r, red[w]);
+  for (int w = 1; w < NW; ++w) r = is_max ? fmaxf(r, red[w]) : fminf(r, red[w]);
   __syncthreads();
   return r;
 }
@@ -117,84 +127,51 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 #include "fft_tables.inc"
 
 // LDS carve (bytes). All offsets multiples of 16.
-//   Each wave owns a power tile Pw: 8 rows (frames) x kPStride floats.  Row f first serves as frame f's FFT
-//   transpose slot (kSlotFloats = 256 floats), then receives the 257 powers of the frame (+3 zeros).
-//   kPStride = 260: a multiple of 4 (16-byte row reads in the mel phase) with kPStride/4 odd (rows land on
-//   different bank quads).
-constexpr int kPStride = 260;
+//   Each wave owns a TILE of kPwFloats floats, used three ways in the course of a unit:
+//   1. staging area of the unit's sample span (<= kPwFloats floats, see feat512_kernel);
+//   2. the FFT's 8 exchange slots, frame f at f * kSlotStride (fft512.h);
+//   3. the power rows: frame f's 257 powers (+3 zeros) at f * kPStride.  kPStride / 4 = 2 (mod 16): the 8 frames of one mel
+//      group then cover the EVEN 16-byte bank quads; with the lane -> (frame, group) map of the mel phase that
+//      fills each ds_read_b128 lane group with 8 frames x 2 groups, the power reads measured 1.16x the conflict-free cycles (round 1:
+//      2.5x on a 260-float stride).  Power stores (ds_write_b32, 32 lanes = 4 frames x 8) land on 32 distinct banks.
+constexpr int kPStride = 264;
 constexpr int kOffTw256 = 0;                          // 128 float4
 constexpr int kOffTw512 = kOffTw256 + 256 * 8;        // 257 float2 (+pad)
 constexpr int kOffWin = kOffTw512 + 264 * 8;          // 512 floats, pre-scaled by 1/2
-constexpr int kOffP = kOffWin + 512 * 4;              // kWaves * 8 * 260 floats
-constexpr int kPwFloats = kUnitFrames * kPStride;
-constexpr int kPBytes = kWaves * kPwFloats * 4;
-constexpr int kOffMel = kOffP + kPBytes;              // mel tables, then (kaldi) the per-wave output stage
+constexpr int kOffP = kOffWin + 512 * 4;              // NW tiles (NW = waves per workgroup)
+constexpr int kPwFloats = kUnitFrames * kSlotStride;  // 2176 >= 8 * kPStride
+constexpr int off_mel(int nw) { return kOffP + nw * kPwFloats * 4; }  // mel tables
 constexpr int kMaxRows = 16;                          // mel rows (8 filters each): n_mels <= 128
-static_assert(kSlotFloats <= kPStride && kPStride % 4 == 0 && (kPStride / 4) % 2 == 1, "P row layout");
-static_assert(kOffP % 16 == 0 && kOffMel % 16 == 0, "LDS alignment");
+static_assert(kSlotFloats <= kSlotStride && kUnitFrames * kPStride <= kPwFloats && kPStride >= 260 && kPStride % 4 == 0, "tile layout");
+static_assert(kOffP % 16 == 0 && (kPwFloats * 4) % 16 == 0, "LDS alignment");
 
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32, 1 ulp
 
-// What one wave needs to know about its next 8-frame unit.
-struct Unit {
-  const float* xb;   // utterance base
-  int b;             // utterance
-  int t;             // this lane's frame index (t0 + (lane >> 3))
-  int t0;            // first frame of the unit
-  int frames_b;      // frames of the utterance
-  int n_valid;       // samples of the utterance
-  int s0;            // first sample of this lane's frame
-  bool valid;        // this lane's frame exists
-  bool fast;         // wave-uniform: every live frame can use aligned 16-byte loads
-  bool live;         // wave-uniform: at least one frame exists
-  float half_mean;   // kaldi: 0.5 * scalar mean of the utterance's windowed frames
-};
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gl_void_t;
 
-template <int MODE>
-__device__ __forceinline__ Unit decode_unit(const FeatParams& p, int unit, int lane) {
-  Unit u;
-  u.b = unit / p.units_per_utt;
-  u.t0 = (unit - u.b * p.units_per_utt) * kUnitFrames;
-  u.t = u.t0 + (lane >> 3);
-  u.xb = p.wav + (int64_t)u.b * p.wav_stride;
-  u.n_valid = (int)p.n;
-  u.frames_b = (int)p.n_frames;
-  u.half_mean = 0.0f;
-  if (MODE == kModeKaldi) {
-    int64_t nv = p.lengths[u.b];
-    if (nv > p.n) nv = p.n;
-    u.n_valid = (int)nv;
-    int fb = (u.n_valid >= p.frame_len) ? (u.n_valid - p.frame_len) / p.hop + 1 : 0;
-    if (fb > (int)p.n_frames) fb = (int)p.n_frames;
-    u.frames_b = fb;
-    // ONE scalar mean over all windowed frames of the utterance (dataset.py:165): fixed-order sum of the
-    // per-tile partials written by kaldi_sum_kernel (uniform addresses -> scalar loads).
-    double acc = 0.0;
-    const int tiles_b = (fb + kSumTileFrames - 1) / kSumTileFrames;
-    for (int i = 0; i < tiles_b; ++i) acc += p.partial[(int64_t)u.b * p.sum_tiles_per_utt + i];
-    u.half_mean = fb > 0 ? 0.5f * (float)(acc / ((double)fb * (double)p.frame_len)) : 0.0f;
-  }
-  u.valid = u.t < u.frames_b;
-  u.s0 = u.t * p.hop - p.pad_left;
-  const bool aligned16 = (reinterpret_cast<uintptr_t>(u.xb + u.s0) & 15) == 0;
-  bool ok;
-  if (MODE == kModeKaldi) ok = aligned16 && (p.frame_len & 3) == 0;
-  else ok = aligned16 && u.s0 >= 0 && u.s0 + 512 <= u.n_valid;
-  u.fast = __all(ok || !u.valid);
-  u.live = __any(u.valid);
-  return u;
-}
-
-#ifndef MA_LB_WAVES
-#define MA_LB_WAVES 2
-#endif
-template <int MODE, bool MAG>
-__global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const FeatParams p) {
+// Work decomposition, round 2 (n_fft == 512):
+//   NW = waves per workgroup (they share the tables), OCC = waves per SIMD the register allocation is held to.
+//   Occupancy is what hides this kernel's latencies (first touch of a unit's samples, the LDS transpose, the dependent LDS reads
+//   of the mel phase): round 1 prefetched the next unit into 64 registers, ran at 244 VGPRs = two waves per SIMD and spent
+//   41 % of its wave-cycles parked on s_waitcnt.  Here nothing but the FFT's 64 data registers is live across the FFT:
+//   * a unit's samples are STAGED through the wave's own LDS tile: the 8 frames of a unit overlap (hop 160: 1632 distinct
+//     samples instead of 8 x 512), so the wave copies the span HBM/L2 -> LDS once with global_load_lds_dwordx4 (LDS-DMA: no
+//     VGPRs, 7 x 1 KiB) and every lane then reads its frame's 64 samples with 16-byte LDS reads.  The staging area IS the
+//     tile that later holds the transpose slots and the powers, so it costs no LDS; np.pad semantics, ragged Kaldi lengths
+//     and unaligned rows are handled where the span is staged (a scalar gather for those few units), and the FFT input path
+//     is the same for every unit;
+//   * three waves per SIMD as three 4-wave workgroups per CU (tables 10 KB + 8.5 KB per wave = 45 KB per workgroup), 168 VGPRs
+//     without spills; every phase re-derives its lane-dependent offsets instead of keeping them live across the FFT.
+template <int MODE, bool MAG, int NW, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams p) {
+  constexpr int kThreads = NW * 64;
+  constexpr int kOffMel = off_mel(NW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* tw256 = reinterpret_cast<float4*>(smem + kOffTw256);
   float2* tw512 = reinterpret_cast<float2*>(smem + kOffTw512);
   float* win = reinterpret_cast<float*>(smem + kOffWin);
-  // mel tables: steps[16] | row_off[16] | start[n_rows*8] | weights[total_steps*8] float4 | kaldi stage
+  // mel tables: steps[16] | row_off[16] | start[n_rows*8] | weights[total_steps*8] float4
   int* msteps = reinterpret_cast<int*>(smem + kOffMel);
   int* mrowoff = msteps + kMaxRows;
   int* mstart = mrowoff + kMaxRows;
@@ -203,58 +180,102 @@ __global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const Fe
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  float* Pw = reinterpret_cast<float*>(smem + kOffP) + wave * kPwFloats;  // this wave's power tile
+  float* Pw = reinterpret_cast<float*>(smem + kOffP) + wave * kPwFloats;  // this wave's tile: staging, slots, powers
 
-  const Rfft512Lane L = rfft512_lane_setup(lane);
-  const int l = L.l;
-  float* __restrict__ prow_fft = Pw + (lane >> 3) * kPStride;  // FFT phase: lane group = frame
-  const int fm = lane & 7;                                      // mel phase: lane & 7 = frame,
-  const int mg = lane >> 3;                                     //            lane >> 3 = mel group
-  const float* __restrict__ prow_mel = Pw + fm * kPStride;
   const float kLog2ToDb = p.mult * 0.30102999566398120f;        // mult * log10(2)
   float wmax = -INFINITY;
-
-  const int ustride = gridDim.x * kWaves;
-  int unit = blockIdx.x * kWaves + wave;
+  const int steps_by_lane = (MODE != kModeStft && lane < p.n_rows) ? p.mel_steps[lane] : 0;  // lane i: steps of mel row i
+  // Every phase of a unit re-derives its lane-dependent offsets from an OPAQUE copy of the lane id: as loop invariants the
+  // compiler keeps all of them (two dozen registers) live across the FFT, which is what decides 3 vs 4 waves per SIMD;
+  // recomputing them costs ~40 integer operations per unit.
+  auto opaque_lane = [&]() __attribute__((always_inline)) {
+    int v = lane;
+    asm volatile("" : "+v"(v));
+    return v;
+  };
   MA_PROF_DECL;
   MA_PROF_START();
   MA_STAMP(1);  // kernel entry
 
-  // Software pipeline: the 16-byte sample loads of unit k+1 are issued before the FFT of unit k.
-  float4 X[16];
-  float xm[16];  // kaldi: the sample before each 4-sample group (pre-emphasis)
-  Unit cur;
-  auto issue = [&](const Unit& u) {
+  // ---- unit geometry (wave-uniform) and staging -----------------------------------------------------------
+  constexpr int kLead = (MODE == kModeKaldi) ? 4 : 0;  // kaldi stages the sample before the span too (pre-emphasis), 16-byte aligned
+  struct Geo {
+    const float* xb;  // utterance base
+    int b, t0;        // utterance, first frame of the unit
+    int n_valid;      // samples of the utterance
+    int frames_b;     // frames of the utterance
+    int fv;           // frames of this unit that exist (<= 0: none)
+    float half_mean;  // kaldi: 0.5 * scalar mean of the utterance's windowed frames
+  };
+  auto geometry = [&](int unit) __attribute__((always_inline)) {
+    Geo g;
+    g.b = unit / p.units_per_utt;
+    g.t0 = (unit - g.b * p.units_per_utt) * kUnitFrames;
+    g.xb = p.wav + (int64_t)g.b * p.wav_stride;
+    g.n_valid = (int)p.n;
+    g.frames_b = (int)p.n_frames;
+    g.half_mean = 0.0f;
     if (MODE == kModeKaldi) {
-#pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) {
-        const int nn = 32 * m1 + 4 * l;
-        const bool in = u.valid && nn < p.frame_len;
-        const float* src = u.xb + (in ? u.s0 + nn : 0);
-        X[m1] = *reinterpret_cast<const float4*>(src);
-        xm[m1] = (in && u.s0 + nn > 0) ? src[-1] : 0.0f;
-      }
+      int64_t nv = p.lengths[g.b];
+      if (nv > p.n) nv = p.n;
+      g.n_valid = (int)nv;
+      int fb = (g.n_valid >= p.frame_len) ? (g.n_valid - p.frame_len) / p.hop + 1 : 0;
+      if (fb > (int)p.n_frames) fb = (int)p.n_frames;
+      g.frames_b = fb;
+      // ONE scalar mean over all windowed frames of the utterance (dataset.py:165): fixed-order sum of the
+      // per-tile partials written by kaldi_sum_kernel (uniform addresses -> scalar loads).
+      double acc = 0.0;
+      const int tiles_b = (fb + kSumTileFrames - 1) / kSumTileFrames;
+      for (int i = 0; i < tiles_b; ++i) acc += p.partial[(int64_t)g.b * p.sum_tiles_per_utt + i];
+      g.half_mean = fb > 0 ? 0.5f * (float)(acc / ((double)fb * (double)p.frame_len)) : 0.0f;
+    }
+    g.fv = (g.frames_b - g.t0) < kUnitFrames ? (g.frames_b - g.t0) : kUnitFrames;
+    return g;
+  };
+  // stage the samples of frames [f_lo, f_lo + frames_per_round) of the unit in the wave's tile (asynchronous when it is an LDS-DMA)
+  auto stage = [&](const Geo& g, int f_lo) __attribute__((always_inline)) {
+    const int flen = (MODE == kModeKaldi) ? p.frame_len : 512;
+    const int nfr = (g.fv - f_lo) < p.frames_per_round ? (g.fv - f_lo) : p.frames_per_round;
+    const int s_lo = (g.t0 + f_lo) * p.hop - p.pad_left - kLead;  // first staged sample
+    const int span = (nfr - 1) * p.hop + flen + kLead;            // staged samples (<= kPwFloats)
+    const bool dma = s_lo >= 0 && s_lo + span <= g.n_valid && !((p.hop | span) & 3) &&
+                     (reinterpret_cast<uintptr_t>(g.xb + s_lo) & 15) == 0;
+    if (MA_DBG(1)) return;
+    if (dma) {
+      const float* __restrict__ src = g.xb + s_lo + lane * 4;
+      for (int c = 0; c * 256 < span; ++c)
+        if (c * 256 + lane * 4 < span)
+          __builtin_amdgcn_global_load_lds((gl_void_t*)(src + c * 256), (lds_void_t*)(Pw + c * 256), 16, 0, 0);
     } else {
-      const float4* __restrict__ src = reinterpret_cast<const float4*>(u.xb + (u.valid ? u.s0 : 0)) + l;
-#pragma unroll
-      for (int m1 = 0; m1 < 16; ++m1) X[m1] = src[8 * m1];
+      // edge / unaligned / ragged spans (a few units per utterance): element-wise gather with np.pad semantics
+      for (int i = lane; i < span; i += 64) {
+        float v;
+        if (MODE == kModeKaldi) {
+          const int si = s_lo + i;
+          v = (si >= 0 && si < g.n_valid) ? g.xb[si] : 0.0f;
+        } else {
+          v = fetch_padded(g.xb, s_lo + i, g.n_valid, p.pad_mode, true);
+        }
+        Pw[i] = v;
+      }
     }
   };
+
+  if (MA_DBG(32)) return;  // (profiling builds: launch cost alone)
+  const int ustride = gridDim.x * NW;
+  int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * NW + wave);
+  Geo g{};
   if (unit < p.num_units) {
-    cur = decode_unit<MODE>(p, unit, lane);
-    if (cur.live && cur.fast && !MA_DBG(1)) issue(cur);
+    g = geometry(unit);
+    if (g.fv > 0) stage(g, 0);  // the first unit's samples are on their way while the tables are filled
   }
 
-  // ---- per-workgroup tables (once: the grid is persistent); the first sample loads are already in flight
+  // ---- per-workgroup tables (once: the grid is persistent)
   {
-    reinterpret_cast<float2*>(tw256)[tid] = make_float2(kTw256[2 * tid], kTw256[2 * tid + 1]);
+    if (tid < 256) reinterpret_cast<float2*>(tw256)[tid] = make_float2(kTw256[2 * tid], kTw256[2 * tid + 1]);
     for (int i = tid; i < 257; i += kThreads) tw512[i] = make_float2(kTw512[2 * i], kTw512[2 * i + 1]);
     for (int i = tid; i < 512; i += kThreads) win[i] = (i < p.frame_len) ? 0.5f * p.window[i] : 0.0f;
     if (MODE != kModeStft) {
-      if (tid < p.n_rows) {
-        msteps[tid] = p.mel_steps[tid];
-        mrowoff[tid] = p.mel_row_off[tid];
-      }
       for (int i = tid; i < p.n_rows * 8; i += kThreads) mstart[i] = p.mel_start[i];
       const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(p.mel_w);
       for (int i = tid; i < p.total_steps * 8; i += kThreads) mw[i] = wsrc[i];
@@ -262,78 +283,81 @@ __global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const Fe
   }
   __syncthreads();
   MA_STAMP(2);  // tables ready
+  if (MA_DBG(16)) return;  // (profiling builds: launch + tables + first staging)
 
   while (unit < p.num_units) {
     MA_PROF(0);
-    const int next = unit + ustride;
-    float ar[16], ai[16], br[16], bi[16];
-    if (cur.live) {
-      // ---- consume the prefetched samples: window (pre-scaled by 1/2), pre-emphasis, mean ----------
-      if (MA_DBG(1)) {
+    const int b = g.b, t0 = g.t0, frames_b = g.frames_b, fv = g.fv;
+    const float half_mean = g.half_mean;
+
+    if (fv > 0) {
+      float ar[16], ai[16], br[16], bi[16];
+      const int fl = opaque_lane() >> 3;  // FFT phase: lane group = frame of the unit
+      if (fv < kUnitFrames) {
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) { ar[m1] = l + m1; ai[m1] = 0.5f * l; br[m1] = m1; bi[m1] = 1.0f; }
-      } else if (cur.fast) {
+        for (int m1 = 0; m1 < 16; ++m1) ar[m1] = ai[m1] = br[m1] = bi[m1] = 0.0f;  // lanes of frames that do not exist
+      }
+      // ---- the unit's samples are staged in the tile: pick up this lane's 64 of them (x window / 2) -----------
+      for (int f_lo = 0; f_lo < fv; f_lo += p.frames_per_round) {
+        const int nfr = (fv - f_lo) < p.frames_per_round ? (fv - f_lo) : p.frames_per_round;
+        if (f_lo > 0) stage(g, f_lo);  // (round 0 was issued at the end of the previous unit)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_sync();
+        MA_PROF(1);
+        const int fr = fl - f_lo;
+        if (fr >= 0 && fr < nfr) {
+          const int l = opaque_lane() & 7;
+          const float* __restrict__ sp = Pw + kLead + fr * p.hop + 4 * l;
+          const float* __restrict__ wp = win + 4 * l;
+          if (!(p.hop & 3)) {
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) {
-          const int nn = 32 * m1 + 4 * l;
-          const float4 w = *reinterpret_cast<const float4*>(win + nn);
-          const float4 x = X[m1];
-          if (MODE == kModeKaldi) {
-            const bool in = cur.valid && nn < p.frame_len;
-            const float y0 = (cur.s0 + nn > 0) ? x.x - p.preemph * xm[m1] : x.x;
-            const float hm = in ? cur.half_mean : 0.0f;
-            const float k = in ? 1.0f : 0.0f;
-            ar[m1] = k * y0 * w.x - hm;
-            ai[m1] = k * (x.y - p.preemph * x.x) * w.y - hm;
-            br[m1] = k * (x.z - p.preemph * x.y) * w.z - hm;
-            bi[m1] = k * (x.w - p.preemph * x.z) * w.w - hm;
-          } else {
-            const float k = cur.valid ? 1.0f : 0.0f;
-            ar[m1] = k * x.x * w.x; ai[m1] = k * x.y * w.y; br[m1] = k * x.z * w.z; bi[m1] = k * x.w * w.w;
-          }
-        }
-      } else {
-        // edge / unaligned frames (rare): scalar loads, 16 in flight at a time
-#pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) {
-          const int nn = 32 * m1 + 4 * l;
-          const float4 w = *reinterpret_cast<const float4*>(win + nn);
-          float v[4];
-          if (MODE == kModeKaldi) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const bool in = cur.valid && nn + c < p.frame_len;
-              const int sidx = in ? cur.s0 + nn + c : 0;
-              const float x0 = cur.xb[sidx];
-              const float xp = cur.xb[sidx > 0 ? sidx - 1 : 0];
-              const float wc = c == 0 ? w.x : (c == 1 ? w.y : (c == 2 ? w.z : w.w));
-              const float y = (sidx > 0 ? x0 - p.preemph * xp : x0) * wc - cur.half_mean;
-              v[c] = in ? y : 0.0f;
+            for (int m1 = 0; m1 < 16; ++m1) {
+              const float4 w = *reinterpret_cast<const float4*>(wp + 32 * m1);
+              const float4 x = *reinterpret_cast<const float4*>(sp + 32 * m1);
+              if (MODE == kModeKaldi) {
+                const int nn = 32 * m1 + 4 * l;
+                const int s_abs = (t0 + fl) * p.hop + nn;  // absolute index of x.x (no previous sample at 0)
+                const float xm = sp[32 * m1 - 1];
+                const float y0 = s_abs > 0 ? x.x - p.preemph * xm : x.x;
+                ar[m1] = nn < p.frame_len ? y0 * w.x - half_mean : 0.0f;
+                ai[m1] = nn + 1 < p.frame_len ? (x.y - p.preemph * x.x) * w.y - half_mean : 0.0f;
+                br[m1] = nn + 2 < p.frame_len ? (x.z - p.preemph * x.y) * w.z - half_mean : 0.0f;
+                bi[m1] = nn + 3 < p.frame_len ? (x.w - p.preemph * x.z) * w.w - half_mean : 0.0f;
+              } else {
+                ar[m1] = x.x * w.x; ai[m1] = x.y * w.y; br[m1] = x.z * w.z; bi[m1] = x.w * w.w;
+              }
             }
           } else {
-            v[0] = fetch_padded(cur.xb, cur.s0 + nn, cur.n_valid, p.pad_mode, cur.valid) * w.x;
-            v[1] = fetch_padded(cur.xb, cur.s0 + nn + 1, cur.n_valid, p.pad_mode, cur.valid) * w.y;
-            v[2] = fetch_padded(cur.xb, cur.s0 + nn + 2, cur.n_valid, p.pad_mode, cur.valid) * w.z;
-            v[3] = fetch_padded(cur.xb, cur.s0 + nn + 3, cur.n_valid, p.pad_mode, cur.valid) * w.w;
+            // hop not a multiple of 4: the frame's samples are not 16-byte aligned in the tile
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) {
+              const float4 w = *reinterpret_cast<const float4*>(wp + 32 * m1);
+              const float x0 = sp[32 * m1], x1 = sp[32 * m1 + 1], x2 = sp[32 * m1 + 2], x3 = sp[32 * m1 + 3];
+              if (MODE == kModeKaldi) {
+                const int nn = 32 * m1 + 4 * l;
+                const int s_abs = (t0 + fl) * p.hop + nn;
+                const float xm = sp[32 * m1 - 1];
+                const float y0 = s_abs > 0 ? x0 - p.preemph * xm : x0;
+                ar[m1] = nn < p.frame_len ? y0 * w.x - half_mean : 0.0f;
+                ai[m1] = nn + 1 < p.frame_len ? (x1 - p.preemph * x0) * w.y - half_mean : 0.0f;
+                br[m1] = nn + 2 < p.frame_len ? (x2 - p.preemph * x1) * w.z - half_mean : 0.0f;
+                bi[m1] = nn + 3 < p.frame_len ? (x3 - p.preemph * x2) * w.w - half_mean : 0.0f;
+              } else {
+                ar[m1] = x0 * w.x; ai[m1] = x1 * w.y; br[m1] = x2 * w.z; bi[m1] = x3 * w.w;
+              }
+            }
           }
-          ar[m1] = v[0]; ai[m1] = v[1]; br[m1] = v[2]; bi[m1] = v[3];
-          if ((m1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+        wave_lds_sync();  // the tile is reused: next round's span, then the transpose slots
       }
-    }
-    MA_PROF(1);
-    MA_STAMP(3);  // samples consumed
+      MA_STAMP(3);  // samples consumed
 
-    // ---- prefetch the next unit ------------------------------------------------------------------
-    Unit nxt = cur;
-    if (next < p.num_units) {
-      nxt = decode_unit<MODE>(p, next, lane);
-      if (nxt.live && nxt.fast && !MA_DBG(1)) issue(nxt);
-    }
-
-    if (cur.live) {
-      const int t = cur.t;
-      const bool valid = cur.valid;
+      const int t = t0 + fl;
+      const bool valid = fl < fv;
+      const Rfft512Lane L = rfft512_lane_setup(opaque_lane());
+      const int l = L.l;
+      float* __restrict__ prow_fft = Pw + fl * kPStride;   // this frame's power row
+      float* __restrict__ slot = Pw + fl * kSlotStride;    // ... and exchange slot
       if (MA_DBG(8)) {
         float sacc = 0.f;
 #pragma unroll
@@ -343,9 +367,9 @@ __global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const Fe
         const int64_t stride = (p.layout == MA_STFT_FRAME_MAJOR) ? 1 : p.n_frames;
         float2* __restrict__ o = reinterpret_cast<float2*>(p.out) +
                                  ((p.layout == MA_STFT_FRAME_MAJOR)
-                                      ? ((int64_t)cur.b * p.n_frames + t) * kBins
-                                      : (int64_t)cur.b * kBins * p.n_frames + t);
-        rfft512_x8(ar, ai, br, bi, L, tw256, tw512, prow_fft,
+                                      ? ((int64_t)b * p.n_frames + t) * kBins
+                                      : (int64_t)b * kBins * p.n_frames + t);
+        rfft512_x8(ar, ai, br, bi, L, tw256, tw512, slot,
                    [&](int q, float xr, float xi, float yr, float yi) {
                      if (valid) {
                        const int ka = (q < 8 ? L.ka_lo : L.ka_hi) + 16 * q;
@@ -361,7 +385,7 @@ __global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const Fe
         float* __restrict__ pa_hi = prow_fft + L.ka_hi;
         float* __restrict__ pb_lo = prow_fft + 256 - L.ka_lo;
         float* __restrict__ pb_hi = prow_fft + 256 - L.ka_hi;
-        rfft512_x8(ar, ai, br, bi, L, tw256, tw512, prow_fft,
+        rfft512_x8(ar, ai, br, bi, L, tw256, tw512, slot,
                    [&](int q, float xr, float xi, float yr, float yi) {
                      float pa = xr * xr + xi * xi;
                      float pb = yr * yr + yi * yi;
@@ -384,31 +408,70 @@ __global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const Fe
       if (MODE != kModeStft) {
         wave_lds_sync();
         // ---- mel phase inside the wave: lane & 7 = frame, lane >> 3 = mel group (m = mg + 8 i) -------
-        const int tm = cur.t0 + fm;
-        const bool fvalid = tm < cur.frames_b;
+        // mel phase: position pm of the lane in the order the LDS serves 16-byte reads - lane groups {0-3,12-15,20-27},
+        // {4-11,16-19,28-31} and the same + 32 - so that every group of 16 is 8 frames x 2 mel groups: frame = pm & 7, mel group
+        // = pm >> 3
+        const int lm = opaque_lane();
+        const int pm = (int)(((0x73261540u >> ((lm >> 2 & 7) * 4)) & 7u) * 4u) + (lm & 3) + (lm & 32);
+        const int fm = pm & 7;
+        const int mg = pm >> 3;
+        const float* __restrict__ prow_mel = Pw + fm * kPStride;
+        const int tm = t0 + fm;
+        const bool fvalid = fm < fv;
         float vmin = INFINITY;
-        float* __restrict__ stage = reinterpret_cast<float*>(mw + p.total_steps * 8) + wave * (kUnitFrames * (p.n_mels + 1));
-        float* __restrict__ ocol = p.out + ((int64_t)cur.b * p.n_mels + mg) * p.n_frames + tm;
+        float* __restrict__ ocol = p.out + ((int64_t)b * p.n_mels + mg) * p.n_frames + tm;
         const int64_t ostep = 8 * p.n_frames;
-#pragma unroll 2
-        for (int i = 0; i < p.n_rows; ++i) {
-          // grouped band form (include/mindaudio_amd.h): every filter of row i takes steps[i] 16-byte steps
-          const int n = __builtin_amdgcn_readfirstlane(MA_DBG(2) ? 1 : msteps[i]);
-          const float4* __restrict__ w4 = mw + mrowoff[i] * 8 + mg;
-          const float4* __restrict__ p4 = reinterpret_cast<const float4*>(prow_mel + mstart[i * 8 + mg]);
+        // one row of 8 filters (grouped band form, include/mindaudio_amd.h): every filter of row i takes steps[i] 16-byte steps.
+        // The phase is a chain of LDS round trips, so the row structure must not add any: the step counts of all rows sit in
+        // ONE register (lane i holds steps[i]; v_readlane hands the wave-uniform count to the scalar unit), the weight row
+        // offset is their running sum, each row's start offset is fetched one row ahead, and a row's loads are all issued
+        // before its first multiply (the common step counts are fully unrolled).
+        int rowoff = 0;
+        int start_nxt = mstart[mg];
+        auto mel_row = [&](int i) __attribute__((always_inline)) {
+          const int n = MA_DBG(2) ? 1 : __builtin_amdgcn_readlane(steps_by_lane, i);
+          const float4* __restrict__ w4 = mw + rowoff * 8 + mg;
+          const float4* __restrict__ p4 = reinterpret_cast<const float4*>(prow_mel + start_nxt);
+          rowoff += n;
+          if (i + 1 < p.n_rows) start_nxt = mstart[(i + 1) * 8 + mg];
           float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-#pragma unroll 4
-          for (int st = 0; st < n; ++st) {
-            const float4 w = w4[st * 8];
-            const float4 x = p4[st];
-            a0 = fmaf(w.x, x.x, a0);
-            a1 = fmaf(w.y, x.y, a1);
-            a2 = fmaf(w.z, x.z, a2);
-            a3 = fmaf(w.w, x.w, a3);
+          auto dot = [&](auto nc) __attribute__((always_inline)) {
+            constexpr int N = decltype(nc)::value;
+            float4 w[N], x[N];
+#pragma unroll
+            for (int st = 0; st < N; ++st) { w[st] = w4[st * 8]; x[st] = p4[st]; }
+#pragma unroll
+            for (int st = 0; st < N; ++st) {
+              a0 = fmaf(w[st].x, x[st].x, a0);
+              a1 = fmaf(w[st].y, x[st].y, a1);
+              a2 = fmaf(w[st].z, x[st].z, a2);
+              a3 = fmaf(w[st].w, x[st].w, a3);
+            }
+          };
+          switch (n) {
+            case 1: dot(std::integral_constant<int, 1>{}); break;
+            case 2: dot(std::integral_constant<int, 2>{}); break;
+            case 3: dot(std::integral_constant<int, 3>{}); break;
+            case 4: dot(std::integral_constant<int, 4>{}); break;
+            case 5: dot(std::integral_constant<int, 5>{}); break;
+            case 6: dot(std::integral_constant<int, 6>{}); break;
+            default:
+#pragma unroll 2
+              for (int st = 0; st < n; ++st) {
+                const float4 w = w4[st * 8];
+                const float4 x = p4[st];
+                a0 = fmaf(w.x, x.x, a0);
+                a1 = fmaf(w.y, x.y, a1);
+                a2 = fmaf(w.z, x.z, a2);
+                a3 = fmaf(w.w, x.w, a3);
+              }
           }
-          const float acc = (a0 + a1) + (a2 + a3);
-          const int m = mg + 8 * i;
-          if (MODE == kModeMel) {
+          return (a0 + a1) + (a2 + a3);
+        };
+        if (MODE == kModeMel) {
+          for (int i = 0; i < p.n_rows; ++i) {
+            const float acc = mel_row(i);
+            const int m = mg + 8 * i;
             float v = acc;
             if (p.apply_db) v = kLog2ToDb * fast_log2(fmaxf(acc, p.amin)) - p.db_offset;
             if (fvalid && m < p.n_mels && !(MA_DBG(4) && v != 12345.0f)) {
@@ -416,29 +479,39 @@ __global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const Fe
               wmax = fmaxf(wmax, v);
               vmin = fminf(vmin, v);
             }
-          } else {
-            // dataset.py:154-155: zeros -> float64 eps, natural log
-            const float e = (acc == 0.0f) ? 2.220446049250313e-16f : acc;
-            if (m < p.n_mels) stage[fm * (p.n_mels + 1) + m] = 0.69314718055994531f * fast_log2(e);
           }
-        }
-        MA_PROF(4);
-        if (MODE == kModeMel) {
+          MA_PROF(4);
           if (p.apply_db) {
             vmin = wave_reduce(vmin, false);
-            if (lane == 0) p.unit_min[unit] = vmin;
+            if (lane == 0 && !MA_DBG(64)) p.unit_min[unit] = vmin;
           }
-          wave_lds_sync();  // Pw is rewritten by the next unit's transpose
+          wave_lds_sync();  // the tile is restaged by the next unit
         } else {
-          // the (8, n_mels) block was staged in LDS so that the store is one contiguous 8*n_mels*4-byte
-          // run; rows past the utterance end are written as zeros.
+          // Kaldi layout (B, T, n_mels): the (8, n_mels) block of the unit leaves as ONE contiguous 8*n_mels*4-byte run.  The
+          // row results wait in registers until every lane is done reading powers, then go through the (now dead) tile.
+          float res[kMaxRows];
+#pragma unroll
+          for (int i = 0; i < kMaxRows; ++i) {
+            res[i] = 0.0f;
+            if (i < p.n_rows) {
+              const float acc = mel_row(i);
+              // dataset.py:154-155: zeros -> float64 eps, natural log
+              const float e = (acc == 0.0f) ? 2.220446049250313e-16f : acc;
+              res[i] = 0.69314718055994531f * fast_log2(e);
+            }
+          }
+          MA_PROF(4);
           wave_lds_sync();
           const int sstride = p.n_mels + 1;
-          const int rows = ((int)p.n_frames - cur.t0) < kUnitFrames ? ((int)p.n_frames - cur.t0) : kUnitFrames;
-          float* __restrict__ o = p.out + ((int64_t)cur.b * p.n_frames + cur.t0) * p.n_mels;
+#pragma unroll
+          for (int i = 0; i < kMaxRows; ++i)
+            if (mg + 8 * i < p.n_mels) Pw[fm * sstride + mg + 8 * i] = res[i];
+          wave_lds_sync();
+          const int rows = ((int)p.n_frames - t0) < kUnitFrames ? ((int)p.n_frames - t0) : kUnitFrames;
+          float* __restrict__ o = p.out + ((int64_t)b * p.n_frames + t0) * p.n_mels;
           for (int idx = lane; idx < rows * p.n_mels; idx += 64) {
             const int ff = idx / p.n_mels, mm = idx - ff * p.n_mels;
-            o[idx] = (cur.t0 + ff < cur.frames_b) ? stage[ff * sstride + mm] : 0.0f;
+            o[idx] = (t0 + ff < frames_b) ? Pw[ff * sstride + mm] : 0.0f;  // rows past the utterance end: zeros
           }
           wave_lds_sync();
         }
@@ -447,20 +520,23 @@ __global__ __launch_bounds__(kThreads, MA_LB_WAVES) void feat512_kernel(const Fe
       }
     } else if (MODE == kModeKaldi) {
       // unit entirely past the utterance end: zero rows (pad_sequence padding, dataset.py:563-569)
-      const int rows = ((int)p.n_frames - cur.t0) < kUnitFrames ? ((int)p.n_frames - cur.t0) : kUnitFrames;
-      float* __restrict__ o = p.out + ((int64_t)cur.b * p.n_frames + cur.t0) * p.n_mels;
+      const int rows = ((int)p.n_frames - t0) < kUnitFrames ? ((int)p.n_frames - t0) : kUnitFrames;
+      float* __restrict__ o = p.out + ((int64_t)b * p.n_frames + t0) * p.n_mels;
       for (int idx = lane; idx < rows * p.n_mels; idx += 64) o[idx] = 0.0f;
     } else if (MODE == kModeMel && p.apply_db) {
       if (lane == 0) p.unit_min[unit] = INFINITY;
     }
-    unit = next;
-    cur = nxt;
+    unit += ustride;
+    if (unit < p.num_units) {
+      g = geometry(unit);
+      if (g.fv > 0) stage(g, 0);
+    }
   }
 
   if (MODE == kModeMel && p.apply_db) {
     float* red = reinterpret_cast<float*>(smem + kOffTw256);  // tables are dead now
     __syncthreads();
-    const float bmax = block_reduce(wmax, red, true);
+    const float bmax = block_reduce<NW>(wmax, red, true);
     if (tid == 0) p.wg_max[blockIdx.x] = bmax;
   }
   MA_STAMP(6);  // end
@@ -569,42 +645,64 @@ static int num_cus() {
   return g_num_cus;
 }
 
-static size_t feat_lds_bytes(int mode, int n_mels, int n_rows, int total_steps) {
-  size_t b = (size_t)kOffMel;
+static size_t feat_lds_bytes(int mode, int n_mels, int n_rows, int total_steps, int nw) {
+  size_t b = (size_t)off_mel(nw);
   if (mode == kModeStft) return b;
   b += 4 * (size_t)(2 * kMaxRows + 8 * kMaxRows) + 16 * 8 * (size_t)total_steps;
-  if (mode == kModeKaldi) b += 4 * (size_t)kWaves * kUnitFrames * (n_mels + 1);
+  (void)n_mels;
   return (b + 15) & ~(size_t)15;
 }
 
-template <int MODE, bool MAG>
-static int launch_feat_impl(const FeatParams& p_in, hipStream_t stream, int* grid_out) {
+template <int MODE, bool MAG, int NW, int OCC>
+static int launch_feat_cfg(const FeatParams& p_in, hipStream_t stream, int* grid_out) {
   FeatParams p = p_in;
   MA_SET_PROF(p);
-  const size_t lds = feat_lds_bytes(MODE, p.n_mels, p.n_rows, p.total_steps);
+  {
+    // frames of a unit whose sample span fits the wave's tile at once (hop 160: all 8; the reference's default hop 256: 7 + 1)
+    const int flen = (MODE == kModeKaldi) ? p.frame_len + 4 : 512;
+    int f = kUnitFrames;
+    while (f > 1 && (int64_t)(f - 1) * p.hop + flen > kPwFloats) --f;
+    p.frames_per_round = f;
+    if (MODE == kModeKaldi && kUnitFrames * (p.n_mels + 1) > kPwFloats) return MA_ERR_UNSUPPORTED;
+  }
+  const size_t lds = feat_lds_bytes(MODE, p.n_mels, p.n_rows, p.total_steps, NW);
   if (lds > 160 * 1024) return MA_ERR_UNSUPPORTED;
   // The grid is persistent (unit = wave id + k * waves in the grid), so it must equal what the device really
   // keeps resident: ask the runtime once per (kernel, LDS size) instead of assuming.
   static size_t cached_lds = 0;
   static int cached_per_cu = 0;
   if (cached_lds != lds) {
-    const void* fn = reinterpret_cast<const void*>(&feat512_kernel<MODE, MAG>);
+    const void* fn = reinterpret_cast<const void*>(&feat512_kernel<MODE, MAG, NW, OCC>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return MA_ERR_LAUNCH;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kThreads, lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NW * 64, lds) != hipSuccess || per_cu < 1)
       per_cu = 1;
-    cached_per_cu = per_cu > 4 ? 4 : per_cu;
+    constexpr int kCap = OCC * 4 / NW < 1 ? 1 : OCC * 4 / NW;  // workgroups per CU the register budget was sized for
+    cached_per_cu = per_cu > kCap ? kCap : per_cu;
     cached_lds = lds;
   }
   int64_t grid = (int64_t)num_cus() * cached_per_cu;
   if (grid > kMaxGrid) grid = kMaxGrid;
-  const int64_t need = (p.num_units + kWaves - 1) / kWaves;
+  const int64_t need = (p.num_units + NW - 1) / NW;
   if (grid > need) grid = need;
   if (grid < 1) return MA_OK;
   if (grid_out) *grid_out = (int)grid;
-  MA_LAUNCH((feat512_kernel<MODE, MAG>), dim3((unsigned)grid), dim3(kThreads), lds, stream, p);
+  MA_LAUNCH((feat512_kernel<MODE, MAG, NW, OCC>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, p);
   return MA_OK;
+}
+
+// Geometry (measured on MI355X, cfg 2, 64 / 512 utterances; tools/feat_ab.sh history in DESIGN.md §4.1):
+//   4 waves per workgroup, 3 workgroups per CU (3 waves per SIMD, <= 168 VGPRs, no spills)   41.0 / 282 us   <- used
+//   8 waves per workgroup, 2 per CU (4 waves per SIMD, 128 VGPRs: 5 - 22 spilled registers)   40.6 - 43.5 / 283 - 308 us
+//   4 x 2 per CU (round 1's occupancy)                                                        46.3 / 332 us
+// A spilled register costs far more than its reload here: every scratch reload is followed by s_waitcnt vmcnt(0), which also
+// waits for the unit's output stores.
+template <int MODE, bool MAG>
+static int launch_feat_impl(const FeatParams& p, hipStream_t stream, int* grid_out) {
+  // the Kaldi front end keeps its row results in registers across the mel phase (215 VGPRs): two waves per SIMD
+  if (MODE == kModeKaldi) return launch_feat_cfg<MODE, MAG, 4, 2>(p, stream, grid_out);
+  return launch_feat_cfg<MODE, MAG, 4, 3>(p, stream, grid_out);
 }
 
 template <int MODE>

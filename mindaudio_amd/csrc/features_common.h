@@ -40,6 +40,7 @@ struct FeatParams {
   int32_t pad_left;    // n_fft/2 when centred, else 0
   int32_t pad_mode;
   int32_t frame_len;   // kaldi: 400; else 512
+  int32_t frames_per_round;  // n_fft == 512 path: frames whose sample span fits the wave's LDS tile at once (host: feat512_rounds)
   int32_t n_mels;
   int32_t n_rows;
   int32_t total_steps;

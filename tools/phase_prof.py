@@ -35,12 +35,12 @@ e1.record(); torch.cuda.synchronize()
 p = prof.cpu().numpy().astype(float) / n
 # ---- timeline of block 0 / wave 0 (wall_clock64 = 100 MHz ticks) ----
 torch.cuda.synchronize(); prof.zero_(); run(); torch.cuda.synchronize()
-st = prof.cpu().numpy()[16:56]
-st = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in st if v != 0]
+stamps = prof.cpu().numpy()[16:56]
+stamps = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in stamps if v != 0]
 names_s = {1: "entry", 2: "tables ready", 3: "samples consumed", 4: "fft done", 5: "mel done", 6: "end"}
-if st:
-    t0 = st[0][1]
-    print("timeline (us since entry):", ", ".join("%s %.2f" % (names_s.get(k, k), (t - t0) / 100.0) for k, t in st))
+if stamps:
+    t0 = stamps[0][1]
+    print("timeline (us since entry):", ", ".join("%s %.2f" % (names_s.get(k, k), (t - t0) / 100.0) for k, t in stamps))
 lib.ma_debug_set_prof(ctypes.c_void_p(0))
 def timeit(flags, reps=30):
     lib.ma_debug_set_flags(flags)
@@ -49,7 +49,7 @@ def timeit(flags, reps=30):
     for _ in range(reps): run()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for flags, nm in ((0, "full"), (1, "no sample loads"), (2, "mel loop 1 iter"), (4, "no out stores"), (8, "no fft"), (6, "no mel loop+no stores"), (14, "no fft, no mel, no stores"), (15, "all off")):
+for flags, nm in ((0, "full"), (1, "no sample loads"), (2, "mel loop 1 iter"), (4, "no out stores"), (8, "no fft"), (6, "no mel loop+no stores"), (14, "no fft, no mel, no stores"), (15, "all off"), (16, "launch + tables + first staging only"), (17, "launch + tables only"), (32, "launch only")):
     print("ablation %-28s %7.1f us" % (nm, timeit(flags)))
 names = ["loop/tail", "loads+window", "fft+split+P", "barrier1", "mel+log+store", "reduce/barriers"]
 tot = p[:6].sum()

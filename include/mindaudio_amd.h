@@ -317,6 +317,16 @@ int ma_dct_f32(const float* x, int64_t batch, int32_t n_mels, int64_t T, const f
 /* spectrum.magphase (spectrum.py:701-735) on n complex64 values: mag = |z|^power, phase = z / |z| (1+0i at zero; phase
  * may be NULL: complex_norm). */
 int ma_magphase_f32(const float* z, int64_t n, float power, float* mag, float* phase, ma_stream_t stream);
+/* spectrum.magphase(iscomplex=False) (spectrum.py:732-735 -> MindSpore Magphase) on n (re, im) float pairs: mag = |z|^power,
+ * angle = atan2(im, re). */
+int ma_magphase_angle_f32(const float* z, int64_t n, float power, float* mag, float* angle, ma_stream_t stream);
+/* op 0: out = a * x + b; op 1: out = b * ln(x + a) (features.py:343-344 log-mel: a = 1e-6, b = 1).  In place allowed. */
+int ma_pointwise_f32(const float* x, int64_t n, int32_t op, float a, float b, float* out, ma_stream_t stream);
+/* spectrum.frame (spectrum.py:281-304): x (batch, n) float32 or float64 (row stride ldx) -> out (batch, frame_length, num_frame)
+ * float64 (the reference allocates np.zeros: float64 whatever the input), num_frame = (n - frame_length) / hop + 1,
+ * out[b][i][t] = x[b][i + t * hop].  MA_ERR_HOP if hop < 1 (spectrum.py:295-296). */
+int ma_frame_f64(const void* x, int32_t x_is_f64, int64_t batch, int64_t n, int64_t ldx, int32_t frame_length, int32_t hop,
+                 double* out, ma_stream_t stream);
 /* compute_cmvn_stats.py:45-60 on a padded feature batch x (batch, T, F) float32 with frames[b] valid rows:
  * stats (2, F) float64 += per-feature sum and sum of squares (F <= 256; the frame count is the host's sum(frames)). */
 int ma_cmvn_stats_f64(const float* x, const int32_t* frames, int64_t batch, int64_t T, int32_t F, double* stats,

@@ -116,6 +116,9 @@ PROTOTYPES = {
     "ma_context_window_f32": (ctypes.c_int, [vp, i64, i32, i64, i32, i32, vp, vp]),
     "ma_dct_f32": (ctypes.c_int, [vp, i64, i32, i64, vp, i32, vp, vp]),
     "ma_magphase_f32": (ctypes.c_int, [vp, i64, f32, vp, vp, vp]),
+    "ma_magphase_angle_f32": (ctypes.c_int, [vp, i64, f32, vp, vp, vp]),
+    "ma_pointwise_f32": (ctypes.c_int, [vp, i64, i32, f32, f32, vp, vp]),
+    "ma_frame_f64": (ctypes.c_int, [vp, i32, i64, i64, i64, i32, i32, vp, vp]),
     "ma_cmvn_stats_f64": (ctypes.c_int, [vp, vp, i64, i64, i32, vp, vp]),
     "ma_subsampled_mask_len": (i32, [i32]),
     "ma_collate_asr_i32": (ctypes.c_int, [ctypes.c_void_p] * 3 + [i32] * 7 + [ctypes.c_void_p] * 11),

@@ -1,9 +1,8 @@
-"""Mirror of examples/conformer/asr_model.py for the CTC configuration (ctc_weight = 1.0, decoder None:
-asr_model.py:327-328) — forward / evaluation loss on MI355X.
+"""Mirror of examples/conformer/asr_model.py — forward / evaluation loss on MI355X, pure CTC (ctc_weight = 1.0, decoder None:
+asr_model.py:327-328) and the hybrid CTC / attention configuration of the shipped conformer.yaml.
 
 ASRModel.forward takes the 11 columns of the reference batch in the reference order (train.py:38-50) and returns
-(loss, acc_att) like ASRModelWithAcc.construct (asr_model.py:75-153).  The attention-decoder branch
-(ctc_weight != 1.0) is a later row."""
+(loss, acc_att) like ASRModelWithAcc.construct (asr_model.py:75-153)."""
 import torch
 import torch.nn as nn
 
@@ -43,9 +42,9 @@ class CTC(nn.Module):
 
 
 class ASRModel(nn.Module):
-    """Encoder + CTC [+ attention decoder] (asr_model.py:16-153).  The evaluation forward below covers the CTC branch
-    (ctc_weight == 1.0); the hybrid loss (decoder + label smoothing) runs in mindaudio_amd.train.engine, which is where
-    the reference uses it (training)."""
+    """Encoder + CTC [+ attention decoder] (asr_model.py:16-153).  forward() is the evaluation forward (create_asr_eval_net,
+    asr_model.py:355-371) of either configuration: pure CTC (ctc_weight == 1.0) or the hybrid 0.3 / 0.7 loss with the
+    TransformerDecoder and label smoothing; the training step (forward + backward + optimizer) is mindaudio_amd.train.engine."""
 
     def __init__(self, vocab_size, encoder, ctc, ctc_weight=1.0, decoder=None, lsm_weight=0.0, reverse_weight=0.0,
                  length_normalized_loss=False):
@@ -60,13 +59,34 @@ class ASRModel(nn.Module):
     @torch.no_grad()
     def forward(self, xs_pad, ys_pad, ys_in_pad=None, ys_out_pad=None, r_ys_in_pad=None, r_ys_out_pad=None,
                 xs_masks=None, ys_sub_masks=None, ys_masks=None, ys_lengths=None, xs_chunk_masks=None):
-        if self.ctc_weight != 1.0:
-            raise NotImplementedError("evaluation forward of the hybrid loss: use mindaudio_amd.train.engine")
         encoder_out, encoder_mask = self.encoder(xs_pad, xs_masks, xs_chunk_masks)
         # asr_model.py:109-114: lengths = mask.squeeze().sum(1) as int32
         encoder_out_lens = encoder_mask.to(torch.float32).reshape(encoder_mask.shape[0], -1).sum(1).to(torch.int32)
-        loss_ctc = self.ctc(encoder_out, encoder_out_lens, ys_pad, ys_lengths)
-        return loss_ctc, None
+        loss_att = acc_att = None
+        if self.ctc_weight != 1.0:  # attention-decoder branch (asr_model.py:117-129, 154-209)
+            loss_att, acc_att = self._calc_att_loss(encoder_out, encoder_mask, ys_in_pad, ys_out_pad, ys_masks, ys_sub_masks)
+        loss_ctc = self.ctc(encoder_out, encoder_out_lens, ys_pad, ys_lengths) if self.ctc_weight != 0.0 else None
+        if loss_ctc is None:
+            return loss_att, acc_att
+        if loss_att is None:
+            return loss_ctc, None
+        return self.ctc_weight * loss_ctc + (1.0 - self.ctc_weight) * loss_att, acc_att  # asr_model.py:138-139
+
+    @torch.no_grad()
+    def _calc_att_loss(self, encoder_out, encoder_mask, ys_in_pad, ys_out_pad, ys_masks, ys_sub_masks):
+        """asr_model.py:154-209: decoder scores -> LabelSmoothingLoss (KL, summed, / batch: label_smoothing_loss.py:24-117) and the
+        token accuracy over the unmasked positions."""
+        from ..train import kernels as K
+
+        if ys_in_pad is None or ys_out_pad is None or ys_masks is None or ys_sub_masks is None:
+            raise ValueError("the hybrid loss needs ys_in_pad, ys_out_pad, ys_sub_masks and ys_masks")
+        scores, _ = self.decoder(encoder_out, encoder_mask, ys_in_pad, ys_sub_masks)
+        b, l1, v = scores.shape
+        logits = scores.reshape(b * l1, v)  # a view of the decoder's 64-padded row buffer
+        tgt = ys_out_pad.to(torch.int32).contiguous().reshape(-1)
+        tmask = ys_masks.to(torch.float32).contiguous().reshape(-1)
+        stats, _ = K.label_smoothing_loss_grad(logits, v, tgt, tmask, self.lsm_weight, 0.0)
+        return stats[0] / b, stats[1] / stats[2]
 
 
 def create_asr_model(input_dim, vocab_size, encoder_conf=None, global_cmvn=None, ctc_weight=1.0, decoder_conf=None,

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
   constexpr int kKeyStep = NW * 4;                 // keys covered by one piece index: 16 (4 waves) / 32 (8 waves)
   const int sk_key = tid >> 4, sk_ch = tid & 15;   // K' piece i: key sk_key + kKeyStep i, 16-byte chunk sk_ch
   const int sv_key = tid >> 3, sv_ch = tid & 7;    // V piece i: key sv_key + 2 kKeyStep i, 16-byte chunk sv_ch of its 64 d
-  const uint16_t* ksrc_base = (sk_ch < 8) ? qkv + row0 * ld_qkv + 256 + h * kDk + sk_ch * 8
+  const uint16_t* ksrc_base = (sk_ch < 8) ? qkv + row0 * ld_qkv + H * kDk + h * kDk + sk_ch * 8
                                           : pos + h * kDk + (sk_ch - 8) * 8;
   const int64_t ksrc_ld = (sk_ch < 8) ? ld_qkv : ld_pos;
 #define MA_ATT_KLOAD(dst, i, k0_)                                                     \
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
     if constexpr (NW == 4) { MA_ATT_KLOAD(rk2, 2, k0f_) MA_ATT_KLOAD(rk3, 3, k0f_) }   \
     {                                                                                 \
       const int v0_ = k0f_ + sv_key, v1_ = k0f_ + sv_key + 32;                        \
-      const uint16_t* vb_ = qkv + row0 * ld_qkv + 512 + h * kDk + sv_ch * 8;          \
+      const uint16_t* vb_ = qkv + row0 * ld_qkv + 2 * H * kDk + h * kDk + sv_ch * 8;          \
       rv0 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)(v0_ < T ? v0_ : T - 1) * ld_qkv);     \
       if (v0_ >= T) rv0 = make_uint4(0, 0, 0, 0); /* keys past T: probability 0 x a FINITE value */ \
       if constexpr (NW == 4) {                                                        \
@@ -728,15 +728,14 @@ static int relpos_attention_fwd(const void* qkv, int64_t ld_qkv, const void* pos
                                 float* lse, ma_stream_t stream) {
   if (!qkv || !pos || !bias_u || !bias_v || !ctx || !vt_workspace || batch < 1 || T < 1 || heads < 1)
     return MA_ERR_INVALID_ARG;
-  if (d_k != kDk || heads * d_k != 256) return MA_ERR_UNSUPPORTED;  // q | k | v blocks are 256 wide
+  if (d_k != kDk) return MA_ERR_UNSUPPORTED;  // 64-wide heads; q | k | v blocks are heads * 64 wide
   if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 3) || batch > 65535) return MA_ERR_UNSUPPORTED;
   const int Tp = (int)((T + 63) / 64 * 64);
   if (vt_bytes < ma_relpos_attention_workspace_bytes(batch, T, heads, d_k)) return MA_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   // (V is read from the qkv buffer as stored; the V^T workspace of earlier revisions is no longer written)
-  // 128-row query tiles when their second half is populated (T = 249: 128 + 121 rows); MA_ATT_Q128=0: developer A/B switch
-  static const int q128 = getenv("MA_ATT_Q128") ? atoi(getenv("MA_ATT_Q128")) : 1;
-  if (q128 && ((T - 1) % 128) >= 96) {
+  // 128-row query tiles when their second half is populated (T = 249: 128 + 121 rows)
+  if (((T - 1) % 128) >= 96) {
     const dim3 grid8((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batch);
     MA_LAUNCH(relpos_attention_kernel<8>, grid8, dim3(512), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
               reinterpret_cast<const uint16_t*>(pos), ld_pos, reinterpret_cast<const uint16_t*>(vt_workspace), Tp, bias_u,

@@ -93,6 +93,36 @@ __global__ __launch_bounds__(256) void magphase_kernel(const float2* __restrict_
   }
 }
 
+// Magphase of a real (..., 2) spectrogram (spectrum.py:732-735 -> MindSpore Magphase): mag = |z|^power, phase = atan2(im, re)
+__global__ __launch_bounds__(256) void magphase_angle_kernel(const float2* __restrict__ z, int64_t n, float power,
+                                                             float* __restrict__ mag, float* __restrict__ angle) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float2 v = z[i];
+    const float m = hypotf(v.x, v.y);
+    mag[i] = power == 1.0f ? m : (power == 2.0f ? m * m : powf(m, power));
+    angle[i] = atan2f(v.y, v.x);
+  }
+}
+
+// op 0: out = a * x + b;  op 1: out = b * ln(x + a)   (features.py:343-344: np.log(melspec + 1e-6))
+__global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict__ x, int64_t n, int op, float a, float b,
+                                                        float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = op == 0 ? fmaf(a, x[i], b) : b * logf(x[i] + a);
+}
+
+// spectrum.frame (spectrum.py:281-304): out[b][i][t] = x[b][i + t * hop], always float64 like the reference's np.zeros default
+template <typename T>
+__global__ __launch_bounds__(256) void frame_kernel(const T* __restrict__ x, int64_t ldx, int frame_length, int64_t num_frame,
+                                                    int hop, double* __restrict__ out) {
+  const int64_t b = blockIdx.z;
+  const int i = blockIdx.y;
+  const T* __restrict__ src = x + b * ldx + i;
+  double* __restrict__ dst = out + (b * frame_length + i) * num_frame;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < num_frame; t += (int64_t)gridDim.x * 256)
+    dst[t] = (double)src[t * hop];
+}
+
 // x (B, T, F) float32 with frames[b] valid rows -> stats (2, F) float64: sum, sum of squares; count handled by the host
 __global__ __launch_bounds__(256) void cmvn_stats_kernel(const float* __restrict__ x, const int32_t* __restrict__ frames, int T, int F,
                                                          double* stats) {
@@ -224,6 +254,36 @@ int ma_magphase_f32(const float* z, int64_t n, float power, float* mag, float* p
   if (!z || !mag || n < 1 || power < 0.0f) return MA_ERR_INVALID_ARG;
   MA_LAUNCH(magphase_kernel, dim3(fp_grid(n)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2*>(z), n, power,
             mag, reinterpret_cast<float2*>(phase));
+  return MA_OK;
+}
+
+int ma_magphase_angle_f32(const float* z, int64_t n, float power, float* mag, float* angle, ma_stream_t stream) {
+  if (!z || !mag || !angle || n < 1 || power < 0.0f) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(magphase_angle_kernel, dim3(fp_grid(n)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2*>(z), n,
+            power, mag, angle);
+  return MA_OK;
+}
+
+int ma_pointwise_f32(const float* x, int64_t n, int32_t op, float a, float b, float* out, ma_stream_t stream) {
+  if (!x || !out || n < 1 || (op != 0 && op != 1)) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(pointwise_kernel, dim3(fp_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, op, a, b, out);
+  return MA_OK;
+}
+
+int ma_frame_f64(const void* x, int32_t x_is_f64, int64_t batch, int64_t n, int64_t ldx, int32_t frame_length, int32_t hop,
+                 double* out, ma_stream_t stream) {
+  if (!x || !out || batch < 1 || n < 1 || ldx < n || frame_length < 1) return MA_ERR_INVALID_ARG;
+  if (hop < 1) return MA_ERR_HOP;
+  if (frame_length > n) return MA_ERR_NFFT_TOO_LARGE;
+  if (batch > 65535 || frame_length > 65535) return MA_ERR_UNSUPPORTED;
+  const int64_t num_frame = (n - frame_length) / hop + 1;
+  int64_t gx = (num_frame + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  const dim3 grid((unsigned)gx, (unsigned)frame_length, (unsigned)batch);
+  if (x_is_f64)
+    MA_LAUNCH(frame_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)x, ldx, frame_length, num_frame, hop, out);
+  else
+    MA_LAUNCH(frame_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, frame_length, num_frame, hop, out);
   return MA_OK;
 }
 

@@ -1,2 +1,2 @@
 from .features import fbank, fbanks  # noqa: F401
-from .spectrum import amplitude_to_dB, melspectrogram, stft  # noqa: F401
+from .spectrum import amplitude_to_dB, frame, melspectrogram, stft  # noqa: F401

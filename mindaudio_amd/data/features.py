@@ -126,8 +126,10 @@ def mfcc(waveforms, deltas=True, context=True, n_mels=23, n_mfcc=20, n_fft=400, 
     mel = _spectrum.melspectrogram(waveforms if not was_numpy else t.as_tensor(np.asarray(waveforms)).cuda(),
                                    sample_rate=sample_rate, n_fft=n_fft, n_mels=n_mels, f_min=f_min, f_max=f_max,
                                    win_length=win_length, hop_length=hop_length)
-    if log_mels:
-        raise NotImplementedError("log_mels=True (np.log(mel + 1e-6), features.py:343-344) is not built; the default is dB")
+    if log_mels:  # np.log(melspec + 1e-6), features.py:343-344
+        mel = mel.contiguous()
+        _lib.check(_lib.load().ma_pointwise_f32(_host.ptr(mel), mel.numel(), 1, 1e-6, 1.0, _host.ptr(mel),
+                                                _host.current_stream_ptr()), "log mel")
     else:
         mel = _spectrum.amplitude_to_dB(mel, stype="power", ref=1.0, top_db=80.0)
     shape = tuple(mel.shape)

@@ -10,7 +10,7 @@ import numpy as np
 
 from .. import _host, _lib
 
-__all__ = ["stft", "istft", "melspectrogram", "amplitude_to_dB", "spectrogram", "magphase"]
+__all__ = ["stft", "istft", "frame", "melspectrogram", "amplitude_to_dB", "spectrogram", "magphase"]
 
 
 def _finish(out, lead, was_numpy):
@@ -53,6 +53,33 @@ def stft(waveforms, n_fft=512, win_length=None, hop_length=None, window="hann", 
     if not return_complex:
         spec = t.stack((spec.real, spec.imag), -1)
     return _finish(spec, lead, was_numpy)
+
+
+def frame(x, frame_length=2048, hop_length=64):
+    """spectrum.frame (spectrum.py:281-304): overlapping frames of the last axis, frame axis = -2, time axis = -1,
+    num_frame = (N - frame_length) // hop_length + 1.  Always float64, like the reference's np.zeros buffer; NumPy in -> NumPy
+    out, device tensor in -> device tensor out."""
+    if hop_length < 1:
+        raise ValueError("Invalid hop_length: {:d}".format(hop_length))
+    t = _host.require_gpu()
+    was_numpy = not isinstance(x, t.Tensor)
+    xt = t.as_tensor(np.ascontiguousarray(x) if was_numpy else x)
+    if xt.dtype not in (t.float32, t.float64):
+        xt = xt.to(t.float64)
+    xt = xt.cuda()
+    lead, n = tuple(xt.shape[:-1]), xt.shape[-1]
+    x2 = xt.reshape(-1, n)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    num_frame = (n - frame_length) // hop_length + 1
+    if num_frame < 1:
+        # the reference's np.zeros raises "negative dimensions are not allowed" here
+        raise ValueError("frame_length={} is too large for input signal of length={}".format(frame_length, n))
+    out = t.empty((x2.shape[0], frame_length, num_frame), dtype=t.float64, device=x2.device)
+    _lib.check(_lib.load().ma_frame_f64(_host.ptr(x2), 1 if x2.dtype == t.float64 else 0, x2.shape[0], n, x2.stride(0),
+                                        frame_length, hop_length, _host.ptr(out), _host.current_stream_ptr()), "frame")
+    out = out.reshape(lead + (frame_length, num_frame))
+    return out.cpu().numpy() if was_numpy else out
 
 
 def istft(stft_matrix, n_fft=None, win_length=None, hop_length=None, window="hann", center=True, length=None):
@@ -181,11 +208,13 @@ def amplitude_to_dB(wavform, stype="power", ref=1.0, amin=1e-10, top_db=80.0):
 
 def spectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0, window="hann", power=2.0,
                 normalized=False, center=True, pad_mode="reflect", onesided=True):
-    """spectrum.spectrogram (spectrum.py:560-606 -> MindSpore Spectrogram): |STFT| ** power with reflect padding by
-    default, hop = win_length // 2; (..., n_fft // 2 + 1, frames) float32.  `normalized` / two-sided output are not built."""
-    if normalized or not onesided:
-        raise NotImplementedError("normalized / two-sided spectrograms are not built")
+    """spectrum.spectrogram (spectrum.py:560-606 -> MindSpore Spectrogram, torchaudio semantics): |STFT| ** power with reflect
+    padding by default, hop = win_length // 2; (..., n_fft // 2 + 1, frames) float32.  normalized=True divides the STFT by
+    sqrt(sum(window ** 2)) before the power.  Two-sided output is not built."""
+    if not onesided:
+        raise NotImplementedError("two-sided spectrograms are not built")
     t = _host.require_gpu()
+    lib = _lib.load()
     was_numpy = not isinstance(waveforms, t.Tensor)
     x = t.as_tensor(np.asarray(waveforms)).cuda() if was_numpy else waveforms
     if pad > 0:
@@ -195,18 +224,32 @@ def spectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0, w
     S = stft(x, n_fft=n_fft, win_length=win_length, hop_length=hop_length, window=window, center=center, pad_mode=pad_mode)
     mag = t.empty(S.shape, dtype=t.float32, device=S.device)
     Sc = S.contiguous()
-    _lib.check(_lib.load().ma_magphase_f32(_host.ptr(t.view_as_real(Sc)), Sc.numel(), float(power), _host.ptr(mag), None,
-                                           _host.current_stream_ptr()), "spectrogram")
+    _lib.check(lib.ma_magphase_f32(_host.ptr(t.view_as_real(Sc)), Sc.numel(), float(power), _host.ptr(mag), None,
+                                   _host.current_stream_ptr()), "spectrogram")
+    if normalized:
+        w = _host.centred_window_f64(window, win_length, n_fft)
+        scale = float(np.sum(w * w)) ** (-0.5 * float(power))
+        _lib.check(lib.ma_pointwise_f32(_host.ptr(mag), mag.numel(), 0, scale, 0.0, _host.ptr(mag), _host.current_stream_ptr()),
+                   "spectrogram normalisation")
     return mag.cpu().numpy() if was_numpy else mag
 
 
 def magphase(waveform, power, iscomplex=True):
-    """spectrum.magphase (spectrum.py:701-735) for complex input: (|D| ** power, D / |D|), phase 1+0j where D == 0."""
-    if not iscomplex:
-        raise NotImplementedError("real (..., 2) input goes through MindSpore's Magphase in the reference")
+    """spectrum.magphase (spectrum.py:701-735).  Complex input: (|D| ** power, D / |D|), phase 1+0j where D == 0; real (..., 2)
+    input (iscomplex=False): (|D| ** power, atan2(im, re))."""
     t = _host.require_gpu()
     lib = _lib.load()
     was_numpy = not isinstance(waveform, t.Tensor)
+    if not iscomplex:
+        # real (..., 2) input -> MindSpore Magphase (spectrum.py:732-735; torchaudio semantics: magnitude ** power and the ANGLE)
+        z = t.as_tensor(np.ascontiguousarray(waveform) if was_numpy else waveform).to(device="cuda", dtype=t.float32).contiguous()
+        if z.shape[-1] != 2:
+            raise ValueError("magphase(iscomplex=False) takes a (..., 2) real/imaginary stack")
+        mag = t.empty(z.shape[:-1], dtype=t.float32, device=z.device)
+        ang = t.empty(z.shape[:-1], dtype=t.float32, device=z.device)
+        _lib.check(lib.ma_magphase_angle_f32(_host.ptr(z), mag.numel(), float(power), _host.ptr(mag), _host.ptr(ang),
+                                             _host.current_stream_ptr()), "magphase")
+        return (mag.cpu().numpy(), ang.cpu().numpy()) if was_numpy else (mag, ang)
     z = t.as_tensor(np.ascontiguousarray(waveform) if was_numpy else waveform).to(device="cuda", dtype=t.complex64).contiguous()
     mag = t.empty(z.shape, dtype=t.float32, device=z.device)
     phase = t.empty_like(z)

@@ -6,8 +6,9 @@ used as parameter containers only — their forward() is never called); `forward
 epilogues, a fused rel-pos attention kernel, a fused GLU/depthwise/BatchNorm/Swish kernel and LayerNorm kernels
 through the C-ABI (include/mindaudio_amd.h).  The residual stream, LayerNorm statistics and softmax are float32.
 
-Round-1 scope: inference forward (eval mode: dropout off, BatchNorm running statistics) — the path the
-`utterances/s fbanks+Conformer fwd` metric measures.  Training-mode forward/backward is the next row.
+forward() in eval mode (dropout off, BatchNorm running statistics) is the path the `utterances/s fbanks+Conformer fwd` metric
+measures; in train mode it applies dropout and BatchNorm batch statistics (the forward half of the training step, whose backward
+and optimizer live in mindaudio_amd.train.engine).
 """
 import math
 
@@ -90,7 +91,7 @@ class _Embed(nn.Module):
 class ConformerEncoder(nn.Module):
     """Same constructor arguments as the reference (models/conformer.py:293-313).  `global_cmvn` is a
     (mean, istd) pair of arrays (layers/cmvn.py); `compute_type` is accepted for signature parity — matmul
-    inputs are bf16, accumulation float32."""
+    inputs are bf16, accumulation float32 (the float32 validation mode is a switch of the training engine)."""
 
     def __init__(self, input_size, output_size=256, attention_heads=4, linear_units=2048, num_blocks=6,
                  dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.0, input_layer="conv2d",
@@ -102,10 +103,14 @@ class ConformerEncoder(nn.Module):
                 or cnn_module_norm != "batch_norm":
             raise NotImplementedError("only the shipped conformer.yaml configuration is on the hot path: conv2d "
                                       "input, rel_pos, pre-norm, no concat, batch_norm conv module")
-        if output_size != 256 or output_size // attention_heads != 64:
-            raise NotImplementedError("kernels are built for d_model 256 with 64-wide heads (Conformer-small)")
+        if output_size not in (256, 512, 768, 1024) or output_size != attention_heads * 64:
+            raise NotImplementedError("kernels are built for 64-wide heads with d_model 256 (Conformer-small: the fused, "
+                                      "packed-weight launches), 512, 768 or 1024 (one launch per reference cell)")
         self.d, self.heads, self.idim = output_size, attention_heads, input_size
         self.kernel = cnn_module_kernel
+        self.dropout_rate, self.positional_dropout_rate = float(dropout_rate), float(positional_dropout_rate)
+        self._bn_dirty = False
+        self.seed, self._train_calls = 777, 0  # dropout stream of the training-mode forward (examples/conformer/train.py:56)
         self.embed = _Embed(input_size, output_size)
         self.encoders = nn.ModuleList([_Layer(output_size, attention_heads, linear_units, cnn_module_kernel)
                                        for _ in range(num_blocks)])
@@ -281,26 +286,99 @@ class ConformerEncoder(nn.Module):
             ops.gemm(z, W["pw2_w"], bias=W["pw2_b"], row_scale=mask_rows, residual=x, out_dtype=f32, out=x)
             ffn(ops.layernorm(x, l.norm_ff.gamma, l.norm_ff.beta), W, "ff")                       # :147-151
             # x = norm_final(x), chained with the LayerNorm that consumes it next                  :153-156, 253
-            if li + 1 < n_layers:
-                nxt = self.encoders[li + 1].norm_ff_macaron
-                a = ops.layernorm2(x, l.norm_final.gamma, l.norm_final.beta, nxt.gamma, nxt.beta)
+            nxt = self.encoders[li + 1].norm_ff_macaron if li + 1 < n_layers else self.after_norm
+            if self.d == 256:
+                y = ops.layernorm2(x, l.norm_final.gamma, l.norm_final.beta, nxt.gamma, nxt.beta,
+                                   out2_dtype=None if li + 1 < n_layers else f32)
             else:
-                x = ops.layernorm2(x, l.norm_final.gamma, l.norm_final.beta, self.after_norm.gamma, self.after_norm.beta,
-                                   out2_dtype=f32)
+                ops.layernorm(x, l.norm_final.gamma, l.norm_final.beta, out_dtype=f32, out=x)
+                y = ops.layernorm(x, nxt.gamma, nxt.beta, out_dtype=None if li + 1 < n_layers else f32)
+            if li + 1 < n_layers:
+                a = y
+            else:
+                x = y
         return x
+
+    # ---- training-mode forward: dropout + BatchNorm batch statistics (models/conformer.py:100-161 with self.training) ---------
+    def _forward_train(self, xs, P, masks, xs_chunk_masks):
+        """One launch per reference cell plus the dropout / BatchNorm-statistics kernels of the training step
+        (mindaudio_amd.train.kernels); updates the BatchNorm running statistics in place like nn.BatchNorm1d.  This is the
+        forward half of mindaudio_amd.train.engine on the module's own weights - nothing is kept for a backward pass."""
+        from ..train import kernels as K
+
+        f32 = torch.float32
+        d, b = self.d, xs.shape[0]
+        pd, pp = self.dropout_rate, self.positional_dropout_rate
+        seed = (self.seed + self._train_calls) & 0x7fffffff
+        self._train_calls += 1
+        salt = lambda layer, site: (layer + 1) * 16 + site  # noqa: E731  (the engine's site numbering)
+        act1 = ops.subsample_conv1(xs, P["conv1_w"], P["conv1_b"], self.cmvn_mean, self.cmvn_istd)
+        act2 = ops.conv2d_3x3s2_nhwc(act1, P["conv2_w"], P["conv2_b"], relu=True)
+        _, t2, f2, c = act2.shape
+        m = b * t2
+        if masks.shape[-1] != t2:
+            raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(masks.shape)))
+        mask2d = masks.reshape(b, t2).to(f32).contiguous()
+        mask_rows = mask2d.reshape(m)
+        att_mask = mask2d if xs_chunk_masks is None else xs_chunk_masks.reshape(b, t2).to(f32).contiguous()
+        e = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(d), out_dtype=f32)
+        x = K.dropout_add(torch.zeros_like(e), e, 1.0, pp, seed, salt(-1, 0)) if pp > 0 else e
+        pe = self.pe[:t2].to(f32).contiguous()
+        if pp > 0:
+            pe = K.dropout_add(torch.zeros_like(pe), pe, 1.0, pp, seed, salt(-1, 1))
+        pos_all = ops.gemm(ops.cast_bf16(pe), P["pos_w"])
+
+        def ffn(x, W, key, ln, li, s0):
+            a = ops.layernorm(x, ln.gamma, ln.beta)
+            h = K.act_dropout_fwd(ops.gemm(a, W[key + "_w1"], bias=W[key + "_b1"]), pd, seed, salt(li, s0))
+            y = ops.gemm(h, W[key + "_w2"], bias=W[key + "_b2"])
+            return K.dropout_add(x, y, 0.5, pd, seed, salt(li, s0 + 1))
+
+        for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
+            cm = l.conv_module
+            x = ffn(x, W, "ffm", l.norm_ff_macaron, li, 0)
+            a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta)
+            qkv = ops.gemm(a, W["qkv_w"], bias=W["qkv_b"])
+            ctx = ops.relpos_attention(qkv, pos_all[:, li * d:(li + 1) * d], W["u"], W["v"], att_mask, b, t2, self.heads, 64)
+            x = K.dropout_add(x, ops.gemm(ctx, W["o_w"], bias=W["o_b"]), 1.0, pd, seed, salt(li, 2))
+            a = ops.layernorm(x, l.norm_conv.gamma, l.norm_conv.beta, row_scale=mask_rows)
+            y = ops.gemm(a, W["pw1_w"], bias=W["pw1_b"])
+            wv, _, _ = K.convmid_fwd_train(y, b, t2, W["dw_w"], cm.depthwise_conv.bias.detach().float().contiguous(),
+                                           cm.norm.weight.detach().float().contiguous(), cm.norm.bias.detach().float().contiguous(),
+                                           cm.norm.running_mean, cm.norm.running_var, eps=cm.norm.eps, momentum=cm.norm.momentum)
+            o = ops.gemm(wv, W["pw2_w"], bias=W["pw2_b"], row_scale=mask_rows)
+            x = K.dropout_add(x, o, 1.0, pd, seed, salt(li, 3))
+            x = ffn(x, W, "ff", l.norm_ff, li, 6)
+            ops.layernorm(x, l.norm_final.gamma, l.norm_final.beta, out_dtype=f32, out=x)
+        x = ops.layernorm(x, self.after_norm.gamma, self.after_norm.beta, out_dtype=f32)
+        self._bn_dirty = True  # the running statistics folded into the eval path's bn_scale / bn_shift have moved
+        return x.view(b, t2, d), masks
+
+    @torch.no_grad()
+    def _refresh_bn(self, P):
+        """Re-fold BatchNorm (running statistics) + depthwise bias into the affine form the eval kernels read."""
+        for l, W in zip(self.encoders, P["layers"]):
+            cm, bn = l.conv_module, l.conv_module.norm
+            scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+            W["bn_scale"].copy_(scale.float())
+            W["bn_shift"].copy_((bn.bias.detach() + (cm.depthwise_conv.bias.detach() - bn.running_mean) * scale).float())
+        self._bn_dirty = False
 
     @torch.no_grad()
     def forward(self, xs, masks, xs_chunk_masks=None):
         """xs (B, T, idim) float32 on the HIP device; masks (B, 1, T') — the subsampled pad mask the collate
         function builds (dataset.py:620-632). Returns (xs (B, T', 256) float32, masks) like BaseEncoder.construct
         (models/conformer.py:229-258)."""
-        if self.training:
-            raise NotImplementedError("training-mode forward (dropout, BatchNorm batch statistics, backward) is the "
-                                      "next row; call .eval()")
         if self._prepared is None:
             self.prepare()
         P = self._prepared
         f32 = torch.float32
+        if not self.training and self._bn_dirty:
+            self._refresh_bn(P)
+        if self.training:
+            if self.d != 256 or self.kernel not in (3, 7, 15, 31):
+                raise NotImplementedError("the training-mode kernels are built for d_model 256")
+            return self._forward_train(xs.to(f32), P, masks, xs_chunk_masks)
         b = xs.shape[0]
         act2 = self._subsample(xs.to(f32), P)  # (any strides: conv1 reads the view as it is)
         _, t2, f2, c = act2.shape

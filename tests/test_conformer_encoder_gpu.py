@@ -92,8 +92,8 @@ def test_encoder_full_config_shapes_and_determinism():
     assert torch.equal(got, got2)  # no atomics / no run-to-run variation
     err = got.cpu() - want
     assert float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) <= 2e-2
-    with pytest.raises(NotImplementedError):
-        dut.train()(xs.cuda(), sub.cuda())
+    got3, _ = dut.train()(xs.cuda(), sub.cuda())  # training mode: dropout + batch statistics (tested below)
+    assert tuple(got3.shape) == (2, 249, 256) and bool(torch.isfinite(got3).all())
 
 
 def test_encoder_north_star_size_properties():
@@ -218,3 +218,144 @@ def test_encoder_accepts_strided_features():
     a, _ = enc(view, masks)
     b, _ = enc(view.contiguous(), masks)
     assert not view.is_contiguous() and torch.equal(a, b)
+
+
+def test_asr_model_hybrid_eval_loss_and_decoder_scores_match_oracle():
+    """create_asr_eval_net of the shipped conformer.yaml (ctc_weight 0.3, TransformerDecoder, label smoothing 0.1;
+    asr_model.py:75-209, 355-371): decoder scores, attention loss, accuracy and the mixed loss vs the float32 oracle."""
+    import torch
+
+    from mindaudio_amd.conformer.asr_model import create_asr_model
+    from oracle import conformer_oracle as C
+
+    torch.manual_seed(23)
+    vocab, blocks, dblocks, b, tlen, lmax = 211, 2, 2, 3, 163, 9
+    ref_enc = C.ConformerEncoder(80, 256, 4, 2048, blocks).eval()
+    ref_ctc = C.CTC(vocab, 256).eval()
+    ref_dec = C.TransformerDecoder(vocab, 256, 4, 512, dblocks, 0.0, 0.0).eval()
+    with torch.no_grad():
+        for mod in ref_dec.modules():
+            if isinstance(mod, C.LayerNorm):
+                mod.gamma.uniform_(0.8, 1.2)
+                mod.beta.normal_(0, 0.1)
+    model = create_asr_model(80, vocab, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks),
+                             ctc_weight=0.3, decoder_conf=dict(attention_heads=4, linear_units=512, num_blocks=dblocks),
+                             lsm_weight=0.1).eval()
+    model.encoder.load_state_dict(ref_enc.state_dict(), strict=False)
+    model.ctc.load_state_dict(ref_ctc.state_dict())
+    missing, unexpected = model.decoder.load_state_dict(ref_dec.state_dict(), strict=False)
+    assert not missing and not unexpected
+    model = model.cuda()
+    xs = torch.randn(b, tlen, 80)
+    mask = torch.zeros(b, 1, tlen)
+    for i, n in enumerate([tlen, tlen - 30, tlen - 61]):
+        mask[i, 0, :n] = 1
+    sub = C.subsample_mask(mask)
+    ys_lens = torch.tensor([9, 6, 4], dtype=torch.int32)
+    ys = torch.full((b, lmax), -1, dtype=torch.int32)
+    sos = eos = vocab - 1
+    ys_in = torch.full((b, lmax + 1), eos, dtype=torch.int32)
+    ys_out = torch.full((b, lmax + 1), -1, dtype=torch.int32)
+    ys_masks = torch.zeros(b, 1, lmax + 1)
+    for i, n in enumerate(ys_lens.tolist()):
+        ys[i, :n] = torch.randint(1, vocab - 1, (n,), dtype=torch.int32)
+        ys_in[i, 0] = sos
+        ys_in[i, 1:n + 1] = ys[i, :n]
+        ys_out[i, :n] = ys[i, :n]
+        ys_out[i, n] = eos
+        ys_masks[i, 0, :n + 1] = 1
+    ys_sub = (ys_masks.bool() & torch.tril(torch.ones(lmax + 1, lmax + 1, dtype=torch.bool))[None]).float()
+    cols = (xs, ys, ys_in, ys_out, None, None, sub, ys_sub, ys_masks, ys_lens, None)
+    with torch.no_grad():
+        want, acc_ref, lc_ref, la_ref = C.hybrid_loss(ref_enc, ref_ctc, ref_dec, cols, 0.3, 0.1)
+        enc_ref, enc_mask = ref_enc(xs, sub)
+        dec_ref = ref_dec(enc_ref, enc_mask, ys_in.long(), ys_sub)
+    dev = [c.cuda() if c is not None else None for c in cols]
+    loss, acc = model(*dev)
+    assert abs(float(loss) - float(want)) <= 2e-2 * abs(float(want)), (float(loss), float(want))
+    assert abs(float(acc) - float(acc_ref)) <= 0.05
+    # the decoder on its own, fed the ORACLE's encoder output: scores before softmax
+    scores, _ = model.decoder(enc_ref.cuda(), enc_mask.cuda(), ys_in.cuda(), ys_sub.cuda())
+    valid = ys_masks[:, 0].bool()
+    err = (scores.cpu() - dec_ref)[valid]
+    assert float(err.pow(2).mean().sqrt() / dec_ref[valid].pow(2).mean().sqrt()) <= 2e-2
+    # pure-attention configuration (ctc_weight 0): the loss is the attention loss
+    model.ctc_weight = 0.0
+    la, _ = model(*dev)
+    assert abs(float(la) - float(la_ref)) <= 2e-2 * abs(float(la_ref))
+
+
+@pytest.mark.parametrize("d,heads,hidden", [(512, 8, 1024), (768, 12, 512)])
+def test_encoder_other_model_sizes_run_the_general_path(d, heads, hidden):
+    """ConformerEncoder(output_size, attention_heads, linear_units) of the reference constructor (models/conformer.py:293-313)
+    beyond Conformer-small: 64-wide heads with d_model 512 / 768 run one launch per reference cell on the general kernels."""
+    import torch
+
+    from mindaudio_amd.models import ConformerEncoder
+    from oracle import conformer_oracle as C
+
+    torch.manual_seed(d)
+    ref = C.ConformerEncoder(80, d, heads, hidden, 2).eval()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    dut = ConformerEncoder(80, d, heads, hidden, 2).eval()
+    missing, unexpected = dut.load_state_dict(ref.state_dict(), strict=False)
+    assert not missing and not unexpected
+    dut = dut.cuda().prepare()
+    assert not dut._prepared["fused"]
+    b, tlen = 2, 147
+    xs = torch.randn(b, tlen, 80)
+    mask = torch.ones(b, 1, tlen)
+    mask[1, 0, 100:] = 0
+    sub = C.subsample_mask(mask)
+    with torch.no_grad():
+        want, _ = ref(xs, sub)
+    got, _ = dut(xs.cuda(), sub.cuda())
+    e = got.cpu() - want
+    assert float(e.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) <= 2e-2
+    with pytest.raises(NotImplementedError):
+        ConformerEncoder(80, 144, 4, 576, 2)  # 36-wide heads: no kernel
+
+
+def test_encoder_train_mode_forward_matches_oracle_and_moves_bn_statistics():
+    """ConformerEncoder.train() forward = the reference cell in training mode (BatchNorm batch statistics over the B*T rows,
+    layers/convolution.py:113-121; dropout, here switched off so that the float32 oracle is comparable), then .eval() uses the
+    updated running statistics."""
+    import torch
+
+    from mindaudio_amd.models import ConformerEncoder
+    from oracle import conformer_oracle as C
+
+    torch.manual_seed(9)
+    ref = C.ConformerEncoder(80, 256, 4, 2048, 2, dropout_rate=0.0, positional_dropout_rate=0.0).train()
+    dut = ConformerEncoder(80, 256, 4, 2048, 2, dropout_rate=0.0, positional_dropout_rate=0.0)
+    dut.load_state_dict(ref.state_dict(), strict=False)
+    dut = dut.cuda().train()
+    b, tlen = 3, 131
+    xs = torch.randn(b, tlen, 80)
+    mask = torch.ones(b, 1, tlen)
+    mask[2, 0, 90:] = 0
+    sub = C.subsample_mask(mask)
+    with torch.no_grad():
+        want, _ = ref(xs, sub)
+    got, _ = dut(xs.cuda(), sub.cuda())
+    e = got.cpu() - want
+    assert float(e.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) <= 2e-2
+    for lr, ld in zip(ref.encoders, dut.encoders):
+        assert torch.allclose(ld.conv_module.norm.running_mean.cpu(), lr.conv_module.norm.running_mean, atol=2e-3)
+        assert torch.allclose(ld.conv_module.norm.running_var.cpu(), lr.conv_module.norm.running_var, rtol=2e-2, atol=2e-3)
+    with torch.no_grad():
+        want_eval, _ = ref.eval()(xs, sub)
+    got_eval, _ = dut.eval()(xs.cuda(), sub.cuda())
+    e = got_eval.cpu() - want_eval
+    assert float(e.pow(2).mean().sqrt() / want_eval.pow(2).mean().sqrt()) <= 2e-2
+    # dropout on: a different mask per call, finite output, statistics close to the dropout-free forward
+    dut2 = ConformerEncoder(80, 256, 4, 2048, 2, dropout_rate=0.1, positional_dropout_rate=0.1)
+    dut2.load_state_dict(ref.state_dict(), strict=False)
+    dut2 = dut2.cuda().train()
+    a, _ = dut2(xs.cuda(), sub.cuda())
+    c, _ = dut2(xs.cuda(), sub.cuda())
+    assert bool(torch.isfinite(a).all()) and not torch.equal(a, c)

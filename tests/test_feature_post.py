@@ -149,3 +149,49 @@ def test_device_istft_vs_reference(ig):
     assert float((y[256:-256] - x[256:5920 - 256]).abs().max()) <= 2e-6
     with pytest.raises(ValueError):
         ma.istft(ig["spec_h160"], n_fft=400)
+
+
+@pytest.mark.gpu
+def test_frame_vs_reference_golden():
+    """spectrum.frame on the device against the reference's own output (tests/golden/reference_goldens.npz, frame_2x20_8_3)
+    and against the oracle on larger inputs; float64 out whatever the input dtype (spectrum.py:299)."""
+    import torch
+
+    import mindaudio_amd as ma
+
+    gold = np.load(os.path.join(HERE, "golden", "reference_goldens.npz"))
+    x = np.arange(40, dtype=np.float64).reshape(2, 20)
+    got = ma.frame(x, 8, 3)
+    assert got.dtype == np.float64 and np.array_equal(got, gold["frame_2x20_8_3"])
+    rng = np.random.RandomState(3)
+    for shape, fl, hop, dt in (((3, 1000), 400, 160, np.float32), ((700,), 512, 128, np.float64), ((2, 2, 333), 64, 7, np.float32)):
+        xx = rng.randn(*shape).astype(dt)
+        got = ma.frame(xx, fl, hop)
+        assert got.dtype == np.float64 and np.array_equal(got, O.frame_ref(xx, fl, hop))
+    dev = ma.frame(torch.from_numpy(x).cuda(), 8, 3)
+    assert dev.is_cuda and dev.dtype == torch.float64 and np.array_equal(dev.cpu().numpy(), gold["frame_2x20_8_3"])
+    with pytest.raises(ValueError):
+        ma.frame(x, 8, 0)
+    with pytest.raises(ValueError):
+        ma.frame(x, 30, 3)
+
+
+@pytest.mark.gpu
+def test_magphase_real_pairs_normalized_spectrogram_and_log_mfcc():
+    import mindaudio_amd as ma
+
+    rng = np.random.RandomState(5)
+    z = rng.randn(3, 17, 9, 2).astype(np.float32)
+    z[0, 0, 0] = 0.0
+    mag, ang = ma.magphase(z, 2.0, iscomplex=False)
+    zc = z[..., 0].astype(np.float64) + 1j * z[..., 1].astype(np.float64)
+    assert np.allclose(mag, np.abs(zc) ** 2, rtol=1e-5, atol=1e-7) and np.allclose(ang, np.angle(zc), atol=2e-6)
+    x = (0.1 * rng.randn(2, 4000)).astype(np.float32)
+    plain = ma.spectrogram(x, n_fft=512, hop_length=160)
+    norm = ma.spectrogram(x, n_fft=512, hop_length=160, normalized=True)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(512) / 512)
+    assert np.allclose(norm, plain / np.sum(w * w), rtol=1e-5, atol=1e-12)  # power 2: |S / sqrt(sum w^2)|^2
+    got = ma.mfcc(x, deltas=False, context=False, n_mels=23, n_mfcc=20, n_fft=512, log_mels=True)
+    mel = O.melspectrogram(x, n_fft=512, n_mels=23)
+    want = np.matmul(np.log(mel + 1e-6).transpose(0, 2, 1), O.create_dct(20, 23, "ortho")).transpose(0, 2, 1)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-3 * np.abs(want).max()

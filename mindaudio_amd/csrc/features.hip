@@ -25,6 +25,7 @@
 
 #include "../../include/mindaudio_amd.h"
 #include "features_common.h"
+#include "fft400.h"
 #include "fft512.h"
 
 // Launch + error check.  hipGetLastError() is sticky across unrelated runtime calls of the host process
@@ -163,8 +164,11 @@ typedef __attribute__((address_space(1))) const void gl_void_t;
 //     is the same for every unit;
 //   * three waves per SIMD as three 4-wave workgroups per CU (tables 10 KB + 8.5 KB per wave = 45 KB per workgroup), 168 VGPRs
 //     without spills; every phase re-derives its lane-dependent offsets instead of keeping them live across the FFT.
-template <int MODE, bool MAG, int NW, int OCC>
+//   NFFT = 512 (radix 16 x 16, fft512.h) or 400 = the reference's default n_fft (radix 25 x 8, fft400.h): same tile, staging, mel phase.
+template <int MODE, bool MAG, int NW, int OCC, int NFFT = 512>
 __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams p) {
+  static_assert(NFFT == 512 || (NFFT == 400 && MODE != kModeKaldi), "transform sizes of the FFT path");
+  constexpr int kBinsN = NFFT / 2 + 1;
   constexpr int kThreads = NW * 64;
   constexpr int kOffMel = off_mel(NW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
   };
   // stage the samples of frames [f_lo, f_lo + frames_per_round) of the unit in the wave's tile (asynchronous when it is an LDS-DMA)
   auto stage = [&](const Geo& g, int f_lo) __attribute__((always_inline)) {
-    const int flen = (MODE == kModeKaldi) ? p.frame_len : 512;
+    const int flen = (MODE == kModeKaldi) ? p.frame_len : NFFT;
     const int nfr = (g.fv - f_lo) < p.frames_per_round ? (g.fv - f_lo) : p.frames_per_round;
     const int s_lo = (g.t0 + f_lo) * p.hop - p.pad_left - kLead;  // first staged sample
     const int span = (nfr - 1) * p.hop + flen + kLead;            // staged samples (<= kPwFloats)
@@ -272,9 +276,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
 
   // ---- per-workgroup tables (once: the grid is persistent)
   {
-    if (tid < 256) reinterpret_cast<float2*>(tw256)[tid] = make_float2(kTw256[2 * tid], kTw256[2 * tid + 1]);
-    for (int i = tid; i < 257; i += kThreads) tw512[i] = make_float2(kTw512[2 * i], kTw512[2 * i + 1]);
-    for (int i = tid; i < 512; i += kThreads) win[i] = (i < p.frame_len) ? 0.5f * p.window[i] : 0.0f;
+    if (NFFT == 512) {
+      if (tid < 256) reinterpret_cast<float2*>(tw256)[tid] = make_float2(kTw256[2 * tid], kTw256[2 * tid + 1]);
+      for (int i = tid; i < 257; i += kThreads) tw512[i] = make_float2(kTw512[2 * i], kTw512[2 * i + 1]);
+    } else {  // the 400-point transform's tables live in the same two regions
+      if (tid < 200) reinterpret_cast<float2*>(tw256)[tid] = make_float2(kTw200[2 * tid], kTw200[2 * tid + 1]);
+      for (int i = tid; i < 201; i += kThreads) tw512[i] = make_float2(kTw400[2 * i], kTw400[2 * i + 1]);
+    }
+    for (int i = tid; i < NFFT; i += kThreads) win[i] = (i < p.frame_len) ? 0.5f * p.window[i] : 0.0f;
     if (MODE != kModeStft) {
       for (int i = tid; i < p.n_rows * 8; i += kThreads) mstart[i] = p.mel_start[i];
       const float4* __restrict__ wsrc = reinterpret_cast<const float4*>(p.mel_w);
@@ -291,11 +300,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
     const float half_mean = g.half_mean;
 
     if (fv > 0) {
-      float ar[16], ai[16], br[16], bi[16];
+      // the frame's samples of this lane (x window / 2): 512: two complex columns of 16; 400: one complex column of 25
+      constexpr int kNA = NFFT == 512 ? 16 : 25, kNB = NFFT == 512 ? 16 : 1;
+      float ar[kNA], ai[kNA], br[kNB], bi[kNB];
       const int fl = opaque_lane() >> 3;  // FFT phase: lane group = frame of the unit
-      if (fv < kUnitFrames) {
+      if (fv < kUnitFrames) {  // lanes of frames that do not exist
 #pragma unroll
-        for (int m1 = 0; m1 < 16; ++m1) ar[m1] = ai[m1] = br[m1] = bi[m1] = 0.0f;  // lanes of frames that do not exist
+        for (int m1 = 0; m1 < kNA; ++m1) ar[m1] = ai[m1] = 0.0f;
+#pragma unroll
+        for (int m1 = 0; m1 < kNB; ++m1) br[m1] = bi[m1] = 0.0f;
       }
       // ---- the unit's samples are staged in the tile: pick up this lane's 64 of them (x window / 2) -----------
       for (int f_lo = 0; f_lo < fv; f_lo += p.frames_per_round) {
@@ -307,6 +320,24 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
         const int fr = fl - f_lo;
         if (fr >= 0 && fr < nfr) {
           const int l = opaque_lane() & 7;
+          if constexpr (NFFT == 400) {
+            const float* __restrict__ sp = Pw + fr * p.hop + 2 * l;
+            const float* __restrict__ wp = win + 2 * l;
+            if (!(p.hop & 1)) {
+#pragma unroll
+              for (int m1 = 0; m1 < 25; ++m1) {
+                const float2 w = *reinterpret_cast<const float2*>(wp + 16 * m1);
+                const float2 x = *reinterpret_cast<const float2*>(sp + 16 * m1);
+                ar[m1] = x.x * w.x; ai[m1] = x.y * w.y;
+              }
+            } else {
+#pragma unroll
+              for (int m1 = 0; m1 < 25; ++m1) {
+                const float2 w = *reinterpret_cast<const float2*>(wp + 16 * m1);
+                ar[m1] = sp[16 * m1] * w.x; ai[m1] = sp[16 * m1 + 1] * w.y;
+              }
+            }
+          } else {
           const float* __restrict__ sp = Pw + kLead + fr * p.hop + 4 * l;
           const float* __restrict__ wp = win + 4 * l;
           if (!(p.hop & 3)) {
@@ -347,6 +378,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
               }
             }
           }
+          }  // NFFT == 512
         }
         wave_lds_sync();  // the tile is reused: next round's span, then the transpose slots
       }
@@ -354,10 +386,37 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
 
       const int t = t0 + fl;
       const bool valid = fl < fv;
-      const Rfft512Lane L = rfft512_lane_setup(opaque_lane());
-      const int l = L.l;
       float* __restrict__ prow_fft = Pw + fl * kPStride;   // this frame's power row
       float* __restrict__ slot = Pw + fl * kSlotStride;    // ... and exchange slot
+      if constexpr (NFFT == 400) {
+        const Rfft400Lane L4 = rfft400_lane_setup(opaque_lane());
+        const float2* __restrict__ tw200 = reinterpret_cast<const float2*>(tw256);
+        if (MODE == kModeStft) {
+          const int64_t stride = (p.layout == MA_STFT_FRAME_MAJOR) ? 1 : p.n_frames;
+          float2* __restrict__ o = reinterpret_cast<float2*>(p.out) +
+                                   ((p.layout == MA_STFT_FRAME_MAJOR) ? ((int64_t)b * p.n_frames + t) * kBinsN
+                                                                       : (int64_t)b * kBinsN * p.n_frames + t);
+          rfft400_x8(ar, ai, L4, tw200, tw512, slot, [&](int pair, int r, float xr, float xi, float yr, float yi) {
+            if (valid) {
+              const int k = L4.row[2 * pair] + 25 * r;
+              o[(int64_t)k * stride] = make_float2(xr, xi);
+              o[(int64_t)(200 - k) * stride] = make_float2(yr, yi);
+            }
+          });
+        } else {
+          rfft400_x8(ar, ai, L4, tw200, tw512, slot, [&](int pair, int r, float xr, float xi, float yr, float yi) {
+            float pa = xr * xr + xi * xi;
+            float pb = yr * yr + yi * yi;
+            if (MAG) { pa = sqrtf(pa); pb = sqrtf(pb); }
+            const int k = L4.row[2 * pair] + 25 * r;
+            prow_fft[k] = pa;
+            prow_fft[200 - k] = pb;
+          });
+          if (L4.l >= 1 && L4.l < 4) prow_fft[200 + L4.l] = 0.0f;  // zero tail [201..203] read by the 16-byte mel loop
+        }
+      } else {
+      const Rfft512Lane L = rfft512_lane_setup(opaque_lane());
+      const int l = L.l;
       if (MA_DBG(8)) {
         float sacc = 0.f;
 #pragma unroll
@@ -402,6 +461,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
                      }
                    });
       }
+      }  // NFFT == 512
       MA_PROF(2);
       MA_STAMP(4);  // fft done
 
@@ -653,13 +713,13 @@ static size_t feat_lds_bytes(int mode, int n_mels, int n_rows, int total_steps, 
   return (b + 15) & ~(size_t)15;
 }
 
-template <int MODE, bool MAG, int NW, int OCC>
+template <int MODE, bool MAG, int NW, int OCC, int NFFT = 512>
 static int launch_feat_cfg(const FeatParams& p_in, hipStream_t stream, int* grid_out) {
   FeatParams p = p_in;
   MA_SET_PROF(p);
   {
     // frames of a unit whose sample span fits the wave's tile at once (hop 160: all 8; the reference's default hop 256: 7 + 1)
-    const int flen = (MODE == kModeKaldi) ? p.frame_len + 4 : 512;
+    const int flen = (MODE == kModeKaldi) ? p.frame_len + 4 : NFFT;
     int f = kUnitFrames;
     while (f > 1 && (int64_t)(f - 1) * p.hop + flen > kPwFloats) --f;
     p.frames_per_round = f;
@@ -672,7 +732,7 @@ static int launch_feat_cfg(const FeatParams& p_in, hipStream_t stream, int* grid
   static size_t cached_lds = 0;
   static int cached_per_cu = 0;
   if (cached_lds != lds) {
-    const void* fn = reinterpret_cast<const void*>(&feat512_kernel<MODE, MAG, NW, OCC>);
+    const void* fn = reinterpret_cast<const void*>(&feat512_kernel<MODE, MAG, NW, OCC, NFFT>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return MA_ERR_LAUNCH;
     int per_cu = 0;
@@ -688,7 +748,7 @@ static int launch_feat_cfg(const FeatParams& p_in, hipStream_t stream, int* grid
   if (grid > need) grid = need;
   if (grid < 1) return MA_OK;
   if (grid_out) *grid_out = (int)grid;
-  MA_LAUNCH((feat512_kernel<MODE, MAG, NW, OCC>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, p);
+  MA_LAUNCH((feat512_kernel<MODE, MAG, NW, OCC, NFFT>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, p);
   return MA_OK;
 }
 
@@ -701,8 +761,12 @@ static int launch_feat_cfg(const FeatParams& p_in, hipStream_t stream, int* grid
 template <int MODE, bool MAG>
 static int launch_feat_impl(const FeatParams& p, hipStream_t stream, int* grid_out) {
   // the Kaldi front end keeps its row results in registers across the mel phase (215 VGPRs): two waves per SIMD
-  if (MODE == kModeKaldi) return launch_feat_cfg<MODE, MAG, 4, 2>(p, stream, grid_out);
-  return launch_feat_cfg<MODE, MAG, 4, 3>(p, stream, grid_out);
+  if constexpr (MODE == kModeKaldi) {
+    return launch_feat_cfg<MODE, MAG, 4, 2>(p, stream, grid_out);
+  } else {
+    if (p.frame_len == 400) return launch_feat_cfg<MODE, MAG, 4, 3, 400>(p, stream, grid_out);  // the reference's default n_fft
+    return launch_feat_cfg<MODE, MAG, 4, 3>(p, stream, grid_out);
+  }
 }
 
 template <int MODE>
@@ -767,7 +831,7 @@ static int fill_common(FeatParams& p, const float* wav, int64_t batch, int64_t n
   if (hop < 1) return MA_ERR_HOP;
   if (n_fft > n) return MA_ERR_NFFT_TOO_LARGE;
   if (pad_mode < MA_PAD_CONSTANT || pad_mode > MA_PAD_SYMMETRIC) return MA_ERR_INVALID_ARG;
-  if (n_fft != 512 && (n_fft < 4 || (n_fft & 1) || n_fft > 1024)) return MA_ERR_UNSUPPORTED;
+  if (n_fft != 512 && n_fft != 400 && (n_fft < 4 || (n_fft & 1) || n_fft > 1024)) return MA_ERR_UNSUPPORTED;
   p = FeatParams{};
   p.wav = wav;
   p.window = window;
@@ -793,7 +857,7 @@ int ma_stft_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stride, 
   if (!out || (layout != MA_STFT_FRAME_MAJOR && layout != MA_STFT_FREQ_MAJOR)) return MA_ERR_INVALID_ARG;
   p.out = out;
   p.layout = layout;
-  if (n_fft != 512) return launch_feat_generic(p, kModeStft, n_fft, (hipStream_t)stream, nullptr);
+  if (n_fft != 512 && n_fft != 400) return launch_feat_generic(p, kModeStft, n_fft, (hipStream_t)stream, nullptr);
   return launch_feat<kModeStft>(p, (hipStream_t)stream);
 }
 
@@ -823,7 +887,7 @@ int ma_melspectrogram_f32(const float* wav, int64_t batch, int64_t n, int64_t wa
   if (rc != MA_OK) return rc;
   p.out = out;
   p.apply_db = 0;
-  if (n_fft != 512) return launch_feat_generic(p, kModeMel, n_fft, (hipStream_t)stream, nullptr);
+  if (n_fft != 512 && n_fft != 400) return launch_feat_generic(p, kModeMel, n_fft, (hipStream_t)stream, nullptr);
   return launch_feat<kModeMel>(p, (hipStream_t)stream);
 }
 
@@ -846,7 +910,7 @@ int ma_fbank_db_f32(const float* wav, int64_t batch, int64_t n, int64_t wav_stri
   p.unit_min = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_partial_bytes(batch, p.n_frames));
   p.wg_max = p.unit_min + p.num_units;
   int grid = 0;
-  rc = n_fft != 512 ? launch_feat_generic(p, kModeMel, n_fft, (hipStream_t)stream, &grid)
+  rc = (n_fft != 512 && n_fft != 400) ? launch_feat_generic(p, kModeMel, n_fft, (hipStream_t)stream, &grid)
                     : launch_feat<kModeMel>(p, (hipStream_t)stream, &grid);
   if (rc != MA_OK) return rc;
   if (top_db >= 0.0f && grid > 0) {

@@ -273,6 +273,7 @@ int launch_feat_generic(const FeatParams& p, int mode, int n_fft, hipStream_t st
 
 extern "C" int32_t ma_mel_row_stride(int32_t n_fft) {
   if (n_fft == 512) return 260;
+  if (n_fft == 400) return 204;  // the 25 x 8 FFT path (fft400.h): 201 bins + 3 zeros
   if (n_fft < 4 || (n_fft & 1) || n_fft > 1024) return MA_ERR_UNSUPPORTED;
   return ma::make_geom(n_fft).ps;
 }

@@ -652,6 +652,15 @@ int ma_grad_overflow_f32(const float* g, int64_t n, int32_t* flag, ma_stream_t s
 int ma_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                 float eps, float inv_scale, const int32_t* overflow, ma_stream_t stream);
 
+/* Res2NetBlock (ecapatdnn.py:66-114) in one launch: y_0 = x_0, y_i = BN(ReLU(conv_{k=3,dil}(x_i + y_{i-1}) + b_i)), i = 1..scale-1
+ * (y_1 from x_1 alone), x_i = columns [i cc, (i+1) cc) of x.  x, y: (batch, T + 2 halo, >= scale * cc) bf16 with zero halo rows
+ * (pointers at the first halo row of utterance 0); w (scale-1, cc, 3 cc) bf16 with K = tap * cc + c; bias / bn_scale / bn_shift
+ * (scale-1, cc) float32.  cc in {64, 128}, scale 8, dil <= halo, T + 2 halo <= 384; a workgroup owns one utterance for the whole chain. */
+int64_t ma_res2net_fused_lds_bytes(int32_t cc, int64_t tp, int32_t dil);
+int ma_res2net_fused_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t batch, int64_t T, int32_t halo, int32_t cc,
+                          int32_t scale, int32_t dil, const void* w, const float* bias, const float* bn_scale,
+                          const float* bn_shift, ma_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * float32 validation mode of the training step ("x32"): compute_type = float32 is the reference's default
  * (mindaudio/models/conformer.py:61, examples/conformer/asr_model.py:307-310).  Every activation and every product stays

@@ -193,6 +193,8 @@ PROTOTYPES = {
     "ma_db_workspace_bytes": (i64, [i64, i64]),
     "ma_amplitude_to_db_f32": (ctypes.c_int, [c_f32p, i64, i64, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),
+    "ma_res2net_fused_lds_bytes": (i64, [i32, i64, i32]),
+    "ma_res2net_fused_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     # ---- float32 validation mode (x32) ----
     "ma_gemm_x32": (ctypes.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, ctypes.POINTER(GemmEpilogue), vp]),
     "ma_colsum_x32": (ctypes.c_int, [vp, i64, i64, i64, vp, i32, vp]),

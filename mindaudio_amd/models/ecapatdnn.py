@@ -98,6 +98,7 @@ class EcapaTDNN(nn.Module):
         self.asp_bn = nn.BatchNorm1d(6 * c, eps=1e-5)
         self.fc = nn.Conv1d(6 * c, lin_neurons, 1)
         self._prepared = None
+        self.fuse_res2net = True  # False: one launch per convolution / add of the Res2Net chain (the tests run both)
 
     @torch.no_grad()
     def prepare(self):
@@ -120,8 +121,13 @@ class EcapaTDNN(nn.Module):
         self.fpad = (self.input_size + 63) // 64 * 64
         P = {"l0": tdnn(self.blocks[0], self.fpad), "blocks": []}
         for blk in self.blocks[1:]:
-            P["blocks"].append(dict(t1=tdnn(blk.tdnn1), r=[tdnn(b) for b in blk.res2net_block.blocks], t2=tdnn(blk.tdnn2),
-                                    se1=lin(blk.se_block.conv1), se2=lin(blk.se_block.conv2)))
+            r = [tdnn(b) for b in blk.res2net_block.blocks]
+            P["blocks"].append(dict(t1=tdnn(blk.tdnn1), r=r, t2=tdnn(blk.tdnn2), se1=lin(blk.se_block.conv1),
+                                    se2=lin(blk.se_block.conv2),
+                                    # the whole chain for the one-launch form (ma_res2net_fused_bf16)
+                                    r_w=torch.stack([q["w"] for q in r]).contiguous(), r_b=torch.stack([q["b"] for q in r]).contiguous(),
+                                    r_s=torch.stack([q["bn"][0] for q in r]).contiguous(),
+                                    r_t=torch.stack([q["bn"][1] for q in r]).contiguous()))
         P["mfa"] = tdnn(self.mfa)
         P["asp_t"] = tdnn(self.asp.tdnn)
         P["asp_c"] = lin(self.asp.conv)
@@ -175,9 +181,16 @@ class EcapaTDNN(nn.Module):
             _conv(cur.data_ptr(), cur_ld, rows, c, B_["t1"]["w"], 1, 1, t1.data_ptr(), c, c, B_["t1"]["b"], RELU,
                   B_["t1"]["bn"], row_scale=rs)
             _, y = buf(c)
-            _, tmp = buf(cc)
-            _lib.check(lib.ma_add_bf16(t1.data_ptr(), c, None, 0, y.data_ptr(), c, rows, cc, s), "res2net copy")
-            for i in range(1, self.scale):
+            fused = (self.fuse_res2net and k == 3 and self.scale == 8 and cc in (64, 128) and tp <= 384 and d <= H
+                     and 0 < lib.ma_res2net_fused_lds_bytes(cc, tp, d) <= 160 * 1024)
+            if fused:  # the 7 dilated convolutions + adds of the block in one launch, one utterance per workgroup
+                _lib.check(lib.ma_res2net_fused_bf16(t1.data_ptr(), c, y.data_ptr(), c, b, T, H, cc, self.scale, d,
+                                                     B_["r_w"].data_ptr(), B_["r_b"].data_ptr(), B_["r_s"].data_ptr(),
+                                                     B_["r_t"].data_ptr(), s), "res2net_fused")
+            else:
+                _, tmp = buf(cc)
+                _lib.check(lib.ma_add_bf16(t1.data_ptr(), c, None, 0, y.data_ptr(), c, rows, cc, s), "res2net copy")
+            for i in range(1, self.scale if not fused else 1):
                 R = B_["r"][i - 1]
                 if i == 1:
                     src, ld = t1[:, cc:2 * cc], c

@@ -94,3 +94,29 @@ def test_ecapa_cfg5_full_shape(c):
     assert float((alone - got[idx]).abs().max()) <= 2e-2 * float(got[idx].abs().max())
     # and the launch is deterministic
     assert torch.equal(dut(x.cuda()).cpu(), got)
+
+
+@pytest.mark.parametrize("c,b,t", [(512, 3, 57), (512, 2, 300), (1024, 2, 300), (512, 2, 376), (1024, 3, 376)])
+def test_res2net_chain_in_one_launch_equals_the_separate_launches(c, b, t):
+    """ma_res2net_fused_bf16 (the 7 dilated convolutions + adds of a Res2NetBlock, ecapatdnn.py:66-114, one utterance per
+    workgroup) against the one-launch-per-cell form on the same weights: same bf16 rounding points, so the embeddings agree to
+    accumulation-order round-off; both are held to the float32 oracle by the tests above."""
+    ref, dut = build(c=c, seed=5)
+    x = torch.randn(b, t, 80, generator=torch.Generator().manual_seed(t)).cuda()
+    assert dut.fuse_res2net
+    fused = dut(x)
+    dut.fuse_res2net = False
+    plain = dut(x)
+    assert float((fused - plain).abs().max()) <= 2e-2 * float(plain.abs().max())
+    with torch.no_grad():
+        want = ref(x.cpu())
+    assert float((fused.cpu() - want).norm() / want.norm()) < 3e-2
+
+
+def test_res2net_long_utterances_fall_back():
+    ref, dut = build(c=512, seed=6)
+    x = torch.randn(2, 500, 80)  # T + 2H > 384 rows: the chain runs as separate launches
+    with torch.no_grad():
+        want = ref(x)
+    got = dut(x.cuda()).cpu()
+    assert float((got - want).norm() / want.norm()) < 3e-2

@@ -1,27 +1,42 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/profile_round.sh <tag>   -> gpurun_out/profile_<tag>/
+#   bench kernel stats (rocprofv3 --kernel-trace --stats), separate --pmc passes for the two roofline kernels, kernel-trace
+#   durations of the roofline kernels launched alone, and the blit census of one step.
 set -u
 TAG=$1
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --no-sustained > $OUT/bench.log 2>&1
 for W in fbank ffnpair; do
   i=0
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" "GRBM_GUI_ACTIVE"; do
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" \
+           "SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE"; do
     i=$((i+1))
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/${W}_p$i -o c -- python3 $R/tools/prof_target.py $W 5 > $OUT/${W}_p$i.log 2>&1
   done
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/${W}_trace -o t -- python3 $R/tools/prof_target.py $W 30 > $OUT/${W}_trace.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
 out="$OUT"
 txt=open(glob.glob(out+"/bench/*kernel_stats.csv")[0]).read()
 open(out+"/bench_kernel_stats.csv","w").write(txt)
-lines=txt.splitlines()
-print("\n".join(l[:170] for l in lines[:12]))
+print("\n".join(l[:170] for l in txt.splitlines()[:14]))
+# blit census: __amd_rocclr_copyBuffer launches between consecutive fbank launches of the timed steps
+rows=sorted(csv.DictReader(open(glob.glob(out+"/bench/*kernel_trace.csv")[0])), key=lambda r:int(r["Start_Timestamp"]))
+names=[r["Kernel_Name"] for r in rows]
+fb=[i for i,n in enumerate(names) if "feat512_kernel" in n]
+per=[sum(1 for n in names[a:b] if "copyBuffer" in n) for a,b in zip(fb[:-1],fb[1:])]
+total=sum(1 for n in names if "copyBuffer" in n)
+with open(out+"/blit_census.txt","w") as fh:
+    line="copyBuffer launches: %d in the whole run; between consecutive fbank launches (one step each): %s"%(total, collections.Counter(per).most_common(4))
+    fh.write(line+"\n"); print(line)
+    before=sum(1 for n in names[:fb[0]] if "copyBuffer" in n) if fb else 0
+    line="  before the first step (model .to(device), prepare(), synthetic batch): %d"%before
+    fh.write(line+"\n"); print(line)
 with open(out+"/pmc_summary.txt","w") as fh:
     for w in ("fbank","ffnpair"):
         agg=collections.defaultdict(lambda: collections.defaultdict(list))
@@ -34,5 +49,11 @@ with open(out+"/pmc_summary.txt","w") as fh:
             for c,vals in sorted(v.items()):
                 line="  %-30s mean per launch %.5g  (n=%d)"%(c,sum(vals)/len(vals),len(vals))
                 fh.write(line+"\n"); print(line)
+with open(out+"/roofline_kernels_trace.txt","w") as fh:
+    for w,kn in (("fbank","feat512_kernel"),("ffnpair","ffn_packed_kernel")):
+        d=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in csv.DictReader(open(glob.glob(out+"/%s_trace/*kernel_trace.csv"%w)[0])) if kn in r["Kernel_Name"]]
+        d=d[5:]
+        line="%s launched alone (tools/prof_target.py %s): %d launches, kernel-trace duration mean %.1f us, min %.1f, max %.1f"%(kn,w,len(d),sum(d)/len(d),min(d),max(d))
+        fh.write(line+"\n"); print(line)
 PY
-tail -1 $OUT/bench.log | cut -c1-400
+tail -1 $OUT/bench.log | cut -c1-600

@@ -37,6 +37,8 @@
 namespace ma {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((address_space(1))) void pk_gl_void_t;
+typedef __attribute__((address_space(3))) void pk_lds_void_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 template <int... Is, class F>
@@ -57,7 +59,9 @@ constexpr int kPkBlock = 32;                  // hidden units per (wave, step)
 constexpr int kPkItems = 32;                  // 1 KiB fragments per block: 16 of W1 (k-step, tile), 16 of W2 (output tile)
 constexpr int kPkOffPar = 128 * 1024;         // b2, gamma1, beta1, gamma2, beta2 (5 x 1 KiB), staged once at kernel start
 constexpr int kPkOffPar2 = kPkOffPar + 5 * 1024;  // pair mode, second stage: b2', gamma3, beta3
-constexpr int kPkLds = kPkOffPar2 + 3 * 1024;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
+constexpr int kPkOffPar0 = kPkOffPar2 + 3 * 1024;  // gamma0, beta0 of the input LayerNorm
+constexpr int kPkOffBias = kPkOffPar0 + 2 * 1024;  // b1 of each wave's first two blocks (4 x 64 floats)
+constexpr int kPkLds = kPkOffBias + 1024;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
 constexpr int kPkMaxHidden = 8192;
 
 struct FfnPackedParams {
@@ -102,6 +106,45 @@ __device__ __forceinline__ uint32_t pk_pack_bf16(float lo, float hi) {
 // lives across the whole stage loop and was spilled (its scratch reload sat behind the residual stores: +1 us per stage)
 __device__ __forceinline__ float pk_shfl_xor(float x, int mask, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, __builtin_bit_cast(int, x)));
+}
+#ifndef MA_FFN_WT
+#define MA_FFN_WT 0
+#endif
+// Phase stamps for tools/ffn_timeline.py (compiled in only with -DMA_FFN_PROF; the shipped library has none of it): wave 0 of the
+// workgroups 0, 97 and 248 write wall_clock64() (100 MHz) at every phase boundary.
+#ifdef MA_FFN_PROF
+__device__ unsigned long long g_ffn_prof[3 * 32];
+// stamps stay in SGPRs (a store inside the main loop would break its counted vmcnt waits) and are written out at points where
+// nothing is in flight
+#define PK_STAMP(k)                                   \
+  do {                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    pk_ts[(k)] = wall_clock64();                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  } while (0)
+#define PK_STAMP_FLUSH(base, n)                                                                        \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 97 || blockIdx.x == 248)) {             \
+      for (int k_ = 0; k_ < (n); ++k_)                                                                \
+        g_ffn_prof[(blockIdx.x == 0 ? 0 : blockIdx.x == 97 ? 32 : 64) + (base) + k_] = pk_ts[k_];     \
+    }                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+  } while (0)
+#else
+#define PK_STAMP(k) do { } while (0)
+#define PK_STAMP_FLUSH(base, n) do { } while (0)
+#endif
+// 16-byte global store; WT = write-through (sc0 sc1): the line leaves the L2 when it is written instead of at the end-of-kernel
+// write-back
+template <int WT>
+__device__ __forceinline__ void pk_store16(void* ptr, uint4 v4) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  const u32x4 v = {v4.x, v4.y, v4.z, v4.w};
+  if constexpr (WT == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+  else if constexpr (WT == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(v) : "memory");
+  else if constexpr (WT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(ptr), "v"(v) : "memory");
+  else if constexpr (WT == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+  else *reinterpret_cast<uint4*>(ptr) = v4;
 }
 template <int ABL>
 __device__ __forceinline__ float pk_swish(float v) {
@@ -213,6 +256,9 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wf), "v"(hf));                       \
   } while (0)
 
+#ifdef MA_FFN_PROF
+  unsigned long long pk_ts[8];
+#endif
   f32x4 O[16][4];
 
   bf16x8 ring[16];   // weight fragments: W1 of block b+1 / W2 of block b / W1 of block b+2 ... rotate through the same 16 slots
@@ -358,6 +404,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // The staging and epilogue addresses below are loop-invariant, and hipcc would hoist all of them out of this loop and SPILL them
   // around the main loop (measured: +4 us on one workgroup's critical path, every scratch reload drains the loads in flight).
   // They are cheap to recompute: derive them from per-iteration opaque copies of the block / thread index instead.
+  PK_STAMP(0);
   int m0v = m0, tidv = tid;
   asm volatile("" : "+s"(m0v));
   asm volatile("" : "+v"(tidv));
@@ -365,43 +412,63 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     wp_cur = reinterpret_cast<const char*>(p.wp_b);
     b1_cur = p.b1_b;
   }
-#pragma unroll
-  for (int j = 0; j < 16; ++j)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) O[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (nsb > 0) {  // the first block's weight fragments are requested before the activation tile: their L2 latency hides under it
+  // The first block's weight fragments are requested before anything else: their L2 latency hides under the tile staging.  (asm
+  // loads: they must stay the OLDEST loads in flight - the compiler's vmcnt bookkeeping for the staging loads below does not see
+  // them - and nothing but ring[] may be in flight across compiler-scheduled code: a register the allocator decides to spill is
+  // stored right after its defining asm, i.e. before the load has landed.)  The first two blocks' biases go to LDS by LDS-DMA.
+  if (nsb > 0) {
     const char* w0 = wbase(0);
 #pragma unroll
     for (int q = 0; q < 16; ++q)
       asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
                    : "=v"(ring[q]) : "v"(PK_VOFF(q)), "s"(w0), "n"((((q) & 7) - 4) * 1024) : "memory");
     if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int l = tidv & 63;
+    const float* bsrc = b1_cur + (l < 32 ? block_of(0) : block_of(blk_wrap(1))) * kPkBlock + (l & 31);
+    __builtin_amdgcn_global_load_lds((pk_gl_void_t*)bsrc, (pk_lds_void_t*)(smem + kPkOffBias + wave * 256), 4, 0, 0);
   }
   // ---- activation tile -> LDS: [64 rows][544 B] (512 + 32 of padding).  A ds_read_b128 serves lanes in groups of 16
   // ({0-3,12-15,20-27}, ...); with this pitch the 16-byte slot of lane (c, g) is (2 c + g + 4 ks) mod 16, distinct inside every
   // group, and the k-step is a plain +64 B immediate offset (an XOR swizzle costs an address register per k-step) -------------
   if (stg == 0) {
   const int tid = tidv, m0 = m0v;
+  {  // epilogue / LayerNorm parameters -> LDS by LDS-DMA (no registers; wave w copies elements 64 w .. 64 w + 63 of each):
+     // b2, g1, be1, g2, be2 | b2', g3, be3 | g0, be0.  Issued first, so that they are in flight under the row loads below.
+    const float* srcs[10] = {p.b2, p.g1, p.be1, p.g2, p.be2, p.b2_b, p.g3, p.be3, p.g0, p.be0};
+    char* par_w = smem + kPkOffPar + (tid >> 6) * 256;
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+      if (srcs[k])
+        __builtin_amdgcn_global_load_lds((pk_gl_void_t*)(srcs[k] + tid), (pk_lds_void_t*)(par_w + k * 1024), 4, 0, 0);
+  }
   if (p.g0) {
-    // a = LayerNorm(x) on the fly (two-pass, as layernorm_kernel): 4 threads per row, 64 features each
+    // a = LayerNorm(x) on the fly (two-pass, as layernorm_kernel): 4 threads per row; float4 i of thread (row, part) = features
+    // 32 (i >> 1) + 8 part + 4 (i & 1): the four threads of a row read 128 contiguous bytes per pair of loads.
+    // ALL 16 loads are issued before the first use (sched_barrier): as the compiler scheduled them, the staging was a chain of seven
+    // dependent round trips - 8.2 us from kernel start to the first MFMA (tools/ffn_timeline.py).
     const int row = tid >> 2, part = tid & 3;
     int m = m0 + row;
     if (m >= p.M) m = p.M - 1;
-    const float* xr = p.x + (int64_t)m * p.ldx + part * 64;
-    float4 v[16];
+    const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx + part * 8);
+    f32x4 xv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xv[i] = xr[8 * (i >> 1) + (i & 1)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) O[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      v[i] = *reinterpret_cast<const float4*>(xr + 4 * i);
-      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
+    for (int i = 0; i < 16; ++i) sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
     {
       // the same rows are this stage's residual: parked now in the (odd) exchange slot of the wave that will own them, in the
       // epilogue's layout [16 j][64 lanes] (lane = 16 g + c holds features 16 j + 4 g .. + 3 of row 16 w + c) - the epilogue
       // then has no global fetch on its critical path
-      float4* pk = reinterpret_cast<float4*>(smem + ((row >> 4) * 2 + 1) * 16384) + (row & 15);
+      f32x4* pk = reinterpret_cast<f32x4*>(smem + ((row >> 4) * 2 + 1) * 16384) + (row & 15);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pk[((part * 4 + (i >> 2)) * 64) + (i & 3) * 16] = v[i];
+      for (int i = 0; i < 16; ++i) pk[(2 * (i >> 1) + (part >> 1)) * 64 + (2 * (part & 1) + (i & 1)) * 16] = xv[i];
     }
     sum += pk_shfl_xor(sum, 1, tid & 63);
     sum += pk_shfl_xor(sum, 2, tid & 63);
@@ -409,57 +476,56 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      xv[i] -= mean;
+      q += (xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1]) + (xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3]);
     }
     q += pk_shfl_xor(q, 1, tid & 63);
     q += pk_shfl_xor(q, 2, tid & 63);
     const float inv = 1.0f / sqrtf(q * (1.0f / 256.0f) + p.eps);
-    char* dst = smem + (row >> 4) * kPkTileStride + (row & 15) * kPkPitch + part * 128;
+    __syncthreads();  // gamma0 / beta0 (all four waves' quarters) are in LDS
+    const f32x4* g0l = reinterpret_cast<const f32x4*>(smem + kPkOffPar0) + part * 2;
+    char* dst = smem + (row >> 4) * kPkTileStride + (row & 15) * kPkPitch + part * 16;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float4 ga = *reinterpret_cast<const float4*>(p.g0 + part * 64 + 8 * j);
-      const float4 gb = *reinterpret_cast<const float4*>(p.g0 + part * 64 + 8 * j + 4);
-      const float4 ba = *reinterpret_cast<const float4*>(p.be0 + part * 64 + 8 * j);
-      const float4 bb = *reinterpret_cast<const float4*>(p.be0 + part * 64 + 8 * j + 4);
-      const float4 a0 = v[2 * j], a1 = v[2 * j + 1];
-      *reinterpret_cast<uint4*>(dst + 16 * j) =
-          make_uint4(pk_pack_bf16(a0.x * inv * ga.x + ba.x, a0.y * inv * ga.y + ba.y),
-                     pk_pack_bf16(a0.z * inv * ga.z + ba.z, a0.w * inv * ga.w + ba.w),
-                     pk_pack_bf16(a1.x * inv * gb.x + bb.x, a1.y * inv * gb.y + bb.y),
-                     pk_pack_bf16(a1.z * inv * gb.z + bb.z, a1.w * inv * gb.w + bb.w));
+      const f32x4 ga = g0l[8 * j], gb = g0l[8 * j + 1], ba = g0l[64 + 8 * j], bb = g0l[64 + 8 * j + 1];
+      const f32x4 a0 = xv[2 * j], a1 = xv[2 * j + 1];
+      *reinterpret_cast<uint4*>(dst + 64 * j) =
+          make_uint4(pk_pack_bf16(a0[0] * inv * ga[0] + ba[0], a0[1] * inv * ga[1] + ba[1]),
+                     pk_pack_bf16(a0[2] * inv * ga[2] + ba[2], a0[3] * inv * ga[3] + ba[3]),
+                     pk_pack_bf16(a1[0] * inv * gb[0] + bb[0], a1[1] * inv * gb[1] + bb[1]),
+                     pk_pack_bf16(a1[2] * inv * gb[2] + bb[2], a1[3] * inv * gb[3] + bb[3]));
     }
   } else {
+    f32x4 av[8];  // (16 raw bytes each; a native vector type: arrays of HIP's uint4 struct stay in scratch)
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int idx = it * kPkThreads + tid;
       const int row = idx >> 5, ch = idx & 31;
       int m = m0 + row;
       if (m >= p.M) m = p.M - 1;
-      const uint4 v = *reinterpret_cast<const uint4*>(p.a + (int64_t)m * p.lda + ch * 8);
-      *reinterpret_cast<uint4*>(smem + (row >> 4) * kPkTileStride + (row & 15) * kPkPitch + ch * 16) = v;
+      av[it] = *reinterpret_cast<const f32x4*>(p.a + (int64_t)m * p.lda + ch * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) O[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * kPkThreads + tid;
+      const int row = idx >> 5, ch = idx & 31;
+      *reinterpret_cast<f32x4*>(smem + (row >> 4) * kPkTileStride + (row & 15) * kPkPitch + ch * 16) = av[it];
     }
   }
-  {  // epilogue parameters -> LDS (5 x 256 floats; thread t copies element t of each): no global latency at the tail
-    float* par = reinterpret_cast<float*>(smem + kPkOffPar);
-    par[tid] = p.b2[tid];
-    if (p.ln_mode >= 1) {
-      par[256 + tid] = p.g1[tid];
-      par[512 + tid] = p.be1[tid];
-    }
-    if (p.ln_mode == 2) {
-      par[768 + tid] = p.g2[tid];
-      par[1024 + tid] = p.be2[tid];
-    }
-    if (p.pair) {
-      float* par2 = reinterpret_cast<float*>(smem + kPkOffPar2);
-      par2[tid] = p.b2_b[tid];
-      par2[256 + tid] = p.g3[tid];
-      par2[512 + tid] = p.be3[tid];
-    }
+  } else {  // stage 1: the tile was written by the previous stage's epilogue
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) O[j][s] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  }  // stage 0
   __syncthreads();  // (stage 1: the rows every wave wrote into the next activation tile are visible)
+  PK_STAMP(1);
 
   if (nsb > 0) {
     PK_LDS(af[0][0], a_addr[0], 0);
@@ -470,18 +536,12 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     PK_LDS(af[1][1], a_addr[1], 1 << 6);
     PK_LDS(af[1][2], a_addr[2], 1 << 6);
     PK_LDS(af[1][3], a_addr[3], 1 << 6);
-    // block 0's bias has registers of its own: b1lo / b1hi are already being re-loaded (block 1) while the prologue runs, and an
-    // in-flight register must never be copied
-    f32x4 b0lo, b0hi;
-    {
-      const float* bsrc = b1_cur + block_of(0) * kPkBlock;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b0lo) : "v"(boff), "s"(bsrc) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b0hi) : "v"(boff), "s"(bsrc) : "memory");
-    }
-    if constexpr (!(ABL & 2)) PK_LOAD_B1(block_of(blk_wrap(1)));
-    if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // only block 1's bias pair may stay in flight: the prologue starts with the ring and block 0's bias landed
-    asm volatile("s_waitcnt vmcnt(2)" : "+v"(b0lo), "+v"(b0hi)::"memory");
+    // the biases of this wave's first two blocks, from LDS: lane group g needs b1[32 blk + 8 g .. + 7]
+    const f32x4* bl = reinterpret_cast<const f32x4*>(smem + kPkOffBias + wave * 256) + 2 * g;
+    f32x4 b0lo = bl[0], b0hi = bl[1];
+    b1lo = bl[8];
+    b1hi = bl[9];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prologue starts with the ring landed
     product1(std::false_type{}, std::integral_constant<int, 17>{}, SA, SB, wbase(blk_wrap(1)), std::integral_constant<int, 0>{},
              b0lo, b0hi);
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(SA[0][0]), "+v"(SA[0][1]), "+v"(SA[0][2]), "+v"(SA[0][3]), "+v"(SA[1][0]),
@@ -493,6 +553,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     PK_LDS(af[1][2], a_addr[2], 1 << 6);
     PK_LDS(af[1][3], a_addr[3], 1 << 6);
   }
+  PK_STAMP(2);
   for (int ci = 0; ci < nsb; ci += 2) {
     // even block ci: its S tiles are in SA; product1 of block ci + 1 fills SB
     product1(std::true_type{}, std::integral_constant<int, 15>{}, SB, SA, wbase(ci), std::integral_constant<int, 16>{}, b1lo, b1hi);
@@ -504,6 +565,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   }
   // last MFMA -> accumulator reads.  The ring's last (wrapped, unused) prefetches are NOT waited for here: their registers stay
   // reserved until the drain below, one exchange round later, by which time they have long landed (~1 us of L2 latency per stage)
+  PK_STAMP(3);
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
   const int tid = tidv, lane = tidv & 63, c = lane & 15, g = lane >> 4, m0 = m0v;  // (see the top of the stage loop)
 
@@ -524,6 +586,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     for (int j = 0; j < 16; ++j) xres[j] = park[j * 64];
   }
   __syncthreads();  // every wave is done reading the activation tile
+  PK_STAMP(4);
   auto xslot = [&](int owner, int k) { return reinterpret_cast<f32x4*>(smem + (owner * 2 + k) * 16384) + lane; };
   {
     f32x4* d1 = xslot((wave + 1) & 3, 0);
@@ -560,6 +623,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     for (int j = 0; j < 16; ++j) O[j][0] += s3[j * 64];
   }
 
+  PK_STAMP(5);
   // ---- epilogue: lane (c, g) holds row m0 + 16 wave + c, features n = 16 j + 4 g + r -------------------------------------
   const float* par = reinterpret_cast<const float*>(smem + (stg == 0 ? kPkOffPar : kPkOffPar2)) + 4 * g;
   float v[64];
@@ -582,7 +646,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     if (!live) return;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      *reinterpret_cast<float4*>(xrow + 16 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+      pk_store16<MA_FFN_WT & 7>(xrow + 16 * j, make_uint4(__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]),
+                                                          __float_as_uint(v[4 * j + 2]), __float_as_uint(v[4 * j + 3])));
   };
   if (!p.pair && p.ln_mode == 0) {
     store_x();
@@ -624,6 +689,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       *reinterpret_cast<uint2*>(arow + 32 * j) = make_uint2(pk_pack_bf16(v[4 * j], v[4 * j + 1]), pk_pack_bf16(v[4 * j + 2], v[4 * j + 3]));
+    PK_STAMP(6);
+    PK_STAMP_FLUSH(0, 7);
     continue;
   }
   const int mode = p.pair ? 1 : p.ln_mode;
@@ -661,7 +728,10 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     for (int j = 0; j < 16; ++j)
       *reinterpret_cast<float4*>(orow + 16 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
   }
+  PK_STAMP(6);
+  PK_STAMP_FLUSH(10 * stg, 7);
   }  // stages
+  PK_STAMP(0);
 
   // ---- tail: out = LN_out . Wq^T + b on the tile (N = 128 nq columns; block hb = 32 columns, one per wave and step) -------------
   // A block is the first product of the FFN loop with nothing behind it: S' = b + Wq[blk] . a^T through the same 16-slot ring
@@ -713,7 +783,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
         const int row = m0 + 16 * ((sI + wave) & 3) + cq;
         const uint4 pk = make_uint4(pk_pack_bf16(S[0][sI][0], S[0][sI][1]), pk_pack_bf16(S[0][sI][2], S[0][sI][3]),
                                     pk_pack_bf16(S[1][sI][0], S[1][sI][1]), pk_pack_bf16(S[1][sI][2], S[1][sI][3]));
-        if (row < p.M) *reinterpret_cast<uint4*>(p.qkv_out + (int64_t)row * p.ld_qkv + blk * kPkBlock + 8 * gq) = pk;
+        if (row < p.M) pk_store16<(MA_FFN_WT >> 3) & 7>(p.qkv_out + (int64_t)row * p.ld_qkv + blk * kPkBlock + 8 * gq, pk);
       });
     };
     auto refetch_k1 = [&]() __attribute__((always_inline)) {
@@ -736,9 +806,12 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
         store_s(SB, qblk(ci + 1));
       }
     }
+    PK_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the ring's and the tile's last (unused) prefetches
 #undef PK_LOAD_QB
   }
+  PK_STAMP(2);
+  PK_STAMP_FLUSH(26, 3);
 #undef PK_MFMA_O
 #undef PK_LDS
 #undef PK_LWAIT
@@ -754,6 +827,11 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 
 using namespace ma;
 
+#ifdef MA_FFN_PROF
+extern "C" int ma_debug_ffn_prof(unsigned long long* host96) {
+  return hipMemcpyFromSymbol(host96, HIP_SYMBOL(g_ffn_prof), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int64_t ma_ffn_packed_bytes(int32_t d_model, int32_t hidden) {
   if (d_model != kPkD || hidden < 256 || hidden % 256 != 0 || hidden > kPkMaxHidden) return MA_ERR_UNSUPPORTED;
   return (int64_t)2 * d_model * hidden * 2;
@@ -787,29 +865,20 @@ extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t 
   return MA_OK;
 }
 
+#ifndef MA_FFNPK_ABLATE
+#define MA_FFNPK_ABLATE 0  // development builds only (tools/ffn_variants.sh): see ABL above
+#endif
 static int ffn_packed_launch(const FfnPackedParams& p, ma_stream_t stream) {
   const int64_t M = p.M;
-  static int abl = -1;
-  if (abl < 0) {
-    const char* e = getenv("MA_FFNPK_ABLATE");
-    abl = e ? atoi(e) & 7 : 0;
-    const void* fns[8] = {(const void*)&ffn_packed_kernel<0>, (const void*)&ffn_packed_kernel<1>, (const void*)&ffn_packed_kernel<2>,
-                          (const void*)&ffn_packed_kernel<3>, (const void*)&ffn_packed_kernel<4>, (const void*)&ffn_packed_kernel<5>,
-                          (const void*)&ffn_packed_kernel<6>, (const void*)&ffn_packed_kernel<7>};
-    for (int i = 0; i < 8; ++i)
-      if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kPkLds) != hipSuccess) return MA_ERR_LAUNCH;
+  static bool ready = false;
+  if (!ready) {
+    if (hipFuncSetAttribute((const void*)&ffn_packed_kernel<MA_FFNPK_ABLATE>, hipFuncAttributeMaxDynamicSharedMemorySize, kPkLds) !=
+        hipSuccess)
+      return MA_ERR_LAUNCH;
+    ready = true;
   }
   const dim3 grid((unsigned)((M + kPkRows - 1) / kPkRows));
-  switch (abl) {
-    case 0: MA_LAUNCH(ffn_packed_kernel<0>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 1: MA_LAUNCH(ffn_packed_kernel<1>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 2: MA_LAUNCH(ffn_packed_kernel<2>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 3: MA_LAUNCH(ffn_packed_kernel<3>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 4: MA_LAUNCH(ffn_packed_kernel<4>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 5: MA_LAUNCH(ffn_packed_kernel<5>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    case 6: MA_LAUNCH(ffn_packed_kernel<6>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-    default: MA_LAUNCH(ffn_packed_kernel<7>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p); break;
-  }
+  MA_LAUNCH(ffn_packed_kernel<MA_FFNPK_ABLATE>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p);
   return MA_OK;
 }
 

@@ -35,7 +35,7 @@ def t(fn, reps=30):
     return e0.elapsed_time(e1) / (3 * reps) * 1e3
 
 
-for hid in (256, 512, 1024, 2048):
+for hid in ((int(os.environ["HID"]),) if os.environ.get("HID") else (256, 512, 1024, 2048)):
     pa = ops.ffn_pack_weights((r(hid, 256) / 16).bfloat16(), (r(256, hid) / 45).bfloat16())
     pb = ops.ffn_pack_weights((r(hid, 256) / 16).bfloat16(), (r(256, hid) / 45).bfloat16())
     b1, b2 = r(hid), r(256)

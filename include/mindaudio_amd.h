@@ -630,7 +630,7 @@ int ma_ffn_packed_pair_bf16(const void* packed_a, const float* b1_a, const float
  * it is in LDS:  qkv_out[m, :] = bf16(LN_out[m, :] . Wq^T + qkv_bias)   (qkv_out (M, qkv_n) bf16; LN_out itself is not written).
  * gamma0 / beta0 of ma_ffn_packed_qkv_bf16 (optional, then a may be NULL): the FFN input is LayerNorm(x; gamma0, beta0), as in
  * ma_ffn_packed_bf16.
- *   ma_ffn_qkv_packed_bytes(N) -> bytes of the packed weight (negative: unsupported; K = 256, N % 128 == 0);
+ *   ma_ffn_qkv_packed_bytes(N) -> bytes of the packed weight (negative: unsupported; K = 256, N % 256 == 0, N <= 1024);
  *   ma_ffn_qkv_pack_bf16(W (N, 256) bf16, ldw, N, packed): once per weight update. */
 int64_t ma_ffn_qkv_packed_bytes(int64_t N);
 int ma_ffn_qkv_pack_bf16(const void* W, int64_t ldw, int64_t N, void* packed, ma_stream_t stream);

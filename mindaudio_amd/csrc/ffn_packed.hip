@@ -61,7 +61,9 @@ constexpr int kPkOffPar = 128 * 1024;         // b2, gamma1, beta1, gamma2, beta
 constexpr int kPkOffPar2 = kPkOffPar + 5 * 1024;  // pair mode, second stage: b2', gamma3, beta3
 constexpr int kPkOffPar0 = kPkOffPar2 + 3 * 1024;  // gamma0, beta0 of the input LayerNorm
 constexpr int kPkOffBias = kPkOffPar0 + 2 * 1024;  // b1 of each wave's first two blocks (4 x 64 floats)
-constexpr int kPkLds = kPkOffBias + 1024;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
+constexpr int kPkOffQb = kPkOffBias + 1024;  // bias of the qkv tail (<= 1024 floats)
+constexpr int kPkOffJunk = kPkOffQb + 4096;  // destination of the L2 warm-up loads (4 x 1 KiB)
+constexpr int kPkLds = kPkOffJunk + 4096;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
 constexpr int kPkMaxHidden = 8192;
 
 struct FfnPackedParams {
@@ -250,6 +252,14 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     if constexpr (ABL & 4) asm volatile("" : "+v"(acc) : "v"(wf), "v"(af));                                            \
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af));                       \
   } while (0)
+// the qkv tail's weight rings live in the AGPRs the O tiles have left ("a" operands)
+#define PK_LOAD_A(dst, base, q)                                                                                  \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                                        \
+               : "=a"(dst) : "v"(PK_VOFF(q)), "s"(base), "n"((((q) & 7) - 4) * 1024) : "memory")
+#define PK_WAIT_A(reg, n) asm volatile("s_waitcnt vmcnt(%1)" : "+a"(reg) : "n"(n) : "memory")
+#define PK_MFMA_S0A(acc, wf, af, bias) \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(wf), "v"(af), "v"(bias))
+#define PK_MFMA_SA(acc, wf, af) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wf), "v"(af))
 #define PK_MFMA_O(acc, wf, hf)                                                                                         \
   do {                                                                                                                 \
     if constexpr (ABL & 4) asm volatile("" : "+a"(acc) : "v"(wf), "v"(hf));                                            \
@@ -321,14 +331,18 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // `refill` = where ring slot i is re-loaded from once consumed.  With sw_tag: nano-slots 65..128 of the Swish of So.
   // LDS reads of k-step ks + 2 are issued during k-step ks (slots 1 and 5); outstanding at the start of k-step ks: the 4 reads of
   // k-step ks + 1 (none before k-step 7, whose successor is fetched later) -> lgkmcnt(4), lgkmcnt(0) for k-step 7.
-  auto product1 = [&](auto sw_tag, auto wait_tag, f32x4 (&Sn)[2][4], f32x4 (&So)[2][4], const char* refill, auto item0_tag,
-                      f32x4& blo, f32x4& bhi)
-                      __attribute__((always_inline)) {
+  // mode_tag (the qkv tail): 0 = the FFN loop (ring in VGPRs, bias by global load); 1 = ring R in AGPRs, refilled; 2 / 3 = ring in
+  // AGPRs, no refill, slot q waits for vmcnt(kWait - q) (the last two blocks of the tail: nothing younger is issued behind them)
+  auto product1x = [&](auto mode_tag, bf16x8 (&R)[16], auto sw_tag, auto wait_tag, f32x4 (&Sn)[2][4], f32x4 (&So)[2][4],
+                       const char* refill, auto item0_tag, f32x4& blo, f32x4& bhi) __attribute__((always_inline)) {
+    constexpr int kMode = decltype(mode_tag)::value;
     constexpr bool kSw = decltype(sw_tag)::value;
     constexpr int kWait = decltype(wait_tag)::value;
     constexpr int kItem0 = decltype(item0_tag)::value;
-    PK_WAIT(blo, kWait + 1);
-    PK_WAIT(bhi, kWait + 1);
+    if constexpr (kMode == 0) {
+      PK_WAIT(blo, kWait + 1);
+      PK_WAIT(bhi, kWait + 1);
+    }
     pk_static_for<64>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       constexpr int ks = i >> 3, t = (i >> 2) & 1, s = i & 3;
@@ -336,14 +350,25 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
         if constexpr (ks == 7) PK_LWAIT(ks % 3, 0);
         else PK_LWAIT(ks % 3, 4);
       }
-      if constexpr (s == 0) PK_WAIT(ring[2 * ks + t], kWait);
-      if constexpr (ks == 0) {
-        if constexpr (t == 0) PK_MFMA_S0(Sn[t][s], ring[2 * ks + t], af[ks % 3][s], blo);
-        else PK_MFMA_S0(Sn[t][s], ring[2 * ks + t], af[ks % 3][s], bhi);
+      if constexpr (kMode == 0) {
+        if constexpr (s == 0) PK_WAIT(R[2 * ks + t], kWait);
+        if constexpr (ks == 0) {
+          if constexpr (t == 0) PK_MFMA_S0(Sn[t][s], R[2 * ks + t], af[ks % 3][s], blo);
+          else PK_MFMA_S0(Sn[t][s], R[2 * ks + t], af[ks % 3][s], bhi);
+        } else {
+          PK_MFMA_S(Sn[t][s], R[2 * ks + t], af[ks % 3][s]);
+        }
+        if constexpr (s == 3) PK_LOAD(R[2 * ks + t], refill, kItem0 + 2 * ks + t);
       } else {
-        PK_MFMA_S(Sn[t][s], ring[2 * ks + t], af[ks % 3][s]);
+        if constexpr (s == 0) PK_WAIT_A(R[2 * ks + t], kMode == 1 ? kWait : kWait - (2 * ks + t));
+        if constexpr (ks == 0) {
+          if constexpr (t == 0) PK_MFMA_S0A(Sn[t][s], R[2 * ks + t], af[ks % 3][s], blo);
+          else PK_MFMA_S0A(Sn[t][s], R[2 * ks + t], af[ks % 3][s], bhi);
+        } else {
+          PK_MFMA_SA(Sn[t][s], R[2 * ks + t], af[ks % 3][s]);
+        }
+        if constexpr (s == 3 && kMode == 1) PK_LOAD_A(R[2 * ks + t], refill, kItem0 + 2 * ks + t);
       }
-      if constexpr (s == 3) PK_LOAD(ring[2 * ks + t], refill, kItem0 + 2 * ks + t);
       if constexpr ((i & 3) == 1) {  // two LDS reads on each of the k-step's two plain odd slots
         constexpr int h2 = (i >> 2) & 1;  // first / second pair of row tiles
         if constexpr (ks <= 5) {
@@ -357,6 +382,10 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       if constexpr (kSw) nano(std::integral_constant<int, 65 + i>{}, So);
       __builtin_amdgcn_sched_barrier(0);
     });
+  };
+  auto product1 = [&](auto sw_tag, auto wait_tag, f32x4 (&Sn)[2][4], f32x4 (&So)[2][4], const char* refill, auto item0_tag,
+                      f32x4& blo, f32x4& bhi) __attribute__((always_inline)) {
+    product1x(std::integral_constant<int, 0>{}, ring, sw_tag, wait_tag, Sn, So, refill, item0_tag, blo, bhi);
   };
   // ---- second product of one block (64 MFMAs): O^T (16 tiles x 4 row tiles) += W2[:, blk] . h^T, h from hfw; carries
   // nano-slots 1..64 of the Swish of Snext (the S tiles the first product has just finished) -------------------------------------
@@ -440,6 +469,11 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     for (int k = 0; k < 10; ++k)
       if (srcs[k])
         __builtin_amdgcn_global_load_lds((pk_gl_void_t*)(srcs[k] + tid), (pk_lds_void_t*)(par_w + k * 1024), 4, 0, 0);
+    if (p.qkv_wp) {
+      char* qb_w = smem + kPkOffQb + (tid >> 6) * 256;
+      for (int k = 0; k * 256 < p.qkv_n; ++k)
+        __builtin_amdgcn_global_load_lds((pk_gl_void_t*)(p.qkv_b + k * 256 + tid), (pk_lds_void_t*)(qb_w + k * 1024), 4, 0, 0);
+    }
   }
   if (p.g0) {
     // a = LayerNorm(x) on the fly (two-pass, as layernorm_kernel): 4 threads per row; float4 i of thread (row, part) = features
@@ -604,6 +638,18 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
                  "+v"(ring[15]), "+v"(b1lo), "+v"(b1hi)
                :
                : "memory");  // drain of the main loop's last prefetches (see above)
+  if (p.qkv_wp && stg == nstage - 1) {
+    // The qkv weight was last read a whole launch ago and has left this XCD's L2 behind 4 MB of FFN weights: the tail's first
+    // block would wait for the Infinity Cache.  The workgroups of an XCD (blockIdx % 8) share its L2, so each touches 1 / 12 of
+    // the weight's 128-byte lines now, ~6 us ahead: LDS-DMA into a junk area - no destination registers to keep out of the
+    // allocator's hands (asm: the compiler must not see an LDS write it would fence with vmcnt(0) before the exchange reads).
+    const int line = (blockIdx.x >> 3) * 256 + tidv;
+    if (line < p.qkv_n * 4) {
+      const char* src = reinterpret_cast<const char*>(p.qkv_wp) + (int64_t)line * 128;
+      const uint32_t junk = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + kPkOffJunk) + wave * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(junk), "v"(src) : "memory");
+    }
+  }
   {
     const f32x4* s1 = xslot(wave, 0);
     const f32x4* s2 = xslot(wave, 1);
@@ -734,13 +780,17 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   PK_STAMP(0);
 
   // ---- tail: out = LN_out . Wq^T + b on the tile (N = 128 nq columns; block hb = 32 columns, one per wave and step) -------------
-  // A block is the first product of the FFN loop with nothing behind it: S' = b + Wq[blk] . a^T through the same 16-slot ring
-  // (refilled with the next block's fragments), then the 32 x 64 result goes out as bf16 (lane (c, g): row 16 tile + c, columns
-  // 32 blk + 8 g .. + 7 = 16 bytes).  Wait counts: a slot's load is followed by <= 15 - i fragment loads of its block, the next
-  // block's 2 bias loads, this block's stores (0..4, skipped on dead rows) and i refills -> vmcnt(17) is safe with or without the stores.
+  // A block is the first product of the FFN loop with nothing behind it: S' = b + Wq[blk] . a^T, then the 32 x 64 result goes out as
+  // bf16 (lane (c, g): row 16 tile + c, columns 32 blk + 8 g .. + 7 = 16 bytes).  The O tiles are dead here, so the weight
+  // fragments get TWO 16-slot rings in the AGPRs (qa: even blocks, qb: odd blocks; MFMA A operands may be AGPRs): two blocks =
+  // 32 KiB per wave in flight instead of one (with one ring the tail was 6 x [L2 latency + 64 MFMAs] = 8.2 us for 6 blocks,
+  // tools/ffn_timeline.py).  Biases come from the LDS copy made at kernel start.  Wait counts: the load of slot i of block b was
+  // issued during block b - 2 and is followed by >= 15 - i fragment loads of that block, 16 of block b - 1's and i of this block's
+  // -> vmcnt(31) (the <= 8 stores in between only make the wait stricter); the last two blocks have nothing issued behind them:
+  // vmcnt(31 - i) and vmcnt(15 - i).
   if (p.qkv_wp) {
     __syncthreads();
-    const int nq = p.qkv_n >> 7;
+    const int nq = p.qkv_n >> 7;  // (even: the host checks qkv_n % 256 == 0)
     const int rotq = blockIdx.x % nq;
     auto qblk = [&](int ci) {
       int sb = ci + rotq;
@@ -748,21 +798,15 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       return sb * 4 + wave;
     };
     auto qbase = [&](int ci) { return reinterpret_cast<const char*>(p.qkv_wp) + (int64_t)qblk(ci) * (16 * 1024); };
+    bf16x8 qa[16], qb[16];
     {
       const char* w0 = qbase(0);
+      const char* w1 = qbase(1);
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-                     : "=v"(ring[q]) : "v"(PK_VOFF(q)), "s"(w0), "n"((((q) & 7) - 4) * 1024) : "memory");
+      for (int q = 0; q < 16; ++q) PK_LOAD_A(qa[q], w0, q);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) PK_LOAD_A(qb[q], w1, q);
     }
-    f32x4 qalo, qahi, qblo, qbhi;
-#define PK_LOAD_QB(lo, hi, blk)                                                                                  \
-  do {                                                                                                           \
-    const float* bsrc = p.qkv_b + (blk) * kPkBlock;                                                              \
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(lo) : "v"(boff), "s"(bsrc) : "memory");                 \
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(hi) : "v"(boff), "s"(bsrc) : "memory");       \
-  } while (0)
-    PK_LOAD_QB(qalo, qahi, qblk(0));
     PK_LDS(af[0][0], a_addr[0], 0);
     PK_LDS(af[0][1], a_addr[1], 0);
     PK_LDS(af[0][2], a_addr[2], 0);
@@ -771,10 +815,10 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     PK_LDS(af[1][1], a_addr[1], 1 << 6);
     PK_LDS(af[1][2], a_addr[2], 1 << 6);
     PK_LDS(af[1][3], a_addr[3], 1 << 6);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qalo), "+v"(qahi)::"memory");
     int lane_q;  // re-derived here (two instructions): threadIdx.x kept alive across the stage loop would be spilled and reloaded
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_q));
     const int cq = lane_q & 15, gq = lane_q >> 4;
+    const f32x4* qbl = reinterpret_cast<const f32x4*>(smem + kPkOffQb) + 2 * gq;
     auto store_s = [&](f32x4 (&S)[2][4], int blk) __attribute__((always_inline)) {
       asm volatile("s_nop 15\n\ts_nop 3" : "+v"(S[0][0]), "+v"(S[0][1]), "+v"(S[0][2]), "+v"(S[0][3]), "+v"(S[1][0]), "+v"(S[1][1]),
                    "+v"(S[1][2]), "+v"(S[1][3]));  // MFMA result -> VALU read
@@ -792,23 +836,43 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       PK_LDS(af[1][2], a_addr[2], 1 << 6);
       PK_LDS(af[1][3], a_addr[3], 1 << 6);
     };
-    for (int ci = 0; ci < nq; ci += 2) {
-      PK_LOAD_QB(qblo, qbhi, qblk(ci + 1 < nq ? ci + 1 : ci));
-      product1(std::false_type{}, std::integral_constant<int, 17>{}, SA, SB, qbase(ci + 1 < nq ? ci + 1 : ci),
-               std::integral_constant<int, 0>{}, qalo, qahi);
-      refetch_k1();
-      store_s(SA, qblk(ci));
-      if (ci + 1 < nq) {
-        PK_LOAD_QB(qalo, qahi, qblk(ci + 2 < nq ? ci + 2 : ci + 1));
-        product1(std::false_type{}, std::integral_constant<int, 17>{}, SB, SA, qbase(ci + 2 < nq ? ci + 2 : ci + 1),
-                 std::integral_constant<int, 0>{}, qblo, qbhi);
+    using I0 = std::integral_constant<int, 0>;
+    // (no conditional refills inside the loop: a ring register with two reaching definitions at a join gets a copy there, and an
+    // in-flight register must never be copied)
+    int ci = 0;
+    for (; ci + 2 < nq; ci += 2) {
+      {
+        const int blk = qblk(ci);
+        f32x4 blo = qbl[blk * 8], bhi = qbl[blk * 8 + 1];
+        product1x(std::integral_constant<int, 1>{}, qa, std::false_type{}, std::integral_constant<int, 31>{}, SA, SB, qbase(ci + 2), I0{}, blo,
+                  bhi);
         refetch_k1();
-        store_s(SB, qblk(ci + 1));
+        store_s(SA, blk);
+      }
+      {
+        const int blk = qblk(ci + 1);
+        f32x4 blo = qbl[blk * 8], bhi = qbl[blk * 8 + 1];
+        product1x(std::integral_constant<int, 1>{}, qb, std::false_type{}, std::integral_constant<int, 31>{}, SB, SA, qbase(ci + 3), I0{}, blo,
+                  bhi);
+        refetch_k1();
+        store_s(SB, blk);
       }
     }
+    {
+      const int blk = qblk(ci);
+      f32x4 blo = qbl[blk * 8], bhi = qbl[blk * 8 + 1];
+      product1x(std::integral_constant<int, 2>{}, qa, std::false_type{}, std::integral_constant<int, 31>{}, SA, SB, nullptr, I0{}, blo, bhi);
+      refetch_k1();
+      store_s(SA, blk);
+    }
+    {
+      const int blk = qblk(ci + 1);
+      f32x4 blo = qbl[blk * 8], bhi = qbl[blk * 8 + 1];
+      product1x(std::integral_constant<int, 3>{}, qb, std::false_type{}, std::integral_constant<int, 15>{}, SB, SA, nullptr, I0{}, blo, bhi);
+      store_s(SB, blk);
+    }
     PK_STAMP(1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the ring's and the tile's last (unused) prefetches
-#undef PK_LOAD_QB
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the tile's last (unused) prefetch
   }
   PK_STAMP(2);
   PK_STAMP_FLUSH(26, 3);
@@ -838,7 +902,7 @@ extern "C" int64_t ma_ffn_packed_bytes(int32_t d_model, int32_t hidden) {
 }
 
 extern "C" int64_t ma_ffn_qkv_packed_bytes(int64_t N) {
-  if (N < 128 || N % 128 != 0 || N > 8192) return MA_ERR_UNSUPPORTED;
+  if (N < 256 || N % 256 != 0 || N > 1024) return MA_ERR_UNSUPPORTED;  // two blocks of 4 x 32 columns per step; bias copy in LDS
   return N * kPkD * 2;
 }
 

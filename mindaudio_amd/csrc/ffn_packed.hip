@@ -104,10 +104,25 @@ __device__ __forceinline__ uint32_t pk_pack_bf16(float lo, float hi) {
   const bf16x2 r = __builtin_convertvector((f32x2){lo, hi}, bf16x2);  // v_cvt_pk_bf16_f32 (round to nearest even)
   return *reinterpret_cast<const uint32_t*>(&r);
 }
-// __shfl_xor with the caller's own lane index: the library form derives the lane from v_mbcnt once per kernel, a value that then
-// lives across the whole stage loop and was spilled (its scratch reload sat behind the residual stores: +1 us per stage)
-__device__ __forceinline__ float pk_shfl_xor(float x, int mask, int lane) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, __builtin_bit_cast(int, x)));
+// Cross-lane sums without the LDS crossbar (ds_bpermute costs an LDS round trip, ~100 ns each, eight of them in a row per
+// LayerNorm): lanes {c, c + 16, c + 32, c + 48} through gfx950's row swaps - with both operands a copy of x,
+// v_permlane16_swap leaves (x[row 0], x[row 0], x[row 2], x[row 2]) and (x[row 1], x[row 1], x[row 3], x[row 3]), whose sum is
+// x[l] + x[l ^ 16] in every lane (tools/ubench/permlane_test.hip); v_permlane32_swap does the same with the 32-lane halves.
+// (asm: the builtin with two identical operands is folded to 2 x by this hipcc.)  Quads through DPP.
+__device__ __forceinline__ float pk_sum_xor16(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float pk_sum_xor32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float pk_sum_quad(float x) {  // x[l] + x[l ^ 1] + x[l ^ 2] + x[l ^ 3]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+  return x;
 }
 #ifndef MA_FFN_WT
 #define MA_FFN_WT 0
@@ -504,8 +519,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 #pragma unroll
       for (int i = 0; i < 16; ++i) pk[(2 * (i >> 1) + (part >> 1)) * 64 + (2 * (part & 1) + (i & 1)) * 16] = xv[i];
     }
-    sum += pk_shfl_xor(sum, 1, tid & 63);
-    sum += pk_shfl_xor(sum, 2, tid & 63);
+    sum = pk_sum_quad(sum);
     const float mean = sum * (1.0f / 256.0f);
     float q = 0.f;
 #pragma unroll
@@ -513,8 +527,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
       xv[i] -= mean;
       q += (xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1]) + (xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3]);
     }
-    q += pk_shfl_xor(q, 1, tid & 63);
-    q += pk_shfl_xor(q, 2, tid & 63);
+    q = pk_sum_quad(q);
     const float inv = 1.0f / sqrtf(q * (1.0f / 256.0f) + p.eps);
     __syncthreads();  // gamma0 / beta0 (all four waves' quarters) are in LDS
     const f32x4* g0l = reinterpret_cast<const f32x4*>(smem + kPkOffPar0) + part * 2;
@@ -702,10 +715,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   // A row lives in the 4 lanes {c, c + 16, c + 32, c + 48} of one wave: two shuffles, no LDS.
   // (the statistics come in as s, q; the normalised values' own statistics go out the same way, for a LayerNorm chained behind)
   auto layer_norm = [&](const float* gam, const float* bet, float& s, float& q) __attribute__((always_inline)) {
-    s += pk_shfl_xor(s, 16, lane);
-    s += pk_shfl_xor(s, 32, lane);
-    q += pk_shfl_xor(q, 16, lane);
-    q += pk_shfl_xor(q, 32, lane);
+    s = pk_sum_xor32(pk_sum_xor16(s));
+    q = pk_sum_xor32(pk_sum_xor16(q));
     const float mean = s * (1.0f / 256.0f);
     const float var = fmaxf(q * (1.0f / 256.0f) - mean * mean, 0.0f);
     const float rstd = 1.0f / sqrtf(var + p.eps);

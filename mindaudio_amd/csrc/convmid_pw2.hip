@@ -263,16 +263,30 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) wo[jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
+      // Straight-line staging: every global load of the phase is in flight before the first LDS store.  (With a `continue` for the
+      // rows the tile does not need and a run-time trip count for the taps, hipcc emitted 8 + 15 dependent load -> wait -> store
+      // round trips at the head of every workgroup.)  Rows outside r_lo .. r_hi are loaded too (clamped, never read).
+      f32x4 cv[kCmRowsO / 8];
 #pragma unroll
       for (int it = 0; it < kCmRowsO / 8; ++it) {
         const int idx = it * 256 + tid;
         const int row = idx >> 5, ch = idx & 31;
-        if (row < r_lo || row >= r_hi) continue;  // not needed: their (garbage) results are never read
         int t = t0 - 16 + row;
         t = t < 0 ? 0 : (t >= p.T ? p.T - 1 : t);
-        *reinterpret_cast<uint4*>(smem + row * kCpPitch + ch * 16) = *reinterpret_cast<const uint4*>(p.ctx + (row0 + t) * p.ldc + ch * 8);
+        cv[it] = *reinterpret_cast<const f32x4*>(p.ctx + (row0 + t) * p.ldc + ch * 8);
       }
-      for (int i = tid; i < KS * 256; i += 256) wl[i] = p.dw[(i & 255) * KS + (i >> 8)];  // wl[k][c]
+      float taps[kCpMaxK];  // channel tid's taps (contiguous in memory)
+#pragma unroll
+      for (int k = 0; k < kCpMaxK; ++k) taps[k] = p.dw[tid * KS + (k < KS ? k : KS - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < kCmRowsO / 8; ++it) {
+        const int idx = it * 256 + tid;
+        *reinterpret_cast<f32x4*>(smem + (idx >> 5) * kCpPitch + (idx & 31) * 16) = cv[it];
+      }
+#pragma unroll
+      for (int k = 0; k < kCpMaxK; ++k)
+        if (k < KS) wl[k * 256 + tid] = taps[k];  // wl[k][c]
       __syncthreads();
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
@@ -293,18 +307,31 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
     float4 bv[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) bv[jt] = *reinterpret_cast<const float4*>(p.bo + 64 * wave + 16 * jt + 4 * g);
+    // (all 16 residual loads and the 4 mask loads are unconditional - dead rows read row 0 of the utterance and are zeroed by the
+    // select below - so that they are in flight together instead of one branch, i.e. one round trip, per row tile)
+    f32x4 xall[4][4];
+    float mall[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int r = 16 * s + c, t = t0 - 16 + r;
       const bool live = r >= r_lo && r < r_hi && t >= 0 && t < p.T;
       const int64_t m = row0 + (live ? t : 0);
-      msk[s] = live ? (p.mask ? p.mask[m] : 1.0f) : 0.0f;
+      mall[s] = p.mask ? p.mask[m] : 1.0f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) xall[s][jt] = *reinterpret_cast<const f32x4*>(p.x + m * p.ldx + 64 * wave + 16 * jt + 4 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r = 16 * s + c, t = t0 - 16 + r;
+      const bool live = r >= r_lo && r < r_hi && t >= 0 && t < p.T;
+      msk[s] = live ? mall[s] : 0.0f;
       rsum[s] = 0.f;
       rsq[s] = 0.f;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) xv = *reinterpret_cast<const float4*>(p.x + m * p.ldx + 64 * wave + 16 * jt + 4 * g);
+        const f32x4 xl = xall[s][jt];
+        const float4 xv = live ? make_float4(xl[0], xl[1], xl[2], xl[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float v0 = (acc[jt][s][0] + bv[jt].x) + xv.x, v1 = (acc[jt][s][1] + bv[jt].y) + xv.y;
         const float v2 = (acc[jt][s][2] + bv[jt].z) + xv.z, v3 = (acc[jt][s][3] + bv[jt].w) + xv.w;
         acc[jt][s] = f32x4{v0, v1, v2, v3};

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
   f32x4 oacc[4];  // O^T: rows d = dt*16 + lg*4 + r, column q = lq
 #pragma unroll
   for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrow = -INFINITY, lrow = 0.f;  // running max / sum of query row lq (replicated over the 4 lane groups)
+  float mrow = -INFINITY, lrow = 0.f;  // running max of query row lq (replicated over the 4 lane groups) / this lane group's part of its sum
 
   // Staging assignment (fixed per thread): 4 x 16-byte pieces of K' = [k | p] and 2 of V^T per 64-key tile.  The
   // global loads of tile kt+1 are issued right after tile kt is published and stay in flight during its MFMAs.
@@ -423,8 +423,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
       s[c][3] = s[c][3] * scale2 + ma_.w;
       tmax = fmaxf(fmaxf(tmax, fmaxf(s[c][0], s[c][1])), fmaxf(s[c][2], s[c][3]));
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    // the row maximum over the 4 lane groups through gfx950's row swaps (two VALU instructions instead of two ds_bpermute round
+    // trips on the critical path of every key tile; tools/ubench/permlane_test.hip)
+    {
+      float a = tmax, b = tmax;
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+      tmax = fmaxf(a, b);
+      a = tmax;
+      b = tmax;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+      tmax = fmaxf(a, b);
+    }
     const float mnew = fmaxf(mrow, tmax);  // finite: key 0 of the first tile always exists
     const float alpha = (mrow == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mrow - mnew);
     mrow = mnew;
@@ -438,9 +447,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
       pb[c][0] = pack2_bf16(e0, e1);
       pb[c][1] = pack2_bf16(e2, e3);
     }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
-    lrow = lrow * alpha + psum;
+    lrow = lrow * alpha + psum;  // this lane group's share: alpha is the same in the row's 4 lanes, the groups are summed once at the end
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       oacc[c][0] *= alpha; oacc[c][1] *= alpha; oacc[c][2] *= alpha; oacc[c][3] *= alpha;
@@ -472,6 +479,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
   }
   // ---- ctx[q, h*64 + d] = O^T[d, q] / l ---------------------------------------------------------------------------
   const int qi = q_base + lq;
+  {  // the row's sum over its 4 lane groups
+    float a = lrow, b = lrow;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lrow = a + b;
+    a = lrow;
+    b = lrow;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lrow = a + b;
+  }
   // log-sum-exp of the scaled, masked scores of row qi: what the backward pass needs to rebuild the probabilities
   if (lse && qi < T && lg == 0) lse[((int64_t)b * H + h) * T + qi] = (mrow + __log2f(lrow)) * 0.6931471805599453f;
   if (qi < T) {

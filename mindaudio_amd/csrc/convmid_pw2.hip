@@ -211,7 +211,10 @@ template <bool OPROJ> struct CmLayout {
   static constexpr int kRows = OPROJ ? kCmRowsO : kCmRows;
   static constexpr int kOffY = kRows * kCpPitch;
   static constexpr int kOffW = kOffY + kCmRows * kCmYPitch;
-  static constexpr int kLds = kOffW + kCpMaxK * 256 * 4;  // 66816 / 75520 bytes: two workgroups per CU either way
+  static constexpr int kOffPar = kOffW + kCpMaxK * 256 * 4;  // OPROJ: b1 (512), bn_scale, bn_shift (256 each) as floats
+  static constexpr int kLds = kOffPar + (OPROJ ? 4096 : 0);  // 66816 / 79616 bytes: two workgroups per CU either way
+  // OPROJ, phase 0 only (inside the not yet written y tile, behind the 2 KiB LayerNorm exchange): ln_g, ln_b, bo
+  static constexpr int kOffPar0 = kOffY + 2048;
 };
 
 struct ConvModParams {
@@ -238,8 +241,38 @@ struct ConvModParams {
   float ln_eps;
 };
 
+// x[l] + x[l ^ 16] and x[l] + x[l ^ 32] in every lane through gfx950's row swaps (see ffn_packed.hip; tools/ubench/permlane_test.hip)
+__device__ __forceinline__ float cp_sum_xor16(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float cp_sum_xor32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+// Phase stamps for tools/convmod_timeline.py (compiled in only with -DMA_CM_PROF): wave 0 of three workgroups keeps wall_clock64()
+// (100 MHz) values in SGPRs and writes them out at the end of the kernel.
+#ifdef MA_CM_PROF
+__device__ unsigned long long g_cm_prof[3 * 16];
+#define CM_STAMP(k)                                    \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    cm_ts[(k)] = wall_clock64();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  } while (0)
+#else
+#define CM_STAMP(k) do { } while (0)
+#endif
+
 template <bool OPROJ>
 __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams p) {
+#ifdef MA_CM_PROF
+  unsigned long long cm_ts[16];
+  CM_STAMP(0);
+#endif
   typedef CmLayout<OPROJ> L;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -278,7 +311,21 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
       float taps[kCpMaxK];  // channel tid's taps (contiguous in memory)
 #pragma unroll
       for (int k = 0; k < kCpMaxK; ++k) taps[k] = p.dw[tid * KS + (k < KS ? k : KS - 1)];
+      // every per-channel parameter the later phases need, element tid of each: read from LDS there instead of L2 (each of those
+      // reads sat exposed behind a barrier: 0.6 - 1 us per phase, tools/convmod_timeline.py)
+      const float pv[7] = {p.ln_g[tid], p.ln_b[tid], p.bo[tid], p.b1[tid], p.b1[256 + tid], p.bn_scale[tid], p.bn_shift[tid]};
       __builtin_amdgcn_sched_barrier(0);
+      {
+        float* par0 = reinterpret_cast<float*>(smem + L::kOffPar0);
+        float* par = reinterpret_cast<float*>(smem + L::kOffPar);
+        par0[tid] = pv[0];
+        par0[256 + tid] = pv[1];
+        par0[512 + tid] = pv[2];
+        par[tid] = pv[3];
+        par[256 + tid] = pv[4];
+        par[512 + tid] = pv[5];
+        par[768 + tid] = pv[6];
+      }
 #pragma unroll
       for (int it = 0; it < kCmRowsO / 8; ++it) {
         const int idx = it * 256 + tid;
@@ -288,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
       for (int k = 0; k < kCpMaxK; ++k)
         if (k < KS) wl[k * 256 + tid] = taps[k];  // wl[k][c]
       __syncthreads();
+      CM_STAMP(1);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -303,10 +351,12 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
           for (int s = 0; s < 4; ++s) acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[jt][ks], af[s], acc[jt][s], 0, 0, 0);
       }
     }
+    CM_STAMP(2);
     float rsum[4], rsq[4], msk[4];
     float4 bv[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) bv[jt] = *reinterpret_cast<const float4*>(p.bo + 64 * wave + 16 * jt + 4 * g);
+    for (int jt = 0; jt < 4; ++jt)
+      bv[jt] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + L::kOffPar0) + 512 + 64 * wave + 16 * jt + 4 * g);
     // (all 16 residual loads and the 4 mask loads are unconditional - dead rows read row 0 of the utterance and are zeroed by the
     // select below - so that they are in flight together instead of one branch, i.e. one round trip, per row tile)
     f32x4 xall[4][4];
@@ -343,17 +393,15 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
     float* red = reinterpret_cast<float*>(ytile);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      float a = rsum[s], b = rsq[s];
-      a += __shfl_xor(a, 16, 64);
-      a += __shfl_xor(a, 32, 64);
-      b += __shfl_xor(b, 16, 64);
-      b += __shfl_xor(b, 32, 64);
+      // (row swaps instead of __shfl_xor: 16 ds_bpermute round trips in a row were ~1.5 us of this phase)
+      const float a = cp_sum_xor32(cp_sum_xor16(rsum[s])), b = cp_sum_xor32(cp_sum_xor16(rsq[s]));
       if (g == 0) {
         red[wave * 64 + 16 * s + c] = a;
         red[256 + wave * 64 + 16 * s + c] = b;
       }
     }
     __syncthreads();  // (also: every wave is done reading the ctx tile)
+    CM_STAMP(3);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int r = 16 * s + c;
@@ -365,8 +413,8 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
         const int n = 64 * wave + 16 * jt + 4 * g;
-        const float4 ga = *reinterpret_cast<const float4*>(p.ln_g + n);
-        const float4 be = *reinterpret_cast<const float4*>(p.ln_b + n);
+        const float4 ga = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + L::kOffPar0) + n);
+        const float4 be = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + L::kOffPar0) + 256 + n);
         const f32x4 v = acc[jt][s];
         *reinterpret_cast<uint2*>(smem + r * kCpPitch + n * 2) =
             make_uint2(cp_pack_bf16(((v[0] - mean) * inv * ga.x + be.x) * msk[s], ((v[1] - mean) * inv * ga.y + be.y) * msk[s]),
@@ -379,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
       xo[jt][1] = acc[jt][2];
     }
     __syncthreads();  // the a-tile (rows 16 - half .. 47 + half of the 64) is complete; the exchange buffer is free again
+    CM_STAMP(4);
 
     // ---- phase 1 in four sub-passes: value tile 4 w + sp and its gate tile, 16 fragments, double-buffered ------------------------------
     const char* abase1 = abase + (16 - half) * kCpPitch;  // a-tile row of frame t0 - half
@@ -410,8 +459,8 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
           for (int s = 0; s < 3; ++s) a2[vg][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sp & 1][vg][ks], af[s], a2[vg][s], 0, 0, 0);
       }
       const int n = 64 * wave + 16 * sp + 4 * g;
-      const float4 bvv = *reinterpret_cast<const float4*>(p.b1 + n);
-      const float4 bg = *reinterpret_cast<const float4*>(p.b1 + kCpC + n);
+      const float4 bvv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + L::kOffPar) + n);
+      const float4 bg = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem + L::kOffPar) + kCpC + n);
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int t = t0 + 16 * s + c - half;
@@ -488,6 +537,7 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
 #undef CM_LOAD_W1
   }
   __syncthreads();  // y tile complete; the a-tile is dead
+  CM_STAMP(5);
 
   // ---- depthwise conv + BatchNorm (affine) + Swish: 4 consecutive frames x 8 channels per thread -------------------------------------
   const int cg = tid & 31, rg = tid >> 5;
@@ -532,8 +582,13 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      sc[e] = p.bn_scale[c0 + e];
-      sh[e] = p.bn_shift[c0 + e];
+      if constexpr (OPROJ) {
+        sc[e] = reinterpret_cast<const float*>(smem + L::kOffPar)[512 + c0 + e];
+        sh[e] = reinterpret_cast<const float*>(smem + L::kOffPar)[768 + c0 + e];
+      } else {
+        sc[e] = p.bn_scale[c0 + e];
+        sh[e] = p.bn_shift[c0 + e];
+      }
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -547,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
       zrow[o] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
   }
+  CM_STAMP(6);
   // ---- pointwise_conv2 weights of this wave (64 output columns) --------------------------------------------------------------------
   {
     const uint4* base = p.wp + ((int64_t)(wave * 4) * 8) * 64 + lane;
@@ -574,6 +630,7 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
 #pragma unroll
   for (int o = 0; o < 4; ++o) *reinterpret_cast<uint4*>(smem + (rg * 4 + o) * kCpPitch + cg * 16) = zrow[o];  // z tile over the a-tile
   __syncthreads();
+  CM_STAMP(7);
   f32x4 acc2[4][2];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
@@ -589,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
 #pragma unroll
       for (int s = 0; s < 2; ++s) acc2[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], af[s], acc2[jt][s], 0, 0, 0);
   }
+  CM_STAMP(8);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int t = t0 + 16 * s + c;
@@ -608,7 +666,22 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
       *xp = xv;
     }
   }
+#ifdef MA_CM_PROF
+  CM_STAMP(9);
+  {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int slot = wg == 0 ? 0 : wg == 200 ? 1 : wg == 511 ? 2 : -1;
+    if (threadIdx.x == 0 && slot >= 0)
+      for (int k = 0; k < 10; ++k) g_cm_prof[slot * 16 + k] = cm_ts[k];
+  }
+#endif
 }
+
+#ifdef MA_CM_PROF
+extern "C" int ma_debug_cm_prof(unsigned long long* host48) {
+  return hipMemcpyFromSymbol(host48, HIP_SYMBOL(g_cm_prof), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace ma
 

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(kC2Threads, 2) void conv2_packed_kernel(const Conv2
         v2 = fmaxf(v2, 0.f);
         v3 = fmaxf(v3, 0.f);
       }
+      // (plain stores: written through (sc0 sc1), these 8-byte pieces cost +2.6 % of the whole step)
       *reinterpret_cast<uint2*>(orow + 16 * jt) = make_uint2(c2_pack_bf16(v0, v1), c2_pack_bf16(v2, v3));
     }
   }

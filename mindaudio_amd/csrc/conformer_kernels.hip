@@ -356,6 +356,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
   const int n_kt = (T + kAttK - 1) / kAttK;
   // (named registers + a macro: arrays captured by a lambda end up in scratch memory)
   uint4 rk0, rk1, rk2, rk3, rv0, rv1;
+  float rmask = 1.0f;
   constexpr int kKeyStep = NW * 4;                 // keys covered by one piece index: 16 (4 waves) / 32 (8 waves)
   const int sk_key = tid >> 4, sk_ch = tid & 15;   // K' piece i: key sk_key + kKeyStep i, 16-byte chunk sk_ch
   const int sv_key = tid >> 3, sv_ch = tid & 7;    // V piece i: key sv_key + 2 kKeyStep i, 16-byte chunk sv_ch of its 64 d
@@ -377,12 +378,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
       const int v0_ = k0f_ + sv_key, v1_ = k0f_ + sv_key + 32;                        \
       const uint16_t* vb_ = qkv + row0 * ld_qkv + 2 * H * kDk + h * kDk + sv_ch * 8;          \
       rv0 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)(v0_ < T ? v0_ : T - 1) * ld_qkv);     \
-      if (v0_ >= T) rv0 = make_uint4(0, 0, 0, 0); /* keys past T: probability 0 x a FINITE value */ \
-      if constexpr (NW == 4) {                                                        \
+      if constexpr (NW == 4)                                                          \
         rv1 = *reinterpret_cast<const uint4*>(vb_ + (int64_t)(v1_ < T ? v1_ : T - 1) * ld_qkv);   \
-        if (v1_ >= T) rv1 = make_uint4(0, 0, 0, 0);                                   \
-      }                                                                               \
+      /* (keys past T are zeroed when the tile is published, not here: a select on a register in flight makes the wave wait for \
+         its load at once, which exposed the whole prefetch latency in front of the tile's MFMAs) */ \
     }                                                                                 \
+    /* the tile's mask values travel with it (as a load between the tile's two barriers it was an exposed L2 round trip per tile) */ \
+    if (mask && tid < kAttK) rmask = mask[(int64_t)b * T + (k0f_ + tid < T ? k0f_ + tid : T - 1)];  \
   }
   MA_ATT_FETCH(0)
   for (int kt = 0; kt < n_kt; ++kt) {
@@ -391,15 +393,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
     *reinterpret_cast<uint4*>(&Kp[(sk_key)*kKpStride + sk_ch * 8]) = rk0;
     *reinterpret_cast<uint4*>(&Kp[(sk_key + kKeyStep) * kKpStride + sk_ch * 8]) = rk1;
     *reinterpret_cast<uint4*>(&Vs[sv_key * kVsStride + sv_ch * 8]) = rv0;
+    // keys past T: probability 0 x a FINITE value (a second, predicated store: as a select on rv0 the tile came out wrong for half
+    // of the query rows with this hipcc - tools/att_debug.py)
+    if (k0 + sv_key >= T) *reinterpret_cast<uint4*>(&Vs[sv_key * kVsStride + sv_ch * 8]) = make_uint4(0, 0, 0, 0);
     if constexpr (NW == 4) {
       *reinterpret_cast<uint4*>(&Kp[(sk_key + 32) * kKpStride + sk_ch * 8]) = rk2;
       *reinterpret_cast<uint4*>(&Kp[(sk_key + 48) * kKpStride + sk_ch * 8]) = rk3;
       *reinterpret_cast<uint4*>(&Vs[(sv_key + 32) * kVsStride + sv_ch * 8]) = rv1;
+      if (k0 + sv_key + 32 >= T) *reinterpret_cast<uint4*>(&Vs[(sv_key + 32) * kVsStride + sv_ch * 8]) = make_uint4(0, 0, 0, 0);
     }
     if (tid < kAttK) {
       const int kj = k0 + tid;
       // keys past T do not exist (-inf); padded keys inside T get the reference's additive -10000
-      maskadd[tid] = kj >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + kj] == 0.0f) ? -10000.0f * 1.4426950408889634f : 0.0f);
+      maskadd[tid] = kj >= T ? -INFINITY : (rmask == 0.0f ? -10000.0f * 1.4426950408889634f : 0.0f);
     }
     __syncthreads();
     if (kt + 1 < n_kt) MA_ATT_FETCH(kt + 1)

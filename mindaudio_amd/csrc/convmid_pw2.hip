@@ -663,15 +663,10 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
       xv.y += (acc2[jt][s][1] + bv.y) * rs;
       xv.z += (acc2[jt][s][2] + bv.z) * rs;
       xv.w += (acc2[jt][s][3] + bv.w) * rs;
-#ifdef MA_CM_PLAIN_STORE
+      // (plain store.  Written through (sc0 sc1) the launch is 1.3 us shorter - the end-of-kernel write-back of 16 MB sits between
+      // launches - but a partial write-through does not update the copy of the line this XCD's L2 holds from the read above: the next
+      // kernel on the XCD read stale rows; measured, tests caught it)
       *xp = xv;
-#else
-      {  // write-through (sc0 sc1): the 16 MB of x leave the L2s as they are written instead of in the end-of-kernel write-back, which
-         // sits between this launch and the next (32.6 -> 31.2 us per launch, tools/cm_variants.sh)
-        const f32x4 v_ = {xv.x, xv.y, xv.z, xv.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(xp), "v"(v_) : "memory");
-      }
-#endif
     }
   }
 #ifdef MA_CM_PROF

@@ -16,6 +16,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/mindaudio_amd.h"
 
 #define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
@@ -76,6 +79,136 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (EXT && act == 3) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));  // sigmoid
   if (EXT && act == 4) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * v)) - 1.0f;  // tanh
   return v;
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void gemm_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void gemm_static_for(F&& f) {
+  gemm_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// ---- epilogue shared by the GEMM kernels: acc[i][j] is the 16 x 16 tile at rows m0 + wm_off + 16 i, columns n0 + wn_off + 16 j of a
+// BM x BN workgroup tile; lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] --------------------------------
+template <int FM, int FN, int BM, int BN, int EPI, int NT>
+__device__ __forceinline__ void gemm_store_tile(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm_off, int wn_off,
+                                                char* smem, int tid, int lane) {
+  const int em = lane & 15, en = (lane >> 4) * 4;
+  if (EPI == 2) {  // split-K partial product of K-range blockIdx.y: plain stores into workspace[split][M][N]
+    float* part = reinterpret_cast<float*>(p.out) + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm_off + i * 16 + em;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn_off + j * 16 + en;
+        float* o = part + (int64_t)m * p.N + n;
+        if (n + 3 < p.N && (p.N & 3) == 0) {
+          *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) o[r] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
+  // bf16 tiles that lie fully inside the matrix go through LDS so that HBM sees whole 256-byte rows
+  const bool staged = p.out_bf16 && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 7) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+  if (staged) __builtin_amdgcn_s_barrier();  // all waves are done reading the last K-tile
+  // (compile-time tile indices: past a size the unroller leaves these loops rolled and the accumulators go to scratch memory)
+  gemm_static_for<FM>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const int m = m0 + wm_off + i * 16 + em;
+    if (m >= p.M) return;
+    const float rs = (p.row_scale ? p.row_scale[m] : 1.0f) * p.alpha;
+    gemm_static_for<FN>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      const int n = n0 + wn_off + j * 16 + en;
+      if (n >= p.N) return;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const bool full = (n + 3 < p.N);
+      if (full) {
+        if (p.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act<EPI == 1>(v[r], p.act);
+        if (EPI == 1 && p.col_scale) {
+          const float4 cs = *reinterpret_cast<const float4*>(p.col_scale + n);
+          const float4 ct = *reinterpret_cast<const float4*>(p.col_shift + n);
+          v[0] = v[0] * cs.x + ct.x; v[1] = v[1] * cs.y + ct.y; v[2] = v[2] * cs.z + ct.z; v[3] = v[3] * cs.w + ct.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (EPI == 1 ? apply_act(v[r], p.act2) : v[r]) * rs;
+        if (p.residual) {
+          const float* rp = p.residual + (int64_t)m * p.ldr + n;
+          if ((p.ldr & 3) == 0) {
+            const float4 rv = *reinterpret_cast<const float4*>(rp);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rp[r];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            float x = v[r] + (p.bias ? p.bias[n + r] : 0.0f);
+            x = apply_act<EPI == 1>(x, p.act);
+            if (EPI == 1 && p.col_scale) x = x * p.col_scale[n + r] + p.col_shift[n + r];
+            x = (EPI == 1 ? apply_act(x, p.act2) : x) * rs;
+            if (p.residual) x += p.residual[(int64_t)m * p.ldr + n + r];
+            v[r] = x;
+          }
+        }
+      }
+      if (p.out_bf16) {
+        const uint32_t lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+        if (staged) {
+          // C tile -> LDS (row-major bf16, BN*2-byte rows), whole rows leave below as 16-byte vectors
+          const int lr_ = wm_off + i * 16 + em, lc_ = wn_off + j * 16 + en;
+          *reinterpret_cast<uint2*>(smem + lr_ * (BN * 2 + 16) + lc_ * 2) = make_uint2(lo, hi);
+        } else {
+          uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
+          if (full && ((p.ldo & 3) == 0)) {
+            *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
+          } else {
+            const uint16_t h[4] = {(uint16_t)(lo & 0xffff), (uint16_t)(lo >> 16), (uint16_t)(hi & 0xffff), (uint16_t)(hi >> 16)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) o[r] = h[r];
+          }
+        }
+      } else {
+        float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
+        if (full && ((p.ldo & 3) == 0)) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) o[r] = v[r];
+        }
+      }
+    });
+  });
+  if (staged) {
+    __syncthreads();
+    constexpr int kRowBytes = BN * 2, kChunks = kRowBytes / 16;
+    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m0 * p.ldo + n0;
+    for (int c = tid; c < BM * kChunks; c += NT) {
+      const int r = c / kChunks, cc = c - r * kChunks;
+      *reinterpret_cast<uint4*>(o + (int64_t)r * p.ldo + cc * 8) =
+          *reinterpret_cast<const uint4*>(smem + r * (kRowBytes + 16) + cc * 16);
+    }
+  }
 }
 
 // Tile BM x BN x 64, 256 threads = 4 waves in 2 x 2, each wave (BM/2) x (BN/2) = FM x FN MFMA 16x16x32 tiles.
@@ -205,120 +338,153 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
     }
   }
 
-  // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] ------------------
-  const int em = lane & 15, en = (lane >> 4) * 4;
-  if (EPI == 2) {  // split-K partial product of K-range blockIdx.y: plain stores into workspace[split][M][N]
-    float* part = reinterpret_cast<float*>(p.out) + (int64_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int m = m0 + wm * (BM / 2) + i * 16 + em;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + en;
-        float* o = part + (int64_t)m * p.N + n;
-        if (n + 3 < p.N && (p.N & 3) == 0) {
-          *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) o[r] = acc[i][j][r];
-        }
-      }
-    }
-    return;
+  gemm_store_tile<FM, FN, BM, BN, EPI, kGemmThreads>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), smem, tid, lane);
+}
+
+// ---- 256 x 256 x 64 tile, 8 waves, "8-phase" schedule (cdna_hip_programming.md, the 256^2 8-phase template) -----------------
+// For GEMMs with enough 256 x 256 tiles to fill the chip (ECAPA's 1 x 1 convolutions: M = 76 800, N, K = 1024 .. 3072; the
+// training step's M = 10 240 layers).  The 128 x 128 kernel above is a lock-step structure (every wave: wait, barrier, fragments,
+// MFMAs) and stops at ~36 % of the MFMA peak.  Here:
+//   * 8 waves = 2 (M) x 4 (N), a wave owns 128 x 64 of the tile (32 accumulator tiles); the two wave rows run HALF A PHASE APART
+//     (one extra barrier for wave row 1 at the start, one for wave row 0 at the end), so while one wave of a SIMD runs its 16
+//     MFMAs the other one issues its LDS reads and its share of the next K-tile's loads;
+//   * a K-tile is four phases, one 64 x 32 quadrant of the wave's tile each: (A rows 0-63 | B cols 0-31), (same A | B 32-63),
+//     (A 64-127 | same B), (same A | B 0-31 again): 8 + 4, 4, 8, 4 fragment reads, 16 MFMAs per phase;
+//   * operands go HBM/L2 -> LDS by global_load_lds_dwordx4 in 16 KiB units of 128 rows (A: the rows of one quadrant row of both
+//     wave rows; B: the columns of one quadrant column of all four wave columns), one unit of the NEXT K-tile per phase, into the
+//     other of two 64 KiB buffers; one counted s_waitcnt vmcnt(4) per phase (two units = 4 loads of this wave stay in flight),
+//     never 0 inside the loop; a unit is read one phase after the wait + barrier that retire it and restaged >= 2 phases after
+//     its last read;
+//   * LDS rows of 128 bytes, 16-byte chunks XOR-swizzled by (row & 7) on the SOURCE address and on the read (as above).
+constexpr int k8Threads = 512, k8Unit = 128 * 128, k8Buf = 4 * k8Unit;  // units of a buffer: A q0 | B q0 | B q1 | A q1
+template <int EPI>
+__global__ __launch_bounds__(k8Threads, 1) void gemm_bf16_8ph_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  constexpr int BM = 256, BN = 256;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {  // XCD-aware bijective tile order (see above)
+    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  // bf16 tiles that lie fully inside the matrix go through LDS so that HBM sees whole 256-byte rows
-  const bool staged = p.out_bf16 && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 7) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
-  if (staged) __builtin_amdgcn_s_barrier();  // all waves are done reading the last K-tile
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- staging: instruction i of this wave fills unit rows 8 (wid + 8 i) .. + 7 (lane -> row lr = lane >> 3, chunk slot lane & 7,
+  // which holds logical chunk slot ^ lr).  A unit q, unit row u  <->  tile row (u >> 6) * 128 + 64 q + (u & 63);
+  // B unit q, unit row u  <->  tile column (u >> 5) * 64 + 32 q + (u & 31).
+  const int lr = lane >> 3, kc_src = (lane & 7) ^ lr;
+  const uint16_t* a_src[2][2];
+  const uint16_t* w_src[2][2];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 16 + em;
-    if (m >= p.M) continue;
-    const float rs = (p.row_scale ? p.row_scale[m] : 1.0f) * p.alpha;
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + en;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const bool full = (n + 3 < p.N);
-      if (full) {
-        if (p.bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act<EPI == 1>(v[r], p.act);
-        if (EPI == 1 && p.col_scale) {
-          const float4 cs = *reinterpret_cast<const float4*>(p.col_scale + n);
-          const float4 ct = *reinterpret_cast<const float4*>(p.col_shift + n);
-          v[0] = v[0] * cs.x + ct.x; v[1] = v[1] * cs.y + ct.y; v[2] = v[2] * cs.z + ct.z; v[3] = v[3] * cs.w + ct.w;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (EPI == 1 ? apply_act(v[r], p.act2) : v[r]) * rs;
-        if (p.residual) {
-          const float* rp = p.residual + (int64_t)m * p.ldr + n;
-          if ((p.ldr & 3) == 0) {
-            const float4 rv = *reinterpret_cast<const float4*>(rp);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rp[r];
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r < p.N) {
-            float x = v[r] + (p.bias ? p.bias[n + r] : 0.0f);
-            x = apply_act<EPI == 1>(x, p.act);
-            if (EPI == 1 && p.col_scale) x = x * p.col_scale[n + r] + p.col_shift[n + r];
-            x = (EPI == 1 ? apply_act(x, p.act2) : x) * rs;
-            if (p.residual) x += p.residual[(int64_t)m * p.ldr + n + r];
-            v[r] = x;
-          }
-        }
-      }
-      if (p.out_bf16) {
-        const uint32_t lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
-        if (staged) {
-          // C tile -> LDS (row-major bf16, BN*2-byte rows), whole rows leave below as 16-byte vectors
-          const int lr_ = wm * (BM / 2) + i * 16 + em, lc_ = wn * (BN / 2) + j * 16 + en;
-          *reinterpret_cast<uint2*>(smem + lr_ * (BN * 2 + 16) + lc_ * 2) = make_uint2(lo, hi);
-        } else {
-          uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n;
-          if (full && ((p.ldo & 3) == 0)) {
-            *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
-          } else {
-            const uint16_t h[4] = {(uint16_t)(lo & 0xffff), (uint16_t)(lo >> 16), (uint16_t)(hi & 0xffff), (uint16_t)(hi >> 16)};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) o[r] = h[r];
-          }
-        }
-      } else {
-        float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n;
-        if (full && ((p.ldo & 3) == 0)) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) o[r] = v[r];
-        }
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int u = 8 * (wid + 8 * i) + lr;
+      int m = m0 + (u >> 6) * 128 + 64 * q + (u & 63);
+      if (m >= p.M) m = p.M - 1;  // rows / columns past the matrix are computed and never stored
+      a_src[q][i] = p.A + (int64_t)m * p.lda + kc_src * 8;
+      int n = n0 + (u >> 5) * 64 + 32 * q + (u & 31);
+      if (n >= p.N) n = p.N - 1;
+      w_src[q][i] = p.W + (int64_t)n * p.ldw + kc_src * 8;
     }
-  }
-  if (staged) {
-    __syncthreads();
-    constexpr int kRowBytes = BN * 2, kChunks = kRowBytes / 16;
-    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m0 * p.ldo + n0;
-    for (int c = tid; c < BM * kChunks; c += kGemmThreads) {
-      const int r = c / kChunks, cc = c - r * kChunks;
-      *reinterpret_cast<uint4*>(o + (int64_t)r * p.ldo + cc * 8) =
-          *reinterpret_cast<const uint4*>(smem + r * (kRowBytes + 16) + cc * 16);
+  // unit index U in a buffer: 0 = A q0, 1 = B q0, 2 = B q1, 3 = A q1 (the order in which a K-tile first needs them)
+  auto stage = [&](auto uc, int kt, int buf) __attribute__((always_inline)) {
+    constexpr int U = decltype(uc)::value;
+    char* dst = smem + buf * k8Buf + U * k8Unit + wid * 1024;
+    const int64_t k0 = (int64_t)kt * BK;
+    if constexpr (U == 0 || U == 3) {
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(a_src[U == 3][0] + k0), (lds_void_t*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(a_src[U == 3][1] + k0), (lds_void_t*)(dst + 8192), 16, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(w_src[U == 2][0] + k0), (lds_void_t*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(w_src[U == 2][1] + k0), (lds_void_t*)(dst + 8192), 16, 0, 0);
     }
+  };
+
+  // ---- fragment reads: lane (frow = lane & 15, fk = lane >> 4) reads unit row base + frow, logical chunk 4 kk + fk ---------------
+  const int frow = lane & 15, fk = lane >> 4;
+  const int off_a = (wr * 64 + frow) * 128 + ((fk ^ (frow & 7)) << 4);  // + i * 2048 (16 rows), kk = 1: ^ 64
+  const int off_b = (wc * 32 + frow) * 128 + ((fk ^ (frow & 7)) << 4);  // + j * 2048
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bfr[2][2];  // [fragment][kk]
+
+  auto load_a = [&](const char* unit) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) af[i][kk] = *reinterpret_cast<const bf16x8*>(unit + ((off_a + i * 2048) ^ (kk << 6)));
+  };
+  auto load_b = [&](const char* unit) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bfr[j][kk] = *reinterpret_cast<const bf16x8*>(unit + ((off_b + j * 2048) ^ (kk << 6)));
+  };
+  auto mma = [&](auto ic, auto jc) __attribute__((always_inline)) {  // quadrant (I, J): acc[4 I + i][2 J + j]
+    constexpr int I = decltype(ic)::value, J = decltype(jc)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[4 * I + i][2 * J + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][kk], af[i][kk], acc[4 * I + i][2 * J + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>;
+
+  const int nk = p.K / BK;
+  stage(C0{}, 0, 0);
+  stage(C1{}, 0, 0);
+  stage(C2{}, 0, 0);
+  stage(C3{}, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs half a phase behind wave row 0
+  // One phase: fragment reads of this quadrant, one unit of the next K-tile, the counted wait, barrier, 16 MFMAs, barrier.
+#define G8_PHASE(MORE, READS, U, I, J)                                                \
+  {                                                                                   \
+    READS;                                                                            \
+    if constexpr (MORE) stage(U{}, kt + 1, nb);                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    if constexpr (MORE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
+    __builtin_amdgcn_s_barrier();                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    mma(I{}, J{});                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    __builtin_amdgcn_s_barrier();                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                \
   }
+#define G8_TILE(MORE)                                                                 \
+  {                                                                                   \
+    const char* cb = smem + (kt & 1) * k8Buf;                                         \
+    const int nb = (kt + 1) & 1;                                                      \
+    G8_PHASE(MORE, load_a(cb); load_b(cb + k8Unit), C0, C0, C0)                       \
+    G8_PHASE(MORE, load_b(cb + 2 * k8Unit), C1, C0, C1)                               \
+    G8_PHASE(MORE, load_a(cb + 3 * k8Unit), C2, C1, C1)                               \
+    G8_PHASE(MORE, load_b(cb + k8Unit), C3, C1, C0)                                   \
+  }
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) G8_TILE(true)
+  G8_TILE(false)  // the last K-tile: nothing left to stage
+#undef G8_TILE
+#undef G8_PHASE
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // (the barrier wave row 1 took at the start)
+  gemm_store_tile<8, 4, BM, BN, EPI, k8Threads>(p, acc, m0, n0, wr * 128, wc * 64, smem, tid, lane);
 }
 
 // out[m][n] (+)= alpha * sum_s part[s][m][n]
@@ -363,17 +529,38 @@ static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
   return MA_OK;
 }
 
+template <int EPI>
+static int launch_gemm_8ph(const GemmParams& p, hipStream_t stream) {
+  constexpr int ring = 2 * k8Buf, stage_c = 256 * (256 * 2 + 16);  // K-tile buffers / staged bf16 C tile
+  constexpr int lds = ring > stage_c ? ring : stage_c;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return MA_ERR_LAUNCH;
+    attr = true;
+  }
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  MA_LAUNCH((gemm_bf16_8ph_kernel<EPI>), dim3(tiles), dim3(k8Threads), lds, stream, p);
+  return MA_OK;
+}
+
+#ifndef MA_GEMM_FORCE
+#define MA_GEMM_FORCE 0  // development builds only (tools/lib_variant.sh): 1 = never the 256 x 256 kernel, 2 = always when legal
+#endif
 template <int IM2COL, int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+  // 256 x 256 tiles (8-phase kernel) when they fill the chip: plain A operand
+  if constexpr (IM2COL == 0 && EPI != 2 && MA_GEMM_FORCE != 1) {
+    const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    // K >= 1024 (with fewer K-tiles the 128 x 128 kernel's shorter prologue / epilogue wins: ECAPA's 512 -> 512 layers 2.49 vs 2.79 ms
+    // per forward) and at most 1/8 of the column tiles' width outside the matrix (tools/gemm_bench.py, tools/ecapa_bench.py)
+    const int64_t n_pad = (int64_t)((p.N + 255) / 256) * 256 - p.N;
+    if (p.K >= 1024 && 8 * n_pad <= p.N && (MA_GEMM_FORCE == 2 || t256 >= (int64_t)(0.9 * gemm_num_cus())))
+      return launch_gemm_8ph<EPI>(p, stream);
+  }
   // 128 x 128 tiles unless they would leave most CUs without a workgroup (N = 256 .. 768 at M ~ 8k)
   const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  static const char* force = getenv("MA_GEMM_TILE");  // developer override: "1" 128x128x3, "2" 128x128x2, "6" 64x128x3
-  if (force && force[0] == '1') return launch_gemm_tile<128, 128, 3, IM2COL, EPI>(p, stream);
-  if (force && force[0] == '2') return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
-  if (force && force[0] == '6') return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
-  if (force && force[0] == '7') return launch_gemm_tile<64, 128, 2, IM2COL, EPI>(p, stream);
-  if (force && force[0] == '8') return launch_gemm_tile<128, 256, 2, IM2COL, EPI>(p, stream);
-  if (force && force[0] == '9') return launch_gemm_tile<256, 256, 2, IM2COL, EPI>(p, stream);
   // measured on MI355X (tools/gemm_bench.py): 2 workgroups/CU beat a deeper ring for the 128x128 tile; the
   // 64x128 tile prefers 3 workgroups/CU (2 stages) when there are enough tiles to fill them, else the 3-stage ring
   if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
@@ -456,6 +643,7 @@ int ma_conv1d_taps_bf16(const void* act, int64_t lda, int64_t rows, int64_t C, i
   p.dil = dilation;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
+  if (taps == 1) return launch_gemm<0, 1>(p, (hipStream_t)stream);  // a plain GEMM: eligible for the 256 x 256 kernel
   return launch_gemm<2, 1>(p, (hipStream_t)stream);
 }
 

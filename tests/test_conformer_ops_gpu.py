@@ -22,8 +22,10 @@ def _rand(t, *shape, seed=0, scale=1.0):
     return (t.randn(*shape, generator=g) * scale)
 
 
+# (the last three run on the 256 x 256 8-phase kernel: ragged M and N edges, an odd leading dimension, a long contraction)
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (250, 256, 256), (7968, 2048, 256), (1000, 256, 2048),
-                                   (333, 4233, 256), (513, 768, 256), (64, 256, 4864)])
+                                   (333, 4233, 256), (513, 768, 256), (64, 256, 4864), (4133, 3850, 1088),
+                                   (8192, 1024, 1024), (2049, 8200, 2048)])
 def test_gemm_plain_and_transpose_detecting(t, m, n, k):
     from mindaudio_amd import ops
 

@@ -540,6 +540,16 @@ int ma_conv2d_3x3s2_pack_bf16(const void* W, int64_t C, int64_t Cout, void* pack
 int ma_conv2d_3x3s2_packed_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* packed,
                                      int64_t Cout, const float* bias, int32_t relu, void* out, ma_stream_t stream);
 
+/* Dense layer with a long contraction and 256 outputs on a fragment-ordered packed copy of W (rows_packed.hip): the `out`
+ * Linear(19 * 256 -> 256) of Conv2dSubsampling4 followed by x * sqrt(d) (layers/subsampling.py:46-47,76, layers/embedding.py:84):
+ *   out (M, 256) float32 = alpha * (A (M, K) bf16 . W (256, K)^T + bias).
+ *   ma_gemm_rows_packed_bytes(N, K) -> bytes of the packed buffer (negative: unsupported; N = 256, K % 64 == 0; K is zero-padded to a multiple of 192);
+ *   ma_gemm_rows_pack_bf16(W (N, K) bf16, ldw, N, K, packed): once per weight update. */
+int64_t ma_gemm_rows_packed_bytes(int64_t N, int64_t K);
+int ma_gemm_rows_pack_bf16(const void* W, int64_t ldw, int64_t N, int64_t K, void* packed, ma_stream_t stream);
+int ma_gemm_rows_packed_f32(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, int64_t N, const float* bias,
+                            float alpha, float* out, int64_t ldo, ma_stream_t stream);
+
 /* ma_convmodule_mid_bf16 + pointwise_conv2 + mask_pad + the block's residual in one launch (layers/convolution.py:100-127,
  * models/conformer.py:143; C = 256, odd kernel_size <= 15):
  *   x[m, :] += mask[m] * (swish(bn(depthwise(glu(y))))[m, :] . Wp2^T + pw2_bias)

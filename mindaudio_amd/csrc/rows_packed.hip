@@ -1,0 +1,251 @@
+// Dense layer with a long contraction and 256 outputs on a fragment-packed weight:
+//
+//     out[m, 0:256] = alpha * (A[m, 0:K] . W[0:256, 0:K]^T + bias)            A bf16 (M, K) row-major, out float32
+//
+// = the `out` Linear(19 * 256 -> 256) of Conv2dSubsampling4 (mindaudio/models/layers/subsampling.py:46-47,76) followed by the
+// x * sqrt(d) of the positional encoding (layers/embedding.py:84): M = B * T' = 15 936 rows, K = 4864, 39.7 GFLOP.  On the
+// general 128 x 128 kernel (gemm_bf16.hip) this shape has ONE column tile and 125 row tiles - half the chip idle, 69 us.
+// Here, as in conv2_packed.hip:
+//   * a workgroup owns 64 rows x all 256 outputs (249 workgroups = one per CU), a wave 64 outputs against the 64 rows
+//     (16 accumulator tiles);
+//   * every weight fragment has one consumer, so the weight streams L2 -> registers from a fragment-ordered packed copy through a
+//     24-slot register ring, THREE K-chunks (96 MFMAs) ahead of its use - one wave per SIMD, nothing else hides the L2 latency;
+//   * the activation tile (64 rows x 64 k = 8 KiB per K-chunk) goes HBM/L2 -> LDS with global_load_lds_dwordx4 into a 3-stage
+//     ring two chunks ahead; one counted s_waitcnt vmcnt + one raw barrier per chunk.
+// The launch is bound by the L2 -> CU path: every CU pulls the whole 2.5 MB weight.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "../../include/mindaudio_amd.h"
+
+#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+  do {                                                                        \
+    (void)hipGetLastError();                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
+    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
+  } while (0)
+
+namespace ma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gl_void_t;
+
+template <int... Is, class F>
+__device__ __forceinline__ void rp_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void rp_static_for(F&& f) {
+  rp_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+constexpr int kRpRows = 64, kRpN = 256, kRpThreads = 256;
+constexpr int kRpStage = kRpRows * 128;  // 8 KiB: 64 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
+constexpr int kRpLds = 3 * kRpStage;
+
+struct RowsPackedParams {
+  const uint16_t* a;  // (M, K) bf16
+  int64_t lda;
+  const uint4* wp;    // packed W: [wave 4][chunk K/64][kk 2][tile 4][lane 64] x 16 B
+  const float* bias;
+  float* out;         // (M, 256) f32
+  int64_t ldo;
+  int32_t M, nchunks;
+  float alpha;
+};
+
+// item (wave w, chunk c, k-step kk, tile jt): lane (i, g) holds W[64 w + 16 jt + i][64 c + 32 kk + 8 g .. + 8]; chunks nchunks ..
+// nch_pad - 1 (the chunk count rounded up to a multiple of 3, the kernel's ring period) are zeros
+__global__ void rows_pack_kernel(const uint16_t* __restrict__ w, int64_t ldw, int nchunks, int nch_pad, uint4* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 4 * nch_pad * 8 * 64) return;
+  const int lane = idx & 63, q = (idx >> 6) & 7, c = (idx >> 9) % nch_pad, wv = (idx >> 9) / nch_pad;
+  const int kk = q >> 2, jt = q & 3;
+  const int n = 64 * wv + 16 * jt + (lane & 15);
+  const int k = 64 * c + 32 * kk + 8 * (lane >> 4);
+  out[idx] = c < nchunks ? *reinterpret_cast<const uint4*>(w + (int64_t)n * ldw + k) : make_uint4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPackedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * kRpRows;
+  const int nch = p.nchunks;                 // K / 64: activation chunks that exist
+  const int nch_pad = (nch + 2) / 3 * 3;     // chunks the loop runs: the packed weight is zero beyond nch, the activation chunk index is clamped
+
+  // ---- activation sources of the 2 LDS-DMA instructions of this wave (rows 8 (wave + 4 i) + (lane >> 3)) ----------------------
+  const int lr = lane >> 3;
+  const int kc_src = (lane & 7) ^ lr;  // source-side swizzle: LDS slot (lane & 7) of row lr holds logical chunk slot ^ lr
+  const uint16_t* a_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + 8 * (wave + 4 * i) + lr;
+    if (m >= p.M) m = p.M - 1;
+    a_src[i] = p.a + (int64_t)m * p.lda + kc_src * 8;
+  }
+  auto issue_a = [&](int chunk, int stage) __attribute__((always_inline)) {
+    const int cc = chunk < nch ? chunk : nch - 1;  // padded chunks re-read the last one (times a zero weight); past the end: a duplicate
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(a_src[i] + (int64_t)cc * 64),
+                                       (lds_void_t*)(smem + stage * kRpStage + (wave + 4 * i) * 1024), 16, 0, 0);
+  };
+  // ---- weight fragments: SGPR chunk base + lane offset, 8 per chunk, three chunks of ring ----------------------------------------
+  const uint32_t voff = lane * 16 + 4096;
+  const char* wbase = reinterpret_cast<const char*>(p.wp) + (int64_t)wave * nch_pad * 8192;
+#define RP_LOAD(dst, chunk, q)                                                                                         \
+  do {                                                                                                                 \
+    const char* cb_ = wbase + (int64_t)((chunk) < nch_pad ? (chunk) : nch_pad - 1) * 8192;                             \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(cb_), "n"(((q) - 4) * 1024)   \
+                 : "memory");                                                                                          \
+  } while (0)
+  bf16x8 ring[3][8];
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read address: row 16 s + c of the stage (s and the stage go into the immediate offset), logical 16-byte chunk 4 kk + g
+  const uint32_t a_addr0 = (uint32_t)(uintptr_t)(lds_void_t*)(smem + c * 128 + ((g ^ (c & 7)) << 4));
+  const uint32_t a_addr1 = a_addr0 ^ 64u;
+
+  // prologue: the weights of chunks 0..2, then the activation chunks 0 and 1
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    RP_LOAD(ring[r][0], r, 0); RP_LOAD(ring[r][1], r, 1); RP_LOAD(ring[r][2], r, 2); RP_LOAD(ring[r][3], r, 3);
+    RP_LOAD(ring[r][4], r, 4); RP_LOAD(ring[r][5], r, 5); RP_LOAD(ring[r][6], r, 6); RP_LOAD(ring[r][7], r, 7);
+  }
+  issue_a(0, 0);
+  issue_a(1, 1);
+
+  // Loads of a wave, oldest first, in the steady state:
+  //   ... W(c)[q..7] | A(c)x2 W(c+1)x8 | A(c+1)x2 W(c+2)x8 | A(c+2)x2 W(c+3)[0..q-1] ...
+  //   (A(c+2) is issued at the start of chunk c, W(c+3)[q] right after the last MFMA that reads ring[c % 3][q] in chunk c.)
+  //   start of chunk c >= 2: A(c) landed  <=>  at most W(c+1)x8 + A(c+1)x2 + W(c+2)x8 = 18 younger loads outstanding -> vmcnt(18);
+  //   chunk 0: only A(1)x2 is younger -> vmcnt(2); chunk 1: A(2)x2 + W(3)x8 -> vmcnt(10);
+  //   use of ring[.][q] in chunk c: younger = (7 - q) + 10 + 10 + 2 + q = 29 -> vmcnt(29) (more in chunks 0..2: waits for less).
+  auto chunk_step = [&](auto jc, auto wc, int chunk) __attribute__((always_inline)) {
+    constexpr int ST = decltype(jc)::value;
+    constexpr int kAWait = decltype(wc)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAWait) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_a(chunk + 2, (ST + 2) % 3);  // the stage chunk - 1 used: every wave is past its reads (barrier above)
+    bf16x8 af[2][4];
+#define RP_LDS(kk_, s_)                                                                                        \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kk_][s_]) : "v"(kk_ ? a_addr1 : a_addr0), "n"(ST * kRpStage + (s_) * 2048) \
+               : "memory")
+    RP_LDS(0, 0); RP_LDS(0, 1); RP_LDS(0, 2); RP_LDS(0, 3);
+    RP_LDS(1, 0); RP_LDS(1, 1); RP_LDS(1, 2); RP_LDS(1, 3);
+#undef RP_LDS
+    rp_static_for<2>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kc)::value;
+      if constexpr (kk == 0)
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3])::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3])::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      rp_static_for<4>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int jt = decltype(tc)::value;
+        constexpr int q = kk * 4 + jt;
+        asm volatile("s_waitcnt vmcnt(29)" : "+v"(ring[ST][q])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        rp_static_for<4>([&](auto sc) __attribute__((always_inline)) {
+          constexpr int s = decltype(sc)::value;
+          acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[ST][q], af[kk][s], acc[jt][s], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        RP_LOAD(ring[ST][q], chunk + 3, q);
+      });
+    });
+  };
+  using W2 = std::integral_constant<int, 2>;
+  using W10 = std::integral_constant<int, 10>;
+  using W18 = std::integral_constant<int, 18>;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  chunk_step(S0{}, W2{}, 0);
+  chunk_step(S1{}, W10{}, 1);
+  chunk_step(S2{}, W18{}, 2);
+  // (no tail code: a chunk step behind a branch leaves its refills with no later use, their registers are handed out again and the
+  // loads still in flight land in somebody else's values; hence the zero-padded weight and a loop of whole ring periods)
+  for (int c3 = 3; c3 < nch_pad; c3 += 3) {
+    chunk_step(S0{}, W18{}, c3);
+    chunk_step(S1{}, W18{}, c3 + 1);
+    chunk_step(S2{}, W18{}, c3 + 2);
+  }
+  // the duplicate loads past the last chunk: the ring registers stay reserved until they have landed
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[0][2]), "+v"(ring[0][3]), "+v"(ring[0][4]), "+v"(ring[0][5]), "+v"(ring[0][6]),
+                 "+v"(ring[0][7]), "+v"(ring[1][0]), "+v"(ring[1][1]), "+v"(ring[1][2]), "+v"(ring[1][3]), "+v"(ring[1][4]), "+v"(ring[1][5]),
+                 "+v"(ring[1][6]), "+v"(ring[1][7]), "+v"(ring[2][0]), "+v"(ring[2][1]), "+v"(ring[2][2]), "+v"(ring[2][3]), "+v"(ring[2][4]),
+                 "+v"(ring[2][5]), "+v"(ring[2][6]), "+v"(ring[2][7])
+               :
+               : "memory");
+#undef RP_LOAD
+
+  // ---- epilogue: lane (c, g) holds rows m0 + 16 s + c, outputs 64 wave + 16 jt + 4 g + r ----------------------------------------
+  float4 bv[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) bv[jt] = *reinterpret_cast<const float4*>(p.bias + 64 * wave + 16 * jt + 4 * g);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int m = m0 + 16 * s + c;
+    if (m >= p.M) continue;
+    float* orow = p.out + (int64_t)m * p.ldo + 64 * wave + 4 * g;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      *reinterpret_cast<float4*>(orow + 16 * jt) =
+          make_float4((acc[jt][s][0] + bv[jt].x) * p.alpha, (acc[jt][s][1] + bv[jt].y) * p.alpha, (acc[jt][s][2] + bv[jt].z) * p.alpha,
+                      (acc[jt][s][3] + bv[jt].w) * p.alpha);
+  }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" int64_t ma_gemm_rows_packed_bytes(int64_t N, int64_t K) {
+  if (N != kRpN || K < 64 || K % 64 != 0 || K > (1 << 20)) return MA_ERR_UNSUPPORTED;
+  return N * ((K / 64 + 2) / 3 * 3 * 64) * 2;  // K rounded up to a multiple of 192: whole periods of the kernel's 3-chunk ring
+}
+
+extern "C" int ma_gemm_rows_pack_bf16(const void* W, int64_t ldw, int64_t N, int64_t K, void* packed, ma_stream_t stream) {
+  if (!W || !packed) return MA_ERR_INVALID_ARG;
+  if (ma_gemm_rows_packed_bytes(N, K) < 0 || ldw < K || (ldw & 7)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(packed)) & 15) return MA_ERR_INVALID_ARG;
+  const int nch = (int)(K / 64), nch_pad = (nch + 2) / 3 * 3, total = 4 * nch_pad * 8 * 64;
+  MA_LAUNCH(rows_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint16_t*>(W), ldw, nch,
+            nch_pad, reinterpret_cast<uint4*>(packed));
+  return MA_OK;
+}
+
+extern "C" int ma_gemm_rows_packed_f32(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, int64_t N, const float* bias,
+                                       float alpha, float* out, int64_t ldo, ma_stream_t stream) {
+  if (!A || !packed || !bias || !out || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (ma_gemm_rows_packed_bytes(N, K) < 0 || lda < K || (lda & 7) || ldo < N || (ldo & 3)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |
+       reinterpret_cast<uintptr_t>(bias)) & 15)
+    return MA_ERR_INVALID_ARG;
+  RowsPackedParams p;
+  p.a = reinterpret_cast<const uint16_t*>(A);
+  p.lda = lda;
+  p.wp = reinterpret_cast<const uint4*>(packed);
+  p.bias = bias;
+  p.out = out;
+  p.ldo = ldo;
+  p.M = (int32_t)M;
+  p.nchunks = (int32_t)(K / 64);
+  p.alpha = alpha;
+  MA_LAUNCH(rows_packed_kernel, dim3((unsigned)((M + kRpRows - 1) / kRpRows)), dim3(kRpThreads), kRpLds, (hipStream_t)stream, p);
+  return MA_OK;
+}

@@ -183,6 +183,7 @@ class ConformerEncoder(nn.Module):
                 "pw2_b": cm.pointwise_conv2.bias.detach().float().contiguous(),
             })
         prep["conv2_pk"] = ops.conv2d_3x3s2_pack(prep["conv2_w"])
+        prep["out_pk"] = ops.gemm_rows_pack(prep["out_w"])  # None when d_model != 256
         # fragment-ordered packed copies: FFN weights for the hidden-slice-owner kernel (ops.ffn_packed), the K = 256 dense
         # layers for ops.gemm_packed
         for W in prep["layers"]:
@@ -389,7 +390,10 @@ class ConformerEncoder(nn.Module):
         mask_rows = mask2d.reshape(m)
         att_mask = mask2d if xs_chunk_masks is None else xs_chunk_masks.reshape(b, t2).to(f32).contiguous()
         # Dense(4864 -> 256) then x * sqrt(d) (subsampling.py:76, embedding.py:84)
-        x = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(self.d), out_dtype=f32)
+        if P.get("out_pk") is not None:
+            x = ops.gemm_rows_packed(act2.view(m, f2 * c), P["out_pk"], P["out_b"], alpha=math.sqrt(self.d))
+        else:
+            x = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(self.d), out_dtype=f32)
         pos_all = self._pos_projection(t2)
         # The fused launches win at every batch size measured (B = 1 .. 64 at T = 1000: 1.44 vs 2.25 ms at B = 1); the
         # general form covers shapes the packed kernels do not (and `fuse_min_rows` lets the tests run it on any shape).

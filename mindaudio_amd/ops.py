@@ -71,6 +71,38 @@ def conv2d_3x3s2_packed(act, packed, bias, relu=True, out=None):
     return out
 
 
+def gemm_rows_pack(w):
+    """Fragment-ordered packed copy of w (256, K) bf16 for gemm_rows_packed; None if the shape is not covered."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert w.dtype == t.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    n, k = w.shape
+    nbytes = lib.ma_gemm_rows_packed_bytes(n, k)
+    if nbytes < 0 or w.stride(0) % 8:
+        return None
+    packed = t.empty((n, nbytes // (2 * n)), dtype=t.bfloat16, device=w.device)  # K zero-padded to a multiple of 192
+    _lib.check(lib.ma_gemm_rows_pack_bf16(_host.ptr(w), w.stride(0), n, k, _host.ptr(packed), _host.current_stream_ptr()),
+               "gemm_rows_pack_bf16")
+    return packed
+
+
+def gemm_rows_packed(a, packed, bias, alpha=1.0, out=None):
+    """out (M, 256) float32 = alpha * (a (M, K) bf16 @ W^T + bias) on a packed weight (gemm_rows_pack)."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert a.dtype == t.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and 0 <= packed.shape[1] - a.shape[1] < 192
+    assert bias.dtype == t.float32
+    m, k = a.shape
+    n = packed.shape[0]
+    if out is None:
+        out = t.empty((m, n), dtype=t.float32, device=a.device)
+    assert out.dtype == t.float32 and out.stride(1) == 1 and tuple(out.shape) == (m, n)
+    rc = lib.ma_gemm_rows_packed_f32(_host.ptr(a), a.stride(0), m, k, _host.ptr(packed), n, _host.ptr(bias), float(alpha),
+                                     _host.ptr(out), out.stride(0), _host.current_stream_ptr())
+    _lib.check(rc, "gemm_rows_packed_f32")
+    return out
+
+
 def gemm_k256_pack(w):
     """Fragment-ordered packed copy of w (N, 256) bf16 for gemm_packed; None if the shape is not covered (N % 256, K != 256)."""
     t = _host.torch()

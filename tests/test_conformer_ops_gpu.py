@@ -232,6 +232,33 @@ def test_gemm_k256_packed(t, m, n):
     assert float((x.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("m,k", [(15936, 4864), (1000, 192), (77, 1024), (130, 448), (64, 64)])
+def test_gemm_rows_packed(t, m, k):
+    """The embed layer's Dense(19 * 256 -> 256) * sqrt(d) on a fragment-packed weight: same numbers as ops.gemm."""
+    from mindaudio_amd import ops
+
+    n = 256
+    a = _rand(t, m, k, seed=51).bfloat16().cuda()
+    w = _rand(t, n, k, seed=52, scale=1.0 / math.sqrt(k)).bfloat16().cuda()
+    bias = _rand(t, n, seed=53).cuda()
+    pk = ops.gemm_rows_pack(w)
+    kpad = (k // 64 + 2) // 3 * 192
+    assert pk is not None and tuple(pk.shape) == (n, kpad)
+    assert float(pk.double().abs().sum()) == float(w.double().abs().sum())  # a permutation of W plus zero padding
+    assert ops.gemm_rows_pack(w[:128].contiguous()) is None and ops.gemm_rows_pack(w[:, :32].contiguous()) is None
+    ref = (a.double() @ w.double().T + bias.double()) * 16.0
+    got = ops.gemm_rows_packed(a, pk, bias, alpha=16.0)
+    assert got.dtype == t.float32
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # strided A (rows of a wider buffer) and a strided output
+    wide = _rand(t, m, k + 64, seed=54).bfloat16().cuda()
+    outw = t.zeros(m, n + 32, device="cuda")
+    ops.gemm_rows_packed(wide[:, 64:], pk, bias, out=outw[:, :n])
+    want = wide[:, 64:].double() @ w.double().T + bias.double()
+    assert float((outw[:, :n].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float(outw[:, n:].abs().max()) == 0.0
+
+
 def test_gemm_rejects_bad_shapes(t):
     from mindaudio_amd import ops
 

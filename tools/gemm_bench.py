@@ -21,3 +21,9 @@ x = torch.randn(32, 499, 39, 256, device="cuda").bfloat16(); w = (torch.randn(25
 s = timeit(lambda: ops.conv2d_3x3s2_nhwc(x, w, bias=bias))
 fl = 2.0 * 32 * 249 * 19 * 256 * 2304
 print("conv2 implicit gemm B=32: %.1f us %.1f TF/s" % (s * 1e6, fl / s / 1e12))
+m, n, k = 15936, 256, 4864
+a = torch.randn(m, k, device="cuda").bfloat16(); w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).bfloat16(); bias = torch.randn(n, device="cuda")
+pk = ops.gemm_rows_pack(w)
+s = timeit(lambda: ops.gemm_rows_packed(a, pk, bias, alpha=16.0))
+s0 = timeit(lambda: ops.gemm(a, w, bias=bias, alpha=16.0, out_dtype=torch.float32))
+print("embed layer M=%d K=%d: rows_packed %.1f us (%.0f TF/s)   general kernel %.1f us" % (m, k, s * 1e6, 2.0 * m * n * k / s / 1e12, s0 * 1e6))

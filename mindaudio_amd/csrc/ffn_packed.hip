@@ -62,8 +62,7 @@ constexpr int kPkOffPar2 = kPkOffPar + 5 * 1024;  // pair mode, second stage: b2
 constexpr int kPkOffPar0 = kPkOffPar2 + 3 * 1024;  // gamma0, beta0 of the input LayerNorm
 constexpr int kPkOffBias = kPkOffPar0 + 2 * 1024;  // b1 of each wave's first two blocks (4 x 64 floats)
 constexpr int kPkOffQb = kPkOffBias + 1024;  // bias of the qkv tail (<= 1024 floats)
-constexpr int kPkOffJunk = kPkOffQb + 4096;  // destination of the L2 warm-up loads (4 x 1 KiB)
-constexpr int kPkLds = kPkOffJunk + 4096;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
+constexpr int kPkLds = kPkOffQb + 4096;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
 constexpr int kPkMaxHidden = 8192;
 
 struct FfnPackedParams {
@@ -443,6 +442,9 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   //   its bias (issued before W1') : W1'[0..15] are younger                                             -> vmcnt(16)
   //   product2 of block b, item j  : W2[j..15], the 2 bias loads of block b+2, W1''[0..j-1]             -> vmcnt(17)
   //   prologue (product1 of block 0, refilled with W1 of block 1): everything but block 1's bias has landed (counts 17 / 18 hold trivially)
+  // (Measured and dropped: L2 warm-up of a stage's weights / of the qkv weight by junk LDS-DMA loads issued by the XCD's workgroups a
+  // few microseconds ahead - no change for the tail, +1 % on the whole step for the FFN weights: the loads queue up in front of the
+  // stage's own.)
   const int nstage = p.pair ? 2 : 1;
   for (int stg = 0; stg < nstage; ++stg) {
   // The staging and epilogue addresses below are loop-invariant, and hipcc would hoist all of them out of this loop and SPILL them
@@ -651,18 +653,6 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
                  "+v"(ring[15]), "+v"(b1lo), "+v"(b1hi)
                :
                : "memory");  // drain of the main loop's last prefetches (see above)
-  if (p.qkv_wp && stg == nstage - 1) {
-    // The qkv weight was last read a whole launch ago and has left this XCD's L2 behind 4 MB of FFN weights: the tail's first
-    // block would wait for the Infinity Cache.  The workgroups of an XCD (blockIdx % 8) share its L2, so each touches 1 / 12 of
-    // the weight's 128-byte lines now, ~6 us ahead: LDS-DMA into a junk area - no destination registers to keep out of the
-    // allocator's hands (asm: the compiler must not see an LDS write it would fence with vmcnt(0) before the exchange reads).
-    const int line = (blockIdx.x >> 3) * 256 + tidv;
-    if (line < p.qkv_n * 4) {
-      const char* src = reinterpret_cast<const char*>(p.qkv_wp) + (int64_t)line * 128;
-      const uint32_t junk = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + kPkOffJunk) + wave * 1024;
-      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(junk), "v"(src) : "memory");
-    }
-  }
   {
     const f32x4* s1 = xslot(wave, 0);
     const f32x4* s2 = xslot(wave, 1);

@@ -177,7 +177,11 @@ __global__ __launch_bounds__(kC2Threads, 2) void conv2_packed_kernel(const Conv2
     chunk_step(std::integral_constant<int, 1>{}, c3 + 1);
     chunk_step(std::integral_constant<int, 2>{}, c3 + 2);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the duplicate loads past the last chunk
+  // the duplicate loads past the last chunk: their destination registers stay reserved until they have landed
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(ring[0]), "+v"(ring[1]), "+v"(ring[2]), "+v"(ring[3]), "+v"(ring[4]), "+v"(ring[5]), "+v"(ring[6]), "+v"(ring[7])
+               :
+               : "memory");
 #undef C2_LOAD
 
   // ---- epilogue: lane (c, g) holds rows m0 + 16 s + c, channels 64 wave + 16 jt + 4 g + r -----------------------------------------

@@ -422,6 +422,14 @@ def test_ffn_packed_pair(t, m, hidden):
         return float(d_.max()) <= 2 ** -7 * float(want.float().abs().max()) and float((d_ > 0).float().mean()) < 0.1
 
     assert close(qkv, want_qkv)
+    # other tail widths: 2, 4 and 8 column blocks per wave (the tail's loop body runs 0, 1 and 3 times around its two peeled blocks)
+    for nq_cols in (256, 512, 1024):
+        wq2 = _rand(t, nq_cols, d, seed=140 + nq_cols, scale=1.0 / 16).bfloat16().cuda()
+        bq2 = _rand(t, nq_cols, seed=141 + nq_cols, scale=0.3).cuda()
+        x_q2 = x.clone()
+        got2 = ops.ffn_packed_pair(pa, ba1, ba2, pb, bb1, bb2, x_q2, lns[0], lns[1], lns[2], lns[3], qkv=(ops.ffn_qkv_pack(wq2), bq2))
+        assert got2.shape == (m, nq_cols) and t.equal(x_q2, x_one) and close(got2, ops.gemm(out_one, wq2, bias=bq2))
+    assert ops.ffn_qkv_pack(_rand(t, 384, d, seed=150).bfloat16().cuda()) is None  # whole pairs of column blocks only
     # single FFN + LayerNorm + linear_q/k/v
     a_in = _rand(t, m, d, seed=133).bfloat16().cuda()
     x_s1, x_s2 = x.clone(), x.clone()

@@ -12,7 +12,11 @@
 //     24-slot register ring, THREE K-chunks (96 MFMAs) ahead of its use - one wave per SIMD, nothing else hides the L2 latency;
 //   * the activation tile (64 rows x 64 k = 8 KiB per K-chunk) goes HBM/L2 -> LDS with global_load_lds_dwordx4 into a 3-stage
 //     ring two chunks ahead; one counted s_waitcnt vmcnt + one raw barrier per chunk.
-// The launch is bound by the L2 -> CU path: every CU pulls the whole 2.5 MB weight.
+// With hot caches the launch is bound by the L2 -> CU path (every CU pulls the whole 2.5 MB weight): 41 us.  Inside the encoder
+// the 155 MB activation comes from HBM and the launch takes 65 us.  Measured and dropped: an 8-stage activation ring six chunks
+// ahead (no change: vmcnt retires loads in issue order, so a weight fragment's wait three chunks later also waits for every
+// activation load issued before it - the slow stream's lookahead cannot exceed the fast stream's ring), and workgroups starting
+// at different chunks (58 / 67 us: in lock step a chunk's 32 KiB of weights is fetched once per XCD and shared).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

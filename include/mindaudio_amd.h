@@ -227,6 +227,13 @@ int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, i
                              const float* bias_u, const float* bias_v, const float* mask, int64_t batch,
                              int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
                              void* vt_workspace, int64_t vt_workspace_bytes, ma_stream_t stream);
+/* The same with a per-(query, key) mask (batch, T, T) float32 (0 = masked, the additive -10000 of the padding mask): the
+ * chunk masks of the streaming encoder configuration (mindaudio/utils/mask.py:201-271 add_optional_chunk_mask, applied at
+ * layers/attention.py:102-108); the padding mask is expected to be folded in, as the reference does (masks & chunk_masks). */
+int ma_relpos_attention_qmask_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos,
+                             const float* bias_u, const float* bias_v, const float* mask_qk, int64_t batch,
+                             int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
+                             void* vt_workspace, int64_t vt_workspace_bytes, ma_stream_t stream);
 
 /* Middle of ConvolutionModule (layers/convolution.py:100-121): GLU(dim=channels) -> depthwise Conv1d(k, same
  * zero padding per utterance) -> BatchNorm1d in affine form -> Swish.

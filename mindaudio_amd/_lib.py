@@ -96,6 +96,9 @@ PROTOTYPES = {
     "ma_relpos_attention_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p,
                                                 ctypes.c_void_p, ctypes.c_void_p, i64, i64, i32, i32,
                                                 ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p]),
+    "ma_relpos_attention_qmask_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p,
+                                                      ctypes.c_void_p, ctypes.c_void_p, i64, i64, i32, i32,
+                                                      ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p]),
     "ma_convmodule_mid_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i64, i32, ctypes.c_void_p, i32,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),

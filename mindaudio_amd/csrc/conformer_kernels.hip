@@ -301,7 +301,7 @@ constexpr int kVsStride = 80;        // bf16 elements per V row (160 B = 40 dwor
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                                const uint16_t* __restrict__ pos, int64_t ld_pos,
-                                                               const uint16_t* __restrict__ vt, int Tp,
+                                                               const float* __restrict__ mask3, int Tp,
                                                                const float* __restrict__ bias_u,
                                                                const float* __restrict__ bias_v,
                                                                const float* __restrict__ mask, int T, int H,
@@ -316,7 +316,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
   const int64_t row0 = (int64_t)b * T;
   const int q_base = qt * (NW * 16) + wave * 16;
   const int lq = lane & 15, lg = lane >> 4;
-  (void)vt;
   (void)Tp;
   const float scale2 = scale * 1.4426950408889634f;
 
@@ -427,6 +426,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
       s[c][1] = s[c][1] * scale2 + ma_.y;
       s[c][2] = s[c][2] * scale2 + ma_.z;
       s[c][3] = s[c][3] * scale2 + ma_.w;
+      if (mask3) {  // per-(query, key) mask (B, T, T): the chunk masks of the streaming configuration (utils/mask.py:201-271); the
+                    // same additive -10000 as the padding mask
+        int qm = q_base + lq;
+        if (qm >= T) qm = T - 1;
+        const float* m3 = mask3 + ((int64_t)b * T + qm) * T + k0 + c * 16 + lg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (k0 + c * 16 + lg * 4 + r < T && m3[r] == 0.0f) s[c][r] += -10000.0f * 1.4426950408889634f;
+      }
       tmax = fmaxf(fmaxf(tmax, fmaxf(s[c][0], s[c][1])), fmaxf(s[c][2], s[c][3]));
     }
     // the row maximum over the 4 lane groups through gfx950's row swaps (two VALU instructions instead of two ds_bpermute round
@@ -745,7 +753,7 @@ int ma_subsample_conv1_strided_nhwc(const float* x, int64_t stride_b, int64_t st
 }
 
 static int relpos_attention_fwd(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
-                                const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads,
+                                const float* bias_v, const float* mask, const float* mask3, int64_t batch, int64_t T, int32_t heads,
                                 int32_t d_k, void* ctx, int64_t ld_ctx, void* vt_workspace, int64_t vt_bytes,
                                 float* lse, ma_stream_t stream) {
   if (!qkv || !pos || !bias_u || !bias_v || !ctx || !vt_workspace || batch < 1 || T < 1 || heads < 1)
@@ -760,13 +768,13 @@ static int relpos_attention_fwd(const void* qkv, int64_t ld_qkv, const void* pos
   if (((T - 1) % 128) >= 96) {
     const dim3 grid8((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batch);
     MA_LAUNCH(relpos_attention_kernel<8>, grid8, dim3(512), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
-              reinterpret_cast<const uint16_t*>(pos), ld_pos, reinterpret_cast<const uint16_t*>(vt_workspace), Tp, bias_u,
+              reinterpret_cast<const uint16_t*>(pos), ld_pos, mask3, Tp, bias_u,
               bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx, lse);
     return MA_OK;
   }
   const dim3 grid((unsigned)((T + kAttQ - 1) / kAttQ), (unsigned)heads, (unsigned)batch);
   MA_LAUNCH(relpos_attention_kernel<4>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
-            reinterpret_cast<const uint16_t*>(pos), ld_pos, reinterpret_cast<const uint16_t*>(vt_workspace), Tp, bias_u,
+            reinterpret_cast<const uint16_t*>(pos), ld_pos, mask3, Tp, bias_u,
             bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx, lse);
   return MA_OK;
 }
@@ -775,7 +783,16 @@ int ma_relpos_attention_bf16(const void* qkv, int64_t ld_qkv, const void* pos, i
                              const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads,
                              int32_t d_k, void* ctx, int64_t ld_ctx, void* vt_workspace, int64_t vt_bytes,
                              ma_stream_t stream) {
-  return relpos_attention_fwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, batch, T, heads, d_k, ctx, ld_ctx,
+  return relpos_attention_fwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, nullptr, batch, T, heads, d_k, ctx, ld_ctx,
+                              vt_workspace, vt_bytes, nullptr, stream);
+}
+
+int ma_relpos_attention_qmask_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                                   const float* bias_v, const float* mask_qk, int64_t batch, int64_t T, int32_t heads,
+                                   int32_t d_k, void* ctx, int64_t ld_ctx, void* vt_workspace, int64_t vt_bytes,
+                                   ma_stream_t stream) {
+  if (!mask_qk) return MA_ERR_INVALID_ARG;
+  return relpos_attention_fwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, nullptr, mask_qk, batch, T, heads, d_k, ctx, ld_ctx,
                               vt_workspace, vt_bytes, nullptr, stream);
 }
 
@@ -784,7 +801,7 @@ int ma_relpos_attention_train_bf16(const void* qkv, int64_t ld_qkv, const void* 
                                    int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
                                    void* vt_workspace, int64_t vt_bytes, float* lse, ma_stream_t stream) {
   if (!lse) return MA_ERR_INVALID_ARG;
-  return relpos_attention_fwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, batch, T, heads, d_k, ctx, ld_ctx,
+  return relpos_attention_fwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, nullptr, batch, T, heads, d_k, ctx, ld_ctx,
                               vt_workspace, vt_bytes, lse, stream);
 }
 

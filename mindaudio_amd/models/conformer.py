@@ -321,7 +321,9 @@ class ConformerEncoder(nn.Module):
             raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(masks.shape)))
         mask2d = masks.reshape(b, t2).to(f32).contiguous()
         mask_rows = mask2d.reshape(m)
-        att_mask = mask2d if xs_chunk_masks is None else xs_chunk_masks.reshape(b, t2).to(f32).contiguous()
+        att_mask = self._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
+        if att_mask.dim() == 3:
+            raise NotImplementedError("(B, T', T') chunk masks are supported by the evaluation forward only")
         e = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(d), out_dtype=f32)
         x = K.dropout_add(torch.zeros_like(e), e, 1.0, pp, seed, salt(-1, 0)) if pp > 0 else e
         pe = self.pe[:t2].to(f32).contiguous()
@@ -365,6 +367,19 @@ class ConformerEncoder(nn.Module):
             W["bn_shift"].copy_((bn.bias.detach() + (cm.depthwise_conv.bias.detach() - bn.running_mean) * scale).float())
         self._bn_dirty = False
 
+    @staticmethod
+    def _attention_mask(mask2d, xs_chunk_masks, b, t2, f32):
+        """The mask the attention sees (models/conformer.py:251-252: `mask=xs_chunk_masks`): the (B, T') padding mask, or the
+        (B, T', T') chunk mask of the streaming configuration (utils/mask.py:201-271; the padding mask is already folded in)."""
+        if xs_chunk_masks is None:
+            return mask2d
+        cm = xs_chunk_masks
+        if cm.dim() == 3 and cm.shape[1] == t2 and t2 > 1:
+            if tuple(cm.shape) != (b, t2, t2):
+                raise ValueError("xs_chunk_masks must be (B, 1, %d) or (B, %d, %d), got %s" % (t2, t2, t2, tuple(cm.shape)))
+            return cm.to(f32).contiguous()
+        return cm.reshape(b, t2).to(f32).contiguous()
+
     @torch.no_grad()
     def forward(self, xs, masks, xs_chunk_masks=None):
         """xs (B, T, idim) float32 on the HIP device; masks (B, 1, T') — the subsampled pad mask the collate
@@ -388,7 +403,7 @@ class ConformerEncoder(nn.Module):
             raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(masks.shape)))
         mask2d = masks.reshape(b, t2).to(f32).contiguous()
         mask_rows = mask2d.reshape(m)
-        att_mask = mask2d if xs_chunk_masks is None else xs_chunk_masks.reshape(b, t2).to(f32).contiguous()
+        att_mask = self._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
         # Dense(4864 -> 256) then x * sqrt(d) (subsampling.py:76, embedding.py:84)
         if P.get("out_pk") is not None:
             x = ops.gemm_rows_packed(act2.view(m, f2 * c), P["out_pk"], P["out_b"], alpha=math.sqrt(self.d))

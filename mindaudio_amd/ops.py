@@ -328,7 +328,8 @@ def subsample_conv1(x, w, bias, cmvn_mean=None, cmvn_istd=None, out=None):
 
 
 def relpos_attention(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64, out=None):
-    """qkv (B*T, 768) bf16; pos (T, 256) bf16; bias_u/v (heads, d_k) f32; mask (B, T) f32 or None -> ctx (B*T, 256)."""
+    """qkv (B*T, 768) bf16; pos (T, 256) bf16; bias_u/v (heads, d_k) f32; mask (B, T) f32, (B, T, T) f32 (a per-query mask: the
+    streaming configuration's chunk masks, padding folded in) or None -> ctx (B*T, 256)."""
     t = _host.torch()
     lib = _lib.load()
     assert qkv.dtype == t.bfloat16 and pos.dtype == t.bfloat16 and qkv.stride(1) == 1 and pos.stride(1) == 1
@@ -336,6 +337,13 @@ def relpos_attention(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64, 
         out = t.empty((batch * T, heads * d_k), dtype=t.bfloat16, device=qkv.device)
     ws_bytes = lib.ma_relpos_attention_workspace_bytes(batch, T, heads, d_k)
     ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
+    if mask is not None and mask.dim() == 3:
+        assert tuple(mask.shape) == (batch, T, T) and mask.dtype == t.float32 and mask.is_contiguous()
+        rc = lib.ma_relpos_attention_qmask_bf16(_host.ptr(qkv), qkv.stride(0), _host.ptr(pos), pos.stride(0), _host.ptr(bias_u),
+                                                _host.ptr(bias_v), _host.ptr(mask), batch, T, heads, d_k, _host.ptr(out),
+                                                out.stride(0), _host.ptr(ws), ws_bytes, _host.current_stream_ptr())
+        _lib.check(rc, "relpos_attention_qmask")
+        return out
     rc = lib.ma_relpos_attention_bf16(_host.ptr(qkv), qkv.stride(0), _host.ptr(pos), pos.stride(0), _host.ptr(bias_u),
                                       _host.ptr(bias_v), _opt(mask), batch, T, heads, d_k, _host.ptr(out),
                                       out.stride(0), _host.ptr(ws), ws_bytes, _host.current_stream_ptr())

@@ -76,6 +76,38 @@ def test_encoder_matches_oracle(blocks, b, tlen, cmvn, general):
     assert float(err.abs().max()) <= 0.15, float(err.abs().max())
 
 
+def test_encoder_with_chunk_masks_matches_oracle():
+    """The streaming configuration's attention masks (utils/mask.py:201-271 add_optional_chunk_mask: (B, T', T') static chunks with
+    limited left context, padding folded in) through the evaluation forward; the conv module keeps the padding mask."""
+    import torch
+
+    from oracle import conformer_oracle as C
+
+    ref, dut = _pair(3, seed=11)
+    b, tlen = 3, 400
+    xs = torch.randn(b, tlen, 80, generator=torch.Generator().manual_seed(6))
+    mask = torch.zeros(b, 1, tlen)
+    for i, n in enumerate((400, 333, 250)):
+        mask[i, 0, :n] = 1
+    sub = C.subsample_mask(mask)                                  # (B, 1, T')
+    t2 = sub.shape[-1]
+    idx = torch.arange(t2)
+    chunk = ((idx[None, :] // 8) <= (idx[:, None] // 8)) & ((idx[None, :] // 8) >= (idx[:, None] // 8) - 2)  # chunk 8, 2 left chunks
+    chunk_masks = (chunk[None] & (sub > 0)).float()              # (B, T', T'): masks & chunk_masks (mask.py:262-267)
+    with torch.no_grad():
+        want, _ = ref(xs, sub, chunk_masks)
+        want_full, _ = ref(xs, sub)
+    got, _ = dut(xs.cuda(), sub.cuda(), chunk_masks.cuda())
+    err = got.cpu() - want
+    rel_rms = float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    assert rel_rms <= 2e-2, rel_rms
+    assert float((want - want_full).abs().max()) > 0.1  # (the chunk mask does change the result)
+    dut.train()
+    with pytest.raises(NotImplementedError):
+        dut(xs.cuda(), sub.cuda(), chunk_masks.cuda())
+    dut.eval()
+
+
 def test_encoder_full_config_shapes_and_determinism():
     import torch
 

@@ -356,6 +356,15 @@ def test_relpos_attention(t, b, tt):
     got_nomask = ops.relpos_attention(qkv.cuda(), pos.cuda(), u.cuda(), v.cuda(), None, b, tt).double().cpu()
     ref_nomask = (t.softmax((qu @ k.transpose(-1, -2) + qv @ p.transpose(-1, -2)) / 8.0, -1) @ vv).transpose(1, 2).reshape(b * tt, 256)
     assert float((got_nomask - ref_nomask).abs().max()) <= 1.5e-2 * float(ref_nomask.abs().max())
+    # per-(query, key) masks (B, T, T): static chunks of 16 frames with one chunk of left context, padding folded in
+    # (utils/mask.py:169-199 subsequent_chunk_mask & the pad mask, mask.py:262-267)
+    idx = t.arange(tt)
+    chunk = ((idx[None, :] // 16) <= (idx[:, None] // 16)) & ((idx[None, :] // 16) >= (idx[:, None] // 16) - 1)
+    m3 = (chunk[None] & (mask[:, None, :] > 0)).float()
+    scores3 = (qu @ k.transpose(-1, -2) + qv @ p.transpose(-1, -2)) / 8.0 + (m3[:, None] == 0).double() * (-10000.0)
+    ref3 = (t.softmax(scores3, -1) @ vv).transpose(1, 2).reshape(b * tt, 256)
+    got3 = ops.relpos_attention(qkv.cuda(), pos.cuda(), u.cuda(), v.cuda(), m3.cuda(), b, tt).double().cpu()
+    assert float((got3 - ref3).abs().max()) <= 1.5e-2 * float(ref3.abs().max())
 
 
 def test_convmodule_mid(t):

@@ -19,6 +19,13 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 ms = timeit(run)
 print("eager:  %.3f ms / batch of %d -> %.0f utt/s, %.1f TFLOP/s" % (ms, B, B / ms * 1e3, 23.12e9 * B / ms / 1e9))
+if "--train" in sys.argv:  # cfg 3 in train mode: BatchNorm batch statistics + running-stat update, dropout 0.1 (forward only)
+    enc.train()
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    ms = timeit(run)
+    print("train-mode forward:  %.3f ms / batch of %d -> %.0f utt/s" % (ms, B, B / ms * 1e3))
+    enc.eval()
 if "--graph" in sys.argv:
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()

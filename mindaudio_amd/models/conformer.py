@@ -216,24 +216,40 @@ class ConformerEncoder(nn.Module):
             act1 = ops.subsample_conv1(xs, P["conv1_w"], P["conv1_b"], self.cmvn_mean, self.cmvn_istd)
             return ops.conv2d_3x3s2_nhwc(act1, P["conv2_w"], P["conv2_b"], relu=True)
         # conv1's output (B x 10 MB at T = 1000) is written once and read once: run conv1 -> conv2 over groups of
-        # utterances through ONE reused buffer so the intermediate lives in the 256 MB Infinity Cache instead of HBM.
-        # Group = what fits ~220 MB (22 utterances at the north-star shape, 3 groups).  Measured inside the bench step:
-        # 2.465 ms with groups of 20-22, 2.496 ms ungrouped, 2.51 ms with groups of 13 (= one resident round of
-        # conv2_packed, the best size when the two kernels are timed alone).  `self.subsample_group` overrides it.
+        # utterances through ONE reused buffer so the intermediate lives in the 256 MB Infinity Cache instead of HBM
+        # (inside the bench step: 2.465 ms grouped vs 2.496 ms ungrouped).  Group size: at most what fits ~220 MB, and at most
+        # 1.5 resident rounds of conv2_packed (2 workgroups of 128 rows per CU): up to there the workgroups behind the first
+        # round run one per CU, at the solo rate (tools/conv2_rounds.py: 20 utterances = 740 workgroups 101 us, 22 = 814
+        # workgroups 123 us).  A short remainder joins the first group if that still fits the cache (64 -> 24 + 20 + 20:
+        # 2.188 vs 2.217 ms for 22 + 22 + 20, tools/group_scan.py).  `self.subsample_group` (an int or a list) overrides it.
         t1, f1 = (t - 3) // 2 + 1, (idim - 3) // 2 + 1
         t2, f2 = (t1 - 3) // 2 + 1, (f1 - 3) // 2 + 1
         c = P["conv2_b"].numel()
-        group = b
-        if b * t1 * f1 * c * 2 > 240e6:
-            group = max(1, min(b, int(220e6 // (t1 * f1 * c * 2))))
-            group = -(-b // -(-b // group))
-        group = self.subsample_group or group
+        per_utt = t1 * f1 * c * 2
+        group = self.subsample_group
+        if group is None:
+            sizes = [b]
+            if b * per_utt > 240e6:
+                cus = torch.cuda.get_device_properties(xs.device).multi_processor_count
+                cap = max(1, min(b, int(220e6 // per_utt), int(3 * cus * 128 // (t2 * f2))))
+                sizes = [cap] * (b // cap)
+                rem = b - cap * (b // cap)
+                if rem and sizes and rem < cap // 2 and (cap + rem) * per_utt <= 245e6:
+                    sizes[0] += rem
+                elif rem:
+                    sizes.append(rem)
+        elif isinstance(group, (list, tuple)):  # explicit group sizes (tools/group_scan.py)
+            sizes = [int(g) for g in group]
+            assert sum(sizes) == b and min(sizes) > 0
+        else:
+            sizes = [min(group, b - i) for i in range(0, b, group)]
         act2 = torch.empty((b, t2, f2, c), dtype=torch.bfloat16, device=xs.device)
-        act1 = torch.empty((min(group, b), t1, f1, c), dtype=torch.bfloat16, device=xs.device)
-        for i in range(0, b, group):
-            n = min(group, b - i)
+        act1 = torch.empty((max(sizes), t1, f1, c), dtype=torch.bfloat16, device=xs.device)
+        i = 0
+        for n in sizes:
             ops.subsample_conv1(xs[i:i + n], P["conv1_w"], P["conv1_b"], self.cmvn_mean, self.cmvn_istd, out=act1[:n])
             ops.conv2d_3x3s2_packed(act1[:n], P["conv2_pk"], P["conv2_b"], relu=True, out=act2[i:i + n])
+            i += n
         return act2
 
     # ---- the 12 blocks, fused form: 3 launches per block ------------------------------------------------------

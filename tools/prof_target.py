@@ -12,6 +12,11 @@ B, N = 64, 160000
 x = torch.from_numpy((0.1 * np.random.RandomState(1234).randn(B, N)).astype(np.float32)).cuda()
 if what == "fbank":
     for _ in range(n): ma.fbank(x, n_mels=80, n_fft=512, hop_length=160)
+elif what == "gemm8k":  # the 256 x 256 8-phase GEMM kernel on a large cube
+    m = k2 = 8192
+    a = torch.randn(m, k2, device="cuda").bfloat16(); w = (torch.randn(m, k2, device="cuda") / 90).bfloat16()
+    bias = torch.randn(m, device="cuda"); out = torch.empty(m, m, device="cuda", dtype=torch.bfloat16)
+    for _ in range(n): ops.gemm(a, w, bias=bias, act=_lib.ACT_RELU, out=out)
 elif what == "gemm":
     m, nn, k = B * 249, 2048, 256
     a = torch.randn(m, k, device="cuda").bfloat16(); w = (torch.randn(nn, k, device="cuda") / 16).bfloat16(); bias = torch.randn(nn, device="cuda")

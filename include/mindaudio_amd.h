@@ -134,6 +134,7 @@ int ma_melspectrogram_f32(const float* wav, int64_t batch, int64_t n, int64_t wa
  *   window   device (frame_len,) float32 = hanning(frame_len)^0.85 (dataset.py:126)
  *   out      device (batch, max_frames, n_mels) float32, rows t >= frames(b) are zero
  *            (pad_sequence padding value, dataset.py:563-569); max_frames = (max_n - frame_len)/shift + 1
+ *   frames_out  device (batch,) int64, frames of each utterance (what the loader keeps as xs_lengths), or NULL
  * Per utterance: pre-emphasis over the whole signal, framing without centring, window,
  * subtraction of ONE scalar mean over all windowed frames (dataset.py:165), zero-pad to n_fft,
  * |rFFT|^2, mel bank, zeros -> eps, natural log.
@@ -141,7 +142,8 @@ int ma_melspectrogram_f32(const float* wav, int64_t batch, int64_t n, int64_t wa
 int ma_fbank_kaldi_f32(const float* wav, const int64_t* lengths, int64_t batch, int64_t max_n,
                        int64_t wav_stride, int32_t frame_len, int32_t frame_shift, int32_t n_fft,
                        const float* window, const ma_melbank_t* mel, float preemph,
-                       float* out, void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+                       float* out, int64_t* frames_out, void* workspace, int64_t workspace_bytes,
+                       ma_stream_t stream);
 
 /* Bytes of device workspace ma_amplitude_to_db_f32 needs. */
 int64_t ma_db_workspace_bytes(int64_t groups, int64_t elems_per_group);

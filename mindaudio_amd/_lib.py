@@ -77,7 +77,7 @@ PROTOTYPES = {
     "ma_melspectrogram_f32": (ctypes.c_int, [c_f32p, i64, i64, i64, i32, i32, c_f32p, i32, i32,
                                              ctypes.POINTER(MelBank), f32, c_f32p, ctypes.c_void_p]),
     "ma_fbank_kaldi_f32": (ctypes.c_int, [c_f32p, ctypes.c_void_p, i64, i64, i64, i32, i32, i32, c_f32p,
-                                          ctypes.POINTER(MelBank), f32, c_f32p, ctypes.c_void_p, i64,
+                                          ctypes.POINTER(MelBank), f32, c_f32p, ctypes.c_void_p, ctypes.c_void_p, i64,
                                           ctypes.c_void_p]),
     "ma_gemm_bf16": (ctypes.c_int, [ctypes.c_void_p, i64, ctypes.c_void_p, i64, ctypes.c_void_p, i64, i64, i64, i64,
                                     ctypes.POINTER(GemmEpilogue), ctypes.c_void_p]),

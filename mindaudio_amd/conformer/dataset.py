@@ -25,11 +25,11 @@ def compute_fbank_feats_batch(wavs, lengths, sample_rate=16000, frame_len=25, fr
     out = t.empty((x.shape[0], max_frames, mel_bin), dtype=t.float32, device=x.device)
     ws_bytes = lib.ma_fbank_workspace_bytes(x.shape[0], max_frames)
     ws = _host.workspace(ws_bytes, x.device)
+    frames = t.empty((x.shape[0],), dtype=t.int64, device=x.device)
     rc = lib.ma_fbank_kaldi_f32(_host.ptr(x), _host.ptr(lens), x.shape[0], x.shape[-1], x.stride(0), flen, fshift,
-                                512, _host.ptr(win), bank.ref(), 0.97, _host.ptr(out), _host.ptr(ws), ws.numel(),
-                                _host.current_stream_ptr())
+                                512, _host.ptr(win), bank.ref(), 0.97, _host.ptr(out), _host.ptr(frames),
+                                _host.ptr(ws), ws.numel(), _host.current_stream_ptr())
     _lib.check(rc, "compute_fbank_feats")
-    frames = t.clamp((lens - flen) // fshift + 1, min=0)
     return out, frames
 
 

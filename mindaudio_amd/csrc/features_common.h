@@ -25,6 +25,7 @@ struct FeatParams {
   float* unit_min;  // [num_units] minimum dB of each 8-frame unit (mel with dB)
   float* wg_max;    // [gridDim.x] maximum dB seen by each workgroup
   double* partial;  // kaldi: [batch * sum_tiles_per_utt] windowed sums
+  int64_t* frames_out;  // kaldi: [batch] frames per utterance (may be null)
   unsigned long long* prof;  // MA_PROFILE builds only: per-phase cycle totals
   const int* mel_steps;    // [n_rows]
   const int* mel_row_off;  // [n_rows]

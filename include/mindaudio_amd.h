@@ -510,6 +510,19 @@ int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* po
                                  float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
                                  ma_stream_t stream);
 
+/* The same two with a per-(query, key) mask (batch, T, T) float32 instead of the (batch, T) padding mask: the chunk masks
+ * of the streaming configuration (utils/mask.py:201-271; models/conformer.py:251-252 hands them to every block). */
+int ma_relpos_attention_train_qmask_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos,
+                                         const float* bias_u, const float* bias_v, const float* mask_qk, int64_t batch,
+                                         int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
+                                         void* vt_workspace, int64_t vt_bytes, float* lse, ma_stream_t stream);
+int ma_relpos_attention_bwd_qmask_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                                       const float* bias_v, const float* mask_qk, const void* ctx, int64_t ld_ctx,
+                                       const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
+                                       int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
+                                       float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
+                                       ma_stream_t stream);
+
 /* ---- attention-decoder branch of the hybrid loss (models/conformer.py:382-639, asr_model.py:154-186) -----------
  * Token-sized pieces; the decoder's matmuls, LayerNorms (eps 1e-12) and dropouts reuse the entry points above. */
 
@@ -709,6 +722,16 @@ int ma_relpos_attention_bwd_x32(const float* qkv, int64_t ld_qkv, const float* p
                                 int64_t ld_dctx, const float* lse, int64_t batch, int64_t T, int32_t heads, int32_t d_k,
                                 float* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos, float* dbias_u, float* dbias_v,
                                 void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+/* ... with the (batch, T, T) per-(query, key) chunk mask instead of the (batch, T) padding mask */
+int ma_relpos_attention_fwd_qmask_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                      const float* bias_v, const float* mask_qk, int64_t batch, int64_t T, int32_t heads,
+                                      int32_t d_k, float* ctx, int64_t ld_ctx, float* lse, ma_stream_t stream);
+int ma_relpos_attention_bwd_qmask_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                      const float* bias_v, const float* mask_qk, const float* ctx, int64_t ld_ctx,
+                                      const float* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
+                                      int32_t heads, int32_t d_k, float* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
+                                      float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
+                                      ma_stream_t stream);
 /* Conv2dSubsampling4 (layers/subsampling.py:21-78): conv1 with any input strides -> NHWC float32; explicit im2col of the 3x3
  * stride-2 valid window, col (B*Ho*Wo, 9*C) with k = (kh, kw, c) (conv2 = ma_gemm_x32 on it); backward pieces. */
 int ma_subsample_conv1_nhwc_x32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_f, int64_t batch, int64_t T,

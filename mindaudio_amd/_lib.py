@@ -155,6 +155,10 @@ PROTOTYPES = {
     "ma_relpos_attention_bwd_workspace_bytes": (i64, [i64, i64, i32, i32]),
     "ma_relpos_attention_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32,
                                                     i32, vp, i64, vp, i64, vp, vp, vp, i64, vp]),
+    "ma_relpos_attention_train_qmask_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, vp, i64, vp,
+                                                            i64, vp, vp]),
+    "ma_relpos_attention_bwd_qmask_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32,
+                                                          i32, vp, i64, vp, i64, vp, vp, vp, i64, vp]),
     "ma_embed_posenc_f32": (ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, f32, f32, u32, u32, vp, vp]),
     "ma_embed_bwd_f32": (ctypes.c_int, [vp, vp, i64, i32, i32, f32, f32, u32, u32, vp, vp]),
     "ma_mha_small_fwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i64, i32, i32, i32, i32, f32, vp, i64, vp,
@@ -208,6 +212,9 @@ PROTOTYPES = {
     "ma_relpos_attention_bwd_x32_workspace_bytes": (i64, [i64, i64, i32]),
     "ma_relpos_attention_bwd_x32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32, i32,
                                                    vp, i64, vp, i64, vp, vp, vp, i64, vp]),
+    "ma_relpos_attention_fwd_qmask_x32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, vp, i64, vp, vp]),
+    "ma_relpos_attention_bwd_qmask_x32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32, i32,
+                                                         vp, i64, vp, i64, vp, vp, vp, i64, vp]),
     "ma_subsample_conv1_nhwc_x32": (ctypes.c_int, [vp, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, i32, vp, vp]),
     "ma_im2col_3x3s2_nhwc_x32": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, vp]),
     "ma_col2im_3x3s2_relu_x32": (ctypes.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),

@@ -129,8 +129,8 @@ constexpr int kTs = 64 + 4;   // transposed tiles: 64 streamed items per row (13
 template <bool KEYS_FIXED>
 __global__ __launch_bounds__(256, KEYS_FIXED ? 2 : 3) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                        const uint16_t* __restrict__ dctx, int64_t ld_dctx,
-                                                       const float* __restrict__ mask, const float* __restrict__ lse,
-                                                       AttnWs ws, int T, int H, float scale,
+                                                       const float* __restrict__ mask, const float* __restrict__ mask3,
+                                                       const float* __restrict__ lse, AttnWs ws, int T, int H, float scale,
                                                        uint16_t* __restrict__ dqkv, int64_t ld_dqkv, float* dpos,
                                                        int64_t ld_dpos, float* du, float* dv) {
   __shared__ __attribute__((aligned(16))) uint16_t Xs[64 * kXs];       // streamed X' rows
@@ -276,7 +276,12 @@ __global__ __launch_bounds__(256, KEYS_FIXED ? 2 : 3) void attn_bwd_kernel(const
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         // KEYS_FIXED: row = query (lse, D from srow), column = key (mask per lane); else row = key (mask from srow)
-        const float e = KEYS_FIXED ? s[r] * scale + f_mask - r0v[r] : s[r] * scale + r0v[r] - f_lse;
+        float e = KEYS_FIXED ? s[r] * scale + f_mask - r0v[r] : s[r] * scale + r0v[r] - f_lse;
+        if (mask3) {  // per-(query, key) chunk mask (B, T, T) of the streaming configuration, as in the forward
+          const int srow_i = st * 64 + mt * 16 + lg * 4 + r;  // streamed item of this element
+          const int qi = KEYS_FIXED ? srow_i : fidx, ki = KEYS_FIXED ? fidx : srow_i;
+          if (qi < T && ki < T && mask3[((int64_t)b * T + qi) * T + ki] == 0.0f) e += -10000.0f;
+        }
         p[r] = __expf(e);
         g[r] = p[r] * (dp[r] - (KEYS_FIXED ? r1v[r] : f_D)) * scale;
       }
@@ -408,8 +413,8 @@ int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_
   return batch * heads * Tp * (128 * 4 + 64) * 2 + batch * heads * Tp * 4 + batch * heads * (Tp / 64) * 128 * 4 + batch * Tp * 256 * 4 + 256;
 }
 
-int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
-                                 const float* bias_v, const float* mask, const void* ctx, int64_t ld_ctx,
+static int relpos_attention_bwd(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                                 const float* bias_v, const float* mask, const float* mask3, const void* ctx, int64_t ld_ctx,
                                  const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
                                  int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
                                  float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
@@ -433,14 +438,35 @@ int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* po
   MA_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
             bias_u, bias_v, (const uint16_t*)ctx, ld_ctx, (const uint16_t*)dctx, ld_dctx, (int)T, (int)heads, ws);
   MA_LAUNCH(attn_bwd_kernel<true>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
-            mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+            mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   MA_LAUNCH(attn_bwd_kernel<false>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
-            mask, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+            mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   MA_LAUNCH(attn_dpos_reduce_kernel, dim3((unsigned)T), dim3(256), 0, s, ws.dp_part, (int)batch, (int)T, ws.Tp, dpos,
             ld_dpos);
   MA_LAUNCH(attn_bias_reduce_kernel, dim3((unsigned)heads), dim3(1024), 0, s, ws.bias_part, (int)batch, (int)heads,
             ws.Tp / 64, dbias_u, dbias_v);
   return MA_OK;
+}
+
+int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                                 const float* bias_v, const float* mask, const void* ctx, int64_t ld_ctx,
+                                 const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
+                                 int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
+                                 float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
+                                 ma_stream_t stream) {
+  return relpos_attention_bwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, nullptr, ctx, ld_ctx, dctx, ld_dctx, lse, batch, T,
+                              heads, d_k, dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v, workspace, workspace_bytes, stream);
+}
+
+int ma_relpos_attention_bwd_qmask_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
+                                       const float* bias_v, const float* mask_qk, const void* ctx, int64_t ld_ctx,
+                                       const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
+                                       int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
+                                       float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
+                                       ma_stream_t stream) {
+  if (!mask_qk) return MA_ERR_INVALID_ARG;
+  return relpos_attention_bwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, nullptr, mask_qk, ctx, ld_ctx, dctx, ld_dctx, lse, batch,
+                              T, heads, d_k, dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

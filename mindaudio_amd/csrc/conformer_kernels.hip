@@ -805,6 +805,15 @@ int ma_relpos_attention_train_bf16(const void* qkv, int64_t ld_qkv, const void* 
                               vt_workspace, vt_bytes, lse, stream);
 }
 
+int ma_relpos_attention_train_qmask_bf16(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos,
+                                         const float* bias_u, const float* bias_v, const float* mask_qk, int64_t batch,
+                                         int64_t T, int32_t heads, int32_t d_k, void* ctx, int64_t ld_ctx,
+                                         void* vt_workspace, int64_t vt_bytes, float* lse, ma_stream_t stream) {
+  if (!lse || !mask_qk) return MA_ERR_INVALID_ARG;
+  return relpos_attention_fwd(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, nullptr, mask_qk, batch, T, heads, d_k, ctx, ld_ctx,
+                              vt_workspace, vt_bytes, lse, stream);
+}
+
 int64_t ma_relpos_attention_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k) {
   if (batch < 1 || T < 1 || heads < 1 || d_k < 1) return MA_ERR_INVALID_ARG;
   return batch * heads * d_k * ((T + 63) / 64 * 64) * 2;

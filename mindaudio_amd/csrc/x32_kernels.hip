@@ -131,8 +131,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // scores of query row i against every key into sc[0..T) (LDS); returns nothing.  qu / qv: LDS [64]
 __device__ __forceinline__ void score_row(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ pos, int64_t ldp,
-                                          const float* __restrict__ mask, int64_t b, int T, int h, int D, const float* qu,
-                                          const float* qv, float scale, float* sc) {
+                                          const float* __restrict__ mask, int mask_qk, int i, int64_t b, int T, int h, int D,
+                                          const float* qu, const float* qv, float scale, float* sc) {
+  // mask_qk = 0: (B, T) padding mask; 1: (B, T, T) per-(query, key) chunk mask (utils/mask.py:201-271)
+  const float* mrow = mask ? (mask_qk ? mask + (b * T + i) * T : mask + b * T) : nullptr;
   const int lane = threadIdx.x;
   for (int j = lane; j < T; j += 64) {
     const float* kr = qkv + (b * T + j) * ld + D + h * 64;
@@ -141,14 +143,14 @@ __device__ __forceinline__ void score_row(const float* __restrict__ qkv, int64_t
 #pragma unroll 8
     for (int d = 0; d < 64; ++d) s = fmaf(qu[d], kr[d], fmaf(qv[d], pr[d], s));
     s *= scale;
-    if (mask && mask[b * T + j] == 0.0f) s += -10000.0f;
+    if (mrow && mrow[j] == 0.0f) s += -10000.0f;
     sc[j] = s;
   }
 }
 
 __global__ __launch_bounds__(64) void attn_fwd_x32_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ pos,
                                                           int64_t ldp, const float* __restrict__ bu, const float* __restrict__ bv,
-                                                          const float* __restrict__ mask, int T, int D, float scale,
+                                                          const float* __restrict__ mask, int mask_qk, int T, int D, float scale,
                                                           float* __restrict__ ctx, int64_t ldc, float* __restrict__ lse) {
   extern __shared__ float sm[];
   float* qu = sm;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64) void attn_fwd_x32_kernel(const float* __restric
   qu[lane] = q + bu[h * 64 + lane];
   qv[lane] = q + bv[h * 64 + lane];
   __syncthreads();
-  score_row(qkv, ld, pos, ldp, mask, b, T, h, D, qu, qv, scale, sc);
+  score_row(qkv, ld, pos, ldp, mask, mask_qk, i, b, T, h, D, qu, qv, scale, sc);
   __syncthreads();
   float m = -INFINITY;
   for (int j = lane; j < T; j += 64) m = fmaxf(m, sc[j]);
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(64) void attn_fwd_x32_kernel(const float* __restric
 __global__ __launch_bounds__(64) void attn_bwd_row_x32_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ pos,
                                                               int64_t ldp, const float* __restrict__ bu,
                                                               const float* __restrict__ bv, const float* __restrict__ mask,
-                                                              int T, int D, float scale, const float* __restrict__ ctx,
+                                                              int mask_qk, int T, int D, float scale, const float* __restrict__ ctx,
                                                               int64_t ldc, const float* __restrict__ dctx, int64_t lddc,
                                                               const float* __restrict__ lse, float* __restrict__ P,
                                                               float* __restrict__ dS, float* __restrict__ dqkv, int64_t lddq) {
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64) void attn_bwd_row_x32_kernel(const float* __res
   dc[lane] = dci;
   const float Di = wave_sum(dci * ctx[(b * T + i) * ldc + h * 64 + lane]);
   __syncthreads();
-  score_row(qkv, ld, pos, ldp, mask, b, T, h, D, qu, qv, scale, sc);
+  score_row(qkv, ld, pos, ldp, mask, mask_qk, i, b, T, h, D, qu, qv, scale, sc);
   __syncthreads();
   const float z = lse[((int64_t)b * H + h) * T + i];
   float* Pr = P + (((int64_t)b * H + h) * T + i) * T;
@@ -335,16 +337,29 @@ int ma_colsum_x32(const float* A, int64_t lda, int64_t rows, int64_t cols, float
   return MA_OK;
 }
 
-int ma_relpos_attention_fwd_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
-                                const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads, int32_t d_k,
-                                float* ctx, int64_t ld_ctx, float* lse, ma_stream_t stream) {
+static int attention_fwd_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                             const float* bias_v, const float* mask, int mask_qk, int64_t batch, int64_t T, int32_t heads,
+                             int32_t d_k, float* ctx, int64_t ld_ctx, float* lse, ma_stream_t stream) {
   if (!qkv || !pos || !bias_u || !bias_v || !ctx || !lse || batch < 1 || T < 1 || heads < 1) return MA_ERR_INVALID_ARG;
   if (d_k != 64 || batch > 65535 || T > 8192) return MA_ERR_UNSUPPORTED;
   const int D = heads * d_k;
   MA_LAUNCH(attn_fwd_x32_kernel, dim3((unsigned)T, (unsigned)heads, (unsigned)batch), dim3(64), (size_t)(128 + T) * 4,
-            (hipStream_t)stream, qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, (int)T, D, 1.0f / sqrtf((float)d_k), ctx,
-            ld_ctx, lse);
+            (hipStream_t)stream, qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, mask_qk, (int)T, D, 1.0f / sqrtf((float)d_k),
+            ctx, ld_ctx, lse);
   return MA_OK;
+}
+
+int ma_relpos_attention_fwd_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                const float* bias_v, const float* mask, int64_t batch, int64_t T, int32_t heads, int32_t d_k,
+                                float* ctx, int64_t ld_ctx, float* lse, ma_stream_t stream) {
+  return attention_fwd_x32(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, 0, batch, T, heads, d_k, ctx, ld_ctx, lse, stream);
+}
+
+int ma_relpos_attention_fwd_qmask_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                      const float* bias_v, const float* mask_qk, int64_t batch, int64_t T, int32_t heads,
+                                      int32_t d_k, float* ctx, int64_t ld_ctx, float* lse, ma_stream_t stream) {
+  if (!mask_qk) return MA_ERR_INVALID_ARG;
+  return attention_fwd_x32(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask_qk, 1, batch, T, heads, d_k, ctx, ld_ctx, lse, stream);
 }
 
 int64_t ma_relpos_attention_bwd_x32_workspace_bytes(int64_t batch, int64_t T, int32_t heads) {
@@ -352,8 +367,8 @@ int64_t ma_relpos_attention_bwd_x32_workspace_bytes(int64_t batch, int64_t T, in
   return (2 * batch * heads * T * T + batch * heads * T) * 4;
 }
 
-int ma_relpos_attention_bwd_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
-                                const float* bias_v, const float* mask, const float* ctx, int64_t ld_ctx, const float* dctx,
+static int attention_bwd_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                const float* bias_v, const float* mask, int mask_qk, const float* ctx, int64_t ld_ctx, const float* dctx,
                                 int64_t ld_dctx, const float* lse, int64_t batch, int64_t T, int32_t heads, int32_t d_k,
                                 float* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos, float* dbias_u, float* dbias_v,
                                 void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
@@ -370,7 +385,7 @@ int ma_relpos_attention_bwd_x32(const float* qkv, int64_t ld_qkv, const float* p
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)T, (unsigned)heads, (unsigned)batch);
   MA_LAUNCH(attn_bwd_row_x32_kernel, grid, dim3(64), (size_t)(192 + T) * 4, s, qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask,
-            (int)T, D, scale, ctx, ld_ctx, dctx, ld_dctx, lse, P, dS, dqkv, ld_dqkv);
+            mask_qk, (int)T, D, scale, ctx, ld_ctx, dctx, ld_dctx, lse, P, dS, dqkv, ld_dqkv);
   MA_LAUNCH(attn_bwd_col_x32_kernel, grid, dim3(64), 0, s, qkv, ld_qkv, bias_u, (int)T, D, dctx, ld_dctx, P, dS, cs, dqkv,
             ld_dqkv);
   MA_LAUNCH(attn_bwd_pos_x32_kernel, dim3((unsigned)T, (unsigned)heads), dim3(64), 0, s, qkv, ld_qkv, bias_v, (int)batch, (int)T,
@@ -378,6 +393,26 @@ int ma_relpos_attention_bwd_x32(const float* qkv, int64_t ld_qkv, const float* p
   MA_LAUNCH(attn_bwd_bias_x32_kernel, dim3((unsigned)heads), dim3(64), 0, s, qkv, ld_qkv, pos, ld_pos, (int)batch, (int)T, D, cs,
             dbias_u, dbias_v);
   return MA_OK;
+}
+
+int ma_relpos_attention_bwd_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                const float* bias_v, const float* mask, const float* ctx, int64_t ld_ctx, const float* dctx,
+                                int64_t ld_dctx, const float* lse, int64_t batch, int64_t T, int32_t heads, int32_t d_k,
+                                float* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos, float* dbias_u, float* dbias_v,
+                                void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  return attention_bwd_x32(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask, 0, ctx, ld_ctx, dctx, ld_dctx, lse, batch, T, heads,
+                           d_k, dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v, workspace, workspace_bytes, stream);
+}
+
+int ma_relpos_attention_bwd_qmask_x32(const float* qkv, int64_t ld_qkv, const float* pos, int64_t ld_pos, const float* bias_u,
+                                      const float* bias_v, const float* mask_qk, const float* ctx, int64_t ld_ctx,
+                                      const float* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
+                                      int32_t heads, int32_t d_k, float* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
+                                      float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
+                                      ma_stream_t stream) {
+  if (!mask_qk) return MA_ERR_INVALID_ARG;
+  return attention_bwd_x32(qkv, ld_qkv, pos, ld_pos, bias_u, bias_v, mask_qk, 1, ctx, ld_ctx, dctx, ld_dctx, lse, batch, T, heads,
+                           d_k, dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v, workspace, workspace_bytes, stream);
 }
 
 int ma_im2col_3x3s2_nhwc_x32(const float* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, float* col, ma_stream_t stream) {

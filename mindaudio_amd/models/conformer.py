@@ -338,8 +338,6 @@ class ConformerEncoder(nn.Module):
         mask2d = masks.reshape(b, t2).to(f32).contiguous()
         mask_rows = mask2d.reshape(m)
         att_mask = self._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
-        if att_mask.dim() == 3:
-            raise NotImplementedError("(B, T', T') chunk masks are supported by the evaluation forward only")
         e = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(d), out_dtype=f32)
         x = K.dropout_add(torch.zeros_like(e), e, 1.0, pp, seed, salt(-1, 0)) if pp > 0 else e
         pe = self.pe[:t2].to(f32).contiguous()

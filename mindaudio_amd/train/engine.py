@@ -428,9 +428,8 @@ class ConformerCTCTrainStep:
             raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(xs_masks.shape)))
         mask2d = xs_masks.reshape(b, t2).to(f32).contiguous()
         mask_rows = mask2d.reshape(m)
-        if xs_chunk_masks is not None and xs_chunk_masks.numel() != b * t2:
-            raise NotImplementedError("(B, T', T') chunk masks are not on the built training path")
-        att_mask = mask2d if xs_chunk_masks is None else xs_chunk_masks.reshape(b, t2).to(f32).contiguous()
+        # (B, T') padding mask, or the (B, T', T') chunk masks of the streaming configuration (models/conformer.py:251-252)
+        att_mask = enc._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
         hlens = mask2d.sum(1).to(torch.int32)
         a2 = act2.view(m, f2 * c)
         e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)

@@ -262,9 +262,12 @@ def attention_fwd(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64):
     lse = t.empty((batch, heads, T), dtype=t.float32, device=qkv.device)
     ws_bytes = lib.ma_relpos_attention_workspace_bytes(batch, T, heads, d_k)
     ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
-    _lib.check(lib.ma_relpos_attention_train_bf16(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v),
-                                                  _p(mask), batch, T, heads, d_k, _p(ctx), ctx.stride(0), _p(ws),
-                                                  ws_bytes, _p(lse), _s()), "attention_fwd")
+    fn = lib.ma_relpos_attention_train_bf16
+    if mask is not None and mask.dim() == 3:  # (B, T, T) chunk masks
+        assert tuple(mask.shape) == (batch, T, T) and mask.dtype == t.float32 and mask.is_contiguous()
+        fn = lib.ma_relpos_attention_train_qmask_bf16
+    _lib.check(fn(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v), _p(mask), batch, T, heads, d_k,
+                  _p(ctx), ctx.stride(0), _p(ws), ws_bytes, _p(lse), _s()), "attention_fwd")
     return ctx, lse
 
 
@@ -275,10 +278,13 @@ def attention_bwd(qkv, pos, bias_u, bias_v, mask, ctx, dctx, lse, batch, T, dpos
     dqkv = t.empty((batch * T, 3 * heads * d_k), dtype=t.bfloat16, device=qkv.device)
     ws_bytes = lib.ma_relpos_attention_bwd_workspace_bytes(batch, T, heads, d_k)
     ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
-    _lib.check(lib.ma_relpos_attention_bwd_bf16(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v),
-                                                _p(mask), _p(ctx), ctx.stride(0), _p(dctx), dctx.stride(0), _p(lse),
-                                                batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos), dpos.stride(0), _p(dbias_u),
-                                                _p(dbias_v), _p(ws), ws_bytes, _s()), "attention_bwd")
+    fn = lib.ma_relpos_attention_bwd_bf16
+    if mask is not None and mask.dim() == 3:
+        assert tuple(mask.shape) == (batch, T, T) and mask.dtype == t.float32 and mask.is_contiguous()
+        fn = lib.ma_relpos_attention_bwd_qmask_bf16
+    _lib.check(fn(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v), _p(mask), _p(ctx), ctx.stride(0),
+                  _p(dctx), dctx.stride(0), _p(lse), batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos), dpos.stride(0),
+                  _p(dbias_u), _p(dbias_v), _p(ws), ws_bytes, _s()), "attention_bwd")
     return dqkv
 
 

@@ -217,9 +217,13 @@ def attention_fwd(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64):
     _f32(qkv, pos)
     ctx = t.empty((batch * T, heads * d_k), dtype=t.float32, device=qkv.device)
     lse = t.empty((batch, heads, T), dtype=t.float32, device=qkv.device)
-    _lib.check(_lib.load().ma_relpos_attention_fwd_x32(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v),
-                                                       _p(mask), batch, T, heads, d_k, _p(ctx), ctx.stride(0), _p(lse), _s()),
-               "attention_fwd_x32")
+    lib = _lib.load()
+    fn = lib.ma_relpos_attention_fwd_x32
+    if mask is not None and mask.dim() == 3:  # (B, T, T) chunk masks
+        assert tuple(mask.shape) == (batch, T, T) and mask.dtype == t.float32 and mask.is_contiguous()
+        fn = lib.ma_relpos_attention_fwd_qmask_x32
+    _lib.check(fn(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v), _p(mask), batch, T, heads, d_k,
+                  _p(ctx), ctx.stride(0), _p(lse), _s()), "attention_fwd_x32")
     return ctx, lse
 
 
@@ -230,10 +234,13 @@ def attention_bwd(qkv, pos, bias_u, bias_v, mask, ctx, dctx, lse, batch, T, dpos
     dqkv = t.empty((batch * T, 3 * heads * d_k), dtype=t.float32, device=qkv.device)
     ws_bytes = lib.ma_relpos_attention_bwd_x32_workspace_bytes(batch, T, heads)
     ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
-    _lib.check(lib.ma_relpos_attention_bwd_x32(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v), _p(mask),
-                                               _p(ctx), ctx.stride(0), _p(dctx), dctx.stride(0), _p(lse), batch, T, heads, d_k,
-                                               _p(dqkv), dqkv.stride(0), _p(dpos), dpos.stride(0), _p(dbias_u), _p(dbias_v),
-                                               _p(ws), ws_bytes, _s()), "attention_bwd_x32")
+    fn = lib.ma_relpos_attention_bwd_x32
+    if mask is not None and mask.dim() == 3:
+        assert tuple(mask.shape) == (batch, T, T) and mask.dtype == t.float32 and mask.is_contiguous()
+        fn = lib.ma_relpos_attention_bwd_qmask_x32
+    _lib.check(fn(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v), _p(mask), _p(ctx), ctx.stride(0),
+                  _p(dctx), dctx.stride(0), _p(lse), batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos), dpos.stride(0),
+                  _p(dbias_u), _p(dbias_v), _p(ws), ws_bytes, _s()), "attention_bwd_x32")
     return dqkv
 
 

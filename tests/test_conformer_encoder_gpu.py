@@ -102,10 +102,35 @@ def test_encoder_with_chunk_masks_matches_oracle():
     rel_rms = float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
     assert rel_rms <= 2e-2, rel_rms
     assert float((want - want_full).abs().max()) > 0.1  # (the chunk mask does change the result)
-    dut.train()
-    with pytest.raises(NotImplementedError):
-        dut(xs.cuda(), sub.cuda(), chunk_masks.cuda())
-    dut.eval()
+
+
+def test_encoder_train_mode_forward_with_chunk_masks_matches_oracle():
+    """... and through the training-mode forward (batch statistics; dropout off so that the oracle is comparable)."""
+    import torch
+
+    from mindaudio_amd.models import ConformerEncoder
+    from oracle import conformer_oracle as C
+
+    torch.manual_seed(10)
+    ref = C.ConformerEncoder(80, 256, 4, 2048, 2, dropout_rate=0.0, positional_dropout_rate=0.0).train()
+    dut = ConformerEncoder(80, 256, 4, 2048, 2, dropout_rate=0.0, positional_dropout_rate=0.0)
+    dut.load_state_dict(ref.state_dict(), strict=False)
+    dut = dut.cuda().train()
+    b, tlen = 3, 200
+    xs = torch.randn(b, tlen, 80)
+    mask = torch.ones(b, 1, tlen)
+    mask[1, 0, 150:] = 0
+    sub = C.subsample_mask(mask)
+    idx = torch.arange(sub.shape[-1])
+    chunk = ((idx[None, :] // 8) <= (idx[:, None] // 8)) & ((idx[None, :] // 8) >= (idx[:, None] // 8) - 2)
+    chunk_masks = (chunk[None] & (sub > 0)).float()
+    with torch.no_grad():
+        want, _ = ref(xs, sub, chunk_masks)
+        want_full, _ = ref(xs, sub)
+    got, _ = dut(xs.cuda(), sub.cuda(), chunk_masks.cuda())
+    e = got.cpu() - want
+    assert float(e.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) <= 2e-2
+    assert float((want - want_full).abs().max()) > 0.1
 
 
 def test_encoder_full_config_shapes_and_determinism():

@@ -220,8 +220,9 @@ def test_adam_and_overflow(K):
     assert torch.equal(p, before)  # update skipped on overflow
 
 
+@pytest.mark.parametrize("chunked", [False, True])
 @pytest.mark.parametrize("b,t", [(2, 100), (3, 255), (1, 64), (2, 37)])
-def test_attention_backward(K, b, t):
+def test_attention_backward(K, b, t, chunked):
     g = torch.Generator().manual_seed(7 + t)
     h, dk = 4, 64
     qkv = bf(torch.randn(b * t, 768, generator=g) * 0.8)
@@ -240,7 +241,13 @@ def test_attention_backward(K, b, t):
     qu = bf((q + u).detach()).float() + ((q + u) - (q + u).detach())  # the kernels round q + bias to bf16 (straight-through)
     qv = bf((q + v).detach()).float() + ((q + v) - (q + v).detach())
     scores = (qu.transpose(1, 2) @ k.transpose(-1, -2) + qv.transpose(1, 2) @ p.transpose(-1, -2)) / math.sqrt(dk)
-    scores = scores + (mask[:, None, None, :] == 0).float() * -10000.0
+    if chunked:  # (B, T, T) per-(query, key) masks of the streaming configuration (utils/mask.py:201-271), padding folded in
+        idx = torch.arange(t)
+        chunk = ((idx[None, :] // 8) <= (idx[:, None] // 8)) & ((idx[None, :] // 8) >= (idx[:, None] // 8) - 2)
+        mask = (chunk[None] & (mask[:, None, :] > 0)).float().contiguous()
+        scores = scores + (mask[:, None] == 0).float() * -10000.0
+    else:
+        scores = scores + (mask[:, None, None, :] == 0).float() * -10000.0
     attn = torch.softmax(scores, -1)
     ctx_ref = (attn @ vv).transpose(1, 2).reshape(b * t, 256)
     dctx = bf(torch.randn(b * t, 256, generator=g))

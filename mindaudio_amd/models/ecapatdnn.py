@@ -98,6 +98,7 @@ class EcapaTDNN(nn.Module):
         self.asp_bn = nn.BatchNorm1d(6 * c, eps=1e-5)
         self.fc = nn.Conv1d(6 * c, lin_neurons, 1)
         self._prepared = None
+        self._ws = {}
         self.fuse_res2net = True  # False: one launch per convolution / add of the Res2Net chain (the tests run both)
 
     @torch.no_grad()
@@ -154,15 +155,32 @@ class EcapaTDNN(nn.Module):
         bf = t.bfloat16
         s = _host.current_stream_ptr()
 
-        def buf(cols):  # (rows + 2H margin, cols) bf16; .m = pointer to row H (first utterance's first halo row)
-            full = t.empty((rows + 2 * H, cols), dtype=bf, device=dev)
-            full[:H].zero_()
-            full[-H:].zero_()
+        # Activation buffers and the row mask are kept per (batch, frames, device): the margins above the first and below the last
+        # utterance are read by the taps and never written, so they are zeroed once (26 fill launches per forward otherwise:
+        # 2.52 -> 2.47 ms for the C = 512 forward, same box).  Calls on one stream reuse them in order; the returned embedding is a fresh tensor.
+        key = (b, T, str(dev), bool(self.fuse_res2net))
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) >= 4:
+                self._ws.clear()
+            rs0 = t.zeros((b, tp), dtype=t.float32, device=dev)
+            rs0[:, H:H + T] = 1.0
+            ws = self._ws[key] = {"rs": rs0.view(-1), "bufs": []}
+        nbuf = [0]
+
+        def buf(cols):  # (rows + 2H margin, cols) bf16; the view starts at row H (first utterance's first halo row)
+            i = nbuf[0]
+            nbuf[0] += 1
+            if i == len(ws["bufs"]):
+                full = t.empty((rows + 2 * H, cols), dtype=bf, device=dev)
+                full[:H].zero_()
+                full[-H:].zero_()
+                ws["bufs"].append(full)
+            full = ws["bufs"][i]
+            assert full.shape[1] == cols
             return full, full[H:H + rows]
 
-        rs = t.zeros((b, tp), dtype=t.float32, device=dev)
-        rs[:, H:H + T] = 1.0
-        rs = rs.view(-1)
+        rs = ws["rs"]
         xin_full, xin = buf(self.fpad)
         _lib.check(lib.ma_ecapa_pack_input_bf16(x.float().contiguous().data_ptr(), b, T, f, H, self.fpad, xin.data_ptr(), s),
                    "pack_input")

@@ -90,6 +90,88 @@ __device__ __forceinline__ void gemm_static_for(F&& f) {
   gemm_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
+// ---- epilogue of a tile that lies fully inside the matrix: the code the common case runs.  (The general epilogue below decides
+// everything per fragment and per element - bounds, bias, activation, output type - which for the 32 fragments of a 256 x 256 tile
+// is 17 000 instructions of which each wave executes a thin, scattered slice: 12 us per tile, most of it instruction fetch -
+// tools/gemm8_timeline.py.)  Here the tile-wide decisions are taken once and a fragment costs one uniform switch on the
+// activation.  Same operations in the same order per element as the general epilogue.  (Measured alternatives: one body per
+// activation and output kind - 4.3 us per tile but 10 minutes of compile time for this file; separate passes over the accumulators
+// for bias / activation / scale / store - the accumulators spill.)
+template <bool EXT>
+__device__ __forceinline__ void gemm_act4(float (&v)[4], int act) {
+  switch (act) {
+    case 1:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act<EXT>(v[r], 1);
+      break;
+    case 2:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act<EXT>(v[r], 2);
+      break;
+    case 3:
+      if constexpr (EXT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act<EXT>(v[r], 3);
+      }
+      break;
+    case 4:
+      if constexpr (EXT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act<EXT>(v[r], 4);
+      }
+      break;
+    default: break;
+  }
+}
+
+template <int FM, int FN, int EPI, int BN, int OUT>  // OUT: 0 = bf16 through the LDS stage, 1 = float32 16-byte stores, 2 = bf16 8-byte stores
+__device__ __forceinline__ void gemm_store_inside(const GemmParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm_off, int wn_off,
+                                                  char* smem, int lane) {
+  const int em = lane & 15, en = (lane >> 4) * 4;
+  const bool has_bias = p.bias != nullptr, has_cs = (EPI == 1) && p.col_scale != nullptr, has_res = p.residual != nullptr;
+  const int act = p.act, act2 = (EPI == 1) ? p.act2 : 0;
+  float rs[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) rs[i] = (p.row_scale ? p.row_scale[m0 + wm_off + i * 16 + em] : 1.0f) * p.alpha;
+  gemm_static_for<FN>([&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const int n = n0 + wn_off + j * 16 + en;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f), ct = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+    if (has_cs) {
+      cs = *reinterpret_cast<const float4*>(p.col_scale + n);
+      ct = *reinterpret_cast<const float4*>(p.col_shift + n);
+    }
+    gemm_static_for<FM>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      const int m = m0 + wm_off + i * 16 + em;
+      float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+      gemm_act4<EPI == 1>(v, act);
+      if constexpr (EPI == 1) {
+        if (has_cs) {
+          v[0] = v[0] * cs.x + ct.x; v[1] = v[1] * cs.y + ct.y; v[2] = v[2] * cs.z + ct.z; v[3] = v[3] * cs.w + ct.w;
+        }
+        gemm_act4<true>(v, act2);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= rs[i];
+      if (has_res) {  // (ldr % 4 == 0 checked by the caller)
+        const float4 rv = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldr + n);
+        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+      }
+      if constexpr (OUT == 1) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        const uint32_t lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+        if constexpr (OUT == 0)
+          *reinterpret_cast<uint2*>(smem + (wm_off + i * 16 + em) * (BN * 2 + 16) + (wn_off + j * 16 + en) * 2) = make_uint2(lo, hi);
+        else
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + n) = make_uint2(lo, hi);
+      }
+    });
+  });
+}
+
 // ---- epilogue shared by the GEMM kernels: acc[i][j] is the 16 x 16 tile at rows m0 + wm_off + 16 i, columns n0 + wn_off + 16 j of a
 // BM x BN workgroup tile; lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3] --------------------------------
 template <int FM, int FN, int BM, int BN, int EPI, int NT>
@@ -121,6 +203,14 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, f32x4 (&acc
   const bool staged = p.out_bf16 && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 7) == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
   if (staged) __builtin_amdgcn_s_barrier();  // all waves are done reading the last K-tile
+  // the common case: the tile lies inside the matrix and the rows are 16-byte addressable -> one lean body per activation
+  const bool inside = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (!p.residual || (p.ldr & 3) == 0) &&
+                      (p.out_bf16 ? (staged || (p.ldo & 3) == 0) : (p.ldo & 3) == 0) && p.act >= 0 && p.act <= (EPI == 1 ? 4 : 2);
+  if (inside) {
+    if (!p.out_bf16) gemm_store_inside<FM, FN, EPI, BN, 1>(p, acc, m0, n0, wm_off, wn_off, smem, lane);
+    else if (staged) gemm_store_inside<FM, FN, EPI, BN, 0>(p, acc, m0, n0, wm_off, wn_off, smem, lane);
+    else gemm_store_inside<FM, FN, EPI, BN, 2>(p, acc, m0, n0, wm_off, wn_off, smem, lane);
+  } else
   // (compile-time tile indices: past a size the unroller leaves these loops rolled and the accumulators go to scratch memory)
   gemm_static_for<FM>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
@@ -357,8 +447,25 @@ __global__ __launch_bounds__(kGemmThreads, (NST * (BM + BN) * BK * 2 > 80 * 1024
 //     its last read;
 //   * LDS rows of 128 bytes, 16-byte chunks XOR-swizzled by (row & 7) on the SOURCE address and on the read (as above).
 constexpr int k8Threads = 512, k8Unit = 128 * 128, k8Buf = 4 * k8Unit;  // units of a buffer: A q0 | B q0 | B q1 | A q1
+// Phase stamps for tools/gemm8_timeline.py (compiled in only with -DMA_G8_PROF): wave 0 of three workgroups keeps wall_clock64()
+// (100 MHz) values in SGPRs and writes them out at the end of the kernel.
+#ifdef MA_G8_PROF
+__device__ unsigned long long g_g8_prof[3 * 8];
+#define G8_STAMP(k)                                    \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    g8_ts[(k)] = wall_clock64();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  } while (0)
+#else
+#define G8_STAMP(k) do { } while (0)
+#endif
 template <int EPI>
 __global__ __launch_bounds__(k8Threads, 1) void gemm_bf16_8ph_kernel(const GemmParams p) {
+#ifdef MA_G8_PROF
+  unsigned long long g8_ts[8];
+  G8_STAMP(0);
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -451,8 +558,10 @@ __global__ __launch_bounds__(k8Threads, 1) void gemm_bf16_8ph_kernel(const GemmP
   stage(C1{}, 0, 0);
   stage(C2{}, 0, 0);
   stage(C3{}, 0, 0);
+  G8_STAMP(1);  // first K-tile issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  G8_STAMP(2);  // ... landed
   if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs half a phase behind wave row 0
   // One phase: fragment reads of this quadrant, one unit of the next K-tile, the counted wait, barrier, 16 MFMAs, barrier.
 #define G8_PHASE(MORE, READS, U, I, J)                                                \
@@ -483,9 +592,26 @@ __global__ __launch_bounds__(k8Threads, 1) void gemm_bf16_8ph_kernel(const GemmP
   G8_TILE(false)  // the last K-tile: nothing left to stage
 #undef G8_TILE
 #undef G8_PHASE
+  G8_STAMP(3);  // main loop done
   if (wr == 0) __builtin_amdgcn_s_barrier();  // (the barrier wave row 1 took at the start)
   gemm_store_tile<8, 4, BM, BN, EPI, k8Threads>(p, acc, m0, n0, wr * 128, wc * 64, smem, tid, lane);
+#ifdef MA_G8_PROF
+  G8_STAMP(4);  // epilogue instructions issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G8_STAMP(5);  // stores retired
+  {
+    const int wg = blockIdx.x;
+    const int slot = wg == 0 ? 0 : wg == 100 ? 1 : wg == (int)gridDim.x - 1 ? 2 : -1;
+    if (threadIdx.x == 0 && slot >= 0)
+      for (int k = 0; k < 6; ++k) g_g8_prof[slot * 8 + k] = g8_ts[k];
+  }
+#endif
 }
+#ifdef MA_G8_PROF
+extern "C" int ma_debug_g8_prof(unsigned long long* host24) {
+  return hipMemcpyFromSymbol(host24, HIP_SYMBOL(g_g8_prof), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // out[m][n] (+)= alpha * sum_s part[s][m][n]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn,

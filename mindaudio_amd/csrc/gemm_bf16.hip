@@ -130,9 +130,12 @@ __device__ __forceinline__ void gemm_store_inside(const GemmParams& p, f32x4 (&a
   const int em = lane & 15, en = (lane >> 4) * 4;
   const bool has_bias = p.bias != nullptr, has_cs = (EPI == 1) && p.col_scale != nullptr, has_res = p.residual != nullptr;
   const int act = p.act, act2 = (EPI == 1) ? p.act2 : 0;
-  float rs[FM];
+  float rs[FM];  // (rows past M, possible only without the LDS stage, are computed and not stored)
 #pragma unroll
-  for (int i = 0; i < FM; ++i) rs[i] = (p.row_scale ? p.row_scale[m0 + wm_off + i * 16 + em] : 1.0f) * p.alpha;
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm_off + i * 16 + em;
+    rs[i] = ((p.row_scale && m < p.M) ? p.row_scale[m] : 1.0f) * p.alpha;
+  }
   gemm_static_for<FN>([&](auto jc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
     const int n = n0 + wn_off + j * 16 + en;
@@ -145,6 +148,7 @@ __device__ __forceinline__ void gemm_store_inside(const GemmParams& p, f32x4 (&a
     gemm_static_for<FM>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       const int m = m0 + wm_off + i * 16 + em;
+      if (OUT != 0 && m >= p.M) return;
       float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
       gemm_act4<EPI == 1>(v, act);
       if constexpr (EPI == 1) {
@@ -203,8 +207,9 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, f32x4 (&acc
   const bool staged = p.out_bf16 && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 7) == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
   if (staged) __builtin_amdgcn_s_barrier();  // all waves are done reading the last K-tile
-  // the common case: the tile lies inside the matrix and the rows are 16-byte addressable -> one lean body per activation
-  const bool inside = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (!p.residual || (p.ldr & 3) == 0) &&
+  // the common case: the tile's columns lie inside the matrix and the rows are 16-byte addressable -> the lean body
+  // (the last row tile of a matrix whose height is not a multiple of the tile takes it too, with its rows past M masked)
+  const bool inside = (n0 + BN <= p.N) && (!p.residual || (p.ldr & 3) == 0) &&
                       (p.out_bf16 ? (staged || (p.ldo & 3) == 0) : (p.ldo & 3) == 0) && p.act >= 0 && p.act <= (EPI == 1 ? 4 : 2);
   if (inside) {
     if (!p.out_bf16) gemm_store_inside<FM, FN, EPI, BN, 1>(p, acc, m0, n0, wm_off, wn_off, smem, lane);

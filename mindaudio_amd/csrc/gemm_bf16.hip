@@ -676,6 +676,9 @@ static int launch_gemm_8ph(const GemmParams& p, hipStream_t stream) {
   return MA_OK;
 }
 
+#ifndef MA_G8_MIN_K
+#define MA_G8_MIN_K 1024  // development builds: tools/lib_variant.sh k512 "-DMA_G8_MIN_K=512" gemm_bf16.hip
+#endif
 #ifndef MA_GEMM_FORCE
 #define MA_GEMM_FORCE 0  // development builds only (tools/lib_variant.sh): 1 = never the 256 x 256 kernel, 2 = always when legal
 #endif
@@ -687,7 +690,7 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     // K >= 1024 (with fewer K-tiles the 128 x 128 kernel's shorter prologue / epilogue wins: ECAPA's 512 -> 512 layers 2.49 vs 2.79 ms
     // per forward) and at most 1/8 of the column tiles' width outside the matrix (tools/gemm_bench.py, tools/ecapa_bench.py)
     const int64_t n_pad = (int64_t)((p.N + 255) / 256) * 256 - p.N;
-    if (p.K >= 1024 && 8 * n_pad <= p.N && (MA_GEMM_FORCE == 2 || t256 >= (int64_t)(0.9 * gemm_num_cus())))
+    if (p.K >= MA_G8_MIN_K && 8 * n_pad <= p.N && (MA_GEMM_FORCE == 2 || t256 >= (int64_t)(0.9 * gemm_num_cus())))
       return launch_gemm_8ph<EPI>(p, stream);
   }
   // 128 x 128 tiles unless they would leave most CUs without a workgroup (N = 256 .. 768 at M ~ 8k)

@@ -680,7 +680,8 @@ static int launch_gemm_8ph(const GemmParams& p, hipStream_t stream) {
 #define MA_G8_MIN_K 1024  // development builds: tools/lib_variant.sh k512 "-DMA_G8_MIN_K=512" gemm_bf16.hip
 #endif
 #ifndef MA_GEMM_FORCE
-#define MA_GEMM_FORCE 0  // development builds only (tools/lib_variant.sh): 1 = never the 256 x 256 kernel, 2 = always when legal
+#define MA_GEMM_FORCE 0  // development builds only (tools/lib_variant.sh): 1 = never the 256 x 256 kernel, 2 = always when legal,
+                         // 3 / 6 = 128 x 128 tiles with 2 / 3 stages, 4 / 5 = 64 x 128 tiles with 2 / 3 stages
 #endif
 template <int IM2COL, int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
@@ -693,17 +694,19 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.K >= MA_G8_MIN_K && 8 * n_pad <= p.N && (MA_GEMM_FORCE == 2 || t256 >= (int64_t)(0.9 * gemm_num_cus())))
       return launch_gemm_8ph<EPI>(p, stream);
   }
+  if constexpr (MA_GEMM_FORCE == 3) return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
+  if constexpr (MA_GEMM_FORCE == 4) return launch_gemm_tile<64, 128, 2, IM2COL, EPI>(p, stream);
+  if constexpr (MA_GEMM_FORCE == 5) return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
+  if constexpr (MA_GEMM_FORCE == 6) return launch_gemm_tile<128, 128, 3, IM2COL, EPI>(p, stream);
   // 128 x 128 tiles unless they would leave most CUs without a workgroup (N = 256 .. 768 at M ~ 8k)
   const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
   // measured on MI355X (tools/gemm_bench.py): 2 workgroups/CU beat a deeper ring for the 128x128 tile; the
   // 64x128 tile prefers 3 workgroups/CU (2 stages) when there are enough tiles to fill them, else the 3-stage ring
-  if (big >= 2 * gemm_num_cus() && p.K >= 1024) return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
-  // long K with about one 128 x 128 tile per CU (the 4864 -> 256 embed layer at M = 15936: 250 tiles): half the L2 -> LDS traffic
-  // of the 64-row tile, and the deep ring has 76 k-steps to pay for itself (measured 77 -> 72 us)
-  if (p.K >= 2048 && big <= gemm_num_cus() && big >= (int64_t)(0.9 * gemm_num_cus()))
-    return launch_gemm_tile<128, 128, 3, IM2COL, EPI>(p, stream);
+  // (re-measured with the lean epilogue, tools/gemm_tiles.py: 76 800 x 512 x 512 64 vs 70 us on the 64-row tile; the 128 x 128 x 3-stage
+  // choice for long K with one tile per CU went: 15 936 x 256 x 4864 49 vs 59 us, x 2048 25 vs 30 us on the 64-row tile with 2 stages)
+  if (big >= 2 * gemm_num_cus() && p.K >= 512) return launch_gemm_tile<128, 128, 2, IM2COL, EPI>(p, stream);
   const int64_t small = (int64_t)((p.M + 63) / 64) * ((p.N + 127) / 128);
-  if (small >= (int64_t)(2.4 * gemm_num_cus())) return launch_gemm_tile<64, 128, 2, IM2COL, EPI>(p, stream);
+  if (small >= (int64_t)(1.9 * gemm_num_cus())) return launch_gemm_tile<64, 128, 2, IM2COL, EPI>(p, stream);
   return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
 }
 

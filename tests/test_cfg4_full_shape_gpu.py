@@ -89,8 +89,9 @@ def test_bucket_1024_batch_of_40_trains():
     # an untrained CTC model scores ~ T' ln V per utterance-ish; the loss is finite, positive and falls once lr > 0
     assert a[0] > 0 and a[-1] < a[1]
     # same seed, same batch -> same curve (dropout masks are a pure function of (seed, step, site, index)); not bit-for-bit:
-    # the BatchNorm batch sums and a few parameter-gradient reductions meet in float32 atomics
-    assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) and max(abs(p - q) / abs(q) for p, q in zip(a, b)) <= 2e-3
+    # the BatchNorm batch sums and a few parameter-gradient reductions meet in float32 atomics (six fresh runs of this test's first
+    # step: 1666.589 .. 1666.613 = 1.4e-5 relative; third step 3.7e-4)
+    assert abs(a[0] - b[0]) <= 1e-4 * abs(b[0]) and max(abs(p - q) / abs(q) for p, q in zip(a, b)) <= 2e-3
     # gradient norm of the last step is finite and non-zero
     gn = float(eng.fp.grad.double().norm()) / 1024.0
     assert np.isfinite(gn) and gn > 0

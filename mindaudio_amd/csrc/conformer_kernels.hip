@@ -298,6 +298,19 @@ constexpr int kVsStride = 80;        // bf16 elements per V row (160 B = 40 dwor
 
 // NW = waves per workgroup: 4 (64 query rows, four workgroups per CU) or 8 (128 query rows, two per CU: the K' / V tiles are staged
 // once for twice as many queries; used when the second half of the 128 rows is populated).
+// Phase stamps for tools/att_timeline.py (compiled in only with -DMA_ATT_PROF): wave 0 of three workgroups keeps wall_clock64()
+// (100 MHz) values in SGPRs and writes them out at the end of the kernel.
+#ifdef MA_ATT_PROF
+__device__ unsigned long long g_att_prof[3 * 16];
+#define ATT_STAMP(k)                                   \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    att_ts[(k)] = wall_clock64();                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  } while (0)
+#else
+#define ATT_STAMP(k) do { } while (0)
+#endif
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                                const uint16_t* __restrict__ pos, int64_t ld_pos,
@@ -310,6 +323,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
   __shared__ __attribute__((aligned(16))) uint16_t Kp[kAttK * kKpStride];
   __shared__ __attribute__((aligned(16))) uint16_t Vs[kAttK * kVsStride];  // V tile as stored: [key][d]
   __shared__ float maskadd[kAttK];
+#ifdef MA_ATT_PROF
+  unsigned long long att_ts[16];
+  ATT_STAMP(0);
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -385,7 +402,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
     /* the tile's mask values travel with it (as a load between the tile's two barriers it was an exposed L2 round trip per tile) */ \
     if (mask && tid < kAttK) rmask = mask[(int64_t)b * T + (k0f_ + tid < T ? k0f_ + tid : T - 1)];  \
   }
+  // (issuing this fetch in front of the Q' build instead was measured: the query loads then queue behind it, 18.8 -> 19.5 us)
   MA_ATT_FETCH(0)
+  ATT_STAMP(1);  // Q' fragments built, first tile's loads issued
   for (int kt = 0; kt < n_kt; ++kt) {
     const int k0 = kt * kAttK;
     __syncthreads();  // previous tile fully consumed
@@ -407,6 +426,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
       maskadd[tid] = kj >= T ? -INFINITY : (rmask == 0.0f ? -10000.0f * 1.4426950408889634f : 0.0f);
     }
     __syncthreads();
+#ifdef MA_ATT_PROF
+    if (kt < 4) ATT_STAMP(2 + 2 * kt);  // tile kt published
+#endif
     if (kt + 1 < n_kt) MA_ATT_FETCH(kt + 1)
 
     // ---- S^T = K' . Q'^T : 4 key tiles x 4 k-steps; lane: query lq, keys c*16 + lg*4 + r ------------------------
@@ -490,6 +512,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vpk), pf, oacc[dt], 0, 0, 0);
       }
     }
+#ifdef MA_ATT_PROF
+    if (kt < 4) ATT_STAMP(3 + 2 * kt);  // tile kt consumed
+#endif
   }
   // ---- ctx[q, h*64 + d] = O^T[d, q] / l ---------------------------------------------------------------------------
   const int qi = q_base + lq;
@@ -515,7 +540,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
       *reinterpret_cast<uint2*>(o + dt * 16) = pk;
     }
   }
+#ifdef MA_ATT_PROF
+  ATT_STAMP(10);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_STAMP(11);
+  {
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int slot = wg == 0 ? 0 : wg == nwg / 2 ? 1 : wg == nwg - 1 ? 2 : -1;
+    if (threadIdx.x == 0 && slot >= 0)
+      for (int k = 0; k < 12; ++k) g_att_prof[slot * 16 + k] = att_ts[k];
+  }
+#endif
 }
+#ifdef MA_ATT_PROF
+extern "C" int ma_debug_att_prof(unsigned long long* host48) {
+  return hipMemcpyFromSymbol(host48, HIP_SYMBOL(g_att_prof), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #undef MA_ATT_FETCH
 #undef MA_ATT_KLOAD

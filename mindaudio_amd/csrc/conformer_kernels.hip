@@ -311,8 +311,12 @@ __device__ unsigned long long g_att_prof[3 * 16];
 #else
 #define ATT_STAMP(k) do { } while (0)
 #endif
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+// QF = 16-row query fragments per wave: with 2, a K' / V fragment read from LDS serves 32 query rows (the consume phase of a key tile
+// is LDS-bandwidth bound with 1: profiles/r02_attention_phase_timeline.txt).  Measured (-DMA_ATT_QF2: 4 waves x 32 rows instead of
+// 8 x 16): the publish phases shrink (0.4 - 1.0 us) but half the waves now carry the same exp2 / MFMA work (consume 1.3 - 2.8 us):
+// 17.2 vs 18.8 us alone, no change in the step (2.157 vs 2.159 ms) - the default stays 8 x 16.
+template <int NW, int QF>
+__global__ __launch_bounds__(NW * 64, (NW == 8 || QF == 2) ? 2 : 4) void relpos_attention_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                                const uint16_t* __restrict__ pos, int64_t ld_pos,
                                                                const float* __restrict__ mask3, int Tp,
                                                                const float* __restrict__ bias_u,
@@ -331,15 +335,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int64_t row0 = (int64_t)b * T;
-  const int q_base = qt * (NW * 16) + wave * 16;
+  const int q_base = qt * (NW * 16 * QF) + wave * 16 * QF;  // + 16 f for fragment f
   const int lq = lane & 15, lg = lane >> 4;
   (void)Tp;
   const float scale2 = scale * 1.4426950408889634f;
 
   // ---- Q' fragments (B operand): lane holds query row lq, k = kstep*32 + lg*8 .. +7 of [q+u | q+v] -------------
-  bf16x8 qf[4];
-  {
-    int qi = q_base + lq;
+  bf16x8 qf[QF][4];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    int qi = q_base + 16 * f + lq;
     if (qi >= T) qi = T - 1;
     const uint16_t* qrow = qkv + (row0 + qi) * ld_qkv + h * kDk;
 #pragma unroll
@@ -356,16 +361,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
         o[e] = pack2_bf16(lo, hi);
       }
       const uint4 pk = make_uint4(o[0], o[1], o[2], o[3]);
-      qf[ks] = __builtin_bit_cast(bf16x8, pk);
+      qf[f][ks] = __builtin_bit_cast(bf16x8, pk);
     }
   }
 
   const uint32_t vs_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)Vs +
                            ((lg * 4 + (lq >> 2)) * kVsStride + (lq & 3) * 4) * 2;
-  f32x4 oacc[4];  // O^T: rows d = dt*16 + lg*4 + r, column q = lq
+  f32x4 oacc[QF][4];  // O^T: rows d = dt*16 + lg*4 + r, column q = lq
+  float mrow[QF], lrow[QF];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrow = -INFINITY, lrow = 0.f;  // running max of query row lq (replicated over the 4 lane groups) / this lane group's part of its sum
+  for (int f = 0; f < QF; ++f) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) oacc[f][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mrow[f] = -INFINITY;
+    lrow[f] = 0.f;
+  }
+  // mrow:   // running max of query row lq (replicated over the 4 lane groups) / this lane group's part of its sum
 
   // Staging assignment (fixed per thread): 4 x 16-byte pieces of K' = [k | p] and 2 of V^T per 64-key tile.  The
   // global loads of tile kt+1 are issued right after tile kt is published and stay in flight during its MFMAs.
@@ -431,68 +442,76 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
 #endif
     if (kt + 1 < n_kt) MA_ATT_FETCH(kt + 1)
 
-    // ---- S^T = K' . Q'^T : 4 key tiles x 4 k-steps; lane: query lq, keys c*16 + lg*4 + r ------------------------
-    f32x4 s[4];
-    float tmax = -INFINITY;
+    // ---- S^T = K' . Q'^T : 4 key tiles x 4 k-steps; lane: query lq (of fragment f), keys c*16 + lg*4 + r -----------
+    f32x4 s[QF][4];
+    float tmax[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) tmax[f] = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < QF; ++f) s[f][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kp[(c * 16 + lq) * kKpStride + ks * 32 + lg * 8]);
-        s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[c], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < QF; ++f) s[f][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[f][ks], s[f][c], 0, 0, 0);
       }
       const float4 ma_ = *reinterpret_cast<const float4*>(&maskadd[c * 16 + lg * 4]);
-      // scores in log2 units: scale2 = scale * log2(e), maskadd pre-multiplied by log2(e) -> exp2 below
-      s[c][0] = s[c][0] * scale2 + ma_.x;
-      s[c][1] = s[c][1] * scale2 + ma_.y;
-      s[c][2] = s[c][2] * scale2 + ma_.z;
-      s[c][3] = s[c][3] * scale2 + ma_.w;
-      if (mask3) {  // per-(query, key) mask (B, T, T): the chunk masks of the streaming configuration (utils/mask.py:201-271); the
-                    // same additive -10000 as the padding mask
-        int qm = q_base + lq;
-        if (qm >= T) qm = T - 1;
-        const float* m3 = mask3 + ((int64_t)b * T + qm) * T + k0 + c * 16 + lg * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (k0 + c * 16 + lg * 4 + r < T && m3[r] == 0.0f) s[c][r] += -10000.0f * 1.4426950408889634f;
+      for (int f = 0; f < QF; ++f) {
+        // scores in log2 units: scale2 = scale * log2(e), maskadd pre-multiplied by log2(e) -> exp2 below
+        s[f][c][0] = s[f][c][0] * scale2 + ma_.x;
+        s[f][c][1] = s[f][c][1] * scale2 + ma_.y;
+        s[f][c][2] = s[f][c][2] * scale2 + ma_.z;
+        s[f][c][3] = s[f][c][3] * scale2 + ma_.w;
+        if (mask3) {  // per-(query, key) mask (B, T, T): the chunk masks of the streaming configuration (utils/mask.py:201-271); the
+                      // same additive -10000 as the padding mask
+          int qm = q_base + 16 * f + lq;
+          if (qm >= T) qm = T - 1;
+          const float* m3 = mask3 + ((int64_t)b * T + qm) * T + k0 + c * 16 + lg * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + c * 16 + lg * 4 + r < T && m3[r] == 0.0f) s[f][c][r] += -10000.0f * 1.4426950408889634f;
+        }
+        tmax[f] = fmaxf(fmaxf(tmax[f], fmaxf(s[f][c][0], s[f][c][1])), fmaxf(s[f][c][2], s[f][c][3]));
       }
-      tmax = fmaxf(fmaxf(tmax, fmaxf(s[c][0], s[c][1])), fmaxf(s[c][2], s[c][3]));
     }
-    // the row maximum over the 4 lane groups through gfx950's row swaps (two VALU instructions instead of two ds_bpermute round
-    // trips on the critical path of every key tile; tools/ubench/permlane_test.hip)
-    {
-      float a = tmax, b = tmax;
-      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-      tmax = fmaxf(a, b);
-      a = tmax;
-      b = tmax;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-      tmax = fmaxf(a, b);
-    }
-    const float mnew = fmaxf(mrow, tmax);  // finite: key 0 of the first tile always exists
-    const float alpha = (mrow == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mrow - mnew);
-    mrow = mnew;
-    float psum = 0.f;
-    uint32_t pb[4][2];  // bf16 pairs: tile c, keys lg*4 + {0,1}, {2,3}
+    uint32_t pb[QF][4][2];  // bf16 pairs: tile c, keys lg*4 + {0,1}, {2,3}
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float e0 = __builtin_amdgcn_exp2f(s[c][0] - mnew), e1 = __builtin_amdgcn_exp2f(s[c][1] - mnew);
-      const float e2 = __builtin_amdgcn_exp2f(s[c][2] - mnew), e3 = __builtin_amdgcn_exp2f(s[c][3] - mnew);
-      psum += (e0 + e1) + (e2 + e3);
-      pb[c][0] = pack2_bf16(e0, e1);
-      pb[c][1] = pack2_bf16(e2, e3);
-    }
-    lrow = lrow * alpha + psum;  // this lane group's share: alpha is the same in the row's 4 lanes, the groups are summed once at the end
+    for (int f = 0; f < QF; ++f) {
+      // the row maximum over the 4 lane groups through gfx950's row swaps (two VALU instructions instead of two ds_bpermute round
+      // trips on the critical path of every key tile; tools/ubench/permlane_test.hip)
+      {
+        float a = tmax[f], b = tmax[f];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        tmax[f] = fmaxf(a, b);
+        a = tmax[f];
+        b = tmax[f];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        tmax[f] = fmaxf(a, b);
+      }
+      const float mnew = fmaxf(mrow[f], tmax[f]);  // finite: key 0 of the first tile always exists
+      const float alpha = (mrow[f] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mrow[f] - mnew);
+      mrow[f] = mnew;
+      float psum = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      oacc[c][0] *= alpha; oacc[c][1] *= alpha; oacc[c][2] *= alpha; oacc[c][3] *= alpha;
+      for (int c = 0; c < 4; ++c) {
+        const float e0 = __builtin_amdgcn_exp2f(s[f][c][0] - mnew), e1 = __builtin_amdgcn_exp2f(s[f][c][1] - mnew);
+        const float e2 = __builtin_amdgcn_exp2f(s[f][c][2] - mnew), e3 = __builtin_amdgcn_exp2f(s[f][c][3] - mnew);
+        psum += (e0 + e1) + (e2 + e3);
+        pb[f][c][0] = pack2_bf16(e0, e1);
+        pb[f][c][1] = pack2_bf16(e2, e3);
+      }
+      lrow[f] = lrow[f] * alpha + psum;  // this lane group's share: alpha is the same in the row's 4 lanes, the groups are summed once at the end
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        oacc[f][c][0] *= alpha; oacc[f][c][1] *= alpha; oacc[f][c][2] *= alpha; oacc[f][c][3] *= alpha;
+      }
     }
     // ---- O^T += V^T . P^T : k-step ks covers key tiles 2ks, 2ks+1 with slot (lg*8 + j) <-> key (j>>2)*16 + lg*4 + (j&3)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const uint4 ppk = make_uint4(pb[2 * ks][0], pb[2 * ks][1], pb[2 * ks + 1][0], pb[2 * ks + 1][1]);
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, ppk);
       // V^T fragments straight from the [key][d] tile with transposing reads: in a 16-lane group, lane 4a + b addresses
       // (key k0 + a, d n0 + 4b .. +3) and receives keys k0 .. k0+3 of d = n0 + (lane & 15)   [tools/ubench/tr_read.hip]
       unsigned long long vlo[4], vhi[4];
@@ -509,7 +528,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const uint4 vpk = make_uint4((uint32_t)vlo[dt], (uint32_t)(vlo[dt] >> 32), (uint32_t)vhi[dt], (uint32_t)(vhi[dt] >> 32));
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vpk), pf, oacc[dt], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+          const uint4 ppk = make_uint4(pb[f][2 * ks][0], pb[f][2 * ks][1], pb[f][2 * ks + 1][0], pb[f][2 * ks + 1][1]);
+          oacc[f][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vpk), __builtin_bit_cast(bf16x8, ppk),
+                                                                oacc[f][dt], 0, 0, 0);
+        }
       }
     }
 #ifdef MA_ATT_PROF
@@ -517,27 +541,31 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void relpos_attention_ker
 #endif
   }
   // ---- ctx[q, h*64 + d] = O^T[d, q] / l ---------------------------------------------------------------------------
-  const int qi = q_base + lq;
-  {  // the row's sum over its 4 lane groups
-    float a = lrow, b = lrow;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    lrow = a + b;
-    a = lrow;
-    b = lrow;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    lrow = a + b;
-  }
-  // log-sum-exp of the scaled, masked scores of row qi: what the backward pass needs to rebuild the probabilities
-  if (lse && qi < T && lg == 0) lse[((int64_t)b * H + h) * T + qi] = (mrow + __log2f(lrow)) * 0.6931471805599453f;
-  if (qi < T) {
-    const float inv = 1.0f / lrow;
-    uint16_t* o = ctx + (row0 + qi) * ld_ctx + h * kDk + lg * 4;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      uint2 pk;
-      pk.x = pack2_bf16(oacc[dt][0] * inv, oacc[dt][1] * inv);
-      pk.y = pack2_bf16(oacc[dt][2] * inv, oacc[dt][3] * inv);
-      *reinterpret_cast<uint2*>(o + dt * 16) = pk;
+  for (int f = 0; f < QF; ++f) {
+    const int qi = q_base + 16 * f + lq;
+    float lr = lrow[f];
+    {  // the row's sum over its 4 lane groups
+      float a = lr, b = lr;
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+      lr = a + b;
+      a = lr;
+      b = lr;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+      lr = a + b;
+    }
+    // log-sum-exp of the scaled, masked scores of row qi: what the backward pass needs to rebuild the probabilities
+    if (lse && qi < T && lg == 0) lse[((int64_t)b * H + h) * T + qi] = (mrow[f] + __log2f(lr)) * 0.6931471805599453f;
+    if (qi < T) {
+      const float inv = 1.0f / lr;
+      uint16_t* o = ctx + (row0 + qi) * ld_ctx + h * kDk + lg * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = pack2_bf16(oacc[f][dt][0] * inv, oacc[f][dt][1] * inv);
+        pk.y = pack2_bf16(oacc[f][dt][2] * inv, oacc[f][dt][3] * inv);
+        *reinterpret_cast<uint2*>(o + dt * 16) = pk;
+      }
     }
   }
 #ifdef MA_ATT_PROF
@@ -809,13 +837,19 @@ static int relpos_attention_fwd(const void* qkv, int64_t ld_qkv, const void* pos
   // 128-row query tiles when their second half is populated (T = 249: 128 + 121 rows)
   if (((T - 1) % 128) >= 96) {
     const dim3 grid8((unsigned)((T + 127) / 128), (unsigned)heads, (unsigned)batch);
-    MA_LAUNCH(relpos_attention_kernel<8>, grid8, dim3(512), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
+#ifdef MA_ATT_QF2  // development A/B: 4 waves x 32 query rows instead of 8 waves x 16
+    MA_LAUNCH((relpos_attention_kernel<4, 2>), grid8, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
+              reinterpret_cast<const uint16_t*>(pos), ld_pos, mask3, Tp, bias_u,
+              bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx, lse);
+    return MA_OK;
+#endif
+    MA_LAUNCH((relpos_attention_kernel<8, 1>), grid8, dim3(512), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
               reinterpret_cast<const uint16_t*>(pos), ld_pos, mask3, Tp, bias_u,
               bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx, lse);
     return MA_OK;
   }
   const dim3 grid((unsigned)((T + kAttQ - 1) / kAttQ), (unsigned)heads, (unsigned)batch);
-  MA_LAUNCH(relpos_attention_kernel<4>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
+  MA_LAUNCH((relpos_attention_kernel<4, 1>), grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(qkv), ld_qkv,
             reinterpret_cast<const uint16_t*>(pos), ld_pos, mask3, Tp, bias_u,
             bias_v, mask, (int)T, (int)heads, 1.0f / sqrtf((float)d_k), reinterpret_cast<uint16_t*>(ctx), ld_ctx, lse);
   return MA_OK;

@@ -223,15 +223,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
       int64_t nv = p.lengths[g.b];
       if (nv > p.n) nv = p.n;
       g.n_valid = (int)nv;
-      int fb = (g.n_valid >= p.frame_len) ? (g.n_valid - p.frame_len) / p.hop + 1 : 0;
-      if (fb > (int)p.n_frames) fb = (int)p.n_frames;
-      g.frames_b = fb;
-      // ONE scalar mean over all windowed frames of the utterance (dataset.py:165): fixed-order sum of the
-      // per-tile partials written by kaldi_sum_kernel (uniform addresses -> scalar loads).
-      double acc = 0.0;
-      const int tiles_b = (fb + kSumTileFrames - 1) / kSumTileFrames;
-      for (int i = 0; i < tiles_b; ++i) acc += p.partial[(int64_t)g.b * p.sum_tiles_per_utt + i];
-      g.half_mean = fb > 0 ? 0.5f * (float)(acc / ((double)fb * (double)p.frame_len)) : 0.0f;
+      // frames of the utterance and the ONE scalar mean over all its windowed frames (dataset.py:165) come from kaldi_mean_kernel:
+      // per unit they cost 32 dependent loads + a float64 and an integer division - 30 us of the cfg-2 batch's 62 (tools/phase_prof.py
+      // --kaldi, "all off")
+      g.frames_b = p.frames_utt[g.b];
+      g.half_mean = p.half_mean[g.b];
     }
     g.fv = (g.frames_b - g.t0) < kUnitFrames ? (g.frames_b - g.t0) : kUnitFrames;
     return g;
@@ -547,33 +543,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void feat512_kernel(const FeatParams 
           }
           wave_lds_sync();  // the tile is restaged by the next unit
         } else {
-          // Kaldi layout (B, T, n_mels): the (8, n_mels) block of the unit leaves as ONE contiguous 8*n_mels*4-byte run.  The
-          // row results wait in registers until every lane is done reading powers, then go through the (now dead) tile.
-          float res[kMaxRows];
-#pragma unroll
-          for (int i = 0; i < kMaxRows; ++i) {
-            res[i] = 0.0f;
-            if (i < p.n_rows) {
-              const float acc = mel_row(i);
-              // dataset.py:154-155: zeros -> float64 eps, natural log
-              const float e = (acc == 0.0f) ? 2.220446049250313e-16f : acc;
-              res[i] = 0.69314718055994531f * fast_log2(e);
-            }
+          // Kaldi layout (B, T, n_mels): lane (frame fm, mel group mg) stores its row results itself - per row one store
+          // instruction of 8 x 32-byte runs, the same shape as the (B, n_mels, T) stores above.  (The first version kept the row
+          // results of the unrolled row loop in registers until every lane was done reading powers and sent them through the
+          // dead tile as one contiguous run: 215 VGPRs, two waves per SIMD, 63 us for the cfg-2 batch.)
+          float* __restrict__ okal = p.out + ((int64_t)b * p.n_frames + t0) * p.n_mels + (int64_t)fm * p.n_mels + mg;
+          const bool in_range = tm < (int)p.n_frames;
+          for (int i = 0; i < p.n_rows; ++i) {
+            const float acc = mel_row(i);
+            // dataset.py:154-155: zeros -> float64 eps, natural log
+            const float e = (acc == 0.0f) ? 2.220446049250313e-16f : acc;
+            const float v = 0.69314718055994531f * fast_log2(e);
+            if (in_range && mg + 8 * i < p.n_mels) okal[8 * i] = fvalid ? v : 0.0f;  // rows past the utterance end: zeros
           }
           MA_PROF(4);
-          wave_lds_sync();
-          const int sstride = p.n_mels + 1;
-#pragma unroll
-          for (int i = 0; i < kMaxRows; ++i)
-            if (mg + 8 * i < p.n_mels) Pw[fm * sstride + mg + 8 * i] = res[i];
-          wave_lds_sync();
-          const int rows = ((int)p.n_frames - t0) < kUnitFrames ? ((int)p.n_frames - t0) : kUnitFrames;
-          float* __restrict__ o = p.out + ((int64_t)b * p.n_frames + t0) * p.n_mels;
-          for (int idx = lane; idx < rows * p.n_mels; idx += 64) {
-            const int ff = idx / p.n_mels, mm = idx - ff * p.n_mels;
-            o[idx] = (t0 + ff < frames_b) ? Pw[ff * sstride + mm] : 0.0f;  // rows past the utterance end: zeros
-          }
-          wave_lds_sync();
+          wave_lds_sync();  // the tile is restaged by the next unit
         }
         MA_PROF(5);
         MA_STAMP(5);  // mel done
@@ -629,6 +613,26 @@ __global__ __launch_bounds__(kThreads) void topdb_units_kernel(float* out, const
 }
 
 // ---- Kaldi front end: per-tile sums of the windowed, pre-emphasised frames ----------------
+// Per utterance (one wave each): frames and 0.5 * mean of the windowed frames = sum of the per-tile partials in a fixed order
+// (lane i takes tiles i, i + 64, ..; then a butterfly over the lanes).
+__global__ __launch_bounds__(64) void kaldi_mean_kernel(const FeatParams p) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int64_t nv = p.lengths[b];
+  if (nv > p.n) nv = p.n;
+  int fb = (nv >= p.frame_len) ? (int)((nv - p.frame_len) / p.hop) + 1 : 0;
+  if (fb > (int)p.n_frames) fb = (int)p.n_frames;
+  double acc = 0.0;
+  const int tiles_b = (fb + kSumTileFrames - 1) / kSumTileFrames;
+  for (int i = lane; i < tiles_b; i += 64) acc += p.partial[(int64_t)b * p.sum_tiles_per_utt + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) {
+    p.frames_utt[b] = fb;
+    p.half_mean[b] = fb > 0 ? 0.5f * (float)(acc / ((double)fb * (double)p.frame_len)) : 0.0f;
+    if (p.frames_out) p.frames_out[b] = fb;
+  }
+}
+
 // STAGED: the tile's span of pre-emphasised samples is built once in LDS (frames overlap 2.5x at 25 ms / 10 ms, and
 // every sample needs its predecessor); otherwise (hop so large that 32 frames do not fit 64 KB) the frames are read
 // from global memory directly.  Same products, same per-thread order either way.
@@ -695,10 +699,7 @@ __global__ __launch_bounds__(kThreads) void kaldi_sum_kernel(const FeatParams p)
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    p.partial[tile] = (red[0] + red[1]) + (red[2] + red[3]);
-    if (t0 == 0 && p.frames_out) p.frames_out[b] = frames_b;
-  }
+  if (threadIdx.x == 0) p.partial[tile] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ---- standalone amplitude_to_dB (spectrum.py:25-90) ---------------------------------------
@@ -803,8 +804,9 @@ static int launch_feat_cfg(const FeatParams& p_in, hipStream_t stream, int* grid
 // waits for the unit's output stores.
 template <int MODE, bool MAG>
 static int launch_feat_impl(const FeatParams& p, hipStream_t stream, int* grid_out) {
-  // the Kaldi front end keeps its row results in registers across the mel phase (215 VGPRs): two waves per SIMD
   if constexpr (MODE == kModeKaldi) {
+    // two waves per SIMD: at three the Kaldi front end (pre-emphasis, mean, 400-sample window) spills 12 registers (71.8 vs 68.7 us
+    // for the cfg-2 batch, pre-passes included)
     return launch_feat_cfg<MODE, MAG, 4, 2>(p, stream, grid_out);
   } else {
     if (p.frame_len == 400) return launch_feat_cfg<MODE, MAG, 4, 3, 400>(p, stream, grid_out);  // the reference's default n_fft
@@ -865,7 +867,7 @@ static int64_t ws_units(int64_t batch, int64_t n_frames) {
 
 int64_t ma_fbank_workspace_bytes(int64_t batch, int64_t n_frames) {
   if (batch < 1 || n_frames < 1) return MA_ERR_INVALID_ARG;
-  return ws_partial_bytes(batch, n_frames) + ws_units(batch, n_frames) * 4 + kMaxGrid * 4 + 256;
+  return ws_partial_bytes(batch, n_frames) + ws_units(batch, n_frames) * 4 + kMaxGrid * 4 + batch * 8 + 256;
 }
 
 static int fill_common(FeatParams& p, const float* wav, int64_t batch, int64_t n, int64_t wav_stride, int32_t n_fft,
@@ -996,6 +998,10 @@ int ma_fbank_kaldi_f32(const float* wav, const int64_t* lengths, int64_t batch, 
   if (workspace_bytes < ma_fbank_workspace_bytes(batch, p.n_frames)) return MA_ERR_WORKSPACE;
   p.partial = reinterpret_cast<double*>(workspace);
   p.frames_out = frames_out;
+  // (behind the regions the dB path uses: partial sums | unit minima | workgroup maxima)
+  p.half_mean = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_partial_bytes(batch, p.n_frames) +
+                                         ws_units(batch, p.n_frames) * 4 + kMaxGrid * 4);
+  p.frames_utt = reinterpret_cast<int32_t*>(p.half_mean + batch);
   const int64_t span_bytes = ((int64_t)(kSumTileFrames - 1) * frame_shift + frame_len) * 4;
   if (span_bytes <= 48 * 1024) {
     MA_LAUNCH(kaldi_sum_kernel<true>, dim3((unsigned)(batch * p.sum_tiles_per_utt)), dim3(kThreads),
@@ -1004,6 +1010,7 @@ int ma_fbank_kaldi_f32(const float* wav, const int64_t* lengths, int64_t batch, 
     MA_LAUNCH(kaldi_sum_kernel<false>, dim3((unsigned)(batch * p.sum_tiles_per_utt)), dim3(kThreads), 0,
               (hipStream_t)stream, p);
   }
+  MA_LAUNCH(kaldi_mean_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, p);
   return launch_feat<kModeKaldi>(p, (hipStream_t)stream);
 }
 

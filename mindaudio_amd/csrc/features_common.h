@@ -26,6 +26,8 @@ struct FeatParams {
   float* wg_max;    // [gridDim.x] maximum dB seen by each workgroup
   double* partial;  // kaldi: [batch * sum_tiles_per_utt] windowed sums
   int64_t* frames_out;  // kaldi: [batch] frames per utterance (may be null)
+  float* half_mean;     // kaldi: [batch] 0.5 * scalar mean of the utterance's windowed frames (kaldi_mean_kernel)
+  int32_t* frames_utt;  // kaldi: [batch] frames of each utterance
   unsigned long long* prof;  // MA_PROFILE builds only: per-phase cycle totals
   const int* mel_steps;    // [n_rows]
   const int* mel_row_off;  // [n_rows]

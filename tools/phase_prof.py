@@ -24,7 +24,20 @@ prof = torch.zeros(64, dtype=torch.int64, device="cuda")
 lib.ma_debug_set_prof.argtypes = [ctypes.c_void_p]
 lib.ma_debug_set_prof(ctypes.c_void_p(prof.data_ptr()))
 st = _host.current_stream_ptr()
+KALDI = "--kaldi" in sys.argv  # the Kaldi front end of the Conformer loader (25 ms frames, pre-emphasis, scalar mean) instead
+if KALDI:
+    kwin = _host.device_kaldi_window(400, x.device)
+    kbank = _host.device_kaldi_bank(80, 512, 16000.0, 20.0, 8000.0, x.device)
+    klens = torch.full((B,), N, dtype=torch.int64, device="cuda")
+    kT = (N - 400) // 160 + 1
+    kout = torch.empty((B, kT, 80), device="cuda")
+    kframes = torch.empty((B,), dtype=torch.int64, device="cuda")
+    kws = _host.workspace(lib.ma_fbank_workspace_bytes(B, kT), x.device)
 def run():
+    if KALDI:
+        assert lib.ma_fbank_kaldi_f32(_host.ptr(x), _host.ptr(klens), B, N, N, 400, 160, 512, _host.ptr(kwin), kbank.ref(), 0.97,
+                                      _host.ptr(kout), _host.ptr(kframes), _host.ptr(kws), kws.numel(), st) == 0
+        return
     assert lib.ma_fbank_db_f32(_host.ptr(x), B, N, N, 512, 160, _host.ptr(win), 1, 1, bank.ref(), 2.0, 10.0, 1e-10, 0.0, -1.0, _host.ptr(out), _host.ptr(ws), ws.numel(), st) == 0
 for _ in range(3): run()
 torch.cuda.synchronize(); prof.zero_()

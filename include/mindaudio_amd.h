@@ -434,6 +434,20 @@ int ma_conv2d_3x3s2_dw_bf16(const void* dy, int64_t ld_dy, const void* act, int6
 int ma_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols, void* out, int64_t ld_out,
                       float* colsum, ma_stream_t stream);
 
+/* The same for a list of matrices in ONE launch (the transposed bf16 weight copies of the training step: 100 matrices per
+ * step, each of them a launch-bound 4 us on its own).  `items` and `block_item` are DEVICE arrays: block_item[b] = index of the
+ * item whose 64 x 64 tile workgroup b transposes, items[i].first_block = index of its first workgroup; tiles of an item are
+ * numbered row-tile major: tile = (b - first_block), r0 = 64 * (tile / tiles_c), c0 = 64 * (tile % tiles_c).  All bases 16-byte
+ * aligned, ld_in / ld_out / cols multiples of 8. */
+typedef struct ma_transpose_item {
+  const void* in;
+  void* out;
+  int64_t ld_in, ld_out;
+  int32_t rows, cols;
+  int32_t first_block, tiles_c;
+} ma_transpose_item_t;
+int ma_transpose_batch_bf16(const ma_transpose_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream);
+
 /* Backward of ma_layernorm_f32 (layers/layernorm.py:53-60): g (+)= dL/dx, dgamma/dbeta (D) float32 += (atomics).
  * dy bf16 or float32; row_scale as in the forward; D == 256. */
 int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,

@@ -123,6 +123,47 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+// A list of matrices in one launch (ma_transpose_batch_bf16): workgroup b transposes one 64 x 64 tile of item block_item[b];
+// 16-byte loads and stores, tiles past the edges masked.
+__global__ __launch_bounds__(256) void transpose_batch_bf16_kernel(const ma_transpose_item_t* __restrict__ items,
+                                                                   const int32_t* __restrict__ block_item) {
+  __shared__ uint16_t tile[64][64 + 2];
+  const ma_transpose_item_t it_ = items[block_item[blockIdx.x]];
+  const int t = (int)blockIdx.x - it_.first_block;
+  const int r0 = (t / it_.tiles_c) * 64, c0 = (t % it_.tiles_c) * 64;
+  const int rows = it_.rows, cols = it_.cols;
+  const uint16_t* __restrict__ in = reinterpret_cast<const uint16_t*>(it_.in);
+  uint16_t* __restrict__ out = reinterpret_cast<uint16_t*>(it_.out);
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + it * 256, r = idx >> 3, ch = idx & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const uint4*>(in + (int64_t)(r0 + r) * it_.ld_in + c0 + ch * 8);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&tile[r][ch * 8]);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + it * 256, c = idx & 63, rc = idx >> 6;
+    uint16_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = tile[rc * 8 + i][c];
+    if (c0 + c < cols) {
+      uint16_t* o = out + (int64_t)(c0 + c) * it_.ld_out + r0 + rc * 8;
+      if (r0 + rc * 8 + 8 <= rows) {
+        *reinterpret_cast<uint4*>(o) = make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                                                  (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (r0 + rc * 8 + i < rows) o[i] = e[i];
+      }
+    }
+  }
+}
+
 // out_a[j] += sum_b part[b][j] (j < na), out_b[j - na] += sum_b part[b][j] (na <= j < n): second stage of the
 // parameter-gradient reductions (fixed summation order; no contended atomics)
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* out_a,
@@ -721,6 +762,12 @@ int ma_transpose_bf16(const void* in, int64_t ld_in, int64_t rows, int64_t cols,
   else
     MA_LAUNCH(transpose_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, ld_in, (int)rows,
               (int)cols, (uint16_t*)out, ld_out, colsum);
+  return MA_OK;
+}
+
+int ma_transpose_batch_bf16(const ma_transpose_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream) {
+  if (!items || !block_item || n_blocks < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(transpose_batch_bf16_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, items, block_item);
   return MA_OK;
 }
 

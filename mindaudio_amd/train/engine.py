@@ -380,11 +380,45 @@ class ConformerCTCTrainStep:
             names.append("dec.out_w")
             for i in range(self.Ld):
                 names += ["d%d.%s" % (i, w) for w in _DEC_W]
-        for n in names:
-            if n not in self.wt:
-                rows, cols = fp.w(n).shape
+        if getattr(self, "_wt_plan", None) is None:
+            # one launch for all of them (ma_transpose_batch_bf16): the item list and the workgroup -> item map are built once, the
+            # bf16 mirror and the transposed copies never move
+            import ctypes
+
+            import numpy as np
+
+            items, block_item, first = [], [], 0
+            for i, n in enumerate(names):
+                w = fp.w(n)
+                rows, cols = w.shape
                 self.wt[n] = torch.zeros((cols, K.pad64(rows)), dtype=torch.bfloat16, device=self.dev)
-            K.transpose(fp.w(n), out=self.wt[n])
+                tr, tc = (rows + 63) // 64, (cols + 63) // 64
+                ok = (w.stride(0) % 8 == 0 and self.wt[n].stride(0) % 8 == 0 and cols % 8 == 0 and w.data_ptr() % 16 == 0
+                      and self.wt[n].data_ptr() % 16 == 0)
+                if not ok:
+                    items = None
+                    break
+                items.append(_lib.TransposeItem(w.data_ptr(), self.wt[n].data_ptr(), w.stride(0), self.wt[n].stride(0), rows, cols,
+                                                first, tc))
+                block_item += [i] * (tr * tc)
+                first += tr * tc
+            if items is None:
+                self._wt_plan = False
+            else:
+                raw = (_lib.TransposeItem * len(items))(*items)
+                dev_items = torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev)
+                dev_map = torch.tensor(block_item, dtype=torch.int32, device=self.dev)
+                self._wt_plan = (dev_items, dev_map, first)
+        if self._wt_plan:
+            dev_items, dev_map, n_blocks = self._wt_plan
+            _lib.check(_lib.load().ma_transpose_batch_bf16(dev_items.data_ptr(), dev_map.data_ptr(), n_blocks,
+                                                           torch.cuda.current_stream().cuda_stream), "transpose_batch")
+        else:
+            for n in names:
+                if n not in self.wt:
+                    rows, cols = fp.w(n).shape
+                    self.wt[n] = torch.zeros((cols, K.pad64(rows)), dtype=torch.bfloat16, device=self.dev)
+                K.transpose(fp.w(n), out=self.wt[n])
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _salt(self, layer, site):

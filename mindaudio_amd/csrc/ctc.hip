@@ -37,6 +37,18 @@ __device__ __forceinline__ float log_add(float a, float b) {
   return m + log1pf(expf(fminf(a, b) - m));
 }
 
+// log(e^a + e^b [+ e^c]) of the recursions in one pass: three independent hardware exponentials and one logarithm (v_exp_f32 /
+// v_log_f32, ~1 ulp) instead of two dependent libm log1p(exp()) chains - the recursion is ONE wave per utterance, so a time step
+// costs the latency of its dependent instructions (0.85 us per step before).  log(sum) lies in [0, ln 3]: the absolute error per
+// step is ~1e-7, against losses of 1e2 .. 1e3.
+__device__ __forceinline__ float log_add3(float a, float b, float c, bool use_c) {
+  const float cc = use_c ? c : -INFINITY;
+  const float m = fmaxf(fmaxf(a, b), cc);
+  if (m == -INFINITY) return -INFINITY;
+  const float sum = __expf(a - m) + __expf(b - m) + __expf(cc - m);
+  return m + __logf(sum);
+}
+
 // one wave per row: lse[row] = log(sum_v exp(logits[row, v]))
 __global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ logits, int64_t ld, int64_t rows, int V,
                                                       float* __restrict__ lse) {
@@ -125,8 +137,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
       if (lane == 1) a2 = carry1;
       carry1 = last1;
       carry2 = last2;
-      float v = log_add(a0, a1);
-      if (skip[c]) v = log_add(v, a2);
+      const float v = log_add3(a0, a1, a2, skip[c]);
       const int s = c * 64 + lane;
       alpha[c] = (s < S) ? v + (e[c] - z) : -INFINITY;
       if (alpha_out && s < S) alpha_out[((int64_t)b * T + t) * Smax + s] = alpha[c];
@@ -228,8 +239,7 @@ __global__ __launch_bounds__(64) void ctc_beta_kernel(const float* __restrict__ 
         if (lane == 62) b2 = carry1;
         carry1 = first1;
         carry2 = first2;
-        v = log_add(b0, b1);
-        if (skip[c]) v = log_add(v, b2);
+        v = log_add3(b0, b1, b2, skip[c]);
       }
       nb[c] = (s < S) ? v + lp : -INFINITY;
       if (s < S) {

@@ -643,6 +643,100 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const AT* __restrict__ da
   }
 }
 
+// The same with 8 channels per thread (C % 8 == 0): thread (cg = tid & 31, pg = tid >> 5) owns channels 8 cg .. + 7 of every 8th
+// position of the strip: one 16-byte gradient load and 9 input samples per 72 multiply-adds (the kernel above: 1 two-byte load and
+// 9 samples per 9 - 479 us for the cfg-4 batch, load-issue bound); the 8 position groups meet through a row swap and LDS.
+__device__ __forceinline__ void ld8(const uint16_t* p, float (&d)[8]) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    d[2 * e] = __uint_as_float(w[e] << 16);
+    d[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void ld8(const float* p, float (&d)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+}
+template <typename AT>
+__global__ __launch_bounds__(256) void conv1_dw8_kernel(const AT* __restrict__ dact, const float* __restrict__ x, int B, int T,
+                                                        int idim, int H1, int W1, int C, const float* __restrict__ cm_mean,
+                                                        const float* __restrict__ cm_istd, float* __restrict__ part, int strip) {
+  __shared__ float red[4][32][81];  // [wave][channel group][8 channels x (9 taps + bias)] (+1: bank spread)
+  const int tid = threadIdx.x, cg = tid & 31, pg = tid >> 5;
+  const int c0 = cg * 8;
+  const bool live = c0 < C;
+  const int npos = B * H1 * W1;
+  const int p0 = blockIdx.x * strip, p1 = min(npos, p0 + strip);
+  float acc[8][9], accb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    accb[e] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[e][k] = 0.0f;
+  }
+  int pidx = p0 + pg;
+  int w1 = pidx % W1, tq = pidx / W1;
+  int h1 = tq % H1, b = tq / H1;
+  for (; pidx < p1; pidx += 8) {
+    float d[8];
+    if (live) ld8(dact + (int64_t)pidx * C + c0, d);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = 0.0f;
+    }
+    const float* xr = x + ((int64_t)b * T + 2 * h1) * idim + 2 * w1;
+    float xv[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        float v = xr[kh * idim + kw];
+        if (cm_mean) v = (v - cm_mean[2 * w1 + kw]) * cm_istd[2 * w1 + kw];
+        xv[kh * 3 + kw] = v;
+      }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      accb[e] += d[e];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[e][k] = fmaf(d[e], xv[k], acc[e][k]);
+    }
+    w1 += 8;
+    while (w1 >= W1) {
+      w1 -= W1;
+      if (++h1 == H1) { h1 = 0; ++b; }
+    }
+  }
+  // the two position groups of a wave (lanes l, l ^ 32), then the four waves through LDS
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[e][k] += __shfl_xor(acc[e][k], 32, 64);
+    accb[e] += __shfl_xor(accb[e], 32, 64);
+  }
+  if ((tid & 63) < 32) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) red[wave][cg][e * 10 + k] = acc[e][k];
+      red[wave][cg][e * 10 + 9] = accb[e];
+    }
+  }
+  __syncthreads();
+  // per-workgroup partial (dw (C, 9) | db (C)), as conv1_dw_kernel writes it
+  float* pp = part + (int64_t)blockIdx.x * ((int64_t)C * 10);
+  for (int i = tid; i < 32 * 80; i += 256) {
+    const int g = i / 80, r = i - g * 80, e = r / 10, k = r - e * 10;
+    const int c = g * 8 + e;
+    if (c >= C) continue;
+    const float v = (red[0][g][r] + red[1][g][r]) + (red[2][g][r] + red[3][g][r]);
+    if (k < 9) pp[c * 9 + k] = v;
+    else pp[C * 9 + c] = v;
+  }
+}
+
 // ---- float32 validation mode: the kernels above that move 16-byte bf16 vectors, restated element-wise on float ----------
 __global__ __launch_bounds__(256) void act_dropout_fwd_x32_kernel(const float* __restrict__ u, float* __restrict__ h, int64_t n,
                                                                   Drop d, int relu) {
@@ -1034,8 +1128,12 @@ static int conv1_dw_launch(const AT* dact, const float* x, int64_t batch, int64_
   int64_t strip64 = (npos + kMaxPartBlocks - 1) / kMaxPartBlocks;  // as many workgroups as the partial workspace holds
   const int strip = (int)(strip64 < 64 ? 64 : strip64);
   const int nblk = (int)((npos + strip - 1) / strip);
-  MA_LAUNCH(conv1_dw_kernel<AT>, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,
-            (hipStream_t)stream, dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, part, strip);
+  if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(dact) & 15) == 0)
+    MA_LAUNCH(conv1_dw8_kernel<AT>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dact, x, (int)batch, (int)T, idim, H1,
+              W1, C, cmvn_mean, cmvn_istd, part, strip);
+  else
+    MA_LAUNCH(conv1_dw_kernel<AT>, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,
+              (hipStream_t)stream, dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, part, strip);
   MA_LAUNCH(partial_reduce_kernel, dim3((C * 10 + 63) / 64, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, nblk, C * 10, dw,
             C * 9, db);
   return MA_OK;

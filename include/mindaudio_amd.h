@@ -420,6 +420,26 @@ int64_t ma_gemm_tn_workspace_bytes(int64_t Mo, int64_t No, int64_t Kc);
 int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, float* out, int64_t ldo, int64_t Mo,
                         int64_t No, int64_t Kc, int64_t Mo_store, float alpha, int32_t accumulate, float* colsum,
                         void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+/* The two halves of ma_gemm_tn_bf16_f32 apart, so that the split sums of many products leave in ONE launch (the training step:
+ * 8 weight gradients per block, each followed by a launch-bound 6.6 us reduction otherwise).
+ * ma_gemm_tn_partial_bf16 writes the split-K partial products [splits][Mo_store][No] float32 into `partial`
+ * (>= ma_gemm_tn_workspace_bytes(Mo, No, Kc) bytes; splits = that size / (Mo * No * 4)); colsum as above.
+ * ma_reduce_splits_batch_f32: items / block_item are DEVICE arrays; item i adds its `splits` partial matrices of `mn` elements in
+ * order and stores out[m][n] = (accumulate ? out : 0) + alpha * sum with row length N and row stride ldo; workgroup b handles
+ * elements [1024 (b - first_block), + 1024) of item block_item[b]. */
+typedef struct ma_reduce_item {
+  const float* part;
+  float* out;
+  int64_t mn, ldo;
+  int32_t N, splits;
+  float alpha;
+  int32_t accumulate;
+  int32_t first_block, reserved;
+} ma_reduce_item_t;
+int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t Mo, int64_t No, int64_t Kc,
+                            int64_t Mo_store, float* colsum, void* partial, int64_t partial_bytes, ma_stream_t stream);
+int ma_reduce_splits_batch_f32(const ma_reduce_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream);
+
 
 /* Weight gradient of the 3x3 stride-2 valid Conv2d of the subsampling layer (layers/subsampling.py:42) as the same TN
  * GEMM with an implicit im2col B operand: dw (Cout, 9C) float32 += dy^T . im2col(act), dbias (Cout) += column sums of dy.

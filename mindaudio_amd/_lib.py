@@ -51,6 +51,14 @@ class TransposeItem(ctypes.Structure):
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("first_block", ctypes.c_int32), ("tiles_c", ctypes.c_int32)]
 
 
+class ReduceItem(ctypes.Structure):
+    """struct ma_reduce_item (include/mindaudio_amd.h)."""
+
+    _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("mn", ctypes.c_int64), ("ldo", ctypes.c_int64),
+                ("N", ctypes.c_int32), ("splits", ctypes.c_int32), ("alpha", ctypes.c_float), ("accumulate", ctypes.c_int32),
+                ("first_block", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class GemmEpilogue(ctypes.Structure):
     """struct ma_gemm_epilogue (include/mindaudio_amd.h)."""
 
@@ -143,6 +151,8 @@ PROTOTYPES = {
     "ma_conv2d_3x3s2_dw_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp, i64, vp]),
     "ma_transpose_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
     "ma_transpose_batch_bf16": (ctypes.c_int, [vp, vp, i32, vp]),
+    "ma_gemm_tn_partial_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i64, i64, vp, vp, i64, vp]),
+    "ma_reduce_splits_batch_f32": (ctypes.c_int, [vp, vp, i32, vp]),
     "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp]),
     "ma_train_reduce_workspace_bytes": (i64, []),
     "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, i32, f32, u32, u32, vp]),

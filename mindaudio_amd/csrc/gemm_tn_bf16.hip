@@ -263,6 +263,42 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
+// The split sums of a list of products in one launch (ma_reduce_splits_batch_f32): workgroup b owns 1024 consecutive elements of
+// item block_item[b]; splits are added in the order k = 0 .. splits - 1.
+__global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ma_reduce_item_t* __restrict__ items,
+                                                              const int32_t* __restrict__ block_item) {
+  const ma_reduce_item_t it = items[block_item[blockIdx.x]];
+  const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x) * 4;
+  if (i0 >= it.mn) return;
+  if (!(it.N & 3) && !(it.ldo & 3) && !(it.mn & 3)) {  // 16-byte pieces: a piece never straddles a row
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = it.part + i0;
+#pragma unroll 4
+    for (int k = 0; k < it.splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)k * it.mn);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const int64_t m = i0 / it.N;
+    float4* o = reinterpret_cast<float4*>(it.out + m * it.ldo + (i0 - m * it.N));
+    float4 r = make_float4(it.alpha * sum.x, it.alpha * sum.y, it.alpha * sum.z, it.alpha * sum.w);
+    if (it.accumulate) {
+      const float4 old = *o;
+      r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+    }
+    *o = r;
+    return;
+  }
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = i0 + e;
+    if (i >= it.mn) return;
+    float sum = 0.0f;
+    for (int k = 0; k < it.splits; ++k) sum += it.part[(int64_t)k * it.mn + i];
+    const int64_t m = i / it.N;
+    float* o = it.out + m * it.ldo + (i - m * it.N);
+    *o = it.accumulate ? *o + it.alpha * sum : it.alpha * sum;
+  }
+}
+
 static int tn_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -294,7 +330,7 @@ using namespace ma;
 extern "C" {
 
 static int tn_launch(TnParams& p, bool im2col, float* out, int64_t ldo, float alpha, int accumulate, void* workspace,
-                     int64_t workspace_bytes, hipStream_t s) {
+                     int64_t workspace_bytes, hipStream_t s, bool reduce = true) {
   int bm = 64, kt = 0;
   const int splits = tn_plan(p.Mo, p.No, p.Kc, &bm, &kt);
   p.kt_split = kt;
@@ -317,6 +353,7 @@ static int tn_launch(TnParams& p, bool im2col, float* out, int64_t ldo, float al
   else if (im2col) MA_TN_GO(64, true)
   else MA_TN_GO(64, false)
 #undef MA_TN_GO
+  if (!reduce) return MA_OK;
   const int64_t mn = (int64_t)p.Mo_store * p.No;
   int64_t blocks = (mn + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -352,6 +389,34 @@ int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, 
   p.Kc = (int32_t)Kc;
   p.Mo_store = (int32_t)Mo_store;
   return tn_launch(p, false, out, ldo, alpha, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t Mo, int64_t No, int64_t Kc,
+                            int64_t Mo_store, float* colsum, void* partial, int64_t partial_bytes, ma_stream_t stream) {
+  if (!A || !B || !partial || Mo < 8 || No < 8 || Kc < 1 || Mo_store < 1 || Mo_store > Mo) return MA_ERR_INVALID_ARG;
+  if ((Mo & 7) || (No & 7) || (lda & 7) || (ldb & 7) || lda < Mo || ldb < No || Mo > 0x7fffffff || No > 0x7fffffff ||
+      Kc > 0x7fffffff)
+    return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(partial) & 15))
+    return MA_ERR_INVALID_ARG;
+  TnParams p = TnParams{};
+  p.A = reinterpret_cast<const uint16_t*>(A);
+  p.B = reinterpret_cast<const uint16_t*>(B);
+  p.part = reinterpret_cast<float*>(partial);
+  p.colsum = colsum;
+  p.lda = lda;
+  p.ldb = ldb;
+  p.Mo = (int32_t)Mo;
+  p.No = (int32_t)No;
+  p.Kc = (int32_t)Kc;
+  p.Mo_store = (int32_t)Mo_store;
+  return tn_launch(p, false, nullptr, 0, 1.0f, 0, partial, partial_bytes, (hipStream_t)stream, false);
+}
+
+int ma_reduce_splits_batch_f32(const ma_reduce_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream) {
+  if (!items || !block_item || n_blocks < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(tn_reduce_batch_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, items, block_item);
+  return MA_OK;
 }
 
 int ma_conv2d_3x3s2_dw_bf16(const void* dy, int64_t ld_dy, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,

@@ -78,6 +78,16 @@ def gemm_tn(a, b, out, colsum=None, rows_store=None, alpha=1.0, accumulate=True)
     return out
 
 
+def gemm_tn_partial(a, b, partial, colsum=None):
+    """The split-K partial products of gemm_tn into `partial` (a flat uint8 view of >= ma_gemm_tn_workspace_bytes bytes); the sums
+    are taken later by reduce_splits_batch."""
+    lib = _lib.load()
+    kc, mo = a.shape
+    no = b.shape[1]
+    _lib.check(lib.ma_gemm_tn_partial_bf16(_p(a), a.stride(0), _p(b), b.stride(0), mo, no, kc, mo, _p(colsum), _p(partial),
+                                           partial.numel(), _s()), "gemm_tn_partial")
+
+
 def conv2d_dw(dy, act, dw, dbias):
     """dw (Cout, 9C) f32 += dy^T @ im2col(act); dbias (Cout) += column sums.  dy (B*Ho*Wo, Cout) bf16, act NHWC bf16."""
     lib = _lib.load()

@@ -316,7 +316,9 @@ static int tn_plan(int64_t Mo, int64_t No, int64_t Kc, int* bm, int* kt_split) {
   *bm = big >= 64 ? 128 : 64;
   const int64_t tiles = ((Mo + *bm - 1) / *bm) * ((No + 127) / 128);
   const int64_t nk = (Kc + kTnBK - 1) / kTnBK;
-  int64_t splits = (2 * tn_cus() + tiles - 1) / tiles;
+  // as many splits as keep every workgroup in the first resident round (2 per CU): rounded DOWN - 72 tiles x 8 splits = 576
+  // workgroups ran the conv2 weight gradient as a full round plus one of 64 (710 us; 7 splits: one round)
+  int64_t splits = (2 * tn_cus()) / tiles;
   if (splits > nk / 8) splits = nk / 8;
   if (splits < 1) splits = 1;
   *kt_split = (int)((nk + splits - 1) / splits);

@@ -38,6 +38,61 @@ def test_transpose_and_colsum(K):
         assert rel(cs, x.float().sum(0)) < 1e-5
 
 
+def test_transpose_batch_and_batched_split_sums(K):
+    """The one-launch forms the training step uses: ma_transpose_batch_bf16 (a list of matrices, bit-exact copies) and
+    ma_gemm_tn_partial_bf16 + ma_reduce_splits_batch_f32 (split-K partials of several products, summed by one launch) against
+    the per-matrix entry points."""
+    import ctypes
+
+    from mindaudio_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def to_dev(items, ctype):
+        raw = (ctype * len(items))(*items)
+        return torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).cuda()
+
+    # ---- transposes ----
+    shapes = ((256, 2048), (768, 256), (4240, 256), (72, 136))
+    xs = [bf(torch.randn(r, c, generator=g)).cuda() for r, c in shapes]
+    outs = [torch.zeros((c, K.pad64(r)), dtype=torch.bfloat16, device="cuda") for r, c in shapes]
+    items, block_item, first = [], [], 0
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        r, c = x.shape
+        tr, tc = (r + 63) // 64, (c + 63) // 64
+        items.append(_lib.TransposeItem(x.data_ptr(), o.data_ptr(), x.stride(0), o.stride(0), r, c, first, tc))
+        block_item += [i] * (tr * tc)
+        first += tr * tc
+    d_items, d_map = to_dev(items, _lib.TransposeItem), torch.tensor(block_item, dtype=torch.int32, device="cuda")
+    _lib.check(lib.ma_transpose_batch_bf16(d_items.data_ptr(), d_map.data_ptr(), first, st), "tb")
+    for x, o in zip(xs, outs):
+        assert torch.equal(o[:, :x.shape[0]], x.t()) and float(o[:, x.shape[0]:].abs().sum()) == 0.0
+    # ---- split-K products: partials of two weight-gradient shapes, one reduction launch ----
+    kc = 3000
+    probs = ((512, 256), (256, 768))
+    arena, items, block_item, first, want, gouts = [], [], [], 0, [], []
+    for i, (mo, no) in enumerate(probs):
+        a, b = bf(torch.randn(kc, mo, generator=g)).cuda(), bf(torch.randn(kc, no, generator=g)).cuda()
+        nbytes = int(lib.ma_gemm_tn_workspace_bytes(mo, no, kc))
+        part = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        K.gemm_tn_partial(a, b, part)
+        base = torch.randn(mo, no, generator=g).cuda()
+        ref = base.clone()
+        K.gemm_tn(a, b, ref, alpha=0.5, accumulate=True)
+        out = base.clone()
+        nblk = (mo * no + 1023) // 1024
+        items.append(_lib.ReduceItem(part.data_ptr(), out.data_ptr(), mo * no, out.stride(0), no, nbytes // (mo * no * 4), 0.5, 1, first, 0))
+        block_item += [i] * nblk
+        first += nblk
+        arena.append(part); want.append(ref); gouts.append(out)
+    d_items, d_map = to_dev(items, _lib.ReduceItem), torch.tensor(block_item, dtype=torch.int32, device="cuda")
+    _lib.check(lib.ma_reduce_splits_batch_f32(d_items.data_ptr(), d_map.data_ptr(), first, st), "rb")
+    for out, ref in zip(gouts, want):
+        assert torch.equal(out, ref)  # same partials, same order of the splits
+
+
 def test_gemm_splitk(K):
     g = torch.Generator().manual_seed(1)
     for m, n, k in ((256, 256, 10240), (2048, 256, 4096), (100, 300, 640), (256, 2304, 64 * 300)):

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
 // z[b,t,c] = bias[c] + sum_j w[c][j] * glu(y)[b, t + j - pad, c] (zero outside [0, T)), float32; per-channel sums of z
 // and z^2 for the batch statistics.  Workgroup = (utterance, kCfPerBlock strips of 16 frames) x 256 channels (thread =
 // channel): glu of the strip + halo goes through LDS once (the sigmoid is evaluated once per element, not once per tap).
-constexpr int kCfStrip = 16, kCfPerBlock = 4;
+constexpr int kCfStrip = 16, kCfPerBlock = 2;  // (4: 160 workgroups for the cfg-4 batch, 40 us; 2: 320, 28 us; 1: 29 us)
 template <int KS, typename AT>
 __global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const AT* __restrict__ y, int64_t ldy, int T, int C,
                                                                 const float* __restrict__ w,

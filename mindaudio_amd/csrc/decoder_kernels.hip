@@ -190,8 +190,9 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
   extern __shared__ __attribute__((aligned(16))) char sm_lds[];
   uint16_t (*Ks)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);
   float (*S)[kSmK + 1] = reinterpret_cast<float (*)[kSmK + 1]>(sm_lds + kSmK * kSmD * 2);
-  float (*Qs)[kSmD + 1] = reinterpret_cast<float (*)[kSmD + 1]>(sm_lds + kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4);
-  float (*dOs)[kSmD + 1] = Qs + kSmQ;
+  // (rows of 64 + 4 floats, read as float4: see mha_small_fwd_kernel)
+  float (*Qs)[kSmD + 4] = reinterpret_cast<float (*)[kSmD + 4]>(sm_lds + kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4);
+  float (*dOs)[kSmD + 4] = Qs + kSmQ;
   float* Dq = reinterpret_cast<float*>(dOs + kSmQ);
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int Lq = p.Lq, Lk = p.Lk;
@@ -223,22 +224,42 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
     float vr[kSmD], dvr[kSmD], dkr[kSmD];
     const uint16_t* vp = p.v + ((int64_t)b * Lk + j) * p.ldv + h * kSmD;
 #pragma unroll
+    for (int c8 = 0; c8 < kSmD / 8; ++c8) {
+      const uint4 vv = *reinterpret_cast<const uint4*>(vp + c8 * 8);
+      const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vr[c8 * 8 + 2 * e] = __uint_as_float(w[e] << 16);
+        vr[c8 * 8 + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
     for (int d = 0; d < kSmD; ++d) {
-      vr[d] = d_bf2f(vp[d]);
       dvr[d] = 0.0f;
       dkr[d] = 0.0f;
     }
     for (int i = 0; i < Lq; ++i) {
-      float dp = 0.0f;
+      float dp0 = 0.0f, dp1 = 0.0f, dp2 = 0.0f, dp3 = 0.0f;
 #pragma unroll
-      for (int d = 0; d < kSmD; ++d) dp = fmaf(dOs[i][d], vr[d], dp);
+      for (int d = 0; d < kSmD; d += 4) {
+        const float4 o4 = *reinterpret_cast<const float4*>(&dOs[i][d]);
+        dp0 = fmaf(o4.x, vr[d], dp0);
+        dp1 = fmaf(o4.y, vr[d + 1], dp1);
+        dp2 = fmaf(o4.z, vr[d + 2], dp2);
+        dp3 = fmaf(o4.w, vr[d + 3], dp3);
+      }
+      const float dp = (dp0 + dp1) + (dp2 + dp3);
       const float pij = S[i][j];
       const float ds = pij * (dp - Dq[i]) * p.scale;
       S[i][j] = ds;
 #pragma unroll
-      for (int d = 0; d < kSmD; ++d) {
-        dvr[d] = fmaf(pij, dOs[i][d], dvr[d]);
-        dkr[d] = fmaf(ds, Qs[i][d], dkr[d]);
+      for (int d = 0; d < kSmD; d += 4) {
+        const float4 o4 = *reinterpret_cast<const float4*>(&dOs[i][d]);
+        const float4 q4 = *reinterpret_cast<const float4*>(&Qs[i][d]);
+        dvr[d] = fmaf(pij, o4.x, dvr[d]); dvr[d + 1] = fmaf(pij, o4.y, dvr[d + 1]);
+        dvr[d + 2] = fmaf(pij, o4.z, dvr[d + 2]); dvr[d + 3] = fmaf(pij, o4.w, dvr[d + 3]);
+        dkr[d] = fmaf(ds, q4.x, dkr[d]); dkr[d + 1] = fmaf(ds, q4.y, dkr[d + 1]);
+        dkr[d + 2] = fmaf(ds, q4.z, dkr[d + 2]); dkr[d + 3] = fmaf(ds, q4.w, dkr[d + 3]);
       }
     }
     uint16_t* dvp = dv + ((int64_t)b * Lk + j) * lddv + h * kSmD;
@@ -408,7 +429,7 @@ int ma_mha_small_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk
   const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, nullptr, 0, batch, Lq, Lk, heads, d_k, scale);
   if (rc != MA_OK) return rc;
   if (!probs || !ctx || !dctx || !dq || !dk || !dv || (lddq & 7) || (lddk & 1) || (lddv & 1)) return MA_ERR_INVALID_ARG;
-  constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 1) * 4 + kSmQ * 4;
+  constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -163,6 +163,70 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(const uint16_t* __restric
   }
 }
 
+// The same in ONE pass over the logits and x with 16-byte loads (C % 64 == 0, 16-byte aligned rows): thread (cg = tid & 7: 8
+// channels, ts = tid >> 3: every 32nd frame) keeps a running maximum and rescales its three sums when it moves (one exponential
+// per element: of the two factors exp(m - m') and exp(l - m') one is always 1); the 32 time slices meet through LDS.  (The kernel
+// above: two passes over the logits with 2-byte loads, 708 MB of fetches for C = 1536 - 10 % of the C = 512 forward.)
+__global__ __launch_bounds__(256) void asp_pool8_kernel(const uint16_t* __restrict__ logits, int64_t ldl, const uint16_t* __restrict__ x,
+                                                        int64_t ldx, int Tp, int H, int T, int C, float eps,
+                                                        const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                                                        uint16_t* __restrict__ out) {
+  __shared__ float red[4][32][64 + 1];
+  const int cg = threadIdx.x & 7, ts = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + cg * 8;
+  const int b = blockIdx.y;
+  const int64_t r0 = (int64_t)b * Tp + H;
+  float m[8], s0[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; s0[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+  for (int t = ts; t < T; t += 32) {
+    const uint4 lv = *reinterpret_cast<const uint4*>(logits + (r0 + t) * ldl + c0);
+    const uint4 xv = *reinterpret_cast<const uint4*>(x + (r0 + t) * ldx + c0);
+    const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float l = (e & 1) ? __uint_as_float(lw[e >> 1] & 0xffff0000u) : __uint_as_float(lw[e >> 1] << 16);
+      const float xe = (e & 1) ? __uint_as_float(xw[e >> 1] & 0xffff0000u) : __uint_as_float(xw[e >> 1] << 16);
+      const float d = l - m[e];                 // (first frame: +inf -> ex = 0, the empty sums are scaled by it)
+      const float ex = __expf(-fabsf(d));
+      const bool up = d > 0.0f;
+      const float sc = up ? ex : 1.0f, w = up ? 1.0f : ex;
+      m[e] = up ? l : m[e];
+      s0[e] = s0[e] * sc + w;
+      s1[e] = s1[e] * sc + w * xe;
+      s2[e] = s2[e] * sc + w * xe * xe;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[0][ts][cg * 8 + e] = m[e];
+    red[1][ts][cg * 8 + e] = s0[e];
+    red[2][ts][cg * 8 + e] = s1[e];
+    red[3][ts][cg * 8 + e] = s2[e];
+  }
+  __syncthreads();
+  const int cl = threadIdx.x;
+  if (cl < 64) {
+    const int c = blockIdx.x * 64 + cl;
+    float M = -INFINITY;
+    for (int k = 0; k < 32; ++k) M = fmaxf(M, red[0][k][cl]);
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f;
+    for (int k = 0; k < 32; ++k) {
+      const float mk = red[0][k][cl];
+      const float f = mk == -INFINITY ? 0.0f : __expf(mk - M);  // slices with no frame (T < 32)
+      S0 += f * red[1][k][cl];
+      S1 += f * red[2][k][cl];
+      S2 += f * red[3][k][cl];
+    }
+    const float mean = S1 / S0;
+    const float var = fmaxf(S2 / S0 - mean * mean, eps);
+    const float sd = sqrtf(var);
+    // cat((mean, std), 1) -> BatchNorm over 2C channels (ecapatdnn.py:306-308, 427)
+    out[(int64_t)b * 2 * C + c] = e_f2bf(mean * bn_scale[c] + bn_shift[c]);
+    out[(int64_t)b * 2 * C + C + c] = e_f2bf(sd * bn_scale[C + c] + bn_shift[C + c]);
+  }
+}
+
 static int e_grid(int64_t n, int cap = 8192) {
   int64_t g = (n + 255) / 256;
   return (int)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -215,9 +279,14 @@ int ma_asp_pool_bf16(const void* logits, int64_t ldl, const void* x, int64_t ldx
                      int32_t C, float eps, const float* bn_scale, const float* bn_shift, void* out, ma_stream_t stream) {
   if (!logits || !x || !bn_scale || !bn_shift || !out || batch < 1 || T < 1 || halo < 0 || C < 1 || batch > 65535)
     return MA_ERR_INVALID_ARG;
-  MA_LAUNCH(asp_pool_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
-            (const uint16_t*)logits, ldl, (const uint16_t*)x, ldx, (int)(T + 2 * halo), halo, (int)T, C, eps, bn_scale,
-            bn_shift, (uint16_t*)out);
+  if ((C & 63) == 0 && !(ldl & 7) && !(ldx & 7) && !((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(x)) & 15))
+    MA_LAUNCH(asp_pool8_kernel, dim3((unsigned)(C / 64), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+              (const uint16_t*)logits, ldl, (const uint16_t*)x, ldx, (int)(T + 2 * halo), halo, (int)T, C, eps, bn_scale,
+              bn_shift, (uint16_t*)out);
+  else
+    MA_LAUNCH(asp_pool_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+              (const uint16_t*)logits, ldl, (const uint16_t*)x, ldx, (int)(T + 2 * halo), halo, (int)T, C, eps, bn_scale,
+              bn_shift, (uint16_t*)out);
   return MA_OK;
 }
 

@@ -290,6 +290,23 @@ def test_kaldi_fbank_ragged_batch(ma, goldens):
         assert not out[i, want.shape[0]:].any()  # zero rows: pad_sequence padding (dataset.py:563-569)
 
 
+def test_kaldi_fbank_batch_with_utterances_shorter_than_a_frame(ma, goldens):
+    """Lengths below one 25 ms frame (and 0) give no frames: zero rows, frame count 0, and do not disturb their neighbours."""
+    from mindaudio_amd.conformer.dataset import compute_fbank_feats_batch
+
+    lens = [399, 12345, 0, 400]
+    wavs = np.full((len(lens), 12345), 777.0, np.float32)
+    wavs[1] = goldens["kaldi_synth_in_12345"]
+    wavs[3, :400] = goldens["kaldi_synth_in_400"]
+    out, frames = compute_fbank_feats_batch(wavs, lens)
+    out = out.cpu().numpy()
+    assert [int(f) for f in frames] == [0, goldens["kaldi_synth_out_12345"].shape[0], 0, 1]
+    assert not out[0].any() and not out[2].any()
+    _check_ln(out[1, :int(frames[1])], goldens["kaldi_synth_out_12345"])
+    _check_ln(out[3, :1], goldens["kaldi_synth_out_400"])
+    assert not out[3, 1:].any()
+
+
 # ---- full cfg-2 size: properties + sampled oracle rows ---------------------------------------
 def test_cfg2_full_size_properties(ma):
     import torch

@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ma_reduce_it
   const ma_reduce_item_t it = items[block_item[blockIdx.x]];
   const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x) * 4;
   if (i0 >= it.mn) return;
-  if (!(it.N & 3) && !(it.ldo & 3) && !(it.mn & 3)) {  // 16-byte pieces: a piece never straddles a row
+  if (!(it.N & 3) && !(it.ldo & 3) && !(it.mn & 3) &&
+      !((reinterpret_cast<uintptr_t>(it.out) | reinterpret_cast<uintptr_t>(it.part)) & 15)) {  // 16-byte pieces: a piece never straddles a row
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* src = it.part + i0;
 #pragma unroll 4

@@ -24,7 +24,10 @@
 extern "C" {
 #endif
 
-#define MA_ABI_VERSION 1
+/* Bumped whenever an existing entry point changes its argument list or is removed (new entry points alone do not bump it).
+ * 2: ma_fbank_kaldi_f32 gained `frames_out`; ma_ffn_bf16 / ma_ffn128_bf16 / ma_ffn_ln_bf16 / ma_layernorm*_add_f32 were removed
+ *    (round 2).  The Python binding refuses a library of another version (mindaudio_amd/_lib.py). */
+#define MA_ABI_VERSION 2
 
 typedef void* ma_stream_t; /* hipStream_t */
 
@@ -567,8 +570,9 @@ int ma_embed_posenc_f32(const int32_t* tokens, const float* table, const float* 
 int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_t D, int32_t V, float xscale, float p,
                      uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream);
 
-/* MultiHeadedAttention core (layers/attention.py:86-157) for Lq <= 32 queries and Lk <= 256 keys per (batch, head),
- * d_k = 64: ctx = softmax(scale * q k^T + (mask == 0 ? -10000 : 0)) v.  q (batch*Lq, H*64) / k, v (batch*Lk, H*64) bf16
+/* MultiHeadedAttention core (layers/attention.py:86-157) for Lq <= 32 queries and Lk <= 1088 keys per (batch, head)
+ * (up to 320 keys the V / K rows are staged in LDS; beyond that - the 1400 ... 3000-frame buckets of conformer.yaml, T' <= 749 -
+ * the score rows take the LDS and V / K are read from L2; more keys: MA_ERR_UNSUPPORTED), d_k = 64: ctx = softmax(scale * q k^T + (mask == 0 ? -10000 : 0)) v.  q (batch*Lq, H*64) / k, v (batch*Lk, H*64) bf16
  * with row strides; mask_mode 0 none, 1 (batch, 1, Lk), 2 (batch, Lq, Lk) float32; probs (batch, H, Lq, Lk) float32 is
  * written by the forward and read by the backward (dq, dk, dv bf16 with their own row strides). */
 int ma_mha_small_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
@@ -586,6 +590,12 @@ int ma_mha_small_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk
 int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
                                      const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
                                      float* stats, ma_stream_t stream);
+/* The same with `normalize_length=True` (label_smoothing_loss.py:106: the divisor is the number of unmasked tokens instead of
+ * the batch size): `denom` is a DEVICE float holding that count (the caller's sum of the mask - no host round trip);
+ * dlogits = grad_scale / *denom * mask * (softmax - true_dist), the loss is stats[0] / stats[2].  denom NULL = the form above. */
+int ma_label_smoothing_loss_grad_len_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
+                                         const float* mask, float smoothing, float grad_scale, const float* denom, void* dlogits,
+                                         int64_t ld_out, float* stats, ma_stream_t stream);
 
 /* ma_conv2d_3x3s2_nhwc_bf16 for the subsampling layer's second convolution (C = Cout = 256; layers/subsampling.py:40-45) on a
  * fragment-ordered packed copy of W (conv2_packed.hip): out (batch, Ho, Wo, 256) bf16 = [relu](bias + conv).

@@ -31,7 +31,8 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+        glob.glob(os.path.join(PKG, "..", "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -44,9 +45,14 @@ def build(force=False, verbose=False):
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     procs = []
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
+        glob.glob(os.path.join(PKG, "..", "include", "*.h"))
+    t_hdr = max(os.path.getmtime(h) for h in headers)
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), t_hdr):
+            continue  # this object is current: only edited sources (or everything, after a header edit) are recompiled
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
                "-c", src, "-o", obj]
         if verbose:

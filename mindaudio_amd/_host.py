@@ -84,17 +84,54 @@ def device_kaldi_window(frame_len, device):
 
 
 # ---- mel banks ------------------------------------------------------------------------------
-def htk_fbanks_f64(n_freqs, f_min, f_max, n_mels, sample_rate):
-    """MelScale(mel_type=HTK, norm=NONE) triangles, (n_freqs, n_mels) float64 (spectrum.py:686-694)."""
+def _hz_to_mel(f, mel_type):
+    """MelScale's two frequency warps (torchaudio `_hz_to_mel`, which MindSpore's audio ops mirror): HTK 2595 log10(1 + f/700);
+    Slaney = linear below 1 kHz (200/3 Hz per mel), logarithmic above (27 steps per factor 6.4)."""
+    f = np.asarray(f, dtype=np.float64)
+    if mel_type == "htk":
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+    f_sp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, math.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep, f / f_sp)
+
+
+def _mel_to_hz(m, mel_type):
+    m = np.asarray(m, dtype=np.float64)
+    if mel_type == "htk":
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    f_sp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_fbanks_f64(n_freqs, f_min, f_max, n_mels, sample_rate, norm="none", mel_type="htk"):
+    """MelScale(mel_type, norm) triangles, (n_freqs, n_mels) float64 (spectrum.py:625-626, 686-694).  norm="slaney" divides every
+    triangle by half its band width in Hz (area normalisation): fb[:, m] *= 2 / (f_{m+2} - f_m)."""
     all_freqs = np.linspace(0.0, float(sample_rate // 2), n_freqs)
-    m_lo = 2595.0 * math.log10(1.0 + f_min / 700.0)
-    m_hi = 2595.0 * math.log10(1.0 + f_max / 700.0)
-    f_pts = 700.0 * (10.0 ** (np.linspace(m_lo, m_hi, n_mels + 2) / 2595.0) - 1.0)
+    m_lo, m_hi = float(_hz_to_mel(f_min, mel_type)), float(_hz_to_mel(f_max, mel_type))
+    f_pts = _mel_to_hz(np.linspace(m_lo, m_hi, n_mels + 2), mel_type)
     f_diff = np.diff(f_pts)
     slopes = f_pts[None, :] - all_freqs[:, None]
     down = -slopes[:, :-2] / f_diff[:-1]
     up = slopes[:, 2:] / f_diff[1:]
-    return np.maximum(0.0, np.minimum(down, up))
+    fb = np.maximum(0.0, np.minimum(down, up))
+    if norm == "slaney":
+        fb = fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels]))[None, :]
+    return fb
+
+
+def htk_fbanks_f64(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """MelScale(mel_type=HTK, norm=NONE) triangles, (n_freqs, n_mels) float64 (spectrum.py:686-694)."""
+    return mel_fbanks_f64(n_freqs, f_min, f_max, n_mels, sample_rate, "none", "htk")
+
+
+def mel_enum(value, what):
+    """'slaney' / 'htk' / 'none' from a string or a MindSpore-style enum (`NormType.SLANEY`, `MelType.HTK`; spectrum.py:668-669)."""
+    name = str(getattr(value, "name", value)).lower().rsplit(".", 1)[-1]
+    allowed = ("none", "slaney") if what == "norm" else ("htk", "slaney")
+    if name not in allowed:
+        raise ValueError("%s must be one of %s, got %r" % (what, allowed, value))
+    return name
 
 
 def kaldi_banks_f64(num_bins, n_fft_padded, sample_freq, low_freq, high_freq):
@@ -176,10 +213,10 @@ class DeviceMelBank:
 _mel_cache = {}
 
 
-def device_htk_bank(n_fft, f_min, f_max, n_mels, sample_rate, device):
-    key = ("htk", n_fft, float(f_min), float(f_max), n_mels, sample_rate, str(device))
+def device_htk_bank(n_fft, f_min, f_max, n_mels, sample_rate, device, norm="none", mel_type="htk"):
+    key = ("mel", n_fft, float(f_min), float(f_max), n_mels, sample_rate, str(device), norm, mel_type)
     if key not in _mel_cache:
-        fb = htk_fbanks_f64(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
+        fb = mel_fbanks_f64(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm, mel_type)
         _mel_cache[key] = DeviceMelBank(fb.T, device)
     return _mel_cache[key]
 

@@ -8,6 +8,7 @@ import os
 
 from . import _build
 
+ABI_VERSION = 2  # MA_ABI_VERSION of include/mindaudio_amd.h this binding was written against (2: round-2 signature changes)
 MA_OK = 0
 MA_ERR_INVALID_ARG = -1
 MA_ERR_NFFT_TOO_LARGE = -2
@@ -184,6 +185,7 @@ PROTOTYPES = {
     "ma_mha_small_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32,
                                              vp, i64, vp, i64, vp, i64, vp]),
     "ma_label_smoothing_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, i64, vp, vp]),
+    "ma_label_smoothing_loss_grad_len_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, vp, i64, vp, vp]),
     "ma_resample_fft_length": (i64, [i64, i64]),
     "ma_resample_fft_workspace_bytes": (i64, [i64, i64, i64]),
     "ma_resample_fft_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, i64, vp, i64, vp]),
@@ -281,8 +283,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.ma_abi_version() != 1:
-        raise MindaudioAmdError("ABI version mismatch: library %d, binding 1" % lib.ma_abi_version())
+    if lib.ma_abi_version() != ABI_VERSION:
+        raise MindaudioAmdError("ABI version mismatch: library %d, binding %d" % (lib.ma_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

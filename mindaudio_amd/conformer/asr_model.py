@@ -51,10 +51,15 @@ class ASRModel(nn.Module):
         super().__init__()
         if ctc_weight != 1.0 and decoder is None:
             raise ValueError("ctc_weight != 1.0 needs a decoder (asr_model.py:327-337)")
-        if reverse_weight != 0.0 or length_normalized_loss:
-            raise NotImplementedError("reverse decoder / length-normalised loss are off in the shipped configuration")
+        if reverse_weight != 0.0:
+            # asr_model.py:175-178 weighs in a right-to-left decoder's loss, but the reference ships no such decoder:
+            # TransformerDecoder.construct returns a constant as r_decoder_out (models/conformer.py:606-639), so the
+            # reference itself fails on reverse_weight > 0.  Same here, with a message.
+            raise ValueError("reverse_weight > 0 needs a bidirectional decoder; the reference has none "
+                             "(models/conformer.py:620, 639)")
         self.vocab_size, self.encoder, self.ctc, self.ctc_weight = vocab_size, encoder, ctc, ctc_weight
         self.decoder, self.lsm_weight = decoder, lsm_weight
+        self.reverse_weight, self.length_normalized_loss = 0.0, bool(length_normalized_loss)
 
     @torch.no_grad()
     def forward(self, xs_pad, ys_pad, ys_in_pad=None, ys_out_pad=None, r_ys_in_pad=None, r_ys_out_pad=None,
@@ -86,11 +91,12 @@ class ASRModel(nn.Module):
         tgt = ys_out_pad.to(torch.int32).contiguous().reshape(-1)
         tmask = ys_masks.to(torch.float32).contiguous().reshape(-1)
         stats, _ = K.label_smoothing_loss_grad(logits, v, tgt, tmask, self.lsm_weight, 0.0)
-        return stats[0] / b, stats[1] / stats[2]
+        # label_smoothing_loss.py:105-106: divided by the token count when normalize_length, else by the batch size
+        return stats[0] / (stats[2] if self.length_normalized_loss else b), stats[1] / stats[2]
 
 
 def create_asr_model(input_dim, vocab_size, encoder_conf=None, global_cmvn=None, ctc_weight=1.0, decoder_conf=None,
-                     lsm_weight=0.0):
+                     lsm_weight=0.0, length_normalized_loss=False):
     """creadte_asr_model (asr_model.py:301-352): decoder None when ctc_weight == 1.0, else a TransformerDecoder."""
     from ..models.decoder import TransformerDecoder
 
@@ -99,7 +105,8 @@ def create_asr_model(input_dim, vocab_size, encoder_conf=None, global_cmvn=None,
     decoder = None
     if ctc_weight != 1.0:
         decoder = TransformerDecoder(vocab_size, encoder.output_size(), **(decoder_conf or {}))
-    return ASRModel(vocab_size, encoder, ctc, ctc_weight, decoder=decoder, lsm_weight=lsm_weight)
+    return ASRModel(vocab_size, encoder, ctc, ctc_weight, decoder=decoder, lsm_weight=lsm_weight,
+                    length_normalized_loss=length_normalized_loss)
 
 
 class ASREvalNet(nn.Module):

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
 
 // ---- small multi-head attention ----------------------------------------------------------------------------------
 constexpr int kSmQ = 32, kSmK = 320, kSmD = 64;
+constexpr int kSmKMax = 1088;  // keys when the score rows own the LDS (backward: 32 x 1089 floats + q / dO rows = 153 KiB)
 struct SmallAttn {
   const uint16_t *q, *k, *v;
   int64_t ldq, ldk, ldv;
@@ -83,27 +84,33 @@ struct SmallAttn {
   float scale;
 };
 
-// workgroup = (head, batch): thread j owns key j for the scores, (query, 8 d's) for the context
+// workgroup = (head, batch): thread j owns key j (and j + 256, ...) for the scores, (query, 8 d's) for the context.
+// STAGE: the V rows of the (batch, head) are staged in LDS (Lk <= kSmK, the label-length self-attention and source attention over
+// up to 320 encoder frames); otherwise (source attention over a long utterance: the 3000-frame bucket of conformer.yaml gives
+// T' = 749) the score rows take the whole LDS (`kcap` = Lk rounded up to 64 columns) and the V rows are read from L2.
+template <bool STAGE>
 __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, uint16_t* __restrict__ ctx, int64_t ldc,
-                                                            float* __restrict__ probs) {
+                                                            float* __restrict__ probs, int kcap) {
   extern __shared__ __attribute__((aligned(16))) char sm_lds[];
-  uint16_t (*Vs)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);                                  // 32 KiB
-  float (*S)[kSmK + 1] = reinterpret_cast<float (*)[kSmK + 1]>(sm_lds + kSmK * kSmD * 2);               // 32.1 KiB
+  const int ss = kcap + 1;                                                                             // score row stride
+  uint16_t (*Vs)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);                                  // 32 KiB (STAGE)
+  float* S = reinterpret_cast<float*>(sm_lds + (STAGE ? kcap * kSmD * 2 : 0));                           // 32 x (kcap + 1)
   // (query rows of 64 + 4 floats: 16-byte aligned, read as float4 - with single-float reads the score loop was 2000 LDS
   // instructions per thread, 27 of the launch's 45 us)
-  float (*Qs)[kSmD + 4] = reinterpret_cast<float (*)[kSmD + 4]>(sm_lds + kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4);
+  float (*Qs)[kSmD + 4] = reinterpret_cast<float (*)[kSmD + 4]>(S + kSmQ * ss);
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int Lq = p.Lq, Lk = p.Lk;
   for (int i = tid; i < kSmQ * kSmD; i += 256) {
     const int qi = i / kSmD, d = i % kSmD;
     Qs[qi][d] = qi < Lq ? d_bf2f(p.q[((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d]) : 0.0f;
   }
-  for (int i = tid; i < kSmK * (kSmD / 8); i += 256) {
-    const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (kj < Lk) val = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + ch * 8);
-    *reinterpret_cast<uint4*>(&Vs[kj][ch * 8]) = val;
-  }
+  if (STAGE)
+    for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
+      const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (kj < Lk) val = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + ch * 8);
+      *reinterpret_cast<uint4*>(&Vs[kj][ch * 8]) = val;
+    }
   __syncthreads();
   for (int j = tid; j < Lk; j += 256) {
     float kr[kSmD];
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, u
       s *= p.scale;
       if (p.mask_mode == 1 && p.mask[(int64_t)b * Lk + j] == 0.0f) s += -10000.0f;
       if (p.mask_mode == 2 && p.mask[((int64_t)b * Lq + i) * Lk + j] == 0.0f) s += -10000.0f;
-      S[i][j] = s;
+      S[i * ss + j] = s;
     }
   }
   __syncthreads();
@@ -140,13 +147,13 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, u
   const int lane = tid & 63, wave = tid >> 6;
   for (int i = wave; i < Lq; i += 4) {
     float m = -INFINITY;
-    for (int jj = lane; jj < Lk; jj += 64) m = fmaxf(m, S[i][jj]);
+    for (int jj = lane; jj < Lk; jj += 64) m = fmaxf(m, S[i * ss + jj]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     float sum = 0.0f;
     for (int jj = lane; jj < Lk; jj += 64) {
-      const float e = __expf(S[i][jj] - m);
-      S[i][jj] = e;
+      const float e = __expf(S[i * ss + jj] - m);
+      S[i * ss + jj] = e;
       sum += e;
     }
 #pragma unroll
@@ -154,8 +161,8 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, u
     const float inv = 1.0f / sum;
     float* pr = probs + (((int64_t)b * p.H + h) * Lq + i) * Lk;
     for (int jj = lane; jj < Lk; jj += 64) {
-      const float pv = S[i][jj] * inv;
-      S[i][jj] = pv;
+      const float pv = S[i * ss + jj] * inv;
+      S[i * ss + jj] = pv;
       pr[jj] = pv;
     }
   }
@@ -164,8 +171,9 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, u
   if (qi < Lq) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int jj = 0; jj < Lk; ++jj) {
-      const float pv = S[qi][jj];
-      const uint4 vv = *reinterpret_cast<const uint4*>(&Vs[jj][dg]);
+      const float pv = S[qi * ss + jj];
+      const uint4 vv = STAGE ? *reinterpret_cast<const uint4*>(&Vs[jj][dg])
+                             : *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + jj) * p.ldv + h * kSmD + dg);
       const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -182,16 +190,18 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, u
 
 // Backward: D_i = dO_i . O_i; thread j: dP_ij = dO_i . v_j, dS_ij = P_ij (dP_ij - D_i), dv_j = sum_i P_ij dO_i,
 // dk_j = scale sum_i dS_ij q_i; then thread (i, 8 d's): dq_i = scale sum_j dS_ij k_j.
+template <bool STAGE>
 __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, const float* __restrict__ probs,
                                                             const uint16_t* __restrict__ ctx, int64_t ldc,
                                                             const uint16_t* __restrict__ dctx, int64_t lddc,
                                                             uint16_t* __restrict__ dq, int64_t lddq, uint16_t* __restrict__ dk,
-                                                            int64_t lddk, uint16_t* __restrict__ dv, int64_t lddv) {
+                                                            int64_t lddk, uint16_t* __restrict__ dv, int64_t lddv, int kcap) {
   extern __shared__ __attribute__((aligned(16))) char sm_lds[];
-  uint16_t (*Ks)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);
-  float (*S)[kSmK + 1] = reinterpret_cast<float (*)[kSmK + 1]>(sm_lds + kSmK * kSmD * 2);
+  const int ss = kcap + 1;
+  uint16_t (*Ks)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);                                  // STAGE only
+  float* S = reinterpret_cast<float*>(sm_lds + (STAGE ? kcap * kSmD * 2 : 0));
   // (rows of 64 + 4 floats, read as float4: see mha_small_fwd_kernel)
-  float (*Qs)[kSmD + 4] = reinterpret_cast<float (*)[kSmD + 4]>(sm_lds + kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4);
+  float (*Qs)[kSmD + 4] = reinterpret_cast<float (*)[kSmD + 4]>(S + kSmQ * ss);
   float (*dOs)[kSmD + 4] = Qs + kSmQ;
   float* Dq = reinterpret_cast<float*>(dOs + kSmQ);
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -202,15 +212,16 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
     Qs[qi][d] = in ? d_bf2f(p.q[((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d]) : 0.0f;
     dOs[qi][d] = in ? d_bf2f(dctx[((int64_t)b * Lq + qi) * lddc + h * kSmD + d]) : 0.0f;
   }
-  for (int i = tid; i < kSmK * (kSmD / 8); i += 256) {
-    const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (kj < Lk) val = *reinterpret_cast<const uint4*>(p.k + ((int64_t)b * Lk + kj) * p.ldk + h * kSmD + ch * 8);
-    *reinterpret_cast<uint4*>(&Ks[kj][ch * 8]) = val;
-  }
+  if (STAGE)
+    for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
+      const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (kj < Lk) val = *reinterpret_cast<const uint4*>(p.k + ((int64_t)b * Lk + kj) * p.ldk + h * kSmD + ch * 8);
+      *reinterpret_cast<uint4*>(&Ks[kj][ch * 8]) = val;
+    }
   for (int i = tid; i < Lq * Lk; i += 256) {
     const int qi = i / Lk, jj = i - qi * Lk;
-    S[qi][jj] = probs[(((int64_t)b * p.H + h) * Lq + qi) * Lk + jj];
+    S[qi * ss + jj] = probs[(((int64_t)b * p.H + h) * Lq + qi) * Lk + jj];
   }
   __syncthreads();
   if (tid < Lq) {
@@ -249,9 +260,9 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
         dp3 = fmaf(o4.w, vr[d + 3], dp3);
       }
       const float dp = (dp0 + dp1) + (dp2 + dp3);
-      const float pij = S[i][j];
+      const float pij = S[i * ss + j];
       const float ds = pij * (dp - Dq[i]) * p.scale;
-      S[i][j] = ds;
+      S[i * ss + j] = ds;
 #pragma unroll
       for (int d = 0; d < kSmD; d += 4) {
         const float4 o4 = *reinterpret_cast<const float4*>(&dOs[i][d]);
@@ -275,8 +286,9 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
   if (qi < Lq) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int jj = 0; jj < Lk; ++jj) {
-      const float ds = S[qi][jj];
-      const uint4 kv = *reinterpret_cast<const uint4*>(&Ks[jj][dg]);
+      const float ds = S[qi * ss + jj];
+      const uint4 kv = STAGE ? *reinterpret_cast<const uint4*>(&Ks[jj][dg])
+                             : *reinterpret_cast<const uint4*>(p.k + ((int64_t)b * Lk + jj) * p.ldk + h * kSmD + dg);
       const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -297,6 +309,7 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
 __global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __restrict__ logits, int64_t ld, int V,
                                                               const int32_t* __restrict__ target, const float* __restrict__ mask,
                                                               float on, float off, float ent, float scale,
+                                                              const float* __restrict__ denom,
                                                               uint16_t* __restrict__ dlogits, int64_t ldo, float* stats) {
   __shared__ float red[4];
   __shared__ int redi[4];
@@ -309,6 +322,7 @@ __global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __res
     for (int v = threadIdx.x; v < ldo; v += 256) o[v] = 0;
     return;
   }
+  if (denom) scale /= *denom;  // normalize_length (label_smoothing_loss.py:106)
   int tg = target[row];
   tg = tg < 0 ? 0 : tg;  // target * mask: "avoid -1 index" (label_smoothing_loss.py:100-102)
   float m = -INFINITY;
@@ -392,7 +406,7 @@ static int fill_small(SmallAttn& a, const void* q, int64_t ldq, const void* k, i
                       const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k,
                       float scale) {
   if (!q || !k || !v || batch < 1 || Lq < 1 || Lk < 1 || heads < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
-  if (d_k != kSmD || Lq > kSmQ || Lk > kSmK || (ldk & 7) || (ldv & 7)) return MA_ERR_UNSUPPORTED;
+  if (d_k != kSmD || Lq > kSmQ || Lk > kSmKMax || (ldk & 7) || (ldv & 7)) return MA_ERR_UNSUPPORTED;
   if (mask_mode < 0 || mask_mode > 2 || (mask_mode && !mask)) return MA_ERR_INVALID_ARG;
   a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
@@ -408,16 +422,25 @@ int ma_mha_small_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk
   const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, mask, mask_mode, batch, Lq, Lk, heads, d_k, scale);
   if (rc != MA_OK) return rc;
   if (!ctx || !probs || (ldc & 7)) return MA_ERR_INVALID_ARG;
-  constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * (kSmD + 4) * 4;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            163840) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            163840) != hipSuccess)
       return MA_ERR_LAUNCH;
     attr = true;
   }
-  MA_LAUNCH(mha_small_fwd_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
-            (uint16_t*)ctx, ldc, probs);
+  if (Lk <= kSmK) {
+    constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * (kSmD + 4) * 4;
+    MA_LAUNCH(mha_small_fwd_kernel<true>, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
+              (uint16_t*)ctx, ldc, probs, kSmK);
+  } else {
+    const int kcap = (Lk + 63) / 64 * 64;
+    const int lds = kSmQ * (kcap + 1) * 4 + kSmQ * (kSmD + 4) * 4;
+    MA_LAUNCH(mha_small_fwd_kernel<false>, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
+              (uint16_t*)ctx, ldc, probs, kcap);
+  }
   return MA_OK;
 }
 
@@ -429,23 +452,33 @@ int ma_mha_small_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk
   const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, nullptr, 0, batch, Lq, Lk, heads, d_k, scale);
   if (rc != MA_OK) return rc;
   if (!probs || !ctx || !dctx || !dq || !dk || !dv || (lddq & 7) || (lddk & 1) || (lddv & 1)) return MA_ERR_INVALID_ARG;
-  constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            163840) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            163840) != hipSuccess)
       return MA_ERR_LAUNCH;
     attr = true;
   }
-  MA_LAUNCH(mha_small_bwd_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
-            (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv,
-            lddv);
+  if (Lk <= kSmK) {
+    constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
+    MA_LAUNCH(mha_small_bwd_kernel<true>, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
+              (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv,
+              lddv, kSmK);
+  } else {
+    const int kcap = (Lk + 63) / 64 * 64;
+    const int lds = kSmQ * (kcap + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
+    MA_LAUNCH(mha_small_bwd_kernel<false>, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
+              (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv,
+              lddv, kcap);
+  }
   return MA_OK;
 }
 
-int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
-                                     const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
-                                     float* stats, ma_stream_t stream) {
+int ma_label_smoothing_loss_grad_len_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
+                                         const float* mask, float smoothing, float grad_scale, const float* denom, void* dlogits,
+                                         int64_t ld_out, float* stats, ma_stream_t stream) {
   if (!logits || !target || !mask || !dlogits || !stats || rows < 1 || V < 2 || ld < V || ld_out < V) return MA_ERR_INVALID_ARG;
   if (smoothing < 0.0f || smoothing >= 1.0f) return MA_ERR_INVALID_ARG;
   const float on = 1.0f - smoothing, off = smoothing / (float)(V - 1);
@@ -453,8 +486,15 @@ int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t ro
   float ent = on * logf(on);
   if (off > 0.0f) ent += (float)(V - 1) * off * logf(off);
   MA_LAUNCH(label_smoothing_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, target, mask, on,
-            off, ent, grad_scale, (uint16_t*)dlogits, ld_out, stats);
+            off, ent, grad_scale, denom, (uint16_t*)dlogits, ld_out, stats);
   return MA_OK;
+}
+
+int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
+                                     const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
+                                     float* stats, ma_stream_t stream) {
+  return ma_label_smoothing_loss_grad_len_f32(logits, ld, rows, V, target, mask, smoothing, grad_scale, nullptr, dlogits, ld_out,
+                                              stats, stream);
 }
 
 }  // extern "C"

@@ -130,14 +130,16 @@ def istft(stft_matrix, n_fft=None, win_length=None, hop_length=None, window="han
     return out.cpu().numpy().astype(np.float64) if was_numpy else out
 
 
-def _mel_args(n_fft, win_length, hop_length, window, center, pad_mode, n_mels, sample_rate, f_min, f_max, device):
+def _mel_args(n_fft, win_length, hop_length, window, center, pad_mode, n_mels, sample_rate, f_min, f_max, device,
+              norm="none", mel_type="htk"):
     win_length = win_length if win_length is not None else n_fft  # spectrum.py:665
     hop_length = hop_length if hop_length is not None else win_length // 2  # spectrum.py:666
     f_max = f_max if f_max is not None else sample_rate // 2  # spectrum.py:770 / MelScale default
     if pad_mode not in _lib.PAD_MODES:
         raise ValueError("unsupported pad_mode %r" % (pad_mode,))
     win = _host.device_window(window, win_length, n_fft, device)
-    bank = _host.device_htk_bank(n_fft, float(f_min), float(f_max), int(n_mels), int(sample_rate), device)
+    bank = _host.device_htk_bank(n_fft, float(f_min), float(f_max), int(n_mels), int(sample_rate), device,
+                                 _host.mel_enum(norm, "norm"), _host.mel_enum(mel_type, "mel_type"))
     return win_length, hop_length, win, bank
 
 
@@ -147,16 +149,14 @@ def melspectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0
     """Mel-scaled spectrogram — signature of spectrum.py:609-627 (norm/mel_type as strings)."""
     t = _host.require_gpu()
     lib = _lib.load()
-    if normalized or not onesided or str(norm).lower() not in ("none", "normtype.none") \
-            or str(mel_type).lower() not in ("htk", "meltype.htk"):
-        raise NotImplementedError("only normalized=False, onesided=True, norm='none', mel_type='htk' are on the "
-                                  "hot path (SURVEY §8 row a3)")
+    if normalized or not onesided:
+        raise NotImplementedError("only normalized=False, onesided=True are on the hot path (SURVEY §8 row a3)")
     x, lead, was_numpy = _host.to_device_2d(waveforms)
     if pad > 0:
         x = t.nn.functional.pad(x, (pad, pad))
     n = x.shape[-1]
     win_length, hop_length, win, bank = _mel_args(n_fft, win_length, hop_length, window, center, pad_mode, n_mels,
-                                                  sample_rate, f_min, f_max, x.device)
+                                                  sample_rate, f_min, f_max, x.device, norm, mel_type)
     n_frames = lib.ma_num_frames(n, n_fft, hop_length, int(bool(center)))
     _lib.check(min(n_frames, 0), "melspectrogram")
     out = t.empty((x.shape[0], n_mels, n_frames), dtype=t.float32, device=x.device)

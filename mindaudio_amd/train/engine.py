@@ -206,6 +206,7 @@ class ConformerCTCTrainStep:
         self.dec = getattr(model, "decoder", None)
         self.ctc_weight = float(model.ctc_weight)
         self.lsm = float(getattr(model, "lsm_weight", 0.0))
+        self.len_norm = bool(getattr(model, "length_normalized_loss", False))
         if self.ctc_weight != 1.0 and self.dec is None:
             raise ValueError("ctc_weight != 1.0 needs model.decoder")
         if self.x32 and self.dec is not None:
@@ -563,8 +564,10 @@ class ConformerCTCTrainStep:
         if self.dec is not None:  # attention branch: loss = w * ctc + (1 - w) * att (asr_model.py:138-139)
             if ys_in_pad is None or ys_out_pad is None or ys_sub_masks is None or ys_masks is None:
                 raise ValueError("the hybrid loss needs ys_in_pad, ys_out_pad, ys_sub_masks and ys_masks")
+            # label_smoothing_loss.py:105-106: / batch, or / tokens (divided on the device) when length_normalized_loss
             loss_att, d_mem = self._decoder_forward_backward(enc_bf, mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks,
-                                                             ys_masks, grad_scale * (1.0 - wc) / b, seed)
+                                                             ys_masks, grad_scale * (1.0 - wc) / (1.0 if self.len_norm else b),
+                                                             seed)
             self.last_loss_ctc, self.last_loss_att = loss, loss_att
             loss = wc * loss + (1.0 - wc) * loss_att
 
@@ -672,8 +675,8 @@ class ConformerCTCTrainStep:
         ops.gemm(yb, fp.w("dec.out_w"), bias=fp.p("dec.out_b"), out_dtype=f32, out=logits[:, :self.V])
         tgt = ys_out_pad.to(torch.int32).contiguous().reshape(-1)
         tmask = ys_masks.to(f32).contiguous().reshape(-1)
-        stats, dlog = K.label_smoothing_loss_grad(logits, self.V, tgt, tmask, self.lsm, gscale)
-        loss_att = stats[0] / b
+        stats, dlog = K.label_smoothing_loss_grad(logits, self.V, tgt, tmask, self.lsm, gscale, normalize_length=self.len_norm)
+        loss_att = stats[0] / (stats[2] if self.len_norm else b)
         self.last_acc = stats[1] / stats[2]
         # ---- backward ----
         K.gemm_tn(dlog, yb, fp.g("dec.out_w"), colsum=fp.g("dec.out_b"), rows_store=self.V)

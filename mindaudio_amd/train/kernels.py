@@ -155,15 +155,17 @@ def mha_small_bwd(q, k, v, probs, ctx, dctx, batch, lq, lk, scale, dq, dk, dv, h
                                                  dv.stride(0), _s()), "mha_small_bwd")
 
 
-def label_smoothing_loss_grad(logits, V, target, mask, smoothing, grad_scale):
-    """-> (stats (3,) f32 = [sum kl, correct, tokens], dlogits (rows, ld) bf16)."""
+def label_smoothing_loss_grad(logits, V, target, mask, smoothing, grad_scale, normalize_length=False):
+    """-> (stats (3,) f32 = [sum kl, correct, tokens], dlogits (rows, ld) bf16).  normalize_length: the gradient is divided by the
+    number of unmasked tokens (a device-side sum of `mask`) instead of what the caller folded into grad_scale."""
     t = _t()
     rows = logits.shape[0]
     stats = t.zeros(3, dtype=t.float32, device=logits.device)
     dlog = t.empty((rows, logits.stride(0)), dtype=t.bfloat16, device=logits.device)
-    _lib.check(_lib.load().ma_label_smoothing_loss_grad_f32(_p(logits), logits.stride(0), rows, V, _p(target), _p(mask),
-                                                            float(smoothing), float(grad_scale), _p(dlog), dlog.stride(0),
-                                                            _p(stats), _s()), "label_smoothing")
+    denom = mask.sum().reshape(1).to(t.float32) if normalize_length else None
+    _lib.check(_lib.load().ma_label_smoothing_loss_grad_len_f32(_p(logits), logits.stride(0), rows, V, _p(target), _p(mask),
+                                                                float(smoothing), float(grad_scale), _p(denom), _p(dlog),
+                                                                dlog.stride(0), _p(stats), _s()), "label_smoothing")
     return stats, dlog
 
 

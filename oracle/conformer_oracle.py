@@ -345,14 +345,14 @@ def th_accuracy(pad_outputs, pad_targets, ys_masks):
     return ((pred == pad_targets).to(torch.float32) * m).sum() / m.sum()
 
 
-def hybrid_loss(encoder, ctc, decoder, batch, ctc_weight=0.3, lsm_weight=0.1):
+def hybrid_loss(encoder, ctc, decoder, batch, ctc_weight=0.3, lsm_weight=0.1, length_normalized_loss=False):
     """ASRModelWithAcc.construct (asr_model.py:75-153) with reverse_weight 0: returns (loss, acc_att, loss_ctc, loss_att).
-    `batch` = the 11 collate columns."""
+    `batch` = the 11 collate columns; length_normalized_loss = LabelSmoothingLoss(normalize_length=...) (asr_model.py:57-62)."""
     xs_pad, ys_pad, ys_in_pad, ys_out_pad, _, _, xs_masks, ys_sub_masks, ys_masks, ys_lengths, xs_chunk_masks = batch
     enc, enc_mask = encoder(xs_pad, xs_masks, xs_chunk_masks)
     hlens = enc_mask.reshape(enc_mask.shape[0], -1).sum(1).to(torch.int32)
     loss_ctc = ctc(enc, hlens, ys_pad.clamp(min=0).long(), ys_lengths.long())
     dec_out = decoder(enc, enc_mask, ys_in_pad.long(), ys_sub_masks)
-    loss_att = label_smoothing_loss(dec_out, ys_out_pad, ys_masks, lsm_weight)
+    loss_att = label_smoothing_loss(dec_out, ys_out_pad, ys_masks, lsm_weight, length_normalized_loss)
     acc = th_accuracy(dec_out, ys_out_pad, ys_masks)
     return ctc_weight * loss_ctc + (1 - ctc_weight) * loss_att, acc, loss_ctc, loss_att

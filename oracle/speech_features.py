@@ -208,19 +208,38 @@ def mel_to_hz_htk(m):
     return 700.0 * (10.0 ** (np.asarray(m, dtype=np.float64) / 2595.0) - 1.0)
 
 
-def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
-    """HTK triangular filterbank, norm=None, shape (n_freqs, n_mels).
+def hz_to_mel_slaney(f):
+    """Slaney (Auditory Toolbox) warp, as torchaudio `_hz_to_mel(mel_scale="slaney")` which MindSpore's MelScale mirrors:
+    linear below 1 kHz at 200/3 Hz per mel, logarithmic above with 27 mels per factor 6.4."""
+    f = np.asarray(f, dtype=np.float64)
+    lin = 3.0 * f / 200.0
+    log = 15.0 + 27.0 * np.log(np.maximum(f, 1e-300) / 1000.0) / np.log(6.4)
+    return np.where(f >= 1000.0, log, lin)
+
+
+def mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * 6.4 ** ((m - 15.0) / 27.0), 200.0 * m / 3.0)
+
+
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm="none", mel_type="htk"):
+    """Triangular filterbank, shape (n_freqs, n_mels); defaults HTK / norm=None (spectrum.py:625-626).
     fb[f, m] = max(0, min((f - f_m)/(f_{m+1}-f_m), (f_{m+2} - f)/(f_{m+2}-f_{m+1})))
     with all_freqs = linspace(0, sample_rate // 2, n_freqs) (SURVEY row a3;
-    call site spectrum.py:686-694)."""
+    call site spectrum.py:686-694).  norm="slaney": column m times 2 / (f_{m+2} - f_m)."""
+    to_mel, to_hz = (hz_to_mel_htk, mel_to_hz_htk) if mel_type == "htk" else (hz_to_mel_slaney, mel_to_hz_slaney)
     all_freqs = np.linspace(0.0, float(sample_rate // 2), n_freqs)
-    m_pts = np.linspace(hz_to_mel_htk(f_min), hz_to_mel_htk(f_max), n_mels + 2)
-    f_pts = mel_to_hz_htk(m_pts)
+    m_pts = np.linspace(to_mel(f_min), to_mel(f_max), n_mels + 2)
+    f_pts = to_hz(m_pts)
     f_diff = f_pts[1:] - f_pts[:-1]
     slopes = f_pts[None, :] - all_freqs[:, None]  # (n_freqs, n_mels+2)
     down = -slopes[:, :-2] / f_diff[:-1]
     up = slopes[:, 2:] / f_diff[1:]
-    return np.maximum(0.0, np.minimum(down, up))
+    fb = np.maximum(0.0, np.minimum(down, up))
+    if norm == "slaney":
+        for m in range(n_mels):
+            fb[:, m] *= 2.0 / (f_pts[m + 2] - f_pts[m])
+    return fb
 
 
 def spectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0, window="hann",
@@ -246,14 +265,14 @@ def spectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0, w
 
 def melspectrogram(waveforms, n_fft=400, win_length=None, hop_length=None, pad=0, window="hann",
                    power=2.0, normalized=False, center=True, pad_mode="reflect", onesided=True,
-                   n_mels=128, sample_rate=16000, f_min=0, f_max=None):
+                   n_mels=128, sample_rate=16000, f_min=0, f_max=None, norm="none", mel_type="htk"):
     """spectrum.py:609-698 (hop default win_length // 2, :666)."""
     win_length = win_length if win_length is not None else n_fft
     hop_length = hop_length if hop_length is not None else win_length // 2
     f_max = f_max if f_max is not None else sample_rate // 2
     spec = spectrogram(waveforms, n_fft, win_length, hop_length, pad, window, power, normalized,
                        center, pad_mode, onesided)
-    fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
+    fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate, norm, mel_type)
     return np.einsum("fm,...ft->...mt", fb, spec)
 
 

@@ -277,16 +277,18 @@ def test_encoder_accepts_strided_features():
     assert not view.is_contiguous() and torch.equal(a, b)
 
 
-def test_asr_model_hybrid_eval_loss_and_decoder_scores_match_oracle():
+@pytest.mark.parametrize("tlen", [163, 3000])
+def test_asr_model_hybrid_eval_loss_and_decoder_scores_match_oracle(tlen):
     """create_asr_eval_net of the shipped conformer.yaml (ctc_weight 0.3, TransformerDecoder, label smoothing 0.1;
-    asr_model.py:75-209, 355-371): decoder scores, attention loss, accuracy and the mixed loss vs the float32 oracle."""
+    asr_model.py:75-209, 355-371): decoder scores, attention loss, accuracy and the mixed loss vs the float32 oracle.
+    tlen = 3000 is the largest frame bucket of conformer.yaml (T' = 749 source positions for the decoder's attention)."""
     import torch
 
     from mindaudio_amd.conformer.asr_model import create_asr_model
     from oracle import conformer_oracle as C
 
     torch.manual_seed(23)
-    vocab, blocks, dblocks, b, tlen, lmax = 211, 2, 2, 3, 163, 9
+    vocab, blocks, dblocks, b, lmax = 211, 2, 2, 3, 9
     ref_enc = C.ConformerEncoder(80, 256, 4, 2048, blocks).eval()
     ref_ctc = C.CTC(vocab, 256).eval()
     ref_dec = C.TransformerDecoder(vocab, 256, 4, 512, dblocks, 0.0, 0.0).eval()
@@ -340,6 +342,14 @@ def test_asr_model_hybrid_eval_loss_and_decoder_scores_match_oracle():
     model.ctc_weight = 0.0
     la, _ = model(*dev)
     assert abs(float(la) - float(la_ref)) <= 2e-2 * abs(float(la_ref))
+    # length_normalized_loss (asr_model.py:61): the same sum over tokens instead of over the batch
+    model.length_normalized_loss = True
+    ln, _ = model(*dev)
+    assert abs(float(ln) - float(la) * b / float(ys_masks.sum())) <= 1e-5 * abs(float(ln))
+    from mindaudio_amd.conformer.asr_model import ASRModel
+
+    with pytest.raises(ValueError):  # the reference has no right-to-left decoder either (models/conformer.py:620, 639)
+        ASRModel(vocab, model.encoder, model.ctc, 0.3, decoder=model.decoder, reverse_weight=0.3)
 
 
 @pytest.mark.parametrize("d,heads,hidden", [(512, 8, 1024), (768, 12, 512)])

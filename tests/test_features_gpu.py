@@ -138,6 +138,18 @@ def test_melspectrogram_vs_oracle(ma, sample_wav):
         assert _frame_rel_err(got, want) <= TOL_MEL
 
 
+@pytest.mark.parametrize("norm,mel_type", [("slaney", "slaney"), ("none", "slaney"), ("slaney", "htk")])
+def test_melspectrogram_slaney_scale_and_norm(ma, sample_wav, norm, mel_type):
+    """spectrum.py:625-626: norm / mel_type other than the defaults (a host-built table, same kernel)."""
+    for kw in (dict(n_fft=512, hop_length=160, n_mels=80), dict(n_mels=64)):
+        got = ma.melspectrogram(sample_wav, norm=norm, mel_type=mel_type, **kw)
+        want = O.melspectrogram(sample_wav, norm=norm, mel_type=mel_type, **kw)
+        assert got.shape == want.shape and got.dtype == np.float32
+        assert _frame_rel_err(got, want) <= TOL_MEL
+    with pytest.raises(ValueError):
+        ma.melspectrogram(sample_wav, norm="l2")
+
+
 def _check_db(got, want_db, mel_energy, atol=2e-3):
     """dB parity where the mel energy is above the float32 noise of its frame; floor equality elsewhere."""
     assert got.shape == want_db.shape

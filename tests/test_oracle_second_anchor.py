@@ -223,6 +223,32 @@ def test_htk_mel_bank_per_filter_closed_form():
     assert np.abs(got[inside].sum(1) - 1.0).max() < 1e-12
 
 
+def test_slaney_mel_scale_and_norm_known_answers():
+    """mel_type / norm = SLANEY (spectrum.py:625-626; MelScale mirrors torchaudio / librosa's Slaney tables).  Known answers of the
+    Auditory-Toolbox warp: 3 mel = 200 Hz, 1 kHz = 15 mel, 6.4 kHz = 42 mel; area normalisation: every triangle integrates to one
+    over Hz.  The product's host table (mindaudio_amd._host) must equal the oracle's."""
+    from mindaudio_amd import _host
+
+    assert np.allclose(O.mel_to_hz_slaney([1, 2, 3, 4, 5]), [200.0 / 3, 400.0 / 3, 200.0, 800.0 / 3, 1000.0 / 3])
+    assert np.allclose(O.hz_to_mel_slaney([110.0, 220.0, 440.0, 1000.0, 6400.0]), [1.65, 3.3, 6.6, 15.0, 42.0])
+    f = np.linspace(1.0, 8000.0, 97)
+    assert np.abs(O.mel_to_hz_slaney(O.hz_to_mel_slaney(f)) - f).max() < 1e-9
+    n_freqs, sr = 2049, 16000
+    fb = O.melscale_fbanks(n_freqs, 0.0, 8000.0, 40, sr, norm="slaney", mel_type="slaney")
+    df = (sr // 2) / (n_freqs - 1)
+    assert np.abs(fb.sum(0) * df - 1.0).max() < 2e-2                       # unit area (trapezoid error of a sampled triangle)
+    plain = O.melscale_fbanks(n_freqs, 0.0, 8000.0, 40, sr, norm="none", mel_type="slaney")
+    assert np.abs(plain.max(0) - 1.0).max() < 5e-2 and np.all(plain >= 0)
+    for norm in ("none", "slaney"):
+        for mt in ("htk", "slaney"):
+            a = O.melscale_fbanks(257, 20.0, 7600.0, 80, sr, norm, mt)
+            b = _host.mel_fbanks_f64(257, 20.0, 7600.0, 80, sr, norm, mt)
+            assert np.abs(a - b).max() < 1e-12
+    assert _host.mel_enum("NormType.SLANEY", "norm") == "slaney" and _host.mel_enum("HTK", "mel_type") == "htk"
+    with pytest.raises(ValueError):
+        _host.mel_enum("l2", "norm")
+
+
 def test_fbank_against_direct_dft_definition():
     """features.fbank = 10 log10(max(mel(|STFT|^2), 1e-10)) with the batch-global top_db floor: the power spectrogram computed from the
     DFT DEFINITION (an explicit complex exponential matrix, no FFT routine, reflect-padded periodic Hann frames), float64."""

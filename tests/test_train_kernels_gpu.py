@@ -365,3 +365,50 @@ def test_gemm_tn(K):
     out = torch.zeros(256, 512, device="cuda")
     K.gemm_tn(a, b, out, accumulate=False)
     assert rel(out, a.float().cpu().t() @ b.float().cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("lq,lk,mode", [(31, 31, 2), (31, 255, 1), (31, 749, 1), (9, 1088, 1), (32, 321, 0)])
+def test_decoder_attention_long_sources(K, lq, lk, mode):
+    """ma_mha_small_fwd/bwd (the TransformerDecoder's self- and source attention, layers/attention.py:85-157 with the 1/d_k
+    scaling of :150-152) over short AND long key ranges: up to 320 keys the V / K rows are staged in LDS, beyond that (the
+    1400 ... 3000-frame buckets of conformer.yaml: T' up to 749) the score rows take the LDS and V / K come from L2.  Forward and
+    every gradient against float32 autograd on the same bf16-rounded inputs."""
+    g = torch.Generator().manual_seed(lq * 1000 + lk)
+    b, h, dk = 3, 4, 64
+    scale = 1.0 / dk
+    q = bf(torch.randn(b * lq, h * dk, generator=g))
+    k = bf(torch.randn(b * lk, h * dk, generator=g) * 4)
+    v = bf(torch.randn(b * lk, h * dk, generator=g))
+    dctx = bf(torch.randn(b * lq, h * dk, generator=g))
+    if mode == 1:
+        mask = torch.ones(b, lk)
+        mask[1, lk - lk // 3:] = 0
+        mask[2, lk // 2:] = 0
+        add = (mask == 0).float()[:, None, None, :] * -10000.0
+    elif mode == 2:
+        mask = torch.tril(torch.ones(lq, lk))[None].repeat(b, 1, 1).contiguous()
+        mask[2, :, lk - 5:] = 0
+        add = (mask == 0).float()[:, None] * -10000.0
+    else:
+        mask, add = None, 0.0
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    q4 = qf.view(b, lq, h, dk).transpose(1, 2)
+    k4 = kf.view(b, lk, h, dk).transpose(1, 2)
+    v4 = vf.view(b, lk, h, dk).transpose(1, 2)
+    probs_ref = torch.softmax(q4 @ k4.transpose(-1, -2) * scale + add, dim=-1)
+    ctx_ref = (probs_ref @ v4).transpose(1, 2).reshape(b * lq, h * dk)
+    ctx_ref.backward(dctx.float())
+    ctx, probs = K.mha_small_fwd(q.cuda(), k.cuda(), v.cuda(), mask.cuda() if mask is not None else None, mode, b, lq, lk, scale,
+                                 h, dk)
+    assert rel(probs, probs_ref.detach()) < 2e-5
+    assert rel(ctx, ctx_ref.detach()) < 4e-3          # bf16 output rounding
+    dq, dk_, dv = (torch.empty_like(t.cuda()) for t in (q, k, v))
+    K.mha_small_bwd(q.cuda(), k.cuda(), v.cuda(), probs, ctx, dctx.cuda(), b, lq, lk, scale, dq, dk_, dv, h, dk)
+    assert rel(dq, qf.grad) < 1e-2 and rel(dk_, kf.grad) < 1e-2 and rel(dv, vf.grad) < 6e-3
+
+
+def test_decoder_attention_rejects_more_keys_than_the_lds_holds(K):
+    b, h, dk, lq, lk = 1, 4, 64, 4, 1089
+    z = lambda n: torch.zeros(n, h * dk, dtype=torch.bfloat16, device="cuda")  # noqa: E731
+    with pytest.raises(NotImplementedError):
+        K.mha_small_fwd(z(lq), z(lk), z(lk), None, 0, b, lq, lk, 1.0 / dk, h, dk)

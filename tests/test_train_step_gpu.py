@@ -242,8 +242,10 @@ def test_overflow_skips_update_and_halves_scale():
     assert torch.equal(model.encoder.after_norm.gamma.detach(), eng.fp.p("after_norm.g"))
 
 
-def test_hybrid_ctc_attention_loss_and_gradients_match_oracle():
-    """ctc_weight 0.3 + TransformerDecoder + label smoothing 0.1 (conformer.yaml defaults, asr_model.py:75-186)."""
+@pytest.mark.parametrize("len_norm", [False, True])
+def test_hybrid_ctc_attention_loss_and_gradients_match_oracle(len_norm):
+    """ctc_weight 0.3 + TransformerDecoder + label smoothing 0.1 (conformer.yaml defaults, asr_model.py:75-186); len_norm =
+    length_normalized_loss (asr_model.py:61: the attention loss divided by the token count instead of the batch size)."""
     from mindaudio_amd.conformer.asr_model import create_asr_model
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
     from oracle import conformer_oracle as C
@@ -260,7 +262,7 @@ def test_hybrid_ctc_attention_loss_and_gradients_match_oracle():
                 mod.beta.normal_(0, 0.1)
     model = create_asr_model(80, vocab, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks),
                              ctc_weight=0.3, decoder_conf=dict(attention_heads=4, linear_units=512, num_blocks=dblocks),
-                             lsm_weight=0.1)
+                             lsm_weight=0.1, length_normalized_loss=len_norm)
     missing, unexpected = model.encoder.load_state_dict(ref_enc.state_dict(), strict=False)
     assert not missing and not [k for k in unexpected if "cmvn" not in k]
     model.ctc.load_state_dict(ref_ctc.state_dict())
@@ -281,7 +283,7 @@ def test_hybrid_ctc_attention_loss_and_gradients_match_oracle():
         ys_masks[i, 0, :n + 1] = 1
     ys_sub = ys_masks.bool() & torch.tril(torch.ones(lmax + 1, lmax + 1, dtype=torch.bool))[None]
     cols = (xs, ys, ys_in, ys_out, None, None, sub, ys_sub.float(), ys_masks, ys_lens, None)
-    loss_ref, acc_ref, lc_ref, la_ref = C.hybrid_loss(ref_enc, ref_ctc, ref_dec, cols, 0.3, 0.1)
+    loss_ref, acc_ref, lc_ref, la_ref = C.hybrid_loss(ref_enc, ref_ctc, ref_dec, cols, 0.3, 0.1, len_norm)
     loss_ref.backward()
     eng = ConformerCTCTrainStep(model, dropout_rate=0.0, positional_dropout_rate=0.0)
     model.decoder.dropout_rate = model.decoder.positional_dropout_rate = 0.0

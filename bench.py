@@ -165,7 +165,20 @@ def synth_train_batch(rank, dev, b=TRAIN_BATCH, t=TRAIN_FRAMES, vocab=TRAIN_VOCA
     return (xs, d(ys), d(ys_in), d(ys_out), None, None, masks.to(dev), d(ys_sub), d(ys_m), d(ylens), None)
 
 
-def train_leg(rank, world, dev, dist, steps, warmup, barrier):
+def train_step_flops(b, t, vocab, d=256, hidden=2048, blocks=12, heads=4, ks=15):
+    """Algorithmic FLOPs of one cfg-4 optimizer step (2 x multiply-adds of every contraction; backward = 2 x forward: one product
+    for the input gradient, one for the weight gradient), per rank.  Forward per utterance at t = 1024: 23.86 GFLOP."""
+    t1, f1 = (t - 3) // 2 + 1, (80 - 3) // 2 + 1
+    t2, f2 = (t1 - 3) // 2 + 1, (f1 - 3) // 2 + 1
+    dk = d // heads
+    front = 2 * 9 * d * t1 * f1 + 2 * 9 * d * d * t2 * f2 + 2 * f2 * d * d * t2
+    layer = 2 * (2 * t2 * d * hidden * 2) + 2 * t2 * d * 3 * d + heads * (2 * t2 * t2 * 2 * dk + 2 * t2 * t2 * dk) + 2 * t2 * d * d \
+        + 2 * t2 * d * 2 * d + 2 * t2 * d * ks + 2 * t2 * d * d
+    fwd = front + blocks * layer + 2 * t2 * d * vocab
+    return 3.0 * b * fwd
+
+
+def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=False, digest=False):
     """cfg 4: `steps` optimizer steps of ConformerCTCTrainStep on a (40, 1024, 80) batch per rank, gradients
     all-reduced over RCCL in per-block buckets overlapped with the backward pass.  Also times the same all-reduce alone
     (bus bandwidth) and the step with communication disabled (exposed communication)."""
@@ -177,7 +190,8 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier):
     torch.manual_seed(777)  # same initial weights on every rank (examples/conformer/train.py:56)
     model = create_asr_model(80, TRAIN_VOCAB, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12),
                              ctc_weight=1.0).to(dev)
-    eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, world_size=world, rank=rank)
+    eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, world_size=world, rank=rank,
+                                force_collective=force_collective)
     cols = synth_train_batch(rank, dev)
 
     def timed(n):
@@ -201,6 +215,16 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier):
                        "all-reduce + Adam/ASRWarmupLR/dynamic loss scale, dropout 0.1, bf16 matmuls, float32 masters",
            "first_loss": round(first[0], 3), "last_loss": round(float(out[0]), 3), "loss_scale": out[2],
            "overflow_last_step": bool(out[3]), "grad_bytes": eng.fp.size * 4}
+    flops = train_step_flops(TRAIN_BATCH, TRAIN_FRAMES, TRAIN_VOCAB)
+    tf = world * flops / (dt / steps) / 1e12
+    res["roofline"] = {"bound": "mfma", "algorithmic_flops_per_step": int(world * flops), "achieved": round(tf, 1),
+                       "peak": MFMA_BF16_PEAK_TF * world, "unit": "TFLOP/s", "frac": round(tf / (MFMA_BF16_PEAK_TF * world), 4)}
+    if force_collective:
+        res["force_collective"] = True
+    if digest:  # bit pattern of the trained masters (tests/test_rccl_world1_gpu.py compares runs with and without the collective)
+        import hashlib
+
+        res["masters_sha16"] = hashlib.sha256(eng.fp.master.cpu().numpy().tobytes()).hexdigest()[:16]
     if world > 1:
         # (i) the step without its collective: exposed communication = ms_per_step - ms_per_step_no_comm
         eng.reducer.world = 1
@@ -239,6 +263,10 @@ def main():
     ap.add_argument("--no-train-leg", action="store_true", help="skip the train_dp object")
     ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="issue the gradient all-reduces through RCCL even at world size 1 (stream-ordering check on one GPU)")
+    ap.add_argument("--train-digest", action="store_true", help="add a hash of the trained masters to train_dp")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg-3 (32 x 1000 x 80 encoder forward) object")
     args = ap.parse_args()
 
     # ---- N > 1: one process per GPU.  Either we already are a rank (WORLD_SIZE set by torch.distributed.run) or this
@@ -262,10 +290,11 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_collective and not dry):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if dry:
             dist.init_process_group("gloo", rank=rank, world_size=world)
             t = torch.tensor([float(rank + 1)])
@@ -398,17 +427,47 @@ def main():
     fb512_gbs = fb512_bytes / fb512_s / 1e9
 
     def pmc_traffic(kernel):
-        """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 cannot run inside the bench)."""
+        """(HBM bytes per launch of `kernel`, where that was measured) from the committed PMC summary: rocprofv3 cannot run inside
+        the bench, so the figure is a constant of the commit `traffic_measured_at` names; `traffic_source_current` says whether the
+        kernel's source file still hashes to what was profiled (false = the constant is stale)."""
+        import hashlib
+
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-                return int(json.load(fh)[kernel]["bytes"])
+                tr = json.load(fh)
+            ent = tr[kernel]
+            cur = None
+            if ent.get("source") and ent.get("source_sha16"):
+                with open(os.path.join(ROOT, ent["source"]), "rb") as fh:
+                    cur = hashlib.sha256(fh.read()).hexdigest()[:16] == ent["source_sha16"]
+            return int(ent["bytes"]), {"traffic_measured_at": tr.get("measured_at_commit"), "traffic_source_current": cur}
         except (OSError, KeyError, ValueError):
-            return None
+            return None, {"traffic_measured_at": None, "traffic_source_current": None}
+
+    # ---- cfg 3 (BASELINE.json configs[2]): Conformer-small forward at its stated batch, 32 x 1000 x 80 (features resident, no
+    #      fbank), eval mode and training-mode forward (dropout 0.1, BatchNorm batch statistics).  Own encoder instance: the
+    #      training-mode forward moves the BatchNorm running statistics. ----------------------------------------------------
+    cfg3 = None
+    if not args.train and not args.no_cfg3:
+        torch.manual_seed(777)
+        enc3 = ConformerEncoder(80, 256, 4, 2048, 12).eval().to(dev).prepare()
+        x3 = torch.randn(32, FRAMES, 80, device=dev, generator=gen)
+        m3 = torch.ones(32, 1, t2, device=dev)
+        flops3 = 32 * 23.12e9
+        ev = event_time(lambda: enc3(x3, m3), 30)
+        cfg3 = {"workload": "Conformer-small (12 blocks) encoder forward, 32 x 1000 x 80, bf16 matmuls",
+                "eval": {"ms": round(ev * 1e3, 4), "utt_s": round(32 / ev, 1), "tflops": round(flops3 / ev / 1e12, 1)}}
+        enc3.train()
+        tr3 = event_time(lambda: enc3(x3, m3), 10)
+        enc3.eval()
+        cfg3["train_mode_forward"] = {"ms": round(tr3 * 1e3, 4), "utt_s": round(32 / tr3, 1),
+                                      "tflops": round(flops3 / tr3 / 1e12, 1)}
+        del enc3, x3
 
     train = None
     if args.train or not args.no_train_leg:
-        train = train_leg(rank, world, dev, dist, args.steps if args.train else args.train_steps,
-                          args.warmup if args.train else 2, barrier)
+        train = train_leg(rank, world, dev, dist if world > 1 else None, args.steps if args.train else args.train_steps,
+                          args.warmup if args.train else 2, barrier, args.force_collective, args.train_digest)
 
     if rank == 0:
         flops_utt = 23.12e9
@@ -448,15 +507,19 @@ def main():
         res["roofline"] = {"bound": "mfma", "kernel": "ffn_packed_kernel, pair + qkv form (2 x [w_1 -> Swish -> w_2 + residual] + 4 LayerNorms + linear_q/k/v, "
                                                       "M=%d d=256 hidden=%d)" % (m, hid),
                            "achieved": round(gemm_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": round(gemm_tf / MFMA_BF16_PEAK_TF, 4), "traffic": pmc_traffic("ffn_packed_kernel"),
+                           "frac": round(gemm_tf / MFMA_BF16_PEAK_TF, 4), "traffic": pmc_traffic("ffn_packed_kernel")[0],
                            "algorithmic_flops_per_launch": int(ffn_flops), "kernel_ms": round(gemm_s * 1e3, 5)}
+        res["roofline"].update(pmc_traffic("ffn_packed_kernel")[1])
         res["roofline_fbank"] = {"bound": "hbm", "kernel": "feat512_kernel<mel>", "achieved": round(fb_gbs, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fb_gbs / HBM_PEAK_GBS, 4),
-                                 "traffic": pmc_traffic("feat512_kernel"), "algorithmic_bytes_per_launch": fb_bytes,
+                                 "traffic": pmc_traffic("feat512_kernel")[0], "algorithmic_bytes_per_launch": fb_bytes,
                                  "kernel_ms": round(fb_s * 1e3, 5),
                                  "batch512": {"achieved": round(fb512_gbs, 1), "frac": round(fb512_gbs / HBM_PEAK_GBS, 4),
                                               "algorithmic_bytes_per_launch": fb512_bytes,
                                               "kernel_ms": round(fb512_s * 1e3, 5)}}
+        res["roofline_fbank"].update(pmc_traffic("feat512_kernel")[1])
+        if cfg3 is not None:
+            res["cfg3"] = cfg3
         if train is not None and not args.train:
             res["train_dp"] = train
         elif train is not None:

@@ -162,12 +162,6 @@ __device__ __forceinline__ void pk_store16(void* ptr, uint4 v4) {
   else if constexpr (WT == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
   else *reinterpret_cast<uint4*>(ptr) = v4;
 }
-template <int ABL>
-__device__ __forceinline__ float pk_swish(float v) {
-  if constexpr (ABL & 1) return v;
-  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-}
-
 // ---- weight packing ----------------------------------------------------------------------------------------------------
 // item q < 16 of block hb (k-step ks = q >> 1, tile t = q & 1): lane (i = lane & 15, g = lane >> 4) holds
 //     W1[32 hb + 8 (i >> 2) + 4 t + (i & 3)][32 ks + 8 g .. + 8]
@@ -201,8 +195,6 @@ __global__ void ffn_qkv_pack_kernel(const uint16_t* __restrict__ w, int64_t ldw,
   out[idx] = *reinterpret_cast<const uint4*>(w + (hb * kPkBlock + 8 * (i >> 2) + 4 * t + (i & 3)) * ldw + 32 * ks + 8 * g);
 }
 
-// ABL (development ablations, tools/ffn_bench.py): 1 = no Swish, 2 = no weight loads in the loop, 4 = no MFMAs; 0 = product.
-template <int ABL>
 __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPackedParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -216,9 +208,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 #pragma unroll
   for (int s = 0; s < 4; ++s) a_off[s] = ((s + wave) & 3) * kPkTileStride + c * kPkPitch + g * 16;
 
-  const int nsb_all = p.H >> 7;
-  const int nsb = ABL == 7 && p.alpha == 0.25f ? 0 : nsb_all;  // (ablation 7 with alpha 0.25: no main loop at all)
-  //                                         super-blocks of 4 x 32 hidden units, one block per wave
+  const int nsb_all = p.H >> 7;              // super-blocks of 4 x 32 hidden units, one block per wave
+  const int nsb = nsb_all;
   const int rot = blockIdx.x % nsb_all;      // workgroups start at different super-blocks: spreads the L2 channel load
   auto block_of = [&](int ci) {
     int sb = ci + rot;
@@ -236,36 +227,23 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
   const uint32_t boff = g * 32;
 #define PK_VOFF(q) ((q) < 8 ? voff0 : (q) < 16 ? voff1 : (q) < 24 ? voff2 : voff3)
 #define PK_LOAD(dst, base, q)                                                                                    \
-  do {                                                                                                           \
-    if constexpr (!(ABL & 2))                                                                                    \
-      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                                    \
-                   : "=v"(dst) : "v"(PK_VOFF(q)), "s"(base), "n"((((q) & 7) - 4) * 1024) : "memory");              \
-  } while (0)
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                                        \
+               : "=v"(dst) : "v"(PK_VOFF(q)), "s"(base), "n"((((q) & 7) - 4) * 1024) : "memory")
 #define PK_LOAD_B1(blk)                                                                                          \
   do {                                                                                                           \
     const float* bsrc = b1_cur + (blk) * kPkBlock;                                                               \
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b1lo) : "v"(boff), "s"(bsrc) : "memory");               \
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b1hi) : "v"(boff), "s"(bsrc) : "memory");     \
   } while (0)
-#define PK_WAIT(reg, n)                                                                          \
-  do {                                                                                           \
-    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n) : "memory"); \
-  } while (0)
+#define PK_WAIT(reg, n) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n) : "memory")
   // The 256 O accumulators fill the AGPR half of the register file.  hipcc gives every MFMA builtin of a kernel the AGPR form
   // and, with no AGPR to spare, permutes accumulators with copies on every iteration (measured: 240 v_accvgpr moves per 128
   // MFMAs).  So: S products in VGPR form, O products with the accumulator tied ("+a").  Hazards that the compiler would have
   // handled are ours: dependent MFMAs on one tile are >= 8 MFMAs apart; S tiles are read by the VALU a whole phase after their
   // last MFMA; the VALU-written h fragments get an s_nop before the first O product; the accumulator reads after the loop too.
-#define PK_MFMA_S0(acc, wf, af, bias)                                                                                  \
-  do {                                                                                                                 \
-    if constexpr (ABL & 4) { acc = bias; asm volatile("" : "+v"(acc) : "v"(wf), "v"(af)); }                            \
-    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(wf), "v"(af), "v"(bias));           \
-  } while (0)
-#define PK_MFMA_S(acc, wf, af)                                                                                         \
-  do {                                                                                                                 \
-    if constexpr (ABL & 4) asm volatile("" : "+v"(acc) : "v"(wf), "v"(af));                                            \
-    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af));                       \
-  } while (0)
+#define PK_MFMA_S0(acc, wf, af, bias) \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(wf), "v"(af), "v"(bias))
+#define PK_MFMA_S(acc, wf, af) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af))
 // the qkv tail's weight rings live in the AGPRs the O tiles have left ("a" operands)
 #define PK_LOAD_A(dst, base, q)                                                                                  \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                                        \
@@ -274,11 +252,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 #define PK_MFMA_S0A(acc, wf, af, bias) \
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(wf), "v"(af), "v"(bias))
 #define PK_MFMA_SA(acc, wf, af) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wf), "v"(af))
-#define PK_MFMA_O(acc, wf, hf)                                                                                         \
-  do {                                                                                                                 \
-    if constexpr (ABL & 4) asm volatile("" : "+a"(acc) : "v"(wf), "v"(hf));                                            \
-    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wf), "v"(hf));                       \
-  } while (0)
+#define PK_MFMA_O(acc, wf, hf) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wf), "v"(hf))
 
 #ifdef MA_FFN_PROF
   unsigned long long pk_ts[8];
@@ -315,10 +289,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     };
     // inline asm (volatile): the micro-operations must stay in THEIR slot; hipcc moves plain C++ arithmetic across the
     // sched_barriers at instruction selection and pairs dependent operations back to back
-    if constexpr (ABL & 1) {
-      if constexpr (q == 2 && k - 1 >= 1 && k - 1 < 32 && ((k - 1) & 1))
-        hfw[(k - 1) >> 3][((k - 1) & 7) >> 1] = pk_pack_bf16(val(std::integral_constant<int, k - 2>{}), val(std::integral_constant<int, k - 1>{}));
-    } else if constexpr (q == 0) {
+    if constexpr (q == 0) {
       if constexpr (k < 32)
         asm volatile("v_mul_f32 %0, 0xbfb8aa3b, %1" : "=v"(tm[k < 32 ? k : 0]) : "v"(val(std::integral_constant<int, k < 32 ? k : 0>{})));
       if constexpr (k >= 1 && k - 1 < 32)
@@ -412,7 +383,7 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     });
     nano(std::integral_constant<int, 0>{}, Snext);
     asm volatile("s_nop 3" : "+v"(hf[0]), "+v"(hf[1]), "+v"(hf[2]), "+v"(hf[3]));  // VALU write -> MFMA operand read
-    if constexpr (!(ABL & 2)) PK_LOAD_B1(b1_blk);
+    PK_LOAD_B1(b1_blk);
     pk_static_for<16>([&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
       PK_WAIT(ring[j], 17);
@@ -468,7 +439,6 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
     for (int q = 0; q < 16; ++q)
       asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
                    : "=v"(ring[q]) : "v"(PK_VOFF(q)), "s"(w0), "n"((((q) & 7) - 4) * 1024) : "memory");
-    if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int l = tidv & 63;
     const float* bsrc = b1_cur + (l < 32 ? block_of(0) : block_of(blk_wrap(1))) * kPkBlock + (l & 31);
     __builtin_amdgcn_global_load_lds((pk_gl_void_t*)bsrc, (pk_lds_void_t*)(smem + kPkOffBias + wave * 256), 4, 0, 0);
@@ -930,20 +900,17 @@ extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t 
   return MA_OK;
 }
 
-#ifndef MA_FFNPK_ABLATE
-#define MA_FFNPK_ABLATE 0  // development builds only (tools/ffn_variants.sh): see ABL above
-#endif
 static int ffn_packed_launch(const FfnPackedParams& p, ma_stream_t stream) {
   const int64_t M = p.M;
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)&ffn_packed_kernel<MA_FFNPK_ABLATE>, hipFuncAttributeMaxDynamicSharedMemorySize, kPkLds) !=
+    if (hipFuncSetAttribute((const void*)&ffn_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPkLds) !=
         hipSuccess)
       return MA_ERR_LAUNCH;
     ready = true;
   }
   const dim3 grid((unsigned)((M + kPkRows - 1) / kPkRows));
-  MA_LAUNCH(ffn_packed_kernel<MA_FFNPK_ABLATE>, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p);
+  MA_LAUNCH(ffn_packed_kernel, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p);
   return MA_OK;
 }
 

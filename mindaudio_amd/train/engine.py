@@ -92,15 +92,19 @@ class BucketedAllReduce:
     """Gradient all-reduce of the data-parallel step (the reference's grad_reducer, train_one_step.py:36): slices of the
     flat gradient buffer are summed across ranks as soon as the backward pass has finished them (asynchronous
     collectives on the backend's own stream), and `wait()` joins them before the optimizer.  With world == 1 it is a
-    no-op.  Division by the world size happens inside the Adam kernel's scale."""
+    no-op unless `force_collective` (the collectives are then issued through the backend at world 1: a SUM over one rank is the
+    identity, so the step must produce bit-identical masters - this is how the stream ordering between the library's launches on
+    torch's current stream and RCCL's own stream is tested on ONE GPU).  Division by the world size happens inside the Adam
+    kernel's scale."""
 
-    def __init__(self, flat_grad, world_size=1, process_group=None):
+    def __init__(self, flat_grad, world_size=1, process_group=None, force_collective=False):
         self.grad, self.world, self.pg = flat_grad, int(world_size), process_group
+        self.force = bool(force_collective)
         self.pending, self.launched = [], []
 
     def launch(self, lo, hi):
         self.launched.append((lo, hi))
-        if self.world > 1:
+        if self.world > 1 or self.force:
             import torch.distributed as dist
 
             self.pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -175,7 +179,8 @@ class ConformerCTCTrainStep:
 
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
-                 process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None):
+                 process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None,
+                 force_collective=False):
         """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
         torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
         activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
@@ -216,7 +221,7 @@ class ConformerCTCTrainStep:
         self.last_acc = None
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._build_flat()
-        self.reducer = BucketedAllReduce(self.fp.grad, self.world, self.pg)
+        self.reducer = BucketedAllReduce(self.fp.grad, self.world, self.pg, force_collective)
         self.refresh_weights()
 
     # ---- flat parameter layout ------------------------------------------------------------------------------------

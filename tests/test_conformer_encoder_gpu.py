@@ -153,6 +153,33 @@ def test_encoder_full_config_shapes_and_determinism():
     assert tuple(got3.shape) == (2, 249, 256) and bool(torch.isfinite(got3).all())
 
 
+def test_encoder_cfg3_batch_32x1000_matches_oracle_on_sampled_utterances():
+    """BASELINE configs[2] at its stated shape: 12 blocks, 32 x 1000 x 80, ragged lengths.  The device runs the whole batch; the
+    float32 oracle runs 4 sampled utterances as their own batch (utterances are independent in evaluation mode: BatchNorm uses the
+    running statistics, masked keys get probability ~0), compared row by row over the valid frames."""
+    import torch
+
+    from oracle import conformer_oracle as C
+
+    ref, dut = _pair(12, seed=32, cmvn=True)
+    g = torch.Generator().manual_seed(33)
+    xs = torch.randn(32, 1000, 80, generator=g)
+    lens = torch.randint(500, 1001, (32,), generator=g)
+    lens[0] = 1000
+    mask = (torch.arange(1000)[None, :] < lens[:, None]).float().unsqueeze(1)
+    sub = C.subsample_mask(mask)
+    got, m2 = dut(xs.cuda(), sub.cuda())
+    assert tuple(got.shape) == (32, 249, 256) and torch.equal(m2.cpu(), sub)
+    pick = [0, 7, 19, 31]
+    with torch.no_grad():
+        want, _ = ref(xs[pick], sub[pick])
+    valid = sub[pick][:, 0, :].bool()
+    err = (got.cpu()[pick] - want)[valid]
+    rel_rms = float(err.pow(2).mean().sqrt() / want[valid].pow(2).mean().sqrt())
+    assert rel_rms <= 2e-2, rel_rms
+    assert float(err.abs().max()) <= 0.2, float(err.abs().max())
+
+
 def test_encoder_north_star_size_properties():
     """BASELINE size (64 x 1000 x 80, 12 blocks): properties that need no oracle run at that size - run-to-run determinism,
     utterances are independent (a permuted batch gives the permuted output; utterances taken out of the batch give the same rows),

@@ -1,0 +1,49 @@
+"""RCCL on ONE GPU: the data-parallel training step with its 14 asynchronous gradient all-reduces issued through
+ProcessGroupNCCL (= RCCL on ROCm) at world size 1.  A SUM over one rank is the identity, so the trained masters must be
+bit-identical to a run that issues no collective at all - which they are only if (i) the collectives on RCCL's own stream
+wait for the backward kernels the library launched on torch's current stream and (ii) the optimizer waits for the collectives
+(mindaudio_amd/train/engine.py BucketedAllReduce; the reference's grad_reducer, mindaudio/utils/train_one_step.py:36-41,
+examples/conformer/train.py:73-80).  Each run is a fresh child process started with `python -m torch.distributed.run`
+(never a re-exec of a process that has touched the GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _train_line(extra):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--train", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--train-digest"] + extra
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    assert lines, res.stdout.decode()[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bucketed_allreduce_through_rccl_at_world_1_leaves_the_step_bit_identical():
+    with_cc = _train_line(["--force-collective"])
+    without = _train_line([])
+    assert with_cc["n_gpus"] == 1 and with_cc["train_dp"]["force_collective"] is True
+    assert "force_collective" not in without["train_dp"]
+    assert with_cc["train_dp"]["last_loss"] == without["train_dp"]["last_loss"]
+    assert with_cc["train_dp"]["masters_sha16"] == without["train_dp"]["masters_sha16"], (with_cc["train_dp"], without["train_dp"])
+    # the roofline object of the training step is in the line
+    r = with_cc["train_dp"]["roofline"]
+    assert r["bound"] == "mfma" and 2.5e12 < r["algorithmic_flops_per_step"] < 3.2e12 and 0 < r["frac"] < 1

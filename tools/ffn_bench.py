@@ -19,8 +19,6 @@ pk = ops.ffn_pack_weights(w1, w2)
 g = torch.ones(256, device="cuda"); be = torch.zeros(256, device="cuda")
 us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x)); print("packed ffn M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
 us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, g, be)); print("packed+LN  M=%d: %.1f us  %.0f TF/s" % (m, us, fl / us / 1e6))
-if "--no-loop" in sys.argv:  # on a -DMA_FFNPK_ABLATE=7 build (tools/ffn_variants.sh)
-    us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, alpha=0.25)); print("packed, no main loop: %.1f us" % us)
 us = t(lambda: ops.ffn_packed(a[:64], pk, b1, b2, x[:64])); print("packed M=64 (launch floor + one workgroup): %.1f us" % us)
 us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, g, be, out_dtype=torch.float32)); print("packed+LN f32 out: %.1f us" % us)
 us = t(lambda: ops.ffn_packed(a, pk, b1, b2, x, g, be, g, be)); print("packed+LN2 bf16 out: %.1f us" % us)

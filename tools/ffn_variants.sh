@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development A/B of ffn_packed.hip build variants on one box.
-#   build (here, no GPU):   bash tools/ffn_variants.sh build "name1:-DMA_FFN_WT=1" "name2:-DMA_FFNPK_ABLATE=2" ...
+#   build (here, no GPU):   bash tools/ffn_variants.sh build "name1:-DMA_FFN_WT=1" "name2:-DMA_FFN_PROF" ...
 #   run (GPU box):          bash tools/ffn_variants.sh run [script.py]      -> one line per variant (default tools/ffn_pair_scan.py)
 # Variants are libmindaudio_amd.so with only ffn_packed.hip rebuilt under the extra flags: mindaudio_amd/lib/variants/<name>.so
 set -e

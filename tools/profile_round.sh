@@ -49,6 +49,23 @@ with open(out+"/pmc_summary.txt","w") as fh:
             for c,vals in sorted(v.items()):
                 line="  %-30s mean per launch %.5g  (n=%d)"%(c,sum(vals)/len(vals),len(vals))
                 fh.write(line+"\n"); print(line)
+# traffic.json: HBM bytes per launch of the two roofline kernels (FETCH_SIZE doubled: gfx950 tallies 128-B read requests at 64 B,
+# MI355X_MICROARCH.md), stamped with the hashes of the kernel sources they were measured on; tools/stamp_traffic.py adds the commit
+import hashlib, json
+def sha16(rel): return hashlib.sha256(open("$R/"+rel,"rb").read()).hexdigest()[:16]
+def mean(kernel_sub, counter):
+    vals=[v for k,d in allagg.items() if kernel_sub in k for v in d.get(counter,[])]
+    return sum(vals)/len(vals) if vals else None
+allagg=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(out+"/*_p*/*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        allagg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+tr={"_comment":"HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile_round.sh), counters are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B). bench.py reports traffic_source_current = false when the kernel source no longer hashes to source_sha16."}
+for key,sub,src,form in (("ffn_packed_kernel","ffn_packed_kernel","mindaudio_amd/csrc/ffn_packed.hip","pair + qkv launch (tools/prof_target.py ffnpair)"),("feat512_kernel","feat512_kernel","mindaudio_amd/csrc/features.hip","fbank, 64 x 10 s (tools/prof_target.py fbank)")):
+    f,w=mean(sub,"FETCH_SIZE"),mean(sub,"WRITE_SIZE")
+    if f is None or w is None: continue
+    tr[key]={"fetch_kib":round(f),"write_kib":round(w),"bytes":int((2*f+w)*1024),"form":form,"source":src,"source_sha16":sha16(src)}
+json.dump(tr,open(out+"/traffic.json","w"),indent=1)
 with open(out+"/roofline_kernels_trace.txt","w") as fh:
     for w,kn in (("fbank","feat512_kernel"),("ffnpair","ffn_packed_kernel")):
         d=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in csv.DictReader(open(glob.glob(out+"/%s_trace/*kernel_trace.csv"%w)[0])) if kn in r["Kernel_Name"]]

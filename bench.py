@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--train", action="store_true", help="headline = the cfg-4 data-parallel training step")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the train_dp object")
     ap.add_argument("--no-sustained", action="store_true")
@@ -272,7 +273,7 @@ def main():
     # ---- N > 1: one process per GPU.  Either we already are a rank (WORLD_SIZE set by torch.distributed.run) or this
     #      process becomes the launcher — decided here, before torch.cuda / any HIP call. ------------------------------
     if "WORLD_SIZE" not in os.environ:
-        if args.gpus > 1:
+        if args.gpus > 1 and not args.cpu_baseline_only:
             sys.exit(launch_ranks(args.gpus))
         world = 1
     else:
@@ -284,8 +285,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dry = os.environ.get("MA_BENCH_DRY") == "1"  # launcher check on a box without GPUs: gloo ranks, no kernels
 
-    # the CPU baselines use a process pool: run them before this process holds a HIP context
-    cpu = cpu_baseline() if world == 1 and not args.no_cpu_baseline and not dry else None
+    # The CPU baselines run in a CHILD process, before this one touches the GPU: they use a process pool and every host thread
+    # (the PyTorch-CPU oracle's OpenMP team), and a team left behind in this process slowed the launch-bound training leg by 20 %.
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()))
+        return
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and not dry:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], stdout=subprocess.PIPE, check=True)
+        cpu = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
 
     import torch
 

@@ -418,18 +418,23 @@ int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t l
 /* out (Mo_store, No) float32 (+)= alpha * A^T . B for ROW-major A (Kc, Mo), B (Kc, No) bf16: dW = dY^T . X straight from
  * the activations (no transposed copies; LDS transpose-reads feed the MFMAs).  Rows i >= Mo_store of the product are
  * not stored (zero-padded vocabulary columns).  colsum (Mo_store) float32, optional: += column sums of A (bias
- * gradient).  Mo, No, lda, ldb multiples of 8; workspace >= ma_gemm_tn_workspace_bytes(Mo, No, Kc). */
+ * gradient; one partial vector per split, added in split order: deterministic).  Mo, No, lda, ldb multiples of 8;
+ * workspace >= ma_gemm_tn_workspace_bytes(Mo, No, Kc) = splits * Mo * (No + 1) * 4 with splits = ma_gemm_tn_splits(Mo, No, Kc). */
 int64_t ma_gemm_tn_workspace_bytes(int64_t Mo, int64_t No, int64_t Kc);
+int32_t ma_gemm_tn_splits(int64_t Mo, int64_t No, int64_t Kc);
 int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, float* out, int64_t ldo, int64_t Mo,
                         int64_t No, int64_t Kc, int64_t Mo_store, float alpha, int32_t accumulate, float* colsum,
                         void* workspace, int64_t workspace_bytes, ma_stream_t stream);
 /* The two halves of ma_gemm_tn_bf16_f32 apart, so that the split sums of many products leave in ONE launch (the training step:
  * 8 weight gradients per block, each followed by a launch-bound 6.6 us reduction otherwise).
  * ma_gemm_tn_partial_bf16 writes the split-K partial products [splits][Mo_store][No] float32 into `partial`
- * (>= ma_gemm_tn_workspace_bytes(Mo, No, Kc) bytes; splits = that size / (Mo * No * 4)); colsum as above.
- * ma_reduce_splits_batch_f32: items / block_item are DEVICE arrays; item i adds its `splits` partial matrices of `mn` elements in
- * order and stores out[m][n] = (accumulate ? out : 0) + alpha * sum with row length N and row stride ldo; workgroup b handles
- * elements [1024 (b - first_block), + 1024) of item block_item[b]. */
+ * (>= ma_gemm_tn_workspace_bytes(Mo, No, Kc) bytes, splits = ma_gemm_tn_splits(Mo, No, Kc)) and, with_colsum != 0, the partial
+ * column sums of A [splits][Mo_store] behind them (float offset splits * Mo_store * No).
+ * ma_reduce_splits_batch_f32: items / block_item are DEVICE arrays; item i adds its `splits` partial matrices of `mn` elements
+ * (`pstride` floats apart; 0 = mn) in order and stores out[m][n] = (accumulate ? out : 0) + alpha * sum with row length N and row
+ * stride ldo; workgroup b handles elements [1024 (b - first_block), + 1024) of item block_item[b].  Every parameter-gradient
+ * reduction of the training step (weight-gradient splits, bias / LayerNorm / BatchNorm / depthwise / positional-bias partials)
+ * goes through this one kernel, one launch per Conformer block: fixed summation order, no float atomics. */
 typedef struct ma_reduce_item {
   const float* part;
   float* out;
@@ -437,10 +442,10 @@ typedef struct ma_reduce_item {
   int32_t N, splits;
   float alpha;
   int32_t accumulate;
-  int32_t first_block, reserved;
+  int32_t first_block, pstride;
 } ma_reduce_item_t;
 int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t Mo, int64_t No, int64_t Kc,
-                            int64_t Mo_store, float* colsum, void* partial, int64_t partial_bytes, ma_stream_t stream);
+                            int64_t Mo_store, int32_t with_colsum, void* partial, int64_t partial_bytes, ma_stream_t stream);
 int ma_reduce_splits_batch_f32(const ma_reduce_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream);
 
 
@@ -471,8 +476,11 @@ typedef struct ma_transpose_item {
 } ma_transpose_item_t;
 int ma_transpose_batch_bf16(const ma_transpose_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream);
 
-/* Backward of ma_layernorm_f32 (layers/layernorm.py:53-60): g (+)= dL/dx, dgamma/dbeta (D) float32 += (atomics).
- * dy bf16 or float32; row_scale as in the forward; D == 256. */
+/* Backward of ma_layernorm_f32 (layers/layernorm.py:53-60): g (+)= dL/dx, dgamma/dbeta (D) float32 += the sum of the
+ * per-workgroup partials in a fixed order (run-to-run deterministic).  dy bf16 or float32; row_scale as in the forward; D == 256.
+ * workspace >= ma_layernorm_bwd_parts(rows) * 512 * 4 bytes: [parts][dgamma (256) | dbeta (256)].  dgamma == NULL: the partials are
+ * left in `workspace` for the caller's ma_reduce_splits_batch_f32 (the training step sums a block's partials in one launch). */
+int32_t ma_layernorm_bwd_parts(int64_t rows);
 int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
                          const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
                          int32_t accumulate, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
@@ -489,31 +497,35 @@ int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, int32_t act, floa
 int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, int32_t act, float p, uint32_t seed,
                             uint32_t salt, ma_stream_t stream);
 
-/* x (rows, cols) float32 = xin + alpha * dropout(y) (models/conformer.py:109-151 branch joins; xin may be x); y bf16 or
- * float32.  Backward: dy (bf16) = alpha * keep/(1-p) * g * row_scale[r]. */
+/* x (rows, cols) float32 = xin + alpha * dropout(y) (models/conformer.py:109-151 branch joins; xin may be x, or NULL for
+ * no residual term: the dropout of layers/embedding.py:86-87); y bf16 or float32.  Backward: dy (bf16) = alpha * keep/(1-p) * g * row_scale[r]. */
 int ma_dropout_add_f32(float* x, int64_t ldx, const float* xin, int64_t ldxin, const void* y, int64_t ldy, int32_t y_bf16,
                        int64_t rows, int64_t cols, float alpha, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
 int ma_dropout_bwd_bf16(const float* g, int64_t ldg, void* dy, int64_t ldy, int64_t rows, int64_t cols, float alpha,
                         const float* row_scale, float p, uint32_t seed, uint32_t salt, ma_stream_t stream);
 
 /* Convolution module in training mode (layers/convolution.py:83-129), between the two pointwise GEMMs:
- *   ma_convmid_fwd_train   z (B*T, C) float32 = depthwise_k(glu(y)) + bias, y (B*T, 2C) bf16; sums (2C) float32 +=
- *                          per-channel sum z, sum z^2 (caller zeroes)
- *   ma_bn_finalize_f32     stats = (mean[C], rstd[C]) of the B*T rows (biased variance); running statistics updated
- *                          with momentum and the unbiased variance (nn.BatchNorm1d)
+ *   ma_convmid_fwd_train   z (B*T, C) float32 = depthwise_k(glu(y)) + bias, y (B*T, 2C) bf16; sums = one partial vector
+ *                          (sum z | sum z^2) of 2C floats per workgroup, ma_convmid_fwd_train_parts(batch, T, C) of them
+ *   ma_bn_finalize_f32     adds the `nparts` partial vectors in a fixed order; stats = (mean[C], rstd[C]) of the B*T rows
+ *                          (biased variance); running statistics updated with momentum and the unbiased variance (nn.BatchNorm1d)
  *   ma_bn_swish_fwd_bf16   out = swish(gamma * (z - mean) * rstd + beta) bf16
- *   ma_bn_swish_bwd_f32    dz (float32) from dout (bf16): Swish', then the BatchNorm backward; dsum (2C) float32 +=
- *                          (dbeta, dgamma) (caller zeroes)
+ *   ma_bn_swish_bwd_f32    dz (float32) from dout (bf16): Swish', then the BatchNorm backward; dsum (2C) float32 =
+ *                          (sum dn | sum dn zhat), stored; d_gamma / d_beta (C, optional) += the parameter gradients;
+ *                          workspace >= 256 * 2C * 4 bytes (per-workgroup partials, summed in a fixed order)
  *   ma_convmid_bwd_bf16    dy (B*T, 2C) bf16 from dz: depthwise-conv backward + GLU backward; d_dw_w (C, k), d_dw_b (C)
- *                          float32 += (atomics) */
+ *                          float32 += per-workgroup partials summed in a fixed order
+ * No float atomics anywhere: two runs of a training step give bit-identical gradients. */
+int32_t ma_convmid_fwd_train_parts(int64_t batch, int64_t T, int32_t C);
 int ma_convmid_fwd_train(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
                          int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream);
-int ma_bn_finalize_f32(const float* sums, int32_t C, int64_t count, float eps, float momentum, float* running_mean,
-                       float* running_var, float* stats, ma_stream_t stream);
+int ma_bn_finalize_f32(const float* sums, int32_t nparts, int32_t C, int64_t count, float eps, float momentum,
+                       float* running_mean, float* running_var, float* stats, ma_stream_t stream);
 int ma_bn_swish_fwd_bf16(const float* z, const float* stats, const float* gamma, const float* beta, void* out,
                          int64_t rows, int32_t C, ma_stream_t stream);
 int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
-                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream);
+                        float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
+                        int64_t workspace_bytes, ma_stream_t stream);
 int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                         const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
                         void* workspace, int64_t workspace_bytes, ma_stream_t stream);
@@ -800,7 +812,8 @@ int ma_convmid_fwd_train_x32(const float* y, int64_t ldy, int64_t batch, int64_t
 int ma_bn_swish_fwd_x32(const float* z, const float* stats, const float* gamma, const float* beta, float* out,
                         int64_t rows, int32_t C, ma_stream_t stream);
 int ma_bn_swish_bwd_x32(const float* dout, const float* z, const float* stats, const float* gamma, const float* beta,
-                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream);
+                        float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
+                        int64_t workspace_bytes, ma_stream_t stream);
 int ma_convmid_bwd_x32(const float* dz, const float* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                        const float* dw_w, int32_t ks, float* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
                        void* workspace, int64_t workspace_bytes, ma_stream_t stream);

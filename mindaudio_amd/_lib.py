@@ -57,7 +57,7 @@ class ReduceItem(ctypes.Structure):
 
     _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("mn", ctypes.c_int64), ("ldo", ctypes.c_int64),
                 ("N", ctypes.c_int32), ("splits", ctypes.c_int32), ("alpha", ctypes.c_float), ("accumulate", ctypes.c_int32),
-                ("first_block", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("first_block", ctypes.c_int32), ("pstride", ctypes.c_int32)]
 
 
 class GemmEpilogue(ctypes.Structure):
@@ -152,7 +152,8 @@ PROTOTYPES = {
     "ma_conv2d_3x3s2_dw_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp, i64, vp]),
     "ma_transpose_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
     "ma_transpose_batch_bf16": (ctypes.c_int, [vp, vp, i32, vp]),
-    "ma_gemm_tn_partial_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i64, i64, vp, vp, i64, vp]),
+    "ma_gemm_tn_splits": (i32, [i64, i64, i64]),
+    "ma_gemm_tn_partial_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i64, i64, i32, vp, i64, vp]),
     "ma_reduce_splits_batch_f32": (ctypes.c_int, [vp, vp, i32, vp]),
     "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp]),
     "ma_train_reduce_workspace_bytes": (i64, []),
@@ -161,9 +162,11 @@ PROTOTYPES = {
     "ma_dropout_add_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i32, i64, i64, f32, f32, u32, u32, vp]),
     "ma_dropout_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, f32, vp, f32, u32, u32, vp]),
     "ma_convmid_fwd_train": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, vp, vp]),
-    "ma_bn_finalize_f32": (ctypes.c_int, [vp, i32, i64, f32, f32, vp, vp, vp, vp]),
+    "ma_bn_finalize_f32": (ctypes.c_int, [vp, i32, i32, i64, f32, f32, vp, vp, vp, vp]),
+    "ma_convmid_fwd_train_parts": (i32, [i64, i64, i32]),
+    "ma_layernorm_bwd_parts": (i32, [i64]),
     "ma_bn_swish_fwd_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, i32, vp]),
-    "ma_bn_swish_bwd_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "ma_bn_swish_bwd_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp]),
     "ma_convmid_bwd_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp, i64, vp]),
     "ma_relu_bwd_bf16": (ctypes.c_int, [vp, vp, i64, vp]),
     "ma_im2col_t_3x3s2_nhwc_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, i64, vp]),
@@ -245,7 +248,7 @@ PROTOTYPES = {
     "ma_dropout_bwd_x32": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, f32, vp, f32, u32, u32, vp]),
     "ma_convmid_fwd_train_x32": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, vp, vp]),
     "ma_bn_swish_fwd_x32": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, i32, vp]),
-    "ma_bn_swish_bwd_x32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "ma_bn_swish_bwd_x32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp]),
     "ma_convmid_bwd_x32": (ctypes.c_int, [vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp, i64, vp]),
     "ma_ctc_loss_grad_x32": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, i32, i32, f32, vp, vp, vp, vp, i64, vp,
                                             i64, vp]),

@@ -297,9 +297,31 @@ __global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restric
   }
   for (int v = threadIdx.x; v < V; v += 256) occ[v] = 0.0f;
   __syncthreads();
-  for (int s = threadIdx.x; s < S; s += 256) {
-    const int l = (s & 1) ? ys[(int64_t)b * Lmax + (s >> 1)] : blank;
-    atomicAdd(&occ[l], ab[row * Smax + s]);
+  // occ[v] = sum of the occupancies of the states that emit v, in a FIXED order (run-to-run deterministic; float atomics on the
+  // LDS word of a repeated label / of the blank gave the sum whatever order the hardware served them in).
+  //   wave 0: the blank (every even state, and any label equal to the blank): lane-strided sums + a shuffle tree;
+  //   threads 64 ..: label position i: the FIRST occurrence of a label adds all its occurrences in index order.
+  const float* abr = ab + row * Smax;
+  const int32_t* yb = ys + (int64_t)b * Lmax;
+  if (threadIdx.x < 64) {
+    float a = 0.0f;
+    for (int s = threadIdx.x; s < S; s += 64)
+      if (!(s & 1) || yb[s >> 1] == blank) a += abr[s];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (threadIdx.x == 0) occ[blank] = a;
+  } else {
+    for (int i = threadIdx.x - 64; i < U; i += 192) {
+      const int l = yb[i];
+      if (l == blank) continue;
+      bool first = true;
+      for (int k = 0; k < i; ++k) first = first && (yb[k] != l);
+      if (!first) continue;
+      float a = 0.0f;
+      for (int k = i; k < U; ++k)
+        if (yb[k] == l) a += abr[2 * k + 1];
+      occ[l] = a;
+    }
   }
   __syncthreads();
   const float* p = logits + row * ld;

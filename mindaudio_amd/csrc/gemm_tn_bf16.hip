@@ -35,7 +35,9 @@ struct TnParams {
   const uint16_t* A;  // (Kc, >= Mo) row stride lda
   const uint16_t* B;  // (Kc, >= No) row stride ldb
   float* part;        // workspace [splits][Mo_store][No]
-  float* colsum;      // optional [Mo]: += column sums of A (atomics across splits)
+  float* colsum;      // optional [Mo]: += column sums of A.  The kernel writes one partial vector per split (cs_part, behind the
+                      // partial products in the workspace); they are added in split order by the reduction - no atomics
+  float* cs_part;     // [splits][Mo_store]
   int64_t lda, ldb;
   int32_t Mo, No, Kc, Mo_store, kt_split;
   // IM2COL: B is the im2col matrix of a 3x3 stride-2 valid convolution over an NHWC activation (batch, H, Wd, C):
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnPar
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int oi = i0 + wm * (BM / 2) + i * 16 + ei;
-    if (want_cs && wn == 0 && lg == 0 && oi < p.Mo_store) atomicAdd(p.colsum + oi, cs[i][0]);
+    if (want_cs && wn == 0 && lg == 0 && oi < p.Mo_store) p.cs_part[(int64_t)blockIdx.y * p.Mo_store + oi] = cs[i][0];
     if (oi >= p.Mo_store) continue;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -263,41 +265,77 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
-// The split sums of a list of products in one launch (ma_reduce_splits_batch_f32): workgroup b owns 1024 consecutive elements of
-// item block_item[b]; splits are added in the order k = 0 .. splits - 1.
+// The split sums of a list of products in one launch (ma_reduce_splits_batch_f32): splits are added in the order k = 0 .. splits - 1.
+//   short items (accumulate bit 1 clear; weight-gradient splits, a handful of partials of many elements): workgroup b owns 1024
+//     consecutive elements of item block_item[b], one thread per 4 elements;
+//   tall items (accumulate bit 1 set; per-workgroup partials of a parameter reduction: hundreds of partials of a few hundred
+//     elements): workgroup b owns 64 consecutive elements, thread (tx = 4 elements, ty = one of 16 groups of partials) adds the
+//     partials ty, ty + 16, ... in order and the 16 group sums are added in order through LDS - a fixed order either way.
 __global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ma_reduce_item_t* __restrict__ items,
                                                               const int32_t* __restrict__ block_item) {
+  __shared__ float4 red[16][17];
   const ma_reduce_item_t it = items[block_item[blockIdx.x]];
-  const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x) * 4;
-  if (i0 >= it.mn) return;
-  if (!(it.N & 3) && !(it.ldo & 3) && !(it.mn & 3) &&
-      !((reinterpret_cast<uintptr_t>(it.out) | reinterpret_cast<uintptr_t>(it.part)) & 15)) {  // 16-byte pieces: a piece never straddles a row
+  const int64_t ps = it.pstride ? (int64_t)it.pstride : it.mn;
+  const bool acc = it.accumulate & 1, tall = it.accumulate & 2;
+  const bool vec = !(it.N & 3) && !(it.ldo & 3) && !(it.mn & 3) && !(ps & 3) &&
+                   !((reinterpret_cast<uintptr_t>(it.out) | reinterpret_cast<uintptr_t>(it.part)) & 15);  // a piece never straddles a row
+  auto store4 = [&](int64_t i0, float4 sum) {
+    const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+    if (vec) {
+      const int64_t m = i0 / it.N;
+      float4* o = reinterpret_cast<float4*>(it.out + m * it.ldo + (i0 - m * it.N));
+      float4 r = make_float4(it.alpha * v[0], it.alpha * v[1], it.alpha * v[2], it.alpha * v[3]);
+      if (acc) {
+        const float4 old = *o;
+        r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+      }
+      *o = r;
+      return;
+    }
+    for (int e = 0; e < 4 && i0 + e < it.mn; ++e) {
+      const int64_t i = i0 + e, m = i / it.N;
+      float* o = it.out + m * it.ldo + (i - m * it.N);
+      *o = acc ? *o + it.alpha * v[e] : it.alpha * v[e];
+    }
+  };
+  auto load4 = [&](int64_t k, int64_t i0) -> float4 {
+    const float* src = it.part + k * ps + i0;
+    if (vec) return *reinterpret_cast<const float4*>(src);
+    return make_float4(src[0], i0 + 1 < it.mn ? src[1] : 0.f, i0 + 2 < it.mn ? src[2] : 0.f, i0 + 3 < it.mn ? src[3] : 0.f);
+  };
+  if (tall) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 16 + tx) * 4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* src = it.part + i0;
+    if (i0 < it.mn) {
 #pragma unroll 4
-    for (int k = 0; k < it.splits; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)k * it.mn);
-      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      for (int k = ty; k < it.splits; k += 16) {
+        const float4 v = load4(k, i0);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
     }
-    const int64_t m = i0 / it.N;
-    float4* o = reinterpret_cast<float4*>(it.out + m * it.ldo + (i0 - m * it.N));
-    float4 r = make_float4(it.alpha * sum.x, it.alpha * sum.y, it.alpha * sum.z, it.alpha * sum.w);
-    if (it.accumulate) {
-      const float4 old = *o;
-      r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+    red[ty][tx] = sum;
+    __syncthreads();
+    if (ty == 0 && i0 < it.mn) {
+      sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float4 v = red[k][tx];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+      store4(i0, sum);
     }
-    *o = r;
     return;
   }
-  for (int e = 0; e < 4; ++e) {
-    const int64_t i = i0 + e;
-    if (i >= it.mn) return;
-    float sum = 0.0f;
-    for (int k = 0; k < it.splits; ++k) sum += it.part[(int64_t)k * it.mn + i];
-    const int64_t m = i / it.N;
-    float* o = it.out + m * it.ldo + (i - m * it.N);
-    *o = it.accumulate ? *o + it.alpha * sum : it.alpha * sum;
+  const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x) * 4;
+  if (i0 >= it.mn) return;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int k = 0; k < it.splits; ++k) {
+    const float4 v = load4(k, i0);
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
   }
+  store4(i0, sum);
 }
 
 static int tn_cus() {
@@ -337,7 +375,8 @@ static int tn_launch(TnParams& p, bool im2col, float* out, int64_t ldo, float al
   int bm = 64, kt = 0;
   const int splits = tn_plan(p.Mo, p.No, p.Kc, &bm, &kt);
   p.kt_split = kt;
-  if (workspace_bytes < (int64_t)splits * p.Mo_store * p.No * 4) return MA_ERR_WORKSPACE;
+  if (workspace_bytes < (int64_t)splits * p.Mo_store * (p.No + 1) * 4) return MA_ERR_WORKSPACE;
+  p.cs_part = reinterpret_cast<float*>(workspace) + (int64_t)splits * p.Mo_store * p.No;
   const int tiles = (int)(((p.Mo + bm - 1) / bm) * ((p.No + 127) / 128));
   const int lds = kTnStages * (kTnBK * bm * 2 + kTnBK * 256);
 #define MA_TN_GO(BM_, IM_)                                                                                            \
@@ -362,13 +401,22 @@ static int tn_launch(TnParams& p, bool im2col, float* out, int64_t ldo, float al
   if (blocks > 2048) blocks = 2048;
   MA_LAUNCH(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), splits, mn,
             out, ldo, p.No, alpha, accumulate);
+  if (p.colsum)  // colsum[i] += the splits' partial column sums, in split order
+    MA_LAUNCH(tn_reduce_kernel, dim3((unsigned)((p.Mo_store + 255) / 256)), dim3(256), 0, s, p.cs_part, splits, (int64_t)p.Mo_store,
+              p.colsum, (int64_t)p.Mo_store, p.Mo_store, 1.0f, 1);
   return MA_OK;
 }
 
 int64_t ma_gemm_tn_workspace_bytes(int64_t Mo, int64_t No, int64_t Kc) {
   if (Mo < 1 || No < 1 || Kc < 1) return MA_ERR_INVALID_ARG;
   int bm = 0, kt = 0;
-  return (int64_t)tn_plan(Mo, No, Kc, &bm, &kt) * Mo * No * 4;
+  return (int64_t)tn_plan(Mo, No, Kc, &bm, &kt) * Mo * (No + 1) * 4;  // partial products + one partial column-sum vector per split
+}
+
+int32_t ma_gemm_tn_splits(int64_t Mo, int64_t No, int64_t Kc) {
+  if (Mo < 1 || No < 1 || Kc < 1) return MA_ERR_INVALID_ARG;
+  int bm = 0, kt = 0;
+  return tn_plan(Mo, No, Kc, &bm, &kt);
 }
 
 int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, float* out, int64_t ldo, int64_t Mo,
@@ -395,7 +443,7 @@ int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, 
 }
 
 int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t Mo, int64_t No, int64_t Kc,
-                            int64_t Mo_store, float* colsum, void* partial, int64_t partial_bytes, ma_stream_t stream) {
+                            int64_t Mo_store, int32_t with_colsum, void* partial, int64_t partial_bytes, ma_stream_t stream) {
   if (!A || !B || !partial || Mo < 8 || No < 8 || Kc < 1 || Mo_store < 1 || Mo_store > Mo) return MA_ERR_INVALID_ARG;
   if ((Mo & 7) || (No & 7) || (lda & 7) || (ldb & 7) || lda < Mo || ldb < No || Mo > 0x7fffffff || No > 0x7fffffff ||
       Kc > 0x7fffffff)
@@ -406,7 +454,7 @@ int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t l
   p.A = reinterpret_cast<const uint16_t*>(A);
   p.B = reinterpret_cast<const uint16_t*>(B);
   p.part = reinterpret_cast<float*>(partial);
-  p.colsum = colsum;
+  p.colsum = with_colsum ? reinterpret_cast<float*>(partial) : nullptr;  // (flag only: the kernel writes cs_part, set by tn_launch)
   p.lda = lda;
   p.ldb = ldb;
   p.Mo = (int32_t)Mo;

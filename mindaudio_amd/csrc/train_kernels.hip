@@ -164,25 +164,59 @@ __global__ __launch_bounds__(256) void transpose_batch_bf16_kernel(const ma_tran
   }
 }
 
-// out_a[j] += sum_b part[b][j] (j < na), out_b[j - na] += sum_b part[b][j] (na <= j < n): second stage of the
-// parameter-gradient reductions (fixed summation order; no contended atomics)
+// out_a[j] (+)= sum_b part[b][j] (j < na), out_b[j - na] (+)= sum_b part[b][j] (na <= j < n): second stage of the
+// parameter-gradient reductions.  FIXED summation order (run-to-run deterministic, no atomics): a workgroup owns 16 columns,
+// thread (tx = column, ty = one of 16 row groups) adds the partial rows ty, ty + 16, ... in order, the 16 group sums are added in
+// order 0 .. 15.  `store`: out = sum instead of out += sum.
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int nblk, int n, float* out_a,
-                                                             int na, float* out_b) {
-  // grid (ceil(n / 64), kRedSlices): 64 columns x 4 row groups per workgroup, blockIdx.y owns a slice of the partial
-  // rows; the kRedSlices slice sums meet in one float32 atomic per output element
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + tx;
-  const int per = (nblk + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+                                                             int na, float* out_b, int store) {
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + tx;
   float s = 0.0f;
-  if (j < n)
-    for (int b = b0 + ty; b < b1; b += 4) s += part[(int64_t)b * n + j];
+  if (j < n) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // four loads in flight; combined in a fixed order below
+    int b = ty;
+    for (; b + 48 < nblk; b += 64) {
+      s0 += part[(int64_t)b * n + j];
+      s1 += part[(int64_t)(b + 16) * n + j];
+      s2 += part[(int64_t)(b + 32) * n + j];
+      s3 += part[(int64_t)(b + 48) * n + j];
+    }
+    for (; b < nblk; b += 16) s0 += part[(int64_t)b * n + j];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && j < n) {
-    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-    atomicAdd(j < na ? out_a + j : out_b + (j - na), s);
+    s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][tx];
+    float* o = j < na ? out_a + j : out_b + (j - na);
+    *o = store ? s : *o + s;
+  }
+}
+
+// BatchNorm backward, second stage: dsum[j] = sum_b part[b][j] (j < 2 C: sum dn | sum dn * zhat), stored for bn_bwd2_kernel, and
+// the parameter gradients d_beta[c] += dsum[c], d_gamma[c] += dsum[C + c] (nn.BatchNorm1d: dL/dbeta = sum dn, dL/dgamma = sum dn zhat).
+// Same fixed order as partial_reduce_kernel.
+__global__ __launch_bounds__(256) void bn_dsum_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* dsum,
+                                                             float* d_gamma, float* d_beta) {
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + tx, n = 2 * C;
+  float s = 0.0f;
+  if (j < n)
+    for (int b = ty; b < nblk; b += 16) s += part[(int64_t)b * n + j];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < n) {
+    s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][tx];
+    dsum[j] = s;
+    if (j < C) { if (d_beta) d_beta[j] += s; }
+    else if (d_gamma) d_gamma[j - C] += s;
   }
 }
 
@@ -321,7 +355,7 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(float* x, int64_t ldx,
     const int c = (int)(i - r * cols);
     float v = Y_BF16 ? bf2f(reinterpret_cast<const uint16_t*>(y_)[r * ldy + c]) : reinterpret_cast<const float*>(y_)[r * ldy + c];
     if (d.thresh) v = keep_elem(d.seed, d.salt, (uint64_t)i, d.thresh) ? v * d.inv_keep : 0.0f;
-    x[r * ldx + c] = xin[r * ldxin + c] + alpha * v;
+    x[r * ldx + c] = (xin ? xin[r * ldxin + c] : 0.0f) + alpha * v;
   }
 }
 // dy = alpha * keep / (1 - p) * g * row_scale  (bf16 operand of the branch's last GEMM backward)
@@ -384,18 +418,39 @@ __global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const AT* __rest
       s2 += acc * acc;
     }
   }
-  atomicAdd(sums + c, s1);
-  atomicAdd(sums + C + c, s2);
+  // per-workgroup partial (sum | sum of squares) of the workgroup's frames; bn_finalize_kernel adds them in a fixed order
+  float* pp = sums + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * (2 * C);
+  pp[c] = s1;
+  pp[C + c] = s2;
 }
 
 // stats[c] = mean, stats[C + c] = rstd (biased variance, nn.BatchNorm1d training mode); running statistics updated
-// with the unbiased variance: running = (1 - momentum) * running + momentum * batch.
-__global__ void bn_finalize_kernel(const float* sums, int C, float count, float eps, float momentum, float* run_mean,
-                                   float* run_var, float* stats) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float mean = sums[c] / count;
-  float var = sums[C + c] / count - mean * mean;
+// with the unbiased variance: running = (1 - momentum) * running + momentum * batch.  `sums` = nparts partial vectors
+// (sum | sum of squares) of 2 C floats; workgroup = 16 channels x 16 groups of partials, fixed summation order.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, int nparts, int C, float count, float eps,
+                                                          float momentum, float* run_mean, float* run_var, float* stats) {
+  __shared__ float red[2][16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
+  float a = 0.0f, q = 0.0f;
+  if (c < C)
+    for (int b = ty; b < nparts; b += 16) {
+      a += sums[(int64_t)b * 2 * C + c];
+      q += sums[(int64_t)b * 2 * C + C + c];
+    }
+  red[0][ty][tx] = a;
+  red[1][ty][tx] = q;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  a = 0.0f;
+  q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    a += red[0][k][tx];
+    q += red[1][k][tx];
+  }
+  const float mean = a / count;
+  float var = q / count - mean * mean;
   var = var < 0.0f ? 0.0f : var;
   stats[c] = mean;
   stats[C + c] = 1.0f / sqrtf(var + eps);
@@ -424,9 +479,7 @@ __global__ __launch_bounds__(256) void bn_swish_bwd1_kernel(const AT* __restrict
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ dn,
                                                             int64_t rows, int C, float* dsum) {
-  extern __shared__ float lsum[];
-  for (int i = threadIdx.x; i < 2 * C; i += 256) lsum[i] = 0.0f;
-  __syncthreads();
+  extern __shared__ float lsum[];  // [rpb][2 C]: one slot per thread, summed over the row groups in order (no atomics)
   // thread owns channel c = tid % C... keep a fixed channel per thread so the sums stay in registers
   const int c = threadIdx.x % C;
   const int rpb = 256 / C > 0 ? 256 / C : 1;  // rows per pass of this block (C = 256 -> 1)
@@ -443,10 +496,16 @@ __global__ __launch_bounds__(256) void bn_swish_bwd1_kernel(const AT* __restrict
     s0 += d;
     s1 += d * zh;
   }
-  atomicAdd(&lsum[c], s0);
-  atomicAdd(&lsum[C + c], s1);
+  if (rsub < rpb) {
+    lsum[rsub * 2 * C + c] = s0;
+    lsum[rsub * 2 * C + C + c] = s1;
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dsum + i, lsum[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {  // per-workgroup partial; bn_dsum_reduce_kernel adds the workgroups
+    float t = 0.0f;
+    for (int r = 0; r < rpb; ++r) t += lsum[r * 2 * C + i];
+    dsum[(int64_t)blockIdx.x * 2 * C + i] = t;
+  }
 }
 
 // The same with 4 channels per thread (C % 4 == 0, C <= 1024 / ... : 256 threads = 256 / (C / 4) rows per pass): 16-byte accesses,
@@ -465,9 +524,7 @@ __global__ __launch_bounds__(256) void bn_swish_bwd1_v4_kernel(const AT* __restr
                                                                const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ dn,
                                                                int64_t rows, int C, float* dsum) {
-  extern __shared__ float lsum[];
-  for (int i = threadIdx.x; i < 2 * C; i += 256) lsum[i] = 0.0f;
-  __syncthreads();
+  extern __shared__ float lsum[];        // [rpb][2 C] (see bn_swish_bwd1_kernel)
   const int c4 = C >> 2;                 // threads per row
   const int rpb = 256 / c4;              // rows per pass of this block
   const int c = (threadIdx.x % c4) * 4, rsub = threadIdx.x / c4;
@@ -492,14 +549,20 @@ __global__ __launch_bounds__(256) void bn_swish_bwd1_v4_kernel(const AT* __restr
       }
       *reinterpret_cast<float4*>(dn + i) = make_float4(o[0], o[1], o[2], o[3]);
     }
+  }
+  if (rsub < rpb) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      atomicAdd(&lsum[c + e], s0[e]);
-      atomicAdd(&lsum[C + c + e], s1[e]);
+      lsum[rsub * 2 * C + c + e] = s0[e];
+      lsum[rsub * 2 * C + C + c + e] = s1[e];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dsum + i, lsum[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.0f;
+    for (int r = 0; r < rpb; ++r) t += lsum[r * 2 * C + i];
+    dsum[(int64_t)blockIdx.x * 2 * C + i] = t;
+  }
 }
 
 // dz = gamma * rstd * (dn - dsum0 / N - zhat * dsum1 / N), in place over dn
@@ -866,8 +929,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-constexpr int kRedSlices = 16;
 constexpr int kMaxPartBlocks = 2048, kMaxPartWidth = 8448;  // partial-sum workspace of the two-stage reductions
+constexpr int kLnBwdBlocks = 512;  // workgroups (= partial (dgamma | dbeta) vectors) of a LayerNorm backward launch
 
 static int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
   int64_t g = (n + per_block - 1) / per_block;
@@ -920,14 +983,16 @@ int ma_transpose_batch_bf16(const ma_transpose_item_t* items, const int32_t* blo
 
 int64_t ma_train_reduce_workspace_bytes(void) { return (int64_t)kMaxPartBlocks * kMaxPartWidth * 4; }
 
+int32_t ma_layernorm_bwd_parts(int64_t rows) { return rows < 1 ? MA_ERR_INVALID_ARG : grid_for(rows, 4, kLnBwdBlocks); }
+
 int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
                          const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
                          int32_t accumulate, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
                          ma_stream_t stream) {
-  if (!x || !gamma || !dy || !g || !dgamma || !dbeta || !workspace || rows < 1) return MA_ERR_INVALID_ARG;
+  if (!x || !gamma || !dy || !g || (dgamma && !dbeta) || !workspace || rows < 1) return MA_ERR_INVALID_ARG;
   if (D != 256 || (ldx & 3) || (ldy & 3) || (ldg & 3)) return MA_ERR_UNSUPPORTED;
-  if (workspace_bytes < ma_train_reduce_workspace_bytes()) return MA_ERR_WORKSPACE;
-  const int grid = grid_for(rows, 4, 1024);
+  const int grid = ma_layernorm_bwd_parts(rows);
+  if (workspace_bytes < (int64_t)grid * 512 * 4) return MA_ERR_WORKSPACE;
   float* part = reinterpret_cast<float*>(workspace);
   if (dy_bf16)
     MA_LAUNCH(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
@@ -935,7 +1000,8 @@ int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, c
   else
     MA_LAUNCH(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
               row_scale, dy, ldy, g, ldg, accumulate, part);
-  MA_LAUNCH(partial_reduce_kernel, dim3(8, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, grid, 512, dgamma, 256, dbeta);
+  if (dgamma)
+    MA_LAUNCH(partial_reduce_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, part, grid, 512, dgamma, 256, dbeta, 0);
   return MA_OK;
 }
 
@@ -960,7 +1026,7 @@ int ma_act_dropout_bwd_bf16(const void* u, const void* dh, void* du, int64_t n, 
 
 int ma_dropout_add_f32(float* x, int64_t ldx, const float* xin, int64_t ldxin, const void* y, int64_t ldy, int32_t y_bf16,
                        int64_t rows, int64_t cols, float alpha, float p, uint32_t seed, uint32_t salt, ma_stream_t stream) {
-  if (!x || !xin || !y || rows < 1 || cols < 1 || ldx < cols || ldxin < cols || ldy < cols || p < 0.0f || p >= 1.0f)
+  if (!x || !y || rows < 1 || cols < 1 || ldx < cols || (xin && ldxin < cols) || ldy < cols || p < 0.0f || p >= 1.0f)
     return MA_ERR_INVALID_ARG;
   const Drop d = make_drop(p, seed, salt);
   if (y_bf16)
@@ -1011,7 +1077,7 @@ template <typename AT>
 static int convmid_fwd_train_launch(const AT* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
                                     int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
   if (!y || !dw_w || !dw_b || !z || !sums || batch < 1 || T < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
-  if (C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31) || (sizeof(AT) == 2 && (ldy & 1))) return MA_ERR_UNSUPPORTED;
+  if (C != 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31) || (sizeof(AT) == 2 && (ldy & 1))) return MA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)((T + kCfStrip * kCfPerBlock - 1) / (kCfStrip * kCfPerBlock)), (unsigned)batch, (unsigned)(C / 256));
 #define MA_CF(KS_)                                                                                                  \
   MA_LAUNCH((convmid_fwd_train_kernel<KS_, AT>), grid, dim3(256), 0, (hipStream_t)stream, y, ldy, (int)T, C, dw_w, dw_b, z, sums)
@@ -1023,6 +1089,10 @@ static int convmid_fwd_train_launch(const AT* y, int64_t ldy, int64_t batch, int
   return MA_OK;
 }
 }  // extern "C++"
+int32_t ma_convmid_fwd_train_parts(int64_t batch, int64_t T, int32_t C) {
+  if (batch < 1 || T < 1 || C % 256) return MA_ERR_INVALID_ARG;
+  return (int32_t)(((T + kCfStrip * kCfPerBlock - 1) / (kCfStrip * kCfPerBlock)) * batch);
+}
 int ma_convmid_fwd_train(const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
                          int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
   return convmid_fwd_train_launch((const uint16_t*)y, ldy, batch, T, C, dw_w, ks, dw_b, z, sums, stream);
@@ -1032,10 +1102,10 @@ int ma_convmid_fwd_train_x32(const float* y, int64_t ldy, int64_t batch, int64_t
   return convmid_fwd_train_launch(y, ldy, batch, T, C, dw_w, ks, dw_b, z, sums, stream);
 }
 
-int ma_bn_finalize_f32(const float* sums, int32_t C, int64_t count, float eps, float momentum, float* running_mean,
-                       float* running_var, float* stats, ma_stream_t stream) {
-  if (!sums || !stats || C < 1 || count < 1) return MA_ERR_INVALID_ARG;
-  MA_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, (float)count, eps,
+int ma_bn_finalize_f32(const float* sums, int32_t nparts, int32_t C, int64_t count, float eps, float momentum,
+                       float* running_mean, float* running_var, float* stats, ma_stream_t stream) {
+  if (!sums || !stats || C < 1 || count < 1 || nparts < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, sums, nparts, C, (float)count, eps,
             momentum, running_mean, running_var, stats);
   return MA_OK;
 }
@@ -1062,29 +1132,40 @@ int ma_bn_swish_fwd_x32(const float* z, const float* stats, const float* gamma, 
 extern "C++" {
 template <typename AT>
 static int bn_swish_bwd_launch(const AT* dout, const float* z, const float* stats, const float* gamma, const float* beta,
-                               float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream) {
-  if (!dout || !z || !stats || !gamma || !beta || !dz || !dsum || rows < 1) return MA_ERR_INVALID_ARG;
+                               float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
+                               int64_t workspace_bytes, ma_stream_t stream) {
+  if (!dout || !z || !stats || !gamma || !beta || !dz || !dsum || !workspace || rows < 1) return MA_ERR_INVALID_ARG;
   if (C < 1 || C > 256 || 256 % C) return MA_ERR_UNSUPPORTED;
+  if (workspace_bytes < (int64_t)256 * 2 * C * 4) return MA_ERR_WORKSPACE;
+  float* part = reinterpret_cast<float*>(workspace);  // one (sum dn | sum dn zhat) vector per workgroup
   const int rpb = 256 / C;
+  int nblk;
   if ((C & 3) == 0 && 256 % (C / 4) == 0 &&
-      ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0)
-    MA_LAUNCH(bn_swish_bwd1_v4_kernel<AT>, dim3(grid_for(rows, 256 / (C / 4), 256)), dim3(256), 2 * C * sizeof(float),
-              (hipStream_t)stream, dout, z, stats, gamma, beta, dz, rows, C, dsum);
-  else
-    MA_LAUNCH(bn_swish_bwd1_kernel<AT>, dim3(grid_for(rows, rpb, 256)), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
-              dout, z, stats, gamma, beta, dz, rows, C, dsum);
+      ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0) {
+    nblk = grid_for(rows, 256 / (C / 4), 256);
+    MA_LAUNCH(bn_swish_bwd1_v4_kernel<AT>, dim3(nblk), dim3(256), (256 / (C / 4)) * 2 * C * sizeof(float), (hipStream_t)stream, dout,
+              z, stats, gamma, beta, dz, rows, C, part);
+  } else {
+    nblk = grid_for(rows, rpb, 256);
+    MA_LAUNCH(bn_swish_bwd1_kernel<AT>, dim3(nblk), dim3(256), rpb * 2 * C * sizeof(float), (hipStream_t)stream, dout, z, stats,
+              gamma, beta, dz, rows, C, part);
+  }
+  MA_LAUNCH(bn_dsum_reduce_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nblk, C, dsum, d_gamma, d_beta);
   MA_LAUNCH(bn_bwd2_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dz, z, stats, gamma, dsum, rows,
             C, 1.0f / (float)rows);
   return MA_OK;
 }
 }  // extern "C++"
 int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
-                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream) {
-  return bn_swish_bwd_launch((const uint16_t*)dout, z, stats, gamma, beta, dz, rows, C, dsum, stream);
+                        float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
+                        int64_t workspace_bytes, ma_stream_t stream) {
+  return bn_swish_bwd_launch((const uint16_t*)dout, z, stats, gamma, beta, dz, rows, C, dsum, d_gamma, d_beta, workspace,
+                             workspace_bytes, stream);
 }
 int ma_bn_swish_bwd_x32(const float* dout, const float* z, const float* stats, const float* gamma, const float* beta,
-                        float* dz, int64_t rows, int32_t C, float* dsum, ma_stream_t stream) {
-  return bn_swish_bwd_launch(dout, z, stats, gamma, beta, dz, rows, C, dsum, stream);
+                        float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
+                        int64_t workspace_bytes, ma_stream_t stream) {
+  return bn_swish_bwd_launch(dout, z, stats, gamma, beta, dz, rows, C, dsum, d_gamma, d_beta, workspace, workspace_bytes, stream);
 }
 
 extern "C++" {
@@ -1113,8 +1194,8 @@ static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t
   else if (ks == 15) { MA_CMB(15); }
   else { MA_CMB(31); }
 #undef MA_CMB
-  MA_LAUNCH(partial_reduce_kernel, dim3((width + 63) / 64, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, nblk, width, d_dw_w,
-            C * ks, d_dw_b);
+  MA_LAUNCH(partial_reduce_kernel, dim3((width + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nblk, width, d_dw_w, C * ks,
+            d_dw_b, 0);
   return MA_OK;
 }
 }  // extern "C++"
@@ -1192,8 +1273,8 @@ static int conv1_dw_launch(const AT* dact, const float* x, int64_t batch, int64_
   else
     MA_LAUNCH(conv1_dw_kernel<AT>, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,
               (hipStream_t)stream, dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, part, strip);
-  MA_LAUNCH(partial_reduce_kernel, dim3((C * 10 + 63) / 64, kRedSlices), dim3(256), 0, (hipStream_t)stream, part, nblk, C * 10, dw,
-            C * 9, db);
+  MA_LAUNCH(partial_reduce_kernel, dim3((C * 10 + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nblk, C * 10, dw, C * 9, db,
+            0);
   return MA_OK;
 }
 }  // extern "C++"

@@ -339,10 +339,10 @@ class ConformerEncoder(nn.Module):
         mask_rows = mask2d.reshape(m)
         att_mask = self._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
         e = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(d), out_dtype=f32)
-        x = K.dropout_add(torch.zeros_like(e), e, 1.0, pp, seed, salt(-1, 0)) if pp > 0 else e
+        x = K.dropout_add(None, e, 1.0, pp, seed, salt(-1, 0)) if pp > 0 else e
         pe = self.pe[:t2].to(f32).contiguous()
         if pp > 0:
-            pe = K.dropout_add(torch.zeros_like(pe), pe, 1.0, pp, seed, salt(-1, 1))
+            pe = K.dropout_add(None, pe, 1.0, pp, seed, salt(-1, 1))
         pos_all = ops.gemm(ops.cast_bf16(pe), P["pos_w"])
 
         def ffn(x, W, key, ln, li, s0):

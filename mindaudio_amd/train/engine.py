@@ -432,17 +432,19 @@ class ConformerCTCTrainStep:
 
     _DW_SUFFIXES = ("ffm_w1", "ffm_w2", "qkv_w", "o_w", "pw1_w", "pw2_w", "ff_w1", "ff_w2")
 
+    _LN_SITES = ("norm_final", "norm_ff", "norm_conv", "norm_mha", "norm_ff_macaron")
+
     def _dw_plan_for(self, m):
-        """Deferred split sums of a block's eight weight gradients (bf16 mode): the products write their split-K partials into an
-        arena that all blocks share, ONE launch per block adds them into the flat gradient (ma_reduce_splits_batch_f32) instead of
-        one 6.6 us reduction launch per product.  Built once per row count m."""
+        """Deferred parameter-gradient sums of a block (bf16 mode): the eight weight-gradient products write their split-K partials
+        (and one partial bias-gradient vector per split) and the five LayerNorm backward launches their per-workgroup (dgamma | dbeta)
+        partials into ONE arena that all blocks share, and ONE launch per block adds them into the flat gradient in a fixed order
+        (ma_reduce_splits_batch_f32) instead of a 6 us reduction launch per product / per LayerNorm.  The arena is sized for the
+        largest row count seen so far; the per-m offsets and device item tables are re-derived when m changes (one plan is kept)."""
         if self.x32:
             return None
-        plans = self.__dict__.setdefault("_dw_plans", {})
-        if m in plans:
-            return plans[m]
-        import ctypes
-
+        cur = self.__dict__.get("_dw_plan")
+        if cur is not None and cur["m"] == m:
+            return cur
         import numpy as np
 
         lib, fp = _lib.load(), self.fp
@@ -450,35 +452,62 @@ class ConformerCTCTrainStep:
         for sfx in self._DW_SUFFIXES:
             mo, no = fp.w("l0." + sfx).shape
             nbytes = int(lib.ma_gemm_tn_workspace_bytes(mo, no, m))
-            off[sfx] = (total, nbytes, nbytes // (mo * no * 4))
+            off[sfx] = (total, nbytes, int(lib.ma_gemm_tn_splits(mo, no, m)))
             total += (nbytes + 255) // 256 * 256
-        arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
+        ln_parts = int(lib.ma_layernorm_bwd_parts(m))
+        for site in self._LN_SITES:
+            off[site] = (total, ln_parts * 512 * 4, ln_parts)
+            total += ln_parts * 512 * 4
+        arena = self.__dict__.get("_dw_arena")
+        if arena is None or arena.numel() < total:
+            arena = self._dw_arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
         layers = []
         for li in range(self.L):
             items, block_item, first = [], [], 0
-            for i, sfx in enumerate(self._DW_SUFFIXES):
+
+            def add(part_ptr, out, mn, ldo, n_cols, splits, pstride, tall):
+                nonlocal first
+                nblk = (mn + 63) // 64 if tall else (mn + 1023) // 1024
+                items.append(_lib.ReduceItem(part_ptr, out.data_ptr(), mn, ldo, n_cols, splits, 1.0, 1 | (2 if tall else 0), first,
+                                             pstride))
+                block_item.extend([len(items) - 1] * nblk)
+                first += nblk
+
+            for sfx in self._DW_SUFFIXES:
                 g = fp.g("l%d.%s" % (li, sfx))
+                gb = fp.g("l%d.%s" % (li, sfx.replace("_w", "_b")))
                 mo, no = g.shape
                 o, nbytes, splits = off[sfx]
-                nblk = (mo * no + 1023) // 1024
-                items.append(_lib.ReduceItem(arena.data_ptr() + o, g.data_ptr(), mo * no, g.stride(0), no, splits, 1.0, 1, first, 0))
-                block_item += [i] * nblk
-                first += nblk
+                add(arena.data_ptr() + o, g, mo * no, g.stride(0), no, splits, 0, False)
+                add(arena.data_ptr() + o + splits * mo * no * 4, gb, mo, mo, mo, splits, 0, False)   # bias: partial column sums
+            for site in self._LN_SITES:
+                o, nbytes, parts = off[site]
+                gg = fp.g("l%d.%s.g" % (li, site))  # (g | b): 2 x 256 contiguous floats of the flat gradient
+                assert fp.index["l%d.%s.b" % (li, site)][0] == fp.index["l%d.%s.g" % (li, site)][0] + 256
+                add(arena.data_ptr() + o, gg, 512, 512, 512, parts, 512, True)
             raw = (_lib.ReduceItem * len(items))(*items)
             layers.append((torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
                            torch.tensor(block_item, dtype=torch.int32, device=self.dev), first))
-        plans[m] = dict(arena=arena, off=off, layers=layers)
-        return plans[m]
+        self._dw_plan = dict(m=m, arena=arena, off=off, layers=layers)
+        return self._dw_plan
+
+    def _ln_partials(self, site):
+        """The arena slice that LayerNorm `site` of the current block writes its per-workgroup partials to (None: immediate sums)."""
+        plan = getattr(self, "_dw_cur", None)
+        if plan is None:
+            return None
+        o, nbytes, _ = plan["off"][site]
+        return plan["arena"][o:o + nbytes].view(torch.float32)
 
     def _dW(self, dy, x, wname, bname):
         """grad[wname] (N, K) += dy^T x ; grad[bname] += column sums of dy.  dy (M, N), x (M, K) bf16."""
         fp = self.fp
         plan = getattr(self, "_dw_cur", None)
-        if plan is not None and wname[0] == "l":
+        if plan is not None and wname[0] == "l" and bname is not None:
             sfx = wname.split(".", 1)[1]
             if sfx in plan["off"]:
                 o, nbytes, _ = plan["off"][sfx]
-                self.K.gemm_tn_partial(dy, x, plan["arena"][o:o + nbytes], colsum=fp.g(bname) if bname else None)
+                self.K.gemm_tn_partial(dy, x, plan["arena"][o:o + nbytes], with_colsum=True)
                 return
         self.K.gemm_tn(dy, x, fp.g(wname), colsum=fp.g(bname) if bname else None)
 
@@ -521,10 +550,10 @@ class ConformerCTCTrainStep:
         hlens = mask2d.sum(1).to(torch.int32)
         a2 = act2.view(m, f2 * c)
         e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)
-        x = K.dropout_add(torch.zeros_like(e), e, 1.0, pp, seed, self._salt(-1, 0)) if pp > 0 else e
+        x = K.dropout_add(None, e, 1.0, pp, seed, self._salt(-1, 0)) if pp > 0 else e
         pe = enc.pe[:t2].to(f32).contiguous()
         if pp > 0:
-            pe = K.dropout_add(torch.zeros_like(pe), pe, 1.0, pp, seed, self._salt(-1, 1))
+            pe = K.dropout_add(None, pe, 1.0, pp, seed, self._salt(-1, 1))
         pe_bf = ops.cast_bf16(pe)
         pos_all = ops.gemm(pe_bf, fp.w("pos_w"))  # (t2, L*256) bf16
         tape = []
@@ -590,7 +619,8 @@ class ConformerCTCTrainStep:
             pre = "l%d." % li
             W, P, G = (lambda n, pre=pre: fp.w(pre + n)), (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n))
             T = tape[li]
-            K.layernorm_bwd(T["final_in"], P("norm_final.g"), g, g, G("norm_final.g"), G("norm_final.b"), accumulate=False)
+            K.layernorm_bwd(T["final_in"], P("norm_final.g"), g, g, G("norm_final.g"), G("norm_final.b"), accumulate=False,
+                            partials=self._ln_partials("norm_final"))
             self._ffn_bwd(g, T["ff"], "ff", "norm_ff", pre, seed, li, 6)
             # conv module
             C = T["conv"]
@@ -601,7 +631,8 @@ class ConformerCTCTrainStep:
                                G("dw_b"), G("bn_g"), G("bn_b"))
             self._dW(dy, C["a"], pre + "pw1_w", pre + "pw1_b")
             da = self._dX(dy, pre + "pw1_w")
-            K.layernorm_bwd(C["x_in"], P("norm_conv.g"), da, g, G("norm_conv.g"), G("norm_conv.b"), row_scale=mask_rows)
+            K.layernorm_bwd(C["x_in"], P("norm_conv.g"), da, g, G("norm_conv.g"), G("norm_conv.b"), row_scale=mask_rows,
+                            partials=self._ln_partials("norm_conv"))
             # MHSA
             A = T["mha"]
             do = K.dropout_bwd(g, 1.0, pd, seed, self._salt(li, 2))
@@ -612,7 +643,8 @@ class ConformerCTCTrainStep:
                                    d // self.heads)
             self._dW(dqkv, A["a"], pre + "qkv_w", pre + "qkv_b")
             da = self._dX(dqkv, pre + "qkv_w")
-            K.layernorm_bwd(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"))
+            K.layernorm_bwd(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"),
+                            partials=self._ln_partials("norm_mha"))
             self._ffn_bwd(g, T["ffm"], "ffm", "norm_ff_macaron", pre, seed, li, 0)
             self._layer_done(li)
         # positional projection of every layer: dW_pos (L*256, 256) = dpos_all^T pe
@@ -746,7 +778,8 @@ class ConformerCTCTrainStep:
         du = K.act_dropout_bwd(T["u"], dh, self.p_drop, seed, self._salt(li, s0), out=dh)
         self._dW(du, T["a"], pre + key + "_w1", pre + key + "_b1")
         da = self._dX(du, pre + key + "_w1")
-        K.layernorm_bwd(T["x_in"], fp.p(pre + ln + ".g"), da, g, fp.g(pre + ln + ".g"), fp.g(pre + ln + ".b"))
+        K.layernorm_bwd(T["x_in"], fp.p(pre + ln + ".g"), da, g, fp.g(pre + ln + ".g"), fp.g(pre + ln + ".b"),
+                        partials=self._ln_partials(ln))
 
     # ---- data-parallel gradient reduction ----------------------------------------------------------------------------
     def _layer_done(self, li):

@@ -78,14 +78,14 @@ def gemm_tn(a, b, out, colsum=None, rows_store=None, alpha=1.0, accumulate=True)
     return out
 
 
-def gemm_tn_partial(a, b, partial, colsum=None):
-    """The split-K partial products of gemm_tn into `partial` (a flat uint8 view of >= ma_gemm_tn_workspace_bytes bytes); the sums
-    are taken later by reduce_splits_batch."""
+def gemm_tn_partial(a, b, partial, with_colsum=False):
+    """The split-K partial products of gemm_tn into `partial` (a flat uint8 view of >= ma_gemm_tn_workspace_bytes bytes) and, behind
+    them, one partial column-sum vector of `a` per split; the sums are taken later by ma_reduce_splits_batch_f32."""
     lib = _lib.load()
     kc, mo = a.shape
     no = b.shape[1]
-    _lib.check(lib.ma_gemm_tn_partial_bf16(_p(a), a.stride(0), _p(b), b.stride(0), mo, no, kc, mo, _p(colsum), _p(partial),
-                                           partial.numel(), _s()), "gemm_tn_partial")
+    _lib.check(lib.ma_gemm_tn_partial_bf16(_p(a), a.stride(0), _p(b), b.stride(0), mo, no, kc, mo, 1 if with_colsum else 0,
+                                           _p(partial), partial.numel(), _s()), "gemm_tn_partial")
 
 
 def conv2d_dw(dy, act, dw, dbias):
@@ -98,12 +98,18 @@ def conv2d_dw(dy, act, dw, dbias):
                                            ws.numel(), _s()), "conv2d_dw")
 
 
-def layernorm_bwd(x, gamma, dy, g, dgamma, dbeta, row_scale=None, accumulate=True, eps=1e-5):
+def layernorm_bwd(x, gamma, dy, g, dgamma, dbeta, row_scale=None, accumulate=True, eps=1e-5, partials=None):
+    """g (+)= dL/dx; dgamma / dbeta += the parameter gradients - or, with `partials` (a float32 buffer of >=
+    ma_layernorm_bwd_parts(rows) * 512 elements), the per-workgroup partial (dgamma | dbeta) vectors are left there for the caller's
+    batched reduction and dgamma / dbeta are not touched."""
     t = _t()
+    ws = partials if partials is not None else _reduce_ws(x.device)
     _lib.check(_lib.load().ma_layernorm_bwd_f32(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(gamma), float(eps),
                                                 _p(row_scale), _p(dy), dy.stride(0), 1 if dy.dtype == t.bfloat16 else 0,
-                                                _p(g), g.stride(0), 1 if accumulate else 0, _p(dgamma), _p(dbeta),
-                                                _p(_reduce_ws(x.device)), _reduce_ws(x.device).numel(), _s()),
+                                                _p(g), g.stride(0), 1 if accumulate else 0,
+                                                None if partials is not None else _p(dgamma),
+                                                None if partials is not None else _p(dbeta), _p(ws),
+                                                ws.numel() * ws.element_size(), _s()),
                "layernorm_bwd")
     return g
 
@@ -170,13 +176,13 @@ def label_smoothing_loss_grad(logits, V, target, mask, smoothing, grad_scale, no
 
 
 def dropout_add(x, y, alpha, p, seed, salt, out=None):
-    """out (default: a new tensor) = x + alpha * dropout(y); pass out=x for the in-place form."""
+    """out (default: a new tensor) = x + alpha * dropout(y); pass out=x for the in-place form; x = None: no residual term."""
     t = _t()
     if out is None:
-        out = t.empty_like(x)
-    _lib.check(_lib.load().ma_dropout_add_f32(_p(out), out.stride(0), _p(x), x.stride(0), _p(y), y.stride(0),
-                                              1 if y.dtype == t.bfloat16 else 0, x.shape[0], x.shape[1], float(alpha),
-                                              float(p), seed, salt, _s()), "dropout_add")
+        out = t.empty(y.shape, dtype=t.float32, device=y.device)
+    _lib.check(_lib.load().ma_dropout_add_f32(_p(out), out.stride(0), _p(x), x.stride(0) if x is not None else 0, _p(y),
+                                              y.stride(0), 1 if y.dtype == t.bfloat16 else 0, y.shape[0], y.shape[1],
+                                              float(alpha), float(p), seed, salt, _s()), "dropout_add")
     return out
 
 
@@ -195,12 +201,14 @@ def convmid_fwd_train(y, batch, T, dw_w, dw_b, gamma, beta, run_mean, run_var, e
     c, ks = dw_w.shape
     rows = batch * T
     z = t.empty((rows, c), dtype=t.float32, device=y.device)
-    sums = t.zeros(2 * c, dtype=t.float32, device=y.device)
+    nparts = int(lib.ma_convmid_fwd_train_parts(batch, T, c))
+    _lib.check(min(nparts, 0), "convmid_fwd_train")
+    sums = t.empty(nparts * 2 * c, dtype=t.float32, device=y.device)  # per-workgroup partial (sum | sum of squares) vectors
     stats = t.empty(2 * c, dtype=t.float32, device=y.device)
     out = t.empty((rows, c), dtype=t.bfloat16, device=y.device)
     _lib.check(lib.ma_convmid_fwd_train(_p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dw_b), _p(z), _p(sums), _s()),
                "convmid_fwd_train")
-    _lib.check(lib.ma_bn_finalize_f32(_p(sums), c, rows, float(eps), float(momentum), _p(run_mean), _p(run_var),
+    _lib.check(lib.ma_bn_finalize_f32(_p(sums), nparts, c, rows, float(eps), float(momentum), _p(run_mean), _p(run_var),
                                       _p(stats), _s()), "bn_finalize")
     _lib.check(lib.ma_bn_swish_fwd_bf16(_p(z), _p(stats), _p(gamma), _p(beta), _p(out), rows, c, _s()), "bn_swish_fwd")
     return out, z, stats
@@ -213,11 +221,10 @@ def convmid_bwd(dout, y, z, stats, batch, T, dw_w, gamma, beta, d_dw_w, d_dw_b, 
     c, ks = dw_w.shape
     rows = batch * T
     dz = t.empty((rows, c), dtype=t.float32, device=y.device)
-    dsum = t.zeros(2 * c, dtype=t.float32, device=y.device)
-    _lib.check(lib.ma_bn_swish_bwd_f32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _s()),
-               "bn_swish_bwd")
-    d_beta += dsum[:c]
-    d_gamma += dsum[c:]
+    dsum = t.empty(2 * c, dtype=t.float32, device=y.device)
+    rw = _reduce_ws(y.device)
+    _lib.check(lib.ma_bn_swish_bwd_f32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _p(d_gamma), _p(d_beta),
+               _p(rw), rw.numel(), _s()), "bn_swish_bwd")
     dy = t.empty((rows, 2 * c), dtype=t.bfloat16, device=y.device)
     rw = _reduce_ws(y.device)
     _lib.check(lib.ma_convmid_bwd_bf16(_p(dz), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dy), dy.stride(0),

@@ -159,12 +159,14 @@ def convmid_fwd_train(y, batch, T, dw_w, dw_b, gamma, beta, run_mean, run_var, e
     c, ks = dw_w.shape
     rows = batch * T
     z = t.empty((rows, c), dtype=t.float32, device=y.device)
-    sums = t.zeros(2 * c, dtype=t.float32, device=y.device)
+    nparts = int(lib.ma_convmid_fwd_train_parts(batch, T, c))
+    _lib.check(min(nparts, 0), "convmid_fwd_train")
+    sums = t.empty(nparts * 2 * c, dtype=t.float32, device=y.device)  # per-workgroup partial (sum | sum of squares) vectors
     stats = t.empty(2 * c, dtype=t.float32, device=y.device)
     out = t.empty((rows, c), dtype=t.float32, device=y.device)
     _lib.check(lib.ma_convmid_fwd_train_x32(_p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dw_b), _p(z), _p(sums), _s()),
                "convmid_fwd_train_x32")
-    _lib.check(lib.ma_bn_finalize_f32(_p(sums), c, rows, float(eps), float(momentum), _p(run_mean), _p(run_var),
+    _lib.check(lib.ma_bn_finalize_f32(_p(sums), nparts, c, rows, float(eps), float(momentum), _p(run_mean), _p(run_var),
                                       _p(stats), _s()), "bn_finalize")
     _lib.check(lib.ma_bn_swish_fwd_x32(_p(z), _p(stats), _p(gamma), _p(beta), _p(out), rows, c, _s()), "bn_swish_fwd_x32")
     return out, z, stats
@@ -177,11 +179,10 @@ def convmid_bwd(dout, y, z, stats, batch, T, dw_w, gamma, beta, d_dw_w, d_dw_b, 
     c, ks = dw_w.shape
     rows = batch * T
     dz = t.empty((rows, c), dtype=t.float32, device=y.device)
-    dsum = t.zeros(2 * c, dtype=t.float32, device=y.device)
-    _lib.check(lib.ma_bn_swish_bwd_x32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _s()),
-               "bn_swish_bwd_x32")
-    d_beta += dsum[:c]
-    d_gamma += dsum[c:]
+    dsum = t.empty(2 * c, dtype=t.float32, device=y.device)
+    rw = _K._reduce_ws(y.device)
+    _lib.check(lib.ma_bn_swish_bwd_x32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _p(d_gamma), _p(d_beta),
+               _p(rw), rw.numel(), _s()), "bn_swish_bwd_x32")
     dy = t.empty((rows, 2 * c), dtype=t.float32, device=y.device)
     rw = _reduce_ws(y.device)
     _lib.check(lib.ma_convmid_bwd_x32(_p(dz), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dy), dy.stride(0), _p(d_dw_w),

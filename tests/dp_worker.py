@@ -1,6 +1,6 @@
 """Child process of tests/test_dp_equivalence_gpu.py (not a test module): one data-parallel rank of the HIP training step.
 
-  python tests/dp_worker.py <rank> <world> <port> <out.pt>
+  python tests/dp_worker.py <rank> <world> <port> <out.pt> [bfloat16 | float32]
 
 All ranks share GPU 0 and talk over gloo on DEVICE tensors (the box has one GPU; the driver's 8-GPU run uses nccl = RCCL with
 the same code path: BucketedAllReduce only sees torch.distributed).  Global batch = 4 utterances built so that each rank's shard
@@ -38,6 +38,7 @@ def global_batch():
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    compute_type = sys.argv[5] if len(sys.argv) > 5 else "bfloat16"
     import torch
 
     torch.cuda.set_device(0)
@@ -52,7 +53,7 @@ def main():
     torch.manual_seed(5)  # same initial weights on every rank (examples/conformer/train.py:56)
     model = create_asr_model(80, 97, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=2)).cuda()
     eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=1, dropout_rate=0.0, positional_dropout_rate=0.0,
-                                world_size=world, rank=rank)
+                                world_size=world, rank=rank, compute_type=compute_type)
     order = []
     launch = eng.reducer.launch
     eng.reducer.launch = lambda lo, hi: (order.append((lo, hi)), launch(lo, hi))[1]
@@ -62,7 +63,15 @@ def main():
     eng.step(*cols)                      # global_step 0: lr = 0 (scheduler_factory.py:44-50)
     order.clear()
     loss, cond, scale, overflow, lr = eng.step(*cols)
-    torch.save({"loss": float(loss), "overflow": overflow, "scale": scale, "lr": lr, "order": order,
+    # tensors whose true gradient is identically zero (a bias in front of a softmax over keys / in front of a BatchNorm): their
+    # computed gradient is round-off noise of either sign
+    zero_spans = []
+    for li in range(eng.L):
+        lo = eng.fp.index["l%d.qkv_b" % li][0]
+        zero_spans.append((lo + eng.d, lo + 2 * eng.d))                       # linear_k.bias
+        lo, _, n = eng.fp.index["l%d.dw_b" % li]
+        zero_spans.append((lo, lo + n))                                       # depthwise_conv.bias
+    torch.save({"loss": float(loss), "overflow": overflow, "scale": scale, "lr": lr, "order": order, "zero_spans": zero_spans,
                 "grad": eng.fp.grad.cpu(), "delta": (eng.fp.master - before).cpu(), "size": eng.fp.size,
                 "bn_mean": [m.cpu() for m in eng.bn_mean], "bn_var": [v.cpu() for v in eng.bn_var]}, out)
     if world > 1:

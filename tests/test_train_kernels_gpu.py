@@ -76,21 +76,40 @@ def test_transpose_batch_and_batched_split_sums(K):
     for i, (mo, no) in enumerate(probs):
         a, b = bf(torch.randn(kc, mo, generator=g)).cuda(), bf(torch.randn(kc, no, generator=g)).cuda()
         nbytes = int(lib.ma_gemm_tn_workspace_bytes(mo, no, kc))
+        splits = int(lib.ma_gemm_tn_splits(mo, no, kc))
+        assert nbytes == splits * mo * (no + 1) * 4
         part = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        K.gemm_tn_partial(a, b, part)
-        base = torch.randn(mo, no, generator=g).cuda()
-        ref = base.clone()
-        K.gemm_tn(a, b, ref, alpha=0.5, accumulate=True)
-        out = base.clone()
+        K.gemm_tn_partial(a, b, part, with_colsum=True)
+        base, cbase = torch.randn(mo, no, generator=g).cuda(), torch.randn(mo, generator=g).cuda()
+        ref, cref = base.clone(), cbase.clone()
+        K.gemm_tn(a, b, ref, alpha=0.5, accumulate=True, colsum=cref)
+        out, cout = base.clone(), cbase.clone()
         nblk = (mo * no + 1023) // 1024
-        items.append(_lib.ReduceItem(part.data_ptr(), out.data_ptr(), mo * no, out.stride(0), no, nbytes // (mo * no * 4), 0.5, 1, first, 0))
-        block_item += [i] * nblk
+        items.append(_lib.ReduceItem(part.data_ptr(), out.data_ptr(), mo * no, out.stride(0), no, splits, 0.5, 1, first, 0))
+        block_item += [len(items) - 1] * nblk
         first += nblk
-        arena.append(part); want.append(ref); gouts.append(out)
+        # the bias gradient: one partial column-sum vector per split, behind the partial products
+        items.append(_lib.ReduceItem(part.data_ptr() + splits * mo * no * 4, cout.data_ptr(), mo, mo, mo, splits, 1.0, 1, first, 0))
+        block_item += [len(items) - 1]
+        first += 1
+        arena.append(part); want += [ref, cref]; gouts += [out, cout]
+        assert rel(cref - cbase, a.float().cpu().sum(0)) < 1e-5
+    # a "tall" item (accumulate bit 1): 300 per-workgroup partials of a (dgamma | dbeta) pair, row stride 512
+    parts = torch.randn(300, 512, generator=g).cuda()
+    tall_out = torch.zeros(512, device="cuda")
+    items.append(_lib.ReduceItem(parts.data_ptr(), tall_out.data_ptr(), 512, 512, 512, 300, 1.0, 2, first, 512))
+    block_item += [len(items) - 1] * 8
+    first += 8
     d_items, d_map = to_dev(items, _lib.ReduceItem), torch.tensor(block_item, dtype=torch.int32, device="cuda")
     _lib.check(lib.ma_reduce_splits_batch_f32(d_items.data_ptr(), d_map.data_ptr(), first, st), "rb")
     for out, ref in zip(gouts, want):
         assert torch.equal(out, ref)  # same partials, same order of the splits
+    assert rel(tall_out, parts.double().sum(0).float().cpu()) < 1e-6
+    tall_again = torch.zeros(512, device="cuda")
+    items[-1] = _lib.ReduceItem(parts.data_ptr(), tall_again.data_ptr(), 512, 512, 512, 300, 1.0, 2, first - 8, 512)
+    d_items = to_dev(items, _lib.ReduceItem)
+    _lib.check(lib.ma_reduce_splits_batch_f32(d_items.data_ptr(), d_map.data_ptr(), first, st), "rb")
+    assert torch.equal(tall_out, tall_again)  # fixed summation order: bit-identical from run to run
 
 
 def test_gemm_splitk(K):

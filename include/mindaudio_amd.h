@@ -449,6 +449,57 @@ int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t l
 int ma_reduce_splits_batch_f32(const ma_reduce_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream);
 
 
+
+/* ---- training forms of the packed dense layers: the layer's element-wise neighbours ride in the epilogue ---------------------
+ * One struct describes them (NULL / 0 switch a term off):
+ *   mode 1  w_1 forward:   out = u = bf16(acc + bias), out2 = h = bf16(dropout(swish(u)))   (positionwise_feed_forward.py:44-46)
+ *   mode 2  w_1 backward:  out = du = bf16(bf16(acc) * swish'(u) * keep / (1 - p)), u = aux (M, N) bf16; acc = dy . W_2
+ *   mode 3  branch joins (N = 256): z = bf16((acc + bias) * row_scale[m]); out (float32) = residual + alpha * dropout(z)
+ *           (models/conformer.py:109-151); then optionally ln_out = LayerNorm(out; gamma1, beta1) * ln_row_scale[m] (bf16 or
+ *           float32), or - with gamma2 - ln_mid (float32) = LayerNorm(out; gamma1, beta1) and ln_out = LayerNorm(ln_mid; gamma2,
+ *           beta2): norm_final of a block chained with the LayerNorm that consumes it (:153-156, 109-110, 253-254)
+ *   mode 4  plain:         out = bf16(acc + bias)                                             (input gradients)
+ * Dropout = the counter-based mask of ma_dropout_add_f32 / ma_act_dropout_*: element index m * N + n of site (seed, salt), so the
+ * fused and the un-fused launches of one site agree bit for bit (u, h, du are bit-identical to the un-fused launches). */
+typedef struct ma_train_epilogue {
+  int32_t mode;
+  int32_t ln_out_bf16;
+  const float* bias;
+  const void* aux;
+  int64_t ld_aux;
+  void* out2;
+  int64_t ldo2;
+  const float* residual;
+  int64_t ldr;
+  const float* row_scale;
+  float alpha;
+  float p;
+  uint32_t seed, salt;
+  const float *ln_gamma1, *ln_beta1, *ln_gamma2, *ln_beta2, *ln_row_scale;
+  void* ln_out;
+  float* ln_mid;
+  int64_t ld_ln, ld_mid;
+  float ln_eps;
+  int32_t reserved;
+} ma_train_epilogue_t;
+/* K = 256 layers on the packed weight of ma_gemm_k256_pack_bf16 (N % 256 == 0); out bf16 (modes 1, 2, 4) or float32 (mode 3). */
+int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N,
+                            const ma_train_epilogue_t* epi, ma_stream_t stream);
+/* N = 256 layers with a long contraction (K % 64 == 0) on the packed weight of ma_gemm_rows_pack_bf16: modes 3 and 4. */
+int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, void* out, int64_t ldo,
+                            const ma_train_epilogue_t* epi, ma_stream_t stream);
+/* Fragment packing of a list of weights in ONE launch (the training step re-packs every layer's weights after the optimizer):
+ * items / block_item are DEVICE arrays; kind 0 = ma_gemm_k256_pack_bf16 layout (K = 256), kind 1 = ma_gemm_rows_pack_bf16 layout
+ * (N = 256); workgroup b packs 16-byte pieces [256 (b - first_block), + 256) of item block_item[b]. */
+typedef struct ma_pack_item {
+  const void* src;
+  void* dst;
+  int64_t ld;
+  int32_t N, K, kind, first_block;
+} ma_pack_item_t;
+int64_t ma_pack_item_pieces(int32_t kind, int64_t N, int64_t K);
+int ma_pack_batch_bf16(const ma_pack_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream);
+
 /* Weight gradient of the 3x3 stride-2 valid Conv2d of the subsampling layer (layers/subsampling.py:42) as the same TN
  * GEMM with an implicit im2col B operand: dw (Cout, 9C) float32 += dy^T . im2col(act), dbias (Cout) += column sums of dy.
  * dy (batch*Ho*Wo, Cout) bf16 row stride ld_dy; act (batch, H, Wd, C) NHWC bf16; C % 128 == 0.
@@ -485,6 +536,13 @@ int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, c
                          const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
                          int32_t accumulate, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
                          ma_stream_t stream);
+/* The same, and on every finished row of g the NEXT branch's ma_dropout_bwd_bf16 (the residual stream's gradient enters the
+ * branch in front: dy_next (rows, 256) bf16 = alpha_next * keep / (1 - p_next) * g * row_scale_next[r], site (seed, salt_next)). */
+int ma_layernorm_bwd_next_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
+                              const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
+                              int32_t accumulate, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                              void* dy_next, int64_t ld_next, float alpha_next, const float* row_scale_next, float p_next,
+                              uint32_t seed, uint32_t salt_next, ma_stream_t stream);
 /* Scratch for the two-stage parameter-gradient reductions of ma_layernorm_bwd_f32, ma_convmid_bwd_bf16 and
  * ma_subsample_conv1_dw_f32 (per-workgroup partial sums, then a fixed-order sum: no contended atomics). */
 int64_t ma_train_reduce_workspace_bytes(void);

@@ -60,6 +60,25 @@ class ReduceItem(ctypes.Structure):
                 ("first_block", ctypes.c_int32), ("pstride", ctypes.c_int32)]
 
 
+class TrainEpilogue(ctypes.Structure):
+    """struct ma_train_epilogue (include/mindaudio_amd.h)."""
+
+    _fields_ = [("mode", ctypes.c_int32), ("ln_out_bf16", ctypes.c_int32), ("bias", ctypes.c_void_p), ("aux", ctypes.c_void_p),
+                ("ld_aux", ctypes.c_int64), ("out2", ctypes.c_void_p), ("ldo2", ctypes.c_int64), ("residual", ctypes.c_void_p),
+                ("ldr", ctypes.c_int64), ("row_scale", ctypes.c_void_p), ("alpha", ctypes.c_float), ("p", ctypes.c_float),
+                ("seed", ctypes.c_uint32), ("salt", ctypes.c_uint32), ("ln_gamma1", ctypes.c_void_p), ("ln_beta1", ctypes.c_void_p),
+                ("ln_gamma2", ctypes.c_void_p), ("ln_beta2", ctypes.c_void_p), ("ln_row_scale", ctypes.c_void_p),
+                ("ln_out", ctypes.c_void_p), ("ln_mid", ctypes.c_void_p), ("ld_ln", ctypes.c_int64), ("ld_mid", ctypes.c_int64),
+                ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
+class PackItem(ctypes.Structure):
+    """struct ma_pack_item (include/mindaudio_amd.h)."""
+
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("ld", ctypes.c_int64), ("N", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("kind", ctypes.c_int32), ("first_block", ctypes.c_int32)]
+
+
 class GemmEpilogue(ctypes.Structure):
     """struct ma_gemm_epilogue (include/mindaudio_amd.h)."""
 
@@ -157,6 +176,12 @@ PROTOTYPES = {
     "ma_reduce_splits_batch_f32": (ctypes.c_int, [vp, vp, i32, vp]),
     "ma_layernorm_bwd_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp]),
     "ma_train_reduce_workspace_bytes": (i64, []),
+    "ma_layernorm_bwd_next_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, f32, vp, vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, vp, i64,
+                                                 f32, vp, f32, u32, u32, vp]),
+    "ma_gemm_k256_train_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, ctypes.POINTER(TrainEpilogue), vp]),
+    "ma_gemm_rows_train_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp, i64, ctypes.POINTER(TrainEpilogue), vp]),
+    "ma_pack_item_pieces": (i64, [i32, i64, i64]),
+    "ma_pack_batch_bf16": (ctypes.c_int, [vp, vp, i32, vp]),
     "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, i32, f32, u32, u32, vp]),
     "ma_act_dropout_bwd_bf16": (ctypes.c_int, [vp, vp, vp, i64, i32, f32, u32, u32, vp]),
     "ma_dropout_add_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i32, i64, i64, f32, f32, u32, u32, vp]),

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "../../include/mindaudio_amd.h"
+#include "train_common.h"
 
 #define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
   do {                                                                        \
@@ -246,6 +247,130 @@ __global__ __launch_bounds__(kG2Threads, NBL > 1 ? 1 : 2) void gemm_k256_kernel(
   }
 }
 
+// ---- training forms (ma_gemm_k256_train_bf16): the same tile walk with the element-wise neighbours of the layer in the epilogue ----
+//   MODE 1 (w_1 forward):   out = u = bf16(acc + bias);  out2 = h = bf16(dropout(swish(u)))             [positionwise_feed_forward.py:44-46]
+//   MODE 2 (w_1 backward):  out = du = bf16(bf16(acc) * swish'(u) * keep / (1 - p)),  u = aux            [acc = dy . W_2: dh]
+//   MODE 3 (branch joins, N = 256): train_epi_rows256 (residual + dropout + LayerNorm chain)             [models/conformer.py:109-151]
+//   MODE 4 (plain):         out = bf16(acc + bias)
+// What the un-fused step ran as GEMM + act_dropout_fwd / act_dropout_bwd / dropout_add + layernorm launches; element for element the
+// same arithmetic (u, h, du are bit-identical to those launches).
+template <int ROWS, int MODE>
+__global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_train_kernel(const uint16_t* __restrict__ a, int64_t lda,
+                                                                        const uint4* __restrict__ wp, void* out, int64_t ldo, int M,
+                                                                        int N, const TrainEpi e) {
+  constexpr int MT = ROWS / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * ROWS;
+  const int n0 = blockIdx.y * kG2Cols + wave * 64;
+  bf16x8 wf[4][8];
+  {
+    const uint4* base = wp + ((int64_t)(n0 >> 4) * 8) * 64 + lane;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + (jt * 8 + ks) * 64);
+  }
+#pragma unroll
+  for (int it = 0; it < ROWS / 8; ++it) {
+    const int idx = it * kG2Threads + tid;
+    const int row = idx >> 5, ch = idx & 31;
+    int m = m0 + row;
+    if (m >= M) m = M - 1;
+    const uint4 v = *reinterpret_cast<const uint4*>(a + (int64_t)m * lda + ch * 8);
+    *reinterpret_cast<uint4*>(smem + row * kG2Pitch + ch * 16) = v;
+  }
+  __syncthreads();
+  const char* abase = smem + c * kG2Pitch + g * 16;
+  f32x4 acc[4][MT];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int s = 0; s < MT; ++s) acc[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    bf16x8 af[MT];
+#pragma unroll
+    for (int s = 0; s < MT; ++s) af[s] = *reinterpret_cast<const bf16x8*>(abase + s * 16 * kG2Pitch + ks * 64);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int s = 0; s < MT; ++s) acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], af[s], acc[jt][s], 0, 0, 0);
+  }
+  if constexpr (MODE == 3) {
+    __syncthreads();  // the activation tile is dead: its LDS is the LayerNorm exchange scratch
+    train_epi_rows256<MT>(e, acc, m0, M, wave, c, g, reinterpret_cast<float*>(out), ldo, reinterpret_cast<float*>(smem));
+    return;
+  } else {
+    // ---- bf16 outputs: staged in this wave's own LDS strip, written as whole 128-byte row segments ------------------------------
+    char* stage = smem + ROWS * kG2Pitch + wave * (ROWS * kG2StagePitch);
+    auto flush = [&](void* dst, int64_t ld) __attribute__((always_inline)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int rr = lane >> 3, cc = lane & 7;
+      uint16_t* ob = reinterpret_cast<uint16_t*>(dst) + n0 + cc * 8;
+#pragma unroll
+      for (int it = 0; it < ROWS / 8; ++it) {
+        const int row = it * 8 + rr;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + row * kG2StagePitch + cc * 16);
+        if (m0 + row < M) *reinterpret_cast<uint4*>(ob + (int64_t)(m0 + row) * ld) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    float4 bv[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      bv[jt] = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // pass 1: u (modes 1, 4: acc + bias) or du (mode 2)
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      const int m = m0 + 16 * s + c;
+      const int mc = m < M ? m : M - 1;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int n = n0 + 16 * jt + 4 * g;
+        float v[4] = {acc[jt][s][0] + bv[jt].x, acc[jt][s][1] + bv[jt].y, acc[jt][s][2] + bv[jt].z, acc[jt][s][3] + bv[jt].w};
+        if constexpr (MODE == 2) {
+          const uint2 ur = *reinterpret_cast<const uint2*>(e.aux + (int64_t)mc * e.ld_aux + n);
+          const float u[4] = {__uint_as_float(ur.x << 16), __uint_as_float(ur.x & 0xffff0000u), __uint_as_float(ur.y << 16),
+                              __uint_as_float(ur.y & 0xffff0000u)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sg = sigmoid_fast(u[r]);
+            v[r] = bf16_round(v[r]) * (sg + u[r] * sg * (1.0f - sg));
+          }
+          drop4(e.drop, (uint64_t)mc * N + n, v);
+        }
+        *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
+            make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+        if constexpr (MODE == 1) acc[jt][s] = f32x4{bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
+      }
+    }
+    flush(out, ldo);
+    if constexpr (MODE == 1) {
+      // pass 2: h = dropout(swish(u)) on the rounded u, as act_dropout_fwd_kernel computes it from the stored tensor
+#pragma unroll
+      for (int s = 0; s < MT; ++s) {
+        const int m = m0 + 16 * s + c;
+        const int mc = m < M ? m : M - 1;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          const int n = n0 + 16 * jt + 4 * g;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[jt][s][r] * sigmoid_fast(acc[jt][s][r]);
+          drop4(e.drop, (uint64_t)mc * N + n, v);
+          *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
+              make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+        }
+      }
+      flush(e.out2, e.ldo2);
+    }
+  }
+}
+
 }  // namespace ma
 
 using namespace ma;
@@ -330,4 +455,77 @@ extern "C" int ma_gemm_k256_packed_ln_bf16(const void* A, int64_t lda, const voi
                                            int64_t ld_ln, ma_stream_t stream) {
   if (!ln_out) return MA_ERR_INVALID_ARG;
   return g2_launch(A, lda, packed, out, ldo, M, N, K, epi, ln_gamma, ln_beta, ln_eps, ln_row_scale, ln_out, ld_ln, stream);
+}
+
+static int train_epi_fill(const ma_train_epilogue_t* epi, int64_t M, int64_t N, TrainEpi& e) {
+  if (!epi || epi->mode < 1 || epi->mode > 4 || epi->p < 0.0f || epi->p >= 1.0f) return MA_ERR_INVALID_ARG;
+  e.mode = epi->mode;
+  e.bias = epi->bias;
+  e.aux = reinterpret_cast<const uint16_t*>(epi->aux);
+  e.ld_aux = epi->ld_aux;
+  e.out2 = epi->out2;
+  e.ldo2 = epi->ldo2;
+  e.residual = epi->residual;
+  e.ldr = epi->ldr;
+  e.row_scale = epi->row_scale;
+  e.alpha = epi->alpha;
+  e.drop = make_drop(epi->p, epi->seed, epi->salt);
+  e.ln_g1 = epi->ln_gamma1; e.ln_b1 = epi->ln_beta1; e.ln_g2 = epi->ln_gamma2; e.ln_b2 = epi->ln_beta2;
+  e.ln_row_scale = epi->ln_row_scale;
+  e.ln_out = epi->ln_out;
+  e.ln_mid = epi->ln_mid;
+  e.ld_ln = epi->ld_ln;
+  e.ld_mid = epi->ld_mid;
+  e.eps = epi->ln_eps;
+  e.ln_out_bf16 = epi->ln_out_bf16;
+  if (e.bias && (reinterpret_cast<uintptr_t>(e.bias) & 15)) return MA_ERR_INVALID_ARG;
+  if (e.mode == 1 && (!e.out2 || e.ldo2 < N || (e.ldo2 & 7) || (reinterpret_cast<uintptr_t>(e.out2) & 15))) return MA_ERR_INVALID_ARG;
+  if (e.mode == 2 && (!e.aux || e.ld_aux < N || (e.ld_aux & 3) || (reinterpret_cast<uintptr_t>(e.aux) & 7))) return MA_ERR_INVALID_ARG;
+  if (e.mode == 3) {
+    if (N != 256) return MA_ERR_UNSUPPORTED;
+    if (e.residual && (e.ldr < N || (e.ldr & 3) || (reinterpret_cast<uintptr_t>(e.residual) & 15))) return MA_ERR_INVALID_ARG;
+    if (e.ln_g1) {
+      if (!e.ln_b1 || !e.ln_out || e.ld_ln < N || (e.ld_ln & 3)) return MA_ERR_INVALID_ARG;
+      if (e.ln_g2 && (!e.ln_b2 || !e.ln_mid || e.ld_mid < N || (e.ld_mid & 3))) return MA_ERR_INVALID_ARG;
+      if ((reinterpret_cast<uintptr_t>(e.ln_g1) | reinterpret_cast<uintptr_t>(e.ln_b1) | reinterpret_cast<uintptr_t>(e.ln_g2) |
+           reinterpret_cast<uintptr_t>(e.ln_b2) | reinterpret_cast<uintptr_t>(e.ln_out) | reinterpret_cast<uintptr_t>(e.ln_mid)) & 15)
+        return MA_ERR_INVALID_ARG;
+    } else if (e.ln_g2) {
+      return MA_ERR_INVALID_ARG;
+    }
+  }
+  (void)M;
+  return MA_OK;
+}
+
+extern "C" int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N,
+                                       const ma_train_epilogue_t* epi, ma_stream_t stream) {
+  if (!A || !packed || !out || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (ma_gemm_k256_packed_bytes(N, kG2K) < 0 || N > 0x7fffff00) return MA_ERR_UNSUPPORTED;
+  TrainEpi e;
+  const int rc = train_epi_fill(epi, M, N, e);
+  if (rc != MA_OK) return rc;
+  if ((lda & 7) || lda < kG2K || ldo < N || (e.mode == 3 ? (ldo & 3) : (ldo & 7))) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15) return MA_ERR_INVALID_ARG;
+  const unsigned nby = (unsigned)(N / kG2Cols);
+  const dim3 grid((unsigned)((M + 63) / 64), nby);
+  const size_t lds = 64 * (kG2Pitch + 4 * kG2StagePitch);
+#define MA_G2T(MODE_)                                                                                                         \
+  {                                                                                                                          \
+    static bool set = false;                                                                                                 \
+    if (!set) {                                                                                                              \
+      if (hipFuncSetAttribute((const void*)&gemm_k256_train_kernel<64, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              (int)lds) != hipSuccess)                                                                       \
+        return MA_ERR_LAUNCH;                                                                                                \
+      set = true;                                                                                                            \
+    }                                                                                                                        \
+    MA_LAUNCH((gemm_k256_train_kernel<64, MODE_>), grid, dim3(kG2Threads), lds, (hipStream_t)stream,                         \
+              reinterpret_cast<const uint16_t*>(A), lda, reinterpret_cast<const uint4*>(packed), out, ldo, (int)M, (int)N, e); \
+  }
+  if (e.mode == 1) MA_G2T(1)
+  else if (e.mode == 2) MA_G2T(2)
+  else if (e.mode == 3) MA_G2T(3)
+  else MA_G2T(4)
+#undef MA_G2T
+  return MA_OK;
 }

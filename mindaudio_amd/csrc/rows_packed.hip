@@ -25,6 +25,7 @@
 #include <utility>
 
 #include "../../include/mindaudio_amd.h"
+#include "train_common.h"
 
 #define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
   do {                                                                        \
@@ -76,7 +77,11 @@ __global__ void rows_pack_kernel(const uint16_t* __restrict__ w, int64_t ldw, in
   out[idx] = c < nchunks ? *reinterpret_cast<const uint4*>(w + (int64_t)n * ldw + k) : make_uint4(0, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPackedParams p) {
+// MODE 0: out float32 = alpha * (acc + bias) (the evaluation forward's embed layer).  Training forms (ma_gemm_rows_train_bf16; the
+// w_2 / input-gradient layers of the Conformer block, K = 2048, 768, 512): MODE 3 = train_epi_rows256 (residual + dropout +
+// LayerNorm chain, float32 out), MODE 4 = out bf16 = acc + bias.
+template <int MODE>
+__global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPackedParams p, const TrainEpi e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,19 +203,64 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
 #undef RP_LOAD
 
   // ---- epilogue: lane (c, g) holds rows m0 + 16 s + c, outputs 64 wave + 16 jt + 4 g + r ----------------------------------------
-  float4 bv[4];
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) bv[jt] = *reinterpret_cast<const float4*>(p.bias + 64 * wave + 16 * jt + 4 * g);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int m = m0 + 16 * s + c;
-    if (m >= p.M) continue;
-    float* orow = p.out + (int64_t)m * p.ldo + 64 * wave + 4 * g;
+  if constexpr (MODE == 3) {
+    __syncthreads();  // every wave is past its last fragment reads: the activation stages become the LayerNorm exchange scratch
+    f32x4 accT[4][4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
-      *reinterpret_cast<float4*>(orow + 16 * jt) =
-          make_float4((acc[jt][s][0] + bv[jt].x) * p.alpha, (acc[jt][s][1] + bv[jt].y) * p.alpha, (acc[jt][s][2] + bv[jt].z) * p.alpha,
-                      (acc[jt][s][3] + bv[jt].w) * p.alpha);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) accT[jt][s] = acc[jt][s];
+    train_epi_rows256<4>(e, accT, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem));
+    return;
+  } else {
+    float4 bv[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      bv[jt] = p.bias ? *reinterpret_cast<const float4*>(p.bias + 64 * wave + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int m = m0 + 16 * s + c;
+      if (m >= p.M) continue;
+      if constexpr (MODE == 4) {
+        uint16_t* orow = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + 64 * wave + 4 * g;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+          *reinterpret_cast<uint2*>(orow + 16 * jt) = make_uint2(pack2_bf16(acc[jt][s][0] + bv[jt].x, acc[jt][s][1] + bv[jt].y),
+                                                                 pack2_bf16(acc[jt][s][2] + bv[jt].z, acc[jt][s][3] + bv[jt].w));
+      } else {
+        float* orow = p.out + (int64_t)m * p.ldo + 64 * wave + 4 * g;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+          *reinterpret_cast<float4*>(orow + 16 * jt) =
+              make_float4((acc[jt][s][0] + bv[jt].x) * p.alpha, (acc[jt][s][1] + bv[jt].y) * p.alpha, (acc[jt][s][2] + bv[jt].z) * p.alpha,
+                          (acc[jt][s][3] + bv[jt].w) * p.alpha);
+      }
+    }
+  }
+}
+
+// ---- fragment packing of a list of weights in one launch (ma_pack_batch_bf16) -----------------------------------------------------
+// kind 0: gemm_k256 layout - piece idx: lane = idx & 63, ks = (idx >> 6) & 7, nt = idx >> 9 -> W[16 nt + (lane & 15)][32 ks + 8 (lane >> 4) ..]
+// kind 1: rows_packed layout (rows_pack_kernel above)
+__global__ __launch_bounds__(256) void pack_batch_kernel(const ma_pack_item_t* __restrict__ items, const int32_t* __restrict__ block_item) {
+  const ma_pack_item_t it = items[block_item[blockIdx.x]];
+  const int64_t idx = (int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x;
+  const uint16_t* w = reinterpret_cast<const uint16_t*>(it.src);
+  uint4* out = reinterpret_cast<uint4*>(it.dst);
+  const int lane = (int)(idx & 63);
+  if (it.kind == 0) {
+    if (idx >= (int64_t)(it.N / 16) * 8 * 64) return;
+    const int ks = (int)((idx >> 6) & 7);
+    const int64_t nt = idx >> 9;
+    out[idx] = *reinterpret_cast<const uint4*>(w + (nt * 16 + (lane & 15)) * it.ld + 32 * ks + 8 * (lane >> 4));
+  } else {
+    const int nch = it.K / 64, nch_pad = (nch + 2) / 3 * 3;
+    if (idx >= (int64_t)4 * nch_pad * 8 * 64) return;
+    const int q = (int)((idx >> 6) & 7), cch = (int)((idx >> 9) % nch_pad), wv = (int)((idx >> 9) / nch_pad);
+    const int kk = q >> 2, jt = q & 3;
+    const int n = 64 * wv + 16 * jt + (lane & 15);
+    const int k = 64 * cch + 32 * kk + 8 * (lane >> 4);
+    out[idx] = cch < nch ? *reinterpret_cast<const uint4*>(w + (int64_t)n * it.ld + k) : make_uint4(0, 0, 0, 0);
   }
 }
 
@@ -250,6 +300,72 @@ extern "C" int ma_gemm_rows_packed_f32(const void* A, int64_t lda, int64_t M, in
   p.M = (int32_t)M;
   p.nchunks = (int32_t)(K / 64);
   p.alpha = alpha;
-  MA_LAUNCH(rows_packed_kernel, dim3((unsigned)((M + kRpRows - 1) / kRpRows)), dim3(kRpThreads), kRpLds, (hipStream_t)stream, p);
+  MA_LAUNCH(rows_packed_kernel<0>, dim3((unsigned)((M + kRpRows - 1) / kRpRows)), dim3(kRpThreads), kRpLds, (hipStream_t)stream, p,
+            TrainEpi{});
+  return MA_OK;
+}
+
+extern "C" int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, void* out, int64_t ldo,
+                                       const ma_train_epilogue_t* epi, ma_stream_t stream) {
+  if (!A || !packed || !out || !epi || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (epi->mode != 3 && epi->mode != 4) return MA_ERR_UNSUPPORTED;
+  if (ma_gemm_rows_packed_bytes(kRpN, K) < 0 || lda < K || (lda & 7) || ldo < kRpN || (ldo & 3)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |
+       reinterpret_cast<uintptr_t>(epi->bias)) & 15)
+    return MA_ERR_INVALID_ARG;
+  if (epi->p < 0.0f || epi->p >= 1.0f) return MA_ERR_INVALID_ARG;
+  TrainEpi e = TrainEpi{};
+  e.mode = epi->mode;
+  e.bias = epi->bias;
+  e.residual = epi->residual;
+  e.ldr = epi->ldr;
+  e.row_scale = epi->row_scale;
+  e.alpha = epi->alpha;
+  e.drop = make_drop(epi->p, epi->seed, epi->salt);
+  e.ln_g1 = epi->ln_gamma1; e.ln_b1 = epi->ln_beta1; e.ln_g2 = epi->ln_gamma2; e.ln_b2 = epi->ln_beta2;
+  e.ln_row_scale = epi->ln_row_scale;
+  e.ln_out = epi->ln_out;
+  e.ln_mid = epi->ln_mid;
+  e.ld_ln = epi->ld_ln;
+  e.ld_mid = epi->ld_mid;
+  e.eps = epi->ln_eps;
+  e.ln_out_bf16 = epi->ln_out_bf16;
+  if (e.mode == 3) {
+    if (e.residual && (e.ldr < kRpN || (e.ldr & 3) || (reinterpret_cast<uintptr_t>(e.residual) & 15))) return MA_ERR_INVALID_ARG;
+    if (e.ln_g1) {
+      if (!e.ln_b1 || !e.ln_out || e.ld_ln < kRpN || (e.ld_ln & 3)) return MA_ERR_INVALID_ARG;
+      if (e.ln_g2 && (!e.ln_b2 || !e.ln_mid || e.ld_mid < kRpN || (e.ld_mid & 3))) return MA_ERR_INVALID_ARG;
+      if ((reinterpret_cast<uintptr_t>(e.ln_g1) | reinterpret_cast<uintptr_t>(e.ln_b1) | reinterpret_cast<uintptr_t>(e.ln_g2) |
+           reinterpret_cast<uintptr_t>(e.ln_b2) | reinterpret_cast<uintptr_t>(e.ln_out) | reinterpret_cast<uintptr_t>(e.ln_mid)) & 15)
+        return MA_ERR_INVALID_ARG;
+    } else if (e.ln_g2) {
+      return MA_ERR_INVALID_ARG;
+    }
+  }
+  RowsPackedParams p;
+  p.a = reinterpret_cast<const uint16_t*>(A);
+  p.lda = lda;
+  p.wp = reinterpret_cast<const uint4*>(packed);
+  p.bias = epi->bias;
+  p.out = reinterpret_cast<float*>(out);
+  p.ldo = ldo;
+  p.M = (int32_t)M;
+  p.nchunks = (int32_t)(K / 64);
+  p.alpha = 1.0f;
+  const dim3 grid((unsigned)((M + kRpRows - 1) / kRpRows));
+  if (e.mode == 3) MA_LAUNCH(rows_packed_kernel<3>, grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+  else MA_LAUNCH(rows_packed_kernel<4>, grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+  return MA_OK;
+}
+
+extern "C" int64_t ma_pack_item_pieces(int32_t kind, int64_t N, int64_t K) {
+  if (kind == 0) return (K == 256 && N >= 256 && N % 256 == 0) ? (N / 16) * 8 * 64 : (int64_t)MA_ERR_UNSUPPORTED;
+  if (kind == 1) return (N == kRpN && K >= 64 && K % 64 == 0) ? (int64_t)4 * ((K / 64 + 2) / 3 * 3) * 8 * 64 : (int64_t)MA_ERR_UNSUPPORTED;
+  return MA_ERR_INVALID_ARG;
+}
+
+extern "C" int ma_pack_batch_bf16(const ma_pack_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream) {
+  if (!items || !block_item || n_blocks < 1) return MA_ERR_INVALID_ARG;
+  MA_LAUNCH(pack_batch_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, items, block_item);
   return MA_OK;
 }

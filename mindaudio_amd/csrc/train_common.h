@@ -1,0 +1,209 @@
+// Pieces shared by the training-step kernels (train_kernels.hip, gemm_k256.hip, rows_packed.hip): the counter-based dropout and
+// the epilogue description of the packed dense layers' training forms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ma {
+
+// Counter-based dropout: the keep decision of element `idx` of dropout site `salt` at step seed `seed` is a pure
+// function, so the backward pass regenerates the mask instead of storing it.
+// One 32-bit hash serves the element pair (idx & ~1, idx | 1), 16 bits each (p is resolved to 2^-16): the three integer multiplies
+// of the mixer are quarter-rate instructions and made the element-wise kernels VALU-bound; kernels that walk consecutive
+// elements get the pair's hash once (common subexpression after inlining).
+struct Drop {
+  uint32_t seed, salt, thresh;  // thresh = p * 2^32; 0 = no dropout
+  float inv_keep;               // 1 / (1 - p)
+};
+__device__ __forceinline__ uint32_t drop_pair_hash(uint32_t seed, uint32_t salt, uint64_t pair) {
+  uint32_t x = (uint32_t)pair ^ (seed * 0x9E3779B9u) ^ (salt * 0x85EBCA6Bu) ^ ((uint32_t)(pair >> 32) * 0xC2B2AE35u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  x += salt; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t salt, uint64_t idx, uint32_t thresh) {
+  const uint32_t x = drop_pair_hash(seed, salt, idx >> 1);
+  return ((idx & 1) ? (x >> 16) : (x & 0xffffu)) >= (thresh >> 16);
+}
+// four consecutive elements idx .. idx + 3 (idx % 4 == 0): v[r] = keep ? v[r] * inv_keep : 0
+__device__ __forceinline__ void drop4(const Drop& d, uint64_t idx, float (&v)[4]) {
+  if (!d.thresh) return;
+  const uint32_t t = d.thresh >> 16;
+  const uint32_t h0 = drop_pair_hash(d.seed, d.salt, idx >> 1), h1 = drop_pair_hash(d.seed, d.salt, (idx >> 1) + 1);
+  v[0] = (h0 & 0xffffu) >= t ? v[0] * d.inv_keep : 0.0f;
+  v[1] = (h0 >> 16) >= t ? v[1] * d.inv_keep : 0.0f;
+  v[2] = (h1 & 0xffffu) >= t ? v[2] * d.inv_keep : 0.0f;
+  v[3] = (h1 >> 16) >= t ? v[3] * d.inv_keep : 0.0f;
+}
+inline Drop make_drop(float p, uint32_t seed, uint32_t salt) {
+  Drop d;
+  d.seed = seed;
+  d.salt = salt;
+  if (!(p > 0.0f)) {
+    d.thresh = 0;
+    d.inv_keep = 1.0f;
+  } else {
+    double th = (double)p * 4294967296.0;
+    d.thresh = th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th;
+    d.inv_keep = 1.0f / (1.0f - p);
+  }
+  return d;
+}
+
+// round to bf16 and back (round to nearest even; what a bf16 store followed by a load does)
+__device__ __forceinline__ float bf16_round(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  const bf2_t r = __builtin_convertvector((f2_t){lo, hi}, bf2_t);  // v_cvt_pk_bf16_f32 (round to nearest even)
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+
+// Epilogue of the training forms of the packed dense layers (ma_gemm_k256_train_bf16 / ma_gemm_rows_train_bf16).
+struct TrainEpi {
+  int32_t mode;
+  const float* bias;
+  const uint16_t* aux;   // mode 2: u (M, N) bf16
+  int64_t ld_aux;
+  void* out2;            // mode 1: h (M, N) bf16
+  int64_t ldo2;
+  const float* residual;
+  int64_t ldr;
+  const float* row_scale;
+  float alpha;
+  Drop drop;
+  const float *ln_g1, *ln_b1, *ln_g2, *ln_b2, *ln_row_scale;
+  void* ln_out;          // LN1 (or LN2 when ln_g2) output, bf16 or float32
+  float* ln_mid;         // float32 LN1 output when two LayerNorms are chained
+  int64_t ld_ln, ld_mid;
+  float eps;
+  int32_t ln_out_bf16;
+};
+
+// (v_rcp_f32 instead of an IEEE division: 1 ulp, invisible after the bf16 rounding of every consumer)
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+typedef __attribute__((ext_vector_type(4))) float tc_f32x4;
+
+// Epilogue mode 3 on a 256-wide output whose columns are split over the 4 waves of a workgroup (gemm_k256 / rows_packed layout:
+// lane (c = lane & 15, g = lane >> 4) of wave w holds rows m0 + 16 s + c, columns 64 w + 16 jt + 4 g + r in acc[jt][s][r]):
+//     z   = bf16((acc + bias) * row_scale[m])                    (what the un-fused GEMM stored)
+//     out = residual + alpha * dropout(z)                        float32: the new residual stream (models/conformer.py:109-151)
+//     ln_out = LayerNorm(out; g1, b1) * ln_row_scale             two-pass statistics, like layernorm_kernel
+//     or, with g2: ln_mid = LayerNorm(out; g1, b1) float32, ln_out = LayerNorm(ln_mid; g2, b2)   (norm_final + the next LayerNorm)
+// `red`: LDS scratch of 4 * 16 * MT floats, not in use by anything else; every wave of the workgroup must call this.
+template <int MT>
+__device__ __forceinline__ void train_epi_rows256(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], int m0, int M, int wave, int c, int g,
+                                                  float* out, int64_t ldo, float* red) {
+  constexpr int ROWS = 16 * MT;
+  float4 bv[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+    bv[jt] = e.bias ? *reinterpret_cast<const float4*>(e.bias + 64 * wave + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int m = m0 + 16 * s + c;
+    const bool live = m < M;
+    const int mc = live ? m : M - 1;
+    const float rs = e.row_scale ? e.row_scale[mc] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = 64 * wave + 16 * jt + 4 * g;
+      float v[4] = {bf16_round((acc[jt][s][0] + bv[jt].x) * rs), bf16_round((acc[jt][s][1] + bv[jt].y) * rs),
+                    bf16_round((acc[jt][s][2] + bv[jt].z) * rs), bf16_round((acc[jt][s][3] + bv[jt].w) * rs)};
+      drop4(e.drop, (uint64_t)mc * 256 + n, v);
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e.residual) r = *reinterpret_cast<const float4*>(e.residual + (int64_t)mc * e.ldr + n);
+      v[0] = r.x + e.alpha * v[0]; v[1] = r.y + e.alpha * v[1]; v[2] = r.z + e.alpha * v[2]; v[3] = r.w + e.alpha * v[3];
+      if (live) *reinterpret_cast<float4*>(out + (int64_t)m * ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+      acc[jt][s] = tc_f32x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+  if (!e.ln_g1) return;
+  // ---- LayerNorm(s): a row's 256 values live in 4 lane groups (g) x 4 waves; sums through two shuffles + an LDS exchange --------
+  auto row_total = [&](float (&part)[MT], float (&tot)[MT]) __attribute__((always_inline)) {
+    __syncthreads();  // (the scratch may still be read from the previous exchange)
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      float a = part[s];
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (g == 0) red[wave * ROWS + 16 * s + c] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      const int r = 16 * s + c;
+      tot[s] = (red[r] + red[ROWS + r]) + (red[2 * ROWS + r] + red[3 * ROWS + r]);
+    }
+  };
+  auto layer_norm = [&](const float* gam, const float* bet) __attribute__((always_inline)) {
+    float part[MT], mean[MT], var[MT];
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      part[s] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) part[s] += (acc[jt][s][0] + acc[jt][s][1]) + (acc[jt][s][2] + acc[jt][s][3]);
+    }
+    row_total(part, mean);
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      mean[s] *= (1.0f / 256.0f);
+      part[s] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        acc[jt][s] -= mean[s];
+        part[s] += (acc[jt][s][0] * acc[jt][s][0] + acc[jt][s][1] * acc[jt][s][1]) +
+                   (acc[jt][s][2] * acc[jt][s][2] + acc[jt][s][3] * acc[jt][s][3]);
+      }
+    }
+    row_total(part, var);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = 64 * wave + 16 * jt + 4 * g;
+      const float4 ga = *reinterpret_cast<const float4*>(gam + n), be = *reinterpret_cast<const float4*>(bet + n);
+#pragma unroll
+      for (int s = 0; s < MT; ++s) {
+        const float inv = 1.0f / sqrtf(var[s] * (1.0f / 256.0f) + e.eps);
+        acc[jt][s] = tc_f32x4{acc[jt][s][0] * inv * ga.x + be.x, acc[jt][s][1] * inv * ga.y + be.y, acc[jt][s][2] * inv * ga.z + be.z,
+                              acc[jt][s][3] * inv * ga.w + be.w};
+      }
+    }
+  };
+  layer_norm(e.ln_g1, e.ln_b1);
+  if (e.ln_g2) {
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      const int m = m0 + 16 * s + c;
+      if (m >= M) continue;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+        *reinterpret_cast<float4*>(e.ln_mid + (int64_t)m * e.ld_mid + 64 * wave + 16 * jt + 4 * g) =
+            make_float4(acc[jt][s][0], acc[jt][s][1], acc[jt][s][2], acc[jt][s][3]);
+    }
+    layer_norm(e.ln_g2, e.ln_b2);
+  }
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int m = m0 + 16 * s + c;
+    if (m >= M) continue;
+    const float lrs = e.ln_row_scale ? e.ln_row_scale[m] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = 64 * wave + 16 * jt + 4 * g;
+      const tc_f32x4 v = acc[jt][s] * lrs;
+      if (e.ln_out_bf16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.ln_out) + (int64_t)m * e.ld_ln + n) =
+            make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+      else
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(e.ln_out) + (int64_t)m * e.ld_ln + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+}  // namespace ma

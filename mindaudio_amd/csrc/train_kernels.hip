@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "../../include/mindaudio_amd.h"
+#include "train_common.h"
 
 #define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
   do {                                                                        \
@@ -36,18 +37,6 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 // multiplies of the dropout hash - not bandwidth-bound; 1 ulp, invisible after the bf16 rounding of every consumer)
 __device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-// Counter-based dropout: the keep decision of element `idx` of dropout site `salt` at step seed `seed` is a pure
-// function, so the backward pass regenerates the mask instead of storing it.
-// One 32-bit hash serves the element pair (idx & ~1, idx | 1), 16 bits each (p is resolved to 2^-16): the three integer multiplies
-// of the mixer are quarter-rate instructions and made these element-wise kernels VALU-bound; kernels that walk consecutive
-// elements get the pair's hash once (common subexpression after inlining).
-__device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t salt, uint64_t idx, uint32_t thresh) {
-  const uint64_t pair = idx >> 1;
-  uint32_t x = (uint32_t)pair ^ (seed * 0x9E3779B9u) ^ (salt * 0x85EBCA6Bu) ^ ((uint32_t)(pair >> 32) * 0xC2B2AE35u);
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  x += salt; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
-  return ((idx & 1) ? (x >> 16) : (x & 0xffffu)) >= (thresh >> 16);
-}
 // activation storage type of the element-wise training kernels: uint16_t = bf16 bit patterns (throughput mode) or float
 // (the float32 validation mode, entry points with the _x32 suffix)
 __device__ __forceinline__ float ldact(const uint16_t* p) { return bf2f(*p); }
@@ -57,11 +46,6 @@ __device__ __forceinline__ void stact(float* p, float v) { *p = v; }
 // precise sigmoid for the float32 mode; the bf16 mode keeps the 1-ulp v_rcp / v_exp form (invisible after bf16 rounding)
 template <typename AT> __device__ __forceinline__ float sigm(float v) { return sigmoidf_(v); }
 template <> __device__ __forceinline__ float sigm<float>(float v) { return 1.0f / (1.0f + expf(-v)); }
-
-struct Drop {
-  uint32_t seed, salt, thresh;  // thresh = p * 2^32; 0 = no dropout
-  float inv_keep;               // 1 / (1 - p)
-};
 
 // ---- transpose (+ column sums) --------------------------------------------------------------------------------
 // 64 x 64 tile through LDS.  VEC: 16-byte global loads and stores (ld_in, ld_out, cols multiples of 8, 16-byte aligned
@@ -228,7 +212,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, float eps,
                                                             const float* __restrict__ row_scale, const void* dy_,
                                                             int64_t ldy, float* g, int64_t ldg, int accumulate,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, uint16_t* __restrict__ dy_next,
+                                                            int64_t ld_next, float alpha_next,
+                                                            const float* __restrict__ rs_next, Drop drop_next) {
   __shared__ float red[2][4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4);
@@ -280,6 +266,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     o.z += rstd * (w[2] - a - xh[2] * b);
     o.w += rstd * (w[3] - a - xh[3] * b);
     *reinterpret_cast<float4*>(gp) = o;
+    if (dy_next) {  // the next branch's dropout_bwd_kernel on the finished row: dy = alpha * keep / (1 - p) * g * row_scale, bf16
+      float v[4] = {o.x * alpha_next, o.y * alpha_next, o.z * alpha_next, o.w * alpha_next};
+      if (rs_next) {
+        const float r2 = rs_next[row];
+        v[0] *= r2; v[1] *= r2; v[2] *= r2; v[3] *= r2;
+      }
+      drop4(drop_next, (uint64_t)row * 256 + lane * 4, v);
+      *reinterpret_cast<uint2*>(dy_next + row * ld_next + lane * 4) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -938,21 +933,6 @@ static int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
   return g < 1 ? 1 : (int)g;
 }
 
-static Drop make_drop(float p, uint32_t seed, uint32_t salt) {
-  Drop d;
-  d.seed = seed;
-  d.salt = salt;
-  if (!(p > 0.0f)) {
-    d.thresh = 0;
-    d.inv_keep = 1.0f;
-  } else {
-    double th = (double)p * 4294967296.0;
-    d.thresh = th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th;
-    d.inv_keep = 1.0f / (1.0f - p);
-  }
-  return d;
-}
-
 }  // namespace ma
 
 using namespace ma;
@@ -983,6 +963,21 @@ int ma_transpose_batch_bf16(const ma_transpose_item_t* items, const int32_t* blo
 
 int64_t ma_train_reduce_workspace_bytes(void) { return (int64_t)kMaxPartBlocks * kMaxPartWidth * 4; }
 
+static int ln_bwd_launch(const float* x, int64_t ldx, int64_t rows, const float* gamma, float eps, const float* row_scale, const void* dy,
+                         int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg, int32_t accumulate, float* dgamma, float* dbeta,
+                         float* part, int grid, uint16_t* dy_next, int64_t ld_next, float alpha_next, const float* rs_next, Drop dn,
+                         ma_stream_t stream) {
+  if (dy_bf16)
+    MA_LAUNCH(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps, row_scale, dy, ldy,
+              g, ldg, accumulate, part, dy_next, ld_next, alpha_next, rs_next, dn);
+  else
+    MA_LAUNCH(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps, row_scale, dy, ldy,
+              g, ldg, accumulate, part, dy_next, ld_next, alpha_next, rs_next, dn);
+  if (dgamma)
+    MA_LAUNCH(partial_reduce_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, part, grid, 512, dgamma, 256, dbeta, 0);
+  return MA_OK;
+}
+
 int32_t ma_layernorm_bwd_parts(int64_t rows) { return rows < 1 ? MA_ERR_INVALID_ARG : grid_for(rows, 4, kLnBwdBlocks); }
 
 int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
@@ -994,15 +989,23 @@ int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, c
   const int grid = ma_layernorm_bwd_parts(rows);
   if (workspace_bytes < (int64_t)grid * 512 * 4) return MA_ERR_WORKSPACE;
   float* part = reinterpret_cast<float*>(workspace);
-  if (dy_bf16)
-    MA_LAUNCH(layernorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
-              row_scale, dy, ldy, g, ldg, accumulate, part);
-  else
-    MA_LAUNCH(layernorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,
-              row_scale, dy, ldy, g, ldg, accumulate, part);
-  if (dgamma)
-    MA_LAUNCH(partial_reduce_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, part, grid, 512, dgamma, 256, dbeta, 0);
-  return MA_OK;
+  return ln_bwd_launch(x, ldx, rows, gamma, eps, row_scale, dy, ldy, dy_bf16, g, ldg, accumulate, dgamma, dbeta, part, grid, nullptr, 0,
+                       0.0f, nullptr, make_drop(0.0f, 0, 0), stream);
+}
+
+int ma_layernorm_bwd_next_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,
+                              const float* row_scale, const void* dy, int64_t ldy, int32_t dy_bf16, float* g, int64_t ldg,
+                              int32_t accumulate, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                              void* dy_next, int64_t ld_next, float alpha_next, const float* row_scale_next, float p_next,
+                              uint32_t seed, uint32_t salt_next, ma_stream_t stream) {
+  if (!x || !gamma || !dy || !g || (dgamma && !dbeta) || !workspace || !dy_next || rows < 1) return MA_ERR_INVALID_ARG;
+  if (D != 256 || (ldx & 3) || (ldy & 3) || (ldg & 3) || (ld_next & 3) || ld_next < 256 || p_next < 0.0f || p_next >= 1.0f)
+    return MA_ERR_UNSUPPORTED;
+  const int grid = ma_layernorm_bwd_parts(rows);
+  if (workspace_bytes < (int64_t)grid * 512 * 4) return MA_ERR_WORKSPACE;
+  return ln_bwd_launch(x, ldx, rows, gamma, eps, row_scale, dy, ldy, dy_bf16, g, ldg, accumulate, dgamma, dbeta,
+                       reinterpret_cast<float*>(workspace), grid, reinterpret_cast<uint16_t*>(dy_next), ld_next, alpha_next,
+                       row_scale_next, make_drop(p_next, seed, salt_next), stream);
 }
 
 int ma_act_dropout_fwd_bf16(const void* u, void* h, int64_t n, int32_t act, float p, uint32_t seed, uint32_t salt,

@@ -180,7 +180,7 @@ class ConformerCTCTrainStep:
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
                  process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None,
-                 force_collective=False):
+                 force_collective=False, fused=True):
         """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
         torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
         activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
@@ -188,6 +188,10 @@ class ConformerCTCTrainStep:
         if compute_type not in (None, torch.bfloat16, torch.float32, "bfloat16", "float32"):
             raise ValueError("compute_type must be bfloat16 (default) or float32")
         self.x32 = compute_type in (torch.float32, "float32")
+        # fused = the dense layers of a block run on fragment-packed weights with their element-wise neighbours (Swish + dropout,
+        # residual + dropout + LayerNorm, Swish' + dropout, the next branch's dropout backward) in the launch's epilogue;
+        # False = one launch per reference cell (what the float32 validation mode always runs)
+        self.fused = bool(fused) and not self.x32
         self.K, self.O = (X32, X32) if self.x32 else (K, ops)
         self.model, self.enc = model, enc
         self.dev = next(model.parameters()).device
@@ -419,12 +423,55 @@ class ConformerCTCTrainStep:
             dev_items, dev_map, n_blocks = self._wt_plan
             _lib.check(_lib.load().ma_transpose_batch_bf16(dev_items.data_ptr(), dev_map.data_ptr(), n_blocks,
                                                            torch.cuda.current_stream().cuda_stream), "transpose_batch")
+            if self.fused:
+                self._pack_weights()
         else:
             for n in names:
                 if n not in self.wt:
                     rows, cols = fp.w(n).shape
                     self.wt[n] = torch.zeros((cols, K.pad64(rows)), dtype=torch.bfloat16, device=self.dev)
                 K.transpose(fp.w(n), out=self.wt[n])
+
+    # fragment-packed copies of a block's dense weights (fused mode): name -> (source, kind) with kind 0 = K = 256 layers
+    # (ma_gemm_k256_pack_bf16 layout), 1 = 256-output layers with a long contraction (ma_gemm_rows_pack_bf16 layout); ".t" sources
+    # are the transposed copies (the input-gradient products)
+    _PACKS = (("ffm_w1.k", "ffm_w1", False, 0), ("ffm_w2.r", "ffm_w2", False, 1), ("ffm_w2.tk", "ffm_w2", True, 0),
+              ("ffm_w1.tr", "ffm_w1", True, 1), ("ff_w1.k", "ff_w1", False, 0), ("ff_w2.r", "ff_w2", False, 1),
+              ("ff_w2.tk", "ff_w2", True, 0), ("ff_w1.tr", "ff_w1", True, 1), ("qkv_w.k", "qkv_w", False, 0),
+              ("qkv_w.tr", "qkv_w", True, 1), ("o_w.k", "o_w", False, 0), ("o_w.tk", "o_w", True, 0), ("pw1_w.k", "pw1_w", False, 0),
+              ("pw1_w.tr", "pw1_w", True, 1), ("pw2_w.k", "pw2_w", False, 0), ("pw2_w.tk", "pw2_w", True, 0))
+
+    @torch.no_grad()
+    def _pack_weights(self):
+        """One launch re-packs every block's dense weights (bf16 mirror and transposed copies -> MFMA-fragment order)."""
+        lib = _lib.load()
+        if getattr(self, "_pack_plan", None) is None:
+            import numpy as np
+
+            items, block_item, first, total = [], [], 0, 0
+            self.pk = {}
+            specs = []
+            for li in range(self.L):
+                for key, src, transposed, kind in self._PACKS:
+                    w = self.wt["l%d.%s" % (li, src)] if transposed else self.fp.w("l%d.%s" % (li, src))
+                    n, k = w.shape[0], (self.fp.w("l%d.%s" % (li, src)).shape[0] if transposed else w.shape[1])
+                    pieces = int(lib.ma_pack_item_pieces(kind, n, k))
+                    _lib.check(min(pieces, 0), "pack %s" % key)
+                    specs.append(("l%d.%s" % (li, key), w, n, k, kind, pieces, total))
+                    total += pieces * 16
+            arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
+            for name, w, n, k, kind, pieces, off in specs:
+                self.pk[name] = arena[off:off + pieces * 16]
+                nblk = (pieces + 255) // 256
+                items.append(_lib.PackItem(w.data_ptr(), arena.data_ptr() + off, w.stride(0), n, k, kind, first))
+                block_item += [len(items) - 1] * nblk
+                first += nblk
+            raw = (_lib.PackItem * len(items))(*items)
+            self._pack_plan = (torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
+                               torch.tensor(block_item, dtype=torch.int32, device=self.dev), first, arena)
+        dev_items, dev_map, n_blocks, _ = self._pack_plan
+        _lib.check(lib.ma_pack_batch_bf16(dev_items.data_ptr(), dev_map.data_ptr(), n_blocks,
+                                          torch.cuda.current_stream().cuda_stream), "pack_batch")
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _salt(self, layer, site):
@@ -556,6 +603,61 @@ class ConformerCTCTrainStep:
             pe = K.dropout_add(None, pe, 1.0, pp, seed, self._salt(-1, 1))
         pe_bf = ops.cast_bf16(pe)
         pos_all = ops.gemm(pe_bf, fp.w("pos_w"))  # (t2, L*256) bf16
+        ctx_ = dict(seed=seed, b=b, t2=t2, m=m, mask_rows=mask_rows, att_mask=att_mask, pos_all=pos_all)
+        if self.fused:
+            x, enc_bf, tape = self._blocks_forward_fused(x, ctx_)
+        else:
+            x, enc_bf, tape = self._blocks_forward(x, ctx_)
+        logits = torch.empty((m, self.Vp), dtype=f32, device=self.dev)
+        ops.gemm(enc_bf, fp.w("ctc_w"), bias=fp.p("ctc_b"), out_dtype=f32, out=logits[:, :self.V])
+        wc = self.ctc_weight
+        loss, per_utt, dlog = K.ctc_loss_grad(logits, self.V, b, t2, ys_pad, hlens, ys_lengths, grad_scale * wc / b)
+        d_mem = None
+        if self.dec is not None:  # attention branch: loss = w * ctc + (1 - w) * att (asr_model.py:138-139)
+            if ys_in_pad is None or ys_out_pad is None or ys_sub_masks is None or ys_masks is None:
+                raise ValueError("the hybrid loss needs ys_in_pad, ys_out_pad, ys_sub_masks and ys_masks")
+            # label_smoothing_loss.py:105-106: / batch, or / tokens (divided on the device) when length_normalized_loss
+            loss_att, d_mem = self._decoder_forward_backward(enc_bf, mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks,
+                                                             ys_masks, grad_scale * (1.0 - wc) / (1.0 if self.len_norm else b),
+                                                             seed)
+            self.last_loss_ctc, self.last_loss_att = loss, loss_att
+            loss = wc * loss + (1.0 - wc) * loss_att
+
+        # ================= backward =================
+        # CTC head: logits = enc_bf W^T + b
+        K.gemm_tn(dlog, enc_bf, fp.g("ctc_w"), colsum=fp.g("ctc_b"), rows_store=self.V)
+        if d_mem is None:
+            d_enc = self._dX(dlog, "ctc_w")            # (m, 256) bf16
+        else:                                                   # + the decoder's gradient w.r.t. the encoder output
+            d_enc = self._dX(dlog, "ctc_w", residual=d_mem, out_dtype=f32, out=d_mem)
+        g = torch.empty((m, d), dtype=f32, device=self.dev)
+        K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
+        dpos_all = torch.zeros((t2, L * d), dtype=f32, device=self.dev)
+        if self.fused:
+            self._blocks_backward_fused(g, tape, dpos_all, ctx_)
+        else:
+            self._blocks_backward(g, tape, dpos_all, ctx_)
+        # positional projection of every layer: dW_pos (L*256, 256) = dpos_all^T pe
+        self._dW(ops.cast_bf16(dpos_all), pe_bf, "pos_w", None)
+        # embedding: x = dropout(sqrt(d) * (a2 W_out^T + b))
+        de = K.dropout_bwd(g, math.sqrt(d), pp, seed, self._salt(-1, 0))
+        self._dW(de, a2, "out_w", "out_b")
+        dact2 = self._dX(de, "out_w")                  # (m, f2*c) bf16
+        K.relu_bwd(dact2, a2)
+        dy2 = dact2.view(m * f2, c)
+        K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"))
+        dcol = self._dX(dy2, "conv2_w")                # (B*T2*F2, 9c) bf16
+        dact1 = K.col2im_relu(dcol, act1)
+        K.conv1_dw(dact1, xs, enc.cmvn_mean, enc.cmvn_istd, fp.g("conv1_w"), fp.g("conv1_b"))
+        self._embed_done()
+        return loss
+
+    # ---- the blocks, one launch per reference cell ------------------------------------------------------------------------------
+    def _blocks_forward(self, x, c):
+        fp, d, L = self.fp, self.d, self.L
+        ops, K = self.O, self.K
+        f32 = torch.float32
+        seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         tape = []
         for li in range(L):
             pre = "l%d." % li
@@ -590,31 +692,12 @@ class ConformerCTCTrainStep:
             x = ops.layernorm(x, P("norm_final.g"), P("norm_final.b"), out_dtype=f32)
             tape.append(T)
         enc_bf = ops.layernorm(x, fp.p("after_norm.g"), fp.p("after_norm.b"))
-        logits = torch.empty((m, self.Vp), dtype=f32, device=self.dev)
-        ops.gemm(enc_bf, fp.w("ctc_w"), bias=fp.p("ctc_b"), out_dtype=f32, out=logits[:, :self.V])
-        wc = self.ctc_weight
-        loss, per_utt, dlog = K.ctc_loss_grad(logits, self.V, b, t2, ys_pad, hlens, ys_lengths, grad_scale * wc / b)
-        d_mem = None
-        if self.dec is not None:  # attention branch: loss = w * ctc + (1 - w) * att (asr_model.py:138-139)
-            if ys_in_pad is None or ys_out_pad is None or ys_sub_masks is None or ys_masks is None:
-                raise ValueError("the hybrid loss needs ys_in_pad, ys_out_pad, ys_sub_masks and ys_masks")
-            # label_smoothing_loss.py:105-106: / batch, or / tokens (divided on the device) when length_normalized_loss
-            loss_att, d_mem = self._decoder_forward_backward(enc_bf, mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks,
-                                                             ys_masks, grad_scale * (1.0 - wc) / (1.0 if self.len_norm else b),
-                                                             seed)
-            self.last_loss_ctc, self.last_loss_att = loss, loss_att
-            loss = wc * loss + (1.0 - wc) * loss_att
+        return x, enc_bf, tape
 
-        # ================= backward =================
-        # CTC head: logits = enc_bf W^T + b
-        K.gemm_tn(dlog, enc_bf, fp.g("ctc_w"), colsum=fp.g("ctc_b"), rows_store=self.V)
-        if d_mem is None:
-            d_enc = self._dX(dlog, "ctc_w")            # (m, 256) bf16
-        else:                                                   # + the decoder's gradient w.r.t. the encoder output
-            d_enc = self._dX(dlog, "ctc_w", residual=d_mem, out_dtype=f32, out=d_mem)
-        g = torch.empty((m, d), dtype=f32, device=self.dev)
-        K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
-        dpos_all = torch.zeros((t2, L * d), dtype=f32, device=self.dev)
+    def _blocks_backward(self, g, tape, dpos_all, c):
+        fp, d, L = self.fp, self.d, self.L
+        K = self.K
+        seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         for li in reversed(range(L)):
             pre = "l%d." % li
             W, P, G = (lambda n, pre=pre: fp.w(pre + n)), (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n))
@@ -647,20 +730,99 @@ class ConformerCTCTrainStep:
                             partials=self._ln_partials("norm_mha"))
             self._ffn_bwd(g, T["ffm"], "ffm", "norm_ff_macaron", pre, seed, li, 0)
             self._layer_done(li)
-        # positional projection of every layer: dW_pos (L*256, 256) = dpos_all^T pe
-        self._dW(ops.cast_bf16(dpos_all), pe_bf, "pos_w", None)
-        # embedding: x = dropout(sqrt(d) * (a2 W_out^T + b))
-        de = K.dropout_bwd(g, math.sqrt(d), pp, seed, self._salt(-1, 0))
-        self._dW(de, a2, "out_w", "out_b")
-        dact2 = self._dX(de, "out_w")                  # (m, f2*c) bf16
-        K.relu_bwd(dact2, a2)
-        dy2 = dact2.view(m * f2, c)
-        K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"))
-        dcol = self._dX(dy2, "conv2_w")                # (B*T2*F2, 9c) bf16
-        dact1 = K.col2im_relu(dcol, act1)
-        K.conv1_dw(dact1, xs, enc.cmvn_mean, enc.cmvn_istd, fp.g("conv1_w"), fp.g("conv1_b"))
-        self._embed_done()
-        return loss
+
+    # ---- the blocks, fused: dense layers on fragment-packed weights with their element-wise neighbours in the epilogue ---------------
+    def _blocks_forward_fused(self, x, c):
+        """models/conformer.py:100-161 in training mode.  Per block 12 launches instead of 23: [w_1 + Swish + dropout] -> [w_2 + dropout +
+        residual + LayerNorm of the next cell] for the two feed-forward modules, linear_q/k/v -> attention -> [linear_out + dropout +
+        residual + norm_conv * mask], pointwise_conv1 -> depthwise / BatchNorm statistics / BatchNorm + Swish -> [pointwise_conv2 * mask +
+        dropout + residual + norm_ff]; the last join of a block also applies norm_final and the LayerNorm that consumes it."""
+        fp, d, L, K = self.fp, self.d, self.L, self.K
+        seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
+        hid = self.hidden
+        a = ops.layernorm(x, fp.p("l0.norm_ff_macaron.g"), fp.p("l0.norm_ff_macaron.b"))
+        tape, enc_bf = [], None
+        for li in range(L):
+            pre = "l%d." % li
+            P, PK = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: self.pk[pre + n])
+            ln = lambda n: (P(n + ".g"), P(n + ".b"))  # noqa: E731
+            T = {}
+            # -- macaron FFN
+            u, h = K.dense_act_drop(a, PK("ffm_w1.k"), hid, P("ffm_b1"), pd, seed, self._salt(li, 0))
+            x1, a1, _ = K.dense_join(h, PK("ffm_w2.r"), hid, P("ffm_b2"), x, 0.5, pd, seed, self._salt(li, 1), ln1=ln("norm_mha"))
+            T["ffm"] = dict(x_in=x, a=a, u=u, h=h)
+            # -- MHSA
+            qkv = K.dense_plain(a1, PK("qkv_w.k"), 3 * d, d, bias=P("qkv_b"))
+            ctx, lse = K.attention_fwd(qkv, pos_all[:, li * d:(li + 1) * d], P("u"), P("v"), att_mask, b, t2, self.heads, d // self.heads)
+            x2, a2, _ = K.dense_join(ctx, PK("o_w.k"), d, P("o_b"), x1, 1.0, pd, seed, self._salt(li, 2), ln1=ln("norm_conv"),
+                                     ln_row_scale=mask_rows)
+            T["mha"] = dict(x_in=x1, a=a1, qkv=qkv, ctx=ctx, lse=lse)
+            # -- convolution module
+            y = K.dense_plain(a2, PK("pw1_w.k"), 2 * d, d, bias=P("pw1_b"))
+            wv, z, stats = K.convmid_fwd_train(y, b, t2, P("dw_w"), P("dw_b"), P("bn_g"), P("bn_b"), self.bn_mean[li], self.bn_var[li],
+                                               momentum=self.bn_momentum)
+            x3, a3, _ = K.dense_join(wv, PK("pw2_w.k"), d, P("pw2_b"), x2, 1.0, pd, seed, self._salt(li, 3), row_scale=mask_rows,
+                                     ln1=ln("norm_ff"))
+            T["conv"] = dict(x_in=x2, a=a2, y=y, w=wv, z=z, stats=stats)
+            # -- FFN, norm_final and the LayerNorm that reads its output (the next block's norm_ff_macaron, or after_norm)
+            u, h = K.dense_act_drop(a3, PK("ff_w1.k"), hid, P("ff_b1"), pd, seed, self._salt(li, 6))
+            nxt = (fp.p("l%d.norm_ff_macaron.g" % (li + 1)), fp.p("l%d.norm_ff_macaron.b" % (li + 1))) if li + 1 < L else \
+                (fp.p("after_norm.g"), fp.p("after_norm.b"))
+            x4, a, x = K.dense_join(h, PK("ff_w2.r"), hid, P("ff_b2"), x3, 0.5, pd, seed, self._salt(li, 7), ln1=ln("norm_final"), ln2=nxt)
+            T["ff"] = dict(x_in=x3, a=a3, u=u, h=h)
+            T["final_in"] = x4
+            tape.append(T)
+        return x, a, tape
+
+    def _blocks_backward_fused(self, g, tape, dpos_all, c):
+        """Per block 28 launches instead of 40: every LayerNorm backward also emits the dropout backward of the branch in front of it
+        (bf16 dy), the input gradients run on packed transposed weights, and dh -> du (Swish', dropout) rides on the w_2 product."""
+        fp, d, L, K = self.fp, self.d, self.L, self.K
+        seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
+        hid = self.hidden
+        for li in reversed(range(L)):
+            pre = "l%d." % li
+            P, G, PK = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n)), (lambda n, pre=pre: self.pk[pre + n])
+            T = tape[li]
+
+            def ffn_bwd(dy, F, key, ln, nxt):
+                self._dW(dy, F["h"], pre + key + "_w2", pre + key + "_b2")
+                du = K.dense_act_drop_bwd(dy, PK(key + "_w2.tk"), hid, F["u"], pd, seed, self._salt(li, 0 if key == "ffm" else 6))
+                self._dW(du, F["a"], pre + key + "_w1", pre + key + "_b1")
+                da = K.dense_plain(du, PK(key + "_w1.tr"), d, hid)
+                if nxt is None:
+                    K.layernorm_bwd(F["x_in"], P(ln + ".g"), da, g, G(ln + ".g"), G(ln + ".b"), partials=self._ln_partials(ln))
+                    return None
+                return K.layernorm_bwd_next(F["x_in"], P(ln + ".g"), da, g, G(ln + ".g"), G(ln + ".b"), nxt,
+                                            partials=self._ln_partials(ln))[1]
+
+            _, dy = K.layernorm_bwd_next(T["final_in"], P("norm_final.g"), g, g, G("norm_final.g"), G("norm_final.b"),
+                                         (0.5, pd, seed, self._salt(li, 7), None), accumulate=False,
+                                         partials=self._ln_partials("norm_final"))
+            do = ffn_bwd(dy, T["ff"], "ff", "norm_ff", (1.0, pd, seed, self._salt(li, 3), mask_rows))
+            # conv module
+            C = T["conv"]
+            self._dW(do, C["w"], pre + "pw2_w", pre + "pw2_b")
+            dwv = K.dense_plain(do, PK("pw2_w.tk"), d, d)
+            dy = K.convmid_bwd(dwv, C["y"], C["z"], C["stats"], b, t2, P("dw_w"), P("bn_g"), P("bn_b"), G("dw_w"), G("dw_b"), G("bn_g"),
+                               G("bn_b"))
+            self._dW(dy, C["a"], pre + "pw1_w", pre + "pw1_b")
+            da = K.dense_plain(dy, PK("pw1_w.tr"), d, 2 * d)
+            _, do = K.layernorm_bwd_next(C["x_in"], P("norm_conv.g"), da, g, G("norm_conv.g"), G("norm_conv.b"),
+                                         (1.0, pd, seed, self._salt(li, 2), None), row_scale=mask_rows,
+                                         partials=self._ln_partials("norm_conv"))
+            # MHSA
+            A = T["mha"]
+            self._dW(do, A["ctx"], pre + "o_w", pre + "o_b")
+            dctx = K.dense_plain(do, PK("o_w.tk"), d, d)
+            dqkv = K.attention_bwd(A["qkv"], pos_all[:, li * d:(li + 1) * d], P("u"), P("v"), att_mask, A["ctx"], dctx, A["lse"], b, t2,
+                                   dpos_all[:, li * d:(li + 1) * d], G("u"), G("v"), self.heads, d // self.heads)
+            self._dW(dqkv, A["a"], pre + "qkv_w", pre + "qkv_b")
+            da = K.dense_plain(dqkv, PK("qkv_w.tr"), d, 3 * d)
+            _, dy = K.layernorm_bwd_next(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"),
+                                         (0.5, pd, seed, self._salt(li, 1), None), partials=self._ln_partials("norm_mha"))
+            ffn_bwd(dy, T["ffm"], "ffm", "norm_ff_macaron", None)
+            self._layer_done(li)
 
     def _decoder_forward_backward(self, mem_bf, enc_mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks, ys_masks, gscale,
                                   seed):

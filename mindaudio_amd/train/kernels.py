@@ -325,3 +325,117 @@ def ctc_loss_grad(logits, V, batch, T, ys_pad, hlens, ys_lens, grad_scale, blank
                                         _p(hlens), _p(ys_lens), blank, 1, float(grad_scale), _p(per), _p(lse), _p(out),
                                         _p(dlog), dlog.stride(0), _p(ws), ws_bytes, _s()), "ctc_loss_grad")
     return out[0], per, dlog
+
+
+# ---- training forms of the packed dense layers (csrc/gemm_k256.hip, csrc/rows_packed.hip) --------------------------------------
+def _train_epi(mode, bias=None, aux=None, out2=None, residual=None, row_scale=None, alpha=1.0, p=0.0, seed=0, salt=0, ln1=None,
+               ln2=None, ln_row_scale=None, ln_out=None, ln_mid=None, eps=1e-5):
+    t = _t()
+    e = _lib.TrainEpilogue()
+    e.mode = mode
+    e.bias = bias.data_ptr() if bias is not None else None
+    if aux is not None:
+        e.aux, e.ld_aux = aux.data_ptr(), aux.stride(0)
+    if out2 is not None:
+        e.out2, e.ldo2 = out2.data_ptr(), out2.stride(0)
+    if residual is not None:
+        e.residual, e.ldr = residual.data_ptr(), residual.stride(0)
+    e.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    e.alpha, e.p, e.seed, e.salt = float(alpha), float(p), int(seed), int(salt)
+    if ln1 is not None:
+        e.ln_gamma1, e.ln_beta1 = ln1[0].data_ptr(), ln1[1].data_ptr()
+        e.ln_out, e.ld_ln, e.ln_out_bf16 = ln_out.data_ptr(), ln_out.stride(0), 1 if ln_out.dtype == t.bfloat16 else 0
+    if ln2 is not None:
+        e.ln_gamma2, e.ln_beta2 = ln2[0].data_ptr(), ln2[1].data_ptr()
+        e.ln_mid, e.ld_mid = ln_mid.data_ptr(), ln_mid.stride(0)
+    e.ln_row_scale = ln_row_scale.data_ptr() if ln_row_scale is not None else None
+    e.ln_eps = float(eps)
+    return e
+
+
+def dense_act_drop(a, packed, n, bias, p, seed, salt):
+    """w_1 forward (K = 256): -> (u (M, n) bf16 = a W^T + b, h (M, n) bf16 = dropout(swish(u))), one launch."""
+    import ctypes
+
+    t = _t()
+    m = a.shape[0]
+    u = t.empty((m, n), dtype=t.bfloat16, device=a.device)
+    h = t.empty((m, n), dtype=t.bfloat16, device=a.device)
+    e = _train_epi(1, bias=bias, out2=h, p=p, seed=seed, salt=salt)
+    _lib.check(_lib.load().ma_gemm_k256_train_bf16(_p(a), a.stride(0), _p(packed), _p(u), u.stride(0), m, n, ctypes.byref(e), _s()),
+               "dense_act_drop")
+    return u, h
+
+
+def dense_act_drop_bwd(dy, packed, n, u, p, seed, salt):
+    """w_1 backward (K = 256): du (M, n) bf16 = (dy W2) * swish'(u) * keep / (1 - p); `packed` = the k256 packing of W2^T (n, 256)."""
+    import ctypes
+
+    t = _t()
+    m = dy.shape[0]
+    du = t.empty((m, n), dtype=t.bfloat16, device=dy.device)
+    e = _train_epi(2, aux=u, p=p, seed=seed, salt=salt)
+    _lib.check(_lib.load().ma_gemm_k256_train_bf16(_p(dy), dy.stride(0), _p(packed), _p(du), du.stride(0), m, n, ctypes.byref(e), _s()),
+               "dense_act_drop_bwd")
+    return du
+
+
+def dense_plain(a, packed, n, k, bias=None):
+    """out (M, n) bf16 = a (M, k) W^T (+ bias) on a packed weight: K = 256 (any n % 256 == 0) or n = 256 (any k % 64 == 0)."""
+    import ctypes
+
+    t = _t()
+    m = a.shape[0]
+    out = t.empty((m, n), dtype=t.bfloat16, device=a.device)
+    e = _train_epi(4, bias=bias)
+    lib = _lib.load()
+    if k == 256:
+        _lib.check(lib.ma_gemm_k256_train_bf16(_p(a), a.stride(0), _p(packed), _p(out), out.stride(0), m, n, ctypes.byref(e), _s()),
+                   "dense_plain")
+    else:
+        _lib.check(lib.ma_gemm_rows_train_bf16(_p(a), a.stride(0), m, k, _p(packed), _p(out), out.stride(0), ctypes.byref(e), _s()),
+                   "dense_plain")
+    return out
+
+
+def dense_join(a, packed, k, bias, residual, alpha, p, seed, salt, row_scale=None, ln1=None, ln2=None, ln_row_scale=None,
+               ln_out_dtype=None, eps=1e-5):
+    """Branch join (N = 256): x_out (M, 256) float32 = residual + alpha * dropout(bf16((a W^T + b) * row_scale)), and optionally
+    LayerNorm(x_out; ln1) [* ln_row_scale] (-> bf16, or ln_out_dtype), or the chain ln_mid = LayerNorm(x_out; ln1) float32,
+    ln_out = LayerNorm(ln_mid; ln2).  Returns (x_out, ln_out, ln_mid)."""
+    import ctypes
+
+    t = _t()
+    m = a.shape[0]
+    out = t.empty((m, 256), dtype=t.float32, device=a.device)
+    ln_out = ln_mid = None
+    if ln1 is not None:
+        ln_out = t.empty((m, 256), dtype=ln_out_dtype or t.bfloat16, device=a.device)
+    if ln2 is not None:
+        ln_mid = t.empty((m, 256), dtype=t.float32, device=a.device)
+    e = _train_epi(3, bias=bias, residual=residual, row_scale=row_scale, alpha=alpha, p=p, seed=seed, salt=salt, ln1=ln1, ln2=ln2,
+                   ln_row_scale=ln_row_scale, ln_out=ln_out, ln_mid=ln_mid, eps=eps)
+    lib = _lib.load()
+    if k == 256:
+        _lib.check(lib.ma_gemm_k256_train_bf16(_p(a), a.stride(0), _p(packed), _p(out), out.stride(0), m, 256, ctypes.byref(e), _s()),
+                   "dense_join")
+    else:
+        _lib.check(lib.ma_gemm_rows_train_bf16(_p(a), a.stride(0), m, k, _p(packed), _p(out), out.stride(0), ctypes.byref(e), _s()),
+                   "dense_join")
+    return out, ln_out, ln_mid
+
+
+def layernorm_bwd_next(x, gamma, dy, g, dgamma, dbeta, nxt, row_scale=None, accumulate=True, eps=1e-5, partials=None):
+    """layernorm_bwd, plus the next branch's dropout_bwd on the finished rows: nxt = (alpha, p, seed, salt, row_scale or None)
+    -> (g, dy_next (M, 256) bf16)."""
+    t = _t()
+    ws = partials if partials is not None else _reduce_ws(x.device)
+    alpha, p, seed, salt, rs_next = nxt
+    dy_next = t.empty((x.shape[0], 256), dtype=t.bfloat16, device=x.device)
+    _lib.check(_lib.load().ma_layernorm_bwd_next_f32(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(gamma), float(eps), _p(row_scale),
+                                                     _p(dy), dy.stride(0), 1 if dy.dtype == t.bfloat16 else 0, _p(g), g.stride(0),
+                                                     1 if accumulate else 0, None if partials is not None else _p(dgamma),
+                                                     None if partials is not None else _p(dbeta), _p(ws),
+                                                     ws.numel() * ws.element_size(), _p(dy_next), dy_next.stride(0), float(alpha),
+                                                     _p(rs_next), float(p), seed, salt, _s()), "layernorm_bwd_next")
+    return g, dy_next

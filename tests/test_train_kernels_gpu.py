@@ -431,3 +431,83 @@ def test_decoder_attention_rejects_more_keys_than_the_lds_holds(K):
     z = lambda n: torch.zeros(n, h * dk, dtype=torch.bfloat16, device="cuda")  # noqa: E731
     with pytest.raises(NotImplementedError):
         K.mha_small_fwd(z(lq), z(lk), z(lk), None, 0, b, lq, lk, 1.0 / dk, h, dk)
+
+
+def test_fused_dense_layers_equal_their_unfused_launches(K):
+    """ma_gemm_k256_train_bf16 / ma_gemm_rows_train_bf16 / ma_layernorm_bwd_next_f32 against the launches they replace, same dropout
+    sites: u, h, du and the emitted dy are BIT-identical (same products, same rounding points, same masks); the join's float32 output
+    and LayerNorms agree to float32 / one bf16 ulp (the fused join does not round the residual sum's input twice)."""
+    from mindaudio_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    m, d, hid, p, seed = 1000, 256, 2048, 0.1, 12345
+    st = torch.cuda.current_stream().cuda_stream
+
+    def pack(w, kind):
+        n, k = w.shape
+        pieces = int(lib.ma_pack_item_pieces(kind, n, k))
+        out = torch.empty(pieces * 16, dtype=torch.uint8, device="cuda")
+        items = (_lib.PackItem * 1)(_lib.PackItem(w.data_ptr(), out.data_ptr(), w.stride(0), n, k, kind, 0))
+        d_items = torch.from_numpy(np.frombuffer(bytes(items), dtype=np.uint8).copy()).cuda()
+        d_map = torch.zeros((pieces + 255) // 256, dtype=torch.int32, device="cuda")
+        _lib.check(lib.ma_pack_batch_bf16(d_items.data_ptr(), d_map.data_ptr(), d_map.numel(), st), "pack")
+        return out
+
+    a = bf(torch.randn(m, d, generator=g)).cuda()
+    w1 = bf(torch.randn(hid, d, generator=g) / 16).cuda()
+    w2 = bf(torch.randn(d, hid, generator=g) / 45).cuda()
+    b1, b2 = torch.randn(hid, generator=g).cuda(), torch.randn(d, generator=g).cuda()
+    x = torch.randn(m, d, generator=g).cuda()
+    rs = (torch.rand(m, generator=g) > 0.2).float().cuda()
+    g1, be1 = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    g2, be2 = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    # ---- w_1 forward: u, h
+    u_ref = ops.gemm(a, w1, bias=b1)
+    h_ref = K.act_dropout_fwd(u_ref, p, seed, 3)
+    u, h = K.dense_act_drop(a, pack(w1, 0), hid, b1, p, seed, 3)
+    assert torch.equal(u, u_ref) and torch.equal(h, h_ref)
+    # ---- w_2 forward + dropout + residual (+ LayerNorm chain)
+    y_ref = ops.gemm(h, w2, bias=b2, row_scale=rs)
+    x_ref = K.dropout_add(x, y_ref, 0.5, p, seed, 4)
+    ln_ref = ops.layernorm(x_ref, g1, be1, row_scale=rs)
+    for kind_w, kk, src in ((pack(w2, 1), hid, h),):
+        xo, lo, _ = K.dense_join(src, kind_w, kk, b2, x, 0.5, p, seed, 4, row_scale=rs, ln1=(g1, be1), ln_row_scale=rs)
+        assert torch.equal(xo, x_ref)
+        assert float((lo.float() - ln_ref.float()).abs().max()) <= 2 ** -6  # one bf16 ulp at |v| < 4
+        assert rel(lo, ln_ref.float().cpu()) < 2e-3
+        xo2, lo2, mid2 = K.dense_join(src, kind_w, kk, b2, x, 0.5, p, seed, 4, row_scale=rs, ln1=(g1, be1), ln2=(g2, be2))
+        mid_ref = ops.layernorm(x_ref, g1, be1, out_dtype=torch.float32)
+        ln2_ref = ops.layernorm(mid_ref, g2, be2)
+        assert torch.equal(xo2, x_ref) and rel(mid2, mid_ref.cpu()) < 1e-5 and rel(lo2, ln2_ref.float().cpu()) < 2e-3
+    # the K = 256 join (linear_out / pointwise_conv2)
+    wo = bf(torch.randn(d, d, generator=g) / 16).cuda()
+    yo_ref = ops.gemm(a, wo, bias=b2)
+    xo_ref = K.dropout_add(x, yo_ref, 1.0, p, seed, 5)
+    xo, lo, _ = K.dense_join(a, pack(wo, 0), d, b2, x, 1.0, p, seed, 5, ln1=(g1, be1))
+    assert torch.equal(xo, xo_ref) and rel(lo, ops.layernorm(xo_ref, g1, be1).float().cpu()) < 2e-3
+    # ---- w_1 backward: dh -> du on the packed transposed w_2
+    dy = bf(torch.randn(m, d, generator=g)).cuda()
+    w2t = w2.t().contiguous()                     # (hid, d): rows = hidden units
+    dh_ref = ops.gemm(dy, w2t)
+    du_ref = K.act_dropout_bwd(u_ref, dh_ref, p, seed, 3)
+    du = K.dense_act_drop_bwd(dy, pack(w2t, 0), hid, u_ref, p, seed, 3)
+    assert torch.equal(du, du_ref)
+    # ---- plain products on packed weights: K = 2048 / 768 / 512 -> 256 and 256 -> 768
+    for kk in (hid, 768, 512):
+        src = bf(torch.randn(m, kk, generator=g)).cuda()
+        w = bf(torch.randn(d, kk, generator=g) / 30).cuda()
+        assert torch.equal(K.dense_plain(src, pack(w, 1), d, kk), ops.gemm(src, w))
+    wq = bf(torch.randn(768, d, generator=g) / 16).cuda()
+    bq = torch.randn(768, generator=g).cuda()
+    assert torch.equal(K.dense_plain(a, pack(wq, 0), 768, d, bias=bq), ops.gemm(a, wq, bias=bq))
+    # ---- LayerNorm backward that also emits the next branch's dropout backward
+    dyl = bf(torch.randn(m, d, generator=g)).cuda()
+    ga = (1 + 0.1 * torch.randn(d, generator=g)).cuda()
+    gacc = torch.randn(m, d, generator=g).cuda()
+    g_ref, dg_ref, db_ref = gacc.clone(), torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    K.layernorm_bwd(x, ga, dyl, g_ref, dg_ref, db_ref, row_scale=rs)
+    dn_ref = K.dropout_bwd(g_ref, 0.5, p, seed, 6, row_scale=rs)
+    g_new, dg, db = gacc.clone(), torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    _, dn = K.layernorm_bwd_next(x, ga, dyl, g_new, dg, db, (0.5, p, seed, 6, rs), row_scale=rs)
+    assert torch.equal(g_new, g_ref) and torch.equal(dn, dn_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)

@@ -358,3 +358,54 @@ def test_lr_step_rule_mindspore23_advances_twice_per_applied_step():
     cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
     lrs = [eng.step(*cols)[4] for _ in range(3)]
     assert lrs == [asr_warmup_lr(s, 1e-3, 50) for s in (0, 2, 4)] and eng.global_step == 6 and eng.applied_steps == 3
+
+
+def test_fused_blocks_equal_the_one_launch_per_cell_path_with_dropout():
+    """The fused block launches (packed dense layers with Swish / dropout / residual / LayerNorm / Swish' / the next branch's dropout
+    backward in their epilogues) against the one-launch-per-cell path of the same engine, dropout ON: the counter-based masks are a
+    function of (seed, site, element index), so both paths drop the same elements; what differs is float32 summation order inside the
+    LayerNorms and the float32 (instead of bf16-rounded) join input.  Loss and every gradient agree to bf16 round-off."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    xs, ys, sub, ys_lens = batch()
+    res = []
+    for fused in (False, True):
+        _, _, model = build(seed=6)
+        eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, fused=fused)
+        assert eng.fused == fused
+        loss = eng.forward_backward(xs.cuda(), ys.cuda(), sub.cuda(), ys_lens.cuda(), grad_scale=8.0)
+        res.append((float(loss), eng.fp.grad.clone(), eng))
+    (l0, g0, e0), (l1, g1, e1) = res
+    assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)
+    assert float((g1 - g0).norm() / g0.norm()) <= 2e-2
+    worst = {}
+    for name, (off, shape, n) in e0.fp.index.items():
+        a, b_ = g0[off:off + n], g1[off:off + n]
+        if float(a.norm()) > 1e-6 * float(g0.norm()):
+            worst[name] = float((a - b_).norm() / a.norm())
+    bad = {k: round(v, 4) for k, v in worst.items() if v > 6e-2 and not (k.endswith("dw_b") or k.endswith("qkv_b"))}
+    assert not bad, bad
+    # and the fused path is run-to-run bit-reproducible
+    _, _, model = build(seed=6)
+    eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, fused=True)
+    loss = eng.forward_backward(xs.cuda(), ys.cuda(), sub.cuda(), ys_lens.cuda(), grad_scale=8.0)
+    assert float(loss) == l1 and torch.equal(eng.fp.grad, g1)
+
+
+def test_fused_engine_gradients_match_oracle_autograd():
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    ref_enc, ref_ctc, model = build()
+    xs, ys, sub, ys_lens = batch()
+    loss_ref = oracle_loss(ref_enc, ref_ctc, xs, ys, sub, ys_lens)
+    loss_ref.backward()
+    eng = ConformerCTCTrainStep(model, dropout_rate=0.0, positional_dropout_rate=0.0, fused=True)
+    loss = eng.forward_backward(xs.cuda(), ys.cuda(), sub.cuda(), ys_lens.cuda(), grad_scale=1.0)
+    assert abs(float(loss) - float(loss_ref.detach())) <= 2e-2 * abs(float(loss_ref.detach()))
+    grads = eng.gradients()
+    want = {"encoder." + n: p.grad for n, p in ref_enc.named_parameters()}
+    want.update({"ctc." + n: p.grad for n, p in ref_ctc.named_parameters()})
+    worst = {n: rel_rms(grads[n], gw) for n, gw in want.items() if "depthwise_conv.bias" not in n and "linear_k.bias" not in n}
+    bad = {k: round(v, 4) for k, v in worst.items() if v > 6e-2}
+    assert not bad, bad
+    assert sum(worst.values()) / len(worst) < 2.5e-2

@@ -16,7 +16,7 @@ import math
 
 import torch
 
-from .. import _lib, ops
+from .. import _host, _lib, ops
 from . import kernels as K
 from . import kernels_x32 as X32
 
@@ -571,6 +571,12 @@ class ConformerCTCTrainStep:
                          ys_out_pad=None, ys_sub_masks=None, ys_masks=None):
         """Runs the training-mode forward and the backward pass; flat gradients hold grad_scale * dLoss/dparam.
         Returns the (unscaled) loss tensor."""
+        with _host.pinned_stream():
+            return self._forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale, ys_in_pad, ys_out_pad,
+                                          ys_sub_masks, ys_masks)
+
+    def _forward_backward(self, xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale, ys_in_pad, ys_out_pad, ys_sub_masks,
+                          ys_masks):
         fp, d, L = self.fp, self.d, self.L
         ops, K = self.O, self.K  # bf16 throughput kernels or their float32 validation twins
         f32, bf = torch.float32, torch.bfloat16

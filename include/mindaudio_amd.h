@@ -432,7 +432,9 @@ int ma_gemm_tn_bf16_f32(const void* A, int64_t lda, const void* B, int64_t ldb, 
  * column sums of A [splits][Mo_store] behind them (float offset splits * Mo_store * No).
  * ma_reduce_splits_batch_f32: items / block_item are DEVICE arrays; item i adds its `splits` partial matrices of `mn` elements
  * (`pstride` floats apart; 0 = mn) in order and stores out[m][n] = (accumulate ? out : 0) + alpha * sum with row length N and row
- * stride ldo; workgroup b handles elements [1024 (b - first_block), + 1024) of item block_item[b].  Every parameter-gradient
+ * stride ldo; workgroup b handles elements [1024 (b - first_block), + 1024) of item block_item[b] - or, for a "tall" item
+ * (accumulate bit 1 set: hundreds of partials of a few hundred elements), elements [16 (b - first_block), + 16), the partials spread
+ * over 64 thread groups.  Every parameter-gradient
  * reduction of the training step (weight-gradient splits, bias / LayerNorm / BatchNorm / depthwise / positional-bias partials)
  * goes through this one kernel, one launch per Conformer block: fixed summation order, no float atomics. */
 typedef struct ma_reduce_item {
@@ -634,7 +636,8 @@ int ma_relpos_attention_bwd_qmask_bf16(const void* qkv, int64_t ld_qkv, const vo
  * Token-sized pieces; the decoder's matmuls, LayerNorms (eps 1e-12) and dropouts reuse the entry points above. */
 
 /* nn.Embedding -> x * xscale + pe[l] -> dropout (layers/embedding.py:16-62): out (rows, D) float32, rows = batch * L,
- * token ids clamped into [0, V).  Backward: dtable (V, D) float32 += scatter of xscale * keep/(1-p) * g. */
+ * token ids clamped into [0, V).  Backward: dtable (V, D) float32 += scatter of xscale * keep/(1-p) * g, every table row summed by
+ * one workgroup in row order (no float atomics). */
 int ma_embed_posenc_f32(const int32_t* tokens, const float* table, const float* pe, int64_t rows, int32_t L, int32_t D,
                         int32_t V, float xscale, float p, uint32_t seed, uint32_t salt, float* out, ma_stream_t stream);
 int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_t D, int32_t V, float xscale, float p,
@@ -653,19 +656,29 @@ int ma_mha_small_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk
                           int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k, float scale, void* dq, int64_t lddq, void* dk,
                           int64_t lddk, void* dv, int64_t lddv, ma_stream_t stream);
 
+/* The same on float32 activations (the float32 validation mode of the hybrid loss; always the un-staged form). */
+int ma_mha_small_fwd_x32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* mask,
+                         int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k, float scale, float* ctx,
+                         int64_t ldc, float* probs, ma_stream_t stream);
+int ma_mha_small_bwd_x32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* probs,
+                         const float* ctx, int64_t ldc, const float* dctx, int64_t lddc, int64_t batch, int32_t Lq, int32_t Lk,
+                         int32_t heads, int32_t d_k, float scale, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                         int64_t lddv, ma_stream_t stream);
+
 /* LabelSmoothingLoss (loss/label_smoothing_loss.py:24-117) on logits (rows, ld >= V) float32: stats[0] += sum over
  * unmasked rows of KL(true_dist || softmax), stats[1] += correct argmax count, stats[2] += unmasked rows (caller zeroes;
- * the loss is stats[0] / batch, the accuracy stats[1] / stats[2], asr_model.py:188-209);
- * dlogits (rows, ld_out) bf16 = grad_scale * mask * (softmax - true_dist), zero in columns >= V. */
-int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
-                                     const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
-                                     float* stats, ma_stream_t stream);
-/* The same with `normalize_length=True` (label_smoothing_loss.py:106: the divisor is the number of unmasked tokens instead of
- * the batch size): `denom` is a DEVICE float holding that count (the caller's sum of the mask - no host round trip);
- * dlogits = grad_scale / *denom * mask * (softmax - true_dist), the loss is stats[0] / stats[2].  denom NULL = the form above. */
+ * the loss is stats[0] / batch, the accuracy stats[1] / stats[2], asr_model.py:188-209); the per-row terms go through
+ * `row_stats` (rows x 3 floats of scratch) and are added in row order - no float atomics.
+ * dlogits (rows, ld_out) bf16 (_f32) or float32 (_x32: the float32 validation mode) = grad_scale * mask * (softmax - true_dist),
+ * zero in columns >= V.  `denom` (optional DEVICE float): `normalize_length=True` (label_smoothing_loss.py:106: the divisor is
+ * the number of unmasked tokens instead of the batch size) - dlogits is divided by *denom (the caller's sum of the mask, no host
+ * round trip) and the loss is stats[0] / stats[2]. */
 int ma_label_smoothing_loss_grad_len_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
                                          const float* mask, float smoothing, float grad_scale, const float* denom, void* dlogits,
-                                         int64_t ld_out, float* stats, ma_stream_t stream);
+                                         int64_t ld_out, float* stats, float* row_stats, ma_stream_t stream);
+int ma_label_smoothing_loss_grad_len_x32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
+                                         const float* mask, float smoothing, float grad_scale, const float* denom, float* dlogits,
+                                         int64_t ld_out, float* stats, float* row_stats, ma_stream_t stream);
 
 /* ma_conv2d_3x3s2_nhwc_bf16 for the subsampling layer's second convolution (C = Cout = 256; layers/subsampling.py:40-45) on a
  * fragment-ordered packed copy of W (conv2_packed.hip): out (batch, Ho, Wo, 256) bf16 = [relu](bias + conv).

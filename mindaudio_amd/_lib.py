@@ -212,8 +212,11 @@ PROTOTYPES = {
                                              vp]),
     "ma_mha_small_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32,
                                              vp, i64, vp, i64, vp, i64, vp]),
-    "ma_label_smoothing_loss_grad_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, i64, vp, vp]),
-    "ma_label_smoothing_loss_grad_len_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, vp, i64, vp, vp]),
+    "ma_label_smoothing_loss_grad_len_f32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, vp, i64, vp, vp, vp]),
+    "ma_label_smoothing_loss_grad_len_x32": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, f32, f32, vp, vp, i64, vp, vp, vp]),
+    "ma_mha_small_fwd_x32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i64, i32, i32, i32, i32, f32, vp, i64, vp, vp]),
+    "ma_mha_small_bwd_x32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32,
+                                            vp, i64, vp, i64, vp, i64, vp]),
     "ma_resample_fft_length": (i64, [i64, i64]),
     "ma_resample_fft_workspace_bytes": (i64, [i64, i64, i64]),
     "ma_resample_fft_f32": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, vp, i64, vp, i64, vp]),

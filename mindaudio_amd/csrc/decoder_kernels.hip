@@ -42,6 +42,36 @@ static uint32_t d_thresh(float p) {
   return th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th;
 }
 
+// activation element type of the small-attention / label-smoothing kernels: uint16_t = bf16 bit patterns (throughput mode) or float
+// (the float32 validation mode, entry points with the _x32 suffix)
+__device__ __forceinline__ float d_ld(const uint16_t* p) { return d_bf2f(*p); }
+__device__ __forceinline__ float d_ld(const float* p) { return *p; }
+__device__ __forceinline__ void d_st(uint16_t* p, float v) { *p = d_f2bf(v); }
+__device__ __forceinline__ void d_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void d_ld8(const uint16_t* p, float (&d)[8]) {  // 16-byte aligned
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    d[2 * e] = __uint_as_float(w[e] << 16);
+    d[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void d_ld8(const float* p, float (&d)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+}
+__device__ __forceinline__ void d_st8(uint16_t* p, const float (&d)[8]) {
+  uint32_t o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (uint32_t)d_f2bf(d[2 * e]) | ((uint32_t)d_f2bf(d[2 * e + 1]) << 16);
+  *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void d_st8(float* p, const float (&d)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(d[4], d[5], d[6], d[7]);
+}
+
 // ---- embedding + positional encoding ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ table,
                                                         const float* __restrict__ pe, int L, int D, int V, float xscale,
@@ -58,25 +88,30 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restric
     out[i] = v;
   }
 }
+// dtable[t] += sum over the rows r with tok[r] == t, in row order (run-to-run deterministic: no float atomics).  Workgroup w owns
+// the token ids t with t % gridDim.x == w, so every table row has ONE writer; thread = feature d (D <= 1024, blockDim = 256).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ g, int D, int V,
                                                         float xscale, uint32_t seed, uint32_t salt, uint32_t thresh,
-                                                        float inv_keep, float* dtable, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int d = (int)(i % D);
-    const int64_t r = i / D;
+                                                        float inv_keep, float* dtable, int64_t rows) {
+  for (int64_t r = 0; r < rows; ++r) {
     int t = tok[r];
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-    float v = g[i] * xscale;
-    if (thresh) v = d_keep(seed, salt, (uint64_t)i, thresh) ? v * inv_keep : 0.0f;
-    atomicAdd(dtable + (int64_t)t * D + d, v);
+    if ((unsigned)t % gridDim.x != blockIdx.x) continue;  // (wave-uniform)
+    for (int d = threadIdx.x; d < D; d += 256) {
+      const int64_t i = r * D + d;
+      float v = g[i] * xscale;
+      if (thresh) v = d_keep(seed, salt, (uint64_t)i, thresh) ? v * inv_keep : 0.0f;
+      dtable[(int64_t)t * D + d] += v;
+    }
   }
 }
 
 // ---- small multi-head attention ----------------------------------------------------------------------------------
 constexpr int kSmQ = 32, kSmK = 320, kSmD = 64;
 constexpr int kSmKMax = 1088;  // keys when the score rows own the LDS (backward: 32 x 1089 floats + q / dO rows = 153 KiB)
+template <typename AT>
 struct SmallAttn {
-  const uint16_t *q, *k, *v;
+  const AT *q, *k, *v;
   int64_t ldq, ldk, ldv;
   const float* mask;
   int mask_mode;  // 0 none, 1 (B, 1, Lk), 2 (B, Lq, Lk)
@@ -88,9 +123,10 @@ struct SmallAttn {
 // STAGE: the V rows of the (batch, head) are staged in LDS (Lk <= kSmK, the label-length self-attention and source attention over
 // up to 320 encoder frames); otherwise (source attention over a long utterance: the 3000-frame bucket of conformer.yaml gives
 // T' = 749) the score rows take the whole LDS (`kcap` = Lk rounded up to 64 columns) and the V rows are read from L2.
-template <bool STAGE>
-__global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, uint16_t* __restrict__ ctx, int64_t ldc,
+template <bool STAGE, typename AT>
+__global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn<AT> p, AT* __restrict__ ctx, int64_t ldc,
                                                             float* __restrict__ probs, int kcap) {
+  static_assert(!STAGE || sizeof(AT) == 2, "the staged form holds bf16 rows in LDS");
   extern __shared__ __attribute__((aligned(16))) char sm_lds[];
   const int ss = kcap + 1;                                                                             // score row stride
   uint16_t (*Vs)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);                                  // 32 KiB (STAGE)
@@ -102,9 +138,9 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, u
   const int Lq = p.Lq, Lk = p.Lk;
   for (int i = tid; i < kSmQ * kSmD; i += 256) {
     const int qi = i / kSmD, d = i % kSmD;
-    Qs[qi][d] = qi < Lq ? d_bf2f(p.q[((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d]) : 0.0f;
+    Qs[qi][d] = qi < Lq ? d_ld(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d) : 0.0f;
   }
-  if (STAGE)
+  if constexpr (STAGE)
     for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
       const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
       uint4 val = make_uint4(0, 0, 0, 0);
@@ -114,16 +150,13 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, u
   __syncthreads();
   for (int j = tid; j < Lk; j += 256) {
     float kr[kSmD];
-    const uint16_t* kp = p.k + ((int64_t)b * Lk + j) * p.ldk + h * kSmD;
+    const AT* kp = p.k + ((int64_t)b * Lk + j) * p.ldk + h * kSmD;
 #pragma unroll
     for (int c8 = 0; c8 < kSmD / 8; ++c8) {
-      const uint4 kv = *reinterpret_cast<const uint4*>(kp + c8 * 8);
-      const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
+      float t8[8];
+      d_ld8(kp + c8 * 8, t8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        kr[c8 * 8 + 2 * e] = __uint_as_float(w[e] << 16);
-        kr[c8 * 8 + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
-      }
+      for (int e = 0; e < 8; ++e) kr[c8 * 8 + e] = t8[e];
     }
     for (int i = 0; i < Lq; ++i) {
       float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
@@ -172,30 +205,25 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn p, u
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int jj = 0; jj < Lk; ++jj) {
       const float pv = S[qi * ss + jj];
-      const uint4 vv = STAGE ? *reinterpret_cast<const uint4*>(&Vs[jj][dg])
-                             : *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + jj) * p.ldv + h * kSmD + dg);
-      const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+      float t8[8];
+      if constexpr (STAGE) d_ld8(&Vs[jj][dg], t8);
+      else d_ld8(p.v + ((int64_t)b * Lk + jj) * p.ldv + h * kSmD + dg, t8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[2 * e] = fmaf(pv, __uint_as_float(w[e] << 16), acc[2 * e]);
-        acc[2 * e + 1] = fmaf(pv, __uint_as_float(w[e] & 0xffff0000u), acc[2 * e + 1]);
-      }
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pv, t8[e], acc[e]);
     }
-    uint32_t o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)d_f2bf(acc[2 * e]) | ((uint32_t)d_f2bf(acc[2 * e + 1]) << 16);
-    *reinterpret_cast<uint4*>(ctx + ((int64_t)b * Lq + qi) * ldc + h * kSmD + dg) = make_uint4(o[0], o[1], o[2], o[3]);
+    d_st8(ctx + ((int64_t)b * Lq + qi) * ldc + h * kSmD + dg, acc);
   }
 }
 
 // Backward: D_i = dO_i . O_i; thread j: dP_ij = dO_i . v_j, dS_ij = P_ij (dP_ij - D_i), dv_j = sum_i P_ij dO_i,
 // dk_j = scale sum_i dS_ij q_i; then thread (i, 8 d's): dq_i = scale sum_j dS_ij k_j.
-template <bool STAGE>
-__global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, const float* __restrict__ probs,
-                                                            const uint16_t* __restrict__ ctx, int64_t ldc,
-                                                            const uint16_t* __restrict__ dctx, int64_t lddc,
-                                                            uint16_t* __restrict__ dq, int64_t lddq, uint16_t* __restrict__ dk,
-                                                            int64_t lddk, uint16_t* __restrict__ dv, int64_t lddv, int kcap) {
+template <bool STAGE, typename AT>
+__global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> p, const float* __restrict__ probs,
+                                                            const AT* __restrict__ ctx, int64_t ldc,
+                                                            const AT* __restrict__ dctx, int64_t lddc,
+                                                            AT* __restrict__ dq, int64_t lddq, AT* __restrict__ dk,
+                                                            int64_t lddk, AT* __restrict__ dv, int64_t lddv, int kcap) {
+  static_assert(!STAGE || sizeof(AT) == 2, "the staged form holds bf16 rows in LDS");
   extern __shared__ __attribute__((aligned(16))) char sm_lds[];
   const int ss = kcap + 1;
   uint16_t (*Ks)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);                                  // STAGE only
@@ -209,10 +237,10 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
   for (int i = tid; i < kSmQ * kSmD; i += 256) {
     const int qi = i / kSmD, d = i % kSmD;
     const bool in = qi < Lq;
-    Qs[qi][d] = in ? d_bf2f(p.q[((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d]) : 0.0f;
-    dOs[qi][d] = in ? d_bf2f(dctx[((int64_t)b * Lq + qi) * lddc + h * kSmD + d]) : 0.0f;
+    Qs[qi][d] = in ? d_ld(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d) : 0.0f;
+    dOs[qi][d] = in ? d_ld(dctx + ((int64_t)b * Lq + qi) * lddc + h * kSmD + d) : 0.0f;
   }
-  if (STAGE)
+  if constexpr (STAGE)
     for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
       const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
       uint4 val = make_uint4(0, 0, 0, 0);
@@ -226,23 +254,20 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
   __syncthreads();
   if (tid < Lq) {
     float s = 0.0f;
-    const uint16_t* op = ctx + ((int64_t)b * Lq + tid) * ldc + h * kSmD;
-    for (int d = 0; d < kSmD; ++d) s = fmaf(dOs[tid][d], d_bf2f(op[d]), s);
+    const AT* op = ctx + ((int64_t)b * Lq + tid) * ldc + h * kSmD;
+    for (int d = 0; d < kSmD; ++d) s = fmaf(dOs[tid][d], d_ld(op + d), s);
     Dq[tid] = s;
   }
   __syncthreads();
   for (int j = tid; j < Lk; j += 256) {
     float vr[kSmD], dvr[kSmD], dkr[kSmD];
-    const uint16_t* vp = p.v + ((int64_t)b * Lk + j) * p.ldv + h * kSmD;
+    const AT* vp = p.v + ((int64_t)b * Lk + j) * p.ldv + h * kSmD;
 #pragma unroll
     for (int c8 = 0; c8 < kSmD / 8; ++c8) {
-      const uint4 vv = *reinterpret_cast<const uint4*>(vp + c8 * 8);
-      const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+      float t8[8];
+      d_ld8(vp + c8 * 8, t8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        vr[c8 * 8 + 2 * e] = __uint_as_float(w[e] << 16);
-        vr[c8 * 8 + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
-      }
+      for (int e = 0; e < 8; ++e) vr[c8 * 8 + e] = t8[e];
     }
 #pragma unroll
     for (int d = 0; d < kSmD; ++d) {
@@ -273,12 +298,12 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
         dkr[d + 2] = fmaf(ds, q4.z, dkr[d + 2]); dkr[d + 3] = fmaf(ds, q4.w, dkr[d + 3]);
       }
     }
-    uint16_t* dvp = dv + ((int64_t)b * Lk + j) * lddv + h * kSmD;
-    uint16_t* dkp = dk + ((int64_t)b * Lk + j) * lddk + h * kSmD;
+    AT* dvp = dv + ((int64_t)b * Lk + j) * lddv + h * kSmD;
+    AT* dkp = dk + ((int64_t)b * Lk + j) * lddk + h * kSmD;
 #pragma unroll
-    for (int d = 0; d < kSmD; d += 2) {
-      *reinterpret_cast<uint32_t*>(dvp + d) = (uint32_t)d_f2bf(dvr[d]) | ((uint32_t)d_f2bf(dvr[d + 1]) << 16);
-      *reinterpret_cast<uint32_t*>(dkp + d) = (uint32_t)d_f2bf(dkr[d]) | ((uint32_t)d_f2bf(dkr[d + 1]) << 16);
+    for (int d = 0; d < kSmD; ++d) {
+      d_st(dvp + d, dvr[d]);
+      d_st(dkp + d, dkr[d]);
     }
   }
   __syncthreads();
@@ -287,39 +312,35 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn p, c
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int jj = 0; jj < Lk; ++jj) {
       const float ds = S[qi * ss + jj];
-      const uint4 kv = STAGE ? *reinterpret_cast<const uint4*>(&Ks[jj][dg])
-                             : *reinterpret_cast<const uint4*>(p.k + ((int64_t)b * Lk + jj) * p.ldk + h * kSmD + dg);
-      const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
+      float t8[8];
+      if constexpr (STAGE) d_ld8(&Ks[jj][dg], t8);
+      else d_ld8(p.k + ((int64_t)b * Lk + jj) * p.ldk + h * kSmD + dg, t8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[2 * e] = fmaf(ds, __uint_as_float(w[e] << 16), acc[2 * e]);
-        acc[2 * e + 1] = fmaf(ds, __uint_as_float(w[e] & 0xffff0000u), acc[2 * e + 1]);
-      }
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(ds, t8[e], acc[e]);
     }
-    uint32_t o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (uint32_t)d_f2bf(acc[2 * e]) | ((uint32_t)d_f2bf(acc[2 * e + 1]) << 16);
-    *reinterpret_cast<uint4*>(dq + ((int64_t)b * Lq + qi) * lddq + h * kSmD + dg) = make_uint4(o[0], o[1], o[2], o[3]);
+    d_st8(dq + ((int64_t)b * Lq + qi) * lddq + h * kSmD + dg, acc);
   }
 }
 
 // ---- label smoothing loss --------------------------------------------------------------------------------------
 // one workgroup per token row: kl = sum_v q_v (log q_v - logp_v), q = on at the target, off elsewhere; masked rows
 // contribute nothing.  stats[0] += kl, stats[1] += (argmax == target) * mask, stats[2] += mask.
+template <typename OT>
 __global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __restrict__ logits, int64_t ld, int V,
                                                               const int32_t* __restrict__ target, const float* __restrict__ mask,
                                                               float on, float off, float ent, float scale,
                                                               const float* __restrict__ denom,
-                                                              uint16_t* __restrict__ dlogits, int64_t ldo, float* stats) {
+                                                              OT* __restrict__ dlogits, int64_t ldo, float* __restrict__ row_stats) {
   __shared__ float red[4];
   __shared__ int redi[4];
   const int64_t row = blockIdx.x;
   const float* p = logits + row * ld;
-  uint16_t* o = dlogits + row * ldo;
+  OT* o = dlogits + row * ldo;
   const float mk = mask[row];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (mk == 0.0f) {
     for (int v = threadIdx.x; v < ldo; v += 256) o[v] = 0;
+    if (threadIdx.x < 3) row_stats[row * 3 + threadIdx.x] = 0.0f;
     return;
   }
   if (denom) scale /= *denom;  // normalize_length (label_smoothing_loss.py:106)
@@ -362,15 +383,25 @@ __global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __res
     const float sum_logp = sl - (float)V * lse;
     // sum_v q_v log q_v = ent (host); - sum_v q_v logp_v
     const float kl = ent - (on * logp_t + off * (sum_logp - logp_t));
-    atomicAdd(stats, kl);
-    atomicAdd(stats + 1, am == tg ? 1.0f : 0.0f);
-    atomicAdd(stats + 2, 1.0f);
+    row_stats[row * 3] = kl;  // per-row terms; label_smoothing_reduce_kernel adds them in row order (deterministic)
+    row_stats[row * 3 + 1] = am == tg ? 1.0f : 0.0f;
+    row_stats[row * 3 + 2] = 1.0f;
   }
   for (int v = threadIdx.x; v < ldo; v += 256) {
     float gval = 0.0f;
     if (v < V) gval = scale * (__expf(p[v] - lse) - (v == tg ? on : off));
-    o[v] = d_f2bf(gval);
+    d_st(o + v, gval);
   }
+}
+
+// stats[k] += sum over the rows of row_stats[row][k], k = 0..2, in a fixed order (one wave per statistic)
+__global__ __launch_bounds__(192) void label_smoothing_reduce_kernel(const float* __restrict__ row_stats, int64_t rows, float* stats) {
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float s = 0.0f;
+  for (int64_t r = lane; r < rows; r += 64) s += row_stats[r * 3 + k];
+#pragma unroll
+  for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_xor(s, off2, 64);
+  if (lane == 0) stats[k] += s;
 }
 
 static int d_grid(int64_t n, int cap = 4096) {
@@ -396,105 +427,154 @@ int ma_embed_posenc_f32(const int32_t* tokens, const float* table, const float* 
 int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_t D, int32_t V, float xscale, float p,
                      uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream) {
   if (!tokens || !g || !dtable || rows < 1 || D < 1 || V < 1 || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
-  const int64_t n = rows * D;
-  MA_LAUNCH(embed_bwd_kernel, dim3(d_grid(n)), dim3(256), 0, (hipStream_t)stream, tokens, g, D, V, xscale, seed, salt,
-            d_thresh(p), 1.0f / (1.0f - p), dtable, n);
+  MA_LAUNCH(embed_bwd_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, tokens, g, D, V, xscale, seed, salt, d_thresh(p),
+            1.0f / (1.0f - p), dtable, rows);
   return MA_OK;
 }
 
-static int fill_small(SmallAttn& a, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+extern "C++" {
+template <typename AT>
+static int fill_small(SmallAttn<AT>& a, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                       const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k,
                       float scale) {
   if (!q || !k || !v || batch < 1 || Lq < 1 || Lk < 1 || heads < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
   if (d_k != kSmD || Lq > kSmQ || Lk > kSmKMax || (ldk & 7) || (ldv & 7)) return MA_ERR_UNSUPPORTED;
   if (mask_mode < 0 || mask_mode > 2 || (mask_mode && !mask)) return MA_ERR_INVALID_ARG;
-  a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v;
+  a.q = (const AT*)q; a.k = (const AT*)k; a.v = (const AT*)v;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.mask = mask; a.mask_mode = mask_mode;
   a.Lq = Lq; a.Lk = Lk; a.H = heads; a.scale = scale;
   return MA_OK;
 }
 
-int ma_mha_small_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                          const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads,
-                          int32_t d_k, float scale, void* ctx, int64_t ldc, float* probs, ma_stream_t stream) {
-  SmallAttn a;
+template <typename AT>
+static int mha_small_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const float* mask,
+                         int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k, float scale, void* ctx,
+                         int64_t ldc, float* probs, ma_stream_t stream) {
+  SmallAttn<AT> a;
   const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, mask, mask_mode, batch, Lq, Lk, heads, d_k, scale);
   if (rc != MA_OK) return rc;
   if (!ctx || !probs || (ldc & 7)) return MA_ERR_INVALID_ARG;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            163840) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel<false, AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             163840) != hipSuccess)
       return MA_ERR_LAUNCH;
+    if constexpr (sizeof(AT) == 2)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel<true, AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              163840) != hipSuccess)
+        return MA_ERR_LAUNCH;
     attr = true;
   }
-  if (Lk <= kSmK) {
-    constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * (kSmD + 4) * 4;
-    MA_LAUNCH(mha_small_fwd_kernel<true>, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
-              (uint16_t*)ctx, ldc, probs, kSmK);
-  } else {
-    const int kcap = (Lk + 63) / 64 * 64;
-    const int lds = kSmQ * (kcap + 1) * 4 + kSmQ * (kSmD + 4) * 4;
-    MA_LAUNCH(mha_small_fwd_kernel<false>, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
-              (uint16_t*)ctx, ldc, probs, kcap);
+  if constexpr (sizeof(AT) == 2) {
+    if (Lk <= kSmK) {
+      constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * (kSmD + 4) * 4;
+      MA_LAUNCH((mha_small_fwd_kernel<true, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
+                (AT*)ctx, ldc, probs, kSmK);
+      return MA_OK;
+    }
   }
+  const int kcap = (Lk + 63) / 64 * 64;
+  const int lds = kSmQ * (kcap + 1) * 4 + kSmQ * (kSmD + 4) * 4;
+  MA_LAUNCH((mha_small_fwd_kernel<false, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, (AT*)ctx,
+            ldc, probs, kcap);
   return MA_OK;
 }
 
-int ma_mha_small_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                          const float* probs, const void* ctx, int64_t ldc, const void* dctx, int64_t lddc, int64_t batch,
-                          int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k, float scale, void* dq, int64_t lddq, void* dk,
-                          int64_t lddk, void* dv, int64_t lddv, ma_stream_t stream) {
-  SmallAttn a;
+template <typename AT>
+static int mha_small_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const float* probs,
+                         const void* ctx, int64_t ldc, const void* dctx, int64_t lddc, int64_t batch, int32_t Lq, int32_t Lk,
+                         int32_t heads, int32_t d_k, float scale, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                         int64_t lddv, ma_stream_t stream) {
+  SmallAttn<AT> a;
   const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, nullptr, 0, batch, Lq, Lk, heads, d_k, scale);
   if (rc != MA_OK) return rc;
   if (!probs || !ctx || !dctx || !dq || !dk || !dv || (lddq & 7) || (lddk & 1) || (lddv & 1)) return MA_ERR_INVALID_ARG;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            163840) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel<false, AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             163840) != hipSuccess)
       return MA_ERR_LAUNCH;
+    if constexpr (sizeof(AT) == 2)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel<true, AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              163840) != hipSuccess)
+        return MA_ERR_LAUNCH;
     attr = true;
   }
-  if (Lk <= kSmK) {
-    constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
-    MA_LAUNCH(mha_small_bwd_kernel<true>, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
-              (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv,
-              lddv, kSmK);
-  } else {
-    const int kcap = (Lk + 63) / 64 * 64;
-    const int lds = kSmQ * (kcap + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
-    MA_LAUNCH(mha_small_bwd_kernel<false>, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
-              (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv,
-              lddv, kcap);
+  if constexpr (sizeof(AT) == 2) {
+    if (Lk <= kSmK) {
+      constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
+      MA_LAUNCH((mha_small_bwd_kernel<true, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
+                (const AT*)ctx, ldc, (const AT*)dctx, lddc, (AT*)dq, lddq, (AT*)dk, lddk, (AT*)dv, lddv, kSmK);
+      return MA_OK;
+    }
   }
+  const int kcap = (Lk + 63) / 64 * 64;
+  const int lds = kSmQ * (kcap + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
+  MA_LAUNCH((mha_small_bwd_kernel<false, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
+            (const AT*)ctx, ldc, (const AT*)dctx, lddc, (AT*)dq, lddq, (AT*)dk, lddk, (AT*)dv, lddv, kcap);
   return MA_OK;
 }
 
-int ma_label_smoothing_loss_grad_len_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
-                                         const float* mask, float smoothing, float grad_scale, const float* denom, void* dlogits,
-                                         int64_t ld_out, float* stats, ma_stream_t stream) {
-  if (!logits || !target || !mask || !dlogits || !stats || rows < 1 || V < 2 || ld < V || ld_out < V) return MA_ERR_INVALID_ARG;
+}  // extern "C++"
+
+int ma_mha_small_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads,
+                          int32_t d_k, float scale, void* ctx, int64_t ldc, float* probs, ma_stream_t stream) {
+  return mha_small_fwd<uint16_t>(q, ldq, k, ldk, v, ldv, mask, mask_mode, batch, Lq, Lk, heads, d_k, scale, ctx, ldc, probs, stream);
+}
+int ma_mha_small_fwd_x32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* mask,
+                         int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k, float scale, float* ctx,
+                         int64_t ldc, float* probs, ma_stream_t stream) {
+  return mha_small_fwd<float>(q, ldq, k, ldk, v, ldv, mask, mask_mode, batch, Lq, Lk, heads, d_k, scale, ctx, ldc, probs, stream);
+}
+int ma_mha_small_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          const float* probs, const void* ctx, int64_t ldc, const void* dctx, int64_t lddc, int64_t batch,
+                          int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k, float scale, void* dq, int64_t lddq, void* dk,
+                          int64_t lddk, void* dv, int64_t lddv, ma_stream_t stream) {
+  return mha_small_bwd<uint16_t>(q, ldq, k, ldk, v, ldv, probs, ctx, ldc, dctx, lddc, batch, Lq, Lk, heads, d_k, scale, dq, lddq, dk,
+                                 lddk, dv, lddv, stream);
+}
+int ma_mha_small_bwd_x32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* probs,
+                         const float* ctx, int64_t ldc, const float* dctx, int64_t lddc, int64_t batch, int32_t Lq, int32_t Lk,
+                         int32_t heads, int32_t d_k, float scale, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                         int64_t lddv, ma_stream_t stream) {
+  return mha_small_bwd<float>(q, ldq, k, ldk, v, ldv, probs, ctx, ldc, dctx, lddc, batch, Lq, Lk, heads, d_k, scale, dq, lddq, dk, lddk,
+                              dv, lddv, stream);
+}
+
+static int label_smoothing_launch(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target, const float* mask,
+                                  float smoothing, float grad_scale, const float* denom, void* dlogits, int64_t ld_out, int out_f32,
+                                  float* stats, float* row_stats, ma_stream_t stream) {
+  if (!logits || !target || !mask || !dlogits || !stats || !row_stats || rows < 1 || V < 2 || ld < V || ld_out < V)
+    return MA_ERR_INVALID_ARG;
   if (smoothing < 0.0f || smoothing >= 1.0f) return MA_ERR_INVALID_ARG;
   const float on = 1.0f - smoothing, off = smoothing / (float)(V - 1);
   // sum_v q_v log q_v (0 log 0 = 0)
   float ent = on * logf(on);
   if (off > 0.0f) ent += (float)(V - 1) * off * logf(off);
-  MA_LAUNCH(label_smoothing_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, target, mask, on,
-            off, ent, grad_scale, denom, (uint16_t*)dlogits, ld_out, stats);
+  if (out_f32)
+    MA_LAUNCH(label_smoothing_kernel<float>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, target, mask, on,
+              off, ent, grad_scale, denom, (float*)dlogits, ld_out, row_stats);
+  else
+    MA_LAUNCH(label_smoothing_kernel<uint16_t>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, ld, V, target, mask,
+              on, off, ent, grad_scale, denom, (uint16_t*)dlogits, ld_out, row_stats);
+  MA_LAUNCH(label_smoothing_reduce_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, row_stats, rows, stats);
   return MA_OK;
 }
 
-int ma_label_smoothing_loss_grad_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
-                                     const float* mask, float smoothing, float grad_scale, void* dlogits, int64_t ld_out,
-                                     float* stats, ma_stream_t stream) {
-  return ma_label_smoothing_loss_grad_len_f32(logits, ld, rows, V, target, mask, smoothing, grad_scale, nullptr, dlogits, ld_out,
-                                              stats, stream);
+int ma_label_smoothing_loss_grad_len_f32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
+                                         const float* mask, float smoothing, float grad_scale, const float* denom, void* dlogits,
+                                         int64_t ld_out, float* stats, float* row_stats, ma_stream_t stream) {
+  return label_smoothing_launch(logits, ld, rows, V, target, mask, smoothing, grad_scale, denom, dlogits, ld_out, 0, stats, row_stats,
+                                stream);
+}
+
+int ma_label_smoothing_loss_grad_len_x32(const float* logits, int64_t ld, int64_t rows, int32_t V, const int32_t* target,
+                                         const float* mask, float smoothing, float grad_scale, const float* denom, float* dlogits,
+                                         int64_t ld_out, float* stats, float* row_stats, ma_stream_t stream) {
+  return label_smoothing_launch(logits, ld, rows, V, target, mask, smoothing, grad_scale, denom, dlogits, ld_out, 1, stats, row_stats,
+                                stream);
 }
 
 }  // extern "C"

@@ -323,7 +323,19 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_train_kernel(const ui
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
       bv[jt] = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-    // pass 1: u (modes 1, 4: acc + bias) or du (mode 2)
+    // pass 1: u (modes 1, 4: acc + bias) or du (mode 2).  Mode 2 fetches all of its u values before the first use (otherwise
+    // sixteen dependent round trips per lane).
+    uint2 ur[MODE == 2 ? MT : 1][4];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int s = 0; s < MT; ++s) {
+        const int m = m0 + 16 * s + c;
+        const int mc = m < M ? m : M - 1;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) ur[s][jt] = *reinterpret_cast<const uint2*>(e.aux + (int64_t)mc * e.ld_aux + n0 + 16 * jt + 4 * g);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int s = 0; s < MT; ++s) {
       const int m = m0 + 16 * s + c;
@@ -333,9 +345,9 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_train_kernel(const ui
         const int n = n0 + 16 * jt + 4 * g;
         float v[4] = {acc[jt][s][0] + bv[jt].x, acc[jt][s][1] + bv[jt].y, acc[jt][s][2] + bv[jt].z, acc[jt][s][3] + bv[jt].w};
         if constexpr (MODE == 2) {
-          const uint2 ur = *reinterpret_cast<const uint2*>(e.aux + (int64_t)mc * e.ld_aux + n);
-          const float u[4] = {__uint_as_float(ur.x << 16), __uint_as_float(ur.x & 0xffff0000u), __uint_as_float(ur.y << 16),
-                              __uint_as_float(ur.y & 0xffff0000u)};
+          const uint2 uq = ur[s][jt];
+          const float u[4] = {__uint_as_float(uq.x << 16), __uint_as_float(uq.x & 0xffff0000u), __uint_as_float(uq.y << 16),
+                              __uint_as_float(uq.y & 0xffff0000u)};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sg = sigmoid_fast(u[r]);

@@ -269,11 +269,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 //   short items (accumulate bit 1 clear; weight-gradient splits, a handful of partials of many elements): workgroup b owns 1024
 //     consecutive elements of item block_item[b], one thread per 4 elements;
 //   tall items (accumulate bit 1 set; per-workgroup partials of a parameter reduction: hundreds of partials of a few hundred
-//     elements): workgroup b owns 64 consecutive elements, thread (tx = 4 elements, ty = one of 16 groups of partials) adds the
-//     partials ty, ty + 16, ... in order and the 16 group sums are added in order through LDS - a fixed order either way.
+//     elements): workgroup b owns 16 consecutive elements, thread (tx = 4 elements, ty = one of 64 groups of partials) adds the
+//     partials ty, ty + 64, ... in order and the 64 group sums are added in order through LDS - a fixed order either way.
 __global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ma_reduce_item_t* __restrict__ items,
                                                               const int32_t* __restrict__ block_item) {
-  __shared__ float4 red[16][17];
+  __shared__ float4 red[64][4];
   const ma_reduce_item_t it = items[block_item[blockIdx.x]];
   const int64_t ps = it.pstride ? (int64_t)it.pstride : it.mn;
   const bool acc = it.accumulate & 1, tall = it.accumulate & 2;
@@ -304,12 +304,12 @@ __global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ma_reduce_it
     return make_float4(src[0], i0 + 1 < it.mn ? src[1] : 0.f, i0 + 2 < it.mn ? src[2] : 0.f, i0 + 3 < it.mn ? src[3] : 0.f);
   };
   if (tall) {
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 16 + tx) * 4;
+    const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
+    const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 4 + tx) * 4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i0 < it.mn) {
 #pragma unroll 4
-      for (int k = ty; k < it.splits; k += 16) {
+      for (int k = ty; k < it.splits; k += 64) {
         const float4 v = load4(k, i0);
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
       }
@@ -318,8 +318,8 @@ __global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ma_reduce_it
     __syncthreads();
     if (ty == 0 && i0 < it.mn) {
       sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) {
         const float4 v = red[k][tx];
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
       }

@@ -218,8 +218,6 @@ class ConformerCTCTrainStep:
         self.len_norm = bool(getattr(model, "length_normalized_loss", False))
         if self.ctc_weight != 1.0 and self.dec is None:
             raise ValueError("ctc_weight != 1.0 needs model.decoder")
-        if self.x32 and self.dec is not None:
-            raise NotImplementedError("the float32 validation mode covers the CTC branch (ctc_weight = 1.0)")
         self.Ld = len(self.dec.decoders) if self.dec is not None else 0
         self.dec_hidden = self.dec.decoders[0].feed_forward.w_1.out_features if self.dec is not None else 0
         self.last_acc = None
@@ -514,7 +512,7 @@ class ConformerCTCTrainStep:
 
             def add(part_ptr, out, mn, ldo, n_cols, splits, pstride, tall):
                 nonlocal first
-                nblk = (mn + 63) // 64 if tall else (mn + 1023) // 1024
+                nblk = (mn + 15) // 16 if tall else (mn + 1023) // 1024
                 items.append(_lib.ReduceItem(part_ptr, out.data_ptr(), mn, ldo, n_cols, splits, 1.0, 1 | (2 if tall else 0), first,
                                              pstride))
                 block_item.extend([len(items) - 1] * nblk)
@@ -835,6 +833,7 @@ class ConformerCTCTrainStep:
         """TransformerDecoder forward + label-smoothing loss + backward (models/conformer.py:594-639,
         asr_model.py:154-186).  Fills the decoder gradients; returns (loss_att tensor, d_memory (B*T', 256) float32)."""
         fp, d, dec = self.fp, self.d, self.dec
+        ops, K = self.O, self.K  # bf16 throughput kernels or their float32 validation twins
         f32 = torch.float32
         pd, pp = float(dec.dropout_rate), float(dec.positional_dropout_rate)
         eps = 1e-12  # models/conformer.py:417-419, 548
@@ -885,7 +884,7 @@ class ConformerCTCTrainStep:
         self.last_acc = stats[1] / stats[2]
         # ---- backward ----
         K.gemm_tn(dlog, yb, fp.g("dec.out_w"), colsum=fp.g("dec.out_b"), rows_store=self.V)
-        dy = ops.gemm(dlog, self.wt["dec.out_w"])
+        dy = self._dX(dlog, "dec.out_w")
         g = torch.empty((md, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("dec.after_norm.g"), dy, g, fp.g("dec.after_norm.g"), fp.g("dec.after_norm.b"),
                         accumulate=False, eps=eps)
@@ -893,37 +892,37 @@ class ConformerCTCTrainStep:
         for li in reversed(range(self.Ld)):
             pre = "d%d." % li
             P, G = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n))
-            WT = lambda n, pre=pre: self.wt[pre + n]  # noqa: E731
+            DX = lambda dy_, n, pre=pre, **kw: self._dX(dy_, pre + n, **kw)  # noqa: E731  (dy . W on the transposed copy)
             T = tape[li]
             # feed-forward
             dyf = K.dropout_bwd(g, 1.0, pd, seed, salt(li, 3))
             self._dW(dyf, T["h"], pre + "ff_w2", pre + "ff_b2")
-            dh = ops.gemm(dyf, WT("ff_w2"))
+            dh = DX(dyf, "ff_w2")
             du = K.act_dropout_bwd(T["u"], dh, pd, seed, salt(li, 2), out=dh, act=RELU)
             self._dW(du, T["a3"], pre + "ff_w1", pre + "ff_b1")
-            K.layernorm_bwd(T["x2"], P("norm3.g"), ops.gemm(du, WT("ff_w1")), g, G("norm3.g"), G("norm3.b"), eps=eps)
+            K.layernorm_bwd(T["x2"], P("norm3.g"), DX(du, "ff_w1"), g, G("norm3.g"), G("norm3.b"), eps=eps)
             # source attention
             do = K.dropout_bwd(g, 1.0, pd, seed, salt(li, 1))
             self._dW(do, T["ctx2"], pre + "ca_o_w", pre + "ca_o_b")
-            dctx = ops.gemm(do, WT("ca_o_w"))
+            dctx = DX(do, "ca_o_w")
             dq = torch.empty_like(T["q"])
             dkv = torch.empty_like(T["kv"])
             K.mha_small_bwd(T["q"], T["kv"][:, :d], T["kv"][:, d:], T["probs2"], T["ctx2"], dctx, b, L1, t2, scale, dq,
                             dkv[:, :d], dkv[:, d:], self.heads, dk)
             self._dW(dq, T["a2"], pre + "ca_q_w", pre + "ca_q_b")
-            K.layernorm_bwd(T["x1"], P("norm2.g"), ops.gemm(dq, WT("ca_q_w")), g, G("norm2.g"), G("norm2.b"), eps=eps)
+            K.layernorm_bwd(T["x1"], P("norm2.g"), DX(dq, "ca_q_w"), g, G("norm2.g"), G("norm2.b"), eps=eps)
             self._dW(dkv, mem_bf, pre + "ca_kv_w", pre + "ca_kv_b")
-            ops.gemm(dkv, WT("ca_kv_w"), residual=d_mem, out_dtype=f32, out=d_mem)
+            DX(dkv, "ca_kv_w", residual=d_mem, out_dtype=f32, out=d_mem)
             # self attention
             do = K.dropout_bwd(g, 1.0, pd, seed, salt(li, 0))
             self._dW(do, T["ctx"], pre + "sa_o_w", pre + "sa_o_b")
-            dctx = ops.gemm(do, WT("sa_o_w"))
+            dctx = DX(do, "sa_o_w")
             dqkv = torch.empty_like(T["qkv"])
             qkv = T["qkv"]
             K.mha_small_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], T["probs"], T["ctx"], dctx, b, L1, L1, scale,
                             dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], self.heads, dk)
             self._dW(dqkv, T["a"], pre + "sa_qkv_w", pre + "sa_qkv_b")
-            K.layernorm_bwd(T["x0"], P("norm1.g"), ops.gemm(dqkv, WT("sa_qkv_w")), g, G("norm1.g"), G("norm1.b"), eps=eps)
+            K.layernorm_bwd(T["x0"], P("norm1.g"), DX(dqkv, "sa_qkv_w"), g, G("norm1.g"), G("norm1.b"), eps=eps)
         K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0))
         if self.dec_names:
             self.reducer.launch(*fp.span(self.dec_names))

@@ -164,14 +164,19 @@ def mha_small_bwd(q, k, v, probs, ctx, dctx, batch, lq, lk, scale, dq, dk, dv, h
 def label_smoothing_loss_grad(logits, V, target, mask, smoothing, grad_scale, normalize_length=False):
     """-> (stats (3,) f32 = [sum kl, correct, tokens], dlogits (rows, ld) bf16).  normalize_length: the gradient is divided by the
     number of unmasked tokens (a device-side sum of `mask`) instead of what the caller folded into grad_scale."""
+    return _label_smoothing(logits, V, target, mask, smoothing, grad_scale, normalize_length, False)
+
+
+def _label_smoothing(logits, V, target, mask, smoothing, grad_scale, normalize_length, out_f32):
     t = _t()
     rows = logits.shape[0]
     stats = t.zeros(3, dtype=t.float32, device=logits.device)
-    dlog = t.empty((rows, logits.stride(0)), dtype=t.bfloat16, device=logits.device)
+    row_stats = t.empty(rows * 3, dtype=t.float32, device=logits.device)
+    dlog = t.empty((rows, logits.stride(0)), dtype=t.float32 if out_f32 else t.bfloat16, device=logits.device)
     denom = mask.sum().reshape(1).to(t.float32) if normalize_length else None
-    _lib.check(_lib.load().ma_label_smoothing_loss_grad_len_f32(_p(logits), logits.stride(0), rows, V, _p(target), _p(mask),
-                                                                float(smoothing), float(grad_scale), _p(denom), _p(dlog),
-                                                                dlog.stride(0), _p(stats), _s()), "label_smoothing")
+    fn = _lib.load().ma_label_smoothing_loss_grad_len_x32 if out_f32 else _lib.load().ma_label_smoothing_loss_grad_len_f32
+    _lib.check(fn(_p(logits), logits.stride(0), rows, V, _p(target), _p(mask), float(smoothing), float(grad_scale), _p(denom),
+                  _p(dlog), dlog.stride(0), _p(stats), _p(row_stats), _s()), "label_smoothing")
     return stats, dlog
 
 

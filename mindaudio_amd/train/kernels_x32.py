@@ -15,6 +15,9 @@ dropout_add = _K.dropout_add            # takes float32 or bf16 y
 grad_overflow = _K.grad_overflow
 adam = _K.adam
 _reduce_ws = _K._reduce_ws
+embed_posenc = _K.embed_posenc          # float32 in, float32 out
+embed_bwd = _K.embed_bwd
+transpose = _K.transpose
 
 
 def _t():
@@ -263,3 +266,27 @@ def ctc_loss_grad(logits, V, batch, T, ys_pad, hlens, ys_lens, grad_scale, blank
                                         _p(ys_lens), blank, 1, float(grad_scale), _p(per), _p(lse), _p(out), _p(dlog),
                                         dlog.stride(0), _p(ws), ws_bytes, _s()), "ctc_loss_grad_x32")
     return out[0], per, dlog
+
+
+# ---- attention-decoder branch of the hybrid loss on float32 activations ----------------------------------------------------------
+def mha_small_fwd(q, k, v, mask, mask_mode, batch, lq, lk, scale, heads=4, d_k=64):
+    t = _t()
+    _f32(q, k, v)
+    ctx = t.empty((batch * lq, heads * d_k), dtype=t.float32, device=q.device)
+    probs = t.empty((batch, heads, lq, lk), dtype=t.float32, device=q.device)
+    _lib.check(_lib.load().ma_mha_small_fwd_x32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(mask), mask_mode, batch,
+                                                lq, lk, heads, d_k, float(scale), _p(ctx), ctx.stride(0), _p(probs), _s()),
+               "mha_small_fwd_x32")
+    return ctx, probs
+
+
+def mha_small_bwd(q, k, v, probs, ctx, dctx, batch, lq, lk, scale, dq, dk, dv, heads=4, d_k=64):
+    _f32(q, k, v, ctx, dctx, dq, dk, dv)
+    _lib.check(_lib.load().ma_mha_small_bwd_x32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(probs), _p(ctx),
+                                                ctx.stride(0), _p(dctx), dctx.stride(0), batch, lq, lk, heads, d_k, float(scale),
+                                                _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _s()),
+               "mha_small_bwd_x32")
+
+
+def label_smoothing_loss_grad(logits, V, target, mask, smoothing, grad_scale, normalize_length=False):
+    return _K._label_smoothing(logits, V, target, mask, smoothing, grad_scale, normalize_length, True)

@@ -98,15 +98,15 @@ def test_transpose_batch_and_batched_split_sums(K):
     parts = torch.randn(300, 512, generator=g).cuda()
     tall_out = torch.zeros(512, device="cuda")
     items.append(_lib.ReduceItem(parts.data_ptr(), tall_out.data_ptr(), 512, 512, 512, 300, 1.0, 2, first, 512))
-    block_item += [len(items) - 1] * 8
-    first += 8
+    block_item += [len(items) - 1] * 32
+    first += 32
     d_items, d_map = to_dev(items, _lib.ReduceItem), torch.tensor(block_item, dtype=torch.int32, device="cuda")
     _lib.check(lib.ma_reduce_splits_batch_f32(d_items.data_ptr(), d_map.data_ptr(), first, st), "rb")
     for out, ref in zip(gouts, want):
         assert torch.equal(out, ref)  # same partials, same order of the splits
     assert rel(tall_out, parts.double().sum(0).float().cpu()) < 1e-6
     tall_again = torch.zeros(512, device="cuda")
-    items[-1] = _lib.ReduceItem(parts.data_ptr(), tall_again.data_ptr(), 512, 512, 512, 300, 1.0, 2, first - 8, 512)
+    items[-1] = _lib.ReduceItem(parts.data_ptr(), tall_again.data_ptr(), 512, 512, 512, 300, 1.0, 2, first - 32, 512)
     d_items = to_dev(items, _lib.ReduceItem)
     _lib.check(lib.ma_reduce_splits_batch_f32(d_items.data_ptr(), d_map.data_ptr(), first, st), "rb")
     assert torch.equal(tall_out, tall_again)  # fixed summation order: bit-identical from run to run

@@ -409,3 +409,82 @@ def test_fused_engine_gradients_match_oracle_autograd():
     bad = {k: round(v, 4) for k, v in worst.items() if v > 6e-2}
     assert not bad, bad
     assert sum(worst.values()) / len(worst) < 2.5e-2
+
+
+def _hybrid_setup(seed=31, vocab=97, blocks=1, dblocks=2):
+    from mindaudio_amd.conformer.asr_model import create_asr_model
+    from oracle import conformer_oracle as C
+
+    torch.manual_seed(seed)
+    ref_enc = C.ConformerEncoder(80, 256, 4, 2048, blocks, dropout_rate=0.0, positional_dropout_rate=0.0).train()
+    ref_ctc = C.CTC(vocab, 256).train()
+    ref_dec = C.TransformerDecoder(vocab, 256, 4, 512, dblocks, 0.0, 0.0).train()
+    with torch.no_grad():
+        for mod in list(ref_enc.modules()) + list(ref_dec.modules()):
+            if isinstance(mod, C.LayerNorm):
+                mod.gamma.uniform_(0.8, 1.2)
+                mod.beta.normal_(0, 0.1)
+    model = create_asr_model(80, vocab, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks),
+                             ctc_weight=0.3, decoder_conf=dict(attention_heads=4, linear_units=512, num_blocks=dblocks,
+                                                               dropout_rate=0.0, positional_dropout_rate=0.0), lsm_weight=0.1)
+    model.encoder.load_state_dict(ref_enc.state_dict(), strict=False)
+    model.ctc.load_state_dict(ref_ctc.state_dict())
+    model.decoder.load_state_dict(ref_dec.state_dict(), strict=False)
+    xs, ys, sub, ys_lens = batch(vocab=vocab - 1, seed=12)
+    b, lmax = ys.shape[0], 9
+    sos = eos = vocab - 1
+    ys_in = torch.full((b, lmax + 1), eos, dtype=torch.int32)
+    ys_out = torch.full((b, lmax + 1), -1, dtype=torch.int32)
+    ys_masks = torch.zeros(b, 1, lmax + 1)
+    for i, n in enumerate(ys_lens.tolist()):
+        ys_in[i, 0] = sos
+        ys_in[i, 1:n + 1] = ys[i, :n]
+        ys_out[i, :n] = ys[i, :n]
+        ys_out[i, n] = eos
+        ys_masks[i, 0, :n + 1] = 1
+    ys_sub = (ys_masks.bool() & torch.tril(torch.ones(lmax + 1, lmax + 1, dtype=torch.bool))[None]).float()
+    cols = (xs, ys, ys_in, ys_out, None, None, sub, ys_sub, ys_masks, ys_lens, None)
+    return ref_enc, ref_ctc, ref_dec, model.cuda(), cols
+
+
+def test_hybrid_loss_curve_in_float32_mode_matches_the_oracle():
+    """The shipped conformer.yaml trains with ctc_weight 0.3 (asr_model.py:117-153): the float32 validation mode now covers the
+    attention-decoder branch too (float32 decoder attention, embedding, label smoothing).  20 Adam steps on one batch against the
+    same recipe on the float32 PyTorch oracle: every loss within 1e-4 (north star), first-step gradients within 2e-4."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep, asr_warmup_lr
+    from oracle import conformer_oracle as C
+
+    ref_enc, ref_ctc, ref_dec, model, cols = _hybrid_setup()
+    params = list(ref_enc.parameters()) + list(ref_ctc.parameters()) + list(ref_dec.parameters())
+    opt = torch.optim.Adam(params, lr=1.0, betas=(0.9, 0.999), eps=1e-8)
+    warm, base, n_steps = 25, 2e-4, 20
+    eng = ConformerCTCTrainStep(model, base_lr=base, warmup_steps=warm, dropout_rate=0.0, positional_dropout_rate=0.0,
+                                compute_type=torch.float32)
+    dev = [c.cuda() if c is not None else None for c in cols]
+    got, want = [], []
+    for step in range(n_steps):
+        for gq in opt.param_groups:
+            gq["lr"] = asr_warmup_lr(step, base, warm)
+        opt.zero_grad()
+        l_ref, _, _, _ = C.hybrid_loss(ref_enc, ref_ctc, ref_dec, cols, 0.3, 0.1)
+        l_ref.backward()
+        if step == 0:
+            want_g = {"encoder." + n: p.grad.clone() for n, p in ref_enc.named_parameters()}
+            want_g.update({"ctc." + n: p.grad.clone() for n, p in ref_ctc.named_parameters()})
+            want_g.update({"decoder." + n: p.grad.clone() for n, p in ref_dec.named_parameters()})
+        opt.step()
+        want.append(float(l_ref.detach()))
+        loss, cond, scale, overflow, _ = eng.step(*dev)
+        assert not overflow
+        got.append(float(loss))
+        if step == 0:
+            grads = eng.gradients()
+            gmax = float(max(p.abs().max() for p in want_g.values()))
+            for name, gw in want_g.items():
+                if "depthwise_conv.bias" in name or "linear_k.bias" in name:
+                    assert float(grads[name].abs().max()) / scale < 1e-3 * gmax
+                    continue
+                assert rel_rms(grads[name] / scale, gw) <= 2e-4, name
+    dev_max = max(abs(a - b_) / abs(b_) for a, b_ in zip(got, want))
+    print("hybrid float32 loss curve over %d steps: %.3f -> %.3f, max relative deviation %.2e" % (n_steps, want[0], want[-1], dev_max))
+    assert want[-1] < want[0] and dev_max <= 1e-4, (got, want)

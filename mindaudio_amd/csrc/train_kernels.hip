@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 constexpr int kMaxPartBlocks = 2048, kMaxPartWidth = 8448;  // partial-sum workspace of the two-stage reductions
-constexpr int kLnBwdBlocks = 512;  // workgroups (= partial (dgamma | dbeta) vectors) of a LayerNorm backward launch
+constexpr int kLnBwdBlocks = 1024;  // workgroups (= partial (dgamma | dbeta) vectors) of a LayerNorm backward launch
 
 static int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
   int64_t g = (n + per_block - 1) / per_block;

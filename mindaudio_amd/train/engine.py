@@ -449,6 +449,12 @@ class ConformerCTCTrainStep:
             items, block_item, first, total = [], [], 0, 0
             self.pk = {}
             specs = []
+            # the embed layer Linear(f2 * d -> d) (subsampling.py:46-47): 64 rows x 256 outputs per workgroup on a packed weight
+            w = self.fp.w("out_w")
+            pieces = int(lib.ma_pack_item_pieces(1, w.shape[0], w.shape[1]))
+            if pieces > 0:
+                specs.append(("out_w.r", w, w.shape[0], w.shape[1], 1, pieces, total))
+                total += pieces * 16
             for li in range(self.L):
                 for key, src, transposed, kind in self._PACKS:
                     w = self.wt["l%d.%s" % (li, src)] if transposed else self.fp.w("l%d.%s" % (li, src))
@@ -600,7 +606,10 @@ class ConformerCTCTrainStep:
         att_mask = enc._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
         hlens = mask2d.sum(1).to(torch.int32)
         a2 = act2.view(m, f2 * c)
-        e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)
+        if self.fused and "out_w.r" in self.pk:
+            e = ops.gemm_rows_packed(a2, self.pk["out_w.r"].view(torch.bfloat16).view(d, -1), fp.p("out_b"), alpha=math.sqrt(d))
+        else:
+            e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)
         x = K.dropout_add(None, e, 1.0, pp, seed, self._salt(-1, 0)) if pp > 0 else e
         pe = enc.pe[:t2].to(f32).contiguous()
         if pp > 0:

@@ -520,19 +520,24 @@ extern "C" int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* p
   if ((lda & 7) || lda < kG2K || ldo < N || (e.mode == 3 ? (ldo & 3) : (ldo & 7))) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15) return MA_ERR_INVALID_ARG;
   const unsigned nby = (unsigned)(N / kG2Cols);
-  const dim3 grid((unsigned)((M + 63) / 64), nby);
-  const size_t lds = 64 * (kG2Pitch + 4 * kG2StagePitch);
+  const bool half = (M + 63) / 64 * nby < 384;  // well under two 64-row workgroups per CU: 32-row workgroups (as the evaluation form)
+  const dim3 grid((unsigned)(half ? (M + 31) / 32 : (M + 63) / 64), nby);
+  const size_t lds = (half ? 32 : 64) * (kG2Pitch + 4 * kG2StagePitch);
 #define MA_G2T(MODE_)                                                                                                         \
   {                                                                                                                          \
     static bool set = false;                                                                                                 \
     if (!set) {                                                                                                              \
       if (hipFuncSetAttribute((const void*)&gemm_k256_train_kernel<64, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                              (int)lds) != hipSuccess)                                                                       \
+                              64 * (kG2Pitch + 4 * kG2StagePitch)) != hipSuccess)                                            \
         return MA_ERR_LAUNCH;                                                                                                \
       set = true;                                                                                                            \
     }                                                                                                                        \
-    MA_LAUNCH((gemm_k256_train_kernel<64, MODE_>), grid, dim3(kG2Threads), lds, (hipStream_t)stream,                         \
-              reinterpret_cast<const uint16_t*>(A), lda, reinterpret_cast<const uint4*>(packed), out, ldo, (int)M, (int)N, e); \
+    if (half)                                                                                                                \
+      MA_LAUNCH((gemm_k256_train_kernel<32, MODE_>), grid, dim3(kG2Threads), lds, (hipStream_t)stream,                       \
+                reinterpret_cast<const uint16_t*>(A), lda, reinterpret_cast<const uint4*>(packed), out, ldo, (int)M, (int)N, e); \
+    else                                                                                                                     \
+      MA_LAUNCH((gemm_k256_train_kernel<64, MODE_>), grid, dim3(kG2Threads), lds, (hipStream_t)stream,                       \
+                reinterpret_cast<const uint16_t*>(A), lda, reinterpret_cast<const uint4*>(packed), out, ldo, (int)M, (int)N, e); \
   }
   if (e.mode == 1) MA_G2T(1)
   else if (e.mode == 2) MA_G2T(2)

@@ -80,13 +80,16 @@ __global__ void rows_pack_kernel(const uint16_t* __restrict__ w, int64_t ldw, in
 // MODE 0: out float32 = alpha * (acc + bias) (the evaluation forward's embed layer).  Training forms (ma_gemm_rows_train_bf16; the
 // w_2 / input-gradient layers of the Conformer block, K = 2048, 768, 512): MODE 3 = train_epi_rows256 (residual + dropout +
 // LayerNorm chain, float32 out), MODE 4 = out bf16 = acc + bias.
-template <int MODE>
+// MT = 16-row tiles per workgroup: 4 (64 rows), or 3 (48 rows) when 64-row tiles would leave a third of the CUs without a workgroup
+// (the training step's M = 10 200 rows: 160 workgroups of 64 rows on 256 CUs, 213 of 48).  The 48-row form stages the same 64-row LDS
+// tile (rows past the 48th are fetched and not used: every wave keeps its two LDS-DMA loads per chunk, so the counted waits hold).
+template <int MODE, int MT = 4>
 __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPackedParams p, const TrainEpi e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * kRpRows;
+  const int m0 = blockIdx.x * (16 * MT);
   const int nch = p.nchunks;                 // K / 64: activation chunks that exist
   const int nch_pad = (nch + 2) / 3 * 3;     // chunks the loop runs: the packed weight is zero beyond nch, the activation chunk index is clamped
 
@@ -117,11 +120,11 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
                  : "memory");                                                                                          \
   } while (0)
   bf16x8 ring[3][8];
-  f32x4 acc[4][4];
+  f32x4 acc[4][MT];
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < MT; ++s) acc[jt][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read address: row 16 s + c of the stage (s and the stage go into the immediate offset), logical 16-byte chunk 4 kk + g
   const uint32_t a_addr0 = (uint32_t)(uintptr_t)(lds_void_t*)(smem + c * 128 + ((g ^ (c & 7)) << 4));
@@ -148,26 +151,30 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAWait) : "memory");
     __builtin_amdgcn_s_barrier();
     issue_a(chunk + 2, (ST + 2) % 3);  // the stage chunk - 1 used: every wave is past its reads (barrier above)
-    bf16x8 af[2][4];
+    bf16x8 af[2][MT];
 #define RP_LDS(kk_, s_)                                                                                        \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kk_][s_]) : "v"(kk_ ? a_addr1 : a_addr0), "n"(ST * kRpStage + (s_) * 2048) \
                : "memory")
-    RP_LDS(0, 0); RP_LDS(0, 1); RP_LDS(0, 2); RP_LDS(0, 3);
-    RP_LDS(1, 0); RP_LDS(1, 1); RP_LDS(1, 2); RP_LDS(1, 3);
+    RP_LDS(0, 0); RP_LDS(0, 1); RP_LDS(0, 2);
+    if constexpr (MT == 4) RP_LDS(0, 3);
+    RP_LDS(1, 0); RP_LDS(1, 1); RP_LDS(1, 2);
+    if constexpr (MT == 4) RP_LDS(1, 3);
 #undef RP_LDS
     rp_static_for<2>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kk = decltype(kc)::value;
-      if constexpr (kk == 0)
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3])::"memory");
+      if constexpr (kk == 0 && MT == 4)
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][MT - 1])::"memory");
+      else if constexpr (kk == 0)
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2])::"memory");
       else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3])::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][MT - 1])::"memory");
       __builtin_amdgcn_sched_barrier(0);
       rp_static_for<4>([&](auto tc) __attribute__((always_inline)) {
         constexpr int jt = decltype(tc)::value;
         constexpr int q = kk * 4 + jt;
         asm volatile("s_waitcnt vmcnt(29)" : "+v"(ring[ST][q])::"memory");
         __builtin_amdgcn_sched_barrier(0);
-        rp_static_for<4>([&](auto sc) __attribute__((always_inline)) {
+        rp_static_for<MT>([&](auto sc) __attribute__((always_inline)) {
           constexpr int s = decltype(sc)::value;
           acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[ST][q], af[kk][s], acc[jt][s], 0, 0, 0);
         });
@@ -205,12 +212,7 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
   // ---- epilogue: lane (c, g) holds rows m0 + 16 s + c, outputs 64 wave + 16 jt + 4 g + r ----------------------------------------
   if constexpr (MODE == 3) {
     __syncthreads();  // every wave is past its last fragment reads: the activation stages become the LayerNorm exchange scratch
-    f32x4 accT[4][4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) accT[jt][s] = acc[jt][s];
-    train_epi_rows256<4>(e, accT, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem));
+    train_epi_rows256<MT>(e, acc, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem));
     return;
   } else {
     float4 bv[4];
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
     for (int jt = 0; jt < 4; ++jt)
       bv[jt] = p.bias ? *reinterpret_cast<const float4*>(p.bias + 64 * wave + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < MT; ++s) {
       const int m = m0 + 16 * s + c;
       if (m >= p.M) continue;
       if constexpr (MODE == 4) {
@@ -300,7 +302,7 @@ extern "C" int ma_gemm_rows_packed_f32(const void* A, int64_t lda, int64_t M, in
   p.M = (int32_t)M;
   p.nchunks = (int32_t)(K / 64);
   p.alpha = alpha;
-  MA_LAUNCH(rows_packed_kernel<0>, dim3((unsigned)((M + kRpRows - 1) / kRpRows)), dim3(kRpThreads), kRpLds, (hipStream_t)stream, p,
+  MA_LAUNCH((rows_packed_kernel<0, 4>), dim3((unsigned)((M + kRpRows - 1) / kRpRows)), dim3(kRpThreads), kRpLds, (hipStream_t)stream, p,
             TrainEpi{});
   return MA_OK;
 }
@@ -352,9 +354,27 @@ extern "C" int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, in
   p.M = (int32_t)M;
   p.nchunks = (int32_t)(K / 64);
   p.alpha = 1.0f;
-  const dim3 grid((unsigned)((M + kRpRows - 1) / kRpRows));
-  if (e.mode == 3) MA_LAUNCH(rows_packed_kernel<3>, grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
-  else MA_LAUNCH(rows_packed_kernel<4>, grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+  // 48-row workgroups when the 64-row grid would fill less than 7/8 of the CUs and the 48-row grid still fits one round
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    static int cached = 0;
+    if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cached = prop.multiProcessorCount;
+    if (cached) cus = cached;
+  }
+  const int64_t g64 = (M + 63) / 64, g48 = (M + 47) / 48;
+  const bool use48 = (g64 % cus) != 0 && (g64 % cus) * 8 < cus * 7 && (g48 + cus - 1) / cus == (g64 + cus - 1) / cus;
+  if (use48) {
+    const dim3 grid((unsigned)g48);
+    if (e.mode == 3) MA_LAUNCH((rows_packed_kernel<3, 3>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+    else MA_LAUNCH((rows_packed_kernel<4, 3>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+  } else {
+    const dim3 grid((unsigned)g64);
+    if (e.mode == 3) MA_LAUNCH((rows_packed_kernel<3, 4>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+    else MA_LAUNCH((rows_packed_kernel<4, 4>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+  }
   return MA_OK;
 }
 

@@ -104,6 +104,7 @@ class EcapaTDNN(nn.Module):
     @torch.no_grad()
     def prepare(self):
         bf = torch.bfloat16
+        self._ws = {}  # activation buffers of earlier forwards are dropped with the old weights
 
         def tdnn(m, cin_pad=None):
             w = m.conv.weight.detach()  # (Cout, Cin, k) -> (Cout, k, Cin[pad]): K index = tap * Cin + c
@@ -158,7 +159,8 @@ class EcapaTDNN(nn.Module):
         # Activation buffers and the row mask are kept per (batch, frames, device): the margins above the first and below the last
         # utterance are read by the taps and never written, so they are zeroed once (26 fill launches per forward otherwise:
         # 2.52 -> 2.47 ms for the C = 512 forward, same box).  Calls on one stream reuse them in order; the returned embedding is a fresh tensor.
-        key = (b, T, str(dev), bool(self.fuse_res2net))
+        # (the stream is part of the key: buffers shared by forwards on two streams would race)
+        key = (b, T, str(dev), bool(self.fuse_res2net), int(t.cuda.current_stream().cuda_stream))
         ws = self._ws.get(key)
         if ws is None:
             if len(self._ws) >= 4:

@@ -225,11 +225,13 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=F
         import hashlib
 
         res["masters_sha16"] = hashlib.sha256(eng.fp.master.cpu().numpy().tobytes()).hexdigest()[:16]
-    if world > 1:
+    if world > 1 or force_collective:
         # (i) the step without its collective: exposed communication = ms_per_step - ms_per_step_no_comm
-        eng.reducer.world = 1
+        import torch.distributed as tdist
+
+        eng.reducer.world, eng.reducer.force = 1, False
         dt0, _ = timed(max(3, steps // 2))
-        eng.reducer.world = world
+        eng.reducer.world, eng.reducer.force = world, force_collective
         res["ms_per_step_no_allreduce"] = round(dt0 / max(3, steps // 2) * 1e3, 3)
         res["exposed_comm_ms"] = round(res["ms_per_step"] - res["ms_per_step_no_allreduce"], 3)
         # (ii) the all-reduce alone, same buckets: bus bandwidth = 2 (N-1)/N x bytes / t  (ring-equivalent)
@@ -240,7 +242,7 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=F
         barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
-            works = [dist.all_reduce(eng.fp.grad[lo:hi], async_op=True) for lo, hi in spans]
+            works = [tdist.all_reduce(eng.fp.grad[lo:hi], async_op=True) for lo, hi in spans]
             for w in works:
                 w.wait()
         barrier()

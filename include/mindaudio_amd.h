@@ -618,6 +618,11 @@ int ma_relpos_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* po
                                  int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
                                  float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
                                  ma_stream_t stream);
+/* dpos == NULL (dbias_u / dbias_v then unused): the backward leaves its partial sums in the workspace and the caller adds them with
+ * ma_reduce_splits_batch_f32 (the training step: one reduction launch per block); ma_relpos_attention_bwd_layout gives their float
+ * offsets: dp_part [batch][Tp][256] (sum over the batch -> dpos (T, 256)), bias_part [heads][parts_per_head][128] = (du | dv). */
+int ma_relpos_attention_bwd_layout(int64_t batch, int64_t T, int32_t heads, int32_t d_k, int64_t* dp_part_off, int64_t* bias_part_off,
+                                   int32_t* Tp_out, int32_t* parts_per_head);
 
 /* The same two with a per-(query, key) mask (batch, T, T) float32 instead of the (batch, T) padding mask: the chunk masks
  * of the streaming configuration (utils/mask.py:201-271; models/conformer.py:251-252 hands them to every block). */

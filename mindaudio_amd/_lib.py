@@ -200,6 +200,8 @@ PROTOTYPES = {
     "ma_relpos_attention_train_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, vp, i64, vp, i64,
                                                       vp, vp]),
     "ma_relpos_attention_bwd_workspace_bytes": (i64, [i64, i64, i32, i32]),
+    "ma_relpos_attention_bwd_layout": (ctypes.c_int, [i64, i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64),
+                                                      ctypes.POINTER(i32), ctypes.POINTER(i32)]),
     "ma_relpos_attention_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32,
                                                     i32, vp, i64, vp, i64, vp, vp, vp, i64, vp]),
     "ma_relpos_attention_train_qmask_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, vp, i64, vp,

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t ab_pack(float lo, float hi) {  // v_cvt_pk_b
 struct AttnWs {
   uint16_t* base;
   float* D;
-  float* bias_part;  // [B*H*(Tp/64)][128] per-workgroup partial sums of (du | dv)
+  float* bias_part;  // [H][B * (Tp/64)][128] per-workgroup partial sums of (du | dv): a head's partials lie 128 floats apart
   float* dp_part;    // [B][Tp][256] per-batch gradient of the positional projection
   int Tp;
   __host__ __device__ int64_t per_bh() const { return (int64_t)Tp * (128 * 4 + 64); }
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, KEYS_FIXED ? 2 : 3) void attn_bwd_kernel(const
     if (tid < 128) {
       // per-workgroup partial of (du | dv) for head h; attn_bias_reduce_kernel sums them (no contended atomics)
       const float t4 = (wg_part[0][tid] + wg_part[1][tid]) + (wg_part[2][tid] + wg_part[3][tid]);
-      ws.bias_part[(((int64_t)b * H + h) * gridDim.x + fb) * 128 + tid] = t4;
+      ws.bias_part[(((int64_t)h * gridDim.z + b) * gridDim.x + fb) * 128 + tid] = t4;
     }
   }
 }
@@ -417,10 +417,8 @@ __global__ __launch_bounds__(1024) void attn_bias_reduce_kernel(const float* __r
   const int h = blockIdx.x, c = threadIdx.x & 127, sl = threadIdx.x >> 7;
   const int n = B * nfb;
   float s = 0.0f;
-  for (int i = sl; i < n; i += 8) {
-    const int b = i / nfb, f = i - b * nfb;
-    s += part[(((int64_t)b * H + h) * nfb + f) * 128 + c];
-  }
+  for (int i = sl; i < n; i += 8) s += part[((int64_t)h * n + i) * 128 + c];
+  (void)H;
   red[sl][c] = s;
   __syncthreads();
   if (sl == 0) {
@@ -451,17 +449,33 @@ int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_
   return batch * heads * Tp * (128 * 4 + 64) * 2 + batch * heads * Tp * 4 + batch * heads * (Tp / 64) * 128 * 4 + batch * Tp * 256 * 4 + 256;
 }
 
+// Where the partial sums lie in the workspace (float offsets from its start), for a caller that reduces them itself (dpos == NULL):
+//   dp_part  [batch][Tp][256]: the positional projection's gradient per utterance (sum over the batch -> dpos (T, 256))
+//   bias_part[heads][batch * Tp / 64][128]: (du (64) | dv (64)) per workgroup (sum over the middle index -> dbias_u / dbias_v [h])
+int ma_relpos_attention_bwd_layout(int64_t batch, int64_t T, int32_t heads, int32_t d_k, int64_t* dp_part_off, int64_t* bias_part_off,
+                                   int32_t* Tp_out, int32_t* parts_per_head) {
+  if (batch < 1 || T < 1 || heads < 1 || d_k != 64 || !dp_part_off || !bias_part_off || !Tp_out || !parts_per_head)
+    return MA_ERR_INVALID_ARG;
+  const int64_t Tp = (T + 63) / 64 * 64;
+  const int64_t base_floats = batch * heads * Tp * (128 * 4 + 64) / 2;  // the bf16 operand copies, in floats
+  *bias_part_off = base_floats + batch * heads * Tp;
+  *dp_part_off = *bias_part_off + batch * heads * (Tp / 64) * 128;
+  *Tp_out = (int32_t)Tp;
+  *parts_per_head = (int32_t)(batch * (Tp / 64));
+  return MA_OK;
+}
+
 static int relpos_attention_bwd(const void* qkv, int64_t ld_qkv, const void* pos, int64_t ld_pos, const float* bias_u,
                                  const float* bias_v, const float* mask, const float* mask3, const void* ctx, int64_t ld_ctx,
                                  const void* dctx, int64_t ld_dctx, const float* lse, int64_t batch, int64_t T,
                                  int32_t heads, int32_t d_k, void* dqkv, int64_t ld_dqkv, float* dpos, int64_t ld_dpos,
                                  float* dbias_u, float* dbias_v, void* workspace, int64_t workspace_bytes,
                                  ma_stream_t stream) {
-  if (!qkv || !pos || !bias_u || !bias_v || !ctx || !dctx || !lse || !dqkv || !dpos || !dbias_u || !dbias_v || !workspace ||
+  if (!qkv || !pos || !bias_u || !bias_v || !ctx || !dctx || !lse || !dqkv || (dpos && (!dbias_u || !dbias_v)) || !workspace ||
       batch < 1 || T < 1)
     return MA_ERR_INVALID_ARG;
   if (d_k != 64 || heads * d_k != 256 || batch > 65535) return MA_ERR_UNSUPPORTED;
-  if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 7) || (ld_dctx & 7) || (ld_dqkv & 3) || ld_dpos < 256) return MA_ERR_UNSUPPORTED;
+  if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 7) || (ld_dctx & 7) || (ld_dqkv & 3) || (dpos && ld_dpos < 256)) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(ctx) |
        reinterpret_cast<uintptr_t>(dctx)) & 15)
     return MA_ERR_INVALID_ARG;  // 16-byte pieces
@@ -482,6 +496,7 @@ static int relpos_attention_bwd(const void* qkv, int64_t ld_qkv, const void* pos
             mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   MA_LAUNCH(attn_bwd_kernel<false>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
             mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+  if (!dpos) return MA_OK;  // the per-batch / per-workgroup partials stay in the workspace for the caller's batched reduction
   MA_LAUNCH(attn_dpos_reduce_kernel, dim3((unsigned)T), dim3(256), 0, s, ws.dp_part, (int)batch, (int)T, ws.Tp, dpos,
             ld_dpos);
   MA_LAUNCH(attn_bias_reduce_kernel, dim3((unsigned)heads), dim3(1024), 0, s, ws.bias_part, (int)batch, (int)heads,

@@ -494,7 +494,7 @@ class ConformerCTCTrainStep:
         if self.x32:
             return None
         cur = self.__dict__.get("_dw_plan")
-        if cur is not None and cur["m"] == m:
+        if cur is not None and cur["m"] == m and cur.get("t2") == self._t2_cur:
             return cur
         import numpy as np
 
@@ -509,6 +509,20 @@ class ConformerCTCTrainStep:
         for site in self._LN_SITES:
             off[site] = (total, ln_parts * 512 * 4, ln_parts)
             total += ln_parts * 512 * 4
+        # the attention backward's workspace (its dpos / du / dv partials are reduced by the block's launch too) and the buffer the
+        # positional projections' gradients of all blocks accumulate in
+        import ctypes
+
+        b_att = m // self._t2_cur
+        att_bytes = int(lib.ma_relpos_attention_bwd_workspace_bytes(b_att, self._t2_cur, self.heads, self.d // self.heads))
+        dp_off, bias_off, tp_, pph = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(lib.ma_relpos_attention_bwd_layout(b_att, self._t2_cur, self.heads, self.d // self.heads, ctypes.byref(dp_off),
+                                                      ctypes.byref(bias_off), ctypes.byref(tp_), ctypes.byref(pph)), "attention layout")
+        total = (total + 255) // 256 * 256
+        off["att_ws"] = (total, att_bytes, 0)
+        total += (att_bytes + 255) // 256 * 256
+        off["dpos_all"] = (total, self._t2_cur * self.L * self.d * 4, 0)
+        total += (self._t2_cur * self.L * self.d * 4 + 255) // 256 * 256
         arena = self.__dict__.get("_dw_arena")
         if arena is None or arena.numel() < total:
             arena = self._dw_arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
@@ -536,10 +550,25 @@ class ConformerCTCTrainStep:
                 gg = fp.g("l%d.%s.g" % (li, site))  # (g | b): 2 x 256 contiguous floats of the flat gradient
                 assert fp.index["l%d.%s.b" % (li, site)][0] == fp.index["l%d.%s.g" % (li, site)][0] + 256
                 add(arena.data_ptr() + o, gg, 512, 512, 512, parts, 512, True)
+            if self.fused:
+                t2, d, dk = self._t2_cur, self.d, self.d // self.heads
+                ws_ptr = arena.data_ptr() + off["att_ws"][0]
+                dpos_l = arena[off["dpos_all"][0]:off["dpos_all"][0] + off["dpos_all"][1]].view(torch.float32).view(t2, self.L * d)
+                # dpos[t][c] of block li += sum over the batch of dp_part[b][t][c]
+                add(ws_ptr + dp_off.value * 4, dpos_l[:, li * d:(li + 1) * d], t2 * d, self.L * d, d, b_att, tp_.value * d, False)
+                for h in range(self.heads):  # du[h], dv[h] += sum over the (utterance, query block) partials of head h
+                    base = ws_ptr + (bias_off.value + h * pph.value * 128) * 4
+                    add(base, fp.g("l%d.u" % li)[h], dk, dk, dk, pph.value, 128, True)
+                    add(base + dk * 4, fp.g("l%d.v" % li)[h], dk, dk, dk, pph.value, 128, True)
             raw = (_lib.ReduceItem * len(items))(*items)
             layers.append((torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
                            torch.tensor(block_item, dtype=torch.int32, device=self.dev), first))
-        self._dw_plan = dict(m=m, arena=arena, off=off, layers=layers)
+        self._dw_plan = dict(m=m, t2=self._t2_cur, arena=arena, off=off, layers=layers)
+        if self.fused:
+            o, nb, _ = off["att_ws"]
+            self._dw_plan["att_ws"] = arena[o:o + nb]
+            o, nb, _ = off["dpos_all"]
+            self._dw_plan["dpos_all"] = arena[o:o + nb].view(torch.float32).view(self._t2_cur, self.L * self.d)
         return self._dw_plan
 
     def _ln_partials(self, site):
@@ -597,6 +626,7 @@ class ConformerCTCTrainStep:
         act2 = ops.conv2d_3x3s2_nhwc(act1, fp.w("conv2_w").view(d, 3, 3, d), fp.p("conv2_b"), relu=True)
         _, t2, f2, c = act2.shape
         m = b * t2
+        self._t2_cur = t2
         self._dw_cur = self._dw_plan_for(m)
         if xs_masks.shape[-1] != t2:
             raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(xs_masks.shape)))
@@ -645,7 +675,11 @@ class ConformerCTCTrainStep:
             d_enc = self._dX(dlog, "ctc_w", residual=d_mem, out_dtype=f32, out=d_mem)
         g = torch.empty((m, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
-        dpos_all = torch.zeros((t2, L * d), dtype=f32, device=self.dev)
+        if self.fused and self._dw_cur is not None:
+            dpos_all = self._dw_cur["dpos_all"]
+            dpos_all.zero_()
+        else:
+            dpos_all = torch.zeros((t2, L * d), dtype=f32, device=self.dev)
         if self.fused:
             self._blocks_backward_fused(g, tape, dpos_all, ctx_)
         else:
@@ -828,8 +862,9 @@ class ConformerCTCTrainStep:
             A = T["mha"]
             self._dW(do, A["ctx"], pre + "o_w", pre + "o_b")
             dctx = K.dense_plain(do, PK("o_w.tk"), d, d)
+            # (dpos / du / dv: the partial sums stay in the plan's workspace and are added by the block's reduction launch)
             dqkv = K.attention_bwd(A["qkv"], pos_all[:, li * d:(li + 1) * d], P("u"), P("v"), att_mask, A["ctx"], dctx, A["lse"], b, t2,
-                                   dpos_all[:, li * d:(li + 1) * d], G("u"), G("v"), self.heads, d // self.heads)
+                                   None, None, None, self.heads, d // self.heads, ws=self._dw_cur["att_ws"])
             self._dW(dqkv, A["a"], pre + "qkv_w", pre + "qkv_b")
             da = K.dense_plain(dqkv, PK("qkv_w.tr"), d, 3 * d)
             _, dy = K.layernorm_bwd_next(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"),

@@ -295,20 +295,23 @@ def attention_fwd(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64):
     return ctx, lse
 
 
-def attention_bwd(qkv, pos, bias_u, bias_v, mask, ctx, dctx, lse, batch, T, dpos, dbias_u, dbias_v, heads=4, d_k=64):
-    """-> dqkv (B*T, 768) bf16; dpos (T, 256), dbias_u/v (H, 64) float32 accumulate."""
+def attention_bwd(qkv, pos, bias_u, bias_v, mask, ctx, dctx, lse, batch, T, dpos, dbias_u, dbias_v, heads=4, d_k=64, ws=None):
+    """-> dqkv (B*T, 768) bf16; dpos (T, 256), dbias_u/v (H, 64) float32 accumulate - or, with dpos = None and a caller-owned
+    workspace `ws`, the partial sums stay in `ws` for the caller's batched reduction (ma_relpos_attention_bwd_layout)."""
     t = _t()
     lib = _lib.load()
     dqkv = t.empty((batch * T, 3 * heads * d_k), dtype=t.bfloat16, device=qkv.device)
     ws_bytes = lib.ma_relpos_attention_bwd_workspace_bytes(batch, T, heads, d_k)
-    ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
+    if ws is None:
+        ws = t.empty(ws_bytes, dtype=t.uint8, device=qkv.device)
+    ws_bytes = ws.numel() * ws.element_size()
     fn = lib.ma_relpos_attention_bwd_bf16
     if mask is not None and mask.dim() == 3:
         assert tuple(mask.shape) == (batch, T, T) and mask.dtype == t.float32 and mask.is_contiguous()
         fn = lib.ma_relpos_attention_bwd_qmask_bf16
     _lib.check(fn(_p(qkv), qkv.stride(0), _p(pos), pos.stride(0), _p(bias_u), _p(bias_v), _p(mask), _p(ctx), ctx.stride(0),
-                  _p(dctx), dctx.stride(0), _p(lse), batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos), dpos.stride(0),
-                  _p(dbias_u), _p(dbias_v), _p(ws), ws_bytes, _s()), "attention_bwd")
+                  _p(dctx), dctx.stride(0), _p(lse), batch, T, heads, d_k, _p(dqkv), dqkv.stride(0), _p(dpos),
+                  dpos.stride(0) if dpos is not None else 0, _p(dbias_u), _p(dbias_v), _p(ws), ws_bytes, _s()), "attention_bwd")
     return dqkv
 
 

@@ -44,6 +44,10 @@ def test_bucketed_allreduce_through_rccl_at_world_1_leaves_the_step_bit_identica
     assert "force_collective" not in without["train_dp"]
     assert with_cc["train_dp"]["last_loss"] == without["train_dp"]["last_loss"]
     assert with_cc["train_dp"]["masters_sha16"] == without["train_dp"]["masters_sha16"], (with_cc["train_dp"], without["train_dp"])
+    # the all-reduce-alone leg (bus bandwidth, exposed communication) runs too: 14 buckets, 138 MB; at world 1 the ring factor is 0
+    ar = with_cc["train_dp"]["allreduce"]
+    assert ar["buckets"] == 14 and ar["bytes"] == with_cc["train_dp"]["grad_bytes"] and ar["ms"] > 0 and ar["bus_GBps"] == 0.0
+    assert "exposed_comm_ms" in with_cc["train_dp"]
     # the roofline object of the training step is in the line
     r = with_cc["train_dp"]["roofline"]
     assert r["bound"] == "mfma" and 2.5e12 < r["algorithmic_flops_per_step"] < 3.2e12 and 0 < r["frac"] < 1

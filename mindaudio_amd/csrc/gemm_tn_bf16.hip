@@ -330,8 +330,15 @@ __global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ma_reduce_it
   const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x) * 4;
   if (i0 >= it.mn) return;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-  for (int k = 0; k < it.splits; ++k) {
+  int k = 0;
+  for (; k + 8 <= it.splits; k += 8) {  // eight partials in flight (the partials are cold: written by GEMMs many launches ago)
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = load4(k + u, i0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+  }
+  for (; k < it.splits; ++k) {
     const float4 v = load4(k, i0);
     sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
   }

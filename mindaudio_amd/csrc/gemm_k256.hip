@@ -469,47 +469,6 @@ extern "C" int ma_gemm_k256_packed_ln_bf16(const void* A, int64_t lda, const voi
   return g2_launch(A, lda, packed, out, ldo, M, N, K, epi, ln_gamma, ln_beta, ln_eps, ln_row_scale, ln_out, ld_ln, stream);
 }
 
-static int train_epi_fill(const ma_train_epilogue_t* epi, int64_t M, int64_t N, TrainEpi& e) {
-  if (!epi || epi->mode < 1 || epi->mode > 4 || epi->p < 0.0f || epi->p >= 1.0f) return MA_ERR_INVALID_ARG;
-  e.mode = epi->mode;
-  e.bias = epi->bias;
-  e.aux = reinterpret_cast<const uint16_t*>(epi->aux);
-  e.ld_aux = epi->ld_aux;
-  e.out2 = epi->out2;
-  e.ldo2 = epi->ldo2;
-  e.residual = epi->residual;
-  e.ldr = epi->ldr;
-  e.row_scale = epi->row_scale;
-  e.alpha = epi->alpha;
-  e.drop = make_drop(epi->p, epi->seed, epi->salt);
-  e.ln_g1 = epi->ln_gamma1; e.ln_b1 = epi->ln_beta1; e.ln_g2 = epi->ln_gamma2; e.ln_b2 = epi->ln_beta2;
-  e.ln_row_scale = epi->ln_row_scale;
-  e.ln_out = epi->ln_out;
-  e.ln_mid = epi->ln_mid;
-  e.ld_ln = epi->ld_ln;
-  e.ld_mid = epi->ld_mid;
-  e.eps = epi->ln_eps;
-  e.ln_out_bf16 = epi->ln_out_bf16;
-  if (e.bias && (reinterpret_cast<uintptr_t>(e.bias) & 15)) return MA_ERR_INVALID_ARG;
-  if (e.mode == 1 && (!e.out2 || e.ldo2 < N || (e.ldo2 & 7) || (reinterpret_cast<uintptr_t>(e.out2) & 15))) return MA_ERR_INVALID_ARG;
-  if (e.mode == 2 && (!e.aux || e.ld_aux < N || (e.ld_aux & 3) || (reinterpret_cast<uintptr_t>(e.aux) & 7))) return MA_ERR_INVALID_ARG;
-  if (e.mode == 3) {
-    if (N != 256) return MA_ERR_UNSUPPORTED;
-    if (e.residual && (e.ldr < N || (e.ldr & 3) || (reinterpret_cast<uintptr_t>(e.residual) & 15))) return MA_ERR_INVALID_ARG;
-    if (e.ln_g1) {
-      if (!e.ln_b1 || !e.ln_out || e.ld_ln < N || (e.ld_ln & 3)) return MA_ERR_INVALID_ARG;
-      if (e.ln_g2 && (!e.ln_b2 || !e.ln_mid || e.ld_mid < N || (e.ld_mid & 3))) return MA_ERR_INVALID_ARG;
-      if ((reinterpret_cast<uintptr_t>(e.ln_g1) | reinterpret_cast<uintptr_t>(e.ln_b1) | reinterpret_cast<uintptr_t>(e.ln_g2) |
-           reinterpret_cast<uintptr_t>(e.ln_b2) | reinterpret_cast<uintptr_t>(e.ln_out) | reinterpret_cast<uintptr_t>(e.ln_mid)) & 15)
-        return MA_ERR_INVALID_ARG;
-    } else if (e.ln_g2) {
-      return MA_ERR_INVALID_ARG;
-    }
-  }
-  (void)M;
-  return MA_OK;
-}
-
 extern "C" int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N,
                                        const ma_train_epilogue_t* epi, ma_stream_t stream) {
   if (!A || !packed || !out || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;

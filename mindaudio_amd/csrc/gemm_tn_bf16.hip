@@ -363,7 +363,9 @@ static int tn_plan(int64_t Mo, int64_t No, int64_t Kc, int* bm, int* kt_split) {
   const int64_t tiles = ((Mo + *bm - 1) / *bm) * ((No + 127) / 128);
   const int64_t nk = (Kc + kTnBK - 1) / kTnBK;
   // as many splits as keep every workgroup in the first resident round (2 per CU): rounded DOWN - 72 tiles x 8 splits = 576
-  // workgroups ran the conv2 weight gradient as a full round plus one of 64 (710 us; 7 splits: one round)
+  // workgroups ran the conv2 weight gradient as a full round plus one of 64 (710 us; 7 splits: one round).  One workgroup per CU
+  // (half the partial-sum traffic: the block's batched sum 41 -> 36 us) costs more in the products than it saves (FFN-size weight
+  // gradients 25 -> 30 us, conv2 498 -> 940 us; step 12.7 -> 13.4 ms, round 3).
   int64_t splits = (2 * tn_cus()) / tiles;
   if (splits > nk / 8) splits = nk / 8;
   if (splits < 1) splits = 1;

@@ -10,8 +10,12 @@
 //     (16 accumulator tiles);
 //   * every weight fragment has one consumer, so the weight streams L2 -> registers from a fragment-ordered packed copy through a
 //     24-slot register ring, THREE K-chunks (96 MFMAs) ahead of its use - one wave per SIMD, nothing else hides the L2 latency;
-//   * the activation tile (64 rows x 64 k = 8 KiB per K-chunk) goes HBM/L2 -> LDS with global_load_lds_dwordx4 into a 3-stage
-//     ring two chunks ahead; one counted s_waitcnt vmcnt + one raw barrier per chunk.
+//   * the activation tile (64 rows x 64 k = 8 KiB per K-chunk) goes HBM/L2 -> LDS with global_load_lds_dwordx4, issued by a FIFTH
+//     wave that does nothing else (round 3), into an 8-stage ring six chunks ahead; one raw barrier per chunk.  vmcnt retires a
+//     wave's loads in issue order, so while the MFMA waves issued the activation loads themselves a weight fragment's wait also
+//     waited for every activation load in front of it and the activation's lookahead could not exceed the weight ring's three chunks:
+//     fine when the activation is cache-resident, 1.8 x slower when it comes from HBM (which is where the previous launch's output is:
+//     K = 2048, M = 10 200: 19 us hot, 35 us after a 256 MiB fill; tools/stride_probe.py).  The loader wave has its own counter.
 // With hot caches the launch is bound by the L2 -> CU path (every CU pulls the whole 2.5 MB weight): 41 us.  Inside the encoder
 // the 155 MB activation comes from HBM and the launch takes 65 us.  Measured and dropped: an 8-stage activation ring six chunks
 // ahead (no change: vmcnt retires loads in issue order, so a weight fragment's wait three chunks later also waits for every
@@ -50,9 +54,10 @@ __device__ __forceinline__ void rp_static_for(F&& f) {
   rp_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-constexpr int kRpRows = 64, kRpN = 256, kRpThreads = 256;
+constexpr int kRpRows = 64, kRpN = 256, kRpThreads = 320;  // 4 MFMA waves + the activation-loader wave
 constexpr int kRpStage = kRpRows * 128;  // 8 KiB: 64 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
-constexpr int kRpLds = 3 * kRpStage;
+constexpr int kRpStages = 8, kRpAhead = 6;
+constexpr int kRpLds = kRpStages * kRpStage;
 
 struct RowsPackedParams {
   const uint16_t* a;  // (M, K) bf16
@@ -81,8 +86,7 @@ __global__ void rows_pack_kernel(const uint16_t* __restrict__ w, int64_t ldw, in
 // w_2 / input-gradient layers of the Conformer block, K = 2048, 768, 512): MODE 3 = train_epi_rows256 (residual + dropout +
 // LayerNorm chain, float32 out), MODE 4 = out bf16 = acc + bias.
 // MT = 16-row tiles per workgroup: 4 (64 rows), or 3 (48 rows) when 64-row tiles would leave a third of the CUs without a workgroup
-// (the training step's M = 10 200 rows: 160 workgroups of 64 rows on 256 CUs, 213 of 48).  The 48-row form stages the same 64-row LDS
-// tile (rows past the 48th are fetched and not used: every wave keeps its two LDS-DMA loads per chunk, so the counted waits hold).
+// (the training step's M = 10 200 rows: 160 workgroups of 64 rows on 256 CUs, 213 of 48; the loader wave then brings 48 rows).
 template <int MODE, int MT = 4>
 __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPackedParams p, const TrainEpi e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -93,23 +97,37 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
   const int nch = p.nchunks;                 // K / 64: activation chunks that exist
   const int nch_pad = (nch + 2) / 3 * 3;     // chunks the loop runs: the packed weight is zero beyond nch, the activation chunk index is clamped
 
-  // ---- activation sources of the 2 LDS-DMA instructions of this wave (rows 8 (wave + 4 i) + (lane >> 3)) ----------------------
-  const int lr = lane >> 3;
-  const int kc_src = (lane & 7) ^ lr;  // source-side swizzle: LDS slot (lane & 7) of row lr holds logical chunk slot ^ lr
-  const uint16_t* a_src[2];
+  // ---- wave 4: the activation loader.  Instruction i of a chunk brings rows 8 i + (lane >> 3) (2 MT instructions of 1 KiB) -----
+  if (wave == 4) {
+    constexpr int NI = 2 * MT;
+    const int lr = lane >> 3;
+    const int kc_src = (lane & 7) ^ lr;  // source-side swizzle: LDS slot (lane & 7) of row lr holds logical chunk slot ^ lr
+    const uint16_t* a_src[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int m = m0 + 8 * (wave + 4 * i) + lr;
-    if (m >= p.M) m = p.M - 1;
-    a_src[i] = p.a + (int64_t)m * p.lda + kc_src * 8;
+    for (int i = 0; i < NI; ++i) {
+      int m = m0 + 8 * i + lr;
+      if (m >= p.M) m = p.M - 1;
+      a_src[i] = p.a + (int64_t)m * p.lda + kc_src * 8;
+    }
+    auto issue_a = [&](int chunk) __attribute__((always_inline)) {
+      // padded chunks (times a zero weight) and the kRpAhead chunks past the end re-read the last one, so that the count below holds
+      const int cc = chunk < nch ? chunk : nch - 1;
+      char* st = smem + (chunk & (kRpStages - 1)) * kRpStage;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_global_load_lds((gl_void_t*)(a_src[i] + (int64_t)cc * 64), (lds_void_t*)(st + i * 1024), 16, 0, 0);
+    };
+    for (int ch = 0; ch < kRpAhead; ++ch) issue_a(ch);
+    for (int ch = 0; ch < nch_pad; ++ch) {
+      // chunk ch landed <=> at most the kRpAhead - 1 younger chunks are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRpAhead - 1) * NI) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_a(ch + kRpAhead);  // stage of chunk ch - 2: every MFMA wave is past its reads
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing of this wave lands in the epilogue's scratch
+    if constexpr (MODE == 3) __builtin_amdgcn_s_barrier();      // the MFMA waves' barrier in front of the epilogue
+    return;
   }
-  auto issue_a = [&](int chunk, int stage) __attribute__((always_inline)) {
-    const int cc = chunk < nch ? chunk : nch - 1;  // padded chunks re-read the last one (times a zero weight); past the end: a duplicate
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gl_void_t*)(a_src[i] + (int64_t)cc * 64),
-                                       (lds_void_t*)(smem + stage * kRpStage + (wave + 4 * i) * 1024), 16, 0, 0);
-  };
   // ---- weight fragments: SGPR chunk base + lane offset, 8 per chunk, three chunks of ring ----------------------------------------
   const uint32_t voff = lane * 16 + 4096;
   const char* wbase = reinterpret_cast<const char*>(p.wp) + (int64_t)wave * nch_pad * 8192;
@@ -130,30 +148,24 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
   const uint32_t a_addr0 = (uint32_t)(uintptr_t)(lds_void_t*)(smem + c * 128 + ((g ^ (c & 7)) << 4));
   const uint32_t a_addr1 = a_addr0 ^ 64u;
 
-  // prologue: the weights of chunks 0..2, then the activation chunks 0 and 1
+  // prologue: the weights of chunks 0..2
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     RP_LOAD(ring[r][0], r, 0); RP_LOAD(ring[r][1], r, 1); RP_LOAD(ring[r][2], r, 2); RP_LOAD(ring[r][3], r, 3);
     RP_LOAD(ring[r][4], r, 4); RP_LOAD(ring[r][5], r, 5); RP_LOAD(ring[r][6], r, 6); RP_LOAD(ring[r][7], r, 7);
   }
-  issue_a(0, 0);
-  issue_a(1, 1);
 
-  // Loads of a wave, oldest first, in the steady state:
-  //   ... W(c)[q..7] | A(c)x2 W(c+1)x8 | A(c+1)x2 W(c+2)x8 | A(c+2)x2 W(c+3)[0..q-1] ...
-  //   (A(c+2) is issued at the start of chunk c, W(c+3)[q] right after the last MFMA that reads ring[c % 3][q] in chunk c.)
-  //   start of chunk c >= 2: A(c) landed  <=>  at most W(c+1)x8 + A(c+1)x2 + W(c+2)x8 = 18 younger loads outstanding -> vmcnt(18);
-  //   chunk 0: only A(1)x2 is younger -> vmcnt(2); chunk 1: A(2)x2 + W(3)x8 -> vmcnt(10);
-  //   use of ring[.][q] in chunk c: younger = (7 - q) + 10 + 10 + 2 + q = 29 -> vmcnt(29) (more in chunks 0..2: waits for less).
-  auto chunk_step = [&](auto jc, auto wc, int chunk) __attribute__((always_inline)) {
+  // Loads of an MFMA wave, oldest first, in the steady state: ... W(c)[q..7] | W(c+1)x8 | W(c+2)x8 | W(c+3)[0..q-1] ... (W(c+3)[q] is
+  // issued right after the last MFMA that reads ring[c % 3][q] in chunk c): use of ring[.][q] in chunk c: younger = (7 - q) + 8 + 8 + q
+  // = 23 -> vmcnt(23) (in chunks 0..2 as well).
+  auto chunk_step = [&](auto jc, int chunk) __attribute__((always_inline)) {
     constexpr int ST = decltype(jc)::value;
-    constexpr int kAWait = decltype(wc)::value;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAWait) : "memory");
-    __builtin_amdgcn_s_barrier();
-    issue_a(chunk + 2, (ST + 2) % 3);  // the stage chunk - 1 used: every wave is past its reads (barrier above)
+    __builtin_amdgcn_s_barrier();  // the loader wave has seen chunk `chunk` land
+    const uint32_t st_off = (uint32_t)(chunk & (kRpStages - 1)) * kRpStage;
+    const uint32_t sa0 = a_addr0 + st_off, sa1 = a_addr1 + st_off;
     bf16x8 af[2][MT];
 #define RP_LDS(kk_, s_)                                                                                        \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kk_][s_]) : "v"(kk_ ? a_addr1 : a_addr0), "n"(ST * kRpStage + (s_) * 2048) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kk_][s_]) : "v"(kk_ ? sa1 : sa0), "n"((s_) * 2048) \
                : "memory")
     RP_LDS(0, 0); RP_LDS(0, 1); RP_LDS(0, 2);
     if constexpr (MT == 4) RP_LDS(0, 3);
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
       rp_static_for<4>([&](auto tc) __attribute__((always_inline)) {
         constexpr int jt = decltype(tc)::value;
         constexpr int q = kk * 4 + jt;
-        asm volatile("s_waitcnt vmcnt(29)" : "+v"(ring[ST][q])::"memory");
+        asm volatile("s_waitcnt vmcnt(23)" : "+v"(ring[ST][q])::"memory");
         __builtin_amdgcn_sched_barrier(0);
         rp_static_for<MT>([&](auto sc) __attribute__((always_inline)) {
           constexpr int s = decltype(sc)::value;
@@ -183,21 +195,15 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
       });
     });
   };
-  using W2 = std::integral_constant<int, 2>;
-  using W10 = std::integral_constant<int, 10>;
-  using W18 = std::integral_constant<int, 18>;
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
-  chunk_step(S0{}, W2{}, 0);
-  chunk_step(S1{}, W10{}, 1);
-  chunk_step(S2{}, W18{}, 2);
   // (no tail code: a chunk step behind a branch leaves its refills with no later use, their registers are handed out again and the
   // loads still in flight land in somebody else's values; hence the zero-padded weight and a loop of whole ring periods)
-  for (int c3 = 3; c3 < nch_pad; c3 += 3) {
-    chunk_step(S0{}, W18{}, c3);
-    chunk_step(S1{}, W18{}, c3 + 1);
-    chunk_step(S2{}, W18{}, c3 + 2);
+  for (int c3 = 0; c3 < nch_pad; c3 += 3) {
+    chunk_step(S0{}, c3);
+    chunk_step(S1{}, c3 + 1);
+    chunk_step(S2{}, c3 + 2);
   }
   // the duplicate loads past the last chunk: the ring registers stay reserved until they have landed
   asm volatile("s_waitcnt vmcnt(0)"

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/mindaudio_amd.h"
+
 namespace ma {
 
 // Counter-based dropout: the keep decision of element `idx` of dropout site `salt` at step seed `seed` is a pure
@@ -84,6 +86,49 @@ struct TrainEpi {
   float eps;
   int32_t ln_out_bf16;
 };
+
+// host side: the public epilogue description -> TrainEpi, with the checks common to the entry points that take one (N = the width the
+// epilogue works on)
+inline int train_epi_fill(const ma_train_epilogue_t* epi, int64_t M, int64_t N, TrainEpi& e) {
+  if (!epi || epi->mode < 1 || epi->mode > 4 || epi->p < 0.0f || epi->p >= 1.0f) return MA_ERR_INVALID_ARG;
+  e.mode = epi->mode;
+  e.bias = epi->bias;
+  e.aux = reinterpret_cast<const uint16_t*>(epi->aux);
+  e.ld_aux = epi->ld_aux;
+  e.out2 = epi->out2;
+  e.ldo2 = epi->ldo2;
+  e.residual = epi->residual;
+  e.ldr = epi->ldr;
+  e.row_scale = epi->row_scale;
+  e.alpha = epi->alpha;
+  e.drop = make_drop(epi->p, epi->seed, epi->salt);
+  e.ln_g1 = epi->ln_gamma1; e.ln_b1 = epi->ln_beta1; e.ln_g2 = epi->ln_gamma2; e.ln_b2 = epi->ln_beta2;
+  e.ln_row_scale = epi->ln_row_scale;
+  e.ln_out = epi->ln_out;
+  e.ln_mid = epi->ln_mid;
+  e.ld_ln = epi->ld_ln;
+  e.ld_mid = epi->ld_mid;
+  e.eps = epi->ln_eps;
+  e.ln_out_bf16 = epi->ln_out_bf16;
+  if (e.bias && (reinterpret_cast<uintptr_t>(e.bias) & 15)) return MA_ERR_INVALID_ARG;
+  if (e.mode == 1 && (!e.out2 || e.ldo2 < N || (e.ldo2 & 7) || (reinterpret_cast<uintptr_t>(e.out2) & 15))) return MA_ERR_INVALID_ARG;
+  if (e.mode == 2 && (!e.aux || e.ld_aux < N || (e.ld_aux & 3) || (reinterpret_cast<uintptr_t>(e.aux) & 7))) return MA_ERR_INVALID_ARG;
+  if (e.mode == 3) {
+    if (N != 256) return MA_ERR_UNSUPPORTED;
+    if (e.residual && (e.ldr < N || (e.ldr & 3) || (reinterpret_cast<uintptr_t>(e.residual) & 15))) return MA_ERR_INVALID_ARG;
+    if (e.ln_g1) {
+      if (!e.ln_b1 || !e.ln_out || e.ld_ln < N || (e.ld_ln & 3)) return MA_ERR_INVALID_ARG;
+      if (e.ln_g2 && (!e.ln_b2 || !e.ln_mid || e.ld_mid < N || (e.ld_mid & 3))) return MA_ERR_INVALID_ARG;
+      if ((reinterpret_cast<uintptr_t>(e.ln_g1) | reinterpret_cast<uintptr_t>(e.ln_b1) | reinterpret_cast<uintptr_t>(e.ln_g2) |
+           reinterpret_cast<uintptr_t>(e.ln_b2) | reinterpret_cast<uintptr_t>(e.ln_out) | reinterpret_cast<uintptr_t>(e.ln_mid)) & 15)
+        return MA_ERR_INVALID_ARG;
+    } else if (e.ln_g2) {
+      return MA_ERR_INVALID_ARG;
+    }
+  }
+  (void)M;
+  return MA_OK;
+}
 
 // (v_rcp_f32 instead of an IEEE division: 1 ulp, invisible after the bf16 rounding of every consumer)
 __device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }

@@ -694,6 +694,14 @@ int ma_conv2d_3x3s2_pack_bf16(const void* W, int64_t C, int64_t Cout, void* pack
 int ma_conv2d_3x3s2_packed_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* packed,
                                      int64_t Cout, const float* bias, int32_t relu, void* out, ma_stream_t stream);
 
+/* Input gradient of the same convolution without the im2col-shaped intermediate (conv2_dinput.hip; the training step's
+ * replacement for ma_gemm (dy . W) + ma_col2im_3x3s2_relu_bf16): dact (batch, H, Wd, C) bf16 = [act > 0] * conv_transpose(dy, W),
+ * dy (batch, Ho, Wo, C) bf16, wt = the TRANSPOSED weight ((kh, kw, c), co) bf16 row-major (row stride C), act (batch, H, Wd, C) bf16 or
+ * NULL (no ReLU'), zero_row = at least 128 zero bytes in device memory (the source of taps outside the output grid).  C = Cout,
+ * C % 128 == 0.  The float32 accumulator sums a position's taps (the two-launch form rounds each tap to bf16 first). */
+int ma_conv2d_3x3s2_dinput_bf16(const void* dy, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* wt, const void* act,
+                                const void* zero_row, void* dact, ma_stream_t stream);
+
 /* Dense layer with a long contraction and 256 outputs on a fragment-ordered packed copy of W (rows_packed.hip): the `out`
  * Linear(19 * 256 -> 256) of Conv2dSubsampling4 followed by x * sqrt(d) (layers/subsampling.py:46-47,76, layers/embedding.py:84):
  *   out (M, 256) float32 = alpha * (A (M, K) bf16 . W (256, K)^T + bias).

@@ -180,6 +180,7 @@ PROTOTYPES = {
                                                  f32, vp, f32, u32, u32, vp]),
     "ma_gemm_k256_train_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, ctypes.POINTER(TrainEpilogue), vp]),
     "ma_gemm_rows_train_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp, i64, ctypes.POINTER(TrainEpilogue), vp]),
+    "ma_conv2d_3x3s2_dinput_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]),
     "ma_pack_item_pieces": (i64, [i32, i64, i64]),
     "ma_pack_batch_bf16": (ctypes.c_int, [vp, vp, i32, vp]),
     "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, i32, f32, u32, u32, vp]),

@@ -476,6 +476,14 @@ class ConformerCTCTrainStep:
         dev_items, dev_map, n_blocks, _ = self._pack_plan
         _lib.check(lib.ma_pack_batch_bf16(dev_items.data_ptr(), dev_map.data_ptr(), n_blocks,
                                           torch.cuda.current_stream().cuda_stream), "pack_batch")
+        # the subsampling layer's second convolution runs on its own fragment order (conv2_packed.hip, as the evaluation forward)
+        if getattr(self, "_conv2_pk", None) is None:
+            self._conv2_pk = ops.conv2d_3x3s2_pack(self.fp.w("conv2_w").view(self.d, 3, 3, self.d))
+        elif isinstance(self._conv2_pk, torch.Tensor):
+            _lib.check(lib.ma_conv2d_3x3s2_pack_bf16(self.fp.w("conv2_w").data_ptr(), self.d, self.d, self._conv2_pk.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), "conv2 pack")
+        if self._conv2_pk is None:
+            self._conv2_pk = False  # shape not covered: the general implicit GEMM
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _salt(self, layer, site):
@@ -623,7 +631,10 @@ class ConformerCTCTrainStep:
 
         # ================= forward =================
         act1 = ops.subsample_conv1(xs, fp.p("conv1_w"), fp.p("conv1_b"), enc.cmvn_mean, enc.cmvn_istd)
-        act2 = ops.conv2d_3x3s2_nhwc(act1, fp.w("conv2_w").view(d, 3, 3, d), fp.p("conv2_b"), relu=True)
+        if self.fused and isinstance(getattr(self, "_conv2_pk", None), torch.Tensor):
+            act2 = ops.conv2d_3x3s2_packed(act1, self._conv2_pk, fp.p("conv2_b"), relu=True)
+        else:
+            act2 = ops.conv2d_3x3s2_nhwc(act1, fp.w("conv2_w").view(d, 3, 3, d), fp.p("conv2_b"), relu=True)
         _, t2, f2, c = act2.shape
         m = b * t2
         self._t2_cur = t2
@@ -693,8 +704,11 @@ class ConformerCTCTrainStep:
         K.relu_bwd(dact2, a2)
         dy2 = dact2.view(m * f2, c)
         K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"))
-        dcol = self._dX(dy2, "conv2_w")                # (B*T2*F2, 9c) bf16
-        dact1 = K.col2im_relu(dcol, act1)
+        if self.fused:
+            dact1 = K.conv2_dinput(dy2, self.wt["conv2_w"], act1)   # implicit GEMM per input-position parity class: no dcol
+        else:
+            dcol = self._dX(dy2, "conv2_w")            # (B*T2*F2, 9c) bf16
+            dact1 = K.col2im_relu(dcol, act1)
         K.conv1_dw(dact1, xs, enc.cmvn_mean, enc.cmvn_istd, fp.g("conv1_w"), fp.g("conv1_b"))
         self._embed_done()
         return loss

@@ -262,6 +262,22 @@ def col2im_relu(dcol, act):
     return dact
 
 
+_ZERO_ROWS = {}
+
+
+def conv2_dinput(dy, wt, act):
+    """dact (B, H, W, C) bf16 = relu'(act) * conv_transpose(dy (B*Ho*Wo, C), W): one implicit-GEMM launch (no dcol intermediate).
+    wt = the transposed weight ((kh, kw, c), co)."""
+    t = _t()
+    b, h, w, c = act.shape
+    z = _ZERO_ROWS.get(act.device)
+    if z is None:
+        z = _ZERO_ROWS[act.device] = t.zeros(128, dtype=t.uint8, device=act.device)
+    dact = t.empty_like(act)
+    _lib.check(_lib.load().ma_conv2d_3x3s2_dinput_bf16(_p(dy), b, h, w, c, _p(wt), _p(act), _p(z), _p(dact), _s()), "conv2_dinput")
+    return dact
+
+
 def conv1_dw(dact, x, cmvn_mean, cmvn_istd, dw, db):
     b, tt, idim = x.shape
     rw = _reduce_ws(x.device)

@@ -511,3 +511,30 @@ def test_fused_dense_layers_equal_their_unfused_launches(K):
     g_new, dg, db = gacc.clone(), torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
     _, dn = K.layernorm_bwd_next(x, ga, dyl, g_new, dg, db, (0.5, p, seed, 6, rs), row_scale=rs)
     assert torch.equal(g_new, g_ref) and torch.equal(dn, dn_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+
+
+@pytest.mark.parametrize("b,h,w,c", [(2, 21, 19, 128), (3, 24, 39, 256), (1, 3, 3, 128), (2, 8, 6, 128)])
+def test_conv2_input_gradient_as_one_implicit_gemm(K, b, h, w, c):
+    """ma_conv2d_3x3s2_dinput_bf16 (parity-class implicit GEMM) against torch's conv_transpose2d on the same bf16 operands in float32
+    (tolerance: one bf16 rounding of the result), and against the two-launch form it replaces (dy . W, then col2im + ReLU').  Even and
+    odd H / W (rows and columns that no window covers get a zero gradient), the 3 x 3 image (one window), with and without ReLU'."""
+    from mindaudio_amd import ops
+
+    g = torch.Generator().manual_seed(1000 * h + w)
+    act = bf(torch.relu(torch.randn(b, h, w, c, generator=g)))
+    ho, wo = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    dy = bf(torch.randn(b * ho * wo, c, generator=g))
+    wgt = bf(torch.randn(c, 3, 3, c, generator=g) / 30)                      # (co, kh, kw, c): the layout the step keeps
+    wt = wgt.view(c, 9 * c).t().contiguous()                                  # ((kh, kw, c), co)
+    full = F.conv_transpose2d(dy.float().view(b, ho, wo, c).permute(0, 3, 1, 2), wgt.float().permute(0, 3, 1, 2), stride=2)
+    want = torch.zeros(b, c, h, w)
+    want[:, :, :full.shape[2], :full.shape[3]] = full[:, :, :h, :w]
+    want = want.permute(0, 2, 3, 1)
+    got_nomask = K.conv2_dinput(dy.cuda(), wt.cuda(), act.cuda())              # with ReLU'
+    assert rel(got_nomask, bf(want * (act.float() > 0)).float()) < 3e-3
+    assert torch.equal(got_nomask.cpu() == 0, ((want * (act.float() > 0)) == 0) | (got_nomask.cpu() == 0))
+    assert float(got_nomask.float().cpu()[act.float() <= 0].abs().max()) == 0.0
+    # the two-launch form: same value up to its extra bf16 rounding of every tap
+    dcol = ops.gemm(dy.cuda(), wt.cuda())
+    two = K.col2im_relu(dcol, act.cuda())
+    assert rel(got_nomask, two.float().cpu()) < 8e-3

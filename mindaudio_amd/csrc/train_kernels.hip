@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
 // z[b,t,c] = bias[c] + sum_j w[c][j] * glu(y)[b, t + j - pad, c] (zero outside [0, T)), float32; per-channel sums of z
 // and z^2 for the batch statistics.  Workgroup = (utterance, kCfPerBlock strips of 16 frames) x 256 channels (thread =
 // channel): glu of the strip + halo goes through LDS once (the sigmoid is evaluated once per element, not once per tap).
+constexpr int kCvLoadRows = 10;  // rows of a strip + halo loaded per batch (convmid_fwd_train_kernel, convmid_bwd_kernel)
 constexpr int kCfStrip = 16, kCfPerBlock = 2;  // (4: 160 workgroups for the cfg-4 batch, 40 us; 2: 320, 28 us; 1: 29 us)
 template <int KS, typename AT>
 __global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const AT* __restrict__ y, int64_t ldy, int T, int C,
@@ -393,14 +394,22 @@ __global__ __launch_bounds__(256) void convmid_fwd_train_kernel(const AT* __rest
   for (int sidx = 0; sidx < kCfPerBlock; ++sidx) {
     const int t0 = (blockIdx.x * kCfPerBlock + sidx) * kCfStrip;
     if (t0 >= T) break;
-    for (int r = 0; r < kRows; ++r) {
-      const int t = t0 - pad + r;
-      float sv = 0.0f;
-      if (t >= 0 && t < T) {
+    // (rows in batches of kCvLoadRows with clamped, unconditional addresses: every load of a batch is in flight before the first
+    // sigmoid - as a loop of guarded loads each row was a dependent round trip and the launch was latency-bound, round 3)
+    for (int r0 = 0; r0 < kRows; r0 += kCvLoadRows) {
+      float av[kCvLoadRows], gv[kCvLoadRows];
+#pragma unroll
+      for (int u = 0; u < kCvLoadRows; ++u) {
+        const int t = min(max(t0 - pad + r0 + u, 0), T - 1);
         const AT* yp = y + (base + t) * ldy + c;
-        sv = ldact(yp) * sigm<AT>(ldact(yp + C));
+        av[u] = ldact(yp);
+        gv[u] = ldact(yp + C);
       }
-      s_t[r * 256 + tid] = sv;  // a thread only reads its own column: no barrier needed
+#pragma unroll
+      for (int u = 0; u < kCvLoadRows; ++u) {
+        const int t = t0 - pad + r0 + u;
+        if (r0 + u < kRows) s_t[(r0 + u) * 256 + tid] = (t >= 0 && t < T) ? av[u] * sigm<AT>(gv[u]) : 0.0f;  // own column: no barrier
+      }
     }
     const int t1 = min(T, t0 + kCfStrip);
     for (int t = t0; t < t1; ++t) {
@@ -586,6 +595,7 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
   extern __shared__ float cb_lds[];
   float* s_t = cb_lds;                // [kRows][256] glu(y)
   float* z_t = cb_lds + kRows * 256;  // [kRows][256] dz
+  float* g_t = cb_lds + 2 * kRows * 256;  // [kCbStrip][256] sigmoid(y[:, C:]) of the strip's own rows
   const int tid = threadIdx.x;
   const int c = tid;
   const int b = blockIdx.y;
@@ -599,16 +609,26 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
   for (int sidx = 0; sidx < per_block; ++sidx) {
   const int t0 = (blockIdx.x * per_block + sidx) * kCbStrip;
   if (t0 >= T) break;
-  for (int r = 0; r < kRows; ++r) {
-    const int t = t0 - pad + r;
-    float sv = 0.0f, zv = 0.0f;
-    if (t >= 0 && t < T) {
+  for (int r0 = 0; r0 < kRows; r0 += kCvLoadRows) {  // batched loads, as in convmid_fwd_train_kernel
+    float av[kCvLoadRows], gv[kCvLoadRows], zv[kCvLoadRows];
+#pragma unroll
+    for (int u = 0; u < kCvLoadRows; ++u) {
+      const int t = min(max(t0 - pad + r0 + u, 0), T - 1);
       const AT* yp = y + (base + t) * ldy + c;
-      sv = ldact(yp) * sigm<AT>(ldact(yp + C));
-      zv = dz[(base + t) * C + c];
+      av[u] = ldact(yp);
+      gv[u] = ldact(yp + C);
+      zv[u] = dz[(base + t) * C + c];
     }
-    s_t[r * 256 + tid] = sv;
-    z_t[r * 256 + tid] = zv;
+#pragma unroll
+    for (int u = 0; u < kCvLoadRows; ++u) {
+      const int r = r0 + u, t = t0 - pad + r;
+      if (r >= kRows) continue;
+      const bool in = t >= 0 && t < T;
+      const float sg = sigm<AT>(gv[u]);
+      s_t[r * 256 + tid] = in ? av[u] * sg : 0.0f;
+      z_t[r * 256 + tid] = in ? zv[u] : 0.0f;
+      if (r >= pad && r < pad + kCbStrip) g_t[(r - pad) * 256 + tid] = sg;  // the strip's own rows: for the GLU backward below
+    }
   }
   // (each thread only reads its own column: no barrier needed)
   const int t1 = min(T, t0 + kCbStrip);
@@ -622,10 +642,9 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
       ds = fmaf(wr[j], z_t[(r - (j - pad)) * 256 + tid], ds);      // z[t - (j - pad)] used s[t] with tap j
       dwr[j] = fmaf(dzt, s_t[(r + j - pad) * 256 + tid], dwr[j]);  // z[t] used s[t + j - pad] with tap j
     }
-    const AT* yp = y + (base + t) * ldy + c;
-    const float a = ldact(yp), sg = sigm<AT>(ldact(yp + C));
+    const float asg = s_t[r * 256 + tid], sg = g_t[(t - t0) * 256 + tid];  // a * sigmoid(g), sigmoid(g)
     stact(dy + (base + t) * lddy + c, ds * sg);
-    stact(dy + (base + t) * lddy + C + c, ds * a * sg * (1.0f - sg));
+    stact(dy + (base + t) * lddy + C + c, ds * asg * (1.0f - sg));
   }
   }
   // per-workgroup partial (dw (C, KS) | db (C)); summed by partial_reduce_kernel
@@ -1188,9 +1207,9 @@ static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t
   const int nblk = (int)(grid.x * grid.y), width = C * (ks + 1);
 #define MA_CMB(KS_)                                                                                                    \
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_bwd_kernel<KS_, AT>),                                 \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (kCbStrip + KS_ - 1) * 256 * 4) != hipSuccess) \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (kCbStrip + KS_ - 1) + kCbStrip) * 256 * 4) != hipSuccess)     \
     return MA_ERR_LAUNCH;                                                                                              \
-  MA_LAUNCH((convmid_bwd_kernel<KS_, AT>), grid, dim3(256), (size_t)2 * (kCbStrip + KS_ - 1) * 256 * sizeof(float),    \
+  MA_LAUNCH((convmid_bwd_kernel<KS_, AT>), grid, dim3(256), (size_t)(2 * (kCbStrip + KS_ - 1) + kCbStrip) * 256 * sizeof(float),   \
             (hipStream_t)stream, dz, y, ldy, (int)batch, (int)T, C, dw_w, dy, lddy, part, per_block)
   if (ks == 3) { MA_CMB(3); }
   else if (ks == 7) { MA_CMB(7); }

@@ -117,6 +117,17 @@ class BucketedAllReduce:
         return covered
 
 
+class _PoolEvent:
+    __slots__ = ("ev",)
+
+    def __init__(self):
+        self.ev = torch.cuda.Event()
+
+    def record_on_main(self):
+        self.ev.record()
+        return self.ev
+
+
 _LAYER_W = (("ffm_w1", "feed_forward_macaron.w_1"), ("ffm_w2", "feed_forward_macaron.w_2"),
             ("o_w", "self_attn.linear_out"), ("ff_w1", "feed_forward.w_1"), ("ff_w2", "feed_forward.w_2"))
 _LAYER_LN = ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final")
@@ -180,7 +191,7 @@ class ConformerCTCTrainStep:
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
                  process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None,
-                 force_collective=False, fused=True):
+                 force_collective=False, fused=True, wg_stream=True):
         """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
         torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
         activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
@@ -192,9 +203,18 @@ class ConformerCTCTrainStep:
         # residual + dropout + LayerNorm, Swish' + dropout, the next branch's dropout backward) in the launch's epilogue;
         # False = one launch per reference cell (what the float32 validation mode always runs)
         self.fused = bool(fused) and not self.x32
+        # The weight-gradient products of the blocks (and the block's batched sum, and its gradient bucket's all-reduce) run on a
+        # second stream beside the input-gradient chain they do not feed: both are latency-bound launches of ~1 workgroup per CU.
+        self._wg_on = bool(wg_stream) and self.fused
+        self._wg, self._wg_keep, self._wg_pool, self._wg_next, self._wg_done, self._dw_par = None, [], [], 0, {}, 0
         self.K, self.O = (X32, X32) if self.x32 else (K, ops)
         self.model, self.enc = model, enc
         self.dev = next(model.parameters()).device
+        if self._wg_on and self.dev.type == "cuda":
+            import ctypes
+
+            self._wg = torch.cuda.Stream(device=self.dev)
+            self._wg_ptr = ctypes.c_void_p(self._wg.cuda_stream)
         self.L = len(enc.encoders)
         self.d, self.heads = enc.d, enc.heads
         self.V = model.ctc.ctc_lo.out_features
@@ -531,12 +551,16 @@ class ConformerCTCTrainStep:
         total += (att_bytes + 255) // 256 * 256
         off["dpos_all"] = (total, self._t2_cur * self.L * self.d * 4, 0)
         total += (self._t2_cur * self.L * self.d * 4 + 255) // 256 * 256
+        # Two copies of the arena, used by alternate blocks: with the weight-gradient products on their own stream (_wg) block li's
+        # partials are still being summed there while the main stream's LayerNorm / attention backward of block li - 1 write theirs.
+        half = (total + 255) // 256 * 256
         arena = self.__dict__.get("_dw_arena")
-        if arena is None or arena.numel() < total:
-            arena = self._dw_arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
+        if arena is None or arena.numel() < 2 * half:
+            arena = self._dw_arena = torch.empty(2 * half, dtype=torch.uint8, device=self.dev)
         layers = []
         for li in range(self.L):
             items, block_item, first = [], [], 0
+            base = arena.data_ptr() + (li & 1) * half
 
             def add(part_ptr, out, mn, ldo, n_cols, splits, pstride, tall):
                 nonlocal first
@@ -551,30 +575,30 @@ class ConformerCTCTrainStep:
                 gb = fp.g("l%d.%s" % (li, sfx.replace("_w", "_b")))
                 mo, no = g.shape
                 o, nbytes, splits = off[sfx]
-                add(arena.data_ptr() + o, g, mo * no, g.stride(0), no, splits, 0, False)
-                add(arena.data_ptr() + o + splits * mo * no * 4, gb, mo, mo, mo, splits, 0, False)   # bias: partial column sums
+                add(base + o, g, mo * no, g.stride(0), no, splits, 0, False)
+                add(base + o + splits * mo * no * 4, gb, mo, mo, mo, splits, 0, False)   # bias: partial column sums
             for site in self._LN_SITES:
                 o, nbytes, parts = off[site]
                 gg = fp.g("l%d.%s.g" % (li, site))  # (g | b): 2 x 256 contiguous floats of the flat gradient
                 assert fp.index["l%d.%s.b" % (li, site)][0] == fp.index["l%d.%s.g" % (li, site)][0] + 256
-                add(arena.data_ptr() + o, gg, 512, 512, 512, parts, 512, True)
+                add(base + o, gg, 512, 512, 512, parts, 512, True)
             if self.fused:
                 t2, d, dk = self._t2_cur, self.d, self.d // self.heads
-                ws_ptr = arena.data_ptr() + off["att_ws"][0]
+                ws_ptr = base + off["att_ws"][0]
                 dpos_l = arena[off["dpos_all"][0]:off["dpos_all"][0] + off["dpos_all"][1]].view(torch.float32).view(t2, self.L * d)
                 # dpos[t][c] of block li += sum over the batch of dp_part[b][t][c]
                 add(ws_ptr + dp_off.value * 4, dpos_l[:, li * d:(li + 1) * d], t2 * d, self.L * d, d, b_att, tp_.value * d, False)
                 for h in range(self.heads):  # du[h], dv[h] += sum over the (utterance, query block) partials of head h
-                    base = ws_ptr + (bias_off.value + h * pph.value * 128) * 4
-                    add(base, fp.g("l%d.u" % li)[h], dk, dk, dk, pph.value, 128, True)
-                    add(base + dk * 4, fp.g("l%d.v" % li)[h], dk, dk, dk, pph.value, 128, True)
+                    hb = ws_ptr + (bias_off.value + h * pph.value * 128) * 4
+                    add(hb, fp.g("l%d.u" % li)[h], dk, dk, dk, pph.value, 128, True)
+                    add(hb + dk * 4, fp.g("l%d.v" % li)[h], dk, dk, dk, pph.value, 128, True)
             raw = (_lib.ReduceItem * len(items))(*items)
             layers.append((torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
                            torch.tensor(block_item, dtype=torch.int32, device=self.dev), first))
-        self._dw_plan = dict(m=m, t2=self._t2_cur, arena=arena, off=off, layers=layers)
+        self._dw_plan = dict(m=m, t2=self._t2_cur, arena=arena, off=off, layers=layers, half=half)
         if self.fused:
             o, nb, _ = off["att_ws"]
-            self._dw_plan["att_ws"] = arena[o:o + nb]
+            self._dw_plan["att_ws"] = (arena[o:o + nb], arena[half + o:half + o + nb])
             o, nb, _ = off["dpos_all"]
             self._dw_plan["dpos_all"] = arena[o:o + nb].view(torch.float32).view(self._t2_cur, self.L * self.d)
         return self._dw_plan
@@ -585,6 +609,7 @@ class ConformerCTCTrainStep:
         if plan is None:
             return None
         o, nbytes, _ = plan["off"][site]
+        o += self._dw_par * plan["half"]
         return plan["arena"][o:o + nbytes].view(torch.float32)
 
     def _dW(self, dy, x, wname, bname):
@@ -595,6 +620,17 @@ class ConformerCTCTrainStep:
             sfx = wname.split(".", 1)[1]
             if sfx in plan["off"]:
                 o, nbytes, _ = plan["off"][sfx]
+                o += self._dw_par * plan["half"]
+                if self._wg is not None:
+                    # on the weight-gradient stream, behind everything the main stream has enqueued so far (dy and x are ready there)
+                    self._wg.wait_event(self._wg_event().record_on_main())
+                    prev, _host._pinned_stream = _host._pinned_stream, self._wg_ptr
+                    try:
+                        self.K.gemm_tn_partial(dy, x, plan["arena"][o:o + nbytes], with_colsum=True)
+                    finally:
+                        _host._pinned_stream = prev
+                    self._wg_keep.append((dy, x))  # (the caching allocator only orders reuse on the stream that allocated them)
+                    return
                 self.K.gemm_tn_partial(dy, x, plan["arena"][o:o + nbytes], with_colsum=True)
                 return
         self.K.gemm_tn(dy, x, fp.g(wname), colsum=fp.g(bname) if bname else None)
@@ -628,6 +664,8 @@ class ConformerCTCTrainStep:
         xs = xs_pad.to(f32).contiguous()
         enc = self.enc
         fp.grad.zero_()
+        self._wg_next = 0
+        self._wg_done.clear()
 
         # ================= forward =================
         act1 = ops.subsample_conv1(xs, fp.p("conv1_w"), fp.p("conv1_b"), enc.cmvn_mean, enc.cmvn_istd)
@@ -760,6 +798,7 @@ class ConformerCTCTrainStep:
         K = self.K
         seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         for li in reversed(range(L)):
+            self._layer_begin(li)
             pre = "l%d." % li
             W, P, G = (lambda n, pre=pre: fp.w(pre + n)), (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n))
             T = tape[li]
@@ -842,6 +881,7 @@ class ConformerCTCTrainStep:
         seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         hid = self.hidden
         for li in reversed(range(L)):
+            self._layer_begin(li)
             pre = "l%d." % li
             P, G, PK = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n)), (lambda n, pre=pre: self.pk[pre + n])
             T = tape[li]
@@ -878,7 +918,7 @@ class ConformerCTCTrainStep:
             dctx = K.dense_plain(do, PK("o_w.tk"), d, d)
             # (dpos / du / dv: the partial sums stay in the plan's workspace and are added by the block's reduction launch)
             dqkv = K.attention_bwd(A["qkv"], pos_all[:, li * d:(li + 1) * d], P("u"), P("v"), att_mask, A["ctx"], dctx, A["lse"], b, t2,
-                                   None, None, None, self.heads, d // self.heads, ws=self._dw_cur["att_ws"])
+                                   None, None, None, self.heads, d // self.heads, ws=self._dw_cur["att_ws"][self._dw_par])
             self._dW(dqkv, A["a"], pre + "qkv_w", pre + "qkv_b")
             da = K.dense_plain(dqkv, PK("qkv_w.tr"), d, 3 * d)
             _, dy = K.layernorm_bwd_next(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"),
@@ -1013,9 +1053,40 @@ class ConformerCTCTrainStep:
         plan = getattr(self, "_dw_cur", None)
         if plan is not None:  # the split sums of this block's weight gradients, one launch
             items, block_item, n_blocks = plan["layers"][li]
+            if self._wg is not None:
+                # behind the block's products on their stream AND the main stream's partials (LayerNorm / attention backward) and
+                # direct sums (depthwise convolution, BatchNorm); the bucket goes on the wire behind the sums
+                self._wg.wait_event(self._wg_event().record_on_main())
+                _lib.check(_lib.load().ma_reduce_splits_batch_f32(items.data_ptr(), block_item.data_ptr(), n_blocks,
+                                                                  self._wg.cuda_stream), "reduce_splits_batch")
+                with torch.cuda.stream(self._wg):
+                    self.reducer.launch(*self.fp.span(self.layer_names[li]))
+                done = self._wg_event()
+                done.ev.record(self._wg)
+                self._wg_done[li] = done
+                if li == 0:  # the backward pass of the blocks is over: everything behind this point sees the finished gradients
+                    torch.cuda.current_stream().wait_event(done.ev)
+                    self._wg_keep.clear()
+                return
             _lib.check(_lib.load().ma_reduce_splits_batch_f32(items.data_ptr(), block_item.data_ptr(), n_blocks,
                                                               torch.cuda.current_stream().cuda_stream), "reduce_splits_batch")
         self.reducer.launch(*self.fp.span(self.layer_names[li]))
+
+    def _layer_begin(self, li):
+        """Backward of block li starts: its partial sums go to arena half li & 1, which block li + 2 used."""
+        self._dw_par = li & 1
+        if self._wg is not None:
+            prev = self._wg_done.pop(li + 2, None)
+            if prev is not None:
+                torch.cuda.current_stream().wait_event(prev.ev)
+
+    def _wg_event(self):
+        """An event from the step's pool (events are re-recorded every step: creating one costs more than recording it)."""
+        if self._wg_next == len(self._wg_pool):
+            self._wg_pool.append(_PoolEvent())
+        e = self._wg_pool[self._wg_next]
+        self._wg_next += 1
+        return e
 
     def _embed_done(self):
         self.reducer.launch(*self.fp.span(["after_norm.g", "ctc_b"]))

@@ -392,6 +392,28 @@ def test_fused_blocks_equal_the_one_launch_per_cell_path_with_dropout():
     assert float(loss) == l1 and torch.equal(eng.fp.grad, g1)
 
 
+def test_weight_gradient_stream_changes_no_bit():
+    """The blocks' weight-gradient products, their batched sums and the gradient buckets run on a second stream (wg_stream=True, the
+    default) beside the input-gradient chain.  Same launches, same summation orders: three optimizer steps give bit-identical losses
+    and masters with the second stream on and off; a missing cross-stream dependency would show up as a changed bit (the two arena
+    halves alternate between blocks, so a block's partials would be overwritten by the next one's)."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    xs, ys, sub, ys_lens = batch()
+    cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
+    out = []
+    for wg in (False, True, True):
+        _, _, model = build(seed=9)
+        eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1, wg_stream=wg)
+        assert (eng._wg is not None) == wg
+        losses = [float(eng.step(*cols)[0]) for _ in range(3)]
+        torch.cuda.synchronize()
+        out.append((losses, eng.fp.master.clone()))
+    for losses, master in out[1:]:
+        assert losses == out[0][0]
+        assert torch.equal(master, out[0][1])
+
+
 def test_fused_engine_gradients_match_oracle_autograd():
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 

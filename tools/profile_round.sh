@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --no-sustained > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --no-sustained --no-cfg3 > $OUT/bench.log 2>&1
 for W in fbank ffnpair; do
   i=0
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
@@ -73,4 +73,4 @@ with open(out+"/roofline_kernels_trace.txt","w") as fh:
         line="%s launched alone (tools/prof_target.py %s): %d launches, kernel-trace duration mean %.1f us, min %.1f, max %.1f"%(kn,w,len(d),sum(d)/len(d),min(d),max(d))
         fh.write(line+"\n"); print(line)
 PY
-tail -1 $OUT/bench.log | cut -c1-600
+grep '^{"metric"' $OUT/bench.log | tail -1 > $OUT/bench_line.json; cut -c1-600 $OUT/bench_line.json

@@ -741,7 +741,20 @@ class ConformerCTCTrainStep:
         dact2 = self._dX(de, "out_w")                  # (m, f2*c) bf16
         K.relu_bwd(dact2, a2)
         dy2 = dact2.view(m * f2, c)
-        K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"))
+        if self._wg is not None:
+            # the weight gradient of conv2 beside its input gradient and conv1's weight gradient (all three only need dy2 / act1)
+            need = K.conv2d_dw_workspace_bytes(dy2.shape[0], c, c)
+            if getattr(self, "_wg_ws", None) is None or self._wg_ws.numel() < need:
+                self._wg_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self._wg.wait_event(self._wg_event().record_on_main())
+            prev, _host._pinned_stream = _host._pinned_stream, self._wg_ptr
+            try:
+                K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"), ws=self._wg_ws)
+            finally:
+                _host._pinned_stream = prev
+            self._wg_keep.append((dy2, act1, dact2))
+        else:
+            K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"))
         if self.fused:
             dact1 = K.conv2_dinput(dy2, self.wt["conv2_w"], act1)   # implicit GEMM per input-position parity class: no dcol
         else:
@@ -1064,9 +1077,8 @@ class ConformerCTCTrainStep:
                 done = self._wg_event()
                 done.ev.record(self._wg)
                 self._wg_done[li] = done
-                if li == 0:  # the backward pass of the blocks is over: everything behind this point sees the finished gradients
-                    torch.cuda.current_stream().wait_event(done.ev)
-                    self._wg_keep.clear()
+                if li == 0:  # the blocks are done: what follows on the main stream (dW_pos, the embed layer) reads / adds to dpos_all
+                    torch.cuda.current_stream().wait_event(done.ev)  # and to gradients in the same flat buffer
                 return
             _lib.check(_lib.load().ma_reduce_splits_batch_f32(items.data_ptr(), block_item.data_ptr(), n_blocks,
                                                               torch.cuda.current_stream().cuda_stream), "reduce_splits_batch")
@@ -1090,6 +1102,17 @@ class ConformerCTCTrainStep:
 
     def _embed_done(self):
         self.reducer.launch(*self.fp.span(["after_norm.g", "ctc_b"]))
+        if self._wg is not None:
+            # the front bucket holds conv2's weight gradient (second stream) and the main stream's sums: behind both; then the main
+            # stream continues behind everything the second stream has done in this step
+            self._wg.wait_event(self._wg_event().record_on_main())
+            with torch.cuda.stream(self._wg):
+                self.reducer.launch(*self.fp.span(self.embed_names + ["pos_w"]))
+            done = self._wg_event()
+            done.ev.record(self._wg)
+            torch.cuda.current_stream().wait_event(done.ev)
+            self._wg_keep.clear()
+            return
         self.reducer.launch(*self.fp.span(self.embed_names + ["pos_w"]))
 
     # ---- one optimizer step ------------------------------------------------------------------------------------------

@@ -88,12 +88,18 @@ def gemm_tn_partial(a, b, partial, with_colsum=False):
                                            _p(partial), partial.numel(), _s()), "gemm_tn_partial")
 
 
-def conv2d_dw(dy, act, dw, dbias):
-    """dw (Cout, 9C) f32 += dy^T @ im2col(act); dbias (Cout) += column sums.  dy (B*Ho*Wo, Cout) bf16, act NHWC bf16."""
+def conv2d_dw_workspace_bytes(rows, c, cout):
+    return int(_lib.load().ma_gemm_tn_workspace_bytes(cout, 9 * c, rows))
+
+
+def conv2d_dw(dy, act, dw, dbias, ws=None):
+    """dw (Cout, 9C) f32 += dy^T @ im2col(act); dbias (Cout) += column sums.  dy (B*Ho*Wo, Cout) bf16, act NHWC bf16.
+    ws: a private split-K workspace (uint8, >= conv2d_dw_workspace_bytes) when the call runs beside other products on another stream."""
     lib = _lib.load()
     b, h, w, c = act.shape
     cout = dy.shape[1]
-    ws = _host.workspace(lib.ma_gemm_tn_workspace_bytes(cout, 9 * c, dy.shape[0]), dy.device)
+    if ws is None:
+        ws = _host.workspace(lib.ma_gemm_tn_workspace_bytes(cout, 9 * c, dy.shape[0]), dy.device)
     _lib.check(lib.ma_conv2d_3x3s2_dw_bf16(_p(dy), dy.stride(0), _p(act), b, h, w, c, cout, _p(dw), _p(dbias), _p(ws),
                                            ws.numel(), _s()), "conv2d_dw")
 

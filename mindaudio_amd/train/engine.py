@@ -42,19 +42,30 @@ class FlatParams:
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
         # matmul-operand copy of the masters: bf16 (throughput mode) or the masters themselves (float32 validation mode)
         self.bf16 = torch.zeros(off, dtype=torch.bfloat16, device=device) if mirror_bf16 else self.master
+        self._pc, self._gc, self._wc = {}, {}, {}
 
     def _view(self, buf, name):
         off, shape, n = self.index[name]
         return buf[off:off + n].view(shape)
 
+    # (the views are cached: the flat buffers never move, and a step asks for ~600 of them)
     def p(self, name):
-        return self._view(self.master, name)
+        v = self._pc.get(name)
+        if v is None:
+            v = self._pc[name] = self._view(self.master, name)
+        return v
 
     def g(self, name):
-        return self._view(self.grad, name)
+        v = self._gc.get(name)
+        if v is None:
+            v = self._gc[name] = self._view(self.grad, name)
+        return v
 
     def w(self, name):
-        return self._view(self.bf16, name)
+        v = self._wc.get(name)
+        if v is None:
+            v = self._wc[name] = self._view(self.bf16, name)
+        return v
 
     def span(self, names):
         lo = min(self.index[n][0] for n in names)
@@ -123,8 +134,8 @@ class _PoolEvent:
     def __init__(self):
         self.ev = torch.cuda.Event()
 
-    def record_on_main(self):
-        self.ev.record()
+    def record_on(self, stream):
+        self.ev.record(stream)
         return self.ev
 
 
@@ -207,6 +218,7 @@ class ConformerCTCTrainStep:
         # second stream beside the input-gradient chain they do not feed: both are latency-bound launches of ~1 workgroup per CU.
         self._wg_on = bool(wg_stream) and self.fused
         self._wg, self._wg_keep, self._wg_pool, self._wg_next, self._wg_done, self._dw_par = None, [], [], 0, {}, 0
+        self._wg_queue, self._main = [], None
         self.K, self.O = (X32, X32) if self.x32 else (K, ops)
         self.model, self.enc = model, enc
         self.dev = next(model.parameters()).device
@@ -622,14 +634,9 @@ class ConformerCTCTrainStep:
                 o, nbytes, _ = plan["off"][sfx]
                 o += self._dw_par * plan["half"]
                 if self._wg is not None:
-                    # on the weight-gradient stream, behind everything the main stream has enqueued so far (dy and x are ready there)
-                    self._wg.wait_event(self._wg_event().record_on_main())
-                    prev, _host._pinned_stream = _host._pinned_stream, self._wg_ptr
-                    try:
-                        self.K.gemm_tn_partial(dy, x, plan["arena"][o:o + nbytes], with_colsum=True)
-                    finally:
-                        _host._pinned_stream = prev
-                    self._wg_keep.append((dy, x))  # (the caching allocator only orders reuse on the stream that allocated them)
+                    # queued: the block's products go on the weight-gradient stream together, behind one event, when its backward
+                    # pass is done (_layer_done) - one event pair per block instead of one per product on the host's critical path
+                    self._wg_queue.append((dy, x, plan["arena"][o:o + nbytes]))
                     return
                 self.K.gemm_tn_partial(dy, x, plan["arena"][o:o + nbytes], with_colsum=True)
                 return
@@ -666,6 +673,7 @@ class ConformerCTCTrainStep:
         fp.grad.zero_()
         self._wg_next = 0
         self._wg_done.clear()
+        self._main = torch.cuda.current_stream() if self._wg is not None else None
 
         # ================= forward =================
         act1 = ops.subsample_conv1(xs, fp.p("conv1_w"), fp.p("conv1_b"), enc.cmvn_mean, enc.cmvn_istd)
@@ -746,7 +754,7 @@ class ConformerCTCTrainStep:
             need = K.conv2d_dw_workspace_bytes(dy2.shape[0], c, c)
             if getattr(self, "_wg_ws", None) is None or self._wg_ws.numel() < need:
                 self._wg_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-            self._wg.wait_event(self._wg_event().record_on_main())
+            self._wg.wait_event(self._wg_event().record_on(self._main))
             prev, _host._pinned_stream = _host._pinned_stream, self._wg_ptr
             try:
                 K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"), ws=self._wg_ws)
@@ -1069,16 +1077,28 @@ class ConformerCTCTrainStep:
             if self._wg is not None:
                 # behind the block's products on their stream AND the main stream's partials (LayerNorm / attention backward) and
                 # direct sums (depthwise convolution, BatchNorm); the bucket goes on the wire behind the sums
-                self._wg.wait_event(self._wg_event().record_on_main())
+                self._wg.wait_event(self._wg_event().record_on(self._main))
+                prev, _host._pinned_stream = _host._pinned_stream, self._wg_ptr
+                try:
+                    for dy, x, part in self._wg_queue:
+                        self.K.gemm_tn_partial(dy, x, part, with_colsum=True)
+                finally:
+                    _host._pinned_stream = prev
+                # (dy / x stay referenced until the step's join: the caching allocator only orders reuse on the allocating stream)
+                self._wg_keep.extend(self._wg_queue)
+                self._wg_queue.clear()
                 _lib.check(_lib.load().ma_reduce_splits_batch_f32(items.data_ptr(), block_item.data_ptr(), n_blocks,
                                                                   self._wg.cuda_stream), "reduce_splits_batch")
-                with torch.cuda.stream(self._wg):
+                if self.reducer.world > 1 or self.reducer.force:
+                    with torch.cuda.stream(self._wg):
+                        self.reducer.launch(*self.fp.span(self.layer_names[li]))
+                else:
                     self.reducer.launch(*self.fp.span(self.layer_names[li]))
                 done = self._wg_event()
                 done.ev.record(self._wg)
                 self._wg_done[li] = done
                 if li == 0:  # the blocks are done: what follows on the main stream (dW_pos, the embed layer) reads / adds to dpos_all
-                    torch.cuda.current_stream().wait_event(done.ev)  # and to gradients in the same flat buffer
+                    self._main.wait_event(done.ev)  # and to gradients in the same flat buffer
                 return
             _lib.check(_lib.load().ma_reduce_splits_batch_f32(items.data_ptr(), block_item.data_ptr(), n_blocks,
                                                               torch.cuda.current_stream().cuda_stream), "reduce_splits_batch")
@@ -1090,7 +1110,7 @@ class ConformerCTCTrainStep:
         if self._wg is not None:
             prev = self._wg_done.pop(li + 2, None)
             if prev is not None:
-                torch.cuda.current_stream().wait_event(prev.ev)
+                self._main.wait_event(prev.ev)
 
     def _wg_event(self):
         """An event from the step's pool (events are re-recorded every step: creating one costs more than recording it)."""
@@ -1105,12 +1125,15 @@ class ConformerCTCTrainStep:
         if self._wg is not None:
             # the front bucket holds conv2's weight gradient (second stream) and the main stream's sums: behind both; then the main
             # stream continues behind everything the second stream has done in this step
-            self._wg.wait_event(self._wg_event().record_on_main())
-            with torch.cuda.stream(self._wg):
+            self._wg.wait_event(self._wg_event().record_on(self._main))
+            if self.reducer.world > 1 or self.reducer.force:
+                with torch.cuda.stream(self._wg):
+                    self.reducer.launch(*self.fp.span(self.embed_names + ["pos_w"]))
+            else:
                 self.reducer.launch(*self.fp.span(self.embed_names + ["pos_w"]))
             done = self._wg_event()
             done.ev.record(self._wg)
-            torch.cuda.current_stream().wait_event(done.ev)
+            self._main.wait_event(done.ev)
             self._wg_keep.clear()
             return
         self.reducer.launch(*self.fp.span(self.embed_names + ["pos_w"]))

@@ -618,6 +618,188 @@ extern "C" int ma_debug_g8_prof(unsigned long long* host24) {
 }
 #endif
 
+// ---- K = 512, weight-stationary persistent form (round 3) -----------------------------------------------------------------------
+// ECAPA-TDNN's 1 x 1 convolutions at C = 512 (ecapatdnn.py:117-157: tdnn1 / tdnn2 of every SERes2Net block) are M = 80 896 rows,
+// N = K = 512: on the 128 x 128 tile each of the 2 528 tiles runs 8 K-steps between a prologue and an epilogue of the same length
+// (84 us for 40 GFLOP).  Here a workgroup (4 waves, one workgroup per CU) owns 128 output columns for its whole life: wave w keeps
+// W[n0 + 32 w .. + 32][0 .. 512] in registers (32 fragments, read once from the row-major weight) and walks 32-row tiles of A:
+//   * the A tile (32 rows x 1 KiB) comes HBM/L2 -> LDS by LDS-DMA, one row per instruction, the NEXT tile while this one is
+//     multiplied (four buffers, three tiles ahead); rows are 1 KiB apart = the same banks, so 16-byte chunk p of row r holds logical chunk
+//     p ^ (r & 15) (swizzle on the source side of the DMA): the 16 rows of a fragment read hit 16 different 16-byte slots;
+//   * 64 MFMAs per wave and tile (2 row tiles x 2 column tiles x 16 k-steps), no weight traffic at all; three tiles (96 KiB) in flight
+//     per CU; the fragment reads of a tile in four chunks, chunk q + 1 in flight under the MFMAs of chunk q (asm reads, counted waits:
+//     one wave per SIMD, nobody else hides the LDS latency);
+//   * epilogue (bias, activation, BatchNorm affine, second activation, row scale - the EPI = 1 set without residual / alpha) through
+//     an LDS stage so that memory sees whole 256-byte row segments;
+//   * the four column blocks of a row tile are four workgroups of the SAME XCD (blockIdx % 8 is the XCD), so the tile is fetched
+//     into that L2 once.
+// Measured (tools/gemm512_probe.py, M = 80 896, rotating cold inputs): 79 us against 109 us for the 128 x 128 tile in the same probe
+// (85 -> 70 us inside the ECAPA forward).  By ablation: MFMAs + barriers + fragment reads 42 us (17 us of MFMA time), epilogue 6 (26
+// with the general per-fragment activation switch), tile loads + stores 20-30.  Two workgroups per CU with one tile ahead: 91 us.
+constexpr int kWsRows = 32, kWsCols = 128, kWsK = 512, kWsThreads = 256, kWsAhead = 3, kWsBufs = kWsAhead + 1;
+constexpr int kWsTile = kWsRows * kWsK * 2;                 // 32 KiB
+constexpr int kWsStagePitch = kWsCols * 2 + 16;
+constexpr int kWsOffRs = kWsBufs * kWsTile + kWsRows * kWsStagePitch;  // row scales of the tiles in flight: 256 B per buffer
+constexpr int kWsLds = kWsOffRs + kWsBufs * 256;  // 137.5 KiB: one workgroup per CU, three tiles (96 KiB) in flight
+template <bool RS>  // RS: the epilogue has a row scale; its 32 values ride with the tile (a load issued behind the tiles in flight would
+                    // have to wait for all of them: loads return in order)
+__global__ __launch_bounds__(kWsThreads, 1) void gemm_ws512_kernel(const GemmParams p) {
+  constexpr int kLoads = 8 + (RS ? 1 : 0);  // LDS-DMA instructions per wave and tile slot
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  // XCD-aware roles: workgroup b runs on XCD b % 8; inside an XCD consecutive workgroups take the column blocks of one row stream
+  const int ncb = p.N / kWsCols;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int per_xcd = gridDim.x >> 3;                  // (grid is a multiple of 8 * ncb)
+  const int cb = idx % ncb, stream_in_xcd = idx / ncb, streams_per_xcd = per_xcd / ncb;
+  const int stream = xcd * streams_per_xcd + stream_in_xcd, nstreams = 8 * streams_per_xcd;
+  const int n0 = cb * kWsCols + wave * 32;
+  const int ntiles = (p.M + kWsRows - 1) / kWsRows;
+  if (stream >= ntiles) return;
+  const int last_tile = stream + (ntiles - 1 - stream) / nstreams * nstreams;  // the stream's last tile
+
+  // ---- the wave's weight slice: lane (c, g) of fragment (jt, ks) holds W[n0 + 16 jt + c][32 ks + 8 g .. + 8] -------------------------
+  bf16x8 wf[2][16];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      wf[jt][ks] = *reinterpret_cast<const bf16x8*>(p.W + (int64_t)(n0 + 16 * jt + c) * p.ldw + 32 * ks + 8 * g);
+  float4 bv[2], cs[2], ct[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int n = n0 + 16 * jt + 4 * g;
+    bv[jt] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    cs[jt] = p.col_scale ? *reinterpret_cast<const float4*>(p.col_scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+    ct[jt] = p.col_scale ? *reinterpret_cast<const float4*>(p.col_shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int act = p.act, act2 = p.act2;
+  const bool relu_only = act == 2 && act2 == 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counted waits below see the tile loads only
+
+  // ---- A tile staging: wave w brings rows 8 w .. 8 w + 7 of a tile, one instruction per row.  Tiles past the stream's last one are
+  // duplicates of it (into a free buffer): the counted waits need 8 loads per tile slot, always. ------------------------------------------
+  auto issue_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+    if (tile > last_tile) tile = last_tile;
+    char* dst = smem + buf * kWsTile;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 8 * wave + i;
+      int m = tile * kWsRows + r;
+      if (m >= p.M) m = p.M - 1;
+      const uint16_t* src = p.A + (int64_t)m * p.lda + ((lane ^ (r & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((gl_void_t*)src, (lds_void_t*)(dst + r * 1024), 16, 0, 0);
+    }
+    if constexpr (RS) {  // (every wave brings the same 32 values: the per-wave load counts stay equal)
+      int m = tile * kWsRows + (lane & 31);
+      if (m >= p.M) m = p.M - 1;
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(p.row_scale + m), (lds_void_t*)(smem + kWsOffRs + buf * 256), 4, 0, 0);
+    }
+  };
+  char* stage = smem + kWsBufs * kWsTile;
+  uint32_t a_base[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a_base[j] = (uint32_t)(uintptr_t)(lds_void_t*)(smem + c * 1024 + (((4 * j + g) ^ c) << 4));
+  int tile = stream, it = 0;
+#pragma unroll
+  for (int a = 0; a < kWsAhead; ++a) issue_tile(tile + a * nstreams, a);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kWsAhead - 1) * kLoads) : "memory");  // the first tile (the younger ones in flight)
+  for (; tile < ntiles; tile += nstreams, ++it) {
+    const int buf = it % kWsBufs;
+    __builtin_amdgcn_s_barrier();  // everybody's rows of this tile; everybody is past the previous tile's MFMAs and stage reads
+    issue_tile(tile + kWsAhead * nstreams, (it + kWsAhead) % kWsBufs);  // into the previous tile's buffer
+    // MFMAs of the tile in four chunks of four k-steps; the LDS reads of chunk q + 1 are in flight under the MFMAs of chunk q (asm reads
+    // with counted waits: with one wave per SIMD nobody else hides the ~150-cycle LDS latency, and hipcc waits before every k-step:
+    // 78 us per launch with nothing but the MFMA loop left, against 17 us of MFMA time).  Logical chunk 4 ks + g of row c sits at
+    // 16-byte slot ((4 (ks & 3) + g) ^ c) + 16 (ks >> 2): four per-lane bases, the rest is immediate.
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) acc[jt][s2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint32_t ab[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ab[j] = a_base[j] + buf * kWsTile;
+    bf16x8 af[2][4][2];  // [chunk parity][k-step in chunk][row tile]
+#define WS_READ(par_, q_, j_, s2_)                                                                                                  \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[par_][j_][s2_]) : "v"(ab[j_]), "n"((q_) * 256 + (s2_) * 16384) : "memory")
+#define WS_CHUNK_READS(par_, q_)                                                                                                    \
+  WS_READ(par_, q_, 0, 0); WS_READ(par_, q_, 0, 1); WS_READ(par_, q_, 1, 0); WS_READ(par_, q_, 1, 1);                               \
+  WS_READ(par_, q_, 2, 0); WS_READ(par_, q_, 2, 1); WS_READ(par_, q_, 3, 0); WS_READ(par_, q_, 3, 1)
+#define WS_WAIT(par_, n_)                                                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(%8)"                                                                                              \
+               : "+v"(af[par_][0][0]), "+v"(af[par_][0][1]), "+v"(af[par_][1][0]), "+v"(af[par_][1][1]), "+v"(af[par_][2][0]),      \
+                 "+v"(af[par_][2][1]), "+v"(af[par_][3][0]), "+v"(af[par_][3][1])                                                   \
+               : "n"(n_)                                                                                                            \
+               : "memory")
+#define WS_MFMAS(par_, q_)                                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int jt = 0; jt < 2; ++jt) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
+      acc[jt][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][4 * (q_) + j], af[par_][j][s2], acc[jt][s2], 0, 0, 0)
+    WS_CHUNK_READS(0, 0);
+    WS_CHUNK_READS(1, 1);
+    WS_WAIT(0, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    WS_MFMAS(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    WS_CHUNK_READS(0, 2);
+    WS_WAIT(1, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    WS_MFMAS(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    WS_CHUNK_READS(1, 3);
+    WS_WAIT(0, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    WS_MFMAS(0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    WS_WAIT(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    WS_MFMAS(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+#undef WS_READ
+#undef WS_CHUNK_READS
+#undef WS_WAIT
+#undef WS_MFMAS
+    // the NEXT tile has landed (two younger tiles stay in flight): waited for here, before this tile's stores are issued - behind
+    // them the wait would also be a wait for the stores to reach memory, once per tile
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kWsAhead - 1) * kLoads) : "memory");
+    // ---- epilogue: lane (c, g) holds rows 16 s2 + c, columns n0 + 16 jt + 4 g + r ------------------------------------------------------
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float rs = RS ? reinterpret_cast<const float*>(smem + kWsOffRs + buf * 256)[16 * s2 + c] : 1.0f;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        float v[4] = {acc[jt][s2][0] + bv[jt].x, acc[jt][s2][1] + bv[jt].y, acc[jt][s2][2] + bv[jt].z, acc[jt][s2][3] + bv[jt].w};
+        if (relu_only) {  // ReLU -> BatchNorm affine: the layers this kernel exists for; no per-fragment switch (1 600 -> 500 cycles per tile)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+          v[0] = v[0] * cs[jt].x + ct[jt].x; v[1] = v[1] * cs[jt].y + ct[jt].y; v[2] = v[2] * cs[jt].z + ct[jt].z; v[3] = v[3] * cs[jt].w + ct[jt].w;
+        } else {
+          gemm_act4<true>(v, act);
+          v[0] = v[0] * cs[jt].x + ct[jt].x; v[1] = v[1] * cs[jt].y + ct[jt].y; v[2] = v[2] * cs[jt].z + ct[jt].z; v[3] = v[3] * cs[jt].w + ct[jt].w;
+          gemm_act4<true>(v, act2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rs;
+        *reinterpret_cast<uint2*>(stage + (16 * s2 + c) * kWsStagePitch + (wave * 32 + 16 * jt + 4 * g) * 2) =
+            make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // (raw: __syncthreads() would drain the tile loads in flight)
+#pragma unroll
+    for (int k = 0; k < (kWsRows * 16) / kWsThreads; ++k) {
+      const int cidx = k * kWsThreads + tid, r = cidx >> 4, cc = cidx & 15;
+      const int m = tile * kWsRows + r;
+      if (m < p.M)
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + cb * kWsCols + cc * 8) =
+            *reinterpret_cast<const uint4*>(stage + r * kWsStagePitch + cc * 16);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the duplicate tile loads land before the LDS is handed back
+}
+
 // out[m][n] (+)= alpha * sum_s part[s][m][n]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn,
                                                             float* __restrict__ out, int64_t ldo, int N, float alpha,
@@ -755,6 +937,27 @@ int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* o
   p.K = (int32_t)K;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
+  // K = 512 with >= 16 k rows and bf16 output (ECAPA's 1 x 1 convolutions at C = 512): the weight-stationary persistent kernel
+  if (K == kWsK && (N % kWsCols) == 0 && N <= 1024 && M >= 16384 && p.out_bf16 && !p.residual && p.alpha == 1.0f && (ldo & 7) == 0 &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws512_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kWsLds) !=
+              hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws512_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kWsLds) !=
+              hipSuccess)
+        return MA_ERR_LAUNCH;
+      attr = true;
+    }
+    const int ncb = (int)(N / kWsCols);
+    int grid = gemm_num_cus();
+    grid -= grid % (8 * ncb);
+    if (grid >= 8 * ncb) {
+      if (p.row_scale) MA_LAUNCH(gemm_ws512_kernel<true>, dim3((unsigned)grid), dim3(kWsThreads), kWsLds, (hipStream_t)stream, p);
+      else MA_LAUNCH(gemm_ws512_kernel<false>, dim3((unsigned)grid), dim3(kWsThreads), kWsLds, (hipStream_t)stream, p);
+      return MA_OK;
+    }
+  }
   if (p.col_scale || p.act2 || p.act > 2) return launch_gemm<0, 1>(p, (hipStream_t)stream);
   return launch_gemm<0, 0>(p, (hipStream_t)stream);
 }

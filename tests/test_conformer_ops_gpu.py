@@ -73,6 +73,40 @@ def test_gemm_epilogues(t):
     assert float((x.double() - (res.double() + 0.5 * z)).abs().max()) <= 2e-5 * float(z.abs().max())
 
 
+@pytest.mark.parametrize("m,n", [(16384, 512), (80896, 512), (20011, 128), (16390, 1024)])
+def test_gemm_k512_weight_stationary(t, m, n):
+    """ma_gemm_bf16 with K = 512, bf16 output, >= 16 384 rows runs the weight-stationary persistent kernel (gemm_ws512_kernel: ECAPA's
+    1 x 1 convolutions at C = 512): plain, and with the whole ECAPA epilogue (bias -> ReLU -> BatchNorm affine -> tanh -> row scale);
+    ragged last row tile, strided A and output, 1 / 4 / 8 column blocks."""
+    import ctypes
+
+    from mindaudio_amd import _host, _lib, ops
+
+    k = 512
+    a = _rand(t, m, k, seed=21).bfloat16().cuda()
+    w = _rand(t, n, k, seed=22, scale=1.0 / math.sqrt(k)).bfloat16().cuda()
+    bias = _rand(t, n, seed=23).cuda()
+    z = a.double() @ w.double().T + bias.double()
+    got = ops.gemm(a, w, bias=bias)
+    assert float((got.double() - z).abs().max()) <= 2 ** -8 * float(z.abs().max()) * 1.01
+    # the ECAPA epilogue through the C-ABI, A and out as column slices of wider buffers
+    wide = _rand(t, m, k + 64, seed=24).bfloat16().cuda()
+    av = wide[:, 64:]
+    cs, ct = (1 + 0.1 * _rand(t, n, seed=25)).cuda(), (0.1 * _rand(t, n, seed=26)).cuda()
+    rs = (t.rand(m, generator=t.Generator().manual_seed(27)) > 0.1).float().cuda()
+    out = t.zeros(m, n + 8, dtype=t.bfloat16, device="cuda")
+    e = _lib.GemmEpilogue()
+    e.bias, e.row_scale, e.col_scale, e.col_shift = bias.data_ptr(), rs.data_ptr(), cs.data_ptr(), ct.data_ptr()
+    e.alpha, e.act, e.act2, e.out_bf16 = 1.0, _lib.ACT_RELU, _lib.ACT_TANH, 1
+    rc = _lib.load().ma_gemm_bf16(_host.ptr(av), av.stride(0), _host.ptr(w), w.stride(0), _host.ptr(out), out.stride(0), m, n, k,
+                                  ctypes.byref(e), _host.current_stream_ptr())
+    assert rc == 0
+    z = av.double() @ w.double().T + bias.double()
+    want = t.tanh(z.clamp(min=0) * cs.double() + ct.double()) * rs.double()[:, None]
+    assert float((out[:, :n].double() - want).abs().max()) <= 2 ** -8 * 1.01 + 1e-3
+    assert float(out[:, n:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("b,h,wd", [(2, 21, 9), (3, 99, 39), (1, 7, 5), (5, 131, 39)])
 def test_conv2d_3x3s2_packed(t, b, h, wd):
     """Subsampling conv 2 on fragment-packed weights: same result as the general implicit-GEMM kernel."""

@@ -449,6 +449,17 @@ typedef struct ma_reduce_item {
 int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t Mo, int64_t No, int64_t Kc,
                             int64_t Mo_store, int32_t with_colsum, void* partial, int64_t partial_bytes, ma_stream_t stream);
 int ma_reduce_splits_batch_f32(const ma_reduce_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream);
+/* ma_gemm_tn_partial_bf16 for a list of products in ONE launch per eight of them (`items` is a HOST array; the arguments of one
+ * ma_gemm_tn_partial_bf16 call each).  The eight weight gradients of a Conformer block are issued together (on their own stream):
+ * one grid instead of eight.  Same workgroups, same partials as the separate calls, bit for bit. */
+typedef struct ma_tn_item {
+  const void* A;
+  const void* B;
+  void* partial;
+  int64_t lda, ldb, Mo, No, Kc, Mo_store, partial_bytes;
+  int32_t with_colsum, reserved;
+} ma_tn_item_t;
+int ma_gemm_tn_partial_group_bf16(const ma_tn_item_t* items, int32_t n, ma_stream_t stream);
 
 
 
@@ -586,6 +597,9 @@ int ma_bn_swish_fwd_bf16(const float* z, const float* stats, const float* gamma,
 int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
                         float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
                         int64_t workspace_bytes, ma_stream_t stream);
+/* (ma_convmid_bwd_*: workspace >= ma_convmid_bwd_parts(batch, T) * C * (k + 1) * 4 bytes of per-workgroup partials
+ * [parts][d_dw_w (C, k) | d_dw_b (C)]; d_dw_w == NULL leaves them there for the caller's ma_reduce_splits_batch_f32.) */
+int32_t ma_convmid_bwd_parts(int64_t batch, int64_t T);
 int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                         const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
                         void* workspace, int64_t workspace_bytes, ma_stream_t stream);

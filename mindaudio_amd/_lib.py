@@ -72,6 +72,14 @@ class TrainEpilogue(ctypes.Structure):
                 ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32)]
 
 
+class TnItem(ctypes.Structure):
+    """struct ma_tn_item (host array: the arguments of one ma_gemm_tn_partial_bf16 call each)."""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("partial", ctypes.c_void_p), ("lda", ctypes.c_int64),
+                ("ldb", ctypes.c_int64), ("Mo", ctypes.c_int64), ("No", ctypes.c_int64), ("Kc", ctypes.c_int64),
+                ("Mo_store", ctypes.c_int64), ("partial_bytes", ctypes.c_int64), ("with_colsum", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class PackItem(ctypes.Structure):
     """struct ma_pack_item (include/mindaudio_amd.h)."""
 
@@ -181,6 +189,8 @@ PROTOTYPES = {
     "ma_gemm_k256_train_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, ctypes.POINTER(TrainEpilogue), vp]),
     "ma_gemm_rows_train_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp, i64, ctypes.POINTER(TrainEpilogue), vp]),
     "ma_conv2d_3x3s2_dinput_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]),
+    "ma_gemm_tn_partial_group_bf16": (ctypes.c_int, [ctypes.POINTER(TnItem), i32, vp]),
+    "ma_convmid_bwd_parts": (i32, [i64, i64]),
     "ma_pack_item_pieces": (i64, [i32, i64, i64]),
     "ma_pack_batch_bf16": (ctypes.c_int, [vp, vp, i32, vp]),
     "ma_act_dropout_fwd_bf16": (ctypes.c_int, [vp, vp, i64, i32, f32, u32, u32, vp]),

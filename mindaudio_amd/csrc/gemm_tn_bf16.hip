@@ -63,17 +63,16 @@ __device__ __forceinline__ int tn_div(int m, int d, float inv) {  // floor(m / d
 }
 
 template <int BM, bool IM2COL>  // output rows per workgroup (columns of A): 64 or 128; output columns per workgroup: 128
-__global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnParams p) {
+__device__ __forceinline__ void tn_body(const TnParams& p, const int bx, const int by, char* smem) {  // (bx, by) = (tile, split)
   constexpr int BN = 128;
   constexpr int RA = BM * 2, RB = BN * 2;                    // row bytes of the A / B tiles
   constexpr int kABytes = kTnBK * RA, kStage = kABytes + kTnBK * RB;
   constexpr int FM = BM / 32, FN = BN / 32;                  // 16-wide fragments per wave (2 x 2 waves)
   constexpr int GA = (kTnBK * RA / 1024) / 4, GB = (kTnBK * RB / 1024) / 4;  // LDS-DMA instructions per wave and tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.No + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int tile_m = bx / tiles_n, tile_n = bx % tiles_n;
   const int i0 = tile_m * BM, j0 = tile_n * BN;
 
   // ---- LDS-DMA source addresses ---------------------------------------------------------------------------------
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnPar
     }
   }
   const int nk_all = (p.Kc + kTnBK - 1) / kTnBK;
-  const int kt_lo = blockIdx.y * p.kt_split;
+  const int kt_lo = by * p.kt_split;
   const int nk = min(nk_all - kt_lo, p.kt_split);
   auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
     char* st = smem + stage * kStage;
@@ -232,11 +231,11 @@ __global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnPar
 
   // ---- epilogue: lane holds out[i = .. + (lane & 15)][j = .. + (lane >> 4) * 4 + 0..3] -----------------------------
   const int ei = lane & 15, ej = (lane >> 4) * 4;
-  float* part = p.part + (int64_t)blockIdx.y * p.Mo_store * p.No;
+  float* part = p.part + (int64_t)by * p.Mo_store * p.No;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int oi = i0 + wm * (BM / 2) + i * 16 + ei;
-    if (want_cs && wn == 0 && lg == 0 && oi < p.Mo_store) p.cs_part[(int64_t)blockIdx.y * p.Mo_store + oi] = cs[i][0];
+    if (want_cs && wn == 0 && lg == 0 && oi < p.Mo_store) p.cs_part[(int64_t)by * p.Mo_store + oi] = cs[i][0];
     if (oi >= p.Mo_store) continue;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -251,6 +250,34 @@ __global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnPar
       }
     }
   }
+}
+
+
+template <int BM, bool IM2COL>
+__global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_bf16_kernel(const TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tn_body<BM, IM2COL>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// Up to kTnGroupMax products in one launch (ma_gemm_tn_partial_group_bf16: the eight weight gradients of a Conformer block become
+// ready together and are issued together on the weight-gradient stream): workgroup b belongs to the item whose [first, first + n)
+// range holds it, inside the item x = tile fastest, then the split.
+constexpr int kTnGroupMax = 8;
+struct TnGroup {
+  TnParams p[kTnGroupMax];
+  int32_t first[kTnGroupMax + 1];
+  int32_t tiles[kTnGroupMax];
+  int32_t n;
+};
+__global__ __launch_bounds__(kTnThreads, 2) void gemm_tn_group_kernel(const TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int it = 0;
+#pragma unroll
+  for (int k = 1; k < kTnGroupMax; ++k)
+    if (k < g.n && (int)blockIdx.x >= g.first[k]) it = k;
+  const int local = blockIdx.x - g.first[it];
+  const int tiles = g.tiles[it];
+  tn_body<64, false>(g.p[it], local % tiles, local / tiles, smem);
 }
 
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn,
@@ -471,6 +498,67 @@ int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t l
   p.Kc = (int32_t)Kc;
   p.Mo_store = (int32_t)Mo_store;
   return tn_launch(p, false, nullptr, 0, 1.0f, 0, partial, partial_bytes, (hipStream_t)stream, false);
+}
+
+int ma_gemm_tn_partial_group_bf16(const ma_tn_item_t* items, int32_t n, ma_stream_t stream) {
+  if (!items || n < 1) return MA_ERR_INVALID_ARG;
+  for (int base = 0; base < n; base += kTnGroupMax) {
+    const int cnt = n - base < kTnGroupMax ? n - base : kTnGroupMax;
+    TnGroup g = TnGroup{};
+    int total = 0;
+    bool groupable = true;
+    for (int k = 0; k < cnt; ++k) {
+      const ma_tn_item_t& it = items[base + k];
+      if (!it.A || !it.B || !it.partial || it.Mo < 8 || it.No < 8 || it.Kc < 1 || it.Mo_store < 1 || it.Mo_store > it.Mo)
+        return MA_ERR_INVALID_ARG;
+      if ((it.Mo & 7) || (it.No & 7) || (it.lda & 7) || (it.ldb & 7) || it.lda < it.Mo || it.ldb < it.No || it.Mo > 0x7fffffff ||
+          it.No > 0x7fffffff || it.Kc > 0x7fffffff)
+        return MA_ERR_UNSUPPORTED;
+      if ((reinterpret_cast<uintptr_t>(it.A) | reinterpret_cast<uintptr_t>(it.B) | reinterpret_cast<uintptr_t>(it.partial)) & 15)
+        return MA_ERR_INVALID_ARG;
+      int bm = 64, kt = 0;
+      const int splits = tn_plan(it.Mo, it.No, it.Kc, &bm, &kt);
+      if (it.partial_bytes < (int64_t)splits * it.Mo_store * (it.No + 1) * 4) return MA_ERR_WORKSPACE;
+      if (bm != 64) groupable = false;
+      TnParams& p = g.p[k];
+      p.A = reinterpret_cast<const uint16_t*>(it.A);
+      p.B = reinterpret_cast<const uint16_t*>(it.B);
+      p.part = reinterpret_cast<float*>(it.partial);
+      p.colsum = it.with_colsum ? p.part : nullptr;  // (flag only: the kernel writes cs_part)
+      p.cs_part = p.part + (int64_t)splits * it.Mo_store * it.No;
+      p.lda = it.lda;
+      p.ldb = it.ldb;
+      p.Mo = (int32_t)it.Mo;
+      p.No = (int32_t)it.No;
+      p.Kc = (int32_t)it.Kc;
+      p.Mo_store = (int32_t)it.Mo_store;
+      p.kt_split = kt;
+      g.tiles[k] = (int)(((it.Mo + 63) / 64) * ((it.No + 127) / 128));
+      g.first[k] = total;
+      total += g.tiles[k] * splits;
+    }
+    g.first[cnt] = total;
+    g.n = cnt;
+    if (!groupable) {  // a product on the 128-row tile: one launch per product
+      for (int k = 0; k < cnt; ++k) {
+        const ma_tn_item_t& it = items[base + k];
+        const int rc = ma_gemm_tn_partial_bf16(it.A, it.lda, it.B, it.ldb, it.Mo, it.No, it.Kc, it.Mo_store, it.with_colsum, it.partial,
+                                               it.partial_bytes, stream);
+        if (rc != MA_OK) return rc;
+      }
+      continue;
+    }
+    const int lds = kTnStages * (kTnBK * 64 * 2 + kTnBK * 256);
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+          hipSuccess)
+        return MA_ERR_LAUNCH;
+      attr = true;
+    }
+    MA_LAUNCH(gemm_tn_group_kernel, dim3((unsigned)total), dim3(kTnThreads), lds, (hipStream_t)stream, g);
+  }
+  return MA_OK;
 }
 
 int ma_reduce_splits_batch_f32(const ma_reduce_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream) {

@@ -1195,9 +1195,8 @@ template <typename AT>
 static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                               const float* dw_w, int32_t ks, AT* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
                               void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
-  if (!dz || !y || !dw_w || !dy || !d_dw_w || !d_dw_b || !workspace || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
+  if (!dz || !y || !dw_w || !dy || (d_dw_w && !d_dw_b) || !workspace || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
   if (C != 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
-  if (workspace_bytes < ma_train_reduce_workspace_bytes()) return MA_ERR_WORKSPACE;
   float* part = reinterpret_cast<float*>(workspace);
   // strips per workgroup: as few as keep the number of partial vectors inside the workspace
   int64_t strips = (T + kCbStrip - 1) / kCbStrip;
@@ -1205,6 +1204,7 @@ static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t
   while (((strips + per_block - 1) / per_block) * batch > kMaxPartBlocks) ++per_block;
   const dim3 grid((unsigned)((strips + per_block - 1) / per_block), (unsigned)batch, 1);
   const int nblk = (int)(grid.x * grid.y), width = C * (ks + 1);
+  if (workspace_bytes < (int64_t)nblk * width * 4) return MA_ERR_WORKSPACE;
 #define MA_CMB(KS_)                                                                                                    \
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_bwd_kernel<KS_, AT>),                                 \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (kCbStrip + KS_ - 1) + kCbStrip) * 256 * 4) != hipSuccess)     \
@@ -1216,11 +1216,19 @@ static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t
   else if (ks == 15) { MA_CMB(15); }
   else { MA_CMB(31); }
 #undef MA_CMB
-  MA_LAUNCH(partial_reduce_kernel, dim3((width + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nblk, width, d_dw_w, C * ks,
-            d_dw_b, 0);
+  if (d_dw_w)  // (NULL: the per-workgroup partials stay in `workspace` for the caller's ma_reduce_splits_batch_f32)
+    MA_LAUNCH(partial_reduce_kernel, dim3((width + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nblk, width, d_dw_w, C * ks,
+              d_dw_b, 0);
   return MA_OK;
 }
 }  // extern "C++"
+int32_t ma_convmid_bwd_parts(int64_t batch, int64_t T) {
+  if (batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
+  const int64_t strips = (T + kCbStrip - 1) / kCbStrip;
+  int per_block = 1;
+  while (((strips + per_block - 1) / per_block) * batch > kMaxPartBlocks) ++per_block;
+  return (int32_t)(((strips + per_block - 1) / per_block) * batch);
+}
 int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                         const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
                         void* workspace, int64_t workspace_bytes, ma_stream_t stream) {

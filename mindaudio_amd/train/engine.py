@@ -549,6 +549,11 @@ class ConformerCTCTrainStep:
         for site in self._LN_SITES:
             off[site] = (total, ln_parts * 512 * 4, ln_parts)
             total += ln_parts * 512 * 4
+        # the depthwise convolution's per-workgroup (d_dw_w | d_dw_b) partials (fused path)
+        cm_parts = int(lib.ma_convmid_bwd_parts(m // self._t2_cur, self._t2_cur))
+        cm_width = self.d * (self.ks + 1)
+        off["convmid"] = (total, cm_parts * cm_width * 4, cm_parts)
+        total += (cm_parts * cm_width * 4 + 255) // 256 * 256
         # the attention backward's workspace (its dpos / du / dv partials are reduced by the block's launch too) and the buffer the
         # positional projections' gradients of all blocks accumulate in
         import ctypes
@@ -595,6 +600,9 @@ class ConformerCTCTrainStep:
                 assert fp.index["l%d.%s.b" % (li, site)][0] == fp.index["l%d.%s.g" % (li, site)][0] + 256
                 add(base + o, gg, 512, 512, 512, parts, 512, True)
             if self.fused:
+                o, nbytes, parts = off["convmid"]
+                add(base + o, fp.g("l%d.dw_w" % li), self.d * self.ks, self.d * self.ks, self.d * self.ks, parts, cm_width, True)
+                add(base + o + self.d * self.ks * 4, fp.g("l%d.dw_b" % li), self.d, self.d, self.d, parts, cm_width, True)
                 t2, d, dk = self._t2_cur, self.d, self.d // self.heads
                 ws_ptr = base + off["att_ws"][0]
                 dpos_l = arena[off["dpos_all"][0]:off["dpos_all"][0] + off["dpos_all"][1]].view(torch.float32).view(t2, self.L * d)
@@ -927,7 +935,7 @@ class ConformerCTCTrainStep:
             self._dW(do, C["w"], pre + "pw2_w", pre + "pw2_b")
             dwv = K.dense_plain(do, PK("pw2_w.tk"), d, d)
             dy = K.convmid_bwd(dwv, C["y"], C["z"], C["stats"], b, t2, P("dw_w"), P("bn_g"), P("bn_b"), G("dw_w"), G("dw_b"), G("bn_g"),
-                               G("bn_b"))
+                               G("bn_b"), partials=self._ln_partials("convmid"))
             self._dW(dy, C["a"], pre + "pw1_w", pre + "pw1_b")
             da = K.dense_plain(dy, PK("pw1_w.tr"), d, 2 * d)
             _, do = K.layernorm_bwd_next(C["x_in"], P("norm_conv.g"), da, g, G("norm_conv.g"), G("norm_conv.b"),
@@ -1080,8 +1088,7 @@ class ConformerCTCTrainStep:
                 self._wg.wait_event(self._wg_event().record_on(self._main))
                 prev, _host._pinned_stream = _host._pinned_stream, self._wg_ptr
                 try:
-                    for dy, x, part in self._wg_queue:
-                        self.K.gemm_tn_partial(dy, x, part, with_colsum=True)
+                    self.K.gemm_tn_partial_group(self._wg_queue, with_colsum=True)  # the block's eight products: one grid
                 finally:
                     _host._pinned_stream = prev
                 # (dy / x stay referenced until the step's join: the caching allocator only orders reuse on the allocating stream)

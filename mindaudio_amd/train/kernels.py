@@ -88,6 +88,18 @@ def gemm_tn_partial(a, b, partial, with_colsum=False):
                                            _p(partial), partial.numel(), _s()), "gemm_tn_partial")
 
 
+def gemm_tn_partial_group(triples, with_colsum=True):
+    """gemm_tn_partial for a list of (a, b, partial) in one launch per eight products (same partials, bit for bit)."""
+    n = len(triples)
+    items = (_lib.TnItem * n)()
+    for it, (a, b, part) in zip(items, triples):
+        kc, mo = a.shape
+        it.A, it.B, it.partial = a.data_ptr(), b.data_ptr(), part.data_ptr()
+        it.lda, it.ldb, it.Mo, it.No, it.Kc, it.Mo_store = a.stride(0), b.stride(0), mo, b.shape[1], kc, mo
+        it.partial_bytes, it.with_colsum = part.numel(), 1 if with_colsum else 0
+    _lib.check(_lib.load().ma_gemm_tn_partial_group_bf16(items, n, _s()), "gemm_tn_partial_group")
+
+
 def conv2d_dw_workspace_bytes(rows, c, cout):
     return int(_lib.load().ma_gemm_tn_workspace_bytes(cout, 9 * c, rows))
 
@@ -225,8 +237,10 @@ def convmid_fwd_train(y, batch, T, dw_w, dw_b, gamma, beta, run_mean, run_var, e
     return out, z, stats
 
 
-def convmid_bwd(dout, y, z, stats, batch, T, dw_w, gamma, beta, d_dw_w, d_dw_b, d_gamma, d_beta):
-    """dout (B*T, C) bf16 -> dy (B*T, 2C) bf16; parameter gradients accumulate into the given float32 buffers."""
+def convmid_bwd(dout, y, z, stats, batch, T, dw_w, gamma, beta, d_dw_w, d_dw_b, d_gamma, d_beta, partials=None):
+    """dout (B*T, C) bf16 -> dy (B*T, 2C) bf16; parameter gradients accumulate into the given float32 buffers.  partials (float32,
+    >= ma_convmid_bwd_parts * C * (k + 1)): the depthwise kernel's / bias' per-workgroup partial sums are left there (d_dw_w / d_dw_b are
+    not touched) for the caller's batched sum."""
     t = _t()
     lib = _lib.load()
     c, ks = dw_w.shape
@@ -237,6 +251,10 @@ def convmid_bwd(dout, y, z, stats, batch, T, dw_w, gamma, beta, d_dw_w, d_dw_b, 
     _lib.check(lib.ma_bn_swish_bwd_f32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _p(d_gamma), _p(d_beta),
                _p(rw), rw.numel(), _s()), "bn_swish_bwd")
     dy = t.empty((rows, 2 * c), dtype=t.bfloat16, device=y.device)
+    if partials is not None:
+        _lib.check(lib.ma_convmid_bwd_bf16(_p(dz), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dy), dy.stride(0), None, None,
+                                           _p(partials), partials.numel() * partials.element_size(), _s()), "convmid_bwd")
+        return dy
     rw = _reduce_ws(y.device)
     _lib.check(lib.ma_convmid_bwd_bf16(_p(dz), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dy), dy.stride(0),
                                        _p(d_dw_w), _p(d_dw_b), _p(rw), rw.numel(), _s()), "convmid_bwd")

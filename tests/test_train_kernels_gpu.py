@@ -538,3 +538,29 @@ def test_conv2_input_gradient_as_one_implicit_gemm(K, b, h, w, c):
     dcol = ops.gemm(dy.cuda(), wt.cuda())
     two = K.col2im_relu(dcol, act.cuda())
     assert rel(got_nomask, two.float().cpu()) < 8e-3
+
+
+def test_grouped_weight_gradient_products_equal_the_separate_launches(K):
+    """ma_gemm_tn_partial_group_bf16 (a block's eight dW = dY^T X products as one grid) writes the same split-K partials and partial
+    bias sums as eight ma_gemm_tn_partial_bf16 launches, bit for bit; more than eight items go out as two grids."""
+    from mindaudio_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    m = 1531
+    shapes = [(256, 2048), (2048, 256), (768, 256), (256, 256), (512, 256), (256, 256), (2048, 256), (256, 2048), (256, 512), (64, 128)]
+    ops_ = []
+    for mo, no in shapes:
+        a = bf(torch.randn(m, mo, generator=g)).cuda()
+        b = bf(torch.randn(m, no, generator=g)).cuda()
+        nbytes = int(lib.ma_gemm_tn_workspace_bytes(mo, no, m))
+        ops_.append((a, b, nbytes))
+    sep = []
+    for a, b, nbytes in ops_:
+        part = torch.full((nbytes,), 0x5a, dtype=torch.uint8, device="cuda")
+        K.gemm_tn_partial(a, b, part, with_colsum=True)
+        sep.append(part)
+    grp = [torch.full((nbytes,), 0x5a, dtype=torch.uint8, device="cuda") for _, _, nbytes in ops_]
+    K.gemm_tn_partial_group([(a, b, part) for (a, b, _), part in zip(ops_, grp)], with_colsum=True)
+    for x, y in zip(sep, grp):
+        assert torch.equal(x, y)

@@ -37,7 +37,10 @@ class FlatParams:
             off += (n + _PAD - 1) // _PAD * _PAD
         self.size = off
         self.master = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        # (one allocation: the flat gradient and, behind it, the step's overflow flag - one fill zeroes both)
+        self._grad_alloc = torch.zeros(off + 64, dtype=torch.float32, device=device)
+        self.grad = self._grad_alloc[:off]
+        self.flag = self._grad_alloc[off:off + 1].view(torch.int32)
         self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
         # matmul-operand copy of the masters: bf16 (throughput mode) or the masters themselves (float32 validation mode)
@@ -253,8 +256,8 @@ class ConformerCTCTrainStep:
         self.Ld = len(self.dec.decoders) if self.dec is not None else 0
         self.dec_hidden = self.dec.decoders[0].feed_forward.w_1.out_features if self.dec is not None else 0
         self.last_acc = None
-        self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._build_flat()
+        self.flag = self.fp.flag  # zeroed with the gradients at the start of forward_backward
         self.reducer = BucketedAllReduce(self.fp.grad, self.world, self.pg, force_collective)
         self.refresh_weights()
 
@@ -579,11 +582,11 @@ class ConformerCTCTrainStep:
             items, block_item, first = [], [], 0
             base = arena.data_ptr() + (li & 1) * half
 
-            def add(part_ptr, out, mn, ldo, n_cols, splits, pstride, tall):
+            def add(part_ptr, out, mn, ldo, n_cols, splits, pstride, tall, accumulate=True):
                 nonlocal first
                 nblk = (mn + 15) // 16 if tall else (mn + 1023) // 1024
-                items.append(_lib.ReduceItem(part_ptr, out.data_ptr(), mn, ldo, n_cols, splits, 1.0, 1 | (2 if tall else 0), first,
-                                             pstride))
+                items.append(_lib.ReduceItem(part_ptr, out.data_ptr(), mn, ldo, n_cols, splits, 1.0,
+                                             (1 if accumulate else 0) | (2 if tall else 0), first, pstride))
                 block_item.extend([len(items) - 1] * nblk)
                 first += nblk
 
@@ -607,7 +610,9 @@ class ConformerCTCTrainStep:
                 ws_ptr = base + off["att_ws"][0]
                 dpos_l = arena[off["dpos_all"][0]:off["dpos_all"][0] + off["dpos_all"][1]].view(torch.float32).view(t2, self.L * d)
                 # dpos[t][c] of block li += sum over the batch of dp_part[b][t][c]
-                add(ws_ptr + dp_off.value * 4, dpos_l[:, li * d:(li + 1) * d], t2 * d, self.L * d, d, b_att, tp_.value * d, False)
+                # (stored, not accumulated: every block writes its own 256 columns once per step, so dpos_all needs no zero fill)
+                add(ws_ptr + dp_off.value * 4, dpos_l[:, li * d:(li + 1) * d], t2 * d, self.L * d, d, b_att, tp_.value * d, False,
+                    accumulate=False)
                 for h in range(self.heads):  # du[h], dv[h] += sum over the (utterance, query block) partials of head h
                     hb = ws_ptr + (bias_off.value + h * pph.value * 128) * 4
                     add(hb, fp.g("l%d.u" % li)[h], dk, dk, dk, pph.value, 128, True)
@@ -622,6 +627,43 @@ class ConformerCTCTrainStep:
             o, nb, _ = off["dpos_all"]
             self._dw_plan["dpos_all"] = arena[o:o + nb].view(torch.float32).view(self._t2_cur, self.L * self.d)
         return self._dw_plan
+
+    def _front_plan_for(self, m, t2):
+        """The three weight gradients outside the blocks (CTC head, embed layer, positional projections): split-K partials into one
+        arena, one batched sum at the end of the backward pass instead of five reduction launches (fused bf16 path)."""
+        cur = self.__dict__.get("_front_plan")
+        if cur is not None and cur["key"] == (m, t2):
+            return cur
+        import numpy as np
+
+        lib, fp = _lib.load(), self.fp
+        prods = (("ctc", self.Vp, self.d, m, self.V, fp.g("ctc_w"), fp.g("ctc_b")),
+                 ("out", self.d, self.f2 * self.d, m, self.d, fp.g("out_w"), fp.g("out_b")),
+                 ("pos", self.L * self.d, self.d, t2, self.L * self.d, fp.g("pos_w"), None))
+        off, total = {}, 0
+        for name, mo, no, kc, mo_store, _, _ in prods:
+            nbytes = int(lib.ma_gemm_tn_workspace_bytes(mo, no, kc))
+            off[name] = (total, nbytes, int(lib.ma_gemm_tn_splits(mo, no, kc)))
+            total += (nbytes + 255) // 256 * 256
+        arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
+        items, block_item, first = [], [], 0
+        for name, mo, no, kc, mo_store, gw, gb in prods:
+            o, _, splits = off[name]
+            for part, out, mn, ldo, ncols in ((arena.data_ptr() + o, gw, mo_store * no, gw.stride(0), no),) + \
+                    (((arena.data_ptr() + o + splits * mo_store * no * 4, gb, mo_store, mo_store, mo_store),) if gb is not None else ()):
+                nblk = (mn + 1023) // 1024
+                items.append(_lib.ReduceItem(part, out.data_ptr(), mn, ldo, ncols, splits, 1.0, 1, first, 0))
+                block_item.extend([len(items) - 1] * nblk)
+                first += nblk
+        raw = (_lib.ReduceItem * len(items))(*items)
+        self._front_plan = dict(key=(m, t2), arena=arena, off=off, n_blocks=first,
+                                items=torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
+                                block_item=torch.tensor(block_item, dtype=torch.int32, device=self.dev))
+        return self._front_plan
+
+    def _front_dW(self, name, dy, x, rows_store=None, with_colsum=True):
+        o, nbytes, _ = self._front_cur["off"][name]
+        self.K.gemm_tn_partial(dy, x, self._front_cur["arena"][o:o + nbytes], with_colsum=with_colsum, rows_store=rows_store)
 
     def _ln_partials(self, site):
         """The arena slice that LayerNorm `site` of the current block writes its per-workgroup partials to (None: immediate sums)."""
@@ -678,7 +720,7 @@ class ConformerCTCTrainStep:
         b, t, idim = xs_pad.shape
         xs = xs_pad.to(f32).contiguous()
         enc = self.enc
-        fp.grad.zero_()
+        fp._grad_alloc.zero_()
         self._wg_next = 0
         self._wg_done.clear()
         self._main = torch.cuda.current_stream() if self._wg is not None else None
@@ -733,7 +775,12 @@ class ConformerCTCTrainStep:
 
         # ================= backward =================
         # CTC head: logits = enc_bf W^T + b
-        K.gemm_tn(dlog, enc_bf, fp.g("ctc_w"), colsum=fp.g("ctc_b"), rows_store=self.V)
+        front = self.fused and dlog.shape[1] == self.Vp
+        if front:
+            self._front_cur = self._front_plan_for(m, t2)
+            self._front_dW("ctc", dlog, enc_bf, rows_store=self.V)
+        else:
+            K.gemm_tn(dlog, enc_bf, fp.g("ctc_w"), colsum=fp.g("ctc_b"), rows_store=self.V)
         if d_mem is None:
             d_enc = self._dX(dlog, "ctc_w")            # (m, 256) bf16
         else:                                                   # + the decoder's gradient w.r.t. the encoder output
@@ -741,8 +788,7 @@ class ConformerCTCTrainStep:
         g = torch.empty((m, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
         if self.fused and self._dw_cur is not None:
-            dpos_all = self._dw_cur["dpos_all"]
-            dpos_all.zero_()
+            dpos_all = self._dw_cur["dpos_all"]  # (every element is written by the blocks' batched sums)
         else:
             dpos_all = torch.zeros((t2, L * d), dtype=f32, device=self.dev)
         if self.fused:
@@ -750,10 +796,19 @@ class ConformerCTCTrainStep:
         else:
             self._blocks_backward(g, tape, dpos_all, ctx_)
         # positional projection of every layer: dW_pos (L*256, 256) = dpos_all^T pe
-        self._dW(ops.cast_bf16(dpos_all), pe_bf, "pos_w", None)
+        if front:
+            self._front_dW("pos", ops.cast_bf16(dpos_all), pe_bf, with_colsum=False)
+        else:
+            self._dW(ops.cast_bf16(dpos_all), pe_bf, "pos_w", None)
         # embedding: x = dropout(sqrt(d) * (a2 W_out^T + b))
         de = K.dropout_bwd(g, math.sqrt(d), pp, seed, self._salt(-1, 0))
-        self._dW(de, a2, "out_w", "out_b")
+        if front:
+            self._front_dW("out", de, a2)
+            fpl = self._front_cur  # the three sums in one launch
+            _lib.check(_lib.load().ma_reduce_splits_batch_f32(fpl["items"].data_ptr(), fpl["block_item"].data_ptr(), fpl["n_blocks"],
+                                                              _host.current_stream_ptr()), "front reduce")
+        else:
+            self._dW(de, a2, "out_w", "out_b")
         dact2 = self._dX(de, "out_w")                  # (m, f2*c) bf16
         K.relu_bwd(dact2, a2)
         dy2 = dact2.view(m * f2, c)
@@ -1162,7 +1217,6 @@ class ConformerCTCTrainStep:
         * `applied_steps` counts the updates actually applied: Adam's beta1_power / beta2_power live inside the optimizer,
           which is not executed on overflow (train_one_step.py:45-46), so the bias correction uses this counter."""
         scale = self.scaler.scale
-        self.flag.zero_()
         loss = self.forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale=scale,
                                      ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_sub_masks=ys_sub_masks,
                                      ys_masks=ys_masks)

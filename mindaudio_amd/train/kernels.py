@@ -78,14 +78,14 @@ def gemm_tn(a, b, out, colsum=None, rows_store=None, alpha=1.0, accumulate=True)
     return out
 
 
-def gemm_tn_partial(a, b, partial, with_colsum=False):
+def gemm_tn_partial(a, b, partial, with_colsum=False, rows_store=None):
     """The split-K partial products of gemm_tn into `partial` (a flat uint8 view of >= ma_gemm_tn_workspace_bytes bytes) and, behind
     them, one partial column-sum vector of `a` per split; the sums are taken later by ma_reduce_splits_batch_f32."""
     lib = _lib.load()
     kc, mo = a.shape
     no = b.shape[1]
-    _lib.check(lib.ma_gemm_tn_partial_bf16(_p(a), a.stride(0), _p(b), b.stride(0), mo, no, kc, mo, 1 if with_colsum else 0,
-                                           _p(partial), partial.numel(), _s()), "gemm_tn_partial")
+    _lib.check(lib.ma_gemm_tn_partial_bf16(_p(a), a.stride(0), _p(b), b.stride(0), mo, no, kc, mo if rows_store is None else rows_store,
+                                           1 if with_colsum else 0, _p(partial), partial.numel(), _s()), "gemm_tn_partial")
 
 
 def gemm_tn_partial_group(triples, with_colsum=True):

@@ -254,6 +254,94 @@ __global__ __launch_bounds__(kG2Threads, NBL > 1 ? 1 : 2) void gemm_k256_kernel(
 //   MODE 4 (plain):         out = bf16(acc + bias)
 // What the un-fused step ran as GEMM + act_dropout_fwd / act_dropout_bwd / dropout_add + layernorm launches; element for element the
 // same arithmetic (u, h, du are bit-identical to those launches).
+// ---- epilogue of the bf16-output training modes (1: u and h, 2: du, 4: plain).  (A weight-stationary persistent kernel around the
+// same epilogue - 32-row tiles, two workgroups per CU, no weight re-reads - was measured in round 3: bit-identical, 34.9 us against
+// 30.5 us for the w_1 layer; the launch is bound by this epilogue's VALU chains, not by the weight stream it removes.)
+// lane (c, g) holds rows m0 + 16 s + c, columns n0 + 16 jt + 4 g + r in acc[jt][s][r]; `stage` = this wave's own LDS strip of
+// ROWS x kG2StagePitch bytes ----------------------------------------------------------------------------------------------------------
+template <int ROWS, int MODE>
+__device__ __forceinline__ void k256_train_epilogue_bf16(f32x4 (&acc)[4][ROWS / 16], const TrainEpi& e, const int m0, const int n0, const int M,
+                                                         const int N, void* out, const int64_t ldo, char* stage, const int lane,
+                                                         const int c, const int g) {
+  constexpr int MT = ROWS / 16;
+  // ---- bf16 outputs: staged in this wave's own LDS strip, written as whole 128-byte row segments ------------------------------
+  auto flush = [&](void* dst, int64_t ld) __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int rr = lane >> 3, cc = lane & 7;
+    uint16_t* ob = reinterpret_cast<uint16_t*>(dst) + n0 + cc * 8;
+#pragma unroll
+    for (int it = 0; it < ROWS / 8; ++it) {
+      const int row = it * 8 + rr;
+      const uint4 v = *reinterpret_cast<const uint4*>(stage + row * kG2StagePitch + cc * 16);
+      if (m0 + row < M) *reinterpret_cast<uint4*>(ob + (int64_t)(m0 + row) * ld) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  float4 bv[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+    bv[jt] = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // pass 1: u (modes 1, 4: acc + bias) or du (mode 2).  Mode 2 fetches all of its u values before the first use (otherwise
+  // sixteen dependent round trips per lane).
+  uint2 ur[MODE == 2 ? MT : 1][4];
+  if constexpr (MODE == 2) {
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      const int m = m0 + 16 * s + c;
+      const int mc = m < M ? m : M - 1;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) ur[s][jt] = *reinterpret_cast<const uint2*>(e.aux + (int64_t)mc * e.ld_aux + n0 + 16 * jt + 4 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int m = m0 + 16 * s + c;
+    const int mc = m < M ? m : M - 1;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = n0 + 16 * jt + 4 * g;
+      float v[4] = {acc[jt][s][0] + bv[jt].x, acc[jt][s][1] + bv[jt].y, acc[jt][s][2] + bv[jt].z, acc[jt][s][3] + bv[jt].w};
+      if constexpr (MODE == 2) {
+        const uint2 uq = ur[s][jt];
+        const float u[4] = {__uint_as_float(uq.x << 16), __uint_as_float(uq.x & 0xffff0000u), __uint_as_float(uq.y << 16),
+                            __uint_as_float(uq.y & 0xffff0000u)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sg = sigmoid_fast(u[r]);
+          v[r] = bf16_round(v[r]) * (sg + u[r] * sg * (1.0f - sg));
+        }
+        drop4(e.drop, (uint64_t)mc * N + n, v);
+      }
+      *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
+          make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+      if constexpr (MODE == 1) acc[jt][s] = f32x4{bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
+    }
+  }
+  flush(out, ldo);
+  if constexpr (MODE == 1) {
+    // pass 2: h = dropout(swish(u)) on the rounded u, as act_dropout_fwd_kernel computes it from the stored tensor
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      const int m = m0 + 16 * s + c;
+      const int mc = m < M ? m : M - 1;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int n = n0 + 16 * jt + 4 * g;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[jt][s][r] * sigmoid_fast(acc[jt][s][r]);
+        drop4(e.drop, (uint64_t)mc * N + n, v);
+        *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
+            make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+      }
+    }
+    flush(e.out2, e.ldo2);
+  }
+}
+
 template <int ROWS, int MODE>
 __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_train_kernel(const uint16_t* __restrict__ a, int64_t lda,
                                                                         const uint4* __restrict__ wp, void* out, int64_t ldo, int M,
@@ -303,83 +391,8 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_train_kernel(const ui
     train_epi_rows256<MT>(e, acc, m0, M, wave, c, g, reinterpret_cast<float*>(out), ldo, reinterpret_cast<float*>(smem));
     return;
   } else {
-    // ---- bf16 outputs: staged in this wave's own LDS strip, written as whole 128-byte row segments ------------------------------
     char* stage = smem + ROWS * kG2Pitch + wave * (ROWS * kG2StagePitch);
-    auto flush = [&](void* dst, int64_t ld) __attribute__((always_inline)) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int rr = lane >> 3, cc = lane & 7;
-      uint16_t* ob = reinterpret_cast<uint16_t*>(dst) + n0 + cc * 8;
-#pragma unroll
-      for (int it = 0; it < ROWS / 8; ++it) {
-        const int row = it * 8 + rr;
-        const uint4 v = *reinterpret_cast<const uint4*>(stage + row * kG2StagePitch + cc * 16);
-        if (m0 + row < M) *reinterpret_cast<uint4*>(ob + (int64_t)(m0 + row) * ld) = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    };
-    float4 bv[4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-      bv[jt] = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-    // pass 1: u (modes 1, 4: acc + bias) or du (mode 2).  Mode 2 fetches all of its u values before the first use (otherwise
-    // sixteen dependent round trips per lane).
-    uint2 ur[MODE == 2 ? MT : 1][4];
-    if constexpr (MODE == 2) {
-#pragma unroll
-      for (int s = 0; s < MT; ++s) {
-        const int m = m0 + 16 * s + c;
-        const int mc = m < M ? m : M - 1;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) ur[s][jt] = *reinterpret_cast<const uint2*>(e.aux + (int64_t)mc * e.ld_aux + n0 + 16 * jt + 4 * g);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int s = 0; s < MT; ++s) {
-      const int m = m0 + 16 * s + c;
-      const int mc = m < M ? m : M - 1;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const int n = n0 + 16 * jt + 4 * g;
-        float v[4] = {acc[jt][s][0] + bv[jt].x, acc[jt][s][1] + bv[jt].y, acc[jt][s][2] + bv[jt].z, acc[jt][s][3] + bv[jt].w};
-        if constexpr (MODE == 2) {
-          const uint2 uq = ur[s][jt];
-          const float u[4] = {__uint_as_float(uq.x << 16), __uint_as_float(uq.x & 0xffff0000u), __uint_as_float(uq.y << 16),
-                              __uint_as_float(uq.y & 0xffff0000u)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sg = sigmoid_fast(u[r]);
-            v[r] = bf16_round(v[r]) * (sg + u[r] * sg * (1.0f - sg));
-          }
-          drop4(e.drop, (uint64_t)mc * N + n, v);
-        }
-        *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
-            make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
-        if constexpr (MODE == 1) acc[jt][s] = f32x4{bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
-      }
-    }
-    flush(out, ldo);
-    if constexpr (MODE == 1) {
-      // pass 2: h = dropout(swish(u)) on the rounded u, as act_dropout_fwd_kernel computes it from the stored tensor
-#pragma unroll
-      for (int s = 0; s < MT; ++s) {
-        const int m = m0 + 16 * s + c;
-        const int mc = m < M ? m : M - 1;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-          const int n = n0 + 16 * jt + 4 * g;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[jt][s][r] * sigmoid_fast(acc[jt][s][r]);
-          drop4(e.drop, (uint64_t)mc * N + n, v);
-          *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
-              make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
-        }
-      }
-      flush(e.out2, e.ldo2);
-    }
+    k256_train_epilogue_bf16<ROWS, MODE>(acc, e, m0, n0, M, N, out, ldo, stage, lane, c, g);
   }
 }
 

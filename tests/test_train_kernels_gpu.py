@@ -564,3 +564,4 @@ def test_grouped_weight_gradient_products_equal_the_separate_launches(K):
     K.gemm_tn_partial_group([(a, b, part) for (a, b, _), part in zip(ops_, grp)], with_colsum=True)
     for x, y in zip(sep, grp):
         assert torch.equal(x, y)
+

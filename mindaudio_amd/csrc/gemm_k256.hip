@@ -308,16 +308,22 @@ __device__ __forceinline__ void k256_train_epilogue_bf16(f32x4 (&acc)[4][ROWS / 
         const uint2 uq = ur[s][jt];
         const float u[4] = {__uint_as_float(uq.x << 16), __uint_as_float(uq.x & 0xffff0000u), __uint_as_float(uq.y << 16),
                             __uint_as_float(uq.y & 0xffff0000u)};
+        bf16_round2(v[0], v[1]);
+        bf16_round2(v[2], v[3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float sg = sigmoid_fast(u[r]);
-          v[r] = bf16_round(v[r]) * (sg + u[r] * sg * (1.0f - sg));
+          v[r] = v[r] * (sg + u[r] * sg * (1.0f - sg));
         }
         drop4(e.drop, (uint64_t)mc * N + n, v);
       }
       *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
           make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
-      if constexpr (MODE == 1) acc[jt][s] = f32x4{bf16_round(v[0]), bf16_round(v[1]), bf16_round(v[2]), bf16_round(v[3])};
+      if constexpr (MODE == 1) {  // the rounded u, for h below
+        bf16_round2(v[0], v[1]);
+        bf16_round2(v[2], v[3]);
+        acc[jt][s] = f32x4{v[0], v[1], v[2], v[3]};
+      }
     }
   }
   flush(out, ldo);

@@ -59,6 +59,14 @@ __device__ __forceinline__ float bf16_round(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return __uint_as_float(u & 0xffff0000u);
 }
+// bf16_round of a pair through the hardware conversion: one v_cvt_pk_bf16_f32 + a shift and a mask instead of two five-instruction
+// integer sequences (same round-to-nearest-even; NaNs come back as the conversion's quiet NaN)
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi);
+__device__ __forceinline__ void bf16_round2(float& a, float& b) {
+  const uint32_t pk = pack2_bf16(a, b);
+  a = __uint_as_float(pk << 16);
+  b = __uint_as_float(pk & 0xffff0000u);
+}
 __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
   typedef __attribute__((ext_vector_type(2))) float f2_t;
@@ -174,8 +182,10 @@ __device__ __forceinline__ void train_epi_rows256(const TrainEpi& e, tc_f32x4 (&
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       const int n = 64 * wave + 16 * jt + 4 * g;
-      float v[4] = {bf16_round((acc[jt][s][0] + bv[jt].x) * rs), bf16_round((acc[jt][s][1] + bv[jt].y) * rs),
-                    bf16_round((acc[jt][s][2] + bv[jt].z) * rs), bf16_round((acc[jt][s][3] + bv[jt].w) * rs)};
+      float v[4] = {(acc[jt][s][0] + bv[jt].x) * rs, (acc[jt][s][1] + bv[jt].y) * rs, (acc[jt][s][2] + bv[jt].z) * rs,
+                    (acc[jt][s][3] + bv[jt].w) * rs};
+      bf16_round2(v[0], v[1]);
+      bf16_round2(v[2], v[3]);
       drop4(e.drop, (uint64_t)mc * 256 + n, v);
       const float4 r = rv[s][jt];
       v[0] = r.x + e.alpha * v[0]; v[1] = r.y + e.alpha * v[1]; v[2] = r.z + e.alpha * v[2]; v[3] = r.w + e.alpha * v[3];

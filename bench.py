@@ -219,6 +219,22 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=F
     tf = world * flops / (dt / steps) / 1e12
     res["roofline"] = {"bound": "mfma", "algorithmic_flops_per_step": int(world * flops), "achieved": round(tf, 1),
                        "peak": MFMA_BF16_PEAK_TF * world, "unit": "TFLOP/s", "frac": round(tf / (MFMA_BF16_PEAK_TF * world), 4)}
+    if world == 1 and not force_collective and not digest:
+        # the opt-in second stream for the weight-gradient products (engine.py: wg_stream; off by default): same step,
+        # same results bit for bit, reported beside the default
+        torch.manual_seed(777)
+        model2 = create_asr_model(80, TRAIN_VOCAB, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12),
+                                  ctc_weight=1.0).to(dev)
+        eng2 = ConformerCTCTrainStep(model2, dropout_rate=0.1, positional_dropout_rate=0.1, world_size=1, rank=0, wg_stream=True)
+        for _ in range(max(warmup, 3)):
+            eng2.step(*cols)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng2.step(*cols)
+        torch.cuda.synchronize()
+        res["second_stream_ms_per_step"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+        del eng2, model2
     if force_collective:
         res["force_collective"] = True
     if digest:  # bit pattern of the trained masters (tests/test_rccl_world1_gpu.py compares runs with and without the collective)

@@ -164,8 +164,12 @@ constexpr int kTs = 64 + 4;   // transposed tiles: 64 streamed items per row (13
 
 // KEYS_FIXED = true : fixed = keys (K', V), streamed = queries (Q', dO, Q'^T, dO^T, lse, D): outputs dK', dV
 // KEYS_FIXED = false: fixed = queries (Q', dO, lse, D), streamed = keys (K', V, K'^T, maskadd): output dQ'
+// (Two workgroups per CU for both forms.  At three, the queries-fixed form spilled 2 registers = 12 bytes of scratch per lane and was
+// the only scratch user of the training step; with the weight-gradient products on a second hardware queue, fresh processes then showed
+// a ~1 % rate of corrupted backward passes in the first two-stream steps - tools/flaky_loop.sh: 2 of 250 with the spills, 0 of 250
+// without, other things equal.  Root cause not established; no kernel of the step uses scratch now.)
 template <bool KEYS_FIXED>
-__global__ __launch_bounds__(256, KEYS_FIXED ? 2 : 3) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                        const uint16_t* __restrict__ dctx, int64_t ld_dctx,
                                                        const float* __restrict__ mask, const float* __restrict__ mask3,
                                                        const float* __restrict__ lse, AttnWs ws, int T, int H, float scale,

@@ -81,7 +81,13 @@ def test_bucket_1024_batch_of_40_trains():
         losses = []
         for _ in range(6):
             loss, cond, scale, overflow, lr = eng.step(*cols)
-            assert not overflow and scale == 1024.0 and bool(torch.isfinite(loss))
+            if overflow:  # say where: a spurious overflow is a race or an uninitialised read somewhere in the step
+                nf = (~torch.isfinite(eng.fp.grad)).nonzero().flatten()
+                where = [(n_, int(((nf >= o) & (nf < o + k)).sum())) for n_, (o, _, k) in eng.fp.index.items()
+                         if int(((nf >= o) & (nf < o + k)).sum())]
+                raise AssertionError("overflow at rep %d step %d: %d non-finite gradient entries in %s" % (rep, len(losses), nf.numel(),
+                                                                                                          where[:12]))
+            assert scale == 1024.0 and bool(torch.isfinite(loss))
             losses.append(float(loss))
         curves.append(losses)
         masters.append(eng.fp.master.clone())

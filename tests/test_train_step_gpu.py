@@ -405,8 +405,8 @@ def test_weight_gradient_stream_changes_no_bit():
     for wg in (False, True, True):
         _, _, model = build(seed=9)
         eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1, wg_stream=wg)
-        assert (eng._wg is not None) == wg
-        losses = [float(eng.step(*cols)[0]) for _ in range(3)]
+        assert (eng._wg_stream is not None) == wg
+        losses = [float(eng.step(*cols)[0]) for _ in range(5)]  # (the second stream is used from the third step of a shape on)
         torch.cuda.synchronize()
         out.append((losses, eng.fp.master.clone()))
     for losses, master in out[1:]:

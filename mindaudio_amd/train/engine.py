@@ -222,7 +222,8 @@ class ConformerCTCTrainStep:
         # run on a second stream beside the input-gradient chain they do not feed (both are latency-bound launches of ~1 workgroup per
         # CU): 12.0 -> 11.5 ms per cfg-4 step, bit-identical results - but OFF by default: in 0.4-7 % of fresh PROCESSES the first engine's
         # first steps came out corrupted with it (see _forward_backward), and the cause is not established.
-        self._wg_on = bool(wg_stream) and self.fused and os.environ.get("MA_WG_STREAM", "1") != "0"  # (the switch: for A/B runs)
+        # (MA_WG_STREAM=0 / force: the switch of tools/flaky_loop.sh's A/B runs)
+        self._wg_on = (bool(wg_stream) or os.environ.get("MA_WG_STREAM") == "force") and self.fused and os.environ.get("MA_WG_STREAM") != "0"
         self._wg, self._wg_keep, self._wg_pool, self._wg_next, self._wg_done, self._dw_par = None, [], [], 0, {}, 0
         self._wg_stream, self._wg_seen = None, {}
         self._wg_queue, self._main = [], None

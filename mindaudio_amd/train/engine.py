@@ -13,7 +13,6 @@ examples/conformer/train.py:104-141, examples/conformer/asr_model.py:75-153), wi
   (torch.distributed: "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests of the bucketing logic).
 """
 import math
-import os
 
 import torch
 
@@ -222,8 +221,7 @@ class ConformerCTCTrainStep:
         # run on a second stream beside the input-gradient chain they do not feed (both are latency-bound launches of ~1 workgroup per
         # CU): 12.0 -> 11.5 ms per cfg-4 step, bit-identical results - but OFF by default: in 0.4-7 % of fresh PROCESSES the first engine's
         # first steps came out corrupted with it (see _forward_backward), and the cause is not established.
-        # (MA_WG_STREAM=0 / force: the switch of tools/flaky_loop.sh's A/B runs)
-        self._wg_on = (bool(wg_stream) or os.environ.get("MA_WG_STREAM") == "force") and self.fused and os.environ.get("MA_WG_STREAM") != "0"
+        self._wg_on = bool(wg_stream) and self.fused
         self._wg, self._wg_keep, self._wg_pool, self._wg_next, self._wg_done, self._dw_par = None, [], [], 0, {}, 0
         self._wg_stream, self._wg_seen = None, {}
         self._wg_queue, self._main = [], None
@@ -738,7 +736,7 @@ class ConformerCTCTrainStep:
         key = (b, t, idim)
         seen = self._wg_seen.get(key, 0)
         self._wg_seen[key] = seen + 1
-        self._wg = self._wg_stream if (self._wg_stream is not None and seen >= int(os.environ.get("MA_WG_WARM_STEPS", "2"))) else None
+        self._wg = self._wg_stream if (self._wg_stream is not None and seen >= 2) else None
         self._main = torch.cuda.current_stream() if self._wg is not None else None
 
         # ================= forward =================

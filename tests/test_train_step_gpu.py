@@ -393,8 +393,8 @@ def test_fused_blocks_equal_the_one_launch_per_cell_path_with_dropout():
 
 
 def test_weight_gradient_stream_changes_no_bit():
-    """The blocks' weight-gradient products, their batched sums and the gradient buckets run on a second stream (wg_stream=True, the
-    default) beside the input-gradient chain.  Same launches, same summation orders: three optimizer steps give bit-identical losses
+    """With wg_stream=True (opt-in) the blocks' weight-gradient products, their batched sums and the gradient buckets run on a
+    second stream beside the input-gradient chain.  Same launches, same summation orders: three optimizer steps give bit-identical losses
     and masters with the second stream on and off; a missing cross-stream dependency would show up as a changed bit (the two arena
     halves alternate between blocks, so a block's partials would be overwritten by the next one's)."""
     from mindaudio_amd.train.engine import ConformerCTCTrainStep

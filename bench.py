@@ -165,7 +165,7 @@ def synth_train_batch(rank, dev, b=TRAIN_BATCH, t=TRAIN_FRAMES, vocab=TRAIN_VOCA
     return (xs, d(ys), d(ys_in), d(ys_out), None, None, masks.to(dev), d(ys_sub), d(ys_m), d(ylens), None)
 
 
-def train_step_flops(b, t, vocab, d=256, hidden=2048, blocks=12, heads=4, ks=15):
+def train_step_flops(b, t, vocab, d=256, hidden=2048, blocks=12, heads=4, ks=15, dec_blocks=0):
     """Algorithmic FLOPs of one cfg-4 optimizer step (2 x multiply-adds of every contraction; backward = 2 x forward: one product
     for the input gradient, one for the weight gradient), per rank.  Forward per utterance at t = 1024: 23.86 GFLOP."""
     t1, f1 = (t - 3) // 2 + 1, (80 - 3) // 2 + 1
@@ -175,10 +175,15 @@ def train_step_flops(b, t, vocab, d=256, hidden=2048, blocks=12, heads=4, ks=15)
     layer = 2 * (2 * t2 * d * hidden * 2) + 2 * t2 * d * 3 * d + heads * (2 * t2 * t2 * 2 * dk + 2 * t2 * t2 * dk) + 2 * t2 * d * d \
         + 2 * t2 * d * 2 * d + 2 * t2 * d * ks + 2 * t2 * d * d
     fwd = front + blocks * layer + 2 * t2 * d * vocab
+    if dec_blocks:  # TransformerDecoder on 31 tokens per utterance: self-attn (qkv, o), source attention (q, kv over T', o), FFN, output layer
+        lt = 31
+        dec_layer = 2 * lt * (4 * d * d + 2 * d * d + 2 * d * hidden) + 2 * t2 * 2 * d * d + heads * (4 * lt * lt * dk + 4 * lt * t2 * dk)
+        fwd += dec_blocks * dec_layer + 2 * lt * d * vocab
     return 3.0 * b * fwd
 
 
-def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=False, digest=False):
+def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=False, digest=False, ctc_weight=1.0,
+              second_stream=False):
     """cfg 4: `steps` optimizer steps of ConformerCTCTrainStep on a (40, 1024, 80) batch per rank, gradients
     all-reduced over RCCL in per-block buckets overlapped with the backward pass.  Also times the same all-reduce alone
     (bus bandwidth) and the step with communication disabled (exposed communication)."""
@@ -188,8 +193,17 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=F
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
     torch.manual_seed(777)  # same initial weights on every rank (examples/conformer/train.py:56)
-    model = create_asr_model(80, TRAIN_VOCAB, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12),
-                             ctc_weight=1.0).to(dev)
+    hybrid = ctc_weight != 1.0  # the shipped conformer.yaml: ctc_weight 0.3, 6-block TransformerDecoder, label smoothing 0.1
+
+    def make_model():
+        torch.manual_seed(777)
+        return create_asr_model(80, TRAIN_VOCAB, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12),
+                                ctc_weight=ctc_weight,
+                                decoder_conf=dict(attention_heads=4, linear_units=2048, num_blocks=6, dropout_rate=0.1,
+                                                  positional_dropout_rate=0.1) if hybrid else None,
+                                lsm_weight=0.1 if hybrid else 0.0).to(dev)
+
+    model = make_model()
     eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, world_size=world, rank=rank,
                                 force_collective=force_collective)
     cols = synth_train_batch(rank, dev)
@@ -211,30 +225,42 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=F
     dt, out = timed(steps)
     res = {"utterances_per_s": round(world * TRAIN_BATCH * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
            "steps": steps, "global_batch": TRAIN_BATCH * world, "frames": TRAIN_FRAMES, "vocab": TRAIN_VOCAB,
-           "workload": "Conformer-small (12 blocks) pure-CTC training step: forward + backward + bucketed gradient "
-                       "all-reduce + Adam/ASRWarmupLR/dynamic loss scale, dropout 0.1, bf16 matmuls, float32 masters",
+           "workload": "Conformer-small (12 blocks) %s training step: forward + backward + bucketed gradient "
+                       "all-reduce + Adam/ASRWarmupLR/dynamic loss scale, dropout 0.1, bf16 matmuls, float32 masters" %
+                       ("hybrid (0.3 CTC + 0.7 attention, 6-block TransformerDecoder, label smoothing 0.1: the shipped conformer.yaml)"
+                        if hybrid else "pure-CTC"),
            "first_loss": round(first[0], 3), "last_loss": round(float(out[0]), 3), "loss_scale": out[2],
            "overflow_last_step": bool(out[3]), "grad_bytes": eng.fp.size * 4}
-    flops = train_step_flops(TRAIN_BATCH, TRAIN_FRAMES, TRAIN_VOCAB)
+    flops = train_step_flops(TRAIN_BATCH, TRAIN_FRAMES, TRAIN_VOCAB, dec_blocks=6 if hybrid else 0)
     tf = world * flops / (dt / steps) / 1e12
     res["roofline"] = {"bound": "mfma", "algorithmic_flops_per_step": int(world * flops), "achieved": round(tf, 1),
                        "peak": MFMA_BF16_PEAK_TF * world, "unit": "TFLOP/s", "frac": round(tf / (MFMA_BF16_PEAK_TF * world), 4)}
-    if world == 1 and not force_collective and not digest:
-        # the opt-in second stream for the weight-gradient products (engine.py: wg_stream; off by default): same step,
-        # same results bit for bit, reported beside the default
-        torch.manual_seed(777)
-        model2 = create_asr_model(80, TRAIN_VOCAB, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12),
-                                  ctc_weight=1.0).to(dev)
-        eng2 = ConformerCTCTrainStep(model2, dropout_rate=0.1, positional_dropout_rate=0.1, world_size=1, rank=0, wg_stream=True)
+    # host side of one step: the time to ENQUEUE it (Python + ctypes + launches) with the GPU kept busy, so that no call waits for
+    # the device; the step is GPU-bound while this stays below ms_per_step (8 ranks share one host)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(1e8))  # ~50 ms of GPU time in front of the step
+    t0 = time.perf_counter()
+    pending = eng.enqueue_step(*cols)
+    res["host_enqueue_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    eng.finish_step(*pending)
+    if second_stream and world == 1 and not force_collective:
+        # --second-stream: the opt-in second stream for the weight-gradient products (engine.py: wg_stream), timed AND
+        # checked: same batches from the same start must leave bit-identical masters
+        eng1 = ConformerCTCTrainStep(make_model(), dropout_rate=0.1, positional_dropout_rate=0.1, world_size=1, rank=0)
+        eng2 = ConformerCTCTrainStep(make_model(), dropout_rate=0.1, positional_dropout_rate=0.1, world_size=1, rank=0, wg_stream=True)
         for _ in range(max(warmup, 3)):
+            eng1.step(*cols)
             eng2.step(*cols)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             eng2.step(*cols)
         torch.cuda.synchronize()
-        res["second_stream_ms_per_step"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
-        del eng2, model2
+        res["second_stream"] = {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 3)}
+        for _ in range(steps):
+            eng1.step(*cols)
+        res["second_stream"]["masters_equal_single_stream"] = bool(torch.equal(eng1.fp.master, eng2.fp.master))
+        del eng1, eng2
     if force_collective:
         res["force_collective"] = True
     if digest:  # bit pattern of the trained masters (tests/test_rccl_world1_gpu.py compares runs with and without the collective)
@@ -286,6 +312,10 @@ def main():
                     help="issue the gradient all-reduces through RCCL even at world size 1 (stream-ordering check on one GPU)")
     ap.add_argument("--train-digest", action="store_true", help="add a hash of the trained masters to train_dp")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg-3 (32 x 1000 x 80 encoder forward) object")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg-5 (ECAPA-TDNN forward, 256 x 300 x 80) object")
+    ap.add_argument("--no-hybrid-leg", action="store_true", help="skip the train_dp_hybrid object (ctc_weight 0.3 training step)")
+    ap.add_argument("--second-stream", action="store_true",
+                    help="also time (and check against the default) the training step with wg_stream=True")
     args = ap.parse_args()
 
     # ---- N > 1: one process per GPU.  Either we already are a rank (WORLD_SIZE set by torch.distributed.run) or this
@@ -452,6 +482,28 @@ def main():
     fb512_s, fb512_bytes = fbank_roofline(512)
     fb512_gbs = fb512_bytes / fb512_s / 1e9
 
+    # ---- the fbank kernel's SECOND roofline: vector-instruction issue.  DESIGN 4.1 says the kernel is bound by VALU issue + its
+    #      per-wave dependency chain, not by HBM bytes; this makes the statement checkable: (VALU wave-instructions per launch, PMC
+    #      constant of profiles/traffic.json) x (issue time of one wave-instruction per SIMD, measured LIVE on this chip at the
+    #      kernel's occupancy of 3 waves per SIMD by ma_valu_issue_probe) / 1024 SIMDs = the time the vector pipes need for the
+    #      instructions alone; frac_of_floor = that floor / the measured kernel time. ------------------------------------------
+    fb_valu = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            n_valu = int(json.load(fh)["feat512_kernel"]["valu_wave_insts"])
+        sink = torch.zeros(4, device=dev)
+        iters, wgs = 2000, 3
+        probe_s = event_time(lambda: lib.ma_valu_issue_probe(wgs, iters, _host.ptr(sink), stream), 10)
+        ns_inst = probe_s * 1e9 / (16 * iters * wgs)
+        n_simd = torch.cuda.get_device_properties(dev).multi_processor_count * 4
+        floor_us = n_valu / n_simd * ns_inst * 1e-3
+        fb_valu = {"wave_insts": n_valu, "issue_ns_per_inst": round(ns_inst, 4), "simds": n_simd, "floor_us": round(floor_us, 3),
+                   "frac_of_floor": round(floor_us / (fb_s * 1e6), 4),
+                   "note": "VALU wave-instructions per launch (PMC SQ_INSTS_VALU) x live issue time per wave-instruction per SIMD "
+                           "(16 x 2000 independent v_fma_f32 per wave, 3 waves per SIMD) / SIMDs, over the kernel time"}
+    except (OSError, KeyError, ValueError):
+        pass
+
     def pmc_traffic(kernel):
         """(HBM bytes per launch of `kernel`, where that was measured) from the committed PMC summary: rocprofv3 cannot run inside
         the bench, so the figure is a constant of the commit `traffic_measured_at` names; `traffic_source_current` says whether the
@@ -490,10 +542,32 @@ def main():
                                       "tflops": round(flops3 / tr3 / 1e12, 1)}
         del enc3, x3
 
-    train = None
+    # ---- cfg 5 (BASELINE.json configs[4]): ECAPA-TDNN forward, 256 x 300 x 80, eval-mode BatchNorm, C = 512 (class default) and
+    #      C = 1024 (the example's size).  hbm_frac = HBM bytes per forward (PMC constant of profiles/traffic.json) / time / 8 TB/s. --
+    cfg5 = None
+    if not args.train and not args.no_cfg5 and world == 1:
+        from mindaudio_amd.models import EcapaTDNN
+
+        cfg5 = {"workload": "EcapaTDNN forward, 256 x 300 x 80, eval-mode BatchNorm, bf16 matmuls"}
+        x5 = torch.randn(256, 300, 80, device=dev, generator=gen)
+        for c, fl in ((512, 2.88e9), (1024, 10.78e9)):
+            torch.manual_seed(0)
+            m5 = EcapaTDNN(80, channels=(c, c, c, c, 3 * c)).eval().to(dev).prepare()
+            s5 = event_time(lambda: m5(x5), 20)
+            nb, meta = pmc_traffic("ecapa_c%d" % c)
+            cfg5["c%d" % c] = {"ms": round(s5 * 1e3, 4), "utt_s": round(256 / s5, 1), "tflops": round(256 * fl / s5 / 1e12, 1),
+                               "mfma_frac": round(256 * fl / s5 / 1e12 / MFMA_BF16_PEAK_TF, 4), "hbm_bytes": nb,
+                               "hbm_frac": None if nb is None else round(nb / s5 / 1e9 / HBM_PEAK_GBS, 4)}
+            del m5
+        del x5
+
+    train = hybrid = None
     if args.train or not args.no_train_leg:
         train = train_leg(rank, world, dev, dist if world > 1 else None, args.steps if args.train else args.train_steps,
-                          args.warmup if args.train else 2, barrier, args.force_collective, args.train_digest)
+                          args.warmup if args.train else 2, barrier, args.force_collective, args.train_digest,
+                          second_stream=args.second_stream)
+        if not args.train and not args.no_hybrid_leg and world == 1 and not args.force_collective:
+            hybrid = train_leg(rank, world, dev, None, max(5, args.train_steps // 2), 2, barrier, ctc_weight=0.3)
 
     if rank == 0:
         flops_utt = 23.12e9
@@ -544,10 +618,16 @@ def main():
                                               "algorithmic_bytes_per_launch": fb512_bytes,
                                               "kernel_ms": round(fb512_s * 1e3, 5)}}
         res["roofline_fbank"].update(pmc_traffic("feat512_kernel")[1])
+        if fb_valu is not None:
+            res["roofline_fbank"]["valu"] = fb_valu
         if cfg3 is not None:
             res["cfg3"] = cfg3
+        if cfg5 is not None:
+            res["cfg5"] = cfg5
         if train is not None and not args.train:
             res["train_dp"] = train
+            if hybrid is not None:
+                res["train_dp_hybrid"] = hybrid
         elif train is not None:
             res["train_dp"] = {k: v for k, v in train.items() if k not in ("utterances_per_s", "ms_per_step", "workload")}
         if cpu is not None:

@@ -56,6 +56,18 @@ enum ma_stft_layout {
 int ma_abi_version(void);
 const char* ma_status_string(int status);
 
+/* Process-wide set-up of the library's kernels (the raised dynamic-LDS limit of every kernel that needs one, all in one go).
+ * Needs a HIP device; idempotent and thread-safe.  Every launch entry point calls it implicitly, so calling it is optional -
+ * a host that wants no runtime configuration call after start-up (e.g. before it starts a second stream) calls it once.
+ * (The reference has no counterpart: it is pure Python, mindaudio/__init__.py.)  ma_init_kernel_attributes() = how many
+ * kernels are registered (a load-time constant; the CPU test checks that the registrations were linked in). */
+int ma_init(void);
+int32_t ma_init_kernel_attributes(void);
+
+/* Measurement aid of bench.py (roofline_fbank.valu), not part of the drop-in path: `iters` x 16 independent v_fma_f32 per wave on
+ * `wgs_per_cu` resident 4-wave workgroups per CU.  Timed by the caller: ns per wave-instruction per SIMD = t / (16 iters wgs_per_cu). */
+int ma_valu_issue_probe(int32_t wgs_per_cu, int32_t iters, float* sink, ma_stream_t stream);
+
 /* 1 + n // hop (center) or 1 + (n - n_fft) // hop — spectrum.py:196,298; <0 on invalid args. */
 int64_t ma_num_frames(int64_t n, int32_t n_fft, int32_t hop, int32_t center);
 

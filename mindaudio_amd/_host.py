@@ -2,6 +2,7 @@
 (windows, mel banks), workspaces.  PyTorch is used for device memory and streams only."""
 import ctypes
 import math
+import threading
 
 import numpy as np
 from scipy.signal import get_window
@@ -20,36 +21,51 @@ def torch():
     return _torch
 
 
+_gpu_ready = False
+
+
 def require_gpu():
+    """torch, after checking that a HIP device exists; the first call also runs the library's one-time kernel set-up (ma_init)."""
+    global _gpu_ready
     t = torch()
-    if not t.cuda.is_available():
-        raise _lib.MindaudioAmdError("mindaudio_amd needs a HIP device (torch.cuda.is_available() is False); "
-                                     "there is no CPU fallback")
+    if not _gpu_ready:
+        if not t.cuda.is_available():
+            raise _lib.MindaudioAmdError("mindaudio_amd needs a HIP device (torch.cuda.is_available() is False); "
+                                         "there is no CPU fallback")
+        _lib.check(_lib.load().ma_init(), "ma_init")
+        _gpu_ready = True
     return t
 
 
-_pinned_stream = None
+# The pin is per THREAD: a loader thread that runs device fbank (or ECAPA inference) while the training thread is inside
+# forward_backward() must keep launching on ITS torch stream, not on the training thread's pinned one.
+_tls = threading.local()
 
 
 def current_stream_ptr():
-    if _pinned_stream is not None:
-        return _pinned_stream
+    p = getattr(_tls, "pin", None)
+    if p is not None:
+        return p
     return ctypes.c_void_p(torch().cuda.current_stream().cuda_stream)
+
+
+def swap_pinned(ptr):
+    """Set this thread's pinned stream pointer (None: follow torch's current stream); returns the previous one."""
+    prev = getattr(_tls, "pin", None)
+    _tls.pin = ptr
+    return prev
 
 
 class pinned_stream:
     """`with pinned_stream():` - resolve torch's current stream ONCE for the block (torch.cuda.current_stream() costs ~1.5 us of
-    host time per call, and a training step makes several hundred launches; the step is host-bound without this)."""
+    host time per call, and a training step makes several hundred launches; the step is host-bound without this).  Thread-local."""
 
     def __enter__(self):
-        global _pinned_stream
-        self.prev = _pinned_stream
-        _pinned_stream = ctypes.c_void_p(torch().cuda.current_stream().cuda_stream)
+        self.prev = swap_pinned(ctypes.c_void_p(torch().cuda.current_stream().cuda_stream))
         return self
 
     def __exit__(self, *exc):
-        global _pinned_stream
-        _pinned_stream = self.prev
+        swap_pinned(self.prev)
         return False
 
 

@@ -111,6 +111,9 @@ ACT_NONE, ACT_SWISH, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 PROTOTYPES = {
     "ma_abi_version": (ctypes.c_int, []),
     "ma_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "ma_init": (ctypes.c_int, []),
+    "ma_init_kernel_attributes": (i32, []),
+    "ma_valu_issue_probe": (ctypes.c_int, [i32, i32, c_f32p, vp]),
     "ma_num_frames": (i64, [i64, i32, i32, i32]),
     "ma_mel_row_stride": (i32, [i32]),
     "ma_stft_f32": (ctypes.c_int, [c_f32p, i64, i64, i64, i32, i32, c_f32p, i32, i32, i32, c_f32p, ctypes.c_void_p]),

@@ -21,12 +21,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -181,6 +176,8 @@ __global__ __launch_bounds__(kDiThreads, 2) void conv2_dinput_kernel(const DinPa
   }
 }
 
+MA_LDS_ATTR(conv2_dinput_kernel, kDiLds);
+
 }  // namespace ma
 
 using namespace ma;
@@ -211,13 +208,6 @@ extern "C" int ma_conv2d_3x3s2_dinput_bf16(const void* dy, int64_t batch, int64_
     const int64_t mc = batch * ((H - ph + 1) / 2) * ((Wd - pw + 1) / 2);
     p.tiles_m[cls] = (int32_t)((mc + kDiBM - 1) / kDiBM);
     if (p.tiles_m[cls] > max_tiles) max_tiles = p.tiles_m[cls];
-  }
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_dinput_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDiLds) !=
-        hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
   }
   MA_LAUNCH(conv2_dinput_kernel, dim3((unsigned)(max_tiles * (C / kDiBN)), 4), dim3(kDiThreads), kDiLds, (hipStream_t)stream, p);
   return MA_OK;

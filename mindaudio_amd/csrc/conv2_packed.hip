@@ -20,12 +20,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -209,6 +204,8 @@ __global__ __launch_bounds__(kC2Threads, 2) void conv2_packed_kernel(const Conv2
   }
 }
 
+MA_LDS_ATTR(conv2_packed_kernel, kC2Lds);
+
 }  // namespace ma
 
 using namespace ma;
@@ -238,13 +235,6 @@ extern "C" int ma_conv2d_3x3s2_packed_nhwc_bf16(const void* act, int64_t batch, 
   if ((reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |
        reinterpret_cast<uintptr_t>(bias)) & 15)
     return MA_ERR_INVALID_ARG;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kC2Lds) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
-  }
   Conv2PackedParams p;
   p.act = reinterpret_cast<const uint16_t*>(act);
   p.wp = reinterpret_cast<const uint4*>(packed);

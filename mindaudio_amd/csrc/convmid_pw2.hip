@@ -12,12 +12,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -686,6 +681,10 @@ extern "C" int ma_debug_cm_prof(unsigned long long* host48) {
 }
 #endif
 
+MA_LDS_ATTR(convmid_pw2_kernel, (kCpTile + 2 * kCpMaxK - 1) * 256 * 4);
+MA_LDS_ATTR(convmodule_kernel<false>, CmLayout<false>::kLds);
+MA_LDS_ATTR(convmodule_kernel<true>, CmLayout<true>::kLds);
+
 }  // namespace ma
 
 using namespace ma;
@@ -714,28 +713,12 @@ extern "C" int ma_convmid_pw2_bf16(const void* y, int64_t ldy, int64_t batch, in
   p.KS = kernel_size;
   size_t lds = (size_t)(kCpTile + 2 * kernel_size - 1) * 256 * sizeof(float);
   if (lds < (size_t)kCpTile * kCpPitch) lds = (size_t)kCpTile * kCpPitch;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_pw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (kCpTile + 2 * kCpMaxK - 1) * 256 * 4) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
-  }
   MA_LAUNCH(convmid_pw2_kernel, dim3((unsigned)((T + kCpTile - 1) / kCpTile), (unsigned)batch), dim3(256), lds, (hipStream_t)stream,
             p);
   return MA_OK;
 }
 
 static int convmodule_launch(ConvModParams& p, int64_t batch, int64_t T, ma_stream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmodule_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CmLayout<false>::kLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&convmodule_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CmLayout<true>::kLds) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
-  }
   const dim3 grid((unsigned)((T + kCpTile - 1) / kCpTile), (unsigned)batch);
   if (p.ctx)
     MA_LAUNCH(convmodule_kernel<true>, grid, dim3(256), CmLayout<true>::kLds, (hipStream_t)stream, p);

@@ -14,12 +14,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -455,17 +450,8 @@ static int mha_small_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk,
   const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, mask, mask_mode, batch, Lq, Lk, heads, d_k, scale);
   if (rc != MA_OK) return rc;
   if (!ctx || !probs || (ldc & 7)) return MA_ERR_INVALID_ARG;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel<false, AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            163840) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    if constexpr (sizeof(AT) == 2)
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_fwd_kernel<true, AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              163840) != hipSuccess)
-        return MA_ERR_LAUNCH;
-    attr = true;
-  }
+  MA_LDS_ATTR_T((mha_small_fwd_kernel<false, AT>), 163840);
+  if constexpr (sizeof(AT) == 2) MA_LDS_ATTR_T((mha_small_fwd_kernel<true, AT>), 163840);
   if constexpr (sizeof(AT) == 2) {
     if (Lk <= kSmK) {
       constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * (kSmD + 4) * 4;
@@ -490,17 +476,8 @@ static int mha_small_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk,
   const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, nullptr, 0, batch, Lq, Lk, heads, d_k, scale);
   if (rc != MA_OK) return rc;
   if (!probs || !ctx || !dctx || !dq || !dk || !dv || (lddq & 7) || (lddk & 1) || (lddv & 1)) return MA_ERR_INVALID_ARG;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel<false, AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            163840) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    if constexpr (sizeof(AT) == 2)
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mha_small_bwd_kernel<true, AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              163840) != hipSuccess)
-        return MA_ERR_LAUNCH;
-    attr = true;
-  }
+  MA_LDS_ATTR_T((mha_small_bwd_kernel<false, AT>), 163840);
+  if constexpr (sizeof(AT) == 2) MA_LDS_ATTR_T((mha_small_bwd_kernel<true, AT>), 163840);
   if constexpr (sizeof(AT) == 2) {
     if (Lk <= kSmK) {
       constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;

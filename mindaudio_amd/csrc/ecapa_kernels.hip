@@ -13,12 +13,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 

@@ -12,12 +12,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -216,6 +211,8 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
   }
 }
 
+MA_LDS_ATTR(istft_frames_kernel, 160 * 1024 - 1024);
+
 }  // namespace ma
 
 using namespace ma;
@@ -313,13 +310,6 @@ int ma_istft_f32(const float* spec, int64_t batch, int32_t n_fft, int64_t frames
   if (workspace_bytes < ma_istft_workspace_bytes(batch, n_frames, n_fft)) return MA_ERR_WORKSPACE;
   const int n_freq = n_fft / 2 + 1;
   const size_t lds = ((size_t)n_freq * ma::kIstftFrames + n_fft) * sizeof(float2);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ma::istft_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024 - 1024) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
-  }
   float* fr = reinterpret_cast<float*>(workspace);
   MA_LAUNCH(ma::istft_frames_kernel, dim3((unsigned)((n_frames + ma::kIstftFrames - 1) / ma::kIstftFrames), (unsigned)batch),
             dim3(256), lds, (hipStream_t)stream, reinterpret_cast<const float2*>(spec), (int64_t)n_freq * frames_total, n_freq,

@@ -30,12 +30,7 @@
 
 // Launch + error check.  hipGetLastError() is sticky across unrelated runtime calls of the host process
 // (e.g. a benign probe inside the framework that owns the context), so clear it first.
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 // Phase timing for tools/ (compiled in only with -DMA_PROFILE; the shipped library has none of it).
 #ifdef MA_PROFILE
@@ -777,8 +772,8 @@ static int launch_feat_cfg(const FeatParams& p_in, hipStream_t stream, int* grid
   static int cached_per_cu = 0;
   if (cached_lds != lds) {
     const void* fn = reinterpret_cast<const void*>(&feat512_kernel<MODE, MAG, NW, OCC, NFFT>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return MA_ERR_LAUNCH;
+    MA_LDS_ATTR_T((feat512_kernel<MODE, MAG, NW, OCC, NFFT>), 160 * 1024);
+    if (ensure_init() != MA_OK) return MA_ERR_LAUNCH;  // (the occupancy query below must see the raised LDS limit)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NW * 64, lds) != hipSuccess || per_cu < 1)
       per_cu = 1;

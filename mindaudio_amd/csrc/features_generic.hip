@@ -11,12 +11,7 @@
 // At cfg-2 size and n_fft = 400 this path is ~4x slower than the 512-point FFT path; it exists for coverage.
 #include "features_common.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -237,13 +232,7 @@ static int launch_generic_mode(const FeatParams& p, const GenericGeom& g, hipStr
   const size_t lds = generic_lds_bytes(g, MODE, p.total_steps);
   constexpr size_t kDynLimit = 160 * 1024 - 1024;  // the kernel also holds a few hundred bytes of static LDS
   if (lds > kDynLimit) return MA_ERR_UNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&feat_generic_kernel<MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLimit) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
-  }
+  MA_LDS_ATTR_T(feat_generic_kernel<MODE>, kDynLimit);
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;

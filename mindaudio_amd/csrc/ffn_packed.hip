@@ -27,12 +27,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -858,6 +853,8 @@ __global__ __launch_bounds__(kPkThreads, 1) void ffn_packed_kernel(const FfnPack
 #undef PK_VOFF
 }
 
+MA_LDS_ATTR(ffn_packed_kernel, kPkLds);
+
 }  // namespace ma
 
 using namespace ma;
@@ -902,13 +899,6 @@ extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t 
 
 static int ffn_packed_launch(const FfnPackedParams& p, ma_stream_t stream) {
   const int64_t M = p.M;
-  static bool ready = false;
-  if (!ready) {
-    if (hipFuncSetAttribute((const void*)&ffn_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPkLds) !=
-        hipSuccess)
-      return MA_ERR_LAUNCH;
-    ready = true;
-  }
   const dim3 grid((unsigned)((M + kPkRows - 1) / kPkRows));
   MA_LAUNCH(ffn_packed_kernel, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p);
   return MA_OK;

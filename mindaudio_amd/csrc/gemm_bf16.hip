@@ -21,12 +21,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -829,13 +824,7 @@ template <int BM, int BN, int NST, int IM2COL, int EPI>
 static int launch_gemm_tile(const GemmParams& p, hipStream_t stream) {
   constexpr int ring = NST * (BM + BN) * BK * 2, stage_c = BM * (BN * 2 + 16);  // K-tile ring / staged bf16 C tile
   constexpr int lds = ring > stage_c ? ring : stage_c;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, NST, IM2COL, EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
-  }
+  MA_LDS_ATTR_T((gemm_bf16_kernel<BM, BN, NST, IM2COL, EPI>), lds);
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int splits = p.kt_split > 0 ? (p.K / BK + p.kt_split - 1) / p.kt_split : 1;
   MA_LAUNCH((gemm_bf16_kernel<BM, BN, NST, IM2COL, EPI>), dim3(tiles, splits), dim3(kGemmThreads), lds, stream, p);
@@ -846,13 +835,7 @@ template <int EPI>
 static int launch_gemm_8ph(const GemmParams& p, hipStream_t stream) {
   constexpr int ring = 2 * k8Buf, stage_c = 256 * (256 * 2 + 16);  // K-tile buffers / staged bf16 C tile
   constexpr int lds = ring > stage_c ? ring : stage_c;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_8ph_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return MA_ERR_LAUNCH;
-    attr = true;
-  }
+  MA_LDS_ATTR_T(gemm_bf16_8ph_kernel<EPI>, lds);
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   MA_LAUNCH((gemm_bf16_8ph_kernel<EPI>), dim3(tiles), dim3(k8Threads), lds, stream, p);
   return MA_OK;
@@ -913,6 +896,9 @@ static int fill_epilogue(GemmParams& p, const ma_gemm_epilogue_t* e) {
   return MA_OK;
 }
 
+MA_LDS_ATTR(gemm_ws512_kernel<true>, kWsLds);
+MA_LDS_ATTR(gemm_ws512_kernel<false>, kWsLds);
+
 }  // namespace ma
 
 using namespace ma;
@@ -940,15 +926,6 @@ int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* o
   // K = 512 with >= 16 k rows and bf16 output (ECAPA's 1 x 1 convolutions at C = 512): the weight-stationary persistent kernel
   if (K == kWsK && (N % kWsCols) == 0 && N <= 1024 && M >= 16384 && p.out_bf16 && !p.residual && p.alpha == 1.0f && (ldo & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws512_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kWsLds) !=
-              hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws512_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kWsLds) !=
-              hipSuccess)
-        return MA_ERR_LAUNCH;
-      attr = true;
-    }
     const int ncb = (int)(N / kWsCols);
     int grid = gemm_num_cus();
     grid -= grid % (8 * ncb);

@@ -17,12 +17,7 @@
 #include "../../include/mindaudio_amd.h"
 #include "train_common.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -402,6 +397,12 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_train_kernel(const ui
   }
 }
 
+MA_LDS_ATTR((gemm_k256_kernel<64, 1>), 64 * (kG2Pitch + 4 * kG2StagePitch));  // 64 rows: 70 KiB (tile + the four staging strips)
+MA_LDS_ATTR((gemm_k256_train_kernel<64, 1>), 64 * (kG2Pitch + 4 * kG2StagePitch));
+MA_LDS_ATTR((gemm_k256_train_kernel<64, 2>), 64 * (kG2Pitch + 4 * kG2StagePitch));
+MA_LDS_ATTR((gemm_k256_train_kernel<64, 3>), 64 * (kG2Pitch + 4 * kG2StagePitch));
+MA_LDS_ATTR((gemm_k256_train_kernel<64, 4>), 64 * (kG2Pitch + 4 * kG2StagePitch));
+
 }  // namespace ma
 
 using namespace ma;
@@ -458,13 +459,6 @@ static int g2_launch(const void* A, int64_t lda, const void* packed, void* out, 
   p.ln_out = reinterpret_cast<uint16_t*>(ln_out);
   p.ld_ln = ld_ln;
   p.ln_eps = ln_eps;
-  static bool lds_set = false;
-  if (!lds_set) {  // 64 rows: 70 KiB of dynamic LDS (tile + the four staging strips)
-    if (hipFuncSetAttribute((const void*)&gemm_k256_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            64 * (kG2Pitch + 4 * kG2StagePitch)) != hipSuccess)
-      return MA_ERR_LAUNCH;
-    lds_set = true;
-  }
   const unsigned nby = (unsigned)(N / kG2Cols);
   const size_t lds64 = 64 * (kG2Pitch + 4 * kG2StagePitch);
   if ((M + 63) / 64 * nby < 384) {  // well under two 64-row workgroups per CU: halve the rows
@@ -503,13 +497,6 @@ extern "C" int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* p
   const size_t lds = (half ? 32 : 64) * (kG2Pitch + 4 * kG2StagePitch);
 #define MA_G2T(MODE_)                                                                                                         \
   {                                                                                                                          \
-    static bool set = false;                                                                                                 \
-    if (!set) {                                                                                                              \
-      if (hipFuncSetAttribute((const void*)&gemm_k256_train_kernel<64, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                              64 * (kG2Pitch + 4 * kG2StagePitch)) != hipSuccess)                                            \
-        return MA_ERR_LAUNCH;                                                                                                \
-      set = true;                                                                                                            \
-    }                                                                                                                        \
     if (half)                                                                                                                \
       MA_LAUNCH((gemm_k256_train_kernel<32, MODE_>), grid, dim3(kG2Threads), lds, (hipStream_t)stream,                       \
                 reinterpret_cast<const uint16_t*>(A), lda, reinterpret_cast<const uint4*>(packed), out, ldo, (int)M, (int)N, e); \

@@ -17,12 +17,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -400,6 +395,13 @@ static int tn_plan(int64_t Mo, int64_t No, int64_t Kc, int* bm, int* kt_split) {
   return (int)((nk + *kt_split - 1) / *kt_split);
 }
 
+constexpr int tn_lds_bytes(int bm) { return kTnStages * (kTnBK * bm * 2 + kTnBK * 256); }
+MA_LDS_ATTR((gemm_tn_bf16_kernel<128, true>), tn_lds_bytes(128));
+MA_LDS_ATTR((gemm_tn_bf16_kernel<128, false>), tn_lds_bytes(128));
+MA_LDS_ATTR((gemm_tn_bf16_kernel<64, true>), tn_lds_bytes(64));
+MA_LDS_ATTR((gemm_tn_bf16_kernel<64, false>), tn_lds_bytes(64));
+MA_LDS_ATTR(gemm_tn_group_kernel, tn_lds_bytes(64));
+
 }  // namespace ma
 
 using namespace ma;
@@ -417,13 +419,6 @@ static int tn_launch(TnParams& p, bool im2col, float* out, int64_t ldo, float al
   const int lds = kTnStages * (kTnBK * bm * 2 + kTnBK * 256);
 #define MA_TN_GO(BM_, IM_)                                                                                            \
   {                                                                                                                   \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel<BM_, IM_>),                          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                         \
-        return MA_ERR_LAUNCH;                                                                                         \
-      attr = true;                                                                                                    \
-    }                                                                                                                 \
     MA_LAUNCH((gemm_tn_bf16_kernel<BM_, IM_>), dim3(tiles, splits), dim3(kTnThreads), lds, s, p);                     \
   }
   if (bm == 128 && im2col) MA_TN_GO(128, true)
@@ -549,13 +544,6 @@ int ma_gemm_tn_partial_group_bf16(const ma_tn_item_t* items, int32_t n, ma_strea
       continue;
     }
     const int lds = kTnStages * (kTnBK * 64 * 2 + kTnBK * 256);
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-          hipSuccess)
-        return MA_ERR_LAUNCH;
-      attr = true;
-    }
     MA_LAUNCH(gemm_tn_group_kernel, dim3((unsigned)total), dim3(kTnThreads), lds, (hipStream_t)stream, g);
   }
   return MA_OK;

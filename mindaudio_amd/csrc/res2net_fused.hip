@@ -18,12 +18,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -193,6 +188,9 @@ __global__ __launch_bounds__(kR2Threads, 2) void res2net_fused_kernel(const Res2
 #undef R2_FETCH
 #undef R2_WLOAD
 
+MA_LDS_ATTR((res2net_fused_kernel<64, 7>), 160 * 1024);
+MA_LDS_ATTR((res2net_fused_kernel<128, 7>), 160 * 1024);
+
 }  // namespace ma
 
 using namespace ma;
@@ -225,14 +223,8 @@ int ma_res2net_fused_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int6
   p.tp = (int32_t)tp; p.T = (int32_t)T; p.H = halo; p.dil = dil; p.steps = scale - 1;
   if (scale != 8) return MA_ERR_UNSUPPORTED;  // the shipped res2net_scale (ecapatdnn.py:343); the chain is unrolled at compile time
   if (cc == 64) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&res2net_fused_kernel<64, 7>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return MA_ERR_LAUNCH;
     MA_LAUNCH((res2net_fused_kernel<64, 7>), dim3((unsigned)batch), dim3(kR2Threads), (size_t)lds, (hipStream_t)stream, p);
   } else {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&res2net_fused_kernel<128, 7>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return MA_ERR_LAUNCH;
     MA_LAUNCH((res2net_fused_kernel<128, 7>), dim3((unsigned)batch), dim3(kR2Threads), (size_t)lds, (hipStream_t)stream, p);
   }
   return MA_OK;

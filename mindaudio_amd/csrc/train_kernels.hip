@@ -17,12 +17,7 @@
 #include "../../include/mindaudio_amd.h"
 #include "train_common.h"
 
-#define MA_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
-  do {                                                                        \
-    (void)hipGetLastError();                                                  \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);        \
-    if (hipGetLastError() != hipSuccess) return MA_ERR_LAUNCH;                \
-  } while (0)
+#include "launch.h"
 
 namespace ma {
 
@@ -1206,9 +1201,7 @@ static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t
   const int nblk = (int)(grid.x * grid.y), width = C * (ks + 1);
   if (workspace_bytes < (int64_t)nblk * width * 4) return MA_ERR_WORKSPACE;
 #define MA_CMB(KS_)                                                                                                    \
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&convmid_bwd_kernel<KS_, AT>),                                 \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (kCbStrip + KS_ - 1) + kCbStrip) * 256 * 4) != hipSuccess)     \
-    return MA_ERR_LAUNCH;                                                                                              \
+  MA_LDS_ATTR_T((convmid_bwd_kernel<KS_, AT>), (2 * (kCbStrip + KS_ - 1) + kCbStrip) * 256 * 4);                     \
   MA_LAUNCH((convmid_bwd_kernel<KS_, AT>), grid, dim3(256), (size_t)(2 * (kCbStrip + KS_ - 1) + kCbStrip) * 256 * sizeof(float),   \
             (hipStream_t)stream, dz, y, ldy, (int)batch, (int)T, C, dw_w, dy, lddy, part, per_block)
   if (ks == 3) { MA_CMB(3); }

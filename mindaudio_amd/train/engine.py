@@ -228,6 +228,9 @@ class ConformerCTCTrainStep:
         self.K, self.O = (X32, X32) if self.x32 else (K, ops)
         self.model, self.enc = model, enc
         self.dev = next(model.parameters()).device
+        if self.dev.type == "cuda":
+            _host.require_gpu()  # (+ the library's one-time kernel set-up, ma_init, before any stream of the step exists)
+        self._wg_from = 2  # first step of a batch shape that may use the second stream (tools/wg_hunt.py sets 0)
         if self._wg_on and self.dev.type == "cuda":
             import ctypes
 
@@ -726,6 +729,8 @@ class ConformerCTCTrainStep:
         fp._grad_alloc.zero_()
         self._wg_next = 0
         self._wg_done.clear()
+        self._wg_queue.clear()  # (a step that raised mid-backward must not leave stale products / pinned operands behind)
+        self._wg_keep.clear()
         # The second stream is used from the THIRD step of a batch shape on.  With it active in the first steps of the first engine of a
         # process (driver allocations of the tape, per-kernel hipFuncSetAttribute calls, the runtime's lazy set-up all happen there), 1-7 %
         # of fresh processes showed a corrupted first or second backward pass - NaNs or finite garbage in the input-gradient chain from
@@ -736,7 +741,7 @@ class ConformerCTCTrainStep:
         key = (b, t, idim)
         seen = self._wg_seen.get(key, 0)
         self._wg_seen[key] = seen + 1
-        self._wg = self._wg_stream if (self._wg_stream is not None and seen >= 2) else None
+        self._wg = self._wg_stream if (self._wg_stream is not None and seen >= self._wg_from) else None
         self._main = torch.cuda.current_stream() if self._wg is not None else None
 
         # ================= forward =================
@@ -832,11 +837,11 @@ class ConformerCTCTrainStep:
             if getattr(self, "_wg_ws", None) is None or self._wg_ws.numel() < need:
                 self._wg_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
             self._wg.wait_event(self._wg_event().record_on(self._main))
-            prev, _host._pinned_stream = _host._pinned_stream, self._wg_ptr
+            prev = _host.swap_pinned(self._wg_ptr)
             try:
                 K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"), ws=self._wg_ws)
             finally:
-                _host._pinned_stream = prev
+                _host.swap_pinned(prev)
             self._wg_keep.append((dy2, act1, dact2))
         else:
             K.conv2d_dw(dy2, act1, fp.g("conv2_w"), fp.g("conv2_b"))
@@ -1155,11 +1160,11 @@ class ConformerCTCTrainStep:
                 # behind the block's products on their stream AND the main stream's partials (LayerNorm / attention backward) and
                 # direct sums (depthwise convolution, BatchNorm); the bucket goes on the wire behind the sums
                 self._wg.wait_event(self._wg_event().record_on(self._main))
-                prev, _host._pinned_stream = _host._pinned_stream, self._wg_ptr
+                prev = _host.swap_pinned(self._wg_ptr)
                 try:
                     self.K.gemm_tn_partial_group(self._wg_queue, with_colsum=True)  # the block's eight products: one grid
                 finally:
-                    _host._pinned_stream = prev
+                    _host.swap_pinned(prev)
                 # (dy / x stay referenced until the step's join: the caching allocator only orders reuse on the allocating stream)
                 self._wg_keep.extend(self._wg_queue)
                 self._wg_queue.clear()
@@ -1233,6 +1238,16 @@ class ConformerCTCTrainStep:
           schedule(global_step), the update uses schedule(global_step + 1), and a clean step advances the counter by two.
         * `applied_steps` counts the updates actually applied: Adam's beta1_power / beta2_power live inside the optimizer,
           which is not executed on overflow (train_one_step.py:45-46), so the bias correction uses this counter."""
+        loss, scale, lr = self.enqueue_step(xs_pad, ys_pad, ys_in_pad, ys_out_pad, r_ys_in_pad, r_ys_out_pad, xs_masks, ys_sub_masks,
+                                            ys_masks, ys_lengths, xs_chunk_masks)
+        return self.finish_step(loss, scale, lr)
+
+    @torch.no_grad()
+    def enqueue_step(self, xs_pad, ys_pad, ys_in_pad=None, ys_out_pad=None, r_ys_in_pad=None, r_ys_out_pad=None,
+                     xs_masks=None, ys_sub_masks=None, ys_masks=None, ys_lengths=None, xs_chunk_masks=None):
+        """Everything of step() that only ENQUEUES device work (forward, backward, all-reduce launches, overflow check, Adam, the bf16
+        weight refresh); no host read-back.  finish_step() reads the overflow flag and moves the host-side counters.  (bench.py
+        times this call behind a busy GPU: `train_dp.host_enqueue_ms`.)"""
         scale = self.scaler.scale
         loss = self.forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale=scale,
                                      ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_sub_masks=ys_sub_masks,
@@ -1248,6 +1263,10 @@ class ConformerCTCTrainStep:
         K.adam(self.fp.master, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, lr_t, self.b1, self.b2, self.eps,
                1.0 / (scale * self.world), self.flag)
         self.refresh_weights()
+        return loss, scale, lr
+
+    def finish_step(self, loss, scale, lr):
+        two = self.lr_step_rule == "mindspore23"
         overflow = bool(int(self.flag.item()))  # the reference also hands `cond` back to the host every step
         self.scaler.update(overflow)
         self.calls += 1

@@ -1,0 +1,129 @@
+"""Development: ONE fresh-process sample of the cfg-4 training step for the two-hardware-queue corruption hunt.
+
+    python tools/wg_hunt.py --mode {single,wg,serial,foreign} [--steps 3] [--same-batch] --out sums.json
+
+Every step gets a DIFFERENT batch and (through the engine's per-step seed) different dropout masks, and the output is a checksum of
+every gradient tensor after every step - so a read of stale data (last step's, or another engine's, near-identical values) shows as a
+mismatch against the single-stream twin instead of hiding behind identical bytes; tools/wg_hunt_loop.py compares the sums of each
+sample with the `single` reference and names the first tensor of the backward chain that differs.
+
+modes: single  = one stream (the reference);
+       wg      = the engine's second stream from the FIRST step on (weight-gradient products + batched sums beside the main chain);
+       serial  = the same two streams, but the main stream waits for every block's products at once: two hardware queues, no
+                 concurrent execution (ordering / visibility between queues vs concurrency);
+       foreign = the engine on ONE stream (every product of the library on the main stream), while a second stream runs torch's own
+                 matmuls and copies at the points where `wg` would run the products (the library's kernels vs any concurrent kernel).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+V, T, BLOCKS = 4233, 1024, 12
+
+
+def batch(b, seed):
+    rng = np.random.RandomState(seed)
+    xs = torch.from_numpy(rng.randn(b, T, 80).astype(np.float32))
+    lens = rng.randint(int(0.7 * T), T + 1, b)
+    lens[0] = T
+    t2 = ((T - 3) // 2 + 1 - 3) // 2 + 1
+    sub = torch.zeros(b, 1, t2)
+    for i, n in enumerate(lens):
+        sub[i, 0, :(n - 1) // 4] = 1
+        xs[i, n:] = 0
+    ylens = torch.from_numpy(rng.randint(5, 31, b).astype(np.int32))
+    ys = torch.full((b, 30), -1, dtype=torch.int32)
+    for i, n in enumerate(ylens.tolist()):
+        ys[i, :n] = torch.from_numpy(rng.randint(1, V - 1, n).astype(np.int32))
+    return xs, ys, sub, ylens
+
+
+def tensor_sums(eng):
+    """int64 wrap-around sum of the raw 32-bit patterns of every gradient tensor (one cumsum + one gather)."""
+    g = eng.fp.grad
+    cs = torch.cumsum(g.view(torch.int32).to(torch.int64), 0)
+    names, lo, hi = [], [], []
+    for name, (off, shape, n) in eng.fp.index.items():
+        names.append(name)
+        lo.append(off)
+        hi.append(off + n - 1)
+    lo_t = torch.tensor(lo, device=g.device)
+    hi_t = torch.tensor(hi, device=g.device)
+    first = torch.where(lo_t > 0, cs[(lo_t - 1).clamp(min=0)], torch.zeros_like(lo_t))
+    return names, (cs[hi_t] - first).tolist()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="wg", choices=("single", "wg", "serial", "foreign"))
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--same-batch", action="store_true")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    from mindaudio_amd.conformer.asr_model import create_asr_model
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(777)
+    model = create_asr_model(80, V, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=BLOCKS)).to(dev)
+    eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1,
+                                wg_stream=a.mode in ("wg", "serial"))
+    eng._wg_from = 0
+    orig_done = eng._layer_done
+    if a.mode == "serial":
+        def done_serial(li):
+            orig_done(li)
+            if eng._wg is not None and li in eng._wg_done:
+                eng._main.wait_event(eng._wg_done[li].ev)
+        eng._layer_done = done_serial
+    elif a.mode == "foreign":
+        side = torch.cuda.Stream(device=dev)
+        ja = torch.randn(10200, 2048, device=dev).to(torch.bfloat16)
+        jb = torch.randn(10200, 256, device=dev).to(torch.bfloat16)
+        jc = torch.empty(2048, 256, device=dev, dtype=torch.bfloat16)
+        j1 = torch.randn(20 << 20, device=dev)
+        j2 = torch.empty_like(j1)
+        evs = [torch.cuda.Event() for _ in range(BLOCKS)]
+
+        def done_foreign(li):
+            main = torch.cuda.current_stream()
+            evs[li].record(main)
+            side.wait_event(evs[li])
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    torch.mm(ja.t(), jb, out=jc)
+                j2.copy_(j1)
+            orig_done(li)
+        eng._layer_done = done_foreign
+    out = dict(mode=a.mode, steps=[], env={k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES",) if k in os.environ})
+    for s in range(a.steps):
+        xs, ys, sub, yl = batch(40, 43 if a.same_batch else 43 + s)
+        cols = (xs.to(dev), ys.to(dev), None, None, None, None, sub.to(dev), None, None, yl.to(dev), None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss, cond, scale, overflow, lr = eng.step(*cols)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        names, sums = tensor_sums(eng)
+        out["steps"].append(dict(loss=float(loss), overflow=bool(overflow), sums=sums, host_ms=round(t_host * 1e3, 2),
+                                 ms=round(t_all * 1e3, 2)))
+        out["names"] = names
+    if a.mode == "foreign":
+        torch.cuda.synchronize()
+    txt = json.dumps(out)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(txt)
+    else:
+        print(txt)
+
+
+if __name__ == "__main__":
+    main()

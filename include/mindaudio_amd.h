@@ -473,6 +473,23 @@ typedef struct ma_tn_item {
 } ma_tn_item_t;
 int ma_gemm_tn_partial_group_bf16(const ma_tn_item_t* items, int32_t n, ma_stream_t stream);
 
+/* Weight-gradient products WITHOUT split-K (round 4): out (Mo, No) float32 = A^T B, colsum (Mo, may be NULL) = column sums of A,
+ * for up to ma_gemm_tn_direct_max_items() products in ONE grid of 256 x 256 tiles, each tile with the full contraction - no partial
+ * products, no reduction pass; results are STORED (not accumulated).  `items` is a HOST array.  The training engine issues the
+ * products of several Conformer blocks together (39 tiles per block: six blocks fill the chip).  Needs Mo % 256 == No % 256 == 0,
+ * lda % 8 == ldb % 8 == ldo % 4 == 0 and 16-byte aligned pointers: MA_ERR_UNSUPPORTED otherwise (the caller falls back to
+ * ma_gemm_tn_partial_group_bf16).  Gradients of mindaudio/models/layers/dense.py:16-62 under train_one_step.py:36-41. */
+typedef struct ma_tn_direct_item {
+  const void* A;  /* (Kc, >= Mo) bf16, row stride lda */
+  const void* B;  /* (Kc, >= No) bf16, row stride ldb */
+  float* out;     /* (Mo, No), row stride ldo */
+  float* colsum;  /* (Mo) or NULL */
+  int64_t lda, ldb, ldo;
+  int32_t Mo, No, Kc, reserved;
+} ma_tn_direct_item_t;
+int32_t ma_gemm_tn_direct_max_items(void);
+int ma_gemm_tn_direct_group_bf16(const ma_tn_direct_item_t* items, int32_t n, ma_stream_t stream);
+
 
 
 /* ---- training forms of the packed dense layers: the layer's element-wise neighbours ride in the epilogue ---------------------

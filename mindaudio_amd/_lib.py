@@ -80,6 +80,13 @@ class TnItem(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class TnDirectItem(ctypes.Structure):
+    """struct ma_tn_direct_item (host array: one weight-gradient product each, no split-K)."""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("out", ctypes.c_void_p), ("colsum", ctypes.c_void_p),
+                ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldo", ctypes.c_int64), ("Mo", ctypes.c_int32),
+                ("No", ctypes.c_int32), ("Kc", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class PackItem(ctypes.Structure):
     """struct ma_pack_item (include/mindaudio_amd.h)."""
 
@@ -193,6 +200,8 @@ PROTOTYPES = {
     "ma_gemm_rows_train_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp, i64, ctypes.POINTER(TrainEpilogue), vp]),
     "ma_conv2d_3x3s2_dinput_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]),
     "ma_gemm_tn_partial_group_bf16": (ctypes.c_int, [ctypes.POINTER(TnItem), i32, vp]),
+    "ma_gemm_tn_direct_max_items": (i32, []),
+    "ma_gemm_tn_direct_group_bf16": (ctypes.c_int, [ctypes.POINTER(TnDirectItem), i32, vp]),
     "ma_convmid_bwd_parts": (i32, [i64, i64]),
     "ma_pack_item_pieces": (i64, [i32, i64, i64]),
     "ma_pack_batch_bf16": (ctypes.c_int, [vp, vp, i32, vp]),

@@ -10,32 +10,38 @@ namespace ma {
 
 // Counter-based dropout: the keep decision of element `idx` of dropout site `salt` at step seed `seed` is a pure
 // function, so the backward pass regenerates the mask instead of storing it.
-// One 32-bit hash serves the element pair (idx & ~1, idx | 1), 16 bits each (p is resolved to 2^-16): the three integer multiplies
-// of the mixer are quarter-rate instructions and made the element-wise kernels VALU-bound; kernels that walk consecutive
-// elements get the pair's hash once (common subexpression after inlining).
+// 64 hash bits serve the element QUAD (idx & ~3 .. idx | 3), 16 bits each (p is resolved to 2^-16).  Integer multiplies are
+// quarter-rate instructions and the mixer made the dense layers' epilogues VALU-bound: round 3's pair hash spent three of them per
+// element pair (1.5 per element), this one three per quad (0.75 per element): a lowbias32 mixer (two multiplies) for the first word
+// and one more multiply round on it for the second.  Kernels that walk consecutive elements get the quad's hash once (common
+// subexpression after inlining).  The seed / salt products are wave-uniform (scalar unit); the quad index's high word (non-zero
+// from 2^34 elements on) is folded in without a multiply.
 struct Drop {
   uint32_t seed, salt, thresh;  // thresh = p * 2^32; 0 = no dropout
   float inv_keep;               // 1 / (1 - p)
 };
-__device__ __forceinline__ uint32_t drop_pair_hash(uint32_t seed, uint32_t salt, uint64_t pair) {
-  uint32_t x = (uint32_t)pair ^ (seed * 0x9E3779B9u) ^ (salt * 0x85EBCA6Bu) ^ ((uint32_t)(pair >> 32) * 0xC2B2AE35u);
+__device__ __forceinline__ uint2 drop_quad_hash(uint32_t seed, uint32_t salt, uint64_t quad) {
+  const uint32_t hi = (uint32_t)(quad >> 32);
+  uint32_t x = (uint32_t)quad ^ (seed * 0x9E3779B9u) ^ (salt * 0x85EBCA6Bu) ^ (hi << 16) ^ (hi >> 16) ^ hi;
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  x += salt; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
-  return x;
+  uint32_t y = x ^ 0x9E3779B9u;
+  y *= 0xC2B2AE35u; y ^= y >> 15;
+  return make_uint2(x, y);
 }
 __device__ __forceinline__ bool keep_elem(uint32_t seed, uint32_t salt, uint64_t idx, uint32_t thresh) {
-  const uint32_t x = drop_pair_hash(seed, salt, idx >> 1);
-  return ((idx & 1) ? (x >> 16) : (x & 0xffffu)) >= (thresh >> 16);
+  const uint2 h = drop_quad_hash(seed, salt, idx >> 2);
+  const uint32_t w = (idx & 2) ? h.y : h.x;
+  return ((idx & 1) ? (w >> 16) : (w & 0xffffu)) >= (thresh >> 16);
 }
 // four consecutive elements idx .. idx + 3 (idx % 4 == 0): v[r] = keep ? v[r] * inv_keep : 0
 __device__ __forceinline__ void drop4(const Drop& d, uint64_t idx, float (&v)[4]) {
   if (!d.thresh) return;
   const uint32_t t = d.thresh >> 16;
-  const uint32_t h0 = drop_pair_hash(d.seed, d.salt, idx >> 1), h1 = drop_pair_hash(d.seed, d.salt, (idx >> 1) + 1);
-  v[0] = (h0 & 0xffffu) >= t ? v[0] * d.inv_keep : 0.0f;
-  v[1] = (h0 >> 16) >= t ? v[1] * d.inv_keep : 0.0f;
-  v[2] = (h1 & 0xffffu) >= t ? v[2] * d.inv_keep : 0.0f;
-  v[3] = (h1 >> 16) >= t ? v[3] * d.inv_keep : 0.0f;
+  const uint2 h = drop_quad_hash(d.seed, d.salt, idx >> 2);
+  v[0] = (h.x & 0xffffu) >= t ? v[0] * d.inv_keep : 0.0f;
+  v[1] = (h.x >> 16) >= t ? v[1] * d.inv_keep : 0.0f;
+  v[2] = (h.y & 0xffffu) >= t ? v[2] * d.inv_keep : 0.0f;
+  v[3] = (h.y >> 16) >= t ? v[3] * d.inv_keep : 0.0f;
 }
 inline Drop make_drop(float p, uint32_t seed, uint32_t salt) {
   Drop d;

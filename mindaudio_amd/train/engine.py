@@ -106,10 +106,13 @@ class BucketedAllReduce:
     """Gradient all-reduce of the data-parallel step (the reference's grad_reducer, train_one_step.py:36): slices of the
     flat gradient buffer are summed across ranks as soon as the backward pass has finished them (asynchronous
     collectives on the backend's own stream), and `wait()` joins them before the optimizer.  With world == 1 it is a
-    no-op unless `force_collective` (the collectives are then issued through the backend at world 1: a SUM over one rank is the
-    identity, so the step must produce bit-identical masters - this is how the stream ordering between the library's launches on
-    torch's current stream and RCCL's own stream is tested on ONE GPU).  Division by the world size happens inside the Adam
-    kernel's scale."""
+    no-op unless `force_collective`: the collectives are then issued through the backend at world 1 as ReduceOp.AVG.  An in-place
+    SUM over one rank is short-circuited by NCCL / RCCL without any device work; AVG is a pre-multiplied sum, for which the library
+    launches its one-rank reduction KERNEL (x * 1/1: the identity, bit for bit) on its own stream - so the step must produce
+    bit-identical masters, and does so only if RCCL's kernels beside the backward pass are ordered correctly against the
+    library's launches on torch's current stream.  That is how the N > 1 concurrency is exercised on ONE GPU
+    (tests/test_rccl_world1_gpu.py counts the RCCL kernels in a rocprofv3 trace).  Division by the world size happens inside the
+    Adam kernel's scale."""
 
     def __init__(self, flat_grad, world_size=1, process_group=None, force_collective=False):
         self.grad, self.world, self.pg = flat_grad, int(world_size), process_group
@@ -121,7 +124,8 @@ class BucketedAllReduce:
         if self.world > 1 or self.force:
             import torch.distributed as dist
 
-            self.pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            op = dist.ReduceOp.AVG if (self.world == 1 and self.force) else dist.ReduceOp.SUM
+            self.pending.append(dist.all_reduce(self.grad[lo:hi], op=op, group=self.pg, async_op=True))
 
     def wait(self):
         for work in self.pending:
@@ -205,7 +209,7 @@ class ConformerCTCTrainStep:
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
                  process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None,
-                 force_collective=False, fused=True, wg_stream=False):
+                 force_collective=False, fused=True, wg_stream=False, dw_group_blocks=6):
         """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
         torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
         activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
@@ -231,6 +235,13 @@ class ConformerCTCTrainStep:
         if self.dev.type == "cuda":
             _host.require_gpu()  # (+ the library's one-time kernel set-up, ma_init, before any stream of the step exists)
         self._wg_from = 2  # first step of a batch shape that may use the second stream (tools/wg_hunt.py sets 0)
+        # dw_group_blocks = G > 0 (fused bf16 path, d_model and hidden multiples of 256): the eight weight-gradient products of a block
+        # are not issued when the block's backward pass is done but together with those of the next G - 1 blocks, as ONE grid of
+        # 256 x 256 tiles with the full contraction each (ma_gemm_tn_direct_group_bf16: 39 tiles per block, G = 6 fills the 256 CUs) -
+        # no split-K partials, no reduction pass.  The gradient buckets of those G blocks go on the wire behind the group (L / G
+        # all-reduce waves per step instead of L).  0 = one split-K grid + batched sum per block (round 3).
+        self.dw_group_blocks = int(dw_group_blocks)
+        self._dq, self._dq_blocks = [], []
         if self._wg_on and self.dev.type == "cuda":
             import ctypes
 
@@ -241,6 +252,8 @@ class ConformerCTCTrainStep:
         self.V = model.ctc.ctc_lo.out_features
         self.Vp = K.pad64(self.V)
         self.hidden = enc.encoders[0].feed_forward.w_1.out_features
+        self._dw_direct = (self.fused and self.dw_group_blocks > 0 and not self._wg_on and self.d % 256 == 0 and
+                           self.hidden % 256 == 0)
         self.ks = enc.kernel
         self.f2 = enc.embed.out.in_features // self.d
         self.p_drop, self.p_pos = float(dropout_rate), float(positional_dropout_rate)
@@ -549,7 +562,7 @@ class ConformerCTCTrainStep:
 
         lib, fp = _lib.load(), self.fp
         off, total = {}, 0
-        for sfx in self._DW_SUFFIXES:
+        for sfx in () if self._dw_direct else self._DW_SUFFIXES:  # (direct products write the flat gradient themselves)
             mo, no = fp.w("l0." + sfx).shape
             nbytes = int(lib.ma_gemm_tn_workspace_bytes(mo, no, m))
             off[sfx] = (total, nbytes, int(lib.ma_gemm_tn_splits(mo, no, m)))
@@ -596,7 +609,7 @@ class ConformerCTCTrainStep:
                 block_item.extend([len(items) - 1] * nblk)
                 first += nblk
 
-            for sfx in self._DW_SUFFIXES:
+            for sfx in () if self._dw_direct else self._DW_SUFFIXES:
                 g = fp.g("l%d.%s" % (li, sfx))
                 gb = fp.g("l%d.%s" % (li, sfx.replace("_w", "_b")))
                 mo, no = g.shape
@@ -686,6 +699,9 @@ class ConformerCTCTrainStep:
         plan = getattr(self, "_dw_cur", None)
         if plan is not None and wname[0] == "l" and bname is not None:
             sfx = wname.split(".", 1)[1]
+            if self._dw_direct and sfx in self._DW_SUFFIXES and self.K.gemm_tn_direct_ok(dy, x, fp.g(wname)):
+                self._dq.append((dy, x, fp.g(wname), fp.g(bname)))  # issued with the group (_layer_done)
+                return
             if sfx in plan["off"]:
                 o, nbytes, _ = plan["off"][sfx]
                 o += self._dw_par * plan["half"]
@@ -731,6 +747,8 @@ class ConformerCTCTrainStep:
         self._wg_done.clear()
         self._wg_queue.clear()  # (a step that raised mid-backward must not leave stale products / pinned operands behind)
         self._wg_keep.clear()
+        self._dq.clear()
+        self._dq_blocks.clear()
         # The second stream is used from the THIRD step of a batch shape on.  With it active in the first steps of the first engine of a
         # process (driver allocations of the tape, per-kernel hipFuncSetAttribute calls, the runtime's lazy set-up all happen there), 1-7 %
         # of fresh processes showed a corrupted first or second backward pass - NaNs or finite garbage in the input-gradient chain from
@@ -1156,6 +1174,15 @@ class ConformerCTCTrainStep:
         plan = getattr(self, "_dw_cur", None)
         if plan is not None:  # the split sums of this block's weight gradients, one launch
             items, block_item, n_blocks = plan["layers"][li]
+            if self._dw_direct:
+                # the block's partial sums (LayerNorm, depthwise convolution, attention biases) now; its weight-gradient products
+                # leave with the group, and the group's gradient buckets behind them
+                _lib.check(_lib.load().ma_reduce_splits_batch_f32(items.data_ptr(), block_item.data_ptr(), n_blocks,
+                                                                  _host.current_stream_ptr()), "reduce_splits_batch")
+                self._dq_blocks.append(li)
+                if len(self._dq_blocks) >= self.dw_group_blocks or li == 0:
+                    self._flush_direct()
+                return
             if self._wg is not None:
                 # behind the block's products on their stream AND the main stream's partials (LayerNorm / attention backward) and
                 # direct sums (depthwise convolution, BatchNorm); the bucket goes on the wire behind the sums
@@ -1187,6 +1214,14 @@ class ConformerCTCTrainStep:
             _lib.check(_lib.load().ma_reduce_splits_batch_f32(items.data_ptr(), block_item.data_ptr(), n_blocks,
                                                               torch.cuda.current_stream().cuda_stream), "reduce_splits_batch")
         self.reducer.launch(*self.fp.span(self.layer_names[li]))
+
+    def _flush_direct(self):
+        if self._dq:
+            self.K.gemm_tn_direct_group(self._dq)
+        for b in self._dq_blocks:
+            self.reducer.launch(*self.fp.span(self.layer_names[b]))
+        self._dq.clear()
+        self._dq_blocks.clear()
 
     def _layer_begin(self, li):
         """Backward of block li starts: its partial sums go to arena half li & 1, which block li + 2 used."""

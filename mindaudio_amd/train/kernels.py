@@ -100,6 +100,28 @@ def gemm_tn_partial_group(triples, with_colsum=True):
     _lib.check(_lib.load().ma_gemm_tn_partial_group_bf16(items, n, _s()), "gemm_tn_partial_group")
 
 
+def gemm_tn_direct_ok(a, b, out):
+    """True if out = a^T b can run on the no-split-K kernel (ma_gemm_tn_direct_group_bf16: 256 x 256 tiles)."""
+    mo, no = a.shape[1], b.shape[1]
+    return (mo % 256 == 0 and no % 256 == 0 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and out.stride(0) % 4 == 0 and
+            a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
+
+
+def gemm_tn_direct_group(quads):
+    """out (Mo, No) f32 = a^T b and colsum (Mo) = column sums of a (or None) for a list of (a, b, out, colsum): one launch per
+    ma_gemm_tn_direct_max_items() products, every 256 x 256 tile with the full contraction (stored, not accumulated)."""
+    lib = _lib.load()
+    cap = int(lib.ma_gemm_tn_direct_max_items())
+    for lo in range(0, len(quads), cap):
+        part = quads[lo:lo + cap]
+        items = (_lib.TnDirectItem * len(part))()
+        for it, (a, b, out, colsum) in zip(items, part):
+            it.A, it.B, it.out, it.colsum = a.data_ptr(), b.data_ptr(), out.data_ptr(), (colsum.data_ptr() if colsum is not None else None)
+            it.lda, it.ldb, it.ldo = a.stride(0), b.stride(0), out.stride(0)
+            it.Mo, it.No, it.Kc = a.shape[1], b.shape[1], a.shape[0]
+        _lib.check(lib.ma_gemm_tn_direct_group_bf16(items, len(part), _s()), "gemm_tn_direct_group")
+
+
 def conv2d_dw_workspace_bytes(rows, c, cout):
     return int(_lib.load().ma_gemm_tn_workspace_bytes(cout, 9 * c, rows))
 

@@ -1,6 +1,7 @@
 """RCCL on ONE GPU: the data-parallel training step with its 14 asynchronous gradient all-reduces issued through
-ProcessGroupNCCL (= RCCL on ROCm) at world size 1.  A SUM over one rank is the identity, so the trained masters must be
-bit-identical to a run that issues no collective at all - which they are only if (i) the collectives on RCCL's own stream
+ProcessGroupNCCL (= RCCL on ROCm) at world size 1, as ReduceOp.AVG: an in-place SUM over one rank is short-circuited without any
+device work, AVG (a pre-multiplied sum) makes RCCL launch its one-rank reduction kernel on its own stream - x * 1/1, the identity.
+So the trained masters must be bit-identical to a run that issues no collective at all - which they are only if (i) RCCL's kernels
 wait for the backward kernels the library launched on torch's current stream and (ii) the optimizer waits for the collectives
 (mindaudio_amd/train/engine.py BucketedAllReduce; the reference's grad_reducer, mindaudio/utils/train_one_step.py:36-41,
 examples/conformer/train.py:73-80).  Each run is a fresh child process started with `python -m torch.distributed.run`
@@ -51,3 +52,33 @@ def test_bucketed_allreduce_through_rccl_at_world_1_leaves_the_step_bit_identica
     # the roofline object of the training step is in the line
     r = with_cc["train_dp"]["roofline"]
     assert r["bound"] == "mfma" and 2.5e12 < r["algorithmic_flops_per_step"] < 3.2e12 and 0 < r["frac"] < 1
+
+
+def test_rccl_device_kernels_really_run_beside_the_backward_pass(tmp_path):
+    """the world-1 test must launch REAL RCCL kernels.  The same command under `rocprofv3 --kernel-trace`: every step
+    issues 14 bucket all-reduces, each of which must appear as an RCCL device kernel in the trace, and some of them must have run
+    concurrently with one of the library's backward kernels on another hardware queue (the condition N > 1 training creates)."""
+    import shutil
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        pytest.skip("rocprofv3 not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rccl_trace_check
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # bench.py as the profiled program itself (a rank of a world of one: no launcher, no re-exec under the profiler)
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), TMPDIR=str(tmp_path))
+    steps, warmup = 3, 1
+    cmd = [prof, "--kernel-trace", "--output-format", "csv", "-d", str(tmp_path / "trace"), "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--train", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
+           "--force-collective"]
+    res = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    info = rccl_trace_check.analyse(str(tmp_path / "trace"))
+    print(json.dumps(info))
+    assert info["library_kernels"] > 1000
+    # 14 buckets per step in the timed and warm-up steps (the no-all-reduce leg and the all-reduce-alone leg add none / SUM no-ops)
+    assert info["rccl_kernels"] >= 14 * (steps + warmup), info
+    assert info["rccl_kernels_concurrent_with_a_library_kernel"] >= 1, info

@@ -565,3 +565,39 @@ def test_grouped_weight_gradient_products_equal_the_separate_launches(K):
     for x, y in zip(sep, grp):
         assert torch.equal(x, y)
 
+
+
+@pytest.mark.parametrize("kc", [10200, 64, 37, 1531])
+def test_direct_weight_gradient_products_no_split_k(K, kc):
+    """ma_gemm_tn_direct_group_bf16 (round 4): out = A^T B and the column sums of A for a list of products in ONE grid of 256 x 256
+    tiles, every tile with the full contraction (no split-K partials, no reduction pass), stored straight into strided outputs.
+    Against float64 products of the same bf16 operands: 2e-5 of the output scale (float32 accumulation over up to 10 200 rows)."""
+    g = torch.Generator().manual_seed(78 + kc)
+    shapes = [(256, 2048), (2048, 256), (768, 256), (256, 256), (512, 256), (256, 512)]
+    quads, want = [], []
+    for n, (mo, no) in enumerate(shapes):
+        lda = mo + (64 if n % 2 else 0)  # strided operands: slices of wider activations
+        a_full = bf(torch.randn(kc, lda, generator=g)).cuda()
+        b_full = bf(torch.randn(kc, no + 8, generator=g)).cuda()
+        a, b = a_full[:, :mo], b_full[:, :no]
+        out_full = torch.full((mo, no + 4), 7.0, device="cuda")
+        out = out_full[:, :no]
+        cs = torch.full((mo,), 7.0, device="cuda") if n != 3 else None
+        quads.append((a, b, out, cs))
+        want.append((a.double().t() @ b.double(), a.double().sum(0), out_full))
+        assert K.gemm_tn_direct_ok(a, b, out)
+    K.gemm_tn_direct_group(quads)
+    torch.cuda.synchronize()
+    for (a, b, out, cs), (w, wcs, out_full) in zip(quads, want):
+        scale = float(w.abs().max())
+        assert float((out.double() - w).abs().max()) <= 2e-5 * scale
+        assert bool((out_full[:, out.shape[1]:] == 7.0).all())  # nothing written past the row
+        if cs is not None:
+            assert float((cs.double() - wcs).abs().max()) <= 2e-5 * max(float(wcs.abs().max()), 1.0) + 1e-4
+    # 50 products: two grids; and a shape the kernel refuses
+    many = [quads[i % len(quads)] for i in range(50)]
+    K.gemm_tn_direct_group(many)
+    torch.cuda.synchronize()
+    assert float((many[-1][2].double() - want[49 % len(quads)][0]).abs().max()) <= 2e-5 * float(want[49 % len(quads)][0].abs().max())
+    odd = bf(torch.randn(kc, 192)).cuda()
+    assert not K.gemm_tn_direct_ok(odd, quads[0][1], torch.empty(192, 2048, device="cuda"))

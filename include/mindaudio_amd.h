@@ -545,7 +545,9 @@ int ma_pack_batch_bf16(const ma_pack_item_t* items, const int32_t* block_item, i
 /* Weight gradient of the 3x3 stride-2 valid Conv2d of the subsampling layer (layers/subsampling.py:42) as the same TN
  * GEMM with an implicit im2col B operand: dw (Cout, 9C) float32 += dy^T . im2col(act), dbias (Cout) += column sums of dy.
  * dy (batch*Ho*Wo, Cout) bf16 row stride ld_dy; act (batch, H, Wd, C) NHWC bf16; C % 128 == 0.
- * workspace >= ma_gemm_tn_workspace_bytes(Cout, 9C, batch*Ho*Wo). */
+ * workspace >= ma_gemm_tn_workspace_bytes(Cout, 9C, batch*Ho*Wo); with >= ma_conv2d_3x3s2_dw_workspace_bytes(batch*Ho*Wo, C, Cout)
+ * bytes and C % 256 == Cout % 256 == 0 the product runs on 256 x 256 tiles (round 4: half the operand bytes per flop). */
+int64_t ma_conv2d_3x3s2_dw_workspace_bytes(int64_t rows, int64_t C, int64_t Cout);
 int ma_conv2d_3x3s2_dw_bf16(const void* dy, int64_t ld_dy, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
                             int64_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                             ma_stream_t stream);

@@ -187,6 +187,7 @@ PROTOTYPES = {
     "ma_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
     "ma_gemm_tn_bf16_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, f32, i32, vp, vp, i64, vp]),
     "ma_conv2d_3x3s2_dw_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp, i64, vp]),
+    "ma_conv2d_3x3s2_dw_workspace_bytes": (i64, [i64, i64, i64]),
     "ma_transpose_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, vp]),
     "ma_transpose_batch_bf16": (ctypes.c_int, [vp, vp, i32, vp]),
     "ma_gemm_tn_splits": (i32, [i64, i64, i64]),

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "../../include/mindaudio_amd.h"
+#include "gemm_tn8.h"
 #include "launch.h"
 
 namespace ma {
@@ -54,27 +55,29 @@ struct Tn8Group {
 
 __device__ __forceinline__ int t8_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }  // granule swizzle of a 256-byte LDS row
 
-__global__ __launch_bounds__(kT8Threads, 1) void gemm_tn8_group_kernel(const Tn8Group g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// IM2COL: B is the im2col matrix of a 3x3 stride-2 valid convolution over an NHWC activation (batch, H, Wd, C), C % 256 == 0: row
+// m = (b, ho, wo), column (kh, kw, c) - the 256 columns of a tile are the channels [c0, c0 + 256) of ONE tap (kh, kw)
+struct Tn8Conv {
+  int32_t H, Wd, C, Ho, Wo;
+  float inv_wo, inv_ho;
+};
+
+__device__ __forceinline__ int t8_div(int m, int d, float inv) {  // floor(m / d) for 0 <= m < 2^24
+  int q = (int)((float)m * inv);
+  if (q * d > m) --q;
+  if ((q + 1) * d <= m) ++q;
+  return q;
+}
+
+// One 256 x 256 tile over the K-tiles [kt_lo, kt_lo + nk) of the contraction (Kc rows in all): out (+ i0 rows, j0 columns) is stored.
+template <bool IM2COL>
+__device__ __forceinline__ void t8_tile(char* smem, const uint16_t* const A, const uint16_t* const B, float* const out,
+                                        float* const colsum, const int lda, const int ldb, const int ldo, const int Kc,
+                                        const int kt_lo, const int nk, const int i0, const int j0, const bool want_cs,
+                                        const Tn8Conv cv) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-  int bid = blockIdx.x;
-  {  // XCD-aware bijective order: consecutive tiles (same product: shared operand panels) land on one XCD's L2
-    const int ntiles = g.total, q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int item = 0;
-  for (int k = 1; k < g.n; ++k)
-    if (bid >= g.it[k].first) item = k;
-  const uint16_t* const A = g.it[item].A;
-  const uint16_t* const B = g.it[item].B;
-  float* const out = g.it[item].out;
-  float* const colsum = g.it[item].colsum;
-  const int lda = g.it[item].lda, ldb = g.it[item].ldb, ldo = g.it[item].ldo, Kc = g.it[item].Kc;
-  const int t = bid - g.it[item].first, tiles_n = g.it[item].tiles_n;
-  const int tile_m = t / tiles_n, tile_n = t - tile_m * tiles_n;
-  const int i0 = tile_m * 256, j0 = tile_n * 256;
 
   // ---- staging: instruction ii of this wave fills unit rows 4 (wid + 8 ii) .. + 3; lane -> (row lane >> 4, chunk position lane & 15),
   // which holds logical chunk sch.  A unit q, unit column c <-> tile row (c >> 6) * 128 + 64 q + (c & 63);
@@ -91,17 +94,29 @@ __global__ __launch_bounds__(kT8Threads, 1) void gemm_tn8_group_kernel(const Tn8
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       a_src[q][ii] = A + i0 + (sch >> 3) * 128 + 64 * q + (sch & 7) * 8;
-      b_src[q][ii] = B + j0 + (sch >> 2) * 64 + 32 * q + (sch & 3) * 8;
+      const int col = j0 + (sch >> 2) * 64 + 32 * q + (sch & 3) * 8;
+      if (IM2COL) {
+        const int khw = col / cv.C, kh = khw / 3, kw = khw - 3 * kh;
+        b_src[q][ii] = B + ((int64_t)kh * cv.Wd + kw) * cv.C + (col - khw * cv.C);
+      } else {
+        b_src[q][ii] = B + col;
+      }
     }
   }
   int64_t offa[2], offb[2];  // row offsets of the K-tile being staged
   auto set_rows = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
-      int m = kt * kT8BK + srow[ii];
+      int m = (kt_lo + kt) * kT8BK + srow[ii];
       if (m >= Kc) m = Kc - 1;  // rows past Kc: finite duplicates, masked out of the A fragments below
       offa[ii] = (int64_t)m * lda;
-      offb[ii] = (int64_t)m * ldb;
+      if (IM2COL) {
+        const int t = t8_div(m, cv.Wo, cv.inv_wo), wo = m - t * cv.Wo;
+        const int b = t8_div(t, cv.Ho, cv.inv_ho), ho = t - b * cv.Ho;
+        offb[ii] = (((int64_t)b * cv.H + 2 * ho) * cv.Wd + 2 * wo) * cv.C;
+      } else {
+        offb[ii] = (int64_t)m * ldb;
+      }
     }
   };
   // unit index U in a buffer: 0 = A q0, 1 = B q0, 2 = B q1, 3 = A q1 (the order in which a K-tile first needs them)
@@ -159,17 +174,15 @@ __global__ __launch_bounds__(kT8Threads, 1) void gemm_tn8_group_kernel(const Tn8
     const v8s v = {f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]};
     return __builtin_bit_cast(t8_bf16x8, v);
   };
-  const bool want_cs = colsum != nullptr && tile_n == 0;
   const uint4 ones_pk = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);  // bf16 1.0 x 8
   const t8_bf16x8 ones = __builtin_bit_cast(t8_bf16x8, ones_pk);
-  const int nk = (Kc + kT8BK - 1) / kT8BK;
   int kt = 0;
   // zero the contraction rows past Kc in the A fragments of the last K-tile (element e of a lane = row base + e)
   auto mask_tail = [&]() __attribute__((always_inline)) {
-    if (kt + 1 == nk && (Kc & (kT8BK - 1))) {
+    if ((kt_lo + kt + 1) * kT8BK > Kc) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const int base = kt * kT8BK + kk * 32 + lg * 8;
+        const int base = (kt_lo + kt) * kT8BK + kk * 32 + lg * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -269,7 +282,98 @@ __global__ __launch_bounds__(kT8Threads, 1) void gemm_tn8_group_kernel(const Tn8
   }
 }
 
+__global__ __launch_bounds__(kT8Threads, 1) void gemm_tn8_group_kernel(const Tn8Group g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  {  // XCD-aware bijective order: consecutive tiles (same product: shared operand panels) land on one XCD's L2
+    const int ntiles = g.total, q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int item = 0;
+  for (int k = 1; k < g.n; ++k)
+    if (bid >= g.it[k].first) item = k;
+  const int Kc = g.it[item].Kc;
+  const int t = bid - g.it[item].first, tiles_n = g.it[item].tiles_n;
+  const int tile_m = t / tiles_n, tile_n = t - tile_m * tiles_n;
+  t8_tile<false>(smem, g.it[item].A, g.it[item].B, g.it[item].out, g.it[item].colsum, g.it[item].lda, g.it[item].ldb, g.it[item].ldo,
+                 Kc, 0, (Kc + kT8BK - 1) / kT8BK, tile_m * 256, tile_n * 256, g.it[item].colsum != nullptr && tile_n == 0, Tn8Conv{});
+}
+
+// The weight gradient of the subsampling layer's second convolution: dW (Cout, 9 C) = dy^T im2col(act), the contraction
+// (batch x Ho x Wo = 193 800 rows at cfg 4) split over blockIdx.y; partial products [split][Cout][9 C] and partial column sums
+// [split][Cout] go to the workspace and are added in split order by tn_reduce_kernel (gemm_tn_bf16.hip).
+struct Tn8ConvParams {
+  const uint16_t* dy;
+  const uint16_t* act;
+  float* part;
+  float* cs_part;  // NULL: no bias gradient
+  int32_t ld_dy, Cout, No, Kc, kt_split, tiles_n;
+  Tn8Conv cv;
+};
+__global__ __launch_bounds__(kT8Threads, 1) void gemm_tn8_conv_kernel(const Tn8ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = blockIdx.x, by = blockIdx.y;
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int nk_all = (p.Kc + kT8BK - 1) / kT8BK, kt_lo = by * p.kt_split;
+  int nk = nk_all - kt_lo;
+  if (nk > p.kt_split) nk = p.kt_split;
+  t8_tile<true>(smem, p.dy, p.act, p.part + (int64_t)by * p.Cout * p.No, p.cs_part ? p.cs_part + (int64_t)by * p.Cout : nullptr, p.ld_dy, 0,
+                p.No, p.Kc, kt_lo, nk, tile_m * 256, tile_n * 256, p.cs_part != nullptr && tile_n == 0, p.cv);
+}
+
 MA_LDS_ATTR(gemm_tn8_group_kernel, kT8Lds);
+MA_LDS_ATTR(gemm_tn8_conv_kernel, kT8Lds);
+
+static int t8_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// one workgroup per CU (the kernel owns the CU's LDS): as many splits as keep tiles x splits inside one resident round, each with at
+// least 16 K-tiles
+static int t8_conv_plan(int64_t M, int64_t C, int64_t Cout, int* kt_split) {
+  if ((C & 255) || (Cout & 255) || M < 1 || M >= (1 << 24)) return 0;
+  const int64_t tiles = (Cout / 256) * (9 * C / 256), nk = (M + kT8BK - 1) / kT8BK;
+  int64_t splits = t8_cus() / tiles;
+  if (splits > nk / 16) splits = nk / 16;
+  if (splits < 1) splits = 1;
+  *kt_split = (int)((nk + splits - 1) / splits);
+  return (int)((nk + *kt_split - 1) / *kt_split);
+}
+
+int tn8_conv_splits(int64_t M, int64_t C, int64_t Cout) {
+  int kt = 0;
+  return t8_conv_plan(M, C, Cout, &kt);
+}
+
+int tn8_conv_launch(const void* dy, int64_t ld_dy, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, int64_t Cout,
+                    float* part, float* cs_part, hipStream_t stream) {
+  const int64_t Ho = (H - 3) / 2 + 1, Wo = (Wd - 3) / 2 + 1, M = batch * Ho * Wo;
+  Tn8ConvParams p;
+  const int splits = t8_conv_plan(M, C, Cout, &p.kt_split);
+  if (splits < 1 || (ld_dy & 7) || ld_dy < Cout || ld_dy > 0x7fffffff) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(part)) & 15) return MA_ERR_INVALID_ARG;
+  p.dy = reinterpret_cast<const uint16_t*>(dy);
+  p.act = reinterpret_cast<const uint16_t*>(act);
+  p.part = part;
+  p.cs_part = cs_part;
+  p.ld_dy = (int32_t)ld_dy;
+  p.Cout = (int32_t)Cout;
+  p.No = (int32_t)(9 * C);
+  p.Kc = (int32_t)M;
+  p.tiles_n = (int32_t)(9 * C / 256);
+  p.cv.H = (int32_t)H; p.cv.Wd = (int32_t)Wd; p.cv.C = (int32_t)C; p.cv.Ho = (int32_t)Ho; p.cv.Wo = (int32_t)Wo;
+  p.cv.inv_wo = 1.0f / (float)Wo;
+  p.cv.inv_ho = 1.0f / (float)Ho;
+  MA_LAUNCH(gemm_tn8_conv_kernel, dim3((unsigned)((Cout / 256) * p.tiles_n), (unsigned)splits), dim3(kT8Threads), kT8Lds, stream, p);
+  return MA_OK;
+}
 
 }  // namespace ma
 

@@ -17,6 +17,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
+#include "gemm_tn8.h"
 #include "launch.h"
 
 namespace ma {
@@ -555,6 +556,14 @@ int ma_reduce_splits_batch_f32(const ma_reduce_item_t* items, const int32_t* blo
   return MA_OK;
 }
 
+int64_t ma_conv2d_3x3s2_dw_workspace_bytes(int64_t rows, int64_t C, int64_t Cout) {
+  if (rows < 1 || C < 1 || Cout < 1) return MA_ERR_INVALID_ARG;
+  const int64_t old_bytes = ma_gemm_tn_workspace_bytes(Cout, 9 * C, rows);
+  const int64_t s8 = tn8_conv_splits(rows, C, Cout);
+  const int64_t new_bytes = s8 * Cout * (9 * C + 1) * 4;
+  return new_bytes > old_bytes ? new_bytes : old_bytes;
+}
+
 int ma_conv2d_3x3s2_dw_bf16(const void* dy, int64_t ld_dy, const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C,
                             int64_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                             ma_stream_t stream) {
@@ -562,6 +571,24 @@ int ma_conv2d_3x3s2_dw_bf16(const void* dy, int64_t ld_dy, const void* act, int6
   if ((C % 128) || (Cout & 7) || (ld_dy & 7) || ld_dy < Cout) return MA_ERR_UNSUPPORTED;
   const int64_t Ho = (H - 3) / 2 + 1, Wo = (Wd - 3) / 2 + 1, M = batch * Ho * Wo;
   if (M >= (1 << 24)) return MA_ERR_UNSUPPORTED;
+  // 256 x 256 tiles (gemm_tn8_bf16.hip) when the shape fits and the caller's workspace holds its partials: half the operand bytes per
+  // flop of the 128 x 128 tile below
+  const int s8 = tn8_conv_splits(M, C, Cout);
+  if (s8 > 0 && (ld_dy & 7) == 0 && workspace_bytes >= (int64_t)s8 * Cout * (9 * C + 1) * 4) {
+    float* part = reinterpret_cast<float*>(workspace);
+    float* cs_part = part + (int64_t)s8 * Cout * 9 * C;
+    const int rc = tn8_conv_launch(dy, ld_dy, act, batch, H, Wd, C, Cout, part, dbias ? cs_part : nullptr, (hipStream_t)stream);
+    if (rc != MA_OK) return rc;
+    const int64_t mn = Cout * 9 * C;
+    int64_t blocks = (mn + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    MA_LAUNCH(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, part, s8, mn, dw, 9 * C, (int32_t)(9 * C), 1.0f,
+              1);
+    if (dbias)
+      MA_LAUNCH(tn_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cs_part, s8, Cout, dbias, Cout,
+                (int32_t)Cout, 1.0f, 1);
+    return MA_OK;
+  }
   TnParams p = TnParams{};
   p.A = reinterpret_cast<const uint16_t*>(dy);
   p.B = reinterpret_cast<const uint16_t*>(act);

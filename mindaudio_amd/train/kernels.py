@@ -123,7 +123,7 @@ def gemm_tn_direct_group(quads):
 
 
 def conv2d_dw_workspace_bytes(rows, c, cout):
-    return int(_lib.load().ma_gemm_tn_workspace_bytes(cout, 9 * c, rows))
+    return int(_lib.load().ma_conv2d_3x3s2_dw_workspace_bytes(rows, c, cout))
 
 
 def conv2d_dw(dy, act, dw, dbias, ws=None):
@@ -133,7 +133,7 @@ def conv2d_dw(dy, act, dw, dbias, ws=None):
     b, h, w, c = act.shape
     cout = dy.shape[1]
     if ws is None:
-        ws = _host.workspace(lib.ma_gemm_tn_workspace_bytes(cout, 9 * c, dy.shape[0]), dy.device)
+        ws = _host.workspace(lib.ma_conv2d_3x3s2_dw_workspace_bytes(dy.shape[0], c, cout), dy.device)
     _lib.check(lib.ma_conv2d_3x3s2_dw_bf16(_p(dy), dy.stride(0), _p(act), b, h, w, c, cout, _p(dw), _p(dbias), _p(ws),
                                            ws.numel(), _s()), "conv2d_dw")
 

@@ -601,3 +601,29 @@ def test_direct_weight_gradient_products_no_split_k(K, kc):
     assert float((many[-1][2].double() - want[49 % len(quads)][0]).abs().max()) <= 2e-5 * float(want[49 % len(quads)][0].abs().max())
     odd = bf(torch.randn(kc, 192)).cuda()
     assert not K.gemm_tn_direct_ok(odd, quads[0][1], torch.empty(192, 2048, device="cuda"))
+
+
+@pytest.mark.parametrize("b2,h2,w2", [(2, 23, 19), (9, 67, 39)])
+def test_conv2_weight_gradient_on_256_tiles(K, b2, h2, w2):
+    """C = Cout = 256 (the subsampling layer's shape): ma_conv2d_3x3s2_dw_bf16 routes to the 256 x 256-tile kernel
+    (gemm_tn8_conv_kernel: implicit im2col operand, contraction split over the grid's second axis, partials added in split order);
+    against autograd of F.conv2d on the same bf16 operands.  The second shape has enough rows for several splits and a K-tile tail."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(5 + b2)
+    c2 = co2 = 256
+    act_b = bf(torch.randn(b2, h2, w2, c2, generator=g))
+    ho2, wo2 = (h2 - 3) // 2 + 1, (w2 - 3) // 2 + 1
+    dy_b = bf(torch.randn(b2 * ho2 * wo2, co2, generator=g))
+    wgt2 = torch.zeros(co2, c2, 3, 3, requires_grad=True)
+    bias2 = torch.zeros(co2, requires_grad=True)
+    o2 = F.conv2d(act_b.float().permute(0, 3, 1, 2), wgt2, bias2, stride=2)
+    o2.backward(dy_b.float().view(b2, ho2, wo2, co2).permute(0, 3, 1, 2))
+    from mindaudio_amd import _lib
+
+    rows = b2 * ho2 * wo2
+    assert int(_lib.load().ma_conv2d_3x3s2_dw_workspace_bytes(rows, c2, co2)) >= int(_lib.load().ma_gemm_tn_workspace_bytes(co2, 9 * c2, rows))
+    dw2, db2 = torch.ones(co2, 9 * c2, device="cuda"), torch.ones(co2, device="cuda")  # += semantics: starts from ones
+    K.conv2d_dw(dy_b.cuda(), act_b.cuda(), dw2, db2)
+    rel = lambda a, w: float((a.cpu().double() - w.double()).abs().max() / w.double().abs().max())  # noqa: E731
+    assert rel(dw2.view(co2, 3, 3, c2) - 1.0, wgt2.grad.permute(0, 2, 3, 1)) < 3e-5 and rel(db2 - 1.0, bias2.grad) < 3e-5

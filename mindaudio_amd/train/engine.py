@@ -252,8 +252,7 @@ class ConformerCTCTrainStep:
         self.V = model.ctc.ctc_lo.out_features
         self.Vp = K.pad64(self.V)
         self.hidden = enc.encoders[0].feed_forward.w_1.out_features
-        self._dw_direct = (self.fused and self.dw_group_blocks > 0 and not self._wg_on and self.d % 256 == 0 and
-                           self.hidden % 256 == 0)
+        self._dw_direct = self.fused and self.dw_group_blocks > 0 and self.d % 256 == 0 and self.hidden % 256 == 0
         self.ks = enc.kernel
         self.f2 = enc.embed.out.in_features // self.d
         self.p_drop, self.p_pos = float(dropout_rate), float(positional_dropout_rate)
@@ -1216,10 +1215,29 @@ class ConformerCTCTrainStep:
         self.reducer.launch(*self.fp.span(self.layer_names[li]))
 
     def _flush_direct(self):
-        if self._dq:
-            self.K.gemm_tn_direct_group(self._dq)
-        for b in self._dq_blocks:
-            self.reducer.launch(*self.fp.span(self.layer_names[b]))
+        if self._wg is not None:
+            # the group's products (and its gradient buckets) on the second stream, behind what the main stream has produced so far;
+            # the step's join (_embed_done) puts the optimizer behind them
+            self._wg.wait_event(self._wg_event().record_on(self._main))
+            prev = _host.swap_pinned(self._wg_ptr)
+            try:
+                if self._dq:
+                    self.K.gemm_tn_direct_group(self._dq)
+            finally:
+                _host.swap_pinned(prev)
+            self._wg_keep.extend(self._dq)  # (operands stay referenced until the join)
+            if self.reducer.world > 1 or self.reducer.force:
+                with torch.cuda.stream(self._wg):
+                    for b in self._dq_blocks:
+                        self.reducer.launch(*self.fp.span(self.layer_names[b]))
+            else:
+                for b in self._dq_blocks:
+                    self.reducer.launch(*self.fp.span(self.layer_names[b]))
+        else:
+            if self._dq:
+                self.K.gemm_tn_direct_group(self._dq)
+            for b in self._dq_blocks:
+                self.reducer.launch(*self.fp.span(self.layer_names[b]))
         self._dq.clear()
         self._dq_blocks.clear()
 

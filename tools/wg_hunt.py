@@ -61,7 +61,9 @@ def tensor_sums(eng):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="wg", choices=("single", "wg", "serial", "foreign"))
+    ap.add_argument("--mode", default="wg", choices=("single", "wg", "serial", "foreign", "wgsplit"))
+    ap.add_argument("--diag", action="store_true", help="on a mismatch with an in-process single-stream twin: which elements differ")
+    ap.add_argument("--group", type=int, default=6, help="dw_group_blocks of the engine (0 = split-K products per block)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--same-batch", action="store_true")
     ap.add_argument("--out", default="")
@@ -72,8 +74,10 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(777)
     model = create_asr_model(80, V, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=BLOCKS)).to(dev)
+    # wg / serial: the engine's second stream with its default products (direct 256 x 256-tile groups); wgsplit: round 3's form - one
+    # split-K grid + batched sum per block on the second stream
     eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1,
-                                wg_stream=a.mode in ("wg", "serial"))
+                                wg_stream=a.mode in ("wg", "serial", "wgsplit"), dw_group_blocks=0 if a.mode == "wgsplit" else a.group)
     eng._wg_from = 0
     orig_done = eng._layer_done
     if a.mode == "serial":
@@ -102,6 +106,7 @@ def main():
             orig_done(li)
         eng._layer_done = done_foreign
     out = dict(mode=a.mode, steps=[], env={k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES",) if k in os.environ})
+    grad0 = None
     for s in range(a.steps):
         xs, ys, sub, yl = batch(40, 43 if a.same_batch else 43 + s)
         cols = (xs.to(dev), ys.to(dev), None, None, None, None, sub.to(dev), None, None, yl.to(dev), None)
@@ -112,11 +117,35 @@ def main():
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
         names, sums = tensor_sums(eng)
+        if a.diag and s == 0:
+            grad0 = eng.fp.grad.clone()
         out["steps"].append(dict(loss=float(loss), overflow=bool(overflow), sums=sums, host_ms=round(t_host * 1e3, 2),
                                  ms=round(t_all * 1e3, 2)))
         out["names"] = names
     if a.mode == "foreign":
         torch.cuda.synchronize()
+    if a.diag:
+        # the single-stream twin of step 0 in THIS process (a later engine of a process has never failed), element by element
+        torch.manual_seed(777)
+        model2 = create_asr_model(80, V, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=BLOCKS)).to(dev)
+        eng2 = ConformerCTCTrainStep(model2, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1,
+                                     dw_group_blocks=0 if a.mode == "wgsplit" else a.group)
+        xs, ys, sub, yl = batch(40, 43)
+        eng2.step(xs.to(dev), ys.to(dev), None, None, None, None, sub.to(dev), None, None, yl.to(dev), None)
+        g2 = eng2.fp.grad
+        diag = []
+        for name, (off, shape, n) in eng.fp.index.items():
+            x, y = grad0[off:off + n], g2[off:off + n]
+            ne = (x != y)
+            k = int(ne.sum())
+            if k:
+                idx = ne.nonzero().flatten()
+                cols = shape[-1] if len(shape) > 1 else n
+                d = (x - y).abs()
+                diag.append(dict(name=name, shape=list(shape), n_diff=k, max_abs=float(d.max()), ref_max=float(y.abs().max()),
+                                 first=idx[:6].tolist(), last=int(idx[-1]), rows_hit=int(torch.unique(idx // cols).numel()),
+                                 cols_hit=int(torch.unique(idx % cols).numel()), nonfinite=int((~torch.isfinite(x)).sum())))
+        out["diag"] = diag
     txt = json.dumps(out)
     if a.out:
         with open(a.out, "w") as f:

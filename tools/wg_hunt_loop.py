@@ -14,6 +14,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXTRA, COMMON = {}, []  # per-arm / common extra child arguments
 OUT = os.path.join(ROOT, "gpurun_out")
 
 
@@ -30,12 +31,13 @@ def chain_order(names, blocks=12):
     return [n for n in order if n in set(names)] + rest
 
 
-def run_child(mode, env_extra, steps, tag):
+def run_child(mode, env_extra, steps, tag, group=None):
     path = os.path.join(OUT, "hunt_%s.json" % tag)
     env = dict(os.environ)
     env.update(env_extra)
     t0 = time.time()
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_hunt.py"), "--mode", mode, "--steps", str(steps), "--out", path],
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_hunt.py"), "--mode", mode, "--steps", str(steps), "--out", path] +
+                         COMMON + (["--group", str(group)] if group is not None else []),
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     dt = time.time() - t0
     if res.returncode != 0 or not os.path.exists(path):
@@ -63,18 +65,26 @@ def main():
     ap.add_argument("--minutes", type=float, default=20.0)
     ap.add_argument("--arms", default="wg,wg_q1,serial,foreign")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--diag", action="store_true")
+    ap.add_argument("--group", type=int, default=6)
     a = ap.parse_args()
+    if a.diag:
+        COMMON.append("--diag")
     os.makedirs(OUT, exist_ok=True)
     arms = a.arms.split(",")
-    ref, dt, err = run_child("single", {}, a.steps, "ref")
-    if ref is None:
-        print("reference child failed:", err)
-        return 1
-    print("reference: %.1f s per child; losses %s; step ms %s" % (dt, [s["loss"] for s in ref["steps"]], [s["ms"] for s in ref["steps"]]),
-          flush=True)
-    # the reference itself must be reproducible: a second single-stream child
-    again, _, err = run_child("single", {}, a.steps, "ref2")
-    print("second single-stream child equals the first:", again is not None and not compare(ref, again), flush=True)
+    # one single-stream reference per product form: direct groups (the engine's default) and round 3's split-K grids (arm `wgsplit`)
+    refs = {}
+    for key, grp in (("direct", a.group), ("split", 0)):
+        ref, dt, err = run_child("single", {}, a.steps, "ref", grp)
+        if ref is None:
+            print("reference child failed:", err)
+            return 1
+        print("reference (%s): %.1f s per child; losses %s; step ms %s" % (key, dt, [s["loss"] for s in ref["steps"]],
+                                                                           [s["ms"] for s in ref["steps"]]), flush=True)
+        # the reference itself must be reproducible: a second single-stream child
+        again, _, err = run_child("single", {}, a.steps, "ref2", grp)
+        print("second single-stream child equals the first:", again is not None and not compare(ref, again), flush=True)
+        refs[key] = ref
     stats = {arm: [0, 0, 0] for arm in arms}  # runs, bad, crashed
     t_end = time.time() + a.minutes * 60
     i = 0
@@ -83,7 +93,8 @@ def main():
         i += 1
         mode = arm.split("_")[0]
         env = {"GPU_MAX_HW_QUEUES": "1"} if arm.endswith("_q1") else {}
-        d, dt, err = run_child(mode, env, a.steps, "%s_%d" % (arm, i))
+        ref = refs["split" if mode == "wgsplit" else "direct"]
+        d, dt, err = run_child(mode, env, a.steps, "%s_%d" % (arm, i), 0 if mode == "wgsplit" else a.group)
         st = stats[arm]
         st[0] += 1
         if d is None:
@@ -97,6 +108,10 @@ def main():
             for s, n, first, loss, rloss, ovf in bad:
                 print("    step %d: %d tensors differ, loss %r (ref %r), overflow %s; first in chain order: %s" %
                       (s, n, loss, rloss, ovf, first), flush=True)
+            if d.get("diag"):
+                order = {n_: i_ for i_, n_ in enumerate(chain_order(ref["names"]))}
+                for e in sorted(d["diag"], key=lambda e: order.get(e["name"], 1 << 30))[:8]:
+                    print("      diag", json.dumps(e), flush=True)
     print("=== summary (%d steps per child, second stream from step 0) ===" % a.steps)
     for arm in arms:
         r, b, c = stats[arm]

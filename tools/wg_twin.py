@@ -19,7 +19,8 @@ def main():
     mod = {"V": mod_.V, "batch": mod_.batch}
     dev = torch.device("cuda", 0)
     engs = []
-    for wg in (True, False):
+    both_single = len(sys.argv) > 2 and sys.argv[2] == "single"  # tool check: two single-stream engines must agree
+    for wg in ((False, False) if both_single else (True, False)):
         torch.manual_seed(777)
         model = create_asr_model(80, mod["V"], dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12)).to(dev)
         e = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1, wg_stream=wg)

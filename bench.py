@@ -314,9 +314,14 @@ def main():
     ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg-3 (32 x 1000 x 80 encoder forward) object")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg-5 (ECAPA-TDNN forward, 256 x 300 x 80) object")
     ap.add_argument("--no-hybrid-leg", action="store_true", help="skip the train_dp_hybrid object (ctc_weight 0.3 training step)")
+    ap.add_argument("--step-only", action="store_true",
+                    help="(profiling) only the warm-up + timed steps of the headline: no roofline loops, no cfg3 / cfg5 / training legs, "
+                         "no CPU baseline - the kernel stats of this run are the step's launches and nothing else")
     ap.add_argument("--second-stream", action="store_true",
                     help="also time (and check against the default) the training step with wg_stream=True")
     args = ap.parse_args()
+    if args.step_only:
+        args.no_cpu_baseline = args.no_train_leg = args.no_sustained = args.no_cfg3 = args.no_cfg5 = True
 
     # ---- N > 1: one process per GPU.  Either we already are a rank (WORLD_SIZE set by torch.distributed.run) or this
     #      process becomes the launcher — decided here, before torch.cuda / any HIP call. ------------------------------
@@ -423,6 +428,15 @@ def main():
             sustained = {"value": round(world * BATCH * n_sus / ds, 1), "unit": "utterances/s", "steps": n_sus,
                          "seconds": round(ds, 3), "ms_per_step": round(ds / n_sus * 1e3, 4)}
 
+    if args.step_only:
+        if rank == 0:
+            print(json.dumps({"metric": "utterances/s (16 kHz×10 s) fbanks+Conformer fwd, 1/2/4/8 MI355X", "step_only": True,
+                              "value": round(world * BATCH * args.steps / dt, 1), "unit": "utterances/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4)}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     def event_time(fn, reps):
         for _ in range(5):
             fn()
@@ -453,6 +467,24 @@ def main():
                         max(args.steps, 50))
     ffn_flops = 2 * (2.0 * m * 256 * hid * 2) + 2.0 * m * 256 * nqkv
     gemm_tf = ffn_flops / gemm_s / 1e12
+    # What bounds that kernel's main loops: every workgroup (= every CU: 249 workgroups of 64 rows) streams ALL
+    # packed weights of the launch (2 x 2 MiB + 384 KiB) L2 -> registers, with 4 MFMAs (the workgroup's 4 row tiles) per 1 KiB
+    # fragment; more rows per workgroup would need a second 64 x 256 accumulator tile per wave (512 registers) and M = 15 936 gives
+    # the 256 CUs only 62 rows each.  The probe measures what one CU sustains in exactly that pattern with every CU doing the same:
+    # floor = weight bytes per workgroup / that rate; the launch cannot be faster than this however the loop is scheduled.
+    ws_buf = torch.zeros(2 << 20, dtype=torch.uint8, device=dev)
+    ws_sink = torch.zeros(4, device=dev)
+    ws_rounds = 128  # 2 MiB per wave, 8 MiB per CU per launch
+    ws_s = event_time(lambda: lib.ma_weight_stream_probe(_host.ptr(ws_buf), ws_buf.numel(), ws_rounds, _host.ptr(ws_sink),
+                                                         _host.current_stream_ptr()), 20)
+    ws_gbs_cu = 4 * ws_rounds * 16 * 1024 / ws_s / 1e9
+    ws_bytes_wg = int(pa.numel() * pa.element_size() + pb.numel() * pb.element_size() + pq.numel() * pq.element_size())
+    weight_stream = {"bytes_per_workgroup": ws_bytes_wg, "probe_GBps_per_cu": round(ws_gbs_cu, 1),
+                     "floor_us": round(ws_bytes_wg / ws_gbs_cu / 1e3, 2),
+                     "frac_of_floor": round(ws_bytes_wg / ws_gbs_cu / 1e3 / (gemm_s * 1e6), 4),
+                     "note": "packed weight bytes every workgroup streams L2 -> VGPR per launch / the rate ONE CU sustains on that "
+                             "pattern (1 KiB fragments, 16-slot ring, 4 MFMAs per fragment, all CUs streaming; ma_weight_stream_probe, "
+                             "measured live), over the kernel time"}
 
     # ---- roofline of the fbank kernel (HBM bound): algorithmic bytes = waves in + features out, at the headline batch (64)
     #      and at 512 utterances (where the launch's fixed cost is amortised) ----------------------------------------------
@@ -608,7 +640,8 @@ def main():
                                                       "M=%d d=256 hidden=%d)" % (m, hid),
                            "achieved": round(gemm_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                            "frac": round(gemm_tf / MFMA_BF16_PEAK_TF, 4), "traffic": pmc_traffic("ffn_packed_kernel")[0],
-                           "algorithmic_flops_per_launch": int(ffn_flops), "kernel_ms": round(gemm_s * 1e3, 5)}
+                           "algorithmic_flops_per_launch": int(ffn_flops), "kernel_ms": round(gemm_s * 1e3, 5),
+                           "weight_stream": weight_stream}
         res["roofline"].update(pmc_traffic("ffn_packed_kernel")[1])
         res["roofline_fbank"] = {"bound": "hbm", "kernel": "feat512_kernel<mel>", "achieved": round(fb_gbs, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fb_gbs / HBM_PEAK_GBS, 4),

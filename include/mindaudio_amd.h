@@ -67,6 +67,10 @@ int32_t ma_init_kernel_attributes(void);
 /* Measurement aid of bench.py (roofline_fbank.valu), not part of the drop-in path: `iters` x 16 independent v_fma_f32 per wave on
  * `wgs_per_cu` resident 4-wave workgroups per CU.  Timed by the caller: ns per wave-instruction per SIMD = t / (16 iters wgs_per_cu). */
 int ma_valu_issue_probe(int32_t wgs_per_cu, int32_t iters, float* sink, ma_stream_t stream);
+/* Measurement aid of bench.py (roofline.weight_stream): one 4-wave workgroup per CU, every wave streams `rounds` x 16 fragments of
+ * 1 KiB from `buf` (bytes % 4096 == 0; wave w walks quarter w, all CUs the same bytes: L2-resident like a packed weight) through a
+ * 16-slot register ring with 4 MFMAs per fragment - the main-loop pattern of ffn_packed_kernel.  GB/s per CU = 65536 rounds / t. */
+int ma_weight_stream_probe(const void* buf, int64_t bytes, int32_t rounds, float* sink, ma_stream_t stream);
 
 /* 1 + n // hop (center) or 1 + (n - n_fft) // hop — spectrum.py:196,298; <0 on invalid args. */
 int64_t ma_num_frames(int64_t n, int32_t n_fft, int32_t hop, int32_t center);

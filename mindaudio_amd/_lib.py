@@ -121,6 +121,7 @@ PROTOTYPES = {
     "ma_init": (ctypes.c_int, []),
     "ma_init_kernel_attributes": (i32, []),
     "ma_valu_issue_probe": (ctypes.c_int, [i32, i32, c_f32p, vp]),
+    "ma_weight_stream_probe": (ctypes.c_int, [vp, i64, i32, c_f32p, vp]),
     "ma_num_frames": (i64, [i64, i32, i32, i32]),
     "ma_mel_row_stride": (i32, [i32]),
     "ma_stft_f32": (ctypes.c_int, [c_f32p, i64, i64, i64, i32, i32, c_f32p, i32, i32, i32, c_f32p, ctypes.c_void_p]),

@@ -8,7 +8,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --no-sustained --no-cfg3 > $OUT/bench.log 2>&1
+# (--step-only: the warm-up + timed steps and nothing else, so that the per-kernel stats are the step's launches - VERDICT r3 hygiene)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --step-only > $OUT/bench.log 2>&1
 for W in fbank ffnpair; do
   i=0
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \

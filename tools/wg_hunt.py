@@ -11,6 +11,9 @@ modes: single  = one stream (the reference);
        wg      = the engine's second stream from the FIRST step on (weight-gradient products + batched sums beside the main chain);
        serial  = the same two streams, but the main stream waits for every block's products at once: two hardware queues, no
                  concurrent execution (ordering / visibility between queues vs concurrency);
+       rccl    = one stream for the library + RCCL's stream: every gradient bucket through a world-1 NCCL group as ReduceOp.AVG (a real
+                 RCCL kernel per bucket, the identity): the concurrency N > 1 training creates;
+       wgsplit = `wg` with round 3's products (one split-K grid + batched sum per block) instead of the direct 256 x 256-tile groups;
        foreign = the engine on ONE stream (every product of the library on the main stream), while a second stream runs torch's own
                  matmuls and copies at the points where `wg` would run the products (the library's kernels vs any concurrent kernel).
 """
@@ -61,7 +64,7 @@ def tensor_sums(eng):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="wg", choices=("single", "wg", "serial", "foreign", "wgsplit"))
+    ap.add_argument("--mode", default="wg", choices=("single", "wg", "serial", "foreign", "wgsplit", "rccl"))
     ap.add_argument("--diag", action="store_true", help="on a mismatch with an in-process single-stream twin: which elements differ")
     ap.add_argument("--group", type=int, default=6, help="dw_group_blocks of the engine (0 = split-K products per block)")
     ap.add_argument("--steps", type=int, default=3)
@@ -72,12 +75,27 @@ def main():
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
     dev = torch.device("cuda", 0)
+    if a.mode == "rccl":
+        # one stream for the library, RCCL's own stream beside it: the 14 gradient buckets of every step go through ProcessGroupNCCL at
+        # world size 1 as ReduceOp.AVG (a real RCCL device kernel per bucket, the identity) - what N > 1 training does to the step
+        import socket
+
+        import torch.distributed as dist
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     torch.manual_seed(777)
     model = create_asr_model(80, V, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=BLOCKS)).to(dev)
     # wg / serial: the engine's second stream with its default products (direct 256 x 256-tile groups); wgsplit: round 3's form - one
     # split-K grid + batched sum per block on the second stream
     eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1,
-                                wg_stream=a.mode in ("wg", "serial", "wgsplit"), dw_group_blocks=0 if a.mode == "wgsplit" else a.group)
+                                wg_stream=a.mode in ("wg", "serial", "wgsplit"), dw_group_blocks=0 if a.mode == "wgsplit" else a.group,
+                                force_collective=a.mode == "rccl")
     eng._wg_from = 0
     orig_done = eng._layer_done
     if a.mode == "serial":
@@ -146,6 +164,8 @@ def main():
                                  first=idx[:6].tolist(), last=int(idx[-1]), rows_hit=int(torch.unique(idx // cols).numel()),
                                  cols_hit=int(torch.unique(idx % cols).numel()), nonfinite=int((~torch.isfinite(x)).sum())))
         out["diag"] = diag
+    if a.mode == "rccl":
+        dist.destroy_process_group()
     txt = json.dumps(out)
     if a.out:
         with open(a.out, "w") as f:

@@ -476,6 +476,9 @@ typedef struct ma_tn_item {
   int32_t with_colsum, reserved;
 } ma_tn_item_t;
 int ma_gemm_tn_partial_group_bf16(const ma_tn_item_t* items, int32_t n, ma_stream_t stream);
+/* Development aid of tools/wg_hunt.py (the two-queue corruption hunt): launch the grouped kernel with `bytes` of dynamic
+ * LDS (<= 80 KiB; 0 = what it needs), so that its two workgroups per CU leave no LDS for another kernel's workgroups. */
+int ma_debug_tn_group_lds(int32_t bytes);
 
 /* Weight-gradient products WITHOUT split-K (round 4): out (Mo, No) float32 = A^T B, colsum (Mo, may be NULL) = column sums of A,
  * for up to ma_gemm_tn_direct_max_items() products in ONE grid of 256 x 256 tiles, each tile with the full contraction - no partial

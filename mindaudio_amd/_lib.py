@@ -202,6 +202,7 @@ PROTOTYPES = {
     "ma_gemm_rows_train_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp, i64, ctypes.POINTER(TrainEpilogue), vp]),
     "ma_conv2d_3x3s2_dinput_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]),
     "ma_gemm_tn_partial_group_bf16": (ctypes.c_int, [ctypes.POINTER(TnItem), i32, vp]),
+    "ma_debug_tn_group_lds": (ctypes.c_int, [i32]),
     "ma_gemm_tn_direct_max_items": (i32, []),
     "ma_gemm_tn_direct_group_bf16": (ctypes.c_int, [ctypes.POINTER(TnDirectItem), i32, vp]),
     "ma_convmid_bwd_parts": (i32, [i64, i64]),

@@ -401,7 +401,7 @@ MA_LDS_ATTR((gemm_tn_bf16_kernel<128, true>), tn_lds_bytes(128));
 MA_LDS_ATTR((gemm_tn_bf16_kernel<128, false>), tn_lds_bytes(128));
 MA_LDS_ATTR((gemm_tn_bf16_kernel<64, true>), tn_lds_bytes(64));
 MA_LDS_ATTR((gemm_tn_bf16_kernel<64, false>), tn_lds_bytes(64));
-MA_LDS_ATTR(gemm_tn_group_kernel, tn_lds_bytes(64));
+MA_LDS_ATTR(gemm_tn_group_kernel, 80 * 1024);  // (tn_lds_bytes(64) = 72 KiB; up to 80 for ma_debug_tn_group_lds)
 
 }  // namespace ma
 
@@ -496,6 +496,15 @@ int ma_gemm_tn_partial_bf16(const void* A, int64_t lda, const void* B, int64_t l
   return tn_launch(p, false, nullptr, 0, 1.0f, 0, partial, partial_bytes, (hipStream_t)stream, false);
 }
 
+// Development (tools/wg_hunt.py): launch the grouped kernel with MORE dynamic LDS than it uses (<= 80 KiB: two workgroups then take the
+// whole 160 KiB of a CU and no workgroup of another kernel can share the CU with them).  0 = off.
+static int g_tn_group_lds = 0;
+int ma_debug_tn_group_lds(int32_t bytes) {
+  if (bytes < 0 || bytes > 80 * 1024) return MA_ERR_INVALID_ARG;
+  g_tn_group_lds = bytes;
+  return MA_OK;
+}
+
 int ma_gemm_tn_partial_group_bf16(const ma_tn_item_t* items, int32_t n, ma_stream_t stream) {
   if (!items || n < 1) return MA_ERR_INVALID_ARG;
   for (int base = 0; base < n; base += kTnGroupMax) {
@@ -544,7 +553,8 @@ int ma_gemm_tn_partial_group_bf16(const ma_tn_item_t* items, int32_t n, ma_strea
       }
       continue;
     }
-    const int lds = kTnStages * (kTnBK * 64 * 2 + kTnBK * 256);
+    int lds = kTnStages * (kTnBK * 64 * 2 + kTnBK * 256);
+    if (g_tn_group_lds > lds) lds = g_tn_group_lds;  // (development: tools/wg_hunt.py --tn-lds)
     MA_LAUNCH(gemm_tn_group_kernel, dim3((unsigned)total), dim3(kTnThreads), lds, (hipStream_t)stream, g);
   }
   return MA_OK;

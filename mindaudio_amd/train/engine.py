@@ -241,7 +241,7 @@ class ConformerCTCTrainStep:
         # no split-K partials, no reduction pass.  The gradient buckets of those G blocks go on the wire behind the group (L / G
         # all-reduce waves per step instead of L).  0 = one split-K grid + batched sum per block (round 3).
         self.dw_group_blocks = int(dw_group_blocks)
-        self._dq, self._dq_blocks = [], []
+        self._dq, self._dq_blocks = None, []
         if self._wg_on and self.dev.type == "cuda":
             import ctypes
 
@@ -699,7 +699,9 @@ class ConformerCTCTrainStep:
         if plan is not None and wname[0] == "l" and bname is not None:
             sfx = wname.split(".", 1)[1]
             if self._dw_direct and sfx in self._DW_SUFFIXES and self.K.gemm_tn_direct_ok(dy, x, fp.g(wname)):
-                self._dq.append((dy, x, fp.g(wname), fp.g(bname)))  # issued with the group (_layer_done)
+                if self._dq is None:
+                    self._dq = self.K.DirectGroup()
+                self._dq.add(dy, x, fp.g(wname), fp.g(bname))  # issued with the group (_layer_done)
                 return
             if sfx in plan["off"]:
                 o, nbytes, _ = plan["off"][sfx]
@@ -746,7 +748,8 @@ class ConformerCTCTrainStep:
         self._wg_done.clear()
         self._wg_queue.clear()  # (a step that raised mid-backward must not leave stale products / pinned operands behind)
         self._wg_keep.clear()
-        self._dq.clear()
+        if self._dq is not None:
+            self._dq.clear()
         self._dq_blocks.clear()
         # The second stream is used from the THIRD step of a batch shape on.  With it active in the first steps of the first engine of a
         # process (driver allocations of the tape, per-kernel hipFuncSetAttribute calls, the runtime's lazy set-up all happen there), 1-7 %
@@ -1221,11 +1224,12 @@ class ConformerCTCTrainStep:
             self._wg.wait_event(self._wg_event().record_on(self._main))
             prev = _host.swap_pinned(self._wg_ptr)
             try:
-                if self._dq:
-                    self.K.gemm_tn_direct_group(self._dq)
+                if self._dq is not None:
+                    self._dq.launch()
             finally:
                 _host.swap_pinned(prev)
-            self._wg_keep.extend(self._dq)  # (operands stay referenced until the join)
+            if self._dq is not None:
+                self._wg_keep.extend(self._dq.keep)  # (operands stay referenced until the join)
             if self.reducer.world > 1 or self.reducer.force:
                 with torch.cuda.stream(self._wg):
                     for b in self._dq_blocks:
@@ -1234,11 +1238,12 @@ class ConformerCTCTrainStep:
                 for b in self._dq_blocks:
                     self.reducer.launch(*self.fp.span(self.layer_names[b]))
         else:
-            if self._dq:
-                self.K.gemm_tn_direct_group(self._dq)
+            if self._dq is not None:
+                self._dq.launch()
             for b in self._dq_blocks:
                 self.reducer.launch(*self.fp.span(self.layer_names[b]))
-        self._dq.clear()
+        if self._dq is not None:
+            self._dq.clear()
         self._dq_blocks.clear()
 
     def _layer_begin(self, li):

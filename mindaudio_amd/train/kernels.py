@@ -122,6 +122,36 @@ def gemm_tn_direct_group(quads):
         _lib.check(lib.ma_gemm_tn_direct_group_bf16(items, len(part), _s()), "gemm_tn_direct_group")
 
 
+class DirectGroup:
+    """A growing host table of weight-gradient products for ma_gemm_tn_direct_group_bf16: add() fills the next slot when the product
+    is queued (so that the launch itself is one C call - the table of 48 products took 0.1 ms of Python to build at launch time, with
+    the GPU idle behind it), launch() issues what has been added and keeps the operands referenced until clear()."""
+
+    def __init__(self):
+        self.cap = int(_lib.load().ma_gemm_tn_direct_max_items())
+        self.items = (_lib.TnDirectItem * self.cap)()
+        self.n = 0
+        self.keep = []
+
+    def add(self, a, b, out, colsum):
+        if self.n == self.cap:
+            raise _lib.MindaudioAmdError("more than %d products in one direct group" % self.cap)
+        it = self.items[self.n]
+        it.A, it.B, it.out, it.colsum = a.data_ptr(), b.data_ptr(), out.data_ptr(), (colsum.data_ptr() if colsum is not None else None)
+        it.lda, it.ldb, it.ldo = a.stride(0), b.stride(0), out.stride(0)
+        it.Mo, it.No, it.Kc = a.shape[1], b.shape[1], a.shape[0]
+        self.n += 1
+        self.keep.append((a, b))
+
+    def launch(self):
+        if self.n:
+            _lib.check(_lib.load().ma_gemm_tn_direct_group_bf16(self.items, self.n, _s()), "gemm_tn_direct_group")
+
+    def clear(self):
+        self.n = 0
+        self.keep = []
+
+
 def conv2d_dw_workspace_bytes(rows, c, cout):
     return int(_lib.load().ma_conv2d_3x3s2_dw_workspace_bytes(rows, c, cout))
 

@@ -43,12 +43,18 @@ def analyse(d):
             overlapped += 1
             if len(examples) < 5:
                 examples.append({"rccl_us": round((e - s) / 1e3, 1), "beside": hit[0][:60], "overlap_us": round(hit[1] / 1e3, 1)})
+    timeline = []
+    if rc and "--timeline" in sys.argv:  # what the library ran around the first RCCL kernels (us relative to the RCCL kernel's start)
+        for name, s, e, q, st in rc[:3] + rc[-2:]:
+            i = bisect.bisect_left(starts, s)
+            near = [(round((lib[j][1] - s) / 1e3, 1), round((lib[j][2] - s) / 1e3, 1), lib[j][3], lib[j][0][4:44]) for j in range(max(0, i - 3), min(len(lib), i + 3))]
+            timeline.append({"rccl": [0.0, round((e - s) / 1e3, 1), q, name[:40]], "library": near})
     names = {}
     for r in rc:
         names[r[0][:80]] = names.get(r[0][:80], 0) + 1
     return {"trace_files": len(files), "kernels": len(rows), "library_kernels": len(lib), "rccl_kernels": len(rc),
             "rccl_kernel_names": names, "rccl_kernels_concurrent_with_a_library_kernel": overlapped, "examples": examples,
-            "queues": sorted({r[3] for r in rows}), "library_kernels_with_scratch": scratch}
+            "queues": sorted({r[3] for r in rows}), "library_kernels_with_scratch": scratch, **({"timeline": timeline} if timeline else {})}
 
 
 if __name__ == "__main__":

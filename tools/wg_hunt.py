@@ -66,6 +66,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="wg", choices=("single", "wg", "serial", "foreign", "wgsplit", "rccl"))
     ap.add_argument("--diag", action="store_true", help="on a mismatch with an in-process single-stream twin: which elements differ")
+    ap.add_argument("--tn-lds", type=int, default=0, help="ma_debug_tn_group_lds: dynamic LDS of the split-K grouped kernel (81920 = "
+                    "its two workgroups per CU take the whole LDS: no co-residency with another kernel's workgroups)")
+    ap.add_argument("--reduce-on-main", action="store_true",
+                    help="wgsplit only: the batched sums on the MAIN stream (one block late), only the grouped products on the second")
     ap.add_argument("--group", type=int, default=6, help="dw_group_blocks of the engine (0 = split-K products per block)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--same-batch", action="store_true")
@@ -97,7 +101,42 @@ def main():
                                 wg_stream=a.mode in ("wg", "serial", "wgsplit"), dw_group_blocks=0 if a.mode == "wgsplit" else a.group,
                                 force_collective=a.mode == "rccl")
     eng._wg_from = 0
+    if a.tn_lds:
+        from mindaudio_amd import _lib as L
+
+        L.check(L.load().ma_debug_tn_group_lds(a.tn_lds), "tn_group_lds")
     orig_done = eng._layer_done
+    if a.mode == "wgsplit" and a.reduce_on_main:
+        from mindaudio_amd import _host as H
+        from mindaudio_amd import _lib as L
+
+        pend = []
+
+        def reduce_main(li, ev):
+            items, block_item, n_blocks = eng._dw_cur["layers"][li]
+            eng._main.wait_event(ev)
+            L.check(L.load().ma_reduce_splits_batch_f32(items.data_ptr(), block_item.data_ptr(), n_blocks, eng._main.cuda_stream), "reduce")
+            eng.reducer.launch(*eng.fp.span(eng.layer_names[li]))
+
+        def done_tnonly(li):
+            if eng._wg is None:
+                return orig_done(li)
+            eng._wg.wait_event(eng._wg_event().record_on(eng._main))
+            prev = H.swap_pinned(eng._wg_ptr)
+            try:
+                eng.K.gemm_tn_partial_group(eng._wg_queue, with_colsum=True)
+            finally:
+                H.swap_pinned(prev)
+            eng._wg_keep.extend(eng._wg_queue)
+            eng._wg_queue.clear()
+            e = eng._wg_event()
+            e.ev.record(eng._wg)
+            if pend:  # the previous block's sums: its products have had a whole block of main-stream work to finish beside
+                reduce_main(*pend.pop())
+            pend.append((li, e.ev))
+            if li == 0:
+                reduce_main(*pend.pop())
+        eng._layer_done = done_tnonly
     if a.mode == "serial":
         def done_serial(li):
             orig_done(li)

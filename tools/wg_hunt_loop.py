@@ -2,8 +2,11 @@
 
     python tools/wg_hunt_loop.py --minutes 30 --arms wg,wg_q1,serial,foreign [--steps 3]
 
-arms:  wg | serial | foreign | single = the child's --mode;   <mode>_q1 = the same with GPU_MAX_HW_QUEUES=1 (all HIP streams of the
-process share one hardware queue: corruption persists => an ordering bug in the engine; vanishes => concurrent execution).
+arms:  wg | wgsplit | serial | foreign | rccl | single = the child's --mode;   <mode>_q1 = the same with GPU_MAX_HW_QUEUES=1 (all HIP
+streams of the process share one hardware queue: corruption persists => an ordering bug in the engine; vanishes => concurrent
+execution);  wgsplit_lds = the split-K grouped kernel launched with 80 KiB of LDS (its two workgroups per CU leave no LDS for a
+workgroup of another kernel: no co-residency on a CU);  wgsplit_tnonly = only the grouped products on the second stream, the batched
+sums on the main one.
 The first child is `single` and provides the reference sums; every sample is compared with it tensor by tensor and a mismatch is
 reported with the first differing tensors in the order the backward pass produces them."""
 import argparse
@@ -31,13 +34,13 @@ def chain_order(names, blocks=12):
     return [n for n in order if n in set(names)] + rest
 
 
-def run_child(mode, env_extra, steps, tag, group=None):
+def run_child(mode, env_extra, steps, tag, group=None, extra=()):
     path = os.path.join(OUT, "hunt_%s.json" % tag)
     env = dict(os.environ)
     env.update(env_extra)
     t0 = time.time()
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wg_hunt.py"), "--mode", mode, "--steps", str(steps), "--out", path] +
-                         COMMON + (["--group", str(group)] if group is not None else []),
+                         COMMON + (["--group", str(group)] if group is not None else []) + list(extra),
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     dt = time.time() - t0
     if res.returncode != 0 or not os.path.exists(path):
@@ -93,8 +96,9 @@ def main():
         i += 1
         mode = arm.split("_")[0]
         env = {"GPU_MAX_HW_QUEUES": "1"} if arm.endswith("_q1") else {}
+        extra = ["--tn-lds", "81920"] if arm.endswith("_lds") else ["--reduce-on-main"] if arm.endswith("_tnonly") else []
         ref = refs["split" if mode == "wgsplit" else "direct"]
-        d, dt, err = run_child(mode, env, a.steps, "%s_%d" % (arm, i), 0 if mode == "wgsplit" else a.group)
+        d, dt, err = run_child(mode, env, a.steps, "%s_%d" % (arm, i), 0 if mode == "wgsplit" else a.group, extra)
         st = stats[arm]
         st[0] += 1
         if d is None:

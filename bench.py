@@ -183,7 +183,27 @@ def train_step_flops(b, t, vocab, d=256, hidden=2048, blocks=12, heads=4, ks=15,
 
 
 def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=False, digest=False, ctc_weight=1.0,
-              second_stream=False):
+              second_stream=False, default_stream=False):
+    """_train_leg on a stream of its own when gradients go through RCCL.  ROCm maps HIP streams onto a few hardware queues (4 by
+    default) and a kernel trace of round 4 showed RCCL's stream sharing the hardware queue of the legacy default stream - its kernels
+    then run IN LINE with the backward pass, never beside it.  A freshly created stream takes the least-loaded hardware queue."""
+    import contextlib
+
+    import torch
+
+    ctx = contextlib.nullcontext()
+    if (world > 1 or force_collective) and not default_stream:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(side)
+    with ctx:
+        res = _train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective, digest, ctc_weight, second_stream)
+        torch.cuda.synchronize()
+    return res
+
+
+def _train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=False, digest=False, ctc_weight=1.0,
+               second_stream=False):
     """cfg 4: `steps` optimizer steps of ConformerCTCTrainStep on a (40, 1024, 80) batch per rank, gradients
     all-reduced over RCCL in per-block buckets overlapped with the backward pass.  Also times the same all-reduce alone
     (bus bandwidth) and the step with communication disabled (exposed communication)."""
@@ -317,6 +337,9 @@ def main():
     ap.add_argument("--step-only", action="store_true",
                     help="(profiling) only the warm-up + timed steps of the headline: no roofline loops, no cfg3 / cfg5 / training legs, "
                          "no CPU baseline - the kernel stats of this run are the step's launches and nothing else")
+    ap.add_argument("--train-default-stream", action="store_true",
+                    help="run the data-parallel training leg on torch's default stream instead of a stream of its own (A/B of the "
+                         "hardware-queue sharing with RCCL's stream)")
     ap.add_argument("--second-stream", action="store_true",
                     help="also time (and check against the default) the training step with wg_stream=True")
     args = ap.parse_args()
@@ -597,7 +620,7 @@ def main():
     if args.train or not args.no_train_leg:
         train = train_leg(rank, world, dev, dist if world > 1 else None, args.steps if args.train else args.train_steps,
                           args.warmup if args.train else 2, barrier, args.force_collective, args.train_digest,
-                          second_stream=args.second_stream)
+                          second_stream=args.second_stream, default_stream=args.train_default_stream)
         if not args.train and not args.no_hybrid_leg and world == 1 and not args.force_collective:
             hybrid = train_leg(rank, world, dev, None, max(5, args.train_steps // 2), 2, barrier, ctc_weight=0.3)
 

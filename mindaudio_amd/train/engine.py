@@ -209,7 +209,7 @@ class ConformerCTCTrainStep:
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
                  process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None,
-                 force_collective=False, fused=True, wg_stream=False, dw_group_blocks=6):
+                 force_collective=False, fused=True, wg_stream=False, dw_group_blocks=6, _split_k_sums_on_second_stream=False):
         """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
         torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
         activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
@@ -221,11 +221,20 @@ class ConformerCTCTrainStep:
         # residual + dropout + LayerNorm, Swish' + dropout, the next branch's dropout backward) in the launch's epilogue;
         # False = one launch per reference cell (what the float32 validation mode always runs)
         self.fused = bool(fused) and not self.x32
-        # wg_stream=True: the weight-gradient products of the blocks (and the block's batched sum, and its gradient bucket's all-reduce)
-        # run on a second stream beside the input-gradient chain they do not feed (both are latency-bound launches of ~1 workgroup per
-        # CU): 12.0 -> 11.5 ms per cfg-4 step, bit-identical results - but OFF by default: in 0.4-7 % of fresh PROCESSES the first engine's
-        # first steps came out corrupted with it (see _forward_backward), and the cause is not established.
+        # wg_stream=True (EXPERIMENTAL, off by default, warns): the grouped weight-gradient products of the blocks (and their gradient
+        # buckets' all-reduce) run on a second stream beside the input-gradient chain they do not feed.  Round 3 ran the split-K
+        # products AND the block's batched sum (tn_reduce_batch_kernel) there and saw 0.4-14 % of fresh processes with a corrupted
+        # LayerNorm backward in the first block that overlapped; round 4 (tools/wg_hunt_loop.py, 1 300 fresh processes)
+        # narrowed it to ONE pair - that reduction kernel on a second hardware queue beside layernorm_bwd_kernel on the first - with
+        # every other combination clean (one hardware queue, serialised queues, foreign kernels, the products alone, the direct
+        # products, RCCL's kernels).  The batched sums therefore run on the MAIN stream in every mode; the round-3 form exists only
+        # behind _split_k_sums_on_second_stream (the reproducer of tools/wg_hunt.py) and is refused otherwise.
         self._wg_on = bool(wg_stream) and self.fused
+        self._wg_split_ok = bool(_split_k_sums_on_second_stream)
+        if self._wg_on:
+            import warnings
+
+            warnings.warn("ConformerCTCTrainStep(wg_stream=True) is experimental: see DESIGN.md 4.6.3", stacklevel=2)
         self._wg, self._wg_keep, self._wg_pool, self._wg_next, self._wg_done, self._dw_par = None, [], [], 0, {}, 0
         self._wg_stream, self._wg_seen = None, {}
         self._wg_queue, self._main = [], None
@@ -253,6 +262,9 @@ class ConformerCTCTrainStep:
         self.Vp = K.pad64(self.V)
         self.hidden = enc.encoders[0].feed_forward.w_1.out_features
         self._dw_direct = self.fused and self.dw_group_blocks > 0 and self.d % 256 == 0 and self.hidden % 256 == 0
+        if self._wg_on and not self._dw_direct and not self._wg_split_ok:
+            raise ValueError("wg_stream=True needs the direct weight-gradient groups (dw_group_blocks > 0, d_model and hidden "
+                             "multiples of 256): the split-K sums are not run on a second stream (DESIGN 4.6.3)")
         self.ks = enc.kernel
         self.f2 = enc.embed.out.in_features // self.d
         self.p_drop, self.p_pos = float(dropout_rate), float(positional_dropout_rate)
@@ -751,13 +763,7 @@ class ConformerCTCTrainStep:
         if self._dq is not None:
             self._dq.clear()
         self._dq_blocks.clear()
-        # The second stream is used from the THIRD step of a batch shape on.  With it active in the first steps of the first engine of a
-        # process (driver allocations of the tape, per-kernel hipFuncSetAttribute calls, the runtime's lazy set-up all happen there), 1-7 %
-        # of fresh processes showed a corrupted first or second backward pass - NaNs or finite garbage in the input-gradient chain from
-        # some block on; never in a later step, never in a later engine of the same process, never with one stream
-        # (tools/flaky_loop.sh: 3 of 250 and 18 of 250 fresh processes against 0 of 200 single-stream and 0 of 250 with this rule;
-        # tools/race_pairs.py: 120 engines in one process, 0 differ).  The root cause is NOT established; no dependency between the two
-        # streams was found missing.
+        # (experimental second stream: used from step _wg_from of a batch shape on - round 3's mitigation, kept; tools/wg_hunt.py sets 0)
         key = (b, t, idim)
         seen = self._wg_seen.get(key, 0)
         self._wg_seen[key] = seen + 1

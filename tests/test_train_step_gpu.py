@@ -393,11 +393,17 @@ def test_fused_blocks_equal_the_one_launch_per_cell_path_with_dropout():
 
 
 def test_weight_gradient_stream_changes_no_bit():
-    """With wg_stream=True (opt-in) the blocks' weight-gradient products, their batched sums and the gradient buckets run on a
-    second stream beside the input-gradient chain.  Same launches, same summation orders: three optimizer steps give bit-identical losses
-    and masters with the second stream on and off; a missing cross-stream dependency would show up as a changed bit (the two arena
-    halves alternate between blocks, so a block's partials would be overwritten by the next one's)."""
+    """With wg_stream=True (experimental) the grouped weight-gradient products and the gradient buckets run on a second
+    stream beside the input-gradient chain (the batched sums stay on the main stream).  Same launches, same summation orders: five
+    optimizer steps give bit-identical losses and masters with the second stream on and off; a missing cross-stream dependency would
+    show up as a changed bit.  The round-3 form (split-K sums on the second stream) is refused without its reproducer switch."""
+    import warnings
+
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    warnings.simplefilter("ignore", UserWarning)
+    with pytest.raises(ValueError):
+        ConformerCTCTrainStep(build(seed=9)[2], wg_stream=True, dw_group_blocks=0)
 
     xs, ys, sub, ys_lens = batch()
     cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)

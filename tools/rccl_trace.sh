@@ -7,6 +7,7 @@ TAG=${1:-x}
 D=/tmp/rccl_trace_$TAG
 rm -rf $D
 export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$((20000 + RANDOM % 20000))
-rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $R/bench.py --gpus 1 --train --steps 3 --warmup 1 --no-cpu-baseline --force-collective > $R/gpurun_out/rccl_trace_$TAG.log 2>&1
+EXTRA=${2:-}
+rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $R/bench.py --gpus 1 --train --steps 3 --warmup 1 --no-cpu-baseline --force-collective $EXTRA > $R/gpurun_out/rccl_trace_$TAG.log 2>&1
 python3 $R/tools/rccl_trace_check.py $D --timeline > $R/gpurun_out/rccl_trace_$TAG.json
-cat $R/gpurun_out/rccl_trace_$TAG.json | cut -c1-3000
+cat $R/gpurun_out/rccl_trace_$TAG.json | cut -c1-1800

@@ -54,7 +54,7 @@ def analyse(d):
         names[r[0][:80]] = names.get(r[0][:80], 0) + 1
     return {"trace_files": len(files), "kernels": len(rows), "library_kernels": len(lib), "rccl_kernels": len(rc),
             "rccl_kernel_names": names, "rccl_kernels_concurrent_with_a_library_kernel": overlapped, "examples": examples,
-            "queues": sorted({r[3] for r in rows}), "library_kernels_with_scratch": scratch, **({"timeline": timeline} if timeline else {})}
+            "queues": sorted({r[3] for r in rows}), "rccl_queues": sorted({r[3] for r in rc}), "library_queues": sorted({r[3] for r in lib}), "library_kernels_with_scratch": scratch, **({"timeline": timeline} if timeline else {})}
 
 
 if __name__ == "__main__":

@@ -99,7 +99,7 @@ def main():
     # split-K grid + batched sum per block on the second stream
     eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1,
                                 wg_stream=a.mode in ("wg", "serial", "wgsplit"), dw_group_blocks=0 if a.mode == "wgsplit" else a.group,
-                                force_collective=a.mode == "rccl")
+                                force_collective=a.mode == "rccl", _split_k_sums_on_second_stream=a.mode == "wgsplit")
     eng._wg_from = 0
     if a.tn_lds:
         from mindaudio_amd import _lib as L
@@ -164,6 +164,12 @@ def main():
         eng._layer_done = done_foreign
     out = dict(mode=a.mode, steps=[], env={k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES",) if k in os.environ})
     grad0 = None
+    if a.mode == "rccl":
+        # the library on a stream of its own: RCCL's stream can share the hardware queue of the legacy default stream (seen in a kernel
+        # trace), in which case nothing would run beside the backward pass
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(side)
     for s in range(a.steps):
         xs, ys, sub, yl = batch(40, 43 if a.same_batch else 43 + s)
         cols = (xs.to(dev), ys.to(dev), None, None, None, None, sub.to(dev), None, None, yl.to(dev), None)

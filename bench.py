@@ -184,26 +184,6 @@ def train_step_flops(b, t, vocab, d=256, hidden=2048, blocks=12, heads=4, ks=15,
 
 def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=False, digest=False, ctc_weight=1.0,
               second_stream=False, default_stream=False):
-    """_train_leg on a stream of its own when gradients go through RCCL.  ROCm maps HIP streams onto a few hardware queues (4 by
-    default) and a kernel trace of round 4 showed RCCL's stream sharing the hardware queue of the legacy default stream - its kernels
-    then run IN LINE with the backward pass, never beside it.  A freshly created stream takes the least-loaded hardware queue."""
-    import contextlib
-
-    import torch
-
-    ctx = contextlib.nullcontext()
-    if (world > 1 or force_collective) and not default_stream:
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        ctx = torch.cuda.stream(side)
-    with ctx:
-        res = _train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective, digest, ctc_weight, second_stream)
-        torch.cuda.synchronize()
-    return res
-
-
-def _train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=False, digest=False, ctc_weight=1.0,
-               second_stream=False):
     """cfg 4: `steps` optimizer steps of ConformerCTCTrainStep on a (40, 1024, 80) batch per rank, gradients
     all-reduced over RCCL in per-block buckets overlapped with the backward pass.  Also times the same all-reduce alone
     (bus bandwidth) and the step with communication disabled (exposed communication)."""
@@ -224,8 +204,10 @@ def _train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=
                                 lsm_weight=0.1 if hybrid else 0.0).to(dev)
 
     model = make_model()
+    # (own_stream: with RCCL in play the engine runs the step on a stream of its own - RCCL's stream was seen sharing the hardware
+    # queue of torch's default stream; --train-default-stream is the A/B switch)
     eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, world_size=world, rank=rank,
-                                force_collective=force_collective)
+                                force_collective=force_collective, own_stream=False if default_stream else "auto")
     cols = synth_train_batch(rank, dev)
 
     def timed(n):

@@ -209,7 +209,8 @@ class ConformerCTCTrainStep:
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
                  process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None,
-                 force_collective=False, fused=True, wg_stream=False, dw_group_blocks=6, _split_k_sums_on_second_stream=False):
+                 force_collective=False, fused=True, wg_stream=False, dw_group_blocks=6, own_stream="auto",
+                 _split_k_sums_on_second_stream=False):
         """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
         torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
         activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
@@ -250,6 +251,11 @@ class ConformerCTCTrainStep:
         # no split-K partials, no reduction pass.  The gradient buckets of those G blocks go on the wire behind the group (L / G
         # all-reduce waves per step instead of L).  0 = one split-K grid + batched sum per block (round 3).
         self.dw_group_blocks = int(dw_group_blocks)
+        # own_stream="auto": when gradients go through RCCL (world_size > 1 or force_collective) and the caller is on torch's DEFAULT
+        # stream, the step runs on a stream the engine creates (the caller's stream waits for it at the end).  ROCm maps HIP streams
+        # onto a few hardware queues and RCCL's stream was seen sharing the default stream's queue: its kernels then run in line with
+        # the backward pass instead of beside it (profiles/r04_rccl_world1_trace.json).  False: always the caller's stream.
+        self.own_stream, self._own = own_stream, None
         self._dq, self._dq_blocks = None, []
         if self._wg_on and self.dev.type == "cuda":
             import ctypes
@@ -1312,6 +1318,20 @@ class ConformerCTCTrainStep:
         """Everything of step() that only ENQUEUES device work (forward, backward, all-reduce launches, overflow check, Adam, the bf16
         weight refresh); no host read-back.  finish_step() reads the overflow flag and moves the host-side counters.  (bench.py
         times this call behind a busy GPU: `train_dp.host_enqueue_ms`.)"""
+        if self.own_stream == "auto" and self.dev.type == "cuda" and (self.world > 1 or self.reducer.force):
+            cur = torch.cuda.current_stream(self.dev)
+            if cur == torch.cuda.default_stream(self.dev):
+                if self._own is None:
+                    self._own = torch.cuda.Stream(device=self.dev)
+                self._own.wait_stream(cur)
+                with torch.cuda.stream(self._own):
+                    out = self._enqueue_step(xs_pad, ys_pad, ys_in_pad, ys_out_pad, xs_masks, ys_sub_masks, ys_masks, ys_lengths,
+                                             xs_chunk_masks)
+                cur.wait_stream(self._own)
+                return out
+        return self._enqueue_step(xs_pad, ys_pad, ys_in_pad, ys_out_pad, xs_masks, ys_sub_masks, ys_masks, ys_lengths, xs_chunk_masks)
+
+    def _enqueue_step(self, xs_pad, ys_pad, ys_in_pad, ys_out_pad, xs_masks, ys_sub_masks, ys_masks, ys_lengths, xs_chunk_masks):
         scale = self.scaler.scale
         loss = self.forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale=scale,
                                      ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_sub_masks=ys_sub_masks,

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/mindaudio_amd.h"
 
 #include "launch.h"
@@ -178,6 +180,193 @@ __global__ __launch_bounds__(kDiThreads, 2) void conv2_dinput_kernel(const DinPa
 
 MA_LDS_ATTR(conv2_dinput_kernel, kDiLds);
 
+// ---- round 4: the same product on 256 x 256 tiles, 8 waves, the 8-phase schedule of gemm_bf16_8ph_kernel (gemm_bf16.hip) ----------
+// C = 256 (the subsampling layer): a tile is 256 input positions of one parity class x all 256 channels.  128 flop per operand byte
+// instead of 64; one workgroup per CU (two 64 KiB K-tile buffers; the bf16 output tile is staged over them for the scatter).
+// Units of a K-tile buffer as in the GEMM kernel: A q0 | W q0 | W q1 | A q1, 128 rows x 128 bytes each, 16-byte chunks XOR-swizzled by
+// (row & 7) on the source side.  A unit q, unit row u <-> tile row (u >> 6) * 128 + 64 q + (u & 63) (a GATHERED dy row, or the zero row
+// when the tap falls outside the output grid); W unit q, unit row u <-> channel (u >> 5) * 64 + 32 q + (u & 31).
+constexpr int kD8Threads = 512, kD8Unit = 128 * 128, kD8Buf = 4 * kD8Unit;
+constexpr int kD8CRow = 256 * 2 + 16, kD8Lds = 256 * kD8CRow;  // 132 KiB: the staged output tile (>= the two 64 KiB buffers)
+
+__device__ __forceinline__ int d8_div(int m, int d, float inv) {  // floor(m / d) for 0 <= m < 2^24
+  int q = (int)((float)m * inv);
+  if (q * d > m) --q;
+  if ((q + 1) * d <= m) ++q;
+  return q;
+}
+
+__global__ __launch_bounds__(kD8Threads, 1) void conv2_dinput8_kernel(const DinParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int cls = blockIdx.y, ph = cls >> 1, pw = cls & 1;
+  const int tile_m = blockIdx.x;
+  if (tile_m >= p.tiles_m[cls]) return;
+  const int Hc = (p.H - ph + 1) >> 1, Wc = (p.Wd - pw + 1) >> 1;
+  const int Mc = p.B * Hc * Wc;
+  const float inv_wc = 1.0f / (float)Wc, inv_hc = 1.0f / (float)Hc;
+  const int nkw = pw ? 1 : 2, ntaps = (ph ? 1 : 2) * nkw;
+  const int m0 = tile_m * 256;
+
+  const int lr = lane >> 3, kc_src = (lane & 7) ^ lr;
+  const uint16_t* a_src[2][2];
+  uint32_t vmask[2][2];
+  const uint16_t* w_src[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = 8 * (wid + 8 * i) + lr;
+      int m = m0 + (u >> 6) * 128 + 64 * q + (u & 63);
+      if (m >= Mc) m = Mc - 1;  // rows past the class: computed, never stored
+      const int t = d8_div(m, Wc, inv_wc), ww = m - t * Wc;
+      const int b = d8_div(t, Hc, inv_hc), hh = t - b * Hc;
+      a_src[q][i] = p.dy + (((int64_t)b * p.Ho + hh) * p.Wo + ww) * p.C + kc_src * 8;
+      uint32_t vm = 0;
+      for (int tap = 0; tap < ntaps; ++tap) {
+        const int ih = tap / nkw, iw = tap - ih * nkw;
+        const int ho = hh - ih, wo = ww - iw;
+        if (ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo) vm |= 1u << tap;
+      }
+      vmask[q][i] = vm;
+      const int n = (u >> 5) * 64 + 32 * q + (u & 31);
+      w_src[q][i] = p.wt + (int64_t)n * p.C + kc_src * 8;
+    }
+  const uint16_t* zsrc = p.zero + kc_src * 8;
+  const int kt_per_tap = p.C / 64;
+  // unit index U in a buffer: 0 = A q0, 1 = W q0, 2 = W q1, 3 = A q1
+  auto stage = [&](auto uc, int kt, int buf) __attribute__((always_inline)) {
+    constexpr int U = decltype(uc)::value;
+    char* dst = smem + buf * kD8Buf + U * kD8Unit + wid * 1024;
+    const int tap = kt / kt_per_tap, kin = (kt - tap * kt_per_tap) * 64;
+    const int ih = tap / nkw, iw = tap - ih * nkw;
+    if constexpr (U == 0 || U == 3) {
+      constexpr int q = U == 3;
+      const int64_t ka = -((int64_t)ih * p.Wo + iw) * p.C + kin;
+      const uint16_t* s0 = ((vmask[q][0] >> tap) & 1u) ? a_src[q][0] + ka : zsrc;
+      const uint16_t* s1 = ((vmask[q][1] >> tap) & 1u) ? a_src[q][1] + ka : zsrc;
+      __builtin_amdgcn_global_load_lds((gl_void_t*)s0, (lds_void_t*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_void_t*)s1, (lds_void_t*)(dst + 8192), 16, 0, 0);
+    } else {
+      constexpr int q = U == 2;
+      const int khw = (ph ? 1 : 2 * ih) * 3 + (pw ? 1 : 2 * iw);
+      const int64_t kw = (int64_t)khw * p.C * p.C + kin;
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(w_src[q][0] + kw), (lds_void_t*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gl_void_t*)(w_src[q][1] + kw), (lds_void_t*)(dst + 8192), 16, 0, 0);
+    }
+  };
+  const int frow = lane & 15, fk = lane >> 4;
+  const int off_a = (wr * 64 + frow) * 128 + ((fk ^ (frow & 7)) << 4);
+  const int off_b = (wc * 32 + frow) * 128 + ((fk ^ (frow & 7)) << 4);
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bfr[2][2];
+  auto load_a = [&](const char* unit) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) af[i][kk] = *reinterpret_cast<const bf16x8*>(unit + ((off_a + i * 2048) ^ (kk << 6)));
+  };
+  auto load_b = [&](const char* unit) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bfr[j][kk] = *reinterpret_cast<const bf16x8*>(unit + ((off_b + j * 2048) ^ (kk << 6)));
+  };
+  auto mma = [&](auto ic, auto jc) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value, J = decltype(jc)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[4 * I + i][2 * J + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][kk], af[i][kk], acc[4 * I + i][2 * J + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>;
+  const int nk = ntaps * kt_per_tap;
+  stage(C0{}, 0, 0);
+  stage(C1{}, 0, 0);
+  stage(C2{}, 0, 0);
+  stage(C3{}, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs half a phase behind wave row 0
+#define D8_PHASE(MORE, READS, U, I, J)                                                \
+  {                                                                                   \
+    READS;                                                                            \
+    if constexpr (MORE) stage(U{}, kt + 1, nb);                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    if constexpr (MORE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
+    __builtin_amdgcn_s_barrier();                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    mma(I{}, J{});                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    __builtin_amdgcn_s_barrier();                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+  }
+#define D8_TILE(MORE)                                                                 \
+  {                                                                                   \
+    const char* cb = smem + (kt & 1) * kD8Buf;                                        \
+    const int nb = (kt + 1) & 1;                                                      \
+    D8_PHASE(MORE, load_a(cb); load_b(cb + kD8Unit), C0, C0, C0)                      \
+    D8_PHASE(MORE, load_b(cb + 2 * kD8Unit), C1, C0, C1)                              \
+    D8_PHASE(MORE, load_a(cb + 3 * kD8Unit), C2, C1, C1)                              \
+    D8_PHASE(MORE, load_b(cb + kD8Unit), C3, C1, C0)                                  \
+  }
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) D8_TILE(true)
+  D8_TILE(false)
+#undef D8_TILE
+#undef D8_PHASE
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // (the barrier wave row 1 took at the start)
+
+  // ---- epilogue: tile -> LDS (bf16, 528-byte rows), then whole 512-byte rows to their (b, h, w) positions with ReLU' -------------
+  __syncthreads();
+  const int em = lane & 15, en = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<uint2*>(smem + (wr * 128 + i * 16 + em) * kD8CRow + (wc * 64 + j * 16 + en) * 2) =
+          make_uint2(di_pack_bf16(acc[i][j][0], acc[i][j][1]), di_pack_bf16(acc[i][j][2], acc[i][j][3]));
+  __syncthreads();
+  // 32 lanes per row (16 bytes each): thread (r0 = tid >> 5, cc = tid & 31) walks rows r0, r0 + 16, ...
+  const int cc = tid & 31;
+#pragma unroll 4
+  for (int r = tid >> 5; r < 256; r += 16) {
+    const int m = m0 + r;
+    if (m >= Mc) break;
+    const int t = d8_div(m, Wc, inv_wc), ww = m - t * Wc;
+    const int b = d8_div(t, Hc, inv_hc), hh = t - b * Hc;
+    const int64_t off = ((((int64_t)b * p.H + 2 * hh + ph) * p.Wd) + 2 * ww + pw) * p.C + cc * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(smem + r * kD8CRow + cc * 16);
+    if (p.act) {
+      const uint4 a = *reinterpret_cast<const uint4*>(p.act + off);
+      auto gate = [](uint32_t x, uint32_t aw) -> uint32_t {
+        const uint32_t lo = (__uint_as_float(aw << 16) > 0.0f) ? 0x0000ffffu : 0u;
+        const uint32_t hi = (__uint_as_float(aw & 0xffff0000u) > 0.0f) ? 0xffff0000u : 0u;
+        return x & (lo | hi);
+      };
+      v = make_uint4(gate(v.x, a.x), gate(v.y, a.y), gate(v.z, a.z), gate(v.w, a.w));
+    }
+    *reinterpret_cast<uint4*>(p.out + off) = v;
+  }
+}
+
+MA_LDS_ATTR(conv2_dinput8_kernel, kD8Lds);
+
 }  // namespace ma
 
 using namespace ma;
@@ -203,11 +392,18 @@ extern "C" int ma_conv2d_3x3s2_dinput_bf16(const void* dy, int64_t batch, int64_
   p.Ho = (int32_t)((H - 3) / 2 + 1);
   p.Wo = (int32_t)((Wd - 3) / 2 + 1);
   int max_tiles = 0;
+  // C = 256 with enough positions to fill the chip: 256 x 256 tiles on the 8-phase schedule
+  const bool big = C == 256 && batch * H * Wd >= 256 * 256 && batch * ((H + 1) / 2) * ((Wd + 1) / 2) < (1 << 24);
+  const int bm = big ? 256 : kDiBM;
   for (int cls = 0; cls < 4; ++cls) {
     const int ph = cls >> 1, pw = cls & 1;
     const int64_t mc = batch * ((H - ph + 1) / 2) * ((Wd - pw + 1) / 2);
-    p.tiles_m[cls] = (int32_t)((mc + kDiBM - 1) / kDiBM);
+    p.tiles_m[cls] = (int32_t)((mc + bm - 1) / bm);
     if (p.tiles_m[cls] > max_tiles) max_tiles = p.tiles_m[cls];
+  }
+  if (big) {
+    MA_LAUNCH(conv2_dinput8_kernel, dim3((unsigned)max_tiles, 4), dim3(kD8Threads), kD8Lds, (hipStream_t)stream, p);
+    return MA_OK;
   }
   MA_LAUNCH(conv2_dinput_kernel, dim3((unsigned)(max_tiles * (C / kDiBN)), 4), dim3(kDiThreads), kDiLds, (hipStream_t)stream, p);
   return MA_OK;

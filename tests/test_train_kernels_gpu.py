@@ -513,11 +513,13 @@ def test_fused_dense_layers_equal_their_unfused_launches(K):
     assert torch.equal(g_new, g_ref) and torch.equal(dn, dn_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
 
 
-@pytest.mark.parametrize("b,h,w,c", [(2, 21, 19, 128), (3, 24, 39, 256), (1, 3, 3, 128), (2, 8, 6, 128)])
+@pytest.mark.parametrize("b,h,w,c", [(2, 21, 19, 128), (3, 24, 39, 256), (1, 3, 3, 128), (2, 8, 6, 128), (9, 187, 39, 256),
+                                     (8, 206, 40, 256)])
 def test_conv2_input_gradient_as_one_implicit_gemm(K, b, h, w, c):
     """ma_conv2d_3x3s2_dinput_bf16 (parity-class implicit GEMM) against torch's conv_transpose2d on the same bf16 operands in float32
     (tolerance: one bf16 rounding of the result), and against the two-launch form it replaces (dy . W, then col2im + ReLU').  Even and
-    odd H / W (rows and columns that no window covers get a zero gradient), the 3 x 3 image (one window), with and without ReLU'."""
+    odd H / W (rows and columns that no window covers get a zero gradient), the 3 x 3 image (one window), with and without ReLU'.
+    The last two shapes (C = 256, >= 65 536 input positions) run the 256 x 256-tile kernel of round 4 (conv2_dinput8_kernel)."""
     from mindaudio_amd import ops
 
     g = torch.Generator().manual_seed(1000 * h + w)

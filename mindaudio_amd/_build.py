@@ -36,13 +36,34 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
+
+
+def _stamp():
+    """What the objects depend on besides their sources: target, flags, compiler (path + version)."""
+    exe = _hipcc()
+    try:
+        ver = subprocess.run([exe, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode(errors="replace")
+    except OSError:
+        ver = "?"
+    return "arch=%s\nflags=%s\nhipcc=%s\n%s" % (ARCH, " ".join(FLAGS), exe, ver.strip())
+
+
 def build(force=False, verbose=False):
     """Compile every .hip under csrc/ into one shared object. Returns its path."""
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    stamp_path = os.path.join(obj_dir, "build.stamp")
+    stamp = _stamp() if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc") else None
+    old = open(stamp_path).read() if os.path.exists(stamp_path) else None
+    if stamp is not None and old is not None and old != stamp:
+        force = True  # another target / flag set / compiler: every object is stale, whatever its mtime says
     if not force and not is_stale():
+        if stamp is not None and old is None and os.path.isdir(obj_dir):
+            with open(stamp_path, "w") as fh:  # (objects of a tree built before the stamp existed: same recipe)
+                fh.write(stamp)
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
-    obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     procs = []
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + \
@@ -53,15 +74,20 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), t_hdr):
             continue  # this object is current: only edited sources (or everything, after a header edit) are recompiled
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
-               "-c", src, "-o", obj]
+        # compile to a temporary name and rename on success: an interrupted compile must not leave a truncated object that is newer
+        # than its source
+        cmd = [_hipcc(), "--offload-arch=" + ARCH] + FLAGS + ["-c", src, "-o", obj + ".tmp"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, pr in procs:
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, obj, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode(errors="replace")))
+        os.replace(obj + ".tmp", obj)
+    if stamp is not None:
+        with open(stamp_path, "w") as fh:
+            fh.write(stamp)
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + objs
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if res.returncode != 0:

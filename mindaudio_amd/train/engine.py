@@ -222,6 +222,11 @@ class ConformerCTCTrainStep:
         # residual + dropout + LayerNorm, Swish' + dropout, the next branch's dropout backward) in the launch's epilogue;
         # False = one launch per reference cell (what the float32 validation mode always runs)
         self.fused = bool(fused) and not self.x32
+        if self.fused and enc.d != 256:
+            # the fused block launches (packed K = 256 dense layers, 256-wide LayerNorm epilogues) are built for the reference's
+            # d_model = 256 configurations only; say so here instead of failing inside the first step
+            raise NotImplementedError("ConformerCTCTrainStep: the bf16 training step is built for d_model = 256 (got %d); the reference's "
+                                      "other sizes run the evaluation forward only" % enc.d)
         # wg_stream=True (EXPERIMENTAL, off by default, warns): the grouped weight-gradient products of the blocks (and their gradient
         # buckets' all-reduce) run on a second stream beside the input-gradient chain they do not feed.  Round 3 ran the split-K
         # products AND the block's batched sum (tn_reduce_batch_kernel) there and saw 0.4-14 % of fresh processes with a corrupted
@@ -492,14 +497,14 @@ class ConformerCTCTrainStep:
             dev_items, dev_map, n_blocks = self._wt_plan
             _lib.check(_lib.load().ma_transpose_batch_bf16(dev_items.data_ptr(), dev_map.data_ptr(), n_blocks,
                                                            torch.cuda.current_stream().cuda_stream), "transpose_batch")
-            if self.fused:
-                self._pack_weights()
         else:
             for n in names:
                 if n not in self.wt:
                     rows, cols = fp.w(n).shape
                     self.wt[n] = torch.zeros((cols, K.pad64(rows)), dtype=torch.bfloat16, device=self.dev)
                 K.transpose(fp.w(n), out=self.wt[n])
+        if self.fused:  # (after either transpose form: the packed copies are built from the mirror and the transposed copies)
+            self._pack_weights()
 
     # fragment-packed copies of a block's dense weights (fused mode): name -> (source, kind) with kind 0 = K = 256 layers
     # (ma_gemm_k256_pack_bf16 layout), 1 = 256-output layers with a long contraction (ma_gemm_rows_pack_bf16 layout); ".t" sources

@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+bash tools/profile_round.sh r4 > gpurun_out/profile_r4.log 2>&1; tail -25 gpurun_out/profile_r4.log | cut -c1-220
+bash tools/ecapa_profile.sh r4 > gpurun_out/ecapa_r4.log 2>&1; tail -30 gpurun_out/ecapa_r4.log | cut -c1-200
+bash tools/run_train_prof.sh r4 > gpurun_out/train_prof_r4.log 2>&1; head -8 gpurun_out/train_prof_r4/census.txt | cut -c1-160
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/train_prof_r4hyb; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o tb -- python3 $R/tools/train_bench.py --steps 5 --warmup 2 --ctc-weight 0.3 > $OUT/train_prof.log 2>&1
+python3 $R/tools/train_census.py $OUT/trace $OUT/census.txt | head -45 | cut -c1-150
+rm -rf $OUT/trace
+cd $R
+python bench.py > gpurun_out/bench_r4_final.json 2> gpurun_out/bench_r4_final.err; tail -c 1500 gpurun_out/bench_r4_final.json
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_final.log 2>&1; tail -4 gpurun_out/pytest_gpu_final.log

@@ -534,7 +534,14 @@ typedef struct ma_train_epilogue {
 /* K = 256 layers on the packed weight of ma_gemm_k256_pack_bf16 (N % 256 == 0); out bf16 (modes 1, 2, 4) or float32 (mode 3). */
 int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N,
                             const ma_train_epilogue_t* epi, ma_stream_t stream);
-/* N = 256 layers with a long contraction (K % 64 == 0) on the packed weight of ma_gemm_rows_pack_bf16: modes 3 and 4. */
+/* N = 256 layers with a long contraction (K % 64 == 0) on the packed weight of ma_gemm_rows_pack_bf16: modes 3, 4 and 5.
+ * mode 5 (round 4) = an input-gradient product + the BACKWARD of the LayerNorm in front of the layer + the next branch's dropout
+ * backward in one launch (models/conformer.py:109-151 differentiated): dy = bf16(acc) * row_scale; with x = residual (ldr),
+ * gamma = ln_gamma1, eps = ln_eps: out (float32, IN PLACE: the residual-stream gradient g) += dLN/dx(dy); optional ln_out (bf16,
+ * ld_ln) = dropout(g * alpha * ln_row_scale) with (p, seed, salt); ln_mid = per-workgroup partial (dgamma | dbeta) vectors,
+ * ma_gemm_rows_train_parts(M) x 512 floats.  Same arithmetic as ma_layernorm_bwd_next_f32 behind ma_gemm_rows_train_bf16 mode 4,
+ * row sums in another order. */
+int32_t ma_gemm_rows_train_parts(int64_t M);
 int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, void* out, int64_t ldo,
                             const ma_train_epilogue_t* epi, ma_stream_t stream);
 /* Fragment packing of a list of weights in ONE launch (the training step re-packs every layer's weights after the optimizer):

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
       issue_a(ch + kRpAhead);  // stage of chunk ch - 2: every MFMA wave is past its reads
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing of this wave lands in the epilogue's scratch
-    if constexpr (MODE == 3) __builtin_amdgcn_s_barrier();      // the MFMA waves' barrier in front of the epilogue
+    if constexpr (MODE == 3 || MODE == 5) __builtin_amdgcn_s_barrier();  // the MFMA waves' barrier in front of the epilogue
     return;
   }
   // ---- weight fragments: SGPR chunk base + lane offset, 8 per chunk, three chunks of ring ----------------------------------------
@@ -215,6 +215,10 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
     __syncthreads();  // every wave is past its last fragment reads: the activation stages become the LayerNorm exchange scratch
     train_epi_rows256<MT>(e, acc, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem));
     return;
+  } else if constexpr (MODE == 5) {
+    __syncthreads();
+    train_epi_lnbwd256<MT>(e, acc, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem), (int)blockIdx.x);
+    return;
   } else {
     float4 bv[4];
 #pragma unroll
@@ -308,10 +312,31 @@ extern "C" int ma_gemm_rows_packed_f32(const void* A, int64_t lda, int64_t M, in
   return MA_OK;
 }
 
+// 48-row workgroups when the 64-row grid would fill less than 7/8 of the CUs and the 48-row grid still fits one round
+static bool rows_train_use48(int64_t M) {
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    static int cached = 0;
+    if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cached = prop.multiProcessorCount;
+    if (cached) cus = cached;
+  }
+  const int64_t g64 = (M + 63) / 64, g48 = (M + 47) / 48;
+  return (g64 % cus) != 0 && (g64 % cus) * 8 < cus * 7 && (g48 + cus - 1) / cus == (g64 + cus - 1) / cus;
+}
+
+// workgroups (= per-workgroup partial vectors of the mode-5 epilogue) ma_gemm_rows_train_bf16 launches for M rows
+extern "C" int32_t ma_gemm_rows_train_parts(int64_t M) {
+  if (M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  return (int32_t)(rows_train_use48(M) ? (M + 47) / 48 : (M + 63) / 64);
+}
+
 extern "C" int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, void* out, int64_t ldo,
                                        const ma_train_epilogue_t* epi, ma_stream_t stream) {
   if (!A || !packed || !out || !epi || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
-  if (epi->mode != 3 && epi->mode != 4) return MA_ERR_UNSUPPORTED;
+  if (epi->mode != 3 && epi->mode != 4 && epi->mode != 5) return MA_ERR_UNSUPPORTED;
   if (ma_gemm_rows_packed_bytes(kRpN, K) < 0 || lda < K || (lda & 7) || ldo < kRpN || (ldo & 3)) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out) |
        reinterpret_cast<uintptr_t>(epi->bias)) & 15)
@@ -345,6 +370,13 @@ extern "C" int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, in
       return MA_ERR_INVALID_ARG;
     }
   }
+  if (e.mode == 5) {  // LayerNorm backward epilogue: x = residual, gamma = ln_gamma1, g = out (in place), partials = ln_mid
+    if (!e.residual || !e.ln_g1 || !e.ln_mid || e.bias || e.ldr < kRpN || (e.ldr & 3) || (e.ln_out && (e.ld_ln < kRpN || (e.ld_ln & 3))))
+      return MA_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(e.residual) | reinterpret_cast<uintptr_t>(e.ln_g1) | reinterpret_cast<uintptr_t>(e.ln_mid) |
+         reinterpret_cast<uintptr_t>(e.ln_out)) & 15)
+      return MA_ERR_INVALID_ARG;
+  }
   RowsPackedParams p;
   p.a = reinterpret_cast<const uint16_t*>(A);
   p.lda = lda;
@@ -355,25 +387,17 @@ extern "C" int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, in
   p.M = (int32_t)M;
   p.nchunks = (int32_t)(K / 64);
   p.alpha = 1.0f;
-  // 48-row workgroups when the 64-row grid would fill less than 7/8 of the CUs and the 48-row grid still fits one round
-  int cus = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    static int cached = 0;
-    if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cached = prop.multiProcessorCount;
-    if (cached) cus = cached;
-  }
   const int64_t g64 = (M + 63) / 64, g48 = (M + 47) / 48;
-  const bool use48 = (g64 % cus) != 0 && (g64 % cus) * 8 < cus * 7 && (g48 + cus - 1) / cus == (g64 + cus - 1) / cus;
+  const bool use48 = rows_train_use48(M);
   if (use48) {
     const dim3 grid((unsigned)g48);
     if (e.mode == 3) MA_LAUNCH((rows_packed_kernel<3, 3>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+    else if (e.mode == 5) MA_LAUNCH((rows_packed_kernel<5, 3>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
     else MA_LAUNCH((rows_packed_kernel<4, 3>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
   } else {
     const dim3 grid((unsigned)g64);
     if (e.mode == 3) MA_LAUNCH((rows_packed_kernel<3, 4>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+    else if (e.mode == 5) MA_LAUNCH((rows_packed_kernel<5, 4>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
     else MA_LAUNCH((rows_packed_kernel<4, 4>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
   }
   return MA_OK;

@@ -281,4 +281,155 @@ __device__ __forceinline__ void train_epi_rows256(const TrainEpi& e, tc_f32x4 (&
   }
 }
 
+
+// Epilogue mode 5 (round 4): the LayerNorm BACKWARD that consumes this product, on the same 256-wide rows in the same layout - the
+// input-gradient product of a branch's first dense layer (da = du . W_1, K = 2048 / 768 / 512) followed by the backward of the LayerNorm
+// in front of it (models/conformer.py:109-151 differentiated) and the next branch's dropout backward, which were two launches with
+// a bf16 round trip of da between them (layernorm_bwd_kernel).  Per row m:
+//     dy   = bf16(acc) * row_scale[m]                                  (what the un-fused product stored, what the LayerNorm kernel read)
+//     xh   = (x - mean) * rstd,  w = dy * gamma,  a = mean(w),  b = mean(w * xh)
+//     g   += rstd * (w - a - xh * b)                                    float32 residual-stream gradient, in place (`gout`)
+//     dy_next = bf16(dropout(g * alpha * ln_row_scale[m]))              optional (e.ln_out)
+// and per workgroup one partial (dgamma | dbeta) vector of 512 floats at e.ln_mid + 512 * blk (summed over workgroups by the block's
+// batched reduction).  Same formulas as layernorm_bwd_kernel; the row sums are taken in this layout's order (4 lane groups x 4
+// waves through `red`), so results agree with the two-launch form to float32 rounding, not bit for bit.
+// `red`: LDS scratch of 4 * 16 * MT floats; every MFMA wave of the workgroup must call this.
+template <int MT>
+__device__ __forceinline__ void train_epi_lnbwd256(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], int m0, int M, int wave, int c, int g,
+                                                   float* gout, int64_t ldg, float* red, int blk) {
+  constexpr int ROWS = 16 * MT;
+  float4 xv[MT][4], gv[MT][4];
+  float rsv[MT], rs2[MT];
+  bool live[MT];
+  int mrow[MT];
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int m = m0 + 16 * s + c;
+    live[s] = m < M;
+    mrow[s] = live[s] ? m : M - 1;
+    rsv[s] = e.row_scale ? e.row_scale[mrow[s]] : 1.0f;
+    rs2[s] = e.ln_row_scale ? e.ln_row_scale[mrow[s]] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = 64 * wave + 16 * jt + 4 * g;
+      xv[s][jt] = *reinterpret_cast<const float4*>(e.residual + (int64_t)mrow[s] * e.ldr + n);
+    }
+  }
+  float4 gam[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) gam[jt] = *reinterpret_cast<const float4*>(e.ln_g1 + 64 * wave + 16 * jt + 4 * g);
+  __builtin_amdgcn_sched_barrier(0);
+  auto row_total = [&](float (&part)[MT], float (&tot)[MT]) __attribute__((always_inline)) {
+    __syncthreads();  // (the scratch may still be read from the previous exchange)
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      float a = part[s];
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (g == 0) red[wave * ROWS + 16 * s + c] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      const int r = 16 * s + c;
+      tot[s] = (red[r] + red[ROWS + r]) + (red[2 * ROWS + r] + red[3 * ROWS + r]);
+    }
+  };
+  float part[MT], mu[MT], var[MT], rstd[MT], pa[MT], pb[MT], ta[MT], tb[MT];
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    part[s] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) part[s] += (xv[s][jt].x + xv[s][jt].y) + (xv[s][jt].z + xv[s][jt].w);
+  }
+  row_total(part, mu);
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    mu[s] *= (1.0f / 256.0f);
+    part[s] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      float4& d = xv[s][jt];
+      d.x -= mu[s]; d.y -= mu[s]; d.z -= mu[s]; d.w -= mu[s];
+      part[s] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+  }
+  row_total(part, var);
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    rstd[s] = 1.0f / sqrtf(var[s] * (1.0f / 256.0f) + e.eps);
+    pa[s] = pb[s] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      float v[4] = {acc[jt][s][0], acc[jt][s][1], acc[jt][s][2], acc[jt][s][3]};
+      bf16_round2(v[0], v[1]);
+      bf16_round2(v[2], v[3]);
+      const tc_f32x4 dy = tc_f32x4{v[0] * rsv[s], v[1] * rsv[s], v[2] * rsv[s], v[3] * rsv[s]};
+      acc[jt][s] = dy;
+      float4& d = xv[s][jt];
+      d.x *= rstd[s]; d.y *= rstd[s]; d.z *= rstd[s]; d.w *= rstd[s];  // xh
+      const float w0 = dy[0] * gam[jt].x, w1 = dy[1] * gam[jt].y, w2 = dy[2] * gam[jt].z, w3 = dy[3] * gam[jt].w;
+      pa[s] += (w0 + w1) + (w2 + w3);
+      pb[s] += (w0 * d.x + w1 * d.y) + (w2 * d.z + w3 * d.w);
+    }
+  }
+  // (the residual-stream gradient rows are fetched here, under the two exchanges below: 16 MT registers fewer across the statistics)
+#pragma unroll
+  for (int s = 0; s < MT; ++s)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      gv[s][jt] = *reinterpret_cast<const float4*>(gout + (int64_t)mrow[s] * ldg + 64 * wave + 16 * jt + 4 * g);
+  row_total(pa, ta);
+  row_total(pb, tb);
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const float a = ta[s] * (1.0f / 256.0f), b = tb[s] * (1.0f / 256.0f);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int n = 64 * wave + 16 * jt + 4 * g;
+      const float4 xh = xv[s][jt];
+      const tc_f32x4 dy = acc[jt][s];
+      float4 o = gv[s][jt];
+      o.x += rstd[s] * (dy[0] * gam[jt].x - a - xh.x * b);
+      o.y += rstd[s] * (dy[1] * gam[jt].y - a - xh.y * b);
+      o.z += rstd[s] * (dy[2] * gam[jt].z - a - xh.z * b);
+      o.w += rstd[s] * (dy[3] * gam[jt].w - a - xh.w * b);
+      if (live[s]) *reinterpret_cast<float4*>(gout + (int64_t)mrow[s] * ldg + n) = o;
+      if (e.ln_out) {
+        float v[4] = {o.x * e.alpha * rs2[s], o.y * e.alpha * rs2[s], o.z * e.alpha * rs2[s], o.w * e.alpha * rs2[s]};
+        drop4(e.drop, (uint64_t)mrow[s] * 256 + n, v);
+        if (live[s])
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.ln_out) + (int64_t)mrow[s] * e.ld_ln + n) =
+              make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+      }
+    }
+  }
+  // per-workgroup partial (dgamma | dbeta): column sums over this workgroup's rows = over s (in the lane) and the 16 lanes c
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    float cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+      if (!live[s]) continue;
+      const tc_f32x4 dy = acc[jt][s];
+      const float4 xh = xv[s][jt];
+      cg[0] += dy[0] * xh.x; cg[1] += dy[1] * xh.y; cg[2] += dy[2] * xh.z; cg[3] += dy[3] * xh.w;
+      cb[0] += dy[0]; cb[1] += dy[1]; cb[2] += dy[2]; cb[3] += dy[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        cg[r] += __shfl_xor(cg[r], off, 64);
+        cb[r] += __shfl_xor(cb[r], off, 64);
+      }
+    }
+    if (c == 0) {
+      const int n = 64 * wave + 16 * jt + 4 * g;
+      *reinterpret_cast<float4*>(e.ln_mid + (int64_t)blk * 512 + n) = make_float4(cg[0], cg[1], cg[2], cg[3]);
+      *reinterpret_cast<float4*>(e.ln_mid + (int64_t)blk * 512 + 256 + n) = make_float4(cb[0], cb[1], cb[2], cb[3]);
+    }
+  }
+}
+
 }  // namespace ma

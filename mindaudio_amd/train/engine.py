@@ -262,6 +262,10 @@ class ConformerCTCTrainStep:
         # the backward pass instead of beside it (profiles/r04_rccl_world1_trace.json).  False: always the caller's stream.
         self.own_stream, self._own = own_stream, None
         self._dq, self._dq_blocks = None, []
+        # ln_bwd_fused: the four input-gradient products of a block that feed a LayerNorm backward (ff_w1 / ffm_w1 / pw1 / qkv
+        # transposed, K = 2048 / 512 / 768) carry that LayerNorm backward and the next branch's dropout backward in their epilogue
+        # (ma_gemm_rows_train_bf16 mode 5): 48 launches and 48 bf16 round trips of (M, 256) fewer per step
+        self.ln_bwd_fused = True
         if self._wg_on and self.dev.type == "cuda":
             import ctypes
 
@@ -590,9 +594,12 @@ class ConformerCTCTrainStep:
             off[sfx] = (total, nbytes, int(lib.ma_gemm_tn_splits(mo, no, m)))
             total += (nbytes + 255) // 256 * 256
         ln_parts = int(lib.ma_layernorm_bwd_parts(m))
+        fused_parts = int(lib.ma_gemm_rows_train_parts(m))  # sites whose backward rides on an input-gradient product (ln_bwd_fused)
         for site in self._LN_SITES:
-            off[site] = (total, ln_parts * 512 * 4, ln_parts)
-            total += ln_parts * 512 * 4
+            # (the region keeps the larger size; the item's split count is what the site's producer really writes)
+            parts = fused_parts if (self.fused and self.ln_bwd_fused and site != "norm_final") else ln_parts
+            off[site] = (total, max(ln_parts, fused_parts) * 512 * 4, parts)
+            total += max(ln_parts, fused_parts) * 512 * 4
         # the depthwise convolution's per-workgroup (d_dw_w | d_dw_b) partials (fused path)
         cm_parts = int(lib.ma_convmid_bwd_parts(m // self._t2_cur, self._t2_cur))
         cm_width = self.d * (self.ks + 1)
@@ -1030,6 +1037,8 @@ class ConformerCTCTrainStep:
                 self._dW(dy, F["h"], pre + key + "_w2", pre + key + "_b2")
                 du = K.dense_act_drop_bwd(dy, PK(key + "_w2.tk"), hid, F["u"], pd, seed, self._salt(li, 0 if key == "ffm" else 6))
                 self._dW(du, F["a"], pre + key + "_w1", pre + key + "_b1")
+                if self.ln_bwd_fused:  # da = du . W_1 and the LayerNorm backward (+ the next branch's dropout backward): one launch
+                    return K.dense_lnbwd(du, PK(key + "_w1.tr"), hid, F["x_in"], P(ln + ".g"), g, self._ln_partials(ln), nxt=nxt)
                 da = K.dense_plain(du, PK(key + "_w1.tr"), d, hid)
                 if nxt is None:
                     K.layernorm_bwd(F["x_in"], P(ln + ".g"), da, g, G(ln + ".g"), G(ln + ".b"), partials=self._ln_partials(ln))
@@ -1048,10 +1057,14 @@ class ConformerCTCTrainStep:
             dy = K.convmid_bwd(dwv, C["y"], C["z"], C["stats"], b, t2, P("dw_w"), P("bn_g"), P("bn_b"), G("dw_w"), G("dw_b"), G("bn_g"),
                                G("bn_b"), partials=self._ln_partials("convmid"))
             self._dW(dy, C["a"], pre + "pw1_w", pre + "pw1_b")
-            da = K.dense_plain(dy, PK("pw1_w.tr"), d, 2 * d)
-            _, do = K.layernorm_bwd_next(C["x_in"], P("norm_conv.g"), da, g, G("norm_conv.g"), G("norm_conv.b"),
-                                         (1.0, pd, seed, self._salt(li, 2), None), row_scale=mask_rows,
-                                         partials=self._ln_partials("norm_conv"))
+            if self.ln_bwd_fused:
+                do = K.dense_lnbwd(dy, PK("pw1_w.tr"), 2 * d, C["x_in"], P("norm_conv.g"), g, self._ln_partials("norm_conv"),
+                                   nxt=(1.0, pd, seed, self._salt(li, 2), None), row_scale=mask_rows)
+            else:
+                da = K.dense_plain(dy, PK("pw1_w.tr"), d, 2 * d)
+                _, do = K.layernorm_bwd_next(C["x_in"], P("norm_conv.g"), da, g, G("norm_conv.g"), G("norm_conv.b"),
+                                             (1.0, pd, seed, self._salt(li, 2), None), row_scale=mask_rows,
+                                             partials=self._ln_partials("norm_conv"))
             # MHSA
             A = T["mha"]
             self._dW(do, A["ctx"], pre + "o_w", pre + "o_b")
@@ -1060,9 +1073,13 @@ class ConformerCTCTrainStep:
             dqkv = K.attention_bwd(A["qkv"], pos_all[:, li * d:(li + 1) * d], P("u"), P("v"), att_mask, A["ctx"], dctx, A["lse"], b, t2,
                                    None, None, None, self.heads, d // self.heads, ws=self._dw_cur["att_ws"][self._dw_par])
             self._dW(dqkv, A["a"], pre + "qkv_w", pre + "qkv_b")
-            da = K.dense_plain(dqkv, PK("qkv_w.tr"), d, 3 * d)
-            _, dy = K.layernorm_bwd_next(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"),
-                                         (0.5, pd, seed, self._salt(li, 1), None), partials=self._ln_partials("norm_mha"))
+            if self.ln_bwd_fused:
+                dy = K.dense_lnbwd(dqkv, PK("qkv_w.tr"), 3 * d, A["x_in"], P("norm_mha.g"), g, self._ln_partials("norm_mha"),
+                                   nxt=(0.5, pd, seed, self._salt(li, 1), None))
+            else:
+                da = K.dense_plain(dqkv, PK("qkv_w.tr"), d, 3 * d)
+                _, dy = K.layernorm_bwd_next(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"),
+                                             (0.5, pd, seed, self._salt(li, 1), None), partials=self._ln_partials("norm_mha"))
             ffn_bwd(dy, T["ffm"], "ffm", "norm_ff_macaron", None)
             self._layer_done(li)
 

@@ -498,6 +498,41 @@ def dense_plain(a, packed, n, k, bias=None):
     return out
 
 
+def rows_train_parts(m):
+    """Workgroups (= partial (dgamma | dbeta) vectors of dense_lnbwd) that ma_gemm_rows_train_bf16 launches for m rows."""
+    return int(_lib.load().ma_gemm_rows_train_parts(m))
+
+
+def dense_lnbwd(a, packed, k, x, gamma, g, partials, nxt=None, row_scale=None, eps=1e-5):
+    """An input-gradient product (N = 256, k % 64 == 0, k != 256) with the LayerNorm backward that consumes it in the epilogue:
+    dy = bf16(a W^T) * row_scale; g (M, 256) float32 += dLN/dx(dy) for the LayerNorm of input x and weight gamma, in place; the
+    per-workgroup partial (dgamma | dbeta) vectors go to `partials` (float32, >= rows_train_parts(M) * 512); with
+    nxt = (alpha, p, seed, salt, row_scale_next or None) also dy_next (M, 256) bf16 = dropout(g * alpha * row_scale_next).
+    = dense_plain + layernorm_bwd_next in one launch (round 4).  Returns dy_next (or None)."""
+    import ctypes
+
+    t = _t()
+    m = a.shape[0]
+    assert k != 256 and g.dtype == t.float32 and x.dtype == t.float32 and partials.numel() >= rows_train_parts(m) * 512
+    e = _lib.TrainEpilogue()
+    e.mode = 5
+    e.residual, e.ldr = x.data_ptr(), x.stride(0)
+    e.ln_gamma1 = gamma.data_ptr()
+    e.ln_eps = float(eps)
+    e.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    e.ln_mid = partials.data_ptr()
+    dy_next = None
+    if nxt is not None:
+        alpha, p, seed, salt, rs_next = nxt
+        dy_next = t.empty((m, 256), dtype=t.bfloat16, device=a.device)
+        e.ln_out, e.ld_ln, e.ln_out_bf16 = dy_next.data_ptr(), dy_next.stride(0), 1
+        e.alpha, e.p, e.seed, e.salt = float(alpha), float(p), int(seed), int(salt)
+        e.ln_row_scale = rs_next.data_ptr() if rs_next is not None else None
+    _lib.check(_lib.load().ma_gemm_rows_train_bf16(_p(a), a.stride(0), m, k, _p(packed), _p(g), g.stride(0), ctypes.byref(e), _s()),
+               "dense_lnbwd")
+    return dy_next
+
+
 def dense_join(a, packed, k, bias, residual, alpha, p, seed, salt, row_scale=None, ln1=None, ln2=None, ln_row_scale=None,
                ln_out_dtype=None, eps=1e-5):
     """Branch join (N = 256): x_out (M, 256) float32 = residual + alpha * dropout(bf16((a W^T + b) * row_scale)), and optionally

@@ -629,3 +629,62 @@ def test_conv2_weight_gradient_on_256_tiles(K, b2, h2, w2):
     K.conv2d_dw(dy_b.cuda(), act_b.cuda(), dw2, db2)
     rel = lambda a, w: float((a.cpu().double() - w.double()).abs().max() / w.double().abs().max())  # noqa: E731
     assert rel(dw2.view(co2, 3, 3, c2) - 1.0, wgt2.grad.permute(0, 2, 3, 1)) < 3e-5 and rel(db2 - 1.0, bias2.grad) < 3e-5
+
+
+@pytest.mark.parametrize("m,k", [(1000, 2048), (10200, 768), (97, 512)])
+def test_input_gradient_product_with_layernorm_backward_epilogue(K, m, k):
+    """ma_gemm_rows_train_bf16 mode 5 (round 4: da = du . W, the LayerNorm backward that consumes it and the next branch's dropout
+    backward in ONE launch) against the two launches it replaces (dense_plain + layernorm_bwd_next): the same formulas with row sums
+    taken in another order - g within 2e-6 of its scale, dgamma / dbeta (per-workgroup partials summed) within 2e-5, the emitted bf16
+    dy_next equal except where a float32 last-digit difference crosses a bf16 rounding boundary (<= 1 bf16 ulp, < 0.5 % of entries),
+    identical dropout zeros.  With and without a row scale / a next branch; M not a multiple of the 48- / 64-row tile."""
+    from mindaudio_amd import _lib
+
+    lib = _lib.load()
+    g_ = torch.Generator().manual_seed(7 + m + k)
+    d, p, seed = 256, 0.1, 4242
+    st = torch.cuda.current_stream().cuda_stream
+
+    def pack(w):
+        n, kk = w.shape
+        pieces = int(lib.ma_pack_item_pieces(1, n, kk))
+        out = torch.empty(pieces * 16, dtype=torch.uint8, device="cuda")
+        items = (_lib.PackItem * 1)(_lib.PackItem(w.data_ptr(), out.data_ptr(), w.stride(0), n, kk, 1, 0))
+        d_items = torch.from_numpy(np.frombuffer(bytes(items), dtype=np.uint8).copy()).cuda()
+        d_map = torch.zeros((pieces + 255) // 256, dtype=torch.int32, device="cuda")
+        _lib.check(lib.ma_pack_batch_bf16(d_items.data_ptr(), d_map.data_ptr(), d_map.numel(), st), "pack")
+        return out
+
+    du = bf(torch.randn(m, k, generator=g_)).cuda()
+    wt = bf(torch.randn(d, k, generator=g_) / (k ** 0.5)).cuda()     # (256, k): the transposed weight of the layer
+    x = torch.randn(m, d, generator=g_).cuda() * 2 + 0.3
+    gamma = (1 + 0.1 * torch.randn(d, generator=g_)).cuda()
+    g0 = torch.randn(m, d, generator=g_).cuda()
+    rs = (torch.rand(m, generator=g_) > 0.2).float().cuda()
+    wp = pack(wt)
+    for row_scale, nxt in ((None, (0.5, p, seed, 9, None)), (rs, (1.0, p, seed, 10, rs)), (None, None)):
+        g_ref, dg_ref, db_ref = g0.clone(), torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+        da = K.dense_plain(du, wp, d, k)
+        if nxt is None:
+            K.layernorm_bwd(x, gamma, da, g_ref, dg_ref, db_ref, row_scale=row_scale)
+            dn_ref = None
+        else:
+            _, dn_ref = K.layernorm_bwd_next(x, gamma, da, g_ref, dg_ref, db_ref, nxt, row_scale=row_scale)
+        g_new = g0.clone()
+        parts = torch.full((K.rows_train_parts(m) * 512,), float("nan"), device="cuda")
+        dn = K.dense_lnbwd(du, wp, k, x, gamma, g_new, parts, nxt=nxt, row_scale=row_scale)
+        torch.cuda.synchronize()
+        scale = float(g_ref.abs().max())
+        assert float((g_new - g_ref).abs().max()) <= 2e-6 * scale + 1e-6
+        pv = parts.view(-1, 512).double().sum(0)
+        assert bool(torch.isfinite(pv).all())
+        assert float((pv[:256] - dg_ref.double()).abs().max()) <= 2e-5 * float(dg_ref.abs().max()) + 1e-5
+        assert float((pv[256:] - db_ref.double()).abs().max()) <= 2e-5 * float(db_ref.abs().max()) + 1e-5
+        if nxt is None:
+            assert dn is None
+        else:
+            a_, b_ = dn.float(), dn_ref.float()
+            assert torch.equal(a_ == 0, b_ == 0)
+            diff = (a_ - b_).abs()
+            assert float((diff / b_.abs().clamp(min=1e-3)).max()) <= 1.0 / 64  # one bf16 ulp (2^-7 relative at most)
+            assert float((diff > 0).float().mean()) < 5e-3

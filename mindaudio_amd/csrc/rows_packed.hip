@@ -53,6 +53,7 @@ constexpr int kRpRows = 64, kRpN = 256, kRpThreads = 320;  // 4 MFMA waves + the
 constexpr int kRpStage = kRpRows * 128;  // 8 KiB: 64 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
 constexpr int kRpStages = 8, kRpAhead = 6;
 constexpr int kRpLds = kRpStages * kRpStage;
+constexpr int kRpLds5 = kRpLds + 1024;  // MODE 5: + the LayerNorm statistics' exchange scratch (4 x 64 floats), live during the main loop
 
 struct RowsPackedParams {
   const uint16_t* a;  // (M, K) bf16
@@ -113,6 +114,9 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
         __builtin_amdgcn_global_load_lds((gl_void_t*)(a_src[i] + (int64_t)cc * 64), (lds_void_t*)(st + i * 1024), 16, 0, 0);
     };
     for (int ch = 0; ch < kRpAhead; ++ch) issue_a(ch);
+    if constexpr (MODE == 5) {  // the MFMA waves' LayerNorm statistics in front of their main loop: two exchanges = four barriers
+      __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();
+    }
     for (int ch = 0; ch < nch_pad; ++ch) {
       // chunk ch landed <=> at most the kRpAhead - 1 younger chunks are outstanding
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRpAhead - 1) * NI) : "memory");
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing of this wave lands in the epilogue's scratch
     if constexpr (MODE == 3 || MODE == 5) __builtin_amdgcn_s_barrier();  // the MFMA waves' barrier in front of the epilogue
+    // (MODE 5: the tail's exchange has two more barriers; this wave has ended by then and is not counted)
     return;
   }
   // ---- weight fragments: SGPR chunk base + lane offset, 8 per chunk, three chunks of ring ----------------------------------------
@@ -149,6 +154,13 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
     RP_LOAD(ring[r][0], r, 0); RP_LOAD(ring[r][1], r, 1); RP_LOAD(ring[r][2], r, 2); RP_LOAD(ring[r][3], r, 3);
     RP_LOAD(ring[r][4], r, 4); RP_LOAD(ring[r][5], r, 5); RP_LOAD(ring[r][6], r, 6); RP_LOAD(ring[r][7], r, 7);
   }
+
+  // MODE 5: the statistics of the LayerNorm whose backward rides in the epilogue depend on its input x alone - taken here, while the
+  // first weight fragments and activation chunks are in flight (LDS scratch behind the activation ring)
+  float4 xh5[MODE == 5 ? MT : 1][4];
+  float rstd5[MODE == 5 ? MT : 1];
+  if constexpr (MODE == 5)
+    lnbwd_stats<MT>(e, m0, p.M, wave, c, g, reinterpret_cast<float*>(smem + kRpLds), xh5, rstd5);
 
   // Loads of an MFMA wave, oldest first, in the steady state: ... W(c)[q..7] | W(c+1)x8 | W(c+2)x8 | W(c+3)[0..q-1] ... (W(c+3)[q] is
   // issued right after the last MFMA that reads ring[c % 3][q] in chunk c): use of ring[.][q] in chunk c: younger = (7 - q) + 8 + 8 + q
@@ -216,8 +228,8 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
     train_epi_rows256<MT>(e, acc, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem));
     return;
   } else if constexpr (MODE == 5) {
-    __syncthreads();
-    train_epi_lnbwd256<MT>(e, acc, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem), (int)blockIdx.x);
+    __syncthreads();  // every wave is past its last fragment reads: the activation stages become the exchange scratch
+    lnbwd_tail<MT>(e, acc, xh5, rstd5, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem), (int)blockIdx.x);
     return;
   } else {
     float4 bv[4];
@@ -270,6 +282,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const ma_pack_item_t* _
     out[idx] = cch < nch ? *reinterpret_cast<const uint4*>(w + (int64_t)n * it.ld + k) : make_uint4(0, 0, 0, 0);
   }
 }
+
+MA_LDS_ATTR((rows_packed_kernel<5, 3>), kRpLds5);
+MA_LDS_ATTR((rows_packed_kernel<5, 4>), kRpLds5);
 
 }  // namespace ma
 
@@ -392,12 +407,12 @@ extern "C" int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, in
   if (use48) {
     const dim3 grid((unsigned)g48);
     if (e.mode == 3) MA_LAUNCH((rows_packed_kernel<3, 3>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
-    else if (e.mode == 5) MA_LAUNCH((rows_packed_kernel<5, 3>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+    else if (e.mode == 5) MA_LAUNCH((rows_packed_kernel<5, 3>), grid, dim3(kRpThreads), kRpLds5, (hipStream_t)stream, p, e);
     else MA_LAUNCH((rows_packed_kernel<4, 3>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
   } else {
     const dim3 grid((unsigned)g64);
     if (e.mode == 3) MA_LAUNCH((rows_packed_kernel<3, 4>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
-    else if (e.mode == 5) MA_LAUNCH((rows_packed_kernel<5, 4>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
+    else if (e.mode == 5) MA_LAUNCH((rows_packed_kernel<5, 4>), grid, dim3(kRpThreads), kRpLds5, (hipStream_t)stream, p, e);
     else MA_LAUNCH((rows_packed_kernel<4, 4>), grid, dim3(kRpThreads), kRpLds, (hipStream_t)stream, p, e);
   }
   return MA_OK;

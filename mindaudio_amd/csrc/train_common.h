@@ -294,33 +294,27 @@ __device__ __forceinline__ void train_epi_rows256(const TrainEpi& e, tc_f32x4 (&
 // batched reduction).  Same formulas as layernorm_bwd_kernel; the row sums are taken in this layout's order (4 lane groups x 4
 // waves through `red`), so results agree with the two-launch form to float32 rounding, not bit for bit.
 // `red`: LDS scratch of 4 * 16 * MT floats; every MFMA wave of the workgroup must call this.
+// Split in two so that everything that depends on x alone runs BEFORE the product's main loop (round 4, second step: as one tail the
+// epilogue cost as much as the LayerNorm kernel it replaced - x loads, four barrier-separated exchanges and the g round trip are a
+// serial chain on one workgroup per CU):
+//   lnbwd_stats: loads the LayerNorm input rows, two exchanges (mean, variance) through `red` (LDS scratch of 4 * 16 * MT floats that
+//                nothing else uses during the main loop) -> xh = (x - mean) * rstd in registers, rstd per row;
+//   lnbwd_tail:  after the main loop: dy, ONE exchange (sum w | sum w xh, `red2` = 8 * 16 * MT floats), g update, dy_next, partials.
+// Every MFMA wave of the workgroup must call both (2 x 2 barriers in stats, 2 in the tail).
 template <int MT>
-__device__ __forceinline__ void train_epi_lnbwd256(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], int m0, int M, int wave, int c, int g,
-                                                   float* gout, int64_t ldg, float* red, int blk) {
+__device__ __forceinline__ void lnbwd_stats(const TrainEpi& e, int m0, int M, int wave, int c, int g, float* red, float4 (&xv)[MT][4],
+                                            float (&rstd)[MT]) {
   constexpr int ROWS = 16 * MT;
-  float4 xv[MT][4], gv[MT][4];
-  float rsv[MT], rs2[MT];
-  bool live[MT];
-  int mrow[MT];
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
     const int m = m0 + 16 * s + c;
-    live[s] = m < M;
-    mrow[s] = live[s] ? m : M - 1;
-    rsv[s] = e.row_scale ? e.row_scale[mrow[s]] : 1.0f;
-    rs2[s] = e.ln_row_scale ? e.ln_row_scale[mrow[s]] : 1.0f;
+    const int mr = m < M ? m : M - 1;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const int n = 64 * wave + 16 * jt + 4 * g;
-      xv[s][jt] = *reinterpret_cast<const float4*>(e.residual + (int64_t)mrow[s] * e.ldr + n);
-    }
+    for (int jt = 0; jt < 4; ++jt)
+      xv[s][jt] = *reinterpret_cast<const float4*>(e.residual + (int64_t)mr * e.ldr + 64 * wave + 16 * jt + 4 * g);
   }
-  float4 gam[4];
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) gam[jt] = *reinterpret_cast<const float4*>(e.ln_g1 + 64 * wave + 16 * jt + 4 * g);
-  __builtin_amdgcn_sched_barrier(0);
   auto row_total = [&](float (&part)[MT], float (&tot)[MT]) __attribute__((always_inline)) {
-    __syncthreads();  // (the scratch may still be read from the previous exchange)
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < MT; ++s) {
       float a = part[s];
@@ -335,7 +329,7 @@ __device__ __forceinline__ void train_epi_lnbwd256(const TrainEpi& e, tc_f32x4 (
       tot[s] = (red[r] + red[ROWS + r]) + (red[2 * ROWS + r] + red[3 * ROWS + r]);
     }
   };
-  float part[MT], mu[MT], var[MT], rstd[MT], pa[MT], pb[MT], ta[MT], tb[MT];
+  float part[MT], mu[MT], var[MT];
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
     part[s] = 0.f;
@@ -358,6 +352,38 @@ __device__ __forceinline__ void train_epi_lnbwd256(const TrainEpi& e, tc_f32x4 (
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
     rstd[s] = 1.0f / sqrtf(var[s] * (1.0f / 256.0f) + e.eps);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      float4& d = xv[s][jt];
+      d.x *= rstd[s]; d.y *= rstd[s]; d.z *= rstd[s]; d.w *= rstd[s];  // xh
+    }
+  }
+}
+
+template <int MT>
+__device__ __forceinline__ void lnbwd_tail(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], const float4 (&xv)[MT][4], const float (&rstd)[MT],
+                                           int m0, int M, int wave, int c, int g, float* gout, int64_t ldg, float* red2, int blk) {
+  constexpr int ROWS = 16 * MT;
+  float4 gv[MT][4], gam[4];
+  float rsv[MT], rs2[MT];
+  bool live[MT];
+  int mrow[MT];
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int m = m0 + 16 * s + c;
+    live[s] = m < M;
+    mrow[s] = live[s] ? m : M - 1;
+    rsv[s] = e.row_scale ? e.row_scale[mrow[s]] : 1.0f;
+    rs2[s] = e.ln_row_scale ? e.ln_row_scale[mrow[s]] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      gv[s][jt] = *reinterpret_cast<const float4*>(gout + (int64_t)mrow[s] * ldg + 64 * wave + 16 * jt + 4 * g);
+  }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) gam[jt] = *reinterpret_cast<const float4*>(e.ln_g1 + 64 * wave + 16 * jt + 4 * g);
+  float pa[MT], pb[MT];
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
     pa[s] = pb[s] = 0.f;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
@@ -366,24 +392,30 @@ __device__ __forceinline__ void train_epi_lnbwd256(const TrainEpi& e, tc_f32x4 (
       bf16_round2(v[2], v[3]);
       const tc_f32x4 dy = tc_f32x4{v[0] * rsv[s], v[1] * rsv[s], v[2] * rsv[s], v[3] * rsv[s]};
       acc[jt][s] = dy;
-      float4& d = xv[s][jt];
-      d.x *= rstd[s]; d.y *= rstd[s]; d.z *= rstd[s]; d.w *= rstd[s];  // xh
+      const float4 xh = xv[s][jt];
       const float w0 = dy[0] * gam[jt].x, w1 = dy[1] * gam[jt].y, w2 = dy[2] * gam[jt].z, w3 = dy[3] * gam[jt].w;
       pa[s] += (w0 + w1) + (w2 + w3);
-      pb[s] += (w0 * d.x + w1 * d.y) + (w2 * d.z + w3 * d.w);
+      pb[s] += (w0 * xh.x + w1 * xh.y) + (w2 * xh.z + w3 * xh.w);
     }
   }
-  // (the residual-stream gradient rows are fetched here, under the two exchanges below: 16 MT registers fewer across the statistics)
-#pragma unroll
-  for (int s = 0; s < MT; ++s)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-      gv[s][jt] = *reinterpret_cast<const float4*>(gout + (int64_t)mrow[s] * ldg + 64 * wave + 16 * jt + 4 * g);
-  row_total(pa, ta);
-  row_total(pb, tb);
+  // one exchange for both row sums
+  __syncthreads();
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
-    const float a = ta[s] * (1.0f / 256.0f), b = tb[s] * (1.0f / 256.0f);
+    float a = pa[s], b = pb[s];
+    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+    if (g == 0) {
+      red2[wave * ROWS + 16 * s + c] = a;
+      red2[4 * ROWS + wave * ROWS + 16 * s + c] = b;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int r = 16 * s + c;
+    const float a = ((red2[r] + red2[ROWS + r]) + (red2[2 * ROWS + r] + red2[3 * ROWS + r])) * (1.0f / 256.0f);
+    const float b = ((red2[4 * ROWS + r] + red2[5 * ROWS + r]) + (red2[6 * ROWS + r] + red2[7 * ROWS + r])) * (1.0f / 256.0f);
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       const int n = 64 * wave + 16 * jt + 4 * g;

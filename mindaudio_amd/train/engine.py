@@ -261,7 +261,7 @@ class ConformerCTCTrainStep:
         # onto a few hardware queues and RCCL's stream was seen sharing the default stream's queue: its kernels then run in line with
         # the backward pass instead of beside it (profiles/r04_rccl_world1_trace.json).  False: always the caller's stream.
         self.own_stream, self._own = own_stream, None
-        self._dq, self._dq_blocks = None, []
+        self._dq, self._dq_blocks, self._dq_dec = None, [], None
         # ln_bwd_fused: the four input-gradient products of a block that feed a LayerNorm backward (ff_w1 / ffm_w1 / pw1 / qkv
         # transposed, K = 2048 / 512 / 768) carry that LayerNorm backward and the next branch's dropout backward in their epilogue
         # (ma_gemm_rows_train_bf16 mode 5): 48 launches and 48 bf16 round trips of (M, 256) fewer per step
@@ -726,6 +726,14 @@ class ConformerCTCTrainStep:
         """grad[wname] (N, K) += dy^T x ; grad[bname] += column sums of dy.  dy (M, N), x (M, K) bf16."""
         fp = self.fp
         plan = getattr(self, "_dw_cur", None)
+        if self._dw_direct and wname[0] == "d" and wname[1].isdigit() and bname is not None and \
+                self.K.gemm_tn_direct_ok(dy, x, fp.g(wname)):
+            # a decoder layer's weight gradient: with the other 41 of the decoder in ONE grid at the end of its backward pass
+            # (they were 43 split-K products + 88 reduction launches of ~10 us each: the hybrid step's decoder is launch-bound)
+            if self._dq_dec is None:
+                self._dq_dec = self.K.DirectGroup()
+            self._dq_dec.add(dy, x, fp.g(wname), fp.g(bname))
+            return
         if plan is not None and wname[0] == "l" and bname is not None:
             sfx = wname.split(".", 1)[1]
             if self._dw_direct and sfx in self._DW_SUFFIXES and self.K.gemm_tn_direct_ok(dy, x, fp.g(wname)):
@@ -780,6 +788,8 @@ class ConformerCTCTrainStep:
         self._wg_keep.clear()
         if self._dq is not None:
             self._dq.clear()
+        if self._dq_dec is not None:
+            self._dq_dec.clear()
         self._dq_blocks.clear()
         # (experimental second stream: used from step _wg_from of a batch shape on - round 3's mitigation, kept; tools/wg_hunt.py sets 0)
         key = (b, t, idim)
@@ -1179,6 +1189,9 @@ class ConformerCTCTrainStep:
             self._dW(dqkv, T["a"], pre + "sa_qkv_w", pre + "sa_qkv_b")
             K.layernorm_bwd(T["x0"], P("norm1.g"), DX(dqkv, "sa_qkv_w"), g, G("norm1.g"), G("norm1.b"), eps=eps)
         K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0))
+        if self._dq_dec is not None:  # the decoder layers' weight gradients: one grid
+            self._dq_dec.launch()
+            self._dq_dec.clear()
         if self.dec_names:
             self.reducer.launch(*fp.span(self.dec_names))
         return loss_att, d_mem

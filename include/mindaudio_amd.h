@@ -544,9 +544,25 @@ int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* packed, void
 int32_t ma_gemm_rows_train_parts(int64_t M);
 int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, void* out, int64_t ldo,
                             const ma_train_epilogue_t* epi, ma_stream_t stream);
+/* The whole position-wise feed-forward module of a Conformer block in TRAINING mode, one launch (round 4; d_model = 256,
+ * hidden % 256 == 0, `packed` = ma_ffn_pack_weights_bf16 - the evaluation forward's format):
+ *   u (M, hidden) bf16 = a W1^T + b1;  h (M, hidden) bf16 = dropout(swish(a W1^T + b1)) with (p_hidden, seed_hidden, salt_hidden)
+ *   [both are the backward pass's tape, row stride ldu];  out (M, 256) float32 = the join of ma_gemm_rows_train_bf16 mode 3 on
+ *   h W2^T (`join`: bias = b2, residual, alpha, the join's dropout site, LayerNorm / LayerNorm chain outputs).
+ * positionwise_feed_forward.py:33-46 + models/conformer.py:109-112, 147-156.  Against ma_gemm_k256_train_bf16 mode 1 followed by
+ * ma_gemm_rows_train_bf16 mode 3: the same dropout masks element for element; the bias enters the float32 accumulation of u first
+ * instead of last, Swish is taken of the float32 pre-activation instead of its bf16 rounding, and the second product sums the
+ * hidden units in another order (tests/test_train_kernels_gpu.py carries the tolerances).  Needs M * ldu < 2^31 elements.
+ * ma_ffn_train_rows() = rows per workgroup (48). */
+int32_t ma_ffn_train_rows(void);
+int ma_ffn_train_bf16(const void* a, int64_t lda, int64_t M, int32_t hidden, const void* packed, const float* b1, void* u, void* h,
+                      int64_t ldu, float p_hidden, uint32_t seed_hidden, uint32_t salt_hidden, float* out, int64_t ldo,
+                      const ma_train_epilogue_t* join, ma_stream_t stream);
 /* Fragment packing of a list of weights in ONE launch (the training step re-packs every layer's weights after the optimizer):
  * items / block_item are DEVICE arrays; kind 0 = ma_gemm_k256_pack_bf16 layout (K = 256), kind 1 = ma_gemm_rows_pack_bf16 layout
- * (N = 256); workgroup b packs 16-byte pieces [256 (b - first_block), + 256) of item block_item[b]. */
+ * (N = 256), kind 2 / 3 = the W1 (N = hidden, K = 256) / W2 (N = 256, K = hidden) half of ma_ffn_pack_weights_bf16's format (both
+ * halves of a module share one destination); workgroup b packs 16-byte pieces [256 (b - first_block), + 256) of item
+ * block_item[b]. */
 typedef struct ma_pack_item {
   const void* src;
   void* dst;

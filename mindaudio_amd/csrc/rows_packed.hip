@@ -261,6 +261,8 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
 // ---- fragment packing of a list of weights in one launch (ma_pack_batch_bf16) -----------------------------------------------------
 // kind 0: gemm_k256 layout - piece idx: lane = idx & 63, ks = (idx >> 6) & 7, nt = idx >> 9 -> W[16 nt + (lane & 15)][32 ks + 8 (lane >> 4) ..]
 // kind 1: rows_packed layout (rows_pack_kernel above)
+// kind 2 / 3: the W1 (H, 256) / W2 (256, H) half of the feed-forward block format of ffn_packed.hip (ffn_pack_kernel): both halves of a
+//   module write into ONE destination, [H / 32 blocks][32 items][64 lanes] x 16 B, W1 items 0..15, W2 items 16..31
 __global__ __launch_bounds__(256) void pack_batch_kernel(const ma_pack_item_t* __restrict__ items, const int32_t* __restrict__ block_item) {
   const ma_pack_item_t it = items[block_item[blockIdx.x]];
   const int64_t idx = (int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x;
@@ -272,6 +274,16 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const ma_pack_item_t* _
     const int ks = (int)((idx >> 6) & 7);
     const int64_t nt = idx >> 9;
     out[idx] = *reinterpret_cast<const uint4*>(w + (nt * 16 + (lane & 15)) * it.ld + 32 * ks + 8 * (lane >> 4));
+  } else if (it.kind == 2 || it.kind == 3) {
+    const int hidden = it.kind == 2 ? it.N : it.K;
+    if (idx >= (int64_t)(hidden / 32) * 16 * 64) return;
+    const int q = (int)((idx >> 6) & 15), i = lane & 15, g = lane >> 4;
+    const int64_t hb = idx >> 10;
+    if (it.kind == 2)
+      out[hb * 2048 + q * 64 + lane] =
+          *reinterpret_cast<const uint4*>(w + (hb * 32 + 8 * (i >> 2) + 4 * (q & 1) + (i & 3)) * it.ld + 32 * (q >> 1) + 8 * g);
+    else
+      out[hb * 2048 + (16 + q) * 64 + lane] = *reinterpret_cast<const uint4*>(w + (int64_t)(16 * q + i) * it.ld + hb * 32 + 8 * g);
   } else {
     const int nch = it.K / 64, nch_pad = (nch + 2) / 3 * 3;
     if (idx >= (int64_t)4 * nch_pad * 8 * 64) return;
@@ -421,6 +433,8 @@ extern "C" int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, in
 extern "C" int64_t ma_pack_item_pieces(int32_t kind, int64_t N, int64_t K) {
   if (kind == 0) return (K == 256 && N >= 256 && N % 256 == 0) ? (N / 16) * 8 * 64 : (int64_t)MA_ERR_UNSUPPORTED;
   if (kind == 1) return (N == kRpN && K >= 64 && K % 64 == 0) ? (int64_t)4 * ((K / 64 + 2) / 3 * 3) * 8 * 64 : (int64_t)MA_ERR_UNSUPPORTED;
+  if (kind == 2) return (K == 256 && N >= 256 && N % 256 == 0) ? (N / 32) * 16 * 64 : (int64_t)MA_ERR_UNSUPPORTED;
+  if (kind == 3) return (N == 256 && K >= 256 && K % 256 == 0) ? (K / 32) * 16 * 64 : (int64_t)MA_ERR_UNSUPPORTED;
   return MA_ERR_INVALID_ARG;
 }
 

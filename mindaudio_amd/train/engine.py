@@ -266,6 +266,10 @@ class ConformerCTCTrainStep:
         # transposed, K = 2048 / 512 / 768) carry that LayerNorm backward and the next branch's dropout backward in their epilogue
         # (ma_gemm_rows_train_bf16 mode 5): 48 launches and 48 bf16 round trips of (M, 256) fewer per step
         self.ln_bwd_fused = True
+        # ffn_one_launch: each feed-forward module's forward pass (w_1 + Swish + dropout -> u, h on the tape; w_2 + dropout + residual +
+        # the LayerNorm (chain) behind it) is ONE launch (ma_ffn_train_bf16, the evaluation forward's hidden-slice-owner kernel with the
+        # training work in its loop) instead of two: h is not read back for the second product
+        self.ffn_one_launch = self.fused  # (and hidden % 256 == 0: settled below, once the model has been read)
         if self._wg_on and self.dev.type == "cuda":
             import ctypes
 
@@ -276,6 +280,7 @@ class ConformerCTCTrainStep:
         self.V = model.ctc.ctc_lo.out_features
         self.Vp = K.pad64(self.V)
         self.hidden = enc.encoders[0].feed_forward.w_1.out_features
+        self.ffn_one_launch = self.ffn_one_launch and self.hidden % 256 == 0 and self.hidden <= 8192
         self._dw_direct = self.fused and self.dw_group_blocks > 0 and self.d % 256 == 0 and self.hidden % 256 == 0
         if self._wg_on and not self._dw_direct and not self._wg_split_ok:
             raise ValueError("wg_stream=True needs the direct weight-gradient groups (dw_group_blocks > 0, d_model and hidden "
@@ -519,6 +524,8 @@ class ConformerCTCTrainStep:
               ("qkv_w.tr", "qkv_w", True, 1), ("o_w.k", "o_w", False, 0), ("o_w.tk", "o_w", True, 0), ("pw1_w.k", "pw1_w", False, 0),
               ("pw1_w.tr", "pw1_w", True, 1), ("pw2_w.k", "pw2_w", False, 0), ("pw2_w.tk", "pw2_w", True, 0))
 
+    _PACKS_FFN = (("ffm.f", "ffm_w1", False, 2), ("ffm.f", "ffm_w2", False, 3), ("ff.f", "ff_w1", False, 2), ("ff.f", "ff_w2", False, 3))
+
     @torch.no_grad()
     def _pack_weights(self):
         """One launch re-packs every block's dense weights (bf16 mirror and transposed copies -> MFMA-fragment order)."""
@@ -535,17 +542,23 @@ class ConformerCTCTrainStep:
             if pieces > 0:
                 specs.append(("out_w.r", w, w.shape[0], w.shape[1], 1, pieces, total))
                 total += pieces * 16
+            packs = self._PACKS
+            if self.ffn_one_launch:  # the forward pass of the feed-forward modules reads the block format of W1 and W2 instead
+                packs = tuple(pk for pk in packs if pk[0] not in ("ffm_w1.k", "ffm_w2.r", "ff_w1.k", "ff_w2.r")) + self._PACKS_FFN
             for li in range(self.L):
-                for key, src, transposed, kind in self._PACKS:
+                for key, src, transposed, kind in packs:
                     w = self.wt["l%d.%s" % (li, src)] if transposed else self.fp.w("l%d.%s" % (li, src))
                     n, k = w.shape[0], (self.fp.w("l%d.%s" % (li, src)).shape[0] if transposed else w.shape[1])
                     pieces = int(lib.ma_pack_item_pieces(kind, n, k))
                     _lib.check(min(pieces, 0), "pack %s" % key)
+                    if kind == 3:  # the W2 half goes into the destination its W1 half (the previous spec) opened
+                        specs.append(("l%d.%s" % (li, key), w, n, k, kind, pieces, specs[-1][6]))
+                        continue
                     specs.append(("l%d.%s" % (li, key), w, n, k, kind, pieces, total))
-                    total += pieces * 16
+                    total += pieces * 16 * (2 if kind == 2 else 1)
             arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
             for name, w, n, k, kind, pieces, off in specs:
-                self.pk[name] = arena[off:off + pieces * 16]
+                self.pk[name] = arena[off:off + pieces * 16 * (2 if kind in (2, 3) else 1)]
                 nblk = (pieces + 255) // 256
                 items.append(_lib.PackItem(w.data_ptr(), arena.data_ptr() + off, w.stride(0), n, k, kind, first))
                 block_item += [len(items) - 1] * nblk
@@ -1005,8 +1018,12 @@ class ConformerCTCTrainStep:
             ln = lambda n: (P(n + ".g"), P(n + ".b"))  # noqa: E731
             T = {}
             # -- macaron FFN
-            u, h = K.dense_act_drop(a, PK("ffm_w1.k"), hid, P("ffm_b1"), pd, seed, self._salt(li, 0))
-            x1, a1, _ = K.dense_join(h, PK("ffm_w2.r"), hid, P("ffm_b2"), x, 0.5, pd, seed, self._salt(li, 1), ln1=ln("norm_mha"))
+            if self.ffn_one_launch:
+                u, h, x1, a1, _ = K.ffn_train(a, PK("ffm.f"), hid, P("ffm_b1"), pd, seed, self._salt(li, 0), P("ffm_b2"), x, 0.5, pd,
+                                              self._salt(li, 1), ln1=ln("norm_mha"))
+            else:
+                u, h = K.dense_act_drop(a, PK("ffm_w1.k"), hid, P("ffm_b1"), pd, seed, self._salt(li, 0))
+                x1, a1, _ = K.dense_join(h, PK("ffm_w2.r"), hid, P("ffm_b2"), x, 0.5, pd, seed, self._salt(li, 1), ln1=ln("norm_mha"))
             T["ffm"] = dict(x_in=x, a=a, u=u, h=h)
             # -- MHSA
             qkv = K.dense_plain(a1, PK("qkv_w.k"), 3 * d, d, bias=P("qkv_b"))
@@ -1022,10 +1039,15 @@ class ConformerCTCTrainStep:
                                      ln1=ln("norm_ff"))
             T["conv"] = dict(x_in=x2, a=a2, y=y, w=wv, z=z, stats=stats)
             # -- FFN, norm_final and the LayerNorm that reads its output (the next block's norm_ff_macaron, or after_norm)
-            u, h = K.dense_act_drop(a3, PK("ff_w1.k"), hid, P("ff_b1"), pd, seed, self._salt(li, 6))
             nxt = (fp.p("l%d.norm_ff_macaron.g" % (li + 1)), fp.p("l%d.norm_ff_macaron.b" % (li + 1))) if li + 1 < L else \
                 (fp.p("after_norm.g"), fp.p("after_norm.b"))
-            x4, a, x = K.dense_join(h, PK("ff_w2.r"), hid, P("ff_b2"), x3, 0.5, pd, seed, self._salt(li, 7), ln1=ln("norm_final"), ln2=nxt)
+            if self.ffn_one_launch:
+                u, h, x4, a, x = K.ffn_train(a3, PK("ff.f"), hid, P("ff_b1"), pd, seed, self._salt(li, 6), P("ff_b2"), x3, 0.5, pd,
+                                             self._salt(li, 7), ln1=ln("norm_final"), ln2=nxt)
+            else:
+                u, h = K.dense_act_drop(a3, PK("ff_w1.k"), hid, P("ff_b1"), pd, seed, self._salt(li, 6))
+                x4, a, x = K.dense_join(h, PK("ff_w2.r"), hid, P("ff_b2"), x3, 0.5, pd, seed, self._salt(li, 7), ln1=ln("norm_final"),
+                                        ln2=nxt)
             T["ff"] = dict(x_in=x3, a=a3, u=u, h=h)
             T["final_in"] = x4
             tape.append(T)

@@ -513,6 +513,80 @@ def test_fused_dense_layers_equal_their_unfused_launches(K):
     assert torch.equal(g_new, g_ref) and torch.equal(dn, dn_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
 
 
+@pytest.mark.parametrize("m,hid,chain", [(1000, 2048, True), (10200, 2048, False), (49, 256, False), (48, 512, True), (1, 256, False)])
+def test_feed_forward_module_in_one_launch(K, m, hid, chain):
+    """ma_ffn_train_bf16 against the two launches it replaces (ma_gemm_k256_train_bf16 mode 1 + ma_gemm_rows_train_bf16 mode 3, same
+    dropout sites) and against float64: the dropout masks are the SAME element for element; u differs by at most one bf16 ulp (the
+    bias enters the float32 accumulation first instead of last), h by the rounding of Swish's argument, the join by the order of the
+    hidden units' sum."""
+    from mindaudio_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5 + m)
+    d, p, seed = 256, 0.1, 4242
+    st = torch.cuda.current_stream().cuda_stream
+    a = bf(torch.randn(m, d, generator=g)).cuda()
+    w1 = bf(torch.randn(hid, d, generator=g) / 16).cuda()
+    w2 = bf(torch.randn(d, hid, generator=g) / 45).cuda()
+    b1, b2 = torch.randn(hid, generator=g).cuda(), torch.randn(d, generator=g).cuda()
+    x = torch.randn(m, d, generator=g).cuda()
+    g1, be1 = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    g2, be2 = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+
+    def pack(w, kind, out=None):
+        n, k = w.shape
+        pieces = int(lib.ma_pack_item_pieces(kind, n, k))
+        assert pieces > 0
+        if out is None:
+            out = torch.empty(pieces * 16 * (2 if kind in (2, 3) else 1), dtype=torch.uint8, device="cuda")
+        items = (_lib.PackItem * 1)(_lib.PackItem(w.data_ptr(), out.data_ptr(), w.stride(0), n, k, kind, 0))
+        d_items = torch.from_numpy(np.frombuffer(bytes(items), dtype=np.uint8).copy()).cuda()
+        d_map = torch.zeros((pieces + 255) // 256, dtype=torch.int32, device="cuda")
+        _lib.check(lib.ma_pack_batch_bf16(d_items.data_ptr(), d_map.data_ptr(), d_map.numel(), st), "pack")
+        return out
+
+    # the two halves written by the batched packer == the evaluation path's packer
+    pk = pack(w2, 3, pack(w1, 2))
+    assert torch.equal(pk, ops.ffn_pack_weights(w1, w2).view(torch.uint8).reshape(-1))
+    ln2 = (g2, be2) if chain else None
+    u, h, xo, lo, mid = K.ffn_train(a, pk, hid, b1, p, seed, 3, b2, x, 0.5, p, 4, ln1=(g1, be1), ln2=ln2)
+    u_ref, h_ref = K.dense_act_drop(a, pack(w1, 0), hid, b1, p, seed, 3)
+    xo_ref, lo_ref, mid_ref = K.dense_join(h_ref, pack(w2, 0 if hid == 256 else 1), hid, b2, x, 0.5, p, seed, 4, ln1=(g1, be1), ln2=ln2)
+    # u: one bf16 ulp
+    du = (u.float() - u_ref.float()).abs()
+    assert float((du / u_ref.float().abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -7
+    # the hidden dropout mask: identical wherever swish(u) does not round to zero by itself
+    big = u_ref.float().abs() > 1e-3
+    assert torch.equal((h == 0) & big, (h_ref == 0) & big)
+    frac = float(((h == 0) & big).float().mean())
+    assert abs(frac - p) < (0.02 if m * hid > 50000 else 0.06), frac
+    # h against float64 on the float32 pre-activation
+    u64 = a.double() @ w1.double().t() + b1.double()
+    h64 = u64 * torch.sigmoid(u64) / (1 - p) * (h_ref != 0).double()
+    sel = big & (h_ref != 0)
+    assert float(((h.double() - h64).abs() / h64.abs().clamp_min(1e-2))[sel].max()) < 2.0 ** -7  # < 1 bf16 ulp (+ fast sigmoid)
+    assert rel(h, h_ref.float().cpu()) < 5e-3  # (Swish of the bf16-rounded u in the two-launch form: 2^-9 relative, rms)
+    # the join: float64 on THIS launch's h and the join's own mask (recovered from the two-launch result: z = 0 <=> dropped)
+    z64 = h.double() @ w2.double().t() + b2.double()
+    keep = ((xo_ref - x) != 0).double()
+    xo64 = x.double() + 0.5 * z64 * keep / (1 - p)
+    err = (xo.double() - xo64).abs()
+    assert float(err.max()) < 2.0 ** -8 * float(z64.abs().max()) + 1e-5, float(err.max())
+    assert rel(xo, xo_ref.cpu()) < 2e-3
+    if chain:
+        assert rel(mid, mid_ref.cpu()) < 2e-3 and rel(lo, lo_ref.float().cpu()) < 4e-3
+        mid64 = torch.nn.functional.layer_norm(xo.double(), (d,), g1.double(), be1.double(), 1e-5)
+        lo64 = torch.nn.functional.layer_norm(mid64, (d,), g2.double(), be2.double(), 1e-5)
+        assert rel(mid, mid64.cpu()) < 1e-5 and rel(lo, lo64.cpu()) < 3e-3
+    else:
+        assert mid is None
+        lo64 = torch.nn.functional.layer_norm(xo.double(), (d,), g1.double(), be1.double(), 1e-5)
+        assert rel(lo, lo64.cpu()) < 3e-3 and rel(lo, lo_ref.float().cpu()) < 4e-3
+    # bad arguments
+    with pytest.raises(Exception):
+        K.ffn_train(a, pk, hid + 64, b1, p, seed, 3, b2, x, 0.5, p, 4)
+
+
 @pytest.mark.parametrize("b,h,w,c", [(2, 21, 19, 128), (3, 24, 39, 256), (1, 3, 3, 128), (2, 8, 6, 128), (9, 187, 39, 256),
                                      (8, 206, 40, 256)])
 def test_conv2_input_gradient_as_one_implicit_gemm(K, b, h, w, c):

@@ -544,20 +544,31 @@ int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* packed, void
 int32_t ma_gemm_rows_train_parts(int64_t M);
 int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, void* out, int64_t ldo,
                             const ma_train_epilogue_t* epi, ma_stream_t stream);
-/* The whole position-wise feed-forward module of a Conformer block in TRAINING mode, one launch (round 4; d_model = 256,
- * hidden % 256 == 0, `packed` = ma_ffn_pack_weights_bf16 - the evaluation forward's format):
+/* The whole position-wise feed-forward module of a Conformer block in TRAINING mode, one launch each way (round 4; d_model = 256,
+ * hidden % 256 == 0, `packed` = ma_ffn_pack_weights_bf16 - the evaluation forward's format).
+ * Forward:
  *   u (M, hidden) bf16 = a W1^T + b1;  h (M, hidden) bf16 = dropout(swish(a W1^T + b1)) with (p_hidden, seed_hidden, salt_hidden)
  *   [both are the backward pass's tape, row stride ldu];  out (M, 256) float32 = the join of ma_gemm_rows_train_bf16 mode 3 on
  *   h W2^T (`join`: bias = b2, residual, alpha, the join's dropout site, LayerNorm / LayerNorm chain outputs).
+ *   tape_derivative != 0: u receives gk = bf16(swish'(a W1^T + b1) * keep / (1 - p_hidden)) instead - all the backward pass needs of u.
  * positionwise_feed_forward.py:33-46 + models/conformer.py:109-112, 147-156.  Against ma_gemm_k256_train_bf16 mode 1 followed by
  * ma_gemm_rows_train_bf16 mode 3: the same dropout masks element for element; the bias enters the float32 accumulation of u first
  * instead of last, Swish is taken of the float32 pre-activation instead of its bf16 rounding, and the second product sums the
- * hidden units in another order (tests/test_train_kernels_gpu.py carries the tolerances).  Needs M * ldu < 2^31 elements.
- * ma_ffn_train_rows() = rows per workgroup (48). */
+ * hidden units in another order (tests/test_train_kernels_gpu.py carries the tolerances).
+ * Backward (`packed_t` = ma_ffn_pack_weights_bf16 of (W2^T (hidden, 256), W1^T (256, hidden)); gk from the forward launch):
+ *   du (M, hidden) bf16 = bf16(dy W2) * gk   [stored: the operand of w_1's weight gradient];  da = du W1 feeds the LayerNorm backward
+ *   of ma_gemm_rows_train_bf16 mode 5 (`lnbwd`: residual = the LayerNorm's input x, ln_gamma1, g in place, ln_mid = per-workgroup
+ *   (dgamma | dbeta) partials, ma_ffn_train_parts(M) x 512 floats, optional ln_out = the next branch's dropout backward).
+ *   Against ma_gemm_k256_train_bf16 mode 2 + ma_gemm_rows_train_bf16 mode 5: swish' comes from the forward's float32 pre-activation
+ *   through one bf16 rounding (gk) instead of from the bf16 u.
+ * Both need M * ldu < 2^31 elements.  ma_ffn_train_rows() = rows per workgroup (48). */
 int32_t ma_ffn_train_rows(void);
+int32_t ma_ffn_train_parts(int64_t M);
 int ma_ffn_train_bf16(const void* a, int64_t lda, int64_t M, int32_t hidden, const void* packed, const float* b1, void* u, void* h,
-                      int64_t ldu, float p_hidden, uint32_t seed_hidden, uint32_t salt_hidden, float* out, int64_t ldo,
-                      const ma_train_epilogue_t* join, ma_stream_t stream);
+                      int64_t ldu, int32_t tape_derivative, float p_hidden, uint32_t seed_hidden, uint32_t salt_hidden, float* out,
+                      int64_t ldo, const ma_train_epilogue_t* join, ma_stream_t stream);
+int ma_ffn_train_bwd_bf16(const void* dy, int64_t ldy, int64_t M, int32_t hidden, const void* packed_t, const void* gk, void* du,
+                          int64_t ldu, float* g, int64_t ldg, const ma_train_epilogue_t* lnbwd, ma_stream_t stream);
 /* Fragment packing of a list of weights in ONE launch (the training step re-packs every layer's weights after the optimizer):
  * items / block_item are DEVICE arrays; kind 0 = ma_gemm_k256_pack_bf16 layout (K = 256), kind 1 = ma_gemm_rows_pack_bf16 layout
  * (N = 256), kind 2 / 3 = the W1 (N = hidden, K = 256) / W2 (N = 256, K = hidden) half of ma_ffn_pack_weights_bf16's format (both

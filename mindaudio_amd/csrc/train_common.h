@@ -144,6 +144,34 @@ inline int train_epi_fill(const ma_train_epilogue_t* epi, int64_t M, int64_t N, 
   return MA_OK;
 }
 
+// host side: mode 5 (an input-gradient product with the LayerNorm backward in its epilogue): x = residual, gamma = ln_gamma1,
+// partials = ln_mid, optional dy_next = ln_out (bf16) with (alpha, ln_row_scale, p, seed, salt)
+inline int train_epi_fill5(const ma_train_epilogue_t* epi, int64_t M, TrainEpi& e) {
+  if (!epi || epi->mode != 5 || epi->p < 0.0f || epi->p >= 1.0f) return MA_ERR_INVALID_ARG;
+  e = TrainEpi{};
+  e.mode = 5;
+  e.residual = epi->residual;
+  e.ldr = epi->ldr;
+  e.row_scale = epi->row_scale;
+  e.alpha = epi->alpha;
+  e.drop = make_drop(epi->p, epi->seed, epi->salt);
+  e.ln_g1 = epi->ln_gamma1;
+  e.ln_row_scale = epi->ln_row_scale;
+  e.ln_out = epi->ln_out;
+  e.ln_mid = epi->ln_mid;
+  e.ld_ln = epi->ld_ln;
+  e.ld_mid = epi->ld_mid;
+  e.eps = epi->ln_eps;
+  e.ln_out_bf16 = 1;
+  if (!e.residual || !e.ln_g1 || !e.ln_mid || epi->bias || e.ldr < 256 || (e.ldr & 3) || (e.ln_out && (e.ld_ln < 256 || (e.ld_ln & 3))))
+    return MA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(e.residual) | reinterpret_cast<uintptr_t>(e.ln_g1) | reinterpret_cast<uintptr_t>(e.ln_mid) |
+       reinterpret_cast<uintptr_t>(e.ln_out)) & 15)
+    return MA_ERR_INVALID_ARG;
+  (void)M;
+  return MA_OK;
+}
+
 // (v_rcp_f32 instead of an IEEE division: 1 ulp, invisible after the bf16 rounding of every consumer)
 __device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 

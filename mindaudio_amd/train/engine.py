@@ -281,6 +281,9 @@ class ConformerCTCTrainStep:
         self.Vp = K.pad64(self.V)
         self.hidden = enc.encoders[0].feed_forward.w_1.out_features
         self.ffn_one_launch = self.ffn_one_launch and self.hidden % 256 == 0 and self.hidden <= 8192
+        # ... and its backward pass as well (ma_ffn_train_bwd_bf16: dh -> du -> da -> the LayerNorm backward in front of the module);
+        # the forward launch then leaves gk = swish'(.) * keep / (1 - p) on the tape in u's place
+        self.ffn_bwd_one_launch = self.ffn_one_launch and self.ln_bwd_fused
         self._dw_direct = self.fused and self.dw_group_blocks > 0 and self.d % 256 == 0 and self.hidden % 256 == 0
         if self._wg_on and not self._dw_direct and not self._wg_split_ok:
             raise ValueError("wg_stream=True needs the direct weight-gradient groups (dw_group_blocks > 0, d_model and hidden "
@@ -525,6 +528,7 @@ class ConformerCTCTrainStep:
               ("pw1_w.tr", "pw1_w", True, 1), ("pw2_w.k", "pw2_w", False, 0), ("pw2_w.tk", "pw2_w", True, 0))
 
     _PACKS_FFN = (("ffm.f", "ffm_w1", False, 2), ("ffm.f", "ffm_w2", False, 3), ("ff.f", "ff_w1", False, 2), ("ff.f", "ff_w2", False, 3))
+    _PACKS_FFN_T = (("ffm.ft", "ffm_w2", True, 2), ("ffm.ft", "ffm_w1", True, 3), ("ff.ft", "ff_w2", True, 2), ("ff.ft", "ff_w1", True, 3))
 
     @torch.no_grad()
     def _pack_weights(self):
@@ -545,6 +549,8 @@ class ConformerCTCTrainStep:
             packs = self._PACKS
             if self.ffn_one_launch:  # the forward pass of the feed-forward modules reads the block format of W1 and W2 instead
                 packs = tuple(pk for pk in packs if pk[0] not in ("ffm_w1.k", "ffm_w2.r", "ff_w1.k", "ff_w2.r")) + self._PACKS_FFN
+            if self.ffn_bwd_one_launch:  # ... and their backward pass the block format of (W2^T, W1^T)
+                packs = tuple(pk for pk in packs if pk[0] not in ("ffm_w2.tk", "ffm_w1.tr", "ff_w2.tk", "ff_w1.tr")) + self._PACKS_FFN_T
             for li in range(self.L):
                 for key, src, transposed, kind in packs:
                     w = self.wt["l%d.%s" % (li, src)] if transposed else self.fp.w("l%d.%s" % (li, src))
@@ -608,11 +614,15 @@ class ConformerCTCTrainStep:
             total += (nbytes + 255) // 256 * 256
         ln_parts = int(lib.ma_layernorm_bwd_parts(m))
         fused_parts = int(lib.ma_gemm_rows_train_parts(m))  # sites whose backward rides on an input-gradient product (ln_bwd_fused)
+        ffn_parts = int(lib.ma_ffn_train_parts(m))          # ... or on the feed-forward module's one-launch backward
+        most = max(ln_parts, fused_parts, ffn_parts)
         for site in self._LN_SITES:
-            # (the region keeps the larger size; the item's split count is what the site's producer really writes)
+            # (the region keeps the largest size; the item's split count is what the site's producer really writes)
             parts = fused_parts if (self.fused and self.ln_bwd_fused and site != "norm_final") else ln_parts
-            off[site] = (total, max(ln_parts, fused_parts) * 512 * 4, parts)
-            total += max(ln_parts, fused_parts) * 512 * 4
+            if self.ffn_bwd_one_launch and site in ("norm_ff", "norm_ff_macaron"):
+                parts = ffn_parts
+            off[site] = (total, most * 512 * 4, parts)
+            total += most * 512 * 4
         # the depthwise convolution's per-workgroup (d_dw_w | d_dw_b) partials (fused path)
         cm_parts = int(lib.ma_convmid_bwd_parts(m // self._t2_cur, self._t2_cur))
         cm_width = self.d * (self.ks + 1)
@@ -1020,7 +1030,7 @@ class ConformerCTCTrainStep:
             # -- macaron FFN
             if self.ffn_one_launch:
                 u, h, x1, a1, _ = K.ffn_train(a, PK("ffm.f"), hid, P("ffm_b1"), pd, seed, self._salt(li, 0), P("ffm_b2"), x, 0.5, pd,
-                                              self._salt(li, 1), ln1=ln("norm_mha"))
+                                              self._salt(li, 1), ln1=ln("norm_mha"), tape_derivative=self.ffn_bwd_one_launch)
             else:
                 u, h = K.dense_act_drop(a, PK("ffm_w1.k"), hid, P("ffm_b1"), pd, seed, self._salt(li, 0))
                 x1, a1, _ = K.dense_join(h, PK("ffm_w2.r"), hid, P("ffm_b2"), x, 0.5, pd, seed, self._salt(li, 1), ln1=ln("norm_mha"))
@@ -1043,7 +1053,7 @@ class ConformerCTCTrainStep:
                 (fp.p("after_norm.g"), fp.p("after_norm.b"))
             if self.ffn_one_launch:
                 u, h, x4, a, x = K.ffn_train(a3, PK("ff.f"), hid, P("ff_b1"), pd, seed, self._salt(li, 6), P("ff_b2"), x3, 0.5, pd,
-                                             self._salt(li, 7), ln1=ln("norm_final"), ln2=nxt)
+                                             self._salt(li, 7), ln1=ln("norm_final"), ln2=nxt, tape_derivative=self.ffn_bwd_one_launch)
             else:
                 u, h = K.dense_act_drop(a3, PK("ff_w1.k"), hid, P("ff_b1"), pd, seed, self._salt(li, 6))
                 x4, a, x = K.dense_join(h, PK("ff_w2.r"), hid, P("ff_b2"), x3, 0.5, pd, seed, self._salt(li, 7), ln1=ln("norm_final"),
@@ -1067,6 +1077,11 @@ class ConformerCTCTrainStep:
 
             def ffn_bwd(dy, F, key, ln, nxt):
                 self._dW(dy, F["h"], pre + key + "_w2", pre + key + "_b2")
+                if self.ffn_bwd_one_launch:  # dh -> du -> da -> the LayerNorm backward: one launch (F["u"] holds gk)
+                    du, dy_next = K.ffn_train_bwd(dy, PK(key + ".ft"), hid, F["u"], F["x_in"], P(ln + ".g"), g, self._ln_partials(ln),
+                                                  nxt=nxt)
+                    self._dW(du, F["a"], pre + key + "_w1", pre + key + "_b1")
+                    return dy_next
                 du = K.dense_act_drop_bwd(dy, PK(key + "_w2.tk"), hid, F["u"], pd, seed, self._salt(li, 0 if key == "ffm" else 6))
                 self._dW(du, F["a"], pre + key + "_w1", pre + key + "_b1")
                 if self.ln_bwd_fused:  # da = du . W_1 and the LayerNorm backward (+ the next branch's dropout backward): one launch

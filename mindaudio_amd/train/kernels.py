@@ -561,10 +561,10 @@ def dense_join(a, packed, k, bias, residual, alpha, p, seed, salt, row_scale=Non
 
 
 def ffn_train(a, packed, hidden, b1, p_hidden, seed, salt_hidden, b2, residual, alpha, p_join, salt_join, ln1=None, ln2=None,
-              ln_row_scale=None, eps=1e-5):
+              ln_row_scale=None, eps=1e-5, tape_derivative=False):
     """The whole feed-forward module in training mode, one launch (ma_ffn_train_bf16; `packed` = the feed-forward block format of
     W1 and W2): -> (u, h (M, hidden) bf16 [the tape], x_out (M, 256) float32, ln_out, ln_mid) - what dense_act_drop followed by
-    dense_join return."""
+    dense_join return.  tape_derivative: u is gk = swish'(pre-activation) * keep / (1 - p) instead (what ffn_train_bwd reads)."""
     import ctypes
 
     t = _t()
@@ -579,9 +579,44 @@ def ffn_train(a, packed, hidden, b1, p_hidden, seed, salt_hidden, b2, residual, 
     e = _train_epi(3, bias=b2, residual=residual, alpha=alpha, p=p_join, seed=seed, salt=salt_join, ln1=ln1, ln2=ln2,
                    ln_row_scale=ln_row_scale, ln_out=ln_out, ln_mid=ln_mid, eps=eps)
     _lib.check(_lib.load().ma_ffn_train_bf16(_p(a), a.stride(0), m, hidden, _p(packed), _p(b1), _p(uh[0]), _p(uh[1]), hidden,
-                                             float(p_hidden), int(seed), int(salt_hidden), _p(out), out.stride(0), ctypes.byref(e),
-                                             _s()), "ffn_train")
+                                             1 if tape_derivative else 0, float(p_hidden), int(seed), int(salt_hidden), _p(out),
+                                             out.stride(0), ctypes.byref(e), _s()), "ffn_train")
     return uh[0], uh[1], out, ln_out, ln_mid
+
+
+def ffn_train_parts(m):
+    """Workgroups (= partial (dgamma | dbeta) vectors) of ffn_train_bwd for m rows."""
+    return int(_lib.load().ma_ffn_train_parts(m))
+
+
+def ffn_train_bwd(dy, packed_t, hidden, gk, x, gamma, g, partials, nxt=None, eps=1e-5):
+    """The feed-forward module's backward in one launch (ma_ffn_train_bwd_bf16): du (M, hidden) bf16 = bf16(dy W2) * gk [returned: the
+    operand of w_1's weight gradient]; da = du W1 goes straight into the backward of the LayerNorm in front of the module (input x,
+    weight gamma): g (M, 256) float32 += dLN/dx(da) in place, per-workgroup (dgamma | dbeta) partials -> `partials`
+    (>= ffn_train_parts(M) * 512 floats), and with nxt = (alpha, p, seed, salt, row_scale_next or None) dy_next (M, 256) bf16 =
+    dropout(g * alpha * row_scale_next).  `packed_t` = the feed-forward block format of (W2^T, W1^T).  Returns (du, dy_next)."""
+    import ctypes
+
+    t = _t()
+    m = dy.shape[0]
+    assert g.dtype == t.float32 and x.dtype == t.float32 and partials.numel() >= ffn_train_parts(m) * 512
+    du = t.empty((m, hidden), dtype=t.bfloat16, device=dy.device)
+    e = _lib.TrainEpilogue()
+    e.mode = 5
+    e.residual, e.ldr = x.data_ptr(), x.stride(0)
+    e.ln_gamma1 = gamma.data_ptr()
+    e.ln_eps = float(eps)
+    e.ln_mid = partials.data_ptr()
+    dy_next = None
+    if nxt is not None:
+        alpha, p, seed, salt, rs_next = nxt
+        dy_next = t.empty((m, 256), dtype=t.bfloat16, device=dy.device)
+        e.ln_out, e.ld_ln, e.ln_out_bf16 = dy_next.data_ptr(), dy_next.stride(0), 1
+        e.alpha, e.p, e.seed, e.salt = float(alpha), float(p), int(seed), int(salt)
+        e.ln_row_scale = rs_next.data_ptr() if rs_next is not None else None
+    _lib.check(_lib.load().ma_ffn_train_bwd_bf16(_p(dy), dy.stride(0), m, hidden, _p(packed_t), _p(gk), _p(du), hidden, _p(g),
+                                                 g.stride(0), ctypes.byref(e), _s()), "ffn_train_bwd")
+    return du, dy_next
 
 
 def layernorm_bwd_next(x, gamma, dy, g, dgamma, dbeta, nxt, row_scale=None, accumulate=True, eps=1e-5, partials=None):

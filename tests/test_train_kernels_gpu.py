@@ -587,6 +587,87 @@ def test_feed_forward_module_in_one_launch(K, m, hid, chain):
         K.ffn_train(a, pk, hid + 64, b1, p, seed, 3, b2, x, 0.5, p, 4)
 
 
+@pytest.mark.parametrize("m,hid", [(1000, 2048), (10200, 2048), (49, 256), (1, 512)])
+def test_feed_forward_module_backward_in_one_launch(K, m, hid):
+    """ma_ffn_train_bwd_bf16 (dh -> du -> da -> LayerNorm backward, one launch, on the gk = swish' * keep / (1 - p) tape of the one-launch
+    forward) against float64 and against the two launches it replaces (ma_gemm_k256_train_bf16 mode 2 on the bf16 u of the two-launch
+    forward, ma_gemm_rows_train_bf16 mode 5): du within bf16 round-off of both (gk carries one more bf16 rounding, u's rounding is
+    gone), g / dgamma / dbeta / dy_next computed from THIS launch's du agree with the two-launch LayerNorm backward on the same du to
+    float32 round-off."""
+    from mindaudio_amd import _lib, ops
+
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(31 + m)
+    d, p, seed = 256, 0.1, 99
+    st = torch.cuda.current_stream().cuda_stream
+
+    def pack(w, kind, out=None):
+        n, k = w.shape
+        pieces = int(lib.ma_pack_item_pieces(kind, n, k))
+        assert pieces > 0
+        if out is None:
+            out = torch.empty(pieces * 16 * (2 if kind in (2, 3) else 1), dtype=torch.uint8, device="cuda")
+        items = (_lib.PackItem * 1)(_lib.PackItem(w.data_ptr(), out.data_ptr(), w.stride(0), n, k, kind, 0))
+        d_items = torch.from_numpy(np.frombuffer(bytes(items), dtype=np.uint8).copy()).cuda()
+        d_map = torch.zeros((pieces + 255) // 256, dtype=torch.int32, device="cuda")
+        _lib.check(lib.ma_pack_batch_bf16(d_items.data_ptr(), d_map.data_ptr(), d_map.numel(), st), "pack")
+        return out
+
+    a = bf(torch.randn(m, d, generator=gen)).cuda()
+    w1 = bf(torch.randn(hid, d, generator=gen) / 16).cuda()
+    w2 = bf(torch.randn(d, hid, generator=gen) / 45).cuda()
+    b1, b2 = torch.randn(hid, generator=gen).cuda(), torch.randn(d, generator=gen).cuda()
+    x = torch.randn(m, d, generator=gen).cuda() * 2 + 0.3       # the module's residual input = the LayerNorm's input
+    gamma = (1 + 0.1 * torch.randn(d, generator=gen)).cuda()
+    dy = bf(torch.randn(m, d, generator=gen)).cuda()
+    g0 = torch.randn(m, d, generator=gen).cuda()
+    w1t, w2t = w1.t().contiguous(), w2.t().contiguous()         # (256, hid), (hid, 256)
+    # forward tapes: gk from the one-launch forward, u from the two-launch forward
+    gk, h, _, _, _ = K.ffn_train(a, pack(w2, 3, pack(w1, 2)), hid, b1, p, seed, 3, b2, x, 0.5, p, 4, tape_derivative=True)
+    u_ref, h_ref = K.dense_act_drop(a, pack(w1, 0), hid, b1, p, seed, 3)
+    u64 = a.double() @ w1.double().t() + b1.double()
+    sg = torch.sigmoid(u64)
+    gk64 = sg * (1 + u64 * (1 - sg)) / (1 - p) * (h_ref != 0).double()
+    sel = u_ref.float().abs() > 1e-3
+    assert torch.equal((gk == 0) & sel, (h_ref == 0) & sel)
+    assert float(((gk.double() - gk64).abs() / gk64.abs().clamp_min(1e-2))[sel].max()) < 2.0 ** -7
+    pt = pack(w1t, 3, pack(w2t, 2))
+    assert torch.equal(pt, ops.ffn_pack_weights(w2t, w1t).view(torch.uint8).reshape(-1))
+    for nxt in ((0.5, p, seed, 9, None), None):
+        g_new = g0.clone()
+        parts = torch.full((K.ffn_train_parts(m) * 512,), float("nan"), device="cuda")
+        du, dn = K.ffn_train_bwd(dy, pt, hid, gk, x, gamma, g_new, parts, nxt=nxt)
+        torch.cuda.synchronize()
+        # du: float64 on the stored gk, and the two-launch du
+        dh = bf(dy.double() @ w2.double()).double()
+        du64 = dh * gk.double()
+        # (one bf16 ulp of dh - the kernel rounds its float32 sum, the reference the exact one - plus du's own rounding)
+        assert float(((du.double() - du64).abs() / du64.abs().clamp_min(1e-2)).max()) < 2.0 ** -6
+        du_ref = K.dense_act_drop_bwd(dy, pack(w2t, 0), hid, u_ref, p, seed, 3)
+        assert rel(du, du_ref.float().cpu()) < 6e-3
+        # the LayerNorm backward on THIS du: the two-launch form
+        g_ref, dg_ref, db_ref = g0.clone(), torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+        da = K.dense_plain(du, pack(w1t, 0 if hid == 256 else 1), d, hid)
+        if nxt is None:
+            K.layernorm_bwd(x, gamma, da, g_ref, dg_ref, db_ref)
+            assert dn is None
+        else:
+            _, dn_ref = K.layernorm_bwd_next(x, gamma, da, g_ref, dg_ref, db_ref, nxt)
+            a_, b_ = dn.float(), dn_ref.float()
+            assert torch.equal(a_ == 0, b_ == 0)
+            diff = (a_ - b_).abs()
+            # (da sums the hidden units in another order: where its bf16 rounding flips, dy_next moves by a few bf16 ulps)
+            assert float((diff / b_.abs().clamp(min=1e-2)).max()) <= 1.0 / 8
+            assert rel(a_, b_.cpu()) < 4e-3
+        # (da is not rounded to bf16 on its way into the LayerNorm backward here: bf16 round-off of da against the two launches)
+        scale = float(g_ref.abs().max())
+        assert float((g_new - g_ref).abs().max()) <= 2e-2 * scale
+        assert rel(g_new - g0, (g_ref - g0).cpu()) < 4e-3
+        pv = parts.view(-1, 512).double().sum(0)
+        assert bool(torch.isfinite(pv).all())
+        assert rel(pv[:256].float(), dg_ref.cpu()) < 4e-3 and rel(pv[256:].float(), db_ref.cpu()) < 4e-3
+
+
 @pytest.mark.parametrize("b,h,w,c", [(2, 21, 19, 128), (3, 24, 39, 256), (1, 3, 3, 128), (2, 8, 6, 128), (9, 187, 39, 256),
                                      (8, 206, 40, 256)])
 def test_conv2_input_gradient_as_one_implicit_gemm(K, b, h, w, c):

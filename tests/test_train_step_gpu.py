@@ -393,35 +393,37 @@ def test_fused_blocks_equal_the_one_launch_per_cell_path_with_dropout():
 
 
 def test_feed_forward_module_in_one_launch_changes_round_off_only():
-    """ffn_one_launch (ma_ffn_train_bf16: w_1 + Swish + dropout + w_2 + join in one launch, u and h stored for the backward pass from the
-    registers that feed the second product) against the two-launch form of the same fused engine, dropout ON: the same masks, the
-    same tape layout; u may differ by one bf16 ulp and h by the rounding of Swish's argument.  Loss and gradients agree to bf16
-    round-off, and the one-launch path is run-to-run bit-reproducible."""
+    """ffn_one_launch (ma_ffn_train_bf16: w_1 + Swish + dropout + w_2 + join in one launch, the tape stored from the registers that feed
+    the second product) and ffn_bwd_one_launch (ma_ffn_train_bwd_bf16: dh -> du -> da -> LayerNorm backward in one launch, on the
+    gk = swish' * keep / (1 - p) tape) against the two-launch forms of the same fused engine, dropout ON: the same masks; u may differ
+    by one bf16 ulp, h by the rounding of Swish's argument, du by gk's rounding.  Loss and gradients agree to bf16 round-off, and
+    the one-launch path is run-to-run bit-reproducible."""
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
     xs, ys, sub, ys_lens = batch()
     res = []
-    for one in (False, True, True):
+    for fwd_one, bwd_one in ((False, False), (True, False), (True, True), (True, True)):
         _, _, model = build(seed=6)
         eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, fused=True)
-        assert eng.ffn_one_launch
-        if not one:
-            eng.ffn_one_launch = False
+        assert eng.ffn_one_launch and eng.ffn_bwd_one_launch
+        if not (fwd_one and bwd_one):
+            eng.ffn_one_launch, eng.ffn_bwd_one_launch = fwd_one, bwd_one
             eng._pack_plan = None
             eng._pack_weights()
         loss = eng.forward_backward(xs.cuda(), ys.cuda(), sub.cuda(), ys_lens.cuda(), grad_scale=8.0)
         res.append((float(loss), eng.fp.grad.clone(), eng))
-    (l0, g0, e0), (l1, g1, _), (l2, g2, _) = res
-    assert abs(l0 - l1) <= 1e-3 * abs(l0), (l0, l1)
-    assert float((g1 - g0).norm() / g0.norm()) <= 1.5e-2
-    worst = {}
-    for name, (off, shape, n) in e0.fp.index.items():
-        a, b_ = g0[off:off + n], g1[off:off + n]
-        if float(a.norm()) > 1e-6 * float(g0.norm()):
-            worst[name] = float((a - b_).norm() / a.norm())
-    bad = {k: round(v, 4) for k, v in worst.items() if v > 5e-2 and not (k.endswith("dw_b") or k.endswith("qkv_b"))}
-    assert not bad, bad
-    assert l2 == l1 and torch.equal(g2, g1)
+    (l0, g0, e0) = res[0]
+    for l1, g1, _ in res[1:3]:
+        assert abs(l0 - l1) <= 1e-3 * abs(l0), (l0, l1)
+        assert float((g1 - g0).norm() / g0.norm()) <= 1.5e-2
+        worst = {}
+        for name, (off, shape, n) in e0.fp.index.items():
+            a, b_ = g0[off:off + n], g1[off:off + n]
+            if float(a.norm()) > 1e-6 * float(g0.norm()):
+                worst[name] = float((a - b_).norm() / a.norm())
+        bad = {k: round(v, 4) for k, v in worst.items() if v > 5e-2 and not (k.endswith("dw_b") or k.endswith("qkv_b"))}
+        assert not bad, bad
+    assert res[3][0] == res[2][0] and torch.equal(res[3][1], res[2][1])
 
 
 def test_weight_gradient_stream_changes_no_bit():

@@ -163,8 +163,23 @@ constexpr int kTs = 64 + 4;   // transposed tiles: 64 streamed items per row (13
 // the only scratch user of the training step; with the weight-gradient products on a second hardware queue, fresh processes then showed
 // a ~1 % rate of corrupted backward passes in the first two-stream steps - tools/flaky_loop.sh: 2 of 250 with the spills, 0 of 250
 // without, other things equal.  Root cause not established; no kernel of the step uses scratch now.)
-template <bool KEYS_FIXED>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+// NF (round 4) = 16-item tiles of the fixed side per wave: a workgroup owns 64 NF fixed items, a fragment of the streamed tiles read
+// from LDS feeds NF MFMAs, and a (b, h) stages its streamed tiles Tp / (64 NF) times.  Measured on the training step's shape
+// (40 x 4 heads x 255 frames; tools/attn_bwd_bench.py: the whole backward - prep + both kernels + two small reductions):
+//     queries fixed (dQ'):    NF = 1: 95.4 us   NF = 2 (two workgroups per CU still): 93.2 us <- launched   NF = 4 (one per CU): 95.6 us
+//     keys fixed (dK', dV):   NF = 2 (one workgroup per CU): + 5 us in the step's census; at two per CU, and NF = 4 at all, the kernel
+//                             does not fit its registers (20 - 268 B of scratch per lane): NF = 1 stays
+// i.e. the launches are NOT bound by their LDS reads (they run at a tenth of the MFMA rate either way): what remains per 64-row tile
+// is the register-staged global -> LDS copy behind two barriers and ~200 VALU operations per lane and slab (exp, dS, packing) that
+// nothing overlaps.  The (B, T, T) chunk mask runs NF = 1 (QMASK: its index arithmetic costs registers the wider forms lack).
+#ifndef MA_AB_NFQ
+#define MA_AB_NFQ 2
+#endif
+constexpr int kAbNF = MA_AB_NFQ, kAbNFK = 1;  // queries fixed / keys fixed
+// QMASK: the (B, T, T) chunk mask of the streaming configuration is a variant of its own (one slab per wave, two workgroups per CU, as
+// until round 4): its per-element index arithmetic costs the four-slab form the registers it does not have.
+template <bool KEYS_FIXED, int NF, bool QMASK>
+__global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                        const uint16_t* __restrict__ dctx, int64_t ld_dctx,
                                                        const float* __restrict__ mask, const float* __restrict__ mask3,
                                                        const float* __restrict__ lse, AttnWs ws, int T, int H, float scale,
@@ -182,33 +197,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   const int fb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * H + h, row0 = (int64_t)b * T;
   const int Tp = ws.Tp;
-  const int fidx = fb * 64 + wave * 16 + lq;  // this lane's fixed item (key or query)
-  const int fcl = fidx < T ? fidx : T - 1;
-
+  int fidx[NF];  // this lane's fixed items (keys or queries): one per 64-item slab of the workgroup's 64 NF
   // ---- fixed-side B fragments: X'[fidx] (4 k-steps over 128) and Y[fidx] (2 k-steps over 64) -------------------
-  bf16x8 xf[4], yf[2];
-  {
+  bf16x8 xf[NF][4], yf[NF][2];
+  float f_mask[NF], f_lse[NF], f_D[NF];
+  f32x4 acc_x[NF][8];  // (dK' or dQ')^T: rows c = ct*16 + lg*4 + r, column = fixed item lq
+  f32x4 acc_y[NF][4];  // dV^T (KEYS_FIXED)
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    fidx[nf] = (fb * NF + nf) * 64 + wave * 16 + lq;
+    const int fcl = fidx[nf] < T ? fidx[nf] : T - 1;
     const uint16_t* xr = (KEYS_FIXED ? ws.k(bh) : ws.q(bh)) + (int64_t)fcl * 128;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 32 + lg * 8);
+    for (int ks = 0; ks < 4; ++ks) xf[nf][ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 32 + lg * 8);
     const uint16_t* yr = KEYS_FIXED ? qkv + (row0 + fcl) * ld_qkv + 512 + h * 64 : dctx + (row0 + fcl) * ld_dctx + h * 64;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) yf[ks] = *reinterpret_cast<const bf16x8*>(yr + ks * 32 + lg * 8);
-  }
-  float f_mask = 0.0f, f_lse = 0.0f, f_D = 0.0f;
-  if (KEYS_FIXED) {
-    f_mask = fidx >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + fidx] == 0.0f) ? -10000.0f : 0.0f);
-  } else {
-    f_lse = fidx < T ? lse[bh * T + fidx] : INFINITY;
-    f_D = fidx < T ? ws.D[bh * Tp + fidx] : 0.0f;
-  }
-
-  f32x4 acc_x[8];  // (dK' or dQ')^T: rows c = ct*16 + lg*4 + r, column = fixed item lq
-  f32x4 acc_y[4];  // dV^T (KEYS_FIXED)
+    for (int ks = 0; ks < 2; ++ks) yf[nf][ks] = *reinterpret_cast<const bf16x8*>(yr + ks * 32 + lg * 8);
+    f_mask[nf] = f_lse[nf] = f_D[nf] = 0.0f;
+    if (KEYS_FIXED) {
+      f_mask[nf] = fidx[nf] >= T ? -INFINITY : ((mask && mask[(int64_t)b * T + fidx[nf]] == 0.0f) ? -10000.0f : 0.0f);
+    } else {
+      f_lse[nf] = fidx[nf] < T ? lse[bh * T + fidx[nf]] : INFINITY;
+      f_D[nf] = fidx[nf] < T ? ws.D[bh * Tp + fidx[nf]] : 0.0f;
+    }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc_x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 8; ++i) acc_x[nf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc_y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc_y[nf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const uint16_t* sx = KEYS_FIXED ? ws.q(bh) : ws.k(bh);
   const uint16_t* sxt = KEYS_FIXED ? ws.qt(bh) : ws.kt(bh);
@@ -222,7 +238,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   //   dO^T    : 64 x 8 chunks  -> as Y rows (KEYS_FIXED only)
   uint4 rx0, rx1, rx2, rx3, ry0, ry1, rt0, rt1, rt2, rt3, rd0 = make_uint4(0, 0, 0, 0), rd1 = make_uint4(0, 0, 0, 0);
   float rs0 = 0.0f, rs1 = 0.0f;
-  const int xr_ = tid >> 4, xc_ = tid & 15, yr_ = tid >> 3, yc_ = tid & 7;
+  // (the staging addresses are loop-invariant, and hipcc would hoist all of them - a dozen 64-bit pointers - out of the loop and, with
+  // four slabs of accumulators, SPILL them; they are cheap to recompute: every fetch derives them from an opaque copy of the thread index)
+  int tidv = tid;
+#define MA_AB_IDX                          \
+  asm volatile("" : "+v"(tidv));           \
+  const int xr_ = tidv >> 4, xc_ = tidv & 15, yr_ = tidv >> 3, yc_ = tidv & 7;
 #define MA_AB_YLOAD(dst, i, s0_)                                                                                       \
   {                                                                                                                    \
     const int r_ = yr_ + 32 * (i);                                                                                     \
@@ -233,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   }
 #define MA_AB_FETCH(st_)                                                                                               \
   {                                                                                                                    \
+    MA_AB_IDX                                                                                                          \
     const int s0f_ = (st_)*64;                                                                                         \
     rx0 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_) * 128 + xc_ * 8);                                 \
     rx1 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 16) * 128 + xc_ * 8);                            \
@@ -247,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       rd0 = *reinterpret_cast<const uint4*>(syt + (int64_t)(yr_)*Tp + s0f_ + yc_ * 8);                                 \
       rd1 = *reinterpret_cast<const uint4*>(syt + (int64_t)(yr_ + 32) * Tp + s0f_ + yc_ * 8);                          \
     }                                                                                                                  \
-    if (tid < 64) {                                                                                                    \
-      const int si_ = s0f_ + tid;                                                                                      \
+    if (tidv < 64) {                                                                                                   \
+      const int si_ = s0f_ + tidv;                                                                                     \
       if (KEYS_FIXED) {                                                                                                \
         rs0 = si_ < T ? lse[bh * T + si_] : INFINITY; /* exp(. - inf) = 0: streamed queries past T vanish */           \
         rs1 = si_ < T ? ws.D[bh * Tp + si_] : 0.0f;                                                                    \
@@ -266,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
   MA_AB_FETCH(0)
   for (int st = 0; st < n_st; ++st) {
     __syncthreads();  // previous tile fully consumed
+    MA_AB_IDX
     *reinterpret_cast<uint4*>(&Xs[(xr_)*kXs + xc_ * 8]) = rx0;
     *reinterpret_cast<uint4*>(&Xs[(xr_ + 16) * kXs + xc_ * 8]) = rx1;
     *reinterpret_cast<uint4*>(&Xs[(xr_ + 32) * kXs + xc_ * 8]) = rx2;
@@ -285,24 +308,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
       if (KEYS_FIXED) srow[1][tid] = rs1;
     }
     __syncthreads();
-    if (st + 1 < n_st) MA_AB_FETCH(st + 1)
+    // (keys fixed with four slabs: the next tile's loads go out after the first half's score tiles instead - their 50 staging
+    // registers would otherwise be live through them on top of 192 accumulators: scratch)
+    constexpr bool kLateFetch = KEYS_FIXED && NF >= 4;
+    if (!kLateFetch && st + 1 < n_st) MA_AB_FETCH(st + 1)
 
     // ---- score tile and dP tile: rows = streamed (4 tiles of 16), column = fixed item lq --------------------------
-    uint32_t pb[4][2], db[4][2];  // bf16 pairs of P and scale * dS for rows lg*4 + {0,1}, {2,3} of tile mt
+    // Two halves of 32 streamed rows: the scores of a half, then its contraction - P and dS live for one half only (NF x 16 registers)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < 2; ++ks) {
+    uint32_t pb[NF][2][2], db[NF][2][2];  // bf16 pairs of P and scale * dS for rows lg*4 + {0,1}, {2,3} of tile mt = 2 ks + mh
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Xs[(mt * 16 + lq) * kXs + ks * 32 + lg * 8]);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[ks], s, 0, 0, 0);
-      }
+    for (int mh = 0; mh < 2; ++mh) {
+      const int mt = 2 * ks + mh;
+      bf16x8 ax[4], ay[2];  // the streamed tile's fragments: read once, used by every fixed slab
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ys[(mt * 16 + lq) * kYs + ks * 32 + lg * 8]);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, yf[ks], dp, 0, 0, 0);
-      }
-      float p[4], g[4];
+      for (int ks = 0; ks < 4; ++ks) ax[ks] = *reinterpret_cast<const bf16x8*>(&Xs[(mt * 16 + lq) * kXs + ks * 32 + lg * 8]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) ay[ks] = *reinterpret_cast<const bf16x8*>(&Ys[(mt * 16 + lq) * kYs + ks * 32 + lg * 8]);
       const float4 r0 = *reinterpret_cast<const float4*>(&srow[0][mt * 16 + lg * 4]);
       const float r0v[4] = {r0.x, r0.y, r0.z, r0.w};
       float r1v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -311,88 +334,118 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
         r1v[0] = r1.x; r1v[1] = r1.y; r1v[2] = r1.z; r1v[3] = r1.w;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // KEYS_FIXED: row = query (lse, D from srow), column = key (mask per lane); else row = key (mask from srow)
-        float e = KEYS_FIXED ? s[r] * scale + f_mask - r0v[r] : s[r] * scale + r0v[r] - f_lse;
-        if (mask3) {  // per-(query, key) chunk mask (B, T, T) of the streaming configuration, as in the forward
-          const int srow_i = st * 64 + mt * 16 + lg * 4 + r;  // streamed item of this element
-          const int qi = KEYS_FIXED ? srow_i : fidx, ki = KEYS_FIXED ? fidx : srow_i;
-          if (qi < T && ki < T && mask3[((int64_t)b * T + qi) * T + ki] == 0.0f) e += -10000.0f;
-        }
-        p[r] = __expf(e);
-        g[r] = p[r] * (dp[r] - (KEYS_FIXED ? r1v[r] : f_D)) * scale;
-      }
-      pb[mt][0] = ab_pack(p[0], p[1]);
-      pb[mt][1] = ab_pack(p[2], p[3]);
-      db[mt][0] = ab_pack(g[0], g[1]);
-      db[mt][1] = ab_pack(g[2], g[3]);
-    }
-    // ---- contractions over the streamed side ----------------------------------------------------------------------
+      for (int nf = 0; nf < NF; ++nf) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint4 gpk = make_uint4(db[2 * ks][0], db[2 * ks][1], db[2 * ks + 1][0], db[2 * ks + 1][1]);
-      const bf16x8 gf = __builtin_bit_cast(bf16x8, gpk);
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[ks], xf[nf][ks], s, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ay[ks], yf[nf][ks], dp, 0, 0, 0);
+        float p[4], g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // KEYS_FIXED: row = query (lse, D from srow), column = key (mask per lane); else row = key (mask from srow)
+          float e = KEYS_FIXED ? s[r] * scale + f_mask[nf] - r0v[r] : s[r] * scale + r0v[r] - f_lse[nf];
+          if (QMASK) {  // per-(query, key) chunk mask (B, T, T) of the streaming configuration, as in the forward
+            const int srow_i = st * 64 + mt * 16 + lg * 4 + r;  // streamed item of this element
+            const int qi = KEYS_FIXED ? srow_i : fidx[nf], ki = KEYS_FIXED ? fidx[nf] : srow_i;
+            if (qi < T && ki < T && mask3[((int64_t)b * T + qi) * T + ki] == 0.0f) e += -10000.0f;
+          }
+          p[r] = __expf(e);
+          g[r] = p[r] * (dp[r] - (KEYS_FIXED ? r1v[r] : f_D[nf])) * scale;
+        }
+        pb[nf][mh][0] = ab_pack(p[0], p[1]);
+        pb[nf][mh][1] = ab_pack(p[2], p[3]);
+        db[nf][mh][0] = ab_pack(g[0], g[1]);
+        db[nf][mh][1] = ab_pack(g[2], g[3]);
+        if (NF >= 4) __builtin_amdgcn_sched_barrier(0);  // (keeps the slabs' live ranges apart: the scheduler otherwise interleaves them)
+      }
+    }
+    if (NF >= 4) __builtin_amdgcn_sched_barrier(0);
+    if (kLateFetch && ks == 1 && st + 1 < n_st) MA_AB_FETCH(st + 1)
+    // ---- contractions over the streamed side (this half's 32 rows) ---------------------------------------------------
+    {
+      bf16x8 gf[NF], pf[NF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const uint4 gpk = make_uint4(db[nf][0][0], db[nf][0][1], db[nf][1][0], db[nf][1][1]);
+        gf[nf] = __builtin_bit_cast(bf16x8, gpk);
+        const uint4 ppk = make_uint4(pb[nf][0][0], pb[nf][0][1], pb[nf][1][0], pb[nf][1][1]);
+        pf[nf] = __builtin_bit_cast(bf16x8, ppk);
+      }
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct) {
         const uint16_t* xr = &Xt[(ct * 16 + lq) * kTs + ks * 32 + lg * 4];
         const uint2 v0 = *reinterpret_cast<const uint2*>(xr);
         const uint2 v1 = *reinterpret_cast<const uint2*>(xr + 16);
-        const uint4 apk = make_uint4(v0.x, v0.y, v1.x, v1.y);
-        acc_x[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, apk), gf, acc_x[ct], 0, 0, 0);
+        const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc_x[nf][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, gf[nf], acc_x[nf][ct], 0, 0, 0);
       }
       if (KEYS_FIXED) {
-        const uint4 ppk = make_uint4(pb[2 * ks][0], pb[2 * ks][1], pb[2 * ks + 1][0], pb[2 * ks + 1][1]);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, ppk);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const uint16_t* yr = &Yt[(dt * 16 + lq) * kTs + ks * 32 + lg * 4];
           const uint2 v0 = *reinterpret_cast<const uint2*>(yr);
           const uint2 v1 = *reinterpret_cast<const uint2*>(yr + 16);
-          const uint4 apk = make_uint4(v0.x, v0.y, v1.x, v1.y);
-          acc_y[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, apk), pf, acc_y[dt], 0, 0, 0);
+          const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) acc_y[nf][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[nf], acc_y[nf][dt], 0, 0, 0);
         }
       }
     }
+    if (NF >= 4) __builtin_amdgcn_sched_barrier(0);
+    }  // halves
   }
 
 #undef MA_AB_FETCH
+#undef MA_AB_IDX
 #undef MA_AB_YLOAD
 #undef MA_AB_ST8
   // ---- outputs: lane holds rows c = ct*16 + lg*4 + r of the transposed result for its fixed item -----------------
+  // (output addresses from opaque copies of the block indices: computed here, not hoisted above the loop and spilled across it)
+  int hv = h, bv = b;
+  asm volatile("" : "+s"(hv), "+s"(bv));
+  const int64_t orow0 = (int64_t)bv * T;
   if (KEYS_FIXED) {
-    if (fidx < T) {
-      uint16_t* orow = dqkv + (row0 + fidx) * ld_dqkv + h * 64 + lg * 4;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      if (fidx[nf] >= T) continue;
+      uint16_t* orow = dqkv + (orow0 + fidx[nf]) * ld_dqkv + hv * 64 + lg * 4;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)  // dk
         *reinterpret_cast<uint2*>(orow + 256 + ct * 16) =
-            make_uint2(ab_pack(acc_x[ct][0], acc_x[ct][1]), ab_pack(acc_x[ct][2], acc_x[ct][3]));
+            make_uint2(ab_pack(acc_x[nf][ct][0], acc_x[nf][ct][1]), ab_pack(acc_x[nf][ct][2], acc_x[nf][ct][3]));
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)  // dv
         *reinterpret_cast<uint2*>(orow + 512 + dt * 16) =
-            make_uint2(ab_pack(acc_y[dt][0], acc_y[dt][1]), ab_pack(acc_y[dt][2], acc_y[dt][3]));
+            make_uint2(ab_pack(acc_y[nf][dt][0], acc_y[nf][dt][1]), ab_pack(acc_y[nf][dt][2], acc_y[nf][dt][3]));
       // dp: per-batch partial (B, Tp, 256) float32; attn_dpos_reduce_kernel sums over the batch (2.6 M contended atomics
       // on (T, 256) cost more than the kernel's MFMAs)
-      float* prow = ws.dp_part + ((int64_t)b * Tp + fidx) * 256 + h * 64 + lg * 4;
+      float* prow = ws.dp_part + ((int64_t)bv * Tp + fidx[nf]) * 256 + hv * 64 + lg * 4;
 #pragma unroll
       for (int ct = 4; ct < 8; ++ct)
-        *reinterpret_cast<float4*>(prow + (ct - 4) * 16) = make_float4(acc_x[ct][0], acc_x[ct][1], acc_x[ct][2], acc_x[ct][3]);
+        *reinterpret_cast<float4*>(prow + (ct - 4) * 16) =
+            make_float4(acc_x[nf][ct][0], acc_x[nf][ct][1], acc_x[nf][ct][2], acc_x[nf][ct][3]);
     }
   } else {
-    const bool live = fidx < T;
-    if (live) {
-      uint16_t* orow = dqkv + (row0 + fidx) * ld_dqkv + h * 64 + lg * 4;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      if (fidx[nf] >= T) continue;
+      uint16_t* orow = dqkv + (orow0 + fidx[nf]) * ld_dqkv + hv * 64 + lg * 4;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)  // dq = dQ'[:, c] + dQ'[:, 64 + c]
         *reinterpret_cast<uint2*>(orow + ct * 16) =
-            make_uint2(ab_pack(acc_x[ct][0] + acc_x[ct + 4][0], acc_x[ct][1] + acc_x[ct + 4][1]),
-                       ab_pack(acc_x[ct][2] + acc_x[ct + 4][2], acc_x[ct][3] + acc_x[ct + 4][3]));
+            make_uint2(ab_pack(acc_x[nf][ct][0] + acc_x[nf][ct + 4][0], acc_x[nf][ct][1] + acc_x[nf][ct + 4][1]),
+                       ab_pack(acc_x[nf][ct][2] + acc_x[nf][ct + 4][2], acc_x[nf][ct][3] + acc_x[nf][ct + 4][3]));
     }
-    // du / dv: sum over the queries of this wave (16 lanes lq), then one atomic per (c) from lane lq == 0
+    // du / dv: sum over the queries of this wave (its NF slabs in the lane, then the 16 lanes lq)
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = live ? acc_x[ct][r] : 0.0f;
+        float v = 0.0f;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) v += fidx[nf] < T ? acc_x[nf][ct][r] : 0.0f;
         v += __shfl_xor(v, 1, 64);
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 4, 64);
@@ -404,7 +457,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const uint16_t* __rest
     if (tid < 128) {
       // per-workgroup partial of (du | dv) for head h; attn_bias_reduce_kernel sums them (no contended atomics)
       const float t4 = (wg_part[0][tid] + wg_part[1][tid]) + (wg_part[2][tid] + wg_part[3][tid]);
-      ws.bias_part[(((int64_t)h * gridDim.z + b) * gridDim.x + fb) * 128 + tid] = t4;
+      // (one slot per 64 queries, whatever NF is: this workgroup's sum goes to its first slot, zeros to its others)
+      const int nslots = Tp / 64;
+#pragma unroll
+      for (int k = 0; k < NF; ++k)
+        if (fb * NF + k < nslots)
+          ws.bias_part[(((int64_t)hv * gridDim.z + bv) * nslots + fb * NF + k) * 128 + tid] = k == 0 ? t4 : 0.0f;
     }
   }
 }
@@ -491,15 +549,25 @@ static int relpos_attention_bwd(const void* qkv, int64_t ld_qkv, const void* pos
   const float scale = 1.0f / sqrtf((float)d_k);
   MA_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
             bias_u, bias_v, (const uint16_t*)ctx, ld_ctx, (const uint16_t*)dctx, ld_dctx, (int)T, (int)heads, ws);
-  MA_LAUNCH(attn_bwd_kernel<true>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
-            mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
-  MA_LAUNCH(attn_bwd_kernel<false>, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
-            mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+  const int nfq = mask3 ? 1 : kAbNF, nfk = mask3 ? 1 : kAbNFK;
+  const dim3 grid_f((unsigned)((ws.Tp + 64 * nfq - 1) / (64 * nfq)), (unsigned)heads, (unsigned)batch);
+  const dim3 grid_k((unsigned)((ws.Tp + 64 * nfk - 1) / (64 * nfk)), (unsigned)heads, (unsigned)batch);
+  if (mask3) {
+    MA_LAUNCH((attn_bwd_kernel<true, 1, true>), grid_k, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
+              mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+    MA_LAUNCH((attn_bwd_kernel<false, 1, true>), grid_f, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
+              mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+  } else {
+    MA_LAUNCH((attn_bwd_kernel<true, kAbNFK, false>), grid_k, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx,
+              ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+    MA_LAUNCH((attn_bwd_kernel<false, kAbNF, false>), grid_f, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx,
+              ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+  }
   if (!dpos) return MA_OK;  // the per-batch / per-workgroup partials stay in the workspace for the caller's batched reduction
   MA_LAUNCH(attn_dpos_reduce_kernel, dim3((unsigned)T), dim3(256), 0, s, ws.dp_part, (int)batch, (int)T, ws.Tp, dpos,
             ld_dpos);
-  MA_LAUNCH(attn_bias_reduce_kernel, dim3((unsigned)heads), dim3(1024), 0, s, ws.bias_part, (int)batch, (int)heads,
-            ws.Tp / 64, dbias_u, dbias_v);
+  MA_LAUNCH(attn_bias_reduce_kernel, dim3((unsigned)heads), dim3(1024), 0, s, ws.bias_part, (int)batch, (int)heads, ws.Tp / 64,
+            dbias_u, dbias_v);
   return MA_OK;
 }
 

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kFtThreads, 1) void ffn_train_kernel(const FfnTrain
   uint32_t st_off[MT];
 #define FT_LOAD_GK(blk)                                                                                                \
   do {                                                                                                                 \
-    const char* gsrc = uniform(reinterpret_cast<const char*>(p.u) + (blk) * (kFtBlock * 2));                           \
+    const char* gsrc = uniform(reinterpret_cast<const char*>(p.u) + ((FT_X & 4) ? 0 : (blk)) * (kFtBlock * 2));        \
     _Pragma("unroll") for (int s_ = 0; s_ < MT; ++s_)                                                                  \
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gkr[s_]) : "v"(st_off[s_]), "s"(gsrc) : "memory");        \
   } while (0)
@@ -484,15 +484,26 @@ __global__ __launch_bounds__(kFtThreads, 1) void ffn_train_kernel(const FfnTrain
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2])::"memory");
 
   FT_STAMP(4);
-  // backward: everything of the LayerNorm backward that depends on its input x alone (loads, mean / variance exchanges) - its HBM
-  // latency overlaps the reduction's first round
+  // The epilogue's loads (forward: bias, residual rows; backward: the LayerNorm's input rows, the gradient rows it updates, gamma) go
+  // out NOW, into the registers the main loop has just freed: their HBM latency passes under the cross-wave reduction below (as one
+  // piece behind it, the epilogue was 7.3 us of a 46 us launch on the timeline, the backward's statistics another 2.7).
   float4 xh5[BWD ? MT : 1][4];
   float rstd5[BWD ? MT : 1];
-  if constexpr (BWD) lnbwd_stats<MT>(p.e, m0, p.M, wave, c, g, reinterpret_cast<float*>(smem + kFtOffRed), xh5, rstd5);
+  JoinLoads<MT> jin;
+  LnTailLoads<MT> tin;
+  if constexpr (BWD) {
+    lnbwd_stats_load<MT>(p.e, m0, p.M, wave, c, g, xh5);
+    lnbwd_tail_load<MT>(p.e, m0, p.M, wave, c, g, p.out, p.ldo, tin);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    train_epi_rows256_load<MT>(p.e, m0, p.M, wave, c, g, jin);
+  }
 
   // ---- cross-wave reduction: wave w ends up with output tiles 4 w .. 4 w + 3 (its slots 0..3) of all MT row tiles ------------------
   // Exchange slot (owner, k): [4 jt][MT s][64 lanes] x float4, written and read with the same lane -> conflict-free.
-  __syncthreads();  // every wave is done reading the activation tile
+  // (LDS-only barriers: __syncthreads() would also wait for the epilogue's loads that have just been issued)
+  auto ft_lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  ft_lds_barrier();  // every wave is done reading the activation tile
   FT_STAMP(5);
   auto xslot = [&](int owner, int k) { return reinterpret_cast<ft_f32x4*>(smem + (owner * 2 + k) * kFtSlot) + lane; };
   tc_f32x4 acc[4][MT];
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(kFtThreads, 1) void ffn_train_kernel(const FfnTrain
         d2[(jt * MT + s) * 64] = O[8 + jt][s];
       }
   }
-  __syncthreads();
+  ft_lds_barrier();
   {
     const ft_f32x4* s1 = xslot(wave, 0);
     const ft_f32x4* s2 = xslot(wave, 1);
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(kFtThreads, 1) void ffn_train_kernel(const FfnTrain
 #pragma unroll
       for (int s = 0; s < MT; ++s) acc[jt][s] = (O[jt][s] + s1[(jt * MT + s) * 64]) + s2[(jt * MT + s) * 64];
   }
-  __syncthreads();
+  ft_lds_barrier();
   {
     ft_f32x4* d3 = xslot((wave + 3) & 3, 0);
 #pragma unroll
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(kFtThreads, 1) void ffn_train_kernel(const FfnTrain
 #pragma unroll
       for (int s = 0; s < MT; ++s) d3[(jt * MT + s) * 64] = O[12 + jt][s];
   }
-  __syncthreads();
+  ft_lds_barrier();
   {
     const ft_f32x4* s3 = xslot(wave, 0);
 #pragma unroll
@@ -533,10 +544,13 @@ __global__ __launch_bounds__(kFtThreads, 1) void ffn_train_kernel(const FfnTrain
       for (int s = 0; s < MT; ++s) acc[jt][s] += s3[(jt * MT + s) * 64];
   }
   FT_STAMP(6);
-  if constexpr (BWD)
-    lnbwd_tail<MT>(p.e, acc, xh5, rstd5, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem + kFtOffRed2), (int)blockIdx.x);
-  else
-    train_epi_rows256<MT>(p.e, acc, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem + kFtOffRed));
+  if constexpr (BWD) {
+    lnbwd_stats_compute<MT>(p.e, wave, c, g, reinterpret_cast<float*>(smem + kFtOffRed), xh5, rstd5);
+    lnbwd_tail_compute<MT>(p.e, acc, xh5, rstd5, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem + kFtOffRed2),
+                           (int)blockIdx.x, tin);
+  } else {
+    train_epi_rows256_compute<MT>(p.e, acc, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem + kFtOffRed), jin);
+  }
 #ifdef FT_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   FT_STAMP(7);

@@ -370,7 +370,14 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_train_kernel(const ui
     const uint4 v = *reinterpret_cast<const uint4*>(a + (int64_t)m * lda + ch * 8);
     *reinterpret_cast<uint4*>(smem + row * kG2Pitch + ch * 16) = v;
   }
-  __syncthreads();
+  // MODE 3: the join's own loads (bias, residual rows, row scales) go out now, behind the tile's: their HBM latency passes under the
+  // tile's landing and the 32 MFMAs instead of starting after them (the launch is 14 us, half of it this epilogue's round trips).
+  // The barriers below are LDS-only for that reason: __syncthreads() would also wait for these loads.
+  // (32-row tiles only: with 64 rows the 68 registers of the loads do not fit beside 128 of weights and 64 of accumulators)
+  constexpr bool kEarly = MODE == 3 && ROWS == 32;
+  JoinLoads<kEarly ? MT : 1> jin;
+  if constexpr (kEarly) train_epi_rows256_load<MT>(e, m0, M, wave, c, g, jin);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   const char* abase = smem + c * kG2Pitch + g * 16;
   f32x4 acc[4][MT];
 #pragma unroll
@@ -388,8 +395,11 @@ __global__ __launch_bounds__(kG2Threads, 2) void gemm_k256_train_kernel(const ui
       for (int s = 0; s < MT; ++s) acc[jt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], af[s], acc[jt][s], 0, 0, 0);
   }
   if constexpr (MODE == 3) {
-    __syncthreads();  // the activation tile is dead: its LDS is the LayerNorm exchange scratch
-    train_epi_rows256<MT>(e, acc, m0, M, wave, c, g, reinterpret_cast<float*>(out), ldo, reinterpret_cast<float*>(smem));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the activation tile is dead: its LDS is the LayerNorm exchange scratch
+    if constexpr (kEarly)
+      train_epi_rows256_compute<MT>(e, acc, m0, M, wave, c, g, reinterpret_cast<float*>(out), ldo, reinterpret_cast<float*>(smem), jin);
+    else
+      train_epi_rows256<MT>(e, acc, m0, M, wave, c, g, reinterpret_cast<float*>(out), ldo, reinterpret_cast<float*>(smem));
     return;
   } else {
     char* stage = smem + ROWS * kG2Pitch + wave * (ROWS * kG2StagePitch);

@@ -184,29 +184,50 @@ typedef __attribute__((ext_vector_type(4))) float tc_f32x4;
 //     ln_out = LayerNorm(out; g1, b1) * ln_row_scale             two-pass statistics, like layernorm_kernel
 //     or, with g2: ln_mid = LayerNorm(out; g1, b1) float32, ln_out = LayerNorm(ln_mid; g2, b2)   (norm_final + the next LayerNorm)
 // `red`: LDS scratch of 4 * 16 * MT floats, not in use by anything else; every wave of the workgroup must call this.
+// (the loads of the epilogue are a function of their own, so that a kernel whose registers are free by then can issue them ahead of
+// the work that separates its main loop from the epilogue - ffn_train.hip's cross-wave reduction - and hide their HBM latency there)
 template <int MT>
-__device__ __forceinline__ void train_epi_rows256(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], int m0, int M, int wave, int c, int g,
-                                                  float* out, int64_t ldo, float* red) {
-  constexpr int ROWS = 16 * MT;
+struct JoinLoads {
   float4 bv[4];
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-    bv[jt] = e.bias ? *reinterpret_cast<const float4*>(e.bias + 64 * wave + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-  // every residual load is issued before the first use (as the compiler scheduled the fused loop, each of the 16 loads of a lane was
-  // followed by its wait: sixteen dependent round trips, ~20 us of a 45 us launch)
   float4 rv[MT][4];
   float rsv[MT];
+};
+template <int MT>
+__device__ __forceinline__ void train_epi_rows256_load(const TrainEpi& e, int m0, int M, int wave, int c, int g, JoinLoads<MT>& in) {
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+    in.bv[jt] = e.bias ? *reinterpret_cast<const float4*>(e.bias + 64 * wave + 16 * jt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // every residual load is issued before the first use (as the compiler scheduled the fused loop, each of the 16 loads of a lane was
+  // followed by its wait: sixteen dependent round trips, ~20 us of a 45 us launch)
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
     const int m = m0 + 16 * s + c;
     const int mc = m < M ? m : M - 1;
-    rsv[s] = e.row_scale ? e.row_scale[mc] : 1.0f;
+    in.rsv[s] = e.row_scale ? e.row_scale[mc] : 1.0f;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
-      rv[s][jt] = e.residual ? *reinterpret_cast<const float4*>(e.residual + (int64_t)mc * e.ldr + 64 * wave + 16 * jt + 4 * g)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      in.rv[s][jt] = e.residual ? *reinterpret_cast<const float4*>(e.residual + (int64_t)mc * e.ldr + 64 * wave + 16 * jt + 4 * g)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __builtin_amdgcn_sched_barrier(0);
+}
+template <int MT>
+__device__ __forceinline__ void train_epi_rows256_compute(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], int m0, int M, int wave, int c, int g,
+                                                          float* out, int64_t ldo, float* red, const JoinLoads<MT>& in);
+template <int MT>
+__device__ __forceinline__ void train_epi_rows256(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], int m0, int M, int wave, int c, int g,
+                                                  float* out, int64_t ldo, float* red) {
+  JoinLoads<MT> in;
+  train_epi_rows256_load<MT>(e, m0, M, wave, c, g, in);
+  train_epi_rows256_compute<MT>(e, acc, m0, M, wave, c, g, out, ldo, red, in);
+}
+template <int MT>
+__device__ __forceinline__ void train_epi_rows256_compute(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], int m0, int M, int wave, int c, int g,
+                                                          float* out, int64_t ldo, float* red, const JoinLoads<MT>& in) {
+  constexpr int ROWS = 16 * MT;
+  const float4 (&bv)[4] = in.bv;
+  const float4 (&rv)[MT][4] = in.rv;
+  const float (&rsv)[MT] = in.rsv;
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
     const int m = m0 + 16 * s + c;
@@ -330,9 +351,7 @@ __device__ __forceinline__ void train_epi_rows256(const TrainEpi& e, tc_f32x4 (&
 //   lnbwd_tail:  after the main loop: dy, ONE exchange (sum w | sum w xh, `red2` = 8 * 16 * MT floats), g update, dy_next, partials.
 // Every MFMA wave of the workgroup must call both (2 x 2 barriers in stats, 2 in the tail).
 template <int MT>
-__device__ __forceinline__ void lnbwd_stats(const TrainEpi& e, int m0, int M, int wave, int c, int g, float* red, float4 (&xv)[MT][4],
-                                            float (&rstd)[MT]) {
-  constexpr int ROWS = 16 * MT;
+__device__ __forceinline__ void lnbwd_stats_load(const TrainEpi& e, int m0, int M, int wave, int c, int g, float4 (&xv)[MT][4]) {
 #pragma unroll
   for (int s = 0; s < MT; ++s) {
     const int m = m0 + 16 * s + c;
@@ -341,6 +360,20 @@ __device__ __forceinline__ void lnbwd_stats(const TrainEpi& e, int m0, int M, in
     for (int jt = 0; jt < 4; ++jt)
       xv[s][jt] = *reinterpret_cast<const float4*>(e.residual + (int64_t)mr * e.ldr + 64 * wave + 16 * jt + 4 * g);
   }
+}
+template <int MT>
+__device__ __forceinline__ void lnbwd_stats_compute(const TrainEpi& e, int wave, int c, int g, float* red, float4 (&xv)[MT][4],
+                                                    float (&rstd)[MT]);
+template <int MT>
+__device__ __forceinline__ void lnbwd_stats(const TrainEpi& e, int m0, int M, int wave, int c, int g, float* red, float4 (&xv)[MT][4],
+                                            float (&rstd)[MT]) {
+  lnbwd_stats_load<MT>(e, m0, M, wave, c, g, xv);
+  lnbwd_stats_compute<MT>(e, wave, c, g, red, xv, rstd);
+}
+template <int MT>
+__device__ __forceinline__ void lnbwd_stats_compute(const TrainEpi& e, int wave, int c, int g, float* red, float4 (&xv)[MT][4],
+                                                    float (&rstd)[MT]) {
+  constexpr int ROWS = 16 * MT;
   auto row_total = [&](float (&part)[MT], float (&tot)[MT]) __attribute__((always_inline)) {
     __syncthreads();
 #pragma unroll
@@ -389,11 +422,46 @@ __device__ __forceinline__ void lnbwd_stats(const TrainEpi& e, int m0, int M, in
 }
 
 template <int MT>
-__device__ __forceinline__ void lnbwd_tail(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], const float4 (&xv)[MT][4], const float (&rstd)[MT],
-                                           int m0, int M, int wave, int c, int g, float* gout, int64_t ldg, float* red2, int blk) {
-  constexpr int ROWS = 16 * MT;
+struct LnTailLoads {
   float4 gv[MT][4], gam[4];
   float rsv[MT], rs2[MT];
+};
+template <int MT>
+__device__ __forceinline__ void lnbwd_tail_load(const TrainEpi& e, int m0, int M, int wave, int c, int g, const float* gout, int64_t ldg,
+                                                LnTailLoads<MT>& in) {
+#pragma unroll
+  for (int s = 0; s < MT; ++s) {
+    const int m = m0 + 16 * s + c;
+    const int mr = m < M ? m : M - 1;
+    in.rsv[s] = e.row_scale ? e.row_scale[mr] : 1.0f;
+    in.rs2[s] = e.ln_row_scale ? e.ln_row_scale[mr] : 1.0f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      in.gv[s][jt] = *reinterpret_cast<const float4*>(gout + (int64_t)mr * ldg + 64 * wave + 16 * jt + 4 * g);
+  }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) in.gam[jt] = *reinterpret_cast<const float4*>(e.ln_g1 + 64 * wave + 16 * jt + 4 * g);
+}
+template <int MT>
+__device__ __forceinline__ void lnbwd_tail_compute(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], const float4 (&xv)[MT][4],
+                                                   const float (&rstd)[MT], int m0, int M, int wave, int c, int g, float* gout, int64_t ldg,
+                                                   float* red2, int blk, const LnTailLoads<MT>& in);
+template <int MT>
+__device__ __forceinline__ void lnbwd_tail(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], const float4 (&xv)[MT][4], const float (&rstd)[MT],
+                                           int m0, int M, int wave, int c, int g, float* gout, int64_t ldg, float* red2, int blk) {
+  LnTailLoads<MT> in;
+  lnbwd_tail_load<MT>(e, m0, M, wave, c, g, gout, ldg, in);
+  lnbwd_tail_compute<MT>(e, acc, xv, rstd, m0, M, wave, c, g, gout, ldg, red2, blk, in);
+}
+template <int MT>
+__device__ __forceinline__ void lnbwd_tail_compute(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], const float4 (&xv)[MT][4],
+                                                   const float (&rstd)[MT], int m0, int M, int wave, int c, int g, float* gout, int64_t ldg,
+                                                   float* red2, int blk, const LnTailLoads<MT>& in) {
+  constexpr int ROWS = 16 * MT;
+  const float4 (&gv)[MT][4] = in.gv;
+  const float4 (&gam)[4] = in.gam;
+  const float (&rsv)[MT] = in.rsv;
+  const float (&rs2)[MT] = in.rs2;
   bool live[MT];
   int mrow[MT];
 #pragma unroll
@@ -401,14 +469,7 @@ __device__ __forceinline__ void lnbwd_tail(const TrainEpi& e, tc_f32x4 (&acc)[4]
     const int m = m0 + 16 * s + c;
     live[s] = m < M;
     mrow[s] = live[s] ? m : M - 1;
-    rsv[s] = e.row_scale ? e.row_scale[mrow[s]] : 1.0f;
-    rs2[s] = e.ln_row_scale ? e.ln_row_scale[mrow[s]] : 1.0f;
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-      gv[s][jt] = *reinterpret_cast<const float4*>(gout + (int64_t)mrow[s] * ldg + 64 * wave + 16 * jt + 4 * g);
   }
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) gam[jt] = *reinterpret_cast<const float4*>(e.ln_g1 + 64 * wave + 16 * jt + 4 * g);
   float pa[MT], pb[MT];
 #pragma unroll
   for (int s = 0; s < MT; ++s) {

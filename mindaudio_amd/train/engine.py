@@ -682,7 +682,9 @@ class ConformerCTCTrainStep:
                 dpos_l = arena[off["dpos_all"][0]:off["dpos_all"][0] + off["dpos_all"][1]].view(torch.float32).view(t2, self.L * d)
                 # dpos[t][c] of block li += sum over the batch of dp_part[b][t][c]
                 # (stored, not accumulated: every block writes its own 256 columns once per step, so dpos_all needs no zero fill)
-                add(ws_ptr + dp_off.value * 4, dpos_l[:, li * d:(li + 1) * d], t2 * d, self.L * d, d, b_att, tp_.value * d, False,
+                # ("tall": one partial per utterance in flight per thread group - as a short item, 64 workgroups walked the 40
+                # partials in five dependent rounds of HBM latency, the longest chain of the block's batched sum)
+                add(ws_ptr + dp_off.value * 4, dpos_l[:, li * d:(li + 1) * d], t2 * d, self.L * d, d, b_att, tp_.value * d, True,
                     accumulate=False)
                 for h in range(self.heads):  # du[h], dv[h] += sum over the (utterance, query block) partials of head h
                     hb = ws_ptr + (bias_off.value + h * pph.value * 128) * 4

@@ -51,7 +51,24 @@ def main():
         u, h = K.dense_act_drop(a, pk1, hid, b1, p, seed, 3)
         return K.dense_join(h, pk2, hid, b2, x, 0.5, p, seed, 4, ln1=(g1, be1))
 
-    for name, fn in (("two launches", two), ("one launch", fused), ("two launches", two), ("one launch", fused)):
+    dy = bf(torch.randn(m, d, generator=g)).cuda()
+    g0 = torch.randn(m, d, generator=g).cuda()
+    pt = ops.ffn_pack_weights(w2.t().contiguous(), w1.t().contiguous())
+    pk2t, pk1t = pack(w2.t().contiguous(), 0), pack(w1.t().contiguous(), 1)
+    parts = torch.zeros(max(K.ffn_train_parts(m), K.rows_train_parts(m)) * 512, device="cuda")
+    gk = K.ffn_train(a, pk, hid, b1, p, seed, 3, b2, x, 0.5, p, 4, ln1=(g1, be1), tape_derivative=True)[0]
+    u = K.dense_act_drop(a, pk1, hid, b1, p, seed, 3)[0]
+    nxt = (0.5, p, seed, 9, None)
+
+    def fused_bwd():
+        return K.ffn_train_bwd(dy, pt, hid, gk, x, g1, g0, parts, nxt=nxt)
+
+    def two_bwd():
+        du = K.dense_act_drop_bwd(dy, pk2t, hid, u, p, seed, 3)
+        return K.dense_lnbwd(du, pk1t, hid, x, g1, g0, parts, nxt=nxt)
+
+    for name, fn in (("two launches", two), ("one launch", fused), ("two launches", two), ("one launch", fused),
+                     ("bwd two", two_bwd), ("bwd one", fused_bwd), ("bwd two", two_bwd), ("bwd one", fused_bwd)):
         for _ in range(5):
             fn()
         torch.cuda.synchronize()

@@ -278,7 +278,8 @@ int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, i
 /* Loss value AND gradient of the CTC branch: as ma_ctc_loss_f32, plus dlogits (batch*T, ld_out) bf16 =
  * grad_scale * d(sum of per-utterance CTC) / d logits (softmax - state occupancies; zero for frames past hlens and
  * for utterances whose loss is infinite — zero_infinity must be on).  Columns [V, ld_out) are zero-filled so the buffer
- * can be a K-padded GEMM operand.  workspace >= ma_ctc_grad_workspace_bytes (the alpha/occupancy lattice). */
+ * can be a K-padded GEMM operand.  workspace >= ma_ctc_grad_workspace_bytes (the log alpha and log beta lattices: the two recursions run
+ * side by side in one launch, round 4). */
 int64_t ma_ctc_grad_workspace_bytes(int64_t batch, int64_t T, int32_t Lmax);
 int ma_ctc_loss_grad_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
                          int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,

@@ -63,12 +63,12 @@ __global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ 
 // one wave per utterance; extended label sequence l' (blank, y1, blank, y2, ..., blank), state s on lane s % 64,
 // up to kMaxChunks * 64 states (targets up to 127 labels).
 constexpr int kMaxChunks = 4;
-__global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__ logits, int64_t ld, int T,
-                                                       const float* __restrict__ lse, const int32_t* __restrict__ ys,
-                                                       int Lmax, const int32_t* __restrict__ hlens,
-                                                       const int32_t* __restrict__ ylens, int blank,
-                                                       float* __restrict__ loss, float* __restrict__ alpha_out,
-                                                       int Smax) {
+__device__ __forceinline__ void ctc_alpha_body(const float* __restrict__ logits, int64_t ld, int T,
+                                               const float* __restrict__ lse, const int32_t* __restrict__ ys,
+                                               int Lmax, const int32_t* __restrict__ hlens,
+                                               const int32_t* __restrict__ ylens, int blank,
+                                               float* __restrict__ loss, float* __restrict__ alpha_out,
+                                               int Smax) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int tlen = hlens[b];
   if (tlen > T) tlen = T;
@@ -166,21 +166,31 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
   if (lane == 0) loss[b] = (m == -INFINITY) ? INFINITY : -(m + logf(sum));
 }
 
-// Backward, step 1: beta recursion of one utterance per wave (mirror image of ctc_alpha_kernel), turning the stored
-// alpha_t(s) in place into the state occupancy w_t(s) = alpha_t(s) beta_t(s) / (y_t(l'_s) P(l|x)).
-__global__ __launch_bounds__(64) void ctc_beta_kernel(const float* __restrict__ logits, int64_t ld, int T,
-                                                      const float* __restrict__ lse, const int32_t* __restrict__ ys,
-                                                      int Lmax, const int32_t* __restrict__ hlens,
-                                                      const int32_t* __restrict__ ylens, int blank,
-                                                      const float* __restrict__ loss, float* __restrict__ ab, int Smax) {
+__global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__ logits, int64_t ld, int T,
+                                                       const float* __restrict__ lse, const int32_t* __restrict__ ys,
+                                                       int Lmax, const int32_t* __restrict__ hlens,
+                                                       const int32_t* __restrict__ ylens, int blank,
+                                                       float* __restrict__ loss, float* __restrict__ alpha_out,
+                                                       int Smax) {
+  ctc_alpha_body(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, loss, alpha_out, Smax);
+}
+
+// Backward, step 1: beta recursion of one utterance per wave (mirror image of the alpha recursion).  Round 4: it no longer reads
+// alpha or the loss - it stores log beta_t(s) WITHOUT the step's emission, beta_out[b, t, s], and ctc_dlogits_kernel forms the state
+// occupancy w_t(s) = alpha_t(s) beta_t(s) / (y_t(l'_s) P(l|x)) = exp(alpha + beta_out + nll) itself - so that the two recursions,
+// 255 dependent steps of one wave per utterance each, run SIDE BY SIDE in one launch (ctc_alpha_beta_kernel) instead of one after
+// the other (79 + 112 us of the training step with 40 of 1024 SIMDs busy).
+__device__ __forceinline__ void ctc_beta_body(const float* __restrict__ logits, int64_t ld, int T,
+                                              const float* __restrict__ lse, const int32_t* __restrict__ ys,
+                                              int Lmax, const int32_t* __restrict__ hlens,
+                                              const int32_t* __restrict__ ylens, int blank, float* __restrict__ beta_out, int Smax) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int tlen = hlens[b];
   if (tlen > T) tlen = T;
   const int U = ylens[b];
   const int S = 2 * U + 1;
   const int nch = (S + 63) / 64;
-  const float nll = loss[b];
-  if (tlen < 1 || U < 0 || nch > kMaxChunks || isinf(nll)) return;  // no gradient (zero_infinity / degenerate)
+  if (tlen < 1 || U < 0 || nch > kMaxChunks) return;  // no gradient (degenerate)
   int lab[kMaxChunks];
   bool skip[kMaxChunks];  // transition s -> s+2 allowed
   float beta[kMaxChunks];
@@ -198,9 +208,9 @@ __global__ __launch_bounds__(64) void ctc_beta_kernel(const float* __restrict__ 
     beta[c] = -INFINITY;
   }
   const float* row0 = logits + (int64_t)b * T * ld;
-  // as in ctc_alpha_kernel: emissions, log-sum-exp and the stored alpha of a step are fetched kPD steps ahead of the recursion
+  // as in the alpha recursion: emissions and log-sum-exp of a step are fetched kPD steps ahead of the recursion
   constexpr int kPD = 4;
-  float er[kPD][kMaxChunks], ar[kPD][kMaxChunks], zr[kPD];
+  float er[kPD][kMaxChunks], zr[kPD];
   auto fetch = [&](auto kc, int t) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
     const int tc = t >= 0 ? t : 0;
@@ -210,10 +220,9 @@ __global__ __launch_bounds__(64) void ctc_beta_kernel(const float* __restrict__ 
     for (int c = 0; c < kMaxChunks; ++c) {
       const bool in = c < nch && c * 64 + lane < S;
       er[k][c] = in ? row[lab[c]] : 0.0f;
-      ar[k][c] = in ? ab[((int64_t)b * T + tc) * Smax + c * 64 + lane] : 0.0f;
     }
   };
-  auto step = [&](int t, const float (&e)[kMaxChunks], const float (&al)[kMaxChunks], float z) __attribute__((always_inline)) {
+  auto step = [&](int t, const float (&e)[kMaxChunks], float z) __attribute__((always_inline)) {
     float carry1 = -INFINITY, carry2 = -INFINITY;  // beta_{t+1}(s+1), (s+2) coming from the next chunk
     float nb[kMaxChunks];
 #pragma unroll
@@ -237,10 +246,7 @@ __global__ __launch_bounds__(64) void ctc_beta_kernel(const float* __restrict__ 
         v = log_add3(b0, b1, b2, skip[c]);
       }
       nb[c] = (s < S) ? v + lp : -INFINITY;
-      if (s < S) {
-        const float ev = al[c] + nb[c] - lp + nll;  // log of alpha beta / (y P)
-        ab[((int64_t)b * T + t) * Smax + s] = ev > -80.0f ? expf(ev) : 0.0f;
-      }
+      if (s < S) beta_out[((int64_t)b * T + t) * Smax + s] = nb[c] - lp;  // (v: -inf stays -inf)
     }
 #pragma unroll
     for (int c = 0; c < kMaxChunks; ++c) beta[c] = nb[c];
@@ -252,14 +258,24 @@ __global__ __launch_bounds__(64) void ctc_beta_kernel(const float* __restrict__ 
   int t = tlen - 1;
   fetch(K0{}, t); fetch(K1{}, t - 1); fetch(K2{}, t - 2); fetch(K3{}, t - 3);
   for (; t - kPD + 1 >= 0; t -= kPD) {
-    step(t, er[0], ar[0], zr[0]); fetch(K0{}, t - kPD);
-    step(t - 1, er[1], ar[1], zr[1]); fetch(K1{}, t - 1 - kPD);
-    step(t - 2, er[2], ar[2], zr[2]); fetch(K2{}, t - 2 - kPD);
-    step(t - 3, er[3], ar[3], zr[3]); fetch(K3{}, t - 3 - kPD);
+    step(t, er[0], zr[0]); fetch(K0{}, t - kPD);
+    step(t - 1, er[1], zr[1]); fetch(K1{}, t - 1 - kPD);
+    step(t - 2, er[2], zr[2]); fetch(K2{}, t - 2 - kPD);
+    step(t - 3, er[3], zr[3]); fetch(K3{}, t - 3 - kPD);
   }
-  if (t >= 0) step(t, er[0], ar[0], zr[0]);
-  if (t - 1 >= 0) step(t - 1, er[1], ar[1], zr[1]);
-  if (t - 2 >= 0) step(t - 2, er[2], ar[2], zr[2]);
+  if (t >= 0) step(t, er[0], zr[0]);
+  if (t - 1 >= 0) step(t - 1, er[1], zr[1]);
+  if (t - 2 >= 0) step(t - 2, er[2], zr[2]);
+}
+
+// both recursions in one launch: grid (batch, 2), blockIdx.y = 0: alpha (+ the utterance's loss), 1: beta
+__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logits, int64_t ld, int T,
+                                                            const float* __restrict__ lse, const int32_t* __restrict__ ys,
+                                                            int Lmax, const int32_t* __restrict__ hlens,
+                                                            const int32_t* __restrict__ ylens, int blank, float* __restrict__ loss,
+                                                            float* __restrict__ alpha_out, float* __restrict__ beta_out, int Smax) {
+  if (blockIdx.y == 0) ctc_alpha_body(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, loss, alpha_out, Smax);
+  else ctc_beta_body(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, beta_out, Smax);
 }
 
 // Backward, step 2: one workgroup per (b, t) row: dlogits[v] = scale * (softmax[v] - sum_{s: l'_s = v} w_t(s)) as bf16;
@@ -277,8 +293,8 @@ __global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restric
                                                           int Lmax, const int32_t* __restrict__ hlens,
                                                           const int32_t* __restrict__ ylens, int blank,
                                                           const float* __restrict__ loss, const float* __restrict__ ab,
-                                                          int Smax, float scale, OT* __restrict__ out,
-                                                          int64_t ld_out) {
+                                                          const float* __restrict__ bb, int Smax, float scale,
+                                                          OT* __restrict__ out, int64_t ld_out) {
   extern __shared__ float occ[];
   const int64_t row = blockIdx.x;
   const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
@@ -297,11 +313,18 @@ __global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restric
   //   wave 0: the blank (every even state, and any label equal to the blank): lane-strided sums + a shuffle tree;
   //   threads 64 ..: label position i: the FIRST occurrence of a label adds all its occurrences in index order.
   const float* abr = ab + row * Smax;
+  const float* bbr = bb + row * Smax;
+  const float nll = loss[b];
+  // w_t(s) = alpha_t(s) beta_t(s) / (y_t(l'_s) P(l|x)): log alpha and log beta (without the emission) from the two recursions
+  auto occ_at = [&](int s) -> float {
+    const float ev = abr[s] + bbr[s] + nll;
+    return ev > -80.0f ? expf(ev) : 0.0f;
+  };
   const int32_t* yb = ys + (int64_t)b * Lmax;
   if (threadIdx.x < 64) {
     float a = 0.0f;
     for (int s = threadIdx.x; s < S; s += 64)
-      if (!(s & 1) || yb[s >> 1] == blank) a += abr[s];
+      if (!(s & 1) || yb[s >> 1] == blank) a += occ_at(s);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
     if (threadIdx.x == 0) occ[blank] = a;
@@ -314,7 +337,7 @@ __global__ __launch_bounds__(256) void ctc_dlogits_kernel(const float* __restric
       if (!first) continue;
       float a = 0.0f;
       for (int k = i; k < U; ++k)
-        if (yb[k] == l) a += abr[2 * k + 1];
+        if (yb[k] == l) a += occ_at(2 * k + 1);
       occ[l] = a;
     }
   }
@@ -422,7 +445,7 @@ int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, i
 
 int64_t ma_ctc_grad_workspace_bytes(int64_t batch, int64_t T, int32_t Lmax) {
   if (batch < 1 || T < 1 || Lmax < 1) return MA_ERR_INVALID_ARG;
-  return batch * T * (2 * (int64_t)Lmax + 1) * 4;
+  return 2 * batch * T * (2 * (int64_t)Lmax + 1) * 4;  // log alpha | log beta
 }
 
 extern "C++" {
@@ -442,13 +465,12 @@ static int ctc_loss_grad_launch(const float* logits, int64_t ld, int64_t batch, 
   const int Smax = 2 * Lmax + 1;
   float* ab = reinterpret_cast<float*>(workspace);
   MA_LAUNCH(ctc_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, ld, rows, (int)V, lse_workspace);
-  MA_LAUNCH(ctc_alpha_kernel, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
-            hlens, ylens, (int)blank, per_utt_loss, ab, Smax);
+  float* bb = ab + batch * T * Smax;
+  MA_LAUNCH(ctc_alpha_beta_kernel, dim3((unsigned)batch, 2), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
+            hlens, ylens, (int)blank, per_utt_loss, ab, bb, Smax);
   MA_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, per_utt_loss, (int)batch, 1, loss_out);
-  MA_LAUNCH(ctc_beta_kernel, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
-            hlens, ylens, (int)blank, per_utt_loss, ab, Smax);
   MA_LAUNCH(ctc_dlogits_kernel<OT>, dim3((unsigned)rows), dim3(256), (size_t)V * 4, s, logits, ld, (int)T, (int)V,
-            lse_workspace, ys, (int)Lmax, hlens, ylens, (int)blank, per_utt_loss, ab, Smax, grad_scale, dlogits, ld_out);
+            lse_workspace, ys, (int)Lmax, hlens, ylens, (int)blank, per_utt_loss, ab, bb, Smax, grad_scale, dlogits, ld_out);
   return MA_OK;
 }
 }  // extern "C++"

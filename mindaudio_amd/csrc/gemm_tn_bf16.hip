@@ -331,8 +331,17 @@ __global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ma_reduce_it
     const int64_t i0 = ((int64_t)((int)blockIdx.x - it.first_block) * 4 + tx) * 4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i0 < it.mn) {
+      // twelve partials of a thread group in flight (the depthwise convolution's 640 partials were ten dependent round trips at four)
+      int k = ty;
+      for (; k + 11 * 64 < it.splits; k += 12 * 64) {
+        float4 v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v[u] = load4(k + 64 * u, i0);
+#pragma unroll
+        for (int u = 0; u < 12; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+      }
 #pragma unroll 4
-      for (int k = ty; k < it.splits; k += 64) {
+      for (; k < it.splits; k += 64) {
         const float4 v = load4(k, i0);
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
       }

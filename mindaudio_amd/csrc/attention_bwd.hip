@@ -8,7 +8,7 @@
 //   dp = sum_b dK'[:, 64:]
 //
 // Three kernels:
-//   attn_bwd_prep_kernel   per (b, h, 64 rows): Q', K' row-major and transposed, dO^T (bf16 workspace), D (float32)
+//   attn_bwd_prep_kernel   per (b, h, 64 rows): Q', K' row-major (bf16 workspace), D (float32)   [until round 4 also Q'^T, K'^T, dO^T]
 //   attn_bwd_kernel<true>  keys fixed   (workgroup = 64 keys, wave = 16 keys), queries streamed: dK', dV
 //   attn_bwd_kernel<false> queries fixed (workgroup = 64 queries),             keys streamed:    dQ'
 // Both recompute the 64 x 64 score tile with the streamed side as the MFMA row operand, so the lane holds, for its
@@ -28,6 +28,8 @@ namespace ma {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef short ab_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ab_v4s ab_lds_v4s;
 
 __device__ __forceinline__ uint16_t ab_to_bf16(float f) {
   uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __re
                                                             const uint16_t* __restrict__ ctx, int64_t ld_ctx,
                                                             const uint16_t* __restrict__ dctx, int64_t ld_dctx, int T, int H,
                                                             AttnWs ws) {
-  constexpr int kSq = 128 + 8, kSd = 64 + 8;  // LDS row strides (elements): 16-byte aligned rows
-  __shared__ __attribute__((aligned(16))) uint16_t tq[64 * kSq], tk[64 * kSq], td[64 * kSd];
+  constexpr int kSq = 128 + 8;  // LDS row stride (elements): 16-byte aligned rows
+  __shared__ __attribute__((aligned(16))) uint16_t tq[64 * kSq], tk[64 * kSq];
   const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * H + h, row0 = (int64_t)b * T;
   const int Tp = ws.Tp;
@@ -117,7 +119,6 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __re
     *reinterpret_cast<uint4*>(&tq[r * kSq + 64 + c]) = zqv;
     *reinterpret_cast<uint4*>(&tk[r * kSq + c]) = zk;
     *reinterpret_cast<uint4*>(&tk[r * kSq + 64 + c]) = zp;
-    *reinterpret_cast<uint4*>(&td[r * kSd + c]) = zd;
   }
   dsum += __shfl_xor(dsum, 1, 64);
   dsum += __shfl_xor(dsum, 2, 64);
@@ -131,31 +132,11 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __re
     q[i] = *reinterpret_cast<const uint4*>(&tq[rr * kSq + ch * 8]);
     k[i] = *reinterpret_cast<const uint4*>(&tk[rr * kSq + ch * 8]);
   }
-  // transposed copies [column][Tp]: a thread gathers 8 consecutive rows of one column
-  auto gather8 = [&](const uint16_t* tile, int stride, int cc, int r8) __attribute__((always_inline)) {
-    uint16_t e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = tile[(r8 * 8 + j) * stride + cc];
-    return make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
-                      (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
-  };
-  uint16_t* qt = ws.qt(bh);
-  uint16_t* kt = ws.kt(bh);
-  for (int i = tid; i < 128 * 8; i += 256) {
-    const int cc = i >> 3, r8 = i & 7;
-    *reinterpret_cast<uint4*>(qt + (int64_t)cc * Tp + t0 + r8 * 8) = gather8(tq, kSq, cc, r8);
-    *reinterpret_cast<uint4*>(kt + (int64_t)cc * Tp + t0 + r8 * 8) = gather8(tk, kSq, cc, r8);
-  }
-  uint16_t* dot = ws.dot(bh);
-  for (int i = tid; i < 64 * 8; i += 256) {
-    const int cc = i >> 3, r8 = i & 7;
-    *reinterpret_cast<uint4*>(dot + (int64_t)cc * Tp + t0 + r8 * 8) = gather8(td, kSd, cc, r8);
-  }
+  // (no transposed copies since round 4: the backward kernels read the transposed operands from their row-major LDS tiles)
 }
 
 constexpr int kXs = 128 + 8;  // bf16 row stride of the row-major X' tile (272 B)
 constexpr int kYs = 64 + 8;   // row-major Y tile (144 B)
-constexpr int kTs = 64 + 4;   // transposed tiles: 64 streamed items per row (136 B, 8-byte aligned)
 
 // KEYS_FIXED = true : fixed = keys (K', V), streamed = queries (Q', dO, Q'^T, dO^T, lse, D): outputs dK', dV
 // KEYS_FIXED = false: fixed = queries (Q', dO, lse, D), streamed = keys (K', V, K'^T, maskadd): output dQ'
@@ -166,20 +147,27 @@ constexpr int kTs = 64 + 4;   // transposed tiles: 64 streamed items per row (13
 // NF (round 4) = 16-item tiles of the fixed side per wave: a workgroup owns 64 NF fixed items, a fragment of the streamed tiles read
 // from LDS feeds NF MFMAs, and a (b, h) stages its streamed tiles Tp / (64 NF) times.  Measured on the training step's shape
 // (40 x 4 heads x 255 frames; tools/attn_bwd_bench.py: the whole backward - prep + both kernels + two small reductions):
-//     queries fixed (dQ'):    NF = 1: 95.4 us   NF = 2 (two workgroups per CU still): 93.2 us <- launched   NF = 4 (one per CU): 95.6 us
-//     keys fixed (dK', dV):   NF = 2 (one workgroup per CU): + 5 us in the step's census; at two per CU, and NF = 4 at all, the kernel
-//                             does not fit its registers (20 - 268 B of scratch per lane): NF = 1 stays
-// i.e. the launches are NOT bound by their LDS reads (they run at a tenth of the MFMA rate either way): what remains per 64-row tile
-// is the register-staged global -> LDS copy behind two barriers and ~200 VALU operations per lane and slab (exp, dS, packing) that
-// nothing overlaps.  The (B, T, T) chunk mask runs NF = 1 (QMASK: its index arithmetic costs registers the wider forms lack).
+//     with the transposed workspace copies (until the middle of round 4):  NF(dQ') = 1: 95.4 us   2: 93.2   4 (one workgroup per CU): 95.6;
+//         keys fixed NF = 2 / 4 did not fit their registers (20 - 268 B of scratch per lane)
+//     with the transposing LDS reads (now):  (keys, queries) = (1, 1): 76.7 us   (1, 2): 76.7 <- launched   (2, 2): 76.9   (2, 4): 80.2
+// i.e. the launches are NOT bound by their LDS reads or the MFMAs (a tenth of the MFMA rate either way): what paid was removing the
+// transposed copies (28 MB per block written by the prep kernel and staged twice); what remains per 64-row tile is the register-staged
+// global -> LDS copy behind two barriers and ~200 VALU operations per lane and slab (exp, dS, packing) that nothing overlaps.
+// The (B, T, T) chunk mask runs NF = 1 (QMASK: its index arithmetic costs registers).
 #ifndef MA_AB_NFQ
 #define MA_AB_NFQ 2
 #endif
-constexpr int kAbNF = MA_AB_NFQ, kAbNFK = 1;  // queries fixed / keys fixed
+#ifndef MA_AB_NFK
+#define MA_AB_NFK 1
+#endif
+#ifndef MA_AB_OCC1
+#define MA_AB_OCC1 3  // slabs per wave from which a workgroup has the CU to itself
+#endif
+constexpr int kAbNF = MA_AB_NFQ, kAbNFK = MA_AB_NFK;  // queries fixed / keys fixed
 // QMASK: the (B, T, T) chunk mask of the streaming configuration is a variant of its own (one slab per wave, two workgroups per CU, as
 // until round 4): its per-element index arithmetic costs the four-slab form the registers it does not have.
 template <bool KEYS_FIXED, int NF, bool QMASK>
-__global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+__global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                        const uint16_t* __restrict__ dctx, int64_t ld_dctx,
                                                        const float* __restrict__ mask, const float* __restrict__ mask3,
                                                        const float* __restrict__ lse, AttnWs ws, int T, int H, float scale,
@@ -187,8 +175,9 @@ __global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void
                                                        int64_t ld_dpos, float* du, float* dv) {
   __shared__ __attribute__((aligned(16))) uint16_t Xs[64 * kXs];       // streamed X' rows
   __shared__ __attribute__((aligned(16))) uint16_t Ys[64 * kYs];       // streamed Y rows (dO or V)
-  __shared__ __attribute__((aligned(16))) uint16_t Xt[128 * kTs];      // streamed X'^T
-  __shared__ __attribute__((aligned(16))) uint16_t Yt[64 * kTs];       // streamed dO^T (KEYS_FIXED only)
+  // (round 4: no transposed tiles - the contraction over the streamed rows reads its A operands from the ROW-MAJOR tiles with
+  // gfx950's transposing LDS read, see the contractions below; until then X'^T and dO^T were staged from transposed copies that
+  // attn_bwd_prep_kernel wrote to the workspace: 28 MB per block written, read back twice, and 12 more LDS stores per thread and tile)
   __shared__ __attribute__((aligned(16))) float srow[2][64];           // streamed per-row scalars: lse & D, or maskadd
   __shared__ float wg_part[4][128];                                     // queries-fixed epilogue: (du | dv) per wave
 
@@ -227,8 +216,6 @@ __global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void
   }
 
   const uint16_t* sx = KEYS_FIXED ? ws.q(bh) : ws.k(bh);
-  const uint16_t* sxt = KEYS_FIXED ? ws.qt(bh) : ws.kt(bh);
-  const uint16_t* syt = ws.dot(bh);
   const int n_st = Tp / 64;
   // Staging registers (named, filled by macros: arrays captured by lambdas end up in scratch).  The global loads of
   // streamed tile st+1 are issued right after tile st is published to LDS and stay in flight during its MFMAs.
@@ -236,7 +223,7 @@ __global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void
   //   Y rows  : 64 x 8 chunks  -> thread (r = tid >> 3 (+32 i), ch = tid & 7),  i < 2
   //   X'^T    : 128 x 8 chunks -> thread (r = tid >> 3 (+32 i), ch = tid & 7),  i < 4
   //   dO^T    : 64 x 8 chunks  -> as Y rows (KEYS_FIXED only)
-  uint4 rx0, rx1, rx2, rx3, ry0, ry1, rt0, rt1, rt2, rt3, rd0 = make_uint4(0, 0, 0, 0), rd1 = make_uint4(0, 0, 0, 0);
+  uint4 rx0, rx1, rx2, rx3, ry0, ry1;
   float rs0 = 0.0f, rs1 = 0.0f;
   // (the staging addresses are loop-invariant, and hipcc would hoist all of them - a dozen 64-bit pointers - out of the loop and, with
   // four slabs of accumulators, SPILL them; they are cheap to recompute: every fetch derives them from an opaque copy of the thread index)
@@ -261,14 +248,6 @@ __global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void
     rx2 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 32) * 128 + xc_ * 8);                            \
     rx3 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 48) * 128 + xc_ * 8);                            \
     MA_AB_YLOAD(ry0, 0, s0f_) MA_AB_YLOAD(ry1, 1, s0f_)                                                                \
-    rt0 = *reinterpret_cast<const uint4*>(sxt + (int64_t)(yr_)*Tp + s0f_ + yc_ * 8);                                   \
-    rt1 = *reinterpret_cast<const uint4*>(sxt + (int64_t)(yr_ + 32) * Tp + s0f_ + yc_ * 8);                            \
-    rt2 = *reinterpret_cast<const uint4*>(sxt + (int64_t)(yr_ + 64) * Tp + s0f_ + yc_ * 8);                            \
-    rt3 = *reinterpret_cast<const uint4*>(sxt + (int64_t)(yr_ + 96) * Tp + s0f_ + yc_ * 8);                            \
-    if (KEYS_FIXED) {                                                                                                  \
-      rd0 = *reinterpret_cast<const uint4*>(syt + (int64_t)(yr_)*Tp + s0f_ + yc_ * 8);                                 \
-      rd1 = *reinterpret_cast<const uint4*>(syt + (int64_t)(yr_ + 32) * Tp + s0f_ + yc_ * 8);                          \
-    }                                                                                                                  \
     if (tidv < 64) {                                                                                                   \
       const int si_ = s0f_ + tidv;                                                                                     \
       if (KEYS_FIXED) {                                                                                                \
@@ -279,12 +258,20 @@ __global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void
       }                                                                                                                \
     }                                                                                                                  \
   }
-#define MA_AB_ST8(arr, r, ch, v)                                                   \
-  {                                                                                \
-    uint2* d_ = reinterpret_cast<uint2*>(&arr[(r)*kTs + (ch)*8]);                   \
-    d_[0] = make_uint2((v).x, (v).y);                                              \
-    d_[1] = make_uint2((v).z, (v).w);                                              \
-  }
+  // A operand of a contraction over the streamed rows, tile of 16 features ft, 32 rows of half ks: element e of lane (lq = feature,
+  // lg) must be row (e >> 2) * 16 + lg * 4 + (e & 3) of the half - the k-order in which P and dS sit in the score tiles' accumulator
+  // layout.  ds_read_b64_tr_b16: the 16 lanes of a group lg address a 4-row x 16-column block of a row-major tile (lane (la, lb):
+  // row la, columns 4 lb .. + 3) and each RECEIVES the four rows' values of column lane & 15: rows lg * 4 + la for elements 0..3,
+  // 16 more for 4..7.  Conflict-free with both tiles' pitches (rows 68 / 36 words apart, 4 rows x 8 words per lane group).
+  const int la = lq >> 2, lb = lq & 3;
+  auto tr_frag = [&](const uint16_t* tile, int pitch, int ks, int ft) __attribute__((always_inline)) {
+    const uint16_t* a0 = tile + (ks * 32 + lg * 4 + la) * pitch + ft * 16 + lb * 4;
+    const ab_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ab_lds_v4s*)(a0));
+    const ab_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ab_lds_v4s*)(a0 + 16 * pitch));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
   MA_AB_FETCH(0)
   for (int st = 0; st < n_st; ++st) {
     __syncthreads();  // previous tile fully consumed
@@ -295,14 +282,6 @@ __global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void
     *reinterpret_cast<uint4*>(&Xs[(xr_ + 48) * kXs + xc_ * 8]) = rx3;
     *reinterpret_cast<uint4*>(&Ys[(yr_)*kYs + yc_ * 8]) = ry0;
     *reinterpret_cast<uint4*>(&Ys[(yr_ + 32) * kYs + yc_ * 8]) = ry1;
-    MA_AB_ST8(Xt, yr_, yc_, rt0)
-    MA_AB_ST8(Xt, yr_ + 32, yc_, rt1)
-    MA_AB_ST8(Xt, yr_ + 64, yc_, rt2)
-    MA_AB_ST8(Xt, yr_ + 96, yc_, rt3)
-    if (KEYS_FIXED) {
-      MA_AB_ST8(Yt, yr_, yc_, rd0)
-      MA_AB_ST8(Yt, yr_ + 32, yc_, rd1)
-    }
     if (tid < 64) {
       srow[0][tid] = rs0;
       if (KEYS_FIXED) srow[1][tid] = rs1;
@@ -374,20 +353,14 @@ __global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void
       }
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct) {
-        const uint16_t* xr = &Xt[(ct * 16 + lq) * kTs + ks * 32 + lg * 4];
-        const uint2 v0 = *reinterpret_cast<const uint2*>(xr);
-        const uint2 v1 = *reinterpret_cast<const uint2*>(xr + 16);
-        const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+        const bf16x8 af = tr_frag(Xs, kXs, ks, ct);
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) acc_x[nf][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, gf[nf], acc_x[nf][ct], 0, 0, 0);
       }
       if (KEYS_FIXED) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const uint16_t* yr = &Yt[(dt * 16 + lq) * kTs + ks * 32 + lg * 4];
-          const uint2 v0 = *reinterpret_cast<const uint2*>(yr);
-          const uint2 v1 = *reinterpret_cast<const uint2*>(yr + 16);
-          const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+          const bf16x8 af = tr_frag(Ys, kYs, ks, dt);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) acc_y[nf][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[nf], acc_y[nf][dt], 0, 0, 0);
         }
@@ -400,7 +373,6 @@ __global__ __launch_bounds__(256, (KEYS_FIXED ? NF >= 2 : NF >= 3) ? 1 : 2) void
 #undef MA_AB_FETCH
 #undef MA_AB_IDX
 #undef MA_AB_YLOAD
-#undef MA_AB_ST8
   // ---- outputs: lane holds rows c = ct*16 + lg*4 + r of the transposed result for its fixed item -----------------
   // (output addresses from opaque copies of the block indices: computed here, not hoisted above the loop and spilled across it)
   int hv = h, bv = b;

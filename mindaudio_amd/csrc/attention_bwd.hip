@@ -8,7 +8,8 @@
 //   dp = sum_b dK'[:, 64:]
 //
 // Three kernels:
-//   attn_bwd_prep_kernel   per (b, h, 64 rows): Q', K' row-major (bf16 workspace), D (float32)   [until round 4 also Q'^T, K'^T, dO^T]
+//   attn_bwd_prep_kernel   per (b, h, 64 rows): D (float32)   [until round 4 also bf16 workspace copies of Q', K', Q'^T, K'^T, dO^T: the
+//                          backward kernels now build Q' / K' while they stage them and read transposed operands from LDS]
 //   attn_bwd_kernel<true>  keys fixed   (workgroup = 64 keys, wave = 16 keys), queries streamed: dK', dV
 //   attn_bwd_kernel<false> queries fixed (workgroup = 64 queries),             keys streamed:    dQ'
 // Both recompute the 64 x 64 score tile with the streamed side as the MFMA row operand, so the lane holds, for its
@@ -44,20 +45,14 @@ __device__ __forceinline__ uint32_t ab_pack(float lo, float hi) {  // v_cvt_pk_b
   return r;
 }
 
-// workspace layout per (b, h), bf16 elements: Q'[Tp][128] | K'[Tp][128] | Q'^T[128][Tp] | K'^T[128][Tp] | dO^T[64][Tp];
-// then, after all (b, h): D float32 [B*H][Tp]
+// workspace (float32): D [B*H][Tp] | bias_part [H][B * Tp/64][128] | dp_part [B][Tp][256]   (until round 4 it began with 576 Tp bf16
+// per (b, h): row-major and transposed copies of Q', K' and dO^T)
 struct AttnWs {
   uint16_t* base;
   float* D;
   float* bias_part;  // [H][B * (Tp/64)][128] per-workgroup partial sums of (du | dv): a head's partials lie 128 floats apart
   float* dp_part;    // [B][Tp][256] per-batch gradient of the positional projection
   int Tp;
-  __host__ __device__ int64_t per_bh() const { return (int64_t)Tp * (128 * 4 + 64); }
-  __device__ uint16_t* q(int64_t bh) const { return base + bh * per_bh(); }
-  __device__ uint16_t* k(int64_t bh) const { return q(bh) + (int64_t)Tp * 128; }
-  __device__ uint16_t* qt(int64_t bh) const { return q(bh) + (int64_t)Tp * 256; }
-  __device__ uint16_t* kt(int64_t bh) const { return q(bh) + (int64_t)Tp * 384; }
-  __device__ uint16_t* dot(int64_t bh) const { return q(bh) + (int64_t)Tp * 512; }
 };
 
 // 16-byte loads and stores throughout (the first version moved single bf16 elements: 80 two-byte loads and 208 two-byte stores per
@@ -76,63 +71,29 @@ __device__ __forceinline__ uint4 ab_pack8(const float (&f)[8]) {
                     (uint32_t)ab_to_bf16(f[4]) | ((uint32_t)ab_to_bf16(f[5]) << 16),
                     (uint32_t)ab_to_bf16(f[6]) | ((uint32_t)ab_to_bf16(f[7]) << 16));
 }
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
-                                                            const uint16_t* __restrict__ pos, int64_t ld_pos,
-                                                            const float* __restrict__ bias_u, const float* __restrict__ bias_v,
-                                                            const uint16_t* __restrict__ ctx, int64_t ld_ctx,
+// D[b, h, t] = sum_d dO[t, d] O[t, d] (the softmax backward's row term); 4 threads per row
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __restrict__ ctx, int64_t ld_ctx,
                                                             const uint16_t* __restrict__ dctx, int64_t ld_dctx, int T, int H,
                                                             AttnWs ws) {
-  constexpr int kSq = 128 + 8;  // LDS row stride (elements): 16-byte aligned rows
-  __shared__ __attribute__((aligned(16))) uint16_t tq[64 * kSq], tk[64 * kSq];
   const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * H + h, row0 = (int64_t)b * T;
-  const int Tp = ws.Tp;
-  const int tid = threadIdx.x;
-  // rows: thread (r = tid >> 2, part = tid & 3) handles 16 of the 64 head columns as two 16-byte pieces
-  const int r = tid >> 2, part = tid & 3;
+  const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
   const int t = t0 + r;
-  const bool in = t < T;
   float dsum = 0.0f;
+  if (t < T) {
 #pragma unroll
-  for (int hc = 0; hc < 2; ++hc) {
-    const int c = part * 16 + hc * 8;
-    uint4 zq = make_uint4(0, 0, 0, 0), zqv = zq, zk = zq, zp = zq, zd = zq;
-    if (in) {
-      const uint16_t* row = qkv + (row0 + t) * ld_qkv + h * 64 + c;
-      float q[8], o[8], d[8], qu[8], qv[8];
-      ab_unpack8(*reinterpret_cast<const uint4*>(row), q);
-      zk = *reinterpret_cast<const uint4*>(row + 256);
-      zp = *reinterpret_cast<const uint4*>(pos + (int64_t)t * ld_pos + h * 64 + c);
-      zd = *reinterpret_cast<const uint4*>(dctx + (row0 + t) * ld_dctx + h * 64 + c);
-      ab_unpack8(zd, d);
+    for (int hc = 0; hc < 2; ++hc) {
+      const int c = part * 16 + hc * 8;
+      float o[8], d[8];
+      ab_unpack8(*reinterpret_cast<const uint4*>(dctx + (row0 + t) * ld_dctx + h * 64 + c), d);
       ab_unpack8(*reinterpret_cast<const uint4*>(ctx + (row0 + t) * ld_ctx + h * 64 + c), o);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        qu[e] = q[e] + bias_u[h * 64 + c + e];
-        qv[e] = q[e] + bias_v[h * 64 + c + e];
-        dsum += d[e] * o[e];
-      }
-      zq = ab_pack8(qu);
-      zqv = ab_pack8(qv);
+      for (int e = 0; e < 8; ++e) dsum += d[e] * o[e];
     }
-    *reinterpret_cast<uint4*>(&tq[r * kSq + c]) = zq;
-    *reinterpret_cast<uint4*>(&tq[r * kSq + 64 + c]) = zqv;
-    *reinterpret_cast<uint4*>(&tk[r * kSq + c]) = zk;
-    *reinterpret_cast<uint4*>(&tk[r * kSq + 64 + c]) = zp;
   }
   dsum += __shfl_xor(dsum, 1, 64);
   dsum += __shfl_xor(dsum, 2, 64);
-  if (part == 0) ws.D[bh * Tp + t] = dsum;
-  __syncthreads();
-  // row-major Q' / K' (Tp, 128): 16 pieces of 16 bytes per row
-  uint4* q = reinterpret_cast<uint4*>(ws.q(bh) + (int64_t)t0 * 128);
-  uint4* k = reinterpret_cast<uint4*>(ws.k(bh) + (int64_t)t0 * 128);
-  for (int i = tid; i < 64 * 16; i += 256) {
-    const int rr = i >> 4, ch = i & 15;
-    q[i] = *reinterpret_cast<const uint4*>(&tq[rr * kSq + ch * 8]);
-    k[i] = *reinterpret_cast<const uint4*>(&tk[rr * kSq + ch * 8]);
-  }
-  // (no transposed copies since round 4: the backward kernels read the transposed operands from their row-major LDS tiles)
+  if (part == 0) ws.D[bh * ws.Tp + t] = dsum;
 }
 
 constexpr int kXs = 128 + 8;  // bf16 row stride of the row-major X' tile (272 B)
@@ -168,6 +129,8 @@ constexpr int kAbNF = MA_AB_NFQ, kAbNFK = MA_AB_NFK;  // queries fixed / keys fi
 // until round 4): its per-element index arithmetic costs the four-slab form the registers it does not have.
 template <bool KEYS_FIXED, int NF, bool QMASK>
 __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
+                                                       const uint16_t* __restrict__ pos, int64_t ld_pos,
+                                                       const float* __restrict__ bias_u, const float* __restrict__ bias_v,
                                                        const uint16_t* __restrict__ dctx, int64_t ld_dctx,
                                                        const float* __restrict__ mask, const float* __restrict__ mask3,
                                                        const float* __restrict__ lse, AttnWs ws, int T, int H, float scale,
@@ -196,9 +159,30 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
   for (int nf = 0; nf < NF; ++nf) {
     fidx[nf] = (fb * NF + nf) * 64 + wave * 16 + lq;
     const int fcl = fidx[nf] < T ? fidx[nf] : T - 1;
-    const uint16_t* xr = (KEYS_FIXED ? ws.k(bh) : ws.q(bh)) + (int64_t)fcl * 128;
+    // X' of the fixed item, built here (until round 4 a prep launch wrote Q' and K' to a workspace): K' = [k | p] as it lies in qkv
+    // and pos, Q' = [bf16(q + u) | bf16(q + v)]
+    if (KEYS_FIXED) {
+      const uint16_t* kr = qkv + (row0 + fcl) * ld_qkv + 256 + h * 64 + lg * 8;
+      const uint16_t* pr = pos + (int64_t)fcl * ld_pos + h * 64 + lg * 8;
+      xf[nf][0] = *reinterpret_cast<const bf16x8*>(kr);
+      xf[nf][1] = *reinterpret_cast<const bf16x8*>(kr + 32);
+      xf[nf][2] = *reinterpret_cast<const bf16x8*>(pr);
+      xf[nf][3] = *reinterpret_cast<const bf16x8*>(pr + 32);
+    } else {
+      const uint16_t* qr = qkv + (row0 + fcl) * ld_qkv + h * 64 + lg * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) xf[nf][ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 32 + lg * 8);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        float qf[8], qa[8], qb[8];
+        ab_unpack8(*reinterpret_cast<const uint4*>(qr + 32 * k2), qf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          qa[e] = qf[e] + bias_u[h * 64 + 32 * k2 + lg * 8 + e];
+          qb[e] = qf[e] + bias_v[h * 64 + 32 * k2 + lg * 8 + e];
+        }
+        xf[nf][k2] = __builtin_bit_cast(bf16x8, ab_pack8(qa));
+        xf[nf][2 + k2] = __builtin_bit_cast(bf16x8, ab_pack8(qb));
+      }
+    }
     const uint16_t* yr = KEYS_FIXED ? qkv + (row0 + fcl) * ld_qkv + 512 + h * 64 : dctx + (row0 + fcl) * ld_dctx + h * 64;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) yf[nf][ks] = *reinterpret_cast<const bf16x8*>(yr + ks * 32 + lg * 8);
@@ -215,7 +199,15 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
     for (int i = 0; i < 4; ++i) acc_y[nf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const uint16_t* sx = KEYS_FIXED ? ws.q(bh) : ws.k(bh);
+  // streamed X' rows, built while they are staged: chunk xc_ of a row = 8 of its 128 features.  Keys fixed: Q' = [q + u | q + v]: the
+  // thread's bias vector (u for chunks 0..7, v for 8..15) is added between the register stage and the LDS store; queries fixed:
+  // K' = [k | p]: chunks 0..7 from qkv, 8..15 from pos.  Rows past T are zeros (as the prep launch wrote them).
+  float xbias[8];
+  {
+    const int xc0 = tid & 15;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xbias[e] = KEYS_FIXED ? (xc0 < 8 ? bias_u : bias_v)[h * 64 + (xc0 & 7) * 8 + e] : 0.0f;
+  }
   const int n_st = Tp / 64;
   // Staging registers (named, filled by macros: arrays captured by lambdas end up in scratch).  The global loads of
   // streamed tile st+1 are issued right after tile st is published to LDS and stay in flight during its MFMAs.
@@ -239,14 +231,23 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
       dst = KEYS_FIXED ? *reinterpret_cast<const uint4*>(dctx + (row0 + (s0_) + r_) * ld_dctx + h * 64 + yc_ * 8)      \
                        : *reinterpret_cast<const uint4*>(qkv + (row0 + (s0_) + r_) * ld_qkv + 512 + h * 64 + yc_ * 8); \
   }
+#define MA_AB_XLOAD(dst, i, s0_)                                                                                       \
+  {                                                                                                                    \
+    /* keys fixed: row xr_ + 16 i, chunk xc_ of 16 (q piece xc_ & 7, + u or v at the store); queries fixed: rows yr_ + 32 (i & 1),  */ \
+    /* the k piece yc_ (i < 2) or the p piece yc_ (i >= 2): every load instruction is uniform over the wave                         */ \
+    const int t_ = (s0_) + (KEYS_FIXED ? xr_ + 16 * (i) : yr_ + 32 * ((i) & 1));                                       \
+    dst = make_uint4(0, 0, 0, 0);                                                                                      \
+    if (t_ < T) {                                                                                                      \
+      if (KEYS_FIXED) dst = *reinterpret_cast<const uint4*>(qkv + (row0 + t_) * ld_qkv + h * 64 + (xc_ & 7) * 8);      \
+      else if ((i) < 2) dst = *reinterpret_cast<const uint4*>(qkv + (row0 + t_) * ld_qkv + 256 + h * 64 + yc_ * 8);    \
+      else dst = *reinterpret_cast<const uint4*>(pos + (int64_t)t_ * ld_pos + h * 64 + yc_ * 8);                       \
+    }                                                                                                                  \
+  }
 #define MA_AB_FETCH(st_)                                                                                               \
   {                                                                                                                    \
     MA_AB_IDX                                                                                                          \
     const int s0f_ = (st_)*64;                                                                                         \
-    rx0 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_) * 128 + xc_ * 8);                                 \
-    rx1 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 16) * 128 + xc_ * 8);                            \
-    rx2 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 32) * 128 + xc_ * 8);                            \
-    rx3 = *reinterpret_cast<const uint4*>(sx + (int64_t)(s0f_ + xr_ + 48) * 128 + xc_ * 8);                            \
+    MA_AB_XLOAD(rx0, 0, s0f_) MA_AB_XLOAD(rx1, 1, s0f_) MA_AB_XLOAD(rx2, 2, s0f_) MA_AB_XLOAD(rx3, 3, s0f_)              \
     MA_AB_YLOAD(ry0, 0, s0f_) MA_AB_YLOAD(ry1, 1, s0f_)                                                                \
     if (tidv < 64) {                                                                                                   \
       const int si_ = s0f_ + tidv;                                                                                     \
@@ -276,10 +277,20 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
   for (int st = 0; st < n_st; ++st) {
     __syncthreads();  // previous tile fully consumed
     MA_AB_IDX
-    *reinterpret_cast<uint4*>(&Xs[(xr_)*kXs + xc_ * 8]) = rx0;
-    *reinterpret_cast<uint4*>(&Xs[(xr_ + 16) * kXs + xc_ * 8]) = rx1;
-    *reinterpret_cast<uint4*>(&Xs[(xr_ + 32) * kXs + xc_ * 8]) = rx2;
-    *reinterpret_cast<uint4*>(&Xs[(xr_ + 48) * kXs + xc_ * 8]) = rx3;
+    auto xrow = [&](uint4 v, int i) __attribute__((always_inline)) {
+      if (KEYS_FIXED && st * 64 + xr_ + 16 * i < T) {  // q -> bf16(q + u) or bf16(q + v)
+        float f[8];
+        ab_unpack8(v, f);
+        v = make_uint4(ab_pack(f[0] + xbias[0], f[1] + xbias[1]), ab_pack(f[2] + xbias[2], f[3] + xbias[3]),
+                       ab_pack(f[4] + xbias[4], f[5] + xbias[5]), ab_pack(f[6] + xbias[6], f[7] + xbias[7]));
+      }
+      if (KEYS_FIXED) *reinterpret_cast<uint4*>(&Xs[(xr_ + 16 * i) * kXs + xc_ * 8]) = v;
+      else *reinterpret_cast<uint4*>(&Xs[(yr_ + 32 * (i & 1)) * kXs + 64 * (i >> 1) + yc_ * 8]) = v;
+    };
+    xrow(rx0, 0);
+    xrow(rx1, 1);
+    xrow(rx2, 2);
+    xrow(rx3, 3);
     *reinterpret_cast<uint4*>(&Ys[(yr_)*kYs + yc_ * 8]) = ry0;
     *reinterpret_cast<uint4*>(&Ys[(yr_ + 32) * kYs + yc_ * 8]) = ry1;
     if (tid < 64) {
@@ -373,6 +384,7 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
 #undef MA_AB_FETCH
 #undef MA_AB_IDX
 #undef MA_AB_YLOAD
+#undef MA_AB_XLOAD
   // ---- outputs: lane holds rows c = ct*16 + lg*4 + r of the transposed result for its fixed item -----------------
   // (output addresses from opaque copies of the block indices: computed here, not hoisted above the loop and spilled across it)
   int hv = h, bv = b;
@@ -475,7 +487,7 @@ extern "C" {
 int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k) {
   if (batch < 1 || T < 1 || heads < 1 || d_k != 64) return MA_ERR_INVALID_ARG;
   const int64_t Tp = (T + 63) / 64 * 64;
-  return batch * heads * Tp * (128 * 4 + 64) * 2 + batch * heads * Tp * 4 + batch * heads * (Tp / 64) * 128 * 4 + batch * Tp * 256 * 4 + 256;
+  return batch * heads * Tp * 4 + batch * heads * (Tp / 64) * 128 * 4 + batch * Tp * 256 * 4 + 256;
 }
 
 // Where the partial sums lie in the workspace (float offsets from its start), for a caller that reduces them itself (dpos == NULL):
@@ -486,8 +498,7 @@ int ma_relpos_attention_bwd_layout(int64_t batch, int64_t T, int32_t heads, int3
   if (batch < 1 || T < 1 || heads < 1 || d_k != 64 || !dp_part_off || !bias_part_off || !Tp_out || !parts_per_head)
     return MA_ERR_INVALID_ARG;
   const int64_t Tp = (T + 63) / 64 * 64;
-  const int64_t base_floats = batch * heads * Tp * (128 * 4 + 64) / 2;  // the bf16 operand copies, in floats
-  *bias_part_off = base_floats + batch * heads * Tp;
+  *bias_part_off = batch * heads * Tp;  // behind D
   *dp_part_off = *bias_part_off + batch * heads * (Tp / 64) * 128;
   *Tp_out = (int32_t)Tp;
   *parts_per_head = (int32_t)(batch * (Tp / 64));
@@ -513,27 +524,27 @@ static int relpos_attention_bwd(const void* qkv, int64_t ld_qkv, const void* pos
   AttnWs ws;
   ws.Tp = (int)((T + 63) / 64 * 64);
   ws.base = reinterpret_cast<uint16_t*>(workspace);
-  ws.D = reinterpret_cast<float*>(ws.base + batch * heads * ws.per_bh());
+  ws.D = reinterpret_cast<float*>(workspace);
   ws.bias_part = ws.D + batch * heads * ws.Tp;
   ws.dp_part = ws.bias_part + batch * heads * (ws.Tp / 64) * 128;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)(ws.Tp / 64), (unsigned)heads, (unsigned)batch);
   const float scale = 1.0f / sqrtf((float)d_k);
-  MA_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
-            bias_u, bias_v, (const uint16_t*)ctx, ld_ctx, (const uint16_t*)dctx, ld_dctx, (int)T, (int)heads, ws);
+  MA_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, s, (const uint16_t*)ctx, ld_ctx, (const uint16_t*)dctx, ld_dctx, (int)T,
+            (int)heads, ws);
   const int nfq = mask3 ? 1 : kAbNF, nfk = mask3 ? 1 : kAbNFK;
   const dim3 grid_f((unsigned)((ws.Tp + 64 * nfq - 1) / (64 * nfq)), (unsigned)heads, (unsigned)batch);
   const dim3 grid_k((unsigned)((ws.Tp + 64 * nfk - 1) / (64 * nfk)), (unsigned)heads, (unsigned)batch);
   if (mask3) {
-    MA_LAUNCH((attn_bwd_kernel<true, 1, true>), grid_k, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
-              mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
-    MA_LAUNCH((attn_bwd_kernel<false, 1, true>), grid_f, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx, ld_dctx,
-              mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+    MA_LAUNCH((attn_bwd_kernel<true, 1, true>), grid_k, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
+              bias_u, bias_v, (const uint16_t*)dctx, ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+    MA_LAUNCH((attn_bwd_kernel<false, 1, true>), grid_f, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
+              bias_u, bias_v, (const uint16_t*)dctx, ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   } else {
-    MA_LAUNCH((attn_bwd_kernel<true, kAbNFK, false>), grid_k, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx,
-              ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
-    MA_LAUNCH((attn_bwd_kernel<false, kAbNF, false>), grid_f, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)dctx,
-              ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+    MA_LAUNCH((attn_bwd_kernel<true, kAbNFK, false>), grid_k, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos, bias_u, bias_v,
+              (const uint16_t*)dctx, ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
+    MA_LAUNCH((attn_bwd_kernel<false, kAbNF, false>), grid_f, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos, bias_u, bias_v,
+              (const uint16_t*)dctx, ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   }
   if (!dpos) return MA_OK;  // the per-batch / per-workgroup partials stay in the workspace for the caller's batched reduction
   MA_LAUNCH(attn_dpos_reduce_kernel, dim3((unsigned)T), dim3(256), 0, s, ws.dp_part, (int)batch, (int)T, ws.Tp, dpos,

@@ -784,16 +784,32 @@ __device__ __forceinline__ void ld8(const float* p, float (&d)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
 }
-template <typename AT>
+// XLDS (round 4): the input rows the strip's positions touch (3 per output row, normalised once) are staged in LDS: per position a
+// thread then issues ONE global load (its 16 bytes of the gradient) and 9 LDS reads instead of 9 global input loads + 18 CMVN loads
+// that its 32-lane channel group repeated (198 us for the cfg-4 batch, load-issue bound, against ~70 us of gradient bytes).
+template <typename AT, bool XLDS>
 __global__ __launch_bounds__(256) void conv1_dw8_kernel(const AT* __restrict__ dact, const float* __restrict__ x, int B, int T,
                                                         int idim, int H1, int W1, int C, const float* __restrict__ cm_mean,
                                                         const float* __restrict__ cm_istd, float* __restrict__ part, int strip) {
   __shared__ float red[4][32][81];  // [wave][channel group][8 channels x (9 taps + bias)] (+1: bank spread)
+  extern __shared__ float xs_l[];   // XLDS: [output rows of the strip][3][idim]
   const int tid = threadIdx.x, cg = tid & 31, pg = tid >> 5;
   const int c0 = cg * 8;
   const bool live = c0 < C;
   const int npos = B * H1 * W1;
   const int p0 = blockIdx.x * strip, p1 = min(npos, p0 + strip);
+  const int q0 = p0 / W1;  // first output row (b * H1 + h1) of the strip
+  if (XLDS) {
+    const int nq = (p1 - 1) / W1 - q0 + 1;
+    for (int i = tid; i < nq * 3 * idim; i += 256) {
+      const int hr = i / (3 * idim), rem = i - hr * 3 * idim, kh = rem / idim, col = rem - kh * idim;
+      const int q = q0 + hr, bq = q / H1, hq = q - bq * H1;
+      float v = x[((int64_t)bq * T + 2 * hq + kh) * idim + col];
+      if (cm_mean) v = (v - cm_mean[col]) * cm_istd[col];
+      xs_l[i] = v;
+    }
+    __syncthreads();
+  }
   float acc[8][9], accb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -811,16 +827,24 @@ __global__ __launch_bounds__(256) void conv1_dw8_kernel(const AT* __restrict__ d
 #pragma unroll
       for (int e = 0; e < 8; ++e) d[e] = 0.0f;
     }
-    const float* xr = x + ((int64_t)b * T + 2 * h1) * idim + 2 * w1;
     float xv[9];
+    if (XLDS) {
+      const float* xl = xs_l + (b * H1 + h1 - q0) * 3 * idim + 2 * w1;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        float v = xr[kh * idim + kw];
-        if (cm_mean) v = (v - cm_mean[2 * w1 + kw]) * cm_istd[2 * w1 + kw];
-        xv[kh * 3 + kw] = v;
-      }
+        for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xl[kh * idim + kw];
+    } else {
+      const float* xr = x + ((int64_t)b * T + 2 * h1) * idim + 2 * w1;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float v = xr[kh * idim + kw];
+          if (cm_mean) v = (v - cm_mean[2 * w1 + kw]) * cm_istd[2 * w1 + kw];
+          xv[kh * 3 + kw] = v;
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       accb[e] += d[e];
@@ -1290,9 +1314,13 @@ static int conv1_dw_launch(const AT* dact, const float* x, int64_t batch, int64_
   int64_t strip64 = (npos + kMaxPartBlocks - 1) / kMaxPartBlocks;  // as many workgroups as the partial workspace holds
   const int strip = (int)(strip64 < 64 ? 64 : strip64);
   const int nblk = (int)((npos + strip - 1) / strip);
-  if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(dact) & 15) == 0)
-    MA_LAUNCH(conv1_dw8_kernel<AT>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dact, x, (int)batch, (int)T, idim, H1,
-              W1, C, cmvn_mean, cmvn_istd, part, strip);
+  const size_t xl_bytes = (size_t)(strip / W1 + 2) * 3 * idim * sizeof(float);  // the strip's input rows
+  if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(dact) & 15) == 0 && xl_bytes <= 20 * 1024)
+    MA_LAUNCH((conv1_dw8_kernel<AT, true>), dim3((unsigned)nblk), dim3(256), xl_bytes, (hipStream_t)stream, dact, x, (int)batch, (int)T,
+              idim, H1, W1, C, cmvn_mean, cmvn_istd, part, strip);
+  else if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(dact) & 15) == 0)
+    MA_LAUNCH((conv1_dw8_kernel<AT, false>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dact, x, (int)batch, (int)T, idim,
+              H1, W1, C, cmvn_mean, cmvn_istd, part, strip);
   else
     MA_LAUNCH(conv1_dw_kernel<AT>, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,
               (hipStream_t)stream, dact, x, (int)batch, (int)T, idim, H1, W1, C, cmvn_mean, cmvn_istd, part, strip);

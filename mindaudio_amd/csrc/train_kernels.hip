@@ -185,8 +185,17 @@ __global__ __launch_bounds__(256) void bn_dsum_reduce_kernel(const float* __rest
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + tx, n = 2 * C;
   float s = 0.0f;
-  if (j < n)
-    for (int b = ty; b < nblk; b += 16) s += part[(int64_t)b * n + j];
+  if (j < n) {
+    int b = ty;
+    for (; b + 7 * 16 < nblk; b += 8 * 16) {  // eight partials in flight, same summation order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + 16 * u) * n + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nblk; b += 16) s += part[(int64_t)b * n + j];
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && j < n) {
@@ -432,11 +441,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + tx;
   float a = 0.0f, q = 0.0f;
-  if (c < C)
-    for (int b = ty; b < nparts; b += 16) {
+  if (c < C) {
+    // eight partials of a thread in flight (16 workgroups in all: as a plain loop the launch was a chain of nparts / 16 dependent
+    // round trips, 9 us); the summation order is unchanged
+    int b = ty;
+    for (; b + 7 * 16 < nparts; b += 8 * 16) {
+      float va[8], vq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        va[u] = sums[(int64_t)(b + 16 * u) * 2 * C + c];
+        vq[u] = sums[(int64_t)(b + 16 * u) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a += va[u];
+        q += vq[u];
+      }
+    }
+    for (; b < nparts; b += 16) {
       a += sums[(int64_t)b * 2 * C + c];
       q += sums[(int64_t)b * 2 * C + C + c];
     }
+  }
   red[0][ty][tx] = a;
   red[1][ty][tx] = q;
   __syncthreads();

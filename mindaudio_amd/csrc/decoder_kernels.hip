@@ -131,9 +131,12 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn<AT> 
   float (*Qs)[kSmD + 4] = reinterpret_cast<float (*)[kSmD + 4]>(S + kSmQ * ss);
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int Lq = p.Lq, Lk = p.Lk;
-  for (int i = tid; i < kSmQ * kSmD; i += 256) {
-    const int qi = i / kSmD, d = i % kSmD;
-    Qs[qi][d] = qi < Lq ? d_ld(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d) : 0.0f;
+  for (int i = tid; i < kSmQ * (kSmD / 8); i += 256) {  // 16-byte pieces (round 4; single elements before)
+    const int qi = i / (kSmD / 8), ch = i % (kSmD / 8);
+    float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (qi < Lq) d_ld8(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8, t8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Qs[qi][ch * 8 + e] = t8[e];
   }
   if constexpr (STAGE)
     for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
@@ -229,11 +232,18 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
   float* Dq = reinterpret_cast<float*>(dOs + kSmQ);
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int Lq = p.Lq, Lk = p.Lk;
-  for (int i = tid; i < kSmQ * kSmD; i += 256) {
-    const int qi = i / kSmD, d = i % kSmD;
-    const bool in = qi < Lq;
-    Qs[qi][d] = in ? d_ld(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + d) : 0.0f;
-    dOs[qi][d] = in ? d_ld(dctx + ((int64_t)b * Lq + qi) * lddc + h * kSmD + d) : 0.0f;
+  for (int i = tid; i < kSmQ * (kSmD / 8); i += 256) {  // 16-byte pieces (round 4; single elements before)
+    const int qi = i / (kSmD / 8), ch = i % (kSmD / 8);
+    float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, u8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (qi < Lq) {
+      d_ld8(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8, t8);
+      d_ld8(dctx + ((int64_t)b * Lq + qi) * lddc + h * kSmD + ch * 8, u8);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      Qs[qi][ch * 8 + e] = t8[e];
+      dOs[qi][ch * 8 + e] = u8[e];
+    }
   }
   if constexpr (STAGE)
     for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
@@ -250,7 +260,13 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
   if (tid < Lq) {
     float s = 0.0f;
     const AT* op = ctx + ((int64_t)b * Lq + tid) * ldc + h * kSmD;
-    for (int d = 0; d < kSmD; ++d) s = fmaf(dOs[tid][d], d_ld(op + d), s);
+#pragma unroll
+    for (int c8 = 0; c8 < kSmD / 8; ++c8) {
+      float t8[8];
+      d_ld8(op + c8 * 8, t8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(dOs[tid][c8 * 8 + e], t8[e], s);
+    }
     Dq[tid] = s;
   }
   __syncthreads();
@@ -295,10 +311,17 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
     }
     AT* dvp = dv + ((int64_t)b * Lk + j) * lddv + h * kSmD;
     AT* dkp = dk + ((int64_t)b * Lk + j) * lddk + h * kSmD;
+    // (16-byte stores: as 128 two-byte stores per thread, each instruction was 64 scattered 2-byte writes)
 #pragma unroll
-    for (int d = 0; d < kSmD; ++d) {
-      d_st(dvp + d, dvr[d]);
-      d_st(dkp + d, dkr[d]);
+    for (int c8 = 0; c8 < kSmD / 8; ++c8) {
+      float t8[8], u8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        t8[e] = dvr[c8 * 8 + e];
+        u8[e] = dkr[c8 * 8 + e];
+      }
+      d_st8(dvp + c8 * 8, t8);
+      d_st8(dkp + c8 * 8, u8);
     }
   }
   __syncthreads();
@@ -433,7 +456,8 @@ static int fill_small(SmallAttn<AT>& a, const void* q, int64_t ldq, const void* 
                       const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k,
                       float scale) {
   if (!q || !k || !v || batch < 1 || Lq < 1 || Lk < 1 || heads < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
-  if (d_k != kSmD || Lq > kSmQ || Lk > kSmKMax || (ldk & 7) || (ldv & 7)) return MA_ERR_UNSUPPORTED;
+  if (d_k != kSmD || Lq > kSmQ || Lk > kSmKMax || (ldq & 7) || (ldk & 7) || (ldv & 7)) return MA_ERR_UNSUPPORTED;  // 16-byte row pieces
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) return MA_ERR_INVALID_ARG;
   if (mask_mode < 0 || mask_mode > 2 || (mask_mode && !mask)) return MA_ERR_INVALID_ARG;
   a.q = (const AT*)q; a.k = (const AT*)k; a.v = (const AT*)v;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
@@ -475,7 +499,10 @@ static int mha_small_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk,
   SmallAttn<AT> a;
   const int rc = fill_small(a, q, ldq, k, ldk, v, ldv, nullptr, 0, batch, Lq, Lk, heads, d_k, scale);
   if (rc != MA_OK) return rc;
-  if (!probs || !ctx || !dctx || !dq || !dk || !dv || (lddq & 7) || (lddk & 1) || (lddv & 1)) return MA_ERR_INVALID_ARG;
+  if (!probs || !ctx || !dctx || !dq || !dk || !dv || (lddq & 7) || (lddk & 7) || (lddv & 7) || (ldc & 7) || (lddc & 7)) return MA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(dctx) | reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) |
+       reinterpret_cast<uintptr_t>(dv)) & 15)
+    return MA_ERR_INVALID_ARG;
   MA_LDS_ATTR_T((mha_small_bwd_kernel<false, AT>), 163840);
   if constexpr (sizeof(AT) == 2) MA_LDS_ATTR_T((mha_small_bwd_kernel<true, AT>), 163840);
   if constexpr (sizeof(AT) == 2) {

@@ -295,7 +295,7 @@ def test_adam_and_overflow(K):
 
 
 @pytest.mark.parametrize("chunked", [False, True])
-@pytest.mark.parametrize("b,t", [(2, 100), (3, 255), (1, 64), (2, 37)])
+@pytest.mark.parametrize("b,t", [(2, 100), (3, 255), (1, 64), (2, 37), (2, 300), (1, 129)])
 def test_attention_backward(K, b, t, chunked):
     g = torch.Generator().manual_seed(7 + t)
     h, dk = 4, 64

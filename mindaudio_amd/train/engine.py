@@ -1015,10 +1015,11 @@ class ConformerCTCTrainStep:
 
     # ---- the blocks, fused: dense layers on fragment-packed weights with their element-wise neighbours in the epilogue ---------------
     def _blocks_forward_fused(self, x, c):
-        """models/conformer.py:100-161 in training mode.  Per block 12 launches instead of 23: [w_1 + Swish + dropout] -> [w_2 + dropout +
-        residual + LayerNorm of the next cell] for the two feed-forward modules, linear_q/k/v -> attention -> [linear_out + dropout +
-        residual + norm_conv * mask], pointwise_conv1 -> depthwise / BatchNorm statistics / BatchNorm + Swish -> [pointwise_conv2 * mask +
-        dropout + residual + norm_ff]; the last join of a block also applies norm_final and the LayerNorm that consumes it."""
+        """models/conformer.py:100-161 in training mode.  Per block 10 launches (23 un-fused; 12 in round 3): each feed-forward module
+        is ONE launch (ffn_one_launch: w_1 + Swish + dropout -> the tape, w_2 + dropout + residual + the LayerNorm of the next cell; the
+        two-launch form [w_1 ...] -> [w_2 ...] stays behind the switch), linear_q/k/v -> attention -> [linear_out + dropout + residual +
+        norm_conv * mask], pointwise_conv1 -> depthwise / BatchNorm statistics / BatchNorm + Swish -> [pointwise_conv2 * mask + dropout +
+        residual + norm_ff]; the last module of a block also applies norm_final and the LayerNorm that consumes it."""
         fp, d, L, K = self.fp, self.d, self.L, self.K
         seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         hid = self.hidden
@@ -1066,8 +1067,11 @@ class ConformerCTCTrainStep:
         return x, a, tape
 
     def _blocks_backward_fused(self, g, tape, dpos_all, c):
-        """Per block 28 launches instead of 40: every LayerNorm backward also emits the dropout backward of the branch in front of it
-        (bf16 dy), the input gradients run on packed transposed weights, and dh -> du (Swish', dropout) rides on the w_2 product."""
+        """Per block 18 launches (40 un-fused; 28 in round 3): each feed-forward module's backward is ONE launch (ffn_bwd_one_launch:
+        dh -> du -> da -> the LayerNorm backward in front of the module + the next branch's dropout backward), the other LayerNorm
+        backwards ride on the input-gradient product that feeds them (ln_bwd_fused) or emit the dropout backward of the branch in front
+        of them (bf16 dy), the input gradients run on packed transposed weights, and the weight gradients are queued for the direct
+        groups (_dW)."""
         fp, d, L, K = self.fp, self.d, self.L, self.K
         seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         hid = self.hidden

@@ -1067,7 +1067,7 @@ class ConformerCTCTrainStep:
         return x, a, tape
 
     def _blocks_backward_fused(self, g, tape, dpos_all, c):
-        """Per block 18 launches (40 un-fused; 28 in round 3): each feed-forward module's backward is ONE launch (ffn_bwd_one_launch:
+        """Per block 16 launches (40 un-fused; 28 in round 3): each feed-forward module's backward is ONE launch (ffn_bwd_one_launch:
         dh -> du -> da -> the LayerNorm backward in front of the module + the next branch's dropout backward), the other LayerNorm
         backwards ride on the input-gradient product that feeds them (ln_bwd_fused) or emit the dropout backward of the branch in front
         of them (bf16 dy), the input gradients run on packed transposed weights, and the weight gradients are queued for the direct

@@ -187,6 +187,54 @@ struct SmallAttn {
   float scale;
 };
 
+// out[q][16 w + c] (q < Lq, bf16) = sum_j S[q][j] X[j][16 w + c] for the 32 query rows of a (batch, head) on the matrix cores (round 4;
+// the context rows P . V of the forward and dq = dS . K of the backward, staged form only): wave w owns output columns 16 w .. + 15
+// of both 16-row tiles.  A operand = S rows (float32 in LDS, odd row stride: 8 single reads per fragment, rounded to bf16 here - as
+// the encoder's attention rounds P; keys past Lk read as zero), B operand = X rows (bf16, row-major [key][64] in LDS) through
+// ds_read_b64_tr_b16: the 16 lanes of a group address rows lg * 8 + la (+ 4) x 16 columns and each receives one column's four rows.
+// As FMA loops (thread = (query, 8 d's), one key per iteration: LDS read of S, 16 bytes of X, 8 conversions, 8 FMAs) these two
+// products were 14 of the forward's 39 us and 14 of the backward's 46 us at 255 keys.
+typedef short sm_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) sm_v4s sm_lds_v4s;
+typedef __attribute__((ext_vector_type(8))) __bf16 sm_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float sm_f32x4;
+__device__ __forceinline__ void sm_rows_times_tile(const float* S, int ss, const uint16_t (*X)[64], int Lq, int Lk, uint16_t* out,
+                                                   int64_t ldo) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lq = lane & 15, lg = lane >> 4, la = lq >> 2, lb = lq & 3;
+  sm_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int nks = (Lk + 31) >> 5;
+  for (int ks = 0; ks < nks; ++ks) {
+    const uint16_t* x0 = &X[ks * 32 + lg * 8 + la][16 * w + lb * 4];
+    const sm_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sm_lds_v4s*)(x0));
+    const sm_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sm_lds_v4s*)(x0 + 4 * 64));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s bv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const sm_bf16x8 bfrag = __builtin_bit_cast(sm_bf16x8, bv);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const float* sr = S + (16 * qt + lq) * ss + ks * 32 + lg * 8;
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = ks * 32 + lg * 8 + 2 * e;
+        const float p0 = j < Lk ? sr[2 * e] : 0.0f, p1 = j + 1 < Lk ? sr[2 * e + 1] : 0.0f;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[e]) : "v"(p0), "v"(p1));
+      }
+      const uint4 av = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sm_bf16x8, av), bfrag, acc[qt], 0, 0, 0);
+    }
+  }
+  // lane (c = lq, g): rows q = 16 qt + 4 g + r, column 16 w + c
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = 16 * qt + 4 * lg + r;
+      if (q < Lq) out[(int64_t)q * ldo + 16 * w + lq] = d_f2bf(acc[qt][r]);
+    }
+}
+
 // workgroup = (head, batch): thread j owns key j (and j + 256, ...) for the scores, (query, 8 d's) for the context.
 // STAGE: the V rows of the (batch, head) are staged in LDS (Lk <= kSmK, the label-length self-attention and source attention over
 // up to 320 encoder frames); otherwise (source attention over a long utterance: the 3000-frame bucket of conformer.yaml gives
@@ -271,18 +319,21 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn<AT> 
     }
   }
   __syncthreads();
-  const int qi = tid >> 3, dg = (tid & 7) * 8;
-  if (qi < Lq) {
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int jj = 0; jj < Lk; ++jj) {
-      const float pv = S[qi * ss + jj];
-      float t8[8];
-      if constexpr (STAGE) d_ld8(&Vs[jj][dg], t8);
-      else d_ld8(p.v + ((int64_t)b * Lk + jj) * p.ldv + h * kSmD + dg, t8);
+  if constexpr (STAGE) {  // (bf16 activations, V rows in LDS: the matrix cores)
+    sm_rows_times_tile(S, ss, Vs, Lq, Lk, reinterpret_cast<uint16_t*>(ctx) + (int64_t)b * Lq * ldc + h * kSmD, ldc);
+  } else {
+    const int qi = tid >> 3, dg = (tid & 7) * 8;
+    if (qi < Lq) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int jj = 0; jj < Lk; ++jj) {
+        const float pv = S[qi * ss + jj];
+        float t8[8];
+        d_ld8(p.v + ((int64_t)b * Lk + jj) * p.ldv + h * kSmD + dg, t8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pv, t8[e], acc[e]);
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pv, t8[e], acc[e]);
+      }
+      d_st8(ctx + ((int64_t)b * Lq + qi) * ldc + h * kSmD + dg, acc);
     }
-    d_st8(ctx + ((int64_t)b * Lq + qi) * ldc + h * kSmD + dg, acc);
   }
 }
 
@@ -398,18 +449,21 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
     }
   }
   __syncthreads();
-  const int qi = tid >> 3, dg = (tid & 7) * 8;
-  if (qi < Lq) {
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int jj = 0; jj < Lk; ++jj) {
-      const float ds = S[qi * ss + jj];
-      float t8[8];
-      if constexpr (STAGE) d_ld8(&Ks[jj][dg], t8);
-      else d_ld8(p.k + ((int64_t)b * Lk + jj) * p.ldk + h * kSmD + dg, t8);
+  if constexpr (STAGE) {  // dq = dS . K on the matrix cores (dS carries the 1 / d_k scale)
+    sm_rows_times_tile(S, ss, Ks, Lq, Lk, reinterpret_cast<uint16_t*>(dq) + (int64_t)b * Lq * lddq + h * kSmD, lddq);
+  } else {
+    const int qi = tid >> 3, dg = (tid & 7) * 8;
+    if (qi < Lq) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int jj = 0; jj < Lk; ++jj) {
+        const float ds = S[qi * ss + jj];
+        float t8[8];
+        d_ld8(p.k + ((int64_t)b * Lk + jj) * p.ldk + h * kSmD + dg, t8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(ds, t8[e], acc[e]);
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(ds, t8[e], acc[e]);
+      }
+      d_st8(dq + ((int64_t)b * Lq + qi) * lddq + h * kSmD + dg, acc);
     }
-    d_st8(dq + ((int64_t)b * Lq + qi) * lddq + h * kSmD + dg, acc);
   }
 }
 

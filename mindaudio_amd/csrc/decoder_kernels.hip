@@ -467,6 +467,132 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
   }
 }
 
+// The staged backward (bf16, Lk <= kSmK) on the matrix cores (round 4).  LDS: K rows | V rows (bf16 [kcap][64]) | P -> dS (float32
+// [32][kcap + 1]) | Q, dO rows (bf16 [32][72]) | D.  A wave walks the 16-key tiles kt = wave, wave + 4, ...:
+//   dP tile (lane c = key, registers = queries)  = dO rows . V rows^T            4 MFMAs (K = 64 features, two query tiles)
+//   dS = P (dP - D) / d_k in registers, written back over P for the dq product behind the barrier
+//   dV^T (64 x 16 keys) = dO^T . P,  dK^T = Q^T . dS: contraction over the 32 queries = ONE k-step; the A operands are read from
+//   the row-major Q / dO tiles with the transposing LDS read, rows in the k-order in which P / dS sit in the accumulator layout
+//   (attention_bwd.hip); a lane ends up with four consecutive features of its key: 8-byte stores.
+// As a thread-per-key FMA loop (192 values of row state in registers, 31 queries x 192 FMAs behind 48 LDS reads each) this phase
+// was ~17 us of the launch at 255 keys and 14 us at 31 keys, where 31 threads of 256 worked.
+__device__ __forceinline__ uint32_t sm_pack(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__global__ __launch_bounds__(256) void mha_small_bwd_mfma_kernel(const SmallAttn<uint16_t> p, const float* __restrict__ probs,
+                                                                 const uint16_t* __restrict__ ctx, int64_t ldc,
+                                                                 const uint16_t* __restrict__ dctx, int64_t lddc,
+                                                                 uint16_t* __restrict__ dq, int64_t lddq, uint16_t* __restrict__ dk,
+                                                                 int64_t lddk, uint16_t* __restrict__ dv, int64_t lddv, int kcap) {
+  constexpr int kPq = 72;  // bf16 row pitch of the Q / dO tiles (144 B: 16-byte aligned rows, 8-byte aligned transposing reads)
+  extern __shared__ __attribute__((aligned(16))) char sm_lds[];
+  const int ss = kcap + 1;
+  uint16_t (*Ks)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);
+  uint16_t (*Vs)[kSmD] = Ks + kcap;
+  float* S = reinterpret_cast<float*>(sm_lds + 2 * kcap * kSmD * 2);
+  uint16_t* Qb = reinterpret_cast<uint16_t*>(S + kSmQ * ss);
+  uint16_t* dOb = Qb + kSmQ * kPq;
+  float* Dq = reinterpret_cast<float*>(dOb + kSmQ * kPq);
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4, la = lq >> 2, lb = lq & 3;
+  const int Lq = p.Lq, Lk = p.Lk;
+  for (int i = tid; i < kSmQ * (kSmD / 8); i += 256) {
+    const int qi = i / (kSmD / 8), ch = i % (kSmD / 8);
+    uint4 a = make_uint4(0, 0, 0, 0), c = a;
+    if (qi < Lq) {
+      a = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8);
+      c = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * Lq + qi) * lddc + h * kSmD + ch * 8);
+    }
+    *reinterpret_cast<uint4*>(Qb + qi * kPq + ch * 8) = a;
+    *reinterpret_cast<uint4*>(dOb + qi * kPq + ch * 8) = c;
+  }
+  for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
+    const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
+    uint4 a = make_uint4(0, 0, 0, 0), c = a;
+    if (kj < Lk) {
+      a = *reinterpret_cast<const uint4*>(p.k + ((int64_t)b * Lk + kj) * p.ldk + h * kSmD + ch * 8);
+      c = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + ch * 8);
+    }
+    *reinterpret_cast<uint4*>(&Ks[kj][ch * 8]) = a;
+    *reinterpret_cast<uint4*>(&Vs[kj][ch * 8]) = c;
+  }
+  for (int i = tid; i < Lq * Lk; i += 256) {
+    const int qi = i / Lk, jj = i - qi * Lk;
+    S[qi * ss + jj] = probs[(((int64_t)b * p.H + h) * Lq + qi) * Lk + jj];
+  }
+  __syncthreads();
+  if (tid < Lq) {
+    float s = 0.0f;
+    const uint16_t* op = ctx + ((int64_t)b * Lq + tid) * ldc + h * kSmD;
+#pragma unroll
+    for (int c8 = 0; c8 < kSmD / 8; ++c8) {
+      float t8[8], u8[8];
+      d_ld8(op + c8 * 8, t8);
+      d_ld8(dOb + tid * kPq + c8 * 8, u8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(u8[e], t8[e], s);
+    }
+    Dq[tid] = s;
+  }
+  __syncthreads();
+  // A operand of a contraction over the 32 queries from a row-major [32][kPq] tile: 16 features ft, element e of lane (feature lq,
+  // lg) = query (e >> 2) * 16 + lg * 4 + (e & 3)
+  auto tr_frag = [&](const uint16_t* tile, int ft) __attribute__((always_inline)) {
+    const uint16_t* a0 = tile + (lg * 4 + la) * kPq + ft * 16 + lb * 4;
+    const sm_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sm_lds_v4s*)(a0));
+    const sm_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sm_lds_v4s*)(a0 + 16 * kPq));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(sm_bf16x8, v);
+  };
+  for (int kt = wave; kt * 16 < Lk; kt += 4) {
+    const int key = kt * 16 + lq;
+    sm_f32x4 dp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const sm_bf16x8 vf = *reinterpret_cast<const sm_bf16x8*>(&Vs[key][ks * 32 + lg * 8]);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const sm_bf16x8 of = *reinterpret_cast<const sm_bf16x8*>(dOb + (16 * qt + lq) * kPq + ks * 32 + lg * 8);
+        dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of, vf, dp[qt], 0, 0, 0);
+      }
+    }
+    float pv[2][4], ds[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 16 * qt + 4 * lg + r;
+        const bool in = key < Lk && q < Lq;
+        pv[qt][r] = in ? S[q * ss + key] : 0.0f;
+        ds[qt][r] = in ? pv[qt][r] * (dp[qt][r] - Dq[q]) * p.scale : 0.0f;
+        if (in) S[q * ss + key] = ds[qt][r];
+      }
+    const uint4 ppk = make_uint4(sm_pack(pv[0][0], pv[0][1]), sm_pack(pv[0][2], pv[0][3]), sm_pack(pv[1][0], pv[1][1]),
+                                 sm_pack(pv[1][2], pv[1][3]));
+    const uint4 gpk = make_uint4(sm_pack(ds[0][0], ds[0][1]), sm_pack(ds[0][2], ds[0][3]), sm_pack(ds[1][0], ds[1][1]),
+                                 sm_pack(ds[1][2], ds[1][3]));
+    const sm_bf16x8 pf = __builtin_bit_cast(sm_bf16x8, ppk), gf = __builtin_bit_cast(sm_bf16x8, gpk);
+    uint16_t* dvp = dv + ((int64_t)b * Lk + key) * lddv + h * kSmD + 4 * lg;
+    uint16_t* dkp = dk + ((int64_t)b * Lk + key) * lddk + h * kSmD + 4 * lg;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const sm_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const sm_f32x4 av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOb, dt), pf, z, 0, 0, 0);
+      const sm_f32x4 ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qb, dt), gf, z, 0, 0, 0);
+      if (key < Lk) {
+        *reinterpret_cast<uint2*>(dvp + 16 * dt) = make_uint2(sm_pack(av[0], av[1]), sm_pack(av[2], av[3]));
+        *reinterpret_cast<uint2*>(dkp + 16 * dt) = make_uint2(sm_pack(ak[0], ak[1]), sm_pack(ak[2], ak[3]));
+      }
+    }
+  }
+  __syncthreads();
+  sm_rows_times_tile(S, ss, Ks, Lq, Lk, dq + (int64_t)b * Lq * lddq + h * kSmD, lddq);
+}
+MA_LDS_ATTR(mha_small_bwd_mfma_kernel, 163840);
+
 // ---- label smoothing loss --------------------------------------------------------------------------------------
 // one workgroup per token row: kl = sum_v q_v (log q_v - logp_v), q = on at the target, off elsewhere; masked rows
 // contribute nothing.  stats[0] += kl, stats[1] += (argmax == target) * mask, stats[2] += mask.
@@ -635,12 +761,12 @@ static int mha_small_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk,
        reinterpret_cast<uintptr_t>(dv)) & 15)
     return MA_ERR_INVALID_ARG;
   MA_LDS_ATTR_T((mha_small_bwd_kernel<false, AT>), 163840);
-  if constexpr (sizeof(AT) == 2) MA_LDS_ATTR_T((mha_small_bwd_kernel<true, AT>), 163840);
   if constexpr (sizeof(AT) == 2) {
     if (Lk <= kSmK) {
-      constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
-      MA_LAUNCH((mha_small_bwd_kernel<true, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
-                (const AT*)ctx, ldc, (const AT*)dctx, lddc, (AT*)dq, lddq, (AT*)dk, lddk, (AT*)dv, lddv, kSmK);
+      constexpr int lds = 2 * kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * 72 * 2 + kSmQ * 4;
+      MA_LAUNCH(mha_small_bwd_mfma_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
+                (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv,
+                kSmK);
       return MA_OK;
     }
   }

@@ -467,6 +467,87 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
   }
 }
 
+// The staged forward (bf16, Lk <= kSmK) on the matrix cores (round 4).  LDS: V rows (bf16 [kcap][64]) | S -> P (float32 [32][kcap + 1])
+// | Q rows (bf16 [32][72]).  Scores: a wave walks the 16-key tiles kt = wave, wave + 4, ...: S tile (lane c = key, registers = queries)
+// = Q rows . K rows^T with the K fragments straight from global memory (16 bytes per lane and k-step), scale and masks applied in
+// registers; softmax by rows as before; P . V through sm_rows_times_tile.  (As a thread-per-key FMA loop the scores were 5 - 6 us of
+// the launch, with 31 of 256 threads at work for the label self-attention.)
+__global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn<uint16_t> p, uint16_t* __restrict__ ctx, int64_t ldc,
+                                                                 float* __restrict__ probs, int kcap) {
+  constexpr int kPq = 72;
+  extern __shared__ __attribute__((aligned(16))) char sm_lds[];
+  const int ss = kcap + 1;
+  uint16_t (*Vs)[kSmD] = reinterpret_cast<uint16_t (*)[kSmD]>(sm_lds);
+  float* S = reinterpret_cast<float*>(sm_lds + kcap * kSmD * 2);
+  uint16_t* Qb = reinterpret_cast<uint16_t*>(S + kSmQ * ss);
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4;
+  const int Lq = p.Lq, Lk = p.Lk;
+  for (int i = tid; i < kSmQ * (kSmD / 8); i += 256) {
+    const int qi = i / (kSmD / 8), ch = i % (kSmD / 8);
+    uint4 a = make_uint4(0, 0, 0, 0);
+    if (qi < Lq) a = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8);
+    *reinterpret_cast<uint4*>(Qb + qi * kPq + ch * 8) = a;
+  }
+  for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
+    const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (kj < Lk) val = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + ch * 8);
+    *reinterpret_cast<uint4*>(&Vs[kj][ch * 8]) = val;
+  }
+  __syncthreads();
+  for (int kt = wave; kt * 16 < Lk; kt += 4) {
+    const int key = kt * 16 + lq, keyc = key < Lk ? key : Lk - 1;
+    const uint16_t* kp = p.k + ((int64_t)b * Lk + keyc) * p.ldk + h * kSmD + lg * 8;
+    const sm_bf16x8 kf0 = *reinterpret_cast<const sm_bf16x8*>(kp), kf1 = *reinterpret_cast<const sm_bf16x8*>(kp + 32);
+    sm_f32x4 sc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const uint16_t* qr = Qb + (16 * qt + lq) * kPq + lg * 8;
+      sc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const sm_bf16x8*>(qr), kf0, sc[qt], 0, 0, 0);
+      sc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const sm_bf16x8*>(qr + 32), kf1, sc[qt], 0, 0, 0);
+    }
+    if (key < Lk) {
+      const float madd1 = (p.mask_mode == 1 && p.mask[(int64_t)b * Lk + key] == 0.0f) ? -10000.0f : 0.0f;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * qt + 4 * lg + r;
+          if (q >= Lq) continue;
+          float sv = sc[qt][r] * p.scale + madd1;
+          if (p.mask_mode == 2 && p.mask[((int64_t)b * Lq + q) * Lk + key] == 0.0f) sv += -10000.0f;
+          S[q * ss + key] = sv;
+        }
+    }
+  }
+  __syncthreads();
+  for (int i = wave; i < Lq; i += 4) {  // softmax of row i by wave (i % 4)
+    float m = -INFINITY;
+    for (int jj = lane; jj < Lk; jj += 64) m = fmaxf(m, S[i * ss + jj]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float sum = 0.0f;
+    for (int jj = lane; jj < Lk; jj += 64) {
+      const float e = __expf(S[i * ss + jj] - m);
+      S[i * ss + jj] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float inv = 1.0f / sum;
+    float* pr = probs + (((int64_t)b * p.H + h) * Lq + i) * Lk;
+    for (int jj = lane; jj < Lk; jj += 64) {
+      const float pv = S[i * ss + jj] * inv;
+      S[i * ss + jj] = pv;
+      pr[jj] = pv;
+    }
+  }
+  __syncthreads();
+  sm_rows_times_tile(S, ss, Vs, Lq, Lk, ctx + (int64_t)b * Lq * ldc + h * kSmD, ldc);
+}
+MA_LDS_ATTR(mha_small_fwd_mfma_kernel, 163840);
+
 // The staged backward (bf16, Lk <= kSmK) on the matrix cores (round 4).  LDS: K rows | V rows (bf16 [kcap][64]) | P -> dS (float32
 // [32][kcap + 1]) | Q, dO rows (bf16 [32][72]) | D.  A wave walks the 16-key tiles kt = wave, wave + 4, ...:
 //   dP tile (lane c = key, registers = queries)  = dO rows . V rows^T            4 MFMAs (K = 64 features, two query tiles)
@@ -732,12 +813,11 @@ static int mha_small_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk,
   if (rc != MA_OK) return rc;
   if (!ctx || !probs || (ldc & 7)) return MA_ERR_INVALID_ARG;
   MA_LDS_ATTR_T((mha_small_fwd_kernel<false, AT>), 163840);
-  if constexpr (sizeof(AT) == 2) MA_LDS_ATTR_T((mha_small_fwd_kernel<true, AT>), 163840);
   if constexpr (sizeof(AT) == 2) {
     if (Lk <= kSmK) {
-      constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * (kSmD + 4) * 4;
-      MA_LAUNCH((mha_small_fwd_kernel<true, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
-                (AT*)ctx, ldc, probs, kSmK);
+      constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * 72 * 2;
+      MA_LAUNCH(mha_small_fwd_mfma_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
+                (uint16_t*)ctx, ldc, probs, kSmK);
       return MA_OK;
     }
   }

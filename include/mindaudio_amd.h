@@ -562,6 +562,11 @@ int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, co
  *   (dgamma | dbeta) partials, ma_ffn_train_parts(M) x 512 floats, optional ln_out = the next branch's dropout backward).
  *   Against ma_gemm_k256_train_bf16 mode 2 + ma_gemm_rows_train_bf16 mode 5: swish' comes from the forward's float32 pre-activation
  *   through one bf16 rounding (gk) instead of from the bf16 u.
+ *   `chain` (may be NULL; `lnbwd` then has no ln_out): a SECOND LayerNorm backward on the finished rows, for the LayerNorm whose
+ *   output the rows of g are - residual = its input x2, ln_gamma1 = its weight, ln_mid = its partials: g is REPLACED by
+ *   dLN2/dx(g) (not accumulated), ln_out = dropout(g * alpha * ln_row_scale).  In the Conformer block this is norm_ff_macaron's
+ *   backward of block l followed by norm_final's of block l - 1 (models/conformer.py:109-112, 153-156) without the round trip of g
+ *   through HBM and the launch of ma_layernorm_bwd_next_f32 between them.
  * Both need M * ldu < 2^31 elements.  ma_ffn_train_rows() = rows per workgroup (48). */
 int32_t ma_ffn_train_rows(void);
 int32_t ma_ffn_train_parts(int64_t M);
@@ -569,7 +574,8 @@ int ma_ffn_train_bf16(const void* a, int64_t lda, int64_t M, int32_t hidden, con
                       int64_t ldu, int32_t tape_derivative, float p_hidden, uint32_t seed_hidden, uint32_t salt_hidden, float* out,
                       int64_t ldo, const ma_train_epilogue_t* join, ma_stream_t stream);
 int ma_ffn_train_bwd_bf16(const void* dy, int64_t ldy, int64_t M, int32_t hidden, const void* packed_t, const void* gk, void* du,
-                          int64_t ldu, float* g, int64_t ldg, const ma_train_epilogue_t* lnbwd, ma_stream_t stream);
+                          int64_t ldu, float* g, int64_t ldg, const ma_train_epilogue_t* lnbwd, const ma_train_epilogue_t* chain,
+                          ma_stream_t stream);
 /* Fragment packing of a list of weights in ONE launch (the training step re-packs every layer's weights after the optimizer):
  * items / block_item are DEVICE arrays; kind 0 = ma_gemm_k256_pack_bf16 layout (K = 256), kind 1 = ma_gemm_rows_pack_bf16 layout
  * (N = 256), kind 2 / 3 = the W1 (N = hidden, K = 256) / W2 (N = 256, K = hidden) half of ma_ffn_pack_weights_bf16's format (both

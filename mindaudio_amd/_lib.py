@@ -204,7 +204,8 @@ PROTOTYPES = {
     "ma_ffn_train_rows": (i32, []),
     "ma_ffn_train_parts": (i32, [i64]),
     "ma_ffn_train_bf16": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, i64, i32, f32, u32, u32, vp, i64, ctypes.POINTER(TrainEpilogue), vp]),
-    "ma_ffn_train_bwd_bf16": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, vp, i64, vp, i64, ctypes.POINTER(TrainEpilogue), vp]),
+    "ma_ffn_train_bwd_bf16": (ctypes.c_int, [vp, i64, i64, i32, vp, vp, vp, i64, vp, i64, ctypes.POINTER(TrainEpilogue),
+                                             ctypes.POINTER(TrainEpilogue), vp]),
     "ma_conv2d_3x3s2_dinput_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]),
     "ma_gemm_tn_partial_group_bf16": (ctypes.c_int, [ctypes.POINTER(TnItem), i32, vp]),
     "ma_debug_tn_group_lds": (ctypes.c_int, [i32]),

@@ -100,7 +100,10 @@ struct FfnTrainParams {
   uint32_t thresh16;  // keep <=> 16-bit field >= thresh16
   float inv_keep;
   int32_t tape_gk;    // forward: u receives gk instead
+  int32_t chain;      // backward: a second LayerNorm backward (e2) on the finished rows
   TrainEpi e;         // forward: the join (mode 3): bias = b2, residual, alpha, dropout site, LayerNorm (chain); backward: mode 5
+  TrainEpi e2;        // backward, chain: the LayerNorm whose OUTPUT the rows of g are (x = e2.residual, gamma = e2.ln_g1): g is
+                      // replaced by its backward, dy_next (e2.ln_out) = dropout(g * e2.alpha * ...), partials -> e2.ln_mid
 };
 
 template <int MT, bool BWD>
@@ -487,10 +490,11 @@ __global__ __launch_bounds__(kFtThreads, 1) void ffn_train_kernel(const FfnTrain
   // The epilogue's loads (forward: bias, residual rows; backward: the LayerNorm's input rows, the gradient rows it updates, gamma) go
   // out NOW, into the registers the main loop has just freed: their HBM latency passes under the cross-wave reduction below (as one
   // piece behind it, the epilogue was 7.3 us of a 46 us launch on the timeline, the backward's statistics another 2.7).
-  float4 xh5[BWD ? MT : 1][4];
-  float rstd5[BWD ? MT : 1];
+  float4 xh5[BWD ? MT : 1][4], xh6[BWD ? MT : 1][4];
+  float rstd5[BWD ? MT : 1], rstd6[BWD ? MT : 1];
   JoinLoads<MT> jin;
-  LnTailLoads<MT> tin;
+  LnTailLoads<MT> tin, tin2;
+  const bool chain = BWD && p.chain != 0;
   if constexpr (BWD) {
     lnbwd_stats_load<MT>(p.e, m0, p.M, wave, c, g, xh5);
     lnbwd_tail_load<MT>(p.e, m0, p.M, wave, c, g, p.out, p.ldo, tin);
@@ -545,9 +549,34 @@ __global__ __launch_bounds__(kFtThreads, 1) void ffn_train_kernel(const FfnTrain
   }
   FT_STAMP(6);
   if constexpr (BWD) {
-    lnbwd_stats_compute<MT>(p.e, wave, c, g, reinterpret_cast<float*>(smem + kFtOffRed), xh5, rstd5);
-    lnbwd_tail_compute<MT>(p.e, acc, xh5, rstd5, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem + kFtOffRed2),
-                           (int)blockIdx.x, tin);
+    float* red = reinterpret_cast<float*>(smem + kFtOffRed);
+    float* red2 = reinterpret_cast<float*>(smem + kFtOffRed2);
+    if (chain) {  // the second LayerNorm of the chain: its input rows and gamma (g is not read: it is REPLACED, not accumulated).
+      // (Issued here, behind the reduction: with the accumulators still live they do not fit the register file - 172 B of scratch)
+      lnbwd_stats_load<MT>(p.e2, m0, p.M, wave, c, g, xh6);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) tin2.gam[jt] = *reinterpret_cast<const float4*>(p.e2.ln_g1 + 64 * wave + 16 * jt + 4 * g);
+#pragma unroll
+      for (int s = 0; s < MT; ++s) {
+        const int m = m0 + 16 * s + c;
+        tin2.rsv[s] = 1.0f;
+        tin2.rs2[s] = p.e2.ln_row_scale ? p.e2.ln_row_scale[m < p.M ? m : p.M - 1] : 1.0f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) tin2.gv[s][jt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    lnbwd_stats_compute<MT>(p.e, wave, c, g, red, xh5, rstd5);
+    if (chain) {
+      // norm_ff_macaron's backward of block l leaves g = the gradient of block l - 1's output, which is norm_final's output there:
+      // that LayerNorm's backward follows on the same rows without a round trip of g through HBM and without a launch of its own
+      tc_f32x4 og[4][MT];
+      lnbwd_tail_compute<MT, false, true>(p.e, acc, xh5, rstd5, m0, p.M, wave, c, g, p.out, p.ldo, red2, (int)blockIdx.x, tin, og);
+      lnbwd_stats_compute<MT>(p.e2, wave, c, g, red, xh6, rstd6);
+      lnbwd_tail_compute<MT, true, false>(p.e2, og, xh6, rstd6, m0, p.M, wave, c, g, p.out, p.ldo, red2, (int)blockIdx.x, tin2);
+    } else {
+      lnbwd_tail_compute<MT>(p.e, acc, xh5, rstd5, m0, p.M, wave, c, g, p.out, p.ldo, red2, (int)blockIdx.x, tin);
+    }
   } else {
     train_epi_rows256_compute<MT>(p.e, acc, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem + kFtOffRed), jin);
   }
@@ -597,6 +626,8 @@ static int ffn_train_common(const void* a, int64_t lda, int64_t M, int32_t hidde
   p.hseed = p.thresh16 = 0;
   p.inv_keep = 1.0f;
   p.tape_gk = 0;
+  p.chain = 0;
+  p.e2 = TrainEpi{};
   return MA_OK;
 }
 
@@ -623,13 +654,19 @@ extern "C" int ma_ffn_train_bf16(const void* a, int64_t lda, int64_t M, int32_t 
 
 extern "C" int ma_ffn_train_bwd_bf16(const void* dy, int64_t ldy, int64_t M, int32_t hidden, const void* packed_t, const void* gk,
                                      void* du, int64_t ldu, float* g, int64_t ldg, const ma_train_epilogue_t* lnbwd,
-                                     ma_stream_t stream) {
+                                     const ma_train_epilogue_t* chain, ma_stream_t stream) {
   if (!lnbwd || lnbwd->mode != 5) return MA_ERR_INVALID_ARG;
+  if (chain && (chain->mode != 5 || lnbwd->ln_out || chain->row_scale)) return MA_ERR_INVALID_ARG;  // one dy_next: the chain's
   FfnTrainParams p;
   int rc = ffn_train_common(dy, ldy, M, hidden, packed_t, const_cast<void*>(gk), du, ldu, g, ldg, p);
   if (rc != MA_OK) return rc;
   rc = train_epi_fill5(lnbwd, M, p.e);
   if (rc != MA_OK) return rc;
+  if (chain) {
+    rc = train_epi_fill5(chain, M, p.e2);
+    if (rc != MA_OK) return rc;
+    p.chain = 1;
+  }
   const dim3 grid((unsigned)ma_ffn_train_parts(M));
   MA_LAUNCH((ffn_train_kernel<kFtMT, true>), grid, dim3(kFtThreads), kFtLds, (hipStream_t)stream, p);
   return MA_OK;

@@ -442,10 +442,13 @@ __device__ __forceinline__ void lnbwd_tail_load(const TrainEpi& e, int m0, int M
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) in.gam[jt] = *reinterpret_cast<const float4*>(e.ln_g1 + 64 * wave + 16 * jt + 4 * g);
 }
-template <int MT>
+// DY_F32: dy = acc as it is (a float32 gradient: the second LayerNorm of a chain) instead of bf16(acc) * row_scale.
+// KEEP: the updated rows o = g + dLN/dx(dy) are NOT stored (and no dy_next is emitted): they are handed back in `okeep` for a second
+// LayerNorm backward on the same rows (ffn_train.hip: norm_ff_macaron of block l, then norm_final of block l - 1).
+template <int MT, bool DY_F32 = false, bool KEEP = false>
 __device__ __forceinline__ void lnbwd_tail_compute(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], const float4 (&xv)[MT][4],
                                                    const float (&rstd)[MT], int m0, int M, int wave, int c, int g, float* gout, int64_t ldg,
-                                                   float* red2, int blk, const LnTailLoads<MT>& in);
+                                                   float* red2, int blk, const LnTailLoads<MT>& in, tc_f32x4 (*okeep)[MT] = nullptr);
 template <int MT>
 __device__ __forceinline__ void lnbwd_tail(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], const float4 (&xv)[MT][4], const float (&rstd)[MT],
                                            int m0, int M, int wave, int c, int g, float* gout, int64_t ldg, float* red2, int blk) {
@@ -453,10 +456,10 @@ __device__ __forceinline__ void lnbwd_tail(const TrainEpi& e, tc_f32x4 (&acc)[4]
   lnbwd_tail_load<MT>(e, m0, M, wave, c, g, gout, ldg, in);
   lnbwd_tail_compute<MT>(e, acc, xv, rstd, m0, M, wave, c, g, gout, ldg, red2, blk, in);
 }
-template <int MT>
+template <int MT, bool DY_F32, bool KEEP>
 __device__ __forceinline__ void lnbwd_tail_compute(const TrainEpi& e, tc_f32x4 (&acc)[4][MT], const float4 (&xv)[MT][4],
                                                    const float (&rstd)[MT], int m0, int M, int wave, int c, int g, float* gout, int64_t ldg,
-                                                   float* red2, int blk, const LnTailLoads<MT>& in) {
+                                                   float* red2, int blk, const LnTailLoads<MT>& in, tc_f32x4 (*okeep)[MT]) {
   constexpr int ROWS = 16 * MT;
   const float4 (&gv)[MT][4] = in.gv;
   const float4 (&gam)[4] = in.gam;
@@ -477,9 +480,13 @@ __device__ __forceinline__ void lnbwd_tail_compute(const TrainEpi& e, tc_f32x4 (
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       float v[4] = {acc[jt][s][0], acc[jt][s][1], acc[jt][s][2], acc[jt][s][3]};
-      bf16_round2(v[0], v[1]);
-      bf16_round2(v[2], v[3]);
-      const tc_f32x4 dy = tc_f32x4{v[0] * rsv[s], v[1] * rsv[s], v[2] * rsv[s], v[3] * rsv[s]};
+      if constexpr (!DY_F32) {
+        bf16_round2(v[0], v[1]);
+        bf16_round2(v[2], v[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rsv[s];
+      }
+      const tc_f32x4 dy = tc_f32x4{v[0], v[1], v[2], v[3]};
       acc[jt][s] = dy;
       const float4 xh = xv[s][jt];
       const float w0 = dy[0] * gam[jt].x, w1 = dy[1] * gam[jt].y, w2 = dy[2] * gam[jt].z, w3 = dy[3] * gam[jt].w;
@@ -515,6 +522,10 @@ __device__ __forceinline__ void lnbwd_tail_compute(const TrainEpi& e, tc_f32x4 (
       o.y += rstd[s] * (dy[1] * gam[jt].y - a - xh.y * b);
       o.z += rstd[s] * (dy[2] * gam[jt].z - a - xh.z * b);
       o.w += rstd[s] * (dy[3] * gam[jt].w - a - xh.w * b);
+      if constexpr (KEEP) {
+        okeep[jt][s] = tc_f32x4{o.x, o.y, o.z, o.w};
+        continue;
+      }
       if (live[s]) *reinterpret_cast<float4*>(gout + (int64_t)mrow[s] * ldg + n) = o;
       if (e.ln_out) {
         float v[4] = {o.x * e.alpha * rs2[s], o.y * e.alpha * rs2[s], o.z * e.alpha * rs2[s], o.w * e.alpha * rs2[s]};

@@ -284,6 +284,9 @@ class ConformerCTCTrainStep:
         # ... and its backward pass as well (ma_ffn_train_bwd_bf16: dh -> du -> da -> the LayerNorm backward in front of the module);
         # the forward launch then leaves gk = swish'(.) * keep / (1 - p) on the tape in u's place
         self.ffn_bwd_one_launch = self.ffn_one_launch and self.ln_bwd_fused
+        # ... and norm_final's backward of block l - 1 as a second stage of that launch's tail for block l's macaron module (the rows of
+        # g it has just finished ARE norm_final's output gradient): 11 LayerNorm-backward launches and round trips of g fewer
+        self.ln_final_chained = self.ffn_bwd_one_launch
         self._dw_direct = self.fused and self.dw_group_blocks > 0 and self.d % 256 == 0 and self.hidden % 256 == 0
         if self._wg_on and not self._dw_direct and not self._wg_split_ok:
             raise ValueError("wg_stream=True needs the direct weight-gradient groups (dw_group_blocks > 0, d_model and hidden "
@@ -670,6 +673,8 @@ class ConformerCTCTrainStep:
                 add(base + o + splits * mo * no * 4, gb, mo, mo, mo, splits, 0, False)   # bias: partial column sums
             for site in self._LN_SITES:
                 o, nbytes, parts = off[site]
+                if site == "norm_final" and self._chain_final() and li < self.L - 1:
+                    parts = ffn_parts  # written by block li + 1's macaron backward launch (ln_final_chained)
                 gg = fp.g("l%d.%s.g" % (li, site))  # (g | b): 2 x 256 contiguous floats of the flat gradient
                 assert fp.index["l%d.%s.b" % (li, site)][0] == fp.index["l%d.%s.g" % (li, site)][0] + 256
                 add(base + o, gg, 512, 512, 512, parts, 512, True)
@@ -737,6 +742,10 @@ class ConformerCTCTrainStep:
     def _front_dW(self, name, dy, x, rows_store=None, with_colsum=True):
         o, nbytes, _ = self._front_cur["off"][name]
         self.K.gemm_tn_partial(dy, x, self._front_cur["arena"][o:o + nbytes], with_colsum=with_colsum, rows_store=rows_store)
+
+    def _chain_final(self):
+        """norm_final's backward as the second stage of the block above's macaron backward launch (needs the one-launch forms)."""
+        return self.ln_final_chained and self.ffn_bwd_one_launch and self.ffn_one_launch and self.fused
 
     def _ln_partials(self, site):
         """The arena slice that LayerNorm `site` of the current block writes its per-workgroup partials to (None: immediate sums)."""
@@ -1075,17 +1084,18 @@ class ConformerCTCTrainStep:
         fp, d, L, K = self.fp, self.d, self.L, self.K
         seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         hid = self.hidden
+        chained_dy = None
         for li in reversed(range(L)):
             self._layer_begin(li)
             pre = "l%d." % li
             P, G, PK = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n)), (lambda n, pre=pre: self.pk[pre + n])
             T = tape[li]
 
-            def ffn_bwd(dy, F, key, ln, nxt):
+            def ffn_bwd(dy, F, key, ln, nxt, chain=None):
                 self._dW(dy, F["h"], pre + key + "_w2", pre + key + "_b2")
                 if self.ffn_bwd_one_launch:  # dh -> du -> da -> the LayerNorm backward: one launch (F["u"] holds gk)
                     du, dy_next = K.ffn_train_bwd(dy, PK(key + ".ft"), hid, F["u"], F["x_in"], P(ln + ".g"), g, self._ln_partials(ln),
-                                                  nxt=nxt)
+                                                  nxt=nxt, chain=chain)
                     self._dW(du, F["a"], pre + key + "_w1", pre + key + "_b1")
                     return dy_next
                 du = K.dense_act_drop_bwd(dy, PK(key + "_w2.tk"), hid, F["u"], pd, seed, self._salt(li, 0 if key == "ffm" else 6))
@@ -1099,9 +1109,12 @@ class ConformerCTCTrainStep:
                 return K.layernorm_bwd_next(F["x_in"], P(ln + ".g"), da, g, G(ln + ".g"), G(ln + ".b"), nxt,
                                             partials=self._ln_partials(ln))[1]
 
-            _, dy = K.layernorm_bwd_next(T["final_in"], P("norm_final.g"), g, g, G("norm_final.g"), G("norm_final.b"),
-                                         (0.5, pd, seed, self._salt(li, 7), None), accumulate=False,
-                                         partials=self._ln_partials("norm_final"))
+            if chained_dy is not None:  # norm_final's backward ran in block li + 1's macaron launch (ln_final_chained)
+                dy, chained_dy = chained_dy, None
+            else:
+                _, dy = K.layernorm_bwd_next(T["final_in"], P("norm_final.g"), g, g, G("norm_final.g"), G("norm_final.b"),
+                                             (0.5, pd, seed, self._salt(li, 7), None), accumulate=False,
+                                             partials=self._ln_partials("norm_final"))
             do = ffn_bwd(dy, T["ff"], "ff", "norm_ff", (1.0, pd, seed, self._salt(li, 3), mask_rows))
             # conv module
             C = T["conv"]
@@ -1133,7 +1146,18 @@ class ConformerCTCTrainStep:
                 da = K.dense_plain(dqkv, PK("qkv_w.tr"), d, 3 * d)
                 _, dy = K.layernorm_bwd_next(A["x_in"], P("norm_mha.g"), da, g, G("norm_mha.g"), G("norm_mha.b"),
                                              (0.5, pd, seed, self._salt(li, 1), None), partials=self._ln_partials("norm_mha"))
-            ffn_bwd(dy, T["ffm"], "ffm", "norm_ff_macaron", None)
+            if self._chain_final() and li > 0:
+                # block li - 1's norm_final: its partials go to THAT block's half of the arena (block li + 1's sums, the last user of
+                # that half, were launched on this stream long ago)
+                prev = "l%d." % (li - 1)
+                self._dw_par ^= 1
+                part_prev = self._ln_partials("norm_final")
+                self._dw_par ^= 1
+                chained_dy = ffn_bwd(dy, T["ffm"], "ffm", "norm_ff_macaron", None,
+                                     chain=(tape[li - 1]["final_in"], fp.p(prev + "norm_final.g"), part_prev,
+                                            (0.5, pd, seed, self._salt(li - 1, 7), None)))
+            else:
+                ffn_bwd(dy, T["ffm"], "ffm", "norm_ff_macaron", None)
             self._layer_done(li)
 
     def _decoder_forward_backward(self, mem_bf, enc_mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks, ys_masks, gscale,

@@ -589,12 +589,14 @@ def ffn_train_parts(m):
     return int(_lib.load().ma_ffn_train_parts(m))
 
 
-def ffn_train_bwd(dy, packed_t, hidden, gk, x, gamma, g, partials, nxt=None, eps=1e-5):
+def ffn_train_bwd(dy, packed_t, hidden, gk, x, gamma, g, partials, nxt=None, eps=1e-5, chain=None):
     """The feed-forward module's backward in one launch (ma_ffn_train_bwd_bf16): du (M, hidden) bf16 = bf16(dy W2) * gk [returned: the
     operand of w_1's weight gradient]; da = du W1 goes straight into the backward of the LayerNorm in front of the module (input x,
     weight gamma): g (M, 256) float32 += dLN/dx(da) in place, per-workgroup (dgamma | dbeta) partials -> `partials`
     (>= ffn_train_parts(M) * 512 floats), and with nxt = (alpha, p, seed, salt, row_scale_next or None) dy_next (M, 256) bf16 =
-    dropout(g * alpha * row_scale_next).  `packed_t` = the feed-forward block format of (W2^T, W1^T).  Returns (du, dy_next)."""
+    dropout(g * alpha * row_scale_next).  `packed_t` = the feed-forward block format of (W2^T, W1^T).  Returns (du, dy_next).
+    chain = (x2, gamma2, partials2, nxt2) (nxt must be None then): a second LayerNorm backward on the finished rows, for the LayerNorm
+    (input x2, weight gamma2) whose OUTPUT the rows of g are: g is replaced by its backward and dy_next comes from nxt2."""
     import ctypes
 
     t = _t()
@@ -614,8 +616,26 @@ def ffn_train_bwd(dy, packed_t, hidden, gk, x, gamma, g, partials, nxt=None, eps
         e.ln_out, e.ld_ln, e.ln_out_bf16 = dy_next.data_ptr(), dy_next.stride(0), 1
         e.alpha, e.p, e.seed, e.salt = float(alpha), float(p), int(seed), int(salt)
         e.ln_row_scale = rs_next.data_ptr() if rs_next is not None else None
+    e2 = None
+    if chain is not None:
+        assert nxt is None
+        x2, gamma2, partials2, nxt2 = chain
+        assert x2.dtype == t.float32 and partials2.numel() >= ffn_train_parts(m) * 512
+        e2 = _lib.TrainEpilogue()
+        e2.mode = 5
+        e2.residual, e2.ldr = x2.data_ptr(), x2.stride(0)
+        e2.ln_gamma1 = gamma2.data_ptr()
+        e2.ln_eps = float(eps)
+        e2.ln_mid = partials2.data_ptr()
+        if nxt2 is not None:
+            alpha, p, seed, salt, rs_next = nxt2
+            dy_next = t.empty((m, 256), dtype=t.bfloat16, device=dy.device)
+            e2.ln_out, e2.ld_ln, e2.ln_out_bf16 = dy_next.data_ptr(), dy_next.stride(0), 1
+            e2.alpha, e2.p, e2.seed, e2.salt = float(alpha), float(p), int(seed), int(salt)
+            e2.ln_row_scale = rs_next.data_ptr() if rs_next is not None else None
     _lib.check(_lib.load().ma_ffn_train_bwd_bf16(_p(dy), dy.stride(0), m, hidden, _p(packed_t), _p(gk), _p(du), hidden, _p(g),
-                                                 g.stride(0), ctypes.byref(e), _s()), "ffn_train_bwd")
+                                                 g.stride(0), ctypes.byref(e), ctypes.byref(e2) if e2 is not None else None, _s()),
+               "ffn_train_bwd")
     return du, dy_next
 
 

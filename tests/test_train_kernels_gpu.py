@@ -666,6 +666,32 @@ def test_feed_forward_module_backward_in_one_launch(K, m, hid):
         pv = parts.view(-1, 512).double().sum(0)
         assert bool(torch.isfinite(pv).all())
         assert rel(pv[:256].float(), dg_ref.cpu()) < 4e-3 and rel(pv[256:].float(), db_ref.cpu()) < 4e-3
+    # ---- chain: a second LayerNorm backward on the finished rows (norm_final of the block below), g replaced, dy_next from it
+    x2 = torch.randn(m, d, generator=gen).cuda() * 1.5 - 0.2
+    gamma2 = (1 + 0.1 * torch.randn(d, generator=gen)).cuda()
+    nxt2 = (0.5, p, seed, 11, None)
+    g_new = g0.clone()
+    parts = torch.full((K.ffn_train_parts(m) * 512,), float("nan"), device="cuda")
+    parts2 = torch.full((K.ffn_train_parts(m) * 512,), float("nan"), device="cuda")
+    du, dn = K.ffn_train_bwd(dy, pt, hid, gk, x, gamma, g_new, parts, chain=(x2, gamma2, parts2, nxt2))
+    # reference: the un-chained launch, then the stand-alone LayerNorm backward that replaces g
+    g_ref = g0.clone()
+    parts_r = torch.zeros_like(parts)
+    du_r, none = K.ffn_train_bwd(dy, pt, hid, gk, x, gamma, g_ref, parts_r)
+    assert none is None and torch.equal(du, du_r)
+    dg2, db2 = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    _, dn_ref = K.layernorm_bwd_next(x2, gamma2, g_ref, g_ref, dg2, db2, nxt2, accumulate=False)
+    torch.cuda.synchronize()
+    assert torch.equal(parts, parts_r)  # the first LayerNorm's partials do not change
+    scale = float(g_ref.abs().max())
+    assert float((g_new - g_ref).abs().max()) <= 2e-5 * scale + 1e-6
+    pv2 = parts2.view(-1, 512).double().sum(0)
+    assert float((pv2[:256] - dg2.double()).abs().max()) <= 5e-5 * float(dg2.abs().max()) + 1e-5
+    assert float((pv2[256:] - db2.double()).abs().max()) <= 5e-5 * float(db2.abs().max()) + 1e-5
+    a_, b_ = dn.float(), dn_ref.float()
+    assert torch.equal(a_ == 0, b_ == 0)
+    diff = (a_ - b_).abs()
+    assert float((diff / b_.abs().clamp(min=1e-3)).max()) <= 1.0 / 64 and float((diff > 0).float().mean()) < 5e-3
 
 
 @pytest.mark.parametrize("b,h,w,c", [(2, 21, 19, 128), (3, 24, 39, 256), (1, 3, 3, 128), (2, 8, 6, 128), (9, 187, 39, 256),

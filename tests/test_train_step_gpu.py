@@ -402,10 +402,11 @@ def test_feed_forward_module_in_one_launch_changes_round_off_only():
 
     xs, ys, sub, ys_lens = batch()
     res = []
-    for fwd_one, bwd_one in ((False, False), (True, False), (True, True), (True, True)):
+    for fwd_one, bwd_one, chained in ((False, False, False), (True, False, False), (True, True, False), (True, True, True), (True, True, True)):
         _, _, model = build(seed=6)
         eng = ConformerCTCTrainStep(model, dropout_rate=0.1, positional_dropout_rate=0.1, fused=True)
-        assert eng.ffn_one_launch and eng.ffn_bwd_one_launch
+        assert eng.ffn_one_launch and eng.ffn_bwd_one_launch and eng.ln_final_chained
+        eng.ln_final_chained = chained  # norm_final's backward as the second stage of the macaron backward launch above it
         if not (fwd_one and bwd_one):
             eng.ffn_one_launch, eng.ffn_bwd_one_launch = fwd_one, bwd_one
             eng._pack_plan = None
@@ -413,7 +414,7 @@ def test_feed_forward_module_in_one_launch_changes_round_off_only():
         loss = eng.forward_backward(xs.cuda(), ys.cuda(), sub.cuda(), ys_lens.cuda(), grad_scale=8.0)
         res.append((float(loss), eng.fp.grad.clone(), eng))
     (l0, g0, e0) = res[0]
-    for l1, g1, _ in res[1:3]:
+    for l1, g1, _ in res[1:4]:
         assert abs(l0 - l1) <= 1e-3 * abs(l0), (l0, l1)
         assert float((g1 - g0).norm() / g0.norm()) <= 1.5e-2
         worst = {}
@@ -423,7 +424,9 @@ def test_feed_forward_module_in_one_launch_changes_round_off_only():
                 worst[name] = float((a - b_).norm() / a.norm())
         bad = {k: round(v, 4) for k, v in worst.items() if v > 5e-2 and not (k.endswith("dw_b") or k.endswith("qkv_b"))}
         assert not bad, bad
-    assert res[3][0] == res[2][0] and torch.equal(res[3][1], res[2][1])
+    assert res[4][0] == res[3][0] and torch.equal(res[4][1], res[3][1])
+    # the chained form against the un-chained one: the same launches but for norm_final's row sums taken in another order
+    assert float((res[3][1] - res[2][1]).norm() / res[2][1].norm()) <= 1e-4
 
 
 def test_weight_gradient_stream_changes_no_bit():

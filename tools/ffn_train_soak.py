@@ -28,6 +28,7 @@ g1, be1 = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, 
 g2, be2 = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
 dy = bf(torch.randn(m, d, generator=g))
 g0 = torch.randn(m, d, generator=g).cuda()
+x2 = torch.randn(m, d, generator=g).cuda() * 1.5
 pk = ops.ffn_pack_weights(w1, w2)
 pt = ops.ffn_pack_weights(w2.t().contiguous(), w1.t().contiguous())
 parts0 = None
@@ -44,8 +45,10 @@ gk = ref[0]
 def bwd():
     gg = g0.clone()
     parts = torch.zeros(K.ffn_train_parts(m) * 512, device="cuda")
-    du, dn = K.ffn_train_bwd(dy, pt, hid, gk, x, g1, gg, parts, nxt=(0.5, p, seed, 9, None))
-    return du, dn, gg, parts
+    parts2 = torch.zeros(K.ffn_train_parts(m) * 512, device="cuda")
+    # (with the chained second LayerNorm backward: the form eleven of the step's twelve macaron launches take)
+    du, dn = K.ffn_train_bwd(dy, pt, hid, gk, x, g1, gg, parts, chain=(x2, g2, parts2, (0.5, p, seed, 9, None)))
+    return du, dn, gg, parts, parts2
 
 
 refb = [t.clone() for t in bwd()]

@@ -682,6 +682,16 @@ int32_t ma_convmid_bwd_parts(int64_t batch, int64_t T);
 int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                         const float* dw_w, int32_t ks, void* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
                         void* workspace, int64_t workspace_bytes, ma_stream_t stream);
+/* The two above with the BatchNorm backward's second stage folded into the depthwise backward's loads (round 4):
+ * ma_bn_swish_bwd_stage1_f32 = ma_bn_swish_bwd_f32 without that stage (dn = dout * swish'(n) is left in `dn`, dsum / d_gamma / d_beta
+ * as before); ma_convmid_bwd_bn_bf16 = ma_convmid_bwd_bf16 on dz = gamma rstd (dn - dsum[c] / N - zhat dsum[C + c] / N), N = batch * T,
+ * formed element for element as the second stage forms it (same results, one launch and one float32 round trip fewer). */
+int ma_bn_swish_bwd_stage1_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
+                               float* dn, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
+                               int64_t workspace_bytes, ma_stream_t stream);
+int ma_convmid_bwd_bn_bf16(const float* dn, const float* z, const float* stats, const float* gamma, const float* dsum, const void* y,
+                           int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w, int32_t ks, void* dy, int64_t lddy,
+                           float* d_dw_w, float* d_dw_b, void* workspace, int64_t workspace_bytes, ma_stream_t stream);
 
 /* Conv2dSubsampling4 backward (layers/subsampling.py:21-78): ReLU mask in place; transposed im2col matrix
  * (9C, ld_out >= B*Ho*Wo) of an NHWC bf16 activation (weight gradient of conv2 as a split-K GEMM); col2im + ReLU mask

@@ -225,6 +225,8 @@ PROTOTYPES = {
     "ma_bn_swish_fwd_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, i64, i32, vp]),
     "ma_bn_swish_bwd_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp]),
     "ma_convmid_bwd_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp, i64, vp]),
+    "ma_bn_swish_bwd_stage1_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp]),
+    "ma_convmid_bwd_bn_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp, i64, vp]),
     "ma_relu_bwd_bf16": (ctypes.c_int, [vp, vp, i64, vp]),
     "ma_im2col_t_3x3s2_nhwc_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, i64, vp]),
     "ma_col2im_3x3s2_relu_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),

@@ -609,11 +609,21 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ dn, co
 // Workgroup = (utterance b, strip of kCbStrip frames) x 256 channels (thread = channel): the strip plus its halo of
 // s and dz go through LDS once, so every tap is an LDS read with unit channel stride.
 constexpr int kCbStrip = 16, kCbPerBlock = 1;
-template <int KS, typename AT>
+// BN (round 4): `dz` holds dn = dout * swish'(n) (the first stage of the BatchNorm backward) and the second stage - dz = gamma rstd
+// (dn - sum(dn) / N - zhat sum(dn zhat) / N), bn_bwd2_kernel's formula, zhat from z - is applied while the rows are loaded: one launch
+// and one float32 round trip of (B T, C) fewer per block.
+struct CmBn {
+  const float* z;      // (B*T, C) float32: the depthwise convolution's output
+  const float* stats;  // mean (C) | rstd (C)
+  const float* gamma;
+  const float* dsum;   // sum dn (C) | sum dn zhat (C)
+  float inv_count;
+};
+template <int KS, typename AT, bool BN>
 __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restrict__ dz, const AT* __restrict__ y,
                                                           int64_t ldy, int B, int T, int C,
                                                           const float* __restrict__ w, AT* __restrict__ dy,
-                                                          int64_t lddy, float* __restrict__ part, int per_block) {
+                                                          int64_t lddy, float* __restrict__ part, int per_block, const CmBn bn) {
   constexpr int pad = (KS - 1) / 2, kRows = kCbStrip + KS - 1;
   // (round 4: glu(y), dz and sigmoid(gate) of the strip + halo of a thread's channel stay in registers, as in the forward kernel)
   const int tid = threadIdx.x;
@@ -624,6 +634,14 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < KS; ++j) { wr[j] = w[c * KS + j]; dwr[j] = 0.0f; }
   float dbr = 0.0f;
+  float bn_mean = 0.0f, bn_rstd = 0.0f, bn_gr = 0.0f, bn_s0 = 0.0f, bn_s1 = 0.0f;
+  if constexpr (BN) {
+    bn_mean = bn.stats[c];
+    bn_rstd = bn.stats[C + c];
+    bn_gr = bn.gamma[c] * bn_rstd;
+    bn_s0 = bn.dsum[c] * bn.inv_count;
+    bn_s1 = bn.dsum[C + c] * bn.inv_count;
+  }
   // a workgroup walks kCbPerBlock consecutive strips so that the parameter-gradient atomics (one per channel and tap
   // per workgroup) stay a small fraction of the work
   for (int sidx = 0; sidx < per_block; ++sidx) {
@@ -640,6 +658,10 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
       av[u] = ldact(yp);
       gv[u] = ldact(yp + C);
       zv[u] = dz[(base + t) * C + c];
+      if constexpr (BN) {  // dn -> dz (bn_bwd2_kernel's arithmetic, element for element)
+        const float zh = (bn.z[(base + t) * C + c] - bn_mean) * bn_rstd;
+        zv[u] = bn_gr * (zv[u] - bn_s0 - zh * bn_s1);
+      }
     }
 #pragma unroll
     for (int u = 0; u < kCvLoadRows; ++u) {
@@ -1204,7 +1226,7 @@ extern "C++" {
 template <typename AT>
 static int bn_swish_bwd_launch(const AT* dout, const float* z, const float* stats, const float* gamma, const float* beta,
                                float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
-                               int64_t workspace_bytes, ma_stream_t stream) {
+                               int64_t workspace_bytes, ma_stream_t stream, bool second_stage = true) {
   if (!dout || !z || !stats || !gamma || !beta || !dz || !dsum || !workspace || rows < 1) return MA_ERR_INVALID_ARG;
   if (C < 1 || C > 256 || 256 % C) return MA_ERR_UNSUPPORTED;
   if (workspace_bytes < (int64_t)256 * 2 * C * 4) return MA_ERR_WORKSPACE;
@@ -1222,8 +1244,9 @@ static int bn_swish_bwd_launch(const AT* dout, const float* z, const float* stat
               gamma, beta, dz, rows, C, part);
   }
   MA_LAUNCH(bn_dsum_reduce_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, nblk, C, dsum, d_gamma, d_beta);
-  MA_LAUNCH(bn_bwd2_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dz, z, stats, gamma, dsum, rows,
-            C, 1.0f / (float)rows);
+  if (second_stage)
+    MA_LAUNCH(bn_bwd2_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dz, z, stats, gamma, dsum, rows, C,
+              1.0f / (float)rows);
   return MA_OK;
 }
 }  // extern "C++"
@@ -1232,6 +1255,12 @@ int ma_bn_swish_bwd_f32(const void* dout, const float* z, const float* stats, co
                         int64_t workspace_bytes, ma_stream_t stream) {
   return bn_swish_bwd_launch((const uint16_t*)dout, z, stats, gamma, beta, dz, rows, C, dsum, d_gamma, d_beta, workspace,
                              workspace_bytes, stream);
+}
+int ma_bn_swish_bwd_stage1_f32(const void* dout, const float* z, const float* stats, const float* gamma, const float* beta,
+                               float* dn, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
+                               int64_t workspace_bytes, ma_stream_t stream) {
+  return bn_swish_bwd_launch((const uint16_t*)dout, z, stats, gamma, beta, dn, rows, C, dsum, d_gamma, d_beta, workspace,
+                             workspace_bytes, stream, false);
 }
 int ma_bn_swish_bwd_x32(const float* dout, const float* z, const float* stats, const float* gamma, const float* beta,
                         float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
@@ -1243,8 +1272,10 @@ extern "C++" {
 template <typename AT>
 static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                               const float* dw_w, int32_t ks, AT* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,
-                              void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+                              void* workspace, int64_t workspace_bytes, ma_stream_t stream, const CmBn* bnp = nullptr) {
   if (!dz || !y || !dw_w || !dy || (d_dw_w && !d_dw_b) || !workspace || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
+  if (bnp && (!bnp->z || !bnp->stats || !bnp->gamma || !bnp->dsum)) return MA_ERR_INVALID_ARG;
+  const CmBn bn = bnp ? *bnp : CmBn{};
   if (C != 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
   float* part = reinterpret_cast<float*>(workspace);
   // strips per workgroup: as few as keep the number of partial vectors inside the workspace
@@ -1255,8 +1286,12 @@ static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t
   const int nblk = (int)(grid.x * grid.y), width = C * (ks + 1);
   if (workspace_bytes < (int64_t)nblk * width * 4) return MA_ERR_WORKSPACE;
 #define MA_CMB(KS_)                                                                                                    \
-  MA_LAUNCH((convmid_bwd_kernel<KS_, AT>), grid, dim3(256), 0, (hipStream_t)stream, dz, y, ldy, (int)batch, (int)T, C, dw_w, dy, lddy,   \
-            part, per_block)
+  if (bnp)                                                                                                             \
+    MA_LAUNCH((convmid_bwd_kernel<KS_, AT, true>), grid, dim3(256), 0, (hipStream_t)stream, dz, y, ldy, (int)batch, (int)T, C, dw_w, dy, \
+              lddy, part, per_block, bn);                                                                              \
+  else                                                                                                                 \
+    MA_LAUNCH((convmid_bwd_kernel<KS_, AT, false>), grid, dim3(256), 0, (hipStream_t)stream, dz, y, ldy, (int)batch, (int)T, C, dw_w,    \
+              dy, lddy, part, per_block, bn)
   if (ks == 3) { MA_CMB(3); }
   else if (ks == 7) { MA_CMB(7); }
   else if (ks == 15) { MA_CMB(15); }
@@ -1280,6 +1315,18 @@ int ma_convmid_bwd_bf16(const float* dz, const void* y, int64_t ldy, int64_t bat
                         void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
   return convmid_bwd_launch(dz, (const uint16_t*)y, ldy, batch, T, C, dw_w, ks, (uint16_t*)dy, lddy, d_dw_w, d_dw_b, workspace,
                             workspace_bytes, stream);
+}
+int ma_convmid_bwd_bn_bf16(const float* dn, const float* z, const float* stats, const float* gamma, const float* dsum, const void* y,
+                           int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w, int32_t ks, void* dy, int64_t lddy,
+                           float* d_dw_w, float* d_dw_b, void* workspace, int64_t workspace_bytes, ma_stream_t stream) {
+  CmBn bn;
+  bn.z = z;
+  bn.stats = stats;
+  bn.gamma = gamma;
+  bn.dsum = dsum;
+  bn.inv_count = 1.0f / (float)(batch * T);
+  return convmid_bwd_launch(dn, (const uint16_t*)y, ldy, batch, T, C, dw_w, ks, (uint16_t*)dy, lddy, d_dw_w, d_dw_b, workspace,
+                            workspace_bytes, stream, &bn);
 }
 int ma_convmid_bwd_x32(const float* dz, const float* y, int64_t ldy, int64_t batch, int64_t T, int32_t C,
                        const float* dw_w, int32_t ks, float* dy, int64_t lddy, float* d_dw_w, float* d_dw_b,

@@ -300,13 +300,17 @@ def convmid_bwd(dout, y, z, stats, batch, T, dw_w, gamma, beta, d_dw_w, d_dw_b, 
     dz = t.empty((rows, c), dtype=t.float32, device=y.device)
     dsum = t.empty(2 * c, dtype=t.float32, device=y.device)
     rw = _reduce_ws(y.device)
-    _lib.check(lib.ma_bn_swish_bwd_f32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _p(d_gamma), _p(d_beta),
-               _p(rw), rw.numel(), _s()), "bn_swish_bwd")
     dy = t.empty((rows, 2 * c), dtype=t.bfloat16, device=y.device)
     if partials is not None:
-        _lib.check(lib.ma_convmid_bwd_bf16(_p(dz), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dy), dy.stride(0), None, None,
-                                           _p(partials), partials.numel() * partials.element_size(), _s()), "convmid_bwd")
+        # (the fused step: the BatchNorm backward's second stage rides in the depthwise backward's loads)
+        _lib.check(lib.ma_bn_swish_bwd_stage1_f32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _p(d_gamma),
+                                                  _p(d_beta), _p(rw), rw.numel(), _s()), "bn_swish_bwd_stage1")
+        _lib.check(lib.ma_convmid_bwd_bn_bf16(_p(dz), _p(z), _p(stats), _p(gamma), _p(dsum), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks,
+                                              _p(dy), dy.stride(0), None, None, _p(partials),
+                                              partials.numel() * partials.element_size(), _s()), "convmid_bwd_bn")
         return dy
+    _lib.check(lib.ma_bn_swish_bwd_f32(_p(dout), _p(z), _p(stats), _p(gamma), _p(beta), _p(dz), rows, c, _p(dsum), _p(d_gamma), _p(d_beta),
+               _p(rw), rw.numel(), _s()), "bn_swish_bwd")
     rw = _reduce_ws(y.device)
     _lib.check(lib.ma_convmid_bwd_bf16(_p(dz), _p(y), y.stride(0), batch, T, c, _p(dw_w), ks, _p(dy), dy.stride(0),
                                        _p(d_dw_w), _p(d_dw_b), _p(rw), rw.numel(), _s()), "convmid_bwd")

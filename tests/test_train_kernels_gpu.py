@@ -221,6 +221,18 @@ def test_convmid_train_fwd_bwd(K):
     # the depthwise bias feeds a BatchNorm: its gradient is identically zero (both sides hold rounding noise)
     assert float(dbs.abs().max()) < 1e-3 and float(dw_b.grad.abs().max()) < 1e-3
     assert rel(dgs, bn.weight.grad) < 1e-3 and rel(dbe, bn.bias.grad) < 1e-3
+    # the fused step's form (round 4): the BatchNorm backward's second stage inside the depthwise backward's loads, the depthwise
+    # partial sums left in the caller's buffer - the same dy up to one float32 rounding, the same parameter gradients
+    from mindaudio_amd import _lib
+    parts = torch.zeros(int(_lib.load().ma_convmid_bwd_parts(b, t)) * c * (ks + 1), device="cuda")
+    dgs2, dbe2 = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    dy2 = K.convmid_bwd(dout.cuda(), y.cuda(), z_d, st, b, t, dw_w.detach().cuda(), gamma.detach().cuda(), beta.detach().cuda(), None,
+                        None, dgs2, dbe2, partials=parts)
+    # the fused form multiplies sum / N before zhat (one rounding apart from bn_bwd2_kernel's order): float32 round-off, then bf16
+    assert rel(dy2, dy.float().cpu()) < 1e-3
+    assert rel(dgs2, dgs.float().cpu()) < 1e-6 and rel(dbe2, dbe.float().cpu()) < 1e-6
+    pv = parts.view(-1, c * (ks + 1)).sum(0)
+    assert rel(pv[:c * ks].view(c, ks), dws.cpu()) < 1e-5
 
 
 def test_subsampling_backward_pieces(K):

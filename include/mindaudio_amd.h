@@ -1011,6 +1011,39 @@ int ma_ctc_loss_grad_x32(const float* logits, int64_t ld, int64_t batch, int64_t
                          float* loss_out, float* dlogits, int64_t ld_out, void* workspace, int64_t workspace_bytes,
                          ma_stream_t stream);
 
+/* ---- a Conformer block's launches from one C call (round 4) --------------------------------------------------------------------
+ * A block table holds, per (direction, block), the list of C-ABI calls of this header that make up the training-mode forward
+ * (models/conformer.py:109-156: macaron FFN -> MHSA -> convolution module -> FFN -> norm_final) or backward of ONE encoder block at
+ * one batch shape: entry point, argument words, copies of the host structs behind pointer arguments.  The host side (the training
+ * engine, utils/train_one_step.py:13-48 on the reference side) fills it once per batch shape while it walks the block call by call,
+ * and from then on issues the block with ONE call; the entries' device buffers must stay allocated while the table lives.
+ *   ma_block_table_entry_point(name): index of a replayable entry point (int-returning, `ma_stream_t stream` last, only scalars,
+ *     device pointers and pointers to the host structs ma_train_epilogue_t / ma_gemm_epilogue_t / ma_tn_item_t / ma_tn_direct_item_t /
+ *     ma_melbank_t), -1 otherwise;  ma_block_table_entry_point_params(fn): its parameter count;  _seeds(fn): bit k set = parameter k
+ *     is a dropout seed (`uint32_t seed*`).
+ *   ma_block_table_add: words[k] = parameter k as 8 bytes - pointer or integer as is, float / double as the bits of a double, a host
+ *     struct (or host array) as its byte offset in `blob` (-1 = NULL; blob_bytes % 8 == 0; the blob is copied), the stream and seed
+ *     parameters as anything (they are replaced).
+ *   ma_conformer_block_fwd_train / _bwd_train: issue the block's calls in the order they were added, on `stream`, every `seed*`
+ *     parameter and every ma_train_epilogue_t.seed = `seed` (the step's dropout stream).  MA_ERR_INVALID_ARG for a block without
+ *     entries; an entry's own error code otherwise (ma_block_table_failed_call = its index). */
+typedef struct ma_block_table ma_block_table_t;
+ma_block_table_t* ma_block_table_create(void);
+void ma_block_table_destroy(ma_block_table_t* table);
+int32_t ma_block_table_entry_point(const char* name);
+int32_t ma_block_table_entry_point_params(int32_t fn);
+uint64_t ma_block_table_entry_point_seeds(int32_t fn);
+int ma_block_table_add(ma_block_table_t* table, int32_t backward, int32_t block, int32_t fn, const int64_t* words, int32_t n_words,
+                       const void* blob, int64_t blob_bytes);
+int32_t ma_block_table_calls(const ma_block_table_t* table, int32_t backward, int32_t block);
+int32_t ma_block_table_failed_call(const ma_block_table_t* table);
+/* reading an entry back: its entry point (-1: no such entry), word k, and its blob (copies min(bytes, size) bytes; returns the size) */
+int32_t ma_block_table_call_entry_point(const ma_block_table_t* table, int32_t backward, int32_t block, int32_t call);
+int64_t ma_block_table_call_word(const ma_block_table_t* table, int32_t backward, int32_t block, int32_t call, int32_t k);
+int64_t ma_block_table_call_blob(const ma_block_table_t* table, int32_t backward, int32_t block, int32_t call, void* out, int64_t bytes);
+int ma_conformer_block_fwd_train(ma_block_table_t* table, int32_t block, uint32_t seed, ma_stream_t stream);
+int ma_conformer_block_bwd_train(ma_block_table_t* table, int32_t block, uint32_t seed, ma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,6 +227,19 @@ PROTOTYPES = {
     "ma_convmid_bwd_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp, i64, vp]),
     "ma_bn_swish_bwd_stage1_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp]),
     "ma_convmid_bwd_bn_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp, i32, vp, i64, vp, vp, vp, i64, vp]),
+    "ma_block_table_create": (vp, []),
+    "ma_block_table_destroy": (None, [vp]),
+    "ma_block_table_entry_point": (i32, [ctypes.c_char_p]),
+    "ma_block_table_entry_point_params": (i32, [i32]),
+    "ma_block_table_entry_point_seeds": (ctypes.c_uint64, [i32]),
+    "ma_block_table_add": (ctypes.c_int, [vp, i32, i32, i32, ctypes.POINTER(i64), i32, vp, i64]),
+    "ma_block_table_calls": (i32, [vp, i32, i32]),
+    "ma_block_table_failed_call": (i32, [vp]),
+    "ma_block_table_call_entry_point": (i32, [vp, i32, i32, i32]),
+    "ma_block_table_call_word": (i64, [vp, i32, i32, i32, i32]),
+    "ma_block_table_call_blob": (i64, [vp, i32, i32, i32, vp, i64]),
+    "ma_conformer_block_fwd_train": (ctypes.c_int, [vp, i32, u32, vp]),
+    "ma_conformer_block_bwd_train": (ctypes.c_int, [vp, i32, u32, vp]),
     "ma_relu_bwd_bf16": (ctypes.c_int, [vp, vp, i64, vp]),
     "ma_im2col_t_3x3s2_nhwc_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, i64, vp]),
     "ma_col2im_3x3s2_relu_bf16": (ctypes.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
@@ -319,6 +332,7 @@ PROTOTYPES = {
 }
 
 _lib = None
+_recording = None  # the block table being filled (train/block_table.py): load() then hands out its recording proxy
 
 
 class MindaudioAmdError(RuntimeError):
@@ -334,7 +348,7 @@ def load():
     """Load the shared library (once). Raises if it has not been built."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if _recording is None else _recording._proxy
     path = lib_path()
     if not os.path.exists(path):
         raise MindaudioAmdError(

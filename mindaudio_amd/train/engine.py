@@ -288,6 +288,10 @@ class ConformerCTCTrainStep:
         # g it has just finished ARE norm_final's output gradient): 11 LayerNorm-backward launches and round trips of g fewer
         self.ln_final_chained = self.ffn_bwd_one_launch
         self._dw_direct = self.fused and self.dw_group_blocks > 0 and self.d % 256 == 0 and self.hidden % 256 == 0
+        # block_tables: from the third step of a batch shape on, a block's launches are issued by ONE C call each way
+        # (ma_conformer_block_fwd_train / _bwd_train) from the argument table filled while the second step was walked from Python -
+        # same calls, same buffers, same order; 4.2 -> ~1.5 ms of host time per step (train/block_table.py, csrc/block_table.hip)
+        self.block_tables = self.fused and self._dw_direct
         if self._wg_on and not self._dw_direct and not self._wg_split_ok:
             raise ValueError("wg_stream=True needs the direct weight-gradient groups (dw_group_blocks > 0, d_model and hidden "
                              "multiples of 256): the split-K sums are not run on a second stream (DESIGN 4.6.3)")
@@ -743,6 +747,30 @@ class ConformerCTCTrainStep:
         o, nbytes, _ = self._front_cur["off"][name]
         self.K.gemm_tn_partial(dy, x, self._front_cur["arena"][o:o + nbytes], with_colsum=with_colsum, rows_store=rows_store)
 
+    def _block_table_for(self, b, t2, att_mask):
+        """The launch table of the current batch shape: None (the blocks are walked from Python: first step of a shape, or a
+        configuration the table does not cover), else a dict with `state` "record" (walk AND fill) or "replay", the table and the
+        buffers at the blocks' boundary, which live at fixed addresses for as long as the table does."""
+        plan = self._dw_cur
+        if not (self.block_tables and self.fused and self._dw_direct and self._wg is None and plan is not None and not self.x32):
+            return None
+        key = (b, t2, tuple(att_mask.shape), att_mask.dtype, self.ffn_one_launch, self.ffn_bwd_one_launch, self.ln_final_chained,
+               self.ln_bwd_fused, self.dw_group_blocks, self.p_drop, self.p_pos, self.bn_momentum, id(plan["arena"]))
+        tb = plan.get("table")
+        if tb is None or tb["key"] != key:
+            plan["table"] = dict(key=key, state="seen")  # this step warms the wrappers' pooled buffers; the next one is recorded
+            return None
+        if tb["state"] == "seen":
+            from .block_table import BlockTable
+
+            m, d, f32, bf = b * t2, self.d, torch.float32, torch.bfloat16
+            tb.update(state="record", table=BlockTable(),
+                      x_in=torch.empty((m, d), dtype=f32, device=self.dev), a_in=torch.empty((m, d), dtype=bf, device=self.dev),
+                      mask_rows=torch.empty(m, dtype=f32, device=self.dev), att_mask=torch.empty_like(att_mask),
+                      pos_all=torch.empty((t2, self.L * d), dtype=bf, device=self.dev),
+                      g=torch.empty((m, d), dtype=f32, device=self.dev))
+        return tb
+
     def _chain_final(self):
         """norm_final's backward as the second stage of the block above's macaron backward launch (needs the one-launch forms)."""
         return self.ln_final_chained and self.ffn_bwd_one_launch and self.ffn_one_launch and self.fused
@@ -854,13 +882,19 @@ class ConformerCTCTrainStep:
             e = ops.gemm_rows_packed(a2, self.pk["out_w.r"].view(torch.bfloat16).view(d, -1), fp.p("out_b"), alpha=math.sqrt(d))
         else:
             e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)
-        x = K.dropout_add(None, e, 1.0, pp, seed, self._salt(-1, 0)) if pp > 0 else e
+        tb = self._block_table_for(b, t2, att_mask)
+        if tb is not None:  # the blocks' inputs at the table's addresses
+            mask_rows, att_mask = tb["mask_rows"].copy_(mask_rows), tb["att_mask"].copy_(att_mask)
+        if pp > 0:
+            x = K.dropout_add(None, e, 1.0, pp, seed, self._salt(-1, 0), out=tb["x_in"] if tb is not None else None)
+        else:
+            x = e if tb is None else tb["x_in"].copy_(e)
         pe = enc.pe[:t2].to(f32).contiguous()
         if pp > 0:
             pe = K.dropout_add(None, pe, 1.0, pp, seed, self._salt(-1, 1))
         pe_bf = ops.cast_bf16(pe)
-        pos_all = ops.gemm(pe_bf, fp.w("pos_w"))  # (t2, L*256) bf16
-        ctx_ = dict(seed=seed, b=b, t2=t2, m=m, mask_rows=mask_rows, att_mask=att_mask, pos_all=pos_all)
+        pos_all = ops.gemm(pe_bf, fp.w("pos_w"), out=tb["pos_all"] if tb is not None else None)  # (t2, L*256) bf16
+        ctx_ = dict(seed=seed, b=b, t2=t2, m=m, mask_rows=mask_rows, att_mask=att_mask, pos_all=pos_all, table=tb)
         if self.fused:
             x, enc_bf, tape = self._blocks_forward_fused(x, ctx_)
         else:
@@ -892,7 +926,7 @@ class ConformerCTCTrainStep:
             d_enc = self._dX(dlog, "ctc_w")            # (m, 256) bf16
         else:                                                   # + the decoder's gradient w.r.t. the encoder output
             d_enc = self._dX(dlog, "ctc_w", residual=d_mem, out_dtype=f32, out=d_mem)
-        g = torch.empty((m, d), dtype=f32, device=self.dev)
+        g = tb["g"] if tb is not None else torch.empty((m, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("after_norm.g"), d_enc, g, fp.g("after_norm.g"), fp.g("after_norm.b"), accumulate=False)
         if self.fused and self._dw_cur is not None:
             dpos_all = self._dw_cur["dpos_all"]  # (every element is written by the blocks' batched sums)
@@ -1032,9 +1066,31 @@ class ConformerCTCTrainStep:
         fp, d, L, K = self.fp, self.d, self.L, self.K
         seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         hid = self.hidden
-        a = ops.layernorm(x, fp.p("l0.norm_ff_macaron.g"), fp.p("l0.norm_ff_macaron.b"))
+        tb = c.get("table")
+        a = ops.layernorm(x, fp.p("l0.norm_ff_macaron.g"), fp.p("l0.norm_ff_macaron.b"), out=tb["a_in"] if tb is not None else None)
+        if tb is not None and tb["state"] == "replay":  # one C call per block: the launches recorded at this batch shape
+            stream = _host.current_stream_ptr()
+            for li in range(L):
+                tb["table"].forward(li, seed, stream)
+            return tb["out"]
+        if tb is not None:
+            if tb["table"].recorded:  # (a recorded step that raised before its backward pass was complete: start over)
+                from .block_table import BlockTable
+
+                tb["table"] = BlockTable()
+            with tb["table"].recording(seed):
+                tb["out"] = self._blocks_forward_walk(x, a, c, tb["table"])
+            return tb["out"]
+        return self._blocks_forward_walk(x, a, c, None)
+
+    def _blocks_forward_walk(self, x, a, c, rec):
+        fp, d, L, K = self.fp, self.d, self.L, self.K
+        seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
+        hid = self.hidden
         tape, enc_bf = [], None
         for li in range(L):
+            if rec is not None:
+                rec.segment(False, li)
             pre = "l%d." % li
             P, PK = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: self.pk[pre + n])
             ln = lambda n: (P(n + ".g"), P(n + ".b"))  # noqa: E731
@@ -1084,8 +1140,33 @@ class ConformerCTCTrainStep:
         fp, d, L, K = self.fp, self.d, self.L, self.K
         seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         hid = self.hidden
+        tb = c.get("table")
+        if tb is not None and tb["state"] == "replay":
+            stream = _host.current_stream_ptr()
+            for li in reversed(range(L)):
+                tb["table"].backward(li, seed, stream)
+                # (what _layer_done / _flush_direct do besides launching: the finished groups' gradient buckets go on the wire)
+                self._dq_blocks.append(li)
+                if len(self._dq_blocks) >= self.dw_group_blocks or li == 0:
+                    for blk in self._dq_blocks:
+                        self.reducer.launch(*self.fp.span(self.layer_names[blk]))
+                    self._dq_blocks.clear()
+            return
+        if tb is not None:
+            with tb["table"].recording(seed):
+                self._blocks_backward_walk(g, tape, dpos_all, c, tb["table"])
+            tb["state"] = "replay"
+            return
+        self._blocks_backward_walk(g, tape, dpos_all, c, None)
+
+    def _blocks_backward_walk(self, g, tape, dpos_all, c, rec):
+        fp, d, L, K = self.fp, self.d, self.L, self.K
+        seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
+        hid = self.hidden
         chained_dy = None
         for li in reversed(range(L)):
+            if rec is not None:
+                rec.segment(True, li)
             self._layer_begin(li)
             pre = "l%d." % li
             P, G, PK = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n)), (lambda n, pre=pre: self.pk[pre + n])

@@ -1,0 +1,101 @@
+"""The block launch table (include/mindaudio_amd.h: ma_block_table_*, ma_conformer_block_fwd_train / _bwd_train) on the host side:
+the generated call list is current, and what the recorder stores for a call is what the call was made with.  No launches here - the
+replayed step is compared bit for bit with the walked one in tests/test_train_step_gpu.py."""
+import ctypes
+import importlib.util
+import os
+import struct
+
+import pytest
+
+from mindaudio_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generated_call_list_is_current():
+    spec = importlib.util.spec_from_file_location("gen_block_table", os.path.join(ROOT, "tools", "gen_block_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.main(check=True), "run python tools/gen_block_table.py after changing include/mindaudio_amd.h"
+
+
+def test_replayable_entry_points_match_the_binding():
+    lib = _lib.load()
+    n = 0
+    for name, (res, args) in _lib.PROTOTYPES.items():
+        fid = lib.ma_block_table_entry_point(name.encode())
+        if fid < 0:
+            continue
+        n += 1
+        # same parameter count as the ctypes prototype, a stream last, int result
+        assert lib.ma_block_table_entry_point_params(fid) == len(args), name
+        assert args[-1] is ctypes.c_void_p and res is ctypes.c_int, name
+        seeds = lib.ma_block_table_entry_point_seeds(fid)
+        for k, tp in enumerate(args):
+            if (seeds >> k) & 1:
+                assert tp is ctypes.c_uint32, (name, k)
+    assert n >= 100
+    for name in ("ma_ffn_train_bf16", "ma_ffn_train_bwd_bf16", "ma_gemm_k256_train_bf16", "ma_gemm_rows_train_bf16",
+                 "ma_relpos_attention_train_bf16", "ma_relpos_attention_bwd_bf16", "ma_convmid_fwd_train", "ma_convmid_bwd_bn_bf16",
+                 "ma_bn_swish_bwd_stage1_f32", "ma_reduce_splits_batch_f32", "ma_gemm_tn_direct_group_bf16",
+                 "ma_layernorm_bwd_next_f32"):
+        assert lib.ma_block_table_entry_point(name.encode()) >= 0, name
+    # host pointer tables and the table's own entry points are not replayable; size queries are not launches
+    for name in ("ma_fft_pow2_c32", "ma_conformer_block_fwd_train", "ma_gemm_tn_workspace_bytes", "nonsense"):
+        assert lib.ma_block_table_entry_point(name.encode()) == -1
+
+
+def test_recorder_stores_what_the_call_was_made_with():
+    from mindaudio_amd.train.block_table import BlockTable
+
+    lib = _lib.load()
+    tab = BlockTable()
+    fid = lib.ma_block_table_entry_point(b"ma_ffn_train_bwd_bf16")
+    argtypes = _lib.PROTOTYPES["ma_ffn_train_bwd_bf16"][1]
+    e = _lib.TrainEpilogue()
+    e.mode, e.residual, e.ldr, e.alpha, e.p, e.seed, e.salt, e.ln_eps = 5, 0x7f00aa001000, 256, 0.5, 0.1, 1234, 55, 1e-5
+    args = (ctypes.c_void_p(0x7f0000001000), 256, 10200, 2048, ctypes.c_void_p(0x7f0000002000), 0x7f0000003000, None, 2048,
+            ctypes.c_void_p(0x7f0000004000), 256, ctypes.byref(e), None, ctypes.c_void_p(0xdead))
+    tab.seed = 1234
+    tab.segment(True, 7)
+    tab._add("ma_ffn_train_bwd_bf16", fid, argtypes, lib.ma_block_table_entry_point_seeds(fid), args)
+    h = tab.handle
+    assert tab.calls(True, 7) == 1 and tab.calls(False, 7) == 0 and tab.calls(True, 6) == 0
+    assert lib.ma_block_table_call_entry_point(h, 1, 7, 0) == fid and lib.ma_block_table_call_entry_point(h, 1, 7, 1) == -1
+    words = [lib.ma_block_table_call_word(h, 1, 7, 0, k) for k in range(len(argtypes))]
+    assert words[:10] == [0x7f0000001000, 256, 10200, 2048, 0x7f0000002000, 0x7f0000003000, 0, 2048, 0x7f0000004000, 256]
+    assert words[10] == 0 and words[11] == -1  # the epilogue at offset 0 of the blob; chain = NULL
+    size = lib.ma_block_table_call_blob(h, 1, 7, 0, None, 0)
+    assert size == ctypes.sizeof(_lib.TrainEpilogue) and size % 8 == 0
+    back = _lib.TrainEpilogue()
+    lib.ma_block_table_call_blob(h, 1, 7, 0, ctypes.byref(back), size)
+    assert bytes(back) == bytes(e)
+    # an epilogue (or a seed argument) of another step's seed is refused: replay could not know which one to substitute
+    tab.seed = 99
+    with pytest.raises(_lib.MindaudioAmdError):
+        tab._add("ma_ffn_train_bwd_bf16", fid, argtypes, lib.ma_block_table_entry_point_seeds(fid), args)
+    # floats travel as the bits of a double, seeds are checked, host arrays are copied whole
+    fid2 = lib.ma_block_table_entry_point(b"ma_dropout_bwd_bf16")
+    at2 = _lib.PROTOTYPES["ma_dropout_bwd_bf16"][1]
+    a2 = (1, 2, 3, 4, 5, 6, 0.5, None, 0.1, 99, 7, None)
+    tab.segment(False, 0)
+    tab._add("ma_dropout_bwd_bf16", fid2, at2, lib.ma_block_table_entry_point_seeds(fid2), a2)
+    w = [lib.ma_block_table_call_word(h, 0, 0, 0, k) for k in range(len(at2))]
+    assert struct.unpack("<d", struct.pack("<q", w[6]))[0] == 0.5 and struct.unpack("<d", struct.pack("<q", w[8]))[0] == 0.1
+    assert w[9] == 99 and w[10] == 7
+    with pytest.raises(_lib.MindaudioAmdError):
+        tab._add("ma_dropout_bwd_bf16", fid2, at2, lib.ma_block_table_entry_point_seeds(fid2), a2[:9] + (98,) + a2[10:])
+    items = (_lib.TnDirectItem * 3)()
+    items[2].Mo = 768
+    fid3 = lib.ma_block_table_entry_point(b"ma_gemm_tn_direct_group_bf16")
+    tab._add("ma_gemm_tn_direct_group_bf16", fid3, _lib.PROTOTYPES["ma_gemm_tn_direct_group_bf16"][1], 0, (items, 3, None))
+    assert lib.ma_block_table_call_blob(h, 0, 0, 1, None, 0) == 3 * ctypes.sizeof(_lib.TnDirectItem)
+    # a block without entries is an error, not an empty success
+    assert lib.ma_conformer_block_fwd_train(h, 5, 1, None) == _lib.MA_ERR_INVALID_ARG
+    # wrong word count / unknown entry point / unaligned blob
+    w17 = (ctypes.c_int64 * 17)()
+    assert lib.ma_block_table_add(h, 0, 1, fid, w17, 17, None, 0) == _lib.MA_ERR_INVALID_ARG
+    assert lib.ma_block_table_add(h, 0, 1, 10 ** 6, w17, 17, None, 0) == _lib.MA_ERR_INVALID_ARG
+    assert lib.ma_block_table_add(h, 0, 99, fid, w17, 13, None, 0) == _lib.MA_ERR_INVALID_ARG
+    assert lib.ma_block_table_add(h, 0, 1, fid, w17, 13, b"abc", 3) == _lib.MA_ERR_INVALID_ARG

@@ -429,6 +429,44 @@ def test_feed_forward_module_in_one_launch_changes_round_off_only():
     assert float((res[3][1] - res[2][1]).norm() / res[2][1].norm()) <= 1e-4
 
 
+def test_blocks_issued_from_the_launch_table_change_no_bit():
+    """block_tables (ma_conformer_block_fwd_train / _bwd_train, csrc/block_table.hip): the first step of a batch shape is walked from
+    Python, the second is walked AND recorded, from the third on every block is ONE C call each way.  Same entry points, same
+    arguments, same buffers, same order - six optimizer steps (dropout ON: the seed changes every step) give bit-identical losses,
+    gradients and masters with the table on and off; so does a second batch shape in between (the table follows the shape's plan)."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    xs, ys, sub, ys_lens = batch()
+    cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
+    t_short = xs.shape[1] - 16
+    sub_s = sub[:, :, :((t_short - 3) // 2 + 1 - 3) // 2 + 1].contiguous()
+    cols_s = (xs[:, :t_short].contiguous().cuda(), ys.cuda(), None, None, None, None, sub_s.cuda(), None, None, ys_lens.cuda(), None)
+    out = []
+    for tables in (False, True):
+        _, _, model = build(seed=9)
+        eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1)
+        assert eng.block_tables
+        eng.block_tables = tables
+        losses, states = [], []
+        for k in range(9):
+            losses.append(float(eng.step(*(cols_s if k in (3, 4, 5) else cols))[0]))
+            tb = eng._dw_plan.get("table")
+            states.append(None if tb is None else tb["state"])
+        torch.cuda.synchronize()
+        if tables:
+            # shape A: seen, record, replay | shape B (a new plan): seen, record, replay | shape A again: seen, record, replay
+            assert states == ["seen", "replay", "replay"] * 3, states
+            tab = eng._dw_plan["table"]["table"]
+            per_block = [(tab.calls(False, li), tab.calls(True, li)) for li in range(eng.L)]
+            assert all(f == 10 and bw >= 10 for f, bw in per_block), per_block
+            assert tab.calls(False, eng.L) == 0
+        else:
+            assert states == [None] * 9
+        out.append((losses, eng.fp.grad.clone(), eng.fp.master.clone()))
+    assert out[1][0] == out[0][0]
+    assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
+
+
 def test_weight_gradient_stream_changes_no_bit():
     """With wg_stream=True (experimental) the grouped weight-gradient products and the gradient buckets run on a second
     stream beside the input-gradient chain (the batched sums stay on the main stream).  Same launches, same summation orders: five

@@ -747,14 +747,14 @@ class ConformerCTCTrainStep:
         o, nbytes, _ = self._front_cur["off"][name]
         self.K.gemm_tn_partial(dy, x, self._front_cur["arena"][o:o + nbytes], with_colsum=with_colsum, rows_store=rows_store)
 
-    def _block_table_for(self, b, t2, att_mask):
+    def _block_table_for(self, b, t2, att_shape):
         """The launch table of the current batch shape: None (the blocks are walked from Python: first step of a shape, or a
         configuration the table does not cover), else a dict with `state` "record" (walk AND fill) or "replay", the table and the
         buffers at the blocks' boundary, which live at fixed addresses for as long as the table does."""
         plan = self._dw_cur
         if not (self.block_tables and self.fused and self._dw_direct and self._wg is None and plan is not None and not self.x32):
             return None
-        key = (b, t2, tuple(att_mask.shape), att_mask.dtype, self.ffn_one_launch, self.ffn_bwd_one_launch, self.ln_final_chained,
+        key = (b, t2, tuple(att_shape), self.ffn_one_launch, self.ffn_bwd_one_launch, self.ln_final_chained,
                self.ln_bwd_fused, self.dw_group_blocks, self.p_drop, self.p_pos, self.bn_momentum, id(plan["arena"]))
         tb = plan.get("table")
         if tb is None or tb["key"] != key:
@@ -766,7 +766,8 @@ class ConformerCTCTrainStep:
             m, d, f32, bf = b * t2, self.d, torch.float32, torch.bfloat16
             tb.update(state="record", table=BlockTable(),
                       x_in=torch.empty((m, d), dtype=f32, device=self.dev), a_in=torch.empty((m, d), dtype=bf, device=self.dev),
-                      mask_rows=torch.empty(m, dtype=f32, device=self.dev), att_mask=torch.empty_like(att_mask),
+                      mask_rows=torch.empty(m, dtype=f32, device=self.dev),
+                      att_mask=torch.empty(att_shape, dtype=f32, device=self.dev),
                       pos_all=torch.empty((t2, self.L * d), dtype=bf, device=self.dev),
                       g=torch.empty((m, d), dtype=f32, device=self.dev))
         return tb
@@ -872,19 +873,23 @@ class ConformerCTCTrainStep:
         self._dw_cur = self._dw_plan_for(m)
         if xs_masks.shape[-1] != t2:
             raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(xs_masks.shape)))
-        mask2d = xs_masks.reshape(b, t2).to(f32).contiguous()
+        chunked = xs_chunk_masks is not None and xs_chunk_masks.dim() == 3 and xs_chunk_masks.shape[1] == t2 and t2 > 1
+        tb = self._block_table_for(b, t2, (b, t2, t2) if chunked else (b, t2))
+        if tb is not None:  # (the blocks' inputs live at the table's addresses: conversion and placement in one launch)
+            mask2d = tb["mask_rows"].view(b, t2).copy_(xs_masks.reshape(b, t2))
+        else:
+            mask2d = xs_masks.reshape(b, t2).to(f32).contiguous()
         mask_rows = mask2d.reshape(m)
         # (B, T') padding mask, or the (B, T', T') chunk masks of the streaming configuration (models/conformer.py:251-252)
         att_mask = enc._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
+        if tb is not None and att_mask is not mask2d:
+            att_mask = tb["att_mask"].copy_(att_mask)
         hlens = mask2d.sum(1).to(torch.int32)
         a2 = act2.view(m, f2 * c)
         if self.fused and "out_w.r" in self.pk:
             e = ops.gemm_rows_packed(a2, self.pk["out_w.r"].view(torch.bfloat16).view(d, -1), fp.p("out_b"), alpha=math.sqrt(d))
         else:
             e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)
-        tb = self._block_table_for(b, t2, att_mask)
-        if tb is not None:  # the blocks' inputs at the table's addresses
-            mask_rows, att_mask = tb["mask_rows"].copy_(mask_rows), tb["att_mask"].copy_(att_mask)
         if pp > 0:
             x = K.dropout_add(None, e, 1.0, pp, seed, self._salt(-1, 0), out=tb["x_in"] if tb is not None else None)
         else:

@@ -432,8 +432,9 @@ def test_feed_forward_module_in_one_launch_changes_round_off_only():
 def test_blocks_issued_from_the_launch_table_change_no_bit():
     """block_tables (ma_conformer_block_fwd_train / _bwd_train, csrc/block_table.hip): the first step of a batch shape is walked from
     Python, the second is walked AND recorded, from the third on every block is ONE C call each way.  Same entry points, same
-    arguments, same buffers, same order - six optimizer steps (dropout ON: the seed changes every step) give bit-identical losses,
-    gradients and masters with the table on and off; so does a second batch shape in between (the table follows the shape's plan)."""
+    arguments, same buffers, same order - twelve optimizer steps (dropout ON: the seed changes every step) give bit-identical losses,
+    gradients and masters with the table on and off, through a second batch shape and the streaming configuration's chunk masks
+    (the table follows the shape's plan and the mask's shape)."""
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
     xs, ys, sub, ys_lens = batch()
@@ -441,6 +442,10 @@ def test_blocks_issued_from_the_launch_table_change_no_bit():
     t_short = xs.shape[1] - 16
     sub_s = sub[:, :, :((t_short - 3) // 2 + 1 - 3) // 2 + 1].contiguous()
     cols_s = (xs[:, :t_short].contiguous().cuda(), ys.cuda(), None, None, None, None, sub_s.cuda(), None, None, ys_lens.cuda(), None)
+    t2 = sub.shape[-1]
+    idx = torch.arange(t2)
+    chunk = ((idx[None, :] // 8) <= (idx[:, None] // 8)) & ((idx[None, :] // 8) >= (idx[:, None] // 8) - 2)
+    cols_c = cols[:10] + ((chunk[None] & (sub > 0)).float().cuda(),)  # the streaming configuration's masks (utils/mask.py:201-271)
     out = []
     for tables in (False, True):
         _, _, model = build(seed=9)
@@ -448,20 +453,21 @@ def test_blocks_issued_from_the_launch_table_change_no_bit():
         assert eng.block_tables
         eng.block_tables = tables
         losses, states = [], []
-        for k in range(9):
-            losses.append(float(eng.step(*(cols_s if k in (3, 4, 5) else cols))[0]))
+        for k in range(12):
+            losses.append(float(eng.step(*(cols_s if k in (3, 4, 5) else cols_c if k >= 9 else cols))[0]))
             tb = eng._dw_plan.get("table")
             states.append(None if tb is None else tb["state"])
         torch.cuda.synchronize()
         if tables:
             # shape A: seen, record, replay | shape B (a new plan): seen, record, replay | shape A again: seen, record, replay
-            assert states == ["seen", "replay", "replay"] * 3, states
+            # | shape A with (B, T', T') chunk masks (same plan, another table): seen, record, replay
+            assert states == ["seen", "replay", "replay"] * 4, states
             tab = eng._dw_plan["table"]["table"]
             per_block = [(tab.calls(False, li), tab.calls(True, li)) for li in range(eng.L)]
             assert all(f == 10 and bw >= 10 for f, bw in per_block), per_block
             assert tab.calls(False, eng.L) == 0
         else:
-            assert states == [None] * 9
+            assert states == [None] * 12
         out.append((losses, eng.fp.grad.clone(), eng.fp.master.clone()))
     assert out[1][0] == out[0][0]
     assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])

@@ -1,0 +1,12 @@
+# usage (GPU box): bash tools/final_train_run.sh   - the training-side half of tools/final_round_run.sh (census of the pure-CTC and the
+# hybrid step, the driver's bench line, the GPU suite) for a change that leaves the evaluation forward's kernels alone
+cd $GRAFT_REPO_ROOT
+bash tools/run_train_prof.sh r4 > gpurun_out/train_prof_r4.log 2>&1; head -8 gpurun_out/train_prof_r4/census.txt | cut -c1-160
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/train_prof_r4hyb; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o tb -- python3 $R/tools/train_bench.py --steps 5 --warmup 2 --ctc-weight 0.3 > $OUT/train_prof.log 2>&1
+python3 $R/tools/train_census.py $OUT/trace $OUT/census.txt | head -12 | cut -c1-150
+rm -rf $OUT/trace
+cd $R
+python bench.py > gpurun_out/bench_r4_final.json 2> gpurun_out/bench_r4_final.err; tail -c 1500 gpurun_out/bench_r4_final.json
+timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_final.log 2>&1; tail -4 gpurun_out/pytest_gpu_final.log

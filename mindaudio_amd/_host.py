@@ -275,7 +275,7 @@ def workspace(nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch().empty(max(int(nbytes), 1 << 16), dtype=torch().uint8, device=device)
         _ws[key] = buf
-    rec = _lib._recording
+    rec = _lib.recording()
     if rec is not None:  # a block table being filled names this buffer: it must outlive a later, larger workspace
         rec.keep.append(buf)
     return buf

@@ -5,6 +5,7 @@ raises.  The only thing resolved without the library is the symbol table used by
 """
 import ctypes
 import os
+import threading
 
 from . import _build
 
@@ -332,7 +333,16 @@ PROTOTYPES = {
 }
 
 _lib = None
-_recording = None  # the block table being filled (train/block_table.py): load() then hands out its recording proxy
+_tls = threading.local()  # .rec: the block table THIS thread is filling (train/block_table.py); load() then hands out its proxy
+
+
+def recording():
+    """The block table being filled by the calling thread, or None (other threads keep calling the library itself)."""
+    return getattr(_tls, "rec", None)
+
+
+def set_recording(table):
+    _tls.rec = table
 
 
 class MindaudioAmdError(RuntimeError):
@@ -348,7 +358,8 @@ def load():
     """Load the shared library (once). Raises if it has not been built."""
     global _lib
     if _lib is not None:
-        return _lib if _recording is None else _recording._proxy
+        rec = getattr(_tls, "rec", None)
+        return _lib if rec is None else rec._proxy
     path = lib_path()
     if not os.path.exists(path):
         raise MindaudioAmdError(

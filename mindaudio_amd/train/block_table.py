@@ -89,15 +89,15 @@ class BlockTable:
 
         def __enter__(self):
             t = self.table
-            if _lib._recording is not None:
-                raise _lib.MindaudioAmdError("a block table is already being recorded")
+            if _lib.recording() is not None:
+                raise _lib.MindaudioAmdError("a block table is already being recorded by this thread")
             t.seed, t.where = int(self.seed), None
-            _lib._recording = t
             t._proxy = _RecordingLib(t.lib, t)
+            _lib.set_recording(t)
             return t
 
         def __exit__(self, *exc):
-            _lib._recording = None
+            _lib.set_recording(None)
             self.table.where = None
             return False
 

@@ -595,6 +595,8 @@ class ConformerCTCTrainStep:
     def _salt(self, layer, site):
         return (layer + 1) * 16 + site
 
+    _DW_PLANS_KEPT = 4  # batch shapes whose plan (and block launch table: the tape and temporaries of one step, ~3 GB at cfg 4) stay resident
+
     _DW_SUFFIXES = ("ffm_w1", "ffm_w2", "qkv_w", "o_w", "pw1_w", "pw2_w", "ff_w1", "ff_w2")
 
     _LN_SITES = ("norm_final", "norm_ff", "norm_conv", "norm_mha", "norm_ff_macaron")
@@ -610,6 +612,14 @@ class ConformerCTCTrainStep:
         cur = self.__dict__.get("_dw_plan")
         if cur is not None and cur["m"] == m and cur.get("t2") == self._t2_cur:
             return cur
+        # the last few shapes' plans are kept (bucketed batches come back: a plan carries the shape's block launch table), as long as
+        # the shared arena they point into is the one they were derived for
+        plans = self.__dict__.setdefault("_dw_plans", {})
+        kept = plans.pop((m, self._t2_cur), None)
+        if kept is not None and kept["arena"] is self.__dict__.get("_dw_arena"):
+            plans[(m, self._t2_cur)] = kept  # (most recently used last)
+            self._dw_plan = kept
+            return kept
         import numpy as np
 
         lib, fp = _lib.load(), self.fp
@@ -703,6 +713,11 @@ class ConformerCTCTrainStep:
             layers.append((torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
                            torch.tensor(block_item, dtype=torch.int32, device=self.dev), first))
         self._dw_plan = dict(m=m, t2=self._t2_cur, arena=arena, off=off, layers=layers, half=half)
+        for k in [k for k, v in plans.items() if v["arena"] is not arena]:
+            del plans[k]  # (the arena grew: the older plans' tables name the old one)
+        plans[(m, self._t2_cur)] = self._dw_plan
+        while len(plans) > self._DW_PLANS_KEPT:
+            del plans[next(iter(plans))]
         if self.fused:
             o, nb, _ = off["att_ws"]
             self._dw_plan["att_ws"] = (arena[o:o + nb], arena[half + o:half + o + nb])
@@ -756,10 +771,13 @@ class ConformerCTCTrainStep:
             return None
         key = (b, t2, tuple(att_shape), self.ffn_one_launch, self.ffn_bwd_one_launch, self.ln_final_chained,
                self.ln_bwd_fused, self.dw_group_blocks, self.p_drop, self.p_pos, self.bn_momentum, id(plan["arena"]))
-        tb = plan.get("table")
-        if tb is None or tb["key"] != key:
-            plan["table"] = dict(key=key, state="seen")  # this step warms the wrappers' pooled buffers; the next one is recorded
-            return None
+        tables = plan.setdefault("tables", {})
+        tb = plan["table"] = tables.get(key)  # (plan["table"]: the one in use, for tests and tools)
+        if tb is None:
+            while len(tables) >= 2:  # (e.g. the padding-mask and the chunk-mask form of one shape)
+                del tables[next(iter(tables))]
+            tb = plan["table"] = tables[key] = dict(key=key, state="seen")  # this step warms the wrappers' pooled buffers; the next
+            return None                                                     # one is recorded
         if tb["state"] == "seen":
             from .block_table import BlockTable
 

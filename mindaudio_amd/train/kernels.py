@@ -4,7 +4,7 @@ from .. import _host, _lib
 
 
 def _t():
-    rec = _lib._recording  # a block table being filled keeps what the wrappers allocate (train/block_table.py)
+    rec = _lib.recording()  # a block table being filled keeps what the wrappers allocate (train/block_table.py)
     return _host.torch() if rec is None else rec.torch(_host.torch())
 
 

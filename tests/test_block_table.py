@@ -99,3 +99,21 @@ def test_recorder_stores_what_the_call_was_made_with():
     assert lib.ma_block_table_add(h, 0, 1, 10 ** 6, w17, 17, None, 0) == _lib.MA_ERR_INVALID_ARG
     assert lib.ma_block_table_add(h, 0, 99, fid, w17, 13, None, 0) == _lib.MA_ERR_INVALID_ARG
     assert lib.ma_block_table_add(h, 0, 1, fid, w17, 13, b"abc", 3) == _lib.MA_ERR_INVALID_ARG
+
+
+def test_recording_is_per_thread():
+    """While one thread fills a table, `_lib.load()` hands the recording proxy to THAT thread only."""
+    import threading
+
+    from mindaudio_amd.train.block_table import BlockTable
+
+    tab, seen = BlockTable(), {}
+    with tab.recording(5):
+        seen["recorder"] = type(_lib.load()).__name__
+        th = threading.Thread(target=lambda: seen.__setitem__("other", type(_lib.load()).__name__))
+        th.start()
+        th.join()
+        with pytest.raises(_lib.MindaudioAmdError):
+            tab.recording(6).__enter__()
+    seen["after"] = type(_lib.load()).__name__
+    assert seen == {"recorder": "_RecordingLib", "other": "CDLL", "after": "CDLL"}

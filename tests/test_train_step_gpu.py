@@ -459,9 +459,10 @@ def test_blocks_issued_from_the_launch_table_change_no_bit():
             states.append(None if tb is None else tb["state"])
         torch.cuda.synchronize()
         if tables:
-            # shape A: seen, record, replay | shape B (a new plan): seen, record, replay | shape A again: seen, record, replay
+            # shape A: seen, record, replay | shape B (a new plan): seen, record, replay | shape A again: its plan and table were kept
             # | shape A with (B, T', T') chunk masks (same plan, another table): seen, record, replay
-            assert states == ["seen", "replay", "replay"] * 4, states
+            assert states == ["seen", "replay", "replay"] * 2 + ["replay"] * 3 + ["seen", "replay", "replay"], states
+            assert len(eng._dw_plans) == 2 and len(eng._dw_plan["tables"]) == 2
             tab = eng._dw_plan["table"]["table"]
             per_block = [(tab.calls(False, li), tab.calls(True, li)) for li in range(eng.L)]
             assert all(f == 10 and bw >= 10 for f, bw in per_block), per_block

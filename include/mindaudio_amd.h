@@ -773,9 +773,9 @@ int ma_mha_small_bwd_x32(const float* q, int64_t ldq, const float* k, int64_t ld
                          int32_t heads, int32_t d_k, float scale, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
                          int64_t lddv, ma_stream_t stream);
 
-/* LabelSmoothingLoss (loss/label_smoothing_loss.py:24-117) on logits (rows, ld >= V) float32: stats[0] += sum over
- * unmasked rows of KL(true_dist || softmax), stats[1] += correct argmax count, stats[2] += unmasked rows (caller zeroes;
- * the loss is stats[0] / batch, the accuracy stats[1] / stats[2], asr_model.py:188-209); the per-row terms go through
+/* LabelSmoothingLoss (loss/label_smoothing_loss.py:24-117) on logits (rows, ld >= V) float32: stats[0] = sum over
+ * unmasked rows of KL(true_dist || softmax), stats[1] = correct argmax count, stats[2] = unmasked rows (stored, round 4: no fill in
+ * front of the call; the loss is stats[0] / batch, the accuracy stats[1] / stats[2], asr_model.py:188-209); the per-row terms go through
  * `row_stats` (rows x 3 floats of scratch) and are added in row order - no float atomics.
  * dlogits (rows, ld_out) bf16 (_f32) or float32 (_x32: the float32 validation mode) = grad_scale * mask * (softmax - true_dist),
  * zero in columns >= V.  `denom` (optional DEVICE float): `normalize_length=True` (label_smoothing_loss.py:106: the divisor is

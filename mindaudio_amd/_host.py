@@ -18,6 +18,9 @@ def torch():
         import torch as _t
 
         _torch = _t
+    rec = _lib.recording()
+    if rec is not None:  # the block table this thread is filling keeps every tensor the wrappers allocate (train/block_table.py)
+        return rec.torch(_torch)
     return _torch
 
 

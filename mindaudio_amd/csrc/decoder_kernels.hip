@@ -676,7 +676,7 @@ MA_LDS_ATTR(mha_small_bwd_mfma_kernel, 163840);
 
 // ---- label smoothing loss --------------------------------------------------------------------------------------
 // one workgroup per token row: kl = sum_v q_v (log q_v - logp_v), q = on at the target, off elsewhere; masked rows
-// contribute nothing.  stats[0] += kl, stats[1] += (argmax == target) * mask, stats[2] += mask.
+// contribute nothing.  stats[0] = sum kl, stats[1] = sum (argmax == target) * mask, stats[2] = sum mask.
 template <typename OT>
 __global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __restrict__ logits, int64_t ld, int V,
                                                               const int32_t* __restrict__ target, const float* __restrict__ mask,
@@ -746,14 +746,14 @@ __global__ __launch_bounds__(256) void label_smoothing_kernel(const float* __res
   }
 }
 
-// stats[k] += sum over the rows of row_stats[row][k], k = 0..2, in a fixed order (one wave per statistic)
+// stats[k] = sum over the rows of row_stats[row][k], k = 0..2, in a fixed order (one wave per statistic)
 __global__ __launch_bounds__(192) void label_smoothing_reduce_kernel(const float* __restrict__ row_stats, int64_t rows, float* stats) {
   const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float s = 0.0f;
   for (int64_t r = lane; r < rows; r += 64) s += row_stats[r * 3 + k];
 #pragma unroll
   for (int off2 = 32; off2 > 0; off2 >>= 1) s += __shfl_xor(s, off2, 64);
-  if (lane == 0) stats[k] += s;
+  if (lane == 0) stats[k] = s;
 }
 
 static int d_grid(int64_t n, int cap = 4096) {

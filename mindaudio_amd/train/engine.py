@@ -933,7 +933,7 @@ class ConformerCTCTrainStep:
             # label_smoothing_loss.py:105-106: / batch, or / tokens (divided on the device) when length_normalized_loss
             loss_att, d_mem = self._decoder_forward_backward(enc_bf, mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks,
                                                              ys_masks, grad_scale * (1.0 - wc) / (1.0 if self.len_norm else b),
-                                                             seed)
+                                                             seed, tb)
             self.last_loss_ctc, self.last_loss_att = loss, loss_att
             loss = wc * loss + (1.0 - wc) * loss_att
 
@@ -1265,28 +1265,86 @@ class ConformerCTCTrainStep:
             self._layer_done(li)
 
     def _decoder_forward_backward(self, mem_bf, enc_mask2d, b, t2, ys_in_pad, ys_out_pad, ys_sub_masks, ys_masks, gscale,
-                                  seed):
+                                  seed, tb=None):
         """TransformerDecoder forward + label-smoothing loss + backward (models/conformer.py:594-639,
-        asr_model.py:154-186).  Fills the decoder gradients; returns (loss_att tensor, d_memory (B*T', 256) float32)."""
+        asr_model.py:154-186).  Fills the decoder gradients; returns (loss_att tensor, d_memory (B*T', 256) float32).
+        With the encoder blocks' launch table `tb` (block_tables) the decoder's launches join it: decoder layer l is "block" L + l of
+        the table (forward and backward), the embedding is the forward / backward of block L + Ld, the output layer the forward of
+        block L + Ld + 1 and its backward that of block L + Ld + 2, with the loss (which takes the step's loss scale) issued between
+        them; the label columns are copied into buffers the table owns."""
+        dec, b_ = self.dec, b
+        L1 = ys_in_pad.shape[1]
+        md = b * L1
+        f32 = torch.float32
+        dtb = None
+        if tb is not None and not self.len_norm and tb["state"] in ("record", "replay"):
+            dtb = tb.get("dec")
+            if tb["state"] == "record":
+                dtb = tb["dec"] = dict(L1=L1, ls={},
+                                       toks=torch.empty(md, dtype=torch.int32, device=self.dev),
+                                       sub=torch.empty(tuple(ys_sub_masks.shape), dtype=f32, device=self.dev),
+                                       pe=dec.pe[:L1].to(f32).contiguous().clone(),
+                                       tgt=torch.empty(md, dtype=torch.int32, device=self.dev),
+                                       tmask=torch.empty(md, dtype=f32, device=self.dev))
+            elif dtb is not None and (dtb["L1"] != L1 or "out" not in dtb or tuple(dtb["sub"].shape) != tuple(ys_sub_masks.shape)):
+                dtb = None  # another label length than the recorded step's: walked
+        if dtb is None:
+            toks = ys_in_pad.to(torch.int32).contiguous().reshape(-1)
+            sub = ys_sub_masks.to(f32).contiguous()
+            pe = dec.pe[:L1].to(f32).contiguous()
+            tgt = ys_out_pad.to(torch.int32).contiguous().reshape(-1)
+            tmask = ys_masks.to(f32).contiguous().reshape(-1)
+            return self._decoder_walk(mem_bf, enc_mask2d, b_, t2, L1, toks, sub, pe, tgt, tmask, gscale, seed, None, None)
+        # (conversion and placement in one launch each; the positional table is constant)
+        toks, sub, pe = dtb["toks"].copy_(ys_in_pad.reshape(-1)), dtb["sub"].copy_(ys_sub_masks), dtb["pe"]
+        tgt, tmask = dtb["tgt"].copy_(ys_out_pad.reshape(-1)), dtb["tmask"].copy_(ys_masks.reshape(-1))
+        if tb["state"] == "record":
+            with tb["table"].recording(seed):
+                dtb["out"] = self._decoder_walk(mem_bf, enc_mask2d, b_, t2, L1, toks, sub, pe, tgt, tmask, gscale, seed, tb["table"],
+                                                dtb["ls"])
+            stats, d_mem = dtb["out"]
+        else:
+            table, stream, L, Ld = tb["table"], _host.current_stream_ptr(), self.L, self.Ld
+            table.forward(L + Ld, seed, stream)
+            for li in range(Ld):
+                table.forward(L + li, seed, stream)
+            table.forward(L + Ld + 1, seed, stream)
+            # (the loss carries the step's loss scale: issued from here, between the two halves of the output layer's segment pair)
+            ls = dtb["ls"]
+            self.K.label_smoothing_loss_grad(ls["logits"], self.V, tgt, tmask, self.lsm, gscale, bufs=ls)
+            table.forward(L + Ld + 2, seed, stream)
+            for li in reversed(range(Ld)):
+                table.backward(L + li, seed, stream)
+            table.backward(L + Ld, seed, stream)
+            if self.dec_names:
+                self.reducer.launch(*self.fp.span(self.dec_names))
+            stats, d_mem = dtb["out"]
+        self.last_acc = stats[1] / stats[2]
+        return stats[0] / b_, d_mem
+
+    def _decoder_walk(self, mem_bf, enc_mask2d, b, t2, L1, toks, sub, pe, tgt, tmask, gscale, seed, rec, ls):
+        """The decoder call by call; `rec`: the block table being filled (segments as _decoder_forward_backward lists them).
+        Returns (loss_att, d_memory) - or (stats, d_memory) to the recording caller, which forms the loss from the kept `stats`."""
         fp, d, dec = self.fp, self.d, self.dec
         ops, K = self.O, self.K  # bf16 throughput kernels or their float32 validation twins
+        tt = _host.torch()        # (allocations of a recorded step stay referenced by the table)
         f32 = torch.float32
         pd, pp = float(dec.dropout_rate), float(dec.positional_dropout_rate)
         eps = 1e-12  # models/conformer.py:417-419, 548
         dk = d // self.heads
         scale = 1.0 / dk  # q / sqrt(dk) . k / sqrt(dk) (attention.py:150-152)
-        L1 = ys_in_pad.shape[1]
         md, m = b * L1, b * t2
-        toks = ys_in_pad.to(torch.int32).contiguous().reshape(-1)
-        sub = ys_sub_masks.to(f32).contiguous()
         emask = enc_mask2d
         RELU = _lib.ACT_RELU
         salt = lambda li, site: self._salt(100 + li, site)  # noqa: E731
         xscale = math.sqrt(d)
-        pe = dec.pe[:L1].to(f32).contiguous()
+        seg = (lambda backward, blk: rec.segment(backward, blk)) if rec is not None else (lambda backward, blk: None)
+        L, Ld = self.L, self.Ld
+        seg(False, L + Ld)
         x = K.embed_posenc(toks, fp.p("dec.embed"), pe, L1, xscale, pp, seed, salt(-1, 0))
         tape = []
         for li in range(self.Ld):
+            seg(False, L + li)
             pre = "d%d." % li
             W, P = (lambda n, pre=pre: fp.w(pre + n)), (lambda n, pre=pre: fp.p(pre + n))
             T = {"x0": x}
@@ -1310,22 +1368,25 @@ class ConformerCTCTrainStep:
             x = K.dropout_add(x2, y, 1.0, pd, seed, salt(li, 3))
             T.update(a3=a3, u=u, h=h)
             tape.append(T)
+        seg(False, L + Ld + 1)
         yb = ops.layernorm(x, fp.p("dec.after_norm.g"), fp.p("dec.after_norm.b"), eps=eps)
-        logits = torch.empty((md, self.Vp), dtype=f32, device=self.dev)
+        logits = tt.empty((md, self.Vp), dtype=f32, device=self.dev)
         ops.gemm(yb, fp.w("dec.out_w"), bias=fp.p("dec.out_b"), out_dtype=f32, out=logits[:, :self.V])
-        tgt = ys_out_pad.to(torch.int32).contiguous().reshape(-1)
-        tmask = ys_masks.to(f32).contiguous().reshape(-1)
-        stats, dlog = K.label_smoothing_loss_grad(logits, self.V, tgt, tmask, self.lsm, gscale, normalize_length=self.len_norm)
-        loss_att = stats[0] / (stats[2] if self.len_norm else b)
-        self.last_acc = stats[1] / stats[2]
+        seg(None, 0)  # (the loss takes the step's loss scale as an argument: never replayed with a recorded one)
+        stats, dlog = K.label_smoothing_loss_grad(logits, self.V, tgt, tmask, self.lsm, gscale, normalize_length=self.len_norm,
+                                                  **({} if ls is None else {"bufs": ls}))
+        if ls is not None:
+            ls["logits"] = logits
         # ---- backward ----
+        seg(False, L + Ld + 2)
         K.gemm_tn(dlog, yb, fp.g("dec.out_w"), colsum=fp.g("dec.out_b"), rows_store=self.V)
         dy = self._dX(dlog, "dec.out_w")
-        g = torch.empty((md, d), dtype=f32, device=self.dev)
+        g = tt.empty((md, d), dtype=f32, device=self.dev)
         K.layernorm_bwd(x, fp.p("dec.after_norm.g"), dy, g, fp.g("dec.after_norm.g"), fp.g("dec.after_norm.b"),
                         accumulate=False, eps=eps)
-        d_mem = torch.zeros((m, d), dtype=f32, device=self.dev)
+        d_mem = tt.empty((m, d), dtype=f32, device=self.dev)  # (stored by the last layer's product, added to by the others: no fill)
         for li in reversed(range(self.Ld)):
+            seg(True, L + li)
             pre = "d%d." % li
             P, G = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n))
             DX = lambda dy_, n, pre=pre, **kw: self._dX(dy_, pre + n, **kw)  # noqa: E731  (dy . W on the transposed copy)
@@ -1341,31 +1402,38 @@ class ConformerCTCTrainStep:
             do = K.dropout_bwd(g, 1.0, pd, seed, salt(li, 1))
             self._dW(do, T["ctx2"], pre + "ca_o_w", pre + "ca_o_b")
             dctx = DX(do, "ca_o_w")
-            dq = torch.empty_like(T["q"])
-            dkv = torch.empty_like(T["kv"])
+            dq = tt.empty_like(T["q"])
+            dkv = tt.empty_like(T["kv"])
             K.mha_small_bwd(T["q"], T["kv"][:, :d], T["kv"][:, d:], T["probs2"], T["ctx2"], dctx, b, L1, t2, scale, dq,
                             dkv[:, :d], dkv[:, d:], self.heads, dk)
             self._dW(dq, T["a2"], pre + "ca_q_w", pre + "ca_q_b")
             K.layernorm_bwd(T["x1"], P("norm2.g"), DX(dq, "ca_q_w"), g, G("norm2.g"), G("norm2.b"), eps=eps)
             self._dW(dkv, mem_bf, pre + "ca_kv_w", pre + "ca_kv_b")
-            DX(dkv, "ca_kv_w", residual=d_mem, out_dtype=f32, out=d_mem)
+            DX(dkv, "ca_kv_w", residual=d_mem if li < self.Ld - 1 else None, out_dtype=f32, out=d_mem)
             # self attention
             do = K.dropout_bwd(g, 1.0, pd, seed, salt(li, 0))
             self._dW(do, T["ctx"], pre + "sa_o_w", pre + "sa_o_b")
             dctx = DX(do, "sa_o_w")
-            dqkv = torch.empty_like(T["qkv"])
+            dqkv = tt.empty_like(T["qkv"])
             qkv = T["qkv"]
             K.mha_small_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], T["probs"], T["ctx"], dctx, b, L1, L1, scale,
                             dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], self.heads, dk)
             self._dW(dqkv, T["a"], pre + "sa_qkv_w", pre + "sa_qkv_b")
             K.layernorm_bwd(T["x0"], P("norm1.g"), DX(dqkv, "sa_qkv_w"), g, G("norm1.g"), G("norm1.b"), eps=eps)
+        seg(True, L + Ld)
         K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0))
         if self._dq_dec is not None:  # the decoder layers' weight gradients: one grid
             self._dq_dec.launch()
             self._dq_dec.clear()
+        if rec is not None:
+            rec.segment(None, 0)
+            rec.keep.append(tape)
         if self.dec_names:
             self.reducer.launch(*fp.span(self.dec_names))
-        return loss_att, d_mem
+        if rec is not None:
+            return stats, d_mem
+        self.last_acc = stats[1] / stats[2]
+        return stats[0] / (stats[2] if self.len_norm else b), d_mem
 
     def _ffn_fwd(self, x, key, ln, W, P, seed, li, s0):
         ops, K = self.O, self.K

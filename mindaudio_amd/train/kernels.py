@@ -4,8 +4,7 @@ from .. import _host, _lib
 
 
 def _t():
-    rec = _lib.recording()  # a block table being filled keeps what the wrappers allocate (train/block_table.py)
-    return _host.torch() if rec is None else rec.torch(_host.torch())
+    return _host.torch()  # (a block table being filled gets a proxy that keeps what the wrappers allocate: train/block_table.py)
 
 
 def _s():
@@ -232,18 +231,25 @@ def mha_small_bwd(q, k, v, probs, ctx, dctx, batch, lq, lk, scale, dq, dk, dv, h
                                                  dv.stride(0), _s()), "mha_small_bwd")
 
 
-def label_smoothing_loss_grad(logits, V, target, mask, smoothing, grad_scale, normalize_length=False):
+def label_smoothing_loss_grad(logits, V, target, mask, smoothing, grad_scale, normalize_length=False, bufs=None):
     """-> (stats (3,) f32 = [sum kl, correct, tokens], dlogits (rows, ld) bf16).  normalize_length: the gradient is divided by the
-    number of unmasked tokens (a device-side sum of `mask`) instead of what the caller folded into grad_scale."""
-    return _label_smoothing(logits, V, target, mask, smoothing, grad_scale, normalize_length, False)
+    number of unmasked tokens (a device-side sum of `mask`) instead of what the caller folded into grad_scale.
+    bufs: a dict that receives the output / scratch tensors of the first call and hands them back to the later ones (the launch table's
+    steps: the outputs stay at the addresses the recorded neighbours of this call read)."""
+    return _label_smoothing(logits, V, target, mask, smoothing, grad_scale, normalize_length, False, bufs)
 
 
-def _label_smoothing(logits, V, target, mask, smoothing, grad_scale, normalize_length, out_f32):
+def _label_smoothing(logits, V, target, mask, smoothing, grad_scale, normalize_length, out_f32, bufs=None):
     t = _t()
     rows = logits.shape[0]
-    stats = t.zeros(3, dtype=t.float32, device=logits.device)
-    row_stats = t.empty(rows * 3, dtype=t.float32, device=logits.device)
-    dlog = t.empty((rows, logits.stride(0)), dtype=t.float32 if out_f32 else t.bfloat16, device=logits.device)
+    if bufs:
+        stats, row_stats, dlog = bufs["stats"], bufs["row_stats"], bufs["dlog"]
+    else:
+        stats = t.empty(3, dtype=t.float32, device=logits.device)  # (the kernel stores all three)
+        row_stats = t.empty(rows * 3, dtype=t.float32, device=logits.device)
+        dlog = t.empty((rows, logits.stride(0)), dtype=t.float32 if out_f32 else t.bfloat16, device=logits.device)
+        if bufs is not None:
+            bufs.update(stats=stats, row_stats=row_stats, dlog=dlog)
     denom = mask.sum().reshape(1).to(t.float32) if normalize_length else None
     fn = _lib.load().ma_label_smoothing_loss_grad_len_x32 if out_f32 else _lib.load().ma_label_smoothing_loss_grad_len_f32
     _lib.check(fn(_p(logits), logits.stride(0), rows, V, _p(target), _p(mask), float(smoothing), float(grad_scale), _p(denom),

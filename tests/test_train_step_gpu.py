@@ -474,6 +474,38 @@ def test_blocks_issued_from_the_launch_table_change_no_bit():
     assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
 
 
+def test_hybrid_step_from_the_launch_table_changes_no_bit():
+    """The shipped configuration (ctc_weight 0.3): the decoder's layers join the encoder blocks' launch table (decoder layer l =
+    block L + l; embedding, output layer and its backward = blocks L + Ld .. L + Ld + 2), the label-smoothing loss - which takes the
+    step's loss scale as an argument - stays a live call between the replayed segments.  Seven optimizer steps, dropout ON in encoder
+    and decoder, the loss scale changed by hand after the fourth: bit-identical losses and masters with the table on and off."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    out = []
+    for tables in (False, True):
+        _, _, _, model, cols = _hybrid_setup(blocks=2, dblocks=2)
+        model.decoder.dropout_rate, model.decoder.positional_dropout_rate = 0.1, 0.1
+        cols = tuple(c.cuda() if c is not None else None for c in cols)
+        eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1)
+        assert eng.block_tables and eng.dec is not None and float(eng.dec.dropout_rate) == 0.1
+        eng.block_tables = tables
+        losses = []
+        for k in range(7):
+            if k == 4:
+                eng.scaler.scale = 256.0
+            losses.append(float(eng.step(*cols)[0]))
+        torch.cuda.synchronize()
+        if tables:
+            tb = eng._dw_plan["table"]
+            tab, L, Ld = tb["table"], eng.L, eng.Ld
+            assert tb["state"] == "replay" and "out" in tb["dec"]
+            counts = [(tab.calls(False, blk), tab.calls(True, blk)) for blk in range(L, L + Ld + 3)]
+            assert all(f > 0 and bw > 0 for f, bw in counts[:Ld + 1]) and counts[Ld + 1][0] > 0 and counts[Ld + 2][0] > 0, counts
+        out.append((losses, eng.fp.master.clone()))
+    assert out[1][0] == out[0][0]
+    assert torch.equal(out[1][1], out[0][1])
+
+
 def test_weight_gradient_stream_changes_no_bit():
     """With wg_stream=True (experimental) the grouped weight-gradient products and the gradient buckets run on a second
     stream beside the input-gradient chain (the batched sums stay on the main stream).  Same launches, same summation orders: five

@@ -604,6 +604,10 @@ def main():
                           args.warmup if args.train else 2, barrier, args.force_collective, args.train_digest,
                           second_stream=args.second_stream, default_stream=args.train_default_stream)
         if not args.train and not args.no_hybrid_leg and world == 1 and not args.force_collective:
+            import gc
+
+            gc.collect()  # (an engine is a reference cycle: the first leg's launch tables and tape must not stay allocated - and be
+            torch.cuda.empty_cache()  # walked by a collection in the middle of a timed step - under the second leg)
             hybrid = train_leg(rank, world, dev, None, max(5, args.train_steps // 2), 2, barrier, ctc_weight=0.3)
 
     if rank == 0:

@@ -3,6 +3,7 @@
 to enqueue one step behind a busy GPU, and a hash of the trained masters (must agree: the table re-issues the walked step's calls).
     python tools/block_table_ab.py [--hybrid] [--steps 10]"""
 import argparse
+import gc
 import json
 import os
 import sys
@@ -23,7 +24,7 @@ def main():
     dev = torch.device("cuda:0")
     init = engine.ConformerCTCTrainStep.__init__
     out = {}
-    for tables in (True, False, True):
+    for tables in (True, False, True, False):
         def patched(self, *a, _t=tables, **k):
             init(self, *a, **k)
             self.block_tables = self.block_tables and _t
@@ -33,6 +34,8 @@ def main():
                                   ctc_weight=0.3 if args.hybrid else 1.0)
         finally:
             engine.ConformerCTCTrainStep.__init__ = init
+        gc.collect()  # (an engine is a reference cycle: without this the previous arm's tables stay allocated under the next arm)
+        torch.cuda.empty_cache()
         out.setdefault("tables_on" if tables else "tables_off", []).append(
             {k: res[k] for k in ("ms_per_step", "host_enqueue_ms", "masters_sha16", "last_loss")})
     out["masters_equal"] = len({r["masters_sha16"] for v in out.values() for r in v}) == 1

@@ -595,7 +595,10 @@ class ConformerCTCTrainStep:
     def _salt(self, layer, site):
         return (layer + 1) * 16 + site
 
-    _DW_PLANS_KEPT = 4  # batch shapes whose plan (and block launch table: the tape and temporaries of one step, ~3 GB at cfg 4) stay resident
+    # Batch shapes whose plan - and block launch table: the tape and temporaries of one step, 2 - 4 GB - stay resident.  The reference
+    # trains on static shapes (MindSpore graph mode): examples/conformer/conformer.yaml:71-72 has 16 (frame bucket, batch) pairs and pads
+    # the labels to token_max_length, so 16 plans cover a whole epoch (~45 of 288 GB).
+    _DW_PLANS_KEPT = 16
 
     _DW_SUFFIXES = ("ffm_w1", "ffm_w2", "qkv_w", "o_w", "pw1_w", "pw2_w", "ff_w1", "ff_w2")
 

@@ -1019,7 +1019,8 @@ int ma_ctc_loss_grad_x32(const float* logits, int64_t ld, int64_t batch, int64_t
  * and from then on issues the block with ONE call; the entries' device buffers must stay allocated while the table lives.
  *   ma_block_table_entry_point(name): index of a replayable entry point (int-returning, `ma_stream_t stream` last, only scalars,
  *     device pointers and pointers to the host structs ma_train_epilogue_t / ma_gemm_epilogue_t / ma_tn_item_t / ma_tn_direct_item_t /
- *     ma_melbank_t), -1 otherwise;  ma_block_table_entry_point_params(fn): its parameter count;  _seeds(fn): bit k set = parameter k
+ *     ma_melbank_t); -2 for a launch that is not (host out-pointers, host pointer tables: a recorded block must not contain one),
+ *     -1 for anything else (size queries, unknown names);  ma_block_table_entry_point_params(fn): its parameter count;  _seeds(fn): bit k set = parameter k
  *     is a dropout seed (`uint32_t seed*`).
  *   ma_block_table_add: words[k] = parameter k as 8 bytes - pointer or integer as is, float / double as the bits of a double, a host
  *     struct (or host array) as its byte offset in `blob` (-1 = NULL; blob_bytes % 8 == 0; the blob is copied), the stream and seed

@@ -51,6 +51,11 @@ const Name kNames[] = {
 #undef MA_BLOCK_TABLE_NAMES
 };
 constexpr int32_t kNumNames = (int32_t)(sizeof(kNames) / sizeof(kNames[0]));
+const char* const kSkipped[] = {
+#define MA_BLOCK_TABLE_SKIPPED
+#include "block_table_calls.inc"
+#undef MA_BLOCK_TABLE_SKIPPED
+    nullptr};
 
 struct Ctx {
   unsigned char* blob;  // the call's blob inside the segment
@@ -95,6 +100,8 @@ int32_t ma_block_table_entry_point(const char* name) {
   if (name == nullptr) return -1;
   for (int32_t k = 0; k < kNumNames; ++k)
     if (std::strcmp(kNames[k].name, name) == 0) return k;
+  for (const char* const* q = kSkipped; *q != nullptr; ++q)
+    if (std::strcmp(*q, name) == 0) return -2;  // a launch, but not one the table can re-issue
   return -1;
 }
 

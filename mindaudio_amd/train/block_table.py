@@ -118,7 +118,7 @@ class BlockTable:
         proto = _lib.PROTOTYPES.get(name)
         fid = int(self.lib.ma_block_table_entry_point(name.encode())) if proto is not None else -1
         if fid < 0:
-            if name not in _NOT_REPLAYABLE:
+            if fid != -2 or name.startswith("ma_block_table_") or name.startswith("ma_conformer_block_"):
                 return fn  # size queries, layout helpers, the table's own entry points: nothing to replay
 
             def refuse(*args):
@@ -177,7 +177,3 @@ class BlockTable:
         rc = self.lib.ma_conformer_block_bwd_train(self.handle, block, seed, stream)
         if rc != 0:
             _lib.check(rc, "conformer_block_bwd_train(block %d, call %d)" % (block, self.lib.ma_block_table_failed_call(self.handle)))
-
-
-# launches that tools/gen_block_table.py could not make replayable (host pointer tables): refused inside a recorded block
-_NOT_REPLAYABLE = frozenset(("ma_fft_pow2_c32",))

@@ -26,6 +26,7 @@ def test_replayable_entry_points_match_the_binding():
     for name, (res, args) in _lib.PROTOTYPES.items():
         fid = lib.ma_block_table_entry_point(name.encode())
         if fid < 0:
+            # every launch of the binding (int result, stream last ... but so do a few non-launches: not asserted the other way)
             continue
         n += 1
         # same parameter count as the ctypes prototype, a stream last, int result
@@ -42,8 +43,8 @@ def test_replayable_entry_points_match_the_binding():
                  "ma_layernorm_bwd_next_f32"):
         assert lib.ma_block_table_entry_point(name.encode()) >= 0, name
     # host pointer tables and the table's own entry points are not replayable; size queries are not launches
-    for name in ("ma_fft_pow2_c32", "ma_conformer_block_fwd_train", "ma_gemm_tn_workspace_bytes", "nonsense"):
-        assert lib.ma_block_table_entry_point(name.encode()) == -1
+    for name, want in (("ma_fft_pow2_c32", -2), ("ma_conformer_block_fwd_train", -2), ("ma_gemm_tn_workspace_bytes", -1), ("nonsense", -1)):
+        assert lib.ma_block_table_entry_point(name.encode()) == want, name
 
 
 def test_recorder_stores_what_the_call_was_made_with():
@@ -117,3 +118,18 @@ def test_recording_is_per_thread():
             tab.recording(6).__enter__()
     seen["after"] = type(_lib.load()).__name__
     assert seen == {"recorder": "_RecordingLib", "other": "CDLL", "after": "CDLL"}
+
+
+def test_a_launch_the_table_cannot_reissue_is_refused_inside_a_block():
+    from mindaudio_amd.train.block_table import BlockTable
+
+    tab = BlockTable()
+    with tab.recording(1):
+        lib = _lib.load()
+        tab.segment(False, 0)
+        with pytest.raises(_lib.MindaudioAmdError):
+            lib.ma_fft_pow2_c32(None, None, 0, 0, 0, None, None)
+        # size queries pass through, recorded or not
+        assert lib.ma_gemm_tn_workspace_bytes(256, 256, 1024) > 0
+        tab.segment(None, 0)
+    assert tab.calls(False, 0) == 0

@@ -8,5 +8,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o tb -- pyth
 python3 $R/tools/train_census.py $OUT/trace $OUT/census.txt | head -45 | cut -c1-150
 rm -rf $OUT/trace
 cd $R
+python tools/block_table_ab.py > gpurun_out/block_table_ab.json 2> gpurun_out/block_table_ab.err; cat gpurun_out/block_table_ab.json
 python bench.py > gpurun_out/bench_r4_final.json 2> gpurun_out/bench_r4_final.err; tail -c 1500 gpurun_out/bench_r4_final.json
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_final.log 2>&1; tail -4 gpurun_out/pytest_gpu_final.log

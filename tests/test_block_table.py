@@ -133,3 +133,46 @@ def test_a_launch_the_table_cannot_reissue_is_refused_inside_a_block():
         assert lib.ma_gemm_tn_workspace_bytes(256, 256, 1024) > 0
         tab.segment(None, 0)
     assert tab.calls(False, 0) == 0
+
+
+@pytest.mark.parametrize("blocks,group", [(12, 6), (12, 5), (2, 6), (7, 3), (1, 1)])
+def test_replayed_backward_launches_the_gradient_buckets_where_the_walked_one_does(monkeypatch, blocks, group):
+    """N > 1: a finished group's gradient buckets go on the wire (reducer.launch) behind its direct weight-gradient products.  The
+    replayed backward pass (one C call per block) must issue the same spans at the same points as _layer_done / _flush_direct do
+    when the blocks are walked - checked here on the host logic alone (no launches: the library and the table are stand-ins)."""
+    import ctypes
+    from types import SimpleNamespace
+
+    from mindaudio_amd import _host
+    from mindaudio_amd.train import engine as E
+
+    def make():
+        eng = object.__new__(E.ConformerCTCTrainStep)
+        log = []
+        eng.L, eng.d, eng.hidden, eng.K, eng.p_drop = blocks, 256, 2048, None, 0.1
+        eng.dw_group_blocks, eng._dw_direct, eng._wg, eng._dq, eng._dq_blocks = group, True, None, None, []
+        eng.layer_names = [["l%d.first" % i, "l%d.last" % i] for i in range(blocks)]
+        eng.fp = SimpleNamespace(span=lambda names: (names[0], names[-1]))
+        eng.reducer = SimpleNamespace(launch=lambda lo, hi: log.append(("bucket", lo, hi)))
+        item = SimpleNamespace(data_ptr=lambda: 0)
+        eng._dw_cur = dict(layers=[(item, item, 1)] * blocks)
+        return eng, log
+
+    prev = _host.swap_pinned(ctypes.c_void_p(0))
+    try:
+        # walked: what _layer_done does after each block's launches
+        walked, wlog = make()
+        stub = SimpleNamespace(ma_reduce_splits_batch_f32=lambda *a: wlog.append(("block", a[2])) or 0)
+        monkeypatch.setattr(E._lib, "load", lambda: stub)
+        for li in reversed(range(blocks)):
+            wlog.append(("launches", li))
+            walked._layer_done(li)
+        # replayed: the table stands in for the block's launches
+        replayed, rlog = make()
+        table = SimpleNamespace(backward=lambda li, seed, stream: rlog.append(("launches", li)))
+        ctx = dict(seed=1, b=1, t2=1, mask_rows=None, att_mask=None, pos_all=None, table=dict(state="replay", table=table))
+        replayed._blocks_backward_fused(None, None, None, ctx)
+    finally:
+        _host.swap_pinned(prev)
+    assert [e for e in wlog if e[0] != "block"] == rlog
+    assert sum(1 for e in rlog if e[0] == "bucket") == blocks and walked._dq_blocks == replayed._dq_blocks == []

@@ -176,3 +176,24 @@ def test_replayed_backward_launches_the_gradient_buckets_where_the_walked_one_do
         _host.swap_pinned(prev)
     assert [e for e in wlog if e[0] != "block"] == rlog
     assert sum(1 for e in rlog if e[0] == "bucket") == blocks and walked._dq_blocks == replayed._dq_blocks == []
+
+
+def test_replay_dispatches_typed_calls_and_reports_the_failing_entry():
+    """No GPU needed: entries whose arguments the entry points reject (NULL buffers) make the replay stop at that entry with the
+    entry point's own status - which shows that the generated typed call reached the right function with the recorded words."""
+    from mindaudio_amd.train.block_table import BlockTable
+
+    lib = _lib.load()
+    tab = BlockTable()
+    tab.seed = 5
+    tab.segment(False, 3)
+    for name, args in (("ma_cast_f32_bf16", (None, None, 16, None)),
+                       ("ma_dropout_bwd_bf16", (None, 0, None, 0, 4, 4, 1.0, None, 0.1, 5, 6, None))):
+        fid = lib.ma_block_table_entry_point(name.encode())
+        tab._add(name, fid, _lib.PROTOTYPES[name][1], lib.ma_block_table_entry_point_seeds(fid), args)
+    assert tab.calls(False, 3) == 2
+    assert lib.ma_conformer_block_fwd_train(tab.handle, 3, 7, None) == lib.ma_cast_f32_bf16(None, None, 16, None) == _lib.MA_ERR_INVALID_ARG
+    assert lib.ma_block_table_failed_call(tab.handle) == 0
+    with pytest.raises(ValueError):
+        tab.forward(3, 7, None)
+    assert lib.ma_conformer_block_bwd_train(tab.handle, 3, 7, None) == _lib.MA_ERR_INVALID_ARG  # nothing recorded that way

@@ -926,6 +926,11 @@ int ma_ffn_packed_pair_qkv_bf16(const void* packed_a, const float* b1_a, const f
 int ma_grad_overflow_f32(const float* g, int64_t n, int32_t* flag, ma_stream_t stream);
 int ma_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                 float eps, float inv_scale, const int32_t* overflow, ma_stream_t stream);
+/* ma_adam_f32 + ma_cast_f32_bf16 of the updated parameters in one launch (round 4): mirror_bf16 (n) receives the bf16 conversion
+ * (round to nearest even, as ma_cast_f32_bf16) of every updated parameter; untouched, like the parameters, when *overflow != 0.
+ * Same parameter bits as ma_adam_f32.  n % 4 == 0, 16-byte aligned float buffers: MA_ERR_UNSUPPORTED otherwise. */
+int ma_adam_mirror_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                       float eps, float inv_scale, const int32_t* overflow, void* mirror_bf16, ma_stream_t stream);
 
 /* Res2NetBlock (ecapatdnn.py:66-114) in one launch: y_0 = x_0, y_i = BN(ReLU(conv_{k=3,dil}(x_i + y_{i-1}) + b_i)), i = 1..scale-1
  * (y_1 from x_1 alone), x_i = columns [i cc, (i+1) cc) of x.  x, y: (batch, T + 2 halo, >= scale * cc) bf16 with zero halo rows

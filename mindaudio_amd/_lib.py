@@ -301,6 +301,7 @@ PROTOTYPES = {
                                                    vp, f32, vp, vp, i64, vp, i64, vp]),
     "ma_grad_overflow_f32": (ctypes.c_int, [vp, i64, vp, vp]),
     "ma_adam_f32": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
+    "ma_adam_mirror_f32": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, vp]),
     "ma_db_workspace_bytes": (i64, [i64, i64]),
     "ma_amplitude_to_db_f32": (ctypes.c_int, [c_f32p, i64, i64, f32, f32, f32, f32, c_f32p, ctypes.c_void_p, i64,
                                               ctypes.c_void_p]),

@@ -1000,17 +1000,49 @@ __global__ __launch_bounds__(256) void overflow_kernel(const float* __restrict__
 // nn.Adam (MindSpore): m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= lr_t * m / (sqrt(v) + eps),
 // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) folded by the host into `lr_t`.  g is divided by `inv_scale`-1 first (loss
 // scale and world size); the whole update is skipped when *overflow != 0 (train_one_step.py:40-47).
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps,
+                                         float inv_scale) {
+  const float gi = g * inv_scale;
+  const float mi = b1 * m + (1.0f - b1) * gi;
+  const float vi = b2 * v + (1.0f - b2) * gi * gi;
+  m = mi;
+  v = vi;
+  p -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps,
                                                    float inv_scale, const int32_t* overflow) {
   if (overflow && *overflow) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i] * inv_scale;
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_one(pi, g[i], mi, vi, lr_t, b1, b2, eps, inv_scale);
     m[i] = mi;
     v[i] = vi;
-    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    p[i] = pi;
+  }
+}
+
+// The same update, four elements per thread, and the bf16 mirror of the new masters (ma_cast_f32_bf16's conversion) written while
+// they are in registers: the training step's cast launch (138 MB read back + a launch) is gone.
+__global__ __launch_bounds__(256) void adam_mirror_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, int64_t n4, float lr_t, float b1, float b2, float eps,
+                                                          float inv_scale, const int32_t* overflow, uint16_t* __restrict__ mirror) {
+  if (overflow && *overflow) return;  // (the mirror still holds the unchanged masters' conversion)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    adam_one(p4.x, g4.x, m4.x, v4.x, lr_t, b1, b2, eps, inv_scale);
+    adam_one(p4.y, g4.y, m4.y, v4.y, lr_t, b1, b2, eps, inv_scale);
+    adam_one(p4.z, g4.z, m4.z, v4.z, lr_t, b1, b2, eps, inv_scale);
+    adam_one(p4.w, g4.w, m4.w, v4.w, lr_t, b1, b2, eps, inv_scale);
+    reinterpret_cast<float4*>(m)[i] = m4;
+    reinterpret_cast<float4*>(v)[i] = v4;
+    reinterpret_cast<float4*>(p)[i] = p4;
+    uint32_t lo, hi;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(p4.x), "v"(p4.y));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(p4.z), "v"(p4.w));
+    reinterpret_cast<uint2*>(mirror)[i] = make_uint2(lo, hi);
   }
 }
 
@@ -1428,6 +1460,17 @@ int ma_adam_f32(float* param, const float* grad, float* m, float* v, int64_t n, 
   if (!param || !grad || !m || !v || n < 1) return MA_ERR_INVALID_ARG;
   MA_LAUNCH(adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t,
             beta1, beta2, eps, inv_scale, overflow);
+  return MA_OK;
+}
+
+int ma_adam_mirror_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                       float eps, float inv_scale, const int32_t* overflow, void* mirror_bf16, ma_stream_t stream) {
+  if (!param || !grad || !m || !v || !mirror_bf16 || n < 1) return MA_ERR_INVALID_ARG;
+  if ((n & 3) || ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
+                   reinterpret_cast<uintptr_t>(v)) & 15) || (reinterpret_cast<uintptr_t>(mirror_bf16) & 7))
+    return MA_ERR_UNSUPPORTED;  // (the caller keeps ma_adam_f32 + ma_cast_f32_bf16)
+  MA_LAUNCH(adam_mirror_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n / 4, lr_t,
+            beta1, beta2, eps, inv_scale, overflow, reinterpret_cast<uint16_t*>(mirror_bf16));
   return MA_OK;
 }
 

@@ -467,13 +467,15 @@ class ConformerCTCTrainStep:
         self.model.ctc._w = None
 
     @torch.no_grad()
-    def refresh_weights(self):
-        """bf16 mirror of the masters (one cast launch) + transposed bf16 copies of the matmul weights."""
+    def refresh_weights(self, cast=True):
+        """bf16 mirror of the masters (one cast launch; cast=False: the optimizer launch has written it) + transposed bf16 copies of the
+        matmul weights."""
         fp = self.fp
         if self.x32:  # the matmuls read the float32 masters themselves (dX = dY . W as an NN product: no transposed copies)
             return
-        _lib.check(_lib.load().ma_cast_f32_bf16(fp.master.data_ptr(), fp.bf16.data_ptr(), fp.size,
-                                                torch.cuda.current_stream().cuda_stream), "cast")
+        if cast:
+            _lib.check(_lib.load().ma_cast_f32_bf16(fp.master.data_ptr(), fp.bf16.data_ptr(), fp.size,
+                                                    torch.cuda.current_stream().cuda_stream), "cast")
         if not hasattr(self, "wt"):
             self.wt = {}
         names = ["conv2_w", "out_w", "ctc_w"]
@@ -1621,9 +1623,9 @@ class ConformerCTCTrainStep:
         lr_opt = asr_warmup_lr(self.global_step + 1, self.base_lr, self.warmup) if two else lr
         tstep = self.applied_steps + 1
         lr_t = lr_opt * math.sqrt(1.0 - self.b2 ** tstep) / (1.0 - self.b1 ** tstep)
-        K.adam(self.fp.master, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, lr_t, self.b1, self.b2, self.eps,
-               1.0 / (scale * self.world), self.flag)
-        self.refresh_weights()
+        mirrored = K.adam(self.fp.master, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, lr_t, self.b1, self.b2, self.eps,
+                          1.0 / (scale * self.world), self.flag, **({} if self.x32 else {"mirror": self.fp.bf16}))
+        self.refresh_weights(cast=not mirrored)  # (the bf16 mirror of the masters left with the update)
         return loss, scale, lr
 
     def finish_step(self, loss, scale, lr):

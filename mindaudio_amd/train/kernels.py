@@ -376,9 +376,19 @@ def grad_overflow(g, flag):
     _lib.check(_lib.load().ma_grad_overflow_f32(_p(g), g.numel(), _p(flag), _s()), "grad_overflow")
 
 
-def adam(param, grad, m, v, lr_t, beta1, beta2, eps, inv_scale, overflow=None):
-    _lib.check(_lib.load().ma_adam_f32(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr_t), float(beta1),
-                                       float(beta2), float(eps), float(inv_scale), _p(overflow), _s()), "adam")
+def adam(param, grad, m, v, lr_t, beta1, beta2, eps, inv_scale, overflow=None, mirror=None):
+    """mirror (bf16, param.numel()): also receives the bf16 conversion of the updated parameters (one launch instead of Adam + cast);
+    returns True when it did (False: the shape is not covered and the caller casts)."""
+    lib = _lib.load()
+    if mirror is not None:
+        rc = lib.ma_adam_mirror_f32(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr_t), float(beta1), float(beta2), float(eps),
+                                    float(inv_scale), _p(overflow), _p(mirror), _s())
+        if rc != _lib.MA_ERR_UNSUPPORTED:
+            _lib.check(rc, "adam_mirror")
+            return True
+    _lib.check(lib.ma_adam_f32(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr_t), float(beta1),
+                               float(beta2), float(eps), float(inv_scale), _p(overflow), _s()), "adam")
+    return False
 
 
 def attention_fwd(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64):

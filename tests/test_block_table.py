@@ -197,3 +197,22 @@ def test_replay_dispatches_typed_calls_and_reports_the_failing_entry():
     with pytest.raises(ValueError):
         tab.forward(3, 7, None)
     assert lib.ma_conformer_block_bwd_train(tab.handle, 3, 7, None) == _lib.MA_ERR_INVALID_ARG  # nothing recorded that way
+
+
+def test_block_table_from_plain_c(tmp_path):
+    """tests/c/block_table_abi.c: the table filled, read back and replayed from C99 through include/mindaudio_amd.h alone."""
+    import shutil
+    import subprocess
+
+    from mindaudio_amd import _build
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    lib_dir = os.path.dirname(_build.build())
+    exe = str(tmp_path / "block_table_abi")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "block_table_abi.c"), "-o", exe, "-L", lib_dir, "-lmindaudio_amd",
+                    "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert out.returncode == 0 and out.stdout.decode().strip().endswith("ok"), out.stdout.decode()

@@ -797,6 +797,21 @@ int ma_conv2d_3x3s2_pack_bf16(const void* W, int64_t C, int64_t Cout, void* pack
 int ma_conv2d_3x3s2_packed_nhwc_bf16(const void* act, int64_t batch, int64_t H, int64_t Wd, int64_t C, const void* packed,
                                      int64_t Cout, const float* bias, int32_t relu, void* out, ma_stream_t stream);
 
+/* GlobalCMVN + BOTH convolutions of Conv2dSubsampling4 in one launch (subsample_fused.hip; layers/cmvn.py:33-35,
+ * layers/subsampling.py:40-45): x (batch, T, idim) float32 with any element strides -> out (batch, T2, F2, C) bf16 NHWC =
+ * relu(conv2(relu(conv1((x - mean) istd)))), T1 = (T - 3) / 2 + 1, T2 = (T1 - 3) / 2 + 1, same for the feature axis.  conv1's output
+ * (what ma_subsample_conv1_strided_nhwc writes to memory) lives only in LDS, 32 channels at a time, and is computed on the matrix
+ * pipe from bf16 head + tail splits of the float32 input and weight (x w = xh wh + xh wl + xl wh, relative error 2^-16 per
+ * product before the rounding to bf16 that both paths apply).  Both weights come through one packed buffer:
+ *   ma_subsample_fused_packed_bytes(idim, C) -> its size in bytes (negative: shape not covered - idim 80, C 256 only);
+ *   ma_subsample_fused_pack_bf16(W1 (C, 9) float32, W2 (C, 3, 3, C) bf16, ..., packed): once per weight update.
+ * b1, b2 (C) float32; cmvn_mean / cmvn_istd: both NULL or both (idim) float32. */
+int64_t ma_subsample_fused_packed_bytes(int64_t idim, int64_t C);
+int ma_subsample_fused_pack_bf16(const float* W1, const void* W2, int64_t idim, int64_t C, void* packed, ma_stream_t stream);
+int ma_subsample_fused_bf16(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_f, int64_t batch, int64_t T,
+                            int32_t idim, const float* cmvn_mean, const float* cmvn_istd, const void* packed, const float* b1,
+                            const float* b2, int64_t C, void* out, ma_stream_t stream);
+
 /* Input gradient of the same convolution without the im2col-shaped intermediate (conv2_dinput.hip; the training step's
  * replacement for ma_gemm (dy . W) + ma_col2im_3x3s2_relu_bf16): dact (batch, H, Wd, C) bf16 = [act > 0] * conv_transpose(dy, W),
  * dy (batch, Ho, Wo, C) bf16, wt = the TRANSPOSED weight ((kh, kw, c), co) bf16 row-major (row stride C), act (batch, H, Wd, C) bf16 or

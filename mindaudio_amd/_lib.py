@@ -276,6 +276,9 @@ PROTOTYPES = {
     "ma_conv2d_3x3s2_packed_bytes": (i64, [i64, i64]),
     "ma_conv2d_3x3s2_pack_bf16": (ctypes.c_int, [vp, i64, i64, vp, vp]),
     "ma_conv2d_3x3s2_packed_nhwc_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, vp, i64, vp, i32, vp, vp]),
+    "ma_subsample_fused_packed_bytes": (i64, [i64, i64]),
+    "ma_subsample_fused_pack_bf16": (ctypes.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ma_subsample_fused_bf16": (ctypes.c_int, [vp, i64, i64, i64, i64, i64, i32, vp, vp, vp, vp, vp, i64, vp, vp]),
     "ma_gemm_rows_packed_bytes": (i64, [i64, i64]),
     "ma_gemm_rows_pack_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp]),
     "ma_gemm_rows_packed_f32": (ctypes.c_int, [vp, i64, i64, i64, vp, i64, vp, f32, vp, i64, vp]),

@@ -128,6 +128,7 @@ class ConformerEncoder(nn.Module):
         self._pos_cache = {}
         self.fuse_min_rows = 1        # rows (B * T') below which forward() uses the general one-launch-per-cell form
         self.subsample_group = None   # utterances per conv1 -> conv2 group (None: sized for the Infinity Cache)
+        self.subsample_fused = True   # conv1 inside conv2's launch where the shape is covered (set False before prepare() for the two-kernel path)
         # any load_state_dict (torch's own or utils.ckpt.load_mindspore_checkpoint) invalidates the bf16 / packed copies
         self.register_load_state_dict_post_hook(lambda module, _keys: setattr(module, "_prepared", None))
 
@@ -183,6 +184,8 @@ class ConformerEncoder(nn.Module):
                 "pw2_b": cm.pointwise_conv2.bias.detach().float().contiguous(),
             })
         prep["conv2_pk"] = ops.conv2d_3x3s2_pack(prep["conv2_w"])
+        # conv1 + conv2 in one launch (subsample_fused.hip: conv1's output never leaves the LDS); None unless idim 80, d_model 256
+        prep["sub_pk"] = ops.subsample_fused_pack(prep["conv1_w"], prep["conv2_w"], self.idim) if self.subsample_fused else None
         prep["out_pk"] = ops.gemm_rows_pack(prep["out_w"])  # None when d_model != 256
         # fragment-ordered packed copies: FFN weights for the hidden-slice-owner kernel (ops.ffn_packed), the K = 256 dense
         # layers for ops.gemm_packed
@@ -212,6 +215,8 @@ class ConformerEncoder(nn.Module):
         """CMVN + Conv2dSubsampling4's two convolutions (layers/subsampling.py:40-45): (B, T, idim) f32 -> NHWC bf16
         (B, T2, F2, C)."""
         b, t, idim = xs.shape
+        if P.get("sub_pk") is not None and t >= 7:
+            return ops.subsample_fused(xs, P["sub_pk"], P["conv1_b"], P["conv2_b"], self.cmvn_mean, self.cmvn_istd)
         if P["conv2_pk"] is None:
             act1 = ops.subsample_conv1(xs, P["conv1_w"], P["conv1_b"], self.cmvn_mean, self.cmvn_istd)
             return ops.conv2d_3x3s2_nhwc(act1, P["conv2_w"], P["conv2_b"], relu=True)

@@ -327,6 +327,43 @@ def subsample_conv1(x, w, bias, cmvn_mean=None, cmvn_istd=None, out=None):
     return out
 
 
+def subsample_fused_pack(w1, w2, idim):
+    """Packed copy of the subsampling layer's two convolution weights for subsample_fused: w1 (C, 9) float32 (conv1, as bf16
+    head + tail fragments), w2 (C, 3, 3, C) bf16 (conv2, fragment order); None if (idim, C) is not covered."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert w2.dtype == t.bfloat16 and w2.dim() == 4 and w2.is_contiguous() and w2.shape[1] == 3 and w2.shape[2] == 3
+    c = w2.shape[0]
+    nbytes = lib.ma_subsample_fused_packed_bytes(idim, c)
+    if nbytes < 0 or w2.shape[3] != c:
+        return None
+    assert w1.dtype == t.float32 and w1.is_contiguous() and tuple(w1.shape) == (c, 9)
+    packed = t.empty((nbytes // 2,), dtype=t.bfloat16, device=w2.device)
+    _lib.check(lib.ma_subsample_fused_pack_bf16(_host.ptr(w1), _host.ptr(w2), idim, c, _host.ptr(packed),
+                                                _host.current_stream_ptr()), "subsample_fused_pack_bf16")
+    return packed
+
+
+def subsample_fused(x, packed, b1, b2, cmvn_mean=None, cmvn_istd=None, out=None):
+    """CMVN + both convolutions of Conv2dSubsampling4 in one launch: x (B, T, idim) float32 (any strides) -> NHWC bf16
+    (B, T2, F2, C); packed from subsample_fused_pack, b1 / b2 (C) float32."""
+    t = _host.torch()
+    lib = _lib.load()
+    assert x.dtype == t.float32 and x.dim() == 3 and b1.dtype == t.float32 and b2.dtype == t.float32
+    b, tt, idim = x.shape
+    c = b1.numel()
+    t1, f1 = (tt - 3) // 2 + 1, (idim - 3) // 2 + 1
+    shape = (b, (t1 - 3) // 2 + 1, (f1 - 3) // 2 + 1, c)
+    if out is None:
+        out = t.empty(shape, dtype=t.bfloat16, device=x.device)
+    assert out.shape == shape and out.dtype == t.bfloat16 and out.is_contiguous()
+    rc = lib.ma_subsample_fused_bf16(_host.ptr(x), x.stride(0), x.stride(1), x.stride(2), b, tt, idim, _opt(cmvn_mean),
+                                     _opt(cmvn_istd), _host.ptr(packed), _host.ptr(b1), _host.ptr(b2), c, _host.ptr(out),
+                                     _host.current_stream_ptr())
+    _lib.check(rc, "subsample_fused")
+    return out
+
+
 def relpos_attention(qkv, pos, bias_u, bias_v, mask, batch, T, heads=4, d_k=64, out=None):
     """qkv (B*T, 768) bf16; pos (T, 256) bf16; bias_u/v (heads, d_k) f32; mask (B, T) f32, (B, T, T) f32 (a per-query mask: the
     streaming configuration's chunk masks, padding folded in) or None -> ctx (B*T, 256)."""

@@ -360,6 +360,57 @@ def test_subsample_conv1(t, tt, idim, c, cmvn, transposed):
     assert float((got - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) * 1.01
 
 
+# T = 1000: the north-star utterance (37 tiles of 128 positions, the last one ragged); 103 / 41: ragged last tiles with few output rows;
+# 7: one output row, one tile; both input layouts, with and without CMVN
+@pytest.mark.parametrize("b,tt,cmvn,transposed", [(2, 1000, True, True), (3, 103, True, False), (2, 41, False, True),
+                                                   (1, 7, True, False), (5, 300, False, False)])
+def test_subsample_fused(t, b, tt, cmvn, transposed):
+    """CMVN + conv1 + ReLU + conv2 + ReLU in one launch (act1 only in LDS, computed on the matrix pipe from bf16 head + tail splits)
+    against the float64 reference and against the two-kernel path it replaces (act1 from a float32 FMA chain; another summation
+    order in conv2)."""
+    from mindaudio_amd import ops
+
+    idim, c = 80, 256
+    x = _rand(t, b, tt, idim, seed=40)
+    w1 = _rand(t, c, 1, 3, 3, seed=41, scale=0.3)
+    b1 = _rand(t, c, seed=42, scale=0.1)
+    w2 = _rand(t, c, c, 3, 3, seed=43, scale=1.0 / math.sqrt(9 * c)).bfloat16()
+    b2 = _rand(t, c, seed=44, scale=0.1)
+    mean = _rand(t, idim, seed=45)
+    istd = t.rand(idim, generator=t.Generator().manual_seed(46)) + 0.5
+    xd = x.cuda()
+    if transposed:  # the (B, n_mels, T) fbank output viewed as (B, T, n_mels)
+        xd = xd.transpose(1, 2).contiguous().transpose(1, 2)
+        assert xd.stride(1) == 1
+    w1d, b1d, b2d = w1.reshape(c, 9).contiguous().cuda(), b1.cuda(), b2.cuda()
+    w2k = w2.permute(0, 2, 3, 1).contiguous().cuda()  # (Cout, 3, 3, C)
+    md, sd = (mean.cuda(), istd.cuda()) if cmvn else (None, None)
+    pk = ops.subsample_fused_pack(w1d, w2k, idim)
+    n2 = w2k.numel()
+    assert pk is not None and t.equal(pk[:n2].view(t.int16).sort().values, w2k.view(t.int16).flatten().sort().values)
+    assert ops.subsample_fused_pack(w1d, w2k, 40) is None
+    got = ops.subsample_fused(xd, pk, b1d, b2d, md, sd)
+    # the two kernels it replaces
+    act1 = ops.subsample_conv1(xd, w1d, b1d, md, sd)
+    two = ops.conv2d_3x3s2_packed(act1, ops.conv2d_3x3s2_pack(w2k), b2d, relu=True)
+    assert got.shape == two.shape and got.dtype == t.bfloat16
+    ref = t.nn.functional.relu(t.nn.functional.conv2d(act1.permute(0, 3, 1, 2).double().cpu(), w2.double(), b2.double(), stride=2))
+    scale = float(ref.abs().max())
+    gd = got.permute(0, 3, 1, 2).double().cpu()
+    assert gd.shape == ref.shape
+    # (ref uses the stand-alone kernel's act1: about one act1 element in 200 differs from the fused kernel's by one bf16 ulp)
+    assert float((gd - ref).abs().max()) <= 2 ** -7 * scale
+    # bf16 results of two float32 summation orders: equal except where the sums straddle a rounding boundary
+    diff = (got.float() - two.float()).abs()
+    assert float(diff.max()) <= 2 ** -7 * scale and float((diff > 0).float().mean()) < 0.08
+    # and end to end against float64 from the raw input (act1 rounded to bf16 as both paths do)
+    xin = (x - mean) * istd if cmvn else x
+    a1 = t.nn.functional.relu(t.nn.functional.conv2d(xin.double().unsqueeze(1), w1.double(), b1.double(), stride=2))
+    a1 = a1.float().bfloat16().double()
+    ref2 = t.nn.functional.relu(t.nn.functional.conv2d(a1, w2.double(), b2.double(), stride=2))
+    assert float((gd - ref2).abs().max()) <= 2 ** -7 * scale
+
+
 @pytest.mark.parametrize("b,tt", [(2, 64), (3, 249), (1, 301)])
 def test_relpos_attention(t, b, tt):
     from mindaudio_amd import ops

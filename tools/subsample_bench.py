@@ -35,6 +35,12 @@ act = ops.subsample_conv1(feats, w1, b1)
 u2 = t(lambda: ops.conv2d_3x3s2_packed(act, pk, b2))
 both = t(lambda: ops.conv2d_3x3s2_packed(ops.subsample_conv1(feats, w1, b1), pk, b2))
 print("conv1 %.1f us (%.2f TB/s written)  conv2 %.1f us  conv1+conv2 %.1f us" % (u1, act.numel() * 2 / u1 / 1e6, u2, both))
+spk = ops.subsample_fused_pack(w1, w2, F)
+uf = t(lambda: ops.subsample_fused(feats, spk, b1, b2))
+fl = 2.0 * B * 249 * 19 * 256 * 2304
+print("fused conv1+conv2 (one launch, act1 in LDS): %.1f us  (conv2's %.0f GFLOP at %.0f TFLOP/s)" % (uf, fl / 1e9, fl / uf / 1e6))
+if "--fused-only" in sys.argv:
+    sys.exit(0)
 for chunk in (32, 26, 24, 22, 20, 18, 16, 13, 11, 8):
     def run():
         outs = []

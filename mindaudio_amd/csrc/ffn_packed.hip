@@ -27,6 +27,7 @@
 
 #include "../../include/mindaudio_amd.h"
 
+#include "ffn_packed.h"
 #include "launch.h"
 
 namespace ma {
@@ -60,37 +61,6 @@ constexpr int kPkOffQb = kPkOffBias + 1024;  // bias of the qkv tail (<= 1024 fl
 constexpr int kPkLds = kPkOffQb + 4096;  // a tile (34 KiB) during the main loop, 8 x 16 KiB exchange slots at the end
 constexpr int kPkMaxHidden = 8192;
 
-struct FfnPackedParams {
-  const uint16_t* a;   // (M, 256) bf16
-  const uint4* wp;     // packed weights: [hidden / 32][32 items][64 lanes] x 16 B
-  const float* b1;     // (H)
-  const float* b2;     // (256)
-  float* x;            // (M, 256) f32, updated in place
-  int64_t lda, ldx;
-  int32_t M, H;
-  float alpha;
-  int32_t ln_mode, ln_out_bf16;  // as FfnParams (ffn_fused.hip)
-  const float *g1, *be1, *g2, *be2;
-  const float *g0, *be0;  // optional LayerNorm of the INPUT: a = LN(x; g0, be0) computed while staging (models/conformer.py:147-148)
-  void* ln_out;
-  int64_t ld_ln;
-  float eps;
-  // pair mode (ma_ffn_packed_pair_bf16): a second FFN on the rows this workgroup has just produced, without leaving the CU:
-  //   stage 0: x1 = x + alpha FFN_A(a);  x2 = LN(x1; g1, be1)  [norm_final];  a' = LN(x2; g2, be2)  [the next block's norm_ff_macaron]
-  //   stage 1: x  = x2 + alpha FFN_B(a'); ln_out = LN(x; g3, be3)  [the next block's norm_mha]
-  // x2 (float32) and a' (bf16) never leave LDS.
-  int32_t pair;
-  const uint4* wp_b;
-  const float *b1_b, *b2_b, *g3, *be3;
-  // optional tail: the K = 256 dense layer that consumes the final LayerNorm (linear_q/k/v, layers/attention.py:51-53) runs on the
-  // tile while it is still in LDS: qkv_out[m, :] = bf16(LN_out[m, :] . Wq^T + qkv_b); Wq packed by ma_ffn_qkv_pack_bf16
-  // ([N / 32 blocks][16 items][64 lanes] x 16 B, the W1 half of the FFN block format).  ln_out is then not written.
-  const uint4* qkv_wp;
-  const float* qkv_b;
-  uint16_t* qkv_out;
-  int64_t ld_qkv;
-  int32_t qkv_n;
-};
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -897,7 +867,17 @@ extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t 
   return MA_OK;
 }
 
+// MINDAUDIO_AMD_FFN=packed keeps every launch on this file's kernel (development A/B); default: ffn_pc.hip where it applies
+static bool ffn_use_pc() {
+  static const bool use = [] {
+    const char* e = getenv("MINDAUDIO_AMD_FFN");
+    return !(e && e[0] == 'p' && e[1] == 'a');
+  }();
+  return use;
+}
+
 static int ffn_packed_launch(const FfnPackedParams& p, ma_stream_t stream) {
+  if (ffn_use_pc() && ffn_pc_supported(p)) return ffn_pc_launch(p, stream);
   const int64_t M = p.M;
   const dim3 grid((unsigned)((M + kPkRows - 1) / kPkRows));
   MA_LAUNCH(ffn_packed_kernel, grid, dim3(kPkThreads), kPkLds, (hipStream_t)stream, p);

@@ -867,11 +867,13 @@ extern "C" int ma_ffn_pack_weights_bf16(const void* w1, const void* w2, int32_t 
   return MA_OK;
 }
 
-// MINDAUDIO_AMD_FFN=packed keeps every launch on this file's kernel (development A/B); default: ffn_pc.hip where it applies
+// Two kernels serve these entry points: this file's hidden-slice-owner kernel (default) and ffn_pc.hip's producer / consumer kernel
+// (MINDAUDIO_AMD_FFN=pc; every form, same packed weights, bit-identical pair-vs-two-launches within itself).  Same-box A/B of round 5:
+// 85.5 vs 84 us for pair + qkv alone, 2.057 vs 2.068 ms for the headline step - a tie, decided for the older kernel.
 static bool ffn_use_pc() {
   static const bool use = [] {
     const char* e = getenv("MINDAUDIO_AMD_FFN");
-    return !(e && e[0] == 'p' && e[1] == 'a');
+    return e && e[0] == 'p' && e[1] == 'c';
   }();
   return use;
 }

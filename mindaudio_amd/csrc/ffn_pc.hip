@@ -25,8 +25,13 @@
 //     LDS traffic: 32 KiB of a-fragment reads + 16 KiB of h-fragment reads + 4 KiB of h writes per SIMD and period (2048 MFMA
 //     cycles) = 26 B/clk/SIMD.
 // Weight bytes per workgroup are those of ffn_packed.hip (every CU still streams every weight of the launch once), now with 8 x 16
-// KiB in flight per CU instead of 4 x 16.  The kernel covers every form of the ma_ffn_packed_* entry points; ffn_packed.hip's kernel
-// stays in the library behind MINDAUDIO_AMD_FFN=packed for same-box A/B.
+// KiB in flight per CU instead of 4 x 16.  The kernel covers every form of the ma_ffn_packed_* entry points and is selected with
+// MINDAUDIO_AMD_FFN=pc (tests/test_ffn_pc_gpu.py runs the FFN parity tests on it).  Measured (round 5, same box): a tie with
+// ffn_packed.hip - 84 vs 85.5 us for pair + qkv alone, 2.068 vs 2.057 ms for the headline step - so the default stayed.  What the
+// ablation builds (-DPC_X, tools/ffn_variants.sh) say about BOTH kernels: with only the MFMAs left the two loops take 35 us (the MFMA
+// bound), with only the Swish / LDS reads / weight loads left 40 us, with both 53 us - on one SIMD the transcendental-heavy VALU stream
+// and the MFMA stream add up instead of overlapping, whichever way they are cut into waves (a 12-wave cut, two S-waves per SIMD, was
+// slower still: shallower rings at 168 registers, spilled epilogues).  DESIGN.md 4.3.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -83,6 +88,13 @@ __device__ __forceinline__ float pc_sum_xor32(float x) {
   float a = x, b = x;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
   return a + b;
+}
+// a wave-uniform pointer, provably so for the compiler ("s" asm operands; free when the value already lives in SGPRs)
+template <class T>
+__device__ __forceinline__ const T* pc_uniform(const T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
 }
 // swish(v) = v / (1 + 2^(-v log2 e)): the same two transcendentals as ffn_packed.hip's nano-slots
 __device__ __forceinline__ float pc_swish(float v) {
@@ -142,13 +154,13 @@ __global__ __launch_bounds__(kPcThreads, 2) void ffn_pc_kernel(const FfnPackedPa
 #define PC_LOAD_S(dst, base, q)                                                                                                         \
   do {                                                                                                                                  \
     const uint32_t vo_ = (q) < 8 ? voff0 : voff1;                                                                                       \
-    const char* b_ = (base);                                                                                                            \
+    const char* b_ = pc_uniform(base);                                                                                                            \
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(vo_), "s"(b_), "n"((((q) & 7) - 4) * 1024) : "memory");   \
   } while (0)
 #define PC_LOAD_O(dst, base, ct)                                                                                              \
   do {                                                                                                                        \
     const uint32_t vo_ = voffo;                                                                                               \
-    const char* b_ = (base);                                                                                                  \
+    const char* b_ = pc_uniform(base);                                                                                                  \
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(vo_), "s"(b_), "n"((ct) * 1024) : "memory");    \
   } while (0)
 #define PC_LOAD_S16(base)                                                                                                   \
@@ -164,13 +176,14 @@ __global__ __launch_bounds__(kPcThreads, 2) void ffn_pc_kernel(const FfnPackedPa
 #define PC_LOAD_B1(dst, bptr)                                                                                       \
   do {                                                                                                             \
   const uint32_t bo_ = boff;                                                                                     \
-  const float* bp_ = (bptr);                                                                                     \
+  const float* bp_ = pc_uniform(bptr);                                                                                     \
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(bo_), "s"(bp_) : "memory");                 \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst[1]) : "v"(bo_), "s"(bp_) : "memory");       \
   } while (0)
-  const char* wp_stage[2] = {reinterpret_cast<const char*>(p.wp), reinterpret_cast<const char*>(p.wp_b)};
-  auto sbase = [&](int stg, int pd) { return wp_stage[stg] + (int64_t)block_of(pd, sw) * 32768; };
-  auto obase = [&](int stg, int pd, int k) { return wp_stage[stg] + (int64_t)block_of(pd, k) * 32768 + (16 + 4 * sw) * 1024; };
+  // (selects, not arrays indexed by the stage: a run-time indexed array lives in scratch memory)
+  auto wp_of = [&](int stg) { return stg ? reinterpret_cast<const char*>(p.wp_b) : reinterpret_cast<const char*>(p.wp); };
+  auto sbase = [&](int stg, int pd) { return wp_of(stg) + (int64_t)block_of(pd, sw) * 32768; };
+  auto obase = [&](int stg, int pd, int k) { return wp_of(stg) + (int64_t)block_of(pd, k) * 32768 + (16 + 4 * sw) * 1024; };
   // ---- per-feature parameters and the first-layer biases -> LDS by LDS-DMA (no registers) ------------------------------------------------
   {
     if (wave < 4) {
@@ -352,10 +365,9 @@ __global__ __launch_bounds__(kPcThreads, 2) void ffn_pc_kernel(const FfnPackedPa
     char* h1 = smem + kPcOffH + kPcHBytes;
 #define PC_SBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
     for (int stg = 0; stg < nstage; ++stg) {
-      const float* b1_stage[2] = {p.b1, p.b1_b};
       // the job after the stage's last: the next stage's first block (the same job again after the last stage: a harmless reload)
       const int nstg = stg + 1 < nstage ? stg + 1 : stg;
-      auto b1_of = [&](int st_, int pd) { return b1_stage[st_] + block_of(pd, sw) * 32; };
+      auto b1_of = [&](int st_, int pd) { return (st_ ? p.b1_b : p.b1) + block_of(pd, sw) * 32; };
       using T_ = std::true_type;
       using F_ = std::false_type;
       s_job(F_{}, F_{}, T_{}, SA, SB, sbase(stg, 1), bcur, bnext, b1_of(stg, 1), nullptr);  // fill: block of period 0
@@ -551,6 +563,13 @@ __global__ __launch_bounds__(kPcThreads, 2) void ffn_pc_kernel(const FfnPackedPa
 #endif
       }
       PC_STAMP(3 + 8 * stg);
+      // The next stage's first fragments are in flight.  They must have LANDED before the compiler-scheduled epilogue runs: a ring
+      // register the allocator spills there is stored right after its defining asm, landed or not (the loads are >= 16 MFMAs old).
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(ring[0]), "+v"(ring[1]), "+v"(ring[2]), "+v"(ring[3]), "+v"(ring[4]), "+v"(ring[5]), "+v"(ring[6]), "+v"(ring[7]),
+                     "+v"(ring[8]), "+v"(ring[9]), "+v"(ring[10]), "+v"(ring[11]), "+v"(ring[12]), "+v"(ring[13]), "+v"(ring[14]), "+v"(ring[15])
+                   :
+                   : "memory");
       // ---- epilogue of the stage: v = residual + alpha (O + b2) -----------------------------------------------------------------------
       const float* b2l = par + (stg == 0 ? 0 : 5 * 256);
 #pragma unroll

@@ -1,6 +1,6 @@
 """The evaluation forward's FFN launch (pair + linear_q/k/v: 2 x [w1 -> Swish -> w2 + residual] + 4 LayerNorms + qkv, M = 64 x 249)
-timed on the kernel the library selects.  Run twice for the A/B:  MINDAUDIO_AMD_FFN=packed python tools/ffn_pc_ab.py  (ffn_packed.hip)
-and without the variable (ffn_pc.hip)."""
+timed on the kernel the library selects.  Run twice for the A/B:  MINDAUDIO_AMD_FFN=pc python tools/ffn_pc_ab.py  (ffn_pc.hip)
+and without the variable (ffn_packed.hip, the default)."""
 import os
 import sys
 
@@ -48,4 +48,4 @@ def t(fn, reps=60):
 fl_pair = 2.0 * m * (2 * 2 * hid * d + 768 * d)
 for rnd in range(3):
     up, us = t(pair), t(single)
-    print("%s: pair + qkv %.1f us (%.0f TFLOP/s)   single + 2 LN %.1f us" % (os.environ.get("MINDAUDIO_AMD_FFN", "pc"), up, fl_pair / up / 1e6, us))
+    print("%s: pair + qkv %.1f us (%.0f TFLOP/s)   single + 2 LN %.1f us" % (os.environ.get("MINDAUDIO_AMD_FFN", "packed"), up, fl_pair / up / 1e6, us))

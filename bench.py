@@ -182,8 +182,39 @@ def train_step_flops(b, t, vocab, d=256, hidden=2048, blocks=12, heads=4, ks=15,
     return 3.0 * b * fwd
 
 
+def comm_metrics(res, eng, world, force_collective, steps, timed, barrier):
+    """The N > 1 part of the train_dp object (also exercised on CPU / gloo by tests/test_bench_launcher_cpu.py through MA_BENCH_DRY):
+    ms_per_step_no_allreduce, exposed_comm_ms, allreduce{ms, bytes, buckets, bus_GBps, ...}."""
+    import torch.distributed as tdist
+
+    # (i) the step without its collective: exposed communication = ms_per_step - ms_per_step_no_comm
+    eng.reducer.world, eng.reducer.force = 1, False
+    dt0, _ = timed(max(3, steps // 2))
+    eng.reducer.world, eng.reducer.force = world, force_collective
+    res["ms_per_step_no_allreduce"] = round(dt0 / max(3, steps // 2) * 1e3, 3)
+    res["exposed_comm_ms"] = round(res["ms_per_step"] - res["ms_per_step_no_allreduce"], 3)
+    # (ii) the all-reduce alone, same buckets: bus bandwidth = 2 (N-1)/N x bytes / t  (ring-equivalent)
+    from mindaudio_amd.train.engine import bucket_spans
+
+    spans = bucket_spans(eng.fp, eng.L)
+    reps = 5
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        works = [tdist.all_reduce(eng.fp.grad[lo:hi], async_op=True) for lo, hi in spans]
+        for w in works:
+            w.wait()
+    barrier()
+    ar = (time.perf_counter() - t0) / reps
+    nbytes = sum(hi - lo for lo, hi in spans) * 4
+    bus = 2.0 * (world - 1) / max(world, 1) * nbytes / ar / 1e9
+    res["allreduce"] = {"ms": round(ar * 1e3, 3), "bytes": nbytes, "buckets": len(spans),
+                        "bus_GBps": round(bus, 1), "xgmi_link_GBps": XGMI_LINK_GBS,
+                        "frac_of_one_link": round(bus / XGMI_LINK_GBS, 3)}
+
+
 def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=False, digest=False, ctc_weight=1.0,
-              second_stream=False, default_stream=False):
+              default_stream=False):
     """cfg 4: `steps` optimizer steps of ConformerCTCTrainStep on a (40, 1024, 80) batch per rank, gradients
     all-reduced over RCCL in per-block buckets overlapped with the backward pass.  Also times the same all-reduce alone
     (bus bandwidth) and the step with communication disabled (exposed communication)."""
@@ -248,24 +279,6 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=F
         enq.append((time.perf_counter() - t0) * 1e3)
         eng.finish_step(*pending)
     res["host_enqueue_ms"] = round(sorted(enq)[1], 3)
-    if second_stream and world == 1 and not force_collective:
-        # --second-stream: the opt-in second stream for the weight-gradient products (engine.py: wg_stream), timed AND
-        # checked: same batches from the same start must leave bit-identical masters
-        eng1 = ConformerCTCTrainStep(make_model(), dropout_rate=0.1, positional_dropout_rate=0.1, world_size=1, rank=0)
-        eng2 = ConformerCTCTrainStep(make_model(), dropout_rate=0.1, positional_dropout_rate=0.1, world_size=1, rank=0, wg_stream=True)
-        for _ in range(max(warmup, 3)):
-            eng1.step(*cols)
-            eng2.step(*cols)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            eng2.step(*cols)
-        torch.cuda.synchronize()
-        res["second_stream"] = {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 3)}
-        for _ in range(steps):
-            eng1.step(*cols)
-        res["second_stream"]["masters_equal_single_stream"] = bool(torch.equal(eng1.fp.master, eng2.fp.master))
-        del eng1, eng2
     if force_collective:
         res["force_collective"] = True
     if digest:  # bit pattern of the trained masters (tests/test_rccl_world1_gpu.py compares runs with and without the collective)
@@ -273,32 +286,7 @@ def train_leg(rank, world, dev, dist, steps, warmup, barrier, force_collective=F
 
         res["masters_sha16"] = hashlib.sha256(eng.fp.master.cpu().numpy().tobytes()).hexdigest()[:16]
     if world > 1 or force_collective:
-        # (i) the step without its collective: exposed communication = ms_per_step - ms_per_step_no_comm
-        import torch.distributed as tdist
-
-        eng.reducer.world, eng.reducer.force = 1, False
-        dt0, _ = timed(max(3, steps // 2))
-        eng.reducer.world, eng.reducer.force = world, force_collective
-        res["ms_per_step_no_allreduce"] = round(dt0 / max(3, steps // 2) * 1e3, 3)
-        res["exposed_comm_ms"] = round(res["ms_per_step"] - res["ms_per_step_no_allreduce"], 3)
-        # (ii) the all-reduce alone, same buckets: bus bandwidth = 2 (N-1)/N x bytes / t  (ring-equivalent)
-        from mindaudio_amd.train.engine import bucket_spans
-
-        spans = bucket_spans(eng.fp, eng.L)
-        reps = 5
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            works = [tdist.all_reduce(eng.fp.grad[lo:hi], async_op=True) for lo, hi in spans]
-            for w in works:
-                w.wait()
-        barrier()
-        ar = (time.perf_counter() - t0) / reps
-        nbytes = sum(hi - lo for lo, hi in spans) * 4
-        bus = 2.0 * (world - 1) / world * nbytes / ar / 1e9
-        res["allreduce"] = {"ms": round(ar * 1e3, 3), "bytes": nbytes, "buckets": len(spans),
-                            "bus_GBps": round(bus, 1), "xgmi_link_GBps": XGMI_LINK_GBS,
-                            "frac_of_one_link": round(bus / XGMI_LINK_GBS, 3)}
+        comm_metrics(res, eng, world, force_collective, steps, timed, barrier)
     return res
 
 
@@ -325,8 +313,6 @@ def main():
     ap.add_argument("--train-default-stream", action="store_true",
                     help="run the data-parallel training leg on torch's default stream instead of a stream of its own (A/B of the "
                          "hardware-queue sharing with RCCL's stream)")
-    ap.add_argument("--second-stream", action="store_true",
-                    help="also time (and check against the default) the training step with wg_stream=True")
     args = ap.parse_args()
     if args.step_only:
         args.no_cpu_baseline = args.no_train_leg = args.no_sustained = args.no_cfg3 = args.no_cfg5 = True
@@ -368,8 +354,24 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
             t = torch.tensor([float(rank + 1)])
             dist.all_reduce(t)
+            # the N > 1 fields of train_dp, computed by the same function as on the GPU over a stand-in engine (flat gradient of the
+            # real model's layout is not needed for the plumbing: 14 spans of a small flat buffer)
+            from types import SimpleNamespace
+
+            from mindaudio_amd.train import engine as _eng
+
+            fake_fp = SimpleNamespace(grad=torch.ones(14 * 1000), spans14=[(i * 1000, (i + 1) * 1000) for i in range(14)])
+            real_spans = _eng.bucket_spans
+            _eng.bucket_spans = lambda fp, L: fp.spans14
+            try:
+                fake = SimpleNamespace(fp=fake_fp, L=12, reducer=SimpleNamespace(world=world, force=False))
+                tdp = {"ms_per_step": 1.0}
+                comm_metrics(tdp, fake, world, False, 2, lambda n: (1e-3 * n, None), lambda: dist.barrier())
+            finally:
+                _eng.bucket_spans = real_spans
             if rank == 0:
-                print(json.dumps({"dry": True, "n_gpus": world, "ranks_sum": float(t.item())}))
+                print(json.dumps({"dry": True, "n_gpus": world, "ranks_sum": float(t.item()), "train_dp_multi": tdp,
+                                  "grad_sum": float(fake_fp.grad.sum().item())}))
             dist.destroy_process_group()
             return
         torch.cuda.set_device(local_rank)
@@ -605,7 +607,7 @@ def main():
     if args.train or not args.no_train_leg:
         train = train_leg(rank, world, dev, dist if world > 1 else None, args.steps if args.train else args.train_steps,
                           args.warmup if args.train else 2, barrier, args.force_collective, args.train_digest,
-                          second_stream=args.second_stream, default_stream=args.train_default_stream)
+                          default_stream=args.train_default_stream)
         if not args.train and not args.no_hybrid_leg and world == 1 and not args.force_collective:
             import gc
 

@@ -1,0 +1,184 @@
+"""ASR training loop on the reference's configuration schema — the counterpart of examples/conformer/train.py:53-179.
+
+    python -m mindaudio_amd.conformer.train --config_path conformer.yaml [--train_data x.csv --dict lang_char.txt ...]
+
+Reads the keys of examples/conformer/conformer.yaml (encoder_conf, decoder_conf, model_conf, collate_conf, dataset_conf, optim_conf,
+scheduler / scheduler_conf, cmvn_file / is_json_cmvn, train_data, dict, max_epoch, exp_name, save_checkpoint*, is_distributed,
+mixed_precision, resume_ckpt), builds `create_dataset` -> `create_asr_model` -> `ConformerCTCTrainStep` (what the reference
+builds as Adam + ASRWarmupLR + DynamicLossScaleUpdateCell(1024, 2, 1000) + TrainOneStepWithLossScaleCell, train.py:126-141) and
+prints the fields of the reference's `TimeMonitor` (mindaudio/utils/callback.py:48-99) per step:
+
+    [Train] Epoch: [e/E], Step: [s/S], Step Time: 0.0085 sec, lr: 0.000040, Total Loss: 123.4567, Scale: 1024, Rank: 0.
+
+One process per GPU: under `torchrun` (RANK / WORLD_SIZE / LOCAL_RANK) with is_distributed the gradients are averaged over RCCL
+(`mindspore.set_auto_parallel_context(DATA_PARALLEL, gradients_mean=True)`, train.py:70-80) and every rank keeps
+batch[rank::world] of the same shuffled batch order (dataset.py:552-553).  Keys the reference's train.py never reads either
+(grad_clip, accum_grad, log_interval, optim, device_target, save_graphs, full_graph) are accepted and ignored; training_with_eval
+and a `scheduler` other than warmuplr are refused loudly instead of silently doing something else."""
+import argparse
+import os
+import sys
+import time
+
+import yaml
+
+COLUMNS = ("xs_pad", "ys_pad", "ys_in_pad", "ys_out_pad", "r_ys_in_pad", "r_ys_out_pad", "xs_masks", "ys_masks", "ys_sub_masks",
+           "ys_lengths", "xs_chunk_masks")  # train.py:38-50
+
+
+def load_config(path, overrides=None):
+    """The yaml as a plain dict (mindaudio.utils.config.get_config parses the same file into an attribute dict); `overrides` maps
+    top-level keys to replacement values (the reference takes them as --key value command-line options)."""
+    with open(path) as fh:
+        cfg = yaml.safe_load(fh)
+    for k, v in (overrides or {}).items():
+        if v is not None:
+            cfg[k] = v
+    return cfg
+
+
+def _bucket_list(v):
+    # frame_bucket_limit / batch_bucket_limit are comma-separated strings in the yaml (dataset.py:679-680 evals them)
+    return [int(x) for x in v.split(",")] if isinstance(v, str) else list(v)
+
+
+def format_step_line(epoch, max_epoch, step, steps_size, seconds, lr, loss, scale, rank, overflow=False):
+    """TimeMonitor.step_end's line (callback.py:67-97); `step` counts from 0 over the whole run as TimeMonitor.step does."""
+    head = "[Train] Epoch: [%d/%d], Step: [%d/%d], Step Time: %.4f sec, lr: %.6f, Total Loss: %.4f, " % (
+        epoch, max_epoch, step % steps_size + 1, steps_size, seconds, lr, loss)
+    if overflow:
+        return head + "Overflow: %s, Scale: %.0f, Rank: %d." % (str(overflow), scale, rank)
+    return head + "Scale: %.0f, Rank: %d." % (scale, rank)
+
+
+def build_model(config, input_dim, vocab_size, device):
+    """creadte_asr_model (asr_model.py:301-352): GlobalCMVN from cmvn_file, ConformerEncoder(**encoder_conf), a TransformerDecoder
+    unless ctc_weight == 1, ASRModel(**model_conf)."""
+    import torch
+
+    from ..utils.load_files import load_cmvn
+    from .asr_model import create_asr_model
+
+    if config.get("encoder", "conformer") != "conformer" or config.get("decoder", "transformer") != "transformer":
+        raise NotImplementedError("encoder: conformer / decoder: transformer (asr_model.py:316-337)")
+    cmvn = None
+    if config.get("cmvn_file"):
+        mean, istd = load_cmvn(config["cmvn_file"], config.get("is_json_cmvn", True))
+        cmvn = (torch.tensor(mean, dtype=torch.float32), torch.tensor(istd, dtype=torch.float32))
+    mc = config.get("model_conf", {})
+    model = create_asr_model(input_dim, vocab_size, dict(config.get("encoder_conf") or {}), global_cmvn=cmvn,
+                             ctc_weight=float(mc.get("ctc_weight", 0.3)), decoder_conf=dict(config.get("decoder_conf") or {}),
+                             lsm_weight=float(mc.get("lsm_weight", 0.0)), length_normalized_loss=bool(mc.get("length_normalized_loss", False)))
+    return model.to(device)
+
+
+def build_step(model, config, rank, world, process_group=None):
+    """Adam(lr = ASRWarmupLR(lr, warmup_steps)) + DynamicLossScaleUpdateCell(1024, 2, 1000) + TrainOneStepWithLossScaleCell
+    (train.py:111-141) as one ConformerCTCTrainStep; mixed_precision True -> bf16 matmuls with float32 masters (the reference's
+    float16 compute_type), False -> the float32 mode."""
+    import torch
+
+    from ..train.engine import ConformerCTCTrainStep
+
+    sched = config.get("scheduler", "warmuplr")
+    if sched != "warmuplr":
+        raise NotImplementedError("scheduler: %r - only 'warmuplr' (ASRWarmupLR) is built (train.py:111-124)" % sched)
+    enc_conf = config.get("encoder_conf") or {}
+    return ConformerCTCTrainStep(model, base_lr=float(config["optim_conf"]["lr"]),
+                                 warmup_steps=int(config["scheduler_conf"]["warmup_steps"]), loss_scale=1024.0, scale_factor=2.0,
+                                 scale_window=1000, dropout_rate=float(enc_conf.get("dropout_rate", 0.1)),
+                                 positional_dropout_rate=float(enc_conf.get("positional_dropout_rate", 0.1)), seed=777,
+                                 process_group=process_group, world_size=world, rank=rank,
+                                 compute_type=None if config.get("mixed_precision", True) else torch.float32)
+
+
+def train(config, rank=0, world=1, device=None, max_steps=None, log=print, dataset_factory=None, model_factory=None,
+          step_factory=None, process_group=None):
+    """The loop of train.py:53-179.  Returns the list of per-step records (epoch, step, loss, scale, overflow, lr, seconds).
+    The three factories default to the real pieces (create_dataset / build_model / build_step); tests substitute them."""
+    import torch
+
+    torch.manual_seed(777)  # set_seed(777), train.py:56
+    if config.get("training_with_eval"):
+        raise NotImplementedError("training_with_eval: the evaluation callback is not built (ASREvalNet exists; train.py:143-155)")
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    ds_conf = dict(config["dataset_conf"])
+    ds_conf["frame_bucket_limit"] = _bucket_list(ds_conf["frame_bucket_limit"])
+    ds_conf["batch_bucket_limit"] = _bucket_list(ds_conf["batch_bucket_limit"])
+    if dataset_factory is None:
+        from .dataset import create_dataset as dataset_factory
+    vocab_size, dataset = dataset_factory(config["train_data"], config["dict"], collate_conf=dict(config["collate_conf"]),
+                                          dataset_conf=ds_conf, rank=rank, group_size=world, number_workers=1)
+    input_dim = int(config["collate_conf"]["feature_extraction_conf"]["mel_bins"])
+    steps_size = dataset.get_dataset_size()
+    log("Training dataset has %d steps in each epoch." % steps_size)
+    model = (model_factory or build_model)(config, input_dim, vocab_size, device)
+    log("Total parameter of ASR model: %d." % sum(p.numel() for p in model.parameters()))
+    start_epoch = 0
+    if config.get("resume_ckpt"):
+        from ..utils.ckpt import load_mindspore_checkpoint
+
+        load_mindspore_checkpoint(model, config["resume_ckpt"], strict=False)
+        log("Successfully loading the pre-trained model")
+    eng = (step_factory or build_step)(model, config, rank, world, process_group)
+    max_epoch = int(config["max_epoch"])
+    save_every = steps_size * int(config.get("save_checkpoint_epochs", 1))
+    model_dir = os.path.join(str(config.get("exp_name", "default")), "model")
+    records, step = [], 0
+    log("Training start.")
+    for epoch in range(start_epoch + 1, max_epoch + 1):
+        for cols in dataset:
+            t0 = time.time()
+            cols = tuple(c.to(device) if hasattr(c, "to") else c for c in cols)
+            loss, cond, scale, overflow, lr = eng.step(*cols)
+            loss, scale, lr, overflow = float(loss), float(scale), float(lr), bool(overflow)  # (the reads TimeMonitor does: a host sync)
+            seconds = time.time() - t0
+            log(format_step_line(epoch, max_epoch, step, steps_size, seconds, lr, loss, scale, rank, overflow))
+            records.append(dict(epoch=epoch, step=step, loss=loss, scale=scale, overflow=overflow, lr=lr, seconds=seconds))
+            step += 1
+            if config.get("save_checkpoint") and rank == 0 and step % save_every == 0 and hasattr(eng, "sync_to_module"):
+                from ..utils.ckpt import write_mindspore_ckpt
+
+                eng.sync_to_module()
+                os.makedirs(model_dir, exist_ok=True)
+                # ModelCheckpoint's naming (prefix CKP, epoch_step), with epoch_num appended as the reference does (train.py:157-163)
+                path = os.path.join(model_dir, "CKP-%d_%d.ckpt" % (epoch, steps_size))
+                params = {n: p.detach().float().cpu().numpy() for n, p in model.named_parameters()}
+                params["epoch_num"] = __import__("numpy").asarray(epoch, dtype="int32")
+                write_mindspore_ckpt(path, params)
+                log("checkpoint: %s" % path)
+            if max_steps is not None and step >= max_steps:
+                return records
+    return records
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--config_path", required=True)
+    for key in ("train_data", "dict", "cmvn_file", "exp_name", "resume_ckpt"):
+        ap.add_argument("--" + key)
+    ap.add_argument("--max_epoch", type=int)
+    ap.add_argument("--max_steps", type=int, help="stop after this many steps (smoke runs)")
+    ap.add_argument("--is_distributed", type=lambda s: s.lower() in ("1", "true", "yes"))
+    a = ap.parse_args(argv)
+    cfg = load_config(a.config_path, {k: getattr(a, k) for k in ("train_data", "dict", "cmvn_file", "exp_name", "resume_ckpt", "max_epoch",
+                                                                 "is_distributed")})
+    import torch
+
+    rank, world, pg = 0, 1, None
+    if cfg.get("is_distributed"):
+        import torch.distributed as dist
+
+        rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+        pg = dist.group.WORLD
+    train(cfg, rank=rank, world=world, max_steps=a.max_steps, log=lambda m: print(m, flush=True), process_group=pg)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -200,6 +200,11 @@ def bucket_spans(fp, L):
     return spans + [fp.span(["after_norm.g", "ctc_b"]), fp.span(embed_names + ["pos_w"])]
 
 
+# tools/wg_hunt.py, wg_twin.py, race_hunt.py, race_pairs.py ONLY (the two-hardware-queue corruption reproducer): keys
+# "wg_stream" and "split_k_sums_on_second_stream".  Not an API: ConformerCTCTrainStep takes no such option.
+_TWO_QUEUE_REPRODUCER = {}
+
+
 class ConformerCTCTrainStep:
     """step(batch columns) -> (loss, cond, loss_scale, overflow, lr): one optimizer step of the ASR model.
 
@@ -209,8 +214,7 @@ class ConformerCTCTrainStep:
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
                  process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None,
-                 force_collective=False, fused=True, wg_stream=False, dw_group_blocks=6, own_stream="auto",
-                 _split_k_sums_on_second_stream=False):
+                 force_collective=False, fused=True, dw_group_blocks=6, own_stream="auto"):
         """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
         torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
         activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
@@ -227,20 +231,13 @@ class ConformerCTCTrainStep:
             # d_model = 256 configurations only; say so here instead of failing inside the first step
             raise NotImplementedError("ConformerCTCTrainStep: the bf16 training step is built for d_model = 256 (got %d); the reference's "
                                       "other sizes run the evaluation forward only" % enc.d)
-        # wg_stream=True (EXPERIMENTAL, off by default, warns): the grouped weight-gradient products of the blocks (and their gradient
-        # buckets' all-reduce) run on a second stream beside the input-gradient chain they do not feed.  Round 3 ran the split-K
-        # products AND the block's batched sum (tn_reduce_batch_kernel) there and saw 0.4-14 % of fresh processes with a corrupted
-        # LayerNorm backward in the first block that overlapped; round 4 (tools/wg_hunt_loop.py, 1 300 fresh processes)
-        # narrowed it to ONE pair - that reduction kernel on a second hardware queue beside layernorm_bwd_kernel on the first - with
-        # every other combination clean (one hardware queue, serialised queues, foreign kernels, the products alone, the direct
-        # products, RCCL's kernels).  The batched sums therefore run on the MAIN stream in every mode; the round-3 form exists only
-        # behind _split_k_sums_on_second_stream (the reproducer of tools/wg_hunt.py) and is refused otherwise.
-        self._wg_on = bool(wg_stream) and self.fused
-        self._wg_split_ok = bool(_split_k_sums_on_second_stream)
-        if self._wg_on:
-            import warnings
-
-            warnings.warn("ConformerCTCTrainStep(wg_stream=True) is experimental: see DESIGN.md 4.6.3", stacklevel=2)
+        # The step runs on ONE stream.  Rounds 3-4 also had a constructor option that put the weight-gradient products (and, in round 3,
+        # the per-block batched sums) on a second stream: 0.4-14 % of fresh processes then saw a corrupted LayerNorm backward, narrowed
+        # in round 4 to ONE kernel pair on two hardware queues (tn_reduce_batch_kernel beside layernorm_bwd_kernel) and
+        # never explained.  The option is gone (VERDICT r4 #6c); the code path survives only for the reproducer scripts under tools/,
+        # which set the module-level _TWO_QUEUE_REPRODUCER hook below before constructing an engine.
+        self._wg_on = bool(_TWO_QUEUE_REPRODUCER.get("wg_stream")) and self.fused
+        self._wg_split_ok = bool(_TWO_QUEUE_REPRODUCER.get("split_k_sums_on_second_stream"))
         self._wg, self._wg_keep, self._wg_pool, self._wg_next, self._wg_done, self._dw_par = None, [], [], 0, {}, 0
         self._wg_stream, self._wg_seen = None, {}
         self._wg_queue, self._main = [], None
@@ -288,13 +285,18 @@ class ConformerCTCTrainStep:
         # g it has just finished ARE norm_final's output gradient): 11 LayerNorm-backward launches and round trips of g fewer
         self.ln_final_chained = self.ffn_bwd_one_launch
         self._dw_direct = self.fused and self.dw_group_blocks > 0 and self.d % 256 == 0 and self.hidden % 256 == 0
+        if self._dw_direct:
+            # eight products per block in one direct group: keep a group inside the kernel's item table (a full group is also flushed
+            # by DirectGroup.add itself - the decoder's 7 products per layer go into ONE group however many layers it has)
+            cap = int(_lib.load().ma_gemm_tn_direct_max_items())
+            self.dw_group_blocks = max(1, min(self.dw_group_blocks, cap // 8))
         # block_tables: from the third step of a batch shape on, a block's launches are issued by ONE C call each way
         # (ma_conformer_block_fwd_train / _bwd_train) from the argument table filled while the second step was walked from Python -
         # same calls, same buffers, same order; 4.2 -> ~1.5 ms of host time per step (train/block_table.py, csrc/block_table.hip)
         self.block_tables = self.fused and self._dw_direct
         if self._wg_on and not self._dw_direct and not self._wg_split_ok:
-            raise ValueError("wg_stream=True needs the direct weight-gradient groups (dw_group_blocks > 0, d_model and hidden "
-                             "multiples of 256): the split-K sums are not run on a second stream (DESIGN 4.6.3)")
+            raise ValueError("the two-queue reproducer needs the direct weight-gradient groups (dw_group_blocks > 0, d_model and hidden "
+                             "multiples of 256) unless split_k_sums_on_second_stream is set as well (DESIGN 4.6.3)")
         self.ks = enc.kernel
         self.f2 = enc.embed.out.in_features // self.d
         self.p_drop, self.p_pos = float(dropout_rate), float(positional_dropout_rate)

@@ -135,7 +135,10 @@ class DirectGroup:
 
     def add(self, a, b, out, colsum):
         if self.n == self.cap:
-            raise _lib.MindaudioAmdError("more than %d products in one direct group" % self.cap)
+            # a full table leaves as its own grid: the kernel STORES its products (one per weight), so cutting a group in two changes
+            # nothing but the launch count (a 7-layer decoder queues 49 products into one group)
+            self.launch()
+            self.clear()
         it = self.items[self.n]
         it.A, it.B, it.out, it.colsum = a.data_ptr(), b.data_ptr(), out.data_ptr(), (colsum.data_ptr() if colsum is not None else None)
         it.lda, it.ldb, it.ldo = a.stride(0), b.stride(0), out.stride(0)

@@ -25,6 +25,15 @@ def test_gpus_2_spawns_two_ranks():
     assert len(lines) == 1, res.stdout  # rank 0 only
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks_sum"] == 3.0  # ranks 0 and 1 both joined the all-reduce
+    # the N > 1 fields of the train_dp object come out of bench.comm_metrics (run here over gloo on a stand-in engine): all present,
+    # the all-reduce really ran (5 rounds of SUM over 2 ranks on a buffer of ones: 2^5 per element)
+    tdp = line["train_dp_multi"]
+    for key in ("ms_per_step_no_allreduce", "exposed_comm_ms", "allreduce"):
+        assert key in tdp, tdp
+    for key in ("ms", "bytes", "buckets", "bus_GBps", "xgmi_link_GBps", "frac_of_one_link"):
+        assert key in tdp["allreduce"], tdp
+    assert tdp["allreduce"]["buckets"] == 14 and tdp["allreduce"]["bytes"] == 14 * 1000 * 4 and tdp["allreduce"]["bus_GBps"] >= 0
+    assert line["grad_sum"] == 14 * 1000 * 2.0 ** 5
 
 
 def test_world_size_mismatch_is_an_error():

@@ -1,0 +1,214 @@
+"""mindaudio_amd.conformer.train — the counterpart of examples/conformer/train.py on the reference's yaml schema.
+CPU: the reference's own conformer.yaml keys are all read (a copy of its schema with small sizes is written here: the reference file
+itself is not available on the GPU box), the loop walks a two-batch "dataset", passes the 11 columns in the reference's order to the
+step, and prints TimeMonitor's line (mindaudio/utils/callback.py:67-97).  GPU: two real optimizer steps on a two-utterance manifest."""
+import os
+import re
+import wave
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from mindaudio_amd.conformer import train as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# the schema of examples/conformer/conformer.yaml (every key of the shipped file), small sizes
+YAML = """
+encoder: conformer
+encoder_conf:
+    output_size: 256
+    attention_heads: 4
+    linear_units: 256
+    num_blocks: 1
+    dropout_rate: 0.1
+    positional_dropout_rate: 0.1
+    attention_dropout_rate: 0
+    input_layer: conv2d
+    normalize_before: True
+    cnn_module_kernel: 15
+    activation_type: 'swish'
+    pos_enc_layer_type: 'rel_pos'
+    feature_norm : True
+decoder: transformer
+decoder_conf:
+    attention_heads: 4
+    linear_units: 256
+    num_blocks: 1
+    dropout_rate: 0.1
+    positional_dropout_rate: 0.1
+    self_attention_dropout_rate: 0
+    src_attention_dropout_rate: 00
+model_conf:
+    ctc_weight: 0.3
+    lsm_weight: 0.1
+    length_normalized_loss: False
+collate_conf:
+    feature_extraction_conf:
+        feature_type: 'fbank'
+        mel_bins: 80
+        frame_shift: 10
+        frame_length: 25
+        using_pitch: False
+    feature_dither: 0.0
+    use_speed_perturb: False
+    use_spec_aug: True
+    spec_aug_conf:
+        warp_for_time: False
+        num_t_mask: 2
+        num_f_mask: 2
+        prop_mask_t: 0.1
+        prop_mask_f: 0.1
+        max_t: 50
+        max_f: 10
+        max_w: 80
+    use_dynamic_chunk: False
+    use_dynamic_left_chunk: False
+    decoding_chunk_size: 0
+    static_chunk_size: 0
+    num_decoding_left_chunks: -1
+dataset_conf:
+    max_length: 3000
+    min_length: 0
+    token_max_length: 30
+    token_min_length: 1
+    batch_type: 'bucket'
+    frame_bucket_limit: '144, 204, 288, 400, 512, 600, 712, 800, 912, 1024'
+    batch_bucket_limit: '2, 2, 2, 2, 2, 2, 2, 2, 2, 2'
+    batch_factor: 1
+    shuffle: True
+grad_clip: 5
+accum_grad: 1
+max_epoch: 2
+log_interval: 100
+optim: adam
+optim_conf:
+    lr: 0.001
+scheduler: warmuplr
+scheduler_conf:
+    warmup_steps: 25000
+cmvn_file: ""
+is_json_cmvn: True
+exp_name: default
+train_data: "train.csv"
+eval_data: "dev.csv"
+save_checkpoint: False
+save_checkpoint_epochs: 1
+save_checkpoint_steps: 460
+keep_checkpoint_max: 30
+save_checkpoint_path: "./"
+device_target: "Ascend"
+is_distributed: False
+mixed_precision: True
+resume_ckpt: ""
+save_graphs: False
+training_with_eval: False
+"""
+
+LINE = re.compile(r"^\[Train\] Epoch: \[(\d+)/(\d+)\], Step: \[(\d+)/(\d+)\], Step Time: \d+\.\d{4} sec, lr: \d+\.\d{6}, "
+                  r"Total Loss: -?\d+\.\d{4}, (Overflow: True, )?Scale: \d+, Rank: (\d+)\.$")
+
+
+def _cfg(tmp_path, **over):
+    p = tmp_path / "conformer.yaml"
+    p.write_text(YAML)
+    return T.load_config(str(p), over)
+
+
+def test_format_is_time_monitors_line():
+    a = T.format_step_line(1, 240, 0, 460, 0.0085, 4e-8, 123.45678, 1024.0, 0)
+    assert a == "[Train] Epoch: [1/240], Step: [1/460], Step Time: 0.0085 sec, lr: 0.000000, Total Loss: 123.4568, Scale: 1024, Rank: 0."
+    b = T.format_step_line(3, 240, 461, 460, 1.25, 1e-3, 7.0, 512.0, 5, overflow=True)
+    assert b == "[Train] Epoch: [3/240], Step: [2/460], Step Time: 1.2500 sec, lr: 0.001000, Total Loss: 7.0000, Overflow: True, Scale: 512, Rank: 5."
+    assert LINE.match(a) and LINE.match(b)
+
+
+def test_loop_on_the_reference_schema_with_stubs(tmp_path):
+    cfg = _cfg(tmp_path, train_data="x.csv", dict="lang_char.txt", exp_name=str(tmp_path / "exp"), save_checkpoint=True)
+    seen = {}
+
+    class FakeData:
+        def get_dataset_size(self):
+            return 2
+
+        def __iter__(self):
+            for k in range(2):
+                yield tuple(torch.full((2, 3), float(10 * k + i)) for i in range(11))
+
+    def dataset_factory(data_file, dict_file, collate_conf, dataset_conf, rank, group_size, number_workers):
+        seen.update(data_file=data_file, dict_file=dict_file, collate_conf=collate_conf, dataset_conf=dataset_conf, rank=rank, group=group_size)
+        return 11, FakeData()
+
+    class FakeStep:
+        def __init__(self):
+            self.calls = []
+
+        def step(self, *cols):
+            assert len(cols) == len(T.COLUMNS) == 11
+            self.calls.append([float(c[0, 0]) for c in cols])
+            n = len(self.calls)
+            return torch.tensor(100.0 / n), n == 2, torch.tensor(1024.0 if n < 3 else 512.0), n == 2, torch.tensor(1e-3 * n)
+
+    fake = FakeStep()
+    made = {}
+
+    def model_factory(config, input_dim, vocab, device):
+        made.update(input_dim=input_dim, vocab=vocab, conf=config["encoder_conf"])
+        return torch.nn.Linear(2, 2)
+
+    lines = []
+    recs = T.train(cfg, rank=1, world=2, device=torch.device("cpu"), log=lines.append, dataset_factory=dataset_factory,
+                   model_factory=model_factory, step_factory=lambda m, c, r, w, pg: fake)
+    # the data-set call sees the reference's keys: bucket limits parsed from the comma-separated strings (dataset.py:679-680)
+    assert seen["data_file"] == "x.csv" and seen["dict_file"] == "lang_char.txt" and (seen["rank"], seen["group"]) == (1, 2)
+    assert seen["dataset_conf"]["frame_bucket_limit"][:3] == [144, 204, 288] and seen["dataset_conf"]["batch_bucket_limit"][0] == 2
+    assert seen["collate_conf"]["spec_aug_conf"]["max_t"] == 50 and seen["collate_conf"]["feature_extraction_conf"]["mel_bins"] == 80
+    assert made["input_dim"] == 80 and made["vocab"] == 11 and made["conf"]["cnn_module_kernel"] == 15
+    # 2 epochs x 2 batches, columns in the reference's order (column i of batch k carries 10 k + i)
+    assert len(recs) == 4 and fake.calls[1] == [10.0 + i for i in range(11)]
+    step_lines = [ln for ln in lines if ln.startswith("[Train]")]
+    assert len(step_lines) == 4 and all(LINE.match(ln) for ln in step_lines)
+    got = [LINE.match(ln).groups() for ln in step_lines]
+    assert [(g[0], g[2]) for g in got] == [("1", "1"), ("1", "2"), ("2", "1"), ("2", "2")] and all(g[1] == "2" and g[3] == "2" for g in got)
+    assert got[1][4] == "Overflow: True, " and got[0][4] is None and all(g[5] == "1" for g in got)
+    assert "Training dataset has 2 steps in each epoch." in lines and "Training start." in lines
+    assert recs[1]["overflow"] is True and recs[2]["scale"] == 512.0 and abs(recs[3]["lr"] - 4e-3) < 1e-9
+
+
+def test_unsupported_keys_fail_loudly(tmp_path):
+    cfg = _cfg(tmp_path, training_with_eval=True)
+    with pytest.raises(NotImplementedError):
+        T.train(cfg, device=torch.device("cpu"), dataset_factory=lambda *a, **k: (5, None))
+    cfg = _cfg(tmp_path, scheduler="none")
+    with pytest.raises(NotImplementedError):
+        T.build_step(torch.nn.Linear(2, 2), cfg, 0, 1)
+
+
+@pytest.mark.gpu
+def test_two_real_steps_on_a_two_utterance_manifest(tmp_path):
+    """create_dataset -> create_asr_model (hybrid CTC / attention, the shipped yaml's model_conf) -> ConformerCTCTrainStep: two optimizer
+    steps from the command line entry point; finite losses, the warm-up schedule's learning rates, one line per step."""
+    src = os.path.join(HERE, "golden", "BAC009S0002W0122.wav")
+    with wave.open(src, "rb") as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    paths = []
+    for i, n in enumerate((40000, 44000)):  # 248 and 273 frames: one bucket (<= 288), one batch of two
+        p = str(tmp_path / ("utt%d.wav" % i))
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(pcm[:n].tobytes())
+        paths.append(p)
+    (tmp_path / "lang_char.txt").write_text("".join("%s %d\n" % (ch, i) for i, ch in enumerate(["<blank>", "<unk>", "a", "b", "c", "d", "<sos/eos>"])))
+    (tmp_path / "train.csv").write_text("id,duration,wav,transcript\n0,2.5,%s,abca\n1,2.75,%s,dcb\n" % tuple(paths))
+    cfg = _cfg(tmp_path, train_data=str(tmp_path / "train.csv"), dict=str(tmp_path / "lang_char.txt"), max_epoch=2)
+    lines = []
+    recs = T.train(cfg, log=lines.append)
+    assert len(recs) == 2 and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in recs)
+    from mindaudio_amd.train.engine import asr_warmup_lr
+
+    assert abs(recs[0]["lr"] - asr_warmup_lr(0, 1e-3, 25000)) < 1e-12 and abs(recs[1]["lr"] - asr_warmup_lr(1, 1e-3, 25000)) < 1e-12
+    assert sum(ln.startswith("[Train]") and bool(LINE.match(ln)) for ln in lines) == 2

@@ -506,32 +506,40 @@ def test_hybrid_step_from_the_launch_table_changes_no_bit():
     assert torch.equal(out[1][1], out[0][1])
 
 
-def test_weight_gradient_stream_changes_no_bit():
-    """With wg_stream=True (experimental) the grouped weight-gradient products and the gradient buckets run on a second
-    stream beside the input-gradient chain (the batched sums stay on the main stream).  Same launches, same summation orders: five
-    optimizer steps give bit-identical losses and masters with the second stream on and off; a missing cross-stream dependency would
-    show up as a changed bit.  The round-3 form (split-K sums on the second stream) is refused without its reproducer switch."""
-    import warnings
-
+def test_no_second_stream_option_and_full_direct_groups_flush():
+    """The step runs on one stream: the rounds-3/4 constructor options that put weight-gradient work on a second stream are gone
+    (VERDICT r4 #6c; the unexplained two-queue corruption of DESIGN 4.6.3 is reachable only through the reproducer hook of tools/).
+    And a direct weight-gradient group that outgrows the kernel's item table leaves as two grids instead of raising:
+    same gradients as with room to spare."""
+    from mindaudio_amd import _lib
+    from mindaudio_amd.train import kernels as K
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
-    warnings.simplefilter("ignore", UserWarning)
-    with pytest.raises(ValueError):
-        ConformerCTCTrainStep(build(seed=9)[2], wg_stream=True, dw_group_blocks=0)
-
-    xs, ys, sub, ys_lens = batch()
-    cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
-    out = []
-    for wg in (False, True, True):
-        _, _, model = build(seed=9)
-        eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1, wg_stream=wg)
-        assert (eng._wg_stream is not None) == wg
-        losses = [float(eng.step(*cols)[0]) for _ in range(5)]  # (the second stream is used from the third step of a shape on)
-        torch.cuda.synchronize()
-        out.append((losses, eng.fp.master.clone()))
-    for losses, master in out[1:]:
-        assert losses == out[0][0]
-        assert torch.equal(master, out[0][1])
+    for kw in ("wg_stream", "_split_k_sums_on_second_stream"):
+        with pytest.raises(TypeError):
+            ConformerCTCTrainStep(build(seed=9)[2], **{kw: True})
+    eng = ConformerCTCTrainStep(build(seed=9)[2], dw_group_blocks=100)
+    cap = int(_lib.load().ma_gemm_tn_direct_max_items())
+    assert eng._wg_stream is None and 1 <= eng.dw_group_blocks <= cap // 8
+    # cap + 3 products through one group: the first `cap` leave when the table is full
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dys = [torch.randn(512, 256, generator=g).bfloat16().cuda() for _ in range(cap + 3)]
+    xs_ = [torch.randn(512, 256, generator=g).bfloat16().cuda() for _ in range(cap + 3)]
+    outs = [torch.zeros(256, 256, device="cuda") for _ in range(cap + 3)]
+    sums = [torch.zeros(256, device="cuda") for _ in range(cap + 3)]
+    grp = K.DirectGroup()
+    if not K.gemm_tn_direct_ok(dys[0], xs_[0], outs[0]):
+        pytest.skip("direct products not available for this shape")
+    for dy, x, o, c_ in zip(dys, xs_, outs, sums):
+        grp.add(dy, x, o, c_)
+    assert grp.n == 3
+    grp.launch()
+    grp.clear()
+    torch.cuda.synchronize()
+    for dy, x, o, c_ in zip(dys, xs_, outs, sums):
+        want = dy.double().T @ x.double()
+        assert float((o.double() - want).abs().max()) <= 2e-4 * float(want.abs().max()) + 1e-3
+        assert float((c_.double() - dy.double().sum(0)).abs().max()) <= 1e-2
 
 
 def test_fused_engine_gradients_match_oracle_autograd():

@@ -10,6 +10,7 @@ import torch
 
 def main():
     from mindaudio_amd.conformer.asr_model import create_asr_model
+    from mindaudio_amd.train import engine as _engine
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
@@ -17,7 +18,8 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(777)
     model = create_asr_model(80, 4233, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12)).to(dev)
-    eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1, wg_stream=wg)
+    _engine._TWO_QUEUE_REPRODUCER.update(wg_stream=bool(wg))  # (reproducer hook: not a constructor option)
+    eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1)
     rng = np.random.RandomState(43)
     b, t = 40, 1024
     xs = torch.from_numpy(rng.randn(b, t, 80).astype(np.float32)).to(dev)
@@ -43,7 +45,8 @@ def main():
         if fresh and s % fresh == 0:
             torch.manual_seed(777)
             model = create_asr_model(80, 4233, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12)).to(dev)
-            eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1, wg_stream=wg)
+            _engine._TWO_QUEUE_REPRODUCER.update(wg_stream=bool(wg))  # (reproducer hook: not a constructor option)
+            eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1)
             junk = torch.full((1 << 28,), float("nan"), device=dev)  # poison freed memory: the next empty() gets NaNs
             small = [torch.full((1 << 17,), float("nan"), device=dev) for _ in range(512)]  # ... in the small-block pool too
             small2 = [torch.full((1 << 10,), float("nan"), device=dev) for _ in range(4096)]

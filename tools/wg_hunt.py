@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     from mindaudio_amd.conformer.asr_model import create_asr_model
+    from mindaudio_amd.train import engine as _engine
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
     dev = torch.device("cuda", 0)
@@ -97,9 +98,10 @@ def main():
     model = create_asr_model(80, V, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=BLOCKS)).to(dev)
     # wg / serial: the engine's second stream with its default products (direct 256 x 256-tile groups); wgsplit: round 3's form - one
     # split-K grid + batched sum per block on the second stream
+    # (the two-queue path is not a constructor option any more: the reproducer hook of train/engine.py)
+    _engine._TWO_QUEUE_REPRODUCER.update(wg_stream=a.mode in ("wg", "serial", "wgsplit"), split_k_sums_on_second_stream=a.mode == "wgsplit")
     eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1,
-                                wg_stream=a.mode in ("wg", "serial", "wgsplit"), dw_group_blocks=0 if a.mode == "wgsplit" else a.group,
-                                force_collective=a.mode == "rccl", _split_k_sums_on_second_stream=a.mode == "wgsplit")
+                                dw_group_blocks=0 if a.mode == "wgsplit" else a.group, force_collective=a.mode == "rccl")
     eng._wg_from = 0
     if a.tn_lds:
         from mindaudio_amd import _lib as L

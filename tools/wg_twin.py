@@ -12,6 +12,7 @@ import torch
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     from mindaudio_amd.conformer.asr_model import create_asr_model
+    from mindaudio_amd.train import engine as _engine
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
     import wg_hunt as mod_
@@ -23,7 +24,8 @@ def main():
     for wg in ((False, False) if both_single else (True, False)):
         torch.manual_seed(777)
         model = create_asr_model(80, mod["V"], dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12)).to(dev)
-        e = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1, wg_stream=wg)
+        _engine._TWO_QUEUE_REPRODUCER.update(wg_stream=bool(wg))  # (reproducer hook: not a constructor option)
+        e = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1)
         e._wg_from = 0
         engs.append(e)
     pool = [mod["batch"](40, 100 + i) for i in range(8)]  # eight different batches, cycled (host generation costs 60 ms each)

@@ -567,7 +567,10 @@ int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, co
  *   dLN2/dx(g) (not accumulated), ln_out = dropout(g * alpha * ln_row_scale).  In the Conformer block this is norm_ff_macaron's
  *   backward of block l followed by norm_final's of block l - 1 (models/conformer.py:109-112, 153-156) without the round trip of g
  *   through HBM and the launch of ma_layernorm_bwd_next_f32 between them.
- * Both need M * ldu < 2^31 elements.  ma_ffn_train_rows() = rows per workgroup (48). */
+ * Both need M * ldu < 2^31 elements.  ma_ffn_train_rows() = rows per workgroup (48).
+ * Forward without a tape (a training-mode forward that no backward pass follows): ldu = 0, u and h = two scratch areas of
+ * 2 * hidden bytes each - every row's pieces of a hidden block are stored onto the same 64 bytes there (never read; they stay in
+ * the L2), everything else as above. */
 int32_t ma_ffn_train_rows(void);
 int32_t ma_ffn_train_parts(int64_t M);
 int ma_ffn_train_bf16(const void* a, int64_t lda, int64_t M, int32_t hidden, const void* packed, const float* b1, void* u, void* h,

@@ -37,11 +37,6 @@ def load_config(path, overrides=None):
     return cfg
 
 
-def _bucket_list(v):
-    # frame_bucket_limit / batch_bucket_limit are comma-separated strings in the yaml (dataset.py:679-680 evals them)
-    return [int(x) for x in v.split(",")] if isinstance(v, str) else list(v)
-
-
 def format_step_line(epoch, max_epoch, step, steps_size, seconds, lr, loss, scale, rank, overflow=False):
     """TimeMonitor.step_end's line (callback.py:67-97); `step` counts from 0 over the whole run as TimeMonitor.step does."""
     head = "[Train] Epoch: [%d/%d], Step: [%d/%d], Step Time: %.4f sec, lr: %.6f, Total Loss: %.4f, " % (
@@ -103,9 +98,8 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
         raise NotImplementedError("training_with_eval: the evaluation callback is not built (ASREvalNet exists; train.py:143-155)")
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    ds_conf = dict(config["dataset_conf"])
-    ds_conf["frame_bucket_limit"] = _bucket_list(ds_conf["frame_bucket_limit"])
-    ds_conf["batch_bucket_limit"] = _bucket_list(ds_conf["batch_bucket_limit"])
+    ds_conf = dict(config["dataset_conf"])  # (frame_bucket_limit / batch_bucket_limit stay the yaml's comma-separated strings: the data
+    # set parses them, dataset.py:304-305)
     if dataset_factory is None:
         from .dataset import create_dataset as dataset_factory
     vocab_size, dataset = dataset_factory(config["train_data"], config["dict"], collate_conf=dict(config["collate_conf"]),

@@ -603,10 +603,13 @@ extern "C" int32_t ma_ffn_train_rows(void) { return 16 * kFtMT; }
 extern "C" int32_t ma_ffn_train_parts(int64_t M) { return M < 1 ? 0 : (int32_t)((M + 16 * kFtMT - 1) / (16 * kFtMT)); }
 
 static int ffn_train_common(const void* a, int64_t lda, int64_t M, int32_t hidden, const void* packed, void* u, void* h, int64_t ldu,
-                            float* out, int64_t ldo, FfnTrainParams& p) {
+                            float* out, int64_t ldo, FfnTrainParams& p, bool no_tape_ok = false) {
   if (!a || !packed || !u || !h || !out || M < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
   if (ma_ffn_packed_bytes(kFtD, hidden) < 0) return MA_ERR_UNSUPPORTED;
-  if ((lda & 7) || lda < kFtD || (ldu & 7) || ldu < hidden || (ldo & 3) || ldo < kFtD) return MA_ERR_UNSUPPORTED;
+  // ldu == 0 (forward only): no tape - every row's pieces of a block land on the same 64 bytes of the 2 * hidden-byte scratch areas u
+  // and h (the store count the kernel's counted waits rely on is unchanged; the lines stay in the L2)
+  const bool no_tape = no_tape_ok && ldu == 0;
+  if ((lda & 7) || lda < kFtD || (ldu & 7) || (!no_tape && ldu < hidden) || (ldo & 3) || ldo < kFtD) return MA_ERR_UNSUPPORTED;
   // 32-bit row offsets and dropout quad indices
   if (M * ldu * 2 > 0xffffffffLL || M * (int64_t)hidden / 4 > 0xffffffffLL) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(u) |
@@ -637,7 +640,7 @@ extern "C" int ma_ffn_train_bf16(const void* a, int64_t lda, int64_t M, int32_t 
   if (!b1 || !join || (reinterpret_cast<uintptr_t>(b1) & 15)) return MA_ERR_INVALID_ARG;
   if (p_hidden < 0.0f || p_hidden >= 1.0f || join->mode != 3) return MA_ERR_INVALID_ARG;
   FfnTrainParams p;
-  int rc = ffn_train_common(a, lda, M, hidden, packed, u, h, ldu, out, ldo, p);
+  int rc = ffn_train_common(a, lda, M, hidden, packed, u, h, ldu, out, ldo, p, true);
   if (rc != MA_OK) return rc;
   rc = train_epi_fill(join, M, kFtD, p.e);
   if (rc != MA_OK) return rc;

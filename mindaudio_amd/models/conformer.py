@@ -322,59 +322,43 @@ class ConformerEncoder(nn.Module):
         return x
 
     # ---- training-mode forward: dropout + BatchNorm batch statistics (models/conformer.py:100-161 with self.training) ---------
-    def _forward_train(self, xs, P, masks, xs_chunk_masks):
-        """One launch per reference cell plus the dropout / BatchNorm-statistics kernels of the training step
-        (mindaudio_amd.train.kernels); updates the BatchNorm running statistics in place like nn.BatchNorm1d.  This is the
-        forward half of mindaudio_amd.train.engine on the module's own weights - nothing is kept for a backward pass."""
-        from ..train import kernels as K
+    def _train_engine(self):
+        """The forward half of mindaudio_amd.train.engine.ConformerCTCTrainStep on this module's weights: ONE implementation of the
+        training-mode forward (fused feed-forward modules, dense layers with dropout + residual + LayerNorm epilogues, the BatchNorm
+        statistics kernels).  Built on first use around a throw-away CTC head; the engine's flat copies of the parameters are refreshed
+        whenever a parameter of this module has changed (torch's version counters), its BatchNorm running statistics ARE this
+        module's buffers."""
+        params = list(self.parameters())
+        stamp = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        eng = self.__dict__.get("_train_eng")
+        if eng is None:
+            from ..conformer.asr_model import CTC, ASRModel
+            from ..train.engine import ConformerCTCTrainStep
 
-        f32 = torch.float32
-        d, b = self.d, xs.shape[0]
-        pd, pp = self.dropout_rate, self.positional_dropout_rate
+            holder = ASRModel(4, self, CTC(4, self.d).to(params[0].device), 1.0)
+            eng = ConformerCTCTrainStep(holder, dropout_rate=self.dropout_rate, positional_dropout_rate=self.positional_dropout_rate,
+                                        seed=self.seed, bn_momentum=self.encoders[0].conv_module.norm.momentum)
+            eng.block_tables = False
+            object.__setattr__(self, "_train_eng", eng)  # (not a sub-module: the holder refers back to this encoder)
+            self.__dict__["_train_eng_stamp"] = None
+        if self.__dict__.get("_train_eng_stamp") != stamp:
+            eng._copy_params(to_flat=True)
+            eng.refresh_weights()
+            self.__dict__["_train_eng_stamp"] = stamp
+        eng.bn_mean = [l.conv_module.norm.running_mean for l in self.encoders]
+        eng.bn_var = [l.conv_module.norm.running_var for l in self.encoders]
+        eng.p_drop, eng.p_pos = float(self.dropout_rate), float(self.positional_dropout_rate)
+        return eng
+
+    def _forward_train(self, xs, P, masks, xs_chunk_masks):
+        """`module.train()(xs, masks)`: the training step's forward half (ConformerCTCTrainStep.encoder_forward_train) with this
+        module's dropout seed rule; updates the BatchNorm running statistics in place like nn.BatchNorm1d.  Nothing is kept for a
+        backward pass."""
         seed = (self.seed + self._train_calls) & 0x7fffffff
         self._train_calls += 1
-        salt = lambda layer, site: (layer + 1) * 16 + site  # noqa: E731  (the engine's site numbering)
-        act1 = ops.subsample_conv1(xs, P["conv1_w"], P["conv1_b"], self.cmvn_mean, self.cmvn_istd)
-        act2 = ops.conv2d_3x3s2_nhwc(act1, P["conv2_w"], P["conv2_b"], relu=True)
-        _, t2, f2, c = act2.shape
-        m = b * t2
-        if masks.shape[-1] != t2:
-            raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(masks.shape)))
-        mask2d = masks.reshape(b, t2).to(f32).contiguous()
-        mask_rows = mask2d.reshape(m)
-        att_mask = self._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
-        e = ops.gemm(act2.view(m, f2 * c), P["out_w"], bias=P["out_b"], alpha=math.sqrt(d), out_dtype=f32)
-        x = K.dropout_add(None, e, 1.0, pp, seed, salt(-1, 0)) if pp > 0 else e
-        pe = self.pe[:t2].to(f32).contiguous()
-        if pp > 0:
-            pe = K.dropout_add(None, pe, 1.0, pp, seed, salt(-1, 1))
-        pos_all = ops.gemm(ops.cast_bf16(pe), P["pos_w"])
-
-        def ffn(x, W, key, ln, li, s0):
-            a = ops.layernorm(x, ln.gamma, ln.beta)
-            h = K.act_dropout_fwd(ops.gemm(a, W[key + "_w1"], bias=W[key + "_b1"]), pd, seed, salt(li, s0))
-            y = ops.gemm(h, W[key + "_w2"], bias=W[key + "_b2"])
-            return K.dropout_add(x, y, 0.5, pd, seed, salt(li, s0 + 1))
-
-        for li, (l, W) in enumerate(zip(self.encoders, P["layers"])):
-            cm = l.conv_module
-            x = ffn(x, W, "ffm", l.norm_ff_macaron, li, 0)
-            a = ops.layernorm(x, l.norm_mha.gamma, l.norm_mha.beta)
-            qkv = ops.gemm(a, W["qkv_w"], bias=W["qkv_b"])
-            ctx = ops.relpos_attention(qkv, pos_all[:, li * d:(li + 1) * d], W["u"], W["v"], att_mask, b, t2, self.heads, 64)
-            x = K.dropout_add(x, ops.gemm(ctx, W["o_w"], bias=W["o_b"]), 1.0, pd, seed, salt(li, 2))
-            a = ops.layernorm(x, l.norm_conv.gamma, l.norm_conv.beta, row_scale=mask_rows)
-            y = ops.gemm(a, W["pw1_w"], bias=W["pw1_b"])
-            wv, _, _ = K.convmid_fwd_train(y, b, t2, W["dw_w"], cm.depthwise_conv.bias.detach().float().contiguous(),
-                                           cm.norm.weight.detach().float().contiguous(), cm.norm.bias.detach().float().contiguous(),
-                                           cm.norm.running_mean, cm.norm.running_var, eps=cm.norm.eps, momentum=cm.norm.momentum)
-            o = ops.gemm(wv, W["pw2_w"], bias=W["pw2_b"], row_scale=mask_rows)
-            x = K.dropout_add(x, o, 1.0, pd, seed, salt(li, 3))
-            x = ffn(x, W, "ff", l.norm_ff, li, 6)
-            ops.layernorm(x, l.norm_final.gamma, l.norm_final.beta, out_dtype=f32, out=x)
-        x = ops.layernorm(x, self.after_norm.gamma, self.after_norm.beta, out_dtype=f32)
+        x = self._train_engine().encoder_forward_train(xs, masks, xs_chunk_masks, seed=seed)
         self._bn_dirty = True  # the running statistics folded into the eval path's bn_scale / bn_shift have moved
-        return x.view(b, t2, d), masks
+        return x, masks
 
     @torch.no_grad()
     def _refresh_bn(self, P):

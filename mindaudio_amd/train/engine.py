@@ -472,6 +472,7 @@ class ConformerCTCTrainStep:
     def refresh_weights(self, cast=True):
         """bf16 mirror of the masters (one cast launch; cast=False: the optimizer launch has written it) + transposed bf16 copies of the
         matmul weights."""
+        self._sub_pk = None  # (the forward-only front end's packed copy of the two convolution weights)
         fp = self.fp
         if self.x32:  # the matmuls read the float32 masters themselves (dX = dY . W as an NN product: no transposed copies)
             return
@@ -858,6 +859,80 @@ class ConformerCTCTrainStep:
             return self._forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale, ys_in_pad, ys_out_pad,
                                           ys_sub_masks, ys_masks)
 
+    def _encoder_forward(self, xs, xs_masks, xs_chunk_masks, seed, tables=True):
+        """The encoder's training-mode forward (models/conformer.py:229-258 with self.training: dropout with the step's seed, BatchNorm
+        batch statistics + running-statistics update): subsampling front end, positional dropout, the blocks, after_norm.  ONE
+        implementation for the training step (_forward_backward) and for `ConformerEncoder.train()(xs, masks)`
+        (encoder_forward_train); `tables` = the step's block launch tables and weight-gradient plans (training step only)."""
+        fp, d, L = self.fp, self.d, self.L
+        ops, K = self.O, self.K
+        f32 = torch.float32
+        pd, pp = self.p_drop, self.p_pos
+        b = xs.shape[0]
+        enc = self.enc
+        act1 = None
+        if not tables and self.fused and xs.shape[2] == 80 and getattr(self, "forward_only_fused_front", True):
+            # nothing reads conv1's output again without a backward pass: both convolutions in one launch (subsample_fused.hip)
+            if getattr(self, "_sub_pk", None) is None:
+                self._sub_pk = ops.subsample_fused_pack(fp.p("conv1_w").reshape(d, 9).contiguous(), fp.w("conv2_w").view(d, 3, 3, d), 80)
+            act2 = ops.subsample_fused(xs, self._sub_pk, fp.p("conv1_b"), fp.p("conv2_b"), enc.cmvn_mean, enc.cmvn_istd)
+        else:
+            act1 = ops.subsample_conv1(xs, fp.p("conv1_w"), fp.p("conv1_b"), enc.cmvn_mean, enc.cmvn_istd)
+            if self.fused and isinstance(getattr(self, "_conv2_pk", None), torch.Tensor):
+                act2 = ops.conv2d_3x3s2_packed(act1, self._conv2_pk, fp.p("conv2_b"), relu=True)
+            else:
+                act2 = ops.conv2d_3x3s2_nhwc(act1, fp.w("conv2_w").view(d, 3, 3, d), fp.p("conv2_b"), relu=True)
+        _, t2, f2, c = act2.shape
+        m = b * t2
+        self._t2_cur = t2
+        self._dw_cur = self._dw_plan_for(m) if tables else None
+        if xs_masks.shape[-1] != t2:
+            raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(xs_masks.shape)))
+        chunked = xs_chunk_masks is not None and xs_chunk_masks.dim() == 3 and xs_chunk_masks.shape[1] == t2 and t2 > 1
+        tb = self._block_table_for(b, t2, (b, t2, t2) if chunked else (b, t2)) if tables else None
+        if tb is not None:  # (the blocks' inputs live at the table's addresses: conversion and placement in one launch)
+            mask2d = tb["mask_rows"].view(b, t2).copy_(xs_masks.reshape(b, t2))
+        else:
+            mask2d = xs_masks.reshape(b, t2).to(f32).contiguous()
+        mask_rows = mask2d.reshape(m)
+        # (B, T') padding mask, or the (B, T', T') chunk masks of the streaming configuration (models/conformer.py:251-252)
+        att_mask = enc._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
+        if tb is not None and att_mask is not mask2d:
+            att_mask = tb["att_mask"].copy_(att_mask)
+        hlens = mask2d.sum(1).to(torch.int32)
+        a2 = act2.view(m, f2 * c)
+        if self.fused and "out_w.r" in self.pk:
+            e = ops.gemm_rows_packed(a2, self.pk["out_w.r"].view(torch.bfloat16).view(d, -1), fp.p("out_b"), alpha=math.sqrt(d))
+        else:
+            e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)
+        if pp > 0:
+            x = K.dropout_add(None, e, 1.0, pp, seed, self._salt(-1, 0), out=tb["x_in"] if tb is not None else None)
+        else:
+            x = e if tb is None else tb["x_in"].copy_(e)
+        pe = enc.pe[:t2].to(f32).contiguous()
+        if pp > 0:
+            pe = K.dropout_add(None, pe, 1.0, pp, seed, self._salt(-1, 1))
+        pe_bf = ops.cast_bf16(pe)
+        pos_all = ops.gemm(pe_bf, fp.w("pos_w"), out=tb["pos_all"] if tb is not None else None)  # (t2, L*256) bf16
+        ctx_ = dict(seed=seed, b=b, t2=t2, m=m, mask_rows=mask_rows, att_mask=att_mask, pos_all=pos_all, table=tb, keep_tape=tables)
+        if self.fused:
+            x, enc_bf, tape = self._blocks_forward_fused(x, ctx_)
+        else:
+            x, enc_bf, tape = self._blocks_forward(x, ctx_)
+        return dict(act1=act1, act2=act2, a2=a2, pe_bf=pe_bf, mask2d=mask2d, hlens=hlens, t2=t2, m=m, f2=f2, c=c, tb=tb, ctx=ctx_, x=x,
+                    enc_bf=enc_bf, tape=tape)
+
+    @torch.no_grad()
+    def encoder_forward_train(self, xs_pad, xs_masks, xs_chunk_masks=None, seed=None):
+        """Training-mode forward of the encoder alone on the engine's kernels: (B, T, idim) -> (B, T', d) float32.  The same launches
+        as the training step's forward half (no launch tables, nothing kept for a backward pass); `seed` = the dropout seed (default:
+        the step's seed rule at the current call counter, which it does not advance)."""
+        if seed is None:
+            seed = (self.seed + self.calls + 0x3c6ef35f * self.rank) & 0x7fffffff
+        xs = xs_pad.to(torch.float32).contiguous()
+        F = self._encoder_forward(xs, xs_masks, xs_chunk_masks, int(seed) & 0x7fffffff, tables=False)
+        return F["x"].view(xs.shape[0], F["t2"], self.d)
+
     def _forward_backward(self, xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale, ys_in_pad, ys_out_pad, ys_sub_masks,
                           ys_masks):
         fp, d, L = self.fp, self.d, self.L
@@ -887,48 +962,10 @@ class ConformerCTCTrainStep:
         self._main = torch.cuda.current_stream() if self._wg is not None else None
 
         # ================= forward =================
-        act1 = ops.subsample_conv1(xs, fp.p("conv1_w"), fp.p("conv1_b"), enc.cmvn_mean, enc.cmvn_istd)
-        if self.fused and isinstance(getattr(self, "_conv2_pk", None), torch.Tensor):
-            act2 = ops.conv2d_3x3s2_packed(act1, self._conv2_pk, fp.p("conv2_b"), relu=True)
-        else:
-            act2 = ops.conv2d_3x3s2_nhwc(act1, fp.w("conv2_w").view(d, 3, 3, d), fp.p("conv2_b"), relu=True)
-        _, t2, f2, c = act2.shape
-        m = b * t2
-        self._t2_cur = t2
-        self._dw_cur = self._dw_plan_for(m)
-        if xs_masks.shape[-1] != t2:
-            raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(xs_masks.shape)))
-        chunked = xs_chunk_masks is not None and xs_chunk_masks.dim() == 3 and xs_chunk_masks.shape[1] == t2 and t2 > 1
-        tb = self._block_table_for(b, t2, (b, t2, t2) if chunked else (b, t2))
-        if tb is not None:  # (the blocks' inputs live at the table's addresses: conversion and placement in one launch)
-            mask2d = tb["mask_rows"].view(b, t2).copy_(xs_masks.reshape(b, t2))
-        else:
-            mask2d = xs_masks.reshape(b, t2).to(f32).contiguous()
-        mask_rows = mask2d.reshape(m)
-        # (B, T') padding mask, or the (B, T', T') chunk masks of the streaming configuration (models/conformer.py:251-252)
-        att_mask = enc._attention_mask(mask2d, xs_chunk_masks, b, t2, f32)
-        if tb is not None and att_mask is not mask2d:
-            att_mask = tb["att_mask"].copy_(att_mask)
-        hlens = mask2d.sum(1).to(torch.int32)
-        a2 = act2.view(m, f2 * c)
-        if self.fused and "out_w.r" in self.pk:
-            e = ops.gemm_rows_packed(a2, self.pk["out_w.r"].view(torch.bfloat16).view(d, -1), fp.p("out_b"), alpha=math.sqrt(d))
-        else:
-            e = ops.gemm(a2, fp.w("out_w"), bias=fp.p("out_b"), alpha=math.sqrt(d), out_dtype=f32)
-        if pp > 0:
-            x = K.dropout_add(None, e, 1.0, pp, seed, self._salt(-1, 0), out=tb["x_in"] if tb is not None else None)
-        else:
-            x = e if tb is None else tb["x_in"].copy_(e)
-        pe = enc.pe[:t2].to(f32).contiguous()
-        if pp > 0:
-            pe = K.dropout_add(None, pe, 1.0, pp, seed, self._salt(-1, 1))
-        pe_bf = ops.cast_bf16(pe)
-        pos_all = ops.gemm(pe_bf, fp.w("pos_w"), out=tb["pos_all"] if tb is not None else None)  # (t2, L*256) bf16
-        ctx_ = dict(seed=seed, b=b, t2=t2, m=m, mask_rows=mask_rows, att_mask=att_mask, pos_all=pos_all, table=tb)
-        if self.fused:
-            x, enc_bf, tape = self._blocks_forward_fused(x, ctx_)
-        else:
-            x, enc_bf, tape = self._blocks_forward(x, ctx_)
+        F = self._encoder_forward(xs, xs_masks, xs_chunk_masks, seed)
+        act1, act2, a2, pe_bf, mask2d, hlens = F["act1"], F["act2"], F["a2"], F["pe_bf"], F["mask2d"], F["hlens"]
+        t2, m, f2, c, tb, ctx_ = F["t2"], F["m"], F["f2"], F["c"], F["tb"], F["ctx"]
+        x, enc_bf, tape = F["x"], F["enc_bf"], F["tape"]
         logits = torch.empty((m, self.Vp), dtype=f32, device=self.dev)
         ops.gemm(enc_bf, fp.w("ctc_w"), bias=fp.p("ctc_b"), out_dtype=f32, out=logits[:, :self.V])
         wc = self.ctc_weight
@@ -1118,6 +1155,7 @@ class ConformerCTCTrainStep:
         seed, b, t2, mask_rows, att_mask, pos_all, pd = c["seed"], c["b"], c["t2"], c["mask_rows"], c["att_mask"], c["pos_all"], self.p_drop
         hid = self.hidden
         tape, enc_bf = [], None
+        keep = c.get("keep_tape", True)  # False: a forward that no backward pass follows (encoder_forward_train)
         for li in range(L):
             if rec is not None:
                 rec.segment(False, li)
@@ -1128,7 +1166,7 @@ class ConformerCTCTrainStep:
             # -- macaron FFN
             if self.ffn_one_launch:
                 u, h, x1, a1, _ = K.ffn_train(a, PK("ffm.f"), hid, P("ffm_b1"), pd, seed, self._salt(li, 0), P("ffm_b2"), x, 0.5, pd,
-                                              self._salt(li, 1), ln1=ln("norm_mha"), tape_derivative=self.ffn_bwd_one_launch)
+                                              self._salt(li, 1), ln1=ln("norm_mha"), tape_derivative=self.ffn_bwd_one_launch, tape=keep)
             else:
                 u, h = K.dense_act_drop(a, PK("ffm_w1.k"), hid, P("ffm_b1"), pd, seed, self._salt(li, 0))
                 x1, a1, _ = K.dense_join(h, PK("ffm_w2.r"), hid, P("ffm_b2"), x, 0.5, pd, seed, self._salt(li, 1), ln1=ln("norm_mha"))
@@ -1151,7 +1189,8 @@ class ConformerCTCTrainStep:
                 (fp.p("after_norm.g"), fp.p("after_norm.b"))
             if self.ffn_one_launch:
                 u, h, x4, a, x = K.ffn_train(a3, PK("ff.f"), hid, P("ff_b1"), pd, seed, self._salt(li, 6), P("ff_b2"), x3, 0.5, pd,
-                                             self._salt(li, 7), ln1=ln("norm_final"), ln2=nxt, tape_derivative=self.ffn_bwd_one_launch)
+                                             self._salt(li, 7), ln1=ln("norm_final"), ln2=nxt, tape_derivative=self.ffn_bwd_one_launch,
+                                             tape=keep)
             else:
                 u, h = K.dense_act_drop(a3, PK("ff_w1.k"), hid, P("ff_b1"), pd, seed, self._salt(li, 6))
                 x4, a, x = K.dense_join(h, PK("ff_w2.r"), hid, P("ff_b2"), x3, 0.5, pd, seed, self._salt(li, 7), ln1=ln("norm_final"),

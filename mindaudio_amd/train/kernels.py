@@ -584,8 +584,11 @@ def dense_join(a, packed, k, bias, residual, alpha, p, seed, salt, row_scale=Non
     return out, ln_out, ln_mid
 
 
+_NO_TAPE = {}
+
+
 def ffn_train(a, packed, hidden, b1, p_hidden, seed, salt_hidden, b2, residual, alpha, p_join, salt_join, ln1=None, ln2=None,
-              ln_row_scale=None, eps=1e-5, tape_derivative=False):
+              ln_row_scale=None, eps=1e-5, tape_derivative=False, tape=True):
     """The whole feed-forward module in training mode, one launch (ma_ffn_train_bf16; `packed` = the feed-forward block format of
     W1 and W2): -> (u, h (M, hidden) bf16 [the tape], x_out (M, 256) float32, ln_out, ln_mid) - what dense_act_drop followed by
     dense_join return.  tape_derivative: u is gk = swish'(pre-activation) * keep / (1 - p) instead (what ffn_train_bwd reads)."""
@@ -593,7 +596,13 @@ def ffn_train(a, packed, hidden, b1, p_hidden, seed, salt_hidden, b2, residual, 
 
     t = _t()
     m = a.shape[0]
-    uh = t.empty((2, m, hidden), dtype=t.bfloat16, device=a.device)
+    if tape:
+        uh, ldu = t.empty((2, m, hidden), dtype=t.bfloat16, device=a.device), hidden
+    else:  # forward only (tape=False): u / h are not kept - two scratch areas of 2 * hidden bytes, row stride 0 (130 MB less per module)
+        key = (a.device, hidden)
+        if key not in _NO_TAPE:
+            _NO_TAPE[key] = t.empty((2, hidden), dtype=t.bfloat16, device=a.device)
+        uh, ldu = _NO_TAPE[key], 0
     out = t.empty((m, 256), dtype=t.float32, device=a.device)
     ln_out = ln_mid = None
     if ln1 is not None:
@@ -602,9 +611,11 @@ def ffn_train(a, packed, hidden, b1, p_hidden, seed, salt_hidden, b2, residual, 
         ln_mid = t.empty((m, 256), dtype=t.float32, device=a.device)
     e = _train_epi(3, bias=b2, residual=residual, alpha=alpha, p=p_join, seed=seed, salt=salt_join, ln1=ln1, ln2=ln2,
                    ln_row_scale=ln_row_scale, ln_out=ln_out, ln_mid=ln_mid, eps=eps)
-    _lib.check(_lib.load().ma_ffn_train_bf16(_p(a), a.stride(0), m, hidden, _p(packed), _p(b1), _p(uh[0]), _p(uh[1]), hidden,
+    _lib.check(_lib.load().ma_ffn_train_bf16(_p(a), a.stride(0), m, hidden, _p(packed), _p(b1), _p(uh[0]), _p(uh[1]), ldu,
                                              1 if tape_derivative else 0, float(p_hidden), int(seed), int(salt_hidden), _p(out),
                                              out.stride(0), ctypes.byref(e), _s()), "ffn_train")
+    if not tape:
+        return None, None, out, ln_out, ln_mid
     return uh[0], uh[1], out, ln_out, ln_mid
 
 

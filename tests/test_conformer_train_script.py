@@ -161,9 +161,9 @@ def test_loop_on_the_reference_schema_with_stubs(tmp_path):
     lines = []
     recs = T.train(cfg, rank=1, world=2, device=torch.device("cpu"), log=lines.append, dataset_factory=dataset_factory,
                    model_factory=model_factory, step_factory=lambda m, c, r, w, pg: fake)
-    # the data-set call sees the reference's keys: bucket limits parsed from the comma-separated strings (dataset.py:679-680)
+    # the data-set call sees the reference's keys (the bucket limits as the yaml's comma-separated strings, parsed by the data set)
     assert seen["data_file"] == "x.csv" and seen["dict_file"] == "lang_char.txt" and (seen["rank"], seen["group"]) == (1, 2)
-    assert seen["dataset_conf"]["frame_bucket_limit"][:3] == [144, 204, 288] and seen["dataset_conf"]["batch_bucket_limit"][0] == 2
+    assert seen["dataset_conf"]["frame_bucket_limit"].startswith("144, 204, 288") and seen["dataset_conf"]["batch_bucket_limit"].startswith("2,")
     assert seen["collate_conf"]["spec_aug_conf"]["max_t"] == 50 and seen["collate_conf"]["feature_extraction_conf"]["mel_bins"] == 80
     assert made["input_dim"] == 80 and made["vocab"] == 11 and made["conf"]["cnn_module_kernel"] == 15
     # 2 epochs x 2 batches, columns in the reference's order (column i of batch k carries 10 k + i)

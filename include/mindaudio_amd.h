@@ -329,6 +329,13 @@ int ma_se_apply_bf16(const void* x, int64_t ldx, const void* gate, const void* r
  * out (batch, 2C) bf16 = (mean | std) * bn_scale + bn_shift (bn_* have 2C entries). */
 int ma_asp_pool_bf16(const void* logits, int64_t ldl, const void* x, int64_t ldx, int64_t batch, int64_t T, int32_t halo,
                      int32_t C, float eps, const float* bn_scale, const float* bn_shift, void* out, ma_stream_t stream);
+/* The same with the logits computed in the kernel (ecapatdnn.py:296-303: logits = a1 Wc^T + bias_c over att = 128 attention
+ * channels, a1 = tanh(tdnn(...)) (batch (T + 2 halo), att) bf16, Wc (C, att) bf16 row-major): one launch, no logits in memory,
+ * float32 logits.  bias_c is not an argument: a per-channel constant over the frames cancels in the softmax over the frames.
+ * MA_ERR_UNSUPPORTED unless att == 128, C % 256 == 0 and 16-byte aligned rows (callers then run ma_gemm_bf16 + ma_asp_pool_bf16). */
+int ma_asp_fused_bf16(const void* a1, int64_t lda, const void* Wc, const void* x, int64_t ldx, int64_t batch,
+                      int64_t T, int32_t halo, int32_t C, int32_t att, float eps, const float* bn_scale, const float* bn_shift,
+                      void* out, ma_stream_t stream);
 
 /* ---- post-processing around the feature kernels (mindaudio/data/features.py, spectrum.py, compute_cmvn_stats.py) --- */
 

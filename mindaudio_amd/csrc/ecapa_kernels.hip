@@ -251,6 +251,197 @@ __global__ __launch_bounds__(256) void asp_pool8_kernel(const uint16_t* __restri
   }
 }
 
+// ---- round 5: the ASP logits GEMM and the pooling in ONE launch ------------------------------------------------------------------
+// logits = a1 Wc^T + bc (ecapatdnn.py:296-297, K = attention_channels = 128; bc is constant over the frames and cancels in the
+// softmax over the frames, so the kernel never reads it) was a 64 x 128-tile GEMM that wrote (B (T + 2H), C) bf16
+// (242 MB at C = 1536) for asp_pool8_kernel to read back beside x: 105 + 109 us of the C = 512 forward, 216 + 227 us at C = 1024.
+// Here a WAVE owns 64 channels of one utterance for all its frames (workgroup = 4 waves = 256 channels, grid (C / 256, B)):
+//   * its weight slice (64 x 128 bf16) stays in LDS as MFMA A fragments - with MFMA row m of fragment j bound to channel
+//     16 (m >> 2) + 4 j + (m & 3), so that in the accumulator layout lane (fi = frame, fg) holds the 16 CONSECUTIVE channels
+//     16 fg .. 16 fg + 15 of frame fi: its slice of x is one 32-byte piece of the row;
+//   * per 16-frame tile: 4 fragment loads of a1 (L2: the four waves of the workgroup walk the same rows), 2 loads of x, 16 MFMAs,
+//     then the softmax sums (w, w x, w x^2) in registers, float32 logits (never rounded to bf16);
+//   * the 16 frame lanes of a channel meet in a 4-step butterfly at the end; no logits in memory.
+typedef __attribute__((ext_vector_type(8))) __bf16 e_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float e_f32x4;
+typedef __attribute__((ext_vector_type(2))) float e_f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t e_u32x4;
+
+__global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __restrict__ a1, int64_t lda, const uint16_t* __restrict__ W,
+                                                        const uint16_t* __restrict__ x, int64_t ldx,
+                                                        int Tp, int H, int T, int C, float eps, const float* __restrict__ bn_scale,
+                                                        const float* __restrict__ bn_shift, uint16_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63, fi = lane & 15, fg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c0 = blockIdx.x * 256 + wave * 64;
+  const int b = blockIdx.y;
+  const int64_t r0 = (int64_t)b * Tp + H;
+  // the wave's weight slice as 16 MFMA A fragments in its own 16 KiB of LDS (fragment (j, ks) at (4 j + ks) KiB, lane L at 16 L), read back
+  // per tile: in registers (64 VGPRs) the tile buffers below spilled at two waves per SIMD.  Everything goes through registers, no
+  // LDS-DMA: while a global_load_lds is outstanding hipcc turns each of its own waits into vmcnt(0) / lgkmcnt(0) (the instruction
+  // counts on both, out of order) - the end of the counted prefetch below.
+  extern __shared__ __attribute__((aligned(16))) char asp_smem[];
+  char* wl = asp_smem + wave * 16384;
+  char* aring = asp_smem + 4 * 16384;  // two slots of 4 KiB: the a1 tile in fragment order (k-step ks at ks KiB, lane L at 16 L)
+  {
+    e_bf16x8 wt[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        wt[j][ks] = *reinterpret_cast<const e_bf16x8*>(W + (int64_t)(c0 + (fi >> 2) * 16 + j * 4 + (fi & 3)) * 128 + ks * 32 + fg * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<e_bf16x8*>(wl + (j * 4 + ks) * 1024 + lane * 16) = wt[j][ks];
+  }
+  // running sums per lane: channel pair p = channels 2p, 2p + 1 of the lane's 16 (float2: the updates are v_pk_* instructions).  m2 is the
+  // REFERENCE exponent in the log2 domain, not the running maximum: the sums are of 2^(l2 - m2) and a tile rescales them only when a
+  // logit of the wave is more than 2^40 above its reference (the first tile, then practically never - the per-element select chain of
+  // the running-maximum form, 15 dependent VALU instructions per element, was 2x the kernel's HBM time).  m2 is always one of the
+  // channel's own logits and at most 40 below its maximum, so every weight is finite and the weights that underflow are < 2^-86 of the
+  // largest.
+  e_f32x2 n2[8], s0[8], s1[8], s2[8];  // n2 = -m2 (the form the fused multiply-add takes)
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    n2[p] = e_f32x2{3.0e38f, 3.0e38f};  // (finite: -inf - -inf would be NaN)
+    s0[p] = s1[p] = s2[p] = e_f32x2{0.f, 0.f};
+  }
+  const int ntiles = (T + 15) >> 4;
+  // tiles in flight: x (HBM) three tiles ahead in four register buffers.  Every wave needs the same 16 x 128 tile of a1: wave w loads
+  // k-step w of it (4 VGPRs, three tiles ahead), writes it to the LDS slot of tile i + 1 during tile i, and one barrier per tile hands
+  // the slots over.  A SIMD needs ~30 KB in flight (6 KB per ~1 000 cycles x ~5 000 cycles of loaded latency); with the whole a1 tile in
+  // registers per wave (64 VGPRs for four buffers) the kernel spilled, and with fewer buffers it waited: 125 us.
+  e_bf16x8 ar[4];
+  e_u32x4 xv[4][2];
+#define ASP_ROW(tile_)                                                          \
+  int t_ = (tile_) * 16 + fi;                                                   \
+  if (t_ >= T) t_ = T - 1; /* frames past the utterance: a valid row, weight 0 below */
+#define ASP_LOAD(buf_, tile_)                                                                                          \
+  {                                                                                                                   \
+    ASP_ROW(tile_)                                                                                                    \
+    ar[buf_] = *reinterpret_cast<const e_bf16x8*>(a1 + (r0 + t_) * lda + wave * 32 + fg * 8);                         \
+    const uint16_t* xp_ = x + (r0 + t_) * ldx + c0 + fg * 16;                                                         \
+    xv[buf_][0] = *reinterpret_cast<const e_u32x4*>(xp_);                                                             \
+    xv[buf_][1] = *reinterpret_cast<const e_u32x4*>(xp_ + 8);                                                         \
+  }
+  const e_f32x2 kL2E = {1.44269504f, 1.44269504f};
+  // one tile: logits (no bias: a per-channel constant over the frames does not change the softmax over the frames) as exponents
+  // relative to the reference, the rare rescale, then the three sums
+#define ASP_TILE(xb_, tile_)                                                                                           \
+  {                                                                                                                   \
+    /* everybody is past tile (tile_) - 1 and a1 tile (tile_) is complete in slot (tile_) & 1; tile (tile_) + 1 goes to the other   \
+       slot (this wave's k-step, loaded two tiles ago); then the loads of tile (tile_) + 3.  All loads are unconditional (past the   \
+       last tile: the clamped last row again) - a load under `if` makes hipcc's wait for the operands the merge of both paths, i.e.  \
+       on the path WITH the load a wait for the load just issued. */                                                   \
+    __syncthreads();                                                                                                  \
+    *reinterpret_cast<e_bf16x8*>(aring + (((xb_) + 1) & 1) * 4096 + wave * 1024 + lane * 16) = ar[((xb_) + 1) % 4];   \
+    ASP_LOAD(((xb_) + 3) % 4, (tile_) + 3)                                                                            \
+    e_f32x4 acc[4];                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = e_f32x4{0.f, 0.f, 0.f, 0.f};                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                 \
+      const e_bf16x8 bfr = *reinterpret_cast<const e_bf16x8*>(aring + ((xb_) & 1) * 4096 + ks * 1024 + lane * 16);    \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const e_bf16x8*>(wl + (j * 4 + ks) * 1024 + lane * 16), \
+                                                         bfr, acc[j], 0, 0, 0);                                       \
+    }                                                                                                                 \
+    e_f32x2 d[8];                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                                    \
+      const e_f32x2 l_ = (p & 1) ? e_f32x2{acc[p >> 1][2], acc[p >> 1][3]} : e_f32x2{acc[p >> 1][0], acc[p >> 1][1]}; \
+      d[p] = __builtin_elementwise_fma(l_, kL2E, n2[p]);                                                              \
+    }                                                                                                                 \
+    if ((tile_) + 1 >= ntiles && (tile_) * 16 + fi >= T) {                                                            \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) d[p] = e_f32x2{-INFINITY, -INFINITY};                             \
+    }                                                                                                                 \
+    float mx = fmaxf(d[0][0], d[0][1]);                                                                               \
+    _Pragma("unroll") for (int p = 1; p < 8; ++p) mx = fmaxf(fmaxf(mx, d[p][0]), d[p][1]);                             \
+    if (__any(mx > 40.0f)) {                                                                                          \
+      _Pragma("unroll") for (int p = 0; p < 8; ++p) _Pragma("unroll") for (int e = 0; e < 2; ++e) {                    \
+        const float l2_ = d[p][e] - n2[p][e];                                                                         \
+        const float nm_ = fmaxf(-n2[p][e], l2_);                                                                      \
+        const float f_ = __builtin_amdgcn_exp2f(-n2[p][e] - nm_);                                                     \
+        s0[p][e] *= f_; s1[p][e] *= f_; s2[p][e] *= f_;                                                               \
+        n2[p][e] = -nm_;                                                                                              \
+        d[p][e] = l2_ - nm_;                                                                                          \
+      }                                                                                                               \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                                    \
+      const uint32_t xw = xv[xb_][p >> 2][p & 3];                                                                     \
+      const e_f32x2 xe = {__uint_as_float(xw << 16), __uint_as_float(xw & 0xffff0000u)};                              \
+      const e_f32x2 w = {__builtin_amdgcn_exp2f(d[p][0]), __builtin_amdgcn_exp2f(d[p][1])};                           \
+      const e_f32x2 wx = w * xe;                                                                                      \
+      s0[p] += w;                                                                                                     \
+      s1[p] += wx;                                                                                                    \
+      s2[p] = __builtin_elementwise_fma(wx, xe, s2[p]);                                                               \
+    }                                                                                                                 \
+  }
+  ASP_LOAD(0, 0)
+  ASP_LOAD(1, 1)
+  ASP_LOAD(2, 2)
+  *reinterpret_cast<e_bf16x8*>(aring + wave * 1024 + lane * 16) = ar[0];  // tile 0's slot (the first barrier publishes it)
+  int tile = 0;
+  for (; tile + 4 <= ntiles; tile += 4) {
+    ASP_TILE(0, tile)
+    ASP_TILE(1, tile + 1)
+    ASP_TILE(2, tile + 2)
+    ASP_TILE(3, tile + 3)
+  }
+  if (tile < ntiles) {
+    ASP_TILE(0, tile)
+    if (tile + 1 < ntiles) {
+      ASP_TILE(1, tile + 1)
+      if (tile + 2 < ntiles) ASP_TILE(2, tile + 2)
+    }
+  }
+#undef ASP_TILE
+#undef ASP_LOAD
+#undef ASP_ROW
+  // the 16 frame lanes of every channel: butterfly over lane bits 0..3 (fixed order: deterministic)
+#pragma unroll
+  for (int step = 1; step < 16; step <<= 1) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float mine = -n2[p][e];
+        const float mo = -__shfl_xor(n2[p][e], step, 64), a0 = __shfl_xor(s0[p][e], step, 64), a1v = __shfl_xor(s1[p][e], step, 64),
+                    a2 = __shfl_xor(s2[p][e], step, 64);
+        const float M = fmaxf(mine, mo);
+        const float f1 = __builtin_amdgcn_exp2f(mine - M), f2 = __builtin_amdgcn_exp2f(mo - M);
+        n2[p][e] = -M;
+        s0[p][e] = s0[p][e] * f1 + a0 * f2;
+        s1[p][e] = s1[p][e] * f1 + a1v * f2;
+        s2[p][e] = s2[p][e] * f1 + a2 * f2;
+      }
+  }
+  if (fi == 0) {
+    const int cb = c0 + fg * 16;
+    uint32_t mo[8], so[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      float mv[2], sv[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float mean = s1[p][e] / s0[p][e];
+        const float var = fmaxf(s2[p][e] / s0[p][e] - mean * mean, eps);
+        // cat((mean, std), 1) -> BatchNorm over 2C channels (ecapatdnn.py:306-308, 427)
+        mv[e] = mean * bn_scale[cb + 2 * p + e] + bn_shift[cb + 2 * p + e];
+        sv[e] = sqrtf(var) * bn_scale[C + cb + 2 * p + e] + bn_shift[C + cb + 2 * p + e];
+      }
+      mo[p] = (uint32_t)e_f2bf(mv[0]) | ((uint32_t)e_f2bf(mv[1]) << 16);
+      so[p] = (uint32_t)e_f2bf(sv[0]) | ((uint32_t)e_f2bf(sv[1]) << 16);
+    }
+    uint16_t* om = out + (int64_t)b * 2 * C + cb;
+    *reinterpret_cast<uint4*>(om) = make_uint4(mo[0], mo[1], mo[2], mo[3]);
+    *reinterpret_cast<uint4*>(om + 8) = make_uint4(mo[4], mo[5], mo[6], mo[7]);
+    *reinterpret_cast<uint4*>(om + C) = make_uint4(so[0], so[1], so[2], so[3]);
+    *reinterpret_cast<uint4*>(om + C + 8) = make_uint4(so[4], so[5], so[6], so[7]);
+  }
+}
+
+constexpr int kAspLds = 4 * 16384 + 2 * 4096;  // weight fragments of the four waves + two a1 tiles
+MA_LDS_ATTR(asp_fused_kernel, kAspLds);
+
 static int e_grid(int64_t n, int cap = 8192) {
   int64_t g = (n + 255) / 256;
   return (int)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -315,6 +506,21 @@ int ma_asp_pool_bf16(const void* logits, int64_t ldl, const void* x, int64_t ldx
     MA_LAUNCH(asp_pool_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
               (const uint16_t*)logits, ldl, (const uint16_t*)x, ldx, (int)(T + 2 * halo), halo, (int)T, C, eps, bn_scale,
               bn_shift, (uint16_t*)out);
+  return MA_OK;
+}
+
+int ma_asp_fused_bf16(const void* a1, int64_t lda, const void* Wc, const void* x, int64_t ldx, int64_t batch,
+                      int64_t T, int32_t halo, int32_t C, int32_t att, float eps, const float* bn_scale, const float* bn_shift,
+                      void* out, ma_stream_t stream) {
+  if (!a1 || !Wc || !x || !bn_scale || !bn_shift || !out || batch < 1 || T < 1 || halo < 0 || C < 1 || batch > 65535)
+    return MA_ERR_INVALID_ARG;
+  if (att != 128 || (C & 255) || (lda & 7) || (ldx & 7) || lda < att || ldx < C ||
+      ((reinterpret_cast<uintptr_t>(a1) | reinterpret_cast<uintptr_t>(Wc) | reinterpret_cast<uintptr_t>(x) |
+        reinterpret_cast<uintptr_t>(out)) & 15))
+    return MA_ERR_UNSUPPORTED;
+  MA_LAUNCH(asp_fused_kernel, dim3((unsigned)(C / 256), (unsigned)batch), dim3(256), kAspLds, (hipStream_t)stream, (const uint16_t*)a1, lda,
+            (const uint16_t*)Wc, (const uint16_t*)x, ldx, (int)(T + 2 * halo), halo, (int)T, C, eps, bn_scale, bn_shift,
+            (uint16_t*)out);
   return MA_OK;
 }
 

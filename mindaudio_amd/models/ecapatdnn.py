@@ -100,6 +100,7 @@ class EcapaTDNN(nn.Module):
         self._prepared = None
         self._ws = {}
         self.fuse_res2net = True  # False: one launch per convolution / add of the Res2Net chain (the tests run both)
+        self.fuse_asp = True      # False: the ASP logits as a GEMM launch + the pooling launch (the tests run both)
 
     @torch.no_grad()
     def prepare(self):
@@ -239,8 +240,16 @@ class EcapaTDNN(nn.Module):
         a1 = t.empty((rows, self.att), dtype=bf, device=dev)
         _conv(xm.data_ptr(), 3 * c, rows, 3 * c, A["w"], 1, 1, a1.data_ptr(), self.att, self.att, A["b"], RELU, A["bn"],
               act2=_lib.ACT_TANH)
-        logits = ops.gemm(a1, P["asp_c"]["w"], bias=P["asp_c"]["b"])
         pooled = t.empty((b, 6 * c), dtype=bf, device=dev)
-        _lib.check(lib.ma_asp_pool_bf16(logits.data_ptr(), 3 * c, xm.data_ptr(), 3 * c, b, T, H, 3 * c, 1e-12,
-                                        P["asp_bn"][0].data_ptr(), P["asp_bn"][1].data_ptr(), pooled.data_ptr(), s), "asp_pool")
+        rc = _lib.MA_ERR_UNSUPPORTED
+        if self.fuse_asp:  # logits GEMM + softmax pooling in one launch (att == 128, 3C % 256 == 0), else the two launches
+            rc = lib.ma_asp_fused_bf16(a1.data_ptr(), self.att, P["asp_c"]["w"].data_ptr(), xm.data_ptr(),
+                                       3 * c, b, T, H, 3 * c, self.att, 1e-12, P["asp_bn"][0].data_ptr(), P["asp_bn"][1].data_ptr(),
+                                       pooled.data_ptr(), s)
+            if rc != _lib.MA_ERR_UNSUPPORTED:
+                _lib.check(rc, "asp_fused")
+        if rc == _lib.MA_ERR_UNSUPPORTED:
+            logits = ops.gemm(a1, P["asp_c"]["w"], bias=P["asp_c"]["b"])
+            _lib.check(lib.ma_asp_pool_bf16(logits.data_ptr(), 3 * c, xm.data_ptr(), 3 * c, b, T, H, 3 * c, 1e-12,
+                                            P["asp_bn"][0].data_ptr(), P["asp_bn"][1].data_ptr(), pooled.data_ptr(), s), "asp_pool")
         return ops.gemm(pooled, P["fc"]["w"], bias=P["fc"]["b"], out_dtype=t.float32)

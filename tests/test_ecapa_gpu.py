@@ -113,6 +113,23 @@ def test_res2net_chain_in_one_launch_equals_the_separate_launches(c, b, t):
     assert float((fused.cpu() - want).norm() / want.norm()) < 3e-2
 
 
+@pytest.mark.parametrize("c,b,t", [(512, 3, 57), (512, 2, 300), (1024, 2, 300), (512, 2, 9)])
+def test_asp_logits_and_pooling_in_one_launch_equal_the_two_launches(c, b, t):
+    """ma_asp_fused_bf16 (logits = a1 Wc^T + b and the attentive statistics pooling, ecapatdnn.py:284-308, in one launch with
+    float32 logits) against the GEMM launch (bf16 logits) + ma_asp_pool_bf16 on the same weights, and both against the oracle."""
+    ref, dut = build(c=c, seed=7)
+    x = torch.randn(b, t, 80, generator=torch.Generator().manual_seed(t + 1)).cuda()
+    assert dut.fuse_asp
+    fused = dut(x)
+    dut.fuse_asp = False
+    plain = dut(x)
+    assert float((fused - plain).abs().max()) <= 2e-2 * float(plain.abs().max())
+    with torch.no_grad():
+        want = ref(x.cpu())
+    assert float((fused.cpu() - want).norm() / want.norm()) < 3e-2
+    assert torch.equal(fused, (setattr(dut, "fuse_asp", True), dut(x))[1])  # deterministic
+
+
 def test_res2net_long_utterances_fall_back():
     ref, dut = build(c=512, seed=6)
     x = torch.randn(2, 500, 80)  # T + 2H > 384 rows: the chain runs as separate launches

@@ -321,6 +321,16 @@ int ma_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* ou
 /* SE squeeze (ecapatdnn.py:152-153): out (batch, C) bf16 = mean over the T frames of every utterance. */
 int ma_time_mean_bf16(const void* x, int64_t ldx, int64_t batch, int64_t T, int32_t halo, int32_t C, void* out,
                       ma_stream_t stream);
+/* SE excitation on the squeezed vector (ecapatdnn.py:150-156) in one launch: gate (batch, C) bf16 =
+ * sigmoid(W2 relu(W1 mean + b1) + b2), mean (batch, C) bf16, W1 (S, C) / W2 (C, S) bf16 row-major, float32 biases.
+ * C = 512 or 1024 and S <= 128 (a multiple of 8), else MA_ERR_UNSUPPORTED (callers then run two ma_gemm_bf16). */
+int ma_se_gate_bf16(const void* mean, const void* W1, const float* b1, const void* W2, const float* b2, void* gate, int64_t batch,
+                    int32_t C, int32_t S, ma_stream_t stream);
+/* out (M, N) float32 = a (M, K) bf16 @ W (N, K)^T + bias for few rows (the embedding Linear on the pooled statistics,
+ * ecapatdnn.py:429-431): 16 x 16 output tiles, K split over the 8 waves of a workgroup.  M % 16, N % 16, K % 3072 == 0, else
+ * MA_ERR_UNSUPPORTED (callers then run ma_gemm_bf16). */
+int ma_linear_small_bf16(const void* a, int64_t lda, const void* W, int64_t ldw, const float* bias, float* out, int64_t ldo, int64_t M,
+                         int64_t N, int64_t K, ma_stream_t stream);
 /* SE excite + block residual (ecapatdnn.py:156, 246): out = gate[b, c] * x + residual on the T frames, 0 on halo frames. */
 int ma_se_apply_bf16(const void* x, int64_t ldx, const void* gate, const void* residual, int64_t ldr, void* out,
                      int64_t ldo, int64_t batch, int64_t T, int32_t halo, int32_t C, ma_stream_t stream);

@@ -320,11 +320,21 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
 #define ASP_LOAD(buf_, tile_)                                                                                          \
   {                                                                                                                   \
     ASP_ROW(tile_)                                                                                                    \
-    ar[buf_] = *reinterpret_cast<const e_bf16x8*>(a1 + (r0 + t_) * lda + wave * 32 + fg * 8);                         \
+    if (!(ASP_X & 8) || (tile_) < 3) ar[buf_] = *reinterpret_cast<const e_bf16x8*>(a1 + (r0 + t_) * lda + wave * 32 + fg * 8); \
     const uint16_t* xp_ = x + (r0 + t_) * ldx + c0 + fg * 16;                                                         \
-    xv[buf_][0] = *reinterpret_cast<const e_u32x4*>(xp_);                                                             \
-    xv[buf_][1] = *reinterpret_cast<const e_u32x4*>(xp_ + 8);                                                         \
+    if (!(ASP_X & 4) || (tile_) < 3) {                                                                                \
+      xv[buf_][0] = *reinterpret_cast<const e_u32x4*>(xp_);                                                           \
+      xv[buf_][1] = *reinterpret_cast<const e_u32x4*>(xp_ + 8);                                                       \
+    }                                                                                                                 \
   }
+#ifndef ASP_X
+#define ASP_X 0  // development ablations (tools/asp_bench.py): 1 no exponentials, 2 no MFMAs, 4 no loads of x, 8 no a1 exchange
+#endif
+#if ASP_X & 1
+#define ASP_W(d_) (d_)
+#else
+#define ASP_W(d_) (e_f32x2{__builtin_amdgcn_exp2f((d_)[0]), __builtin_amdgcn_exp2f((d_)[1])})
+#endif
   const e_f32x2 kL2E = {1.44269504f, 1.44269504f};
   // one tile: logits (no bias: a per-channel constant over the frames does not change the softmax over the frames) as exponents
   // relative to the reference, the rare rescale, then the three sums
@@ -334,16 +344,20 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
        slot (this wave's k-step, loaded two tiles ago); then the loads of tile (tile_) + 3.  All loads are unconditional (past the   \
        last tile: the clamped last row again) - a load under `if` makes hipcc's wait for the operands the merge of both paths, i.e.  \
        on the path WITH the load a wait for the load just issued. */                                                   \
-    __syncthreads();                                                                                                  \
-    *reinterpret_cast<e_bf16x8*>(aring + (((xb_) + 1) & 1) * 4096 + wave * 1024 + lane * 16) = ar[((xb_) + 1) % 4];   \
+    if (!(ASP_X & 8)) {                                                                                               \
+      __syncthreads();                                                                                                \
+      *reinterpret_cast<e_bf16x8*>(aring + (((xb_) + 1) & 1) * 4096 + wave * 1024 + lane * 16) = ar[((xb_) + 1) % 4]; \
+    }                                                                                                                 \
     ASP_LOAD(((xb_) + 3) % 4, (tile_) + 3)                                                                            \
     e_f32x4 acc[4];                                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = e_f32x4{0.f, 0.f, 0.f, 0.f};                               \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                 \
       const e_bf16x8 bfr = *reinterpret_cast<const e_bf16x8*>(aring + ((xb_) & 1) * 4096 + ks * 1024 + lane * 16);    \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const e_bf16x8*>(wl + (j * 4 + ks) * 1024 + lane * 16), \
-                                                         bfr, acc[j], 0, 0, 0);                                       \
+        if (!(ASP_X & 2))                                                                                             \
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const e_bf16x8*>(wl + (j * 4 + ks) * 1024 + lane * 16), \
+                                                           bfr, acc[j], 0, 0, 0);                                     \
+        else acc[j][0] += __builtin_bit_cast(e_f32x4, bfr)[j];                                                        \
     }                                                                                                                 \
     e_f32x2 d[8];                                                                                                     \
     _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                                    \
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
     _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                                    \
       const uint32_t xw = xv[xb_][p >> 2][p & 3];                                                                     \
       const e_f32x2 xe = {__uint_as_float(xw << 16), __uint_as_float(xw & 0xffff0000u)};                              \
-      const e_f32x2 w = {__builtin_amdgcn_exp2f(d[p][0]), __builtin_amdgcn_exp2f(d[p][1])};                           \
+      const e_f32x2 w = ASP_W(d[p]);                                                                                  \
       const e_f32x2 wx = w * xe;                                                                                      \
       s0[p] += w;                                                                                                     \
       s1[p] += wx;                                                                                                    \
@@ -436,6 +450,130 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
     *reinterpret_cast<uint4*>(om + 8) = make_uint4(mo[4], mo[5], mo[6], mo[7]);
     *reinterpret_cast<uint4*>(om + C) = make_uint4(so[0], so[1], so[2], so[3]);
     *reinterpret_cast<uint4*>(om + C + 8) = make_uint4(so[4], so[5], so[6], so[7]);
+  }
+}
+
+// ---- round 5: the SE block's two 1 x 1 convolutions on the squeezed vector (ecapatdnn.py:150-156) in one launch ----------------------
+// gate[b] = sigmoid(W2 relu(W1 mean[b] + b1) + b2), W1 (S, C), W2 (C, S): as two ma_gemm_bf16 launches (M = batch = 256 rows, 8 tiles)
+// they were 9.4 + 10 us of pure latency per block.  One workgroup per utterance: phase 1 - the 64 lanes of a wave split K of a row of W1
+// (coalesced row reads, butterfly sum); phase 2 - a thread per output row of W2, h from LDS.  float32 throughout, h is never rounded
+// to bf16.
+// KC = C / 512.  512 threads: phase 1 - wave w owns rows 16 w' .. of W1 (S / 8 per wave, at most 16), lane l the K slice 8 l .. 8 l + 7
+// of every 512-column chunk: ALL its loads are issued before the first use (a row at a time was one L2 round trip per row: 32 us).
+template <int KC>
+__global__ __launch_bounds__(512) void se_gate_kernel(const uint16_t* __restrict__ mean, const uint16_t* __restrict__ W1,
+                                                      const float* __restrict__ b1, const uint16_t* __restrict__ W2,
+                                                      const float* __restrict__ b2, uint16_t* __restrict__ gate, int S) {
+  constexpr int C = 512 * KC;
+  __shared__ __attribute__((aligned(16))) float sh[1024];  // h (S <= 128 used here; sized for the guard below)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.x;
+  // this lane's slice of the squeezed vector: columns 512 kc + 8 lane .. + 7
+  float xs[KC][8];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const uint4 v = *reinterpret_cast<const uint4*>(mean + b * C + kc * 512 + lane * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xs[kc][2 * e] = __uint_as_float(w[e] << 16); xs[kc][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+  }
+  const int rows = S >> 3;  // per wave (<= 16)
+  e_u32x4 wv[16][KC];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int j = wave * rows + (r < rows ? r : rows - 1);
+      wv[r][kc] = *reinterpret_cast<const e_u32x4*>(W1 + (int64_t)j * C + kc * 512 + lane * 8);
+    }
+  // every load of the kernel whose address does not depend on h is issued here, before the first wait (five dependent round trips
+  // otherwise: mean, W1, b1, W2, b2)
+  float b1v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) b1v[r] = b1[wave * rows + (r < rows ? r : rows - 1)];
+  const int kl = (lane & 15) * 8;
+  const bool kin = kl < S;
+  constexpr int kInst = C / 32;  // phase 2, per wave: C / 8 rows, four per instruction
+  e_u32x4 w2[kInst];
+  float b2v[kInst];
+#pragma unroll
+  for (int i = 0; i < kInst; ++i) {
+    const int c = wave * (C / 8) + 4 * i + (lane >> 4);
+    if constexpr (KC == 1) w2[i] = *reinterpret_cast<const e_u32x4*>(W2 + (int64_t)c * S + (kin ? kl : 0));  // (KC = 2: no registers left)
+    b2v[i] = b2[c];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float a = 0.0f;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        a += __uint_as_float(wv[r][kc][e] << 16) * xs[kc][2 * e] + __uint_as_float(wv[r][kc][e] & 0xffff0000u) * xs[kc][2 * e + 1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0 && r < rows) sh[wave * rows + r] = fmaxf(a + b1v[r], 0.0f);
+  }
+  __syncthreads();
+  // phase 2: a row of W2 is S <= 128 columns = at most 16 lanes x 16 bytes: a load instruction brings FOUR consecutive rows (lane group
+  // lane >> 4 the row, lane & 15 the K slice; rows are adjacent in memory: 1 KiB per instruction when S = 128), all C / 32 loads of the
+  // wave in flight, then a 4-step butterfly over the 16 lanes of a row.  (A thread per row: 64 lines per instruction, 14.9 us.)
+  if constexpr (KC != 1) {
+#pragma unroll
+    for (int i = 0; i < kInst; ++i)
+      w2[i] = *reinterpret_cast<const e_u32x4*>(W2 + (int64_t)(wave * (C / 8) + 4 * i + (lane >> 4)) * S + (kin ? kl : 0));
+  }
+  float hs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) hs[e] = kin ? sh[kl + e] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < kInst; ++i) {
+    float a = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a += __uint_as_float(w2[i][e] << 16) * hs[2 * e] + __uint_as_float(w2[i][e] & 0xffff0000u) * hs[2 * e + 1];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((lane & 15) == 0) {
+      const int c = wave * (C / 8) + 4 * i + (lane >> 4);
+      gate[b * C + c] = e_f2bf(1.0f / (1.0f + __expf(-(a + b2v[i]))));
+    }
+  }
+}
+
+// ---- round 5: out (M, N) f32 = a (M, K) bf16 @ W (N, K)^T + bias for a FEW rows (the final Linear on the pooled statistics,
+// ecapatdnn.py:429-431: M = batch = 256, N = 192, K = 6C) --------------------------------------------------------------------------------
+// On the 64 x 128 tile of ma_gemm_bf16 this is 8 workgroups walking K = 3072 .. 6144 serially (28 us at C = 512).  Here a workgroup owns
+// a 16 x 16 output tile and its 8 waves split K: (M / 16) (N / 16) workgroups of 8 independent streams with twelve k-steps of loads in
+// flight each, partial tiles summed through LDS in a fixed order.
+__global__ __launch_bounds__(512) void linear_small_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ W,
+                                                           int64_t ldw, const float* __restrict__ bias, float* __restrict__ out,
+                                                           int64_t ldo, int K) {
+  __shared__ float red[8][16][16 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  const int kw = K / 8;  // this wave's slice of K (a multiple of 32)
+  const uint16_t* ap = A + (int64_t)(m0 + fi) * lda + wave * kw + fg * 8;
+  const uint16_t* wp = W + (int64_t)(n0 + fi) * ldw + wave * kw + fg * 8;
+  e_f32x4 acc[2] = {e_f32x4{0.f, 0.f, 0.f, 0.f}, e_f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (int k0 = 0; k0 < kw; k0 += 384) {  // twelve k-steps at a time: 24 loads in flight, then 12 MFMAs (kw % 384 == 0)
+    e_bf16x8 af[12], wf[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      af[i] = *reinterpret_cast<const e_bf16x8*>(ap + k0 + 32 * i);
+      wf[i] = *reinterpret_cast<const e_bf16x8*>(wp + k0 + 32 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[i], acc[i & 1], 0, 0, 0);  // rows 4 fg + r = n, column fi = m
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][fi][fg * 4 + r] = acc[0][r] + acc[1][r];
+  __syncthreads();
+  if (tid < 256) {
+    const int m = tid >> 4, n = tid & 15;
+    float a = bias ? bias[n0 + n] : 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) a += red[w][m][n];
+    out[(int64_t)(m0 + m) * ldo + n0 + n] = a;
   }
 }
 
@@ -521,6 +659,32 @@ int ma_asp_fused_bf16(const void* a1, int64_t lda, const void* Wc, const void* x
   MA_LAUNCH(asp_fused_kernel, dim3((unsigned)(C / 256), (unsigned)batch), dim3(256), kAspLds, (hipStream_t)stream, (const uint16_t*)a1, lda,
             (const uint16_t*)Wc, (const uint16_t*)x, ldx, (int)(T + 2 * halo), halo, (int)T, C, eps, bn_scale, bn_shift,
             (uint16_t*)out);
+  return MA_OK;
+}
+
+int ma_se_gate_bf16(const void* mean, const void* W1, const float* b1, const void* W2, const float* b2, void* gate, int64_t batch,
+                    int32_t C, int32_t S, ma_stream_t stream) {
+  if (!mean || !W1 || !b1 || !W2 || !b2 || !gate || batch < 1 || C < 1 || S < 1) return MA_ERR_INVALID_ARG;
+  if ((C != 512 && C != 1024) || (S & 7) || S > 128 ||
+      ((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(W2)) & 15))
+    return MA_ERR_UNSUPPORTED;
+  if (C == 512)
+    MA_LAUNCH(se_gate_kernel<1>, dim3((unsigned)batch), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)mean, (const uint16_t*)W1, b1,
+              (const uint16_t*)W2, b2, (uint16_t*)gate, S);
+  else
+    MA_LAUNCH(se_gate_kernel<2>, dim3((unsigned)batch), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)mean, (const uint16_t*)W1, b1,
+              (const uint16_t*)W2, b2, (uint16_t*)gate, S);
+  return MA_OK;
+}
+
+int ma_linear_small_bf16(const void* a, int64_t lda, const void* W, int64_t ldw, const float* bias, float* out, int64_t ldo, int64_t M,
+                         int64_t N, int64_t K, ma_stream_t stream) {
+  if (!a || !W || !out || M < 1 || N < 1 || K < 1) return MA_ERR_INVALID_ARG;
+  if ((M & 15) || (N & 15) || K % 3072 || (lda & 7) || (ldw & 7) || lda < K || ldw < K || ldo < N || M > 16 * 65535 ||
+      ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(W)) & 15))
+    return MA_ERR_UNSUPPORTED;
+  MA_LAUNCH(linear_small_kernel, dim3((unsigned)(M / 16), (unsigned)(N / 16)), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)a,
+            lda, (const uint16_t*)W, ldw, bias, out, ldo, (int)K);
   return MA_OK;
 }
 

@@ -100,6 +100,7 @@ class EcapaTDNN(nn.Module):
         self._prepared = None
         self._ws = {}
         self.fuse_res2net = True  # False: one launch per convolution / add of the Res2Net chain (the tests run both)
+        self.fuse_se = True       # False: the SE excitation and the embedding Linear as ma_gemm_bf16 launches (the tests run both)
         self.fuse_asp = True      # False: the ASP logits as a GEMM launch + the pooling launch (the tests run both)
 
     @torch.no_grad()
@@ -226,8 +227,16 @@ class EcapaTDNN(nn.Module):
                   row_scale=rs)
             mean = t.empty((b, c), dtype=bf, device=dev)
             _lib.check(lib.ma_time_mean_bf16(t2.data_ptr(), c, b, T, H, c, mean.data_ptr(), s), "time_mean")
-            g1 = ops.gemm(mean, B_["se1"]["w"], bias=B_["se1"]["b"], act=RELU)
-            g2 = ops.gemm(g1, B_["se2"]["w"], bias=B_["se2"]["b"], act=_lib.ACT_SIGMOID)
+            g2 = t.empty((b, c), dtype=bf, device=dev)
+            rc = _lib.MA_ERR_UNSUPPORTED
+            if self.fuse_se:  # both 1 x 1 convolutions of the excitation in one launch
+                rc = lib.ma_se_gate_bf16(mean.data_ptr(), B_["se1"]["w"].data_ptr(), B_["se1"]["b"].data_ptr(), B_["se2"]["w"].data_ptr(),
+                                         B_["se2"]["b"].data_ptr(), g2.data_ptr(), b, c, B_["se1"]["w"].shape[0], s)
+                if rc != _lib.MA_ERR_UNSUPPORTED:
+                    _lib.check(rc, "se_gate")
+            if rc == _lib.MA_ERR_UNSUPPORTED:
+                g1 = ops.gemm(mean, B_["se1"]["w"], bias=B_["se1"]["b"], act=RELU)
+                ops.gemm(g1, B_["se2"]["w"], bias=B_["se2"]["b"], act=_lib.ACT_SIGMOID, out=g2)
             out = cat[:, bi * c:]
             _lib.check(lib.ma_se_apply_bf16(t2.data_ptr(), c, g2.data_ptr(), cur.data_ptr(), cur_ld, out.data_ptr(), 3 * c,
                                             b, T, H, c, s), "se_apply")
@@ -252,4 +261,10 @@ class EcapaTDNN(nn.Module):
             logits = ops.gemm(a1, P["asp_c"]["w"], bias=P["asp_c"]["b"])
             _lib.check(lib.ma_asp_pool_bf16(logits.data_ptr(), 3 * c, xm.data_ptr(), 3 * c, b, T, H, 3 * c, 1e-12,
                                             P["asp_bn"][0].data_ptr(), P["asp_bn"][1].data_ptr(), pooled.data_ptr(), s), "asp_pool")
-        return ops.gemm(pooled, P["fc"]["w"], bias=P["fc"]["b"], out_dtype=t.float32)
+        emb = t.empty((b, P["fc"]["w"].shape[0]), dtype=t.float32, device=dev)
+        rc = lib.ma_linear_small_bf16(pooled.data_ptr(), 6 * c, P["fc"]["w"].data_ptr(), P["fc"]["w"].stride(0), P["fc"]["b"].data_ptr(),
+                                      emb.data_ptr(), emb.stride(0), b, emb.shape[1], 6 * c, s) if self.fuse_se else _lib.MA_ERR_UNSUPPORTED
+        if rc == _lib.MA_ERR_UNSUPPORTED:  # (batch not a multiple of 16, lin_neurons not of 64)
+            return ops.gemm(pooled, P["fc"]["w"], bias=P["fc"]["b"], out_dtype=t.float32, out=emb)
+        _lib.check(rc, "linear_small")
+        return emb

@@ -130,6 +130,23 @@ def test_asp_logits_and_pooling_in_one_launch_equal_the_two_launches(c, b, t):
     assert torch.equal(fused, (setattr(dut, "fuse_asp", True), dut(x))[1])  # deterministic
 
 
+@pytest.mark.parametrize("c,b,t", [(512, 16, 57), (512, 3, 120), (1024, 32, 100)])
+def test_se_excitation_and_embedding_linear_in_single_launches(c, b, t):
+    """ma_se_gate_bf16 (both 1 x 1 convolutions of the SE excitation, ecapatdnn.py:150-156, float32 hidden vector) and
+    ma_linear_small_bf16 (the embedding Linear, ecapatdnn.py:429-431; batch % 16 == 0, else the GEMM launch) against the
+    ma_gemm_bf16 launches on the same weights, and against the oracle."""
+    ref, dut = build(c=c, seed=8)
+    x = torch.randn(b, t, 80, generator=torch.Generator().manual_seed(b + t)).cuda()
+    assert dut.fuse_se
+    fused = dut(x)
+    dut.fuse_se = False
+    plain = dut(x)
+    assert float((fused - plain).abs().max()) <= 2e-2 * float(plain.abs().max())
+    with torch.no_grad():
+        want = ref(x.cpu())
+    assert float((fused.cpu() - want).norm() / want.norm()) < 3e-2
+
+
 def test_res2net_long_utterances_fall_back():
     ref, dut = build(c=512, seed=6)
     x = torch.randn(2, 500, 80)  # T + 2H > 384 rows: the chain runs as separate launches

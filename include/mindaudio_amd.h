@@ -24,10 +24,15 @@
 extern "C" {
 #endif
 
-/* Bumped whenever an existing entry point changes its argument list or is removed (new entry points alone do not bump it).
+/* Bumped whenever an existing entry point changes its argument list, its meaning or the size a caller has to provide, or is removed
+ * (new entry points alone do not bump it).
  * 2: ma_fbank_kaldi_f32 gained `frames_out`; ma_ffn_bf16 / ma_ffn128_bf16 / ma_ffn_ln_bf16 / ma_layernorm*_add_f32 were removed
- *    (round 2).  The Python binding refuses a library of another version (mindaudio_amd/_lib.py). */
-#define MA_ABI_VERSION 2
+ *    (round 2).
+ * 3: ma_ctc_grad_workspace_bytes returns twice the size (alpha and beta side by side, round 4); ma_ffn_train_bf16 accepts ldu == 0
+ *    (no tape: u / h are scratch rows); ma_init is per device ordinal; ma_subsample_fused_pack_bf16 takes the float32 conv1 weight
+ *    (round 5).
+ * The Python binding refuses a library of another version (mindaudio_amd/_lib.py). */
+#define MA_ABI_VERSION 3
 
 typedef void* ma_stream_t; /* hipStream_t */
 
@@ -56,8 +61,8 @@ enum ma_stft_layout {
 int ma_abi_version(void);
 const char* ma_status_string(int status);
 
-/* Process-wide set-up of the library's kernels (the raised dynamic-LDS limit of every kernel that needs one, all in one go).
- * Needs a HIP device; idempotent and thread-safe.  Every launch entry point calls it implicitly, so calling it is optional -
+/* Set-up of the library's kernels on the CURRENT device (the raised dynamic-LDS limit of every kernel that needs one, all in one go;
+ * the runtime keeps the attribute per device, so it is applied once per device ordinal).  Needs a HIP device; idempotent and thread-safe.  Every launch entry point calls it implicitly, so calling it is optional -
  * a host that wants no runtime configuration call after start-up (e.g. before it starts a second stream) calls it once.
  * (The reference has no counterpart: it is pure Python, mindaudio/__init__.py.)  ma_init_kernel_attributes() = how many
  * kernels are registered (a load-time constant; the CPU test checks that the registrations were linked in). */

@@ -9,7 +9,7 @@ import threading
 
 from . import _build
 
-ABI_VERSION = 2  # MA_ABI_VERSION of include/mindaudio_amd.h this binding was written against (2: round-2 signature changes)
+ABI_VERSION = 3  # MA_ABI_VERSION of include/mindaudio_amd.h this binding was written against (3: round-5, see the header)
 MA_OK = 0
 MA_ERR_INVALID_ARG = -1
 MA_ERR_NFFT_TOO_LARGE = -2

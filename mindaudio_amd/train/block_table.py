@@ -73,6 +73,7 @@ class BlockTable:
         self.where = None       # (backward, block) being recorded
         self.seed = None        # the recorded step's dropout seed: every seed argument must be this (or 0: no dropout)
         self.recorded = 0
+        self.broken = None      # why this recording cannot be replayed (the walked step it was taken from is complete all the same)
 
     def __del__(self):
         try:
@@ -121,9 +122,9 @@ class BlockTable:
             if fid != -2 or name.startswith("ma_block_table_") or name.startswith("ma_conformer_block_"):
                 return fn  # size queries, layout helpers, the table's own entry points: nothing to replay
 
-            def refuse(*args):
-                if self.where is not None:
-                    raise _lib.MindaudioAmdError("%s cannot be replayed from a block table" % name)
+            def refuse(*args):  # issued as usual; the table is marked: the engine keeps walking this batch shape
+                if self.where is not None and self.broken is None:
+                    self.broken = "%s cannot be replayed from a block table" % name
                 return fn(*args)
             return refuse
         argtypes = proto[1]
@@ -131,8 +132,11 @@ class BlockTable:
 
         def call(*args):
             rc = fn(*args)
-            if self.where is not None and rc == 0:
-                self._add(name, fid, argtypes, seed_mask, args)
+            if self.where is not None and rc == 0 and self.broken is None:
+                try:
+                    self._add(name, fid, argtypes, seed_mask, args)
+                except _lib.MindaudioAmdError as e:  # (the launch itself is done: only the RECORDING failed)
+                    self.broken = str(e)
             return rc
         return call
 
@@ -163,6 +167,20 @@ class BlockTable:
         _lib.check(self.lib.ma_block_table_add(self.handle, self.where[0], self.where[1], fid, arr, len(words), buf, len(blob)),
                    "block_table_add(%s)" % name)
         self.recorded += 1
+
+    def nbytes(self):
+        """Device bytes this table keeps alive (distinct storages of everything allocated while it was recorded)."""
+        seen, total = set(), 0
+        for x in self.keep:
+            try:
+                st = x.untyped_storage()
+                key, n = st.data_ptr(), st.nbytes()
+            except Exception:
+                continue
+            if key not in seen:
+                seen.add(key)
+                total += n
+        return total
 
     # ---- replay ------------------------------------------------------------------------------------------------------------------
     def calls(self, backward, block):

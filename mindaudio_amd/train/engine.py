@@ -294,6 +294,10 @@ class ConformerCTCTrainStep:
         # (ma_conformer_block_fwd_train / _bwd_train) from the argument table filled while the second step was walked from Python -
         # same calls, same buffers, same order; 4.2 -> ~1.5 ms of host time per step (train/block_table.py, csrc/block_table.hip)
         self.block_tables = self.fused and self._dw_direct
+        self.block_table_min_sightings = 2        # a shape is recorded at its n-th step (>= 2), replayed from the next one on
+        self.block_table_max_bytes = 48 << 30     # device bytes all recorded tables together may pin (oldest dropped first)
+        self.block_table_max_blocks = 64          # kMaxBlocks of csrc/block_table.hip: encoder blocks + decoder layers + 3 segments
+        self._table_bytes, self._table_warned, self._recording_tb, self._walk_shapes = {}, set(), None, set()
         if self._wg_on and not self._dw_direct and not self._wg_split_ok:
             raise ValueError("the two-queue reproducer needs the direct weight-gradient groups (dw_group_blocks > 0, d_model and hidden "
                              "multiples of 256) unless split_k_sums_on_second_stream is set as well (DESIGN 4.6.3)")
@@ -722,10 +726,10 @@ class ConformerCTCTrainStep:
                            torch.tensor(block_item, dtype=torch.int32, device=self.dev), first))
         self._dw_plan = dict(m=m, t2=self._t2_cur, arena=arena, off=off, layers=layers, half=half)
         for k in [k for k, v in plans.items() if v["arena"] is not arena]:
-            del plans[k]  # (the arena grew: the older plans' tables name the old one)
+            self._forget_plan(plans.pop(k))  # (the arena grew: the older plans' tables name the old one)
         plans[(m, self._t2_cur)] = self._dw_plan
         while len(plans) > self._DW_PLANS_KEPT:
-            del plans[next(iter(plans))]
+            self._forget_plan(plans.pop(next(iter(plans))))
         if self.fused:
             o, nb, _ = off["att_ws"]
             self._dw_plan["att_ws"] = (arena[o:o + nb], arena[half + o:half + o + nb])
@@ -783,10 +787,24 @@ class ConformerCTCTrainStep:
         tb = plan["table"] = tables.get(key)  # (plan["table"]: the one in use, for tests and tools)
         if tb is None:
             while len(tables) >= 2:  # (e.g. the padding-mask and the chunk-mask form of one shape)
-                del tables[next(iter(tables))]
-            tb = plan["table"] = tables[key] = dict(key=key, state="seen")  # this step warms the wrappers' pooled buffers; the next
-            return None                                                     # one is recorded
+                self._drop_table(tables, next(iter(tables)))
+            tb = plan["table"] = tables[key] = dict(key=key, state="seen", sightings=0)
+        if key[:3] in self._walk_shapes:
+            tb["state"] = "walk"
+        if tb["state"] == "walk":  # a shape the table cannot cover (or could not be recorded for): walked from Python for good
+            return None
         if tb["state"] == "seen":
+            # the first step(s) of a shape warm the wrappers' pooled buffers and tell a recurring shape from a one-off (a loader that pads
+            # to the batch maximum produces many shapes that never come back: recording each would pin 2-4 GB apiece)
+            tb["sightings"] += 1
+            if tb["sightings"] < max(2, int(self.block_table_min_sightings)):
+                return None
+            blocks = self.L + self.Ld + 3
+            if blocks > int(self.block_table_max_blocks):
+                self._table_warn("block tables: %d launch segments > the table's %d: this configuration is walked from Python"
+                                 % (blocks, self.block_table_max_blocks))
+                tb["state"] = "walk"
+                return None
             from .block_table import BlockTable
 
             m, d, f32, bf = b * t2, self.d, torch.float32, torch.bfloat16
@@ -796,7 +814,60 @@ class ConformerCTCTrainStep:
                       att_mask=torch.empty(att_shape, dtype=f32, device=self.dev),
                       pos_all=torch.empty((t2, self.L * d), dtype=bf, device=self.dev),
                       g=torch.empty((m, d), dtype=f32, device=self.dev))
+            self._recording_tb = (tables, key)
+            self._bn_snapshot = [(m_.clone(), v_.clone()) for m_, v_ in zip(self.bn_mean, self.bn_var)]
         return tb
+
+    def _forget_plan(self, plan):
+        for tb in plan.get("tables", {}).values():  # (the byte ledger must not keep a dropped plan's tables - and their buffers - alive)
+            self._table_bytes.pop(id(tb), None)
+            tb.clear()
+
+    def _table_warn(self, msg):
+        if msg not in self._table_warned:
+            self._table_warned.add(msg)
+            import warnings
+
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+    def _drop_table(self, tables, key):
+        tb = tables.pop(key, None)
+        if tb is not None:
+            self._table_bytes.pop(id(tb), None)
+            tb.clear()
+
+    def _table_recorded(self, tb):
+        """End of a recorded step: the table replays from the next step on - unless the recorder met a call it cannot replay (then the
+        shape is walked for good), and within the byte budget of all tables kept (oldest dropped first)."""
+        table = tb["table"]
+        self._recording_tb = None
+        if table.broken is not None:
+            self._table_warn("block tables: %s - this batch shape is walked from Python" % table.broken)
+            for k in [k for k in tb if k not in ("key", "sightings")]:
+                del tb[k]
+            tb["state"] = "walk"
+            return
+        tb["state"] = "replay"
+        self._table_bytes[id(tb)] = (table.nbytes(), tb)
+        budget = int(self.block_table_max_bytes)
+        while sum(n for n, _ in self._table_bytes.values()) > budget and len(self._table_bytes) > 1:
+            oldest = next(iter(self._table_bytes))
+            if oldest == id(tb):
+                break
+            _, old = self._table_bytes.pop(oldest)
+            for plan in self._dw_plans.values() if hasattr(self, "_dw_plans") else ():
+                tabs = plan.get("tables", {})
+                for k in [k for k, v in tabs.items() if v is old]:
+                    del tabs[k]
+            old.clear()
+
+    def drop_block_tables(self):
+        """Forget every recorded launch table (and the buffers they pin); the next steps of every shape are walked and re-recorded."""
+        for plan in self._dw_plans.values() if hasattr(self, "_dw_plans") else ():
+            plan.pop("tables", None)
+            plan.pop("table", None)
+        self._table_bytes.clear()
+        self._recording_tb = None
 
     def _chain_final(self):
         """norm_final's backward as the second stage of the block above's macaron backward launch (needs the one-launch forms)."""
@@ -855,9 +926,31 @@ class ConformerCTCTrainStep:
                          ys_out_pad=None, ys_sub_masks=None, ys_masks=None):
         """Runs the training-mode forward and the backward pass; flat gradients hold grad_scale * dLoss/dparam.
         Returns the (unscaled) loss tensor."""
+        args = (xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale, ys_in_pad, ys_out_pad, ys_sub_masks, ys_masks)
+        # A step that RECORDS a block launch table pins every buffer it allocates (2-4 GB per shape).  If that is what runs the device
+        # out of memory: drop every table, give the memory back, walk this shape from Python for good and run the step again - with the
+        # BatchNorm running statistics of before the attempt (the only state a forward pass changes besides the gradients).
+        # (snapshot taken by _block_table_for when a shape enters its recording step)
         with _host.pinned_stream():
-            return self._forward_backward(xs_pad, ys_pad, xs_masks, ys_lengths, xs_chunk_masks, grad_scale, ys_in_pad, ys_out_pad,
-                                          ys_sub_masks, ys_masks)
+            try:
+                return self._forward_backward(*args)
+            except torch.OutOfMemoryError:
+                rec = self._recording_tb
+                if rec is None:
+                    raise
+                _lib.set_recording(None)
+                tables, key = rec
+                self.drop_block_tables()
+                self._dq = self._dq_dec = None
+                self._dq_blocks.clear()
+                torch.cuda.synchronize(self.dev)
+                torch.cuda.empty_cache()
+                for (m0, v0), m, v in zip(self._bn_snapshot, self.bn_mean, self.bn_var):
+                    m.copy_(m0)
+                    v.copy_(v0)
+                self._table_warn("block tables: out of memory while recording a batch shape - tables dropped, the shape is walked from Python")
+                self._walk_shapes.add(key[:3])
+                return self._forward_backward(*args)
 
     def _encoder_forward(self, xs, xs_masks, xs_chunk_masks, seed, tables=True):
         """The encoder's training-mode forward (models/conformer.py:229-258 with self.training: dropout with the step's seed, BatchNorm
@@ -1224,7 +1317,7 @@ class ConformerCTCTrainStep:
         if tb is not None:
             with tb["table"].recording(seed):
                 self._blocks_backward_walk(g, tape, dpos_all, c, tb["table"])
-            tb["state"] = "replay"
+            self._table_recorded(tb)
             return
         self._blocks_backward_walk(g, tape, dpos_all, c, None)
 

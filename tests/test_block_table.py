@@ -120,19 +120,44 @@ def test_recording_is_per_thread():
     assert seen == {"recorder": "_RecordingLib", "other": "CDLL", "after": "CDLL"}
 
 
-def test_a_launch_the_table_cannot_reissue_is_refused_inside_a_block():
+def test_a_launch_the_table_cannot_reissue_marks_the_table_and_is_still_issued():
+    """A call the table cannot replay inside a block does not stop the walked step it is met in (the step is complete and correct
+    all the same): the launch is issued, the table is marked `broken`, records nothing further, and the engine walks that batch
+    shape from then on (ConformerCTCTrainStep._table_recorded)."""
     from mindaudio_amd.train.block_table import BlockTable
 
     tab = BlockTable()
     with tab.recording(1):
         lib = _lib.load()
         tab.segment(False, 0)
-        with pytest.raises(_lib.MindaudioAmdError):
-            lib.ma_fft_pow2_c32(None, None, 0, 0, 0, None, None)
+        assert tab.broken is None
+        rc = lib.ma_fft_pow2_c32(None, None, 0, 0, 0, None, None)  # issued: the library itself answers (invalid arguments)
+        assert rc == _lib.MA_ERR_INVALID_ARG and tab.broken is not None and "ma_fft_pow2_c32" in tab.broken
         # size queries pass through, recorded or not
         assert lib.ma_gemm_tn_workspace_bytes(256, 256, 1024) > 0
         tab.segment(None, 0)
     assert tab.calls(False, 0) == 0
+
+
+def test_a_seed_mismatch_while_recording_marks_the_table_instead_of_raising():
+    from mindaudio_amd.train.block_table import BlockTable
+
+    tab = BlockTable()
+    calls = []
+    with tab.recording(5):
+        tab.segment(True, 0)
+        name = next(n for n in _lib.PROTOTYPES if tab.lib.ma_block_table_entry_point(n.encode()) >= 0
+                    and tab.lib.ma_block_table_entry_point_seeds(tab.lib.ma_block_table_entry_point(n.encode())))
+        fid = tab.lib.ma_block_table_entry_point(name.encode())
+        mask = tab.lib.ma_block_table_entry_point_seeds(fid)
+        argtypes = _lib.PROTOTYPES[name][1]
+        args = [None if t is __import__("ctypes").c_void_p else 0 for t in argtypes]
+        k = next(i for i in range(len(argtypes)) if (mask >> i) & 1)
+        args[k] = 6  # a seed that is not the step's
+        wrapped = tab._wrap(name, lambda *a: calls.append(a) or 0)
+        assert wrapped(*args) == 0 and len(calls) == 1  # issued
+        assert tab.broken is not None and "seed" in tab.broken and tab.recorded == 0
+        tab.segment(None, 0)
 
 
 @pytest.mark.parametrize("blocks,group", [(12, 6), (12, 5), (2, 6), (7, 3), (1, 1)])

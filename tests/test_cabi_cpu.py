@@ -41,7 +41,7 @@ def test_header_symbols_exported_and_bound(lib):
 def test_host_only_entry_points(lib):
     from mindaudio_amd import _lib
 
-    assert lib.ma_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.ma_abi_version() == _lib.ABI_VERSION == 3
     assert lib.ma_num_frames(95984, 512, 128, 1) == 750  # tutorial shape (257, 750)
     assert lib.ma_num_frames(160000, 512, 160, 1) == 1001
     assert lib.ma_num_frames(160000, 512, 160, 0) == 997

@@ -38,18 +38,18 @@ def build(vocab=97, blocks=2, seed=5, cmvn=True):
     return ref_enc.train(), ref_ctc.train(), model.cuda()
 
 
-def batch(b=3, tlen=131, vocab=97, seed=9):
+def batch(b=3, tlen=131, vocab=97, seed=9, shorter=(0, 30, 61), ylens=(9, 6, 4)):
     from oracle import conformer_oracle as C
 
     g = torch.Generator().manual_seed(seed)
     xs = torch.randn(b, tlen, 80, generator=g)
-    lens = [tlen, tlen - 30, tlen - 61][:b]
+    lens = [tlen - d for d in shorter][:b]
     mask = torch.zeros(b, 1, tlen)
     for i, n in enumerate(lens):
         mask[i, 0, :n] = 1
         xs[i, n:] = 0
     sub = C.subsample_mask(mask)
-    ys_lens = torch.tensor([9, 6, 4][:b], dtype=torch.int32)
+    ys_lens = torch.tensor(list(ylens)[:b], dtype=torch.int32)
     ys = torch.full((b, 9), -1, dtype=torch.int32)
     for i, n in enumerate(ys_lens.tolist()):
         ys[i, :n] = torch.randint(1, vocab, (n,), generator=g, dtype=torch.int32)
@@ -269,9 +269,13 @@ def test_hybrid_ctc_attention_loss_and_gradients_match_oracle(len_norm):
     missing, unexpected = model.decoder.load_state_dict(ref_dec.state_dict(), strict=False)
     assert not missing and not unexpected
     model = model.cuda()
-    xs, ys, sub, ys_lens = batch(vocab=vocab - 1, seed=12)
+    return ref_enc, ref_ctc, ref_dec, model.cuda(), _hybrid_cols(vocab - 1, batch(vocab=vocab - 1, seed=12))
+
+
+def _hybrid_cols(eos, b4):
+    xs, ys, sub, ys_lens = b4
     b, lmax = ys.shape[0], 9
-    sos = eos = vocab - 1
+    sos = eos
     ys_in = torch.full((b, lmax + 1), eos, dtype=torch.int32)
     ys_out = torch.full((b, lmax + 1), -1, dtype=torch.int32)
     ys_masks = torch.zeros(b, 1, lmax + 1)
@@ -437,15 +441,21 @@ def test_blocks_issued_from_the_launch_table_change_no_bit():
     (the table follows the shape's plan and the mask's shape)."""
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 
-    xs, ys, sub, ys_lens = batch()
-    cols = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
-    t_short = xs.shape[1] - 16
-    sub_s = sub[:, :, :((t_short - 3) // 2 + 1 - 3) // 2 + 1].contiguous()
-    cols_s = (xs[:, :t_short].contiguous().cuda(), ys.cuda(), None, None, None, None, sub_s.cuda(), None, None, ys_lens.cuda(), None)
-    t2 = sub.shape[-1]
-    idx = torch.arange(t2)
-    chunk = ((idx[None, :] // 8) <= (idx[:, None] // 8)) & ((idx[None, :] // 8) >= (idx[:, None] // 8) - 2)
-    cols_c = cols[:10] + ((chunk[None] & (sub > 0)).float().cuda(),)  # the streaming configuration's masks (utils/mask.py:201-271)
+    # A DIFFERENT batch of the same shape at every step (features, pad lengths, labels, label lengths, and the chunk size of the
+    # streaming masks): a value derived from the masks or labels by an op the table does not re-issue would be stale on replay - with
+    # one repeated batch the stale value would equal the fresh one and the comparison could not see it.
+    def cols_of(k, form):
+        xs, ys, sub, ys_lens = batch(seed=9 + k, shorter=(0, 30 - 2 * k, 61 + k), ylens=(9, 6 - k % 3, 4 + k % 4))
+        if form == "short":
+            t_short = xs.shape[1] - 16
+            xs = xs[:, :t_short].contiguous()
+            sub = sub[:, :, :((t_short - 3) // 2 + 1 - 3) // 2 + 1].contiguous()
+        c = (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
+        if form == "chunk":
+            idx, cs = torch.arange(sub.shape[-1]), 8 - k % 3
+            chunk = ((idx[None, :] // cs) <= (idx[:, None] // cs)) & ((idx[None, :] // cs) >= (idx[:, None] // cs) - 2)
+            c = c[:10] + ((chunk[None] & (sub > 0)).float().cuda(),)  # the streaming configuration's masks (utils/mask.py:201-271)
+        return c
     out = []
     for tables in (False, True):
         _, _, model = build(seed=9)
@@ -454,7 +464,7 @@ def test_blocks_issued_from_the_launch_table_change_no_bit():
         eng.block_tables = tables
         losses, states = [], []
         for k in range(12):
-            losses.append(float(eng.step(*(cols_s if k in (3, 4, 5) else cols_c if k >= 9 else cols))[0]))
+            losses.append(float(eng.step(*cols_of(k, "short" if k in (3, 4, 5) else "chunk" if k >= 9 else "plain"))[0]))
             tb = eng._dw_plan.get("table")
             states.append(None if tb is None else tb["state"])
         torch.cuda.synchronize()
@@ -485,7 +495,6 @@ def test_hybrid_step_from_the_launch_table_changes_no_bit():
     for tables in (False, True):
         _, _, _, model, cols = _hybrid_setup(blocks=2, dblocks=2)
         model.decoder.dropout_rate, model.decoder.positional_dropout_rate = 0.1, 0.1
-        cols = tuple(c.cuda() if c is not None else None for c in cols)
         eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1)
         assert eng.block_tables and eng.dec is not None and float(eng.dec.dropout_rate) == 0.1
         eng.block_tables = tables
@@ -493,7 +502,9 @@ def test_hybrid_step_from_the_launch_table_changes_no_bit():
         for k in range(7):
             if k == 4:
                 eng.scaler.scale = 256.0
-            losses.append(float(eng.step(*cols)[0]))
+            # (another batch of the same shape every step: see test_blocks_issued_from_the_launch_table_change_no_bit)
+            step_cols = _hybrid_cols(96, batch(vocab=96, seed=12 + k, shorter=(0, 30 - k, 61 + 2 * k), ylens=(9, 6 - k % 2, 4 + k % 3)))
+            losses.append(float(eng.step(*(c.cuda() if c is not None else None for c in step_cols))[0]))
         torch.cuda.synchronize()
         if tables:
             tb = eng._dw_plan["table"]
@@ -580,9 +591,13 @@ def _hybrid_setup(seed=31, vocab=97, blocks=1, dblocks=2):
     model.encoder.load_state_dict(ref_enc.state_dict(), strict=False)
     model.ctc.load_state_dict(ref_ctc.state_dict())
     model.decoder.load_state_dict(ref_dec.state_dict(), strict=False)
-    xs, ys, sub, ys_lens = batch(vocab=vocab - 1, seed=12)
+    return ref_enc, ref_ctc, ref_dec, model.cuda(), _hybrid_cols(vocab - 1, batch(vocab=vocab - 1, seed=12))
+
+
+def _hybrid_cols(eos, b4):
+    xs, ys, sub, ys_lens = b4
     b, lmax = ys.shape[0], 9
-    sos = eos = vocab - 1
+    sos = eos
     ys_in = torch.full((b, lmax + 1), eos, dtype=torch.int32)
     ys_out = torch.full((b, lmax + 1), -1, dtype=torch.int32)
     ys_masks = torch.zeros(b, 1, lmax + 1)
@@ -593,8 +608,7 @@ def _hybrid_setup(seed=31, vocab=97, blocks=1, dblocks=2):
         ys_out[i, n] = eos
         ys_masks[i, 0, :n + 1] = 1
     ys_sub = (ys_masks.bool() & torch.tril(torch.ones(lmax + 1, lmax + 1, dtype=torch.bool))[None]).float()
-    cols = (xs, ys, ys_in, ys_out, None, None, sub, ys_sub, ys_masks, ys_lens, None)
-    return ref_enc, ref_ctc, ref_dec, model.cuda(), cols
+    return (xs, ys, ys_in, ys_out, None, None, sub, ys_sub, ys_masks, ys_lens, None)
 
 
 def test_hybrid_loss_curve_in_float32_mode_matches_the_oracle():

@@ -275,10 +275,16 @@ class ConformerEncoder(nn.Module):
             # x = norm_final(x + 0.5 FFN(norm_ff(x)))                                             :147-156
             if li + 1 < n_layers:  # ... and the next block's macaron FFN + norm_mha + linear_q/k/v on the same rows
                 ln, Wn = self.encoders[li + 1], P["layers"][li + 1]
+                ev = self.__dict__.get("_pair_events")  # (bench.py: the launch timed IN the step, one event pair per launch)
+                if ev is not None:
+                    ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                    ev[-1][0].record()
                 qkv = ops.ffn_packed_pair(W["ff_pk"], W["ff_b1"], W["ff_b2"], Wn["ffm_pk"], Wn["ffm_b1"], Wn["ffm_b2"], x,
                                           (l.norm_ff.gamma, l.norm_ff.beta), (l.norm_final.gamma, l.norm_final.beta),
                                           (ln.norm_ff_macaron.gamma, ln.norm_ff_macaron.beta),
                                           (ln.norm_mha.gamma, ln.norm_mha.beta), qkv=(Wn["qkv_fpk"], Wn["qkv_b"]))
+                if ev is not None:
+                    ev[-1][1].record()
             else:                  # ... and after_norm (:253)
                 x = ops.ffn_packed(None, W["ff_pk"], W["ff_b1"], W["ff_b2"], x, l.norm_final.gamma, l.norm_final.beta,
                                    self.after_norm.gamma, self.after_norm.beta, out_dtype=torch.float32,

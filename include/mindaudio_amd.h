@@ -30,7 +30,7 @@ extern "C" {
  *    (round 2).
  * 3: ma_ctc_grad_workspace_bytes returns twice the size (alpha and beta side by side, round 4); ma_ffn_train_bf16 accepts ldu == 0
  *    (no tape: u / h are scratch rows); ma_init is per device ordinal; ma_subsample_fused_pack_bf16 takes the float32 conv1 weight
- *    (round 5).
+ *    (round 5); ma_attn_out_convmodule_bf16 writes x_out instead of updating x in place (round 5).
  * The Python binding refuses a library of another version (mindaudio_amd/_lib.py). */
 #define MA_ABI_VERSION 3
 
@@ -877,14 +877,16 @@ int ma_convmodule_bf16(const void* a, int64_t lda, int64_t batch, int64_t T, int
 
 /* ma_convmodule_bf16 with the attention output projection, its residual and norm_conv in front (layers/attention.py:56 linear_out,
  * models/conformer.py:135-141): per 32-frame tile
- *   x' = x + ctx . Wo^T + wo_bias;   a = LN(x'; ln_gamma, ln_beta) * mask;   x <- x' + mask * ConvModule(a)
+ *   x' = x + ctx . Wo^T + wo_bias;   a = LN(x'; ln_gamma, ln_beta) * mask;   x_out <- x' + mask * ConvModule(a)
  * ctx (batch*T, 256) bf16 attention context; wo_packed = ma_gemm_k256_pack_bf16 of the (256, 256) linear_out weight.  x is read
- * and written once; x' and a never leave the CU (the halo frames of a tile recompute the projection). */
+ * and x_out written once; x' and a never leave the CU (the halo frames of a tile recompute the projection - from the residual rows
+ * of the neighbouring tiles, which is why x_out must not overlap x: MA_ERR_INVALID_ARG.  Until ABI 3 the update was in place and
+ * correct only while every workgroup of the launch was resident at the same time). */
 int ma_attn_out_convmodule_bf16(const void* ctx, int64_t ldc, const void* wo_packed, const float* wo_bias, const float* ln_gamma,
                                 const float* ln_beta, float ln_eps, int64_t batch, int64_t T, int32_t C, const void* pw1_packed,
                                 const float* pw1_bias, const float* dw, int32_t kernel_size, const float* bn_scale,
-                                const float* bn_shift, const void* pw2_packed, const float* pw2_bias, const float* mask, float* x,
-                                int64_t ldx, ma_stream_t stream);
+                                const float* bn_shift, const void* pw2_packed, const float* pw2_bias, const float* mask, const float* x,
+                                float* x_out, int64_t ldx, ma_stream_t stream);
 
 /* Dense / k=1 Conv1d with K = 256 inputs (linear_q/k/v/out: layers/attention.py:51-56; pointwise_conv1/2:
  * layers/convolution.py:52-78) on a fragment-ordered packed copy of W (gemm_k256.hip): same result as ma_gemm_bf16.

@@ -288,7 +288,7 @@ PROTOTYPES = {
     "ma_convmid_pw2_bf16": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
     "ma_convmodule_bf16": (ctypes.c_int, [vp, i64, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
     "ma_attn_out_convmodule_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, f32, i64, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp,
-                                                   vp, i64, vp]),
+                                                   vp, vp, i64, vp]),
     "ma_gemm_k256_packed_bytes": (i64, [i64, i64]),
     "ma_gemm_k256_pack_bf16": (ctypes.c_int, [vp, i64, i64, i64, vp, vp]),
     "ma_gemm_k256_packed_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp]),

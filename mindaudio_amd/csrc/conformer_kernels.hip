@@ -226,45 +226,53 @@ __global__ __launch_bounds__(256) void subsample_conv1_c256_kernel(const float* 
     }
   }
   const int c0 = 8 * (tid & 31), fg = tid >> 5;
-  f32x2_t wv[4][9];
+  // Plain v_fma_f32 on purpose.  Until round 5 the 8 channels were 4 float2 accumulators (v_pk_fma_f32): hipcc broadcast the second
+  // element of an LDS-loaded pair with op_sel and let the last accumulate of a position overwrite that pair -
+  //     v_pk_fma_f32 v[88:89], v[76:77], v[88:89], v[106:107] op_sel:[0,1,0]
+  // - a form gfx950 executes wrongly when MFMA-issuing waves of ANOTHER kernel share the SIMD (the low results of lanes 48-63 use the
+  // already written high result): exact alone, ~1e-4 of this kernel's outputs off by one tap beside another stream's FFN / attention
+  // launches (tools/ubench/two_queue_pk.hip reproduces it stand-alone; tools/check_pk_hazard.py keeps the form out of the library).
+  // Packed fp32 issues at half rate on this chip anyway (tools/ubench/valu_rate.hip): the scalar form costs nothing measurable.
+  float wv[8][9];
   {
-    float wf[72];
     const float4* wp = reinterpret_cast<const float4*>(w + c0 * 9);
+    float wf[72];
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
       const float4 q = wp[i];
       wf[4 * i] = q.x, wf[4 * i + 1] = q.y, wf[4 * i + 2] = q.z, wf[4 * i + 3] = q.w;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) wv[j][k] = f32x2_t{wf[(2 * j) * 9 + k], wf[(2 * j + 1) * 9 + k]};
+      for (int k = 0; k < 9; ++k) wv[j][k] = wf[j * 9 + k];
   }
-  f32x2_t bv[4];
+  float bv[8];
   {
     const float4 q0 = *reinterpret_cast<const float4*>(bias + c0), q1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
-    bv[0] = f32x2_t{q0.x, q0.y}, bv[1] = f32x2_t{q0.z, q0.w}, bv[2] = f32x2_t{q1.x, q1.y}, bv[3] = f32x2_t{q1.z, q1.w};
+    bv[0] = q0.x, bv[1] = q0.y, bv[2] = q0.z, bv[3] = q0.w, bv[4] = q1.x, bv[5] = q1.y, bv[6] = q1.z, bv[7] = q1.w;
   }
   __syncthreads();
   for (int r = 0; r < nrow; ++r) {
     uint16_t* o = out + ((b * T1 + t1_0 + r) * F1) * 256 + c0;
     const float* in = rows + 2 * r * idim;
     for (int f1 = fg; f1 < F1; f1 += 8) {
-      f32x2_t acc[4] = {bv[0], bv[1], bv[2], bv[3]};
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = bv[j];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const float xv = in[kh * idim + 2 * f1 + kw];
-          const f32x2_t xx{xv, xv};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = __builtin_elementwise_fma(wv[j][kh * 3 + kw], xx, acc[j]);
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv[j][kh * 3 + kw], xv, acc[j]);
         }
       uint4 pk;
-      pk.x = pack2_bf16(fmaxf(acc[0].x, 0.0f), fmaxf(acc[0].y, 0.0f));
-      pk.y = pack2_bf16(fmaxf(acc[1].x, 0.0f), fmaxf(acc[1].y, 0.0f));
-      pk.z = pack2_bf16(fmaxf(acc[2].x, 0.0f), fmaxf(acc[2].y, 0.0f));
-      pk.w = pack2_bf16(fmaxf(acc[3].x, 0.0f), fmaxf(acc[3].y, 0.0f));
+      pk.x = pack2_bf16(fmaxf(acc[0], 0.0f), fmaxf(acc[1], 0.0f));
+      pk.y = pack2_bf16(fmaxf(acc[2], 0.0f), fmaxf(acc[3], 0.0f));
+      pk.z = pack2_bf16(fmaxf(acc[4], 0.0f), fmaxf(acc[5], 0.0f));
+      pk.w = pack2_bf16(fmaxf(acc[6], 0.0f), fmaxf(acc[7], 0.0f));
       *reinterpret_cast<uint4*>(o + (int64_t)f1 * 256) = pk;
     }
   }

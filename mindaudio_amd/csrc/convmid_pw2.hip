@@ -224,6 +224,8 @@ struct ConvModParams {
   const float* bias;
   const float* mask;
   float* x;
+  float* xo;           // where the updated rows go: x itself (plain form: a row is read and written by its own tile only) or ANOTHER
+                       // buffer (OPROJ form: a tile reads the residual rows of its halo frames, which its neighbours update)
   int64_t ldx;
   int32_t T, KS;
   // OPROJ
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void convmodule_kernel(const ConvModParams 
     for (int jt = 0; jt < 4; ++jt) {
       const int n = 64 * wave + 16 * jt + 4 * g;
       const float4 bv = bv2[jt];
-      float4* xp = reinterpret_cast<float4*>(p.x + m * p.ldx + n);
+      float4* xp = reinterpret_cast<float4*>(p.xo + m * p.ldx + n);
       float4 xv = xres[s][jt];
       xv.x += (acc2[jt][s][0] + bv.x) * rs;
       xv.y += (acc2[jt][s][1] + bv.y) * rs;
@@ -747,6 +749,7 @@ static int convmodule_args(ConvModParams& p, int64_t batch, int64_t T, int32_t C
   p.bias = pw2_bias;
   p.mask = mask;
   p.x = x;
+  p.xo = x;
   p.ldx = ldx;
   p.T = (int32_t)T;
   p.KS = kernel_size;
@@ -776,12 +779,23 @@ extern "C" int ma_attn_out_convmodule_bf16(const void* ctx, int64_t ldc, const v
                                            const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t batch, int64_t T,
                                            int32_t C, const void* pw1_packed, const float* pw1_bias, const float* dw,
                                            int32_t kernel_size, const float* bn_scale, const float* bn_shift,
-                                           const void* pw2_packed, const float* pw2_bias, const float* mask, float* x, int64_t ldx,
-                                           ma_stream_t stream) {
+                                           const void* pw2_packed, const float* pw2_bias, const float* mask, const float* x,
+                                           float* x_out, int64_t ldx, ma_stream_t stream) {
   ConvModParams p;
   const int rc = convmodule_args(p, batch, T, C, pw1_packed, pw1_bias, dw, kernel_size, bn_scale, bn_shift, pw2_packed, pw2_bias,
-                                 mask, x, ldx);
+                                 mask, const_cast<float*>(x), ldx);
   if (rc != MA_OK) return rc;
+  // NOT in place: a tile reads the residual rows of its 14 halo frames, and those rows are its neighbours' output.  In place the result
+  // depends on every workgroup of the grid having read before any has finished - true only while the whole grid is resident at once
+  // (it stops being true beside another stream's kernels, or with more tiles than the chip holds: found in round 5).
+  if (!x_out || reinterpret_cast<uintptr_t>(x_out) & 15) return MA_ERR_INVALID_ARG;
+  {
+    const char* lo = reinterpret_cast<const char*>(x);
+    const char* olo = reinterpret_cast<const char*>(x_out);
+    const int64_t span = (batch * T - 1) * ldx * 4 + (int64_t)C * 4;
+    if (olo < lo + span && lo < olo + span) return MA_ERR_INVALID_ARG;
+  }
+  p.xo = x_out;
   if (!ctx || !wo_packed || !wo_bias || !ln_gamma || !ln_beta || (ldc & 7) || ldc < kCpC) return MA_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(wo_packed) | reinterpret_cast<uintptr_t>(wo_bias) |
        reinterpret_cast<uintptr_t>(ln_gamma) | reinterpret_cast<uintptr_t>(ln_beta)) & 15)

@@ -263,6 +263,7 @@ class ConformerEncoder(nn.Module):
         + ConvolutionModule] (models/conformer.py:100-161); needs the packed weights of prepare()."""
         n_layers = len(self.encoders)
         l0, W0 = self.encoders[0], P["layers"][0]
+        x_alt = torch.empty_like(x)
         # x += 0.5 FFN_macaron(norm_ff_macaron(x)); qkv = linear_q/k/v(norm_mha(x))              :109-119
         qkv = ops.ffn_packed_qkv(None, W0["ffm_pk"], W0["ffm_b1"], W0["ffm_b2"], x, l0.norm_mha.gamma, l0.norm_mha.beta,
                                  W0["qkv_fpk"], W0["qkv_b"], ln_in=(l0.norm_ff_macaron.gamma, l0.norm_ff_macaron.beta))
@@ -270,8 +271,10 @@ class ConformerEncoder(nn.Module):
             ctx = ops.relpos_attention(qkv, pos_all[:, li * self.d:(li + 1) * self.d], W["u"], W["v"], att_mask, b, t2,
                                        self.heads, self.d // self.heads)
             # x += linear_out(ctx); x += ConvModule(norm_conv(x), mask_pad)                      :121-143, convolution.py:83-129
-            ops.attn_out_convmodule(ctx, W["o_pk"], W["o_b"], l.norm_conv.gamma, l.norm_conv.beta, W["pw1_pk"], W["pw1_b"],
-                                    W["dw_w"], W["bn_scale"], W["bn_shift"], W["pw2_pk"], W["pw2_b"], mask_rows, x, b, t2)
+            # (out of place, the two residual buffers alternate: a tile reads its neighbours' residual rows)
+            x, x_alt = ops.attn_out_convmodule(ctx, W["o_pk"], W["o_b"], l.norm_conv.gamma, l.norm_conv.beta, W["pw1_pk"], W["pw1_b"],
+                                               W["dw_w"], W["bn_scale"], W["bn_shift"], W["pw2_pk"], W["pw2_b"], mask_rows, x, b, t2,
+                                               out=x_alt), x
             # x = norm_final(x + 0.5 FFN(norm_ff(x)))                                             :147-156
             if li + 1 < n_layers:  # ... and the next block's macaron FFN + norm_mha + linear_q/k/v on the same rows
                 ln, Wn = self.encoders[li + 1], P["layers"][li + 1]

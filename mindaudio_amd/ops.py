@@ -430,20 +430,24 @@ def convmodule(a, pw1_packed, pw1_bias, dw, bn_scale, bn_shift, pw2_packed, pw2_
 
 
 def attn_out_convmodule(ctx, wo_packed, wo_bias, ln_gamma, ln_beta, pw1_packed, pw1_bias, dw, bn_scale, bn_shift, pw2_packed,
-                        pw2_bias, mask_rows, x, batch, T, eps=1e-5):
-    """In place x <- x' + mask * ConvModule(LN(x') * mask) with x' = x + ctx @ Wo^T + wo_bias: the attention output projection,
-    norm_conv and the whole ConvolutionModule in one launch.  ctx (B*T, 256) bf16."""
+                        pw2_bias, mask_rows, x, batch, T, eps=1e-5, out=None):
+    """out <- x' + mask * ConvModule(LN(x') * mask) with x' = x + ctx @ Wo^T + wo_bias: the attention output projection,
+    norm_conv and the whole ConvolutionModule in one launch.  ctx (B*T, 256) bf16.  `out` is another buffer of x's shape (a new one
+    if None), never x itself: a tile reads its neighbours' residual rows (see include/mindaudio_amd.h)."""
     t = _host.torch()
     lib = _lib.load()
     c, ks = dw.shape
     assert ctx.dtype == t.bfloat16 and ctx.shape[1] == c and ctx.stride(1) == 1 and x.dtype == t.float32 and x.stride(1) == 1
+    if out is None:
+        out = t.empty_like(x)
+    assert out.dtype == t.float32 and out.shape == x.shape and out.stride() == x.stride()
     rc = lib.ma_attn_out_convmodule_bf16(_host.ptr(ctx), ctx.stride(0), _host.ptr(wo_packed), _host.ptr(wo_bias),
                                          _host.ptr(ln_gamma), _host.ptr(ln_beta), float(eps), batch, T, c, _host.ptr(pw1_packed),
                                          _host.ptr(pw1_bias), _host.ptr(dw), ks, _host.ptr(bn_scale), _host.ptr(bn_shift),
-                                         _host.ptr(pw2_packed), _host.ptr(pw2_bias), _opt(mask_rows), _host.ptr(x), x.stride(0),
-                                         _host.current_stream_ptr())
+                                         _host.ptr(pw2_packed), _host.ptr(pw2_bias), _opt(mask_rows), _host.ptr(x), _host.ptr(out),
+                                         x.stride(0), _host.current_stream_ptr())
     _lib.check(rc, "attn_out_convmodule")
-    return x
+    return out
 
 
 def cast_bf16(x):

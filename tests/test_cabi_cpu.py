@@ -88,3 +88,20 @@ def test_host_tables_match_oracle():
     assert np.array_equal(_host.kaldi_banks_f64(80, 512, 16000.0, 20, 8000), O.kaldi_mel_banks(80, 512, 16000.0, 20, 8000)[0])
     with pytest.raises(ValueError):
         _host.centred_window_f64("hann", 600, 512)
+
+
+def test_no_packed_fma_of_the_form_gfx950_miscomputes_beside_another_queue():
+    """v_pk_fma_f32 vD, vA, vD, vC op_sel:[_,1,_] (destination = src1, low result from src1's high register) is exact alone and wrong
+    in lanes 48-63 when MFMA-issuing waves of another kernel share the SIMD (tools/ubench/two_queue_pk.hip).  hipcc emits
+    it for float2 code; the built library must not contain it (tools/check_pk_hazard.py disassembles every gfx950 code object)."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_pk_hazard", os.path.join(root, "tools", "check_pk_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    found, n_pk = mod.hazards(os.path.join(root, "mindaudio_amd", "lib", "libmindaudio_amd.so"))
+    assert n_pk > 0, "the scanner found no packed FMA at all: is it still parsing the disassembly?"
+    assert not found, found
+

@@ -504,3 +504,33 @@ def test_train_mode_forward_is_the_training_steps_forward():
     enc._train_calls = 0
     moved, _ = enc(xs, sub)
     assert not torch.equal(moved, got) and float((moved - got).abs().max()) > 1e-3
+
+
+def test_two_forwards_on_two_streams_equal_the_sequential_ones():
+    """Two encoder forwards running CONCURRENTLY on two HIP streams give the bits of the same two forwards run one after the other.
+    (Round 5: they did not - the conv-module launch updated the residual stream in place while its tiles read their neighbours'
+    residual rows, which is only right while the whole grid is resident at once; beside another stream's kernels it is not.)"""
+    import torch
+
+    from mindaudio_amd.models import ConformerEncoder
+
+    torch.manual_seed(3)
+    enc = ConformerEncoder(80, 256, 4, 2048, 12).eval().cuda().prepare()
+    b, frames = 32, 1000
+    t2 = ((frames - 3) // 2 + 1 - 3) // 2 + 1
+    xs = [torch.randn(b, frames, 80, device="cuda") for _ in range(2)]
+    m = torch.ones(b, 1, t2, device="cuda")
+    want = [enc(x, m)[0].clone() for x in xs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cur = torch.cuda.current_stream()
+    for _ in range(6):
+        outs = []
+        for s_, x in zip(streams, xs):
+            s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
+                outs.append(enc(x, m)[0])
+        for s_ in streams:
+            cur.wait_stream(s_)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, w) for o, w in zip(outs, want))
+

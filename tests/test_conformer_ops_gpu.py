@@ -194,10 +194,12 @@ def test_convmodule_one_launch(t, b, tt, ks):
         assert float(err) <= 2 ** -7 * float(branch.abs().max()), float(err)
 
 
-@pytest.mark.parametrize("b,tt,ks", [(3, 249, 15), (2, 33, 7), (5, 64, 15), (1, 5, 3), (2, 32, 15)])
+@pytest.mark.parametrize("b,tt,ks", [(3, 249, 15), (2, 33, 7), (5, 64, 15), (1, 5, 3), (2, 32, 15), (150, 224, 15)])
 def test_attn_out_convmodule_one_launch(t, b, tt, ks):
     """linear_out + residual + norm_conv + ConvolutionModule in one launch == output projection with the LayerNorm epilogue
-    (ops.gemm_packed_ln) followed by ops.convmodule (same arithmetic per row; halo frames recomputed)."""
+    (ops.gemm_packed_ln) followed by ops.convmodule (same arithmetic per row; halo frames recomputed).  Out of place: a tile reads the
+    residual rows of its halo frames, i.e. its neighbours' rows - the (150, 224) case is 1 050 tiles of 7 per utterance, more than the
+    chip holds at once, where the in-place form of rounds 2-4 let late tiles read rows their neighbours had already updated."""
     from mindaudio_amd import ops
 
     c = 256
@@ -218,10 +220,16 @@ def test_attn_out_convmodule_one_launch(t, b, tt, ks):
         want = x0.clone()
         _, a = ops.gemm_packed_ln(ctx, po, lg, lb, ln_row_scale=m_, bias=bo, residual=want, out=want)
         ops.convmodule(a, p1, b1, dw, sc, sh, p2, b2, m_, want, b, tt)
-        got = x0.clone()
-        assert ops.attn_out_convmodule(ctx, po, bo, lg, lb, p1, b1, dw, sc, sh, p2, b2, m_, got, b, tt) is got
-        err = float((got - want).abs().max())
-        assert err <= 1e-5 * float(want.abs().max()), err
+        xin, buf = x0.clone(), t.full_like(x0, float("nan"))
+        got = ops.attn_out_convmodule(ctx, po, bo, lg, lb, p1, b1, dw, sc, sh, p2, b2, m_, xin, b, tt, out=buf)
+        assert got is buf and t.equal(xin, x0)
+        d, top = (got - want).abs(), float(want.abs().max())
+        # same arithmetic per row; in a large case a few elements of the bf16 tile a = LN(x') round the other way (x' is summed in
+        # another order) and move the rows that convolve them by one bf16 step of a: bounded, and rare
+        assert float(d.max()) <= (1e-5 if d.numel() < 1 << 20 else 1e-3) * top, float(d.max())
+        assert int((d > 1e-5 * top).sum()) <= 1e-4 * d.numel()
+    with pytest.raises(ValueError):  # x_out overlapping x (MA_ERR_INVALID_ARG): refused, not raced
+        ops.attn_out_convmodule(ctx, po, bo, lg, lb, p1, b1, dw, sc, sh, p2, b2, None, xin, b, tt, out=xin)
 
 
 @pytest.mark.parametrize("m,n", [(64, 256), (777, 512), (15936, 768), (1, 256), (130, 1024)])

@@ -227,7 +227,7 @@ def test_attn_out_convmodule_one_launch(t, b, tt, ks):
         # same arithmetic per row; in a large case a few elements of the bf16 tile a = LN(x') round the other way (x' is summed in
         # another order) and move the rows that convolve them by one bf16 step of a: bounded, and rare
         assert float(d.max()) <= (1e-5 if d.numel() < 1 << 20 else 1e-3) * top, float(d.max())
-        assert int((d > 1e-5 * top).sum()) <= 1e-4 * d.numel()
+        assert int((d > 1e-5 * top).sum()) <= 1e-3 * d.numel()  # (one flipped element of a reaches 15 frames x 256 channels)
     with pytest.raises(ValueError):  # x_out overlapping x (MA_ERR_INVALID_ARG): refused, not raced
         ops.attn_out_convmodule(ctx, po, bo, lg, lb, p1, b1, dw, sc, sh, p2, b2, None, xin, b, tt, out=xin)
 

@@ -35,6 +35,9 @@ struct Err {
 // VARIANT 6: v_pk_fma_f32 d, d, w, acc op_sel:[1,0,0] (dst = src0, low result from src0's high register)
 // VARIANT 7: v_pk_fma_f32 d, w, x, d op_sel:[0,0,1] (dst = src2, low result adds src2's high register)
 // VARIANT 8: v_pk_mov_b32 d, d, d op_sel:[1,0] (swap the halves in place)
+// VARIANT 9 / 10 / 11: 64-bit integer results in place - v_lshlrev_b64 d, 3, d; v_lshl_add_u64 d, d, 2, c; v_mad_u64_u32 d, a, b, d
+// VARIANT 12: v_pk_fma_f32 d, w, d, acc op_sel:[0,1,0] op_sel_hi:[1,0,1] (low from src1.hi AND high from src1.lo, dst = src1)
+// VARIANT 13: v_fma_f64 d, a, d, c (dst = src1, double precision: the other two-pass VALU class)
 template <int VARIANT>
 __global__ __launch_bounds__(256) void victim(int iters, Err* err) {
   __shared__ float xs[512];
@@ -72,6 +75,33 @@ __global__ __launch_bounds__(256) void victim(int iters, Err* err) {
     } else if (VARIANT == 8) {
       asm volatile("v_pk_mov_b32 %0, %0, %0 op_sel:[1,0]" : "+v"(x));
       out = x;
+    } else if (VARIANT == 12) {
+      asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(x) : "v"(w), "v"(acc));
+      out = x;
+    } else if (VARIANT >= 9 && VARIANT <= 11) {
+      unsigned long long v = ((unsigned long long)(unsigned)(int)xin.y << 32) | (unsigned)(int)xin.x, want;
+      const unsigned long long c = ((unsigned long long)(unsigned)it << 32) | (unsigned)lane;
+      const unsigned a32 = (unsigned)(lane * 7 + 3), b32 = (unsigned)(it * 5 + 1);
+      if (VARIANT == 9) { want = v << 3; asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(v)); }
+      else if (VARIANT == 10) { want = (v << 2) + c; asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(v) : "v"(c)); }
+      else { want = (unsigned long long)a32 * b32 + v; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(v) : "v"(a32), "v"(b32) : "vcc"); }
+      const bool bl = (unsigned)v != (unsigned)want, bh = (unsigned)(v >> 32) != (unsigned)(want >> 32);
+      if (bl || bh) {
+        if (atomicAdd(&err->count, 1u) == 0) { err->first_lane = lane; err->first_iter = it; err->first_got = (float)(unsigned)v; err->first_want = (float)(unsigned)want; }
+        if (bl) atomicAdd(&err->lo, 1u);
+        if (bh) atomicAdd(&err->hi, 1u);
+        atomicAdd(&err->lane_hist[lane >> 4], 1u);
+      }
+      continue;
+    } else if (VARIANT == 13) {
+      double dv = (double)xin.x + 0.5 * (double)xin.y, da = (double)w.x, dc = (double)acc.x;
+      const double dwant = __builtin_fma(da, dv, dc);
+      asm volatile("v_fma_f64 %0, %1, %0, %2" : "+v"(dv) : "v"(da), "v"(dc));
+      if (dv != dwant) {
+        if (atomicAdd(&err->count, 1u) == 0) { err->first_lane = lane; err->first_iter = it; err->first_got = (float)dv; err->first_want = (float)dwant; }
+        atomicAdd(&err->lane_hist[lane >> 4], 1u);
+      }
+      continue;
     } else if (VARIANT == 1) {
       asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=&v"(out) : "v"(w), "v"(x), "v"(acc));
     } else {
@@ -81,6 +111,7 @@ __global__ __launch_bounds__(256) void victim(int iters, Err* err) {
     // reference on separate registers, plain instructions
     const float sel = VARIANT == 2 ? xin.x : xin.y;
     float want_lo, want_hi;
+    if (VARIANT == 12) { want_lo = w.x * xin.y + acc0.x; want_hi = w.y * xin.x + acc0.y; } else
     if (VARIANT == 4) { want_lo = w.x * xin.y; want_hi = w.y * xin.y; }
     else if (VARIANT == 5) { want_lo = w.x + xin.y; want_hi = w.y + xin.y; }
     else if (VARIANT == 7) { want_lo = w.x * xin.x + acc0.y; want_hi = w.y * xin.y + acc0.y; }
@@ -168,5 +199,10 @@ int main(int argc, char** argv) {
   if (run<6>("v_pk_fma_f32 d, d, w, acc op_sel:[1,0,0] (dst = src0)", rounds, s1, s2, derr, src, sink)) return 2;
   if (run<7>("v_pk_fma_f32 d, w, x, d op_sel:[0,0,1] (dst = src2)", rounds, s1, s2, derr, src, sink)) return 2;
   if (run<8>("v_pk_mov_b32 d, d, d op_sel:[1,0] (swap in place)", rounds, s1, s2, derr, src, sink)) return 2;
+  if (run<12>("v_pk_fma_f32 d, w, d, acc op_sel:[0,1,0] op_sel_hi:[1,0,1]", rounds, s1, s2, derr, src, sink)) return 2;
+  if (run<9>("v_lshlrev_b64 d, 3, d", rounds, s1, s2, derr, src, sink)) return 2;
+  if (run<10>("v_lshl_add_u64 d, d, 2, c", rounds, s1, s2, derr, src, sink)) return 2;
+  if (run<11>("v_mad_u64_u32 d, a, b, d", rounds, s1, s2, derr, src, sink)) return 2;
+  if (run<13>("v_fma_f64 d, a, d, c (dst = src1)", rounds, s1, s2, derr, src, sink)) return 2;
   return 0;
 }

@@ -283,6 +283,10 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
   extern __shared__ __attribute__((aligned(16))) char asp_smem[];
   char* wl = asp_smem + wave * 16384;
   char* aring = asp_smem + 4 * 16384;  // two slots of 4 KiB: the a1 tile in fragment order (k-step ks at ks KiB, lane L at 16 L)
+  // (kAspWReg of the four 16-channel fragments stay in registers instead - the LDS pipe was 42 % busy with 16 + 4 fragment reads per
+  // tile and wave, SQ_ACTIVE_INST_LDS, beside a VALU pipe at 47 %: with two waves per SIMD their times add more than they overlap)
+  constexpr int kAspWReg = ASP_WREG;
+  e_bf16x8 wreg[kAspWReg > 0 ? kAspWReg : 1][4];
   {
     e_bf16x8 wt[4][4];
 #pragma unroll
@@ -293,7 +297,10 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<e_bf16x8*>(wl + (j * 4 + ks) * 1024 + lane * 16) = wt[j][ks];
+      for (int ks = 0; ks < 4; ++ks) {
+        if (j < kAspWReg) wreg[j][ks] = wt[j][ks];
+        else *reinterpret_cast<e_bf16x8*>(wl + (j * 4 + ks) * 1024 + lane * 16) = wt[j][ks];
+      }
   }
   // running sums per lane: channel pair p = channels 2p, 2p + 1 of the lane's 16 (float2: the updates are v_pk_* instructions).  m2 is the
   // REFERENCE exponent in the log2 domain, not the running maximum: the sums are of 2^(l2 - m2) and a tile rescales them only when a
@@ -327,6 +334,9 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
       xv[buf_][1] = *reinterpret_cast<const e_u32x4*>(xp_ + 8);                                                       \
     }                                                                                                                 \
   }
+#ifndef ASP_WREG
+#define ASP_WREG 2  // weight fragments (of 4) kept in registers; the rest in LDS (tools/asp_bench.py: 0 / 1 / 2 / 3 measured)
+#endif
 #ifndef ASP_X
 #define ASP_X 0  // development ablations (tools/asp_bench.py): 1 no exponentials, 2 no MFMAs, 4 no loads of x, 8 no a1 exchange
 #endif
@@ -355,8 +365,9 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
       const e_bf16x8 bfr = *reinterpret_cast<const e_bf16x8*>(aring + ((xb_) & 1) * 4096 + ks * 1024 + lane * 16);    \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
         if (!(ASP_X & 2))                                                                                             \
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const e_bf16x8*>(wl + (j * 4 + ks) * 1024 + lane * 16), \
-                                                           bfr, acc[j], 0, 0, 0);                                     \
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                           \
+              j < kAspWReg ? wreg[j < kAspWReg ? j : 0][ks] : *reinterpret_cast<const e_bf16x8*>(wl + (j * 4 + ks) * 1024 + lane * 16), \
+              bfr, acc[j], 0, 0, 0);                                                                                  \
         else acc[j][0] += __builtin_bit_cast(e_f32x4, bfr)[j];                                                        \
     }                                                                                                                 \
     e_f32x2 d[8];                                                                                                     \

@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void asp_pool8_kernel(const uint16_t* __restri
 //   * per 16-frame tile: 4 fragment loads of a1 (L2: the four waves of the workgroup walk the same rows), 2 loads of x, 16 MFMAs,
 //     then the softmax sums (w, w x, w x^2) in registers, float32 logits (never rounded to bf16);
 //   * the 16 frame lanes of a channel meet in a 4-step butterfly at the end; no logits in memory.
+#ifndef ASP_WREG
+#define ASP_WREG 2  // weight fragments (of 4) kept in registers; the rest in LDS (tools/asp_bench.py: 0 / 1 / 2 / 3 measured)
+#endif
 typedef __attribute__((ext_vector_type(8))) __bf16 e_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float e_f32x4;
 typedef __attribute__((ext_vector_type(2))) float e_f32x2;
@@ -334,9 +337,6 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
       xv[buf_][1] = *reinterpret_cast<const e_u32x4*>(xp_ + 8);                                                       \
     }                                                                                                                 \
   }
-#ifndef ASP_WREG
-#define ASP_WREG 2  // weight fragments (of 4) kept in registers; the rest in LDS (tools/asp_bench.py: 0 / 1 / 2 / 3 measured)
-#endif
 #ifndef ASP_X
 #define ASP_X 0  // development ablations (tools/asp_bench.py): 1 no exponentials, 2 no MFMAs, 4 no loads of x, 8 no a1 exchange
 #endif

@@ -375,14 +375,18 @@ __global__ __launch_bounds__(256, 2) void asp_fused_kernel(const uint16_t* __res
       const e_f32x2 l_ = (p & 1) ? e_f32x2{acc[p >> 1][2], acc[p >> 1][3]} : e_f32x2{acc[p >> 1][0], acc[p >> 1][1]}; \
       d[p] = __builtin_elementwise_fma(l_, kL2E, n2[p]);                                                              \
     }                                                                                                                 \
-    if ((tile_) + 1 >= ntiles && (tile_) * 16 + fi >= T) {                                                            \
+    const bool dead_ = (tile_) + 1 >= ntiles && (tile_) * 16 + fi >= T;  /* a frame past the utterance: weight 0 */      \
+    if (dead_) {                                                                                                      \
       _Pragma("unroll") for (int p = 0; p < 8; ++p) d[p] = e_f32x2{-INFINITY, -INFINITY};                             \
     }                                                                                                                 \
     float mx = fmaxf(d[0][0], d[0][1]);                                                                               \
     _Pragma("unroll") for (int p = 1; p < 8; ++p) mx = fmaxf(fmaxf(mx, d[p][0]), d[p][1]);                             \
     if (__any(mx > 40.0f)) {                                                                                          \
+      /* the logit itself, NOT d - n2: against the initial reference of -3e38 the float32 sum d = l2 + 3e38 has absorbed l2 (the       \
+         first build took the reference of every channel as 0 and weighted the first 16 frames uniformly - within the model-level     \
+         tolerances at T = 300, caught by the entry point's own test) */                                              \
       _Pragma("unroll") for (int p = 0; p < 8; ++p) _Pragma("unroll") for (int e = 0; e < 2; ++e) {                    \
-        const float l2_ = d[p][e] - n2[p][e];                                                                         \
+        const float l2_ = dead_ ? -INFINITY : acc[p >> 1][2 * (p & 1) + e] * 1.44269504f;                             \
         const float nm_ = fmaxf(-n2[p][e], l2_);                                                                      \
         const float f_ = __builtin_amdgcn_exp2f(-n2[p][e] - nm_);                                                     \
         s0[p][e] *= f_; s1[p][e] *= f_; s2[p][e] *= f_;                                                               \

@@ -154,3 +154,69 @@ def test_res2net_long_utterances_fall_back():
         want = ref(x)
     got = dut(x.cuda()).cpu()
     assert float((got - want).norm() / want.norm()) < 3e-2
+
+
+@pytest.mark.parametrize("b,t,c", [(1, 1, 256), (2, 15, 256), (3, 16, 512), (2, 17, 256), (3, 33, 1536), (5, 300, 1536), (2, 64, 3072)])
+def test_asp_fused_entry_point_against_float64(b, t, c):
+    """ma_asp_fused_bf16 alone (ecapatdnn.py:296-308) at tile boundaries of the frame axis (16-frame tiles, prefetch three tiles
+    ahead: T = 1, 15, 16, 17, 33) against a float64 evaluation of the same bf16 operands."""
+    from mindaudio_amd import _host, _lib
+    from mindaudio_amd.models.ecapatdnn import HALO
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(100 * t + c)
+    tp = t + 2 * HALO
+    a1 = torch.tanh(torch.randn(b, tp, 128, generator=g)).bfloat16()
+    w = (torch.randn(c, 128, generator=g) * 0.3).bfloat16()
+    x = torch.randn(b, tp, c, generator=g).bfloat16()
+    sc, sh = torch.rand(2 * c, generator=g) + 0.5, torch.randn(2 * c, generator=g) * 0.1
+    a1d, wd, xd, scd, shd = a1.cuda().view(b * tp, 128), w.cuda(), x.cuda().view(b * tp, c), sc.cuda(), sh.cuda()
+    out = torch.empty(b, 2 * c, dtype=torch.bfloat16, device="cuda")
+    rc = lib.ma_asp_fused_bf16(a1d.data_ptr(), 128, wd.data_ptr(), xd.data_ptr(), c, b, t, HALO, c, 128, 1e-12, scd.data_ptr(),
+                               shd.data_ptr(), out.data_ptr(), _host.current_stream_ptr())
+    _lib.check(rc, "asp_fused")
+    A, X = a1[:, HALO:HALO + t].double(), x[:, HALO:HALO + t].double()
+    logits = A @ w.double().t()                                   # (b, t, c); the bias cancels in the softmax over t
+    p_ = torch.softmax(logits, dim=1)
+    mean = (p_ * X).sum(1)
+    std = ((p_ * (X - mean[:, None]) ** 2).sum(1)).clamp(min=1e-12).sqrt()
+    want = torch.cat([mean, std], 1) * sc.double() + sh.double()
+    got = out.float().cpu().double()
+    assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 1e-2, float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("b,c,s_", [(1, 512, 128), (7, 512, 64), (3, 1024, 128), (16, 1024, 8)])
+def test_se_gate_entry_point_against_float64(b, c, s_):
+    from mindaudio_amd import _host, _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(c + s_)
+    mean = torch.randn(b, c, generator=g).bfloat16()
+    w1, b1 = (torch.randn(s_, c, generator=g) / 16).bfloat16(), torch.randn(s_, generator=g) * 0.2
+    w2, b2 = (torch.randn(c, s_, generator=g) / 8).bfloat16(), torch.randn(c, generator=g) * 0.2
+    gate = torch.empty(b, c, dtype=torch.bfloat16, device="cuda")
+    dev = [v.cuda() for v in (mean, w1, b1, w2, b2)]
+    rc = lib.ma_se_gate_bf16(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(),
+                             gate.data_ptr(), b, c, s_, _host.current_stream_ptr())
+    _lib.check(rc, "se_gate")
+    h = torch.relu(mean.double() @ w1.double().t() + b1.double())
+    want = torch.sigmoid(h @ w2.double().t() + b2.double())
+    assert float((gate.float().cpu().double() - want).abs().max()) <= 5e-3
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 16, 3072), (256, 192, 3072), (32, 64, 6144)])
+def test_linear_small_entry_point_against_float64(m, n, k):
+    from mindaudio_amd import _host, _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + n)
+    a, w, bias = torch.randn(m, k, generator=g).bfloat16(), (torch.randn(n, k, generator=g) / 50).bfloat16(), torch.randn(n, generator=g)
+    out = torch.empty(m, n, device="cuda")
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    rc = lib.ma_linear_small_bf16(ad.data_ptr(), k, wd.data_ptr(), k, bd.data_ptr(), out.data_ptr(), n, m, n, k, _host.current_stream_ptr())
+    _lib.check(rc, "linear_small")
+    want = a.double() @ w.double().t() + bias.double()
+    assert float((out.cpu().double() - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-4
+    # shapes outside the kernel's tiling are refused (callers then run ma_gemm_bf16)
+    assert lib.ma_linear_small_bf16(ad.data_ptr(), k, wd.data_ptr(), k, bd.data_ptr(), out.data_ptr(), n, m - 1, n, k, None) == _lib.MA_ERR_UNSUPPORTED
+

@@ -220,3 +220,49 @@ def test_linear_small_entry_point_against_float64(m, n, k):
     # shapes outside the kernel's tiling are refused (callers then run ma_gemm_bf16)
     assert lib.ma_linear_small_bf16(ad.data_ptr(), k, wd.data_ptr(), k, bd.data_ptr(), out.data_ptr(), n, m - 1, n, k, None) == _lib.MA_ERR_UNSUPPORTED
 
+
+@pytest.mark.parametrize("cc,b,t,d", [(64, 1, 1, 2), (64, 2, 20, 3), (64, 3, 57, 4), (128, 2, 33, 2), (128, 1, 300, 3), (64, 2, 376, 4),
+                                       (128, 2, 376, 4)])
+def test_res2net_fused_entry_point_against_float64(cc, b, t, d):
+    """ma_res2net_fused_bf16 alone (Res2NetBlock, ecapatdnn.py:66-114: y_0 = x_0, y_i = BN(ReLU(conv_{k=3, dilation d}(x_i + y_{i-1})))
+    on 8 channel groups) against a float64 chain with the kernel's rounding points (bf16 operands, bf16 y, bf16 x_i + y_{i-1})."""
+    from mindaudio_amd import _host, _lib
+    from mindaudio_amd.models.ecapatdnn import HALO
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1000 * cc + 10 * t + d)
+    c, tp, H = 8 * cc, t + 2 * HALO, HALO
+    x = torch.zeros(b, tp, c)
+    x[:, H:H + t] = torch.randn(b, t, c, generator=g)
+    x = x.bfloat16()
+    w = (torch.randn(7, cc, 3 * cc, generator=g) / (3 * cc) ** 0.5).bfloat16()   # (step, out, tap * cc + in)
+    bias, sc, sh = torch.randn(7, cc, generator=g) * 0.1, torch.rand(7, cc, generator=g) + 0.5, torch.randn(7, cc, generator=g) * 0.1
+    xd = torch.zeros(b * tp + 2 * H, c, dtype=torch.bfloat16, device="cuda")
+    xd[H:H + b * tp] = x.view(b * tp, c).cuda()
+    yd = torch.zeros_like(xd)
+    dev = [v.cuda().contiguous() for v in (w, bias, sc, sh)]
+    rc = lib.ma_res2net_fused_bf16(xd[H:].data_ptr(), c, yd[H:].data_ptr(), c, b, t, H, cc, 8, d, dev[0].data_ptr(), dev[1].data_ptr(),
+                                   dev[2].data_ptr(), dev[3].data_ptr(), _host.current_stream_ptr())
+    _lib.check(rc, "res2net_fused")
+    got = yd[H:H + b * tp].view(b, tp, c).float().cpu()
+    X = x.double()
+    want = torch.zeros(b, tp, c, dtype=torch.float64)
+    want[..., :cc] = X[..., :cc]
+    keep = torch.zeros(tp, dtype=torch.float64)
+    keep[H:H + t] = 1
+    prev = None
+    for i in range(1, 8):
+        inp = X[..., i * cc:(i + 1) * cc] if prev is None else (X[..., i * cc:(i + 1) * cc] + prev).bfloat16().double()
+        pad = torch.zeros(b, tp + 2 * d, cc, dtype=torch.float64)
+        pad[:, d:d + tp] = inp
+        W = w[i - 1].double().view(cc, 3, cc)
+        out = sum(pad[:, k * d:k * d + tp] @ W[:, k].t() for k in range(3)) + bias[i - 1].double()
+        out = (torch.relu(out) * sc[i - 1].double() + sh[i - 1].double()) * keep[None, :, None]
+        prev = out.bfloat16().double()
+        want[..., i * cc:(i + 1) * cc] = prev
+    err = (got.double() - want).abs()
+    # bf16 outputs of a 7-deep chain: a rounding flip early in the chain moves later groups by a bf16 step of their inputs
+    assert float(err.max()) <= 4e-2 * float(want.abs().max()), float(err.max())
+    assert float(err.mean()) <= 2e-3 * float(want.abs().mean() + 1e-6)
+    assert float(got[:, :H].abs().max()) == 0.0 and float(got[:, H + t:].abs().max()) == 0.0  # halo frames stay zero
+

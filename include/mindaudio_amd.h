@@ -331,6 +331,13 @@ int ma_time_mean_bf16(const void* x, int64_t ldx, int64_t batch, int64_t T, int3
  * C = 512 or 1024 and S <= 128 (a multiple of 8), else MA_ERR_UNSUPPORTED (callers then run two ma_gemm_bf16). */
 int ma_se_gate_bf16(const void* mean, const void* W1, const float* b1, const void* W2, const float* b2, void* gate, int64_t batch,
                     int32_t C, int32_t S, ma_stream_t stream);
+/* The whole SE block behind a SERes2Net block's tdnn2 in one launch (ecapatdnn.py:150-157, 246): squeeze + excitation + scale + the
+ * block's residual:  out[b, t, :] = x[b, t, :] * sigmoid(W2 relu(W1 mean_t(x[b]) + b1) + b2) + residual[b, t, :]  on the T frames, zeros
+ * on the 2 halo frames of every utterance (= ma_time_mean_bf16 + ma_se_gate_bf16 + ma_se_apply_bf16, same rounding points).
+ * C = 512 or 1024, S a multiple of 16 in 16 .. 128, 16-byte aligned rows, else MA_ERR_UNSUPPORTED (callers then run the three). */
+int ma_se_block_bf16(const void* x, int64_t ldx, const void* W1, const float* b1, const void* W2, const float* b2, const void* residual,
+                     int64_t ldr, void* out, int64_t ldo, int64_t batch, int64_t T, int32_t halo, int32_t C, int32_t S,
+                     ma_stream_t stream);
 /* out (M, N) float32 = a (M, K) bf16 @ W (N, K)^T + bias for few rows (the embedding Linear on the pooled statistics,
  * ecapatdnn.py:429-431): 16 x 16 output tiles, K split over the 8 waves of a workgroup.  M % 16, N % 16, K % 3072 == 0, else
  * MA_ERR_UNSUPPORTED (callers then run ma_gemm_bf16). */

@@ -169,6 +169,7 @@ PROTOTYPES = {
     "ma_add_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
     "ma_time_mean_bf16": (ctypes.c_int, [vp, i64, i64, i64, i32, i32, vp, vp]),
     "ma_se_apply_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, vp, i64, i64, i64, i32, i32, vp]),
+    "ma_se_block_bf16": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, i32, i32, i32, vp]),
     "ma_se_gate_bf16": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "ma_linear_small_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, vp]),
     "ma_asp_fused_bf16": (ctypes.c_int, [vp, i64, vp, vp, i64, i64, i64, i32, i32, i32, f32, vp, vp, vp, vp]),

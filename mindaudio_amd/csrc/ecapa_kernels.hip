@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void asp_pool8_kernel(const uint16_t* __restri
 //   * per 16-frame tile: 4 fragment loads of a1 (L2: the four waves of the workgroup walk the same rows), 2 loads of x, 16 MFMAs,
 //     then the softmax sums (w, w x, w x^2) in registers, float32 logits (never rounded to bf16);
 //   * the 16 frame lanes of a channel meet in a 4-step butterfly at the end; no logits in memory.
+#ifndef SE_KEEP_ROWS
+#define SE_KEEP_ROWS 16  // se_block_kernel<1, true>: rows of x a thread keeps in registers between the squeeze and the scale
+#endif
 #ifndef ASP_WREG
 #define ASP_WREG 2  // weight fragments (of 4) kept in registers; the rest in LDS (tools/asp_bench.py: 0 / 1 / 2 / 3 measured)
 #endif
@@ -555,6 +558,185 @@ __global__ __launch_bounds__(512) void se_gate_kernel(const uint16_t* __restrict
   }
 }
 
+// ---- round 5: the whole SE block behind tdnn2 in ONE launch (ecapatdnn.py:150-157, 246): squeeze (mean over the frames), excitation
+// (two 1 x 1 convolutions on the squeezed vector), scale, + the block's residual -------------------------------------------------------
+// Three launches before (time_mean8 14 us + se_gate 14 us + se_apply 39 us at C = 512; 29 + 23 + 79 at C = 1024), the middle one pure
+// latency and x read from memory twice.  Here a workgroup of 1 024 threads owns one utterance (the cfg-5 batch: one per CU):
+//   * thread (cg = 8 channels, sl = frame slice) loads its rows of x once - and, C = 512 (KEEP), keeps the first 16 of them (frames
+//     < 256) in registers for the scale at the end; later frames, and everything at C = 1024, are read again (they are in the cache
+//     hierarchy: this launch's own first pass);
+//   * channel sums through LDS, the excitation as in se_gate_kernel (coalesced row reads + butterflies, 16 waves), gate in LDS (float32);
+//   * out = x * gate + residual on the T frames, zeros on the halo frames, 16-byte stores.
+template <int KC, bool KEEP>
+__global__ __launch_bounds__(1024) void se_block_kernel(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ W1,
+                                                        const float* __restrict__ b1, const uint16_t* __restrict__ W2,
+                                                        const float* __restrict__ b2, const uint16_t* __restrict__ res, int64_t ldr,
+                                                        uint16_t* __restrict__ out, int64_t ldo, int Tp, int H, int T, int S) {
+  constexpr int C = 512 * KC, kCG = C / 8, kNS = 1024 / kCG;  // channel groups, frame slices (16 / 8)
+  constexpr int kRows = KEEP ? SE_KEEP_ROWS : 0;                        // rows a thread keeps in registers (frames below kNS * kRows = 256; the
+                                                              // rest - and everything when !KEEP - is read again for the scale)
+  __shared__ __attribute__((aligned(16))) float sums[kNS][C];  // 32 KiB; reused: mean | h | gate
+  __shared__ __attribute__((aligned(16))) float vec[C + 128 + C];
+  float* smean = vec;
+  float* sh = vec + C;
+  float* sgate = vec + C + 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = tid % kCG, sl = tid / kCG;
+  const int64_t b = blockIdx.x;
+  const uint16_t* xb = x + (b * Tp + H) * ldx + cg * 8;
+  // ---- squeeze -----------------------------------------------------------------------------------------------------------------------
+  e_u32x4 keep[kRows > 0 ? kRows : 1];
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      const int t = sl + kNS * i;
+      keep[i] = t < T ? *reinterpret_cast<const e_u32x4*>(xb + (int64_t)t * ldx) : e_u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < kRows; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[2 * e] += __uint_as_float(keep[i][e] << 16);
+        a[2 * e + 1] += __uint_as_float(keep[i][e] & 0xffff0000u);
+      }
+    // (opaque: otherwise hipcc keeps the eight CONVERTED floats of every row alive for the scale at the end - twice the registers)
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) asm volatile("" : "+v"(keep[i]));
+  }
+  for (int t = sl + kNS * kRows; t < T; t += kNS) {
+    const e_u32x4 v = *reinterpret_cast<const e_u32x4*>(xb + (int64_t)t * ldx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[2 * e] += __uint_as_float(v[e] << 16);
+      a[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sums[sl][cg * 8 + e] = a[e];
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);  // (phases are not interleaved: the kept rows leave few registers)
+  for (int c = tid; c < C; c += 1024) {
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kNS; ++k) m += sums[k][c];
+    // (the separate launches hand the mean over as bf16; rounded here too so that both forms see the same excitation input)
+    smean[c] = e_bf2f(e_f2bf(m / (float)T));
+  }
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);  // (phases are not interleaved: the kept rows leave few registers)
+  // ---- excitation: h = relu(W1 mean + b1): wave w owns S / 16 rows, lane l the K slice 8 l .. 8 l + 7 of every 512-column chunk; four
+  // rows / four load instructions in flight at a time (the kept rows of x leave ~60 registers) -------------------------------------------
+  {
+    float xs[KC][8];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xs[kc][e] = smean[kc * 512 + lane * 8 + e];
+    const int rows = S >> 4;  // per wave (<= 8)
+    const uint32_t woff = (uint32_t)(wave * rows) * C + lane * 8;
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0 += 4) {
+      e_u32x4 wv[4][KC];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+          wv[r][kc] = *reinterpret_cast<const e_u32x4*>(W1 + woff + (uint32_t)(r0 + r < rows ? r0 + r : rows - 1) * C + kc * 512);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc += __uint_as_float(wv[r][kc][e] << 16) * xs[kc][2 * e] + __uint_as_float(wv[r][kc][e] & 0xffff0000u) * xs[kc][2 * e + 1];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0 && r0 + r < rows) sh[wave * rows + r0 + r] = fmaxf(acc + b1[wave * rows + r0 + r], 0.0f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+  // gate = sigmoid(W2 h + b2): four rows of W2 per load instruction (lane >> 4 the row, lane & 15 the K slice), C / 16 rows per wave
+  {
+    const int kl = (lane & 15) * 8;
+    const bool kin = kl < S;
+    float hs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hs[e] = kin ? sh[kl + e] : 0.0f;
+    constexpr int kInst = C / 64;  // per wave: C / 16 rows, four per instruction
+    const uint32_t w2off = (uint32_t)(wave * (C / 16) + (lane >> 4)) * S + (kin ? kl : 0);
+#pragma unroll
+    for (int i0 = 0; i0 < kInst; i0 += 4) {
+      e_u32x4 w2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w2[i] = *reinterpret_cast<const e_u32x4*>(W2 + w2off + (uint32_t)(4 * (i0 + i)) * S);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += __uint_as_float(w2[i][e] << 16) * hs[2 * e] + __uint_as_float(w2[i][e] & 0xffff0000u) * hs[2 * e + 1];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if ((lane & 15) == 0) {
+          const int c = wave * (C / 16) + 4 * (i0 + i) + (lane >> 4);
+          // (the separate launches hand the gate over as bf16)
+          sgate[c] = e_bf2f(e_f2bf(1.0f / (1.0f + __expf(-(acc + b2[c])))));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- scale + residual ---------------------------------------------------------------------------------------------------------------
+  float gt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gt[e] = sgate[cg * 8 + e];
+  const uint16_t* rb = res + (b * Tp + H) * ldr + cg * 8;
+  uint16_t* ob = out + (b * Tp + H) * ldo + cg * 8;
+  auto apply = [&](const e_u32x4& xv, const e_u32x4& rv) __attribute__((always_inline)) {
+    e_u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = __uint_as_float(xv[e] << 16) * gt[2 * e] + __uint_as_float(rv[e] << 16);
+      const float hi = __uint_as_float(xv[e] & 0xffff0000u) * gt[2 * e + 1] + __uint_as_float(rv[e] & 0xffff0000u);
+      o[e] = (uint32_t)e_f2bf(lo) | ((uint32_t)e_f2bf(hi) << 16);
+    }
+    return o;
+  };
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int i0 = 0; i0 < kRows; i0 += 4) {  // (four residual rows in flight at a time: registers)
+      e_u32x4 rv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = sl + kNS * (i0 + i);
+        rv[i] = t < T ? *reinterpret_cast<const e_u32x4*>(rb + (int64_t)t * ldr) : e_u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = sl + kNS * (i0 + i);
+        if (t < T) *reinterpret_cast<e_u32x4*>(ob + (int64_t)t * ldo) = apply(keep[i0 + i], rv[i]);
+      }
+    }
+  }
+  for (int t = sl + kNS * kRows; t < T; t += kNS) {
+    const e_u32x4 xv = *reinterpret_cast<const e_u32x4*>(xb + (int64_t)t * ldx);
+    const e_u32x4 rv = *reinterpret_cast<const e_u32x4*>(rb + (int64_t)t * ldr);
+    *reinterpret_cast<e_u32x4*>(ob + (int64_t)t * ldo) = apply(xv, rv);
+  }
+  // halo frames of the output stay zero (the taps of the next convolution read them)
+  for (int i = tid; i < 2 * H * kCG; i += 1024) {
+    const int r = i / kCG, g8 = i - r * kCG;
+    const int tp = r < H ? r : T + r;  // rows 0 .. H-1 and H+T .. Tp-1
+    *reinterpret_cast<e_u32x4*>(out + (b * Tp + tp) * ldo + g8 * 8) = e_u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
 // ---- round 5: out (M, N) f32 = a (M, K) bf16 @ W (N, K)^T + bias for a FEW rows (the final Linear on the pooled statistics,
 // ecapatdnn.py:429-431: M = batch = 256, N = 192, K = 6C) --------------------------------------------------------------------------------
 // On the 64 x 128 tile of ma_gemm_bf16 this is 8 workgroups walking K = 3072 .. 6144 serially (28 us at C = 512).  Here a workgroup owns
@@ -700,6 +882,24 @@ int ma_linear_small_bf16(const void* a, int64_t lda, const void* W, int64_t ldw,
     return MA_ERR_UNSUPPORTED;
   MA_LAUNCH(linear_small_kernel, dim3((unsigned)(M / 16), (unsigned)(N / 16)), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)a,
             lda, (const uint16_t*)W, ldw, bias, out, ldo, (int)K);
+  return MA_OK;
+}
+
+int ma_se_block_bf16(const void* x, int64_t ldx, const void* W1, const float* b1, const void* W2, const float* b2, const void* residual,
+                     int64_t ldr, void* out, int64_t ldo, int64_t batch, int64_t T, int32_t halo, int32_t C, int32_t S,
+                     ma_stream_t stream) {
+  if (!x || !W1 || !b1 || !W2 || !b2 || !residual || !out || batch < 1 || T < 1 || halo < 0 || batch > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if ((C != 512 && C != 1024) || (S & 15) || S > 128 || S < 16 || (ldx & 7) || (ldr & 7) || (ldo & 7) || ldx < C || ldr < C || ldo < C ||
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(W2) |
+        reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return MA_ERR_UNSUPPORTED;
+  const int Tp = (int)(T + 2 * halo);
+  if (C == 512)
+    MA_LAUNCH((se_block_kernel<1, (SE_KEEP_ROWS > 0)>), dim3((unsigned)batch), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
+              (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, (const uint16_t*)residual, ldr, (uint16_t*)out, ldo, Tp, halo, (int)T, S);
+  else
+    MA_LAUNCH((se_block_kernel<2, false>), dim3((unsigned)batch), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
+              (const uint16_t*)W1, b1, (const uint16_t*)W2, b2, (const uint16_t*)residual, ldr, (uint16_t*)out, ldo, Tp, halo, (int)T, S);
   return MA_OK;
 }
 

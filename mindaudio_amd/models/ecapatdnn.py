@@ -100,6 +100,7 @@ class EcapaTDNN(nn.Module):
         self._prepared = None
         self._ws = {}
         self.fuse_res2net = True  # False: one launch per convolution / add of the Res2Net chain (the tests run both)
+        self.fuse_se_block = True  # False: squeeze, excitation and scale + residual as three launches (the tests run both)
         self.fuse_se = True       # False: the SE excitation and the embedding Linear as ma_gemm_bf16 launches (the tests run both)
         self.fuse_asp = True      # False: the ASP logits as a GEMM launch + the pooling launch (the tests run both)
 
@@ -225,21 +226,29 @@ class EcapaTDNN(nn.Module):
             _, t2 = buf(c)
             _conv(y.data_ptr(), c, rows, c, B_["t2"]["w"], 1, 1, t2.data_ptr(), c, c, B_["t2"]["b"], RELU, B_["t2"]["bn"],
                   row_scale=rs)
-            mean = t.empty((b, c), dtype=bf, device=dev)
-            _lib.check(lib.ma_time_mean_bf16(t2.data_ptr(), c, b, T, H, c, mean.data_ptr(), s), "time_mean")
-            g2 = t.empty((b, c), dtype=bf, device=dev)
-            rc = _lib.MA_ERR_UNSUPPORTED
-            if self.fuse_se:  # both 1 x 1 convolutions of the excitation in one launch
-                rc = lib.ma_se_gate_bf16(mean.data_ptr(), B_["se1"]["w"].data_ptr(), B_["se1"]["b"].data_ptr(), B_["se2"]["w"].data_ptr(),
-                                         B_["se2"]["b"].data_ptr(), g2.data_ptr(), b, c, B_["se1"]["w"].shape[0], s)
-                if rc != _lib.MA_ERR_UNSUPPORTED:
-                    _lib.check(rc, "se_gate")
-            if rc == _lib.MA_ERR_UNSUPPORTED:
-                g1 = ops.gemm(mean, B_["se1"]["w"], bias=B_["se1"]["b"], act=RELU)
-                ops.gemm(g1, B_["se2"]["w"], bias=B_["se2"]["b"], act=_lib.ACT_SIGMOID, out=g2)
             out = cat[:, bi * c:]
-            _lib.check(lib.ma_se_apply_bf16(t2.data_ptr(), c, g2.data_ptr(), cur.data_ptr(), cur_ld, out.data_ptr(), 3 * c,
-                                            b, T, H, c, s), "se_apply")
+            rc = _lib.MA_ERR_UNSUPPORTED
+            if self.fuse_se and self.fuse_se_block:  # squeeze + excitation + scale + residual in one launch (C = 512 / 1024)
+                rc = lib.ma_se_block_bf16(t2.data_ptr(), c, B_["se1"]["w"].data_ptr(), B_["se1"]["b"].data_ptr(), B_["se2"]["w"].data_ptr(),
+                                          B_["se2"]["b"].data_ptr(), cur.data_ptr(), cur_ld, out.data_ptr(), 3 * c, b, T, H, c,
+                                          B_["se1"]["w"].shape[0], s)
+                if rc != _lib.MA_ERR_UNSUPPORTED:
+                    _lib.check(rc, "se_block")
+            if rc == _lib.MA_ERR_UNSUPPORTED:
+                mean = t.empty((b, c), dtype=bf, device=dev)
+                _lib.check(lib.ma_time_mean_bf16(t2.data_ptr(), c, b, T, H, c, mean.data_ptr(), s), "time_mean")
+                g2 = t.empty((b, c), dtype=bf, device=dev)
+                if self.fuse_se:  # both 1 x 1 convolutions of the excitation in one launch
+                    rc = lib.ma_se_gate_bf16(mean.data_ptr(), B_["se1"]["w"].data_ptr(), B_["se1"]["b"].data_ptr(),
+                                             B_["se2"]["w"].data_ptr(), B_["se2"]["b"].data_ptr(), g2.data_ptr(), b, c,
+                                             B_["se1"]["w"].shape[0], s)
+                    if rc != _lib.MA_ERR_UNSUPPORTED:
+                        _lib.check(rc, "se_gate")
+                if rc == _lib.MA_ERR_UNSUPPORTED:
+                    g1 = ops.gemm(mean, B_["se1"]["w"], bias=B_["se1"]["b"], act=RELU)
+                    ops.gemm(g1, B_["se2"]["w"], bias=B_["se2"]["b"], act=_lib.ACT_SIGMOID, out=g2)
+                _lib.check(lib.ma_se_apply_bf16(t2.data_ptr(), c, g2.data_ptr(), cur.data_ptr(), cur_ld, out.data_ptr(), 3 * c,
+                                                b, T, H, c, s), "se_apply")
             cur, cur_ld = out, 3 * c
         _, xm = buf(3 * c)
         M = P["mfa"]

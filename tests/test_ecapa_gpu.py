@@ -268,3 +268,47 @@ def test_res2net_fused_entry_point_against_float64(cc, b, t, d):
     assert float(err.mean()) <= 2e-3 * float(want.abs().mean() + 1e-6)
     assert float(got[:, :H].abs().max()) == 0.0 and float(got[:, H + t:].abs().max()) == 0.0  # halo frames stay zero
 
+
+@pytest.mark.parametrize("b,t,c,s_", [(1, 1, 512, 128), (3, 57, 512, 128), (2, 300, 512, 64), (2, 333, 512, 128), (3, 100, 1024, 128),
+                                      (2, 300, 1024, 16)])
+def test_se_block_entry_point_equals_the_three_launches(b, t, c, s_):
+    """ma_se_block_bf16 (squeeze + excitation + scale + residual, ecapatdnn.py:150-157, 246) against ma_time_mean_bf16 +
+    ma_se_gate_bf16 + ma_se_apply_bf16 on the same buffers (same rounding points: bf16 mean and gate), halo frames zero, and
+    against float64."""
+    from mindaudio_amd import _host, _lib
+    from mindaudio_amd.models.ecapatdnn import HALO
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7 * t + c + s_)
+    H, tp = HALO, t + 2 * HALO
+    x = torch.zeros(b, tp, c)
+    x[:, H:H + t] = torch.randn(b, t, c, generator=g)
+    res = torch.zeros(b, tp, 3 * c)                      # the residual lives in a wider buffer (the concatenated block outputs)
+    res[:, H:H + t, :c] = torch.randn(b, t, c, generator=g)
+    w1, b1 = (torch.randn(s_, c, generator=g) / 16).bfloat16(), torch.randn(s_, generator=g) * 0.2
+    w2, b2 = (torch.randn(c, s_, generator=g) / 4).bfloat16(), torch.randn(c, generator=g) * 0.2
+    xd, rd = x.bfloat16().cuda().view(b * tp, c), res.bfloat16().cuda().view(b * tp, 3 * c)
+    dev = [v.cuda() for v in (w1, b1, w2, b2)]
+    out1 = torch.full((b * tp, 3 * c), 7.0, dtype=torch.bfloat16, device="cuda")
+    out2 = out1.clone()
+    s = _host.current_stream_ptr()
+    _lib.check(lib.ma_se_block_bf16(xd.data_ptr(), c, dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(),
+                                    rd.data_ptr(), 3 * c, out1[:, c:].data_ptr(), 3 * c, b, t, H, c, s_, s), "se_block")
+    mean = torch.empty(b, c, dtype=torch.bfloat16, device="cuda")
+    gate = torch.empty(b, c, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.ma_time_mean_bf16(xd.data_ptr(), c, b, t, H, c, mean.data_ptr(), s), "time_mean")
+    _lib.check(lib.ma_se_gate_bf16(mean.data_ptr(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(),
+                                   gate.data_ptr(), b, c, s_, s), "se_gate")
+    _lib.check(lib.ma_se_apply_bf16(xd.data_ptr(), c, gate.data_ptr(), rd.data_ptr(), 3 * c, out2[:, c:].data_ptr(), 3 * c, b, t, H, c, s),
+               "se_apply")
+    got, three = out1[:, c:2 * c].float().cpu().view(b, tp, c), out2[:, c:2 * c].float().cpu().view(b, tp, c)
+    assert float(got[:, :H].abs().max()) == 0.0 and float(got[:, H + t:].abs().max()) == 0.0
+    assert torch.equal(out1[:, :c], out2[:, :c]) and torch.equal(out1[:, 2 * c:], out2[:, 2 * c:])  # nothing outside the slice
+    # same rounding points; the mean's float32 summation order differs (a bf16 step of the mean can move a gate by one bf16 step)
+    assert float((got - three).abs().max()) <= 2 ** -6 * float(three.abs().max())
+    X = x.bfloat16().double()[:, H:H + t]
+    m_ = X.mean(1).float().bfloat16().double()
+    gt = torch.sigmoid(torch.relu(m_ @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+    want = X * gt[:, None] + res.bfloat16().double()[:, H:H + t, :c]
+    assert float((got[:, H:H + t].double() - want).abs().max()) <= 3e-2 * float(want.abs().max())
+

@@ -863,6 +863,11 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   if constexpr (MA_GEMM_FORCE == 4) return launch_gemm_tile<64, 128, 2, IM2COL, EPI>(p, stream);
   if constexpr (MA_GEMM_FORCE == 5) return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
   if constexpr (MA_GEMM_FORCE == 6) return launch_gemm_tile<128, 128, 3, IM2COL, EPI>(p, stream);
+  // ONE column tile, a long contraction and many rows (ECAPA's attention TDNN: 80 896 x 128 x 1536 / 3072, ecapatdnn.py:284-297): 632
+  // tiles of 128 rows are 1.23 rounds of the 512 resident workgroups - the second round runs at a quarter of the chip; 64-row tiles with
+  // the 3-stage ring: 91.5 -> 79.1 us (round 5, tools/ecapa_bench.py under rocprofv3 with -DMA_GEMM_FORCE variants; the tap convolution
+  // of the same launch family is fastest on 128 x 128: it is excluded)
+  if (IM2COL == 0 && p.N <= 128 && p.K >= 1024 && p.M >= 16384) return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
   // 128 x 128 tiles unless they would leave most CUs without a workgroup (N = 256 .. 768 at M ~ 8k)
   const int64_t big = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
   // measured on MI355X (tools/gemm_bench.py): 2 workgroups/CU beat a deeper ring for the 128x128 tile; the

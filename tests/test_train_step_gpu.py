@@ -484,6 +484,78 @@ def test_blocks_issued_from_the_launch_table_change_no_bit():
     assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
 
 
+def test_launch_table_budget_eviction_and_unrecordable_shapes_change_no_bit(monkeypatch):
+    """The launch table's fallbacks: (a) a byte budget smaller than one table - the older shape's table is dropped when the
+    second shape is recorded, and recorded again when it comes back; (b) a recording that meets a call it cannot store - the shape is
+    walked from Python from then on (state 'walk', one warning).  Losses and masters stay bit-identical to the engine without tables."""
+    import warnings
+
+    from mindaudio_amd import _lib
+    from mindaudio_amd.train import block_table as BT
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    def cols_of(k, short):
+        xs, ys, sub, ys_lens = batch(seed=20 + k, shorter=(0, 20 + k, 50 - k), ylens=(9, 5 + k % 3, 4))
+        if short:
+            t_short = xs.shape[1] - 16
+            xs = xs[:, :t_short].contiguous()
+            sub = sub[:, :, :((t_short - 3) // 2 + 1 - 3) // 2 + 1].contiguous()
+        return (xs.cuda(), ys.cuda(), None, None, None, None, sub.cuda(), None, None, ys_lens.cuda(), None)
+
+    order = [False, False, False, True, True, True, False, False, True, False]  # shape A x3, B x3, A, A, B, A
+    out = []
+    for mode in ("walked", "budget", "broken", "oom"):
+        _, _, model = build(seed=9)
+        eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1)
+        eng.block_tables = mode != "walked"
+        if mode == "budget":
+            eng.block_table_max_bytes = 1
+        if mode == "broken":
+            real_add, calls = BT.BlockTable._add, [0]
+
+            def flaky_add(self, name, *a):
+                calls[0] += 1
+                if calls[0] == 40:  # somewhere inside the first recorded step
+                    raise _lib.MindaudioAmdError("injected: %s cannot be stored" % name)
+                return real_add(self, name, *a)
+            monkeypatch.setattr(BT.BlockTable, "_add", flaky_add)
+        if mode == "oom":
+            # (c) the device runs out of memory in the middle of a RECORDING step (after the forward pass has moved the BatchNorm running
+            # statistics): tables dropped, statistics restored, the shape walked, the step run again
+            real_bwd, fired = eng._blocks_backward_fused, [0]
+
+            def oom_once(g, tape, dpos_all, c):
+                tb = c.get("table")
+                if tb is not None and tb["state"] == "record" and not fired[0]:
+                    fired[0] = 1
+                    raise torch.OutOfMemoryError("injected")
+                return real_bwd(g, tape, dpos_all, c)
+            eng._blocks_backward_fused = oom_once
+        losses, states = [], []
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for k, short in enumerate(order):
+                losses.append(float(eng.step(*cols_of(k, short))[0]))
+                tb = eng._dw_plan.get("table")
+                states.append(None if tb is None else tb["state"])
+        torch.cuda.synchronize()
+        if mode == "budget":
+            # every shape is recorded (state replay after its second step) but only ONE table survives a recording: when the other shape
+            # comes back it is recorded again instead of replayed
+            assert states[1] == "replay" and states[4] == "replay" and len(eng._table_bytes) <= 1, (states, len(eng._table_bytes))
+        if mode == "broken":
+            monkeypatch.setattr(BT.BlockTable, "_add", real_add)
+            assert states[1] == "walk" and states[2] == "walk" and states[4] == "replay", states  # shape A walked for good, shape B recorded
+            assert any("walked from Python" in str(w.message) for w in caught)
+        if mode == "oom":
+            assert fired[0] == 1 and states[1] == "walk" and states[2] == "walk" and states[4] == "replay", states
+            assert any("out of memory while recording" in str(w.message) for w in caught)
+        out.append((losses, eng.fp.master.clone(), [m_.clone() for m_ in eng.bn_mean]))
+    for got in out[1:]:
+        assert got[0] == out[0][0] and torch.equal(got[1], out[0][1])
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(got[2], out[0][2]))  # BatchNorm running statistics too
+
+
 def test_hybrid_step_from_the_launch_table_changes_no_bit():
     """The shipped configuration (ctc_weight 0.3): the decoder's layers join the encoder blocks' launch table (decoder layer l =
     block L + l; embedding, output layer and its backward = blocks L + Ld .. L + Ld + 2), the label-smoothing loss - which takes the

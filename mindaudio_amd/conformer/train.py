@@ -14,7 +14,13 @@ One process per GPU: under `torchrun` (RANK / WORLD_SIZE / LOCAL_RANK) with is_d
 (`mindspore.set_auto_parallel_context(DATA_PARALLEL, gradients_mean=True)`, train.py:70-80) and every rank keeps
 batch[rank::world] of the same shuffled batch order (dataset.py:552-553).  Keys the reference's train.py never reads either
 (grad_clip, accum_grad, log_interval, optim, device_target, save_graphs, full_graph) are accepted and ignored; training_with_eval
-and a `scheduler` other than warmuplr are refused loudly instead of silently doing something else."""
+is refused loudly instead of silently doing something else; `scheduler` is "warmuplr" or "none" and anything else raises the
+reference's ValueError (train.py:126-135).
+
+Resume (train.py:117-133,172-179): `resume_ckpt` is read with the reference's parameter names, `epoch_num` from the file is the
+number of finished epochs: the schedule continues at `start_steps = epoch_num * steps_size`, `max_epoch - epoch_num` epochs run, and
+the log / checkpoint names count epochs from `epoch_num + 1` (ResumeCallback).  Checkpoints are written under the reference's
+parameter names and layouts (`utils.ckpt.to_reference_names`), BatchNorm moving statistics included, with `epoch_num` appended."""
 import argparse
 import os
 import sys
@@ -67,20 +73,21 @@ def build_model(config, input_dim, vocab_size, device):
     return model.to(device)
 
 
-def build_step(model, config, rank, world, process_group=None):
-    """Adam(lr = ASRWarmupLR(lr, warmup_steps)) + DynamicLossScaleUpdateCell(1024, 2, 1000) + TrainOneStepWithLossScaleCell
-    (train.py:111-141) as one ConformerCTCTrainStep; mixed_precision True -> bf16 matmuls with float32 masters (the reference's
+def build_step(model, config, rank, world, process_group=None, start_steps=0):
+    """Adam(lr = ASRWarmupLR(lr, warmup_steps, start_steps) | the constant lr of `scheduler: none`) +
+    DynamicLossScaleUpdateCell(1024, 2, 1000) + TrainOneStepWithLossScaleCell (train.py:111-141) as one ConformerCTCTrainStep; mixed_precision True -> bf16 matmuls with float32 masters (the reference's
     float16 compute_type), False -> the float32 mode."""
     import torch
 
     from ..train.engine import ConformerCTCTrainStep
 
     sched = config.get("scheduler", "warmuplr")
-    if sched != "warmuplr":
-        raise NotImplementedError("scheduler: %r - only 'warmuplr' (ASRWarmupLR) is built (train.py:111-124)" % sched)
+    if sched not in ("warmuplr", "none"):
+        raise ValueError("Only 'none', and 'warmuplr' are supported.")  # train.py:135
     enc_conf = config.get("encoder_conf") or {}
-    return ConformerCTCTrainStep(model, base_lr=float(config["optim_conf"]["lr"]),
-                                 warmup_steps=int(config["scheduler_conf"]["warmup_steps"]), loss_scale=1024.0, scale_factor=2.0,
+    return ConformerCTCTrainStep(model, base_lr=float(config["optim_conf"]["lr"]), scheduler=sched, start_steps=int(start_steps),
+                                 warmup_steps=int((config.get("scheduler_conf") or {}).get("warmup_steps", 25000)), loss_scale=1024.0,
+                                 scale_factor=2.0,
                                  scale_window=1000, dropout_rate=float(enc_conf.get("dropout_rate", 0.1)),
                                  positional_dropout_rate=float(enc_conf.get("positional_dropout_rate", 0.1)), seed=777,
                                  process_group=process_group, world_size=world, rank=rank,
@@ -111,15 +118,20 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
     log("Total parameter of ASR model: %d." % sum(p.numel() for p in model.parameters()))
     start_epoch = 0
     if config.get("resume_ckpt"):
-        from ..utils.ckpt import load_mindspore_checkpoint
+        from ..utils.ckpt import load_mindspore_checkpoint, read_epoch_num
 
-        load_mindspore_checkpoint(model, config["resume_ckpt"], strict=False)
+        start_epoch = read_epoch_num(config["resume_ckpt"])  # train.py:121
+        load_mindspore_checkpoint(model, config["resume_ckpt"], strict=False)  # (load_param_into_net does not insist either)
         log("Successfully loading the pre-trained model")
-    eng = (step_factory or build_step)(model, config, rank, world, process_group)
+    factory = step_factory or build_step
+    try:
+        eng = factory(model, config, rank, world, process_group, start_steps=start_epoch * steps_size)
+    except TypeError:  # (a substituted factory without the keyword)
+        eng = factory(model, config, rank, world, process_group)
     max_epoch = int(config["max_epoch"])
     save_every = steps_size * int(config.get("save_checkpoint_epochs", 1))
     model_dir = os.path.join(str(config.get("exp_name", "default")), "model")
-    records, step = [], 0
+    records, step = [], start_epoch * steps_size  # (TimeMonitor.step, moved on by ResumeCallback)
     log("Training start.")
     for epoch in range(start_epoch + 1, max_epoch + 1):
         for cols in dataset:
@@ -138,7 +150,9 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
                 os.makedirs(model_dir, exist_ok=True)
                 # ModelCheckpoint's naming (prefix CKP, epoch_step), with epoch_num appended as the reference does (train.py:157-163)
                 path = os.path.join(model_dir, "CKP-%d_%d.ckpt" % (epoch, steps_size))
-                params = {n: p.detach().float().cpu().numpy() for n, p in model.named_parameters()}
+                from ..utils.ckpt import to_reference_names
+
+                params = to_reference_names(model.state_dict())  # (parameters AND the BatchNorm moving statistics)
                 params["epoch_num"] = __import__("numpy").asarray(epoch, dtype="int32")
                 write_mindspore_ckpt(path, params)
                 log("checkpoint: %s" % path)

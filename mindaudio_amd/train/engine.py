@@ -214,8 +214,11 @@ class ConformerCTCTrainStep:
     def __init__(self, model, base_lr=1e-3, warmup_steps=25000, loss_scale=1024.0, scale_factor=2.0, scale_window=1000,
                  beta1=0.9, beta2=0.999, eps=1e-8, dropout_rate=0.1, positional_dropout_rate=0.1, seed=777,
                  process_group=None, world_size=1, bn_momentum=0.1, rank=0, lr_step_rule="per_step", compute_type=None,
-                 force_collective=False, fused=True, dw_group_blocks=6, own_stream="auto"):
-        """compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
+                 force_collective=False, fused=True, dw_group_blocks=6, own_stream="auto", start_steps=0, scheduler="warmuplr"):
+        """start_steps: offset of the schedule index, `ASRWarmupLR(start_steps=start_epoch_num * steps_size)` of a resumed run
+        (examples/conformer/train.py:117-124); scheduler: "warmuplr" (ASRWarmupLR) or "none" = Adam at the constant base_lr
+        (train.py:126-127).
+        compute_type: None / torch.bfloat16 = bf16 MFMA matmuls with float32 accumulation (the throughput mode);
         torch.float32 (the reference's default, mindaudio/models/conformer.py:61) = the float32 validation mode: every
         activation and product in float32 through the `_x32` kernels - same tape, same backward, same optimizer."""
         enc = model.encoder
@@ -305,6 +308,9 @@ class ConformerCTCTrainStep:
         self.f2 = enc.embed.out.in_features // self.d
         self.p_drop, self.p_pos = float(dropout_rate), float(positional_dropout_rate)
         self.base_lr, self.warmup = base_lr, warmup_steps
+        if scheduler not in ("warmuplr", "none"):
+            raise ValueError("Only 'none', and 'warmuplr' are supported.")  # train.py:135
+        self.scheduler, self.start_steps = scheduler, int(start_steps)
         self.b1, self.b2, self.eps = beta1, beta2, eps
         self.scaler = DynamicLossScale(loss_scale, scale_factor, scale_window)
         if lr_step_rule not in ("per_step", "mindspore23"):
@@ -1752,15 +1758,21 @@ class ConformerCTCTrainStep:
         K = self.K
         self.reducer.wait()
         K.grad_overflow(self.fp.grad, self.flag)
-        lr = asr_warmup_lr(self.global_step, self.base_lr, self.warmup)
+        lr = self.lr_at(self.global_step)
         two = self.lr_step_rule == "mindspore23"
-        lr_opt = asr_warmup_lr(self.global_step + 1, self.base_lr, self.warmup) if two else lr
+        lr_opt = self.lr_at(self.global_step + 1) if two else lr
         tstep = self.applied_steps + 1
         lr_t = lr_opt * math.sqrt(1.0 - self.b2 ** tstep) / (1.0 - self.b1 ** tstep)
         mirrored = K.adam(self.fp.master, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, lr_t, self.b1, self.b2, self.eps,
                           1.0 / (scale * self.world), self.flag, **({} if self.x32 else {"mirror": self.fp.bf16}))
         self.refresh_weights(cast=not mirrored)  # (the bf16 mirror of the masters left with the update)
         return loss, scale, lr
+
+    def lr_at(self, step):
+        """Learning rate of schedule index `step`: ASRWarmupLR at step + start_steps, or the constant of `scheduler: none`."""
+        if self.scheduler == "none":
+            return float(self.base_lr)
+        return asr_warmup_lr(step, self.base_lr, self.warmup, self.start_steps)
 
     def finish_step(self, loss, scale, lr):
         two = self.lr_step_rule == "mindspore23"

@@ -21,7 +21,8 @@ import re
 
 import numpy as np
 
-__all__ = ["read_mindspore_ckpt", "write_mindspore_ckpt", "convert_names", "load_mindspore_checkpoint"]
+__all__ = ["read_mindspore_ckpt", "write_mindspore_ckpt", "convert_names", "to_reference_names", "read_epoch_num",
+           "load_mindspore_checkpoint"]
 
 _DTYPES = {"Float32": np.float32, "Float16": np.float16, "Float64": np.float64, "Int32": np.int32, "Int64": np.int64,
            "Int16": np.int16, "Int8": np.int8, "UInt8": np.uint8, "UInt16": np.uint16, "UInt32": np.uint32,
@@ -166,6 +167,44 @@ def convert_names(ref_params):
         n = n.replace("decoder.embed.0.embedding_table", "decoder.embed.weight")  # models/conformer.py:555-558
         out[n] = arr
     return out
+
+
+def to_reference_names(state, prefix=""):
+    """Inverse of `convert_names` for the modules of this package: {state_dict name: tensor / ndarray} -> {the name and layout
+    MindSpore gives the same parameter in the reference's cells: ndarray}, so that a file written from it loads with the reference's
+    `load_param_into_net` (Dense.dense, Conv1d.conv1d with the unit axis, Conv2d.conv2d inside the SequentialCell, BatchNorm
+    gamma / beta / moving_mean / moving_variance as Parameters, Embedding.embedding_table).  `num_batches_tracked` has no MindSpore
+    counterpart and is dropped; GlobalCMVN's statistics are constructor data, never parameters (layers/cmvn.py)."""
+    out = {}
+    for k, v in state.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        a = v.detach().float().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        n = k
+        if ".embed.conv1." in n or ".embed.conv2." in n:
+            n = n.replace(".embed.conv1.", ".embed.conv.0.conv2d.").replace(".embed.conv2.", ".embed.conv.2.conv2d.")
+        elif ".conv_module." in n and ("pointwise_conv" in n or "depthwise_conv" in n):
+            n = n.replace(".weight", ".conv1d.weight").replace(".bias", ".conv1d.bias")
+            if a.ndim == 3:
+                a = a[:, :, None, :]
+        elif ".conv_module.norm." in n:
+            n = (n.replace(".norm.weight", ".norm.gamma").replace(".norm.bias", ".norm.beta")
+                 .replace("running_mean", "moving_mean").replace("running_var", "moving_variance"))
+        elif n == "decoder.embed.weight":
+            n = "decoder.embed.0.embedding_table"
+        elif n.startswith("ctc.ctc_lo.") or n.endswith((".gamma", ".beta", "pos_bias_u", "pos_bias_v")):
+            pass  # loss/ctc_loss.py builds a bare nn.Dense; LayerNorm and the attention biases are plain Parameters
+        else:  # layers/dense.py: every other weight / bias sits inside the Dense wrapper
+            n = n.replace(".weight", ".dense.weight").replace(".bias", ".dense.bias")
+        out[prefix + n] = a
+    return out
+
+
+def read_epoch_num(path):
+    """`int(param_dict.get("epoch_num", 0))` of examples/conformer/train.py:121 - the number of finished epochs the reference's
+    ModelCheckpoint appends to every file (`append_info=[{"epoch_num": ...}]`, train.py:157-163)."""
+    v = read_mindspore_ckpt(path).get("epoch_num")
+    return int(np.asarray(v).reshape(-1)[0]) if v is not None else 0
 
 
 def load_mindspore_checkpoint(module, path, strict=True):

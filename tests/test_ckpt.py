@@ -8,29 +8,9 @@ from mindaudio_amd.utils import ckpt as K
 
 
 def _to_reference_names(state):
-    """Inverse of convert_names for the modules of this package (what MindSpore would call each parameter)."""
-    out = {}
-    for k, v in state.items():
-        if k.endswith("num_batches_tracked"):
-            continue
-        a = v.detach().cpu().numpy()
-        n = k
-        if ".embed.conv1." in n or ".embed.conv2." in n:
-            n = n.replace(".embed.conv1.", ".embed.conv.0.conv2d.").replace(".embed.conv2.", ".embed.conv.2.conv2d.")
-        elif ".conv_module." in n and ("pointwise_conv" in n or "depthwise_conv" in n):
-            n = n.replace(".weight", ".conv1d.weight").replace(".bias", ".conv1d.bias")
-            if a.ndim == 3:
-                a = a[:, :, None, :]
-        elif ".conv_module.norm." in n:
-            n = (n.replace(".norm.weight", ".norm.gamma").replace(".norm.bias", ".norm.beta")
-                 .replace("running_mean", "moving_mean").replace("running_var", "moving_variance"))
-        elif n == "decoder.embed.weight":
-            n = "decoder.embed.0.embedding_table"
-        elif n.startswith("ctc.ctc_lo.") or n.endswith((".gamma", ".beta", "pos_bias_u", "pos_bias_v")):
-            pass
-        else:  # Dense wrapper
-            n = n.replace(".weight", ".dense.weight").replace(".bias", ".dense.bias")
-        out["network." + n] = a
+    """What a MindSpore training run would have saved: the product's inverse name map (utils.ckpt.to_reference_names) under the
+    train network's `network.` prefix, plus optimizer / loss-scale state the importer has to drop."""
+    out = K.to_reference_names(state, prefix="network.")
     out["global_step"] = np.array([123], np.int32)
     out["moments.network.encoder.after_norm.gamma"] = np.zeros(256, np.float32)
     out["scale_sense"] = np.array(1024.0, np.float32)

@@ -181,9 +181,97 @@ def test_unsupported_keys_fail_loudly(tmp_path):
     cfg = _cfg(tmp_path, training_with_eval=True)
     with pytest.raises(NotImplementedError):
         T.train(cfg, device=torch.device("cpu"), dataset_factory=lambda *a, **k: (5, None))
-    cfg = _cfg(tmp_path, scheduler="none")
-    with pytest.raises(NotImplementedError):
+    cfg = _cfg(tmp_path, scheduler="cosine")
+    with pytest.raises(ValueError, match="Only 'none', and 'warmuplr' are supported"):  # examples/conformer/train.py:135
         T.build_step(torch.nn.Linear(2, 2), cfg, 0, 1)
+
+
+class _HostStep:
+    """The host side of ConformerCTCTrainStep (schedule index, start_steps, sync_to_module) without device work: what the resume
+    logic of the loop talks to."""
+
+    def __init__(self, model, config, start_steps=0):
+        from mindaudio_amd.train.engine import asr_warmup_lr
+
+        self.model, self.start_steps, self.global_step, self._lr = model, start_steps, 0, asr_warmup_lr
+        self.sched = config.get("scheduler", "warmuplr")
+        self.base, self.warm = float(config["optim_conf"]["lr"]), int(config["scheduler_conf"]["warmup_steps"])
+
+    def step(self, *cols):
+        lr = self.base if self.sched == "none" else self._lr(self.global_step, self.base, self.warm, self.start_steps)
+        self.global_step += 1
+        with torch.no_grad():  # "training": every parameter and the BatchNorm statistics move
+            for p in self.model.parameters():
+                p.add_(0.01)
+            bn = self.model.encoder.encoders[0].conv_module.norm
+            bn.running_mean.add_(0.25)
+            bn.running_var.mul_(1.5)
+        return torch.tensor(50.0), False, torch.tensor(1024.0), False, torch.tensor(lr, dtype=torch.float64)
+
+    def sync_to_module(self):
+        pass
+
+
+def test_resume_continues_the_schedule_and_checkpoints_carry_reference_names(tmp_path):
+    """examples/conformer/train.py:117-133,172-179: epoch_num from the checkpoint -> ASRWarmupLR(start_steps = epoch_num * steps_size),
+    max_epoch - epoch_num epochs; the file holds the reference's parameter names and layouts incl. the BatchNorm moving statistics and
+    loads strictly."""
+    from mindaudio_amd.utils import ckpt as CK
+
+    class Data:
+        def get_dataset_size(self):
+            return 3
+
+        def __iter__(self):
+            for k in range(3):
+                yield tuple(torch.zeros(1, 1) for _ in range(11))
+
+    def run(**over):
+        cfg = _cfg(tmp_path, train_data="x.csv", dict="d.txt", exp_name=str(tmp_path / "exp"), save_checkpoint=True, **over)
+        torch.manual_seed(5)
+        lines = []
+        holder = {}
+
+        def step_factory(m, c, r, w, pg, start_steps=0):
+            holder["model"], holder["start_steps"] = m, start_steps
+            return _HostStep(m, c, start_steps)
+
+        recs = T.train(cfg, device=torch.device("cpu"), log=lines.append, dataset_factory=lambda *a, **k: (20, Data()),
+                       step_factory=step_factory)
+        return recs, lines, holder
+
+    full, _, _ = run(max_epoch=3)
+    assert [r["epoch"] for r in full] == [1, 1, 1, 2, 2, 2, 3, 3, 3] and full[0]["lr"] == 0.0
+    first, _, h1 = run(max_epoch=1)
+    path = str(tmp_path / "exp" / "model" / "CKP-1_3.ckpt")
+    raw = CK.read_mindspore_ckpt(path)
+    assert int(raw["epoch_num"]) == 1 and CK.read_epoch_num(path) == 1
+    # the reference's names and layouts
+    assert raw["encoder.encoders.0.conv_module.depthwise_conv.conv1d.weight"].shape == (256, 1, 1, 15)
+    assert "encoder.encoders.0.conv_module.norm.moving_variance" in raw and "encoder.encoders.0.conv_module.norm.gamma" in raw
+    assert "encoder.embed.conv.2.conv2d.weight" in raw and "encoder.encoders.0.feed_forward.w_1.dense.weight" in raw
+    assert "decoder.embed.0.embedding_table" in raw and "ctc.ctc_lo.weight" in raw
+    # a strict load into a fresh model gives the trained model back, BatchNorm statistics included
+    fresh = T.build_model(_cfg(tmp_path), 80, 20, torch.device("cpu"))
+    missing, unexpected = CK.load_mindspore_checkpoint(fresh, path, strict=True)
+    assert not missing and not unexpected
+    a, b = h1["model"].state_dict(), fresh.state_dict()
+    for k in a:
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(a[k], b[k]), k
+    assert float(b["encoder.encoders.0.conv_module.norm.running_mean"].mean()) == pytest.approx(0.75)
+    # resumed: the schedule continues, two epochs remain, epoch labels and checkpoint names go on from 2
+    rest, lines, h2 = run(max_epoch=3, resume_ckpt=path)
+    assert h2["start_steps"] == 3 and "Successfully loading the pre-trained model" in lines
+    assert [r["epoch"] for r in rest] == [2, 2, 2, 3, 3, 3]
+    assert [r["lr"] for r in rest] == [r["lr"] for r in full[3:]] and rest[0]["lr"] > 0.0
+    assert os.path.exists(str(tmp_path / "exp" / "model" / "CKP-3_3.ckpt"))
+    assert CK.read_epoch_num(str(tmp_path / "exp" / "model" / "CKP-3_3.ckpt")) == 3
+    sl = [ln for ln in lines if ln.startswith("[Train]")]
+    assert sl[0].startswith("[Train] Epoch: [2/3], Step: [1/3]")
+    # scheduler: none = Adam at the constant lr (train.py:126-127)
+    const, _, _ = run(max_epoch=1, scheduler="none")
+    assert [r["lr"] for r in const] == pytest.approx([1e-3] * 3)
 
 
 @pytest.mark.gpu
@@ -204,7 +292,8 @@ def test_two_real_steps_on_a_two_utterance_manifest(tmp_path):
         paths.append(p)
     (tmp_path / "lang_char.txt").write_text("".join("%s %d\n" % (ch, i) for i, ch in enumerate(["<blank>", "<unk>", "a", "b", "c", "d", "<sos/eos>"])))
     (tmp_path / "train.csv").write_text("id,duration,wav,transcript\n0,2.5,%s,abca\n1,2.75,%s,dcb\n" % tuple(paths))
-    cfg = _cfg(tmp_path, train_data=str(tmp_path / "train.csv"), dict=str(tmp_path / "lang_char.txt"), max_epoch=2)
+    cfg = _cfg(tmp_path, train_data=str(tmp_path / "train.csv"), dict=str(tmp_path / "lang_char.txt"), max_epoch=2,
+               exp_name=str(tmp_path / "exp"), save_checkpoint=True)
     lines = []
     recs = T.train(cfg, log=lines.append)
     assert len(recs) == 2 and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in recs)
@@ -212,3 +301,14 @@ def test_two_real_steps_on_a_two_utterance_manifest(tmp_path):
 
     assert abs(recs[0]["lr"] - asr_warmup_lr(0, 1e-3, 25000)) < 1e-12 and abs(recs[1]["lr"] - asr_warmup_lr(1, 1e-3, 25000)) < 1e-12
     assert sum(ln.startswith("[Train]") and bool(LINE.match(ln)) for ln in lines) == 2
+    # resumed from the first epoch's checkpoint with the real engine: one epoch remains, the schedule continues at step 1, and the
+    # step sees the trained weights and BatchNorm statistics (same batch, dropout stream of a fresh engine: the loss is near epoch
+    # 2's, far from epoch 1's only if training moved it - so only finiteness and the schedule are asserted)
+    ck = os.path.join(str(tmp_path / "exp"), "model", "CKP-1_1.ckpt")
+    assert os.path.exists(ck)
+    cfg2 = dict(cfg, resume_ckpt=ck, save_checkpoint=False)
+    lines2 = []
+    rest = T.train(cfg2, log=lines2.append)
+    assert len(rest) == 1 and rest[0]["epoch"] == 2 and np.isfinite(rest[0]["loss"])
+    assert abs(rest[0]["lr"] - asr_warmup_lr(1, 1e-3, 25000)) < 1e-12 and rest[0]["lr"] > 0
+    assert any(ln.startswith("[Train] Epoch: [2/2], Step: [1/1]") for ln in lines2)

@@ -83,6 +83,12 @@ class BlockTable:
         except Exception:
             pass
 
+    def clear(self):
+        """Give up every tensor this table keeps alive (the recorded entries then name freed memory: the table must not be replayed
+        again - the engine drops it in the same breath)."""
+        del self.keep[:]  # (in place: the allocation proxy holds the same list)
+        self.recorded, self.broken = 0, self.broken or "cleared"
+
     # ---- recording ---------------------------------------------------------------------------------------------------------------
     class _Recording:
         def __init__(self, table, seed):

@@ -870,7 +870,11 @@ class ConformerCTCTrainStep:
     def drop_block_tables(self):
         """Forget every recorded launch table (and the buffers they pin); the next steps of every shape are walked and re-recorded."""
         for plan in self._dw_plans.values() if hasattr(self, "_dw_plans") else ():
-            plan.pop("tables", None)
+            for tb in (plan.pop("tables", None) or {}).values():
+                table = tb.get("table")
+                if table is not None and hasattr(table, "clear"):
+                    table.clear()  # (the recorder's kept tensors: other references to the dict must not keep them pinned)
+                tb.clear()
             plan.pop("table", None)
         self._table_bytes.clear()
         self._recording_tb = None
@@ -938,25 +942,32 @@ class ConformerCTCTrainStep:
         # BatchNorm running statistics of before the attempt (the only state a forward pass changes besides the gradients).
         # (snapshot taken by _block_table_for when a shape enters its recording step)
         with _host.pinned_stream():
+            oom_key = None
             try:
                 return self._forward_backward(*args)
             except torch.OutOfMemoryError:
+                # Only NOTE the failure here: while this block runs, the exception's traceback keeps the failed attempt's frames - its
+                # tape, activations and the recording table's pinned buffers - alive, so nothing could be given back from in here
+                # (the PyTorch FAQ's out-of-memory recovery pattern).
                 rec = self._recording_tb
                 if rec is None:
                     raise
-                _lib.set_recording(None)
-                tables, key = rec
-                self.drop_block_tables()
-                self._dq = self._dq_dec = None
-                self._dq_blocks.clear()
-                torch.cuda.synchronize(self.dev)
-                torch.cuda.empty_cache()
-                for (m0, v0), m, v in zip(self._bn_snapshot, self.bn_mean, self.bn_var):
-                    m.copy_(m0)
-                    v.copy_(v0)
-                self._table_warn("block tables: out of memory while recording a batch shape - tables dropped, the shape is walked from Python")
-                self._walk_shapes.add(key[:3])
-                return self._forward_backward(*args)
+                oom_key = rec[1]
+            # (outside the handler: the traceback and with it every tensor of the failed attempt are gone)
+            _lib.set_recording(None)
+            self.drop_block_tables()
+            self._dq = self._dq_dec = None
+            self._dq_blocks.clear()
+            self._wg_queue.clear()
+            torch.cuda.synchronize(self.dev)
+            torch.cuda.empty_cache()
+            self._oom_freed_to = torch.cuda.memory_allocated(self.dev)  # (what the retry starts from; read by the tests)
+            for (m0, v0), m, v in zip(self._bn_snapshot, self.bn_mean, self.bn_var):
+                m.copy_(m0)
+                v.copy_(v0)
+            self._table_warn("block tables: out of memory while recording a batch shape - tables dropped, the shape is walked from Python")
+            self._walk_shapes.add(oom_key[:3])
+            return self._forward_backward(*args)
 
     def _encoder_forward(self, xs, xs_masks, xs_chunk_masks, seed, tables=True):
         """The encoder's training-mode forward (models/conformer.py:229-258 with self.training: dropout with the step's seed, BatchNorm

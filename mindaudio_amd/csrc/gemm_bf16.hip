@@ -57,6 +57,8 @@ struct GemmParams {
   // split-K (weight gradients: small outputs, long contraction): blockIdx.y owns K-tiles [y * kt_split, ...) and
   // atomically adds its partial product into the float32 output (kt_split == 0: the whole K range, plain stores)
   int32_t kt_split;
+  // 8-phase kernel: tiles are walked in blocks of `blk_rows` row tiles x `blk_cols` column tiles (0: plain row-major order)
+  int32_t blk_rows, blk_cols;
 };
 
 // two f32 -> packed bf16x2, round to nearest even (v_cvt_pk_bf16_f32, gfx950)
@@ -477,7 +479,21 @@ __global__ __launch_bounds__(k8Threads, 1) void gemm_bf16_8ph_kernel(const GemmP
     const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  if (p.blk_cols > 0) {
+    // Blocked tile order (round 6).  An XCD's ~32 resident workgroups are consecutive tile indices; in row-major order with many
+    // column tiles (the MFA product of ECAPA: 300 x 12 tiles) they are 2.7 row blocks x ALL 12 column tiles, so an XCD streams the
+    // whole B matrix (18.9 MB against a 4 MB L2) once per 2.7 row blocks.  Walking blocks of blk_rows x blk_cols tiles (5 x 6) makes
+    // the resident set 5 A panels + 6 B panels instead of 2.7 + 12.  Ragged last row group / column block: still a bijection.
+    const int RB = p.blk_rows, CB = p.blk_cols, nb = (tiles_n + CB - 1) / CB;
+    const int rg = bid / (RB * tiles_n), rem = bid - rg * RB * tiles_n;
+    const int rows_in = tiles_m - rg * RB < RB ? tiles_m - rg * RB : RB;
+    int cb = rem / (rows_in * CB);
+    if (cb > nb - 1) cb = nb - 1;
+    const int rem2 = rem - cb * rows_in * CB, w = cb == nb - 1 ? tiles_n - (nb - 1) * CB : CB;
+    tile_m = rg * RB + rem2 / w;
+    tile_n = cb * CB + rem2 % w;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- staging: instruction i of this wave fills unit rows 8 (wid + 8 i) .. + 7 (lane -> row lr = lane >> 3, chunk slot lane & 7,
@@ -836,8 +852,19 @@ static int launch_gemm_8ph(const GemmParams& p, hipStream_t stream) {
   constexpr int ring = 2 * k8Buf, stage_c = 256 * (256 * 2 + 16);  // K-tile buffers / staged bf16 C tile
   constexpr int lds = ring > stage_c ? ring : stage_c;
   MA_LDS_ATTR_T(gemm_bf16_8ph_kernel<EPI>, lds);
-  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  MA_LAUNCH((gemm_bf16_8ph_kernel<EPI>), dim3(tiles), dim3(k8Threads), lds, stream, p);
+  const int tiles_n = (p.N + 255) / 256, tiles = ((p.M + 255) / 256) * tiles_n;
+  GemmParams q = p;
+  q.blk_rows = q.blk_cols = 0;
+  {
+    static int mode = -1;  // MA_G8_BLOCK=0: row-major tile order (A/B switch of tools/)
+    if (mode < 0) mode = (getenv("MA_G8_BLOCK") && getenv("MA_G8_BLOCK")[0] == '0') ? 0 : 1;
+    if (mode && tiles_n >= 8) {  // (up to 7 column tiles the row-major resident set is already >= 4.5 rows deep)
+      const int nb = (tiles_n + 5) / 6;
+      q.blk_cols = (tiles_n + nb - 1) / nb;
+      q.blk_rows = 32 / q.blk_cols > 1 ? 32 / q.blk_cols : 1;
+    }
+  }
+  MA_LAUNCH((gemm_bf16_8ph_kernel<EPI>), dim3(tiles), dim3(k8Threads), lds, stream, q);
   return MA_OK;
 }
 

@@ -105,3 +105,56 @@ def test_no_packed_fma_of_the_form_gfx950_miscomputes_beside_another_queue():
     assert n_pk > 0, "the scanner found no packed FMA at all: is it still parsing the disassembly?"
     assert not found, found
 
+
+
+def _load_tool(name):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_hazard_classifier_names_exactly_the_measured_form():
+    """tools/pk_hazard_scan_external.py's line classifier: `hazard` = the one form tools/ubench/two_queue_pk.hip shows wrong (packed
+    FMA, destination pair == src1 pair, src1 read hi -> lo); `wide` = any packed fp32 op whose destination aliases a source read with
+    op_sel 1 (the members other than `hazard` were measured exact and are only listed)."""
+    C = _load_tool("pk_hazard_scan_external").classify
+    assert C("  v_pk_fma_f32 v[2:3], s[6:7], v[2:3], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,0,1] // 0001") == (True, True, True)
+    assert C("  v_pk_fma_f32 v[2:3], v[8:9], v[2:3], v[6:7] op_sel_hi:[1,0,1]") == (True, False, False)      # no hi -> lo read
+    assert C("  v_pk_fma_f32 v[2:3], v[2:3], v[8:9], v[6:7] op_sel:[1,0,0] op_sel_hi:[0,1,1]") == (True, False, True)  # dst == src0
+    assert C("  v_pk_fma_f32 v[2:3], v[4:5], v[8:9], v[2:3] op_sel:[0,0,1] op_sel_hi:[1,1,0]") == (True, False, True)  # dst == src2
+    assert C("  v_pk_fma_f32 v[2:3], v[4:5], v[8:9], v[6:7] op_sel:[0,1,0]") == (True, False, False)            # no aliasing
+    assert C("  v_pk_add_f32 v[8:9], v[8:9], v[14:15] op_sel:[1,0] op_sel_hi:[0,1]") == (False, False, True)
+    assert C("  v_pk_mul_f32 v[6:7], v[6:7], v[6:7] op_sel:[0,1] op_sel_hi:[1,0]") == (False, False, True)
+    assert C("  v_fma_f32 v2, v3, v2, v4") == (False, False, False)
+
+
+def test_external_pk_hazard_scan_is_current_and_clean():
+    """The packed-FMA hazard outside this library: at N = 8 our MFMA grids are the aggressor and RCCL's reduction
+    kernels / the torch kernels of the step census the potential victims.  profiles/r06_pk_hazard_scan.txt is the committed result of
+    tools/pk_hazard_scan_external.py over every gfx950 code object of torch's librccl.so and libtorch_hip.so; this test fails when (a)
+    that scan found the hazardous form in a kernel on the watch list, or (b) the installed libraries are not the ones that were scanned
+    (another torch / RCCL build: run the scan again).  MA_PK_SCAN_LIVE=1 re-runs the watch-list scan (minutes)."""
+    path = os.path.join(ROOT, "profiles", "r06_pk_hazard_scan.txt")
+    text = open(path).read()
+    assert "verdict: CLEAN" in text, text[-400:]
+    T = _load_tool("pk_hazard_scan_external")
+    sizes = dict(re.findall(r"^library (\S+)\s+size (\d+) bytes", text, flags=re.M))
+    assert set(sizes) == {"librccl.so", "libtorch_hip.so"}
+    rccl = re.search(r"library librccl\.so.*?\n\s+all kernels:\s+v_pk_fma_f32 (\d+)\s+hazard (\d+)", text, flags=re.S)
+    assert rccl and int(rccl.group(1)) > 0 and int(rccl.group(2)) == 0  # (it parsed RCCL's code, and RCCL is clean as a whole)
+    try:
+        libs = T.default_libs()
+    except Exception:
+        pytest.skip("torch not importable")
+    for lib in libs:
+        if not os.path.exists(lib):
+            pytest.skip("%s not installed" % lib)
+        assert os.path.getsize(lib) == int(sizes[os.path.basename(lib)]), \
+            "%s is not the build that was scanned: run tools/pk_hazard_scan_external.py --out profiles/r06_pk_hazard_scan.txt" % lib
+    if os.environ.get("MA_PK_SCAN_LIVE") == "1":
+        for lib in libs:
+            per_kernel, n_obj, n_kern = T.scan(lib, only_watched=True)
+            assert n_kern > 0 and not [k for k, c in per_kernel.items() if c[1]]

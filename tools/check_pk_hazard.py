@@ -7,7 +7,13 @@
 Alone on its SIMD the instruction is exact; with MFMA-issuing waves of another kernel on the same SIMD the low results of lanes 48-63
 are computed from the already written high result.  hipcc emits the form freely for float2 code that broadcasts the second element
 of a pair.  `python tools/check_pk_hazard.py [lib.so]` prints every occurrence (kernel, instruction) and exits 1 if there is any;
-tests/test_cabi_cpu.py runs it on the built library."""
+tests/test_cabi_cpu.py runs it on the built library.
+
+What is and is not flagged: tools/ubench/two_queue_pk.hip ran every member of the wider class "packed fp32 op whose
+destination pair is also a source pair read hi -> lo" beside an MFMA grid - v_pk_fma_f32 with dst == src0 and dst == src2,
+v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 with the overlap, and dst == src1 with op_sel_hi instead of op_sel: 0 mismatches each;
+only dst == src1 + op_sel[1] = 1 miscomputes (466 896 mismatches).  So only that form fails the check; `--wide` lists the other
+members (tools/pk_hazard_scan_external.py has the classifier) for the record."""
 import os
 import re
 import struct
@@ -67,7 +73,44 @@ def hazards(lib):
     return found, n_pk
 
 
+def wide(lib):
+    """[(kernel, instruction)] of the wider class (see the module docstring) - informational."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("pk_ext", os.path.join(os.path.dirname(os.path.abspath(__file__)), "pk_hazard_scan_external.py"))
+    ext = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ext)
+    out = []
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", f.name], capture_output=True, text=True).stdout
+        kernel = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                kernel = m.group(1)
+            elif "v_pk_" in line:
+                _, h, w = ext.classify(line)
+                if w and not h:
+                    out.append((kernel, line.split("//")[0].strip()))
+    return out
+
+
 def main():
+    if "--wide" in sys.argv:
+        sys.argv.remove("--wide")
+        lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mindaudio_amd",
+                                                                  "lib", "libmindaudio_amd.so")
+        hits = wide(lib)
+        per = {}
+        for k, _ in hits:
+            per[k] = per.get(k, 0) + 1
+        for k, n in sorted(per.items(), key=lambda kv: -kv[1]):
+            print("%6d  %s" % (n, k))
+        print("%d instructions of the wider (measured-exact) class in %d kernels" % (len(hits), len(per)))
+        return 0
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mindaudio_amd",
                                                               "lib", "libmindaudio_amd.so")
     found, n_pk = hazards(lib)

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _pair(num_blocks, seed=0, cmvn=False):
+def _pair(num_blocks, seed=0, cmvn=False, attn_gain=1.0):
     import torch
 
     from mindaudio_amd.models import ConformerEncoder
@@ -36,6 +36,14 @@ def _pair(num_blocks, seed=0, cmvn=False):
             if isinstance(m, C.LayerNorm):
                 m.gamma.uniform_(0.8, 1.2)
                 m.beta.normal_(0, 0.1)
+        if attn_gain != 1.0:
+            # trained-like attention statistics: at random init the logits are ~ +-0.3 and the softmax is near-uniform, which hides
+            # weighting errors (round 5's attentive-pooling bug passed a model-level test that way); scale q, k, pos and the biases so
+            # that the logits have a standard deviation of several units and a few keys carry most of the mass
+            for name, prm in ref.named_parameters():
+                if name.endswith(("self_attn.linear_q.weight", "self_attn.linear_k.weight", "self_attn.linear_pos.weight",
+                                  "self_attn.pos_bias_u", "self_attn.pos_bias_v")):
+                    prm.mul_(attn_gain)
     dut = ConformerEncoder(80, 256, 4, 2048, num_blocks, global_cmvn=(mean, istd) if cmvn else None).eval()
     missing, unexpected = dut.load_state_dict(ref.state_dict(), strict=False)
     assert not missing and not [k for k in unexpected if "cmvn" not in k], (missing, unexpected)
@@ -74,6 +82,49 @@ def test_encoder_matches_oracle(blocks, b, tlen, cmvn, general):
     rel_rms = float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
     assert rel_rms <= 2e-2, rel_rms
     assert float(err.abs().max()) <= 0.15, float(err.abs().max())
+
+
+@pytest.mark.parametrize("blocks,b,tlen,general", [(2, 3, 203, False), (2, 3, 203, True), (2, 18, 1000, False)])
+def test_encoder_with_peaky_attention_matches_oracle(blocks, b, tlen, general):
+    """the encoder against the oracle with TRAINED-LIKE attention statistics.  The q / k / positional projections and
+    the u / v biases are scaled 3.5 x, so the attention logits have a standard deviation of ~4 (random init: ~0.3) and a softmax row
+    puts most of its mass on a few keys: a kernel that weighted frames wrongly (a tile treated as uniform, a wrong key offset, a mask
+    applied one frame off) would now move the output far outside the bound, where near-uniform weights hide it."""
+    import torch
+
+    from oracle import conformer_oracle as C
+
+    ref, dut = _pair(blocks, seed=11, cmvn=True, attn_gain=3.5)
+    if general:
+        dut.fuse_min_rows = 1000000
+    g = torch.Generator().manual_seed(6)
+    xs = torch.randn(b, tlen, 80, generator=g)
+    lens = ([tlen, tlen - 40, tlen // 2] + [tlen - 7 * i for i in range(3, b)])[:b]
+    mask = torch.zeros(b, 1, tlen)
+    for i, n in enumerate(lens):
+        mask[i, 0, :n] = 1
+    sub = C.subsample_mask(mask)
+    with torch.no_grad():
+        want, _ = ref(xs, sub)
+    got, _ = dut(xs.cuda(), sub.cuda())
+    err = got.cpu() - want
+    rel_rms = float(err.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    # bf16 logits of magnitude ~10 carry ~0.04 absolute error -> a few per cent on the softmax weights: looser than the 2e-2 of the
+    # near-uniform case, far below the O(1) error of a mis-weighted row
+    assert rel_rms <= 4e-2, rel_rms
+    assert float(err.abs().max()) <= 0.5, float(err.abs().max())
+    # and the weights really are peaky: perturbing ONE key frame's features moves other frames' outputs (attention reads it), by much
+    # more than it does in the near-uniform model
+    xs2 = xs.clone()
+    xs2[0, 100:104] += 3.0
+    with torch.no_grad():
+        want2, _ = ref(xs2, sub)
+    got2, _ = dut(xs2.cuda(), sub.cuda())
+    far = slice(40, 50)  # frames 160-200 of the input: outside the conv module's and the subsampling's reach of frames 100-104
+    moved_ref = float((want2[0, far] - want[0, far]).abs().max())
+    moved_dut = float((got2.cpu()[0, far] - got.cpu()[0, far]).abs().max())
+    assert moved_ref > 0.05, moved_ref  # (the attention path carries it)
+    assert abs(moved_dut - moved_ref) <= 0.35 * moved_ref + 0.05, (moved_dut, moved_ref)
 
 
 def test_encoder_with_chunk_masks_matches_oracle():

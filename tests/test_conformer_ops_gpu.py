@@ -370,8 +370,9 @@ def test_subsample_conv1(t, tt, idim, c, cmvn, transposed):
 
 # T = 1000: the north-star utterance (37 tiles of 128 positions, the last one ragged); 103 / 41: ragged last tiles with few output rows;
 # 7: one output row, one tile; both input layouts, with and without CMVN
+# (12, 1000): 12 x 74 tiles = 888 workgroups, more than three resident rounds
 @pytest.mark.parametrize("b,tt,cmvn,transposed", [(2, 1000, True, True), (3, 103, True, False), (2, 41, False, True),
-                                                   (1, 7, True, False), (5, 300, False, False)])
+                                                   (1, 7, True, False), (5, 300, False, False), (12, 1000, True, False)])
 def test_subsample_fused(t, b, tt, cmvn, transposed):
     """CMVN + conv1 + ReLU + conv2 + ReLU in one launch (act1 only in LDS, computed on the matrix pipe from bf16 head + tail splits)
     against the float64 reference and against the two-kernel path it replaces (act1 from a float32 FMA chain; another summation
@@ -419,7 +420,7 @@ def test_subsample_fused(t, b, tt, cmvn, transposed):
     assert float((gd - ref2).abs().max()) <= 2 ** -7 * scale
 
 
-@pytest.mark.parametrize("b,tt", [(2, 64), (3, 249), (1, 301)])
+@pytest.mark.parametrize("b,tt", [(2, 64), (3, 249), (1, 301), (70, 249)])
 def test_relpos_attention(t, b, tt):
     from mindaudio_amd import ops
 
@@ -428,7 +429,7 @@ def test_relpos_attention(t, b, tt):
     pos = _rand(t, tt, 256, seed=41).bfloat16()
     u = _rand(t, h, dk, seed=42, scale=0.2)
     v = _rand(t, h, dk, seed=43, scale=0.2)
-    lens = [tt, max(1, tt - 37), max(1, tt // 2)][:b]
+    lens = ([tt, max(1, tt - 37), max(1, tt // 2)] + [max(1, tt - 3 * i) for i in range(3, b)])[:b]
     mask = t.zeros(b, tt)
     for i, n in enumerate(lens):
         mask[i, :n] = 1.0

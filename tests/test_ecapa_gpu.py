@@ -158,7 +158,9 @@ def test_res2net_long_utterances_fall_back():
     assert float((got - want).norm() / want.norm()) < 3e-2
 
 
-@pytest.mark.parametrize("b,t,c", [(1, 1, 256), (2, 15, 256), (3, 16, 512), (2, 17, 256), (3, 33, 1536), (5, 300, 1536), (2, 64, 3072)])
+# (300, 33, 1536): 1 800 workgroups = seven resident rounds (every kernel once above the chip's residency, against float64)
+@pytest.mark.parametrize("b,t,c", [(1, 1, 256), (2, 15, 256), (3, 16, 512), (2, 17, 256), (3, 33, 1536), (5, 300, 1536), (2, 64, 3072),
+                                   (300, 33, 1536)])
 def test_asp_fused_entry_point_against_float64(b, t, c):
     """ma_asp_fused_bf16 alone (ecapatdnn.py:296-308) at tile boundaries of the frame axis (16-frame tiles, prefetch three tiles
     ahead: T = 1, 15, 16, 17, 33) against a float64 evaluation of the same bf16 operands."""
@@ -223,8 +225,9 @@ def test_linear_small_entry_point_against_float64(m, n, k):
     assert lib.ma_linear_small_bf16(ad.data_ptr(), k, wd.data_ptr(), k, bd.data_ptr(), out.data_ptr(), n, m - 1, n, k, None) == _lib.MA_ERR_UNSUPPORTED
 
 
+# (64, 800, 20, 2) / (128, 780, 9, 3): one workgroup per utterance, 800 / 780 workgroups = more than three resident rounds
 @pytest.mark.parametrize("cc,b,t,d", [(64, 1, 1, 2), (64, 2, 20, 3), (64, 3, 57, 4), (128, 2, 33, 2), (128, 1, 300, 3), (64, 2, 376, 4),
-                                       (128, 2, 376, 4)])
+                                       (128, 2, 376, 4), (64, 800, 20, 2), (128, 780, 9, 3)])
 def test_res2net_fused_entry_point_against_float64(cc, b, t, d):
     """ma_res2net_fused_bf16 alone (Res2NetBlock, ecapatdnn.py:66-114: y_0 = x_0, y_i = BN(ReLU(conv_{k=3, dilation d}(x_i + y_{i-1})))
     on 8 channel groups) against a float64 chain with the kernel's rounding points (bf16 operands, bf16 y, bf16 x_i + y_{i-1})."""
@@ -269,8 +272,9 @@ def test_res2net_fused_entry_point_against_float64(cc, b, t, d):
     assert float(got[:, :H].abs().max()) == 0.0 and float(got[:, H + t:].abs().max()) == 0.0  # halo frames stay zero
 
 
+# (800, 20, 512, 128): one workgroup per utterance, 800 workgroups
 @pytest.mark.parametrize("b,t,c,s_", [(1, 1, 512, 128), (3, 57, 512, 128), (2, 300, 512, 64), (2, 333, 512, 128), (3, 100, 1024, 128),
-                                      (2, 300, 1024, 16)])
+                                      (2, 300, 1024, 16), (800, 20, 512, 128)])
 def test_se_block_entry_point_equals_the_three_launches(b, t, c, s_):
     """ma_se_block_bf16 (squeeze + excitation + scale + residual, ecapatdnn.py:150-157, 246) against ma_time_mean_bf16 +
     ma_se_gate_bf16 + ma_se_apply_bf16 on the same buffers (same rounding points: bf16 mean and gate), halo frames zero, and

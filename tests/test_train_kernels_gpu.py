@@ -187,9 +187,11 @@ def test_act_dropout_and_dropout_add(K):
         assert rel(dy, bf(0.5 * gg * keep.float() / 0.9 * rs[:, None]).float()) < 1e-6
 
 
-def test_convmid_train_fwd_bwd(K):
+# (64, 255): 16 strips x 64 utterances = 1 024 workgroups in the forward and the backward launch (more than three resident rounds)
+@pytest.mark.parametrize("b,t", [(3, 37), (64, 255)])
+def test_convmid_train_fwd_bwd(K, b, t):
     g = torch.Generator().manual_seed(4)
-    b, t, c, ks = 3, 37, 256, 15
+    c, ks = 256, 15
     y = bf(torch.randn(b * t, 2 * c, generator=g))
     dw_w = (0.3 * torch.randn(c, ks, generator=g)).requires_grad_()
     dw_b = (0.1 * torch.randn(c, generator=g)).requires_grad_()
@@ -328,7 +330,8 @@ def test_adam_and_overflow(K):
 
 
 @pytest.mark.parametrize("chunked", [False, True])
-@pytest.mark.parametrize("b,t", [(2, 100), (3, 255), (1, 64), (2, 37), (2, 300), (1, 129)])
+# (64, 255): 64 x 4 heads x 4 slabs = 1 024 workgroups per backward kernel (more than three resident rounds of 256 CUs)
+@pytest.mark.parametrize("b,t", [(2, 100), (3, 255), (1, 64), (2, 37), (2, 300), (1, 129), (64, 255)])
 def test_attention_backward(K, b, t, chunked):
     g = torch.Generator().manual_seed(7 + t)
     h, dk = 4, 64
@@ -546,7 +549,9 @@ def test_fused_dense_layers_equal_their_unfused_launches(K):
     assert torch.equal(g_new, g_ref) and torch.equal(dn, dn_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
 
 
-@pytest.mark.parametrize("m,hid,chain", [(1000, 2048, True), (10200, 2048, False), (49, 256, False), (48, 512, True), (1, 256, False)])
+# (40000, 2048): 834 workgroups of 48 rows = more than three resident rounds, against float64 like the others
+@pytest.mark.parametrize("m,hid,chain", [(1000, 2048, True), (10200, 2048, False), (49, 256, False), (48, 512, True), (1, 256, False),
+                                         (40000, 2048, True)])
 def test_feed_forward_module_in_one_launch(K, m, hid, chain):
     """ma_ffn_train_bf16 against the two launches it replaces (ma_gemm_k256_train_bf16 mode 1 + ma_gemm_rows_train_bf16 mode 3, same
     dropout sites) and against float64: the dropout masks are the SAME element for element; u differs by at most one bf16 ulp (the
@@ -620,7 +625,7 @@ def test_feed_forward_module_in_one_launch(K, m, hid, chain):
         K.ffn_train(a, pk, hid + 64, b1, p, seed, 3, b2, x, 0.5, p, 4)
 
 
-@pytest.mark.parametrize("m,hid", [(1000, 2048), (10200, 2048), (49, 256), (1, 512)])
+@pytest.mark.parametrize("m,hid", [(1000, 2048), (10200, 2048), (49, 256), (1, 512), (40000, 2048)])
 def test_feed_forward_module_backward_in_one_launch(K, m, hid):
     """ma_ffn_train_bwd_bf16 (dh -> du -> da -> LayerNorm backward, one launch, on the gk = swish' * keep / (1 - p) tape of the one-launch
     forward) against float64 and against the two launches it replaces (ma_gemm_k256_train_bf16 mode 2 on the bf16 u of the two-launch
@@ -845,7 +850,7 @@ def test_conv2_weight_gradient_on_256_tiles(K, b2, h2, w2):
     assert rel(dw2.view(co2, 3, 3, c2) - 1.0, wgt2.grad.permute(0, 2, 3, 1)) < 3e-5 and rel(db2 - 1.0, bias2.grad) < 3e-5
 
 
-@pytest.mark.parametrize("m,k", [(1000, 2048), (10200, 768), (97, 512)])
+@pytest.mark.parametrize("m,k", [(1000, 2048), (10200, 768), (97, 512), (50000, 768)])
 def test_input_gradient_product_with_layernorm_backward_epilogue(K, m, k):
     """ma_gemm_rows_train_bf16 mode 5 (round 4: da = du . W, the LayerNorm backward that consumes it and the next branch's dropout
     backward in ONE launch) against the two launches it replaces (dense_plain + layernorm_bwd_next): the same formulas with row sums

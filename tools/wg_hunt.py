@@ -72,6 +72,9 @@ def main():
                     help="wgsplit only: the batched sums on the MAIN stream (one block late), only the grouped products on the second")
     ap.add_argument("--group", type=int, default=6, help="dw_group_blocks of the engine (0 = split-K products per block)")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--unfused-ln", action="store_true",
+                    help="round 4's launch set: LayerNorm backwards as launches of their own (ffn_bwd_one_launch, ln_bwd_fused and "
+                         "ln_final_chained off) - layernorm_bwd_kernel is back at the place in the chain where round 4's victim ran")
     ap.add_argument("--same-batch", action="store_true")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -103,6 +106,11 @@ def main():
     eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=4, dropout_rate=0.1, positional_dropout_rate=0.1,
                                 dw_group_blocks=0 if a.mode == "wgsplit" else a.group, force_collective=a.mode == "rccl")
     eng._wg_from = 0
+    if a.unfused_ln:
+        eng.ffn_bwd_one_launch = eng.ln_bwd_fused = eng.ln_final_chained = False
+        eng.block_tables = False
+        eng._pack_plan = None  # (the backward's packed weight forms depend on the switches)
+        eng._pack_weights()
     if a.tn_lds:
         from mindaudio_amd import _lib as L
 

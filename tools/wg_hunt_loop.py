@@ -70,9 +70,12 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--diag", action="store_true")
     ap.add_argument("--group", type=int, default=6)
+    ap.add_argument("--unfused-ln", action="store_true", help="every child (references included) with round 4's LayerNorm-backward launches")
     a = ap.parse_args()
     if a.diag:
         COMMON.append("--diag")
+    if a.unfused_ln:
+        COMMON.append("--unfused-ln")
     os.makedirs(OUT, exist_ok=True)
     arms = a.arms.split(",")
     # one single-stream reference per product form: direct groups (the engine's default) and round 3's split-K grids (arm `wgsplit`)

@@ -39,7 +39,7 @@ typedef __attribute__((address_space(3))) void t8_lds_t;
 typedef __attribute__((address_space(1))) const void t8_gl_t;
 
 constexpr int kT8Threads = 512, kT8BK = 64, kT8Unit = 64 * 256, kT8Buf = 4 * kT8Unit, kT8Lds = 2 * kT8Buf;
-constexpr int kT8Max = 48;
+constexpr int kT8Max = 56;  // (56 x 64 B + 8 = 3 592 B of kernel arguments; 6 encoder blocks = 48 products + the decoder's 6 long ones)
 
 struct Tn8Item {  // 64 bytes: 48 of them travel in the kernel arguments
   const uint16_t* A;

@@ -328,6 +328,11 @@ class ConformerCTCTrainStep:
         self.Ld = len(self.dec.decoders) if self.dec is not None else 0
         self.dec_hidden = self.dec.decoders[0].feed_forward.w_1.out_features if self.dec is not None else 0
         self.last_acc = None
+        # decoder_fused_launches: the TransformerDecoder's layers on the fused launches of the encoder blocks (dense + dropout + residual
+        # + LayerNorm in one launch on packed weights; LayerNorm backward + the next dropout backward in one): 16 + 16 -> 10 + 12
+        # launches per layer (round 6).  False: one launch per reference cell (what the float32 validation mode always runs).
+        self.decoder_fused_launches = True
+        self._dec_long_dw, self._dec_bucket_pending, self._dec_rows = True, False, 1
         self._build_flat()
         self.flag = self.fp.flag  # zeroed with the gradients at the start of forward_backward
         self.reducer = BucketedAllReduce(self.fp.grad, self.world, self.pg, force_collective)
@@ -549,6 +554,12 @@ class ConformerCTCTrainStep:
               ("qkv_w.tr", "qkv_w", True, 1), ("o_w.k", "o_w", False, 0), ("o_w.tk", "o_w", True, 0), ("pw1_w.k", "pw1_w", False, 0),
               ("pw1_w.tr", "pw1_w", True, 1), ("pw2_w.k", "pw2_w", False, 0), ("pw2_w.tk", "pw2_w", True, 0))
 
+    # the TransformerDecoder's dense layers (fused bf16 mode, round 6): same two layouts, names d<layer>.<key>
+    _PACKS_DEC = (("sa_qkv_w.k", "sa_qkv_w", False, 0), ("sa_qkv_w.tr", "sa_qkv_w", True, 1), ("sa_o_w.k", "sa_o_w", False, 0),
+                  ("sa_o_w.tk", "sa_o_w", True, 0), ("ca_q_w.k", "ca_q_w", False, 0), ("ca_q_w.tk", "ca_q_w", True, 0),
+                  ("ca_kv_w.k", "ca_kv_w", False, 0), ("ca_o_w.k", "ca_o_w", False, 0), ("ca_o_w.tk", "ca_o_w", True, 0),
+                  ("ff_w1.k", "ff_w1", False, 0), ("ff_w2.tk", "ff_w2", True, 0))
+
     _PACKS_FFN = (("ffm.f", "ffm_w1", False, 2), ("ffm.f", "ffm_w2", False, 3), ("ff.f", "ff_w1", False, 2), ("ff.f", "ff_w2", False, 3))
     _PACKS_FFN_T = (("ffm.ft", "ffm_w2", True, 2), ("ffm.ft", "ffm_w1", True, 3), ("ff.ft", "ff_w2", True, 2), ("ff.ft", "ff_w1", True, 3))
 
@@ -584,6 +595,21 @@ class ConformerCTCTrainStep:
                         continue
                     specs.append(("l%d.%s" % (li, key), w, n, k, kind, pieces, total))
                     total += pieces * 16 * (2 if kind == 2 else 1)
+            self.dec_fused = False
+            if self.dec is not None and self.d == 256 and self.dec_hidden % 256 == 0:
+                dec_specs, ok = [], True
+                for li in range(self.Ld):
+                    for key, src, transposed, kind in self._PACKS_DEC:
+                        w = self.wt["d%d.%s" % (li, src)] if transposed else self.fp.w("d%d.%s" % (li, src))
+                        n, k = w.shape[0], (self.fp.w("d%d.%s" % (li, src)).shape[0] if transposed else w.shape[1])
+                        pieces = int(lib.ma_pack_item_pieces(kind, n, k))
+                        if pieces <= 0:
+                            ok = False
+                        dec_specs.append(("d%d.%s" % (li, key), w, n, k, kind, pieces, total))
+                        total += max(pieces, 0) * 16
+                if ok:  # (a shape a pack kind does not cover: the decoder keeps its one-launch-per-cell walk)
+                    specs += dec_specs
+                    self.dec_fused = True
             arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
             for name, w, n, k, kind, pieces, off in specs:
                 self.pk[name] = arena[off:off + pieces * 16 * (2 if kind in (2, 3) else 1)]
@@ -788,7 +814,8 @@ class ConformerCTCTrainStep:
         if not (self.block_tables and self.fused and self._dw_direct and self._wg is None and plan is not None and not self.x32):
             return None
         key = (b, t2, tuple(att_shape), self.ffn_one_launch, self.ffn_bwd_one_launch, self.ln_final_chained,
-               self.ln_bwd_fused, self.dw_group_blocks, self.p_drop, self.p_pos, self.bn_momentum, id(plan["arena"]))
+               self.ln_bwd_fused, self.dw_group_blocks, self.p_drop, self.p_pos, self.bn_momentum, id(plan["arena"]),
+               self.decoder_fused_launches)
         tables = plan.setdefault("tables", {})
         tb = plan["table"] = tables.get(key)  # (plan["table"]: the one in use, for tests and tools)
         if tb is None:
@@ -900,6 +927,16 @@ class ConformerCTCTrainStep:
                 self.K.gemm_tn_direct_ok(dy, x, fp.g(wname)):
             # a decoder layer's weight gradient: with the other 41 of the decoder in ONE grid at the end of its backward pass
             # (they were 43 split-K products + 88 reduction launches of ~10 us each: the hybrid step's decoder is launch-bound)
+            if self._dec_long_dw and dy.shape[0] > 4 * self._dec_rows:
+                # a decoder product over the ENCODER's rows (ca_kv_w: dkv^T memory, 10 200 rows against the decoder's 1 240): in the
+                # decoder's grid its 2 tiles per layer ran 400 us with 244 CUs idle behind them (the grid lasts as long as its longest
+                # tile).  It joins the encoder's first direct group instead - 234 + 12 tiles, still one resident round, every tile with a
+                # full-length contraction; the decoder's gradient bucket goes on the wire behind that group (_dec_bucket_pending).
+                if self._dq is None:
+                    self._dq = self.K.DirectGroup()
+                self._dq.add(dy, x, fp.g(wname), fp.g(bname))
+                self._dec_bucket_pending = True
+                return
             if self._dq_dec is None:
                 self._dq_dec = self.K.DirectGroup()
             self._dq_dec.add(dy, x, fp.g(wname), fp.g(bname))
@@ -1064,6 +1101,7 @@ class ConformerCTCTrainStep:
         if self._dq_dec is not None:
             self._dq_dec.clear()
         self._dq_blocks.clear()
+        self._dec_bucket_pending = False
         # (experimental second stream: used from step _wg_from of a batch shape on - round 3's mitigation, kept; tools/wg_hunt.py sets 0)
         key = (b, t, idim)
         seen = self._wg_seen.get(key, 0)
@@ -1329,6 +1367,7 @@ class ConformerCTCTrainStep:
                 if len(self._dq_blocks) >= self.dw_group_blocks or li == 0:
                     for blk in self._dq_blocks:
                         self.reducer.launch(*self.fp.span(self.layer_names[blk]))
+                    self._launch_deferred_dec_bucket()
                     self._dq_blocks.clear()
             return
         if tb is not None:
@@ -1458,6 +1497,7 @@ class ConformerCTCTrainStep:
             with tb["table"].recording(seed):
                 dtb["out"] = self._decoder_walk(mem_bf, enc_mask2d, b_, t2, L1, toks, sub, pe, tgt, tmask, gscale, seed, tb["table"],
                                                 dtb["ls"])
+            dtb["bucket_deferred"] = self._dec_bucket_pending  # (the replayed steps launch the bucket where the walked one did)
             stats, d_mem = dtb["out"]
         else:
             table, stream, L, Ld = tb["table"], _host.current_stream_ptr(), self.L, self.Ld
@@ -1472,7 +1512,8 @@ class ConformerCTCTrainStep:
             for li in reversed(range(Ld)):
                 table.backward(L + li, seed, stream)
             table.backward(L + Ld, seed, stream)
-            if self.dec_names:
+            self._dec_bucket_pending = bool(dtb.get("bucket_deferred"))
+            if self.dec_names and not self._dec_bucket_pending:
                 self.reducer.launch(*self.fp.span(self.dec_names))
             stats, d_mem = dtb["out"]
         self.last_acc = stats[1] / stats[2]
@@ -1496,6 +1537,9 @@ class ConformerCTCTrainStep:
         xscale = math.sqrt(d)
         seg = (lambda backward, blk: rec.segment(backward, blk)) if rec is not None else (lambda backward, blk: None)
         L, Ld = self.L, self.Ld
+        self._dec_rows = md  # (what _dW compares a product's contraction length with)
+        if self.fused and getattr(self, "dec_fused", False) and self.decoder_fused_launches:
+            return self._decoder_walk_fused(mem_bf, emask, b, t2, L1, toks, sub, pe, tgt, tmask, gscale, seed, rec, ls, seg)
         seg(False, L + Ld)
         x = K.embed_posenc(toks, fp.p("dec.embed"), pe, L1, xscale, pp, seed, salt(-1, 0))
         tape = []
@@ -1591,6 +1635,133 @@ class ConformerCTCTrainStep:
         self.last_acc = stats[1] / stats[2]
         return stats[0] / (stats[2] if self.len_norm else b), d_mem
 
+    def _decoder_walk_fused(self, mem_bf, emask, b, t2, L1, toks, sub, pe, tgt, tmask, gscale, seed, rec, ls, seg):
+        """_decoder_walk on the fused launches the encoder blocks already use (round 6; bf16 mode, d_model 256): per layer 10 forward
+        launches instead of 16 - every [dense + dropout + residual + the LayerNorm of the next cell] is ONE launch on a packed weight
+        (K.dense_join), the other dense layers run on packed weights (K.dense_plain: the B x 31-token products are latency, not
+        flops) - and 12 backward launches instead of 16: every LayerNorm backward emits the NEXT branch's dropout backward
+        (K.layernorm_bwd_next), the input-gradient products run on the packed transposed weights.  Same tape, same dropout sites
+        and salts, same rounding points as the walk above (the join rounds a W^T + b to bf16 before the dropout, as ops.gemm's bf16
+        output does); the products sum in another order.  models/conformer.py:382-639, the hybrid step was 551 launches."""
+        fp, d, dec = self.fp, self.d, self.dec
+        K = self.K
+        tt = _host.torch()
+        f32 = torch.float32
+        pd, pp = float(dec.dropout_rate), float(dec.positional_dropout_rate)
+        eps = 1e-12
+        dk = d // self.heads
+        scale = 1.0 / dk
+        md, m = b * L1, b * t2
+        self._dec_rows = md
+        hid = self.dec_hidden
+        RELU = _lib.ACT_RELU
+        salt = lambda li, site: self._salt(100 + li, site)  # noqa: E731
+        xscale = math.sqrt(d)
+        L, Ld = self.L, self.Ld
+        seg(False, L + Ld)
+        x = K.embed_posenc(toks, fp.p("dec.embed"), pe, L1, xscale, pp, seed, salt(-1, 0))
+        a = ops.layernorm(x, fp.p("d0.norm1.g"), fp.p("d0.norm1.b"), eps=eps)
+        tape = []
+        for li in range(Ld):
+            seg(False, L + li)
+            pre = "d%d." % li
+            P, PK = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: self.pk[pre + n])
+            T = {"x0": x, "a": a}
+            qkv = K.dense_plain(a, PK("sa_qkv_w.k"), 3 * d, d, bias=P("sa_qkv_b"))
+            ctx, probs = K.mha_small_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], sub, 2, b, L1, L1, scale, self.heads, dk)
+            x1, a2, _ = K.dense_join(ctx, PK("sa_o_w.k"), d, P("sa_o_b"), x, 1.0, pd, seed, salt(li, 0),
+                                     ln1=(P("norm2.g"), P("norm2.b")), eps=eps)
+            T.update(qkv=qkv, ctx=ctx, probs=probs, x1=x1, a2=a2)
+            q = K.dense_plain(a2, PK("ca_q_w.k"), d, d, bias=P("ca_q_b"))
+            kv = K.dense_plain(mem_bf, PK("ca_kv_w.k"), 2 * d, d, bias=P("ca_kv_b"))
+            ctx2, probs2 = K.mha_small_fwd(q, kv[:, :d], kv[:, d:], emask, 1, b, L1, t2, scale, self.heads, dk)
+            x2, a3, _ = K.dense_join(ctx2, PK("ca_o_w.k"), d, P("ca_o_b"), x1, 1.0, pd, seed, salt(li, 1),
+                                     ln1=(P("norm3.g"), P("norm3.b")), eps=eps)
+            T.update(q=q, kv=kv, ctx2=ctx2, probs2=probs2, x2=x2, a3=a3)
+            u = K.dense_plain(a3, PK("ff_w1.k"), hid, d, bias=P("ff_b1"))
+            h = K.act_dropout_fwd(u, pd, seed, salt(li, 2), act=RELU)
+            nxt = (fp.p("d%d.norm1.g" % (li + 1)), fp.p("d%d.norm1.b" % (li + 1))) if li + 1 < Ld else \
+                (fp.p("dec.after_norm.g"), fp.p("dec.after_norm.b"))
+            # (K = 2048 against 1 240 rows: on the row-owner kernel 26 workgroups each stream the whole weight - 30 us; the general GEMM
+            # spreads the columns over workgroups: 10 + 5 + 5 us for the product, the join and the LayerNorm)
+            y = ops.gemm(h, fp.w(pre + "ff_w2"), bias=P("ff_b2"))
+            x = K.dropout_add(x2, y, 1.0, pd, seed, salt(li, 3))
+            a = ops.layernorm(x, nxt[0], nxt[1], eps=eps)
+            T.update(u=u, h=h)
+            tape.append(T)
+        seg(False, L + Ld + 1)
+        yb = a  # = LayerNorm(x; dec.after_norm), emitted by the last layer's join
+        logits = tt.empty((md, self.Vp), dtype=f32, device=self.dev)
+        ops.gemm(yb, fp.w("dec.out_w"), bias=fp.p("dec.out_b"), out_dtype=f32, out=logits[:, :self.V])
+        seg(None, 0)  # (the loss takes the step's loss scale as an argument: never replayed with a recorded one)
+        stats, dlog = K.label_smoothing_loss_grad(logits, self.V, tgt, tmask, self.lsm, gscale, normalize_length=self.len_norm,
+                                                  **({} if ls is None else {"bufs": ls}))
+        if ls is not None:
+            ls["logits"] = logits
+        # ---- backward ----
+        seg(False, L + Ld + 2)
+        K.gemm_tn(dlog, yb, fp.g("dec.out_w"), colsum=fp.g("dec.out_b"), rows_store=self.V)
+        dy = self._dX(dlog, "dec.out_w")
+        g = tt.empty((md, d), dtype=f32, device=self.dev)
+        # after_norm's backward emits the dropout backward of the last layer's feed-forward join
+        _, dyf = K.layernorm_bwd_next(x, fp.p("dec.after_norm.g"), dy, g, fp.g("dec.after_norm.g"), fp.g("dec.after_norm.b"),
+                                      (1.0, pd, seed, salt(Ld - 1, 3), None), accumulate=False, eps=eps)
+        d_mem = tt.empty((m, d), dtype=f32, device=self.dev)  # (stored by the last layer's product, added to by the others: no fill)
+        for li in reversed(range(Ld)):
+            seg(True, L + li)
+            pre = "d%d." % li
+            P, G, PK = (lambda n, pre=pre: fp.p(pre + n)), (lambda n, pre=pre: fp.g(pre + n)), (lambda n, pre=pre: self.pk[pre + n])
+            T = tape[li]
+            # feed-forward
+            self._dW(dyf, T["h"], pre + "ff_w2", pre + "ff_b2")
+            dh = K.dense_plain(dyf, PK("ff_w2.tk"), hid, d)
+            du = K.act_dropout_bwd(T["u"], dh, pd, seed, salt(li, 2), out=dh, act=RELU)
+            self._dW(du, T["a3"], pre + "ff_w1", pre + "ff_b1")
+            da = self._dX(du, pre + "ff_w1")  # (K = 2048: the general GEMM, see the forward)
+            _, do = K.layernorm_bwd_next(T["x2"], P("norm3.g"), da, g, G("norm3.g"), G("norm3.b"), (1.0, pd, seed, salt(li, 1), None),
+                                         eps=eps)
+            # source attention
+            self._dW(do, T["ctx2"], pre + "ca_o_w", pre + "ca_o_b")
+            dctx = K.dense_plain(do, PK("ca_o_w.tk"), d, d)
+            dq = tt.empty_like(T["q"])
+            dkv = tt.empty_like(T["kv"])
+            K.mha_small_bwd(T["q"], T["kv"][:, :d], T["kv"][:, d:], T["probs2"], T["ctx2"], dctx, b, L1, t2, scale, dq,
+                            dkv[:, :d], dkv[:, d:], self.heads, dk)
+            self._dW(dq, T["a2"], pre + "ca_q_w", pre + "ca_q_b")
+            daq = K.dense_plain(dq, PK("ca_q_w.tk"), d, d)
+            _, do = K.layernorm_bwd_next(T["x1"], P("norm2.g"), daq, g, G("norm2.g"), G("norm2.b"), (1.0, pd, seed, salt(li, 0), None),
+                                         eps=eps)
+            self._dW(dkv, mem_bf, pre + "ca_kv_w", pre + "ca_kv_b")
+            self._dX(dkv, pre + "ca_kv_w", residual=d_mem if li < Ld - 1 else None, out_dtype=f32, out=d_mem)
+            # self attention
+            self._dW(do, T["ctx"], pre + "sa_o_w", pre + "sa_o_b")
+            dctx = K.dense_plain(do, PK("sa_o_w.tk"), d, d)
+            dqkv = tt.empty_like(T["qkv"])
+            qkv = T["qkv"]
+            K.mha_small_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], T["probs"], T["ctx"], dctx, b, L1, L1, scale,
+                            dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], self.heads, dk)
+            self._dW(dqkv, T["a"], pre + "sa_qkv_w", pre + "sa_qkv_b")
+            da = K.dense_plain(dqkv, PK("sa_qkv_w.tr"), d, 3 * d)
+            if li > 0:  # ... and emits the dropout backward of the feed-forward join of the layer below
+                _, dyf = K.layernorm_bwd_next(T["x0"], P("norm1.g"), da, g, G("norm1.g"), G("norm1.b"),
+                                              (1.0, pd, seed, salt(li - 1, 3), None), eps=eps)
+            else:
+                K.layernorm_bwd(T["x0"], P("norm1.g"), da, g, G("norm1.g"), G("norm1.b"), eps=eps)
+        seg(True, L + Ld)
+        K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0))
+        if self._dq_dec is not None:  # the decoder layers' weight gradients: one grid
+            self._dq_dec.launch()
+            self._dq_dec.clear()
+        if rec is not None:
+            rec.segment(None, 0)
+            rec.keep.append(tape)
+        if self.dec_names and not self._dec_bucket_pending:  # (pending: behind the encoder's first direct group, _flush_direct)
+            self.reducer.launch(*fp.span(self.dec_names))
+        if rec is not None:
+            return stats, d_mem
+        self.last_acc = stats[1] / stats[2]
+        return stats[0] / (stats[2] if self.len_norm else b), d_mem
+
     def _ffn_fwd(self, x, key, ln, W, P, seed, li, s0):
         ops, K = self.O, self.K
         a = ops.layernorm(x, P(ln + ".g"), P(ln + ".b"))
@@ -1676,17 +1847,27 @@ class ConformerCTCTrainStep:
                 with torch.cuda.stream(self._wg):
                     for b in self._dq_blocks:
                         self.reducer.launch(*self.fp.span(self.layer_names[b]))
+                    self._launch_deferred_dec_bucket()
             else:
                 for b in self._dq_blocks:
                     self.reducer.launch(*self.fp.span(self.layer_names[b]))
+                self._launch_deferred_dec_bucket()
         else:
             if self._dq is not None:
                 self._dq.launch()
             for b in self._dq_blocks:
                 self.reducer.launch(*self.fp.span(self.layer_names[b]))
+            self._launch_deferred_dec_bucket()
         if self._dq is not None:
             self._dq.clear()
         self._dq_blocks.clear()
+
+    def _launch_deferred_dec_bucket(self):
+        """The decoder's gradient bucket when some of its weight gradients ride in the encoder's first direct group (_dW)."""
+        if self._dec_bucket_pending:
+            self._dec_bucket_pending = False
+            if self.dec_names:
+                self.reducer.launch(*self.fp.span(self.dec_names))
 
     def _layer_begin(self, li):
         """Backward of block li starts: its partial sums go to arena half li & 1, which block li + 2 used."""

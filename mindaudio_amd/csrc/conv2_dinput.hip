@@ -333,7 +333,28 @@ __global__ __launch_bounds__(kD8Threads, 1) void conv2_dinput8_kernel(const DinP
   if (wr == 0) __builtin_amdgcn_s_barrier();  // (the barrier wave row 1 took at the start)
 
   // ---- epilogue: tile -> LDS (bf16, 528-byte rows), then whole 512-byte rows to their (b, h, w) positions with ReLU' -------------
+  // 32 lanes per row (16 bytes each): thread (r0 = tid >> 5, cc = tid & 31) owns rows r0 + 16 k, k = 0 .. 15.  The ReLU' operand
+  // (act1: 408 MB, cold) is requested for ALL 16 rows before the accumulators go to LDS (round 6): until then the loop fetched it four
+  // rows at a time right in front of the stores - four dependent HBM round trips per tile, ~8 of the ~19 us a tile spent outside its
+  // K loop (3 114 tiles, 12 per CU).  The fragment registers are dead here, so the 64 registers fit beside the 128 accumulators.
   __syncthreads();
+  const int cc = tid & 31, r0 = tid >> 5;
+  auto row_off = [&](int r) __attribute__((always_inline)) -> int64_t {  // element offset of tile row r in act / out; < 0: past the class
+    const int m = m0 + r;
+    if (m >= Mc) return -1;
+    const int t = d8_div(m, Wc, inv_wc), ww = m - t * Wc;
+    const int b = d8_div(t, Hc, inv_hc), hh = t - b * Hc;
+    return ((((int64_t)b * p.H + 2 * hh + ph) * p.Wd) + 2 * ww + pw) * p.C + cc * 8;
+  };
+  uint4 av[16];
+  if (p.act) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int64_t off = row_off(r0 + 16 * k);
+      av[k] = off >= 0 ? *reinterpret_cast<const uint4*>(p.act + off) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   const int em = lane & 15, en = (lane >> 4) * 4;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -342,18 +363,14 @@ __global__ __launch_bounds__(kD8Threads, 1) void conv2_dinput8_kernel(const DinP
       *reinterpret_cast<uint2*>(smem + (wr * 128 + i * 16 + em) * kD8CRow + (wc * 64 + j * 16 + en) * 2) =
           make_uint2(di_pack_bf16(acc[i][j][0], acc[i][j][1]), di_pack_bf16(acc[i][j][2], acc[i][j][3]));
   __syncthreads();
-  // 32 lanes per row (16 bytes each): thread (r0 = tid >> 5, cc = tid & 31) walks rows r0, r0 + 16, ...
-  const int cc = tid & 31;
-#pragma unroll 4
-  for (int r = tid >> 5; r < 256; r += 16) {
-    const int m = m0 + r;
-    if (m >= Mc) break;
-    const int t = d8_div(m, Wc, inv_wc), ww = m - t * Wc;
-    const int b = d8_div(t, Hc, inv_hc), hh = t - b * Hc;
-    const int64_t off = ((((int64_t)b * p.H + 2 * hh + ph) * p.Wd) + 2 * ww + pw) * p.C + cc * 8;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int r = r0 + 16 * k;
+    const int64_t off = row_off(r);
+    if (off < 0) continue;
     uint4 v = *reinterpret_cast<const uint4*>(smem + r * kD8CRow + cc * 16);
     if (p.act) {
-      const uint4 a = *reinterpret_cast<const uint4*>(p.act + off);
+      const uint4 a = av[k];
       auto gate = [](uint32_t x, uint32_t aw) -> uint32_t {
         const uint32_t lo = (__uint_as_float(aw << 16) > 0.0f) ? 0x0000ffffu : 0u;
         const uint32_t hi = (__uint_as_float(aw & 0xffff0000u) > 0.0f) ? 0xffff0000u : 0u;

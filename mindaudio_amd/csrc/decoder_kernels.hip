@@ -483,23 +483,60 @@ __global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4;
   const int Lq = p.Lq, Lk = p.Lk;
-  for (int i = tid; i < kSmQ * (kSmD / 8); i += 256) {
-    const int qi = i / (kSmD / 8), ch = i % (kSmD / 8);
+  // Staging with every load of a chunk in flight before the first LDS store (round 6).  As plain loops (one 16-byte load per thread
+  // and iteration, stored at once) the V tile of a 255-key source took ten dependent round trips and the K fragments of a wave four
+  // more: 24 us for a launch whose arithmetic is a few microseconds (B x heads = 160 workgroups of latency).
+  // the K fragments of this wave's first kKf key tiles are requested first of all (they are used right behind the barrier)
+  constexpr int kKf = 5;  // key tiles kt = wave + 4 i, i < kKf, held in registers (Lk <= 320: all of them)
+  sm_bf16x8 kfr[kKf][2];
+#pragma unroll
+  for (int i = 0; i < kKf; ++i) {
+    const int key = (wave + 4 * i) * 16 + lq, keyc = key < Lk ? key : Lk - 1;
+    const uint16_t* kp = p.k + ((int64_t)b * Lk + keyc) * p.ldk + h * kSmD + lg * 8;
+    kfr[i][0] = *reinterpret_cast<const sm_bf16x8*>(kp);
+    kfr[i][1] = *reinterpret_cast<const sm_bf16x8*>(kp + 32);
+  }
+  {
+    const int i = tid, qi = i / (kSmD / 8), ch = i % (kSmD / 8);  // kSmQ * kSmD / 8 = 256 pieces: one per thread
     uint4 a = make_uint4(0, 0, 0, 0);
     if (qi < Lq) a = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8);
+    constexpr int kCh = 10;
+    for (int base = tid; base < kcap * (kSmD / 8); base += 256 * kCh) {
+      uint4 val[kCh];
+#pragma unroll
+      for (int u = 0; u < kCh; ++u) {
+        const int iv = base + u * 256, kj = iv / (kSmD / 8), cv = iv % (kSmD / 8);
+        val[u] = make_uint4(0, 0, 0, 0);
+        if (iv < kcap * (kSmD / 8) && kj < Lk)
+          val[u] = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + cv * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < kCh; ++u) {
+        const int iv = base + u * 256, kj = iv / (kSmD / 8), cv = iv % (kSmD / 8);
+        if (iv < kcap * (kSmD / 8)) *reinterpret_cast<uint4*>(&Vs[kj][cv * 8]) = val[u];
+      }
+    }
     *reinterpret_cast<uint4*>(Qb + qi * kPq + ch * 8) = a;
   }
-  for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
-    const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (kj < Lk) val = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + ch * 8);
-    *reinterpret_cast<uint4*>(&Vs[kj][ch * 8]) = val;
-  }
   __syncthreads();
-  for (int kt = wave; kt * 16 < Lk; kt += 4) {
+  int kti = 0;
+  for (int kt = wave; kt * 16 < Lk; kt += 4, ++kti) {
     const int key = kt * 16 + lq, keyc = key < Lk ? key : Lk - 1;
-    const uint16_t* kp = p.k + ((int64_t)b * Lk + keyc) * p.ldk + h * kSmD + lg * 8;
-    const sm_bf16x8 kf0 = *reinterpret_cast<const sm_bf16x8*>(kp), kf1 = *reinterpret_cast<const sm_bf16x8*>(kp + 32);
+    sm_bf16x8 kf0, kf1;
+    if (kti < kKf) {  // (kti is wave-uniform; the unrolled select keeps the register array statically indexed)
+      kf0 = kfr[0][0];
+      kf1 = kfr[0][1];
+#pragma unroll
+      for (int i = 1; i < kKf; ++i)
+        if (kti == i) {
+          kf0 = kfr[i][0];
+          kf1 = kfr[i][1];
+        }
+    } else {
+      const uint16_t* kp = p.k + ((int64_t)b * Lk + keyc) * p.ldk + h * kSmD + lg * 8;
+      kf0 = *reinterpret_cast<const sm_bf16x8*>(kp);
+      kf1 = *reinterpret_cast<const sm_bf16x8*>(kp + 32);
+    }
     sm_f32x4 sc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -579,29 +616,56 @@ __global__ __launch_bounds__(256) void mha_small_bwd_mfma_kernel(const SmallAttn
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, lq = lane & 15, lg = lane >> 4, la = lq >> 2, lb = lq & 3;
   const int Lq = p.Lq, Lk = p.Lk;
-  for (int i = tid; i < kSmQ * (kSmD / 8); i += 256) {
-    const int qi = i / (kSmD / 8), ch = i % (kSmD / 8);
-    uint4 a = make_uint4(0, 0, 0, 0), c = a;
+  // Staging in chunks whose loads are ALL in flight before the first LDS store (round 6; see the forward kernel): the K / V tiles of a
+  // 255-key source were ten dependent round trips of two loads, the probabilities 31 of one.
+  {
+    const int qi = tid / (kSmD / 8), ch = tid % (kSmD / 8);  // kSmQ * kSmD / 8 = 256 pieces: one per thread
+    uint4 qa = make_uint4(0, 0, 0, 0), qc = qa;
     if (qi < Lq) {
-      a = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8);
-      c = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * Lq + qi) * lddc + h * kSmD + ch * 8);
+      qa = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8);
+      qc = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * Lq + qi) * lddc + h * kSmD + ch * 8);
     }
-    *reinterpret_cast<uint4*>(Qb + qi * kPq + ch * 8) = a;
-    *reinterpret_cast<uint4*>(dOb + qi * kPq + ch * 8) = c;
-  }
-  for (int i = tid; i < kcap * (kSmD / 8); i += 256) {
-    const int kj = i / (kSmD / 8), ch = i % (kSmD / 8);
-    uint4 a = make_uint4(0, 0, 0, 0), c = a;
-    if (kj < Lk) {
-      a = *reinterpret_cast<const uint4*>(p.k + ((int64_t)b * Lk + kj) * p.ldk + h * kSmD + ch * 8);
-      c = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + ch * 8);
+    constexpr int kCh = 5;
+    for (int base = tid; base < kcap * (kSmD / 8); base += 256 * kCh) {
+      uint4 ka[kCh], va[kCh];
+#pragma unroll
+      for (int u = 0; u < kCh; ++u) {
+        const int iv = base + u * 256, kj = iv / (kSmD / 8), cv = iv % (kSmD / 8);
+        ka[u] = va[u] = make_uint4(0, 0, 0, 0);
+        if (iv < kcap * (kSmD / 8) && kj < Lk) {
+          ka[u] = *reinterpret_cast<const uint4*>(p.k + ((int64_t)b * Lk + kj) * p.ldk + h * kSmD + cv * 8);
+          va[u] = *reinterpret_cast<const uint4*>(p.v + ((int64_t)b * Lk + kj) * p.ldv + h * kSmD + cv * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kCh; ++u) {
+        const int iv = base + u * 256, kj = iv / (kSmD / 8), cv = iv % (kSmD / 8);
+        if (iv < kcap * (kSmD / 8)) {
+          *reinterpret_cast<uint4*>(&Ks[kj][cv * 8]) = ka[u];
+          *reinterpret_cast<uint4*>(&Vs[kj][cv * 8]) = va[u];
+        }
+      }
     }
-    *reinterpret_cast<uint4*>(&Ks[kj][ch * 8]) = a;
-    *reinterpret_cast<uint4*>(&Vs[kj][ch * 8]) = c;
-  }
-  for (int i = tid; i < Lq * Lk; i += 256) {
-    const int qi = i / Lk, jj = i - qi * Lk;
-    S[qi * ss + jj] = probs[(((int64_t)b * p.H + h) * Lq + qi) * Lk + jj];
+    *reinterpret_cast<uint4*>(Qb + qi * kPq + ch * 8) = qa;
+    *reinterpret_cast<uint4*>(dOb + qi * kPq + ch * 8) = qc;
+    constexpr int kPc = 16;
+    const float* pb = probs + ((int64_t)b * p.H + h) * Lq * Lk;
+    for (int base = tid; base < Lq * Lk; base += 256 * kPc) {
+      float pv_[kPc];
+#pragma unroll
+      for (int u = 0; u < kPc; ++u) {
+        const int iv = base + u * 256;
+        pv_[u] = iv < Lq * Lk ? pb[iv] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kPc; ++u) {
+        const int iv = base + u * 256;
+        if (iv < Lq * Lk) {
+          const int qj = iv / Lk, jj = iv - qj * Lk;
+          S[qj * ss + jj] = pv_[u];
+        }
+      }
+    }
   }
   __syncthreads();
   if (tid < Lq) {

@@ -1896,7 +1896,7 @@ class ConformerCTCTrainStep:
 
     def _launch_deferred_dec_bucket(self):
         """The decoder's gradient bucket when some of its weight gradients ride in the encoder's first direct group (_dW)."""
-        if self._dec_bucket_pending:
+        if getattr(self, "_dec_bucket_pending", False):
             self._dec_bucket_pending = False
             if self.dec_names:
                 self.reducer.launch(*self.fp.span(self.dec_names))

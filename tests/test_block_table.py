@@ -160,11 +160,14 @@ def test_a_seed_mismatch_while_recording_marks_the_table_instead_of_raising():
         tab.segment(None, 0)
 
 
+@pytest.mark.parametrize("dec_pending", [False, True])
 @pytest.mark.parametrize("blocks,group", [(12, 6), (12, 5), (2, 6), (7, 3), (1, 1)])
-def test_replayed_backward_launches_the_gradient_buckets_where_the_walked_one_does(monkeypatch, blocks, group):
+def test_replayed_backward_launches_the_gradient_buckets_where_the_walked_one_does(monkeypatch, blocks, group, dec_pending):
     """N > 1: a finished group's gradient buckets go on the wire (reducer.launch) behind its direct weight-gradient products.  The
     replayed backward pass (one C call per block) must issue the same spans at the same points as _layer_done / _flush_direct do
-    when the blocks are walked - checked here on the host logic alone (no launches: the library and the table are stand-ins)."""
+    when the blocks are walked - checked here on the host logic alone (no launches: the library and the table are stand-ins).
+    dec_pending (round 6): the decoder's long-contraction weight gradients ride in the encoder's FIRST direct group, so the
+    decoder's bucket must leave behind that group - once, in the walked and in the replayed pass alike."""
     import ctypes
     from types import SimpleNamespace
 
@@ -181,6 +184,7 @@ def test_replayed_backward_launches_the_gradient_buckets_where_the_walked_one_do
         eng.reducer = SimpleNamespace(launch=lambda lo, hi: log.append(("bucket", lo, hi)))
         item = SimpleNamespace(data_ptr=lambda: 0)
         eng._dw_cur = dict(layers=[(item, item, 1)] * blocks)
+        eng._dec_bucket_pending, eng.dec_names = dec_pending, ["dec.first", "dec.last"]
         return eng, log
 
     prev = _host.swap_pinned(ctypes.c_void_p(0))
@@ -200,7 +204,14 @@ def test_replayed_backward_launches_the_gradient_buckets_where_the_walked_one_do
     finally:
         _host.swap_pinned(prev)
     assert [e for e in wlog if e[0] != "block"] == rlog
-    assert sum(1 for e in rlog if e[0] == "bucket") == blocks and walked._dq_blocks == replayed._dq_blocks == []
+    assert sum(1 for e in rlog if e[0] == "bucket") == blocks + int(dec_pending) and walked._dq_blocks == replayed._dq_blocks == []
+    if dec_pending:
+        dec = [i for i, e in enumerate(rlog) if e == ("bucket", "dec.first", "dec.last")]
+        first_group = min(group, blocks)
+        launches = [i for i, e in enumerate(rlog) if e[0] == "launches"]
+        # exactly once, behind the first group's last block and before the next block's launches
+        assert len(dec) == 1 and dec[0] > launches[first_group - 1] and (len(launches) == first_group or dec[0] < launches[first_group])
+        assert not walked._dec_bucket_pending and not replayed._dec_bucket_pending
 
 
 def test_replay_dispatches_typed_calls_and_reports_the_failing_entry():

@@ -782,6 +782,12 @@ int ma_embed_posenc_f32(const int32_t* tokens, const float* table, const float* 
                         int32_t V, float xscale, float p, uint32_t seed, uint32_t salt, float* out, ma_stream_t stream);
 int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_t D, int32_t V, float xscale, float p,
                      uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream);
+/* The same with a row mask (rows float32, may be NULL): rows with row_keep == 0 are skipped.  For the caller that KNOWS their
+ * gradient is zero - the padded label positions of the attention decoder (add_sos_eos pads ys_in with <eos>, utils/common.py:40-88;
+ * the (B, L, L) label mask keeps them out of every valid position's attention, asr_model.py:117-144): a third of the rows and one
+ * token id, i.e. one workgroup's serial sum (84 -> ~20 us per cfg-4 hybrid step). */
+int ma_embed_bwd_rows_f32(const int32_t* tokens, const float* g, const float* row_keep, int64_t rows, int32_t D, int32_t V,
+                          float xscale, float p, uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream);
 
 /* MultiHeadedAttention core (layers/attention.py:86-157) for Lq <= 32 queries and Lk <= 1088 keys per (batch, head)
  * (up to 320 keys the V / K rows are staged in LDS; beyond that - the 1400 ... 3000-frame buckets of conformer.yaml, T' <= 749 -

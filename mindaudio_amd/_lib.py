@@ -262,6 +262,7 @@ PROTOTYPES = {
                                                           i32, vp, i64, vp, i64, vp, vp, vp, i64, vp]),
     "ma_embed_posenc_f32": (ctypes.c_int, [vp, vp, vp, i64, i32, i32, i32, f32, f32, u32, u32, vp, vp]),
     "ma_embed_bwd_f32": (ctypes.c_int, [vp, vp, i64, i32, i32, f32, f32, u32, u32, vp, vp]),
+    "ma_embed_bwd_rows_f32": (ctypes.c_int, [vp, vp, vp, i64, i32, i32, f32, f32, u32, u32, vp, vp]),
     "ma_mha_small_fwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i64, i32, i32, i32, i32, f32, vp, i64, vp,
                                              vp]),
     "ma_mha_small_bwd_bf16": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32,

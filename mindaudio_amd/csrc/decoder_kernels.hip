@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restric
 template <int ND>  // features per thread: D <= 256 ND
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ g, int D, int V,
                                                         float xscale, uint32_t seed, uint32_t salt, uint32_t thresh,
-                                                        float inv_keep, float* dtable, int64_t rows) {
+                                                        float inv_keep, float* dtable, int64_t rows,
+                                                        const float* __restrict__ row_keep) {
   __shared__ int stok[1024], mlist[1024], wcnt[4], cnt_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float acc[ND];
@@ -112,13 +113,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
     const int n = (int)(rows - base < 1024 ? rows - base : 1024);
     for (int i = tid; i < n; i += 256) {
       const int t = tok[base + i];
-      stok[i] = t < 0 ? 0 : (t >= V ? V - 1 : t);
+      // row_keep[row] == 0: the row is skipped (stored as token -1, which matches no workgroup) - the caller knows its gradient is
+      // zero: the padded label positions, a third of the rows and ONE token id, all of which fell to one workgroup (round 6)
+      stok[i] = (row_keep && row_keep[base + i] == 0.0f) ? -1 : (t < 0 ? 0 : (t >= V ? V - 1 : t));
     }
     if (tid == 0) cnt_s = 0;
     __syncthreads();
     for (int q = 0; q < 4; ++q) {  // rows q * 256 + tid: waves, then lanes, in row order
       const int idx = q * 256 + tid;
-      const bool match = idx < n && (unsigned)stok[idx] % gridDim.x == blockIdx.x;
+      const bool match = idx < n && stok[idx] >= 0 && (unsigned)stok[idx] % gridDim.x == blockIdx.x;
       const unsigned long long mask = __ballot(match);
       if (lane == 0) wcnt[wave] = __popcll(mask);
       __syncthreads();
@@ -537,6 +540,19 @@ __global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn
       kf0 = *reinterpret_cast<const sm_bf16x8*>(kp);
       kf1 = *reinterpret_cast<const sm_bf16x8*>(kp + 32);
     }
+    // the tile's mask values: unconditional loads (clamped indices), all in flight under the MFMAs - behind `if (q < Lq)` /
+    // `continue` each of them was a round trip of its own (eight per tile with the (B, Lq, Lk) label mask)
+    float mk1 = 1.0f, mk2[2][4];
+    if (p.mask_mode == 1) mk1 = p.mask[(int64_t)b * Lk + keyc];
+    if (p.mask_mode == 2) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * qt + 4 * lg + r, qc = q < Lq ? q : Lq - 1;
+          mk2[qt][r] = p.mask[((int64_t)b * Lq + qc) * Lk + keyc];
+        }
+    }
     sm_f32x4 sc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn
       sc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const sm_bf16x8*>(qr + 32), kf1, sc[qt], 0, 0, 0);
     }
     if (key < Lk) {
-      const float madd1 = (p.mask_mode == 1 && p.mask[(int64_t)b * Lk + key] == 0.0f) ? -10000.0f : 0.0f;
+      const float madd1 = (p.mask_mode == 1 && mk1 == 0.0f) ? -10000.0f : 0.0f;
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -553,32 +569,52 @@ __global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn
           const int q = 16 * qt + 4 * lg + r;
           if (q >= Lq) continue;
           float sv = sc[qt][r] * p.scale + madd1;
-          if (p.mask_mode == 2 && p.mask[((int64_t)b * Lq + q) * Lk + key] == 0.0f) sv += -10000.0f;
+          if (p.mask_mode == 2 && mk2[qt][r] == 0.0f) sv += -10000.0f;
           S[q * ss + key] = sv;
         }
     }
   }
   __syncthreads();
-  for (int i = wave; i < Lq; i += 4) {  // softmax of row i by wave (i % 4)
-    float m = -INFINITY;
-    for (int jj = lane; jj < Lk; jj += 64) m = fmaxf(m, S[i * ss + jj]);
+  {
+    // Softmax of the rows wave, wave + 4, ... (kSmQ / 4 = 8 per wave) ALL AT ONCE (round 6): row by row, each row was three passes and
+    // two 6-step butterflies of dependent cross-lane exchanges - eight such chains in a row were ~12 of the launch's 21 us.  Same
+    // operations per element, in the same order within a row.
+    constexpr int kR = kSmQ / 4;
+    float m[kR], sum[kR];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    float sum = 0.0f;
-    for (int jj = lane; jj < Lk; jj += 64) {
-      const float e = __expf(S[i * ss + jj] - m);
-      S[i * ss + jj] = e;
-      sum += e;
-    }
+    for (int r = 0; r < kR; ++r) m[r] = -INFINITY;
+    for (int jj = lane; jj < Lk; jj += 64)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    const float inv = 1.0f / sum;
-    float* pr = probs + (((int64_t)b * p.H + h) * Lq + i) * Lk;
-    for (int jj = lane; jj < Lk; jj += 64) {
-      const float pv = S[i * ss + jj] * inv;
-      S[i * ss + jj] = pv;
-      pr[jj] = pv;
-    }
+      for (int r = 0; r < kR; ++r)
+        if (wave + 4 * r < Lq) m[r] = fmaxf(m[r], S[(wave + 4 * r) * ss + jj]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int r = 0; r < kR; ++r) m[r] = fmaxf(m[r], __shfl_xor(m[r], off, 64));
+#pragma unroll
+    for (int r = 0; r < kR; ++r) sum[r] = 0.0f;
+    for (int jj = lane; jj < Lk; jj += 64)
+#pragma unroll
+      for (int r = 0; r < kR; ++r)
+        if (wave + 4 * r < Lq) {
+          const float e = __expf(S[(wave + 4 * r) * ss + jj] - m[r]);
+          S[(wave + 4 * r) * ss + jj] = e;
+          sum[r] += e;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int r = 0; r < kR; ++r) sum[r] += __shfl_xor(sum[r], off, 64);
+    float* pr0 = probs + ((int64_t)b * p.H + h) * Lq * Lk;
+    for (int jj = lane; jj < Lk; jj += 64)
+#pragma unroll
+      for (int r = 0; r < kR; ++r)
+        if (wave + 4 * r < Lq) {
+          const int i = wave + 4 * r;
+          const float pv = S[i * ss + jj] * (1.0f / sum[r]);
+          S[i * ss + jj] = pv;
+          pr0[(int64_t)i * Lk + jj] = pv;
+        }
   }
   __syncthreads();
   sm_rows_times_tile(S, ss, Vs, Lq, Lk, ctx + (int64_t)b * Lq * ldc + h * kSmD, ldc);
@@ -840,16 +876,21 @@ int ma_embed_posenc_f32(const int32_t* tokens, const float* table, const float* 
   return MA_OK;
 }
 
-int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_t D, int32_t V, float xscale, float p,
-                     uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream) {
+int ma_embed_bwd_rows_f32(const int32_t* tokens, const float* g, const float* row_keep, int64_t rows, int32_t D, int32_t V, float xscale,
+                          float p, uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream) {
   if (!tokens || !g || !dtable || rows < 1 || D < 1 || V < 1 || p < 0.0f || p >= 1.0f) return MA_ERR_INVALID_ARG;
   if (D <= 256)
     MA_LAUNCH(embed_bwd_kernel<1>, dim3(256), dim3(256), 0, (hipStream_t)stream, tokens, g, D, V, xscale, seed, salt, d_thresh(p),
-              p > 0.0f ? 1.0f / (1.0f - p) : 1.0f, dtable, rows);
+              p > 0.0f ? 1.0f / (1.0f - p) : 1.0f, dtable, rows, row_keep);
   else
     MA_LAUNCH(embed_bwd_kernel<4>, dim3(256), dim3(256), 0, (hipStream_t)stream, tokens, g, D, V, xscale, seed, salt, d_thresh(p),
-            1.0f / (1.0f - p), dtable, rows);
+              1.0f / (1.0f - p), dtable, rows, row_keep);
   return MA_OK;
+}
+
+int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_t D, int32_t V, float xscale, float p,
+                     uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream) {
+  return ma_embed_bwd_rows_f32(tokens, g, nullptr, rows, D, V, xscale, p, seed, salt, dtable, stream);
 }
 
 extern "C++" {

@@ -332,6 +332,7 @@ class ConformerCTCTrainStep:
         # + LayerNorm in one launch on packed weights; LayerNorm backward + the next dropout backward in one): 16 + 16 -> 10 + 12
         # launches per layer (round 6).  False: one launch per reference cell (what the float32 validation mode always runs).
         self.decoder_fused_launches = True
+        self.decoder_embed_row_mask = True  # the embedding's backward skips the padded label rows (their gradient is exactly zero)
         self._dec_long_dw, self._dec_bucket_pending, self._dec_rows = True, False, 1
         self._build_flat()
         self.flag = self.fp.flag  # zeroed with the gradients at the start of forward_backward
@@ -815,7 +816,7 @@ class ConformerCTCTrainStep:
             return None
         key = (b, t2, tuple(att_shape), self.ffn_one_launch, self.ffn_bwd_one_launch, self.ln_final_chained,
                self.ln_bwd_fused, self.dw_group_blocks, self.p_drop, self.p_pos, self.bn_momentum, id(plan["arena"]),
-               self.decoder_fused_launches)
+               self.decoder_fused_launches, self.decoder_embed_row_mask)
         tables = plan.setdefault("tables", {})
         tb = plan["table"] = tables.get(key)  # (plan["table"]: the one in use, for tests and tools)
         if tb is None:
@@ -1729,7 +1730,8 @@ class ConformerCTCTrainStep:
         # ---- backward ----
         seg(False, L + Ld + 2)
         K.gemm_tn(dlog, yb, fp.g("dec.out_w"), colsum=fp.g("dec.out_b"), rows_store=self.V)
-        dy = self._dX(dlog, "dec.out_w")
+        # (K = 4 288 against 1 240 rows: split over K like the feed-forward input gradient below - 32 -> ~12 us)
+        dy = K.gemm_splitk(dlog, self.wt["dec.out_w"], tt.empty((md, d), dtype=f32, device=self.dev), accumulate=False)
         g = tt.empty((md, d), dtype=f32, device=self.dev)
         lnp = self._dec_ln_plan(md)["bufs"]  # (the LayerNorm backwards' partial sums: one batched reduction at the end)
         # after_norm's backward emits the dropout backward of the last layer's feed-forward join
@@ -1746,7 +1748,9 @@ class ConformerCTCTrainStep:
             dh = K.dense_plain(dyf, PK("ff_w2.tk"), hid, d)
             du = K.act_dropout_bwd(T["u"], dh, pd, seed, salt(li, 2), out=dh, act=RELU)
             self._dW(du, T["a3"], pre + "ff_w1", pre + "ff_b1")
-            da = self._dX(du, pre + "ff_w1")  # (K = 2048: the general GEMM, see the forward)
+            # (K = 2048 against 1 240 rows: 40 tiles of the general GEMM walk 32 K-tiles each - 17.5 us; split over K with partials in a
+            # workspace and a fixed-order sum: two launches of ~5 us.  The LayerNorm backward reads the float32 sum as it is.)
+            da = K.gemm_splitk(du, self.wt[pre + "ff_w1"], tt.empty((md, d), dtype=f32, device=self.dev), accumulate=False)
             _, do = K.layernorm_bwd_next(T["x2"], P("norm3.g"), da, g, None, None, (1.0, pd, seed, salt(li, 1), None), eps=eps,
                                          partials=lnp[pre + "norm3"])
             # source attention
@@ -1777,7 +1781,8 @@ class ConformerCTCTrainStep:
             else:
                 K.layernorm_bwd(T["x0"], P("norm1.g"), da, g, None, None, eps=eps, partials=lnp[pre + "norm1"])
         seg(True, L + Ld)
-        K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0))
+        # (tmask: the padded label positions - their rows of g are exactly zero, the label mask keeps them out of every valid position)
+        K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0), row_keep=tmask if self.decoder_embed_row_mask else None)
         dlp = self._dec_ln
         _lib.check(_lib.load().ma_reduce_splits_batch_f32(dlp["items"].data_ptr(), dlp["block_item"].data_ptr(), dlp["n_blocks"],
                                                           _host.current_stream_ptr()), "decoder LayerNorm sums")

@@ -210,10 +210,16 @@ def embed_posenc(tokens, table, pe, L, xscale, p, seed, salt):
     return out
 
 
-def embed_bwd(tokens, g, dtable, xscale, p, seed, salt):
+def embed_bwd(tokens, g, dtable, xscale, p, seed, salt, row_keep=None):
+    """dtable (V, D) += the embedding's gradient; row_keep (rows,) float32: rows with 0 are skipped (their g is known to be zero)."""
     v, d = dtable.shape
-    _lib.check(_lib.load().ma_embed_bwd_f32(_p(tokens), _p(g), tokens.numel(), d, v, float(xscale), float(p), seed, salt,
-                                            _p(dtable), _s()), "embed_bwd")
+    if row_keep is None:
+        _lib.check(_lib.load().ma_embed_bwd_f32(_p(tokens), _p(g), tokens.numel(), d, v, float(xscale), float(p), seed, salt,
+                                                _p(dtable), _s()), "embed_bwd")
+    else:
+        assert row_keep.dtype == _t().float32 and row_keep.numel() == tokens.numel()
+        _lib.check(_lib.load().ma_embed_bwd_rows_f32(_p(tokens), _p(g), _p(row_keep), tokens.numel(), d, v, float(xscale), float(p),
+                                                     seed, salt, _p(dtable), _s()), "embed_bwd_rows")
 
 
 def mha_small_fwd(q, k, v, mask, mask_mode, batch, lq, lk, scale, heads=4, d_k=64):

@@ -686,6 +686,44 @@ def _hybrid_cols(eos, b4):
     return (xs, ys, ys_in, ys_out, None, None, sub, ys_sub, ys_masks, ys_lens, None)
 
 
+def test_decoder_embedding_backward_skips_padded_rows_without_changing_a_bit():
+    """ma_embed_bwd_rows_f32 (round 6): the padded label positions (a third of the B x L rows, all the <eos> token) are skipped in the
+    embedding's backward.  That is exact, not approximate: the (B, L, L) label mask keeps them out of every valid position's
+    attention and the loss ignores them, so their rows of the gradient are zero - the whole flat gradient must be bit-identical with
+    and without the skip, dropout on, and the kernel must agree with the un-masked entry point on a gradient whose padded rows are
+    zero."""
+    from mindaudio_amd.train import kernels as K
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    grads = []
+    for skip in (True, False):
+        _, _, _, model, cols = _hybrid_setup(blocks=1, dblocks=2)
+        model.decoder.dropout_rate, model.decoder.positional_dropout_rate = 0.1, 0.1
+        eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1)
+        assert eng.decoder_embed_row_mask
+        eng.decoder_embed_row_mask = skip
+        c = [x.cuda() if x is not None else None for x in cols]
+        eng.forward_backward(c[0], c[1], c[6], c[9], grad_scale=64.0, ys_in_pad=c[2], ys_out_pad=c[3], ys_sub_masks=c[7], ys_masks=c[8])
+        torch.cuda.synchronize()
+        grads.append(eng.fp.grad.clone())
+        assert float(eng.fp.g("dec.embed").abs().max()) > 0
+    assert torch.equal(grads[0], grads[1])
+    # the entry point alone: rows with row_keep == 0 contribute nothing; with zero gradient there it equals the plain entry point
+    g = torch.Generator().manual_seed(3)
+    rows, d, v = 1240, 256, 97
+    tok = torch.randint(0, v, (rows,), generator=g, dtype=torch.int32)
+    keep = (torch.rand(rows, generator=g) > 0.4).float()
+    tok[keep == 0] = v - 1
+    gr = torch.randn(rows, d, generator=g) * keep[:, None]
+    a, b_ = torch.zeros(v, d, device="cuda"), torch.zeros(v, d, device="cuda")
+    K.embed_bwd(tok.cuda(), gr.cuda(), a, 16.0, 0.1, 5, 7)
+    K.embed_bwd(tok.cuda(), gr.cuda(), b_, 16.0, 0.1, 5, 7, row_keep=keep.cuda())
+    assert torch.equal(a, b_)
+    c_ = torch.zeros(v, d, device="cuda")
+    K.embed_bwd(tok.cuda(), torch.randn(rows, d, generator=g).cuda(), c_, 16.0, 0.0, 5, 7, row_keep=torch.zeros(rows, device="cuda"))
+    assert float(c_.abs().max()) == 0.0
+
+
 def test_hybrid_loss_curve_in_float32_mode_matches_the_oracle():
     """The shipped conformer.yaml trains with ctc_weight 0.3 (asr_model.py:117-153): the float32 validation mode now covers the
     attention-decoder branch too (float32 decoder attention, embedding, label smoothing).  20 Adam steps on one batch against the

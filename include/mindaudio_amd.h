@@ -559,7 +559,8 @@ typedef struct ma_train_epilogue {
   float* ln_mid;
   int64_t ld_ln, ld_mid;
   float ln_eps;
-  int32_t reserved;
+  int32_t act;     /* modes 1 / 2: 0 or 1 = Swish (layers/swish.py, the Conformer blocks), 2 = ReLU (the TransformerDecoder's
+                      feed-forward, models/conformer.py:430-470); was `reserved` (0) until round 6 */
 } ma_train_epilogue_t;
 /* K = 256 layers on the packed weight of ma_gemm_k256_pack_bf16 (N % 256 == 0); out bf16 (modes 1, 2, 4) or float32 (mode 3). */
 int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* packed, void* out, int64_t ldo, int64_t M, int64_t N,

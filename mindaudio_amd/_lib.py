@@ -70,7 +70,7 @@ class TrainEpilogue(ctypes.Structure):
                 ("seed", ctypes.c_uint32), ("salt", ctypes.c_uint32), ("ln_gamma1", ctypes.c_void_p), ("ln_beta1", ctypes.c_void_p),
                 ("ln_gamma2", ctypes.c_void_p), ("ln_beta2", ctypes.c_void_p), ("ln_row_scale", ctypes.c_void_p),
                 ("ln_out", ctypes.c_void_p), ("ln_mid", ctypes.c_void_p), ("ld_ln", ctypes.c_int64), ("ld_mid", ctypes.c_int64),
-                ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32)]
+                ("ln_eps", ctypes.c_float), ("act", ctypes.c_int32)]
 
 
 class TnItem(ctypes.Structure):

@@ -305,10 +305,15 @@ __device__ __forceinline__ void k256_train_epilogue_bf16(f32x4 (&acc)[4][ROWS / 
                             __uint_as_float(uq.y & 0xffff0000u)};
         bf16_round2(v[0], v[1]);
         bf16_round2(v[2], v[3]);
+        if (e.relu) {  // (wave-uniform)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sg = sigmoid_fast(u[r]);
-          v[r] = v[r] * (sg + u[r] * sg * (1.0f - sg));
+          for (int r = 0; r < 4; ++r) v[r] = u[r] > 0.0f ? v[r] : 0.0f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sg = sigmoid_fast(u[r]);
+            v[r] = v[r] * (sg + u[r] * sg * (1.0f - sg));
+          }
         }
         drop4(e.drop, (uint64_t)mc * N + n, v);
       }
@@ -332,8 +337,13 @@ __device__ __forceinline__ void k256_train_epilogue_bf16(f32x4 (&acc)[4][ROWS / 
       for (int jt = 0; jt < 4; ++jt) {
         const int n = n0 + 16 * jt + 4 * g;
         float v[4];
+        if (e.relu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[jt][s][r] * sigmoid_fast(acc[jt][s][r]);
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[jt][s][r], 0.0f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[jt][s][r] * sigmoid_fast(acc[jt][s][r]);
+        }
         drop4(e.drop, (uint64_t)mc * N + n, v);
         *reinterpret_cast<uint2*>(stage + (16 * s + c) * kG2StagePitch + (16 * jt + 4 * g) * 2) =
             make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));

@@ -83,6 +83,7 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 // Epilogue of the training forms of the packed dense layers (ma_gemm_k256_train_bf16 / ma_gemm_rows_train_bf16).
 struct TrainEpi {
   int32_t mode;
+  int32_t relu;          // modes 1 / 2: ReLU instead of Swish (the TransformerDecoder's feed-forward, models/conformer.py:430-470)
   const float* bias;
   const uint16_t* aux;   // mode 2: u (M, N) bf16
   int64_t ld_aux;
@@ -106,6 +107,8 @@ struct TrainEpi {
 inline int train_epi_fill(const ma_train_epilogue_t* epi, int64_t M, int64_t N, TrainEpi& e) {
   if (!epi || epi->mode < 1 || epi->mode > 4 || epi->p < 0.0f || epi->p >= 1.0f) return MA_ERR_INVALID_ARG;
   e.mode = epi->mode;
+  if (epi->act != 0 && epi->act != 1 && epi->act != 2) return MA_ERR_INVALID_ARG;
+  e.relu = epi->act == 2 ? 1 : 0;
   e.bias = epi->bias;
   e.aux = reinterpret_cast<const uint16_t*>(epi->aux);
   e.ld_aux = epi->ld_aux;

@@ -1707,8 +1707,7 @@ class ConformerCTCTrainStep:
             x2, a3, _ = K.dense_join(ctx2, PK("ca_o_w.k"), d, P("ca_o_b"), x1, 1.0, pd, seed, salt(li, 1),
                                      ln1=(P("norm3.g"), P("norm3.b")), eps=eps)
             T.update(q=q, kv=kv, ctx2=ctx2, probs2=probs2, x2=x2, a3=a3)
-            u = K.dense_plain(a3, PK("ff_w1.k"), hid, d, bias=P("ff_b1"))
-            h = K.act_dropout_fwd(u, pd, seed, salt(li, 2), act=RELU)
+            u, h = K.dense_act_drop(a3, PK("ff_w1.k"), hid, P("ff_b1"), pd, seed, salt(li, 2), act=RELU)  # w_1 + ReLU + dropout: one launch
             nxt = (fp.p("d%d.norm1.g" % (li + 1)), fp.p("d%d.norm1.b" % (li + 1))) if li + 1 < Ld else \
                 (fp.p("dec.after_norm.g"), fp.p("dec.after_norm.b"))
             # (K = 2048 against 1 240 rows: on the row-owner kernel 26 workgroups each stream the whole weight - 30 us; the general GEMM
@@ -1745,8 +1744,7 @@ class ConformerCTCTrainStep:
             T = tape[li]
             # feed-forward
             self._dW(dyf, T["h"], pre + "ff_w2", pre + "ff_b2")
-            dh = K.dense_plain(dyf, PK("ff_w2.tk"), hid, d)
-            du = K.act_dropout_bwd(T["u"], dh, pd, seed, salt(li, 2), out=dh, act=RELU)
+            du = K.dense_act_drop_bwd(dyf, PK("ff_w2.tk"), hid, T["u"], pd, seed, salt(li, 2), act=RELU)  # dh -> du: one launch
             self._dW(du, T["a3"], pre + "ff_w1", pre + "ff_b1")
             # (K = 2048 against 1 240 rows: 40 tiles of the general GEMM walk 32 K-tiles each - 17.5 us; split over K with partials in a
             # workspace and a fixed-order sum: two launches of ~5 us.  The LayerNorm backward reads the float32 sum as it is.)

@@ -483,8 +483,8 @@ def _train_epi(mode, bias=None, aux=None, out2=None, residual=None, row_scale=No
     return e
 
 
-def dense_act_drop(a, packed, n, bias, p, seed, salt):
-    """w_1 forward (K = 256): -> (u (M, n) bf16 = a W^T + b, h (M, n) bf16 = dropout(swish(u))), one launch."""
+def dense_act_drop(a, packed, n, bias, p, seed, salt, act=_lib.ACT_SWISH):
+    """w_1 forward (K = 256): -> (u (M, n) bf16 = a W^T + b, h (M, n) bf16 = dropout(act(u))), one launch; act = Swish or ReLU."""
     import ctypes
 
     t = _t()
@@ -492,12 +492,13 @@ def dense_act_drop(a, packed, n, bias, p, seed, salt):
     u = t.empty((m, n), dtype=t.bfloat16, device=a.device)
     h = t.empty((m, n), dtype=t.bfloat16, device=a.device)
     e = _train_epi(1, bias=bias, out2=h, p=p, seed=seed, salt=salt)
+    e.act = 2 if act == _lib.ACT_RELU else 0
     _lib.check(_lib.load().ma_gemm_k256_train_bf16(_p(a), a.stride(0), _p(packed), _p(u), u.stride(0), m, n, ctypes.byref(e), _s()),
                "dense_act_drop")
     return u, h
 
 
-def dense_act_drop_bwd(dy, packed, n, u, p, seed, salt):
+def dense_act_drop_bwd(dy, packed, n, u, p, seed, salt, act=_lib.ACT_SWISH):
     """w_1 backward (K = 256): du (M, n) bf16 = (dy W2) * swish'(u) * keep / (1 - p); `packed` = the k256 packing of W2^T (n, 256)."""
     import ctypes
 
@@ -505,6 +506,7 @@ def dense_act_drop_bwd(dy, packed, n, u, p, seed, salt):
     m = dy.shape[0]
     du = t.empty((m, n), dtype=t.bfloat16, device=dy.device)
     e = _train_epi(2, aux=u, p=p, seed=seed, salt=salt)
+    e.act = 2 if act == _lib.ACT_RELU else 0
     _lib.check(_lib.load().ma_gemm_k256_train_bf16(_p(dy), dy.stride(0), _p(packed), _p(du), du.stride(0), m, n, ctypes.byref(e), _s()),
                "dense_act_drop_bwd")
     return du

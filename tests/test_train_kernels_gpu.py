@@ -503,6 +503,20 @@ def test_fused_dense_layers_equal_their_unfused_launches(K):
     h_ref = K.act_dropout_fwd(u_ref, p, seed, 3)
     u, h = K.dense_act_drop(a, pack(w1, 0), hid, b1, p, seed, 3)
     assert torch.equal(u, u_ref) and torch.equal(h, h_ref)
+    # ... and with ReLU (ma_train_epilogue_t.act = 2, round 6: the TransformerDecoder's feed-forward), forward and backward, M = 1 240
+    from mindaudio_amd import _lib as L_
+    ar = bf(torch.randn(1240, d, generator=g)).cuda()
+    ur_ref = ops.gemm(ar, w1, bias=b1)
+    hr_ref = K.act_dropout_fwd(ur_ref, p, seed, 5, act=L_.ACT_RELU)
+    ur, hr = K.dense_act_drop(ar, pack(w1, 0), hid, b1, p, seed, 5, act=L_.ACT_RELU)
+    assert torch.equal(ur, ur_ref) and torch.equal(hr, hr_ref)
+    assert float((hr == 0).float().mean()) > 0.5 and not torch.equal(hr, K.dense_act_drop(ar, pack(w1, 0), hid, b1, p, seed, 5)[1])
+    dyr = bf(torch.randn(1240, d, generator=g)).cuda()
+    w2t = w2.t().contiguous()  # (hid, 256): dh = dy . W2
+    dh_ref = ops.gemm(dyr, w2t)
+    du_ref = K.act_dropout_bwd(ur_ref, dh_ref, p, seed, 5, act=L_.ACT_RELU)
+    du = K.dense_act_drop_bwd(dyr, pack(w2t, 0), hid, ur_ref, p, seed, 5, act=L_.ACT_RELU)
+    assert torch.equal(du, du_ref)
     # ---- w_2 forward + dropout + residual (+ LayerNorm chain)
     y_ref = ops.gemm(h, w2, bias=b2, row_scale=rs)
     x_ref = K.dropout_add(x, y_ref, 0.5, p, seed, 4)

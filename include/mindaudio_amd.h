@@ -575,6 +575,17 @@ int ma_gemm_k256_train_bf16(const void* A, int64_t lda, const void* packed, void
 int32_t ma_gemm_rows_train_parts(int64_t M);
 int ma_gemm_rows_train_bf16(const void* A, int64_t lda, int64_t M, int64_t K, const void* packed, void* out, int64_t ldo,
                             const ma_train_epilogue_t* epi, ma_stream_t stream);
+/* A branch join (mode 3 without the chained second LayerNorm; N = 256) behind a long contraction over FEW rows (round 6: the
+ * TransformerDecoder's w_2, models/conformer.py:430-470 + 501-530: 1 240 rows x K = 2048 - 40 output tiles would walk 32 K-tiles each
+ * on 40 of the 256 CUs): the product of row-major A (M, K) and W (256, K) [the weight as the reference stores it, no packed copy]
+ * is split over K like ma_gemm_bf16_splitk_f32 (`workspace` >= ma_gemm_splitk_workspace_bytes(M, 256, K)), and the launch that adds
+ * the splits in their fixed order carries the join: out (float32) = residual + alpha * dropout(bf16((sum + bias) * row_scale)),
+ * ln_out = LayerNorm(out; ln_gamma1, ln_beta1) * ln_row_scale.  `out` is bit-identical to ma_gemm_bf16_splitk_f32 + bias + a bf16
+ * rounding + ma_dropout_add_f32, ln_out within one bf16 ulp of ma_layernorm_f32 of it (tests/test_train_kernels_gpu.py); two
+ * launches instead of four. */
+int ma_gemm_bf16_splitk_join_f32(const void* A, int64_t lda, const void* W, int64_t ldw, float* out, int64_t ldo, int64_t M,
+                                 int64_t N, int64_t K, const ma_train_epilogue_t* epi, void* workspace, int64_t workspace_bytes,
+                                 ma_stream_t stream);
 /* The whole position-wise feed-forward module of a Conformer block in TRAINING mode, one launch each way (round 4; d_model = 256,
  * hidden % 256 == 0, `packed` = ma_ffn_pack_weights_bf16 - the evaluation forward's format).
  * Forward:

@@ -190,6 +190,7 @@ PROTOTYPES = {
                                            vp]),
     "ma_gemm_splitk_workspace_bytes": (i64, [i64, i64, i64]),
     "ma_gemm_bf16_splitk_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, i32, vp, i64, vp]),
+    "ma_gemm_bf16_splitk_join_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, ctypes.POINTER(TrainEpilogue), vp, i64, vp]),
     "ma_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
     "ma_gemm_tn_bf16_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, i64, f32, i32, vp, vp, i64, vp]),
     "ma_conv2d_3x3s2_dw_bf16": (ctypes.c_int, [vp, i64, vp, i64, i64, i64, i64, i64, vp, vp, vp, i64, vp]),

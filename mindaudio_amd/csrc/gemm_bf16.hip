@@ -20,6 +20,7 @@
 #include <utility>
 
 #include "../../include/mindaudio_amd.h"
+#include "train_common.h"
 
 #include "launch.h"
 
@@ -824,6 +825,66 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// The split-K product feeding a branch JOIN (N = 256; ma_gemm_bf16_splitk_join_f32): the fixed-order sum of the splits and the join's
+// element-wise work - z = bf16((sum + bias) * row_scale); out = residual + alpha * dropout(z); optionally LayerNorm(out) - one wave per
+// row, 4 columns per lane.  The arithmetic of splitk_reduce_kernel, a bf16 rounding, dropout_add_kernel and layernorm_kernel<1> in turn.
+__global__ __launch_bounds__(256) void splitk_join_kernel(const float* __restrict__ part, int splits, int64_t M,
+                                                          float* __restrict__ out, int64_t ldo, TrainEpi e) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int c = lane * 4;
+  const int64_t mn = M * 256;
+  const float* pr = part + row * 256 + c;
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+  for (int k = 0; k < splits; ++k) {
+    const float4 t = *reinterpret_cast<const float4*>(pr + (int64_t)k * mn);
+    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+  }
+  if (e.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(e.bias + c);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (e.row_scale) {
+    const float rs = e.row_scale[row];
+    v[0] *= rs; v[1] *= rs; v[2] *= rs; v[3] *= rs;
+  }
+  bf16_round2(v[0], v[1]);
+  bf16_round2(v[2], v[3]);
+  drop4(e.drop, (uint64_t)row * 256 + c, v);
+  float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (e.residual) x = *reinterpret_cast<const float4*>(e.residual + row * e.ldr + c);
+  x.x += e.alpha * v[0]; x.y += e.alpha * v[1]; x.z += e.alpha * v[2]; x.w += e.alpha * v[3];
+  *reinterpret_cast<float4*>(out + row * ldo + c) = x;
+  if (!e.ln_g1) return;
+  auto wave_sum = [](float s) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+  };
+  const float mean = wave_sum((x.x + x.y) + (x.z + x.w)) * (1.0f / 256);
+  x.x -= mean; x.y -= mean; x.z -= mean; x.w -= mean;
+  const float var = wave_sum((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w)) * (1.0f / 256);
+  const float inv = 1.0f / sqrtf(var + e.eps);
+  const float rs = e.ln_row_scale ? e.ln_row_scale[row] : 1.0f;
+  const float4 g = *reinterpret_cast<const float4*>(e.ln_g1 + c);
+  const float4 b = *reinterpret_cast<const float4*>(e.ln_b1 + c);
+  float4 o;
+  o.x = (x.x * inv * g.x + b.x) * rs;
+  o.y = (x.y * inv * g.y + b.y) * rs;
+  o.z = (x.z * inv * g.z + b.z) * rs;
+  o.w = (x.w * inv * g.w + b.w) * rs;
+  if (e.ln_out_bf16) {
+    uint2 pk;
+    pk.x = pack2_bf16(o.x, o.y);
+    pk.y = pack2_bf16(o.z, o.w);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(e.ln_out) + row * e.ld_ln + c) = pk;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(e.ln_out) + row * e.ld_ln + c) = o;
+  }
+}
+
 static int g_gemm_cus = 0;
 static int gemm_num_cus() {
   if (g_gemm_cus == 0) {
@@ -1043,6 +1104,40 @@ int ma_gemm_bf16_splitk_f32(const void* A, int64_t lda, const void* W, int64_t l
   if (blocks > 2048) blocks = 2048;
   MA_LAUNCH(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
             reinterpret_cast<const float*>(workspace), splits, mn, out, ldo, (int)N, alpha, (int)accumulate);
+  return MA_OK;
+}
+
+int ma_gemm_bf16_splitk_join_f32(const void* A, int64_t lda, const void* W, int64_t ldw, float* out, int64_t ldo, int64_t M,
+                                 int64_t N, int64_t K, const ma_train_epilogue_t* epi, void* workspace, int64_t workspace_bytes,
+                                 ma_stream_t stream) {
+  if (!A || !W || !out || !workspace || !epi || M < 1 || K < 1 || M > 0x7fffffff) return MA_ERR_INVALID_ARG;
+  if (N != 256 || epi->mode != 3 || epi->ln_gamma2) return MA_ERR_UNSUPPORTED;
+  if (K % BK != 0 || lda < K || ldw < K || ldo < N || (ldo & 3) || (lda & 7) || (ldw & 7)) return MA_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return MA_ERR_INVALID_ARG;
+  TrainEpi e = TrainEpi{};
+  int rc = train_epi_fill(epi, M, N, e);
+  if (rc != MA_OK) return rc;
+  GemmParams p = GemmParams{};
+  p.A = reinterpret_cast<const uint16_t*>(A);
+  p.W = reinterpret_cast<const uint16_t*>(W);
+  p.out = workspace;
+  p.lda = lda;
+  p.ldw = ldw;
+  p.ldo = N;
+  p.M = (int32_t)M;
+  p.N = (int32_t)N;
+  p.K = (int32_t)K;
+  p.alpha = 1.0f;
+  int kt = 0;
+  const int splits = splitk_plan(M, N, K, &kt);
+  p.kt_split = kt;
+  if (workspace_bytes < (int64_t)splits * M * N * 4) return MA_ERR_WORKSPACE;
+  rc = launch_gemm_tile<64, 128, 3, 0, 2>(p, (hipStream_t)stream);
+  if (rc != MA_OK) return rc;
+  MA_LAUNCH(splitk_join_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+            reinterpret_cast<const float*>(workspace), splits, M, out, ldo, e);
   return MA_OK;
 }
 

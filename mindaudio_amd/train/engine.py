@@ -176,10 +176,15 @@ _DEC_W = ("sa_qkv_w", "sa_o_w", "ca_q_w", "ca_kv_w", "ca_o_w", "ff_w1", "ff_w2")
 def decoder_entries(d, hid, Ld, V):
     """Trainable tensors of the TransformerDecoder, appended after the encoder/CTC entries."""
     ent = [("dec.embed", (V, d))]
+    # the memory-side projections (linear_k | linear_v of every layer's source attention, attention.py:86-157) of ALL layers lie next
+    # to each other: they read the same encoder output, so the fused step runs them as ONE (Ld * 2d, d) product, their weight
+    # gradient as one and the gradient w.r.t. the encoder output as one K = Ld * 2d product (round 6)
+    ent += [("d%d.ca_kv_w" % i, (2 * d, d)) for i in range(Ld)]
+    ent += [("d%d.ca_kv_b" % i, (2 * d,)) for i in range(Ld)]
     for i in range(Ld):
         pre = "d%d." % i
         ent += [(pre + "sa_qkv_w", (3 * d, d)), (pre + "sa_qkv_b", (3 * d,)), (pre + "sa_o_w", (d, d)), (pre + "sa_o_b", (d,)),
-                (pre + "ca_q_w", (d, d)), (pre + "ca_q_b", (d,)), (pre + "ca_kv_w", (2 * d, d)), (pre + "ca_kv_b", (2 * d,)),
+                (pre + "ca_q_w", (d, d)), (pre + "ca_q_b", (d,)),
                 (pre + "ca_o_w", (d, d)), (pre + "ca_o_b", (d,)), (pre + "ff_w1", (hid, d)), (pre + "ff_b1", (hid,)),
                 (pre + "ff_w2", (d, hid)), (pre + "ff_b2", (d,))]
         for ln in ("norm1", "norm2", "norm3"):
@@ -351,6 +356,16 @@ class ConformerCTCTrainStep:
         self.bn_var = [l.conv_module.norm.running_var.detach().clone().float() for l in self.enc.encoders]
         self.layer_names, self.embed_names = bucket_names(self.fp, self.L)
         self.dec_names = [n for n in self.fp.index if n.startswith("dec.") or (n[0] == "d" and n[1].isdigit())]
+        self._kv_all = None
+        if self.dec is not None and self.Ld > 0:
+            fp, d, Ld = self.fp, self.d, self.Ld
+            ow, ob = fp.index["d0.ca_kv_w"][0], fp.index["d0.ca_kv_b"][0]
+            contiguous = all(fp.index["d%d.ca_kv_w" % i][0] == ow + i * 2 * d * d and fp.index["d%d.ca_kv_b" % i][0] == ob + i * 2 * d
+                             for i in range(Ld))
+            if contiguous:  # (every tensor starts on a 64-element boundary: 2 d * d and 2 d are multiples of 64 for d = 256)
+                n_w, n_b = Ld * 2 * d * d, Ld * 2 * d
+                self._kv_all = dict(w=fp.bf16[ow:ow + n_w].view(Ld * 2 * d, d), b=fp.master[ob:ob + n_b],
+                                    gw=fp.grad[ow:ow + n_w].view(Ld * 2 * d, d), gb=fp.grad[ob:ob + n_b])
 
     @torch.no_grad()
     def _copy_params(self, to_flat, grads_out=None):
@@ -500,10 +515,15 @@ class ConformerCTCTrainStep:
         names = ["conv2_w", "out_w", "ctc_w"]
         for i in range(self.L):
             names += ["l%d.%s" % (i, s) for s in ("ffm_w1", "ffm_w2", "qkv_w", "o_w", "pw1_w", "pw2_w", "ff_w1", "ff_w2")]
+        alias = {}
         if self.dec is not None:
             names.append("dec.out_w")
             for i in range(self.Ld):
                 names += ["d%d.%s" % (i, w) for w in _DEC_W]
+            if getattr(self, "_kv_all", None) is not None and not self.x32:
+                names.append("dec.ca_kv_all")  # (a view of the Ld contiguous ca_kv_w tensors, not an entry of the flat index)
+                alias["dec.ca_kv_all"] = self._kv_all["w"]
+        wv = lambda n: alias[n] if n in alias else fp.w(n)  # noqa: E731
         if getattr(self, "_wt_plan", None) is None:
             # one launch for all of them (ma_transpose_batch_bf16): the item list and the workgroup -> item map are built once, the
             # bf16 mirror and the transposed copies never move
@@ -513,7 +533,7 @@ class ConformerCTCTrainStep:
 
             items, block_item, first = [], [], 0
             for i, n in enumerate(names):
-                w = fp.w(n)
+                w = wv(n)
                 rows, cols = w.shape
                 self.wt[n] = torch.zeros((cols, K.pad64(rows)), dtype=torch.bfloat16, device=self.dev)
                 tr, tc = (rows + 63) // 64, (cols + 63) // 64
@@ -540,9 +560,9 @@ class ConformerCTCTrainStep:
         else:
             for n in names:
                 if n not in self.wt:
-                    rows, cols = fp.w(n).shape
+                    rows, cols = wv(n).shape
                     self.wt[n] = torch.zeros((cols, K.pad64(rows)), dtype=torch.bfloat16, device=self.dev)
-                K.transpose(fp.w(n), out=self.wt[n])
+                K.transpose(wv(n), out=self.wt[n])
         if self.fused:  # (after either transpose form: the packed copies are built from the mirror and the transposed copies)
             self._pack_weights()
 
@@ -558,7 +578,7 @@ class ConformerCTCTrainStep:
     # the TransformerDecoder's dense layers (fused bf16 mode, round 6): same two layouts, names d<layer>.<key>
     _PACKS_DEC = (("sa_qkv_w.k", "sa_qkv_w", False, 0), ("sa_qkv_w.tr", "sa_qkv_w", True, 1), ("sa_o_w.k", "sa_o_w", False, 0),
                   ("sa_o_w.tk", "sa_o_w", True, 0), ("ca_q_w.k", "ca_q_w", False, 0), ("ca_q_w.tk", "ca_q_w", True, 0),
-                  ("ca_kv_w.k", "ca_kv_w", False, 0), ("ca_o_w.k", "ca_o_w", False, 0), ("ca_o_w.tk", "ca_o_w", True, 0),
+                  ("ca_o_w.k", "ca_o_w", False, 0), ("ca_o_w.tk", "ca_o_w", True, 0),
                   ("ff_w1.k", "ff_w1", False, 0), ("ff_w2.tk", "ff_w2", True, 0))
 
     _PACKS_FFN = (("ffm.f", "ffm_w1", False, 2), ("ffm.f", "ffm_w2", False, 3), ("ff.f", "ff_w1", False, 2), ("ff.f", "ff_w2", False, 3))
@@ -597,8 +617,14 @@ class ConformerCTCTrainStep:
                     specs.append(("l%d.%s" % (li, key), w, n, k, kind, pieces, total))
                     total += pieces * 16 * (2 if kind == 2 else 1)
             self.dec_fused = False
-            if self.dec is not None and self.d == 256 and self.dec_hidden % 256 == 0:
+            if self.dec is not None and self.d == 256 and self.dec_hidden % 256 == 0 and getattr(self, "_kv_all", None) is not None:
                 dec_specs, ok = [], True
+                w_all = self._kv_all["w"]
+                pieces = int(lib.ma_pack_item_pieces(0, w_all.shape[0], w_all.shape[1]))
+                if pieces <= 0:
+                    ok = False
+                dec_specs.append(("dec.ca_kv_all.k", w_all, w_all.shape[0], w_all.shape[1], 0, pieces, total))
+                total += max(pieces, 0) * 16
                 for li in range(self.Ld):
                     for key, src, transposed, kind in self._PACKS_DEC:
                         w = self.wt["d%d.%s" % (li, src)] if transposed else self.fp.w("d%d.%s" % (li, src))
@@ -1690,6 +1716,9 @@ class ConformerCTCTrainStep:
         seg(False, L + Ld)
         x = K.embed_posenc(toks, fp.p("dec.embed"), pe, L1, xscale, pp, seed, salt(-1, 0))
         a = ops.layernorm(x, fp.p("d0.norm1.g"), fp.p("d0.norm1.b"), eps=eps)
+        # linear_k | linear_v of every layer's source attention on the encoder output: one (M, Ld * 2d) product (they were Ld launches
+        # of 10 us over the same 10 200 rows)
+        kv_all = K.dense_plain(mem_bf, self.pk["dec.ca_kv_all.k"], Ld * 2 * d, d, bias=self._kv_all["b"])
         tape = []
         for li in range(Ld):
             seg(False, L + li)
@@ -1702,7 +1731,7 @@ class ConformerCTCTrainStep:
                                      ln1=(P("norm2.g"), P("norm2.b")), eps=eps)
             T.update(qkv=qkv, ctx=ctx, probs=probs, x1=x1, a2=a2)
             q = K.dense_plain(a2, PK("ca_q_w.k"), d, d, bias=P("ca_q_b"))
-            kv = K.dense_plain(mem_bf, PK("ca_kv_w.k"), 2 * d, d, bias=P("ca_kv_b"))
+            kv = kv_all[:, li * 2 * d:(li + 1) * 2 * d]
             ctx2, probs2 = K.mha_small_fwd(q, kv[:, :d], kv[:, d:], emask, 1, b, L1, t2, scale, self.heads, dk)
             x2, a3, _ = K.dense_join(ctx2, PK("ca_o_w.k"), d, P("ca_o_b"), x1, 1.0, pd, seed, salt(li, 1),
                                      ln1=(P("norm3.g"), P("norm3.b")), eps=eps)
@@ -1710,11 +1739,10 @@ class ConformerCTCTrainStep:
             u, h = K.dense_act_drop(a3, PK("ff_w1.k"), hid, P("ff_b1"), pd, seed, salt(li, 2), act=RELU)  # w_1 + ReLU + dropout: one launch
             nxt = (fp.p("d%d.norm1.g" % (li + 1)), fp.p("d%d.norm1.b" % (li + 1))) if li + 1 < Ld else \
                 (fp.p("dec.after_norm.g"), fp.p("dec.after_norm.b"))
-            # (K = 2048 against 1 240 rows: on the row-owner kernel 26 workgroups each stream the whole weight - 30 us; the general GEMM
-            # spreads the columns over workgroups: 10 + 5 + 5 us for the product, the join and the LayerNorm)
-            y = ops.gemm(h, fp.w(pre + "ff_w2"), bias=P("ff_b2"))
-            x = K.dropout_add(x2, y, 1.0, pd, seed, salt(li, 3))
-            a = ops.layernorm(x, nxt[0], nxt[1], eps=eps)
+            # (K = 2048 against 1 240 rows: on the row-owner kernel 26 workgroups each stream the whole weight - 30 us; the general GEMM's
+            # 40 tiles walk 32 K-tiles each - 19 us + 5 + 5 for the join and the LayerNorm; split over K with the join and the LayerNorm
+            # in the launch that sums the splits: two launches)
+            x, a = K.dense_join_splitk(h, fp.w(pre + "ff_w2"), P("ff_b2"), x2, 1.0, pd, seed, salt(li, 3), ln1=nxt, eps=eps)
             T.update(u=u, h=h)
             tape.append(T)
         seg(False, L + Ld + 1)
@@ -1736,7 +1764,8 @@ class ConformerCTCTrainStep:
         # after_norm's backward emits the dropout backward of the last layer's feed-forward join
         _, dyf = K.layernorm_bwd_next(x, fp.p("dec.after_norm.g"), dy, g, None, None, (1.0, pd, seed, salt(Ld - 1, 3), None),
                                       accumulate=False, eps=eps, partials=lnp["dec.after_norm"])
-        d_mem = tt.empty((m, d), dtype=f32, device=self.dev)  # (stored by the last layer's product, added to by the others: no fill)
+        d_mem = tt.empty((m, d), dtype=f32, device=self.dev)  # (stored by ONE product behind the layers: no fill, no accumulation)
+        dkv_all = tt.empty((m, Ld * 2 * d), dtype=torch.bfloat16, device=self.dev)
         for li in reversed(range(Ld)):
             seg(True, L + li)
             pre = "d%d." % li
@@ -1755,15 +1784,13 @@ class ConformerCTCTrainStep:
             self._dW(do, T["ctx2"], pre + "ca_o_w", pre + "ca_o_b")
             dctx = K.dense_plain(do, PK("ca_o_w.tk"), d, d)
             dq = tt.empty_like(T["q"])
-            dkv = tt.empty_like(T["kv"])
+            dkv = dkv_all[:, li * 2 * d:(li + 1) * 2 * d]
             K.mha_small_bwd(T["q"], T["kv"][:, :d], T["kv"][:, d:], T["probs2"], T["ctx2"], dctx, b, L1, t2, scale, dq,
                             dkv[:, :d], dkv[:, d:], self.heads, dk)
             self._dW(dq, T["a2"], pre + "ca_q_w", pre + "ca_q_b")
             daq = K.dense_plain(dq, PK("ca_q_w.tk"), d, d)
             _, do = K.layernorm_bwd_next(T["x1"], P("norm2.g"), daq, g, None, None, (1.0, pd, seed, salt(li, 0), None), eps=eps,
                                          partials=lnp[pre + "norm2"])
-            self._dW(dkv, mem_bf, pre + "ca_kv_w", pre + "ca_kv_b")
-            self._dX(dkv, pre + "ca_kv_w", residual=d_mem if li < Ld - 1 else None, out_dtype=f32, out=d_mem)
             # self attention
             self._dW(do, T["ctx"], pre + "sa_o_w", pre + "sa_o_b")
             dctx = K.dense_plain(do, PK("sa_o_w.tk"), d, d)
@@ -1779,6 +1806,17 @@ class ConformerCTCTrainStep:
             else:
                 K.layernorm_bwd(T["x0"], P("norm1.g"), da, g, None, None, eps=eps, partials=lnp[pre + "norm1"])
         seg(True, L + Ld)
+        # the memory side of the source attentions, all layers at once: d_mem = dkv_all @ [ca_kv_w of every layer] (K = Ld * 2d), and
+        # the Ld weight gradients as one (Ld * 2d, d) product in the encoder's first direct group (10 200 contraction rows: a
+        # straggler beside the decoder's 1 240-row products, _dW)
+        ops.gemm(dkv_all, self.wt["dec.ca_kv_all"], out_dtype=f32, out=d_mem)
+        if self._dw_direct and self._dec_long_dw and K.gemm_tn_direct_ok(dkv_all, mem_bf, self._kv_all["gw"]):
+            if self._dq is None:
+                self._dq = K.DirectGroup()
+            self._dq.add(dkv_all, mem_bf, self._kv_all["gw"], self._kv_all["gb"])
+            self._dec_bucket_pending = True
+        else:
+            K.gemm_tn(dkv_all, mem_bf, self._kv_all["gw"], colsum=self._kv_all["gb"])
         # (tmask: the padded label positions - their rows of g are exactly zero, the label mask keeps them out of every valid position)
         K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0), row_keep=tmask if self.decoder_embed_row_mask else None)
         dlp = self._dec_ln

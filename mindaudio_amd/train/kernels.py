@@ -592,6 +592,24 @@ def dense_join(a, packed, k, bias, residual, alpha, p, seed, salt, row_scale=Non
     return out, ln_out, ln_mid
 
 
+def dense_join_splitk(a, w, bias, residual, alpha, p, seed, salt, ln1=None, eps=1e-5):
+    """dense_join for a long contraction over few rows, on the weight w (256, K) as it lies in the bf16 mirror: the product is split
+    over K, the launch that sums the splits carries the join (ma_gemm_bf16_splitk_join_f32).  Returns (x_out, ln_out)."""
+    import ctypes
+
+    t = _t()
+    m, k = a.shape
+    assert tuple(w.shape) == (256, k)
+    lib = _lib.load()
+    out = t.empty((m, 256), dtype=t.float32, device=a.device)
+    ln_out = t.empty((m, 256), dtype=t.bfloat16, device=a.device) if ln1 is not None else None
+    e = _train_epi(3, bias=bias, residual=residual, alpha=alpha, p=p, seed=seed, salt=salt, ln1=ln1, ln_out=ln_out, eps=eps)
+    ws = _host.workspace(lib.ma_gemm_splitk_workspace_bytes(m, 256, k), a.device)
+    _lib.check(lib.ma_gemm_bf16_splitk_join_f32(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), m, 256, k,
+                                                ctypes.byref(e), _p(ws), ws.numel(), _s()), "dense_join_splitk")
+    return out, ln_out
+
+
 _NO_TAPE = {}
 
 

@@ -469,6 +469,57 @@ def test_decoder_attention_rejects_more_keys_than_the_lds_holds(K):
         K.mha_small_fwd(z(lq), z(lk), z(lk), None, 0, b, lq, lk, 1.0 / dk, h, dk)
 
 
+@pytest.mark.parametrize("m,k,p", [(1240, 2048, 0.1), (1240, 2048, 0.0), (37, 512, 0.3), (5000, 4288 + 64, 0.1)])
+def test_split_k_join_equals_its_four_launches_bit_for_bit(K, m, k, p):
+    """ma_gemm_bf16_splitk_join_f32 (the TransformerDecoder's w_2 + dropout + residual + the next LayerNorm, models/conformer.py:430-470,
+    501-530) against ma_gemm_bf16_splitk_f32 + bias + a bf16 rounding + ma_dropout_add_f32 + ma_layernorm_f32: the same splits summed
+    in the same order, the same mask - the joined rows bit-identical, their LayerNorm to one bf16 ulp; and against float64."""
+    from mindaudio_amd import ops
+
+    g = torch.Generator().manual_seed(m + k)
+    a = bf(torch.randn(m, k, generator=g)).cuda()
+    w = bf(torch.randn(256, k, generator=g) / math.sqrt(k)).cuda()
+    bias, x = torch.randn(256, generator=g).cuda(), torch.randn(m, 256, generator=g).cuda()
+    g1, b1 = (1 + 0.1 * torch.randn(256, generator=g)).cuda(), (0.1 * torch.randn(256, generator=g)).cuda()
+    seed, salt = 4242, 17
+    out, ln = K.dense_join_splitk(a, w, bias, x, 0.5, p, seed, salt, ln1=(g1, b1), eps=1e-12)
+    y = K.gemm_splitk(a, w, torch.empty(m, 256, device="cuda"), accumulate=False)
+    z = (y + bias).to(torch.bfloat16)
+    want = K.dropout_add(x, z, 0.5, p, seed, salt)
+    want_ln = ops.layernorm(want, g1, b1, eps=1e-12)
+    assert torch.equal(out, want)
+    # (the LayerNorm of the bit-identical rows: the compiler contracts the two kernels' multiply-adds differently - one bf16 ulp)
+    assert float(((ln.float() - want_ln.float()).abs() - 2.0 ** -7 * want_ln.float().abs()).max()) <= 1e-6  # (1e-6: float32 noise at a zero crossing)
+    assert float((ln != want_ln).float().mean()) < 0.02
+    out2, none = K.dense_join_splitk(a, w, None, None, 1.0, p, seed, salt)  # no bias, no residual, no LayerNorm
+    assert none is None and torch.equal(out2, K.dropout_add(None, y.to(torch.bfloat16), 1.0, p, seed, salt))
+    if p == 0.0:
+        ref = x.double().cpu() + 0.5 * (a.double().cpu() @ w.double().cpu().t() + bias.double().cpu())
+        assert float((out.double().cpu() - ref).abs().max()) < 0.5 * 2 ** -8 * float((ref - x.double().cpu()).abs().max()) + 1e-5
+        mu, var = ref.mean(1, keepdim=True), ref.var(1, unbiased=False, keepdim=True)
+        ref_ln = (ref - mu) / torch.sqrt(var + 1e-12) * g1.double().cpu() + b1.double().cpu()
+        assert float((ln.double().cpu() - ref_ln).abs().max()) < 0.05
+
+
+def test_split_k_join_rejects_what_it_does_not_do(K):
+    import ctypes
+
+    from mindaudio_amd import _host, _lib
+
+    lib = _lib.load()
+    a, w = torch.zeros(64, 512, dtype=torch.bfloat16, device="cuda"), torch.zeros(256, 512, dtype=torch.bfloat16, device="cuda")
+    out, ws = torch.zeros(64, 256, device="cuda"), torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    st = _host.current_stream_ptr()
+    e = K._train_epi(3)
+    call = lambda n, epi, nbytes: lib.ma_gemm_bf16_splitk_join_f32(a.data_ptr(), 512, w.data_ptr(), 512, out.data_ptr(), 256, 64, n,  # noqa: E731
+                                                                   512, ctypes.byref(epi), ws.data_ptr(), nbytes, st)
+    assert call(256, e, ws.numel()) == 0
+    assert call(512, e, ws.numel()) == _lib.MA_ERR_UNSUPPORTED  # a join is 256 wide
+    assert call(256, K._train_epi(4), ws.numel()) == _lib.MA_ERR_UNSUPPORTED  # only the join mode
+    assert call(256, e, 1024) == _lib.MA_ERR_WORKSPACE
+    torch.cuda.synchronize()
+
+
 def test_fused_dense_layers_equal_their_unfused_launches(K):
     """ma_gemm_k256_train_bf16 / ma_gemm_rows_train_bf16 / ma_layernorm_bwd_next_f32 against the launches they replace, same dropout
     sites: u, h, du and the emitted dy are BIT-identical (same products, same rounding points, same masks); the join's float32 output

@@ -495,7 +495,8 @@ def test_split_k_join_equals_its_four_launches_bit_for_bit(K, m, k, p):
     assert none is None and torch.equal(out2, K.dropout_add(None, y.to(torch.bfloat16), 1.0, p, seed, salt))
     if p == 0.0:
         ref = x.double().cpu() + 0.5 * (a.double().cpu() @ w.double().cpu().t() + bias.double().cpu())
-        assert float((out.double().cpu() - ref).abs().max()) < 0.5 * 2 ** -8 * float((ref - x.double().cpu()).abs().max()) + 1e-5
+        # (one bf16 rounding of z = a W^T + b, |z| = 2 |ref - x| at alpha = 0.5: half an ulp of the largest z)
+        assert float((out.double().cpu() - ref).abs().max()) < 2 ** -8 * float((ref - x.double().cpu()).abs().max()) + 1e-4
         mu, var = ref.mean(1, keepdim=True), ref.var(1, unbiased=False, keepdim=True)
         ref_ln = (ref - mu) / torch.sqrt(var + 1e-12) * g1.double().cpu() + b1.double().cpu()
         assert float((ln.double().cpu() - ref_ln).abs().max()) < 0.05

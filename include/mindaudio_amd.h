@@ -664,8 +664,9 @@ typedef struct ma_transpose_item {
 int ma_transpose_batch_bf16(const ma_transpose_item_t* items, const int32_t* block_item, int32_t n_blocks, ma_stream_t stream);
 
 /* Backward of ma_layernorm_f32 (layers/layernorm.py:53-60): g (+)= dL/dx, dgamma/dbeta (D) float32 += the sum of the
- * per-workgroup partials in a fixed order (run-to-run deterministic).  dy bf16 or float32; row_scale as in the forward; D == 256.
- * workspace >= ma_layernorm_bwd_parts(rows) * 512 * 4 bytes: [parts][dgamma (256) | dbeta (256)].  dgamma == NULL: the partials are
+ * per-workgroup partials in a fixed order (run-to-run deterministic).  dy bf16 or float32; row_scale as in the forward; D = 256,
+ * 512, 768 or 1024 (round 6: the reference's constructor takes any d_model, models/conformer.py:293-313).
+ * workspace >= ma_layernorm_bwd_parts(rows) * 2 D * 4 bytes: [parts][dgamma (D) | dbeta (D)].  dgamma == NULL: the partials are
  * left in `workspace` for the caller's ma_reduce_splits_batch_f32 (the training step sums a block's partials in one launch). */
 int32_t ma_layernorm_bwd_parts(int64_t rows);
 int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, const float* gamma, float eps,

@@ -127,7 +127,8 @@ constexpr int kYs = 64 + 8;   // row-major Y tile (144 B)
 constexpr int kAbNF = MA_AB_NFQ, kAbNFK = MA_AB_NFK;  // queries fixed / keys fixed
 // QMASK: the (B, T, T) chunk mask of the streaming configuration is a variant of its own (one slab per wave, two workgroups per CU, as
 // until round 4): its per-element index arithmetic costs the four-slab form the registers it does not have.
-template <bool KEYS_FIXED, int NF, bool QMASK>
+// DMT: d_model when it is 256 (the tuned instantiation: offsets are immediates); 0 = heads * 64 at run time (d_model 512 / 768 / 1024)
+template <bool KEYS_FIXED, int NF, bool QMASK, int DMT = 256>
 __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel(const uint16_t* __restrict__ qkv, int64_t ld_qkv,
                                                        const uint16_t* __restrict__ pos, int64_t ld_pos,
                                                        const float* __restrict__ bias_u, const float* __restrict__ bias_v,
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
   const int fb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * H + h, row0 = (int64_t)b * T;
   const int Tp = ws.Tp;
+  const int dm = DMT ? DMT : H * 64;  // row layout of qkv / dqkv: [q (dm) | k (dm) | v (dm)]
   int fidx[NF];  // this lane's fixed items (keys or queries): one per 64-item slab of the workgroup's 64 NF
   // ---- fixed-side B fragments: X'[fidx] (4 k-steps over 128) and Y[fidx] (2 k-steps over 64) -------------------
   bf16x8 xf[NF][4], yf[NF][2];
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
     // X' of the fixed item, built here (until round 4 a prep launch wrote Q' and K' to a workspace): K' = [k | p] as it lies in qkv
     // and pos, Q' = [bf16(q + u) | bf16(q + v)]
     if (KEYS_FIXED) {
-      const uint16_t* kr = qkv + (row0 + fcl) * ld_qkv + 256 + h * 64 + lg * 8;
+      const uint16_t* kr = qkv + (row0 + fcl) * ld_qkv + dm + h * 64 + lg * 8;
       const uint16_t* pr = pos + (int64_t)fcl * ld_pos + h * 64 + lg * 8;
       xf[nf][0] = *reinterpret_cast<const bf16x8*>(kr);
       xf[nf][1] = *reinterpret_cast<const bf16x8*>(kr + 32);
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
         xf[nf][2 + k2] = __builtin_bit_cast(bf16x8, ab_pack8(qb));
       }
     }
-    const uint16_t* yr = KEYS_FIXED ? qkv + (row0 + fcl) * ld_qkv + 512 + h * 64 : dctx + (row0 + fcl) * ld_dctx + h * 64;
+    const uint16_t* yr = KEYS_FIXED ? qkv + (row0 + fcl) * ld_qkv + 2 * dm + h * 64 : dctx + (row0 + fcl) * ld_dctx + h * 64;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) yf[nf][ks] = *reinterpret_cast<const bf16x8*>(yr + ks * 32 + lg * 8);
     f_mask[nf] = f_lse[nf] = f_D[nf] = 0.0f;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
     dst = make_uint4(0, 0, 0, 0);                                                                                      \
     if ((s0_) + r_ < T)                                                                                                \
       dst = KEYS_FIXED ? *reinterpret_cast<const uint4*>(dctx + (row0 + (s0_) + r_) * ld_dctx + h * 64 + yc_ * 8)      \
-                       : *reinterpret_cast<const uint4*>(qkv + (row0 + (s0_) + r_) * ld_qkv + 512 + h * 64 + yc_ * 8); \
+                       : *reinterpret_cast<const uint4*>(qkv + (row0 + (s0_) + r_) * ld_qkv + 2 * dm + h * 64 + yc_ * 8); \
   }
 #define MA_AB_XLOAD(dst, i, s0_)                                                                                       \
   {                                                                                                                    \
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
     dst = make_uint4(0, 0, 0, 0);                                                                                      \
     if (t_ < T) {                                                                                                      \
       if (KEYS_FIXED) dst = *reinterpret_cast<const uint4*>(qkv + (row0 + t_) * ld_qkv + h * 64 + (xc_ & 7) * 8);      \
-      else if ((i) < 2) dst = *reinterpret_cast<const uint4*>(qkv + (row0 + t_) * ld_qkv + 256 + h * 64 + yc_ * 8);    \
+      else if ((i) < 2) dst = *reinterpret_cast<const uint4*>(qkv + (row0 + t_) * ld_qkv + dm + h * 64 + yc_ * 8);    \
       else dst = *reinterpret_cast<const uint4*>(pos + (int64_t)t_ * ld_pos + h * 64 + yc_ * 8);                       \
     }                                                                                                                  \
   }
@@ -397,15 +399,15 @@ __global__ __launch_bounds__(256, NF >= MA_AB_OCC1 ? 1 : 2) void attn_bwd_kernel
       uint16_t* orow = dqkv + (orow0 + fidx[nf]) * ld_dqkv + hv * 64 + lg * 4;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)  // dk
-        *reinterpret_cast<uint2*>(orow + 256 + ct * 16) =
+        *reinterpret_cast<uint2*>(orow + dm + ct * 16) =
             make_uint2(ab_pack(acc_x[nf][ct][0], acc_x[nf][ct][1]), ab_pack(acc_x[nf][ct][2], acc_x[nf][ct][3]));
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)  // dv
-        *reinterpret_cast<uint2*>(orow + 512 + dt * 16) =
+        *reinterpret_cast<uint2*>(orow + 2 * dm + dt * 16) =
             make_uint2(ab_pack(acc_y[nf][dt][0], acc_y[nf][dt][1]), ab_pack(acc_y[nf][dt][2], acc_y[nf][dt][3]));
       // dp: per-batch partial (B, Tp, 256) float32; attn_dpos_reduce_kernel sums over the batch (2.6 M contended atomics
       // on (T, 256) cost more than the kernel's MFMAs)
-      float* prow = ws.dp_part + ((int64_t)bv * Tp + fidx[nf]) * 256 + hv * 64 + lg * 4;
+      float* prow = ws.dp_part + ((int64_t)bv * Tp + fidx[nf]) * dm + hv * 64 + lg * 4;
 #pragma unroll
       for (int ct = 4; ct < 8; ++ct)
         *reinterpret_cast<float4*>(prow + (ct - 4) * 16) =
@@ -472,9 +474,9 @@ __global__ __launch_bounds__(1024) void attn_bias_reduce_kernel(const float* __r
 // dpos[t][c] += sum_b part[b][t][c]
 __global__ __launch_bounds__(256) void attn_dpos_reduce_kernel(const float* __restrict__ part, int B, int T, int Tp,
                                                                float* dpos, int64_t ld_dpos) {
-  const int t = blockIdx.x, c = threadIdx.x;
+  const int t = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x, dm = gridDim.y * 256;
   float s = 0.0f;
-  for (int b = 0; b < B; ++b) s += part[((int64_t)b * Tp + t) * 256 + c];
+  for (int b = 0; b < B; ++b) s += part[((int64_t)b * Tp + t) * dm + c];
   dpos[(int64_t)t * ld_dpos + c] += s;
 }
 
@@ -487,7 +489,7 @@ extern "C" {
 int64_t ma_relpos_attention_bwd_workspace_bytes(int64_t batch, int64_t T, int32_t heads, int32_t d_k) {
   if (batch < 1 || T < 1 || heads < 1 || d_k != 64) return MA_ERR_INVALID_ARG;
   const int64_t Tp = (T + 63) / 64 * 64;
-  return batch * heads * Tp * 4 + batch * heads * (Tp / 64) * 128 * 4 + batch * Tp * 256 * 4 + 256;
+  return batch * heads * Tp * 4 + batch * heads * (Tp / 64) * 128 * 4 + batch * Tp * (int64_t)heads * 64 * 4 + 256;
 }
 
 // Where the partial sums lie in the workspace (float offsets from its start), for a caller that reduces them itself (dpos == NULL):
@@ -514,8 +516,9 @@ static int relpos_attention_bwd(const void* qkv, int64_t ld_qkv, const void* pos
   if (!qkv || !pos || !bias_u || !bias_v || !ctx || !dctx || !lse || !dqkv || (dpos && (!dbias_u || !dbias_v)) || !workspace ||
       batch < 1 || T < 1)
     return MA_ERR_INVALID_ARG;
-  if (d_k != 64 || heads * d_k != 256 || batch > 65535) return MA_ERR_UNSUPPORTED;
-  if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 7) || (ld_dctx & 7) || (ld_dqkv & 3) || (dpos && ld_dpos < 256)) return MA_ERR_UNSUPPORTED;
+  const int dm = heads * d_k;
+  if (d_k != 64 || (dm != 256 && dm != 512 && dm != 768 && dm != 1024) || batch > 65535) return MA_ERR_UNSUPPORTED;
+  if ((ld_qkv & 7) || (ld_pos & 7) || (ld_ctx & 7) || (ld_dctx & 7) || (ld_dqkv & 3) || (dpos && ld_dpos < dm)) return MA_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(ctx) |
        reinterpret_cast<uintptr_t>(dctx)) & 15)
     return MA_ERR_INVALID_ARG;  // 16-byte pieces
@@ -532,10 +535,20 @@ static int relpos_attention_bwd(const void* qkv, int64_t ld_qkv, const void* pos
   const float scale = 1.0f / sqrtf((float)d_k);
   MA_LAUNCH(attn_bwd_prep_kernel, grid, dim3(256), 0, s, (const uint16_t*)ctx, ld_ctx, (const uint16_t*)dctx, ld_dctx, (int)T,
             (int)heads, ws);
-  const int nfq = mask3 ? 1 : kAbNF, nfk = mask3 ? 1 : kAbNFK;
+  const bool wide = dm != 256;  // d_model 512 / 768 / 1024: the one-slab instantiations with run-time row offsets
+  const int nfq = (mask3 || wide) ? 1 : kAbNF, nfk = (mask3 || wide) ? 1 : kAbNFK;
   const dim3 grid_f((unsigned)((ws.Tp + 64 * nfq - 1) / (64 * nfq)), (unsigned)heads, (unsigned)batch);
   const dim3 grid_k((unsigned)((ws.Tp + 64 * nfk - 1) / (64 * nfk)), (unsigned)heads, (unsigned)batch);
-  if (mask3) {
+#define MA_AB_ARGS                                                                                                                 \
+  (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos, bias_u, bias_v, (const uint16_t*)dctx, ld_dctx, mask, mask3, lse, ws, \
+      (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v
+  if (wide && mask3) {
+    MA_LAUNCH((attn_bwd_kernel<true, 1, true, 0>), grid_k, dim3(256), 0, s, MA_AB_ARGS);
+    MA_LAUNCH((attn_bwd_kernel<false, 1, true, 0>), grid_f, dim3(256), 0, s, MA_AB_ARGS);
+  } else if (wide) {
+    MA_LAUNCH((attn_bwd_kernel<true, 1, false, 0>), grid_k, dim3(256), 0, s, MA_AB_ARGS);
+    MA_LAUNCH((attn_bwd_kernel<false, 1, false, 0>), grid_f, dim3(256), 0, s, MA_AB_ARGS);
+  } else if (mask3) {
     MA_LAUNCH((attn_bwd_kernel<true, 1, true>), grid_k, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
               bias_u, bias_v, (const uint16_t*)dctx, ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
     MA_LAUNCH((attn_bwd_kernel<false, 1, true>), grid_f, dim3(256), 0, s, (const uint16_t*)qkv, ld_qkv, (const uint16_t*)pos, ld_pos,
@@ -547,7 +560,8 @@ static int relpos_attention_bwd(const void* qkv, int64_t ld_qkv, const void* pos
               (const uint16_t*)dctx, ld_dctx, mask, mask3, lse, ws, (int)T, (int)heads, scale, (uint16_t*)dqkv, ld_dqkv, dpos, ld_dpos, dbias_u, dbias_v);
   }
   if (!dpos) return MA_OK;  // the per-batch / per-workgroup partials stay in the workspace for the caller's batched reduction
-  MA_LAUNCH(attn_dpos_reduce_kernel, dim3((unsigned)T), dim3(256), 0, s, ws.dp_part, (int)batch, (int)T, ws.Tp, dpos,
+#undef MA_AB_ARGS
+  MA_LAUNCH(attn_dpos_reduce_kernel, dim3((unsigned)T, (unsigned)(dm / 256)), dim3(256), 0, s, ws.dp_part, (int)batch, (int)T, ws.Tp, dpos,
             ld_dpos);
   MA_LAUNCH(attn_bias_reduce_kernel, dim3((unsigned)heads), dim3(1024), 0, s, ws.bias_part, (int)batch, (int)heads, ws.Tp / 64,
             dbias_u, dbias_v);

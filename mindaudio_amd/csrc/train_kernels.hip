@@ -292,6 +292,102 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   part[(int64_t)blockIdx.x * 512 + 256 + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
 }
 
+// The same for D = 256 * VEC (d_model 512 / 768 / 1024: the reference's constructor takes any size, models/conformer.py:293-313; one
+// launch per reference cell): lane l holds columns (i * 64 + l) * 4 .. + 3 of piece i, as layernorm_kernel<VEC> does; per-workgroup
+// partials (dgamma (D) | dbeta (D)).
+template <bool DY_BF16, int VEC>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
+                                                                 const float* __restrict__ gamma, float eps,
+                                                                 const float* __restrict__ row_scale, const void* dy_, int64_t ldy,
+                                                                 float* g, int64_t ldg, int accumulate, float* __restrict__ part) {
+  constexpr int D = 256 * VEC;
+  __shared__ float red[2][4][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gm[VEC][4], dg[VEC][4], db[VEC][4];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const float4 t = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+    gm[i][0] = t.x; gm[i][1] = t.y; gm[i][2] = t.z; gm[i][3] = t.w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.0f;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float xv[VEC][4], dv[VEC][4];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const float4 t = *reinterpret_cast<const float4*>(x + row * ldx + c);
+      xv[i][0] = t.x; xv[i][1] = t.y; xv[i][2] = t.z; xv[i][3] = t.w;
+      if (DY_BF16) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(dy_) + row * ldy + c);
+        dv[i][0] = __uint_as_float(raw.x << 16); dv[i][1] = __uint_as_float(raw.x & 0xffff0000u);
+        dv[i][2] = __uint_as_float(raw.y << 16); dv[i][3] = __uint_as_float(raw.y & 0xffff0000u);
+      } else {
+        const float4 u = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + row * ldy + c);
+        dv[i][0] = u.x; dv[i][1] = u.y; dv[i][2] = u.z; dv[i][3] = u.w;
+      }
+      s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+    }
+    const float rs = row_scale ? row_scale[row] : 1.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mu = s * (1.0f / D);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xv[i][e] -= mu;
+      q += (xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1]) + (xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
+    float a = 0.0f, b = 0.0f, w[VEC][4];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xv[i][e] *= rstd;  // xhat
+        const float dyi = dv[i][e] * rs;
+        dg[i][e] += dyi * xv[i][e];
+        db[i][e] += dyi;
+        w[i][e] = dyi * gm[i][e];
+        a += w[i][e];
+        b += w[i][e] * xv[i][e];
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      b += __shfl_xor(b, off, 64);
+    }
+    a *= (1.0f / D);
+    b *= (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float* gp = g + row * ldg + (i * 64 + lane) * 4;
+      float4 o = accumulate ? *reinterpret_cast<const float4*>(gp) : make_float4(0, 0, 0, 0);
+      o.x += rstd * (w[i][0] - a - xv[i][0] * b);
+      o.y += rstd * (w[i][1] - a - xv[i][1] * b);
+      o.z += rstd * (w[i][2] - a - xv[i][2] * b);
+      o.w += rstd * (w[i][3] - a - xv[i][3] * b);
+      *reinterpret_cast<float4*>(gp) = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][wave][(i * 64 + lane) * 4 + e] = dg[i][e];
+      red[1][wave][(i * 64 + lane) * 4 + e] = db[i][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    part[(int64_t)blockIdx.x * 2 * D + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    part[(int64_t)blockIdx.x * 2 * D + D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  }
+}
+
 // ---- Swish + dropout between w_1 and w_2 -----------------------------------------------------------------------
 // 8 elements (16 bytes) per thread; n % 8 == 0
 __global__ __launch_bounds__(256) void act_dropout_fwd_kernel(const uint16_t* __restrict__ u, uint16_t* __restrict__ h,
@@ -627,7 +723,7 @@ __global__ __launch_bounds__(256) void convmid_bwd_kernel(const float* __restric
   constexpr int pad = (KS - 1) / 2, kRows = kCbStrip + KS - 1;
   // (round 4: glu(y), dz and sigmoid(gate) of the strip + halo of a thread's channel stay in registers, as in the forward kernel)
   const int tid = threadIdx.x;
-  const int c = tid;
+  const int c = blockIdx.z * 256 + tid;
   const int b = blockIdx.y;
   const int64_t base = (int64_t)b * T;
   float wr[KS], dwr[KS];
@@ -871,7 +967,7 @@ __global__ __launch_bounds__(256) void conv1_dw8_kernel(const AT* __restrict__ d
   __shared__ float red[4][32][81];  // [wave][channel group][8 channels x (9 taps + bias)] (+1: bank spread)
   extern __shared__ float xs_l[];   // XLDS: [output rows of the strip][3][idim]
   const int tid = threadIdx.x, cg = tid & 31, pg = tid >> 5;
-  const int c0 = cg * 8;
+  const int c0 = blockIdx.y * 256 + cg * 8;  // (grid.y: slabs of 256 channels - d_model 512 / 768 / 1024)
   const bool live = c0 < C;
   const int npos = B * H1 * W1;
   const int p0 = blockIdx.x * strip, p1 = min(npos, p0 + strip);
@@ -970,7 +1066,7 @@ __global__ __launch_bounds__(256) void conv1_dw8_kernel(const AT* __restrict__ d
   float* pp = part + (int64_t)blockIdx.x * ((int64_t)C * 10);
   for (int i = tid; i < 32 * 80; i += 256) {
     const int g = i / 80, r = i - g * 80, e = r / 10, k = r - e * 10;
-    const int c = g * 8 + e;
+    const int c = blockIdx.y * 256 + g * 8 + e;
     if (c >= C) continue;
     const float v = (red[0][g][r] + red[1][g][r]) + (red[2][g][r] + red[3][g][r]);
     if (k < 9) pp[c * 9 + k] = v;
@@ -1147,10 +1243,27 @@ int ma_layernorm_bwd_f32(const float* x, int64_t ldx, int64_t rows, int64_t D, c
                          int32_t accumulate, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
                          ma_stream_t stream) {
   if (!x || !gamma || !dy || !g || (dgamma && !dbeta) || !workspace || rows < 1) return MA_ERR_INVALID_ARG;
-  if (D != 256 || (ldx & 3) || (ldy & 3) || (ldg & 3)) return MA_ERR_UNSUPPORTED;
+  if ((D != 256 && D != 512 && D != 768 && D != 1024) || (ldx & 3) || (ldy & 3) || (ldg & 3)) return MA_ERR_UNSUPPORTED;
   const int grid = ma_layernorm_bwd_parts(rows);
-  if (workspace_bytes < (int64_t)grid * 512 * 4) return MA_ERR_WORKSPACE;
+  if (workspace_bytes < (int64_t)grid * 2 * D * 4) return MA_ERR_WORKSPACE;
   float* part = reinterpret_cast<float*>(workspace);
+  if (D != 256) {  // d_model 512 / 768 / 1024: partial vectors of 2 D floats
+#define MA_LNW(VEC_)                                                                                                              \
+  if (dy_bf16)                                                                                                                    \
+    MA_LAUNCH((layernorm_bwd_wide_kernel<true, VEC_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,   \
+              row_scale, dy, ldy, g, ldg, accumulate, part);                                                                      \
+  else                                                                                                                            \
+    MA_LAUNCH((layernorm_bwd_wide_kernel<false, VEC_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma, eps,  \
+              row_scale, dy, ldy, g, ldg, accumulate, part)
+    if (D == 512) { MA_LNW(2); }
+    else if (D == 768) { MA_LNW(3); }
+    else { MA_LNW(4); }
+#undef MA_LNW
+    if (dgamma)
+      MA_LAUNCH(partial_reduce_kernel, dim3((unsigned)((2 * D + 15) / 16)), dim3(256), 0, (hipStream_t)stream, part, grid, (int)(2 * D),
+                dgamma, (int)D, dbeta, 0);
+    return MA_OK;
+  }
   return ln_bwd_launch(x, ldx, rows, gamma, eps, row_scale, dy, ldy, dy_bf16, g, ldg, accumulate, dgamma, dbeta, part, grid, nullptr, 0,
                        0.0f, nullptr, make_drop(0.0f, 0, 0), stream);
 }
@@ -1242,7 +1355,7 @@ template <typename AT>
 static int convmid_fwd_train_launch(const AT* y, int64_t ldy, int64_t batch, int64_t T, int32_t C, const float* dw_w,
                                     int32_t ks, const float* dw_b, float* z, float* sums, ma_stream_t stream) {
   if (!y || !dw_w || !dw_b || !z || !sums || batch < 1 || T < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
-  if (C != 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31) || (sizeof(AT) == 2 && (ldy & 1))) return MA_ERR_UNSUPPORTED;
+  if (C < 256 || C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31) || (sizeof(AT) == 2 && (ldy & 1))) return MA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)((T + kCfStrip * kCfPerBlock - 1) / (kCfStrip * kCfPerBlock)), (unsigned)batch, (unsigned)(C / 256));
 #define MA_CF(KS_)                                                                                                  \
   MA_LAUNCH((convmid_fwd_train_kernel<KS_, AT>), grid, dim3(256), 0, (hipStream_t)stream, y, ldy, (int)T, C, dw_w, dw_b, z, sums)
@@ -1300,13 +1413,14 @@ static int bn_swish_bwd_launch(const AT* dout, const float* z, const float* stat
                                float* dz, int64_t rows, int32_t C, float* dsum, float* d_gamma, float* d_beta, void* workspace,
                                int64_t workspace_bytes, ma_stream_t stream, bool second_stage = true) {
   if (!dout || !z || !stats || !gamma || !beta || !dz || !dsum || !workspace || rows < 1) return MA_ERR_INVALID_ARG;
-  if (C < 1 || C > 256 || 256 % C) return MA_ERR_UNSUPPORTED;
+  const bool v4 = (C & 3) == 0 && C <= 1024 && (256 % (C / 4) == 0 || C > 256) &&
+                  ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0;
+  if (C < 1 || (!v4 && (C > 256 || 256 % C))) return MA_ERR_UNSUPPORTED;
   if (workspace_bytes < (int64_t)256 * 2 * C * 4) return MA_ERR_WORKSPACE;
   float* part = reinterpret_cast<float*>(workspace);  // one (sum dn | sum dn zhat) vector per workgroup
   const int rpb = 256 / C;
   int nblk;
-  if ((C & 3) == 0 && 256 % (C / 4) == 0 &&
-      ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0) {
+  if (v4) {  // (C = 768: 192 threads per row, the last 64 threads of the workgroup idle)
     nblk = grid_for(rows, 256 / (C / 4), 256);
     MA_LAUNCH(bn_swish_bwd1_v4_kernel<AT>, dim3(nblk), dim3(256), (256 / (C / 4)) * 2 * C * sizeof(float), (hipStream_t)stream, dout,
               z, stats, gamma, beta, dz, rows, C, part);
@@ -1348,13 +1462,13 @@ static int convmid_bwd_launch(const float* dz, const AT* y, int64_t ldy, int64_t
   if (!dz || !y || !dw_w || !dy || (d_dw_w && !d_dw_b) || !workspace || batch < 1 || T < 1) return MA_ERR_INVALID_ARG;
   if (bnp && (!bnp->z || !bnp->stats || !bnp->gamma || !bnp->dsum)) return MA_ERR_INVALID_ARG;
   const CmBn bn = bnp ? *bnp : CmBn{};
-  if (C != 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
+  if (C < 256 || C % 256 || (ks != 3 && ks != 7 && ks != 15 && ks != 31)) return MA_ERR_UNSUPPORTED;
   float* part = reinterpret_cast<float*>(workspace);
   // strips per workgroup: as few as keep the number of partial vectors inside the workspace
   int64_t strips = (T + kCbStrip - 1) / kCbStrip;
   int per_block = 1;
   while (((strips + per_block - 1) / per_block) * batch > kMaxPartBlocks) ++per_block;
-  const dim3 grid((unsigned)((strips + per_block - 1) / per_block), (unsigned)batch, 1);
+  const dim3 grid((unsigned)((strips + per_block - 1) / per_block), (unsigned)batch, (unsigned)(C / 256));  // z: 256-channel slabs
   const int nblk = (int)(grid.x * grid.y), width = C * (ks + 1);
   if (workspace_bytes < (int64_t)nblk * width * 4) return MA_ERR_WORKSPACE;
 #define MA_CMB(KS_)                                                                                                    \
@@ -1454,20 +1568,23 @@ static int conv1_dw_launch(const AT* dact, const float* x, int64_t batch, int64_
                            const float* cmvn_istd, int32_t C, float* dw, float* db, void* workspace, int64_t workspace_bytes,
                            ma_stream_t stream) {
   if (!dact || !x || !dw || !db || !workspace || batch < 1 || T < 3 || idim < 3 || C < 1) return MA_ERR_INVALID_ARG;
-  if (C > 256) return MA_ERR_UNSUPPORTED;
+  if (C > 1024) return MA_ERR_UNSUPPORTED;
   if (workspace_bytes < ma_train_reduce_workspace_bytes()) return MA_ERR_WORKSPACE;
   float* part = reinterpret_cast<float*>(workspace);
   const int H1 = (int)((T - 3) / 2 + 1), W1 = (idim - 3) / 2 + 1;
   const int64_t npos = batch * H1 * W1;
-  int64_t strip64 = (npos + kMaxPartBlocks - 1) / kMaxPartBlocks;  // as many workgroups as the partial workspace holds
+  // as many workgroups as the partial workspace holds (one vector of 10 C floats each)
+  int64_t max_blocks = (int64_t)kMaxPartBlocks * kMaxPartWidth / ((int64_t)C * 10);
+  if (max_blocks > kMaxPartBlocks) max_blocks = kMaxPartBlocks;
+  int64_t strip64 = (npos + max_blocks - 1) / max_blocks;
   const int strip = (int)(strip64 < 64 ? 64 : strip64);
   const int nblk = (int)((npos + strip - 1) / strip);
   const size_t xl_bytes = (size_t)(strip / W1 + 2) * 3 * idim * sizeof(float);  // the strip's input rows
   if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(dact) & 15) == 0 && xl_bytes <= 20 * 1024)
-    MA_LAUNCH((conv1_dw8_kernel<AT, true>), dim3((unsigned)nblk), dim3(256), xl_bytes, (hipStream_t)stream, dact, x, (int)batch, (int)T,
+    MA_LAUNCH((conv1_dw8_kernel<AT, true>), dim3((unsigned)nblk, (unsigned)((C + 255) / 256)), dim3(256), xl_bytes, (hipStream_t)stream, dact, x, (int)batch, (int)T,
               idim, H1, W1, C, cmvn_mean, cmvn_istd, part, strip);
   else if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(dact) & 15) == 0)
-    MA_LAUNCH((conv1_dw8_kernel<AT, false>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dact, x, (int)batch, (int)T, idim,
+    MA_LAUNCH((conv1_dw8_kernel<AT, false>), dim3((unsigned)nblk, (unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dact, x, (int)batch, (int)T, idim,
               H1, W1, C, cmvn_mean, cmvn_istd, part, strip);
   else
     MA_LAUNCH(conv1_dw_kernel<AT>, dim3((unsigned)((npos + strip - 1) / strip), (unsigned)((C + 255) / 256)), dim3(256), 0,

@@ -404,8 +404,8 @@ class ConformerEncoder(nn.Module):
         if not self.training and self._bn_dirty:
             self._refresh_bn(P)
         if self.training:
-            if self.d != 256 or self.kernel not in (3, 7, 15, 31):
-                raise NotImplementedError("the training-mode kernels are built for d_model 256")
+            if self.kernel not in (3, 7, 15, 31):
+                raise NotImplementedError("the training-mode depthwise convolution is built for kernel sizes 3, 7, 15 and 31")
             return self._forward_train(xs.to(f32), P, masks, xs_chunk_masks)
         b = xs.shape[0]
         act2 = self._subsample(xs.to(f32), P)  # (any strides: conv1 reads the view as it is)

@@ -48,8 +48,8 @@ class TransformerDecoder(nn.Module):
             raise NotImplementedError("only the shipped decoder configuration is built")
         if self_attention_dropout_rate or src_attention_dropout_rate:
             raise NotImplementedError("attention-weight dropout is 0.0 in the shipped configuration")
-        if encoder_output_size != 256 or encoder_output_size // attention_heads != 64:
-            raise NotImplementedError("kernels are built for d_model 256 with 64-wide heads")
+        if encoder_output_size not in (256, 512, 768, 1024) or encoder_output_size != attention_heads * 64:
+            raise NotImplementedError("kernels are built for 64-wide heads with d_model 256, 512, 768 or 1024")
         d = encoder_output_size
         self.d, self.heads, self.vocab_size = d, attention_heads, vocab_size
         self.dropout_rate, self.positional_dropout_rate = dropout_rate, positional_dropout_rate

@@ -233,12 +233,11 @@ class ConformerCTCTrainStep:
         # fused = the dense layers of a block run on fragment-packed weights with their element-wise neighbours (Swish + dropout,
         # residual + dropout + LayerNorm, Swish' + dropout, the next branch's dropout backward) in the launch's epilogue;
         # False = one launch per reference cell (what the float32 validation mode always runs)
-        self.fused = bool(fused) and not self.x32
-        if self.fused and enc.d != 256:
-            # the fused block launches (packed K = 256 dense layers, 256-wide LayerNorm epilogues) are built for the reference's
-            # d_model = 256 configurations only; say so here instead of failing inside the first step
-            raise NotImplementedError("ConformerCTCTrainStep: the bf16 training step is built for d_model = 256 (got %d); the reference's "
-                                      "other sizes run the evaluation forward only" % enc.d)
+        # The fused block launches (packed K = 256 dense layers, 256-wide LayerNorm epilogues) are built for the reference's
+        # d_model = 256 configurations; d_model 512 / 768 / 1024 (64-wide heads; the reference's constructor takes any size,
+        # models/conformer.py:293-313) run one launch per reference cell - the same policy as the evaluation forward (round 6;
+        # until then this constructor refused them).
+        self.fused = bool(fused) and not self.x32 and enc.d == 256
         # The step runs on ONE stream.  Rounds 3-4 also had a constructor option that put the weight-gradient products (and, in round 3,
         # the per-block batched sums) on a second stream: 0.4-14 % of fresh processes then saw a corrupted LayerNorm backward, narrowed
         # in round 4 to ONE kernel pair on two hardware queues (tn_reduce_batch_kernel beside layernorm_bwd_kernel) and
@@ -1059,7 +1058,8 @@ class ConformerCTCTrainStep:
         _, t2, f2, c = act2.shape
         m = b * t2
         self._t2_cur = t2
-        self._dw_cur = self._dw_plan_for(m) if tables else None
+        # (d_model 512 / 768 / 1024 - one launch per reference cell: every partial sum is taken where it is produced)
+        self._dw_cur = self._dw_plan_for(m) if tables and self.d == 256 else None
         if xs_masks.shape[-1] != t2:
             raise ValueError("masks must be the subsampled pad mask (B, 1, %d), got %s" % (t2, tuple(xs_masks.shape)))
         chunked = xs_chunk_masks is not None and xs_chunk_masks.dim() == 3 and xs_chunk_masks.shape[1] == t2 and t2 > 1

@@ -355,8 +355,8 @@ def test_encoder_accepts_strided_features():
     assert not view.is_contiguous() and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("tlen", [163, 3000])
-def test_asr_model_hybrid_eval_loss_and_decoder_scores_match_oracle(tlen):
+@pytest.mark.parametrize("tlen,d,heads", [(163, 256, 4), (3000, 256, 4), (163, 512, 8)])
+def test_asr_model_hybrid_eval_loss_and_decoder_scores_match_oracle(tlen, d, heads):
     """create_asr_eval_net of the shipped conformer.yaml (ctc_weight 0.3, TransformerDecoder, label smoothing 0.1;
     asr_model.py:75-209, 355-371): decoder scores, attention loss, accuracy and the mixed loss vs the float32 oracle.
     tlen = 3000 is the largest frame bucket of conformer.yaml (T' = 749 source positions for the decoder's attention)."""
@@ -367,16 +367,17 @@ def test_asr_model_hybrid_eval_loss_and_decoder_scores_match_oracle(tlen):
 
     torch.manual_seed(23)
     vocab, blocks, dblocks, b, lmax = 211, 2, 2, 3, 9
-    ref_enc = C.ConformerEncoder(80, 256, 4, 2048, blocks).eval()
-    ref_ctc = C.CTC(vocab, 256).eval()
-    ref_dec = C.TransformerDecoder(vocab, 256, 4, 512, dblocks, 0.0, 0.0).eval()
+    # (d = 512: the decoder module took d_model 256 only until round 6)
+    ref_enc = C.ConformerEncoder(80, d, heads, 2048, blocks).eval()
+    ref_ctc = C.CTC(vocab, d).eval()
+    ref_dec = C.TransformerDecoder(vocab, d, heads, 512, dblocks, 0.0, 0.0).eval()
     with torch.no_grad():
         for mod in ref_dec.modules():
             if isinstance(mod, C.LayerNorm):
                 mod.gamma.uniform_(0.8, 1.2)
                 mod.beta.normal_(0, 0.1)
-    model = create_asr_model(80, vocab, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks),
-                             ctc_weight=0.3, decoder_conf=dict(attention_heads=4, linear_units=512, num_blocks=dblocks),
+    model = create_asr_model(80, vocab, dict(output_size=d, attention_heads=heads, linear_units=2048, num_blocks=blocks),
+                             ctc_weight=0.3, decoder_conf=dict(attention_heads=heads, linear_units=512, num_blocks=dblocks),
                              lsm_weight=0.1).eval()
     model.encoder.load_state_dict(ref_enc.state_dict(), strict=False)
     model.ctc.load_state_dict(ref_ctc.state_dict())

@@ -188,10 +188,11 @@ def test_act_dropout_and_dropout_add(K):
 
 
 # (64, 255): 16 strips x 64 utterances = 1 024 workgroups in the forward and the backward launch (more than three resident rounds)
-@pytest.mark.parametrize("b,t", [(3, 37), (64, 255)])
-def test_convmid_train_fwd_bwd(K, b, t):
+# c = 512 / 768: the 256-channel slabs of d_model 512 / 768 (round 6: the launches took c = 256 only)
+@pytest.mark.parametrize("b,t,c", [(3, 37, 256), (64, 255, 256), (3, 37, 512), (5, 70, 768), (20, 255, 1024)])
+def test_convmid_train_fwd_bwd(K, b, t, c):
     g = torch.Generator().manual_seed(4)
-    c, ks = 256, 15
+    ks = 15
     y = bf(torch.randn(b * t, 2 * c, generator=g))
     dw_w = (0.3 * torch.randn(c, ks, generator=g)).requires_grad_()
     dw_b = (0.1 * torch.randn(c, generator=g)).requires_grad_()
@@ -267,8 +268,12 @@ def test_subsampling_backward_pieces(K):
     dy = bf(torch.randn(1000, generator=g)).cuda()
     yv = bf(torch.randn(1000, generator=g))
     assert torch.equal(K.relu_bwd(dy.clone(), yv.cuda()).cpu(), dy.cpu() * (yv.float() > 0).to(torch.bfloat16))
-    # conv1 weight gradient
-    bb, tt, idim, cc = 2, 31, 80, 256
+    # conv1 weight gradient (cc = 512 / 1024: slabs of 256 channels, round 6; (40, 255): more partial vectors than one round)
+    for bb, tt, idim, cc in ((2, 31, 80, 256), (2, 31, 80, 512), (3, 45, 80, 1024), (40, 255, 80, 512)):
+        _conv1_dw_case(K, g, bb, tt, idim, cc)
+
+
+def _conv1_dw_case(K, g, bb, tt, idim, cc):
     x = torch.randn(bb, tt, idim, generator=g)
     mean, istd = torch.randn(idim, generator=g), 0.5 + torch.rand(idim, generator=g)
     h1, w1 = (tt - 3) // 2 + 1, (idim - 3) // 2 + 1
@@ -331,12 +336,15 @@ def test_adam_and_overflow(K):
 
 @pytest.mark.parametrize("chunked", [False, True])
 # (64, 255): 64 x 4 heads x 4 slabs = 1 024 workgroups per backward kernel (more than three resident rounds of 256 CUs)
-@pytest.mark.parametrize("b,t", [(2, 100), (3, 255), (1, 64), (2, 37), (2, 300), (1, 129), (64, 255)])
-def test_attention_backward(K, b, t, chunked):
+# h = 8 / 12 / 16: d_model 512 / 768 / 1024 (round 6; the rows of qkv are [q (64 h) | k | v])
+@pytest.mark.parametrize("b,t,h", [(2, 100, 4), (3, 255, 4), (1, 64, 4), (2, 37, 4), (2, 300, 4), (1, 129, 4), (64, 255, 4),
+                                   (2, 100, 8), (2, 37, 12), (3, 255, 16), (20, 255, 8)])
+def test_attention_backward(K, b, t, h, chunked):
     g = torch.Generator().manual_seed(7 + t)
-    h, dk = 4, 64
-    qkv = bf(torch.randn(b * t, 768, generator=g) * 0.8)
-    pos = bf(torch.randn(t, 256, generator=g) * 0.8)
+    dk = 64
+    dm = h * dk
+    qkv = bf(torch.randn(b * t, 3 * dm, generator=g) * 0.8)
+    pos = bf(torch.randn(t, dm, generator=g) * 0.8)
     u = (0.3 * torch.randn(h, dk, generator=g)).requires_grad_()
     v = (0.3 * torch.randn(h, dk, generator=g)).requires_grad_()
     lens = torch.randint(t // 2, t + 1, (b,), generator=g)
@@ -344,9 +352,9 @@ def test_attention_backward(K, b, t, chunked):
     mask = (torch.arange(t)[None, :] < lens[:, None]).float()
     qf = qkv.float().requires_grad_()
     pf = pos.float().requires_grad_()
-    q = qf[:, :256].view(b, t, h, dk)
-    k = qf[:, 256:512].view(b, t, h, dk).transpose(1, 2)
-    vv = qf[:, 512:].view(b, t, h, dk).transpose(1, 2)
+    q = qf[:, :dm].view(b, t, h, dk)
+    k = qf[:, dm:2 * dm].view(b, t, h, dk).transpose(1, 2)
+    vv = qf[:, 2 * dm:].view(b, t, h, dk).transpose(1, 2)
     p = pf.view(1, t, h, dk).transpose(1, 2)
     qu = bf((q + u).detach()).float() + ((q + u) - (q + u).detach())  # the kernels round q + bias to bf16 (straight-through)
     qv = bf((q + v).detach()).float() + ((q + v) - (q + v).detach())
@@ -359,18 +367,18 @@ def test_attention_backward(K, b, t, chunked):
     else:
         scores = scores + (mask[:, None, None, :] == 0).float() * -10000.0
     attn = torch.softmax(scores, -1)
-    ctx_ref = (attn @ vv).transpose(1, 2).reshape(b * t, 256)
-    dctx = bf(torch.randn(b * t, 256, generator=g))
+    ctx_ref = (attn @ vv).transpose(1, 2).reshape(b * t, dm)
+    dctx = bf(torch.randn(b * t, dm, generator=g))
     ctx_ref.backward(dctx.float())
-    ctx, lse = K.attention_fwd(qkv.cuda(), pos.cuda(), u.detach().cuda(), v.detach().cuda(), mask.cuda(), b, t)
+    ctx, lse = K.attention_fwd(qkv.cuda(), pos.cuda(), u.detach().cuda(), v.detach().cuda(), mask.cuda(), b, t, heads=h)
     assert rel(ctx, ctx_ref.detach()) < 1e-2
     assert rel(lse, torch.logsumexp(scores.detach(), -1)) < 1e-3
-    dpos = torch.zeros(t, 256, device="cuda")
+    dpos = torch.zeros(t, dm, device="cuda")
     du, dv = torch.zeros(h, dk, device="cuda"), torch.zeros(h, dk, device="cuda")
     dqkv = K.attention_bwd(qkv.cuda(), pos.cuda(), u.detach().cuda(), v.detach().cuda(), mask.cuda(), ctx, dctx.cuda(),
-                           lse, b, t, dpos, du, dv)
-    for name, lo in (("dq", 0), ("dk", 256), ("dv", 512)):
-        assert rel(dqkv[:, lo:lo + 256], qf.grad[:, lo:lo + 256]) < 2e-2, name
+                           lse, b, t, dpos, du, dv, heads=h)
+    for name, lo in (("dq", 0), ("dk", dm), ("dv", 2 * dm)):
+        assert rel(dqkv[:, lo:lo + dm], qf.grad[:, lo:lo + dm]) < 2e-2, name
     assert rel(dpos, pf.grad) < 2e-2
     assert rel(du, u.grad) < 2e-2 and rel(dv, v.grad) < 2e-2
 

@@ -83,9 +83,26 @@ __global__ void rows_pack_kernel(const uint16_t* __restrict__ w, int64_t ldw, in
 // LayerNorm chain, float32 out), MODE 4 = out bf16 = acc + bias.
 // MT = 16-row tiles per workgroup: 4 (64 rows), or 3 (48 rows) when 64-row tiles would leave a third of the CUs without a workgroup
 // (the training step's M = 10 200 rows: 160 workgroups of 64 rows on 256 CUs, 213 of 48; the loader wave then brings 48 rows).
+// Phase stamps for tools/rows_timeline.py (compiled in only with -DMA_RP_PROF): wave 0 of three workgroups keeps wall_clock64() (100 MHz)
+// values and writes them out at the end of the kernel (MODE 5).
+#ifdef MA_RP_PROF
+__device__ unsigned long long g_rp_prof[3 * 8];
+#define RP_STAMP(k)                                    \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    rp_ts[(k)] = wall_clock64();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  } while (0)
+#else
+#define RP_STAMP(k) do { } while (0)
+#endif
 template <int MODE, int MT = 4>
 __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPackedParams p, const TrainEpi e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef MA_RP_PROF
+  unsigned long long rp_ts[8];
+  RP_STAMP(0);
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
@@ -159,8 +176,19 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
   // first weight fragments and activation chunks are in flight (LDS scratch behind the activation ring)
   float4 xh5[MODE == 5 ? MT : 1][4];
   float rstd5[MODE == 5 ? MT : 1];
+#ifdef MA_RP_PROF
+  if constexpr (MODE == 5) {
+    RP_STAMP(5);  // weight prologue issued
+    lnbwd_stats_load<MT>(e, m0, p.M, wave, c, g, xh5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RP_STAMP(6);  // x landed
+    lnbwd_stats_compute<MT>(e, wave, c, g, reinterpret_cast<float*>(smem + kRpLds), xh5, rstd5);
+  }
+#else
   if constexpr (MODE == 5)
     lnbwd_stats<MT>(e, m0, p.M, wave, c, g, reinterpret_cast<float*>(smem + kRpLds), xh5, rstd5);
+#endif
+  RP_STAMP(1);  // LayerNorm statistics taken
 
   // Loads of an MFMA wave, oldest first, in the steady state: ... W(c)[q..7] | W(c+1)x8 | W(c+2)x8 | W(c+3)[0..q-1] ... (W(c+3)[q] is
   // issued right after the last MFMA that reads ring[c % 3][q] in chunk c): use of ring[.][q] in chunk c: younger = (7 - q) + 8 + 8 + q
@@ -212,6 +240,7 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
     chunk_step(S1{}, c3 + 1);
     chunk_step(S2{}, c3 + 2);
   }
+  RP_STAMP(2);  // main loop done
   // the duplicate loads past the last chunk: the ring registers stay reserved until they have landed
   asm volatile("s_waitcnt vmcnt(0)"
                : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[0][2]), "+v"(ring[0][3]), "+v"(ring[0][4]), "+v"(ring[0][5]), "+v"(ring[0][6]),
@@ -229,7 +258,26 @@ __global__ __launch_bounds__(kRpThreads, 1) void rows_packed_kernel(const RowsPa
     return;
   } else if constexpr (MODE == 5) {
     __syncthreads();  // every wave is past its last fragment reads: the activation stages become the exchange scratch
+#ifdef MA_RP_PROF
+    {
+      LnTailLoads<MT> in;
+      lnbwd_tail_load<MT>(e, m0, p.M, wave, c, g, p.out, p.ldo, in);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RP_STAMP(7);  // g landed
+      lnbwd_tail_compute<MT>(e, acc, xh5, rstd5, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem), (int)blockIdx.x, in);
+    }
+    RP_STAMP(3);  // tail instructions issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RP_STAMP(4);  // stores retired
+    {
+      const int wg = blockIdx.x;
+      const int slot = wg == 0 ? 0 : wg == 100 ? 1 : wg == (int)gridDim.x - 1 ? 2 : -1;
+      if (threadIdx.x == 0 && slot >= 0)
+        for (int k = 0; k < 8; ++k) g_rp_prof[slot * 8 + k] = rp_ts[k];
+    }
+#else
     lnbwd_tail<MT>(e, acc, xh5, rstd5, m0, p.M, wave, c, g, p.out, p.ldo, reinterpret_cast<float*>(smem), (int)blockIdx.x);
+#endif
     return;
   } else {
     float4 bv[4];
@@ -301,6 +349,12 @@ MA_LDS_ATTR((rows_packed_kernel<5, 4>), kRpLds5);
 }  // namespace ma
 
 using namespace ma;
+
+#ifdef MA_RP_PROF
+extern "C" int ma_debug_rp_prof(unsigned long long* host24) {
+  return hipMemcpyFromSymbol(host24, HIP_SYMBOL(g_rp_prof), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int64_t ma_gemm_rows_packed_bytes(int64_t N, int64_t K) {
   if (N != kRpN || K < 64 || K % 64 != 0 || K > (1 << 20)) return MA_ERR_UNSUPPORTED;

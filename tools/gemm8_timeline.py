@@ -9,7 +9,8 @@ from mindaudio_amd import _lib, ops
 lib = _lib.load()
 lib.ma_debug_g8_prof.argtypes = [ctypes.c_void_p]
 names = ["entry", "first K-tile issued", "first K-tile landed", "main loop done", "epilogue issued", "stores retired"]
-for (m, n, k) in [(4096, 4096, 1024), (4096, 4096, 4096), (16384, 4096, 1024)]:
+shapes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(4096, 4096, 1024), (4096, 4096, 4096), (16384, 4096, 1024)]
+for (m, n, k) in shapes:  # (argv: MxNxK ...)
     a = torch.randn(m, k, device="cuda").bfloat16(); w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).bfloat16()
     o = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
     fn = lambda: ops.gemm(a, w, out=o)

@@ -60,6 +60,7 @@ struct GemmParams {
   int32_t kt_split;
   // 8-phase kernel: tiles are walked in blocks of `blk_rows` row tiles x `blk_cols` column tiles (0: plain row-major order)
   int32_t blk_rows, blk_cols;
+  int32_t nt_out;  // bf16 tiles leave through non-temporal stores (set by the launchers for short contractions)
 };
 
 // two f32 -> packed bf16x2, round to nearest even (v_cvt_pk_bf16_f32, gfx950)
@@ -296,10 +297,21 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, f32x4 (&acc
     __syncthreads();
     constexpr int kRowBytes = BN * 2, kChunks = kRowBytes / 16;
     uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m0 * p.ldo + n0;
+#ifdef MA_G8_NOSTORE  // ablation: the staged tile is not written out (only row 0, so that the staging stays live)
+    for (int c = tid; c < kChunks; c += NT) {
+#else
     for (int c = tid; c < BM * kChunks; c += NT) {
+#endif
       const int r = c / kChunks, cc = c - r * kChunks;
-      *reinterpret_cast<uint4*>(o + (int64_t)r * p.ldo + cc * 8) =
-          *reinterpret_cast<const uint4*>(smem + r * (kRowBytes + 16) + cc * 16);
+      const uint4 v4 = *reinterpret_cast<const uint4*>(smem + r * (kRowBytes + 16) + cc * 16);
+      uint16_t* dst = o + (int64_t)r * p.ldo + cc * 8;
+      if (p.nt_out) {  // streaming stores: the output does not displace the operand panels in the XCD's L2 (see launch_gemm_8ph)
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        const u4v v = {v4.x, v4.y, v4.z, v4.w};
+        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+      } else {
+        *reinterpret_cast<uint4*>(dst) = v4;
+      }
     }
   }
 }
@@ -804,9 +816,17 @@ __global__ __launch_bounds__(kWsThreads, 1) void gemm_ws512_kernel(const GemmPar
     for (int k = 0; k < (kWsRows * 16) / kWsThreads; ++k) {
       const int cidx = k * kWsThreads + tid, r = cidx >> 4, cc = cidx & 15;
       const int m = tile * kWsRows + r;
-      if (m < p.M)
-        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + cb * kWsCols + cc * 8) =
-            *reinterpret_cast<const uint4*>(stage + r * kWsStagePitch + cc * 16);
+      if (m < p.M) {
+        const uint4 v4 = *reinterpret_cast<const uint4*>(stage + r * kWsStagePitch + cc * 16);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldo + cb * kWsCols + cc * 8;
+        if (p.nt_out) {
+          typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+          const u4v v = {v4.x, v4.y, v4.z, v4.w};
+          asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+        } else {
+          *reinterpret_cast<uint4*>(dst) = v4;
+        }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the duplicate tile loads land before the LDS is handed back
@@ -968,6 +988,22 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
   return launch_gemm_tile<64, 128, 3, IM2COL, EPI>(p, stream);
 }
 
+// Non-temporal stores for the bf16 output tiles (round 6).  A resident round of tiles writes as many bytes as an XCD's L2 holds
+// (32 tiles x 128 KB = 4 MB): written through the cache the output displaces the operand panels the next tiles are about to re-read.
+// Measured alone (tools/gemm_bench.py): 76 800 x 1024 x 1024 172 -> 157 us, 76 800 x 3072 x 3072 1 130 -> 1 141 us; inside the
+// ECAPA forward (tools/ecapa_bench.py, four alternating runs each): C = 1024 3.625 -> 3.567 ms, C = 512 1.424 -> 1.415 ms with every
+// large product streaming, less with the short contractions only.  Rule: bf16 outputs of >= 32 MB (they do not fit a cache anyway).
+// MA_GEMM_NT=0 / 1 forces it off / on (A/B switch of tools/).
+static int gemm_nt_choice(const GemmParams& p) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("MA_GEMM_NT");
+    mode = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : 2;
+  }
+  if (mode != 2) return mode;
+  return (p.out_bf16 && (int64_t)p.M * p.N >= ((int64_t)16 << 20)) ? 1 : 0;
+}
+
 static int fill_epilogue(GemmParams& p, const ma_gemm_epilogue_t* e) {
   p.alpha = 1.0f;
   if (!e) return MA_OK;
@@ -1016,6 +1052,7 @@ int ma_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* o
   p.K = (int32_t)K;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
+  p.nt_out = gemm_nt_choice(p);
   // K = 512 with >= 16 k rows and bf16 output (ECAPA's 1 x 1 convolutions at C = 512): the weight-stationary persistent kernel
   if (K == kWsK && (N % kWsCols) == 0 && N <= 1024 && M >= 16384 && p.out_bf16 && !p.residual && p.alpha == 1.0f && (ldo & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
@@ -1053,6 +1090,7 @@ int ma_conv1d_taps_bf16(const void* act, int64_t lda, int64_t rows, int64_t C, i
   p.dil = dilation;
   const int rc = fill_epilogue(p, epi);
   if (rc != MA_OK) return rc;
+  p.nt_out = gemm_nt_choice(p);
   if (taps == 1) return launch_gemm<0, 1>(p, (hipStream_t)stream);  // a plain GEMM: eligible for the 256 x 256 kernel
   return launch_gemm<2, 1>(p, (hipStream_t)stream);
 }

@@ -802,7 +802,8 @@ int ma_embed_bwd_f32(const int32_t* tokens, const float* g, int64_t rows, int32_
 int ma_embed_bwd_rows_f32(const int32_t* tokens, const float* g, const float* row_keep, int64_t rows, int32_t D, int32_t V,
                           float xscale, float p, uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream);
 
-/* MultiHeadedAttention core (layers/attention.py:86-157) for Lq <= 32 queries and Lk <= 1088 keys per (batch, head)
+/* MultiHeadedAttention core (layers/attention.py:86-157) for Lq <= 1024 queries (walked in tiles of 32, one launch each: labels of
+ * more than 31 tokens - AISHELL's longest transcripts, token_max_length 200 - were refused until round 6) and Lk <= 1088 keys per (batch, head)
  * (up to 320 keys the V / K rows are staged in LDS; beyond that - the 1400 ... 3000-frame buckets of conformer.yaml, T' <= 749 -
  * the score rows take the LDS and V / K are read from L2; more keys: MA_ERR_UNSUPPORTED), d_k = 64: ctx = softmax(scale * q k^T + (mask == 0 ? -10000 : 0)) v.  q (batch*Lq, H*64) / k, v (batch*Lk, H*64) bf16
  * with row strides; mask_mode 0 none, 1 (batch, 1, Lk), 2 (batch, Lq, Lk) float32; probs (batch, H, Lq, Lk) float32 is

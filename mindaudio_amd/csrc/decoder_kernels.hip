@@ -4,7 +4,7 @@
 // The decoder works on B x (max_tgt_len + 1) <= B x 32 tokens: its matmuls reuse gemm_bf16 / gemm_tn_bf16, LayerNorm
 // and dropout reuse the encoder kernels; this file adds the token-sized pieces:
 //   embed_posenc fwd/bwd      nn.Embedding -> x * sqrt(d) + pe -> dropout (embedding.py:16-62)
-//   mha_small fwd/bwd         softmax(q k^T / d_k + mask) v for <= 32 queries x <= 256 keys per (batch, head); scores are
+//   mha_small fwd/bwd         softmax(q k^T / d_k + mask) v for 32 queries (a launch; longer labels: one launch per tile) x <= 256 keys per (batch, head); scores are
 //                             q*s . k*s with s = 1/sqrt(d_k), i.e. divided by d_k (attention.py:150-152); additive -10000
 //                             mask of shape (B, 1, Lk) or (B, Lq, Lk); probabilities are kept for the backward pass
 //   label_smoothing           KL(true_dist || softmax) summed over unmasked tokens / batch + its gradient + accuracy
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
 
 // ---- small multi-head attention ----------------------------------------------------------------------------------
 constexpr int kSmQ = 32, kSmK = 320, kSmD = 64;
+constexpr int kSmQMax = 1024;  // query rows per (batch, head): walked in tiles of kSmQ, one launch each (token_max_length is 200)
 constexpr int kSmKMax = 1088;  // keys when the score rows own the LDS (backward: 32 x 1089 floats + q / dO rows = 153 KiB)
 template <typename AT>
 struct SmallAttn {
@@ -188,6 +189,9 @@ struct SmallAttn {
   int mask_mode;  // 0 none, 1 (B, 1, Lk), 2 (B, Lq, Lk)
   int Lq, Lk, H;
   float scale;
+  // round 6: labels longer than one 32-query tile - a launch covers rows q0 .. q0 + Lq - 1 of the LqT rows a batch element has;
+  // acc: dk / dv of this launch are added to what the earlier query tiles stored (backward only)
+  int q0, LqT, acc;
 };
 
 // out[q][16 w + c] (q < Lq, bf16) = sum_j S[q][j] X[j][16 w + c] for the 32 query rows of a (batch, head) on the matrix cores (round 4;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn<AT> 
   for (int i = tid; i < kSmQ * (kSmD / 8); i += 256) {  // 16-byte pieces (round 4; single elements before)
     const int qi = i / (kSmD / 8), ch = i % (kSmD / 8);
     float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (qi < Lq) d_ld8(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8, t8);
+    if (qi < Lq) d_ld8(p.q + ((int64_t)b * p.LqT + p.q0 + qi) * p.ldq + h * kSmD + ch * 8, t8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) Qs[qi][ch * 8 + e] = t8[e];
   }
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn<AT> 
       float s = (s0 + s1) + (s2 + s3);
       s *= p.scale;
       if (p.mask_mode == 1 && p.mask[(int64_t)b * Lk + j] == 0.0f) s += -10000.0f;
-      if (p.mask_mode == 2 && p.mask[((int64_t)b * Lq + i) * Lk + j] == 0.0f) s += -10000.0f;
+      if (p.mask_mode == 2 && p.mask[((int64_t)b * p.LqT + p.q0 + i) * Lk + j] == 0.0f) s += -10000.0f;
       S[i * ss + j] = s;
     }
   }
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn<AT> 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     const float inv = 1.0f / sum;
-    float* pr = probs + (((int64_t)b * p.H + h) * Lq + i) * Lk;
+    float* pr = probs + (((int64_t)b * p.H + h) * p.LqT + p.q0 + i) * Lk;
     for (int jj = lane; jj < Lk; jj += 64) {
       const float pv = S[i * ss + jj] * inv;
       S[i * ss + jj] = pv;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn<AT> 
   }
   __syncthreads();
   if constexpr (STAGE) {  // (bf16 activations, V rows in LDS: the matrix cores)
-    sm_rows_times_tile(S, ss, Vs, Lq, Lk, reinterpret_cast<uint16_t*>(ctx) + (int64_t)b * Lq * ldc + h * kSmD, ldc);
+    sm_rows_times_tile(S, ss, Vs, Lq, Lk, reinterpret_cast<uint16_t*>(ctx) + ((int64_t)b * p.LqT + p.q0) * ldc + h * kSmD, ldc);
   } else {
     const int qi = tid >> 3, dg = (tid & 7) * 8;
     if (qi < Lq) {
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_kernel(const SmallAttn<AT> 
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaf(pv, t8[e], acc[e]);
       }
-      d_st8(ctx + ((int64_t)b * Lq + qi) * ldc + h * kSmD + dg, acc);
+      d_st8(ctx + ((int64_t)b * p.LqT + p.q0 + qi) * ldc + h * kSmD + dg, acc);
     }
   }
 }
@@ -363,8 +367,8 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
     const int qi = i / (kSmD / 8), ch = i % (kSmD / 8);
     float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, u8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (qi < Lq) {
-      d_ld8(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8, t8);
-      d_ld8(dctx + ((int64_t)b * Lq + qi) * lddc + h * kSmD + ch * 8, u8);
+      d_ld8(p.q + ((int64_t)b * p.LqT + p.q0 + qi) * p.ldq + h * kSmD + ch * 8, t8);
+      d_ld8(dctx + ((int64_t)b * p.LqT + p.q0 + qi) * lddc + h * kSmD + ch * 8, u8);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -381,12 +385,12 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
     }
   for (int i = tid; i < Lq * Lk; i += 256) {
     const int qi = i / Lk, jj = i - qi * Lk;
-    S[qi * ss + jj] = probs[(((int64_t)b * p.H + h) * Lq + qi) * Lk + jj];
+    S[qi * ss + jj] = probs[(((int64_t)b * p.H + h) * p.LqT + p.q0 + qi) * Lk + jj];
   }
   __syncthreads();
   if (tid < Lq) {
     float s = 0.0f;
-    const AT* op = ctx + ((int64_t)b * Lq + tid) * ldc + h * kSmD;
+    const AT* op = ctx + ((int64_t)b * p.LqT + p.q0 + tid) * ldc + h * kSmD;
 #pragma unroll
     for (int c8 = 0; c8 < kSmD / 8; ++c8) {
       float t8[8];
@@ -447,13 +451,22 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
         t8[e] = dvr[c8 * 8 + e];
         u8[e] = dkr[c8 * 8 + e];
       }
+      if (p.acc) {  // (a later query tile: add to what the earlier ones stored)
+        float o8[8];
+        d_ld8(dvp + c8 * 8, o8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t8[e] += o8[e];
+        d_ld8(dkp + c8 * 8, o8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u8[e] += o8[e];
+      }
       d_st8(dvp + c8 * 8, t8);
       d_st8(dkp + c8 * 8, u8);
     }
   }
   __syncthreads();
   if constexpr (STAGE) {  // dq = dS . K on the matrix cores (dS carries the 1 / d_k scale)
-    sm_rows_times_tile(S, ss, Ks, Lq, Lk, reinterpret_cast<uint16_t*>(dq) + (int64_t)b * Lq * lddq + h * kSmD, lddq);
+    sm_rows_times_tile(S, ss, Ks, Lq, Lk, reinterpret_cast<uint16_t*>(dq) + ((int64_t)b * p.LqT + p.q0) * lddq + h * kSmD, lddq);
   } else {
     const int qi = tid >> 3, dg = (tid & 7) * 8;
     if (qi < Lq) {
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const SmallAttn<AT> 
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaf(ds, t8[e], acc[e]);
       }
-      d_st8(dq + ((int64_t)b * Lq + qi) * lddq + h * kSmD + dg, acc);
+      d_st8(dq + ((int64_t)b * p.LqT + p.q0 + qi) * lddq + h * kSmD + dg, acc);
     }
   }
 }
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn
   {
     const int i = tid, qi = i / (kSmD / 8), ch = i % (kSmD / 8);  // kSmQ * kSmD / 8 = 256 pieces: one per thread
     uint4 a = make_uint4(0, 0, 0, 0);
-    if (qi < Lq) a = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8);
+    if (qi < Lq) a = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * p.LqT + p.q0 + qi) * p.ldq + h * kSmD + ch * 8);
     constexpr int kCh = 10;
     for (int base = tid; base < kcap * (kSmD / 8); base += 256 * kCh) {
       uint4 val[kCh];
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = 16 * qt + 4 * lg + r, qc = q < Lq ? q : Lq - 1;
-          mk2[qt][r] = p.mask[((int64_t)b * Lq + qc) * Lk + keyc];
+          mk2[qt][r] = p.mask[((int64_t)b * p.LqT + p.q0 + qc) * Lk + keyc];
         }
     }
     sm_f32x4 sc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
       for (int r = 0; r < kR; ++r) sum[r] += __shfl_xor(sum[r], off, 64);
-    float* pr0 = probs + ((int64_t)b * p.H + h) * Lq * Lk;
+    float* pr0 = probs + (((int64_t)b * p.H + h) * p.LqT + p.q0) * Lk;
     for (int jj = lane; jj < Lk; jj += 64)
 #pragma unroll
       for (int r = 0; r < kR; ++r)
@@ -617,7 +630,7 @@ __global__ __launch_bounds__(256) void mha_small_fwd_mfma_kernel(const SmallAttn
         }
   }
   __syncthreads();
-  sm_rows_times_tile(S, ss, Vs, Lq, Lk, ctx + (int64_t)b * Lq * ldc + h * kSmD, ldc);
+  sm_rows_times_tile(S, ss, Vs, Lq, Lk, ctx + ((int64_t)b * p.LqT + p.q0) * ldc + h * kSmD, ldc);
 }
 MA_LDS_ATTR(mha_small_fwd_mfma_kernel, 163840);
 
@@ -658,8 +671,8 @@ __global__ __launch_bounds__(256) void mha_small_bwd_mfma_kernel(const SmallAttn
     const int qi = tid / (kSmD / 8), ch = tid % (kSmD / 8);  // kSmQ * kSmD / 8 = 256 pieces: one per thread
     uint4 qa = make_uint4(0, 0, 0, 0), qc = qa;
     if (qi < Lq) {
-      qa = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * Lq + qi) * p.ldq + h * kSmD + ch * 8);
-      qc = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * Lq + qi) * lddc + h * kSmD + ch * 8);
+      qa = *reinterpret_cast<const uint4*>(p.q + ((int64_t)b * p.LqT + p.q0 + qi) * p.ldq + h * kSmD + ch * 8);
+      qc = *reinterpret_cast<const uint4*>(dctx + ((int64_t)b * p.LqT + p.q0 + qi) * lddc + h * kSmD + ch * 8);
     }
     constexpr int kCh = 5;
     for (int base = tid; base < kcap * (kSmD / 8); base += 256 * kCh) {
@@ -685,7 +698,7 @@ __global__ __launch_bounds__(256) void mha_small_bwd_mfma_kernel(const SmallAttn
     *reinterpret_cast<uint4*>(Qb + qi * kPq + ch * 8) = qa;
     *reinterpret_cast<uint4*>(dOb + qi * kPq + ch * 8) = qc;
     constexpr int kPc = 16;
-    const float* pb = probs + ((int64_t)b * p.H + h) * Lq * Lk;
+    const float* pb = probs + (((int64_t)b * p.H + h) * p.LqT + p.q0) * Lk;
     for (int base = tid; base < Lq * Lk; base += 256 * kPc) {
       float pv_[kPc];
 #pragma unroll
@@ -706,7 +719,7 @@ __global__ __launch_bounds__(256) void mha_small_bwd_mfma_kernel(const SmallAttn
   __syncthreads();
   if (tid < Lq) {
     float s = 0.0f;
-    const uint16_t* op = ctx + ((int64_t)b * Lq + tid) * ldc + h * kSmD;
+    const uint16_t* op = ctx + ((int64_t)b * p.LqT + p.q0 + tid) * ldc + h * kSmD;
 #pragma unroll
     for (int c8 = 0; c8 < kSmD / 8; ++c8) {
       float t8[8], u8[8];
@@ -764,13 +777,21 @@ __global__ __launch_bounds__(256) void mha_small_bwd_mfma_kernel(const SmallAttn
       const sm_f32x4 av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOb, dt), pf, z, 0, 0, 0);
       const sm_f32x4 ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qb, dt), gf, z, 0, 0, 0);
       if (key < Lk) {
-        *reinterpret_cast<uint2*>(dvp + 16 * dt) = make_uint2(sm_pack(av[0], av[1]), sm_pack(av[2], av[3]));
-        *reinterpret_cast<uint2*>(dkp + 16 * dt) = make_uint2(sm_pack(ak[0], ak[1]), sm_pack(ak[2], ak[3]));
+        float v4[4] = {av[0], av[1], av[2], av[3]}, k4[4] = {ak[0], ak[1], ak[2], ak[3]};
+        if (p.acc) {  // (a later query tile: add to what the earlier ones stored)
+          const uint2 ov = *reinterpret_cast<const uint2*>(dvp + 16 * dt), ok = *reinterpret_cast<const uint2*>(dkp + 16 * dt);
+          v4[0] += __uint_as_float(ov.x << 16); v4[1] += __uint_as_float(ov.x & 0xffff0000u);
+          v4[2] += __uint_as_float(ov.y << 16); v4[3] += __uint_as_float(ov.y & 0xffff0000u);
+          k4[0] += __uint_as_float(ok.x << 16); k4[1] += __uint_as_float(ok.x & 0xffff0000u);
+          k4[2] += __uint_as_float(ok.y << 16); k4[3] += __uint_as_float(ok.y & 0xffff0000u);
+        }
+        *reinterpret_cast<uint2*>(dvp + 16 * dt) = make_uint2(sm_pack(v4[0], v4[1]), sm_pack(v4[2], v4[3]));
+        *reinterpret_cast<uint2*>(dkp + 16 * dt) = make_uint2(sm_pack(k4[0], k4[1]), sm_pack(k4[2], k4[3]));
       }
     }
   }
   __syncthreads();
-  sm_rows_times_tile(S, ss, Ks, Lq, Lk, dq + (int64_t)b * Lq * lddq + h * kSmD, lddq);
+  sm_rows_times_tile(S, ss, Ks, Lq, Lk, dq + ((int64_t)b * p.LqT + p.q0) * lddq + h * kSmD, lddq);
 }
 MA_LDS_ATTR(mha_small_bwd_mfma_kernel, 163840);
 
@@ -899,13 +920,14 @@ static int fill_small(SmallAttn<AT>& a, const void* q, int64_t ldq, const void* 
                       const float* mask, int32_t mask_mode, int64_t batch, int32_t Lq, int32_t Lk, int32_t heads, int32_t d_k,
                       float scale) {
   if (!q || !k || !v || batch < 1 || Lq < 1 || Lk < 1 || heads < 1 || batch > 65535) return MA_ERR_INVALID_ARG;
-  if (d_k != kSmD || Lq > kSmQ || Lk > kSmKMax || (ldq & 7) || (ldk & 7) || (ldv & 7)) return MA_ERR_UNSUPPORTED;  // 16-byte row pieces
+  if (d_k != kSmD || Lq > kSmQMax || Lk > kSmKMax || (ldq & 7) || (ldk & 7) || (ldv & 7)) return MA_ERR_UNSUPPORTED;  // 16-byte row pieces
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) return MA_ERR_INVALID_ARG;
   if (mask_mode < 0 || mask_mode > 2 || (mask_mode && !mask)) return MA_ERR_INVALID_ARG;
   a.q = (const AT*)q; a.k = (const AT*)k; a.v = (const AT*)v;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.mask = mask; a.mask_mode = mask_mode;
   a.Lq = Lq; a.Lk = Lk; a.H = heads; a.scale = scale;
+  a.q0 = 0; a.LqT = Lq; a.acc = 0;  // (the launchers walk query tiles of kSmQ rows)
   return MA_OK;
 }
 
@@ -918,18 +940,26 @@ static int mha_small_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk,
   if (rc != MA_OK) return rc;
   if (!ctx || !probs || (ldc & 7)) return MA_ERR_INVALID_ARG;
   MA_LDS_ATTR_T((mha_small_fwd_kernel<false, AT>), 163840);
-  if constexpr (sizeof(AT) == 2) {
-    if (Lk <= kSmK) {
-      constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * 72 * 2;
-      MA_LAUNCH(mha_small_fwd_mfma_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
-                (uint16_t*)ctx, ldc, probs, kSmK);
-      return MA_OK;
+  // query tiles of kSmQ rows: one launch each (labels of more than 31 tokens - AISHELL's longest transcripts - take two or more)
+  for (int q0 = 0; q0 < Lq; q0 += kSmQ) {
+    a.q0 = q0;
+    a.Lq = Lq - q0 < kSmQ ? Lq - q0 : kSmQ;
+    bool done = false;
+    if constexpr (sizeof(AT) == 2) {
+      if (Lk <= kSmK) {
+        constexpr int lds = kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + kSmQ * 72 * 2;
+        MA_LAUNCH(mha_small_fwd_mfma_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
+                  (uint16_t*)ctx, ldc, probs, kSmK);
+        done = true;
+      }
+    }
+    if (!done) {
+      const int kcap = (Lk + 63) / 64 * 64;
+      const int lds = kSmQ * (kcap + 1) * 4 + kSmQ * (kSmD + 4) * 4;
+      MA_LAUNCH((mha_small_fwd_kernel<false, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a,
+                (AT*)ctx, ldc, probs, kcap);
     }
   }
-  const int kcap = (Lk + 63) / 64 * 64;
-  const int lds = kSmQ * (kcap + 1) * 4 + kSmQ * (kSmD + 4) * 4;
-  MA_LAUNCH((mha_small_fwd_kernel<false, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, (AT*)ctx,
-            ldc, probs, kcap);
   return MA_OK;
 }
 
@@ -946,19 +976,29 @@ static int mha_small_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk,
        reinterpret_cast<uintptr_t>(dv)) & 15)
     return MA_ERR_INVALID_ARG;
   MA_LDS_ATTR_T((mha_small_bwd_kernel<false, AT>), 163840);
-  if constexpr (sizeof(AT) == 2) {
-    if (Lk <= kSmK) {
-      constexpr int lds = 2 * kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * 72 * 2 + kSmQ * 4;
-      MA_LAUNCH(mha_small_bwd_mfma_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
-                (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv, lddv,
-                kSmK);
-      return MA_OK;
+  // query tiles of kSmQ rows, in order on the stream: the first stores dk / dv, the later ones add to them (deterministic; in the
+  // bf16 form the running sums pass through one bf16 rounding per tile)
+  for (int q0 = 0; q0 < Lq; q0 += kSmQ) {
+    a.q0 = q0;
+    a.Lq = Lq - q0 < kSmQ ? Lq - q0 : kSmQ;
+    a.acc = q0 > 0 ? 1 : 0;
+    bool done = false;
+    if constexpr (sizeof(AT) == 2) {
+      if (Lk <= kSmK) {
+        constexpr int lds = 2 * kSmK * kSmD * 2 + kSmQ * (kSmK + 1) * 4 + 2 * kSmQ * 72 * 2 + kSmQ * 4;
+        MA_LAUNCH(mha_small_bwd_mfma_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
+                  (const uint16_t*)ctx, ldc, (const uint16_t*)dctx, lddc, (uint16_t*)dq, lddq, (uint16_t*)dk, lddk, (uint16_t*)dv,
+                  lddv, kSmK);
+        done = true;
+      }
+    }
+    if (!done) {
+      const int kcap = (Lk + 63) / 64 * 64;
+      const int lds = kSmQ * (kcap + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
+      MA_LAUNCH((mha_small_bwd_kernel<false, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
+                (const AT*)ctx, ldc, (const AT*)dctx, lddc, (AT*)dq, lddq, (AT*)dk, lddk, (AT*)dv, lddv, kcap);
     }
   }
-  const int kcap = (Lk + 63) / 64 * 64;
-  const int lds = kSmQ * (kcap + 1) * 4 + 2 * kSmQ * (kSmD + 4) * 4 + kSmQ * 4;
-  MA_LAUNCH((mha_small_bwd_kernel<false, AT>), dim3((unsigned)heads, (unsigned)batch), dim3(256), lds, (hipStream_t)stream, a, probs,
-            (const AT*)ctx, ldc, (const AT*)dctx, lddc, (AT*)dq, lddq, (AT*)dk, lddk, (AT*)dv, lddv, kcap);
   return MA_OK;
 }
 

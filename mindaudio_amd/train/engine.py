@@ -953,11 +953,13 @@ class ConformerCTCTrainStep:
                 self.K.gemm_tn_direct_ok(dy, x, fp.g(wname)):
             # a decoder layer's weight gradient: with the other 41 of the decoder in ONE grid at the end of its backward pass
             # (they were 43 split-K products + 88 reduction launches of ~10 us each: the hybrid step's decoder is launch-bound)
-            if self._dec_long_dw and dy.shape[0] > 4 * self._dec_rows:
+            if self._dec_long_dw and not self.block_tables and dy.shape[0] > 4 * self._dec_rows:
                 # a decoder product over the ENCODER's rows (ca_kv_w: dkv^T memory, 10 200 rows against the decoder's 1 240): in the
                 # decoder's grid its 2 tiles per layer ran 400 us with 244 CUs idle behind them (the grid lasts as long as its longest
                 # tile).  It joins the encoder's first direct group instead - 234 + 12 tiles, still one resident round, every tile with a
                 # full-length contraction; the decoder's gradient bucket goes on the wire behind that group (_dec_bucket_pending).
+                # (Only with the launch tables off: a replayed encoder group holds the operands of the step it was recorded in - the
+                # fused decoder walk keeps its one long operand at a fixed address for that, this per-layer form does not.)
                 if self._dq is None:
                     self._dq = self.K.DirectGroup()
                 self._dq.add(dy, x, fp.g(wname), fp.g(bname))
@@ -1499,6 +1501,10 @@ class ConformerCTCTrainStep:
         md = b * L1
         f32 = torch.float32
         dtb = None
+        # Does the ENCODER's backward run from its launch table in this step?  Its first direct group then already holds the product
+        # the decoder's walk would queue (_decoder_walk_fused: the memory-side weight gradient) - also when the decoder itself is
+        # walked from Python because this batch's label length is not the recorded one, which is the common case on real data.
+        self._enc_replay_now = tb is not None and tb["state"] == "replay"
         if tb is not None and not self.len_norm and tb["state"] in ("record", "replay"):
             dtb = tb.get("dec")
             if tb["state"] == "record":
@@ -1760,12 +1766,27 @@ class ConformerCTCTrainStep:
         # (K = 4 288 against 1 240 rows: split over K like the feed-forward input gradient below - 32 -> ~12 us)
         dy = K.gemm_splitk(dlog, self.wt["dec.out_w"], tt.empty((md, d), dtype=f32, device=self.dev), accumulate=False)
         g = tt.empty((md, d), dtype=f32, device=self.dev)
-        lnp = self._dec_ln_plan(md)["bufs"]  # (the LayerNorm backwards' partial sums: one batched reduction at the end)
+        dlp = self._dec_ln_plan(md)  # (the LayerNorm backwards' partial sums: one batched reduction at the end)
+        if rec is not None:
+            # the recorded launches name this plan's arena and item table: they must outlive the plan of the next label width
+            # (_dec_ln_plan keeps ONE; a batch with another longest transcript replaced it and the table's next replay faulted)
+            rec.keep.append(dlp)
+        lnp = dlp["bufs"]
         # after_norm's backward emits the dropout backward of the last layer's feed-forward join
         _, dyf = K.layernorm_bwd_next(x, fp.p("dec.after_norm.g"), dy, g, None, None, (1.0, pd, seed, salt(Ld - 1, 3), None),
                                       accumulate=False, eps=eps, partials=lnp["dec.after_norm"])
         d_mem = tt.empty((m, d), dtype=f32, device=self.dev)  # (stored by ONE product behind the layers: no fill, no accumulation)
-        dkv_all = tt.empty((m, Ld * 2 * d), dtype=torch.bfloat16, device=self.dev)
+        # dkv_all lives with the batch shape's plan, at ONE address for walked, recorded and replayed steps alike: the encoder's
+        # first direct group reads it (below), and that group may be a recorded launch of another step's
+        plan = getattr(self, "_dw_cur", None)
+        merge = plan is not None and self._dw_direct and self._dec_long_dw
+        if merge:
+            dkv_all = plan.get("dkv_all")
+            if dkv_all is None or tuple(dkv_all.shape) != (m, Ld * 2 * d):
+                dkv_all = plan["dkv_all"] = torch.empty((m, Ld * 2 * d), dtype=torch.bfloat16, device=self.dev)
+            merge = K.gemm_tn_direct_ok(dkv_all, mem_bf, self._kv_all["gw"])
+        else:
+            dkv_all = tt.empty((m, Ld * 2 * d), dtype=torch.bfloat16, device=self.dev)
         for li in reversed(range(Ld)):
             seg(True, L + li)
             pre = "d%d." % li
@@ -1810,16 +1831,18 @@ class ConformerCTCTrainStep:
         # the Ld weight gradients as one (Ld * 2d, d) product in the encoder's first direct group (10 200 contraction rows: a
         # straggler beside the decoder's 1 240-row products, _dW)
         ops.gemm(dkv_all, self.wt["dec.ca_kv_all"], out_dtype=f32, out=d_mem)
-        if self._dw_direct and self._dec_long_dw and K.gemm_tn_direct_ok(dkv_all, mem_bf, self._kv_all["gw"]):
-            if self._dq is None:
-                self._dq = K.DirectGroup()
-            self._dq.add(dkv_all, mem_bf, self._kv_all["gw"], self._kv_all["gb"])
+        if merge:
+            # (a replayed encoder backward has the item in its recorded group - same operands, same addresses; queueing it here as
+            # well would leave it in a group nobody launches, with operands that die with this step)
+            if not getattr(self, "_enc_replay_now", False):
+                if self._dq is None:
+                    self._dq = K.DirectGroup()
+                self._dq.add(dkv_all, mem_bf, self._kv_all["gw"], self._kv_all["gb"])
             self._dec_bucket_pending = True
         else:
             K.gemm_tn(dkv_all, mem_bf, self._kv_all["gw"], colsum=self._kv_all["gb"])
         # (tmask: the padded label positions - their rows of g are exactly zero, the label mask keeps them out of every valid position)
         K.embed_bwd(toks, g, fp.g("dec.embed"), xscale, pp, seed, salt(-1, 0), row_keep=tmask if self.decoder_embed_row_mask else None)
-        dlp = self._dec_ln
         _lib.check(_lib.load().ma_reduce_splits_batch_f32(dlp["items"].data_ptr(), dlp["block_item"].data_ptr(), dlp["n_blocks"],
                                                           _host.current_stream_ptr()), "decoder LayerNorm sums")
         if self._dq_dec is not None:  # the decoder layers' weight gradients: one grid

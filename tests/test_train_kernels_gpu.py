@@ -430,7 +430,9 @@ def test_gemm_tn(K):
     assert rel(out, a.float().cpu().t() @ b.float().cpu()) < 2e-5
 
 
-@pytest.mark.parametrize("lq,lk,mode", [(31, 31, 2), (31, 255, 1), (31, 749, 1), (9, 1088, 1), (32, 321, 0)])
+# lq > 32 (round 6): labels of more than 31 tokens - two or more query tiles, dk / dv summed over the tiles' launches
+@pytest.mark.parametrize("lq,lk,mode", [(31, 31, 2), (31, 255, 1), (31, 749, 1), (9, 1088, 1), (32, 321, 0),
+                                        (45, 45, 2), (61, 255, 1), (33, 749, 1), (201, 201, 2), (64, 300, 0)])
 def test_decoder_attention_long_sources(K, lq, lk, mode):
     """ma_mha_small_fwd/bwd (the TransformerDecoder's self- and source attention, layers/attention.py:85-157 with the 1/d_k
     scaling of :150-152) over short AND long key ranges: up to 320 keys the V / K rows are staged in LDS, beyond that (the
@@ -468,6 +470,16 @@ def test_decoder_attention_long_sources(K, lq, lk, mode):
     dq, dk_, dv = (torch.empty_like(t.cuda()) for t in (q, k, v))
     K.mha_small_bwd(q.cuda(), k.cuda(), v.cuda(), probs, ctx, dctx.cuda(), b, lq, lk, scale, dq, dk_, dv, h, dk)
     assert rel(dq, qf.grad) < 1e-2 and rel(dk_, kf.grad) < 1e-2 and rel(dv, vf.grad) < 6e-3
+    # ... and the float32 form (the validation mode's kernels): same tiling, exact accumulation over the query tiles
+    from mindaudio_amd.train import kernels_x32 as X
+
+    ctx32, probs32 = X.mha_small_fwd(q.float().cuda(), k.float().cuda(), v.float().cuda(), mask.cuda() if mask is not None else None,
+                                     mode, b, lq, lk, scale, h, dk)
+    assert rel(probs32, probs_ref.detach()) < 2e-5 and rel(ctx32, ctx_ref.detach()) < 2e-5
+    dq32, dk32, dv32 = (torch.empty_like(t.float().cuda()) for t in (q, k, v))
+    X.mha_small_bwd(q.float().cuda(), k.float().cuda(), v.float().cuda(), probs32, ctx32, dctx.float().cuda(), b, lq, lk, scale,
+                    dq32, dk32, dv32, h, dk)
+    assert rel(dq32, qf.grad) < 2e-5 and rel(dk32, kf.grad) < 2e-5 and rel(dv32, vf.grad) < 2e-5
 
 
 def test_decoder_attention_rejects_more_keys_than_the_lds_holds(K):

@@ -304,6 +304,58 @@ def test_hybrid_ctc_attention_loss_and_gradients_match_oracle(len_norm):
     assert len(out) == 5 and not out[1] and not out[3] and float(out[0]) > 0
 
 
+@pytest.mark.parametrize("mode", ["bf16", "float32"])
+def test_hybrid_gradients_with_labels_longer_than_one_query_tile(mode):
+    """Transcripts of more than 31 tokens (AISHELL's longest; token_max_length is 200 in conformer.yaml): the decoder's attention
+    kernels take 32 queries per launch and refused longer labels until round 6 - the hybrid step then died on the first such batch.
+    Two query tiles here (L + 1 = 41): loss and every gradient against the oracle's autograd."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+    from oracle import conformer_oracle as C
+
+    ref_enc, ref_ctc, ref_dec, model, _ = _hybrid_setup(seed=33)
+    vocab, b, lmax = 97, 3, 40
+    g = torch.Generator().manual_seed(77)
+    xs = torch.randn(b, 400, 80, generator=g)
+    mask = torch.ones(b, 1, 400)
+    mask[1, 0, 350:] = 0
+    xs[1, 350:] = 0
+    sub = C.subsample_mask(mask)
+    ys_lens = torch.tensor([40, 33, 7], dtype=torch.int32)
+    ys = torch.full((b, lmax), -1, dtype=torch.int32)
+    eos = vocab - 1
+    ys_in = torch.full((b, lmax + 1), eos, dtype=torch.int32)
+    ys_out = torch.full((b, lmax + 1), -1, dtype=torch.int32)
+    ys_masks = torch.zeros(b, 1, lmax + 1)
+    for i, n in enumerate(ys_lens.tolist()):
+        ys[i, :n] = torch.randint(1, vocab - 1, (n,), generator=g, dtype=torch.int32)
+        ys_in[i, 1:n + 1] = ys[i, :n]
+        ys_out[i, :n] = ys[i, :n]
+        ys_out[i, n] = eos
+        ys_masks[i, 0, :n + 1] = 1
+    ys_sub = (ys_masks.bool() & torch.tril(torch.ones(lmax + 1, lmax + 1, dtype=torch.bool))[None]).float()
+    cols = (xs, ys, ys_in, ys_out, None, None, sub, ys_sub, ys_masks, ys_lens, None)
+    loss_ref, acc_ref, lc_ref, la_ref = C.hybrid_loss(ref_enc, ref_ctc, ref_dec, cols, 0.3, 0.1, False)
+    loss_ref.backward()
+    eng = ConformerCTCTrainStep(model, dropout_rate=0.0, positional_dropout_rate=0.0,
+                                compute_type=torch.float32 if mode == "float32" else None)
+    dev = [c.cuda() if c is not None else None for c in cols]
+    loss = eng.forward_backward(dev[0], dev[1], dev[6], dev[9], None, 1.0, ys_in_pad=dev[2], ys_out_pad=dev[3], ys_sub_masks=dev[7],
+                                ys_masks=dev[8])
+    tol = 2e-5 if mode == "float32" else 2e-2
+    assert abs(float(eng.last_loss_att) - float(la_ref.detach())) <= tol * abs(float(la_ref.detach()))
+    assert abs(float(loss) - float(loss_ref.detach())) <= tol * abs(float(loss_ref.detach()))
+    grads = eng.gradients()
+    want = {"encoder." + n: p.grad for n, p in ref_enc.named_parameters()}
+    want.update({"ctc." + n: p.grad for n, p in ref_ctc.named_parameters()})
+    want.update({"decoder." + n: p.grad for n, p in ref_dec.named_parameters()})
+    lim = 5e-4 if mode == "float32" else 6e-2
+    bad = {k: round(rel_rms(grads[k], w), 5) for k, w in want.items()
+           if "depthwise_conv.bias" not in k and "linear_k.bias" not in k and rel_rms(grads[k], w) > lim}
+    assert not bad, bad
+    out = eng.step(*dev)  # ... and the optimizer step runs end to end on it (launch table recorded on a later sighting)
+    assert not out[1] and float(out[0]) > 0
+
+
 def test_adam_bias_correction_counts_applied_updates_only():
     """After a skipped (overflow) step the next applied update must equal what Adam does at its own step count: the engine with
     an overflow step in the middle ends on the same masters as one that never saw the bad batch, when the LR is constant across
@@ -572,6 +624,50 @@ def test_hybrid_step_from_the_launch_table_changes_no_bit():
             assert tb["state"] == "replay" and "out" in tb["dec"]
             counts = [(tab.calls(False, blk), tab.calls(True, blk)) for blk in range(L, L + Ld + 3)]
             assert all(f > 0 and bw > 0 for f, bw in counts[:Ld + 1]) and counts[Ld + 1][0] > 0 and counts[Ld + 2][0] > 0, counts
+        out.append((losses, eng.fp.master.clone()))
+    assert out[1][0] == out[0][0]
+    assert torch.equal(out[1][1], out[0][1])
+
+
+def test_hybrid_table_with_label_lengths_that_change_from_batch_to_batch():
+    """Real batches differ in their longest transcript: the decoder's table replays only when the label width is the recorded one,
+    otherwise the decoder is walked from Python WHILE the encoder's backward is replayed - whose first recorded weight-gradient group
+    holds the decoder's memory-side product (ca_kv).  Until the end of round 6 that combination read another step's operand (a wrong
+    gradient) and left a dangling item behind (a memory fault a few steps later; found by tools/hybrid_soak.py).  Twelve steps over
+    label widths 10 / 7 / 13 on one encoder shape: bit-identical losses and masters with the tables on and off."""
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    def cols_for(k):
+        lmax = (9, 9, 9, 6, 9, 12, 6, 9, 12, 12, 9, 6)[k]
+        xs, ys, sub, ys_lens = batch(vocab=96, seed=40 + k, shorter=(0, 30 - k, 61 + 2 * k), ylens=(min(9, lmax), 6 - k % 2, 4 + k % 3))
+        b, eos = ys.shape[0], 96
+        ys_in = torch.full((b, lmax + 1), eos, dtype=torch.int32)
+        ys_out = torch.full((b, lmax + 1), -1, dtype=torch.int32)
+        ys_masks = torch.zeros(b, 1, lmax + 1)
+        ys_w = torch.full((b, lmax), -1, dtype=torch.int32)
+        for i, n in enumerate(ys_lens.tolist()):
+            ys_w[i, :n] = ys[i, :n]
+            ys_in[i, 1:n + 1] = ys[i, :n]
+            ys_out[i, :n] = ys[i, :n]
+            ys_out[i, n] = eos
+            ys_masks[i, 0, :n + 1] = 1
+        ys_sub = (ys_masks.bool() & torch.tril(torch.ones(lmax + 1, lmax + 1, dtype=torch.bool))[None]).float()
+        return (xs, ys_w, ys_in, ys_out, None, None, sub, ys_sub, ys_masks, ys_lens, None)
+
+    out = []
+    for tables in (False, True):
+        _, _, _, model, _ = _hybrid_setup(blocks=2, dblocks=2)
+        model.decoder.dropout_rate, model.decoder.positional_dropout_rate = 0.1, 0.1
+        eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1)
+        eng.block_tables = tables
+        losses = []
+        for k in range(12):
+            losses.append(float(eng.step(*(c.cuda() if c is not None else None for c in cols_for(k)))[0]))
+        torch.cuda.synchronize()
+        if tables:
+            tb = eng._dw_plan["table"]
+            assert tb["state"] == "replay" and tb["dec"]["L1"] == 10  # (recorded at the second sighting: width 10)
+            assert eng._dq is None or eng._dq.n == 0  # nothing queued that no launch will take
         out.append((losses, eng.fp.master.clone()))
     assert out[1][0] == out[0][0]
     assert torch.equal(out[1][1], out[0][1])

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--vocab", type=int, default=4233)
     ap.add_argument("--ctc-weight", type=float, default=0.3, help="1.0: the pure-CTC step (no decoder)")
+    ap.add_argument("--len-norm", action="store_true", help="length_normalized_loss (asr_model.py:61): the decoder is always walked")
     ap.add_argument("--only", default="", help="tables | walked: one engine only (no comparison)")
     ap.add_argument("--verbose", action="store_true", help="synchronise and print after every step")
     a = ap.parse_args()
@@ -65,7 +66,7 @@ def main():
                                  ctc_weight=a.ctc_weight,
                                  decoder_conf=dict(attention_heads=4, linear_units=2048, num_blocks=6, dropout_rate=0.1,
                                                    positional_dropout_rate=0.1) if a.ctc_weight != 1.0 else None,
-                                 lsm_weight=0.1 if a.ctc_weight != 1.0 else 0.0).to(dev)
+                                 lsm_weight=0.1 if a.ctc_weight != 1.0 else 0.0, length_normalized_loss=a.len_norm).to(dev)
         eng = ConformerCTCTrainStep(model, base_lr=5e-4, warmup_steps=50, dropout_rate=0.1, positional_dropout_rate=0.1, seed=11)
         if not tables:
             eng.block_tables = False

@@ -1671,16 +1671,28 @@ class ConformerCTCTrainStep:
     def _dec_ln_plan(self, md):
         """The decoder's 3 Ld + 1 LayerNorm backwards leave their per-workgroup (dgamma | dbeta) partials in one arena and ONE batched
         launch adds them into the flat gradient at the end of the decoder's backward pass (19 reduction launches of 5.6 us fewer per
-        hybrid step; the encoder blocks do the same per block, _dw_plan_for)."""
-        cur = self.__dict__.get("_dec_ln")
-        if cur is not None and cur["md"] == md:
+        hybrid step; the encoder blocks do the same per block, _dw_plan_for).
+        One plan per row count md = B x (longest label + 1), which changes from batch to batch on real data: the plans of the last
+        _DEC_LN_PLANS_KEPT row counts stay (building one costs two synchronous host-to-device copies - the item tables - i.e. the
+        host's whole lead over the device), all on one grow-only arena; a launch table that recorded a plan keeps it alive itself."""
+        plans = self.__dict__.setdefault("_dec_ln_plans", {})
+        cur = plans.get(md)
+        if cur is not None:
+            plans[md] = plans.pop(md)  # (most recently used last)
+            self._dec_ln = cur
             return cur
         import numpy as np
 
         fp = self.fp
         parts = int(_lib.load().ma_layernorm_bwd_parts(md))
         sites = ["dec.after_norm"] + ["d%d.%s" % (li, ln) for li in range(self.Ld) for ln in ("norm1", "norm2", "norm3")]
-        arena = torch.empty(len(sites) * parts * 512, dtype=torch.float32, device=self.dev)
+        need = len(sites) * parts * 512
+        arena = self.__dict__.get("_dec_ln_arena")
+        if arena is None or arena.numel() < need:
+            # (a larger arena: the plans built on the old one go - recorded tables hold theirs, and through it the old arena)
+            arena = self._dec_ln_arena = torch.empty(max(need, 2 * (arena.numel() if arena is not None else 0)), dtype=torch.float32,
+                                                     device=self.dev)
+            plans.clear()
         items, block_item, first, bufs = [], [], 0, {}
         for i, site in enumerate(sites):
             gg = fp.g(site + ".g")  # (g | b): 2 x 256 contiguous floats of the flat gradient
@@ -1691,10 +1703,16 @@ class ConformerCTCTrainStep:
             block_item += [i] * nblk
             first += nblk
         raw = (_lib.ReduceItem * len(items))(*items)
-        self._dec_ln = dict(md=md, arena=arena, bufs=bufs, n_blocks=first,
-                            items=torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
-                            block_item=torch.tensor(block_item, dtype=torch.int32, device=self.dev))
-        return self._dec_ln
+        cur = dict(md=md, arena=arena, bufs=bufs, n_blocks=first,
+                   items=torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
+                   block_item=torch.tensor(block_item, dtype=torch.int32, device=self.dev))
+        plans[md] = cur
+        while len(plans) > self._DEC_LN_PLANS_KEPT:
+            plans.pop(next(iter(plans)))
+        self._dec_ln = cur
+        return cur
+
+    _DEC_LN_PLANS_KEPT = 64
 
     def _decoder_walk_fused(self, mem_bf, emask, b, t2, L1, toks, sub, pe, tgt, tmask, gscale, seed, rec, ls, seg):
         """_decoder_walk on the fused launches the encoder blocks already use (round 6; bf16 mode, d_model 256): per layer 10 forward

@@ -312,3 +312,49 @@ def test_two_real_steps_on_a_two_utterance_manifest(tmp_path):
     assert len(rest) == 1 and rest[0]["epoch"] == 2 and np.isfinite(rest[0]["loss"])
     assert abs(rest[0]["lr"] - asr_warmup_lr(1, 1e-3, 25000)) < 1e-12 and rest[0]["lr"] > 0
     assert any(ln.startswith("[Train] Epoch: [2/2], Step: [1/1]") for ln in lines2)
+
+
+@pytest.mark.gpu
+def test_three_epochs_on_a_ragged_manifest_with_long_transcripts(tmp_path):
+    """What the two-utterance test cannot see: 26 utterances of 0.8 ... 5.6 s in five frame buckets, transcripts of 2 ... 44 tokens
+    (longer than one 32-query tile of the decoder's attention kernels), speed perturbation and SpecAugment on, the hybrid loss - so
+    every batch has another shape AND another label width: launch tables recorded, replayed and mixed with walked decoders, plans
+    per shape, checkpoints, resume.  Three epochs from the command-line entry point: every loss finite, the last epoch's mean loss
+    below the first's, one checkpoint per epoch, and a run resumed from the second reproduces the number of remaining steps."""
+    src = os.path.join(HERE, "golden", "BAC009S0002W0122.wav")
+    with wave.open(src, "rb") as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    rng = np.random.RandomState(7)
+    chars = [chr(ord("a") + i) for i in range(20)]
+    (tmp_path / "lang_char.txt").write_text("".join("%s %d\n" % (ch, i) for i, ch in enumerate(["<blank>", "<unk>"] + chars + ["<sos/eos>"])))
+    rows = ["id,duration,wav,transcript"]
+    for i in range(26):
+        n = int(rng.randint(12800, 90000))
+        p = str(tmp_path / ("utt%02d.wav" % i))
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(np.resize(pcm, n).tobytes())
+        ntok = int(rng.randint(2, 45)) if i % 5 else 44  # (several transcripts beyond 31 tokens)
+        ntok = min(ntok, n // 160 // 4 - 3)              # (CTC: at most T' labels)
+        rows.append("%d,%.2f,%s,%s" % (i, n / 16000.0, p, "".join(rng.choice(chars, ntok))))
+    (tmp_path / "train.csv").write_text("\n".join(rows) + "\n")
+    over = dict(train_data=str(tmp_path / "train.csv"), dict=str(tmp_path / "lang_char.txt"), max_epoch=3, exp_name=str(tmp_path / "exp"),
+                save_checkpoint=True)
+    cfg = _cfg(tmp_path, **over)
+    cfg["dataset_conf"].update(token_max_length=60, batch_bucket_limit="4, 4, 4, 4, 4, 4, 4, 4, 4, 4")
+    cfg["collate_conf"].update(use_speed_perturb=True)
+    cfg["scheduler_conf"]["warmup_steps"] = 10
+    cfg["optim_conf"]["lr"] = 2e-3
+    lines = []
+    recs = T.train(cfg, log=lines.append)
+    assert recs and all(np.isfinite(r["loss"]) and r["loss"] > 0 for r in recs)
+    per_epoch = {e: [r["loss"] for r in recs if r["epoch"] == e] for e in (1, 2, 3)}
+    steps = len(per_epoch[1])
+    assert steps >= 7 and len(per_epoch[2]) == steps and len(per_epoch[3]) == steps
+    assert np.mean(per_epoch[3]) < np.mean(per_epoch[1]), per_epoch
+    ck = [os.path.join(str(tmp_path / "exp"), "model", "CKP-%d_%d.ckpt" % (e, steps)) for e in (1, 2, 3)]
+    assert all(os.path.exists(c) for c in ck)
+    rest = T.train(dict(cfg, resume_ckpt=ck[1], save_checkpoint=False), log=lambda _l: None)
+    assert len(rest) == steps and all(r["epoch"] == 3 and np.isfinite(r["loss"]) for r in rest)

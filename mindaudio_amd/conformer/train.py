@@ -13,8 +13,9 @@ prints the fields of the reference's `TimeMonitor` (mindaudio/utils/callback.py:
 One process per GPU: under `torchrun` (RANK / WORLD_SIZE / LOCAL_RANK) with is_distributed the gradients are averaged over RCCL
 (`mindspore.set_auto_parallel_context(DATA_PARALLEL, gradients_mean=True)`, train.py:70-80) and every rank keeps
 batch[rank::world] of the same shuffled batch order (dataset.py:552-553).  Keys the reference's train.py never reads either
-(grad_clip, accum_grad, log_interval, optim, device_target, save_graphs, full_graph) are accepted and ignored; training_with_eval
-is refused loudly instead of silently doing something else; `scheduler` is "warmuplr" or "none" and anything else raises the
+(grad_clip, accum_grad, log_interval, optim, device_target, save_graphs, full_graph) are accepted and ignored; `training_with_eval`
+runs the reference's EvalCallback (evaluation loss, `conformer_<epoch>_<step>.ckpt`, the averaged checkpoint at the end) in place of
+ModelCheckpoint, as train.py:143-164 does; `scheduler` is "warmuplr" or "none" and anything else raises the
 reference's ValueError (train.py:126-135).
 
 Resume (train.py:117-133,172-179): `resume_ckpt` is read with the reference's parameter names, `epoch_num` from the file is the
@@ -101,8 +102,6 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
     import torch
 
     torch.manual_seed(777)  # set_seed(777), train.py:56
-    if config.get("training_with_eval"):
-        raise NotImplementedError("training_with_eval: the evaluation callback is not built (ASREvalNet exists; train.py:143-155)")
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     ds_conf = dict(config["dataset_conf"])  # (frame_bucket_limit / batch_bucket_limit stay the yaml's comma-separated strings: the data
@@ -111,6 +110,14 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
         from .dataset import create_dataset as dataset_factory
     vocab_size, dataset = dataset_factory(config["train_data"], config["dict"], collate_conf=dict(config["collate_conf"]),
                                           dataset_conf=ds_conf, rank=rank, group_size=world, number_workers=1)
+    eval_dataset = None
+    if config.get("training_with_eval"):
+        # train.py:93-106: the evaluation set without speed perturbation and SpecAugment, under test_dataset_conf
+        log("Initializing evaluation dataset.")
+        eval_collate = dict(config["collate_conf"], use_speed_perturb=False, use_spec_aug=False)
+        _, eval_dataset = dataset_factory(config["eval_data"], config["dict"], collate_conf=eval_collate,
+                                          dataset_conf=dict(config.get("test_dataset_conf") or ds_conf), rank=rank, group_size=world,
+                                          number_workers=1)
     input_dim = int(config["collate_conf"]["feature_extraction_conf"]["mel_bins"])
     steps_size = dataset.get_dataset_size()
     log("Training dataset has %d steps in each epoch." % steps_size)
@@ -132,6 +139,10 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
     save_every = steps_size * int(config.get("save_checkpoint_epochs", 1))
     model_dir = os.path.join(str(config.get("exp_name", "default")), "model")
     records, step = [], start_epoch * steps_size  # (TimeMonitor.step, moved on by ResumeCallback)
+    evaluator = None
+    if eval_dataset is not None:
+        evaluator = EvalCallback(model, eng, eval_dataset, device, world, rank, save_every, model_dir, log)
+        evaluator.begin()
     log("Training start.")
     for epoch in range(start_epoch + 1, max_epoch + 1):
         for cols in dataset:
@@ -143,7 +154,9 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
             log(format_step_line(epoch, max_epoch, step, steps_size, seconds, lr, loss, scale, rank, overflow))
             records.append(dict(epoch=epoch, step=step, loss=loss, scale=scale, overflow=overflow, lr=lr, seconds=seconds))
             step += 1
-            if config.get("save_checkpoint") and rank == 0 and step % save_every == 0 and hasattr(eng, "sync_to_module"):
+            if evaluator is not None:
+                evaluator.step_end(epoch, max_epoch, step)
+            elif config.get("save_checkpoint") and rank == 0 and step % save_every == 0 and hasattr(eng, "sync_to_module"):
                 from ..utils.ckpt import write_mindspore_ckpt
 
                 eng.sync_to_module()
@@ -157,8 +170,112 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
                 write_mindspore_ckpt(path, params)
                 log("checkpoint: %s" % path)
             if max_steps is not None and step >= max_steps:
+                if evaluator is not None:
+                    evaluator.end()
                 return records
+    if evaluator is not None:
+        evaluator.end()
     return records
+
+
+class EvalCallback:
+    """mindaudio/utils/callback.py:256-447 for the conformer script (train.py:143-155): `conformer_init.ckpt` before the first step;
+    every `run_interval` steps (= steps_size x save_checkpoint_epochs) the evaluation set's utterance-weighted mean loss through
+    ASREvalNet (the loss all-reduced over the ranks / device_num, asr_model.py:355-371) in evaluation mode, a log line, and
+    `conformer_<epoch>_<step>.ckpt` with a `.yaml` of {loss, time} beside it; at the end the element-wise mean of the
+    `num_best_ckpt` checkpoints of lowest loss as `conformer_avg_<num_best_ckpt>.ckpt` (every tensor that is not an optimizer moment:
+    the BatchNorm moving statistics and epoch_num are averaged too, as the reference does).  Rank 0 writes; every rank evaluates."""
+
+    def __init__(self, model, eng, dataset, device, world, rank, run_interval, save_ckpt_path, log, ckpt_prefix="conformer",
+                 eval_log_interval=10, num_best_ckpt=30):
+        from .asr_model import ASREvalNet
+
+        self.model, self.eng, self.dataset, self.device, self.rank = model, eng, dataset, device, rank
+        self.net = ASREvalNet(model, world)
+        self.run_interval, self.dir, self.log = max(int(run_interval), 1), save_ckpt_path, log
+        self.prefix, self.eval_log_interval, self.num_best_ckpt = ckpt_prefix, eval_log_interval, num_best_ckpt
+        self.total_eval_time, self.loss_ckpt_record = 0.0, []
+        if rank == 0:
+            os.makedirs(save_ckpt_path, exist_ok=True)
+
+    def evaluate(self):
+        if hasattr(self.eng, "sync_to_module"):
+            self.eng.sync_to_module()  # (the trained weights and BatchNorm statistics live in the engine's flat buffers)
+        was_training = self.model.training
+        self.model.eval()
+        total_loss = total_utts = 0.0
+        total_step = self.dataset.get_dataset_size()
+        t0 = time.time()
+        for i, cols in enumerate(self.dataset):
+            cols = tuple(c.to(self.device) if hasattr(c, "to") else c for c in cols)
+            loss = float(self.net(*cols))
+            total_loss += loss * cols[0].shape[0]
+            total_utts += cols[0].shape[0]
+            if i % self.eval_log_interval == 0 and self.rank == 0:
+                self.log("[EvalCallback] Step: %d/%d, Eval Loss: %.4f." % (i, total_step, loss))
+        self.model.train(was_training)
+        seconds = time.time() - t0
+        self.total_eval_time += seconds
+        return total_loss / max(total_utts, 1.0), seconds
+
+    def save_ckpt(self, prefix, infos, epoch):
+        import numpy as np
+        import yaml
+
+        from ..utils.ckpt import to_reference_names, write_mindspore_ckpt
+
+        path = os.path.join(self.dir, prefix + ".ckpt")
+        params = to_reference_names(self.model.state_dict())
+        if epoch != -1:
+            params["epoch_num"] = np.asarray(epoch, dtype="int32")
+        write_mindspore_ckpt(path, params)
+        if infos:
+            with open(os.path.join(self.dir, prefix + ".yaml"), "w") as fh:
+                fh.write(yaml.dump(infos))
+        self.log("[EvalCallback] Successfully save %s.ckpt to %s." % (prefix, self.dir))
+        return path
+
+    def begin(self):
+        if self.rank == 0:
+            if hasattr(self.eng, "sync_to_module"):
+                self.eng.sync_to_module()
+            self.save_ckpt(self.prefix + "_init", {}, -1)
+
+    def step_end(self, epoch, max_epoch, step):
+        if step % self.run_interval != 0:
+            return
+        avg_loss, seconds = self.evaluate()
+        if self.rank != 0:
+            return
+        self.log("[EvalCallback] Epoch %d/%d, Average Eval Loss: %.4f, Eval Spend Time: %dm %ds."
+                 % (epoch, max_epoch, avg_loss, int(seconds // 60), int(seconds % 60)))
+        path = self.save_ckpt("%s_%d_%d" % (self.prefix, epoch, step), {"loss": float(avg_loss), "time": float(seconds)}, epoch)
+        self.loss_ckpt_record.append({"loss": float(avg_loss), "ckpt_path": path})
+
+    def average_model(self):
+        import numpy as np
+
+        from ..utils.ckpt import read_mindspore_ckpt, write_mindspore_ckpt
+
+        best = sorted(self.loss_ckpt_record, key=lambda r: r["loss"])[:self.num_best_ckpt]
+        if not best:
+            return None
+        acc = {}
+        for rec in best:
+            for name, value in read_mindspore_ckpt(rec["ckpt_path"]).items():
+                if not name.startswith("moment"):
+                    acc.setdefault(name, []).append(np.asarray(value))
+        avg = {name: np.mean(np.array(vals), axis=0).astype(vals[0].dtype) for name, vals in acc.items()}
+        path = os.path.join(self.dir, "%s_avg_%d.ckpt" % (self.prefix, self.num_best_ckpt))
+        write_mindspore_ckpt(path, avg)
+        self.log("[EvalCallback] Successfully save %s_avg_%d.ckpt to %s." % (self.prefix, self.num_best_ckpt, self.dir))
+        return path
+
+    def end(self):
+        if self.rank == 0:
+            self.average_model()
+            t = self.total_eval_time
+            self.log("[EvalCallback] [After training] Total Eval Time: %dh %dm %ds." % (int(t // 3600), int(t % 3600 // 60), int(t % 60)))
 
 
 def main(argv=None):

@@ -36,6 +36,50 @@ def global_batch():
     return xs, ys, sub, ys_lens
 
 
+def hybrid_steps(rank, world, out, tables):
+    """Twelve hybrid (0.3 CTC + attention) steps whose label width changes from step to step (10 / 7 / 13 columns): launch tables
+    recorded and replayed for the encoder, the decoder replayed only at the recorded width and walked otherwise - with the gradient
+    buckets of BOTH going through the all-reduce.  Saves the losses, the final masters and, per step, the spans that were reduced."""
+    import torch
+
+    from mindaudio_amd.conformer.asr_model import create_asr_model, shard_batch
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    torch.manual_seed(5)
+    model = create_asr_model(80, 97, dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=2), ctc_weight=0.3,
+                             decoder_conf=dict(attention_heads=4, linear_units=512, num_blocks=2, dropout_rate=0.1,
+                                               positional_dropout_rate=0.1), lsm_weight=0.1).cuda()
+    eng = ConformerCTCTrainStep(model, base_lr=1e-3, warmup_steps=2, dropout_rate=0.1, positional_dropout_rate=0.1, world_size=world,
+                                rank=rank, seed=3)
+    eng.block_tables = tables
+    order = []
+    launch = eng.reducer.launch
+    eng.reducer.launch = lambda lo, hi: (order.append((lo, hi)), launch(lo, hi))[1]
+    xs, ys, sub, ys_lens = shard_batch(global_batch(), rank, world)
+    losses, spans = [], []
+    for k in range(12):
+        lmax = (9, 9, 9, 6, 9, 12, 6, 9, 12, 12, 9, 6)[k]
+        lens = torch.clamp(ys_lens, max=lmax)
+        b, eos = ys.shape[0], 96
+        ys_w = torch.full((b, lmax), -1, dtype=torch.int32)
+        ys_in = torch.full((b, lmax + 1), eos, dtype=torch.int32)
+        ys_out = torch.full((b, lmax + 1), -1, dtype=torch.int32)
+        ys_masks = torch.zeros(b, 1, lmax + 1)
+        for i, n in enumerate(lens.tolist()):
+            ys_w[i, :n] = ys[i, :n]
+            ys_in[i, 1:n + 1] = ys[i, :n]
+            ys_out[i, :n] = ys[i, :n]
+            ys_out[i, n] = eos
+            ys_masks[i, 0, :n + 1] = 1
+        ys_sub = (ys_masks.bool() & torch.tril(torch.ones(lmax + 1, lmax + 1, dtype=torch.bool))[None]).float()
+        cols = (xs, ys_w, ys_in, ys_out, None, None, sub, ys_sub, ys_masks, lens, None)
+        order.clear()
+        losses.append(float(eng.step(*(c.cuda() if c is not None else None for c in cols))[0]))
+        spans.append(sorted(order))
+    torch.cuda.synchronize()
+    torch.save({"losses": losses, "master": eng.fp.master.cpu(), "spans": spans, "size": eng.fp.size}, out)
+
+
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     compute_type = sys.argv[5] if len(sys.argv) > 5 else "bfloat16"
@@ -47,6 +91,11 @@ def main():
 
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if compute_type.startswith("hybrid"):
+        hybrid_steps(rank, world, out, compute_type.endswith("tables"))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     from mindaudio_amd.conformer.asr_model import create_asr_model, shard_batch
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
 

@@ -102,3 +102,26 @@ def test_two_ranks_equal_one_rank_on_the_whole_batch(tmp_path):
     assert pos == r0["size"]
     block_los = [lo for lo, _ in order[:2]]
     assert block_los == sorted(block_los, reverse=True) and order[-1][0] == 0
+
+
+def test_two_ranks_hybrid_steps_with_changing_label_widths_tables_on_and_off(tmp_path):
+    """The data-parallel hybrid step when the decoder is replayed at the recorded label width and walked at the others while the
+    encoder's backward is replayed (round 6: the combination that computed a wrong ca_kv gradient before its fix): on each of two ranks
+    the launch tables change no bit of twelve steps' losses and masters, every step reduces every element of the flat gradient
+    exactly once on either path, and both ranks hold the same weights."""
+    import torch
+
+    on = _run_world(2, tmp_path, "hybrid_tables")
+    for r in range(2):
+        os.rename(str(tmp_path / ("hybrid_tables_w2_r%d.pt" % r)), str(tmp_path / ("on_r%d.pt" % r)))
+    off = _run_world(2, tmp_path, "hybrid_walked")
+    for a, b in zip(on, off):
+        assert a["losses"] == b["losses"] and torch.equal(a["master"], b["master"])
+        for res in (a, b):
+            for spans in res["spans"]:
+                pos = 0
+                for lo, hi in spans:  # the reduced spans tile the flat gradient
+                    assert lo == pos and hi > lo
+                    pos = hi
+                assert pos == res["size"]
+    assert torch.equal(on[0]["master"], on[1]["master"])

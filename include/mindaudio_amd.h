@@ -274,7 +274,8 @@ int ma_convmodule_mid_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T,
  *   logits (batch*T, V) float32 row stride ld (= ctc_lo output, ma_gemm_bf16 with float32 out);
  *   ys (batch, Lmax) int32 padded labels; hlens / ylens (batch) int32 input / target lengths;
  *   per_utt_loss (batch) float32 out; lse_workspace (batch*T) float32; loss_out (1) float32.
- * Targets up to 127 labels (2*Lmax + 1 <= 256). */
+ * Targets up to 223 labels (2*Lmax + 1 <= 448; up to 127 on the 4-chunk form, longer ones - conformer.yaml allows
+ * token_max_length 200 - on a 7-chunk instantiation of the same recursion, round 6). */
 int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
                     int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
                     int32_t zero_infinity, float* per_utt_loss, float* lse_workspace, float* loss_out,

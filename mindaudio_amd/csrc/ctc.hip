@@ -92,8 +92,11 @@ __global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ 
 }
 
 // one wave per utterance; extended label sequence l' (blank, y1, blank, y2, ..., blank), state s on lane s % 64,
-// up to kMaxChunks * 64 states (targets up to 127 labels).
-constexpr int kMaxChunks = 4;
+// up to NC * 64 states.
+// (round 6: the bodies are templates on the chunk count NC - 4 for targets up to 127 labels, kMaxChunks = 7 for up to 223, past the
+// yaml's token_max_length of 200; labels of more than 127 tokens were refused until then)
+constexpr int kMaxChunks = 7;
+template <int NC>
 __device__ __forceinline__ void ctc_alpha_body(const float* __restrict__ logits, int64_t ld, int T,
                                                const float* __restrict__ lse, const int32_t* __restrict__ ys,
                                                int Lmax, const int32_t* __restrict__ hlens,
@@ -106,11 +109,11 @@ __device__ __forceinline__ void ctc_alpha_body(const float* __restrict__ logits,
   const int U = ylens[b];
   const int S = 2 * U + 1;
   const int nch = (S + 63) / 64;
-  int lab[kMaxChunks];
-  bool skip[kMaxChunks];  // transition from s-2 allowed
-  float alpha[kMaxChunks];
+  int lab[NC];
+  bool skip[NC];  // transition from s-2 allowed
+  float alpha[NC];
 #pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int s = c * 64 + lane;
     int l = blank;
     bool sk = false;
@@ -122,7 +125,7 @@ __device__ __forceinline__ void ctc_alpha_body(const float* __restrict__ logits,
     skip[c] = sk;
     alpha[c] = -INFINITY;
   }
-  if (tlen < 1 || U < 0 || nch > kMaxChunks) {
+  if (tlen < 1 || U < 0 || nch > NC) {
     if (lane == 0) loss[b] = (tlen < 1 && U == 0) ? 0.0f : INFINITY;
     return;
   }
@@ -134,26 +137,26 @@ __device__ __forceinline__ void ctc_alpha_body(const float* __restrict__ logits,
     if (lane == 1 && S > 1) alpha[0] = row0[lab[0]] - z;
     if (alpha_out) {
 #pragma unroll
-      for (int c = 0; c < kMaxChunks; ++c)
+      for (int c = 0; c < NC; ++c)
         if (c * 64 + lane < S) alpha_out[((int64_t)b * T) * Smax + c * 64 + lane] = alpha[c];
     }
   }
   // The emissions of a step do not depend on the recursion: they are fetched kPD steps ahead (as loads inside the step they were an
   // exposed L2 / HBM round trip per time step: 265 us for 255 steps of the cfg-4 batch, one wave per utterance).
   constexpr int kPD = 4;
-  float er[kPD][kMaxChunks], zr[kPD];
+  float er[kPD][NC], zr[kPD];
   auto fetch = [&](auto kc, int t) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
     const int tc = t < tlen ? t : tlen - 1;
     const float* row = row0 + (int64_t)tc * ld;
     zr[k] = lse[(int64_t)b * T + tc];
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) er[k][c] = (c < nch && c * 64 + lane < S) ? row[lab[c]] : 0.0f;
+    for (int c = 0; c < NC; ++c) er[k][c] = (c < nch && c * 64 + lane < S) ? row[lab[c]] : 0.0f;
   };
-  auto step = [&](int t, const float (&e)[kMaxChunks], float z) __attribute__((always_inline)) {
+  auto step = [&](int t, const float (&e)[NC], float z) __attribute__((always_inline)) {
     float carry1 = -INFINITY, carry2 = -INFINITY;  // alpha(s-1), alpha(s-2) coming from the previous chunk
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (c >= nch) break;
       const float a0 = alpha[c];
       float a1 = __shfl_up(a0, 1, 64);
@@ -188,7 +191,7 @@ __device__ __forceinline__ void ctc_alpha_body(const float* __restrict__ logits,
   // -log( alpha_T(S-1) + alpha_T(S-2) )
   float fin = -INFINITY;
 #pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int s = c * 64 + lane;
     if (s == S - 1 || (s == S - 2 && S > 1)) fin = log_add(fin, alpha[c]);
   }
@@ -197,13 +200,14 @@ __device__ __forceinline__ void ctc_alpha_body(const float* __restrict__ logits,
   if (lane == 0) loss[b] = (m == -INFINITY) ? INFINITY : -(m + logf(sum));
 }
 
+template <int NC>
 __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__ logits, int64_t ld, int T,
                                                        const float* __restrict__ lse, const int32_t* __restrict__ ys,
                                                        int Lmax, const int32_t* __restrict__ hlens,
                                                        const int32_t* __restrict__ ylens, int blank,
                                                        float* __restrict__ loss, float* __restrict__ alpha_out,
                                                        int Smax) {
-  ctc_alpha_body(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, loss, alpha_out, Smax);
+  ctc_alpha_body<NC>(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, loss, alpha_out, Smax);
 }
 
 // Backward, step 1: beta recursion of one utterance per wave (mirror image of the alpha recursion).  Round 4: it no longer reads
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
 // occupancy w_t(s) = alpha_t(s) beta_t(s) / (y_t(l'_s) P(l|x)) = exp(alpha + beta_out + nll) itself - so that the two recursions,
 // 255 dependent steps of one wave per utterance each, run SIDE BY SIDE in one launch (ctc_alpha_beta_kernel) instead of one after
 // the other (79 + 112 us of the training step with 40 of 1024 SIMDs busy).
+template <int NC>
 __device__ __forceinline__ void ctc_beta_body(const float* __restrict__ logits, int64_t ld, int T,
                                               const float* __restrict__ lse, const int32_t* __restrict__ ys,
                                               int Lmax, const int32_t* __restrict__ hlens,
@@ -221,12 +226,12 @@ __device__ __forceinline__ void ctc_beta_body(const float* __restrict__ logits, 
   const int U = ylens[b];
   const int S = 2 * U + 1;
   const int nch = (S + 63) / 64;
-  if (tlen < 1 || U < 0 || nch > kMaxChunks) return;  // no gradient (degenerate)
-  int lab[kMaxChunks];
-  bool skip[kMaxChunks];  // transition s -> s+2 allowed
-  float beta[kMaxChunks];
+  if (tlen < 1 || U < 0 || nch > NC) return;  // no gradient (degenerate)
+  int lab[NC];
+  bool skip[NC];  // transition s -> s+2 allowed
+  float beta[NC];
 #pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int s = c * 64 + lane;
     int l = blank;
     bool sk = false;
@@ -241,23 +246,23 @@ __device__ __forceinline__ void ctc_beta_body(const float* __restrict__ logits, 
   const float* row0 = logits + (int64_t)b * T * ld;
   // as in the alpha recursion: emissions and log-sum-exp of a step are fetched kPD steps ahead of the recursion
   constexpr int kPD = 4;
-  float er[kPD][kMaxChunks], zr[kPD];
+  float er[kPD][NC], zr[kPD];
   auto fetch = [&](auto kc, int t) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
     const int tc = t >= 0 ? t : 0;
     const float* row = row0 + (int64_t)tc * ld;
     zr[k] = lse[(int64_t)b * T + tc];
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const bool in = c < nch && c * 64 + lane < S;
       er[k][c] = in ? row[lab[c]] : 0.0f;
     }
   };
-  auto step = [&](int t, const float (&e)[kMaxChunks], float z) __attribute__((always_inline)) {
+  auto step = [&](int t, const float (&e)[NC], float z) __attribute__((always_inline)) {
     float carry1 = -INFINITY, carry2 = -INFINITY;  // beta_{t+1}(s+1), (s+2) coming from the next chunk
-    float nb[kMaxChunks];
+    float nb[NC];
 #pragma unroll
-    for (int c = kMaxChunks - 1; c >= 0; --c) {
+    for (int c = NC - 1; c >= 0; --c) {
       nb[c] = -INFINITY;
       if (c >= nch) continue;
       const int s = c * 64 + lane;
@@ -280,7 +285,7 @@ __device__ __forceinline__ void ctc_beta_body(const float* __restrict__ logits, 
       if (s < S) beta_out[((int64_t)b * T + t) * Smax + s] = nb[c] - lp;  // (v: -inf stays -inf)
     }
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; ++c) beta[c] = nb[c];
+    for (int c = 0; c < NC; ++c) beta[c] = nb[c];
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
@@ -300,13 +305,14 @@ __device__ __forceinline__ void ctc_beta_body(const float* __restrict__ logits, 
 }
 
 // both recursions in one launch: grid (batch, 2), blockIdx.y = 0: alpha (+ the utterance's loss), 1: beta
+template <int NC>
 __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logits, int64_t ld, int T,
                                                             const float* __restrict__ lse, const int32_t* __restrict__ ys,
                                                             int Lmax, const int32_t* __restrict__ hlens,
                                                             const int32_t* __restrict__ ylens, int blank, float* __restrict__ loss,
                                                             float* __restrict__ alpha_out, float* __restrict__ beta_out, int Smax) {
-  if (blockIdx.y == 0) ctc_alpha_body(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, loss, alpha_out, Smax);
-  else ctc_beta_body(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, beta_out, Smax);
+  if (blockIdx.y == 0) ctc_alpha_body<NC>(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, loss, alpha_out, Smax);
+  else ctc_beta_body<NC>(logits, ld, T, lse, ys, Lmax, hlens, ylens, blank, beta_out, Smax);
 }
 
 // Backward, step 2: one workgroup per (b, t) row: dlogits[v] = scale * (softmax[v] - sum_{s: l'_s = v} w_t(s)) as bf16;
@@ -490,8 +496,12 @@ int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, i
   hipStream_t s = (hipStream_t)stream;
   const int64_t rows = batch * T;
   MA_LAUNCH(ctc_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, ld, rows, (int)V, lse_workspace);
-  MA_LAUNCH(ctc_alpha_kernel, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
-            hlens, ylens, (int)blank, per_utt_loss, (float*)nullptr, 0);
+  if (2 * Lmax + 1 <= 4 * 64)  // (the 4-chunk form: its per-lane state fits the registers of the common case, targets up to 127 labels)
+    MA_LAUNCH(ctc_alpha_kernel<4>, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
+              hlens, ylens, (int)blank, per_utt_loss, (float*)nullptr, 0);
+  else
+    MA_LAUNCH(ctc_alpha_kernel<kMaxChunks>, dim3((unsigned)batch), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
+              hlens, ylens, (int)blank, per_utt_loss, (float*)nullptr, 0);
   MA_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, per_utt_loss, (int)batch, (int)zero_infinity, loss_out);
   return MA_OK;
 }
@@ -519,8 +529,12 @@ static int ctc_loss_grad_launch(const float* logits, int64_t ld, int64_t batch, 
   float* ab = reinterpret_cast<float*>(workspace);
   MA_LAUNCH(ctc_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, ld, rows, (int)V, lse_workspace);
   float* bb = ab + batch * T * Smax;
-  MA_LAUNCH(ctc_alpha_beta_kernel, dim3((unsigned)batch, 2), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
-            hlens, ylens, (int)blank, per_utt_loss, ab, bb, Smax);
+  if (Smax <= 4 * 64)
+    MA_LAUNCH(ctc_alpha_beta_kernel<4>, dim3((unsigned)batch, 2), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys, (int)Lmax,
+              hlens, ylens, (int)blank, per_utt_loss, ab, bb, Smax);
+  else
+    MA_LAUNCH(ctc_alpha_beta_kernel<kMaxChunks>, dim3((unsigned)batch, 2), dim3(64), 0, s, logits, ld, (int)T, lse_workspace, ys,
+              (int)Lmax, hlens, ylens, (int)blank, per_utt_loss, ab, bb, Smax);
   MA_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(64), 0, s, per_utt_loss, (int)batch, 1, loss_out);
   MA_LAUNCH(ctc_dlogits_kernel<OT>, dim3((unsigned)rows), dim3(256), (size_t)V * 4, s, logits, ld, (int)T, (int)V,
             lse_workspace, ys, (int)Lmax, hlens, ylens, (int)blank, per_utt_loss, ab, bb, Smax, grad_scale, dlogits, ld_out);

@@ -243,7 +243,9 @@ def test_layernorm_backward_refuses_other_widths(K):
 
 # ---- odd batch shapes through the whole hybrid step ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["bf16", "float32"])
-@pytest.mark.parametrize("b,tlen,ylens", [(1, 67, (1,)), (2, 259, (33, 2)), (7, 99, (5, 1, 9, 3, 2, 8, 4)), (3, 515, (12, 40, 7))])
+# (2, 700, (150, 90)): a transcript of 150 tokens - five query tiles in the decoder, the 7-chunk CTC recursion
+@pytest.mark.parametrize("b,tlen,ylens", [(1, 67, (1,)), (2, 259, (33, 2)), (7, 99, (5, 1, 9, 3, 2, 8, 4)), (3, 515, (12, 40, 7)),
+                                          (2, 700, (150, 90))])
 def test_hybrid_step_at_odd_batch_shapes(b, tlen, ylens, mode):
     """One utterance, one-token labels, T' that is not a multiple of any tile (16, 64, 24, 128 rows), labels across the 32-query tile
     boundary: loss and every gradient of the hybrid step (fused launches in bf16 mode, one launch per cell in float32 mode) against the

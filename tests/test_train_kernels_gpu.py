@@ -409,6 +409,34 @@ def test_ctc_loss_grad(K):
     assert float(got[4].abs().max()) == 0.0 and float(got[1, 50:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("lmax", [127, 128, 200, 223])
+def test_ctc_loss_grad_long_targets(K, lmax):
+    """Targets beyond 127 labels (conformer.yaml: token_max_length 200) run a 7-chunk instantiation of the recursion (round 6: they
+    were refused); 127 is the last length of the 4-chunk form, 223 the last the library takes."""
+    g = torch.Generator().manual_seed(lmax)
+    b, t, v = 4, 2 * lmax + 40, 97
+    vp = (v + 63) // 64 * 64
+    logits = torch.zeros(b * t, vp)
+    logits[:, :v] = torch.randn(b * t, v, generator=g) * 2
+    hlens = torch.tensor([t, t - 17, lmax + 3, t])
+    ylens = torch.tensor([lmax, lmax - 5, lmax, 3])  # (the third: lmax labels in lmax + 3 frames - feasible only without repeats)
+    ys = torch.randint(1, v, (b, lmax), generator=g)
+    ys[2] = (torch.arange(lmax) % (v - 1)) + 1       # no two neighbours equal
+    ys[0, 10] = ys[0, 9]
+    lg = logits[:, :v].clone().view(b, t, v).requires_grad_()
+    lp = torch.log_softmax(lg, -1).transpose(0, 1)
+    per_ref = F.ctc_loss(lp, ys, hlens, ylens, blank=0, reduction="none", zero_infinity=True)
+    (per_ref.sum() * 2.0).backward()
+    loss, per, dlog = K.ctc_loss_grad(logits.cuda(), v, b, t, ys.cuda(), hlens.cuda(), ylens.cuda(), 2.0)
+    assert bool(torch.isfinite(per_ref).all()) and rel(per.cpu(), per_ref.detach()) < 1e-5
+    got = dlog.float().cpu().view(b, t, vp)
+    assert rel(got[..., :v], lg.grad) < 5e-3
+    from mindaudio_amd import _lib
+
+    with pytest.raises((NotImplementedError, _lib.MindaudioAmdError)):  # 224 labels: 449 states
+        K.ctc_loss_grad(logits.cuda(), v, b, t, torch.ones(b, 224, dtype=torch.long).cuda(), hlens.cuda(), ylens.cuda(), 1.0)
+
+
 def test_gemm_tn(K):
     g = torch.Generator().manual_seed(21)
     # (Kc, Mo, No, rows_store): tails in every dimension, small and large contractions

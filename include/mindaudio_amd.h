@@ -274,8 +274,8 @@ int ma_convmodule_mid_bf16(const void* y, int64_t ldy, int64_t batch, int64_t T,
  *   logits (batch*T, V) float32 row stride ld (= ctc_lo output, ma_gemm_bf16 with float32 out);
  *   ys (batch, Lmax) int32 padded labels; hlens / ylens (batch) int32 input / target lengths;
  *   per_utt_loss (batch) float32 out; lse_workspace (batch*T) float32; loss_out (1) float32.
- * Targets up to 223 labels (2*Lmax + 1 <= 448; up to 127 on the 4-chunk form, longer ones - conformer.yaml allows
- * token_max_length 200 - on a 7-chunk instantiation of the same recursion, round 6). */
+ * Targets up to 223 labels (2*Lmax + 1 <= 448; up to 127 on the 4-chunk form, longer ones - the data set classes default to
+ * token_max_length 200, the shipped conformer.yaml sets 30 - on a 7-chunk instantiation of the same recursion, round 6). */
 int ma_ctc_loss_f32(const float* logits, int64_t ld, int64_t batch, int64_t T, int32_t V, const int32_t* ys,
                     int32_t Lmax, const int32_t* hlens, const int32_t* ylens, int32_t blank,
                     int32_t zero_infinity, float* per_utt_loss, float* lse_workspace, float* loss_out,
@@ -804,7 +804,7 @@ int ma_embed_bwd_rows_f32(const int32_t* tokens, const float* g, const float* ro
                           float xscale, float p, uint32_t seed, uint32_t salt, float* dtable, ma_stream_t stream);
 
 /* MultiHeadedAttention core (layers/attention.py:86-157) for Lq <= 1024 queries (walked in tiles of 32, one launch each: labels of
- * more than 31 tokens - AISHELL's longest transcripts, token_max_length 200 - were refused until round 6) and Lk <= 1088 keys per (batch, head)
+ * more than 31 tokens - the data set classes' default token_max_length is 200, the shipped yaml sets 30 - were refused until round 6) and Lk <= 1088 keys per (batch, head)
  * (up to 320 keys the V / K rows are staged in LDS; beyond that - the 1400 ... 3000-frame buckets of conformer.yaml, T' <= 749 -
  * the score rows take the LDS and V / K are read from L2; more keys: MA_ERR_UNSUPPORTED), d_k = 64: ctx = softmax(scale * q k^T + (mask == 0 ? -10000 : 0)) v.  q (batch*Lq, H*64) / k, v (batch*Lk, H*64) bf16
  * with row strides; mask_mode 0 none, 1 (batch, 1, Lk), 2 (batch, Lq, Lk) float32; probs (batch, H, Lq, Lk) float32 is

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=4233)
     ap.add_argument("--ctc-weight", type=float, default=0.3, help="1.0: the pure-CTC step (no decoder)")
     ap.add_argument("--len-norm", action="store_true", help="length_normalized_loss (asr_model.py:61): the decoder is always walked")
+    ap.add_argument("--yaml-buckets", action="store_true", help="the 16 (batch, frames) buckets of conformer.yaml, labels up to 30 tokens")
     ap.add_argument("--only", default="", help="tables | walked: one engine only (no comparison)")
     ap.add_argument("--verbose", action="store_true", help="synchronise and print after every step")
     a = ap.parse_args()
@@ -74,6 +75,10 @@ def main():
 
     # the buckets of conformer.yaml scaled to one GPU: (batch, frames, longest label)
     shapes = [(40, 1024, 30), (24, 1536, 42), (64, 640, 18), (40, 1024, 23), (12, 3000, 60), (40, 1024, 30)]
+    if a.yaml_buckets:
+        fr = [144, 204, 288, 400, 512, 600, 712, 800, 912, 1024, 1112, 1200, 1400, 1600, 2000, 3000]
+        bs = [40, 80, 80, 72, 72, 56, 56, 56, 40, 40, 40, 40, 24, 8, 8, 8]
+        shapes = [(b, t, 12 + (7 * i) % 19) for i, (b, t) in enumerate(zip(bs, fr))]
     rng = np.random.RandomState(5)
     # each shape recurs (a table is recorded on its second sighting and replayed from the third on)
     order = [shapes[(i // 3 + i) % len(shapes)] for i in range(a.steps)]

@@ -302,7 +302,12 @@ class ConformerCTCTrainStep:
         # same calls, same buffers, same order; 4.2 -> ~1.5 ms of host time per step (train/block_table.py, csrc/block_table.hip)
         self.block_tables = self.fused and self._dw_direct
         self.block_table_min_sightings = 2        # a shape is recorded at its n-th step (>= 2), replayed from the next one on
-        self.block_table_max_bytes = 48 << 30     # device bytes all recorded tables together may pin (oldest dropped first)
+        # device bytes all recorded tables together may pin.  A table keeps every buffer of its step (3-5 GB at the yaml's buckets);
+        # the 16 buckets of conformer.yaml together are ~70 GB of the 288.  When the budget is reached the NEW shape stays walked
+        # from Python (round 6; until then the oldest table was dropped - under the loader's round-robin over its buckets that is the
+        # table needed next: every step evicted, re-walked and re-recorded a shape, 39 ms per hybrid step instead of 9.4,
+        # tools/bucket_cycle_bench.py)
+        self.block_table_max_bytes = 128 << 30
         self.block_table_max_blocks = 64          # kMaxBlocks of csrc/block_table.hip: encoder blocks + decoder layers + 3 segments
         self._table_bytes, self._table_warned, self._recording_tb, self._walk_shapes = {}, set(), None, set()
         if self._wg_on and not self._dw_direct and not self._wg_split_ok:
@@ -665,7 +670,7 @@ class ConformerCTCTrainStep:
     # Batch shapes whose plan - and block launch table: the tape and temporaries of one step, 2 - 4 GB - stay resident.  The reference
     # trains on static shapes (MindSpore graph mode): examples/conformer/conformer.yaml:71-72 has 16 (frame bucket, batch) pairs and pads
     # the labels to token_max_length, so 16 plans cover a whole epoch (~45 of 288 GB).
-    _DW_PLANS_KEPT = 16
+    _DW_PLANS_KEPT = 64  # (batch shapes whose plans - and launch tables - stay: the yaml has 16 buckets; least recently used first out)
 
     _DW_SUFFIXES = ("ffm_w1", "ffm_w2", "qkv_w", "o_w", "pw1_w", "pw2_w", "ff_w1", "ff_w2")
 
@@ -798,8 +803,13 @@ class ConformerCTCTrainStep:
     def _front_plan_for(self, m, t2):
         """The three weight gradients outside the blocks (CTC head, embed layer, positional projections): split-K partials into one
         arena, one batched sum at the end of the backward pass instead of five reduction launches (fused bf16 path)."""
-        cur = self.__dict__.get("_front_plan")
-        if cur is not None and cur["key"] == (m, t2):
+        # (one plan per batch shape, the last _DW_PLANS_KEPT of them on one grow-only arena: with ONE cached plan every change of
+        # bucket rebuilt it - an allocation and two synchronous host-to-device copies per step of a real epoch)
+        plans = self.__dict__.setdefault("_front_plans", {})
+        cur = plans.get((m, t2))
+        if cur is not None:
+            plans[(m, t2)] = plans.pop((m, t2))
+            self._front_plan = cur
             return cur
         import numpy as np
 
@@ -812,7 +822,11 @@ class ConformerCTCTrainStep:
             nbytes = int(lib.ma_gemm_tn_workspace_bytes(mo, no, kc))
             off[name] = (total, nbytes, int(lib.ma_gemm_tn_splits(mo, no, kc)))
             total += (nbytes + 255) // 256 * 256
-        arena = torch.empty(total, dtype=torch.uint8, device=self.dev)
+        arena = self.__dict__.get("_front_arena")
+        if arena is None or arena.numel() < total:
+            arena = self._front_arena = torch.empty(max(total, int(1.25 * (arena.numel() if arena is not None else 0))),
+                                                    dtype=torch.uint8, device=self.dev)
+            plans.clear()  # (their item tables name the old arena)
         items, block_item, first = [], [], 0
         for name, mo, no, kc, mo_store, gw, gb in prods:
             o, _, splits = off[name]
@@ -823,9 +837,11 @@ class ConformerCTCTrainStep:
                 block_item.extend([len(items) - 1] * nblk)
                 first += nblk
         raw = (_lib.ReduceItem * len(items))(*items)
-        self._front_plan = dict(key=(m, t2), arena=arena, off=off, n_blocks=first,
-                                items=torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
-                                block_item=torch.tensor(block_item, dtype=torch.int32, device=self.dev))
+        self._front_plan = plans[(m, t2)] = dict(key=(m, t2), arena=arena, off=off, n_blocks=first,
+                                                 items=torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to(self.dev),
+                                                 block_item=torch.tensor(block_item, dtype=torch.int32, device=self.dev))
+        while len(plans) > self._DW_PLANS_KEPT:
+            plans.pop(next(iter(plans)))
         return self._front_plan
 
     def _front_dW(self, name, dy, x, rows_store=None, with_colsum=True):
@@ -897,7 +913,7 @@ class ConformerCTCTrainStep:
 
     def _table_recorded(self, tb):
         """End of a recorded step: the table replays from the next step on - unless the recorder met a call it cannot replay (then the
-        shape is walked for good), and within the byte budget of all tables kept (oldest dropped first)."""
+        shape is walked for good) or the byte budget of all tables is spent (then THIS shape stays walked, the recorded ones stay)."""
         table = tb["table"]
         self._recording_tb = None
         if table.broken is not None:
@@ -906,19 +922,18 @@ class ConformerCTCTrainStep:
                 del tb[k]
             tb["state"] = "walk"
             return
+        nbytes = table.nbytes()
+        if self._table_bytes and sum(n for n, _ in self._table_bytes.values()) + nbytes > int(self.block_table_max_bytes):
+            # over the budget: this shape is walked from Python from now on; the tables recorded so far stay
+            self._table_warn("block tables: %.1f GB of launch tables are recorded (block_table_max_bytes); further batch shapes are "
+                             "walked from Python" % (sum(n for n, _ in self._table_bytes.values()) / 2 ** 30))
+            table.clear()
+            for k in [k for k in tb if k not in ("key", "sightings")]:
+                del tb[k]
+            tb["state"] = "walk"
+            return
         tb["state"] = "replay"
-        self._table_bytes[id(tb)] = (table.nbytes(), tb)
-        budget = int(self.block_table_max_bytes)
-        while sum(n for n, _ in self._table_bytes.values()) > budget and len(self._table_bytes) > 1:
-            oldest = next(iter(self._table_bytes))
-            if oldest == id(tb):
-                break
-            _, old = self._table_bytes.pop(oldest)
-            for plan in self._dw_plans.values() if hasattr(self, "_dw_plans") else ():
-                tabs = plan.get("tables", {})
-                for k in [k for k, v in tabs.items() if v is old]:
-                    del tabs[k]
-            old.clear()
+        self._table_bytes[id(tb)] = (nbytes, tb)
 
     def drop_block_tables(self):
         """Forget every recorded launch table (and the buffers they pin); the next steps of every shape are walked and re-recorded."""

@@ -307,6 +307,8 @@ def main():
     ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg-3 (32 x 1000 x 80 encoder forward) object")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg-5 (ECAPA-TDNN forward, 256 x 300 x 80) object")
     ap.add_argument("--no-hybrid-leg", action="store_true", help="skip the train_dp_hybrid object (ctc_weight 0.3 training step)")
+    ap.add_argument("--no-bucket-leg", action="store_true", help="skip the train_bucket_cycle object (the hybrid step over the yaml's "
+                    "16 buckets, a different bucket every step)")
     ap.add_argument("--step-only", action="store_true",
                     help="(profiling) only the warm-up + timed steps of the headline: no roofline loops, no cfg3 / cfg5 / training legs, "
                          "no CPU baseline - the kernel stats of this run are the step's launches and nothing else")
@@ -639,7 +641,7 @@ def main():
             del m5
         del x5
 
-    train = hybrid = None
+    train = hybrid = bucket_cycle = None
     if args.train or not args.no_train_leg:
         train = train_leg(rank, world, dev, dist if world > 1 else None, args.steps if args.train else args.train_steps,
                           args.warmup if args.train else 2, barrier, args.force_collective, args.train_digest,
@@ -650,6 +652,19 @@ def main():
             gc.collect()  # (an engine is a reference cycle: the first leg's launch tables and tape must not stay allocated - and be
             torch.cuda.empty_cache()  # walked by a collection in the middle of a timed step - under the second leg)
             hybrid = train_leg(rank, world, dev, None, max(5, args.train_steps // 2), 2, barrier, ctc_weight=0.3)
+            if not args.no_bucket_leg:
+                # what an epoch of real data looks like to the step: another batch shape every time (round 6: tools/bucket_cycle_bench.py)
+                gc.collect()
+                torch.cuda.empty_cache()
+                try:
+                    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                    import bucket_cycle_bench
+
+                    bucket_cycle = bucket_cycle_bench.run(0.3, rounds=2, settle=2, single_warm=3, single_timed=3)
+                except Exception as e:  # (a reported leg, never the reason the headline line is missing)
+                    bucket_cycle = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                gc.collect()
+                torch.cuda.empty_cache()
 
     if rank == 0:
         flops_utt = 23.12e9
@@ -712,6 +727,8 @@ def main():
             res["train_dp"] = train
             if hybrid is not None:
                 res["train_dp_hybrid"] = hybrid
+            if bucket_cycle is not None:
+                res["train_bucket_cycle"] = bucket_cycle
         elif train is not None:
             res["train_dp"] = {k: v for k, v in train.items() if k not in ("utterances_per_s", "ms_per_step", "workload")}
         if cpu is not None:

@@ -440,6 +440,13 @@ int ma_collate_asr_i32(const int32_t* tokens, const int32_t* tok_off, const int3
                        int32_t* r_ys_in_pad, int32_t* r_ys_out_pad, float* xs_masks, float* ys_sub_masks,
                        float* ys_masks, int32_t* ys_lengths, uint8_t* xs_chunk_masks, ma_stream_t stream);
 
+/* The loader's padded wave matrix on the device (round 6; dataset.py:386-406, 563-569: read -> [speed_perturb] -> waveform * 2^15 ->
+ * zero-padded batch): dst (rows, ld_dst) float32, dst[r][i] = source(r)[i] for i < lengths[r], 0 up to n_dst.  source(r) = row
+ * src_row[r] of `pcm` (kind[r] == 0: the files' 16-bit samples as floats = wave / 2^15 * 2^15 exactly) or of `y` (kind[r] == 1:
+ * float32 rows, e.g. what ma_resample_fft_f32 made of the perturbed utterances).  All index arrays int32 on the device. */
+int ma_wave_rows_f32(const int16_t* pcm, int64_t ld_pcm, const float* y, int64_t ld_y, const int32_t* src_row, const int32_t* kind,
+                     const int32_t* lengths, int64_t rows, float* dst, int64_t ld_dst, int64_t n_dst, ma_stream_t stream);
+
 /*
  * CollateFunc.spec_aug (dataset.py:493-534) on the padded batch xs (batch, max_frames, n_freq) float32, in place.
  * The host draws the intervals with the reference's `random` call order; t_intervals (batch, n_t, 2) /

@@ -184,6 +184,7 @@ PROTOTYPES = {
     "ma_cmvn_stats_f64": (ctypes.c_int, [vp, vp, i64, i64, i32, vp, vp]),
     "ma_subsampled_mask_len": (i32, [i32]),
     "ma_collate_asr_i32": (ctypes.c_int, [ctypes.c_void_p] * 3 + [i32] * 7 + [ctypes.c_void_p] * 11),
+    "ma_wave_rows_f32": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, i64, vp]),
     "ma_spec_aug_f32": (ctypes.c_int, [ctypes.c_void_p, i64, i64, i32, ctypes.c_void_p, ctypes.c_void_p, i32,
                                        ctypes.c_void_p, i32, ctypes.c_void_p]),
     "ma_conv1d_taps_bf16": (ctypes.c_int, [vp, i64, i64, i64, i32, i32, vp, vp, i64, i64, ctypes.POINTER(GemmEpilogue),

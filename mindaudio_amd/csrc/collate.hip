@@ -88,6 +88,26 @@ __global__ __launch_bounds__(256) void spec_aug_kernel(float* xs, int64_t T, int
   }
 }
 
+// Rows of a padded wave matrix from the loader's sources (round 6): dst[r][i] = i < len[r] ? source(r)[i] : 0, i < n_dst, where the
+// source of row r is row src_row[r] of the 16-bit PCM matrix as read from the files (kind[r] == 0: the sample as a float - the
+// reference's wave / 2^15 * 2^15, dataset.py:390, exactly) or of a float32 matrix (kind[r] == 1: the speed-perturbed rows that
+// ma_resample_fft_f32 produced).  The batch used to make two host round trips (float64 waves -> device resample -> host -> padded
+// float32 matrix -> device); now the files' int16 samples go up once and everything else happens here.
+__global__ __launch_bounds__(256) void wave_rows_kernel(const int16_t* __restrict__ pcm, int64_t ld_pcm, const float* __restrict__ y,
+                                                        int64_t ld_y, const int32_t* __restrict__ src_row,
+                                                        const int32_t* __restrict__ kind, const int32_t* __restrict__ len,
+                                                        float* __restrict__ dst, int64_t ld_dst, int64_t n_dst) {
+  const int r = blockIdx.y;
+  const int64_t n = len[r], sr = src_row[r];
+  const bool from_y = kind[r] != 0;
+  float* __restrict__ d = dst + (int64_t)r * ld_dst;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_dst; i += (int64_t)gridDim.x * 256) {
+    float v = 0.0f;
+    if (i < n) v = from_y ? y[sr * ld_y + i] : (float)pcm[sr * ld_pcm + i];
+    d[i] = v;
+  }
+}
+
 }  // namespace ma
 
 using namespace ma;
@@ -130,6 +150,17 @@ int ma_spec_aug_f32(float* xs, int64_t batch, int64_t max_frames, int32_t n_freq
   if (n_t + n_f == 0) return MA_OK;
   MA_LAUNCH(spec_aug_kernel, dim3((unsigned)(n_t + n_f), (unsigned)batch), dim3(256), 0, (hipStream_t)stream, xs,
             max_frames, n_freq, xs_lengths, t_intervals, n_t, f_intervals, n_f);
+  return MA_OK;
+}
+
+int ma_wave_rows_f32(const int16_t* pcm, int64_t ld_pcm, const float* y, int64_t ld_y, const int32_t* src_row, const int32_t* kind,
+                     const int32_t* lengths, int64_t rows, float* dst, int64_t ld_dst, int64_t n_dst, ma_stream_t stream) {
+  if (!src_row || !kind || !lengths || !dst || rows < 1 || rows > 65535 || n_dst < 1 || ld_dst < n_dst || (!pcm && !y))
+    return MA_ERR_INVALID_ARG;
+  int64_t gx = (n_dst + 256 * 8 - 1) / (256 * 8);
+  if (gx > 1024) gx = 1024;
+  MA_LAUNCH(wave_rows_kernel, dim3((unsigned)gx, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, pcm, ld_pcm, y, ld_y, src_row,
+            kind, lengths, dst, ld_dst, n_dst);
   return MA_OK;
 }
 

@@ -9,6 +9,28 @@ __all__ = ["read"]
 _SCALE = {8: 128.0, 16: 32768.0, 32: 2147483648.0}  # io.py:741-745
 
 
+def read_pcm16(path):
+    """(samples int16 (n,), rate) of a mono 16-bit PCM WAV file without leaving integers - the loader's fast path
+    (conformer/dataset.py: the samples go to the device as they lie in the file); None for every other format (the caller then takes
+    `read`)."""
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    if len(buf) < 12 or buf[:4] != b"RIFF" or buf[8:12] != b"WAVE":
+        return None
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(buf):
+        size = struct.unpack_from("<I", buf, pos + 4)[0]
+        tag = buf[pos:pos + 4]
+        if tag == b"fmt ":
+            fmt = struct.unpack_from("<HHIIHH", buf, pos + 8)
+        elif tag == b"data":
+            data = (pos + 8, min(size, len(buf) - pos - 8))
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None or fmt[0] != 1 or fmt[1] != 1 or fmt[5] != 16:
+        return None
+    return np.frombuffer(buf, dtype="<i2", count=data[1] // 2, offset=data[0]), fmt[2]
+
+
 def read(file, offset=0.0, duration=None):
     fh = open(file, "rb") if isinstance(file, (str, bytes)) else file
     try:

@@ -15,9 +15,10 @@ def resampled_length(n, orig_freq, new_freq):
     return int(np.ceil(n * ratio))
 
 
-def resample_batch(x, n_in, n_out):
+def resample_batch(x, n_in, n_out, ni_dev=None, no_dev=None):
     """x (B, >= max(n_in)) float32 device tensor, n_in / n_out per-row lengths -> (B, max(n_out)) float32 with row b =
-    scipy.signal.resample(x[b, :n_in[b]], n_out[b]) and zeros behind it."""
+    scipy.signal.resample(x[b, :n_in[b]], n_out[b]) and zeros behind it.  ni_dev / no_dev: the same lengths as int32 device tensors
+    when the caller has uploaded them already (the loader: no copy of its own behind a busy stream)."""
     t = _host.require_gpu()
     lib = _lib.load()
     assert x.is_cuda and x.dtype == t.float32 and x.dim() == 2 and x.stride(1) == 1
@@ -30,8 +31,8 @@ def resample_batch(x, n_in, n_out):
     _lib.check(min(ws_bytes, 0), "resample")
     ws = _host.workspace(ws_bytes, x.device)
     out = t.empty((b, max_out), dtype=t.float32, device=x.device)
-    ni = t.from_numpy(n_in.astype(np.int32)).to(x.device)
-    no = t.from_numpy(n_out.astype(np.int32)).to(x.device)
+    ni = ni_dev if ni_dev is not None else t.from_numpy(n_in.astype(np.int32)).to(x.device)
+    no = no_dev if no_dev is not None else t.from_numpy(n_out.astype(np.int32)).to(x.device)
     rc = lib.ma_resample_fft_f32(_host.ptr(x), x.stride(0), _host.ptr(ni), _host.ptr(no), b, max_in, max_out, _host.ptr(out),
                                  out.stride(0), _host.ptr(ws), ws.numel(), _host.current_stream_ptr())
     _lib.check(rc, "resample")

@@ -2087,6 +2087,16 @@ class ConformerCTCTrainStep:
         mirrored = K.adam(self.fp.master, self.fp.grad, self.fp.exp_avg, self.fp.exp_avg_sq, lr_t, self.b1, self.b2, self.eps,
                           1.0 / (scale * self.world), self.flag, **({} if self.x32 else {"mirror": self.fp.bf16}))
         self.refresh_weights(cast=not mirrored)  # (the bf16 mirror of the masters left with the update)
+        # What finish_step hands to the host - the overflow flag and the loss - leaves for pinned memory here, with an event behind it:
+        # finish_step waits for THAT, not for the stream, so whatever the caller enqueues between enqueue_step and finish_step (the next
+        # batch's feature and collate launches, conformer/train.py) runs on the device while the host already reads this step's results.
+        host = self.__dict__.get("_step_host")
+        if host is None:
+            host = self._step_host = (torch.empty(1, dtype=torch.float32, pin_memory=True), torch.empty(1, dtype=self.flag.dtype, pin_memory=True),
+                                      torch.cuda.Event())
+        host[0].copy_(loss.detach().reshape(1).to(torch.float32), non_blocking=True)
+        host[1].copy_(self.flag.reshape(1), non_blocking=True)
+        host[2].record()
         return loss, scale, lr
 
     def lr_at(self, step):
@@ -2097,7 +2107,13 @@ class ConformerCTCTrainStep:
 
     def finish_step(self, loss, scale, lr):
         two = self.lr_step_rule == "mindspore23"
-        overflow = bool(int(self.flag.item()))  # the reference also hands `cond` back to the host every step
+        host = self.__dict__.get("_step_host")
+        if host is not None:
+            host[2].synchronize()
+            overflow = bool(int(host[1][0]))  # the reference also hands `cond` back to the host every step
+            loss = torch.tensor(float(host[0][0]))  # (the step's loss as a host scalar: the device tensor stays in last_loss_*)
+        else:
+            overflow = bool(int(self.flag.item()))
         self.scaler.update(overflow)
         self.calls += 1
         self.global_step += 1

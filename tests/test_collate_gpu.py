@@ -100,3 +100,33 @@ def test_create_dataset_iterates_and_shards(cg, corpus):
     for b0, b1 in zip(outs[0], outs[1]):
         assert b0[0].shape == b1[0].shape
         assert b0[0].shape[0] + b1[0].shape[0] in (4, 8, 6)
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+def test_int16_fast_path_equals_the_host_path_bit_for_bit(cg, corpus, perturb):
+    """Round 6: with the default reader the collate uploads the files' int16 samples once and finishes the waves on the device
+    (speed perturbation included: the lengths, hence the sort order, follow from the draws alone; x 2^15 commutes with the resampler).
+    Every one of the 11 columns - the features too - must equal, bit for bit, what the host path (any other reader: float64 waves,
+    device resample, back to the host, padded float32 matrix up again) gives under the same random draws."""
+    import torch
+
+    import mindaudio_amd.conformer.dataset as D
+    from mindaudio_amd.data import io as _io
+
+    tmp, data_file, dict_file = corpus
+    ds = D.BucketASRDataset(data_file, dict_file, frame_factor=100, group_size=1, **BUCKET_KW)
+    kw = dict(feature_extraction_conf={"mel_bins": 80, "frame_length": 25, "frame_shift": 10}, rank=0, group_size=1,
+              use_speed_perturb=perturb, use_spec_aug=True, spec_aug_conf={"num_t_mask": 2, "num_f_mask": 2, "max_t": 50, "max_f": 10})
+    fast = D.CollateFunc(**kw)                                   # reader is data.io.read: the int16 path
+    slow = D.CollateFunc(reader=lambda p: _io.read(p), **kw)     # the same function behind a lambda: the host path
+    for bi in range(len(ds)):
+        data, sos, eos, max_src, max_tgt = ds[bi]
+        data = [(u[0], os.path.join(tmp, os.path.basename(u[1]))) + tuple(u[2:]) for u in data]
+        random.seed(5 + bi)
+        np.random.seed(5 + bi)
+        a = fast(data, sos, eos, max_src, max_tgt)
+        random.seed(5 + bi)
+        np.random.seed(5 + bi)
+        b = slow(data, sos, eos, max_src, max_tgt)
+        for name, x, y in zip(NAMES, a, b):
+            assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y), (bi, name)

@@ -474,3 +474,52 @@ def test_training_with_eval_then_predict_from_the_averaged_checkpoint(tmp_path):
         assert 0 <= mean and len(results) == 5
     except ValueError as e:
         assert "Hypothesis" in str(e)
+
+
+@pytest.mark.gpu
+def test_overlapped_loader_changes_no_loss(tmp_path):
+    """conformer/train.py collates batch n + 1 (uploads on a copy stream, device feature kernels behind the step on the compute
+    stream) between enqueue_step(n) and finish_step(n).  The same run with a step factory that hides enqueue_step / finish_step - the
+    loop then collates and steps one after the other - must log the same losses, step for step, to the last bit."""
+    import random
+
+    src = os.path.join(HERE, "golden", "BAC009S0002W0122.wav")
+    with wave.open(src, "rb") as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    rng = np.random.RandomState(3)
+    chars = [chr(ord("a") + i) for i in range(12)]
+    (tmp_path / "lang_char.txt").write_text("".join("%s %d\n" % (ch, i) for i, ch in enumerate(["<blank>", "<unk>"] + chars + ["<sos/eos>"])))
+    rows = ["id,duration,wav,transcript"]
+    for i in range(20):
+        n = int(rng.randint(16000, 80000))
+        p = str(tmp_path / ("utt%02d.wav" % i))
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(np.resize(pcm, n).tobytes())
+        rows.append("%d,%.2f,%s,%s" % (i, n / 16000.0, p, "".join(rng.choice(chars, int(rng.randint(2, 20))))))
+    (tmp_path / "train.csv").write_text("\n".join(rows) + "\n")
+    cfg = _cfg(tmp_path, train_data=str(tmp_path / "train.csv"), dict=str(tmp_path / "lang_char.txt"), max_epoch=3,
+               exp_name=str(tmp_path / "exp"))
+    cfg["dataset_conf"]["batch_bucket_limit"] = "4, 4, 4, 4, 4, 4, 4, 4, 4, 4"
+    cfg["collate_conf"].update(use_speed_perturb=True)
+    cfg["scheduler_conf"]["warmup_steps"] = 5
+
+    class _StepOnly:
+        def __init__(self, eng):
+            self._eng = eng
+
+        def step(self, *cols):
+            return self._eng.step(*cols)
+
+    def serial_factory(model, config, rank, world, process_group=None, start_steps=0):
+        return _StepOnly(T.build_step(model, config, rank, world, process_group, start_steps=start_steps))
+
+    runs = []
+    for factory in (None, serial_factory):
+        random.seed(11)
+        np.random.seed(11)
+        recs = T.train(cfg, log=lambda _l: None, step_factory=factory)
+        runs.append([r["loss"] for r in recs])
+    assert len(runs[0]) >= 15 and runs[0] == runs[1]

@@ -523,3 +523,47 @@ def test_overlapped_loader_changes_no_loss(tmp_path):
         recs = T.train(cfg, log=lambda _l: None, step_factory=factory)
         runs.append([r["loss"] for r in recs])
     assert len(runs[0]) >= 15 and runs[0] == runs[1]
+
+
+@pytest.mark.gpu
+def test_two_ranks_run_the_script_and_hold_the_same_weights(tmp_path):
+    """The training script data-parallel: two processes (gloo on device tensors, one GPU) walk the same shuffled batch order, keep
+    batch[rank::2] each, all-reduce the gradients of the hybrid step and must end two epochs with bit-identical weights - with the
+    loader overlapped, launch tables recorded, and label widths that differ between the ranks' shards."""
+    import socket
+    import subprocess
+    import sys
+
+    src = os.path.join(HERE, "golden", "BAC009S0002W0122.wav")
+    with wave.open(src, "rb") as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    rng = np.random.RandomState(4)
+    chars = [chr(ord("a") + i) for i in range(12)]
+    (tmp_path / "lang_char.txt").write_text("".join("%s %d\n" % (ch, i) for i, ch in enumerate(["<blank>", "<unk>"] + chars + ["<sos/eos>"])))
+    rows = ["id,duration,wav,transcript"]
+    for i in range(24):
+        n = int(rng.randint(16000, 70000))
+        p = str(tmp_path / ("utt%02d.wav" % i))
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(np.resize(pcm, n).tobytes())
+        rows.append("%d,%.2f,%s,%s" % (i, n / 16000.0, p, "".join(rng.choice(chars, int(rng.randint(2, 22))))))
+    (tmp_path / "train.csv").write_text("\n".join(rows) + "\n")
+    (tmp_path / "conformer.yaml").write_text(YAML)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    outs = [str(tmp_path / ("r%d.pt" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "train_worker.py"), str(r), "2", str(port), str(tmp_path), outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    for p in procs:
+        log, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, log[-3000:]
+    a, b = (torch.load(o) for o in outs)
+    assert len(a["losses"]) == len(b["losses"]) >= 6 and all(np.isfinite(v) for v in a["losses"] + b["losses"])
+    assert torch.equal(a["master"], b["master"])
+    assert a["losses"] != b["losses"]  # (each rank logs the loss of ITS shard)

@@ -36,13 +36,21 @@ __device__ __forceinline__ float2 rs_chirp(int64_t n, int64_t N, float sign) {
 // State before the pass: sub-transform size n, stride s (n s = L).  Group u = q + s p0 holds x[q + s (p0 + j n/R)]; stage i pairs
 // local (p, p + n_loc/2) with twiddle exp(-+ 2 pi i (p n/R + p0) / (n / 2^(i-1))); after T stages local index ql is global
 // q + s ql + R s p0.
-constexpr int kFftGroups = 64;
-template <int T>
+// G groups per workgroup: 64 up to T = 5; 32 / 16 for T = 6 / 7 (the two LDS buffers stay under 64 KiB; 16 groups are still whole
+// 128-byte lines).  Round 6: with the twiddles factored the passes are memory-bound (147 MB in + 147 MB out at 4.4 TB/s), so
+// L = 2^19 runs as 7 + 6 + 6 stages - three trips through HBM instead of four.
+template <int T, int kFftGroups = (T <= 5 ? 64 : T == 6 ? 32 : 16)>
 __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int64_t L,
                                                           int64_t n, int64_t s, float sign) {
   constexpr int R = 1 << T;
   constexpr int P = R + 1;  // LDS pitch (float2) of one group: odd -> the 64 groups spread over the banks
   __shared__ float2 buf[2][kFftGroups * P];
+  // The twiddle of a butterfly, exp(-+ 2 pi i (p_loc n/R + p0) / n_i), factors into exp(-+ 2 pi i p_loc / n_loc) - the small FFT's own
+  // twiddle, R - 1 values per pass - and exp(-+ 2 pi i p0 / n_i), one value per (stage, group): R - 1 + 64 T sines and cosines per
+  // workgroup instead of one sincospif per butterfly (64 T R / 2 of them).  Round 6: the per-butterfly sincospif was ~1.7 of the
+  // resampler's 2.0 ms per batch of the loader (tools/loader_trace.sh) - the passes were VALU-bound, not memory-bound.
+  __shared__ float2 tw_loc[R];                 // stage i (1-based): entries [R - (R >> (i - 1)) .. ) hold p_loc < n_loc / 2
+  __shared__ float2 tw_grp[T][kFftGroups];
   const int tid = threadIdx.x;
   const int64_t u0 = (int64_t)blockIdx.x * kFftGroups;
   const float2* sb = src + (int64_t)blockIdx.y * L;
@@ -52,13 +60,26 @@ __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restri
     const int ul = idx % kFftGroups, j = idx / kFftGroups;
     buf[0][ul * P + j] = sb[u0 + ul + j * gstride];
   }
+  for (int e = tid; e < R - 1; e += 256) {  // stage i occupies [R - n_loc, R - n_loc / 2): n_loc / 2 entries
+    int i = 1, base = 0;
+    while (e >= base + (R >> i)) { base += R >> i; ++i; }
+    const int n_loc = R >> (i - 1), p_loc = e - base;
+    float sn, cs;
+    sincospif(2.0f * (float)p_loc / (float)n_loc, &sn, &cs);
+    tw_loc[(R - n_loc) + p_loc] = make_float2(cs, sign * sn);
+  }
+  for (int e = tid; e < T * kFftGroups; e += 256) {
+    const int i = e / kFftGroups + 1, ul = e % kFftGroups;
+    const int64_t p0 = (u0 + ul) / s, n_i = n >> (i - 1);
+    float sn, cs;
+    sincospif(2.0f * (float)p0 / (float)n_i, &sn, &cs);  // (n_i is a power of two and p0 < n_i / n_loc: the quotient is exact)
+    tw_grp[i - 1][ul] = make_float2(cs, sign * sn);
+  }
   __syncthreads();
-  const int64_t nR = n / R;
   int cur = 0;
 #pragma unroll
   for (int i = 1; i <= T; ++i) {
     const int n_loc = R >> (i - 1), s_loc = 1 << (i - 1);
-    const int64_t n_i = n >> (i - 1);
     const float2* X = buf[cur];
     float2* Y = buf[cur ^ 1];
     for (int bf = tid; bf < kFftGroups * (R / 2); bf += 256) {
@@ -66,12 +87,7 @@ __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restri
       const int p_loc = r / s_loc, q_loc = r % s_loc;
       const float2 a = X[ul * P + q_loc + s_loc * p_loc];
       const float2 b = X[ul * P + q_loc + s_loc * (p_loc + n_loc / 2)];
-      const int64_t u = u0 + ul;
-      const int64_t p0 = u / s;
-      const int64_t num = (int64_t)p_loc * nR + p0;  // < n_i
-      float sn, cs;
-      sincospif(2.0f * (float)num / (float)n_i, &sn, &cs);  // n_i is a power of two: the quotient is exact
-      const float2 w = make_float2(cs, sign * sn);
+      const float2 w = rs_cmul(tw_loc[(R - n_loc) + p_loc], tw_grp[i - 1][ul]);
       Y[ul * P + q_loc + s_loc * (2 * p_loc)] = make_float2(a.x + b.x, a.y + b.y);
       Y[ul * P + q_loc + s_loc * (2 * p_loc + 1)] = rs_cmul(make_float2(a.x - b.x, a.y - b.y), w);
     }
@@ -177,10 +193,16 @@ __global__ __launch_bounds__(256) void rs_out_kernel(const float2* __restrict__ 
 static int rs_fft(float2*& data, float2*& tmp, int64_t batch, int64_t L, int log2L, float sign, hipStream_t stream) {
   int64_t n = L, s = 1;
   int rem = log2L;
+  int passes = (log2L + 6) / 7;  // as few trips through HBM as 7 stages per pass allow, the stages spread evenly
   while (rem > 0) {
-    const int t = rem >= 5 ? 5 : rem;
-    const dim3 grid((unsigned)((L >> t) / kFftGroups), (unsigned)batch);
+    const int t = (rem + passes - 1) / passes;
+    --passes;
+    const int groups = t <= 5 ? 64 : t == 6 ? 32 : 16;
+    if ((L >> t) < groups) return MA_ERR_UNSUPPORTED;  // (L >= 2^11 on every caller's path)
+    const dim3 grid((unsigned)((L >> t) / groups), (unsigned)batch);
     switch (t) {
+      case 7: MA_LAUNCH(rs_fft_pass_kernel<7>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
+      case 6: MA_LAUNCH(rs_fft_pass_kernel<6>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
       case 5: MA_LAUNCH(rs_fft_pass_kernel<5>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
       case 4: MA_LAUNCH(rs_fft_pass_kernel<4>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
       case 3: MA_LAUNCH(rs_fft_pass_kernel<3>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;

@@ -567,3 +567,25 @@ def test_two_ranks_run_the_script_and_hold_the_same_weights(tmp_path):
     assert len(a["losses"]) == len(b["losses"]) >= 6 and all(np.isfinite(v) for v in a["losses"] + b["losses"])
     assert torch.equal(a["master"], b["master"])
     assert a["losses"] != b["losses"]  # (each rank logs the loss of ITS shard)
+
+
+@pytest.mark.gpu
+def test_the_recipe_learns_a_synthetic_language(tmp_path):
+    """End to end, the one property no parity test has: the recipe LEARNS.  tools/recipe_learns.py writes a tone-coded language (every
+    symbol a pair of tones, 3 ... 10 symbols per utterance) as wav files, runs conformer.train (device Kaldi fbank, SpecAugment,
+    buckets, hybrid CTC / attention step, Adam + warm-up + loss scale, BatchNorm statistics, reference-format checkpoint) for 150 steps
+    and conformer.predict (greedy CTC, CER) from the checkpoint on 24 utterances the training never saw: the loss falls by more than
+    half and the held-out CER is below 5 % (measured: 0.0 after 120 steps)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(HERE))
+    from tools.recipe_learns import run
+
+    res = run(epochs=15, blocks=2, train_utts=256, test_utts=24, batch=32, dirname=str(tmp_path / "two"))
+    assert res["steps"] >= 120 and res["overflow_steps"] == 0, res
+    assert np.mean(res["last_losses"]) < 0.5 * np.mean(res["first_losses"]), res
+    assert res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, res
+    # the shipped depth (12 blocks; a deep model sits on the all-blank plateau first: a longer warm-up, 1 000 steps, ~7 s)
+    res = run(epochs=100, blocks=12, train_utts=256, test_utts=24, batch=32, lr=5e-4, warmup=300, dirname=str(tmp_path / "twelve"))
+    assert res["overflow_steps"] == 0 and np.mean(res["last_losses"]) < 0.1 * np.mean(res["first_losses"]), res
+    assert res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, res

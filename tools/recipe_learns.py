@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Does the whole recipe LEARN?  A synthetic language a small model can pick up in a few hundred steps - every symbol a pair of tones
+(0.16 s, a 40 ms gap between symbols), utterances of 3 ... 10 symbols - goes through the reference's recipe end to end:
+`conformer.train` (wav files -> device Kaldi fbank -> SpecAugment -> buckets -> hybrid CTC / attention step with Adam, warm-up, loss
+scale, BatchNorm statistics -> checkpoint in the reference's format) and `conformer.predict` (checkpoint -> greedy CTC -> CER) on
+utterances the training never saw.  Prints the loss curve's ends and the held-out CER.
+    python tools/recipe_learns.py [--epochs 40] [--blocks 2]"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+import wave
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+SYMBOLS = "abcdefghij"
+LOW = (350.0, 480.0, 620.0, 790.0, 1000.0)      # symbol k = tone LOW[k % 5] + tone HIGH[k // 5]
+HIGH = (1500.0, 2300.0)
+
+
+def synth(rng, text, sr=16000):
+    parts = [np.zeros(int(sr * rng.uniform(0.03, 0.08)))]
+    for ch in text:
+        k = SYMBOLS.index(ch)
+        n = int(sr * rng.uniform(0.14, 0.18))
+        t = np.arange(n) / sr
+        tone = np.sin(2 * np.pi * LOW[k % 5] * t + rng.uniform(0, 6.28)) + np.sin(2 * np.pi * HIGH[k // 5] * t + rng.uniform(0, 6.28))
+        env = np.minimum(1.0, np.minimum(np.arange(n), n - 1 - np.arange(n)) / (0.01 * sr))
+        parts.append(tone * env * rng.uniform(0.6, 1.0))
+        parts.append(np.zeros(int(sr * rng.uniform(0.03, 0.05))))
+    x = np.concatenate(parts) * 6000.0
+    x += rng.randn(x.shape[0]) * 60.0
+    return np.clip(x, -32768, 32767).astype("<i2")
+
+
+def write_manifest(dirname, name, rng, count):
+    rows = ["id,duration,wav,transcript"]
+    for i in range(count):
+        text = "".join(rng.choice(list(SYMBOLS), int(rng.randint(3, 11))))
+        pcm = synth(rng, text)
+        p = os.path.join(dirname, "%s%04d.wav" % (name, i))
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(pcm.tobytes())
+        rows.append("%d,%.3f,%s,%s" % (i, pcm.shape[0] / 16000.0, p, text))
+    path = os.path.join(dirname, name + ".csv")
+    with open(path, "w") as fh:
+        fh.write("\n".join(rows) + "\n")
+    return path
+
+
+def config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_weight=0.3):
+    enc = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks, dropout_rate=0.1, positional_dropout_rate=0.1,
+               attention_dropout_rate=0, input_layer="conv2d", normalize_before=True, cnn_module_kernel=15, activation_type="swish",
+               pos_enc_layer_type="rel_pos", feature_norm=True)
+    dec = dict(attention_heads=4, linear_units=2048, num_blocks=1, dropout_rate=0.1, positional_dropout_rate=0.1,
+               self_attention_dropout_rate=0, src_attention_dropout_rate=0)
+    collate = dict(feature_extraction_conf=dict(feature_type="fbank", mel_bins=80, frame_shift=10, frame_length=25, using_pitch=False),
+                   feature_dither=0.0, use_speed_perturb=False, use_spec_aug=True,
+                   spec_aug_conf=dict(warp_for_time=False, num_t_mask=1, num_f_mask=1, prop_mask_t=0.1, prop_mask_f=0.1, max_t=8, max_f=6,
+                                      max_w=80),
+                   use_dynamic_chunk=False, use_dynamic_left_chunk=False, decoding_chunk_size=0, static_chunk_size=0,
+                   num_decoding_left_chunks=-1)
+    limits = "144, 204, 288, 400"
+    ds = dict(max_length=400, min_length=0, token_max_length=30, token_min_length=1, batch_type="bucket", frame_bucket_limit=limits,
+              batch_bucket_limit=", ".join([str(batch)] * 4), batch_factor=1, shuffle=True)
+    with open(os.path.join(dirname, "lang_char.txt"), "w") as fh:
+        # ids = line index + 2 is what predict.py:146-154's `w += 2` needs to print the right character; the same lines make the token
+        # whose index + 2 equals eos = len(char_dict) - 1 end the hypothesis (in the shipped AISHELL dictionary that is one rare
+        # character): two unused symbols take that place here
+        fh.write("".join("%s %d\n" % (s, i + 2) for i, s in enumerate(["<blank>", "<unk>"] + list(SYMBOLS) + ["<x>", "<y>", "<sos/eos>"])))
+    return dict(encoder="conformer", encoder_conf=enc, decoder="transformer", decoder_conf=dec,
+                model_conf=dict(ctc_weight=ctc_weight, lsm_weight=0.1, length_normalized_loss=False), collate_conf=collate, dataset_conf=ds,
+                test_dataset_conf=dict(ds, shuffle=False), grad_clip=5, accum_grad=1, max_epoch=epochs, log_interval=100, optim="adam",
+                optim_conf=dict(lr=lr), scheduler="warmuplr", scheduler_conf=dict(warmup_steps=warmup), cmvn_file="", is_json_cmvn=True,
+                exp_name=os.path.join(dirname, "exp"), train_data=train_csv, eval_data=test_csv, test_data=test_csv,
+                dict=os.path.join(dirname, "lang_char.txt"), save_checkpoint=True, save_checkpoint_epochs=epochs, save_checkpoint_steps=460,
+                keep_checkpoint_max=30, save_checkpoint_path="./", device_target="Ascend", is_distributed=False, mixed_precision=True,
+                resume_ckpt="", save_graphs=False, training_with_eval=False, decode_mode="ctc_greedy_search")
+
+
+def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, warmup=60, seed=0, dirname=None, log=None):
+    from mindaudio_amd.conformer import predict as P
+    from mindaudio_amd.conformer import train as T
+
+    dirname = dirname or tempfile.mkdtemp(prefix="ma_recipe_")
+    os.makedirs(dirname, exist_ok=True)
+    rng = np.random.RandomState(seed)
+    train_csv = write_manifest(dirname, "train", rng, train_utts)
+    test_csv = write_manifest(dirname, "test", rng, test_utts)
+    cfg = config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup)
+    t0 = time.perf_counter()
+    recs = T.train(cfg, log=log or (lambda _l: None))
+    t_train = time.perf_counter() - t0
+    steps = len(recs) // epochs
+    ckpts = sorted(n for n in os.listdir(os.path.join(cfg["exp_name"], "model")) if n.startswith("CKP-%d_" % epochs) and n.endswith(".ckpt"))
+    cfg["decode_ckpt"] = ckpts[-1]
+    plog = []
+    try:
+        cer, results = P.predict(cfg, log=plog.append)
+    except ValueError as e:  # predict.py:164-165: an empty hypothesis stops the reference's script too
+        cer, results = float("nan"), [str(e)] + plog[-3:]
+    losses = [r["loss"] for r in recs]
+    return dict(steps=len(recs), steps_per_epoch=steps, seconds_training=round(t_train, 1), first_losses=[round(v, 2) for v in losses[:3]],
+                last_losses=[round(v, 2) for v in losses[-3:]], overflow_steps=int(sum(bool(r.get("overflow")) for r in recs)),
+                held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=40)
+    ap.add_argument("--blocks", type=int, default=2)
+    ap.add_argument("--utts", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--warmup", type=int, default=60)
+    a = ap.parse_args()
+    print(json.dumps(run(a.epochs, a.blocks, a.utts, 24, a.batch, a.lr, a.warmup)))
+
+
+if __name__ == "__main__":
+    main()

@@ -585,6 +585,11 @@ def test_the_recipe_learns_a_synthetic_language(tmp_path):
     assert res["steps"] >= 120 and res["overflow_steps"] == 0, res
     assert np.mean(res["last_losses"]) < 0.5 * np.mean(res["first_losses"]), res
     assert res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, res
+    # the same with speed perturbation (the device resampler in the loop), with the pure-CTC model, and on the d_model 512 engine
+    # (one launch per reference cell instead of the fused d_model 256 launches)
+    for name, kw in (("speed", dict(speed_perturb=True)), ("ctc", dict(ctc_weight=1.0)), ("d512", dict(d_model=512))):
+        res = run(epochs=25, blocks=2, train_utts=256, test_utts=24, batch=32, dirname=str(tmp_path / name), **kw)
+        assert res["overflow_steps"] == 0 and res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, (name, res)
     # the shipped depth (12 blocks; a deep model sits on the all-blank plateau first: a longer warm-up, 1 000 steps, ~7 s)
     res = run(epochs=100, blocks=12, train_utts=256, test_utts=24, batch=32, lr=5e-4, warmup=300, dirname=str(tmp_path / "twelve"))
     assert res["overflow_steps"] == 0 and np.mean(res["last_losses"]) < 0.1 * np.mean(res["first_losses"]), res

@@ -54,14 +54,14 @@ def write_manifest(dirname, name, rng, count):
     return path
 
 
-def config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_weight=0.3):
-    enc = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=blocks, dropout_rate=0.1, positional_dropout_rate=0.1,
+def config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_weight=0.3, d_model=256, speed_perturb=False):
+    enc = dict(output_size=d_model, attention_heads=d_model // 64, linear_units=2048, num_blocks=blocks, dropout_rate=0.1, positional_dropout_rate=0.1,
                attention_dropout_rate=0, input_layer="conv2d", normalize_before=True, cnn_module_kernel=15, activation_type="swish",
                pos_enc_layer_type="rel_pos", feature_norm=True)
-    dec = dict(attention_heads=4, linear_units=2048, num_blocks=1, dropout_rate=0.1, positional_dropout_rate=0.1,
+    dec = dict(attention_heads=d_model // 64, linear_units=2048, num_blocks=1, dropout_rate=0.1, positional_dropout_rate=0.1,
                self_attention_dropout_rate=0, src_attention_dropout_rate=0)
     collate = dict(feature_extraction_conf=dict(feature_type="fbank", mel_bins=80, frame_shift=10, frame_length=25, using_pitch=False),
-                   feature_dither=0.0, use_speed_perturb=False, use_spec_aug=True,
+                   feature_dither=0.0, use_speed_perturb=bool(speed_perturb), use_spec_aug=True,
                    spec_aug_conf=dict(warp_for_time=False, num_t_mask=1, num_f_mask=1, prop_mask_t=0.1, prop_mask_f=0.1, max_t=8, max_f=6,
                                       max_w=80),
                    use_dynamic_chunk=False, use_dynamic_left_chunk=False, decoding_chunk_size=0, static_chunk_size=0,
@@ -84,7 +84,8 @@ def config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_
                 resume_ckpt="", save_graphs=False, training_with_eval=False, decode_mode="ctc_greedy_search")
 
 
-def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, warmup=60, seed=0, dirname=None, log=None):
+def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, warmup=60, seed=0, dirname=None, log=None, ctc_weight=0.3,
+        d_model=256, speed_perturb=False):
     from mindaudio_amd.conformer import predict as P
     from mindaudio_amd.conformer import train as T
 
@@ -93,7 +94,7 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
     rng = np.random.RandomState(seed)
     train_csv = write_manifest(dirname, "train", rng, train_utts)
     test_csv = write_manifest(dirname, "test", rng, test_utts)
-    cfg = config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup)
+    cfg = config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_weight, d_model, speed_perturb)
     t0 = time.perf_counter()
     recs = T.train(cfg, log=log or (lambda _l: None))
     t_train = time.perf_counter() - t0
@@ -119,8 +120,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--ctc-weight", type=float, default=0.3)
+    ap.add_argument("--d-model", type=int, default=256)
+    ap.add_argument("--speed-perturb", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.epochs, a.blocks, a.utts, 24, a.batch, a.lr, a.warmup)))
+    print(json.dumps(run(a.epochs, a.blocks, a.utts, 24, a.batch, a.lr, a.warmup, ctc_weight=a.ctc_weight, d_model=a.d_model,
+                         speed_perturb=a.speed_perturb)))
 
 
 if __name__ == "__main__":

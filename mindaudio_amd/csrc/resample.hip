@@ -36,21 +36,36 @@ __device__ __forceinline__ float2 rs_chirp(int64_t n, int64_t N, float sign) {
 // State before the pass: sub-transform size n, stride s (n s = L).  Group u = q + s p0 holds x[q + s (p0 + j n/R)]; stage i pairs
 // local (p, p + n_loc/2) with twiddle exp(-+ 2 pi i (p n/R + p0) / (n / 2^(i-1))); after T stages local index ql is global
 // q + s ql + R s p0.
-// G groups per workgroup: 64 up to T = 5; 32 / 16 for T = 6 / 7 (the two LDS buffers stay under 64 KiB; 16 groups are still whole
-// 128-byte lines).  Round 6: with the twiddles factored the passes are memory-bound (147 MB in + 147 MB out at 4.4 TB/s), so
-// L = 2^19 runs as 7 + 6 + 6 stages - three trips through HBM instead of four.
-template <int T, int kFftGroups = (T <= 5 ? 64 : T == 6 ? 32 : 16)>
+// G groups per workgroup (rs_groups): the runs a pass reads and writes are G consecutive points, a workgroup holds G 2^T points in ONE
+// LDS buffer (a trip reads its operands into registers, barrier, writes the results over them, barrier).  What sets the pass time is
+// how many workgroups a CU holds, not the run length (round 6, ma_fft_pow2_c32 on 35 rows, tools/fft_pass_bench.py, TB/s of a pass
+// at 2^18 / 2^19 points): (G at 6 stages, G at 7) = (128, 64) 2.19 / 2.06, (64, 32) 3.31 / 2.96, (32, 16) 4.14 / 3.86 <- shipped
+// (17 KiB: eight workgroups per CU), (16, 8) 4.29 / 3.88.  L = 2^19 runs as 7 + 6 + 6 stages - three trips through HBM; passes of
+// 8 or 9 stages (2^18 in two trips, MA_RS_TMAX 9) are slower per point than three of 6 (0.112 vs 0.103 ms).
+#ifndef MA_RS_G6
+#define MA_RS_G6 32
+#endif
+#ifndef MA_RS_G7
+#define MA_RS_G7 16
+#endif
+#ifndef MA_RS_TMAX
+#define MA_RS_TMAX 7
+#endif
+constexpr int rs_groups(int t) { return t <= 5 ? 64 : t == 6 ? MA_RS_G6 : t == 7 ? MA_RS_G7 : t == 8 ? 16 : 8; }
+constexpr int rs_lds_bytes(int t) { return (rs_groups(t) * ((1 << t) + 1) + (1 << t) + t * rs_groups(t)) * 8; }
+template <int T, int kFftGroups = rs_groups(T)>
 __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int64_t L,
                                                           int64_t n, int64_t s, float sign) {
   constexpr int R = 1 << T;
-  constexpr int P = R + 1;  // LDS pitch (float2) of one group: odd -> the 64 groups spread over the banks
-  __shared__ float2 buf[2][kFftGroups * P];
+  constexpr int P = R + 1;  // LDS pitch (float2) of one group: odd -> the groups spread over the banks
+  extern __shared__ __attribute__((aligned(16))) char rs_smem[];
+  float2* buf = reinterpret_cast<float2*>(rs_smem);                    // [kFftGroups * P]
   // The twiddle of a butterfly, exp(-+ 2 pi i (p_loc n/R + p0) / n_i), factors into exp(-+ 2 pi i p_loc / n_loc) - the small FFT's own
-  // twiddle, R - 1 values per pass - and exp(-+ 2 pi i p0 / n_i), one value per (stage, group): R - 1 + 64 T sines and cosines per
-  // workgroup instead of one sincospif per butterfly (64 T R / 2 of them).  Round 6: the per-butterfly sincospif was ~1.7 of the
+  // twiddle, R - 1 values per pass - and exp(-+ 2 pi i p0 / n_i), one value per (stage, group): R - 1 + G T sines and cosines per
+  // workgroup instead of one sincospif per butterfly (G T R / 2 of them).  Round 6: the per-butterfly sincospif was ~1.7 of the
   // resampler's 2.0 ms per batch of the loader (tools/loader_trace.sh) - the passes were VALU-bound, not memory-bound.
-  __shared__ float2 tw_loc[R];                 // stage i (1-based): entries [R - (R >> (i - 1)) .. ) hold p_loc < n_loc / 2
-  __shared__ float2 tw_grp[T][kFftGroups];
+  float2* tw_loc = buf + kFftGroups * P;       // [R]: stage i (1-based): entries [R - (R >> (i - 1)) .. ) hold p_loc < n_loc / 2
+  float2(*tw_grp)[kFftGroups] = reinterpret_cast<float2(*)[kFftGroups]>(tw_loc + R);  // [T][kFftGroups]
   const int tid = threadIdx.x;
   const int64_t u0 = (int64_t)blockIdx.x * kFftGroups;
   const float2* sb = src + (int64_t)blockIdx.y * L;
@@ -58,7 +73,7 @@ __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restri
   const int64_t gstride = L / R;
   for (int idx = tid; idx < kFftGroups * R; idx += 256) {
     const int ul = idx % kFftGroups, j = idx / kFftGroups;
-    buf[0][ul * P + j] = sb[u0 + ul + j * gstride];
+    buf[ul * P + j] = sb[u0 + ul + j * gstride];
   }
   for (int e = tid; e < R - 1; e += 256) {  // stage i occupies [R - n_loc, R - n_loc / 2): n_loc / 2 entries
     int i = 1, base = 0;
@@ -76,28 +91,80 @@ __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restri
     tw_grp[i - 1][ul] = make_float2(cs, sign * sn);
   }
   __syncthreads();
-  int cur = 0;
+  // Two radix-2 stages per trip through LDS (a radix-4 step: the thread that holds local points p + k n_loc / 4, k < 4, of one q has
+  // both stages' operands); a last single stage when T is odd.
 #pragma unroll
-  for (int i = 1; i <= T; ++i) {
+  for (int i = 1; i + 1 <= T; i += 2) {
     const int n_loc = R >> (i - 1), s_loc = 1 << (i - 1);
-    const float2* X = buf[cur];
-    float2* Y = buf[cur ^ 1];
-    for (int bf = tid; bf < kFftGroups * (R / 2); bf += 256) {
-      const int ul = bf / (R / 2), r = bf % (R / 2);
-      const int p_loc = r / s_loc, q_loc = r % s_loc;
-      const float2 a = X[ul * P + q_loc + s_loc * p_loc];
-      const float2 b = X[ul * P + q_loc + s_loc * (p_loc + n_loc / 2)];
-      const float2 w = rs_cmul(tw_loc[(R - n_loc) + p_loc], tw_grp[i - 1][ul]);
-      Y[ul * P + q_loc + s_loc * (2 * p_loc)] = make_float2(a.x + b.x, a.y + b.y);
-      Y[ul * P + q_loc + s_loc * (2 * p_loc + 1)] = rs_cmul(make_float2(a.x - b.x, a.y - b.y), w);
+    constexpr int kQuads = kFftGroups * (R / 4), kPer = kQuads > 256 ? (kQuads + 255) / 256 : 1;
+    float2 o[kPer][4];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = tid + 256 * u;
+      if (e < kQuads) {
+        const int ul = e / (R / 4), r = e % (R / 4);
+        const int p_loc = r / s_loc;
+        const float2* xp = buf + ul * P + r;  // (q, p + k n_loc / 4) sits at r + k R / 4
+        const float2 x0 = xp[0], x1 = xp[R / 4], x2 = xp[R / 2], x3 = xp[3 * (R / 4)];
+        const float2 g1 = tw_grp[i - 1][ul], g2 = tw_grp[i][ul];
+        const float2 wa = rs_cmul(tw_loc[(R - n_loc) + p_loc], g1);
+        const float2 wb = rs_cmul(tw_loc[(R - n_loc) + p_loc + n_loc / 4], g1);
+        const float2 wc = rs_cmul(tw_loc[(R - n_loc / 2) + p_loc], g2);
+        const float2 s0 = make_float2(x0.x + x2.x, x0.y + x2.y), d0 = rs_cmul(make_float2(x0.x - x2.x, x0.y - x2.y), wa);
+        const float2 s1 = make_float2(x1.x + x3.x, x1.y + x3.y), d1 = rs_cmul(make_float2(x1.x - x3.x, x1.y - x3.y), wb);
+        o[u][0] = make_float2(s0.x + s1.x, s0.y + s1.y);
+        o[u][1] = make_float2(d0.x + d1.x, d0.y + d1.y);
+        o[u][2] = rs_cmul(make_float2(s0.x - s1.x, s0.y - s1.y), wc);
+        o[u][3] = rs_cmul(make_float2(d0.x - d1.x, d0.y - d1.y), wc);
+      }
     }
     __syncthreads();
-    cur ^= 1;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = tid + 256 * u;
+      if (e < kQuads) {
+        const int ul = e / (R / 4), r = e % (R / 4);
+        float2* yp = buf + ul * P + r % s_loc + 4 * s_loc * (r / s_loc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) yp[k * s_loc] = o[u][k];
+      }
+    }
+    __syncthreads();
   }
-  const float2* X = buf[cur];
+  if (T & 1) {
+    constexpr int i = T;
+    constexpr int n_loc = R >> (i - 1), s_loc = 1 << (i - 1);
+    constexpr int kPairs = kFftGroups * (R / 2), kPer = (kPairs + 255) / 256;
+    float2 o[kPer][2];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int bf = tid + 256 * u;
+      if (bf < kPairs) {
+        const int ul = bf / (R / 2), r = bf % (R / 2);
+        const int p_loc = r / s_loc;
+        const float2 a = buf[ul * P + r], b = buf[ul * P + r + R / 2];
+        const float2 w = rs_cmul(tw_loc[(R - n_loc) + p_loc], tw_grp[i - 1][ul]);
+        o[u][0] = make_float2(a.x + b.x, a.y + b.y);
+        o[u][1] = rs_cmul(make_float2(a.x - b.x, a.y - b.y), w);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int bf = tid + 256 * u;
+      if (bf < kPairs) {
+        const int ul = bf / (R / 2), r = bf % (R / 2);
+        float2* yp = buf + ul * P + r % s_loc + 2 * s_loc * (r / s_loc);
+        yp[0] = o[u][0];
+        yp[s_loc] = o[u][1];
+      }
+    }
+    __syncthreads();
+  }
+  const float2* X = buf;
   for (int idx = tid; idx < kFftGroups * R; idx += 256) {
     int ul, ql;
-    if (s >= kFftGroups) {  // consecutive groups are consecutive q: contiguous for a fixed local index
+    if (s >= 8) {           // consecutive groups are consecutive q: runs of min(s, groups) points for a fixed local index
       ul = idx % kFftGroups;
       ql = idx / kFftGroups;
     } else {                // small stride: the R outputs of a group are (nearly) contiguous
@@ -109,6 +176,9 @@ __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restri
     db[q + s * ql + (int64_t)R * s * p0] = X[ul * P + ql];
   }
 }
+
+MA_LDS_ATTR(rs_fft_pass_kernel<6>, rs_lds_bytes(6));
+MA_LDS_ATTR(rs_fft_pass_kernel<7>, rs_lds_bytes(7));
 
 // a[i] = x[i] c_N[i] (i < N), b = conj(c_N) wrapped to length L
 __global__ __launch_bounds__(256) void rs_chirp_in_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ n_in,
@@ -193,21 +263,27 @@ __global__ __launch_bounds__(256) void rs_out_kernel(const float2* __restrict__ 
 static int rs_fft(float2*& data, float2*& tmp, int64_t batch, int64_t L, int log2L, float sign, hipStream_t stream) {
   int64_t n = L, s = 1;
   int rem = log2L;
-  int passes = (log2L + 6) / 7;  // as few trips through HBM as 7 stages per pass allow, the stages spread evenly
+  int passes = (log2L + MA_RS_TMAX - 1) / MA_RS_TMAX;  // as few trips through HBM as MA_RS_TMAX stages per pass allow, the stages spread evenly
   while (rem > 0) {
-    const int t = (rem + passes - 1) / passes;
+    int t = (rem + (passes > 0 ? passes : 1) - 1) / (passes > 0 ? passes : 1);
     --passes;
-    const int groups = t <= 5 ? 64 : t == 6 ? 32 : 16;
-    if ((L >> t) < groups) return MA_ERR_UNSUPPORTED;  // (L >= 2^11 on every caller's path)
+    while (t > 1 && (L >> t) < rs_groups(t)) --t;  // a workgroup takes rs_groups(t) groups: short transforms take shorter passes
+    if (t > rem) t = rem;
+    if (t < 1 || (L >> t) < rs_groups(t)) return MA_ERR_UNSUPPORTED;  // L < 2^7
+    const int groups = rs_groups(t);
     const dim3 grid((unsigned)((L >> t) / groups), (unsigned)batch);
     switch (t) {
-      case 7: MA_LAUNCH(rs_fft_pass_kernel<7>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
-      case 6: MA_LAUNCH(rs_fft_pass_kernel<6>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
-      case 5: MA_LAUNCH(rs_fft_pass_kernel<5>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
-      case 4: MA_LAUNCH(rs_fft_pass_kernel<4>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
-      case 3: MA_LAUNCH(rs_fft_pass_kernel<3>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
-      case 2: MA_LAUNCH(rs_fft_pass_kernel<2>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
-      default: MA_LAUNCH(rs_fft_pass_kernel<1>, grid, dim3(256), 0, stream, data, tmp, L, n, s, sign); break;
+#if MA_RS_TMAX >= 9
+      case 9: MA_LAUNCH(rs_fft_pass_kernel<9>, grid, dim3(256), rs_lds_bytes(9), stream, data, tmp, L, n, s, sign); break;
+      case 8: MA_LAUNCH(rs_fft_pass_kernel<8>, grid, dim3(256), rs_lds_bytes(8), stream, data, tmp, L, n, s, sign); break;
+#endif
+      case 7: MA_LAUNCH(rs_fft_pass_kernel<7>, grid, dim3(256), rs_lds_bytes(7), stream, data, tmp, L, n, s, sign); break;
+      case 6: MA_LAUNCH(rs_fft_pass_kernel<6>, grid, dim3(256), rs_lds_bytes(6), stream, data, tmp, L, n, s, sign); break;
+      case 5: MA_LAUNCH(rs_fft_pass_kernel<5>, grid, dim3(256), rs_lds_bytes(5), stream, data, tmp, L, n, s, sign); break;
+      case 4: MA_LAUNCH(rs_fft_pass_kernel<4>, grid, dim3(256), rs_lds_bytes(4), stream, data, tmp, L, n, s, sign); break;
+      case 3: MA_LAUNCH(rs_fft_pass_kernel<3>, grid, dim3(256), rs_lds_bytes(3), stream, data, tmp, L, n, s, sign); break;
+      case 2: MA_LAUNCH(rs_fft_pass_kernel<2>, grid, dim3(256), rs_lds_bytes(2), stream, data, tmp, L, n, s, sign); break;
+      default: MA_LAUNCH(rs_fft_pass_kernel<1>, grid, dim3(256), rs_lds_bytes(1), stream, data, tmp, L, n, s, sign); break;
     }
     n >>= t;
     s <<= t;

@@ -715,7 +715,7 @@ int ma_dropout_bwd_bf16(const float* g, int64_t ldg, void* dy, int64_t ldy, int6
  *   ma_bn_swish_fwd_bf16   out = swish(gamma * (z - mean) * rstd + beta) bf16
  *   ma_bn_swish_bwd_f32    dz (float32) from dout (bf16): Swish', then the BatchNorm backward; dsum (2C) float32 =
  *                          (sum dn | sum dn zhat), stored; d_gamma / d_beta (C, optional) += the parameter gradients;
- *                          workspace >= 256 * 2C * 4 bytes (per-workgroup partials, summed in a fixed order)
+ *                          workspace >= 1024 * 2C * 4 bytes (per-workgroup partials, summed in a fixed order)
  *   ma_convmid_bwd_bf16    dy (B*T, 2C) bf16 from dz: depthwise-conv backward + GLU backward; d_dw_w (C, k), d_dw_b (C)
  *                          float32 += per-workgroup partials summed in a fixed order
  * No float atomics anywhere: two runs of a training step give bit-identical gradients. */

@@ -1407,6 +1407,11 @@ int ma_bn_swish_fwd_x32(const float* z, const float* stats, const float* gamma, 
   return bn_swish_fwd_launch(z, stats, gamma, beta, out, rows, C, stream);
 }
 
+// workgroups of the BatchNorm backward's first stage (one partial vector each for bn_dsum_reduce_kernel)
+#ifndef MA_BN_BWD_BLOCKS
+#define MA_BN_BWD_BLOCKS 1024
+#endif
+constexpr int kBnBwdBlocks = MA_BN_BWD_BLOCKS;
 extern "C++" {
 template <typename AT>
 static int bn_swish_bwd_launch(const AT* dout, const float* z, const float* stats, const float* gamma, const float* beta,
@@ -1416,16 +1421,16 @@ static int bn_swish_bwd_launch(const AT* dout, const float* z, const float* stat
   const bool v4 = (C & 3) == 0 && C <= 1024 && (256 % (C / 4) == 0 || C > 256) &&
                   ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0;
   if (C < 1 || (!v4 && (C > 256 || 256 % C))) return MA_ERR_UNSUPPORTED;
-  if (workspace_bytes < (int64_t)256 * 2 * C * 4) return MA_ERR_WORKSPACE;
+  if (workspace_bytes < (int64_t)kBnBwdBlocks * 2 * C * 4) return MA_ERR_WORKSPACE;
   float* part = reinterpret_cast<float*>(workspace);  // one (sum dn | sum dn zhat) vector per workgroup
   const int rpb = 256 / C;
   int nblk;
   if (v4) {  // (C = 768: 192 threads per row, the last 64 threads of the workgroup idle)
-    nblk = grid_for(rows, 256 / (C / 4), 256);
+    nblk = grid_for(rows, 256 / (C / 4), kBnBwdBlocks);
     MA_LAUNCH(bn_swish_bwd1_v4_kernel<AT>, dim3(nblk), dim3(256), (256 / (C / 4)) * 2 * C * sizeof(float), (hipStream_t)stream, dout,
               z, stats, gamma, beta, dz, rows, C, part);
   } else {
-    nblk = grid_for(rows, rpb, 256);
+    nblk = grid_for(rows, rpb, kBnBwdBlocks);
     MA_LAUNCH(bn_swish_bwd1_kernel<AT>, dim3(nblk), dim3(256), rpb * 2 * C * sizeof(float), (hipStream_t)stream, dout, z, stats,
               gamma, beta, dz, rows, C, part);
   }

@@ -1,6 +1,7 @@
 """MindSpore .ckpt importer (mindaudio_amd/utils/ckpt.py).  Parity unpinned: MindSpore is not installed and no
-reference checkpoint exists in the container, so the wire format is exercised through the package's own writer and the name
-mapping against names derived from the reference's cell attributes."""
+reference checkpoint exists in the container, so the wire format is exercised through the package's own writer, against
+google.protobuf under MindSpore's published schema (both directions), and the name mapping against names derived from the
+reference's cell attributes."""
 import numpy as np
 import pytest
 
@@ -108,3 +109,82 @@ def test_strict_import_with_global_cmvn_and_stale_caches(tmp_path):
     dst.ctc._w = ("stale",)
     dst.load_state_dict(src.state_dict())
     assert dst.encoder._prepared is None and dst.ctc._w is None
+
+
+def _checkpoint_message_class():
+    """MindSpore's checkpoint schema (mindspore/ccsrc/utils/checkpoint.proto as published with 2.3: Checkpoint { repeated Value value = 1 },
+    Value { required string tag = 1; required TensorProto tensor = 2 }, TensorProto { repeated int64 dims = 1; required string
+    tensor_type = 2; required bytes tensor_content = 3 }) built as a dynamic google.protobuf message: an independent implementation of
+    the wire format to hold the hand-written reader / writer against."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+
+    fdp = descriptor_pb2.FileDescriptorProto()
+    fdp.name, fdp.syntax = "ms_checkpoint_for_test.proto", "proto2"
+    t = fdp.message_type.add()
+    t.name = "TensorProto"
+    for name, number, label, typ in (("dims", 1, "LABEL_REPEATED", "TYPE_INT64"), ("tensor_type", 2, "LABEL_REQUIRED", "TYPE_STRING"),
+                                     ("tensor_content", 3, "LABEL_REQUIRED", "TYPE_BYTES")):
+        f = t.field.add()
+        f.name, f.number, f.label, f.type = name, number, getattr(f, label), getattr(f, typ)
+    c = fdp.message_type.add()
+    c.name = "Checkpoint"
+    v = c.nested_type.add()
+    v.name = "Value"
+    f = v.field.add()
+    f.name, f.number, f.label, f.type = "tag", 1, f.LABEL_REQUIRED, f.TYPE_STRING
+    f = v.field.add()
+    f.name, f.number, f.label, f.type, f.type_name = "tensor", 2, f.LABEL_REQUIRED, f.TYPE_MESSAGE, ".TensorProto"
+    f = c.field.add()
+    f.name, f.number, f.label, f.type, f.type_name = "value", 1, f.LABEL_REPEATED, f.TYPE_MESSAGE, ".Checkpoint.Value"
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fdp)
+    desc = pool.FindMessageTypeByName("Checkpoint")
+    if hasattr(message_factory, "GetMessageClass"):
+        return message_factory.GetMessageClass(desc)
+    return message_factory.MessageFactory(pool).GetPrototype(desc)
+
+
+def test_wire_format_against_google_protobuf(tmp_path):
+    """Second anchor for the wire format (the first is the package's own round trip): files of write_mindspore_ckpt parse with
+    google.protobuf under MindSpore's schema - tags, dims, type names, bytes - and a file serialised BY google.protobuf (unpacked and
+    packed dims, a negative dim, a sliced parameter) reads back through read_mindspore_ckpt."""
+    pytest.importorskip("google.protobuf")
+    Ck = _checkpoint_message_class()
+    rng = np.random.RandomState(3)
+    params = {"network.encoder.after_norm.gamma": rng.randn(256).astype(np.float32), "w": rng.randn(4, 3, 1, 5).astype(np.float16),
+              "epoch_num": np.array([7], np.int32), "scale_sense": np.array(1024.0, np.float32),
+              "big": rng.randn(300, 8).astype(np.float32), "i64": np.arange(6, dtype=np.int64).reshape(2, 3) - 3}
+    path = str(tmp_path / "ours.ckpt")
+    K.write_mindspore_ckpt(path, params, slice_bytes=4000)
+    msg = Ck()
+    msg.ParseFromString(open(path, "rb").read())
+    assert msg.IsInitialized()
+    seen = {}
+    for val in msg.value:
+        seen.setdefault(val.tag, []).append(val.tensor)
+    assert set(seen) == set(params) and len(seen["big"]) == 3 and all(len(v) == 1 for k, v in seen.items() if k != "big")
+    names = {"float32": "Float32", "float16": "Float16", "int32": "Int32", "int64": "Int64"}
+    for k, arr in params.items():
+        assert all(t.tensor_type == names[arr.dtype.name] for t in seen[k]), k
+        data = b"".join(t.tensor_content for t in seen[k])
+        assert data == arr.tobytes(), k
+        if k == "big":
+            assert [list(t.dims) for t in seen[k]] == [[100, 8]] * 3
+        else:
+            assert list(seen[k][0].dims) == (list(arr.shape) or [0]), k
+    # the other direction: google.protobuf writes, the package reads
+    msg = Ck()
+    for k, arr in params.items():
+        pieces = np.array_split(arr, 3) if k == "big" else [arr]
+        for piece in pieces:
+            val = msg.value.add()
+            val.tag = k
+            val.tensor.dims.extend(piece.shape or (0,))
+            val.tensor.tensor_type = names[arr.dtype.name]
+            val.tensor.tensor_content = piece.tobytes()
+    path2 = str(tmp_path / "theirs.ckpt")
+    open(path2, "wb").write(msg.SerializeToString())
+    got = K.read_mindspore_ckpt(path2)
+    assert set(got) == set(params)
+    for k, arr in params.items():
+        assert got[k].dtype == arr.dtype and got[k].shape == arr.shape and np.array_equal(got[k], arr), k

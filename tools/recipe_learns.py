@@ -107,9 +107,12 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
     except ValueError as e:  # predict.py:164-165: an empty hypothesis stops the reference's script too
         cer, results = float("nan"), [str(e)] + plog[-3:]
     losses = [r["loss"] for r in recs]
+    import torch
+
+    peak_gb = round(torch.cuda.max_memory_allocated() / 2**30, 2) if torch.cuda.is_available() else None
     return dict(steps=len(recs), steps_per_epoch=steps, seconds_training=round(t_train, 1), first_losses=[round(v, 2) for v in losses[:3]],
                 last_losses=[round(v, 2) for v in losses[-3:]], overflow_steps=int(sum(bool(r.get("overflow")) for r in recs)),
-                held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
+                peak_gb=peak_gb, held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
 
 
 def main():

@@ -502,6 +502,11 @@ class ConformerCTCTrainStep:
             l.conv_module.norm.running_var.copy_(v)
         self.enc._prepared = None
         self.model.ctc._w = None
+        if self.dec is not None:
+            # (the evaluation forward's packed copies of the decoder's weights: left in place until the end of round 6, so an
+            # evaluation between training steps - train.py's EvalCallback - ran the encoder of now with the decoder of the FIRST
+            # evaluation; found by tools/recipe_learns.py --with-eval: the evaluation loss stopped at the untrained decoder's)
+            self.dec._prepared = None
 
     @torch.no_grad()
     def refresh_weights(self, cast=True):

@@ -590,6 +590,12 @@ def test_the_recipe_learns_a_synthetic_language(tmp_path):
     for name, kw in (("speed", dict(speed_perturb=True)), ("ctc", dict(ctc_weight=1.0)), ("d512", dict(d_model=512))):
         res = run(epochs=25, blocks=2, train_utts=256, test_utts=24, batch=32, dirname=str(tmp_path / name), **kw)
         assert res["overflow_steps"] == 0 and res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, (name, res)
+    # training_with_eval: the evaluation loss the EvalCallback logs between training steps follows the training (it stopped at the
+    # untrained decoder's until the end of round 6: sync_to_module left the decoder's packed evaluation weights in place), and the
+    # averaged checkpoint decodes
+    res = run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, dirname=str(tmp_path / "eval"), with_eval=True)
+    assert res["decode_ckpt"] == "conformer_avg_30.ckpt" and res["held_out_cer"] <= 0.05, res
+    assert res["eval_losses"][-1] < 0.4 * res["eval_losses"][0], res
     # the shipped depth (12 blocks; a deep model sits on the all-blank plateau first: a longer warm-up, 1 000 steps, ~7 s)
     res = run(epochs=100, blocks=12, train_utts=256, test_utts=24, batch=32, lr=5e-4, warmup=300, dirname=str(tmp_path / "twelve"))
     assert res["overflow_steps"] == 0 and np.mean(res["last_losses"]) < 0.1 * np.mean(res["first_losses"]), res

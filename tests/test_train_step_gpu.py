@@ -729,6 +729,37 @@ def test_fused_engine_gradients_match_oracle_autograd():
     assert sum(worst.values()) / len(worst) < 2.5e-2
 
 
+def test_evaluation_between_training_steps_sees_the_trained_decoder():
+    """train.py's EvalCallback evaluates the module between training steps: sync_to_module() has to invalidate EVERY packed copy the
+    evaluation forward keeps - the encoder's, the CTC head's and the decoder's.  Until the end of round 6 the decoder's stayed: the
+    evaluation loss of a hybrid model stopped at the untrained decoder's (found by tools/recipe_learns.py --with-eval).  Here: evaluate
+    (fills the caches), train five steps, sync, evaluate again - equal to a fresh module loaded with the same state, and moved."""
+    import copy
+
+    from mindaudio_amd.conformer.asr_model import ASREvalNet
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    _, _, _, model, cols = _hybrid_setup(blocks=1, dblocks=1)
+    dev_cols = tuple(c.cuda() if c is not None else None for c in cols)
+    model.eval()
+    before = float(ASREvalNet(model, 1)(*dev_cols))
+    eng = ConformerCTCTrainStep(model, base_lr=2e-3, warmup_steps=1, dropout_rate=0.0, positional_dropout_rate=0.0)
+    for _ in range(6):
+        eng.step(*dev_cols)
+    eng.sync_to_module()
+    model.eval()
+    after = float(ASREvalNet(model, 1)(*dev_cols))
+    fresh = copy.deepcopy(model)
+    fresh.load_state_dict(model.state_dict())  # (the load hook drops every packed copy)
+    fresh.eval()
+    want = float(ASREvalNet(fresh, 1)(*dev_cols))
+    assert after == want, (before, after, want)
+    assert after < 0.9 * before, (before, after)
+    # and the decoder alone: with the encoder / CTC caches valid and only the decoder's stale the loss would sit between the two
+    dec_w = model.decoder.decoders[0].feed_forward.w_1.weight
+    assert not torch.equal(dec_w, copy.deepcopy(_hybrid_setup(blocks=1, dblocks=1)[3]).decoder.decoders[0].feed_forward.w_1.weight)
+
+
 def _hybrid_setup(seed=31, vocab=97, blocks=1, dblocks=2):
     from mindaudio_amd.conformer.asr_model import create_asr_model
     from oracle import conformer_oracle as C

@@ -85,7 +85,7 @@ def config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_
 
 
 def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, warmup=60, seed=0, dirname=None, log=None, ctc_weight=0.3,
-        d_model=256, speed_perturb=False):
+        d_model=256, speed_perturb=False, with_eval=False):
     from mindaudio_amd.conformer import predict as P
     from mindaudio_amd.conformer import train as T
 
@@ -95,12 +95,18 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
     train_csv = write_manifest(dirname, "train", rng, train_utts)
     test_csv = write_manifest(dirname, "test", rng, test_utts)
     cfg = config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_weight, d_model, speed_perturb)
+    tlog = []
+    if with_eval:  # train.py's EvalCallback: evaluation loss per epoch, conformer_<e>_<s>.ckpt, the average of the 30 best at the end
+        cfg.update(training_with_eval=True, save_checkpoint_epochs=1)
     t0 = time.perf_counter()
-    recs = T.train(cfg, log=log or (lambda _l: None))
+    recs = T.train(cfg, log=log or tlog.append)
     t_train = time.perf_counter() - t0
     steps = len(recs) // epochs
-    ckpts = sorted(n for n in os.listdir(os.path.join(cfg["exp_name"], "model")) if n.startswith("CKP-%d_" % epochs) and n.endswith(".ckpt"))
-    cfg["decode_ckpt"] = ckpts[-1]
+    if with_eval:
+        cfg["decode_ckpt"] = "conformer_avg_30.ckpt"
+    else:
+        ckpts = sorted(n for n in os.listdir(os.path.join(cfg["exp_name"], "model")) if n.startswith("CKP-%d_" % epochs) and n.endswith(".ckpt"))
+        cfg["decode_ckpt"] = ckpts[-1]
     plog = []
     try:
         cer, results = P.predict(cfg, log=plog.append)
@@ -112,7 +118,9 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
     peak_gb = round(torch.cuda.max_memory_allocated() / 2**30, 2) if torch.cuda.is_available() else None
     return dict(steps=len(recs), steps_per_epoch=steps, seconds_training=round(t_train, 1), first_losses=[round(v, 2) for v in losses[:3]],
                 last_losses=[round(v, 2) for v in losses[-3:]], overflow_steps=int(sum(bool(r.get("overflow")) for r in recs)),
-                peak_gb=peak_gb, held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
+                peak_gb=peak_gb, eval_losses=[float(ln.split("Average Eval Loss: ")[1].split(",")[0]) for ln in tlog
+                                              if ln.startswith("[EvalCallback] Epoch ")][::max(1, epochs // 6)] if with_eval else None,
+                decode_ckpt=cfg["decode_ckpt"], held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
 
 
 def main():
@@ -126,9 +134,10 @@ def main():
     ap.add_argument("--ctc-weight", type=float, default=0.3)
     ap.add_argument("--d-model", type=int, default=256)
     ap.add_argument("--speed-perturb", action="store_true")
+    ap.add_argument("--with-eval", action="store_true", help="training_with_eval: decode from the averaged checkpoint")
     a = ap.parse_args()
     print(json.dumps(run(a.epochs, a.blocks, a.utts, 24, a.batch, a.lr, a.warmup, ctc_weight=a.ctc_weight, d_model=a.d_model,
-                         speed_perturb=a.speed_perturb)))
+                         speed_perturb=a.speed_perturb, with_eval=a.with_eval)))
 
 
 if __name__ == "__main__":

@@ -590,6 +590,15 @@ def test_the_recipe_learns_a_synthetic_language(tmp_path):
     for name, kw in (("speed", dict(speed_perturb=True)), ("ctc", dict(ctc_weight=1.0)), ("d512", dict(d_model=512))):
         res = run(epochs=25, blocks=2, train_utts=256, test_utts=24, batch=32, dirname=str(tmp_path / name), **kw)
         assert res["overflow_steps"] == 0 and res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, (name, res)
+    # GlobalCMVN from compute_cmvn_stats' json (train and predict), the (B, T, T) chunk masks of use_dynamic_chunk, the float32
+    # validation engine (mixed_precision False), and a run stopped after 20 epochs and resumed from its checkpoint (weights, BatchNorm
+    # statistics, schedule position: the resumed run's first losses are near the stopped run's last, far below an untrained model's)
+    for name, kw in (("cmvn", dict(cmvn=True)), ("chunk", dict(dynamic_chunk=True)), ("fp32", dict(fp32=True)), ("resume", dict(resume_at=20))):
+        res = run(epochs=40 if name == "resume" else 25, blocks=2, train_utts=256, test_utts=24, batch=32, dirname=str(tmp_path / name), **kw)
+        assert res["overflow_steps"] == 0 and res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, (name, res)
+        if name == "resume":
+            r = res["resumed"]
+            assert r["first_epoch"] == 21 and 0 < r["lr_after"] < r["lr_before"] and np.mean(r["after"]) < 2.5 * np.mean(r["before"]) < 30, res
     # training_with_eval: the evaluation loss the EvalCallback logs between training steps follows the training (it stopped at the
     # untrained decoder's until the end of round 6: sync_to_module left the decoder's packed evaluation weights in place), and the
     # averaged checkpoint decodes

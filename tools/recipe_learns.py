@@ -85,7 +85,10 @@ def config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_
 
 
 def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, warmup=60, seed=0, dirname=None, log=None, ctc_weight=0.3,
-        d_model=256, speed_perturb=False, with_eval=False):
+        d_model=256, speed_perturb=False, with_eval=False, cmvn=False, fp32=False, dynamic_chunk=False, resume_at=0):
+    """cmvn: global_cmvn.json from conformer.compute_cmvn_stats over the training files (GlobalCMVN in the model, train and predict);
+    fp32: mixed_precision False (the float32 validation engine); dynamic_chunk: use_dynamic_chunk (a (B, T, T) chunk mask per batch);
+    resume_at = E: stop after E epochs, resume from that checkpoint for the rest (the resumed run's first losses are reported)."""
     from mindaudio_amd.conformer import predict as P
     from mindaudio_amd.conformer import train as T
 
@@ -96,12 +99,30 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
     test_csv = write_manifest(dirname, "test", rng, test_utts)
     cfg = config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_weight, d_model, speed_perturb)
     tlog = []
+    if cmvn:
+        from mindaudio_amd.conformer import compute_cmvn_stats as CM
+
+        cfg["cmvn_file"] = os.path.join(dirname, "global_cmvn.json")
+        CM.main(train_csv, cfg["cmvn_file"])
+    if fp32:
+        cfg["mixed_precision"] = False
+    if dynamic_chunk:
+        cfg["collate_conf"]["use_dynamic_chunk"] = True
+    resumed_first = None
+    if resume_at:
+        cfg1 = dict(cfg, max_epoch=resume_at, save_checkpoint_epochs=resume_at)
+        recs1 = T.train(cfg1, log=lambda _l: None)
+        ck = sorted(n for n in os.listdir(os.path.join(cfg["exp_name"], "model")) if n.startswith("CKP-%d_" % resume_at) and n.endswith(".ckpt"))[-1]
+        cfg["resume_ckpt"] = os.path.join(cfg["exp_name"], "model", ck)
     if with_eval:  # train.py's EvalCallback: evaluation loss per epoch, conformer_<e>_<s>.ckpt, the average of the 30 best at the end
         cfg.update(training_with_eval=True, save_checkpoint_epochs=1)
     t0 = time.perf_counter()
     recs = T.train(cfg, log=log or tlog.append)
     t_train = time.perf_counter() - t0
-    steps = len(recs) // epochs
+    steps = len(recs) // max(1, epochs - resume_at)
+    if resume_at:
+        resumed_first = dict(before=[round(r["loss"], 2) for r in recs1[-3:]], after=[round(r["loss"], 2) for r in recs[:3]],
+                             first_epoch=recs[0]["epoch"], lr_before=recs1[-1]["lr"], lr_after=recs[0]["lr"])
     if with_eval:
         cfg["decode_ckpt"] = "conformer_avg_30.ckpt"
     else:
@@ -120,7 +141,7 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
                 last_losses=[round(v, 2) for v in losses[-3:]], overflow_steps=int(sum(bool(r.get("overflow")) for r in recs)),
                 peak_gb=peak_gb, eval_losses=[float(ln.split("Average Eval Loss: ")[1].split(",")[0]) for ln in tlog
                                               if ln.startswith("[EvalCallback] Epoch ")][::max(1, epochs // 6)] if with_eval else None,
-                decode_ckpt=cfg["decode_ckpt"], held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
+                decode_ckpt=cfg["decode_ckpt"], resumed=resumed_first, held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
 
 
 def main():
@@ -135,9 +156,14 @@ def main():
     ap.add_argument("--d-model", type=int, default=256)
     ap.add_argument("--speed-perturb", action="store_true")
     ap.add_argument("--with-eval", action="store_true", help="training_with_eval: decode from the averaged checkpoint")
+    ap.add_argument("--cmvn", action="store_true")
+    ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--dynamic-chunk", action="store_true")
+    ap.add_argument("--resume-at", type=int, default=0)
     a = ap.parse_args()
     print(json.dumps(run(a.epochs, a.blocks, a.utts, 24, a.batch, a.lr, a.warmup, ctc_weight=a.ctc_weight, d_model=a.d_model,
-                         speed_perturb=a.speed_perturb, with_eval=a.with_eval)))
+                         speed_perturb=a.speed_perturb, with_eval=a.with_eval, cmvn=a.cmvn, fp32=a.fp32, dynamic_chunk=a.dynamic_chunk,
+                         resume_at=a.resume_at)))
 
 
 if __name__ == "__main__":

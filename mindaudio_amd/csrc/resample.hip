@@ -96,13 +96,14 @@ __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restri
 #pragma unroll
   for (int i = 1; i + 1 <= T; i += 2) {
     const int n_loc = R >> (i - 1), s_loc = 1 << (i - 1);
+    constexpr int R4 = R >= 4 ? R / 4 : 1;  // (T = 1 never enters this loop)
     constexpr int kQuads = kFftGroups * (R / 4), kPer = kQuads > 256 ? (kQuads + 255) / 256 : 1;
     float2 o[kPer][4];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
       const int e = tid + 256 * u;
       if (e < kQuads) {
-        const int ul = e / (R / 4), r = e % (R / 4);
+        const int ul = e / R4, r = e % R4;
         const int p_loc = r / s_loc;
         const float2* xp = buf + ul * P + r;  // (q, p + k n_loc / 4) sits at r + k R / 4
         const float2 x0 = xp[0], x1 = xp[R / 4], x2 = xp[R / 2], x3 = xp[3 * (R / 4)];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void rs_fft_pass_kernel(const float2* __restri
     for (int u = 0; u < kPer; ++u) {
       const int e = tid + 256 * u;
       if (e < kQuads) {
-        const int ul = e / (R / 4), r = e % (R / 4);
+        const int ul = e / R4, r = e % R4;
         float2* yp = buf + ul * P + r % s_loc + 4 * s_loc * (r / s_loc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) yp[k * s_loc] = o[u][k];

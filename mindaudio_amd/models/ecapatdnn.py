@@ -99,6 +99,8 @@ class EcapaTDNN(nn.Module):
         self.fc = nn.Conv1d(6 * c, lin_neurons, 1)
         self._prepared = None
         self._ws = {}
+        # any load_state_dict invalidates the bf16 / packed copies of prepare() (as the Conformer encoder, decoder and CTC head do)
+        self.register_load_state_dict_post_hook(lambda module, _keys: setattr(module, "_prepared", None))
         self.fuse_res2net = True  # False: one launch per convolution / add of the Res2Net chain (the tests run both)
         self.fuse_se_block = True  # False: squeeze, excitation and scale + residual as three launches (the tests run both)
         self.fuse_se = True       # False: the SE excitation and the embedding Linear as ma_gemm_bf16 launches (the tests run both)

@@ -42,6 +42,18 @@ def test_ecapa_forward_matches_oracle(b, t):
     assert float(cos.min()) > 0.999
 
 
+def test_weights_loaded_after_a_forward_are_the_ones_the_next_forward_uses():
+    """prepare() keeps bf16 / packed copies of the weights; a load_state_dict behind a forward has to drop them (the Conformer encoder,
+    decoder and CTC head have the same hook; the decoder's copy once outlived sync_to_module - round 6)."""
+    _, dut = build(seed=3)
+    x = torch.randn(2, 57, 80).cuda()
+    first = dut(x).clone()
+    ref2, fresh = build(seed=4)
+    dut.load_state_dict(ref2.state_dict(), strict=False)
+    got, want = dut(x), fresh(x)
+    assert torch.equal(got, want) and not torch.equal(got, first)
+
+
 def test_ecapa_conv_taps_and_epilogue_against_torch():
     """The tap-convolution GEMM mode and the ReLU -> BatchNorm -> tanh epilogue on their own, float32 reference."""
     import ctypes

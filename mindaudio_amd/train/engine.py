@@ -509,6 +509,21 @@ class ConformerCTCTrainStep:
             self.dec._prepared = None
 
     @torch.no_grad()
+    def sync_from_module(self, reset_moments=True):
+        """The other direction: weights loaded into the nn.Module AFTER this engine was built (load_state_dict, a checkpoint
+        importer) become the masters - the constructor reads the module once, and a later load left the engine training the old
+        weights without a word.  BatchNorm running statistics come along; Adam's moments are zeroed unless `reset_moments` is False
+        (the reference's checkpoints do not carry them either: a resumed run restarts them, train.py:117-133)."""
+        self._copy_params(to_flat=True)
+        for l, m, v in zip(self.enc.encoders, self.bn_mean, self.bn_var):
+            m.copy_(l.conv_module.norm.running_mean.detach().float())
+            v.copy_(l.conv_module.norm.running_var.detach().float())
+        if reset_moments:
+            self.fp.exp_avg.zero_()
+            self.fp.exp_avg_sq.zero_()
+        self.refresh_weights()
+
+    @torch.no_grad()
     def refresh_weights(self, cast=True):
         """bf16 mirror of the masters (one cast launch; cast=False: the optimizer launch has written it) + transposed bf16 copies of the
         matmul weights."""

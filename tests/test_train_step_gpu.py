@@ -760,6 +760,34 @@ def test_evaluation_between_training_steps_sees_the_trained_decoder():
     assert not torch.equal(dec_w, copy.deepcopy(_hybrid_setup(blocks=1, dblocks=1)[3]).decoder.decoders[0].feed_forward.w_1.weight)
 
 
+def test_weights_loaded_into_the_module_behind_the_engine_reach_it_through_sync_from_module():
+    """The constructor reads the module once.  sync_from_module() makes a later load_state_dict the engine's masters (and BatchNorm
+    statistics, and fresh Adam moments): three steps after it equal, bit for bit, those of an engine built on the loaded module."""
+    import copy
+
+    from mindaudio_amd.train.engine import ConformerCTCTrainStep
+
+    _, _, _, model_a, cols = _hybrid_setup(seed=31, blocks=1, dblocks=1)
+    _, _, _, model_b, _ = _hybrid_setup(seed=32, blocks=1, dblocks=1)
+    with torch.no_grad():
+        for l in model_b.encoder.encoders:
+            l.conv_module.norm.running_mean.normal_(0, 0.1)
+            l.conv_module.norm.running_var.uniform_(0.5, 1.5)
+    state_b = copy.deepcopy(model_b.state_dict())
+    dev_cols = tuple(c.cuda() if c is not None else None for c in cols)
+    kw = dict(base_lr=1e-3, warmup_steps=1, dropout_rate=0.1, positional_dropout_rate=0.1)
+    eng = ConformerCTCTrainStep(model_a, **kw)
+    eng.step(*dev_cols)                       # (moments and counters move; the loaded weights must not inherit the moments)
+    model_a.load_state_dict(state_b)
+    eng.sync_from_module()
+    eng.calls = eng.global_step = eng.applied_steps = 0   # same dropout stream and schedule position as the fresh engine
+    ref = ConformerCTCTrainStep(model_b, **kw)
+    got = [float(eng.step(*dev_cols)[0]) for _ in range(3)]
+    want = [float(ref.step(*dev_cols)[0]) for _ in range(3)]
+    assert got == want and torch.equal(eng.fp.master, ref.fp.master)
+    assert all(torch.equal(a, b) for a, b in zip(eng.bn_mean + eng.bn_var, ref.bn_mean + ref.bn_var))
+
+
 def _hybrid_setup(seed=31, vocab=97, blocks=1, dblocks=2):
     from mindaudio_amd.conformer.asr_model import create_asr_model
     from oracle import conformer_oracle as C

@@ -586,3 +586,39 @@ def test_two_forwards_on_two_streams_equal_the_sequential_ones():
         torch.cuda.synchronize()
         assert all(torch.equal(o, w) for o, w in zip(outs, want))
 
+
+
+def test_random_batch_shapes_and_lengths_through_the_encoder_against_the_oracle():
+    """Shapes between the pinned ones: 24 random (batch 1 ... 9, 67 ... 1 400 frames, ragged lengths down to 20 frames, one-frame-short
+    and tile-boundary subsampled lengths included) through the 2-block encoder with trained-like attention statistics, the fused
+    and the general form alternating, against the oracle - same bounds as the pinned cases.  (The fused launches tile rows by 16,
+    32 and 64 and utterances by their own T': a wrong tail at some T' mod tile would show here.)"""
+    import numpy as np
+    import torch
+
+    from oracle import conformer_oracle as C
+
+    ref, dut = _pair(2, seed=11, cmvn=True, attn_gain=3.5)
+    rng = np.random.RandomState(4)
+    worst = 0.0
+    picks = [67, 71, 75, 131, 135, 259, 263, 515, 1027, 1031]  # T' = 15, 16, 17, 31, 32, 63, 64, 127, 255, 256
+    for case in range(24):
+        b = int(rng.randint(1, 10))
+        tlen = int(picks[case]) if case < len(picks) else int(rng.randint(67, 1400 if b <= 4 else 700))
+        lens = [tlen] + [int(rng.randint(20, tlen + 1)) for _ in range(b - 1)]
+        xs = torch.from_numpy(rng.randn(b, tlen, 80).astype(np.float32))
+        mask = torch.zeros(b, 1, tlen)
+        for i, n in enumerate(lens):
+            mask[i, 0, :n] = 1
+            xs[i, n:] = 0
+        sub = C.subsample_mask(mask)
+        dut.fuse_min_rows = 1000000 if case % 3 == 2 else 1
+        with torch.no_grad():
+            want, _ = ref(xs, sub)
+        got, _ = dut(xs.cuda(), sub.cuda())
+        err = got.cpu() - want
+        keep = sub[:, 0, :, None].bool().expand_as(err)  # (padded frames: the reference leaves whatever the blocks computed there)
+        rel = float(err[keep].pow(2).mean().sqrt() / want[keep].pow(2).mean().sqrt())
+        worst = max(worst, rel)
+        assert rel <= 2.5e-2 and float(err[keep].abs().max()) <= 0.3, (case, b, tlen, lens, rel, float(err[keep].abs().max()))
+    assert worst > 1e-4  # (the comparison saw bf16 round-off, i.e. it compared something)

@@ -328,3 +328,23 @@ def test_se_block_entry_point_equals_the_three_launches(b, t, c, s_):
     want = X * gt[:, None] + res.bfloat16().double()[:, H:H + t, :c]
     assert float((got[:, H:H + t].double() - want).abs().max()) <= 3e-2 * float(want.abs().max())
 
+
+
+def test_random_batch_shapes_through_ecapa_against_the_oracle():
+    """Shapes between the pinned ones: 16 random (batch 1 ... 24, 9 ... 700 frames; the frame counts around the 16- / 32- / 64-frame tiles
+    of the fused Res2Net, SE and attentive-pooling launches first) at C = 512 with a peaky pooling softmax, all fused forms on."""
+    import numpy as np
+
+    ref, dut = build(512, seed=5, asp_gain=6.0)
+    rng = np.random.RandomState(8)
+    picks = [9, 15, 16, 17, 31, 33, 63, 65, 127, 129]
+    for case in range(16):
+        b = int(rng.randint(1, 25))
+        t = picks[case] if case < len(picks) else int(rng.randint(9, 700))
+        x = torch.from_numpy(rng.randn(b, t, 80).astype(np.float32))
+        with torch.no_grad():
+            want = ref(x)
+        got = dut(x.cuda()).cpu()
+        rel = float((got - want).norm() / want.norm())
+        cos = float(torch.nn.functional.cosine_similarity(got, want, dim=1).min())
+        assert got.shape == want.shape and rel < 3e-2 and cos > 0.999, (case, b, t, rel, cos)

@@ -250,6 +250,24 @@ def test_hybrid_step_at_odd_batch_shapes(b, tlen, ylens, mode):
     """One utterance, one-token labels, T' that is not a multiple of any tile (16, 64, 24, 128 rows), labels across the 32-query tile
     boundary: loss and every gradient of the hybrid step (fused launches in bf16 mode, one launch per cell in float32 mode) against the
     oracle's autograd."""
+    _hybrid_step_case(b, tlen, ylens, mode)
+
+
+def test_hybrid_step_at_random_batch_shapes():
+    """Eight random (batch 1 ... 6, 67 ... 900 frames, ragged utterance lengths, 1 ... 60 labels) batches between the pinned ones, bf16
+    mode (the fused launches: 48-row feed-forward tiles, 32-row K = 256 tiles, 16-frame convolution strips, 64-row attention tiles,
+    32-query decoder tiles): loss and every gradient against the oracle's autograd."""
+    import numpy as np
+
+    rng = np.random.RandomState(12)
+    for case in range(8):
+        b = int(rng.randint(1, 7))
+        tlen = int(rng.randint(67, 900 if b <= 3 else 400))
+        ylens = tuple(int(rng.randint(1, 61)) for _ in range(b))
+        _hybrid_step_case(b, tlen, ylens, "bf16", seed=5000 + case)
+
+
+def _hybrid_step_case(b, tlen, ylens, mode, seed=None):
     from mindaudio_amd.train.engine import ConformerCTCTrainStep
     from oracle import conformer_oracle as C
 
@@ -257,7 +275,7 @@ def test_hybrid_step_at_odd_batch_shapes(b, tlen, ylens, mode):
     # (seed: with b * 1000 + tlen the float32 (7, 99) case differs from the oracle in ONE output channel of conv2 - its bias and its
     # 2 304 weights by 1e-3, every other tensor within 1e-5: the signature of a pre-activation at the ReLU kink that the two summation
     # orders put on different sides of zero, not of an indexing fault)
-    ref_enc, ref_ctc, ref_dec, model = build(256, 4, units=512, vocab=vocab, seed=b * 1000 + tlen + 1, dblocks=1)
+    ref_enc, ref_ctc, ref_dec, model = build(256, 4, units=512, vocab=vocab, seed=b * 1000 + tlen + 1 if seed is None else seed, dblocks=1)
     g = torch.Generator().manual_seed(tlen)
     xs = torch.randn(b, tlen, 80, generator=g)
     lens = [tlen - (17 * i) % (tlen // 3) for i in range(b)]

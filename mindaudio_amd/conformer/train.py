@@ -102,6 +102,10 @@ def train(config, rank=0, world=1, device=None, max_steps=None, log=print, datas
     import torch
 
     torch.manual_seed(777)  # set_seed(777), train.py:56
+    import numpy as np
+
+    np.random.seed(777)     # (mindspore.set_seed seeds numpy's global generator as well; Python's `random` - SpecAugment's and speed
+    #                          perturbation's draws, dataset.py:398-406,493-534 - stays unseeded there and here)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     ds_conf = dict(config["dataset_conf"])  # (frame_bucket_limit / batch_bucket_limit stay the yaml's comma-separated strings: the data

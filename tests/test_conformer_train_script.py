@@ -598,7 +598,9 @@ def test_the_recipe_learns_a_synthetic_language(tmp_path):
         assert res["overflow_steps"] == 0 and res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, (name, res)
         if name == "resume":
             r = res["resumed"]
-            assert r["first_epoch"] == 21 and 0 < r["lr_after"] < r["lr_before"] and np.mean(r["after"]) < 2.5 * np.mean(r["before"]) < 30, res
+            # (epoch means: single batches differ in size and so in loss)
+            assert r["first_epoch"] == 21 and 0 < r["lr_after"] < r["lr_before"], res
+            assert r["after"] < 1.6 * r["before"] and r["after"] < 0.5 * r["first_epoch_mean"], res
     # training_with_eval: the evaluation loss the EvalCallback logs between training steps follows the training (it stopped at the
     # untrained decoder's until the end of round 6: sync_to_module left the decoder's packed evaluation weights in place), and the
     # averaged checkpoint decodes
@@ -606,6 +608,10 @@ def test_the_recipe_learns_a_synthetic_language(tmp_path):
     assert res["decode_ckpt"] == "conformer_avg_30.ckpt" and res["held_out_cer"] <= 0.05, res
     assert res["eval_losses"][-1] < 0.4 * res["eval_losses"][0], res
     # the shipped depth (12 blocks; a deep model sits on the all-blank plateau first: a longer warm-up, 1 000 steps, ~7 s)
-    res = run(epochs=100, blocks=12, train_utts=256, test_utts=24, batch=32, lr=5e-4, warmup=300, dirname=str(tmp_path / "twelve"))
+    res = run(epochs=100, blocks=12, train_utts=256, test_utts=24, batch=32, lr=5e-4, warmup=300, dirname=str(tmp_path / "twelve"),
+              batch_check=True)
     assert res["overflow_steps"] == 0 and np.mean(res["last_losses"]) < 0.1 * np.mean(res["first_losses"]), res
     assert res["held_out_cer"] == res["held_out_cer"] and res["held_out_cer"] <= 0.05, res
+    # ... and the trained model's hypotheses do not depend on how the utterances are batched and padded (batches of 7, 16 and all 24
+    # against one at a time: masks and padding of the fused evaluation forward on weights that are no longer random)
+    assert res["batched_decode_mismatches"] == 0, res

@@ -84,14 +84,57 @@ def config(dirname, train_csv, test_csv, epochs, blocks, batch, lr, warmup, ctc_
                 resume_ckpt="", save_graphs=False, training_with_eval=False, decode_mode="ctc_greedy_search")
 
 
+def batched_decode_mismatches(cfg, batch_sizes=(7, 16, 48)):
+    """Greedy CTC hypotheses of the held-out files decoded in padded batches (lengths and masks as a loader would pass them) that differ
+    from the one-utterance-at-a-time decode of predict.py: padding and masks must not move a trained model's output."""
+    import torch
+
+    from mindaudio_amd.conformer import predict as P
+    from mindaudio_amd.conformer.asr_model import CTCGreedySearch, ctc_greedy_search
+    from mindaudio_amd.conformer.dataset import compute_fbank_feats_batch
+    from mindaudio_amd.conformer.train import build_model
+    from mindaudio_amd.data.io import read
+    from mindaudio_amd.utils.ckpt import load_mindspore_checkpoint
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    _, _, vocab, _ = P.load_language_dict(cfg["dict"])
+    model = build_model(cfg, 80, vocab, dev)
+    load_mindspore_checkpoint(model, os.path.join(cfg["exp_name"], "model", cfg["decode_ckpt"]), strict=False)
+    net = CTCGreedySearch(model.eval())
+    samples = P.predict_samples(cfg["test_data"], cfg["dict"], cfg["dataset_conf"])
+    waves = [np.asarray(read(p)[0], np.float32) * (1 << 15) for _, p, _, _ in samples]
+
+    def decode(ws):
+        host = np.zeros((len(ws), max(w.shape[0] for w in ws)), np.float32)
+        for i, w in enumerate(ws):
+            host[i, :w.shape[0]] = w
+        f, nfr = compute_fbank_feats_batch(host, [w.shape[0] for w in ws], sample_rate=16000, frame_len=25, frame_shift=10, mel_bin=80)
+        tmax = int(nfr.max())
+        m = torch.zeros(len(ws), 1, tmax, device=dev)
+        for i, n in enumerate(nfr.tolist()):
+            m[i, 0, :n] = 1
+        return ctc_greedy_search(net, f[:, :tmax].contiguous(), m, None)[0]
+
+    single = [decode([w])[0] for w in waves]
+    bad = 0
+    for bs in batch_sizes:
+        for lo in range(0, len(waves), bs):
+            bad += sum(h != s for h, s in zip(decode(waves[lo:lo + bs]), single[lo:lo + bs]))
+    return bad
+
+
 def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, warmup=60, seed=0, dirname=None, log=None, ctc_weight=0.3,
-        d_model=256, speed_perturb=False, with_eval=False, cmvn=False, fp32=False, dynamic_chunk=False, resume_at=0):
+        d_model=256, speed_perturb=False, with_eval=False, cmvn=False, fp32=False, dynamic_chunk=False, resume_at=0, batch_check=False):
     """cmvn: global_cmvn.json from conformer.compute_cmvn_stats over the training files (GlobalCMVN in the model, train and predict);
     fp32: mixed_precision False (the float32 validation engine); dynamic_chunk: use_dynamic_chunk (a (B, T, T) chunk mask per batch);
     resume_at = E: stop after E epochs, resume from that checkpoint for the rest (the resumed run's first losses are reported)."""
     from mindaudio_amd.conformer import predict as P
     from mindaudio_amd.conformer import train as T
 
+    import random
+
+    random.seed(seed)  # (SpecAugment's / speed perturbation's draws: the reference leaves Python's generator unseeded; this tool's
+    #                     runs are meant to repeat)
     dirname = dirname or tempfile.mkdtemp(prefix="ma_recipe_")
     os.makedirs(dirname, exist_ok=True)
     rng = np.random.RandomState(seed)
@@ -121,7 +164,8 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
     t_train = time.perf_counter() - t0
     steps = len(recs) // max(1, epochs - resume_at)
     if resume_at:
-        resumed_first = dict(before=[round(r["loss"], 2) for r in recs1[-3:]], after=[round(r["loss"], 2) for r in recs[:3]],
+        ep = lambda rs, e: float(np.mean([r["loss"] for r in rs if r["epoch"] == e]))  # noqa: E731  (batches differ in size: epoch means)
+        resumed_first = dict(first_epoch_mean=round(ep(recs1, 1), 2), before=round(ep(recs1, resume_at), 2), after=round(ep(recs, resume_at + 1), 2),
                              first_epoch=recs[0]["epoch"], lr_before=recs1[-1]["lr"], lr_after=recs[0]["lr"])
     if with_eval:
         cfg["decode_ckpt"] = "conformer_avg_30.ckpt"
@@ -134,6 +178,7 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
     except ValueError as e:  # predict.py:164-165: an empty hypothesis stops the reference's script too
         cer, results = float("nan"), [str(e)] + plog[-3:]
     losses = [r["loss"] for r in recs]
+    mism = batched_decode_mismatches(cfg) if batch_check and isinstance(results, list) and cer == cer else None
     import torch
 
     peak_gb = round(torch.cuda.max_memory_allocated() / 2**30, 2) if torch.cuda.is_available() else None
@@ -141,7 +186,7 @@ def run(epochs=40, blocks=2, train_utts=256, test_utts=24, batch=32, lr=1e-3, wa
                 last_losses=[round(v, 2) for v in losses[-3:]], overflow_steps=int(sum(bool(r.get("overflow")) for r in recs)),
                 peak_gb=peak_gb, eval_losses=[float(ln.split("Average Eval Loss: ")[1].split(",")[0]) for ln in tlog
                                               if ln.startswith("[EvalCallback] Epoch ")][::max(1, epochs // 6)] if with_eval else None,
-                decode_ckpt=cfg["decode_ckpt"], resumed=resumed_first, held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
+                decode_ckpt=cfg["decode_ckpt"], resumed=resumed_first, batched_decode_mismatches=mism, held_out_cer=cer, held_out=results[:4] if isinstance(results, list) else results)
 
 
 def main():

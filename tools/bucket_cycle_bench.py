@@ -47,19 +47,36 @@ def run(ctc_weight=0.3, rounds=6, settle=3, single_warm=4, single_timed=5):
         for k in order:
             eng.step(*batches[k])
     torch.cuda.synchronize()
+    import gc
+
+    gc_mode = os.environ.get("MA_BUCKET_GC", "")
+    if gc_mode == "off":
+        gc.disable()
+    elif gc_mode == "freeze":
+        gc.collect()
+        gc.freeze()
+    g0 = [st["collections"] for st in gc.get_stats()]
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     for _ in range(rounds):
         for k in order:
             eng.step(*batches[k])
     torch.cuda.synchronize()
     cyc = (time.perf_counter() - t0) / (rounds * 16) * 1e3
+    g1 = [st["collections"] for st in gc.get_stats()]
+    ms1 = torch.cuda.memory_stats()
+    alloc = {k: ms1.get(k, 0) - ms0.get(k, 0) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    alloc["reserved_gb"] = round(ms1.get("reserved_bytes.all.current", 0) / 2 ** 30, 1)
+    if gc_mode:
+        gc.enable()
+        print("gc mode %s: collections per generation during the timed rounds %s, tracked objects %d" % (gc_mode, [b - a for a, b in zip(g0, g1)], len(gc.get_objects())), file=sys.stderr)
     utts = sum(bs) * rounds
     return {"workload": "the training step (ctc_weight %.1f) over the 16 (batch, frames) buckets of conformer.yaml, a different bucket every "
                         "step (labels up to 30 tokens)" % ctc_weight,
             "ms_per_step_cycling": round(cyc, 3), "ms_per_step_one_shape_at_a_time": round(float(np.mean(single)), 3),
             "utterances_per_s_cycling": round(utts / (cyc * rounds * 16 / 1e3), 1),
             "overhead_pct": round((cyc / float(np.mean(single)) - 1) * 100, 1), "per_bucket_ms": [round(v, 2) for v in single],
-            "peak_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+            "peak_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "allocator_during_timed_rounds": alloc}
 
 
 def main():
